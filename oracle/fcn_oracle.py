@@ -1,0 +1,250 @@
+"""PyTorch-CPU fp32 restatement of the reference FCN graph (TEST INFRASTRUCTURE, see
+oracle/__init__.py).  NHWC numpy arrays in, NHWC numpy arrays out; weights in the
+reference npz schema (HWIO conv kernels, [kh,kw,out,in] transposed-conv kernels).
+
+`policy` mirrors where the MI355X path rounds to a storage dtype so that the oracle can
+be fed *the same* rounded operands:
+  'fp32'  every tensor fp32 (the reference's arithmetic)
+  'bf16'  activations between layers and conv weights (all but conv1_1) rounded to
+          bf16 (round-to-nearest-even), accumulation fp32, decoder head (upscore x8,
+          score, softmax) fp32 from the bf16 `fused` features
+"""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+ENCODER_CONVS = [  # name, Cout  (simple_fcn.py:39-67)
+    ('conv1_1', 64), ('conv1_2', 64), 'pool1',
+    ('conv2_1', 128), ('conv2_2', 128), 'pool2',
+    ('conv3_1', 256), ('conv3_2', 256), ('conv3_3', 256), 'pool3',
+    ('conv4_1', 512), ('conv4_2', 512), ('conv4_3', 512), 'pool4',
+    ('conv5_1', 512), ('conv5_2', 512), ('conv5_3', 512)]
+
+
+def bilinear_1d(k):
+    """1-D factor of bilinear_filter_initializer (custom_layers.py:8-25)."""
+    factor = np.ceil(k / 2.0)
+    center = (2 * factor - 1 - factor % 2) / (2.0 * factor)
+    return np.array([1 - abs(x / factor - center) for x in range(k)], dtype=np.float64)
+
+
+def bilinear_kernel(k, channels):
+    """custom_layers.py:8-25: W[x,y,i,i] = w1[x]*w1[y], zero off the channel diagonal."""
+    w1 = bilinear_1d(k)
+    w = np.zeros((k, k, channels, channels))
+    for i in range(channels):
+        w[:, :, i, i] = np.outer(w1, w1)
+    return w.astype(np.float32)
+
+
+def glorot_uniform(rng, shape):
+    """[TF1] default kernel initialiser of tf.layers.conv2d."""
+    kh, kw, cin, cout = shape
+    lim = np.sqrt(6.0 / (kh * kw * cin + kh * kw * cout))
+    return rng.uniform(-lim, lim, size=shape).astype(np.float32)
+
+
+def init_fcn_weights(prefix, in_channels, num_units, num_classes, seed=1, bias_scale=0.0):
+    """Random-init weights in the reference npz schema (names: 'Synthia Rand Cityscapes
+    Examples.ipynb':897-931).  bias_scale>0 gives non-zero biases (tests)."""
+    rng = np.random.default_rng(seed)
+    w = {}
+    cin = in_channels
+    for item in ENCODER_CONVS:
+        if isinstance(item, str):
+            continue
+        name, cout = item
+        w['%s/%s/kernel' % (prefix, name)] = glorot_uniform(rng, (3, 3, cin, cout))
+        w['%s/%s/bias' % (prefix, name)] = (bias_scale * rng.standard_normal(cout)).astype(np.float32)
+        cin = cout
+    for name in ('score_conv4', 'score_conv5'):
+        w['%s/%s/kernel' % (prefix, name)] = glorot_uniform(rng, (1, 1, 512, num_units))
+        w['%s/%s/bias' % (prefix, name)] = (bias_scale * rng.standard_normal(num_units)).astype(np.float32)
+    w['%s/upscore_conv5/kernel' % prefix] = bilinear_kernel(4, num_units)
+    w['%s/upscore/kernel' % prefix] = bilinear_kernel(16, num_units)
+    w['%s/score/kernel' % prefix] = glorot_uniform(rng, (1, 1, num_units, num_classes))
+    w['%s/score/bias' % prefix] = (bias_scale * rng.standard_normal(num_classes)).astype(np.float32)
+    return w
+
+
+def _t(x):
+    return torch.from_numpy(np.ascontiguousarray(x))
+
+
+def round_bf16(x):
+    """Round-to-nearest-even to bf16, returned as fp32 (torch tensor or ndarray)."""
+    if isinstance(x, np.ndarray):
+        return _t(x.astype(np.float32)).bfloat16().float().numpy()
+    return x.bfloat16().float()
+
+
+def conv2d_same(x, w, b=None, relu=False):
+    """tf.layers.conv2d(padding='same', strides 1) [+ relu]  (custom_layers.py:124-139).
+    x: torch NCHW fp32, w: numpy HWIO."""
+    k = w.shape[0]
+    wt = _t(w).permute(3, 2, 0, 1).contiguous()
+    y = F.conv2d(x, wt, None if b is None else _t(b), padding=(k - 1) // 2)
+    return F.relu(y) if relu else y
+
+
+def maxpool2(x):
+    """max_pooling2d(2,2,'valid') (simple_fcn.py:41,44,48,58)."""
+    return F.max_pool2d(x, 2, 2)
+
+
+def deconv_same(x, w, stride, relu=False):
+    """tf.layers.conv2d_transpose(padding='same', use_bias=False) with kernel layout
+    [kh,kw,out,in] (custom_layers.py:71-121).  [TF1] out = stride*in, pad_before=(k-s)//2."""
+    k = w.shape[0]
+    wt = _t(w).permute(3, 2, 0, 1).contiguous()        # torch wants [in,out,kh,kw]
+    y = F.conv_transpose2d(x, wt, stride=stride, padding=(k - stride) // 2)
+    return F.relu(y) if relu else y
+
+
+def fcn_forward(x_nhwc, weights, prefix, policy='fp32', keep=None):
+    """fcn() = encoder + decoder (simple_fcn.py:137-170) with batchnorm=False, no dropout.
+    Returns dict of NHWC fp32 numpy arrays.  keep: iterable of layer names to return
+    (default: fused, upscore, score)."""
+    assert policy in ('fp32', 'bf16')
+    rnd = (lambda t: t) if policy == 'fp32' else round_bf16
+    keep = set(keep) if keep is not None else {'fused', 'upscore', 'score'}
+    out = {}
+
+    def W(name):
+        w = weights['%s/%s/kernel' % (prefix, name)]
+        if policy == 'bf16' and name != 'conv1_1':
+            w = round_bf16(w)
+        return w
+
+    def B(name):
+        return weights['%s/%s/bias' % (prefix, name)]
+
+    with torch.no_grad():
+        h = _t(np.asarray(x_nhwc, np.float32)).permute(0, 3, 1, 2).contiguous()
+        layers = {}
+        for item in ENCODER_CONVS:
+            if isinstance(item, str):
+                h = maxpool2(h)
+                layers[item] = h
+            else:
+                name = item[0]
+                h = rnd(conv2d_same(h, W(name), B(name), relu=True))
+                layers[name] = h
+        score_conv4 = rnd(conv2d_same(layers['conv4_3'], W('score_conv4'), B('score_conv4'), relu=True))
+        score_conv5 = rnd(conv2d_same(layers['conv5_3'], W('score_conv5'), B('score_conv5'), relu=True))
+        # deconv kernels are exact in bf16 only for the 4x4 one; they are constants applied
+        # in fp32 on the MI355X path, so they are never rounded here.
+        up5 = deconv_same(score_conv5, weights['%s/upscore_conv5/kernel' % prefix], 2, relu=True)
+        fused = rnd(score_conv4 + up5)                                   # tf.add_n (simple_fcn.py:85)
+        layers.update(score_conv4=score_conv4, score_conv5=score_conv5, upscore_conv5=up5,
+                      fused=fused)
+        upscore = deconv_same(fused, weights['%s/upscore/kernel' % prefix], 8, relu=True)
+        score = conv2d_same(upscore, W('score'), B('score'), relu=False)  # no activation
+        layers.update(upscore=upscore, score=score)
+        for k in keep:
+            out[k] = layers[k].permute(0, 2, 3, 1).contiguous().numpy()
+    return out
+
+
+def softmax(score):
+    """tf.nn.softmax over the last axis, fp32: exp(x-max)/sum(exp(x-max))."""
+    s = np.asarray(score, np.float32)
+    e = np.exp(s - s.max(axis=-1, keepdims=True), dtype=np.float32)
+    return (e / e.sum(axis=-1, keepdims=True, dtype=np.float32)).astype(np.float32)
+
+
+def log_softmax(score):
+    s = np.asarray(score, np.float32)
+    z = s - s.max(axis=-1, keepdims=True)
+    return (z - np.log(np.exp(z, dtype=np.float32).sum(axis=-1, keepdims=True, dtype=np.float32))).astype(np.float32)
+
+
+def argmax_last(x):
+    """tf.argmax(.,3): int64, lowest index among ties."""
+    return np.argmax(x, axis=-1).astype(np.int64)
+
+
+def cross_entropy(log_p, labels_int, num_classes):
+    """utils.py:43-53 with one_hot(label) (base_model.py:198-201): labels outside [0,C)
+    give an all-zero row and drop out.  Returns (loss, dloss/dscore) in fp64/fp32."""
+    lab = np.asarray(labels_int)
+    valid = (lab >= 0) & (lab < num_classes)
+    onehot = np.zeros(log_p.shape, np.float32)
+    idx = np.nonzero(valid)
+    onehot[idx + (lab[idx],)] = 1.0
+    denom = 1e-20 + float(onehot.sum())
+    loss = -float((onehot.astype(np.float64) * log_p.astype(np.float64)).sum()) / denom
+    # d loss / d score = (softmax * sum(onehot,-1) - onehot) / denom
+    p = np.exp(log_p.astype(np.float64))
+    grad = (p * onehot.sum(-1, keepdims=True) - onehot) / denom
+    return loss, grad.astype(np.float32)
+
+
+# ---------------------------------------------------------------------------------------
+# independent pure-numpy loop twin (small cases only): restates the TF op definitions
+# directly, sharing no code with the torch path above.
+# ---------------------------------------------------------------------------------------
+
+def naive_conv2d_same(x, w, b=None, relu=False):
+    n, h, wd, cin = x.shape
+    k = w.shape[0]
+    p = (k - 1) // 2
+    cout = w.shape[3]
+    xp = np.zeros((n, h + k - 1, wd + k - 1, cin), np.float64)
+    xp[:, p:p + h, p:p + wd] = x
+    y = np.zeros((n, h, wd, cout), np.float64)
+    for dy in range(k):
+        for dx in range(k):
+            y += xp[:, dy:dy + h, dx:dx + wd, :] @ w[dy, dx].astype(np.float64)
+    if b is not None:
+        y += b
+    return np.maximum(y, 0) if relu else y
+
+
+def naive_maxpool2(x):
+    n, h, w, c = x.shape
+    return x.reshape(n, h // 2, 2, w // 2, 2, c).max(axis=(2, 4))
+
+
+def naive_deconv_same(x, w, stride, relu=False):
+    """out[o] += in[i] * W[p, :, out_c, in_c], o = i*s + p - (k-s)//2   (SURVEY App. B)."""
+    n, h, wd, cin = x.shape
+    k = w.shape[0]
+    cout = w.shape[2]
+    pb = (k - stride) // 2
+    y = np.zeros((n, h * stride, wd * stride, cout), np.float64)
+    for iy in range(h):
+        for ix in range(wd):
+            for py in range(k):
+                oy = iy * stride + py - pb
+                if oy < 0 or oy >= h * stride:
+                    continue
+                for px in range(k):
+                    ox = ix * stride + px - pb
+                    if ox < 0 or ox >= wd * stride:
+                        continue
+                    y[:, oy, ox, :] += x[:, iy, ix, :].astype(np.float64) @ w[py, px].astype(np.float64).T
+    return np.maximum(y, 0) if relu else y
+
+
+def depthwise_bilinear_up(x, stride, relu=False):
+    """What the dense deconv collapses to when the kernel is the (diagonal) bilinear
+    constant: out[o] = sum_{i,p: i*s+p-pb=o} x[i]*w1[p] per axis, zero outside."""
+    k = 2 * stride
+    w1 = bilinear_1d(k)
+    pb = (k - stride) // 2
+    n, h, wd, c = x.shape
+
+    def up_axis(a, axis):
+        a = np.moveaxis(a, axis, 0)
+        L = a.shape[0]
+        out = np.zeros((L * stride,) + a.shape[1:], np.float64)
+        for i in range(L):
+            for p in range(k):
+                o = i * stride + p - pb
+                if 0 <= o < L * stride:
+                    out[o] += a[i] * w1[p]
+        return np.moveaxis(out, 0, axis)
+
+    y = up_axis(up_axis(x.astype(np.float64), 1), 2)
+    return np.maximum(y, 0) if relu else y

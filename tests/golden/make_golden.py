@@ -1,0 +1,184 @@
+#!/usr/bin/env python3
+"""Generate the committed golden vectors under tests/golden/ from the reference.
+
+TEST INFRASTRUCTURE.  Runs ONLY in the build container, where the read-only
+reference checkout is mounted at /root/reference.  Nothing here is shipped or
+imported by the product; only the *outputs* (small .npz / .json data files)
+are committed.  No reference source is copied: the numpy/scipy-only reference
+functions are imported in-place (TensorFlow stubbed, package __init__ files
+bypassed) and called on inputs defined in this script.
+
+What is produced (and what pins it):
+  bilinear_kernels.npz   xview/models/custom_layers.py:8-25  bilinear_filter_initializer
+  notebook_868.npz       'Experimental Details.ipynb' cell 12 output: experiment 868
+                         confusion matrices (rgb, depth measure set; fused test set)
+                         and the measures printed there (base_model.py:315-329)
+  bayes_lut.npz          xview/models/bayes_mix.py:61-112 bayes_decision_matrix on the
+                         notebook matrices, class_prior in {'data','uniform',0.5}
+  dirichlet_fit.npz      xview/models/dirichletDifferentiation.py:129-192
+                         findDirichletPriors on seeded synthetic sufficient statistics
+  weight_names.json      'Synthia Rand Cityscapes Examples.ipynb' variable-name list of a
+                         BN-free FCN expert (npz weight schema)
+
+Usage:  python tests/golden/make_golden.py     (from the repo root)
+"""
+import contextlib
+import importlib
+import importlib.util
+import io
+import json
+import os
+import re
+import sys
+import types
+
+import numpy as np
+
+REF = '/root/reference'
+OUT = os.path.dirname(os.path.abspath(__file__))
+sys.dont_write_bytecode = True
+
+
+class _Any(types.ModuleType):
+    """Attribute-absorbing stand-in for modules that are absent here (tensorflow...)."""
+
+    def __getattr__(self, k):
+        if k.startswith('__'):
+            raise AttributeError(k)
+        m = _Any(self.__name__ + '.' + k)
+        setattr(self, k, m)
+        return m
+
+    def __call__(self, *a, **k):
+        return _Any('call')
+
+
+def _install_stubs():
+    for n in ['tensorflow', 'tensorflow.python', 'tensorflow.python.layers',
+              'tensorflow.python.layers.layers', 'tensorflow.python.ops',
+              'tensorflow.python.ops.init_ops', 'experiments', 'experiments.utils', 'tqdm']:
+        sys.modules[n] = _Any(n)
+    sys.modules['tensorflow.python.ops.init_ops'].Initializer = object
+    sys.modules['tensorflow'].constant_initializer = lambda value=None, **k: value
+    for pkg, path in [('xview', REF + '/xview'), ('xview.models', REF + '/xview/models')]:
+        m = types.ModuleType(pkg)
+        m.__path__ = [path]
+        sys.modules[pkg] = m
+
+
+def _load_file(name, path):
+    spec = importlib.util.spec_from_file_location(name, path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def notebook_868():
+    nb = json.load(open(REF + '/Experimental Details.ipynb'))
+    text = None
+    for cell in nb['cells']:
+        for o in cell.get('outputs', []):
+            t = o.get('text') or o.get('data', {}).get('text/plain')
+            if t and "'confusion_matrices'" in ''.join(t):
+                text = ''.join(t)
+    assert text is not None
+    text = re.sub(r"\{'py/id': \d+\}", 'None', text)
+    info = eval(text, {'array': np.array, 'nan': float('nan')})
+    return info
+
+
+def main():
+    _install_stubs()
+    cl = importlib.import_module('xview.models.custom_layers')
+    bm = importlib.import_module('xview.models.bayes_mix')
+    dd = _load_file('ref_dirichletDifferentiation',
+                    REF + '/xview/models/dirichletDifferentiation.py')
+
+    # --- bilinear kernels -------------------------------------------------
+    k4 = np.asarray(cl.bilinear_filter_initializer([4, 4, 5, 5]), dtype=np.float64)
+    k16 = np.asarray(cl.bilinear_filter_initializer([16, 16, 3, 3]), dtype=np.float64)
+    np.savez_compressed(os.path.join(OUT, 'bilinear_kernels.npz'), k4=k4, k16=k16)
+
+    # --- notebook confusion matrices + measures ----------------------------
+    info = notebook_868()
+    cms = info['confusion_matrices']
+    meas = info['measurements']
+    # cm_*: measure-set matrices the Bayes fusion is built from (info['confusion_matrices']);
+    # test_cm_*: the test-set matrices the printed measures were derived from.
+    save = {'cm_rgb': np.asarray(cms['rgb'], np.float64),
+            'cm_depth': np.asarray(cms['depth'], np.float64),
+            'test_cm_fusion': np.asarray(info['confusion_matrix'], np.float64),
+            'test_cm_rgb': np.asarray(meas['rgb']['confusion_matrix'], np.float64),
+            'test_cm_depth': np.asarray(meas['depth']['confusion_matrix'], np.float64)}
+    for who, m in meas.items():
+        for key, val in m.items():
+            if val is None or key == 'confusion_matrix':
+                continue
+            save['{}__{}'.format(who, key)] = np.asarray(val, np.float64)
+    np.savez_compressed(os.path.join(OUT, 'notebook_868.npz'), **save)
+
+    # --- bayes decision matrices (reference numpy function) ---------------
+    # BayesFusion.__init__ (bayes_mix.py:141,145-147) hands bayes_fusion the TRANSPOSED
+    # float32 matrices; the LUT function is fed the same way here.
+    mats = [save['cm_rgb'].astype('float32').T, save['cm_depth'].astype('float32').T]
+    luts = {}
+    with np.errstate(divide='ignore', invalid='ignore'):
+        for name, prior in [('data', 'data'), ('uniform', 'uniform'), ('w0p5', 0.5)]:
+            luts['lut_' + name] = bm.bayes_decision_matrix(mats, prior).astype(np.int64)
+        # a matrix with an empty ground-truth class (exercises nan_to_num)
+        holes = [m.copy() for m in mats]
+        for m in holes:
+            m[:, 5] = 0
+        luts['lut_holes_data'] = bm.bayes_decision_matrix(holes, 'data').astype(np.int64)
+        luts['lut_holes_uniform'] = bm.bayes_decision_matrix(holes, 'uniform').astype(np.int64)
+    np.savez_compressed(os.path.join(OUT, 'bayes_lut.npz'), **luts)
+
+    # --- Dirichlet fitter ---------------------------------------------------
+    rng = np.random.default_rng(20181001)
+    cases = {}
+    idx = 0
+    for C in (4, 12):
+        for (delta, beta) in [(0.0, 0.0), (1e-2, 1e-2), (0.05, 0.3)]:
+            alpha_true = rng.uniform(0.3, 6.0, size=C)
+            alpha_neg = rng.uniform(0.3, 3.0, size=C)
+            x = rng.dirichlet(alpha_true, size=4000)
+            y = rng.dirichlet(alpha_neg, size=4000)
+            ss = np.log(1e-10 + x).mean(0)
+            neg_ss = np.log(1e-10 + y).mean(0)
+            with contextlib.redirect_stdout(io.StringIO()):
+                fit = dd.findDirichletPriors(ss, neg_ss, np.ones(C), max_iter=10000,
+                                             delta=delta, beta=beta)
+            cases['case%d_ss' % idx] = ss
+            cases['case%d_neg_ss' % idx] = neg_ss
+            cases['case%d_delta_beta' % idx] = np.array([delta, beta])
+            cases['case%d_alpha' % idx] = np.asarray(fit, np.float64)
+            idx += 1
+    cases['num_cases'] = np.array(idx)
+    np.savez_compressed(os.path.join(OUT, 'dirichlet_fit.npz'), **cases)
+
+    # --- variable-name list of a BN-free FCN expert -------------------------
+    nb = json.load(open(REF + '/Synthia Rand Cityscapes Examples.ipynb'))
+    names = None
+    for cell in nb['cells']:
+        for o in cell.get('outputs', []):
+            t = o.get('text') or o.get('data', {}).get('text/plain')
+            if not t:
+                continue
+            s = ''.join(t)
+            # the list appears as import_weights' per-variable warnings (base_model.py:446-448)
+            found = re.findall(r"WARNING: (rgb/[A-Za-z0-9_]+/(?:kernel|bias)) not found", s)
+            if len(found) > 20:
+                names = found
+    assert names, 'variable list not found'
+    # de-duplicate, keep order
+    seen, uniq = set(), []
+    for n in names:
+        if n not in seen:
+            seen.add(n)
+            uniq.append(n)
+    json.dump({'variables': uniq}, open(os.path.join(OUT, 'weight_names.json'), 'w'), indent=1)
+    print('golden vectors written to', OUT)
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,169 @@
+"""The oracle checked against the reference-generated golden vectors (tests/golden/,
+made by tests/golden/make_golden.py) and against its own independent numpy twin."""
+import os
+
+import numpy as np
+import pytest
+from scipy.stats import dirichlet as sp_dirichlet
+
+from oracle import fcn_oracle as fo
+from oracle import fusion_oracle as fu
+
+
+def _g(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name))
+
+
+def test_bilinear_kernels_match_reference(golden_dir):
+    g = _g(golden_dir, 'bilinear_kernels.npz')
+    np.testing.assert_array_equal(fo.bilinear_kernel(4, 5), g['k4'].astype(np.float32))
+    np.testing.assert_array_equal(fo.bilinear_kernel(16, 3), g['k16'].astype(np.float32))
+
+
+def test_score_measures_match_notebook(golden_dir):
+    g = _g(golden_dir, 'notebook_868.npz')
+    for who, cm in (('rgb', 'test_cm_rgb'), ('depth', 'test_cm_depth'), ('fusion', 'test_cm_fusion')):
+        m = fu.score_measures(g[cm])
+        for key in ('mean_IoU', 'mean_F1', 'total_accuracy'):
+            assert m[key] == float(g['%s__%s' % (who, key)]), (who, key)
+        for key in ('IoU', 'F1', 'precision', 'recall'):
+            np.testing.assert_allclose(m[key], g['%s__%s' % (who, key)], rtol=0, atol=5e-9)
+
+
+@pytest.mark.parametrize('name,prior', [('data', 'data'), ('uniform', 'uniform'), ('w0p5', 0.5)])
+def test_bayes_decision_matrix_matches_reference(golden_dir, name, prior):
+    g = _g(golden_dir, 'notebook_868.npz')
+    luts = _g(golden_dir, 'bayes_lut.npz')
+    mats = [g['cm_rgb'].astype('float32').T, g['cm_depth'].astype('float32').T]
+    np.testing.assert_array_equal(fu.bayes_decision_matrix(mats, prior), luts['lut_' + name])
+
+
+@pytest.mark.parametrize('prior', ['data', 'uniform'])
+def test_bayes_decision_matrix_empty_class(golden_dir, prior):
+    g = _g(golden_dir, 'notebook_868.npz')
+    luts = _g(golden_dir, 'bayes_lut.npz')
+    mats = [g['cm_rgb'].astype('float32').T.copy(), g['cm_depth'].astype('float32').T.copy()]
+    for m in mats:
+        m[:, 5] = 0
+    np.testing.assert_array_equal(fu.bayes_decision_matrix(mats, prior), luts['lut_holes_' + prior])
+
+
+def test_bayes_fusion_graph_agrees_with_lut(golden_dir):
+    """The fp32 per-pixel graph (bayes_mix.py:12-58) and the float64 LUT (61-112) decide
+    the same class wherever the top-2 margin exceeds fp32 rounding."""
+    g = _g(golden_dir, 'notebook_868.npz')
+    mats = [g['cm_rgb'].astype('float32').T, g['cm_depth'].astype('float32').T]
+    C = 12
+    a, b = np.meshgrid(np.arange(C), np.arange(C), indexing='ij')
+    score, lls, conds = fu.bayes_fusion([a[None], b[None]], mats, 'data')
+    lut = fu.bayes_decision_matrix(mats, 'data')
+    top2 = np.sort(score[0], axis=-1)[..., -2:]
+    clear = (top2[..., 1] - top2[..., 0]) > 1e-4
+    assert clear.mean() > 0.95
+    np.testing.assert_array_equal(np.argmax(score[0], -1)[clear], lut[clear])
+
+
+def test_dirichlet_log_prob_vs_scipy():
+    rng = np.random.default_rng(3)
+    for C in (3, 12):
+        alpha = rng.uniform(0.2, 8.0, C)
+        x = rng.dirichlet(np.ones(C), size=64)
+        ours = fu.dirichlet_log_prob(x, alpha)
+        ref = np.array([sp_dirichlet.logpdf(xi / xi.sum(), alpha) for xi in x])
+        np.testing.assert_allclose(ours, ref, rtol=2e-5, atol=2e-4)
+
+
+def test_conv_pool_deconv_torch_vs_naive_twin():
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal((2, 6, 8, 5)).astype(np.float32)
+    w = rng.standard_normal((3, 3, 5, 7)).astype(np.float32)
+    b = rng.standard_normal(7).astype(np.float32)
+    import torch
+    xt = torch.from_numpy(x).permute(0, 3, 1, 2)
+    y = fo.conv2d_same(xt, w, b, relu=True).permute(0, 2, 3, 1).numpy()
+    np.testing.assert_allclose(y, fo.naive_conv2d_same(x, w, b, relu=True), rtol=1e-5, atol=1e-5)
+    w1 = rng.standard_normal((1, 1, 5, 4)).astype(np.float32)
+    y = fo.conv2d_same(xt, w1, None).permute(0, 2, 3, 1).numpy()
+    np.testing.assert_allclose(y, fo.naive_conv2d_same(x, w1), rtol=1e-5, atol=1e-5)
+    np.testing.assert_array_equal(fo.maxpool2(xt).permute(0, 2, 3, 1).numpy(), fo.naive_maxpool2(x))
+    for k, s in ((4, 2), (16, 8)):
+        # general (non-diagonal) kernel: checks layout [kh,kw,out,in] and the 'same' crop
+        wd = rng.standard_normal((k, k, 3, 5)).astype(np.float32)
+        y = fo.deconv_same(xt, wd, s).permute(0, 2, 3, 1).numpy()
+        assert y.shape == (2, 6 * s, 8 * s, 3)
+        np.testing.assert_allclose(y, fo.naive_deconv_same(x, wd, s), rtol=1e-4, atol=1e-4)
+        # bilinear constant: dense == depthwise
+        wb = fo.bilinear_kernel(k, 5)
+        y = fo.deconv_same(xt, wb, s, relu=True).permute(0, 2, 3, 1).numpy()
+        np.testing.assert_allclose(y, fo.depthwise_bilinear_up(x, s, relu=True), rtol=1e-5, atol=1e-5)
+
+
+def test_bilinear_interior_of_ones_is_ones():
+    x = np.ones((1, 5, 6, 2), np.float32)
+    for s in (2, 8):
+        y = fo.depthwise_bilinear_up(x, s)
+        np.testing.assert_allclose(y[:, s:-s, s:-s], 1.0, atol=1e-12)
+        assert y[0, 0, 0, 0] < 1.0          # zero padding attenuates the border
+
+
+def test_fcn_forward_shapes_and_policy():
+    rng = np.random.default_rng(0)
+    w = fo.init_fcn_weights('rgb', 3, 8, 12, seed=1, bias_scale=0.05)
+    x = rng.integers(0, 256, (1, 32, 48, 3)).astype(np.float32)
+    o32 = fo.fcn_forward(x, w, 'rgb', 'fp32', keep=['fused', 'score', 'conv1_1', 'pool4'])
+    assert o32['score'].shape == (1, 32, 48, 12) and o32['fused'].shape == (1, 4, 6, 8)
+    assert o32['pool4'].shape == (1, 2, 3, 512)
+    o16 = fo.fcn_forward(x, w, 'rgb', 'bf16')
+    rel = np.abs(o16['score'] - o32['score']).max() / np.abs(o32['score']).max()
+    assert rel < 0.05
+    p = fo.softmax(o32['score'])
+    np.testing.assert_allclose(p.sum(-1), 1.0, atol=1e-5)
+    assert fo.argmax_last(p).dtype == np.int64
+
+
+def test_argmax_first_index_on_ties():
+    s = np.zeros((1, 1, 2, 4), np.float32)
+    s[0, 0, 1] = [1, 3, 3, 0]
+    np.testing.assert_array_equal(fo.argmax_last(fo.softmax(s))[0, 0], [0, 1])
+
+
+def test_cross_entropy_ignores_negative_labels():
+    rng = np.random.default_rng(1)
+    score = rng.standard_normal((1, 4, 4, 5)).astype(np.float32)
+    lab = rng.integers(-1, 5, (1, 4, 4))
+    lp = fo.log_softmax(score)
+    loss, grad = fo.cross_entropy(lp, lab, 5)
+    valid = lab >= 0
+    ref = -lp[valid, lab[valid]].astype(np.float64).mean()
+    assert abs(loss - ref) < 1e-6
+    assert np.all(grad[~valid] == 0)
+    # finite-difference check of the gradient
+    i = (0, 1, 2, 3)
+    eps = 1e-2
+    s2 = score.copy(); s2[i] += eps
+    l2, _ = fo.cross_entropy(fo.log_softmax(s2), lab, 5)
+    assert abs((l2 - loss) / eps - grad[i]) < 5e-3
+
+
+def test_confusion_matrix_and_suffstats():
+    rng = np.random.default_rng(2)
+    lab = rng.integers(-1, 4, (2, 5, 5))
+    pred = rng.integers(0, 4, (2, 5, 5))
+    cm = fu.confusion_matrix(lab, pred, 4)
+    assert cm.sum() == (lab >= 0).sum()
+    assert cm[2, 3] == ((lab == 2) & (pred == 3)).sum()
+    p = rng.dirichlet(np.ones(4), size=(2, 5, 5)).astype(np.float32)
+    S, n = fu.sufficient_statistics(p, lab, 4)
+    assert n.sum() == (lab >= 0).sum()
+    np.testing.assert_allclose(S[1], np.log(1e-10 + p[lab == 1].astype(np.float64)).sum(0), rtol=1e-6)
+
+
+def test_optimizer_formulas():
+    th, g = np.array([1.0, -2.0]), np.array([0.5, -0.25])
+    t1, m, v = fu.adam_step(th, g, np.zeros(2), np.zeros(2), 1, lr=0.1)
+    # first Adam step moves by ~lr*sign(g)
+    np.testing.assert_allclose(t1, th - 0.1 * np.sign(g), atol=1e-6)
+    t1, ms = fu.rmsprop_step(th, g, np.ones(2), lr=0.1)
+    np.testing.assert_allclose(t1, th - 0.1 * g / np.sqrt(0.9 + 0.1 * g * g + 1e-10))
+    t1, acc = fu.adagrad_step(th, g, np.full(2, 0.1), lr=0.1)
+    np.testing.assert_allclose(t1, th - 0.1 * g / np.sqrt(0.1 + g * g))
