@@ -1,0 +1,188 @@
+#!/usr/bin/env python3
+"""Headline benchmark: images/sec of the two-stream (RGB + depth) SimpleFCN experts + Bayes
+fusion + argmax at 768x384 on MI355X (BASELINE.json configs[1]); protocol of the reference's
+experiments/timing.py (inputs resident on the device, wall clock around the whole pipeline).
+
+  python bench.py [--gpus N --steps K --warmup W] [--batch B] [--height 384 --width 768]
+                  [--fusion bayes|dirichlet] [--no-cpu-baseline]
+N > 1 is launched by the driver through torch.distributed.run (one rank per GPU); images are
+independent, so ranks shard the batch with no data-path collective ("weak" scaling) and only the
+timing is reduced (MAX over ranks).  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_BF16_TFLOPS = 2500.0     # dense bf16 MFMA, MI355X_MICROARCH.md chip table
+C, U = 12, 64
+
+
+def conv_flops_per_image(h, w, cin):
+    """Credited conv FLOPs of one FCN stream (181.23 GFLOP at 384x768 RGB)."""
+    layers = [(cin, 64, 1), (64, 64, 1), (64, 128, 2), (128, 128, 2), (128, 256, 4), (256, 256, 4), (256, 256, 4),
+              (256, 512, 8), (512, 512, 8), (512, 512, 8), (512, 512, 16), (512, 512, 16), (512, 512, 16)]
+    f = sum(2.0 * (h // s) * (w // s) * ci * co * 9 for ci, co, s in layers)
+    f += 2.0 * (h // 8) * (w // 8) * 512 * U + 2.0 * (h // 16) * (w // 16) * 512 * U + 2.0 * h * w * U * C
+    return f
+
+
+def build_model(args, device):
+    from modular_semantic_segmentation_amd import get_model
+    g = np.load(os.path.join(ROOT, 'tests', 'golden', 'notebook_868.npz'))
+    desc = ({'rgb': 'float32', 'depth': 'float32', 'labels': 'int32'},
+            {'rgb': (None, None, 3), 'depth': (None, None, 1), 'labels': (None, None)}, C)
+    common = dict(data_description=desc, num_units=U, num_channels={'rgb': 3, 'depth': 1}, expert_model='fcn',
+                  class_prior='data', batchsize=args.batch, seed=1, device=str(device))
+    if args.fusion == 'bayes':
+        net = get_model('bayes_fusion')(confusion_matrices={'rgb': g['cm_rgb'], 'depth': g['cm_depth']},
+                                        prefixes={'rgb': 'rgb', 'depth': 'depth'}, **common)
+    else:
+        rng = np.random.default_rng(2)
+        params = {'rgb': rng.uniform(0.5, 4.0, (C, C)), 'depth': rng.uniform(0.5, 4.0, (C, C)),
+                  'class_counts': g['cm_depth'].sum(1)}
+        net = get_model('dirichlet_fusion')(dirichlet_params=params, modalities=['rgb', 'depth'], sigma=1.0,
+                                            delta=1e-2, beta=1e-2, **common)
+    # a trained depth expert absorbs the raw uint16 range in conv1_1; random init needs the scale
+    net.variables['depth/conv1_1/kernel'] = net.variables['depth/conv1_1/kernel'] / 256.0
+    net._variables_changed()
+    return net
+
+
+def cpu_baseline(args, variables, cms):
+    """The oracle (op-for-op fp32 restatement of the reference graph) timed on this host's cores
+    on a bounded sample of the same workload: whole 768x384 RGB-D images, one at a time."""
+    from oracle import fcn_oracle as fo
+    from oracle import fusion_oracle as fu
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    rng = np.random.default_rng(0)
+    mats = [cms['rgb'].astype('float32').T, cms['depth'].astype('float32').T]
+
+    def one():
+        rgb = rng.integers(0, 256, (1, args.height, args.width, 3)).astype(np.float32)
+        depth = rng.integers(0, 65536, (1, args.height, args.width, 1)).astype(np.float32)
+        la = fo.argmax_last(fo.softmax(fo.fcn_forward(rgb, variables, 'rgb', 'fp32', keep=['score'])['score']))
+        lb = fo.argmax_last(fo.softmax(fo.fcn_forward(depth, variables, 'depth', 'fp32', keep=['score'])['score']))
+        return np.argmax(fu.bayes_fusion([la, lb], mats, 'data')[0], -1)
+
+    one()                                    # warm-up
+    t0 = time.perf_counter()
+    n = 0
+    while n < 5 and (time.perf_counter() - t0) < 20.0:
+        one()
+        n += 1
+    dt = time.perf_counter() - t0
+    return {'value': n / dt, 'unit': 'images/s', 'cores': cores, 'kind': 'port',
+            'sample': '%d RGB-D images of %dx%d, batch 1, fp32 PyTorch-CPU oracle (two FCN experts + Bayes fusion), '
+                      '%.1f s' % (n, args.width, args.height, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--batch', type=int, default=8, help='images per GPU per step')
+    ap.add_argument('--height', type=int, default=384)
+    ap.add_argument('--width', type=int, default=768)
+    ap.add_argument('--fusion', default='bayes', choices=['bayes', 'dirichlet'])
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+    device = torch.device('cuda', local_rank)
+    torch.cuda.set_device(device)
+
+    from modular_semantic_segmentation_amd import ops
+    net = build_model(args, device)
+    gen = torch.Generator(device='cpu').manual_seed(1234 + rank)
+    rgb = torch.randint(0, 256, (args.batch, args.height, args.width, 3), generator=gen).float().to(device)
+    depth = torch.randint(0, 65536, (args.batch, args.height, args.width, 1), generator=gen).float().to(device)
+    batch = {'rgb': rgb, 'depth': depth}
+
+    def step():
+        return net._predict_batch(batch)
+
+    for _ in range(args.warmup):
+        step()
+
+    def fence():
+        torch.cuda.synchronize(device)
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize(device)
+
+    prof = []
+    ops.CONV_PROFILE = prof           # HIP events around every MFMA conv launch, on the launch stream
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    fence()
+    dt = time.perf_counter() - t0
+    ops.CONV_PROFILE = None
+    tmax = torch.tensor([dt], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+
+    # dominant kernel: the 3x3 implicit-GEMM MFMA conv with Cout % 128 == 0 (conv2_1 .. conv5_3)
+    kinds = {}
+    for kind, flops, e0, e1 in prof:
+        d = kinds.setdefault(kind, [0.0, 0.0, 0])
+        d[0] += flops
+        d[1] += e0.elapsed_time(e1) * 1e-3
+        d[2] += 1
+    dom = 'k3_cout128'
+    roofline = None
+    if dom in kinds and kinds[dom][1] > 0:
+        fl, sec, cnt = kinds[dom]
+        achieved = fl / sec / 1e12
+        roofline = {'bound': 'mfma', 'kernel': 'conv_mfma_kernel<2,1,2,3>', 'achieved': round(achieved, 2),
+                    'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(achieved / PEAK_BF16_TFLOPS, 4),
+                    'traffic': None, 'launches': cnt, 'avg_launch_ms': round(sec / cnt * 1e3, 4),
+                    'all_mfma_conv_tflops': round(sum(v[0] for v in kinds.values()) /
+                                                  sum(v[1] for v in kinds.values()) / 1e12, 2)}
+
+    if rank == 0:
+        images = args.batch * world * args.steps
+        flops_img = conv_flops_per_image(args.height, args.width, 3) + conv_flops_per_image(args.height, args.width, 1)
+        res = {
+            'metric': 'images/sec at 768x384 RGB-D FCN (two SimpleFCN experts + %s fusion + argmax, inference)' % args.fusion,
+            'value': round(images / dt, 2), 'unit': 'images/s', 'n_gpus': world, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True,
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
+            'config': {'workload': 'two-stream SimpleFCN RGB+Depth %dx%d + %s fusion, U=%d, C=%d, random-init weights'
+                                   % (args.width, args.height, args.fusion, U, C),
+                       'images_per_gpu_per_step': args.batch, 'global_batch': args.batch * world,
+                       'parallelism': 'dp%d (batch sharding, no data-path collective)' % world},
+            'conv_tflops_end_to_end': round(images * flops_img / dt / 1e12, 2),
+            'roofline': roofline,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            g = np.load(os.path.join(ROOT, 'tests', 'golden', 'notebook_868.npz'))
+            res['cpu_baseline'] = cpu_baseline(args, net.variables, {'rgb': g['cm_rgb'], 'depth': g['cm_depth']})
+        else:
+            res['cpu_baseline'] = None
+        print(json.dumps(res))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

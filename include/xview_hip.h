@@ -1,0 +1,139 @@
+/*
+ * xview_hip.h -- C ABI of libxview_hip.so: the MI355X (gfx950 / CDNA4) kernels behind the
+ * two-stream FCN + probabilistic-fusion hot path of ethz-asl/modular_semantic_segmentation.
+ *
+ * The reference has NO native boundary for this path: every op below is a TensorFlow-1 graph
+ * op reached through `sess.run` (xview/models/base_model.py:257-258,288-289,310-311).  Each
+ * entry point therefore cites the reference graph call site it replaces; INTEGRATION.md shows
+ * the ctypes binding a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative XV_E* code for a bad argument, or a
+ *     positive hipError_t from the launch; nothing throws, allocates or synchronises
+ *   - all pointers are DEVICE pointers owned by the caller; `stream` is a hipStream_t
+ *   - activations are bf16 "padded NHWC": a dense [N][H+2][W+2][C] buffer whose 1-pixel border is
+ *     zero and is never written by any kernel (3x3 'same' convolutions read it as their zero
+ *     padding; custom_layers.py:124-139 `padding='same'`).  `xv_act.data` points at the first
+ *     element of the padded buffer.  Network inputs/outputs (images, probabilities, label maps)
+ *     are dense unpadded NHWC / NHW tensors in the reference's dtypes (float32 / int64 / int32).
+ */
+#ifndef XVIEW_HIP_H
+#define XVIEW_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define XV_OK 0
+#define XV_EINVAL (-1)      /* bad argument (null pointer, non-positive size, ...)          */
+#define XV_ESHAPE (-2)      /* shape not supported by the kernel (see each function)        */
+#define XV_EWORKSPACE (-3)  /* workspace too small                                          */
+
+/* bf16 padded-NHWC activation: dense [n][h+2][w+2][c], zero border, data -> padded origin */
+typedef struct xv_act {
+  void* data;
+  int32_t n, h, w, c;
+} xv_act;
+
+/* Library version (major*10000 + minor*100 + patch). */
+int xv_version(void);
+/* Name of the gfx target the device code was compiled for ("gfx950"). */
+const char* xv_arch(void);
+
+/* ---- weight packing ------------------------------------------------------------------------
+ * Conv kernels arrive in the reference npz schema: float32 HWIO [k][k][cin][cout]
+ * (base_model.py:361-393 export_weights; tf.layers.conv2d kernel layout).  The MFMA kernels read
+ * them as bf16 [tap][cin/64][cout][64 swizzled], 128 B per (tap, cin-chunk, cout) row with
+ * 16-byte slot s of row `co` stored at slot s ^ ((co>>1)&7) (so a weight tile is a linear copy
+ * into bank-conflict-free LDS).  k = 1 or 3, cin % 64 == 0, cout % 64 == 0.                       */
+size_t xv_packed_weight_bytes(int k, int cin, int cout);
+int xv_pack_conv_weights(const float* w_hwio, void* packed, int k, int cin, int cout, void* stream);
+
+/* ---- conv2d forward ------------------------------------------------------------------------
+ * y = act(conv(x, W) + b): tf.layers.conv2d(padding='same', strides 1) via
+ * custom_layers.py:124-139 (call sites simple_fcn.py:39-79).  Implicit GEMM on bf16 MFMA
+ * (v_mfma_f32_16x16x32_bf16, fp32 accumulate), input halo tile + weight tile staged in LDS.
+ * k = 3 (conv1_2 .. conv5_3) or 1 (score_conv4 / score_conv5); cin % 64 == 0, cout % 64 == 0.
+ * Inference batch-norm is folded into (W, b) by the host before packing.
+ * If pooled != NULL (k = 3 only, h and w even) the 2x2/2 max-pool of y
+ * (max_pooling2d, simple_fcn.py:41,44,48,58) is written to `pooled` from the same accumulators;
+ * y itself may then be NULL (data == NULL) to skip the full-resolution store.                    */
+int xv_conv2d_fwd(const xv_act* x, const void* w_packed, const float* bias, const xv_act* y,
+                  const xv_act* pooled, int k, int relu, void* stream);
+
+/* First layer: conv1_1 = relu(conv3x3(x) + b) on the RAW float32 network input (dense unpadded
+ * NHWC, cin = 1..4; simple_fcn.py:39), fp32 weights HWIO [3][3][cin][64], fp32 math, bf16 out.    */
+int xv_conv2d_first_fwd(const float* x, int n, int h, int w, int cin, const float* w_hwio,
+                        const float* bias, const xv_act* y, int relu, void* stream);
+
+/* 2x2 stride-2 'valid' max pooling (max_pooling2d, simple_fcn.py:41,44,48,58).                  */
+int xv_maxpool2x2_fwd(const xv_act* x, const xv_act* y, void* stream);
+
+/* y = relu(bilinear_x2(x)) [+ residual]: deconv2d(k=4, strides 2, 'same', constant bilinear
+ * diagonal kernel) + relu, then tf.add_n with score_conv4 (custom_layers.py:8-25,71-121;
+ * simple_fcn.py:82-85), computed as the depthwise 2x2-tap interpolation the diagonal kernel
+ * collapses to.  residual may be NULL.                                                           */
+int xv_upsample2x_relu_add(const xv_act* x, const xv_act* residual, const xv_act* y, void* stream);
+
+/* Decoder head, fused: upscore = relu(bilinear_x8(fused)) (deconv2d k=16 s=8, simple_fcn.py:129-130),
+ * score = conv1x1(upscore, Ws) + bs (no activation, simple_fcn.py:131-133), prob = softmax(score),
+ * label = argmax(prob, 3) (basic_fusion_model.py:21-22 / simple_fcn.py:223-224), all fp32 from the
+ * bf16 `fused` features without materialising the full-resolution U-channel tensor.
+ * w_score: float32 [U][C] (HWIO of the 1x1 kernel), b_score: float32 [C], C <= 32, U % 8 == 0, U <= 128.
+ * Outputs (each may be NULL): score / prob float32 [N][8h][8w][C], label int64 [N][8h][8w].        */
+int xv_decoder_head_fwd(const xv_act* fused, const float* w_score, const float* b_score, int num_classes,
+                        float* score, float* prob, int64_t* label, void* stream);
+
+/* prob = softmax(score), label = argmax(prob) on a dense float32 [npix][C] score tensor
+ * (tf.nn.softmax + tf.argmax, basic_fusion_model.py:21-22); lowest index wins ties.  prob / label
+ * may be NULL.                                                                                    */
+int xv_softmax_argmax(const float* score, int64_t npix, int num_classes, float* prob, int64_t* label,
+                      void* stream);
+
+/* ---- fusion --------------------------------------------------------------------------------
+ * Bayes fusion of E experts' label maps (bayes_mix.py:12-58 + tf.argmax at :161):
+ *   score[c] = sum_e loglik[e][label_e][c] + logprior[c],  fused = argmax_c score[c]
+ * labels: E device pointers (host array of device pointers) to int64 [npix]; loglik: float32
+ * [E][C][C] = log(1e-20 + cond_e) computed by the host in fp32; logprior float32 [C].
+ * score_out (float32 [npix][C]) may be NULL.  E <= 4, C <= 32.                                     */
+int xv_bayes_fuse(const int64_t* const* labels, int num_experts, const float* loglik, const float* logprior,
+                  int num_classes, int64_t npix, int64_t* fused, float* score_out, void* stream);
+
+/* Same decision through the C^2 lookup table of bayes_decision_matrix (bayes_mix.py:61-112;
+ * experiments/timing.py:87-115): fused = lut[label_a][label_b], lut int64 [C][C].                  */
+int xv_bayes_fuse_lut(const int64_t* label_a, const int64_t* label_b, const int64_t* lut, int num_classes,
+                      int64_t npix, int64_t* fused, void* stream);
+
+/* Dirichlet fusion of E experts' softmax vectors (dirichlet_mix.py:14-36,96-136):
+ *   p_e <- p_e / sum(p_e);  L_e[c] = sum_k am1[e][c][k] * log(1e-20 + p_e[k]) - lognorm[e][c]
+ *   fused_score[c] = sum_e L_e[c] + logprior[c];  label = argmax_c
+ * am1: float32 [E][C][C] with am1[e][c][k] = sigma*A_e[k][c] - 1; lognorm: float32 [E][C] =
+ * sum_k lgamma(sigma*A_e[k][c]) - lgamma(sum_k ...); logprior = log(1e-20 + prior) float32 [C].
+ * probs: E device pointers to float32 [npix][C].  score_out may be NULL.  E <= 4, C <= 32.          */
+int xv_dirichlet_fuse(const float* const* probs, int num_experts, const float* am1, const float* lognorm,
+                      const float* logprior, int num_classes, int64_t npix, int64_t* fused, float* score_out,
+                      void* stream);
+
+/* Mean of the experts' probabilities then argmax (average_mix.py:18-21).                         */
+int xv_average_fuse(const float* const* probs, int num_experts, int num_classes, int64_t npix,
+                    int64_t* fused, void* stream);
+
+/* ---- statistics ----------------------------------------------------------------------------
+ * Dirichlet sufficient statistics (dirichlet_mix.py:142-163): for every pixel with 0 <= label < C
+ *   S[label][k] += log(1e-10 + prob[k]),  counts[label] += 1
+ * S: float64 [C][C] (accumulated, not zeroed), counts: int64 [C] (accumulated).  labels int32.     */
+int xv_dirichlet_suffstats(const float* prob, const int32_t* labels, int num_classes, int64_t npix,
+                           double* S, int64_t* counts, void* stream);
+
+/* Confusion matrix (base_model.py:136-151): cm[label][pred] += 1 for 0 <= label < C (negative
+ * labels are the dropped (C+1)-th row); cm int64 [C][C], accumulated, rows = ground truth.         */
+int xv_confusion_matrix(const int32_t* labels, const int64_t* pred, int num_classes, int64_t npix,
+                        int64_t* cm, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* XVIEW_HIP_H */

@@ -1,0 +1,80 @@
+"""ctypes binding of libxview_hip.so (the C ABI declared in include/xview_hip.h).
+
+The library is the product's only compute path: if it is missing or a call fails this module
+raises -- there is no CPU or PyTorch fallback.
+"""
+import ctypes
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libxview_hip.so')
+CSRC = os.path.join(_HERE, 'csrc')
+
+
+class XvError(RuntimeError):
+    pass
+
+
+class xv_act(ctypes.Structure):
+    _fields_ = [('data', ctypes.c_void_p), ('n', ctypes.c_int32), ('h', ctypes.c_int32),
+                ('w', ctypes.c_int32), ('c', ctypes.c_int32)]
+
+
+_vp, _i, _i64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64
+_actp = ctypes.POINTER(xv_act)
+_vpp = ctypes.POINTER(ctypes.c_void_p)
+
+# name -> (restype, argtypes); every symbol include/xview_hip.h declares
+SIGNATURES = {
+    'xv_version': (_i, []),
+    'xv_arch': (ctypes.c_char_p, []),
+    'xv_packed_weight_bytes': (ctypes.c_size_t, [_i, _i, _i]),
+    'xv_pack_conv_weights': (_i, [_vp, _vp, _i, _i, _i, _vp]),
+    'xv_conv2d_fwd': (_i, [_actp, _vp, _vp, _actp, _actp, _i, _i, _vp]),
+    'xv_conv2d_first_fwd': (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _actp, _i, _vp]),
+    'xv_maxpool2x2_fwd': (_i, [_actp, _actp, _vp]),
+    'xv_upsample2x_relu_add': (_i, [_actp, _actp, _actp, _vp]),
+    'xv_decoder_head_fwd': (_i, [_actp, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
+    'xv_softmax_argmax': (_i, [_vp, _i64, _i, _vp, _vp, _vp]),
+    'xv_bayes_fuse': (_i, [_vpp, _i, _vp, _vp, _i, _i64, _vp, _vp, _vp]),
+    'xv_bayes_fuse_lut': (_i, [_vp, _vp, _vp, _i, _i64, _vp, _vp]),
+    'xv_dirichlet_fuse': (_i, [_vpp, _i, _vp, _vp, _vp, _i, _i64, _vp, _vp, _vp]),
+    'xv_average_fuse': (_i, [_vpp, _i, _i, _i64, _vp, _vp]),
+    'xv_dirichlet_suffstats': (_i, [_vp, _vp, _i, _i64, _vp, _vp, _vp]),
+    'xv_confusion_matrix': (_i, [_vp, _vp, _i, _i64, _vp, _vp]),
+}
+
+_lib = None
+
+
+def build(force=False):
+    """Compile csrc/*.hip for gfx950 into libxview_hip.so (hipcc cross-compiles without a GPU)."""
+    if force and os.path.exists(LIB_PATH):
+        os.remove(LIB_PATH)
+    subprocess.run(['make', '-C', CSRC, '-j4'], check=True, stdout=subprocess.DEVNULL)
+    if not os.path.exists(LIB_PATH):
+        raise XvError('build did not produce ' + LIB_PATH)
+    return LIB_PATH
+
+
+def lib():
+    """Load (once) and return the ctypes handle; raises XvError if the library is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise XvError('%s not found: run `python -c "import __graft_entry__ as g; g.build()"` '
+                          '(hipcc --offload-arch=gfx950); there is no fallback path' % LIB_PATH)
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)      # AttributeError if the export is missing
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def check(code, what):
+    if code != 0:
+        kind = {-1: 'XV_EINVAL', -2: 'XV_ESHAPE', -3: 'XV_EWORKSPACE'}.get(code, 'hipError_t %d' % code)
+        raise XvError('%s failed: %s' % (what, kind))

@@ -1,0 +1,245 @@
+"""BaseModel: the drop-in API boundary of the hot path (reference: xview/models/base_model.py).
+
+Same constructor contract, same method names / arguments / return types as the reference's
+TensorFlow BaseModel -- `fit`, `predict`, `score`, `export_weights`, `import_weights`, `close`,
+context-manager use -- but there is no graph or session: a model owns HIP-resident engines
+(fcn.FcnEngine) and every per-pixel op runs in libxview_hip.so on the current HIP stream.
+
+Data contract (base_model.py:10-38 transform_inputdata): `data` is either a dict of arrays with a
+leading sample axis ({'rgb': [N,H,W,3] f32, 'depth': [N,H,W,1] f32, 'labels': [N,H,W] i32}), or any
+iterable of per-sample dicts (the tf.data.Dataset case); both are cut into batches of
+config['batchsize'].
+"""
+import os
+from copy import deepcopy
+
+import numpy as np
+import torch
+
+
+def iterate_batches(data, batchsize, max_batches=None):
+    """Yield dicts of numpy arrays with a leading batch axis (<= batchsize samples each)."""
+    count = 0
+    if isinstance(data, dict):
+        n = len(next(iter(data.values())))
+        for i in range(0, n, batchsize):
+            if max_batches is not None and count >= max_batches:
+                return
+            yield {k: np.asarray(v[i:i + batchsize]) for k, v in data.items()}
+            count += 1
+        return
+    pending = []
+    for sample in data:
+        pending.append(sample)
+        if len(pending) == batchsize:
+            if max_batches is not None and count >= max_batches:
+                return
+            yield {k: np.stack([np.asarray(s[k]) for s in pending]) for k in pending[0]}
+            count += 1
+            pending = []
+    if pending and (max_batches is None or count < max_batches):
+        yield {k: np.stack([np.asarray(s[k]) for s in pending]) for k in pending[0]}
+
+
+def score_measures(confusion_matrix):
+    """Measures of base_model.py:315-329 from a [C,C] matrix (rows = ground truth)."""
+    cm = np.asarray(confusion_matrix, np.float64)
+    with np.errstate(divide='ignore', invalid='ignore'):
+        measures = {'confusion_matrix': cm}
+        diag = np.diag(cm)
+        measures['recall'] = diag / cm.sum(1)
+        measures['precision'] = diag / cm.sum(0)
+        measures['F1'] = 2 * measures['precision'] * measures['recall'] / \
+            (measures['precision'] + measures['recall'])
+        measures['mean_F1'] = np.nanmean(measures['F1'])
+        measures['total_accuracy'] = diag[1:].sum() / cm[1:, :].sum()   # class 0 = void is excluded
+        measures['IoU'] = diag / (cm.sum(1) + cm.sum(0) - diag)
+        measures['mean_IoU'] = np.nanmean(measures['IoU'][1:])
+    return measures
+
+
+class BaseModel(object):
+    """Handles IO, batching, scoring and weight files; subclasses implement `_build_graph`
+    (create engines / tables) and `_predict_batch`."""
+
+    required_attributes = [["loss"], ["prediction"]]
+
+    def __init__(self, data_description, name=None, output_dir=None, custom_training=False,
+                 batchsize=1, **config):
+        self.name = type(self).__name__ if name is None else name
+        self.output_dir = output_dir
+        self.custom_training = custom_training
+        self.config = config
+        self.config['batchsize'] = batchsize
+        self.config['num_classes'] = data_description[2]
+        # (dtypes, shapes, num_classes) as produced by DataBaseclass.get_data_description
+        self.testdata_description = [data_description[0],
+                                     {key: [None, *shape] for key, shape in data_description[1].items()}]
+        self.device = torch.device(config.get('device', 'cuda'))
+        self.variables = {}          # name -> np.ndarray, the reference's tf.global_variables()
+        self.global_step = 0
+        self._closed = False
+        self._initialize_graph()
+
+    # ---- to be provided by subclasses ----------------------------------------------------------
+    def _build_graph(self):
+        raise NotImplementedError
+
+    def _predict_batch(self, batch, output_attr=None):
+        """batch: dict of numpy arrays -> device tensor (int64 [N,H,W] labels by default)."""
+        raise NotImplementedError
+
+    def _train_batch(self, batch):
+        raise UserWarning('ERROR: Model %s does not support training' % self.name)
+
+    def _initialize_graph(self):
+        self._build_graph()
+        if not self.custom_training:
+            missing = [attrs for attrs in self.required_attributes
+                       if True not in [hasattr(self, attr) for attr in attrs]]
+            if missing:
+                raise AttributeError('Model class requires attributes %s' % missing)
+        elif not hasattr(self, 'prediction'):
+            raise AttributeError('Model class required attribute prediction')
+
+    # ---- helpers ------------------------------------------------------------------------------------
+    def _to_device(self, array, dtype):
+        """numpy (host) or torch (already resident in HBM) -> contiguous device tensor of `dtype`."""
+        if isinstance(array, torch.Tensor):
+            return array.to(device=self.device, dtype=dtype).contiguous()
+        t = torch.from_numpy(np.ascontiguousarray(array))
+        return t.to(device=self.device, dtype=dtype, non_blocking=False).contiguous()
+
+    def _confusion_of_batch(self, batch, cm_dev):
+        from . import ops
+        pred = self._predict_batch(batch)
+        labels = self._to_device(batch['labels'], torch.int32)
+        ops.confusion_matrix(labels, pred.contiguous(), cm_dev)
+
+    # ---- public API -----------------------------------------------------------------------------------
+    def fit(self, dataset, iterations, output=True, validation_dataset=None, validation_interval=100,
+            additional_eval_datasets={}):
+        """Train for `iterations` steps (base_model.py:180-261)."""
+        if self.custom_training:
+            raise UserWarning('ERROR: Model %s does not support training' % self.name)
+
+        def endless():
+            while True:
+                empty = True
+                for b in iterate_batches(dataset, self.config['batchsize']):
+                    empty = False
+                    yield b
+                if empty:
+                    return
+
+        if output:
+            print('INFO: Start training')
+        batches = endless()
+        for i in range(iterations):
+            loss = self._train_batch(next(batches))
+            self.global_step += 1
+            if i % validation_interval == 0 and validation_dataset is not None:
+                score, _ = self.score(validation_dataset)
+                if output:
+                    print('{:4d}: loss {:.4f} accuracy {:.2f}, IoU {:.2f}'.format(
+                        i, float(loss), score['total_accuracy'], score['mean_IoU']))
+                for key, extra in additional_eval_datasets.items():
+                    self.score(extra)
+                if 'abort_at_iou' in self.config and score['mean_IoU'] > self.config['abort_at_iou']:
+                    break
+        if output:
+            print('INFO: Training finished.')
+
+    def predict(self, data, output_attr=None):
+        """Semantic segmentation of `data` (base_model.py:263-292): np.int64 [N,H,W], or the named
+        output (e.g. 'prob', 'fused_score') when `output_attr` names something the model exposes."""
+        ret = []
+        for batch in iterate_batches(data, self.config['batchsize']):
+            out = self._predict_batch(batch, output_attr=output_attr)
+            ret.append(out.cpu().numpy())
+        return np.concatenate(ret)
+
+    def score(self, data, max_iterations=None):
+        """(measures dict, confusion matrix float64 [C,C]) over `data` (base_model.py:294-331)."""
+        C = self.config['num_classes']
+        cm_dev = torch.zeros((C, C), dtype=torch.int64, device=self.device)
+        for batch in iterate_batches(data, self.config['batchsize'], max_iterations):
+            self._confusion_of_batch(batch, cm_dev)
+        confusion_matrix = cm_dev.cpu().numpy().astype(np.float64)
+        return score_measures(confusion_matrix), confusion_matrix
+
+    # ---- weights ----------------------------------------------------------------------------------------
+    def _variables_changed(self):
+        """Called after self.variables was modified; subclasses re-upload to the GPU."""
+
+    def export_weights(self, save_dir=None):
+        """npz of every variable keyed by its TF op name, `{name}_weights_{step}.npz`
+        (base_model.py:361-393)."""
+        if save_dir is None and self.output_dir is None:
+            print('ERROR: No path specified to save weights to.')
+            return
+        save_dict = {k: np.asarray(v) for k, v in self.variables.items()}
+        save_dict['global_step'] = np.asarray(self.global_step, np.int32)
+        output_path = os.path.join(save_dir if save_dir is not None else self.output_dir,
+                                   '{}_weights_{}.npz'.format(self.name, int(self.global_step)))
+        np.savez_compressed(output_path, **save_dict)
+        print('INFO: Weights saved to {}'.format(output_path))
+        return output_path
+
+    def import_weights(self, filepath, translate_prefix=False, chill_mode=False, warnings=True):
+        """Assign variables from an npz by name (base_model.py:396-451): optional prefix translation,
+        legacy `prefix_layer/...` names, optimizer slots skipped, `chill_mode` ignores shape
+        mismatches (leaves the variable unassigned)."""
+        if warnings:
+            print(filepath)
+        weights = np.load(filepath)
+        keys = list(weights.keys())
+        import_prefix = keys[0].split('/')[0].split('_')[0]
+
+        def translate_name(name):
+            if not translate_prefix or not name.startswith(translate_prefix):
+                return name
+            splitted = name.split('/')
+            further = splitted[0].split('_')
+            if further[0] == 'forest':
+                return name
+            further[0] = import_prefix
+            splitted[0] = '_'.join(further)
+            return '/'.join(splitted)
+
+        for var_name in list(self.variables):
+            name = translate_name(var_name)
+            if 'grad' in name or 'Adam' in name or 'RMS' in name:
+                continue
+            legacy = name.replace('/', '_', 1)
+            if name in weights or legacy in weights:
+                if legacy in weights:
+                    name = legacy
+                value = weights[name]
+                if tuple(value.shape) != tuple(self.variables[var_name].shape):
+                    if warnings:
+                        print('WARNING: wrong shape found for {}, but ignored in chill mode'.format(name))
+                        print('stored shape: ', value.shape, 'expected shape: ', self.variables[var_name].shape)
+                    if not chill_mode:
+                        raise ValueError('shape mismatch for %s' % name)
+                else:
+                    self.variables[var_name] = np.asarray(value, self.variables[var_name].dtype)
+            elif warnings:
+                print('WARNING: {} not found in saved weights'.format(name))
+        if 'global_step' in weights and 'global_step' in self.__dict__:
+            pass
+        self._variables_changed()
+
+    def load_weights(self, filepath):
+        """The reference restores a TF checkpoint here (base_model.py:333-339); this build's
+        checkpoint format is the npz schema, so it forwards to import_weights."""
+        self.import_weights(filepath, warnings=False)
+
+    def close(self):
+        self._closed = True
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *args):
+        self.close()

@@ -1,0 +1,63 @@
+"""FusionModel base + test_pipeline (reference: xview/models/basic_fusion_model.py)."""
+import torch
+
+from .base_model import BaseModel
+from .fcn import FcnEngine, init_variables
+
+
+def test_pipeline(engine, inputs, want=('prob', 'classification')):
+    """Expert forward + softmax + argmax (basic_fusion_model.py:9-23) on an FcnEngine:
+    returns {'prob': f32 [N,H,W,C], 'classification': i64 [N,H,W]} (only what `want` names)."""
+    out = engine.forward(inputs, want=tuple('label' if w == 'classification' else w for w in want))
+    return out
+
+
+class FusionModel(BaseModel):
+    """Mixture of per-modality FCN experts; subclasses implement `_fusion(expert_outputs)`.
+    config: prefixes {modality: prefix}, num_units, num_channels {modality: C_in}, expert_model."""
+
+    expert_wants = ('classification',)
+
+    def __init__(self, name=None, output_dir=None, **config):
+        self.modalities = list(config['prefixes'].keys())
+        BaseModel.__init__(self, name=name, output_dir=output_dir, custom_training=True, **config)
+
+    def _fusion(self, expert_outputs, output_attr=None):
+        raise NotImplementedError
+
+    def _build_graph(self):
+        if self.config['expert_model'] != 'fcn':
+            raise UserWarning('ERROR: Expert Model %s not found' % self.config['expert_model'])
+        self.experts = {}
+        for m in self.modalities:
+            prefix = self.config['prefixes'][m]
+            cin = self._modality_channels(m)
+            # experts run with trainable=False, batchnorm=False (basic_fusion_model.py:17-18)
+            self.variables.update(init_variables(prefix, cin, self.config['num_units'],
+                                                 self.config['num_classes'], seed=self.config.get('seed')))
+            self.experts[m] = FcnEngine(prefix, cin, self.config['num_units'], self.config['num_classes'],
+                                        self.variables, device=self.device)
+        self.prediction = 'fused_label'
+
+    def _modality_channels(self, m):
+        if 'num_channels' in self.config:
+            return int(self.config['num_channels'][m])
+        return int(self.testdata_description[1][m][-1])
+
+    def _variables_changed(self):
+        for m in self.modalities:
+            self.experts[m].load(self.variables)
+
+    def _expert_outputs(self, batch, wants):
+        outs = {}
+        for m in self.modalities:
+            x = self._to_device(batch[m], torch.float32)
+            outs[m] = test_pipeline(self.experts[m], x, want=wants)
+        return outs
+
+    def _predict_batch(self, batch, output_attr=None):
+        wants = self.expert_wants
+        if output_attr in ('probs', 'prob') and 'prob' not in wants:
+            wants = tuple(wants) + ('prob',)
+        self.expert_outputs = self._expert_outputs(batch, wants)
+        return self._fusion(self.expert_outputs, output_attr=output_attr)

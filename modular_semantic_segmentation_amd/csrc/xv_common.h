@@ -1,0 +1,48 @@
+// Shared device/host helpers for libxview_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/xview_hip.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
+
+#define XV_CHECK_ARG(cond) \
+  do {                     \
+    if (!(cond)) return XV_EINVAL; \
+  } while (0)
+#define XV_CHECK_SHAPE(cond) \
+  do {                       \
+    if (!(cond)) return XV_ESHAPE; \
+  } while (0)
+
+static inline int xv_launch_status() {
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? XV_OK : (int)e;
+}
+
+// padded-NHWC geometry helpers
+__host__ __device__ static inline int64_t xv_row_pitch(int w, int c) { return (int64_t)(w + 2) * c; }
+__host__ __device__ static inline int64_t xv_img_pitch(int h, int w, int c) {
+  return (int64_t)(h + 2) * (w + 2) * c;
+}
+
+// 16-byte-slot swizzle shared by the weight packer and the conv kernels: slot s of 128-byte row
+// `row` lives at slot s ^ ((row >> 1) & 7).  With 128-B rows two consecutive rows fill one 256-B
+// LDS bank row, so 16 lanes reading the same logical slot of 16 consecutive rows touch 16
+// distinct slots (conflict-free ds_read_b128).
+__host__ __device__ static inline int xv_swz(int row, int slot) { return slot ^ ((row >> 1) & 7); }
+
+__device__ static inline uint32_t pack_bf16x2(float lo, float hi) {
+  typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+  bf16x2 v = {(__bf16)lo, (__bf16)hi};
+  return __builtin_bit_cast(uint32_t, v);
+}
+
+__device__ static inline float bf16_bits_to_f32(uint32_t bits16) {
+  return __builtin_bit_cast(float, bits16 << 16);
+}

@@ -1,0 +1,186 @@
+"""The FCN expert on MI355X: host-side mirror of `encoder` / `decoder` / `fcn`
+(xview/models/simple_fcn.py:10-170) driving the HIP kernels through the C ABI.
+
+Data layout in HBM: bf16 padded-NHWC activations (see ops.Act), packed bf16 conv weights,
+fp32 first-layer / score weights.  Per image and stream the encoder runs 13 convs (12 on MFMA;
+pool1..pool4 fused into the epilogues of conv1_2/2_2/3_3/4_3), two 1x1 score convs, the x2
+bilinear + add, and ONE fused decoder-head kernel (x8 bilinear + relu + score + softmax + argmax).
+"""
+import numpy as np
+import torch
+
+from . import ops
+from .custom_layers import bilinear_filter, is_bilinear_filter
+
+ENCODER = [  # (name, cout, pool_after)   simple_fcn.py:39-67
+    ('conv1_1', 64, None), ('conv1_2', 64, 'pool1'),
+    ('conv2_1', 128, None), ('conv2_2', 128, 'pool2'),
+    ('conv3_1', 256, None), ('conv3_2', 256, None), ('conv3_3', 256, 'pool3'),
+    ('conv4_1', 512, None), ('conv4_2', 512, None), ('conv4_3', 512, 'pool4'),
+    ('conv5_1', 512, None), ('conv5_2', 512, None), ('conv5_3', 512, None)]
+BN_EPS = 1e-3  # [TF1] tf.layers.batch_normalization default epsilon
+
+
+def variable_shapes(prefix, in_channels, num_units, num_classes, batch_normalization=False):
+    """name -> shape of every variable of one FCN expert, in the reference npz schema
+    (names: 'Synthia Rand Cityscapes Examples.ipynb':897-931; BN adds gamma/beta/moving_*)."""
+    shapes = {}
+    cin = in_channels
+    for name, cout, _ in ENCODER:
+        shapes['%s/%s/kernel' % (prefix, name)] = (3, 3, cin, cout)
+        shapes['%s/%s/bias' % (prefix, name)] = (cout,)
+        cin = cout
+    for name in ('score_conv4', 'score_conv5'):
+        shapes['%s/%s/kernel' % (prefix, name)] = (1, 1, 512, num_units)
+        shapes['%s/%s/bias' % (prefix, name)] = (num_units,)
+    shapes['%s/upscore_conv5/kernel' % prefix] = (4, 4, num_units, num_units)
+    shapes['%s/upscore/kernel' % prefix] = (16, 16, num_units, num_units)
+    shapes['%s/score/kernel' % prefix] = (1, 1, num_units, num_classes)
+    shapes['%s/score/bias' % prefix] = (num_classes,)
+    if batch_normalization:
+        for key in list(shapes):
+            if key.endswith('/kernel'):
+                layer = key[:-len('/kernel')]
+                c = shapes[key][2] if 'upscore' in layer else shapes[key][3]
+                for v in ('gamma', 'beta', 'moving_mean', 'moving_variance'):
+                    shapes['%s/%s' % (layer, v)] = (c,)
+    return shapes
+
+
+def init_variables(prefix, in_channels, num_units, num_classes, batch_normalization=False, seed=None):
+    """[TF1] default initialisers: Glorot-uniform kernels, zero biases, bilinear deconv constants,
+    BN gamma=1 beta=0 mean=0 var=1."""
+    rng = np.random.default_rng(seed)
+    out = {}
+    for name, shape in variable_shapes(prefix, in_channels, num_units, num_classes, batch_normalization).items():
+        leaf = name.rsplit('/', 1)[1]
+        if 'upscore' in name and leaf == 'kernel':
+            out[name] = bilinear_filter(shape)
+        elif leaf == 'kernel':
+            kh, kw, cin, cout = shape
+            lim = np.sqrt(6.0 / (kh * kw * cin + kh * kw * cout))
+            out[name] = rng.uniform(-lim, lim, size=shape).astype(np.float32)
+        elif leaf in ('gamma', 'moving_variance'):
+            out[name] = np.ones(shape, np.float32)
+        else:
+            out[name] = np.zeros(shape, np.float32)
+    return out
+
+
+def _fold_bn(variables, layer, kernel, bias):
+    """Inference batch-norm after the conv (custom_layers.py:126-137, BN before the activation):
+    y = gamma*(conv+b-mean)/sqrt(var+eps)+beta  ==  conv(x, W*s) + ((b-mean)*s+beta)."""
+    g = variables.get(layer + '/gamma')
+    if g is None:
+        return kernel, bias
+    s = g / np.sqrt(variables[layer + '/moving_variance'] + BN_EPS)
+    return kernel * s, (bias - variables[layer + '/moving_mean']) * s + variables[layer + '/beta']
+
+
+class FcnEngine(object):
+    """One FCN expert resident on one GPU (inference graph of simple_fcn.py:137-170)."""
+
+    def __init__(self, prefix, in_channels, num_units, num_classes, variables, device='cuda'):
+        self.prefix, self.cin, self.U, self.C = prefix, int(in_channels), int(num_units), int(num_classes)
+        self.device = torch.device(device)
+        self.Up = ((self.U + 63) // 64) * 64      # score convs run on the MFMA kernel: pad U to 64 lanes of zeros
+        self._arena = {}
+        self.load(variables)
+
+    # ---- weights -----------------------------------------------------------------------------
+    def load(self, variables):
+        p, dev = self.prefix, self.device
+        v = {k: np.asarray(a, np.float32) for k, a in variables.items() if k.startswith(p + '/')}
+        for need, shape in variable_shapes(p, self.cin, self.U, self.C).items():
+            if need not in v:
+                raise KeyError('missing variable %s' % need)
+            if tuple(v[need].shape) != tuple(shape):
+                raise ValueError('variable %s has shape %s, expected %s' % (need, v[need].shape, shape))
+        for name in ('upscore_conv5', 'upscore'):
+            if not is_bilinear_filter(v['%s/%s/kernel' % (p, name)]):
+                raise NotImplementedError(
+                    '%s/%s/kernel is not the constant bilinear kernel (custom_layers.py:8-25); the dense '
+                    'transposed-conv fallback is not built' % (p, name))
+            if '%s/%s/gamma' % (p, name) in v:
+                raise NotImplementedError('batch-norm after a deconv layer is not supported on this path')
+        self.w, self.b = {}, {}
+
+        def up(a):
+            return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dev)
+
+        for name, cout, _ in ENCODER:
+            k, b = _fold_bn(v, '%s/%s' % (p, name), v['%s/%s/kernel' % (p, name)], v['%s/%s/bias' % (p, name)])
+            self.w[name] = up(k) if name == 'conv1_1' else ops.pack_conv_weights(up(k))
+            self.b[name] = up(b)
+        for name in ('score_conv4', 'score_conv5'):
+            k, b = _fold_bn(v, '%s/%s' % (p, name), v['%s/%s/kernel' % (p, name)], v['%s/%s/bias' % (p, name)])
+            kp = np.zeros((1, 1, 512, self.Up), np.float32)
+            kp[..., :self.U] = k
+            bp = np.zeros(self.Up, np.float32)
+            bp[:self.U] = b
+            self.w[name] = ops.pack_conv_weights(up(kp))
+            self.b[name] = up(bp)
+        k, b = _fold_bn(v, p + '/score', v[p + '/score/kernel'], v[p + '/score/bias'])
+        ws = np.zeros((self.Up, self.C), np.float32)
+        ws[:self.U] = k.reshape(self.U, self.C)
+        self.w['score'] = up(ws)
+        self.b['score'] = up(b)
+        torch.cuda.synchronize(dev)
+
+    # ---- activations ---------------------------------------------------------------------------
+    def _act(self, name, n, h, w, c):
+        key = (name, n, h, w, c)
+        a = self._arena.get(key)
+        if a is None:
+            a = ops.Act(n, h, w, c, self.device)
+            self._arena[key] = a
+        return a
+
+    def encoder(self, x, keep_all=False):
+        """x: float32 [N,H,W,cin] device tensor (raw 0..255 RGB / raw depth, data contract of
+        xview/datasets/*) -> dict of Acts; 'fused' is the encoding (simple_fcn.py:10-87).
+        keep_all=True also materialises every convX_Y / poolX like the reference's layer dict."""
+        n, h, w, cin = x.shape
+        if cin != self.cin:
+            raise ValueError('expected %d input channels, got %d' % (self.cin, cin))
+        if h % 16 or w % 16:
+            raise ValueError('H and W must be multiples of 16 (augmentation.py:244-262 crop_multiple)')
+        L = {}
+        cur = self._act('conv1_1', n, h, w, 64)
+        ops.conv2d_first_fwd(x.contiguous(), self.w['conv1_1'], self.b['conv1_1'], cur, relu=True)
+        L['conv1_1'] = cur
+        ch, cw = h, w
+        for name, cout, pool in ENCODER[1:]:
+            if pool is None:
+                y = self._act(name, n, ch, cw, cout)
+                ops.conv2d_fwd(cur, self.w[name], self.b[name], 3, relu=True, y=y)
+                L[name] = cur = y
+            else:
+                q = self._act(pool, n, ch // 2, cw // 2, cout)
+                need_full = keep_all or name == 'conv4_3'       # conv4_3 feeds score_conv4
+                y = self._act(name, n, ch, cw, cout) if need_full else None
+                ops.conv2d_fwd(cur, self.w[name], self.b[name], 3, relu=True, y=y, pooled=q, write_y=need_full)
+                if y is not None:
+                    L[name] = y
+                L[pool] = cur = q
+                ch, cw = ch // 2, cw // 2
+        s4 = self._act('score_conv4', n, h // 8, w // 8, self.Up)
+        ops.conv2d_fwd(L['conv4_3'], self.w['score_conv4'], self.b['score_conv4'], 1, relu=True, y=s4)
+        s5 = self._act('score_conv5', n, h // 16, w // 16, self.Up)
+        ops.conv2d_fwd(L['conv5_3'], self.w['score_conv5'], self.b['score_conv5'], 1, relu=True, y=s5)
+        fused = self._act('fused', n, h // 8, w // 8, self.Up)
+        ops.upsample2x_relu_add(s5, residual=s4, y=fused)
+        L.update(score_conv4=s4, score_conv5=s5, fused=fused)
+        return L
+
+    def forward(self, x, want=('label',), keep_all=False):
+        """fcn + test_pipeline (basic_fusion_model.py:9-23): returns dict with any of
+        'score', 'prob' (float32 [N,H,W,C]) and 'label' == 'classification' (int64 [N,H,W])."""
+        L = self.encoder(x, keep_all=keep_all)
+        out = ops.decoder_head_fwd(L['fused'], self.w['score'], self.b['score'], self.C,
+                                   want_score='score' in want, want_prob='prob' in want,
+                                   want_label=('label' in want or 'classification' in want))
+        if 'label' in out:
+            out['classification'] = out['label']
+        out['layers'] = L
+        return out

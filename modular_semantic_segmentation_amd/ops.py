@@ -1,0 +1,220 @@
+"""Thin torch-tensor wrappers over the C ABI (pointers + sizes in, nothing else).
+
+PyTorch is plumbing here: it owns device memory and the stream; every arithmetic op of the
+hot path runs in libxview_hip.so.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import xv_act
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+def _need(t, dtype, name):
+    if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == dtype and t.is_contiguous()):
+        raise TypeError('%s must be a contiguous CUDA tensor of dtype %s' % (name, dtype))
+
+
+class Act(object):
+    """bf16 padded-NHWC activation (include/xview_hip.h `xv_act`): dense [n][h+2][w+2][c]
+    with a zero 1-pixel border that no kernel ever writes."""
+
+    def __init__(self, n, h, w, c, device='cuda'):
+        self.n, self.h, self.w, self.c = int(n), int(h), int(w), int(c)
+        self.t = torch.zeros((self.n, self.h + 2, self.w + 2, self.c), dtype=torch.bfloat16, device=device)
+        self._xv = xv_act(self.t.data_ptr(), self.n, self.h, self.w, self.c)
+
+    def xv(self):
+        return ctypes.byref(self._xv)
+
+    def interior(self):
+        """Logical [n][h][w][c] view (bf16)."""
+        return self.t[:, 1:-1, 1:-1, :]
+
+    @classmethod
+    def from_dense(cls, x):
+        """Test helper: pad a dense NHWC float tensor into a new Act (rounds to bf16)."""
+        n, h, w, c = x.shape
+        a = cls(n, h, w, c, device=x.device)
+        a.interior().copy_(x.to(torch.bfloat16))
+        return a
+
+
+_NULL_ACT = ctypes.POINTER(xv_act)()
+
+# bench.py sets this to a list to collect (kind, flops, start_event, end_event) per MFMA-conv launch;
+# the events are recorded on the stream the kernel is launched on.
+CONV_PROFILE = None
+
+
+def pack_conv_weights(w_hwio):
+    """float32 HWIO device tensor -> packed bf16 weight buffer for conv2d_fwd."""
+    _need(w_hwio, torch.float32, 'w_hwio')
+    k, k2, cin, cout = w_hwio.shape
+    nbytes = _lib.lib().xv_packed_weight_bytes(k, cin, cout)
+    if k != k2 or nbytes == 0:
+        raise _lib.XvError('unsupported conv weight shape %s' % (tuple(w_hwio.shape),))
+    out = torch.empty(nbytes // 2, dtype=torch.bfloat16, device=w_hwio.device)
+    _lib.check(_lib.lib().xv_pack_conv_weights(_ptr(w_hwio), _ptr(out), k, cin, cout, _stream()), 'xv_pack_conv_weights')
+    return out
+
+
+def conv2d_fwd(x, w_packed, bias, k, relu=True, y=None, pooled=None, write_y=True):
+    """x: Act; returns (y Act or None, pooled Act or None)."""
+    cout = bias.numel()
+    _need(bias, torch.float32, 'bias')
+    if y is None and write_y:
+        y = Act(x.n, x.h, x.w, cout, x.t.device)
+    ydesc = y._xv if y is not None else xv_act(None, x.n, x.h, x.w, cout)
+    prof = CONV_PROFILE
+    if prof is not None:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+    rc = _lib.lib().xv_conv2d_fwd(x.xv(), _ptr(w_packed), _ptr(bias), ctypes.byref(ydesc),
+                                 pooled.xv() if pooled is not None else _NULL_ACT, k, int(bool(relu)), _stream())
+    _lib.check(rc, 'xv_conv2d_fwd')
+    if prof is not None:
+        ev1.record()
+        prof.append(('k%d_cout%s' % (k, '128' if cout % 128 == 0 else '64'),
+                     2.0 * x.n * x.h * x.w * x.c * cout * k * k, ev0, ev1))
+    return y, pooled
+
+
+def conv2d_first_fwd(x, w_hwio, bias, y, relu=True):
+    _need(x, torch.float32, 'x')
+    _need(w_hwio, torch.float32, 'w_hwio')
+    _need(bias, torch.float32, 'bias')
+    n, h, w, cin = x.shape
+    rc = _lib.lib().xv_conv2d_first_fwd(_ptr(x), n, h, w, cin, _ptr(w_hwio), _ptr(bias), y.xv(), int(bool(relu)), _stream())
+    _lib.check(rc, 'xv_conv2d_first_fwd')
+    return y
+
+
+def maxpool2x2_fwd(x, y=None):
+    if y is None:
+        y = Act(x.n, x.h // 2, x.w // 2, x.c, x.t.device)
+    _lib.check(_lib.lib().xv_maxpool2x2_fwd(x.xv(), y.xv(), _stream()), 'xv_maxpool2x2_fwd')
+    return y
+
+
+def upsample2x_relu_add(x, residual=None, y=None):
+    if y is None:
+        y = Act(x.n, 2 * x.h, 2 * x.w, x.c, x.t.device)
+    rc = _lib.lib().xv_upsample2x_relu_add(x.xv(), residual.xv() if residual is not None else _NULL_ACT, y.xv(), _stream())
+    _lib.check(rc, 'xv_upsample2x_relu_add')
+    return y
+
+
+def decoder_head_fwd(fused, w_score, b_score, num_classes, want_score=False, want_prob=False, want_label=True,
+                     out=None):
+    """Returns dict with the requested dense outputs (score/prob float32 NHWC, label int64 NHW)."""
+    _need(w_score, torch.float32, 'w_score')
+    _need(b_score, torch.float32, 'b_score')
+    dev = fused.t.device
+    n, ho, wo = fused.n, fused.h * 8, fused.w * 8
+    out = {} if out is None else out
+    if want_score and 'score' not in out:
+        out['score'] = torch.empty((n, ho, wo, num_classes), dtype=torch.float32, device=dev)
+    if want_prob and 'prob' not in out:
+        out['prob'] = torch.empty((n, ho, wo, num_classes), dtype=torch.float32, device=dev)
+    if want_label and 'label' not in out:
+        out['label'] = torch.empty((n, ho, wo), dtype=torch.int64, device=dev)
+    rc = _lib.lib().xv_decoder_head_fwd(fused.xv(), _ptr(w_score), _ptr(b_score), num_classes,
+                                       _ptr(out.get('score') if want_score else None),
+                                       _ptr(out.get('prob') if want_prob else None),
+                                       _ptr(out.get('label') if want_label else None), _stream())
+    _lib.check(rc, 'xv_decoder_head_fwd')
+    return out
+
+
+def softmax_argmax(score, want_prob=True, want_label=True):
+    _need(score, torch.float32, 'score')
+    c = score.shape[-1]
+    npix = score.numel() // c
+    prob = torch.empty_like(score) if want_prob else None
+    label = torch.empty(score.shape[:-1], dtype=torch.int64, device=score.device) if want_label else None
+    _lib.check(_lib.lib().xv_softmax_argmax(_ptr(score), npix, c, _ptr(prob), _ptr(label), _stream()), 'xv_softmax_argmax')
+    return prob, label
+
+
+def _ptr_array(tensors):
+    arr = (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+    return arr
+
+
+def bayes_fuse(labels, loglik, logprior, want_score=False):
+    """labels: list of int64 tensors (same shape); loglik float32 [E,C,C]; logprior float32 [C]."""
+    for l in labels:
+        _need(l, torch.int64, 'labels')
+    _need(loglik, torch.float32, 'loglik')
+    _need(logprior, torch.float32, 'logprior')
+    e, c = loglik.shape[0], loglik.shape[1]
+    npix = labels[0].numel()
+    fused = torch.empty_like(labels[0])
+    score = torch.empty(tuple(labels[0].shape) + (c,), dtype=torch.float32, device=fused.device) if want_score else None
+    rc = _lib.lib().xv_bayes_fuse(_ptr_array(labels), e, _ptr(loglik), _ptr(logprior), c, npix, _ptr(fused), _ptr(score), _stream())
+    _lib.check(rc, 'xv_bayes_fuse')
+    return fused, score
+
+
+def bayes_fuse_lut(label_a, label_b, lut):
+    _need(label_a, torch.int64, 'label_a')
+    _need(label_b, torch.int64, 'label_b')
+    _need(lut, torch.int64, 'lut')
+    fused = torch.empty_like(label_a)
+    rc = _lib.lib().xv_bayes_fuse_lut(_ptr(label_a), _ptr(label_b), _ptr(lut), lut.shape[0], label_a.numel(), _ptr(fused), _stream())
+    _lib.check(rc, 'xv_bayes_fuse_lut')
+    return fused
+
+
+def dirichlet_fuse(probs, am1, lognorm, logprior, want_score=False):
+    for p in probs:
+        _need(p, torch.float32, 'probs')
+    e, c = am1.shape[0], am1.shape[1]
+    npix = probs[0].numel() // c
+    fused = torch.empty(probs[0].shape[:-1], dtype=torch.int64, device=probs[0].device)
+    score = torch.empty_like(probs[0]) if want_score else None
+    rc = _lib.lib().xv_dirichlet_fuse(_ptr_array(probs), e, _ptr(am1), _ptr(lognorm), _ptr(logprior), c, npix,
+                                     _ptr(fused), _ptr(score), _stream())
+    _lib.check(rc, 'xv_dirichlet_fuse')
+    return fused, score
+
+
+def average_fuse(probs):
+    for p in probs:
+        _need(p, torch.float32, 'probs')
+    c = probs[0].shape[-1]
+    fused = torch.empty(probs[0].shape[:-1], dtype=torch.int64, device=probs[0].device)
+    rc = _lib.lib().xv_average_fuse(_ptr_array(probs), len(probs), c, probs[0].numel() // c, _ptr(fused), _stream())
+    _lib.check(rc, 'xv_average_fuse')
+    return fused
+
+
+def dirichlet_suffstats(prob, labels, S, counts):
+    """Accumulates into S (float64 [C,C]) and counts (int64 [C]) in place."""
+    _need(prob, torch.float32, 'prob')
+    _need(labels, torch.int32, 'labels')
+    _need(S, torch.float64, 'S')
+    _need(counts, torch.int64, 'counts')
+    c = prob.shape[-1]
+    rc = _lib.lib().xv_dirichlet_suffstats(_ptr(prob), _ptr(labels), c, labels.numel(), _ptr(S), _ptr(counts), _stream())
+    _lib.check(rc, 'xv_dirichlet_suffstats')
+
+
+def confusion_matrix(labels, pred, cm):
+    """Accumulates into cm (int64 [C,C], rows = ground truth) in place."""
+    _need(labels, torch.int32, 'labels')
+    _need(pred, torch.int64, 'pred')
+    _need(cm, torch.int64, 'cm')
+    rc = _lib.lib().xv_confusion_matrix(_ptr(labels), _ptr(pred), cm.shape[0], labels.numel(), _ptr(cm), _stream())
+    _lib.check(rc, 'xv_confusion_matrix')

@@ -1,0 +1,44 @@
+"""SimpleFCN model (reference: xview/models/simple_fcn.py:173-224) on the MI355X engine."""
+import numpy as np
+import torch
+
+from . import fcn as _fcn
+from . import ops
+from .base_model import BaseModel
+from .fcn import FcnEngine, init_variables  # noqa: F401  (fcn-level API re-exported for callers)
+
+
+class SimpleFCN(BaseModel):
+    """FCN expert.  Args as the reference: prefix, data_description, modality, output_dir,
+    **config with required `num_units`, `batch_normalization`; optional learning_rate, trainer,
+    batchsize, train_encoder, dropout_rate (the last two are unused by the reference too,
+    simple_fcn.py:192-211)."""
+
+    def __init__(self, prefix, data_description, modality, output_dir=None, **config):
+        self.prefix = prefix
+        self.modality = modality
+        standard_config = {'train_encoder': True, 'dropout_rate': 0}
+        standard_config.update(config)
+        BaseModel.__init__(self, data_description, output_dir=output_dir, **standard_config)
+
+    def _build_graph(self):
+        shape = self.testdata_description[1][self.modality]
+        self.in_channels = int(shape[-1])
+        self.variables = init_variables(self.prefix, self.in_channels, self.config['num_units'],
+                                        self.config['num_classes'],
+                                        batch_normalization=self.config['batch_normalization'],
+                                        seed=self.config.get('seed'))
+        self.engine = FcnEngine(self.prefix, self.in_channels, self.config['num_units'],
+                                self.config['num_classes'], self.variables, device=self.device)
+        self.loss = None            # scalar of the last training step (set by _train_batch)
+        self.prediction = 'label'   # name of the engine output that is the model's prediction
+
+    def _variables_changed(self):
+        self.engine.load(self.variables)
+
+    def _predict_batch(self, batch, output_attr=None):
+        x = self._to_device(batch[self.modality], torch.float32)
+        want = 'label'
+        if output_attr in ('prob', 'score'):
+            want = output_attr
+        return self.engine.forward(x, want=(want,))[want]

@@ -1,0 +1,183 @@
+"""CPU-only tests: host logic of the product against the reference-generated golden vectors,
+and the C-ABI library's exports (no compute calls without a GPU)."""
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+
+from modular_semantic_segmentation_amd import _lib, get_model
+from modular_semantic_segmentation_amd import base_model, bayes_mix, custom_layers, dirichlet_fit, dirichlet_mix, fcn
+from oracle import fusion_oracle as fu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _g(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name))
+
+
+def test_library_builds_and_exports_every_declared_symbol():
+    _lib.build()
+    header = open(os.path.join(ROOT, 'include', 'xview_hip.h')).read()
+    declared = set(re.findall(r'\b(xv_[a-z0-9_]+)\s*\(', header))
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    handle = _lib.lib()
+    for name in declared:
+        assert hasattr(handle, name)
+    assert handle.xv_version() >= 100
+    assert handle.xv_arch() == b'gfx950'
+    assert handle.xv_packed_weight_bytes(3, 64, 128) == 9 * 64 * 128 * 2
+    assert handle.xv_packed_weight_bytes(3, 3, 64) == 0          # first layer is not an MFMA conv
+
+
+def test_abi_rejects_bad_arguments_without_touching_the_gpu():
+    handle = _lib.lib()
+    assert handle.xv_softmax_argmax(None, 10, 12, None, None, None) == -1           # XV_EINVAL
+    assert handle.xv_bayes_fuse_lut(None, None, None, 12, 10, None, None) == -1
+    a = _lib.xv_act(None, 1, 16, 16, 64)
+    assert handle.xv_maxpool2x2_fwd(a, a, None) == -1
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    monkeypatch.setattr(_lib, '_lib', None)
+    monkeypatch.setattr(_lib, 'LIB_PATH', str(tmp_path / 'nope.so'))
+    with pytest.raises(_lib.XvError):
+        _lib.lib()
+
+
+def test_bilinear_filter_golden(golden_dir):
+    g = _g(golden_dir, 'bilinear_kernels.npz')
+    np.testing.assert_array_equal(custom_layers.bilinear_filter([4, 4, 5, 5]), g['k4'].astype(np.float32))
+    np.testing.assert_array_equal(custom_layers.bilinear_filter([16, 16, 3, 3]), g['k16'].astype(np.float32))
+    assert custom_layers.is_bilinear_filter(g['k16'])
+    bad = g['k4'].copy()
+    bad[0, 0, 0, 1] = 0.1
+    assert not custom_layers.is_bilinear_filter(bad)
+
+
+def test_score_measures_golden(golden_dir):
+    g = _g(golden_dir, 'notebook_868.npz')
+    for who in ('rgb', 'depth', 'fusion'):
+        m = base_model.score_measures(g['test_cm_' + who])
+        for key in ('mean_IoU', 'mean_F1', 'total_accuracy'):
+            assert m[key] == float(g['%s__%s' % (who, key)])
+        for key in ('IoU', 'F1', 'precision', 'recall'):
+            np.testing.assert_allclose(m[key], g['%s__%s' % (who, key)], rtol=0, atol=5e-9)
+
+
+@pytest.mark.parametrize('name,prior', [('data', 'data'), ('uniform', 'uniform'), ('w0p5', 0.5)])
+def test_bayes_decision_matrix_golden(golden_dir, name, prior):
+    g = _g(golden_dir, 'notebook_868.npz')
+    mats = [g['cm_rgb'].astype('float32').T, g['cm_depth'].astype('float32').T]
+    lut = _g(golden_dir, 'bayes_lut.npz')['lut_' + name]
+    np.testing.assert_array_equal(bayes_mix.bayes_decision_matrix(mats, prior), lut)
+
+
+def test_bayes_tables_match_oracle(golden_dir):
+    g = _g(golden_dir, 'notebook_868.npz')
+    mats = [g['cm_rgb'].astype('float32').T, g['cm_depth'].astype('float32').T]
+    mats[0][:, 3] = 0                                  # empty class -> nan_to_num path
+    C = 12
+    a, b = np.meshgrid(np.arange(C), np.arange(C), indexing='ij')
+    for prior in ('data', 'uniform', 0.25):
+        loglik, logprior = bayes_mix.bayes_tables(mats, prior)
+        score = (loglik[0][a] + loglik[1][b]) + logprior
+        ref, _, _ = fu.bayes_fusion([a, b], mats, prior)
+        np.testing.assert_array_equal(score.astype(np.float32), ref)
+
+
+def test_dirichlet_fitter_golden(golden_dir):
+    f = _g(golden_dir, 'dirichlet_fit.npz')
+    for i in range(int(f['num_cases'])):
+        delta, beta = f['case%d_delta_beta' % i]
+        ss = f['case%d_ss' % i]
+        alpha = dirichlet_fit.find_dirichlet_priors(ss, f['case%d_neg_ss' % i], np.ones(len(ss)),
+                                                    max_iter=10000, delta=delta, beta=beta)
+        np.testing.assert_allclose(alpha, f['case%d_alpha' % i], rtol=1e-12, atol=1e-12)
+
+
+def test_dirichlet_tables_match_oracle():
+    rng = np.random.default_rng(0)
+    C = 12
+    A = [rng.uniform(0.3, 5, (C, C)).astype(np.float32) for _ in range(2)]
+    counts = rng.integers(0, 100, C)
+    p = [rng.dirichlet(np.ones(C), size=(1, 3, 4)).astype(np.float32) for _ in range(2)]
+    for prior_cfg, sigma in (('data', 1.0), ('uniform', 0.7), (0.4, 1.5)):
+        am1, lognorm, logprior = dirichlet_mix.dirichlet_tables(A, counts, prior_cfg, sigma)
+        score = logprior.copy()[None, None, None, :]
+        total = 0
+        for e in range(2):
+            lx = np.log(np.float32(1e-20) + fu.renormalise(p[e]))
+            total = total + (lx @ am1[e].T - lognorm[e])
+        ref = fu.dirichlet_fusion([fu.renormalise(q) for q in p], A, fu.dirichlet_prior(counts, prior_cfg), sigma)
+        np.testing.assert_allclose(total + score, ref, rtol=1e-5, atol=1e-3)
+
+
+def test_variable_schema_matches_reference_names(golden_dir):
+    names = json.load(open(os.path.join(golden_dir, 'weight_names.json')))['variables']
+    shapes = fcn.variable_shapes('rgb', 3, 64, 12)
+    assert list(shapes) == names
+    assert shapes['rgb/conv1_1/kernel'] == (3, 3, 3, 64)
+    assert shapes['rgb/upscore/kernel'] == (16, 16, 64, 64)
+    assert shapes['rgb/score/kernel'] == (1, 1, 64, 12)
+    n_train = sum(int(np.prod(s)) for k, s in shapes.items() if 'upscore' not in k)
+    assert n_train == 14781132
+    bn = fcn.variable_shapes('rgb', 3, 64, 12, batch_normalization=True)
+    assert bn['rgb/conv3_2/moving_variance'] == (256,)
+
+
+def test_iterate_batches_dict_and_samples():
+    data = {'rgb': np.zeros((5, 4, 4, 3), np.float32), 'labels': np.arange(5)}
+    sizes = [len(b['labels']) for b in base_model.iterate_batches(data, 2)]
+    assert sizes == [2, 2, 1]
+    samples = ({'rgb': np.zeros((4, 4, 3)), 'labels': np.array(i)} for i in range(5))
+    got = [b['labels'].tolist() for b in base_model.iterate_batches(samples, 3, max_batches=1)]
+    assert got == [[0, 1, 2]]
+
+
+class _HostOnly(base_model.BaseModel):
+    """BaseModel without engines: exercises the npz import/export logic on the CPU."""
+
+    def _build_graph(self):
+        self.variables = {'rgb/conv1_1/kernel': np.zeros((3, 3, 3, 64), np.float32),
+                          'rgb/conv1_1/bias': np.zeros(64, np.float32)}
+        self.prediction = 'label'
+        self.loss = None
+
+
+def test_export_import_weights_roundtrip(tmp_path, capsys):
+    desc = ({'rgb': 'float32', 'labels': 'int32'}, {'rgb': (None, None, 3), 'labels': (None, None)}, 12)
+    with _HostOnly(desc, name='SimpleFCN', output_dir=str(tmp_path), device='cpu') as net:
+        net.variables['rgb/conv1_1/bias'][:] = 3
+        net.global_step = 7
+        path = net.export_weights()
+    assert os.path.basename(path) == 'SimpleFCN_weights_7.npz'
+    saved = np.load(path)
+    assert set(saved.keys()) == {'rgb/conv1_1/kernel', 'rgb/conv1_1/bias', 'global_step'}
+    net2 = _HostOnly(desc, device='cpu')
+    net2.import_weights(path, warnings=False)
+    assert np.all(net2.variables['rgb/conv1_1/bias'] == 3)
+    # legacy 'prefix_layer/...' names and prefix translation (base_model.py:435-437, 411-425)
+    legacy = str(tmp_path / 'legacy.npz')
+    np.savez(legacy, **{'depth_conv1_1/kernel': np.ones((3, 3, 3, 64), np.float32),
+                        'depth_conv1_1/bias': np.full(64, 5, np.float32)})
+    net2.import_weights(legacy, translate_prefix='rgb', warnings=False)
+    assert np.all(net2.variables['rgb/conv1_1/bias'] == 5)
+    # wrong shape: error unless chill_mode
+    bad = str(tmp_path / 'bad.npz')
+    np.savez(bad, **{'rgb/conv1_1/bias': np.zeros(3, np.float32)})
+    with pytest.raises(ValueError):
+        net2.import_weights(bad, warnings=False)
+    net2.import_weights(bad, chill_mode=True, warnings=False)
+    assert np.all(net2.variables['rgb/conv1_1/bias'] == 5)
+
+
+def test_registry_names():
+    assert get_model('fcn').__name__ == 'SimpleFCN'
+    assert get_model('bayes_mix') is get_model('bayes_fusion')
+    assert get_model('dirichlet_fusion').__name__ == 'DirichletFusion'
+    assert get_model('average_mix').__name__ == 'AverageFusion'
+    with pytest.raises(UserWarning):
+        get_model('nope')

@@ -1,0 +1,245 @@
+"""Parity of every HIP kernel (called through the C ABI) against the CPU oracle.
+Integer-valued operands make the conv checks bit-exact (fp32 sums of small integers are exact
+in any order), so a layout / swizzle / fragment-map bug cannot hide inside a tolerance."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import fcn_oracle as fo
+from oracle import fusion_oracle as fu
+
+
+@pytest.fixture(scope='module')
+def ops():
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU')
+    from modular_semantic_segmentation_amd import ops as _ops
+    return _ops
+
+
+def _dev(a, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a))
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.cuda()
+
+
+def _conv_oracle(x, w, b, relu, k):
+    xt = torch.from_numpy(x).permute(0, 3, 1, 2).contiguous()
+    y = fo.conv2d_same(xt, w, b, relu=relu)
+    return y, fo.round_bf16(y).permute(0, 2, 3, 1).numpy()
+
+
+CONV_CASES = [
+    # n, h, w, cin, cout, k, pool
+    (1, 16, 16, 64, 64, 3, False),
+    (2, 16, 32, 64, 128, 3, True),
+    (1, 24, 40, 128, 128, 3, False),    # partial tiles in both directions
+    (1, 6, 10, 256, 512, 3, True),      # tiny image, many channel chunks
+    (3, 8, 8, 512, 64, 1, False),       # score_conv shape (1x1, Cout 64)
+    (1, 18, 22, 128, 256, 1, False),
+    (1, 32, 48, 64, 64, 3, True),       # conv1_2-like with fused pool1
+]
+
+
+@pytest.mark.parametrize('n,h,w,cin,cout,k,pool', CONV_CASES)
+def test_conv2d_mfma_exact_on_integers(ops, n, h, w, cin, cout, k, pool):
+    rng = np.random.default_rng(hash((n, h, w, cin, cout, k)) % 2**32)
+    x = rng.integers(-2, 3, (n, h, w, cin)).astype(np.float32)
+    wt = rng.integers(-1, 2, (k, k, cin, cout)).astype(np.float32)
+    b = rng.integers(-3, 4, cout).astype(np.float32)
+    xa = ops.Act.from_dense(_dev(x))
+    wp = ops.pack_conv_weights(_dev(wt))
+    q = ops.Act(n, h // 2, w // 2, cout) if pool else None
+    y, _ = ops.conv2d_fwd(xa, wp, _dev(b), k, relu=True, pooled=q)
+    torch.cuda.synchronize()
+    y32, ref = _conv_oracle(x, wt, b, True, k)
+    got = y.interior().float().cpu().numpy()
+    bad = np.argwhere(got != ref)
+    assert bad.size == 0, 'first mismatches (n,y,x,c): %s got %s want %s' % (
+        bad[:5].tolist(), got[tuple(bad[:5].T)], ref[tuple(bad[:5].T)])
+    # the zero border must be untouched
+    full = y.t.float().cpu().numpy()
+    assert np.all(full[:, 0] == 0) and np.all(full[:, -1] == 0) and np.all(full[:, :, 0] == 0) and np.all(full[:, :, -1] == 0)
+    if pool:
+        refq = fo.round_bf16(fo.maxpool2(y32)).permute(0, 2, 3, 1).numpy()
+        gotq = q.interior().float().cpu().numpy()
+        assert np.array_equal(gotq, refq)
+        # standalone pool kernel agrees with the fused epilogue
+        q2 = ops.maxpool2x2_fwd(y)
+        torch.cuda.synchronize()
+        assert torch.equal(q2.t, q.t)
+        # pooled-only launch (no full-resolution store)
+        q3 = ops.Act(n, h // 2, w // 2, cout)
+        ops.conv2d_fwd(xa, wp, _dev(b), k, relu=True, pooled=q3, write_y=False)
+        torch.cuda.synchronize()
+        assert torch.equal(q3.t, q.t)
+
+
+def test_conv2d_mfma_random_bf16(ops):
+    """Random bf16 operands: fp32-accumulate result within accumulation-order tolerance."""
+    rng = np.random.default_rng(7)
+    n, h, w, cin, cout = 2, 24, 32, 256, 256
+    x = fo.round_bf16(rng.standard_normal((n, h, w, cin)).astype(np.float32))
+    wt = fo.round_bf16((rng.standard_normal((3, 3, cin, cout)) / np.sqrt(9 * cin)).astype(np.float32))
+    b = rng.standard_normal(cout).astype(np.float32)
+    y, _ = ops.conv2d_fwd(ops.Act.from_dense(_dev(x)), ops.pack_conv_weights(_dev(wt)), _dev(b), 3, relu=False)
+    torch.cuda.synchronize()
+    y32, _ = _conv_oracle(x, wt, b, False, 3)
+    ref = y32.permute(0, 2, 3, 1).numpy()
+    got = y.interior().float().cpu().numpy()
+    # bf16 output rounding (2^-9 relative) dominates; fp32 accumulation order adds ~1e-6
+    np.testing.assert_allclose(got, ref, rtol=2 ** -8, atol=2e-3)
+
+
+@pytest.mark.parametrize('cin', [1, 3])
+def test_conv_first_layer(ops, cin):
+    rng = np.random.default_rng(cin)
+    n, h, w = 2, 20, 28
+    hi = 256 if cin == 3 else 65536
+    x = rng.integers(0, hi, (n, h, w, cin)).astype(np.float32)
+    wt = (rng.standard_normal((3, 3, cin, 64)) * 0.05).astype(np.float32)
+    b = rng.standard_normal(64).astype(np.float32)
+    y = ops.Act(n, h, w, 64)
+    ops.conv2d_first_fwd(_dev(x), _dev(wt), _dev(b), y, relu=True)
+    torch.cuda.synchronize()
+    y32, _ = _conv_oracle(x, wt, b, True, 3)
+    ref = y32.permute(0, 2, 3, 1).numpy()
+    got = y.interior().float().cpu().numpy()
+    # fp32 math on both sides (different summation order) then one bf16 rounding
+    np.testing.assert_allclose(got, ref, rtol=2 ** -8, atol=1e-5 * hi)
+
+
+def test_upsample2x_relu_add(ops):
+    rng = np.random.default_rng(5)
+    n, h, w, c = 2, 5, 7, 64
+    x = fo.round_bf16(rng.standard_normal((n, h, w, c)).astype(np.float32))
+    res = fo.round_bf16(np.abs(rng.standard_normal((n, 2 * h, 2 * w, c))).astype(np.float32))
+    y = ops.upsample2x_relu_add(ops.Act.from_dense(_dev(x)), ops.Act.from_dense(_dev(res)))
+    torch.cuda.synchronize()
+    xt = torch.from_numpy(x).permute(0, 3, 1, 2)
+    up = fo.deconv_same(xt, fo.bilinear_kernel(4, c), 2, relu=True).permute(0, 2, 3, 1).numpy()
+    ref = fo.round_bf16(up + res)
+    got = y.interior().float().cpu().numpy()
+    # the x2 weights (1/16, 3/16, 9/16) are exact; only the 4-term fp32 sum order differs
+    np.testing.assert_allclose(got, ref, rtol=2 ** -7, atol=1e-6)
+    assert (got != ref).mean() < 0.01
+
+
+@pytest.mark.parametrize('C,U', [(12, 64), (14, 64), (20, 128)])
+def test_decoder_head(ops, C, U):
+    rng = np.random.default_rng(C)
+    n, h, w = 2, 3, 5
+    f = fo.round_bf16(np.abs(rng.standard_normal((n, h, w, U))).astype(np.float32))
+    ws = (rng.standard_normal((U, C)) * 0.3).astype(np.float32)
+    bs = rng.standard_normal(C).astype(np.float32)
+    out = ops.decoder_head_fwd(ops.Act.from_dense(_dev(f)), _dev(ws), _dev(bs), C, want_score=True, want_prob=True)
+    torch.cuda.synchronize()
+    ft = torch.from_numpy(f).permute(0, 3, 1, 2)
+    up = fo.deconv_same(ft, fo.bilinear_kernel(16, U), 8, relu=True)
+    score = fo.conv2d_same(up, ws.reshape(1, 1, U, C), bs).permute(0, 2, 3, 1).numpy()
+    got_score = out['score'].cpu().numpy()
+    np.testing.assert_allclose(got_score, score, rtol=1e-4, atol=1e-4)          # stated logit tolerance
+    # probabilities and labels are checked against the oracle fed the SAME (kernel) logits
+    np.testing.assert_allclose(out['prob'].cpu().numpy(), fo.softmax(got_score), rtol=1e-5, atol=1e-7)
+    assert np.array_equal(out['label'].cpu().numpy(), fo.argmax_last(fo.softmax(got_score)))
+    assert out['label'].dtype == torch.int64
+
+
+def test_softmax_argmax_bit_exact_labels_and_ties(ops):
+    rng = np.random.default_rng(11)
+    s = (rng.standard_normal((3, 17, 23, 12)) * 4).astype(np.float32)
+    s[0, 0, 0] = 0.0                      # all-equal logits -> class 0
+    s[0, 0, 1] = [1, 5, 5, 0, 5, 0, 0, 0, 0, 0, 0, 0]   # tie -> lowest index
+    s[0, 0, 2] = -200.0
+    s[0, 0, 2, 7] = 90.0                  # saturated softmax
+    prob, label = ops.softmax_argmax(_dev(s))
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(prob.cpu().numpy(), fo.softmax(s), rtol=1e-5, atol=1e-30)
+    assert np.array_equal(label.cpu().numpy(), fo.argmax_last(fo.softmax(s)))
+    assert label[0, 0, 0].item() == 0 and label[0, 0, 1].item() == 1 and label[0, 0, 2].item() == 7
+
+
+def _notebook_mats(golden_dir):
+    import os
+    g = np.load(os.path.join(golden_dir, 'notebook_868.npz'))
+    return [g['cm_rgb'].astype('float32').T, g['cm_depth'].astype('float32').T]
+
+
+@pytest.mark.parametrize('prior', ['data', 'uniform', 0.5])
+def test_bayes_fuse_matches_oracle_and_reference_lut(ops, golden_dir, prior):
+    import os
+    from modular_semantic_segmentation_amd import bayes_mix
+    mats = _notebook_mats(golden_dir)
+    rng = np.random.default_rng(0)
+    la = rng.integers(0, 12, (2, 37, 41)).astype(np.int64)
+    lb = rng.integers(0, 12, (2, 37, 41)).astype(np.int64)
+    loglik, logprior = bayes_mix.bayes_tables(mats, prior)
+    fused, score = ops.bayes_fuse([_dev(la), _dev(lb)], _dev(loglik), _dev(logprior), want_score=True)
+    torch.cuda.synchronize()
+    ref_score, _, _ = fu.bayes_fusion([la, lb], mats, prior)
+    np.testing.assert_allclose(score.cpu().numpy(), ref_score, rtol=1e-6, atol=1e-5)
+    assert np.array_equal(fused.cpu().numpy(), np.argmax(score.cpu().numpy(), -1))
+    # against the reference's own decision matrix (golden): identical wherever the decision is not a near-tie
+    name = {'data': 'data', 'uniform': 'uniform', 0.5: 'w0p5'}[prior]
+    lut = np.load(os.path.join(golden_dir, 'bayes_lut.npz'))['lut_' + name]
+    top2 = np.sort(ref_score, -1)[..., -2:]
+    clear = (top2[..., 1] - top2[..., 0]) > 1e-4
+    assert np.array_equal(fused.cpu().numpy()[clear], lut[la, lb][clear])
+    fused_lut = ops.bayes_fuse_lut(_dev(la), _dev(lb), _dev(lut))
+    torch.cuda.synchronize()
+    assert np.array_equal(fused_lut.cpu().numpy(), lut[la, lb])
+
+
+def test_dirichlet_fuse(ops):
+    from modular_semantic_segmentation_amd import dirichlet_mix
+    rng = np.random.default_rng(4)
+    C = 12
+    pa = fo.softmax((rng.standard_normal((2, 19, 21, C)) * 3).astype(np.float32))
+    pb = fo.softmax((rng.standard_normal((2, 19, 21, C)) * 3).astype(np.float32))
+    pa[0, 0, 0] = 0
+    pa[0, 0, 0, 3] = 1.0          # exact zeros: exercises the 1e-20 guard
+    A = [rng.uniform(0.3, 5.0, (C, C)).astype(np.float32) for _ in range(2)]
+    counts = rng.integers(1, 1000, C)
+    for prior_cfg, sigma in (('data', 1.0), ('uniform', 0.5), (0.3, 2.0)):
+        am1, lognorm, logprior = dirichlet_mix.dirichlet_tables(A, counts, prior_cfg, sigma)
+        fused, score = ops.dirichlet_fuse([_dev(pa), _dev(pb)], _dev(am1), _dev(lognorm), _dev(logprior), want_score=True)
+        torch.cuda.synchronize()
+        prior = fu.dirichlet_prior(counts, prior_cfg)
+        ref = fu.dirichlet_fusion([fu.renormalise(pa), fu.renormalise(pb)], A, prior, sigma)
+        np.testing.assert_allclose(score.cpu().numpy(), ref, rtol=2e-5, atol=2e-3)
+        assert np.array_equal(fused.cpu().numpy(), np.argmax(score.cpu().numpy(), -1))
+        top2 = np.sort(ref, -1)[..., -2:]
+        clear = (top2[..., 1] - top2[..., 0]) > 1e-2
+        assert np.array_equal(fused.cpu().numpy()[clear], np.argmax(ref, -1)[clear])
+
+
+def test_average_fuse(ops):
+    rng = np.random.default_rng(8)
+    pa = fo.softmax(rng.standard_normal((1, 9, 9, 14)).astype(np.float32))
+    pb = fo.softmax(rng.standard_normal((1, 9, 9, 14)).astype(np.float32))
+    fused = ops.average_fuse([_dev(pa), _dev(pb)])
+    torch.cuda.synchronize()
+    assert np.array_equal(fused.cpu().numpy(), np.argmax((pa + pb) / np.float32(2), -1))
+
+
+def test_confusion_matrix_and_suffstats(ops):
+    rng = np.random.default_rng(9)
+    C = 12
+    lab = rng.integers(-1, C, (3, 33, 47)).astype(np.int32)
+    pred = rng.integers(0, C, (3, 33, 47)).astype(np.int64)
+    cm = torch.zeros((C, C), dtype=torch.int64, device='cuda')
+    ops.confusion_matrix(_dev(lab), _dev(pred), cm)
+    ops.confusion_matrix(_dev(lab), _dev(pred), cm)          # accumulates
+    torch.cuda.synchronize()
+    assert np.array_equal(cm.cpu().numpy(), 2 * fu.confusion_matrix(lab, pred, C))
+    p = fo.softmax((rng.standard_normal((3, 33, 47, C)) * 2).astype(np.float32))
+    S = torch.zeros((C, C), dtype=torch.float64, device='cuda')
+    cnt = torch.zeros(C, dtype=torch.int64, device='cuda')
+    ops.dirichlet_suffstats(_dev(p), _dev(lab), S, cnt)
+    torch.cuda.synchronize()
+    Sref, nref = fu.sufficient_statistics(p, lab, C)
+    assert np.array_equal(cnt.cpu().numpy(), nref)
+    np.testing.assert_allclose(S.cpu().numpy(), Sref, rtol=1e-6, atol=1e-4)
