@@ -64,6 +64,13 @@ int xv_pack_conv_weights(const float* w_hwio, void* packed, int k, int cin, int 
 int xv_conv2d_fwd(const xv_act* x, const void* w_packed, const float* bias, const xv_act* y,
                   const xv_act* pooled, int k, int relu, void* stream);
 
+/* Tuning / test entry: the same op with an explicit tile configuration 0 <= cfg < xv_conv2d_num_cfgs()
+ * (cfg < 0 = the library's own choice, i.e. xv_conv2d_fwd).  Results are bit-identical across
+ * configurations; XV_ESHAPE if the configuration cannot tile this shape.                            */
+int xv_conv2d_fwd_cfg(const xv_act* x, const void* w_packed, const float* bias, const xv_act* y,
+                      const xv_act* pooled, int k, int relu, int cfg, void* stream);
+int xv_conv2d_num_cfgs(void);
+
 /* First layer: conv1_1 = relu(conv3x3(x) + b) on the RAW float32 network input (dense unpadded
  * NHWC, cin = 1..4; simple_fcn.py:39), fp32 weights HWIO [3][3][cin][64], fp32 math, bf16 out.    */
 int xv_conv2d_first_fwd(const float* x, int n, int h, int w, int cin, const float* w_hwio,

@@ -27,10 +27,10 @@ struct ConvArgs {
   int relu;
 };
 
-template <int WR, int WC, int NW, int KS>
+template <int MT, int WR, int WC, int NW, int KS>
 struct ConvCfg {
   static constexpr int NT = 64 * WR * WC * NW;
-  static constexpr int TH = 8 * WR, TW = 16 * WC;
+  static constexpr int TH = MT * WR, TW = 16 * WC;
   static constexpr int HALO = (KS == 3) ? 1 : 0;
   static constexpr int HH = TH + 2 * HALO, HW = TW + 2 * HALO;
   static constexpr int NPIX = HH * HW;
@@ -44,9 +44,13 @@ struct ConvCfg {
   static_assert(B_BYTES % (16 * NT) == 0, "weight tile must split evenly over the threads");
 };
 
-template <int WR, int WC, int NW, int KS>
-__global__ __launch_bounds__(64 * WR * WC * NW, (ConvCfg<WR, WC, NW, KS>::LDS_BYTES <= 76 * 1024) ? 2 : 1) void conv_mfma_kernel(ConvArgs a) {
-  using C = ConvCfg<WR, WC, NW, KS>;
+// OCC = waves per SIMD the register allocation is bounded for (2 -> <= 256 VGPRs, two 4-wave
+// workgroups per CU; 1 -> up to 512).  The next-chunk patch prefetch (PFA) keeps A_ITERS*4 extra
+// registers live under the last tap, which only fits with MT = 4 or OCC = 1.
+template <int MT, int WR, int WC, int NW, int KS, int OCC>
+__global__ __launch_bounds__(64 * WR * WC * NW, OCC * 4 / (WR * WC * NW) > 0 ? OCC * 4 / (WR * WC * NW) : 1) void conv_mfma_kernel(ConvArgs a) {
+  using C = ConvCfg<MT, WR, WC, NW, KS>;
+  constexpr bool PFA = (MT == 4) || (OCC == 1);
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* As = smem;
   char* Bs = smem + C::A_BYTES;
@@ -79,61 +83,77 @@ __global__ __launch_bounds__(64 * WR * WC * NW, (ConvCfg<WR, WC, NW, KS>::LDS_BY
   const __bf16* ximg = a.x + (int64_t)n * (H + 2) * Wp * Cin;
   const int nchunks = Cin >> 6;
 
-  f32x4 acc[8][4];
+  f32x4 acc[MT][4];
 #pragma unroll
-  for (int i = 0; i < 8; ++i)
+  for (int i = 0; i < MT; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int l15 = lane & 15, lg = lane >> 4;
-  const int pbase = (wr * 8) * C::HW + wc * 16 + l15;  // halo-patch pixel of (row 0 of this wave, tap (0,0))
+  const int pbase = (wr * MT) * C::HW + wc * 16 + l15;  // halo-patch pixel of (row 0 of this wave, tap (0,0))
   const int wrow = wn * 64 + l15;                       // weight-tile row of n-tile 0
   const int wswz = (l15 >> 1) & 7;                      // swizzle term of every weight row this lane reads
 
+  // staging helpers: global -> registers (issued early) and registers -> LDS (after the barrier).
+  // Patch coordinates are clamped to the zero border of the padded buffer, so every load is
+  // in-bounds and unconditional; outputs fed by clamped pixels are never stored.
+  auto a_load = [&](int chunk, auto& v) {
+#pragma unroll
+    for (int it = 0; it < C::A_ITERS; ++it) {
+      int idx = tid + it * C::NT;
+      idx = idx < C::NPIX * 8 ? idx : C::NPIX * 8 - 1;
+      const int p = idx >> 3, s = idx & 7;
+      const int hy = p / C::HW, hx = p - hy * C::HW;
+      int yy = y0 + hy + (1 - C::HALO), xx = x0 + hx + (1 - C::HALO);  // padded coords
+      yy = yy < H + 1 ? yy : H + 1;
+      xx = xx < W + 1 ? xx : W + 1;
+      v[it] = *reinterpret_cast<const u32x4*>(ximg + ((int64_t)yy * Wp + xx) * Cin + chunk * 64 + s * 8);
+    }
+  };
+  auto a_store = [&](const auto& v) {
+#pragma unroll
+    for (int it = 0; it < C::A_ITERS; ++it) {
+      const int idx = tid + it * C::NT;
+      const int p = idx >> 3, s = idx & 7;
+      if (idx < C::NPIX * 8) *reinterpret_cast<u32x4*>(As + p * 128 + (xv_swz(p, s) << 4)) = v[it];
+    }
+  };
+  auto b_load = [&](int tap, int chunk, u32x4(&v)[C::B_ITERS]) {
+    const char* src = reinterpret_cast<const char*>(a.wpk) + (((int64_t)(tap * nchunks + chunk) * Cout + co0) << 7);
+#pragma unroll
+    for (int it = 0; it < C::B_ITERS; ++it) v[it] = *reinterpret_cast<const u32x4*>(src + ((tid + it * C::NT) << 4));
+  };
+  auto b_store = [&](int buf, const u32x4(&v)[C::B_ITERS]) {
+    char* dst = Bs + buf * C::B_BYTES;
+#pragma unroll
+    for (int it = 0; it < C::B_ITERS; ++it) *reinterpret_cast<u32x4*>(dst + ((tid + it * C::NT) << 4)) = v[it];
+  };
+
+  u32x4 areg[PFA ? C::A_ITERS : 1];
+  u32x4 breg[C::B_ITERS];
+  if constexpr (PFA) a_load(0, areg);
+  b_load(0, 0, breg);
   for (int chunk = 0; chunk < nchunks; ++chunk) {
-    __syncthreads();  // all waves are done with As / Bs of the previous chunk
-    // ---- stage the halo patch of this 64-channel chunk --------------------------------------
-    {
-      u32x4 v[C::A_ITERS];
-#pragma unroll
-      for (int it = 0; it < C::A_ITERS; ++it) {
-        const int idx = tid + it * C::NT;
-        const int p = idx >> 3, s = idx & 7;
-        const int hy = p / C::HW, hx = p - hy * C::HW;
-        const int yy = y0 + hy + (1 - C::HALO), xx = x0 + hx + (1 - C::HALO);  // padded coords
-        v[it] = u32x4{0u, 0u, 0u, 0u};
-        if (idx < C::NPIX * 8 && yy < H + 2 && xx < Wp)
-          v[it] = *reinterpret_cast<const u32x4*>(ximg + ((int64_t)yy * Wp + xx) * Cin + chunk * 64 + s * 8);
-      }
-#pragma unroll
-      for (int it = 0; it < C::A_ITERS; ++it) {
-        const int idx = tid + it * C::NT;
-        const int p = idx >> 3, s = idx & 7;
-        if (idx < C::NPIX * 8) *reinterpret_cast<u32x4*>(As + p * 128 + (xv_swz(p, s) << 4)) = v[it];
-      }
+    if (chunk > 0) __syncthreads();  // all waves are done reading As / Bs of the previous chunk
+    if constexpr (PFA) {
+      a_store(areg);
+    } else {
+      u32x4 atmp[C::A_ITERS];
+      a_load(chunk, atmp);
+      a_store(atmp);
     }
-    // ---- weight tile of tap 0 ------------------------------------------------------------------
-    {
-      const char* src = reinterpret_cast<const char*>(a.wpk) + (((int64_t)(0 * nchunks + chunk) * Cout + co0) << 7);
-#pragma unroll
-      for (int it = 0; it < C::B_ITERS; ++it) {
-        const int o = (tid + it * C::NT) << 4;
-        *reinterpret_cast<u32x4*>(Bs + o) = *reinterpret_cast<const u32x4*>(src + o);
-      }
-    }
+    b_store(0, breg);
     __syncthreads();
 
     for (int tap = 0; tap < C::NTAPS; ++tap) {
       const int cur = tap & 1;
       const char* Bcur = Bs + cur * C::B_BYTES;
-      u32x4 breg[C::B_ITERS];
       const bool more = tap + 1 < C::NTAPS;
       if (more) {
-        const char* src =
-            reinterpret_cast<const char*>(a.wpk) + (((int64_t)((tap + 1) * nchunks + chunk) * Cout + co0) << 7);
-#pragma unroll
-        for (int it = 0; it < C::B_ITERS; ++it)
-          breg[it] = *reinterpret_cast<const u32x4*>(src + ((tid + it * C::NT) << 4));
+        b_load(tap + 1, chunk, breg);
+      } else if (chunk + 1 < nchunks) {
+        if constexpr (PFA) a_load(chunk + 1, areg);  // next chunk's patch + first weight tile travel under the last tap's MFMAs
+        b_load(0, chunk + 1, breg);
       }
       const int dy = (KS == 3) ? tap / 3 : 0;
       const int dx = (KS == 3) ? tap - dy * 3 : 0;
@@ -146,7 +166,7 @@ __global__ __launch_bounds__(64 * WR * WC * NW, (ConvCfg<WR, WC, NW, KS>::LDS_BY
         for (int j = 0; j < 4; ++j)
           wf[j] = *reinterpret_cast<const bf16x8*>(Bcur + (wrow + j * 16) * 128 + ((slot ^ wswz) << 4));
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
+        for (int i = 0; i < MT; ++i) {
           const int p = ptap + i * C::HW;
           const bf16x8 xf = *reinterpret_cast<const bf16x8*>(As + p * 128 + (xv_swz(p, slot) << 4));
 #pragma unroll
@@ -155,12 +175,9 @@ __global__ __launch_bounds__(64 * WR * WC * NW, (ConvCfg<WR, WC, NW, KS>::LDS_BY
         }
       }
       if (more) {
-        char* Bnxt = Bs + (cur ^ 1) * C::B_BYTES;
-#pragma unroll
-        for (int it = 0; it < C::B_ITERS; ++it)
-          *reinterpret_cast<u32x4*>(Bnxt + ((tid + it * C::NT) << 4)) = breg[it];
+        b_store(cur ^ 1, breg);
+        __syncthreads();
       }
-      if (more) __syncthreads();
     }
   }
 
@@ -171,7 +188,7 @@ __global__ __launch_bounds__(64 * WR * WC * NW, (ConvCfg<WR, WC, NW, KS>::LDS_BY
 #pragma unroll
   for (int j = 0; j < 4; ++j) bj[j] = *reinterpret_cast<const f32x4*>(a.bias + cbase + j * 16);
 #pragma unroll
-  for (int i = 0; i < 8; ++i)
+  for (int i = 0; i < MT; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       f32x4 v = acc[i][j] + bj[j];
@@ -186,8 +203,8 @@ __global__ __launch_bounds__(64 * WR * WC * NW, (ConvCfg<WR, WC, NW, KS>::LDS_BY
   if (a.y != nullptr) {
     __bf16* yimg = a.y + (int64_t)n * (H + 2) * Wp * Cout;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int py = y0 + wr * 8 + i;
+    for (int i = 0; i < MT; ++i) {
+      const int py = y0 + wr * MT + i;
       if (py < H && px < W) {
         __bf16* dst = yimg + ((int64_t)(py + 1) * Wp + (px + 1)) * Cout + cbase;
 #pragma unroll
@@ -203,8 +220,8 @@ __global__ __launch_bounds__(64 * WR * WC * NW, (ConvCfg<WR, WC, NW, KS>::LDS_BY
     const int Hq = H >> 1, Wq = W >> 1;
     __bf16* qimg = a.pooled + (int64_t)n * (Hq + 2) * (Wq + 2) * Cout;
 #pragma unroll
-    for (int i = 0; i < 8; i += 2) {
-      const int py = y0 + wr * 8 + i;
+    for (int i = 0; i < MT; i += 2) {
+      const int py = y0 + wr * MT + i;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         f32x4 m;
@@ -225,23 +242,24 @@ __global__ __launch_bounds__(64 * WR * WC * NW, (ConvCfg<WR, WC, NW, KS>::LDS_BY
   }
 }
 
-template <int WR, int WC, int NW, int KS>
+template <int MT, int WR, int WC, int NW, int KS, int OCC>
 int launch_conv(const ConvArgs& a0, hipStream_t stream) {
-  using C = ConvCfg<WR, WC, NW, KS>;
+  using C = ConvCfg<MT, WR, WC, NW, KS>;
   ConvArgs a = a0;
   a.tiles_x = (a.W + C::TW - 1) / C::TW;
   a.tiles_y = (a.H + C::TH - 1) / C::TH;
   a.n_ct = a.Cout / C::BN;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_kernel<WR, WC, NW, KS>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_kernel<MT, WR, WC, NW, KS, OCC>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
   const int64_t nblk = (int64_t)a.tiles_x * a.tiles_y * a.N * a.n_ct;
   if (nblk <= 0 || nblk > 0x7fffffff) return XV_ESHAPE;
-  hipLaunchKernelGGL((conv_mfma_kernel<WR, WC, NW, KS>), dim3((unsigned)nblk), dim3(C::NT), C::LDS_BYTES, stream, a);
+  if (a.pooled && (C::TH & 1)) return XV_ESHAPE;
+  hipLaunchKernelGGL((conv_mfma_kernel<MT, WR, WC, NW, KS, OCC>), dim3((unsigned)nblk), dim3(C::NT), C::LDS_BYTES, stream, a);
   return xv_launch_status();
 }
 
@@ -266,25 +284,64 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, __bf16* __restr
   }
 }
 
-}  // namespace
+// ---- tile configurations ---------------------------------------------------------------------
+// id: pixel patch x output channels, waves, LDS, workgroups per CU (register bound)
+//   0: 16x16 x 128, 4 waves, 74 KB, 2/CU          1:  8x16 x 128, 4 waves, 55 KB, 2/CU
+//   2:  8x32 x 128, 4 waves, 75 KB, 2/CU          3: 16x32 x 128, 8 waves, 110 KB, 1/CU
+//   4: 16x16 x  64, 4 waves, 57 KB, 2/CU          5: 16x32 x  64, 4 waves, 94 KB, 1/CU
+//   6:  8x32 x  64, 4 waves, 59 KB, 2/CU          7:  8x16 x 256, 4 waves, 87 KB, 1/CU
+//   8: as 0 but 1/CU with the patch prefetch      9: as 2 but 1/CU with the patch prefetch
+constexpr int XV_NUM_CONV_CFG = 10;
+struct Geo {
+  int th, tw, bn, per_cu;
+};
+const Geo kGeo[XV_NUM_CONV_CFG] = {{16, 16, 128, 2}, {8, 16, 128, 2}, {8, 32, 128, 2}, {16, 32, 128, 1},
+                                   {16, 16, 64, 2},  {16, 32, 64, 1}, {8, 32, 64, 2},  {8, 16, 256, 1},
+                                   {16, 16, 128, 1}, {8, 32, 128, 1}};
 
-extern "C" size_t xv_packed_weight_bytes(int k, int cin, int cout) {
-  if ((k != 1 && k != 3) || cin <= 0 || cout <= 0 || (cin & 63) || (cout & 63)) return 0;
-  return (size_t)k * k * cin * cout * 2;
+template <int KS>
+int launch_cfg(int cfg, const ConvArgs& a, hipStream_t s) {
+  if (cfg < 0 || cfg >= XV_NUM_CONV_CFG) return XV_EINVAL;
+  if (a.Cout % kGeo[cfg].bn) return XV_ESHAPE;
+  switch (cfg) {
+    case 0: return launch_conv<8, 2, 1, 2, KS, 2>(a, s);
+    case 1: return launch_conv<4, 2, 1, 2, KS, 2>(a, s);
+    case 2: return launch_conv<8, 1, 2, 2, KS, 2>(a, s);
+    case 3: return launch_conv<8, 2, 2, 2, KS, 2>(a, s);
+    case 4: return launch_conv<4, 4, 1, 1, KS, 2>(a, s);
+    case 5: return launch_conv<8, 2, 2, 1, KS, 1>(a, s);
+    case 6: return launch_conv<4, 2, 2, 1, KS, 2>(a, s);
+    case 7: return launch_conv<8, 1, 1, 4, KS, 1>(a, s);
+    case 8: return launch_conv<8, 2, 1, 2, KS, 1>(a, s);
+    default: return launch_conv<8, 1, 2, 2, KS, 1>(a, s);
+  }
 }
 
-extern "C" int xv_pack_conv_weights(const float* w_hwio, void* packed, int k, int cin, int cout, void* stream) {
-  XV_CHECK_ARG(w_hwio && packed);
-  XV_CHECK_SHAPE((k == 1 || k == 3) && cin > 0 && cout > 0 && (cin & 63) == 0 && (cout & 63) == 0);
-  const int64_t total = (int64_t)k * k * cin * cout;
-  const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
-  hipLaunchKernelGGL(pack_weights_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w_hwio, (__bf16*)packed,
-                     k * k, cin, cout);
-  return xv_launch_status();
+// Default choice: fewest "rounds" of workgroups over the 256 CUs, ties to the larger tile.
+int pick_cfg(const ConvArgs& a) {
+  int best = -1;
+  double best_cost = 0;
+  for (int c = 0; c < 8; ++c) {
+    const Geo& g = kGeo[c];
+    if (a.Cout % g.bn) continue;
+    if (a.pooled && (g.th & 1)) continue;
+    const double blocks = (double)((a.H + g.th - 1) / g.th) * ((a.W + g.tw - 1) / g.tw) * a.N * (a.Cout / g.bn);
+    const double slots = 256.0 * g.per_cu;
+    const double rounds = __builtin_ceil(blocks / slots);
+    // time ~ rounds * work per workgroup * (co-resident workgroups share the CU's MFMA pipes)
+    double cost = rounds * (double)g.th * g.tw * g.bn * g.per_cu;
+    // halo + weight re-fetch overhead favours the larger tiles at equal rounds
+    cost *= 1.0 + 0.08 * (256.0 * 128.0) / ((double)g.th * g.tw * g.bn);
+    if (best < 0 || cost < best_cost) {
+      best = c;
+      best_cost = cost;
+    }
+  }
+  return best;
 }
 
-extern "C" int xv_conv2d_fwd(const xv_act* x, const void* w_packed, const float* bias, const xv_act* y,
-                             const xv_act* pooled, int k, int relu, void* stream) {
+int conv_fwd_impl(const xv_act* x, const void* w_packed, const float* bias, const xv_act* y, const xv_act* pooled,
+                  int k, int relu, int cfg, void* stream) {
   XV_CHECK_ARG(x && x->data && w_packed && bias && y);
   XV_CHECK_ARG(y->data || (pooled && pooled->data));
   XV_CHECK_SHAPE(k == 1 || k == 3);
@@ -309,11 +366,37 @@ extern "C" int xv_conv2d_fwd(const xv_act* x, const void* w_packed, const float*
     XV_CHECK_ARG(((uintptr_t)pooled->data & 15) == 0);
     a.pooled = (__bf16*)pooled->data;
   }
+  if (cfg < 0) cfg = pick_cfg(a);
+  if (cfg < 0) return XV_ESHAPE;
   hipStream_t s = (hipStream_t)stream;
-  if (k == 3) {
-    if (a.Cout % 128 == 0) return launch_conv<2, 1, 2, 3>(a, s);
-    return launch_conv<2, 2, 1, 3>(a, s);
-  }
-  if (a.Cout % 128 == 0) return launch_conv<2, 1, 2, 1>(a, s);
-  return launch_conv<2, 2, 1, 1>(a, s);
+  return k == 3 ? launch_cfg<3>(cfg, a, s) : launch_cfg<1>(cfg, a, s);
 }
+
+}  // namespace
+
+extern "C" size_t xv_packed_weight_bytes(int k, int cin, int cout) {
+  if ((k != 1 && k != 3) || cin <= 0 || cout <= 0 || (cin & 63) || (cout & 63)) return 0;
+  return (size_t)k * k * cin * cout * 2;
+}
+
+extern "C" int xv_pack_conv_weights(const float* w_hwio, void* packed, int k, int cin, int cout, void* stream) {
+  XV_CHECK_ARG(w_hwio && packed);
+  XV_CHECK_SHAPE((k == 1 || k == 3) && cin > 0 && cout > 0 && (cin & 63) == 0 && (cout & 63) == 0);
+  const int64_t total = (int64_t)k * k * cin * cout;
+  const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+  hipLaunchKernelGGL(pack_weights_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w_hwio, (__bf16*)packed,
+                     k * k, cin, cout);
+  return xv_launch_status();
+}
+
+extern "C" int xv_conv2d_fwd(const xv_act* x, const void* w_packed, const float* bias, const xv_act* y,
+                             const xv_act* pooled, int k, int relu, void* stream) {
+  return conv_fwd_impl(x, w_packed, bias, y, pooled, k, relu, -1, stream);
+}
+
+extern "C" int xv_conv2d_fwd_cfg(const xv_act* x, const void* w_packed, const float* bias, const xv_act* y,
+                                 const xv_act* pooled, int k, int relu, int cfg, void* stream) {
+  return conv_fwd_impl(x, w_packed, bias, y, pooled, k, relu, cfg, stream);
+}
+
+extern "C" int xv_conv2d_num_cfgs(void) { return XV_NUM_CONV_CFG; }

@@ -69,7 +69,7 @@ def pack_conv_weights(w_hwio):
     return out
 
 
-def conv2d_fwd(x, w_packed, bias, k, relu=True, y=None, pooled=None, write_y=True):
+def conv2d_fwd(x, w_packed, bias, k, relu=True, y=None, pooled=None, write_y=True, cfg=-1):
     """x: Act; returns (y Act or None, pooled Act or None)."""
     cout = bias.numel()
     _need(bias, torch.float32, 'bias')
@@ -80,8 +80,9 @@ def conv2d_fwd(x, w_packed, bias, k, relu=True, y=None, pooled=None, write_y=Tru
     if prof is not None:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
-    rc = _lib.lib().xv_conv2d_fwd(x.xv(), _ptr(w_packed), _ptr(bias), ctypes.byref(ydesc),
-                                 pooled.xv() if pooled is not None else _NULL_ACT, k, int(bool(relu)), _stream())
+    rc = _lib.lib().xv_conv2d_fwd_cfg(x.xv(), _ptr(w_packed), _ptr(bias), ctypes.byref(ydesc),
+                                     pooled.xv() if pooled is not None else _NULL_ACT, k, int(bool(relu)), int(cfg),
+                                     _stream())
     _lib.check(rc, 'xv_conv2d_fwd')
     if prof is not None:
         ev1.record()

@@ -78,6 +78,27 @@ def test_conv2d_mfma_exact_on_integers(ops, n, h, w, cin, cout, k, pool):
         assert torch.equal(q3.t, q.t)
 
 
+@pytest.mark.parametrize('k', [3, 1])
+def test_conv2d_every_tile_configuration(ops, k):
+    """All tile configurations compute bit-identical results (same accumulation order)."""
+    from modular_semantic_segmentation_amd import _lib
+    rng = np.random.default_rng(k)
+    n, h, w, cin, cout = 2, 24, 40, 128, 256
+    x = rng.integers(-2, 3, (n, h, w, cin)).astype(np.float32)
+    wt = rng.integers(-1, 2, (k, k, cin, cout)).astype(np.float32)
+    b = rng.integers(-3, 4, cout).astype(np.float32)
+    xa, wp, bd = ops.Act.from_dense(_dev(x)), ops.pack_conv_weights(_dev(wt)), _dev(b)
+    y32, ref = _conv_oracle(x, wt, b, True, k)
+    refq = fo.round_bf16(fo.maxpool2(y32)).permute(0, 2, 3, 1).numpy()
+    for cfg in range(_lib.lib().xv_conv2d_num_cfgs()):
+        q = ops.Act(n, h // 2, w // 2, cout) if k == 3 else None
+        y, _ = ops.conv2d_fwd(xa, wp, bd, k, relu=True, pooled=q, cfg=cfg)
+        torch.cuda.synchronize()
+        assert np.array_equal(y.interior().float().cpu().numpy(), ref), 'cfg %d' % cfg
+        if q is not None:
+            assert np.array_equal(q.interior().float().cpu().numpy(), refq), 'cfg %d pooled' % cfg
+
+
 def test_conv2d_mfma_random_bf16(ops):
     """Random bf16 operands: fp32-accumulate result within accumulation-order tolerance."""
     rng = np.random.default_rng(7)

@@ -1,0 +1,58 @@
+#!/usr/bin/env python3
+"""Time every conv tile configuration on every SimpleFCN layer shape (GPU box only).
+Prints TFLOP/s per (layer, cfg); used to set the default choice in csrc/conv_mfma.hip."""
+import argparse
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from modular_semantic_segmentation_amd import _lib, ops  # noqa: E402
+
+LAYERS = [('conv1_2', 1, 64, 64, 3, True), ('conv2_1', 2, 64, 128, 3, False), ('conv2_2', 2, 128, 128, 3, True),
+          ('conv3_1', 4, 128, 256, 3, False), ('conv3_2', 4, 256, 256, 3, False), ('conv3_3', 4, 256, 256, 3, True),
+          ('conv4_1', 8, 256, 512, 3, False), ('conv4_2', 8, 512, 512, 3, False), ('conv4_3', 8, 512, 512, 3, True),
+          ('conv5_1', 16, 512, 512, 3, False), ('score_conv4', 8, 512, 64, 1, False),
+          ('score_conv5', 16, 512, 64, 1, False)]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--batch', type=int, default=8)
+    ap.add_argument('--height', type=int, default=384)
+    ap.add_argument('--width', type=int, default=768)
+    ap.add_argument('--iters', type=int, default=5)
+    args = ap.parse_args()
+    ncfg = _lib.lib().xv_conv2d_num_cfgs()
+    print('layer        ' + ''.join('cfg%-6d' % c for c in range(ncfg)) + ' default')
+    for name, s, cin, cout, k, pool in LAYERS:
+        h, w = args.height // s, args.width // s
+        x = ops.Act(args.batch, h, w, cin)
+        x.interior().normal_()
+        wt = torch.randn(k, k, cin, cout, device='cuda') * (1.0 / (k * k * cin) ** 0.5)
+        wp = ops.pack_conv_weights(wt)
+        b = torch.zeros(cout, device='cuda')
+        y = ops.Act(args.batch, h, w, cout)
+        q = ops.Act(args.batch, h // 2, w // 2, cout) if pool else None
+        flops = 2.0 * args.batch * h * w * cin * cout * k * k
+        row = '%-12s ' % name
+        for cfg in list(range(ncfg)) + [-1]:
+            try:
+                for _ in range(2):
+                    ops.conv2d_fwd(x, wp, b, k, y=y, pooled=q, cfg=cfg)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(args.iters):
+                    ops.conv2d_fwd(x, wp, b, k, y=y, pooled=q, cfg=cfg)
+                e1.record()
+                torch.cuda.synchronize()
+                ms = e0.elapsed_time(e1) / args.iters
+                row += '%-9.0f' % (flops / ms / 1e9)
+            except _lib.XvError:
+                row += '%-9s' % '-'
+        print(row, flush=True)
+
+
+if __name__ == '__main__':
+    main()
