@@ -12,6 +12,31 @@ def test_pipeline(engine, inputs, want=('prob', 'classification')):
     return out
 
 
+def run_experts(model, batch, wants):
+    """Forward every modality's expert, each on its own HIP stream: the experts are independent
+    until the fusion kernel, and the tail of one stream's persistent conv grid is filled by the
+    other stream's workgroups.  The current stream waits for all of them before fusing."""
+    if not getattr(model, 'concurrent_experts', True):
+        return {m: test_pipeline(model.experts[m], model._to_device(batch[m], torch.float32), want=wants)
+                for m in model.modalities}
+    main = torch.cuda.current_stream(model.device)
+    if not hasattr(model, '_expert_streams'):
+        model._expert_streams = {m: torch.cuda.Stream(device=model.device) for m in model.modalities}
+    outs = {}
+    inputs = {m: model._to_device(batch[m], torch.float32) for m in model.modalities}
+    for m in model.modalities:
+        side = model._expert_streams[m]
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            outs[m] = test_pipeline(model.experts[m], inputs[m], want=wants)
+            for v in outs[m].values():
+                if isinstance(v, torch.Tensor):
+                    v.record_stream(main)
+    for m in model.modalities:
+        main.wait_stream(model._expert_streams[m])
+    return outs
+
+
 class FusionModel(BaseModel):
     """Mixture of per-modality FCN experts; subclasses implement `_fusion(expert_outputs)`.
     config: prefixes {modality: prefix}, num_units, num_channels {modality: C_in}, expert_model."""
@@ -49,11 +74,7 @@ class FusionModel(BaseModel):
             self.experts[m].load(self.variables)
 
     def _expert_outputs(self, batch, wants):
-        outs = {}
-        for m in self.modalities:
-            x = self._to_device(batch[m], torch.float32)
-            outs[m] = test_pipeline(self.experts[m], x, want=wants)
-        return outs
+        return run_experts(self, batch, wants)
 
     def _predict_batch(self, batch, output_attr=None):
         wants = self.expert_wants

@@ -12,6 +12,8 @@
 //   staged ONCE in LDS and re-read by all 9 taps; the 64*NW x 64 weight tile of each tap is
 //   double-buffered.  Pixel rows / weight rows are 128 B in LDS with a 16-byte-slot XOR swizzle
 //   (xv_swz) so the 16-lane ds_read_b128 groups are bank-conflict free.
+#include <type_traits>
+
 #include "xv_common.h"
 
 namespace {
@@ -23,8 +25,9 @@ struct ConvArgs {
   __bf16* y;       // may be null
   __bf16* pooled;  // may be null
   int N, H, W, Cin, Cout;
-  int tiles_x, tiles_y, n_ct;
+  int tiles_x, tiles_y, n_ct, n_tiles;
   int relu;
+  int num_cus;
 };
 
 template <int MT, int WR, int WC, int NW, int KS>
@@ -45,15 +48,22 @@ struct ConvCfg {
 };
 
 // OCC = waves per SIMD the register allocation is bounded for (2 -> <= 256 VGPRs, two 4-wave
-// workgroups per CU; 1 -> up to 512).  The next-chunk patch prefetch (PFA) keeps A_ITERS*4 extra
+// workgroups per CU; 1 -> up to 512).  The next-item patch prefetch (PFA) keeps A_ITERS*4 extra
 // registers live under the last tap, which only fits with MT = 4 or OCC = 1.
+//
+// Persistent workgroups: the grid is min(#tiles, resident slots); a workgroup walks its share of
+// the (pixel patch, cout tile) list of its XCD, and while the last tap of one work item (= one
+// 64-channel input chunk of one tile) runs on the matrix cores the next item's activation patch and
+// first weight tile are already in flight to registers -- across chunk AND tile boundaries.
+// All LDS fragment reads use a per-lane base register + compile-time immediate offset (taps are
+// fully unrolled), so the inner loop issues no address arithmetic.
 template <int MT, int WR, int WC, int NW, int KS, int OCC>
 __global__ __launch_bounds__(64 * WR * WC * NW, OCC * 4 / (WR * WC * NW) > 0 ? OCC * 4 / (WR * WC * NW) : 1) void conv_mfma_kernel(ConvArgs a) {
   using C = ConvCfg<MT, WR, WC, NW, KS>;
   constexpr bool PFA = (MT == 4) || (OCC == 1);
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* As = smem;
-  char* Bs = smem + C::A_BYTES;
+  char* const As = smem;
+  char* const Bs = smem + C::A_BYTES;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -62,63 +72,78 @@ __global__ __launch_bounds__(64 * WR * WC * NW, OCC * 4 / (WR * WC * NW) > 0 ? O
   const int wm = wave / NW;
   const int wr = wm / WC;
   const int wc = wm % WC;
+  const int l15 = lane & 15, lg = lane >> 4;
 
-  // XCD-aware block remap (bijective): consecutive logical ids share an XCD (and its L2), and
-  // consecutive logical ids are the cout tiles of ONE pixel patch, then the neighbouring patch.
-  const int nblk = gridDim.x;
-  const int bid = blockIdx.x;
-  const int xcd = bid & 7, q = nblk >> 3, r = nblk & 7;
-  const int lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-  const int ct = lid % a.n_ct;
-  int t = lid / a.n_ct;
-  const int tx = t % a.tiles_x;
-  t /= a.tiles_x;
-  const int ty = t % a.tiles_y;
-  const int n = t / a.tiles_y;
-
-  const int y0 = ty * C::TH, x0 = tx * C::TW;  // logical coords of the patch origin
-  const int co0 = ct * C::BN;
   const int H = a.H, W = a.W, Cin = a.Cin, Cout = a.Cout;
   const int Wp = W + 2;
-  const __bf16* ximg = a.x + (int64_t)n * (H + 2) * Wp * Cin;
   const int nchunks = Cin >> 6;
 
-  f32x4 acc[MT][4];
-#pragma unroll
-  for (int i = 0; i < MT; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // ---- this workgroup's share of the tile list (XCD-aware, placement affects speed only) --------
+  // workgroups b, b+8, ... share an XCD (round-robin dispatch); each XCD owns a contiguous range of
+  // logical tile ids, in which consecutive ids are the cout tiles of ONE pixel patch (shared L2 lines).
+  const int G = gridDim.x, b = blockIdx.x;
+  const int xcd = b & 7, bi = b >> 3;
+  const int nb = (G - xcd + 7) >> 3;  // workgroups of this XCD
+  const int T = a.n_tiles;
+  const int tq = T >> 3, trm = T & 7;
+  const int t_begin = xcd * tq + (xcd < trm ? xcd : trm);
+  const int t_end = t_begin + tq + (xcd < trm ? 1 : 0);
 
-  const int l15 = lane & 15, lg = lane >> 4;
-  const int pbase = (wr * MT) * C::HW + wc * 16 + l15;  // halo-patch pixel of (row 0 of this wave, tap (0,0))
-  const int wrow = wn * 64 + l15;                       // weight-tile row of n-tile 0
-  const int wswz = (l15 >> 1) & 7;                      // swizzle term of every weight row this lane reads
+  struct Tile {
+    int n, y0, x0, co0;
+  };
+  auto decode = [&](int lid) {
+    Tile t;
+    t.co0 = (lid % a.n_ct) * C::BN;
+    int r = lid / a.n_ct;
+    t.x0 = (r % a.tiles_x) * C::TW;
+    r /= a.tiles_x;
+    t.y0 = (r % a.tiles_y) * C::TH;
+    t.n = r / a.tiles_y;
+    return t;
+  };
 
-  // staging helpers: global -> registers (issued early) and registers -> LDS (after the barrier).
-  // Patch coordinates are clamped to the zero border of the padded buffer, so every load is
-  // in-bounds and unconditional; outputs fed by clamped pixels are never stored.
-  auto a_load = [&](int chunk, auto& v) {
+  // ---- per-lane LDS fragment bases (16-byte slot s of pixel column hx / weight row n lives at
+  //      slot s ^ ((hx or n) >> 1 & 7): conflict-free ds_read_b128 for 16 consecutive columns) ----
+  int abase[KS][2];
 #pragma unroll
-    for (int it = 0; it < C::A_ITERS; ++it) {
+  for (int dx = 0; dx < KS; ++dx)
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const int hx = wc * 16 + l15 + dx;
+      abase[dx][kk] = ((wr * MT) * C::HW + hx) * 128 + (xv_swz(hx, kk * 4 + lg) << 4);
+    }
+  int wbase[2];
+#pragma unroll
+  for (int kk = 0; kk < 2; ++kk) wbase[kk] = C::A_BYTES + (wn * 64 + l15) * 128 + (xv_swz(l15, kk * 4 + lg) << 4);
+
+  // ---- staging: global -> registers (issued early), registers -> LDS (after the barrier) ---------
+  // Patch coordinates are clamped onto the zero border of the padded buffer: every load is in-bounds
+  // and unconditional; outputs fed by clamped pixels are never stored.
+  auto a_load = [&](const Tile& t, int chunk, auto& v, auto IT0, auto IT1) {
+    const __bf16* ximg = a.x + (int64_t)t.n * (H + 2) * Wp * Cin + chunk * 64;
+#pragma unroll
+    for (int it = IT0; it < IT1; ++it) {
       int idx = tid + it * C::NT;
       idx = idx < C::NPIX * 8 ? idx : C::NPIX * 8 - 1;
       const int p = idx >> 3, s = idx & 7;
       const int hy = p / C::HW, hx = p - hy * C::HW;
-      int yy = y0 + hy + (1 - C::HALO), xx = x0 + hx + (1 - C::HALO);  // padded coords
+      int yy = t.y0 + hy + (1 - C::HALO), xx = t.x0 + hx + (1 - C::HALO);  // padded coords
       yy = yy < H + 1 ? yy : H + 1;
       xx = xx < W + 1 ? xx : W + 1;
-      v[it] = *reinterpret_cast<const u32x4*>(ximg + ((int64_t)yy * Wp + xx) * Cin + chunk * 64 + s * 8);
+      v[it - IT0] = *reinterpret_cast<const u32x4*>(ximg + ((int64_t)yy * Wp + xx) * Cin + s * 8);
     }
   };
-  auto a_store = [&](const auto& v) {
+  auto a_store = [&](const auto& v, auto IT0, auto IT1) {
 #pragma unroll
-    for (int it = 0; it < C::A_ITERS; ++it) {
+    for (int it = IT0; it < IT1; ++it) {
       const int idx = tid + it * C::NT;
       const int p = idx >> 3, s = idx & 7;
-      if (idx < C::NPIX * 8) *reinterpret_cast<u32x4*>(As + p * 128 + (xv_swz(p, s) << 4)) = v[it];
+      const int hx = p % C::HW;
+      if (idx < C::NPIX * 8) *reinterpret_cast<u32x4*>(As + p * 128 + (xv_swz(hx, s) << 4)) = v[it - IT0];
     }
   };
-  auto b_load = [&](int tap, int chunk, u32x4(&v)[C::B_ITERS]) {
+  auto b_load = [&](int co0, int tap, int chunk, u32x4(&v)[C::B_ITERS]) {
     const char* src = reinterpret_cast<const char*>(a.wpk) + (((int64_t)(tap * nchunks + chunk) * Cout + co0) << 7);
 #pragma unroll
     for (int it = 0; it < C::B_ITERS; ++it) v[it] = *reinterpret_cast<const u32x4*>(src + ((tid + it * C::NT) << 4));
@@ -129,116 +154,149 @@ __global__ __launch_bounds__(64 * WR * WC * NW, OCC * 4 / (WR * WC * NW) > 0 ? O
     for (int it = 0; it < C::B_ITERS; ++it) *reinterpret_cast<u32x4*>(dst + ((tid + it * C::NT) << 4)) = v[it];
   };
 
+  int lid = t_begin + bi;
+  if (lid >= t_end) return;
+  Tile cur = decode(lid);
+  int chunk = 0;
+
+  f32x4 acc[MT][4];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
   u32x4 areg[PFA ? C::A_ITERS : 1];
   u32x4 breg[C::B_ITERS];
-  if constexpr (PFA) a_load(0, areg);
-  b_load(0, 0, breg);
-  for (int chunk = 0; chunk < nchunks; ++chunk) {
-    if (chunk > 0) __syncthreads();  // all waves are done reading As / Bs of the previous chunk
+  constexpr std::integral_constant<int, 0> I0{};
+  constexpr std::integral_constant<int, (C::A_ITERS + 1) / 2> IH{};
+  constexpr std::integral_constant<int, C::A_ITERS> IN{};
+  if constexpr (PFA) a_load(cur, 0, areg, I0, IN);
+  b_load(cur.co0, 0, 0, breg);
+  bool first = true;
+
+  while (true) {
+    if (!first) __syncthreads();  // every wave is done reading As / Bs of the previous work item
+    first = false;
     if constexpr (PFA) {
-      a_store(areg);
+      a_store(areg, I0, IN);
     } else {
-      u32x4 atmp[C::A_ITERS];
-      a_load(chunk, atmp);
-      a_store(atmp);
+      // no registers to spare for a prefetch: stage the patch in two halves
+      u32x4 atmp[(C::A_ITERS + 1) / 2];
+      a_load(cur, chunk, atmp, I0, IH);
+      a_store(atmp, I0, IH);
+      a_load(cur, chunk, atmp, IH, IN);
+      a_store(atmp, IH, IN);
     }
     b_store(0, breg);
     __syncthreads();
 
+    // the work item after this one: next chunk of this tile, else chunk 0 of this workgroup's next tile
+    const bool last_chunk = chunk + 1 == nchunks;
+    const int nlid = last_chunk ? lid + nb : lid;
+    const bool has_next = nlid < t_end;
+    const Tile nxt = (last_chunk && has_next) ? decode(nlid) : cur;
+    const int nchunk = last_chunk ? 0 : chunk + 1;
+
+#pragma unroll
     for (int tap = 0; tap < C::NTAPS; ++tap) {
-      const int cur = tap & 1;
-      const char* Bcur = Bs + cur * C::B_BYTES;
-      const bool more = tap + 1 < C::NTAPS;
-      if (more) {
-        b_load(tap + 1, chunk, breg);
-      } else if (chunk + 1 < nchunks) {
-        if constexpr (PFA) a_load(chunk + 1, areg);  // next chunk's patch + first weight tile travel under the last tap's MFMAs
-        b_load(0, chunk + 1, breg);
+      constexpr int kB = C::B_BYTES;
+      const int cb = (tap & 1) * kB;
+      if (tap + 1 < C::NTAPS) {
+        b_load(cur.co0, tap + 1, chunk, breg);
+      } else if (has_next) {
+        if constexpr (PFA) a_load(nxt, nchunk, areg, I0, IN);
+        b_load(nxt.co0, 0, nchunk, breg);
       }
       const int dy = (KS == 3) ? tap / 3 : 0;
-      const int dx = (KS == 3) ? tap - dy * 3 : 0;
-      const int ptap = pbase + dy * C::HW + dx;
+      const int dx = (KS == 3) ? tap % 3 : 0;
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) {
-        const int slot = kk * 4 + lg;
         bf16x8 wf[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-          wf[j] = *reinterpret_cast<const bf16x8*>(Bcur + (wrow + j * 16) * 128 + ((slot ^ wswz) << 4));
+        for (int j = 0; j < 4; ++j) wf[j] = *reinterpret_cast<const bf16x8*>(smem + wbase[kk] + cb + j * 2048);
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
-          const int p = ptap + i * C::HW;
-          const bf16x8 xf = *reinterpret_cast<const bf16x8*>(As + p * 128 + (xv_swz(p, slot) << 4));
+          const bf16x8 xf = *reinterpret_cast<const bf16x8*>(smem + abase[dx][kk] + (i + dy) * (C::HW * 128));
 #pragma unroll
           for (int j = 0; j < 4; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], xf, acc[i][j], 0, 0, 0);
         }
       }
-      if (more) {
-        b_store(cur ^ 1, breg);
+      if (tap + 1 < C::NTAPS) {
+        b_store((tap & 1) ^ 1, breg);
         __syncthreads();
       }
     }
-  }
 
-  // ---- epilogue: bias + relu, bf16, 8-byte NHWC stores (4 consecutive channels per lane) --------
-  const int px = x0 + wc * 16 + l15;
-  const int cbase = co0 + wn * 64 + lg * 4;
-  f32x4 bj[4];
+    if (last_chunk) {
+      // ---- epilogue: bias + relu, bf16, 8-byte NHWC stores (4 consecutive channels per lane) ------
+      const int px = cur.x0 + wc * 16 + l15;
+      const int cbase = cur.co0 + wn * 64 + lg * 4;
+      f32x4 bj[4];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) bj[j] = *reinterpret_cast<const f32x4*>(a.bias + cbase + j * 16);
+      for (int j = 0; j < 4; ++j) bj[j] = *reinterpret_cast<const f32x4*>(a.bias + cbase + j * 16);
 #pragma unroll
-  for (int i = 0; i < MT; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      f32x4 v = acc[i][j] + bj[j];
-      if (a.relu) {
-        v.x = fmaxf(v.x, 0.f);
-        v.y = fmaxf(v.y, 0.f);
-        v.z = fmaxf(v.z, 0.f);
-        v.w = fmaxf(v.w, 0.f);
-      }
-      acc[i][j] = v;
-    }
-  if (a.y != nullptr) {
-    __bf16* yimg = a.y + (int64_t)n * (H + 2) * Wp * Cout;
-#pragma unroll
-    for (int i = 0; i < MT; ++i) {
-      const int py = y0 + wr * MT + i;
-      if (py < H && px < W) {
-        __bf16* dst = yimg + ((int64_t)(py + 1) * Wp + (px + 1)) * Cout + cbase;
+      for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          const f32x4 v = acc[i][j];
-          *reinterpret_cast<u32x2*>(dst + j * 16) = u32x2{pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w)};
+          f32x4 v = acc[i][j] + bj[j];
+          if (a.relu) {
+            v.x = fmaxf(v.x, 0.f);
+            v.y = fmaxf(v.y, 0.f);
+            v.z = fmaxf(v.z, 0.f);
+            v.w = fmaxf(v.w, 0.f);
+          }
+          acc[i][j] = v;
+        }
+      if (a.y != nullptr) {
+        __bf16* yimg = a.y + (int64_t)cur.n * (H + 2) * Wp * Cout;
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+          const int py = cur.y0 + wr * MT + i;
+          if (py < H && px < W) {
+            __bf16* dst = yimg + ((int64_t)(py + 1) * Wp + (px + 1)) * Cout + cbase;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const f32x4 v = acc[i][j];
+              *reinterpret_cast<u32x2*>(dst + j * 16) = u32x2{pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w)};
+            }
+          }
         }
       }
-    }
-  }
-  if (a.pooled != nullptr) {
-    // fused max_pooling2d(2,2): rows (i, i+1) live in this lane, columns (px, px^1) in lanes l, l^1
-    const int Hq = H >> 1, Wq = W >> 1;
-    __bf16* qimg = a.pooled + (int64_t)n * (Hq + 2) * (Wq + 2) * Cout;
+      if (a.pooled != nullptr) {
+        // fused max_pooling2d(2,2): rows (i, i+1) live in this lane, columns (px, px^1) in lanes l, l^1
+        const int Hq = H >> 1, Wq = W >> 1;
+        __bf16* qimg = a.pooled + (int64_t)cur.n * (Hq + 2) * (Wq + 2) * Cout;
 #pragma unroll
-    for (int i = 0; i < MT; i += 2) {
-      const int py = y0 + wr * MT + i;
+        for (int i = 0; i < MT; i += 2) {
+          const int py = cur.y0 + wr * MT + i;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        f32x4 m;
-        m.x = fmaxf(acc[i][j].x, acc[i + 1][j].x);
-        m.y = fmaxf(acc[i][j].y, acc[i + 1][j].y);
-        m.z = fmaxf(acc[i][j].z, acc[i + 1][j].z);
-        m.w = fmaxf(acc[i][j].w, acc[i + 1][j].w);
-        m.x = fmaxf(m.x, __shfl_xor(m.x, 1));
-        m.y = fmaxf(m.y, __shfl_xor(m.y, 1));
-        m.z = fmaxf(m.z, __shfl_xor(m.z, 1));
-        m.w = fmaxf(m.w, __shfl_xor(m.w, 1));
-        if ((lane & 1) == 0 && py < H && px < W) {
-          __bf16* dst = qimg + ((int64_t)((py >> 1) + 1) * (Wq + 2) + ((px >> 1) + 1)) * Cout + cbase + j * 16;
-          *reinterpret_cast<u32x2*>(dst) = u32x2{pack_bf16x2(m.x, m.y), pack_bf16x2(m.z, m.w)};
+          for (int j = 0; j < 4; ++j) {
+            f32x4 m;
+            m.x = fmaxf(acc[i][j].x, acc[i + 1][j].x);
+            m.y = fmaxf(acc[i][j].y, acc[i + 1][j].y);
+            m.z = fmaxf(acc[i][j].z, acc[i + 1][j].z);
+            m.w = fmaxf(acc[i][j].w, acc[i + 1][j].w);
+            m.x = fmaxf(m.x, __shfl_xor(m.x, 1));
+            m.y = fmaxf(m.y, __shfl_xor(m.y, 1));
+            m.z = fmaxf(m.z, __shfl_xor(m.z, 1));
+            m.w = fmaxf(m.w, __shfl_xor(m.w, 1));
+            if ((lane & 1) == 0 && py < H && px < W) {
+              __bf16* dst = qimg + ((int64_t)((py >> 1) + 1) * (Wq + 2) + ((px >> 1) + 1)) * Cout + cbase + j * 16;
+              *reinterpret_cast<u32x2*>(dst) = u32x2{pack_bf16x2(m.x, m.y), pack_bf16x2(m.z, m.w)};
+            }
+          }
         }
       }
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
+    if (!has_next) break;
+    lid = nlid;
+    cur = nxt;
+    chunk = nchunk;
   }
 }
 
@@ -256,9 +314,16 @@ int launch_conv(const ConvArgs& a0, hipStream_t stream) {
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
-  const int64_t nblk = (int64_t)a.tiles_x * a.tiles_y * a.N * a.n_ct;
-  if (nblk <= 0 || nblk > 0x7fffffff) return XV_ESHAPE;
+  const int64_t ntiles = (int64_t)a.tiles_x * a.tiles_y * a.N * a.n_ct;
+  if (ntiles <= 0 || ntiles > 0x7fffffff) return XV_ESHAPE;
   if (a.pooled && (C::TH & 1)) return XV_ESHAPE;
+  a.n_tiles = (int)ntiles;
+  // resident workgroups: limited by LDS (160 KB / CU) and by the register bound OCC
+  constexpr int by_lds = (160 * 1024) / C::LDS_BYTES;
+  constexpr int by_reg = (OCC * 4 * 64) / C::NT > 0 ? (OCC * 4 * 64) / C::NT : 1;
+  constexpr int per_cu = by_lds < by_reg ? by_lds : by_reg;
+  const int64_t slots = (int64_t)a.num_cus * per_cu;
+  const int64_t nblk = ntiles < slots ? ntiles : slots;
   hipLaunchKernelGGL((conv_mfma_kernel<MT, WR, WC, NW, KS, OCC>), dim3((unsigned)nblk), dim3(C::NT), C::LDS_BYTES, stream, a);
   return xv_launch_status();
 }
@@ -317,27 +382,19 @@ int launch_cfg(int cfg, const ConvArgs& a, hipStream_t s) {
   }
 }
 
-// Default choice: fewest "rounds" of workgroups over the 256 CUs, ties to the larger tile.
+// Default choice, from tools/conv_tune.py on MI355X (profiles/conv_tune_r1.txt): the two
+// 64-channel, 4-rows-per-wave configurations (two 4-wave workgroups per CU, cross-item prefetch) win
+// on every SimpleFCN layer at 8-16 images; pick the one that wastes fewer pixels on partial tiles,
+// the wide 8x32 patch on ties for wide images.
 int pick_cfg(const ConvArgs& a) {
-  int best = -1;
-  double best_cost = 0;
-  for (int c = 0; c < 8; ++c) {
+  auto covered = [&](int c) {
     const Geo& g = kGeo[c];
-    if (a.Cout % g.bn) continue;
-    if (a.pooled && (g.th & 1)) continue;
-    const double blocks = (double)((a.H + g.th - 1) / g.th) * ((a.W + g.tw - 1) / g.tw) * a.N * (a.Cout / g.bn);
-    const double slots = 256.0 * g.per_cu;
-    const double rounds = __builtin_ceil(blocks / slots);
-    // time ~ rounds * work per workgroup * (co-resident workgroups share the CU's MFMA pipes)
-    double cost = rounds * (double)g.th * g.tw * g.bn * g.per_cu;
-    // halo + weight re-fetch overhead favours the larger tiles at equal rounds
-    cost *= 1.0 + 0.08 * (256.0 * 128.0) / ((double)g.th * g.tw * g.bn);
-    if (best < 0 || cost < best_cost) {
-      best = c;
-      best_cost = cost;
-    }
-  }
-  return best;
+    return (double)((a.H + g.th - 1) / g.th * g.th) * ((a.W + g.tw - 1) / g.tw * g.tw);
+  };
+  const double c4 = covered(4), c6 = covered(6);
+  if (c6 < c4) return 6;
+  if (c4 < c6) return 4;
+  return a.W >= 96 ? 6 : 4;
 }
 
 int conv_fwd_impl(const xv_act* x, const void* w_packed, const float* bias, const xv_act* y, const xv_act* pooled,
@@ -360,6 +417,7 @@ int conv_fwd_impl(const xv_act* x, const void* w_packed, const float* bias, cons
   a.Cin = x->c;
   a.Cout = y->c;
   a.relu = relu;
+  a.num_cus = xv_num_cus();
   if (pooled && pooled->data) {
     XV_CHECK_SHAPE(k == 3 && (x->h & 1) == 0 && (x->w & 1) == 0);
     XV_CHECK_SHAPE(pooled->n == x->n && pooled->h == x->h / 2 && pooled->w == x->w / 2 && pooled->c == y->c);

@@ -25,16 +25,33 @@ static inline int xv_launch_status() {
   return e == hipSuccess ? XV_OK : (int)e;
 }
 
+// CU count of the current device (cached; 256 on MI355X) -- sizes persistent grids.
+static inline int xv_num_cus() {
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) == hipSuccess &&
+        hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0)
+      cus = n;
+    else
+      cus = 256;
+  }
+  return cus;
+}
+
 // padded-NHWC geometry helpers
 __host__ __device__ static inline int64_t xv_row_pitch(int w, int c) { return (int64_t)(w + 2) * c; }
 __host__ __device__ static inline int64_t xv_img_pitch(int h, int w, int c) {
   return (int64_t)(h + 2) * (w + 2) * c;
 }
 
-// 16-byte-slot swizzle shared by the weight packer and the conv kernels: slot s of 128-byte row
-// `row` lives at slot s ^ ((row >> 1) & 7).  With 128-B rows two consecutive rows fill one 256-B
-// LDS bank row, so 16 lanes reading the same logical slot of 16 consecutive rows touch 16
-// distinct slots (conflict-free ds_read_b128).
+// 16-byte-slot swizzle shared by the weight packer and the conv kernels: slot s of the 128-byte
+// LDS row of weight row / patch column `row` lives at slot s ^ ((row >> 1) & 7).  Two consecutive
+// 128-B rows fill one 256-B LDS bank row, so 16 lanes reading the same logical slot of 16
+// consecutive rows touch 16 distinct slots (conflict-free ds_read_b128).  For activation patches
+// `row` is the pixel's COLUMN inside the patch (the patch pitch is even, so parity is preserved),
+// which makes the swizzle independent of the patch row and lets every fragment read be
+// base-register + immediate.
 __host__ __device__ static inline int xv_swz(int row, int slot) { return slot ^ ((row >> 1) & 7); }
 
 __device__ static inline uint32_t pack_bf16x2(float lo, float hi) {

@@ -7,7 +7,7 @@ from scipy.special import gammaln
 
 from . import ops
 from .base_model import BaseModel, iterate_batches
-from .basic_fusion_model import test_pipeline
+from .basic_fusion_model import run_experts, test_pipeline  # noqa: F401
 from .dirichlet_fit import find_dirichlet_priors
 from .fcn import FcnEngine, init_variables
 
@@ -105,10 +105,8 @@ class DirichletFusion(BaseModel):
     def _predict_batch(self, batch, output_attr=None):
         if not hasattr(self, 'am1'):
             raise UserWarning('ERROR: DirichletFusion has no measurements yet, call fit() first')
-        probs = []
-        for m in self.modalities:
-            x = self._to_device(batch[m], torch.float32)
-            probs.append(test_pipeline(self.experts[m], x, want=('prob',))['prob'])
+        outs = run_experts(self, batch, ('prob',))
+        probs = [outs[m]['prob'] for m in self.modalities]
         self.probs = dict(zip(self.modalities, probs))
         want_score = output_attr in ('fused_score', 'score')
         fused, score = ops.dirichlet_fuse(probs, self.am1, self.lognorm, self.logprior, want_score=want_score)
@@ -124,10 +122,9 @@ class DirichletFusion(BaseModel):
         scratch = torch.zeros(C, dtype=torch.int64, device=self.device)
         for batch in iterate_batches(data, self.config['batchsize']):
             labels = self._to_device(batch['labels'], torch.int32)
+            outs = run_experts(self, batch, ('prob',))
             for i, m in enumerate(self.modalities):
-                x = self._to_device(batch[m], torch.float32)
-                prob = test_pipeline(self.experts[m], x, want=('prob',))['prob']
-                ops.dirichlet_suffstats(prob, labels, S[m], counts if i == 0 else scratch)
+                ops.dirichlet_suffstats(outs[m]['prob'], labels, S[m], counts if i == 0 else scratch)
         return self._allreduce_statistics({m: S[m] for m in self.modalities}, counts)
 
     def _allreduce_statistics(self, S, counts):

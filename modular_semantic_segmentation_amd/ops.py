@@ -86,7 +86,7 @@ def conv2d_fwd(x, w_packed, bias, k, relu=True, y=None, pooled=None, write_y=Tru
     _lib.check(rc, 'xv_conv2d_fwd')
     if prof is not None:
         ev1.record()
-        prof.append(('k%d_cout%s' % (k, '128' if cout % 128 == 0 else '64'),
+        prof.append(('k%d' % k,
                      2.0 * x.n * x.h * x.w * x.c * cout * k * k, ev0, ev1))
     return y, pooled
 
