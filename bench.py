@@ -167,13 +167,20 @@ def main():
         d[2] += 1
     dom = 'k3'
     roofline = None
+    traffic = None
+    tfiles = sorted(f for f in os.listdir(os.path.join(ROOT, 'profiles')) if f.endswith('_conv_traffic.json')) \
+        if os.path.isdir(os.path.join(ROOT, 'profiles')) else []
+    if tfiles and args.batch == 8 and (args.height, args.width) == (384, 768):
+        # HBM bytes per conv launch from the committed rocprofv3 FETCH_SIZE / WRITE_SIZE passes of this
+        # same command (tools/pmc_summary.py); PMC counters cannot be read from inside the process
+        traffic = json.load(open(os.path.join(ROOT, 'profiles', tfiles[-1]))).get('hbm_bytes_per_launch')
     if dom in kinds and kinds[dom][1] > 0:
         fl, sec, cnt = kinds[dom]
         achieved = fl / sec / 1e12
         roofline = {'bound': 'mfma', 'kernel': 'conv_mfma_kernel (3x3 implicit GEMM, all tile configurations)',
                     'achieved': round(achieved, 2),
                     'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(achieved / PEAK_BF16_TFLOPS, 4),
-                    'traffic': None, 'launches': cnt, 'avg_launch_ms': round(sec / cnt * 1e3, 4),
+                    'traffic': traffic, 'launches': cnt, 'avg_launch_ms': round(sec / cnt * 1e3, 4),
                     'gflop_per_launch': round(fl / cnt / 1e9, 2),
                     'measured': 'HIP events per launch, experts serialised on one stream (%.3f ms/step)'
                                 % (dt_serial / args.steps * 1e3)}

@@ -165,6 +165,10 @@ class BaseModel(object):
         cm_dev = torch.zeros((C, C), dtype=torch.int64, device=self.device)
         for batch in iterate_batches(data, self.config['batchsize'], max_iterations):
             self._confusion_of_batch(batch, cm_dev)
+        if self.config.get('reduce_score_over_ranks', False):
+            # one process per GPU, each scored its own shard: sum the [C,C] counts (RCCL all-reduce)
+            from .parallel import allreduce_sum_
+            allreduce_sum_(cm_dev)
         confusion_matrix = cm_dev.cpu().numpy().astype(np.float64)
         return score_measures(confusion_matrix), confusion_matrix
 

@@ -5,21 +5,17 @@
 namespace {
 
 // ---- conv1_1: relu(conv3x3(x) + b) on the raw fp32 input, fp32 math, bf16 padded-NHWC out -------
-// simple_fcn.py:39.  One thread = one pixel x 64 output channels; the 9*CIN x 64 fp32 weight
-// matrix sits in LDS and is read with wave-uniform (broadcast) ds_read_b128.
+// simple_fcn.py:39.  One thread = one pixel x 64 output channels.  The 9*CIN x 64 fp32 weight
+// matrix is read through wave-uniform addresses (scalar loads into SGPRs), so the inner loop is
+// pure v_fmac with one SGPR operand: VALU-bound, no LDS traffic.
 template <int CIN>
 __global__ __launch_bounds__(256) void conv_first_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                         const float* __restrict__ b, __bf16* __restrict__ y, int N,
                                                         int H, int W, int relu) {
   constexpr int K = 9 * CIN;
-  __shared__ __attribute__((aligned(16))) float ws[K * 64];
-  __shared__ __attribute__((aligned(16))) float bs[64];
-  for (int i = threadIdx.x; i < K * 64; i += 256) ws[i] = w[i];
-  if (threadIdx.x < 64) bs[threadIdx.x] = b[threadIdx.x];
-  __syncthreads();
   const int64_t npix = (int64_t)N * H * W;
-  const int64_t pix = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (pix >= npix) return;
+  int64_t pix = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  pix = pix < npix ? pix : npix - 1;  // tail lanes recompute the last pixel; only in-range pixels are stored
   const int px = (int)(pix % W);
   const int py = (int)((pix / W) % H);
   const int n = (int)(pix / ((int64_t)W * H));
@@ -34,24 +30,46 @@ __global__ __launch_bounds__(256) void conv_first_kernel(const float* __restrict
 #pragma unroll
       for (int c = 0; c < CIN; ++c) in[(dy * 3 + dx) * CIN + c] = ok ? src[c] : 0.f;
     }
-  __bf16* dst = y + (((int64_t)n * (H + 2) + (py + 1)) * (W + 2) + (px + 1)) * 64;
-#pragma unroll 1
-  for (int g = 0; g < 8; ++g) {
-    f32x4 a0 = *reinterpret_cast<const f32x4*>(bs + g * 8);
-    f32x4 a1 = *reinterpret_cast<const f32x4*>(bs + g * 8 + 4);
+  // results go through LDS so that every store instruction writes whole 128-byte pixel rows
+  // (8 lanes x 16 B per pixel, 8 pixels per instruction) instead of 64 scattered 16-byte pieces
+  __shared__ __attribute__((aligned(16))) u32x4 stage[256 * 8];
+  u32x4* mine = stage + threadIdx.x * 8;
 #pragma unroll
-    for (int t = 0; t < K; ++t) {
-      const f32x4 w0 = *reinterpret_cast<const f32x4*>(ws + t * 64 + g * 8);
-      const f32x4 w1 = *reinterpret_cast<const f32x4*>(ws + t * 64 + g * 8 + 4);
-      a0 += in[t] * w0;
-      a1 += in[t] * w1;
-    }
+  for (int g = 0; g < 4; ++g) {  // 16 output channels at a time (accumulators in VGPRs, weights in SGPRs)
+    float acc[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) acc[c] = b[g * 16 + c];
+#pragma unroll
+    for (int t = 0; t < K; ++t)
+#pragma unroll
+      for (int c = 0; c < 16; ++c) acc[c] = fmaf(in[t], w[t * 64 + g * 16 + c], acc[c]);
     if (relu) {
-      a0.x = fmaxf(a0.x, 0.f); a0.y = fmaxf(a0.y, 0.f); a0.z = fmaxf(a0.z, 0.f); a0.w = fmaxf(a0.w, 0.f);
-      a1.x = fmaxf(a1.x, 0.f); a1.y = fmaxf(a1.y, 0.f); a1.z = fmaxf(a1.z, 0.f); a1.w = fmaxf(a1.w, 0.f);
+#pragma unroll
+      for (int c = 0; c < 16; ++c) acc[c] = fmaxf(acc[c], 0.f);
     }
-    *reinterpret_cast<u32x4*>(dst + g * 8) =
-        u32x4{pack_bf16x2(a0.x, a0.y), pack_bf16x2(a0.z, a0.w), pack_bf16x2(a1.x, a1.y), pack_bf16x2(a1.z, a1.w)};
+    // slot swizzle (slot ^ pixel) keeps the 16-byte LDS writes of 8 consecutive lanes on distinct banks
+    mine[(2 * g) ^ (threadIdx.x & 7)] = u32x4{pack_bf16x2(acc[0], acc[1]), pack_bf16x2(acc[2], acc[3]),
+                                              pack_bf16x2(acc[4], acc[5]), pack_bf16x2(acc[6], acc[7])};
+    mine[(2 * g + 1) ^ (threadIdx.x & 7)] = u32x4{pack_bf16x2(acc[8], acc[9]), pack_bf16x2(acc[10], acc[11]),
+                                                  pack_bf16x2(acc[12], acc[13]), pack_bf16x2(acc[14], acc[15])};
+  }
+  // each wave stores its own 64 pixels: no block barrier needed (the wave's LDS region is private)
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  const int lane = threadIdx.x & 63;
+  const int wbase = threadIdx.x & ~63;
+#pragma unroll
+  for (int it = 0; it < 8; ++it) {
+    const int lp = it * 8 + (lane >> 3);  // pixel within the wave
+    const int slot = lane & 7;
+    const int64_t gp = (int64_t)blockIdx.x * 256 + wbase + lp;
+    if (gp < npix) {
+      const int qx = (int)(gp % W);
+      const int qy = (int)((gp / W) % H);
+      const int qn = (int)(gp / ((int64_t)W * H));
+      const u32x4 v = stage[(wbase + lp) * 8 + (slot ^ (lp & 7))];
+      *reinterpret_cast<u32x4*>(y + (((int64_t)qn * (H + 2) + (qy + 1)) * (W + 2) + (qx + 1)) * 64 + slot * 8) = v;
+    }
   }
 }
 
@@ -149,98 +167,125 @@ __global__ __launch_bounds__(256) void upsample2x_kernel(const __bf16* __restric
   }
 }
 
-// ---- decoder head: bilinear x8 + relu + 1x1 score + softmax + argmax, one thread per pixel ------
-// simple_fcn.py:129-133 + basic_fusion_model.py:21-22.  CMAX = padded class count (static register
-// indexing); Ws is staged in LDS as [U][CMAX] and read with wave-uniform addresses.
-template <int CMAX>
+// ---- decoder head: bilinear x8 + relu + 1x1 score + softmax + argmax ----------------------------
+// simple_fcn.py:129-133 + basic_fusion_model.py:21-22.  One thread = 4 horizontally consecutive
+// output pixels (aligned to 4): they share the same 2x2 source pixels, so the bf16 unpack and the
+// vertical interpolation are done once per 4 outputs.  CM = class count rounded up to 4 (static
+// register indexing).  The U x C score weights are read through wave-uniform addresses (scalar
+// loads -> SGPR operands of the FMAs), CM floats per channel row; a row's read overlaps the next
+// row's first CM-C weights (multiplied into ignored accumulators), and the rows whose CM-wide read
+// would leave the array take an index-clamped path.
+template <int CM, bool CLAMP>
+__device__ inline void head_group(const u32x4& a00, const u32x4& a01, const u32x4& a10, const u32x4& a11, float wy0,
+                                  float wy1, const float (&wx0)[4], const float (&wx1)[4],
+                                  const float* __restrict__ wrow, int C, int remain, float (&sc)[4][CM]) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int sh = (i & 1) * 16, q = i >> 1;
+    const float f00 = bf16_bits_to_f32((a00[q] >> sh) & 0xffffu), f01 = bf16_bits_to_f32((a01[q] >> sh) & 0xffffu);
+    const float f10 = bf16_bits_to_f32((a10[q] >> sh) & 0xffffu), f11 = bf16_bits_to_f32((a11[q] >> sh) & 0xffffu);
+    const float v0 = f00 * wy0 + f10 * wy1;  // source column ix0
+    const float v1 = f01 * wy0 + f11 * wy1;  // source column ix1
+    float up[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) up[j] = fmaxf(v0 * wx0[j] + v1 * wx1[j], 0.f);
+    if (CLAMP && i * C + CM > remain) {  // wave-uniform
+#pragma unroll
+      for (int k = 0; k < CM; ++k) {
+        int off = i * C + k;
+        off = off < remain ? off : remain - 1;
+        const float wv = wrow[off];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) sc[j][k] = fmaf(up[j], wv, sc[j][k]);
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < CM; ++k) {
+        const float wv = wrow[i * C + k];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) sc[j][k] = fmaf(up[j], wv, sc[j][k]);
+      }
+    }
+  }
+}
+
+template <int CM>
 __global__ __launch_bounds__(256) void decoder_head_kernel(const __bf16* __restrict__ f, const float* __restrict__ ws_g,
                                                           const float* __restrict__ bs_g, int N, int Hi, int Wi, int U,
                                                           int C, float* __restrict__ score, float* __restrict__ prob,
                                                           int64_t* __restrict__ label) {
-  extern __shared__ __attribute__((aligned(16))) float wsm[];  // [U][CMAX] then [CMAX] bias
-  float* bsm = wsm + U * CMAX;
-  for (int i = threadIdx.x; i < U * CMAX; i += 256) {
-    const int u = i / CMAX, k = i - u * CMAX;
-    wsm[i] = k < C ? ws_g[u * C + k] : 0.f;
-  }
-  if (threadIdx.x < CMAX) bsm[threadIdx.x] = threadIdx.x < C ? bs_g[threadIdx.x] : 0.f;
-  __syncthreads();
   const int Ho = Hi * 8, Wo = Wi * 8;
-  // block = 32 x 8 output pixels so a wave covers 2 rows x 32 columns (few distinct source pixels)
-  const int tilesx = (Wo + 31) / 32;
+  // block = 128 x 8 output pixels: a wave covers 2 rows x 128 columns
+  const int tilesx = (Wo + 127) / 128;
   const int tx = blockIdx.x % tilesx;
   int r = blockIdx.x / tilesx;
-  const int tilesy = (Ho + 7) / 8;
+  const int tilesy = Hi;  // Ho / 8
   const int ty = r % tilesy;
   const int n = r / tilesy;
-  const int ox = tx * 32 + (threadIdx.x & 31), oy = ty * 8 + (threadIdx.x >> 5);
-  if (ox >= Wo || oy >= Ho) return;
+  const int ox = tx * 128 + (threadIdx.x & 31) * 4, oy = ty * 8 + (threadIdx.x >> 5);
+  if (ox >= Wo) return;
   int iy1, ix1;
-  float wy1, wy0, wx1, wx0;
+  float wy1, wy0, wx1[4], wx0[4];
   bilinear_taps<8>(oy, iy1, wy1, wy0);
-  bilinear_taps<8>(ox, ix1, wx1, wx0);
-  const float w00 = wy0 * wx0, w01 = wy0 * wx1, w10 = wy1 * wx0, w11 = wy1 * wx1;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) bilinear_taps<8>(ox + j, ix1, wx1[j], wx0[j]);  // same ix1 for the 4 aligned pixels
   const __bf16* p00 = f + (((int64_t)n * (Hi + 2) + iy1) * (Wi + 2) + ix1) * U;
   const int64_t rowp = (int64_t)(Wi + 2) * U;
-  float sc[CMAX];
+  float sc[4][CM];
 #pragma unroll
-  for (int k = 0; k < CMAX; ++k) sc[k] = 0.f;
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int k = 0; k < CM; ++k) sc[j][k] = 0.f;
   for (int u0 = 0; u0 < U; u0 += 8) {
     const u32x4 a00 = *reinterpret_cast<const u32x4*>(p00 + u0), a01 = *reinterpret_cast<const u32x4*>(p00 + U + u0);
     const u32x4 a10 = *reinterpret_cast<const u32x4*>(p00 + rowp + u0),
                 a11 = *reinterpret_cast<const u32x4*>(p00 + rowp + U + u0);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int sh = (i & 1) * 16, q = i >> 1;
-      const float f00 = bf16_bits_to_f32((a00[q] >> sh) & 0xffffu), f01 = bf16_bits_to_f32((a01[q] >> sh) & 0xffffu);
-      const float f10 = bf16_bits_to_f32((a10[q] >> sh) & 0xffffu), f11 = bf16_bits_to_f32((a11[q] >> sh) & 0xffffu);
-      float up = f00 * w00 + f01 * w01 + f10 * w10 + f11 * w11;
-      up = fmaxf(up, 0.f);
-      const float* wrow = wsm + (u0 + i) * CMAX;
-#pragma unroll
-      for (int k4 = 0; k4 < CMAX; k4 += 4) {
-        const f32x4 wv = *reinterpret_cast<const f32x4*>(wrow + k4);
-        sc[k4] += up * wv.x;
-        sc[k4 + 1] += up * wv.y;
-        sc[k4 + 2] += up * wv.z;
-        sc[k4 + 3] += up * wv.w;
-      }
-    }
+    const float* wrow = ws_g + u0 * C;
+    if (u0 + 16 <= U)
+      head_group<CM, false>(a00, a01, a10, a11, wy0, wy1, wx0, wx1, wrow, C, 0, sc);
+    else
+      head_group<CM, true>(a00, a01, a10, a11, wy0, wy1, wx0, wx1, wrow, C, (U - u0) * C, sc);
   }
-#pragma unroll
-  for (int k = 0; k < CMAX; ++k) sc[k] += bsm[k];
   const int64_t opix = ((int64_t)n * Ho + oy) * Wo + ox;
-  if (score) {
+  int64_t lab[4];
 #pragma unroll
-    for (int k = 0; k < CMAX; ++k)
-      if (k < C) score[opix * C + k] = sc[k];
-  }
-  if (prob || label) {
-    float m = sc[0];
+  for (int j = 0; j < 4; ++j) {
 #pragma unroll
-    for (int k = 1; k < CMAX; ++k)
-      if (k < C) m = fmaxf(m, sc[k]);
-    float e[CMAX];
+    for (int k = 0; k < CM; ++k) sc[j][k] += bs_g[k < C ? k : C - 1];
+    if (score) {
+#pragma unroll
+      for (int k = 0; k < CM; ++k)
+        if (k < C) score[(opix + j) * C + k] = sc[j][k];
+    }
+    float m = sc[j][0];
+#pragma unroll
+    for (int k = 1; k < CM; ++k)
+      if (k < C) m = fmaxf(m, sc[j][k]);
     float sum = 0.f;
 #pragma unroll
-    for (int k = 0; k < CMAX; ++k) {
-      e[k] = k < C ? expf(sc[k] - m) : 0.f;
-      sum += e[k];
+    for (int k = 0; k < CM; ++k) {
+      sc[j][k] = k < C ? expf(sc[j][k] - m) : 0.f;
+      sum += sc[j][k];
     }
     float best = -1.f;
     int bi = 0;
 #pragma unroll
-    for (int k = 0; k < CMAX; ++k) {
-      const float p = e[k] / sum;
+    for (int k = 0; k < CM; ++k) {
+      const float p = sc[j][k] / sum;
       if (k < C) {
-        if (prob) prob[opix * C + k] = p;
+        if (prob) prob[(opix + j) * C + k] = p;
         if (p > best) {
           best = p;
           bi = k;
         }
       }
     }
-    if (label) label[opix] = bi;
+    lab[j] = bi;
+  }
+  if (label) {
+    typedef __attribute__((ext_vector_type(2))) int64_t i64x2;
+    *reinterpret_cast<i64x2*>(label + opix) = i64x2{lab[0], lab[1]};
+    *reinterpret_cast<i64x2*>(label + opix + 2) = i64x2{lab[2], lab[3]};
   }
 }
 
@@ -336,20 +381,25 @@ extern "C" int xv_decoder_head_fwd(const xv_act* fused, const float* w_score, co
   XV_CHECK_ARG(score || prob || label);
   XV_CHECK_SHAPE(fused->n > 0 && fused->h > 0 && fused->w > 0);
   XV_CHECK_SHAPE(fused->c > 0 && (fused->c & 7) == 0 && fused->c <= 128 && num_classes >= 1 && num_classes <= 32);
-  const int Ho = fused->h * 8, Wo = fused->w * 8;
-  const int64_t nblk = (int64_t)((Wo + 31) / 32) * ((Ho + 7) / 8) * fused->n;
+  const int Wo = fused->w * 8;
+  const int64_t nblk = (int64_t)((Wo + 127) / 128) * fused->h * fused->n;
   XV_CHECK_SHAPE(nblk <= 0x7fffffff);
   hipStream_t s = (hipStream_t)stream;
   const __bf16* f = (const __bf16*)fused->data;
-  if (num_classes <= 16) {
-    const size_t lds = (size_t)(fused->c * 16 + 16) * 4;
-    hipLaunchKernelGGL(decoder_head_kernel<16>, dim3((unsigned)nblk), dim3(256), lds, s, f, w_score, b_score, fused->n,
-                       fused->h, fused->w, fused->c, num_classes, score, prob, label);
-  } else {
-    const size_t lds = (size_t)(fused->c * 32 + 32) * 4;
-    hipLaunchKernelGGL(decoder_head_kernel<32>, dim3((unsigned)nblk), dim3(256), lds, s, f, w_score, b_score, fused->n,
-                       fused->h, fused->w, fused->c, num_classes, score, prob, label);
+#define XV_HEAD(CMV)                                                                                          \
+  hipLaunchKernelGGL(decoder_head_kernel<CMV>, dim3((unsigned)nblk), dim3(256), 0, s, f, w_score, b_score, \
+                     fused->n, fused->h, fused->w, fused->c, num_classes, score, prob, label)
+  switch ((num_classes + 3) / 4) {
+    case 1: XV_HEAD(4); break;
+    case 2: XV_HEAD(8); break;
+    case 3: XV_HEAD(12); break;
+    case 4: XV_HEAD(16); break;
+    case 5: XV_HEAD(20); break;
+    case 6: XV_HEAD(24); break;
+    case 7: XV_HEAD(28); break;
+    default: XV_HEAD(32); break;
   }
+#undef XV_HEAD
   return xv_launch_status();
 }
 

@@ -130,11 +130,8 @@ class DirichletFusion(BaseModel):
     def _allreduce_statistics(self, S, counts):
         """Sum the per-rank statistics when running one process per GPU (each rank measured its
         shard of the data): one tiny all-reduce per tensor, RCCL over xGMI."""
-        import torch.distributed as dist
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-            for m in S:
-                dist.all_reduce(S[m])
-            dist.all_reduce(counts)
+        from .parallel import allreduce_sum_
+        allreduce_sum_(counts, *[S[m] for m in S])
         return {m: S[m].cpu().numpy() for m in S}, counts.cpu().numpy()
 
     def _fit_sufficient_statistic(self, counts, class_counts):
