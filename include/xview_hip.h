@@ -47,7 +47,7 @@ const char* xv_arch(void);
  * Conv kernels arrive in the reference npz schema: float32 HWIO [k][k][cin][cout]
  * (base_model.py:361-393 export_weights; tf.layers.conv2d kernel layout).  The MFMA kernels read
  * them as bf16 [tap][cin/64][cout][64 swizzled], 128 B per (tap, cin-chunk, cout) row with
- * 16-byte slot s of row `co` stored at slot s ^ ((co>>1)&7) (so a weight tile is a linear copy
+ * 16-byte slot s of row `co` stored at slot s ^ (co & 6) (so a weight tile is a linear copy
  * into bank-conflict-free LDS).  k = 1 or 3, cin % 64 == 0, cout % 64 == 0.                       */
 size_t xv_packed_weight_bytes(int k, int cin, int cout);
 int xv_pack_conv_weights(const float* w_hwio, void* packed, int k, int cin, int cout, void* stream);

@@ -30,8 +30,9 @@ struct ConvArgs {
   int num_cus;
 };
 
-template <int MT, int WR, int WC, int NW, int KS>
+template <int MT, int WR, int WC, int NW, int KS, int TPS_ = 1>
 struct ConvCfg {
+  static constexpr int TPS = (KS == 3) ? TPS_ : 1;  // taps per barrier stage
   static constexpr int NT = 64 * WR * WC * NW;
   static constexpr int TH = MT * WR, TW = 16 * WC;
   static constexpr int HALO = (KS == 3) ? 1 : 0;
@@ -41,7 +42,8 @@ struct ConvCfg {
   static constexpr int A_BYTES = ((NPIX * 128 + 255) / 256) * 256;
   static constexpr int B_BYTES = BN * 128;
   static constexpr int NTAPS = KS * KS;
-  static constexpr int LDS_BYTES = A_BYTES + 2 * B_BYTES;
+  static constexpr int NST = (NTAPS + TPS - 1) / TPS;  // stages per input chunk
+  static constexpr int LDS_BYTES = A_BYTES + 2 * TPS * B_BYTES;
   static constexpr int A_ITERS = (NPIX * 8 + NT - 1) / NT;
   static constexpr int B_ITERS = B_BYTES / 16 / NT;
   static_assert(B_BYTES % (16 * NT) == 0, "weight tile must split evenly over the threads");
@@ -57,9 +59,9 @@ struct ConvCfg {
 // first weight tile are already in flight to registers -- across chunk AND tile boundaries.
 // All LDS fragment reads use a per-lane base register + compile-time immediate offset (taps are
 // fully unrolled), so the inner loop issues no address arithmetic.
-template <int MT, int WR, int WC, int NW, int KS, int OCC>
+template <int MT, int WR, int WC, int NW, int KS, int OCC, int TPS>
 __global__ __launch_bounds__(64 * WR * WC * NW, OCC * 4 / (WR * WC * NW) > 0 ? OCC * 4 / (WR * WC * NW) : 1) void conv_mfma_kernel(ConvArgs a) {
-  using C = ConvCfg<MT, WR, WC, NW, KS>;
+  using C = ConvCfg<MT, WR, WC, NW, KS, TPS>;
   constexpr bool PFA = (MT == 4) || (OCC == 1);
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const As = smem;
@@ -104,7 +106,7 @@ __global__ __launch_bounds__(64 * WR * WC * NW, OCC * 4 / (WR * WC * NW) > 0 ? O
   };
 
   // ---- per-lane LDS fragment bases (16-byte slot s of pixel column hx / weight row n lives at
-  //      slot s ^ ((hx or n) >> 1 & 7): conflict-free ds_read_b128 for 16 consecutive columns) ----
+  //      slot s ^ ((hx or n) & 6): conflict-free ds_read_b128 for 16 consecutive columns) ----
   int abase[KS][2];
 #pragma unroll
   for (int dx = 0; dx < KS; ++dx)
@@ -143,15 +145,29 @@ __global__ __launch_bounds__(64 * WR * WC * NW, OCC * 4 / (WR * WC * NW) > 0 ? O
       if (idx < C::NPIX * 8) *reinterpret_cast<u32x4*>(As + p * 128 + (xv_swz(hx, s) << 4)) = v[it - IT0];
     }
   };
-  auto b_load = [&](int co0, int tap, int chunk, u32x4(&v)[C::B_ITERS]) {
-    const char* src = reinterpret_cast<const char*>(a.wpk) + (((int64_t)(tap * nchunks + chunk) * Cout + co0) << 7);
+  // a stage = C::TPS consecutive taps sharing one barrier; its weight tiles sit back to back in LDS
+  auto b_load = [&](int co0, int stage, int chunk, u32x4(&v)[C::TPS * C::B_ITERS]) {
 #pragma unroll
-    for (int it = 0; it < C::B_ITERS; ++it) v[it] = *reinterpret_cast<const u32x4*>(src + ((tid + it * C::NT) << 4));
+    for (int tt = 0; tt < C::TPS; ++tt) {
+      const int tap = stage * C::TPS + tt;
+      if (tap < C::NTAPS) {
+        const char* src =
+            reinterpret_cast<const char*>(a.wpk) + (((int64_t)(tap * nchunks + chunk) * Cout + co0) << 7);
+#pragma unroll
+        for (int it = 0; it < C::B_ITERS; ++it)
+          v[tt * C::B_ITERS + it] = *reinterpret_cast<const u32x4*>(src + ((tid + it * C::NT) << 4));
+      }
+    }
   };
-  auto b_store = [&](int buf, const u32x4(&v)[C::B_ITERS]) {
-    char* dst = Bs + buf * C::B_BYTES;
+  auto b_store = [&](int buf, int stage, const u32x4(&v)[C::TPS * C::B_ITERS]) {
+    char* dst = Bs + buf * (C::TPS * C::B_BYTES);
 #pragma unroll
-    for (int it = 0; it < C::B_ITERS; ++it) *reinterpret_cast<u32x4*>(dst + ((tid + it * C::NT) << 4)) = v[it];
+    for (int tt = 0; tt < C::TPS; ++tt)
+      if (stage * C::TPS + tt < C::NTAPS) {
+#pragma unroll
+        for (int it = 0; it < C::B_ITERS; ++it)
+          *reinterpret_cast<u32x4*>(dst + tt * C::B_BYTES + ((tid + it * C::NT) << 4)) = v[tt * C::B_ITERS + it];
+      }
   };
 
   int lid = t_begin + bi;
@@ -166,7 +182,7 @@ __global__ __launch_bounds__(64 * WR * WC * NW, OCC * 4 / (WR * WC * NW) > 0 ? O
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   u32x4 areg[PFA ? C::A_ITERS : 1];
-  u32x4 breg[C::B_ITERS];
+  u32x4 breg[C::TPS * C::B_ITERS];
   constexpr std::integral_constant<int, 0> I0{};
   constexpr std::integral_constant<int, (C::A_ITERS + 1) / 2> IH{};
   constexpr std::integral_constant<int, C::A_ITERS> IN{};
@@ -187,7 +203,7 @@ __global__ __launch_bounds__(64 * WR * WC * NW, OCC * 4 / (WR * WC * NW) > 0 ? O
       a_load(cur, chunk, atmp, IH, IN);
       a_store(atmp, IH, IN);
     }
-    b_store(0, breg);
+    b_store(0, 0, breg);
     __syncthreads();
 
     // the work item after this one: next chunk of this tile, else chunk 0 of this workgroup's next tile
@@ -198,32 +214,38 @@ __global__ __launch_bounds__(64 * WR * WC * NW, OCC * 4 / (WR * WC * NW) > 0 ? O
     const int nchunk = last_chunk ? 0 : chunk + 1;
 
 #pragma unroll
-    for (int tap = 0; tap < C::NTAPS; ++tap) {
-      constexpr int kB = C::B_BYTES;
-      const int cb = (tap & 1) * kB;
-      if (tap + 1 < C::NTAPS) {
-        b_load(cur.co0, tap + 1, chunk, breg);
+    for (int st = 0; st < C::NST; ++st) {
+      const int cb = (st & 1) * (C::TPS * C::B_BYTES);
+      if (st + 1 < C::NST) {
+        b_load(cur.co0, st + 1, chunk, breg);
       } else if (has_next) {
         if constexpr (PFA) a_load(nxt, nchunk, areg, I0, IN);
         b_load(nxt.co0, 0, nchunk, breg);
       }
-      const int dy = (KS == 3) ? tap / 3 : 0;
-      const int dx = (KS == 3) ? tap % 3 : 0;
 #pragma unroll
-      for (int kk = 0; kk < 2; ++kk) {
-        bf16x8 wf[4];
+      for (int tt = 0; tt < C::TPS; ++tt) {
+        const int tap = st * C::TPS + tt;
+        if (tap < C::NTAPS) {
+          const int dy = (KS == 3) ? tap / 3 : 0;
+          const int dx = (KS == 3) ? tap % 3 : 0;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) wf[j] = *reinterpret_cast<const bf16x8*>(smem + wbase[kk] + cb + j * 2048);
+          for (int kk = 0; kk < 2; ++kk) {
+            bf16x8 wf[4];
 #pragma unroll
-        for (int i = 0; i < MT; ++i) {
-          const bf16x8 xf = *reinterpret_cast<const bf16x8*>(smem + abase[dx][kk] + (i + dy) * (C::HW * 128));
+            for (int j = 0; j < 4; ++j)
+              wf[j] = *reinterpret_cast<const bf16x8*>(smem + wbase[kk] + cb + tt * C::B_BYTES + j * 2048);
 #pragma unroll
-          for (int j = 0; j < 4; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], xf, acc[i][j], 0, 0, 0);
+            for (int i = 0; i < MT; ++i) {
+              const bf16x8 xf = *reinterpret_cast<const bf16x8*>(smem + abase[dx][kk] + (i + dy) * (C::HW * 128));
+#pragma unroll
+              for (int j = 0; j < 4; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], xf, acc[i][j], 0, 0, 0);
+            }
+          }
         }
       }
-      if (tap + 1 < C::NTAPS) {
-        b_store((tap & 1) ^ 1, breg);
+      if (st + 1 < C::NST) {
+        b_store((st & 1) ^ 1, st + 1, breg);
         __syncthreads();
       }
     }
@@ -300,16 +322,16 @@ __global__ __launch_bounds__(64 * WR * WC * NW, OCC * 4 / (WR * WC * NW) > 0 ? O
   }
 }
 
-template <int MT, int WR, int WC, int NW, int KS, int OCC>
+template <int MT, int WR, int WC, int NW, int KS, int OCC, int TPS = 1>
 int launch_conv(const ConvArgs& a0, hipStream_t stream) {
-  using C = ConvCfg<MT, WR, WC, NW, KS>;
+  using C = ConvCfg<MT, WR, WC, NW, KS, TPS>;
   ConvArgs a = a0;
   a.tiles_x = (a.W + C::TW - 1) / C::TW;
   a.tiles_y = (a.H + C::TH - 1) / C::TH;
   a.n_ct = a.Cout / C::BN;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_kernel<MT, WR, WC, NW, KS, OCC>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_kernel<MT, WR, WC, NW, KS, OCC, TPS>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
     if (e != hipSuccess) return (int)e;
     attr_set = true;
@@ -324,7 +346,7 @@ int launch_conv(const ConvArgs& a0, hipStream_t stream) {
   constexpr int per_cu = by_lds < by_reg ? by_lds : by_reg;
   const int64_t slots = (int64_t)a.num_cus * per_cu;
   const int64_t nblk = ntiles < slots ? ntiles : slots;
-  hipLaunchKernelGGL((conv_mfma_kernel<MT, WR, WC, NW, KS, OCC>), dim3((unsigned)nblk), dim3(C::NT), C::LDS_BYTES, stream, a);
+  hipLaunchKernelGGL((conv_mfma_kernel<MT, WR, WC, NW, KS, OCC, TPS>), dim3((unsigned)nblk), dim3(C::NT), C::LDS_BYTES, stream, a);
   return xv_launch_status();
 }
 
@@ -356,13 +378,17 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, __bf16* __restr
 //   4: 16x16 x  64, 4 waves, 57 KB, 2/CU          5: 16x32 x  64, 4 waves, 94 KB, 1/CU
 //   6:  8x32 x  64, 4 waves, 59 KB, 2/CU          7:  8x16 x 256, 4 waves, 87 KB, 1/CU
 //   8: as 0 but 1/CU with the patch prefetch      9: as 2 but 1/CU with the patch prefetch
-constexpr int XV_NUM_CONV_CFG = 10;
+//  10: as 4 with two taps per barrier (74 KB)    11: as 6 with two taps per barrier (76 KB)
+//  12: 16x32 x 64, 8 waves, 3 taps per barrier, 126 KB, 1/CU
+//  13: 16x32 x 64, 8 waves, 5 taps per barrier, 158 KB, 1/CU
+constexpr int XV_NUM_CONV_CFG = 14;
 struct Geo {
   int th, tw, bn, per_cu;
 };
 const Geo kGeo[XV_NUM_CONV_CFG] = {{16, 16, 128, 2}, {8, 16, 128, 2}, {8, 32, 128, 2}, {16, 32, 128, 1},
                                    {16, 16, 64, 2},  {16, 32, 64, 1}, {8, 32, 64, 2},  {8, 16, 256, 1},
-                                   {16, 16, 128, 1}, {8, 32, 128, 1}};
+                                   {16, 16, 128, 1}, {8, 32, 128, 1}, {16, 16, 64, 2},  {8, 32, 64, 2},
+                                   {16, 32, 64, 1},  {16, 32, 64, 1}};
 
 template <int KS>
 int launch_cfg(int cfg, const ConvArgs& a, hipStream_t s) {
@@ -378,23 +404,26 @@ int launch_cfg(int cfg, const ConvArgs& a, hipStream_t s) {
     case 6: return launch_conv<4, 2, 2, 1, KS, 2>(a, s);
     case 7: return launch_conv<8, 1, 1, 4, KS, 1>(a, s);
     case 8: return launch_conv<8, 2, 1, 2, KS, 1>(a, s);
-    default: return launch_conv<8, 1, 2, 2, KS, 1>(a, s);
+    case 9: return launch_conv<8, 1, 2, 2, KS, 1>(a, s);
+    case 10: return launch_conv<4, 4, 1, 1, KS, 2, 2>(a, s);
+    case 11: return launch_conv<4, 2, 2, 1, KS, 2, 2>(a, s);
+    case 12: return launch_conv<4, 4, 2, 1, KS, 2, 3>(a, s);
+    default: return launch_conv<4, 4, 2, 1, KS, 2, 5>(a, s);
   }
 }
 
-// Default choice, from tools/conv_tune.py on MI355X (profiles/conv_tune_r1.txt): the two
-// 64-channel, 4-rows-per-wave configurations (two 4-wave workgroups per CU, cross-item prefetch) win
-// on every SimpleFCN layer at 8-16 images; pick the one that wastes fewer pixels on partial tiles,
-// the wide 8x32 patch on ties for wide images.
+// Default choice, from tools/conv_tune.py on MI355X (profiles/r1_conv_tune_b8.txt): 64 output
+// channels x 4 rows per wave, two taps per barrier.  Large images (conv1_2 / conv2_x at 8+ images)
+// prefer the 8-wave 16x32 patch with five taps per barrier (lower halo + barrier overhead); otherwise
+// two 4-wave workgroups per CU, patch shape by least waste on partial tiles.
 int pick_cfg(const ConvArgs& a) {
   auto covered = [&](int c) {
     const Geo& g = kGeo[c];
     return (double)((a.H + g.th - 1) / g.th * g.th) * ((a.W + g.tw - 1) / g.tw * g.tw);
   };
-  const double c4 = covered(4), c6 = covered(6);
-  if (c6 < c4) return 6;
-  if (c4 < c6) return 4;
-  return a.W >= 96 ? 6 : 4;
+  const double pixels = (double)a.N * a.H * a.W;
+  if (pixels >= 4.0e5 && a.H % 16 == 0 && a.W % 32 == 0) return 13;
+  return covered(11) < covered(10) ? 11 : 10;
 }
 
 int conv_fwd_impl(const xv_act* x, const void* w_packed, const float* bias, const xv_act* y, const xv_act* pooled,

@@ -46,13 +46,16 @@ __host__ __device__ static inline int64_t xv_img_pitch(int h, int w, int c) {
 }
 
 // 16-byte-slot swizzle shared by the weight packer and the conv kernels: slot s of the 128-byte
-// LDS row of weight row / patch column `row` lives at slot s ^ ((row >> 1) & 7).  Two consecutive
-// 128-B rows fill one 256-B LDS bank row, so 16 lanes reading the same logical slot of 16
-// consecutive rows touch 16 distinct slots (conflict-free ds_read_b128).  For activation patches
-// `row` is the pixel's COLUMN inside the patch (the patch pitch is even, so parity is preserved),
-// which makes the swizzle independent of the patch row and lets every fragment read be
-// base-register + immediate.
-__host__ __device__ static inline int xv_swz(int row, int slot) { return slot ^ ((row >> 1) & 7); }
+// LDS row of weight row / patch column `row` lives at slot s ^ (row & 6).  Two consecutive 128-B
+// rows fill one 256-B LDS bank row; a ds_read_b128 is served in 16-lane groups that, for the
+// 16x16x32 MFMA fragment map, hold 16 consecutive rows with two adjacent logical slots
+// ({0-3,12-15} slot a, {4-11} slot a+1).  An exhaustive search over GF(2)-linear maps of the row
+// index (tools/lds_swizzle_search.py) shows `row & 6` is conflict-free for EVERY starting row, i.e.
+// for all three horizontal taps of a 3x3 conv; the earlier (row>>1)&7 was 2-way for 3 of 4 starts.
+// For activation patches `row` is the pixel's COLUMN inside the patch (the patch pitch is even, so
+// bank-row parity is preserved), which makes the swizzle independent of the patch row and lets
+// every fragment read be base-register + immediate.
+__host__ __device__ static inline int xv_swz(int row, int slot) { return slot ^ (row & 6); }
 
 __device__ static inline uint32_t pack_bf16x2(float lo, float hi) {
   typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
