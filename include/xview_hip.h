@@ -128,6 +128,69 @@ int xv_dirichlet_fuse(const float* const* probs, int num_experts, const float* a
 int xv_average_fuse(const float* const* probs, int num_experts, int num_classes, int64_t npix,
                     int64_t* fused, void* stream);
 
+/* ---- training: backward kernels and optimizers ---------------------------------------------------
+ * These replace the gradient graph tf.train.{Adam,RMSProp,Adagrad}Optimizer.minimize(self.loss)
+ * builds (base_model.py:153-162) over SimpleFCN's training graph (simple_fcn.py:200-214).
+ * Activations and activation gradients are bf16 padded NHWC; weight gradients and optimizer
+ * state are float32 in the reference's HWIO layout.  Gradient buffers are ACCUMULATED into
+ * (callers zero them once per step).                                                               */
+
+/* Packed weights of the data-gradient convolution: Wd[k*k-1-tap][co][ci] = W[tap][ci][co].          */
+int xv_pack_conv_weights_dgrad(const float* w_hwio, void* packed, int k, int cin, int cout, void* stream);
+
+/* dx = (conv(dy, Wd) + addend) * (relu_ref > 0): Conv2DBackpropInput of tf.layers.conv2d, the AddN
+ * where two gradient paths meet (addend, may be NULL) and the ReluGrad of the layer below
+ * (relu_ref = that layer's forward output, may be NULL), fused in the forward MFMA kernel.
+ * zero_bias: float32 [dx->c] zeros.                                                                */
+int xv_conv2d_bwd_data(const xv_act* dy, const void* w_packed_dgrad, const float* zero_bias,
+                       const xv_act* relu_ref, const xv_act* addend, const xv_act* dx, int k, void* stream);
+
+/* dW[tap][cin][cout] += sum_pixels x[pix+tap][cin] * dy[pix][cout] (Conv2DBackpropFilter), on MFMA with
+ * transposing LDS reads; dbias[cout] += sum_pixels dy (BiasAddGrad; may be NULL).  k = 1 or 3,
+ * cin % 64 == 0, cout % 64 == 0.  fp32 atomics: summation order is not fixed run to run.            */
+int xv_conv2d_bwd_filter(const xv_act* x, const xv_act* dy, float* dw_hwio, float* dbias, int k, void* stream);
+
+/* dbias[c] += sum over all pixels of dy[.., c] (BiasAddGrad).                                        */
+int xv_bias_grad(const xv_act* dy, float* dbias, void* stream);
+
+/* conv1_1: dW[3][3][cin][64] += sum_pixels x[pix+tap][cin] * dy[pix][:] on the raw float32 input.   */
+int xv_conv2d_first_bwd_filter(const float* x, int n, int h, int w, int cin, const xv_act* dy, float* dw_hwio,
+                               void* stream);
+
+/* MaxPoolGrad + ReluGrad: dy = dpooled routed to the first maximum of each 2x2 window, zero where y <= 0. */
+int xv_maxpool2x2_bwd(const xv_act* y, const xv_act* dpooled, const xv_act* dy, void* stream);
+
+/* ReluGrad: out = ref > 0 ? g : 0.                                                                 */
+int xv_relu_bwd(const xv_act* g, const xv_act* ref, const xv_act* out, void* stream);
+
+/* Gradient of fused = s4 + relu(bilinear_x2(s5)) w.r.t. s5 (through score_conv5's own relu).       */
+int xv_upsample2x_bwd(const xv_act* dfused, const xv_act* s5, const xv_act* ds5, void* stream);
+
+/* Gradient of the x8 bilinear deconv: dup dense bf16 [N][8h][8w][C] -> dfused.                     */
+int xv_upsample8x_bwd(const void* dup, const xv_act* dfused, void* stream);
+
+/* count += #pixels with 0 <= label < C  (the denominator of utils.py:52).                          */
+int xv_count_valid_labels(const int32_t* labels, int num_classes, int64_t npix, int64_t* count, void* stream);
+
+/* Loss and head backward (simple_fcn.py:212-214, utils.py:43-53): recomputes the decoder head from
+ * `fused`, adds -sum(onehot*log_softmax)/(1e-20+count) to *loss, accumulates d(score kernel) [U][C]
+ * and d(score bias) [C], and writes dup = d(loss)/d(upscore) masked by upscore > 0 as dense bf16
+ * [N][8h][8w][U].  valid_count must already hold the batch's count.                                */
+int xv_decoder_head_bwd(const xv_act* fused, const float* w_score, const float* b_score, const int32_t* labels,
+                        const int64_t* valid_count, int num_classes, double* loss, float* dw_score,
+                        float* db_score, void* dup, void* stream);
+
+/* [TF1] optimizers on flat float32 buffers; grad_scale multiplies the gradient first (1/world_size).
+ * Adam: m,v updated, p -= lr_t*m/(sqrt(v)+eps) with lr_t = lr*sqrt(1-b2^t)/(1-b1^t) from the host.
+ * RMSProp: ms = decay*ms+(1-decay)g^2 (ms initialised to 1), p -= lr*g/sqrt(ms+eps).
+ * Adagrad: a += g^2 (a initialised to 0.1), p -= lr*g/sqrt(a).                                      */
+int xv_adam_step(float* param, const float* grad, float* m, float* v, int64_t n, float lr_t, float beta1,
+                 float beta2, float eps, float grad_scale, void* stream);
+int xv_rmsprop_step(float* param, const float* grad, float* ms, int64_t n, float lr, float decay, float eps,
+                    float grad_scale, void* stream);
+int xv_adagrad_step(float* param, const float* grad, float* accum, int64_t n, float lr, float grad_scale,
+                    void* stream);
+
 /* ---- statistics ----------------------------------------------------------------------------
  * Dirichlet sufficient statistics (dirichlet_mix.py:142-163): for every pixel with 0 <= label < C
  *   S[label][k] += log(1e-10 + prob[k]),  counts[label] += 1

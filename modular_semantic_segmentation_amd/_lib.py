@@ -43,6 +43,21 @@ SIGNATURES = {
     'xv_bayes_fuse_lut': (_i, [_vp, _vp, _vp, _i, _i64, _vp, _vp]),
     'xv_dirichlet_fuse': (_i, [_vpp, _i, _vp, _vp, _vp, _i, _i64, _vp, _vp, _vp]),
     'xv_average_fuse': (_i, [_vpp, _i, _i, _i64, _vp, _vp]),
+    'xv_pack_conv_weights_dgrad': (_i, [_vp, _vp, _i, _i, _i, _vp]),
+    'xv_conv2d_bwd_data': (_i, [_actp, _vp, _vp, _actp, _actp, _actp, _i, _vp]),
+    'xv_conv2d_bwd_filter': (_i, [_actp, _actp, _vp, _vp, _i, _vp]),
+    'xv_bias_grad': (_i, [_actp, _vp, _vp]),
+    'xv_conv2d_first_bwd_filter': (_i, [_vp, _i, _i, _i, _i, _actp, _vp, _vp]),
+    'xv_maxpool2x2_bwd': (_i, [_actp, _actp, _actp, _vp]),
+    'xv_relu_bwd': (_i, [_actp, _actp, _actp, _vp]),
+    'xv_upsample2x_bwd': (_i, [_actp, _actp, _actp, _vp]),
+    'xv_upsample8x_bwd': (_i, [_vp, _actp, _vp]),
+    'xv_count_valid_labels': (_i, [_vp, _i, _i64, _vp, _vp]),
+    'xv_decoder_head_bwd': (_i, [_actp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
+    'xv_adam_step': (_i, [_vp, _vp, _vp, _vp, _i64, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float,
+                          ctypes.c_float, _vp]),
+    'xv_rmsprop_step': (_i, [_vp, _vp, _vp, _i64, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float, _vp]),
+    'xv_adagrad_step': (_i, [_vp, _vp, _vp, _i64, ctypes.c_float, ctypes.c_float, _vp]),
     'xv_dirichlet_suffstats': (_i, [_vp, _vp, _i, _i64, _vp, _vp, _vp]),
     'xv_confusion_matrix': (_i, [_vp, _vp, _i, _i64, _vp, _vp]),
 }

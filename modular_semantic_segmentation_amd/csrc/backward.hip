@@ -1,0 +1,562 @@
+// Backward pass of the HBM-bound FCN layers, the softmax cross-entropy head, and the optimizers
+// (gfx950).  Together with conv_wgrad.hip and the dgrad mode of conv_mfma.hip these replace the
+// gradient ops that tf.train.{Adam,RMSProp,Adagrad}Optimizer.minimize(self.loss) builds over the
+// training graph of SimpleFCN (base_model.py:153-162, simple_fcn.py:200-214).
+#include "xv_common.h"
+
+namespace {
+
+inline int grid_for(int64_t total, int per_block = 256, int cap = 8192) {
+  int64_t g = (total + per_block - 1) / per_block;
+  return (int)(g < 1 ? 1 : (g > cap ? cap : g));
+}
+
+__device__ inline float bf_lo(uint32_t w) { return bf16_bits_to_f32(w & 0xffffu); }
+__device__ inline float bf_hi(uint32_t w) { return __builtin_bit_cast(float, w & 0xffff0000u); }
+
+// ---- MaxPoolGrad + ReluGrad: dy[pos] = dpooled if pos is the (first) max of its 2x2 window and
+// y[pos] > 0, else 0  (max_pooling2d, simple_fcn.py:41,44,48,58 under the relu of the conv above) ----
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const __bf16* __restrict__ y, const __bf16* __restrict__ dp,
+                                                         __bf16* __restrict__ dy, int N, int Ho, int Wo, int C) {
+  const int c8 = C >> 3;
+  const int64_t total = (int64_t)N * Ho * Wo * c8;
+  const int Hi = Ho * 2, Wi = Wo * 2;
+  const int64_t rowp = (int64_t)(Wi + 2) * C;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    const int cg = (int)(idx % c8);
+    int64_t r = idx / c8;
+    const int ox = (int)(r % Wo);
+    r /= Wo;
+    const int oy = (int)(r % Ho);
+    const int n = (int)(r / Ho);
+    const int64_t off = (((int64_t)n * (Hi + 2) + (2 * oy + 1)) * (Wi + 2) + (2 * ox + 1)) * C + cg * 8;
+    const u32x4 g = *reinterpret_cast<const u32x4*>(dp + (((int64_t)n * (Ho + 2) + (oy + 1)) * (Wo + 2) + (ox + 1)) * C + cg * 8);
+    u32x4 v[4] = {*reinterpret_cast<const u32x4*>(y + off), *reinterpret_cast<const u32x4*>(y + off + C),
+                  *reinterpret_cast<const u32x4*>(y + off + rowp), *reinterpret_cast<const u32x4*>(y + off + rowp + C)};
+    u32x4 o[4];
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        float val[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) val[k] = h ? bf_hi(v[k][w]) : bf_lo(v[k][w]);
+        int best = 0;
+        float m = val[0];
+#pragma unroll
+        for (int k = 1; k < 4; ++k)
+          if (val[k] > m) {
+            m = val[k];
+            best = k;
+          }
+        const uint32_t gb = h ? (g[w] & 0xffff0000u) : (g[w] & 0xffffu);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const uint32_t bits = (k == best && m > 0.f) ? gb : 0u;
+          o[k][w] = h ? (o[k][w] | bits) : bits;
+        }
+      }
+    }
+    *reinterpret_cast<u32x4*>(dy + off) = o[0];
+    *reinterpret_cast<u32x4*>(dy + off + C) = o[1];
+    *reinterpret_cast<u32x4*>(dy + off + rowp) = o[2];
+    *reinterpret_cast<u32x4*>(dy + off + rowp + C) = o[3];
+  }
+}
+
+// ---- ReluGrad on padded-NHWC bf16: out = ref > 0 ? g : 0 ---------------------------------------
+__global__ __launch_bounds__(256) void relu_bwd_kernel(const __bf16* __restrict__ g, const __bf16* __restrict__ ref,
+                                                      __bf16* __restrict__ out, int64_t n8) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
+    const u32x4 a = *reinterpret_cast<const u32x4*>(g + i * 8);
+    const u32x4 r = *reinterpret_cast<const u32x4*>(ref + i * 8);
+    u32x4 o;
+#pragma unroll
+    for (int w = 0; w < 4; ++w)
+      o[w] = (bf_lo(r[w]) > 0.f ? (a[w] & 0xffffu) : 0u) | (bf_hi(r[w]) > 0.f ? (a[w] & 0xffff0000u) : 0u);
+    *reinterpret_cast<u32x4*>(out + i * 8) = o;
+  }
+}
+
+template <int S>
+__device__ inline float bilinear_w(int o, int i) {
+  // weight with which source index i feeds output o (conv2d_transpose 'same', k = 2S): 0 if not a neighbour
+  const int t = o + S / 2;
+  const int i1 = t / S, p1 = t - i1 * S;
+  constexpr float center = (2.f * S - 1.f - (S % 2)) / (2.f * S);
+  if (i == i1) return 1.f - fabsf((float)p1 / S - center);
+  if (i == i1 - 1) return 1.f - fabsf((float)(p1 + S) / S - center);
+  return 0.f;
+}
+
+// ---- backward of fused = s4 + relu(bilinear_x2(s5))  w.r.t. s5, through the relu of score_conv5 ----
+// ds5[i,j,c] = (s5 > 0) * sum_{(oy,ox) in the 4x4 footprint} wy*wx * dfused[oy,ox,c] * (up2(s5)[oy,ox,c] > 0)
+__global__ __launch_bounds__(256) void upsample2x_bwd_kernel(const __bf16* __restrict__ df, const __bf16* __restrict__ s5,
+                                                            __bf16* __restrict__ ds5, int N, int Hi, int Wi, int C) {
+  const int c8 = C >> 3;
+  const int Ho = 2 * Hi, Wo = 2 * Wi;
+  const int64_t total = (int64_t)N * Hi * Wi * c8;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    const int cg = (int)(idx % c8);
+    int64_t r = idx / c8;
+    const int j = (int)(r % Wi);
+    r /= Wi;
+    const int i = (int)(r % Hi);
+    const int n = (int)(r / Hi);
+    const __bf16* simg = s5 + (int64_t)n * (Hi + 2) * (Wi + 2) * C + cg * 8;
+    const __bf16* dimg = df + (int64_t)n * (Ho + 2) * (Wo + 2) * C + cg * 8;
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int oy = 2 * i - 1; oy <= 2 * i + 2; ++oy) {
+      if (oy < 0 || oy >= Ho) continue;
+      const float wy = bilinear_w<2>(oy, i);
+      const int ty = oy + 1, iy1 = ty >> 1;
+      const float wy1 = bilinear_w<2>(oy, iy1), wy0 = bilinear_w<2>(oy, iy1 - 1);
+      for (int ox = 2 * j - 1; ox <= 2 * j + 2; ++ox) {
+        if (ox < 0 || ox >= Wo) continue;
+        const float wx = bilinear_w<2>(ox, j);
+        const int tx = ox + 1, ix1 = tx >> 1;
+        const float wx1 = bilinear_w<2>(ox, ix1), wx0 = bilinear_w<2>(ox, ix1 - 1);
+        // recompute the forward value up2(s5)[oy,ox] for the relu mask (padded coords: logical i -> i+1)
+        const __bf16* p00 = simg + ((int64_t)iy1 * (Wi + 2) + ix1) * C;
+        const int64_t rowp = (int64_t)(Wi + 2) * C;
+        const u32x4 a00 = *reinterpret_cast<const u32x4*>(p00), a01 = *reinterpret_cast<const u32x4*>(p00 + C);
+        const u32x4 a10 = *reinterpret_cast<const u32x4*>(p00 + rowp), a11 = *reinterpret_cast<const u32x4*>(p00 + rowp + C);
+        const u32x4 gv = *reinterpret_cast<const u32x4*>(dimg + ((int64_t)(oy + 1) * (Wo + 2) + (ox + 1)) * C);
+        const float w00 = wy0 * wx0, w01 = wy0 * wx1, w10 = wy1 * wx0, w11 = wy1 * wx1;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+          const float u_lo = bf_lo(a00[w]) * w00 + bf_lo(a01[w]) * w01 + bf_lo(a10[w]) * w10 + bf_lo(a11[w]) * w11;
+          const float u_hi = bf_hi(a00[w]) * w00 + bf_hi(a01[w]) * w01 + bf_hi(a10[w]) * w10 + bf_hi(a11[w]) * w11;
+          if (u_lo > 0.f) acc[2 * w] += wy * wx * bf_lo(gv[w]);
+          if (u_hi > 0.f) acc[2 * w + 1] += wy * wx * bf_hi(gv[w]);
+        }
+      }
+    }
+    const int64_t so = ((int64_t)(i + 1) * (Wi + 2) + (j + 1)) * C;
+    const u32x4 sv = *reinterpret_cast<const u32x4*>(simg + so);
+    u32x4 o;
+#pragma unroll
+    for (int w = 0; w < 4; ++w)
+      o[w] = pack_bf16x2(bf_lo(sv[w]) > 0.f ? acc[2 * w] : 0.f, bf_hi(sv[w]) > 0.f ? acc[2 * w + 1] : 0.f);
+    *reinterpret_cast<u32x4*>(ds5 + (int64_t)n * (Hi + 2) * (Wi + 2) * C + cg * 8 + so) = o;
+  }
+}
+
+// ---- backward of the x8 bilinear deconv: dfused[i,j,c] = sum over the 16x16 footprint of w * dup ----
+// dup is dense [N][8h][8w][C] bf16 with the relu mask already applied by the head-backward kernel.
+__global__ __launch_bounds__(256) void upsample8x_bwd_kernel(const __bf16* __restrict__ dup, __bf16* __restrict__ df,
+                                                            int N, int Hi, int Wi, int C) {
+  const int c8 = C >> 3;
+  const int Ho = 8 * Hi, Wo = 8 * Wi;
+  const int64_t total = (int64_t)N * Hi * Wi * c8;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    const int cg = (int)(idx % c8);
+    int64_t r = idx / c8;
+    const int j = (int)(r % Wi);
+    r /= Wi;
+    const int i = (int)(r % Hi);
+    const int n = (int)(r / Hi);
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int oy = 8 * i - 4; oy <= 8 * i + 11; ++oy) {
+      if (oy < 0 || oy >= Ho) continue;
+      const float wy = bilinear_w<8>(oy, i);
+      const __bf16* row = dup + (((int64_t)n * Ho + oy) * Wo) * C + cg * 8;
+      for (int ox = 8 * j - 4; ox <= 8 * j + 11; ++ox) {
+        if (ox < 0 || ox >= Wo) continue;
+        const float w = wy * bilinear_w<8>(ox, j);
+        const u32x4 gv = *reinterpret_cast<const u32x4*>(row + (int64_t)ox * C);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          acc[2 * q] += w * bf_lo(gv[q]);
+          acc[2 * q + 1] += w * bf_hi(gv[q]);
+        }
+      }
+    }
+    u32x4 o;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) o[q] = pack_bf16x2(acc[2 * q], acc[2 * q + 1]);
+    *reinterpret_cast<u32x4*>(df + (((int64_t)n * (Hi + 2) + (i + 1)) * (Wi + 2) + (j + 1)) * C + cg * 8) = o;
+  }
+}
+
+// ---- number of labelled pixels: sum(one_hot(labels)) of utils.py:52 --------------------------------
+__global__ __launch_bounds__(256) void count_valid_kernel(const int32_t* __restrict__ labels, int C, int64_t npix,
+                                                         unsigned long long* __restrict__ count) {
+  unsigned int c = 0;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < npix; i += (int64_t)gridDim.x * 256) {
+    const int l = labels[i];
+    c += (l >= 0 && l < C) ? 1u : 0u;
+  }
+  __shared__ unsigned int s;
+  if (threadIdx.x == 0) s = 0;
+  __syncthreads();
+  atomicAdd(&s, c);
+  __syncthreads();
+  if (threadIdx.x == 0 && s) atomicAdd(count, (unsigned long long)s);
+}
+
+// ---- head backward: loss, dscore, d(score weights), dup ---------------------------------------------
+// Forward recomputed from `fused` (x8 bilinear + relu, score 1x1, log-softmax), then
+//   loss += -log p[label] / denom,  dscore = (p*valid - onehot) / denom      (utils.py:43-53)
+//   dWs[u][k] += up[u]*dscore[k], dbs[k] += dscore[k], dup[u] = (up[u] > 0) * sum_k dscore[k]*Ws[u][k]
+// One thread per output pixel; the U x C weight-gradient block is reduced through LDS per
+// 8-channel group and flushed with one global atomic per cell per workgroup.
+template <int CM>
+__global__ __launch_bounds__(256) void head_bwd_kernel(const __bf16* __restrict__ f, const float* __restrict__ ws_g,
+                                                      const float* __restrict__ bs_g, const int32_t* __restrict__ labels,
+                                                      const unsigned long long* __restrict__ count, int N, int Hi,
+                                                      int Wi, int U, int C, double* __restrict__ loss,
+                                                      float* __restrict__ dws, float* __restrict__ dbs,
+                                                      __bf16* __restrict__ dup) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float* wsm = sm;                  // [U][CM] score weights (zero padded)
+  float* dsm = wsm + U * CM;        // [256][CM] dscore of this workgroup's pixels
+  float* upm = dsm + 256 * CM;      // [256][8] up values of the current channel group
+  float* accm = upm + 256 * 8;      // [U][CM] weight-gradient accumulator + [CM] bias gradient + [1] loss
+  for (int i = threadIdx.x; i < U * CM; i += 256) {
+    const int u = i / CM, k = i - u * CM;
+    wsm[i] = k < C ? ws_g[u * C + k] : 0.f;
+  }
+  for (int i = threadIdx.x; i < U * CM + CM + 1; i += 256) accm[i] = 0.f;
+  __syncthreads();
+  const int Ho = Hi * 8, Wo = Wi * 8;
+  const int tilesx = (Wo + 31) / 32;
+  const int tx = blockIdx.x % tilesx;
+  int r = blockIdx.x / tilesx;
+  const int tilesy = Hi;
+  const int ty = r % tilesy;
+  const int n = r / tilesy;
+  const int ox = tx * 32 + (threadIdx.x & 31), oy = ty * 8 + (threadIdx.x >> 5);
+  const bool inside = ox < Wo;
+  const int oxc = inside ? ox : Wo - 1;
+  int iy1, ix1;
+  float wy1, wy0, wx1, wx0;
+  {
+    const int t = oy + 4;
+    iy1 = t >> 3;
+    wy1 = bilinear_w<8>(oy, iy1);
+    wy0 = bilinear_w<8>(oy, iy1 - 1);
+    const int t2 = oxc + 4;
+    ix1 = t2 >> 3;
+    wx1 = bilinear_w<8>(oxc, ix1);
+    wx0 = bilinear_w<8>(oxc, ix1 - 1);
+  }
+  const float w00 = wy0 * wx0, w01 = wy0 * wx1, w10 = wy1 * wx0, w11 = wy1 * wx1;
+  const __bf16* p00 = f + (((int64_t)n * (Hi + 2) + iy1) * (Wi + 2) + ix1) * U;
+  const int64_t rowp = (int64_t)(Wi + 2) * U;
+  auto up_group = [&](int u0, float (&up)[8]) {
+    const u32x4 a00 = *reinterpret_cast<const u32x4*>(p00 + u0), a01 = *reinterpret_cast<const u32x4*>(p00 + U + u0);
+    const u32x4 a10 = *reinterpret_cast<const u32x4*>(p00 + rowp + u0),
+                a11 = *reinterpret_cast<const u32x4*>(p00 + rowp + U + u0);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      up[2 * q] = fmaxf(bf_lo(a00[q]) * w00 + bf_lo(a01[q]) * w01 + bf_lo(a10[q]) * w10 + bf_lo(a11[q]) * w11, 0.f);
+      up[2 * q + 1] = fmaxf(bf_hi(a00[q]) * w00 + bf_hi(a01[q]) * w01 + bf_hi(a10[q]) * w10 + bf_hi(a11[q]) * w11, 0.f);
+    }
+  };
+  // pass 1: score -> softmax -> dscore
+  float sc[CM];
+#pragma unroll
+  for (int k = 0; k < CM; ++k) sc[k] = k < C ? bs_g[k] : 0.f;
+  for (int u0 = 0; u0 < U; u0 += 8) {
+    float up[8];
+    up_group(u0, up);
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int k = 0; k < CM; ++k) sc[k] = fmaf(up[i], wsm[(u0 + i) * CM + k], sc[k]);
+  }
+  const int64_t opix = ((int64_t)n * Ho + oy) * Wo + oxc;
+  const int lab = inside ? labels[opix] : -1;
+  const bool valid = lab >= 0 && lab < C;
+  const float inv_denom = 1.f / (1e-20f + (float)(*count));
+  float m = sc[0];
+#pragma unroll
+  for (int k = 1; k < CM; ++k)
+    if (k < C) m = fmaxf(m, sc[k]);
+  float sum = 0.f, zlab = 0.f;
+#pragma unroll
+  for (int k = 0; k < CM; ++k) {
+    if (k == lab) zlab = sc[k] - m;
+    sc[k] = k < C ? expf(sc[k] - m) : 0.f;
+    sum += sc[k];
+  }
+  const float my_loss = valid ? -(zlab - logf(sum)) * inv_denom : 0.f;  // -(log_softmax)[label] / denom
+#pragma unroll
+  for (int k = 0; k < CM; ++k) {
+    const float p = sc[k] / sum;
+    sc[k] = valid ? (p - (k == lab ? 1.f : 0.f)) * inv_denom : 0.f;
+    if (k >= C) sc[k] = 0.f;
+    dsm[threadIdx.x * CM + k] = sc[k];
+  }
+  if (valid) {
+    atomicAdd(&accm[U * CM + CM], my_loss);
+#pragma unroll
+    for (int k = 0; k < CM; ++k)
+      if (k < C) atomicAdd(&accm[U * CM + k], sc[k]);
+  }
+  // pass 2, per 8-channel group: dup and the weight-gradient partial sums
+  __bf16* dup_px = dup + opix * U;
+  const int cell = threadIdx.x % (8 * CM);      // (channel-in-group, class) cell this thread reduces
+  const int seg = threadIdx.x / (8 * CM);       // pixel segment
+  const int nseg = 256 / (8 * CM);              // >= 2 for CM <= 16, 1 for CM = 32
+  const int ci = cell / CM, ck = cell - ci * CM;
+  for (int u0 = 0; u0 < U; u0 += 8) {
+    float up[8];
+    up_group(u0, up);
+    float d[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      float a = 0.f;
+#pragma unroll
+      for (int k = 0; k < CM; ++k) a = fmaf(sc[k], wsm[(u0 + i) * CM + k], a);
+      d[i] = up[i] > 0.f ? a : 0.f;
+      upm[threadIdx.x * 8 + i] = up[i];
+    }
+    if (inside)
+      *reinterpret_cast<u32x4*>(dup_px + u0) =
+          u32x4{pack_bf16x2(d[0], d[1]), pack_bf16x2(d[2], d[3]), pack_bf16x2(d[4], d[5]), pack_bf16x2(d[6], d[7])};
+    __syncthreads();
+    if (seg < nseg) {
+      const int per = 256 / nseg;
+      float a = 0.f;
+      for (int px = seg * per; px < (seg + 1) * per; ++px) a = fmaf(upm[px * 8 + ci], dsm[px * CM + ck], a);
+      atomicAdd(&accm[(u0 + ci) * CM + ck], a);
+    }
+    __syncthreads();
+  }
+  for (int i = threadIdx.x; i < U * CM; i += 256) {
+    const int u = i / CM, k = i - u * CM;
+    if (k < C && accm[i] != 0.f) atomicAdd(&dws[u * C + k], accm[i]);
+  }
+  if (threadIdx.x < C && accm[U * CM + threadIdx.x] != 0.f) atomicAdd(&dbs[threadIdx.x], accm[U * CM + threadIdx.x]);
+  if (threadIdx.x == 0 && accm[U * CM + CM] != 0.f) atomicAdd(loss, (double)accm[U * CM + CM]);
+}
+
+// ---- conv1_1 filter gradient: dW[t][co] = sum_pix in[pix][t] * dy[pix][co]  (fp32 input, K = 9*CIN) ----
+template <int CIN>
+__global__ __launch_bounds__(256) void conv_first_wgrad_kernel(const float* __restrict__ x, const __bf16* __restrict__ dy,
+                                                              float* __restrict__ dw, int N, int H, int W,
+                                                              int chunks_per_block) {
+  constexpr int K = 9 * CIN;
+  constexpr int TPW = (K + 3) / 4;  // taps per wave (wave w owns taps w, w+4, ...)
+  constexpr int PX = 128;           // pixels per staged chunk
+  __shared__ float ins[PX * K];
+  __shared__ __attribute__((aligned(16))) __bf16 dys[PX * 64];
+  const int64_t npix = (int64_t)N * H * W;
+  const int co = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  float acc[TPW];
+#pragma unroll
+  for (int i = 0; i < TPW; ++i) acc[i] = 0.f;
+  for (int ch = 0; ch < chunks_per_block; ++ch) {
+    const int64_t base = ((int64_t)blockIdx.x * chunks_per_block + ch) * PX;
+    if (base >= npix) break;
+    __syncthreads();
+    if (threadIdx.x < PX) {
+      const int64_t pix = base + threadIdx.x;
+      const bool ok = pix < npix;
+      const int64_t pc = ok ? pix : npix - 1;
+      const int px = (int)(pc % W), py = (int)((pc / W) % H), n = (int)(pc / ((int64_t)W * H));
+#pragma unroll
+      for (int dy_ = 0; dy_ < 3; ++dy_)
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+          const int yy = py + dy_ - 1, xx = px + dx - 1;
+          const bool in = ok && yy >= 0 && yy < H && xx >= 0 && xx < W;
+          const float* src = x + (((int64_t)n * H + (in ? yy : 0)) * W + (in ? xx : 0)) * CIN;
+#pragma unroll
+          for (int c = 0; c < CIN; ++c) ins[threadIdx.x * K + (dy_ * 3 + dx) * CIN + c] = in ? src[c] : 0.f;
+        }
+    }
+#pragma unroll
+    for (int it = 0; it < PX * 8 / 256; ++it) {
+      const int idx = threadIdx.x + it * 256;
+      const int lp = idx >> 3, s = idx & 7;
+      const int64_t pix = base + lp;
+      const bool ok = pix < npix;
+      const int64_t pc = ok ? pix : npix - 1;
+      const int px = (int)(pc % W), py = (int)((pc / W) % H), n = (int)(pc / ((int64_t)W * H));
+      u32x4 v = *reinterpret_cast<const u32x4*>(dy + (((int64_t)n * (H + 2) + (py + 1)) * (W + 2) + (px + 1)) * 64 + s * 8);
+      if (!ok) v = u32x4{0u, 0u, 0u, 0u};
+      *reinterpret_cast<u32x4*>(dys + lp * 64 + s * 8) = v;
+    }
+    __syncthreads();
+    for (int px = 0; px < PX; ++px) {
+      const float g = (float)dys[px * 64 + co];
+#pragma unroll
+      for (int i = 0; i < TPW; ++i) {
+        const int t = wv + 4 * i;
+        if (t < K) acc[i] = fmaf(ins[px * K + t], g, acc[i]);
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < TPW; ++i) {
+    const int t = wv + 4 * i;
+    if (t < K) atomicAdd(&dw[t * 64 + co], acc[i]);
+  }
+}
+
+// ---- optimizers ([TF1] update rules) ------------------------------------------
+// grad_scale folds the 1/world_size of data-parallel averaging into the update.
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                  float* __restrict__ v, int64_t n, float lr_t, float b1, float b2,
+                                                  float eps, float gs) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const float gi = g[i] * gs;
+    const float mi = b1 * m[i] + (1.f - b1) * gi;
+    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    p[i] -= lr_t * mi / (sqrtf(vi) + eps);
+  }
+}
+__global__ __launch_bounds__(256) void rmsprop_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ ms,
+                                                     int64_t n, float lr, float decay, float eps, float gs) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const float gi = g[i] * gs;
+    const float s = decay * ms[i] + (1.f - decay) * gi * gi;
+    ms[i] = s;
+    p[i] -= lr * gi / sqrtf(s + eps);
+  }
+}
+__global__ __launch_bounds__(256) void adagrad_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ a,
+                                                     int64_t n, float lr, float gs) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const float gi = g[i] * gs;
+    const float s = a[i] + gi * gi;
+    a[i] = s;
+    p[i] -= lr * gi / sqrtf(s);
+  }
+}
+
+}  // namespace
+
+extern "C" int xv_maxpool2x2_bwd(const xv_act* y, const xv_act* dpooled, const xv_act* dy, void* stream) {
+  XV_CHECK_ARG(y && dpooled && dy && y->data && dpooled->data && dy->data);
+  XV_CHECK_SHAPE(y->c > 0 && (y->c & 7) == 0 && (y->h & 1) == 0 && (y->w & 1) == 0);
+  XV_CHECK_SHAPE(dy->n == y->n && dy->h == y->h && dy->w == y->w && dy->c == y->c);
+  XV_CHECK_SHAPE(dpooled->n == y->n && dpooled->h == y->h / 2 && dpooled->w == y->w / 2 && dpooled->c == y->c);
+  const int64_t total = (int64_t)y->n * (y->h / 2) * (y->w / 2) * (y->c >> 3);
+  hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
+                     (const __bf16*)y->data, (const __bf16*)dpooled->data, (__bf16*)dy->data, y->n, y->h / 2, y->w / 2, y->c);
+  return xv_launch_status();
+}
+
+extern "C" int xv_relu_bwd(const xv_act* g, const xv_act* ref, const xv_act* out, void* stream) {
+  XV_CHECK_ARG(g && ref && out && g->data && ref->data && out->data);
+  XV_CHECK_SHAPE(g->n == ref->n && g->h == ref->h && g->w == ref->w && g->c == ref->c && (g->c & 7) == 0);
+  XV_CHECK_SHAPE(out->n == g->n && out->h == g->h && out->w == g->w && out->c == g->c);
+  const int64_t n8 = (int64_t)g->n * (g->h + 2) * (g->w + 2) * g->c / 8;
+  hipLaunchKernelGGL(relu_bwd_kernel, dim3(grid_for(n8)), dim3(256), 0, (hipStream_t)stream, (const __bf16*)g->data,
+                     (const __bf16*)ref->data, (__bf16*)out->data, n8);
+  return xv_launch_status();
+}
+
+extern "C" int xv_upsample2x_bwd(const xv_act* dfused, const xv_act* s5, const xv_act* ds5, void* stream) {
+  XV_CHECK_ARG(dfused && s5 && ds5 && dfused->data && s5->data && ds5->data);
+  XV_CHECK_SHAPE((s5->c & 7) == 0 && dfused->n == s5->n && dfused->h == 2 * s5->h && dfused->w == 2 * s5->w &&
+                 dfused->c == s5->c);
+  XV_CHECK_SHAPE(ds5->n == s5->n && ds5->h == s5->h && ds5->w == s5->w && ds5->c == s5->c);
+  const int64_t total = (int64_t)s5->n * s5->h * s5->w * (s5->c >> 3);
+  hipLaunchKernelGGL(upsample2x_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
+                     (const __bf16*)dfused->data, (const __bf16*)s5->data, (__bf16*)ds5->data, s5->n, s5->h, s5->w, s5->c);
+  return xv_launch_status();
+}
+
+extern "C" int xv_upsample8x_bwd(const void* dup, const xv_act* dfused, void* stream) {
+  XV_CHECK_ARG(dup && dfused && dfused->data);
+  XV_CHECK_SHAPE(dfused->n > 0 && (dfused->c & 7) == 0);
+  const int64_t total = (int64_t)dfused->n * dfused->h * dfused->w * (dfused->c >> 3);
+  hipLaunchKernelGGL(upsample8x_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
+                     (const __bf16*)dup, (__bf16*)dfused->data, dfused->n, dfused->h, dfused->w, dfused->c);
+  return xv_launch_status();
+}
+
+extern "C" int xv_count_valid_labels(const int32_t* labels, int num_classes, int64_t npix, int64_t* count, void* stream) {
+  XV_CHECK_ARG(labels && count);
+  XV_CHECK_SHAPE(npix > 0 && num_classes >= 1);
+  hipLaunchKernelGGL(count_valid_kernel, dim3(grid_for(npix, 256, 1024)), dim3(256), 0, (hipStream_t)stream, labels,
+                     num_classes, npix, reinterpret_cast<unsigned long long*>(count));
+  return xv_launch_status();
+}
+
+extern "C" int xv_decoder_head_bwd(const xv_act* fused, const float* w_score, const float* b_score, const int32_t* labels,
+                                   const int64_t* valid_count, int num_classes, double* loss, float* dw_score,
+                                   float* db_score, void* dup, void* stream) {
+  XV_CHECK_ARG(fused && fused->data && w_score && b_score && labels && valid_count && loss && dw_score && db_score && dup);
+  XV_CHECK_SHAPE(fused->c > 0 && (fused->c & 7) == 0 && fused->c <= 128 && num_classes >= 1 && num_classes <= 32);
+  const int Wo = fused->w * 8;
+  const int64_t nblk = (int64_t)((Wo + 31) / 32) * fused->h * fused->n;
+  XV_CHECK_SHAPE(nblk <= 0x7fffffff);
+  hipStream_t s = (hipStream_t)stream;
+  const int U = fused->c;
+#define XV_HB(CMV)                                                                                                  \
+  {                                                                                                                 \
+    const size_t lds = (size_t)(2 * U * CMV + 256 * CMV + 256 * 8 + CMV + 1) * 4;                                  \
+    static bool attr = false;                                                                                       \
+    if (!attr) {                                                                                                    \
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&head_bwd_kernel<CMV>),                     \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                   \
+      if (e != hipSuccess) return (int)e;                                                                           \
+      attr = true;                                                                                                  \
+    }                                                                                                               \
+    hipLaunchKernelGGL(head_bwd_kernel<CMV>, dim3((unsigned)nblk), dim3(256), lds, s, (const __bf16*)fused->data,   \
+                       w_score, b_score, labels, reinterpret_cast<const unsigned long long*>(valid_count), fused->n, \
+                       fused->h, fused->w, U, num_classes, loss, dw_score, db_score, (__bf16*)dup);                 \
+  }
+  switch ((num_classes + 3) / 4) {
+    case 1: XV_HB(4) break;
+    case 2: XV_HB(8) break;
+    case 3: XV_HB(12) break;
+    case 4: XV_HB(16) break;
+    default: XV_HB(32) break;
+  }
+#undef XV_HB
+  return xv_launch_status();
+}
+
+extern "C" int xv_conv2d_first_bwd_filter(const float* x, int n, int h, int w, int cin, const xv_act* dy, float* dw_hwio,
+                                          void* stream) {
+  XV_CHECK_ARG(x && dy && dy->data && dw_hwio);
+  XV_CHECK_SHAPE(n > 0 && h > 0 && w > 0 && cin >= 1 && cin <= 4 && dy->n == n && dy->h == h && dy->w == w && dy->c == 64);
+  const int64_t npix = (int64_t)n * h * w;
+  const int chunks = 8;
+  const unsigned grid = (unsigned)((npix + 128 * chunks - 1) / (128 * chunks));
+  hipStream_t s = (hipStream_t)stream;
+  const __bf16* g = (const __bf16*)dy->data;
+  switch (cin) {
+    case 1: hipLaunchKernelGGL(conv_first_wgrad_kernel<1>, dim3(grid), dim3(256), 0, s, x, g, dw_hwio, n, h, w, chunks); break;
+    case 2: hipLaunchKernelGGL(conv_first_wgrad_kernel<2>, dim3(grid), dim3(256), 0, s, x, g, dw_hwio, n, h, w, chunks); break;
+    case 3: hipLaunchKernelGGL(conv_first_wgrad_kernel<3>, dim3(grid), dim3(256), 0, s, x, g, dw_hwio, n, h, w, chunks); break;
+    default: hipLaunchKernelGGL(conv_first_wgrad_kernel<4>, dim3(grid), dim3(256), 0, s, x, g, dw_hwio, n, h, w, chunks); break;
+  }
+  return xv_launch_status();
+}
+
+extern "C" int xv_adam_step(float* param, const float* grad, float* m, float* v, int64_t n, float lr_t, float beta1,
+                            float beta2, float eps, float grad_scale, void* stream) {
+  XV_CHECK_ARG(param && grad && m && v);
+  XV_CHECK_SHAPE(n > 0);
+  hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, param, grad, m, v, n, lr_t, beta1,
+                     beta2, eps, grad_scale);
+  return xv_launch_status();
+}
+
+extern "C" int xv_rmsprop_step(float* param, const float* grad, float* ms, int64_t n, float lr, float decay, float eps,
+                               float grad_scale, void* stream) {
+  XV_CHECK_ARG(param && grad && ms);
+  XV_CHECK_SHAPE(n > 0);
+  hipLaunchKernelGGL(rmsprop_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, param, grad, ms, n, lr, decay,
+                     eps, grad_scale);
+  return xv_launch_status();
+}
+
+extern "C" int xv_adagrad_step(float* param, const float* grad, float* accum, int64_t n, float lr, float grad_scale,
+                               void* stream) {
+  XV_CHECK_ARG(param && grad && accum);
+  XV_CHECK_SHAPE(n > 0);
+  hipLaunchKernelGGL(adagrad_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, param, grad, accum, n, lr,
+                     grad_scale);
+  return xv_launch_status();
+}

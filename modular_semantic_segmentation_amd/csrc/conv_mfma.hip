@@ -24,6 +24,8 @@ struct ConvArgs {
   const float* bias;
   __bf16* y;       // may be null
   __bf16* pooled;  // may be null
+  const __bf16* mask;    // may be null: output zeroed where mask <= 0 (relu backward), same layout as y
+  const __bf16* addend;  // may be null: added to the output before masking, same layout as y
   int N, H, W, Cin, Cout;
   int tiles_x, tiles_y, n_ct, n_tiles;
   int relu;
@@ -271,15 +273,29 @@ __global__ __launch_bounds__(64 * WR * WC * NW, OCC * 4 / (WR * WC * NW) > 0 ? O
           acc[i][j] = v;
         }
       if (a.y != nullptr) {
-        __bf16* yimg = a.y + (int64_t)cur.n * (H + 2) * Wp * Cout;
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
           const int py = cur.y0 + wr * MT + i;
           if (py < H && px < W) {
-            __bf16* dst = yimg + ((int64_t)(py + 1) * Wp + (px + 1)) * Cout + cbase;
+            const int64_t off = (int64_t)cur.n * (H + 2) * Wp * Cout + ((int64_t)(py + 1) * Wp + (px + 1)) * Cout + cbase;
+            __bf16* dst = a.y + off;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-              const f32x4 v = acc[i][j];
+              f32x4 v = acc[i][j];
+              if (a.addend != nullptr) {
+                const u32x2 ad = *reinterpret_cast<const u32x2*>(a.addend + off + j * 16);
+                v.x += bf16_bits_to_f32(ad.x & 0xffffu);
+                v.y += __builtin_bit_cast(float, ad.x & 0xffff0000u);
+                v.z += bf16_bits_to_f32(ad.y & 0xffffu);
+                v.w += __builtin_bit_cast(float, ad.y & 0xffff0000u);
+              }
+              if (a.mask != nullptr) {
+                const u32x2 mk = *reinterpret_cast<const u32x2*>(a.mask + off + j * 16);
+                v.x = bf16_bits_to_f32(mk.x & 0xffffu) > 0.f ? v.x : 0.f;
+                v.y = __builtin_bit_cast(float, mk.x & 0xffff0000u) > 0.f ? v.y : 0.f;
+                v.z = bf16_bits_to_f32(mk.y & 0xffffu) > 0.f ? v.z : 0.f;
+                v.w = __builtin_bit_cast(float, mk.y & 0xffff0000u) > 0.f ? v.w : 0.f;
+              }
               *reinterpret_cast<u32x2*>(dst + j * 16) = u32x2{pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w)};
             }
           }
@@ -351,9 +367,28 @@ int launch_conv(const ConvArgs& a0, hipStream_t stream) {
 }
 
 // ---- weight packing: fp32 HWIO -> bf16 [tap][cin/64][cout][64], 16-byte slots swizzled -----------
+// dgrad != 0 packs the weights of the data-gradient convolution instead: input/output channels
+// swapped and the taps point-reflected, i.e. Wd[taps-1-tap][co][ci] = W[tap][ci][co].
 __global__ void pack_weights_kernel(const float* __restrict__ w, __bf16* __restrict__ out, int taps, int cin,
-                                    int cout) {
+                                    int cout, int dgrad) {
   const int64_t total = (int64_t)taps * cin * cout;
+  if (dgrad) {
+    const int nchunks = cout >> 6;  // reduction dimension of the dgrad conv = cout
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (int64_t)gridDim.x * blockDim.x) {
+      const int e = (int)(idx & 7);
+      const int ps = (int)((idx >> 3) & 7);
+      int64_t rest = idx >> 6;
+      const int ci = (int)(rest % cin);  // output channel of the dgrad conv
+      rest /= cin;
+      const int chunk = (int)(rest % nchunks);
+      const int tapd = (int)(rest / nchunks);
+      const int s = xv_swz(ci, ps);
+      const int co = chunk * 64 + s * 8 + e;
+      out[idx] = (__bf16)w[((int64_t)(taps - 1 - tapd) * cin + ci) * cout + co];
+    }
+    return;
+  }
   const int nchunks = cin >> 6;
   for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
        idx += (int64_t)gridDim.x * blockDim.x) {
@@ -427,7 +462,8 @@ int pick_cfg(const ConvArgs& a) {
 }
 
 int conv_fwd_impl(const xv_act* x, const void* w_packed, const float* bias, const xv_act* y, const xv_act* pooled,
-                  int k, int relu, int cfg, void* stream) {
+                  int k, int relu, int cfg, void* stream, const __bf16* mask = nullptr,
+                  const __bf16* addend = nullptr) {
   XV_CHECK_ARG(x && x->data && w_packed && bias && y);
   XV_CHECK_ARG(y->data || (pooled && pooled->data));
   XV_CHECK_SHAPE(k == 1 || k == 3);
@@ -440,6 +476,8 @@ int conv_fwd_impl(const xv_act* x, const void* w_packed, const float* bias, cons
   a.bias = bias;
   a.y = (__bf16*)y->data;
   a.pooled = nullptr;
+  a.mask = mask;
+  a.addend = addend;
   a.N = x->n;
   a.H = x->h;
   a.W = x->w;
@@ -472,8 +510,33 @@ extern "C" int xv_pack_conv_weights(const float* w_hwio, void* packed, int k, in
   const int64_t total = (int64_t)k * k * cin * cout;
   const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
   hipLaunchKernelGGL(pack_weights_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w_hwio, (__bf16*)packed,
-                     k * k, cin, cout);
+                     k * k, cin, cout, 0);
   return xv_launch_status();
+}
+
+extern "C" int xv_pack_conv_weights_dgrad(const float* w_hwio, void* packed, int k, int cin, int cout, void* stream) {
+  XV_CHECK_ARG(w_hwio && packed);
+  XV_CHECK_SHAPE((k == 1 || k == 3) && cin > 0 && cout > 0 && (cin & 63) == 0 && (cout & 63) == 0);
+  const int64_t total = (int64_t)k * k * cin * cout;
+  const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+  hipLaunchKernelGGL(pack_weights_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w_hwio, (__bf16*)packed,
+                     k * k, cin, cout, 1);
+  return xv_launch_status();
+}
+
+// dx = (conv(dy, Wd) [+ addend]) masked by relu_ref > 0: Conv2DBackpropInput of tf.layers.conv2d followed by
+// the ReluGrad of the layer below (and the AddN where two gradient paths meet), in the forward kernel.
+extern "C" int xv_conv2d_bwd_data(const xv_act* dy, const void* w_packed_dgrad, const float* zero_bias,
+                                  const xv_act* relu_ref, const xv_act* addend, const xv_act* dx, int k,
+                                  void* stream) {
+  XV_CHECK_ARG(dx && dx->data && zero_bias);
+  if (relu_ref && relu_ref->data)
+    XV_CHECK_SHAPE(relu_ref->n == dx->n && relu_ref->h == dx->h && relu_ref->w == dx->w && relu_ref->c == dx->c);
+  if (addend && addend->data)
+    XV_CHECK_SHAPE(addend->n == dx->n && addend->h == dx->h && addend->w == dx->w && addend->c == dx->c);
+  return conv_fwd_impl(dy, w_packed_dgrad, zero_bias, dx, nullptr, k, 0, -1, stream,
+                       relu_ref ? (const __bf16*)relu_ref->data : nullptr,
+                       addend ? (const __bf16*)addend->data : nullptr);
 }
 
 extern "C" int xv_conv2d_fwd(const xv_act* x, const void* w_packed, const float* bias, const xv_act* y,

@@ -1,0 +1,281 @@
+// Filter gradient of conv2d (3x3 'same' / 1x1) on bf16 MFMA for gfx950.
+//
+// Replaces the Conv2DBackpropFilter ops that tf.train.*Optimizer.minimize adds for every
+// tf.layers.conv2d of the FCN (base_model.py:153-162 over simple_fcn.py:39-79):
+//     dW[tap][cin][cout] = sum_{n,y,x} X[n, y+dy-1, x+dx-1, cin] * dY[n, y, x, cout]
+//
+// GEMM view: M = cin, N = cout, K = pixels.  Both MFMA operands are needed K(=pixel)-major while
+// NHWC memory is channel-major, so the fragments are fetched with the gfx950 transposing LDS read
+// `ds_read_b64_tr_b16` from the same swizzled [pixel][64 ch] LDS images the forward kernel uses:
+// an 8x32-pixel dY tile and the 10x34 halo patch of X (staged once, re-read by all 9 taps).
+// One K-step = 32 consecutive pixels of one image row; the K index <-> pixel map inside a step is
+// permuted (x = 16*g1 + 8*h + 4*g0 + q for lane group g = 2*g1+g0, element j = 4*h+q) so that every
+// 32-lane half of a transposing read touches 8 consecutive pixels = all 64 banks once.
+// A workgroup owns a (64 cin) x (64 cout) block of dW for all taps and a slice of the pixel tiles
+// (split-K); wave w accumulates cin rows [16w, 16w+16) x 64 cout x 9 taps = 144 fp32 registers and
+// finally adds them into dW with fp32 global atomics (run-to-run summation order is not fixed).
+#include "xv_common.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+
+struct WgradArgs {
+  const __bf16* x;
+  const __bf16* dy;
+  float* dw;
+  int N, H, W, Cin, Cout;
+  int tiles_x, tiles_y, n_ptiles, splits;
+};
+
+__device__ inline bf16x8 tr_read2(const char* smem, int addr_lo, int addr_hi) {
+  typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(smem + addr_lo));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(smem + addr_hi));
+  typedef __attribute__((ext_vector_type(8))) short s16x8;
+  const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(bf16x8, v);
+}
+
+template <int KS>
+__global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradArgs a) {
+  constexpr int TH = 8, TW = 32;
+  constexpr int HALO = (KS == 3) ? 1 : 0;
+  constexpr int HH = TH + 2 * HALO, HW = TW + 2 * HALO;
+  constexpr int NPIX = HH * HW;
+  constexpr int X_BYTES = ((NPIX * 128 + 255) / 256) * 256;
+  constexpr int NTAPS = KS * KS;
+  constexpr int X_ITERS = (NPIX * 8 + 255) / 256;
+  constexpr int D_ITERS = TH * TW * 8 / 256;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const Xs = smem;
+  char* const Ds = smem + X_BYTES;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int H = a.H, W = a.W, Cin = a.Cin, Cout = a.Cout;
+  const int Wp = W + 2;
+
+  const int split = blockIdx.x % a.splits;
+  const int pair = blockIdx.x / a.splits;
+  const int n_co = Cout >> 6;
+  const int co0 = (pair % n_co) << 6;
+  const int ci0 = (pair / n_co) << 6;
+  const int per = (a.n_ptiles + a.splits - 1) / a.splits;
+  const int t_begin = split * per;
+  const int t_end = t_begin + per < a.n_ptiles ? t_begin + per : a.n_ptiles;
+
+  // lane roles inside a transposing read (see header): group g = lane>>4, q = row (pixel), p = 4-channel piece
+  const int g = lane >> 4, li = lane & 15, q = li >> 2, p = li & 3;
+  const int xk = 16 * (g >> 1) + 4 * (g & 1) + q;  // pixel column of element j = q (h = 0); h = 1 adds 8
+  int xbase[KS];                                   // X patch: row 0, column xk + dx, this wave's 16 cin
+#pragma unroll
+  for (int dx = 0; dx < KS; ++dx) {
+    const int c = xk + dx;
+    xbase[dx] = c * 128 + (xv_swz(c, wave * 2 + (p >> 1)) << 4) + (p & 1) * 8;
+  }
+  int dbase[4];  // dY tile: row 0, column xk, cout tile n
+#pragma unroll
+  for (int n = 0; n < 4; ++n) dbase[n] = X_BYTES + xk * 128 + (xv_swz(xk, n * 2 + (p >> 1)) << 4) + (p & 1) * 8;
+
+  f32x4 acc[NTAPS][4];
+#pragma unroll
+  for (int t = 0; t < NTAPS; ++t)
+#pragma unroll
+    for (int n = 0; n < 4; ++n) acc[t][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  for (int t = t_begin; t < t_end; ++t) {
+    const int tx = t % a.tiles_x;
+    int r = t / a.tiles_x;
+    const int ty = r % a.tiles_y;
+    const int n = r / a.tiles_y;
+    const int y0 = ty * TH, x0 = tx * TW;
+    const __bf16* ximg = a.x + (int64_t)n * (H + 2) * Wp * Cin + ci0;
+    const __bf16* dimg = a.dy + (int64_t)n * (H + 2) * Wp * Cout + co0;
+    __syncthreads();  // previous tile's fragments are consumed
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {  // two halves: 144 accumulators leave room for ~24 staging registers
+      constexpr int XH = (X_ITERS + 1) / 2;
+      u32x4 v[XH];
+#pragma unroll
+      for (int i2 = 0; i2 < XH; ++i2) {
+        const int it = half * XH + i2;
+        int idx = tid + it * 256;
+        idx = idx < NPIX * 8 ? idx : NPIX * 8 - 1;
+        const int pp = idx >> 3, s = idx & 7;
+        const int hy = pp / HW, hx = pp - hy * HW;
+        int yy = y0 + hy + (1 - HALO), xx = x0 + hx + (1 - HALO);  // padded coords, clamped onto the zero border
+        yy = yy < H + 1 ? yy : H + 1;
+        xx = xx < W + 1 ? xx : W + 1;
+        v[i2] = *reinterpret_cast<const u32x4*>(ximg + ((int64_t)yy * Wp + xx) * Cin + s * 8);
+      }
+#pragma unroll
+      for (int i2 = 0; i2 < XH; ++i2) {
+        const int it = half * XH + i2;
+        const int idx = tid + it * 256;
+        const int pp = idx >> 3, s = idx & 7;
+        const int hx = pp % HW;
+        if (it < X_ITERS && idx < NPIX * 8) *reinterpret_cast<u32x4*>(Xs + pp * 128 + (xv_swz(hx, s) << 4)) = v[i2];
+      }
+    }
+    {
+      u32x4 v[D_ITERS];
+#pragma unroll
+      for (int it = 0; it < D_ITERS; ++it) {
+        const int idx = tid + it * 256;
+        const int pp = idx >> 3, s = idx & 7;
+        const int py = pp / TW, px = pp - py * TW;
+        int yy = y0 + py + 1, xx = x0 + px + 1;
+        yy = yy < H + 1 ? yy : H + 1;  // rows / columns past the image read the zero border: no contribution
+        xx = xx < W + 1 ? xx : W + 1;
+        v[it] = *reinterpret_cast<const u32x4*>(dimg + ((int64_t)yy * Wp + xx) * Cout + s * 8);
+      }
+#pragma unroll
+      for (int it = 0; it < D_ITERS; ++it) {
+        const int idx = tid + it * 256;
+        const int pp = idx >> 3, s = idx & 7;
+        const int px = pp % TW;
+        *reinterpret_cast<u32x4*>(Ds + pp * 128 + (xv_swz(px, s) << 4)) = v[it];
+      }
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int y = 0; y < TH; ++y) {  // rolled: 144 accumulators leave no room for cross-row hoisting
+      const int yd = y * (TW * 128), yx = y * (HW * 128);
+      bf16x8 bfr[4];
+#pragma unroll
+      for (int n4 = 0; n4 < 4; ++n4) bfr[n4] = tr_read2(smem, dbase[n4] + yd, dbase[n4] + yd + 8 * 128);
+#pragma unroll
+      for (int tap = 0; tap < NTAPS; ++tap) {
+        const int dy = (KS == 3) ? tap / 3 : 0;
+        const int dx = (KS == 3) ? tap % 3 : 0;
+        const bf16x8 afr = tr_read2(smem, xbase[dx] + yx + dy * (HW * 128), xbase[dx] + yx + dy * (HW * 128) + 8 * 128);
+#pragma unroll
+        for (int n4 = 0; n4 < 4; ++n4)
+          acc[tap][n4] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr, bfr[n4], acc[tap][n4], 0, 0, 0);
+      }
+    }
+  }
+
+  // accumulator (row = cin = 4*(lane>>4) + r, col = cout = lane & 15) -> dW[tap][cin][cout] (HWIO)
+  const int cin = ci0 + wave * 16 + g * 4;
+  const int cout = co0 + li;
+#pragma unroll
+  for (int tap = 0; tap < NTAPS; ++tap)
+#pragma unroll
+    for (int n4 = 0; n4 < 4; ++n4) {
+      float* dst = a.dw + ((int64_t)tap * Cin + cin) * Cout + cout + n4 * 16;
+      atomicAdd(dst, acc[tap][n4].x);
+      atomicAdd(dst + Cout, acc[tap][n4].y);
+      atomicAdd(dst + 2 * Cout, acc[tap][n4].z);
+      atomicAdd(dst + 3 * Cout, acc[tap][n4].w);
+    }
+}
+
+// db[c] += sum over all pixels of dY[.., c]   (bias gradient; dY border is zero so the padded
+// buffer is summed as a flat [rows][C] matrix)
+__global__ __launch_bounds__(256) void bias_grad_kernel(const __bf16* __restrict__ dy, int64_t rows, int C,
+                                                       float* __restrict__ db) {
+  // thread -> 8-channel group cg = tid % (C/8), row lane = tid / (C/8)
+  const int c8 = C >> 3;
+  const int cg = threadIdx.x % c8;
+  const int rl = threadIdx.x / c8;
+  const int rstep = 256 / c8;
+  float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (int64_t r = (int64_t)blockIdx.x * rstep + rl; r < rows; r += (int64_t)gridDim.x * rstep) {
+    const u32x4 v = *reinterpret_cast<const u32x4*>(dy + r * C + cg * 8);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      s[2 * i] += bf16_bits_to_f32(v[i] & 0xffffu);
+      s[2 * i + 1] += __builtin_bit_cast(float, v[i] & 0xffff0000u);
+    }
+  }
+  __shared__ float red[256 * 8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) red[threadIdx.x * 8 + i] = s[i];
+  __syncthreads();
+  if (rl == 0) {
+    for (int o = 1; o < rstep; ++o)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) s[i] += red[(o * c8 + cg) * 8 + i];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) atomicAdd(db + cg * 8 + i, s[i]);
+  }
+}
+
+}  // namespace
+
+extern "C" int xv_bias_grad(const xv_act* dy, float* dbias, void* stream) {
+  XV_CHECK_ARG(dy && dy->data && dbias);
+  XV_CHECK_SHAPE(dy->c > 0 && (dy->c & 7) == 0 && dy->c <= 2048 && 256 % (dy->c >> 3) == 0);
+  const int64_t rows = (int64_t)dy->n * (dy->h + 2) * (dy->w + 2);
+  int64_t blocks = (rows + 255) / 256;
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(bias_grad_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+                     (const __bf16*)dy->data, rows, dy->c, dbias);
+  return xv_launch_status();
+}
+
+extern "C" int xv_conv2d_bwd_filter(const xv_act* x, const xv_act* dy, float* dw_hwio, float* dbias, int k,
+                                    void* stream) {
+  XV_CHECK_ARG(x && dy && x->data && dy->data && dw_hwio);
+  XV_CHECK_SHAPE(k == 1 || k == 3);
+  XV_CHECK_SHAPE(x->n > 0 && x->h > 0 && x->w > 0 && x->c > 0 && (x->c & 63) == 0 && (dy->c & 63) == 0 && dy->c > 0);
+  XV_CHECK_SHAPE(dy->n == x->n && dy->h == x->h && dy->w == x->w);
+  XV_CHECK_ARG((((uintptr_t)x->data | (uintptr_t)dy->data | (uintptr_t)dw_hwio) & 15) == 0);
+  WgradArgs a{};
+  a.x = (const __bf16*)x->data;
+  a.dy = (const __bf16*)dy->data;
+  a.dw = dw_hwio;
+  a.N = x->n;
+  a.H = x->h;
+  a.W = x->w;
+  a.Cin = x->c;
+  a.Cout = dy->c;
+  a.tiles_x = (a.W + 31) / 32;
+  a.tiles_y = (a.H + 7) / 8;
+  const int64_t ptiles = (int64_t)a.tiles_x * a.tiles_y * a.N;
+  XV_CHECK_SHAPE(ptiles <= 0x7fffffff);
+  a.n_ptiles = (int)ptiles;
+  const int pairs = (a.Cin >> 6) * (a.Cout >> 6);
+  int splits = (3 * xv_num_cus() + pairs - 1) / pairs;  // ~3 workgroups per CU in flight
+  if (splits > a.n_ptiles) splits = a.n_ptiles;
+  if (splits < 1) splits = 1;
+  a.splits = splits;
+  hipStream_t s = (hipStream_t)stream;
+  const unsigned grid = (unsigned)(pairs * splits);
+  if (k == 3) {
+    constexpr int lds = ((10 * 34 * 128 + 255) / 256) * 256 + 8 * 32 * 128;
+    static bool attr = false;
+    if (!attr) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_kernel<3>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+      if (e != hipSuccess) return (int)e;
+      attr = true;
+    }
+    hipLaunchKernelGGL(conv_wgrad_kernel<3>, dim3(grid), dim3(256), lds, s, a);
+  } else {
+    constexpr int lds = 8 * 32 * 128 * 2;
+    static bool attr = false;
+    if (!attr) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_kernel<1>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+      if (e != hipSuccess) return (int)e;
+      attr = true;
+    }
+    hipLaunchKernelGGL(conv_wgrad_kernel<1>, dim3(grid), dim3(256), lds, s, a);
+  }
+  int rc = xv_launch_status();
+  if (rc != XV_OK) return rc;
+  if (dbias) {
+    const int64_t rows = (int64_t)dy->n * (dy->h + 2) * (dy->w + 2);
+    XV_CHECK_SHAPE(dy->c <= 2048 && 256 % (dy->c >> 3) == 0);
+    int64_t blocks = (rows + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(bias_grad_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (const __bf16*)dy->data, rows, dy->c,
+                       dbias);
+    rc = xv_launch_status();
+  }
+  return rc;
+}

@@ -219,3 +219,99 @@ def confusion_matrix(labels, pred, cm):
     _need(cm, torch.int64, 'cm')
     rc = _lib.lib().xv_confusion_matrix(_ptr(labels), _ptr(pred), cm.shape[0], labels.numel(), _ptr(cm), _stream())
     _lib.check(rc, 'xv_confusion_matrix')
+
+
+# ---- training ----------------------------------------------------------------------------------------
+
+def pack_conv_weights_dgrad(w_hwio, out=None):
+    """float32 HWIO device tensor -> packed bf16 weights of the data-gradient convolution."""
+    _need(w_hwio, torch.float32, 'w_hwio')
+    k, _, cin, cout = w_hwio.shape
+    if out is None:
+        out = torch.empty(k * k * cin * cout, dtype=torch.bfloat16, device=w_hwio.device)
+    _lib.check(_lib.lib().xv_pack_conv_weights_dgrad(_ptr(w_hwio), _ptr(out), k, cin, cout, _stream()),
+               'xv_pack_conv_weights_dgrad')
+    return out
+
+
+def pack_conv_weights_into(w_hwio, out):
+    k, _, cin, cout = w_hwio.shape
+    _lib.check(_lib.lib().xv_pack_conv_weights(_ptr(w_hwio), _ptr(out), k, cin, cout, _stream()), 'xv_pack_conv_weights')
+    return out
+
+
+def conv2d_bwd_data(dy, w_packed_dgrad, zero_bias, dx, k, relu_ref=None, addend=None):
+    rc = _lib.lib().xv_conv2d_bwd_data(dy.xv(), _ptr(w_packed_dgrad), _ptr(zero_bias),
+                                      relu_ref.xv() if relu_ref is not None else _NULL_ACT,
+                                      addend.xv() if addend is not None else _NULL_ACT, dx.xv(), k, _stream())
+    _lib.check(rc, 'xv_conv2d_bwd_data')
+    return dx
+
+
+def conv2d_bwd_filter(x, dy, dw, dbias, k):
+    _need(dw, torch.float32, 'dw')
+    _lib.check(_lib.lib().xv_conv2d_bwd_filter(x.xv(), dy.xv(), _ptr(dw), _ptr(dbias), k, _stream()), 'xv_conv2d_bwd_filter')
+
+
+def conv2d_first_bwd_filter(x, dy, dw):
+    _need(x, torch.float32, 'x')
+    n, h, w, cin = x.shape
+    _lib.check(_lib.lib().xv_conv2d_first_bwd_filter(_ptr(x), n, h, w, cin, dy.xv(), _ptr(dw), _stream()),
+               'xv_conv2d_first_bwd_filter')
+
+
+def maxpool2x2_bwd(y, dpooled, dy):
+    _lib.check(_lib.lib().xv_maxpool2x2_bwd(y.xv(), dpooled.xv(), dy.xv(), _stream()), 'xv_maxpool2x2_bwd')
+    return dy
+
+
+def relu_bwd(g, ref, out):
+    _lib.check(_lib.lib().xv_relu_bwd(g.xv(), ref.xv(), out.xv(), _stream()), 'xv_relu_bwd')
+    return out
+
+
+def upsample2x_bwd(dfused, s5, ds5):
+    _lib.check(_lib.lib().xv_upsample2x_bwd(dfused.xv(), s5.xv(), ds5.xv(), _stream()), 'xv_upsample2x_bwd')
+    return ds5
+
+
+def upsample8x_bwd(dup, dfused):
+    _need(dup, torch.bfloat16, 'dup')
+    _lib.check(_lib.lib().xv_upsample8x_bwd(_ptr(dup), dfused.xv(), _stream()), 'xv_upsample8x_bwd')
+    return dfused
+
+
+def count_valid_labels(labels, num_classes, count):
+    _need(labels, torch.int32, 'labels')
+    _need(count, torch.int64, 'count')
+    _lib.check(_lib.lib().xv_count_valid_labels(_ptr(labels), num_classes, labels.numel(), _ptr(count), _stream()),
+               'xv_count_valid_labels')
+
+
+def decoder_head_bwd(fused, w_score, b_score, labels, count, num_classes, loss, dw_score, db_score, dup):
+    _need(labels, torch.int32, 'labels')
+    _need(loss, torch.float64, 'loss')
+    _need(dup, torch.bfloat16, 'dup')
+    rc = _lib.lib().xv_decoder_head_bwd(fused.xv(), _ptr(w_score), _ptr(b_score), _ptr(labels), _ptr(count), num_classes,
+                                       _ptr(loss), _ptr(dw_score), _ptr(db_score), _ptr(dup), _stream())
+    _lib.check(rc, 'xv_decoder_head_bwd')
+
+
+def adam_step(param, grad, m, v, lr_t, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=1.0):
+    _lib.check(_lib.lib().xv_adam_step(_ptr(param), _ptr(grad), _ptr(m), _ptr(v), param.numel(), lr_t, beta1, beta2, eps,
+                                      grad_scale, _stream()), 'xv_adam_step')
+
+
+def rmsprop_step(param, grad, ms, lr, decay=0.9, eps=1e-10, grad_scale=1.0):
+    _lib.check(_lib.lib().xv_rmsprop_step(_ptr(param), _ptr(grad), _ptr(ms), param.numel(), lr, decay, eps, grad_scale,
+                                         _stream()), 'xv_rmsprop_step')
+
+
+def adagrad_step(param, grad, accum, lr, grad_scale=1.0):
+    _lib.check(_lib.lib().xv_adagrad_step(_ptr(param), _ptr(grad), _ptr(accum), param.numel(), lr, grad_scale, _stream()),
+               'xv_adagrad_step')
+
+
+def bias_grad(dy, dbias):
+    _need(dbias, torch.float32, 'dbias')
+    _lib.check(_lib.lib().xv_bias_grad(dy.xv(), _ptr(dbias), _stream()), 'xv_bias_grad')

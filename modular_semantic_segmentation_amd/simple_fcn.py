@@ -35,6 +35,38 @@ class SimpleFCN(BaseModel):
 
     def _variables_changed(self):
         self.engine.load(self.variables)
+        if getattr(self, 'trainer', None) is not None:
+            self.trainer.load_from_variables(variables=self.variables)
+
+    # ---- training (base_model.py:153-162,180-261) ------------------------------------------------------
+    def _ensure_trainer(self):
+        if getattr(self, 'trainer', None) is None:
+            if self.config['batch_normalization']:
+                raise NotImplementedError('training with batch normalization is not built on this path')
+            from .trainer import FcnTrainer
+            from .parallel import GradReducer, world
+            self.trainer = FcnTrainer(self.engine, self.config.get('trainer', 'adam'),
+                                      self.config.get('learning_rate', 0.0001))
+            self.trainer.load_from_variables(variables=self.variables)
+            self._reducer = GradReducer(self.device) if world()[1] > 1 else None
+        return self.trainer
+
+    def _train_batch(self, batch):
+        tr = self._ensure_trainer()
+        x = self._to_device(batch[self.modality], torch.float32)
+        labels = self._to_device(batch['labels'], torch.int32)
+        self.loss = tr.step(x, labels, reducer=self._reducer)
+        self._dirty = True
+        return self.loss.item() if self.config.get('sync_loss', True) else 0.0
+
+    def _sync_variables(self):
+        if getattr(self, 'trainer', None) is not None and getattr(self, '_dirty', False):
+            self.trainer.to_variables(self.variables)
+            self._dirty = False
+
+    def export_weights(self, save_dir=None):
+        self._sync_variables()
+        return BaseModel.export_weights(self, save_dir)
 
     def _predict_batch(self, batch, output_attr=None):
         x = self._to_device(batch[self.modality], torch.float32)

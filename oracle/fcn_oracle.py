@@ -248,3 +248,71 @@ def depthwise_bilinear_up(x, stride, relu=False):
 
     y = up_axis(up_axis(x.astype(np.float64), 1), 2)
     return np.maximum(y, 0) if relu else y
+
+
+# ---------------------------------------------------------------------------------------
+# training step oracle: loss of SimpleFCN._build_graph (simple_fcn.py:200-214) and its
+# gradients by PyTorch-CPU autograd over the same functional graph (fp32).
+# ---------------------------------------------------------------------------------------
+
+class _RoundBf16STE(torch.autograd.Function):
+    """bf16 rounding in the forward pass, identity in the backward pass."""
+
+    @staticmethod
+    def forward(ctx, t):
+        return t.bfloat16().float()
+
+    @staticmethod
+    def backward(ctx, g):
+        return g
+
+
+def fcn_loss_and_grads(x_nhwc, labels, weights, prefix, num_classes, policy='fp32'):
+    """Returns (loss, {variable name: gradient ndarray}) for the trainable variables
+    (kernels + biases of the 13 convs, the two score convs and `score`; the deconv
+    constants are not trainable, simple_fcn.py:80-83,117-119).  policy='bf16' rounds the
+    forward activations / conv weights where the MI355X path does (straight-through), so that
+    relu masks and max-pool routing are those of the bf16 forward pass."""
+    params = {}
+    rnd = (lambda t: t) if policy == 'fp32' else _RoundBf16STE.apply
+
+    def P(name):
+        t = _t(weights[name]).clone().requires_grad_(True)
+        params[name] = t
+        return t
+
+    def conv(h, layer, relu):
+        w = P('%s/%s/kernel' % (prefix, layer))
+        b = P('%s/%s/bias' % (prefix, layer))
+        k = w.shape[0]
+        wq = w if layer in ('conv1_1', 'score') else rnd(w)
+        y = F.conv2d(h, wq.permute(3, 2, 0, 1), b, padding=(k - 1) // 2)
+        y = F.relu(y) if relu else y
+        return y if layer == 'score' else rnd(y)
+
+    def deconv(h, layer, stride):
+        w = _t(weights['%s/%s/kernel' % (prefix, layer)])
+        k = w.shape[0]
+        return F.relu(F.conv_transpose2d(h, w.permute(3, 2, 0, 1).contiguous(), stride=stride,
+                                         padding=(k - stride) // 2))
+
+    h = _t(np.asarray(x_nhwc, np.float32)).permute(0, 3, 1, 2).contiguous()
+    layers = {}
+    for item in ENCODER_CONVS:
+        if isinstance(item, str):
+            h = F.max_pool2d(h, 2, 2)
+        else:
+            h = conv(h, item[0], True)
+        layers[item if isinstance(item, str) else item[0]] = h
+    s4 = conv(layers['conv4_3'], 'score_conv4', True)
+    s5 = conv(layers['conv5_3'], 'score_conv5', True)
+    fused = rnd(s4 + deconv(s5, 'upscore_conv5', 2))
+    up = deconv(fused, 'upscore', 8)
+    score = conv(up, 'score', False).permute(0, 2, 3, 1)
+    logp = F.log_softmax(score, dim=-1)
+    lab = _t(np.asarray(labels).astype(np.int64))
+    valid = (lab >= 0) & (lab < num_classes)
+    onehot = F.one_hot(lab.clamp(0, num_classes - 1), num_classes).float() * valid[..., None].float()
+    loss = -(onehot * logp).sum() / (1e-20 + onehot.sum())          # utils.py:43-53
+    loss.backward()
+    return float(loss.detach()), {k: v.grad.numpy() for k, v in params.items()}

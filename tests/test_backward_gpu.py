@@ -1,0 +1,270 @@
+"""Parity of the backward kernels and of a full training step against PyTorch-CPU autograd over the
+oracle's restatement of the training graph (simple_fcn.py:200-214, utils.py:43-53)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from oracle import fcn_oracle as fo
+from oracle import fusion_oracle as fu
+
+
+@pytest.fixture(scope='module')
+def ops():
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU')
+    from modular_semantic_segmentation_amd import ops as _ops
+    return _ops
+
+
+def _dev(a, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a))
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.cuda()
+
+
+def _nchw(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).permute(0, 3, 1, 2).contiguous()
+
+
+def _nhwc(t):
+    return t.permute(0, 2, 3, 1).contiguous().numpy()
+
+
+@pytest.mark.parametrize('n,h,w,cin,cout,k', [(2, 16, 32, 64, 64, 3), (1, 24, 40, 128, 64, 3), (2, 6, 10, 64, 128, 3),
+                                              (1, 20, 36, 128, 64, 1), (3, 8, 8, 512, 64, 1)])
+def test_conv_filter_and_bias_gradient_exact_on_integers(ops, n, h, w, cin, cout, k):
+    rng = np.random.default_rng(cin + cout + h)
+    x = rng.integers(-2, 3, (n, h, w, cin)).astype(np.float32)
+    dy = rng.integers(-1, 2, (n, h, w, cout)).astype(np.float32)
+    dw = torch.zeros((k, k, cin, cout), device='cuda')
+    db = torch.zeros(cout, device='cuda')
+    ops.conv2d_bwd_filter(ops.Act.from_dense(_dev(x)), ops.Act.from_dense(_dev(dy)), dw, db, k)
+    torch.cuda.synchronize()
+    wt = torch.zeros((cout, cin, k, k), requires_grad=True)
+    b = torch.zeros(cout, requires_grad=True)
+    F.conv2d(_nchw(x), wt, b, padding=(k - 1) // 2).backward(_nchw(dy))
+    ref = wt.grad.permute(2, 3, 1, 0).numpy()              # -> HWIO
+    assert np.array_equal(dw.cpu().numpy(), ref)
+    assert np.array_equal(db.cpu().numpy(), b.grad.numpy())
+
+
+@pytest.mark.parametrize('k', [3, 1])
+def test_conv_data_gradient_with_relu_mask_and_addend(ops, k):
+    rng = np.random.default_rng(k)
+    n, h, w, cin, cout = 2, 24, 40, 128, 64
+    wt = rng.integers(-1, 2, (k, k, cin, cout)).astype(np.float32)
+    dy = rng.integers(-2, 3, (n, h, w, cout)).astype(np.float32)
+    ref_act = rng.integers(-1, 3, (n, h, w, cin)).astype(np.float32)     # forward output of the layer below
+    add = rng.integers(-3, 4, (n, h, w, cin)).astype(np.float32)
+    wd = ops.pack_conv_weights_dgrad(_dev(wt))
+    dx = ops.Act(n, h, w, cin)
+    ops.conv2d_bwd_data(ops.Act.from_dense(_dev(dy)), wd, torch.zeros(cin, device='cuda'), dx, k,
+                        relu_ref=ops.Act.from_dense(_dev(ref_act)), addend=ops.Act.from_dense(_dev(add)))
+    torch.cuda.synchronize()
+    xin = torch.zeros((n, cin, h, w), requires_grad=True)
+    F.conv2d(xin, torch.from_numpy(wt).permute(3, 2, 0, 1), padding=(k - 1) // 2).backward(_nchw(dy))
+    ref = fo.round_bf16((_nhwc(xin.grad) + add) * (ref_act > 0))
+    assert np.array_equal(dx.interior().float().cpu().numpy(), ref)
+
+
+def test_maxpool_relu_backward_with_ties(ops):
+    rng = np.random.default_rng(1)
+    n, h, w, c = 2, 12, 20, 64
+    y = rng.integers(0, 3, (n, h, w, c)).astype(np.float32)          # many ties, many zeros
+    dp = rng.integers(-4, 5, (n, h // 2, w // 2, c)).astype(np.float32)
+    dy = ops.Act(n, h, w, c)
+    ops.maxpool2x2_bwd(ops.Act.from_dense(_dev(y)), ops.Act.from_dense(_dev(dp)), dy)
+    torch.cuda.synchronize()
+    yt = _nchw(y).requires_grad_(True)
+    F.max_pool2d(yt, 2, 2).backward(_nchw(dp))
+    ref = _nhwc(yt.grad) * (y > 0)
+    assert np.array_equal(dy.interior().float().cpu().numpy(), ref)
+
+
+def test_relu_backward(ops):
+    rng = np.random.default_rng(2)
+    g = fo.round_bf16(rng.standard_normal((1, 5, 7, 64)).astype(np.float32))
+    ref_act = rng.integers(-1, 2, (1, 5, 7, 64)).astype(np.float32)
+    out = ops.Act(1, 5, 7, 64)
+    ops.relu_bwd(ops.Act.from_dense(_dev(g)), ops.Act.from_dense(_dev(ref_act)), out)
+    torch.cuda.synchronize()
+    assert np.array_equal(out.interior().float().cpu().numpy(), g * (ref_act > 0))
+
+
+def test_upsample2x_backward(ops):
+    rng = np.random.default_rng(3)
+    n, h, w, c = 2, 5, 7, 64
+    s5 = fo.round_bf16(np.maximum(rng.standard_normal((n, h, w, c)), 0).astype(np.float32))
+    df = fo.round_bf16(rng.standard_normal((n, 2 * h, 2 * w, c)).astype(np.float32))
+    ds5 = ops.Act(n, h, w, c)
+    ops.upsample2x_bwd(ops.Act.from_dense(_dev(df)), ops.Act.from_dense(_dev(s5)), ds5)
+    torch.cuda.synchronize()
+    st = _nchw(s5).requires_grad_(True)
+    wk = torch.from_numpy(fo.bilinear_kernel(4, c)).permute(3, 2, 0, 1).contiguous()
+    F.relu(F.conv_transpose2d(st, wk, stride=2, padding=1)).backward(_nchw(df))
+    ref = _nhwc(st.grad) * (s5 > 0)
+    got = ds5.interior().float().cpu().numpy()
+    np.testing.assert_allclose(got, ref, rtol=2 ** -7, atol=1e-6)
+
+
+def test_upsample8x_backward(ops):
+    rng = np.random.default_rng(4)
+    n, h, w, c = 1, 3, 4, 64
+    dup = fo.round_bf16(rng.standard_normal((n, 8 * h, 8 * w, c)).astype(np.float32))
+    df = ops.Act(n, h, w, c)
+    ops.upsample8x_bwd(_dev(dup, torch.bfloat16), df)
+    torch.cuda.synchronize()
+    ft = torch.zeros((n, c, h, w), requires_grad=True)
+    wk = torch.from_numpy(fo.bilinear_kernel(16, c)).permute(3, 2, 0, 1).contiguous()
+    F.conv_transpose2d(ft, wk, stride=8, padding=4).backward(_nchw(dup))
+    np.testing.assert_allclose(df.interior().float().cpu().numpy(), _nhwc(ft.grad), rtol=2 ** -7, atol=1e-5)
+
+
+@pytest.mark.parametrize('C', [12, 5])
+def test_head_backward_loss_and_gradients(ops, C):
+    rng = np.random.default_rng(C)
+    n, h, w, U = 2, 3, 5, 64
+    f = fo.round_bf16(np.abs(rng.standard_normal((n, h, w, U))).astype(np.float32))
+    ws = (rng.standard_normal((U, C)) * 0.3).astype(np.float32)
+    bs = rng.standard_normal(C).astype(np.float32)
+    lab = rng.integers(-1, C, (n, 8 * h, 8 * w)).astype(np.int32)
+    count = torch.zeros(1, dtype=torch.int64, device='cuda')
+    ops.count_valid_labels(_dev(lab), C, count)
+    loss = torch.zeros(1, dtype=torch.float64, device='cuda')
+    dws = torch.zeros((U, C), device='cuda')
+    dbs = torch.zeros(C, device='cuda')
+    dup = torch.zeros((n, 8 * h, 8 * w, U), dtype=torch.bfloat16, device='cuda')
+    ops.decoder_head_bwd(ops.Act.from_dense(_dev(f)), _dev(ws), _dev(bs), _dev(lab), count, C, loss, dws, dbs, dup)
+    torch.cuda.synchronize()
+    assert count.item() == (lab >= 0).sum()
+    ft = _nchw(f)
+    wk = torch.from_numpy(fo.bilinear_kernel(16, U)).permute(3, 2, 0, 1).contiguous()
+    pre = F.conv_transpose2d(ft, wk, stride=8, padding=4).requires_grad_(True)
+    wst = torch.from_numpy(ws).requires_grad_(True)
+    bst = torch.from_numpy(bs).requires_grad_(True)
+    score = F.relu(pre).permute(0, 2, 3, 1) @ wst + bst
+    logp = F.log_softmax(score, -1)
+    labt = torch.from_numpy(lab.astype(np.int64))
+    valid = labt >= 0
+    onehot = F.one_hot(labt.clamp(0), C).float() * valid[..., None]
+    ref_loss = -(onehot * logp).sum() / (1e-20 + onehot.sum())
+    ref_loss.backward()
+    assert abs(loss.item() - ref_loss.item()) < 1e-5 * max(1.0, abs(ref_loss.item()))
+    np.testing.assert_allclose(dws.cpu().numpy(), wst.grad.numpy(), rtol=1e-3, atol=1e-6)
+    np.testing.assert_allclose(dbs.cpu().numpy(), bst.grad.numpy(), rtol=1e-3, atol=1e-7)
+    ref_dup = _nhwc(pre.grad)
+    scale = np.abs(ref_dup).max()
+    np.testing.assert_allclose(dup.float().cpu().numpy(), ref_dup, rtol=2 ** -7, atol=1e-3 * scale)
+
+
+@pytest.mark.parametrize('cin', [1, 3])
+def test_first_layer_filter_gradient(ops, cin):
+    rng = np.random.default_rng(cin)
+    n, h, w = 2, 12, 20
+    x = rng.integers(0, 256, (n, h, w, cin)).astype(np.float32)
+    dy = fo.round_bf16(rng.standard_normal((n, h, w, 64)).astype(np.float32))
+    dw = torch.zeros((3, 3, cin, 64), device='cuda')
+    db = torch.zeros(64, device='cuda')
+    dya = ops.Act.from_dense(_dev(dy))
+    ops.conv2d_first_bwd_filter(_dev(x), dya, dw)
+    ops.bias_grad(dya, db)
+    torch.cuda.synchronize()
+    wt = torch.zeros((64, cin, 3, 3), requires_grad=True)
+    b = torch.zeros(64, requires_grad=True)
+    F.conv2d(_nchw(x), wt, b, padding=1).backward(_nchw(dy))
+    ref = wt.grad.permute(2, 3, 1, 0).numpy()
+    np.testing.assert_allclose(dw.cpu().numpy(), ref, rtol=1e-4, atol=1e-2)
+    np.testing.assert_allclose(db.cpu().numpy(), b.grad.numpy(), rtol=1e-4, atol=1e-4)
+
+
+def test_optimizers_match_tf1_formulas(ops):
+    rng = np.random.default_rng(0)
+    p0 = rng.standard_normal(1000).astype(np.float32)
+    g = rng.standard_normal(1000).astype(np.float32)
+    p, m, v = _dev(p0), torch.zeros(1000, device='cuda'), torch.zeros(1000, device='cuda')
+    pr, mr, vr = p0.astype(np.float64), np.zeros(1000), np.zeros(1000)
+    for t in (1, 2, 3):
+        lr_t = 1e-2 * np.sqrt(1 - 0.999 ** t) / (1 - 0.9 ** t)
+        ops.adam_step(p, _dev(g), m, v, float(lr_t))
+        pr, mr, vr = fu.adam_step(pr, g.astype(np.float64), mr, vr, t, lr=1e-2)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(p.cpu().numpy(), pr, rtol=1e-5, atol=1e-6)
+    p, ms = _dev(p0), torch.ones(1000, device='cuda')
+    ops.rmsprop_step(p, _dev(g), ms, 1e-2)
+    ref, _ = fu.rmsprop_step(p0.astype(np.float64), g.astype(np.float64), np.ones(1000), lr=1e-2)
+    np.testing.assert_allclose(p.cpu().numpy(), ref, rtol=1e-5, atol=1e-6)
+    p, acc = _dev(p0), torch.full((1000,), 0.1, device='cuda')
+    ops.adagrad_step(p, _dev(g), acc, 1e-2, grad_scale=0.5)
+    ref, _ = fu.adagrad_step(p0.astype(np.float64), 0.5 * g.astype(np.float64), np.full(1000, 0.1), lr=1e-2)
+    np.testing.assert_allclose(p.cpu().numpy(), ref, rtol=1e-5, atol=1e-6)
+
+
+def _rel(a, b):
+    return np.linalg.norm(a.astype(np.float64) - b) / (np.linalg.norm(b) + 1e-30)
+
+
+def test_training_step_gradients_and_fit(ops, tmp_path):
+    from modular_semantic_segmentation_amd import get_model
+    C, U, H, W = 12, 64, 32, 48
+    rng = np.random.default_rng(0)
+    data = {'rgb': rng.integers(0, 256, (2, H, W, 3)).astype(np.float32),
+            'labels': rng.integers(-1, C, (2, H, W)).astype(np.int32)}
+    w = fo.init_fcn_weights('rgb', 3, U, C, seed=1, bias_scale=0.02)
+    w['rgb/conv1_1/kernel'] *= 0.02
+    for k in w:
+        if k.endswith('/kernel') and 'upscore' not in k and 'conv1_1' not in k:
+            w[k] *= 1.6
+    path = str(tmp_path / 'w.npz')
+    np.savez(path, **w)
+    desc = ({'rgb': 'float32', 'labels': 'int32'}, {'rgb': (None, None, 3), 'labels': (None, None)}, C)
+    net = get_model('fcn')('rgb', desc, 'rgb', output_dir=str(tmp_path), num_units=U, batch_normalization=False,
+                           batchsize=2, learning_rate=1e-3, trainer='adam')
+    net.import_weights(path, warnings=False)
+    tr = net._ensure_trainer()
+    loss = tr.step(_dev(data['rgb']), _dev(data['labels']))
+    torch.cuda.synchronize()
+    got = tr.grads_as_variables()
+    # (1) against autograd over the bf16-policy forward (same relu masks / pool routing): the only
+    # difference left is bf16 rounding of the activation gradients and summation order
+    ref_loss, ref_g = fo.fcn_loss_and_grads(data['rgb'], data['labels'], w, 'rgb', C, policy='bf16')
+    assert abs(loss.item() - ref_loss) < 2e-3 * abs(ref_loss)
+    err16 = {name: _rel(got[name], g) for name, g in ref_g.items()}
+    # (2) against the fp32 graph the reference differentiates: bf16 storage noise accumulates down the
+    # 16-layer backward chain (relu masks / pool arg-maxes flip on near-ties)
+    _, ref_g32 = fo.fcn_loss_and_grads(data['rgb'], data['labels'], w, 'rgb', C, policy='fp32')
+    err32 = {name: _rel(got[name], g) for name, g in ref_g32.items()}
+    print('relative gradient error vs bf16-policy / fp32 oracle:')
+    for name in ref_g:
+        print('  %-28s %.4f %.4f' % (name, err16[name], err32[name]))
+    # Measured on MI355X: 0.2-0.5 % at the head, growing to 5-8 % at the far end of the chain.  The growth
+    # is conditioning, not a defect: activation gradients have mixed signs, so every transposed-conv /
+    # pooling sum cancels and amplifies the 2^-9 relative rounding of the bf16 gradient tensors (each
+    # kernel alone is exact or within bf16 rounding in the tests above).
+    assert max(err16.values()) < 0.10, err16
+    assert max(v for k, v in err16.items() if k.split('/')[1] in ('score', 'score_conv4')) < 0.01, err16
+    assert max(err32.values()) < 0.2, err32
+    for name, g in ref_g32.items():
+        a, b = got[name].ravel().astype(np.float64), g.ravel().astype(np.float64)
+        assert a @ b / (np.linalg.norm(a) * np.linalg.norm(b)) > 0.99, name
+    # Adam's first step moves every weight by ~lr against the sign of its gradient (TF1 formula)
+    net2 = dict(net.variables)
+    tr.to_variables(net2)
+    k = 'rgb/conv3_2/kernel'
+    moved = net2[k] - w[k]
+    big = np.abs(got[k]) > 1e-3 * np.abs(got[k]).max()
+    assert (np.sign(moved[big]) == -np.sign(got[k][big])).mean() > 0.999
+    # |step| = lr * |g| / (|g| + eps * sqrt(1 - beta2) ... ) -> lr for all but vanishing gradients
+    assert (np.abs(np.abs(moved[big]) - 1e-3) < 5e-5).mean() > 0.999
+    # fit() runs and lowers the loss on a fixed batch
+    first = net._train_batch(data)
+    for _ in range(8):
+        last = net._train_batch(data)
+    assert last < first
+    net.fit(data, 2, output=False)
+    assert net.global_step == 2
+    out = net.export_weights()
+    assert np.load(out)['rgb/conv1_1/kernel'].shape == (3, 3, 3, 64)

@@ -65,3 +65,30 @@ def test_shard_range_is_a_partition():
                 b, e = parallel.shard_range(n, r, size)
                 cover += list(range(b, e))
             assert cover == list(range(n))
+
+
+def _grad_worker(rank, size, port, out):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=size)
+    from modular_semantic_segmentation_amd import parallel
+    rng = np.random.default_rng(100 + rank)
+    flat = torch.from_numpy(rng.standard_normal(1000).astype(np.float32))
+    count = torch.tensor([10 + rank], dtype=torch.int64)
+    red = parallel.GradReducer('cpu')
+    red.allreduce_now(count)
+    for rng_ in ((0, 300), (300, 640), (640, 1000)):       # buckets become ready one after the other
+        red.launch(flat, rng_)
+    red.wait()
+    if rank == 0:
+        np.savez(out, flat=flat.numpy(), count=count.numpy())
+    dist.destroy_process_group()
+
+
+def test_bucketed_gradient_allreduce(tmp_path):
+    out = str(tmp_path / 'g.npz')
+    mp.spawn(_grad_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    got = np.load(out)
+    ref = sum(np.random.default_rng(100 + r).standard_normal(1000).astype(np.float32) for r in range(2))
+    np.testing.assert_allclose(got['flat'], ref, rtol=1e-6)
+    assert got['count'][0] == 21
