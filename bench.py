@@ -85,6 +85,52 @@ def cpu_baseline(args, variables, cms):
                       '%.1f s' % (n, args.width, args.height, dt)}
 
 
+def bench_train(args, device, world, rank, dist):
+    """Data-parallel expert training: every rank differentiates its own images, gradients are
+    all-reduced in three buckets on a side stream during backward (RCCL over xGMI)."""
+    from modular_semantic_segmentation_amd import get_model
+    desc = ({'rgb': 'float32', 'labels': 'int32'}, {'rgb': (None, None, 3), 'labels': (None, None)}, C)
+    net = get_model('fcn')('rgb', desc, 'rgb', num_units=U, batch_normalization=False, batchsize=args.batch,
+                           learning_rate=1e-4, trainer='adam', seed=1, device=str(device), sync_loss=False)
+    gen = torch.Generator(device='cpu').manual_seed(99 + rank)
+    rgb = torch.randint(0, 256, (args.batch, args.height, args.width, 3), generator=gen).float().to(device)
+    labels = torch.randint(-1, C, (args.batch, args.height, args.width), generator=gen).int().to(device)
+    batch = {'rgb': rgb, 'labels': labels}
+    for _ in range(args.warmup):
+        net._train_batch(batch)
+
+    def fence():
+        torch.cuda.synchronize(device)
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize(device)
+
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        net._train_batch(batch)
+    fence()
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+    if rank == 0:
+        images = args.batch * world * args.steps
+        flops = 3.0 * conv_flops_per_image(args.height, args.width, 3)
+        print(json.dumps({
+            'metric': 'images/sec, SimpleFCN RGB expert training step (fwd + bwd + Adam) at 768x384',
+            'value': round(images / dt, 2), 'unit': 'images/s', 'n_gpus': world, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True,
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
+            'config': {'workload': 'SimpleFCN RGB %dx%d training, U=%d, C=%d, Adam' % (args.width, args.height, U, C),
+                       'images_per_gpu_per_step': args.batch, 'global_batch': args.batch * world,
+                       'parallelism': 'dp%d, 3-bucket gradient all-reduce overlapped with backward' % world},
+            'conv_tflops_end_to_end': round(images * flops / dt / 1e12, 2)}))
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -94,6 +140,8 @@ def main():
     ap.add_argument('--height', type=int, default=384)
     ap.add_argument('--width', type=int, default=768)
     ap.add_argument('--fusion', default='bayes', choices=['bayes', 'dirichlet'])
+    ap.add_argument('--mode', default='infer', choices=['infer', 'train'],
+                    help="'infer' (headline): two experts + fusion; 'train': one SimpleFCN training step (fwd+bwd+Adam)")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--serial-experts', action='store_true',
                     help='run the RGB and depth experts back to back on one stream (profiling: per-kernel times)')
@@ -111,6 +159,8 @@ def main():
     torch.cuda.set_device(device)
 
     from modular_semantic_segmentation_amd import ops
+    if args.mode == 'train':
+        return bench_train(args, device, world, rank, dist)
     net = build_model(args, device)
     gen = torch.Generator(device='cpu').manual_seed(1234 + rank)
     rgb = torch.randint(0, 256, (args.batch, args.height, args.width, 3), generator=gen).float().to(device)

@@ -24,6 +24,7 @@ struct WgradArgs {
   const __bf16* x;
   const __bf16* dy;
   float* dw;
+  float* db;  // may be null; accumulated by the workgroups of input-channel block 0 from their dY tiles
   int N, H, W, Cin, Cout;
   int tiles_x, tiles_y, n_ptiles, splits;
 };
@@ -84,6 +85,9 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradArgs a) {
   for (int t = 0; t < NTAPS; ++t)
 #pragma unroll
     for (int n = 0; n < 4; ++n) acc[t][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // BiasAddGrad rides along: thread (cout = tid & 63, pixel quarter = tid >> 6) sums the staged dY tile
+  const bool do_bias = a.db != nullptr && ci0 == 0;
+  float bsum = 0.f;
 
   for (int t = t_begin; t < t_end; ++t) {
     const int tx = t % a.tiles_x;
@@ -140,6 +144,15 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradArgs a) {
       }
     }
     __syncthreads();
+    if (do_bias) {
+      const int co = tid & 63, qtr = tid >> 6;
+      const int slot = co >> 3, e = co & 7;
+#pragma unroll 4
+      for (int pp = qtr * 64; pp < qtr * 64 + 64; ++pp) {
+        const int px = pp & (TW - 1);
+        bsum += (float)*reinterpret_cast<const __bf16*>(Ds + pp * 128 + (xv_swz(px, slot) << 4) + e * 2);
+      }
+    }
 #pragma unroll 1
     for (int y = 0; y < TH; ++y) {  // rolled: 144 accumulators leave no room for cross-row hoisting
       const int yd = y * (TW * 128), yx = y * (HW * 128);
@@ -158,6 +171,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradArgs a) {
     }
   }
 
+  if (do_bias) atomicAdd(a.db + co0 + (tid & 63), bsum);
   // accumulator (row = cin = 4*(lane>>4) + r, col = cout = lane & 15) -> dW[tap][cin][cout] (HWIO)
   const int cin = ci0 + wave * 16 + g * 4;
   const int cout = co0 + li;
@@ -228,6 +242,7 @@ extern "C" int xv_conv2d_bwd_filter(const xv_act* x, const xv_act* dy, float* dw
   a.x = (const __bf16*)x->data;
   a.dy = (const __bf16*)dy->data;
   a.dw = dw_hwio;
+  a.db = dbias;
   a.N = x->n;
   a.H = x->h;
   a.W = x->w;
@@ -266,16 +281,5 @@ extern "C" int xv_conv2d_bwd_filter(const xv_act* x, const xv_act* dy, float* dw
     }
     hipLaunchKernelGGL(conv_wgrad_kernel<1>, dim3(grid), dim3(256), lds, s, a);
   }
-  int rc = xv_launch_status();
-  if (rc != XV_OK) return rc;
-  if (dbias) {
-    const int64_t rows = (int64_t)dy->n * (dy->h + 2) * (dy->w + 2);
-    XV_CHECK_SHAPE(dy->c <= 2048 && 256 % (dy->c >> 3) == 0);
-    int64_t blocks = (rows + 255) / 256;
-    if (blocks > 1024) blocks = 1024;
-    hipLaunchKernelGGL(bias_grad_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (const __bf16*)dy->data, rows, dy->c,
-                       dbias);
-    rc = xv_launch_status();
-  }
-  return rc;
+  return xv_launch_status();
 }
