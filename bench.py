@@ -61,7 +61,21 @@ def cpu_baseline(args, variables, cms):
     on a bounded sample of the same workload: whole 768x384 RGB-D images, one at a time."""
     from oracle import fcn_oracle as fo
     from oracle import fusion_oracle as fu
-    cores = os.cpu_count() or 1
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    # pick the thread count that runs a mid-network conv fastest (all logical CPUs is not it on a big host)
+    probe_x = torch.randn(1, 256, args.height // 4, args.width // 4)
+    probe_w = torch.randn(256, 256, 3, 3)
+    best = (None, 1)
+    for nthr in sorted({min(avail, c) for c in (8, 16, 32, 64, 128)}):
+        torch.set_num_threads(nthr)
+        torch.nn.functional.conv2d(probe_x, probe_w, padding=1)
+        t0 = time.perf_counter()
+        for _ in range(3):
+            torch.nn.functional.conv2d(probe_x, probe_w, padding=1)
+        dtp = time.perf_counter() - t0
+        if best[0] is None or dtp < best[0]:
+            best = (dtp, nthr)
+    cores = best[1]
     torch.set_num_threads(cores)
     rng = np.random.default_rng(0)
     mats = [cms['rgb'].astype('float32').T, cms['depth'].astype('float32').T]
@@ -76,13 +90,14 @@ def cpu_baseline(args, variables, cms):
     one()                                    # warm-up
     t0 = time.perf_counter()
     n = 0
-    while n < 5 and (time.perf_counter() - t0) < 20.0:
+    while n < 64 and (time.perf_counter() - t0) < 12.0:
         one()
         n += 1
     dt = time.perf_counter() - t0
     return {'value': n / dt, 'unit': 'images/s', 'cores': cores, 'kind': 'port',
             'sample': '%d RGB-D images of %dx%d, batch 1, fp32 PyTorch-CPU oracle (two FCN experts + Bayes fusion), '
-                      '%.1f s' % (n, args.width, args.height, dt)}
+                      '%.1f s, %d threads (fastest of a probe; %d logical CPUs available)'
+                      % (n, args.width, args.height, dt, cores, avail)}
 
 
 def bench_train(args, device, world, rank, dist):
