@@ -16,6 +16,10 @@
 
 #include "xv_common.h"
 
+#ifndef XV_CONV_PFD
+#define XV_CONV_PFD 2
+#endif
+
 namespace {
 
 struct ConvArgs {
@@ -65,6 +69,7 @@ template <int MT, int WR, int WC, int NW, int KS, int OCC, int TPS>
 __global__ __launch_bounds__(64 * WR * WC * NW, OCC * 4 / (WR * WC * NW) > 0 ? OCC * 4 / (WR * WC * NW) : 1) void conv_mfma_kernel(ConvArgs a) {
   using C = ConvCfg<MT, WR, WC, NW, KS, TPS>;
   constexpr bool PFA = (MT == 4) || (OCC == 1);
+  constexpr int PFD = XV_CONV_PFD;  // how many stages before the end of an item its successor's patch is requested
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const As = smem;
   char* const Bs = smem + C::A_BYTES;
@@ -218,10 +223,14 @@ __global__ __launch_bounds__(64 * WR * WC * NW, OCC * 4 / (WR * WC * NW) > 0 ? O
 #pragma unroll
     for (int st = 0; st < C::NST; ++st) {
       const int cb = (st & 1) * (C::TPS * C::B_BYTES);
+      // the next work item's patch is requested PFD stages before the end of this one (its HBM/L2 latency
+      // must be covered by MFMA work: one stage is only ~1-2k cycles), its first weight tile in the last stage
+      if constexpr (PFA) {
+        if (st == (C::NST - 1 - PFD > 0 ? C::NST - 1 - PFD : 0) && has_next) a_load(nxt, nchunk, areg, I0, IN);
+      }
       if (st + 1 < C::NST) {
         b_load(cur.co0, st + 1, chunk, breg);
       } else if (has_next) {
-        if constexpr (PFA) a_load(nxt, nchunk, areg, I0, IN);
         b_load(nxt.co0, 0, nchunk, breg);
       }
 #pragma unroll

@@ -8,6 +8,41 @@ from .base_model import BaseModel
 from .fcn import FcnEngine, init_variables  # noqa: F401  (fcn-level API re-exported for callers)
 
 
+_ENGINES = {}
+
+
+def _engine_for(prefix, inputs, num_units, num_classes, variables):
+    """Functional entry points cache one engine per (prefix, shape, weights object), like
+    tf.variable_scope(prefix, reuse=tf.AUTO_REUSE) shares variables between calls (simple_fcn.py:11)."""
+    key = (prefix, int(inputs.shape[-1]), int(num_units), int(num_classes), id(variables))
+    eng = _ENGINES.get(key)
+    if eng is None:
+        if variables is None:
+            variables = init_variables(prefix, int(inputs.shape[-1]), num_units, num_classes)
+        eng = FcnEngine(prefix, int(inputs.shape[-1]), num_units, num_classes, variables, device=inputs.device)
+        _ENGINES[key] = eng
+    return eng
+
+
+def encoder(inputs, prefix, num_units, variables=None, num_classes=2, **unused):
+    """Functional form of simple_fcn.py:10-87: dict of layer outputs (ops.Act, bf16 padded NHWC), the
+    encoding has key 'fused'.  inputs: float32 CUDA tensor [N,H,W,C_in]; variables: reference-schema dict
+    (default: fresh [TF1] initialisers).  trainable / batchnorm / dropout arguments of the reference are
+    accepted and ignored (inference graph, BN folded at load time)."""
+    return _engine_for(prefix, inputs, num_units, num_classes, variables).encoder(inputs, keep_all=True)
+
+
+def fcn(inputs, prefix, num_units, num_classes, variables=None, **unused):
+    """Functional form of simple_fcn.py:137-170 as experiments/timing.py uses it: all encoder layers plus
+    'score' (float32 [N,H,W,C]); 'prob' and 'classification' of test_pipeline come for free from the same
+    fused decoder kernel."""
+    eng = _engine_for(prefix, inputs, num_units, num_classes, variables)
+    out = eng.forward(inputs, want=('score', 'prob', 'label'), keep_all=True)
+    layers = dict(out['layers'])
+    layers.update(score=out['score'], prob=out['prob'], classification=out['label'])
+    return layers
+
+
 class SimpleFCN(BaseModel):
     """FCN expert.  Args as the reference: prefix, data_description, modality, output_dir,
     **config with required `num_units`, `batch_normalization`; optional learning_rate, trainer,

@@ -132,7 +132,28 @@ def test_bayes_fusion_model(gpu, tmp_path, golden_dir):
     assert np.array_equal(fused, np.argmax(got_score, -1))
     measures, cm = net.score(data)
     assert np.array_equal(cm, fu.confusion_matrix(data['labels'], fused, C).astype(np.float64))
+    # the lookup-table variant decides identically wherever the fp32 score is not a near-tie
+    net.config['decision_matrix'] = True
+    fused_lut = net.predict(data)
+    top2 = np.sort(ref_score, -1)[..., -2:]
+    clear = (top2[..., 1] - top2[..., 0]) > 1e-4
+    assert np.array_equal(fused_lut[clear], fused[clear])
     net.close()
+
+
+def test_functional_fcn_entry_point(gpu, tmp_path):
+    """fcn() as experiments/timing.py calls it: layer dict incl. score / prob / classification."""
+    from modular_semantic_segmentation_amd.simple_fcn import fcn
+    w, _ = _weights(tmp_path, 'rgb', 3, 1, 0.02)
+    data = _data(1, seed=9)
+    x = torch.from_numpy(data['rgb']).cuda()
+    layers = fcn(x, 'rgb', U, C, variables=w)
+    torch.cuda.synchronize()
+    assert set(['conv1_1', 'pool4', 'conv5_3', 'fused', 'score', 'prob', 'classification']) <= set(layers)
+    ref = fo.fcn_forward(data['rgb'], w, 'rgb', 'bf16')['score']
+    _check_logits_and_labels(layers['score'].cpu().numpy(), layers['classification'].cpu().numpy(), ref, 'fcn()')
+    again = fcn(x, 'rgb', U, C, variables=w)          # AUTO_REUSE: same engine, same result
+    assert torch.equal(again['classification'], layers['classification'])
 
 
 def test_dirichlet_fusion_fit_and_predict(gpu, tmp_path):
