@@ -5,70 +5,98 @@
 namespace {
 
 // ---- conv1_1: relu(conv3x3(x) + b) on the raw fp32 input, fp32 math, bf16 padded-NHWC out -------
-// simple_fcn.py:39.  One thread = one pixel x 64 output channels.  The 9*CIN x 64 fp32 weight
-// matrix is read through wave-uniform addresses (scalar loads into SGPRs), so the inner loop is
-// pure v_fmac with one SGPR operand: VALU-bound, no LDS traffic.
+// simple_fcn.py:39.  One thread = TWO horizontally adjacent pixels x 64 output channels.  The
+// 9*CIN x 64 fp32 weight matrix is read through wave-uniform addresses (scalar loads into SGPRs), each
+// weight feeding both pixels; results go through LDS so that every store instruction writes whole
+// 128-byte pixel rows.
 template <int CIN>
 __global__ __launch_bounds__(256) void conv_first_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                         const float* __restrict__ b, __bf16* __restrict__ y, int N,
                                                         int H, int W, int relu) {
   constexpr int K = 9 * CIN;
-  const int64_t npix = (int64_t)N * H * W;
-  int64_t pix = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  pix = pix < npix ? pix : npix - 1;  // tail lanes recompute the last pixel; only in-range pixels are stored
-  const int px = (int)(pix % W);
-  const int py = (int)((pix / W) % H);
-  const int n = (int)(pix / ((int64_t)W * H));
-  float in[K];
+  const int Wh = W >> 1;  // pixel pairs per row (W is even: multiple of 16)
+  const int npair = N * H * Wh;  // < 2^31, checked by the host
+  int pr = blockIdx.x * 256 + threadIdx.x;
+  pr = pr < npair ? pr : npair - 1;  // tail lanes recompute the last pair; only in-range pixels are stored
+  const int row = pr / Wh;         // n * H + py
+  const int px = (pr - row * Wh) * 2;
+  const int n = row / H;
+  const int py = row - n * H;
+  float in[3][4][CIN];  // rows py-1..py+1, columns px-1..px+2
 #pragma unroll
   for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
-    for (int dx = 0; dx < 3; ++dx) {
+    for (int dx = 0; dx < 4; ++dx) {
       const int yy = py + dy - 1, xx = px + dx - 1;
       const bool ok = yy >= 0 && yy < H && xx >= 0 && xx < W;
       const float* src = x + (((int64_t)n * H + (ok ? yy : 0)) * W + (ok ? xx : 0)) * CIN;
 #pragma unroll
-      for (int c = 0; c < CIN; ++c) in[(dy * 3 + dx) * CIN + c] = ok ? src[c] : 0.f;
+      for (int c = 0; c < CIN; ++c) in[dy][dx][c] = ok ? src[c] : 0.f;
     }
-  // results go through LDS so that every store instruction writes whole 128-byte pixel rows
-  // (8 lanes x 16 B per pixel, 8 pixels per instruction) instead of 64 scattered 16-byte pieces
-  __shared__ __attribute__((aligned(16))) u32x4 stage[256 * 8];
-  u32x4* mine = stage + threadIdx.x * 8;
+  __shared__ __attribute__((aligned(16))) u32x4 stage[512 * 8];  // [pixel within block][8 slots of 8 channels]
+  u32x4* mine = stage + threadIdx.x * 16;
 #pragma unroll
   for (int g = 0; g < 4; ++g) {  // 16 output channels at a time (accumulators in VGPRs, weights in SGPRs)
-    float acc[16];
+    float a0[16], a1[16];
 #pragma unroll
-    for (int c = 0; c < 16; ++c) acc[c] = b[g * 16 + c];
+    for (int c = 0; c < 16; ++c) a0[c] = a1[c] = b[g * 16 + c];
 #pragma unroll
-    for (int t = 0; t < K; ++t)
+    for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
-      for (int c = 0; c < 16; ++c) acc[c] = fmaf(in[t], w[t * 64 + g * 16 + c], acc[c]);
+      for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+        for (int ci = 0; ci < CIN; ++ci) {
+          const int t = (dy * 3 + dx) * CIN + ci;
+#pragma unroll
+          for (int c = 0; c < 16; ++c) {
+            const float wv = w[t * 64 + g * 16 + c];
+            a0[c] = fmaf(in[dy][dx][ci], wv, a0[c]);
+            a1[c] = fmaf(in[dy][dx + 1][ci], wv, a1[c]);
+          }
+        }
     if (relu) {
 #pragma unroll
-      for (int c = 0; c < 16; ++c) acc[c] = fmaxf(acc[c], 0.f);
+      for (int c = 0; c < 16; ++c) {
+        a0[c] = fmaxf(a0[c], 0.f);
+        a1[c] = fmaxf(a1[c], 0.f);
+      }
     }
-    // slot swizzle (slot ^ pixel) keeps the 16-byte LDS writes of 8 consecutive lanes on distinct banks
-    mine[(2 * g) ^ (threadIdx.x & 7)] = u32x4{pack_bf16x2(acc[0], acc[1]), pack_bf16x2(acc[2], acc[3]),
-                                              pack_bf16x2(acc[4], acc[5]), pack_bf16x2(acc[6], acc[7])};
-    mine[(2 * g + 1) ^ (threadIdx.x & 7)] = u32x4{pack_bf16x2(acc[8], acc[9]), pack_bf16x2(acc[10], acc[11]),
-                                                  pack_bf16x2(acc[12], acc[13]), pack_bf16x2(acc[14], acc[15])};
+    // 16-byte slot swizzle (slot ^ pixel) keeps the LDS writes of consecutive lanes on distinct banks
+    const int p0 = 2 * threadIdx.x, p1 = p0 + 1;
+    mine[(2 * g) ^ (p0 & 7)] = u32x4{pack_bf16x2(a0[0], a0[1]), pack_bf16x2(a0[2], a0[3]), pack_bf16x2(a0[4], a0[5]),
+                                     pack_bf16x2(a0[6], a0[7])};
+    mine[(2 * g + 1) ^ (p0 & 7)] = u32x4{pack_bf16x2(a0[8], a0[9]), pack_bf16x2(a0[10], a0[11]),
+                                         pack_bf16x2(a0[12], a0[13]), pack_bf16x2(a0[14], a0[15])};
+    mine[8 + ((2 * g) ^ (p1 & 7))] = u32x4{pack_bf16x2(a1[0], a1[1]), pack_bf16x2(a1[2], a1[3]),
+                                           pack_bf16x2(a1[4], a1[5]), pack_bf16x2(a1[6], a1[7])};
+    mine[8 + ((2 * g + 1) ^ (p1 & 7))] = u32x4{pack_bf16x2(a1[8], a1[9]), pack_bf16x2(a1[10], a1[11]),
+                                               pack_bf16x2(a1[12], a1[13]), pack_bf16x2(a1[14], a1[15])};
   }
-  // each wave stores its own 64 pixels: no block barrier needed (the wave's LDS region is private)
+  // each wave stores its own 128 pixels: no block barrier needed (the wave's LDS region is private)
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   const int lane = threadIdx.x & 63;
-  const int wbase = threadIdx.x & ~63;
+  const int wbase = (threadIdx.x & ~63) * 2;  // first pixel (within the block) of this wave
+  const int slot = lane & 7;
+  // this lane stores pixel lp = it*8 + (lane>>3) of the wave: pair index advances by 4 per iteration
+  int gpair = blockIdx.x * 256 + ((wbase + (lane >> 3)) >> 1);
+  int qrow = gpair / Wh;  // n * H + y
+  int qxh = gpair - qrow * Wh;
 #pragma unroll
-  for (int it = 0; it < 8; ++it) {
-    const int lp = it * 8 + (lane >> 3);  // pixel within the wave
-    const int slot = lane & 7;
-    const int64_t gp = (int64_t)blockIdx.x * 256 + wbase + lp;
-    if (gp < npix) {
-      const int qx = (int)(gp % W);
-      const int qy = (int)((gp / W) % H);
-      const int qn = (int)(gp / ((int64_t)W * H));
+  for (int it = 0; it < 16; ++it) {
+    const int lp = it * 8 + (lane >> 3);
+    if (gpair < npair) {
+      const int qn = qrow / H;
+      const int qy = qrow - qn * H;
       const u32x4 v = stage[(wbase + lp) * 8 + (slot ^ (lp & 7))];
-      *reinterpret_cast<u32x4*>(y + (((int64_t)qn * (H + 2) + (qy + 1)) * (W + 2) + (qx + 1)) * 64 + slot * 8) = v;
+      *reinterpret_cast<u32x4*>(y + (((int64_t)qn * (H + 2) + (qy + 1)) * (W + 2) + (qxh * 2 + (lp & 1) + 1)) * 64 +
+                                slot * 8) = v;
+    }
+    gpair += 4;
+    qxh += 4;
+    if (qxh >= Wh) {  // Wh >= 8: at most one row wrap per step
+      qxh -= Wh;
+      qrow += 1;
     }
   }
 }
@@ -236,10 +264,17 @@ __global__ __launch_bounds__(256) void decoder_head_kernel(const __bf16* __restr
   for (int j = 0; j < 4; ++j)
 #pragma unroll
     for (int k = 0; k < CM; ++k) sc[j][k] = 0.f;
+  // software pipeline: the four 16-byte source loads of channel group g+1 are in flight while group g is
+  // multiplied (few waves per SIMD fit beside 4*CM accumulators, so the loop must hide its own L2 latency)
+  u32x4 n00 = *reinterpret_cast<const u32x4*>(p00), n01 = *reinterpret_cast<const u32x4*>(p00 + U);
+  u32x4 n10 = *reinterpret_cast<const u32x4*>(p00 + rowp), n11 = *reinterpret_cast<const u32x4*>(p00 + rowp + U);
   for (int u0 = 0; u0 < U; u0 += 8) {
-    const u32x4 a00 = *reinterpret_cast<const u32x4*>(p00 + u0), a01 = *reinterpret_cast<const u32x4*>(p00 + U + u0);
-    const u32x4 a10 = *reinterpret_cast<const u32x4*>(p00 + rowp + u0),
-                a11 = *reinterpret_cast<const u32x4*>(p00 + rowp + U + u0);
+    const u32x4 a00 = n00, a01 = n01, a10 = n10, a11 = n11;
+    const int un = u0 + 8 < U ? u0 + 8 : u0;
+    n00 = *reinterpret_cast<const u32x4*>(p00 + un);
+    n01 = *reinterpret_cast<const u32x4*>(p00 + U + un);
+    n10 = *reinterpret_cast<const u32x4*>(p00 + rowp + un);
+    n11 = *reinterpret_cast<const u32x4*>(p00 + rowp + U + un);
     const float* wrow = ws_g + u0 * C;
     if (u0 + 16 <= U)
       head_group<CM, false>(a00, a01, a10, a11, wy0, wy1, wx0, wx1, wrow, C, 0, sc);
@@ -337,8 +372,9 @@ extern "C" int xv_conv2d_first_fwd(const float* x, int n, int h, int w, int cin,
   XV_CHECK_ARG(x && w_hwio && bias && y && y->data);
   XV_CHECK_SHAPE(n > 0 && h > 0 && w > 0 && cin >= 1 && cin <= 4);
   XV_CHECK_SHAPE(y->n == n && y->h == h && y->w == w && y->c == 64);
-  const int64_t npix = (int64_t)n * h * w;
-  const unsigned grid = (unsigned)((npix + 255) / 256);
+  XV_CHECK_SHAPE((w & 1) == 0 && w >= 16 && (int64_t)n * h * (w / 2) < 0x7fffff00);
+  const int64_t npair = (int64_t)n * h * (w / 2);
+  const unsigned grid = (unsigned)((npair + 255) / 256);
   hipStream_t s = (hipStream_t)stream;
   __bf16* yp = (__bf16*)y->data;
   switch (cin) {
