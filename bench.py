@@ -158,6 +158,8 @@ def main():
     ap.add_argument('--mode', default='infer', choices=['infer', 'train'],
                     help="'infer' (headline): two experts + fusion; 'train': one SimpleFCN training step (fwd+bwd+Adam)")
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-graph', dest='graph', action='store_false',
+                    help='launch every kernel eagerly instead of replaying the step from a captured hipGraph')
     ap.add_argument('--serial-experts', action='store_true',
                     help='run the RGB and depth experts back to back on one stream (profiling: per-kernel times)')
     args = ap.parse_args()
@@ -189,6 +191,14 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    if args.graph:
+        net.capture_graph(batch)
+        graph = net._graph[0]
+
+        def step():             # noqa: F811  (inputs already sit in the graph's static buffers)
+            graph.replay()
+            return net._graph[2]
+        step()
 
     def fence():
         torch.cuda.synchronize(device)
@@ -207,6 +217,8 @@ def main():
     # a HIP-event pair around a conv launch (recorded on the launch stream) times that kernel alone
     # (in the timed region above the RGB and depth experts overlap on two streams).
     prof = []
+    net._graph = None
+    step = lambda: net._predict_batch(batch)        # noqa: E731  (the roofline pass is always eager)
     net.concurrent_experts = False
     step()
     ops.CONV_PROFILE = prof
@@ -261,7 +273,7 @@ def main():
             'config': {'workload': 'two-stream SimpleFCN RGB+Depth %dx%d + %s fusion, U=%d, C=%d, random-init weights'
                                    % (args.width, args.height, args.fusion, U, C),
                        'images_per_gpu_per_step': args.batch, 'global_batch': args.batch * world,
-                       'expert_streams': 1 if args.serial_experts else 2,
+                       'expert_streams': 1 if args.serial_experts else 2, 'hip_graph': bool(args.graph),
                        'parallelism': 'dp%d (batch sharding, no data-path collective)' % world},
             'conv_tflops_end_to_end': round(images * flops_img / dt / 1e12, 2),
             'roofline': roofline,

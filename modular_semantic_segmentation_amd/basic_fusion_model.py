@@ -76,7 +76,7 @@ class FusionModel(BaseModel):
     def _expert_outputs(self, batch, wants):
         return run_experts(self, batch, wants)
 
-    def _predict_batch(self, batch, output_attr=None):
+    def _predict_batch_impl(self, batch, output_attr=None):
         wants = self.expert_wants
         if output_attr in ('probs', 'prob') and 'prob' not in wants:
             wants = tuple(wants) + ('prob',)

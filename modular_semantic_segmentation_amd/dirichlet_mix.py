@@ -102,7 +102,7 @@ class DirichletFusion(BaseModel):
         for m in self.modalities:
             self.experts[m].load(self.variables)
 
-    def _predict_batch(self, batch, output_attr=None):
+    def _predict_batch_impl(self, batch, output_attr=None):
         if not hasattr(self, 'am1'):
             raise UserWarning('ERROR: DirichletFusion has no measurements yet, call fit() first')
         outs = run_experts(self, batch, ('prob',))

@@ -103,7 +103,7 @@ class SimpleFCN(BaseModel):
         self._sync_variables()
         return BaseModel.export_weights(self, save_dir)
 
-    def _predict_batch(self, batch, output_attr=None):
+    def _predict_batch_impl(self, batch, output_attr=None):
         x = self._to_device(batch[self.modality], torch.float32)
         want = 'label'
         if output_attr in ('prob', 'score'):
