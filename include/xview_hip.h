@@ -85,14 +85,20 @@ int xv_maxpool2x2_fwd(const xv_act* x, const xv_act* y, void* stream);
  * collapses to.  residual may be NULL.                                                           */
 int xv_upsample2x_relu_add(const xv_act* x, const xv_act* residual, const xv_act* y, void* stream);
 
-/* Decoder head, fused: upscore = relu(bilinear_x8(fused)) (deconv2d k=16 s=8, simple_fcn.py:129-130),
+/* Decoder head: upscore = relu(bilinear_x8(fused)) (deconv2d k=16 s=8, simple_fcn.py:129-130),
  * score = conv1x1(upscore, Ws) + bs (no activation, simple_fcn.py:131-133), prob = softmax(score),
- * label = argmax(prob, 3) (basic_fusion_model.py:21-22 / simple_fcn.py:223-224), all fp32 from the
- * bf16 `fused` features without materialising the full-resolution U-channel tensor.
- * w_score: float32 [U][C] (HWIO of the 1x1 kernel), b_score: float32 [C], C <= 32, U % 8 == 0, U <= 128.
- * Outputs (each may be NULL): score / prob float32 [N][8h][8w][C], label int64 [N][8h][8w].        */
+ * label = argmax(prob, 3) (basic_fusion_model.py:21-22 / simple_fcn.py:223-224), fp32 from the bf16 `fused`
+ * features.  `fused` is non-negative by construction (a sum of two relu outputs) and the bilinear
+ * weights are positive, so the relu is the identity and the linear x8 deconv and 1x1 conv commute: the
+ * 1x1 conv runs at 1/8 resolution into `workspace` and C class scores are interpolated instead of U
+ * features; the full-resolution U-channel tensor is never formed.
+ * w_score: float32 [U][C] (HWIO of the 1x1 kernel), b_score: float32 [C], C <= 32, U % 8 == 0.
+ * Outputs (each may be NULL): score / prob float32 [N][8h][8w][C], label int64 [N][8h][8w].
+ * workspace: xv_decoder_head_workspace_bytes(n, h, w, C) bytes, 16-byte aligned (h, w of `fused`).      */
+size_t xv_decoder_head_workspace_bytes(int n, int h, int w, int num_classes);
 int xv_decoder_head_fwd(const xv_act* fused, const float* w_score, const float* b_score, int num_classes,
-                        float* score, float* prob, int64_t* label, void* stream);
+                        float* score, float* prob, int64_t* label, void* workspace, size_t workspace_bytes,
+                        void* stream);
 
 /* prob = softmax(score), label = argmax(prob) on a dense float32 [npix][C] score tensor
  * (tf.nn.softmax + tf.argmax, basic_fusion_model.py:21-22); lowest index wins ties.  prob / label

@@ -196,131 +196,118 @@ __global__ __launch_bounds__(256) void upsample2x_kernel(const __bf16* __restric
 }
 
 // ---- decoder head: bilinear x8 + relu + 1x1 score + softmax + argmax ----------------------------
-// simple_fcn.py:129-133 + basic_fusion_model.py:21-22.  One thread = 4 horizontally consecutive
-// output pixels (aligned to 4): they share the same 2x2 source pixels, so the bf16 unpack and the
-// vertical interpolation are done once per 4 outputs.  CM = class count rounded up to 4 (static
-// register indexing).  The U x C score weights are read through wave-uniform addresses (scalar
-// loads -> SGPR operands of the FMAs), CM floats per channel row; a row's read overlaps the next
-// row's first CM-C weights (multiplied into ignored accumulators), and the rows whose CM-wide read
-// would leave the array take an index-clamped path.
-template <int CM, bool CLAMP>
-__device__ inline void head_group(const u32x4& a00, const u32x4& a01, const u32x4& a10, const u32x4& a11, float wy0,
-                                  float wy1, const float (&wx0)[4], const float (&wx1)[4],
-                                  const float* __restrict__ wrow, int C, int remain, float (&sc)[4][CM]) {
+// simple_fcn.py:129-133 + basic_fusion_model.py:21-22.
+//
+// `fused` = relu(score_conv4) + relu(bilinear_x2(..)) is non-negative by construction and the
+// bilinear weights are positive, so relu(bilinear_x8(fused)) == bilinear_x8(fused): the x8 deconv and
+// the 1x1 `score` conv are both linear and commute.  The head therefore runs the 1x1 conv at 1/8
+// resolution (U -> C channels on h*w pixels instead of 64*h*w) and interpolates C class scores instead
+// of U features: 16x fewer FMAs per output pixel, same value up to fp32 summation order.  The bias is
+// added after the interpolation (at the image border the zero-padded bilinear weights do not sum to 1).
+//
+// Kernel 1: S[n][i][j][k] = sum_u fused[n,i,j,u] * Ws[u][k] into a zero-bordered fp32 [N][h+2][w+2][CP]
+// workspace (CP = C rounded up to 4).  Score weights come through wave-uniform scalar loads.
+template <int CM>
+__global__ __launch_bounds__(256) void score_lowres_kernel(const __bf16* __restrict__ f, const float* __restrict__ ws_g,
+                                                          int N, int Hi, int Wi, int U, int C, float* __restrict__ S) {
+  const int64_t total = (int64_t)N * (Hi + 2) * (Wi + 2);
+  const int64_t pp = (int64_t)blockIdx.x * 256 + threadIdx.x;  // padded pixel index (same geometry as `fused`)
+  if (pp >= total) return;
+  const int x = (int)(pp % (Wi + 2));
+  const int y = (int)((pp / (Wi + 2)) % (Hi + 2));
+  float sc[CM];
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int sh = (i & 1) * 16, q = i >> 1;
-    const float f00 = bf16_bits_to_f32((a00[q] >> sh) & 0xffffu), f01 = bf16_bits_to_f32((a01[q] >> sh) & 0xffffu);
-    const float f10 = bf16_bits_to_f32((a10[q] >> sh) & 0xffffu), f11 = bf16_bits_to_f32((a11[q] >> sh) & 0xffffu);
-    const float v0 = f00 * wy0 + f10 * wy1;  // source column ix0
-    const float v1 = f01 * wy0 + f11 * wy1;  // source column ix1
-    float up[4];
+  for (int k = 0; k < CM; ++k) sc[k] = 0.f;
+  const bool interior = x >= 1 && x <= Wi && y >= 1 && y <= Hi;
+  if (interior) {
+    const __bf16* src = f + pp * U;
+    for (int u0 = 0; u0 < U; u0 += 8) {
+      const u32x4 v = *reinterpret_cast<const u32x4*>(src + u0);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) up[j] = fmaxf(v0 * wx0[j] + v1 * wx1[j], 0.f);
-    if (CLAMP && i * C + CM > remain) {  // wave-uniform
+      for (int i = 0; i < 8; ++i) {
+        const float fv = bf16_bits_to_f32((v[i >> 1] >> ((i & 1) * 16)) & 0xffffu);
+        const int remain = (U - u0 - i) * C;  // weights left from this row to the end of the array
+        if (remain >= CM) {
 #pragma unroll
-      for (int k = 0; k < CM; ++k) {
-        int off = i * C + k;
-        off = off < remain ? off : remain - 1;
-        const float wv = wrow[off];
+          for (int k = 0; k < CM; ++k) sc[k] = fmaf(fv, ws_g[(u0 + i) * C + k], sc[k]);
+        } else {  // last row(s): a CM-wide read would leave the array
 #pragma unroll
-        for (int j = 0; j < 4; ++j) sc[j][k] = fmaf(up[j], wv, sc[j][k]);
-      }
-    } else {
-#pragma unroll
-      for (int k = 0; k < CM; ++k) {
-        const float wv = wrow[i * C + k];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) sc[j][k] = fmaf(up[j], wv, sc[j][k]);
+          for (int k = 0; k < CM; ++k) sc[k] = fmaf(fv, ws_g[(u0 + i) * C + (k < remain ? k : remain - 1)], sc[k]);
+        }
       }
     }
   }
+  float* dst = S + pp * CM;
+#pragma unroll
+  for (int k4 = 0; k4 < CM; k4 += 4)
+    *reinterpret_cast<f32x4*>(dst + k4) = f32x4{k4 < C ? sc[k4] : 0.f, k4 + 1 < C ? sc[k4 + 1] : 0.f,
+                                                k4 + 2 < C ? sc[k4 + 2] : 0.f, k4 + 3 < C ? sc[k4 + 3] : 0.f};
 }
 
+// Kernel 2: one thread per output pixel: 4-tap bilinear interpolation of the CM low-resolution class
+// scores, + bias, softmax, argmax.
 template <int CM>
-__global__ __launch_bounds__(256) void decoder_head_kernel(const __bf16* __restrict__ f, const float* __restrict__ ws_g,
-                                                          const float* __restrict__ bs_g, int N, int Hi, int Wi, int U,
-                                                          int C, float* __restrict__ score, float* __restrict__ prob,
-                                                          int64_t* __restrict__ label) {
+__global__ __launch_bounds__(256) void decoder_head_kernel(const float* __restrict__ S, const float* __restrict__ bs_g,
+                                                          int N, int Hi, int Wi, int C, float* __restrict__ score,
+                                                          float* __restrict__ prob, int64_t* __restrict__ label) {
   const int Ho = Hi * 8, Wo = Wi * 8;
-  // block = 128 x 8 output pixels: a wave covers 2 rows x 128 columns
-  const int tilesx = (Wo + 127) / 128;
-  const int tx = blockIdx.x % tilesx;
-  int r = blockIdx.x / tilesx;
-  const int tilesy = Hi;  // Ho / 8
-  const int ty = r % tilesy;
-  const int n = r / tilesy;
-  const int ox = tx * 128 + (threadIdx.x & 31) * 4, oy = ty * 8 + (threadIdx.x >> 5);
-  if (ox >= Wo) return;
+  const int64_t npix = (int64_t)N * Ho * Wo;
+  const int64_t opix = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (opix >= npix) return;
+  const int ox = (int)(opix % Wo);
+  const int oy = (int)((opix / Wo) % Ho);
+  const int n = (int)(opix / ((int64_t)Wo * Ho));
   int iy1, ix1;
-  float wy1, wy0, wx1[4], wx0[4];
+  float wy1, wy0, wx1, wx0;
   bilinear_taps<8>(oy, iy1, wy1, wy0);
+  bilinear_taps<8>(ox, ix1, wx1, wx0);
+  const float w00 = wy0 * wx0, w01 = wy0 * wx1, w10 = wy1 * wx0, w11 = wy1 * wx1;
+  // padded coords: logical source (iy1-1, ix1-1) is padded (iy1, ix1)
+  const float* p00 = S + (((int64_t)n * (Hi + 2) + iy1) * (Wi + 2) + ix1) * CM;
+  const int64_t rowp = (int64_t)(Wi + 2) * CM;
+  float sc[CM];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) bilinear_taps<8>(ox + j, ix1, wx1[j], wx0[j]);  // same ix1 for the 4 aligned pixels
-  const __bf16* p00 = f + (((int64_t)n * (Hi + 2) + iy1) * (Wi + 2) + ix1) * U;
-  const int64_t rowp = (int64_t)(Wi + 2) * U;
-  float sc[4][CM];
-#pragma unroll
-  for (int j = 0; j < 4; ++j)
-#pragma unroll
-    for (int k = 0; k < CM; ++k) sc[j][k] = 0.f;
-  // software pipeline: the four 16-byte source loads of channel group g+1 are in flight while group g is
-  // multiplied (few waves per SIMD fit beside 4*CM accumulators, so the loop must hide its own L2 latency)
-  u32x4 n00 = *reinterpret_cast<const u32x4*>(p00), n01 = *reinterpret_cast<const u32x4*>(p00 + U);
-  u32x4 n10 = *reinterpret_cast<const u32x4*>(p00 + rowp), n11 = *reinterpret_cast<const u32x4*>(p00 + rowp + U);
-  for (int u0 = 0; u0 < U; u0 += 8) {
-    const u32x4 a00 = n00, a01 = n01, a10 = n10, a11 = n11;
-    const int un = u0 + 8 < U ? u0 + 8 : u0;
-    n00 = *reinterpret_cast<const u32x4*>(p00 + un);
-    n01 = *reinterpret_cast<const u32x4*>(p00 + U + un);
-    n10 = *reinterpret_cast<const u32x4*>(p00 + rowp + un);
-    n11 = *reinterpret_cast<const u32x4*>(p00 + rowp + U + un);
-    const float* wrow = ws_g + u0 * C;
-    if (u0 + 16 <= U)
-      head_group<CM, false>(a00, a01, a10, a11, wy0, wy1, wx0, wx1, wrow, C, 0, sc);
-    else
-      head_group<CM, true>(a00, a01, a10, a11, wy0, wy1, wx0, wx1, wrow, C, (U - u0) * C, sc);
+  for (int k4 = 0; k4 < CM; k4 += 4) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(p00 + k4), b = *reinterpret_cast<const f32x4*>(p00 + CM + k4);
+    const f32x4 c = *reinterpret_cast<const f32x4*>(p00 + rowp + k4), d = *reinterpret_cast<const f32x4*>(p00 + rowp + CM + k4);
+    const f32x4 v = a * w00 + b * w01 + c * w10 + d * w11;
+    sc[k4] = v.x;
+    sc[k4 + 1] = v.y;
+    sc[k4 + 2] = v.z;
+    sc[k4 + 3] = v.w;
   }
-  const int64_t opix = ((int64_t)n * Ho + oy) * Wo + ox;
-  int64_t lab[4];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
+  for (int k = 0; k < CM; ++k) sc[k] += bs_g[k < C ? k : C - 1];
+  if (score) {
 #pragma unroll
-    for (int k = 0; k < CM; ++k) sc[j][k] += bs_g[k < C ? k : C - 1];
-    if (score) {
-#pragma unroll
-      for (int k = 0; k < CM; ++k)
-        if (k < C) score[(opix + j) * C + k] = sc[j][k];
-    }
-    float m = sc[j][0];
+    for (int k = 0; k < CM; ++k)
+      if (k < C) score[opix * C + k] = sc[k];
+  }
+  if (prob || label) {
+    float m = sc[0];
 #pragma unroll
     for (int k = 1; k < CM; ++k)
-      if (k < C) m = fmaxf(m, sc[j][k]);
+      if (k < C) m = fmaxf(m, sc[k]);
     float sum = 0.f;
 #pragma unroll
     for (int k = 0; k < CM; ++k) {
-      sc[j][k] = k < C ? expf(sc[j][k] - m) : 0.f;
-      sum += sc[j][k];
+      sc[k] = k < C ? expf(sc[k] - m) : 0.f;
+      sum += sc[k];
     }
     float best = -1.f;
     int bi = 0;
 #pragma unroll
     for (int k = 0; k < CM; ++k) {
-      const float p = sc[j][k] / sum;
+      const float p = sc[k] / sum;
       if (k < C) {
-        if (prob) prob[(opix + j) * C + k] = p;
+        if (prob) prob[opix * C + k] = p;
         if (p > best) {
           best = p;
           bi = k;
         }
       }
     }
-    lab[j] = bi;
-  }
-  if (label) {
-    typedef __attribute__((ext_vector_type(2))) int64_t i64x2;
-    *reinterpret_cast<i64x2*>(label + opix) = i64x2{lab[0], lab[1]};
-    *reinterpret_cast<i64x2*>(label + opix + 2) = i64x2{lab[2], lab[3]};
+    if (label) label[opix] = bi;
   }
 }
 
@@ -411,20 +398,32 @@ extern "C" int xv_upsample2x_relu_add(const xv_act* x, const xv_act* residual, c
   return xv_launch_status();
 }
 
+extern "C" size_t xv_decoder_head_workspace_bytes(int n, int h, int w, int num_classes) {
+  if (n <= 0 || h <= 0 || w <= 0 || num_classes < 1 || num_classes > 32) return 0;
+  return (size_t)n * (h + 2) * (w + 2) * ((num_classes + 3) / 4 * 4) * sizeof(float);
+}
+
 extern "C" int xv_decoder_head_fwd(const xv_act* fused, const float* w_score, const float* b_score, int num_classes,
-                                   float* score, float* prob, int64_t* label, void* stream) {
-  XV_CHECK_ARG(fused && fused->data && w_score && b_score);
+                                   float* score, float* prob, int64_t* label, void* workspace, size_t workspace_bytes,
+                                   void* stream) {
+  XV_CHECK_ARG(fused && fused->data && w_score && b_score && workspace);
   XV_CHECK_ARG(score || prob || label);
   XV_CHECK_SHAPE(fused->n > 0 && fused->h > 0 && fused->w > 0);
-  XV_CHECK_SHAPE(fused->c > 0 && (fused->c & 7) == 0 && fused->c <= 128 && num_classes >= 1 && num_classes <= 32);
-  const int Wo = fused->w * 8;
-  const int64_t nblk = (int64_t)((Wo + 127) / 128) * fused->h * fused->n;
-  XV_CHECK_SHAPE(nblk <= 0x7fffffff);
+  XV_CHECK_SHAPE(fused->c > 0 && (fused->c & 7) == 0 && num_classes >= 1 && num_classes <= 32);
+  if (workspace_bytes < xv_decoder_head_workspace_bytes(fused->n, fused->h, fused->w, num_classes)) return XV_EWORKSPACE;
+  XV_CHECK_ARG(((uintptr_t)workspace & 15) == 0);
   hipStream_t s = (hipStream_t)stream;
   const __bf16* f = (const __bf16*)fused->data;
-#define XV_HEAD(CMV)                                                                                          \
-  hipLaunchKernelGGL(decoder_head_kernel<CMV>, dim3((unsigned)nblk), dim3(256), 0, s, f, w_score, b_score, \
-                     fused->n, fused->h, fused->w, fused->c, num_classes, score, prob, label)
+  float* S = (float*)workspace;
+  const int64_t lowres = (int64_t)fused->n * (fused->h + 2) * (fused->w + 2);
+  const int64_t npix = (int64_t)fused->n * fused->h * fused->w * 64;
+  XV_CHECK_SHAPE((npix + 255) / 256 <= 0x7fffffff);
+  const unsigned g1 = (unsigned)((lowres + 255) / 256), g2 = (unsigned)((npix + 255) / 256);
+#define XV_HEAD(CMV)                                                                                              \
+  hipLaunchKernelGGL(score_lowres_kernel<CMV>, dim3(g1), dim3(256), 0, s, f, w_score, fused->n, fused->h, fused->w, \
+                     fused->c, num_classes, S);                                                                   \
+  hipLaunchKernelGGL(decoder_head_kernel<CMV>, dim3(g2), dim3(256), 0, s, (const float*)S, b_score, fused->n,      \
+                     fused->h, fused->w, num_classes, score, prob, label)
   switch ((num_classes + 3) / 4) {
     case 1: XV_HEAD(4); break;
     case 2: XV_HEAD(8); break;

@@ -177,9 +177,16 @@ class FcnEngine(object):
         """fcn + test_pipeline (basic_fusion_model.py:9-23): returns dict with any of
         'score', 'prob' (float32 [N,H,W,C]) and 'label' == 'classification' (int64 [N,H,W])."""
         L = self.encoder(x, keep_all=keep_all)
-        out = ops.decoder_head_fwd(L['fused'], self.w['score'], self.b['score'], self.C,
+        f = L['fused']
+        key = ('head_ws', f.n, f.h, f.w)
+        ws = self._arena.get(key)
+        if ws is None:             # per-engine workspace: the two experts run on different streams
+            ws = torch.empty(ops._lib.lib().xv_decoder_head_workspace_bytes(f.n, f.h, f.w, self.C) // 4,
+                             dtype=torch.float32, device=self.device)
+            self._arena[key] = ws
+        out = ops.decoder_head_fwd(f, self.w['score'], self.b['score'], self.C,
                                    want_score='score' in want, want_prob='prob' in want,
-                                   want_label=('label' in want or 'classification' in want))
+                                   want_label=('label' in want or 'classification' in want), workspace=ws)
         if 'label' in out:
             out['classification'] = out['label']
         out['layers'] = L

@@ -116,8 +116,21 @@ def upsample2x_relu_add(x, residual=None, y=None):
     return y
 
 
+_HEAD_WS = {}
+
+
+def _head_workspace(fused, num_classes):
+    key = (fused.t.device, fused.n, fused.h, fused.w, num_classes)
+    ws = _HEAD_WS.get(key)
+    if ws is None:
+        nbytes = _lib.lib().xv_decoder_head_workspace_bytes(fused.n, fused.h, fused.w, num_classes)
+        ws = torch.empty(nbytes // 4, dtype=torch.float32, device=fused.t.device)
+        _HEAD_WS[key] = ws
+    return ws
+
+
 def decoder_head_fwd(fused, w_score, b_score, num_classes, want_score=False, want_prob=False, want_label=True,
-                     out=None):
+                     out=None, workspace=None):
     """Returns dict with the requested dense outputs (score/prob float32 NHWC, label int64 NHW)."""
     _need(w_score, torch.float32, 'w_score')
     _need(b_score, torch.float32, 'b_score')
@@ -130,10 +143,12 @@ def decoder_head_fwd(fused, w_score, b_score, num_classes, want_score=False, wan
         out['prob'] = torch.empty((n, ho, wo, num_classes), dtype=torch.float32, device=dev)
     if want_label and 'label' not in out:
         out['label'] = torch.empty((n, ho, wo), dtype=torch.int64, device=dev)
+    ws = workspace if workspace is not None else _head_workspace(fused, num_classes)
     rc = _lib.lib().xv_decoder_head_fwd(fused.xv(), _ptr(w_score), _ptr(b_score), num_classes,
                                        _ptr(out.get('score') if want_score else None),
                                        _ptr(out.get('prob') if want_prob else None),
-                                       _ptr(out.get('label') if want_label else None), _stream())
+                                       _ptr(out.get('label') if want_label else None), _ptr(ws), ws.numel() * 4,
+                                       _stream())
     _lib.check(rc, 'xv_decoder_head_fwd')
     return out
 
