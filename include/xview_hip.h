@@ -172,19 +172,23 @@ int xv_relu_bwd(const xv_act* g, const xv_act* ref, const xv_act* out, void* str
 /* Gradient of fused = s4 + relu(bilinear_x2(s5)) w.r.t. s5 (through score_conv5's own relu).       */
 int xv_upsample2x_bwd(const xv_act* dfused, const xv_act* s5, const xv_act* ds5, void* stream);
 
-/* Gradient of the x8 bilinear deconv: dup dense bf16 [N][8h][8w][C] -> dfused.                     */
-int xv_upsample8x_bwd(const void* dup, const xv_act* dfused, void* stream);
-
 /* count += #pixels with 0 <= label < C  (the denominator of utils.py:52).                          */
 int xv_count_valid_labels(const int32_t* labels, int num_classes, int64_t npix, int64_t* count, void* stream);
 
-/* Loss and head backward (simple_fcn.py:212-214, utils.py:43-53): recomputes the decoder head from
- * `fused`, adds -sum(onehot*log_softmax)/(1e-20+count) to *loss, accumulates d(score kernel) [U][C]
- * and d(score bias) [C], and writes dup = d(loss)/d(upscore) masked by upscore > 0 as dense bf16
- * [N][8h][8w][U].  valid_count must already hold the batch's count.                                */
+/* S = fused . Ws at 1/8 resolution into a zero-bordered float32 [N][h+2][w+2][CM] buffer, CM = C rounded up
+ * to 4: the first half of the decoder head in its commuted form (see xv_decoder_head_fwd).          */
+int xv_score_lowres(const xv_act* fused, const float* w_score, int num_classes, float* S, void* stream);
+
+/* Loss and head backward (simple_fcn.py:212-214, utils.py:43-53) in the same commuted form: recomputes
+ * score = bilinear_x8(fused . Ws) + bs, adds -sum(onehot*log_softmax)/(1e-20+count) to *loss, accumulates
+ * d(score kernel) [U][C] and d(score bias) [C], and writes dfused = d(loss)/d(fused) (bf16 padded NHWC; the
+ * relu masks below `fused` are applied by the callers' next kernels).  valid_count must already hold the
+ * batch's count.  workspace: xv_decoder_head_bwd_workspace_bytes(n, h, w, C) bytes, 16-byte aligned.   */
+size_t xv_decoder_head_bwd_workspace_bytes(int n, int h, int w, int num_classes);
 int xv_decoder_head_bwd(const xv_act* fused, const float* w_score, const float* b_score, const int32_t* labels,
                         const int64_t* valid_count, int num_classes, double* loss, float* dw_score,
-                        float* db_score, void* dup, void* stream);
+                        float* db_score, const xv_act* dfused, void* workspace, size_t workspace_bytes,
+                        void* stream);
 
 /* [TF1] optimizers on flat float32 buffers; grad_scale multiplies the gradient first (1/world_size).
  * Adam: m,v updated, p -= lr_t*m/(sqrt(v)+eps) with lr_t = lr*sqrt(1-b2^t)/(1-b1^t) from the host.

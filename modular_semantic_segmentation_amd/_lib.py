@@ -52,9 +52,10 @@ SIGNATURES = {
     'xv_maxpool2x2_bwd': (_i, [_actp, _actp, _actp, _vp]),
     'xv_relu_bwd': (_i, [_actp, _actp, _actp, _vp]),
     'xv_upsample2x_bwd': (_i, [_actp, _actp, _actp, _vp]),
-    'xv_upsample8x_bwd': (_i, [_vp, _actp, _vp]),
     'xv_count_valid_labels': (_i, [_vp, _i, _i64, _vp, _vp]),
-    'xv_decoder_head_bwd': (_i, [_actp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
+    'xv_score_lowres': (_i, [_actp, _vp, _i, _vp, _vp]),
+    'xv_decoder_head_bwd_workspace_bytes': (ctypes.c_size_t, [_i, _i, _i, _i]),
+    'xv_decoder_head_bwd': (_i, [_actp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _actp, _vp, ctypes.c_size_t, _vp]),
     'xv_adam_step': (_i, [_vp, _vp, _vp, _vp, _i64, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float,
                           ctypes.c_float, _vp]),
     'xv_rmsprop_step': (_i, [_vp, _vp, _vp, _i64, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float, _vp]),

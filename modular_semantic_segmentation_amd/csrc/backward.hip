@@ -142,43 +142,6 @@ __global__ __launch_bounds__(256) void upsample2x_bwd_kernel(const __bf16* __res
   }
 }
 
-// ---- backward of the x8 bilinear deconv: dfused[i,j,c] = sum over the 16x16 footprint of w * dup ----
-// dup is dense [N][8h][8w][C] bf16 with the relu mask already applied by the head-backward kernel.
-__global__ __launch_bounds__(256) void upsample8x_bwd_kernel(const __bf16* __restrict__ dup, __bf16* __restrict__ df,
-                                                            int N, int Hi, int Wi, int C) {
-  const int c8 = C >> 3;
-  const int Ho = 8 * Hi, Wo = 8 * Wi;
-  const int64_t total = (int64_t)N * Hi * Wi * c8;
-  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
-    const int cg = (int)(idx % c8);
-    int64_t r = idx / c8;
-    const int j = (int)(r % Wi);
-    r /= Wi;
-    const int i = (int)(r % Hi);
-    const int n = (int)(r / Hi);
-    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (int oy = 8 * i - 4; oy <= 8 * i + 11; ++oy) {
-      if (oy < 0 || oy >= Ho) continue;
-      const float wy = bilinear_w<8>(oy, i);
-      const __bf16* row = dup + (((int64_t)n * Ho + oy) * Wo) * C + cg * 8;
-      for (int ox = 8 * j - 4; ox <= 8 * j + 11; ++ox) {
-        if (ox < 0 || ox >= Wo) continue;
-        const float w = wy * bilinear_w<8>(ox, j);
-        const u32x4 gv = *reinterpret_cast<const u32x4*>(row + (int64_t)ox * C);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          acc[2 * q] += w * bf_lo(gv[q]);
-          acc[2 * q + 1] += w * bf_hi(gv[q]);
-        }
-      }
-    }
-    u32x4 o;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) o[q] = pack_bf16x2(acc[2 * q], acc[2 * q + 1]);
-    *reinterpret_cast<u32x4*>(df + (((int64_t)n * (Hi + 2) + (i + 1)) * (Wi + 2) + (j + 1)) * C + cg * 8) = o;
-  }
-}
-
 // ---- number of labelled pixels: sum(one_hot(labels)) of utils.py:52 --------------------------------
 __global__ __launch_bounds__(256) void count_valid_kernel(const int32_t* __restrict__ labels, int C, int64_t npix,
                                                          unsigned long long* __restrict__ count) {
@@ -195,142 +158,161 @@ __global__ __launch_bounds__(256) void count_valid_kernel(const int32_t* __restr
   if (threadIdx.x == 0 && s) atomicAdd(count, (unsigned long long)s);
 }
 
-// ---- head backward: loss, dscore, d(score weights), dup ---------------------------------------------
-// Forward recomputed from `fused` (x8 bilinear + relu, score 1x1, log-softmax), then
-//   loss += -log p[label] / denom,  dscore = (p*valid - onehot) / denom      (utils.py:43-53)
-//   dWs[u][k] += up[u]*dscore[k], dbs[k] += dscore[k], dup[u] = (up[u] > 0) * sum_k dscore[k]*Ws[u][k]
-// One thread per output pixel; the U x C weight-gradient block is reduced through LDS per
-// 8-channel group and flushed with one global atomic per cell per workgroup.
+// ---- head backward (loss + gradients), in the same commuted form as the forward head ---------------
+// score = bilinear_x8(S) + bs with S = fused . Ws at 1/8 resolution (see pointwise.hip): the relu of the
+// x8 deconv is the identity because fused >= 0, and wherever it is not strictly the identity (all four
+// source features of a channel are 0) the gradient entries that differ are zeroed again by the relu
+// masks of score_conv4 / upscore_conv5 further down, so the linear form gives the reference's gradients.
+// Kernel 1, per output pixel: interpolate S, softmax, loss += -log p[label]/denom,
+//   dscore = (p*valid - onehot)/denom -> dense fp32 [N][H][W][CM]; bias gradient by block reduction.
 template <int CM>
-__global__ __launch_bounds__(256) void head_bwd_kernel(const __bf16* __restrict__ f, const float* __restrict__ ws_g,
-                                                      const float* __restrict__ bs_g, const int32_t* __restrict__ labels,
-                                                      const unsigned long long* __restrict__ count, int N, int Hi,
-                                                      int Wi, int U, int C, double* __restrict__ loss,
-                                                      float* __restrict__ dws, float* __restrict__ dbs,
-                                                      __bf16* __restrict__ dup) {
+__global__ __launch_bounds__(256) void head_loss_kernel(const float* __restrict__ S, const float* __restrict__ bs_g,
+                                                       const int32_t* __restrict__ labels,
+                                                       const unsigned long long* __restrict__ count, int N, int Hi,
+                                                       int Wi, int C, double* __restrict__ loss, float* __restrict__ dbs,
+                                                       float* __restrict__ dscore) {
+  __shared__ float red[CM + 1];
+  if (threadIdx.x <= CM) red[threadIdx.x] = 0.f;
+  __syncthreads();
+  const int Ho = Hi * 8, Wo = Wi * 8;
+  const int64_t npix = (int64_t)N * Ho * Wo;
+  const int64_t opix = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (opix < npix) {
+    const int ox = (int)(opix % Wo);
+    const int oy = (int)((opix / Wo) % Ho);
+    const int n = (int)(opix / ((int64_t)Wo * Ho));
+    const int iy1 = (oy + 4) >> 3, ix1 = (ox + 4) >> 3;
+    const float wy1 = bilinear_w<8>(oy, iy1), wy0 = bilinear_w<8>(oy, iy1 - 1);
+    const float wx1 = bilinear_w<8>(ox, ix1), wx0 = bilinear_w<8>(ox, ix1 - 1);
+    const float w00 = wy0 * wx0, w01 = wy0 * wx1, w10 = wy1 * wx0, w11 = wy1 * wx1;
+    const float* p00 = S + (((int64_t)n * (Hi + 2) + iy1) * (Wi + 2) + ix1) * CM;
+    const int64_t rowp = (int64_t)(Wi + 2) * CM;
+    float sc[CM];
+#pragma unroll
+    for (int k4 = 0; k4 < CM; k4 += 4) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(p00 + k4), b = *reinterpret_cast<const f32x4*>(p00 + CM + k4);
+      const f32x4 c = *reinterpret_cast<const f32x4*>(p00 + rowp + k4),
+                  d = *reinterpret_cast<const f32x4*>(p00 + rowp + CM + k4);
+      const f32x4 v = a * w00 + b * w01 + c * w10 + d * w11;
+      sc[k4] = v.x;
+      sc[k4 + 1] = v.y;
+      sc[k4 + 2] = v.z;
+      sc[k4 + 3] = v.w;
+    }
+#pragma unroll
+    for (int k = 0; k < CM; ++k) sc[k] += bs_g[k < C ? k : C - 1];
+    const int lab = labels[opix];
+    const bool valid = lab >= 0 && lab < C;
+    const float inv_denom = 1.f / (1e-20f + (float)(*count));
+    float m = sc[0];
+#pragma unroll
+    for (int k = 1; k < CM; ++k)
+      if (k < C) m = fmaxf(m, sc[k]);
+    float sum = 0.f, zlab = 0.f;
+#pragma unroll
+    for (int k = 0; k < CM; ++k) {
+      if (k == lab) zlab = sc[k] - m;
+      sc[k] = k < C ? expf(sc[k] - m) : 0.f;
+      sum += sc[k];
+    }
+#pragma unroll
+    for (int k = 0; k < CM; ++k) {
+      const float p = sc[k] / sum;
+      sc[k] = (valid && k < C) ? (p - (k == lab ? 1.f : 0.f)) * inv_denom : 0.f;
+    }
+    float* dst = dscore + opix * CM;
+#pragma unroll
+    for (int k4 = 0; k4 < CM; k4 += 4)
+      *reinterpret_cast<f32x4*>(dst + k4) = f32x4{sc[k4], sc[k4 + 1], sc[k4 + 2], sc[k4 + 3]};
+    if (valid) {
+      atomicAdd(&red[CM], -(zlab - logf(sum)) * inv_denom);  // -(log_softmax)[label] / denom
+#pragma unroll
+      for (int k = 0; k < CM; ++k)
+        if (k < C) atomicAdd(&red[k], sc[k]);
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < C && red[threadIdx.x] != 0.f) atomicAdd(&dbs[threadIdx.x], red[threadIdx.x]);
+  if (threadIdx.x == 0 && red[CM] != 0.f) atomicAdd(loss, (double)red[CM]);
+}
+
+// Kernel 2, per 1/8-resolution pixel: dS[k] = sum over the 16x16 output footprint of w * dscore[k]
+// (gradient of the x8 bilinear deconv), dfused[u] = sum_k dS[k]*Ws[u][k], and the score-weight
+// gradient dWs[u][k] += fused[u]*dS[k] reduced over the workgroup's 256 pixels through LDS.
+template <int CM>
+__global__ __launch_bounds__(256) void head_bwd_lowres_kernel(const float* __restrict__ dscore,
+                                                             const __bf16* __restrict__ f,
+                                                             const float* __restrict__ ws_g, int N, int Hi, int Wi,
+                                                             int U, int C, float* __restrict__ dws,
+                                                             __bf16* __restrict__ df) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
-  float* wsm = sm;                  // [U][CM] score weights (zero padded)
-  float* dsm = wsm + U * CM;        // [256][CM] dscore of this workgroup's pixels
-  float* upm = dsm + 256 * CM;      // [256][8] up values of the current channel group
-  float* accm = upm + 256 * 8;      // [U][CM] weight-gradient accumulator + [CM] bias gradient + [1] loss
+  float* wsm = sm;                                         // [U][CM]
+  float* dsm = wsm + U * CM;                               // [256][CM]
+  __bf16* fm = reinterpret_cast<__bf16*>(dsm + 256 * CM);  // [256][U]
   for (int i = threadIdx.x; i < U * CM; i += 256) {
     const int u = i / CM, k = i - u * CM;
     wsm[i] = k < C ? ws_g[u * C + k] : 0.f;
   }
-  for (int i = threadIdx.x; i < U * CM + CM + 1; i += 256) accm[i] = 0.f;
-  __syncthreads();
-  const int Ho = Hi * 8, Wo = Wi * 8;
-  const int tilesx = (Wo + 31) / 32;
-  const int tx = blockIdx.x % tilesx;
-  int r = blockIdx.x / tilesx;
-  const int tilesy = Hi;
-  const int ty = r % tilesy;
-  const int n = r / tilesy;
-  const int ox = tx * 32 + (threadIdx.x & 31), oy = ty * 8 + (threadIdx.x >> 5);
-  const bool inside = ox < Wo;
-  const int oxc = inside ? ox : Wo - 1;
-  int iy1, ix1;
-  float wy1, wy0, wx1, wx0;
-  {
-    const int t = oy + 4;
-    iy1 = t >> 3;
-    wy1 = bilinear_w<8>(oy, iy1);
-    wy0 = bilinear_w<8>(oy, iy1 - 1);
-    const int t2 = oxc + 4;
-    ix1 = t2 >> 3;
-    wx1 = bilinear_w<8>(oxc, ix1);
-    wx0 = bilinear_w<8>(oxc, ix1 - 1);
-  }
-  const float w00 = wy0 * wx0, w01 = wy0 * wx1, w10 = wy1 * wx0, w11 = wy1 * wx1;
-  const __bf16* p00 = f + (((int64_t)n * (Hi + 2) + iy1) * (Wi + 2) + ix1) * U;
-  const int64_t rowp = (int64_t)(Wi + 2) * U;
-  auto up_group = [&](int u0, float (&up)[8]) {
-    const u32x4 a00 = *reinterpret_cast<const u32x4*>(p00 + u0), a01 = *reinterpret_cast<const u32x4*>(p00 + U + u0);
-    const u32x4 a10 = *reinterpret_cast<const u32x4*>(p00 + rowp + u0),
-                a11 = *reinterpret_cast<const u32x4*>(p00 + rowp + U + u0);
+  const int Ho = 8 * Hi, Wo = 8 * Wi;
+  const int64_t total = (int64_t)N * Hi * Wi;
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const bool live = idx < total;
+  float ds[CM];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      up[2 * q] = fmaxf(bf_lo(a00[q]) * w00 + bf_lo(a01[q]) * w01 + bf_lo(a10[q]) * w10 + bf_lo(a11[q]) * w11, 0.f);
-      up[2 * q + 1] = fmaxf(bf_hi(a00[q]) * w00 + bf_hi(a01[q]) * w01 + bf_hi(a10[q]) * w10 + bf_hi(a11[q]) * w11, 0.f);
+  for (int k = 0; k < CM; ++k) ds[k] = 0.f;
+  int64_t pad_off = 0;
+  if (live) {
+    const int j = (int)(idx % Wi);
+    const int i = (int)((idx / Wi) % Hi);
+    const int n = (int)(idx / ((int64_t)Wi * Hi));
+    for (int oy = 8 * i - 4; oy <= 8 * i + 11; ++oy) {
+      if (oy < 0 || oy >= Ho) continue;
+      const float wy = bilinear_w<8>(oy, i);
+      const float* row = dscore + (((int64_t)n * Ho + oy) * Wo) * CM;
+      for (int ox = 8 * j - 4; ox <= 8 * j + 11; ++ox) {
+        if (ox < 0 || ox >= Wo) continue;
+        const float w = wy * bilinear_w<8>(ox, j);
+#pragma unroll
+        for (int k4 = 0; k4 < CM; k4 += 4) {
+          const f32x4 g = *reinterpret_cast<const f32x4*>(row + (int64_t)ox * CM + k4);
+          ds[k4] = fmaf(w, g.x, ds[k4]);
+          ds[k4 + 1] = fmaf(w, g.y, ds[k4 + 1]);
+          ds[k4 + 2] = fmaf(w, g.z, ds[k4 + 2]);
+          ds[k4 + 3] = fmaf(w, g.w, ds[k4 + 3]);
+        }
+      }
     }
-  };
-  // pass 1: score -> softmax -> dscore
-  float sc[CM];
+    pad_off = (((int64_t)n * (Hi + 2) + (i + 1)) * (Wi + 2) + (j + 1)) * U;
+  }
 #pragma unroll
-  for (int k = 0; k < CM; ++k) sc[k] = k < C ? bs_g[k] : 0.f;
+  for (int k = 0; k < CM; ++k) dsm[threadIdx.x * CM + k] = ds[k];
+  __syncthreads();  // wsm ready
   for (int u0 = 0; u0 < U; u0 += 8) {
-    float up[8];
-    up_group(u0, up);
+    u32x4 fv = u32x4{0u, 0u, 0u, 0u};
+    if (live) fv = *reinterpret_cast<const u32x4*>(f + pad_off + u0);
+    *reinterpret_cast<u32x4*>(fm + threadIdx.x * U + u0) = fv;
+    if (live) {
+      float d[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
+      for (int q = 0; q < 8; ++q) {
+        float a = 0.f;
 #pragma unroll
-      for (int k = 0; k < CM; ++k) sc[k] = fmaf(up[i], wsm[(u0 + i) * CM + k], sc[k]);
-  }
-  const int64_t opix = ((int64_t)n * Ho + oy) * Wo + oxc;
-  const int lab = inside ? labels[opix] : -1;
-  const bool valid = lab >= 0 && lab < C;
-  const float inv_denom = 1.f / (1e-20f + (float)(*count));
-  float m = sc[0];
-#pragma unroll
-  for (int k = 1; k < CM; ++k)
-    if (k < C) m = fmaxf(m, sc[k]);
-  float sum = 0.f, zlab = 0.f;
-#pragma unroll
-  for (int k = 0; k < CM; ++k) {
-    if (k == lab) zlab = sc[k] - m;
-    sc[k] = k < C ? expf(sc[k] - m) : 0.f;
-    sum += sc[k];
-  }
-  const float my_loss = valid ? -(zlab - logf(sum)) * inv_denom : 0.f;  // -(log_softmax)[label] / denom
-#pragma unroll
-  for (int k = 0; k < CM; ++k) {
-    const float p = sc[k] / sum;
-    sc[k] = valid ? (p - (k == lab ? 1.f : 0.f)) * inv_denom : 0.f;
-    if (k >= C) sc[k] = 0.f;
-    dsm[threadIdx.x * CM + k] = sc[k];
-  }
-  if (valid) {
-    atomicAdd(&accm[U * CM + CM], my_loss);
-#pragma unroll
-    for (int k = 0; k < CM; ++k)
-      if (k < C) atomicAdd(&accm[U * CM + k], sc[k]);
-  }
-  // pass 2, per 8-channel group: dup and the weight-gradient partial sums
-  __bf16* dup_px = dup + opix * U;
-  const int cell = threadIdx.x % (8 * CM);      // (channel-in-group, class) cell this thread reduces
-  const int seg = threadIdx.x / (8 * CM);       // pixel segment
-  const int nseg = 256 / (8 * CM);              // >= 2 for CM <= 16, 1 for CM = 32
-  const int ci = cell / CM, ck = cell - ci * CM;
-  for (int u0 = 0; u0 < U; u0 += 8) {
-    float up[8];
-    up_group(u0, up);
-    float d[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      float a = 0.f;
-#pragma unroll
-      for (int k = 0; k < CM; ++k) a = fmaf(sc[k], wsm[(u0 + i) * CM + k], a);
-      d[i] = up[i] > 0.f ? a : 0.f;
-      upm[threadIdx.x * 8 + i] = up[i];
-    }
-    if (inside)
-      *reinterpret_cast<u32x4*>(dup_px + u0) =
+        for (int k = 0; k < CM; ++k) a = fmaf(ds[k], wsm[(u0 + q) * CM + k], a);
+        d[q] = a;
+      }
+      *reinterpret_cast<u32x4*>(df + pad_off + u0) =
           u32x4{pack_bf16x2(d[0], d[1]), pack_bf16x2(d[2], d[3]), pack_bf16x2(d[4], d[5]), pack_bf16x2(d[6], d[7])};
-    __syncthreads();
-    if (seg < nseg) {
-      const int per = 256 / nseg;
-      float a = 0.f;
-      for (int px = seg * per; px < (seg + 1) * per; ++px) a = fmaf(upm[px * 8 + ci], dsm[px * CM + ck], a);
-      atomicAdd(&accm[(u0 + ci) * CM + ck], a);
     }
-    __syncthreads();
   }
-  for (int i = threadIdx.x; i < U * CM; i += 256) {
-    const int u = i / CM, k = i - u * CM;
-    if (k < C && accm[i] != 0.f) atomicAdd(&dws[u * C + k], accm[i]);
+  __syncthreads();
+  // weight gradient: cell (u, k) = sum over this workgroup's pixels of fused[px][u] * dS[px][k]
+  for (int cell = threadIdx.x; cell < U * CM; cell += 256) {
+    const int u = cell / CM, k = cell - u * CM;
+    if (k >= C) continue;
+    float a = 0.f;
+    for (int px = 0; px < 256; ++px) a = fmaf((float)fm[px * U + u], dsm[px * CM + k], a);
+    if (a != 0.f) atomicAdd(&dws[u * C + k], a);
   }
-  if (threadIdx.x < C && accm[U * CM + threadIdx.x] != 0.f) atomicAdd(&dbs[threadIdx.x], accm[U * CM + threadIdx.x]);
-  if (threadIdx.x == 0 && accm[U * CM + CM] != 0.f) atomicAdd(loss, (double)accm[U * CM + CM]);
 }
 
 // ---- conv1_1 filter gradient: dW[t][co] = sum_pix in[pix][t] * dy[pix][co]  (fp32 input, K = 9*CIN) ----
@@ -464,15 +446,6 @@ extern "C" int xv_upsample2x_bwd(const xv_act* dfused, const xv_act* s5, const x
   return xv_launch_status();
 }
 
-extern "C" int xv_upsample8x_bwd(const void* dup, const xv_act* dfused, void* stream) {
-  XV_CHECK_ARG(dup && dfused && dfused->data);
-  XV_CHECK_SHAPE(dfused->n > 0 && (dfused->c & 7) == 0);
-  const int64_t total = (int64_t)dfused->n * dfused->h * dfused->w * (dfused->c >> 3);
-  hipLaunchKernelGGL(upsample8x_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
-                     (const __bf16*)dup, (__bf16*)dfused->data, dfused->n, dfused->h, dfused->w, dfused->c);
-  return xv_launch_status();
-}
-
 extern "C" int xv_count_valid_labels(const int32_t* labels, int num_classes, int64_t npix, int64_t* count, void* stream) {
   XV_CHECK_ARG(labels && count);
   XV_CHECK_SHAPE(npix > 0 && num_classes >= 1);
@@ -481,35 +454,60 @@ extern "C" int xv_count_valid_labels(const int32_t* labels, int num_classes, int
   return xv_launch_status();
 }
 
+extern "C" size_t xv_decoder_head_bwd_workspace_bytes(int n, int h, int w, int num_classes) {
+  if (n <= 0 || h <= 0 || w <= 0 || num_classes < 1 || num_classes > 32) return 0;
+  const size_t cm = (size_t)(num_classes + 3) / 4 * 4;
+  return ((size_t)n * (h + 2) * (w + 2) + (size_t)n * h * w * 64) * cm * sizeof(float);
+}
+
+extern "C" int xv_score_lowres(const xv_act* fused, const float* w_score, int num_classes, float* S, void* stream);
+
 extern "C" int xv_decoder_head_bwd(const xv_act* fused, const float* w_score, const float* b_score, const int32_t* labels,
                                    const int64_t* valid_count, int num_classes, double* loss, float* dw_score,
-                                   float* db_score, void* dup, void* stream) {
-  XV_CHECK_ARG(fused && fused->data && w_score && b_score && labels && valid_count && loss && dw_score && db_score && dup);
-  XV_CHECK_SHAPE(fused->c > 0 && (fused->c & 7) == 0 && fused->c <= 128 && num_classes >= 1 && num_classes <= 32);
-  const int Wo = fused->w * 8;
-  const int64_t nblk = (int64_t)((Wo + 31) / 32) * fused->h * fused->n;
-  XV_CHECK_SHAPE(nblk <= 0x7fffffff);
+                                   float* db_score, const xv_act* dfused, void* workspace, size_t workspace_bytes,
+                                   void* stream) {
+  XV_CHECK_ARG(fused && fused->data && w_score && b_score && labels && valid_count && loss && dw_score && db_score &&
+               dfused && dfused->data && workspace);
+  XV_CHECK_SHAPE(fused->c > 0 && (fused->c & 7) == 0 && fused->c <= 256 && num_classes >= 1 && num_classes <= 32);
+  XV_CHECK_SHAPE(dfused->n == fused->n && dfused->h == fused->h && dfused->w == fused->w && dfused->c == fused->c);
+  if (workspace_bytes < xv_decoder_head_bwd_workspace_bytes(fused->n, fused->h, fused->w, num_classes)) return XV_EWORKSPACE;
+  XV_CHECK_ARG(((uintptr_t)workspace & 15) == 0);
   hipStream_t s = (hipStream_t)stream;
+  const int CM = (num_classes + 3) / 4 * 4;
+  float* S = (float*)workspace;
+  float* dscore = S + (size_t)fused->n * (fused->h + 2) * (fused->w + 2) * CM;
+  int rc = xv_score_lowres(fused, w_score, num_classes, S, stream);
+  if (rc != XV_OK) return rc;
+  const int64_t npix = (int64_t)fused->n * fused->h * fused->w * 64;
+  const int64_t lowres = (int64_t)fused->n * fused->h * fused->w;
+  XV_CHECK_SHAPE((npix + 255) / 256 <= 0x7fffffff);
+  const unsigned g1 = (unsigned)((npix + 255) / 256), g2 = (unsigned)((lowres + 255) / 256);
   const int U = fused->c;
-#define XV_HB(CMV)                                                                                                  \
-  {                                                                                                                 \
-    const size_t lds = (size_t)(2 * U * CMV + 256 * CMV + 256 * 8 + CMV + 1) * 4;                                  \
-    static bool attr = false;                                                                                       \
-    if (!attr) {                                                                                                    \
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&head_bwd_kernel<CMV>),                     \
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                   \
-      if (e != hipSuccess) return (int)e;                                                                           \
-      attr = true;                                                                                                  \
-    }                                                                                                               \
-    hipLaunchKernelGGL(head_bwd_kernel<CMV>, dim3((unsigned)nblk), dim3(256), lds, s, (const __bf16*)fused->data,   \
-                       w_score, b_score, labels, reinterpret_cast<const unsigned long long*>(valid_count), fused->n, \
-                       fused->h, fused->w, U, num_classes, loss, dw_score, db_score, (__bf16*)dup);                 \
+  const unsigned long long* cnt = reinterpret_cast<const unsigned long long*>(valid_count);
+#define XV_HB(CMV)                                                                                                   \
+  {                                                                                                                  \
+    hipLaunchKernelGGL(head_loss_kernel<CMV>, dim3(g1), dim3(256), 0, s, (const float*)S, b_score, labels, cnt,       \
+                       fused->n, fused->h, fused->w, num_classes, loss, db_score, dscore);                            \
+    const size_t lds = (size_t)(U * CMV + 256 * CMV) * 4 + (size_t)256 * U * 2;                                       \
+    static bool attr = false;                                                                                        \
+    if (!attr) {                                                                                                     \
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&head_bwd_lowres_kernel<CMV>),                \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                    \
+      if (e != hipSuccess) return (int)e;                                                                            \
+      attr = true;                                                                                                   \
+    }                                                                                                                \
+    hipLaunchKernelGGL(head_bwd_lowres_kernel<CMV>, dim3(g2), dim3(256), lds, s, (const float*)dscore,                \
+                       (const __bf16*)fused->data, w_score, fused->n, fused->h, fused->w, U, num_classes, dw_score,   \
+                       (__bf16*)dfused->data);                                                                        \
   }
-  switch ((num_classes + 3) / 4) {
+  switch (CM / 4) {
     case 1: XV_HB(4) break;
     case 2: XV_HB(8) break;
     case 3: XV_HB(12) break;
     case 4: XV_HB(16) break;
+    case 5: XV_HB(20) break;
+    case 6: XV_HB(24) break;
+    case 7: XV_HB(28) break;
     default: XV_HB(32) break;
   }
 #undef XV_HB

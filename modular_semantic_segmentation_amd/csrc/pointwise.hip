@@ -398,6 +398,32 @@ extern "C" int xv_upsample2x_relu_add(const xv_act* x, const xv_act* residual, c
   return xv_launch_status();
 }
 
+// S = fused . Ws at 1/8 resolution into a zero-bordered fp32 [N][h+2][w+2][CM] buffer (shared by the
+// forward head and the head backward)
+extern "C" int xv_score_lowres(const xv_act* fused, const float* w_score, int num_classes, float* S, void* stream) {
+  XV_CHECK_ARG(fused && fused->data && w_score && S);
+  XV_CHECK_SHAPE(fused->c > 0 && (fused->c & 7) == 0 && num_classes >= 1 && num_classes <= 32);
+  const int64_t lowres = (int64_t)fused->n * (fused->h + 2) * (fused->w + 2);
+  const unsigned g1 = (unsigned)((lowres + 255) / 256);
+  hipStream_t s = (hipStream_t)stream;
+  const __bf16* f = (const __bf16*)fused->data;
+#define XV_SL(CMV)                                                                                               \
+  hipLaunchKernelGGL(score_lowres_kernel<CMV>, dim3(g1), dim3(256), 0, s, f, w_score, fused->n, fused->h, fused->w, \
+                     fused->c, num_classes, S)
+  switch ((num_classes + 3) / 4) {
+    case 1: XV_SL(4); break;
+    case 2: XV_SL(8); break;
+    case 3: XV_SL(12); break;
+    case 4: XV_SL(16); break;
+    case 5: XV_SL(20); break;
+    case 6: XV_SL(24); break;
+    case 7: XV_SL(28); break;
+    default: XV_SL(32); break;
+  }
+#undef XV_SL
+  return xv_launch_status();
+}
+
 extern "C" size_t xv_decoder_head_workspace_bytes(int n, int h, int w, int num_classes) {
   if (n <= 0 || h <= 0 || w <= 0 || num_classes < 1 || num_classes > 32) return 0;
   return (size_t)n * (h + 2) * (w + 2) * ((num_classes + 3) / 4 * 4) * sizeof(float);

@@ -290,12 +290,6 @@ def upsample2x_bwd(dfused, s5, ds5):
     return ds5
 
 
-def upsample8x_bwd(dup, dfused):
-    _need(dup, torch.bfloat16, 'dup')
-    _lib.check(_lib.lib().xv_upsample8x_bwd(_ptr(dup), dfused.xv(), _stream()), 'xv_upsample8x_bwd')
-    return dfused
-
-
 def count_valid_labels(labels, num_classes, count):
     _need(labels, torch.int32, 'labels')
     _need(count, torch.int64, 'count')
@@ -303,13 +297,18 @@ def count_valid_labels(labels, num_classes, count):
                'xv_count_valid_labels')
 
 
-def decoder_head_bwd(fused, w_score, b_score, labels, count, num_classes, loss, dw_score, db_score, dup):
+def decoder_head_bwd(fused, w_score, b_score, labels, count, num_classes, loss, dw_score, db_score, dfused,
+                     workspace=None):
     _need(labels, torch.int32, 'labels')
     _need(loss, torch.float64, 'loss')
-    _need(dup, torch.bfloat16, 'dup')
+    if workspace is None:
+        nbytes = _lib.lib().xv_decoder_head_bwd_workspace_bytes(fused.n, fused.h, fused.w, num_classes)
+        workspace = torch.empty(nbytes // 4, dtype=torch.float32, device=fused.t.device)
     rc = _lib.lib().xv_decoder_head_bwd(fused.xv(), _ptr(w_score), _ptr(b_score), _ptr(labels), _ptr(count), num_classes,
-                                       _ptr(loss), _ptr(dw_score), _ptr(db_score), _ptr(dup), _stream())
+                                       _ptr(loss), _ptr(dw_score), _ptr(db_score), dfused.xv(), _ptr(workspace),
+                                       workspace.numel() * 4, _stream())
     _lib.check(rc, 'xv_decoder_head_bwd')
+    return workspace
 
 
 def adam_step(param, grad, m, v, lr_t, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=1.0):

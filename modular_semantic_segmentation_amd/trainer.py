@@ -141,15 +141,11 @@ class FcnTrainer(object):
         if reducer is not None:
             reducer.allreduce_now(self.count)           # loss denominator = labelled pixels of the GLOBAL batch
         G = lambda name, kind: self.view(self.grad, name, kind)   # noqa: E731
-        key = ('dup', n, h, w)
-        dup = self._g.get(key)
-        if dup is None:
-            dup = torch.empty((n, h, w, e.Up), dtype=torch.bfloat16, device=e.device)
-            self._g[key] = dup
-        ops.decoder_head_bwd(L['fused'], e.w['score'], e.b['score'], labels, self.count, e.C, self.loss,
-                             G('score', 'kernel'), G('score', 'bias'), dup)
         dfused = self._gact(L['fused'], 'dfused')
-        ops.upsample8x_bwd(dup, dfused)
+        key = ('head_ws', n, h, w)
+        self._g[key] = ops.decoder_head_bwd(L['fused'], e.w['score'], e.b['score'], labels, self.count, e.C, self.loss,
+                                            G('score', 'kernel'), G('score', 'bias'), dfused,
+                                            workspace=self._g.get(key))
         ds4 = ops.relu_bwd(dfused, L['score_conv4'], self._gact(L['score_conv4'], 'ds4'))
         ds5 = ops.upsample2x_bwd(dfused, L['score_conv5'], self._gact(L['score_conv5'], 'ds5'))
         ops.conv2d_bwd_filter(L['conv5_3'], ds5, G('score_conv5', 'kernel'), G('score_conv5', 'bias'), 1)
