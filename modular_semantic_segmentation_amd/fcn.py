@@ -101,8 +101,20 @@ class FcnEngine(object):
                 raise NotImplementedError(
                     '%s/%s/kernel is not the constant bilinear kernel (custom_layers.py:8-25); the dense '
                     'transposed-conv fallback is not built' % (p, name))
-            if '%s/%s/gamma' % (p, name) in v:
-                raise NotImplementedError('batch-norm after a deconv layer is not supported on this path')
+        # Batch norm after a deconv (custom_layers.py:112-119) is a per-channel affine before its relu.  A
+        # positive scale with zero shift commutes with the relu and the (linear) deconv and is folded into
+        # the 1x1 conv on the other side; a non-zero shift would need the un-commuted decoder head.
+        deconv_scale = {}
+        for name in ('upscore_conv5', 'upscore'):
+            layer = '%s/%s' % (p, name)
+            if layer + '/gamma' in v:
+                s = v[layer + '/gamma'] / np.sqrt(v[layer + '/moving_variance'] + BN_EPS)
+                t = v[layer + '/beta'] - v[layer + '/moving_mean'] * s
+                if np.any(s <= 0) or np.any(np.abs(t) > 1e-12):
+                    raise NotImplementedError(
+                        '%s has a batch norm with a non-zero shift or non-positive scale; only scale-only batch '
+                        'norm after the bilinear deconvs is supported on this path' % layer)
+                deconv_scale[name] = s.astype(np.float32)
         self.w, self.b = {}, {}
 
         def up(a):
@@ -114,6 +126,9 @@ class FcnEngine(object):
             self.b[name] = up(b)
         for name in ('score_conv4', 'score_conv5'):
             k, b = _fold_bn(v, '%s/%s' % (p, name), v['%s/%s/kernel' % (p, name)], v['%s/%s/bias' % (p, name)])
+            if name == 'score_conv5' and 'upscore_conv5' in deconv_scale:
+                # s*relu(up2(relu(z))) == relu(up2(relu(s*z))) for s > 0
+                k, b = k * deconv_scale['upscore_conv5'], b * deconv_scale['upscore_conv5']
             kp = np.zeros((1, 1, 512, self.Up), np.float32)
             kp[..., :self.U] = k
             bp = np.zeros(self.Up, np.float32)
@@ -121,8 +136,11 @@ class FcnEngine(object):
             self.w[name] = ops.pack_conv_weights(up(kp))
             self.b[name] = up(bp)
         k, b = _fold_bn(v, p + '/score', v[p + '/score/kernel'], v[p + '/score/bias'])
+        k = k.reshape(self.U, self.C)
+        if 'upscore' in deconv_scale:
+            k = k * deconv_scale['upscore'][:, None]       # score(s*up) == (s-scaled score weights)(up)
         ws = np.zeros((self.Up, self.C), np.float32)
-        ws[:self.U] = k.reshape(self.U, self.C)
+        ws[:self.U] = k
         self.w['score'] = up(ws)
         self.b['score'] = up(b)
         torch.cuda.synchronize(dev)

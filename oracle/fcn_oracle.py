@@ -110,14 +110,29 @@ def fcn_forward(x_nhwc, weights, prefix, policy='fp32', keep=None):
     keep = set(keep) if keep is not None else {'fused', 'upscore', 'score'}
     out = {}
 
+    def _bn(name):
+        """Inference batch norm AFTER the conv and BEFORE the activation (custom_layers.py:126-137;
+        [TF1] epsilon 1e-3), expressed as a per-channel scale/shift of the conv output."""
+        g = weights.get('%s/%s/gamma' % (prefix, name))
+        if g is None:
+            return None
+        s = g / np.sqrt(weights['%s/%s/moving_variance' % (prefix, name)] + 1e-3)
+        return s.astype(np.float32), (weights['%s/%s/beta' % (prefix, name)] -
+                                      weights['%s/%s/moving_mean' % (prefix, name)] * s).astype(np.float32)
+
     def W(name):
         w = weights['%s/%s/kernel' % (prefix, name)]
+        bn = _bn(name)
+        if bn is not None:          # y = s*(conv(x,W)+b)+t == conv(x, W*s) + (b*s+t): what the MI355X path folds
+            w = w * bn[0]
         if policy == 'bf16' and name != 'conv1_1':
             w = round_bf16(w)
         return w
 
     def B(name):
-        return weights['%s/%s/bias' % (prefix, name)]
+        b = weights['%s/%s/bias' % (prefix, name)]
+        bn = _bn(name)
+        return b if bn is None else (b * bn[0] + bn[1]).astype(np.float32)
 
     with torch.no_grad():
         h = _t(np.asarray(x_nhwc, np.float32)).permute(0, 3, 1, 2).contiguous()
@@ -134,11 +149,19 @@ def fcn_forward(x_nhwc, weights, prefix, policy='fp32', keep=None):
         score_conv5 = rnd(conv2d_same(layers['conv5_3'], W('score_conv5'), B('score_conv5'), relu=True))
         # deconv kernels are exact in bf16 only for the 4x4 one; they are constants applied
         # in fp32 on the MI355X path, so they are never rounded here.
-        up5 = deconv_same(score_conv5, weights['%s/upscore_conv5/kernel' % prefix], 2, relu=True)
+        def deconv_bn_relu(t, name, stride):
+            """deconv -> [batch norm] -> relu (custom_layers.py:112-119)."""
+            y = deconv_same(t, weights['%s/%s/kernel' % (prefix, name)], stride, relu=False)
+            bn = _bn(name)
+            if bn is not None:
+                y = y * _t(bn[0]).view(1, -1, 1, 1) + _t(bn[1]).view(1, -1, 1, 1)
+            return F.relu(y)
+
+        up5 = deconv_bn_relu(score_conv5, 'upscore_conv5', 2)
         fused = rnd(score_conv4 + up5)                                   # tf.add_n (simple_fcn.py:85)
         layers.update(score_conv4=score_conv4, score_conv5=score_conv5, upscore_conv5=up5,
                       fused=fused)
-        upscore = deconv_same(fused, weights['%s/upscore/kernel' % prefix], 8, relu=True)
+        upscore = deconv_bn_relu(fused, 'upscore', 8)
         score = conv2d_same(upscore, W('score'), B('score'), relu=False)  # no activation
         layers.update(upscore=upscore, score=score)
         for k in keep:

@@ -206,3 +206,36 @@ def test_hip_graph_replay_matches_eager(gpu, tmp_path, golden_dir):
     assert np.array_equal(net.predict(a), eager_a)
     # a different batch size falls back to eager launches
     assert np.array_equal(net.predict({k: v[:1] for k, v in a.items()}), eager_a[:1])
+
+
+def test_simple_fcn_with_batch_normalization_inference(gpu, tmp_path):
+    """batch_normalization=True: moving statistics are folded into (W, b) at load time; parity against the
+    oracle's conv -> BN -> relu (custom_layers.py:126-137)."""
+    from modular_semantic_segmentation_amd import get_model
+    w, _ = _weights(tmp_path, 'rgb', 3, 1, 0.02)
+    rng = np.random.default_rng(5)
+    for key in list(w):
+        if key.endswith('/kernel'):
+            layer = key[:-len('/kernel')]
+            deconv = 'upscore' in key
+            c = w[key].shape[2] if deconv else w[key].shape[3]
+            w[layer + '/gamma'] = rng.uniform(0.7, 1.3, c).astype(np.float32)
+            w[layer + '/moving_variance'] = rng.uniform(0.6, 1.4, c).astype(np.float32)
+            # the bilinear deconvs take a scale-only batch norm on this path (see fcn.FcnEngine.load)
+            w[layer + '/beta'] = np.zeros(c, np.float32) if deconv else (0.05 * rng.standard_normal(c)).astype(np.float32)
+            w[layer + '/moving_mean'] = np.zeros(c, np.float32) if deconv else \
+                (0.05 * rng.standard_normal(c)).astype(np.float32)
+    path = os.path.join(str(tmp_path), 'bn.npz')
+    np.savez(path, **w)
+    data = _data(1, seed=21)
+    net = get_model('fcn')('rgb', _desc(depth=False), 'rgb', num_units=U, batch_normalization=True, batchsize=1)
+    assert 'rgb/conv3_2/moving_variance' in net.variables
+    net.import_weights(path, warnings=False)
+    score = net.predict(data, output_attr='score')
+    label = net.predict(data)
+    ref = fo.fcn_forward(data['rgb'], w, 'rgb', 'bf16')['score']
+    _check_logits_and_labels(score, label, ref, 'SimpleFCN with BN')
+    # and the fold really matters: ignoring the BN variables gives different logits
+    plain = {k: v for k, v in w.items() if k.rsplit('/', 1)[1] in ('kernel', 'bias')}
+    ref_plain = fo.fcn_forward(data['rgb'], plain, 'rgb', 'bf16')['score']
+    assert np.abs(ref_plain - ref).max() > 0.05 * np.abs(ref).max()

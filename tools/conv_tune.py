@@ -51,6 +51,20 @@ def main():
                 row += '%-9.0f' % (flops / ms / 1e9)
             except _lib.XvError:
                 row += '%-9s' % '-'
+        # filter gradient of the same layer (one configuration)
+        dy = ops.Act(args.batch, h, w, cout)
+        dy.interior().normal_()
+        dw = torch.zeros((k, k, cin, cout), device='cuda')
+        db = torch.zeros(cout, device='cuda')
+        for _ in range(2):
+            ops.conv2d_bwd_filter(x, dy, dw, db, k)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(args.iters):
+            ops.conv2d_bwd_filter(x, dy, dw, db, k)
+        e1.record()
+        torch.cuda.synchronize()
+        row += ' wgrad %-6.0f' % (flops / (e0.elapsed_time(e1) / args.iters) / 1e9)
         print(row, flush=True)
 
 
