@@ -239,3 +239,24 @@ def test_simple_fcn_with_batch_normalization_inference(gpu, tmp_path):
     plain = {k: v for k, v in w.items() if k.rsplit('/', 1)[1] in ('kernel', 'bias')}
     ref_plain = fo.fcn_forward(data['rgb'], plain, 'rgb', 'bf16')['score']
     assert np.abs(ref_plain - ref).max() > 0.05 * np.abs(ref).max()
+
+
+def test_odd_sizes_num_units_20_classes_14(gpu, tmp_path):
+    """num_units not a multiple of 64 (experiment 868 uses 20), 14 classes (Synthia), image sides that are
+    multiples of 16 but not of the 32-pixel tiles."""
+    from modular_semantic_segmentation_amd.fcn import FcnEngine
+    u, c, h, w = 20, 14, 48, 80
+    wts = fo.init_fcn_weights('depth', 1, u, c, seed=7, bias_scale=0.02)
+    wts['depth/conv1_1/kernel'] *= 2e-4
+    for k in wts:
+        if k.endswith('/kernel') and 'upscore' not in k and 'conv1_1' not in k:
+            wts[k] *= 1.6
+    rng = np.random.default_rng(8)
+    x = rng.integers(0, 65536, (2, h, w, 1)).astype(np.float32)
+    eng = FcnEngine('depth', 1, u, c, wts)
+    out = eng.forward(torch.from_numpy(x).cuda(), want=('score', 'prob', 'label'))
+    torch.cuda.synchronize()
+    ref = fo.fcn_forward(x, wts, 'depth', 'bf16')['score']
+    assert out['score'].shape == (2, h, w, c)
+    _check_logits_and_labels(out['score'].cpu().numpy(), out['label'].cpu().numpy(), ref, 'U=20 C=14 48x80')
+    np.testing.assert_allclose(out['prob'].cpu().numpy(), fo.softmax(out['score'].cpu().numpy()), rtol=1e-5, atol=1e-7)
