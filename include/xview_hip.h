@@ -159,9 +159,10 @@ int xv_conv2d_bwd_filter(const xv_act* x, const xv_act* dy, float* dw_hwio, floa
 /* dbias[c] += sum over all pixels of dy[.., c] (BiasAddGrad).                                        */
 int xv_bias_grad(const xv_act* dy, float* dbias, void* stream);
 
-/* conv1_1: dW[3][3][cin][64] += sum_pixels x[pix+tap][cin] * dy[pix][:] on the raw float32 input.   */
+/* conv1_1: dW[3][3][cin][64] += sum_pixels x[pix+tap][cin] * dy[pix][:] on the raw float32 input, and
+ * dbias[64] += sum_pixels dy (may be NULL).                                                         */
 int xv_conv2d_first_bwd_filter(const float* x, int n, int h, int w, int cin, const xv_act* dy, float* dw_hwio,
-                               void* stream);
+                               float* dbias, void* stream);
 
 /* MaxPoolGrad + ReluGrad: dy = dpooled routed to the first maximum of each 2x2 window, zero where y <= 0. */
 int xv_maxpool2x2_bwd(const xv_act* y, const xv_act* dpooled, const xv_act* dy, void* stream);

@@ -315,21 +315,25 @@ __global__ __launch_bounds__(256) void head_bwd_lowres_kernel(const float* __res
   }
 }
 
-// ---- conv1_1 filter gradient: dW[t][co] = sum_pix in[pix][t] * dy[pix][co]  (fp32 input, K = 9*CIN) ----
+// ---- conv1_1 filter + bias gradient: dW[t][co] = sum_pix in[pix][t] * dy[pix][co], db[co] = sum_pix dy ----
+// fp32 input, K = 9*CIN taps.  128-pixel chunks are staged in LDS (input taps fp32, dy bf16); wave w owns 32 of
+// the pixels, lane = output channel, all K accumulators in registers: per pixel one 2-byte dy read and K/4
+// wave-uniform (broadcast) 16-byte tap reads feed K FMAs.
 template <int CIN>
 __global__ __launch_bounds__(256) void conv_first_wgrad_kernel(const float* __restrict__ x, const __bf16* __restrict__ dy,
-                                                              float* __restrict__ dw, int N, int H, int W,
-                                                              int chunks_per_block) {
+                                                              float* __restrict__ dw, float* __restrict__ db, int N,
+                                                              int H, int W, int chunks_per_block) {
   constexpr int K = 9 * CIN;
-  constexpr int TPW = (K + 3) / 4;  // taps per wave (wave w owns taps w, w+4, ...)
-  constexpr int PX = 128;           // pixels per staged chunk
-  __shared__ float ins[PX * K];
+  constexpr int KP = (K + 3) / 4 * 4;  // padded to a multiple of 4 for 16-byte reads
+  constexpr int PX = 128;              // pixels per staged chunk
+  __shared__ __attribute__((aligned(16))) float ins[PX * KP];
   __shared__ __attribute__((aligned(16))) __bf16 dys[PX * 64];
   const int64_t npix = (int64_t)N * H * W;
   const int co = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  float acc[TPW];
+  float acc[KP];
 #pragma unroll
-  for (int i = 0; i < TPW; ++i) acc[i] = 0.f;
+  for (int i = 0; i < KP; ++i) acc[i] = 0.f;
+  float bacc = 0.f;
   for (int ch = 0; ch < chunks_per_block; ++ch) {
     const int64_t base = ((int64_t)blockIdx.x * chunks_per_block + ch) * PX;
     if (base >= npix) break;
@@ -347,8 +351,10 @@ __global__ __launch_bounds__(256) void conv_first_wgrad_kernel(const float* __re
           const bool in = ok && yy >= 0 && yy < H && xx >= 0 && xx < W;
           const float* src = x + (((int64_t)n * H + (in ? yy : 0)) * W + (in ? xx : 0)) * CIN;
 #pragma unroll
-          for (int c = 0; c < CIN; ++c) ins[threadIdx.x * K + (dy_ * 3 + dx) * CIN + c] = in ? src[c] : 0.f;
+          for (int c = 0; c < CIN; ++c) ins[threadIdx.x * KP + (dy_ * 3 + dx) * CIN + c] = in ? src[c] : 0.f;
         }
+#pragma unroll
+      for (int t = K; t < KP; ++t) ins[threadIdx.x * KP + t] = 0.f;
     }
 #pragma unroll
     for (int it = 0; it < PX * 8 / 256; ++it) {
@@ -363,20 +369,23 @@ __global__ __launch_bounds__(256) void conv_first_wgrad_kernel(const float* __re
       *reinterpret_cast<u32x4*>(dys + lp * 64 + s * 8) = v;
     }
     __syncthreads();
-    for (int px = 0; px < PX; ++px) {
+#pragma unroll 2
+    for (int px = wv * 32; px < wv * 32 + 32; ++px) {
       const float g = (float)dys[px * 64 + co];
+      bacc += g;
 #pragma unroll
-      for (int i = 0; i < TPW; ++i) {
-        const int t = wv + 4 * i;
-        if (t < K) acc[i] = fmaf(ins[px * K + t], g, acc[i]);
+      for (int t4 = 0; t4 < KP; t4 += 4) {
+        const f32x4 iv = *reinterpret_cast<const f32x4*>(ins + px * KP + t4);
+        acc[t4] = fmaf(iv.x, g, acc[t4]);
+        acc[t4 + 1] = fmaf(iv.y, g, acc[t4 + 1]);
+        acc[t4 + 2] = fmaf(iv.z, g, acc[t4 + 2]);
+        acc[t4 + 3] = fmaf(iv.w, g, acc[t4 + 3]);
       }
     }
   }
 #pragma unroll
-  for (int i = 0; i < TPW; ++i) {
-    const int t = wv + 4 * i;
-    if (t < K) atomicAdd(&dw[t * 64 + co], acc[i]);
-  }
+  for (int t = 0; t < K; ++t) atomicAdd(&dw[t * 64 + co], acc[t]);
+  if (db != nullptr) atomicAdd(&db[co], bacc);
 }
 
 // ---- optimizers ([TF1] update rules) ------------------------------------------
@@ -515,19 +524,19 @@ extern "C" int xv_decoder_head_bwd(const xv_act* fused, const float* w_score, co
 }
 
 extern "C" int xv_conv2d_first_bwd_filter(const float* x, int n, int h, int w, int cin, const xv_act* dy, float* dw_hwio,
-                                          void* stream) {
+                                          float* dbias, void* stream) {
   XV_CHECK_ARG(x && dy && dy->data && dw_hwio);
   XV_CHECK_SHAPE(n > 0 && h > 0 && w > 0 && cin >= 1 && cin <= 4 && dy->n == n && dy->h == h && dy->w == w && dy->c == 64);
   const int64_t npix = (int64_t)n * h * w;
-  const int chunks = 8;
+  const int chunks = 32;
   const unsigned grid = (unsigned)((npix + 128 * chunks - 1) / (128 * chunks));
   hipStream_t s = (hipStream_t)stream;
   const __bf16* g = (const __bf16*)dy->data;
   switch (cin) {
-    case 1: hipLaunchKernelGGL(conv_first_wgrad_kernel<1>, dim3(grid), dim3(256), 0, s, x, g, dw_hwio, n, h, w, chunks); break;
-    case 2: hipLaunchKernelGGL(conv_first_wgrad_kernel<2>, dim3(grid), dim3(256), 0, s, x, g, dw_hwio, n, h, w, chunks); break;
-    case 3: hipLaunchKernelGGL(conv_first_wgrad_kernel<3>, dim3(grid), dim3(256), 0, s, x, g, dw_hwio, n, h, w, chunks); break;
-    default: hipLaunchKernelGGL(conv_first_wgrad_kernel<4>, dim3(grid), dim3(256), 0, s, x, g, dw_hwio, n, h, w, chunks); break;
+    case 1: hipLaunchKernelGGL(conv_first_wgrad_kernel<1>, dim3(grid), dim3(256), 0, s, x, g, dw_hwio, dbias, n, h, w, chunks); break;
+    case 2: hipLaunchKernelGGL(conv_first_wgrad_kernel<2>, dim3(grid), dim3(256), 0, s, x, g, dw_hwio, dbias, n, h, w, chunks); break;
+    case 3: hipLaunchKernelGGL(conv_first_wgrad_kernel<3>, dim3(grid), dim3(256), 0, s, x, g, dw_hwio, dbias, n, h, w, chunks); break;
+    default: hipLaunchKernelGGL(conv_first_wgrad_kernel<4>, dim3(grid), dim3(256), 0, s, x, g, dw_hwio, dbias, n, h, w, chunks); break;
   }
   return xv_launch_status();
 }

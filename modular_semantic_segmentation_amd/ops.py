@@ -268,10 +268,10 @@ def conv2d_bwd_filter(x, dy, dw, dbias, k):
     _lib.check(_lib.lib().xv_conv2d_bwd_filter(x.xv(), dy.xv(), _ptr(dw), _ptr(dbias), k, _stream()), 'xv_conv2d_bwd_filter')
 
 
-def conv2d_first_bwd_filter(x, dy, dw):
+def conv2d_first_bwd_filter(x, dy, dw, dbias=None):
     _need(x, torch.float32, 'x')
     n, h, w, cin = x.shape
-    _lib.check(_lib.lib().xv_conv2d_first_bwd_filter(_ptr(x), n, h, w, cin, dy.xv(), _ptr(dw), _stream()),
+    _lib.check(_lib.lib().xv_conv2d_first_bwd_filter(_ptr(x), n, h, w, cin, dy.xv(), _ptr(dw), _ptr(dbias), _stream()),
                'xv_conv2d_first_bwd_filter')
 
 

@@ -164,8 +164,7 @@ class FcnTrainer(object):
         for nm in reversed(names):
             xin = inputs[nm]
             if nm == 'conv1_1':
-                ops.conv2d_first_bwd_filter(x, g, G(nm, 'kernel'))
-                ops.bias_grad(g, G(nm, 'bias'))
+                ops.conv2d_first_bwd_filter(x, g, G(nm, 'kernel'), G(nm, 'bias'))
             else:
                 ops.conv2d_bwd_filter(L[xin], g, G(nm, 'kernel'), G(nm, 'bias'), 3)
             if reducer is not None and nm == BUCKETS[done_buckets][-1]:

@@ -162,9 +162,11 @@ def test_first_layer_filter_gradient(ops, cin):
     dw = torch.zeros((3, 3, cin, 64), device='cuda')
     db = torch.zeros(64, device='cuda')
     dya = ops.Act.from_dense(_dev(dy))
-    ops.conv2d_first_bwd_filter(_dev(x), dya, dw)
-    ops.bias_grad(dya, db)
+    ops.conv2d_first_bwd_filter(_dev(x), dya, dw, db)
+    db2 = torch.zeros(64, device='cuda')
+    ops.bias_grad(dya, db2)
     torch.cuda.synchronize()
+    np.testing.assert_allclose(db2.cpu().numpy(), db.cpu().numpy(), rtol=1e-5, atol=1e-5)
     wt = torch.zeros((64, cin, 3, 3), requires_grad=True)
     b = torch.zeros(64, requires_grad=True)
     F.conv2d(_nchw(x), wt, b, padding=1).backward(_nchw(dy))
