@@ -47,6 +47,9 @@ SIGNATURES = {
     'xv_pack_conv_weights_dgrad': (_i, [_vp, _vp, _i, _i, _i, _vp]),
     'xv_conv2d_bwd_data': (_i, [_actp, _vp, _vp, _actp, _actp, _actp, _i, _vp]),
     'xv_conv2d_bwd_filter': (_i, [_actp, _actp, _vp, _vp, _i, _vp]),
+    'xv_set_wgrad_variant': (_i, [_i]),
+    'xv_conv2d_bwd_filter_workspace_bytes': (ctypes.c_size_t, [_i, _i, _i, _i, _i, _i]),
+    'xv_conv2d_bwd_filter_ws': (_i, [_actp, _actp, _vp, _vp, _i, _vp, ctypes.c_size_t, _vp]),
     'xv_bias_grad': (_i, [_actp, _vp, _vp]),
     'xv_conv2d_first_bwd_filter': (_i, [_vp, _i, _i, _i, _i, _actp, _vp, _vp, _vp]),
     'xv_maxpool2x2_bwd': (_i, [_actp, _actp, _actp, _vp]),

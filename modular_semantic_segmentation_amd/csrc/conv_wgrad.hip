@@ -16,6 +16,10 @@
 // finally adds them into dW with fp32 global atomics (run-to-run summation order is not fixed).
 #include "xv_common.h"
 
+#ifndef XV_WGRAD_UNROLL
+#define XV_WGRAD_UNROLL 8  // rows of a tile fully unrolled: +30 % over the rolled loop (profiles/r1_conv_tune_*.txt)
+#endif
+
 namespace {
 
 typedef __attribute__((ext_vector_type(4))) short s16x4;
@@ -25,6 +29,8 @@ struct WgradArgs {
   const __bf16* dy;
   float* dw;
   float* db;  // may be null; accumulated by the workgroups of input-channel block 0 from their dY tiles
+  float* slab;  // may be null: per-split partial dW slabs [splits][taps][Cin][Cout] (plain stores, reduced by a
+                // second kernel in a fixed order) instead of fp32 atomics straight into dw
   int N, H, W, Cin, Cout;
   int tiles_x, tiles_y, n_ptiles, splits;
 };
@@ -175,16 +181,207 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradArgs a) {
   // accumulator (row = cin = 4*(lane>>4) + r, col = cout = lane & 15) -> dW[tap][cin][cout] (HWIO)
   const int cin = ci0 + wave * 16 + g * 4;
   const int cout = co0 + li;
+  float* const out = a.slab ? a.slab + (int64_t)split * NTAPS * Cin * Cout : a.dw;
 #pragma unroll
   for (int tap = 0; tap < NTAPS; ++tap)
 #pragma unroll
     for (int n4 = 0; n4 < 4; ++n4) {
-      float* dst = a.dw + ((int64_t)tap * Cin + cin) * Cout + cout + n4 * 16;
-      atomicAdd(dst, acc[tap][n4].x);
-      atomicAdd(dst + Cout, acc[tap][n4].y);
-      atomicAdd(dst + 2 * Cout, acc[tap][n4].z);
-      atomicAdd(dst + 3 * Cout, acc[tap][n4].w);
+      float* dst = out + ((int64_t)tap * Cin + cin) * Cout + cout + n4 * 16;
+      if (a.slab) {
+        dst[0] = acc[tap][n4].x;
+        dst[Cout] = acc[tap][n4].y;
+        dst[2 * Cout] = acc[tap][n4].z;
+        dst[3 * Cout] = acc[tap][n4].w;
+      } else {
+        atomicAdd(dst, acc[tap][n4].x);
+        atomicAdd(dst + Cout, acc[tap][n4].y);
+        atomicAdd(dst + 2 * Cout, acc[tap][n4].z);
+        atomicAdd(dst + 3 * Cout, acc[tap][n4].w);
+      }
     }
+}
+
+// ---- version 2: LDS-DMA double buffering -----------------------------------------------------------
+// One 8-wave workgroup per CU.  While the matrix cores work on pixel tile t out of LDS buffer t&1, the
+// next tile's X halo patch and dY tile stream HBM/L2 -> LDS directly (`global_load_lds_dwordx4`, no
+// VGPR staging; the swizzle is applied through the per-lane SOURCE address because an LDS-DMA
+// instruction writes 1 KB linearly), so a tile costs exactly one barrier and the staging latency is
+// covered by a whole tile of MFMA work.  Wave w accumulates cin rows [16*(w&3), +16) x 64 cout for the
+// taps of group w>>2 (taps 0-4 / 5-8): 80 / 64 accumulator registers.
+template <int KS>
+__global__ __launch_bounds__(512, 2) void conv_wgrad_dma_kernel(WgradArgs a) {
+  constexpr int TH = 8, TW = 32;
+  constexpr int HALO = (KS == 3) ? 1 : 0;
+  constexpr int HH = TH + 2 * HALO, HW = TW + 2 * HALO;
+  constexpr int NPIX = HH * HW;
+  constexpr int X_BYTES = ((NPIX * 128 + 1023) / 1024) * 1024;  // whole 1-KB DMA pieces
+  constexpr int D_BYTES = TH * TW * 128;
+  constexpr int BUF = X_BYTES + D_BYTES;
+  constexpr int NTAPS = KS * KS;
+  constexpr int T0 = (NTAPS + 1) / 2;        // taps of group 0: [0, T0), group 1: [T0, NTAPS)
+  constexpr int XI = X_BYTES / 1024, DI = D_BYTES / 1024;  // DMA instructions per tile
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int cb = wave & 3, tg = wave >> 2;
+  const int H = a.H, W = a.W, Cin = a.Cin, Cout = a.Cout;
+  const int Wp = W + 2;
+
+  const int split = blockIdx.x % a.splits;
+  const int pair = blockIdx.x / a.splits;
+  const int n_co = Cout >> 6;
+  const int co0 = (pair % n_co) << 6;
+  const int ci0 = (pair / n_co) << 6;
+  const int per = (a.n_ptiles + a.splits - 1) / a.splits;
+  const int t_begin = split * per;
+  const int t_end = t_begin + per < a.n_ptiles ? t_begin + per : a.n_ptiles;
+
+  const int g = lane >> 4, li = lane & 15, q = li >> 2, p = li & 3;
+  const int xk = 16 * (g >> 1) + 4 * (g & 1) + q;
+  int xbase[KS];
+#pragma unroll
+  for (int dx = 0; dx < KS; ++dx) {
+    const int c = xk + dx;
+    xbase[dx] = c * 128 + (xv_swz(c, cb * 2 + (p >> 1)) << 4) + (p & 1) * 8;
+  }
+  int dbase[4];
+#pragma unroll
+  for (int n = 0; n < 4; ++n) dbase[n] = X_BYTES + xk * 128 + (xv_swz(xk, n * 2 + (p >> 1)) << 4) + (p & 1) * 8;
+
+  // issue the LDS-DMA of pixel tile t into buffer b: instruction i of the tile is done by wave i % 8
+  auto stage = [&](int t, int b) {
+    const int tx = t % a.tiles_x;
+    int r = t / a.tiles_x;
+    const int ty = r % a.tiles_y;
+    const int n = r / a.tiles_y;
+    const int y0 = ty * TH, x0 = tx * TW;
+    const __bf16* ximg = a.x + (int64_t)n * (H + 2) * Wp * Cin + ci0;
+    const __bf16* dimg = a.dy + (int64_t)n * (H + 2) * Wp * Cout + co0;
+    char* buf = smem + b * BUF;
+    for (int i = wave; i < XI + DI; i += 8) {
+      if (i < XI) {
+        int idx = i * 64 + lane;  // 16-byte piece of the patch image: pixel idx>>3, PHYSICAL slot idx&7
+        idx = idx < NPIX * 8 ? idx : NPIX * 8 - 1;
+        const int pp = idx >> 3, ps = idx & 7;
+        const int hy = pp / HW, hx = pp - hy * HW;
+        const int s = xv_swz(hx, ps);  // logical slot stored at this physical slot (involution)
+        int yy = y0 + hy + (1 - HALO), xx = x0 + hx + (1 - HALO);
+        yy = yy < H + 1 ? yy : H + 1;
+        xx = xx < W + 1 ? xx : W + 1;
+        const __bf16* src = ximg + ((int64_t)yy * Wp + xx) * Cin + s * 8;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(buf + i * 1024), 16, 0, 0);
+      } else {
+        const int j = i - XI;
+        const int idx = j * 64 + lane;
+        const int pp = idx >> 3, ps = idx & 7;
+        const int py = pp / TW, px = pp - py * TW;
+        const int s = xv_swz(px, ps);
+        int yy = y0 + py + 1, xx = x0 + px + 1;
+        yy = yy < H + 1 ? yy : H + 1;
+        xx = xx < W + 1 ? xx : W + 1;
+        const __bf16* src = dimg + ((int64_t)yy * Wp + xx) * Cout + s * 8;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(buf + X_BYTES + j * 1024), 16, 0, 0);
+      }
+    }
+  };
+
+  constexpr int NT = (T0 > NTAPS - T0) ? T0 : NTAPS - T0;  // accumulator tap slots per wave
+  f32x4 acc[NT][4];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int n = 0; n < 4; ++n) acc[t][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const bool do_bias = a.db != nullptr && ci0 == 0;
+  float bsum = 0.f;
+
+  if (t_begin < t_end) stage(t_begin, 0);
+  __syncthreads();
+  for (int t = t_begin; t < t_end; ++t) {
+    const int b = (t - t_begin) & 1;
+    if (t + 1 < t_end) stage(t + 1, b ^ 1);
+    const char* buf = smem + b * BUF;
+    if (do_bias) {
+      const int co = tid & 63, part = tid >> 6;  // 8 parts x 32 pixels
+      const int slot = co >> 3, e = co & 7;
+#pragma unroll 4
+      for (int pp = part * 32; pp < part * 32 + 32; ++pp) {
+        const int px = pp & (TW - 1);
+        bsum += (float)*reinterpret_cast<const __bf16*>(buf + X_BYTES + pp * 128 + (xv_swz(px, slot) << 4) + e * 2);
+      }
+    }
+#pragma unroll XV_WGRAD_UNROLL
+    for (int y = 0; y < TH; ++y) {
+      const int yd = y * (TW * 128), yx = y * (HW * 128);
+      bf16x8 bfr[4];
+#pragma unroll
+      for (int n4 = 0; n4 < 4; ++n4) bfr[n4] = tr_read2(buf, dbase[n4] + yd, dbase[n4] + yd + 8 * 128);
+#pragma unroll
+      for (int ts = 0; ts < NT; ++ts) {
+        // tap handled in slot ts by this wave's group (compile-time for each group; the branch is wave-uniform)
+        if (tg == 0) {
+          if (ts < T0) {
+            const int tap = ts;
+            const int dy = (KS == 3) ? tap / 3 : 0, dx = (KS == 3) ? tap % 3 : 0;
+            const bf16x8 afr = tr_read2(buf, xbase[dx] + yx + dy * (HW * 128), xbase[dx] + yx + dy * (HW * 128) + 8 * 128);
+#pragma unroll
+            for (int n4 = 0; n4 < 4; ++n4)
+              acc[ts][n4] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr, bfr[n4], acc[ts][n4], 0, 0, 0);
+          }
+        } else {
+          if (T0 + ts < NTAPS) {
+            const int tap = T0 + ts;
+            const int dy = (KS == 3) ? tap / 3 : 0, dx = (KS == 3) ? tap % 3 : 0;
+            const bf16x8 afr = tr_read2(buf, xbase[dx] + yx + dy * (HW * 128), xbase[dx] + yx + dy * (HW * 128) + 8 * 128);
+#pragma unroll
+            for (int n4 = 0; n4 < 4; ++n4)
+              acc[ts][n4] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr, bfr[n4], acc[ts][n4], 0, 0, 0);
+          }
+        }
+      }
+    }
+    __syncthreads();  // DMA of tile t+1 has landed (vmcnt(0)) and every wave is done with buffer b
+  }
+
+  if (do_bias) atomicAdd(a.db + co0 + (tid & 63), bsum);
+  const int cin = ci0 + cb * 16 + g * 4;
+  const int cout = co0 + li;
+  float* const out = a.slab ? a.slab + (int64_t)split * NTAPS * Cin * Cout : a.dw;
+#pragma unroll
+  for (int ts = 0; ts < NT; ++ts) {
+    const int tap = tg == 0 ? ts : T0 + ts;
+    if (tap < (tg == 0 ? T0 : NTAPS)) {
+#pragma unroll
+      for (int n4 = 0; n4 < 4; ++n4) {
+        float* dst = out + ((int64_t)tap * Cin + cin) * Cout + cout + n4 * 16;
+        if (a.slab) {
+          dst[0] = acc[ts][n4].x;
+          dst[Cout] = acc[ts][n4].y;
+          dst[2 * Cout] = acc[ts][n4].z;
+          dst[3 * Cout] = acc[ts][n4].w;
+        } else {
+          atomicAdd(dst, acc[ts][n4].x);
+          atomicAdd(dst + Cout, acc[ts][n4].y);
+          atomicAdd(dst + 2 * Cout, acc[ts][n4].z);
+          atomicAdd(dst + 3 * Cout, acc[ts][n4].w);
+        }
+      }
+    }
+  }
+}
+
+// dw[i] += sum_s slab[s][i], splits summed in a fixed order (bitwise reproducible filter gradients)
+__global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw,
+                                                         int64_t n4, int splits) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    f32x4 s = *reinterpret_cast<const f32x4*>(slab + i * 4);
+    for (int k = 1; k < splits; ++k) s += *reinterpret_cast<const f32x4*>(slab + ((int64_t)k * n4 + i) * 4);
+    f32x4* d = reinterpret_cast<f32x4*>(dw + i * 4);
+    *d = *d + s;
+  }
 }
 
 // db[c] += sum over all pixels of dY[.., c]   (bias gradient; dY border is zero so the padded
@@ -231,8 +428,41 @@ extern "C" int xv_bias_grad(const xv_act* dy, float* dbias, void* stream) {
   return xv_launch_status();
 }
 
+static int g_wgrad_variant = 2;
+extern "C" int xv_set_wgrad_variant(int v) {
+  if (v != 1 && v != 2) return XV_EINVAL;
+  g_wgrad_variant = v;
+  return XV_OK;
+}
+
+static int wgrad_splits(int k, int pairs, int n_ptiles) {
+  // 3x3, LDS-DMA kernel: one 8-wave workgroup per CU; otherwise ~3 four-wave workgroups per CU
+  int sp = (g_wgrad_variant == 2 && k == 3) ? (xv_num_cus() + pairs - 1) / pairs : (3 * xv_num_cus() + pairs - 1) / pairs;
+  if (sp > n_ptiles) sp = n_ptiles;
+  return sp < 1 ? 1 : sp;
+}
+
+extern "C" size_t xv_conv2d_bwd_filter_workspace_bytes(int n, int h, int w, int cin, int cout, int k) {
+  if (n <= 0 || h <= 0 || w <= 0 || cin <= 0 || cout <= 0 || (cin & 63) || (cout & 63) || (k != 1 && k != 3)) return 0;
+  const int64_t ptiles = (int64_t)((w + 31) / 32) * ((h + 7) / 8) * n;
+  const int pairs = (cin >> 6) * (cout >> 6);
+  // upper bound over both kernel variants
+  int sp = (3 * xv_num_cus() + pairs - 1) / pairs;
+  if (sp > ptiles) sp = (int)ptiles;
+  if (sp < 1) sp = 1;
+  return (size_t)sp * k * k * cin * cout * sizeof(float);
+}
+
+extern "C" int xv_conv2d_bwd_filter_ws(const xv_act* x, const xv_act* dy, float* dw_hwio, float* dbias, int k,
+                                       void* workspace, size_t workspace_bytes, void* stream);
+
 extern "C" int xv_conv2d_bwd_filter(const xv_act* x, const xv_act* dy, float* dw_hwio, float* dbias, int k,
                                     void* stream) {
+  return xv_conv2d_bwd_filter_ws(x, dy, dw_hwio, dbias, k, nullptr, 0, stream);
+}
+
+extern "C" int xv_conv2d_bwd_filter_ws(const xv_act* x, const xv_act* dy, float* dw_hwio, float* dbias, int k,
+                                       void* workspace, size_t workspace_bytes, void* stream) {
   XV_CHECK_ARG(x && dy && x->data && dy->data && dw_hwio);
   XV_CHECK_SHAPE(k == 1 || k == 3);
   XV_CHECK_SHAPE(x->n > 0 && x->h > 0 && x->w > 0 && x->c > 0 && (x->c & 63) == 0 && (dy->c & 63) == 0 && dy->c > 0);
@@ -254,11 +484,40 @@ extern "C" int xv_conv2d_bwd_filter(const xv_act* x, const xv_act* dy, float* dw
   XV_CHECK_SHAPE(ptiles <= 0x7fffffff);
   a.n_ptiles = (int)ptiles;
   const int pairs = (a.Cin >> 6) * (a.Cout >> 6);
-  int splits = (3 * xv_num_cus() + pairs - 1) / pairs;  // ~3 workgroups per CU in flight
-  if (splits > a.n_ptiles) splits = a.n_ptiles;
-  if (splits < 1) splits = 1;
+  const int splits = wgrad_splits(k, pairs, a.n_ptiles);
   a.splits = splits;
   hipStream_t s = (hipStream_t)stream;
+  const int64_t dw_elems = (int64_t)k * k * a.Cin * a.Cout;
+  a.slab = nullptr;
+  // slabs pay off once several (cin, cout) block pairs share the reduce kernel's work; with 1-2 pairs (64-channel
+  // layers) and for the small 1x1 layers the fp32 atomics are faster (tools/conv_tune.py)
+  if (workspace != nullptr && splits > 1 && k == 3 && pairs >= 4) {
+    if (workspace_bytes < (size_t)splits * dw_elems * sizeof(float)) return XV_EWORKSPACE;
+    XV_CHECK_ARG(((uintptr_t)workspace & 15) == 0);
+    a.slab = (float*)workspace;
+  }
+  auto finish = [&]() -> int {
+    int rc = xv_launch_status();
+    if (rc != XV_OK || a.slab == nullptr) return rc;
+    const int64_t n4 = dw_elems / 4;
+    int64_t blocks = (n4 + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (const float*)a.slab, dw_hwio, n4,
+                       splits);
+    return xv_launch_status();
+  };
+  if (g_wgrad_variant == 2 && k == 3) {
+    constexpr int lds = 2 * (((10 * 34 * 128 + 1023) / 1024) * 1024 + 8 * 32 * 128);
+    static bool attr = false;
+    if (!attr) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_dma_kernel<3>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+      if (e != hipSuccess) return (int)e;
+      attr = true;
+    }
+    hipLaunchKernelGGL(conv_wgrad_dma_kernel<3>, dim3((unsigned)(pairs * splits)), dim3(512), lds, s, a);
+    return finish();
+  }
   const unsigned grid = (unsigned)(pairs * splits);
   if (k == 3) {
     constexpr int lds = ((10 * 34 * 128 + 255) / 256) * 256 + 8 * 32 * 128;
@@ -281,5 +540,5 @@ extern "C" int xv_conv2d_bwd_filter(const xv_act* x, const xv_act* dy, float* dw
     }
     hipLaunchKernelGGL(conv_wgrad_kernel<1>, dim3(grid), dim3(256), lds, s, a);
   }
-  return xv_launch_status();
+  return finish();
 }

@@ -263,9 +263,20 @@ def conv2d_bwd_data(dy, w_packed_dgrad, zero_bias, dx, k, relu_ref=None, addend=
     return dx
 
 
-def conv2d_bwd_filter(x, dy, dw, dbias, k):
+def conv2d_bwd_filter_workspace_bytes(x, cout, k):
+    return _lib.lib().xv_conv2d_bwd_filter_workspace_bytes(x.n, x.h, x.w, x.c, cout, k)
+
+
+def conv2d_bwd_filter(x, dy, dw, dbias, k, workspace=None):
+    """workspace (float32 tensor of >= conv2d_bwd_filter_workspace_bytes): deterministic slab reduction;
+    None: fp32 atomics."""
     _need(dw, torch.float32, 'dw')
-    _lib.check(_lib.lib().xv_conv2d_bwd_filter(x.xv(), dy.xv(), _ptr(dw), _ptr(dbias), k, _stream()), 'xv_conv2d_bwd_filter')
+    if workspace is None:
+        rc = _lib.lib().xv_conv2d_bwd_filter(x.xv(), dy.xv(), _ptr(dw), _ptr(dbias), k, _stream())
+    else:
+        rc = _lib.lib().xv_conv2d_bwd_filter_ws(x.xv(), dy.xv(), _ptr(dw), _ptr(dbias), k, _ptr(workspace),
+                                               workspace.numel() * 4, _stream())
+    _lib.check(rc, 'xv_conv2d_bwd_filter')
 
 
 def conv2d_first_bwd_filter(x, dy, dw, dbias=None):

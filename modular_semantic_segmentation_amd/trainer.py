@@ -119,6 +119,16 @@ class FcnTrainer(object):
             ops.pack_conv_weights_into(kv, e.w[name])
             ops.pack_conv_weights_dgrad(kv, self.wd[name])
 
+    @staticmethod
+    def _input_of(name):
+        """Layer whose output feeds conv `name` (a conv or a pool)."""
+        prev = None
+        for nm, _, pool in ENCODER:
+            if nm == name:
+                return prev
+            prev = pool if pool else nm
+        raise KeyError(name)
+
     def _gact(self, like, tag):
         key = (tag, like.n, like.h, like.w, like.c)
         a = self._g.get(key)
@@ -141,6 +151,16 @@ class FcnTrainer(object):
         if reducer is not None:
             reducer.allreduce_now(self.count)           # loss denominator = labelled pixels of the GLOBAL batch
         G = lambda name, kind: self.view(self.grad, name, kind)   # noqa: E731
+        # one workspace for the split-K slabs of every filter gradient (largest layer decides)
+        wkey = ('wgrad_ws', n, h, w)
+        if wkey not in self._g:
+            need = 0
+            for nm in [m for m, _, _ in ENCODER[1:]]:
+                need = max(need, ops.conv2d_bwd_filter_workspace_bytes(L[self._input_of(nm)], self.shapes[nm][1][0], 3))
+            for nm, src in (('score_conv4', 'conv4_3'), ('score_conv5', 'conv5_3')):
+                need = max(need, ops.conv2d_bwd_filter_workspace_bytes(L[src], e.Up, 1))
+            self._g[wkey] = torch.empty(need // 4, dtype=torch.float32, device=e.device)
+        wws = self._g[wkey]
         dfused = self._gact(L['fused'], 'dfused')
         key = ('head_ws', n, h, w)
         self._g[key] = ops.decoder_head_bwd(L['fused'], e.w['score'], e.b['score'], labels, self.count, e.C, self.loss,
@@ -148,8 +168,8 @@ class FcnTrainer(object):
                                             workspace=self._g.get(key))
         ds4 = ops.relu_bwd(dfused, L['score_conv4'], self._gact(L['score_conv4'], 'ds4'))
         ds5 = ops.upsample2x_bwd(dfused, L['score_conv5'], self._gact(L['score_conv5'], 'ds5'))
-        ops.conv2d_bwd_filter(L['conv5_3'], ds5, G('score_conv5', 'kernel'), G('score_conv5', 'bias'), 1)
-        ops.conv2d_bwd_filter(L['conv4_3'], ds4, G('score_conv4', 'kernel'), G('score_conv4', 'bias'), 1)
+        ops.conv2d_bwd_filter(L['conv5_3'], ds5, G('score_conv5', 'kernel'), G('score_conv5', 'bias'), 1, workspace=wws)
+        ops.conv2d_bwd_filter(L['conv4_3'], ds4, G('score_conv4', 'kernel'), G('score_conv4', 'bias'), 1, workspace=wws)
         g = ops.conv2d_bwd_data(ds5, self.wd['score_conv5'], self.zero_bias, self._gact(L['conv5_3'], 'g_conv5_3'), 1,
                                 relu_ref=L['conv5_3'])
         # walk the encoder backwards
@@ -166,7 +186,7 @@ class FcnTrainer(object):
             if nm == 'conv1_1':
                 ops.conv2d_first_bwd_filter(x, g, G(nm, 'kernel'), G(nm, 'bias'))
             else:
-                ops.conv2d_bwd_filter(L[xin], g, G(nm, 'kernel'), G(nm, 'bias'), 3)
+                ops.conv2d_bwd_filter(L[xin], g, G(nm, 'kernel'), G(nm, 'bias'), 3, workspace=wws)
             if reducer is not None and nm == BUCKETS[done_buckets][-1]:
                 reducer.launch(self.grad, self.bucket_ranges[done_buckets])
                 done_buckets += 1

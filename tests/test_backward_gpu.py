@@ -35,8 +35,11 @@ def _nhwc(t):
 
 
 @pytest.mark.parametrize('n,h,w,cin,cout,k', [(2, 16, 32, 64, 64, 3), (1, 24, 40, 128, 64, 3), (2, 6, 10, 64, 128, 3),
-                                              (1, 20, 36, 128, 64, 1), (3, 8, 8, 512, 64, 1)])
-def test_conv_filter_and_bias_gradient_exact_on_integers(ops, n, h, w, cin, cout, k):
+                                              (1, 20, 36, 128, 64, 1), (3, 8, 8, 512, 64, 1), (2, 16, 32, 128, 256, 3)])
+@pytest.mark.parametrize('variant', [1, 2])
+def test_conv_filter_and_bias_gradient_exact_on_integers(ops, n, h, w, cin, cout, k, variant):
+    from modular_semantic_segmentation_amd import _lib
+    assert _lib.lib().xv_set_wgrad_variant(variant) == 0
     rng = np.random.default_rng(cin + cout + h)
     x = rng.integers(-2, 3, (n, h, w, cin)).astype(np.float32)
     dy = rng.integers(-1, 2, (n, h, w, cout)).astype(np.float32)
@@ -50,6 +53,14 @@ def test_conv_filter_and_bias_gradient_exact_on_integers(ops, n, h, w, cin, cout
     ref = wt.grad.permute(2, 3, 1, 0).numpy()              # -> HWIO
     assert np.array_equal(dw.cpu().numpy(), ref)
     assert np.array_equal(db.cpu().numpy(), b.grad.numpy())
+    # slab (workspace) reduction: same sums, accumulated INTO dw, identical from run to run
+    xa, dya = ops.Act.from_dense(_dev(x)), ops.Act.from_dense(_dev(dy))
+    ws = torch.empty(ops.conv2d_bwd_filter_workspace_bytes(xa, cout, k) // 4, device='cuda')
+    dw2 = torch.ones((k, k, cin, cout), device='cuda')
+    ops.conv2d_bwd_filter(xa, dya, dw2, None, k, workspace=ws)
+    torch.cuda.synchronize()
+    _lib.lib().xv_set_wgrad_variant(2)
+    assert np.array_equal(dw2.cpu().numpy(), ref + 1)
 
 
 @pytest.mark.parametrize('k', [3, 1])

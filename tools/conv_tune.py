@@ -56,15 +56,19 @@ def main():
         dy.interior().normal_()
         dw = torch.zeros((k, k, cin, cout), device='cuda')
         db = torch.zeros(cout, device='cuda')
-        for _ in range(2):
-            ops.conv2d_bwd_filter(x, dy, dw, db, k)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(args.iters):
-            ops.conv2d_bwd_filter(x, dy, dw, db, k)
-        e1.record()
-        torch.cuda.synchronize()
-        row += ' wgrad %-6.0f' % (flops / (e0.elapsed_time(e1) / args.iters) / 1e9)
+        for variant in (1, 2):
+            _lib.lib().xv_set_wgrad_variant(variant)
+            for wsp in (None, torch.empty(ops.conv2d_bwd_filter_workspace_bytes(x, cout, k) // 4, device='cuda')):
+                for _ in range(2):
+                    ops.conv2d_bwd_filter(x, dy, dw, db, k, workspace=wsp)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(args.iters):
+                    ops.conv2d_bwd_filter(x, dy, dw, db, k, workspace=wsp)
+                e1.record()
+                torch.cuda.synchronize()
+                row += ' wg%d%s %-5.0f' % (variant, 'a' if wsp is None else 's',
+                                          flops / (e0.elapsed_time(e1) / args.iters) / 1e9)
         print(row, flush=True)
 
 
