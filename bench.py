@@ -158,6 +158,9 @@ def main():
     ap.add_argument('--mode', default='infer', choices=['infer', 'train'],
                     help="'infer' (headline): two experts + fusion; 'train': one SimpleFCN training step (fwd+bwd+Adam)")
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--dist-backend', default='nccl', help="'nccl' (= RCCL over xGMI); 'gloo' only for smoke tests")
+    ap.add_argument('--share-device', action='store_true',
+                    help='smoke test: all ranks use GPU 0 (gloo backend only)')
     ap.add_argument('--no-graph', dest='graph', action='store_false',
                     help='launch every kernel eagerly instead of replaying the step from a captured hipGraph')
     ap.add_argument('--serial-experts', action='store_true',
@@ -168,10 +171,15 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     import torch.distributed as dist
+    if args.share_device:
+        local_rank = 0
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         torch.cuda.set_device(local_rank)
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        if args.dist_backend == 'nccl':
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        else:
+            dist.init_process_group(args.dist_backend)
     device = torch.device('cuda', local_rank)
     torch.cuda.set_device(device)
 

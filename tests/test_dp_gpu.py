@@ -1,0 +1,72 @@
+"""Data-parallel training on the GPU box: two ranks (gloo, both on GPU 0 -- the box has one GPU) each
+differentiate half of a batch; after the bucketed all-reduce and the optimizer step their weights must
+equal a single process trained on the whole batch."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+C, U, H, W = 12, 64, 32, 48
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _data():
+    rng = np.random.default_rng(0)
+    return {'rgb': rng.integers(0, 256, (2, H, W, 3)).astype(np.float32),
+            'labels': rng.integers(-1, C, (2, H, W)).astype(np.int32)}
+
+
+def _make_net(batchsize):
+    from modular_semantic_segmentation_amd import get_model
+    desc = ({'rgb': 'float32', 'labels': 'int32'}, {'rgb': (None, None, 3), 'labels': (None, None)}, C)
+    net = get_model('fcn')('rgb', desc, 'rgb', num_units=U, batch_normalization=False, batchsize=batchsize,
+                           learning_rate=1e-3, trainer='rmsprop', seed=5)
+    net.variables['rgb/conv1_1/kernel'] = net.variables['rgb/conv1_1/kernel'] * 0.05
+    net._variables_changed()
+    return net
+
+
+def _worker(rank, size, port, out):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group('gloo', rank=rank, world_size=size)
+    from modular_semantic_segmentation_amd import parallel
+    net = _make_net(1)
+    shard = parallel.shard_data(_data())
+    loss = net._train_batch(shard)
+    net._sync_variables()
+    if rank == 0:
+        np.savez(out, loss=loss, **{k.replace('/', '__'): v for k, v in net.variables.items()})
+    dist.destroy_process_group()
+
+
+def test_two_rank_training_step_equals_single_process(tmp_path):
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU')
+    out = str(tmp_path / 'dp.npz')
+    mp.spawn(_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    got = np.load(out)
+    net = _make_net(2)
+    loss = net._train_batch(_data())
+    net._sync_variables()
+    # each rank reports the loss of its shard normalised by the GLOBAL count; the sum over ranks is the batch loss
+    assert got['loss'] < loss
+    for name, ref in net.variables.items():
+        a = got[name.replace('/', '__')]
+        if name.endswith('/kernel') and 'upscore' not in name:
+            # RMSProp's first step is lr*g/sqrt(0.9+0.1 g^2): continuous in g, so fp32-atomic ordering noise stays tiny
+            np.testing.assert_allclose(a, ref, rtol=0, atol=2e-5, err_msg=name)
