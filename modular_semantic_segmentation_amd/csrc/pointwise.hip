@@ -13,7 +13,6 @@ template <int CIN>
 __global__ __launch_bounds__(256) void conv_first_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                         const float* __restrict__ b, __bf16* __restrict__ y, int N,
                                                         int H, int W, int relu) {
-  constexpr int K = 9 * CIN;
   const int Wh = W >> 1;  // pixel pairs per row (W is even: multiple of 16)
   const int npair = N * H * Wh;  // < 2^31, checked by the host
   int pr = blockIdx.x * 256 + threadIdx.x;
@@ -206,12 +205,19 @@ __global__ __launch_bounds__(256) void upsample2x_kernel(const __bf16* __restric
 // added after the interpolation (at the image border the zero-padded bilinear weights do not sum to 1).
 //
 // Kernel 1: S[n][i][j][k] = sum_u fused[n,i,j,u] * Ws[u][k] into a zero-bordered fp32 [N][h+2][w+2][CP]
-// workspace (CP = C rounded up to 4).  Score weights come through wave-uniform scalar loads.
+// workspace (CP = C rounded up to 4).  Score weights sit zero-padded in LDS and are read with wave-uniform
+// (broadcast) addresses.
 template <int CM>
-__global__ __launch_bounds__(256) void score_lowres_kernel(const __bf16* __restrict__ f, const float* __restrict__ ws_g,
+__global__ __launch_bounds__(128) void score_lowres_kernel(const __bf16* __restrict__ f, const float* __restrict__ ws_g,
                                                           int N, int Hi, int Wi, int U, int C, float* __restrict__ S) {
+  extern __shared__ __attribute__((aligned(16))) float wsm[];  // [U][CM], zero padded
+  for (int i = threadIdx.x; i < U * CM; i += 128) {
+    const int u = i / CM, k = i - u * CM;
+    wsm[i] = k < C ? ws_g[u * C + k] : 0.f;
+  }
+  __syncthreads();
   const int64_t total = (int64_t)N * (Hi + 2) * (Wi + 2);
-  const int64_t pp = (int64_t)blockIdx.x * 256 + threadIdx.x;  // padded pixel index (same geometry as `fused`)
+  const int64_t pp = (int64_t)blockIdx.x * 128 + threadIdx.x;  // padded pixel index (same geometry as `fused`)
   if (pp >= total) return;
   const int x = (int)(pp % (Wi + 2));
   const int y = (int)((pp / (Wi + 2)) % (Hi + 2));
@@ -226,22 +232,21 @@ __global__ __launch_bounds__(256) void score_lowres_kernel(const __bf16* __restr
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         const float fv = bf16_bits_to_f32((v[i >> 1] >> ((i & 1) * 16)) & 0xffffu);
-        const int remain = (U - u0 - i) * C;  // weights left from this row to the end of the array
-        if (remain >= CM) {
+        const float* wrow = wsm + (u0 + i) * CM;  // wave-uniform address: LDS broadcast reads
 #pragma unroll
-          for (int k = 0; k < CM; ++k) sc[k] = fmaf(fv, ws_g[(u0 + i) * C + k], sc[k]);
-        } else {  // last row(s): a CM-wide read would leave the array
-#pragma unroll
-          for (int k = 0; k < CM; ++k) sc[k] = fmaf(fv, ws_g[(u0 + i) * C + (k < remain ? k : remain - 1)], sc[k]);
+        for (int k4 = 0; k4 < CM; k4 += 4) {
+          const f32x4 wv = *reinterpret_cast<const f32x4*>(wrow + k4);
+          sc[k4] = fmaf(fv, wv.x, sc[k4]);
+          sc[k4 + 1] = fmaf(fv, wv.y, sc[k4 + 1]);
+          sc[k4 + 2] = fmaf(fv, wv.z, sc[k4 + 2]);
+          sc[k4 + 3] = fmaf(fv, wv.w, sc[k4 + 3]);
         }
       }
     }
   }
   float* dst = S + pp * CM;
 #pragma unroll
-  for (int k4 = 0; k4 < CM; k4 += 4)
-    *reinterpret_cast<f32x4*>(dst + k4) = f32x4{k4 < C ? sc[k4] : 0.f, k4 + 1 < C ? sc[k4 + 1] : 0.f,
-                                                k4 + 2 < C ? sc[k4 + 2] : 0.f, k4 + 3 < C ? sc[k4 + 3] : 0.f};
+  for (int k4 = 0; k4 < CM; k4 += 4) *reinterpret_cast<f32x4*>(dst + k4) = f32x4{sc[k4], sc[k4 + 1], sc[k4 + 2], sc[k4 + 3]};
 }
 
 // Kernel 2: one thread per output pixel: 4-tap bilinear interpolation of the CM low-resolution class
@@ -404,12 +409,13 @@ extern "C" int xv_score_lowres(const xv_act* fused, const float* w_score, int nu
   XV_CHECK_ARG(fused && fused->data && w_score && S);
   XV_CHECK_SHAPE(fused->c > 0 && (fused->c & 7) == 0 && num_classes >= 1 && num_classes <= 32);
   const int64_t lowres = (int64_t)fused->n * (fused->h + 2) * (fused->w + 2);
-  const unsigned g1 = (unsigned)((lowres + 255) / 256);
+  const unsigned g1 = (unsigned)((lowres + 127) / 128);
   hipStream_t s = (hipStream_t)stream;
   const __bf16* f = (const __bf16*)fused->data;
-#define XV_SL(CMV)                                                                                               \
-  hipLaunchKernelGGL(score_lowres_kernel<CMV>, dim3(g1), dim3(256), 0, s, f, w_score, fused->n, fused->h, fused->w, \
-                     fused->c, num_classes, S)
+  XV_CHECK_SHAPE(fused->c <= 256);
+#define XV_SL(CMV)                                                                                             \
+  hipLaunchKernelGGL(score_lowres_kernel<CMV>, dim3(g1), dim3(128), (size_t)fused->c * CMV * 4, s, f, w_score, \
+                     fused->n, fused->h, fused->w, fused->c, num_classes, S)
   switch ((num_classes + 3) / 4) {
     case 1: XV_SL(4); break;
     case 2: XV_SL(8); break;
@@ -439,15 +445,15 @@ extern "C" int xv_decoder_head_fwd(const xv_act* fused, const float* w_score, co
   if (workspace_bytes < xv_decoder_head_workspace_bytes(fused->n, fused->h, fused->w, num_classes)) return XV_EWORKSPACE;
   XV_CHECK_ARG(((uintptr_t)workspace & 15) == 0);
   hipStream_t s = (hipStream_t)stream;
-  const __bf16* f = (const __bf16*)fused->data;
   float* S = (float*)workspace;
-  const int64_t lowres = (int64_t)fused->n * (fused->h + 2) * (fused->w + 2);
   const int64_t npix = (int64_t)fused->n * fused->h * fused->w * 64;
   XV_CHECK_SHAPE((npix + 255) / 256 <= 0x7fffffff);
-  const unsigned g1 = (unsigned)((lowres + 255) / 256), g2 = (unsigned)((npix + 255) / 256);
+  const unsigned g2 = (unsigned)((npix + 255) / 256);
+  {
+    const int rc = xv_score_lowres(fused, w_score, num_classes, S, stream);
+    if (rc != XV_OK) return rc;
+  }
 #define XV_HEAD(CMV)                                                                                              \
-  hipLaunchKernelGGL(score_lowres_kernel<CMV>, dim3(g1), dim3(256), 0, s, f, w_score, fused->n, fused->h, fused->w, \
-                     fused->c, num_classes, S);                                                                   \
   hipLaunchKernelGGL(decoder_head_kernel<CMV>, dim3(g2), dim3(256), 0, s, (const float*)S, b_score, fused->n,      \
                      fused->h, fused->w, num_classes, score, prob, label)
   switch ((num_classes + 3) / 4) {
