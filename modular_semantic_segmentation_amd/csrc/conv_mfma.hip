@@ -66,7 +66,7 @@ struct ConvCfg {
 // All LDS fragment reads use a per-lane base register + compile-time immediate offset (taps are
 // fully unrolled), so the inner loop issues no address arithmetic.
 template <int MT, int WR, int WC, int NW, int KS, int OCC, int TPS>
-__global__ __launch_bounds__(64 * WR * WC * NW, OCC * 4 / (WR * WC * NW) > 0 ? OCC * 4 / (WR * WC * NW) : 1) void conv_mfma_kernel(ConvArgs a) {
+__global__ __launch_bounds__(64 * WR * WC * NW, OCC) void conv_mfma_kernel(ConvArgs a) {
   using C = ConvCfg<MT, WR, WC, NW, KS, TPS>;
   constexpr bool PFA = (MT == 4) || (OCC == 1);
   constexpr int PFD = XV_CONV_PFD;  // how many stages before the end of an item its successor's patch is requested
@@ -425,6 +425,9 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, __bf16* __restr
 //  10: as 4 with two taps per barrier (74 KB)    11: as 6 with two taps per barrier (76 KB)
 //  12: 16x32 x 64, 8 waves, 3 taps per barrier, 126 KB, 1/CU
 //  13: 16x32 x 64, 8 waves, 5 taps per barrier, 158 KB, 1/CU
+// Tried and dropped (slower, tools/conv_tune.py): 8-wave 128-channel tiles with 2-3 taps per barrier,
+// a single-weight-buffer variant at three workgroups per CU, two-wave workgroups at four per CU,
+// weight fragments streamed L1 -> VGPR without LDS, s_setprio around the MFMA clusters.
 constexpr int XV_NUM_CONV_CFG = 14;
 struct Geo {
   int th, tw, bn, per_cu;
