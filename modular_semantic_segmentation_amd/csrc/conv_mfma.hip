@@ -65,7 +65,15 @@ struct ConvCfg {
 // first weight tile are already in flight to registers -- across chunk AND tile boundaries.
 // All LDS fragment reads use a per-lane base register + compile-time immediate offset (taps are
 // fully unrolled), so the inner loop issues no address arithmetic.
-template <int MT, int WR, int WC, int NW, int KS, int OCC, int TPS>
+// DMAB: the weight tiles of a stage stream global -> LDS by LDS-DMA (`global_load_lds_dwordx4`, a linear copy
+// because the packed image is pre-swizzled) instead of global -> VGPR -> ds_write: no staging registers and,
+// more importantly, 63 % fewer bytes through the VGPR->LDS store path, which together with the fragment
+// reads keeps the LDS ~80 % busy in the register-staged form.  The DMA of stage s+1 is issued at the start
+// of stage s BEFORE any patch prefetch loads, so a counted `s_waitcnt vmcnt(#patch loads)` at the end of the
+// stage retires exactly the DMA (VMEM operations complete in order) and leaves the patch in flight across
+// the raw `s_barrier`.  Stage buffers alternate with a per-item parity because a chunk has an odd number of
+// stages.
+template <int MT, int WR, int WC, int NW, int KS, int OCC, int TPS, int DMAB>
 __global__ __launch_bounds__(64 * WR * WC * NW, OCC) void conv_mfma_kernel(ConvArgs a) {
   using C = ConvCfg<MT, WR, WC, NW, KS, TPS>;
   constexpr bool PFA = (MT == 4) || (OCC == 1);
@@ -177,6 +185,29 @@ __global__ __launch_bounds__(64 * WR * WC * NW, OCC) void conv_mfma_kernel(ConvA
       }
   };
 
+  // LDS-DMA of one stage's weight tiles (TPS taps x B_BYTES, each a contiguous run of the packed image)
+  constexpr int STAGE_BYTES = C::TPS * C::B_BYTES;
+  constexpr int DMA_PER_TAP = C::B_BYTES / 1024;  // 1 KB per wave-instruction
+  constexpr int NWAVES = C::NT / 64;
+  auto b_dma = [&](int co0, int stage, int chunk, int buf) {
+#pragma unroll
+    for (int tt = 0; tt < C::TPS; ++tt) {
+      const int tap = stage * C::TPS + tt;
+      if (tap < C::NTAPS) {
+        const char* src =
+            reinterpret_cast<const char*>(a.wpk) + (((int64_t)(tap * nchunks + chunk) * Cout + co0) << 7) + lane * 16;
+        char* dst = Bs + buf * STAGE_BYTES + tt * C::B_BYTES;
+#pragma unroll
+        for (int i = 0; i < (DMA_PER_TAP + NWAVES - 1) / NWAVES; ++i) {
+          const int piece = wave + i * NWAVES;
+          if (piece < DMA_PER_TAP)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + piece * 1024),
+                                             (__attribute__((address_space(3))) void*)(dst + piece * 1024), 16, 0, 0);
+        }
+      }
+    }
+  };
+
   int lid = t_begin + bi;
   if (lid >= t_end) return;
   Tile cur = decode(lid);
@@ -193,8 +224,10 @@ __global__ __launch_bounds__(64 * WR * WC * NW, OCC) void conv_mfma_kernel(ConvA
   constexpr std::integral_constant<int, 0> I0{};
   constexpr std::integral_constant<int, (C::A_ITERS + 1) / 2> IH{};
   constexpr std::integral_constant<int, C::A_ITERS> IN{};
+  int par = 0;  // DMAB: stage s of the current item lives in weight buffer (s + par) & 1
+  if constexpr (DMAB) b_dma(cur.co0, 0, 0, 0);
   if constexpr (PFA) a_load(cur, 0, areg, I0, IN);
-  b_load(cur.co0, 0, 0, breg);
+  if constexpr (!DMAB) b_load(cur.co0, 0, 0, breg);
   bool first = true;
 
   while (true) {
@@ -210,8 +243,8 @@ __global__ __launch_bounds__(64 * WR * WC * NW, OCC) void conv_mfma_kernel(ConvA
       a_load(cur, chunk, atmp, IH, IN);
       a_store(atmp, IH, IN);
     }
-    b_store(0, 0, breg);
-    __syncthreads();
+    if constexpr (!DMAB) b_store(0, 0, breg);
+    __syncthreads();  // (DMAB: drains vmcnt, so this item's first weight stage has landed)
 
     // the work item after this one: next chunk of this tile, else chunk 0 of this workgroup's next tile
     const bool last_chunk = chunk + 1 == nchunks;
@@ -222,16 +255,29 @@ __global__ __launch_bounds__(64 * WR * WC * NW, OCC) void conv_mfma_kernel(ConvA
 
 #pragma unroll
     for (int st = 0; st < C::NST; ++st) {
-      const int cb = (st & 1) * (C::TPS * C::B_BYTES);
+      const int cb = DMAB ? ((st + par) & 1) * STAGE_BYTES : (st & 1) * STAGE_BYTES;
+      constexpr int PF_STAGE = C::NST - 1 - PFD > 0 ? C::NST - 1 - PFD : 0;
+      if constexpr (DMAB) {
+        // next stage's weights first (oldest VMEM operation of this stage) ...
+        if (st + 1 < C::NST)
+          b_dma(cur.co0, st + 1, chunk, (st + 1 + par) & 1);
+        else if (has_next)
+          b_dma(nxt.co0, 0, nchunk, (st + 1 + par) & 1);
+        // the counted wait below relies on the DMA being issued BEFORE the patch loads: pin the order
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+      }
       // the next work item's patch is requested PFD stages before the end of this one (its HBM/L2 latency
       // must be covered by MFMA work: one stage is only ~1-2k cycles), its first weight tile in the last stage
       if constexpr (PFA) {
-        if (st == (C::NST - 1 - PFD > 0 ? C::NST - 1 - PFD : 0) && has_next) a_load(nxt, nchunk, areg, I0, IN);
+        if (st == PF_STAGE && has_next) a_load(nxt, nchunk, areg, I0, IN);
       }
-      if (st + 1 < C::NST) {
-        b_load(cur.co0, st + 1, chunk, breg);
-      } else if (has_next) {
-        b_load(nxt.co0, 0, nchunk, breg);
+      if constexpr (!DMAB) {
+        if (st + 1 < C::NST) {
+          b_load(cur.co0, st + 1, chunk, breg);
+        } else if (has_next) {
+          b_load(nxt.co0, 0, nchunk, breg);
+        }
       }
 #pragma unroll
       for (int tt = 0; tt < C::TPS; ++tt) {
@@ -256,10 +302,21 @@ __global__ __launch_bounds__(64 * WR * WC * NW, OCC) void conv_mfma_kernel(ConvA
         }
       }
       if (st + 1 < C::NST) {
-        b_store((st & 1) ^ 1, st + 1, breg);
-        __syncthreads();
+        if constexpr (DMAB) {
+          // retire this stage's DMA but not the patch loads issued after it (in-order VMEM completion);
+          // in every other stage nothing newer than the DMA is outstanding -> vmcnt(0)
+          if (PFA && st == PF_STAGE && has_next) {
+            asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(C::A_ITERS) : "memory");
+          } else {
+            asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+          }
+        } else {
+          b_store((st & 1) ^ 1, st + 1, breg);
+          __syncthreads();
+        }
       }
     }
+    if constexpr (DMAB) par = (par + C::NST) & 1;
 
     if (last_chunk) {
       // ---- epilogue: bias + relu, bf16, 8-byte NHWC stores (4 consecutive channels per lane) ------
@@ -347,7 +404,7 @@ __global__ __launch_bounds__(64 * WR * WC * NW, OCC) void conv_mfma_kernel(ConvA
   }
 }
 
-template <int MT, int WR, int WC, int NW, int KS, int OCC, int TPS = 1>
+template <int MT, int WR, int WC, int NW, int KS, int OCC, int TPS = 1, int DMAB = 0>
 int launch_conv(const ConvArgs& a0, hipStream_t stream) {
   using C = ConvCfg<MT, WR, WC, NW, KS, TPS>;
   ConvArgs a = a0;
@@ -356,7 +413,7 @@ int launch_conv(const ConvArgs& a0, hipStream_t stream) {
   a.n_ct = a.Cout / C::BN;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_kernel<MT, WR, WC, NW, KS, OCC, TPS>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_kernel<MT, WR, WC, NW, KS, OCC, TPS, DMAB>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
     if (e != hipSuccess) return (int)e;
     attr_set = true;
@@ -371,7 +428,7 @@ int launch_conv(const ConvArgs& a0, hipStream_t stream) {
   constexpr int per_cu = by_lds < by_reg ? by_lds : by_reg;
   const int64_t slots = (int64_t)a.num_cus * per_cu;
   const int64_t nblk = ntiles < slots ? ntiles : slots;
-  hipLaunchKernelGGL((conv_mfma_kernel<MT, WR, WC, NW, KS, OCC, TPS>), dim3((unsigned)nblk), dim3(C::NT), C::LDS_BYTES, stream, a);
+  hipLaunchKernelGGL((conv_mfma_kernel<MT, WR, WC, NW, KS, OCC, TPS, DMAB>), dim3((unsigned)nblk), dim3(C::NT), C::LDS_BYTES, stream, a);
   return xv_launch_status();
 }
 
@@ -425,17 +482,19 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, __bf16* __restr
 //  10: as 4 with two taps per barrier (74 KB)    11: as 6 with two taps per barrier (76 KB)
 //  12: 16x32 x 64, 8 waves, 3 taps per barrier, 126 KB, 1/CU
 //  13: 16x32 x 64, 8 waves, 5 taps per barrier, 158 KB, 1/CU
+//  14 / 15 / 16: as 10 / 11 / 13 with the weight tiles staged by LDS-DMA
 // Tried and dropped (slower, tools/conv_tune.py): 8-wave 128-channel tiles with 2-3 taps per barrier,
 // a single-weight-buffer variant at three workgroups per CU, two-wave workgroups at four per CU,
 // weight fragments streamed L1 -> VGPR without LDS, s_setprio around the MFMA clusters.
-constexpr int XV_NUM_CONV_CFG = 14;
+constexpr int XV_NUM_CONV_CFG = 17;
 struct Geo {
   int th, tw, bn, per_cu;
 };
 const Geo kGeo[XV_NUM_CONV_CFG] = {{16, 16, 128, 2}, {8, 16, 128, 2}, {8, 32, 128, 2}, {16, 32, 128, 1},
                                    {16, 16, 64, 2},  {16, 32, 64, 1}, {8, 32, 64, 2},  {8, 16, 256, 1},
                                    {16, 16, 128, 1}, {8, 32, 128, 1}, {16, 16, 64, 2},  {8, 32, 64, 2},
-                                   {16, 32, 64, 1},  {16, 32, 64, 1}};
+                                   {16, 32, 64, 1},  {16, 32, 64, 1},  {16, 16, 64, 2},  {8, 32, 64, 2},
+                                   {16, 32, 64, 1}};
 
 template <int KS>
 int launch_cfg(int cfg, const ConvArgs& a, hipStream_t s) {
@@ -455,12 +514,15 @@ int launch_cfg(int cfg, const ConvArgs& a, hipStream_t s) {
     case 10: return launch_conv<4, 4, 1, 1, KS, 2, 2>(a, s);
     case 11: return launch_conv<4, 2, 2, 1, KS, 2, 2>(a, s);
     case 12: return launch_conv<4, 4, 2, 1, KS, 2, 3>(a, s);
-    default: return launch_conv<4, 4, 2, 1, KS, 2, 5>(a, s);
+    case 13: return launch_conv<4, 4, 2, 1, KS, 2, 5>(a, s);
+    case 14: return launch_conv<4, 4, 1, 1, KS, 2, 2, 1>(a, s);
+    case 15: return launch_conv<4, 2, 2, 1, KS, 2, 2, 1>(a, s);
+    default: return launch_conv<4, 4, 2, 1, KS, 2, 5, 1>(a, s);
   }
 }
 
 // Default choice, from tools/conv_tune.py on MI355X (profiles/r1_conv_tune_b8.txt): 64 output
-// channels x 4 rows per wave, two taps per barrier.  Large images (conv1_2 / conv2_x at 8+ images)
+// channels x 4 rows per wave, two taps per barrier, weight tiles by LDS-DMA.  Large images (conv1_2 / conv2_x at 8+ images)
 // prefer the 8-wave 16x32 patch with five taps per barrier (lower halo + barrier overhead); otherwise
 // two 4-wave workgroups per CU, patch shape by least waste on partial tiles.
 int pick_cfg(const ConvArgs& a) {
@@ -469,8 +531,8 @@ int pick_cfg(const ConvArgs& a) {
     return (double)((a.H + g.th - 1) / g.th * g.th) * ((a.W + g.tw - 1) / g.tw * g.tw);
   };
   const double pixels = (double)a.N * a.H * a.W;
-  if (pixels >= 4.0e5 && a.H % 16 == 0 && a.W % 32 == 0) return 13;
-  return covered(11) < covered(10) ? 11 : 10;
+  if (pixels >= 4.0e5 && a.H % 16 == 0 && a.W % 32 == 0) return 16;
+  return covered(15) < covered(14) ? 15 : 14;
 }
 
 int conv_fwd_impl(const xv_act* x, const void* w_packed, const float* bias, const xv_act* y, const xv_act* pooled,
