@@ -151,7 +151,7 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--batch', type=int, default=8, help='images per GPU per step')
+    ap.add_argument('--batch', type=int, default=16, help='images per GPU per step')
     ap.add_argument('--height', type=int, default=384)
     ap.add_argument('--width', type=int, default=768)
     ap.add_argument('--fusion', default='bayes', choices=['bayes', 'dirichlet'])
@@ -255,10 +255,12 @@ def main():
     traffic = None
     tfiles = sorted(f for f in os.listdir(os.path.join(ROOT, 'profiles')) if f.endswith('_conv_traffic.json')) \
         if os.path.isdir(os.path.join(ROOT, 'profiles')) else []
-    if tfiles and args.batch == 8 and (args.height, args.width) == (384, 768):
+    if tfiles and (args.height, args.width) == (384, 768):
         # HBM bytes per conv launch from the committed rocprofv3 FETCH_SIZE / WRITE_SIZE passes of this
         # same command (tools/pmc_summary.py); PMC counters cannot be read from inside the process
-        traffic = json.load(open(os.path.join(ROOT, 'profiles', tfiles[-1]))).get('hbm_bytes_per_launch')
+        tj = json.load(open(os.path.join(ROOT, 'profiles', tfiles[-1])))
+        if tj.get('batch') == args.batch:
+            traffic = tj.get('hbm_bytes_per_launch')
     if dom in kinds and kinds[dom][1] > 0:
         fl, sec, cnt = kinds[dom]
         achieved = fl / sec / 1e12

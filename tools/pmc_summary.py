@@ -22,12 +22,13 @@ def counter_avg(dirname, counter, match):
     return (tot / n, n) if n else None
 
 
-def main(tag):
+def main(tag, batch=16):
     is_conv3 = lambda k: 'conv_mfma_kernel' in k and ', 3, ' in k      # noqa: E731
     fetch = counter_avg('pmc_fetch', 'FETCH_SIZE', is_conv3)
     write = counter_avg('pmc_write', 'WRITE_SIZE', is_conv3)
     out = {'kernel': 'conv_mfma_kernel (3x3, all tile configurations)', 'source': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, '
-           'python3 bench.py --steps 3 --warmup 1 --serial-experts (batch 8, 768x384)'}
+           'python3 bench.py --steps 3 --warmup 1 --serial-experts --no-graph (batch %d, 768x384)' % batch,
+           'batch': batch}
     if fetch and write:
         out.update(fetch_size_kb_per_launch=round(fetch[0], 1), write_size_kb_per_launch=round(write[0], 1),
                    launches=fetch[1],
@@ -38,4 +39,4 @@ def main(tag):
 
 
 if __name__ == '__main__':
-    main(sys.argv[1] if len(sys.argv) > 1 else 'r1')
+    main(sys.argv[1] if len(sys.argv) > 1 else 'r1', int(sys.argv[2]) if len(sys.argv) > 2 else 16)
