@@ -48,7 +48,10 @@ const char* xv_arch(void);
  * (base_model.py:361-393 export_weights; tf.layers.conv2d kernel layout).  The MFMA kernels read
  * them as bf16 [tap][cin/64][cout][64 swizzled], 128 B per (tap, cin-chunk, cout) row with
  * 16-byte slot s of row `co` stored at slot s ^ (co & 6) (so a weight tile is a linear copy
- * into bank-conflict-free LDS).  k = 1 or 3, cin % 64 == 0, cout % 64 == 0.                       */
+ * into bank-conflict-free LDS).  For k = 3 a second image follows in the same buffer for the
+ * 32-channel-chunk kernel: bf16 [tap][cin/32][cout][32], 64-byte rows, slot s of row `co` at
+ * s ^ ((co >> 1) & 2).  xv_packed_weight_bytes is the size of both.
+ * k = 1 or 3, cin % 64 == 0, cout % 64 == 0.                                                       */
 size_t xv_packed_weight_bytes(int k, int cin, int cout);
 int xv_pack_conv_weights(const float* w_hwio, void* packed, int k, int cin, int cout, void* stream);
 
@@ -141,7 +144,8 @@ int xv_average_fuse(const float* const* probs, int num_experts, int num_classes,
  * state are float32 in the reference's HWIO layout.  Gradient buffers are ACCUMULATED into
  * (callers zero them once per step).                                                               */
 
-/* Packed weights of the data-gradient convolution: Wd[k*k-1-tap][co][ci] = W[tap][ci][co].          */
+/* Packed weights of the data-gradient convolution: Wd[k*k-1-tap][co][ci] = W[tap][ci][co]
+ * (xv_packed_weight_bytes(k, cout, cin) bytes).                                                     */
 int xv_pack_conv_weights_dgrad(const float* w_hwio, void* packed, int k, int cin, int cout, void* stream);
 
 /* dx = (conv(dy, Wd) + addend) * (relu_ref > 0): Conv2DBackpropInput of tf.layers.conv2d, the AddN

@@ -36,6 +36,129 @@ struct ConvArgs {
   int num_cus;
 };
 
+
+// ---- epilogue shared by both kernel generations: bias + relu, bf16, 8-byte NHWC stores (a lane holds 4
+// consecutive output channels of pixel column px for MT rows), optional addend / relu mask (data gradient)
+// and the fused 2x2 max-pool.  Zeroes the accumulators for the next tile.
+__device__ __forceinline__ float dpp_swap1(float v) {
+  // value of lane ^ 1 (quad_perm [1,0,3,2]) on the VALU, no LDS crossbar
+  return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));
+}
+
+template <int MT>
+__device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[MT][4], int n, int py0, int px, int cbase,
+                                              int lane) {
+  const int H = a.H, W = a.W, Cout = a.Cout, Wp = W + 2;
+  f32x4 bj[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) bj[j] = *reinterpret_cast<const f32x4*>(a.bias + cbase + j * 16);
+  if (a.y == nullptr && a.pooled != nullptr) {
+    // pooled-only output: max first (bias add and relu are monotone, so they commute with it), then bias +
+    // relu on a quarter of the values
+    const int Hq = H >> 1, Wq = W >> 1;
+    __bf16* qimg = a.pooled + (int64_t)n * (Hq + 2) * (Wq + 2) * Cout;
+#pragma unroll
+    for (int i = 0; i < MT; i += 2) {
+      const int py = py0 + i;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        f32x4 m;
+        m.x = fmaxf(acc[i][j].x, acc[i + 1][j].x);
+        m.y = fmaxf(acc[i][j].y, acc[i + 1][j].y);
+        m.z = fmaxf(acc[i][j].z, acc[i + 1][j].z);
+        m.w = fmaxf(acc[i][j].w, acc[i + 1][j].w);
+        m.x = fmaxf(m.x, dpp_swap1(m.x));
+        m.y = fmaxf(m.y, dpp_swap1(m.y));
+        m.z = fmaxf(m.z, dpp_swap1(m.z));
+        m.w = fmaxf(m.w, dpp_swap1(m.w));
+        m += bj[j];
+        if (a.relu) {
+          m.x = fmaxf(m.x, 0.f);
+          m.y = fmaxf(m.y, 0.f);
+          m.z = fmaxf(m.z, 0.f);
+          m.w = fmaxf(m.w, 0.f);
+        }
+        if ((lane & 1) == 0 && py < H && px < W) {
+          __bf16* dst = qimg + ((int64_t)((py >> 1) + 1) * (Wq + 2) + ((px >> 1) + 1)) * Cout + cbase + j * 16;
+          *reinterpret_cast<u32x2*>(dst) = u32x2{pack_bf16x2(m.x, m.y), pack_bf16x2(m.z, m.w)};
+        }
+      }
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        f32x4 v = acc[i][j] + bj[j];
+        if (a.relu) {
+          v.x = fmaxf(v.x, 0.f);
+          v.y = fmaxf(v.y, 0.f);
+          v.z = fmaxf(v.z, 0.f);
+          v.w = fmaxf(v.w, 0.f);
+        }
+        acc[i][j] = v;
+      }
+    if (a.y != nullptr) {
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        const int py = py0 + i;
+        if (py < H && px < W) {
+          const int64_t off = (int64_t)n * (H + 2) * Wp * Cout + ((int64_t)(py + 1) * Wp + (px + 1)) * Cout + cbase;
+          __bf16* dst = a.y + off;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            f32x4 v = acc[i][j];
+            if (a.addend != nullptr) {
+              const u32x2 ad = *reinterpret_cast<const u32x2*>(a.addend + off + j * 16);
+              v.x += bf16_bits_to_f32(ad.x & 0xffffu);
+              v.y += __builtin_bit_cast(float, ad.x & 0xffff0000u);
+              v.z += bf16_bits_to_f32(ad.y & 0xffffu);
+              v.w += __builtin_bit_cast(float, ad.y & 0xffff0000u);
+            }
+            if (a.mask != nullptr) {
+              const u32x2 mk = *reinterpret_cast<const u32x2*>(a.mask + off + j * 16);
+              v.x = bf16_bits_to_f32(mk.x & 0xffffu) > 0.f ? v.x : 0.f;
+              v.y = __builtin_bit_cast(float, mk.x & 0xffff0000u) > 0.f ? v.y : 0.f;
+              v.z = bf16_bits_to_f32(mk.y & 0xffffu) > 0.f ? v.z : 0.f;
+              v.w = __builtin_bit_cast(float, mk.y & 0xffff0000u) > 0.f ? v.w : 0.f;
+            }
+            *reinterpret_cast<u32x2*>(dst + j * 16) = u32x2{pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w)};
+          }
+        }
+      }
+    }
+    if (a.pooled != nullptr) {
+      // fused max_pooling2d(2,2): rows (i, i+1) live in this lane, columns (px, px^1) in lanes l, l^1
+      const int Hq = H >> 1, Wq = W >> 1;
+      __bf16* qimg = a.pooled + (int64_t)n * (Hq + 2) * (Wq + 2) * Cout;
+#pragma unroll
+      for (int i = 0; i < MT; i += 2) {
+        const int py = py0 + i;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          f32x4 m;
+          m.x = fmaxf(acc[i][j].x, acc[i + 1][j].x);
+          m.y = fmaxf(acc[i][j].y, acc[i + 1][j].y);
+          m.z = fmaxf(acc[i][j].z, acc[i + 1][j].z);
+          m.w = fmaxf(acc[i][j].w, acc[i + 1][j].w);
+          m.x = fmaxf(m.x, dpp_swap1(m.x));
+          m.y = fmaxf(m.y, dpp_swap1(m.y));
+          m.z = fmaxf(m.z, dpp_swap1(m.z));
+          m.w = fmaxf(m.w, dpp_swap1(m.w));
+          if ((lane & 1) == 0 && py < H && px < W) {
+            __bf16* dst = qimg + ((int64_t)((py >> 1) + 1) * (Wq + 2) + ((px >> 1) + 1)) * Cout + cbase + j * 16;
+            *reinterpret_cast<u32x2*>(dst) = u32x2{pack_bf16x2(m.x, m.y), pack_bf16x2(m.z, m.w)};
+          }
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+}
+
 template <int MT, int WR, int WC, int NW, int KS, int TPS_ = 1>
 struct ConvCfg {
   static constexpr int TPS = (KS == 3) ? TPS_ : 1;  // taps per barrier stage
@@ -319,83 +442,7 @@ __global__ __launch_bounds__(64 * WR * WC * NW, OCC) void conv_mfma_kernel(ConvA
     if constexpr (DMAB) par = (par + C::NST) & 1;
 
     if (last_chunk) {
-      // ---- epilogue: bias + relu, bf16, 8-byte NHWC stores (4 consecutive channels per lane) ------
-      const int px = cur.x0 + wc * 16 + l15;
-      const int cbase = cur.co0 + wn * 64 + lg * 4;
-      f32x4 bj[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) bj[j] = *reinterpret_cast<const f32x4*>(a.bias + cbase + j * 16);
-#pragma unroll
-      for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          f32x4 v = acc[i][j] + bj[j];
-          if (a.relu) {
-            v.x = fmaxf(v.x, 0.f);
-            v.y = fmaxf(v.y, 0.f);
-            v.z = fmaxf(v.z, 0.f);
-            v.w = fmaxf(v.w, 0.f);
-          }
-          acc[i][j] = v;
-        }
-      if (a.y != nullptr) {
-#pragma unroll
-        for (int i = 0; i < MT; ++i) {
-          const int py = cur.y0 + wr * MT + i;
-          if (py < H && px < W) {
-            const int64_t off = (int64_t)cur.n * (H + 2) * Wp * Cout + ((int64_t)(py + 1) * Wp + (px + 1)) * Cout + cbase;
-            __bf16* dst = a.y + off;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              f32x4 v = acc[i][j];
-              if (a.addend != nullptr) {
-                const u32x2 ad = *reinterpret_cast<const u32x2*>(a.addend + off + j * 16);
-                v.x += bf16_bits_to_f32(ad.x & 0xffffu);
-                v.y += __builtin_bit_cast(float, ad.x & 0xffff0000u);
-                v.z += bf16_bits_to_f32(ad.y & 0xffffu);
-                v.w += __builtin_bit_cast(float, ad.y & 0xffff0000u);
-              }
-              if (a.mask != nullptr) {
-                const u32x2 mk = *reinterpret_cast<const u32x2*>(a.mask + off + j * 16);
-                v.x = bf16_bits_to_f32(mk.x & 0xffffu) > 0.f ? v.x : 0.f;
-                v.y = __builtin_bit_cast(float, mk.x & 0xffff0000u) > 0.f ? v.y : 0.f;
-                v.z = bf16_bits_to_f32(mk.y & 0xffffu) > 0.f ? v.z : 0.f;
-                v.w = __builtin_bit_cast(float, mk.y & 0xffff0000u) > 0.f ? v.w : 0.f;
-              }
-              *reinterpret_cast<u32x2*>(dst + j * 16) = u32x2{pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w)};
-            }
-          }
-        }
-      }
-      if (a.pooled != nullptr) {
-        // fused max_pooling2d(2,2): rows (i, i+1) live in this lane, columns (px, px^1) in lanes l, l^1
-        const int Hq = H >> 1, Wq = W >> 1;
-        __bf16* qimg = a.pooled + (int64_t)cur.n * (Hq + 2) * (Wq + 2) * Cout;
-#pragma unroll
-        for (int i = 0; i < MT; i += 2) {
-          const int py = cur.y0 + wr * MT + i;
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            f32x4 m;
-            m.x = fmaxf(acc[i][j].x, acc[i + 1][j].x);
-            m.y = fmaxf(acc[i][j].y, acc[i + 1][j].y);
-            m.z = fmaxf(acc[i][j].z, acc[i + 1][j].z);
-            m.w = fmaxf(acc[i][j].w, acc[i + 1][j].w);
-            m.x = fmaxf(m.x, __shfl_xor(m.x, 1));
-            m.y = fmaxf(m.y, __shfl_xor(m.y, 1));
-            m.z = fmaxf(m.z, __shfl_xor(m.z, 1));
-            m.w = fmaxf(m.w, __shfl_xor(m.w, 1));
-            if ((lane & 1) == 0 && py < H && px < W) {
-              __bf16* dst = qimg + ((int64_t)((py >> 1) + 1) * (Wq + 2) + ((px >> 1) + 1)) * Cout + cbase + j * 16;
-              *reinterpret_cast<u32x2*>(dst) = u32x2{pack_bf16x2(m.x, m.y), pack_bf16x2(m.z, m.w)};
-            }
-          }
-        }
-      }
-#pragma unroll
-      for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      conv_epilogue<MT>(a, acc, cur.n, cur.y0 + wr * MT, cur.x0 + wc * 16 + l15, cur.co0 + wn * 64 + lg * 4, lane);
     }
     if (!has_next) break;
     lid = nlid;
@@ -432,43 +479,298 @@ int launch_conv(const ConvArgs& a0, hipStream_t stream) {
   return xv_launch_status();
 }
 
-// ---- weight packing: fp32 HWIO -> bf16 [tap][cin/64][cout][64], 16-byte slots swizzled -----------
-// dgrad != 0 packs the weights of the data-gradient convolution instead: input/output channels
-// swapped and the taps point-reflected, i.e. Wd[taps-1-tap][co][ci] = W[tap][ci][co].
+
+// =================================================================================================
+// Generation 2: every operand reaches LDS by LDS-DMA; 32-channel input chunks.
+//
+// One 8-wave workgroup per CU owns a (4*WR) x (16*WC) pixel patch x 64 output channels; a work item is one
+// 32-channel chunk of one tile = 9 taps x 16 MFMAs per wave (K = 32 is exactly one v_mfma_f32_16x16x32_bf16).
+// With 64-byte pixel rows the halo patch of a 16x32 tile is 38 KB and ALL nine 64x32 weight tiles of the
+// item are 36 KB, so both are double-buffered whole (150 KB LDS): the DMA of item i+1 is issued right after
+// the single barrier that starts item i and has the full item (~2.3 k MFMA cycles per wave) to land.  No
+// VGPR staging, no ds_write, one barrier per item; fragment reads are software-pipelined one tap ahead in
+// a second register set.
+// LDS images: pixel p = hy*HW + hx at p*64, weight row n at n*64 (per tap 4 KB); 16-byte slot s lives at
+// s ^ ((hx or n) >> 1 & 2): in every 16-lane ds_read_b128 group the four lanes that share an address
+// residue mod 4 rows sit 4 rows apart with logical slots {a, a^1, a^1, a} -> physical {a, a^3, a^1, a^2}:
+// conflict-free for any start column, and independent of the patch row (immediates for dy / row offsets).
+template <int I, int N, class F>
+__device__ __forceinline__ void xv_static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    xv_static_for<I + 1, N>(f);
+  }
+}
+
+template <int WR, int WC>
+struct DmaCfg {
+  static constexpr int MT = 4;
+  static constexpr int NWAVES = WR * WC, NT = 64 * NWAVES;
+  static constexpr int TH = MT * WR, TW = 16 * WC, HH = TH + 2, HW = TW + 2, NPIX = HH * HW;
+  static constexpr int A_PIECES = (NPIX * 4 + 63) / 64;  // 1 KB per DMA wave-instruction
+  static constexpr int A_BYTES = A_PIECES * 1024;
+  static constexpr int B_PIECES = 9 * 4;  // 9 taps x (64 rows x 64 B)
+  static constexpr int B_BYTES = B_PIECES * 1024;
+  static constexpr int LDS_BYTES = 2 * (A_BYTES + B_BYTES);
+  static constexpr int A_ITERS = (A_PIECES + NWAVES - 1) / NWAVES;
+  static constexpr int B_ITERS = (B_PIECES + NWAVES - 1) / NWAVES;
+  static_assert(LDS_BYTES <= 160 * 1024, "does not fit the LDS");
+};
+
+template <int WR, int WC>
+__global__ __launch_bounds__(64 * WR * WC, 2) void conv_dma_kernel(ConvArgs a) {
+  using C = DmaCfg<WR, WC>;
+  constexpr int MT = C::MT;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave / WC, wc = wave % WC;
+  const int l15 = lane & 15, lg = lane >> 4;
+  const int H = a.H, W = a.W, Cin = a.Cin, Cout = a.Cout;
+  const int Wp = W + 2;
+  const int nchunks = Cin >> 5;
+
+  const int G = gridDim.x, b = blockIdx.x;
+  const int xcd = b & 7, bi = b >> 3;
+  const int nb = (G - xcd + 7) >> 3;
+  const int T = a.n_tiles;
+  const int tq = T >> 3, trm = T & 7;
+  const int t_begin = xcd * tq + (xcd < trm ? xcd : trm);
+  const int t_end = t_begin + tq + (xcd < trm ? 1 : 0);
+
+  struct Tile {
+    int n, y0, x0, co0;
+  };
+  auto decode = [&](int lid) {
+    Tile t;
+    t.co0 = (lid % a.n_ct) * 64;
+    int r = lid / a.n_ct;
+    t.x0 = (r % a.tiles_x) * C::TW;
+    r /= a.tiles_x;
+    t.y0 = (r % a.tiles_y) * C::TH;
+    t.n = r / a.tiles_y;
+    return t;
+  };
+
+  // per-lane source offsets (bytes, relative to the patch origin) of the patch pieces this wave moves: LDS
+  // granule g = piece*64 + lane holds physical slot g&3 of pixel g>>2
+  int aoff[C::A_ITERS];
+#pragma unroll
+  for (int it = 0; it < C::A_ITERS; ++it) {
+    const int g = (wave + it * C::NWAVES) * 64 + lane;
+    int p = g >> 2;
+    p = p < C::NPIX ? p : C::NPIX - 1;
+    const int hy = p / C::HW, hx = p - hy * C::HW;
+    aoff[it] = ((hy * Wp + hx) * Cin + xv_swz32(hx, g & 3) * 8) * 2;
+  }
+  int pbase[3];
+#pragma unroll
+  for (int dx = 0; dx < 3; ++dx) {
+    const int hx = wc * 16 + l15 + dx;
+    pbase[dx] = ((wr * MT) * C::HW + hx) * 64 + (xv_swz32(hx, lg) << 4);
+  }
+  const int wbase = 2 * C::A_BYTES + l15 * 64 + (xv_swz32(l15, lg) << 4);
+  const char* const wlane = reinterpret_cast<const char*>(a.wpk) + lane * 16;
+  const int64_t tap_pitch = (int64_t)nchunks * Cout * 64;  // bytes between taps of the packed image
+
+  auto issue = [&](const Tile& t, int chunk, int buf) {
+    const char* xsrc = reinterpret_cast<const char*>(a.x) +
+                       ((((int64_t)t.n * (H + 2) + t.y0) * Wp + t.x0) * Cin + chunk * 32) * 2;
+#pragma unroll
+    for (int it = 0; it < C::A_ITERS; ++it) {
+      const int piece = wave + it * C::NWAVES;
+      if (piece < C::A_PIECES)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xsrc + aoff[it]),
+                                         (__attribute__((address_space(3))) void*)(smem + buf * C::A_BYTES + piece * 1024),
+                                         16, 0, 0);
+    }
+    const char* wsrc = wlane + (((int64_t)chunk * Cout + t.co0) << 6);
+#pragma unroll
+    for (int it = 0; it < C::B_ITERS; ++it) {
+      const int piece = wave + it * C::NWAVES;
+      if (piece < C::B_PIECES)
+        __builtin_amdgcn_global_load_lds(
+            (const __attribute__((address_space(1))) void*)(wsrc + (piece >> 2) * tap_pitch + (piece & 3) * 1024),
+            (__attribute__((address_space(3))) void*)(smem + 2 * C::A_BYTES + buf * C::B_BYTES + piece * 1024), 16, 0, 0);
+    }
+  };
+
+  int lid = t_begin + bi;
+  if (lid >= t_end) return;
+  Tile cur = decode(lid);
+  int chunk = 0, buf = 0;
+
+  f32x4 acc[MT][4];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  issue(cur, 0, 0);
+
+  while (true) {
+    // this item's operands have landed (each wave drains its own DMA: __syncthreads emits vmcnt(0), and as a
+    // compiler-visible wait it keeps the waitcnt pass from serialising the DMA issue below), every wave has
+    // finished reading the other buffer pair
+    __syncthreads();
+
+    // Taps run dx-major: for one horizontal offset the 3 vertical taps of the wave's 4 rows touch only 6
+    // patch rows, loaded once (18 + 36 fragment reads per item instead of 72).  Fragment reads run one tap
+    // (weights) / one dx group (pixels) ahead in a second register set.  They are issued and waited for by
+    // hand (inline asm + counted lgkmcnt): the compiler models an LDS-DMA as a FLAT access, which degrades
+    // every later LDS wait of its own to lgkmcnt(0) and would drain the reads of the future with those of the
+    // present.  Every wait names the fragments it releases as in/out operands, so the MFMAs that consume
+    // them cannot move above it.  No other LGKM operation (s_load, ds_*) may sit inside this region -- the
+    // counts below are exact: [W0 P0] W1 | W2 P1 | W3 | W4 | W5 P2 | W6 | W7 | W8 | -.
+    const int wb = wbase + buf * C::B_BYTES;
+    int pb[3];
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx) pb[dx] = pbase[dx] + buf * C::A_BYTES;
+    bf16x8 wf[2][4], xf[2][MT + 2];
+    static_assert(MT == 4, "operand lists below");
+    constexpr int PROW = C::HW * 64;
+#define XV_LDS128(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
+    // t = dx*3 + dy  ->  packed tap dy*3 + dx
+#define XV_LDW(t, set)                                                          \
+  {                                                                             \
+    constexpr int tap_ = (((t) % 3) * 3 + (t) / 3) * 4096;                       \
+    XV_LDS128(wf[set][0], wb, tap_);                                            \
+    XV_LDS128(wf[set][1], wb, tap_ + 1024);                                     \
+    XV_LDS128(wf[set][2], wb, tap_ + 2048);                                     \
+    XV_LDS128(wf[set][3], wb, tap_ + 3072);                                     \
+  }
+#define XV_LDP(dx, set)                       \
+  {                                           \
+    XV_LDS128(xf[set][0], pb[dx], 0);         \
+    XV_LDS128(xf[set][1], pb[dx], PROW);      \
+    XV_LDS128(xf[set][2], pb[dx], 2 * PROW);  \
+    XV_LDS128(xf[set][3], pb[dx], 3 * PROW);  \
+    XV_LDS128(xf[set][4], pb[dx], 4 * PROW);  \
+    XV_LDS128(xf[set][5], pb[dx], 5 * PROW);  \
+  }
+    // at most n newer reads outstanding: wf[ws] (and xf[ps]) have landed
+#define XV_WAIT_W(n, ws)                                                                           \
+  asm volatile("s_waitcnt lgkmcnt(%4)"                                                             \
+               : "+v"(wf[ws][0]), "+v"(wf[ws][1]), "+v"(wf[ws][2]), "+v"(wf[ws][3])                 \
+               : "n"(n))
+#define XV_WAIT_WP(n, ws, ps)                                                                      \
+  asm volatile("s_waitcnt lgkmcnt(%10)"                                                            \
+               : "+v"(wf[ws][0]), "+v"(wf[ws][1]), "+v"(wf[ws][2]), "+v"(wf[ws][3]), "+v"(xf[ps][0]), \
+                 "+v"(xf[ps][1]), "+v"(xf[ps][2]), "+v"(xf[ps][3]), "+v"(xf[ps][4]), "+v"(xf[ps][5])  \
+               : "n"(n))
+#define XV_TAP(t)                                                                                  \
+  {                                                                                                \
+    constexpr int dx_ = (t) / 3, dy_ = (t) % 3;                                                    \
+    if constexpr ((t) + 1 < 9) XV_LDW((t) + 1, ((t) + 1) & 1);                                      \
+    if constexpr (dy_ == 1 && dx_ + 1 < 3) XV_LDP(dx_ + 1, (dx_ + 1) & 1);                          \
+    /* reads issued after W_t: P(dx+1) of this tap (dy 1) or of the previous one (dy 2), and W_t+1 */ \
+    constexpr int newer_ = ((t) + 1 < 9 ? 4 : 0) + ((dy_ != 0 && dx_ + 1 < 3) ? 6 : 0);             \
+    if constexpr (dy_ == 0)                                                                        \
+      XV_WAIT_WP(newer_, (t) & 1, dx_ & 1);                                                        \
+    else                                                                                           \
+      XV_WAIT_W(newer_, (t) & 1);                                                                  \
+    __builtin_amdgcn_sched_barrier(0);                                                             \
+    _Pragma("unroll") for (int i = 0; i < MT; ++i) _Pragma("unroll") for (int j = 0; j < 4; ++j)   \
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[(t) & 1][j], xf[dx_ & 1][i + dy_], acc[i][j], 0, 0, 0); \
+    __builtin_amdgcn_sched_barrier(0);                                                             \
+  }
+    XV_LDW(0, 0);
+    XV_LDP(0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+
+    const bool last_chunk = chunk + 1 == nchunks;
+    const int nlid = last_chunk ? lid + nb : lid;
+    const bool has_next = nlid < t_end;
+    const Tile nxt = (last_chunk && has_next) ? decode(nlid) : cur;
+    const int nchunk = last_chunk ? 0 : chunk + 1;
+    if (has_next) issue(nxt, nchunk, buf ^ 1);  // overlaps the LDS latency of the first fragments
+    __builtin_amdgcn_sched_barrier(0);
+
+    XV_TAP(0) XV_TAP(1) XV_TAP(2) XV_TAP(3) XV_TAP(4) XV_TAP(5) XV_TAP(6) XV_TAP(7) XV_TAP(8)
+#undef XV_TAP
+#undef XV_WAIT_WP
+#undef XV_WAIT_W
+#undef XV_LDP
+#undef XV_LDW
+#undef XV_LDS128
+
+    if (last_chunk)
+      conv_epilogue<MT>(a, acc, cur.n, cur.y0 + wr * MT, cur.x0 + wc * 16 + l15, cur.co0 + lg * 4, lane);
+    if (!has_next) break;
+    lid = nlid;
+    cur = nxt;
+    chunk = nchunk;
+    buf ^= 1;
+  }
+}
+
+template <int WR, int WC>
+int launch_conv_dma(const ConvArgs& a0, hipStream_t stream) {
+  using C = DmaCfg<WR, WC>;
+  ConvArgs a = a0;
+  if (a.H % C::TH || a.W % C::TW) return XV_ESHAPE;  // the DMA offsets are not clamped: whole tiles only
+  // second half of the packed buffer: the 32-channel-chunk image
+  a.wpk = a0.wpk + (int64_t)9 * a.Cin * a.Cout;
+  a.tiles_x = a.W / C::TW;
+  a.tiles_y = a.H / C::TH;
+  a.n_ct = a.Cout / 64;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_dma_kernel<WR, WC>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  const int64_t ntiles = (int64_t)a.tiles_x * a.tiles_y * a.N * a.n_ct;
+  if (ntiles <= 0 || ntiles > 0x7fffffff) return XV_ESHAPE;
+  if ((int64_t)(C::HH * (a.W + 2) + C::HW) * a.Cin * 2 > 0x7fffffff) return XV_ESHAPE;  // 32-bit patch offsets
+  a.n_tiles = (int)ntiles;
+  const int64_t slots = a.num_cus;
+  const int64_t nblk = ntiles < slots ? ntiles : slots;
+  hipLaunchKernelGGL((conv_dma_kernel<WR, WC>), dim3((unsigned)nblk), dim3(C::NT), C::LDS_BYTES, stream, a);
+  return xv_launch_status();
+}
+
+// ---- weight packing: fp32 HWIO -> bf16 [tap][cin/64][cout][64] (16-byte slots swizzled by xv_swz), followed for
+// 3x3 filters by the generation-2 image [tap][cin/32][cout][32] (xv_swz32).  dgrad != 0 packs the weights of the
+// data-gradient convolution instead: input/output channels swapped and the taps point-reflected.
 __global__ void pack_weights_kernel(const float* __restrict__ w, __bf16* __restrict__ out, int taps, int cin,
                                     int cout, int dgrad) {
+  // logical operand of the convolution that will consume the image: Wl[tap][ci][co]; for the data gradient
+  // Wl[tap][ci = dgrad input = cout of w][co = cin of w] = w[taps-1-tap][co][ci]
+  const int rc = dgrad ? cout : cin;  // reduction channels
+  const int oc = dgrad ? cin : cout;  // output channels
+  auto wl = [&](int tap, int ci, int co) -> float {
+    return dgrad ? w[((int64_t)(taps - 1 - tap) * cin + co) * cout + ci] : w[((int64_t)tap * cin + ci) * cout + co];
+  };
   const int64_t total = (int64_t)taps * cin * cout;
-  if (dgrad) {
-    const int nchunks = cout >> 6;  // reduction dimension of the dgrad conv = cout
-    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
-         idx += (int64_t)gridDim.x * blockDim.x) {
+  const int nch64 = rc >> 6, nch32 = rc >> 5;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    {  // image 1, destination-linear [tap][chunk64][co][phys_slot 0..7][e]
       const int e = (int)(idx & 7);
       const int ps = (int)((idx >> 3) & 7);
       int64_t rest = idx >> 6;
-      const int ci = (int)(rest % cin);  // output channel of the dgrad conv
-      rest /= cin;
-      const int chunk = (int)(rest % nchunks);
-      const int tapd = (int)(rest / nchunks);
-      const int s = xv_swz(ci, ps);
-      const int co = chunk * 64 + s * 8 + e;
-      out[idx] = (__bf16)w[((int64_t)(taps - 1 - tapd) * cin + ci) * cout + co];
+      const int co = (int)(rest % oc);
+      rest /= oc;
+      const int chunk = (int)(rest % nch64);
+      const int tap = (int)(rest / nch64);
+      const int sl = xv_swz(co, ps);  // involution: logical slot stored at this physical slot
+      out[idx] = (__bf16)wl(tap, chunk * 64 + sl * 8 + e, co);
     }
-    return;
-  }
-  const int nchunks = cin >> 6;
-  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
-       idx += (int64_t)gridDim.x * blockDim.x) {
-    // destination-linear index: [tap][chunk][co][phys_slot][e]
-    const int e = (int)(idx & 7);
-    const int ps = (int)((idx >> 3) & 7);
-    int64_t rest = idx >> 6;
-    const int co = (int)(rest % cout);
-    rest /= cout;
-    const int chunk = (int)(rest % nchunks);
-    const int tap = (int)(rest / nchunks);
-    const int s = xv_swz(co, ps);  // involution: logical slot stored at this physical slot
-    const int ci = chunk * 64 + s * 8 + e;
-    out[idx] = (__bf16)w[((int64_t)tap * cin + ci) * cout + co];
+    if (taps == 9) {  // image 2 (generation-2 kernel), [tap][chunk32][co][phys_slot 0..3][e]
+      const int e = (int)(idx & 7);
+      const int ps = (int)((idx >> 3) & 3);
+      int64_t rest = idx >> 5;
+      const int co = (int)(rest % oc);
+      rest /= oc;
+      const int chunk = (int)(rest % nch32);
+      const int tap = (int)(rest / nch32);
+      const int sl = xv_swz32(co, ps);
+      out[total + idx] = (__bf16)wl(tap, chunk * 32 + sl * 8 + e, co);
+    }
   }
 }
 
@@ -483,10 +785,12 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, __bf16* __restr
 //  12: 16x32 x 64, 8 waves, 3 taps per barrier, 126 KB, 1/CU
 //  13: 16x32 x 64, 8 waves, 5 taps per barrier, 158 KB, 1/CU
 //  14 / 15 / 16: as 10 / 11 / 13 with the weight tiles staged by LDS-DMA
+//  17: generation 2 (conv_dma_kernel): 16x32 x 64, 8 waves, 32-channel chunks, all operands by LDS-DMA, 150 KB, 1/CU;
+//      3x3 only, whole tiles only
 // Tried and dropped (slower, tools/conv_tune.py): 8-wave 128-channel tiles with 2-3 taps per barrier,
 // a single-weight-buffer variant at three workgroups per CU, two-wave workgroups at four per CU,
 // weight fragments streamed L1 -> VGPR without LDS, s_setprio around the MFMA clusters.
-constexpr int XV_NUM_CONV_CFG = 17;
+constexpr int XV_NUM_CONV_CFG = 18;
 struct Geo {
   int th, tw, bn, per_cu;
 };
@@ -494,7 +798,7 @@ const Geo kGeo[XV_NUM_CONV_CFG] = {{16, 16, 128, 2}, {8, 16, 128, 2}, {8, 32, 12
                                    {16, 16, 64, 2},  {16, 32, 64, 1}, {8, 32, 64, 2},  {8, 16, 256, 1},
                                    {16, 16, 128, 1}, {8, 32, 128, 1}, {16, 16, 64, 2},  {8, 32, 64, 2},
                                    {16, 32, 64, 1},  {16, 32, 64, 1},  {16, 16, 64, 2},  {8, 32, 64, 2},
-                                   {16, 32, 64, 1}};
+                                   {16, 32, 64, 1},  {16, 32, 64, 1}};
 
 template <int KS>
 int launch_cfg(int cfg, const ConvArgs& a, hipStream_t s) {
@@ -517,7 +821,10 @@ int launch_cfg(int cfg, const ConvArgs& a, hipStream_t s) {
     case 13: return launch_conv<4, 4, 2, 1, KS, 2, 5>(a, s);
     case 14: return launch_conv<4, 4, 1, 1, KS, 2, 2, 1>(a, s);
     case 15: return launch_conv<4, 2, 2, 1, KS, 2, 2, 1>(a, s);
-    default: return launch_conv<4, 4, 2, 1, KS, 2, 5, 1>(a, s);
+    case 16: return launch_conv<4, 4, 2, 1, KS, 2, 5, 1>(a, s);
+    default:
+      if constexpr (KS == 3) return launch_conv_dma<4, 2>(a, s);
+      return XV_ESHAPE;
   }
 }
 
@@ -525,7 +832,9 @@ int launch_cfg(int cfg, const ConvArgs& a, hipStream_t s) {
 // channels x 4 rows per wave, two taps per barrier, weight tiles by LDS-DMA.  Large images (conv1_2 / conv2_x at 8+ images)
 // prefer the 8-wave 16x32 patch with five taps per barrier (lower halo + barrier overhead); otherwise
 // two 4-wave workgroups per CU, patch shape by least waste on partial tiles.
-int pick_cfg(const ConvArgs& a) {
+int pick_cfg(const ConvArgs& a, int k) {
+  // generation 2 wherever its whole-tile restriction holds (every 3x3 layer of a 768x384 input down to 1/8)
+  if (k == 3 && a.H % 16 == 0 && a.W % 32 == 0) return 17;
   auto covered = [&](int c) {
     const Geo& g = kGeo[c];
     return (double)((a.H + g.th - 1) / g.th * g.th) * ((a.W + g.tw - 1) / g.tw * g.tw);
@@ -565,7 +874,7 @@ int conv_fwd_impl(const xv_act* x, const void* w_packed, const float* bias, cons
     XV_CHECK_ARG(((uintptr_t)pooled->data & 15) == 0);
     a.pooled = (__bf16*)pooled->data;
   }
-  if (cfg < 0) cfg = pick_cfg(a);
+  if (cfg < 0) cfg = pick_cfg(a, k);
   if (cfg < 0) return XV_ESHAPE;
   hipStream_t s = (hipStream_t)stream;
   return k == 3 ? launch_cfg<3>(cfg, a, s) : launch_cfg<1>(cfg, a, s);
@@ -575,7 +884,7 @@ int conv_fwd_impl(const xv_act* x, const void* w_packed, const float* bias, cons
 
 extern "C" size_t xv_packed_weight_bytes(int k, int cin, int cout) {
   if ((k != 1 && k != 3) || cin <= 0 || cout <= 0 || (cin & 63) || (cout & 63)) return 0;
-  return (size_t)k * k * cin * cout * 2;
+  return (size_t)k * k * cin * cout * 2 * (k == 3 ? 2 : 1);  // 3x3: both packed images
 }
 
 extern "C" int xv_pack_conv_weights(const float* w_hwio, void* packed, int k, int cin, int cout, void* stream) {

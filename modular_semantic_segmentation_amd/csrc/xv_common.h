@@ -57,6 +57,9 @@ __host__ __device__ static inline int64_t xv_img_pitch(int h, int w, int c) {
 // every fragment read be base-register + immediate.
 __host__ __device__ static inline int xv_swz(int row, int slot) { return slot ^ (row & 6); }
 
+// 64-byte rows (generation-2 conv kernel): slot s of row `row` lives at s ^ ((row >> 1) & 2)
+__host__ __device__ static inline int xv_swz32(int row, int slot) { return slot ^ ((row >> 1) & 2); }
+
 __device__ static inline uint32_t pack_bf16x2(float lo, float hi) {
   typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
   bf16x2 v = {(__bf16)lo, (__bf16)hi};

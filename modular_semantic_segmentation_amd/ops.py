@@ -57,6 +57,11 @@ _NULL_ACT = ctypes.POINTER(xv_act)()
 CONV_PROFILE = None
 
 
+def packed_weight_elems(k, cin, cout):
+    """bf16 elements of the packed weight buffer of a k x k conv (3x3: two images, see xview_hip.h)."""
+    return _lib.lib().xv_packed_weight_bytes(k, cin, cout) // 2
+
+
 def pack_conv_weights(w_hwio):
     """float32 HWIO device tensor -> packed bf16 weight buffer for conv2d_fwd."""
     _need(w_hwio, torch.float32, 'w_hwio')
@@ -243,7 +248,7 @@ def pack_conv_weights_dgrad(w_hwio, out=None):
     _need(w_hwio, torch.float32, 'w_hwio')
     k, _, cin, cout = w_hwio.shape
     if out is None:
-        out = torch.empty(k * k * cin * cout, dtype=torch.bfloat16, device=w_hwio.device)
+        out = torch.empty(_lib.lib().xv_packed_weight_bytes(k, cout, cin) // 2, dtype=torch.bfloat16, device=w_hwio.device)
     _lib.check(_lib.lib().xv_pack_conv_weights_dgrad(_ptr(w_hwio), _ptr(out), k, cin, cout, _stream()),
                'xv_pack_conv_weights_dgrad')
     return out

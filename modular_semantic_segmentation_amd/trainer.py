@@ -114,8 +114,10 @@ class FcnTrainer(object):
                 e.w[name] = kv
                 continue
             if name not in self.wd:
-                e.w[name] = torch.empty(kv.numel(), dtype=torch.bfloat16, device=e.device)
-                self.wd[name] = torch.empty(kv.numel(), dtype=torch.bfloat16, device=e.device)
+                k, _, cin, cout = kv.shape
+                nel = ops.packed_weight_elems(k, cin, cout)
+                e.w[name] = torch.empty(nel, dtype=torch.bfloat16, device=e.device)
+                self.wd[name] = torch.empty(nel, dtype=torch.bfloat16, device=e.device)
             ops.pack_conv_weights_into(kv, e.w[name])
             ops.pack_conv_weights_dgrad(kv, self.wd[name])
 

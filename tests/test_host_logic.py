@@ -28,7 +28,8 @@ def test_library_builds_and_exports_every_declared_symbol():
         assert hasattr(handle, name)
     assert handle.xv_version() >= 100
     assert handle.xv_arch() == b'gfx950'
-    assert handle.xv_packed_weight_bytes(3, 64, 128) == 9 * 64 * 128 * 2
+    assert handle.xv_packed_weight_bytes(3, 64, 128) == 2 * 9 * 64 * 128 * 2     # two packed images (64- and 32-channel chunks)
+    assert handle.xv_packed_weight_bytes(1, 64, 128) == 64 * 128 * 2
     assert handle.xv_packed_weight_bytes(3, 3, 64) == 0          # first layer is not an MFMA conv
 
 

@@ -23,9 +23,13 @@ def main():
     ap.add_argument('--height', type=int, default=384)
     ap.add_argument('--width', type=int, default=768)
     ap.add_argument('--iters', type=int, default=5)
+    ap.add_argument('--cfgs', type=str, default='', help='comma-separated subset of configurations')
+    ap.add_argument('--no-wgrad', action='store_true')
+    ap.add_argument('--pooled-only', action='store_true', help='pool layers write only the pooled map')
     args = ap.parse_args()
     ncfg = _lib.lib().xv_conv2d_num_cfgs()
-    print('layer        ' + ''.join('cfg%-6d' % c for c in range(ncfg)) + ' default')
+    cfgs = [int(c) for c in args.cfgs.split(',')] if args.cfgs else list(range(ncfg))
+    print('layer        ' + ''.join('cfg%-6d' % c for c in cfgs) + ' default')
     for name, s, cin, cout, k, pool in LAYERS:
         h, w = args.height // s, args.width // s
         x = ops.Act(args.batch, h, w, cin)
@@ -37,14 +41,15 @@ def main():
         q = ops.Act(args.batch, h // 2, w // 2, cout) if pool else None
         flops = 2.0 * args.batch * h * w * cin * cout * k * k
         row = '%-12s ' % name
-        for cfg in list(range(ncfg)) + [-1]:
+        yy = None if (pool and args.pooled_only) else y
+        for cfg in cfgs + [-1]:
             try:
                 for _ in range(2):
-                    ops.conv2d_fwd(x, wp, b, k, y=y, pooled=q, cfg=cfg)
+                    ops.conv2d_fwd(x, wp, b, k, y=yy, pooled=q, write_y=yy is not None, cfg=cfg)
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
                 for _ in range(args.iters):
-                    ops.conv2d_fwd(x, wp, b, k, y=y, pooled=q, cfg=cfg)
+                    ops.conv2d_fwd(x, wp, b, k, y=yy, pooled=q, write_y=yy is not None, cfg=cfg)
                 e1.record()
                 torch.cuda.synchronize()
                 ms = e0.elapsed_time(e1) / args.iters
@@ -56,7 +61,7 @@ def main():
         dy.interior().normal_()
         dw = torch.zeros((k, k, cin, cout), device='cuda')
         db = torch.zeros(cout, device='cuda')
-        for variant in (1, 2):
+        for variant in (() if args.no_wgrad else (1, 2)):
             _lib.lib().xv_set_wgrad_variant(variant)
             for wsp in (None, torch.empty(ops.conv2d_bwd_filter_workspace_bytes(x, cout, k) // 4, device='cuda')):
                 for _ in range(2):
