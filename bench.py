@@ -151,6 +151,7 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--layer-profile', action='store_true', help='print per-conv-launch times of the roofline pass')
     ap.add_argument('--batch', type=int, default=16, help='images per GPU per step')
     ap.add_argument('--height', type=int, default=384)
     ap.add_argument('--width', type=int, default=768)
@@ -250,6 +251,14 @@ def main():
         d[0] += flops
         d[1] += e0.elapsed_time(e1) * 1e-3
         d[2] += 1
+    if args.layer_profile and rank == 0:
+        # per-launch-slot breakdown (launch order repeats every step): flops, mean time, TFLOP/s
+        per = len(prof) // max(args.steps, 1)
+        for i in range(per):
+            evs = prof[i::per]
+            ms = sum(e0.elapsed_time(e1) for _, _, e0, e1 in evs) / len(evs)
+            print('  conv launch %2d %s %7.1f GF %8.1f us %7.0f TF/s' % (i, evs[0][0], evs[0][1] / 1e9, ms * 1e3,
+                                                                      evs[0][1] / ms / 1e9), file=sys.stderr)
     dom = 'k3'
     roofline = None
     traffic = None

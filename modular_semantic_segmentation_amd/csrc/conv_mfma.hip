@@ -494,6 +494,144 @@ int launch_conv(const ConvArgs& a0, hipStream_t stream) {
 // s ^ ((hx or n) >> 1 & 2): in every 16-lane ds_read_b128 group the four lanes that share an address
 // residue mod 4 rows sit 4 rows apart with logical slots {a, a^1, a^1, a} -> physical {a, a^3, a^1, a^2}:
 // conflict-free for any start column, and independent of the patch row (immediates for dy / row offsets).
+//
+// Epilogue in two phases.  Loads, stores and LDS-DMA share one in-order counter (vmcnt) and one in-order queue
+// per CU, so a tile stored in one burst at its end (a) is waited for together with the next item's operands
+// and (b) holds up those operands' DMA behind 128 store instructions -- measured 12-70 % of the kernel on the
+// layers that write full-resolution maps.  Instead the tile is only CONVERTED at its end (bias from LDS,
+// relu, addend, mask, pool, bf16 pack; v_permlane16_swap pairs the 4-channel groups of lanes l and l+16 into
+// 16-byte pieces -> half as many stores, 64 contiguous bytes per pixel), and the 8 (pooled: 4) store
+// instructions are issued one per tap during the NEXT work item, behind that item's DMA; the wait that
+// ends the item is a counted vmcnt(#stores), which retires the DMA and leaves the stores in flight.
+struct DmaPend {
+  int n, y0, x0, co0;
+  bool on;
+};
+
+__device__ __forceinline__ void xv_pair16(const u32x2 a, const u32x2 b, u32x4& out) {
+  // lanes of row r (= lane >> 4) hold channel groups r*4 of `a` (block j) and `b` (block j+1); after the swap a
+  // lane holds 8 consecutive channels: rows 0..3 -> channel offsets 0, 16, 8, 24 of the 32-channel pair
+  const auto s0 = __builtin_amdgcn_permlane16_swap(a.x, b.x, false, false);
+  const auto s1 = __builtin_amdgcn_permlane16_swap(a.y, b.y, false, false);
+  out = u32x4{s0[0], s1[0], s0[1], s1[1]};
+}
+
+template <int MT>
+__device__ __forceinline__ void dma_epilogue_pack(const ConvArgs& a, f32x4 (&acc)[MT][4], u32x4 (&pq)[MT][2],
+                                                  const float* bias_lds, int n, int py0, int px, int cbase, int lane) {
+  const int H = a.H, W = a.W, Cout = a.Cout, Wp = W + 2;
+  const int lg = lane >> 4;
+  f32x4 bj[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) bj[j] = *reinterpret_cast<const f32x4*>(bias_lds + lg * 4 + j * 16);
+  if (a.y == nullptr) {
+    // pooled-only: max first (bias add and relu are monotone), bias + relu on a quarter of the values
+#pragma unroll
+    for (int i = 0; i < MT; i += 2) {
+      u32x2 h[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        f32x4 m;
+        m.x = fmaxf(acc[i][j].x, acc[i + 1][j].x);
+        m.y = fmaxf(acc[i][j].y, acc[i + 1][j].y);
+        m.z = fmaxf(acc[i][j].z, acc[i + 1][j].z);
+        m.w = fmaxf(acc[i][j].w, acc[i + 1][j].w);
+        m.x = fmaxf(m.x, dpp_swap1(m.x));
+        m.y = fmaxf(m.y, dpp_swap1(m.y));
+        m.z = fmaxf(m.z, dpp_swap1(m.z));
+        m.w = fmaxf(m.w, dpp_swap1(m.w));
+        m += bj[j];
+        if (a.relu) {
+          m.x = fmaxf(m.x, 0.f);
+          m.y = fmaxf(m.y, 0.f);
+          m.z = fmaxf(m.z, 0.f);
+          m.w = fmaxf(m.w, 0.f);
+        }
+        h[j] = u32x2{pack_bf16x2(m.x, m.y), pack_bf16x2(m.z, m.w)};
+      }
+      xv_pair16(h[0], h[1], pq[i >> 1][0]);
+      xv_pair16(h[2], h[3], pq[i >> 1][1]);
+    }
+  } else {
+    // data-gradient extras: all addend / mask words of the tile are requested before the first is used (one
+    // memory round trip instead of 32 dependent ones)
+    u32x2 ad[MT][4], mk[MT][4];
+    if (a.addend != nullptr) {
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        const int64_t off = (int64_t)n * (H + 2) * Wp * Cout + ((int64_t)(py0 + i + 1) * Wp + (px + 1)) * Cout + cbase;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) ad[i][j] = *reinterpret_cast<const u32x2*>(a.addend + off + j * 16);
+      }
+    }
+    if (a.mask != nullptr) {
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        const int64_t off = (int64_t)n * (H + 2) * Wp * Cout + ((int64_t)(py0 + i + 1) * Wp + (px + 1)) * Cout + cbase;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) mk[i][j] = *reinterpret_cast<const u32x2*>(a.mask + off + j * 16);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      u32x2 h[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        f32x4 v = acc[i][j] + bj[j];
+        if (a.relu) {
+          v.x = fmaxf(v.x, 0.f);
+          v.y = fmaxf(v.y, 0.f);
+          v.z = fmaxf(v.z, 0.f);
+          v.w = fmaxf(v.w, 0.f);
+        }
+        acc[i][j] = v;  // the pool below takes the activation before addend / mask (forward layers have neither)
+        if (a.addend != nullptr) {
+          v.x += bf16_bits_to_f32(ad[i][j].x & 0xffffu);
+          v.y += __builtin_bit_cast(float, ad[i][j].x & 0xffff0000u);
+          v.z += bf16_bits_to_f32(ad[i][j].y & 0xffffu);
+          v.w += __builtin_bit_cast(float, ad[i][j].y & 0xffff0000u);
+        }
+        if (a.mask != nullptr) {
+          v.x = bf16_bits_to_f32(mk[i][j].x & 0xffffu) > 0.f ? v.x : 0.f;
+          v.y = __builtin_bit_cast(float, mk[i][j].x & 0xffff0000u) > 0.f ? v.y : 0.f;
+          v.z = bf16_bits_to_f32(mk[i][j].y & 0xffffu) > 0.f ? v.z : 0.f;
+          v.w = __builtin_bit_cast(float, mk[i][j].y & 0xffff0000u) > 0.f ? v.w : 0.f;
+        }
+        h[j] = u32x2{pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w)};
+      }
+      xv_pair16(h[0], h[1], pq[i][0]);
+      xv_pair16(h[2], h[3], pq[i][1]);
+    }
+    if (a.pooled != nullptr) {
+      // both maps wanted (conv4_3, training forward): the quarter-size pooled map is stored at once
+      const int Hq = H >> 1, Wq = W >> 1;
+      __bf16* qimg = a.pooled + (int64_t)n * (Hq + 2) * (Wq + 2) * Cout;
+#pragma unroll
+      for (int i = 0; i < MT; i += 2)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          f32x4 m;
+          m.x = fmaxf(acc[i][j].x, acc[i + 1][j].x);
+          m.y = fmaxf(acc[i][j].y, acc[i + 1][j].y);
+          m.z = fmaxf(acc[i][j].z, acc[i + 1][j].z);
+          m.w = fmaxf(acc[i][j].w, acc[i + 1][j].w);
+          m.x = fmaxf(m.x, dpp_swap1(m.x));
+          m.y = fmaxf(m.y, dpp_swap1(m.y));
+          m.z = fmaxf(m.z, dpp_swap1(m.z));
+          m.w = fmaxf(m.w, dpp_swap1(m.w));
+          if ((lane & 1) == 0) {
+            __bf16* dst = qimg + ((int64_t)(((py0 + i) >> 1) + 1) * (Wq + 2) + ((px >> 1) + 1)) * Cout + cbase + j * 16;
+            *reinterpret_cast<u32x2*>(dst) = u32x2{pack_bf16x2(m.x, m.y), pack_bf16x2(m.z, m.w)};
+          }
+        }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+}
+
 template <int I, int N, class F>
 __device__ __forceinline__ void xv_static_for(F&& f) {
   if constexpr (I < N) {
@@ -511,7 +649,8 @@ struct DmaCfg {
   static constexpr int A_BYTES = A_PIECES * 1024;
   static constexpr int B_PIECES = 9 * 4;  // 9 taps x (64 rows x 64 B)
   static constexpr int B_BYTES = B_PIECES * 1024;
-  static constexpr int LDS_BYTES = 2 * (A_BYTES + B_BYTES);
+  static constexpr int BIAS_OFF = 2 * (A_BYTES + B_BYTES);  // two 256-byte bias slots (tile parity)
+  static constexpr int LDS_BYTES = BIAS_OFF + 512;
   static constexpr int A_ITERS = (A_PIECES + NWAVES - 1) / NWAVES;
   static constexpr int B_ITERS = (B_PIECES + NWAVES - 1) / NWAVES;
   static_assert(LDS_BYTES <= 160 * 1024, "does not fit the LDS");
@@ -574,8 +713,10 @@ __global__ __launch_bounds__(64 * WR * WC, 2) void conv_dma_kernel(ConvArgs a) {
   const int wbase = 2 * C::A_BYTES + l15 * 64 + (xv_swz32(l15, lg) << 4);
   const char* const wlane = reinterpret_cast<const char*>(a.wpk) + lane * 16;
   const int64_t tap_pitch = (int64_t)nchunks * Cout * 64;  // bytes between taps of the packed image
+  // channel offset of this lane's 16-byte output piece inside a 32-channel pair (see xv_pair16)
+  const int csub = (lg & 1) * 16 + (lg >> 1) * 8;
 
-  auto issue = [&](const Tile& t, int chunk, int buf) {
+  auto issue = [&](const Tile& t, int chunk, int buf, int bslot) {
     const char* xsrc = reinterpret_cast<const char*>(a.x) +
                        ((((int64_t)t.n * (H + 2) + t.y0) * Wp + t.x0) * Cin + chunk * 32) * 2;
 #pragma unroll
@@ -595,12 +736,17 @@ __global__ __launch_bounds__(64 * WR * WC, 2) void conv_dma_kernel(ConvArgs a) {
             (const __attribute__((address_space(1))) void*)(wsrc + (piece >> 2) * tap_pitch + (piece & 3) * 1024),
             (__attribute__((address_space(3))) void*)(smem + 2 * C::A_BYTES + buf * C::B_BYTES + piece * 1024), 16, 0, 0);
     }
+    // the tile's 64 bias values ride along with its first chunk (one 4-byte-per-lane DMA by the last wave)
+    if (chunk == 0 && wave == C::NWAVES - 1)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.bias + t.co0 + lane),
+                                       (__attribute__((address_space(3))) void*)(smem + C::BIAS_OFF + bslot * 256), 4, 0,
+                                       0);
   };
 
   int lid = t_begin + bi;
   if (lid >= t_end) return;
   Tile cur = decode(lid);
-  int chunk = 0, buf = 0;
+  int chunk = 0, buf = 0, bslot = 0;
 
   f32x4 acc[MT][4];
 #pragma unroll
@@ -608,13 +754,22 @@ __global__ __launch_bounds__(64 * WR * WC, 2) void conv_dma_kernel(ConvArgs a) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  issue(cur, 0, 0);
+  u32x4 pq[MT][2];
+  DmaPend pend{0, 0, 0, 0, false};
+  const int npieces = a.y != nullptr ? 2 * MT : MT;  // 16-byte store instructions per tile and wave
+  int in_flight = 0;  // stores issued after the last DMA of the previous item
+  issue(cur, 0, 0, 0);
 
   while (true) {
-    // this item's operands have landed (each wave drains its own DMA: __syncthreads emits vmcnt(0), and as a
-    // compiler-visible wait it keeps the waitcnt pass from serialising the DMA issue below), every wave has
-    // finished reading the other buffer pair
-    __syncthreads();
+    // This item's operands have landed (each wave retires its own DMA; stores issued after it may stay in flight:
+    // vmcnt counts in issue order), and every wave has finished reading the other buffer pair.
+    if (in_flight == 2 * MT)
+      asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(2 * MT) : "memory");
+    else if (in_flight == MT)
+      asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(MT) : "memory");
+    else
+      asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    in_flight = 0;
 
     // Taps run dx-major: for one horizontal offset the 3 vertical taps of the wave's 4 rows touch only 6
     // patch rows, loaded once (18 + 36 fragment reads per item instead of 72).  Fragment reads run one tap
@@ -660,11 +815,20 @@ __global__ __launch_bounds__(64 * WR * WC, 2) void conv_dma_kernel(ConvArgs a) {
                : "+v"(wf[ws][0]), "+v"(wf[ws][1]), "+v"(wf[ws][2]), "+v"(wf[ws][3]), "+v"(xf[ps][0]), \
                  "+v"(xf[ps][1]), "+v"(xf[ps][2]), "+v"(xf[ps][3]), "+v"(xf[ps][4]), "+v"(xf[ps][5])  \
                : "n"(n))
+    // one 16-byte store of the previous tile per tap (piece t = row t/2, channel pair t%2; pooled-only: 4 pieces)
+#define XV_STORE_PIECE(t)                                                                          \
+  if ((t) < 2 * MT && stores_now > (t)) {                                                          \
+    if (a.y != nullptr)                                                                            \
+      *reinterpret_cast<u32x4*>(st_base + (int64_t)((t) >> 1) * st_pitch + ((t) & 1) * 32) = pq[((t) >> 1) % MT][(t) & 1]; \
+    else if ((lane & 1) == 0)                                                                      \
+      *reinterpret_cast<u32x4*>(st_base + (int64_t)((t) >> 1) * st_pitch + ((t) & 1) * 32) = pq[((t) >> 1) % MT][(t) & 1]; \
+  }
 #define XV_TAP(t)                                                                                  \
   {                                                                                                \
     constexpr int dx_ = (t) / 3, dy_ = (t) % 3;                                                    \
     if constexpr ((t) + 1 < 9) XV_LDW((t) + 1, ((t) + 1) & 1);                                      \
     if constexpr (dy_ == 1 && dx_ + 1 < 3) XV_LDP(dx_ + 1, (dx_ + 1) & 1);                          \
+    XV_STORE_PIECE(t)                                                                              \
     /* reads issued after W_t: P(dx+1) of this tap (dy 1) or of the previous one (dy 2), and W_t+1 */ \
     constexpr int newer_ = ((t) + 1 < 9 ? 4 : 0) + ((dy_ != 0 && dx_ + 1 < 3) ? 6 : 0);             \
     if constexpr (dy_ == 0)                                                                        \
@@ -685,25 +849,67 @@ __global__ __launch_bounds__(64 * WR * WC, 2) void conv_dma_kernel(ConvArgs a) {
     const bool has_next = nlid < t_end;
     const Tile nxt = (last_chunk && has_next) ? decode(nlid) : cur;
     const int nchunk = last_chunk ? 0 : chunk + 1;
-    if (has_next) issue(nxt, nchunk, buf ^ 1);  // overlaps the LDS latency of the first fragments
+    if (has_next) issue(nxt, nchunk, buf ^ 1, bslot ^ 1);  // overlaps the LDS latency of the first fragments
+
+    // the previous tile's stores go out one per tap, behind this item's DMA
+    const int stores_now = pend.on ? npieces : 0;
+    __bf16* st_base = nullptr;
+    int st_pitch = 0;
+    if (pend.on) {
+      const int px = pend.x0 + wc * 16 + l15, py0 = pend.y0 + wr * MT;
+      if (a.y != nullptr) {
+        st_pitch = Wp * Cout;
+        st_base = a.y + (int64_t)pend.n * (H + 2) * Wp * Cout + ((int64_t)(py0 + 1) * Wp + (px + 1)) * Cout + pend.co0 + csub;
+      } else {
+        const int Hq = H >> 1, Wq = W >> 1;
+        st_pitch = (Wq + 2) * Cout;
+        st_base = a.pooled + (int64_t)pend.n * (Hq + 2) * (Wq + 2) * Cout +
+                  ((int64_t)((py0 >> 1) + 1) * (Wq + 2) + ((px >> 1) + 1)) * Cout + pend.co0 + csub;
+      }
+      pend.on = false;
+    }
+    in_flight = stores_now;
     __builtin_amdgcn_sched_barrier(0);
 
     XV_TAP(0) XV_TAP(1) XV_TAP(2) XV_TAP(3) XV_TAP(4) XV_TAP(5) XV_TAP(6) XV_TAP(7) XV_TAP(8)
-#undef XV_TAP
-#undef XV_WAIT_WP
-#undef XV_WAIT_W
-#undef XV_LDP
-#undef XV_LDW
-#undef XV_LDS128
 
-    if (last_chunk)
-      conv_epilogue<MT>(a, acc, cur.n, cur.y0 + wr * MT, cur.x0 + wc * 16 + l15, cur.co0 + lg * 4, lane);
-    if (!has_next) break;
+    if (last_chunk) {
+      dma_epilogue_pack<MT>(a, acc, pq, reinterpret_cast<const float*>(smem + C::BIAS_OFF + bslot * 256), cur.n,
+                            cur.y0 + wr * MT, cur.x0 + wc * 16 + l15, cur.co0 + lg * 4, lane);
+      pend = DmaPend{cur.n, cur.y0, cur.x0, cur.co0, true};
+      bslot ^= 1;
+      in_flight = 0;  // the pack phase read the bias from LDS behind a full vmcnt(0)/lgkmcnt(0) drain
+    }
+    if (!has_next) {
+      // last tile of this workgroup: store it now
+      const int px = pend.x0 + wc * 16 + l15, py0 = pend.y0 + wr * MT;
+      if (a.y != nullptr) {
+        __bf16* base = a.y + (int64_t)pend.n * (H + 2) * Wp * Cout + ((int64_t)(py0 + 1) * Wp + (px + 1)) * Cout + pend.co0 + csub;
+#pragma unroll
+        for (int t = 0; t < 2 * MT; ++t)
+          *reinterpret_cast<u32x4*>(base + (int64_t)(t >> 1) * Wp * Cout + (t & 1) * 32) = pq[t >> 1][t & 1];
+      } else if ((lane & 1) == 0) {
+        const int Hq = H >> 1, Wq = W >> 1;
+        __bf16* base = a.pooled + (int64_t)pend.n * (Hq + 2) * (Wq + 2) * Cout +
+                       ((int64_t)((py0 >> 1) + 1) * (Wq + 2) + ((px >> 1) + 1)) * Cout + pend.co0 + csub;
+#pragma unroll
+        for (int t = 0; t < MT; ++t)
+          *reinterpret_cast<u32x4*>(base + (int64_t)(t >> 1) * (Wq + 2) * Cout + (t & 1) * 32) = pq[t >> 1][t & 1];
+      }
+      break;
+    }
     lid = nlid;
     cur = nxt;
     chunk = nchunk;
     buf ^= 1;
   }
+#undef XV_TAP
+#undef XV_STORE_PIECE
+#undef XV_WAIT_WP
+#undef XV_WAIT_W
+#undef XV_LDP
+#undef XV_LDW
+#undef XV_LDS128
 }
 
 template <int WR, int WC>
