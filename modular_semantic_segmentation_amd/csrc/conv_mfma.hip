@@ -516,6 +516,19 @@ __device__ __forceinline__ void xv_pair16(const u32x2 a, const u32x2 b, u32x4& o
   out = u32x4{s0[0], s1[0], s0[1], s1[1]};
 }
 
+// relu and 2x2 max on PACKED bf16 pairs: a non-negative bf16 orders like its bit pattern as a signed 16-bit
+// integer and every negative one (sign bit) is a negative integer, so relu is v_pk_max_i16 against 0 and, after
+// it, so is the max-pool -- two values per instruction and none of the NaN-quieting v_max_f32 x,x,x that fmaxf
+// costs under IEEE mode.  Rounding to bf16 is monotone, so pooling after rounding equals rounding after pooling.
+__device__ __forceinline__ uint32_t pk_max_i16(uint32_t a, uint32_t b) {
+  typedef short s16x2 __attribute__((ext_vector_type(2)));
+  return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s16x2, a), __builtin_bit_cast(s16x2, b)));
+}
+__device__ __forceinline__ uint32_t dpp_swap1_u32(uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xf, 0xf, true);
+}
+
+// Conversion phase.  Does NOT clear the accumulators: the first tap of the next tile starts from C = 0.
 template <int MT>
 __device__ __forceinline__ void dma_epilogue_pack(const ConvArgs& a, f32x4 (&acc)[MT][4], u32x4 (&pq)[MT][2],
                                                   const float* bias_lds, int n, int py0, int px, int cbase, int lane) {
@@ -524,85 +537,94 @@ __device__ __forceinline__ void dma_epilogue_pack(const ConvArgs& a, f32x4 (&acc
   f32x4 bj[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) bj[j] = *reinterpret_cast<const f32x4*>(bias_lds + lg * 4 + j * 16);
-  if (a.y == nullptr) {
-    // pooled-only: max first (bias add and relu are monotone), bias + relu on a quarter of the values
-#pragma unroll
-    for (int i = 0; i < MT; i += 2) {
-      u32x2 h[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        f32x4 m;
-        m.x = fmaxf(acc[i][j].x, acc[i + 1][j].x);
-        m.y = fmaxf(acc[i][j].y, acc[i + 1][j].y);
-        m.z = fmaxf(acc[i][j].z, acc[i + 1][j].z);
-        m.w = fmaxf(acc[i][j].w, acc[i + 1][j].w);
-        m.x = fmaxf(m.x, dpp_swap1(m.x));
-        m.y = fmaxf(m.y, dpp_swap1(m.y));
-        m.z = fmaxf(m.z, dpp_swap1(m.z));
-        m.w = fmaxf(m.w, dpp_swap1(m.w));
-        m += bj[j];
-        if (a.relu) {
-          m.x = fmaxf(m.x, 0.f);
-          m.y = fmaxf(m.y, 0.f);
-          m.z = fmaxf(m.z, 0.f);
-          m.w = fmaxf(m.w, 0.f);
-        }
-        h[j] = u32x2{pack_bf16x2(m.x, m.y), pack_bf16x2(m.z, m.w)};
-      }
-      xv_pair16(h[0], h[1], pq[i >> 1][0]);
-      xv_pair16(h[2], h[3], pq[i >> 1][1]);
-    }
-  } else {
-    // data-gradient extras: all addend / mask words of the tile are requested before the first is used (one
-    // memory round trip instead of 32 dependent ones)
-    u32x2 ad[MT][4], mk[MT][4];
-    if (a.addend != nullptr) {
-#pragma unroll
-      for (int i = 0; i < MT; ++i) {
-        const int64_t off = (int64_t)n * (H + 2) * Wp * Cout + ((int64_t)(py0 + i + 1) * Wp + (px + 1)) * Cout + cbase;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) ad[i][j] = *reinterpret_cast<const u32x2*>(a.addend + off + j * 16);
-      }
-    }
-    if (a.mask != nullptr) {
-#pragma unroll
-      for (int i = 0; i < MT; ++i) {
-        const int64_t off = (int64_t)n * (H + 2) * Wp * Cout + ((int64_t)(py0 + i + 1) * Wp + (px + 1)) * Cout + cbase;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) mk[i][j] = *reinterpret_cast<const u32x2*>(a.mask + off + j * 16);
-      }
-    }
+  // data-gradient extras: all addend / mask words of the tile are requested before the first is used (one
+  // memory round trip instead of 32 dependent ones)
+  u32x2 ad[MT][4], mk[MT][4];
+  if (a.addend != nullptr) {
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
-      u32x2 h[4];
+      const int64_t off = (int64_t)n * (H + 2) * Wp * Cout + ((int64_t)(py0 + i + 1) * Wp + (px + 1)) * Cout + cbase;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        f32x4 v = acc[i][j] + bj[j];
-        if (a.relu) {
-          v.x = fmaxf(v.x, 0.f);
-          v.y = fmaxf(v.y, 0.f);
-          v.z = fmaxf(v.z, 0.f);
-          v.w = fmaxf(v.w, 0.f);
-        }
-        acc[i][j] = v;  // the pool below takes the activation before addend / mask (forward layers have neither)
-        if (a.addend != nullptr) {
-          v.x += bf16_bits_to_f32(ad[i][j].x & 0xffffu);
-          v.y += __builtin_bit_cast(float, ad[i][j].x & 0xffff0000u);
-          v.z += bf16_bits_to_f32(ad[i][j].y & 0xffffu);
-          v.w += __builtin_bit_cast(float, ad[i][j].y & 0xffff0000u);
-        }
-        if (a.mask != nullptr) {
-          v.x = bf16_bits_to_f32(mk[i][j].x & 0xffffu) > 0.f ? v.x : 0.f;
-          v.y = __builtin_bit_cast(float, mk[i][j].x & 0xffff0000u) > 0.f ? v.y : 0.f;
-          v.z = bf16_bits_to_f32(mk[i][j].y & 0xffffu) > 0.f ? v.z : 0.f;
-          v.w = __builtin_bit_cast(float, mk[i][j].y & 0xffff0000u) > 0.f ? v.w : 0.f;
-        }
-        h[j] = u32x2{pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w)};
-      }
-      xv_pair16(h[0], h[1], pq[i][0]);
-      xv_pair16(h[2], h[3], pq[i][1]);
+      for (int j = 0; j < 4; ++j) ad[i][j] = *reinterpret_cast<const u32x2*>(a.addend + off + j * 16);
     }
-    if (a.pooled != nullptr) {
+  }
+  if (a.mask != nullptr) {
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      const int64_t off = (int64_t)n * (H + 2) * Wp * Cout + ((int64_t)(py0 + i + 1) * Wp + (px + 1)) * Cout + cbase;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) mk[i][j] = *reinterpret_cast<const u32x2*>(a.mask + off + j * 16);
+    }
+  }
+  // bias (+ addend, mask) in fp32, round to bf16 pairs, relu on the pairs
+  u32x2 h[MT][4];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      f32x4 v = acc[i][j] + bj[j];
+      if (a.addend != nullptr) {
+        v.x += bf16_bits_to_f32(ad[i][j].x & 0xffffu);
+        v.y += __builtin_bit_cast(float, ad[i][j].x & 0xffff0000u);
+        v.z += bf16_bits_to_f32(ad[i][j].y & 0xffffu);
+        v.w += __builtin_bit_cast(float, ad[i][j].y & 0xffff0000u);
+      }
+      if (a.mask != nullptr) {
+        v.x = bf16_bits_to_f32(mk[i][j].x & 0xffffu) > 0.f ? v.x : 0.f;
+        v.y = __builtin_bit_cast(float, mk[i][j].x & 0xffff0000u) > 0.f ? v.y : 0.f;
+        v.z = bf16_bits_to_f32(mk[i][j].y & 0xffffu) > 0.f ? v.z : 0.f;
+        v.w = __builtin_bit_cast(float, mk[i][j].y & 0xffff0000u) > 0.f ? v.w : 0.f;
+      }
+      h[i][j] = u32x2{pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w)};
+      if (a.relu) {
+        h[i][j].x = pk_max_i16(h[i][j].x, 0u);
+        h[i][j].y = pk_max_i16(h[i][j].y, 0u);
+      }
+    }
+  if (a.y != nullptr) {
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      xv_pair16(h[i][0], h[i][1], pq[i][0]);
+      xv_pair16(h[i][2], h[i][3], pq[i][1]);
+    }
+  }
+  if (a.pooled != nullptr) {
+    // fused max_pooling2d(2,2): rows (i, i+1) live in this lane, columns (px, px^1) in lanes l, l^1
+    u32x2 m[MT / 2][4];
+    if (a.relu) {
+#pragma unroll
+      for (int i = 0; i < MT; i += 2)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          u32x2 t = u32x2{pk_max_i16(h[i][j].x, h[i + 1][j].x), pk_max_i16(h[i][j].y, h[i + 1][j].y)};
+          m[i >> 1][j] = u32x2{pk_max_i16(t.x, dpp_swap1_u32(t.x)), pk_max_i16(t.y, dpp_swap1_u32(t.y))};
+        }
+    } else {
+      // signed inputs: the integer order is wrong for negative values, pool in fp32 (bias add is monotone)
+#pragma unroll
+      for (int i = 0; i < MT; i += 2)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          f32x4 t;
+          t.x = fmaxf(acc[i][j].x, acc[i + 1][j].x);
+          t.y = fmaxf(acc[i][j].y, acc[i + 1][j].y);
+          t.z = fmaxf(acc[i][j].z, acc[i + 1][j].z);
+          t.w = fmaxf(acc[i][j].w, acc[i + 1][j].w);
+          t.x = fmaxf(t.x, dpp_swap1(t.x));
+          t.y = fmaxf(t.y, dpp_swap1(t.y));
+          t.z = fmaxf(t.z, dpp_swap1(t.z));
+          t.w = fmaxf(t.w, dpp_swap1(t.w));
+          t += bj[j];
+          m[i >> 1][j] = u32x2{pack_bf16x2(t.x, t.y), pack_bf16x2(t.z, t.w)};
+        }
+    }
+    if (a.y == nullptr) {
+#pragma unroll
+      for (int i = 0; i < MT / 2; ++i) {
+        xv_pair16(m[i][0], m[i][1], pq[i][0]);
+        xv_pair16(m[i][2], m[i][3], pq[i][1]);
+      }
+    } else if ((lane & 1) == 0) {
       // both maps wanted (conv4_3, training forward): the quarter-size pooled map is stored at once
       const int Hq = H >> 1, Wq = W >> 1;
       __bf16* qimg = a.pooled + (int64_t)n * (Hq + 2) * (Wq + 2) * Cout;
@@ -610,26 +632,11 @@ __device__ __forceinline__ void dma_epilogue_pack(const ConvArgs& a, f32x4 (&acc
       for (int i = 0; i < MT; i += 2)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          f32x4 m;
-          m.x = fmaxf(acc[i][j].x, acc[i + 1][j].x);
-          m.y = fmaxf(acc[i][j].y, acc[i + 1][j].y);
-          m.z = fmaxf(acc[i][j].z, acc[i + 1][j].z);
-          m.w = fmaxf(acc[i][j].w, acc[i + 1][j].w);
-          m.x = fmaxf(m.x, dpp_swap1(m.x));
-          m.y = fmaxf(m.y, dpp_swap1(m.y));
-          m.z = fmaxf(m.z, dpp_swap1(m.z));
-          m.w = fmaxf(m.w, dpp_swap1(m.w));
-          if ((lane & 1) == 0) {
-            __bf16* dst = qimg + ((int64_t)(((py0 + i) >> 1) + 1) * (Wq + 2) + ((px >> 1) + 1)) * Cout + cbase + j * 16;
-            *reinterpret_cast<u32x2*>(dst) = u32x2{pack_bf16x2(m.x, m.y), pack_bf16x2(m.z, m.w)};
-          }
+          __bf16* dst = qimg + ((int64_t)(((py0 + i) >> 1) + 1) * (Wq + 2) + ((px >> 1) + 1)) * Cout + cbase + j * 16;
+          *reinterpret_cast<u32x2*>(dst) = m[i >> 1][j];
         }
     }
   }
-#pragma unroll
-  for (int i = 0; i < MT; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 }
 
 template <int I, int N, class F>
@@ -655,6 +662,19 @@ struct DmaCfg {
   static constexpr int B_ITERS = (B_PIECES + NWAVES - 1) / NWAVES;
   static_assert(LDS_BYTES <= 160 * 1024, "does not fit the LDS");
 };
+
+#ifdef XV_CONV_TRACE
+// debug build only (tools/conv_trace.py): per work item four cycle stamps of wave 0 of every 32nd workgroup, kept in
+// spare LDS during the kernel (a global store per stamp would sit in the vmcnt queue this kernel counts on)
+__device__ long long xv_trace_buf[8 * 8 * 20 * 6];
+#define XV_TRACE_LDS 8192
+#define XV_STAMP(k)                                                                                   \
+  if ((blockIdx.x & 31) == 0 && trace_item < 20 && lane == 0)                                         \
+    reinterpret_cast<long long*>(smem + C::LDS_BYTES)[(wave * 20 + trace_item) * 6 + (k)] = __builtin_readcyclecounter();
+#else
+#define XV_TRACE_LDS 0
+#define XV_STAMP(k)
+#endif
 
 template <int WR, int WC>
 __global__ __launch_bounds__(64 * WR * WC, 2) void conv_dma_kernel(ConvArgs a) {
@@ -716,32 +736,56 @@ __global__ __launch_bounds__(64 * WR * WC, 2) void conv_dma_kernel(ConvArgs a) {
   // channel offset of this lane's 16-byte output piece inside a 32-channel pair (see xv_pair16)
   const int csub = (lg & 1) * 16 + (lg >> 1) * 8;
 
-  auto issue = [&](const Tile& t, int chunk, int buf, int bslot) {
-    const char* xsrc = reinterpret_cast<const char*>(a.x) +
-                       ((((int64_t)t.n * (H + 2) + t.y0) * Wp + t.x0) * Cin + chunk * 32) * 2;
-#pragma unroll
-    for (int it = 0; it < C::A_ITERS; ++it) {
-      const int piece = wave + it * C::NWAVES;
-      if (piece < C::A_PIECES)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xsrc + aoff[it]),
-                                         (__attribute__((address_space(3))) void*)(smem + buf * C::A_BYTES + piece * 1024),
-                                         16, 0, 0);
-    }
-    const char* wsrc = wlane + (((int64_t)chunk * Cout + t.co0) << 6);
-#pragma unroll
-    for (int it = 0; it < C::B_ITERS; ++it) {
-      const int piece = wave + it * C::NWAVES;
-      if (piece < C::B_PIECES)
-        __builtin_amdgcn_global_load_lds(
-            (const __attribute__((address_space(1))) void*)(wsrc + (piece >> 2) * tap_pitch + (piece & 3) * 1024),
-            (__attribute__((address_space(3))) void*)(smem + 2 * C::A_BYTES + buf * C::B_BYTES + piece * 1024), 16, 0, 0);
-    }
-    // the tile's 64 bias values ride along with its first chunk (one 4-byte-per-lane DMA by the last wave)
+  // One work item's operands = A_ITERS patch pieces + B_ITERS weight pieces per wave (1 KB each) + the tile's
+  // bias.  The CU's vector-memory pipe takes ~25 cycles per piece and a wave whose DMA does not fit its queue
+  // stalls in order, MFMAs included (measured: ~200 cycles per DMA when all ten were issued in one burst), so
+  // the pieces are issued one patch + one weight piece per tap over the first taps of the PREVIOUS item.
+  auto dma_bases = [&](const Tile& t, int chunk, const char*& xsrc, const char*& wsrc) {
+    xsrc = reinterpret_cast<const char*>(a.x) + ((((int64_t)t.n * (H + 2) + t.y0) * Wp + t.x0) * Cin + chunk * 32) * 2;
+    wsrc = wlane + (((int64_t)chunk * Cout + t.co0) << 6);
+  };
+  auto dma_a = [&](const char* xsrc, int it, int buf) {
+    const int piece = wave + it * C::NWAVES;
+#ifdef XV_SKIP_A
+    if (piece < 0)
+#else
+    if (piece < C::A_PIECES)
+#endif
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xsrc + aoff[it]),
+                                       (__attribute__((address_space(3))) void*)(smem + buf * C::A_BYTES + piece * 1024), 16,
+                                       0, 0);
+  };
+  auto dma_b = [&](const char* wsrc, int it, int buf) {
+    const int piece = wave + it * C::NWAVES;
+#ifdef XV_SKIP_B
+    if (piece < 0)
+#else
+    if (piece < C::B_PIECES)
+#endif
+      __builtin_amdgcn_global_load_lds(
+          (const __attribute__((address_space(1))) void*)(wsrc + (piece >> 2) * tap_pitch + (piece & 3) * 1024),
+          (__attribute__((address_space(3))) void*)(smem + 2 * C::A_BYTES + buf * C::B_BYTES + piece * 1024), 16, 0, 0);
+  };
+  // the tile's 64 bias values ride along with its first chunk (one 4-byte-per-lane DMA by the last wave)
+  auto dma_bias = [&](const Tile& t, int chunk, int bslot) {
     if (chunk == 0 && wave == C::NWAVES - 1)
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.bias + t.co0 + lane),
-                                       (__attribute__((address_space(3))) void*)(smem + C::BIAS_OFF + bslot * 256), 4, 0,
-                                       0);
+                                       (__attribute__((address_space(3))) void*)(smem + C::BIAS_OFF + bslot * 256), 4, 0, 0);
   };
+  auto issue_all = [&](const Tile& t, int chunk, int buf, int bslot) {
+    const char *xsrc, *wsrc;
+    dma_bases(t, chunk, xsrc, wsrc);
+#pragma unroll
+    for (int it = 0; it < C::A_ITERS; ++it) dma_a(xsrc, it, buf);
+#pragma unroll
+    for (int it = 0; it < C::B_ITERS; ++it) dma_b(wsrc, it, buf);
+    dma_bias(t, chunk, bslot);
+  };
+  constexpr int A_TAPS = (C::A_ITERS + 1) / 2;  // taps 0..A_TAPS-1 issue the patch pieces, two each
+  constexpr int LAST_DMA_TAP = A_TAPS + C::B_ITERS - 1;
+  static_assert(LAST_DMA_TAP <= 8, "DMA pieces are issued inside the 9 taps");
+  // full-map tile: pieces 0..7 leave in taps 1..8; those of taps LAST_DMA_TAP+1..8 are younger than every DMA
+  constexpr int YTAIL = 8 - LAST_DMA_TAP;
 
   int lid = t_begin + bi;
   if (lid >= t_end) return;
@@ -754,22 +798,28 @@ __global__ __launch_bounds__(64 * WR * WC, 2) void conv_dma_kernel(ConvArgs a) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
   u32x4 pq[MT][2];
   DmaPend pend{0, 0, 0, 0, false};
   const int npieces = a.y != nullptr ? 2 * MT : MT;  // 16-byte store instructions per tile and wave
   int in_flight = 0;  // stores issued after the last DMA of the previous item
-  issue(cur, 0, 0, 0);
+  issue_all(cur, 0, 0, 0);
+#ifdef XV_CONV_TRACE
+  int trace_item = 0;
+#endif
 
   while (true) {
+    XV_STAMP(0)  // arrival at the item barrier
     // This item's operands have landed (each wave retires its own DMA; stores issued after it may stay in flight:
     // vmcnt counts in issue order), and every wave has finished reading the other buffer pair.
-    if (in_flight == 2 * MT)
+    if (in_flight == YTAIL)
+      asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(YTAIL) : "memory");
+    else if (in_flight == 2 * MT)
       asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(2 * MT) : "memory");
-    else if (in_flight == MT)
-      asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(MT) : "memory");
     else
       asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
     in_flight = 0;
+    XV_STAMP(1)  // barrier passed
 
     // Taps run dx-major: for one horizontal offset the 3 vertical taps of the wave's 4 rows touch only 6
     // patch rows, loaded once (18 + 36 fragment reads per item instead of 72).  Fragment reads run one tap
@@ -815,20 +865,32 @@ __global__ __launch_bounds__(64 * WR * WC, 2) void conv_dma_kernel(ConvArgs a) {
                : "+v"(wf[ws][0]), "+v"(wf[ws][1]), "+v"(wf[ws][2]), "+v"(wf[ws][3]), "+v"(xf[ps][0]), \
                  "+v"(xf[ps][1]), "+v"(xf[ps][2]), "+v"(xf[ps][3]), "+v"(xf[ps][4]), "+v"(xf[ps][5])  \
                : "n"(n))
-    // one 16-byte store of the previous tile per tap (piece t = row t/2, channel pair t%2; pooled-only: 4 pieces)
-#define XV_STORE_PIECE(t)                                                                          \
-  if ((t) < 2 * MT && stores_now > (t)) {                                                          \
+    // one 16-byte store of the previous tile per tap, taps 1..8 (piece = row p/2, channel pair p%2; pooled-only:
+    // 4 pieces), each ahead of that tap's DMA: the stores younger than the last DMA are those of the taps after
+    // LAST_DMA_TAP -- the count the item-end vmcnt leaves in flight
+#define XV_STORE_PIECE(p)                                                                          \
+  if ((p) >= 0 && (p) < 2 * MT && stores_now > (p)) {                                              \
     if (a.y != nullptr)                                                                            \
-      *reinterpret_cast<u32x4*>(st_base + (int64_t)((t) >> 1) * st_pitch + ((t) & 1) * 32) = pq[((t) >> 1) % MT][(t) & 1]; \
+      *reinterpret_cast<u32x4*>(st_base + (int64_t)((p) >> 1) * st_pitch + ((p) & 1) * 32) = pq[(((p) >> 1) + MT) % MT][(p) & 1]; \
     else if ((lane & 1) == 0)                                                                      \
-      *reinterpret_cast<u32x4*>(st_base + (int64_t)((t) >> 1) * st_pitch + ((t) & 1) * 32) = pq[((t) >> 1) % MT][(t) & 1]; \
+      *reinterpret_cast<u32x4*>(st_base + (int64_t)((p) >> 1) * st_pitch + ((p) & 1) * 32) = pq[(((p) >> 1) + MT) % MT][(p) & 1]; \
+  }
+  // patch pieces first, two per tap (they come from HBM / Infinity Cache: ~an item of latency), then the weight
+  // pieces (L2-resident), one per tap
+#define XV_DMA_PIECES(t)                                                                   \
+  if (has_next) {                                                                          \
+    if (2 * (t) < C::A_ITERS) dma_a(nx_src, 2 * (t), buf ^ 1);                             \
+    if (2 * (t) + 1 < C::A_ITERS) dma_a(nx_src, 2 * (t) + 1, buf ^ 1);                     \
+    if ((t) >= A_TAPS && (t) - A_TAPS < C::B_ITERS) dma_b(nw_src, (t) - A_TAPS, buf ^ 1);  \
+    if ((t) == A_TAPS) dma_bias(nxt, nchunk, bslot ^ 1);                                   \
   }
 #define XV_TAP(t)                                                                                  \
   {                                                                                                \
     constexpr int dx_ = (t) / 3, dy_ = (t) % 3;                                                    \
     if constexpr ((t) + 1 < 9) XV_LDW((t) + 1, ((t) + 1) & 1);                                      \
     if constexpr (dy_ == 1 && dx_ + 1 < 3) XV_LDP(dx_ + 1, (dx_ + 1) & 1);                          \
-    XV_STORE_PIECE(t)                                                                              \
+    XV_STORE_PIECE((t) - 1)                                                                        \
+    XV_DMA_PIECES(t)                                                                               \
     /* reads issued after W_t: P(dx+1) of this tap (dy 1) or of the previous one (dy 2), and W_t+1 */ \
     constexpr int newer_ = ((t) + 1 < 9 ? 4 : 0) + ((dy_ != 0 && dx_ + 1 < 3) ? 6 : 0);             \
     if constexpr (dy_ == 0)                                                                        \
@@ -836,8 +898,28 @@ __global__ __launch_bounds__(64 * WR * WC, 2) void conv_dma_kernel(ConvArgs a) {
     else                                                                                           \
       XV_WAIT_W(newer_, (t) & 1);                                                                  \
     __builtin_amdgcn_sched_barrier(0);                                                             \
-    _Pragma("unroll") for (int i = 0; i < MT; ++i) _Pragma("unroll") for (int j = 0; j < 4; ++j)   \
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[(t) & 1][j], xf[dx_ & 1][i + dy_], acc[i][j], 0, 0, 0); \
+    /* Two waves share a SIMD and the older one wins every arbitration: it ran its 16-MFMA bursts back to back  \
+       and let the other in only during its own gaps (measured: 144 vs ~40 MFMAs while both were active, the   \
+       whole workgroup then waiting ~1.9 k cycles per item for the starved waves).  A burst therefore raises   \
+       its priority after its first MFMA and drops it at its end: a wave cannot break into the other's burst, \
+       and the two alternate tap by tap. */                                                                  \
+    if ((t) == 0 && chunk == 0) { /* first tap of a tile: C = 0 instead of cleared accumulators */   \
+      acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[(t) & 1][0], xf[dx_ & 1][dy_], zero4, 0, 0, 0); \
+      __builtin_amdgcn_s_setprio(2);                                                               \
+      __builtin_amdgcn_sched_barrier(0);                                                           \
+      _Pragma("unroll") for (int i = 0; i < MT; ++i) _Pragma("unroll") for (int j = 0; j < 4; ++j) \
+          if (i + j > 0)                                                                           \
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[(t) & 1][j], xf[dx_ & 1][i + dy_], zero4, 0, 0, 0); \
+    } else {                                                                                       \
+      acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[(t) & 1][0], xf[dx_ & 1][dy_], acc[0][0], 0, 0, 0); \
+      __builtin_amdgcn_s_setprio(2);                                                               \
+      __builtin_amdgcn_sched_barrier(0);                                                           \
+      _Pragma("unroll") for (int i = 0; i < MT; ++i) _Pragma("unroll") for (int j = 0; j < 4; ++j) \
+          if (i + j > 0)                                                                           \
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[(t) & 1][j], xf[dx_ & 1][i + dy_], acc[i][j], 0, 0, 0); \
+    }                                                                                              \
+    __builtin_amdgcn_sched_barrier(0);                                                             \
+    __builtin_amdgcn_s_setprio(1);                                                                 \
     __builtin_amdgcn_sched_barrier(0);                                                             \
   }
     XV_LDW(0, 0);
@@ -849,7 +931,8 @@ __global__ __launch_bounds__(64 * WR * WC, 2) void conv_dma_kernel(ConvArgs a) {
     const bool has_next = nlid < t_end;
     const Tile nxt = (last_chunk && has_next) ? decode(nlid) : cur;
     const int nchunk = last_chunk ? 0 : chunk + 1;
-    if (has_next) issue(nxt, nchunk, buf ^ 1, bslot ^ 1);  // overlaps the LDS latency of the first fragments
+    const char *nx_src = nullptr, *nw_src = nullptr;
+    if (has_next) dma_bases(nxt, nchunk, nx_src, nw_src);
 
     // the previous tile's stores go out one per tap, behind this item's DMA
     const int stores_now = pend.on ? npieces : 0;
@@ -868,18 +951,27 @@ __global__ __launch_bounds__(64 * WR * WC, 2) void conv_dma_kernel(ConvArgs a) {
       }
       pend.on = false;
     }
-    in_flight = stores_now;
+    // stores issued after the last DMA piece of this item (pieces LAST_DMA_TAP .. npieces-1 go out in later taps)
+    in_flight = (stores_now == 2 * MT) ? YTAIL : 0;
     __builtin_amdgcn_sched_barrier(0);
+    XV_STAMP(2)  // first fragments requested, DMA issued
 
     XV_TAP(0) XV_TAP(1) XV_TAP(2) XV_TAP(3) XV_TAP(4) XV_TAP(5) XV_TAP(6) XV_TAP(7) XV_TAP(8)
+    XV_STAMP(3)  // all MFMAs of the item issued
 
     if (last_chunk) {
       dma_epilogue_pack<MT>(a, acc, pq, reinterpret_cast<const float*>(smem + C::BIAS_OFF + bslot * 256), cur.n,
                             cur.y0 + wr * MT, cur.x0 + wc * 16 + l15, cur.co0 + lg * 4, lane);
       pend = DmaPend{cur.n, cur.y0, cur.x0, cur.co0, true};
+      XV_STAMP(4)  // tile converted
       bslot ^= 1;
-      in_flight = 0;  // the pack phase read the bias from LDS behind a full vmcnt(0)/lgkmcnt(0) drain
+      // both maps wanted: the pack phase stored the pooled map (MT/2 x 4 instructions), the youngest operations now
+      static_assert(YTAIL != 2 * MT, "the two counted waits must differ");
+      in_flight = (a.y != nullptr && a.pooled != nullptr) ? 2 * MT : 0;
     }
+#ifdef XV_CONV_TRACE
+    ++trace_item;
+#endif
     if (!has_next) {
       // last tile of this workgroup: store it now
       const int px = pend.x0 + wc * 16 + l15, py0 = pend.y0 + wr * MT;
@@ -903,8 +995,15 @@ __global__ __launch_bounds__(64 * WR * WC, 2) void conv_dma_kernel(ConvArgs a) {
     chunk = nchunk;
     buf ^= 1;
   }
+#ifdef XV_CONV_TRACE
+  __syncthreads();
+  if (wave == 0 && (blockIdx.x & 31) == 0)
+    for (int i = lane; i < 8 * 20 * 6; i += 64)
+      xv_trace_buf[(blockIdx.x >> 5) * 960 + i] = reinterpret_cast<long long*>(smem + C::LDS_BYTES)[i];
+#endif
 #undef XV_TAP
 #undef XV_STORE_PIECE
+#undef XV_DMA_PIECES
 #undef XV_WAIT_WP
 #undef XV_WAIT_W
 #undef XV_LDP
@@ -925,7 +1024,7 @@ int launch_conv_dma(const ConvArgs& a0, hipStream_t stream) {
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_dma_kernel<WR, WC>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES + XV_TRACE_LDS);
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
@@ -935,7 +1034,7 @@ int launch_conv_dma(const ConvArgs& a0, hipStream_t stream) {
   a.n_tiles = (int)ntiles;
   const int64_t slots = a.num_cus;
   const int64_t nblk = ntiles < slots ? ntiles : slots;
-  hipLaunchKernelGGL((conv_dma_kernel<WR, WC>), dim3((unsigned)nblk), dim3(C::NT), C::LDS_BYTES, stream, a);
+  hipLaunchKernelGGL((conv_dma_kernel<WR, WC>), dim3((unsigned)nblk), dim3(C::NT), C::LDS_BYTES + XV_TRACE_LDS, stream, a);
   return xv_launch_status();
 }
 
@@ -1139,3 +1238,9 @@ extern "C" int xv_conv2d_fwd_cfg(const xv_act* x, const void* w_packed, const fl
 }
 
 extern "C" int xv_conv2d_num_cfgs(void) { return XV_NUM_CONV_CFG; }
+
+#ifdef XV_CONV_TRACE
+extern "C" int xv_debug_read_trace(void* dst, size_t bytes) {
+  return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(xv_trace_buf), bytes);
+}
+#endif
