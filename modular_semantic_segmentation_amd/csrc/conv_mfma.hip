@@ -731,7 +731,6 @@ __global__ __launch_bounds__(64 * WR * WC, 2) void conv_dma_kernel(ConvArgs a) {
     pbase[dx] = ((wr * MT) * C::HW + hx) * 64 + (xv_swz32(hx, lg) << 4);
   }
   const int wbase = 2 * C::A_BYTES + l15 * 64 + (xv_swz32(l15, lg) << 4);
-  const char* const wlane = reinterpret_cast<const char*>(a.wpk) + lane * 16;
   const int64_t tap_pitch = (int64_t)nchunks * Cout * 64;  // bytes between taps of the packed image
   // channel offset of this lane's 16-byte output piece inside a 32-channel pair (see xv_pair16)
   const int csub = (lg & 1) * 16 + (lg >> 1) * 8;
@@ -740,9 +739,17 @@ __global__ __launch_bounds__(64 * WR * WC, 2) void conv_dma_kernel(ConvArgs a) {
   // bias.  The CU's vector-memory pipe takes ~25 cycles per piece and a wave whose DMA does not fit its queue
   // stalls in order, MFMAs included (measured: ~200 cycles per DMA when all ten were issued in one burst), so
   // the pieces are issued one patch + one weight piece per tap over the first taps of the PREVIOUS item.
+  // The DMA is written in assembly: `global_load_lds` in its SGPR-base + 32-bit-VGPR-offset form keeps ONE offset
+  // register per patch piece (the builtin wants a 64-bit flat pointer per lane) and keeps the instruction out of the
+  // compiler's waitcnt model, which treats an LDS-DMA as a FLAT access and drains counters around it.  M0 (LDS
+  // destination of the wave) is set inside the statement; nothing else in this kernel uses M0.
+  auto dma16 = [&](const char* sbase, int voff, int lds_off) {
+    asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_off), "v"(voff), "s"(sbase) : "memory");
+  };
+  const int lane16 = lane * 16;
   auto dma_bases = [&](const Tile& t, int chunk, const char*& xsrc, const char*& wsrc) {
     xsrc = reinterpret_cast<const char*>(a.x) + ((((int64_t)t.n * (H + 2) + t.y0) * Wp + t.x0) * Cin + chunk * 32) * 2;
-    wsrc = wlane + (((int64_t)chunk * Cout + t.co0) << 6);
+    wsrc = reinterpret_cast<const char*>(a.wpk) + (((int64_t)chunk * Cout + t.co0) << 6);
   };
   auto dma_a = [&](const char* xsrc, int it, int buf) {
     const int piece = wave + it * C::NWAVES;
@@ -751,9 +758,7 @@ __global__ __launch_bounds__(64 * WR * WC, 2) void conv_dma_kernel(ConvArgs a) {
 #else
     if (piece < C::A_PIECES)
 #endif
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xsrc + aoff[it]),
-                                       (__attribute__((address_space(3))) void*)(smem + buf * C::A_BYTES + piece * 1024), 16,
-                                       0, 0);
+      dma16(xsrc, aoff[it], buf * C::A_BYTES + piece * 1024);
   };
   auto dma_b = [&](const char* wsrc, int it, int buf) {
     const int piece = wave + it * C::NWAVES;
@@ -762,15 +767,14 @@ __global__ __launch_bounds__(64 * WR * WC, 2) void conv_dma_kernel(ConvArgs a) {
 #else
     if (piece < C::B_PIECES)
 #endif
-      __builtin_amdgcn_global_load_lds(
-          (const __attribute__((address_space(1))) void*)(wsrc + (piece >> 2) * tap_pitch + (piece & 3) * 1024),
-          (__attribute__((address_space(3))) void*)(smem + 2 * C::A_BYTES + buf * C::B_BYTES + piece * 1024), 16, 0, 0);
+      dma16(wsrc + (piece >> 2) * tap_pitch + (piece & 3) * 1024, lane16, 2 * C::A_BYTES + buf * C::B_BYTES + piece * 1024);
   };
   // the tile's 64 bias values ride along with its first chunk (one 4-byte-per-lane DMA by the last wave)
   auto dma_bias = [&](const Tile& t, int chunk, int bslot) {
     if (chunk == 0 && wave == C::NWAVES - 1)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.bias + t.co0 + lane),
-                                       (__attribute__((address_space(3))) void*)(smem + C::BIAS_OFF + bslot * 256), 4, 0, 0);
+      asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dword %1, %2" ::"s"(C::BIAS_OFF + bslot * 256), "v"(lane * 4),
+                   "s"(a.bias + t.co0)
+                   : "memory");
   };
   auto issue_all = [&](const Tile& t, int chunk, int buf, int bslot) {
     const char *xsrc, *wsrc;
@@ -870,13 +874,10 @@ __global__ __launch_bounds__(64 * WR * WC, 2) void conv_dma_kernel(ConvArgs a) {
     // LAST_DMA_TAP -- the count the item-end vmcnt leaves in flight
 #define XV_STORE_PIECE(p)                                                                          \
   if ((p) >= 0 && (p) < 2 * MT && stores_now > (p)) {                                              \
-    if (a.y != nullptr)                                                                            \
-      *reinterpret_cast<u32x4*>(st_base + (int64_t)((p) >> 1) * st_pitch + ((p) & 1) * 32) = pq[(((p) >> 1) + MT) % MT][(p) & 1]; \
-    else if ((lane & 1) == 0)                                                                      \
-      *reinterpret_cast<u32x4*>(st_base + (int64_t)((p) >> 1) * st_pitch + ((p) & 1) * 32) = pq[(((p) >> 1) + MT) % MT][(p) & 1]; \
+    if (a.y != nullptr || (lane & 1) == 0)                                                         \
+      *reinterpret_cast<u32x4*>(st_ptr + ((p) & 1) * 64) = pq[(((p) >> 1) + MT) % MT][(p) & 1];    \
+    if ((p) & 1) st_ptr += st_pitch;                                                               \
   }
-  // patch pieces first, two per tap (they come from HBM / Infinity Cache: ~an item of latency), then the weight
-  // pieces (L2-resident), one per tap
 #define XV_DMA_PIECES(t)                                                                   \
   if (has_next) {                                                                          \
     if (2 * (t) < C::A_ITERS) dma_a(nx_src, 2 * (t), buf ^ 1);                             \
@@ -936,18 +937,19 @@ __global__ __launch_bounds__(64 * WR * WC, 2) void conv_dma_kernel(ConvArgs a) {
 
     // the previous tile's stores go out one per tap, behind this item's DMA
     const int stores_now = pend.on ? npieces : 0;
-    __bf16* st_base = nullptr;
-    int st_pitch = 0;
+    char* st_ptr = nullptr;  // this lane's 16-byte piece of row 0; steps one row every two pieces
+    int st_pitch = 0;        // bytes
     if (pend.on) {
       const int px = pend.x0 + wc * 16 + l15, py0 = pend.y0 + wr * MT;
       if (a.y != nullptr) {
-        st_pitch = Wp * Cout;
-        st_base = a.y + (int64_t)pend.n * (H + 2) * Wp * Cout + ((int64_t)(py0 + 1) * Wp + (px + 1)) * Cout + pend.co0 + csub;
+        st_pitch = Wp * Cout * 2;
+        st_ptr = reinterpret_cast<char*>(a.y + (int64_t)pend.n * (H + 2) * Wp * Cout +
+                                         ((int64_t)(py0 + 1) * Wp + (px + 1)) * Cout + pend.co0 + csub);
       } else {
         const int Hq = H >> 1, Wq = W >> 1;
-        st_pitch = (Wq + 2) * Cout;
-        st_base = a.pooled + (int64_t)pend.n * (Hq + 2) * (Wq + 2) * Cout +
-                  ((int64_t)((py0 >> 1) + 1) * (Wq + 2) + ((px >> 1) + 1)) * Cout + pend.co0 + csub;
+        st_pitch = (Wq + 2) * Cout * 2;
+        st_ptr = reinterpret_cast<char*>(a.pooled + (int64_t)pend.n * (Hq + 2) * (Wq + 2) * Cout +
+                                         ((int64_t)((py0 >> 1) + 1) * (Wq + 2) + ((px >> 1) + 1)) * Cout + pend.co0 + csub);
       }
       pend.on = false;
     }
