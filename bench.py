@@ -273,7 +273,7 @@ def main():
     if dom in kinds and kinds[dom][1] > 0:
         fl, sec, cnt = kinds[dom]
         achieved = fl / sec / 1e12
-        roofline = {'bound': 'mfma', 'kernel': 'conv_mfma_kernel (3x3 implicit GEMM, all tile configurations)',
+        roofline = {'bound': 'mfma', 'kernel': 'conv_dma_kernel / conv_mfma_kernel (3x3 implicit GEMM, all launches)',
                     'achieved': round(achieved, 2),
                     'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(achieved / PEAK_BF16_TFLOPS, 4),
                     'traffic': traffic, 'launches': cnt, 'avg_launch_ms': round(sec / cnt * 1e3, 4),

@@ -23,10 +23,10 @@ def counter_avg(dirname, counter, match):
 
 
 def main(tag, batch=16):
-    is_conv3 = lambda k: 'conv_mfma_kernel' in k and ', 3, ' in k      # noqa: E731
+    is_conv3 = lambda k: 'conv_dma_kernel' in k or ('conv_mfma_kernel' in k and ', 3, ' in k)      # noqa: E731
     fetch = counter_avg('pmc_fetch', 'FETCH_SIZE', is_conv3)
     write = counter_avg('pmc_write', 'WRITE_SIZE', is_conv3)
-    out = {'kernel': 'conv_mfma_kernel (3x3, all tile configurations)', 'source': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, '
+    out = {'kernel': 'conv_dma_kernel + conv_mfma_kernel (all 3x3 launches)', 'source': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, '
            'python3 bench.py --steps 3 --warmup 1 --serial-experts --no-graph (batch %d, 768x384)' % batch,
            'batch': batch}
     if fetch and write:
