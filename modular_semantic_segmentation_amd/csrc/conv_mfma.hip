@@ -528,9 +528,13 @@ __device__ __forceinline__ uint32_t dpp_swap1_u32(uint32_t v) {
   return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xf, 0xf, true);
 }
 
-// Conversion phase.  Does NOT clear the accumulators: the first tap of the next tile starts from C = 0.
+// Conversion phase: bias (+ addend, mask) in fp32 and rounding to bf16 pairs -- all eight waves of the workgroup
+// do this at the same moment, so nothing hides it and it is kept minimal: relu and the lane pairing of the map
+// that will be stored are left to the store phase, where they ride between the MFMAs of the next work item.
+// pq[i][j] = the two bf16 pairs of row i, channel block j (pooled-only: pooled row i of rows 2i, 2i+1).
+// Does NOT clear the accumulators: the first tap of the next tile starts from C = 0.
 template <int MT>
-__device__ __forceinline__ void dma_epilogue_pack(const ConvArgs& a, f32x4 (&acc)[MT][4], u32x4 (&pq)[MT][2],
+__device__ __forceinline__ void dma_epilogue_pack(const ConvArgs& a, f32x4 (&acc)[MT][4], u32x2 (&pq)[MT][4],
                                                   const float* bias_lds, int n, int py0, int px, int cbase, int lane) {
   const int H = a.H, W = a.W, Cout = a.Cout, Wp = W + 2;
   const int lg = lane >> 4;
@@ -556,7 +560,6 @@ __device__ __forceinline__ void dma_epilogue_pack(const ConvArgs& a, f32x4 (&acc
       for (int j = 0; j < 4; ++j) mk[i][j] = *reinterpret_cast<const u32x2*>(a.mask + off + j * 16);
     }
   }
-  // bias (+ addend, mask) in fp32, round to bf16 pairs, relu on the pairs
   u32x2 h[MT][4];
 #pragma unroll
   for (int i = 0; i < MT; ++i)
@@ -576,55 +579,59 @@ __device__ __forceinline__ void dma_epilogue_pack(const ConvArgs& a, f32x4 (&acc
         v.w = __builtin_bit_cast(float, mk[i][j].y & 0xffff0000u) > 0.f ? v.w : 0.f;
       }
       h[i][j] = u32x2{pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w)};
-      if (a.relu) {
-        h[i][j].x = pk_max_i16(h[i][j].x, 0u);
-        h[i][j].y = pk_max_i16(h[i][j].y, 0u);
-      }
     }
-  if (a.y != nullptr) {
+  if (a.pooled == nullptr) {
 #pragma unroll
-    for (int i = 0; i < MT; ++i) {
-      xv_pair16(h[i][0], h[i][1], pq[i][0]);
-      xv_pair16(h[i][2], h[i][3], pq[i][1]);
-    }
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) pq[i][j] = h[i][j];
+    return;
   }
-  if (a.pooled != nullptr) {
-    // fused max_pooling2d(2,2): rows (i, i+1) live in this lane, columns (px, px^1) in lanes l, l^1
-    u32x2 m[MT / 2][4];
-    if (a.relu) {
+  // fused max_pooling2d(2,2): rows (i, i+1) live in this lane, columns (px, px^1) in lanes l, l^1
+  u32x2 m[MT / 2][4];
+  if (a.relu) {
+    // relu first (once more at store time: idempotent), then the integer max is the float max
 #pragma unroll
-      for (int i = 0; i < MT; i += 2)
+    for (int i = 0; i < MT; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          u32x2 t = u32x2{pk_max_i16(h[i][j].x, h[i + 1][j].x), pk_max_i16(h[i][j].y, h[i + 1][j].y)};
-          m[i >> 1][j] = u32x2{pk_max_i16(t.x, dpp_swap1_u32(t.x)), pk_max_i16(t.y, dpp_swap1_u32(t.y))};
-        }
-    } else {
-      // signed inputs: the integer order is wrong for negative values, pool in fp32 (bias add is monotone)
+      for (int j = 0; j < 4; ++j) h[i][j] = u32x2{pk_max_i16(h[i][j].x, 0u), pk_max_i16(h[i][j].y, 0u)};
 #pragma unroll
-      for (int i = 0; i < MT; i += 2)
+    for (int i = 0; i < MT; i += 2)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          f32x4 t;
-          t.x = fmaxf(acc[i][j].x, acc[i + 1][j].x);
-          t.y = fmaxf(acc[i][j].y, acc[i + 1][j].y);
-          t.z = fmaxf(acc[i][j].z, acc[i + 1][j].z);
-          t.w = fmaxf(acc[i][j].w, acc[i + 1][j].w);
-          t.x = fmaxf(t.x, dpp_swap1(t.x));
-          t.y = fmaxf(t.y, dpp_swap1(t.y));
-          t.z = fmaxf(t.z, dpp_swap1(t.z));
-          t.w = fmaxf(t.w, dpp_swap1(t.w));
-          t += bj[j];
-          m[i >> 1][j] = u32x2{pack_bf16x2(t.x, t.y), pack_bf16x2(t.z, t.w)};
-        }
-    }
-    if (a.y == nullptr) {
-#pragma unroll
-      for (int i = 0; i < MT / 2; ++i) {
-        xv_pair16(m[i][0], m[i][1], pq[i][0]);
-        xv_pair16(m[i][2], m[i][3], pq[i][1]);
+      for (int j = 0; j < 4; ++j) {
+        u32x2 t = u32x2{pk_max_i16(h[i][j].x, h[i + 1][j].x), pk_max_i16(h[i][j].y, h[i + 1][j].y)};
+        m[i >> 1][j] = u32x2{pk_max_i16(t.x, dpp_swap1_u32(t.x)), pk_max_i16(t.y, dpp_swap1_u32(t.y))};
       }
-    } else if ((lane & 1) == 0) {
+  } else {
+    // signed inputs: the integer order is wrong for negative values, pool in fp32 (bias add is monotone)
+#pragma unroll
+    for (int i = 0; i < MT; i += 2)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        f32x4 t;
+        t.x = fmaxf(acc[i][j].x, acc[i + 1][j].x);
+        t.y = fmaxf(acc[i][j].y, acc[i + 1][j].y);
+        t.z = fmaxf(acc[i][j].z, acc[i + 1][j].z);
+        t.w = fmaxf(acc[i][j].w, acc[i + 1][j].w);
+        t.x = fmaxf(t.x, dpp_swap1(t.x));
+        t.y = fmaxf(t.y, dpp_swap1(t.y));
+        t.z = fmaxf(t.z, dpp_swap1(t.z));
+        t.w = fmaxf(t.w, dpp_swap1(t.w));
+        t += bj[j];
+        m[i >> 1][j] = u32x2{pack_bf16x2(t.x, t.y), pack_bf16x2(t.z, t.w)};
+      }
+  }
+  if (a.y == nullptr) {
+#pragma unroll
+    for (int i = 0; i < MT / 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) pq[i][j] = m[i][j];
+  } else {
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) pq[i][j] = h[i][j];
+    if ((lane & 1) == 0) {
       // both maps wanted (conv4_3, training forward): the quarter-size pooled map is stored at once
       const int Hq = H >> 1, Wq = W >> 1;
       __bf16* qimg = a.pooled + (int64_t)n * (Hq + 2) * (Wq + 2) * Cout;
@@ -637,6 +644,15 @@ __device__ __forceinline__ void dma_epilogue_pack(const ConvArgs& a, f32x4 (&acc
         }
     }
   }
+}
+
+// store phase, one 16-byte piece: relu on the packed pairs (rfloor = 0, or 0x80008000 = no-op without relu), then
+// v_permlane16_swap pairs the 4-channel groups of lanes l and l+16
+__device__ __forceinline__ u32x4 dma_store_piece(const u32x2 h0, const u32x2 h1, uint32_t rfloor) {
+  u32x4 o;
+  xv_pair16(u32x2{pk_max_i16(h0.x, rfloor), pk_max_i16(h0.y, rfloor)},
+            u32x2{pk_max_i16(h1.x, rfloor), pk_max_i16(h1.y, rfloor)}, o);
+  return o;
 }
 
 template <int I, int N, class F>
@@ -803,7 +819,8 @@ __global__ __launch_bounds__(64 * WR * WC, 2) void conv_dma_kernel(ConvArgs a) {
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-  u32x4 pq[MT][2];
+  u32x2 pq[MT][4];
+  const uint32_t rfloor = a.relu ? 0u : 0x80008000u;
   DmaPend pend{0, 0, 0, 0, false};
   const int npieces = a.y != nullptr ? 2 * MT : MT;  // 16-byte store instructions per tile and wave
   int in_flight = 0;  // stores issued after the last DMA of the previous item
@@ -874,8 +891,9 @@ __global__ __launch_bounds__(64 * WR * WC, 2) void conv_dma_kernel(ConvArgs a) {
     // LAST_DMA_TAP -- the count the item-end vmcnt leaves in flight
 #define XV_STORE_PIECE(p)                                                                          \
   if ((p) >= 0 && (p) < 2 * MT && stores_now > (p)) {                                              \
-    if (a.y != nullptr || (lane & 1) == 0)                                                         \
-      *reinterpret_cast<u32x4*>(st_ptr + ((p) & 1) * 64) = pq[(((p) >> 1) + MT) % MT][(p) & 1];    \
+    const u32x4 o_ = dma_store_piece(pq[(((p) >> 1) + MT) % MT][2 * ((p) & 1)],                    \
+                                     pq[(((p) >> 1) + MT) % MT][2 * ((p) & 1) + 1], rfloor);       \
+    if (a.y != nullptr || (lane & 1) == 0) *reinterpret_cast<u32x4*>(st_ptr + ((p) & 1) * 64) = o_; \
     if ((p) & 1) st_ptr += st_pitch;                                                               \
   }
 #define XV_DMA_PIECES(t)                                                                   \
@@ -981,14 +999,17 @@ __global__ __launch_bounds__(64 * WR * WC, 2) void conv_dma_kernel(ConvArgs a) {
         __bf16* base = a.y + (int64_t)pend.n * (H + 2) * Wp * Cout + ((int64_t)(py0 + 1) * Wp + (px + 1)) * Cout + pend.co0 + csub;
 #pragma unroll
         for (int t = 0; t < 2 * MT; ++t)
-          *reinterpret_cast<u32x4*>(base + (int64_t)(t >> 1) * Wp * Cout + (t & 1) * 32) = pq[t >> 1][t & 1];
-      } else if ((lane & 1) == 0) {
+          *reinterpret_cast<u32x4*>(base + (int64_t)(t >> 1) * Wp * Cout + (t & 1) * 32) =
+              dma_store_piece(pq[t >> 1][2 * (t & 1)], pq[t >> 1][2 * (t & 1) + 1], rfloor);
+      } else {
         const int Hq = H >> 1, Wq = W >> 1;
         __bf16* base = a.pooled + (int64_t)pend.n * (Hq + 2) * (Wq + 2) * Cout +
                        ((int64_t)((py0 >> 1) + 1) * (Wq + 2) + ((px >> 1) + 1)) * Cout + pend.co0 + csub;
 #pragma unroll
-        for (int t = 0; t < MT; ++t)
-          *reinterpret_cast<u32x4*>(base + (int64_t)(t >> 1) * (Wq + 2) * Cout + (t & 1) * 32) = pq[t >> 1][t & 1];
+        for (int t = 0; t < MT; ++t) {
+          const u32x4 o = dma_store_piece(pq[t >> 1][2 * (t & 1)], pq[t >> 1][2 * (t & 1) + 1], rfloor);
+          if ((lane & 1) == 0) *reinterpret_cast<u32x4*>(base + (int64_t)(t >> 1) * (Wq + 2) * Cout + (t & 1) * 32) = o;
+        }
       }
       break;
     }
