@@ -69,3 +69,22 @@ __device__ static inline uint32_t pack_bf16x2(float lo, float hi) {
 __device__ static inline float bf16_bits_to_f32(uint32_t bits16) {
   return __builtin_bit_cast(float, bits16 << 16);
 }
+
+// Output-side helpers shared by the MFMA conv kernels (a lane holds 4 consecutive output channels of one pixel for
+// each of the four 16-channel blocks).
+__device__ static __forceinline__ void xv_pair16(const u32x2 a, const u32x2 b, u32x4& out) {
+  // lanes of row r (= lane >> 4) hold channel groups r*4 of `a` (block j) and `b` (block j+1); after the swap a
+  // lane holds 8 consecutive channels: rows 0..3 -> channel offsets 0, 16, 8, 24 of the 32-channel pair
+  const auto s0 = __builtin_amdgcn_permlane16_swap(a.x, b.x, false, false);
+  const auto s1 = __builtin_amdgcn_permlane16_swap(a.y, b.y, false, false);
+  out = u32x4{s0[0], s1[0], s0[1], s1[1]};
+}
+
+// relu and 2x2 max on PACKED bf16 pairs: a non-negative bf16 orders like its bit pattern as a signed 16-bit
+// integer and every negative one (sign bit) is a negative integer, so relu is v_pk_max_i16 against 0 and, after
+// it, so is the max-pool -- two values per instruction and none of the NaN-quieting v_max_f32 x,x,x that fmaxf
+// costs under IEEE mode.  Rounding to bf16 is monotone, so pooling after rounding equals rounding after pooling.
+__device__ static __forceinline__ uint32_t pk_max_i16(uint32_t a, uint32_t b) {
+  typedef short s16x2 __attribute__((ext_vector_type(2)));
+  return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s16x2, a), __builtin_bit_cast(s16x2, b)));
+}
