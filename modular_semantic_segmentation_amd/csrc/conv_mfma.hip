@@ -317,15 +317,17 @@ __global__ __launch_bounds__(64 * WR * WC * NW, OCC) void conv_mfma_kernel(ConvA
     for (int tt = 0; tt < C::TPS; ++tt) {
       const int tap = stage * C::TPS + tt;
       if (tap < C::NTAPS) {
-        const char* src =
-            reinterpret_cast<const char*>(a.wpk) + (((int64_t)(tap * nchunks + chunk) * Cout + co0) << 7) + lane * 16;
-        char* dst = Bs + buf * STAGE_BYTES + tt * C::B_BYTES;
+        // in assembly (SGPR base + lane offset): the builtin makes hipcc model a FLAT access, after which every
+        // LDS wait it inserts is lgkmcnt(0) instead of a counted one
+        const char* src = reinterpret_cast<const char*>(a.wpk) + (((int64_t)(tap * nchunks + chunk) * Cout + co0) << 7);
+        const int dst = C::A_BYTES + buf * STAGE_BYTES + tt * C::B_BYTES;
 #pragma unroll
         for (int i = 0; i < (DMA_PER_TAP + NWAVES - 1) / NWAVES; ++i) {
           const int piece = wave + i * NWAVES;
           if (piece < DMA_PER_TAP)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + piece * 1024),
-                                             (__attribute__((address_space(3))) void*)(dst + piece * 1024), 16, 0, 0);
+            asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(dst + piece * 1024), "v"(lane * 16),
+                         "s"(src + piece * 1024)
+                         : "memory");
         }
       }
     }

@@ -259,7 +259,6 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_dma_kernel(WgradArgs a) {
     const int y0 = ty * TH, x0 = tx * TW;
     const __bf16* ximg = a.x + (int64_t)n * (H + 2) * Wp * Cin + ci0;
     const __bf16* dimg = a.dy + (int64_t)n * (H + 2) * Wp * Cout + co0;
-    char* buf = smem + b * BUF;
     for (int i = wave; i < XI + DI; i += 8) {
       if (i < XI) {
         int idx = i * 64 + lane;  // 16-byte piece of the patch image: pixel idx>>3, PHYSICAL slot idx&7
@@ -270,9 +269,11 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_dma_kernel(WgradArgs a) {
         int yy = y0 + hy + (1 - HALO), xx = x0 + hx + (1 - HALO);
         yy = yy < H + 1 ? yy : H + 1;
         xx = xx < W + 1 ? xx : W + 1;
-        const __bf16* src = ximg + ((int64_t)yy * Wp + xx) * Cin + s * 8;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                         (__attribute__((address_space(3))) void*)(buf + i * 1024), 16, 0, 0);
+        // in assembly (SGPR base + 32-bit lane offset): the builtin makes hipcc model a FLAT access, after which
+        // every LDS wait it inserts is lgkmcnt(0) instead of a counted one
+        const int voff = ((yy * Wp + xx) * Cin + s * 8) * 2;
+        asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(__builtin_amdgcn_readfirstlane(b * BUF + i * 1024)), "v"(voff), "s"(ximg)
+                     : "memory");
       } else {
         const int j = i - XI;
         const int idx = j * 64 + lane;
@@ -282,9 +283,10 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_dma_kernel(WgradArgs a) {
         int yy = y0 + py + 1, xx = x0 + px + 1;
         yy = yy < H + 1 ? yy : H + 1;
         xx = xx < W + 1 ? xx : W + 1;
-        const __bf16* src = dimg + ((int64_t)yy * Wp + xx) * Cout + s * 8;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                         (__attribute__((address_space(3))) void*)(buf + X_BYTES + j * 1024), 16, 0, 0);
+        const int voff = ((yy * Wp + xx) * Cout + s * 8) * 2;
+        asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(__builtin_amdgcn_readfirstlane(b * BUF + X_BYTES + j * 1024)), "v"(voff),
+                     "s"(dimg)
+                     : "memory");
       }
     }
   };
