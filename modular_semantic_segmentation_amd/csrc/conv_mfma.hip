@@ -534,7 +534,8 @@ __device__ __forceinline__ void dma_epilogue_pack(const ConvArgs& a, f32x4 (&acc
   if (a.addend != nullptr) {
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
-      const int64_t off = (int64_t)n * (H + 2) * Wp * Cout + ((int64_t)(py0 + i + 1) * Wp + (px + 1)) * Cout + cbase;
+      const bool in = py0 + i < H && px < W;  // edge tiles: pixels past the image read the image's first pixel instead
+      const int64_t off = (int64_t)n * (H + 2) * Wp * Cout + ((int64_t)((in ? py0 + i : 0) + 1) * Wp + ((in ? px : 0) + 1)) * Cout + cbase;
 #pragma unroll
       for (int j = 0; j < 4; ++j) ad[i][j] = *reinterpret_cast<const u32x2*>(a.addend + off + j * 16);
     }
@@ -542,7 +543,8 @@ __device__ __forceinline__ void dma_epilogue_pack(const ConvArgs& a, f32x4 (&acc
   if (a.mask != nullptr) {
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
-      const int64_t off = (int64_t)n * (H + 2) * Wp * Cout + ((int64_t)(py0 + i + 1) * Wp + (px + 1)) * Cout + cbase;
+      const bool in = py0 + i < H && px < W;
+      const int64_t off = (int64_t)n * (H + 2) * Wp * Cout + ((int64_t)((in ? py0 + i : 0) + 1) * Wp + ((in ? px : 0) + 1)) * Cout + cbase;
 #pragma unroll
       for (int j = 0; j < 4; ++j) mk[i][j] = *reinterpret_cast<const u32x2*>(a.mask + off + j * 16);
     }
@@ -618,7 +620,7 @@ __device__ __forceinline__ void dma_epilogue_pack(const ConvArgs& a, f32x4 (&acc
     for (int i = 0; i < MT; ++i)
 #pragma unroll
       for (int j = 0; j < 4; ++j) pq[i][j] = h[i][j];
-    if ((lane & 1) == 0) {
+    if ((lane & 1) == 0 && px < W) {
       // both maps wanted (conv4_3, training forward): the quarter-size pooled map is stored at once
       const int Hq = H >> 1, Wq = W >> 1;
       __bf16* qimg = a.pooled + (int64_t)n * (Hq + 2) * (Wq + 2) * Cout;
@@ -626,6 +628,7 @@ __device__ __forceinline__ void dma_epilogue_pack(const ConvArgs& a, f32x4 (&acc
       for (int i = 0; i < MT; i += 2)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
+          if (py0 + i >= H) continue;
           __bf16* dst = qimg + ((int64_t)(((py0 + i) >> 1) + 1) * (Wq + 2) + ((px >> 1) + 1)) * Cout + cbase + j * 16;
           *reinterpret_cast<u32x2*>(dst) = m[i >> 1][j];
         }
@@ -754,14 +757,25 @@ __global__ __launch_bounds__(64 * WR * WC, 2) void conv_dma_kernel(ConvArgs a) {
     xsrc = reinterpret_cast<const char*>(a.x) + ((((int64_t)t.n * (H + 2) + t.y0) * Wp + t.x0) * Cin + chunk * 32) * 2;
     wsrc = reinterpret_cast<const char*>(a.wpk) + (((int64_t)chunk * Cout + t.co0) << 6);
   };
-  auto dma_a = [&](const char* xsrc, int it, int buf) {
+  // edge tiles (the patch reaches past the padded image): patch coordinates are clamped onto the zero border, i.e.
+  // the source offset is recomputed with hy <= ylim, hx <= xlim; the LDS position (and its swizzle) is unchanged
+  auto dma_a = [&](const char* xsrc, int it, int buf, bool edge, int ylim, int xlim) {
     const int piece = wave + it * C::NWAVES;
 #ifdef XV_SKIP_A
-    if (piece < 0)
+    if (piece < 0) {
 #else
-    if (piece < C::A_PIECES)
+    if (piece < C::A_PIECES) {
 #endif
-      dma16(xsrc, aoff[it], buf * C::A_BYTES + piece * 1024);
+      int voff = aoff[it];
+      if (edge) {
+        const int g = piece * 64 + lane;
+        int p = g >> 2;
+        p = p < C::NPIX ? p : C::NPIX - 1;
+        const int hy = p / C::HW, hx = p - hy * C::HW;
+        voff = (((hy < ylim ? hy : ylim) * Wp + (hx < xlim ? hx : xlim)) * Cin + xv_swz32(hx, g & 3) * 8) * 2;
+      }
+      dma16(xsrc, voff, buf * C::A_BYTES + piece * 1024);
+    }
   };
   auto dma_b = [&](const char* wsrc, int it, int buf) {
     const int piece = wave + it * C::NWAVES;
@@ -783,7 +797,8 @@ __global__ __launch_bounds__(64 * WR * WC, 2) void conv_dma_kernel(ConvArgs a) {
     const char *xsrc, *wsrc;
     dma_bases(t, chunk, xsrc, wsrc);
 #pragma unroll
-    for (int it = 0; it < C::A_ITERS; ++it) dma_a(xsrc, it, buf);
+    for (int it = 0; it < C::A_ITERS; ++it)
+      dma_a(xsrc, it, buf, t.y0 + C::TH > H || t.x0 + C::TW > W, H + 1 - t.y0, W + 1 - t.x0);
 #pragma unroll
     for (int it = 0; it < C::B_ITERS; ++it) dma_b(wsrc, it, buf);
     dma_bias(t, chunk, bslot);
@@ -880,13 +895,13 @@ __global__ __launch_bounds__(64 * WR * WC, 2) void conv_dma_kernel(ConvArgs a) {
   if ((p) >= 0 && (p) < 2 * MT && stores_now > (p)) {                                              \
     const u32x4 o_ = dma_store_piece(pq[(((p) >> 1) + MT) % MT][2 * ((p) & 1)],                    \
                                      pq[(((p) >> 1) + MT) % MT][2 * ((p) & 1) + 1], rfloor);       \
-    if (a.y != nullptr || (lane & 1) == 0) *reinterpret_cast<u32x4*>(st_ptr + ((p) & 1) * 64) = o_; \
+    if (((p) >> 1) < st_rows && st_lane) *reinterpret_cast<u32x4*>(st_ptr + ((p) & 1) * 64) = o_;  \
     if ((p) & 1) st_ptr += st_pitch;                                                               \
   }
 #define XV_DMA_PIECES(t)                                                                   \
   if (has_next) {                                                                          \
-    if (2 * (t) < C::A_ITERS) dma_a(nx_src, 2 * (t), buf ^ 1);                             \
-    if (2 * (t) + 1 < C::A_ITERS) dma_a(nx_src, 2 * (t) + 1, buf ^ 1);                     \
+    if (2 * (t) < C::A_ITERS) dma_a(nx_src, 2 * (t), buf ^ 1, nx_edge, nx_ylim, nx_xlim);         \
+    if (2 * (t) + 1 < C::A_ITERS) dma_a(nx_src, 2 * (t) + 1, buf ^ 1, nx_edge, nx_ylim, nx_xlim); \
     if ((t) >= A_TAPS && (t) - A_TAPS < C::B_ITERS) dma_b(nw_src, (t) - A_TAPS, buf ^ 1);  \
     if ((t) == A_TAPS) dma_bias(nxt, nchunk, bslot ^ 1);                                   \
   }
@@ -939,27 +954,39 @@ __global__ __launch_bounds__(64 * WR * WC, 2) void conv_dma_kernel(ConvArgs a) {
     const int nchunk = last_chunk ? 0 : chunk + 1;
     const char *nx_src = nullptr, *nw_src = nullptr;
     if (has_next) dma_bases(nxt, nchunk, nx_src, nw_src);
+    const bool nx_edge = nxt.y0 + C::TH > H || nxt.x0 + C::TW > W;
+    const int nx_ylim = H + 1 - nxt.y0, nx_xlim = W + 1 - nxt.x0;
 
     // the previous tile's stores go out one per tap, behind this item's DMA
     const int stores_now = pend.on ? npieces : 0;
     char* st_ptr = nullptr;  // this lane's 16-byte piece of row 0; steps one row every two pieces
     int st_pitch = 0;        // bytes
+    int st_rows = 0;         // rows of the (pooled) map this wave may store: all of them except on a bottom edge tile
+    bool st_lane = false;    // this lane stores: its pixel column is inside the image (and even, for the pooled map)
+    bool st_edge = false;
     if (pend.on) {
       const int px = pend.x0 + wc * 16 + l15, py0 = pend.y0 + wr * MT;
+      const int vrows = H - py0 < 0 ? 0 : (H - py0 < MT ? H - py0 : MT);
+      st_edge = pend.y0 + C::TH > H || pend.x0 + C::TW > W;
       if (a.y != nullptr) {
         st_pitch = Wp * Cout * 2;
+        st_rows = vrows;
+        st_lane = px < W;
         st_ptr = reinterpret_cast<char*>(a.y + (int64_t)pend.n * (H + 2) * Wp * Cout +
                                          ((int64_t)(py0 + 1) * Wp + (px + 1)) * Cout + pend.co0 + csub);
       } else {
         const int Hq = H >> 1, Wq = W >> 1;
         st_pitch = (Wq + 2) * Cout * 2;
+        st_rows = (vrows + 1) >> 1;
+        st_lane = px < W && (lane & 1) == 0;
         st_ptr = reinterpret_cast<char*>(a.pooled + (int64_t)pend.n * (Hq + 2) * (Wq + 2) * Cout +
                                          ((int64_t)((py0 >> 1) + 1) * (Wq + 2) + ((px >> 1) + 1)) * Cout + pend.co0 + csub);
       }
       pend.on = false;
     }
     // stores issued after the last DMA piece of this item (pieces LAST_DMA_TAP .. npieces-1 go out in later taps)
-    in_flight = (stores_now == 2 * MT) ? YTAIL : 0;
+    // (an edge tile may skip store instructions: no counted wait then)
+    in_flight = (stores_now == 2 * MT && !st_edge) ? YTAIL : 0;
     __builtin_amdgcn_sched_barrier(0);
     XV_STAMP(2)  // first fragments requested, DMA issued
 
@@ -974,7 +1001,7 @@ __global__ __launch_bounds__(64 * WR * WC, 2) void conv_dma_kernel(ConvArgs a) {
       bslot ^= 1;
       // both maps wanted: the pack phase stored the pooled map (MT/2 x 4 instructions), the youngest operations now
       static_assert(YTAIL != 2 * MT, "the two counted waits must differ");
-      in_flight = (a.y != nullptr && a.pooled != nullptr) ? 2 * MT : 0;
+      in_flight = (a.y != nullptr && a.pooled != nullptr && !(cur.y0 + C::TH > H || cur.x0 + C::TW > W)) ? 2 * MT : 0;
     }
 #ifdef XV_CONV_TRACE
     ++trace_item;
@@ -982,12 +1009,14 @@ __global__ __launch_bounds__(64 * WR * WC, 2) void conv_dma_kernel(ConvArgs a) {
     if (!has_next) {
       // last tile of this workgroup: store it now
       const int px = pend.x0 + wc * 16 + l15, py0 = pend.y0 + wr * MT;
+      const int vrows = H - py0 < 0 ? 0 : (H - py0 < MT ? H - py0 : MT);
       if (a.y != nullptr) {
         __bf16* base = a.y + (int64_t)pend.n * (H + 2) * Wp * Cout + ((int64_t)(py0 + 1) * Wp + (px + 1)) * Cout + pend.co0 + csub;
 #pragma unroll
-        for (int t = 0; t < 2 * MT; ++t)
-          *reinterpret_cast<u32x4*>(base + (int64_t)(t >> 1) * Wp * Cout + (t & 1) * 32) =
-              dma_store_piece(pq[t >> 1][2 * (t & 1)], pq[t >> 1][2 * (t & 1) + 1], rfloor);
+        for (int t = 0; t < 2 * MT; ++t) {
+          const u32x4 o = dma_store_piece(pq[t >> 1][2 * (t & 1)], pq[t >> 1][2 * (t & 1) + 1], rfloor);
+          if ((t >> 1) < vrows && px < W) *reinterpret_cast<u32x4*>(base + (int64_t)(t >> 1) * Wp * Cout + (t & 1) * 32) = o;
+        }
       } else {
         const int Hq = H >> 1, Wq = W >> 1;
         __bf16* base = a.pooled + (int64_t)pend.n * (Hq + 2) * (Wq + 2) * Cout +
@@ -995,7 +1024,8 @@ __global__ __launch_bounds__(64 * WR * WC, 2) void conv_dma_kernel(ConvArgs a) {
 #pragma unroll
         for (int t = 0; t < MT; ++t) {
           const u32x4 o = dma_store_piece(pq[t >> 1][2 * (t & 1)], pq[t >> 1][2 * (t & 1) + 1], rfloor);
-          if ((lane & 1) == 0) *reinterpret_cast<u32x4*>(base + (int64_t)(t >> 1) * (Wq + 2) * Cout + (t & 1) * 32) = o;
+          if ((t >> 1) < ((vrows + 1) >> 1) && px < W && (lane & 1) == 0)
+            *reinterpret_cast<u32x4*>(base + (int64_t)(t >> 1) * (Wq + 2) * Cout + (t & 1) * 32) = o;
         }
       }
       break;
@@ -1025,11 +1055,10 @@ template <int WR, int WC>
 int launch_conv_dma(const ConvArgs& a0, hipStream_t stream) {
   using C = DmaCfg<WR, WC>;
   ConvArgs a = a0;
-  if (a.H % C::TH || a.W % C::TW) return XV_ESHAPE;  // the DMA offsets are not clamped: whole tiles only
   // second half of the packed buffer: the 32-channel-chunk image
   a.wpk = a0.wpk + (int64_t)9 * a.Cin * a.Cout;
-  a.tiles_x = a.W / C::TW;
-  a.tiles_y = a.H / C::TH;
+  a.tiles_x = (a.W + C::TW - 1) / C::TW;
+  a.tiles_y = (a.H + C::TH - 1) / C::TH;
   a.n_ct = a.Cout / 64;
   static bool attr_set = false;
   if (!attr_set) {
@@ -1101,7 +1130,7 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, __bf16* __restr
 //  13: 16x32 x 64, 8 waves, 5 taps per barrier, 158 KB, 1/CU
 //  14 / 15 / 16: as 10 / 11 / 13 with the weight tiles staged by LDS-DMA
 //  17: generation 2 (conv_dma_kernel): 16x32 x 64, 8 waves, 32-channel chunks, all operands by LDS-DMA, 150 KB, 1/CU;
-//      3x3 only, whole tiles only
+//      3x3 only
 // Tried and dropped (slower, tools/conv_tune.py): 8-wave 128-channel tiles with 2-3 taps per barrier,
 // a single-weight-buffer variant at three workgroups per CU, two-wave workgroups at four per CU,
 // weight fragments streamed L1 -> VGPR without LDS, s_setprio around the MFMA clusters.
@@ -1148,14 +1177,14 @@ int launch_cfg(int cfg, const ConvArgs& a, hipStream_t s) {
 // prefer the 8-wave 16x32 patch with five taps per barrier (lower halo + barrier overhead); otherwise
 // two 4-wave workgroups per CU, patch shape by least waste on partial tiles.
 int pick_cfg(const ConvArgs& a, int k) {
-  // generation 2 wherever its whole-tile restriction holds (every 3x3 layer of a 768x384 input down to 1/8)
-  if (k == 3 && a.H % 16 == 0 && a.W % 32 == 0) return 17;
   auto covered = [&](int c) {
     const Geo& g = kGeo[c];
     return (double)((a.H + g.th - 1) / g.th * g.th) * ((a.W + g.tw - 1) / g.tw * g.tw);
   };
-  const double pixels = (double)a.N * a.H * a.W;
-  if (pixels >= 4.0e5 && a.H % 16 == 0 && a.W % 32 == 0) return 16;
+  const double g1 = covered(14) < covered(15) ? covered(14) : covered(15);
+  // generation 2 (16x32 tiles) unless its partial tiles waste more than its ~1.25x per-pixel advantage over the
+  // 16x16 / 8x32 tiles of generation 1 (e.g. the 24x48 conv5 maps of a 768x384 input)
+  if (k == 3 && covered(17) <= 1.25 * g1) return 17;
   return covered(15) < covered(14) ? 15 : 14;
 }
 

@@ -63,10 +63,10 @@ def test_conv_filter_and_bias_gradient_exact_on_integers(ops, n, h, w, cin, cout
     assert np.array_equal(dw2.cpu().numpy(), ref + 1)
 
 
-@pytest.mark.parametrize('k,h,w', [(3, 24, 40), (1, 24, 40), (3, 32, 64)])
+@pytest.mark.parametrize('k,h,w', [(3, 24, 40), (1, 24, 40), (3, 32, 64), (3, 40, 72)])
 def test_conv_data_gradient_with_relu_mask_and_addend(ops, k, h, w):
-    """24x40: partial tiles (generation-1 kernel); 32x64: whole tiles, i.e. the all-DMA generation-2 kernel with
-    its split-phase epilogue."""
+    """24x40: generation-1 kernel; 32x64: whole tiles of the all-DMA generation-2 kernel with its split-phase
+    epilogue; 40x72: its partial tiles (clamped offsets, predicated addend / mask loads and stores)."""
     rng = np.random.default_rng(k + h)
     n, cin, cout = 2, 128, 64
     wt = rng.integers(-1, 2, (k, k, cin, cout)).astype(np.float32)
