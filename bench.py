@@ -285,7 +285,8 @@ def main():
         images = args.batch * world * args.steps
         flops_img = conv_flops_per_image(args.height, args.width, 3) + conv_flops_per_image(args.height, args.width, 1)
         res = {
-            'metric': 'images/sec at 768x384 RGB-D FCN (two SimpleFCN experts + %s fusion + argmax, inference)' % args.fusion,
+            'metric': 'images/sec at %dx%d RGB-D FCN (two SimpleFCN experts + %s fusion + argmax, inference)' % (
+                args.width, args.height, args.fusion),
             'value': round(images / dt, 2), 'unit': 'images/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
