@@ -88,6 +88,15 @@ int xv_maxpool2x2_fwd(const xv_act* x, const xv_act* y, void* stream);
  * collapses to.  residual may be NULL.                                                           */
 int xv_upsample2x_relu_add(const xv_act* x, const xv_act* residual, const xv_act* y, void* stream);
 
+/* The same with an inference batch norm between the deconv and its relu (deconv2d(..., batch_normalization=True),
+ * custom_layers.py:112-119): y = relu(bilinear_x2(x) * scale[c] + shift[c]) [+ residual]; scale / shift float32 [C]
+ * (gamma / sqrt(moving_variance + 1e-3), beta - moving_mean * scale), both NULL = no batch norm.                   */
+int xv_upsample2x_affine_relu_add(const xv_act* x, const float* scale, const float* shift, const xv_act* residual,
+                                  const xv_act* y, void* stream);
+
+/* y = concat(a, b) along channels (tf.concat(axis=3) of the two trunks' conv4_3 / conv5_3, fusion_fcn.py:27-28). */
+int xv_concat_channels(const xv_act* a, const xv_act* b, const xv_act* y, void* stream);
+
 /* Decoder head: upscore = relu(bilinear_x8(fused)) (deconv2d k=16 s=8, simple_fcn.py:129-130),
  * score = conv1x1(upscore, Ws) + bs (no activation, simple_fcn.py:131-133), prob = softmax(score),
  * label = argmax(prob, 3) (basic_fusion_model.py:21-22 / simple_fcn.py:223-224), fp32 from the bf16 `fused`
@@ -102,6 +111,14 @@ size_t xv_decoder_head_workspace_bytes(int n, int h, int w, int num_classes);
 int xv_decoder_head_fwd(const xv_act* fused, const float* w_score, const float* b_score, int num_classes,
                         float* score, float* prob, int64_t* label, void* workspace, size_t workspace_bytes,
                         void* stream);
+
+/* General decoder head for a batch norm with a non-zero shift between the x8 deconv and its relu (the default of
+ * decoder() as called by fusion_fcn.py:38; custom_layers.py:112-119): upscore = relu(bilinear_x8(fused) * scale[u] +
+ * shift[u]), then score / softmax / argmax as above.  The 1x1 conv no longer commutes with the interpolation, so
+ * all U features are interpolated per pixel (16x the FMAs of xv_decoder_head_fwd; no workspace).                 */
+int xv_decoder_head_affine_fwd(const xv_act* fused, const float* scale, const float* shift, const float* w_score,
+                               const float* b_score, int num_classes, float* score, float* prob, int64_t* label,
+                               void* stream);
 
 /* prob = softmax(score), label = argmax(prob) on a dense float32 [npix][C] score tensor
  * (tf.nn.softmax + tf.argmax, basic_fusion_model.py:21-22); lowest index wins ties.  prob / label

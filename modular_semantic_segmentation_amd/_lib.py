@@ -37,8 +37,11 @@ SIGNATURES = {
     'xv_conv2d_first_fwd': (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _actp, _i, _vp]),
     'xv_maxpool2x2_fwd': (_i, [_actp, _actp, _vp]),
     'xv_upsample2x_relu_add': (_i, [_actp, _actp, _actp, _vp]),
+    'xv_upsample2x_affine_relu_add': (_i, [_actp, _vp, _vp, _actp, _actp, _vp]),
+    'xv_concat_channels': (_i, [_actp, _actp, _actp, _vp]),
     'xv_decoder_head_workspace_bytes': (ctypes.c_size_t, [_i, _i, _i, _i]),
     'xv_decoder_head_fwd': (_i, [_actp, _vp, _vp, _i, _vp, _vp, _vp, _vp, ctypes.c_size_t, _vp]),
+    'xv_decoder_head_affine_fwd': (_i, [_actp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
     'xv_softmax_argmax': (_i, [_vp, _i64, _i, _vp, _vp, _vp]),
     'xv_bayes_fuse': (_i, [_vpp, _i, _vp, _vp, _i, _i64, _vp, _vp, _vp]),
     'xv_bayes_fuse_lut': (_i, [_vp, _vp, _vp, _i, _i64, _vp, _vp]),

@@ -150,7 +150,9 @@ __device__ inline void bilinear_taps(int o, int& i1, float& w_i1, float& w_i0) {
 }
 
 // ---- upscore_conv5 + add_score: y = residual + relu(bilinear_x2(x)) (simple_fcn.py:82-85) ------
+// scale / shift (may be null): inference batch norm between the deconv and its relu (custom_layers.py:112-119)
 __global__ __launch_bounds__(256) void upsample2x_kernel(const __bf16* __restrict__ x, const __bf16* __restrict__ res,
+                                                        const float* __restrict__ scale, const float* __restrict__ shift,
                                                         __bf16* __restrict__ y, int N, int Hi, int Wi, int C) {
   const int c8 = C >> 3;
   const int Ho = Hi * 2, Wo = Wi * 2;
@@ -185,6 +187,7 @@ __global__ __launch_bounds__(256) void upsample2x_kernel(const __bf16* __restric
         const float f00 = bf16_bits_to_f32((a00[i] >> sh) & 0xffffu), f01 = bf16_bits_to_f32((a01[i] >> sh) & 0xffffu);
         const float f10 = bf16_bits_to_f32((a10[i] >> sh) & 0xffffu), f11 = bf16_bits_to_f32((a11[i] >> sh) & 0xffffu);
         float u = f00 * w00 + f01 * w01 + f10 * w10 + f11 * w11;
+        if (scale) u = u * scale[cg * 8 + i * 2 + h] + shift[cg * 8 + i * 2 + h];
         u = fmaxf(u, 0.f);
         v[h] = u + bf16_bits_to_f32((rv[i] >> sh) & 0xffffu);
       }
@@ -352,6 +355,146 @@ __global__ __launch_bounds__(256) void softmax_argmax_kernel(const float* __rest
   }
 }
 
+// ---- general decoder head: bilinear x8 -> per-channel affine (inference batch norm) -> relu -> 1x1 score ->
+// softmax -> argmax, un-commuted.  The default head (score_lowres + decoder_head_kernel) moves the 1x1 conv in
+// front of the interpolation, which is only valid while relu(up8(f)) == up8(f); a batch norm with a non-zero shift
+// between the deconv and its relu (custom_layers.py:112-119, the default of decoder() when fusion_fcn.py:38
+// calls it) breaks that, and this kernel interpolates all U features per pixel instead (16x the FMAs).
+// One thread = 4 horizontally consecutive output pixels sharing the same 2x2 source pixels.
+template <int CM, bool CLAMP>
+__device__ inline void head_affine_group(const u32x4& a00, const u32x4& a01, const u32x4& a10, const u32x4& a11, float wy0,
+                                  float wy1, const float (&wx0)[4], const float (&wx1)[4],
+                                  const float* __restrict__ wrow, const float* __restrict__ srow,
+                                  const float* __restrict__ trow, int C, int remain, float (&sc)[4][CM]) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int sh = (i & 1) * 16, q = i >> 1;
+    const float f00 = bf16_bits_to_f32((a00[q] >> sh) & 0xffffu), f01 = bf16_bits_to_f32((a01[q] >> sh) & 0xffffu);
+    const float f10 = bf16_bits_to_f32((a10[q] >> sh) & 0xffffu), f11 = bf16_bits_to_f32((a11[q] >> sh) & 0xffffu);
+    const float v0 = f00 * wy0 + f10 * wy1;  // source column ix0
+    const float v1 = f01 * wy0 + f11 * wy1;  // source column ix1
+    float up[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) up[j] = fmaxf((v0 * wx0[j] + v1 * wx1[j]) * srow[i] + trow[i], 0.f);
+    if (CLAMP && i * C + CM > remain) {  // wave-uniform
+#pragma unroll
+      for (int k = 0; k < CM; ++k) {
+        int off = i * C + k;
+        off = off < remain ? off : remain - 1;
+        const float wv = wrow[off];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) sc[j][k] = fmaf(up[j], wv, sc[j][k]);
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < CM; ++k) {
+        const float wv = wrow[i * C + k];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) sc[j][k] = fmaf(up[j], wv, sc[j][k]);
+      }
+    }
+  }
+}
+
+template <int CM>
+__global__ __launch_bounds__(256) void decoder_head_affine_kernel(const __bf16* __restrict__ f, const float* __restrict__ sc_g,
+                                                                 const float* __restrict__ sh_g, const float* __restrict__ ws_g,
+                                                          const float* __restrict__ bs_g, int N, int Hi, int Wi, int U,
+                                                          int C, float* __restrict__ score, float* __restrict__ prob,
+                                                          int64_t* __restrict__ label) {
+  const int Ho = Hi * 8, Wo = Wi * 8;
+  // block = 128 x 8 output pixels: a wave covers 2 rows x 128 columns
+  const int tilesx = (Wo + 127) / 128;
+  const int tx = blockIdx.x % tilesx;
+  int r = blockIdx.x / tilesx;
+  const int tilesy = Hi;  // Ho / 8
+  const int ty = r % tilesy;
+  const int n = r / tilesy;
+  const int ox = tx * 128 + (threadIdx.x & 31) * 4, oy = ty * 8 + (threadIdx.x >> 5);
+  if (ox >= Wo) return;
+  int iy1, ix1;
+  float wy1, wy0, wx1[4], wx0[4];
+  bilinear_taps<8>(oy, iy1, wy1, wy0);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) bilinear_taps<8>(ox + j, ix1, wx1[j], wx0[j]);  // same ix1 for the 4 aligned pixels
+  const __bf16* p00 = f + (((int64_t)n * (Hi + 2) + iy1) * (Wi + 2) + ix1) * U;
+  const int64_t rowp = (int64_t)(Wi + 2) * U;
+  float sc[4][CM];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int k = 0; k < CM; ++k) sc[j][k] = 0.f;
+  // software pipeline: the four 16-byte source loads of channel group g+1 are in flight while group g is
+  // multiplied (few waves per SIMD fit beside 4*CM accumulators, so the loop must hide its own L2 latency)
+  u32x4 n00 = *reinterpret_cast<const u32x4*>(p00), n01 = *reinterpret_cast<const u32x4*>(p00 + U);
+  u32x4 n10 = *reinterpret_cast<const u32x4*>(p00 + rowp), n11 = *reinterpret_cast<const u32x4*>(p00 + rowp + U);
+  for (int u0 = 0; u0 < U; u0 += 8) {
+    const u32x4 a00 = n00, a01 = n01, a10 = n10, a11 = n11;
+    const int un = u0 + 8 < U ? u0 + 8 : u0;
+    n00 = *reinterpret_cast<const u32x4*>(p00 + un);
+    n01 = *reinterpret_cast<const u32x4*>(p00 + U + un);
+    n10 = *reinterpret_cast<const u32x4*>(p00 + rowp + un);
+    n11 = *reinterpret_cast<const u32x4*>(p00 + rowp + U + un);
+    const float* wrow = ws_g + u0 * C;
+    if (u0 + 16 <= U)
+      head_affine_group<CM, false>(a00, a01, a10, a11, wy0, wy1, wx0, wx1, wrow, sc_g + u0, sh_g + u0, C, 0, sc);
+    else
+      head_affine_group<CM, true>(a00, a01, a10, a11, wy0, wy1, wx0, wx1, wrow, sc_g + u0, sh_g + u0, C, (U - u0) * C, sc);
+  }
+  const int64_t opix = ((int64_t)n * Ho + oy) * Wo + ox;
+  int64_t lab[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+#pragma unroll
+    for (int k = 0; k < CM; ++k) sc[j][k] += bs_g[k < C ? k : C - 1];
+    if (score) {
+#pragma unroll
+      for (int k = 0; k < CM; ++k)
+        if (k < C) score[(opix + j) * C + k] = sc[j][k];
+    }
+    float m = sc[j][0];
+#pragma unroll
+    for (int k = 1; k < CM; ++k)
+      if (k < C) m = fmaxf(m, sc[j][k]);
+    float sum = 0.f;
+#pragma unroll
+    for (int k = 0; k < CM; ++k) {
+      sc[j][k] = k < C ? expf(sc[j][k] - m) : 0.f;
+      sum += sc[j][k];
+    }
+    float best = -1.f;
+    int bi = 0;
+#pragma unroll
+    for (int k = 0; k < CM; ++k) {
+      const float p = sc[j][k] / sum;
+      if (k < C) {
+        if (prob) prob[(opix + j) * C + k] = p;
+        if (p > best) {
+          best = p;
+          bi = k;
+        }
+      }
+    }
+    lab[j] = bi;
+  }
+  if (label) {
+    typedef __attribute__((ext_vector_type(2))) int64_t i64x2;
+    *reinterpret_cast<i64x2*>(label + opix) = i64x2{lab[0], lab[1]};
+    *reinterpret_cast<i64x2*>(label + opix + 2) = i64x2{lab[2], lab[3]};
+  }
+}
+
+
+__global__ __launch_bounds__(256) void concat_kernel(const u32x4* __restrict__ a, const u32x4* __restrict__ b,
+                                                    u32x4* __restrict__ y, int64_t pixels, int ca8, int cb8) {
+  const int cy8 = ca8 + cb8;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < pixels * cy8; idx += (int64_t)gridDim.x * 256) {
+    const int64_t p = idx / cy8;
+    const int c = (int)(idx - p * cy8);
+    y[idx] = c < ca8 ? a[p * ca8 + c] : b[p * cb8 + (c - ca8)];
+  }
+}
+
 inline int grid_for(int64_t total, int per_block = 256, int cap = 8192) {
   int64_t g = (total + per_block - 1) / per_block;
   return (int)(g < 1 ? 1 : (g > cap ? cap : g));
@@ -388,8 +531,10 @@ extern "C" int xv_maxpool2x2_fwd(const xv_act* x, const xv_act* y, void* stream)
   return xv_launch_status();
 }
 
-extern "C" int xv_upsample2x_relu_add(const xv_act* x, const xv_act* residual, const xv_act* y, void* stream) {
+extern "C" int xv_upsample2x_affine_relu_add(const xv_act* x, const float* scale, const float* shift,
+                                            const xv_act* residual, const xv_act* y, void* stream) {
   XV_CHECK_ARG(x && y && x->data && y->data);
+  XV_CHECK_ARG((scale == nullptr) == (shift == nullptr));
   XV_CHECK_SHAPE(x->n > 0 && x->h > 0 && x->w > 0 && x->c > 0 && (x->c & 7) == 0);
   XV_CHECK_SHAPE(y->n == x->n && y->h == 2 * x->h && y->w == 2 * x->w && y->c == x->c);
   const __bf16* res = nullptr;
@@ -399,7 +544,23 @@ extern "C" int xv_upsample2x_relu_add(const xv_act* x, const xv_act* residual, c
   }
   const int64_t total = (int64_t)y->n * y->h * y->w * (y->c >> 3);
   hipLaunchKernelGGL(upsample2x_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
-                     (const __bf16*)x->data, res, (__bf16*)y->data, x->n, x->h, x->w, x->c);
+                     (const __bf16*)x->data, res, scale, shift, (__bf16*)y->data, x->n, x->h, x->w, x->c);
+  return xv_launch_status();
+}
+
+extern "C" int xv_upsample2x_relu_add(const xv_act* x, const xv_act* residual, const xv_act* y, void* stream) {
+  return xv_upsample2x_affine_relu_add(x, nullptr, nullptr, residual, y, stream);
+}
+
+// y[..., :Ca] = a, y[..., Ca:] = b over the whole padded buffers (tf.concat(axis=3), fusion_fcn.py:27-28)
+extern "C" int xv_concat_channels(const xv_act* a, const xv_act* b, const xv_act* y, void* stream) {
+  XV_CHECK_ARG(a && b && y && a->data && b->data && y->data);
+  XV_CHECK_SHAPE(a->n == b->n && a->h == b->h && a->w == b->w && y->n == a->n && y->h == a->h && y->w == a->w);
+  XV_CHECK_SHAPE(y->c == a->c + b->c && (a->c & 7) == 0 && (b->c & 7) == 0);
+  const int64_t total = (int64_t)y->n * (y->h + 2) * (y->w + 2) * (y->c >> 3);
+  hipLaunchKernelGGL(concat_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const u32x4*)a->data,
+                     (const u32x4*)b->data, (u32x4*)y->data, (int64_t)y->n * (y->h + 2) * (y->w + 2), a->c >> 3,
+                     b->c >> 3);
   return xv_launch_status();
 }
 
@@ -427,6 +588,33 @@ extern "C" int xv_score_lowres(const xv_act* fused, const float* w_score, int nu
     default: XV_SL(32); break;
   }
 #undef XV_SL
+  return xv_launch_status();
+}
+
+extern "C" int xv_decoder_head_affine_fwd(const xv_act* fused, const float* scale, const float* shift,
+                                         const float* w_score, const float* b_score, int num_classes, float* score,
+                                         float* prob, int64_t* label, void* stream) {
+  XV_CHECK_ARG(fused && fused->data && scale && shift && w_score && b_score && (score || prob || label));
+  XV_CHECK_SHAPE(fused->c > 0 && (fused->c & 7) == 0 && num_classes >= 1 && num_classes <= 32);
+  const int Wo = fused->w * 8;
+  const int64_t nblk = (int64_t)((Wo + 127) / 128) * fused->h * fused->n;
+  XV_CHECK_SHAPE(nblk <= 0x7fffffff);
+  hipStream_t s = (hipStream_t)stream;
+  const __bf16* f = (const __bf16*)fused->data;
+#define XV_HA(CMV)                                                                                                  \
+  hipLaunchKernelGGL(decoder_head_affine_kernel<CMV>, dim3((unsigned)nblk), dim3(256), 0, s, f, scale, shift, w_score, \
+                     b_score, fused->n, fused->h, fused->w, fused->c, num_classes, score, prob, label)
+  switch ((num_classes + 3) / 4) {
+    case 1: XV_HA(4); break;
+    case 2: XV_HA(8); break;
+    case 3: XV_HA(12); break;
+    case 4: XV_HA(16); break;
+    case 5: XV_HA(20); break;
+    case 6: XV_HA(24); break;
+    case 7: XV_HA(28); break;
+    default: XV_HA(32); break;
+  }
+#undef XV_HA
   return xv_launch_status();
 }
 

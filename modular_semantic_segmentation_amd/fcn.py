@@ -103,18 +103,20 @@ class FcnEngine(object):
                     'transposed-conv fallback is not built' % (p, name))
         # Batch norm after a deconv (custom_layers.py:112-119) is a per-channel affine before its relu.  A
         # positive scale with zero shift commutes with the relu and the (linear) deconv and is folded into
-        # the 1x1 conv on the other side; a non-zero shift would need the un-commuted decoder head.
-        deconv_scale = {}
+        # the 1x1 conv on the other side; anything else goes through the affine forms of the x2 kernel and of the
+        # decoder head (the un-commuted one: 16x the FMAs of the default head).
+        deconv_scale, self.affine = {}, {}
         for name in ('upscore_conv5', 'upscore'):
             layer = '%s/%s' % (p, name)
             if layer + '/gamma' in v:
                 s = v[layer + '/gamma'] / np.sqrt(v[layer + '/moving_variance'] + BN_EPS)
                 t = v[layer + '/beta'] - v[layer + '/moving_mean'] * s
-                if np.any(s <= 0) or np.any(np.abs(t) > 1e-12):
-                    raise NotImplementedError(
-                        '%s has a batch norm with a non-zero shift or non-positive scale; only scale-only batch '
-                        'norm after the bilinear deconvs is supported on this path' % layer)
-                deconv_scale[name] = s.astype(np.float32)
+                if np.all(s > 0) and np.all(np.abs(t) <= 1e-12):
+                    deconv_scale[name] = s.astype(np.float32)
+                else:
+                    sp, tp = np.ones(self.Up, np.float32), np.zeros(self.Up, np.float32)
+                    sp[:self.U], tp[:self.U] = s, t                  # padding channels: relu(0 * 1 + 0) = 0
+                    self.affine[name] = (torch.from_numpy(sp).to(dev), torch.from_numpy(tp).to(dev))
         self.w, self.b = {}, {}
 
         def up(a):
@@ -187,7 +189,8 @@ class FcnEngine(object):
         s5 = self._act('score_conv5', n, h // 16, w // 16, self.Up)
         ops.conv2d_fwd(L['conv5_3'], self.w['score_conv5'], self.b['score_conv5'], 1, relu=True, y=s5)
         fused = self._act('fused', n, h // 8, w // 8, self.Up)
-        ops.upsample2x_relu_add(s5, residual=s4, y=fused)
+        aff = self.affine.get('upscore_conv5', (None, None))
+        ops.upsample2x_relu_add(s5, residual=s4, y=fused, scale=aff[0], shift=aff[1])
         L.update(score_conv4=s4, score_conv5=s5, fused=fused)
         return L
 
@@ -202,9 +205,11 @@ class FcnEngine(object):
             ws = torch.empty(ops._lib.lib().xv_decoder_head_workspace_bytes(f.n, f.h, f.w, self.C) // 4,
                              dtype=torch.float32, device=self.device)
             self._arena[key] = ws
+        aff = self.affine.get('upscore', (None, None))
         out = ops.decoder_head_fwd(f, self.w['score'], self.b['score'], self.C,
                                    want_score='score' in want, want_prob='prob' in want,
-                                   want_label=('label' in want or 'classification' in want), workspace=ws)
+                                   want_label=('label' in want or 'classification' in want), workspace=ws,
+                                   scale=aff[0], shift=aff[1])
         if 'label' in out:
             out['classification'] = out['label']
         out['layers'] = L

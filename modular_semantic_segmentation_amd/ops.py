@@ -113,11 +113,23 @@ def maxpool2x2_fwd(x, y=None):
     return y
 
 
-def upsample2x_relu_add(x, residual=None, y=None):
+def upsample2x_relu_add(x, residual=None, y=None, scale=None, shift=None):
+    """y = relu(bilinear_x2(x) [* scale + shift]) [+ residual]; scale / shift: float32 [C] inference batch norm."""
     if y is None:
         y = Act(x.n, 2 * x.h, 2 * x.w, x.c, x.t.device)
-    rc = _lib.lib().xv_upsample2x_relu_add(x.xv(), residual.xv() if residual is not None else _NULL_ACT, y.xv(), _stream())
-    _lib.check(rc, 'xv_upsample2x_relu_add')
+    if scale is not None:
+        _need(scale, torch.float32, 'scale')
+        _need(shift, torch.float32, 'shift')
+    rc = _lib.lib().xv_upsample2x_affine_relu_add(x.xv(), _ptr(scale), _ptr(shift),
+                                                 residual.xv() if residual is not None else _NULL_ACT, y.xv(), _stream())
+    _lib.check(rc, 'xv_upsample2x_affine_relu_add')
+    return y
+
+
+def concat_channels(a, b, y=None):
+    if y is None:
+        y = Act(a.n, a.h, a.w, a.c + b.c, a.t.device)
+    _lib.check(_lib.lib().xv_concat_channels(a.xv(), b.xv(), y.xv(), _stream()), 'xv_concat_channels')
     return y
 
 
@@ -135,8 +147,9 @@ def _head_workspace(fused, num_classes):
 
 
 def decoder_head_fwd(fused, w_score, b_score, num_classes, want_score=False, want_prob=False, want_label=True,
-                     out=None, workspace=None):
-    """Returns dict with the requested dense outputs (score/prob float32 NHWC, label int64 NHW)."""
+                     out=None, workspace=None, scale=None, shift=None):
+    """Returns dict with the requested dense outputs (score/prob float32 NHWC, label int64 NHW).
+    scale / shift (float32 [U]): batch norm between the x8 deconv and its relu -> the general (un-commuted) head."""
     _need(w_score, torch.float32, 'w_score')
     _need(b_score, torch.float32, 'b_score')
     dev = fused.t.device
@@ -148,6 +161,15 @@ def decoder_head_fwd(fused, w_score, b_score, num_classes, want_score=False, wan
         out['prob'] = torch.empty((n, ho, wo, num_classes), dtype=torch.float32, device=dev)
     if want_label and 'label' not in out:
         out['label'] = torch.empty((n, ho, wo), dtype=torch.int64, device=dev)
+    if scale is not None:
+        _need(scale, torch.float32, 'scale')
+        _need(shift, torch.float32, 'shift')
+        rc = _lib.lib().xv_decoder_head_affine_fwd(fused.xv(), _ptr(scale), _ptr(shift), _ptr(w_score), _ptr(b_score),
+                                                  num_classes, _ptr(out.get('score') if want_score else None),
+                                                  _ptr(out.get('prob') if want_prob else None),
+                                                  _ptr(out.get('label') if want_label else None), _stream())
+        _lib.check(rc, 'xv_decoder_head_affine_fwd')
+        return out
     ws = workspace if workspace is not None else _head_workspace(fused, num_classes)
     rc = _lib.lib().xv_decoder_head_fwd(fused.xv(), _ptr(w_score), _ptr(b_score), num_classes,
                                        _ptr(out.get('score') if want_score else None),

@@ -208,9 +208,12 @@ def test_hip_graph_replay_matches_eager(gpu, tmp_path, golden_dir):
     assert np.array_equal(net.predict({k: v[:1] for k, v in a.items()}), eager_a[:1])
 
 
-def test_simple_fcn_with_batch_normalization_inference(gpu, tmp_path):
+@pytest.mark.parametrize('deconv_shift', [False, True])
+def test_simple_fcn_with_batch_normalization_inference(gpu, tmp_path, deconv_shift):
     """batch_normalization=True: moving statistics are folded into (W, b) at load time; parity against the
-    oracle's conv -> BN -> relu (custom_layers.py:126-137)."""
+    oracle's conv -> BN -> relu (custom_layers.py:126-137).  deconv_shift: the batch norms after the two bilinear
+    deconvs also carry a shift (and one negative scale), which takes the affine x2 kernel and the general,
+    un-commuted decoder head instead of the folded forms."""
     from modular_semantic_segmentation_amd import get_model
     w, _ = _weights(tmp_path, 'rgb', 3, 1, 0.02)
     rng = np.random.default_rng(5)
@@ -221,10 +224,13 @@ def test_simple_fcn_with_batch_normalization_inference(gpu, tmp_path):
             c = w[key].shape[2] if deconv else w[key].shape[3]
             w[layer + '/gamma'] = rng.uniform(0.7, 1.3, c).astype(np.float32)
             w[layer + '/moving_variance'] = rng.uniform(0.6, 1.4, c).astype(np.float32)
-            # the bilinear deconvs take a scale-only batch norm on this path (see fcn.FcnEngine.load)
-            w[layer + '/beta'] = np.zeros(c, np.float32) if deconv else (0.05 * rng.standard_normal(c)).astype(np.float32)
-            w[layer + '/moving_mean'] = np.zeros(c, np.float32) if deconv else \
+            # a scale-only batch norm after a bilinear deconv is folded into the neighbouring 1x1 conv
+            plain = deconv and not deconv_shift
+            w[layer + '/beta'] = np.zeros(c, np.float32) if plain else (0.05 * rng.standard_normal(c)).astype(np.float32)
+            w[layer + '/moving_mean'] = np.zeros(c, np.float32) if plain else \
                 (0.05 * rng.standard_normal(c)).astype(np.float32)
+            if deconv and deconv_shift:
+                w[layer + '/gamma'][3] *= -1.0
     path = os.path.join(str(tmp_path), 'bn.npz')
     np.savez(path, **w)
     data = _data(1, seed=21)
