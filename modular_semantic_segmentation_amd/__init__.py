@@ -9,8 +9,11 @@ def get_model(name):
     from .bayes_mix import BayesFusion
     from .dirichlet_mix import DirichletFusion
     from .average_mix import AverageFusion
+    from .fusion_fcn import FusionFCN
     if name == 'fcn':
         return SimpleFCN
+    elif name == 'fusion_fcn':
+        return FusionFCN
     elif name in ['bayes_mix', 'bayes_fusion']:
         return BayesFusion
     elif name in ['dirichlet_mix', 'dirichlet_fusion']:

@@ -339,3 +339,90 @@ def fcn_loss_and_grads(x_nhwc, labels, weights, prefix, num_classes, policy='fp3
     loss = -(onehot * logp).sum() / (1e-20 + onehot.sum())          # utils.py:43-53
     loss.backward()
     return float(loss.detach()), {k: v.grad.numpy() for k, v in params.items()}
+
+
+# ---- fusion_fcn: the joint two-stream baseline (xview/models/fusion_fcn.py:11-40, vgg16.py:7-51) --------------
+def init_fusion_fcn_weights(prefixes, num_channels, num_units, num_classes, seed=1, bias_scale=0.0, bn=True):
+    """Random-init weights under the variable names the reference graph creates: trunks `{prefix}_convX_Y`
+    (vgg16.py:18-37), `fused_score_conv4/5`, `fused_upscore_conv5` (fusion_fcn.py:30-36) and the decoder's
+    `fused/upscore`, `fused/score` (simple_fcn.py:121-133), which -- decoder() being called without `batchnorm` --
+    carry batch norm variables (bn=True: random moving statistics)."""
+    rng = np.random.default_rng(seed)
+    w = {}
+    for m, prefix in prefixes.items():
+        cin = num_channels[m]
+        for item in ENCODER_CONVS:
+            if isinstance(item, str):
+                continue
+            name, cout = item
+            w['%s_%s/kernel' % (prefix, name)] = glorot_uniform(rng, (3, 3, cin, cout))
+            w['%s_%s/bias' % (prefix, name)] = (bias_scale * rng.standard_normal(cout)).astype(np.float32)
+            cin = cout
+    e = len(prefixes)
+    for name in ('fused_score_conv4', 'fused_score_conv5'):
+        w[name + '/kernel'] = glorot_uniform(rng, (1, 1, 512 * e, num_units))
+        w[name + '/bias'] = (bias_scale * rng.standard_normal(num_units)).astype(np.float32)
+    w['fused_upscore_conv5/kernel'] = bilinear_kernel(4, num_units)
+    w['fused/upscore/kernel'] = bilinear_kernel(16, num_units)
+    w['fused/score/kernel'] = glorot_uniform(rng, (1, 1, num_units, num_classes))
+    w['fused/score/bias'] = (bias_scale * rng.standard_normal(num_classes)).astype(np.float32)
+    if bn:
+        for layer, c in (('fused/upscore', num_units), ('fused/score', num_classes)):
+            w[layer + '/gamma'] = rng.uniform(0.7, 1.3, c).astype(np.float32)
+            w[layer + '/beta'] = (0.1 * rng.standard_normal(c)).astype(np.float32)
+            w[layer + '/moving_mean'] = (0.1 * rng.standard_normal(c)).astype(np.float32)
+            w[layer + '/moving_variance'] = rng.uniform(0.6, 1.4, c).astype(np.float32)
+    return w
+
+
+def fusion_fcn_forward(inputs, weights, prefixes, policy='fp32', keep=None):
+    """fusion_fcn() at inference (fusion_fcn.py:11-40): one VGG16 trunk per modality (no batch norm), channel
+    concat of the conv4_3 / conv5_3 maps, 1x1 `fused_score_conv4/5` + relu, x2 bilinear deconv + relu, add, then
+    decoder(features, 'fused') WITH its default batch norm: upscore = relu(BN(deconv x8)), score = BN(conv1x1).
+    inputs: {modality: NHWC fp32}.  Returns dict of NHWC fp32 arrays (default keys: features, score)."""
+    assert policy in ('fp32', 'bf16')
+    rnd = (lambda t: t) if policy == 'fp32' else round_bf16
+    keep = set(keep) if keep is not None else {'features', 'score'}
+
+    def bn(layer):
+        g = weights.get(layer + '/gamma')
+        if g is None:
+            return None
+        s = g / np.sqrt(weights[layer + '/moving_variance'] + 1e-3)
+        return s.astype(np.float32), (weights[layer + '/beta'] - weights[layer + '/moving_mean'] * s).astype(np.float32)
+
+    def W(layer, first=False):
+        w = weights[layer + '/kernel']
+        return w if (policy == 'fp32' or first) else round_bf16(w)
+
+    with torch.no_grad():
+        layers = {}
+        c4, c5 = [], []
+        for m, prefix in prefixes.items():
+            h = _t(np.asarray(inputs[m], np.float32)).permute(0, 3, 1, 2).contiguous()
+            for item in ENCODER_CONVS:
+                if isinstance(item, str):
+                    h = maxpool2(h)
+                else:
+                    layer = '%s_%s' % (prefix, item[0])
+                    h = rnd(conv2d_same(h, W(layer, item[0] == 'conv1_1'), weights[layer + '/bias'], relu=True))
+                    if item[0] == 'conv4_3':
+                        c4.append(h)
+            c5.append(h)
+        concat4, concat5 = torch.cat(c4, dim=1), torch.cat(c5, dim=1)          # tf.concat(axis=3) in NHWC
+        s4 = rnd(conv2d_same(concat4, W('fused_score_conv4'), weights['fused_score_conv4/bias'], relu=True))
+        s5 = rnd(conv2d_same(concat5, W('fused_score_conv5'), weights['fused_score_conv5/bias'], relu=True))
+        up5 = deconv_same(s5, weights['fused_upscore_conv5/kernel'], 2, relu=True)
+        features = rnd(s4 + up5)
+        y = deconv_same(features, weights['fused/upscore/kernel'], 8, relu=False)
+        b = bn('fused/upscore')
+        if b is not None:
+            y = y * _t(b[0]).view(1, -1, 1, 1) + _t(b[1]).view(1, -1, 1, 1)
+        upscore = F.relu(y)
+        score = conv2d_same(upscore, weights['fused/score/kernel'], weights['fused/score/bias'], relu=False)
+        b = bn('fused/score')
+        if b is not None:
+            score = score * _t(b[0]).view(1, -1, 1, 1) + _t(b[1]).view(1, -1, 1, 1)
+        layers.update(concat_conv4=concat4, concat_conv5=concat5, score_conv4=s4, score_conv5=s5, upscore_conv5=up5,
+                      features=features, upscore=upscore, score=score)
+        return {k: layers[k].permute(0, 2, 3, 1).contiguous().numpy() for k in keep}

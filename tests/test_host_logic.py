@@ -182,3 +182,17 @@ def test_registry_names():
     assert get_model('average_mix').__name__ == 'AverageFusion'
     with pytest.raises(UserWarning):
         get_model('nope')
+
+
+def test_fusion_fcn_variable_schema():
+    """Variable names of the joint baseline follow the reference graph: trunks '{prefix}_convX_Y' (vgg16.py:18-37),
+    'fused_score_conv4/5', 'fused_upscore_conv5' (fusion_fcn.py:30-36), decoder scope 'fused' with batch norm."""
+    from modular_semantic_segmentation_amd.fusion_fcn import variable_shapes
+    from oracle import fcn_oracle as fo
+    prefixes, nch = {'rgb': 'rgb', 'depth': 'depth'}, {'rgb': 3, 'depth': 1}
+    shapes = variable_shapes(prefixes, nch, 64, 12)
+    assert shapes['rgb_conv1_1/kernel'] == (3, 3, 3, 64) and shapes['depth_conv1_1/kernel'] == (3, 3, 1, 64)
+    assert shapes['fused_score_conv4/kernel'] == (1, 1, 1024, 64)
+    assert shapes['fused/upscore/kernel'] == (16, 16, 64, 64) and shapes['fused/score/gamma'] == (12,)
+    ref = fo.init_fusion_fcn_weights(prefixes, nch, 64, 12)
+    assert {k: tuple(v.shape) for k, v in ref.items()} == shapes

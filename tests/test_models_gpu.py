@@ -266,3 +266,43 @@ def test_odd_sizes_num_units_20_classes_14(gpu, tmp_path):
     assert out['score'].shape == (2, h, w, c)
     _check_logits_and_labels(out['score'].cpu().numpy(), out['label'].cpu().numpy(), ref, 'U=20 C=14 48x80')
     np.testing.assert_allclose(out['prob'].cpu().numpy(), fo.softmax(out['score'].cpu().numpy()), rtol=1e-5, atol=1e-7)
+
+
+@pytest.mark.parametrize('decoder_bn', ['shifted', 'scale_only'])
+def test_fusion_fcn_joint_baseline(gpu, tmp_path, decoder_bn):
+    """fusion_fcn() (fusion_fcn.py:11-40): two VGG16 trunks, channel concat, fused 1x1 score convs, decoder with
+    its default batch norm -- functional entry point and FusionFCN model against the oracle restatement."""
+    from modular_semantic_segmentation_amd import get_model
+    from modular_semantic_segmentation_amd.fusion_fcn import fusion_fcn
+    prefixes, nch = {'rgb': 'rgb', 'depth': 'depth'}, {'rgb': 3, 'depth': 1}
+    w = fo.init_fusion_fcn_weights(prefixes, nch, U, C, seed=3, bias_scale=0.02)
+    w['rgb_conv1_1/kernel'] *= 0.02
+    w['depth_conv1_1/kernel'] *= 2e-4
+    for k in w:
+        if k.endswith('/kernel') and 'upscore' not in k and 'conv1_1' not in k:
+            w[k] *= 1.6
+    if decoder_bn == 'scale_only':
+        w['fused/upscore/beta'][:] = 0
+        w['fused/upscore/moving_mean'][:] = 0
+    data = _data(2, seed=31)
+    ref = fo.fusion_fcn_forward(data, w, prefixes, 'bf16')['score']
+    # functional form, as experiments/timing.py calls it
+    x = {m: torch.from_numpy(data[m]).cuda() for m in prefixes}
+    layers = fusion_fcn(x, prefixes, U, C, variables=w)
+    torch.cuda.synchronize()
+    assert layers['concat_conv4'].c == 1024 and layers['rgb']['conv3_2'].c == 256
+    _check_logits_and_labels(layers['score'].cpu().numpy(), layers['classification'].cpu().numpy(), ref,
+                             'fusion_fcn %s' % decoder_bn)
+    # model class: import the same weights from an npz in the reference's variable-name schema
+    path = os.path.join(str(tmp_path), 'fusion.npz')
+    np.savez(path, **w)
+    with get_model('fusion_fcn')(prefixes, nch, U, C, batchsize=2) as net:
+        assert sorted(net.variables) == sorted(w)
+        net.import_weights(path, warnings=False)
+        label = net.predict(data)
+        score = net.predict(data, output_attr='score')
+        _check_logits_and_labels(score, label, ref, 'FusionFCN %s' % decoder_bn)
+        measures, cm = net.score(data)
+        assert cm.sum() == (data['labels'] >= 0).sum()
+        out = net.export_weights(str(tmp_path))
+        assert np.array_equal(np.load(out)['fused/score/kernel'], w['fused/score/kernel'])
