@@ -4,7 +4,7 @@ fusion + argmax at 768x384 on MI355X (BASELINE.json configs[1]); protocol of the
 experiments/timing.py (inputs resident on the device, wall clock around the whole pipeline).
 
   python bench.py [--gpus N --steps K --warmup W] [--batch B] [--height 384 --width 768]
-                  [--fusion bayes|dirichlet] [--no-cpu-baseline]
+                  [--fusion bayes|dirichlet|joint] [--no-cpu-baseline]
 N > 1 is launched by the driver through torch.distributed.run (one rank per GPU); images are
 independent, so ranks shard the batch with no data-path collective ("weak" scaling) and only the
 timing is reduced (MAX over ranks).  Rank 0 prints ONE JSON line.
@@ -41,6 +41,13 @@ def build_model(args, device):
             {'rgb': (None, None, 3), 'depth': (None, None, 1), 'labels': (None, None)}, C)
     common = dict(data_description=desc, num_units=U, num_channels={'rgb': 3, 'depth': 1}, expert_model='fcn',
                   class_prior='data', batchsize=args.batch, seed=1, device=str(device))
+    if args.fusion == 'joint':
+        # the reference's joint baseline fusion_fcn (experiments/timing.py:24-45): two VGG16 trunks + fused decoder
+        net = get_model('fusion_fcn')({'rgb': 'rgb', 'depth': 'depth'}, {'rgb': 3, 'depth': 1}, U, C,
+                                      batchsize=args.batch, seed=1, device=str(device))
+        net.variables['depth_conv1_1/kernel'] = net.variables['depth_conv1_1/kernel'] / 256.0
+        net._variables_changed()
+        return net
     if args.fusion == 'bayes':
         net = get_model('bayes_fusion')(confusion_matrices={'rgb': g['cm_rgb'], 'depth': g['cm_depth']},
                                         prefixes={'rgb': 'rgb', 'depth': 'depth'}, **common)
@@ -155,7 +162,8 @@ def main():
     ap.add_argument('--batch', type=int, default=16, help='images per GPU per step')
     ap.add_argument('--height', type=int, default=384)
     ap.add_argument('--width', type=int, default=768)
-    ap.add_argument('--fusion', default='bayes', choices=['bayes', 'dirichlet'])
+    ap.add_argument('--fusion', default='bayes', choices=['bayes', 'dirichlet', 'joint'],
+                    help="'joint' = the fusion_fcn baseline model instead of two experts + probabilistic fusion")
     ap.add_argument('--mode', default='infer', choices=['infer', 'train'],
                     help="'infer' (headline): two experts + fusion; 'train': one SimpleFCN training step (fwd+bwd+Adam)")
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -298,7 +306,11 @@ def main():
             'conv_tflops_end_to_end': round(images * flops_img / dt / 1e12, 2),
             'roofline': roofline,
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if args.fusion == 'joint':
+            res['metric'] = 'images/sec at %dx%d, fusion_fcn joint RGB-D baseline (inference)' % (args.width, args.height)
+            res['config']['workload'] = 'fusion_fcn (two VGG16 trunks + fused decoder) RGB+Depth %dx%d, U=%d, C=%d' % (
+                args.width, args.height, U, C)
+        if world == 1 and not args.no_cpu_baseline and args.fusion != 'joint':
             g = np.load(os.path.join(ROOT, 'tests', 'golden', 'notebook_868.npz'))
             res['cpu_baseline'] = cpu_baseline(args, net.variables, {'rgb': g['cm_rgb'], 'depth': g['cm_depth']})
         else:
