@@ -247,6 +247,40 @@ int xv_dirichlet_suffstats(const float* prob, const int32_t* labels, int num_cla
 int xv_confusion_matrix(const int32_t* labels, const int64_t* pred, int num_classes, int64_t npix,
                         int64_t* cm, void* stream);
 
+/* ---- training-mode batch normalisation -----------------------------------------------------------
+ * tf.layers.batch_normalization(training=True) between a conv / deconv and its activation
+ * (custom_layers.py:112-119,124-139): per-channel statistics over (N, H, W), normalisation with the biased batch
+ * variance, [TF1] epsilon 1e-3 and momentum 0.99 (moving variance fed the unbiased estimate), and its gradient.
+ * z: pre-normalisation conv output, y: post-relu output (relu mask of the backward; NULL = no activation).
+ * sums: double [2*C] scratch (zeroed inside).  C in {64, 128, 256, 512, ...}: C/8 must divide 256.              */
+int xv_bn_stats(const xv_act* z, double* sums, void* stream);
+int xv_bn_finalize(const double* sums, int channels, int64_t count, const float* gamma, const float* beta, float eps,
+                   float momentum, float* moving_mean, float* moving_var, float* mean, float* invstd, float* scale,
+                   float* shift, void* stream);
+int xv_bn_apply(const xv_act* z, const float* scale, const float* shift, int relu, const xv_act* y, void* stream);
+/* dz = gamma*invstd*(g - mean(g) - zhat*mean(g*zhat)), g = dy*(y>0); dgamma += sum g*zhat, dbeta += sum g.      */
+int xv_bn_bwd(const xv_act* dy, const xv_act* y, const xv_act* z, const float* mean, const float* invstd,
+              const float* gamma, double* sums, float* dgamma, float* dbeta, const xv_act* dz, void* stream);
+/* The same on a dense float32 [rows][C] tensor, C <= 32 (the batch norm on `score`, simple_fcn.py:131-133).        */
+int xv_bn_dense_stats(const float* z, int64_t rows, int channels, double* sums, void* stream);
+int xv_bn_dense_apply(const float* z, int64_t rows, int channels, const float* scale, const float* shift, float* y,
+                      void* stream);
+int xv_bn_dense_bwd(const float* dy, const float* z, int64_t rows, int channels, const float* mean, const float* invstd,
+                    const float* gamma, double* sums, float* dgamma, float* dbeta, float* dz, void* stream);
+
+/* ---- un-commuted training head (batch norm between the x8 deconv and its relu) ---------------------
+ * y = bilinear_x{2,8}(x) with no activation (deconv2d with the constant kernel, custom_layers.py:8-25,71-110) and its
+ * transpose; score = u . Ws + bs per full-resolution pixel (dense float32 [N*H*W][C]); softmax cross-entropy over the
+ * labelled pixels with the loss normalised by *valid_count (models/utils.py:43-53); gradients of the score conv.   */
+int xv_upsample_raw_fwd(const xv_act* x, int factor, const xv_act* y, void* stream);
+int xv_upsample_raw_bwd(const xv_act* dy, int factor, const xv_act* dx, void* stream);
+int xv_score_dense_fwd(const xv_act* u, const float* w_score, const float* b_score, int num_classes, float* score,
+                       void* stream);
+int xv_softmax_ce_dense(const float* logits, const int32_t* labels, const int64_t* valid_count, int num_classes,
+                        int64_t npix, double* loss, float* dlogits, void* stream);
+int xv_score_dense_bwd(const xv_act* u, const float* dscore, const float* w_score, int num_classes, float* dw_score,
+                       float* db_score, const xv_act* du, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

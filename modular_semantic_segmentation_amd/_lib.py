@@ -62,6 +62,18 @@ SIGNATURES = {
     'xv_score_lowres': (_i, [_actp, _vp, _i, _vp, _vp]),
     'xv_decoder_head_bwd_workspace_bytes': (ctypes.c_size_t, [_i, _i, _i, _i]),
     'xv_decoder_head_bwd': (_i, [_actp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _actp, _vp, ctypes.c_size_t, _vp]),
+    'xv_bn_stats': (_i, [_actp, _vp, _vp]),
+    'xv_bn_finalize': (_i, [_vp, _i, _i64, _vp, _vp, ctypes.c_float, ctypes.c_float, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    'xv_bn_apply': (_i, [_actp, _vp, _vp, _i, _actp, _vp]),
+    'xv_bn_bwd': (_i, [_actp, _actp, _actp, _vp, _vp, _vp, _vp, _vp, _vp, _actp, _vp]),
+    'xv_bn_dense_stats': (_i, [_vp, _i64, _i, _vp, _vp]),
+    'xv_bn_dense_apply': (_i, [_vp, _i64, _i, _vp, _vp, _vp, _vp]),
+    'xv_bn_dense_bwd': (_i, [_vp, _vp, _i64, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    'xv_upsample_raw_fwd': (_i, [_actp, _i, _actp, _vp]),
+    'xv_upsample_raw_bwd': (_i, [_actp, _i, _actp, _vp]),
+    'xv_score_dense_fwd': (_i, [_actp, _vp, _vp, _i, _vp, _vp]),
+    'xv_softmax_ce_dense': (_i, [_vp, _vp, _vp, _i, _i64, _vp, _vp, _vp]),
+    'xv_score_dense_bwd': (_i, [_actp, _vp, _vp, _i, _vp, _vp, _actp, _vp]),
     'xv_adam_step': (_i, [_vp, _vp, _vp, _vp, _i64, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float,
                           ctypes.c_float, _vp]),
     'xv_rmsprop_step': (_i, [_vp, _vp, _vp, _i64, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float, _vp]),

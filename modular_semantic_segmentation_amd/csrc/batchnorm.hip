@@ -1,0 +1,643 @@
+// Training-mode batch normalisation and the un-commuted training head for gfx950.
+//
+// Replaces tf.layers.batch_normalization(training=True) between a conv / deconv and its activation
+// (custom_layers.py:112-119,124-139) and its gradient, as the reference trains SimpleFCN with
+// `batch_normalization: true` (experiments/example_config.yaml).  [TF1] semantics: statistics over (N, H, W) per
+// channel, normalisation with the BIASED batch variance, epsilon 1e-3, moving averages with momentum 0.99 fed the
+// UNBIASED variance (fused kernel), gamma / beta trainable.
+//
+// With a batch norm between the x8 deconv and its relu the decoder head no longer commutes (see
+// decoder_head_affine_kernel), so training materialises the full-resolution U-channel map: raw bilinear up-sampling
+// (forward and transpose), a per-pixel U->C score conv and a dense softmax cross-entropy.  All HBM-bound.
+#include "xv_common.h"
+
+namespace {
+
+__device__ __forceinline__ float bf_lo(uint32_t v) { return __builtin_bit_cast(float, v << 16); }
+__device__ __forceinline__ float bf_hi(uint32_t v) { return __builtin_bit_cast(float, v & 0xffff0000u); }
+
+inline int bn_grid(int64_t total, int cap = 2048) {
+  int64_t g = (total + 255) / 256;
+  return (int)(g < 1 ? 1 : (g > cap ? cap : g));
+}
+
+// ---- per-channel sums over the interior of a padded-NHWC bf16 tensor ----------------------------------------
+// MODE 0: sums[c] = sum z, sums[C + c] = sum z^2                                     (forward statistics)
+// MODE 1: sums[c] = sum g, sums[C + c] = sum g * zhat, g = dy * (y > 0 or 1)        (backward reductions)
+// A thread owns one 8-channel group (the grid stride is a multiple of C/8), accumulates in fp32 over its pixels,
+// the block reduces through LDS and issues one double atomic per channel.
+template <int MODE>
+__global__ __launch_bounds__(256) void bn_reduce_kernel(const __bf16* __restrict__ z, const __bf16* __restrict__ dy,
+                                                       const __bf16* __restrict__ y, const float* __restrict__ mean,
+                                                       const float* __restrict__ invstd, double* __restrict__ sums,
+                                                       int N, int H, int W, int C) {
+  const int c8 = C >> 3;
+  const int64_t total = (int64_t)N * H * W * c8;
+  const int cg = threadIdx.x % c8;  // constant over the loop: 256 and gridDim.x * 256 are multiples of c8
+  float s0[8], s1[8], mu[8], is[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    s0[e] = s1[e] = 0.f;
+    mu[e] = MODE == 1 ? mean[cg * 8 + e] : 0.f;
+    is[e] = MODE == 1 ? invstd[cg * 8 + e] : 0.f;
+  }
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    int64_t r = idx / c8;
+    const int x = (int)(r % W);
+    r /= W;
+    const int yy = (int)(r % H);
+    const int n = (int)(r / H);
+    const int64_t off = (((int64_t)n * (H + 2) + yy + 1) * (W + 2) + x + 1) * C + cg * 8;
+    const u32x4 zv = *reinterpret_cast<const u32x4*>(z + off);
+    if (MODE == 0) {
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        const float a = bf_lo(zv[w]), b = bf_hi(zv[w]);
+        s0[2 * w] += a;
+        s1[2 * w] += a * a;
+        s0[2 * w + 1] += b;
+        s1[2 * w + 1] += b * b;
+      }
+    } else {
+      const u32x4 gv = *reinterpret_cast<const u32x4*>(dy + off);
+      u32x4 yv = u32x4{0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};  // ones: no relu mask
+      if (y) yv = *reinterpret_cast<const u32x4*>(y + off);
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        const float ga = bf_lo(yv[w]) > 0.f ? bf_lo(gv[w]) : 0.f, gb = bf_hi(yv[w]) > 0.f ? bf_hi(gv[w]) : 0.f;
+        s0[2 * w] += ga;
+        s1[2 * w] += ga * (bf_lo(zv[w]) - mu[2 * w]) * is[2 * w];
+        s0[2 * w + 1] += gb;
+        s1[2 * w + 1] += gb * (bf_hi(zv[w]) - mu[2 * w + 1]) * is[2 * w + 1];
+      }
+    }
+  }
+  __shared__ float red[256][17];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    red[threadIdx.x][e] = s0[e];
+    red[threadIdx.x][8 + e] = s1[e];
+  }
+  __syncthreads();
+  // thread t < c8 * 16 sums column (t % 16) of the rows with cg == t / 16
+  for (int t = threadIdx.x; t < c8 * 16; t += 256) {
+    const int g = t >> 4, col = t & 15;
+    float acc = 0.f;
+    for (int row = g; row < 256; row += c8) acc += red[row][col];
+    const int ch = g * 8 + (col & 7);
+    atomicAdd(sums + (col < 8 ? ch : C + ch), (double)acc);
+  }
+}
+
+// mean / biased variance -> invstd, scale = gamma * invstd, shift = beta - mean * scale; moving statistics
+__global__ void bn_finalize_kernel(const double* __restrict__ sums, int C, double M, const float* __restrict__ gamma,
+                                   const float* __restrict__ beta, float eps, float momentum,
+                                   float* __restrict__ moving_mean, float* __restrict__ moving_var,
+                                   float* __restrict__ mean, float* __restrict__ invstd, float* __restrict__ scale,
+                                   float* __restrict__ shift) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const double mu = sums[c] / M;
+  double var = sums[C + c] / M - mu * mu;
+  var = var > 0.0 ? var : 0.0;
+  const float is = (float)(1.0 / sqrt(var + (double)eps));
+  mean[c] = (float)mu;
+  invstd[c] = is;
+  scale[c] = gamma[c] * is;
+  shift[c] = beta[c] - (float)mu * gamma[c] * is;
+  if (moving_mean) {
+    const double unbiased = M > 1.0 ? var * M / (M - 1.0) : var;
+    moving_mean[c] = moving_mean[c] * momentum + (float)mu * (1.f - momentum);
+    moving_var[c] = moving_var[c] * momentum + (float)unbiased * (1.f - momentum);
+  }
+}
+
+// y = [relu](z * scale + shift) over the interior
+__global__ __launch_bounds__(256) void bn_apply_kernel(const __bf16* __restrict__ z, const float* __restrict__ scale,
+                                                      const float* __restrict__ shift, int relu,
+                                                      __bf16* __restrict__ y, int N, int H, int W, int C) {
+  const int c8 = C >> 3;
+  const int64_t total = (int64_t)N * H * W * c8;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    const int cg = (int)(idx % c8);
+    int64_t r = idx / c8;
+    const int x = (int)(r % W);
+    r /= W;
+    const int yy = (int)(r % H);
+    const int n = (int)(r / H);
+    const int64_t off = (((int64_t)n * (H + 2) + yy + 1) * (W + 2) + x + 1) * C + cg * 8;
+    const u32x4 zv = *reinterpret_cast<const u32x4*>(z + off);
+    u32x4 o;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      float a = bf_lo(zv[w]) * scale[cg * 8 + 2 * w] + shift[cg * 8 + 2 * w];
+      float b = bf_hi(zv[w]) * scale[cg * 8 + 2 * w + 1] + shift[cg * 8 + 2 * w + 1];
+      if (relu) {
+        a = a > 0.f ? a : 0.f;
+        b = b > 0.f ? b : 0.f;
+      }
+      o[w] = pack_bf16x2(a, b);
+    }
+    *reinterpret_cast<u32x4*>(y + off) = o;
+  }
+}
+
+// dz = scale * (g - dbeta / M - zhat * dgamma / M), g = dy * (y > 0 or 1)
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const __bf16* __restrict__ dy, const __bf16* __restrict__ y,
+                                                          const __bf16* __restrict__ z, const float* __restrict__ mean,
+                                                          const float* __restrict__ invstd,
+                                                          const float* __restrict__ gamma,
+                                                          const double* __restrict__ sums, double M,
+                                                          __bf16* __restrict__ dz, int N, int H, int W, int C) {
+  const int c8 = C >> 3;
+  const int64_t total = (int64_t)N * H * W * c8;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    const int cg = (int)(idx % c8);
+    int64_t r = idx / c8;
+    const int x = (int)(r % W);
+    r /= W;
+    const int yy = (int)(r % H);
+    const int n = (int)(r / H);
+    const int64_t off = (((int64_t)n * (H + 2) + yy + 1) * (W + 2) + x + 1) * C + cg * 8;
+    const u32x4 zv = *reinterpret_cast<const u32x4*>(z + off);
+    const u32x4 gv = *reinterpret_cast<const u32x4*>(dy + off);
+    u32x4 yv = u32x4{0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
+    if (y) yv = *reinterpret_cast<const u32x4*>(y + off);
+    u32x4 o;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      float v[2];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int c = cg * 8 + 2 * w + h;
+        const float yy_ = h ? bf_hi(yv[w]) : bf_lo(yv[w]);
+        const float g = yy_ > 0.f ? (h ? bf_hi(gv[w]) : bf_lo(gv[w])) : 0.f;
+        const float zh = ((h ? bf_hi(zv[w]) : bf_lo(zv[w])) - mean[c]) * invstd[c];
+        const float db = (float)(sums[c] / M), dg = (float)(sums[C + c] / M);
+        v[h] = gamma[c] * invstd[c] * (g - db - zh * dg);
+      }
+      o[w] = pack_bf16x2(v[0], v[1]);
+    }
+    *reinterpret_cast<u32x4*>(dz + off) = o;
+  }
+}
+
+// dgamma[c] += sums[C + c], dbeta[c] += sums[c]
+__global__ void bn_grads_kernel(const double* __restrict__ sums, int C, float* __restrict__ dgamma,
+                                float* __restrict__ dbeta) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  dbeta[c] += (float)sums[c];
+  dgamma[c] += (float)sums[C + c];
+}
+
+// ---- dense float32 [M][C] forms (the batch norm on `score`, C <= 32) ------------------------------------------
+template <int MODE>
+__global__ __launch_bounds__(256) void bn_dense_reduce_kernel(const float* __restrict__ z, const float* __restrict__ dy,
+                                                             const float* __restrict__ mean,
+                                                             const float* __restrict__ invstd,
+                                                             double* __restrict__ sums, int64_t M, int C) {
+  __shared__ float red[64];
+  if (threadIdx.x < 64) red[threadIdx.x] = 0.f;
+  __syncthreads();
+  float s0[32], s1[32];
+#pragma unroll
+  for (int c = 0; c < 32; ++c) s0[c] = s1[c] = 0.f;
+  for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < M; p += (int64_t)gridDim.x * 256) {
+#pragma unroll
+    for (int c = 0; c < 32; ++c)
+      if (c < C) {
+        const float v = z[p * C + c];
+        if (MODE == 0) {
+          s0[c] += v;
+          s1[c] += v * v;
+        } else {
+          const float g = dy[p * C + c];
+          s0[c] += g;
+          s1[c] += g * (v - mean[c]) * invstd[c];
+        }
+      }
+  }
+#pragma unroll
+  for (int c = 0; c < 32; ++c)
+    if (c < C) {
+      atomicAdd(&red[c], s0[c]);
+      atomicAdd(&red[32 + c], s1[c]);
+    }
+  __syncthreads();
+  if ((int)threadIdx.x < C) {
+    atomicAdd(sums + threadIdx.x, (double)red[threadIdx.x]);
+    atomicAdd(sums + C + threadIdx.x, (double)red[32 + threadIdx.x]);
+  }
+}
+
+__global__ __launch_bounds__(256) void bn_dense_apply_kernel(const float* __restrict__ z, const float* __restrict__ scale,
+                                                            const float* __restrict__ shift, float* __restrict__ y,
+                                                            int64_t total, int C) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int c = (int)(i % C);
+    y[i] = z[i] * scale[c] + shift[c];
+  }
+}
+
+__global__ __launch_bounds__(256) void bn_dense_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ z,
+                                                                const float* __restrict__ mean,
+                                                                const float* __restrict__ invstd,
+                                                                const float* __restrict__ gamma,
+                                                                const double* __restrict__ sums, double M,
+                                                                float* __restrict__ dz, int64_t total, int C) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int c = (int)(i % C);
+    const float zh = (z[i] - mean[c]) * invstd[c];
+    dz[i] = gamma[c] * invstd[c] * (dy[i] - (float)(sums[c] / M) - zh * (float)(sums[C + c] / M));
+  }
+}
+
+// ---- raw bilinear up-sampling (the constant deconv kernel, custom_layers.py:8-25) and its transpose -----------
+template <int S>
+__device__ __forceinline__ float bl_w(int o, int i) {  // weight of source pixel i in output pixel o (0 if not a tap)
+  constexpr float center = (2.f * S - 1.f - (S % 2)) / (2.f * S);
+  const int p = o + S / 2 - i * S;  // tap index along the kernel: 0 .. 2S-1
+  if (p < 0 || p >= 2 * S) return 0.f;
+  return 1.f - fabsf((float)p / S - center);
+}
+
+template <int S>
+__global__ __launch_bounds__(256) void upsample_raw_kernel(const __bf16* __restrict__ x, __bf16* __restrict__ y, int N,
+                                                          int Hi, int Wi, int C) {
+  const int c8 = C >> 3;
+  const int Ho = Hi * S, Wo = Wi * S;
+  const int64_t total = (int64_t)N * Ho * Wo * c8;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    const int cg = (int)(idx % c8);
+    int64_t r = idx / c8;
+    const int ox = (int)(r % Wo);
+    r /= Wo;
+    const int oy = (int)(r % Ho);
+    const int n = (int)(r / Ho);
+    const int iy1 = (oy + S / 2) / S, ix1 = (ox + S / 2) / S;  // taps iy1-1, iy1 (padded coords iy1, iy1+1)
+    const float wy1 = bl_w<S>(oy, iy1), wy0 = bl_w<S>(oy, iy1 - 1), wx1 = bl_w<S>(ox, ix1), wx0 = bl_w<S>(ox, ix1 - 1);
+    const __bf16* p00 = x + (((int64_t)n * (Hi + 2) + iy1) * (Wi + 2) + ix1) * C + cg * 8;
+    const int64_t rowp = (int64_t)(Wi + 2) * C;
+    const u32x4 a00 = *reinterpret_cast<const u32x4*>(p00), a01 = *reinterpret_cast<const u32x4*>(p00 + C);
+    const u32x4 a10 = *reinterpret_cast<const u32x4*>(p00 + rowp), a11 = *reinterpret_cast<const u32x4*>(p00 + rowp + C);
+    const float w00 = wy0 * wx0, w01 = wy0 * wx1, w10 = wy1 * wx0, w11 = wy1 * wx1;
+    u32x4 o;
+#pragma unroll
+    for (int w = 0; w < 4; ++w)
+      o[w] = pack_bf16x2(bf_lo(a00[w]) * w00 + bf_lo(a01[w]) * w01 + bf_lo(a10[w]) * w10 + bf_lo(a11[w]) * w11,
+                         bf_hi(a00[w]) * w00 + bf_hi(a01[w]) * w01 + bf_hi(a10[w]) * w10 + bf_hi(a11[w]) * w11);
+    *reinterpret_cast<u32x4*>(y + (((int64_t)n * (Ho + 2) + oy + 1) * (Wo + 2) + ox + 1) * C + cg * 8) = o;
+  }
+}
+
+// dx[i, j] = sum over the 2S x 2S output footprint of w(oy, i) * w(ox, j) * dy[oy, ox]
+template <int S>
+__global__ __launch_bounds__(256) void upsample_raw_bwd_kernel(const __bf16* __restrict__ dy, __bf16* __restrict__ dx,
+                                                              int N, int Hi, int Wi, int C) {
+  const int c8 = C >> 3;
+  const int Ho = Hi * S, Wo = Wi * S;
+  const int64_t total = (int64_t)N * Hi * Wi * c8;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    const int cg = (int)(idx % c8);
+    int64_t r = idx / c8;
+    const int j = (int)(r % Wi);
+    r /= Wi;
+    const int i = (int)(r % Hi);
+    const int n = (int)(r / Hi);
+    const __bf16* dimg = dy + (int64_t)n * (Ho + 2) * (Wo + 2) * C + cg * 8;
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int oy = i * S - S / 2; oy < i * S - S / 2 + 2 * S; ++oy) {
+      if (oy < 0 || oy >= Ho) continue;
+      const float wy = bl_w<S>(oy, i);
+      for (int ox = j * S - S / 2; ox < j * S - S / 2 + 2 * S; ++ox) {
+        if (ox < 0 || ox >= Wo) continue;
+        const float wgt = wy * bl_w<S>(ox, j);
+        const u32x4 gv = *reinterpret_cast<const u32x4*>(dimg + ((int64_t)(oy + 1) * (Wo + 2) + (ox + 1)) * C);
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+          acc[2 * w] += wgt * bf_lo(gv[w]);
+          acc[2 * w + 1] += wgt * bf_hi(gv[w]);
+        }
+      }
+    }
+    u32x4 o;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) o[w] = pack_bf16x2(acc[2 * w], acc[2 * w + 1]);
+    *reinterpret_cast<u32x4*>(dx + (((int64_t)n * (Hi + 2) + i + 1) * (Wi + 2) + j + 1) * C + cg * 8) = o;
+  }
+}
+
+// ---- per-pixel U -> C score conv on the full-resolution map, dense float32 output -------------------------------
+template <int CM>
+__global__ __launch_bounds__(256) void score_dense_kernel(const __bf16* __restrict__ u, const float* __restrict__ ws,
+                                                         const float* __restrict__ bs, float* __restrict__ score, int N,
+                                                         int H, int W, int U, int C) {
+  extern __shared__ float wsm[];  // [U][CM]
+  for (int i = threadIdx.x; i < U * CM; i += 256) {
+    const int uu = i / CM, c = i - uu * CM;
+    wsm[i] = c < C ? ws[uu * C + c] : 0.f;
+  }
+  __syncthreads();
+  const int64_t npix = (int64_t)N * H * W;
+  for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < npix; p += (int64_t)gridDim.x * 256) {
+    const int x = (int)(p % W);
+    const int64_t r = p / W;
+    const int yy = (int)(r % H), n = (int)(r / H);
+    const __bf16* src = u + (((int64_t)n * (H + 2) + yy + 1) * (W + 2) + x + 1) * U;
+    float acc[CM];
+#pragma unroll
+    for (int c = 0; c < CM; ++c) acc[c] = c < C ? bs[c] : 0.f;
+    for (int u0 = 0; u0 < U; u0 += 8) {
+      const u32x4 v = *reinterpret_cast<const u32x4*>(src + u0);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float f = (e & 1) ? bf_hi(v[e >> 1]) : bf_lo(v[e >> 1]);
+        const float* wr = wsm + (u0 + e) * CM;
+#pragma unroll
+        for (int c = 0; c < CM; ++c) acc[c] = fmaf(f, wr[c], acc[c]);
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < CM; ++c)
+      if (c < C) score[p * C + c] = acc[c];
+  }
+}
+
+// loss += -sum_pix log_softmax(logits)[label] / count; dlogits = (softmax - onehot) / count (0 for label < 0)
+__global__ __launch_bounds__(256) void softmax_ce_dense_kernel(const float* __restrict__ logits,
+                                                              const int32_t* __restrict__ labels,
+                                                              const unsigned long long* __restrict__ count, int C,
+                                                              int64_t npix, double* __restrict__ loss,
+                                                              float* __restrict__ dlogits) {
+  const float inv = 1.f / (1e-20f + (float)count[0]);
+  double local = 0.0;
+  for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < npix; p += (int64_t)gridDim.x * 256) {
+    const int lab = labels[p];
+    const float* l = logits + p * C;
+    float m = l[0];
+    for (int c = 1; c < C; ++c) m = fmaxf(m, l[c]);
+    float sum = 0.f;
+    for (int c = 0; c < C; ++c) sum += expf(l[c] - m);
+    const float lse = m + logf(sum);
+    const bool valid = lab >= 0 && lab < C;
+    if (valid) local += (double)(lse - l[lab]) * inv;
+    for (int c = 0; c < C; ++c) dlogits[p * C + c] = valid ? (expf(l[c] - lse) - (c == lab ? 1.f : 0.f)) * inv : 0.f;
+  }
+  __shared__ double red[256];
+  red[threadIdx.x] = local;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) atomicAdd(loss, red[0]);
+}
+
+// dws[u][c] += sum_pix u[pix][u] * ds[pix][c]; dbs[c] += sum_pix ds[pix][c].  Thread (uu = t % 64, g = t / 64) owns
+// channels uu, uu+64, .. and classes g, g+4, ..; a block walks a contiguous run of pixels.
+template <int CM>
+__global__ __launch_bounds__(256) void score_dense_wgrad_kernel(const __bf16* __restrict__ u, const float* __restrict__ ds,
+                                                               float* __restrict__ dws, float* __restrict__ dbs, int N,
+                                                               int H, int W, int U, int C, int64_t per_block) {
+  const int uu = threadIdx.x & 63, g = threadIdx.x >> 6;
+  constexpr int KC = CM / 4;
+  const int64_t npix = (int64_t)N * H * W;
+  const int64_t p0 = (int64_t)blockIdx.x * per_block, p1 = p0 + per_block < npix ? p0 + per_block : npix;
+  for (int ub = 0; ub < U; ub += 64) {
+    float acc[KC], bacc[KC];
+#pragma unroll
+    for (int k = 0; k < KC; ++k) acc[k] = bacc[k] = 0.f;
+    for (int64_t p = p0; p < p1; ++p) {
+      const int x = (int)(p % W);
+      const int64_t r = p / W;
+      const int yy = (int)(r % H), n = (int)(r / H);
+      const float f = (float)u[(((int64_t)n * (H + 2) + yy + 1) * (W + 2) + x + 1) * U + ub + uu];
+#pragma unroll
+      for (int k = 0; k < KC; ++k) {
+        const int c = g + 4 * k;
+        const float d = c < C ? ds[p * C + c] : 0.f;
+        acc[k] = fmaf(f, d, acc[k]);
+        bacc[k] += d;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < KC; ++k) {
+      const int c = g + 4 * k;
+      if (c < C) {
+        atomicAdd(dws + (ub + uu) * C + c, acc[k]);
+        if (ub == 0 && uu == 0) atomicAdd(dbs + c, bacc[k]);
+      }
+    }
+  }
+}
+
+// du[pix][u] = sum_c ds[pix][c] * ws[u][c]
+template <int CM>
+__global__ __launch_bounds__(256) void score_dense_dgrad_kernel(const float* __restrict__ ds, const float* __restrict__ ws,
+                                                               __bf16* __restrict__ du, int N, int H, int W, int U,
+                                                               int C) {
+  extern __shared__ float wsm[];  // [U][CM]
+  for (int i = threadIdx.x; i < U * CM; i += 256) {
+    const int uu = i / CM, c = i - uu * CM;
+    wsm[i] = c < C ? ws[uu * C + c] : 0.f;
+  }
+  __syncthreads();
+  const int c8 = U >> 3;
+  const int64_t total = (int64_t)N * H * W * c8;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    const int cg = (int)(idx % c8);
+    const int64_t p = idx / c8;
+    const int x = (int)(p % W);
+    const int64_t r = p / W;
+    const int yy = (int)(r % H), n = (int)(r / H);
+    float d[CM];
+#pragma unroll
+    for (int c = 0; c < CM; ++c) d[c] = c < C ? ds[p * C + c] : 0.f;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float* wr = wsm + (cg * 8 + e) * CM;
+      float a = 0.f;
+#pragma unroll
+      for (int c = 0; c < CM; ++c) a = fmaf(d[c], wr[c], a);
+      v[e] = a;
+    }
+    *reinterpret_cast<u32x4*>(du + (((int64_t)n * (H + 2) + yy + 1) * (W + 2) + x + 1) * U + cg * 8) =
+        u32x4{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
+  }
+}
+
+bool same_shape(const xv_act* a, const xv_act* b) { return a->n == b->n && a->h == b->h && a->w == b->w && a->c == b->c; }
+
+}  // namespace
+
+extern "C" int xv_bn_stats(const xv_act* z, double* sums, void* stream) {
+  XV_CHECK_ARG(z && z->data && sums);
+  XV_CHECK_SHAPE(z->c >= 64 && 2048 % z->c == 0 && z->n > 0 && z->h > 0 && z->w > 0);  // C/8 divides the block size
+  hipError_t e = hipMemsetAsync(sums, 0, sizeof(double) * 2 * z->c, (hipStream_t)stream);
+  if (e != hipSuccess) return (int)e;
+  const int64_t total = (int64_t)z->n * z->h * z->w * (z->c >> 3);
+  hipLaunchKernelGGL(bn_reduce_kernel<0>, dim3(bn_grid(total, 1024)), dim3(256), 0, (hipStream_t)stream,
+                     (const __bf16*)z->data, nullptr, nullptr, nullptr, nullptr, sums, z->n, z->h, z->w, z->c);
+  return xv_launch_status();
+}
+
+extern "C" int xv_bn_finalize(const double* sums, int channels, int64_t count, const float* gamma, const float* beta,
+                              float eps, float momentum, float* moving_mean, float* moving_var, float* mean,
+                              float* invstd, float* scale, float* shift, void* stream) {
+  XV_CHECK_ARG(sums && gamma && beta && mean && invstd && scale && shift && (moving_mean == nullptr) == (moving_var == nullptr));
+  XV_CHECK_SHAPE(channels > 0 && count > 0);
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((channels + 63) / 64), dim3(64), 0, (hipStream_t)stream, sums, channels,
+                     (double)count, gamma, beta, eps, momentum, moving_mean, moving_var, mean, invstd, scale, shift);
+  return xv_launch_status();
+}
+
+extern "C" int xv_bn_apply(const xv_act* z, const float* scale, const float* shift, int relu, const xv_act* y,
+                           void* stream) {
+  XV_CHECK_ARG(z && y && z->data && y->data && scale && shift);
+  XV_CHECK_SHAPE(same_shape(z, y) && (z->c & 7) == 0);
+  const int64_t total = (int64_t)z->n * z->h * z->w * (z->c >> 3);
+  hipLaunchKernelGGL(bn_apply_kernel, dim3(bn_grid(total, 8192)), dim3(256), 0, (hipStream_t)stream,
+                     (const __bf16*)z->data, scale, shift, relu, (__bf16*)y->data, z->n, z->h, z->w, z->c);
+  return xv_launch_status();
+}
+
+extern "C" int xv_bn_bwd(const xv_act* dy, const xv_act* y, const xv_act* z, const float* mean, const float* invstd,
+                         const float* gamma, double* sums, float* dgamma, float* dbeta, const xv_act* dz, void* stream) {
+  XV_CHECK_ARG(dy && z && dz && dy->data && z->data && dz->data && mean && invstd && gamma && sums && dgamma && dbeta);
+  XV_CHECK_SHAPE(same_shape(dy, z) && same_shape(dz, z) && z->c >= 64 && 2048 % z->c == 0);
+  const __bf16* yp = nullptr;
+  if (y && y->data) {
+    XV_CHECK_SHAPE(same_shape(y, z));
+    yp = (const __bf16*)y->data;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  hipError_t e = hipMemsetAsync(sums, 0, sizeof(double) * 2 * z->c, s);
+  if (e != hipSuccess) return (int)e;
+  const int64_t total = (int64_t)z->n * z->h * z->w * (z->c >> 3);
+  const double M = (double)z->n * z->h * z->w;
+  hipLaunchKernelGGL(bn_reduce_kernel<1>, dim3(bn_grid(total, 1024)), dim3(256), 0, s, (const __bf16*)z->data,
+                     (const __bf16*)dy->data, yp, mean, invstd, sums, z->n, z->h, z->w, z->c);
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(bn_grid(total, 8192)), dim3(256), 0, s, (const __bf16*)dy->data, yp,
+                     (const __bf16*)z->data, mean, invstd, gamma, sums, M, (__bf16*)dz->data, z->n, z->h, z->w, z->c);
+  hipLaunchKernelGGL(bn_grads_kernel, dim3((z->c + 63) / 64), dim3(64), 0, s, sums, z->c, dgamma, dbeta);
+  return xv_launch_status();
+}
+
+extern "C" int xv_bn_dense_stats(const float* z, int64_t rows, int channels, double* sums, void* stream) {
+  XV_CHECK_ARG(z && sums);
+  XV_CHECK_SHAPE(rows > 0 && channels >= 1 && channels <= 32);
+  hipError_t e = hipMemsetAsync(sums, 0, sizeof(double) * 2 * channels, (hipStream_t)stream);
+  if (e != hipSuccess) return (int)e;
+  hipLaunchKernelGGL(bn_dense_reduce_kernel<0>, dim3(bn_grid(rows, 1024)), dim3(256), 0, (hipStream_t)stream, z, nullptr,
+                     nullptr, nullptr, sums, rows, channels);
+  return xv_launch_status();
+}
+
+extern "C" int xv_bn_dense_apply(const float* z, int64_t rows, int channels, const float* scale, const float* shift,
+                                 float* y, void* stream) {
+  XV_CHECK_ARG(z && y && scale && shift);
+  XV_CHECK_SHAPE(rows > 0 && channels >= 1 && channels <= 32);
+  hipLaunchKernelGGL(bn_dense_apply_kernel, dim3(bn_grid(rows * channels, 8192)), dim3(256), 0, (hipStream_t)stream, z,
+                     scale, shift, y, rows * channels, channels);
+  return xv_launch_status();
+}
+
+extern "C" int xv_bn_dense_bwd(const float* dy, const float* z, int64_t rows, int channels, const float* mean,
+                               const float* invstd, const float* gamma, double* sums, float* dgamma, float* dbeta,
+                               float* dz, void* stream) {
+  XV_CHECK_ARG(dy && z && mean && invstd && gamma && sums && dgamma && dbeta && dz);
+  XV_CHECK_SHAPE(rows > 0 && channels >= 1 && channels <= 32);
+  hipStream_t s = (hipStream_t)stream;
+  hipError_t e = hipMemsetAsync(sums, 0, sizeof(double) * 2 * channels, s);
+  if (e != hipSuccess) return (int)e;
+  hipLaunchKernelGGL(bn_dense_reduce_kernel<1>, dim3(bn_grid(rows, 1024)), dim3(256), 0, s, z, dy, mean, invstd, sums,
+                     rows, channels);
+  hipLaunchKernelGGL(bn_dense_bwd_apply_kernel, dim3(bn_grid(rows * channels, 8192)), dim3(256), 0, s, dy, z, mean,
+                     invstd, gamma, sums, (double)rows, dz, rows * channels, channels);
+  hipLaunchKernelGGL(bn_grads_kernel, dim3(1), dim3(64), 0, s, sums, channels, dgamma, dbeta);
+  return xv_launch_status();
+}
+
+extern "C" int xv_upsample_raw_fwd(const xv_act* x, int factor, const xv_act* y, void* stream) {
+  XV_CHECK_ARG(x && y && x->data && y->data);
+  XV_CHECK_SHAPE((factor == 2 || factor == 8) && (x->c & 7) == 0 && y->n == x->n && y->h == factor * x->h &&
+                 y->w == factor * x->w && y->c == x->c);
+  const int64_t total = (int64_t)y->n * y->h * y->w * (y->c >> 3);
+  if (factor == 2)
+    hipLaunchKernelGGL(upsample_raw_kernel<2>, dim3(bn_grid(total, 8192)), dim3(256), 0, (hipStream_t)stream,
+                       (const __bf16*)x->data, (__bf16*)y->data, x->n, x->h, x->w, x->c);
+  else
+    hipLaunchKernelGGL(upsample_raw_kernel<8>, dim3(bn_grid(total, 8192)), dim3(256), 0, (hipStream_t)stream,
+                       (const __bf16*)x->data, (__bf16*)y->data, x->n, x->h, x->w, x->c);
+  return xv_launch_status();
+}
+
+extern "C" int xv_upsample_raw_bwd(const xv_act* dy, int factor, const xv_act* dx, void* stream) {
+  XV_CHECK_ARG(dx && dy && dx->data && dy->data);
+  XV_CHECK_SHAPE((factor == 2 || factor == 8) && (dx->c & 7) == 0 && dy->n == dx->n && dy->h == factor * dx->h &&
+                 dy->w == factor * dx->w && dy->c == dx->c);
+  const int64_t total = (int64_t)dx->n * dx->h * dx->w * (dx->c >> 3);
+  if (factor == 2)
+    hipLaunchKernelGGL(upsample_raw_bwd_kernel<2>, dim3(bn_grid(total, 8192)), dim3(256), 0, (hipStream_t)stream,
+                       (const __bf16*)dy->data, (__bf16*)dx->data, dx->n, dx->h, dx->w, dx->c);
+  else
+    hipLaunchKernelGGL(upsample_raw_bwd_kernel<8>, dim3(bn_grid(total, 8192)), dim3(256), 0, (hipStream_t)stream,
+                       (const __bf16*)dy->data, (__bf16*)dx->data, dx->n, dx->h, dx->w, dx->c);
+  return xv_launch_status();
+}
+
+#define XV_CM_SWITCH(C_, CALL) \
+  switch (((C_) + 3) / 4) {    \
+    case 1: CALL(4); break;    \
+    case 2: CALL(8); break;    \
+    case 3: CALL(12); break;   \
+    case 4: CALL(16); break;   \
+    case 5: CALL(20); break;   \
+    case 6: CALL(24); break;   \
+    case 7: CALL(28); break;   \
+    default: CALL(32); break;  \
+  }
+
+extern "C" int xv_score_dense_fwd(const xv_act* u, const float* w_score, const float* b_score, int num_classes,
+                                  float* score, void* stream) {
+  XV_CHECK_ARG(u && u->data && w_score && b_score && score);
+  XV_CHECK_SHAPE((u->c & 7) == 0 && u->c <= 256 && num_classes >= 1 && num_classes <= 32);
+  const int64_t npix = (int64_t)u->n * u->h * u->w;
+  hipStream_t s = (hipStream_t)stream;
+#define XV_SD(CMV)                                                                                                   \
+  hipLaunchKernelGGL(score_dense_kernel<CMV>, dim3(bn_grid(npix, 4096)), dim3(256), (size_t)u->c * CMV * 4, s,        \
+                     (const __bf16*)u->data, w_score, b_score, score, u->n, u->h, u->w, u->c, num_classes)
+  XV_CM_SWITCH(num_classes, XV_SD)
+#undef XV_SD
+  return xv_launch_status();
+}
+
+extern "C" int xv_softmax_ce_dense(const float* logits, const int32_t* labels, const int64_t* valid_count,
+                                   int num_classes, int64_t npix, double* loss, float* dlogits, void* stream) {
+  XV_CHECK_ARG(logits && labels && valid_count && loss && dlogits);
+  XV_CHECK_SHAPE(npix > 0 && num_classes >= 1 && num_classes <= 32);
+  hipLaunchKernelGGL(softmax_ce_dense_kernel, dim3(bn_grid(npix, 2048)), dim3(256), 0, (hipStream_t)stream, logits, labels,
+                     reinterpret_cast<const unsigned long long*>(valid_count), num_classes, npix, loss, dlogits);
+  return xv_launch_status();
+}
+
+extern "C" int xv_score_dense_bwd(const xv_act* u, const float* dscore, const float* w_score, int num_classes,
+                                  float* dw_score, float* db_score, const xv_act* du, void* stream) {
+  XV_CHECK_ARG(u && u->data && dscore && w_score && dw_score && db_score && du && du->data);
+  XV_CHECK_SHAPE((u->c & 63) == 0 && u->c <= 256 && num_classes >= 1 && num_classes <= 32 && same_shape(u, du));
+  const int64_t npix = (int64_t)u->n * u->h * u->w;
+  const int64_t per_block = 512;
+  const unsigned gw = (unsigned)((npix + per_block - 1) / per_block);
+  const int64_t total = npix * (u->c >> 3);
+  hipStream_t s = (hipStream_t)stream;
+#define XV_SB(CMV)                                                                                                   \
+  hipLaunchKernelGGL(score_dense_wgrad_kernel<CMV>, dim3(gw), dim3(256), 0, s, (const __bf16*)u->data, dscore, dw_score, \
+                     db_score, u->n, u->h, u->w, u->c, num_classes, per_block);                                     \
+  hipLaunchKernelGGL(score_dense_dgrad_kernel<CMV>, dim3(bn_grid(total, 8192)), dim3(256), (size_t)u->c * CMV * 4, s, \
+                     dscore, w_score, (__bf16*)du->data, u->n, u->h, u->w, u->c, num_classes)
+  XV_CM_SWITCH(num_classes, XV_SB)
+#undef XV_SB
+  return xv_launch_status();
+}

@@ -367,3 +367,92 @@ def adagrad_step(param, grad, accum, lr, grad_scale=1.0):
 def bias_grad(dy, dbias):
     _need(dbias, torch.float32, 'dbias')
     _lib.check(_lib.lib().xv_bias_grad(dy.xv(), _ptr(dbias), _stream()), 'xv_bias_grad')
+
+
+# ---- training-mode batch norm and the un-commuted training head (csrc/batchnorm.hip) -------------------------
+BN_EPS, BN_MOMENTUM = 1e-3, 0.99        # [TF1] tf.layers.batch_normalization defaults
+
+
+class BnState(object):
+    """Per-layer buffers of one training-mode batch norm: batch statistics, folded scale / shift, scratch."""
+
+    def __init__(self, channels, device):
+        f = lambda: torch.zeros(channels, dtype=torch.float32, device=device)   # noqa: E731
+        self.c = channels
+        self.mean, self.invstd, self.scale, self.shift = f(), f(), f(), f()
+        self.sums = torch.zeros(2 * channels, dtype=torch.float64, device=device)
+
+
+def bn_forward(z, gamma, beta, moving_mean, moving_var, st, y, relu=True):
+    """y = [relu](BN_batch(z)); updates the moving statistics in place (z, y: Act)."""
+    lib = _lib.lib()
+    _lib.check(lib.xv_bn_stats(z.xv(), _ptr(st.sums), _stream()), 'xv_bn_stats')
+    _lib.check(lib.xv_bn_finalize(_ptr(st.sums), st.c, z.n * z.h * z.w, _ptr(gamma), _ptr(beta), BN_EPS, BN_MOMENTUM,
+                                  _ptr(moving_mean), _ptr(moving_var), _ptr(st.mean), _ptr(st.invstd), _ptr(st.scale),
+                                  _ptr(st.shift), _stream()), 'xv_bn_finalize')
+    _lib.check(lib.xv_bn_apply(z.xv(), _ptr(st.scale), _ptr(st.shift), int(bool(relu)), y.xv(), _stream()), 'xv_bn_apply')
+    return y
+
+
+def bn_backward(dy, y, z, gamma, st, dgamma, dbeta, dz):
+    """dz from dy (gradient w.r.t. the post-relu output; y = None: no activation); accumulates dgamma / dbeta."""
+    rc = _lib.lib().xv_bn_bwd(dy.xv(), y.xv() if y is not None else _NULL_ACT, z.xv(), _ptr(st.mean), _ptr(st.invstd),
+                              _ptr(gamma), _ptr(st.sums), _ptr(dgamma), _ptr(dbeta), dz.xv(), _stream())
+    _lib.check(rc, 'xv_bn_bwd')
+    return dz
+
+
+def bn_dense_forward(z, gamma, beta, moving_mean, moving_var, st, y):
+    """The same on a dense float32 [..., C] tensor (no activation)."""
+    lib = _lib.lib()
+    c = z.shape[-1]
+    rows = z.numel() // c
+    _lib.check(lib.xv_bn_dense_stats(_ptr(z), rows, c, _ptr(st.sums), _stream()), 'xv_bn_dense_stats')
+    _lib.check(lib.xv_bn_finalize(_ptr(st.sums), c, rows, _ptr(gamma), _ptr(beta), BN_EPS, BN_MOMENTUM,
+                                  _ptr(moving_mean), _ptr(moving_var), _ptr(st.mean), _ptr(st.invstd), _ptr(st.scale),
+                                  _ptr(st.shift), _stream()), 'xv_bn_finalize')
+    _lib.check(lib.xv_bn_dense_apply(_ptr(z), rows, c, _ptr(st.scale), _ptr(st.shift), _ptr(y), _stream()),
+               'xv_bn_dense_apply')
+    return y
+
+
+def bn_dense_backward(dy, z, gamma, st, dgamma, dbeta, dz):
+    c = z.shape[-1]
+    rows = z.numel() // c
+    rc = _lib.lib().xv_bn_dense_bwd(_ptr(dy), _ptr(z), rows, c, _ptr(st.mean), _ptr(st.invstd), _ptr(gamma),
+                                    _ptr(st.sums), _ptr(dgamma), _ptr(dbeta), _ptr(dz), _stream())
+    _lib.check(rc, 'xv_bn_dense_bwd')
+    return dz
+
+
+def upsample_raw_fwd(x, factor, y=None):
+    if y is None:
+        y = Act(x.n, factor * x.h, factor * x.w, x.c, x.t.device)
+    _lib.check(_lib.lib().xv_upsample_raw_fwd(x.xv(), factor, y.xv(), _stream()), 'xv_upsample_raw_fwd')
+    return y
+
+
+def upsample_raw_bwd(dy, factor, dx):
+    _lib.check(_lib.lib().xv_upsample_raw_bwd(dy.xv(), factor, dx.xv(), _stream()), 'xv_upsample_raw_bwd')
+    return dx
+
+
+def score_dense_fwd(u, w_score, b_score, num_classes, score):
+    _lib.check(_lib.lib().xv_score_dense_fwd(u.xv(), _ptr(w_score), _ptr(b_score), num_classes, _ptr(score), _stream()),
+               'xv_score_dense_fwd')
+    return score
+
+
+def softmax_ce_dense(logits, labels, count, num_classes, loss, dlogits):
+    _need(labels, torch.int32, 'labels')
+    npix = labels.numel()
+    _lib.check(_lib.lib().xv_softmax_ce_dense(_ptr(logits), _ptr(labels), _ptr(count), num_classes, npix, _ptr(loss),
+                                              _ptr(dlogits), _stream()), 'xv_softmax_ce_dense')
+    return dlogits
+
+
+def score_dense_bwd(u, dscore, w_score, num_classes, dw_score, db_score, du):
+    rc = _lib.lib().xv_score_dense_bwd(u.xv(), _ptr(dscore), _ptr(w_score), num_classes, _ptr(dw_score), _ptr(db_score),
+                                       du.xv(), _stream())
+    _lib.check(rc, 'xv_score_dense_bwd')
+    return du

@@ -1,0 +1,149 @@
+"""Training-mode batch norm and the un-commuted training head (csrc/batchnorm.hip) against PyTorch-CPU autograd of the
+same [TF1] formulas (tf.layers.batch_normalization(training=True): biased batch variance, eps 1e-3, momentum 0.99 with
+the unbiased variance in the moving average)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from oracle import fcn_oracle as fo
+
+
+@pytest.fixture(scope='module')
+def ops():
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU')
+    from modular_semantic_segmentation_amd import ops as o
+    return o
+
+
+def _dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def _nchw(a):
+    return torch.from_numpy(a).permute(0, 3, 1, 2).contiguous()
+
+
+@pytest.mark.parametrize('c,relu', [(64, True), (128, False), (512, True)])
+def test_bn_forward_backward(ops, c, relu):
+    rng = np.random.default_rng(c)
+    n, h, w = 2, 12, 20
+    z = fo.round_bf16((rng.standard_normal((n, h, w, c)) * 1.5 + 0.3).astype(np.float32))
+    gamma = rng.uniform(0.5, 1.5, c).astype(np.float32)
+    beta = (0.3 * rng.standard_normal(c)).astype(np.float32)
+    mm0 = (0.1 * rng.standard_normal(c)).astype(np.float32)
+    mv0 = rng.uniform(0.5, 1.5, c).astype(np.float32)
+    dy = fo.round_bf16(rng.standard_normal((n, h, w, c)).astype(np.float32))
+    # reference: autograd through the explicit formula
+    zt = _nchw(z).double().requires_grad_(True)
+    g, b = torch.from_numpy(gamma).double().requires_grad_(True), torch.from_numpy(beta).double().requires_grad_(True)
+    mean = zt.mean(dim=(0, 2, 3), keepdim=True)
+    var = ((zt - mean) ** 2).mean(dim=(0, 2, 3), keepdim=True)
+    yt = (zt - mean) / torch.sqrt(var + 1e-3) * g.view(1, -1, 1, 1) + b.view(1, -1, 1, 1)
+    if relu:
+        yt = F.relu(yt)
+    yt.backward(_nchw(dy).double())
+    # GPU
+    za, ya = ops.Act.from_dense(_dev(z)), ops.Act(n, h, w, c)
+    st = ops.BnState(c, 'cuda')
+    mm, mv = _dev(mm0.copy()), _dev(mv0.copy())
+    ops.bn_forward(za, _dev(gamma), _dev(beta), mm, mv, st, ya, relu=relu)
+    dgamma, dbeta = torch.zeros(c, device='cuda'), torch.zeros(c, device='cuda')
+    dza = ops.Act(n, h, w, c)
+    ops.bn_backward(ops.Act.from_dense(_dev(dy)), ya if relu else None, za, _dev(gamma), st, dgamma, dbeta, dza)
+    torch.cuda.synchronize()
+    y_ref = yt.detach().permute(0, 2, 3, 1).numpy()
+    got_y = ya.interior().float().cpu().numpy()
+    np.testing.assert_allclose(got_y, y_ref, rtol=2 ** -7, atol=2e-3)
+    M = n * h * w
+    np.testing.assert_allclose(mm.cpu().numpy(), 0.99 * mm0 + 0.01 * mean.detach().numpy().ravel(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(mv.cpu().numpy(), 0.99 * mv0 + 0.01 * var.detach().numpy().ravel() * M / (M - 1),
+                               rtol=1e-5, atol=1e-6)
+    # the relu mask of the kernel is y > 0 on the ROUNDED output: compare where the reference is not at a rounding edge
+    np.testing.assert_allclose(dgamma.cpu().numpy(), g.grad.numpy(), rtol=2e-2, atol=5e-2)
+    np.testing.assert_allclose(dbeta.cpu().numpy(), b.grad.numpy(), rtol=2e-2, atol=5e-2)
+    dz_ref = zt.grad.permute(0, 2, 3, 1).numpy()
+    got = dza.interior().float().cpu().numpy()
+    assert np.abs(got - dz_ref).max() < 2e-2 * np.abs(dz_ref).max() + 1e-3
+
+
+def test_bn_dense_forward_backward(ops):
+    rng = np.random.default_rng(3)
+    rows, c = 3000, 12
+    z = rng.standard_normal((rows, c)).astype(np.float32) * 2 + 0.5
+    gamma, beta = rng.uniform(0.5, 1.5, c).astype(np.float32), rng.standard_normal(c).astype(np.float32)
+    dy = rng.standard_normal((rows, c)).astype(np.float32)
+    zt = torch.from_numpy(z).double().requires_grad_(True)
+    g, b = torch.from_numpy(gamma).double().requires_grad_(True), torch.from_numpy(beta).double().requires_grad_(True)
+    mean, var = zt.mean(0), ((zt - zt.mean(0)) ** 2).mean(0)
+    yt = (zt - mean) / torch.sqrt(var + 1e-3) * g + b
+    yt.backward(torch.from_numpy(dy).double())
+    st = ops.BnState(c, 'cuda')
+    zd, y = _dev(z), torch.empty((rows, c), device='cuda')
+    mm, mv = torch.zeros(c, device='cuda'), torch.ones(c, device='cuda')
+    ops.bn_dense_forward(zd, _dev(gamma), _dev(beta), mm, mv, st, y)
+    dgamma, dbeta, dz = torch.zeros(c, device='cuda'), torch.zeros(c, device='cuda'), torch.empty((rows, c), device='cuda')
+    ops.bn_dense_backward(_dev(dy), zd, _dev(gamma), st, dgamma, dbeta, dz)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(y.cpu().numpy(), yt.detach().numpy(), rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(dgamma.cpu().numpy(), g.grad.numpy(), rtol=1e-4, atol=1e-3)
+    np.testing.assert_allclose(dbeta.cpu().numpy(), b.grad.numpy(), rtol=1e-4, atol=1e-3)
+    np.testing.assert_allclose(dz.cpu().numpy(), zt.grad.numpy(), rtol=1e-3, atol=1e-4)
+
+
+@pytest.mark.parametrize('factor', [2, 8])
+def test_upsample_raw_and_its_transpose(ops, factor):
+    rng = np.random.default_rng(factor)
+    n, h, w, c = 2, 5, 7, 64
+    x = fo.round_bf16(rng.standard_normal((n, h, w, c)).astype(np.float32))
+    xt = _nchw(x).requires_grad_(True)
+    yt = fo.deconv_same(xt, fo.bilinear_kernel(2 * factor, c), factor, relu=False)
+    y = ops.upsample_raw_fwd(ops.Act.from_dense(_dev(x)), factor)
+    torch.cuda.synchronize()
+    ref = yt.detach().permute(0, 2, 3, 1).numpy()
+    np.testing.assert_allclose(y.interior().float().cpu().numpy(), ref, rtol=2 ** -7, atol=1e-5)
+    dy = fo.round_bf16(rng.standard_normal((n, factor * h, factor * w, c)).astype(np.float32))
+    yt.backward(_nchw(dy))
+    dx = ops.upsample_raw_bwd(ops.Act.from_dense(_dev(dy)), factor, ops.Act(n, h, w, c))
+    torch.cuda.synchronize()
+    dref = xt.grad.permute(0, 2, 3, 1).numpy()
+    got = dx.interior().float().cpu().numpy()
+    assert np.abs(got - dref).max() < 2 ** -7 * np.abs(dref).max() + 1e-4
+
+
+@pytest.mark.parametrize('C', [12, 5])
+def test_dense_score_conv_and_cross_entropy(ops, C):
+    rng = np.random.default_rng(C)
+    n, h, w, U = 2, 8, 12, 64
+    u = fo.round_bf16(np.abs(rng.standard_normal((n, h, w, U))).astype(np.float32))
+    ws = (0.3 * rng.standard_normal((U, C))).astype(np.float32)
+    bs = rng.standard_normal(C).astype(np.float32)
+    labels = rng.integers(-1, C, (n, h, w)).astype(np.int32)
+    ut = torch.from_numpy(u).requires_grad_(True)
+    wt, bt = torch.from_numpy(ws).requires_grad_(True), torch.from_numpy(bs).requires_grad_(True)
+    score_t = ut.reshape(-1, U) @ wt + bt
+    lab = torch.from_numpy(labels.reshape(-1).astype(np.int64))
+    valid = lab >= 0
+    logp = F.log_softmax(score_t, dim=1)
+    loss_t = -(logp[valid, lab[valid]]).sum() / (1e-20 + valid.sum())
+    loss_t.backward()
+    ua = ops.Act.from_dense(_dev(u))
+    score = torch.empty((n, h, w, C), device='cuda')
+    ops.score_dense_fwd(ua, _dev(ws), _dev(bs), C, score)
+    count = torch.tensor([int(valid.sum())], dtype=torch.int64, device='cuda')
+    loss = torch.zeros(1, dtype=torch.float64, device='cuda')
+    dlogits = torch.empty_like(score)
+    ops.softmax_ce_dense(score, _dev(labels), count, C, loss, dlogits)
+    dws, dbs, du = torch.zeros((U, C), device='cuda'), torch.zeros(C, device='cuda'), ops.Act(n, h, w, U)
+    ops.score_dense_bwd(ua, dlogits, _dev(ws), C, dws, dbs, du)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(score.cpu().numpy().reshape(-1, C), score_t.detach().numpy(), rtol=1e-4, atol=1e-4)
+    assert abs(loss.item() - loss_t.item()) < 1e-5 * abs(loss_t.item()) + 1e-7
+    np.testing.assert_allclose(dws.cpu().numpy(), wt.grad.numpy(), rtol=1e-3, atol=1e-5)
+    np.testing.assert_allclose(dbs.cpu().numpy(), bt.grad.numpy(), rtol=1e-3, atol=1e-6)
+    got = du.interior().float().cpu().numpy()
+    ref = ut.grad.numpy()
+    assert np.abs(got - ref).max() < 2 ** -7 * np.abs(ref).max() + 1e-7
