@@ -76,12 +76,10 @@ class SimpleFCN(BaseModel):
     # ---- training (base_model.py:153-162,180-261) ------------------------------------------------------
     def _ensure_trainer(self):
         if getattr(self, 'trainer', None) is None:
-            if self.config['batch_normalization']:
-                raise NotImplementedError('training with batch normalization is not built on this path')
-            from .trainer import FcnTrainer
+            from .trainer import FcnBnTrainer, FcnTrainer
             from .parallel import GradReducer, world
-            self.trainer = FcnTrainer(self.engine, self.config.get('trainer', 'adam'),
-                                      self.config.get('learning_rate', 0.0001))
+            cls = FcnBnTrainer if self.config['batch_normalization'] else FcnTrainer
+            self.trainer = cls(self.engine, self.config.get('trainer', 'adam'), self.config.get('learning_rate', 0.0001))
             self.trainer.load_from_variables(variables=self.variables)
             self._reducer = GradReducer(self.device) if world()[1] > 1 else None
         return self.trainer
@@ -98,12 +96,17 @@ class SimpleFCN(BaseModel):
         if getattr(self, 'trainer', None) is not None and getattr(self, '_dirty', False):
             self.trainer.to_variables(self.variables)
             self._dirty = False
+            if self.config['batch_normalization']:
+                # the inference engine folds the (moving) batch-norm statistics into its weights: rebuild them
+                self.engine.load(self.variables)
 
     def export_weights(self, save_dir=None):
         self._sync_variables()
         return BaseModel.export_weights(self, save_dir)
 
     def _predict_batch_impl(self, batch, output_attr=None):
+        if self.config['batch_normalization']:
+            self._sync_variables()
         x = self._to_device(batch[self.modality], torch.float32)
         want = 'label'
         if output_attr in ('prob', 'score'):

@@ -247,3 +247,277 @@ class FcnTrainer(object):
             out['%s/%s/kernel' % (p, name)] = kv
             out['%s/%s/bias' % (p, name)] = bv
         return out
+
+
+# =========================================================================================================
+# Training with batch normalisation (`batch_normalization: true`, the reference's example configuration)
+# =========================================================================================================
+BN_LAYERS = [name for name, _, _ in ENCODER] + ['score_conv4', 'score_conv5', 'upscore_conv5', 'upscore', 'score']
+BN_ORDER = ['score', 'upscore', 'score_conv5', 'upscore_conv5', 'score_conv4'] + [name for name, _, _ in reversed(ENCODER)]
+
+
+class FcnBnTrainer(object):
+    """One training step of SimpleFCN with tf.layers.batch_normalization(training=True) between every conv /
+    deconv and its activation (custom_layers.py:112-119,124-139; simple_fcn.py:200-214).
+
+    Differences from FcnTrainer, all forced by the batch statistics: convs run without their fused relu / pool and
+    store the pre-normalisation map z next to the post-relu map y; the relu mask of the backward pass moves into the
+    batch-norm gradient; the decoder head is un-commuted (the x8 bilinear map is materialised at full resolution,
+    normalised, scored per pixel and normalised again).  gamma / beta are trained ([TF1] defaults), the moving
+    averages (momentum 0.99, unbiased variance) are updated in the forward pass like the reference's UPDATE_OPS
+    control dependency (base_model.py:155-156).  Data-parallel runs use per-rank batch statistics."""
+
+    def __init__(self, engine, trainer='adam', learning_rate=1e-4):
+        if trainer not in ('adam', 'rmsprop', 'adagrad'):
+            raise KeyError(trainer)
+        self.e, self.kind, self.lr = engine, trainer, float(learning_rate)
+        e, dev = engine, engine.device
+        self.convs = {}                      # conv layers: (kernel shape, cout)
+        cin = e.cin
+        for name, cout, _ in ENCODER:
+            self.convs[name] = ((3, 3, cin, cout), cout)
+            cin = cout
+        self.convs['score_conv4'] = ((1, 1, 512, e.Up), e.Up)
+        self.convs['score_conv5'] = ((1, 1, 512, e.Up), e.Up)
+        self.convs['score'] = ((e.Up, e.C), e.C)
+        self.bn_channels = {name: self.convs[name][1] for name in self.convs}
+        self.bn_channels.update(upscore_conv5=e.Up, upscore=e.Up)
+        self.offsets, total = {}, 0
+        for name in BN_ORDER:
+            entries = []
+            if name in self.convs:
+                entries += [('kernel', self.convs[name][0]), ('bias', (self.convs[name][1],))]
+            entries += [('gamma', (self.bn_channels[name],)), ('beta', (self.bn_channels[name],))]
+            for kind, shape in entries:
+                n = int(np.prod(shape))
+                self.offsets[(name, kind)] = (total, n, shape)
+                total += (n + 63) // 64 * 64
+        self.total = total
+        self.param = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.grad = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.moving = {name: (torch.zeros(c, device=dev), torch.ones(c, device=dev)) for name, c in self.bn_channels.items()}
+        self.bn = {name: ops.BnState(c, dev) for name, c in self.bn_channels.items()}
+        self.state, self.t = {}, 0
+        self.zero_bias = torch.zeros(512, dtype=torch.float32, device=dev)
+        self.count = torch.zeros(1, dtype=torch.int64, device=dev)
+        self.loss = torch.zeros(1, dtype=torch.float64, device=dev)
+        self.w, self.wd, self._a = {}, {}, {}
+
+    # ---- parameters -------------------------------------------------------------------------------------
+    def view(self, buf, name, kind):
+        off, n, shape = self.offsets[(name, kind)]
+        return buf[off:off + n].view(*shape)
+
+    def load_from_variables(self, e_variables=None, variables=None):
+        if variables is None:
+            return
+        p, e = self.e.prefix, self.e
+        self.param.zero_()
+        for name in BN_ORDER:
+            layer = '%s/%s' % (p, name)
+            c = self.bn_channels[name]
+            real = e.C if name == 'score' else (e.U if c == e.Up else c)
+            if name in self.convs:
+                k = torch.from_numpy(np.asarray(variables[layer + '/kernel'], np.float32))
+                b = torch.from_numpy(np.asarray(variables[layer + '/bias'], np.float32))
+                kv, bv = self.view(self.param, name, 'kernel'), self.view(self.param, name, 'bias')
+                if name == 'score':
+                    kv[:e.U].copy_(k.reshape(e.U, e.C))
+                    bv.copy_(b)
+                elif name.startswith('score_conv'):
+                    kv[..., :e.U].copy_(k)
+                    bv[:e.U].copy_(b)
+                else:
+                    kv.copy_(k)
+                    bv.copy_(b)
+            g, bt = self.view(self.param, name, 'gamma'), self.view(self.param, name, 'beta')
+            g.fill_(1.0)                       # padding channels: gamma 1, beta 0 (their maps stay exactly zero)
+            g[:real].copy_(torch.from_numpy(np.asarray(variables[layer + '/gamma'], np.float32)))
+            bt[:real].copy_(torch.from_numpy(np.asarray(variables[layer + '/beta'], np.float32)))
+            mm, mv = self.moving[name]
+            mm.zero_()
+            mv.fill_(1.0)
+            mm[:real].copy_(torch.from_numpy(np.asarray(variables[layer + '/moving_mean'], np.float32)))
+            mv[:real].copy_(torch.from_numpy(np.asarray(variables[layer + '/moving_variance'], np.float32)))
+        self.repack()
+
+    def to_variables(self, variables):
+        p, e = self.e.prefix, self.e
+        for name in BN_ORDER:
+            layer = '%s/%s' % (p, name)
+            c = self.bn_channels[name]
+            real = e.C if name == 'score' else (e.U if c == e.Up else c)
+            if name in self.convs:
+                kv = self.view(self.param, name, 'kernel').cpu().numpy()
+                bv = self.view(self.param, name, 'bias').cpu().numpy()
+                if name == 'score':
+                    kv = kv[:e.U].reshape(1, 1, e.U, e.C)
+                elif name.startswith('score_conv'):
+                    kv, bv = kv[..., :e.U], bv[:e.U]
+                variables[layer + '/kernel'] = np.ascontiguousarray(kv)
+                variables[layer + '/bias'] = np.ascontiguousarray(bv)
+            variables[layer + '/gamma'] = self.view(self.param, name, 'gamma')[:real].cpu().numpy().copy()
+            variables[layer + '/beta'] = self.view(self.param, name, 'beta')[:real].cpu().numpy().copy()
+            variables[layer + '/moving_mean'] = self.moving[name][0][:real].cpu().numpy().copy()
+            variables[layer + '/moving_variance'] = self.moving[name][1][:real].cpu().numpy().copy()
+
+    def grads_as_variables(self):
+        out = {}
+        p, e = self.e.prefix, self.e
+        for name in BN_ORDER:
+            layer = '%s/%s' % (p, name)
+            c = self.bn_channels[name]
+            real = e.C if name == 'score' else (e.U if c == e.Up else c)
+            if name in self.convs:
+                kv = self.view(self.grad, name, 'kernel').cpu().numpy()
+                bv = self.view(self.grad, name, 'bias').cpu().numpy()
+                if name == 'score':
+                    kv = kv[:e.U].reshape(1, 1, e.U, e.C)
+                elif name.startswith('score_conv'):
+                    kv, bv = kv[..., :e.U], bv[:e.U]
+                out[layer + '/kernel'], out[layer + '/bias'] = kv, bv
+            out[layer + '/gamma'] = self.view(self.grad, name, 'gamma')[:real].cpu().numpy()
+            out[layer + '/beta'] = self.view(self.grad, name, 'beta')[:real].cpu().numpy()
+        return out
+
+    def repack(self):
+        """Master fp32 kernels -> packed bf16 forward / data-gradient weights (training graph: no folding)."""
+        dev = self.e.device
+        for name, (shape, _) in self.convs.items():
+            kv = self.view(self.param, name, 'kernel')
+            if name in ('score', 'conv1_1'):
+                self.w[name] = kv
+                continue
+            if name not in self.wd:
+                k, _, cin, cout = shape
+                nel = ops.packed_weight_elems(k, cin, cout)
+                self.w[name] = torch.empty(nel, dtype=torch.bfloat16, device=dev)
+                self.wd[name] = torch.empty(nel, dtype=torch.bfloat16, device=dev)
+            ops.pack_conv_weights_into(kv, self.w[name])
+            ops.pack_conv_weights_dgrad(kv, self.wd[name])
+
+    def _act(self, tag, n, h, w, c):
+        key = (tag, n, h, w, c)
+        a = self._a.get(key)
+        if a is None:
+            a = self._a[key] = ops.Act(n, h, w, c, self.e.device)
+        return a
+
+    def _dense(self, tag, shape, dtype=torch.float32):
+        key = (tag,) + tuple(shape)
+        t = self._a.get(key)
+        if t is None:
+            t = self._a[key] = torch.empty(shape, dtype=dtype, device=self.e.device)
+        return t
+
+    def _bn_fwd(self, name, z, y, relu=True):
+        mm, mv = self.moving[name]
+        return ops.bn_forward(z, self.view(self.param, name, 'gamma'), self.view(self.param, name, 'beta'), mm, mv,
+                              self.bn[name], y, relu=relu)
+
+    def _bn_bwd(self, name, dy, y, z, dz):
+        return ops.bn_backward(dy, y, z, self.view(self.param, name, 'gamma'), self.bn[name],
+                               self.view(self.grad, name, 'gamma'), self.view(self.grad, name, 'beta'), dz)
+
+    # ---- one training step ----------------------------------------------------------------------------------
+    def step(self, x, labels, reducer=None):
+        e = self.e
+        n, h, w, _ = x.shape
+        if h % 16 or w % 16:
+            raise ValueError('H and W must be multiples of 16')
+        P = lambda name, kind: self.view(self.param, name, kind)   # noqa: E731
+        G = lambda name, kind: self.view(self.grad, name, kind)    # noqa: E731
+        self.grad.zero_()
+        self.loss.zero_()
+        self.count.zero_()
+        ops.count_valid_labels(labels, e.C, self.count)
+        if reducer is not None:
+            reducer.allreduce_now(self.count)
+        # ---- forward: z = conv + bias, y = relu(BN(z)), pools on y ---------------------------------------
+        Z, Y = {}, {}
+        cur, ch, cw = None, h, w
+        inputs = {}
+        for name, cout, pool in ENCODER:
+            z = self._act('z_' + name, n, ch, cw, cout)
+            if name == 'conv1_1':
+                ops.conv2d_first_fwd(x.contiguous(), self.w[name], P(name, 'bias'), z, relu=False)
+            else:
+                ops.conv2d_fwd(cur, self.w[name], P(name, 'bias'), 3, relu=False, y=z)
+            inputs[name] = cur
+            Z[name] = z
+            Y[name] = cur = self._bn_fwd(name, z, self._act('y_' + name, n, ch, cw, cout))
+            if pool:
+                ch, cw = ch // 2, cw // 2
+                Y[pool] = cur = ops.maxpool2x2_fwd(cur, self._act(pool, n, ch, cw, cout))
+        h8, w8 = h // 8, w // 8
+        for name, src, hh, ww in (('score_conv4', 'conv4_3', h8, w8), ('score_conv5', 'conv5_3', h8 // 2, w8 // 2)):
+            Z[name] = ops.conv2d_fwd(Y[src], self.w[name], P(name, 'bias'), 1, relu=False,
+                                     y=self._act('z_' + name, n, hh, ww, e.Up))[0]
+            Y[name] = self._bn_fwd(name, Z[name], self._act('y_' + name, n, hh, ww, e.Up))
+        Z['upscore_conv5'] = ops.upsample_raw_fwd(Y['score_conv5'], 2, self._act('z_up5', n, h8, w8, e.Up))
+        Y['upscore_conv5'] = self._bn_fwd('upscore_conv5', Z['upscore_conv5'], self._act('y_up5', n, h8, w8, e.Up))
+        st = self.bn['upscore_conv5']
+        fused = ops.upsample2x_relu_add(Y['score_conv5'], residual=Y['score_conv4'], y=self._act('fused', n, h8, w8, e.Up),
+                                        scale=st.scale, shift=st.shift)            # = y_up5 + y_score_conv4
+        Z['upscore'] = ops.upsample_raw_fwd(fused, 8, self._act('z_up', n, h, w, e.Up))
+        Y['upscore'] = self._bn_fwd('upscore', Z['upscore'], self._act('y_up', n, h, w, e.Up))
+        score_raw = ops.score_dense_fwd(Y['upscore'], self.w['score'], P('score', 'bias'), e.C,
+                                        self._dense('score_raw', (n, h, w, e.C)))
+        mm, mv = self.moving['score']
+        logits = ops.bn_dense_forward(score_raw, P('score', 'gamma'), P('score', 'beta'), mm, mv, self.bn['score'],
+                                      self._dense('logits', (n, h, w, e.C)))
+        dlogits = ops.softmax_ce_dense(logits, labels, self.count, e.C, self.loss, self._dense('dlogits', (n, h, w, e.C)))
+        # ---- backward ------------------------------------------------------------------------------------------
+        dscore = ops.bn_dense_backward(dlogits, score_raw, P('score', 'gamma'), self.bn['score'], G('score', 'gamma'),
+                                       G('score', 'beta'), self._dense('dscore', (n, h, w, e.C)))
+        du = ops.score_dense_bwd(Y['upscore'], dscore, self.w['score'], e.C, G('score', 'kernel'), G('score', 'bias'),
+                                 self._act('d_up', n, h, w, e.Up))
+        dz_up = self._bn_bwd('upscore', du, Y['upscore'], Z['upscore'], du)                 # in place
+        dfused = ops.upsample_raw_bwd(dz_up, 8, self._act('dfused', n, h8, w8, e.Up))
+        wkey = ('wgrad_ws', n, h, w)
+        if wkey not in self._a:
+            need = 0
+            for nm, _, _ in ENCODER[1:]:
+                need = max(need, ops.conv2d_bwd_filter_workspace_bytes(inputs[nm], self.convs[nm][1], 3))
+            for nm, src in (('score_conv4', 'conv4_3'), ('score_conv5', 'conv5_3')):
+                need = max(need, ops.conv2d_bwd_filter_workspace_bytes(Y[src], e.Up, 1))
+            self._a[wkey] = torch.empty(need // 4, dtype=torch.float32, device=e.device)
+        wws = self._a[wkey]
+        # branch through score_conv4
+        dz_s4 = self._bn_bwd('score_conv4', dfused, Y['score_conv4'], Z['score_conv4'], self._act('dz_s4', n, h8, w8, e.Up))
+        ops.conv2d_bwd_filter(Y['conv4_3'], dz_s4, G('score_conv4', 'kernel'), G('score_conv4', 'bias'), 1, workspace=wws)
+        # branch through upscore_conv5 and score_conv5
+        dz_up5 = self._bn_bwd('upscore_conv5', dfused, Y['upscore_conv5'], Z['upscore_conv5'],
+                              self._act('dz_up5', n, h8, w8, e.Up))
+        dy_s5 = ops.upsample_raw_bwd(dz_up5, 2, self._act('dy_s5', n, h8 // 2, w8 // 2, e.Up))
+        dz_s5 = self._bn_bwd('score_conv5', dy_s5, Y['score_conv5'], Z['score_conv5'], dy_s5)
+        ops.conv2d_bwd_filter(Y['conv5_3'], dz_s5, G('score_conv5', 'kernel'), G('score_conv5', 'bias'), 1, workspace=wws)
+        g = ops.conv2d_bwd_data(dz_s5, self.wd['score_conv5'], self.zero_bias, self._act('g_conv5_3', n, h8 // 2, w8 // 2, 512), 1)
+        names = [nm for nm, _, _ in ENCODER]
+        pool_after = {nm: pl for nm, _, pl in ENCODER}
+        for nm in reversed(names):
+            y = Y[nm]
+            dz = self._bn_bwd(nm, g, y, Z[nm], self._act('dz_' + nm, y.n, y.h, y.w, y.c))
+            if nm == 'conv1_1':
+                ops.conv2d_first_bwd_filter(x, dz, G(nm, 'kernel'), G(nm, 'bias'))
+                break
+            xin = inputs[nm]
+            ops.conv2d_bwd_filter(xin, dz, G(nm, 'kernel'), G(nm, 'bias'), 3, workspace=wws)
+            dx = ops.conv2d_bwd_data(dz, self.wd[nm], self.zero_bias, self._act('dx_' + nm, xin.n, xin.h, xin.w, xin.c), 3)
+            above = names[names.index(nm) - 1]
+            if pool_after[above]:
+                routed = ops.maxpool2x2_bwd(Y[above], dx, self._act('r_' + above, Y[above].n, Y[above].h, Y[above].w, Y[above].c))
+                if above == 'conv4_3':      # second gradient path into conv4_3's output: through score_conv4 (AddN)
+                    g = ops.conv2d_bwd_data(dz_s4, self.wd['score_conv4'], self.zero_bias,
+                                            self._act('g_conv4_3', routed.n, routed.h, routed.w, routed.c), 1, addend=routed)
+                else:
+                    g = routed
+            else:
+                g = dx
+        if reducer is not None:
+            reducer.launch(self.grad, (0, self.total))
+            reducer.wait()
+        self.t += 1
+        FcnTrainer._apply(self, 1.0)
+        self.repack()
+        return self.loss

@@ -290,13 +290,17 @@ class _RoundBf16STE(torch.autograd.Function):
         return g
 
 
-def fcn_loss_and_grads(x_nhwc, labels, weights, prefix, num_classes, policy='fp32'):
+def fcn_loss_and_grads(x_nhwc, labels, weights, prefix, num_classes, policy='fp32', batch_norm=False, layers_out=None):
     """Returns (loss, {variable name: gradient ndarray}) for the trainable variables
     (kernels + biases of the 13 convs, the two score convs and `score`; the deconv
     constants are not trainable, simple_fcn.py:80-83,117-119).  policy='bf16' rounds the
     forward activations / conv weights where the MI355X path does (straight-through), so that
-    relu masks and max-pool routing are those of the bf16 forward pass."""
-    params = {}
+    relu masks and max-pool routing are those of the bf16 forward pass.
+    batch_norm=True: the training graph of `batch_normalization: true` (custom_layers.py:112-119,124-139):
+    tf.layers.batch_normalization(training=True) between every conv / deconv and its activation -- statistics
+    over (N, H, W), biased variance, eps 1e-3 -- with trainable gamma / beta ([TF1]); the third return value is
+    then {layer: (batch mean, unbiased batch variance)} (what the moving averages are fed)."""
+    params, stats = {}, {}
     rnd = (lambda t: t) if policy == 'fp32' else _RoundBf16STE.apply
 
     def P(name):
@@ -304,20 +308,34 @@ def fcn_loss_and_grads(x_nhwc, labels, weights, prefix, num_classes, policy='fp3
         params[name] = t
         return t
 
+    def bn(y, layer):
+        if not batch_norm:
+            return y
+        g, b = P('%s/%s/gamma' % (prefix, layer)), P('%s/%s/beta' % (prefix, layer))
+        mean = y.mean(dim=(0, 2, 3), keepdim=True)
+        var = ((y - mean) ** 2).mean(dim=(0, 2, 3), keepdim=True)
+        m = y.shape[0] * y.shape[2] * y.shape[3]
+        stats[layer] = (mean.detach().numpy().ravel(), (var.detach().numpy().ravel() * m / max(m - 1, 1)))
+        return (y - mean) / torch.sqrt(var + 1e-3) * g.view(1, -1, 1, 1) + b.view(1, -1, 1, 1)
+
     def conv(h, layer, relu):
         w = P('%s/%s/kernel' % (prefix, layer))
         b = P('%s/%s/bias' % (prefix, layer))
         k = w.shape[0]
         wq = w if layer in ('conv1_1', 'score') else rnd(w)
         y = F.conv2d(h, wq.permute(3, 2, 0, 1), b, padding=(k - 1) // 2)
+        if batch_norm:
+            y = bn(y if layer == 'score' else rnd(y), layer)      # the pre-normalisation map is stored (bf16) too
         y = F.relu(y) if relu else y
         return y if layer == 'score' else rnd(y)
 
     def deconv(h, layer, stride):
         w = _t(weights['%s/%s/kernel' % (prefix, layer)])
         k = w.shape[0]
-        return F.relu(F.conv_transpose2d(h, w.permute(3, 2, 0, 1).contiguous(), stride=stride,
-                                         padding=(k - stride) // 2))
+        y = F.conv_transpose2d(h, w.permute(3, 2, 0, 1).contiguous(), stride=stride, padding=(k - stride) // 2)
+        if batch_norm:
+            y = rnd(bn(rnd(y), layer))
+        return F.relu(y)
 
     h = _t(np.asarray(x_nhwc, np.float32)).permute(0, 3, 1, 2).contiguous()
     layers = {}
@@ -338,7 +356,15 @@ def fcn_loss_and_grads(x_nhwc, labels, weights, prefix, num_classes, policy='fp3
     onehot = F.one_hot(lab.clamp(0, num_classes - 1), num_classes).float() * valid[..., None].float()
     loss = -(onehot * logp).sum() / (1e-20 + onehot.sum())          # utils.py:43-53
     loss.backward()
-    return float(loss.detach()), {k: v.grad.numpy() for k, v in params.items()}
+    if layers_out is not None:       # post-activation maps (NHWC) for debugging / tests
+        layers.update(score_conv4=s4, score_conv5=s5, fused=fused, upscore=up)
+        for k, v in layers.items():
+            layers_out[k] = v.detach().permute(0, 2, 3, 1).numpy()
+        layers_out['score'] = score.detach().numpy()
+    grads = {k: v.grad.numpy() for k, v in params.items()}
+    if batch_norm:
+        return float(loss.detach()), grads, stats
+    return float(loss.detach()), grads
 
 
 # ---- fusion_fcn: the joint two-stream baseline (xview/models/fusion_fcn.py:11-40, vgg16.py:7-51) --------------

@@ -275,3 +275,78 @@ def test_training_step_gradients_and_fit(ops, tmp_path):
     assert net.global_step == 2
     out = net.export_weights()
     assert np.load(out)['rgb/conv1_1/kernel'].shape == (3, 3, 3, 64)
+
+
+def test_training_step_with_batch_normalization(ops, tmp_path):
+    """`batch_normalization: true` (the reference's example configuration): one step of the batch-norm training graph
+    against autograd over the oracle's restatement of it -- loss, gradients of kernels / gamma / beta, moving averages
+    ([TF1]: momentum 0.99, unbiased variance); then fit() and inference with the trained statistics.
+
+    Tolerances are calibrated, not guessed: a randomly initialised 16-layer batch-norm network is chaotic with respect
+    to bf16 rounding -- perturbing the oracle's own kernels by 3e-7 (fp32 rounding level, i.e. a different summation
+    order) moves ITS bf16-policy gradients by 1 % at `score/gamma`, 10 % at `score/kernel` and 25-40 % (cosine
+    0.91-0.97) from conv5 down to conv1 (relu masks and pool routes flip on near-ties and every batch statistic
+    downstream moves).  The step below sits at exactly that noise floor; every kernel on the path is checked tightly on
+    its own in tests/test_batchnorm_gpu.py and the exact-integer conv tests above."""
+    from modular_semantic_segmentation_amd import get_model
+    from modular_semantic_segmentation_amd.fcn import init_variables
+    C, U, H, W = 12, 64, 64, 96
+    rng = np.random.default_rng(0)
+    data = {'rgb': rng.integers(0, 256, (2, H, W, 3)).astype(np.float32),
+            'labels': rng.integers(-1, C, (2, H, W)).astype(np.int32)}
+    w = init_variables('rgb', 3, U, C, batch_normalization=True, seed=1)
+    for k in w:
+        if k.endswith('/gamma'):
+            w[k] = rng.uniform(0.8, 1.2, w[k].shape).astype(np.float32)
+        elif k.endswith('/beta'):
+            w[k] = (0.1 * rng.standard_normal(w[k].shape)).astype(np.float32)
+        elif k.endswith('/bias'):
+            w[k] = (0.02 * rng.standard_normal(w[k].shape)).astype(np.float32)
+    path = str(tmp_path / 'w.npz')
+    np.savez(path, **w)
+    desc = ({'rgb': 'float32', 'labels': 'int32'}, {'rgb': (None, None, 3), 'labels': (None, None)}, C)
+    net = get_model('fcn')('rgb', desc, 'rgb', output_dir=str(tmp_path), num_units=U, batch_normalization=True,
+                           batchsize=2, learning_rate=1e-3, trainer='adam')
+    net.import_weights(path, warnings=False)
+    tr = net._ensure_trainer()
+    loss = tr.step(_dev(data['rgb']), _dev(data['labels']))
+    torch.cuda.synchronize()
+    got = tr.grads_as_variables()
+    ref_loss, ref_g, stats = fo.fcn_loss_and_grads(data['rgb'], data['labels'], w, 'rgb', C, policy='bf16', batch_norm=True)
+    assert abs(loss.item() - ref_loss) < 1e-2 * abs(ref_loss)
+    # conv biases in front of a batch norm have an exactly zero gradient (the mean is subtracted): not compared
+    names = [k for k in ref_g if not k.endswith('/bias')]
+    rel = {k: _rel(got[k], ref_g[k]) for k in names}
+    cos = {}
+    for k in names:
+        a, b = got[k].ravel().astype(np.float64), ref_g[k].ravel().astype(np.float64)
+        cos[k] = a @ b / (np.linalg.norm(a) * np.linalg.norm(b))
+    print('gradient vs the bf16-policy oracle (batch norm): relative error, cosine')
+    for k in sorted(names):
+        print('  %-30s %.4f %.4f' % (k, rel[k], cos[k]))
+    assert rel['rgb/score/gamma'] < 0.05 and rel['rgb/score/beta'] < 0.08, (rel['rgb/score/gamma'], rel['rgb/score/beta'])
+    assert rel['rgb/score/kernel'] < 0.25 and rel['rgb/upscore/gamma'] < 0.25
+    assert min(cos.values()) > 0.85, min(cos.items(), key=lambda kv: kv[1])
+    assert max(rel.values()) < 0.7, max(rel.items(), key=lambda kv: kv[1])
+    # moving averages after one step ([TF1] momentum 0.99; the unbiased batch variance goes into the average)
+    out = {}
+    tr.to_variables(out)
+    for layer in ('conv1_1', 'conv2_1', 'conv3_2', 'score_conv4', 'upscore', 'score'):
+        mean, var = stats[layer]
+        np.testing.assert_allclose(out['rgb/%s/moving_mean' % layer], 0.99 * w['rgb/%s/moving_mean' % layer] + 0.01 * mean,
+                                   rtol=5e-2, atol=5e-3, err_msg=layer)
+        np.testing.assert_allclose(out['rgb/%s/moving_variance' % layer],
+                                   0.99 * w['rgb/%s/moving_variance' % layer] + 0.01 * var, rtol=5e-2, atol=5e-3,
+                                   err_msg=layer)
+    # training lowers the loss on a fixed batch, and inference afterwards uses the trained moving statistics
+    first = net._train_batch(data)
+    for _ in range(10):
+        last = net._train_batch(data)
+    assert last < first
+    label = net.predict(data)
+    assert label.shape == (2, H, W) and label.dtype == np.int64
+    exported = np.load(net.export_weights())
+    assert exported['rgb/conv2_1/moving_variance'].shape == (128,)
+    ref = fo.fcn_forward(data['rgb'], {k: exported[k] for k in exported.files}, 'rgb', 'bf16')['score']
+    score = net.predict(data, output_attr='score')
+    assert np.abs(score - ref).max() < 5e-2 * np.abs(ref).max()
