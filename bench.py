@@ -112,7 +112,7 @@ def bench_train(args, device, world, rank, dist):
     all-reduced in three buckets on a side stream during backward (RCCL over xGMI)."""
     from modular_semantic_segmentation_amd import get_model
     desc = ({'rgb': 'float32', 'labels': 'int32'}, {'rgb': (None, None, 3), 'labels': (None, None)}, C)
-    net = get_model('fcn')('rgb', desc, 'rgb', num_units=U, batch_normalization=False, batchsize=args.batch,
+    net = get_model('fcn')('rgb', desc, 'rgb', num_units=U, batch_normalization=bool(args.batch_norm), batchsize=args.batch,
                            learning_rate=1e-4, trainer='adam', seed=1, device=str(device), sync_loss=False)
     gen = torch.Generator(device='cpu').manual_seed(99 + rank)
     rgb = torch.randint(0, 256, (args.batch, args.height, args.width, 3), generator=gen).float().to(device)
@@ -141,7 +141,8 @@ def bench_train(args, device, world, rank, dist):
         images = args.batch * world * args.steps
         flops = 3.0 * conv_flops_per_image(args.height, args.width, 3)
         print(json.dumps({
-            'metric': 'images/sec, SimpleFCN RGB expert training step (fwd + bwd + Adam) at 768x384',
+            'metric': 'images/sec, SimpleFCN RGB expert training step (fwd + bwd + Adam%s) at %dx%d' % (
+                ', batch norm' if args.batch_norm else '', args.width, args.height),
             'value': round(images / dt, 2), 'unit': 'images/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
@@ -158,6 +159,7 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--batch-norm', action='store_true', help='train mode: the batch_normalization=true training graph')
     ap.add_argument('--layer-profile', action='store_true', help='print per-conv-launch times of the roofline pass')
     ap.add_argument('--batch', type=int, default=16, help='images per GPU per step')
     ap.add_argument('--height', type=int, default=384)

@@ -395,30 +395,53 @@ __global__ __launch_bounds__(256) void softmax_ce_dense_kernel(const float* __re
 }
 
 // dws[u][c] += sum_pix u[pix][u] * ds[pix][c]; dbs[c] += sum_pix ds[pix][c].  Thread (uu = t % 64, g = t / 64) owns
-// channels uu, uu+64, .. and classes g, g+4, ..; a block walks a contiguous run of pixels.
+// channels uu, uu+64, .. and classes g, g+4, ..; a block walks a contiguous run of pixels in tiles of 64 that are
+// staged through LDS (coalesced 16-byte loads; the inner loop then reads LDS only).
 template <int CM>
 __global__ __launch_bounds__(256) void score_dense_wgrad_kernel(const __bf16* __restrict__ u, const float* __restrict__ ds,
                                                                float* __restrict__ dws, float* __restrict__ dbs, int N,
                                                                int H, int W, int U, int C, int64_t per_block) {
-  const int uu = threadIdx.x & 63, g = threadIdx.x >> 6;
+  constexpr int TP = 64;  // pixels per tile
   constexpr int KC = CM / 4;
+  __shared__ __attribute__((aligned(16))) __bf16 ut[TP][64 + 8];  // +8: rows 144 B apart, conflict-free column reads
+  __shared__ float dt[TP][CM];
+  const int uu = threadIdx.x & 63, g = threadIdx.x >> 6;
   const int64_t npix = (int64_t)N * H * W;
   const int64_t p0 = (int64_t)blockIdx.x * per_block, p1 = p0 + per_block < npix ? p0 + per_block : npix;
   for (int ub = 0; ub < U; ub += 64) {
     float acc[KC], bacc[KC];
 #pragma unroll
     for (int k = 0; k < KC; ++k) acc[k] = bacc[k] = 0.f;
-    for (int64_t p = p0; p < p1; ++p) {
-      const int x = (int)(p % W);
-      const int64_t r = p / W;
-      const int yy = (int)(r % H), n = (int)(r / H);
-      const float f = (float)u[(((int64_t)n * (H + 2) + yy + 1) * (W + 2) + x + 1) * U + ub + uu];
+    for (int64_t t0 = p0; t0 < p1; t0 += TP) {
+      __syncthreads();
+      // stage: 64 pixels x 64 channels (8 x 16-byte pieces per pixel) and 64 x C gradients
+      for (int i = threadIdx.x; i < TP * 8; i += 256) {
+        const int pp = i >> 3, piece = i & 7;
+        const int64_t p = t0 + pp;
+        u32x4 v = u32x4{0u, 0u, 0u, 0u};
+        if (p < p1) {
+          const int x = (int)(p % W);
+          const int64_t r = p / W;
+          const int yy = (int)(r % H), n = (int)(r / H);
+          v = *reinterpret_cast<const u32x4*>(u + (((int64_t)n * (H + 2) + yy + 1) * (W + 2) + x + 1) * U + ub + piece * 8);
+        }
+        *reinterpret_cast<u32x4*>(&ut[pp][piece * 8]) = v;
+      }
+      for (int i = threadIdx.x; i < TP * CM; i += 256) {
+        const int pp = i / CM, c = i - pp * CM;
+        const int64_t p = t0 + pp;
+        dt[pp][c] = (p < p1 && c < C) ? ds[p * C + c] : 0.f;
+      }
+      __syncthreads();
+#pragma unroll 8
+      for (int pp = 0; pp < TP; ++pp) {
+        const float f = (float)ut[pp][uu];
 #pragma unroll
-      for (int k = 0; k < KC; ++k) {
-        const int c = g + 4 * k;
-        const float d = c < C ? ds[p * C + c] : 0.f;
-        acc[k] = fmaf(f, d, acc[k]);
-        bacc[k] += d;
+        for (int k = 0; k < KC; ++k) {
+          const float d = dt[pp][g + 4 * k];
+          acc[k] = fmaf(f, d, acc[k]);
+          bacc[k] += d;
+        }
       }
     }
 #pragma unroll
@@ -628,7 +651,7 @@ extern "C" int xv_score_dense_bwd(const xv_act* u, const float* dscore, const fl
   XV_CHECK_ARG(u && u->data && dscore && w_score && dw_score && db_score && du && du->data);
   XV_CHECK_SHAPE((u->c & 63) == 0 && u->c <= 256 && num_classes >= 1 && num_classes <= 32 && same_shape(u, du));
   const int64_t npix = (int64_t)u->n * u->h * u->w;
-  const int64_t per_block = 512;
+  const int64_t per_block = 2048;
   const unsigned gw = (unsigned)((npix + per_block - 1) / per_block);
   const int64_t total = npix * (u->c >> 3);
   hipStream_t s = (hipStream_t)stream;
