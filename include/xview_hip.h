@@ -261,12 +261,24 @@ int xv_bn_apply(const xv_act* z, const float* scale, const float* shift, int rel
 /* dz = gamma*invstd*(g - mean(g) - zhat*mean(g*zhat)), g = dy*(y>0); dgamma += sum g*zhat, dbeta += sum g.      */
 int xv_bn_bwd(const xv_act* dy, const xv_act* y, const xv_act* z, const float* mean, const float* invstd,
               const float* gamma, double* sums, float* dgamma, float* dbeta, const xv_act* dz, void* stream);
+/* The gradient in two steps for data-parallel callers (Sync-BN): xv_bn_bwd_reduce fills `sums` with the LOCAL
+ * sum g / sum g*zhat and adds them into dgamma / dbeta; the caller may all-reduce `sums`; xv_bn_bwd_apply then forms
+ * dz from `sums` and `count` (the global N*H*W).                                                                    */
+int xv_bn_bwd_reduce(const xv_act* dy, const xv_act* y, const xv_act* z, const float* mean, const float* invstd,
+                     double* sums, float* dgamma, float* dbeta, void* stream);
+int xv_bn_bwd_apply(const xv_act* dy, const xv_act* y, const xv_act* z, const float* mean, const float* invstd,
+                    const float* gamma, const double* sums, int64_t count, const xv_act* dz, void* stream);
 /* The same on a dense float32 [rows][C] tensor, C <= 32 (the batch norm on `score`, simple_fcn.py:131-133).        */
 int xv_bn_dense_stats(const float* z, int64_t rows, int channels, double* sums, void* stream);
 int xv_bn_dense_apply(const float* z, int64_t rows, int channels, const float* scale, const float* shift, float* y,
                       void* stream);
 int xv_bn_dense_bwd(const float* dy, const float* z, int64_t rows, int channels, const float* mean, const float* invstd,
                     const float* gamma, double* sums, float* dgamma, float* dbeta, float* dz, void* stream);
+int xv_bn_dense_bwd_reduce(const float* dy, const float* z, int64_t rows, int channels, const float* mean,
+                           const float* invstd, double* sums, float* dgamma, float* dbeta, void* stream);
+int xv_bn_dense_bwd_apply(const float* dy, const float* z, int64_t rows, int channels, const float* mean,
+                          const float* invstd, const float* gamma, const double* sums, int64_t count, float* dz,
+                          void* stream);
 
 /* ---- un-commuted training head (batch norm between the x8 deconv and its relu) ---------------------
  * y = bilinear_x{2,8}(x) with no activation (deconv2d with the constant kernel, custom_layers.py:8-25,71-110) and its

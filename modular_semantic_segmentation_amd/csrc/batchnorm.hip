@@ -526,10 +526,13 @@ extern "C" int xv_bn_apply(const xv_act* z, const float* scale, const float* shi
   return xv_launch_status();
 }
 
-extern "C" int xv_bn_bwd(const xv_act* dy, const xv_act* y, const xv_act* z, const float* mean, const float* invstd,
-                         const float* gamma, double* sums, float* dgamma, float* dbeta, const xv_act* dz, void* stream) {
-  XV_CHECK_ARG(dy && z && dz && dy->data && z->data && dz->data && mean && invstd && gamma && sums && dgamma && dbeta);
-  XV_CHECK_SHAPE(same_shape(dy, z) && same_shape(dz, z) && z->c >= 64 && 2048 % z->c == 0);
+// The gradient in two steps, so that a data-parallel caller can all-reduce `sums` in between (Sync-BN): the reduce
+// step also adds the LOCAL sums into dgamma / dbeta (the gradient all-reduce sums those over ranks), the apply step
+// uses whatever `sums` / `count` hold by then (global under Sync-BN).
+extern "C" int xv_bn_bwd_reduce(const xv_act* dy, const xv_act* y, const xv_act* z, const float* mean,
+                                const float* invstd, double* sums, float* dgamma, float* dbeta, void* stream) {
+  XV_CHECK_ARG(dy && z && dy->data && z->data && mean && invstd && sums && dgamma && dbeta);
+  XV_CHECK_SHAPE(same_shape(dy, z) && z->c >= 64 && 2048 % z->c == 0);
   const __bf16* yp = nullptr;
   if (y && y->data) {
     XV_CHECK_SHAPE(same_shape(y, z));
@@ -539,13 +542,31 @@ extern "C" int xv_bn_bwd(const xv_act* dy, const xv_act* y, const xv_act* z, con
   hipError_t e = hipMemsetAsync(sums, 0, sizeof(double) * 2 * z->c, s);
   if (e != hipSuccess) return (int)e;
   const int64_t total = (int64_t)z->n * z->h * z->w * (z->c >> 3);
-  const double M = (double)z->n * z->h * z->w;
   hipLaunchKernelGGL(bn_reduce_kernel<1>, dim3(bn_grid(total, 1024)), dim3(256), 0, s, (const __bf16*)z->data,
                      (const __bf16*)dy->data, yp, mean, invstd, sums, z->n, z->h, z->w, z->c);
-  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(bn_grid(total, 8192)), dim3(256), 0, s, (const __bf16*)dy->data, yp,
-                     (const __bf16*)z->data, mean, invstd, gamma, sums, M, (__bf16*)dz->data, z->n, z->h, z->w, z->c);
   hipLaunchKernelGGL(bn_grads_kernel, dim3((z->c + 63) / 64), dim3(64), 0, s, sums, z->c, dgamma, dbeta);
   return xv_launch_status();
+}
+
+extern "C" int xv_bn_bwd_apply(const xv_act* dy, const xv_act* y, const xv_act* z, const float* mean,
+                               const float* invstd, const float* gamma, const double* sums, int64_t count,
+                               const xv_act* dz, void* stream) {
+  XV_CHECK_ARG(dy && z && dz && dy->data && z->data && dz->data && mean && invstd && gamma && sums);
+  XV_CHECK_SHAPE(same_shape(dy, z) && same_shape(dz, z) && (z->c & 7) == 0 && count > 0);
+  const __bf16* yp = (y && y->data) ? (const __bf16*)y->data : nullptr;
+  const int64_t total = (int64_t)z->n * z->h * z->w * (z->c >> 3);
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(bn_grid(total, 8192)), dim3(256), 0, (hipStream_t)stream,
+                     (const __bf16*)dy->data, yp, (const __bf16*)z->data, mean, invstd, gamma, sums, (double)count,
+                     (__bf16*)dz->data, z->n, z->h, z->w, z->c);
+  return xv_launch_status();
+}
+
+extern "C" int xv_bn_bwd(const xv_act* dy, const xv_act* y, const xv_act* z, const float* mean, const float* invstd,
+                         const float* gamma, double* sums, float* dgamma, float* dbeta, const xv_act* dz, void* stream) {
+  XV_CHECK_ARG(dz && z);
+  const int rc = xv_bn_bwd_reduce(dy, y, z, mean, invstd, sums, dgamma, dbeta, stream);
+  if (rc != XV_OK) return rc;
+  return xv_bn_bwd_apply(dy, y, z, mean, invstd, gamma, sums, (int64_t)z->n * z->h * z->w, dz, stream);
 }
 
 extern "C" int xv_bn_dense_stats(const float* z, int64_t rows, int channels, double* sums, void* stream) {
@@ -567,20 +588,35 @@ extern "C" int xv_bn_dense_apply(const float* z, int64_t rows, int channels, con
   return xv_launch_status();
 }
 
-extern "C" int xv_bn_dense_bwd(const float* dy, const float* z, int64_t rows, int channels, const float* mean,
-                               const float* invstd, const float* gamma, double* sums, float* dgamma, float* dbeta,
-                               float* dz, void* stream) {
-  XV_CHECK_ARG(dy && z && mean && invstd && gamma && sums && dgamma && dbeta && dz);
+extern "C" int xv_bn_dense_bwd_reduce(const float* dy, const float* z, int64_t rows, int channels, const float* mean,
+                                      const float* invstd, double* sums, float* dgamma, float* dbeta, void* stream) {
+  XV_CHECK_ARG(dy && z && mean && invstd && sums && dgamma && dbeta);
   XV_CHECK_SHAPE(rows > 0 && channels >= 1 && channels <= 32);
   hipStream_t s = (hipStream_t)stream;
   hipError_t e = hipMemsetAsync(sums, 0, sizeof(double) * 2 * channels, s);
   if (e != hipSuccess) return (int)e;
   hipLaunchKernelGGL(bn_dense_reduce_kernel<1>, dim3(bn_grid(rows, 1024)), dim3(256), 0, s, z, dy, mean, invstd, sums,
                      rows, channels);
-  hipLaunchKernelGGL(bn_dense_bwd_apply_kernel, dim3(bn_grid(rows * channels, 8192)), dim3(256), 0, s, dy, z, mean,
-                     invstd, gamma, sums, (double)rows, dz, rows * channels, channels);
   hipLaunchKernelGGL(bn_grads_kernel, dim3(1), dim3(64), 0, s, sums, channels, dgamma, dbeta);
   return xv_launch_status();
+}
+
+extern "C" int xv_bn_dense_bwd_apply(const float* dy, const float* z, int64_t rows, int channels, const float* mean,
+                                     const float* invstd, const float* gamma, const double* sums, int64_t count,
+                                     float* dz, void* stream) {
+  XV_CHECK_ARG(dy && z && mean && invstd && gamma && sums && dz);
+  XV_CHECK_SHAPE(rows > 0 && channels >= 1 && channels <= 32 && count > 0);
+  hipLaunchKernelGGL(bn_dense_bwd_apply_kernel, dim3(bn_grid(rows * channels, 8192)), dim3(256), 0, (hipStream_t)stream,
+                     dy, z, mean, invstd, gamma, sums, (double)count, dz, rows * channels, channels);
+  return xv_launch_status();
+}
+
+extern "C" int xv_bn_dense_bwd(const float* dy, const float* z, int64_t rows, int channels, const float* mean,
+                               const float* invstd, const float* gamma, double* sums, float* dgamma, float* dbeta,
+                               float* dz, void* stream) {
+  const int rc = xv_bn_dense_bwd_reduce(dy, z, rows, channels, mean, invstd, sums, dgamma, dbeta, stream);
+  if (rc != XV_OK) return rc;
+  return xv_bn_dense_bwd_apply(dy, z, rows, channels, mean, invstd, gamma, sums, rows, dz, stream);
 }
 
 extern "C" int xv_upsample_raw_fwd(const xv_act* x, int factor, const xv_act* y, void* stream) {

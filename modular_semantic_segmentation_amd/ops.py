@@ -383,32 +383,50 @@ class BnState(object):
         self.sums = torch.zeros(2 * channels, dtype=torch.float64, device=device)
 
 
-def bn_forward(z, gamma, beta, moving_mean, moving_var, st, y, relu=True):
-    """y = [relu](BN_batch(z)); updates the moving statistics in place (z, y: Act)."""
+def _sync_sums(st, sync):
+    """Sync-BN: sum the per-channel statistics over the data-parallel ranks (equal shards assumed); returns the factor
+    by which the local sample count grows."""
+    if not sync:
+        return 1
+    from .parallel import allreduce_sum_, world
+    allreduce_sum_(st.sums)
+    return world()[1]
+
+
+def bn_forward(z, gamma, beta, moving_mean, moving_var, st, y, relu=True, sync=False):
+    """y = [relu](BN_batch(z)); updates the moving statistics in place (z, y: Act).  sync: statistics over all
+    data-parallel ranks (one all-reduce of 2*C doubles)."""
     lib = _lib.lib()
     _lib.check(lib.xv_bn_stats(z.xv(), _ptr(st.sums), _stream()), 'xv_bn_stats')
-    _lib.check(lib.xv_bn_finalize(_ptr(st.sums), st.c, z.n * z.h * z.w, _ptr(gamma), _ptr(beta), BN_EPS, BN_MOMENTUM,
-                                  _ptr(moving_mean), _ptr(moving_var), _ptr(st.mean), _ptr(st.invstd), _ptr(st.scale),
-                                  _ptr(st.shift), _stream()), 'xv_bn_finalize')
+    mult = _sync_sums(st, sync)
+    _lib.check(lib.xv_bn_finalize(_ptr(st.sums), st.c, z.n * z.h * z.w * mult, _ptr(gamma), _ptr(beta), BN_EPS,
+                                  BN_MOMENTUM, _ptr(moving_mean), _ptr(moving_var), _ptr(st.mean), _ptr(st.invstd),
+                                  _ptr(st.scale), _ptr(st.shift), _stream()), 'xv_bn_finalize')
     _lib.check(lib.xv_bn_apply(z.xv(), _ptr(st.scale), _ptr(st.shift), int(bool(relu)), y.xv(), _stream()), 'xv_bn_apply')
     return y
 
 
-def bn_backward(dy, y, z, gamma, st, dgamma, dbeta, dz):
-    """dz from dy (gradient w.r.t. the post-relu output; y = None: no activation); accumulates dgamma / dbeta."""
-    rc = _lib.lib().xv_bn_bwd(dy.xv(), y.xv() if y is not None else _NULL_ACT, z.xv(), _ptr(st.mean), _ptr(st.invstd),
-                              _ptr(gamma), _ptr(st.sums), _ptr(dgamma), _ptr(dbeta), dz.xv(), _stream())
-    _lib.check(rc, 'xv_bn_bwd')
+def bn_backward(dy, y, z, gamma, st, dgamma, dbeta, dz, sync=False):
+    """dz from dy (gradient w.r.t. the post-relu output; y = None: no activation); accumulates the LOCAL dgamma /
+    dbeta (the gradient all-reduce sums them over ranks)."""
+    lib = _lib.lib()
+    yx = y.xv() if y is not None else _NULL_ACT
+    _lib.check(lib.xv_bn_bwd_reduce(dy.xv(), yx, z.xv(), _ptr(st.mean), _ptr(st.invstd), _ptr(st.sums), _ptr(dgamma),
+                                    _ptr(dbeta), _stream()), 'xv_bn_bwd_reduce')
+    mult = _sync_sums(st, sync)
+    _lib.check(lib.xv_bn_bwd_apply(dy.xv(), yx, z.xv(), _ptr(st.mean), _ptr(st.invstd), _ptr(gamma), _ptr(st.sums),
+                                   z.n * z.h * z.w * mult, dz.xv(), _stream()), 'xv_bn_bwd_apply')
     return dz
 
 
-def bn_dense_forward(z, gamma, beta, moving_mean, moving_var, st, y):
+def bn_dense_forward(z, gamma, beta, moving_mean, moving_var, st, y, sync=False):
     """The same on a dense float32 [..., C] tensor (no activation)."""
     lib = _lib.lib()
     c = z.shape[-1]
     rows = z.numel() // c
     _lib.check(lib.xv_bn_dense_stats(_ptr(z), rows, c, _ptr(st.sums), _stream()), 'xv_bn_dense_stats')
-    _lib.check(lib.xv_bn_finalize(_ptr(st.sums), c, rows, _ptr(gamma), _ptr(beta), BN_EPS, BN_MOMENTUM,
+    mult = _sync_sums(st, sync)
+    _lib.check(lib.xv_bn_finalize(_ptr(st.sums), c, rows * mult, _ptr(gamma), _ptr(beta), BN_EPS, BN_MOMENTUM,
                                   _ptr(moving_mean), _ptr(moving_var), _ptr(st.mean), _ptr(st.invstd), _ptr(st.scale),
                                   _ptr(st.shift), _stream()), 'xv_bn_finalize')
     _lib.check(lib.xv_bn_dense_apply(_ptr(z), rows, c, _ptr(st.scale), _ptr(st.shift), _ptr(y), _stream()),
@@ -416,12 +434,15 @@ def bn_dense_forward(z, gamma, beta, moving_mean, moving_var, st, y):
     return y
 
 
-def bn_dense_backward(dy, z, gamma, st, dgamma, dbeta, dz):
+def bn_dense_backward(dy, z, gamma, st, dgamma, dbeta, dz, sync=False):
+    lib = _lib.lib()
     c = z.shape[-1]
     rows = z.numel() // c
-    rc = _lib.lib().xv_bn_dense_bwd(_ptr(dy), _ptr(z), rows, c, _ptr(st.mean), _ptr(st.invstd), _ptr(gamma),
-                                    _ptr(st.sums), _ptr(dgamma), _ptr(dbeta), _ptr(dz), _stream())
-    _lib.check(rc, 'xv_bn_dense_bwd')
+    _lib.check(lib.xv_bn_dense_bwd_reduce(_ptr(dy), _ptr(z), rows, c, _ptr(st.mean), _ptr(st.invstd), _ptr(st.sums),
+                                          _ptr(dgamma), _ptr(dbeta), _stream()), 'xv_bn_dense_bwd_reduce')
+    mult = _sync_sums(st, sync)
+    _lib.check(lib.xv_bn_dense_bwd_apply(_ptr(dy), _ptr(z), rows, c, _ptr(st.mean), _ptr(st.invstd), _ptr(gamma),
+                                         _ptr(st.sums), rows * mult, _ptr(dz), _stream()), 'xv_bn_dense_bwd_apply')
     return dz
 
 

@@ -265,7 +265,7 @@ class FcnBnTrainer(object):
     batch-norm gradient; the decoder head is un-commuted (the x8 bilinear map is materialised at full resolution,
     normalised, scored per pixel and normalised again).  gamma / beta are trained ([TF1] defaults), the moving
     averages (momentum 0.99, unbiased variance) are updated in the forward pass like the reference's UPDATE_OPS
-    control dependency (base_model.py:155-156).  Data-parallel runs use per-rank batch statistics."""
+    control dependency (base_model.py:155-156).  Data-parallel runs synchronise the batch statistics (Sync-BN)."""
 
     def __init__(self, engine, trainer='adam', learning_rate=1e-4):
         if trainer not in ('adam', 'rmsprop', 'adagrad'):
@@ -413,11 +413,12 @@ class FcnBnTrainer(object):
     def _bn_fwd(self, name, z, y, relu=True):
         mm, mv = self.moving[name]
         return ops.bn_forward(z, self.view(self.param, name, 'gamma'), self.view(self.param, name, 'beta'), mm, mv,
-                              self.bn[name], y, relu=relu)
+                              self.bn[name], y, relu=relu, sync=self._sync)
 
     def _bn_bwd(self, name, dy, y, z, dz):
         return ops.bn_backward(dy, y, z, self.view(self.param, name, 'gamma'), self.bn[name],
-                               self.view(self.grad, name, 'gamma'), self.view(self.grad, name, 'beta'), dz)
+                               self.view(self.grad, name, 'gamma'), self.view(self.grad, name, 'beta'), dz,
+                               sync=self._sync)
 
     # ---- one training step ----------------------------------------------------------------------------------
     def step(self, x, labels, reducer=None):
@@ -431,6 +432,9 @@ class FcnBnTrainer(object):
         self.loss.zero_()
         self.count.zero_()
         ops.count_valid_labels(labels, e.C, self.count)
+        # Sync-BN under data parallelism: batch statistics (and their gradient sums) over the GLOBAL batch, one small
+        # all-reduce per batch norm and direction, so that N ranks reproduce a single device on the whole batch
+        self._sync = reducer is not None
         if reducer is not None:
             reducer.allreduce_now(self.count)
         # ---- forward: z = conv + bias, y = relu(BN(z)), pools on y ---------------------------------------
@@ -465,11 +469,11 @@ class FcnBnTrainer(object):
                                         self._dense('score_raw', (n, h, w, e.C)))
         mm, mv = self.moving['score']
         logits = ops.bn_dense_forward(score_raw, P('score', 'gamma'), P('score', 'beta'), mm, mv, self.bn['score'],
-                                      self._dense('logits', (n, h, w, e.C)))
+                                      self._dense('logits', (n, h, w, e.C)), sync=self._sync)
         dlogits = ops.softmax_ce_dense(logits, labels, self.count, e.C, self.loss, self._dense('dlogits', (n, h, w, e.C)))
         # ---- backward ------------------------------------------------------------------------------------------
         dscore = ops.bn_dense_backward(dlogits, score_raw, P('score', 'gamma'), self.bn['score'], G('score', 'gamma'),
-                                       G('score', 'beta'), self._dense('dscore', (n, h, w, e.C)))
+                                       G('score', 'beta'), self._dense('dscore', (n, h, w, e.C)), sync=self._sync)
         du = ops.score_dense_bwd(Y['upscore'], dscore, self.w['score'], e.C, G('score', 'kernel'), G('score', 'bias'),
                                  self._act('d_up', n, h, w, e.Up))
         dz_up = self._bn_bwd('upscore', du, Y['upscore'], Z['upscore'], du)                 # in place

@@ -29,24 +29,24 @@ def _data():
             'labels': rng.integers(-1, C, (2, H, W)).astype(np.int32)}
 
 
-def _make_net(batchsize):
+def _make_net(batchsize, bn=False):
     from modular_semantic_segmentation_amd import get_model
     desc = ({'rgb': 'float32', 'labels': 'int32'}, {'rgb': (None, None, 3), 'labels': (None, None)}, C)
-    net = get_model('fcn')('rgb', desc, 'rgb', num_units=U, batch_normalization=False, batchsize=batchsize,
+    net = get_model('fcn')('rgb', desc, 'rgb', num_units=U, batch_normalization=bn, batchsize=batchsize,
                            learning_rate=1e-3, trainer='rmsprop', seed=5)
     net.variables['rgb/conv1_1/kernel'] = net.variables['rgb/conv1_1/kernel'] * 0.05
     net._variables_changed()
     return net
 
 
-def _worker(rank, size, port, out):
+def _worker(rank, size, port, out, bn=False, hw=None):
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
     torch.cuda.set_device(0)
     dist.init_process_group('gloo', rank=rank, world_size=size)
     from modular_semantic_segmentation_amd import parallel
-    net = _make_net(1)
-    shard = parallel.shard_data(_data())
+    net = _make_net(1, bn)
+    shard = parallel.shard_data(_data() if hw is None else _data_hw(*hw))
     loss = net._train_batch(shard)
     net._sync_variables()
     if rank == 0:
@@ -70,3 +70,36 @@ def test_two_rank_training_step_equals_single_process(tmp_path):
         if name.endswith('/kernel') and 'upscore' not in name:
             # RMSProp's first step is lr*g/sqrt(0.9+0.1 g^2): continuous in g, so fp32-atomic ordering noise stays tiny
             np.testing.assert_allclose(a, ref, rtol=0, atol=2e-5, err_msg=name)
+
+
+def _data_hw(h, w):
+    rng = np.random.default_rng(3)
+    # two visibly different images, so that per-rank statistics would differ from the global ones
+    rgb = np.stack([rng.integers(0, 128, (h, w, 3)), rng.integers(96, 256, (h, w, 3))]).astype(np.float32)
+    return {'rgb': rgb, 'labels': rng.integers(-1, C, (2, h, w)).astype(np.int32)}
+
+
+def test_two_rank_batch_norm_training_uses_global_statistics(tmp_path):
+    """Sync-BN: with batch_normalization=True two ranks (one image each) all-reduce every layer's statistics, so the
+    moving averages after one step are those of the WHOLE batch, as in a single process -- per-rank statistics of the two
+    deliberately different images would be far off.  (Weights are compared loosely: see the calibration note in
+    tests/test_backward_gpu.py on how bf16 rounding noise spreads through a batch-norm network.)"""
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU')
+    hw = (64, 96)
+    out = str(tmp_path / 'dp_bn.npz')
+    mp.spawn(_worker, args=(2, _free_port(), out, True, hw), nprocs=2, join=True)
+    got = np.load(out)
+    net = _make_net(2, True)
+    net._train_batch(_data_hw(*hw))
+    net._sync_variables()
+    for layer in ('conv1_1', 'conv1_2', 'conv2_1', 'conv3_1'):
+        for v in ('moving_mean', 'moving_variance'):
+            name = 'rgb/%s/%s' % (layer, v)
+            a, ref = got[name.replace('/', '__')], net.variables[name]
+            init = 0.0 if v == 'moving_mean' else 1.0
+            # compare the UPDATE (1 % of the batch statistic), which is what distinguishes global from per-rank
+            upd_a, upd_ref = (a - 0.99 * init) / 0.01, (ref - 0.99 * init) / 0.01
+            assert np.abs(upd_a - upd_ref).max() < 0.03 * np.abs(upd_ref).max() + 1e-3, name
+    a, ref = got['rgb__score__gamma'], net.variables['rgb/score/gamma']
+    np.testing.assert_allclose(a, ref, rtol=0, atol=3e-4)
