@@ -645,14 +645,6 @@ __device__ __forceinline__ u32x4 dma_store_piece(const u32x2 h0, const u32x2 h1,
   return o;
 }
 
-template <int I, int N, class F>
-__device__ __forceinline__ void xv_static_for(F&& f) {
-  if constexpr (I < N) {
-    f(std::integral_constant<int, I>{});
-    xv_static_for<I + 1, N>(f);
-  }
-}
-
 template <int WR, int WC>
 struct DmaCfg {
   static constexpr int MT = 4;
@@ -761,11 +753,7 @@ __global__ __launch_bounds__(64 * WR * WC, 2) void conv_dma_kernel(ConvArgs a) {
   // the source offset is recomputed with hy <= ylim, hx <= xlim; the LDS position (and its swizzle) is unchanged
   auto dma_a = [&](const char* xsrc, int it, int buf, bool edge, int ylim, int xlim) {
     const int piece = wave + it * C::NWAVES;
-#ifdef XV_SKIP_A
-    if (piece < 0) {
-#else
     if (piece < C::A_PIECES) {
-#endif
       int voff = aoff[it];
       if (edge) {
         const int g = piece * 64 + lane;
@@ -779,11 +767,7 @@ __global__ __launch_bounds__(64 * WR * WC, 2) void conv_dma_kernel(ConvArgs a) {
   };
   auto dma_b = [&](const char* wsrc, int it, int buf) {
     const int piece = wave + it * C::NWAVES;
-#ifdef XV_SKIP_B
-    if (piece < 0)
-#else
     if (piece < C::B_PIECES)
-#endif
       dma16(wsrc + (piece >> 2) * tap_pitch + (piece & 3) * 1024, lane16, 2 * C::A_BYTES + buf * C::B_BYTES + piece * 1024);
   };
   // the tile's 64 bias values ride along with its first chunk (one 4-byte-per-lane DMA by the last wave)
