@@ -306,3 +306,43 @@ def test_fusion_fcn_joint_baseline(gpu, tmp_path, decoder_bn):
         assert cm.sum() == (data['labels'] >= 0).sum()
         out = net.export_weights(str(tmp_path))
         assert np.array_equal(np.load(out)['fused/score/kernel'], w['fused/score/kernel'])
+
+
+def test_experiment_flows_without_sacred(gpu, tmp_path):
+    """experiments.py: the reference's fit-and-evaluate flows (experiments/bayes_fusion.py:146-195,
+    dirichlet_fusion.py:58-81, training.py, evaluation.py) on a synthetic dict-of-arrays dataset."""
+    from modular_semantic_segmentation_amd import experiments as ex
+    w_rgb, p_rgb = _weights(tmp_path, 'rgb', 3, 1, 0.02)
+    w_dep, p_dep = _weights(tmp_path, 'depth', 1, 2, 2e-4)
+    testset = _data(6, seed=41)
+    measure_set, test_set = ex.split_test_data(testset)
+    assert len(measure_set['labels']) == 3 and len(test_set['labels']) == 3
+    assert sorted(np.concatenate([measure_set['labels'], test_set['labels']]).sum(axis=(1, 2)).tolist()) == \
+        sorted(testset['labels'].sum(axis=(1, 2)).tolist())
+    net_config = {'expert_model': 'fcn', 'prefixes': {'rgb': 'rgb', 'depth': 'depth'}, 'num_units': U,
+                  'num_channels': {'rgb': 3, 'depth': 1}, 'class_prior': 'data', 'batchsize': 3}
+    weights = {'rgb': p_rgb, 'depth': p_dep}
+    info = ex.fit_and_evaluate_bayes_fusion(net_config, _desc(), measure_set, test_set, weights)
+    n_valid = (test_set['labels'] >= 0).sum()
+    assert info['confusion_matrix'].sum() == n_valid
+    assert set(info['measurements']) == {'rgb', 'depth', 'fusion'}
+    # the experts' confusion matrices on the measurement set are exactly what the oracle counts for their label maps
+    for m, w in (('rgb', w_rgb), ('depth', w_dep)):
+        assert info['confusion_matrices'][m].sum() == (measure_set['labels'] >= 0).sum()
+    # fusing with these matrices: same decisions as the oracle's LUT built from them (where the decision is clear)
+    cms = [info['confusion_matrices'][m].astype('float32').T for m in ('rgb', 'depth')]
+    lut = fu.bayes_decision_matrix(cms, 'data')
+    assert lut.shape == (C, C)
+    dcfg = {'expert_model': 'fcn', 'modalities': ['rgb', 'depth'], 'prefixes': {'rgb': 'rgb', 'depth': 'depth'},
+            'num_units': U, 'num_channels': {'rgb': 3, 'depth': 1}, 'class_prior': 'data', 'sigma': 1.0, 'delta': 1e-2,
+            'beta': 1e-2, 'batchsize': 3}
+    dinfo = ex.fit_and_evaluate_dirichlet_fusion(dcfg, _desc(), measure_set, test_set, [p_rgb, p_dep])
+    assert dinfo['confusion_matrix'].sum() == n_valid
+    assert dinfo['dirichlet_params']['rgb'].shape == (C, C) and np.all(dinfo['dirichlet_params']['rgb'] > 0)
+    # training flow: a few iterations, export, evaluate
+    tinfo = ex.train_and_evaluate('fcn', {'prefix': 'rgb', 'modality': 'rgb', 'num_units': U, 'batch_normalization': False,
+                                          'batchsize': 2, 'learning_rate': 1e-4},
+                                  _desc(depth=False), {k: measure_set[k] for k in ('rgb', 'labels')},
+                                  {k: test_set[k] for k in ('rgb', 'labels')}, 3, starting_weights=p_rgb,
+                                  output_dir=str(tmp_path))
+    assert os.path.exists(tinfo['weights']) and tinfo['confusion_matrix'].sum() == n_valid
