@@ -296,6 +296,22 @@ __global__ __launch_bounds__(256) void decoder_head_kernel(const float* __restri
 #pragma unroll
     for (int k = 1; k < CM; ++k)
       if (k < C) m = fmaxf(m, sc[k]);
+    if (!prob) {
+      // labels only (the experts of a Bayes fusion): argmax(softmax(x)) is argmax(x) unless the runner-up is so close
+      // that the two probabilities round to the same float (|difference| < ~1e-7); only then does the reference's
+      // tie rule (lowest index among equal PROBABILITIES) need the probabilities themselves
+      int bi = 0, near = 0;
+#pragma unroll
+      for (int k = CM - 1; k >= 0; --k)
+        if (k < C) {
+          if (sc[k] == m) bi = k;
+          near += (m - sc[k]) <= 1e-5f ? 1 : 0;
+        }
+      if (near == 1) {
+        label[opix] = bi;
+        return;
+      }
+    }
     float sum = 0.f;
 #pragma unroll
     for (int k = 0; k < CM; ++k) {
