@@ -308,6 +308,14 @@ class FcnBnTrainer(object):
         off, n, shape = self.offsets[(name, kind)]
         return buf[off:off + n].view(*shape)
 
+    def _real_channels(self, name):
+        """Channels of a batch norm that exist in the reference graph (the U-channel layers are padded to Up lanes)."""
+        if name == 'score':
+            return self.e.C
+        if name in ('score_conv4', 'score_conv5', 'upscore_conv5', 'upscore'):
+            return self.e.U
+        return self.bn_channels[name]
+
     def load_from_variables(self, e_variables=None, variables=None):
         if variables is None:
             return
@@ -316,7 +324,7 @@ class FcnBnTrainer(object):
         for name in BN_ORDER:
             layer = '%s/%s' % (p, name)
             c = self.bn_channels[name]
-            real = e.C if name == 'score' else (e.U if c == e.Up else c)
+            real = self._real_channels(name)
             if name in self.convs:
                 k = torch.from_numpy(np.asarray(variables[layer + '/kernel'], np.float32))
                 b = torch.from_numpy(np.asarray(variables[layer + '/bias'], np.float32))
@@ -346,7 +354,7 @@ class FcnBnTrainer(object):
         for name in BN_ORDER:
             layer = '%s/%s' % (p, name)
             c = self.bn_channels[name]
-            real = e.C if name == 'score' else (e.U if c == e.Up else c)
+            real = self._real_channels(name)
             if name in self.convs:
                 kv = self.view(self.param, name, 'kernel').cpu().numpy()
                 bv = self.view(self.param, name, 'bias').cpu().numpy()
@@ -367,7 +375,7 @@ class FcnBnTrainer(object):
         for name in BN_ORDER:
             layer = '%s/%s' % (p, name)
             c = self.bn_channels[name]
-            real = e.C if name == 'score' else (e.U if c == e.Up else c)
+            real = self._real_channels(name)
             if name in self.convs:
                 kv = self.view(self.grad, name, 'kernel').cpu().numpy()
                 bv = self.view(self.grad, name, 'bias').cpu().numpy()

@@ -346,3 +346,40 @@ def test_experiment_flows_without_sacred(gpu, tmp_path):
                                   {k: test_set[k] for k in ('rgb', 'labels')}, 3, starting_weights=p_rgb,
                                   output_dir=str(tmp_path))
     assert os.path.exists(tinfo['weights']) and tinfo['confusion_matrix'].sum() == n_valid
+
+
+def test_fusion_fcn_and_bn_training_with_padded_units(gpu, tmp_path):
+    """num_units = 20 (padded to 64 lanes inside the engines) and 14 classes: the joint model against the oracle,
+    and a few batch-norm training steps (the padding channels must stay exactly zero and the loss must fall)."""
+    from modular_semantic_segmentation_amd import get_model
+    from modular_semantic_segmentation_amd.fusion_fcn import FusionFcnEngine
+    u, c, h, w = 20, 14, 48, 80
+    prefixes, nch = {'rgb': 'rgb', 'depth': 'depth'}, {'rgb': 3, 'depth': 1}
+    wts = fo.init_fusion_fcn_weights(prefixes, nch, u, c, seed=9, bias_scale=0.02)
+    wts['rgb_conv1_1/kernel'] *= 0.02
+    wts['depth_conv1_1/kernel'] *= 2e-4
+    for k in wts:
+        if k.endswith('/kernel') and 'upscore' not in k and 'conv1_1' not in k:
+            wts[k] *= 1.6
+    rng = np.random.default_rng(10)
+    data = {'rgb': rng.integers(0, 256, (2, h, w, 3)).astype(np.float32),
+            'depth': rng.integers(0, 65536, (2, h, w, 1)).astype(np.float32)}
+    eng = FusionFcnEngine(prefixes, nch, u, c, wts)
+    out = eng.forward({m: torch.from_numpy(v).cuda() for m, v in data.items()}, want=('score', 'label'))
+    torch.cuda.synchronize()
+    ref = fo.fusion_fcn_forward(data, wts, prefixes, 'bf16')['score']
+    got = out['score'].cpu().numpy()
+    assert got.shape == (2, h, w, c)
+    assert np.abs(got - ref).max() < 2e-2 * np.abs(ref).max()
+    # batch-norm training with padded units
+    desc = ({'rgb': 'float32', 'labels': 'int32'}, {'rgb': (None, None, 3), 'labels': (None, None)}, c)
+    net = get_model('fcn')('rgb', desc, 'rgb', num_units=u, batch_normalization=True, batchsize=2, learning_rate=1e-3,
+                           trainer='adam', seed=3)
+    batch = {'rgb': data['rgb'], 'labels': rng.integers(-1, c, (2, h, w)).astype(np.int32)}
+    first = net._train_batch(batch)
+    for _ in range(8):
+        last = net._train_batch(batch)
+    assert np.isfinite(last) and last < first
+    tr = net.trainer
+    assert float(tr.view(tr.param, 'score_conv4', 'kernel')[..., u:].abs().max()) == 0.0
+    assert net.predict(batch).shape == (2, h, w)
