@@ -18,8 +18,6 @@ from .base_model import BaseModel
 from .custom_layers import bilinear_filter, is_bilinear_filter
 from .fcn import BN_EPS, ENCODER, _fold_bn
 
-FUSED_BN_LAYERS = (('fused/upscore', 'num_units'), ('fused/score', 'num_classes'))
-
 
 def vgg16_variable_shapes(prefix, in_channels):
     """vgg16.py:18-37: conv layers named '{prefix}_convX_Y' (no variable scope)."""
@@ -208,9 +206,19 @@ class FusionFcnEngine(object):
         """inputs: {modality: float32 [N,H,W,c] device tensor}.  Returns dict with any of 'score', 'prob',
         'label' plus 'layers' (the reference's layer dict: per modality the trunk, then the fused layers)."""
         layers = {}
-        for m in self.prefixes:
-            layers[m] = self.trunks[m].forward(inputs[m], keep_all=keep_all)
         mods = list(self.prefixes)
+        # the trunks are independent up to the concat: one HIP stream each (as basic_fusion_model.run_experts does for
+        # the experts), so that the tail round of one trunk's persistent conv grid is filled by the other's workgroups
+        main = torch.cuda.current_stream(self.device)
+        if not hasattr(self, '_streams'):
+            self._streams = {m: torch.cuda.Stream(device=self.device) for m in mods}
+        for m in mods:
+            side = self._streams[m]
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                layers[m] = self.trunks[m].forward(inputs[m], keep_all=keep_all)
+        for m in mods:
+            main.wait_stream(self._streams[m])
         first = layers[mods[0]]['conv4_3']
         n, h8, w8 = first.n, first.h, first.w
 
