@@ -209,16 +209,20 @@ class FusionFcnEngine(object):
         mods = list(self.prefixes)
         # the trunks are independent up to the concat: one HIP stream each (as basic_fusion_model.run_experts does for
         # the experts), so that the tail round of one trunk's persistent conv grid is filled by the other's workgroups
-        main = torch.cuda.current_stream(self.device)
-        if not hasattr(self, '_streams'):
-            self._streams = {m: torch.cuda.Stream(device=self.device) for m in mods}
-        for m in mods:
-            side = self._streams[m]
-            side.wait_stream(main)
-            with torch.cuda.stream(side):
+        if not getattr(self, 'concurrent', True):
+            for m in mods:
                 layers[m] = self.trunks[m].forward(inputs[m], keep_all=keep_all)
-        for m in mods:
-            main.wait_stream(self._streams[m])
+        else:
+            main = torch.cuda.current_stream(self.device)
+            if not hasattr(self, '_streams'):
+                self._streams = {m: torch.cuda.Stream(device=self.device) for m in mods}
+            for m in mods:
+                side = self._streams[m]
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    layers[m] = self.trunks[m].forward(inputs[m], keep_all=keep_all)
+            for m in mods:
+                main.wait_stream(self._streams[m])
         first = layers[mods[0]]['conv4_3']
         n, h8, w8 = first.n, first.h, first.w
 
@@ -324,5 +328,6 @@ class FusionFCN(BaseModel):
 
     def _predict_batch_impl(self, batch, output_attr=None):
         x = {m: self._to_device(batch[m], torch.float32) for m in self.modalities}
+        self.engine.concurrent = getattr(self, 'concurrent_experts', True)     # one stream per trunk unless told otherwise
         want = output_attr if output_attr in ('prob', 'score') else 'label'
         return self.engine.forward(x, want=(want,))[want]
