@@ -20,7 +20,7 @@ for (n, h, w, cin, cout, pool) in [(16, 48, 96, 512, 512, False), (16, 96, 192, 
     wp = ops.pack_conv_weights(wt)
     b = torch.randn(cout, device='cuda')
     ref_y = ref_q = None
-    for it in range(150):
+    for it in range(int(os.environ.get("XV_STRESS_ITERS", "150"))):
         y = ops.Act(n, h, w, cout)
         q = ops.Act(n, h // 2, w // 2, cout) if pool else None
         ops.conv2d_fwd(x, wp, b, 3, y=y, pooled=q)
