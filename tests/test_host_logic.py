@@ -196,3 +196,17 @@ def test_fusion_fcn_variable_schema():
     assert shapes['fused/upscore/kernel'] == (16, 16, 64, 64) and shapes['fused/score/gamma'] == (12,)
     ref = fo.init_fusion_fcn_weights(prefixes, nch, 64, 12)
     assert {k: tuple(v.shape) for k, v in ref.items()} == shapes
+
+
+def test_split_test_data_is_the_sklearn_half_split():
+    """experiments.split_test_data == train_test_split(test_size=.5, random_state=1) of the reference flow
+    (experiments/bayes_fusion.py:21-33): deterministic, disjoint, covering."""
+    from sklearn.model_selection import train_test_split
+    from modular_semantic_segmentation_amd.experiments import split_test_data
+    n = 11
+    data = {'rgb': np.arange(n * 2).reshape(n, 2), 'labels': np.arange(n)}
+    measure, test = split_test_data(data)
+    ref_measure, ref_test = train_test_split(np.arange(n), test_size=.5, random_state=1)
+    assert measure['labels'].tolist() == ref_measure.tolist() and test['labels'].tolist() == ref_test.tolist()
+    assert sorted(measure['labels'].tolist() + test['labels'].tolist()) == list(range(n))
+    assert np.array_equal(measure['rgb'][:, 0] // 2, measure['labels'])
