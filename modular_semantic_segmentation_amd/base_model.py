@@ -151,14 +151,24 @@ class BaseModel(object):
         if self.custom_training:
             raise UserWarning('ERROR: Model %s does not support training' % self.name)
 
-        def endless():
+        def samples():
+            # dataset.repeat() of the reference (base_model.py:203-206): epochs are chained sample by
+            # sample before batching, so every training batch has exactly `batchsize` images
             while True:
                 empty = True
-                for b in iterate_batches(dataset, self.config['batchsize']):
-                    empty = False
-                    yield b
+                if isinstance(dataset, dict):
+                    for i in range(len(next(iter(dataset.values())))):
+                        empty = False
+                        yield {k: v[i] for k, v in dataset.items()}
+                else:
+                    for sample in dataset:
+                        empty = False
+                        yield sample
                 if empty:
                     return
+
+        def endless():
+            return iterate_batches(samples(), self.config['batchsize'])
 
         if output:
             print('INFO: Start training')

@@ -383,3 +383,37 @@ def test_fusion_fcn_and_bn_training_with_padded_units(gpu, tmp_path):
     tr = net.trainer
     assert float(tr.view(tr.param, 'score_conv4', 'kernel')[..., u:].abs().max()) == 0.0
     assert net.predict(batch).shape == (2, h, w)
+
+
+def test_dataset_readers_drive_training_and_fusion_flows(gpu, tmp_path):
+    """the SynthiaCityscapes reader's streams (per-image dicts, the reference's tf.data
+    role) feed fit / score and the Bayes-fusion experiment flow; a stream and the stacked numpy batch of the
+    same items give the same confusion matrix."""
+    import dataset_fixtures as fx
+    from modular_semantic_segmentation_amd import experiments as ex, get_model
+    from modular_semantic_segmentation_amd.datasets import get_dataset
+    fx.build_synthia_tree(str(tmp_path / 'synthia'), image_hw=(70, 100))
+    Data = get_dataset('synthia_cityscapes')
+    data = Data(base_path=str(tmp_path / 'synthia'),
+                augmentation={'crop': [1, 64], 'scale': False, 'vflip': .3, 'hflip': False, 'gamma': [.4, .3, 1.2],
+                              'rotate': False, 'shear': False, 'contrast': [.3, .5, 1.5], 'brightness': [.2, -40, 40]})
+    desc = Data.get_data_description()
+    assert desc[2] == 12
+    w_rgb, p_rgb = _weights(tmp_path, 'rgb', 3, 1, 0.02)
+    w_dep, p_dep = _weights(tmp_path, 'depth', 1, 2, 2e-4)
+    with get_model('fcn')('rgb', desc, 'rgb', num_units=U, batch_normalization=False, batchsize=2,
+                          learning_rate=1e-5) as net:
+        net.import_weights(p_rgb)
+        net.fit(data.get_trainset(), 4, output=False, validation_dataset=data.get_validation_set(num_items=2))
+        assert net.global_step == 4
+        m_stream, cm_stream = net.score(data.get_measureset())
+        m_batch, cm_batch = net.score(data.get_measureset(tf_dataset=False))
+        assert np.array_equal(cm_stream, cm_batch) and cm_stream.sum() == len(data.measureset) * 64 * 96
+        pred = net.predict(data.get_testset(num_items=3))
+        assert pred.shape == (3, 64, 96) and pred.dtype == np.int64
+    net_config = {'expert_model': 'fcn', 'prefixes': {'rgb': 'rgb', 'depth': 'depth'}, 'num_units': U,
+                  'num_channels': {'rgb': 3, 'depth': 1}, 'class_prior': 'data', 'batchsize': 2}
+    info = ex.fit_and_evaluate_bayes_fusion(net_config, desc, data.get_measureset(), data.get_testset(),
+                                            {'rgb': p_rgb, 'depth': p_dep})
+    assert info['confusion_matrix'].sum() == len(data.testset) * 64 * 96
+    assert info['confusion_matrices']['rgb'].sum() == len(data.measureset) * 64 * 96
