@@ -98,3 +98,76 @@ def warp_affine(image, matrix, out_w, out_h):
     out = (fetch(y0, x0) * (1 - fx) + fetch(y0, x0 + 1) * fx) * (1 - fy) \
         + (fetch(y0 + 1, x0) * (1 - fx) + fetch(y0 + 1, x0 + 1) * fx) * fy
     return _restore_dtype(out, image)
+
+
+def png_channels(filename):
+    """Decode a non-interlaced 8- or 16-bit grey / RGB / RGBA PNG to [H,W,channels] at full bit depth.
+
+    SYNTHIA stores class ids in the first channel of 16-bit RGB PNGs, which PIL truncates to the high
+    byte; the reference decodes them with pypng (`synthia.py:215-228` `one_channel_image_reader`).
+    This is the PNG specification's inflate + per-row unfilter, nothing else."""
+    import struct
+    import zlib
+    with open(filename, 'rb') as f:
+        raw = f.read()
+    if raw[:8] != b'\x89PNG\r\n\x1a\n':
+        raise ValueError('%s is not a PNG file' % filename)
+    pos, idat, header = 8, [], None
+    while pos < len(raw):
+        length, kind = struct.unpack('>I4s', raw[pos:pos + 8])
+        body = raw[pos + 8:pos + 8 + length]
+        pos += 12 + length
+        if kind == b'IHDR':
+            header = struct.unpack('>IIBBBBB', body)
+        elif kind == b'IDAT':
+            idat.append(body)
+        elif kind == b'IEND':
+            break
+    width, height, depth, colour, _, _, interlace = header
+    channels = {0: 1, 2: 3, 4: 2, 6: 4}.get(colour)
+    if channels is None or depth not in (8, 16) or interlace:
+        raise ValueError('unsupported PNG layout in %s (colour type %d, depth %d, interlace %d)'
+                         % (filename, colour, depth, interlace))
+    bpp = channels * depth // 8
+    stride = width * bpp
+    data = np.frombuffer(zlib.decompress(b''.join(idat)), dtype=np.uint8).reshape(height, stride + 1)
+    out = np.zeros((height, stride), dtype=np.uint8)
+    above = np.zeros(stride, dtype=np.int64)
+    for y in range(height):
+        kind, line = int(data[y, 0]), data[y, 1:].astype(np.int64)
+        if kind == 0:
+            row = line
+        elif kind == 2:
+            row = (line + above) & 255
+        elif kind == 1:
+            # each byte lane (stride bpp) is a running sum
+            row = (np.cumsum(line.reshape(width, bpp), axis=0) & 255).reshape(-1)
+        elif kind in (3, 4):
+            row = np.zeros(stride, dtype=np.int64)
+            cur, up = row.tolist(), above.tolist()
+            src = line.tolist()
+            for i in range(stride):
+                a = cur[i - bpp] if i >= bpp else 0
+                b = up[i]
+                if kind == 3:
+                    pred = (a + b) >> 1
+                else:
+                    c = up[i - bpp] if i >= bpp else 0
+                    p = a + b - c
+                    pa, pb, pc = abs(p - a), abs(p - b), abs(p - c)
+                    pred = a if (pa <= pb and pa <= pc) else (b if pb <= pc else c)
+                cur[i] = (src[i] + pred) & 255
+            row = np.asarray(cur, dtype=np.int64)
+        else:
+            raise ValueError('bad PNG filter type %d in %s' % (kind, filename))
+        out[y] = row
+        above = row
+    if depth == 16:
+        out = out.reshape(height, width, channels, 2)
+        return (out[..., 0].astype(np.uint16) << 8) | out[..., 1]
+    return out.reshape(height, width, channels)
+
+
+def one_channel_image_reader(filename, datatype):
+    """First channel of a PNG as `datatype`: SYNTHIA's class-id and depth encoding (synthia.py:215-228)."""
+    return png_channels(filename)[:, :, 0].astype(datatype)

@@ -4,16 +4,17 @@ scheme of the experts.
 Counterpart of the reference's `xview/datasets/synthia_cityscapes.py` (`__init__` :40-106,
 `_load_data` :143-181, `_get_data` :183-222): `<base>/RAND_CITYSCAPES/{RGB,Depth,GT/LABELS_NPY}/
 Stereo_Right/Omni_F/<name>.{png,png,npy}`, the train/test item lists of `train_test_split.json`, the
-test list halved (seed 1) into measure and test sets.  `GT/LABELS_NPY` is what the reference's one-off
-preprocessing leaves behind (first channel of the label PNGs); this reader consumes it, it does not
-redo that step.  In training format the reference's reader emits one-hot labels, which its own
+test list halved (seed 1) into measure and test sets.  `GT/LABELS_NPY` holds the first channel of the
+16-bit label PNGs, made once by `preprocess()` (the reference's `_preprocessing`, :112-141, whose paths
+do not agree with its own `_load_data`; the layout `_load_data` reads is the one written here).  In
+training format the reference's reader emits one-hot labels, which its own
 `BaseModel.fit` would one-hot a second time; labels stay integer maps here, the contract every model
 (and the reference's Cityscapes reader) uses.
 """
 import json
 import tarfile
 from copy import deepcopy
-from os import environ, path
+from os import environ, listdir, makedirs, path
 
 import numpy as np
 from sklearn.model_selection import train_test_split
@@ -73,6 +74,8 @@ class SynthiaCityscapes(DataBaseclass):
             with tarfile.open(path.join(base_path, 'RAND_CITYSCAPES.tar.gz')) as tar:
                 tar.extractall(path=environ['TMPDIR'])
             self.basepath = environ['TMPDIR']
+        if force_preprocessing or not path.exists(path.join(self.basepath, 'train_test_split.json')):
+            self.preprocess(force=force_preprocessing)
         with open(path.join(self.basepath, 'train_test_split.json')) as f:
             split = json.load(f)
         if in_memory:
@@ -87,6 +90,23 @@ class SynthiaCityscapes(DataBaseclass):
         if self.config['labels']['lanemarkings']:
             labelinfo[LANEMARKING] = {'name': 'lanemarking', 'color': [0, 192, 0]}
         DataBaseclass.__init__(self, trainset, measureset, testset, labelinfo)
+
+    def preprocess(self, force=False):
+        """One-off: class-id channel of `GT/LABELS/.../*.png` -> `GT/LABELS_NPY/.../*.npy`, and an 80/20
+        `train_test_split.json` if there is none yet."""
+        source = path.join(self.basepath, 'GT/LABELS/Stereo_Right/Omni_F')
+        target = path.join(self.basepath, 'GT/LABELS_NPY/Stereo_Right/Omni_F')
+        makedirs(target, exist_ok=True)
+        names = sorted(path.splitext(n)[0] for n in listdir(source))
+        for name in names:
+            if force or not path.exists(path.join(target, name + '.npy')):
+                np.save(path.join(target, name), imageops.one_channel_image_reader(
+                    path.join(source, name + '.png'), np.uint8))
+        split_file = path.join(self.basepath, 'train_test_split.json')
+        if not path.exists(split_file):
+            trainset, testset = train_test_split(names, test_size=0.2)
+            with open(split_file, 'w') as f:
+                json.dump({'trainset': trainset, 'testset': testset}, f)
 
     def _load_data(self, image_name):
         def filename(folder, extension):

@@ -167,3 +167,78 @@ def test_resampling_conventions():
     assert quarter.shape == (20, 12)
     # the centre is (w/2, h/2) in pixel-corner coordinates, as cv2.getRotationMatrix2D is called: one row off rot90
     assert np.array_equal(quarter[1:], np.rot90(img[:, :, 0])[:-1])
+
+
+def _write_png(filename, array, filter_type=0):
+    """Minimal PNG writer for [H,W,C] uint8 / uint16 arrays with one fixed row filter (0 none, 1 sub, 2 up)."""
+    import struct
+    import zlib
+    h, w, c = array.shape
+    depth = 16 if array.dtype == np.uint16 else 8
+    rows = array.astype('>u2' if depth == 16 else np.uint8).reshape(h, -1).view(np.uint8).astype(np.int64)
+    bpp = c * depth // 8
+    prev = np.zeros_like(rows[0])
+    lines = []
+    for row in rows:
+        if filter_type == 1:
+            left = np.concatenate([np.zeros(bpp, dtype=np.int64), row[:-bpp]])
+            enc = (row - left) & 255
+        elif filter_type == 2:
+            enc = (row - prev) & 255
+        else:
+            enc = row
+        prev = row
+        lines.append(bytes([filter_type]) + enc.astype(np.uint8).tobytes())
+
+    def chunk(kind, body):
+        return struct.pack('>I', len(body)) + kind + body + struct.pack('>I', zlib.crc32(kind + body) & 0xffffffff)
+
+    colour = {1: 0, 3: 2, 4: 6}[c]
+    with open(filename, 'wb') as f:
+        f.write(b'\x89PNG\r\n\x1a\n' + chunk(b'IHDR', struct.pack('>IIBBBBB', w, h, depth, colour, 0, 0, 0))
+                + chunk(b'IDAT', zlib.compress(b''.join(lines))) + chunk(b'IEND', b''))
+
+
+def test_png_decoder_and_synthia_preprocessing(tmp_path):
+    """SYNTHIA label PNGs are 16-bit RGB with the class id in the first channel (synthia.py:215-228)."""
+    from PIL import Image
+    rng = np.random.default_rng(3)
+    smooth = np.cumsum(rng.integers(-3, 4, (40, 50, 3)), axis=1).astype(np.uint8)
+    Image.fromarray(smooth).save(str(tmp_path / 'adaptive.png'))          # PIL picks sub / up / average / paeth rows
+    assert np.array_equal(imageops.png_channels(str(tmp_path / 'adaptive.png')), smooth)
+    grey = rng.integers(0, 65536, (20, 30)).astype(np.uint16)
+    Image.fromarray(grey).save(str(tmp_path / 'grey16.png'))
+    assert np.array_equal(imageops.png_channels(str(tmp_path / 'grey16.png'))[:, :, 0], grey)
+    assert np.array_equal(imageops.imread_anydepth(str(tmp_path / 'grey16.png')), grey)
+    rgb16 = rng.integers(0, 65536, (12, 9, 3)).astype(np.uint16)
+    for filter_type in (0, 1, 2):
+        _write_png(str(tmp_path / 'rgb16.png'), rgb16, filter_type)
+        assert np.array_equal(imageops.png_channels(str(tmp_path / 'rgb16.png')), rgb16), filter_type
+    with pytest.raises(ValueError):
+        (tmp_path / 'junk.png').write_bytes(b'not a png at all')
+        imageops.png_channels(str(tmp_path / 'junk.png'))
+
+    # a raw RAND_CITYSCAPES tree: label PNGs only, no LABELS_NPY, no split file
+    root = str(tmp_path / 'synthia')
+    fx.build_synthia_tree(root)
+    base = os.path.join(root, 'RAND_CITYSCAPES')
+    os.remove(os.path.join(base, 'train_test_split.json'))
+    npy_dir = os.path.join(base, 'GT/LABELS_NPY/Stereo_Right/Omni_F')
+    png_dir = os.path.join(base, 'GT/LABELS/Stereo_Right/Omni_F')
+    os.makedirs(png_dir)
+    want = {}
+    for name in sorted(os.listdir(npy_dir)):
+        labels = np.load(os.path.join(npy_dir, name))
+        want[name] = labels
+        planes = np.stack([labels.astype(np.uint16), rng.integers(0, 65536, labels.shape).astype(np.uint16),
+                           rng.integers(0, 65536, labels.shape).astype(np.uint16)], axis=-1)
+        _write_png(os.path.join(png_dir, name.replace('.npy', '.png')), planes, filter_type=1)
+        os.remove(os.path.join(npy_dir, name))
+    data = SynthiaCityscapes(base_path=root)
+    for name, labels in want.items():
+        assert np.array_equal(np.load(os.path.join(npy_dir, name)), labels)
+    with open(os.path.join(base, 'train_test_split.json')) as f:
+        split = json.load(f)
+    assert len(split['testset']) == round(0.2 * len(want) + 0.499) and \
+        sorted(split['trainset'] + split['testset']) == sorted(n[:-4] for n in want)
+    assert len(data.trainset) + len(data.validation_set) == len(split['trainset'])
