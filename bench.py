@@ -34,12 +34,35 @@ def conv_flops_per_image(h, w, cin):
     return f
 
 
+def adapnet_flops_per_image(h, w, cin):
+    """Algorithmic conv FLOPs of one AdapNet stream (adapnet.py:103-173): every conv at its own kernel size, stride and
+    resolution (7x7 stride 2 = 49 taps at H/2, atrous 3x3 = 9 taps), first_deconvolution_conv counted for the
+    num_units channels the x2 deconv reads."""
+    from modular_semantic_segmentation_amd.adapnet import BLOCKS
+    f = 2.0 * h * w * cin * 64 * 9 + 2.0 * (h // 2) * (w // 2) * 64 * 64 * 49
+    c, s = 64, 4
+    for name, kind, a in BLOCKS:
+        if kind == 'a':
+            mid, cout, stride, shortcut = a
+            s *= stride
+            px = (h // s) * (w // s)
+            f += 2.0 * px * (c * mid + 9 * mid * mid + mid * cout + (c * cout if shortcut else 0))
+        else:
+            f1, f2, cout, _, _, shortcut = a
+            px = (h // s) * (w // s)
+            f += 2.0 * px * (c * f1 + 9 * f1 * f2 + f2 * cout + (c * cout if shortcut else 0))
+        if name == 'block_layer_7':
+            f += 2.0 * px * cout * U
+        c = cout
+    return f + 2.0 * (h // 16) * (w // 16) * 2048 * U
+
+
 def build_model(args, device):
     from modular_semantic_segmentation_amd import get_model
     g = np.load(os.path.join(ROOT, 'tests', 'golden', 'notebook_868.npz'))
     desc = ({'rgb': 'float32', 'depth': 'float32', 'labels': 'int32'},
             {'rgb': (None, None, 3), 'depth': (None, None, 1), 'labels': (None, None)}, C)
-    common = dict(data_description=desc, num_units=U, num_channels={'rgb': 3, 'depth': 1}, expert_model='fcn',
+    common = dict(data_description=desc, num_units=U, num_channels={'rgb': 3, 'depth': 1}, expert_model=args.expert,
                   class_prior='data', batchsize=args.batch, seed=1, device=str(device))
     if args.fusion == 'joint':
         # the reference's joint baseline fusion_fcn (experiments/timing.py:24-45): two VGG16 trunks + fused decoder
@@ -58,7 +81,8 @@ def build_model(args, device):
         net = get_model('dirichlet_fusion')(dirichlet_params=params, modalities=['rgb', 'depth'], sigma=1.0,
                                             delta=1e-2, beta=1e-2, **common)
     # a trained depth expert absorbs the raw uint16 range in conv1_1; random init needs the scale
-    net.variables['depth/conv1_1/kernel'] = net.variables['depth/conv1_1/kernel'] / 256.0
+    first = 'depth/conv1_1/kernel' if args.expert == 'fcn' else 'depth/block_0_1/kernel'
+    net.variables[first] = net.variables[first] / 256.0
     net._variables_changed()
     return net
 
@@ -166,6 +190,8 @@ def main():
     ap.add_argument('--width', type=int, default=768)
     ap.add_argument('--fusion', default='bayes', choices=['bayes', 'dirichlet', 'joint'],
                     help="'joint' = the fusion_fcn baseline model instead of two experts + probabilistic fusion")
+    ap.add_argument('--expert', default='fcn', choices=['fcn', 'adapnet'],
+                    help="expert architecture of the two streams (default: the headline SimpleFCN; 'adapnet' = side measurement)")
     ap.add_argument('--mode', default='infer', choices=['infer', 'train'],
                     help="'infer' (headline): two experts + fusion; 'train': one SimpleFCN training step (fwd+bwd+Adam)")
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -291,9 +317,18 @@ def main():
                     'measured': 'HIP events per launch, experts serialised on one stream (%.3f ms/step)'
                                 % (dt_serial / args.steps * 1e3)}
 
+    per_image = conv_flops_per_image if args.expert == 'fcn' else adapnet_flops_per_image
+    flops_img = per_image(args.height, args.width, 3) + per_image(args.height, args.width, 1)
+    if args.expert == 'adapnet':
+        # no single dominant kernel: the whole serialised expert step against the algorithmic conv FLOPs
+        achieved = args.batch * args.steps * flops_img / dt_serial / 1e12
+        roofline = {'bound': 'mfma', 'kernel': 'whole AdapNet step, every kernel (algorithmic conv FLOPs / step time)',
+                    'achieved': round(achieved, 2), 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s',
+                    'frac': round(achieved / PEAK_BF16_TFLOPS, 4), 'traffic': None,
+                    'gflop_per_image_pair': round(flops_img / 1e9, 2),
+                    'measured': 'wall clock of the serialised eager steps (%.3f ms/step)' % (dt_serial / args.steps * 1e3)}
     if rank == 0:
         images = args.batch * world * args.steps
-        flops_img = conv_flops_per_image(args.height, args.width, 3) + conv_flops_per_image(args.height, args.width, 1)
         res = {
             'metric': 'images/sec at %dx%d RGB-D FCN (two SimpleFCN experts + %s fusion + argmax, inference)' % (
                 args.width, args.height, args.fusion),
@@ -308,11 +343,16 @@ def main():
             'conv_tflops_end_to_end': round(images * flops_img / dt / 1e12, 2),
             'roofline': roofline,
         }
+        if args.expert == 'adapnet':
+            res['metric'] = 'images/sec at %dx%d RGB-D, two AdapNet experts + %s fusion + argmax (inference)' % (
+                args.width, args.height, args.fusion)
+            res['config']['workload'] = 'two-stream AdapNet RGB+Depth %dx%d + %s fusion, U=%d, C=%d, random-init weights' % (
+                args.width, args.height, args.fusion, U, C)
         if args.fusion == 'joint':
             res['metric'] = 'images/sec at %dx%d, fusion_fcn joint RGB-D baseline (inference)' % (args.width, args.height)
             res['config']['workload'] = 'fusion_fcn (two VGG16 trunks + fused decoder) RGB+Depth %dx%d, U=%d, C=%d' % (
                 args.width, args.height, U, C)
-        if world == 1 and not args.no_cpu_baseline and args.fusion != 'joint':
+        if world == 1 and not args.no_cpu_baseline and args.fusion != 'joint' and args.expert == 'fcn':
             g = np.load(os.path.join(ROOT, 'tests', 'golden', 'notebook_868.npz'))
             res['cpu_baseline'] = cpu_baseline(args, net.variables, {'rgb': g['cm_rgb'], 'depth': g['cm_depth']})
         else:

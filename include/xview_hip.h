@@ -67,6 +67,12 @@ int xv_pack_conv_weights(const float* w_hwio, void* packed, int k, int cin, int 
 int xv_conv2d_fwd(const xv_act* x, const void* w_packed, const float* bias, const xv_act* y,
                   const xv_act* pooled, int k, int relu, void* stream);
 
+/* Residual form for the 1x1 convs that close a ResNet block: y = act(conv1x1(x, W) + b) + residual
+ * (block_a / block_b of adapnet.py:38-51,80-100: stage_3 carries its own relu, the block's outer relu is the identity
+ * on the sum of two non-negative maps).                                                                               */
+int xv_conv2d_fwd_residual(const xv_act* x, const void* w_packed, const float* bias, const xv_act* residual,
+                           const xv_act* y, int relu, void* stream);
+
 /* Tuning / test entry: the same op with an explicit tile configuration 0 <= cfg < xv_conv2d_num_cfgs()
  * (cfg < 0 = the library's own choice, i.e. xv_conv2d_fwd).  Results are bit-identical across
  * configurations; XV_ESHAPE if the configuration cannot tile this shape.                            */
@@ -94,8 +100,25 @@ int xv_upsample2x_relu_add(const xv_act* x, const xv_act* residual, const xv_act
 int xv_upsample2x_affine_relu_add(const xv_act* x, const float* scale, const float* shift, const xv_act* residual,
                                   const xv_act* y, void* stream);
 
+/* The general form: y = act(bilinear_x2(x) * scale[c] + shift[c]) [+ residual], relu = 0 for AdapNet's
+ * first_deconvolution_upconv (deconv2d(activation=None, batch_normalization=True) then tf.add with the block-7
+ * shortcut, adapnet.py:157-163).                                                                                      */
+int xv_upsample2x_affine_act_add(const xv_act* x, const float* scale, const float* shift, const xv_act* residual,
+                                 const xv_act* y, int relu, void* stream);
+
 /* y = concat(a, b) along channels (tf.concat(axis=3) of the two trunks' conv4_3 / conv5_3, fusion_fcn.py:27-28). */
 int xv_concat_channels(const xv_act* a, const xv_act* b, const xv_act* y, void* stream);
+
+/* ---- gathers that map AdapNet's strided / dilated convs onto the stride-1 kernels above (adapnet.py:12-173) ----
+ * xv_subsample2: y[i][j] = x[2i][2j], the input of a 1x1 stride-2 conv (block_a with strides 2, adapnet.py:39,45).
+ * xv_gather_conv7s2: z [N,H/2,W/2,9C] such that the 7x7 stride-2 'same' conv of block_0_2 (adapnet.py:127) equals a 3x3
+ *   stride-1 conv of z: group g = 3*rv + cv, variants (parity, shift) = (0,0), (0,1), (1,0) per axis,
+ *   z[j][i][g] = x[2(j+sr)+pr][2(i+sc)+pc] (zero outside); the 7x7 tap k = 2(t+s)+p lands on 3x3 tap t.
+ * xv_im2col_dilated_pair: z [N,H,W,18C], z[y][x][t] = x[y+ty*d][x+tx*d] with t = 0..8 at rate d1 and 9..17 at rate d2:
+ *   the two atrous convs of block_b (adapnet.py:84-88) become one 1x1 conv whose output is their concatenation.     */
+int xv_subsample2(const xv_act* x, const xv_act* y, void* stream);
+int xv_gather_conv7s2(const xv_act* x, const xv_act* z, void* stream);
+int xv_im2col_dilated_pair(const xv_act* x, int dilation1, int dilation2, const xv_act* z, void* stream);
 
 /* Decoder head: upscore = relu(bilinear_x8(fused)) (deconv2d k=16 s=8, simple_fcn.py:129-130),
  * score = conv1x1(upscore, Ws) + bs (no activation, simple_fcn.py:131-133), prob = softmax(score),

@@ -10,10 +10,13 @@ def get_model(name):
     from .dirichlet_mix import DirichletFusion
     from .average_mix import AverageFusion
     from .fusion_fcn import FusionFCN
+    from .adapnet import Adapnet
     if name == 'fcn':
         return SimpleFCN
     elif name == 'fusion_fcn':
         return FusionFCN
+    elif name == 'adapnet':
+        return Adapnet
     elif name in ['bayes_mix', 'bayes_fusion']:
         return BayesFusion
     elif name in ['dirichlet_mix', 'dirichlet_fusion']:

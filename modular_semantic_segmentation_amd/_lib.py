@@ -38,7 +38,12 @@ SIGNATURES = {
     'xv_maxpool2x2_fwd': (_i, [_actp, _actp, _vp]),
     'xv_upsample2x_relu_add': (_i, [_actp, _actp, _actp, _vp]),
     'xv_upsample2x_affine_relu_add': (_i, [_actp, _vp, _vp, _actp, _actp, _vp]),
+    'xv_upsample2x_affine_act_add': (_i, [_actp, _vp, _vp, _actp, _actp, _i, _vp]),
     'xv_concat_channels': (_i, [_actp, _actp, _actp, _vp]),
+    'xv_conv2d_fwd_residual': (_i, [_actp, _vp, _vp, _actp, _actp, _i, _vp]),
+    'xv_subsample2': (_i, [_actp, _actp, _vp]),
+    'xv_gather_conv7s2': (_i, [_actp, _actp, _vp]),
+    'xv_im2col_dilated_pair': (_i, [_actp, _i, _i, _actp, _vp]),
     'xv_decoder_head_workspace_bytes': (ctypes.c_size_t, [_i, _i, _i, _i]),
     'xv_decoder_head_fwd': (_i, [_actp, _vp, _vp, _i, _vp, _vp, _vp, _vp, ctypes.c_size_t, _vp]),
     'xv_decoder_head_affine_fwd': (_i, [_actp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp]),

@@ -12,6 +12,17 @@ def test_pipeline(engine, inputs, want=('prob', 'classification')):
     return out
 
 
+def expert_factory(expert_model):
+    """(engine class, initialiser) of an `expert_model` name, the choice test_pipeline makes
+    (basic_fusion_model.py:13-20)."""
+    if expert_model == 'fcn':
+        return FcnEngine, init_variables
+    if expert_model == 'adapnet':
+        from .adapnet import AdapnetEngine, init_variables as init_adapnet
+        return AdapnetEngine, init_adapnet
+    raise UserWarning('ERROR: Expert Model %s not found' % expert_model)
+
+
 def run_experts(model, batch, wants):
     """Forward every modality's expert, each on its own HIP stream: the experts are independent
     until the fusion kernel, and the tail of one stream's persistent conv grid is filled by the
@@ -51,17 +62,16 @@ class FusionModel(BaseModel):
         raise NotImplementedError
 
     def _build_graph(self):
-        if self.config['expert_model'] != 'fcn':
-            raise UserWarning('ERROR: Expert Model %s not found' % self.config['expert_model'])
+        engine_cls, init = expert_factory(self.config['expert_model'])
         self.experts = {}
         for m in self.modalities:
             prefix = self.config['prefixes'][m]
             cin = self._modality_channels(m)
             # experts run with trainable=False, batchnorm=False (basic_fusion_model.py:17-18)
-            self.variables.update(init_variables(prefix, cin, self.config['num_units'],
-                                                 self.config['num_classes'], seed=self.config.get('seed')))
-            self.experts[m] = FcnEngine(prefix, cin, self.config['num_units'], self.config['num_classes'],
-                                        self.variables, device=self.device)
+            self.variables.update(init(prefix, cin, self.config['num_units'], self.config['num_classes'],
+                                       seed=self.config.get('seed')))
+            self.experts[m] = engine_cls(prefix, cin, self.config['num_units'], self.config['num_classes'],
+                                         self.variables, device=self.device)
         self.prediction = 'fused_label'
 
     def _modality_channels(self, m):

@@ -1250,6 +1250,15 @@ extern "C" int xv_conv2d_bwd_data(const xv_act* dy, const void* w_packed_dgrad, 
                        addend ? (const __bf16*)addend->data : nullptr);
 }
 
+extern "C" int xv_conv2d_fwd_residual(const xv_act* x, const void* w_packed, const float* bias,
+                                      const xv_act* residual, const xv_act* y, int relu, void* stream) {
+  // 1x1 only: those shapes always run on the first-generation kernel, whose epilogue applies the activation before
+  // the addend (the second generation clamps at the store, after it)
+  XV_CHECK_ARG(y && y->data && residual && residual->data);
+  XV_CHECK_SHAPE(residual->n == y->n && residual->h == y->h && residual->w == y->w && residual->c == y->c);
+  return conv_fwd_impl(x, w_packed, bias, y, nullptr, 1, relu, -1, stream, nullptr, (const __bf16*)residual->data);
+}
+
 extern "C" int xv_conv2d_fwd(const xv_act* x, const void* w_packed, const float* bias, const xv_act* y,
                              const xv_act* pooled, int k, int relu, void* stream) {
   return conv_fwd_impl(x, w_packed, bias, y, pooled, k, relu, -1, stream);

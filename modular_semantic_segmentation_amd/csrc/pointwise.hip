@@ -153,7 +153,8 @@ __device__ inline void bilinear_taps(int o, int& i1, float& w_i1, float& w_i0) {
 // scale / shift (may be null): inference batch norm between the deconv and its relu (custom_layers.py:112-119)
 __global__ __launch_bounds__(256) void upsample2x_kernel(const __bf16* __restrict__ x, const __bf16* __restrict__ res,
                                                         const float* __restrict__ scale, const float* __restrict__ shift,
-                                                        __bf16* __restrict__ y, int N, int Hi, int Wi, int C) {
+                                                        __bf16* __restrict__ y, int N, int Hi, int Wi, int C,
+                                                        int relu) {
   const int c8 = C >> 3;
   const int Ho = Hi * 2, Wo = Wi * 2;
   const int64_t total = (int64_t)N * Ho * Wo * c8;
@@ -188,7 +189,7 @@ __global__ __launch_bounds__(256) void upsample2x_kernel(const __bf16* __restric
         const float f10 = bf16_bits_to_f32((a10[i] >> sh) & 0xffffu), f11 = bf16_bits_to_f32((a11[i] >> sh) & 0xffffu);
         float u = f00 * w00 + f01 * w01 + f10 * w10 + f11 * w11;
         if (scale) u = u * scale[cg * 8 + i * 2 + h] + shift[cg * 8 + i * 2 + h];
-        u = fmaxf(u, 0.f);
+        if (relu) u = fmaxf(u, 0.f);
         v[h] = u + bf16_bits_to_f32((rv[i] >> sh) & 0xffffu);
       }
       out[i] = pack_bf16x2(v[0], v[1]);
@@ -547,8 +548,8 @@ extern "C" int xv_maxpool2x2_fwd(const xv_act* x, const xv_act* y, void* stream)
   return xv_launch_status();
 }
 
-extern "C" int xv_upsample2x_affine_relu_add(const xv_act* x, const float* scale, const float* shift,
-                                            const xv_act* residual, const xv_act* y, void* stream) {
+extern "C" int xv_upsample2x_affine_act_add(const xv_act* x, const float* scale, const float* shift,
+                                           const xv_act* residual, const xv_act* y, int relu, void* stream) {
   XV_CHECK_ARG(x && y && x->data && y->data);
   XV_CHECK_ARG((scale == nullptr) == (shift == nullptr));
   XV_CHECK_SHAPE(x->n > 0 && x->h > 0 && x->w > 0 && x->c > 0 && (x->c & 7) == 0);
@@ -560,8 +561,13 @@ extern "C" int xv_upsample2x_affine_relu_add(const xv_act* x, const float* scale
   }
   const int64_t total = (int64_t)y->n * y->h * y->w * (y->c >> 3);
   hipLaunchKernelGGL(upsample2x_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
-                     (const __bf16*)x->data, res, scale, shift, (__bf16*)y->data, x->n, x->h, x->w, x->c);
+                     (const __bf16*)x->data, res, scale, shift, (__bf16*)y->data, x->n, x->h, x->w, x->c, relu);
   return xv_launch_status();
+}
+
+extern "C" int xv_upsample2x_affine_relu_add(const xv_act* x, const float* scale, const float* shift,
+                                            const xv_act* residual, const xv_act* y, void* stream) {
+  return xv_upsample2x_affine_act_add(x, scale, shift, residual, y, 1, stream);
 }
 
 extern "C" int xv_upsample2x_relu_add(const xv_act* x, const xv_act* residual, const xv_act* y, void* stream) {

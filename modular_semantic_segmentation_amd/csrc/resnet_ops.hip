@@ -1,0 +1,112 @@
+// Data-movement kernels that put AdapNet's strided and dilated convolutions onto the stride-1 MFMA conv kernels
+// (adapnet.py:12-173).  All three are pure gathers over padded-NHWC bf16 maps, 16 bytes per thread, HBM-bound.
+//
+//  * xv_subsample2      y[i][j] = x[2i][2j]: the input of a 1x1 stride-2 conv ([TF1] 'same', no padding).
+//  * xv_gather_conv7s2  the 7x7 stride-2 conv as ONE 3x3 stride-1 conv over 9*C channels.  With [TF1] 'same' padding
+//                       (2 before) out(o) = sum_k W[k] x[2o + k - 2]; writing k = 2(t + s) + p, t in {0,1,2} the 3x3 tap,
+//                       p the pixel parity and s in {0,1} an extra whole-pixel shift, the row variants
+//                       (p,s) = (0,0) -> k = 0,2,4; (0,1) -> k = 6 (tap t = 2 only); (1,0) -> k = 1,3,5 cover k = 0..6
+//                       exactly once.  Rows x columns = 9 channel groups; z[j][i][g] = x[2(j+sr)+pr][2(i+sc)+pc].
+//                       The host scatters the 7x7 kernel into the [3][3][9C][Cout] kernel accordingly.
+//  * xv_im2col_dilated_pair  block_b's two atrous 3x3 convs on the same input (rates d1, d2) as ONE 1x1 conv over
+//                       18*C channels: z[y][x][t] = x[y + ty*d][x + tx*d], t = 0..8 at rate d1, 9..17 at rate d2, zero
+//                       outside the image; the host stacks the two kernels block-wise so that the concatenated
+//                       output of adapnet.py:84-88 comes out of one launch.
+#include "xv_common.h"
+
+namespace {
+
+inline int rn_grid(int64_t total, int cap = 8192) {
+  int64_t g = (total + 255) / 256;
+  return (int)(g < 1 ? 1 : (g > cap ? cap : g));
+}
+
+__global__ __launch_bounds__(256) void subsample2_kernel(const u32x4* __restrict__ x, u32x4* __restrict__ y, int N,
+                                                        int Ho, int Wo, int c8) {
+  const int Hi = Ho * 2, Wi = Wo * 2;
+  const int64_t total = (int64_t)N * Ho * Wo * c8;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    const int cg = (int)(idx % c8);
+    int64_t r = idx / c8;
+    const int j = (int)(r % Wo);
+    r /= Wo;
+    const int i = (int)(r % Ho);
+    const int n = (int)(r / Ho);
+    y[(((int64_t)n * (Ho + 2) + i + 1) * (Wo + 2) + j + 1) * c8 + cg] =
+        x[(((int64_t)n * (Hi + 2) + 2 * i + 1) * (Wi + 2) + 2 * j + 1) * c8 + cg];
+  }
+}
+
+__global__ __launch_bounds__(256) void gather_conv7s2_kernel(const u32x4* __restrict__ x, u32x4* __restrict__ z, int N,
+                                                            int Ho, int Wo, int c8) {
+  const int Hi = Ho * 2, Wi = Wo * 2;
+  const int g8 = 9 * c8;
+  const int64_t total = (int64_t)N * Ho * Wo * g8;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    const int gc = (int)(idx % g8);
+    int64_t r = idx / g8;
+    const int i = (int)(r % Wo);
+    r /= Wo;
+    const int j = (int)(r % Ho);
+    const int n = (int)(r / Ho);
+    const int g = gc / c8, cg = gc - g * c8;
+    const int rv = g / 3, cv = g - rv * 3;  // variants 0: (p=0,s=0), 1: (p=0,s=1), 2: (p=1,s=0)
+    const int sy = 2 * j + (rv == 1 ? 2 : (rv == 2 ? 1 : 0));
+    const int sx = 2 * i + (cv == 1 ? 2 : (cv == 2 ? 1 : 0));
+    u32x4 v = u32x4{0u, 0u, 0u, 0u};
+    if (sy < Hi && sx < Wi) v = x[(((int64_t)n * (Hi + 2) + sy + 1) * (Wi + 2) + sx + 1) * c8 + cg];
+    z[(((int64_t)n * (Ho + 2) + j + 1) * (Wo + 2) + i + 1) * g8 + gc] = v;
+  }
+}
+
+__global__ __launch_bounds__(256) void im2col_pair_kernel(const u32x4* __restrict__ x, u32x4* __restrict__ z, int N,
+                                                         int H, int W, int c8, int d1, int d2) {
+  const int g8 = 18 * c8;
+  const int64_t total = (int64_t)N * H * W * g8;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    const int gc = (int)(idx % g8);
+    int64_t r = idx / g8;
+    const int px = (int)(r % W);
+    r /= W;
+    const int py = (int)(r % H);
+    const int n = (int)(r / H);
+    const int t = gc / c8, cg = gc - t * c8;
+    const int d = t < 9 ? d1 : d2;
+    const int tt = t < 9 ? t : t - 9;
+    const int sy = py + (tt / 3 - 1) * d, sx = px + (tt % 3 - 1) * d;
+    u32x4 v = u32x4{0u, 0u, 0u, 0u};
+    if (sy >= 0 && sy < H && sx >= 0 && sx < W) v = x[(((int64_t)n * (H + 2) + sy + 1) * (W + 2) + sx + 1) * c8 + cg];
+    z[(((int64_t)n * (H + 2) + py + 1) * (W + 2) + px + 1) * g8 + gc] = v;
+  }
+}
+
+}  // namespace
+
+extern "C" int xv_subsample2(const xv_act* x, const xv_act* y, void* stream) {
+  XV_CHECK_ARG(x && y && x->data && y->data);
+  XV_CHECK_SHAPE(x->n == y->n && x->c == y->c && (x->c & 7) == 0 && x->h == 2 * y->h && x->w == 2 * y->w && y->h > 0);
+  const int64_t total = (int64_t)y->n * y->h * y->w * (y->c >> 3);
+  hipLaunchKernelGGL(subsample2_kernel, dim3(rn_grid(total)), dim3(256), 0, (hipStream_t)stream, (const u32x4*)x->data,
+                     (u32x4*)y->data, y->n, y->h, y->w, y->c >> 3);
+  return xv_launch_status();
+}
+
+extern "C" int xv_gather_conv7s2(const xv_act* x, const xv_act* z, void* stream) {
+  XV_CHECK_ARG(x && z && x->data && z->data);
+  XV_CHECK_SHAPE(x->n == z->n && z->c == 9 * x->c && (x->c & 7) == 0 && x->h == 2 * z->h && x->w == 2 * z->w &&
+                 z->h > 0);
+  const int64_t total = (int64_t)z->n * z->h * z->w * (z->c >> 3);
+  hipLaunchKernelGGL(gather_conv7s2_kernel, dim3(rn_grid(total)), dim3(256), 0, (hipStream_t)stream,
+                     (const u32x4*)x->data, (u32x4*)z->data, z->n, z->h, z->w, x->c >> 3);
+  return xv_launch_status();
+}
+
+extern "C" int xv_im2col_dilated_pair(const xv_act* x, int dilation1, int dilation2, const xv_act* z, void* stream) {
+  XV_CHECK_ARG(x && z && x->data && z->data);
+  XV_CHECK_SHAPE(x->n == z->n && x->h == z->h && x->w == z->w && z->c == 18 * x->c && (x->c & 7) == 0 &&
+                 dilation1 >= 1 && dilation2 >= 1);
+  const int64_t total = (int64_t)z->n * z->h * z->w * (z->c >> 3);
+  hipLaunchKernelGGL(im2col_pair_kernel, dim3(rn_grid(total)), dim3(256), 0, (hipStream_t)stream, (const u32x4*)x->data,
+                     (u32x4*)z->data, z->n, z->h, z->w, x->c >> 3, dilation1, dilation2);
+  return xv_launch_status();
+}

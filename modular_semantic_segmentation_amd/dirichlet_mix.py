@@ -7,9 +7,8 @@ from scipy.special import gammaln
 
 from . import ops
 from .base_model import BaseModel, iterate_batches
-from .basic_fusion_model import run_experts, test_pipeline  # noqa: F401
+from .basic_fusion_model import expert_factory, run_experts, test_pipeline  # noqa: F401
 from .dirichlet_fit import find_dirichlet_priors
-from .fcn import FcnEngine, init_variables
 
 UNIFORM_PRIOR = 1.0 / 14     # dirichlet_mix.py:116
 
@@ -77,16 +76,15 @@ class DirichletFusion(BaseModel):
                            **standard_config)
 
     def _build_graph(self):
-        if self.config['expert_model'] != 'fcn':
-            raise UserWarning('ERROR: Expert Model %s not found' % self.config['expert_model'])
+        engine_cls, init = expert_factory(self.config['expert_model'])
         if not hasattr(self, 'experts'):
             self.experts = {}
             for m in self.modalities:
                 cin = int(self.config['num_channels'][m])
-                self.variables.update(init_variables(m, cin, self.config['num_units'],
-                                                     self.config['num_classes'], seed=self.config.get('seed')))
-                self.experts[m] = FcnEngine(m, cin, self.config['num_units'], self.config['num_classes'],
-                                            self.variables, device=self.device)
+                self.variables.update(init(m, cin, self.config['num_units'], self.config['num_classes'],
+                                           seed=self.config.get('seed')))
+                self.experts[m] = engine_cls(m, cin, self.config['num_units'], self.config['num_classes'],
+                                             self.variables, device=self.device)
         if hasattr(self, 'dirichlet_params'):
             am1, lognorm, logprior = dirichlet_tables([self.dirichlet_params[m] for m in self.modalities],
                                                       self.class_counts, self.config['class_prior'],

@@ -113,17 +113,53 @@ def maxpool2x2_fwd(x, y=None):
     return y
 
 
-def upsample2x_relu_add(x, residual=None, y=None, scale=None, shift=None):
-    """y = relu(bilinear_x2(x) [* scale + shift]) [+ residual]; scale / shift: float32 [C] inference batch norm."""
+def upsample2x_relu_add(x, residual=None, y=None, scale=None, shift=None, relu=True):
+    """y = act(bilinear_x2(x) [* scale + shift]) [+ residual]; scale / shift: float32 [C] inference batch norm."""
     if y is None:
         y = Act(x.n, 2 * x.h, 2 * x.w, x.c, x.t.device)
     if scale is not None:
         _need(scale, torch.float32, 'scale')
         _need(shift, torch.float32, 'shift')
-    rc = _lib.lib().xv_upsample2x_affine_relu_add(x.xv(), _ptr(scale), _ptr(shift),
-                                                 residual.xv() if residual is not None else _NULL_ACT, y.xv(), _stream())
-    _lib.check(rc, 'xv_upsample2x_affine_relu_add')
+    rc = _lib.lib().xv_upsample2x_affine_act_add(x.xv(), _ptr(scale), _ptr(shift),
+                                                residual.xv() if residual is not None else _NULL_ACT, y.xv(),
+                                                int(bool(relu)), _stream())
+    _lib.check(rc, 'xv_upsample2x_affine_act_add')
     return y
+
+
+def conv1x1_residual(x, w_packed, bias, residual, relu=True, y=None):
+    """y = act(conv1x1(x) + bias) + residual (the closing conv of a ResNet block)."""
+    _need(bias, torch.float32, 'bias')
+    if y is None:
+        y = Act(x.n, x.h, x.w, bias.numel(), x.t.device)
+    rc = _lib.lib().xv_conv2d_fwd_residual(x.xv(), _ptr(w_packed), _ptr(bias), residual.xv(), y.xv(), int(bool(relu)),
+                                          _stream())
+    _lib.check(rc, 'xv_conv2d_fwd_residual')
+    return y
+
+
+def subsample2(x, y=None):
+    """y[i][j] = x[2i][2j]."""
+    if y is None:
+        y = Act(x.n, x.h // 2, x.w // 2, x.c, x.t.device)
+    _lib.check(_lib.lib().xv_subsample2(x.xv(), y.xv(), _stream()), 'xv_subsample2')
+    return y
+
+
+def gather_conv7s2(x, z=None):
+    """[N,H/2,W/2,9C] operand that turns a 7x7 stride-2 'same' conv into a 3x3 stride-1 one (see pack_conv7s2)."""
+    if z is None:
+        z = Act(x.n, x.h // 2, x.w // 2, 9 * x.c, x.t.device)
+    _lib.check(_lib.lib().xv_gather_conv7s2(x.xv(), z.xv(), _stream()), 'xv_gather_conv7s2')
+    return z
+
+
+def im2col_dilated_pair(x, d1, d2, z=None):
+    """[N,H,W,18C]: the nine taps at dilation d1 then the nine at d2."""
+    if z is None:
+        z = Act(x.n, x.h, x.w, 18 * x.c, x.t.device)
+    _lib.check(_lib.lib().xv_im2col_dilated_pair(x.xv(), int(d1), int(d2), z.xv(), _stream()), 'xv_im2col_dilated_pair')
+    return z
 
 
 def concat_channels(a, b, y=None):

@@ -1,0 +1,218 @@
+"""AdapNet expert: the gather kernels that put its strided / dilated convs on the MFMA
+kernels, bit-exact on integers against plain torch convs with [TF1] padding, then the whole inference graph and the
+model / fusion classes against oracle/adapnet_oracle.py."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from oracle import adapnet_oracle as ao
+from oracle import fcn_oracle as fo
+
+C, U = 12, 64
+H, W = 64, 96
+
+
+@pytest.fixture(scope='module')
+def ops():
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU')
+    from modular_semantic_segmentation_amd import ops as _ops
+    return _ops
+
+
+def _dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def _nchw(x):
+    return torch.from_numpy(x).permute(0, 3, 1, 2).contiguous()
+
+
+def _nhwc(t):
+    return t.permute(0, 2, 3, 1).contiguous().numpy()
+
+
+def _wt(w):
+    return torch.from_numpy(w).permute(3, 2, 0, 1).contiguous()
+
+
+def test_subsample2(ops):
+    x = np.random.default_rng(0).integers(-8, 9, (2, 12, 20, 64)).astype(np.float32)
+    y = ops.subsample2(ops.Act.from_dense(_dev(x)))
+    torch.cuda.synchronize()
+    assert np.array_equal(y.interior().float().cpu().numpy(), x[:, ::2, ::2])
+    assert not y.t[:, 0].any() and not y.t[:, :, -1].any()
+
+
+@pytest.mark.parametrize('n,h,w,pool', [(1, 16, 32, False), (2, 28, 44, True), (1, 64, 96, True)])
+def test_conv7x7_stride2_through_gather_is_exact(ops, n, h, w, pool):
+    """block_0_2 (adapnet.py:127): 7x7, stride 2, [TF1] 'same' = pad 2 before / 3 after."""
+    from modular_semantic_segmentation_amd.adapnet import conv7s2_as_3x3
+    rng = np.random.default_rng(h * w)
+    x = rng.integers(-2, 3, (n, h, w, 64)).astype(np.float32)
+    k7 = rng.integers(-1, 2, (7, 7, 64, 64)).astype(np.float32)
+    b = rng.integers(-3, 4, 64).astype(np.float32)
+    z = ops.gather_conv7s2(ops.Act.from_dense(_dev(x)))
+    q = ops.Act(n, h // 4, w // 4, 64) if pool else None
+    y, _ = ops.conv2d_fwd(z, ops.pack_conv_weights(_dev(conv7s2_as_3x3(k7))), _dev(b), 3, relu=True, pooled=q)
+    torch.cuda.synchronize()
+    ref = F.relu(F.conv2d(F.pad(_nchw(x), (2, 3, 2, 3)), _wt(k7), torch.from_numpy(b), stride=2))
+    assert np.array_equal(y.interior().float().cpu().numpy(), fo.round_bf16(_nhwc(ref)))
+    if pool:
+        assert np.array_equal(q.interior().float().cpu().numpy(), fo.round_bf16(_nhwc(F.max_pool2d(ref, 2, 2))))
+
+
+@pytest.mark.parametrize('h,w,c,half,d1,d2', [(12, 20, 128, 32, 1, 2), (6, 10, 256, 128, 1, 16), (8, 12, 64, 32, 2, 4),
+                                              (4, 6, 512, 256, 2, 16)])
+def test_dilated_pair_through_im2col_is_exact(ops, h, w, c, half, d1, d2):
+    """block_b's stage_2_1 / stage_2_2 + concat (adapnet.py:84-88), dilation rates up to beyond the image."""
+    from modular_semantic_segmentation_amd.adapnet import dilated_pair_as_1x1
+    rng = np.random.default_rng(h * w + d2)
+    x = rng.integers(-2, 3, (2, h, w, c)).astype(np.float32)
+    k1 = rng.integers(-1, 2, (3, 3, c, half)).astype(np.float32)
+    k2 = rng.integers(-1, 2, (3, 3, c, half)).astype(np.float32)
+    b = rng.integers(-3, 4, 2 * half).astype(np.float32)
+    z = ops.im2col_dilated_pair(ops.Act.from_dense(_dev(x)), d1, d2)
+    y, _ = ops.conv2d_fwd(z, ops.pack_conv_weights(_dev(dilated_pair_as_1x1(k1, k2))), _dev(b), 1, relu=True)
+    torch.cuda.synchronize()
+    xt = _nchw(x)
+    ref = torch.cat([F.conv2d(xt, _wt(k1), torch.from_numpy(b[:half]), padding=d1, dilation=d1),
+                     F.conv2d(xt, _wt(k2), torch.from_numpy(b[half:]), padding=d2, dilation=d2)], dim=1)
+    assert np.array_equal(y.interior().float().cpu().numpy(), fo.round_bf16(_nhwc(F.relu(ref))))
+
+
+def test_residual_conv_and_affine_upsample(ops):
+    rng = np.random.default_rng(3)
+    x = rng.integers(-2, 3, (2, 10, 14, 128)).astype(np.float32)
+    k = rng.integers(-1, 2, (1, 1, 128, 256)).astype(np.float32)
+    b = rng.integers(-3, 4, 256).astype(np.float32)
+    r = rng.integers(0, 9, (2, 10, 14, 256)).astype(np.float32)
+    y = ops.conv1x1_residual(ops.Act.from_dense(_dev(x)), ops.pack_conv_weights(_dev(k)), _dev(b),
+                             ops.Act.from_dense(_dev(r)), relu=True)
+    torch.cuda.synchronize()
+    ref = F.relu(F.conv2d(_nchw(x), _wt(k), torch.from_numpy(b))) + _nchw(r)
+    assert np.array_equal(y.interior().float().cpu().numpy(), fo.round_bf16(_nhwc(ref)))
+    # x2 bilinear + batch norm without activation + residual (adapnet.py:157-163)
+    xs = rng.integers(-4, 5, (1, 6, 8, 64)).astype(np.float32)
+    res = rng.integers(-4, 5, (1, 12, 16, 64)).astype(np.float32)
+    s = rng.uniform(-1.5, 1.5, 64).astype(np.float32)
+    t = rng.uniform(-1, 1, 64).astype(np.float32)
+    got = ops.upsample2x_relu_add(ops.Act.from_dense(_dev(xs)), residual=ops.Act.from_dense(_dev(res)),
+                                  scale=_dev(s), shift=_dev(t), relu=False)
+    torch.cuda.synchronize()
+    up = fo.deconv_same(_nchw(xs), fo.bilinear_kernel(4, 64), 2)
+    want = _nhwc(up) * s + t + res
+    assert np.abs(got.interior().float().cpu().numpy() - want).max() <= 2 ** -7 * np.abs(want).max()
+    assert (want < 0).any()
+
+
+def _weights(tmp_path, prefix, cin, seed, scale_first):
+    w = ao.init_adapnet_weights(prefix, cin, U, C, seed=seed, gain=1.3)
+    w['%s/block_0_1/kernel' % prefix] *= scale_first
+    path = os.path.join(str(tmp_path), prefix + '_adapnet.npz')
+    np.savez(path, **w)
+    return w, path
+
+
+def _inputs(n, seed=0):
+    rng = np.random.default_rng(seed)
+    return {'rgb': rng.integers(0, 256, (n, H, W, 3)).astype(np.float32),
+            'depth': rng.integers(0, 65536, (n, H, W, 1)).astype(np.float32),
+            'labels': rng.integers(-1, C, (n, H, W)).astype(np.int32)}
+
+
+def _desc():
+    return ({'rgb': 'float32', 'depth': 'float32', 'labels': 'int32'},
+            {'rgb': (None, None, 3), 'depth': (None, None, 1), 'labels': (None, None)}, C)
+
+
+def test_adapnet_graph_matches_oracle(ops, tmp_path):
+    from modular_semantic_segmentation_amd.adapnet import AdapnetEngine, variable_shapes
+    w, _ = _weights(tmp_path, 'rgb', 3, 1, 0.02)
+    assert {k: tuple(v.shape) for k, v in w.items()} == variable_shapes('rgb', 3, U, C)
+    data = _inputs(2)
+    eng = AdapnetEngine('rgb', 3, U, C, w)
+    out = eng.forward(_dev(data['rgb']), want=('score', 'prob', 'label'))
+    torch.cuda.synchronize()
+    ref = ao.adapnet_forward(data['rgb'], w, 'rgb', policy='bf16',
+                             keep=['block_0_pool', 'block_3', 'block_7', 'block_13', 'block_16', 'shortcut', 'merge', 'score'])
+    for name in ('block_0_pool', 'block_3', 'block_7', 'block_13', 'block_16', 'shortcut', 'merge'):
+        got = out['layers'][name].interior().float().cpu().numpy()[..., :ref[name].shape[-1]]
+        err = np.abs(got - ref[name]).max() / np.abs(ref[name]).max()
+        # bf16 storage of 50 chained layers: a few ulps (2^-8) of the largest activation
+        assert err < 3e-2, '%s differs by %.3g of its max' % (name, err)
+    score = out['score'].cpu().numpy()
+    scale = np.abs(ref['score']).max()
+    assert np.abs(score - ref['score']).max() / scale < 3e-2
+    label = out['label'].cpu().numpy()
+    # labels: bit-exact against the oracle's softmax + argmax of the SAME logits, and agreeing with the oracle's own
+    # wherever its decision is clear
+    assert np.array_equal(label, fo.argmax_last(fo.softmax(score)))
+    ref_label = fo.argmax_last(fo.softmax(ref['score']))
+    top2 = np.sort(ref['score'], -1)[..., -2:]
+    clear = (top2[..., 1] - top2[..., 0]) > 6e-2 * scale
+    assert clear.mean() > 0.3 and np.array_equal(label[clear], ref_label[clear])
+    assert (label == ref_label).mean() > 0.95
+    assert np.allclose(out['prob'].cpu().numpy(), fo.softmax(score), atol=1e-5)
+    assert len(np.unique(ref_label)) > 2
+
+
+def test_adapnet_model_and_fusion_classes(ops, tmp_path):
+    from modular_semantic_segmentation_amd import get_model
+    w_rgb, p_rgb = _weights(tmp_path, 'rgb', 3, 1, 0.02)
+    w_dep, p_dep = _weights(tmp_path, 'depth', 1, 2, 2e-4)
+    data = _inputs(3, seed=5)
+    with get_model('adapnet')(_desc(), output_dir=str(tmp_path), modality='rgb', num_units=U, batchsize=2) as net:
+        net.import_weights(p_rgb)
+        pred = net.predict(data)
+        assert pred.shape == (3, H, W) and pred.dtype == np.int64
+        ref = ao.adapnet_forward(data['rgb'], w_rgb, 'rgb', policy='bf16')['score']
+        assert (pred == fo.argmax_last(fo.softmax(ref))).mean() > 0.95
+        measures, cm = net.score(data)
+        assert cm.sum() == (data['labels'] >= 0).sum()
+        exported = np.load(net.export_weights())
+        assert np.array_equal(exported['rgb/block_layer_7/stage_2_2/kernel'], w_rgb['rgb/block_layer_7/stage_2_2/kernel'])
+        with pytest.raises(NotImplementedError):
+            net.fit(data, 1, output=False)
+    cms = {m: np.eye(C) * 50 + 1 for m in ('rgb', 'depth')}
+    with get_model('bayes_fusion')(data_description=_desc(), confusion_matrices=cms,
+                                   prefixes={'rgb': 'rgb', 'depth': 'depth'}, num_units=U,
+                                   num_channels={'rgb': 3, 'depth': 1}, expert_model='adapnet', class_prior='uniform',
+                                   batchsize=3) as net:
+        net.import_weights(p_rgb)
+        net.import_weights(p_dep)
+        fused = net.predict(data)
+        labels = {m: fo.argmax_last(fo.softmax(ao.adapnet_forward(data[m], w, m, policy='bf16')['score']))
+                  for m, w in (('rgb', w_rgb), ('depth', w_dep))}
+        # identical diagonal-dominant confusion matrices + uniform prior: where the experts agree, so does the fusion
+        agree = labels['rgb'] == labels['depth']
+        assert agree.any() and (fused[agree] == labels['rgb'][agree]).mean() > 0.95
+
+
+def test_dirichlet_fusion_with_adapnet_experts(ops, tmp_path):
+    """DirichletFusion's expert choice goes through the same test_pipeline switch (dirichlet_mix.py:96-99)."""
+    from modular_semantic_segmentation_amd import get_model
+    _, p_rgb = _weights(tmp_path, 'rgb', 3, 1, 0.02)
+    _, p_dep = _weights(tmp_path, 'depth', 1, 2, 2e-4)
+    data = _inputs(4, seed=9)
+    cfg = {'expert_model': 'adapnet', 'modalities': ['rgb', 'depth'], 'num_units': U,
+           'num_channels': {'rgb': 3, 'depth': 1}, 'class_prior': 'data', 'sigma': 1.0, 'delta': 1e-2, 'beta': 1e-2,
+           'batchsize': 2}
+    with get_model('dirichlet_fusion')(data_description=_desc(), **cfg) as net:
+        net.import_weights(p_rgb)
+        net.import_weights(p_dep)
+        params = net.fit(data)
+        assert params['rgb'].shape == (C, C) and np.all(params['rgb'] > 0)
+        net.import_weights(p_rgb)
+        net.import_weights(p_dep)
+        measures, cm = net.score(data)
+        assert cm.sum() == (data['labels'] >= 0).sum()
+    with pytest.raises(UserWarning):
+        get_model('bayes_fusion')(data_description=_desc(), confusion_matrices={m: np.eye(C) for m in ('rgb', 'depth')},
+                                  prefixes={'rgb': 'rgb', 'depth': 'depth'}, num_units=U,
+                                  num_channels={'rgb': 3, 'depth': 1}, expert_model='resnet', class_prior='uniform')
