@@ -1169,6 +1169,9 @@ int pick_cfg(const ConvArgs& a, int k) {
   // generation 2 (16x32 tiles) unless its partial tiles waste more than its ~1.25x per-pixel advantage over the
   // 16x16 / 8x32 tiles of generation 1 (e.g. the 24x48 conv5 maps of a 768x384 input)
   if (k == 3 && covered(17) <= 1.25 * g1) return 17;
+  // 1x1 convs (plain GEMMs, AdapNet's block stages): 128 output channels per workgroup halve the activation re-reads
+  // (tools/conv1x1_tune.py: 1.1-1.7x over the 64-channel tiles from 128 input channels up)
+  if (k == 1 && a.Cout % 128 == 0 && a.Cin >= 128 && covered(1) <= 1.1 * g1) return 1;
   return covered(15) < covered(14) ? 15 : 14;
 }
 
