@@ -97,7 +97,10 @@ def main():
     # --- bilinear kernels -------------------------------------------------
     k4 = np.asarray(cl.bilinear_filter_initializer([4, 4, 5, 5]), dtype=np.float64)
     k16 = np.asarray(cl.bilinear_filter_initializer([16, 16, 3, 3]), dtype=np.float64)
-    np.savez_compressed(os.path.join(OUT, 'bilinear_kernels.npz'), k4=k4, k16=k16)
+    # the [k,k,filters,in] kernels AdapNet asks for (adapnet.py:158,164): filters < in
+    k4_rect = np.asarray(cl.bilinear_filter_initializer([4, 4, 3, 7]), dtype=np.float64)
+    k16_rect = np.asarray(cl.bilinear_filter_initializer([16, 16, 2, 5]), dtype=np.float64)
+    np.savez_compressed(os.path.join(OUT, 'bilinear_kernels.npz'), k4=k4, k16=k16, k4_rect=k4_rect, k16_rect=k16_rect)
 
     # --- notebook confusion matrices + measures ----------------------------
     info = notebook_868()

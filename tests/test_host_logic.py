@@ -210,3 +210,52 @@ def test_split_test_data_is_the_sklearn_half_split():
     assert measure['labels'].tolist() == ref_measure.tolist() and test['labels'].tolist() == ref_test.tolist()
     assert sorted(measure['labels'].tolist() + test['labels'].tolist()) == list(range(n))
     assert np.array_equal(measure['rgb'][:, 0] // 2, measure['labels'])
+
+
+def test_adapnet_weight_transforms_on_cpu():
+    """adapnet.conv7s2_as_3x3 / dilated_pair_as_1x1 with numpy stand-ins for the two gather kernels reproduce
+    the strided / atrous convs of adapnet.py:84-88,127 ([TF1] 'same' padding), and the variable schema matches the
+    oracle's."""
+    import torch
+    import torch.nn.functional as F
+    from modular_semantic_segmentation_amd import adapnet
+    from oracle import adapnet_oracle as ao
+    rng = np.random.default_rng(0)
+    wt = lambda w: torch.from_numpy(w).permute(3, 2, 0, 1).contiguous()                      # noqa: E731
+    nchw = lambda x: torch.from_numpy(x).permute(0, 3, 1, 2).contiguous()                    # noqa: E731
+    nhwc = lambda t: t.permute(0, 2, 3, 1).numpy()                                           # noqa: E731
+
+    x = rng.integers(-3, 4, (1, 12, 16, 4)).astype(np.float32)
+    k7 = rng.integers(-2, 3, (7, 7, 4, 5)).astype(np.float32)
+    ho, wo, c = 6, 8, 4
+    z = np.zeros((1, ho, wo, 9 * c), np.float32)
+    xp = np.pad(x, ((0, 0), (0, 4), (0, 4), (0, 0)))
+    offs = (0, 2, 1)                                                        # variants (p,s) = (0,0), (0,1), (1,0)
+    for rv in range(3):
+        for cv in range(3):
+            g = rv * 3 + cv
+            z[..., g * c:(g + 1) * c] = xp[:, offs[rv]:offs[rv] + 2 * ho:2, offs[cv]:offs[cv] + 2 * wo:2]
+    got = F.conv2d(nchw(z), wt(adapnet.conv7s2_as_3x3(k7)), padding=1)
+    want = F.conv2d(F.pad(nchw(x), (2, 3, 2, 3)), wt(k7), stride=2)
+    assert np.array_equal(nhwc(got), nhwc(want))
+
+    x = rng.integers(-3, 4, (1, 9, 11, 3)).astype(np.float32)
+    k1 = rng.integers(-2, 3, (3, 3, 3, 2)).astype(np.float32)
+    k2 = rng.integers(-2, 3, (3, 3, 3, 2)).astype(np.float32)
+    for d1, d2 in ((1, 2), (2, 16)):
+        cols = []
+        for d in (d1, d2):
+            xp = np.pad(x, ((0, 0), (d, d), (d, d), (0, 0)))
+            cols += [xp[:, d + ty * d:d + ty * d + 9, d + tx * d:d + tx * d + 11] for ty in (-1, 0, 1) for tx in (-1, 0, 1)]
+        z = np.concatenate(cols, axis=-1)
+        got = F.conv2d(nchw(z), wt(adapnet.dilated_pair_as_1x1(k1, k2)))
+        want = torch.cat([F.conv2d(nchw(x), wt(k1), padding=d1, dilation=d1),
+                          F.conv2d(nchw(x), wt(k2), padding=d2, dilation=d2)], dim=1)
+        assert np.array_equal(nhwc(got), nhwc(want))
+
+    shapes = adapnet.variable_shapes('rgb', 3, 20, 14)
+    assert shapes['rgb/first_deconvolution_upconv/kernel'] == (4, 4, 20, 2048)
+    assert shapes['rgb/block_layer_7/stage_2_1/kernel'] == (3, 3, 128, 32) and 'rgb/block_layer_7/stage_2_1/bias' not in shapes
+    assert {k: tuple(v.shape) for k, v in ao.init_adapnet_weights('rgb', 3, 20, 14).items()} == shapes
+    init = adapnet.init_variables('rgb', 3, 20, 14, seed=0)
+    assert np.array_equal(init['rgb/second_deconvolution_upconv/kernel'], ao.rect_bilinear_kernel(16, 14, 20))

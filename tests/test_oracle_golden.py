@@ -18,6 +18,13 @@ def test_bilinear_kernels_match_reference(golden_dir):
     g = _g(golden_dir, 'bilinear_kernels.npz')
     np.testing.assert_array_equal(fo.bilinear_kernel(4, 5), g['k4'].astype(np.float32))
     np.testing.assert_array_equal(fo.bilinear_kernel(16, 3), g['k16'].astype(np.float32))
+    # AdapNet's [k,k,filters,in] deconv kernels: oracle and product initialiser
+    from oracle import adapnet_oracle as ao
+    from modular_semantic_segmentation_amd.custom_layers import bilinear_filter
+    np.testing.assert_array_equal(ao.rect_bilinear_kernel(4, 3, 7), g['k4_rect'].astype(np.float32))
+    np.testing.assert_array_equal(ao.rect_bilinear_kernel(16, 2, 5), g['k16_rect'].astype(np.float32))
+    np.testing.assert_array_equal(bilinear_filter((4, 4, 3, 7)), g['k4_rect'].astype(np.float32))
+    np.testing.assert_array_equal(bilinear_filter((16, 16, 2, 5)), g['k16_rect'].astype(np.float32))
 
 
 def test_score_measures_match_notebook(golden_dir):
