@@ -59,7 +59,8 @@ int xv_pack_conv_weights(const float* w_hwio, void* packed, int k, int cin, int 
  * y = act(conv(x, W) + b): tf.layers.conv2d(padding='same', strides 1) via
  * custom_layers.py:124-139 (call sites simple_fcn.py:39-79).  Implicit GEMM on bf16 MFMA
  * (v_mfma_f32_16x16x32_bf16, fp32 accumulate), input halo tile + weight tile staged in LDS.
- * k = 3 (conv1_2 .. conv5_3) or 1 (score_conv4 / score_conv5); cin % 64 == 0, cout % 64 == 0.
+ * k = 3 (conv1_2 .. conv5_3) or 1 (score_conv4 / score_conv5, AdapNet's block stages: a flat GEMM over the padded rows
+ * from 256 input channels, conv1x1_gemm.hip); cin % 64 == 0, cout % 64 == 0.
  * Inference batch-norm is folded into (W, b) by the host before packing.
  * If pooled != NULL (k = 3 only, h and w even) the 2x2/2 max-pool of y
  * (max_pooling2d, simple_fcn.py:41,44,48,58) is written to `pooled` from the same accumulators;

@@ -20,6 +20,10 @@
 #define XV_CONV_PFD 2
 #endif
 
+// conv1x1_gemm.hip
+int xv_launch_conv1x1_gemm(const __bf16* x, const __bf16* wpk, const float* bias, __bf16* y, const __bf16* mask,
+                           const __bf16* addend, int N, int H, int W, int Cin, int Cout, int relu, hipStream_t stream);
+
 namespace {
 
 struct ConvArgs {
@@ -1118,7 +1122,9 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, __bf16* __restr
 // Tried and dropped (slower, tools/conv_tune.py): 8-wave 128-channel tiles with 2-3 taps per barrier,
 // a single-weight-buffer variant at three workgroups per CU, two-wave workgroups at four per CU,
 // weight fragments streamed L1 -> VGPR without LDS, s_setprio around the MFMA clusters.
-constexpr int XV_NUM_CONV_CFG = 18;
+//  18: generation 3 for 1x1 convs (conv1x1_gemm.hip): flat GEMM over the padded rows, 128 px x 128 channels, 4 waves,
+//      both operands by LDS-DMA, 64 KB, 2/CU
+constexpr int XV_NUM_CONV_CFG = 19;
 struct Geo {
   int th, tw, bn, per_cu;
 };
@@ -1126,7 +1132,7 @@ const Geo kGeo[XV_NUM_CONV_CFG] = {{16, 16, 128, 2}, {8, 16, 128, 2}, {8, 32, 12
                                    {16, 16, 64, 2},  {16, 32, 64, 1}, {8, 32, 64, 2},  {8, 16, 256, 1},
                                    {16, 16, 128, 1}, {8, 32, 128, 1}, {16, 16, 64, 2},  {8, 32, 64, 2},
                                    {16, 32, 64, 1},  {16, 32, 64, 1},  {16, 16, 64, 2},  {8, 32, 64, 2},
-                                   {16, 32, 64, 1},  {16, 32, 64, 1}};
+                                   {16, 32, 64, 1},  {16, 32, 64, 1},  {1, 128, 128, 2}};
 
 template <int KS>
 int launch_cfg(int cfg, const ConvArgs& a, hipStream_t s) {
@@ -1150,8 +1156,14 @@ int launch_cfg(int cfg, const ConvArgs& a, hipStream_t s) {
     case 14: return launch_conv<4, 4, 1, 1, KS, 2, 2, 1>(a, s);
     case 15: return launch_conv<4, 2, 2, 1, KS, 2, 2, 1>(a, s);
     case 16: return launch_conv<4, 4, 2, 1, KS, 2, 5, 1>(a, s);
-    default:
+    case 17:
       if constexpr (KS == 3) return launch_conv_dma<4, 2>(a, s);
+      return XV_ESHAPE;
+    default:
+      if constexpr (KS == 1) {
+        if (a.pooled != nullptr || a.y == nullptr) return XV_ESHAPE;
+        return xv_launch_conv1x1_gemm(a.x, a.wpk, a.bias, a.y, a.mask, a.addend, a.N, a.H, a.W, a.Cin, a.Cout, a.relu, s);
+      }
       return XV_ESHAPE;
   }
 }
@@ -1170,7 +1182,9 @@ int pick_cfg(const ConvArgs& a, int k) {
   // 16x16 / 8x32 tiles of generation 1 (e.g. the 24x48 conv5 maps of a 768x384 input)
   if (k == 3 && covered(17) <= 1.25 * g1) return 17;
   // 1x1 convs (plain GEMMs, AdapNet's block stages): 128 output channels per workgroup halve the activation re-reads
-  // (tools/conv1x1_tune.py: 1.1-1.7x over the 64-channel tiles from 128 input channels up)
+  // (tools/conv1x1_tune.py: 1.1-1.7x over the 64-channel tiles from 128 input channels up); from 256 input channels
+  // the flat-GEMM kernel (generation 3) is ahead by another 1.1-1.5x
+  if (k == 1 && a.Cout % 128 == 0 && a.Cin >= 256 && a.pooled == nullptr && a.y != nullptr) return 18;
   if (k == 1 && a.Cout % 128 == 0 && a.Cin >= 128 && covered(1) <= 1.1 * g1) return 1;
   return covered(15) < covered(14) ? 15 : 14;
 }

@@ -96,14 +96,36 @@ def test_conv2d_every_tile_configuration(ops, k):
         try:
             y, _ = ops.conv2d_fwd(xa, wp, bd, k, relu=True, pooled=q, cfg=cfg)
         except _lib.XvError:
-            assert cfg >= 17 and k == 1      # generation-2 configurations are 3x3 only
+            assert (cfg == 17 and k == 1) or (cfg == 18 and k == 3)    # generation 2 is 3x3 only, generation 3 1x1 only
             continue
         ran += 1
         torch.cuda.synchronize()
         assert np.array_equal(y.interior().float().cpu().numpy(), ref), 'cfg %d' % cfg
         if q is not None:
             assert np.array_equal(q.interior().float().cpu().numpy(), refq), 'cfg %d pooled' % cfg
-    assert ran >= (18 if k == 3 else 17)
+    assert ran == 18
+
+
+@pytest.mark.parametrize('n,h,w,cin,cout', [(1, 6, 10, 64, 128), (2, 24, 48, 576, 256), (3, 7, 5, 128, 384),
+                                            (1, 30, 33, 256, 128)])
+def test_conv1x1_flat_gemm(ops, n, h, w, cin, cout):
+    """Generation 3 (flat GEMM over the padded rows, cfg 18): exact on integers, with activation + addend + mask in
+    the order of the other kernels, border untouched, row counts that are not multiples of the 128-row tile."""
+    rng = np.random.default_rng(n * h * w + cin)
+    x = rng.integers(-2, 3, (n, h, w, cin)).astype(np.float32)
+    wt = rng.integers(-1, 2, (1, 1, cin, cout)).astype(np.float32)
+    b = rng.integers(-3, 4, cout).astype(np.float32)
+    xa, wp, bd = ops.Act.from_dense(_dev(x)), ops.pack_conv_weights(_dev(wt)), _dev(b)
+    y, _ = ops.conv2d_fwd(xa, wp, bd, 1, relu=True, cfg=18)
+    torch.cuda.synchronize()
+    _, ref = _conv_oracle(x, wt, b, True, 1)
+    assert np.array_equal(y.interior().float().cpu().numpy(), ref)
+    for edge in (y.t[:, 0], y.t[:, -1], y.t[:, :, 0], y.t[:, :, -1]):
+        assert not edge.any()
+    y0, _ = ops.conv2d_fwd(xa, wp, bd, 1, relu=False, cfg=18)
+    y1, _ = ops.conv2d_fwd(xa, wp, bd, 1, relu=False, cfg=14)
+    torch.cuda.synchronize()
+    assert torch.equal(y0.t, y1.t)
 
 
 @pytest.mark.parametrize('shape', [(2, 16, 32, 64, 64), (3, 32, 64, 128, 192), (1, 48, 96, 32, 64),

@@ -19,7 +19,7 @@ SHAPES = [(96, 192, 64, 64), (96, 192, 64, 256), (96, 192, 256, 64), (48, 96, 25
           (24, 48, 4608, 256), (24, 48, 1024, 512), (24, 48, 9216, 512), (24, 48, 512, 2048), (24, 48, 2048, 512),
           (24, 48, 1024, 2048), (24, 48, 2048, 64)]
 ncfg = _lib.lib().xv_conv2d_num_cfgs()
-print('%-24s' % 'h x w x cin -> cout' + ''.join('%6d' % c for c in range(ncfg - 1)) + '   best')
+print('%-24s' % 'h x w x cin -> cout' + ''.join('%6d' % c for c in range(ncfg)) + '   best')
 for h, w, cin, cout in SHAPES:
     x = ops.Act(args.batch, h, w, cin)
     x.interior().normal_()
@@ -28,7 +28,7 @@ for h, w, cin, cout in SHAPES:
     y = ops.Act(args.batch, h, w, cout)
     flops = 2.0 * args.batch * h * w * cin * cout
     row, best = [], (0.0, -1)
-    for cfg in range(ncfg - 1):                     # the last configuration is 3x3 only
+    for cfg in range(ncfg):                         # configurations that cannot run a shape report XV_ESHAPE
         try:
             ops.conv2d_fwd(x, wp, b, 1, y=y, cfg=cfg)
         except _lib.XvError:
