@@ -162,6 +162,21 @@ def test_adapnet_graph_matches_oracle(ops, tmp_path):
     assert len(np.unique(ref_label)) > 2
 
 
+@pytest.mark.parametrize('n,h,w,cin', [(1, 16, 32, 1), (3, 48, 80, 3)])
+def test_adapnet_small_and_odd_shapes(ops, tmp_path, n, h, w, cin):
+    """Maps down to 1x2 pixels at stride 16 (every atrous tap but the centre off the image), a depth-style one-channel
+    input, batch sizes that do not fill a GEMM row tile."""
+    from modular_semantic_segmentation_amd.adapnet import AdapnetEngine
+    w_, _ = _weights(tmp_path, 'm', cin, 7, 0.02)
+    x = np.random.default_rng(h).integers(0, 256, (n, h, w, cin)).astype(np.float32)
+    out = AdapnetEngine('m', cin, U, C, w_).forward(_dev(x), want=('score', 'label'))
+    torch.cuda.synchronize()
+    ref = ao.adapnet_forward(x, w_, 'm', policy='bf16')
+    score = out['score'].cpu().numpy()
+    assert np.abs(score - ref['score']).max() / np.abs(ref['score']).max() < 3e-2
+    assert np.array_equal(out['label'].cpu().numpy(), fo.argmax_last(fo.softmax(score)))
+
+
 def test_adapnet_model_and_fusion_classes(ops, tmp_path):
     from modular_semantic_segmentation_amd import get_model
     w_rgb, p_rgb = _weights(tmp_path, 'rgb', 3, 1, 0.02)
