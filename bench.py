@@ -136,12 +136,22 @@ def bench_train(args, device, world, rank, dist):
     all-reduced in three buckets on a side stream during backward (RCCL over xGMI)."""
     from modular_semantic_segmentation_amd import get_model
     desc = ({'rgb': 'float32', 'labels': 'int32'}, {'rgb': (None, None, 3), 'labels': (None, None)}, C)
-    net = get_model('fcn')('rgb', desc, 'rgb', num_units=U, batch_normalization=bool(args.batch_norm), batchsize=args.batch,
-                           learning_rate=1e-4, trainer='adam', seed=1, device=str(device), sync_loss=False)
+    joint = args.fusion == 'joint'
     gen = torch.Generator(device='cpu').manual_seed(99 + rank)
     rgb = torch.randint(0, 256, (args.batch, args.height, args.width, 3), generator=gen).float().to(device)
     labels = torch.randint(-1, C, (args.batch, args.height, args.width), generator=gen).int().to(device)
     batch = {'rgb': rgb, 'labels': labels}
+    if joint:
+        # the joint two-stream model (FusionFCN, [reference default] RMSProp): both trunks + fused decoder with batch norm
+        net = get_model('fusion_fcn')({'rgb': 'rgb', 'depth': 'depth'}, {'rgb': 3, 'depth': 1}, U, C, batchsize=args.batch,
+                                      learning_rate=1e-4, trainer='rmsprop', seed=1, device=str(device), sync_loss=False)
+        net.variables['depth_conv1_1/kernel'] = net.variables['depth_conv1_1/kernel'] / 256.0
+        net._variables_changed()
+        batch['depth'] = torch.randint(0, 65536, (args.batch, args.height, args.width, 1), generator=gen).float().to(device)
+    else:
+        net = get_model('fcn')('rgb', desc, 'rgb', num_units=U, batch_normalization=bool(args.batch_norm),
+                               batchsize=args.batch, learning_rate=1e-4, trainer='adam', seed=1, device=str(device),
+                               sync_loss=False)
     for _ in range(args.warmup):
         net._train_batch(batch)
 
@@ -164,15 +174,23 @@ def bench_train(args, device, world, rank, dist):
     if rank == 0:
         images = args.batch * world * args.steps
         flops = 3.0 * conv_flops_per_image(args.height, args.width, 3)
+        if joint:
+            flops += 3.0 * conv_flops_per_image(args.height, args.width, 1)
+        metric = 'images/sec, SimpleFCN RGB expert training step (fwd + bwd + Adam%s) at %dx%d' % (
+            ', batch norm' if args.batch_norm else '', args.width, args.height)
+        workload = 'SimpleFCN RGB %dx%d training, U=%d, C=%d, Adam' % (args.width, args.height, U, C)
+        if joint:
+            metric = 'RGB-D images/sec, fusion_fcn joint model training step (fwd + bwd + RMSProp, decoder batch norm) at %dx%d' % (
+                args.width, args.height)
+            workload = 'fusion_fcn RGB+Depth %dx%d training, U=%d, C=%d, RMSProp' % (args.width, args.height, U, C)
         print(json.dumps({
-            'metric': 'images/sec, SimpleFCN RGB expert training step (fwd + bwd + Adam%s) at %dx%d' % (
-                ', batch norm' if args.batch_norm else '', args.width, args.height),
+            'metric': metric,
             'value': round(images / dt, 2), 'unit': 'images/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
-            'config': {'workload': 'SimpleFCN RGB %dx%d training, U=%d, C=%d, Adam' % (args.width, args.height, U, C),
+            'config': {'workload': workload,
                        'images_per_gpu_per_step': args.batch, 'global_batch': args.batch * world,
-                       'parallelism': 'dp%d, 3-bucket gradient all-reduce overlapped with backward' % world},
+                       'parallelism': 'dp%d, bucketed gradient all-reduce overlapped with backward' % world},
             'conv_tflops_end_to_end': round(images * flops / dt / 1e12, 2)}))
     if world > 1:
         dist.destroy_process_group()

@@ -7,8 +7,8 @@ reference calls decoder() without `batchnorm`, i.e. with its default batch norm 
 `fused/score`: the first goes through the general (un-commuted) decoder head unless it is scale-only, the second
 is folded into the 1x1 score weights.
 
-Inference graph only in this round (functional `vgg16` / `fusion_fcn` as used by experiments/timing.py:24-45 and
-the `FusionFCN` model's predict / score / import / export); training the joint model is not built yet.
+Functional `vgg16` / `fusion_fcn` as used by experiments/timing.py:24-45, and the `FusionFCN` model with predict /
+score / import / export and `fit` (trainer.FusionFcnTrainer: batch norm of the decoder in training mode).
 """
 import numpy as np
 import torch
@@ -322,11 +322,42 @@ class FusionFCN(BaseModel):
 
     def _variables_changed(self):
         self.engine.load(self.variables)
+        if getattr(self, 'trainer', None) is not None:
+            self.trainer.load_from_variables(self.variables)
+
+    # ---- training (FusionFCN._build_graph :50-92; optimizer setup base_model.py:153-162) -------------------------
+    def _ensure_trainer(self):
+        if getattr(self, 'trainer', None) is None:
+            from .trainer import FusionFcnTrainer
+            from .parallel import GradReducer, world
+            self.trainer = FusionFcnTrainer(self.engine, self.config.get('trainer', 'rmsprop'),
+                                            self.config.get('learning_rate', 0.0001))
+            self.trainer.load_from_variables(self.variables)
+            self._reducer = GradReducer(self.device) if world()[1] > 1 else None
+        return self.trainer
 
     def _train_batch(self, batch):
-        raise NotImplementedError('training the joint fusion_fcn model is not built on this path yet')
+        tr = self._ensure_trainer()
+        x = {m: self._to_device(batch[m], torch.float32) for m in self.modalities}
+        labels = self._to_device(batch['labels'], torch.int32)
+        self.loss = tr.step(x, labels, reducer=self._reducer)
+        self._dirty = True
+        return self.loss.item() if self.config.get('sync_loss', True) else 0.0
+
+    def _sync_variables(self):
+        """Master weights and moving statistics back into the variable dict; the inference engine folds the batch norm
+        of the decoder into its weights, so it is rebuilt from them."""
+        if getattr(self, 'trainer', None) is not None and getattr(self, '_dirty', False):
+            self.trainer.to_variables(self.variables)
+            self._dirty = False
+            self.engine.load(self.variables)
+
+    def export_weights(self, save_dir=None):
+        self._sync_variables()
+        return BaseModel.export_weights(self, save_dir)
 
     def _predict_batch_impl(self, batch, output_attr=None):
+        self._sync_variables()
         x = {m: self._to_device(batch[m], torch.float32) for m in self.modalities}
         self.engine.concurrent = getattr(self, 'concurrent_experts', True)     # one stream per trunk unless told otherwise
         want = output_attr if output_attr in ('prob', 'score') else 'label'

@@ -23,6 +23,43 @@ BUCKETS = [['score', 'score_conv5', 'score_conv4', 'conv5_3', 'conv5_2', 'conv5_
            ['conv3_3', 'conv3_2', 'conv3_1', 'conv2_2', 'conv2_1', 'conv1_2', 'conv1_1']]
 
 
+def encoder_backward(x, L, g, ds4, wd_s4, wd, zero_bias, G, gact, wws, after_layer=None):
+    """Backward walk over the 13 trunk convs (relu + fused pools) of one modality.
+    x: raw network input; L: forward layer dict (every convX_Y and poolX); g: gradient w.r.t. conv5_3's output, already
+    masked by its relu; ds4 / wd_s4: gradient of the 1x1 score conv on conv4_3 and its packed data-gradient weights
+    (the second path into conv4_3, AddN); wd[name]: packed data-gradient weights; G(name, kind): gradient views;
+    gact(like, tag): scratch activations; after_layer(name): called once a layer's filter gradient is complete."""
+    names = [nm for nm, _, _ in ENCODER]
+    pool_after = {nm: pl for nm, _, pl in ENCODER}
+    inputs, prev = {}, None
+    for nm in names:
+        inputs[nm] = prev
+        prev = pool_after[nm] if pool_after[nm] else nm
+    for nm in reversed(names):
+        xin = inputs[nm]
+        if nm == 'conv1_1':
+            ops.conv2d_first_bwd_filter(x, g, G(nm, 'kernel'), G(nm, 'bias'))
+        else:
+            ops.conv2d_bwd_filter(L[xin], g, G(nm, 'kernel'), G(nm, 'bias'), 3, workspace=wws)
+        if after_layer is not None:
+            after_layer(nm)
+        if nm == 'conv1_1':
+            break
+        if xin.startswith('pool'):
+            # gradient w.r.t. the pooled map, then MaxPoolGrad + ReluGrad onto the conv above
+            dpool = ops.conv2d_bwd_data(g, wd[nm], zero_bias, gact(L[xin], 'g_' + xin), 3)
+            above = names[names.index(nm) - 1]
+            routed = ops.maxpool2x2_bwd(L[above], dpool, gact(L[above], 'r_' + above))
+            if above == 'conv4_3':
+                # second gradient path into conv4_3: through the 1x1 score conv (AddN), then its relu
+                g = ops.conv2d_bwd_data(ds4, wd_s4, zero_bias, gact(L[above], 'g_' + above), 1, relu_ref=L[above],
+                                        addend=routed)
+            else:
+                g = routed
+        else:
+            g = ops.conv2d_bwd_data(g, wd[nm], zero_bias, gact(L[xin], 'g_' + xin), 3, relu_ref=L[xin])
+
+
 class FcnTrainer(object):
     def __init__(self, engine, trainer='adam', learning_rate=1e-4):
         self.e = engine
@@ -174,40 +211,14 @@ class FcnTrainer(object):
         ops.conv2d_bwd_filter(L['conv4_3'], ds4, G('score_conv4', 'kernel'), G('score_conv4', 'bias'), 1, workspace=wws)
         g = ops.conv2d_bwd_data(ds5, self.wd['score_conv5'], self.zero_bias, self._gact(L['conv5_3'], 'g_conv5_3'), 1,
                                 relu_ref=L['conv5_3'])
-        # walk the encoder backwards
-        names = [nm for nm, _, _ in ENCODER]
-        pool_after = {nm: pl for nm, _, pl in ENCODER}
-        inputs = {}
-        prev = None
-        for nm in names:
-            inputs[nm] = prev
-            prev = pool_after[nm] if pool_after[nm] else nm
-        done_buckets = 0
-        for nm in reversed(names):
-            xin = inputs[nm]
-            if nm == 'conv1_1':
-                ops.conv2d_first_bwd_filter(x, g, G(nm, 'kernel'), G(nm, 'bias'))
-            else:
-                ops.conv2d_bwd_filter(L[xin], g, G(nm, 'kernel'), G(nm, 'bias'), 3, workspace=wws)
-            if reducer is not None and nm == BUCKETS[done_buckets][-1]:
-                reducer.launch(self.grad, self.bucket_ranges[done_buckets])
-                done_buckets += 1
-            if nm == 'conv1_1':
-                break
-            if xin.startswith('pool'):
-                # gradient w.r.t. the pooled map, then MaxPoolGrad + ReluGrad onto the conv above
-                dpool = ops.conv2d_bwd_data(g, self.wd[nm], self.zero_bias, self._gact(L[xin], 'g_' + xin), 3)
-                above = names[names.index(nm) - 1]
-                routed = ops.maxpool2x2_bwd(L[above], dpool, self._gact(L[above], 'r_' + above))
-                if above == 'conv4_3':
-                    # second gradient path into conv4_3: through score_conv4 (AddN), then its relu
-                    g = ops.conv2d_bwd_data(ds4, self.wd['score_conv4'], self.zero_bias,
-                                            self._gact(L[above], 'g_' + above), 1, relu_ref=L[above], addend=routed)
-                else:
-                    g = routed
-            else:
-                g = ops.conv2d_bwd_data(g, self.wd[nm], self.zero_bias, self._gact(L[xin], 'g_' + xin), 3,
-                                        relu_ref=L[xin])
+        state = {'done': 0}
+
+        def after_layer(nm):
+            if reducer is not None and state['done'] < len(BUCKETS) and nm == BUCKETS[state['done']][-1]:
+                reducer.launch(self.grad, self.bucket_ranges[state['done']])
+                state['done'] += 1
+
+        encoder_backward(x, L, g, ds4, self.wd['score_conv4'], self.wd, self.zero_bias, G, self._gact, wws, after_layer)
         scale = 1.0
         if reducer is not None:
             reducer.wait()
@@ -528,6 +539,270 @@ class FcnBnTrainer(object):
                 g = dx
         if reducer is not None:
             reducer.launch(self.grad, (0, self.total))
+            reducer.wait()
+        self.t += 1
+        FcnTrainer._apply(self, 1.0)
+        self.repack()
+        return self.loss
+
+
+# =========================================================================================================
+# Training the joint two-stream model fusion_fcn (fusion_fcn.py:11-40, FusionFCN._build_graph :50-92)
+# =========================================================================================================
+class FusionFcnTrainer(object):
+    """One training step of the joint model: per modality the relu / pool-fused VGG16 trunk of FcnTrainer (no batch
+    norm), `fused_score_conv4/5` over the channel concat of the trunks' conv4_3 / conv5_3 maps, the constant x2 deconv
+    + add, and decoder() with its default batch norm in training mode -- the un-commuted head of FcnBnTrainer
+    (`fused/upscore` normalised between the x8 deconv and its relu, `fused/score` normalised after the 1x1 conv).
+
+    The concat only exists in the forward pass: a 1x1 conv over concatenated channels is the sum of one 1x1 conv per
+    modality, so the filter gradient is taken per 512-row block of the kernel and the data gradient per modality with
+    that block's weights, straight into the trunk walk (encoder_backward)."""
+
+    HEAD = ('score', 'upscore')            # decoder layers with batch norm (scope `fused/`)
+
+    def __init__(self, engine, trainer='rmsprop', learning_rate=1e-4):
+        if trainer not in ('adam', 'rmsprop', 'adagrad'):
+            raise KeyError(trainer)
+        self.e, self.kind, self.lr = engine, trainer, float(learning_rate)
+        e, dev = engine, engine.device
+        self.mods = list(e.prefixes)
+        nm = len(self.mods)
+        entries = [(('score', 'kernel'), (e.Up, e.C)), (('score', 'bias'), (e.C,)), (('score', 'gamma'), (e.C,)),
+                   (('score', 'beta'), (e.C,)), (('upscore', 'gamma'), (e.Up,)), (('upscore', 'beta'), (e.Up,))]
+        for name in ('fused_score_conv5', 'fused_score_conv4'):
+            entries += [((name, 'kernel'), (1, 1, 512 * nm, e.Up)), ((name, 'bias'), (e.Up,))]
+        self.bucket_ranges, total = [], 0
+        self.offsets = {}
+
+        def place(items):
+            nonlocal total
+            b0 = total
+            for key, shape in items:
+                n = int(np.prod(shape))
+                self.offsets[key] = (total, n, shape)
+                total += (n + 63) // 64 * 64
+            self.bucket_ranges.append((b0, total))
+
+        place(entries)
+        for m in self.mods:                # one bucket per trunk, in backward order
+            cins = [e.num_channels[m]] + [c for _, c, _ in ENCODER[:-1]]
+            items = []
+            for (name, cout, _), cin in reversed(list(zip(ENCODER, cins))):
+                items += [(((m, name), 'kernel'), (3, 3, cin, cout)), (((m, name), 'bias'), (cout,))]
+            place(items)
+        self.total = total
+        self.param = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.grad = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.bn_channels = {'score': e.C, 'upscore': e.Up}
+        self.moving = {k: (torch.zeros(c, device=dev), torch.ones(c, device=dev)) for k, c in self.bn_channels.items()}
+        self.bn = {k: ops.BnState(c, dev) for k, c in self.bn_channels.items()}
+        self.state, self.t = {}, 0
+        self.zero_bias = torch.zeros(512, dtype=torch.float32, device=dev)
+        self.count = torch.zeros(1, dtype=torch.int64, device=dev)
+        self.loss = torch.zeros(1, dtype=torch.float64, device=dev)
+        self.wd, self._a, self._sync = {}, {}, False
+
+    def view(self, buf, name, kind):
+        off, n, shape = self.offsets[(name, kind)]
+        return buf[off:off + n].view(*shape)
+
+    # ---- variables <-> master buffer ---------------------------------------------------------------------
+    def _names(self):
+        """(key in the master buffer, kind, variable name in the reference schema, real leading/trailing slice)."""
+        e = self.e
+        for m in self.mods:
+            for name, _, _ in ENCODER:
+                for kind in ('kernel', 'bias'):
+                    yield (m, name), kind, '%s_%s/%s' % (e.prefixes[m], name, kind)
+        for name in ('fused_score_conv4', 'fused_score_conv5'):
+            for kind in ('kernel', 'bias'):
+                yield name, kind, '%s/%s' % (name, kind)
+        for kind in ('kernel', 'bias', 'gamma', 'beta'):
+            yield 'score', kind, 'fused/score/' + kind
+        for kind in ('gamma', 'beta'):
+            yield 'upscore', kind, 'fused/upscore/' + kind
+
+    def _real(self, key, kind, t):
+        """View of the channels that exist in the reference graph (U of the Up padded lanes)."""
+        e = self.e
+        if key == 'score' and kind == 'kernel':
+            return t[:e.U]
+        if key in ('fused_score_conv4', 'fused_score_conv5') or (key == 'upscore'):
+            return t[..., :e.U]
+        return t
+
+    def load_from_variables(self, variables):
+        e = self.e
+        self.param.zero_()
+        self.view(self.param, 'upscore', 'gamma').fill_(1.0)     # padding lanes: gamma 1, beta 0, maps stay zero
+        for key, kind, vname in self._names():
+            src = torch.from_numpy(np.asarray(variables[vname], np.float32))
+            dst = self._real(key, kind, self.view(self.param, key, kind))
+            dst.copy_(src.reshape(dst.shape))
+        for key, layer in (('score', 'fused/score'), ('upscore', 'fused/upscore')):
+            mm, mv = self.moving[key]
+            mm.zero_()
+            mv.fill_(1.0)
+            real = e.C if key == 'score' else e.U
+            mm[:real].copy_(torch.from_numpy(np.asarray(variables[layer + '/moving_mean'], np.float32)))
+            mv[:real].copy_(torch.from_numpy(np.asarray(variables[layer + '/moving_variance'], np.float32)))
+        self.repack()
+
+    def _export(self, buf):
+        out = {}
+        for key, kind, vname in self._names():
+            t = self._real(key, kind, self.view(buf, key, kind)).cpu().numpy()
+            if key == 'score' and kind == 'kernel':
+                t = t.reshape(1, 1, self.e.U, self.e.C)
+            out[vname] = np.ascontiguousarray(t)
+        return out
+
+    def to_variables(self, variables):
+        variables.update(self._export(self.param))
+        for key, layer in (('score', 'fused/score'), ('upscore', 'fused/upscore')):
+            real = self.e.C if key == 'score' else self.e.U
+            variables[layer + '/moving_mean'] = self.moving[key][0][:real].cpu().numpy().copy()
+            variables[layer + '/moving_variance'] = self.moving[key][1][:real].cpu().numpy().copy()
+
+    def grads_as_variables(self):
+        return self._export(self.grad)
+
+    def repack(self):
+        """Master fp32 weights -> packed bf16 forward weights inside the engine's trunks, packed data-gradient weights
+        here (per modality for the 512-row blocks of the fused 1x1 kernels)."""
+        e, dev = self.e, self.e.device
+
+        def packed(store, key, kv, dgrad):
+            if key not in store:
+                k, _, cin, cout = kv.shape
+                store[key] = torch.empty(ops.packed_weight_elems(k, cin, cout), dtype=torch.bfloat16, device=dev)
+            (ops.pack_conv_weights_dgrad if dgrad else ops.pack_conv_weights_into)(kv, store[key])
+
+        for m in self.mods:
+            trunk = e.trunks[m]
+            for name, _, _ in ENCODER:
+                kv = self.view(self.param, (m, name), 'kernel')
+                trunk.b[name] = self.view(self.param, (m, name), 'bias')
+                if name == 'conv1_1':
+                    trunk.w[name] = kv
+                    continue
+                if not getattr(trunk, '_trainer_owned', False) or name not in trunk.w:
+                    trunk.w[name] = torch.empty(ops.packed_weight_elems(3, kv.shape[2], kv.shape[3]), dtype=torch.bfloat16,
+                                                device=dev)
+                ops.pack_conv_weights_into(kv, trunk.w[name])
+                packed(self.wd, (m, name), kv, True)
+            trunk._trainer_owned = True
+        for name in ('fused_score_conv4', 'fused_score_conv5'):
+            kv = self.view(self.param, name, 'kernel')
+            e.b[name] = self.view(self.param, name, 'bias')
+            packed(e.w, name, kv, False)
+            for i, m in enumerate(self.mods):
+                packed(self.wd, (m, name), kv[:, :, 512 * i:512 * (i + 1), :].contiguous(), True)
+
+    # ---- scratch -----------------------------------------------------------------------------------------------
+    def _act(self, tag, n, h, w, c):
+        key = (tag, n, h, w, c)
+        a = self._a.get(key)
+        if a is None:
+            a = self._a[key] = ops.Act(n, h, w, c, self.e.device)
+        return a
+
+    def _gact(self, like, tag):
+        return self._act(tag, like.n, like.h, like.w, like.c)
+
+    def _dense(self, tag, shape):
+        key = (tag,) + tuple(shape)
+        t = self._a.get(key)
+        if t is None:
+            t = self._a[key] = torch.empty(shape, dtype=torch.float32, device=self.e.device)
+        return t
+
+    # ---- one training step ----------------------------------------------------------------------------------
+    def step(self, inputs, labels, reducer=None):
+        """inputs: {modality: float32 [N,H,W,c]}, labels: int32 [N,H,W] (device tensors) -> loss (device float64)."""
+        e = self.e
+        P = lambda name, kind: self.view(self.param, name, kind)   # noqa: E731
+        G = lambda name, kind: self.view(self.grad, name, kind)    # noqa: E731
+        x0 = inputs[self.mods[0]]
+        n, h, w, _ = x0.shape
+        h8, w8 = h // 8, w // 8
+        self.grad.zero_()
+        self.loss.zero_()
+        self.count.zero_()
+        ops.count_valid_labels(labels, e.C, self.count)
+        self._sync = reducer is not None
+        if reducer is not None:
+            reducer.allreduce_now(self.count)
+        # ---- forward ---------------------------------------------------------------------------------------------
+        L = {m: e.trunks[m].forward(inputs[m], keep_all=True) for m in self.mods}
+
+        def concat(name):
+            cur = L[self.mods[0]][name]
+            for i, m in enumerate(self.mods[1:]):
+                nxt = L[m][name]
+                cur = ops.concat_channels(cur, nxt, self._act('cat_%s_%d' % (name, i), cur.n, cur.h, cur.w, cur.c + nxt.c))
+            return cur
+
+        s4 = ops.conv2d_fwd(concat('conv4_3'), e.w['fused_score_conv4'], e.b['fused_score_conv4'], 1, relu=True,
+                            y=self._act('s4', n, h8, w8, e.Up))[0]
+        s5 = ops.conv2d_fwd(concat('conv5_3'), e.w['fused_score_conv5'], e.b['fused_score_conv5'], 1, relu=True,
+                            y=self._act('s5', n, h8 // 2, w8 // 2, e.Up))[0]
+        feat = ops.upsample2x_relu_add(s5, residual=s4, y=self._act('features', n, h8, w8, e.Up))
+        z_up = ops.upsample_raw_fwd(feat, 8, self._act('z_up', n, h, w, e.Up))
+        mm, mv = self.moving['upscore']
+        y_up = ops.bn_forward(z_up, P('upscore', 'gamma'), P('upscore', 'beta'), mm, mv, self.bn['upscore'],
+                              self._act('y_up', n, h, w, e.Up), relu=True, sync=self._sync)
+        score_raw = ops.score_dense_fwd(y_up, P('score', 'kernel'), P('score', 'bias'), e.C,
+                                        self._dense('score_raw', (n, h, w, e.C)))
+        mm, mv = self.moving['score']
+        logits = ops.bn_dense_forward(score_raw, P('score', 'gamma'), P('score', 'beta'), mm, mv, self.bn['score'],
+                                      self._dense('logits', (n, h, w, e.C)), sync=self._sync)
+        dlogits = ops.softmax_ce_dense(logits, labels, self.count, e.C, self.loss, self._dense('dlogits', (n, h, w, e.C)))
+        # ---- backward: head ------------------------------------------------------------------------------------
+        dscore = ops.bn_dense_backward(dlogits, score_raw, P('score', 'gamma'), self.bn['score'], G('score', 'gamma'),
+                                       G('score', 'beta'), self._dense('dscore', (n, h, w, e.C)), sync=self._sync)
+        du = ops.score_dense_bwd(y_up, dscore, P('score', 'kernel'), e.C, G('score', 'kernel'), G('score', 'bias'),
+                                 self._act('d_up', n, h, w, e.Up))
+        dz_up = ops.bn_backward(du, y_up, z_up, P('upscore', 'gamma'), self.bn['upscore'], G('upscore', 'gamma'),
+                                G('upscore', 'beta'), du, sync=self._sync)
+        dfeat = ops.upsample_raw_bwd(dz_up, 8, self._act('dfeat', n, h8, w8, e.Up))
+        ds4 = ops.relu_bwd(dfeat, s4, self._act('ds4', n, h8, w8, e.Up))
+        ds5 = ops.upsample2x_bwd(dfeat, s5, self._act('ds5', n, h8 // 2, w8 // 2, e.Up))
+        wkey = ('wgrad_ws', n, h, w)
+        if wkey not in self._a:
+            need = 0
+            for m in self.mods:
+                prev = None
+                for nm, cout, pool in ENCODER:
+                    if prev is not None:
+                        need = max(need, ops.conv2d_bwd_filter_workspace_bytes(L[m][prev], cout, 3))
+                    prev = pool if pool else nm
+                for src in ('conv4_3', 'conv5_3'):
+                    need = max(need, ops.conv2d_bwd_filter_workspace_bytes(L[m][src], e.Up, 1))
+            self._a[wkey] = torch.empty(max(need // 4, 1), dtype=torch.float32, device=e.device)
+        wws = self._a[wkey]
+        # ---- backward: fused 1x1 convs block by block, then each trunk ----------------------------------------------
+        for i, m in enumerate(self.mods):
+            rows = slice(512 * i, 512 * (i + 1))
+            first = i == 0                                      # the bias gradient is the same sum for every block
+            ops.conv2d_bwd_filter(L[m]['conv4_3'], ds4, G('fused_score_conv4', 'kernel')[:, :, rows, :],
+                                  G('fused_score_conv4', 'bias') if first else None, 1, workspace=wws)
+            ops.conv2d_bwd_filter(L[m]['conv5_3'], ds5, G('fused_score_conv5', 'kernel')[:, :, rows, :],
+                                  G('fused_score_conv5', 'bias') if first else None, 1, workspace=wws)
+        if reducer is not None:
+            reducer.launch(self.grad, self.bucket_ranges[0])
+        for i, m in enumerate(self.mods):
+            Lm = L[m]
+            g = ops.conv2d_bwd_data(ds5, self.wd[(m, 'fused_score_conv5')], self.zero_bias,
+                                    self._act('g5_' + m, n, h8 // 2, w8 // 2, 512), 1, relu_ref=Lm['conv5_3'])
+            wd = {name: self.wd[(m, name)] for name, _, _ in ENCODER[1:]}
+            Gm = lambda name, kind, m=m: self.view(self.grad, (m, name), kind)              # noqa: E731
+            gact = lambda like, tag, m=m: self._gact(like, '%s_%s' % (tag, m))              # noqa: E731
+            encoder_backward(inputs[m], Lm, g, ds4, self.wd[(m, 'fused_score_conv4')], wd, self.zero_bias, Gm, gact, wws)
+            if reducer is not None:
+                reducer.launch(self.grad, self.bucket_ranges[1 + i])
+        if reducer is not None:
             reducer.wait()
         self.t += 1
         FcnTrainer._apply(self, 1.0)

@@ -452,3 +452,62 @@ def fusion_fcn_forward(inputs, weights, prefixes, policy='fp32', keep=None):
         layers.update(concat_conv4=concat4, concat_conv5=concat5, score_conv4=s4, score_conv5=s5, upscore_conv5=up5,
                       features=features, upscore=upscore, score=score)
         return {k: layers[k].permute(0, 2, 3, 1).contiguous().numpy() for k in keep}
+
+
+def fusion_fcn_loss_and_grads(inputs, labels, weights, prefixes, num_classes, policy='fp32'):
+    """Training graph of the joint model (fusion_fcn.py:11-40 with is_training=True, loss of FusionFCN._build_graph
+    :87-92 = models/utils.py:43-53): trunks and the fused 1x1 convs without batch norm, decoder() with its default
+    batch norm in training mode on `fused/upscore` (between the x8 deconv and its relu) and `fused/score`.
+    Returns (loss, {variable: gradient}, {bn layer: (batch mean, unbiased batch variance)}).  policy as in
+    fcn_loss_and_grads."""
+    params, stats = {}, {}
+    rnd = (lambda t: t) if policy == 'fp32' else _RoundBf16STE.apply
+
+    def P(name):
+        t = _t(weights[name]).clone().requires_grad_(True)
+        params[name] = t
+        return t
+
+    def bn(y, layer):
+        g, b = P(layer + '/gamma'), P(layer + '/beta')
+        mean = y.mean(dim=(0, 2, 3), keepdim=True)
+        var = ((y - mean) ** 2).mean(dim=(0, 2, 3), keepdim=True)
+        m = y.shape[0] * y.shape[2] * y.shape[3]
+        stats[layer] = (mean.detach().numpy().ravel(), var.detach().numpy().ravel() * m / max(m - 1, 1))
+        return (y - mean) / torch.sqrt(var + 1e-3) * g.view(1, -1, 1, 1) + b.view(1, -1, 1, 1)
+
+    def conv(h, layer, first=False):
+        w, b = P(layer + '/kernel'), P(layer + '/bias')
+        k = w.shape[0]
+        y = F.conv2d(h, (w if first else rnd(w)).permute(3, 2, 0, 1), b, padding=(k - 1) // 2)
+        return rnd(F.relu(y))
+
+    def deconv(h, layer, stride):
+        w = _t(weights[layer + '/kernel'])
+        k = w.shape[0]
+        return F.conv_transpose2d(h, w.permute(3, 2, 0, 1).contiguous(), stride=stride, padding=(k - stride) // 2)
+
+    c4, c5 = [], []
+    for m, prefix in prefixes.items():
+        h = _t(np.asarray(inputs[m], np.float32)).permute(0, 3, 1, 2).contiguous()
+        for item in ENCODER_CONVS:
+            if isinstance(item, str):
+                h = F.max_pool2d(h, 2, 2)
+            else:
+                h = conv(h, '%s_%s' % (prefix, item[0]), first=item[0] == 'conv1_1')
+                if item[0] == 'conv4_3':
+                    c4.append(h)
+        c5.append(h)
+    s4 = conv(torch.cat(c4, dim=1), 'fused_score_conv4')
+    s5 = conv(torch.cat(c5, dim=1), 'fused_score_conv5')
+    features = rnd(s4 + F.relu(deconv(s5, 'fused_upscore_conv5', 2)))
+    up = rnd(F.relu(bn(rnd(deconv(features, 'fused/upscore', 8)), 'fused/upscore')))
+    w, b = P('fused/score/kernel'), P('fused/score/bias')
+    score = bn(F.conv2d(up, w.permute(3, 2, 0, 1), b), 'fused/score').permute(0, 2, 3, 1)
+    logp = F.log_softmax(score, dim=-1)
+    lab = _t(np.asarray(labels).astype(np.int64))
+    valid = (lab >= 0) & (lab < num_classes)
+    onehot = F.one_hot(lab.clamp(0, num_classes - 1), num_classes).float() * valid[..., None].float()
+    loss = -(onehot * logp).sum() / (1e-20 + onehot.sum())
+    loss.backward()
+    return float(loss.detach()), {k: v.grad.numpy() for k, v in params.items()}, stats

@@ -350,3 +350,80 @@ def test_training_step_with_batch_normalization(ops, tmp_path):
     ref = fo.fcn_forward(data['rgb'], {k: exported[k] for k in exported.files}, 'rgb', 'bf16')['score']
     score = net.predict(data, output_attr='score')
     assert np.abs(score - ref).max() < 5e-2 * np.abs(ref).max()
+
+
+def test_fusion_fcn_training_step(ops, tmp_path):
+    """Joint model (fusion_fcn.py:11-40, FusionFCN._build_graph :50-92): one step against autograd over the oracle's
+    restatement of the training graph -- loss, every kernel / bias / gamma / beta gradient, the decoder's moving
+    averages -- then fit(), export and inference with the trained statistics.
+
+    Tolerances are calibrated like the batch-norm step above: perturbing the oracle's own kernels by 3e-7 moves ITS
+    bf16-policy gradients by 0.5-5 % in the decoder head and by 10-19 % (L2) in the fused 1x1 convs and both trunks
+    (every gradient passes through the batch statistics of `fused/upscore` at full resolution); the step below sits at
+    9-14 % there (cosine 0.99), 0.4-4 % in the head."""
+    from modular_semantic_segmentation_amd import get_model
+    C, U, H, W = 12, 64, 32, 48
+    prefixes, channels = {'rgb': 'rgb', 'depth': 'depth'}, {'rgb': 3, 'depth': 1}
+    rng = np.random.default_rng(0)
+    data = {'rgb': rng.integers(0, 256, (2, H, W, 3)).astype(np.float32),
+            'depth': rng.integers(0, 65536, (2, H, W, 1)).astype(np.float32),
+            'labels': rng.integers(-1, C, (2, H, W)).astype(np.int32)}
+    w = fo.init_fusion_fcn_weights(prefixes, channels, U, C, seed=1, bias_scale=0.02)
+    w['rgb_conv1_1/kernel'] *= 0.02
+    w['depth_conv1_1/kernel'] *= 2e-4
+    for k in w:
+        if k.endswith('/kernel') and 'upscore' not in k and 'conv1_1' not in k:
+            w[k] *= 1.6
+    path = str(tmp_path / 'joint.npz')
+    np.savez(path, **w)
+    net = get_model('fusion_fcn')(prefixes, channels, U, C, trainer='rmsprop', learning_rate=1e-4,
+                                  output_dir=str(tmp_path), batchsize=2)
+    net.import_weights(path, warnings=False)
+    tr = net._ensure_trainer()
+    x = {m: _dev(data[m]) for m in prefixes}
+    loss = tr.step(x, _dev(data['labels']))
+    torch.cuda.synchronize()
+    got = tr.grads_as_variables()
+    ref_loss, ref_g, stats = fo.fusion_fcn_loss_and_grads({m: data[m] for m in prefixes}, data['labels'], w, prefixes, C,
+                                                          policy='bf16')
+    assert abs(loss.item() - ref_loss) < 1e-2 * abs(ref_loss)
+    assert set(got) == set(ref_g)
+    names = [k for k in ref_g if k != 'fused/score/bias']     # exactly zero: the batch norm subtracts the mean
+    rel = {k: _rel(got[k], ref_g[k]) for k in names}
+    cos = {}
+    for k in names:
+        a, b = got[k].ravel().astype(np.float64), ref_g[k].ravel().astype(np.float64)
+        cos[k] = a @ b / (np.linalg.norm(a) * np.linalg.norm(b))
+    print('joint model: gradient vs the bf16-policy oracle: relative error, cosine')
+    for k in sorted(names):
+        print('  %-30s %.4f %.4f' % (k, rel[k], cos[k]))
+    head = ('fused/score/gamma', 'fused/score/beta', 'fused/score/kernel', 'fused/upscore/gamma', 'fused/upscore/beta')
+    assert max(rel[k] for k in head) < 0.05, {k: rel[k] for k in head}
+    assert max(rel.values()) < 0.30, max(rel.items(), key=lambda kv: kv[1])
+    assert min(cos.values()) > 0.96, min(cos.items(), key=lambda kv: kv[1])
+    out = {}
+    tr.to_variables(out)
+    for layer in ('fused/upscore', 'fused/score'):
+        mean, var = stats[layer]
+        np.testing.assert_allclose(out[layer + '/moving_mean'], 0.99 * w[layer + '/moving_mean'] + 0.01 * mean,
+                                   rtol=2e-2, atol=2e-3)
+        np.testing.assert_allclose(out[layer + '/moving_variance'], 0.99 * w[layer + '/moving_variance'] + 0.01 * var,
+                                   rtol=2e-2, atol=2e-3)
+    # RMSProp ([TF1]: ms starts at 1): step = -lr * g / sqrt(0.9 + 0.1 g^2 + 1e-10)
+    k = 'rgb_conv3_2/kernel'
+    g = got[k]
+    # (the difference of two float32 weights of size ~0.02 is only known to an ulp, 1.9e-9)
+    np.testing.assert_allclose(out[k] - w[k], -1e-4 * g / np.sqrt(0.9 + 0.1 * g * g + 1e-10), rtol=1e-3, atol=4e-9)
+    first = net._train_batch(data)
+    for _ in range(8):
+        last = net._train_batch(data)
+    assert last < first
+    net.fit(data, 2, output=False)
+    assert net.global_step == 2
+    pred = net.predict(data)                         # inference engine rebuilt from the trained variables
+    assert pred.shape == (2, H, W)
+    saved = np.load(net.export_weights())
+    assert saved['fused_score_conv4/kernel'].shape == (1, 1, 1024, U) and not np.array_equal(
+        saved['fused_score_conv4/kernel'], w['fused_score_conv4/kernel'])
+    ref = fo.fusion_fcn_forward({m: data[m] for m in prefixes}, {k: saved[k] for k in saved.files}, prefixes, policy='bf16')
+    assert (pred == fo.argmax_last(fo.softmax(ref['score']))).mean() > 0.97

@@ -103,3 +103,60 @@ def test_two_rank_batch_norm_training_uses_global_statistics(tmp_path):
             assert np.abs(upd_a - upd_ref).max() < 0.03 * np.abs(upd_ref).max() + 1e-3, name
     a, ref = got['rgb__score__gamma'], net.variables['rgb/score/gamma']
     np.testing.assert_allclose(a, ref, rtol=0, atol=3e-4)
+
+
+def _joint_data():
+    rng = np.random.default_rng(4)
+    return {'rgb': np.stack([rng.integers(0, 128, (H, W, 3)), rng.integers(96, 256, (H, W, 3))]).astype(np.float32),
+            'depth': rng.integers(0, 65536, (2, H, W, 1)).astype(np.float32),
+            'labels': rng.integers(-1, C, (2, H, W)).astype(np.int32)}
+
+
+def _make_joint(batchsize):
+    from modular_semantic_segmentation_amd import get_model
+    net = get_model('fusion_fcn')({'rgb': 'rgb', 'depth': 'depth'}, {'rgb': 3, 'depth': 1}, U, C, trainer='rmsprop',
+                                  learning_rate=1e-3, batchsize=batchsize, seed=5)
+    net.variables['rgb_conv1_1/kernel'] = net.variables['rgb_conv1_1/kernel'] * 0.05
+    net.variables['depth_conv1_1/kernel'] = net.variables['depth_conv1_1/kernel'] * 2e-4
+    net._variables_changed()
+    return net
+
+
+def _joint_worker(rank, size, port, out):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group('gloo', rank=rank, world_size=size)
+    from modular_semantic_segmentation_amd import parallel
+    net = _make_joint(1)
+    net._train_batch(parallel.shard_data(_joint_data()))
+    net._sync_variables()
+    if rank == 0:
+        np.savez(out, **{k.replace('/', '__'): v for k, v in net.variables.items()})
+    dist.destroy_process_group()
+
+
+def test_two_rank_joint_model_training(tmp_path):
+    """fusion_fcn under data parallelism: gradient buckets (head + fused convs, then one per trunk) and the decoder's
+    batch statistics are all-reduced, so two ranks with one image each reproduce one process on both images."""
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU')
+    out = str(tmp_path / 'dp_joint.npz')
+    mp.spawn(_joint_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    got = np.load(out)
+    net = _make_joint(2)
+    net._train_batch(_joint_data())
+    net._sync_variables()
+    for layer, init in (('fused/upscore/moving_mean', 0.0), ('fused/upscore/moving_variance', 1.0),
+                        ('fused/score/moving_mean', 0.0), ('fused/score/moving_variance', 1.0)):
+        a, ref = got[layer.replace('/', '__')], net.variables[layer]
+        upd_a, upd_ref = (a - 0.99 * init) / 0.01, (ref - 0.99 * init) / 0.01
+        assert np.abs(upd_a - upd_ref).max() < 0.03 * np.abs(upd_ref).max() + 1e-3, layer
+    # RMSProp's first step is lr * g / sqrt(0.9 + 0.1 g^2), continuous in g: equal weights up to the bf16 noise of a
+    # batch-norm head (see tests/test_backward_gpu.py) -- compare the step directions
+    moved = 0
+    for name in ('rgb_conv5_3/kernel', 'depth_conv3_1/kernel', 'fused_score_conv4/kernel', 'fused/score/kernel'):
+        a, ref = got[name.replace('/', '__')].ravel().astype(np.float64), net.variables[name].ravel().astype(np.float64)
+        assert np.abs(a - ref).max() < 2e-4, name           # steps are at most lr / sqrt(0.1) = 3.2e-3
+        moved += 1
+    assert moved == 4
