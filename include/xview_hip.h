@@ -120,6 +120,12 @@ int xv_concat_channels(const xv_act* a, const xv_act* b, const xv_act* y, void* 
 int xv_subsample2(const xv_act* x, const xv_act* y, void* stream);
 int xv_gather_conv7s2(const xv_act* x, const xv_act* z, void* stream);
 int xv_im2col_dilated_pair(const xv_act* x, int dilation1, int dilation2, const xv_act* z, void* stream);
+/* Their transposes for the training graph (each destination element summed by one thread: deterministic), and the
+ * residual add y = a + b of a block whose closing conv is followed by a batch norm (adapnet.py:38-51).             */
+int xv_subsample2_bwd(const xv_act* dy, const xv_act* dx, void* stream);
+int xv_gather_conv7s2_bwd(const xv_act* dz, const xv_act* dx, void* stream);
+int xv_im2col_dilated_pair_bwd(const xv_act* dz, int dilation1, int dilation2, const xv_act* dx, void* stream);
+int xv_add(const xv_act* a, const xv_act* b, const xv_act* y, void* stream);
 
 /* Decoder head: upscore = relu(bilinear_x8(fused)) (deconv2d k=16 s=8, simple_fcn.py:129-130),
  * score = conv1x1(upscore, Ws) + bs (no activation, simple_fcn.py:131-133), prob = softmax(score),

@@ -80,6 +80,106 @@ __global__ __launch_bounds__(256) void im2col_pair_kernel(const u32x4* __restric
   }
 }
 
+// ---- transposes of the three gathers (training) and the residual add, all written as gathers themselves: every
+// destination element is produced by exactly one thread, no atomics, deterministic -------------------------------------
+__device__ __forceinline__ void acc_bf16x8(float (&s)[8], const u32x4 v) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    s[2 * i] += bf16_bits_to_f32(v[i] & 0xffffu);
+    s[2 * i + 1] += __builtin_bit_cast(float, v[i] & 0xffff0000u);
+  }
+}
+__device__ __forceinline__ u32x4 pack8(const float (&s)[8]) {
+  return u32x4{pack_bf16x2(s[0], s[1]), pack_bf16x2(s[2], s[3]), pack_bf16x2(s[4], s[5]), pack_bf16x2(s[6], s[7])};
+}
+
+// dx[2i][2j] = dy[i][j], zero elsewhere
+__global__ __launch_bounds__(256) void subsample2_bwd_kernel(const u32x4* __restrict__ dy, u32x4* __restrict__ dx, int N,
+                                                            int Ho, int Wo, int c8) {
+  const int Hi = Ho * 2, Wi = Wo * 2;
+  const int64_t total = (int64_t)N * Hi * Wi * c8;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    const int cg = (int)(idx % c8);
+    int64_t r = idx / c8;
+    const int x = (int)(r % Wi);
+    r /= Wi;
+    const int y = (int)(r % Hi);
+    const int n = (int)(r / Hi);
+    u32x4 v = u32x4{0u, 0u, 0u, 0u};
+    if (((x | y) & 1) == 0) v = dy[(((int64_t)n * (Ho + 2) + (y >> 1) + 1) * (Wo + 2) + (x >> 1) + 1) * c8 + cg];
+    dx[(((int64_t)n * (Hi + 2) + y + 1) * (Wi + 2) + x + 1) * c8 + cg] = v;
+  }
+}
+
+// dx[sy][sx] = sum over the (row variant, column variant) pairs that read this pixel of dz[j][i][group]:
+// an even coordinate s is read by variant 0 at j = s/2 and by variant 1 (shift) at j = s/2 - 1, an odd one by variant 2
+__global__ __launch_bounds__(256) void gather_conv7s2_bwd_kernel(const u32x4* __restrict__ dz, u32x4* __restrict__ dx,
+                                                                int N, int Ho, int Wo, int c8) {
+  const int Hi = Ho * 2, Wi = Wo * 2;
+  const int g8 = 9 * c8;
+  const int64_t total = (int64_t)N * Hi * Wi * c8;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    const int cg = (int)(idx % c8);
+    int64_t r = idx / c8;
+    const int sx = (int)(r % Wi);
+    r /= Wi;
+    const int sy = (int)(r % Hi);
+    const int n = (int)(r / Hi);
+    int rvs[2], js[2], nr = 0, cvs[2], is[2], nc = 0;
+    if (sy & 1) {
+      rvs[nr] = 2, js[nr++] = sy >> 1;
+    } else {
+      rvs[nr] = 0, js[nr++] = sy >> 1;
+      if (sy >= 2) rvs[nr] = 1, js[nr++] = (sy >> 1) - 1;
+    }
+    if (sx & 1) {
+      cvs[nc] = 2, is[nc++] = sx >> 1;
+    } else {
+      cvs[nc] = 0, is[nc++] = sx >> 1;
+      if (sx >= 2) cvs[nc] = 1, is[nc++] = (sx >> 1) - 1;
+    }
+    float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int a = 0; a < nr; ++a)
+      for (int b = 0; b < nc; ++b)
+        acc_bf16x8(s, dz[(((int64_t)n * (Ho + 2) + js[a] + 1) * (Wo + 2) + is[b] + 1) * g8 + (rvs[a] * 3 + cvs[b]) * c8 + cg]);
+    dx[(((int64_t)n * (Hi + 2) + sy + 1) * (Wi + 2) + sx + 1) * c8 + cg] = pack8(s);
+  }
+}
+
+// col2im: dx[y][x] = sum_t dz[y - ty*d][x - tx*d][t] over the 18 taps whose reader lies inside the image
+__global__ __launch_bounds__(256) void im2col_pair_bwd_kernel(const u32x4* __restrict__ dz, u32x4* __restrict__ dx, int N,
+                                                             int H, int W, int c8, int d1, int d2) {
+  const int g8 = 18 * c8;
+  const int64_t total = (int64_t)N * H * W * c8;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    const int cg = (int)(idx % c8);
+    int64_t r = idx / c8;
+    const int px = (int)(r % W);
+    r /= W;
+    const int py = (int)(r % H);
+    const int n = (int)(r / H);
+    float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < 18; ++t) {
+      const int d = t < 9 ? d1 : d2;
+      const int tt = t < 9 ? t : t - 9;
+      const int ry = py - (tt / 3 - 1) * d, rx = px - (tt % 3 - 1) * d;
+      if (ry >= 0 && ry < H && rx >= 0 && rx < W)
+        acc_bf16x8(s, dz[(((int64_t)n * (H + 2) + ry + 1) * (W + 2) + rx + 1) * g8 + t * c8 + cg]);
+    }
+    dx[(((int64_t)n * (H + 2) + py + 1) * (W + 2) + px + 1) * c8 + cg] = pack8(s);
+  }
+}
+
+__global__ __launch_bounds__(256) void add_kernel(const u32x4* __restrict__ a, const u32x4* __restrict__ b,
+                                                 u32x4* __restrict__ y, int64_t total) {
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    acc_bf16x8(s, a[idx]);
+    acc_bf16x8(s, b[idx]);
+    y[idx] = pack8(s);
+  }
+}
+
 }  // namespace
 
 extern "C" int xv_subsample2(const xv_act* x, const xv_act* y, void* stream) {
@@ -108,5 +208,48 @@ extern "C" int xv_im2col_dilated_pair(const xv_act* x, int dilation1, int dilati
   const int64_t total = (int64_t)z->n * z->h * z->w * (z->c >> 3);
   hipLaunchKernelGGL(im2col_pair_kernel, dim3(rn_grid(total)), dim3(256), 0, (hipStream_t)stream, (const u32x4*)x->data,
                      (u32x4*)z->data, z->n, z->h, z->w, x->c >> 3, dilation1, dilation2);
+  return xv_launch_status();
+}
+
+extern "C" int xv_subsample2_bwd(const xv_act* dy, const xv_act* dx, void* stream) {
+  XV_CHECK_ARG(dy && dx && dy->data && dx->data);
+  XV_CHECK_SHAPE(dx->n == dy->n && dx->c == dy->c && (dx->c & 7) == 0 && dx->h == 2 * dy->h && dx->w == 2 * dy->w &&
+                 dy->h > 0);
+  const int64_t total = (int64_t)dx->n * dx->h * dx->w * (dx->c >> 3);
+  hipLaunchKernelGGL(subsample2_bwd_kernel, dim3(rn_grid(total)), dim3(256), 0, (hipStream_t)stream,
+                     (const u32x4*)dy->data, (u32x4*)dx->data, dy->n, dy->h, dy->w, dy->c >> 3);
+  return xv_launch_status();
+}
+
+extern "C" int xv_gather_conv7s2_bwd(const xv_act* dz, const xv_act* dx, void* stream) {
+  XV_CHECK_ARG(dz && dx && dz->data && dx->data);
+  XV_CHECK_SHAPE(dx->n == dz->n && dz->c == 9 * dx->c && (dx->c & 7) == 0 && dx->h == 2 * dz->h && dx->w == 2 * dz->w &&
+                 dz->h > 0);
+  const int64_t total = (int64_t)dx->n * dx->h * dx->w * (dx->c >> 3);
+  hipLaunchKernelGGL(gather_conv7s2_bwd_kernel, dim3(rn_grid(total)), dim3(256), 0, (hipStream_t)stream,
+                     (const u32x4*)dz->data, (u32x4*)dx->data, dz->n, dz->h, dz->w, dx->c >> 3);
+  return xv_launch_status();
+}
+
+extern "C" int xv_im2col_dilated_pair_bwd(const xv_act* dz, int dilation1, int dilation2, const xv_act* dx,
+                                          void* stream) {
+  XV_CHECK_ARG(dz && dx && dz->data && dx->data);
+  XV_CHECK_SHAPE(dx->n == dz->n && dx->h == dz->h && dx->w == dz->w && dz->c == 18 * dx->c && (dx->c & 7) == 0 &&
+                 dilation1 >= 1 && dilation2 >= 1);
+  const int64_t total = (int64_t)dx->n * dx->h * dx->w * (dx->c >> 3);
+  hipLaunchKernelGGL(im2col_pair_bwd_kernel, dim3(rn_grid(total)), dim3(256), 0, (hipStream_t)stream,
+                     (const u32x4*)dz->data, (u32x4*)dx->data, dx->n, dx->h, dx->w, dx->c >> 3, dilation1, dilation2);
+  return xv_launch_status();
+}
+
+// y = a + b over the whole padded buffers (the residual add of a ResNet block in the training graph, where a batch
+// norm sits between the conv and the add; borders are 0 + 0)
+extern "C" int xv_add(const xv_act* a, const xv_act* b, const xv_act* y, void* stream) {
+  XV_CHECK_ARG(a && b && y && a->data && b->data && y->data);
+  XV_CHECK_SHAPE(a->n == b->n && a->h == b->h && a->w == b->w && a->c == b->c && y->n == a->n && y->h == a->h &&
+                 y->w == a->w && y->c == a->c && (a->c & 7) == 0);
+  const int64_t total = (int64_t)a->n * (a->h + 2) * (a->w + 2) * (a->c >> 3);
+  hipLaunchKernelGGL(add_kernel, dim3(rn_grid(total)), dim3(256), 0, (hipStream_t)stream, (const u32x4*)a->data,
+                     (const u32x4*)b->data, (u32x4*)y->data, total);
   return xv_launch_status();
 }

@@ -154,6 +154,30 @@ def gather_conv7s2(x, z=None):
     return z
 
 
+def subsample2_bwd(dy, dx):
+    _lib.check(_lib.lib().xv_subsample2_bwd(dy.xv(), dx.xv(), _stream()), 'xv_subsample2_bwd')
+    return dx
+
+
+def gather_conv7s2_bwd(dz, dx):
+    _lib.check(_lib.lib().xv_gather_conv7s2_bwd(dz.xv(), dx.xv(), _stream()), 'xv_gather_conv7s2_bwd')
+    return dx
+
+
+def im2col_dilated_pair_bwd(dz, d1, d2, dx):
+    _lib.check(_lib.lib().xv_im2col_dilated_pair_bwd(dz.xv(), int(d1), int(d2), dx.xv(), _stream()),
+               'xv_im2col_dilated_pair_bwd')
+    return dx
+
+
+def add(a, b, y=None):
+    """y = a + b (Acts of one shape)."""
+    if y is None:
+        y = Act(a.n, a.h, a.w, a.c, a.t.device)
+    _lib.check(_lib.lib().xv_add(a.xv(), b.xv(), y.xv(), _stream()), 'xv_add')
+    return y
+
+
 def im2col_dilated_pair(x, d1, d2, z=None):
     """[N,H,W,18C]: the nine taps at dilation d1 then the nine at d2."""
     if z is None:
