@@ -136,7 +136,8 @@ def bench_train(args, device, world, rank, dist):
     all-reduced in three buckets on a side stream during backward (RCCL over xGMI)."""
     from modular_semantic_segmentation_amd import get_model
     desc = ({'rgb': 'float32', 'labels': 'int32'}, {'rgb': (None, None, 3), 'labels': (None, None)}, C)
-    joint = args.fusion == 'joint'
+    joint = args.fusion == 'joint' and args.expert == 'fcn'
+    adap = args.expert == 'adapnet'
     gen = torch.Generator(device='cpu').manual_seed(99 + rank)
     rgb = torch.randint(0, 256, (args.batch, args.height, args.width, 3), generator=gen).float().to(device)
     labels = torch.randint(-1, C, (args.batch, args.height, args.width), generator=gen).int().to(device)
@@ -148,6 +149,9 @@ def bench_train(args, device, world, rank, dist):
         net.variables['depth_conv1_1/kernel'] = net.variables['depth_conv1_1/kernel'] / 256.0
         net._variables_changed()
         batch['depth'] = torch.randint(0, 65536, (args.batch, args.height, args.width, 1), generator=gen).float().to(device)
+    elif adap:
+        net = get_model('adapnet')(desc, modality='rgb', num_units=U, batchsize=args.batch, learning_rate=1e-4,
+                                   trainer='adam', seed=1, device=str(device), sync_loss=False)
     else:
         net = get_model('fcn')('rgb', desc, 'rgb', num_units=U, batch_normalization=bool(args.batch_norm),
                                batchsize=args.batch, learning_rate=1e-4, trainer='adam', seed=1, device=str(device),
@@ -183,6 +187,11 @@ def bench_train(args, device, world, rank, dist):
             metric = 'RGB-D images/sec, fusion_fcn joint model training step (fwd + bwd + RMSProp, decoder batch norm) at %dx%d' % (
                 args.width, args.height)
             workload = 'fusion_fcn RGB+Depth %dx%d training, U=%d, C=%d, RMSProp' % (args.width, args.height, U, C)
+        if adap:
+            flops = 3.0 * adapnet_flops_per_image(args.height, args.width, 3)
+            metric = 'images/sec, AdapNet RGB expert training step (fwd + bwd + Adam, batch norm everywhere) at %dx%d' % (
+                args.width, args.height)
+            workload = 'AdapNet RGB %dx%d training, U=%d, C=%d, Adam' % (args.width, args.height, U, C)
         print(json.dumps({
             'metric': metric,
             'value': round(images / dt, 2), 'unit': 'images/s', 'n_gpus': world, 'steps': args.steps,

@@ -11,7 +11,7 @@ gathers (csrc/resnet_ops.hip) that express the rest through them:
   * the two constant bilinear deconvs (kernel [k,k,filters,in], non-zero only at [.,.,i,i]) -> channel slices:
     `first_deconvolution_conv` computes only the num_units channels the x2 deconv reads, and the x8 deconv + batch norm
     + softmax + argmax is the FCN decoder-head kernel with a diagonal "score conv" holding the batch-norm scale.
-Training (`fit`) of this expert is not built.
+Training: adapnet_trainer.AdapnetTrainer (every batch norm in training mode, the gathers' transposes).
 """
 import numpy as np
 import torch
@@ -37,11 +37,11 @@ BLOCKS = [
 BN_VARS = ('gamma', 'beta', 'moving_mean', 'moving_variance')
 
 
-def _conv_scopes(in_channels, num_units):
+def _conv_scopes(in_channels, num_units, blocks=None):
     """(scope, k, cin, cout, has_bias) of every conv; blocks pass use_bias=False, the rest keep the default bias."""
     scopes = [('block_0_1', 3, in_channels, 64, True), ('block_0_2', 7, 64, 64, True)]
     cin = 64
-    for name, kind, args in BLOCKS:
+    for name, kind, args in (blocks or BLOCKS):
         if kind == 'a':
             mid, cout, _, shortcut = args
             scopes += [(name + '/stage_1', 1, cin, mid, False), (name + '/stage_2', 3, mid, mid, False),
@@ -55,20 +55,21 @@ def _conv_scopes(in_channels, num_units):
         if name == 'block_layer_7':
             scopes.append(('shortcut', 1, cout, num_units, True))
         cin = cout
-    scopes.append(('first_deconvolution_conv', 1, 2048, 2048, True))
+    scopes.append(('first_deconvolution_conv', 1, cin, cin, True))      # 2048 -> 2048 in the reference graph
     return scopes
 
 
-def variable_shapes(prefix, in_channels, num_units, num_classes):
+def variable_shapes(prefix, in_channels, num_units, num_classes, blocks=None):
     """name -> shape in the reference's npz schema: a conv and its batch norm share one variable scope."""
     shapes = {}
-    for scope, k, cin, cout, has_bias in _conv_scopes(in_channels, num_units):
+    scopes = _conv_scopes(in_channels, num_units, blocks)
+    for scope, k, cin, cout, has_bias in scopes:
         shapes['%s/%s/kernel' % (prefix, scope)] = (k, k, cin, cout)
         if has_bias:
             shapes['%s/%s/bias' % (prefix, scope)] = (cout,)
         for v in BN_VARS:
             shapes['%s/%s/%s' % (prefix, scope, v)] = (cout,)
-    for scope, k, filters, cin in (('first_deconvolution_upconv', 4, num_units, 2048),
+    for scope, k, filters, cin in (('first_deconvolution_upconv', 4, num_units, scopes[-1][3]),
                                    ('second_deconvolution_upconv', 16, num_classes, num_units)):
         shapes['%s/%s/kernel' % (prefix, scope)] = (k, k, filters, cin)
         for v in BN_VARS:
@@ -81,11 +82,11 @@ def rect_bilinear_filter(shape):
     return bilinear_filter(tuple(shape))
 
 
-def init_variables(prefix, in_channels, num_units, num_classes, seed=None):
+def init_variables(prefix, in_channels, num_units, num_classes, seed=None, blocks=None):
     """[TF1] default initialisers: Glorot-uniform kernels, zero biases, gamma 1, beta 0, mean 0, variance 1."""
     rng = np.random.default_rng(seed)
     out = {}
-    for name, shape in variable_shapes(prefix, in_channels, num_units, num_classes).items():
+    for name, shape in variable_shapes(prefix, in_channels, num_units, num_classes, blocks).items():
         leaf = name.rsplit('/', 1)[1]
         if 'deconvolution_upconv' in name and leaf == 'kernel':
             out[name] = rect_bilinear_filter(shape)
@@ -133,8 +134,10 @@ def dilated_pair_as_1x1(kernel1, kernel2):
 class AdapnetEngine(object):
     """One AdapNet expert resident on one GPU; same surface as fcn.FcnEngine (load / forward)."""
 
-    def __init__(self, prefix, in_channels, num_units, num_classes, variables, device='cuda'):
+    def __init__(self, prefix, in_channels, num_units, num_classes, variables, device='cuda', blocks=None):
+        """blocks: another block list in the format of BLOCKS (tests run shallow graphs); default: the reference's 16."""
         self.prefix, self.cin, self.U, self.C = prefix, int(in_channels), int(num_units), int(num_classes)
+        self.blocks = list(blocks or BLOCKS)
         if self.C > self.U:
             raise ValueError('the x8 deconv kernel [16,16,num_classes,num_units] needs num_classes <= num_units '
                              '(custom_layers.py:20-24)')
@@ -147,7 +150,7 @@ class AdapnetEngine(object):
     def load(self, variables):
         p, dev = self.prefix, self.device
         v = {k: np.asarray(a, np.float32) for k, a in variables.items() if k.startswith(p + '/')}
-        for need, shape in variable_shapes(p, self.cin, self.U, self.C).items():
+        for need, shape in variable_shapes(p, self.cin, self.U, self.C, self.blocks).items():
             if need not in v:
                 raise KeyError('missing variable %s' % need)
             if tuple(v[need].shape) != tuple(shape):
@@ -176,7 +179,7 @@ class AdapnetEngine(object):
         self.w['block_0_1'], self.b['block_0_1'] = up(k), up(b)            # fp32 first-layer kernel
         k, b = folded('block_0_2')
         self.w['block_0_2'], self.b['block_0_2'] = ops.pack_conv_weights(up(conv7s2_as_3x3(k))), up(b)
-        for name, kind, args in BLOCKS:
+        for name, kind, args in self.blocks:
             stages = ['stage_1', 'stage_3'] + (['stage_2'] if kind == 'a' else []) + (['shortcut'] if args[-1] else [])
             for stage in stages:
                 k, b = folded('%s/%s' % (name, stage))
@@ -239,7 +242,7 @@ class AdapnetEngine(object):
         cur = self._act('block_0_pool', n, h // 4, w // 4, 64)
         ops.conv2d_fwd(z, self.w['block_0_2'], self.b['block_0_2'], 3, relu=True, pooled=cur, write_y=False)
         L['block_0_pool'] = cur
-        for index, (name, kind, args) in enumerate(BLOCKS, start=1):
+        for index, (name, kind, args) in enumerate(self.blocks, start=1):
             inp = cur
             if kind == 'a':
                 mid, cout, stride, shortcut_conv = args
@@ -286,7 +289,8 @@ class AdapnetEngine(object):
 
 class Adapnet(BaseModel):
     """AdapNet expert behind the BaseModel API (adapnet.py:175-219): `Adapnet(data_description, prefix=None,
-    output_dir=None, **config)` with config keys modality, num_units (and num_classes from the data description)."""
+    output_dir=None, **config)` with config keys modality, num_units (and num_classes from the data description),
+    optional trainer / learning_rate / batchsize."""
 
     def __init__(self, data_description, prefix=None, output_dir=None, **config):
         standard_config = {'train_encoder': True}
@@ -297,20 +301,52 @@ class Adapnet(BaseModel):
 
     def _build_graph(self):
         self.in_channels = int(self.testdata_description[1][self.modality][-1])
+        blocks = self.config.get('blocks')          # None = the reference's 16 blocks; tests pass shallower lists
         self.variables = init_variables(self.prefix, self.in_channels, self.config['num_units'],
-                                        self.config['num_classes'], seed=self.config.get('seed'))
+                                        self.config['num_classes'], seed=self.config.get('seed'), blocks=blocks)
         self.engine = AdapnetEngine(self.prefix, self.in_channels, self.config['num_units'],
-                                    self.config['num_classes'], self.variables, device=self.device)
+                                    self.config['num_classes'], self.variables, device=self.device, blocks=blocks)
         self.loss = None
         self.prediction = 'label'
 
     def _variables_changed(self):
         self.engine.load(self.variables)
+        if getattr(self, 'trainer', None) is not None:
+            self.trainer.load_from_variables(self.variables)
+
+    # ---- training (adapnet.py:190-203, optimizer setup base_model.py:153-162) ---------------------------------------
+    def _ensure_trainer(self):
+        if getattr(self, 'trainer', None) is None:
+            from .adapnet_trainer import AdapnetTrainer
+            from .parallel import GradReducer, world
+            self.trainer = AdapnetTrainer(self.engine, self.config.get('trainer', 'adam'),
+                                          self.config.get('learning_rate', 0.0001))
+            self.trainer.load_from_variables(self.variables)
+            self._reducer = GradReducer(self.device) if world()[1] > 1 else None
+        return self.trainer
 
     def _train_batch(self, batch):
-        raise NotImplementedError('training the AdapNet expert is not built on the MI355X path; import trained weights')
+        tr = self._ensure_trainer()
+        x = self._to_device(batch[self.modality], torch.float32)
+        labels = self._to_device(batch['labels'], torch.int32)
+        self.loss = tr.step(x, labels, reducer=self._reducer)
+        self._dirty = True
+        return self.loss.item() if self.config.get('sync_loss', True) else 0.0
+
+    def _sync_variables(self):
+        """Master weights and moving statistics back into the variable dict; the inference engine folds every batch
+        norm into its conv, so it is rebuilt from them."""
+        if getattr(self, 'trainer', None) is not None and getattr(self, '_dirty', False):
+            self.trainer.to_variables(self.variables)
+            self._dirty = False
+            self.engine.load(self.variables)
+
+    def export_weights(self, save_dir=None):
+        self._sync_variables()
+        return BaseModel.export_weights(self, save_dir)
 
     def _predict_batch_impl(self, batch, output_attr=None):
+        self._sync_variables()
         x = self._to_device(batch[self.modality], torch.float32)
         want = output_attr if output_attr in ('prob', 'score') else 'label'
         return self.engine.forward(x, want=(want,))[want]

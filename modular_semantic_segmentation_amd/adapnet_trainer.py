@@ -1,0 +1,436 @@
+"""One training step of the AdapNet expert on MI355X: adapnet(..., is_training=True) (adapnet.py:103-173), the loss of
+Adapnet._build_graph (adapnet.py:196-203) and the [TF1] optimizers of base_model.py:153-162.
+
+Every conv / deconv of the graph is followed by tf.layers.batch_normalization(training=True), so nothing folds: a
+unit is conv -> z (stored) -> batch statistics -> y = [relu](BN(z)) (stored), and its backward is the batch-norm
+gradient (which carries the relu mask), the MFMA filter gradient and the MFMA data gradient.  The graph is a DAG
+(block inputs feed the first stage and the shortcut, block 7 feeds block 8 and the `shortcut` conv), so the step
+records a tape of backward closures and accumulates gradients per tensor name.  The strided / atrous convs run
+through the same gathers as the inference engine (adapnet.AdapnetEngine); their weights are DERIVED tensors (the 7x7
+kernel scattered into 3x3 x 9 groups, the atrous pair stacked block-wise), rebuilt from the master weights every step,
+and their filter gradients are mapped back through the same index maps.
+
+`first_deconvolution_conv` is trained on the num_units output channels the x2 deconv reads; the remaining 2048 - U
+channels of that layer have exactly zero gradient in the reference too (the constant deconv kernel is zero there) and
+keep their imported values.  The loss is the reference's: the mean cross-entropy over the labelled pixels divided once
+more by their number (adapnet.py:202-203).
+"""
+import numpy as np
+import torch
+
+from . import ops
+from .adapnet import _conv_scopes, conv7s2_as_3x3
+from .trainer import FcnTrainer
+
+
+class AdapnetTrainer(object):
+    def __init__(self, engine, trainer='adam', learning_rate=1e-4):
+        if trainer not in ('adam', 'rmsprop', 'adagrad'):
+            raise KeyError(trainer)
+        self.e, self.kind, self.lr = engine, trainer, float(learning_rate)
+        e, dev = engine, engine.device
+        # ---- units: name -> (k, cin, cout as trained, has_bias) ----------------------------------------------------
+        self.units = {}
+        self.blocks = e.blocks
+        for scope, k, cin, cout, has_bias in _conv_scopes(e.cin, e.U, self.blocks):
+            if scope in ('shortcut', 'first_deconvolution_conv'):
+                cout = e.Up                                   # U padded to 64 lanes (zero kernels, gamma 1, beta 0)
+            self.units[scope] = (k, cin, cout, has_bias)
+        self.bn_channels = {scope: u[2] for scope, u in self.units.items()}
+        self.bn_channels.update(first_deconvolution_upconv=e.Up, second_deconvolution_upconv=e.C)
+        self.offsets, total = {}, 0
+        for scope, (k, cin, cout, has_bias) in self.units.items():
+            entries = [('kernel', (k, k, cin, cout))] + ([('bias', (cout,))] if has_bias else [])
+            for kind, shape in entries + [('gamma', (cout,)), ('beta', (cout,))]:
+                n = int(np.prod(shape))
+                self.offsets[(scope, kind)] = (total, n, shape)
+                total += (n + 63) // 64 * 64
+        for scope in ('first_deconvolution_upconv', 'second_deconvolution_upconv'):
+            for kind in ('gamma', 'beta'):
+                n = self.bn_channels[scope]
+                self.offsets[(scope, kind)] = (total, n, (n,))
+                total += (n + 63) // 64 * 64
+        self.total = total
+        self.param = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.grad = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.moving = {s: (torch.zeros(c, device=dev), torch.ones(c, device=dev)) for s, c in self.bn_channels.items()}
+        self.bn = {s: ops.BnState(c, dev) for s, c in self.bn_channels.items()}
+        self.state, self.t = {}, 0
+        self.zeros = torch.zeros(9216, dtype=torch.float32, device=dev)
+        self.count = torch.zeros(1, dtype=torch.int64, device=dev)
+        self.loss = torch.zeros(1, dtype=torch.float64, device=dev)
+        self.grad_scale = 1.0
+        self.w, self.wd, self._a, self._scratch = {}, {}, {}, {}
+        # x8 deconv kernel [16,16,C,U] = channel i -> class i: a selector "score conv" in front of the dense batch norm
+        sel = torch.zeros(e.Up, e.C, dtype=torch.float32, device=dev)
+        sel[torch.arange(e.C), torch.arange(e.C)] = 1.0
+        self.selector = sel
+        # 7x7 -> 3x3 x 9 groups: index of the source tap for every derived element (-1: structural zero)
+        probe = np.arange(1, 49 * 64 * 64 + 1, dtype=np.float64).reshape(7, 7, 64, 64)
+        derived = conv7s2_as_3x3(probe.astype(np.float32)).astype(np.int64)          # exact below 2^24
+        assert 49 * 64 * 64 < 2 ** 24
+        idx = torch.from_numpy(derived.ravel() - 1).to(dev)
+        self.map7 = (idx.clamp(min=0), (idx >= 0))
+        inv = torch.empty(49 * 64 * 64, dtype=torch.int64, device=dev)
+        pos = torch.nonzero(idx >= 0).ravel()
+        inv[idx[pos]] = pos
+        self.inv7 = inv
+        self._sync = False
+
+    # ---- parameters ------------------------------------------------------------------------------------------------
+    def view(self, buf, name, kind):
+        off, n, shape = self.offsets[(name, kind)]
+        return buf[off:off + n].view(*shape)
+
+    def _real(self, scope):
+        e = self.e
+        if scope in ('shortcut', 'first_deconvolution_conv', 'first_deconvolution_upconv'):
+            return e.U
+        return self.bn_channels[scope]
+
+    def load_from_variables(self, variables):
+        p = self.e.prefix
+        self.param.zero_()
+        for (scope, kind), _ in self.offsets.items():
+            real = self._real(scope)
+            dst = self.view(self.param, scope, kind)
+            if kind == 'gamma':
+                dst.fill_(1.0)
+            src = torch.from_numpy(np.asarray(variables['%s/%s/%s' % (p, scope, kind)], np.float32))
+            dst[..., :real].copy_(src[..., :real])
+        for scope, (mm, mv) in self.moving.items():
+            real = self._real(scope)
+            mm.zero_()
+            mv.fill_(1.0)
+            mm[:real].copy_(torch.from_numpy(np.asarray(variables['%s/%s/moving_mean' % (p, scope)], np.float32))[:real])
+            mv[:real].copy_(torch.from_numpy(np.asarray(variables['%s/%s/moving_variance' % (p, scope)], np.float32))[:real])
+        self.repack()
+
+    def _export(self, buf, variables, scale=1.0):
+        p = self.e.prefix
+        for (scope, kind), _ in self.offsets.items():
+            real = self._real(scope)
+            name = '%s/%s/%s' % (p, scope, kind)
+            t = (self.view(buf, scope, kind)[..., :real] * scale).cpu().numpy()
+            if scope == 'first_deconvolution_conv':
+                # only the first U output channels are trained; the others keep the values they had
+                full = np.array(variables[name], np.float32, copy=True) if name in variables else None
+                if full is not None and full.shape[-1] != real:
+                    full[..., :real] = t
+                    t = full
+            variables[name] = np.ascontiguousarray(t)
+        return variables
+
+    def to_variables(self, variables):
+        p = self.e.prefix
+        self._export(self.param, variables)
+        for scope, (mm, mv) in self.moving.items():
+            real = self._real(scope)
+            for v, src in (('moving_mean', mm), ('moving_variance', mv)):
+                name = '%s/%s/%s' % (p, scope, v)
+                t = src[:real].cpu().numpy().copy()
+                if name in variables and np.shape(variables[name])[-1] != real:
+                    full = np.array(variables[name], np.float32, copy=True)
+                    full[:real] = t
+                    t = full
+                variables[name] = t
+
+    def grads_as_variables(self):
+        """Gradient of the last step in the reference schema, including the 1/count of the loss (tests); the untrained
+        channels of first_deconvolution_conv are reported as the zeros they are."""
+        out = self._export(self.grad, {}, scale=self.grad_scale)
+        p = self.e.prefix
+        for kind in ('kernel', 'bias', 'gamma', 'beta'):
+            name = '%s/first_deconvolution_conv/%s' % (p, kind)
+            t = out[name]
+            full = np.zeros(t.shape[:-1] + (self.units['first_deconvolution_conv'][1],), np.float32)
+            full[..., :t.shape[-1]] = t
+            out[name] = full
+        return out
+
+    def _kernel_for(self, scope):
+        """The kernel the MFMA convs consume for `scope` (derived for the 7x7 stride-2 conv)."""
+        kv = self.view(self.param, scope, 'kernel')
+        if scope == 'block_0_2':
+            src, mask = self.map7
+            return (kv.reshape(-1)[src] * mask).view(3, 3, 9 * 64, 64)
+        return kv
+
+    def _pair_kernel(self, name):
+        k1, k2 = self.view(self.param, name + '/stage_2_1', 'kernel'), self.view(self.param, name + '/stage_2_2', 'kernel')
+        c, half = k1.shape[2], k1.shape[3]
+        w = self._scratch.get(('pairw', name))
+        if w is None:
+            w = self._scratch[('pairw', name)] = torch.zeros(1, 1, 18 * c, 2 * half, dtype=torch.float32, device=k1.device)
+        w[0, 0, :9 * c, :half] = k1.reshape(9 * c, half)
+        w[0, 0, 9 * c:, half:] = k2.reshape(9 * c, half)
+        return w
+
+    def _pack(self, key, kernel):
+        if key not in self.w:
+            k, _, cin, cout = kernel.shape
+            nel = ops.packed_weight_elems(k, cin, cout)
+            self.w[key] = torch.empty(nel, dtype=torch.bfloat16, device=kernel.device)
+            self.wd[key] = torch.empty(nel, dtype=torch.bfloat16, device=kernel.device)
+        kernel = kernel.contiguous()
+        ops.pack_conv_weights_into(kernel, self.w[key])
+        ops.pack_conv_weights_dgrad(kernel, self.wd[key])
+
+    def repack(self):
+        for scope in self.units:
+            if scope == 'block_0_1' or '/stage_2_' in scope:
+                continue
+            self._pack(scope, self._kernel_for(scope))
+        for name, kind, _ in self.blocks:
+            if kind == 'b':
+                self._pack(name + '/stage_2', self._pair_kernel(name))
+
+    # ---- scratch ---------------------------------------------------------------------------------------------------
+    def _act(self, tag, n, h, w, c):
+        key = (tag, n, h, w, c)
+        a = self._a.get(key)
+        if a is None:
+            a = self._a[key] = ops.Act(n, h, w, c, self.e.device)
+        return a
+
+    def _like(self, tag, a):
+        return self._act(tag, a.n, a.h, a.w, a.c)
+
+    def _dense(self, tag, shape):
+        key = (tag,) + tuple(shape)
+        t = self._a.get(key)
+        if t is None:
+            t = self._a[key] = torch.empty(shape, dtype=torch.float32, device=self.e.device)
+        return t
+
+    # ---- gradient bookkeeping ------------------------------------------------------------------------------------
+    def _accum(self, name, g):
+        """Add g to the gradient of tensor `name` (first contribution: keep a reference; later ones: into a buffer this
+        bookkeeping owns, since the first reference may be shared with another tensor's gradient)."""
+        cur = self._grads.get(name)
+        if cur is None:
+            self._grads[name] = (g, False)
+            return
+        buf, owned = cur
+        if not owned:
+            own = self._like('gsum_' + name, buf)
+            ops.add(buf, g, own)
+            self._grads[name] = (own, True)
+        else:
+            ops.add(buf, g, buf)
+
+    def _bn_unit(self, scope, z, relu, name):
+        mm, mv = self.moving[scope]
+        P = lambda kind: self.view(self.param, scope, kind)        # noqa: E731
+        G = lambda kind: self.view(self.grad, scope, kind)         # noqa: E731
+        y = ops.bn_forward(z, P('gamma'), P('beta'), mm, mv, self.bn[scope], self._like('y_' + name, z), relu=relu,
+                           sync=self._sync)
+
+        def bwd_bn(dy):
+            return ops.bn_backward(dy, y if relu else None, z, P('gamma'), self.bn[scope], G('gamma'), G('beta'),
+                                   self._like('dz_' + name, z), sync=self._sync)
+        return y, bwd_bn
+
+    # ---- one training step ----------------------------------------------------------------------------------------
+    def step(self, x, labels, reducer=None):
+        """x: float32 [N,H,W,cin], labels: int32 [N,H,W] (device tensors) -> loss (device float64 scalar)."""
+        e = self.e
+        n, h, w, _ = x.shape
+        if h % 16 or w % 16:
+            raise ValueError('H and W must be multiples of 16')
+        self.grad.zero_()
+        self.loss.zero_()
+        self.count.zero_()
+        ops.count_valid_labels(labels, e.C, self.count)
+        self._sync = reducer is not None
+        if reducer is not None:
+            reducer.allreduce_now(self.count)
+        self._grads, tape = {}, []
+        P = lambda scope, kind: self.view(self.param, scope, kind)    # noqa: E731
+        G = lambda scope, kind: self.view(self.grad, scope, kind)     # noqa: E731
+        wkey = ('wgrad_ws', n, h, w)
+        wws = self._a.get(wkey)          # split-K slabs of the filter gradients; sized after the forward pass, read by
+        wneed = [0]                      # the backward closures (which run after it is assigned)
+
+        def conv_bn(scope, xname, xact, k, relu, out, key=None, cout=None, scatter=None, bn_scope=None):
+            """out = [relu](BN(conv(x))); bn_scope: where gamma / beta live (a list of (scope, channels) for the stacked
+            atrous pair, whose batch norm is two independent ones side by side)."""
+            key = key or scope
+            cout = cout or self.units[scope][2]
+            has_bias = key == scope and self.units[scope][3]
+            bias = P(scope, 'bias') if has_bias else self.zeros[:cout]
+            z = ops.conv2d_fwd(xact, self.w[key], bias, k, relu=False, y=self._act('z_' + out, xact.n, xact.h, xact.w, cout))[0]
+            wneed[0] = max(wneed[0], ops.conv2d_bwd_filter_workspace_bytes(xact, cout, k))
+            y, bwd_bn = self._bn_pair(bn_scope, z, relu, out) if bn_scope else self._bn_unit(scope, z, relu, out)
+
+            def bwd():
+                dy = self._grads.pop(out)[0]
+                dz = bwd_bn(dy)
+                if scatter is None:
+                    ops.conv2d_bwd_filter(xact, dz, G(scope, 'kernel'), G(scope, 'bias') if has_bias else None, k,
+                                          workspace=wws)
+                else:
+                    dw = self._scratch.get(('dw', key))
+                    if dw is None:
+                        dw = self._scratch[('dw', key)] = torch.empty(k, k, xact.c, cout, dtype=torch.float32,
+                                                                      device=e.device)
+                    dw.zero_()
+                    ops.conv2d_bwd_filter(xact, dz, dw, G(scope, 'bias') if has_bias else None, k, workspace=wws)
+                    scatter(dw)
+                if xname is not None:
+                    dx = ops.conv2d_bwd_data(dz, self.wd[key], self.zeros[:xact.c], self._like('dx_' + out, xact), k)
+                    self._accum(xname, dx)
+            tape.append(bwd)
+            return y
+
+        # ---- forward -----------------------------------------------------------------------------------------------
+        z0 = self._act('z_block_0_1', n, h, w, 64)
+        ops.conv2d_first_fwd(x.contiguous(), P('block_0_1', 'kernel'), P('block_0_1', 'bias'), z0, relu=False)
+        y0, bwd_bn0 = self._bn_unit('block_0_1', z0, True, 'block_0_1')
+
+        def bwd_first():
+            dz = bwd_bn0(self._grads.pop('block_0_1')[0])
+            ops.conv2d_first_bwd_filter(x, dz, G('block_0_1', 'kernel'), G('block_0_1', 'bias'))
+        tape.append(bwd_first)
+
+        g7 = ops.gather_conv7s2(y0, self._act('op_block_0_2', n, h // 2, w // 2, 576))
+
+        def bwd_gather7():
+            self._accum('block_0_1', ops.gather_conv7s2_bwd(self._grads.pop('op_block_0_2')[0], self._like('dg7', y0)))
+        tape.append(bwd_gather7)
+
+        def scatter7(dw):
+            G('block_0_2', 'kernel').view(-1).add_(dw.view(-1)[self.inv7])
+        y02 = conv_bn('block_0_2', 'op_block_0_2', g7, 3, True, 'block_0_2', scatter=scatter7)
+        cur = ops.maxpool2x2_fwd(y02, self._act('block_0_pool', n, h // 4, w // 4, 64))
+
+        def bwd_pool():
+            self._accum('block_0_2', ops.maxpool2x2_bwd(y02, self._grads.pop('block_0_pool')[0], self._like('dpool', y02)))
+        tape.append(bwd_pool)
+        curname = 'block_0_pool'
+
+        def residual(a_name, a, b_name, b, out):
+            y = ops.add(a, b, self._like(out, a))
+
+            def bwd():
+                dy = self._grads.pop(out)[0]
+                self._accum(a_name, dy)
+                self._accum(b_name, dy)
+            tape.append(bwd)
+            return y
+
+        shortcut = None
+        for index, (name, kind, args) in enumerate(self.blocks, start=1):
+            inp, inpname = cur, curname
+            if kind == 'a':
+                mid, cout, stride, shortcut_conv = args
+                if stride == 2:
+                    full, fullname = cur, curname
+                    inp = ops.subsample2(cur, self._act(name + '/input', cur.n, cur.h // 2, cur.w // 2, cur.c))
+                    inpname = name + '/input'
+
+                    def bwd_sub(full=full, fullname=fullname, inpname=inpname):
+                        self._accum(fullname, ops.subsample2_bwd(self._grads.pop(inpname)[0], self._like('dsub_' + inpname, full)))
+                    tape.append(bwd_sub)
+                s1 = conv_bn(name + '/stage_1', inpname, inp, 1, True, name + '/s1')
+                s2 = conv_bn(name + '/stage_2', name + '/s1', s1, 3, True, name + '/s2')
+            else:
+                f1, f2, cout, d1, d2, shortcut_conv = args
+                s1 = conv_bn(name + '/stage_1', inpname, inp, 1, True, name + '/s1')
+                op = ops.im2col_dilated_pair(s1, d1, d2, self._act(name + '/operand', s1.n, s1.h, s1.w, 18 * f1))
+
+                def bwd_col(name=name, s1=s1, d1=d1, d2=d2):
+                    self._accum(name + '/s1', ops.im2col_dilated_pair_bwd(self._grads.pop(name + '/operand')[0], d1, d2,
+                                                                          self._like('dcol_' + name, s1)))
+                tape.append(bwd_col)
+
+                def scatter_pair(dw, name=name, f1=f1, f2=f2):
+                    half = f2 // 2
+                    G(name + '/stage_2_1', 'kernel').add_(dw[0, 0, :9 * f1, :half].reshape(3, 3, f1, half))
+                    G(name + '/stage_2_2', 'kernel').add_(dw[0, 0, 9 * f1:, half:].reshape(3, 3, f1, half))
+                s2 = conv_bn(name + '/stage_2_1', name + '/operand', op, 1, True, name + '/s2', key=name + '/stage_2',
+                             cout=f2, scatter=scatter_pair,
+                             bn_scope=[(name + '/stage_2_1', f2 // 2), (name + '/stage_2_2', f2 // 2)])
+            s3 = conv_bn(name + '/stage_3', name + '/s2', s2, 1, True, name + '/s3')
+            if shortcut_conv:
+                short, shortname = conv_bn(name + '/shortcut', inpname, inp, 1, True, name + '/sc'), name + '/sc'
+            else:
+                short, shortname = inp, inpname
+            curname = 'block_%d' % index
+            cur = residual(name + '/s3', s3, shortname, short, curname)
+            if name == 'block_layer_7':
+                shortcut = conv_bn('shortcut', curname, cur, 1, False, 'shortcut')
+        d = conv_bn('first_deconvolution_conv', curname, cur, 1, True, 'deconv_in')
+        z_up = ops.upsample_raw_fwd(d, 2, self._act('z_deconv_1', d.n, 2 * d.h, 2 * d.w, e.Up))
+        y_up, bwd_bn_up = self._bn_unit('first_deconvolution_upconv', z_up, False, 'deconv_1')
+
+        def bwd_up2():
+            dz = bwd_bn_up(self._grads.pop('deconv_1')[0])
+            self._accum('deconv_in', ops.upsample_raw_bwd(dz, 2, self._like('d_deconv_in', d)))
+        tape.append(bwd_up2)
+        merge = residual('deconv_1', y_up, 'shortcut', shortcut, 'merge')
+        # ---- head: x8 deconv of the first C channels, batch norm, softmax cross-entropy -----------------------------
+        z8 = ops.upsample_raw_fwd(merge, 8, self._act('z_score', n, h, w, e.Up))
+        raw = ops.score_dense_fwd(z8, self.selector, self.zeros[:e.C], e.C, self._dense('score_raw', (n, h, w, e.C)))
+        s2d = 'second_deconvolution_upconv'
+        mm, mv = self.moving[s2d]
+        logits = ops.bn_dense_forward(raw, P(s2d, 'gamma'), P(s2d, 'beta'), mm, mv, self.bn[s2d],
+                                      self._dense('logits', (n, h, w, e.C)), sync=self._sync)
+        dlogits = ops.softmax_ce_dense(logits, labels, self.count, e.C, self.loss, self._dense('dlogits', (n, h, w, e.C)))
+        # ---- backward ------------------------------------------------------------------------------------------------
+        if wws is None or wws.numel() * 4 < wneed[0]:
+            wws = self._a[wkey] = torch.empty(max(wneed[0] // 4, 1), dtype=torch.float32, device=e.device)
+        dscore = ops.bn_dense_backward(dlogits, raw, P(s2d, 'gamma'), self.bn[s2d], G(s2d, 'gamma'), G(s2d, 'beta'),
+                                       self._dense('dscore', (n, h, w, e.C)), sync=self._sync)
+        dsel = self._scratch.setdefault('dsel', torch.zeros_like(self.selector))
+        dbias = self._scratch.setdefault('dselb', torch.zeros(e.C, dtype=torch.float32, device=e.device))
+        du = ops.score_dense_bwd(z8, dscore, self.selector, e.C, dsel, dbias, self._act('d_z_score', n, h, w, e.Up))
+        self._accum('merge', ops.upsample_raw_bwd(du, 8, self._like('d_merge', merge)))
+        for bwd in reversed(tape):
+            bwd()
+        if reducer is not None:
+            reducer.launch(self.grad, (0, self.total))
+            reducer.wait()
+        self.t += 1
+        count = max(int(self.count.item()), 1)
+        self.grad_scale = 1.0 / count                     # the second normalisation of adapnet.py:202-203
+        self.loss.mul_(self.grad_scale)
+        FcnTrainer._apply(self, self.grad_scale)
+        self.repack()
+        return self.loss
+
+    def _bn_pair(self, scopes, z, relu, name):
+        """Batch norm of the stacked atrous pair: per-channel, so one pass over the concatenated map with gamma / beta of
+        the two scopes side by side; the moving statistics and parameter gradients are split back afterwards."""
+        (s1, c1), (s2, c2) = scopes
+        key = ('pairbn', name)
+        st = self._scratch.get(key)
+        if st is None:
+            dev = self.e.device
+            st = self._scratch[key] = {'bn': ops.BnState(c1 + c2, dev),
+                                       'gamma': torch.empty(c1 + c2, device=dev), 'beta': torch.empty(c1 + c2, device=dev),
+                                       'mm': torch.empty(c1 + c2, device=dev), 'mv': torch.empty(c1 + c2, device=dev),
+                                       'dg': torch.empty(c1 + c2, device=dev), 'db': torch.empty(c1 + c2, device=dev)}
+        P = lambda s, kind: self.view(self.param, s, kind)     # noqa: E731
+        torch.cat([P(s1, 'gamma'), P(s2, 'gamma')], out=st['gamma'])
+        torch.cat([P(s1, 'beta'), P(s2, 'beta')], out=st['beta'])
+        torch.cat([self.moving[s1][0], self.moving[s2][0]], out=st['mm'])
+        torch.cat([self.moving[s1][1], self.moving[s2][1]], out=st['mv'])
+        y = ops.bn_forward(z, st['gamma'], st['beta'], st['mm'], st['mv'], st['bn'], self._like('y_' + name, z), relu=relu,
+                           sync=self._sync)
+        self.moving[s1][0].copy_(st['mm'][:c1])
+        self.moving[s2][0].copy_(st['mm'][c1:])
+        self.moving[s1][1].copy_(st['mv'][:c1])
+        self.moving[s2][1].copy_(st['mv'][c1:])
+
+        def bwd_bn(dy):
+            st['dg'].zero_()
+            st['db'].zero_()
+            dz = ops.bn_backward(dy, y if relu else None, z, st['gamma'], st['bn'], st['dg'], st['db'],
+                                 self._like('dz_' + name, z), sync=self._sync)
+            self.view(self.grad, s1, 'gamma').add_(st['dg'][:c1])
+            self.view(self.grad, s2, 'gamma').add_(st['dg'][c1:])
+            self.view(self.grad, s1, 'beta').add_(st['db'][:c1])
+            self.view(self.grad, s2, 'beta').add_(st['db'][c1:])
+            return dz
+        return y, bwd_bn

@@ -34,11 +34,11 @@ BLOCKS = [
 ]
 
 
-def conv_layers(in_channels, num_units):
+def conv_layers(in_channels, num_units, blocks=None):
     """Every convolution of the graph as (variable scope, k, cin, cout, has_bias), in graph order."""
     layers = [('block_0_1', 3, in_channels, 64, True), ('block_0_2', 7, 64, 64, True)]
     cin = 64
-    for name, kind, args in BLOCKS:
+    for name, kind, args in (blocks or BLOCKS):
         if kind == 'a':
             mid, cout, _, shortcut = args
             layers += [(name + '/stage_1', 1, cin, mid, False), (name + '/stage_2', 3, mid, mid, False),
@@ -52,7 +52,7 @@ def conv_layers(in_channels, num_units):
         if name == 'block_layer_7':
             layers.append(('shortcut', 1, cout, num_units, True))
         cin = cout
-    layers.append(('first_deconvolution_conv', 1, 2048, 2048, True))
+    layers.append(('first_deconvolution_conv', 1, cin, cin, True))          # 2048 -> 2048 in the reference graph
     return layers
 
 
@@ -65,7 +65,7 @@ def rect_bilinear_kernel(k, filters, in_channels):
     return w.astype(np.float32)
 
 
-def init_adapnet_weights(prefix, in_channels, num_units, num_classes, seed=1, gain=1.0):
+def init_adapnet_weights(prefix, in_channels, num_units, num_classes, seed=1, gain=1.0, blocks=None):
     """Random weights in the reference's npz schema: '<prefix>/<scope>/{kernel,bias,gamma,beta,moving_mean,
     moving_variance}' (conv and its batch norm share the scope name, custom_layers.py:131-135)."""
     rng = np.random.default_rng(seed)
@@ -77,19 +77,20 @@ def init_adapnet_weights(prefix, in_channels, num_units, num_classes, seed=1, ga
         w['%s/%s/moving_mean' % (prefix, scope)] = (0.1 * rng.standard_normal(c)).astype(np.float32)
         w['%s/%s/moving_variance' % (prefix, scope)] = rng.uniform(0.5, 1.5, c).astype(np.float32)
 
-    for scope, k, cin, cout, has_bias in conv_layers(in_channels, num_units):
+    layers = conv_layers(in_channels, num_units, blocks)
+    for scope, k, cin, cout, has_bias in layers:
         w['%s/%s/kernel' % (prefix, scope)] = glorot_uniform(rng, (k, k, cin, cout)) * gain
         if has_bias:
             w['%s/%s/bias' % (prefix, scope)] = (0.02 * rng.standard_normal(cout)).astype(np.float32)
         bn(scope, cout)
-    w['%s/first_deconvolution_upconv/kernel' % prefix] = rect_bilinear_kernel(4, num_units, 2048)
+    w['%s/first_deconvolution_upconv/kernel' % prefix] = rect_bilinear_kernel(4, num_units, layers[-1][3])
     bn('first_deconvolution_upconv', num_units)
     w['%s/second_deconvolution_upconv/kernel' % prefix] = rect_bilinear_kernel(16, num_classes, num_units)
     bn('second_deconvolution_upconv', num_classes)
     return w
 
 
-def adapnet_forward(x_nhwc, weights, prefix, policy='fp32', keep=None):
+def adapnet_forward(x_nhwc, weights, prefix, policy='fp32', keep=None, blocks=None):
     """adapnet(..., is_training=False) (adapnet.py:103-173); dict of NHWC fp32 arrays for the layers in `keep`
     (default: merge, score).  policy 'bf16': folded conv weights (all but block_0_1) and the activations
     between layers rounded to bf16, accumulation and the two deconvolution stages fp32 -- the MI355X path's
@@ -133,7 +134,7 @@ def adapnet_forward(x_nhwc, weights, prefix, policy='fp32', keep=None):
         h = layers['block_0_1'] = rnd(conv(h, 'block_0_1'))
         h = layers['block_0_2'] = rnd(conv(h, 'block_0_2', stride=2))
         h = layers['block_0_pool'] = F.max_pool2d(h, 2, 2)
-        for index, (name, kind, args) in enumerate(BLOCKS, start=1):
+        for index, (name, kind, args) in enumerate(blocks or BLOCKS, start=1):
             if kind == 'a':
                 _, _, stride, shortcut_conv = args
                 s1 = rnd(conv(h, name + '/stage_1', stride=stride))
@@ -156,3 +157,87 @@ def adapnet_forward(x_nhwc, weights, prefix, policy='fp32', keep=None):
         for k in keep:
             out[k] = layers[k].permute(0, 2, 3, 1).contiguous().numpy()
     return out
+
+
+def adapnet_loss_and_grads(x_nhwc, labels, weights, prefix, num_classes, policy='fp32', units=None, blocks=None):
+    """Training graph of the AdapNet expert: adapnet(..., is_training=True) (adapnet.py:103-173) with
+    tf.layers.batch_normalization(training=True) after every conv / deconv -- statistics over (N, H, W), biased
+    variance, eps 1e-3, trainable gamma / beta -- and the loss of Adapnet._build_graph (adapnet.py:196-203):
+    cross_entropy (models/utils.py:43-53, already a mean over the labelled pixels) divided once more by the number
+    of labelled pixels.  Returns (loss, {variable: gradient}, {bn scope: (batch mean, unbiased batch variance)}).
+    `first_deconvolution_conv` is evaluated for the first `units` output channels only (default: all 2048): the others
+    feed nothing (the x2 deconv kernel is zero there) and have exactly zero gradients.
+    policy 'bf16': straight-through rounding where the MI355X path stores bf16 (see fcn_oracle.fcn_loss_and_grads)."""
+    from .fcn_oracle import _RoundBf16STE
+    params, stats = {}, {}
+    rnd = (lambda t: t) if policy == 'fp32' else _RoundBf16STE.apply
+
+    def P(name, sl=None):
+        if name not in params:
+            params[name] = _t(weights[name]).clone().requires_grad_(True)
+        return params[name] if sl is None else params[name][..., :sl]
+
+    def bn(y, scope, sl=None):
+        g, b = P('%s/%s/gamma' % (prefix, scope), sl), P('%s/%s/beta' % (prefix, scope), sl)
+        mean = y.mean(dim=(0, 2, 3), keepdim=True)
+        var = ((y - mean) ** 2).mean(dim=(0, 2, 3), keepdim=True)
+        m = y.shape[0] * y.shape[2] * y.shape[3]
+        stats[scope] = (mean.detach().numpy().ravel(), var.detach().numpy().ravel() * m / max(m - 1, 1))
+        return (y - mean) / torch.sqrt(var + 1e-3) * g.view(1, -1, 1, 1) + b.view(1, -1, 1, 1)
+
+    def conv(h, scope, stride=1, dilation=1, relu=True, sl=None):
+        w = P('%s/%s/kernel' % (prefix, scope), sl)
+        has_bias = '%s/%s/bias' % (prefix, scope) in weights
+        b = P('%s/%s/bias' % (prefix, scope), sl) if has_bias else None
+        k = w.shape[0]
+        total = max((k - 1) * dilation + 1 - stride, 0)
+        before = total // 2
+        h = F.pad(h, (before, total - before, before, total - before))
+        wq = w if scope == 'block_0_1' else rnd(w)
+        y = bn(rnd(F.conv2d(h, wq.permute(3, 2, 0, 1), b, stride=stride, dilation=dilation)), scope, sl)
+        return rnd(F.relu(y) if relu else y)
+
+    def deconv_bn(h, scope, stride):
+        w = _t(weights['%s/%s/kernel' % (prefix, scope)])
+        k = w.shape[0]
+        y = F.conv_transpose2d(h, w.permute(3, 2, 0, 1).contiguous(), stride=stride, padding=(k - stride) // 2)
+        return y
+
+    h = _t(np.asarray(x_nhwc, np.float32)).permute(0, 3, 1, 2).contiguous()
+    h = conv(h, 'block_0_1')
+    h = conv(h, 'block_0_2', stride=2)
+    h = F.max_pool2d(h, 2, 2)
+    shortcut = None
+    for name, kind, args in (blocks or BLOCKS):
+        if kind == 'a':
+            _, _, stride, shortcut_conv = args
+            s1 = conv(h, name + '/stage_1', stride=stride)
+            s2 = conv(s1, name + '/stage_2')
+        else:
+            _, _, _, d1, d2, shortcut_conv = args
+            stride = 1
+            s1 = conv(h, name + '/stage_1')
+            s2 = torch.cat([conv(s1, name + '/stage_2_1', dilation=d1), conv(s1, name + '/stage_2_2', dilation=d2)], dim=1)
+        s3 = conv(s2, name + '/stage_3')
+        short = conv(h, name + '/shortcut', stride=stride) if shortcut_conv else h
+        h = rnd(F.relu(s3 + short))
+        if name == 'block_layer_7':
+            shortcut = conv(h, 'shortcut', relu=False)
+    u = weights['%s/first_deconvolution_upconv/kernel' % prefix].shape[2]
+    d = conv(h, 'first_deconvolution_conv', sl=units)
+    width = weights['%s/first_deconvolution_conv/kernel' % prefix].shape[3]
+    if units is not None and units < width:
+        d = F.pad(d, (0, 0, 0, 0, 0, width - d.shape[1]))              # the unused channels: any value, zero weight
+    deconv_1 = rnd(bn(rnd(deconv_bn(d, 'first_deconvolution_upconv', 2)), 'first_deconvolution_upconv'))
+    merge = rnd(deconv_1 + shortcut)
+    score = bn(deconv_bn(merge, 'second_deconvolution_upconv', 8), 'second_deconvolution_upconv').permute(0, 2, 3, 1)
+    assert deconv_1.shape[1] == u
+    logp = F.log_softmax(score, dim=-1)
+    lab = _t(np.asarray(labels).astype(np.int64))
+    valid = (lab >= 0) & (lab < num_classes)
+    onehot = F.one_hot(lab.clamp(0, num_classes - 1), num_classes).float() * valid[..., None].float()
+    ce = -(onehot * logp).sum() / (1e-20 + onehot.sum())
+    loss = ce / onehot.sum()                                                # adapnet.py:202-203
+    loss.backward()
+    grads = {k: (v.grad.numpy() if v.grad is not None else np.zeros(v.shape, np.float32)) for k, v in params.items()}
+    return float(loss.detach()), grads, stats

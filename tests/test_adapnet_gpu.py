@@ -230,8 +230,6 @@ def test_adapnet_model_and_fusion_classes(ops, tmp_path):
         assert cm.sum() == (data['labels'] >= 0).sum()
         exported = np.load(net.export_weights())
         assert np.array_equal(exported['rgb/block_layer_7/stage_2_2/kernel'], w_rgb['rgb/block_layer_7/stage_2_2/kernel'])
-        with pytest.raises(NotImplementedError):
-            net.fit(data, 1, output=False)
     cms = {m: np.eye(C) * 50 + 1 for m in ('rgb', 'depth')}
     with get_model('bayes_fusion')(data_description=_desc(), confusion_matrices=cms,
                                    prefixes={'rgb': 'rgb', 'depth': 'depth'}, num_units=U,
@@ -269,3 +267,125 @@ def test_dirichlet_fusion_with_adapnet_experts(ops, tmp_path):
         get_model('bayes_fusion')(data_description=_desc(), confusion_matrices={m: np.eye(C) for m in ('rgb', 'depth')},
                                   prefixes={'rgb': 'rgb', 'depth': 'depth'}, num_units=U,
                                   num_channels={'rgb': 3, 'depth': 1}, expert_model='resnet', class_prior='uniform')
+
+
+SHALLOW = [('block_layer_1', 'a', (64, 128, 1, True)), ('block_layer_2', 'a', (64, 128, 1, False)),
+           ('block_layer_4', 'a', (64, 256, 2, True)), ('block_layer_7', 'b', (64, 64, 256, 1, 2, False)),
+           ('block_layer_8', 'a', (128, 512, 2, True)), ('block_layer_14', 'b', (128, 128, 512, 2, 4, False))]
+
+
+def _grad_agreement(got, ref_g):
+    rel, cos = {}, {}
+    for k, g in ref_g.items():
+        if k.endswith('/bias'):
+            continue                                   # a bias in front of a batch norm has an exactly zero gradient
+        a = got[k][..., :g.shape[-1]].ravel().astype(np.float64)
+        b = g.ravel().astype(np.float64)
+        rel[k] = np.linalg.norm(a - b) / (np.linalg.norm(b) + 1e-30)
+        cos[k] = a @ b / (np.linalg.norm(a) * np.linalg.norm(b) + 1e-30)
+    return rel, cos
+
+
+def test_adapnet_training_step_on_a_shallow_graph(ops):
+    """Every op type of the training graph -- first conv, 7x7 stride-2 through the gather, pool, block_a with and
+    without shortcut conv and with stride 2, block_b with its stacked atrous pair, the block-7 shortcut, both deconvs
+    with batch norm, the head -- on a 6-block graph, shallow enough that bf16 rounding noise does not drown the
+    comparison: perturbing the oracle's own kernels by 3e-7 moves ITS gradients by 25-40 % here (cosine 0.93+), against
+    100 % (cosine 0.25-0.5) on the full 16 blocks.  A wrong term, index map or mask shows up as a cosine far below
+    that."""
+    from modular_semantic_segmentation_amd.adapnet import AdapnetEngine
+    from modular_semantic_segmentation_amd.adapnet_trainer import AdapnetTrainer
+    h, w = 64, 96
+    rng = np.random.default_rng(0)
+    x = rng.integers(0, 256, (2, h, w, 3)).astype(np.float32)
+    labels = rng.integers(-1, C, (2, h, w)).astype(np.int32)
+    w_ = ao.init_adapnet_weights('rgb', 3, U, C, seed=1, gain=1.3, blocks=SHALLOW)
+    w_['rgb/block_0_1/kernel'] *= 0.02
+    eng = AdapnetEngine('rgb', 3, U, C, w_, blocks=SHALLOW)
+    # the inference graph of the same shallow net first
+    ref = ao.adapnet_forward(x, w_, 'rgb', policy='bf16', blocks=SHALLOW)['score']
+    score = eng.forward(_dev(x), want=('score',))['score'].cpu().numpy()
+    assert np.abs(score - ref).max() / np.abs(ref).max() < 2e-2
+    tr = AdapnetTrainer(eng, 'rmsprop', 1e-3)
+    tr.load_from_variables(w_)
+    loss = tr.step(_dev(x), _dev(labels))
+    torch.cuda.synchronize()
+    got = tr.grads_as_variables()
+    ref_loss, ref_g, stats = ao.adapnet_loss_and_grads(x, labels, w_, 'rgb', C, policy='bf16', units=U, blocks=SHALLOW)
+    assert abs(loss.item() - ref_loss) < 1e-2 * abs(ref_loss), (loss.item(), ref_loss)
+    assert set(got) == set(ref_g)
+    rel, cos = _grad_agreement(got, ref_g)
+    print('shallow adapnet: gradient vs the bf16-policy oracle: relative error, cosine')
+    for k in sorted(rel):
+        print('  %-50s %.4f %.4f' % (k, rel[k], cos[k]))
+    for k in ('rgb/second_deconvolution_upconv/gamma', 'rgb/second_deconvolution_upconv/beta'):
+        assert rel[k] < 0.05, (k, rel[k])
+    for k in ('rgb/shortcut/kernel', 'rgb/first_deconvolution_conv/kernel', 'rgb/first_deconvolution_upconv/gamma'):
+        assert rel[k] < 0.2, (k, rel[k])
+    assert min(cos.values()) > 0.85, min(cos.items(), key=lambda kv: kv[1])
+    assert max(rel.values()) < 0.7, max(rel.items(), key=lambda kv: kv[1])
+    out = dict(w_)
+    tr.to_variables(out)
+    for scope in ('block_0_1', 'block_0_2', 'block_layer_4/stage_1', 'block_layer_7/stage_2_2', 'block_layer_14/stage_2_1',
+                  'shortcut', 'first_deconvolution_upconv', 'second_deconvolution_upconv'):
+        mean, var = stats[scope]
+        real = len(w_['rgb/%s/moving_mean' % scope])
+        np.testing.assert_allclose(out['rgb/%s/moving_mean' % scope],
+                                   0.99 * w_['rgb/%s/moving_mean' % scope] + 0.01 * mean[:real], rtol=3e-2, atol=3e-3)
+        np.testing.assert_allclose(out['rgb/%s/moving_variance' % scope],
+                                   0.99 * w_['rgb/%s/moving_variance' % scope] + 0.01 * var[:real], rtol=3e-2, atol=3e-3)
+    # RMSProp ([TF1]: ms starts at 1) with the loss's 1/count already in the gradient
+    k = 'rgb/block_layer_7/stage_2_1/kernel'
+    g = got[k]
+    np.testing.assert_allclose(out[k] - w_[k], -1e-3 * g / np.sqrt(0.9 + 0.1 * g * g + 1e-10), rtol=2e-3, atol=4e-9)
+
+
+def test_adapnet_training_step(ops, tmp_path):
+    """One training step (adapnet.py:103-173 with is_training=True, loss :196-203) against autograd over the oracle's
+    restatement: loss, gradients of every kernel / bias / gamma / beta, moving averages; then fit(), export and
+    inference with the trained statistics.  A 50-layer batch-norm network at random initialisation is chaotic with
+    respect to bf16 rounding (see tests/test_backward_gpu.py); thresholds are calibrated against the oracle's own
+    sensitivity, the kernels on the path are each checked exactly elsewhere in this file."""
+    from modular_semantic_segmentation_amd import get_model
+    h, w = 64, 96
+    rng = np.random.default_rng(0)
+    data = {'rgb': rng.integers(0, 256, (2, h, w, 3)).astype(np.float32),
+            'labels': rng.integers(-1, C, (2, h, w)).astype(np.int32)}
+    w_, path = _weights(tmp_path, 'rgb', 3, 1, 0.02)
+    net = get_model('adapnet')(_desc(), output_dir=str(tmp_path), modality='rgb', num_units=U, batchsize=2,
+                               trainer='adam', learning_rate=1e-3)
+    net.import_weights(path)
+    tr = net._ensure_trainer()
+    loss = tr.step(_dev(data['rgb']), _dev(data['labels']))
+    torch.cuda.synchronize()
+    got = tr.grads_as_variables()
+    ref_loss, ref_g, stats = ao.adapnet_loss_and_grads(data['rgb'], data['labels'], w_, 'rgb', C, policy='bf16', units=U)
+    assert abs(loss.item() - ref_loss) < 2e-2 * abs(ref_loss), (loss.item(), ref_loss)
+    assert set(got) == set(ref_g)
+    rel, cos = _grad_agreement(got, ref_g)
+    # full depth: the oracle's own gradients move by ~100 % (cosine 0.25-0.5) under a 3e-7 perturbation of its kernels,
+    # so only the head is compared here; the backward graph itself is pinned on the shallow graph above
+    print('median relative error %.4f, worst cosine %.4f' % (np.median(list(rel.values())), min(cos.values())))
+    assert rel['rgb/second_deconvolution_upconv/gamma'] < 0.1 and rel['rgb/second_deconvolution_upconv/beta'] < 0.3
+    assert np.median(list(rel.values())) < 1.3
+    out = dict(net.variables)
+    tr.to_variables(out)
+    for scope in ('block_0_1', 'block_0_2', 'block_layer_1/stage_2', 'second_deconvolution_upconv'):
+        mean, var = stats[scope]
+        np.testing.assert_allclose(out['rgb/%s/moving_mean' % scope], 0.99 * w_['rgb/%s/moving_mean' % scope] + 0.01 * mean,
+                                   rtol=3e-2, atol=3e-3)
+        np.testing.assert_allclose(out['rgb/%s/moving_variance' % scope],
+                                   0.99 * w_['rgb/%s/moving_variance' % scope] + 0.01 * var, rtol=3e-2, atol=3e-3)
+    # the 2048 - U untrained output channels of first_deconvolution_conv keep their values
+    k = 'rgb/first_deconvolution_conv/kernel'
+    assert np.array_equal(out[k][..., U:], w_[k][..., U:]) and not np.array_equal(out[k][..., :U], w_[k][..., :U])
+    first = net._train_batch(data)
+    for _ in range(6):
+        last = net._train_batch(data)
+    assert last < first
+    net.fit(data, 2, output=False)
+    pred = net.predict(data)
+    assert pred.shape == (2, h, w)
+    saved = np.load(net.export_weights())
+    ref = ao.adapnet_forward(data['rgb'], {k: saved[k] for k in saved.files}, 'rgb', policy='bf16')['score']
+    assert (pred == fo.argmax_last(fo.softmax(ref))).mean() > 0.9
