@@ -11,7 +11,6 @@ iterable of per-sample dicts (the tf.data.Dataset case); both are cut into batch
 config['batchsize'].
 """
 import os
-from copy import deepcopy
 
 import numpy as np
 import torch

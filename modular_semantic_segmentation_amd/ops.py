@@ -5,7 +5,6 @@ hot path runs in libxview_hip.so.
 """
 import ctypes
 
-import numpy as np
 import torch
 
 from . import _lib

@@ -1,9 +1,6 @@
 """SimpleFCN model (reference: xview/models/simple_fcn.py:173-224) on the MI355X engine."""
-import numpy as np
 import torch
 
-from . import fcn as _fcn
-from . import ops
 from .base_model import BaseModel
 from .fcn import FcnEngine, init_variables  # noqa: F401  (fcn-level API re-exported for callers)
 

@@ -14,7 +14,7 @@ import numpy as np
 import torch
 
 from . import ops
-from .fcn import ENCODER, variable_shapes
+from .fcn import ENCODER
 
 # backward order of the trainable layers
 LAYER_ORDER = ['score', 'score_conv5', 'score_conv4'] + [name for name, _, _ in reversed(ENCODER)]

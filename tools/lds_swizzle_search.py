@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Exhaustive search for a bank-conflict-free 16-byte-slot swizzle of the conv LDS images
 (ds_read_b128 lane groups and the 16x16x32 MFMA fragment map; see csrc/xv_common.h xv_swz)."""
-import itertools, numpy as np
+import itertools
 groups=[list(range(0,4))+list(range(12,16))+list(range(20,28)),
         list(range(4,12))+list(range(16,20))+list(range(28,32)),
         list(range(32,36))+list(range(44,48))+list(range(52,60)),

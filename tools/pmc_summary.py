@@ -3,7 +3,6 @@
 under profiles/: per-kernel time stats and per-launch HBM traffic of the conv kernel from the
 FETCH_SIZE / WRITE_SIZE passes (separate --pmc passes; gfx950 correction: FETCH_SIZE reports half
 the bytes of wide coalesced reads -> doubled, WRITE_SIZE exact; MI355X_MICROARCH.md 'HBM')."""
-import collections
 import csv
 import glob
 import json
