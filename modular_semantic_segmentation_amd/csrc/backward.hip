@@ -330,61 +330,77 @@ __global__ __launch_bounds__(256) void conv_first_wgrad_kernel(const float* __re
   __shared__ __attribute__((aligned(16))) __bf16 dys[PX * 64];
   const int64_t npix = (int64_t)N * H * W;
   const int co = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  float acc[KP];
+  typedef __attribute__((ext_vector_type(2))) float f32x2;
+  f32x2 acc[KP / 2];  // pairs of taps: one v_pk_fma_f32 per pair and pixel
 #pragma unroll
-  for (int i = 0; i < KP; ++i) acc[i] = 0.f;
+  for (int i = 0; i < KP / 2; ++i) acc[i] = f32x2{0.f, 0.f};
   float bacc = 0.f;
   for (int ch = 0; ch < chunks_per_block; ++ch) {
     const int64_t base = ((int64_t)blockIdx.x * chunks_per_block + ch) * PX;
     if (base >= npix) break;
     __syncthreads();
+    // staging: every global load of a thread is issued before its first LDS store (addresses are clamped onto valid
+    // pixels and the out-of-image taps selected to zero afterwards, so the loads are unconditional and batch up)
     if (threadIdx.x < PX) {
-      const int64_t pix = base + threadIdx.x;
-      const bool ok = pix < npix;
-      const int64_t pc = ok ? pix : npix - 1;
-      const int px = (int)(pc % W), py = (int)((pc / W) % H), n = (int)(pc / ((int64_t)W * H));
+      const int pix = (int)base + (int)threadIdx.x;  // npix < 2^31 (checked by the launcher): 32-bit divisions
+      const bool ok = pix < (int)npix;
+      const int pc = ok ? pix : (int)npix - 1;
+      const int row = pc / W;
+      const int px = pc - row * W, n = row / H, py = row - n * H;
+      float v[9][CIN];
+      bool inside[9];
 #pragma unroll
-      for (int dy_ = 0; dy_ < 3; ++dy_)
+      for (int t = 0; t < 9; ++t) {
+        const int yy = py + t / 3 - 1, xx = px + t % 3 - 1;
+        inside[t] = ok && yy >= 0 && yy < H && xx >= 0 && xx < W;
+        const int yc = yy < 0 ? 0 : (yy >= H ? H - 1 : yy), xc = xx < 0 ? 0 : (xx >= W ? W - 1 : xx);
+        const float* src = x + (((int64_t)n * H + yc) * W + xc) * CIN;
 #pragma unroll
-        for (int dx = 0; dx < 3; ++dx) {
-          const int yy = py + dy_ - 1, xx = px + dx - 1;
-          const bool in = ok && yy >= 0 && yy < H && xx >= 0 && xx < W;
-          const float* src = x + (((int64_t)n * H + (in ? yy : 0)) * W + (in ? xx : 0)) * CIN;
+        for (int c = 0; c < CIN; ++c) v[t][c] = src[c];
+      }
 #pragma unroll
-          for (int c = 0; c < CIN; ++c) ins[threadIdx.x * KP + (dy_ * 3 + dx) * CIN + c] = in ? src[c] : 0.f;
-        }
+      for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int c = 0; c < CIN; ++c) ins[threadIdx.x * KP + t * CIN + c] = inside[t] ? v[t][c] : 0.f;
 #pragma unroll
       for (int t = K; t < KP; ++t) ins[threadIdx.x * KP + t] = 0.f;
     }
+    {
+      constexpr int ITERS = PX * 8 / 256;
+      u32x4 dv[ITERS];
 #pragma unroll
-    for (int it = 0; it < PX * 8 / 256; ++it) {
-      const int idx = threadIdx.x + it * 256;
-      const int lp = idx >> 3, s = idx & 7;
-      const int64_t pix = base + lp;
-      const bool ok = pix < npix;
-      const int64_t pc = ok ? pix : npix - 1;
-      const int px = (int)(pc % W), py = (int)((pc / W) % H), n = (int)(pc / ((int64_t)W * H));
-      u32x4 v = *reinterpret_cast<const u32x4*>(dy + (((int64_t)n * (H + 2) + (py + 1)) * (W + 2) + (px + 1)) * 64 + s * 8);
-      if (!ok) v = u32x4{0u, 0u, 0u, 0u};
-      *reinterpret_cast<u32x4*>(dys + lp * 64 + s * 8) = v;
+      for (int it = 0; it < ITERS; ++it) {
+        const int idx = threadIdx.x + it * 256;
+        const int pix = (int)base + (idx >> 3);
+        const bool ok = pix < (int)npix;
+        const int pc = ok ? pix : (int)npix - 1;
+        const int row = pc / W;
+        const int px = pc - row * W, n = row / H, py = row - n * H;
+        dv[it] = *reinterpret_cast<const u32x4*>(dy + (((int64_t)n * (H + 2) + (py + 1)) * (W + 2) + (px + 1)) * 64 + (idx & 7) * 8);
+        if (!ok) dv[it] = u32x4{0u, 0u, 0u, 0u};
+      }
+#pragma unroll
+      for (int it = 0; it < ITERS; ++it) {
+        const int idx = threadIdx.x + it * 256;
+        *reinterpret_cast<u32x4*>(dys + (idx >> 3) * 64 + (idx & 7) * 8) = dv[it];
+      }
     }
     __syncthreads();
 #pragma unroll 2
     for (int px = wv * 32; px < wv * 32 + 32; ++px) {
       const float g = (float)dys[px * 64 + co];
       bacc += g;
+      const f32x2 g2 = f32x2{g, g};
 #pragma unroll
       for (int t4 = 0; t4 < KP; t4 += 4) {
         const f32x4 iv = *reinterpret_cast<const f32x4*>(ins + px * KP + t4);
-        acc[t4] = fmaf(iv.x, g, acc[t4]);
-        acc[t4 + 1] = fmaf(iv.y, g, acc[t4 + 1]);
-        acc[t4 + 2] = fmaf(iv.z, g, acc[t4 + 2]);
-        acc[t4 + 3] = fmaf(iv.w, g, acc[t4 + 3]);
+        acc[t4 / 2] = __builtin_elementwise_fma(f32x2{iv.x, iv.y}, g2, acc[t4 / 2]);
+        acc[t4 / 2 + 1] = __builtin_elementwise_fma(f32x2{iv.z, iv.w}, g2, acc[t4 / 2 + 1]);
       }
     }
   }
 #pragma unroll
-  for (int t = 0; t < K; ++t) atomicAdd(&dw[t * 64 + co], acc[t]);
+  for (int t = 0; t < K; ++t) atomicAdd(&dw[t * 64 + co], acc[t / 2][t & 1]);
   if (db != nullptr) atomicAdd(&db[co], bacc);
 }
 
@@ -527,6 +543,7 @@ extern "C" int xv_conv2d_first_bwd_filter(const float* x, int n, int h, int w, i
                                           float* dbias, void* stream) {
   XV_CHECK_ARG(x && dy && dy->data && dw_hwio);
   XV_CHECK_SHAPE(n > 0 && h > 0 && w > 0 && cin >= 1 && cin <= 4 && dy->n == n && dy->h == h && dy->w == w && dy->c == 64);
+  XV_CHECK_SHAPE((int64_t)n * h * w < 0x7fff0000);
   const int64_t npix = (int64_t)n * h * w;
   const int chunks = 32;
   const unsigned grid = (unsigned)((npix + 128 * chunks - 1) / (128 * chunks));
