@@ -176,11 +176,15 @@ __global__ __launch_bounds__(256) void head_loss_kernel(const float* __restrict_
   __syncthreads();
   const int Ho = Hi * 8, Wo = Wi * 8;
   const int64_t npix = (int64_t)N * Ho * Wo;
-  const int64_t opix = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (opix < npix) {
-    const int ox = (int)(opix % Wo);
-    const int oy = (int)((opix / Wo) % Ho);
-    const int n = (int)(opix / ((int64_t)Wo * Ho));
+  float part[CM], lossterm = 0.f;
+#pragma unroll
+  for (int k = 0; k < CM; ++k) part[k] = 0.f;
+  // grid-stride over the pixels with the sums kept in registers: the 13 global atomics at the end are issued once
+  // per workgroup of a bounded grid, not once per 256 pixels (same-address atomics serialise in L2)
+  for (int64_t opix = (int64_t)blockIdx.x * 256 + threadIdx.x; opix < npix; opix += (int64_t)gridDim.x * 256) {
+    const int op32 = (int)opix;  // npix < 2^31 (checked by the launcher): 32-bit divisions
+    const int orow = op32 / Wo;
+    const int ox = op32 - orow * Wo, n = orow / Ho, oy = orow - n * Ho;
     const int iy1 = (oy + 4) >> 3, ix1 = (ox + 4) >> 3;
     const float wy1 = bilinear_w<8>(oy, iy1), wy0 = bilinear_w<8>(oy, iy1 - 1);
     const float wx1 = bilinear_w<8>(ox, ix1), wx0 = bilinear_w<8>(ox, ix1 - 1);
@@ -224,12 +228,23 @@ __global__ __launch_bounds__(256) void head_loss_kernel(const float* __restrict_
 #pragma unroll
     for (int k4 = 0; k4 < CM; k4 += 4)
       *reinterpret_cast<f32x4*>(dst + k4) = f32x4{sc[k4], sc[k4 + 1], sc[k4 + 2], sc[k4 + 3]};
-    if (valid) {
-      atomicAdd(&red[CM], -(zlab - logf(sum)) * inv_denom);  // -(log_softmax)[label] / denom
+    lossterm += valid ? -(zlab - logf(sum)) * inv_denom : 0.f;  // -(log_softmax)[label] / denom
 #pragma unroll
-      for (int k = 0; k < CM; ++k)
-        if (k < C) atomicAdd(&red[k], sc[k]);
-    }
+    for (int k = 0; k < CM; ++k) part[k] += sc[k];               // already zero for unlabelled pixels
+  }
+  // bias gradient and loss: butterfly sum over the wave, then ONE LDS atomic per wave and channel (per-lane LDS
+  // atomics on 13 shared addresses serialise 64-fold and used to be most of this kernel's time)
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    lossterm += __shfl_xor(lossterm, off, 64);
+#pragma unroll
+    for (int k = 0; k < CM; ++k) part[k] += __shfl_xor(part[k], off, 64);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    atomicAdd(&red[CM], lossterm);
+#pragma unroll
+    for (int k = 0; k < CM; ++k)
+      if (k < C) atomicAdd(&red[k], part[k]);
   }
   __syncthreads();
   if (threadIdx.x < C && red[threadIdx.x] != 0.f) atomicAdd(&dbs[threadIdx.x], red[threadIdx.x]);
@@ -505,8 +520,8 @@ extern "C" int xv_decoder_head_bwd(const xv_act* fused, const float* w_score, co
   if (rc != XV_OK) return rc;
   const int64_t npix = (int64_t)fused->n * fused->h * fused->w * 64;
   const int64_t lowres = (int64_t)fused->n * fused->h * fused->w;
-  XV_CHECK_SHAPE((npix + 255) / 256 <= 0x7fffffff);
-  const unsigned g1 = (unsigned)((npix + 255) / 256), g2 = (unsigned)((lowres + 255) / 256);
+  XV_CHECK_SHAPE(npix < 0x7fff0000);
+  const unsigned g1 = (unsigned)((npix + 255) / 256 < 4096 ? (npix + 255) / 256 : 4096), g2 = (unsigned)((lowres + 255) / 256);
   const int U = fused->c;
   const unsigned long long* cnt = reinterpret_cast<const unsigned long long*>(valid_count);
 #define XV_HB(CMV)                                                                                                   \
