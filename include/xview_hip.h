@@ -54,6 +54,10 @@ const char* xv_arch(void);
  * k = 1 or 3, cin % 64 == 0, cout % 64 == 0.                                                       */
 size_t xv_packed_weight_bytes(int k, int cin, int cout);
 int xv_pack_conv_weights(const float* w_hwio, void* packed, int k, int cin, int cout, void* stream);
+/* Forward image and data-gradient image (xv_pack_conv_weights_dgrad) of one layer in a single launch: what a training
+ * step does for every conv after the optimizer update.                                                               */
+int xv_pack_conv_weights_pair(const float* w_hwio, void* packed, void* packed_dgrad, int k, int cin, int cout,
+                              void* stream);
 
 /* ---- conv2d forward ------------------------------------------------------------------------
  * y = act(conv(x, W) + b): tf.layers.conv2d(padding='same', strides 1) via

@@ -31,6 +31,7 @@ SIGNATURES = {
     'xv_arch': (ctypes.c_char_p, []),
     'xv_packed_weight_bytes': (ctypes.c_size_t, [_i, _i, _i]),
     'xv_pack_conv_weights': (_i, [_vp, _vp, _i, _i, _i, _vp]),
+    'xv_pack_conv_weights_pair': (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
     'xv_conv2d_fwd': (_i, [_actp, _vp, _vp, _actp, _actp, _i, _i, _vp]),
     'xv_conv2d_fwd_cfg': (_i, [_actp, _vp, _vp, _actp, _actp, _i, _i, _i, _vp]),
     'xv_conv2d_num_cfgs': (_i, []),

@@ -173,8 +173,7 @@ class AdapnetTrainer(object):
             self.w[key] = torch.empty(nel, dtype=torch.bfloat16, device=kernel.device)
             self.wd[key] = torch.empty(nel, dtype=torch.bfloat16, device=kernel.device)
         kernel = kernel.contiguous()
-        ops.pack_conv_weights_into(kernel, self.w[key])
-        ops.pack_conv_weights_dgrad(kernel, self.wd[key])
+        ops.pack_conv_weights_pair(kernel, self.w[key], self.wd[key])
 
     def repack(self):
         for scope in self.units:

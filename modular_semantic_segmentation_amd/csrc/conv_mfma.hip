@@ -1068,8 +1068,8 @@ int launch_conv_dma(const ConvArgs& a0, hipStream_t stream) {
 // ---- weight packing: fp32 HWIO -> bf16 [tap][cin/64][cout][64] (16-byte slots swizzled by xv_swz), followed for
 // 3x3 filters by the generation-2 image [tap][cin/32][cout][32] (xv_swz32).  dgrad != 0 packs the weights of the
 // data-gradient convolution instead: input/output channels swapped and the taps point-reflected.
-__global__ void pack_weights_kernel(const float* __restrict__ w, __bf16* __restrict__ out, int taps, int cin,
-                                    int cout, int dgrad) {
+__device__ __forceinline__ void pack_weights_image(const float* __restrict__ w, __bf16* __restrict__ out, int taps,
+                                                   int cin, int cout, int dgrad, int64_t idx, int64_t total) {
   // logical operand of the convolution that will consume the image: Wl[tap][ci][co]; for the data gradient
   // Wl[tap][ci = dgrad input = cout of w][co = cin of w] = w[taps-1-tap][co][ci]
   const int rc = dgrad ? cout : cin;  // reduction channels
@@ -1077,32 +1077,40 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, __bf16* __restr
   auto wl = [&](int tap, int ci, int co) -> float {
     return dgrad ? w[((int64_t)(taps - 1 - tap) * cin + co) * cout + ci] : w[((int64_t)tap * cin + ci) * cout + co];
   };
-  const int64_t total = (int64_t)taps * cin * cout;
   const int nch64 = rc >> 6, nch32 = rc >> 5;
+  {  // image 1, destination-linear [tap][chunk64][co][phys_slot 0..7][e]
+    const int e = (int)(idx & 7);
+    const int ps = (int)((idx >> 3) & 7);
+    int64_t rest = idx >> 6;
+    const int co = (int)(rest % oc);
+    rest /= oc;
+    const int chunk = (int)(rest % nch64);
+    const int tap = (int)(rest / nch64);
+    const int sl = xv_swz(co, ps);  // involution: logical slot stored at this physical slot
+    out[idx] = (__bf16)wl(tap, chunk * 64 + sl * 8 + e, co);
+  }
+  if (taps == 9) {  // image 2 (generation-2 kernel), [tap][chunk32][co][phys_slot 0..3][e]
+    const int e = (int)(idx & 7);
+    const int ps = (int)((idx >> 3) & 3);
+    int64_t rest = idx >> 5;
+    const int co = (int)(rest % oc);
+    rest /= oc;
+    const int chunk = (int)(rest % nch32);
+    const int tap = (int)(rest / nch32);
+    const int sl = xv_swz32(co, ps);
+    out[total + idx] = (__bf16)wl(tap, chunk * 32 + sl * 8 + e, co);
+  }
+}
+
+// out: the image selected by `dgrad`; out_dgrad (may be null): additionally the data-gradient image, so that a
+// training step re-packs a layer's forward and backward weights in one launch
+__global__ void pack_weights_kernel(const float* __restrict__ w, __bf16* __restrict__ out, int taps, int cin,
+                                    int cout, int dgrad, __bf16* __restrict__ out_dgrad) {
+  const int64_t total = (int64_t)taps * cin * cout;
   for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
        idx += (int64_t)gridDim.x * blockDim.x) {
-    {  // image 1, destination-linear [tap][chunk64][co][phys_slot 0..7][e]
-      const int e = (int)(idx & 7);
-      const int ps = (int)((idx >> 3) & 7);
-      int64_t rest = idx >> 6;
-      const int co = (int)(rest % oc);
-      rest /= oc;
-      const int chunk = (int)(rest % nch64);
-      const int tap = (int)(rest / nch64);
-      const int sl = xv_swz(co, ps);  // involution: logical slot stored at this physical slot
-      out[idx] = (__bf16)wl(tap, chunk * 64 + sl * 8 + e, co);
-    }
-    if (taps == 9) {  // image 2 (generation-2 kernel), [tap][chunk32][co][phys_slot 0..3][e]
-      const int e = (int)(idx & 7);
-      const int ps = (int)((idx >> 3) & 3);
-      int64_t rest = idx >> 5;
-      const int co = (int)(rest % oc);
-      rest /= oc;
-      const int chunk = (int)(rest % nch32);
-      const int tap = (int)(rest / nch32);
-      const int sl = xv_swz32(co, ps);
-      out[total + idx] = (__bf16)wl(tap, chunk * 32 + sl * 8 + e, co);
-    }
+    pack_weights_image(w, out, taps, cin, cout, dgrad, idx, total);
+    if (out_dgrad != nullptr) pack_weights_image(w, out_dgrad, taps, cin, cout, 1, idx, total);
   }
 }
 
@@ -1238,7 +1246,18 @@ extern "C" int xv_pack_conv_weights(const float* w_hwio, void* packed, int k, in
   const int64_t total = (int64_t)k * k * cin * cout;
   const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
   hipLaunchKernelGGL(pack_weights_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w_hwio, (__bf16*)packed,
-                     k * k, cin, cout, 0);
+                     k * k, cin, cout, 0, (__bf16*)nullptr);
+  return xv_launch_status();
+}
+
+extern "C" int xv_pack_conv_weights_pair(const float* w_hwio, void* packed, void* packed_dgrad, int k, int cin, int cout,
+                                          void* stream) {
+  XV_CHECK_ARG(w_hwio && packed && packed_dgrad);
+  XV_CHECK_SHAPE((k == 1 || k == 3) && cin > 0 && cout > 0 && (cin & 63) == 0 && (cout & 63) == 0);
+  const int64_t total = (int64_t)k * k * cin * cout;
+  const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+  hipLaunchKernelGGL(pack_weights_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w_hwio, (__bf16*)packed,
+                     k * k, cin, cout, 0, (__bf16*)packed_dgrad);
   return xv_launch_status();
 }
 
@@ -1248,7 +1267,7 @@ extern "C" int xv_pack_conv_weights_dgrad(const float* w_hwio, void* packed, int
   const int64_t total = (int64_t)k * k * cin * cout;
   const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
   hipLaunchKernelGGL(pack_weights_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w_hwio, (__bf16*)packed,
-                     k * k, cin, cout, 1);
+                     k * k, cin, cout, 1, (__bf16*)nullptr);
   return xv_launch_status();
 }
 

@@ -341,6 +341,14 @@ def pack_conv_weights_into(w_hwio, out):
     return out
 
 
+def pack_conv_weights_pair(w_hwio, out, out_dgrad):
+    """Forward and data-gradient packed images of one kernel in one launch."""
+    _need(w_hwio, torch.float32, 'w_hwio')
+    k, _, cin, cout = w_hwio.shape
+    _lib.check(_lib.lib().xv_pack_conv_weights_pair(_ptr(w_hwio), _ptr(out), _ptr(out_dgrad), k, cin, cout, _stream()),
+               'xv_pack_conv_weights_pair')
+
+
 def conv2d_bwd_data(dy, w_packed_dgrad, zero_bias, dx, k, relu_ref=None, addend=None):
     rc = _lib.lib().xv_conv2d_bwd_data(dy.xv(), _ptr(w_packed_dgrad), _ptr(zero_bias),
                                       relu_ref.xv() if relu_ref is not None else _NULL_ACT,

@@ -155,8 +155,7 @@ class FcnTrainer(object):
                 nel = ops.packed_weight_elems(k, cin, cout)
                 e.w[name] = torch.empty(nel, dtype=torch.bfloat16, device=e.device)
                 self.wd[name] = torch.empty(nel, dtype=torch.bfloat16, device=e.device)
-            ops.pack_conv_weights_into(kv, e.w[name])
-            ops.pack_conv_weights_dgrad(kv, self.wd[name])
+            ops.pack_conv_weights_pair(kv, e.w[name], self.wd[name])
 
     @staticmethod
     def _input_of(name):
@@ -412,8 +411,7 @@ class FcnBnTrainer(object):
                 nel = ops.packed_weight_elems(k, cin, cout)
                 self.w[name] = torch.empty(nel, dtype=torch.bfloat16, device=dev)
                 self.wd[name] = torch.empty(nel, dtype=torch.bfloat16, device=dev)
-            ops.pack_conv_weights_into(kv, self.w[name])
-            ops.pack_conv_weights_dgrad(kv, self.wd[name])
+            ops.pack_conv_weights_pair(kv, self.w[name], self.wd[name])
 
     def _act(self, tag, n, h, w, c):
         key = (tag, n, h, w, c)
@@ -690,8 +688,9 @@ class FusionFcnTrainer(object):
                 if not getattr(trunk, '_trainer_owned', False) or name not in trunk.w:
                     trunk.w[name] = torch.empty(ops.packed_weight_elems(3, kv.shape[2], kv.shape[3]), dtype=torch.bfloat16,
                                                 device=dev)
-                ops.pack_conv_weights_into(kv, trunk.w[name])
-                packed(self.wd, (m, name), kv, True)
+                if (m, name) not in self.wd:
+                    self.wd[(m, name)] = torch.empty_like(trunk.w[name])
+                ops.pack_conv_weights_pair(kv, trunk.w[name], self.wd[(m, name)])
             trunk._trainer_owned = True
         for name in ('fused_score_conv4', 'fused_score_conv5'):
             kv = self.view(self.param, name, 'kernel')
