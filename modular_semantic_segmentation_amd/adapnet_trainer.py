@@ -23,6 +23,21 @@ from .adapnet import _conv_scopes, conv7s2_as_3x3
 from .trainer import FcnTrainer
 
 
+def conv7s2_index_maps(cin, cout):
+    """Index maps between the 7x7 stride-2 kernel [7,7,cin,cout] and the derived [3,3,9*cin,cout] kernel of
+    adapnet.conv7s2_as_3x3 (both flattened): src[j] = flat index of the 7x7 element that derived element j copies, -1
+    where the derived kernel is structurally zero; inv[i] = the derived position of 7x7 element i (each is used exactly
+    once).  derived = w7.ravel()[src] (masked), and the filter gradient maps back as dw7.ravel() = dw3.ravel()[inv]."""
+    n = 49 * cin * cout
+    assert n < 2 ** 24                                    # the probe values below are exact in float32
+    probe = np.arange(1, n + 1, dtype=np.float32).reshape(7, 7, cin, cout)
+    src = conv7s2_as_3x3(probe).astype(np.int64).ravel() - 1
+    inv = np.empty(n, np.int64)
+    pos = np.nonzero(src >= 0)[0]
+    inv[src[pos]] = pos
+    return src, inv
+
+
 class AdapnetTrainer(object):
     def __init__(self, engine, trainer='adam', learning_rate=1e-4):
         if trainer not in ('adam', 'rmsprop', 'adagrad'):
@@ -65,16 +80,10 @@ class AdapnetTrainer(object):
         sel = torch.zeros(e.Up, e.C, dtype=torch.float32, device=dev)
         sel[torch.arange(e.C), torch.arange(e.C)] = 1.0
         self.selector = sel
-        # 7x7 -> 3x3 x 9 groups: index of the source tap for every derived element (-1: structural zero)
-        probe = np.arange(1, 49 * 64 * 64 + 1, dtype=np.float64).reshape(7, 7, 64, 64)
-        derived = conv7s2_as_3x3(probe.astype(np.float32)).astype(np.int64)          # exact below 2^24
-        assert 49 * 64 * 64 < 2 ** 24
-        idx = torch.from_numpy(derived.ravel() - 1).to(dev)
+        src, inv = conv7s2_index_maps(64, 64)
+        idx = torch.from_numpy(src).to(dev)
         self.map7 = (idx.clamp(min=0), (idx >= 0))
-        inv = torch.empty(49 * 64 * 64, dtype=torch.int64, device=dev)
-        pos = torch.nonzero(idx >= 0).ravel()
-        inv[idx[pos]] = pos
-        self.inv7 = inv
+        self.inv7 = torch.from_numpy(inv).to(dev)
         self._sync = False
 
     # ---- parameters ------------------------------------------------------------------------------------------------

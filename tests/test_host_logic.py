@@ -259,3 +259,21 @@ def test_adapnet_weight_transforms_on_cpu():
     assert {k: tuple(v.shape) for k, v in ao.init_adapnet_weights('rgb', 3, 20, 14).items()} == shapes
     init = adapnet.init_variables('rgb', 3, 20, 14, seed=0)
     assert np.array_equal(init['rgb/second_deconvolution_upconv/kernel'], ao.rect_bilinear_kernel(16, 14, 20))
+
+
+def test_adapnet_trainer_index_maps_on_cpu():
+    """adapnet_trainer.conv7s2_index_maps: the derived 3x3 kernel is a masked gather of the 7x7 one, every 7x7 tap is
+    used exactly once, and mapping a filter gradient back is the adjoint of that gather."""
+    from modular_semantic_segmentation_amd.adapnet import conv7s2_as_3x3
+    from modular_semantic_segmentation_amd.adapnet_trainer import conv7s2_index_maps
+    cin, cout = 4, 3
+    src, inv = conv7s2_index_maps(cin, cout)
+    rng = np.random.default_rng(0)
+    w7 = rng.standard_normal((7, 7, cin, cout)).astype(np.float32)
+    derived = np.where(src >= 0, w7.ravel()[np.maximum(src, 0)], 0).reshape(3, 3, 9 * cin, cout)
+    assert np.array_equal(derived, conv7s2_as_3x3(w7))
+    assert sorted(src[src >= 0].tolist()) == list(range(49 * cin * cout)) and np.array_equal(src[inv], np.arange(49 * cin * cout))
+    dw3 = rng.standard_normal(derived.shape).astype(np.float32)
+    dw7 = dw3.ravel()[inv].reshape(w7.shape)
+    # <derive(w7), dw3> == <w7, back(dw3)>
+    assert np.isclose((derived.astype(np.float64) * dw3).sum(), (w7.astype(np.float64) * dw7).sum())
