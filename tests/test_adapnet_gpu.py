@@ -389,3 +389,34 @@ def test_adapnet_training_step(ops, tmp_path):
     saved = np.load(net.export_weights())
     ref = ao.adapnet_forward(data['rgb'], {k: saved[k] for k in saved.files}, 'rgb', policy='bf16')['score']
     assert (pred == fo.argmax_last(fo.softmax(ref))).mean() > 0.9
+
+
+def test_adapnet_with_the_reference_tests_configuration(ops):
+    """num_classes 14, num_units 20 (xview/models/test_adapnet.py:4-8): unit counts that are not lane multiples (U is
+    padded to 64 zero lanes inside, the variables keep their reference shapes), inference and one training step."""
+    from modular_semantic_segmentation_amd.adapnet import AdapnetEngine
+    from modular_semantic_segmentation_amd.adapnet_trainer import AdapnetTrainer
+    c, u, h, w = 14, 20, 32, 48
+    rng = np.random.default_rng(2)
+    x = rng.integers(0, 256, (2, h, w, 3)).astype(np.float32)
+    labels = rng.integers(-1, c, (2, h, w)).astype(np.int32)
+    w_ = ao.init_adapnet_weights('rgb', 3, u, c, seed=4, gain=1.3, blocks=SHALLOW)
+    w_['rgb/block_0_1/kernel'] *= 0.02
+    eng = AdapnetEngine('rgb', 3, u, c, w_, blocks=SHALLOW)
+    out = eng.forward(_dev(x), want=('score', 'label'))
+    ref = ao.adapnet_forward(x, w_, 'rgb', policy='bf16', blocks=SHALLOW)['score']
+    score = out['score'].cpu().numpy()
+    assert score.shape == (2, h, w, c) and np.abs(score - ref).max() / np.abs(ref).max() < 2e-2
+    tr = AdapnetTrainer(eng, 'adam', 1e-3)
+    tr.load_from_variables(w_)
+    loss = tr.step(_dev(x), _dev(labels))
+    ref_loss, ref_g, _ = ao.adapnet_loss_and_grads(x, labels, w_, 'rgb', c, policy='bf16', units=u, blocks=SHALLOW)
+    assert abs(loss.item() - ref_loss) < 1e-2 * abs(ref_loss)
+    got = tr.grads_as_variables()
+    assert {k: v.shape for k, v in got.items()} == {k: v.shape for k, v in ref_g.items()}
+    rel, cos = _grad_agreement(got, ref_g)
+    assert rel['rgb/second_deconvolution_upconv/gamma'] < 0.05 and rel['rgb/shortcut/kernel'] < 0.2, rel
+    assert min(cos.values()) > 0.8, min(cos.items(), key=lambda kv: kv[1])
+    out_vars = dict(w_)
+    tr.to_variables(out_vars)
+    assert {k: np.shape(v) for k, v in out_vars.items()} == {k: v.shape for k, v in w_.items()}
