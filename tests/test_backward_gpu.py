@@ -427,3 +427,39 @@ def test_fusion_fcn_training_step(ops, tmp_path):
         saved['fused_score_conv4/kernel'], w['fused_score_conv4/kernel'])
     ref = fo.fusion_fcn_forward({m: data[m] for m in prefixes}, {k: saved[k] for k in saved.files}, prefixes, policy='bf16')
     assert (pred == fo.argmax_last(fo.softmax(ref['score']))).mean() > 0.97
+
+
+def test_fusion_fcn_training_with_padded_units(ops, tmp_path):
+    """Joint model with num_units = 20, num_classes = 14: the U lanes are padded to 64 inside, variables and gradients
+    keep the reference shapes."""
+    from modular_semantic_segmentation_amd import get_model
+    C, U, H, W = 14, 20, 32, 48
+    prefixes, channels = {'rgb': 'rgb', 'depth': 'depth'}, {'rgb': 3, 'depth': 1}
+    rng = np.random.default_rng(1)
+    data = {'rgb': rng.integers(0, 256, (2, H, W, 3)).astype(np.float32),
+            'depth': rng.integers(0, 65536, (2, H, W, 1)).astype(np.float32),
+            'labels': rng.integers(-1, C, (2, H, W)).astype(np.int32)}
+    w = fo.init_fusion_fcn_weights(prefixes, channels, U, C, seed=3, bias_scale=0.02)
+    w['rgb_conv1_1/kernel'] *= 0.02
+    w['depth_conv1_1/kernel'] *= 2e-4
+    for k in w:
+        if k.endswith('/kernel') and 'upscore' not in k and 'conv1_1' not in k:
+            w[k] *= 1.6
+    path = str(tmp_path / 'joint20.npz')
+    np.savez(path, **w)
+    net = get_model('fusion_fcn')(prefixes, channels, U, C, trainer='adam', learning_rate=1e-4, batchsize=2)
+    net.import_weights(path, warnings=False)
+    tr = net._ensure_trainer()
+    loss = tr.step({m: _dev(data[m]) for m in prefixes}, _dev(data['labels']))
+    torch.cuda.synchronize()
+    ref_loss, ref_g, _ = fo.fusion_fcn_loss_and_grads({m: data[m] for m in prefixes}, data['labels'], w, prefixes, C,
+                                                      policy='bf16')
+    assert abs(loss.item() - ref_loss) < 1e-2 * abs(ref_loss)
+    got = tr.grads_as_variables()
+    assert {k: v.shape for k, v in got.items()} == {k: v.shape for k, v in ref_g.items()}
+    for k in ('fused/score/gamma', 'fused/score/kernel', 'fused_score_conv5/kernel'):
+        assert _rel(got[k], ref_g[k]) < 0.25, (k, _rel(got[k], ref_g[k]))
+    out = {}
+    tr.to_variables(out)
+    assert all(out[k].shape == w[k].shape for k in out)
+    assert net.predict(data).shape == (2, H, W)
