@@ -560,8 +560,10 @@ extern "C" int xv_conv2d_first_bwd_filter(const float* x, int n, int h, int w, i
   XV_CHECK_SHAPE(n > 0 && h > 0 && w > 0 && cin >= 1 && cin <= 4 && dy->n == n && dy->h == h && dy->w == w && dy->c == 64);
   XV_CHECK_SHAPE((int64_t)n * h * w < 0x7fff0000);
   const int64_t npix = (int64_t)n * h * w;
-  const int chunks = 32;
-  const unsigned grid = (unsigned)((npix + 128 * chunks - 1) / (128 * chunks));
+  // at most 512 workgroups: each ends with 9*cin*64 same-address global atomics (see xv_score_dense_bwd)
+  int chunks = (int)((npix + 128 * 512 - 1) / (128 * 512));
+  if (chunks < 32) chunks = 32;
+  const unsigned grid = (unsigned)((npix + 128 * (int64_t)chunks - 1) / (128 * (int64_t)chunks));
   hipStream_t s = (hipStream_t)stream;
   const __bf16* g = (const __bf16*)dy->data;
   switch (cin) {

@@ -440,35 +440,37 @@ __global__ __launch_bounds__(256) void softmax_ce_dense_kernel(const float* __re
   if (threadIdx.x == 0) atomicAdd(loss, red[0]);
 }
 
-// dws[u][c] += sum_pix u[pix][u] * ds[pix][c]; dbs[c] += sum_pix ds[pix][c].  Thread (uu = t % 64, g = t / 64) owns
-// channels uu, uu+64, .. and classes g, g+4, ..; a block walks a contiguous run of pixels in tiles of 64 that are
-// staged through LDS (coalesced 16-byte loads; the inner loop then reads LDS only).
+// dws[u][c] += sum_pix u[pix][u] * ds[pix][c]; dbs[c] += sum_pix ds[pix][c].  A block walks a contiguous run of pixels
+// in tiles of 256 staged through LDS (coalesced 16-byte loads).  Thread (uu = t % 64, q = t / 64) owns channel uu for
+// ALL classes and every fourth pixel of a tile: per pixel one 2-byte column read and CM/4 broadcast 16-byte reads feed
+// CM FMAs.  (With the classes split over the four waves instead, every wave walked every pixel and the LDS pipe saw
+// 4x the instructions: 503 us for 8 images against 0.4 GB of operands.)  The four partial sums meet in LDS before the
+// global atomics.
 template <int CM>
 __global__ __launch_bounds__(256) void score_dense_wgrad_kernel(const __bf16* __restrict__ u, const float* __restrict__ ds,
                                                                float* __restrict__ dws, float* __restrict__ dbs, int N,
                                                                int H, int W, int U, int C, int64_t per_block) {
-  constexpr int TP = 64;  // pixels per tile
-  constexpr int KC = CM / 4;
+  constexpr int TP = 256;
   __shared__ __attribute__((aligned(16))) __bf16 ut[TP][64 + 8];  // +8: rows 144 B apart, conflict-free column reads
-  __shared__ float dt[TP][CM];
-  const int uu = threadIdx.x & 63, g = threadIdx.x >> 6;
+  __shared__ __attribute__((aligned(16))) float dt[TP][CM];
+  __shared__ float part[3][64][CM + 1];
+  const int uu = threadIdx.x & 63, q = threadIdx.x >> 6;
   const int64_t npix = (int64_t)N * H * W;
   const int64_t p0 = (int64_t)blockIdx.x * per_block, p1 = p0 + per_block < npix ? p0 + per_block : npix;
   for (int ub = 0; ub < U; ub += 64) {
-    float acc[KC], bacc[KC];
+    float acc[CM], bacc[CM];
 #pragma unroll
-    for (int k = 0; k < KC; ++k) acc[k] = bacc[k] = 0.f;
+    for (int k = 0; k < CM; ++k) acc[k] = bacc[k] = 0.f;
     for (int64_t t0 = p0; t0 < p1; t0 += TP) {
       __syncthreads();
-      // stage: 64 pixels x 64 channels (8 x 16-byte pieces per pixel) and 64 x C gradients
       for (int i = threadIdx.x; i < TP * 8; i += 256) {
         const int pp = i >> 3, piece = i & 7;
         const int64_t p = t0 + pp;
         u32x4 v = u32x4{0u, 0u, 0u, 0u};
         if (p < p1) {
-          const int x = (int)(p % W);
-          const int64_t r = p / W;
-          const int yy = (int)(r % H), n = (int)(r / H);
+          const int p32 = (int)p;  // npix < 2^31 (checked by the launcher)
+          const int row = p32 / W;
+          const int x = p32 - row * W, n = row / H, yy = row - n * H;
           v = *reinterpret_cast<const u32x4*>(u + (((int64_t)n * (H + 2) + yy + 1) * (W + 2) + x + 1) * U + ub + piece * 8);
         }
         *reinterpret_cast<u32x4*>(&ut[pp][piece * 8]) = v;
@@ -479,23 +481,41 @@ __global__ __launch_bounds__(256) void score_dense_wgrad_kernel(const __bf16* __
         dt[pp][c] = (p < p1 && c < C) ? ds[p * C + c] : 0.f;
       }
       __syncthreads();
-#pragma unroll 8
-      for (int pp = 0; pp < TP; ++pp) {
+#pragma unroll 4
+      for (int pp = q; pp < TP; pp += 4) {
         const float f = (float)ut[pp][uu];
 #pragma unroll
-        for (int k = 0; k < KC; ++k) {
-          const float d = dt[pp][g + 4 * k];
-          acc[k] = fmaf(f, d, acc[k]);
-          bacc[k] += d;
+        for (int k4 = 0; k4 < CM; k4 += 4) {
+          const f32x4 d = *reinterpret_cast<const f32x4*>(&dt[pp][k4]);  // wave-uniform address: broadcast
+          acc[k4] = fmaf(f, d.x, acc[k4]);
+          acc[k4 + 1] = fmaf(f, d.y, acc[k4 + 1]);
+          acc[k4 + 2] = fmaf(f, d.z, acc[k4 + 2]);
+          acc[k4 + 3] = fmaf(f, d.w, acc[k4 + 3]);
+          bacc[k4] += d.x;
+          bacc[k4 + 1] += d.y;
+          bacc[k4 + 2] += d.z;
+          bacc[k4 + 3] += d.w;
         }
       }
     }
+    __syncthreads();
+    if (q > 0) {
 #pragma unroll
-    for (int k = 0; k < KC; ++k) {
-      const int c = g + 4 * k;
-      if (c < C) {
-        atomicAdd(dws + (ub + uu) * C + c, acc[k]);
-        if (ub == 0 && uu == 0) atomicAdd(dbs + c, bacc[k]);
+      for (int k = 0; k < CM; ++k) part[q - 1][uu][k] = acc[k];
+      if (uu == 0) {
+#pragma unroll
+        for (int k = 0; k < CM; ++k) dt[q][k] = bacc[k];  // dt is free now: rows 1..3 carry the bias sums
+      }
+    }
+    __syncthreads();
+    if (q == 0) {
+#pragma unroll
+      for (int k = 0; k < CM; ++k) {
+        if (k < C) {
+          const float a = acc[k] + part[0][uu][k] + part[1][uu][k] + part[2][uu][k];
+          atomicAdd(dws + (ub + uu) * C + k, a);
+          if (ub == 0 && uu == 0) atomicAdd(dbs + k, bacc[k] + dt[1][k] + dt[2][k] + dt[3][k]);
+        }
       }
     }
   }
@@ -742,7 +762,11 @@ extern "C" int xv_score_dense_bwd(const xv_act* u, const float* dscore, const fl
   XV_CHECK_ARG(u && u->data && dscore && w_score && dw_score && db_score && du && du->data);
   XV_CHECK_SHAPE((u->c & 63) == 0 && u->c <= 256 && num_classes >= 1 && num_classes <= 32 && same_shape(u, du));
   const int64_t npix = (int64_t)u->n * u->h * u->w;
-  const int64_t per_block = 2048;
+  // at most 512 workgroups: each ends with U*C same-address global atomics, which cross the XCDs' L2s and serialise
+  // (1152 workgroups spent most of this kernel's 0.5 ms there)
+  int64_t per_block = (npix + 511) / 512;
+  per_block = (per_block + 255) / 256 * 256;
+  if (per_block < 2048) per_block = 2048;
   const unsigned gw = (unsigned)((npix + per_block - 1) / per_block);
   XV_CHECK_SHAPE(npix < 0x7fff0000);
   const size_t lds = (size_t)SD_TILE * (u->c + 8) * 2;
