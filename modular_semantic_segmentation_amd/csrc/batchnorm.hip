@@ -226,20 +226,37 @@ __global__ __launch_bounds__(256) void bn_dense_reduce_kernel(const float* __res
   float s0[32], s1[32];
 #pragma unroll
   for (int c = 0; c < 32; ++c) s0[c] = s1[c] = 0.f;
-  for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < M; p += (int64_t)gridDim.x * 256) {
+  auto accumulate = [&](int c, float v, float g) {
+    if (MODE == 0) {
+      s0[c] += v;
+      s1[c] += v * v;
+    } else {
+      s0[c] += g;
+      s1[c] += g * (v - mean[c]) * invstd[c];
+    }
+  };
+  if ((C & 3) == 0) {
+    // rows of C floats are 16-byte multiples: a lane reads its row as C/4 vector loads, the wave a dense span (with
+    // scalar loads every instruction touched 24 cache lines for 256 bytes and the kernel ran at 1 TB/s)
+    for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < M; p += (int64_t)gridDim.x * 256) {
 #pragma unroll
-    for (int c = 0; c < 32; ++c)
-      if (c < C) {
-        const float v = z[p * C + c];
-        if (MODE == 0) {
-          s0[c] += v;
-          s1[c] += v * v;
-        } else {
-          const float g = dy[p * C + c];
-          s0[c] += g;
-          s1[c] += g * (v - mean[c]) * invstd[c];
+      for (int c4 = 0; c4 < 8; ++c4)
+        if (c4 * 4 < C) {
+          const f32x4 v = *reinterpret_cast<const f32x4*>(z + p * C + c4 * 4);
+          f32x4 g = f32x4{0.f, 0.f, 0.f, 0.f};
+          if (MODE == 1) g = *reinterpret_cast<const f32x4*>(dy + p * C + c4 * 4);
+          accumulate(c4 * 4, v.x, g.x);
+          accumulate(c4 * 4 + 1, v.y, g.y);
+          accumulate(c4 * 4 + 2, v.z, g.z);
+          accumulate(c4 * 4 + 3, v.w, g.w);
         }
-      }
+    }
+  } else {
+    for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < M; p += (int64_t)gridDim.x * 256) {
+#pragma unroll
+      for (int c = 0; c < 32; ++c)
+        if (c < C) accumulate(c, z[p * C + c], MODE == 1 ? dy[p * C + c] : 0.f);
+    }
   }
 #pragma unroll
   for (int c = 0; c < 32; ++c)
@@ -646,7 +663,7 @@ extern "C" int xv_bn_dense_stats(const float* z, int64_t rows, int channels, dou
   XV_CHECK_SHAPE(rows > 0 && channels >= 1 && channels <= 32);
   hipError_t e = hipMemsetAsync(sums, 0, sizeof(double) * 2 * channels, (hipStream_t)stream);
   if (e != hipSuccess) return (int)e;
-  hipLaunchKernelGGL(bn_dense_reduce_kernel<0>, dim3(bn_grid(rows, 1024)), dim3(256), 0, (hipStream_t)stream, z, nullptr,
+  hipLaunchKernelGGL(bn_dense_reduce_kernel<0>, dim3(bn_grid(rows, 512)), dim3(256), 0, (hipStream_t)stream, z, nullptr,
                      nullptr, nullptr, sums, rows, channels);
   return xv_launch_status();
 }
@@ -667,7 +684,7 @@ extern "C" int xv_bn_dense_bwd_reduce(const float* dy, const float* z, int64_t r
   hipStream_t s = (hipStream_t)stream;
   hipError_t e = hipMemsetAsync(sums, 0, sizeof(double) * 2 * channels, s);
   if (e != hipSuccess) return (int)e;
-  hipLaunchKernelGGL(bn_dense_reduce_kernel<1>, dim3(bn_grid(rows, 1024)), dim3(256), 0, s, z, dy, mean, invstd, sums,
+  hipLaunchKernelGGL(bn_dense_reduce_kernel<1>, dim3(bn_grid(rows, 512)), dim3(256), 0, s, z, dy, mean, invstd, sums,
                      rows, channels);
   hipLaunchKernelGGL(bn_grads_kernel, dim3(1), dim3(64), 0, s, sums, channels, dgamma, dbeta);
   return xv_launch_status();
