@@ -34,6 +34,25 @@ for (n, h, w, cin, cout, pool) in [(16, 48, 96, 512, 512, False), (16, 96, 192, 
     torch.cuda.synchronize()
     print('conv', (n, h, w, cin, cout, pool), 'done')
 
+# 1x1 convs: the flat-GEMM kernel (double-buffered LDS-DMA, interior-predicated stores) and the 128-channel tile
+for (n, h, w, cin, cout) in [(16, 24, 48, 4608, 256), (8, 24, 48, 1024, 2048), (5, 17, 23, 256, 128), (4, 48, 96, 128, 512)]:
+    x = ops.Act(n, h, w, cin)
+    x.interior().normal_()
+    wp = ops.pack_conv_weights(torch.randn(1, 1, cin, cout, device='cuda') * cin ** -0.5)
+    b = torch.randn(cout, device='cuda')
+    res = ops.Act(n, h, w, cout)
+    res.interior().normal_()
+    ref_y = None
+    for it in range(int(os.environ.get("XV_STRESS_ITERS", "150"))):
+        y = ops.conv1x1_residual(x, wp, b, res, relu=True, y=ops.Act(n, h, w, cout))
+        if ref_y is None:
+            ref_y = y.t.clone()
+        elif not torch.equal(y.t, ref_y):
+            bad += 1
+            print('MISMATCH conv1x1', (n, h, w, cin, cout), 'iter', it)
+    torch.cuda.synchronize()
+    print('conv1x1', (n, h, w, cin, cout), 'done')
+
 g = np.load(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests', 'golden', 'notebook_868.npz'))
 desc = ({'rgb': 'float32', 'depth': 'float32', 'labels': 'int32'},
         {'rgb': (None, None, 3), 'depth': (None, None, 1), 'labels': (None, None)}, 12)
