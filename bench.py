@@ -331,7 +331,11 @@ def main():
         # HBM bytes per conv launch from the committed rocprofv3 FETCH_SIZE / WRITE_SIZE passes of this
         # same command (tools/pmc_summary.py); PMC counters cannot be read from inside the process
         tj = json.load(open(os.path.join(ROOT, 'profiles', tfiles[-1])))
-        if tj.get('batch') == args.batch:
+        import hashlib
+        src = os.path.join(ROOT, 'modular_semantic_segmentation_amd', 'csrc', 'conv_mfma.hip')
+        sha = hashlib.sha256(open(src, 'rb').read()).hexdigest()[:16]
+        # the counters were collected on ONE version of the kernel: a summary of another version is not reported
+        if tj.get('batch') == args.batch and tj.get('kernel_source_sha256_16') == sha:
             traffic = tj.get('hbm_bytes_per_launch')
     if dom in kinds and kinds[dom][1] > 0:
         fl, sec, cnt = kinds[dom]

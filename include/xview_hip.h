@@ -42,6 +42,9 @@ typedef struct xv_act {
 int xv_version(void);
 /* Name of the gfx target the device code was compiled for ("gfx950"). */
 const char* xv_arch(void);
+/* First 16 hex digits of the sha256 over the sources this binary was compiled from (csrc/Makefile SRC_HASH);
+ * the Python loader compares it with the sources next to it and refuses a stale library. */
+const char* xv_source_hash(void);
 
 /* ---- weight packing ------------------------------------------------------------------------
  * Conv kernels arrive in the reference npz schema: float32 HWIO [k][k][cin][cout]

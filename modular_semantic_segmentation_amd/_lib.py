@@ -29,6 +29,7 @@ _vpp = ctypes.POINTER(ctypes.c_void_p)
 SIGNATURES = {
     'xv_version': (_i, []),
     'xv_arch': (ctypes.c_char_p, []),
+    'xv_source_hash': (ctypes.c_char_p, []),
     'xv_packed_weight_bytes': (ctypes.c_size_t, [_i, _i, _i]),
     'xv_pack_conv_weights': (_i, [_vp, _vp, _i, _i, _i, _vp]),
     'xv_pack_conv_weights_pair': (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
@@ -99,18 +100,39 @@ SIGNATURES = {
 _lib = None
 
 
+def source_hash():
+    """sha256 (first 16 hex digits) over the library's sources, as csrc/Makefile computes SRC_HASH."""
+    import hashlib
+    import re
+    mk = open(os.path.join(CSRC, 'Makefile')).read()
+    srcs = re.search(r'^SRCS := (.*)$', mk, re.M).group(1).split()
+    h = hashlib.sha256()
+    for rel in srcs + ['xv_common.h', '../../include/xview_hip.h', 'Makefile']:
+        with open(os.path.join(CSRC, rel), 'rb') as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
 def build(force=False):
-    """Compile csrc/*.hip for gfx950 into libxview_hip.so (hipcc cross-compiles without a GPU)."""
-    if force and os.path.exists(LIB_PATH):
-        os.remove(LIB_PATH)
+    """Compile csrc/*.hip for gfx950 into libxview_hip.so (hipcc cross-compiles without a GPU).
+    force=True (or XV_FORCE_REBUILD=1) recompiles every object from scratch; otherwise `make` rebuilds what
+    changed.  Either way the result must carry the hash of the sources it sits next to."""
+    if force or os.environ.get('XV_FORCE_REBUILD') == '1':
+        subprocess.run(['make', '-C', CSRC, 'clean'], check=True, stdout=subprocess.DEVNULL)
     subprocess.run(['make', '-C', CSRC, '-j4'], check=True, stdout=subprocess.DEVNULL)
     if not os.path.exists(LIB_PATH):
         raise XvError('build did not produce ' + LIB_PATH)
+    global _lib
+    _lib = None
+    got = lib().xv_source_hash().decode()
+    if got != source_hash():
+        raise XvError('built library is stamped %s but the sources hash to %s' % (got, source_hash()))
     return LIB_PATH
 
 
 def lib():
-    """Load (once) and return the ctypes handle; raises XvError if the library is absent."""
+    """Load (once) and return the ctypes handle; raises XvError if the library is absent or was built from
+    other sources than the ones next to it (when those are present: they always are in this repository)."""
     global _lib
     if _lib is None:
         if not os.path.exists(LIB_PATH):
@@ -121,6 +143,11 @@ def lib():
             fn = getattr(handle, name)      # AttributeError if the export is missing
             fn.restype = res
             fn.argtypes = args
+        if os.path.exists(os.path.join(CSRC, 'Makefile')) and os.environ.get('XV_ALLOW_STALE_LIB') != '1':
+            got = handle.xv_source_hash().decode()
+            if got != source_hash():
+                raise XvError('%s was built from other sources (stamp %s, sources %s): rebuild with '
+                              '`python -c "import __graft_entry__ as g; g.build()"`' % (LIB_PATH, got, source_hash()))
         _lib = handle
     return _lib
 

@@ -310,18 +310,23 @@ class Adapnet(BaseModel):
         self.prediction = 'label'
 
     def _variables_changed(self):
+        BaseModel._variables_changed(self)
         self.engine.load(self.variables)
         if getattr(self, 'trainer', None) is not None:
+            from .parallel import sync_trainer_from_rank0
             self.trainer.load_from_variables(self.variables)
+            sync_trainer_from_rank0(self.trainer)
 
     # ---- training (adapnet.py:190-203, optimizer setup base_model.py:153-162) ---------------------------------------
     def _ensure_trainer(self):
         if getattr(self, 'trainer', None) is None:
             from .adapnet_trainer import AdapnetTrainer
-            from .parallel import GradReducer, world
+            from .parallel import GradReducer, require_equal_batchsize, sync_trainer_from_rank0, world
             self.trainer = AdapnetTrainer(self.engine, self.config.get('trainer', 'adam'),
                                           self.config.get('learning_rate', 0.0001))
             self.trainer.load_from_variables(self.variables)
+            sync_trainer_from_rank0(self.trainer)        # every replica starts from rank 0's initialisers
+            require_equal_batchsize(self.config['batchsize'], self.device)
             self._reducer = GradReducer(self.device) if world()[1] > 1 else None
         return self.trainer
 
@@ -329,6 +334,9 @@ class Adapnet(BaseModel):
         tr = self._ensure_trainer()
         x = self._to_device(batch[self.modality], torch.float32)
         labels = self._to_device(batch['labels'], torch.int32)
+        self._graph = None          # a captured inference graph holds the pre-update weight pointers
+        if self._reducer is not None and len(labels) != self.config['batchsize']:
+            raise ValueError('data-parallel step with %d images, batchsize is %d' % (len(labels), self.config['batchsize']))
         self.loss = tr.step(x, labels, reducer=self._reducer)
         self._dirty = True
         return self.loss.item() if self.config.get('sync_loss', True) else 0.0

@@ -103,6 +103,7 @@ class BaseModel(object):
         raise UserWarning('ERROR: Model %s does not support training' % self.name)
 
     def _initialize_graph(self):
+        self._graph = None           # a captured hipGraph replays the old tables / weight pointers
         self._build_graph()
         if not self.custom_training:
             missing = [attrs for attrs in self.required_attributes
@@ -182,8 +183,12 @@ class BaseModel(object):
                         i, float(loss), score['total_accuracy'], score['mean_IoU']))
                 for key, extra in additional_eval_datasets.items():
                     self.score(extra)
-                if 'abort_at_iou' in self.config and score['mean_IoU'] > self.config['abort_at_iou']:
-                    break
+                if 'abort_at_iou' in self.config:
+                    # collective decision: a rank that stopped alone would leave the others waiting in the next
+                    # gradient all-reduce
+                    from .parallel import agree_any
+                    if agree_any(score['mean_IoU'] > self.config['abort_at_iou'], self.device):
+                        break
         if output:
             print('INFO: Training finished.')
 
@@ -211,7 +216,10 @@ class BaseModel(object):
 
     # ---- weights ----------------------------------------------------------------------------------------
     def _variables_changed(self):
-        """Called after self.variables was modified; subclasses re-upload to the GPU."""
+        """Called after self.variables was modified; subclasses re-upload to the GPU.  The engines allocate
+        new weight tensors when they load, so a captured hipGraph (which replays the old pointers) is dropped;
+        `capture_graph` must be called again."""
+        self._graph = None
 
     def export_weights(self, save_dir=None):
         """npz of every variable keyed by its TF op name, `{name}_weights_{step}.npz`
@@ -229,8 +237,9 @@ class BaseModel(object):
 
     def import_weights(self, filepath, translate_prefix=False, chill_mode=False, warnings=True):
         """Assign variables from an npz by name (base_model.py:396-451): optional prefix translation,
-        legacy `prefix_layer/...` names, optimizer slots skipped, `chill_mode` ignores shape
-        mismatches (leaves the variable unassigned)."""
+        legacy `prefix_layer/...` names, optimizer slots skipped; a variable stored with another
+        shape is reported and skipped (with `chill_mode` the assign is attempted and fails, as in the
+        reference); `global_step` is restored for trainable models."""
         if warnings:
             print(filepath)
         weights = np.load(filepath)
@@ -258,17 +267,23 @@ class BaseModel(object):
                     name = legacy
                 value = weights[name]
                 if tuple(value.shape) != tuple(self.variables[var_name].shape):
+                    # base_model.py:438-445, literally: the warning is printed, then OUTSIDE chill mode the variable
+                    # is skipped (keeps its value) while IN chill mode the assign is attempted anyway -- which
+                    # tf.assign rejects for a different static shape with a ValueError
                     if warnings:
                         print('WARNING: wrong shape found for {}, but ignored in chill mode'.format(name))
                         print('stored shape: ', value.shape, 'expected shape: ', self.variables[var_name].shape)
                     if not chill_mode:
-                        raise ValueError('shape mismatch for %s' % name)
-                else:
-                    self.variables[var_name] = np.asarray(value, self.variables[var_name].dtype)
+                        continue
+                    raise ValueError('Shapes %s and %s are incompatible (%s)' % (
+                        tuple(self.variables[var_name].shape), tuple(value.shape), name))
+                self.variables[var_name] = np.asarray(value, self.variables[var_name].dtype)
             elif warnings:
                 print('WARNING: {} not found in saved weights'.format(name))
-        if 'global_step' in weights and 'global_step' in self.__dict__:
-            pass
+        # global_step is a tf.global_variable of every trainable model (base_model.py:153-156), so the loop above
+        # restores it in the reference; fusion models (custom_training) have none
+        if not self.custom_training and 'global_step' in weights:
+            self.global_step = int(weights['global_step'])
         self._variables_changed()
 
     def load_weights(self, filepath):

@@ -80,6 +80,7 @@ class FusionModel(BaseModel):
         return int(self.testdata_description[1][m][-1])
 
     def _variables_changed(self):
+        BaseModel._variables_changed(self)
         for m in self.modalities:
             self.experts[m].load(self.variables)
 

@@ -97,6 +97,7 @@ class DirichletFusion(BaseModel):
             self.prediction = 0      # dirichlet_mix.py:165-168: no fusion possible before fit()
 
     def _variables_changed(self):
+        BaseModel._variables_changed(self)
         for m in self.modalities:
             self.experts[m].load(self.variables)
 

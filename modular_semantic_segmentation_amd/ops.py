@@ -451,8 +451,10 @@ class BnState(object):
 
 
 def _sync_sums(st, sync):
-    """Sync-BN: sum the per-channel statistics over the data-parallel ranks (equal shards assumed); returns the factor
-    by which the local sample count grows."""
+    """Sync-BN: sum the per-channel statistics over the data-parallel ranks; returns the factor by which the local
+    sample count grows.  Every rank holds the same number of images per step: the models check that the ranks agree on
+    `batchsize` when the trainer is created and that every data-parallel step has exactly that many images
+    (parallel.require_equal_batchsize)."""
     if not sync:
         return 1
     from .parallel import allreduce_sum_, world

@@ -38,6 +38,67 @@ def allreduce_sum_(*tensors):
     return tensors
 
 
+def broadcast_(*tensors, src=0):
+    """In-place broadcast from rank `src` (no-op for a single process)."""
+    _, size = world()
+    if size > 1:
+        for t in tensors:
+            dist.broadcast(t, src=src)
+    return tensors
+
+
+def require_equal_batchsize(batchsize, device):
+    """Sync-BN sums per-rank moments and divides by local count x world size (ops._sync_sums), and the gradient
+    all-reduce weights every rank's images equally: both need the SAME number of images per rank and step.  `fit`
+    always feeds exactly config['batchsize'] samples per step, so it is enough that the ranks agree on it."""
+    _, size = world()
+    if size == 1:
+        return
+    t = torch.tensor([int(batchsize), -int(batchsize)], dtype=torch.int64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    if int(t[0]) != -int(t[1]):
+        raise ValueError('data-parallel training needs the same batchsize on every rank (got %d .. %d)'
+                         % (-int(t[1]), int(t[0])))
+
+
+def sync_trainer_from_rank0(trainer):
+    """Data-parallel replicas must start from ONE set of parameters: the reference trains a single graph
+    (base_model.py:153-162), so N ranks reproduce it only if rank 0's master weights, batch-norm moving
+    statistics and optimizer slots are everybody's.  Called when a trainer is created and after every
+    `load_from_variables` (random initialisers are drawn per process, imported files may differ per rank)."""
+    _, size = world()
+    if size == 1:
+        return
+    broadcast_(trainer.param)
+    for mm, mv in getattr(trainer, 'moving', {}).values():
+        broadcast_(mm, mv)
+    # optimizer slots exist on a rank only once it has stepped: agree on who has them before broadcasting
+    has = torch.tensor([1 if trainer.state else 0, int(getattr(trainer, 't', 0))], dtype=torch.int64,
+                       device=trainer.param.device)
+    broadcast_(has)
+    if int(has[0]):
+        if not trainer.state:
+            from .trainer import init_optimizer_state
+            init_optimizer_state(trainer)
+        for key in sorted(trainer.state):
+            broadcast_(trainer.state[key])
+    else:
+        trainer.state = {}
+    trainer.t = int(has[1])
+    trainer.repack()
+
+
+def agree_any(flag, device):
+    """True on every rank if `flag` is true on any rank (early-abort decisions must be collective, otherwise the
+    ranks that keep training hang in the next gradient all-reduce)."""
+    _, size = world()
+    if size == 1:
+        return bool(flag)
+    t = torch.tensor([1 if flag else 0], dtype=torch.int64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return bool(int(t.item()))
+
+
 class GradReducer(object):
     """Bucketed gradient all-reduce on a side HIP stream, overlapped with the rest of backward.
 

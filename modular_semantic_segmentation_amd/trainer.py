@@ -60,6 +60,16 @@ def encoder_backward(x, L, g, ds4, wd_s4, wd, zero_bias, G, gact, wws, after_lay
             g = ops.conv2d_bwd_data(g, wd[nm], zero_bias, gact(L[xin], 'g_' + xin), 3, relu_ref=L[xin])
 
 
+def init_optimizer_state(tr):
+    """[TF1] slot initial values: Adam m = v = 0; RMSProp ms = 1 (momentum 0); Adagrad accumulator = 0.1."""
+    if tr.kind == 'adam':
+        tr.state = {'m': torch.zeros_like(tr.param), 'v': torch.zeros_like(tr.param)}
+    elif tr.kind == 'rmsprop':
+        tr.state = {'ms': torch.ones_like(tr.param)}
+    else:
+        tr.state = {'acc': torch.full_like(tr.param, 0.1)}
+
+
 class FcnTrainer(object):
     def __init__(self, engine, trainer='adam', learning_rate=1e-4):
         self.e = engine
@@ -228,19 +238,15 @@ class FcnTrainer(object):
         return self.loss
 
     def _apply(self, scale):
+        if not self.state:
+            init_optimizer_state(self)
         if self.kind == 'adam':
-            if not self.state:
-                self.state = {'m': torch.zeros_like(self.param), 'v': torch.zeros_like(self.param)}
             b1, b2 = 0.9, 0.999
             lr_t = self.lr * np.sqrt(1 - b2 ** self.t) / (1 - b1 ** self.t)
             ops.adam_step(self.param, self.grad, self.state['m'], self.state['v'], float(lr_t), b1, b2, 1e-8, scale)
         elif self.kind == 'rmsprop':
-            if not self.state:
-                self.state = {'ms': torch.ones_like(self.param)}
             ops.rmsprop_step(self.param, self.grad, self.state['ms'], self.lr, 0.9, 1e-10, scale)
         else:
-            if not self.state:
-                self.state = {'acc': torch.full_like(self.param, 0.1)}
             ops.adagrad_step(self.param, self.grad, self.state['acc'], self.lr, scale)
 
     def grads_as_variables(self):

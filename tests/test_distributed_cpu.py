@@ -92,3 +92,62 @@ def test_bucketed_gradient_allreduce(tmp_path):
     ref = sum(np.random.default_rng(100 + r).standard_normal(1000).astype(np.float32) for r in range(2))
     np.testing.assert_allclose(got['flat'], ref, rtol=1e-6)
     assert got['count'][0] == 21
+
+
+class _StubTrainer(object):
+    """The attributes parallel.sync_trainer_from_rank0 touches (trainer.FcnTrainer and friends have the same)."""
+
+    def __init__(self, seed, stepped):
+        rng = np.random.default_rng(seed)
+        self.kind = 'adam'
+        self.param = torch.from_numpy(rng.standard_normal(257).astype(np.float32))
+        self.moving = {'conv1_1': (torch.from_numpy(rng.standard_normal(8).astype(np.float32)),
+                                   torch.from_numpy(rng.random(8).astype(np.float32)))}
+        self.state, self.t, self.repacked = {}, 0, 0
+        if stepped:
+            self.state = {'m': torch.from_numpy(rng.standard_normal(257).astype(np.float32)),
+                          'v': torch.from_numpy(rng.random(257).astype(np.float32))}
+            self.t = 3
+
+    def repack(self):
+        self.repacked += 1
+
+
+def _sync_worker(rank, size, port, out):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=size)
+    from modular_semantic_segmentation_amd import parallel
+    # every rank draws its own initialisers (seed=None in the models); rank 0 alone has optimizer slots (a resumed run)
+    tr = _StubTrainer(seed=10 + rank, stepped=(rank == 0))
+    parallel.sync_trainer_from_rank0(tr)
+    fresh = _StubTrainer(seed=20 + rank, stepped=False)
+    parallel.sync_trainer_from_rank0(fresh)
+    stop = parallel.agree_any(rank == 1, 'cpu')              # only rank 1 crossed abort_at_iou
+    go_on = parallel.agree_any(False, 'cpu')
+    parallel.require_equal_batchsize(4, 'cpu')
+    try:
+        parallel.require_equal_batchsize(4 + rank, 'cpu')
+        unequal = False
+    except ValueError:
+        unequal = True
+    np.savez(out % rank, param=tr.param.numpy(), mm=tr.moving['conv1_1'][0].numpy(), mv=tr.moving['conv1_1'][1].numpy(),
+             m=tr.state['m'].numpy(), v=tr.state['v'].numpy(), t=tr.t, repacked=tr.repacked,
+             fresh=fresh.param.numpy(), fresh_state=len(fresh.state), stop=stop, go_on=go_on, unequal=unequal)
+    dist.destroy_process_group()
+
+
+def test_replicas_start_from_rank0_parameters(tmp_path):
+    """without a broadcast every rank trains its own Glorot draw and the replicas diverge."""
+    out = str(tmp_path / 's%d.npz')
+    mp.spawn(_sync_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    r0, r1 = np.load(out % 0), np.load(out % 1)
+    src = _StubTrainer(seed=10, stepped=True)
+    for key, ref in (('param', src.param), ('mm', src.moving['conv1_1'][0]), ('mv', src.moving['conv1_1'][1]),
+                     ('m', src.state['m']), ('v', src.state['v'])):
+        assert np.array_equal(r0[key], ref.numpy()) and np.array_equal(r1[key], ref.numpy()), key
+    assert int(r0['t']) == int(r1['t']) == 3 and int(r1['repacked']) == 1
+    assert np.array_equal(r1['fresh'], _StubTrainer(seed=20, stepped=False).param.numpy())
+    assert int(r0['fresh_state']) == int(r1['fresh_state']) == 0
+    assert bool(r0['stop']) and bool(r1['stop']) and not bool(r0['go_on']) and not bool(r1['go_on'])
+    assert bool(r0['unequal']) and bool(r1['unequal'])

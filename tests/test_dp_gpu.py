@@ -210,3 +210,58 @@ def test_two_rank_adapnet_training(tmp_path):
             assert np.abs(upd_a - upd_ref).max() < 0.05 * np.abs(upd_ref).max() + 2e-3, name
     for name in ('rgb/second_deconvolution_upconv/gamma', 'rgb/shortcut/kernel'):
         np.testing.assert_allclose(got[name.replace('/', '__')], net.variables[name], rtol=0, atol=4e-4, err_msg=name)
+
+
+def _unseeded_worker(rank, size, port, out, backend='gloo'):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dev = rank if backend == 'nccl' else 0
+    torch.cuda.set_device(dev)
+    if backend == 'nccl':
+        dist.init_process_group('nccl', rank=rank, world_size=size, device_id=torch.device('cuda', dev))
+    else:
+        dist.init_process_group('gloo', rank=rank, world_size=size)
+    from modular_semantic_segmentation_amd import get_model, parallel
+    desc = ({'rgb': 'float32', 'labels': 'int32'}, {'rgb': (None, None, 3), 'labels': (None, None)}, C)
+    # a different initialiser draw on every rank (the models' default is seed=None): the trainer must start every
+    # replica from rank 0's parameters
+    net = get_model('fcn')('rgb', desc, 'rgb', num_units=U, batch_normalization=False, batchsize=1, learning_rate=1e-3,
+                           trainer='rmsprop', seed=5 + 7 * rank, device='cuda:%d' % dev)
+    net.variables['rgb/conv1_1/kernel'] = net.variables['rgb/conv1_1/kernel'] * 0.05
+    net._variables_changed()
+    shard = parallel.shard_data(_data())
+    for _ in range(2):
+        net._train_batch(shard)
+    net._sync_variables()
+    np.savez(out % rank, **{k.replace('/', '__'): v for k, v in net.variables.items()})
+    dist.destroy_process_group()
+
+
+def _check_unseeded(tmp_path, backend):
+    out = str(tmp_path / ('unseeded_%s_%%d.npz' % backend))
+    mp.spawn(_unseeded_worker, args=(2, _free_port(), out, backend), nprocs=2, join=True)
+    r0, r1 = np.load(out % 0), np.load(out % 1)
+    net = _make_net(2)                      # seed 5 = rank 0's draw, whole batch in one process
+    for _ in range(2):
+        net._train_batch(_data())
+    net._sync_variables()
+    for name, ref in net.variables.items():
+        key = name.replace('/', '__')
+        # identical replicas: same start, same all-reduced gradients (bitwise: every rank applies the same sums)
+        assert np.array_equal(r0[key], r1[key]), name
+        if name.endswith('/kernel') and 'upscore' not in name:
+            np.testing.assert_allclose(r0[key], ref, rtol=0, atol=5e-5, err_msg=name)
+
+
+def test_two_rank_replicas_start_from_rank0_parameters(tmp_path):
+    """ranks that draw different initialisers must still train ONE model."""
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU')
+    _check_unseeded(tmp_path, 'gloo')
+
+
+def test_two_rank_training_over_rccl(tmp_path):
+    """The same over the 'nccl' backend (= RCCL over xGMI), one rank per GPU; needs two GPUs."""
+    if not torch.cuda.is_available() or torch.cuda.device_count() < 2:
+        pytest.skip('needs 2 GPUs')
+    _check_unseeded(tmp_path, 'nccl')

@@ -5,8 +5,19 @@ FETCH_SIZE / WRITE_SIZE passes (separate --pmc passes; gfx950 correction: FETCH_
 the bytes of wide coalesced reads -> doubled, WRITE_SIZE exact; MI355X_MICROARCH.md 'HBM')."""
 import csv
 import glob
+import hashlib
 import json
+import os
 import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CONV_SRC = os.path.join(ROOT, 'modular_semantic_segmentation_amd', 'csrc', 'conv_mfma.hip')
+
+
+def kernel_source_hash():
+    """Ties a committed counter summary to the kernel source it was measured on: bench.py reports `traffic` only
+    while this still matches."""
+    return hashlib.sha256(open(CONV_SRC, 'rb').read()).hexdigest()[:16]
 
 
 def counter_avg(dirname, counter, match):
@@ -27,7 +38,7 @@ def main(tag, batch=16):
     write = counter_avg('pmc_write', 'WRITE_SIZE', is_conv3)
     out = {'kernel': 'conv_dma_kernel + conv_mfma_kernel (all 3x3 launches)', 'source': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, '
            'python3 bench.py --steps 3 --warmup 1 --serial-experts --no-graph (batch %d, 768x384)' % batch,
-           'batch': batch}
+           'batch': batch, 'kernel_source': 'csrc/conv_mfma.hip', 'kernel_source_sha256_16': kernel_source_hash()}
     if fetch and write:
         out.update(fetch_size_kb_per_launch=round(fetch[0], 1), write_size_kb_per_launch=round(write[0], 1),
                    launches=fetch[1],
