@@ -168,7 +168,17 @@ class BaseModel(object):
                     return
 
         def endless():
-            return iterate_batches(samples(), self.config['batchsize'])
+            if isinstance(dataset, dict):
+                # same sample order as chaining the epochs, without a per-sample round trip through numpy: index the
+                # arrays (numpy on the host or torch tensors already resident in HBM) with wrapped indices
+                n, bs, start = len(next(iter(dataset.values()))), self.config['batchsize'], 0
+                while n > 0:
+                    idx = (start + np.arange(bs)) % n
+                    start = (start + bs) % n
+                    yield {k: (v[torch.from_numpy(idx).to(v.device)] if isinstance(v, torch.Tensor) else
+                               np.asarray(v)[idx]) for k, v in dataset.items()}
+                return
+            return (yield from iterate_batches(samples(), self.config['batchsize']))
 
         if output:
             print('INFO: Start training')

@@ -1,0 +1,163 @@
+"""Accuracy evidence for BASELINE.json's north_star ("labels bit-exact / logits within a stated tolerance vs the
+reference's fp32 path; mIoU within 0.1 pp"): train both SimpleFCN experts with the MI355X `fit()` on the procedural
+RGB-D task (datasets/synthetic.py -- no real dataset is reachable), then run the SAME trained weights through
+
+  * the HIP path (bf16 storage, fp32 accumulation) and
+  * the fp32 oracle (oracle/fcn_oracle.py + fusion_oracle.py: the op-for-op restatement of the reference graph)
+
+on held-out 768x384 images, for each expert and for Bayes and Dirichlet fusion, and report mean IoU
+(base_model.py:315-329, the measure behind 'Synthia Rand Cityscapes Examples.ipynb':846-847) of both, their
+difference, the label agreement and the logit error.
+
+TEST INFRASTRUCTURE (imports oracle/): used by tests/test_accuracy_gpu.py and by bench.py's cpu_baseline leg, where
+the oracle pass over the held-out images is also the timed CPU sample."""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+C, U = 12, 64
+MODS = (('rgb', 3), ('depth', 1))
+
+
+def train_experts(h, w, steps, batch=8, n_train=48, seed=1, device='cuda', learning_rate=1e-4, log=None):
+    """Both experts from [TF1] initialisers with the reference's default optimizer (Adam, 1e-4; base_model.py:153-162)
+    through `SimpleFCN.fit`.  Returns (variables of both experts, training set)."""
+    from modular_semantic_segmentation_amd import get_model
+    from modular_semantic_segmentation_amd.datasets.synthetic import data_description, make_rgbd_shapes
+    train = make_rgbd_shapes(n_train, h, w, seed=seed)
+    desc = data_description()
+    variables = {}
+    for m, cin in MODS:
+        net = get_model('fcn')(m, desc, m, num_units=U, batch_normalization=False, batchsize=batch,
+                               learning_rate=learning_rate, trainer='adam', seed=seed + cin, device=str(device),
+                               sync_loss=False)
+        if m == 'depth':
+            # raw uint16 depth: the first layer of a trained expert absorbs the range; start it there
+            net.variables['depth/conv1_1/kernel'] = net.variables['depth/conv1_1/kernel'] / 256.0
+            net._variables_changed()
+        t0 = time.perf_counter()
+        data = {m: torch.from_numpy(train[m]).to(device), 'labels': torch.from_numpy(train['labels']).to(device)}
+        net.fit(data, steps, output=False)
+        net._sync_variables()
+        torch.cuda.synchronize()
+        if log is not None:
+            log('trained %s expert: %d steps of %d images at %dx%d in %.1f s, last loss %.4f'
+                % (m, steps, batch, w, h, time.perf_counter() - t0, float(net.loss.item())))
+        variables.update(net.variables)
+    return variables, train
+
+
+def _miou(labels, pred):
+    from modular_semantic_segmentation_amd.base_model import score_measures
+    lab = labels.reshape(-1).astype(np.int64)
+    ok = lab >= 0
+    cm = np.bincount(lab[ok] * C + pred.reshape(-1)[ok].astype(np.int64), minlength=C * C).reshape(C, C)
+    return float(score_measures(cm)['mean_IoU']), cm
+
+
+def hip_predictions(variables, measure, heldout, device='cuda'):
+    """HIP path: expert confusion matrices and the Dirichlet fit on `measure` (the flows of
+    experiments/bayes_fusion.py:146-195 and dirichlet_fusion.py:58-81), then every model's labels (and the experts'
+    logits) on `heldout`."""
+    from modular_semantic_segmentation_amd import get_model
+    from modular_semantic_segmentation_amd.datasets.synthetic import data_description
+    desc = data_description()
+    out, cms = {}, {}
+    for m, cin in MODS:
+        net = get_model('fcn')(m, desc, m, num_units=U, batch_normalization=False, batchsize=4, device=str(device))
+        net.variables.update({k: v for k, v in variables.items() if k.startswith(m + '/')})
+        net._variables_changed()
+        cms[m] = net.score(measure)[1]
+        out[m] = net.predict(heldout)
+        out[m + '_score'] = net.predict(heldout, output_attr='score')
+    common = dict(data_description=desc, num_units=U, num_channels={'rgb': 3, 'depth': 1}, expert_model='fcn',
+                  class_prior='data', batchsize=4, device=str(device))
+    bayes = get_model('bayes_fusion')(confusion_matrices=cms, prefixes={'rgb': 'rgb', 'depth': 'depth'}, **common)
+    bayes.variables.update(variables)
+    bayes._variables_changed()
+    out['bayes'] = bayes.predict(heldout)
+    diri = get_model('dirichlet_fusion')(modalities=['rgb', 'depth'], sigma=1.0, delta=1e-2, beta=1e-2, **common)
+    diri.variables.update(variables)
+    diri._variables_changed()
+    dparams = diri.fit(measure)
+    out['dirichlet'] = diri.predict(heldout)
+    return out, cms, dparams
+
+
+def oracle_predictions(variables, heldout, cms, dparams, policy='fp32'):
+    """The reference pipeline restated on the CPU (fp32), image by image: expert logits -> softmax -> argmax
+    (basic_fusion_model.py:9-23), Bayes fusion of the labels (bayes_mix.py:12-58), Dirichlet fusion of the
+    probabilities (dirichlet_mix.py:96-138) with the same tables.  Returns (predictions, seconds, images)."""
+    from oracle import fcn_oracle as fo
+    from oracle import fusion_oracle as fu
+    n = len(heldout['labels'])
+    out = {k: [] for k in ('rgb', 'depth', 'rgb_score', 'depth_score', 'bayes', 'dirichlet')}
+    mats = [np.asarray(cms[m], np.float32).T for m, _ in MODS]
+    prior = fu.dirichlet_prior(dparams['class_counts'], 'data')
+    t0 = time.perf_counter()
+    for i in range(n):
+        probs, labs = [], []
+        for m, _ in MODS:
+            score = fo.fcn_forward(heldout[m][i:i + 1], variables, m, policy, keep=['score'])['score']
+            p = fo.softmax(score)
+            out[m + '_score'].append(score)
+            probs.append(p)
+            labs.append(fo.argmax_last(p))
+            out[m].append(labs[-1])
+        out['bayes'].append(np.argmax(fu.bayes_fusion(labs, mats, 'data')[0], -1))
+        fused = fu.dirichlet_fusion([fu.renormalise(p) for p in probs],
+                                    [np.asarray(dparams[m], np.float32) for m, _ in MODS], prior, 1.0)
+        out['dirichlet'].append(np.argmax(fused, -1))
+    dt = time.perf_counter() - t0
+    return {k: np.concatenate(v) for k, v in out.items()}, dt, n
+
+
+def compare(hip, ref, labels):
+    """Per model: mIoU of both paths, the difference in percentage points, label agreement; per expert the logit
+    error relative to the largest |logit| and the agreement on pixels whose fp32 top-2 margin exceeds it."""
+    res = {}
+    for k in ('rgb', 'depth', 'bayes', 'dirichlet'):
+        a, _ = _miou(labels, hip[k])
+        b, _ = _miou(labels, ref[k])
+        res[k] = {'miou_hip_bf16': round(a, 5), 'miou_fp32_oracle': round(b, 5),
+                  'delta_miou_pp': round(100 * (a - b), 4), 'label_agreement': round(float((hip[k] == ref[k]).mean()), 6)}
+    for m, _ in MODS:
+        s, r = hip[m + '_score'], ref[m + '_score']
+        scale = float(np.abs(r).max())
+        err = float(np.abs(s - r).max())
+        top2 = np.sort(r, -1)[..., -2:]
+        clear = (top2[..., 1] - top2[..., 0]) > 2 * err
+        res[m].update(logit_max_abs_err=round(err, 5), logit_scale=round(scale, 3),
+                      logit_rel_err=round(err / scale, 6), clear_margin_fraction=round(float(clear.mean()), 5),
+                      label_agreement_clear_margin=round(float((hip[m][clear] == ref[m][clear]).mean()), 6))
+    return res
+
+
+def run(h=384, w=768, steps=1500, batch=8, n_heldout=8, n_measure=16, device='cuda', log=None):
+    """The whole protocol; returns (accuracy dict, oracle seconds, oracle images)."""
+    from modular_semantic_segmentation_amd.datasets.synthetic import make_rgbd_shapes
+    variables, train = train_experts(h, w, steps, batch=batch, device=device, log=log)
+    measure = {k: v[:n_measure] for k, v in train.items()}
+    heldout = make_rgbd_shapes(n_heldout, h, w, seed=1001)
+    hip, cms, dparams = hip_predictions(variables, measure, heldout, device=device)
+    ref, dt, n = oracle_predictions(variables, heldout, cms, dparams)
+    acc = compare(hip, ref, heldout['labels'])
+    acc['protocol'] = ('experts trained %d Adam steps x %d images on procedural RGB-D shapes at %dx%d through the HIP fit(); '
+                       '%d held-out images; same trained weights through the HIP bf16 path and the fp32 CPU oracle; '
+                       'mean IoU over classes 1..%d (base_model.py:329)' % (steps, batch, w, h, n_heldout, C - 1))
+    return acc, dt, n
+
+
+if __name__ == '__main__':
+    import json
+    steps = int(sys.argv[1]) if len(sys.argv) > 1 else 1500
+    acc, dt, n = run(steps=steps, log=lambda s: print(s, file=sys.stderr, flush=True))
+    acc['oracle_seconds'] = round(dt, 2)
+    print(json.dumps(acc, indent=1))

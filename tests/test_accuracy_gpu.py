@@ -1,0 +1,27 @@
+"""north_star's accuracy clause on TRAINED weights: the HIP bf16 path and the fp32 oracle (the restated reference
+graph) segment held-out 768x384 RGB-D images with the same experts; mean IoU (base_model.py:315-329) of every model
+-- RGB expert, depth expert, Bayes fusion, Dirichlet fusion -- must agree within 0.1 percentage points, labels must
+be identical wherever the fp32 top-2 logit margin exceeds twice the measured logit error, and the logits must be
+within 2 % of the logit scale (the stated fp tolerance of the bf16 path at 13 conv layers)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def test_miou_of_hip_path_matches_fp32_oracle_on_trained_experts():
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU')
+    from accuracy_evidence import run
+    torch.set_num_threads(min(32, torch.get_num_threads()))
+    acc, _, _ = run(h=384, w=768, steps=1000, batch=8, n_heldout=16)
+    for m in ('rgb', 'depth'):
+        assert acc[m]['miou_fp32_oracle'] > 0.6, (m, acc[m])              # a trained, useful expert
+        assert acc[m]['logit_rel_err'] < 2e-2, (m, acc[m])
+        assert acc[m]['label_agreement_clear_margin'] == 1.0, (m, acc[m])
+        assert acc[m]['clear_margin_fraction'] > 0.8, (m, acc[m])
+    for m in ('rgb', 'depth', 'bayes', 'dirichlet'):
+        assert abs(acc[m]['delta_miou_pp']) <= 0.1, (m, acc[m])
+        assert acc[m]['label_agreement'] > 0.995, (m, acc[m])
+    # the fusion has something to gain on this task (fusion above both experts)
+    assert acc['bayes']['miou_fp32_oracle'] > min(acc['rgb']['miou_fp32_oracle'], acc['depth']['miou_fp32_oracle'])

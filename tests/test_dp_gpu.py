@@ -250,7 +250,10 @@ def _check_unseeded(tmp_path, backend):
         # identical replicas: same start, same all-reduced gradients (bitwise: every rank applies the same sums)
         assert np.array_equal(r0[key], r1[key]), name
         if name.endswith('/kernel') and 'upscore' not in name:
-            np.testing.assert_allclose(r0[key], ref, rtol=0, atol=5e-5, err_msg=name)
+            # two RMSProp steps of up to lr / sqrt(0.1) = 3.2e-3 each; the second one differentiates weights that
+            # already differ by the first step's bf16 / atomic-order noise.  Another initialiser draw would be off by
+            # the Glorot scale (1e-2 .. 1e-1).
+            np.testing.assert_allclose(r0[key], ref, rtol=0, atol=4e-4, err_msg=name)
 
 
 def test_two_rank_replicas_start_from_rank0_parameters(tmp_path):
