@@ -32,10 +32,17 @@ extern "C" {
 #define XV_ESHAPE (-2)      /* shape not supported by the kernel (see each function)        */
 #define XV_EWORKSPACE (-3)  /* workspace too small                                          */
 
-/* bf16 padded-NHWC activation: dense [n][h+2][w+2][c], zero border, data -> padded origin */
+/* padded-NHWC activation: dense [n][h+2][w+2][c], zero border, data -> padded origin.
+ * dtype XV_BF16 (every entry point) or XV_FP8 (OCP e4m3fn, one byte per element; xv_conv2d_fwd* only, BASELINE
+ * config "fp8 MFMA conv path"): a stored value q stands for q * 2^scale_exp (per-tensor power-of-two scale, 0 for
+ * bf16).  Entry points other than the forward convolutions read bf16 maps and ignore the last two fields.          */
+#define XV_BF16 0
+#define XV_FP8 1
 typedef struct xv_act {
   void* data;
   int32_t n, h, w, c;
+  int32_t dtype;
+  int32_t scale_exp;
 } xv_act;
 
 /* Library version (major*10000 + minor*100 + patch). */
@@ -62,6 +69,14 @@ int xv_pack_conv_weights(const float* w_hwio, void* packed, int k, int cin, int 
 int xv_pack_conv_weights_pair(const float* w_hwio, void* packed, void* packed_dgrad, int k, int cin, int cout,
                               void* stream);
 
+/* fp8 weights (config "fp8 MFMA conv path", vgg16.py:7-51 / custom_layers.py:124-139 call sites): OCP e4m3fn,
+ * [tap][cin/128][cout][128] (128-byte rows, slots swizzled like the bf16 image: a weight tile has the same bytes
+ * geometry), preceded by a 256-byte header whose first int32 is the per-tensor scale exponent e_w (stored value q
+ * stands for q * 2^e_w; the kernel feeds it to the MFMA as a uniform E8M0 block scale).  Values are rounded to
+ * nearest-even after the scaling and saturate at +-448.  k = 1 or 3, cin % 128 == 0, cout % 64 == 0.             */
+size_t xv_packed_weight_bytes_f8(int k, int cin, int cout);
+int xv_pack_conv_weights_f8(const float* w_hwio, void* packed, int k, int cin, int cout, int scale_exp, void* stream);
+
 /* ---- conv2d forward ------------------------------------------------------------------------
  * y = act(conv(x, W) + b): tf.layers.conv2d(padding='same', strides 1) via
  * custom_layers.py:124-139 (call sites simple_fcn.py:39-79).  Implicit GEMM on bf16 MFMA
@@ -71,7 +86,13 @@ int xv_pack_conv_weights_pair(const float* w_hwio, void* packed, void* packed_dg
  * Inference batch-norm is folded into (W, b) by the host before packing.
  * If pooled != NULL (k = 3 only, h and w even) the 2x2/2 max-pool of y
  * (max_pooling2d, simple_fcn.py:41,44,48,58) is written to `pooled` from the same accumulators;
- * y itself may then be NULL (data == NULL) to skip the full-resolution store.                    */
+ * y itself may then be NULL (data == NULL) to skip the full-resolution store.
+ * fp8 (the dtype fields select it, no second entry point): x->dtype == XV_FP8 runs the block-scaled
+ * v_mfma_scale_f32_16x16x128_f8f6f4 kernel (e4m3 operands, 128-channel chunks, fp32 accumulate; x->scale_exp and the
+ * weight header's exponent go in as uniform E8M0 scales, so the accumulators are in real units) and needs weights
+ * packed by xv_pack_conv_weights_f8 and cin % 128 == 0; y->dtype / pooled->dtype == XV_FP8 make the epilogue write
+ * e4m3 (value * 2^-scale_exp, round-to-nearest-even, saturating at 448) from either kernel -- conv2_1 (64 input
+ * channels) stays a bf16 convolution and hands an fp8 map to conv2_2.                                            */
 int xv_conv2d_fwd(const xv_act* x, const void* w_packed, const float* bias, const xv_act* y,
                   const xv_act* pooled, int k, int relu, void* stream);
 

@@ -18,7 +18,8 @@ class XvError(RuntimeError):
 
 class xv_act(ctypes.Structure):
     _fields_ = [('data', ctypes.c_void_p), ('n', ctypes.c_int32), ('h', ctypes.c_int32),
-                ('w', ctypes.c_int32), ('c', ctypes.c_int32)]
+                ('w', ctypes.c_int32), ('c', ctypes.c_int32), ('dtype', ctypes.c_int32),
+                ('scale_exp', ctypes.c_int32)]
 
 
 _vp, _i, _i64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64
@@ -33,6 +34,8 @@ SIGNATURES = {
     'xv_packed_weight_bytes': (ctypes.c_size_t, [_i, _i, _i]),
     'xv_pack_conv_weights': (_i, [_vp, _vp, _i, _i, _i, _vp]),
     'xv_pack_conv_weights_pair': (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
+    'xv_packed_weight_bytes_f8': (ctypes.c_size_t, [_i, _i, _i]),
+    'xv_pack_conv_weights_f8': (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     'xv_conv2d_fwd': (_i, [_actp, _vp, _vp, _actp, _actp, _i, _i, _vp]),
     'xv_conv2d_fwd_cfg': (_i, [_actp, _vp, _vp, _actp, _actp, _i, _i, _i, _vp]),
     'xv_conv2d_num_cfgs': (_i, []),

@@ -19,6 +19,9 @@
 #ifndef XV_CONV_PFD
 #define XV_CONV_PFD 2
 #endif
+#ifndef XV_F8_BIG_MAP
+#define XV_F8_BIG_MAP (1 << 30)  // pixels per launch from which the fp8 chooser takes configuration 16 (tools/conv_tune.py)
+#endif
 
 // conv1x1_gemm.hip
 int xv_launch_conv1x1_gemm(const __bf16* x, const __bf16* wpk, const float* bias, __bf16* y, const __bf16* mask,
@@ -38,7 +41,35 @@ struct ConvArgs {
   int tiles_x, tiles_y, n_ct, n_tiles;
   int relu;
   int num_cus;
+  // fp8 path (OCP e4m3fn): in_f8 = x and the packed weights are fp8 (kernel template F8); out_f8 = y / pooled are
+  // written as fp8 of value * out_mul (= 2^-scale_exp of the output map) by the shared epilogue
+  int in_f8, out_f8;
+  int scale_x;    // E8M0 byte (127 + scale_exp of x) in all four bytes: the uniform block scale of the B operand
+  float out_mul;
 };
+
+typedef __attribute__((ext_vector_type(8))) int i32x8;
+
+// four fp32 -> four e4m3 bytes (round-to-nearest-even), value * mul, saturating at the largest finite e4m3 (the
+// conversion's own overflow behaviour depends on a mode bit, so the clamp is explicit)
+__device__ __forceinline__ uint32_t pack_fp8x4(f32x4 v, float mul) {
+  const float a = __builtin_amdgcn_fmed3f(v.x * mul, -448.f, 448.f);
+  const float b = __builtin_amdgcn_fmed3f(v.y * mul, -448.f, 448.f);
+  const float c = __builtin_amdgcn_fmed3f(v.z * mul, -448.f, 448.f);
+  const float d = __builtin_amdgcn_fmed3f(v.w * mul, -448.f, 448.f);
+  int p = 0;
+  p = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, p, false);
+  p = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, p, true);
+  return (uint32_t)p;
+}
+
+// a lane's 4 consecutive output channels of one pixel: 8 bytes of bf16 or 4 bytes of e4m3 at ELEMENT offset eoff
+__device__ __forceinline__ void store_out4(const ConvArgs& a, void* base, int64_t eoff, f32x4 v) {
+  if (a.out_f8)
+    *reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(base) + eoff) = pack_fp8x4(v, a.out_mul);
+  else
+    *reinterpret_cast<u32x2*>(reinterpret_cast<__bf16*>(base) + eoff) = u32x2{pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w)};
+}
 
 
 // ---- epilogue shared by both kernel generations: bias + relu, bf16, 8-byte NHWC stores (a lane holds 4
@@ -60,7 +91,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[MT
     // pooled-only output: max first (bias add and relu are monotone, so they commute with it), then bias +
     // relu on a quarter of the values
     const int Hq = H >> 1, Wq = W >> 1;
-    __bf16* qimg = a.pooled + (int64_t)n * (Hq + 2) * (Wq + 2) * Cout;
+    const int64_t qimg = (int64_t)n * (Hq + 2) * (Wq + 2) * Cout;
 #pragma unroll
     for (int i = 0; i < MT; i += 2) {
       const int py = py0 + i;
@@ -82,10 +113,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[MT
           m.z = fmaxf(m.z, 0.f);
           m.w = fmaxf(m.w, 0.f);
         }
-        if ((lane & 1) == 0 && py < H && px < W) {
-          __bf16* dst = qimg + ((int64_t)((py >> 1) + 1) * (Wq + 2) + ((px >> 1) + 1)) * Cout + cbase + j * 16;
-          *reinterpret_cast<u32x2*>(dst) = u32x2{pack_bf16x2(m.x, m.y), pack_bf16x2(m.z, m.w)};
-        }
+        if ((lane & 1) == 0 && py < H && px < W)
+          store_out4(a, a.pooled, qimg + ((int64_t)((py >> 1) + 1) * (Wq + 2) + ((px >> 1) + 1)) * Cout + cbase + j * 16, m);
       }
     }
   } else {
@@ -108,7 +137,6 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[MT
         const int py = py0 + i;
         if (py < H && px < W) {
           const int64_t off = (int64_t)n * (H + 2) * Wp * Cout + ((int64_t)(py + 1) * Wp + (px + 1)) * Cout + cbase;
-          __bf16* dst = a.y + off;
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             f32x4 v = acc[i][j];
@@ -126,7 +154,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[MT
               v.z = bf16_bits_to_f32(mk.y & 0xffffu) > 0.f ? v.z : 0.f;
               v.w = __builtin_bit_cast(float, mk.y & 0xffff0000u) > 0.f ? v.w : 0.f;
             }
-            *reinterpret_cast<u32x2*>(dst + j * 16) = u32x2{pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w)};
+            store_out4(a, a.y, off + j * 16, v);
           }
         }
       }
@@ -134,7 +162,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[MT
     if (a.pooled != nullptr) {
       // fused max_pooling2d(2,2): rows (i, i+1) live in this lane, columns (px, px^1) in lanes l, l^1
       const int Hq = H >> 1, Wq = W >> 1;
-      __bf16* qimg = a.pooled + (int64_t)n * (Hq + 2) * (Wq + 2) * Cout;
+      const int64_t qimg = (int64_t)n * (Hq + 2) * (Wq + 2) * Cout;
 #pragma unroll
       for (int i = 0; i < MT; i += 2) {
         const int py = py0 + i;
@@ -149,10 +177,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[MT
           m.y = fmaxf(m.y, dpp_swap1(m.y));
           m.z = fmaxf(m.z, dpp_swap1(m.z));
           m.w = fmaxf(m.w, dpp_swap1(m.w));
-          if ((lane & 1) == 0 && py < H && px < W) {
-            __bf16* dst = qimg + ((int64_t)((py >> 1) + 1) * (Wq + 2) + ((px >> 1) + 1)) * Cout + cbase + j * 16;
-            *reinterpret_cast<u32x2*>(dst) = u32x2{pack_bf16x2(m.x, m.y), pack_bf16x2(m.z, m.w)};
-          }
+          if ((lane & 1) == 0 && py < H && px < W)
+            store_out4(a, a.pooled, qimg + ((int64_t)((py >> 1) + 1) * (Wq + 2) + ((px >> 1) + 1)) * Cout + cbase + j * 16, m);
         }
       }
     }
@@ -200,10 +226,20 @@ struct ConvCfg {
 // stage retires exactly the DMA (VMEM operations complete in order) and leaves the patch in flight across
 // the raw `s_barrier`.  Stage buffers alternate with a per-item parity because a chunk has an odd number of
 // stages.
-template <int MT, int WR, int WC, int NW, int KS, int OCC, int TPS, int DMAB>
+// F8: the fp8 form (BASELINE config "fp8 MFMA conv path").  A 128-channel chunk of e4m3 bytes has the byte geometry of
+// a 64-channel bf16 chunk (128-byte pixel / weight rows), so staging, LDS images, swizzle and stage pipeline are shared;
+// a lane's fragment is the SAME two 16-byte slots it reads for the two bf16 k-halves, concatenated into the 32 bytes
+// v_mfma_scale_f32_16x16x128_f8f6f4 wants: lane (row r, group g) holds channels [16g, 16g+16) and [64+16g, 64+16g+16)
+// of the chunk for the A (weights) and the B (pixels) operand alike, so every product pairs equal channels whatever
+// k index the hardware gives a byte.  One MFMA per (row, channel block) and tap instead of two, at twice the K and
+// twice the cycles of the bf16 instruction = 2x the FLOP per clock (MI355X_MICROARCH.md, Matrix cores).  The per-tensor
+// power-of-two scales of the two operands ride in as uniform E8M0 block scales: accumulators are in real units.
+template <int MT, int WR, int WC, int NW, int KS, int OCC, int TPS, int DMAB, int F8 = 0>
 __global__ __launch_bounds__(64 * WR * WC * NW, OCC) void conv_mfma_kernel(ConvArgs a) {
   using C = ConvCfg<MT, WR, WC, NW, KS, TPS>;
-  constexpr bool PFA = (MT == 4) || (OCC == 1);
+  constexpr int ESZ = F8 ? 1 : 2;  // bytes per activation element
+  // (fp8: fragments are twice as wide and the cross-item prefetch no longer fits 256 registers -- it spilled 500+)
+  constexpr bool PFA = !F8 && ((MT == 4) || (OCC == 1));
   constexpr int PFD = XV_CONV_PFD;  // how many stages before the end of an item its successor's patch is requested
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const As = smem;
@@ -220,7 +256,11 @@ __global__ __launch_bounds__(64 * WR * WC * NW, OCC) void conv_mfma_kernel(ConvA
 
   const int H = a.H, W = a.W, Cin = a.Cin, Cout = a.Cout;
   const int Wp = W + 2;
-  const int nchunks = Cin >> 6;
+  const int nchunks = F8 ? Cin >> 7 : Cin >> 6;  // 128 bytes of input channels per chunk
+  // fp8 weights: [256-byte header: int32 scale exponent][image]
+  const char* const wimg = reinterpret_cast<const char*>(a.wpk) + (F8 ? 256 : 0);
+  int scale_w = 0;
+  if constexpr (F8) scale_w = ((127 + *reinterpret_cast<const int*>(a.wpk)) & 0xff) * 0x01010101;
 
   // ---- this workgroup's share of the tile list (XCD-aware, placement affects speed only) --------
   // workgroups b, b+8, ... share an XCD (round-robin dispatch); each XCD owns a contiguous range of
@@ -265,7 +305,7 @@ __global__ __launch_bounds__(64 * WR * WC * NW, OCC) void conv_mfma_kernel(ConvA
   // Patch coordinates are clamped onto the zero border of the padded buffer: every load is in-bounds
   // and unconditional; outputs fed by clamped pixels are never stored.
   auto a_load = [&](const Tile& t, int chunk, auto& v, auto IT0, auto IT1) {
-    const __bf16* ximg = a.x + (int64_t)t.n * (H + 2) * Wp * Cin + chunk * 64;
+    const char* ximg = reinterpret_cast<const char*>(a.x) + (int64_t)t.n * (H + 2) * Wp * Cin * ESZ + chunk * 128;
 #pragma unroll
     for (int it = IT0; it < IT1; ++it) {
       int idx = tid + it * C::NT;
@@ -275,7 +315,7 @@ __global__ __launch_bounds__(64 * WR * WC * NW, OCC) void conv_mfma_kernel(ConvA
       int yy = t.y0 + hy + (1 - C::HALO), xx = t.x0 + hx + (1 - C::HALO);  // padded coords
       yy = yy < H + 1 ? yy : H + 1;
       xx = xx < W + 1 ? xx : W + 1;
-      v[it - IT0] = *reinterpret_cast<const u32x4*>(ximg + ((int64_t)yy * Wp + xx) * Cin + s * 8);
+      v[it - IT0] = *reinterpret_cast<const u32x4*>(ximg + ((int64_t)yy * Wp + xx) * Cin * ESZ + s * 16);
     }
   };
   auto a_store = [&](const auto& v, auto IT0, auto IT1) {
@@ -293,8 +333,7 @@ __global__ __launch_bounds__(64 * WR * WC * NW, OCC) void conv_mfma_kernel(ConvA
     for (int tt = 0; tt < C::TPS; ++tt) {
       const int tap = stage * C::TPS + tt;
       if (tap < C::NTAPS) {
-        const char* src =
-            reinterpret_cast<const char*>(a.wpk) + (((int64_t)(tap * nchunks + chunk) * Cout + co0) << 7);
+        const char* src = wimg + (((int64_t)(tap * nchunks + chunk) * Cout + co0) << 7);
 #pragma unroll
         for (int it = 0; it < C::B_ITERS; ++it)
           v[tt * C::B_ITERS + it] = *reinterpret_cast<const u32x4*>(src + ((tid + it * C::NT) << 4));
@@ -323,7 +362,7 @@ __global__ __launch_bounds__(64 * WR * WC * NW, OCC) void conv_mfma_kernel(ConvA
       if (tap < C::NTAPS) {
         // in assembly (SGPR base + lane offset): the builtin makes hipcc model a FLAT access, after which every
         // LDS wait it inserts is lgkmcnt(0) instead of a counted one
-        const char* src = reinterpret_cast<const char*>(a.wpk) + (((int64_t)(tap * nchunks + chunk) * Cout + co0) << 7);
+        const char* src = wimg + (((int64_t)(tap * nchunks + chunk) * Cout + co0) << 7);
         const int dst = C::A_BYTES + buf * STAGE_BYTES + tt * C::B_BYTES;
 #pragma unroll
         for (int i = 0; i < (DMA_PER_TAP + NWAVES - 1) / NWAVES; ++i) {
@@ -414,18 +453,65 @@ __global__ __launch_bounds__(64 * WR * WC * NW, OCC) void conv_mfma_kernel(ConvA
         if (tap < C::NTAPS) {
           const int dy = (KS == 3) ? tap / 3 : 0;
           const int dx = (KS == 3) ? tap % 3 : 0;
+          if constexpr (F8) {
+            // Fragment reads in assembly, waited for by hand: left to the compiler, the 32-byte fragments of several
+            // taps were hoisted above the MFMAs and 400 registers (accumulators included) went to scratch.  One tap =
+            // 16 ds_read_b128 (W: 4 channel blocks x 2 slots, X: MT rows x 2 slots), one wait, 4*MT MFMAs of 32 cycles;
+            // the SIMD's other wave (two 4-wave workgroups per CU, or the 8-wave tile) computes during the reads.
+            // Addresses are LDS byte offsets (the dynamic segment starts at 0: the kernel has no static LDS).
+            u32x4 wlo[4], whi[4], xlo[MT], xhi[MT];
+            const int wa0 = wbase[0] + cb, wa1 = wbase[1] + cb;
+#define XV_F8_RD(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
 #pragma unroll
-          for (int kk = 0; kk < 2; ++kk) {
-            bf16x8 wf[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-              wf[j] = *reinterpret_cast<const bf16x8*>(smem + wbase[kk] + cb + tt * C::B_BYTES + j * 2048);
+            for (int j = 0; j < 4; ++j) {
+              XV_F8_RD(wlo[j], wa0, tt * C::B_BYTES + j * 2048);
+              XV_F8_RD(whi[j], wa1, tt * C::B_BYTES + j * 2048);
+            }
 #pragma unroll
             for (int i = 0; i < MT; ++i) {
-              const bf16x8 xf = *reinterpret_cast<const bf16x8*>(smem + abase[dx][kk] + (i + dy) * (C::HW * 128));
+              XV_F8_RD(xlo[i], abase[dx][0], (i + dy) * (C::HW * 128));
+              XV_F8_RD(xhi[i], abase[dx][1], (i + dy) * (C::HW * 128));
+            }
+#undef XV_F8_RD
+            static_assert(MT == 4, "operand list of the wait below");
+            asm volatile("s_waitcnt lgkmcnt(0)"
+                         : "+v"(wlo[0]), "+v"(whi[0]), "+v"(wlo[1]), "+v"(whi[1]), "+v"(wlo[2]), "+v"(whi[2]), "+v"(wlo[3]),
+                           "+v"(whi[3]), "+v"(xlo[0]), "+v"(xhi[0]), "+v"(xlo[1]), "+v"(xhi[1]), "+v"(xlo[2]), "+v"(xhi[2]),
+                           "+v"(xlo[3]), "+v"(xhi[3]));
+            __builtin_amdgcn_sched_barrier(0);
+            auto cat = [](const u32x4 lo, const u32x4 hi) {
+              return i32x8{(int)lo.x, (int)lo.y, (int)lo.z, (int)lo.w, (int)hi.x, (int)hi.y, (int)hi.z, (int)hi.w};
+            };
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+              const i32x8 xf = cat(xlo[i], xhi[i]);
 #pragma unroll
               for (int j = 0; j < 4; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], xf, acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(cat(wlo[j], whi[j]), xf, acc[i][j], 0, 0, 0,
+                                                                            scale_w, 0, a.scale_x);
+            }
+            // An MFMA is a pure value to the instruction selector: nothing orders it against the (chained) asm reads of
+            // the next tap, and it sank below them -- every tap's fragments then lived until the end of the item.  An
+            // empty asm that "modifies" each accumulator pins this tap's MFMAs in front of the next tap's reads.
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+              for (int j = 0; j < 4; ++j) asm volatile("" : "+v"(acc[i][j]));
+            __builtin_amdgcn_sched_barrier(0);
+          } else {
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+              bf16x8 wf[4];
+#pragma unroll
+              for (int j = 0; j < 4; ++j)
+                wf[j] = *reinterpret_cast<const bf16x8*>(smem + wbase[kk] + cb + tt * C::B_BYTES + j * 2048);
+#pragma unroll
+              for (int i = 0; i < MT; ++i) {
+                const bf16x8 xf = *reinterpret_cast<const bf16x8*>(smem + abase[dx][kk] + (i + dy) * (C::HW * 128));
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                  acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], xf, acc[i][j], 0, 0, 0);
+              }
             }
           }
         }
@@ -457,7 +543,7 @@ __global__ __launch_bounds__(64 * WR * WC * NW, OCC) void conv_mfma_kernel(ConvA
   }
 }
 
-template <int MT, int WR, int WC, int NW, int KS, int OCC, int TPS = 1, int DMAB = 0>
+template <int MT, int WR, int WC, int NW, int KS, int OCC, int TPS = 1, int DMAB = 0, int F8 = 0>
 int launch_conv(const ConvArgs& a0, hipStream_t stream) {
   using C = ConvCfg<MT, WR, WC, NW, KS, TPS>;
   ConvArgs a = a0;
@@ -466,7 +552,7 @@ int launch_conv(const ConvArgs& a0, hipStream_t stream) {
   a.n_ct = a.Cout / C::BN;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_kernel<MT, WR, WC, NW, KS, OCC, TPS, DMAB>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_kernel<MT, WR, WC, NW, KS, OCC, TPS, DMAB, F8>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
     if (e != hipSuccess) return (int)e;
     attr_set = true;
@@ -481,7 +567,7 @@ int launch_conv(const ConvArgs& a0, hipStream_t stream) {
   constexpr int per_cu = by_lds < by_reg ? by_lds : by_reg;
   const int64_t slots = (int64_t)a.num_cus * per_cu;
   const int64_t nblk = ntiles < slots ? ntiles : slots;
-  hipLaunchKernelGGL((conv_mfma_kernel<MT, WR, WC, NW, KS, OCC, TPS, DMAB>), dim3((unsigned)nblk), dim3(C::NT), C::LDS_BYTES, stream, a);
+  hipLaunchKernelGGL((conv_mfma_kernel<MT, WR, WC, NW, KS, OCC, TPS, DMAB, F8>), dim3((unsigned)nblk), dim3(C::NT), C::LDS_BYTES, stream, a);
   return xv_launch_status();
 }
 
@@ -1114,6 +1200,31 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, __bf16* __restr
   }
 }
 
+// fp8 image: [256-byte header][tap][cin/128][cout][128 B, 16-byte slots swizzled by xv_swz]; one thread = 4 bytes
+__global__ void pack_weights_f8_kernel(const float* __restrict__ w, char* __restrict__ out, int taps, int cin, int cout,
+                                       int scale_exp, float mul) {
+  const int64_t total4 = (int64_t)taps * cin * cout / 4;
+  const int nch = cin >> 7;
+  if (blockIdx.x == 0 && threadIdx.x < 64) reinterpret_cast<int*>(out)[threadIdx.x] = threadIdx.x == 0 ? scale_exp : 0;
+  for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < total4; q += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t idx = q * 4;  // destination byte
+    const int e = (int)(idx & 15);
+    const int ps = (int)((idx >> 4) & 7);
+    int64_t rest = idx >> 7;
+    const int co = (int)(rest % cout);
+    rest /= cout;
+    const int chunk = (int)(rest % nch);
+    const int tap = (int)(rest / nch);
+    const int ci = chunk * 128 + xv_swz(co, ps) * 16 + e;
+    f32x4 v;
+    v.x = w[((int64_t)tap * cin + ci) * cout + co];
+    v.y = w[((int64_t)tap * cin + ci + 1) * cout + co];
+    v.z = w[((int64_t)tap * cin + ci + 2) * cout + co];
+    v.w = w[((int64_t)tap * cin + ci + 3) * cout + co];
+    *reinterpret_cast<uint32_t*>(out + 256 + idx) = pack_fp8x4(v, mul);
+  }
+}
+
 // ---- tile configurations ---------------------------------------------------------------------
 // id: pixel patch x output channels, waves, LDS, workgroups per CU (register bound)
 //   0: 16x16 x 128, 4 waves, 74 KB, 2/CU          1:  8x16 x 128, 4 waves, 55 KB, 2/CU
@@ -1146,6 +1257,16 @@ template <int KS>
 int launch_cfg(int cfg, const ConvArgs& a, hipStream_t s) {
   if (cfg < 0 || cfg >= XV_NUM_CONV_CFG) return XV_EINVAL;
   if (a.Cout % kGeo[cfg].bn) return XV_ESHAPE;
+  if (a.in_f8) {
+    // the fp8 kernel is built for the tile shapes with LDS-DMA weight stages (the ones the bf16 chooser falls back to)
+    switch (cfg) {
+      case 14: return launch_conv<4, 4, 1, 1, KS, 2, 2, 1, 1>(a, s);
+      case 15: return launch_conv<4, 2, 2, 1, KS, 2, 2, 1, 1>(a, s);
+      case 16: return launch_conv<4, 4, 2, 1, KS, 2, 5, 1, 1>(a, s);
+      default: return XV_ESHAPE;
+    }
+  }
+  if (a.out_f8 && cfg >= 17) return XV_ESHAPE;  // fp8 outputs come from the shared first-generation epilogue
   switch (cfg) {
     case 0: return launch_conv<8, 2, 1, 2, KS, 2>(a, s);
     case 1: return launch_conv<4, 2, 1, 2, KS, 2>(a, s);
@@ -1186,6 +1307,11 @@ int pick_cfg(const ConvArgs& a, int k) {
     return (double)((a.H + g.th - 1) / g.th * g.th) * ((a.W + g.tw - 1) / g.tw * g.tw);
   };
   const double g1 = covered(14) < covered(15) ? covered(14) : covered(15);
+  if (a.in_f8 || a.out_f8) {
+    // 16x32 patch, 8 waves, five taps per barrier where it tiles the map (large maps); else two 4-wave workgroups
+    if (k == 3 && covered(16) <= g1 && (int64_t)a.N * a.H * a.W >= XV_F8_BIG_MAP) return 16;
+    return covered(15) < covered(14) ? 15 : 14;
+  }
   // generation 2 (16x32 tiles) unless its partial tiles waste more than its ~1.25x per-pixel advantage over the
   // 16x16 / 8x32 tiles of generation 1 (e.g. the 24x48 conv5 maps of a 768x384 input)
   if (k == 3 && covered(17) <= 1.25 * g1) return 17;
@@ -1205,6 +1331,12 @@ int conv_fwd_impl(const xv_act* x, const void* w_packed, const float* bias, cons
   XV_CHECK_SHAPE(k == 1 || k == 3);
   XV_CHECK_SHAPE(x->n > 0 && x->h > 0 && x->w > 0 && x->c > 0 && (x->c & 63) == 0);
   XV_CHECK_SHAPE(y->n == x->n && y->h == x->h && y->w == x->w && y->c > 0 && (y->c & 63) == 0);
+  XV_CHECK_ARG((x->dtype == XV_BF16 || x->dtype == XV_FP8) && (y->dtype == XV_BF16 || y->dtype == XV_FP8));
+  const int in_f8 = x->dtype == XV_FP8, out_f8 = y->dtype == XV_FP8;
+  if (in_f8) XV_CHECK_SHAPE((x->c & 127) == 0 && x->scale_exp > -127 && x->scale_exp < 127);
+  if (in_f8 || out_f8) XV_CHECK_SHAPE(mask == nullptr && addend == nullptr);  // forward only
+  if (out_f8) XV_CHECK_SHAPE(y->scale_exp > -100 && y->scale_exp < 100);
+  if (pooled && pooled->data) XV_CHECK_ARG(pooled->dtype == y->dtype && pooled->scale_exp == y->scale_exp);
   XV_CHECK_ARG((((uintptr_t)x->data | (uintptr_t)w_packed | (uintptr_t)bias | (uintptr_t)y->data) & 15) == 0);
   ConvArgs a{};
   a.x = (const __bf16*)x->data;
@@ -1221,6 +1353,10 @@ int conv_fwd_impl(const xv_act* x, const void* w_packed, const float* bias, cons
   a.Cout = y->c;
   a.relu = relu;
   a.num_cus = xv_num_cus();
+  a.in_f8 = in_f8;
+  a.out_f8 = out_f8;
+  a.scale_x = in_f8 ? ((127 + x->scale_exp) & 0xff) * 0x01010101 : 0;
+  a.out_mul = out_f8 ? exp2f((float)-y->scale_exp) : 1.f;
   if (pooled && pooled->data) {
     XV_CHECK_SHAPE(k == 3 && (x->h & 1) == 0 && (x->w & 1) == 0);
     XV_CHECK_SHAPE(pooled->n == x->n && pooled->h == x->h / 2 && pooled->w == x->w / 2 && pooled->c == y->c);
@@ -1238,6 +1374,23 @@ int conv_fwd_impl(const xv_act* x, const void* w_packed, const float* bias, cons
 extern "C" size_t xv_packed_weight_bytes(int k, int cin, int cout) {
   if ((k != 1 && k != 3) || cin <= 0 || cout <= 0 || (cin & 63) || (cout & 63)) return 0;
   return (size_t)k * k * cin * cout * 2 * (k == 3 ? 2 : 1);  // 3x3: both packed images
+}
+
+extern "C" size_t xv_packed_weight_bytes_f8(int k, int cin, int cout) {
+  if ((k != 1 && k != 3) || cin <= 0 || cout <= 0 || (cin & 127) || (cout & 63)) return 0;
+  return 256 + (size_t)k * k * cin * cout;
+}
+
+extern "C" int xv_pack_conv_weights_f8(const float* w_hwio, void* packed, int k, int cin, int cout, int scale_exp,
+                                        void* stream) {
+  XV_CHECK_ARG(w_hwio && packed && (((uintptr_t)packed) & 15) == 0);
+  XV_CHECK_SHAPE((k == 1 || k == 3) && cin > 0 && cout > 0 && (cin & 127) == 0 && (cout & 63) == 0);
+  XV_CHECK_SHAPE(scale_exp > -127 && scale_exp < 127);
+  const int64_t total4 = (int64_t)k * k * cin * cout / 4;
+  const int blocks = (int)((total4 + 255) / 256 < 4096 ? (total4 + 255) / 256 : 4096);
+  hipLaunchKernelGGL(pack_weights_f8_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w_hwio, (char*)packed, k * k,
+                     cin, cout, scale_exp, exp2f((float)-scale_exp));
+  return xv_launch_status();
 }
 
 extern "C" int xv_pack_conv_weights(const float* w_hwio, void* packed, int k, int cin, int cout, void* stream) {

@@ -24,29 +24,58 @@ def _need(t, dtype, name):
         raise TypeError('%s must be a contiguous CUDA tensor of dtype %s' % (name, dtype))
 
 
-class Act(object):
-    """bf16 padded-NHWC activation (include/xview_hip.h `xv_act`): dense [n][h+2][w+2][c]
-    with a zero 1-pixel border that no kernel ever writes."""
+BF16, FP8 = 0, 1            # xv_act.dtype (include/xview_hip.h)
+FP8_MAX = 448.0             # largest finite OCP e4m3fn
 
-    def __init__(self, n, h, w, c, device='cuda'):
+
+class Act(object):
+    """padded-NHWC activation (include/xview_hip.h `xv_act`): dense [n][h+2][w+2][c] with a zero 1-pixel border
+    that no kernel ever writes.  dtype 'bf16' (default) or 'fp8' (OCP e4m3fn bytes; a stored q stands for
+    q * 2**scale_exp -- the forward convolutions' fp8 path)."""
+
+    def __init__(self, n, h, w, c, device='cuda', dtype='bf16', scale_exp=0):
         self.n, self.h, self.w, self.c = int(n), int(h), int(w), int(c)
-        self.t = torch.zeros((self.n, self.h + 2, self.w + 2, self.c), dtype=torch.bfloat16, device=device)
-        self._xv = xv_act(self.t.data_ptr(), self.n, self.h, self.w, self.c)
+        self.dtype, self.scale_exp = dtype, int(scale_exp)
+        tdt = torch.bfloat16 if dtype == 'bf16' else torch.float8_e4m3fn
+        self.t = torch.zeros((self.n, self.h + 2, self.w + 2, self.c), dtype=tdt, device=device)
+        self._xv = xv_act(self.t.data_ptr(), self.n, self.h, self.w, self.c, BF16 if dtype == 'bf16' else FP8,
+                          self.scale_exp)
 
     def xv(self):
         return ctypes.byref(self._xv)
 
+    def set_scale_exp(self, scale_exp):
+        self.scale_exp = self._xv.scale_exp = int(scale_exp)
+
     def interior(self):
-        """Logical [n][h][w][c] view (bf16)."""
+        """Logical [n][h][w][c] view (storage dtype)."""
         return self.t[:, 1:-1, 1:-1, :]
 
+    def real(self):
+        """Interior as float32 in real units (test / calibration helper)."""
+        v = self.interior().float()
+        return v * (2.0 ** self.scale_exp) if self.dtype == 'fp8' else v
+
     @classmethod
-    def from_dense(cls, x):
-        """Test helper: pad a dense NHWC float tensor into a new Act (rounds to bf16)."""
+    def from_dense(cls, x, dtype='bf16', scale_exp=0):
+        """Test helper: pad a dense NHWC float tensor into a new Act (rounds to the storage dtype; fp8 stores
+        x / 2**scale_exp, saturating)."""
         n, h, w, c = x.shape
-        a = cls(n, h, w, c, device=x.device)
-        a.interior().copy_(x.to(torch.bfloat16))
+        a = cls(n, h, w, c, device=x.device, dtype=dtype, scale_exp=scale_exp)
+        if dtype == 'bf16':
+            a.interior().copy_(x.to(torch.bfloat16))
+        else:
+            a.interior().copy_((x.float() * (2.0 ** -scale_exp)).clamp(-FP8_MAX, FP8_MAX).to(torch.float8_e4m3fn))
         return a
+
+
+def fp8_scale_exp(amax, margin_bits=0):
+    """Smallest power-of-two exponent e with amax / 2**e <= 448 (plus `margin_bits` of headroom)."""
+    import math
+    amax = float(amax)
+    if not amax > 0:
+        return 0
+    return int(math.ceil(math.log2(amax / FP8_MAX))) + int(margin_bits)
 
 
 _NULL_ACT = ctypes.POINTER(xv_act)()
@@ -73,13 +102,33 @@ def pack_conv_weights(w_hwio):
     return out
 
 
+def pack_conv_weights_f8(w_hwio, scale_exp=None):
+    """float32 HWIO device tensor -> (packed e4m3 weight buffer with its scale-exponent header, exponent); the
+    exponent defaults to the smallest one that keeps max|w| finite."""
+    _need(w_hwio, torch.float32, 'w_hwio')
+    k, k2, cin, cout = w_hwio.shape
+    nbytes = _lib.lib().xv_packed_weight_bytes_f8(k, cin, cout)
+    if k != k2 or nbytes == 0:
+        raise _lib.XvError('unsupported fp8 conv weight shape %s' % (tuple(w_hwio.shape),))
+    if scale_exp is None:
+        scale_exp = fp8_scale_exp(w_hwio.abs().max().item())        # one-off, at load time
+    out = torch.empty(nbytes, dtype=torch.uint8, device=w_hwio.device)
+    _lib.check(_lib.lib().xv_pack_conv_weights_f8(_ptr(w_hwio), _ptr(out), k, cin, cout, int(scale_exp), _stream()),
+               'xv_pack_conv_weights_f8')
+    return out, int(scale_exp)
+
+
 def conv2d_fwd(x, w_packed, bias, k, relu=True, y=None, pooled=None, write_y=True, cfg=-1):
-    """x: Act; returns (y Act or None, pooled Act or None)."""
+    """x: Act; returns (y Act or None, pooled Act or None).  An fp8 `x` needs weights from pack_conv_weights_f8; the
+    dtype / scale of y and pooled (which must agree) select the output conversion."""
     cout = bias.numel()
     _need(bias, torch.float32, 'bias')
     if y is None and write_y:
         y = Act(x.n, x.h, x.w, cout, x.t.device)
-    ydesc = y._xv if y is not None else xv_act(None, x.n, x.h, x.w, cout)
+    if y is not None:
+        ydesc = y._xv
+    else:   # pooled-only: the descriptor still names the output dtype
+        ydesc = xv_act(None, x.n, x.h, x.w, cout, pooled._xv.dtype, pooled._xv.scale_exp)
     prof = CONV_PROFILE
     if prof is not None:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -90,7 +139,7 @@ def conv2d_fwd(x, w_packed, bias, k, relu=True, y=None, pooled=None, write_y=Tru
     _lib.check(rc, 'xv_conv2d_fwd')
     if prof is not None:
         ev1.record()
-        prof.append(('k%d' % k,
+        prof.append(('k%d%s' % (k, 'f8' if x.dtype == 'fp8' else ''),
                      2.0 * x.n * x.h * x.w * x.c * cout * k * k, ev0, ev1))
     return y, pooled
 

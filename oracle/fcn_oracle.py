@@ -8,6 +8,10 @@ be fed *the same* rounded operands:
   'bf16'  activations between layers and conv weights (all but conv1_1) rounded to
           bf16 (round-to-nearest-even), accumulation fp32, decoder head (upscore x8,
           score, softmax) fp32 from the bf16 `fused` features
+  'fp8'   BASELINE config "fp8 MFMA conv path": as 'bf16', but the operands of conv2_2 .. conv5_3 and of the
+          two 1x1 score convs are OCP e4m3fn with per-tensor power-of-two scales (`fp8_scales`: the output
+          exponent of every map that is stored as fp8, 'w:<layer>' the weight exponents); conv1_1 (fp32),
+          conv1_2 and conv2_1 (64 input channels: bf16 operands) are unchanged except that conv2_1 WRITES fp8
 """
 import numpy as np
 import torch
@@ -78,6 +82,33 @@ def round_bf16(x):
     return x.bfloat16().float()
 
 
+FP8_MAX = 448.0            # largest finite OCP e4m3fn (1.75 * 2^8)
+FP8_LAYERS = ('conv2_2', 'conv3_1', 'conv3_2', 'conv3_3', 'conv4_1', 'conv4_2', 'conv4_3', 'conv5_1', 'conv5_2',
+              'conv5_3', 'score_conv4', 'score_conv5')       # convs whose operands are e4m3 in the 'fp8' policy
+
+
+def round_e4m3(x, scale_exp=0):
+    """Quantise to OCP e4m3fn with a per-tensor power-of-two scale and return the REAL values q * 2^scale_exp (fp32):
+    q = round-to-nearest-even(x / 2^scale_exp) on the e4m3 grid (3 mantissa bits, normal exponents 2^-6 .. 2^8,
+    subnormal step 2^-9), saturating at +-448.  Restated from the OCP 8-bit floating point specification; cross-checked
+    against torch.float8_e4m3fn for in-range values in tests/test_oracle_golden.py."""
+    tensor = not isinstance(x, np.ndarray)
+    a = (x.numpy() if tensor else np.asarray(x)).astype(np.float64) * 2.0 ** (-scale_exp)
+    mag = np.minimum(np.abs(a), FP8_MAX)
+    with np.errstate(divide='ignore'):
+        e = np.floor(np.log2(np.where(mag > 0, mag, 1.0)))
+    step = 2.0 ** (np.maximum(e, -6.0) - 3.0)           # spacing of the grid around mag (subnormals: 2^-9)
+    q = np.rint(mag / step) * step                      # np.rint rounds half to even
+    out = (np.sign(a) * np.minimum(q, FP8_MAX) * 2.0 ** scale_exp).astype(np.float32)
+    return _t(out) if tensor else out
+
+
+def fp8_scale_exp(amax, margin_bits=0):
+    """Smallest power-of-two exponent e with amax / 2^e <= 448 (+ margin_bits)."""
+    amax = float(amax)
+    return 0 if not amax > 0 else int(np.ceil(np.log2(amax / FP8_MAX))) + int(margin_bits)
+
+
 def conv2d_same(x, w, b=None, relu=False):
     """tf.layers.conv2d(padding='same', strides 1) [+ relu]  (custom_layers.py:124-139).
     x: torch NCHW fp32, w: numpy HWIO."""
@@ -101,12 +132,19 @@ def deconv_same(x, w, stride, relu=False):
     return F.relu(y) if relu else y
 
 
-def fcn_forward(x_nhwc, weights, prefix, policy='fp32', keep=None):
+def fcn_forward(x_nhwc, weights, prefix, policy='fp32', keep=None, fp8_scales=None):
     """fcn() = encoder + decoder (simple_fcn.py:137-170) with batchnorm=False, no dropout.
     Returns dict of NHWC fp32 numpy arrays.  keep: iterable of layer names to return
-    (default: fused, upscore, score)."""
-    assert policy in ('fp32', 'bf16')
+    (default: fused, upscore, score).  fp8_scales: {layer: output exponent, 'w:layer': weight exponent}
+    for policy 'fp8' (missing weight exponents default to the smallest that keeps max|w| finite)."""
+    assert policy in ('fp32', 'bf16', 'fp8')
     rnd = (lambda t: t) if policy == 'fp32' else round_bf16
+    fp8_scales = fp8_scales or {}
+    # maps stored as e4m3 in the 'fp8' policy: the outputs of conv2_1 .. conv5_3 (the score convs write bf16)
+    fp8_out = set(('conv2_1',) + FP8_LAYERS[:10]) if policy == 'fp8' else set()
+
+    def rnd_out(t, name):
+        return round_e4m3(t, fp8_scales[name]) if name in fp8_out else rnd(t)
     keep = set(keep) if keep is not None else {'fused', 'upscore', 'score'}
     out = {}
 
@@ -125,7 +163,9 @@ def fcn_forward(x_nhwc, weights, prefix, policy='fp32', keep=None):
         bn = _bn(name)
         if bn is not None:          # y = s*(conv(x,W)+b)+t == conv(x, W*s) + (b*s+t): what the MI355X path folds
             w = w * bn[0]
-        if policy == 'bf16' and name != 'conv1_1':
+        if policy == 'fp8' and name in FP8_LAYERS:
+            return round_e4m3(w, fp8_scales.get('w:' + name, fp8_scale_exp(np.abs(w).max())))
+        if policy != 'fp32' and name != 'conv1_1':
             w = round_bf16(w)
         return w
 
@@ -143,7 +183,7 @@ def fcn_forward(x_nhwc, weights, prefix, policy='fp32', keep=None):
                 layers[item] = h
             else:
                 name = item[0]
-                h = rnd(conv2d_same(h, W(name), B(name), relu=True))
+                h = rnd_out(conv2d_same(h, W(name), B(name), relu=True), name)
                 layers[name] = h
         score_conv4 = rnd(conv2d_same(layers['conv4_3'], W('score_conv4'), B('score_conv4'), relu=True))
         score_conv5 = rnd(conv2d_same(layers['conv5_3'], W('score_conv5'), B('score_conv5'), relu=True))

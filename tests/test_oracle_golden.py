@@ -174,3 +174,24 @@ def test_optimizer_formulas():
     np.testing.assert_allclose(t1, th - 0.1 * g / np.sqrt(0.9 + 0.1 * g * g + 1e-10))
     t1, acc = fu.adagrad_step(th, g, np.full(2, 0.1), lr=0.1)
     np.testing.assert_allclose(t1, th - 0.1 * g / np.sqrt(0.1 + g * g))
+
+
+def test_e4m3_quantiser_matches_the_format_definition():
+    """oracle.round_e4m3 (the rounding the fp8 conv path is checked against) on the OCP e4m3fn grid: every one of the
+    256 encodings is a fixed point, in-range values round to nearest-even exactly as torch.float8_e4m3fn does, and
+    out-of-range values saturate at 448 (the kernel clamps before converting)."""
+    import torch
+    from oracle import fcn_oracle as fo
+    codes = torch.arange(256, dtype=torch.uint8).view(torch.float8_e4m3fn).float().numpy()
+    finite = np.isfinite(codes)
+    assert finite.sum() == 254 and np.abs(codes[finite]).max() == 448.0
+    assert np.array_equal(fo.round_e4m3(codes[finite]), codes[finite])
+    rng = np.random.default_rng(0)
+    x = np.concatenate([rng.standard_normal(50000) * s for s in (1e-3, 1e-2, 1, 30, 150)]).astype(np.float32)
+    x = x[np.abs(x) <= 448]
+    assert np.array_equal(fo.round_e4m3(x), torch.from_numpy(x).to(torch.float8_e4m3fn).float().numpy())
+    # ties go to the even mantissa; the subnormal step is 2^-9; saturation; power-of-two scales shift the grid
+    assert fo.round_e4m3(np.array([17.0, 19.0, 2.0 ** -10, 3 * 2.0 ** -10, 1e6, -460.0], np.float32)).tolist() == \
+        [16.0, 20.0, 0.0, 2.0 ** -8, 448.0, -448.0]
+    assert fo.round_e4m3(np.array([17.0, 1000.0], np.float32), 2).tolist() == [16.0, 1024.0]
+    assert fo.fp8_scale_exp(448.0) == 0 and fo.fp8_scale_exp(449.0) == 1 and fo.fp8_scale_exp(0.05) == -13
