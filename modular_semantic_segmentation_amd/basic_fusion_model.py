@@ -23,6 +23,22 @@ def expert_factory(expert_model):
     raise UserWarning('ERROR: Expert Model %s not found' % expert_model)
 
 
+def engine_options(config):
+    """Extra constructor arguments of the expert engines named by the model config (conv_dtype: the fp8 conv path of
+    the FCN expert; the AdapNet engine has none)."""
+    if config.get('expert_model', 'fcn') == 'fcn' and config.get('conv_dtype', 'bf16') != 'bf16':
+        return {'conv_dtype': config['conv_dtype']}
+    return {}
+
+
+def calibrate_experts(model, data):
+    """conv_dtype='fp8': fix every expert's activation scales from the first batch of `data`."""
+    from .base_model import iterate_batches
+    batch = next(iterate_batches(data, model.config['batchsize']))
+    model._graph = None
+    return {m: model.experts[m].calibrate(model._to_device(batch[m], torch.float32)) for m in model.modalities}
+
+
 def run_experts(model, batch, wants):
     """Forward every modality's expert, each on its own HIP stream: the experts are independent
     until the fusion kernel, and the tail of one stream's persistent conv grid is filled by the
@@ -71,7 +87,7 @@ class FusionModel(BaseModel):
             self.variables.update(init(prefix, cin, self.config['num_units'], self.config['num_classes'],
                                        seed=self.config.get('seed')))
             self.experts[m] = engine_cls(prefix, cin, self.config['num_units'], self.config['num_classes'],
-                                         self.variables, device=self.device)
+                                         self.variables, device=self.device, **engine_options(self.config))
         self.prediction = 'fused_label'
 
     def _modality_channels(self, m):
@@ -83,6 +99,9 @@ class FusionModel(BaseModel):
         BaseModel._variables_changed(self)
         for m in self.modalities:
             self.experts[m].load(self.variables)
+
+    def calibrate(self, data):
+        return calibrate_experts(self, data)
 
     def _expert_outputs(self, batch, wants):
         return run_experts(self, batch, wants)

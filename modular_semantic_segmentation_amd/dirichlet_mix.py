@@ -7,7 +7,7 @@ from scipy.special import gammaln
 
 from . import ops
 from .base_model import BaseModel, iterate_batches
-from .basic_fusion_model import expert_factory, run_experts, test_pipeline  # noqa: F401
+from .basic_fusion_model import calibrate_experts, engine_options, expert_factory, run_experts, test_pipeline  # noqa: F401
 from .dirichlet_fit import find_dirichlet_priors
 
 UNIFORM_PRIOR = 1.0 / 14     # dirichlet_mix.py:116
@@ -84,7 +84,7 @@ class DirichletFusion(BaseModel):
                 self.variables.update(init(m, cin, self.config['num_units'], self.config['num_classes'],
                                            seed=self.config.get('seed')))
                 self.experts[m] = engine_cls(m, cin, self.config['num_units'], self.config['num_classes'],
-                                             self.variables, device=self.device)
+                                             self.variables, device=self.device, **engine_options(self.config))
         if hasattr(self, 'dirichlet_params'):
             am1, lognorm, logprior = dirichlet_tables([self.dirichlet_params[m] for m in self.modalities],
                                                       self.class_counts, self.config['class_prior'],
@@ -100,6 +100,9 @@ class DirichletFusion(BaseModel):
         BaseModel._variables_changed(self)
         for m in self.modalities:
             self.experts[m].load(self.variables)
+
+    def calibrate(self, data):
+        return calibrate_experts(self, data)
 
     def _predict_batch_impl(self, batch, output_attr=None):
         if not hasattr(self, 'am1'):

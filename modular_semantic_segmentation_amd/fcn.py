@@ -19,6 +19,11 @@ ENCODER = [  # (name, cout, pool_after)   simple_fcn.py:39-67
     ('conv4_1', 512, None), ('conv4_2', 512, None), ('conv4_3', 512, 'pool4'),
     ('conv5_1', 512, None), ('conv5_2', 512, None), ('conv5_3', 512, None)]
 BN_EPS = 1e-3  # [TF1] tf.layers.batch_normalization default epsilon
+# conv_dtype='fp8' (BASELINE config "fp8 MFMA conv path"): the convs from 128 input channels up run on the block-scaled
+# e4m3 MFMA kernel; conv1_1 (fp32, raw input), conv1_2 and conv2_1 (64 input channels = half an fp8 MFMA) stay as they
+# are, conv2_1 writing the first fp8 map; the two 1x1 score convs read fp8 and write bf16 for the fp32 decoder head.
+FP8_CONVS = ('conv2_2', 'conv3_1', 'conv3_2', 'conv3_3', 'conv4_1', 'conv4_2', 'conv4_3', 'conv5_1', 'conv5_2', 'conv5_3')
+FP8_MAPS = ('conv2_1',) + FP8_CONVS            # conv outputs stored as e4m3 (pools inherit their conv's scale)
 
 
 def variable_shapes(prefix, in_channels, num_units, num_classes, batch_normalization=False):
@@ -80,10 +85,14 @@ def _fold_bn(variables, layer, kernel, bias):
 class FcnEngine(object):
     """One FCN expert resident on one GPU (inference graph of simple_fcn.py:137-170)."""
 
-    def __init__(self, prefix, in_channels, num_units, num_classes, variables, device='cuda'):
+    def __init__(self, prefix, in_channels, num_units, num_classes, variables, device='cuda', conv_dtype='bf16'):
         self.prefix, self.cin, self.U, self.C = prefix, int(in_channels), int(num_units), int(num_classes)
         self.device = torch.device(device)
         self.Up = ((self.U + 63) // 64) * 64      # score convs run on the MFMA kernel: pad U to 64 lanes of zeros
+        if conv_dtype not in ('bf16', 'fp8'):
+            raise ValueError("conv_dtype must be 'bf16' or 'fp8'")
+        self.conv_dtype = conv_dtype
+        self.fp8_scales = None                    # {map name: power-of-two exponent}, set by calibrate()
         self._arena = {}
         self.load(variables)
 
@@ -145,16 +154,81 @@ class FcnEngine(object):
         ws[:self.U] = k
         self.w['score'] = up(ws)
         self.b['score'] = up(b)
+        if self.conv_dtype == 'fp8':
+            # e4m3 images of the same (batch-norm folded) kernels, each with its own power-of-two scale
+            self.w8, self.w8_exp = {}, {}
+            for name in FP8_CONVS + ('score_conv4', 'score_conv5'):
+                k, _ = _fold_bn(v, '%s/%s' % (p, name), v['%s/%s/kernel' % (p, name)], v['%s/%s/bias' % (p, name)])
+                if name == 'score_conv5' and 'upscore_conv5' in deconv_scale:
+                    k = k * deconv_scale['upscore_conv5']
+                if name.startswith('score_conv'):
+                    kp = np.zeros((1, 1, 512, self.Up), np.float32)
+                    kp[..., :self.U] = k
+                    k = kp
+                self.w8[name], self.w8_exp[name] = ops.pack_conv_weights_f8(up(k))
         torch.cuda.synchronize(dev)
 
     # ---- activations ---------------------------------------------------------------------------
-    def _act(self, name, n, h, w, c):
-        key = (name, n, h, w, c)
+    def _act(self, name, n, h, w, c, dtype='bf16', scale_exp=0):
+        key = (name, n, h, w, c, dtype)
         a = self._arena.get(key)
         if a is None:
-            a = ops.Act(n, h, w, c, self.device)
+            a = ops.Act(n, h, w, c, self.device, dtype=dtype, scale_exp=scale_exp)
             self._arena[key] = a
+        elif a.scale_exp != scale_exp:
+            a.set_scale_exp(scale_exp)
         return a
+
+    # ---- fp8: static per-tensor scales -----------------------------------------------------------------------
+    def calibrate(self, x, margin_bits=1):
+        """Choose the power-of-two scale of every fp8 activation map from one representative batch: run the bf16
+        graph, take max|activation| per layer, and leave `margin_bits` of headroom (an e4m3 value keeps its 3
+        mantissa bits anywhere in 2^-6 .. 2^8 of the scale, so headroom costs no precision; values beyond it
+        saturate at 448 * 2^e).  Returns the exponents; they stay fixed until the next call (static calibration:
+        no data-dependent work on the inference path)."""
+        dtype, self.conv_dtype = self.conv_dtype, 'bf16'
+        try:
+            L = self.encoder(x, keep_all=True)
+        finally:
+            self.conv_dtype = dtype
+        self.fp8_scales = {name: ops.fp8_scale_exp(L[name].interior().abs().max().item(), margin_bits)
+                           for name in FP8_MAPS}
+        return dict(self.fp8_scales)
+
+    def _encoder_fp8(self, x, keep_all=False):
+        """The trunk with e4m3 operands from conv2_2 on (see FP8_CONVS); same layer dict as `encoder`."""
+        if self.fp8_scales is None:
+            self.calibrate(x)           # first batch seen = calibration batch
+        n, h, w, _ = x.shape
+        e = self.fp8_scales
+        L = {}
+        cur = self._act('conv1_1', n, h, w, 64)
+        ops.conv2d_first_fwd(x.contiguous(), self.w['conv1_1'], self.b['conv1_1'], cur, relu=True)
+        L['conv1_1'] = cur
+        ch, cw = h, w
+        for name, cout, pool in ENCODER[1:]:
+            f8_in = name in FP8_CONVS
+            f8_out = name in FP8_MAPS
+            wts = self.w8[name] if f8_in else self.w[name]
+            kw = dict(dtype='fp8', scale_exp=e[name]) if f8_out else {}
+            if pool is None:
+                y = self._act(name, n, ch, cw, cout, **kw)
+                ops.conv2d_fwd(cur, wts, self.b[name], 3, relu=True, y=y)
+                L[name] = cur = y
+            else:
+                q = self._act(pool, n, ch // 2, cw // 2, cout, **kw)
+                need_full = keep_all or name == 'conv4_3'
+                y = self._act(name, n, ch, cw, cout, **kw) if need_full else None
+                ops.conv2d_fwd(cur, wts, self.b[name], 3, relu=True, y=y, pooled=q, write_y=need_full)
+                if y is not None:
+                    L[name] = y
+                L[pool] = cur = q
+                ch, cw = ch // 2, cw // 2
+        s4 = self._act('score_conv4', n, h // 8, w // 8, self.Up)
+        ops.conv2d_fwd(L['conv4_3'], self.w8['score_conv4'], self.b['score_conv4'], 1, relu=True, y=s4)
+        s5 = self._act('score_conv5', n, h // 16, w // 16, self.Up)
+        ops.conv2d_fwd(L['conv5_3'], self.w8['score_conv5'], self.b['score_conv5'], 1, relu=True, y=s5)
+        return L, s4, s5
 
     def encoder(self, x, keep_all=False):
         """x: float32 [N,H,W,cin] device tensor (raw 0..255 RGB / raw depth, data contract of
@@ -165,29 +239,32 @@ class FcnEngine(object):
             raise ValueError('expected %d input channels, got %d' % (self.cin, cin))
         if h % 16 or w % 16:
             raise ValueError('H and W must be multiples of 16 (augmentation.py:244-262 crop_multiple)')
-        L = {}
-        cur = self._act('conv1_1', n, h, w, 64)
-        ops.conv2d_first_fwd(x.contiguous(), self.w['conv1_1'], self.b['conv1_1'], cur, relu=True)
-        L['conv1_1'] = cur
-        ch, cw = h, w
-        for name, cout, pool in ENCODER[1:]:
-            if pool is None:
-                y = self._act(name, n, ch, cw, cout)
-                ops.conv2d_fwd(cur, self.w[name], self.b[name], 3, relu=True, y=y)
-                L[name] = cur = y
-            else:
-                q = self._act(pool, n, ch // 2, cw // 2, cout)
-                need_full = keep_all or name == 'conv4_3'       # conv4_3 feeds score_conv4
-                y = self._act(name, n, ch, cw, cout) if need_full else None
-                ops.conv2d_fwd(cur, self.w[name], self.b[name], 3, relu=True, y=y, pooled=q, write_y=need_full)
-                if y is not None:
-                    L[name] = y
-                L[pool] = cur = q
-                ch, cw = ch // 2, cw // 2
-        s4 = self._act('score_conv4', n, h // 8, w // 8, self.Up)
-        ops.conv2d_fwd(L['conv4_3'], self.w['score_conv4'], self.b['score_conv4'], 1, relu=True, y=s4)
-        s5 = self._act('score_conv5', n, h // 16, w // 16, self.Up)
-        ops.conv2d_fwd(L['conv5_3'], self.w['score_conv5'], self.b['score_conv5'], 1, relu=True, y=s5)
+        if self.conv_dtype == 'fp8':
+            L, s4, s5 = self._encoder_fp8(x, keep_all)
+        else:
+            L = {}
+            cur = self._act('conv1_1', n, h, w, 64)
+            ops.conv2d_first_fwd(x.contiguous(), self.w['conv1_1'], self.b['conv1_1'], cur, relu=True)
+            L['conv1_1'] = cur
+            ch, cw = h, w
+            for name, cout, pool in ENCODER[1:]:
+                if pool is None:
+                    y = self._act(name, n, ch, cw, cout)
+                    ops.conv2d_fwd(cur, self.w[name], self.b[name], 3, relu=True, y=y)
+                    L[name] = cur = y
+                else:
+                    q = self._act(pool, n, ch // 2, cw // 2, cout)
+                    need_full = keep_all or name == 'conv4_3'       # conv4_3 feeds score_conv4
+                    y = self._act(name, n, ch, cw, cout) if need_full else None
+                    ops.conv2d_fwd(cur, self.w[name], self.b[name], 3, relu=True, y=y, pooled=q, write_y=need_full)
+                    if y is not None:
+                        L[name] = y
+                    L[pool] = cur = q
+                    ch, cw = ch // 2, cw // 2
+            s4 = self._act('score_conv4', n, h // 8, w // 8, self.Up)
+            ops.conv2d_fwd(L['conv4_3'], self.w['score_conv4'], self.b['score_conv4'], 1, relu=True, y=s4)
+            s5 = self._act('score_conv5', n, h // 16, w // 16, self.Up)
+            ops.conv2d_fwd(L['conv5_3'], self.w['score_conv5'], self.b['score_conv5'], 1, relu=True, y=s5)
         fused = self._act('fused', n, h // 8, w // 8, self.Up)
         aff = self.affine.get('upscore_conv5', (None, None))
         ops.upsample2x_relu_add(s5, residual=s4, y=fused, scale=aff[0], shift=aff[1])

@@ -61,7 +61,8 @@ class SimpleFCN(BaseModel):
                                         batch_normalization=self.config['batch_normalization'],
                                         seed=self.config.get('seed'))
         self.engine = FcnEngine(self.prefix, self.in_channels, self.config['num_units'],
-                                self.config['num_classes'], self.variables, device=self.device)
+                                self.config['num_classes'], self.variables, device=self.device,
+                                conv_dtype=self.config.get('conv_dtype', 'bf16'))
         self.loss = None            # scalar of the last training step (set by _train_batch)
         self.prediction = 'label'   # name of the engine output that is the model's prediction
 
@@ -74,7 +75,16 @@ class SimpleFCN(BaseModel):
             sync_trainer_from_rank0(self.trainer)
 
     # ---- training (base_model.py:153-162,180-261) ------------------------------------------------------
+    def calibrate(self, data):
+        """conv_dtype='fp8': fix the activation scales from the first batch of `data` (FcnEngine.calibrate)."""
+        from .base_model import iterate_batches
+        batch = next(iterate_batches(data, self.config['batchsize']))
+        self._graph = None
+        return self.engine.calibrate(self._to_device(batch[self.modality], torch.float32))
+
     def _ensure_trainer(self):
+        if self.engine.conv_dtype != 'bf16':
+            raise UserWarning("ERROR: conv_dtype='fp8' is an inference configuration; train with conv_dtype='bf16'")
         if getattr(self, 'trainer', None) is None:
             from .trainer import FcnBnTrainer, FcnTrainer
             from .parallel import GradReducer, require_equal_batchsize, sync_trainer_from_rank0, world

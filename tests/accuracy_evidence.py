@@ -62,6 +62,31 @@ def _miou(labels, pred):
     return float(score_measures(cm)['mean_IoU']), cm
 
 
+def hip_predictions_fp8(variables, calibration, heldout, cms, device='cuda'):
+    """The same experts with conv_dtype='fp8' (BASELINE config "fp8 MFMA conv path"): scales calibrated on a batch of the
+    training set, then each expert's labels and the Bayes fusion of them on `heldout`."""
+    from modular_semantic_segmentation_amd import get_model
+    from modular_semantic_segmentation_amd.datasets.synthetic import data_description
+    desc = data_description()
+    out = {}
+    for m, cin in MODS:
+        net = get_model('fcn')(m, desc, m, num_units=U, batch_normalization=False, batchsize=4, device=str(device),
+                               conv_dtype='fp8')
+        net.variables.update({k: v for k, v in variables.items() if k.startswith(m + '/')})
+        net._variables_changed()
+        net.calibrate(calibration)
+        out[m] = net.predict(heldout)
+    bayes = get_model('bayes_fusion')(confusion_matrices=cms, prefixes={'rgb': 'rgb', 'depth': 'depth'},
+                                      data_description=desc, num_units=U, num_channels={'rgb': 3, 'depth': 1},
+                                      expert_model='fcn', class_prior='data', batchsize=4, device=str(device),
+                                      conv_dtype='fp8')
+    bayes.variables.update(variables)
+    bayes._variables_changed()
+    bayes.calibrate(calibration)
+    out['bayes'] = bayes.predict(heldout)
+    return out
+
+
 def hip_predictions(variables, measure, heldout, device='cuda'):
     """HIP path: expert confusion matrices and the Dirichlet fit on `measure` (the flows of
     experiments/bayes_fusion.py:146-195 and dirichlet_fusion.py:58-81), then every model's labels (and the experts'
@@ -140,7 +165,7 @@ def compare(hip, ref, labels):
     return res
 
 
-def run(h=384, w=768, steps=1500, batch=8, n_heldout=8, n_measure=16, device='cuda', log=None):
+def run(h=384, w=768, steps=1500, batch=8, n_heldout=8, n_measure=16, device='cuda', log=None, fp8=True):
     """The whole protocol; returns (accuracy dict, oracle seconds, oracle images)."""
     from modular_semantic_segmentation_amd.datasets.synthetic import make_rgbd_shapes
     variables, train = train_experts(h, w, steps, batch=batch, device=device, log=log)
@@ -149,6 +174,13 @@ def run(h=384, w=768, steps=1500, batch=8, n_heldout=8, n_measure=16, device='cu
     hip, cms, dparams = hip_predictions(variables, measure, heldout, device=device)
     ref, dt, n = oracle_predictions(variables, heldout, cms, dparams)
     acc = compare(hip, ref, heldout['labels'])
+    if fp8:
+        hip8 = hip_predictions_fp8(variables, measure, heldout, cms, device=device)
+        acc['fp8'] = {}
+        for k in ('rgb', 'depth', 'bayes'):
+            a, _ = _miou(heldout['labels'], hip8[k])
+            acc['fp8'][k] = {'miou_hip_fp8': round(a, 5), 'delta_miou_pp_vs_fp32': round(100 * (a - acc[k]['miou_fp32_oracle']), 4),
+                             'label_agreement_vs_fp32': round(float((hip8[k] == ref[k]).mean()), 6)}
     acc['protocol'] = ('experts trained %d Adam steps x %d images on procedural RGB-D shapes at %dx%d through the HIP fit(); '
                        '%d held-out images; same trained weights through the HIP bf16 path and the fp32 CPU oracle; '
                        'mean IoU over classes 1..%d (base_model.py:329)' % (steps, batch, w, h, n_heldout, C - 1))

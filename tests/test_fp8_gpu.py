@@ -163,3 +163,115 @@ def test_fp8_conv_random_operands_and_weight_packing(ops):
     got8, ref8 = y8.real().cpu().numpy(), fo.round_e4m3(y32, ey)
     assert (got8 != ref8).mean() < 2e-3
     np.testing.assert_allclose(got8, ref8, rtol=2.0 ** -3, atol=2.0 ** (ey - 9))
+
+
+def _weights(prefix, cin, seed, scale_first):
+    w = fo.init_fcn_weights(prefix, cin, 64, 12, seed=seed, bias_scale=0.02)
+    w['%s/conv1_1/kernel' % prefix] *= scale_first
+    for k in w:
+        if k.endswith('/kernel') and 'upscore' not in k and 'conv1_1' not in k:
+            w[k] *= 1.6                       # keeps the activations of a random-init net from dying out
+    return w
+
+
+@pytest.mark.parametrize('h,w', [(64, 96), (384, 768)])
+def test_fp8_engine_against_fp8_policy_oracle(ops, h, w):
+    """The whole expert with conv_dtype='fp8' against the oracle that quantises at the same points with the same
+    scales (the engine's own calibration).  Layer by layer the two differ only where fp32 accumulation order moves a
+    value across an e4m3 rounding boundary (one grid step = 6-12 % of the value, on a small fraction of the
+    elements); end to end (flips compound through ten coarse-grid layers) the logits stay within 12 % of the logit scale and the
+    labels agree wherever the oracle's margin is clear.  Also reported: agreement with the fp32 graph (the cost of 3-bit mantissas, not a kernel
+    property)."""
+    from modular_semantic_segmentation_amd.fcn import FP8_MAPS, FcnEngine
+    wts = _weights('rgb', 3, 1, 0.02)
+    rng = np.random.default_rng(0)
+    x = rng.integers(0, 256, (1, h, w, 3)).astype(np.float32)
+    eng = FcnEngine('rgb', 3, 64, 12, wts, conv_dtype='fp8')
+    xd = torch.from_numpy(x).cuda()
+    scales = eng.calibrate(xd)
+    assert sorted(scales) == sorted(FP8_MAPS)
+    out = eng.forward(xd, want=('score', 'label'), keep_all=True)
+    torch.cuda.synchronize()
+    fs = dict(scales)
+    fs.update({'w:' + k: v for k, v in eng.w8_exp.items()})
+    keep = ['conv2_1', 'conv2_2', 'conv3_3', 'conv4_3', 'conv5_3', 'fused', 'score']
+    ref = fo.fcn_forward(x, wts, 'rgb', 'fp8', keep=keep, fp8_scales=fs)
+    L = out['layers']
+    # ---- every fp8 layer on the GPU's OWN input map: oracle conv of the same e4m3 operands, then the same output
+    # rounding.  Only fp32 accumulation order separates the two, so they differ on the few values that sit on an
+    # e4m3 rounding boundary, by one grid step.
+    from modular_semantic_segmentation_amd.fcn import ENCODER, FP8_CONVS
+    prev = None
+    for name, cout, pool in ENCODER:
+        if name in FP8_CONVS:
+            xin = L[prev].real().cpu().numpy()
+            wq = fo.round_e4m3(wts['rgb/%s/kernel' % name], eng.w8_exp[name])
+            y32 = _nhwc(_oracle(xin, wq, wts['rgb/%s/bias' % name], True))
+            want = fo.round_e4m3(y32, scales[name])
+            got = L[name].real().cpu().numpy()
+            flips = got != want
+            assert flips.mean() < 1e-2, (name, flips.mean())
+            np.testing.assert_allclose(got, want, rtol=0.13, atol=5e-3 * np.abs(want).max(), err_msg=name)
+            if pool:
+                assert np.array_equal(L[pool].real().cpu().numpy(),
+                                      _nhwc(fo.maxpool2(torch.from_numpy(got).permute(0, 3, 1, 2))))
+        prev = pool if pool else name
+    for name, src in (('score_conv4', 'conv4_3'), ('score_conv5', 'conv5_3')):
+        kp = np.zeros((1, 1, 512, 64), np.float32)
+        kp[...] = wts['rgb/%s/kernel' % name]
+        y32 = _nhwc(_oracle(L[src].real().cpu().numpy(), fo.round_e4m3(kp, eng.w8_exp[name]), wts['rgb/%s/bias' % name], True))
+        got = L[name].interior().float().cpu().numpy()
+        np.testing.assert_allclose(got, fo.round_bf16(y32), rtol=2.0 ** -7, atol=1e-4 * np.abs(y32).max(), err_msg=name)
+    # ---- end to end against the oracle run from the image: rounding flips compound through 10 coarse-grid layers of a
+    # random-init network (the first fp8 maps agree almost everywhere, deeper ones drift)
+    for name, max_flip in (('conv2_1', 2e-3), ('conv2_2', 2e-2)):
+        got = L[name].real().cpu().numpy()
+        assert (got != ref[name]).mean() < max_flip, (name, (got != ref[name]).mean())
+    for name, tol in (('conv3_3', 0.03), ('conv4_3', 0.1), ('conv5_3', 0.15)):
+        got = L[name].real().cpu().numpy()
+        err = np.abs(got - ref[name]).mean() / (np.abs(ref[name]).mean() + 1e-20)
+        assert err < tol, (name, err)
+    got, want = out['score'].cpu().numpy(), ref['score']
+    scale = np.abs(want).max()
+    print('fp8 path vs fp8-policy oracle at %dx%d: max logit error %.4f of scale' % (w, h, np.abs(got - want).max() / scale))
+    assert np.abs(got - want).max() / scale < 0.12
+    lab, ref_lab = out['label'].cpu().numpy(), fo.argmax_last(fo.softmax(want))
+    assert np.array_equal(lab, fo.argmax_last(fo.softmax(got)))
+    top2 = np.sort(want, -1)[..., -2:]
+    clear = (top2[..., 1] - top2[..., 0]) > 0.24 * scale
+    assert np.array_equal(lab[clear], ref_lab[clear])
+    # (overall agreement on random-init weights says little: the logits of an untrained net are nearly degenerate and
+    # ten coarse-grid layers are chaotic under rounding flips; trained weights: tests/test_accuracy_gpu.py)
+    print('label agreement with the fp8-policy oracle: %.4f' % (lab == ref_lab).mean())
+    ref32 = fo.fcn_forward(x, wts, 'rgb', 'fp32', keep=['score'])['score']
+    print('fp8 vs fp32 graph at %dx%d: label agreement %.4f, max logit error %.3f of scale' % (
+        w, h, (lab == fo.argmax_last(fo.softmax(ref32))).mean(), np.abs(got - ref32).max() / np.abs(ref32).max()))
+
+
+def test_fp8_fusion_model_predicts(ops, golden_dir):
+    """conv_dtype='fp8' through the model API: BayesFusion calibrates on the first batch it sees and predicts; the
+    bf16 model on the same weights mostly agrees."""
+    import os
+    from modular_semantic_segmentation_amd import get_model
+    g = np.load(os.path.join(golden_dir, 'notebook_868.npz'))
+    desc = ({'rgb': 'float32', 'depth': 'float32', 'labels': 'int32'},
+            {'rgb': (None, None, 3), 'depth': (None, None, 1), 'labels': (None, None)}, 12)
+    cfg = dict(data_description=desc, confusion_matrices={'rgb': g['cm_rgb'], 'depth': g['cm_depth']}, num_units=64,
+               prefixes={'rgb': 'rgb', 'depth': 'depth'}, num_channels={'rgb': 3, 'depth': 1}, expert_model='fcn',
+               class_prior='data', batchsize=2, seed=3)
+    rng = np.random.default_rng(1)
+    data = {'rgb': rng.integers(0, 256, (2, 64, 96, 3)).astype(np.float32),
+            'depth': rng.integers(0, 65536, (2, 64, 96, 1)).astype(np.float32)}
+    preds = {}
+    for dt in ('bf16', 'fp8'):
+        net = get_model('bayes_fusion')(conv_dtype=dt, **cfg)
+        net.variables['depth/conv1_1/kernel'] = net.variables['depth/conv1_1/kernel'] / 256.0
+        net._variables_changed()
+        if dt == 'fp8':
+            scales = net.calibrate(data)
+            assert set(scales) == {'rgb', 'depth'}
+        preds[dt] = net.predict(data)
+        la = net.expert_outputs['rgb']['classification']
+        assert la.shape == (2, 64, 96)
+    assert preds['fp8'].shape == (2, 64, 96) and preds['fp8'].dtype == np.int64
+    assert (preds['fp8'] == preds['bf16']).mean() > 0.5      # random-init logits are nearly degenerate
