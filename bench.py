@@ -4,12 +4,22 @@ fusion + argmax at 768x384 on MI355X (BASELINE.json configs[1]); protocol of the
 experiments/timing.py (inputs resident on the device, wall clock around the whole pipeline).
 
   python bench.py [--gpus N --steps K --warmup W] [--batch B] [--height 384 --width 768]
-                  [--fusion bayes|dirichlet|joint] [--no-cpu-baseline]
+                  [--fusion bayes|dirichlet|joint] [--dtype bf16|fp8] [--mode infer|train]
+                  [--no-cpu-baseline] [--no-accuracy] [--no-extra]
 N > 1 is launched by the driver through torch.distributed.run (one rank per GPU); images are
 independent, so ranks shard the batch with no data-path collective ("weak" scaling) and only the
-timing is reduced (MAX over ranks).  Rank 0 prints ONE JSON line.
+timing is reduced (MAX over ranks).  Rank 0 prints ONE JSON line:
+
+  metric / value / roofline / cpu_baseline   the headline workload (contract of the driver)
+  accuracy     mean IoU of the HIP bf16 and fp8 paths against the fp32 oracle on TRAINED experts (N = 1)
+  extra        the other BASELINE.json configurations, each with its own roofline fraction: the reference's
+               timing.py protocol (batch 1, tf.ones input, label map fetched to the host), 1024x512 Bayes,
+               2048x1024 bf16 and fp8, Dirichlet fusion, the training step
+  train_dp     N > 1: the data-parallel training step (bucketed RCCL all-reduce overlapped with backward) with the
+               exposed all-reduce time -- the collective path an inference scaling curve never touches
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -21,7 +31,8 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-PEAK_BF16_TFLOPS = 2500.0     # dense bf16 MFMA, MI355X_MICROARCH.md chip table
+_JSON_OUT = sys.stdout
+PEAK_TFLOPS = {'bf16': 2500.0, 'fp8': 5000.0}     # dense MFMA, MI355X_MICROARCH.md chip table
 C, U = 12, 64
 
 
@@ -57,21 +68,21 @@ def adapnet_flops_per_image(h, w, cin):
     return f + 2.0 * (h // 16) * (w // 16) * 2048 * U
 
 
-def build_model(args, device):
+def build_model(device, fusion='bayes', expert='fcn', batch=16, dtype='bf16'):
     from modular_semantic_segmentation_amd import get_model
     g = np.load(os.path.join(ROOT, 'tests', 'golden', 'notebook_868.npz'))
     desc = ({'rgb': 'float32', 'depth': 'float32', 'labels': 'int32'},
             {'rgb': (None, None, 3), 'depth': (None, None, 1), 'labels': (None, None)}, C)
-    common = dict(data_description=desc, num_units=U, num_channels={'rgb': 3, 'depth': 1}, expert_model=args.expert,
-                  class_prior='data', batchsize=args.batch, seed=1, device=str(device))
-    if args.fusion == 'joint':
+    common = dict(data_description=desc, num_units=U, num_channels={'rgb': 3, 'depth': 1}, expert_model=expert,
+                  class_prior='data', batchsize=batch, seed=1, device=str(device), conv_dtype=dtype)
+    if fusion == 'joint':
         # the reference's joint baseline fusion_fcn (experiments/timing.py:24-45): two VGG16 trunks + fused decoder
         net = get_model('fusion_fcn')({'rgb': 'rgb', 'depth': 'depth'}, {'rgb': 3, 'depth': 1}, U, C,
-                                      batchsize=args.batch, seed=1, device=str(device))
+                                      batchsize=batch, seed=1, device=str(device))
         net.variables['depth_conv1_1/kernel'] = net.variables['depth_conv1_1/kernel'] / 256.0
         net._variables_changed()
         return net
-    if args.fusion == 'bayes':
+    if fusion == 'bayes':
         net = get_model('bayes_fusion')(confusion_matrices={'rgb': g['cm_rgb'], 'depth': g['cm_depth']},
                                         prefixes={'rgb': 'rgb', 'depth': 'depth'}, **common)
     else:
@@ -81,20 +92,26 @@ def build_model(args, device):
         net = get_model('dirichlet_fusion')(dirichlet_params=params, modalities=['rgb', 'depth'], sigma=1.0,
                                             delta=1e-2, beta=1e-2, **common)
     # a trained depth expert absorbs the raw uint16 range in conv1_1; random init needs the scale
-    first = 'depth/conv1_1/kernel' if args.expert == 'fcn' else 'depth/block_0_1/kernel'
+    first = 'depth/conv1_1/kernel' if expert == 'fcn' else 'depth/block_0_1/kernel'
     net.variables[first] = net.variables[first] / 256.0
     net._variables_changed()
     return net
 
 
-def cpu_baseline(args, variables, cms):
-    """The oracle (op-for-op fp32 restatement of the reference graph) timed on this host's cores
-    on a bounded sample of the same workload: whole 768x384 RGB-D images, one at a time."""
-    from oracle import fcn_oracle as fo
-    from oracle import fusion_oracle as fu
+def synthetic_batch(device, batch, h, w, seed, ones=False):
+    """rgb = integers(0, 256), depth = integers(0, 65536); ones=True: the degenerate tf.ones input of
+    experiments/timing.py:26-27."""
+    if ones:
+        return {'rgb': torch.ones((batch, h, w, 3), device=device), 'depth': torch.ones((batch, h, w, 1), device=device)}
+    gen = torch.Generator(device='cpu').manual_seed(seed)
+    return {'rgb': torch.randint(0, 256, (batch, h, w, 3), generator=gen).float().to(device),
+            'depth': torch.randint(0, 65536, (batch, h, w, 1), generator=gen).float().to(device)}
+
+
+def pick_cpu_threads(h, w):
+    """The thread count that runs a mid-network conv fastest (all logical CPUs is not it on a big host)."""
     avail = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
-    # pick the thread count that runs a mid-network conv fastest (all logical CPUs is not it on a big host)
-    probe_x = torch.randn(1, 256, args.height // 4, args.width // 4)
+    probe_x = torch.randn(1, 256, h // 4, w // 4)
     probe_w = torch.randn(256, 256, 3, 3)
     best = (None, 1)
     for nthr in sorted({min(avail, c) for c in (8, 16, 32, 64, 128)}):
@@ -106,8 +123,15 @@ def cpu_baseline(args, variables, cms):
         dtp = time.perf_counter() - t0
         if best[0] is None or dtp < best[0]:
             best = (dtp, nthr)
-    cores = best[1]
-    torch.set_num_threads(cores)
+    torch.set_num_threads(best[1])
+    return best[1], avail
+
+
+def cpu_baseline_random(args, variables, cms, cores, avail):
+    """The oracle (op-for-op fp32 restatement of the reference graph) timed on this host's cores on a bounded sample
+    of the headline workload: whole 768x384 RGB-D images of the synthetic input, one at a time."""
+    from oracle import fcn_oracle as fo
+    from oracle import fusion_oracle as fu
     rng = np.random.default_rng(0)
     mats = [cms['rgb'].astype('float32').T, cms['depth'].astype('float32').T]
 
@@ -131,55 +155,251 @@ def cpu_baseline(args, variables, cms):
                       % (n, args.width, args.height, dt, cores, avail)}
 
 
-def bench_train(args, device, world, rank, dist):
-    """Data-parallel expert training: every rank differentiates its own images, gradients are
-    all-reduced in three buckets on a side stream during backward (RCCL over xGMI)."""
+def accuracy_and_cpu_baseline(args, device, cores, avail):
+    """cpu_baseline leg with the accuracy evidence folded in: both SimpleFCN experts are trained on the procedural
+    RGB-D task through the HIP fit(), the held-out images go through the HIP path (bf16 and fp8) and through the
+    fp32 oracle -- that oracle pass is the timed CPU sample (same workload: two experts + fusion, 768x384, batch 1)."""
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    import accuracy_evidence as ae
+    from modular_semantic_segmentation_amd.datasets.synthetic import make_rgbd_shapes
+    h, w = args.height, args.width
+    variables, train = ae.train_experts(h, w, args.accuracy_steps, batch=8, device=device)
+    measure = {k: v[:16] for k, v in train.items()}
+    heldout = make_rgbd_shapes(args.accuracy_images, h, w, seed=1001)
+    hip, cms, dparams = ae.hip_predictions(variables, measure, heldout, device=device)
+    hip8 = ae.hip_predictions_fp8(variables, measure, heldout, cms, device=device)
+    ref, dt, n = ae.oracle_predictions(variables, heldout, cms, dparams)
+    acc = ae.compare(hip, ref, heldout['labels'])
+    acc['fp8'] = {}
+    for k in ('rgb', 'depth', 'bayes'):
+        a, _ = ae._miou(heldout['labels'], hip8[k])
+        acc['fp8'][k] = {'miou_hip_fp8': round(a, 5),
+                         'delta_miou_pp_vs_fp32': round(100 * (a - acc[k]['miou_fp32_oracle']), 4),
+                         'label_agreement_vs_fp32': round(float((hip8[k] == ref[k]).mean()), 6)}
+    acc['protocol'] = ('both experts trained %d Adam steps x 8 images on procedural RGB-D shapes (datasets/synthetic.py) at '
+                       '%dx%d through the HIP fit(); %d held-out images; the same trained weights through the HIP path and '
+                       'the fp32 CPU oracle; mean IoU over classes 1..%d (base_model.py:329)'
+                       % (args.accuracy_steps, w, h, n, C - 1))
+    base = {'value': n / dt, 'unit': 'images/s', 'cores': cores, 'kind': 'port',
+            'sample': '%d held-out RGB-D images of %dx%d, batch 1, fp32 PyTorch-CPU oracle (two trained FCN experts + Bayes '
+                      'and Dirichlet fusion), %.1f s, %d threads (fastest of a probe; %d logical CPUs available)'
+                      % (n, w, h, dt, cores, avail)}
+    return acc, base
+
+
+def fence(device, world, dist):
+    torch.cuda.synchronize(device)
+    if world > 1:
+        dist.barrier()
+        torch.cuda.synchronize(device)
+
+
+def measure_inference(net, batch, device, steps, warmup, graph=True, serial=False, world=1, dist=None, fetch=False):
+    """Timed region + per-kernel roofline pass of one inference configuration.  Returns (seconds of the timed region
+    on this rank, [per-iteration seconds] if fetch, conv profile list, seconds of the serialised pass)."""
+    from modular_semantic_segmentation_amd import ops
+    net.concurrent_experts = not serial
+    net._graph = None
+
+    def step():
+        return net._predict_batch(batch)
+
+    for _ in range(warmup):
+        step()
+    if graph:
+        net.capture_graph(batch)
+        g = net._graph[0]
+
+        def step():             # noqa: F811  (inputs already sit in the graph's static buffers)
+            g.replay()
+            return net._graph[2]
+        step()
+    fence(device, world, dist)
+    per_iter = []
+    t0 = time.perf_counter()
+    if fetch:
+        # experiments/timing.py:38-45: wall clock around every sess.run, whose fetch hands the label map to the host
+        for _ in range(steps):
+            ts = time.perf_counter()
+            step().cpu()
+            per_iter.append(time.perf_counter() - ts)
+    else:
+        for _ in range(steps):
+            step()
+    fence(device, world, dist)
+    dt = time.perf_counter() - t0
+
+    # Per-kernel roofline pass: the same steps with the two experts serialised on one stream, so that a HIP-event
+    # pair around a conv launch (recorded on the launch stream) times that kernel alone (in the timed region above
+    # the RGB and depth experts overlap on two streams).
+    prof = []
+    net._graph = None
+    net.concurrent_experts = False
+    net._predict_batch(batch)
+    ops.CONV_PROFILE = prof
+    torch.cuda.synchronize(device)
+    ts = time.perf_counter()
+    for _ in range(steps):
+        net._predict_batch(batch)
+    torch.cuda.synchronize(device)
+    dt_serial = time.perf_counter() - ts
+    ops.CONV_PROFILE = None
+    net.concurrent_experts = not serial
+    return dt, per_iter, prof, dt_serial
+
+
+def roofline_of(prof, kinds, peak, kernel, dt_serial, steps, traffic=None):
+    fl = sec = 0.0
+    cnt = 0
+    for kind, flops, e0, e1 in prof:
+        if kind in kinds:
+            fl += flops
+            sec += e0.elapsed_time(e1) * 1e-3
+            cnt += 1
+    if cnt == 0 or sec <= 0:
+        return None
+    achieved = fl / sec / 1e12
+    return {'bound': 'mfma', 'kernel': kernel, 'achieved': round(achieved, 2), 'peak': peak, 'unit': 'TFLOP/s',
+            'frac': round(achieved / peak, 4), 'traffic': traffic, 'launches': cnt,
+            'avg_launch_ms': round(sec / cnt * 1e3, 4), 'gflop_per_launch': round(fl / cnt / 1e9, 2),
+            'measured': 'HIP events per launch, experts serialised on one stream (%.3f ms/step)' % (dt_serial / steps * 1e3)}
+
+
+def committed_traffic(batch, h, w):
+    """HBM bytes per conv launch from the committed rocprofv3 FETCH_SIZE / WRITE_SIZE passes of this same command
+    (tools/pmc_summary.py): PMC counters cannot be read from inside the process.  The counters were collected on ONE
+    version of the kernel: a summary of another version (source hash) is not reported."""
+    pdir = os.path.join(ROOT, 'profiles')
+    tfiles = sorted(f for f in os.listdir(pdir) if f.endswith('_conv_traffic.json')) if os.path.isdir(pdir) else []
+    if not tfiles or (h, w) != (384, 768):
+        return None
+    tj = json.load(open(os.path.join(pdir, tfiles[-1])))
+    src = os.path.join(ROOT, 'modular_semantic_segmentation_amd', 'csrc', 'conv_mfma.hip')
+    sha = hashlib.sha256(open(src, 'rb').read()).hexdigest()[:16]
+    if tj.get('batch') == batch and tj.get('kernel_source_sha256_16') == sha:
+        return tj.get('hbm_bytes_per_launch')
+    return None
+
+
+def extra_inference(device, label, fusion, batch, h, w, dtype='bf16', steps=10, warmup=2, ones=False, fetch=False):
+    """One more BASELINE.json configuration as an `extra` record (its own model, graph and roofline pass)."""
+    net = build_model(device, fusion=fusion, batch=batch, dtype=dtype)
+    data = synthetic_batch(device, batch, h, w, seed=77, ones=ones)
+    if dtype == 'fp8':
+        net.calibrate(data)
+    dt, per_iter, prof, dt_serial = measure_inference(net, data, device, steps, warmup, fetch=fetch)
+    rec = {'workload': label, 'images_per_step': batch, 'dtype': dtype, 'value': round(batch * steps / dt, 2),
+           'unit': 'images/s', 'ms_per_step': round(dt / steps * 1e3, 3)}
+    if fetch:
+        rec['seconds_per_image_mean_std'] = [round(float(np.mean(per_iter)), 6), round(float(np.std(per_iter)), 6)]
+    if dtype == 'fp8':
+        rec['roofline'] = roofline_of(prof, ('k3f8',), PEAK_TFLOPS['fp8'],
+                                      'conv_mfma_kernel<F8> (v_mfma_scale_f32_16x16x128_f8f6f4, 3x3 launches on e4m3 operands)',
+                                      dt_serial, steps)
+        rec['roofline_bf16_layers'] = roofline_of(prof, ('k3',), PEAK_TFLOPS['bf16'], 'conv1_2 / conv2_1 (bf16 operands)',
+                                                  dt_serial, steps)
+    else:
+        rec['roofline'] = roofline_of(prof, ('k3',), PEAK_TFLOPS['bf16'], 'conv_dma_kernel / conv_mfma_kernel (3x3, all launches)',
+                                      dt_serial, steps)
+    flops_img = conv_flops_per_image(h, w, 3) + conv_flops_per_image(h, w, 1)
+    rec['conv_tflops_end_to_end'] = round(batch * steps * flops_img / dt / 1e12, 2)
+    del net
+    torch.cuda.empty_cache()
+    return rec
+
+
+def make_trainer_net(args, device, expert, joint, batch):
     from modular_semantic_segmentation_amd import get_model
     desc = ({'rgb': 'float32', 'labels': 'int32'}, {'rgb': (None, None, 3), 'labels': (None, None)}, C)
-    joint = args.fusion == 'joint' and args.expert == 'fcn'
-    adap = args.expert == 'adapnet'
-    gen = torch.Generator(device='cpu').manual_seed(99 + rank)
-    rgb = torch.randint(0, 256, (args.batch, args.height, args.width, 3), generator=gen).float().to(device)
-    labels = torch.randint(-1, C, (args.batch, args.height, args.width), generator=gen).int().to(device)
-    batch = {'rgb': rgb, 'labels': labels}
     if joint:
         # the joint two-stream model (FusionFCN, [reference default] RMSProp): both trunks + fused decoder with batch norm
-        net = get_model('fusion_fcn')({'rgb': 'rgb', 'depth': 'depth'}, {'rgb': 3, 'depth': 1}, U, C, batchsize=args.batch,
+        net = get_model('fusion_fcn')({'rgb': 'rgb', 'depth': 'depth'}, {'rgb': 3, 'depth': 1}, U, C, batchsize=batch,
                                       learning_rate=1e-4, trainer='rmsprop', seed=1, device=str(device), sync_loss=False)
         net.variables['depth_conv1_1/kernel'] = net.variables['depth_conv1_1/kernel'] / 256.0
         net._variables_changed()
-        batch['depth'] = torch.randint(0, 65536, (args.batch, args.height, args.width, 1), generator=gen).float().to(device)
-    elif adap:
-        net = get_model('adapnet')(desc, modality='rgb', num_units=U, batchsize=args.batch, learning_rate=1e-4,
+    elif expert == 'adapnet':
+        net = get_model('adapnet')(desc, modality='rgb', num_units=U, batchsize=batch, learning_rate=1e-4,
                                    trainer='adam', seed=1, device=str(device), sync_loss=False)
     else:
         net = get_model('fcn')('rgb', desc, 'rgb', num_units=U, batch_normalization=bool(args.batch_norm),
-                               batchsize=args.batch, learning_rate=1e-4, trainer='adam', seed=1, device=str(device),
+                               batchsize=batch, learning_rate=1e-4, trainer='adam', seed=1, device=str(device),
                                sync_loss=False)
-    for _ in range(args.warmup):
-        net._train_batch(batch)
+    return net
 
-    def fence():
-        torch.cuda.synchronize(device)
+
+def measure_training(args, device, world, rank, dist, batch, steps, warmup, expert='fcn', joint=False, h=None, w=None):
+    """Data-parallel expert training: every rank differentiates its own images, gradients are all-reduced in buckets on
+    a side stream during backward (RCCL over xGMI).  Returns a record with images/s, the roofline of the MFMA convs
+    (forward + data gradient + filter gradient FLOPs over their summed HIP-event times) and, for N > 1, the exposed
+    all-reduce time (step time minus the same step with the reducer stubbed out)."""
+    from modular_semantic_segmentation_amd import ops
+    h, w = h or args.height, w or args.width
+    gen = torch.Generator(device='cpu').manual_seed(99 + rank)
+    data = {'rgb': torch.randint(0, 256, (batch, h, w, 3), generator=gen).float().to(device),
+            'labels': torch.randint(-1, C, (batch, h, w), generator=gen).int().to(device)}
+    if joint:
+        data['depth'] = torch.randint(0, 65536, (batch, h, w, 1), generator=gen).float().to(device)
+    net = make_trainer_net(args, device, expert, joint, batch)
+
+    def timed(n):
+        fence(device, world, dist)
+        t0 = time.perf_counter()
+        for _ in range(n):
+            net._train_batch(data)
+        fence(device, world, dist)
+        t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=device)
         if world > 1:
-            dist.barrier()
-            torch.cuda.synchronize(device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
 
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        net._train_batch(batch)
-    fence()
-    dt = time.perf_counter() - t0
-    tmax = torch.tensor([dt], dtype=torch.float64, device=device)
+    for _ in range(warmup):
+        net._train_batch(data)
+    dt = timed(steps)
+    rec = {'value': round(batch * world * steps / dt, 2), 'unit': 'images/s', 'ms_per_step': round(dt / steps * 1e3, 3),
+           'images_per_gpu_per_step': batch, 'n_gpus': world}
     if world > 1:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt = float(tmax.item())
+        # the same steps without the collective: what the all-reduce costs beyond what backward hides
+        reducer, net._reducer = net._reducer, None
+        net._train_batch(data)
+        dt_local = timed(steps)
+        net._reducer = reducer
+        rec['ms_per_step_without_allreduce'] = round(dt_local / steps * 1e3, 3)
+        rec['allreduce_ms_exposed'] = round((dt - dt_local) / steps * 1e3, 3)
+        rec['gradient_bytes_per_step'] = int(net.trainer.grad.numel() * 4)
+    # roofline of the MFMA convs of the step (rank 0's kernels; collectives run on their own stream)
+    prof = []
+    ops.CONV_PROFILE = prof
+    torch.cuda.synchronize(device)
+    for _ in range(min(steps, 5)):
+        net._train_batch(data)
+    torch.cuda.synchronize(device)
+    ops.CONV_PROFILE = None
+    fl = sum(p[1] for p in prof)
+    sec = sum(p[2].elapsed_time(p[3]) for p in prof) * 1e-3
+    if sec > 0:
+        by = {}
+        for kind, f, e0, e1 in prof:
+            d = by.setdefault(kind.split('_')[0] if kind.startswith(('dgrad', 'wgrad')) else 'fwd', [0.0, 0.0])
+            d[0] += f
+            d[1] += e0.elapsed_time(e1) * 1e-3
+        rec['roofline'] = {'bound': 'mfma', 'kernel': 'MFMA convs of the training step: forward + data gradient (conv_dma_kernel / '
+                           'conv_mfma_kernel) + filter gradient (conv_wgrad_dma_kernel)', 'achieved': round(fl / sec / 1e12, 2),
+                           'peak': PEAK_TFLOPS['bf16'], 'unit': 'TFLOP/s', 'frac': round(fl / sec / 1e12 / PEAK_TFLOPS['bf16'], 4),
+                           'traffic': None, 'launches': len(prof),
+                           'by_pass_tflops': {k: round(v[0] / v[1] / 1e12, 1) for k, v in by.items() if v[1] > 0},
+                           'measured': 'HIP events per launch on the compute stream'}
+    flops = 3.0 * conv_flops_per_image(h, w, 3) + (3.0 * conv_flops_per_image(h, w, 1) if joint else 0.0)
+    if expert == 'adapnet':
+        flops = 3.0 * adapnet_flops_per_image(h, w, 3)
+    rec['conv_tflops_end_to_end'] = round(batch * world * steps * flops / dt / 1e12, 2)
+    return rec
+
+
+def bench_train(args, device, world, rank, dist):
+    joint = args.fusion == 'joint' and args.expert == 'fcn'
+    adap = args.expert == 'adapnet'
+    rec = measure_training(args, device, world, rank, dist, args.batch, args.steps, args.warmup, args.expert, joint)
     if rank == 0:
-        images = args.batch * world * args.steps
-        flops = 3.0 * conv_flops_per_image(args.height, args.width, 3)
-        if joint:
-            flops += 3.0 * conv_flops_per_image(args.height, args.width, 1)
         metric = 'images/sec, SimpleFCN RGB expert training step (fwd + bwd + Adam%s) at %dx%d' % (
             ', batch norm' if args.batch_norm else '', args.width, args.height)
         workload = 'SimpleFCN RGB %dx%d training, U=%d, C=%d, Adam' % (args.width, args.height, U, C)
@@ -188,19 +408,22 @@ def bench_train(args, device, world, rank, dist):
                 args.width, args.height)
             workload = 'fusion_fcn RGB+Depth %dx%d training, U=%d, C=%d, RMSProp' % (args.width, args.height, U, C)
         if adap:
-            flops = 3.0 * adapnet_flops_per_image(args.height, args.width, 3)
             metric = 'images/sec, AdapNet RGB expert training step (fwd + bwd + Adam, batch norm everywhere) at %dx%d' % (
                 args.width, args.height)
             workload = 'AdapNet RGB %dx%d training, U=%d, C=%d, Adam' % (args.width, args.height, U, C)
-        print(json.dumps({
-            'metric': metric,
-            'value': round(images / dt, 2), 'unit': 'images/s', 'n_gpus': world, 'steps': args.steps,
-            'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True,
-            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
-            'config': {'workload': workload,
-                       'images_per_gpu_per_step': args.batch, 'global_batch': args.batch * world,
-                       'parallelism': 'dp%d, bucketed gradient all-reduce overlapped with backward' % world},
-            'conv_tflops_end_to_end': round(images * flops / dt / 1e12, 2)}))
+        out = {'metric': metric, 'value': rec['value'], 'unit': 'images/s', 'n_gpus': world, 'steps': args.steps,
+               'warmup': args.warmup, 'ms_per_step': rec['ms_per_step'], 'higher_is_better': True,
+               'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
+               'config': {'workload': workload, 'images_per_gpu_per_step': args.batch, 'global_batch': args.batch * world,
+                          'parallelism': 'dp%d, bucketed gradient all-reduce overlapped with backward' % world},
+               'conv_tflops_end_to_end': rec['conv_tflops_end_to_end'], 'roofline': rec.get('roofline'),
+               'cpu_baseline': None,
+               'cpu_baseline_note': 'training has no CPU leg: the oracle differentiates one 64x96 image in seconds (tests), a '
+                                    '768x384 step would take minutes; the inference line carries the CPU baseline'}
+        for k in ('ms_per_step_without_allreduce', 'allreduce_ms_exposed', 'gradient_bytes_per_step'):
+            if k in rec:
+                out[k] = rec[k]
+        print(json.dumps(out), file=_JSON_OUT, flush=True)
     if world > 1:
         dist.destroy_process_group()
 
@@ -219,9 +442,15 @@ def main():
                     help="'joint' = the fusion_fcn baseline model instead of two experts + probabilistic fusion")
     ap.add_argument('--expert', default='fcn', choices=['fcn', 'adapnet'],
                     help="expert architecture of the two streams (default: the headline SimpleFCN; 'adapnet' = side measurement)")
+    ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp8'],
+                    help="'fp8': the block-scaled e4m3 conv path (BASELINE config 5; quote it with --height 1024 --width 2048)")
     ap.add_argument('--mode', default='infer', choices=['infer', 'train'],
                     help="'infer' (headline): two experts + fusion; 'train': one SimpleFCN training step (fwd+bwd+Adam)")
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-accuracy', action='store_true', help='skip the trained-experts accuracy evidence (N = 1 only)')
+    ap.add_argument('--accuracy-steps', type=int, default=1500)
+    ap.add_argument('--accuracy-images', type=int, default=12)
+    ap.add_argument('--no-extra', action='store_true', help='skip the extra configurations / the train_dp record')
     ap.add_argument('--dist-backend', default='nccl', help="'nccl' (= RCCL over xGMI); 'gloo' only for smoke tests")
     ap.add_argument('--share-device', action='store_true',
                     help='smoke test: all ranks use GPU 0 (gloo backend only)')
@@ -230,6 +459,9 @@ def main():
     ap.add_argument('--serial-experts', action='store_true',
                     help='run the RGB and depth experts back to back on one stream (profiling: per-kernel times)')
     args = ap.parse_args()
+    # stdout carries exactly ONE JSON line: everything the models print (reference-style INFO / WARNING lines) goes to stderr
+    global _JSON_OUT
+    _JSON_OUT, sys.stdout = sys.stdout, sys.stderr
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
@@ -247,73 +479,20 @@ def main():
     device = torch.device('cuda', local_rank)
     torch.cuda.set_device(device)
 
-    from modular_semantic_segmentation_amd import ops
     if args.mode == 'train':
         return bench_train(args, device, world, rank, dist)
-    net = build_model(args, device)
-    gen = torch.Generator(device='cpu').manual_seed(1234 + rank)
-    rgb = torch.randint(0, 256, (args.batch, args.height, args.width, 3), generator=gen).float().to(device)
-    depth = torch.randint(0, 65536, (args.batch, args.height, args.width, 1), generator=gen).float().to(device)
-    batch = {'rgb': rgb, 'depth': depth}
-
-    net.concurrent_experts = not args.serial_experts
-
-    def step():
-        return net._predict_batch(batch)
-
-    for _ in range(args.warmup):
-        step()
-    if args.graph:
-        net.capture_graph(batch)
-        graph = net._graph[0]
-
-        def step():             # noqa: F811  (inputs already sit in the graph's static buffers)
-            graph.replay()
-            return net._graph[2]
-        step()
-
-    def fence():
-        torch.cuda.synchronize(device)
-        if world > 1:
-            dist.barrier()
-            torch.cuda.synchronize(device)
-
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
-    fence()
-    dt = time.perf_counter() - t0
-
-    # Per-kernel roofline pass: the same steps with the two experts serialised on one stream, so that
-    # a HIP-event pair around a conv launch (recorded on the launch stream) times that kernel alone
-    # (in the timed region above the RGB and depth experts overlap on two streams).
-    prof = []
-    net._graph = None
-    step = lambda: net._predict_batch(batch)        # noqa: E731  (the roofline pass is always eager)
-    net.concurrent_experts = False
-    step()
-    ops.CONV_PROFILE = prof
-    torch.cuda.synchronize(device)
-    ts = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize(device)
-    dt_serial = time.perf_counter() - ts
-    ops.CONV_PROFILE = None
-    net.concurrent_experts = not args.serial_experts
+    default_line = (args.fusion, args.expert, args.dtype, args.height, args.width) == ('bayes', 'fcn', 'bf16', 384, 768)
+    net = build_model(device, args.fusion, args.expert, args.batch, args.dtype)
+    batch = synthetic_batch(device, args.batch, args.height, args.width, seed=1234 + rank)
+    if args.dtype == 'fp8':
+        net.calibrate(batch)
+    dt, _, prof, dt_serial = measure_inference(net, batch, device, args.steps, args.warmup, graph=args.graph,
+                                               serial=args.serial_experts, world=world, dist=dist)
     tmax = torch.tensor([dt], dtype=torch.float64, device=device)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
 
-    # dominant kernel: the 3x3 implicit-GEMM MFMA conv with Cout % 128 == 0 (conv2_1 .. conv5_3)
-    kinds = {}
-    for kind, flops, e0, e1 in prof:
-        d = kinds.setdefault(kind, [0.0, 0.0, 0])
-        d[0] += flops
-        d[1] += e0.elapsed_time(e1) * 1e-3
-        d[2] += 1
     if args.layer_profile and rank == 0:
         # per-launch-slot breakdown (launch order repeats every step): flops, mean time, TFLOP/s
         per = len(prof) // max(args.steps, 1)
@@ -322,42 +501,65 @@ def main():
             ms = sum(e0.elapsed_time(e1) for _, _, e0, e1 in evs) / len(evs)
             print('  conv launch %2d %s %7.1f GF %8.1f us %7.0f TF/s' % (i, evs[0][0], evs[0][1] / 1e9, ms * 1e3,
                                                                       evs[0][1] / ms / 1e9), file=sys.stderr)
-    dom = 'k3'
-    roofline = None
-    traffic = None
-    tfiles = sorted(f for f in os.listdir(os.path.join(ROOT, 'profiles')) if f.endswith('_conv_traffic.json')) \
-        if os.path.isdir(os.path.join(ROOT, 'profiles')) else []
-    if tfiles and (args.height, args.width) == (384, 768):
-        # HBM bytes per conv launch from the committed rocprofv3 FETCH_SIZE / WRITE_SIZE passes of this
-        # same command (tools/pmc_summary.py); PMC counters cannot be read from inside the process
-        tj = json.load(open(os.path.join(ROOT, 'profiles', tfiles[-1])))
-        import hashlib
-        src = os.path.join(ROOT, 'modular_semantic_segmentation_amd', 'csrc', 'conv_mfma.hip')
-        sha = hashlib.sha256(open(src, 'rb').read()).hexdigest()[:16]
-        # the counters were collected on ONE version of the kernel: a summary of another version is not reported
-        if tj.get('batch') == args.batch and tj.get('kernel_source_sha256_16') == sha:
-            traffic = tj.get('hbm_bytes_per_launch')
-    if dom in kinds and kinds[dom][1] > 0:
-        fl, sec, cnt = kinds[dom]
-        achieved = fl / sec / 1e12
-        roofline = {'bound': 'mfma', 'kernel': 'conv_dma_kernel / conv_mfma_kernel (3x3 implicit GEMM, all launches)',
-                    'achieved': round(achieved, 2),
-                    'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(achieved / PEAK_BF16_TFLOPS, 4),
-                    'traffic': traffic, 'launches': cnt, 'avg_launch_ms': round(sec / cnt * 1e3, 4),
-                    'gflop_per_launch': round(fl / cnt / 1e9, 2),
-                    'measured': 'HIP events per launch, experts serialised on one stream (%.3f ms/step)'
-                                % (dt_serial / args.steps * 1e3)}
-
+    # dominant kernel: the 3x3 implicit-GEMM MFMA conv (fp8: the launches on e4m3 operands, against the fp8 peak)
+    if args.dtype == 'fp8':
+        roofline = roofline_of(prof, ('k3f8',), PEAK_TFLOPS['fp8'],
+                               'conv_mfma_kernel<F8> (v_mfma_scale_f32_16x16x128_f8f6f4, 3x3 launches on e4m3 operands)',
+                               dt_serial, args.steps)
+    else:
+        roofline = roofline_of(prof, ('k3',), PEAK_TFLOPS['bf16'],
+                               'conv_dma_kernel / conv_mfma_kernel (3x3 implicit GEMM, all launches)', dt_serial, args.steps,
+                               traffic=committed_traffic(args.batch, args.height, args.width))
     per_image = conv_flops_per_image if args.expert == 'fcn' else adapnet_flops_per_image
     flops_img = per_image(args.height, args.width, 3) + per_image(args.height, args.width, 1)
     if args.expert == 'adapnet':
         # no single dominant kernel: the whole serialised expert step against the algorithmic conv FLOPs
         achieved = args.batch * args.steps * flops_img / dt_serial / 1e12
         roofline = {'bound': 'mfma', 'kernel': 'whole AdapNet step, every kernel (algorithmic conv FLOPs / step time)',
-                    'achieved': round(achieved, 2), 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s',
-                    'frac': round(achieved / PEAK_BF16_TFLOPS, 4), 'traffic': None,
+                    'achieved': round(achieved, 2), 'peak': PEAK_TFLOPS['bf16'], 'unit': 'TFLOP/s',
+                    'frac': round(achieved / PEAK_TFLOPS['bf16'], 4), 'traffic': None,
                     'gflop_per_image_pair': round(flops_img / 1e9, 2),
                     'measured': 'wall clock of the serialised eager steps (%.3f ms/step)' % (dt_serial / args.steps * 1e3)}
+
+    # ---- records beyond the headline ---------------------------------------------------------------------------------
+    accuracy = cpu = None
+    extra = []
+    train_dp = None
+    if world == 1 and rank == 0:
+        variables = dict(net.variables)
+        del net
+        torch.cuda.empty_cache()
+        if not args.no_cpu_baseline and args.fusion != 'joint' and args.expert == 'fcn':
+            cores, avail = pick_cpu_threads(args.height, args.width)
+            if default_line and not args.no_accuracy:
+                accuracy, cpu = accuracy_and_cpu_baseline(args, device, cores, avail)
+            else:
+                g = np.load(os.path.join(ROOT, 'tests', 'golden', 'notebook_868.npz'))
+                cpu = cpu_baseline_random(args, variables, {'rgb': g['cm_rgb'], 'depth': g['cm_depth']}, cores, avail)
+        if default_line and not args.no_extra:
+            extra.append(extra_inference(device, 'experiments/timing.py protocol: two SimpleFCN experts + Bayes fusion, batch 1, '
+                                         'tf.ones([1,768,384,.]) input, label map fetched to the host every iteration '
+                                         '(Inference Time.ipynb:139 publishes 0.0461 s on a GTX 1080 Ti)', 'bayes', 1, 768, 384,
+                                         steps=50, warmup=5, ones=True, fetch=True))
+            extra.append(extra_inference(device, 'two-stream SimpleFCN + Bayes fusion 768x384, batch 1, random input', 'bayes', 1,
+                                         384, 768, steps=30, warmup=3))
+            extra.append(extra_inference(device, 'two-stream SimpleFCN + Dirichlet fusion 768x384 (configs[3] inference side)',
+                                         'dirichlet', 16, 384, 768))
+            extra.append(extra_inference(device, 'BayesFusion of RGB+Depth FCN experts 1024x512 (configs[2])', 'bayes', 8, 512, 1024))
+            extra.append(extra_inference(device, 'two-stream SimpleFCN + Bayes fusion 2048x1024 bf16', 'bayes', 4, 1024, 2048,
+                                         steps=5))
+            extra.append(extra_inference(device, 'VGG-16-encoder FCN experts 2048x1024, fp8 MFMA conv path (configs[4])', 'bayes',
+                                         4, 1024, 2048, dtype='fp8', steps=5))
+            tr = measure_training(args, device, 1, 0, dist, 16, 8, 2)
+            tr['workload'] = 'SimpleFCN RGB expert training step 768x384 (fwd + bwd + Adam), 16 images'
+            extra.append(tr)
+    elif world > 1 and not args.no_extra and default_line:
+        del net
+        torch.cuda.empty_cache()
+        train_dp = measure_training(args, device, world, rank, dist, 8, 8, 2)
+        train_dp['workload'] = ('SimpleFCN RGB expert training 768x384, 8 images per GPU per step, dp%d: three gradient buckets '
+                                'all-reduced over RCCL on a side stream during backward' % world)
+
     if rank == 0:
         images = args.batch * world * args.steps
         res = {
@@ -365,7 +567,7 @@ def main():
                 args.width, args.height, args.fusion),
             'value': round(images / dt, 2), 'unit': 'images/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True,
-            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
             'config': {'workload': 'two-stream SimpleFCN RGB+Depth %dx%d + %s fusion, U=%d, C=%d, random-init weights'
                                    % (args.width, args.height, args.fusion, U, C),
                        'images_per_gpu_per_step': args.batch, 'global_batch': args.batch * world,
@@ -374,6 +576,8 @@ def main():
             'conv_tflops_end_to_end': round(images * flops_img / dt / 1e12, 2),
             'roofline': roofline,
         }
+        if args.dtype == 'fp8':
+            res['config']['conv_dtype'] = 'e4m3 operands from conv2_2 on (81 % of the conv FLOPs), conv1_1 fp32, conv1_2 / conv2_1 bf16'
         if args.expert == 'adapnet':
             res['metric'] = 'images/sec at %dx%d RGB-D, two AdapNet experts + %s fusion + argmax (inference)' % (
                 args.width, args.height, args.fusion)
@@ -383,12 +587,14 @@ def main():
             res['metric'] = 'images/sec at %dx%d, fusion_fcn joint RGB-D baseline (inference)' % (args.width, args.height)
             res['config']['workload'] = 'fusion_fcn (two VGG16 trunks + fused decoder) RGB+Depth %dx%d, U=%d, C=%d' % (
                 args.width, args.height, U, C)
-        if world == 1 and not args.no_cpu_baseline and args.fusion != 'joint' and args.expert == 'fcn':
-            g = np.load(os.path.join(ROOT, 'tests', 'golden', 'notebook_868.npz'))
-            res['cpu_baseline'] = cpu_baseline(args, net.variables, {'rgb': g['cm_rgb'], 'depth': g['cm_depth']})
-        else:
-            res['cpu_baseline'] = None
-        print(json.dumps(res))
+        res['cpu_baseline'] = cpu
+        if accuracy is not None:
+            res['accuracy'] = accuracy
+        if extra:
+            res['extra'] = extra
+        if train_dp is not None:
+            res['train_dp'] = train_dp
+        print(json.dumps(res), file=_JSON_OUT, flush=True)
     if world > 1:
         dist.destroy_process_group()
 

@@ -24,7 +24,9 @@ def iterate_batches(data, batchsize, max_batches=None):
         for i in range(0, n, batchsize):
             if max_batches is not None and count >= max_batches:
                 return
-            yield {k: np.asarray(v[i:i + batchsize]) for k, v in data.items()}
+            # numpy on the host, or torch tensors (possibly already resident in HBM) passed through as they are
+            yield {k: (v[i:i + batchsize] if isinstance(v, torch.Tensor) else np.asarray(v[i:i + batchsize]))
+                   for k, v in data.items()}
             count += 1
         return
     pending = []

@@ -8,8 +8,9 @@ determines colour AND depth, built so that neither modality suffices alone --
 
   * classes (2,3), (4,5), (6,7) have nearly the same colour (20 grey levels apart in one channel, against a pixel
     noise of sigma 30 and an illumination gain of +-15 %) and clearly different depths,
-  * classes (3,4), (5,6), (8,9) have nearly the same depth (4000 apart, noise sigma 2200, ramp +-800) and clearly
-    different colours,
+  * depths sit on a ladder 5000 apart (noise sigma 2200, ramp +-800), so the depth expert confuses ladder neighbours
+    -- (4,6), (6,3), (3,8), (8,5), (5,7), (7,9), ... -- all of which have clearly different colours, while the
+    look-alike colour pairs are at least 20000 apart in depth,
   * per-pixel sensor noise, a per-image illumination gain and a smooth depth ramp on top,
 
 so a single expert confuses its look-alike pairs and the Bayes / Dirichlet fusion of both has something to gain,
@@ -19,13 +20,13 @@ import numpy as np
 
 NUM_CLASSES = 12
 
-# BGR colours / depths per class; class 0 (void) is rendered as a dark noisy region of mid depth
+# BGR colours / depths per class; class 0 (void) is rendered as a dark noisy region at a depth of its own
 _COLOUR = np.array([[20, 20, 20], [200, 160, 120],
                     [60, 60, 190], [60, 60, 210], [60, 190, 60], [60, 210, 60], [190, 60, 60], [210, 60, 60],
                     [40, 180, 220], [220, 40, 180], [120, 120, 120], [240, 240, 80]], np.float32)
-_DEPTH = np.array([30000, 60000,
-                   8000, 16000, 20000, 28000, 32000, 40000,
-                   46000, 50000, 55000, 3000], np.float32)
+_DEPTH = np.array([13000, 60000,
+                   8000, 28000, 18000, 38000, 23000, 43000,
+                   33000, 48000, 53000, 3000], np.float32)
 
 
 def make_rgbd_shapes(n, h, w, seed=0, num_classes=NUM_CLASSES, rgb_noise=30.0, depth_noise=2200.0):

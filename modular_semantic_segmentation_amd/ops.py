@@ -398,10 +398,28 @@ def pack_conv_weights_pair(w_hwio, out, out_dgrad):
                'xv_pack_conv_weights_pair')
 
 
+class _Profiled(object):
+    """with _Profiled(kind, flops): ... -- a HIP-event pair on the launch stream when bench.py collects CONV_PROFILE."""
+
+    def __init__(self, kind, flops):
+        self.kind, self.flops, self.prof = kind, flops, CONV_PROFILE
+
+    def __enter__(self):
+        if self.prof is not None:
+            self.ev0, self.ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            self.ev0.record()
+
+    def __exit__(self, *exc):
+        if self.prof is not None:
+            self.ev1.record()
+            self.prof.append((self.kind, self.flops, self.ev0, self.ev1))
+
+
 def conv2d_bwd_data(dy, w_packed_dgrad, zero_bias, dx, k, relu_ref=None, addend=None):
-    rc = _lib.lib().xv_conv2d_bwd_data(dy.xv(), _ptr(w_packed_dgrad), _ptr(zero_bias),
-                                      relu_ref.xv() if relu_ref is not None else _NULL_ACT,
-                                      addend.xv() if addend is not None else _NULL_ACT, dx.xv(), k, _stream())
+    with _Profiled('dgrad_k%d' % k, 2.0 * dx.n * dx.h * dx.w * dx.c * dy.c * k * k):
+        rc = _lib.lib().xv_conv2d_bwd_data(dy.xv(), _ptr(w_packed_dgrad), _ptr(zero_bias),
+                                          relu_ref.xv() if relu_ref is not None else _NULL_ACT,
+                                          addend.xv() if addend is not None else _NULL_ACT, dx.xv(), k, _stream())
     _lib.check(rc, 'xv_conv2d_bwd_data')
     return dx
 
@@ -414,11 +432,12 @@ def conv2d_bwd_filter(x, dy, dw, dbias, k, workspace=None):
     """workspace (float32 tensor of >= conv2d_bwd_filter_workspace_bytes): deterministic slab reduction;
     None: fp32 atomics."""
     _need(dw, torch.float32, 'dw')
-    if workspace is None:
-        rc = _lib.lib().xv_conv2d_bwd_filter(x.xv(), dy.xv(), _ptr(dw), _ptr(dbias), k, _stream())
-    else:
-        rc = _lib.lib().xv_conv2d_bwd_filter_ws(x.xv(), dy.xv(), _ptr(dw), _ptr(dbias), k, _ptr(workspace),
-                                               workspace.numel() * 4, _stream())
+    with _Profiled('wgrad_k%d' % k, 2.0 * x.n * x.h * x.w * x.c * dy.c * k * k):
+        if workspace is None:
+            rc = _lib.lib().xv_conv2d_bwd_filter(x.xv(), dy.xv(), _ptr(dw), _ptr(dbias), k, _stream())
+        else:
+            rc = _lib.lib().xv_conv2d_bwd_filter_ws(x.xv(), dy.xv(), _ptr(dw), _ptr(dbias), k, _ptr(workspace),
+                                                   workspace.numel() * 4, _stream())
     _lib.check(rc, 'xv_conv2d_bwd_filter')
 
 
