@@ -102,6 +102,19 @@ int xv_conv2d_fwd(const xv_act* x, const void* w_packed, const float* bias, cons
 int xv_conv2d_fwd_residual(const xv_act* x, const void* w_packed, const float* bias, const xv_act* residual,
                            const xv_act* y, int relu, void* stream);
 
+/* Dense transposed convolution: tf.layers.conv2d_transpose(filters, k, strides=s, padding='same', use_bias=False) with
+ * an ARBITRARY kernel (custom_layers.py:71-121 `deconv2d`; the FCN's upscore layers are constants and take the
+ * depthwise bilinear kernels below, a trained or imported non-bilinear kernel -- AdapNet trains its deconvs,
+ * adapnet.py:156-163 -- takes this path), followed by the optional inference batch norm (scale / shift per channel),
+ * the activation and a residual add:  y = act(deconv(x, W) * scale + shift) + residual.
+ * k = 2s only ([4,4]/2 and [16,16]/8, every call site of the reference).  w_phases_packed: the kernel re-arranged by
+ * the host into a 3x3 conv cin -> s*s*cout (one 2x2-tap sub-conv per output phase; custom_layers.
+ * dense_deconv_as_conv3x3) and packed by xv_pack_conv_weights; zero_bias: s*s*cout zeros; workspace: the phase map.  */
+size_t xv_deconv_dense_workspace_bytes(int n, int h, int w, int cout, int stride);
+int xv_deconv_dense_fwd(const xv_act* x, const void* w_phases_packed, const float* zero_bias, const float* scale,
+                        const float* shift, const xv_act* residual, const xv_act* y, int stride, int relu,
+                        void* workspace, size_t workspace_bytes, void* stream);
+
 /* Tuning / test entry: the same op with an explicit tile configuration 0 <= cfg < xv_conv2d_num_cfgs()
  * (cfg < 0 = the library's own choice, i.e. xv_conv2d_fwd).  Results are bit-identical across
  * configurations; XV_ESHAPE if the configuration cannot tile this shape.                            */

@@ -39,6 +39,8 @@ SIGNATURES = {
     'xv_conv2d_fwd': (_i, [_actp, _vp, _vp, _actp, _actp, _i, _i, _vp]),
     'xv_conv2d_fwd_cfg': (_i, [_actp, _vp, _vp, _actp, _actp, _i, _i, _i, _vp]),
     'xv_conv2d_num_cfgs': (_i, []),
+    'xv_deconv_dense_workspace_bytes': (ctypes.c_size_t, [_i, _i, _i, _i, _i]),
+    'xv_deconv_dense_fwd': (_i, [_actp, _vp, _vp, _vp, _vp, _actp, _actp, _i, _i, _vp, ctypes.c_size_t, _vp]),
     'xv_conv2d_first_fwd': (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _actp, _i, _vp]),
     'xv_maxpool2x2_fwd': (_i, [_actp, _actp, _vp]),
     'xv_upsample2x_relu_add': (_i, [_actp, _actp, _actp, _vp]),

@@ -158,8 +158,17 @@ class AdapnetEngine(object):
         for scope in ('first_deconvolution_upconv', 'second_deconvolution_upconv'):
             k = v['%s/%s/kernel' % (p, scope)]
             if not np.allclose(k, rect_bilinear_filter(k.shape), atol=1e-6):
-                raise NotImplementedError('%s/%s/kernel is not the constant bilinear kernel (custom_layers.py:8-25)'
-                                          % (p, scope))
+                # KNOWN DEVIATION: the reference builds AdapNet's two deconvs with
+                # custom_layers.deconv2d's default trainable=True (adapnet.py:156-163), so a checkpoint it trained
+                # holds dense kernels after the first optimizer step.  This engine evaluates them as the depthwise
+                # bilinear constant they are initialised to (and AdapnetTrainer keeps them constant); the dense
+                # transposed-conv path (xv_deconv_dense_fwd) is wired into the FCN expert only.
+                raise NotImplementedError(
+                    '%s/%s/kernel differs from the bilinear constant it is initialised to (custom_layers.py:8-25): it was '
+                    'trained (the reference leaves AdapNet\'s deconvs trainable, adapnet.py:156-163).  This build keeps '
+                    'them constant; to import the other variables anyway, overwrite this kernel with '
+                    'adapnet.rect_bilinear_filter(kernel.shape) in the npz (accuracy will differ from the reference).'
+                    % (p, scope))
 
         def up(a):
             return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dev)

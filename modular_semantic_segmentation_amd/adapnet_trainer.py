@@ -10,9 +10,12 @@ through the same gathers as the inference engine (adapnet.AdapnetEngine); their 
 kernel scattered into 3x3 x 9 groups, the atrous pair stacked block-wise), rebuilt from the master weights every step,
 and their filter gradients are mapped back through the same index maps.
 
-`first_deconvolution_conv` is trained on the num_units output channels the x2 deconv reads; the remaining 2048 - U
-channels of that layer have exactly zero gradient in the reference too (the constant deconv kernel is zero there) and
-keep their imported values.  The loss is the reference's: the mean cross-entropy over the labelled pixels divided once
+KNOWN DEVIATION from the reference's training trajectory: adapnet.py:156-163 calls custom_layers.deconv2d without
+trainable=False, so the reference TRAINS the two deconv kernels (they start as the bilinear constant and become dense
+after the first optimizer step).  This trainer keeps them constant.  Consequences: `first_deconvolution_conv` is trained
+on the num_units output channels the x2 deconv reads -- the remaining 2048 - U channels have exactly zero gradient in the
+reference only at step 0 (while the deconv kernel is still zero there) and here at every step, so they keep their
+imported values; and a checkpoint trained by the reference cannot be imported unchanged (AdapnetEngine.load explains).  The loss is the reference's: the mean cross-entropy over the labelled pixels divided once
 more by their number (adapnet.py:202-203).
 """
 import numpy as np

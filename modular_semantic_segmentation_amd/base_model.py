@@ -29,17 +29,22 @@ def iterate_batches(data, batchsize, max_batches=None):
                    for k, v in data.items()}
             count += 1
         return
+    def stack(samples, k):
+        if isinstance(samples[0][k], torch.Tensor):          # samples already resident in HBM stay there
+            return torch.stack([s[k] for s in samples])
+        return np.stack([np.asarray(s[k]) for s in samples])
+
     pending = []
     for sample in data:
         pending.append(sample)
         if len(pending) == batchsize:
             if max_batches is not None and count >= max_batches:
                 return
-            yield {k: np.stack([np.asarray(s[k]) for s in pending]) for k in pending[0]}
+            yield {k: stack(pending, k) for k in pending[0]}
             count += 1
             pending = []
     if pending and (max_batches is None or count < max_batches):
-        yield {k: np.stack([np.asarray(s[k]) for s in pending]) for k in pending[0]}
+        yield {k: stack(pending, k) for k in pending[0]}
 
 
 def score_measures(confusion_matrix):
@@ -182,6 +187,14 @@ class BaseModel(object):
                 return
             return (yield from iterate_batches(samples(), self.config['batchsize']))
 
+        # The reference writes loss / accuracy / IoU (and one scalar per additional dataset) as tf.summary events into
+        # output_dir every validation interval (base_model.py:191-195,226-251); here the same scalars go to a JSON-lines
+        # file there, one record per validation step.
+        log = None
+        if self.output_dir is not None:
+            import json
+            os.makedirs(self.output_dir, exist_ok=True)
+            log = open(os.path.join(self.output_dir, 'training_log.jsonl'), 'a')
         if output:
             print('INFO: Start training')
         batches = endless()
@@ -193,14 +206,21 @@ class BaseModel(object):
                 if output:
                     print('{:4d}: loss {:.4f} accuracy {:.2f}, IoU {:.2f}'.format(
                         i, float(loss), score['total_accuracy'], score['mean_IoU']))
+                record = {'step': i, 'global_step': int(self.global_step), 'loss': float(loss),
+                          'accuracy': float(score['total_accuracy']), 'IoU': float(score['mean_IoU'])}
                 for key, extra in additional_eval_datasets.items():
-                    self.score(extra)
+                    record[key] = float(self.score(extra)[0]['mean_IoU'])
+                if log is not None:
+                    log.write(json.dumps(record) + '\n')
+                    log.flush()
                 if 'abort_at_iou' in self.config:
                     # collective decision: a rank that stopped alone would leave the others waiting in the next
                     # gradient all-reduce
                     from .parallel import agree_any
                     if agree_any(score['mean_IoU'] > self.config['abort_at_iou'], self.device):
                         break
+        if log is not None:
+            log.close()
         if output:
             print('INFO: Training finished.')
 

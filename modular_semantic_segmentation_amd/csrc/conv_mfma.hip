@@ -1448,6 +1448,36 @@ extern "C" int xv_conv2d_fwd_residual(const xv_act* x, const void* w_packed, con
   return conv_fwd_impl(x, w_packed, bias, y, nullptr, 1, relu, -1, stream, nullptr, (const __bf16*)residual->data);
 }
 
+// pointwise.hip
+int xv_launch_depth_to_space(const xv_act* z, const float* scale, const float* shift, const xv_act* residual, const xv_act* y,
+                             int stride, int relu, hipStream_t stream);
+
+extern "C" size_t xv_deconv_dense_workspace_bytes(int n, int h, int w, int cout, int stride) {
+  if (n <= 0 || h <= 0 || w <= 0 || cout <= 0 || stride <= 0) return 0;
+  return (size_t)n * (h + 2) * (w + 2) * stride * stride * cout * 2;
+}
+
+// A k x k / stride s transposed conv with k = 2s ('same': pad (k - s) / 2) is, per output phase (py, px), a 2x2-tap
+// stride-1 conv of the input -- the taps of every phase fit the 3x3 window, so all s*s phases run as ONE 3x3 MFMA conv
+// cin -> s*s*cout at the INPUT resolution (custom_layers.dense_deconv_as_conv3x3 arranges the kernel), followed by a
+// depth-to-space pass that carries the batch norm, the activation and the residual add.
+extern "C" int xv_deconv_dense_fwd(const xv_act* x, const void* w_phases_packed, const float* zero_bias, const float* scale,
+                                   const float* shift, const xv_act* residual, const xv_act* y, int stride, int relu,
+                                   void* workspace, size_t workspace_bytes, void* stream) {
+  XV_CHECK_ARG(x && x->data && y && y->data && w_phases_packed && zero_bias && workspace);
+  XV_CHECK_ARG((scale == nullptr) == (shift == nullptr) && (((uintptr_t)workspace) & 15) == 0);
+  XV_CHECK_SHAPE(stride >= 1 && stride <= 8 && y->n == x->n && y->h == x->h * stride && y->w == x->w * stride);
+  XV_CHECK_SHAPE((y->c & 7) == 0 && ((stride * stride * y->c) & 63) == 0 && x->dtype == XV_BF16 && y->dtype == XV_BF16);
+  if (residual && residual->data)
+    XV_CHECK_SHAPE(residual->n == y->n && residual->h == y->h && residual->w == y->w && residual->c == y->c);
+  if (workspace_bytes < xv_deconv_dense_workspace_bytes(x->n, x->h, x->w, y->c, stride)) return XV_EWORKSPACE;
+  // the phase map: padded NHWC like every activation; its border is never read (depth-to-space reads the interior)
+  xv_act z{workspace, x->n, x->h, x->w, stride * stride * y->c, XV_BF16, 0};
+  const int rc = conv_fwd_impl(x, w_phases_packed, zero_bias, &z, nullptr, 3, 0, -1, stream);
+  if (rc != XV_OK) return rc;
+  return xv_launch_depth_to_space(&z, scale, shift, residual, y, stride, relu, (hipStream_t)stream);
+}
+
 extern "C" int xv_conv2d_fwd(const xv_act* x, const void* w_packed, const float* bias, const xv_act* y,
                              const xv_act* pooled, int k, int relu, void* stream) {
   return conv_fwd_impl(x, w_packed, bias, y, pooled, k, relu, -1, stream);

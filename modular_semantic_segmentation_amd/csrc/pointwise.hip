@@ -574,6 +574,59 @@ extern "C" int xv_upsample2x_relu_add(const xv_act* x, const xv_act* residual, c
   return xv_upsample2x_affine_relu_add(x, nullptr, nullptr, residual, y, stream);
 }
 
+// Depth-to-space behind the dense transposed convolution (xv_deconv_dense_fwd): z holds the s*s output phases of every
+// input pixel side by side in its channels ([(py*s + px)*C + c]); y[n][qy*s + py][qx*s + px][c] = act(z * scale + shift)
+// [+ residual].  One thread = 8 channels of one output pixel; for a fixed output row the s*C channels of an input pixel
+// are contiguous, so reads and writes are both 16-byte coalesced.
+__global__ __launch_bounds__(256) void depth_to_space_kernel(const __bf16* __restrict__ z, const __bf16* __restrict__ res,
+                                                            const float* __restrict__ scale, const float* __restrict__ shift,
+                                                            __bf16* __restrict__ y, int N, int Hi, int Wi, int C, int S,
+                                                            int relu) {
+  const int c8 = C >> 3;
+  const int Ho = Hi * S, Wo = Wi * S;
+  const int64_t total = (int64_t)N * Ho * Wo * c8;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    const int cg = (int)(idx % c8);
+    int64_t r = idx / c8;
+    const int ox = (int)(r % Wo);
+    r /= Wo;
+    const int oy = (int)(r % Ho);
+    const int n = (int)(r / Ho);
+    const int qy = oy / S, py = oy - qy * S, qx = ox / S, px = ox - qx * S;
+    const u32x4 a = *reinterpret_cast<const u32x4*>(z + (((int64_t)n * (Hi + 2) + qy + 1) * (Wi + 2) + qx + 1) * ((int64_t)S * S * C) +
+                                                    (int64_t)(py * S + px) * C + cg * 8);
+    const int64_t yoff = (((int64_t)n * (Ho + 2) + oy + 1) * (Wo + 2) + ox + 1) * C + cg * 8;
+    u32x4 rr = {0, 0, 0, 0};
+    if (res != nullptr) rr = *reinterpret_cast<const u32x4*>(res + yoff);
+    u32x4 o;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      float lo = bf16_bits_to_f32(a[w] & 0xffffu), hi = __builtin_bit_cast(float, a[w] & 0xffff0000u);
+      if (scale != nullptr) {
+        lo = lo * scale[cg * 8 + 2 * w] + shift[cg * 8 + 2 * w];
+        hi = hi * scale[cg * 8 + 2 * w + 1] + shift[cg * 8 + 2 * w + 1];
+      }
+      if (relu) {
+        lo = fmaxf(lo, 0.f);
+        hi = fmaxf(hi, 0.f);
+      }
+      lo += bf16_bits_to_f32(rr[w] & 0xffffu);
+      hi += __builtin_bit_cast(float, rr[w] & 0xffff0000u);
+      o[w] = pack_bf16x2(lo, hi);
+    }
+    *reinterpret_cast<u32x4*>(y + yoff) = o;
+  }
+}
+
+int xv_launch_depth_to_space(const xv_act* z, const float* scale, const float* shift, const xv_act* residual, const xv_act* y,
+                             int stride, int relu, hipStream_t stream) {
+  const int64_t total = (int64_t)y->n * y->h * y->w * (y->c >> 3);
+  hipLaunchKernelGGL(depth_to_space_kernel, dim3(grid_for(total)), dim3(256), 0, stream, (const __bf16*)z->data,
+                     residual && residual->data ? (const __bf16*)residual->data : nullptr, scale, shift, (__bf16*)y->data, z->n,
+                     z->h, z->w, y->c, stride, relu);
+  return xv_launch_status();
+}
+
 // y[..., :Ca] = a, y[..., Ca:] = b over the whole padded buffers (tf.concat(axis=3), fusion_fcn.py:27-28)
 extern "C" int xv_concat_channels(const xv_act* a, const xv_act* b, const xv_act* y, void* stream) {
   XV_CHECK_ARG(a && b && y && a->data && b->data && y->data);

@@ -25,3 +25,33 @@ def is_bilinear_filter(kernel, atol=1e-6):
     if kernel.ndim != 4 or kernel.shape[0] != kernel.shape[1] or kernel.shape[2] != kernel.shape[3]:
         return False
     return bool(np.allclose(kernel, bilinear_filter(kernel.shape), rtol=0, atol=atol))
+
+
+def dense_deconv_as_conv3x3(kernel, stride):
+    """Re-arrange a dense transposed-conv kernel [k, k, out, in] (tf.layers.conv2d_transpose layout,
+    custom_layers.py:71-121) with k = 2 * stride and 'same' padding into the HWIO kernel [3, 3, in, s*s*out] of a
+    stride-1 3x3 'same' convolution that computes all s*s output phases at the input resolution:
+
+        [TF1] out[s*q + p] = sum_i in[i] * W[p + pad - (i - q)*s],  pad = (k - s) // 2 = s / 2
+        =>  phase p sees in[q + d] for d in {-1, 0, 1} through tap ky = p + pad - d*s (when 0 <= ky < k)
+
+    so K[d_y + 1, d_x + 1, ci, (p_y*s + p_x)*out + co] = W[ky, kx, co, ci].  xv_deconv_dense_fwd runs it on the MFMA
+    conv and un-shuffles the phases (depth-to-space)."""
+    kernel = np.asarray(kernel, np.float32)
+    k, k2, cout, cin = kernel.shape
+    s = int(stride)
+    if k != k2 or k != 2 * s:
+        raise NotImplementedError('dense transposed conv: kernel %dx%d with stride %d (only k = 2*stride)' % (k, k2, s))
+    pad = (k - s) // 2
+    out = np.zeros((3, 3, cin, s * s * cout), np.float32)
+    for py in range(s):
+        for dy in (-1, 0, 1):
+            ky = py + pad - dy * s
+            if not 0 <= ky < k:
+                continue
+            for px in range(s):
+                for dx in (-1, 0, 1):
+                    kx = px + pad - dx * s
+                    if 0 <= kx < k:
+                        out[dy + 1, dx + 1, :, (py * s + px) * cout:(py * s + px + 1) * cout] = kernel[ky, kx].T
+    return out

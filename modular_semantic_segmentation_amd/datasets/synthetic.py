@@ -8,7 +8,7 @@ determines colour AND depth, built so that neither modality suffices alone --
 
   * classes (2,3), (4,5), (6,7) have nearly the same colour (20 grey levels apart in one channel, against a pixel
     noise of sigma 30 and an illumination gain of +-15 %) and clearly different depths,
-  * depths sit on a ladder 5000 apart (noise sigma 2200, ramp +-800), so the depth expert confuses ladder neighbours
+  * depths sit on a ladder 5000 apart (noise sigma 1500, ramp +-800), so the depth expert confuses ladder neighbours
     -- (4,6), (6,3), (3,8), (8,5), (5,7), (7,9), ... -- all of which have clearly different colours, while the
     look-alike colour pairs are at least 20000 apart in depth,
   * per-pixel sensor noise, a per-image illumination gain and a smooth depth ramp on top,
@@ -29,7 +29,7 @@ _DEPTH = np.array([13000, 60000,
                    33000, 48000, 53000, 3000], np.float32)
 
 
-def make_rgbd_shapes(n, h, w, seed=0, num_classes=NUM_CLASSES, rgb_noise=30.0, depth_noise=2200.0):
+def make_rgbd_shapes(n, h, w, seed=0, num_classes=NUM_CLASSES, rgb_noise=30.0, depth_noise=1500.0):
     """n samples as a dict of arrays.  Deterministic in (n, h, w, seed)."""
     if num_classes != NUM_CLASSES:
         raise ValueError('the procedural palette has %d classes' % NUM_CLASSES)
@@ -66,3 +66,27 @@ def data_description(h=None, w=None, num_classes=NUM_CLASSES):
     """(dtypes, shapes, num_classes) as DataBaseclass.get_data_description (data_baseclass.py:33-55)."""
     return ({'rgb': 'float32', 'depth': 'float32', 'labels': 'int32'},
             {'rgb': (h, w, 3), 'depth': (h, w, 1), 'labels': (h, w)}, num_classes)
+
+
+def augmented_stream(clean, modality, seed=0, rgb_noise=30.0, depth_noise=1500.0):
+    """Endless stream of per-sample dicts {modality, 'labels'} for `fit` (the tf.data generator dataset of the reference,
+    data_baseclass.py:57-126, with the augmentations of augmentation.py:143-262 in spirit: flips and shifts) from
+    NOISE-FREE renderings `clean` = make_rgbd_shapes(..., rgb_noise=0, depth_noise=0) held as torch tensors on the
+    training device: every sample is a random image, flipped, cyclically shifted, with fresh sensor noise -- so a
+    15 M-parameter FCN cannot memorise the few dozen layouts and has to learn colour / depth -> class."""
+    import torch
+    x, lab = clean[modality], clean['labels']
+    n, h, w = lab.shape
+    g = torch.Generator(device=x.device).manual_seed(seed)
+    sigma = rgb_noise if modality == 'rgb' else depth_noise
+    top = 255.0 if modality == 'rgb' else 65535.0
+    while True:
+        i = int(torch.randint(0, n, (1,), generator=g, device=x.device))
+        dy, dx = (int(v) for v in torch.randint(0, max(h, w), (2,), generator=g, device=x.device))
+        flips = [d for d, f in zip((0, 1), torch.rand(2, generator=g, device=x.device) < 0.5) if bool(f)]
+        img, la = x[i], lab[i]
+        if flips:
+            img, la = torch.flip(img, flips), torch.flip(la, flips)
+        img, la = torch.roll(img, (dy % h, dx % w), (0, 1)), torch.roll(la, (dy % h, dx % w), (0, 1))
+        noise = torch.randn(img.shape, generator=g, device=x.device) * sigma
+        yield {modality: torch.clamp(torch.round(img + noise), 0, top), 'labels': la}

@@ -10,7 +10,7 @@ import numpy as np
 import torch
 
 from . import ops
-from .custom_layers import bilinear_filter, is_bilinear_filter
+from .custom_layers import bilinear_filter, dense_deconv_as_conv3x3, is_bilinear_filter
 
 ENCODER = [  # (name, cout, pool_after)   simple_fcn.py:39-67
     ('conv1_1', 64, None), ('conv1_2', 64, 'pool1'),
@@ -105,11 +105,18 @@ class FcnEngine(object):
                 raise KeyError('missing variable %s' % need)
             if tuple(v[need].shape) != tuple(shape):
                 raise ValueError('variable %s has shape %s, expected %s' % (need, v[need].shape, shape))
-        for name in ('upscore_conv5', 'upscore'):
-            if not is_bilinear_filter(v['%s/%s/kernel' % (p, name)]):
-                raise NotImplementedError(
-                    '%s/%s/kernel is not the constant bilinear kernel (custom_layers.py:8-25); the dense '
-                    'transposed-conv fallback is not built' % (p, name))
+        # The reference never trains its deconvs (simple_fcn.py:80-83,117-119), so their kernels are the bilinear
+        # constant and run as depthwise interpolations.  An imported kernel that is anything else takes the dense
+        # transposed-conv path (xv_deconv_dense_fwd on the MFMA conv; the decoder head is then the un-commuted one).
+        self.dense_deconv = {}
+        for name, stride in (('upscore_conv5', 2), ('upscore', 8)):
+            kern = v['%s/%s/kernel' % (p, name)]
+            if not is_bilinear_filter(kern):
+                kp = np.zeros((kern.shape[0], kern.shape[1], self.Up, self.Up), np.float32)
+                kp[:, :, :self.U, :self.U] = kern                       # padding units: zero rows and columns
+                k3 = torch.from_numpy(dense_deconv_as_conv3x3(kp, stride)).to(dev)
+                self.dense_deconv[name] = (ops.pack_conv_weights(k3),
+                                           torch.zeros(stride * stride * self.Up, dtype=torch.float32, device=dev))
         # Batch norm after a deconv (custom_layers.py:112-119) is a per-channel affine before its relu.  A
         # positive scale with zero shift commutes with the relu and the (linear) deconv and is folded into
         # the 1x1 conv on the other side; anything else goes through the affine forms of the x2 kernel and of the
@@ -120,7 +127,7 @@ class FcnEngine(object):
             if layer + '/gamma' in v:
                 s = v[layer + '/gamma'] / np.sqrt(v[layer + '/moving_variance'] + BN_EPS)
                 t = v[layer + '/beta'] - v[layer + '/moving_mean'] * s
-                if np.all(s > 0) and np.all(np.abs(t) <= 1e-12):
+                if np.all(s > 0) and np.all(np.abs(t) <= 1e-12) and name not in self.dense_deconv:
                     deconv_scale[name] = s.astype(np.float32)
                 else:
                     sp, tp = np.ones(self.Up, np.float32), np.zeros(self.Up, np.float32)
@@ -267,7 +274,12 @@ class FcnEngine(object):
             ops.conv2d_fwd(L['conv5_3'], self.w['score_conv5'], self.b['score_conv5'], 1, relu=True, y=s5)
         fused = self._act('fused', n, h // 8, w // 8, self.Up)
         aff = self.affine.get('upscore_conv5', (None, None))
-        ops.upsample2x_relu_add(s5, residual=s4, y=fused, scale=aff[0], shift=aff[1])
+        if 'upscore_conv5' in self.dense_deconv:
+            wk, zb = self.dense_deconv['upscore_conv5']
+            _, self._arena['dd_ws5'] = ops.deconv_dense_fwd(s5, wk, zb, 2, self.Up, y=fused, scale=aff[0], shift=aff[1],
+                                                           residual=s4, relu=True, workspace=self._arena.get('dd_ws5'))
+        else:
+            ops.upsample2x_relu_add(s5, residual=s4, y=fused, scale=aff[0], shift=aff[1])
         L.update(score_conv4=s4, score_conv5=s5, fused=fused)
         return L
 
@@ -283,6 +295,27 @@ class FcnEngine(object):
                              dtype=torch.float32, device=self.device)
             self._arena[key] = ws
         aff = self.affine.get('upscore', (None, None))
+        if 'upscore' in self.dense_deconv:
+            # dense x8 deconv -> [batch norm] -> relu at full resolution, then the per-pixel score conv, softmax, argmax
+            wk, zb = self.dense_deconv['upscore']
+            up = self._act('upscore', f.n, 8 * f.h, 8 * f.w, self.Up)
+            _, self._arena['dd_ws'] = ops.deconv_dense_fwd(f, wk, zb, 8, self.Up, y=up, scale=aff[0], shift=aff[1],
+                                                          relu=True, workspace=self._arena.get('dd_ws'))
+            skey = ('dense_score', f.n, f.h, f.w)
+            if skey not in self._arena:
+                self._arena[skey] = torch.empty((f.n, 8 * f.h, 8 * f.w, self.C), dtype=torch.float32, device=self.device)
+            score = ops.score_dense_fwd(up, self.w['score'], self.b['score'], self.C, self._arena[skey])
+            want_label = 'label' in want or 'classification' in want
+            prob, label = ops.softmax_argmax(score, want_prob='prob' in want, want_label=want_label)
+            out = {'layers': L}
+            L['upscore'] = up
+            if 'score' in want:
+                out['score'] = score
+            if prob is not None:
+                out['prob'] = prob
+            if label is not None:
+                out['label'] = out['classification'] = label
+            return out
         out = ops.decoder_head_fwd(f, self.w['score'], self.b['score'], self.C,
                                    want_score='score' in want, want_prob='prob' in want,
                                    want_label=('label' in want or 'classification' in want), workspace=ws,

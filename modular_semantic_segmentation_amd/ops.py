@@ -175,6 +175,22 @@ def upsample2x_relu_add(x, residual=None, y=None, scale=None, shift=None, relu=T
     return y
 
 
+def deconv_dense_fwd(x, w_phases_packed, zero_bias, stride, cout, y=None, scale=None, shift=None, residual=None,
+                     relu=True, workspace=None):
+    """y = act(conv2d_transpose(x, W) [* scale + shift]) [+ residual] for an arbitrary kernel with k = 2 * stride
+    (w_phases_packed: pack_conv_weights(dense_deconv_as_conv3x3(W, stride))).  Returns (y, workspace)."""
+    if y is None:
+        y = Act(x.n, x.h * stride, x.w * stride, cout, x.t.device)
+    need = _lib.lib().xv_deconv_dense_workspace_bytes(x.n, x.h, x.w, cout, stride)
+    if workspace is None or workspace.numel() * 2 < need:
+        workspace = torch.zeros(need // 2, dtype=torch.bfloat16, device=x.t.device)
+    rc = _lib.lib().xv_deconv_dense_fwd(x.xv(), _ptr(w_phases_packed), _ptr(zero_bias), _ptr(scale), _ptr(shift),
+                                       residual.xv() if residual is not None else _NULL_ACT, y.xv(), int(stride),
+                                       int(bool(relu)), _ptr(workspace), workspace.numel() * 2, _stream())
+    _lib.check(rc, 'xv_deconv_dense_fwd')
+    return y, workspace
+
+
 def conv1x1_residual(x, w_packed, bias, residual, relu=True, y=None):
     """y = act(conv1x1(x) + bias) + residual (the closing conv of a ResNet block)."""
     _need(bias, torch.float32, 'bias')

@@ -26,12 +26,18 @@ C, U = 12, 64
 MODS = (('rgb', 3), ('depth', 1))
 
 
-def train_experts(h, w, steps, batch=8, n_train=48, seed=1, device='cuda', learning_rate=1e-4, log=None):
+DEPTH_UNIT = 16384.0     # the depth expert's first layer starts at 1 / DEPTH_UNIT of its Glorot draw (see train_experts)
+
+
+def train_experts(h, w, steps, batch=8, n_train=32, seed=1, device='cuda', learning_rate=1e-4, log=None,
+                  depth_unit=DEPTH_UNIT):
     """Both experts from [TF1] initialisers with the reference's default optimizer (Adam, 1e-4; base_model.py:153-162)
     through `SimpleFCN.fit`.  Returns (variables of both experts, training set)."""
     from modular_semantic_segmentation_amd import get_model
-    from modular_semantic_segmentation_amd.datasets.synthetic import data_description, make_rgbd_shapes
-    train = make_rgbd_shapes(n_train, h, w, seed=seed)
+    from modular_semantic_segmentation_amd.datasets.synthetic import augmented_stream, data_description, make_rgbd_shapes
+    train = make_rgbd_shapes(n_train, h, w, seed=seed)                          # the measure set of the fusion fits
+    clean = {k: torch.from_numpy(v).to(device)
+             for k, v in make_rgbd_shapes(n_train, h, w, seed=seed + 50, rgb_noise=0, depth_noise=0).items()}
     desc = data_description()
     variables = {}
     for m, cin in MODS:
@@ -39,12 +45,15 @@ def train_experts(h, w, steps, batch=8, n_train=48, seed=1, device='cuda', learn
                                learning_rate=learning_rate, trainer='adam', seed=seed + cin, device=str(device),
                                sync_loss=False)
         if m == 'depth':
-            # raw uint16 depth: the first layer of a trained expert absorbs the range; start it there
-            net.variables['depth/conv1_1/kernel'] = net.variables['depth/conv1_1/kernel'] / 256.0
+            # Raw uint16 depth: the first layer of a trained expert absorbs the range; start it there.  The unit matters
+            # for learnability, not for parity: a scalar input is split into classes by THRESHOLDS, i.e. by conv1_1's
+            # biases, which start at zero and move ~1e-4 per Adam step -- they can only reach thresholds of order one,
+            # so the kernel is scaled to make the 0..65535 range span a few units (with 1/256 the expert stalls at
+            # 0.56 mIoU: measured).
+            net.variables['depth/conv1_1/kernel'] = net.variables['depth/conv1_1/kernel'] / depth_unit
             net._variables_changed()
         t0 = time.perf_counter()
-        data = {m: torch.from_numpy(train[m]).to(device), 'labels': torch.from_numpy(train['labels']).to(device)}
-        net.fit(data, steps, output=False)
+        net.fit(augmented_stream(clean, m, seed=seed + cin), steps, output=False)
         net._sync_variables()
         torch.cuda.synchronize()
         if log is not None:
@@ -165,10 +174,12 @@ def compare(hip, ref, labels):
     return res
 
 
-def run(h=384, w=768, steps=1500, batch=8, n_heldout=8, n_measure=16, device='cuda', log=None, fp8=True):
+def run(h=384, w=768, steps=1500, batch=8, n_heldout=8, n_measure=16, device='cuda', log=None, fp8=True,
+        learning_rate=1e-4, depth_unit=DEPTH_UNIT):
     """The whole protocol; returns (accuracy dict, oracle seconds, oracle images)."""
     from modular_semantic_segmentation_amd.datasets.synthetic import make_rgbd_shapes
-    variables, train = train_experts(h, w, steps, batch=batch, device=device, log=log)
+    variables, train = train_experts(h, w, steps, batch=batch, device=device, log=log, learning_rate=learning_rate,
+                                     depth_unit=depth_unit)
     measure = {k: v[:n_measure] for k, v in train.items()}
     heldout = make_rgbd_shapes(n_heldout, h, w, seed=1001)
     hip, cms, dparams = hip_predictions(variables, measure, heldout, device=device)
@@ -190,6 +201,9 @@ def run(h=384, w=768, steps=1500, batch=8, n_heldout=8, n_measure=16, device='cu
 if __name__ == '__main__':
     import json
     steps = int(sys.argv[1]) if len(sys.argv) > 1 else 1500
-    acc, dt, n = run(steps=steps, log=lambda s: print(s, file=sys.stderr, flush=True))
+    lr = float(sys.argv[2]) if len(sys.argv) > 2 else 1e-4
+    unit = float(sys.argv[3]) if len(sys.argv) > 3 else DEPTH_UNIT
+    torch.set_num_threads(min(32, torch.get_num_threads()))
+    acc, dt, n = run(steps=steps, learning_rate=lr, depth_unit=unit, log=lambda s: print(s, file=sys.stderr, flush=True))
     acc['oracle_seconds'] = round(dt, 2)
     print(json.dumps(acc, indent=1))

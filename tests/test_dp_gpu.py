@@ -253,7 +253,7 @@ def _check_unseeded(tmp_path, backend):
             # two RMSProp steps of up to lr / sqrt(0.1) = 3.2e-3 each; the second one differentiates weights that
             # already differ by the first step's bf16 / atomic-order noise.  Another initialiser draw would be off by
             # the Glorot scale (1e-2 .. 1e-1).
-            np.testing.assert_allclose(r0[key], ref, rtol=0, atol=4e-4, err_msg=name)
+            np.testing.assert_allclose(r0[key], ref, rtol=0, atol=1.5e-3, err_msg=name)
 
 
 def test_two_rank_replicas_start_from_rank0_parameters(tmp_path):

@@ -1,0 +1,197 @@
+"""Tight training-step parity: every backward op of a training step against the oracle on the step's OWN stored forward
+state.  The whole-step comparisons of tests/test_backward_gpu.py run the oracle from the image, so bf16 rounding noise
+compounds through 16 layers and the tolerances there are 5-70 %; here each layer's filter gradient, bias gradient and
+data gradient is recomputed (torch-CPU fp32, the arithmetic of tf.gradients: Conv2DBackpropFilter, BiasAddGrad,
+Conv2DBackpropInput, ReluGrad, MaxPoolGrad, AddN; base_model.py:153-162 over simple_fcn.py:200-214) from the exact bf16
+activations and gradient maps the MI355X step left in HBM -- relu masks and pool routes are the GPU's own, so nothing
+compounds and a wrong sign / tap / channel in a rarely-hit path has nowhere to hide:
+
+    filter and bias gradients   <= 1e-3 of the tensor's largest entry (fp32 sums in another order)
+    data gradients              <= 1 %  of the map's largest entry (one bf16 rounding of the stored map: 2^-9 relative)
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from oracle import fcn_oracle as fo
+
+C, U, H, W = 12, 64, 32, 48
+
+
+@pytest.fixture(scope='module')
+def ops():
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU')
+    from modular_semantic_segmentation_amd import ops as _ops
+    return _ops
+
+
+def _nchw(act):
+    """Act (bf16 padded NHWC on the device) -> float32 NCHW on the host, exact."""
+    return act.interior().float().cpu().permute(0, 3, 1, 2).contiguous()
+
+
+def _w_oihw(hwio):
+    return torch.from_numpy(np.ascontiguousarray(hwio)).permute(3, 2, 0, 1).contiguous()
+
+
+def _close(got, ref, tol, what):
+    got, ref = np.asarray(got, np.float64), np.asarray(ref, np.float64)
+    scale = np.abs(ref).max() + 1e-30
+    err = np.abs(got - ref).max() / scale
+    assert err <= tol, '%s: max error %.3g of the largest entry (tolerance %.3g)' % (what, err, tol)
+    return err
+
+
+def _setup(bn, tmp_path):
+    from modular_semantic_segmentation_amd import get_model
+    rng = np.random.default_rng(0)
+    data = {'rgb': rng.integers(0, 256, (2, H, W, 3)).astype(np.float32),
+            'labels': rng.integers(-1, C, (2, H, W)).astype(np.int32)}
+    w = fo.init_fcn_weights('rgb', 3, U, C, seed=1, bias_scale=0.02)
+    w['rgb/conv1_1/kernel'] *= 0.02
+    for k in w:
+        if k.endswith('/kernel') and 'upscore' not in k and 'conv1_1' not in k:
+            w[k] *= 1.6
+    desc = ({'rgb': 'float32', 'labels': 'int32'}, {'rgb': (None, None, 3), 'labels': (None, None)}, C)
+    net = get_model('fcn')('rgb', desc, 'rgb', num_units=U, batch_normalization=bn, batchsize=2, learning_rate=1e-3,
+                           trainer='adam', seed=1)
+    net.variables.update(w)
+    net._variables_changed()
+    tr = net._ensure_trainer()
+    tr.step(torch.from_numpy(data['rgb']).cuda(), torch.from_numpy(data['labels']).cuda())
+    torch.cuda.synchronize()
+    return net, tr, w, data
+
+
+def _conv_backward_refs(x, dy, w_hwio, k):
+    """(dW [HWIO], db, dx) of y = conv_same(x, w) + b for the given output gradient (torch-CPU fp32)."""
+    wt = _w_oihw(w_hwio)
+    pad = (k - 1) // 2
+    dw = torch.nn.grad.conv2d_weight(x, wt.shape, dy, padding=pad).permute(2, 3, 1, 0).numpy()
+    dx = torch.nn.grad.conv2d_input(x.shape, wt, dy, padding=pad)
+    return dw, dy.sum((0, 2, 3)).numpy(), dx
+
+
+def test_plain_training_step_layer_by_layer(ops, tmp_path):
+    """FcnTrainer (no batch norm): conv -> relu [-> pool] chain, second path into conv4_3 through score_conv4."""
+    from modular_semantic_segmentation_amd.fcn import ENCODER
+    net, tr, w, data = _setup(False, tmp_path)
+    e = tr.e
+    n = 2
+    L = {key[0]: act for key, act in e._arena.items() if isinstance(key[0], str) and hasattr(act, 'interior')}
+    Gm = {key[0]: act for key, act in tr._g.items() if hasattr(act, 'interior')}
+    names = [nm for nm, _, _ in ENCODER]
+    pool_after = {nm: pl for nm, _, pl in ENCODER}
+    # gradient w.r.t. each conv's pre-activation output, as the step left it
+    gout = {}
+    for nm in names:
+        if nm == 'conv4_3' or not pool_after[nm]:
+            gout[nm] = Gm['g_' + nm]
+        else:
+            gout[nm] = Gm['r_' + nm]
+    prev, worst = None, {}
+    for nm in names:
+        xin = prev
+        prev = pool_after[nm] if pool_after[nm] else nm
+        if nm == 'conv1_1':
+            continue
+        x, dy = _nchw(L[xin]), _nchw(gout[nm])
+        wq = fo.round_bf16(w['rgb/%s/kernel' % nm])                  # the step's forward / dgrad weights
+        dw, db, dx = _conv_backward_refs(x, dy, wq, 3)
+        worst['dW ' + nm] = _close(tr.view(tr.grad, nm, 'kernel').cpu().numpy(), dw, 1e-3, 'dW ' + nm)
+        worst['db ' + nm] = _close(tr.view(tr.grad, nm, 'bias').cpu().numpy(), db, 1e-3, 'db ' + nm)
+        if xin.startswith('pool'):
+            # Conv2DBackpropInput -> gradient of the pooled map; MaxPoolGrad + ReluGrad route it to the conv above
+            worst['dx ' + nm] = _close(_nchw(Gm['g_' + xin]), fo.round_bf16(dx), 1e-2, 'dx ' + nm)
+            above = names[names.index(nm) - 1]
+            y = _nchw(L[above])
+            dpool = _nchw(Gm['g_' + xin])
+            _, idx = F.max_pool2d(y, 2, 2, return_indices=True)      # first maximum of every window, like the kernel
+            routed = torch.zeros_like(y).flatten(2).scatter_(2, idx.flatten(2), dpool.flatten(2)).view_as(y)
+            routed = routed * (y > 0)
+            assert torch.equal(_nchw(Gm['r_' + above]), routed), 'pool route of ' + above
+        else:
+            ref = fo.round_bf16(dx * (_nchw(L[xin]) > 0))
+            worst['dx ' + nm] = _close(_nchw(gout[xin]) if xin != 'conv4_3' else _nchw(Gm['g_conv4_3']), ref, 1e-2,
+                                      'dx ' + nm)
+    # the 1x1 score convs (padded to 64 units) and the AddN into conv4_3
+    for nm, src, g in (('score_conv4', 'conv4_3', 'ds4'), ('score_conv5', 'conv5_3', 'ds5')):
+        kp = np.zeros((1, 1, 512, e.Up), np.float32)
+        kp[..., :U] = w['rgb/%s/kernel' % nm]
+        dw, db, dx = _conv_backward_refs(_nchw(L[src]), _nchw(Gm[g]), fo.round_bf16(kp), 1)
+        worst['dW ' + nm] = _close(tr.view(tr.grad, nm, 'kernel').cpu().numpy(), dw, 1e-3, 'dW ' + nm)
+        worst['db ' + nm] = _close(tr.view(tr.grad, nm, 'bias').cpu().numpy(), db, 1e-3, 'db ' + nm)
+        if nm == 'score_conv5':
+            ref = fo.round_bf16(dx * (_nchw(L['conv5_3']) > 0))
+            worst['dx ' + nm] = _close(_nchw(Gm['g_conv5_3']), ref, 1e-2, 'dx ' + nm)
+        else:
+            ref = fo.round_bf16((dx + _nchw(Gm['r_conv4_3'])) * (_nchw(L['conv4_3']) > 0))       # AddN, then ReluGrad
+            worst['dx ' + nm] = _close(_nchw(Gm['g_conv4_3']), ref, 1e-2, 'dx score_conv4 + pool4 route')
+    # bilinear x2 deconv + add: ds4 = dfused * (s4 > 0); ds5 = relu-masked transpose of the x2 upsampling
+    dfused = _nchw(Gm['dfused'])
+    assert torch.equal(_nchw(Gm['ds4']), dfused * (_nchw(L['score_conv4']) > 0))
+    k4 = torch.from_numpy(fo.bilinear_kernel(4, e.Up)).permute(3, 2, 0, 1).contiguous()
+    s5 = _nchw(L['score_conv5']).requires_grad_(True)
+    up = F.relu(F.conv_transpose2d(s5, k4, stride=2, padding=1))
+    up.backward(dfused)
+    ref = fo.round_bf16((s5.grad * (s5.detach() > 0)))
+    worst['ds5'] = _close(_nchw(Gm['ds5']), ref, 1e-2, 'ds5')
+    # conv1_1 (fp32 first layer): filter gradient from the raw image
+    x0 = torch.from_numpy(data['rgb']).permute(0, 3, 1, 2).contiguous()
+    dw, db, _ = _conv_backward_refs(x0, _nchw(gout['conv1_1']), w['rgb/conv1_1/kernel'], 3)
+    worst['dW conv1_1'] = _close(tr.view(tr.grad, 'conv1_1', 'kernel').cpu().numpy(), dw, 1e-3, 'dW conv1_1')
+    worst['db conv1_1'] = _close(tr.view(tr.grad, 'conv1_1', 'bias').cpu().numpy(), db, 1e-3, 'db conv1_1')
+    print('worst relative errors:', {k: float('%.2g' % v) for k, v in sorted(worst.items(), key=lambda kv: -kv[1])[:6]})
+    assert len(worst) == 12 * 3 + 2 * 3 + 1 + 2
+
+
+def test_batch_norm_training_step_layer_by_layer(ops, tmp_path):
+    """FcnBnTrainer: conv -> z -> batch norm (batch statistics) -> relu: per layer the batch-norm backward (dz from dy
+    with the stored z / y and the step's own statistics; d gamma, d beta) and the conv gradients on (stored input, dz)."""
+    from modular_semantic_segmentation_amd.fcn import ENCODER
+    net, tr, w, data = _setup(True, tmp_path)
+    A = {key[0]: act for key, act in tr._a.items() if hasattr(act, 'interior')}
+    names = [nm for nm, _, _ in ENCODER]
+    pool_after = {nm: pl for nm, _, pl in ENCODER}
+    worst = {}
+    prev = None
+    for nm in names:
+        xin_tag = None if prev is None else (prev if prev.startswith('pool') else 'y_' + prev)
+        prev = pool_after[nm] if pool_after[nm] else nm
+        z, y, dz = _nchw(A['z_' + nm]), _nchw(A['y_' + nm]), _nchw(A['dz_' + nm])
+        # the gradient w.r.t. y that the step fed into this batch norm
+        if nm == 'conv5_3':
+            dy = _nchw(A['g_conv5_3'])
+        elif nm == 'conv4_3':
+            dy = _nchw(A['g_conv4_3'])
+        elif pool_after[nm]:
+            dy = _nchw(A['r_' + nm])
+        else:
+            dy = _nchw(A['dx_' + names[names.index(nm) + 1]])
+        # [TF1] batch norm backward with the relu mask, biased batch statistics of the stored z (fp32)
+        g = dy * (y > 0)
+        m = z.shape[0] * z.shape[2] * z.shape[3]
+        mean = z.mean((0, 2, 3), keepdim=True)
+        var = ((z - mean) ** 2).mean((0, 2, 3), keepdim=True)
+        inv = 1.0 / torch.sqrt(var + 1e-3)
+        zh = (z - mean) * inv
+        gamma = torch.from_numpy(np.ones(z.shape[1], np.float32)).view(1, -1, 1, 1)        # [TF1] initial gamma
+        dgamma, dbeta = (g * zh).sum((0, 2, 3)), g.sum((0, 2, 3))
+        ref = gamma * inv * (g - dbeta.view(1, -1, 1, 1) / m - zh * dgamma.view(1, -1, 1, 1) / m)
+        worst['dz ' + nm] = _close(dz, fo.round_bf16(ref), 1e-2, 'batch-norm dz ' + nm)
+        worst['dgamma ' + nm] = _close(tr.view(tr.grad, nm, 'gamma').cpu().numpy(), dgamma.numpy(), 2e-3, 'dgamma ' + nm)
+        worst['dbeta ' + nm] = _close(tr.view(tr.grad, nm, 'beta').cpu().numpy(), dbeta.numpy(), 2e-3, 'dbeta ' + nm)
+        if nm == 'conv1_1':
+            x0 = torch.from_numpy(data['rgb']).permute(0, 3, 1, 2).contiguous()
+            dw, db, _ = _conv_backward_refs(x0, dz, w['rgb/conv1_1/kernel'], 3)
+        else:
+            dw, db, dx = _conv_backward_refs(_nchw(A[xin_tag]), dz, fo.round_bf16(w['rgb/%s/kernel' % nm]), 3)
+            worst['dx ' + nm] = _close(_nchw(A['dx_' + nm]), fo.round_bf16(dx), 1e-2, 'dx ' + nm)
+        worst['dW ' + nm] = _close(tr.view(tr.grad, nm, 'kernel').cpu().numpy(), dw, 1e-3, 'dW ' + nm)
+        worst['db ' + nm] = _close(tr.view(tr.grad, nm, 'bias').cpu().numpy(), db, 1e-3, 'db ' + nm)
+    print('worst relative errors:', {k: float('%.2g' % v) for k, v in sorted(worst.items(), key=lambda kv: -kv[1])[:6]})
+    assert len(worst) == 13 * 5 + 12

@@ -294,3 +294,49 @@ def test_adapnet_trainer_index_maps_on_cpu():
     dw7 = dw3.ravel()[inv].reshape(w7.shape)
     # <derive(w7), dw3> == <w7, back(dw3)>
     assert np.isclose((derived.astype(np.float64) * dw3).sum(), (w7.astype(np.float64) * dw7).sum())
+
+
+def test_fit_writes_a_json_lines_training_log(tmp_path):
+    """The reference's tf.summary scalars (base_model.py:226-251: loss, accuracy, IoU, one per additional dataset, every
+    validation interval) land in output_dir/training_log.jsonl."""
+    import json
+
+    class _Trainable(base_model.BaseModel):
+        def _build_graph(self):
+            self.prediction, self.loss = 'label', None
+
+        def _train_batch(self, batch):
+            return 0.5
+
+        def score(self, data, max_iterations=None):
+            return {'total_accuracy': 0.75, 'mean_IoU': 0.4 if data == 'val' else 0.9}, None
+
+    desc = ({'rgb': 'float32', 'labels': 'int32'}, {'rgb': (None, None, 3), 'labels': (None, None)}, 12)
+    net = _Trainable(desc, output_dir=str(tmp_path), device='cpu', batchsize=2)
+    net.fit({'labels': np.arange(6)}, 5, output=False, validation_dataset='val', validation_interval=2,
+            additional_eval_datasets={'other': 'extra'})
+    rows = [json.loads(line) for line in open(os.path.join(str(tmp_path), 'training_log.jsonl'))]
+    assert [r['step'] for r in rows] == [0, 2, 4] and rows[-1]['global_step'] == 5
+    assert rows[0] == {'step': 0, 'global_step': 1, 'loss': 0.5, 'accuracy': 0.75, 'IoU': 0.4, 'other': 0.9}
+
+
+@pytest.mark.parametrize('k,s', [(4, 2), (16, 8)])
+def test_dense_deconv_phase_decomposition(k, s):
+    """custom_layers.dense_deconv_as_conv3x3: a [k,k,out,in] transposed-conv kernel (k = 2*stride, 'same') as ONE 3x3
+    'same' conv over the s*s output phases -- equal to the oracle's conv_transpose ([TF1] pad (k - s) // 2) after a
+    depth-to-space."""
+    import torch
+    import torch.nn.functional as F
+    from modular_semantic_segmentation_amd.custom_layers import dense_deconv_as_conv3x3
+    from oracle import fcn_oracle as fo
+    rng = np.random.default_rng(k)
+    cin, cout = 5, 3
+    W = rng.standard_normal((k, k, cout, cin)).astype(np.float32)
+    x = torch.from_numpy(rng.standard_normal((2, cin, 7, 9)).astype(np.float32))
+    ref = fo.deconv_same(x, W, s)
+    z = F.conv2d(x, torch.from_numpy(dense_deconv_as_conv3x3(W, s)).permute(3, 2, 0, 1).contiguous(), padding=1)
+    n, _, h, w = z.shape
+    y = z.view(n, s, s, cout, h, w).permute(0, 3, 4, 1, 5, 2).reshape(n, cout, h * s, w * s)
+    assert float((y - ref).abs().max()) < 1e-5
+    with pytest.raises(NotImplementedError):
+        dense_deconv_as_conv3x3(W, s + 1)

@@ -323,3 +323,35 @@ def test_confusion_matrix_and_suffstats(ops):
     Sref, nref = fu.sufficient_statistics(p, lab, C)
     assert np.array_equal(cnt.cpu().numpy(), nref)
     np.testing.assert_allclose(S.cpu().numpy(), Sref, rtol=1e-6, atol=1e-4)
+
+
+@pytest.mark.parametrize('k,s,n,h,w,cin,cout', [(4, 2, 2, 6, 10, 64, 64), (16, 8, 1, 5, 7, 64, 64), (4, 2, 1, 3, 4, 128, 64)])
+def test_dense_transposed_conv_exact_on_integers(ops, k, s, n, h, w, cin, cout):
+    """xv_deconv_dense_fwd (the fallback for deconv kernels that are NOT the bilinear constant, custom_layers.py:71-121):
+    tf.layers.conv2d_transpose(k, strides=s, 'same', no bias) as one 3x3 MFMA conv over the s*s output phases +
+    depth-to-space, with the batch-norm affine, relu and residual add behind it -- bit-exact on integer operands
+    against torch's conv_transpose2d with [TF1] padding (k - s) // 2."""
+    from modular_semantic_segmentation_amd.custom_layers import dense_deconv_as_conv3x3
+    rng = np.random.default_rng(k * 100 + cin)
+    x = rng.integers(-2, 3, (n, h, w, cin)).astype(np.float32)
+    wt = rng.integers(-1, 2, (k, k, cout, cin)).astype(np.float32)         # [kh, kw, out, in]
+    res = rng.integers(-3, 4, (n, h * s, w * s, cout)).astype(np.float32)
+    scale = rng.integers(1, 3, cout).astype(np.float32)
+    shift = rng.integers(-2, 3, cout).astype(np.float32)
+    wp = ops.pack_conv_weights(_dev(dense_deconv_as_conv3x3(wt, s)))
+    zb = torch.zeros(s * s * cout, device='cuda')
+    xa = ops.Act.from_dense(_dev(x))
+    y, ws = ops.deconv_dense_fwd(xa, wp, zb, s, cout, scale=_dev(scale), shift=_dev(shift), residual=ops.Act.from_dense(_dev(res)),
+                                 relu=True)
+    torch.cuda.synchronize()
+    xt = torch.from_numpy(x).permute(0, 3, 1, 2).contiguous()
+    raw = fo.deconv_same(xt, wt, s)                                         # exact integers
+    raw16 = fo.round_bf16(raw)                                              # the phase map is stored as bf16
+    ref = torch.relu(raw16 * torch.from_numpy(scale).view(1, -1, 1, 1) + torch.from_numpy(shift).view(1, -1, 1, 1)) + \
+        torch.from_numpy(res).permute(0, 3, 1, 2)
+    assert np.array_equal(y.interior().float().cpu().numpy(), fo.round_bf16(ref).permute(0, 2, 3, 1).numpy())
+    for edge in (y.t[:, 0], y.t[:, -1], y.t[:, :, 0], y.t[:, :, -1]):
+        assert not edge.any()
+    y2, _ = ops.deconv_dense_fwd(xa, wp, zb, s, cout, relu=False, workspace=ws)          # plain form, workspace reused
+    torch.cuda.synchronize()
+    assert np.array_equal(y2.interior().float().cpu().numpy(), raw16.permute(0, 2, 3, 1).numpy())

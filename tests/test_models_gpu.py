@@ -417,3 +417,31 @@ def test_dataset_readers_drive_training_and_fusion_flows(gpu, tmp_path):
                                             {'rgb': p_rgb, 'depth': p_dep})
     assert info['confusion_matrix'].sum() == len(data.testset) * 64 * 96
     assert info['confusion_matrices']['rgb'].sum() == len(data.measureset) * 64 * 96
+
+
+def test_fcn_with_imported_dense_deconv_kernels(gpu):
+    """An imported deconv kernel that is not the bilinear constant (custom_layers.deconv2d is a general
+    tf.layers.conv2d_transpose) takes the dense transposed-conv path: x2 deconv + add into `fused`, x8 deconv + relu at
+    full resolution, per-pixel score conv, softmax, argmax -- against the oracle's dense deconv."""
+    from modular_semantic_segmentation_amd.fcn import FcnEngine
+    w = fo.init_fcn_weights('rgb', 3, U, C, seed=3, bias_scale=0.02)
+    w['rgb/conv1_1/kernel'] *= 0.02
+    for k in w:
+        if k.endswith('/kernel') and 'upscore' not in k and 'conv1_1' not in k:
+            w[k] *= 1.6
+    rng = np.random.default_rng(5)
+    for name in ('upscore_conv5', 'upscore'):
+        kern = w['rgb/%s/kernel' % name]
+        w['rgb/%s/kernel' % name] = (kern + 0.02 * rng.standard_normal(kern.shape) * np.abs(kern).max()).astype(np.float32)
+    x = rng.integers(0, 256, (2, 64, 96, 3)).astype(np.float32)
+    eng = FcnEngine('rgb', 3, U, C, w)
+    assert sorted(eng.dense_deconv) == ['upscore', 'upscore_conv5']
+    out = eng.forward(torch.from_numpy(x).cuda(), want=('score', 'prob', 'label'))
+    torch.cuda.synchronize()
+    ref = fo.fcn_forward(x, w, 'rgb', 'bf16', keep=['fused', 'upscore', 'score'])
+    fused = out['layers']['fused'].interior().float().cpu().numpy()[..., :U]
+    assert np.abs(fused - ref['fused']).max() < 2e-2 * np.abs(ref['fused']).max()
+    up = out['layers']['upscore'].interior().float().cpu().numpy()[..., :U]
+    assert np.abs(up - ref['upscore']).max() < 2e-2 * np.abs(ref['upscore']).max()
+    _check_logits_and_labels(out['score'].cpu().numpy(), out['label'].cpu().numpy(), ref['score'], 'dense deconv')
+    np.testing.assert_allclose(out['prob'].cpu().numpy().sum(-1), 1.0, atol=1e-5)
