@@ -284,6 +284,16 @@ int xv_count_valid_labels(const int32_t* labels, int num_classes, int64_t npix, 
  * to 4: the first half of the decoder head in its commuted form (see xv_decoder_head_fwd).          */
 int xv_score_lowres(const xv_act* fused, const float* w_score, int num_classes, float* S, void* stream);
 
+/* Fused head of a two-expert fusion model: both experts' low-resolution class scores (xv_score_lowres of each `fused`
+ * map) -> per-pixel x8 bilinear logits + bias -> each expert's softmax / argmax (basic_fusion_model.py:21-22) -> Bayes
+ * fusion of the two labels (mode 0; bayes_mix.py:33-58,161: tab = loglik [2][C][C]) or Dirichlet fusion of the two
+ * probability vectors (mode 1; dirichlet_mix.py:14-36,96-136: tab = alpha-1 [2][C][C], lognorm [2][C]) -> the fused
+ * label map int64 [n][8hi][8wi], and nothing else: no per-pixel intermediate reaches HBM.  Same arithmetic, term for
+ * term, as xv_decoder_head_fwd + xv_bayes_fuse / xv_dirichlet_fuse (bit-identical labels).                        */
+int xv_fused_head_fwd(const float* Sa, const float* Sb, const float* bias_a, const float* bias_b, int n, int hi, int wi,
+                      int num_classes, int mode, const float* tab, const float* lognorm, const float* logprior,
+                      int64_t* fused_label, void* stream);
+
 /* Loss and head backward (simple_fcn.py:212-214, utils.py:43-53) in the same commuted form: recomputes
  * score = bilinear_x8(fused . Ws) + bs, adds -sum(onehot*log_softmax)/(1e-20+count) to *loss, accumulates
  * d(score kernel) [U][C] and d(score bias) [C], and writes dfused = d(loss)/d(fused) (bf16 padded NHWC; the

@@ -76,6 +76,7 @@ SIGNATURES = {
     'xv_upsample2x_bwd': (_i, [_actp, _actp, _actp, _vp]),
     'xv_count_valid_labels': (_i, [_vp, _i, _i64, _vp, _vp]),
     'xv_score_lowres': (_i, [_actp, _vp, _i, _vp, _vp]),
+    'xv_fused_head_fwd': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     'xv_decoder_head_bwd_workspace_bytes': (ctypes.c_size_t, [_i, _i, _i, _i]),
     'xv_decoder_head_bwd': (_i, [_actp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _actp, _vp, ctypes.c_size_t, _vp]),
     'xv_bn_stats': (_i, [_actp, _vp, _vp]),

@@ -64,6 +64,40 @@ def run_experts(model, batch, wants):
     return outs
 
 
+def fused_head_applicable(model):
+    """The fused two-expert head (ops.fused_head) serves the default prediction of a fusion model with two FCN experts
+    whose decoder heads are in the commuted form; config fused_head=False keeps the per-expert outputs
+    (`expert_outputs`, `probs`) materialised as the unfused path does."""
+    if not model.config.get('fused_head', True) or len(model.modalities) != 2:
+        return False
+    return all(isinstance(e, FcnEngine) and e.commuted_head() for e in model.experts.values())
+
+
+def run_fused_head(model, batch, tab, logprior, lognorm=None):
+    """Both trunks (each on its own HIP stream) up to their low-resolution class scores, then ONE kernel: per-pixel
+    logits, softmax / argmax per expert and the Bayes or Dirichlet fusion -> fused labels."""
+    main = torch.cuda.current_stream(model.device)
+    inputs = {m: model._to_device(batch[m], torch.float32) for m in model.modalities}
+    S, geo = {}, None
+    if getattr(model, 'concurrent_experts', True):
+        if not hasattr(model, '_expert_streams'):
+            model._expert_streams = {m: torch.cuda.Stream(device=model.device) for m in model.modalities}
+        for m in model.modalities:
+            side = model._expert_streams[m]
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                S[m], geo = model.experts[m].lowres_scores(inputs[m])
+        for m in model.modalities:
+            main.wait_stream(model._expert_streams[m])
+    else:
+        for m in model.modalities:
+            S[m], geo = model.experts[m].lowres_scores(inputs[m])
+    a, b = model.modalities
+    from . import ops
+    return ops.fused_head(S[a], S[b], model.experts[a].b['score'], model.experts[b].b['score'], geo[0], geo[1], geo[2],
+                          model.config['num_classes'], tab, logprior, lognorm=lognorm)
+
+
 class FusionModel(BaseModel):
     """Mixture of per-modality FCN experts; subclasses implement `_fusion(expert_outputs)`.
     config: prefixes {modality: prefix}, num_units, num_channels {modality: C_in}, expert_model."""

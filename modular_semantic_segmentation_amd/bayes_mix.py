@@ -5,7 +5,7 @@ import numpy as np
 import torch
 
 from . import ops
-from .basic_fusion_model import FusionModel
+from .basic_fusion_model import FusionModel, fused_head_applicable, run_fused_head
 
 UNIFORM_PRIOR = 1.0 / 14     # the reference hard-codes 1/14 regardless of num_classes (bayes_mix.py:42,95)
 
@@ -72,7 +72,8 @@ class BayesFusion(FusionModel):
     """config: num_units, num_classes (via data_description), prefixes, num_channels, expert_model,
     class_prior ('data' | 'uniform' | float), confusion_matrices {modality: [C,C] label x pred};
     decision_matrix=True fuses two experts through the bayes_decision_matrix lookup table instead of the
-    per-pixel log-likelihood sum (the faster variant timed by experiments/timing.py:87-115)."""
+    per-pixel log-likelihood sum (the faster variant timed by experiments/timing.py:87-115); fused_head=False keeps
+    the experts' label maps materialised (`expert_outputs`) instead of fusing inside the decoder-head kernel."""
 
     def __init__(self, output_dir=None, confusion_matrices=False, **config):
         standard_config = {'learning_rate': 0.0, 'class_prior': 'data'}
@@ -99,6 +100,13 @@ class BayesFusion(FusionModel):
         self.conditionals = [_conditional(m) for m in mats]
         self.decision_matrix = torch.from_numpy(
             bayes_decision_matrix(mats, self.config['class_prior']).astype(np.int64)).to(self.device)
+
+    def _predict_batch_impl(self, batch, output_attr=None):
+        if output_attr is None and not self.config.get('decision_matrix', False) and fused_head_applicable(self):
+            # default prediction: nothing but the fused label map is wanted -> one fused head kernel after the trunks
+            self.expert_outputs = None
+            return run_fused_head(self, batch, self.loglik, self.logprior)
+        return FusionModel._predict_batch_impl(self, batch, output_attr)
 
     def _fusion(self, expert_outputs, output_attr=None):
         labels = [expert_outputs[m]['classification'] for m in self.modalities]

@@ -109,9 +109,11 @@ __global__ __launch_bounds__(256) void dirichlet_fuse_kernel(ProbPtrs probs, int
       for (int k = 0; k < CMAX; ++k) lx[k] = k < C ? logf(1e-20f + lx[k] / sum) : 0.f;  // renormalise, then log(1e-20 + p)
       for (int c = 0; c < C; ++c) {
         const float* row = tab + ((int64_t)e * C + c) * CMAX;
+        // explicit fmaf chain: the fused two-expert head (pointwise.hip fused_head_kernel) repeats this arithmetic and
+        // must produce the same bits, so nothing is left to the compiler's contraction choices
         float dot = 0.f;
 #pragma unroll
-        for (int k = 0; k < CMAX; ++k) dot += row[k] * lx[k];
+        for (int k = 0; k < CMAX; ++k) dot = fmaf(row[k], lx[k], dot);
         const float L = dot - ln[e * CMAX + c];
         // static register indexing: select instead of total[c] with runtime c
 #pragma unroll

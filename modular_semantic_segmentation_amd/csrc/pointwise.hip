@@ -254,7 +254,79 @@ __global__ __launch_bounds__(128) void score_lowres_kernel(const __bf16* __restr
 }
 
 // Kernel 2: one thread per output pixel: 4-tap bilinear interpolation of the CM low-resolution class
-// scores, + bias, softmax, argmax.
+// scores, + bias, softmax, argmax.  The per-pixel pieces are device functions shared with the fused two-expert head
+// (fused_head_kernel), so both paths execute the same arithmetic in the same order: their labels are bit-identical.
+template <int CM>
+__device__ __forceinline__ void head_logits(const float* __restrict__ S, const float* __restrict__ bs_g, int n, int oy, int ox,
+                                            int Hi, int Wi, int C, float (&sc)[CM]) {
+  int iy1, ix1;
+  float wy1, wy0, wx1, wx0;
+  bilinear_taps<8>(oy, iy1, wy1, wy0);
+  bilinear_taps<8>(ox, ix1, wx1, wx0);
+  const float w00 = wy0 * wx0, w01 = wy0 * wx1, w10 = wy1 * wx0, w11 = wy1 * wx1;
+  // padded coords: logical source (iy1-1, ix1-1) is padded (iy1, ix1)
+  const float* p00 = S + (((int64_t)n * (Hi + 2) + iy1) * (Wi + 2) + ix1) * CM;
+  const int64_t rowp = (int64_t)(Wi + 2) * CM;
+#pragma unroll
+  for (int k4 = 0; k4 < CM; k4 += 4) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(p00 + k4), b = *reinterpret_cast<const f32x4*>(p00 + CM + k4);
+    const f32x4 c = *reinterpret_cast<const f32x4*>(p00 + rowp + k4), d = *reinterpret_cast<const f32x4*>(p00 + rowp + CM + k4);
+    // explicit fmaf chain (shared by the unfused and the fused head: identical bits by construction)
+    sc[k4] = fmaf(d.x, w11, fmaf(c.x, w10, fmaf(b.x, w01, a.x * w00)));
+    sc[k4 + 1] = fmaf(d.y, w11, fmaf(c.y, w10, fmaf(b.y, w01, a.y * w00)));
+    sc[k4 + 2] = fmaf(d.z, w11, fmaf(c.z, w10, fmaf(b.z, w01, a.z * w00)));
+    sc[k4 + 3] = fmaf(d.w, w11, fmaf(c.w, w10, fmaf(b.w, w01, a.w * w00)));
+  }
+#pragma unroll
+  for (int k = 0; k < CM; ++k) sc[k] += bs_g[k < C ? k : C - 1];
+}
+
+template <int CM>
+__device__ __forceinline__ float head_max(const float (&sc)[CM], int C) {
+  float m = sc[0];
+#pragma unroll
+  for (int k = 1; k < CM; ++k)
+    if (k < C) m = fmaxf(m, sc[k]);
+  return m;
+}
+
+// labels only (the experts of a Bayes fusion): argmax(softmax(x)) is argmax(x) unless the runner-up is so close that
+// the two probabilities round to the same float (|difference| < ~1e-7); only then does the reference's tie rule
+// (lowest index among equal PROBABILITIES) need the probabilities themselves.  Returns -1 in that case.
+template <int CM>
+__device__ __forceinline__ int head_label_fast(const float (&sc)[CM], float m, int C) {
+  int bi = 0, near = 0;
+#pragma unroll
+  for (int k = CM - 1; k >= 0; --k)
+    if (k < C) {
+      if (sc[k] == m) bi = k;
+      near += (m - sc[k]) <= 1e-5f ? 1 : 0;
+    }
+  return near == 1 ? bi : -1;
+}
+
+// sc <- softmax(sc) (tf.nn.softmax: exp(x - max) / sum); returns the label, lowest index on ties
+template <int CM>
+__device__ __forceinline__ int head_softmax(float (&sc)[CM], float m, int C) {
+  float sum = 0.f;
+#pragma unroll
+  for (int k = 0; k < CM; ++k) {
+    sc[k] = k < C ? expf(sc[k] - m) : 0.f;
+    sum += sc[k];
+  }
+  float best = -1.f;
+  int bi = 0;
+#pragma unroll
+  for (int k = 0; k < CM; ++k) {
+    sc[k] = sc[k] / sum;
+    if (k < C && sc[k] > best) {
+      best = sc[k];
+      bi = k;
+    }
+  }
+  return bi;
+}
+
 template <int CM>
 __global__ __launch_bounds__(256) void decoder_head_kernel(const float* __restrict__ S, const float* __restrict__ bs_g,
                                                           int N, int Hi, int Wi, int C, float* __restrict__ score,
@@ -266,74 +338,110 @@ __global__ __launch_bounds__(256) void decoder_head_kernel(const float* __restri
   const int ox = (int)(opix % Wo);
   const int oy = (int)((opix / Wo) % Ho);
   const int n = (int)(opix / ((int64_t)Wo * Ho));
-  int iy1, ix1;
-  float wy1, wy0, wx1, wx0;
-  bilinear_taps<8>(oy, iy1, wy1, wy0);
-  bilinear_taps<8>(ox, ix1, wx1, wx0);
-  const float w00 = wy0 * wx0, w01 = wy0 * wx1, w10 = wy1 * wx0, w11 = wy1 * wx1;
-  // padded coords: logical source (iy1-1, ix1-1) is padded (iy1, ix1)
-  const float* p00 = S + (((int64_t)n * (Hi + 2) + iy1) * (Wi + 2) + ix1) * CM;
-  const int64_t rowp = (int64_t)(Wi + 2) * CM;
   float sc[CM];
-#pragma unroll
-  for (int k4 = 0; k4 < CM; k4 += 4) {
-    const f32x4 a = *reinterpret_cast<const f32x4*>(p00 + k4), b = *reinterpret_cast<const f32x4*>(p00 + CM + k4);
-    const f32x4 c = *reinterpret_cast<const f32x4*>(p00 + rowp + k4), d = *reinterpret_cast<const f32x4*>(p00 + rowp + CM + k4);
-    const f32x4 v = a * w00 + b * w01 + c * w10 + d * w11;
-    sc[k4] = v.x;
-    sc[k4 + 1] = v.y;
-    sc[k4 + 2] = v.z;
-    sc[k4 + 3] = v.w;
-  }
-#pragma unroll
-  for (int k = 0; k < CM; ++k) sc[k] += bs_g[k < C ? k : C - 1];
+  head_logits<CM>(S, bs_g, n, oy, ox, Hi, Wi, C, sc);
   if (score) {
 #pragma unroll
     for (int k = 0; k < CM; ++k)
       if (k < C) score[opix * C + k] = sc[k];
   }
   if (prob || label) {
-    float m = sc[0];
-#pragma unroll
-    for (int k = 1; k < CM; ++k)
-      if (k < C) m = fmaxf(m, sc[k]);
+    const float m = head_max<CM>(sc, C);
     if (!prob) {
-      // labels only (the experts of a Bayes fusion): argmax(softmax(x)) is argmax(x) unless the runner-up is so close
-      // that the two probabilities round to the same float (|difference| < ~1e-7); only then does the reference's
-      // tie rule (lowest index among equal PROBABILITIES) need the probabilities themselves
-      int bi = 0, near = 0;
-#pragma unroll
-      for (int k = CM - 1; k >= 0; --k)
-        if (k < C) {
-          if (sc[k] == m) bi = k;
-          near += (m - sc[k]) <= 1e-5f ? 1 : 0;
-        }
-      if (near == 1) {
-        label[opix] = bi;
+      const int fast = head_label_fast<CM>(sc, m, C);
+      if (fast >= 0) {
+        label[opix] = fast;
         return;
       }
     }
-    float sum = 0.f;
+    const int bi = head_softmax<CM>(sc, m, C);
+    if (prob) {
 #pragma unroll
-    for (int k = 0; k < CM; ++k) {
-      sc[k] = k < C ? expf(sc[k] - m) : 0.f;
-      sum += sc[k];
-    }
-    float best = -1.f;
-    int bi = 0;
-#pragma unroll
-    for (int k = 0; k < CM; ++k) {
-      const float p = sc[k] / sum;
-      if (k < C) {
-        if (prob) prob[opix * C + k] = p;
-        if (p > best) {
-          best = p;
-          bi = k;
-        }
-      }
+      for (int k = 0; k < CM; ++k)
+        if (k < C) prob[opix * C + k] = sc[k];
     }
     if (label) label[opix] = bi;
   }
+}
+
+// ---- fused two-expert head: both experts' low-resolution class scores -> per-pixel logits -> softmax / argmax of
+// each expert -> Bayes (bayes_mix.py:33-58) or Dirichlet (dirichlet_mix.py:14-36,96-136) fusion -> ONE fused label.
+// Replaces, for the default prediction of a two-expert fusion model, two decoder_head launches + the fusion kernel and
+// every per-pixel intermediate between them (Bayes: two int64 label maps written and read back; Dirichlet: two fp32
+// probability maps, 2 x 4C B per pixel each way).  The fusion arithmetic is the one of fusion.hip's kernels, term for
+// term, on the values the unfused path would have stored.  Tables in LDS: tab [2][C][CM], lognorm [2][CM] (Dirichlet),
+// logprior [CM].
+template <int CM, int DIRICHLET>
+__global__ __launch_bounds__(256) void fused_head_kernel(const float* __restrict__ Sa, const float* __restrict__ Sb,
+                                                        const float* __restrict__ ba, const float* __restrict__ bb, int N,
+                                                        int Hi, int Wi, int C, const float* __restrict__ tab_g,
+                                                        const float* __restrict__ lognorm_g,
+                                                        const float* __restrict__ logprior_g, int64_t* __restrict__ fused) {
+  extern __shared__ __attribute__((aligned(16))) float tab[];
+  float* ln = tab + 2 * C * CM;
+  float* lp = ln + 2 * CM;
+  for (int i = threadIdx.x; i < 2 * C * CM; i += 256) {
+    const int k = i % CM, row = i / CM;
+    tab[i] = k < C ? tab_g[row * C + k] : 0.f;
+  }
+  for (int i = threadIdx.x; i < 2 * CM; i += 256) {
+    const int k = i % CM, e = i / CM;
+    ln[i] = (DIRICHLET && k < C) ? lognorm_g[e * C + k] : 0.f;
+  }
+  if (threadIdx.x < CM) lp[threadIdx.x] = threadIdx.x < C ? logprior_g[threadIdx.x] : 0.f;
+  __syncthreads();
+  const int Ho = Hi * 8, Wo = Wi * 8;
+  const int64_t npix = (int64_t)N * Ho * Wo;
+  const int64_t opix = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (opix >= npix) return;
+  const int ox = (int)(opix % Wo);
+  const int oy = (int)((opix / Wo) % Ho);
+  const int n = (int)(opix / ((int64_t)Wo * Ho));
+  float total[CM];
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    float sc[CM];
+    head_logits<CM>(e == 0 ? Sa : Sb, e == 0 ? ba : bb, n, oy, ox, Hi, Wi, C, sc);
+    const float m = head_max<CM>(sc, C);
+    if (!DIRICHLET) {
+      int l = head_label_fast<CM>(sc, m, C);
+      if (l < 0) l = head_softmax<CM>(sc, m, C);
+      const float* row = tab + ((int64_t)e * C + l) * CM;
+#pragma unroll
+      for (int k = 0; k < CM; ++k) total[k] = e == 0 ? row[k] : total[k] + row[k];
+    } else {
+      head_softmax<CM>(sc, m, C);  // sc = the probabilities the unfused path stores
+      float sum = 0.f;
+#pragma unroll
+      for (int k = 0; k < CM; ++k) {
+        sc[k] = k < C ? sc[k] : 0.f;
+        sum += sc[k];
+      }
+#pragma unroll
+      for (int k = 0; k < CM; ++k) sc[k] = k < C ? logf(1e-20f + sc[k] / sum) : 0.f;  // renormalise, then log(1e-20 + p)
+      for (int c = 0; c < C; ++c) {
+        const float* row = tab + ((int64_t)e * C + c) * CM;
+        float dot = 0.f;
+#pragma unroll
+        for (int k = 0; k < CM; ++k) dot = fmaf(row[k], sc[k], dot);  // as dirichlet_fuse_kernel, bit for bit
+        const float L = dot - ln[e * CM + c];
+#pragma unroll
+        for (int cc = 0; cc < CM; ++cc)
+          if (cc == c) total[cc] = e == 0 ? L : total[cc] + L;
+      }
+    }
+  }
+  float best = 0.f;
+  int bi = 0;
+#pragma unroll
+  for (int k = 0; k < CM; ++k) {
+    const float v = total[k] + lp[k];
+    if (k < C && (k == 0 || v > best)) {
+      best = v;
+      bi = k;
+    }
+  }
+  fused[opix] = bi;
 }
 
 // ---- softmax + argmax on dense fp32 scores (basic_fusion_model.py:21-22) -------------------------
@@ -663,6 +771,40 @@ extern "C" int xv_score_lowres(const xv_act* fused, const float* w_score, int nu
     default: XV_SL(32); break;
   }
 #undef XV_SL
+  return xv_launch_status();
+}
+
+// Fused head of a two-expert fusion model (see fused_head_kernel): Sa / Sb from xv_score_lowres of each expert's `fused`
+// map; mode 0 = Bayes (tab = loglik [2][C][C], lognorm unused), 1 = Dirichlet (tab = am1 [2][C][C], lognorm [2][C]).
+extern "C" int xv_fused_head_fwd(const float* Sa, const float* Sb, const float* bias_a, const float* bias_b, int n, int hi,
+                                 int wi, int num_classes, int mode, const float* tab, const float* lognorm,
+                                 const float* logprior, int64_t* fused_label, void* stream) {
+  XV_CHECK_ARG(Sa && Sb && bias_a && bias_b && tab && logprior && fused_label && (mode == 0 || (mode == 1 && lognorm)));
+  XV_CHECK_SHAPE(n > 0 && hi > 0 && wi > 0 && num_classes >= 1 && num_classes <= 32);
+  const int64_t npix = (int64_t)n * hi * 8 * wi * 8;
+  const unsigned grid = (unsigned)((npix + 255) / 256);
+  hipStream_t s = (hipStream_t)stream;
+#define XV_FH(CMV)                                                                                                      \
+  {                                                                                                                     \
+    const size_t lds = (size_t)(2 * num_classes * CMV + 3 * CMV) * 4;                                                   \
+    if (mode == 0)                                                                                                      \
+      hipLaunchKernelGGL((fused_head_kernel<CMV, 0>), dim3(grid), dim3(256), lds, s, Sa, Sb, bias_a, bias_b, n, hi, wi,  \
+                         num_classes, tab, lognorm, logprior, fused_label);                                             \
+    else                                                                                                                \
+      hipLaunchKernelGGL((fused_head_kernel<CMV, 1>), dim3(grid), dim3(256), lds, s, Sa, Sb, bias_a, bias_b, n, hi, wi,  \
+                         num_classes, tab, lognorm, logprior, fused_label);                                             \
+  }
+  switch ((num_classes + 3) / 4) {
+    case 1: XV_FH(4); break;
+    case 2: XV_FH(8); break;
+    case 3: XV_FH(12); break;
+    case 4: XV_FH(16); break;
+    case 5: XV_FH(20); break;
+    case 6: XV_FH(24); break;
+    case 7: XV_FH(28); break;
+    default: XV_FH(32); break;
+  }
+#undef XV_FH
   return xv_launch_status();
 }
 

@@ -7,7 +7,8 @@ from scipy.special import gammaln
 
 from . import ops
 from .base_model import BaseModel, iterate_batches
-from .basic_fusion_model import calibrate_experts, engine_options, expert_factory, run_experts, test_pipeline  # noqa: F401
+from .basic_fusion_model import (calibrate_experts, engine_options, expert_factory, fused_head_applicable,  # noqa: F401
+                                 run_experts, run_fused_head, test_pipeline)
 from .dirichlet_fit import find_dirichlet_priors
 
 UNIFORM_PRIOR = 1.0 / 14     # dirichlet_mix.py:116
@@ -107,6 +108,10 @@ class DirichletFusion(BaseModel):
     def _predict_batch_impl(self, batch, output_attr=None):
         if not hasattr(self, 'am1'):
             raise UserWarning('ERROR: DirichletFusion has no measurements yet, call fit() first')
+        if output_attr is None and fused_head_applicable(self):
+            # default prediction: the experts' probabilities never leave the registers of the fused head kernel
+            self.probs = None
+            return run_fused_head(self, batch, self.am1, self.logprior, lognorm=self.lognorm)
         outs = run_experts(self, batch, ('prob',))
         probs = [outs[m]['prob'] for m in self.modalities]
         self.probs = dict(zip(self.modalities, probs))

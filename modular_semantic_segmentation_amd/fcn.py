@@ -283,6 +283,24 @@ class FcnEngine(object):
         L.update(score_conv4=s4, score_conv5=s5, fused=fused)
         return L
 
+    def commuted_head(self):
+        """True if the decoder head runs in its commuted form (class scores interpolated at 1/8 resolution): no batch-norm
+        shift between the x8 deconv and its relu, bilinear deconv kernel -- the precondition of `lowres_scores`."""
+        return 'upscore' not in self.affine and 'upscore' not in self.dense_deconv
+
+    def lowres_scores(self, x):
+        """Trunk + the 1x1 score conv at 1/8 resolution: float32 [N][h/8+2][w/8+2][CP] (the first half of the decoder
+        head, xv_score_lowres); the fused two-expert head of the fusion models takes it from here."""
+        L = self.encoder(x)
+        f = L['fused']
+        cp = (self.C + 3) // 4 * 4
+        key = ('lowres_S', f.n, f.h, f.w)
+        S = self._arena.get(key)
+        if S is None:
+            S = self._arena[key] = torch.zeros((f.n, f.h + 2, f.w + 2, cp), dtype=torch.float32, device=self.device)
+        ops.score_lowres(f, self.w['score'], self.C, S)
+        return S, (f.n, f.h, f.w)
+
     def forward(self, x, want=('label',), keep_all=False):
         """fcn + test_pipeline (basic_fusion_model.py:9-23): returns dict with any of
         'score', 'prob' (float32 [N,H,W,C]) and 'label' == 'classification' (int64 [N,H,W])."""

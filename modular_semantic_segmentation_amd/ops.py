@@ -304,6 +304,24 @@ def decoder_head_fwd(fused, w_score, b_score, num_classes, want_score=False, wan
     return out
 
 
+def score_lowres(fused, w_score, num_classes, S):
+    """S[n][i][j][k] = fused . Ws at 1/8 resolution (float32 [N][h+2][w+2][CP], CP = C rounded up to 4)."""
+    _lib.check(_lib.lib().xv_score_lowres(fused.xv(), _ptr(w_score), int(num_classes), _ptr(S), _stream()), 'xv_score_lowres')
+    return S
+
+
+def fused_head(Sa, Sb, bias_a, bias_b, n, hi, wi, num_classes, tab, logprior, lognorm=None, out=None):
+    """Both experts' low-resolution scores -> the fused label map (int64 [n, 8hi, 8wi]); lognorm given = Dirichlet
+    fusion (tab = alpha - 1), else Bayes (tab = log-likelihood tables)."""
+    if out is None:
+        out = torch.empty((n, 8 * hi, 8 * wi), dtype=torch.int64, device=Sa.device)
+    rc = _lib.lib().xv_fused_head_fwd(_ptr(Sa), _ptr(Sb), _ptr(bias_a), _ptr(bias_b), n, hi, wi, int(num_classes),
+                                     0 if lognorm is None else 1, _ptr(tab), _ptr(lognorm), _ptr(logprior), _ptr(out),
+                                     _stream())
+    _lib.check(rc, 'xv_fused_head_fwd')
+    return out
+
+
 def softmax_argmax(score, want_prob=True, want_label=True):
     _need(score, torch.float32, 'score')
     c = score.shape[-1]

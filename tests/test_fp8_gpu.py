@@ -271,6 +271,8 @@ def test_fp8_fusion_model_predicts(ops, golden_dir):
             scales = net.calibrate(data)
             assert set(scales) == {'rgb', 'depth'}
         preds[dt] = net.predict(data)
+        score = net.predict(data, output_attr='fused_score')
+        assert np.array_equal(preds[dt], np.argmax(score, -1))           # fused head == unfused path, fp8 trunk too
         la = net.expert_outputs['rgb']['classification']
         assert la.shape == (2, 64, 96)
     assert preds['fp8'].shape == (2, 64, 96) and preds['fp8'].dtype == np.int64

@@ -95,14 +95,15 @@ def test_bayes_fusion_model_large_images(ops, golden_dir, h, w):
     data = {'rgb': rng.integers(0, 256, (2, h, w, 3)).astype(np.float32),
             'depth': rng.integers(0, 65536, (2, h, w, 1)).astype(np.float32),
             'labels': rng.integers(-1, C, (2, h, w)).astype(np.int32)}
-    both = net.predict(data)
+    both = net.predict(data)                         # default path: fused two-expert head
+    assert both.shape == (2, h, w) and both.dtype == np.int64
+    score = net.predict(data, output_attr='fused_score')          # unfused path, expert label maps materialised
+    assert np.array_equal(both, np.argmax(score, -1))             # fused head == head + fusion kernels, bit for bit
     la = net.expert_outputs['rgb']['classification'].clone()
     lb = net.expert_outputs['depth']['classification'].clone()
-    assert both.shape == (2, h, w) and both.dtype == np.int64
     single = net.predict({k: v[1:2] for k, v in data.items()})
     assert np.array_equal(single[0], both[1])
     lut = ops.bayes_fuse_lut(la, lb, net.decision_matrix).cpu().numpy()
-    score = net.predict(data, output_attr='fused_score')
     top2 = np.sort(score, -1)[..., -2:]
     clear = (top2[..., 1] - top2[..., 0]) > 1e-4
     assert np.array_equal(lut[clear], both[clear])

@@ -122,12 +122,13 @@ def test_bayes_fusion_model(gpu, tmp_path, golden_dir):
                                     expert_model='fcn', class_prior='data', batchsize=2)
     net.import_weights(pr, warnings=False)
     net.import_weights(pd, warnings=False)
-    fused = net.predict(data)
+    fused = net.predict(data)                        # default path: the fused two-expert head kernel
+    assert net.expert_outputs is None
+    got_score = net.predict(data, output_attr='fused_score')      # unfused path: expert label maps materialised
     la = net.expert_outputs['rgb']['classification'].cpu().numpy()
     lb = net.expert_outputs['depth']['classification'].cpu().numpy()
     mats = [cms['rgb'].astype('float32').T, cms['depth'].astype('float32').T]
     ref_score, _, _ = fu.bayes_fusion([la, lb], mats, 'data')
-    got_score = net.predict(data, output_attr='fused_score')
     np.testing.assert_allclose(got_score, ref_score, rtol=1e-6, atol=1e-5)
     assert np.array_equal(fused, np.argmax(got_score, -1))
     measures, cm = net.score(data)
@@ -182,7 +183,7 @@ def test_dirichlet_fusion_fit_and_predict(gpu, tmp_path):
     S, counts = net._get_sufficient_statistic(data)
     Sref = np.zeros((C, C))
     for b in (slice(0, 2), slice(2, 4)):
-        net.predict({k: v[b] for k, v in data.items()})
+        net.predict({k: v[b] for k, v in data.items()}, output_attr='fused_score')
         p = net.probs['rgb'].cpu().numpy()
         Sref += fu.sufficient_statistics(p, data['labels'][b], C)[0]
     np.testing.assert_allclose(S['rgb'], Sref, rtol=1e-6, atol=1e-3)
@@ -445,3 +446,43 @@ def test_fcn_with_imported_dense_deconv_kernels(gpu):
     assert np.abs(up - ref['upscore']).max() < 2e-2 * np.abs(ref['upscore']).max()
     _check_logits_and_labels(out['score'].cpu().numpy(), out['label'].cpu().numpy(), ref['score'], 'dense deconv')
     np.testing.assert_allclose(out['prob'].cpu().numpy().sum(-1), 1.0, atol=1e-5)
+
+
+@pytest.mark.parametrize('kind', ['bayes', 'dirichlet'])
+def test_fused_head_equals_unfused_path(gpu, tmp_path, golden_dir, kind):
+    """The default prediction of a two-expert fusion model runs ONE fused head kernel after the trunks (logits, per-expert
+    softmax / argmax and the Bayes / Dirichlet mix in registers).  Its labels must equal, bit for bit, those of the
+    unfused path (decoder head per expert -> label / probability maps in HBM -> fusion kernel), which is the path the
+    oracle comparisons of this file pin; serial and two-stream execution agree as well."""
+    from modular_semantic_segmentation_amd import get_model
+    g = np.load(os.path.join(golden_dir, 'notebook_868.npz'))
+    data = _data(3, seed=21)
+    _, pr = _weights(tmp_path, 'rgb', 3, 1, 0.02)
+    _, pd = _weights(tmp_path, 'depth', 1, 2, 2e-4)
+    common = dict(data_description=_desc(), num_units=U, num_channels={'rgb': 3, 'depth': 1}, expert_model='fcn',
+                  class_prior='data', batchsize=3)
+    rng = np.random.default_rng(4)
+
+    def make(**kw):
+        if kind == 'bayes':
+            net = get_model('bayes_fusion')(confusion_matrices={'rgb': g['cm_rgb'], 'depth': g['cm_depth']},
+                                            prefixes={'rgb': 'rgb', 'depth': 'depth'}, **common, **kw)
+        else:
+            params = {'rgb': rng.uniform(0.5, 4.0, (C, C)), 'depth': rng.uniform(0.5, 4.0, (C, C)),
+                      'class_counts': g['cm_depth'].sum(1)}
+            net = get_model('dirichlet_fusion')(dirichlet_params=params, modalities=['rgb', 'depth'], sigma=1.0, delta=1e-2,
+                                                beta=1e-2, **common, **kw)
+            make.params = params
+        net.import_weights(pr, warnings=False)
+        net.import_weights(pd, warnings=False)
+        return net
+
+    fused_net = make()
+    got = fused_net.predict(data)
+    plain = fused_net
+    plain.config['fused_head'] = False
+    ref = plain.predict(data)
+    assert np.array_equal(got, ref)
+    plain.config['fused_head'] = True
+    plain.concurrent_experts = False
+    assert np.array_equal(plain.predict(data), ref)
