@@ -12,6 +12,7 @@
 //   staged ONCE in LDS and re-read by all 9 taps; the 64*NW x 64 weight tile of each tap is
 //   double-buffered.  Pixel rows / weight rows are 128 B in LDS with a 16-byte-slot XOR swizzle
 //   (xv_swz) so the 16-lane ds_read_b128 groups are bank-conflict free.
+#include <cstdlib>
 #include <type_traits>
 
 #include "xv_common.h"
@@ -239,7 +240,8 @@ __global__ __launch_bounds__(64 * WR * WC * NW, OCC) void conv_mfma_kernel(ConvA
   using C = ConvCfg<MT, WR, WC, NW, KS, TPS>;
   constexpr int ESZ = F8 ? 1 : 2;  // bytes per activation element
   // (fp8: fragments are twice as wide and the cross-item prefetch no longer fits 256 registers -- it spilled 500+)
-  constexpr bool PFA = !F8 && ((MT == 4) || (OCC == 1));
+  // F8 == 2: the fp8 kernel WITH the prefetch (tuning variant, XV_F8_PFA=1)
+  constexpr bool PFA = (F8 != 1) && ((MT == 4) || (OCC == 1));
   constexpr int PFD = XV_CONV_PFD;  // how many stages before the end of an item its successor's patch is requested
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const As = smem;
@@ -1259,6 +1261,15 @@ int launch_cfg(int cfg, const ConvArgs& a, hipStream_t s) {
   if (a.Cout % kGeo[cfg].bn) return XV_ESHAPE;
   if (a.in_f8) {
     // the fp8 kernel is built for the tile shapes with LDS-DMA weight stages (the ones the bf16 chooser falls back to)
+    static const bool pfa = getenv("XV_F8_PFA") != nullptr && getenv("XV_F8_PFA")[0] == '1';
+    if (pfa) {
+      switch (cfg) {
+        case 14: return launch_conv<4, 4, 1, 1, KS, 2, 2, 1, 2>(a, s);
+        case 15: return launch_conv<4, 2, 2, 1, KS, 2, 2, 1, 2>(a, s);
+        case 16: return launch_conv<4, 4, 2, 1, KS, 2, 5, 1, 2>(a, s);
+        default: return XV_ESHAPE;
+      }
+    }
     switch (cfg) {
       case 14: return launch_conv<4, 4, 1, 1, KS, 2, 2, 1, 1>(a, s);
       case 15: return launch_conv<4, 2, 2, 1, KS, 2, 2, 1, 1>(a, s);

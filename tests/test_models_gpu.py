@@ -486,3 +486,37 @@ def test_fused_head_equals_unfused_path(gpu, tmp_path, golden_dir, kind):
     plain.config['fused_head'] = True
     plain.concurrent_experts = False
     assert np.array_equal(plain.predict(data), ref)
+
+
+def test_config1_simple_fcn_rgb_256x512_14_classes(gpu, tmp_path):
+    """BASELINE.json configs[0]: SimpleFCN RGB-only, Synthia 256x512 (tensor [1,256,512,3]), batch 1, 14 classes -- the
+    reference's own CPU-runnable case: the oracle IS that CPU path restated; the HIP path must reproduce its label map
+    (wherever the fp32 margin is clear) and its `score` measures on the same weights through the model API."""
+    from modular_semantic_segmentation_amd import get_model
+    C14 = 14
+    rng = np.random.default_rng(14)
+    data = {'rgb': rng.integers(0, 256, (1, 256, 512, 3)).astype(np.float32),
+            'labels': rng.integers(-1, C14, (1, 256, 512)).astype(np.int32)}
+    w = fo.init_fcn_weights('rgb', 3, U, C14, seed=7, bias_scale=0.02)
+    w['rgb/conv1_1/kernel'] *= 0.02
+    for k in w:
+        if k.endswith('/kernel') and 'upscore' not in k and 'conv1_1' not in k:
+            w[k] *= 1.6
+    desc = ({'rgb': 'float32', 'labels': 'int32'}, {'rgb': (256, 512, 3), 'labels': (256, 512)}, C14)
+    net = get_model('fcn')('rgb', desc, 'rgb', num_units=U, batch_normalization=False, batchsize=1)
+    net.variables.update(w)
+    net._variables_changed()
+    pred = net.predict(data)
+    score = net.predict(data, output_attr='score')
+    assert pred.shape == (1, 256, 512) and pred.dtype == np.int64 and score.shape == (1, 256, 512, C14)
+    ref = fo.fcn_forward(data['rgb'], w, 'rgb', 'fp32', keep=['score'])['score']          # the reference's fp32 graph
+    scale = np.abs(ref).max()
+    assert np.abs(score - ref).max() / scale < 3e-2
+    ref_lab = fo.argmax_last(fo.softmax(ref))
+    top2 = np.sort(ref, -1)[..., -2:]
+    clear = (top2[..., 1] - top2[..., 0]) > 6e-2 * scale
+    assert np.array_equal(pred[clear], ref_lab[clear])
+    measures, cm = net.score(data)
+    assert np.array_equal(cm, fu.confusion_matrix(data['labels'], pred, C14).astype(np.float64))
+    ref_measures = fu.score_measures(fu.confusion_matrix(data['labels'], pred, C14))
+    assert measures['mean_IoU'] == ref_measures['mean_IoU'] or (np.isnan(measures['mean_IoU']) and np.isnan(ref_measures['mean_IoU']))

@@ -17,6 +17,38 @@ LAYERS = [('conv1_2', 1, 64, 64, 3, True), ('conv2_1', 2, 64, 128, 3, False), ('
           ('score_conv5', 16, 512, 64, 1, False)]
 
 
+def tune_fp8(args):
+    cfgs = [int(c) for c in args.cfgs.split(',')] if args.cfgs else [14, 15, 16]
+    print('layer        ' + ''.join('cfg%-6d' % c for c in cfgs) + ' default   (fp8 e4m3 operands, TFLOP/s)')
+    for name, s, cin, cout, k, pool in LAYERS:
+        if cin < 128:
+            continue
+        h, w = args.height // s, args.width // s
+        x = ops.Act.from_dense(torch.randn(args.batch, h, w, cin, device='cuda').abs() * 40, dtype='fp8', scale_exp=0)
+        wt = torch.randn(k, k, cin, cout, device='cuda') * (1.0 / (k * k * cin) ** 0.5)
+        wp, _ = ops.pack_conv_weights_f8(wt)
+        b = torch.zeros(cout, device='cuda')
+        y = ops.Act(args.batch, h, w, cout, dtype='fp8', scale_exp=1)
+        q = ops.Act(args.batch, h // 2, w // 2, cout, dtype='fp8', scale_exp=1) if pool else None
+        flops = 2.0 * args.batch * h * w * cin * cout * k * k
+        row = '%-12s ' % name
+        yy = None if (pool and args.pooled_only) else y
+        for cfg in cfgs + [-1]:
+            try:
+                for _ in range(2):
+                    ops.conv2d_fwd(x, wp, b, k, y=yy, pooled=q, write_y=yy is not None, cfg=cfg)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(args.iters):
+                    ops.conv2d_fwd(x, wp, b, k, y=yy, pooled=q, write_y=yy is not None, cfg=cfg)
+                e1.record()
+                torch.cuda.synchronize()
+                row += '%-9.0f' % (flops / (e0.elapsed_time(e1) / args.iters) / 1e9)
+            except _lib.XvError:
+                row += '%-9s' % '-'
+        print(row, flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--batch', type=int, default=8)
@@ -26,7 +58,10 @@ def main():
     ap.add_argument('--cfgs', type=str, default='', help='comma-separated subset of configurations')
     ap.add_argument('--no-wgrad', action='store_true')
     ap.add_argument('--pooled-only', action='store_true', help='pool layers write only the pooled map')
+    ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp8'], help="fp8: e4m3 operands and outputs (cin >= 128)")
     args = ap.parse_args()
+    if args.dtype == 'fp8':
+        return tune_fp8(args)
     ncfg = _lib.lib().xv_conv2d_num_cfgs()
     cfgs = [int(c) for c in args.cfgs.split(',')] if args.cfgs else list(range(ncfg))
     print('layer        ' + ''.join('cfg%-6d' % c for c in cfgs) + ' default')
