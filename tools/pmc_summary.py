@@ -8,6 +8,7 @@ import glob
 import hashlib
 import json
 import os
+import re
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -21,7 +22,7 @@ def kernel_source_hash():
 
 
 def counter_avg(dirname, counter, match):
-    f = glob.glob('gpurun_out/%s/*/*counter_collection.csv' % dirname)
+    f = glob.glob('gpurun_out/%s/**/*counter_collection.csv' % dirname, recursive=True)
     if not f:
         return None
     n, tot = 0, 0.0
@@ -30,6 +31,58 @@ def counter_avg(dirname, counter, match):
             n += 1
             tot += float(r['Counter_Value'])
     return (tot / n, n) if n else None
+
+
+def counters_by_kernel(dirname, groups):
+    """{group: {counter: (mean per launch, launches)}} from one --pmc pass; groups = {name: predicate on kernel name}."""
+    f = glob.glob('gpurun_out/%s/**/*counter_collection.csv' % dirname, recursive=True)
+    out = {}
+    if not f:
+        return out
+    acc = {}
+    for r in csv.DictReader(open(f[0])):
+        for g, match in groups.items():
+            if match(r['Kernel_Name']):
+                d = acc.setdefault((g, r['Counter_Name']), [0.0, 0])
+                d[0] += float(r['Counter_Value'])
+                d[1] += 1
+    for (g, c), (tot, n) in acc.items():
+        out.setdefault(g, {})[c] = (tot / n, n)
+    return out
+
+
+def mfma_summary(tag, suffix, groups, command):
+    """MFMA utilisation and the wave-cycle split per kernel group (gfx94x MfmaUtil formula: matrix-pipe busy cycles
+    summed over the 1024 SIMDs over GRBM_GUI_ACTIVE summed over the 8 XCDs)."""
+    mf = counters_by_kernel('pmc_mfma' + suffix, groups)
+    wv = counters_by_kernel('pmc_wave' + suffix, groups)
+    out = {'source': 'rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_WAVE_CYCLES -- ' + command +
+           ' (counters only, no traces); second pass: SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY '
+           'SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS',
+           'note': 'mfma_util = MFMA_BUSY / (1024 * GUI_ACTIVE / 8); wave-cycle fractions are of SQ_WAVE_CYCLES (WAIT_ANY = parked '
+                   'at s_waitcnt / s_barrier, WAIT_INST_ANY = issue stall, mostly the matrix pipe busy with the SIMD\'s other wave)',
+           'kernel_source_sha256_16': kernel_source_hash(), 'kernels': {}}
+    for g in groups:
+        if g not in mf or 'SQ_VALU_MFMA_BUSY_CYCLES' not in mf[g]:
+            continue
+        busy, n = mf[g]['SQ_VALU_MFMA_BUSY_CYCLES']
+        gui = mf[g]['GRBM_GUI_ACTIVE'][0]
+        rec = {'launches': n, 'mfma_busy_cycles_per_launch': int(busy), 'gui_active_cycles_per_launch': int(gui),
+               'mfma_util': round(busy / (1024 * gui / 8), 4)}
+        if g in wv and 'SQ_WAVE_CYCLES' in wv[g]:
+            tot = wv[g]['SQ_WAVE_CYCLES'][0]
+            rec['wave_cycle_fractions'] = {c: round(v[0] / tot, 3) for c, v in sorted(wv[g].items()) if c != 'SQ_WAVE_CYCLES'}
+        out['kernels'][g] = rec
+    json.dump(out, open('profiles/%s_conv_mfma_util%s.json' % (tag, '_fp8' if suffix else ''), 'w'), indent=1)
+    print(out)
+
+
+def copy_stats(tag, sub, dest):
+    """The rocprofv3 --kernel-trace --stats summary (per-kernel calls / total / average ns) -> profiles/."""
+    f = glob.glob('gpurun_out/%s/**/*kernel_stats.csv' % sub, recursive=True)
+    if f:
+        open('profiles/%s' % dest, 'w').write(open(f[0]).read())
+        print('copied', f[0], '->', dest)
 
 
 def main(tag, batch=16):
@@ -46,6 +99,20 @@ def main(tag, batch=16):
                    correction='read bytes = 2 x FETCH_SIZE (gfx950 counts 128-B requests as 64 B); WRITE_SIZE exact')
     json.dump(out, open('profiles/%s_conv_traffic.json' % tag, 'w'), indent=1)
     print(out)
+    def is_f8(k):
+        """conv_mfma_kernel<MT, WR, WC, NW, KS, OCC, TPS, DMAB, F8>: the last template argument"""
+        m = re.search(r'conv_mfma_kernel<([^>]*)>', k)
+        return bool(m) and m.group(1).split(',')[-1].strip() in ('1', '2')
+
+    cmd = 'python3 bench.py --steps 3 --warmup 1 --serial-experts --no-graph --no-cpu-baseline --no-accuracy --no-extra'
+    mfma_summary(tag, '', {'conv_dma_kernel': lambda k: 'conv_dma_kernel' in k,
+                           'conv_mfma_kernel (bf16, first generation)': lambda k: 'conv_mfma_kernel' in k and not is_f8(k)},
+                 cmd + ' (batch 16, 768x384)')
+    mfma_summary(tag, '8', {'conv_mfma_kernel<F8> (e4m3 operands)': is_f8,
+                            'conv_dma_kernel (conv1_2, bf16)': lambda k: 'conv_dma_kernel' in k},
+                 cmd + ' --dtype fp8 --height 1024 --width 2048 --batch 4')
+    copy_stats(tag, tag + '_trace', '%s_bench_serial_kernel_stats.csv' % tag)
+    copy_stats(tag, tag + '_trace8', '%s_bench_fp8_2048_kernel_stats.csv' % tag)
 
 
 if __name__ == '__main__':

@@ -1,0 +1,24 @@
+#!/bin/bash
+# Run on the GPU box (gpurun -- 'bash tools/profile_round.sh r2'): the rocprofv3 passes whose summaries are committed
+# under profiles/ -- kernel trace + stats of the headline command with the experts serialised (per-kernel times), the
+# FETCH_SIZE / WRITE_SIZE passes (HBM traffic of the conv kernel; separate --pmc passes, counters only), the MFMA /
+# wave-cycle passes, and the same for the fp8 configuration at 2048x1024.  Raw outputs go to gpurun_out/ (scratch);
+# tools/pmc_summary.py condenses them.
+TAG=${1:-r2}
+ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+OUT=$ROOT/gpurun_out
+cd /tmp && export TMPDIR=/tmp
+BENCH="python3 $ROOT/bench.py --steps 3 --warmup 1 --serial-experts --no-graph --no-cpu-baseline --no-accuracy --no-extra"
+FP8="$BENCH --dtype fp8 --height 1024 --width 2048 --batch 4"
+run() { d=$1; shift; rm -rf $OUT/$d; rocprofv3 --output-format csv "$@" > $OUT/$d.log 2>&1; }
+run ${TAG}_trace   --kernel-trace --stats -d $OUT/${TAG}_trace -o bench -- $BENCH
+run ${TAG}_trace8  --kernel-trace --stats -d $OUT/${TAG}_trace8 -o bench -- $FP8
+run pmc_fetch      --pmc FETCH_SIZE -d $OUT/pmc_fetch -o c -- $BENCH
+run pmc_write      --pmc WRITE_SIZE -d $OUT/pmc_write -o c -- $BENCH
+run pmc_mfma       --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_WAVE_CYCLES -d $OUT/pmc_mfma -o c -- $BENCH
+run pmc_wave       --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS -d $OUT/pmc_wave -o c -- $BENCH
+run pmc_mfma8      --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_WAVE_CYCLES -d $OUT/pmc_mfma8 -o c -- $FP8
+run pmc_wave8      --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS -d $OUT/pmc_wave8 -o c -- $FP8
+cd $ROOT
+python3 tools/pmc_summary.py $TAG 16
+ls $OUT/${TAG}_trace/*/ 2>/dev/null | head; tail -3 $OUT/${TAG}_trace.log
