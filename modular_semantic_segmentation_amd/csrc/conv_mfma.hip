@@ -766,7 +766,10 @@ __device__ long long xv_trace_buf[8 * 8 * 20 * 6];
 #define XV_STAMP(k)
 #endif
 
-template <int WR, int WC>
+// PRIO (tuning variants, XV_DMA_PRIO): 0 = a burst raises its priority after its first MFMA and drops it at its end (default);
+// 1 = static: waves 4-7 (the second-dispatched half, the arbitration loser) run at priority 1, no per-burst flips
+// (MI355X_MICROARCH.md, two waves per SIMD, item 4); 2 = no priority changes at all
+template <int WR, int WC, int PRIO = 0>
 __global__ __launch_bounds__(64 * WR * WC, 2) void conv_dma_kernel(ConvArgs a) {
   using C = DmaCfg<WR, WC>;
   constexpr int MT = C::MT;
@@ -887,6 +890,9 @@ __global__ __launch_bounds__(64 * WR * WC, 2) void conv_dma_kernel(ConvArgs a) {
 
   int lid = t_begin + bi;
   if (lid >= t_end) return;
+  if constexpr (PRIO == 1) {
+    if (wave >= C::NWAVES / 2) __builtin_amdgcn_s_setprio(1);
+  }
   Tile cur = decode(lid);
   int chunk = 0, buf = 0, bslot = 0;
 
@@ -1002,21 +1008,21 @@ __global__ __launch_bounds__(64 * WR * WC, 2) void conv_dma_kernel(ConvArgs a) {
        and the two alternate tap by tap. */                                                                  \
     if ((t) == 0 && chunk == 0) { /* first tap of a tile: C = 0 instead of cleared accumulators */   \
       acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[(t) & 1][0], xf[dx_ & 1][dy_], zero4, 0, 0, 0); \
-      __builtin_amdgcn_s_setprio(2);                                                               \
+      if constexpr (PRIO == 0) __builtin_amdgcn_s_setprio(2);                                      \
       __builtin_amdgcn_sched_barrier(0);                                                           \
       _Pragma("unroll") for (int i = 0; i < MT; ++i) _Pragma("unroll") for (int j = 0; j < 4; ++j) \
           if (i + j > 0)                                                                           \
             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[(t) & 1][j], xf[dx_ & 1][i + dy_], zero4, 0, 0, 0); \
     } else {                                                                                       \
       acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[(t) & 1][0], xf[dx_ & 1][dy_], acc[0][0], 0, 0, 0); \
-      __builtin_amdgcn_s_setprio(2);                                                               \
+      if constexpr (PRIO == 0) __builtin_amdgcn_s_setprio(2);                                      \
       __builtin_amdgcn_sched_barrier(0);                                                           \
       _Pragma("unroll") for (int i = 0; i < MT; ++i) _Pragma("unroll") for (int j = 0; j < 4; ++j) \
           if (i + j > 0)                                                                           \
             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[(t) & 1][j], xf[dx_ & 1][i + dy_], acc[i][j], 0, 0, 0); \
     }                                                                                              \
     __builtin_amdgcn_sched_barrier(0);                                                             \
-    __builtin_amdgcn_s_setprio(1);                                                                 \
+    if constexpr (PRIO == 0) __builtin_amdgcn_s_setprio(1);                                        \
     __builtin_amdgcn_sched_barrier(0);                                                             \
   }
     XV_LDW(0, 0);
@@ -1127,7 +1133,7 @@ __global__ __launch_bounds__(64 * WR * WC, 2) void conv_dma_kernel(ConvArgs a) {
 #undef XV_LDS128
 }
 
-template <int WR, int WC>
+template <int WR, int WC, int PRIO = 0>
 int launch_conv_dma(const ConvArgs& a0, hipStream_t stream) {
   using C = DmaCfg<WR, WC>;
   ConvArgs a = a0;
@@ -1138,7 +1144,7 @@ int launch_conv_dma(const ConvArgs& a0, hipStream_t stream) {
   a.n_ct = a.Cout / 64;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_dma_kernel<WR, WC>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_dma_kernel<WR, WC, PRIO>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES + XV_TRACE_LDS);
     if (e != hipSuccess) return (int)e;
     attr_set = true;
@@ -1149,7 +1155,7 @@ int launch_conv_dma(const ConvArgs& a0, hipStream_t stream) {
   a.n_tiles = (int)ntiles;
   const int64_t slots = a.num_cus;
   const int64_t nblk = ntiles < slots ? ntiles : slots;
-  hipLaunchKernelGGL((conv_dma_kernel<WR, WC>), dim3((unsigned)nblk), dim3(C::NT), C::LDS_BYTES + XV_TRACE_LDS, stream, a);
+  hipLaunchKernelGGL((conv_dma_kernel<WR, WC, PRIO>), dim3((unsigned)nblk), dim3(C::NT), C::LDS_BYTES + XV_TRACE_LDS, stream, a);
   return xv_launch_status();
 }
 
@@ -1297,7 +1303,16 @@ int launch_cfg(int cfg, const ConvArgs& a, hipStream_t s) {
     case 15: return launch_conv<4, 2, 2, 1, KS, 2, 2, 1>(a, s);
     case 16: return launch_conv<4, 4, 2, 1, KS, 2, 5, 1>(a, s);
     case 17:
-      if constexpr (KS == 3) return launch_conv_dma<4, 2>(a, s);
+      if constexpr (KS == 3) {
+#ifdef XV_DMA_PRIO_VARIANTS
+        // tuning build only (measured round 2, tools/conv_tune.py --cfgs 17 at 16 images: the per-burst scheme is 3-5 % ahead
+        // of both the static and the no-priority variant on every layer)
+        static const int prio = getenv("XV_DMA_PRIO") ? atoi(getenv("XV_DMA_PRIO")) : 0;
+        if (prio == 1) return launch_conv_dma<4, 2, 1>(a, s);
+        if (prio == 2) return launch_conv_dma<4, 2, 2>(a, s);
+#endif
+        return launch_conv_dma<4, 2>(a, s);
+      }
       return XV_ESHAPE;
     default:
       if constexpr (KS == 1) {
