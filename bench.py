@@ -449,7 +449,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-accuracy', action='store_true', help='skip the trained-experts accuracy evidence (N = 1 only)')
     ap.add_argument('--accuracy-steps', type=int, default=1500)
-    ap.add_argument('--accuracy-images', type=int, default=12)
+    ap.add_argument('--accuracy-images', type=int, default=24)
     ap.add_argument('--no-extra', action='store_true', help='skip the extra configurations / the train_dp record')
     ap.add_argument('--dist-backend', default='nccl', help="'nccl' (= RCCL over xGMI); 'gloo' only for smoke tests")
     ap.add_argument('--share-device', action='store_true',
