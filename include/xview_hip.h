@@ -148,6 +148,12 @@ int xv_upsample2x_affine_relu_add(const xv_act* x, const float* scale, const flo
 int xv_upsample2x_affine_act_add(const xv_act* x, const float* scale, const float* shift, const xv_act* residual,
                                  const xv_act* y, int relu, void* stream);
 
+/* tf.layers.dropout(x, rate, training=True) at the MC-dropout sites of encoder / decoder (simple_fcn.py:50-62,71-78,
+ * 124-126; enabled only by the uncertainty models, bayesian_fcn.py:74-89): y = x / (1 - rate) where a counter-based
+ * random draw per element (a function of `seed` and the element index only) keeps it, else 0.  Not TensorFlow's random
+ * stream: masks are reproducible per seed, not comparable with the reference's.                                    */
+int xv_dropout(const xv_act* x, const xv_act* y, float rate, uint64_t seed, void* stream);
+
 /* y = concat(a, b) along channels (tf.concat(axis=3) of the two trunks' conv4_3 / conv5_3, fusion_fcn.py:27-28). */
 int xv_concat_channels(const xv_act* a, const xv_act* b, const xv_act* y, void* stream);
 

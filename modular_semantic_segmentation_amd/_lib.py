@@ -47,6 +47,7 @@ SIGNATURES = {
     'xv_upsample2x_affine_relu_add': (_i, [_actp, _vp, _vp, _actp, _actp, _vp]),
     'xv_upsample2x_affine_act_add': (_i, [_actp, _vp, _vp, _actp, _actp, _i, _vp]),
     'xv_concat_channels': (_i, [_actp, _actp, _actp, _vp]),
+    'xv_dropout': (_i, [_actp, _actp, ctypes.c_float, ctypes.c_uint64, _vp]),
     'xv_conv2d_fwd_residual': (_i, [_actp, _vp, _vp, _actp, _actp, _i, _vp]),
     'xv_subsample2': (_i, [_actp, _actp, _vp]),
     'xv_gather_conv7s2': (_i, [_actp, _actp, _vp]),

@@ -735,6 +735,45 @@ int xv_launch_depth_to_space(const xv_act* z, const float* scale, const float* s
   return xv_launch_status();
 }
 
+// tf.layers.dropout(x, rate, training=True) (simple_fcn.py:50-62,71-78,124-126: the MC-dropout sites of encoder /
+// decoder): each element is kept with probability 1 - rate and scaled by 1 / (1 - rate), else zero.  Counter-based
+// random bits: a 64-bit mix of (seed, element index) per element, so a mask depends only on the seed, not on the launch
+// geometry.  Runs over the whole padded buffer (the zero border stays zero).  One thread = 8 channels.
+__device__ __forceinline__ uint32_t xv_mix32(uint64_t z) {  // splitmix64 finaliser, upper 32 bits
+  z += 0x9e3779b97f4a7c15ull;
+  z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+  z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+  return (uint32_t)((z ^ (z >> 31)) >> 32);
+}
+
+__global__ __launch_bounds__(256) void dropout_kernel(const u32x4* __restrict__ x, u32x4* __restrict__ y, int64_t total8,
+                                                     uint32_t drop_below, float scale, uint64_t seed) {
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total8; idx += (int64_t)gridDim.x * 256) {
+    const u32x4 v = x[idx];
+    u32x4 o;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const uint32_t r0 = xv_mix32(seed ^ (uint64_t)(idx * 8 + 2 * w) * 0xd1342543de82ef95ull);
+      const uint32_t r1 = xv_mix32(seed ^ (uint64_t)(idx * 8 + 2 * w + 1) * 0xd1342543de82ef95ull);
+      const float lo = r0 >= drop_below ? bf16_bits_to_f32(v[w] & 0xffffu) * scale : 0.f;
+      const float hi = r1 >= drop_below ? __builtin_bit_cast(float, v[w] & 0xffff0000u) * scale : 0.f;
+      o[w] = pack_bf16x2(lo, hi);
+    }
+    y[idx] = o;
+  }
+}
+
+extern "C" int xv_dropout(const xv_act* x, const xv_act* y, float rate, uint64_t seed, void* stream) {
+  XV_CHECK_ARG(x && y && x->data && y->data && rate >= 0.f && rate < 1.f);
+  XV_CHECK_SHAPE(x->n == y->n && x->h == y->h && x->w == y->w && x->c == y->c && (x->c & 7) == 0);
+  XV_CHECK_SHAPE(x->dtype == XV_BF16 && y->dtype == XV_BF16);
+  const int64_t total8 = (int64_t)x->n * (x->h + 2) * (x->w + 2) * (x->c >> 3);
+  const double thr = (double)rate * 4294967296.0;
+  hipLaunchKernelGGL(dropout_kernel, dim3(grid_for(total8)), dim3(256), 0, (hipStream_t)stream, (const u32x4*)x->data,
+                     (u32x4*)y->data, total8, (uint32_t)(thr > 4294967295.0 ? 4294967295.0 : thr), 1.f / (1.f - rate), seed);
+  return xv_launch_status();
+}
+
 // y[..., :Ca] = a, y[..., Ca:] = b over the whole padded buffers (tf.concat(axis=3), fusion_fcn.py:27-28)
 extern "C" int xv_concat_channels(const xv_act* a, const xv_act* b, const xv_act* y, void* stream) {
   XV_CHECK_ARG(a && b && y && a->data && b->data && y->data);

@@ -93,6 +93,10 @@ class FcnEngine(object):
             raise ValueError("conv_dtype must be 'bf16' or 'fp8'")
         self.conv_dtype = conv_dtype
         self.fp8_scales = None                    # {map name: power-of-two exponent}, set by calibrate()
+        # MC dropout (simple_fcn.py:50-62,71-78,124-126; only the uncertainty models enable it): sites after which
+        # tf.layers.dropout(training=True) is applied -- 'pool3', 'conv4_3', 'conv5_3' in the encoder, 'features' for the
+        # decoder input -- at rate dropout_rate; every forward pass draws new masks (dropout_seed + pass counter)
+        self.dropout_layers, self.dropout_rate, self.dropout_seed, self._dropout_pass = (), 0.0, 0, 0
         self._arena = {}
         self.load(variables)
 
@@ -254,6 +258,7 @@ class FcnEngine(object):
             ops.conv2d_first_fwd(x.contiguous(), self.w['conv1_1'], self.b['conv1_1'], cur, relu=True)
             L['conv1_1'] = cur
             ch, cw = h, w
+            drop = self._dropout if self.dropout_layers and self.dropout_rate > 0 else None
             for name, cout, pool in ENCODER[1:]:
                 if pool is None:
                     y = self._act(name, n, ch, cw, cout)
@@ -268,10 +273,16 @@ class FcnEngine(object):
                         L[name] = y
                     L[pool] = cur = q
                     ch, cw = ch // 2, cw // 2
+                    # simple_fcn.py:51-63: the dropout after pool4 is gated by 'pool3' too (a quirk of the reference:
+                    # 'pool4' alone enables nothing)
+                    if drop is not None and pool in ('pool3', 'pool4') and 'pool3' in self.dropout_layers:
+                        L[pool + '_drop'] = cur = drop(q, pool + '_drop')
             s4 = self._act('score_conv4', n, h // 8, w // 8, self.Up)
-            ops.conv2d_fwd(L['conv4_3'], self.w['score_conv4'], self.b['score_conv4'], 1, relu=True, y=s4)
+            c43 = drop(L['conv4_3'], 'conv4_3_drop') if drop is not None and 'conv4_3' in self.dropout_layers else L['conv4_3']
+            ops.conv2d_fwd(c43, self.w['score_conv4'], self.b['score_conv4'], 1, relu=True, y=s4)
             s5 = self._act('score_conv5', n, h // 16, w // 16, self.Up)
-            ops.conv2d_fwd(L['conv5_3'], self.w['score_conv5'], self.b['score_conv5'], 1, relu=True, y=s5)
+            c53 = drop(L['conv5_3'], 'conv5_3_drop') if drop is not None and 'conv5_3' in self.dropout_layers else L['conv5_3']
+            ops.conv2d_fwd(c53, self.w['score_conv5'], self.b['score_conv5'], 1, relu=True, y=s5)
         fused = self._act('fused', n, h // 8, w // 8, self.Up)
         aff = self.affine.get('upscore_conv5', (None, None))
         if 'upscore_conv5' in self.dense_deconv:
@@ -281,7 +292,22 @@ class FcnEngine(object):
         else:
             ops.upsample2x_relu_add(s5, residual=s4, y=fused, scale=aff[0], shift=aff[1])
         L.update(score_conv4=s4, score_conv5=s5, fused=fused)
+        if self.dropout_rate > 0 and 'features' in self.dropout_layers:
+            # decoder(..., dropout_rate) on its input features (simple_fcn.py:124-126)
+            L['fused'] = L['features_drop'] = self._dropout(fused, 'features_drop')
+        self._dropout_pass += 1
         return L
+
+    def set_dropout(self, dropout_layers, dropout_rate, seed=0):
+        """Enable (or, with an empty list / rate 0, disable) the MC-dropout sites of encoder / decoder."""
+        if self.conv_dtype != 'bf16' and dropout_layers and dropout_rate > 0:
+            raise NotImplementedError("dropout sites exist in the bf16 graph only (conv_dtype='fp8' is plain inference)")
+        self.dropout_layers, self.dropout_rate, self.dropout_seed = tuple(dropout_layers), float(dropout_rate), int(seed)
+
+    def _dropout(self, x, tag):
+        site = sum(ord(ch) for ch in tag)
+        seed = (self.dropout_seed * 0x9E3779B1 + self._dropout_pass * 1000003 + site) & 0xffffffffffffffff
+        return ops.dropout(x, self.dropout_rate, seed, y=self._act(tag, x.n, x.h, x.w, x.c))
 
     def commuted_head(self):
         """True if the decoder head runs in its commuted form (class scores interpolated at 1/8 resolution): no batch-norm

@@ -250,6 +250,14 @@ def im2col_dilated_pair(x, d1, d2, z=None):
     return z
 
 
+def dropout(x, rate, seed, y=None):
+    """tf.layers.dropout(x, rate, training=True): keep with probability 1 - rate, scale by 1 / (1 - rate)."""
+    if y is None:
+        y = Act(x.n, x.h, x.w, x.c, x.t.device)
+    _lib.check(_lib.lib().xv_dropout(x.xv(), y.xv(), float(rate), int(seed) & 0xffffffffffffffff, _stream()), 'xv_dropout')
+    return y
+
+
 def concat_channels(a, b, y=None):
     if y is None:
         y = Act(a.n, a.h, a.w, a.c + b.c, a.t.device)

@@ -21,20 +21,34 @@ def _engine_for(prefix, inputs, num_units, num_classes, variables):
     return eng
 
 
-def encoder(inputs, prefix, num_units, variables=None, num_classes=2, **unused):
+def encoder(inputs, prefix, num_units, dropout_rate=0.0, variables=None, num_classes=2, dropout_layers=(),
+            dropout_seed=0, **unused):
     """Functional form of simple_fcn.py:10-87: dict of layer outputs (ops.Act, bf16 padded NHWC), the
     encoding has key 'fused'.  inputs: float32 CUDA tensor [N,H,W,C_in]; variables: reference-schema dict
-    (default: fresh [TF1] initialisers).  trainable / batchnorm / dropout arguments of the reference are
-    accepted and ignored (inference graph, BN folded at load time)."""
-    return _engine_for(prefix, inputs, num_units, num_classes, variables).encoder(inputs, keep_all=True)
+    (default: fresh [TF1] initialisers).  dropout_rate / dropout_layers ('pool3', 'conv4_3', 'conv5_3'): the
+    reference's MC-dropout sites (always training=True; 'pool3' also drops after pool4, 'pool4' alone does nothing,
+    simple_fcn.py:51-63), adding 'pool3_drop' / 'pool4_drop' to the dict; every call draws new masks.  trainable /
+    batchnorm / is_training / reuse are accepted and ignored (inference graph, BN folded at load time)."""
+    eng = _engine_for(prefix, inputs, num_units, num_classes, variables)
+    eng.set_dropout([d for d in dropout_layers if d != 'features'], dropout_rate, dropout_seed)
+    try:
+        return eng.encoder(inputs, keep_all=True)
+    finally:
+        eng.set_dropout((), 0.0)
 
 
-def fcn(inputs, prefix, num_units, num_classes, variables=None, **unused):
+def fcn(inputs, prefix, num_units, num_classes, variables=None, dropout_rate=0.0, dropout_layers=(), dropout_seed=0,
+        **unused):
     """Functional form of simple_fcn.py:137-170 as experiments/timing.py uses it: all encoder layers plus
     'score' (float32 [N,H,W,C]); 'prob' and 'classification' of test_pipeline come for free from the same
-    fused decoder kernel."""
+    fused decoder kernel.  dropout_layers may name the encoder sites and 'features' (the decoder's input dropout,
+    simple_fcn.py:124-126), as bayesian_fcn.py:74-89 passes them."""
     eng = _engine_for(prefix, inputs, num_units, num_classes, variables)
-    out = eng.forward(inputs, want=('score', 'prob', 'label'), keep_all=True)
+    eng.set_dropout(dropout_layers, dropout_rate, dropout_seed)
+    try:
+        out = eng.forward(inputs, want=('score', 'prob', 'label'), keep_all=True)
+    finally:
+        eng.set_dropout((), 0.0)
     layers = dict(out['layers'])
     layers.update(score=out['score'], prob=out['prob'], classification=out['label'])
     return layers

@@ -520,3 +520,38 @@ def test_config1_simple_fcn_rgb_256x512_14_classes(gpu, tmp_path):
     assert np.array_equal(cm, fu.confusion_matrix(data['labels'], pred, C14).astype(np.float64))
     ref_measures = fu.score_measures(fu.confusion_matrix(data['labels'], pred, C14))
     assert measures['mean_IoU'] == ref_measures['mean_IoU'] or (np.isnan(measures['mean_IoU']) and np.isnan(ref_measures['mean_IoU']))
+
+
+def test_mc_dropout_sites_of_encoder_and_decoder(gpu):
+    """The dropout branches of encoder() / decoder() (simple_fcn.py:50-62,71-78,124-126: tf.layers.dropout with
+    training=True, used by the uncertainty models): kept elements are x / (1 - rate), the rest zero, about `rate` of
+    them; 'pool3' also drops after pool4 and 'pool4' alone drops nothing (the reference's key quirk); every call draws
+    new masks, a seed reproduces them; without dropout arguments the graph is the plain one."""
+    from modular_semantic_segmentation_amd.simple_fcn import encoder, fcn
+    w = fo.init_fcn_weights('rgb', 3, U, C, seed=9, bias_scale=0.02)
+    w['rgb/conv1_1/kernel'] *= 0.02
+    for k in w:
+        if k.endswith('/kernel') and 'upscore' not in k and 'conv1_1' not in k:
+            w[k] *= 1.6
+    x = torch.from_numpy(np.random.default_rng(3).integers(0, 256, (1, 64, 96, 3)).astype(np.float32)).cuda()
+    plain = {k: v.interior().float().clone() for k, v in encoder(x, 'rgb', U, variables=w, num_classes=C).items()}
+    L = encoder(x, 'rgb', U, 0.5, variables=w, num_classes=C, dropout_layers=['pool3', 'conv5_3'], dropout_seed=7)
+    torch.cuda.synchronize()
+    assert 'pool3_drop' in L and 'pool4_drop' in L
+    p3, d3 = L['pool3'].interior().float(), L['pool3_drop'].interior().float()
+    assert torch.equal(p3, plain['pool3'])                        # everything before the first site is untouched
+    kept = d3 != 0
+    frac = 1.0 - kept.float().mean().item() / max((p3 != 0).float().mean().item(), 1e-9)
+    assert 0.45 < frac < 0.55, frac
+    assert torch.allclose(d3[kept], (p3[kept] * 2).bfloat16().float())
+    assert not L['pool3_drop'].t[:, 0].any() and not L['pool3_drop'].t[:, :, -1].any()        # zero border kept
+    assert not torch.equal(L['fused'].interior().float(), plain['fused'])
+    d3_first = d3.clone()
+    L2 = encoder(x, 'rgb', U, 0.5, variables=w, num_classes=C, dropout_layers=['pool3', 'conv5_3'], dropout_seed=7)
+    assert not torch.equal(L2['pool3_drop'].interior().float(), d3_first)                      # a new pass, new masks
+    only4 = encoder(x, 'rgb', U, 0.5, variables=w, num_classes=C, dropout_layers=['pool4'])
+    assert 'pool4_drop' not in only4 and torch.equal(only4['fused'].interior().float(), plain['fused'])
+    out = fcn(x, 'rgb', U, C, variables=w, dropout_rate=0.3, dropout_layers=['features'])
+    assert 'features_drop' in out and out['score'].shape == (1, 64, 96, C)
+    again = encoder(x, 'rgb', U, variables=w, num_classes=C)                                   # dropout is off again
+    assert torch.equal(again['fused'].interior().float(), plain['fused'])
