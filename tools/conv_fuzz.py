@@ -16,9 +16,58 @@ from modular_semantic_segmentation_amd import ops  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument('--cases', type=int, default=60)
 ap.add_argument('--seed', type=int, default=0)
+ap.add_argument('--fp8', action='store_true',
+                help='the e4m3 kernel (configurations 14 / 15 / 16 and the default choice) against torch conv2d on exact '
+                     'integer operands, random shapes / scales / output modes')
 args = ap.parse_args()
 rng = np.random.default_rng(args.seed)
 bad = 0
+
+
+def fuzz_fp8():
+    import torch.nn.functional as F
+    bad = 0
+    for case in range(args.cases):
+        big = case % 6 == 0
+        n = int(rng.integers(1, 12 if not big else 3))
+        h = int(rng.integers(1, 24 if not big else 70)) * 2
+        w = int(rng.integers(1, 30 if not big else 100)) * 2
+        k = 1 if case % 5 == 4 else 3
+        cin = int(rng.choice([128, 256, 384, 512]))
+        cout = int(rng.choice([64, 128, 192]))
+        ex, ew, ey = int(rng.integers(-3, 4)), int(rng.integers(-6, 2)), int(rng.integers(-2, 8))
+        mode = int(rng.integers(0, 3)) if k == 3 else 0       # 0 full map, 1 full + pool, 2 pooled only
+        relu = bool(rng.integers(0, 2))
+        x = (rng.integers(-4, 5, (n, h, w, cin)) * 2.0 ** ex).astype(np.float32)
+        wt = (rng.integers(-3, 4, (k, k, cin, cout)) * 2.0 ** ew).astype(np.float32)
+        b = (rng.integers(-3, 4, cout) * 2.0 ** (ex + ew)).astype(np.float32)
+        xa = ops.Act.from_dense(torch.from_numpy(x).cuda(), dtype='fp8', scale_exp=ex)
+        wp, _ = ops.pack_conv_weights_f8(torch.from_numpy(wt).cuda(), scale_exp=ew)
+        y32 = F.conv2d(torch.from_numpy(x).permute(0, 3, 1, 2), torch.from_numpy(wt).permute(3, 2, 0, 1),
+                       torch.from_numpy(b), padding=(k - 1) // 2)
+        if relu:
+            y32 = torch.relu(y32)
+        q8 = lambda t: (t * 2.0 ** -ey).clamp(-448, 448).to(torch.float8_e4m3fn).float() * 2.0 ** ey      # noqa: E731
+        want_y = q8(y32).permute(0, 2, 3, 1)
+        want_q = q8(F.max_pool2d(y32, 2, 2)).permute(0, 2, 3, 1) if mode else None
+        for cfg in (14, 15, 16, -1):
+            y = ops.Act(n, h, w, cout, dtype='fp8', scale_exp=ey) if mode != 2 else None
+            q = ops.Act(n, h // 2, w // 2, cout, dtype='fp8', scale_exp=ey) if mode else None
+            ops.conv2d_fwd(xa, wp, torch.from_numpy(b).cuda(), k, relu=relu, y=y, pooled=q, write_y=y is not None, cfg=cfg)
+            torch.cuda.synchronize()
+            ok = (y is None or torch.equal(y.real().cpu(), want_y)) and (q is None or torch.equal(q.real().cpu(), want_q))
+            if y is not None:
+                raw = y.t.view(torch.uint8)
+                ok = ok and not (raw[:, 0].any() or raw[:, -1].any() or raw[:, :, 0].any() or raw[:, :, -1].any())
+            if not ok:
+                bad += 1
+                print('MISMATCH fp8 case', case, 'cfg', cfg, (n, h, w, cin, cout, k), 'mode', mode, 'relu', relu, (ex, ew, ey))
+    print('fp8 cases', args.cases, 'x 4 configurations, mismatches', bad)
+    sys.exit(1 if bad else 0)
+
+
+if args.fp8:
+    fuzz_fp8()
 for case in range(args.cases):
     big = case % 6 == 0
     n = int(rng.integers(1, 40 if not big else 4))
