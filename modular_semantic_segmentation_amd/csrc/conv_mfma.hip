@@ -1251,7 +1251,10 @@ __global__ void pack_weights_f8_kernel(const float* __restrict__ w, char* __rest
 // weight fragments streamed L1 -> VGPR without LDS, s_setprio around the MFMA clusters.
 //  18: generation 3 for 1x1 convs (conv1x1_gemm.hip): flat GEMM over the padded rows, 128 px x 128 channels, 4 waves,
 //      both operands by LDS-DMA, 64 KB, 2/CU
-constexpr int XV_NUM_CONV_CFG = 19;
+//  19 / 20: 16x16 / 8x32 x 128 output channels, 8 waves (4 pixel waves x 2 channel halves), two taps per barrier, weight
+//      stages by LDS-DMA, 105 KB, 1/CU: the staged patch is shared by both channel halves (half the patch traffic per
+//      FLOP of configurations 14 / 15) -- built for the fp8 kernel, which is bound by what feeds it
+constexpr int XV_NUM_CONV_CFG = 21;
 struct Geo {
   int th, tw, bn, per_cu;
 };
@@ -1259,7 +1262,8 @@ const Geo kGeo[XV_NUM_CONV_CFG] = {{16, 16, 128, 2}, {8, 16, 128, 2}, {8, 32, 12
                                    {16, 16, 64, 2},  {16, 32, 64, 1}, {8, 32, 64, 2},  {8, 16, 256, 1},
                                    {16, 16, 128, 1}, {8, 32, 128, 1}, {16, 16, 64, 2},  {8, 32, 64, 2},
                                    {16, 32, 64, 1},  {16, 32, 64, 1},  {16, 16, 64, 2},  {8, 32, 64, 2},
-                                   {16, 32, 64, 1},  {16, 32, 64, 1},  {1, 128, 128, 2}};
+                                   {16, 32, 64, 1},  {16, 32, 64, 1},  {1, 128, 128, 2},
+                                   {16, 16, 128, 1}, {8, 32, 128, 1}};
 
 template <int KS>
 int launch_cfg(int cfg, const ConvArgs& a, hipStream_t s) {
@@ -1273,6 +1277,8 @@ int launch_cfg(int cfg, const ConvArgs& a, hipStream_t s) {
         case 14: return launch_conv<4, 4, 1, 1, KS, 2, 2, 1, 2>(a, s);
         case 15: return launch_conv<4, 2, 2, 1, KS, 2, 2, 1, 2>(a, s);
         case 16: return launch_conv<4, 4, 2, 1, KS, 2, 5, 1, 2>(a, s);
+        case 19: return launch_conv<4, 4, 1, 2, KS, 2, 2, 1, 2>(a, s);
+        case 20: return launch_conv<4, 2, 2, 2, KS, 2, 2, 1, 2>(a, s);
         default: return XV_ESHAPE;
       }
     }
@@ -1280,10 +1286,12 @@ int launch_cfg(int cfg, const ConvArgs& a, hipStream_t s) {
       case 14: return launch_conv<4, 4, 1, 1, KS, 2, 2, 1, 1>(a, s);
       case 15: return launch_conv<4, 2, 2, 1, KS, 2, 2, 1, 1>(a, s);
       case 16: return launch_conv<4, 4, 2, 1, KS, 2, 5, 1, 1>(a, s);
+      case 19: return launch_conv<4, 4, 1, 2, KS, 2, 2, 1, 1>(a, s);
+      case 20: return launch_conv<4, 2, 2, 2, KS, 2, 2, 1, 1>(a, s);
       default: return XV_ESHAPE;
     }
   }
-  if (a.out_f8 && cfg >= 17) return XV_ESHAPE;  // fp8 outputs come from the shared first-generation epilogue
+  if (a.out_f8 && (cfg == 17 || cfg == 18)) return XV_ESHAPE;  // fp8 outputs come from the shared first-generation epilogue
   switch (cfg) {
     case 0: return launch_conv<8, 2, 1, 2, KS, 2>(a, s);
     case 1: return launch_conv<4, 2, 1, 2, KS, 2>(a, s);
@@ -1302,6 +1310,8 @@ int launch_cfg(int cfg, const ConvArgs& a, hipStream_t s) {
     case 14: return launch_conv<4, 4, 1, 1, KS, 2, 2, 1>(a, s);
     case 15: return launch_conv<4, 2, 2, 1, KS, 2, 2, 1>(a, s);
     case 16: return launch_conv<4, 4, 2, 1, KS, 2, 5, 1>(a, s);
+    case 19: return launch_conv<4, 4, 1, 2, KS, 2, 2, 1>(a, s);
+    case 20: return launch_conv<4, 2, 2, 2, KS, 2, 2, 1>(a, s);
     case 17:
       if constexpr (KS == 3) {
 #ifdef XV_DMA_PRIO_VARIANTS

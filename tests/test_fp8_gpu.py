@@ -89,7 +89,7 @@ def test_fp8_conv_exact_on_integers(ops, n, h, w, cin, cout, k, pool, cfg, exps)
 
 
 def test_fp8_conv_tile_configurations_agree(ops):
-    """Configurations 14 / 15 / 16 of the fp8 kernel: bit-identical outputs; the others refuse fp8 operands."""
+    """Configurations 14 / 15 / 16 / 19 / 20 of the fp8 kernel: bit-identical outputs; the others refuse fp8 operands."""
     from modular_semantic_segmentation_amd import _lib
     rng = np.random.default_rng(5)
     n, h, w, cin, cout = 2, 24, 40, 256, 128
@@ -104,12 +104,12 @@ def test_fp8_conv_tile_configurations_agree(ops):
         try:
             ops.conv2d_fwd(xa, wp, _dev(b), 3, relu=True, y=y, cfg=cfg)
         except _lib.XvError:
-            assert cfg not in (14, 15, 16)
+            assert cfg not in (14, 15, 16, 19, 20)
             continue
         torch.cuda.synchronize()
         outs[cfg] = y.t.view(torch.uint8).clone()
-    assert sorted(outs) == [14, 15, 16]
-    assert torch.equal(outs[14], outs[15]) and torch.equal(outs[14], outs[16])
+    assert sorted(outs) == [14, 15, 16, 19, 20]
+    assert all(torch.equal(outs[14], outs[c]) for c in (15, 16, 19, 20))
 
 
 @pytest.mark.parametrize('cfg', [-1, 4, 10, 14, 16])

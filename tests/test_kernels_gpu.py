@@ -103,7 +103,7 @@ def test_conv2d_every_tile_configuration(ops, k):
         assert np.array_equal(y.interior().float().cpu().numpy(), ref), 'cfg %d' % cfg
         if q is not None:
             assert np.array_equal(q.interior().float().cpu().numpy(), refq), 'cfg %d pooled' % cfg
-    assert ran == 18
+    assert ran == 20
 
 
 @pytest.mark.parametrize('n,h,w,cin,cout', [(1, 6, 10, 64, 128), (2, 24, 48, 576, 256), (3, 7, 5, 128, 384),
