@@ -45,14 +45,6 @@ def train_experts(h, w, steps, batch=8, n_train=32, seed=1, device='cuda', learn
         net = get_model('fcn')(m, desc, m, num_units=U, batch_normalization=False, batchsize=batch,
                                learning_rate=learning_rate, trainer='adam', seed=seed + cin, device=str(device),
                                sync_loss=False)
-        # [TF1] Glorot-uniform kernels halve the signal variance at every relu: through 13 conv layers the logits and
-        # gradients of a from-scratch net start ~100x too small and some runs never leave that plateau (measured: the same
-        # recipe ended anywhere between 0.25 and 0.75 mIoU -- fp32 atomics make training run-to-run different).  He's gain
-        # (sqrt(2)) keeps the variance; it only changes where training starts, not what is compared.
-        for key in list(net.variables):
-            if key.endswith('/kernel') and 'upscore' not in key:
-                net.variables[key] = (net.variables[key] * np.sqrt(2.0)).astype(np.float32)
-        net._variables_changed()
         if m == 'depth':
             # Raw uint16 depth: the first layer of a trained expert absorbs the range; start it there.  The unit matters
             # for learnability, not for parity: a scalar input is split into classes by THRESHOLDS, i.e. by conv1_1's
