@@ -388,7 +388,14 @@ def test_adapnet_training_step(ops, tmp_path):
     assert pred.shape == (2, h, w)
     saved = np.load(net.export_weights())
     ref = ao.adapnet_forward(data['rgb'], {k: saved[k] for k in saved.files}, 'rgb', policy='bf16')['score']
-    assert (pred == fo.argmax_last(fo.softmax(ref))).mean() > 0.9
+    # A handful of large steps can collapse the net onto near-constant logits whose top two classes are a rounding error
+    # apart (then the label maps agree everywhere or nowhere): compare the logits, and the labels on clear margins
+    got = net.predict(data, output_attr='score')
+    scale = np.abs(ref).max()
+    assert np.abs(got - ref).max() < 3e-2 * scale
+    top2 = np.sort(ref, -1)[..., -2:]
+    clear = (top2[..., 1] - top2[..., 0]) > 6e-2 * scale
+    assert np.array_equal(pred[clear], fo.argmax_last(fo.softmax(ref))[clear])
 
 
 def test_adapnet_with_the_reference_tests_configuration(ops):
