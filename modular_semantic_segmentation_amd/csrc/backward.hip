@@ -529,12 +529,11 @@ extern "C" int xv_decoder_head_bwd(const xv_act* fused, const float* w_score, co
     hipLaunchKernelGGL(head_loss_kernel<CMV>, dim3(g1), dim3(256), 0, s, (const float*)S, b_score, labels, cnt,       \
                        fused->n, fused->h, fused->w, num_classes, loss, db_score, dscore);                            \
     const size_t lds = (size_t)(U * CMV + 256 * CMV) * 4 + (size_t)256 * U * 2;                                       \
-    static bool attr = false;                                                                                        \
-    if (!attr) {                                                                                                     \
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&head_bwd_lowres_kernel<CMV>),                \
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                    \
+    static bool attr[XV_MAX_DEVICES] = {false};                                                                      \
+    {                                                                                                                \
+      const hipError_t e =                                                                                           \
+          xv_allow_dynamic_lds(reinterpret_cast<const void*>(&head_bwd_lowres_kernel<CMV>), 160 * 1024, attr);        \
       if (e != hipSuccess) return (int)e;                                                                            \
-      attr = true;                                                                                                   \
     }                                                                                                                \
     hipLaunchKernelGGL(head_bwd_lowres_kernel<CMV>, dim3(g2), dim3(256), lds, s, (const float*)dscore,                \
                        (const __bf16*)fused->data, w_score, fused->n, fused->h, fused->w, U, num_classes, dw_score,   \

@@ -791,12 +791,8 @@ extern "C" int xv_score_dense_bwd(const xv_act* u, const float* dscore, const fl
   hipStream_t s = (hipStream_t)stream;
 #define XV_SB(CMV)                                                                                                   \
   {                                                                                                                  \
-    static bool attr = false;                                                                                        \
-    if (!attr) {                                                                                                     \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&score_dense_dgrad_kernel<CMV>),                        \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                             \
-      attr = true;                                                                                                   \
-    }                                                                                                                \
+    static bool attr[XV_MAX_DEVICES] = {false};                                                                      \
+    (void)xv_allow_dynamic_lds(reinterpret_cast<const void*>(&score_dense_dgrad_kernel<CMV>), 160 * 1024, attr);      \
     hipLaunchKernelGGL(score_dense_wgrad_kernel<CMV>, dim3(gw), dim3(256), 0, s, (const __bf16*)u->data, dscore,      \
                        dw_score, db_score, u->n, u->h, u->w, u->c, num_classes, per_block);                           \
     hipLaunchKernelGGL(score_dense_dgrad_kernel<CMV>, dim3(gd), dim3(256), lds, s, dscore, w_score,                   \

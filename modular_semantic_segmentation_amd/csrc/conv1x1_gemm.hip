@@ -187,12 +187,8 @@ int xv_launch_conv1x1_gemm(const __bf16* x, const __bf16* wpk, const float* bias
   const int64_t nblk = m_tiles * a.n_tiles;
   if (nblk > 0x7fffffff || a.Mp + G_BM > 0x7fffffff || (int64_t)G_BM * Cin * 2 > 0x7fffffff) return XV_ESHAPE;
   a.nblk = (int)nblk;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv1x1_gemm_kernel),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, G_LDS_BYTES);
-    attr_set = true;
-  }
+  static bool attr_set[XV_MAX_DEVICES] = {false};
+  (void)xv_allow_dynamic_lds(reinterpret_cast<const void*>(conv1x1_gemm_kernel), G_LDS_BYTES, attr_set);
   hipLaunchKernelGGL(conv1x1_gemm_kernel, dim3((unsigned)nblk), dim3(256), G_LDS_BYTES, stream, a);
   return xv_launch_status();
 }

@@ -552,12 +552,11 @@ int launch_conv(const ConvArgs& a0, hipStream_t stream) {
   a.tiles_x = (a.W + C::TW - 1) / C::TW;
   a.tiles_y = (a.H + C::TH - 1) / C::TH;
   a.n_ct = a.Cout / C::BN;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_kernel<MT, WR, WC, NW, KS, OCC, TPS, DMAB, F8>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+  static bool attr_set[XV_MAX_DEVICES] = {false};
+  {
+    const hipError_t e = xv_allow_dynamic_lds(reinterpret_cast<const void*>(&conv_mfma_kernel<MT, WR, WC, NW, KS, OCC, TPS, DMAB, F8>),
+                                              C::LDS_BYTES, attr_set);
     if (e != hipSuccess) return (int)e;
-    attr_set = true;
   }
   const int64_t ntiles = (int64_t)a.tiles_x * a.tiles_y * a.N * a.n_ct;
   if (ntiles <= 0 || ntiles > 0x7fffffff) return XV_ESHAPE;
@@ -1142,12 +1141,11 @@ int launch_conv_dma(const ConvArgs& a0, hipStream_t stream) {
   a.tiles_x = (a.W + C::TW - 1) / C::TW;
   a.tiles_y = (a.H + C::TH - 1) / C::TH;
   a.n_ct = a.Cout / 64;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_dma_kernel<WR, WC, PRIO>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES + XV_TRACE_LDS);
+  static bool attr_set[XV_MAX_DEVICES] = {false};
+  {
+    const hipError_t e = xv_allow_dynamic_lds(reinterpret_cast<const void*>(&conv_dma_kernel<WR, WC, PRIO>),
+                                              C::LDS_BYTES + XV_TRACE_LDS, attr_set);
     if (e != hipSuccess) return (int)e;
-    attr_set = true;
   }
   const int64_t ntiles = (int64_t)a.tiles_x * a.tiles_y * a.N * a.n_ct;
   if (ntiles <= 0 || ntiles > 0x7fffffff) return XV_ESHAPE;

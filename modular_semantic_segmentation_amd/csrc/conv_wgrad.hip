@@ -510,12 +510,10 @@ extern "C" int xv_conv2d_bwd_filter_ws(const xv_act* x, const xv_act* dy, float*
   };
   if (g_wgrad_variant == 2 && k == 3) {
     constexpr int lds = 2 * (((10 * 34 * 128 + 1023) / 1024) * 1024 + 8 * 32 * 128);
-    static bool attr = false;
-    if (!attr) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_dma_kernel<3>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    static bool attr[XV_MAX_DEVICES] = {false};
+    {
+      const hipError_t e = xv_allow_dynamic_lds(reinterpret_cast<const void*>(&conv_wgrad_dma_kernel<3>), lds, attr);
       if (e != hipSuccess) return (int)e;
-      attr = true;
     }
     hipLaunchKernelGGL(conv_wgrad_dma_kernel<3>, dim3((unsigned)(pairs * splits)), dim3(512), lds, s, a);
     return finish();
@@ -523,22 +521,18 @@ extern "C" int xv_conv2d_bwd_filter_ws(const xv_act* x, const xv_act* dy, float*
   const unsigned grid = (unsigned)(pairs * splits);
   if (k == 3) {
     constexpr int lds = ((10 * 34 * 128 + 255) / 256) * 256 + 8 * 32 * 128;
-    static bool attr = false;
-    if (!attr) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_kernel<3>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    static bool attr[XV_MAX_DEVICES] = {false};
+    {
+      const hipError_t e = xv_allow_dynamic_lds(reinterpret_cast<const void*>(&conv_wgrad_kernel<3>), lds, attr);
       if (e != hipSuccess) return (int)e;
-      attr = true;
     }
     hipLaunchKernelGGL(conv_wgrad_kernel<3>, dim3(grid), dim3(256), lds, s, a);
   } else {
     constexpr int lds = 8 * 32 * 128 * 2;
-    static bool attr = false;
-    if (!attr) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_kernel<1>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    static bool attr[XV_MAX_DEVICES] = {false};
+    {
+      const hipError_t e = xv_allow_dynamic_lds(reinterpret_cast<const void*>(&conv_wgrad_kernel<1>), lds, attr);
       if (e != hipSuccess) return (int)e;
-      attr = true;
     }
     hipLaunchKernelGGL(conv_wgrad_kernel<1>, dim3(grid), dim3(256), lds, s, a);
   }

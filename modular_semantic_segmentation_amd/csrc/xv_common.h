@@ -25,18 +25,32 @@ static inline int xv_launch_status() {
   return e == hipSuccess ? XV_OK : (int)e;
 }
 
-// CU count of the current device (cached; 256 on MI355X) -- sizes persistent grids.
+// Per-device caches (one process normally drives one GPU, but nothing here may depend on it): up to XV_MAX_DEVICES devices
+// of one process; an out-of-range device index falls back to querying every time.
+#define XV_MAX_DEVICES 16
+static inline int xv_current_device() {
+  int dev = 0;
+  return hipGetDevice(&dev) == hipSuccess ? dev : 0;
+}
+
+// CU count of the current device (cached per device; 256 on MI355X) -- sizes persistent grids.
 static inline int xv_num_cus() {
-  static int cus = 0;
-  if (cus == 0) {
-    int dev = 0, n = 0;
-    if (hipGetDevice(&dev) == hipSuccess &&
-        hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0)
-      cus = n;
-    else
-      cus = 256;
-  }
-  return cus;
+  static int cus[XV_MAX_DEVICES] = {0};
+  const int dev = xv_current_device();
+  if (dev >= 0 && dev < XV_MAX_DEVICES && cus[dev] > 0) return cus[dev];
+  int n = 0;
+  if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+  if (dev >= 0 && dev < XV_MAX_DEVICES) cus[dev] = n;
+  return n;
+}
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is per device and per kernel: `done` is the kernel's own flag array
+static inline hipError_t xv_allow_dynamic_lds(const void* kernel, int bytes, bool (&done)[XV_MAX_DEVICES]) {
+  const int dev = xv_current_device();
+  if (dev >= 0 && dev < XV_MAX_DEVICES && done[dev]) return hipSuccess;
+  const hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e == hipSuccess && dev >= 0 && dev < XV_MAX_DEVICES) done[dev] = true;
+  return e;
 }
 
 // padded-NHWC geometry helpers
