@@ -96,14 +96,14 @@ def test_conv2d_every_tile_configuration(ops, k):
         try:
             y, _ = ops.conv2d_fwd(xa, wp, bd, k, relu=True, pooled=q, cfg=cfg)
         except _lib.XvError:
-            assert (cfg == 17 and k == 1) or (cfg == 18 and k == 3)    # generation 2 is 3x3 only, generation 3 1x1 only
+            assert (cfg in (17, 21) and k == 1) or (cfg == 18 and k == 3)    # generation 2 / 2b: 3x3 only, generation 3: 1x1 only
             continue
         ran += 1
         torch.cuda.synchronize()
         assert np.array_equal(y.interior().float().cpu().numpy(), ref), 'cfg %d' % cfg
         if q is not None:
             assert np.array_equal(q.interior().float().cpu().numpy(), refq), 'cfg %d pooled' % cfg
-    assert ran == 20
+    assert ran == (21 if k == 3 else 20)
 
 
 @pytest.mark.parametrize('n,h,w,cin,cout', [(1, 6, 10, 64, 128), (2, 24, 48, 576, 256), (3, 7, 5, 128, 384),
@@ -128,10 +128,13 @@ def test_conv1x1_flat_gemm(ops, n, h, w, cin, cout):
     assert torch.equal(y0.t, y1.t)
 
 
+@pytest.mark.parametrize('gen2', [17, 21])
 @pytest.mark.parametrize('shape', [(2, 16, 32, 64, 64), (3, 32, 64, 128, 192), (1, 48, 96, 32, 64),
-                                   (2, 24, 40, 64, 64), (1, 20, 36, 128, 64), (2, 6, 10, 64, 128)])
-def test_conv2d_generation2_all_dma(ops, shape):
-    """The all-LDS-DMA kernel (32-channel chunks, its own packed image) against the oracle, bit for bit on
+                                   (2, 24, 40, 64, 64), (1, 20, 36, 128, 64), (2, 6, 10, 64, 128),
+                                   (9, 64, 96, 256, 128)])
+def test_conv2d_generation2_all_dma(ops, shape, gen2):
+    """The all-LDS-DMA kernels (32-channel chunks, their own packed image; 17 = conv_dma_kernel, 21 = conv_dma2_kernel with
+    the item barrier inside the last tap; the last shape gives every workgroup several tiles of several chunks) against the oracle, bit for bit on
     integer operands: full output, fused pool, pooled-only launch, untouched border -- whole 16x32 tiles and
     partial ones (clamped DMA offsets, predicated stores)."""
     from modular_semantic_segmentation_amd import _lib
@@ -146,14 +149,14 @@ def test_conv2d_generation2_all_dma(ops, shape):
     y32, ref = _conv_oracle(x, wt, b, True, 3)
     refq = fo.round_bf16(fo.maxpool2(y32)).permute(0, 2, 3, 1).numpy()
     q = ops.Act(n, h // 2, w // 2, cout)
-    y, _ = ops.conv2d_fwd(xa, wp, bd, 3, relu=True, pooled=q, cfg=17)
+    y, _ = ops.conv2d_fwd(xa, wp, bd, 3, relu=True, pooled=q, cfg=gen2)
     torch.cuda.synchronize()
     assert np.array_equal(y.interior().float().cpu().numpy(), ref)
     assert np.array_equal(q.interior().float().cpu().numpy(), refq)
     full = y.t.float().cpu().numpy()
     assert np.all(full[:, 0] == 0) and np.all(full[:, -1] == 0) and np.all(full[:, :, 0] == 0) and np.all(full[:, :, -1] == 0)
     q2 = ops.Act(n, h // 2, w // 2, cout)
-    ops.conv2d_fwd(xa, wp, bd, 3, relu=True, pooled=q2, write_y=False, cfg=17)
+    ops.conv2d_fwd(xa, wp, bd, 3, relu=True, pooled=q2, write_y=False, cfg=gen2)
     torch.cuda.synchronize()
     assert torch.equal(q2.t, q.t)
 
