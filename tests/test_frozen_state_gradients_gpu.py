@@ -76,48 +76,56 @@ def _conv_backward_refs(x, dy, w_hwio, k):
     return dw, dy.sum((0, 2, 3)).numpy(), dx
 
 
-def test_plain_training_step_layer_by_layer(ops, tmp_path):
-    """FcnTrainer (no batch norm): conv -> relu [-> pool] chain, second path into conv4_3 through score_conv4."""
+def _check_trunk(L, Gm, gradview, kernel_of, x0, worst, tag=''):
+    """The 13 trunk convs of one modality on the step's own state.  L: forward maps by layer name; Gm: gradient maps by
+    the trainer's tags; gradview(layer, kind): the flat gradient buffer's view; kernel_of(layer): the step's fp32 HWIO
+    kernel (before the update); x0: the raw input (NCHW).  Returns the gradient map of every conv's output."""
     from modular_semantic_segmentation_amd.fcn import ENCODER
-    net, tr, w, data = _setup(False, tmp_path)
-    e = tr.e
-    n = 2
-    L = {key[0]: act for key, act in e._arena.items() if isinstance(key[0], str) and hasattr(act, 'interior')}
-    Gm = {key[0]: act for key, act in tr._g.items() if hasattr(act, 'interior')}
     names = [nm for nm, _, _ in ENCODER]
     pool_after = {nm: pl for nm, _, pl in ENCODER}
-    # gradient w.r.t. each conv's pre-activation output, as the step left it
     gout = {}
     for nm in names:
-        if nm == 'conv4_3' or not pool_after[nm]:
-            gout[nm] = Gm['g_' + nm]
-        else:
-            gout[nm] = Gm['r_' + nm]
-    prev, worst = None, {}
+        gout[nm] = Gm['g_' + nm] if (nm == 'conv4_3' or not pool_after[nm]) else Gm['r_' + nm]
+    prev = None
     for nm in names:
         xin = prev
         prev = pool_after[nm] if pool_after[nm] else nm
         if nm == 'conv1_1':
             continue
         x, dy = _nchw(L[xin]), _nchw(gout[nm])
-        wq = fo.round_bf16(w['rgb/%s/kernel' % nm])                  # the step's forward / dgrad weights
+        wq = fo.round_bf16(kernel_of(nm))                  # the step's forward / dgrad weights
         dw, db, dx = _conv_backward_refs(x, dy, wq, 3)
-        worst['dW ' + nm] = _close(tr.view(tr.grad, nm, 'kernel').cpu().numpy(), dw, 1e-3, 'dW ' + nm)
-        worst['db ' + nm] = _close(tr.view(tr.grad, nm, 'bias').cpu().numpy(), db, 1e-3, 'db ' + nm)
+        worst[tag + 'dW ' + nm] = _close(gradview(nm, 'kernel').cpu().numpy(), dw, 1e-3, tag + 'dW ' + nm)
+        worst[tag + 'db ' + nm] = _close(gradview(nm, 'bias').cpu().numpy(), db, 1e-3, tag + 'db ' + nm)
         if xin.startswith('pool'):
             # Conv2DBackpropInput -> gradient of the pooled map; MaxPoolGrad + ReluGrad route it to the conv above
-            worst['dx ' + nm] = _close(_nchw(Gm['g_' + xin]), fo.round_bf16(dx), 1e-2, 'dx ' + nm)
+            worst[tag + 'dx ' + nm] = _close(_nchw(Gm['g_' + xin]), fo.round_bf16(dx), 1e-2, tag + 'dx ' + nm)
             above = names[names.index(nm) - 1]
             y = _nchw(L[above])
             dpool = _nchw(Gm['g_' + xin])
             _, idx = F.max_pool2d(y, 2, 2, return_indices=True)      # first maximum of every window, like the kernel
             routed = torch.zeros_like(y).flatten(2).scatter_(2, idx.flatten(2), dpool.flatten(2)).view_as(y)
             routed = routed * (y > 0)
-            assert torch.equal(_nchw(Gm['r_' + above]), routed), 'pool route of ' + above
+            assert torch.equal(_nchw(Gm['r_' + above]), routed), tag + 'pool route of ' + above
         else:
             ref = fo.round_bf16(dx * (_nchw(L[xin]) > 0))
-            worst['dx ' + nm] = _close(_nchw(gout[xin]) if xin != 'conv4_3' else _nchw(Gm['g_conv4_3']), ref, 1e-2,
-                                      'dx ' + nm)
+            worst[tag + 'dx ' + nm] = _close(_nchw(gout[xin]), ref, 1e-2, tag + 'dx ' + nm)
+    # conv1_1 (fp32 first layer): filter gradient from the raw image
+    dw, db, _ = _conv_backward_refs(x0, _nchw(gout['conv1_1']), kernel_of('conv1_1'), 3)
+    worst[tag + 'dW conv1_1'] = _close(gradview('conv1_1', 'kernel').cpu().numpy(), dw, 1e-3, tag + 'dW conv1_1')
+    worst[tag + 'db conv1_1'] = _close(gradview('conv1_1', 'bias').cpu().numpy(), db, 1e-3, tag + 'db conv1_1')
+    return gout
+
+
+def test_plain_training_step_layer_by_layer(ops, tmp_path):
+    """FcnTrainer (no batch norm): conv -> relu [-> pool] chain, second path into conv4_3 through score_conv4."""
+    net, tr, w, data = _setup(False, tmp_path)
+    e = tr.e
+    L = {key[0]: act for key, act in e._arena.items() if isinstance(key[0], str) and hasattr(act, 'interior')}
+    Gm = {key[0]: act for key, act in tr._g.items() if hasattr(act, 'interior')}
+    worst = {}
+    x0 = torch.from_numpy(data['rgb']).permute(0, 3, 1, 2).contiguous()
+    _check_trunk(L, Gm, lambda nm, kind: tr.view(tr.grad, nm, kind), lambda nm: w['rgb/%s/kernel' % nm], x0, worst)
     # the 1x1 score convs (padded to 64 units) and the AddN into conv4_3
     for nm, src, g in (('score_conv4', 'conv4_3', 'ds4'), ('score_conv5', 'conv5_3', 'ds5')):
         kp = np.zeros((1, 1, 512, e.Up), np.float32)
@@ -140,13 +148,60 @@ def test_plain_training_step_layer_by_layer(ops, tmp_path):
     up.backward(dfused)
     ref = fo.round_bf16((s5.grad * (s5.detach() > 0)))
     worst['ds5'] = _close(_nchw(Gm['ds5']), ref, 1e-2, 'ds5')
-    # conv1_1 (fp32 first layer): filter gradient from the raw image
-    x0 = torch.from_numpy(data['rgb']).permute(0, 3, 1, 2).contiguous()
-    dw, db, _ = _conv_backward_refs(x0, _nchw(gout['conv1_1']), w['rgb/conv1_1/kernel'], 3)
-    worst['dW conv1_1'] = _close(tr.view(tr.grad, 'conv1_1', 'kernel').cpu().numpy(), dw, 1e-3, 'dW conv1_1')
-    worst['db conv1_1'] = _close(tr.view(tr.grad, 'conv1_1', 'bias').cpu().numpy(), db, 1e-3, 'db conv1_1')
     print('worst relative errors:', {k: float('%.2g' % v) for k, v in sorted(worst.items(), key=lambda kv: -kv[1])[:6]})
     assert len(worst) == 12 * 3 + 2 * 3 + 1 + 2
+
+
+def test_joint_model_training_step_layer_by_layer(ops, tmp_path):
+    """FusionFcnTrainer (fusion_fcn.py:11-40,50-92): both trunks (the walk shared with FcnTrainer, the gradient maps tagged
+    per modality), the two fused 1x1 convs over the channel concat taken block by block -- filter gradient per 512-row
+    block, data gradient per modality with that block's weights (+ the pool4 route: AddN) -- on the step's own state."""
+    from modular_semantic_segmentation_amd import get_model
+    rng = np.random.default_rng(4)
+    data = {'rgb': rng.integers(0, 256, (2, H, W, 3)).astype(np.float32),
+            'depth': rng.integers(0, 65536, (2, H, W, 1)).astype(np.float32),
+            'labels': rng.integers(-1, C, (2, H, W)).astype(np.int32)}
+    prefixes, nch = {'rgb': 'rgb', 'depth': 'depth'}, {'rgb': 3, 'depth': 1}
+    w = fo.init_fusion_fcn_weights(prefixes, nch, U, C, seed=2, bias_scale=0.02)
+    w['rgb_conv1_1/kernel'] *= 0.02
+    w['depth_conv1_1/kernel'] *= 1e-4
+    for k in w:
+        if k.endswith('/kernel') and 'upscore' not in k and 'conv1_1' not in k:
+            w[k] *= 1.6
+    net = get_model('fusion_fcn')(prefixes, nch, U, C, trainer='rmsprop', learning_rate=1e-3, batchsize=2, seed=5)
+    net.variables.update(w)
+    net._variables_changed()
+    tr = net._ensure_trainer()
+    tr.step({m: torch.from_numpy(data[m]).cuda() for m in prefixes}, torch.from_numpy(data['labels']).cuda())
+    torch.cuda.synchronize()
+    A = {key[0]: act for key, act in tr._a.items() if hasattr(act, 'interior')}
+    worst = {}
+    ds4, ds5 = _nchw(A['ds4']), _nchw(A['ds5'])
+    for i, m in enumerate(('rgb', 'depth')):
+        trunk = tr.e.trunks[m]
+        L = {key[0]: act for key, act in trunk._arena.items() if hasattr(act, 'interior')}
+        Gm = {tag[:-len(m) - 1]: act for tag, act in A.items() if tag.endswith('_' + m)}
+        Gm['g_conv5_3'] = A['g5_' + m]                    # the data gradient of the fused 1x1 conv, per modality
+        x0 = torch.from_numpy(data[m]).permute(0, 3, 1, 2).contiguous()
+        _check_trunk(L, Gm, lambda nm, kind, m=m: tr.view(tr.grad, (m, nm), kind), lambda nm, m=m: w['%s_%s/kernel' % (m, nm)],
+                     x0, worst, tag=m + ' ')
+        rows = slice(512 * i, 512 * (i + 1))
+        for nm, src, g in (('fused_score_conv4', 'conv4_3', ds4), ('fused_score_conv5', 'conv5_3', ds5)):
+            kp = np.zeros((1, 1, 512, tr.e.Up), np.float32)
+            kp[..., :U] = w[nm + '/kernel'][:, :, rows, :]
+            dw, db, dx = _conv_backward_refs(_nchw(L[src]), g, fo.round_bf16(kp), 1)
+            got = tr.view(tr.grad, nm, 'kernel')[:, :, rows, :].cpu().numpy()
+            worst['%s dW %s' % (m, nm)] = _close(got, dw, 1e-3, '%s dW %s' % (m, nm))
+            if i == 0:
+                worst['db ' + nm] = _close(tr.view(tr.grad, nm, 'bias').cpu().numpy(), db, 1e-3, 'db ' + nm)
+            if src == 'conv5_3':
+                ref = fo.round_bf16(dx * (_nchw(L['conv5_3']) > 0))
+                worst['%s dx %s' % (m, nm)] = _close(_nchw(A['g5_' + m]), ref, 1e-2, '%s dx %s' % (m, nm))
+            else:
+                ref = fo.round_bf16((dx + _nchw(Gm['r_conv4_3'])) * (_nchw(L['conv4_3']) > 0))
+                worst['%s dx %s' % (m, nm)] = _close(_nchw(Gm['g_conv4_3']), ref, 1e-2, '%s dx %s + pool4 route' % (m, nm))
+    print('worst relative errors:', {k: float('%.2g' % v) for k, v in sorted(worst.items(), key=lambda kv: -kv[1])[:6]})
+    assert len(worst) == 2 * (12 * 3 + 2) + 2 * 4 + 2
 
 
 def test_batch_norm_training_step_layer_by_layer(ops, tmp_path):
