@@ -250,3 +250,103 @@ def test_batch_norm_training_step_layer_by_layer(ops, tmp_path):
         worst['db ' + nm] = _close(tr.view(tr.grad, nm, 'bias').cpu().numpy(), db, 1e-3, 'db ' + nm)
     print('worst relative errors:', {k: float('%.2g' % v) for k, v in sorted(worst.items(), key=lambda kv: -kv[1])[:6]})
     assert len(worst) == 13 * 5 + 12
+
+
+SHALLOW = [('block_layer_1', 'a', (64, 128, 1, True)), ('block_layer_2', 'a', (64, 128, 1, False)),
+           ('block_layer_4', 'a', (64, 256, 2, True)), ('block_layer_7', 'b', (64, 64, 256, 1, 2, False)),
+           ('block_layer_8', 'a', (128, 512, 2, True)), ('block_layer_14', 'b', (128, 128, 512, 2, 4, False))]
+
+
+def test_adapnet_training_step_op_by_op(ops, monkeypatch):
+    """AdapnetTrainer on the 6-block graph with every op type (adapnet.py:12-173, loss / optimizer :190-203): its backward
+    is a tape over a DAG, so instead of walking named buffers the test RECORDS every filter-gradient, data-gradient and
+    batch-norm-backward call of the step -- the exact operand maps as they sit in HBM at call time -- and recomputes each
+    one with torch-CPU fp32 on the spot (the kernel a data gradient used is identified by its packed buffer).  Same
+    tolerances as the layer-by-layer tests above; ~25 convs (1x1, 3x3, the 7x7 stride-2 conv as a 3x3 over 9 gathered
+    groups, the stacked atrous pair as one 1x1) and ~30 batch norms are covered."""
+    from modular_semantic_segmentation_amd.adapnet import AdapnetEngine
+    from modular_semantic_segmentation_amd.adapnet_trainer import AdapnetTrainer
+    from oracle import adapnet_oracle as ao
+    h, w = 64, 96
+    rng = np.random.default_rng(0)
+    x = rng.integers(0, 256, (2, h, w, 3)).astype(np.float32)
+    labels = rng.integers(-1, C, (2, h, w)).astype(np.int32)
+    w_ = ao.init_adapnet_weights('rgb', 3, U, C, seed=1, gain=1.3, blocks=SHALLOW)
+    w_['rgb/block_0_1/kernel'] *= 0.02
+    eng = AdapnetEngine('rgb', 3, U, C, w_, blocks=SHALLOW)
+    tr = AdapnetTrainer(eng, 'rmsprop', 1e-3)
+    tr.load_from_variables(w_)
+    torch.cuda.synchronize()
+    # fp32 kernels (as the MFMA convs consume them, rounded to bf16) of every packed data-gradient buffer, before the update
+    kernels = {}
+    for key, buf in tr.wd.items():
+        name = key[:-len('/stage_2')] if key.endswith('/stage_2') else None
+        is_pair = name is not None and any(b[0] == name and b[1] == 'b' for b in SHALLOW)
+        kern = tr._pair_kernel(name) if is_pair else tr._kernel_for(key)
+        kernels[buf.data_ptr()] = fo.round_bf16(kern.detach().float().cpu().numpy().copy())
+    worst = {'wgrad': 0.0, 'dbias': 0.0, 'dgrad': 0.0, 'bn_dz': 0.0, 'bn_dgamma': 0.0, 'bn_dbeta': 0.0}
+    calls = {'wgrad': 0, 'dgrad': 0, 'bn': 0}
+
+    def rel(got, ref):
+        got, ref = np.asarray(got, np.float64), np.asarray(ref, np.float64)
+        return float(np.abs(got - ref).max() / (np.abs(ref).max() + 1e-30))
+
+    orig_wgrad, orig_dgrad, orig_bn = ops.conv2d_bwd_filter, ops.conv2d_bwd_data, ops.bn_backward
+
+    def wgrad(xa, dy, dw, dbias, k, workspace=None):
+        before = dw.detach().clone()
+        bias_before = dbias.detach().clone() if dbias is not None else None
+        orig_wgrad(xa, dy, dw, dbias, k, workspace=workspace)
+        torch.cuda.synchronize()
+        xr, dyr = _nchw(xa), _nchw(dy)
+        ref = torch.nn.grad.conv2d_weight(xr, (dy.c, xa.c, k, k), dyr, padding=(k - 1) // 2).permute(2, 3, 1, 0).numpy()
+        worst['wgrad'] = max(worst['wgrad'], rel((dw - before).cpu().numpy(), ref))
+        if dbias is not None:
+            worst['dbias'] = max(worst['dbias'], rel((dbias - bias_before).cpu().numpy(), dyr.sum((0, 2, 3)).numpy()))
+        calls['wgrad'] += 1
+
+    def dgrad(dy, w_packed_dgrad, zero_bias, dx, k, relu_ref=None, addend=None):
+        dyr = _nchw(dy)
+        add = _nchw(addend) if addend is not None else None
+        out = orig_dgrad(dy, w_packed_dgrad, zero_bias, dx, k, relu_ref=relu_ref, addend=addend)
+        torch.cuda.synchronize()
+        wt = _w_oihw(kernels[w_packed_dgrad.data_ptr()])
+        ref = torch.nn.grad.conv2d_input((dx.n, dx.c, dx.h, dx.w), wt, dyr, padding=(k - 1) // 2)
+        if add is not None:
+            ref = ref + add
+        if relu_ref is not None:
+            ref = ref * (_nchw(relu_ref) > 0)
+        worst['dgrad'] = max(worst['dgrad'], rel(_nchw(dx).numpy(), fo.round_bf16(ref).numpy()))
+        calls['dgrad'] += 1
+        return out
+
+    def bn_backward(dy, y, z, gamma, st, dgamma, dbeta, dz, sync=False):
+        dyr, zr = _nchw(dy), _nchw(z)                     # before the call: dz may alias dy
+        yr = _nchw(y) if y is not None else None
+        g0, b0 = dgamma.detach().clone(), dbeta.detach().clone()
+        out = orig_bn(dy, y, z, gamma, st, dgamma, dbeta, dz, sync=sync)
+        torch.cuda.synchronize()
+        g = dyr * (yr > 0) if yr is not None else dyr
+        m = zr.shape[0] * zr.shape[2] * zr.shape[3]
+        mean = zr.mean((0, 2, 3), keepdim=True)
+        var = ((zr - mean) ** 2).mean((0, 2, 3), keepdim=True)
+        inv = 1.0 / torch.sqrt(var + 1e-3)
+        zh = (zr - mean) * inv
+        dga, dbe = (g * zh).sum((0, 2, 3)), g.sum((0, 2, 3))
+        ref = gamma.detach().float().cpu().view(1, -1, 1, 1) * inv * (g - dbe.view(1, -1, 1, 1) / m - zh * dga.view(1, -1, 1, 1) / m)
+        worst['bn_dz'] = max(worst['bn_dz'], rel(_nchw(dz).numpy(), fo.round_bf16(ref).numpy()))
+        worst['bn_dgamma'] = max(worst['bn_dgamma'], rel((dgamma - g0).cpu().numpy(), dga.numpy()))
+        worst['bn_dbeta'] = max(worst['bn_dbeta'], rel((dbeta - b0).cpu().numpy(), dbe.numpy()))
+        calls['bn'] += 1
+        return out
+
+    monkeypatch.setattr(ops, 'conv2d_bwd_filter', wgrad)
+    monkeypatch.setattr(ops, 'conv2d_bwd_data', dgrad)
+    monkeypatch.setattr(ops, 'bn_backward', bn_backward)
+    tr.step(torch.from_numpy(x).cuda(), torch.from_numpy(labels).cuda())
+    torch.cuda.synchronize()
+    print('adapnet step: calls', calls, 'worst relative errors', {k: float('%.2g' % v) for k, v in worst.items()})
+    assert calls['wgrad'] >= 22 and calls['dgrad'] >= 20 and calls['bn'] >= 24
+    assert worst['wgrad'] < 1e-3 and worst['dbias'] < 1e-3
+    assert worst['dgrad'] < 1e-2 and worst['bn_dz'] < 1e-2
+    assert worst['bn_dgamma'] < 2e-3 and worst['bn_dbeta'] < 2e-3
