@@ -34,6 +34,38 @@ for (n, h, w, cin, cout, pool) in [(16, 48, 96, 512, 512, False), (16, 96, 192, 
     torch.cuda.synchronize()
     print('conv', (n, h, w, cin, cout, pool), 'done')
 
+# generation 2b (item barrier inside tap 8) and the fp8 kernel: the same run-to-run comparison
+for (n, h, w, cin, cout, pool, kind) in [(16, 48, 96, 512, 512, False, 'cfg21'), (16, 96, 192, 256, 256, True, 'cfg21'),
+                                         (4, 384, 768, 64, 64, True, 'cfg21'), (3, 40, 72, 128, 64, False, 'cfg21'),
+                                         (4, 128, 256, 512, 512, True, 'fp8'), (8, 48, 96, 256, 128, False, 'fp8'),
+                                         (3, 40, 72, 128, 64, False, 'fp8')]:
+    wt = torch.randn(3, 3, cin, cout, device='cuda') * (1.0 / (9 * cin) ** 0.5)
+    b = torch.randn(cout, device='cuda')
+    if kind == 'fp8':
+        x = ops.Act.from_dense(torch.randn(n, h, w, cin, device='cuda').abs() * 30, dtype='fp8', scale_exp=0)
+        wp, _ = ops.pack_conv_weights_f8(wt)
+        okw = dict(dtype='fp8', scale_exp=1)
+        cfg = -1
+    else:
+        x = ops.Act(n, h, w, cin)
+        x.interior().normal_()
+        wp = ops.pack_conv_weights(wt)
+        okw = {}
+        cfg = 21
+    ref_y = ref_q = None
+    for it in range(int(os.environ.get("XV_STRESS_ITERS", "150"))):
+        y = ops.Act(n, h, w, cout, **okw)
+        q = ops.Act(n, h // 2, w // 2, cout, **okw) if pool else None
+        ops.conv2d_fwd(x, wp, b, 3, y=y, pooled=q, cfg=cfg)
+        raw_y, raw_q = y.t.view(torch.uint8), (q.t.view(torch.uint8) if pool else None)
+        if ref_y is None:
+            ref_y, ref_q = raw_y.clone(), (raw_q.clone() if pool else None)
+        elif not torch.equal(raw_y, ref_y) or (pool and not torch.equal(raw_q, ref_q)):
+            bad += 1
+            print('MISMATCH', kind, (n, h, w, cin, cout, pool), 'iter', it)
+    torch.cuda.synchronize()
+    print(kind, (n, h, w, cin, cout, pool), 'done')
+
 # 1x1 convs: the flat-GEMM kernel (double-buffered LDS-DMA, interior-predicated stores) and the 128-channel tile
 for (n, h, w, cin, cout) in [(16, 24, 48, 4608, 256), (8, 24, 48, 1024, 2048), (5, 17, 23, 256, 128), (4, 48, 96, 128, 512)]:
     x = ops.Act(n, h, w, cin)
