@@ -1,5 +1,7 @@
 // HBM-bound layers of the FCN for gfx950: first conv (fp32 in), max-pool, bilinear x2 (+add),
 // and the fused decoder head (bilinear x8 + relu + 1x1 score + softmax + argmax).
+#include <stdlib.h>
+
 #include "xv_common.h"
 
 namespace {
@@ -98,6 +100,207 @@ __global__ __launch_bounds__(256) void conv_first_kernel(const float* __restrict
       qrow += 1;
     }
   }
+}
+
+// ---- conv1_1 on the matrix cores -------------------------------------------------------------------------------------
+// The same layer (fp32 image, fp32 weights, fp32 accumulation, one bf16 rounding at the end) as 16 x 16 x 32 bf16 MFMAs:
+// every fp32 operand is split EXACTLY into three bf16 terms (x = xh + xm + xl: 3 x 8 significant bits), and the six
+// products down to 2^-16 relative (h.h, h.m, m.h, m.m, h.l, l.h) are accumulated in fp32, smallest first -- the dropped
+// terms are below 2^-24 of |x||w|, i.e. below the fp32 rounding of the plain FMA chain.  K = 9 CIN <= 27 fits one
+// MFMA: k-group g (8 values, lanes 16 g .. 16 g + 15) holds image row dy = g, columns dx = 0..2 x CIN channels in
+// memory order (8 of its 9 values for CIN = 3); the three leftover values (dx = 2, ci = 2 of each row) form k-group 3.
+// One wave = one tile of 16 consecutive pixels of an image row x 64 channels: 24 MFMAs against 1,728 packed FMAs per
+// lane pair of conv_first_kernel, which leaves the layer bound by its output stores.  The tile goes through a 2 KB LDS
+// transpose so that each store instruction writes eight whole 128-byte pixel rows (1 KB contiguous).
+template <int CIN>
+__device__ __forceinline__ bool first_k_map(int g, int e, int& dy, int& dx, int& ci) {
+  if (CIN == 3) {
+    if (g < 3) {
+      dy = g, dx = e / 3, ci = e % 3;
+      return true;
+    }
+    dy = e, dx = 2, ci = 2;
+    return e < 3;
+  }
+  dy = g, dx = e, ci = 0;  // CIN == 1
+  return g < 3 && e < 3;
+}
+
+// v = h + m + l exactly, each term a bf16 (returned as fp32 bit patterns with zero low halves): truncation keeps the
+// top 8 significant bits, the remainder of a 24-bit significand has at most 16, then at most 8
+__device__ __forceinline__ void split3_bf16(float v, uint32_t& h, uint32_t& m, uint32_t& l) {
+  h = __builtin_bit_cast(uint32_t, v) & 0xffff0000u;
+  const float r1 = v - __builtin_bit_cast(float, h);  // exact
+  m = __builtin_bit_cast(uint32_t, r1) & 0xffff0000u;
+  l = __builtin_bit_cast(uint32_t, r1 - __builtin_bit_cast(float, m));  // exact, fits 8 bits
+}
+__device__ __forceinline__ uint32_t cvt_pk_bf16(float lo, float hi) {  // one v_cvt_pk_bf16_f32
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{lo, hi}, bf16x2));
+}
+__device__ __forceinline__ uint32_t hi16_pair(uint32_t a, uint32_t b) {  // (a >> 16) | (b & 0xffff0000): v_perm_b32
+  return __builtin_amdgcn_perm(b, a, 0x07060302u);
+}
+__device__ __forceinline__ void split3_bf16x8(const float (&v)[8], bf16x8& h, bf16x8& m, bf16x8& l) {
+  uint32_t hh[8], mm[8], ll[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) split3_bf16(v[e], hh[e], mm[e], ll[e]);
+  h = __builtin_bit_cast(bf16x8, u32x4{hi16_pair(hh[0], hh[1]), hi16_pair(hh[2], hh[3]), hi16_pair(hh[4], hh[5]), hi16_pair(hh[6], hh[7])});
+  m = __builtin_bit_cast(bf16x8, u32x4{hi16_pair(mm[0], mm[1]), hi16_pair(mm[2], mm[3]), hi16_pair(mm[4], mm[5]), hi16_pair(mm[6], mm[7])});
+  l = __builtin_bit_cast(bf16x8, u32x4{hi16_pair(ll[0], ll[1]), hi16_pair(ll[2], ll[3]), hi16_pair(ll[4], ll[5]), hi16_pair(ll[6], ll[7])});
+}
+
+template <int CIN>
+__global__ __launch_bounds__(256) void conv_first_mfma_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                             const float* __restrict__ b, __bf16* __restrict__ y, int N,
+                                                             int H, int W, int relu) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int j = lane & 15, g = lane >> 4;
+  const int Wt = W >> 4;  // tiles per image row (W is a multiple of 16, checked by the host)
+  const int ntiles = N * H * Wt;
+  __shared__ __attribute__((aligned(16))) u32x4 stage_all[4 * 128];
+  u32x4* stage = stage_all + wave * 128;  // [16 pixels][8 slots of 8 channels], private to the wave
+
+  // weight fragments (A operand: row = channel j of the 16-channel block, k-group g), split three ways; bias per
+  // accumulator row (channels 4 g .. 4 g + 3 of each block)
+  bf16x8 wh[4], wm[4], wl[4];
+  f32x4 bias[4];
+#pragma unroll
+  for (int jb = 0; jb < 4; ++jb) {
+    float wv[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      int dy, dx, ci;
+      const bool ok = first_k_map<CIN>(g, e, dy, dx, ci);
+      wv[e] = ok ? w[((dy * 3 + dx) * CIN + ci) * 64 + jb * 16 + j] : 0.f;
+    }
+    split3_bf16x8(wv, wh[jb], wm[jb], wl[jb]);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) bias[jb][r] = b[jb * 16 + g * 4 + r];
+  }
+
+  // Lane constants of the tap loads.  A lane of k-group g < 3 reads image row py + g - 1 at columns px - 1, px, px + 1
+  // (CIN contiguous floats each); a lane of k-group 3 reads column px + 1 of rows py - 1, py, py + 1 (CIN == 3 only: it
+  // uses the last channel).  Position t is at float offset (tile origin) + lc + t * lstride; it lies outside the image
+  // when one of the tile's edge flags (bit 0 top row, 1 bottom row, 2 first tile of the row, 3 last tile; bit 4: set
+  // always, kills the lanes that never load; bit 5: there is no such tile, kills every lane) meets the position's
+  // kill mask.
+  const bool main = g < 3;
+  const int lc = main ? ((g - 1) * W + j - 1) * CIN : (-W + j + 1) * CIN;
+  const int lstride = main ? CIN : W * CIN;
+  int kill[3];
+#pragma unroll
+  for (int t = 0; t < 3; ++t) {
+    const int dy = main ? g : t, dx = main ? t : 2;
+    kill[t] = 32 | (dy == 0 ? 1 : 0) | (dy == 2 ? 2 : 0) | ((j == 0 && dx == 0) ? 4 : 0) | ((j == 15 && dx == 2) ? 8 : 0) |
+              ((CIN == 1 && !main) ? 16 : 0);
+  }
+  const int slot = ((g & 1) << 1) | (g >> 1);
+  const int st_w0 = j * 8 + (slot ^ (j & 7)), st_w1 = j * 8 + ((slot + 4) ^ (j & 7));
+  const int pj0 = lane >> 3, sl = lane & 7;
+  const int st_r0 = pj0 * 8 + (sl ^ (pj0 & 7)), st_r1 = (pj0 + 8) * 8 + (sl ^ (pj0 & 7));
+  const int st_g = pj0 * 64 + sl * 8;
+
+  // wave-uniform tile walk (no divisions in the loop): tile -> (image n, row py, tile tx of the row)
+  const int wstride = gridDim.x * 4;
+  int tile = blockIdx.x * 4 + wave;
+  int n, py, tx;
+  {
+    const int row = tile / Wt;
+    tx = tile - row * Wt;
+    n = row / H;
+    py = row - n * H;
+  }
+  const int drow = wstride / Wt, dtx = wstride - drow * Wt;
+  const int dn = drow / H, dpy = drow - dn * H;
+
+  // requests the taps of tile TILE = (n, py, tx), unmasked: they are masked where they are consumed, one tile later, so
+  // that nothing here waits for the loads
+#define XV_FIRST_LOAD(TILE)                                                                                           \
+  {                                                                                                                   \
+    const int sbase = ((n * H + py) * W + tx * 16) * CIN;                                                             \
+    const int edge = (py == 0 ? 1 : 0) | (py == H - 1 ? 2 : 0) | (tx == 0 ? 4 : 0) | (tx == Wt - 1 ? 8 : 0) | 16 |    \
+                     ((TILE) < ntiles ? 0 : 32);                                                                      \
+    _Pragma("unroll") for (int t = 0; t < 3; ++t) {                                                                   \
+      ok[t] = (kill[t] & edge) == 0;                                                                                  \
+      const int off = ok[t] ? sbase + lc + t * lstride : 0;                                                           \
+      _Pragma("unroll") for (int c = 0; c < CIN; ++c) raw[t][c] = x[off + c];                                         \
+    }                                                                                                                 \
+  }
+
+  const uint32_t floor2 = relu ? 0u : 0x80008000u;  // relu as a packed signed-integer max (xv_common.h); -32768 = none
+  float raw[3][CIN];
+  bool ok[3];
+  XV_FIRST_LOAD(tile)
+  for (; tile < ntiles; tile += wstride) {
+    // B operand of this tile (column = pixel j, k-group g): masked taps in k order, split three ways
+    float v[8];
+    if (CIN == 3) {
+      v[0] = ok[0] ? (main ? raw[0][0] : raw[0][2]) : 0.f;
+      v[1] = main ? (ok[0] ? raw[0][1] : 0.f) : (ok[1] ? raw[1][2] : 0.f);
+      v[2] = main ? (ok[0] ? raw[0][2] : 0.f) : (ok[2] ? raw[2][2] : 0.f);
+      v[3] = main && ok[1] ? raw[1][0] : 0.f;
+      v[4] = main && ok[1] ? raw[1][1] : 0.f;
+      v[5] = main && ok[1] ? raw[1][2] : 0.f;
+      v[6] = main && ok[2] ? raw[2][0] : 0.f;
+      v[7] = main && ok[2] ? raw[2][1] : 0.f;
+    } else {
+      v[0] = ok[0] ? raw[0][0] : 0.f, v[1] = ok[1] ? raw[1][0] : 0.f, v[2] = ok[2] ? raw[2][0] : 0.f;
+      v[3] = v[4] = v[5] = v[6] = v[7] = 0.f;
+    }
+    bf16x8 xh, xm, xl;
+    split3_bf16x8(v, xh, xm, xl);
+    __bf16* dst = y + (((int64_t)n * (H + 2) + (py + 1)) * (W + 2) + (tx * 16 + 1)) * 64 + st_g;
+    // next tile: advance the walk and request its taps; they land behind this tile's MFMAs, and this tile's stores are
+    // issued after them (the vector-memory counter retires in order: waiting for the taps then never waits for the
+    // stores issued behind them)
+    {
+      tx += dtx;
+      const int c1 = tx >= Wt ? 1 : 0;
+      tx -= c1 ? Wt : 0;
+      py += dpy + c1;
+      const int c2 = py >= H ? 1 : 0;
+      py -= c2 ? H : 0;
+      n += dn + c2;
+    }
+    XV_FIRST_LOAD(tile + wstride)
+    __builtin_amdgcn_sched_barrier(0x78f);  // no memory request may sink below the MFMAs (everything else may move)
+    f32x4 acc[4];
+#pragma unroll
+    for (int jb = 0; jb < 4; ++jb) acc[jb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[jb], xl, bias[jb], 0, 0, 0);
+#pragma unroll
+    for (int jb = 0; jb < 4; ++jb) acc[jb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[jb], xh, acc[jb], 0, 0, 0);
+#pragma unroll
+    for (int jb = 0; jb < 4; ++jb) acc[jb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm[jb], xm, acc[jb], 0, 0, 0);
+#pragma unroll
+    for (int jb = 0; jb < 4; ++jb) acc[jb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[jb], xm, acc[jb], 0, 0, 0);
+#pragma unroll
+    for (int jb = 0; jb < 4; ++jb) acc[jb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm[jb], xh, acc[jb], 0, 0, 0);
+#pragma unroll
+    for (int jb = 0; jb < 4; ++jb) acc[jb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[jb], xh, acc[jb], 0, 0, 0);
+    u32x2 packed[4];
+#pragma unroll
+    for (int jb = 0; jb < 4; ++jb)
+      packed[jb] = u32x2{pk_max_i16(cvt_pk_bf16(acc[jb][0], acc[jb][1]), floor2),
+                         pk_max_i16(cvt_pk_bf16(acc[jb][2], acc[jb][3]), floor2)};
+    // lane (pixel j, row group g) now holds 8 consecutive channels of each 32-channel pair, starting at channel
+    // {0, 16, 8, 24}[g] of the pair: 16-byte slot {0, 2, 1, 3}[g] + 4 pair of the pixel's 128-byte row
+    u32x4 o0, o1;
+    xv_pair16(packed[0], packed[1], o0);
+    xv_pair16(packed[2], packed[3], o1);
+    stage[st_w0] = o0;
+    stage[st_w1] = o1;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const u32x4 r0 = stage[st_r0], r1 = stage[st_r1];
+    *reinterpret_cast<u32x4*>(dst) = r0;
+    *reinterpret_cast<u32x4*>(dst + 8 * 64) = r1;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+#undef XV_FIRST_LOAD
 }
 
 __device__ inline u32x4 bf16x8_max(u32x4 a, u32x4 b) {
@@ -637,6 +840,21 @@ extern "C" int xv_conv2d_first_fwd(const float* x, int n, int h, int w, int cin,
   const unsigned grid = (unsigned)((npair + 255) / 256);
   hipStream_t s = (hipStream_t)stream;
   __bf16* yp = (__bf16*)y->data;
+  // The MFMA form takes whole 16-pixel tiles and 32-bit float offsets into x; XV_FIRST_OLD=1 keeps the FMA kernel
+  // (A/B timing), XV_FIRST_WG_PER_CU sizes the persistent grid.
+  static const bool use_old = getenv("XV_FIRST_OLD") != nullptr;
+  if ((cin == 1 || cin == 3) && (w & 15) == 0 && (int64_t)n * h * w * cin < 0x7ff00000 && !use_old) {
+    // twice the resident workgroups (113 VGPRs: four waves per SIMD): the second round evens out the tail
+    static const int per_cu = getenv("XV_FIRST_WG_PER_CU") ? atoi(getenv("XV_FIRST_WG_PER_CU")) : 8;
+    const int64_t ntiles = (int64_t)n * h * (w / 16);
+    const int64_t want = (ntiles + 3) / 4, cap = (int64_t)xv_num_cus() * (per_cu > 0 ? per_cu : 8);
+    const unsigned g2 = (unsigned)(want < cap ? want : cap);
+    if (cin == 1)
+      hipLaunchKernelGGL(conv_first_mfma_kernel<1>, dim3(g2), dim3(256), 0, s, x, w_hwio, bias, yp, n, h, w, relu);
+    else
+      hipLaunchKernelGGL(conv_first_mfma_kernel<3>, dim3(g2), dim3(256), 0, s, x, w_hwio, bias, yp, n, h, w, relu);
+    return xv_launch_status();
+  }
   switch (cin) {
     case 1: hipLaunchKernelGGL(conv_first_kernel<1>, dim3(grid), dim3(256), 0, s, x, w_hwio, bias, yp, n, h, w, relu); break;
     case 2: hipLaunchKernelGGL(conv_first_kernel<2>, dim3(grid), dim3(256), 0, s, x, w_hwio, bias, yp, n, h, w, relu); break;

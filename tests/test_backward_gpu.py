@@ -252,7 +252,10 @@ def test_training_step_gradients_and_fit(ops, tmp_path):
     # pooling sum cancels and amplifies the 2^-9 relative rounding of the bf16 gradient tensors (each
     # kernel alone is exact or within bf16 rounding in the tests above).
     assert max(err16.values()) < 0.10, err16
-    assert max(v for k, v in err16.items() if k.split('/')[1] in ('score', 'score_conv4')) < 0.01, err16
+    # which near-tie relu masks flip depends on the last bit of conv1_1: the head figures were 0.3-0.6 % with the FMA
+    # first conv and 0.6-1.1 % with the MFMA one (both within fp32 rounding of the exact layer, see
+    # test_conv_first_layer_fp32_exactness)
+    assert max(v for k, v in err16.items() if k.split('/')[1] in ('score', 'score_conv4')) < 0.02, err16
     assert max(err32.values()) < 0.2, err32
     for name, g in ref_g32.items():
         a, b = got[name].ravel().astype(np.float64), g.ravel().astype(np.float64)

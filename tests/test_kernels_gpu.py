@@ -177,22 +177,75 @@ def test_conv2d_mfma_random_bf16(ops):
     np.testing.assert_allclose(got, ref, rtol=2 ** -8, atol=2e-3)
 
 
+@pytest.mark.parametrize('relu', [True, False])
+@pytest.mark.parametrize('shape', [(2, 20, 28), (3, 23, 50), (1, 64, 272), (3, 21, 64), (2, 7, 16)])
 @pytest.mark.parametrize('cin', [1, 3])
-def test_conv_first_layer(ops, cin):
+def test_conv_first_layer(ops, cin, shape, relu):
     rng = np.random.default_rng(cin)
-    n, h, w = 2, 20, 28
+    n, h, w = shape
     hi = 256 if cin == 3 else 65536
     x = rng.integers(0, hi, (n, h, w, cin)).astype(np.float32)
     wt = (rng.standard_normal((3, 3, cin, 64)) * 0.05).astype(np.float32)
     b = rng.standard_normal(64).astype(np.float32)
     y = ops.Act(n, h, w, 64)
-    ops.conv2d_first_fwd(_dev(x), _dev(wt), _dev(b), y, relu=True)
+    ops.conv2d_first_fwd(_dev(x), _dev(wt), _dev(b), y, relu=relu)
     torch.cuda.synchronize()
-    y32, _ = _conv_oracle(x, wt, b, True, 3)
+    y32, _ = _conv_oracle(x, wt, b, relu, 3)
     ref = y32.permute(0, 2, 3, 1).numpy()
     got = y.interior().float().cpu().numpy()
     # fp32 math on both sides (different summation order) then one bf16 rounding
     np.testing.assert_allclose(got, ref, rtol=2 ** -8, atol=1e-5 * hi)
+    raw = y.t.view(torch.int16)
+    assert not (raw[:, 0].any() or raw[:, -1].any() or raw[:, :, 0].any() or raw[:, :, -1].any())   # halo stays zero
+    if relu:
+        assert not (raw < 0).any()              # no negative zeros either: the next layer's relu mask reads the sign bit
+
+
+def test_conv_first_layer_fp32_exactness(ops):
+    """W % 16 == 0 takes the MFMA form (three-way bf16 split of every fp32 operand): on operands whose products and
+    sums are exact in fp32 it must reproduce the exact result bit for bit, and on random fp32 data it must round to
+    the same bf16 as a float64 evaluation except where the float64 value sits within fp32 noise of a rounding boundary."""
+    rng = np.random.default_rng(11)
+    n, h, w = 2, 18, 48
+    for cin in (1, 3):
+        # 16-bit integers x 12-bit dyadic weights: every product needs 28 bits -> only the three-way split gets them all
+        x = rng.integers(0, 65536, (n, h, w, cin)).astype(np.float32)
+        wt = (rng.integers(-2048, 2048, (3, 3, cin, 64)) / 2.0 ** 14).astype(np.float32)
+        b = rng.integers(-8, 8, 64).astype(np.float32)
+        y = ops.Act(n, h, w, 64)
+        ops.conv2d_first_fwd(_dev(x), _dev(wt), _dev(b), y, relu=False)
+        torch.cuda.synchronize()
+        xt = torch.from_numpy(x).double().permute(0, 3, 1, 2)
+        wtt = torch.from_numpy(wt).double().permute(3, 2, 0, 1)
+        exact = torch.nn.functional.conv2d(xt, wtt, torch.from_numpy(b).double(), padding=1).permute(0, 2, 3, 1)
+        got = y.interior().cpu()
+        # the float64 result rounded to bf16, except where it sits within the fp32 accumulation's own rounding
+        # (2^-22 of the summed magnitudes) of a bf16 rounding boundary
+        want = exact.float().to(torch.bfloat16)
+        mag = torch.nn.functional.conv2d(xt.abs(), wtt.abs(), torch.from_numpy(b).double().abs(), padding=1).permute(0, 2, 3, 1)
+        diff = got != want
+        if diff.any():
+            e = exact[diff]
+            ulp = 2.0 ** (torch.floor(torch.log2(e.abs())) - 7)
+            frac = torch.remainder(e / ulp, 1.0)
+            assert ((frac - 0.5).abs() * ulp <= mag[diff] * 2.0 ** -22).all()
+            assert ((got[diff].double() - e).abs() <= ulp).all()
+        assert diff.float().mean() < 2e-3
+        # random fp32 data
+        x = (rng.standard_normal((n, h, w, cin)) * 100).astype(np.float32)
+        wt = (rng.standard_normal((3, 3, cin, 64)) * 0.1).astype(np.float32)
+        b = rng.standard_normal(64).astype(np.float32)
+        ops.conv2d_first_fwd(_dev(x), _dev(wt), _dev(b), y, relu=False)
+        torch.cuda.synchronize()
+        exact = torch.nn.functional.conv2d(torch.from_numpy(x).double().permute(0, 3, 1, 2),
+                                           torch.from_numpy(wt).double().permute(3, 2, 0, 1),
+                                           torch.from_numpy(b).double(), padding=1).permute(0, 2, 3, 1)
+        got = y.interior().cpu()
+        mism = (got != exact.float().to(torch.bfloat16)).float().mean().item()
+        # measured 6e-5 .. 7e-5, the same as an fp32 FMA chain (torch fp32 on the CPU: 4e-5 .. 8e-5); a two-way split
+        # (2^-17 relative) would flip ~100x more roundings
+        assert mism < 4e-4, mism
+        assert (got.float() - exact.float()).abs().max() <= 2.0 ** -7 * exact.abs().max()
 
 
 def test_upsample2x_relu_add(ops):
