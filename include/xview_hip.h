@@ -123,7 +123,9 @@ int xv_conv2d_fwd_cfg(const xv_act* x, const void* w_packed, const float* bias, 
 int xv_conv2d_num_cfgs(void);
 
 /* First layer: conv1_1 = relu(conv3x3(x) + b) on the RAW float32 network input (dense unpadded
- * NHWC, cin = 1..4; simple_fcn.py:39), fp32 weights HWIO [3][3][cin][64], fp32 math, bf16 out.    */
+ * NHWC, cin = 1..4; simple_fcn.py:39), fp32 weights HWIO [3][3][cin][64], fp32 math, bf16 out.
+ * cin = 1 / 3 with w % 16 == 0 runs on the matrix cores with every fp32 operand split exactly into
+ * three bf16 terms (fp32 accumulation; rounds like the fp32 FMA chain the other shapes use).        */
 int xv_conv2d_first_fwd(const float* x, int n, int h, int w, int cin, const float* w_hwio,
                         const float* bias, const xv_act* y, int relu, void* stream);
 

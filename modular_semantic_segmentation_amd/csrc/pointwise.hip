@@ -163,10 +163,11 @@ __global__ __launch_bounds__(256) void conv_first_mfma_kernel(const float* __res
   __shared__ __attribute__((aligned(16))) u32x4 stage_all[4 * 128];
   u32x4* stage = stage_all + wave * 128;  // [16 pixels][8 slots of 8 channels], private to the wave
 
-  // weight fragments (A operand: row = channel j of the 16-channel block, k-group g), split three ways; bias per
-  // accumulator row (channels 4 g .. 4 g + 3 of each block)
+  // weight fragments (A operand: row = channel j of the 16-channel block, k-group g), split three ways.  The bias
+  // rides in the first spare k slot of group 3 against a constant 1.0 on the image side (1.0 = xh exactly, so the
+  // three terms wh + wm + wl = b enter the sum exactly): the accumulators start from zero and cost no registers.
+  constexpr int BIAS_E = CIN == 3 ? 3 : 0;
   bf16x8 wh[4], wm[4], wl[4];
-  f32x4 bias[4];
 #pragma unroll
   for (int jb = 0; jb < 4; ++jb) {
     float wv[8];
@@ -175,10 +176,9 @@ __global__ __launch_bounds__(256) void conv_first_mfma_kernel(const float* __res
       int dy, dx, ci;
       const bool ok = first_k_map<CIN>(g, e, dy, dx, ci);
       wv[e] = ok ? w[((dy * 3 + dx) * CIN + ci) * 64 + jb * 16 + j] : 0.f;
+      if (e == BIAS_E) wv[e] = g == 3 ? b[jb * 16 + j] : wv[e];
     }
     split3_bf16x8(wv, wh[jb], wm[jb], wl[jb]);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) bias[jb][r] = b[jb * 16 + g * 4 + r];
   }
 
   // Lane constants of the tap loads.  A lane of k-group g < 3 reads image row py + g - 1 at columns px - 1, px, px + 1
@@ -241,13 +241,14 @@ __global__ __launch_bounds__(256) void conv_first_mfma_kernel(const float* __res
       v[0] = ok[0] ? (main ? raw[0][0] : raw[0][2]) : 0.f;
       v[1] = main ? (ok[0] ? raw[0][1] : 0.f) : (ok[1] ? raw[1][2] : 0.f);
       v[2] = main ? (ok[0] ? raw[0][2] : 0.f) : (ok[2] ? raw[2][2] : 0.f);
-      v[3] = main && ok[1] ? raw[1][0] : 0.f;
+      v[3] = main ? (ok[1] ? raw[1][0] : 0.f) : 1.f;  // k-group 3: the bias slot
       v[4] = main && ok[1] ? raw[1][1] : 0.f;
       v[5] = main && ok[1] ? raw[1][2] : 0.f;
       v[6] = main && ok[2] ? raw[2][0] : 0.f;
       v[7] = main && ok[2] ? raw[2][1] : 0.f;
     } else {
-      v[0] = ok[0] ? raw[0][0] : 0.f, v[1] = ok[1] ? raw[1][0] : 0.f, v[2] = ok[2] ? raw[2][0] : 0.f;
+      v[0] = main ? (ok[0] ? raw[0][0] : 0.f) : 1.f;  // k-group 3: the bias slot
+      v[1] = ok[1] ? raw[1][0] : 0.f, v[2] = ok[2] ? raw[2][0] : 0.f;
       v[3] = v[4] = v[5] = v[6] = v[7] = 0.f;
     }
     bf16x8 xh, xm, xl;
@@ -269,7 +270,7 @@ __global__ __launch_bounds__(256) void conv_first_mfma_kernel(const float* __res
     __builtin_amdgcn_sched_barrier(0x78f);  // no memory request may sink below the MFMAs (everything else may move)
     f32x4 acc[4];
 #pragma unroll
-    for (int jb = 0; jb < 4; ++jb) acc[jb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[jb], xl, bias[jb], 0, 0, 0);
+    for (int jb = 0; jb < 4; ++jb) acc[jb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[jb], xl, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
 #pragma unroll
     for (int jb = 0; jb < 4; ++jb) acc[jb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[jb], xh, acc[jb], 0, 0, 0);
 #pragma unroll
@@ -844,10 +845,11 @@ extern "C" int xv_conv2d_first_fwd(const float* x, int n, int h, int w, int cin,
   // (A/B timing), XV_FIRST_WG_PER_CU sizes the persistent grid.
   static const bool use_old = getenv("XV_FIRST_OLD") != nullptr;
   if ((cin == 1 || cin == 3) && (w & 15) == 0 && (int64_t)n * h * w * cin < 0x7ff00000 && !use_old) {
-    // twice the resident workgroups (113 VGPRs: four waves per SIMD): the second round evens out the tail
-    static const int per_cu = getenv("XV_FIRST_WG_PER_CU") ? atoi(getenv("XV_FIRST_WG_PER_CU")) : 8;
+    // 98 VGPRs: five workgroups resident per CU; measured at 8 x 384 x 768: 5 per CU (one round) 78 / 102 us
+    // (depth / RGB), 8: 70 / 92, 16: 65 / 92, 32: 67 / 98, 64: 83 / 122 -- a few rounds even out the tail
+    static const int per_cu = getenv("XV_FIRST_WG_PER_CU") ? atoi(getenv("XV_FIRST_WG_PER_CU")) : 16;
     const int64_t ntiles = (int64_t)n * h * (w / 16);
-    const int64_t want = (ntiles + 3) / 4, cap = (int64_t)xv_num_cus() * (per_cu > 0 ? per_cu : 8);
+    const int64_t want = (ntiles + 3) / 4, cap = (int64_t)xv_num_cus() * (per_cu > 0 ? per_cu : 16);
     const unsigned g2 = (unsigned)(want < cap ? want : cap);
     if (cin == 1)
       hipLaunchKernelGGL(conv_first_mfma_kernel<1>, dim3(g2), dim3(256), 0, s, x, w_hwio, bias, yp, n, h, w, relu);
