@@ -674,7 +674,11 @@ __device__ __forceinline__ void dma_epilogue_pack(const ConvArgs& a, f32x4 (&acc
       for (int j = 0; j < 4; ++j) pq[i][j] = h[i][j];
     return;
   }
-  // fused max_pooling2d(2,2): rows (i, i+1) live in this lane, columns (px, px^1) in lanes l, l^1
+  // fused max_pooling2d(2,2): rows (i, i+1) live in this lane, columns (px, px^1) in lanes l, l^1 (even MT only: the
+  // launcher refuses a pooled output for the 3-row configuration)
+  if constexpr (MT % 2 != 0) {
+    return;
+  } else {
   u32x2 m[MT / 2][4];
   if (a.relu) {
     // relu first (once more at store time: idempotent), then the integer max is the float max
@@ -732,6 +736,7 @@ __device__ __forceinline__ void dma_epilogue_pack(const ConvArgs& a, f32x4 (&acc
         }
     }
   }
+  }
 }
 
 // store phase, one 16-byte piece: relu on the packed pairs (rfloor = 0, or 0x80008000 = no-op without relu), then
@@ -743,9 +748,9 @@ __device__ __forceinline__ u32x4 dma_store_piece(const u32x2 h0, const u32x2 h1,
   return o;
 }
 
-template <int WR, int WC>
+template <int WR, int WC, int MT_ = 4>
 struct DmaCfg {
-  static constexpr int MT = 4;
+  static constexpr int MT = MT_;  // image rows per wave (4; 3 for the 24-row tile of configuration 22)
   static constexpr int NWAVES = WR * WC, NT = 64 * NWAVES;
   static constexpr int TH = MT * WR, TW = 16 * WC, HH = TH + 2, HW = TW + 2, NPIX = HH * HW;
   static constexpr int A_PIECES = (NPIX * 4 + 63) / 64;  // 1 KB per DMA wave-instruction
@@ -775,9 +780,9 @@ __device__ long long xv_trace_buf[8 * 8 * 20 * 6];
 // PRIO (tuning variants, XV_DMA_PRIO): 0 = a burst raises its priority after its first MFMA and drops it at its end (default);
 // 1 = static: waves 4-7 (the second-dispatched half, the arbitration loser) run at priority 1, no per-burst flips
 // (MI355X_MICROARCH.md, two waves per SIMD, item 4); 2 = no priority changes at all
-template <int WR, int WC, int PRIO = 0>
+template <int WR, int WC, int PRIO = 0, int MT_ = 4>
 __global__ __launch_bounds__(64 * WR * WC, 2) void conv_dma_kernel(ConvArgs a) {
-  using C = DmaCfg<WR, WC>;
+  using C = DmaCfg<WR, WC, MT_>;
   constexpr int MT = C::MT;
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -891,8 +896,9 @@ __global__ __launch_bounds__(64 * WR * WC, 2) void conv_dma_kernel(ConvArgs a) {
   constexpr int A_TAPS = (C::A_ITERS + 1) / 2;  // taps 0..A_TAPS-1 issue the patch pieces, two each
   constexpr int LAST_DMA_TAP = A_TAPS + C::B_ITERS - 1;
   static_assert(LAST_DMA_TAP <= 8, "DMA pieces are issued inside the 9 taps");
-  // full-map tile: pieces 0..7 leave in taps 1..8; those of taps LAST_DMA_TAP+1..8 are younger than every DMA
-  constexpr int YTAIL = 8 - LAST_DMA_TAP;
+  // full-map tile: store pieces 0 .. 2 MT - 1 leave in taps 1 .. 2 MT; those of the taps after LAST_DMA_TAP are younger
+  // than every DMA
+  constexpr int YTAIL = 2 * MT > LAST_DMA_TAP ? 2 * MT - LAST_DMA_TAP : 0;
 
   int lid = t_begin + bi;
   if (lid >= t_end) return;
@@ -923,7 +929,7 @@ __global__ __launch_bounds__(64 * WR * WC, 2) void conv_dma_kernel(ConvArgs a) {
     XV_STAMP(0)  // arrival at the item barrier
     // This item's operands have landed (each wave retires its own DMA; stores issued after it may stay in flight:
     // vmcnt counts in issue order), and every wave has finished reading the other buffer pair.
-    if (in_flight == YTAIL)
+    if (YTAIL > 0 && in_flight == YTAIL)
       asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(YTAIL) : "memory");
     else if (in_flight == 2 * MT)
       asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(2 * MT) : "memory");
@@ -944,8 +950,9 @@ __global__ __launch_bounds__(64 * WR * WC, 2) void conv_dma_kernel(ConvArgs a) {
     int pb[3];
 #pragma unroll
     for (int dx = 0; dx < 3; ++dx) pb[dx] = pbase[dx] + buf * C::A_BYTES;
-    bf16x8 wf[2][4], xf[2][MT + 2];
-    static_assert(MT == 4, "operand lists below");
+    bf16x8 wf[2][4], xf[2][6];
+    static_assert(MT == 4 || MT == 3, "operand lists below");
+    if constexpr (MT == 3) xf[0][5] = xf[1][5] = bf16x8{};  // named by the waits, never loaded
     constexpr int PROW = C::HW * 64;
 #define XV_LDS128(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
     // t = dx*3 + dy  ->  packed tap dy*3 + dx
@@ -964,7 +971,7 @@ __global__ __launch_bounds__(64 * WR * WC, 2) void conv_dma_kernel(ConvArgs a) {
     XV_LDS128(xf[set][2], pb[dx], 2 * PROW);  \
     XV_LDS128(xf[set][3], pb[dx], 3 * PROW);  \
     XV_LDS128(xf[set][4], pb[dx], 4 * PROW);  \
-    XV_LDS128(xf[set][5], pb[dx], 5 * PROW);  \
+    if constexpr (MT == 4) XV_LDS128(xf[set][5], pb[dx], 5 * PROW);  \
   }
     // at most n newer reads outstanding: wf[ws] (and xf[ps]) have landed
 #define XV_WAIT_W(n, ws)                                                                           \
@@ -1001,7 +1008,7 @@ __global__ __launch_bounds__(64 * WR * WC, 2) void conv_dma_kernel(ConvArgs a) {
     XV_STORE_PIECE((t) - 1)                                                                        \
     XV_DMA_PIECES(t)                                                                               \
     /* reads issued after W_t: P(dx+1) of this tap (dy 1) or of the previous one (dy 2), and W_t+1 */ \
-    constexpr int newer_ = ((t) + 1 < 9 ? 4 : 0) + ((dy_ != 0 && dx_ + 1 < 3) ? 6 : 0);             \
+    constexpr int newer_ = ((t) + 1 < 9 ? 4 : 0) + ((dy_ != 0 && dx_ + 1 < 3) ? MT + 2 : 0);        \
     if constexpr (dy_ == 0)                                                                        \
       XV_WAIT_WP(newer_, (t) & 1, dx_ & 1);                                                        \
     else                                                                                           \
@@ -1139,9 +1146,10 @@ __global__ __launch_bounds__(64 * WR * WC, 2) void conv_dma_kernel(ConvArgs a) {
 #undef XV_LDS128
 }
 
-template <int WR, int WC, int PRIO = 0>
+template <int WR, int WC, int PRIO = 0, int MT = 4>
 int launch_conv_dma(const ConvArgs& a0, hipStream_t stream) {
-  using C = DmaCfg<WR, WC>;
+  using C = DmaCfg<WR, WC, MT>;
+  if (MT % 2 != 0 && a0.pooled != nullptr) return XV_ESHAPE;  // the fused pool pairs rows inside a wave
   ConvArgs a = a0;
   // second half of the packed buffer: the 32-channel-chunk image
   a.wpk = a0.wpk + (int64_t)9 * a.Cin * a.Cout;
@@ -1150,7 +1158,7 @@ int launch_conv_dma(const ConvArgs& a0, hipStream_t stream) {
   a.n_ct = a.Cout / 64;
   static bool attr_set[XV_MAX_DEVICES] = {false};
   {
-    const hipError_t e = xv_allow_dynamic_lds(reinterpret_cast<const void*>(&conv_dma_kernel<WR, WC, PRIO>),
+    const hipError_t e = xv_allow_dynamic_lds(reinterpret_cast<const void*>(&conv_dma_kernel<WR, WC, PRIO, MT>),
                                               C::LDS_BYTES + XV_TRACE_LDS, attr_set);
     if (e != hipSuccess) return (int)e;
   }
@@ -1160,7 +1168,7 @@ int launch_conv_dma(const ConvArgs& a0, hipStream_t stream) {
   a.n_tiles = (int)ntiles;
   const int64_t slots = a.num_cus;
   const int64_t nblk = ntiles < slots ? ntiles : slots;
-  hipLaunchKernelGGL((conv_dma_kernel<WR, WC, PRIO>), dim3((unsigned)nblk), dim3(C::NT), C::LDS_BYTES + XV_TRACE_LDS, stream, a);
+  hipLaunchKernelGGL((conv_dma_kernel<WR, WC, PRIO, MT>), dim3((unsigned)nblk), dim3(C::NT), C::LDS_BYTES + XV_TRACE_LDS, stream, a);
   return xv_launch_status();
 }
 
@@ -1676,7 +1684,9 @@ __global__ void pack_weights_f8_kernel(const float* __restrict__ w, char* __rest
 //      stages by LDS-DMA, 105 KB, 1/CU: the staged patch is shared by both channel halves (half the patch traffic per
 //      FLOP of configurations 14 / 15) -- built for the fp8 kernel, which is bound by what feeds it
 //  21: generation 2b (conv_dma2_kernel): as 17 with the item barrier and the next item's first fragment reads inside tap 8
-constexpr int XV_NUM_CONV_CFG = 22;
+//  22: generation 2 on a 24x16 tile (8 waves x 3 rows x 16 columns; 132 KB): the 24x48 conv5 maps of a 768x384 input, which
+//      the 16x32 tile covers at 56 %; no fused pool (a wave holds an odd number of rows)
+constexpr int XV_NUM_CONV_CFG = 23;
 struct Geo {
   int th, tw, bn, per_cu;
 };
@@ -1685,7 +1695,7 @@ const Geo kGeo[XV_NUM_CONV_CFG] = {{16, 16, 128, 2}, {8, 16, 128, 2}, {8, 32, 12
                                    {16, 16, 128, 1}, {8, 32, 128, 1}, {16, 16, 64, 2},  {8, 32, 64, 2},
                                    {16, 32, 64, 1},  {16, 32, 64, 1},  {16, 16, 64, 2},  {8, 32, 64, 2},
                                    {16, 32, 64, 1},  {16, 32, 64, 1},  {1, 128, 128, 2},
-                                   {16, 16, 128, 1}, {8, 32, 128, 1}, {16, 32, 64, 1}};
+                                   {16, 16, 128, 1}, {8, 32, 128, 1}, {16, 32, 64, 1}, {24, 16, 64, 1}};
 
 template <int KS>
 int launch_cfg(int cfg, const ConvArgs& a, hipStream_t s) {
@@ -1713,7 +1723,7 @@ int launch_cfg(int cfg, const ConvArgs& a, hipStream_t s) {
       default: return XV_ESHAPE;
     }
   }
-  if (a.out_f8 && (cfg == 17 || cfg == 18 || cfg == 21)) return XV_ESHAPE;  // fp8 outputs come from the shared first-generation epilogue
+  if (a.out_f8 && (cfg == 17 || cfg == 18 || cfg == 21 || cfg == 22)) return XV_ESHAPE;  // fp8 outputs come from the shared first-generation epilogue
   switch (cfg) {
     case 0: return launch_conv<8, 2, 1, 2, KS, 2>(a, s);
     case 1: return launch_conv<4, 2, 1, 2, KS, 2>(a, s);
@@ -1736,6 +1746,9 @@ int launch_cfg(int cfg, const ConvArgs& a, hipStream_t s) {
     case 20: return launch_conv<4, 2, 2, 2, KS, 2, 2, 1>(a, s);
     case 21:
       if constexpr (KS == 3) return launch_conv_dma2<4, 2>(a, s);
+      return XV_ESHAPE;
+    case 22:
+      if constexpr (KS == 3) return launch_conv_dma<8, 1, 0, 3>(a, s);
       return XV_ESHAPE;
     case 17:
       if constexpr (KS == 3) {
@@ -1775,6 +1788,12 @@ int pick_cfg(const ConvArgs& a, int k) {
   }
   // generation 2 (16x32 tiles) unless its partial tiles waste more than its ~1.25x per-pixel advantage over the
   // 16x16 / 8x32 tiles of generation 1 (e.g. the 24x48 conv5 maps of a 768x384 input)
+  // ... and unless the 24x16 tile of configuration 22 (measured 1.15-1.2x generation 1 per covered pixel, conv_tune.py at 16
+  // images: conv5_1 1 064 against 910 TFLOP/s) covers the map with less waste than either -- the 24x48 conv5 maps
+  if (k == 3 && a.pooled == nullptr) {
+    const double other = covered(17) / 1.25 < g1 ? covered(17) / 1.25 : g1;
+    if (covered(22) / 1.15 < other) return 22;
+  }
   if (k == 3 && covered(17) <= 1.25 * g1) return 17;
   // 1x1 convs (plain GEMMs, AdapNet's block stages): 128 output channels per workgroup halve the activation re-reads
   // (tools/conv1x1_tune.py: 1.1-1.7x over the 64-channel tiles from 128 input channels up); from 256 input channels

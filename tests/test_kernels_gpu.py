@@ -92,18 +92,18 @@ def test_conv2d_every_tile_configuration(ops, k):
     refq = fo.round_bf16(fo.maxpool2(y32)).permute(0, 2, 3, 1).numpy()
     ran = 0
     for cfg in range(_lib.lib().xv_conv2d_num_cfgs()):
-        q = ops.Act(n, h // 2, w // 2, cout) if k == 3 else None
+        q = ops.Act(n, h // 2, w // 2, cout) if k == 3 and cfg != 22 else None   # 22: three rows per wave, no fused pool
         try:
             y, _ = ops.conv2d_fwd(xa, wp, bd, k, relu=True, pooled=q, cfg=cfg)
         except _lib.XvError:
-            assert (cfg in (17, 21) and k == 1) or (cfg == 18 and k == 3)    # generation 2 / 2b: 3x3 only, generation 3: 1x1 only
+            assert (cfg in (17, 21, 22) and k == 1) or (cfg == 18 and k == 3)    # generation 2 / 2b: 3x3 only, generation 3: 1x1 only
             continue
         ran += 1
         torch.cuda.synchronize()
         assert np.array_equal(y.interior().float().cpu().numpy(), ref), 'cfg %d' % cfg
         if q is not None:
             assert np.array_equal(q.interior().float().cpu().numpy(), refq), 'cfg %d pooled' % cfg
-    assert ran == (21 if k == 3 else 20)
+    assert ran == (22 if k == 3 else 20)
 
 
 @pytest.mark.parametrize('n,h,w,cin,cout', [(1, 6, 10, 64, 128), (2, 24, 48, 576, 256), (3, 7, 5, 128, 384),
@@ -159,6 +159,31 @@ def test_conv2d_generation2_all_dma(ops, shape, gen2):
     ops.conv2d_fwd(xa, wp, bd, 3, relu=True, pooled=q2, write_y=False, cfg=gen2)
     torch.cuda.synchronize()
     assert torch.equal(q2.t, q.t)
+
+
+@pytest.mark.parametrize('shape', [(2, 24, 48, 512, 128), (1, 24, 16, 64, 64), (3, 30, 40, 128, 64), (2, 48, 20, 64, 192),
+                                   (40, 24, 48, 128, 128), (1, 6, 10, 64, 64)])
+def test_conv2d_generation2_three_row_tile(ops, shape):
+    """Configuration 22 (conv_dma_kernel on a 24x16 tile, three rows per wave -- the 24x48 conv5 maps): bit for bit against
+    the oracle on integer operands, whole and partial tiles, several tiles per workgroup, border untouched; a pooled
+    output is refused; the data-gradient epilogue (addend + relu mask) equals generation 1's."""
+    from modular_semantic_segmentation_amd import _lib
+    n, h, w, cin, cout = shape
+    rng = np.random.default_rng(sum(shape))
+    x = rng.integers(-2, 3, (n, h, w, cin)).astype(np.float32)
+    wt = rng.integers(-1, 2, (3, 3, cin, cout)).astype(np.float32)
+    b = rng.integers(-3, 4, cout).astype(np.float32)
+    xa, wp, bd = ops.Act.from_dense(_dev(x)), ops.pack_conv_weights(_dev(wt)), _dev(b)
+    for relu in (True, False):
+        _, ref = _conv_oracle(x, wt, b, relu, 3)
+        y, _ = ops.conv2d_fwd(xa, wp, bd, 3, relu=relu, cfg=22)
+        torch.cuda.synchronize()
+        assert np.array_equal(y.interior().float().cpu().numpy(), ref)
+        full = y.t.float().cpu().numpy()
+        assert np.all(full[:, 0] == 0) and np.all(full[:, -1] == 0) and np.all(full[:, :, 0] == 0) and np.all(full[:, :, -1] == 0)
+    if h % 2 == 0 and w % 2 == 0:
+        with pytest.raises(_lib.XvError):
+            ops.conv2d_fwd(xa, wp, bd, 3, relu=True, pooled=ops.Act(n, h // 2, w // 2, cout), cfg=22)
 
 
 def test_conv2d_mfma_random_bf16(ops):

@@ -88,7 +88,7 @@ for case in range(args.cases):
         ref = ops.Act.from_dense(torch.from_numpy(rng.integers(-1, 3, (n, h, w, cin)).astype(np.float32)).cuda())
         add = ops.Act.from_dense(torch.from_numpy(rng.integers(-3, 4, (n, h, w, cin)).astype(np.float32)).cuda())
         zb = torch.zeros(cin, device='cuda')
-        for cfg in (14, 17, 21):
+        for cfg in (14, 17, 21, 22):
             dx = ops.Act(n, h, w, cin)
             # both generations through the forward entry on the data-gradient weights; the public data-gradient op
             # (default pick, addend + mask epilogue) is then checked against generation 1 + the same arithmetic
@@ -102,17 +102,16 @@ for case in range(args.cases):
             print('MISMATCH data-gradient epilogue', (n, h, w, cin, cout))
     else:
         wp = ops.pack_conv_weights(wt)
-        for cfg in (14, 17, 21):
+        for cfg in (14, 17, 21) + ((22,) if mode == 0 else ()):          # 22: no fused pool
             y = ops.Act(n, h, w, cout) if mode != 2 else None
             q = ops.Act(n, h // 2, w // 2, cout) if mode in (1, 2) else None
             ops.conv2d_fwd(xa, wp, b, 3, relu=relu, y=y, pooled=q, write_y=y is not None, cfg=cfg)
             outs.append((y.t.clone() if y is not None else None, q.t.clone() if q is not None else None))
     torch.cuda.synchronize()
     if mode == 3:
-        ok = torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+        ok = all(torch.equal(outs[0], o) for o in outs[1:])
     else:
-        ok = all((a is None and c is None) or torch.equal(a, c) for a, c in zip(outs[0], outs[1])) and \
-            all((a is None and c is None) or torch.equal(a, c) for a, c in zip(outs[0], outs[2]))
+        ok = all(all((a is None and c is None) or torch.equal(a, c) for a, c in zip(outs[0], o)) for o in outs[1:])
     if not ok:
         bad += 1
         print('MISMATCH case', case, (n, h, w, cin, cout), 'mode', mode, 'relu', relu)

@@ -34,9 +34,10 @@ for (n, h, w, cin, cout, pool) in [(16, 48, 96, 512, 512, False), (16, 96, 192, 
     torch.cuda.synchronize()
     print('conv', (n, h, w, cin, cout, pool), 'done')
 
-# generation 2b (item barrier inside tap 8) and the fp8 kernel: the same run-to-run comparison
+# generation 2b (item barrier inside tap 8), the 24x16 tile of generation 2 and the fp8 kernel: the same run-to-run comparison
 for (n, h, w, cin, cout, pool, kind) in [(16, 48, 96, 512, 512, False, 'cfg21'), (16, 96, 192, 256, 256, True, 'cfg21'),
                                          (4, 384, 768, 64, 64, True, 'cfg21'), (3, 40, 72, 128, 64, False, 'cfg21'),
+                                         (16, 24, 48, 512, 512, False, 'cfg22'), (5, 30, 40, 128, 64, False, 'cfg22'),
                                          (4, 128, 256, 512, 512, True, 'fp8'), (8, 48, 96, 256, 128, False, 'fp8'),
                                          (3, 40, 72, 128, 64, False, 'fp8')]:
     wt = torch.randn(3, 3, cin, cout, device='cuda') * (1.0 / (9 * cin) ** 0.5)
@@ -51,7 +52,7 @@ for (n, h, w, cin, cout, pool, kind) in [(16, 48, 96, 512, 512, False, 'cfg21'),
         x.interior().normal_()
         wp = ops.pack_conv_weights(wt)
         okw = {}
-        cfg = 21
+        cfg = int(kind[3:])
     ref_y = ref_q = None
     for it in range(int(os.environ.get("XV_STRESS_ITERS", "150"))):
         y = ops.Act(n, h, w, cout, **okw)
