@@ -163,74 +163,97 @@ __global__ __launch_bounds__(256) void count_valid_kernel(const int32_t* __restr
 // x8 deconv is the identity because fused >= 0, and wherever it is not strictly the identity (all four
 // source features of a channel are 0) the gradient entries that differ are zeroed again by the relu
 // masks of score_conv4 / upscore_conv5 further down, so the linear form gives the reference's gradients.
-// Kernel 1, per output pixel: interpolate S, softmax, loss += -log p[label]/denom,
-//   dscore = (p*valid - onehot)/denom -> dense fp32 [N][H][W][CM]; bias gradient by block reduction.
+// Kernel 1, per COLUMN of eight output pixels (rows 8 ib .. 8 ib + 7 of column ox): interpolate S, softmax,
+//   loss += -log p[label]/denom, dscore = (p*valid - onehot)/denom; bias gradient by block reduction.  dscore itself
+//   never reaches memory: the x8 bilinear deconv's gradient is separable, and the column's eight pixels feed only the
+//   1/8-resolution rows ib-1, ib, ib+1 -- the thread keeps those three row-weighted sums (P[n][ib][slot][ox][CM], slot =
+//   target row - (ib - 1)) and kernel 2 finishes along x.  (Round 1 wrote the dense fp32 gradient, 226 MB at 16 images,
+//   and kernel 2 gathered each 1/8-resolution pixel's 16 x 16 footprint from it: 390 us for the pair.)
 template <int CM>
 __global__ __launch_bounds__(256) void head_loss_kernel(const float* __restrict__ S, const float* __restrict__ bs_g,
                                                        const int32_t* __restrict__ labels,
                                                        const unsigned long long* __restrict__ count, int N, int Hi,
                                                        int Wi, int C, double* __restrict__ loss, float* __restrict__ dbs,
-                                                       float* __restrict__ dscore) {
+                                                       float* __restrict__ P) {
   __shared__ float red[CM + 1];
   if (threadIdx.x <= CM) red[threadIdx.x] = 0.f;
   __syncthreads();
   const int Ho = Hi * 8, Wo = Wi * 8;
-  const int64_t npix = (int64_t)N * Ho * Wo;
+  const int64_t ncols = (int64_t)N * Hi * Wo;
   float part[CM], lossterm = 0.f;
 #pragma unroll
   for (int k = 0; k < CM; ++k) part[k] = 0.f;
-  // grid-stride over the pixels with the sums kept in registers: the 13 global atomics at the end are issued once
-  // per workgroup of a bounded grid, not once per 256 pixels (same-address atomics serialise in L2)
-  for (int64_t opix = (int64_t)blockIdx.x * 256 + threadIdx.x; opix < npix; opix += (int64_t)gridDim.x * 256) {
-    const int op32 = (int)opix;  // npix < 2^31 (checked by the launcher): 32-bit divisions
-    const int orow = op32 / Wo;
-    const int ox = op32 - orow * Wo, n = orow / Ho, oy = orow - n * Ho;
-    const int iy1 = (oy + 4) >> 3, ix1 = (ox + 4) >> 3;
-    const float wy1 = bilinear_w<8>(oy, iy1), wy0 = bilinear_w<8>(oy, iy1 - 1);
+  const float inv_denom = 1.f / (1e-20f + (float)(*count));
+  // grid-stride over the columns with the sums kept in registers: the 13 global atomics at the end are issued once
+  // per workgroup of a bounded grid (same-address atomics serialise at the memory side)
+  for (int64_t col = (int64_t)blockIdx.x * 256 + threadIdx.x; col < ncols; col += (int64_t)gridDim.x * 256) {
+    const int c32 = (int)col;  // ncols < 2^31 (checked by the launcher): 32-bit divisions
+    const int crow = c32 / Wo;  // n * Hi + ib
+    const int ox = c32 - crow * Wo, n = crow / Hi, ib = crow - n * Hi;
+    const int ix1 = (ox + 4) >> 3;
     const float wx1 = bilinear_w<8>(ox, ix1), wx0 = bilinear_w<8>(ox, ix1 - 1);
-    const float w00 = wy0 * wx0, w01 = wy0 * wx1, w10 = wy1 * wx0, w11 = wy1 * wx1;
-    const float* p00 = S + (((int64_t)n * (Hi + 2) + iy1) * (Wi + 2) + ix1) * CM;
     const int64_t rowp = (int64_t)(Wi + 2) * CM;
-    float sc[CM];
+    float colsum[3][CM];
 #pragma unroll
-    for (int k4 = 0; k4 < CM; k4 += 4) {
-      const f32x4 a = *reinterpret_cast<const f32x4*>(p00 + k4), b = *reinterpret_cast<const f32x4*>(p00 + CM + k4);
-      const f32x4 c = *reinterpret_cast<const f32x4*>(p00 + rowp + k4),
-                  d = *reinterpret_cast<const f32x4*>(p00 + rowp + CM + k4);
-      const f32x4 v = a * w00 + b * w01 + c * w10 + d * w11;
-      sc[k4] = v.x;
-      sc[k4 + 1] = v.y;
-      sc[k4 + 2] = v.z;
-      sc[k4 + 3] = v.w;
+    for (int sl = 0; sl < 3; ++sl)
+#pragma unroll
+      for (int k = 0; k < CM; ++k) colsum[sl][k] = 0.f;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const int oy = 8 * ib + r;
+      const int iy1 = ib + (r >= 4 ? 1 : 0);  // = (oy + 4) >> 3
+      const float wy1 = bilinear_w<8>(oy, iy1), wy0 = bilinear_w<8>(oy, iy1 - 1);
+      const float w00 = wy0 * wx0, w01 = wy0 * wx1, w10 = wy1 * wx0, w11 = wy1 * wx1;
+      const float* p00 = S + (((int64_t)n * (Hi + 2) + iy1) * (Wi + 2) + ix1) * CM;
+      float sc[CM];
+#pragma unroll
+      for (int k4 = 0; k4 < CM; k4 += 4) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(p00 + k4), b = *reinterpret_cast<const f32x4*>(p00 + CM + k4);
+        const f32x4 c = *reinterpret_cast<const f32x4*>(p00 + rowp + k4),
+                    d = *reinterpret_cast<const f32x4*>(p00 + rowp + CM + k4);
+        const f32x4 v = a * w00 + b * w01 + c * w10 + d * w11;
+        sc[k4] = v.x;
+        sc[k4 + 1] = v.y;
+        sc[k4 + 2] = v.z;
+        sc[k4 + 3] = v.w;
+      }
+#pragma unroll
+      for (int k = 0; k < CM; ++k) sc[k] += bs_g[k < C ? k : C - 1];
+      const int lab = labels[((int64_t)n * Ho + oy) * Wo + ox];
+      const bool valid = lab >= 0 && lab < C;
+      float m = sc[0];
+#pragma unroll
+      for (int k = 1; k < CM; ++k)
+        if (k < C) m = fmaxf(m, sc[k]);
+      float sum = 0.f, zlab = 0.f;
+#pragma unroll
+      for (int k = 0; k < CM; ++k) {
+        if (k == lab) zlab = sc[k] - m;
+        sc[k] = k < C ? expf(sc[k] - m) : 0.f;
+        sum += sc[k];
+      }
+      const float rsum = 1.f / sum;  // one division per pixel (the gradient does not need the forward's exact quotients)
+#pragma unroll
+      for (int k = 0; k < CM; ++k) {
+        const float p = sc[k] * rsum;
+        sc[k] = (valid && k < C) ? (p - (k == lab ? 1.f : 0.f)) * inv_denom : 0.f;
+      }
+      lossterm += valid ? -(zlab - logf(sum)) * inv_denom : 0.f;  // -(log_softmax)[label] / denom
+      // this row feeds 1/8-resolution rows iy1 - 1 (weight wy0) and iy1 (weight wy1): slots r < 4 ? (0, 1) : (1, 2)
+#pragma unroll
+      for (int k = 0; k < CM; ++k) {
+        part[k] += sc[k];  // already zero for unlabelled pixels
+        colsum[r >= 4 ? 1 : 0][k] = fmaf(wy0, sc[k], colsum[r >= 4 ? 1 : 0][k]);
+        colsum[r >= 4 ? 2 : 1][k] = fmaf(wy1, sc[k], colsum[r >= 4 ? 2 : 1][k]);
+      }
     }
 #pragma unroll
-    for (int k = 0; k < CM; ++k) sc[k] += bs_g[k < C ? k : C - 1];
-    const int lab = labels[opix];
-    const bool valid = lab >= 0 && lab < C;
-    const float inv_denom = 1.f / (1e-20f + (float)(*count));
-    float m = sc[0];
+    for (int sl = 0; sl < 3; ++sl) {
+      float* dst = P + (((int64_t)crow * 3 + sl) * Wo + ox) * CM;
 #pragma unroll
-    for (int k = 1; k < CM; ++k)
-      if (k < C) m = fmaxf(m, sc[k]);
-    float sum = 0.f, zlab = 0.f;
-#pragma unroll
-    for (int k = 0; k < CM; ++k) {
-      if (k == lab) zlab = sc[k] - m;
-      sc[k] = k < C ? expf(sc[k] - m) : 0.f;
-      sum += sc[k];
+      for (int k4 = 0; k4 < CM; k4 += 4)
+        *reinterpret_cast<f32x4*>(dst + k4) = f32x4{colsum[sl][k4], colsum[sl][k4 + 1], colsum[sl][k4 + 2], colsum[sl][k4 + 3]};
     }
-#pragma unroll
-    for (int k = 0; k < CM; ++k) {
-      const float p = sc[k] / sum;
-      sc[k] = (valid && k < C) ? (p - (k == lab ? 1.f : 0.f)) * inv_denom : 0.f;
-    }
-    float* dst = dscore + opix * CM;
-#pragma unroll
-    for (int k4 = 0; k4 < CM; k4 += 4)
-      *reinterpret_cast<f32x4*>(dst + k4) = f32x4{sc[k4], sc[k4 + 1], sc[k4 + 2], sc[k4 + 3]};
-    lossterm += valid ? -(zlab - logf(sum)) * inv_denom : 0.f;  // -(log_softmax)[label] / denom
-#pragma unroll
-    for (int k = 0; k < CM; ++k) part[k] += sc[k];               // already zero for unlabelled pixels
   }
   // bias gradient and loss: butterfly sum over the wave, then ONE LDS atomic per wave and channel (per-lane LDS
   // atomics on 13 shared addresses serialise 64-fold and used to be most of this kernel's time)
@@ -251,26 +274,30 @@ __global__ __launch_bounds__(256) void head_loss_kernel(const float* __restrict_
   if (threadIdx.x == 0 && red[CM] != 0.f) atomicAdd(loss, (double)red[CM]);
 }
 
-// Kernel 2, per 1/8-resolution pixel: dS[k] = sum over the 16x16 output footprint of w * dscore[k]
+// Kernel 2, per 1/8-resolution pixel: dS[k] = sum over the 16 footprint columns of wx * (kernel 1's row sums)
 // (gradient of the x8 bilinear deconv), dfused[u] = sum_k dS[k]*Ws[u][k], and the score-weight
 // gradient dWs[u][k] += fused[u]*dS[k] reduced over the workgroup's 256 pixels through LDS.
+// FOUR threads per pixel (1,024-thread workgroups; a 1/8-resolution map has only 74 k pixels at 16 images): thread q of
+// a pixel sums footprint columns 4q .. 4q+3, the four partial sums meet through two lane exchanges; then it produces
+// units 8q .. 8q+7 (+32 ...) of dfused, and the workgroup's 768 weight-gradient cells get one thread each.
 template <int CM>
-__global__ __launch_bounds__(256) void head_bwd_lowres_kernel(const float* __restrict__ dscore,
-                                                             const __bf16* __restrict__ f,
-                                                             const float* __restrict__ ws_g, int N, int Hi, int Wi,
-                                                             int U, int C, float* __restrict__ dws,
-                                                             __bf16* __restrict__ df) {
+__global__ __launch_bounds__(1024) void head_bwd_lowres_kernel(const float* __restrict__ P,
+                                                              const __bf16* __restrict__ f,
+                                                              const float* __restrict__ ws_g, int N, int Hi, int Wi,
+                                                              int U, int C, float* __restrict__ dws_part,
+                                                              __bf16* __restrict__ df) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   float* wsm = sm;                                         // [U][CM]
   float* dsm = wsm + U * CM;                               // [256][CM]
   __bf16* fm = reinterpret_cast<__bf16*>(dsm + 256 * CM);  // [256][U]
-  for (int i = threadIdx.x; i < U * CM; i += 256) {
+  for (int i = threadIdx.x; i < U * CM; i += 1024) {
     const int u = i / CM, k = i - u * CM;
     wsm[i] = k < C ? ws_g[u * C + k] : 0.f;
   }
   const int Ho = 8 * Hi, Wo = 8 * Wi;
   const int64_t total = (int64_t)N * Hi * Wi;
-  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int lp = threadIdx.x >> 2, q = threadIdx.x & 3;  // pixel of the workgroup, quarter
+  const int64_t idx = (int64_t)blockIdx.x * 256 + lp;
   const bool live = idx < total;
   float ds[CM];
 #pragma unroll
@@ -280,16 +307,19 @@ __global__ __launch_bounds__(256) void head_bwd_lowres_kernel(const float* __res
     const int j = (int)(idx % Wi);
     const int i = (int)((idx / Wi) % Hi);
     const int n = (int)(idx / ((int64_t)Wi * Hi));
-    for (int oy = 8 * i - 4; oy <= 8 * i + 11; ++oy) {
-      if (oy < 0 || oy >= Ho) continue;
-      const float wy = bilinear_w<8>(oy, i);
-      const float* row = dscore + (((int64_t)n * Ho + oy) * Wo) * CM;
-      for (int ox = 8 * j - 4; ox <= 8 * j + 11; ++ox) {
-        if (ox < 0 || ox >= Wo) continue;
-        const float w = wy * bilinear_w<8>(ox, j);
+    // along x over kernel 1's row sums: 1/8-resolution row i collects slot 1 of its own column block, slot 0 of the
+    // block below and slot 2 of the block above; this thread takes 4 of the 16 footprint columns
+    for (int ox = 8 * j - 4 + 4 * q; ox < 8 * j + 4 * q; ++ox) {
+      if (ox < 0 || ox >= Wo) continue;
+      const float w = bilinear_w<8>(ox, j);
+#pragma unroll
+      for (int sl = 0; sl < 3; ++sl) {
+        const int ib = i + 1 - sl;  // the column block whose slot sl targets row i
+        if (ib < 0 || ib >= Hi) continue;
+        const float* src = P + ((((int64_t)n * Hi + ib) * 3 + sl) * Wo + ox) * CM;
 #pragma unroll
         for (int k4 = 0; k4 < CM; k4 += 4) {
-          const f32x4 g = *reinterpret_cast<const f32x4*>(row + (int64_t)ox * CM + k4);
+          const f32x4 g = *reinterpret_cast<const f32x4*>(src + k4);
           ds[k4] = fmaf(w, g.x, ds[k4]);
           ds[k4 + 1] = fmaf(w, g.y, ds[k4 + 1]);
           ds[k4 + 2] = fmaf(w, g.z, ds[k4 + 2]);
@@ -299,35 +329,61 @@ __global__ __launch_bounds__(256) void head_bwd_lowres_kernel(const float* __res
     }
     pad_off = (((int64_t)n * (Hi + 2) + (i + 1)) * (Wi + 2) + (j + 1)) * U;
   }
+  // the four quarters of a pixel sit in adjacent lanes: after the two exchanges every one of them holds the sum
 #pragma unroll
-  for (int k = 0; k < CM; ++k) dsm[threadIdx.x * CM + k] = ds[k];
+  for (int k = 0; k < CM; ++k) {
+    ds[k] += __shfl_xor(ds[k], 1);
+    ds[k] += __shfl_xor(ds[k], 2);
+  }
+  if (q == 0) {
+#pragma unroll
+    for (int k = 0; k < CM; ++k) dsm[lp * CM + k] = ds[k];
+  }
   __syncthreads();  // wsm ready
-  for (int u0 = 0; u0 < U; u0 += 8) {
+  for (int u0 = q * 8; u0 < U; u0 += 32) {
     u32x4 fv = u32x4{0u, 0u, 0u, 0u};
     if (live) fv = *reinterpret_cast<const u32x4*>(f + pad_off + u0);
-    *reinterpret_cast<u32x4*>(fm + threadIdx.x * U + u0) = fv;
+    *reinterpret_cast<u32x4*>(fm + lp * U + u0) = fv;
     if (live) {
       float d[8];
 #pragma unroll
-      for (int q = 0; q < 8; ++q) {
+      for (int qq = 0; qq < 8; ++qq) {
         float a = 0.f;
 #pragma unroll
-        for (int k = 0; k < CM; ++k) a = fmaf(ds[k], wsm[(u0 + q) * CM + k], a);
-        d[q] = a;
+        for (int k = 0; k < CM; ++k) a = fmaf(ds[k], wsm[(u0 + qq) * CM + k], a);
+        d[qq] = a;
       }
       *reinterpret_cast<u32x4*>(df + pad_off + u0) =
           u32x4{pack_bf16x2(d[0], d[1]), pack_bf16x2(d[2], d[3]), pack_bf16x2(d[4], d[5]), pack_bf16x2(d[6], d[7])};
     }
   }
   __syncthreads();
-  // weight gradient: cell (u, k) = sum over this workgroup's pixels of fused[px][u] * dS[px][k]
-  for (int cell = threadIdx.x; cell < U * CM; cell += 256) {
+  // weight gradient: cell (u, k) = sum over this workgroup's pixels of fused[px][u] * dS[px][k], written as this
+  // workgroup's slab of partial sums (head_dws_reduce_kernel adds the slabs up: 288 workgroups x 768 atomics onto the
+  // same 768 addresses serialised at the memory side and WERE the kernel's run time, 276 of ~300 us)
+  for (int cell = threadIdx.x; cell < U * CM; cell += 1024) {
     const int u = cell / CM, k = cell - u * CM;
-    if (k >= C) continue;
     float a = 0.f;
-    for (int px = 0; px < 256; ++px) a = fmaf((float)fm[px * U + u], dsm[px * CM + k], a);
-    if (a != 0.f) atomicAdd(&dws[u * C + k], a);
+    if (k < C)
+      for (int px = 0; px < 256; ++px) a = fmaf((float)fm[px * U + u], dsm[px * CM + k], a);
+    dws_part[(int64_t)blockIdx.x * U * CM + cell] = a;
   }
+}
+
+// dWs[u][k] += sum over the slabs: 16 lanes per cell each take every 16th slab, then a butterfly (fixed order:
+// deterministic)
+__global__ __launch_bounds__(256) void head_dws_reduce_kernel(const float* __restrict__ part, int nslabs, int U, int CM, int C,
+                                                             float* __restrict__ dws) {
+  const int cell = blockIdx.x * 16 + (threadIdx.x >> 4), sub = threadIdx.x & 15;
+  const bool live = cell < U * CM;
+  float a = 0.f;
+  if (live)
+    for (int b = sub; b < nslabs; b += 16) a += part[(int64_t)b * U * CM + cell];
+#pragma unroll
+  for (int off = 8; off >= 1; off >>= 1) a += __shfl_xor(a, off, 64);
+  if (!live || sub != 0) return;
+  const int u = cell / CM, k = cell - u * CM;
+  if (k < C) dws[u * C + k] += a;
 }
 
 // ---- conv1_1 filter + bias gradient: dW[t][co] = sum_pix in[pix][t] * dy[pix][co], db[co] = sum_pix dy ----
@@ -497,7 +553,10 @@ extern "C" int xv_count_valid_labels(const int32_t* labels, int num_classes, int
 extern "C" size_t xv_decoder_head_bwd_workspace_bytes(int n, int h, int w, int num_classes) {
   if (n <= 0 || h <= 0 || w <= 0 || num_classes < 1 || num_classes > 32) return 0;
   const size_t cm = (size_t)(num_classes + 3) / 4 * 4;
-  return ((size_t)n * (h + 2) * (w + 2) + (size_t)n * h * w * 64) * cm * sizeof(float);
+  // padded low-resolution scores + the row sums of the score gradient (3 target rows x 8w columns per 1/8-resolution
+  // row) + one slab of weight-gradient partial sums per 256 low-resolution pixels (up to 256 decoder units)
+  const size_t slabs = ((size_t)n * h * w + 255) / 256;
+  return ((size_t)n * (h + 2) * (w + 2) + (size_t)n * h * w * 24 + slabs * 256) * cm * sizeof(float);
 }
 
 extern "C" int xv_score_lowres(const xv_act* fused, const float* w_score, int num_classes, float* S, void* stream);
@@ -520,9 +579,11 @@ extern "C" int xv_decoder_head_bwd(const xv_act* fused, const float* w_score, co
   if (rc != XV_OK) return rc;
   const int64_t npix = (int64_t)fused->n * fused->h * fused->w * 64;
   const int64_t lowres = (int64_t)fused->n * fused->h * fused->w;
+  const int64_t ncols = lowres * 8;  // columns of eight output pixels
   XV_CHECK_SHAPE(npix < 0x7fff0000);
-  const unsigned g1 = (unsigned)((npix + 255) / 256 < 4096 ? (npix + 255) / 256 : 4096), g2 = (unsigned)((lowres + 255) / 256);
+  const unsigned g1 = (unsigned)((ncols + 255) / 256 < 4096 ? (ncols + 255) / 256 : 4096), g2 = (unsigned)((lowres + 255) / 256);
   const int U = fused->c;
+  float* dws_part = dscore + (size_t)lowres * 24 * CM;  // g2 slabs of U x CM partial sums (U <= 256: sized by the query above)
   const unsigned long long* cnt = reinterpret_cast<const unsigned long long*>(valid_count);
 #define XV_HB(CMV)                                                                                                   \
   {                                                                                                                  \
@@ -535,9 +596,11 @@ extern "C" int xv_decoder_head_bwd(const xv_act* fused, const float* w_score, co
           xv_allow_dynamic_lds(reinterpret_cast<const void*>(&head_bwd_lowres_kernel<CMV>), 160 * 1024, attr);        \
       if (e != hipSuccess) return (int)e;                                                                            \
     }                                                                                                                \
-    hipLaunchKernelGGL(head_bwd_lowres_kernel<CMV>, dim3(g2), dim3(256), lds, s, (const float*)dscore,                \
-                       (const __bf16*)fused->data, w_score, fused->n, fused->h, fused->w, U, num_classes, dw_score,   \
+    hipLaunchKernelGGL(head_bwd_lowres_kernel<CMV>, dim3(g2), dim3(1024), lds, s, (const float*)dscore,               \
+                       (const __bf16*)fused->data, w_score, fused->n, fused->h, fused->w, U, num_classes, dws_part,   \
                        (__bf16*)dfused->data);                                                                        \
+    hipLaunchKernelGGL(head_dws_reduce_kernel, dim3((U * CMV + 15) / 16), dim3(256), 0, s, (const float*)dws_part,    \
+                       (int)g2, U, CMV, num_classes, dw_score);                                                       \
   }
   switch (CM / 4) {
     case 1: XV_HB(4) break;

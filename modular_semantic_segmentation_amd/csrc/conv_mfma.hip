@@ -421,7 +421,13 @@ __global__ __launch_bounds__(64 * WR * WC * NW, OCC) void conv_mfma_kernel(ConvA
       a_store(atmp, IH, IN);
     }
     if constexpr (!DMAB) b_store(0, 0, breg);
-    __syncthreads();  // (DMAB: drains vmcnt, so this item's first weight stage has landed)
+    // DMAB: this item's first weight stage was requested at the start of the previous item's last stage, AFTER that
+    // item's patch prefetch -- the compiler's counted waits for the patch registers (it cannot see the asm DMA) do
+    // not cover it, and __syncthreads() waits for LDS operations only (s_waitcnt lgkmcnt(0); s_barrier).  Without this
+    // explicit wait a wave could pass the barrier with its DMA pieces still in flight: seen as wrong outputs once in
+    // ~100 launches on freshly mapped weights (cold TLB: a slow DMA) -- every other launch read the stage in time.
+    if constexpr (DMAB) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
 
     // the work item after this one: next chunk of this tile, else chunk 0 of this workgroup's next tile
     const bool last_chunk = chunk + 1 == nchunks;

@@ -300,7 +300,10 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_dma_kernel(WgradArgs a) {
   const bool do_bias = a.db != nullptr && ci0 == 0;
   float bsum = 0.f;
 
+  // (the LDS-DMA is issued in assembly, invisible to the compiler's wait insertion, and __syncthreads() waits for LDS
+  // operations only: the vector-memory counter is drained by hand before every barrier that publishes a staged tile)
   if (t_begin < t_end) stage(t_begin, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   for (int t = t_begin; t < t_end; ++t) {
     const int b = (t - t_begin) & 1;
@@ -345,7 +348,8 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_dma_kernel(WgradArgs a) {
         }
       }
     }
-    __syncthreads();  // DMA of tile t+1 has landed (vmcnt(0)) and every wave is done with buffer b
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();  // DMA of tile t+1 has landed and every wave is done with buffer b
   }
 
   if (do_bias) atomicAdd(a.db + co0 + (tid & 63), bsum);
