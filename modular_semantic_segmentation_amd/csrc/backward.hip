@@ -2,6 +2,8 @@
 // (gfx950).  Together with conv_wgrad.hip and the dgrad mode of conv_mfma.hip these replace the
 // gradient ops that tf.train.{Adam,RMSProp,Adagrad}Optimizer.minimize(self.loss) builds over the
 // training graph of SimpleFCN (base_model.py:153-162, simple_fcn.py:200-214).
+#include <stdlib.h>
+
 #include "xv_common.h"
 
 namespace {
@@ -294,7 +296,7 @@ __global__ __launch_bounds__(1024) void head_bwd_lowres_kernel(const float* __re
     const int u = i / CM, k = i - u * CM;
     wsm[i] = k < C ? ws_g[u * C + k] : 0.f;
   }
-  const int Ho = 8 * Hi, Wo = 8 * Wi;
+  const int Wo = 8 * Wi;
   const int64_t total = (int64_t)N * Hi * Wi;
   const int lp = threadIdx.x >> 2, q = threadIdx.x & 3;  // pixel of the workgroup, quarter
   const int64_t idx = (int64_t)blockIdx.x * 256 + lp;
@@ -508,6 +510,115 @@ __global__ __launch_bounds__(256) void adagrad_kernel(float* __restrict__ p, con
   }
 }
 
+
+// ---- conv1_1 filter + bias gradient on the matrix cores, in exact fp32 -----------------------------------------------
+// dW[t][co] = sum_pix X[pix][t] * dY[pix][co] is a (9 CIN + 1) x 64 x pixels GEMM (row 9 CIN: X = 1 gives the bias
+// gradient).  v_mfma_f32_16x16x4_f32 takes ONE fp32 element per lane and operand and multiplies exactly like an fmaf chain
+// (157 TFLOP/s, the vector rate, but none of the packed-FMA kernel's LDS broadcast reads): lane (i = lane & 15,
+// k = lane >> 4) supplies X of pixel p0 + k at tap row 16 tb + i and dY of the same pixel at channels 4 i .. 4 i + 3 (one
+// 8-byte load; channel block cb of the MFMA grid is channel 4 i + cb, un-permuted when the sums are written).  A wave
+// walks its share of the pixels four quads at a time (the 12 loads of a batch in flight before its 32 MFMAs); the
+// workgroup's 8 waves meet in LDS and issue one atomic per cell.
+template <int CIN>
+__global__ __launch_bounds__(512) void conv_first_wgrad_mfma_kernel(const float* __restrict__ x, const __bf16* __restrict__ dy,
+                                                                   float* __restrict__ dw, float* __restrict__ db, int N,
+                                                                   int H, int W, int quads_per_wave) {
+  constexpr int K = 9 * CIN, TB = (K + 1 + 15) / 16;
+  __shared__ float red[TB * 16 * 64];
+  for (int c = threadIdx.x; c < TB * 16 * 64; c += 512) red[c] = 0.f;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i = lane & 15, kq = lane >> 4;
+  // lane constants of the X operand: tap row t = 16 tb + i -> (dy, dx, ci), the bias row, or nothing
+  int tdy[TB], tdx[TB], tci[TB], kind[TB];
+#pragma unroll
+  for (int tb = 0; tb < TB; ++tb) {
+    const int t = 16 * tb + i;
+    const int tap = t / CIN;
+    kind[tb] = t < K ? 0 : (t == K ? 1 : 2);
+    tdy[tb] = tap / 3 - 1;
+    tdx[tb] = tap % 3 - 1;
+    tci[tb] = t - tap * CIN;
+  }
+  f32x4 acc[TB][4];
+#pragma unroll
+  for (int tb = 0; tb < TB; ++tb)
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb) acc[tb][cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // A quad = 4 consecutive pixels of one image row (W % 4 == 0, checked by the launcher): its position is wave-uniform
+  // and walks incrementally (scalar unit); a lane's tap is at (quad origin) + a lane constant, outside the image only
+  // on the quad's edge flags (bit 0 first row, 1 last row, 2 first quad of the row, 3 last quad) -- as in the forward kernel
+  int loff[TB], kill[TB];
+#pragma unroll
+  for (int tb = 0; tb < TB; ++tb) {
+    loff[tb] = ((tdy[tb] * W + tdx[tb] + kq) * CIN + tci[tb]);
+    kill[tb] = kind[tb] != 0 ? 16 : ((tdy[tb] < 0 ? 1 : 0) | (tdy[tb] > 0 ? 2 : 0) | ((kq == 0 && tdx[tb] < 0) ? 4 : 0) |
+                                     ((kq == 3 && tdx[tb] > 0) ? 8 : 0));
+  }
+  const int nquads = (N * H * W) >> 2;  // N * H * W < 2^31 (checked by the launcher)
+  const int wid = __builtin_amdgcn_readfirstlane(blockIdx.x * 8 + wave);
+  const int q0 = wid * quads_per_wave;
+  const int q1 = q0 + quads_per_wave < nquads ? q0 + quads_per_wave : nquads;
+  const int Wq = W >> 2;
+  int qrow = q0 / Wq;                 // n * H + y of the next quad to request
+  int qx = (q0 - qrow * Wq) * 4;
+  int qn = qrow / H, qy = qrow - qn * H;
+  for (int q = q0; q < q1; q += 4) {
+    float a[4][TB];
+    u32x2 g[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const bool ok = q + b < q1;
+      const int edge = (qy == 0 ? 1 : 0) | (qy == H - 1 ? 2 : 0) | (qx == 0 ? 4 : 0) | (qx == W - 4 ? 8 : 0) | 16;
+      const int xbase = ((qn * H + qy) * W + qx) * CIN;  // < 2^31: N * H * W * CIN is checked by the launcher
+      const int64_t dbase = (((int64_t)qn * (H + 2) + (qy + 1)) * (W + 2) + (qx + 1)) * 64;
+      const u32x2 gv = *reinterpret_cast<const u32x2*>(dy + (ok ? dbase : 0) + (ok ? kq * 64 : 0) + 4 * i);
+      g[b] = ok ? gv : u32x2{0u, 0u};
+#pragma unroll
+      for (int tb = 0; tb < TB; ++tb) {
+        const bool in = ok && (kill[tb] & edge) == 0;
+        const float v = x[in ? xbase + loff[tb] : 0];
+        a[b][tb] = in ? v : ((ok && kind[tb] == 1) ? 1.f : 0.f);
+      }
+      // next quad (wave-uniform walk)
+      qx += 4;
+      if (qx == W) {
+        qx = 0;
+        qy += 1;
+        if (qy == H) {
+          qy = 0;
+          qn += 1;
+        }
+      }
+    }
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const float gf[4] = {bf16_bits_to_f32(g[b].x & 0xffffu), __builtin_bit_cast(float, g[b].x & 0xffff0000u),
+                           bf16_bits_to_f32(g[b].y & 0xffffu), __builtin_bit_cast(float, g[b].y & 0xffff0000u)};
+#pragma unroll
+      for (int tb = 0; tb < TB; ++tb)
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb) acc[tb][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[b][tb], gf[cb], acc[tb][cb], 0, 0, 0);
+    }
+  }
+  __syncthreads();  // red is zeroed
+  // accumulator rows: tap row 16 tb + 4 kq + r, column i of block cb = channel 4 i + cb
+#pragma unroll
+  for (int tb = 0; tb < TB; ++tb)
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) atomicAdd(&red[(16 * tb + 4 * kq + r) * 64 + 4 * i + cb], acc[tb][cb][r]);
+  __syncthreads();
+  for (int c = threadIdx.x; c < (K + 1) * 64; c += 512) {
+    const float v = red[c];
+    if (v == 0.f) continue;
+    if (c < K * 64)
+      atomicAdd(dw + c, v);
+    else if (db != nullptr)
+      atomicAdd(db + (c - K * 64), v);
+  }
+}
+
 }  // namespace
 
 extern "C" int xv_maxpool2x2_bwd(const xv_act* y, const xv_act* dpooled, const xv_act* dy, void* stream) {
@@ -622,12 +733,31 @@ extern "C" int xv_conv2d_first_bwd_filter(const float* x, int n, int h, int w, i
   XV_CHECK_SHAPE(n > 0 && h > 0 && w > 0 && cin >= 1 && cin <= 4 && dy->n == n && dy->h == h && dy->w == w && dy->c == 64);
   XV_CHECK_SHAPE((int64_t)n * h * w < 0x7fff0000);
   const int64_t npix = (int64_t)n * h * w;
+  hipStream_t s = (hipStream_t)stream;
+  const __bf16* g = (const __bf16*)dy->data;
+  static const bool use_old = getenv("XV_FIRST_WGRAD_OLD") != nullptr;  // the packed-FMA kernel (A/B timing)
+  if (!use_old && (w & 3) == 0 && npix * cin < 0x7ff00000) {
+    // 4 workgroups of 8 waves per CU (each ends with (9 cin + 1) * 64 same-address atomics: a bounded grid); 16 images at
+    // 768x384: 317 us RGB / 181 us depth (packed-FMA kernel: 537 / 340); widths that are not a multiple of 4 keep that kernel
+    const int64_t nquads = (npix + 3) / 4;
+    static const int per_cu = getenv("XV_FIRST_WGRAD_PER_CU") ? atoi(getenv("XV_FIRST_WGRAD_PER_CU")) : 4;
+    int64_t blocks = (int64_t)xv_num_cus() * (per_cu > 0 ? per_cu : 4);
+    if (blocks * 8 * 4 > nquads) blocks = (nquads + 31) / 32;
+    int64_t qpw = (nquads + blocks * 8 - 1) / (blocks * 8);
+    qpw = (qpw + 3) / 4 * 4;
+    const unsigned grid = (unsigned)((nquads + qpw * 8 - 1) / (qpw * 8));
+    switch (cin) {
+      case 1: hipLaunchKernelGGL(conv_first_wgrad_mfma_kernel<1>, dim3(grid), dim3(512), 0, s, x, g, dw_hwio, dbias, n, h, w, (int)qpw); break;
+      case 2: hipLaunchKernelGGL(conv_first_wgrad_mfma_kernel<2>, dim3(grid), dim3(512), 0, s, x, g, dw_hwio, dbias, n, h, w, (int)qpw); break;
+      case 3: hipLaunchKernelGGL(conv_first_wgrad_mfma_kernel<3>, dim3(grid), dim3(512), 0, s, x, g, dw_hwio, dbias, n, h, w, (int)qpw); break;
+      default: hipLaunchKernelGGL(conv_first_wgrad_mfma_kernel<4>, dim3(grid), dim3(512), 0, s, x, g, dw_hwio, dbias, n, h, w, (int)qpw); break;
+    }
+    return xv_launch_status();
+  }
   // at most 512 workgroups: each ends with 9*cin*64 same-address global atomics (see xv_score_dense_bwd)
   int chunks = (int)((npix + 128 * 512 - 1) / (128 * 512));
   if (chunks < 32) chunks = 32;
   const unsigned grid = (unsigned)((npix + 128 * (int64_t)chunks - 1) / (128 * (int64_t)chunks));
-  hipStream_t s = (hipStream_t)stream;
-  const __bf16* g = (const __bf16*)dy->data;
   switch (cin) {
     case 1: hipLaunchKernelGGL(conv_first_wgrad_kernel<1>, dim3(grid), dim3(256), 0, s, x, g, dw_hwio, dbias, n, h, w, chunks); break;
     case 2: hipLaunchKernelGGL(conv_first_wgrad_kernel<2>, dim3(grid), dim3(256), 0, s, x, g, dw_hwio, dbias, n, h, w, chunks); break;

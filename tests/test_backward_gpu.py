@@ -166,10 +166,12 @@ def test_head_backward_loss_and_gradients(ops, C):
     np.testing.assert_allclose(got_df[pos], ref_df[pos], rtol=2 ** -7, atol=2e-3 * scale)
 
 
+@pytest.mark.parametrize('shape', [(2, 12, 20), (1, 9, 22), (3, 33, 64), (5, 40, 132)])
 @pytest.mark.parametrize('cin', [1, 3])
-def test_first_layer_filter_gradient(ops, cin):
+def test_first_layer_filter_gradient(ops, cin, shape):
+    """W % 4 == 0: the fp32-MFMA kernel (exact fp32 products); other widths: the packed-FMA kernel."""
     rng = np.random.default_rng(cin)
-    n, h, w = 2, 12, 20
+    n, h, w = shape
     x = rng.integers(0, 256, (n, h, w, cin)).astype(np.float32)
     dy = fo.round_bf16(rng.standard_normal((n, h, w, 64)).astype(np.float32))
     dw = torch.zeros((3, 3, cin, 64), device='cuda')
@@ -179,13 +181,14 @@ def test_first_layer_filter_gradient(ops, cin):
     db2 = torch.zeros(64, device='cuda')
     ops.bias_grad(dya, db2)
     torch.cuda.synchronize()
-    np.testing.assert_allclose(db2.cpu().numpy(), db.cpu().numpy(), rtol=1e-5, atol=1e-5)
+    grow = max(1.0, n * h * w / 480.0) ** 0.5          # fp32 sums over more pixels, in different orders
+    np.testing.assert_allclose(db2.cpu().numpy(), db.cpu().numpy(), rtol=1e-5, atol=1e-5 * grow)
     wt = torch.zeros((64, cin, 3, 3), requires_grad=True)
     b = torch.zeros(64, requires_grad=True)
     F.conv2d(_nchw(x), wt, b, padding=1).backward(_nchw(dy))
     ref = wt.grad.permute(2, 3, 1, 0).numpy()
-    np.testing.assert_allclose(dw.cpu().numpy(), ref, rtol=1e-4, atol=1e-2)
-    np.testing.assert_allclose(db.cpu().numpy(), b.grad.numpy(), rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(dw.cpu().numpy(), ref, rtol=1e-4, atol=1e-2 * grow)
+    np.testing.assert_allclose(db.cpu().numpy(), b.grad.numpy(), rtol=1e-4, atol=1e-4 * grow)
 
 
 def test_optimizers_match_tf1_formulas(ops):
