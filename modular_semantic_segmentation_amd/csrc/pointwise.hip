@@ -154,7 +154,7 @@ __device__ __forceinline__ void split3_bf16x8(const float (&v)[8], bf16x8& h, bf
 template <int CIN>
 __global__ __launch_bounds__(256) void conv_first_mfma_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                              const float* __restrict__ b, __bf16* __restrict__ y, int N,
-                                                             int H, int W, int relu) {
+                                                             int H, int W, int relu, int tpw) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int j = lane & 15, g = lane >> 4;
@@ -204,8 +204,11 @@ __global__ __launch_bounds__(256) void conv_first_mfma_kernel(const float* __res
   const int st_g = pj0 * 64 + sl * 8;
 
   // wave-uniform tile walk (no divisions in the loop): tile -> (image n, row py, tile tx of the row)
-  const int wstride = gridDim.x * 4;
-  int tile = blockIdx.x * 4 + wave;
+  // a wave takes a contiguous run of tpw tiles (its stores and taps stream through memory; measured 5-10 % ahead of a
+  // grid-stride assignment); tpw = 0: grid stride
+  const int wstride = tpw ? 1 : gridDim.x * 4;
+  int tile = tpw ? (blockIdx.x * 4 + wave) * tpw : blockIdx.x * 4 + wave;
+  const int tile_end = tpw ? (tile + tpw < ntiles ? tile + tpw : ntiles) : ntiles;
   int n, py, tx;
   {
     const int row = tile / Wt;
@@ -222,7 +225,7 @@ __global__ __launch_bounds__(256) void conv_first_mfma_kernel(const float* __res
   {                                                                                                                   \
     const int sbase = ((n * H + py) * W + tx * 16) * CIN;                                                             \
     const int edge = (py == 0 ? 1 : 0) | (py == H - 1 ? 2 : 0) | (tx == 0 ? 4 : 0) | (tx == Wt - 1 ? 8 : 0) | 16 |    \
-                     ((TILE) < ntiles ? 0 : 32);                                                                      \
+                     ((TILE) < tile_end ? 0 : 32);                                                                      \
     _Pragma("unroll") for (int t = 0; t < 3; ++t) {                                                                   \
       ok[t] = (kill[t] & edge) == 0;                                                                                  \
       const int off = ok[t] ? sbase + lc + t * lstride : 0;                                                           \
@@ -234,7 +237,7 @@ __global__ __launch_bounds__(256) void conv_first_mfma_kernel(const float* __res
   float raw[3][CIN];
   bool ok[3];
   XV_FIRST_LOAD(tile)
-  for (; tile < ntiles; tile += wstride) {
+  for (; tile < tile_end; tile += wstride) {
     // B operand of this tile (column = pixel j, k-group g): masked taps in k order, split three ways
     float v[8];
     if (CIN == 3) {
@@ -845,16 +848,19 @@ extern "C" int xv_conv2d_first_fwd(const float* x, int n, int h, int w, int cin,
   // (A/B timing), XV_FIRST_WG_PER_CU sizes the persistent grid.
   static const bool use_old = getenv("XV_FIRST_OLD") != nullptr;
   if ((cin == 1 || cin == 3) && (w & 15) == 0 && (int64_t)n * h * w * cin < 0x7ff00000 && !use_old) {
-    // 98 VGPRs: five workgroups resident per CU; measured at 8 x 384 x 768: 5 per CU (one round) 78 / 102 us
-    // (depth / RGB), 8: 70 / 92, 16: 65 / 92, 32: 67 / 98, 64: 83 / 122 -- a few rounds even out the tail
-    static const int per_cu = getenv("XV_FIRST_WG_PER_CU") ? atoi(getenv("XV_FIRST_WG_PER_CU")) : 16;
+    // 98 VGPRs: five workgroups resident per CU; measured at 8 x 384 x 768 with grid-stride tiles: 5 per CU (one round)
+    // 78 / 102 us (depth / RGB), 8: 70 / 92, 16: 65 / 92, 32: 67 / 98, 64: 83 / 122; with contiguous runs per wave 8 per CU:
+    // 59 / 84, 16: 62 / 96, 32: 71 / 101 -- a few rounds even out the tail
+    static const int per_cu = getenv("XV_FIRST_WG_PER_CU") ? atoi(getenv("XV_FIRST_WG_PER_CU")) : 8;
     const int64_t ntiles = (int64_t)n * h * (w / 16);
-    const int64_t want = (ntiles + 3) / 4, cap = (int64_t)xv_num_cus() * (per_cu > 0 ? per_cu : 16);
-    const unsigned g2 = (unsigned)(want < cap ? want : cap);
+    const int64_t want = (ntiles + 3) / 4, cap = (int64_t)xv_num_cus() * (per_cu > 0 ? per_cu : 8);
+    const int64_t g0 = want < cap ? want : cap;
+    const int tpw = (int)((ntiles + g0 * 4 - 1) / (g0 * 4));               // tiles per wave
+    const unsigned g2 = (unsigned)((ntiles + (int64_t)tpw * 4 - 1) / ((int64_t)tpw * 4));
     if (cin == 1)
-      hipLaunchKernelGGL(conv_first_mfma_kernel<1>, dim3(g2), dim3(256), 0, s, x, w_hwio, bias, yp, n, h, w, relu);
+      hipLaunchKernelGGL(conv_first_mfma_kernel<1>, dim3(g2), dim3(256), 0, s, x, w_hwio, bias, yp, n, h, w, relu, tpw);
     else
-      hipLaunchKernelGGL(conv_first_mfma_kernel<3>, dim3(g2), dim3(256), 0, s, x, w_hwio, bias, yp, n, h, w, relu);
+      hipLaunchKernelGGL(conv_first_mfma_kernel<3>, dim3(g2), dim3(256), 0, s, x, w_hwio, bias, yp, n, h, w, relu, tpw);
     return xv_launch_status();
   }
   switch (cin) {
