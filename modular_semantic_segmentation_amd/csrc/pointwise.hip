@@ -850,10 +850,11 @@ extern "C" int xv_conv2d_first_fwd(const float* x, int n, int h, int w, int cin,
   if ((cin == 1 || cin == 3) && (w & 15) == 0 && (int64_t)n * h * w * cin < 0x7ff00000 && !use_old) {
     // 98 VGPRs: five workgroups resident per CU; measured at 8 x 384 x 768 with grid-stride tiles: 5 per CU (one round)
     // 78 / 102 us (depth / RGB), 8: 70 / 92, 16: 65 / 92, 32: 67 / 98, 64: 83 / 122; with contiguous runs per wave 8 per CU:
-    // 59 / 84, 16: 62 / 96, 32: 71 / 101 -- a few rounds even out the tail
-    static const int per_cu = getenv("XV_FIRST_WG_PER_CU") ? atoi(getenv("XV_FIRST_WG_PER_CU")) : 8;
+    // 59 / 84, 16: 62 / 96, 32: 71 / 101; 4 or 5 per CU (all resident, one round): 57 / 83; 3: 88 / 100; 6 (one more than
+    // fits): 71 / 97.  4: still one round if a rebuild needs a few more registers
+    static const int per_cu = getenv("XV_FIRST_WG_PER_CU") ? atoi(getenv("XV_FIRST_WG_PER_CU")) : 4;
     const int64_t ntiles = (int64_t)n * h * (w / 16);
-    const int64_t want = (ntiles + 3) / 4, cap = (int64_t)xv_num_cus() * (per_cu > 0 ? per_cu : 8);
+    const int64_t want = (ntiles + 3) / 4, cap = (int64_t)xv_num_cus() * (per_cu > 0 ? per_cu : 4);
     const int64_t g0 = want < cap ? want : cap;
     const int tpw = (int)((ntiles + g0 * 4 - 1) / (g0 * 4));               // tiles per wave
     const unsigned g2 = (unsigned)((ntiles + (int64_t)tpw * 4 - 1) / ((int64_t)tpw * 4));
