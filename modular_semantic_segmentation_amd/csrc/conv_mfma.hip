@@ -905,6 +905,15 @@ __global__ __launch_bounds__(64 * WR * WC, 2) void conv_dma_kernel(ConvArgs a) {
   // full-map tile: store pieces 0 .. 2 MT - 1 leave in taps 1 .. 2 MT; those of the taps after LAST_DMA_TAP are younger
   // than every DMA
   constexpr int YTAIL = 2 * MT > LAST_DMA_TAP ? 2 * MT - LAST_DMA_TAP : 0;
+  // RESIDENT WEIGHTS.  A layer with two 32-channel chunks (conv1_2, conv2_1) alternates chunk 0 / chunk 1 item by item in
+  // step with the buffer parity, so weight buffer p only ever holds chunk p's weights -- of the same output-channel tile
+  // too when every workgroup of the XCD keeps its tile parity (nb % n_ct == 0).  From its third item on such a workgroup
+  // requests no weights at all: half the DMA pieces of these layers.  The last DMA of such an item is the bias piece in
+  // tap A_TAPS (last wave, chunk 0) or the patch piece before it, so RTAIL stores are younger than every DMA.
+  constexpr int RTAIL = 2 * MT > A_TAPS ? 2 * MT - A_TAPS : 0;
+  static_assert(RTAIL != YTAIL && RTAIL != 2 * MT, "the counted waits must differ");
+  const bool resident = nchunks == 2 && (nb % a.n_ct) == 0;
+  int items_done = 0;
 
   int lid = t_begin + bi;
   if (lid >= t_end) return;
@@ -937,6 +946,8 @@ __global__ __launch_bounds__(64 * WR * WC, 2) void conv_dma_kernel(ConvArgs a) {
     // vmcnt counts in issue order), and every wave has finished reading the other buffer pair.
     if (YTAIL > 0 && in_flight == YTAIL)
       asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(YTAIL) : "memory");
+    else if (RTAIL > 0 && in_flight == RTAIL)
+      asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(RTAIL) : "memory");
     else if (in_flight == 2 * MT)
       asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(2 * MT) : "memory");
     else
@@ -1003,7 +1014,7 @@ __global__ __launch_bounds__(64 * WR * WC, 2) void conv_dma_kernel(ConvArgs a) {
   if (has_next) {                                                                          \
     if (2 * (t) < C::A_ITERS) dma_a(nx_src, 2 * (t), buf ^ 1, nx_edge, nx_ylim, nx_xlim);         \
     if (2 * (t) + 1 < C::A_ITERS) dma_a(nx_src, 2 * (t) + 1, buf ^ 1, nx_edge, nx_ylim, nx_xlim); \
-    if ((t) >= A_TAPS && (t) - A_TAPS < C::B_ITERS) dma_b(nw_src, (t) - A_TAPS, buf ^ 1);  \
+    if ((t) >= A_TAPS && (t) - A_TAPS < C::B_ITERS && !skip_b) dma_b(nw_src, (t) - A_TAPS, buf ^ 1);  \
     if ((t) == A_TAPS) dma_bias(nxt, nchunk, bslot ^ 1);                                   \
   }
 #define XV_TAP(t)                                                                                  \
@@ -1087,7 +1098,8 @@ __global__ __launch_bounds__(64 * WR * WC, 2) void conv_dma_kernel(ConvArgs a) {
     }
     // stores issued after the last DMA piece of this item (pieces LAST_DMA_TAP .. npieces-1 go out in later taps)
     // (an edge tile may skip store instructions: no counted wait then)
-    in_flight = (stores_now == 2 * MT && !st_edge) ? YTAIL : 0;
+    const bool skip_b = resident && items_done >= 1;  // the NEXT item is this workgroup's third or later
+    in_flight = (stores_now == 2 * MT && !st_edge) ? (skip_b ? RTAIL : YTAIL) : 0;
     __builtin_amdgcn_sched_barrier(0);
     XV_STAMP(2)  // first fragments requested, DMA issued
 
@@ -1135,6 +1147,7 @@ __global__ __launch_bounds__(64 * WR * WC, 2) void conv_dma_kernel(ConvArgs a) {
     cur = nxt;
     chunk = nchunk;
     buf ^= 1;
+    ++items_done;
   }
 #ifdef XV_CONV_TRACE
   __syncthreads();
