@@ -912,7 +912,7 @@ __global__ __launch_bounds__(64 * WR * WC, 2) void conv_dma_kernel(ConvArgs a) {
   // tap A_TAPS (last wave, chunk 0) or the patch piece before it, so RTAIL stores are younger than every DMA.
   constexpr int RTAIL = 2 * MT > A_TAPS ? 2 * MT - A_TAPS : 0;
   static_assert(RTAIL != YTAIL && RTAIL != 2 * MT, "the counted waits must differ");
-  const bool resident = nchunks == 2 && (nb % a.n_ct) == 0;
+  const bool resident = nchunks == 2 && (nb % a.n_ct) == 0 && !(a.debug_same_patch & 8);  // (bit 3: XV_DMA_NO_RESIDENT, A/B timing)
   int items_done = 0;
 
   int lid = t_begin + bi;
@@ -1170,6 +1170,8 @@ int launch_conv_dma(const ConvArgs& a0, hipStream_t stream) {
   using C = DmaCfg<WR, WC, MT>;
   if (MT % 2 != 0 && a0.pooled != nullptr) return XV_ESHAPE;  // the fused pool pairs rows inside a wave
   ConvArgs a = a0;
+  static const bool no_resident = getenv("XV_DMA_NO_RESIDENT") != nullptr;
+  if (no_resident) a.debug_same_patch |= 8;
   // second half of the packed buffer: the 32-channel-chunk image
   a.wpk = a0.wpk + (int64_t)9 * a.Cin * a.Cout;
   a.tiles_x = (a.W + C::TW - 1) / C::TW;
