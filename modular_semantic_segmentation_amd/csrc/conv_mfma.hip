@@ -1807,15 +1807,24 @@ int pick_cfg(const ConvArgs& a, int k) {
     if (k == 3 && covered(16) <= g1 && (int64_t)a.N * a.H * a.W >= XV_F8_BIG_MAP) return 16;
     return covered(15) < covered(14) ? 15 : 14;
   }
-  // generation 2 (16x32 tiles) unless its partial tiles waste more than its ~1.25x per-pixel advantage over the
-  // 16x16 / 8x32 tiles of generation 1 (e.g. the 24x48 conv5 maps of a 768x384 input)
-  // ... and unless the 24x16 tile of configuration 22 (measured 1.15-1.2x generation 1 per covered pixel, conv_tune.py at 16
-  // images: conv5_1 1 064 against 910 TFLOP/s) covers the map with less waste than either -- the 24x48 conv5 maps
-  if (k == 3 && a.pooled == nullptr) {
-    const double other = covered(17) / 1.25 < g1 ? covered(17) / 1.25 : g1;
-    if (covered(22) / 1.15 < other) return 22;
+  // Generation 2 unless its partial tiles waste more than its per-pixel advantage over the 16x16 / 8x32 tiles of
+  // generation 1 (~1.25x on 16x32 tiles, ~1.15x on the 24x16 tile of configuration 22; conv_tune.py at 16 images: conv5_1
+  // 1 064 against 910 TFLOP/s).  Between its two tiles the ROUNDS decide (one workgroup per CU, so a launch takes
+  // ceil(items / CUs) item times): the 24x48 conv5 maps tile exactly in 24x16 (2 rounds of 384-pixel items against 2 of
+  // 512), the 48x96 conv4 maps at 16 images make 6 even rounds instead of 4.5, and at one or two images -- fewer items
+  // than CUs -- the smaller item simply ends sooner.  No fused pool on the 24x16 tile.
+  if (k == 3) {
+    auto round_cost = [&](int c, double speed) {
+      const Geo& g = kGeo[c];
+      const int64_t items = (int64_t)a.N * ((a.H + g.th - 1) / g.th) * ((a.W + g.tw - 1) / g.tw) * (a.Cout / 64);
+      const int64_t rounds = (items + a.num_cus - 1) / a.num_cus;
+      return (double)rounds * g.th * g.tw / speed;
+    };
+    int g2 = 17;
+    double s2 = 1.25;
+    if (a.pooled == nullptr && round_cost(22, 1.15) < round_cost(17, 1.25)) g2 = 22, s2 = 1.15;
+    if (covered(g2) <= s2 * g1) return g2;
   }
-  if (k == 3 && covered(17) <= 1.25 * g1) return 17;
   // 1x1 convs (plain GEMMs, AdapNet's block stages): 128 output channels per workgroup halve the activation re-reads
   // (tools/conv1x1_tune.py: 1.1-1.7x over the 64-channel tiles from 128 input channels up); from 256 input channels
   // the flat-GEMM kernel (generation 3) is ahead by another 1.1-1.5x
