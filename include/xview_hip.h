@@ -306,7 +306,9 @@ int xv_fused_head_fwd(const float* Sa, const float* Sb, const float* bias_a, con
  * score = bilinear_x8(fused . Ws) + bs, adds -sum(onehot*log_softmax)/(1e-20+count) to *loss, accumulates
  * d(score kernel) [U][C] and d(score bias) [C], and writes dfused = d(loss)/d(fused) (bf16 padded NHWC; the
  * relu masks below `fused` are applied by the callers' next kernels).  valid_count must already hold the
- * batch's count.  workspace: xv_decoder_head_bwd_workspace_bytes(n, h, w, C) bytes, 16-byte aligned.   */
+ * batch's count.  workspace: xv_decoder_head_bwd_workspace_bytes(n, h, w, C) bytes, 16-byte aligned (the padded
+ * 1/8-resolution scores, the row-weighted column sums of the score gradient -- the dense gradient is never stored --
+ * and one slab of score-weight partial sums per 256 low-resolution pixels, reduced in a fixed order).   */
 size_t xv_decoder_head_bwd_workspace_bytes(int n, int h, int w, int num_classes);
 int xv_decoder_head_bwd(const xv_act* fused, const float* w_score, const float* b_score, const int32_t* labels,
                         const int64_t* valid_count, int num_classes, double* loss, float* dw_score,
