@@ -468,8 +468,17 @@ def main():
                     help='run the RGB and depth experts back to back on one stream (profiling: per-kernel times)')
     args = ap.parse_args()
     # stdout carries exactly ONE JSON line: everything the models print (reference-style INFO / WARNING lines) goes to stderr
+    # (at the file-descriptor level too: native libraries -- gloo's connection banner, a collective library's debug lines --
+    # write to descriptor 1 directly)
     global _JSON_OUT
-    _JSON_OUT, sys.stdout = sys.stdout, sys.stderr
+    sys.stdout.flush()
+    try:
+        saved = os.dup(1)
+        os.dup2(2, 1)
+        _JSON_OUT = os.fdopen(saved, 'w')
+    except OSError:
+        _JSON_OUT = sys.stdout
+    sys.stdout = sys.stderr
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
