@@ -22,7 +22,10 @@ import argparse
 import hashlib
 import json
 import os
+import re
+import subprocess
 import sys
+import threading
 import time
 
 import numpy as np
@@ -194,9 +197,53 @@ def fence(device, world, dist):
         torch.cuda.synchronize(device)
 
 
-def measure_inference(net, batch, device, steps, warmup, graph=True, serial=False, world=1, dist=None, fetch=False):
-    """Timed region + per-kernel roofline pass of one inference configuration.  Returns (seconds of the timed region
-    on this rank, [per-iteration seconds] if fetch, conv profile list, seconds of the serialised pass)."""
+def read_sclk():
+    """Current shader clock (MHz) of GPU 0 from sysfs, if this user may read it (a record of the box's clock state
+    next to the number; never a GPU call)."""
+    try:
+        import glob
+        for path in sorted(glob.glob('/sys/class/drm/card*/device/pp_dpm_sclk')):
+            for line in open(path):
+                if line.rstrip().endswith('*'):
+                    return int(re.search(r'(\d+)\s*mhz', line.lower()).group(1))
+    except Exception:       # noqa: BLE001
+        pass
+    return None
+
+
+def timed_blocks(step, steps, device, world, dist, min_seconds):
+    """The timed region, made robust: blocks of EXACTLY `steps` steps, each bracketed by barrier + synchronize on both
+    sides and reduced to the MAX over ranks, repeated until `min_seconds` of timed work have accumulated (a single block
+    of 20 steps is 0.1 s, and box / clock state moved that by +-5 %).  Returns the list of block times (identical on every
+    rank: the loop exit depends only on all-reduced numbers)."""
+    times = []
+    while True:
+        fence(device, world, dist)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        fence(device, world, dist)
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device=device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        times.append(dt)
+        if sum(times) >= min_seconds or len(times) >= 400:
+            return times
+
+
+def block_stats(times, steps):
+    med = float(np.median(times))
+    return {'ms_per_step': round(med / steps * 1e3, 4), 'ms_per_step_min': round(min(times) / steps * 1e3, 4),
+            'ms_per_step_max': round(max(times) / steps * 1e3, 4), 'timed_blocks': len(times),
+            'timed_seconds': round(sum(times), 3)}
+
+
+def measure_inference(net, batch, device, steps, warmup, graph=True, serial=False, world=1, dist=None, fetch=False,
+                      min_seconds=2.0):
+    """Timed region + per-kernel roofline pass of one inference configuration.  Returns (block times of the timed region
+    (max over ranks), [per-iteration seconds] if fetch, conv profile list, block times of the serialised pass)."""
     from modular_semantic_segmentation_amd import ops
     net.concurrent_experts = not serial
     net._graph = None
@@ -222,55 +269,59 @@ def measure_inference(net, batch, device, steps, warmup, graph=True, serial=Fals
         for _ in range(10):
             step()
         torch.cuda.synchronize(device)
-    fence(device, world, dist)
     per_iter = []
-    t0 = time.perf_counter()
     if fetch:
         # experiments/timing.py:38-45: wall clock around every sess.run, whose fetch hands the label map to the host
-        for _ in range(steps):
+        def fstep():
             ts = time.perf_counter()
             step().cpu()
             per_iter.append(time.perf_counter() - ts)
+        times = timed_blocks(fstep, steps, device, world, dist, min_seconds)
     else:
-        for _ in range(steps):
-            step()
-    fence(device, world, dist)
-    dt = time.perf_counter() - t0
+        times = timed_blocks(step, steps, device, world, dist, min_seconds)
 
     # Per-kernel roofline pass: the same steps with the two experts serialised on one stream, so that a HIP-event
     # pair around a conv launch (recorded on the launch stream) times that kernel alone (in the timed region above
-    # the RGB and depth experts overlap on two streams).
+    # the RGB and depth experts overlap on two streams).  Same block scheme (this rank only: no collective).
     prof = []
     net._graph = None
     net.concurrent_experts = False
     net._predict_batch(batch)
     ops.CONV_PROFILE = prof
-    torch.cuda.synchronize(device)
-    ts = time.perf_counter()
-    for _ in range(steps):
-        net._predict_batch(batch)
-    torch.cuda.synchronize(device)
-    dt_serial = time.perf_counter() - ts
+    times_serial = timed_blocks(lambda: net._predict_batch(batch), steps, device, 1, None, min(min_seconds, 1.0))
     ops.CONV_PROFILE = None
     net.concurrent_experts = not serial
-    return dt, per_iter, prof, dt_serial
+    return times, per_iter, prof, times_serial
 
 
-def roofline_of(prof, kinds, peak, kernel, dt_serial, steps, traffic=None):
-    fl = sec = 0.0
+def roofline_of(prof, kinds, peak, kernel, times_serial, steps, traffic=None):
+    """Algorithmic FLOPs of the selected launches / their summed HIP-event durations, per block of the serialised pass;
+    `achieved` is the MEDIAN block, the extremes are reported next to it."""
+    nblk = max(len(times_serial), 1)
+    per = len(prof) // nblk
+    blocks = []
+    fl_all = sec_all = 0.0
     cnt = 0
-    for kind, flops, e0, e1 in prof:
-        if kind in kinds:
-            fl += flops
-            sec += e0.elapsed_time(e1) * 1e-3
-            cnt += 1
-    if cnt == 0 or sec <= 0:
+    for bi in range(nblk):
+        fl = sec = 0.0
+        for kind, flops, e0, e1 in prof[bi * per:(bi + 1) * per]:
+            if kind in kinds:
+                fl += flops
+                sec += e0.elapsed_time(e1) * 1e-3
+                cnt += 1
+        if sec > 0:
+            blocks.append(fl / sec / 1e12)
+            fl_all += fl
+            sec_all += sec
+    if not blocks:
         return None
-    achieved = fl / sec / 1e12
+    achieved = float(np.median(blocks))
     return {'bound': 'mfma', 'kernel': kernel, 'achieved': round(achieved, 2), 'peak': peak, 'unit': 'TFLOP/s',
             'frac': round(achieved / peak, 4), 'traffic': traffic, 'launches': cnt,
-            'avg_launch_ms': round(sec / cnt * 1e3, 4), 'gflop_per_launch': round(fl / cnt / 1e9, 2),
-            'measured': 'HIP events per launch, experts serialised on one stream (%.3f ms/step)' % (dt_serial / steps * 1e3)}
+            'avg_launch_ms': round(sec_all / cnt * 1e3, 4), 'gflop_per_launch': round(fl_all / cnt / 1e9, 2),
+            'frac_min': round(min(blocks) / peak, 4), 'frac_max': round(max(blocks) / peak, 4), 'blocks': len(blocks),
+            'measured': 'HIP events per launch, experts serialised on one stream (median of %d blocks of %d steps, '
+                        '%.3f ms/step)' % (len(blocks), steps, float(np.median(times_serial)) / steps * 1e3)}
 
 
 def committed_traffic(batch, h, w):
@@ -295,9 +346,11 @@ def extra_inference(device, label, fusion, batch, h, w, dtype='bf16', steps=10, 
     data = synthetic_batch(device, batch, h, w, seed=77, ones=ones)
     if dtype == 'fp8':
         net.calibrate(data)
-    dt, per_iter, prof, dt_serial = measure_inference(net, data, device, steps, warmup, fetch=fetch)
+    times, per_iter, prof, dt_serial = measure_inference(net, data, device, steps, warmup, fetch=fetch, min_seconds=1.0)
+    dt = float(np.median(times))
     rec = {'workload': label, 'images_per_step': batch, 'dtype': dtype, 'value': round(batch * steps / dt, 2),
-           'unit': 'images/s', 'ms_per_step': round(dt / steps * 1e3, 3)}
+           'unit': 'images/s'}
+    rec.update(block_stats(times, steps))
     if fetch:
         rec['seconds_per_image_mean_std'] = [round(float(np.mean(per_iter)), 6), round(float(np.std(per_iter)), 6)]
     if dtype == 'fp8':
@@ -349,28 +402,27 @@ def measure_training(args, device, world, rank, dist, batch, steps, warmup, expe
         data['depth'] = torch.randint(0, 65536, (batch, h, w, 1), generator=gen).float().to(device)
     net = make_trainer_net(args, device, expert, joint, batch)
 
-    def timed(n):
-        fence(device, world, dist)
-        t0 = time.perf_counter()
-        for _ in range(n):
-            net._train_batch(data)
-        fence(device, world, dist)
-        t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=device)
-        if world > 1:
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        return float(t.item())
+    def timed(n, min_seconds=1.0):
+        return timed_blocks(lambda: net._train_batch(data), n, device, world, dist, min_seconds)
 
     for _ in range(warmup):
         net._train_batch(data)
-    dt = timed(steps)
-    rec = {'value': round(batch * world * steps / dt, 2), 'unit': 'images/s', 'ms_per_step': round(dt / steps * 1e3, 3),
-           'images_per_gpu_per_step': batch, 'n_gpus': world}
+    times = timed(steps)
+    dt = float(np.median(times))
+    rec = {'value': round(batch * world * steps / dt, 2), 'unit': 'images/s', 'images_per_gpu_per_step': batch,
+           'n_gpus': world}
+    rec.update(block_stats(times, steps))
     if world > 1:
-        # the same steps without the collective: what the all-reduce costs beyond what backward hides
+        # the same steps without the collective: what the all-reduce costs beyond what backward hides.  The replicas
+        # drift apart while the reducer is off, so rank 0's parameters and optimizer slots are broadcast again afterwards.
+        from modular_semantic_segmentation_amd.parallel import sync_trainer_from_rank0
         reducer, net._reducer = net._reducer, None
-        net._train_batch(data)
-        dt_local = timed(steps)
-        net._reducer = reducer
+        try:
+            net._train_batch(data)
+            dt_local = float(np.median(timed(steps, 0.5)))
+        finally:
+            net._reducer = reducer
+        sync_trainer_from_rank0(net.trainer)
         rec['ms_per_step_without_allreduce'] = round(dt_local / steps * 1e3, 3)
         rec['allreduce_ms_exposed'] = round((dt - dt_local) / steps * 1e3, 3)
         rec['gradient_bytes_per_step'] = int(net.trainer.grad.numel() * 4)
@@ -420,7 +472,8 @@ def bench_train(args, device, world, rank, dist):
                 args.width, args.height)
             workload = 'AdapNet RGB %dx%d training, U=%d, C=%d, Adam' % (args.width, args.height, U, C)
         out = {'metric': metric, 'value': rec['value'], 'unit': 'images/s', 'n_gpus': world, 'steps': args.steps,
-               'warmup': args.warmup, 'ms_per_step': rec['ms_per_step'], 'higher_is_better': True,
+               'warmup': args.warmup, 'ms_per_step': rec['ms_per_step'], 'ms_per_step_min': rec['ms_per_step_min'],
+               'ms_per_step_max': rec['ms_per_step_max'], 'timed_blocks': rec['timed_blocks'], 'higher_is_better': True,
                'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
                'config': {'workload': workload, 'images_per_gpu_per_step': args.batch, 'global_batch': args.batch * world,
                           'parallelism': 'dp%d, bucketed gradient all-reduce overlapped with backward' % world},
@@ -466,7 +519,14 @@ def main():
                     help='launch every kernel eagerly instead of replaying the step from a captured hipGraph')
     ap.add_argument('--serial-experts', action='store_true',
                     help='run the RGB and depth experts back to back on one stream (profiling: per-kernel times)')
+    ap.add_argument('--min-seconds', type=float, default=2.0,
+                    help='the timed block of --steps steps is repeated until this many seconds of timed work; the median '
+                         'block is reported (0 = exactly one block)')
+    ap.add_argument('--train-dp-timeout', type=float, default=240.0,
+                    help='N > 1: seconds the train_dp phase may take before the headline line is printed without it')
     args = ap.parse_args()
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        return launch_ranks(args)
     # stdout carries exactly ONE JSON line: everything the models print (reference-style INFO / WARNING lines) goes to stderr
     # (at the file-descriptor level too: native libraries -- gloo's connection banner, a collective library's debug lines --
     # write to descriptor 1 directly)
@@ -483,16 +543,19 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    import datetime
     import torch.distributed as dist
     if args.share_device:
         local_rank = 0
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         torch.cuda.set_device(local_rank)
+        # a short collective timeout: a rank that fails alone makes the others' next collective RAISE instead of hanging
+        tmo = datetime.timedelta(seconds=max(60.0, args.train_dp_timeout))
         if args.dist_backend == 'nccl':
-            dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank), timeout=tmo)
         else:
-            dist.init_process_group(args.dist_backend)
+            dist.init_process_group(args.dist_backend, timeout=tmo)
     device = torch.device('cuda', local_rank)
     torch.cuda.set_device(device)
 
@@ -503,16 +566,15 @@ def main():
     batch = synthetic_batch(device, args.batch, args.height, args.width, seed=1234 + rank)
     if args.dtype == 'fp8':
         net.calibrate(batch)
-    dt, _, prof, dt_serial = measure_inference(net, batch, device, args.steps, args.warmup, graph=args.graph,
-                                               serial=args.serial_experts, world=world, dist=dist)
-    tmax = torch.tensor([dt], dtype=torch.float64, device=device)
-    if world > 1:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt = float(tmax.item())
+    times, _, prof, times_serial = measure_inference(net, batch, device, args.steps, args.warmup, graph=args.graph,
+                                                     serial=args.serial_experts, world=world, dist=dist,
+                                                     min_seconds=args.min_seconds)
+    dt = float(np.median(times))            # block times are already the max over ranks
+    dt_serial = float(np.median(times_serial))
 
     if args.layer_profile and rank == 0:
         # per-launch-slot breakdown (launch order repeats every step): flops, mean time, TFLOP/s
-        per = len(prof) // max(args.steps, 1)
+        per = len(prof) // max(args.steps * len(times_serial), 1)
         for i in range(per):
             evs = prof[i::per]
             ms = sum(e0.elapsed_time(e1) for _, _, e0, e1 in evs) / len(evs)
@@ -522,11 +584,11 @@ def main():
     if args.dtype == 'fp8':
         roofline = roofline_of(prof, ('k3f8',), PEAK_TFLOPS['fp8'],
                                'conv_mfma_kernel<F8> (v_mfma_scale_f32_16x16x128_f8f6f4, 3x3 launches on e4m3 operands)',
-                               dt_serial, args.steps)
+                               times_serial, args.steps)
     else:
         roofline = roofline_of(prof, ('k3',), PEAK_TFLOPS['bf16'],
-                               'conv_dma_kernel / conv_mfma_kernel (3x3 implicit GEMM, all launches)', dt_serial, args.steps,
-                               traffic=committed_traffic(args.batch, args.height, args.width))
+                               'conv_dma_kernel / conv_mfma_kernel (3x3 implicit GEMM, all launches)', times_serial,
+                               args.steps, traffic=committed_traffic(args.batch, args.height, args.width))
     per_image = conv_flops_per_image if args.expert == 'fcn' else adapnet_flops_per_image
     flops_img = per_image(args.height, args.width, 3) + per_image(args.height, args.width, 1)
     if args.expert == 'adapnet':
@@ -538,10 +600,50 @@ def main():
                     'gflop_per_image_pair': round(flops_img / 1e9, 2),
                     'measured': 'wall clock of the serialised eager steps (%.3f ms/step)' % (dt_serial / args.steps * 1e3)}
 
+    # ---- the headline record: complete BEFORE anything below can fail or hang --------------------------------------------
+    images = args.batch * world * args.steps
+    res = {
+        'metric': 'images/sec at %dx%d RGB-D FCN (two SimpleFCN experts + %s fusion + argmax, inference)' % (
+            args.width, args.height, args.fusion),
+        'value': round(images / dt, 2), 'unit': 'images/s', 'n_gpus': world, 'steps': args.steps,
+        'warmup': args.warmup, 'higher_is_better': True,
+        'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
+        'config': {'workload': 'two-stream SimpleFCN RGB+Depth %dx%d + %s fusion, U=%d, C=%d, random-init weights'
+                               % (args.width, args.height, args.fusion, U, C),
+                   'images_per_gpu_per_step': args.batch, 'global_batch': args.batch * world,
+                   'expert_streams': 1 if args.serial_experts else 2, 'hip_graph': bool(args.graph),
+                   'parallelism': 'dp%d (batch sharding, no data-path collective)' % world},
+        'conv_tflops_end_to_end': round(images * flops_img / dt / 1e12, 2),
+        'roofline': roofline,
+    }
+    res.update(block_stats(times, args.steps))
+    res['timing'] = ('blocks of exactly --steps steps, barrier + synchronize on both sides, max over ranks, repeated until '
+                     '%.1f s; value and ms_per_step are the MEDIAN block' % args.min_seconds)
+    sclk = read_sclk()
+    if sclk is not None:
+        res['sclk_mhz_after_timed_region'] = sclk
+    if args.dtype == 'fp8':
+        res['config']['conv_dtype'] = 'e4m3 operands from conv2_2 on (81 % of the conv FLOPs), conv1_1 fp32, conv1_2 / conv2_1 bf16'
+    if args.expert == 'adapnet':
+        res['metric'] = 'images/sec at %dx%d RGB-D, two AdapNet experts + %s fusion + argmax (inference)' % (
+            args.width, args.height, args.fusion)
+        res['config']['workload'] = 'two-stream AdapNet RGB+Depth %dx%d + %s fusion, U=%d, C=%d, random-init weights' % (
+            args.width, args.height, args.fusion, U, C)
+    if args.fusion == 'joint':
+        res['metric'] = 'images/sec at %dx%d, fusion_fcn joint RGB-D baseline (inference)' % (args.width, args.height)
+        res['config']['workload'] = 'fusion_fcn (two VGG16 trunks + fused decoder) RGB+Depth %dx%d, U=%d, C=%d' % (
+            args.width, args.height, U, C)
+    res['cpu_baseline'] = None
+
+    printed = threading.Lock()
+
+    def emit():
+        """Print the ONE line (rank 0), exactly once whoever gets here first: the normal end or the watchdog."""
+        if rank == 0 and printed.acquire(blocking=False):
+            print(json.dumps(res), file=_JSON_OUT, flush=True)
+
     # ---- records beyond the headline ---------------------------------------------------------------------------------
-    accuracy = cpu = None
     extra = []
-    train_dp = None
     if world == 1 and rank == 0:
         variables = dict(net.variables)
         del net
@@ -549,13 +651,16 @@ def main():
         if not args.no_cpu_baseline and args.fusion != 'joint' and args.expert == 'fcn':
             cores, avail = pick_cpu_threads(args.height, args.width)
             g = np.load(os.path.join(ROOT, 'tests', 'golden', 'notebook_868.npz'))
+            cpu = None
             if default_line and not args.no_accuracy:
                 try:
-                    accuracy, cpu = accuracy_and_cpu_baseline(args, device, cores, avail)
+                    res['accuracy'], cpu = accuracy_and_cpu_baseline(args, device, cores, avail)
                 except Exception as exc:       # noqa: BLE001  (the headline and its CPU baseline must still be printed)
-                    accuracy = {'error': '%s: %s' % (type(exc).__name__, exc)}
+                    res['accuracy'] = {'error': '%s: %s' % (type(exc).__name__, exc)}
             if cpu is None:
                 cpu = cpu_baseline_random(args, variables, {'rgb': g['cm_rgb'], 'depth': g['cm_depth']}, cores, avail)
+            res['cpu_baseline'] = cpu
+
         def guarded(fn, *a, **kw):
             try:
                 extra.append(fn(*a, **kw))
@@ -577,62 +682,84 @@ def main():
                                          steps=5)
             guarded(extra_inference, device, 'VGG-16-encoder FCN experts 2048x1024, fp8 MFMA conv path (configs[4])', 'bayes',
                                          4, 1024, 2048, dtype='fp8', steps=5)
+
             def training_record():
                 tr = measure_training(args, device, 1, 0, dist, 16, 8, 2)
                 tr['workload'] = 'SimpleFCN RGB expert training step 768x384 (fwd + bwd + Adam), 16 images'
                 return tr
             guarded(training_record)
+        if extra:
+            res['extra'] = extra
     elif world > 1 and not args.no_extra and default_line:
         del net
         torch.cuda.empty_cache()
-        # the headline line above must survive whatever happens here (the RCCL path has never run on this pool: one GPU
-        # per call); a failure on any rank is reported in the record instead of losing the line.  Ranks fail or succeed
-        # together in the collectives, so a raised exception does not leave the others waiting in general -- and if it
-        # does, the driver's own timeout still has the inference numbers of the N = 1 run.
+        # The data-parallel TRAINING step: the collective path an inference scaling curve never touches.  The headline
+        # record above is already complete and must survive whatever happens here.  A rank that fails alone leaves the
+        # others inside a collective: the process group's timeout turns that into an exception, and a watchdog on EVERY
+        # rank ends the process after --train-dp-timeout seconds -- rank 0 prints the headline with the error noted --
+        # instead of waiting for the collective library's own watchdog to abort it with the line lost.  (No re-exec: a
+        # process that has touched the GPU is never replaced.)
+        def watchdog():
+            res['train_dp'] = {'error': 'timeout: the train_dp phase did not finish within %.0f s' % args.train_dp_timeout}
+            emit()
+            os._exit(0)
+        timer = threading.Timer(args.train_dp_timeout, watchdog)
+        timer.daemon = True
+        timer.start()
+        from modular_semantic_segmentation_amd.parallel import agree_any
+        failure = None
         try:
             train_dp = measure_training(args, device, world, rank, dist, 8, 8, 2)
             train_dp['workload'] = ('SimpleFCN RGB expert training 768x384, 8 images per GPU per step, dp%d: three gradient '
                                     'buckets all-reduced over RCCL on a side stream during backward' % world)
         except Exception as exc:       # noqa: BLE001
-            train_dp = {'error': '%s: %s' % (type(exc).__name__, exc)}
+            failure = '%s: %s' % (type(exc).__name__, exc)
+        try:
+            # agree on the outcome collectively: a record is reported only if EVERY rank finished the phase
+            if agree_any(failure is not None, device):
+                train_dp = {'error': failure or 'another rank failed (see its stderr)'}
+        except Exception as exc:       # noqa: BLE001
+            train_dp = {'error': failure or '%s: %s' % (type(exc).__name__, exc)}
+        timer.cancel()
+        res['train_dp'] = train_dp
 
-    if rank == 0:
-        images = args.batch * world * args.steps
-        res = {
-            'metric': 'images/sec at %dx%d RGB-D FCN (two SimpleFCN experts + %s fusion + argmax, inference)' % (
-                args.width, args.height, args.fusion),
-            'value': round(images / dt, 2), 'unit': 'images/s', 'n_gpus': world, 'steps': args.steps,
-            'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True,
-            'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
-            'config': {'workload': 'two-stream SimpleFCN RGB+Depth %dx%d + %s fusion, U=%d, C=%d, random-init weights'
-                                   % (args.width, args.height, args.fusion, U, C),
-                       'images_per_gpu_per_step': args.batch, 'global_batch': args.batch * world,
-                       'expert_streams': 1 if args.serial_experts else 2, 'hip_graph': bool(args.graph),
-                       'parallelism': 'dp%d (batch sharding, no data-path collective)' % world},
-            'conv_tflops_end_to_end': round(images * flops_img / dt / 1e12, 2),
-            'roofline': roofline,
-        }
-        if args.dtype == 'fp8':
-            res['config']['conv_dtype'] = 'e4m3 operands from conv2_2 on (81 % of the conv FLOPs), conv1_1 fp32, conv1_2 / conv2_1 bf16'
-        if args.expert == 'adapnet':
-            res['metric'] = 'images/sec at %dx%d RGB-D, two AdapNet experts + %s fusion + argmax (inference)' % (
-                args.width, args.height, args.fusion)
-            res['config']['workload'] = 'two-stream AdapNet RGB+Depth %dx%d + %s fusion, U=%d, C=%d, random-init weights' % (
-                args.width, args.height, args.fusion, U, C)
-        if args.fusion == 'joint':
-            res['metric'] = 'images/sec at %dx%d, fusion_fcn joint RGB-D baseline (inference)' % (args.width, args.height)
-            res['config']['workload'] = 'fusion_fcn (two VGG16 trunks + fused decoder) RGB+Depth %dx%d, U=%d, C=%d' % (
-                args.width, args.height, U, C)
-        res['cpu_baseline'] = cpu
-        if accuracy is not None:
-            res['accuracy'] = accuracy
-        if extra:
-            res['extra'] = extra
-        if train_dp is not None:
-            res['train_dp'] = train_dp
-        print(json.dumps(res), file=_JSON_OUT, flush=True)
+    emit()
     if world > 1:
-        dist.destroy_process_group()
+        try:
+            dist.destroy_process_group()
+        except Exception:           # noqa: BLE001  (after a failed collective the group may already be unusable)
+            pass
+
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` without a launcher around it: start the N ranks as a CHILD process (the same command
+    line under torch.distributed.run, one rank per GPU over RCCL), relay rank 0's JSON line and exit with the child's
+    code.  Nothing here touches the GPU: a process that has initialised it must never exec another program, so the
+    ranks are children and this parent only waits (torch.cuda.device_count() does not initialise the device)."""
+    import socket
+    if not args.share_device and torch.cuda.device_count() < args.gpus:
+        print('bench.py: --gpus %d but %d GPU(s) visible (use --share-device --dist-backend gloo for a one-GPU smoke run '
+              'of the multi-rank path)' % (args.gpus, torch.cuda.device_count()), file=sys.stderr)
+        sys.exit(2)
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    line = None
+    for out in proc.stdout:
+        out = out.strip()
+        if out.startswith('{') and out.endswith('}'):
+            line = out                  # rank 0's record (the last such line wins)
+        elif out:
+            print(out, file=sys.stderr)
+    rc = proc.wait()
+    if line is not None:
+        print(line, flush=True)
+    sys.exit(rc if rc != 0 or line is not None else 1)
 
 
 if __name__ == '__main__':

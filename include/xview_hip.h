@@ -35,7 +35,8 @@ extern "C" {
 /* padded-NHWC activation: dense [n][h+2][w+2][c], zero border, data -> padded origin.
  * dtype XV_BF16 (every entry point) or XV_FP8 (OCP e4m3fn, one byte per element; xv_conv2d_fwd* only, BASELINE
  * config "fp8 MFMA conv path"): a stored value q stands for q * 2^scale_exp (per-tensor power-of-two scale, 0 for
- * bf16).  Entry points other than the forward convolutions read bf16 maps and ignore the last two fields.          */
+ * bf16).  Entry points other than the forward convolutions take bf16 maps only and return XV_EINVAL for an XV_FP8
+ * descriptor (they would otherwise reinterpret one-byte elements as bf16).                                          */
 #define XV_BF16 0
 #define XV_FP8 1
 typedef struct xv_act {

@@ -622,6 +622,7 @@ __global__ __launch_bounds__(512) void conv_first_wgrad_mfma_kernel(const float*
 }  // namespace
 
 extern "C" int xv_maxpool2x2_bwd(const xv_act* y, const xv_act* dpooled, const xv_act* dy, void* stream) {
+  XV_REQUIRE_BF16(y, dpooled, dy);
   XV_CHECK_ARG(y && dpooled && dy && y->data && dpooled->data && dy->data);
   XV_CHECK_SHAPE(y->c > 0 && (y->c & 7) == 0 && (y->h & 1) == 0 && (y->w & 1) == 0);
   XV_CHECK_SHAPE(dy->n == y->n && dy->h == y->h && dy->w == y->w && dy->c == y->c);
@@ -633,6 +634,7 @@ extern "C" int xv_maxpool2x2_bwd(const xv_act* y, const xv_act* dpooled, const x
 }
 
 extern "C" int xv_relu_bwd(const xv_act* g, const xv_act* ref, const xv_act* out, void* stream) {
+  XV_REQUIRE_BF16(g, ref, out);
   XV_CHECK_ARG(g && ref && out && g->data && ref->data && out->data);
   XV_CHECK_SHAPE(g->n == ref->n && g->h == ref->h && g->w == ref->w && g->c == ref->c && (g->c & 7) == 0);
   XV_CHECK_SHAPE(out->n == g->n && out->h == g->h && out->w == g->w && out->c == g->c);
@@ -643,6 +645,7 @@ extern "C" int xv_relu_bwd(const xv_act* g, const xv_act* ref, const xv_act* out
 }
 
 extern "C" int xv_upsample2x_bwd(const xv_act* dfused, const xv_act* s5, const xv_act* ds5, void* stream) {
+  XV_REQUIRE_BF16(dfused, s5, ds5);
   XV_CHECK_ARG(dfused && s5 && ds5 && dfused->data && s5->data && ds5->data);
   XV_CHECK_SHAPE((s5->c & 7) == 0 && dfused->n == s5->n && dfused->h == 2 * s5->h && dfused->w == 2 * s5->w &&
                  dfused->c == s5->c);
@@ -676,6 +679,7 @@ extern "C" int xv_decoder_head_bwd(const xv_act* fused, const float* w_score, co
                                    const int64_t* valid_count, int num_classes, double* loss, float* dw_score,
                                    float* db_score, const xv_act* dfused, void* workspace, size_t workspace_bytes,
                                    void* stream) {
+  XV_REQUIRE_BF16(fused, dfused);
   XV_CHECK_ARG(fused && fused->data && w_score && b_score && labels && valid_count && loss && dw_score && db_score &&
                dfused && dfused->data && workspace);
   XV_CHECK_SHAPE(fused->c > 0 && (fused->c & 7) == 0 && fused->c <= 256 && num_classes >= 1 && num_classes <= 32);
@@ -729,6 +733,7 @@ extern "C" int xv_decoder_head_bwd(const xv_act* fused, const float* w_score, co
 
 extern "C" int xv_conv2d_first_bwd_filter(const float* x, int n, int h, int w, int cin, const xv_act* dy, float* dw_hwio,
                                           float* dbias, void* stream) {
+  XV_REQUIRE_BF16(dy);
   XV_CHECK_ARG(x && dy && dy->data && dw_hwio);
   XV_CHECK_SHAPE(n > 0 && h > 0 && w > 0 && cin >= 1 && cin <= 4 && dy->n == n && dy->h == h && dy->w == w && dy->c == 64);
   XV_CHECK_SHAPE((int64_t)n * h * w < 0x7fff0000);

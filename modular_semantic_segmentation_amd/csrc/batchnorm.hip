@@ -583,6 +583,7 @@ bool same_shape(const xv_act* a, const xv_act* b) { return a->n == b->n && a->h 
 }  // namespace
 
 extern "C" int xv_bn_stats(const xv_act* z, double* sums, void* stream) {
+  XV_REQUIRE_BF16(z);
   XV_CHECK_ARG(z && z->data && sums);
   XV_CHECK_SHAPE(z->c >= 64 && 2048 % z->c == 0 && z->n > 0 && z->h > 0 && z->w > 0);  // C/8 divides the block size
   hipError_t e = hipMemsetAsync(sums, 0, sizeof(double) * 2 * z->c, (hipStream_t)stream);
@@ -606,6 +607,7 @@ extern "C" int xv_bn_finalize(const double* sums, int channels, int64_t count, c
 
 extern "C" int xv_bn_apply(const xv_act* z, const float* scale, const float* shift, int relu, const xv_act* y,
                            void* stream) {
+  XV_REQUIRE_BF16(z, y);
   XV_CHECK_ARG(z && y && z->data && y->data && scale && shift);
   XV_CHECK_SHAPE(same_shape(z, y) && (z->c & 7) == 0);
   const int64_t total = (int64_t)z->n * z->h * z->w * (z->c >> 3);
@@ -619,6 +621,7 @@ extern "C" int xv_bn_apply(const xv_act* z, const float* scale, const float* shi
 // uses whatever `sums` / `count` hold by then (global under Sync-BN).
 extern "C" int xv_bn_bwd_reduce(const xv_act* dy, const xv_act* y, const xv_act* z, const float* mean,
                                 const float* invstd, double* sums, float* dgamma, float* dbeta, void* stream) {
+  XV_REQUIRE_BF16(dy, y, z);
   XV_CHECK_ARG(dy && z && dy->data && z->data && mean && invstd && sums && dgamma && dbeta);
   XV_CHECK_SHAPE(same_shape(dy, z) && z->c >= 64 && 2048 % z->c == 0);
   const __bf16* yp = nullptr;
@@ -640,6 +643,7 @@ extern "C" int xv_bn_bwd_reduce(const xv_act* dy, const xv_act* y, const xv_act*
 extern "C" int xv_bn_bwd_apply(const xv_act* dy, const xv_act* y, const xv_act* z, const float* mean,
                                const float* invstd, const float* gamma, const double* sums, int64_t count,
                                const xv_act* dz, void* stream) {
+  XV_REQUIRE_BF16(dy, y, z, dz);
   XV_CHECK_ARG(dy && z && dz && dy->data && z->data && dz->data && mean && invstd && gamma && sums);
   XV_CHECK_SHAPE(same_shape(dy, z) && same_shape(dz, z) && (z->c & 7) == 0 && count > 0);
   const __bf16* yp = (y && y->data) ? (const __bf16*)y->data : nullptr;
@@ -652,6 +656,7 @@ extern "C" int xv_bn_bwd_apply(const xv_act* dy, const xv_act* y, const xv_act* 
 
 extern "C" int xv_bn_bwd(const xv_act* dy, const xv_act* y, const xv_act* z, const float* mean, const float* invstd,
                          const float* gamma, double* sums, float* dgamma, float* dbeta, const xv_act* dz, void* stream) {
+  XV_REQUIRE_BF16(dy, y, z, dz);
   XV_CHECK_ARG(dz && z);
   const int rc = xv_bn_bwd_reduce(dy, y, z, mean, invstd, sums, dgamma, dbeta, stream);
   if (rc != XV_OK) return rc;
@@ -709,6 +714,7 @@ extern "C" int xv_bn_dense_bwd(const float* dy, const float* z, int64_t rows, in
 }
 
 extern "C" int xv_upsample_raw_fwd(const xv_act* x, int factor, const xv_act* y, void* stream) {
+  XV_REQUIRE_BF16(x, y);
   XV_CHECK_ARG(x && y && x->data && y->data);
   XV_CHECK_SHAPE((factor == 2 || factor == 8) && (x->c & 7) == 0 && y->n == x->n && y->h == factor * x->h &&
                  y->w == factor * x->w && y->c == x->c);
@@ -723,6 +729,7 @@ extern "C" int xv_upsample_raw_fwd(const xv_act* x, int factor, const xv_act* y,
 }
 
 extern "C" int xv_upsample_raw_bwd(const xv_act* dy, int factor, const xv_act* dx, void* stream) {
+  XV_REQUIRE_BF16(dy, dx);
   XV_CHECK_ARG(dx && dy && dx->data && dy->data);
   XV_CHECK_SHAPE((factor == 2 || factor == 8) && (dx->c & 7) == 0 && dy->n == dx->n && dy->h == factor * dx->h &&
                  dy->w == factor * dx->w && dy->c == dx->c);
@@ -750,6 +757,7 @@ extern "C" int xv_upsample_raw_bwd(const xv_act* dy, int factor, const xv_act* d
 
 extern "C" int xv_score_dense_fwd(const xv_act* u, const float* w_score, const float* b_score, int num_classes,
                                   float* score, void* stream) {
+  XV_REQUIRE_BF16(u);
   XV_CHECK_ARG(u && u->data && w_score && b_score && score);
   XV_CHECK_SHAPE((u->c & 7) == 0 && u->c <= 256 && num_classes >= 1 && num_classes <= 32);
   const int64_t npix = (int64_t)u->n * u->h * u->w;
@@ -776,6 +784,7 @@ extern "C" int xv_softmax_ce_dense(const float* logits, const int32_t* labels, c
 
 extern "C" int xv_score_dense_bwd(const xv_act* u, const float* dscore, const float* w_score, int num_classes,
                                   float* dw_score, float* db_score, const xv_act* du, void* stream) {
+  XV_REQUIRE_BF16(u, du);
   XV_CHECK_ARG(u && u->data && dscore && w_score && dw_score && db_score && du && du->data);
   XV_CHECK_SHAPE((u->c & 63) == 0 && u->c <= 256 && num_classes >= 1 && num_classes <= 32 && same_shape(u, du));
   const int64_t npix = (int64_t)u->n * u->h * u->w;

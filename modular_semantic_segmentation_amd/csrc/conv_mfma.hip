@@ -1939,6 +1939,7 @@ extern "C" int xv_pack_conv_weights_dgrad(const float* w_hwio, void* packed, int
 extern "C" int xv_conv2d_bwd_data(const xv_act* dy, const void* w_packed_dgrad, const float* zero_bias,
                                   const xv_act* relu_ref, const xv_act* addend, const xv_act* dx, int k,
                                   void* stream) {
+  XV_REQUIRE_BF16(dy, relu_ref, addend, dx);
   XV_CHECK_ARG(dx && dx->data && zero_bias);
   if (relu_ref && relu_ref->data)
     XV_CHECK_SHAPE(relu_ref->n == dx->n && relu_ref->h == dx->h && relu_ref->w == dx->w && relu_ref->c == dx->c);
@@ -1951,6 +1952,7 @@ extern "C" int xv_conv2d_bwd_data(const xv_act* dy, const void* w_packed_dgrad, 
 
 extern "C" int xv_conv2d_fwd_residual(const xv_act* x, const void* w_packed, const float* bias,
                                       const xv_act* residual, const xv_act* y, int relu, void* stream) {
+  XV_REQUIRE_BF16(x, residual, y);
   // 1x1 only: those shapes always run on the first-generation kernel, whose epilogue applies the activation before
   // the addend (the second generation clamps at the store, after it)
   XV_CHECK_ARG(y && y->data && residual && residual->data);
@@ -1974,6 +1976,7 @@ extern "C" size_t xv_deconv_dense_workspace_bytes(int n, int h, int w, int cout,
 extern "C" int xv_deconv_dense_fwd(const xv_act* x, const void* w_phases_packed, const float* zero_bias, const float* scale,
                                    const float* shift, const xv_act* residual, const xv_act* y, int stride, int relu,
                                    void* workspace, size_t workspace_bytes, void* stream) {
+  XV_REQUIRE_BF16(x, residual, y);
   XV_CHECK_ARG(x && x->data && y && y->data && w_phases_packed && zero_bias && workspace);
   XV_CHECK_ARG((scale == nullptr) == (shift == nullptr) && (((uintptr_t)workspace) & 15) == 0);
   XV_CHECK_SHAPE(stride >= 1 && stride <= 8 && y->n == x->n && y->h == x->h * stride && y->w == x->w * stride);

@@ -424,6 +424,7 @@ __global__ __launch_bounds__(256) void bias_grad_kernel(const __bf16* __restrict
 }  // namespace
 
 extern "C" int xv_bias_grad(const xv_act* dy, float* dbias, void* stream) {
+  XV_REQUIRE_BF16(dy);
   XV_CHECK_ARG(dy && dy->data && dbias);
   XV_CHECK_SHAPE(dy->c > 0 && (dy->c & 7) == 0 && dy->c <= 2048 && 256 % (dy->c >> 3) == 0);
   const int64_t rows = (int64_t)dy->n * (dy->h + 2) * (dy->w + 2);
@@ -464,11 +465,13 @@ extern "C" int xv_conv2d_bwd_filter_ws(const xv_act* x, const xv_act* dy, float*
 
 extern "C" int xv_conv2d_bwd_filter(const xv_act* x, const xv_act* dy, float* dw_hwio, float* dbias, int k,
                                     void* stream) {
+  XV_REQUIRE_BF16(x, dy);
   return xv_conv2d_bwd_filter_ws(x, dy, dw_hwio, dbias, k, nullptr, 0, stream);
 }
 
 extern "C" int xv_conv2d_bwd_filter_ws(const xv_act* x, const xv_act* dy, float* dw_hwio, float* dbias, int k,
                                        void* workspace, size_t workspace_bytes, void* stream) {
+  XV_REQUIRE_BF16(x, dy);
   XV_CHECK_ARG(x && dy && x->data && dy->data && dw_hwio);
   XV_CHECK_SHAPE(k == 1 || k == 3);
   XV_CHECK_SHAPE(x->n > 0 && x->h > 0 && x->w > 0 && x->c > 0 && (x->c & 63) == 0 && (dy->c & 63) == 0 && dy->c > 0);

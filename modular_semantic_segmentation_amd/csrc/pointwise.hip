@@ -836,6 +836,7 @@ inline int grid_for(int64_t total, int per_block = 256, int cap = 8192) {
 
 extern "C" int xv_conv2d_first_fwd(const float* x, int n, int h, int w, int cin, const float* w_hwio,
                                    const float* bias, const xv_act* y, int relu, void* stream) {
+  XV_REQUIRE_BF16(y);
   XV_CHECK_ARG(x && w_hwio && bias && y && y->data);
   XV_CHECK_SHAPE(n > 0 && h > 0 && w > 0 && cin >= 1 && cin <= 4);
   XV_CHECK_SHAPE(y->n == n && y->h == h && y->w == w && y->c == 64);
@@ -874,6 +875,7 @@ extern "C" int xv_conv2d_first_fwd(const float* x, int n, int h, int w, int cin,
 }
 
 extern "C" int xv_maxpool2x2_fwd(const xv_act* x, const xv_act* y, void* stream) {
+  XV_REQUIRE_BF16(x, y);
   XV_CHECK_ARG(x && y && x->data && y->data);
   XV_CHECK_SHAPE(x->n > 0 && x->h > 0 && x->w > 0 && x->c > 0 && (x->c & 7) == 0 && (x->h & 1) == 0 && (x->w & 1) == 0);
   XV_CHECK_SHAPE(y->n == x->n && y->h == x->h / 2 && y->w == x->w / 2 && y->c == x->c);
@@ -885,6 +887,7 @@ extern "C" int xv_maxpool2x2_fwd(const xv_act* x, const xv_act* y, void* stream)
 
 extern "C" int xv_upsample2x_affine_act_add(const xv_act* x, const float* scale, const float* shift,
                                            const xv_act* residual, const xv_act* y, int relu, void* stream) {
+  XV_REQUIRE_BF16(x, residual, y);
   XV_CHECK_ARG(x && y && x->data && y->data);
   XV_CHECK_ARG((scale == nullptr) == (shift == nullptr));
   XV_CHECK_SHAPE(x->n > 0 && x->h > 0 && x->w > 0 && x->c > 0 && (x->c & 7) == 0);
@@ -902,10 +905,12 @@ extern "C" int xv_upsample2x_affine_act_add(const xv_act* x, const float* scale,
 
 extern "C" int xv_upsample2x_affine_relu_add(const xv_act* x, const float* scale, const float* shift,
                                             const xv_act* residual, const xv_act* y, void* stream) {
+  XV_REQUIRE_BF16(x, residual, y);
   return xv_upsample2x_affine_act_add(x, scale, shift, residual, y, 1, stream);
 }
 
 extern "C" int xv_upsample2x_relu_add(const xv_act* x, const xv_act* residual, const xv_act* y, void* stream) {
+  XV_REQUIRE_BF16(x, residual, y);
   return xv_upsample2x_affine_relu_add(x, nullptr, nullptr, residual, y, stream);
 }
 
@@ -991,6 +996,7 @@ __global__ __launch_bounds__(256) void dropout_kernel(const u32x4* __restrict__ 
 }
 
 extern "C" int xv_dropout(const xv_act* x, const xv_act* y, float rate, uint64_t seed, void* stream) {
+  XV_REQUIRE_BF16(x, y);
   XV_CHECK_ARG(x && y && x->data && y->data && rate >= 0.f && rate < 1.f);
   XV_CHECK_SHAPE(x->n == y->n && x->h == y->h && x->w == y->w && x->c == y->c && (x->c & 7) == 0);
   XV_CHECK_SHAPE(x->dtype == XV_BF16 && y->dtype == XV_BF16);
@@ -1003,6 +1009,7 @@ extern "C" int xv_dropout(const xv_act* x, const xv_act* y, float rate, uint64_t
 
 // y[..., :Ca] = a, y[..., Ca:] = b over the whole padded buffers (tf.concat(axis=3), fusion_fcn.py:27-28)
 extern "C" int xv_concat_channels(const xv_act* a, const xv_act* b, const xv_act* y, void* stream) {
+  XV_REQUIRE_BF16(a, b, y);
   XV_CHECK_ARG(a && b && y && a->data && b->data && y->data);
   XV_CHECK_SHAPE(a->n == b->n && a->h == b->h && a->w == b->w && y->n == a->n && y->h == a->h && y->w == a->w);
   XV_CHECK_SHAPE(y->c == a->c + b->c && (a->c & 7) == 0 && (b->c & 7) == 0);
@@ -1016,6 +1023,7 @@ extern "C" int xv_concat_channels(const xv_act* a, const xv_act* b, const xv_act
 // S = fused . Ws at 1/8 resolution into a zero-bordered fp32 [N][h+2][w+2][CM] buffer (shared by the
 // forward head and the head backward)
 extern "C" int xv_score_lowres(const xv_act* fused, const float* w_score, int num_classes, float* S, void* stream) {
+  XV_REQUIRE_BF16(fused);
   XV_CHECK_ARG(fused && fused->data && w_score && S);
   XV_CHECK_SHAPE(fused->c > 0 && (fused->c & 7) == 0 && num_classes >= 1 && num_classes <= 32);
   const int64_t lowres = (int64_t)fused->n * (fused->h + 2) * (fused->w + 2);
@@ -1077,6 +1085,7 @@ extern "C" int xv_fused_head_fwd(const float* Sa, const float* Sb, const float* 
 extern "C" int xv_decoder_head_affine_fwd(const xv_act* fused, const float* scale, const float* shift,
                                          const float* w_score, const float* b_score, int num_classes, float* score,
                                          float* prob, int64_t* label, void* stream) {
+  XV_REQUIRE_BF16(fused);
   XV_CHECK_ARG(fused && fused->data && scale && shift && w_score && b_score && (score || prob || label));
   XV_CHECK_SHAPE(fused->c > 0 && (fused->c & 7) == 0 && num_classes >= 1 && num_classes <= 32);
   const int Wo = fused->w * 8;
@@ -1109,6 +1118,7 @@ extern "C" size_t xv_decoder_head_workspace_bytes(int n, int h, int w, int num_c
 extern "C" int xv_decoder_head_fwd(const xv_act* fused, const float* w_score, const float* b_score, int num_classes,
                                    float* score, float* prob, int64_t* label, void* workspace, size_t workspace_bytes,
                                    void* stream) {
+  XV_REQUIRE_BF16(fused);
   XV_CHECK_ARG(fused && fused->data && w_score && b_score && workspace);
   XV_CHECK_ARG(score || prob || label);
   XV_CHECK_SHAPE(fused->n > 0 && fused->h > 0 && fused->w > 0);

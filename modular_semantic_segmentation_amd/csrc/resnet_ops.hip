@@ -183,6 +183,7 @@ __global__ __launch_bounds__(256) void add_kernel(const u32x4* __restrict__ a, c
 }  // namespace
 
 extern "C" int xv_subsample2(const xv_act* x, const xv_act* y, void* stream) {
+  XV_REQUIRE_BF16(x, y);
   XV_CHECK_ARG(x && y && x->data && y->data);
   XV_CHECK_SHAPE(x->n == y->n && x->c == y->c && (x->c & 7) == 0 && x->h == 2 * y->h && x->w == 2 * y->w && y->h > 0);
   const int64_t total = (int64_t)y->n * y->h * y->w * (y->c >> 3);
@@ -192,6 +193,7 @@ extern "C" int xv_subsample2(const xv_act* x, const xv_act* y, void* stream) {
 }
 
 extern "C" int xv_gather_conv7s2(const xv_act* x, const xv_act* z, void* stream) {
+  XV_REQUIRE_BF16(x, z);
   XV_CHECK_ARG(x && z && x->data && z->data);
   XV_CHECK_SHAPE(x->n == z->n && z->c == 9 * x->c && (x->c & 7) == 0 && x->h == 2 * z->h && x->w == 2 * z->w &&
                  z->h > 0);
@@ -202,6 +204,7 @@ extern "C" int xv_gather_conv7s2(const xv_act* x, const xv_act* z, void* stream)
 }
 
 extern "C" int xv_im2col_dilated_pair(const xv_act* x, int dilation1, int dilation2, const xv_act* z, void* stream) {
+  XV_REQUIRE_BF16(x, z);
   XV_CHECK_ARG(x && z && x->data && z->data);
   XV_CHECK_SHAPE(x->n == z->n && x->h == z->h && x->w == z->w && z->c == 18 * x->c && (x->c & 7) == 0 &&
                  dilation1 >= 1 && dilation2 >= 1);
@@ -212,6 +215,7 @@ extern "C" int xv_im2col_dilated_pair(const xv_act* x, int dilation1, int dilati
 }
 
 extern "C" int xv_subsample2_bwd(const xv_act* dy, const xv_act* dx, void* stream) {
+  XV_REQUIRE_BF16(dy, dx);
   XV_CHECK_ARG(dy && dx && dy->data && dx->data);
   XV_CHECK_SHAPE(dx->n == dy->n && dx->c == dy->c && (dx->c & 7) == 0 && dx->h == 2 * dy->h && dx->w == 2 * dy->w &&
                  dy->h > 0);
@@ -222,6 +226,7 @@ extern "C" int xv_subsample2_bwd(const xv_act* dy, const xv_act* dx, void* strea
 }
 
 extern "C" int xv_gather_conv7s2_bwd(const xv_act* dz, const xv_act* dx, void* stream) {
+  XV_REQUIRE_BF16(dz, dx);
   XV_CHECK_ARG(dz && dx && dz->data && dx->data);
   XV_CHECK_SHAPE(dx->n == dz->n && dz->c == 9 * dx->c && (dx->c & 7) == 0 && dx->h == 2 * dz->h && dx->w == 2 * dz->w &&
                  dz->h > 0);
@@ -233,6 +238,7 @@ extern "C" int xv_gather_conv7s2_bwd(const xv_act* dz, const xv_act* dx, void* s
 
 extern "C" int xv_im2col_dilated_pair_bwd(const xv_act* dz, int dilation1, int dilation2, const xv_act* dx,
                                           void* stream) {
+  XV_REQUIRE_BF16(dz, dx);
   XV_CHECK_ARG(dz && dx && dz->data && dx->data);
   XV_CHECK_SHAPE(dx->n == dz->n && dx->h == dz->h && dx->w == dz->w && dz->c == 18 * dx->c && (dx->c & 7) == 0 &&
                  dilation1 >= 1 && dilation2 >= 1);
@@ -245,6 +251,7 @@ extern "C" int xv_im2col_dilated_pair_bwd(const xv_act* dz, int dilation1, int d
 // y = a + b over the whole padded buffers (the residual add of a ResNet block in the training graph, where a batch
 // norm sits between the conv and the add; borders are 0 + 0)
 extern "C" int xv_add(const xv_act* a, const xv_act* b, const xv_act* y, void* stream) {
+  XV_REQUIRE_BF16(a, b, y);
   XV_CHECK_ARG(a && b && y && a->data && b->data && y->data);
   XV_CHECK_SHAPE(a->n == b->n && a->h == b->h && a->w == b->w && a->c == b->c && y->n == a->n && y->h == a->h &&
                  y->w == a->w && y->c == a->c && (a->c & 7) == 0);

@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <initializer_list>
+
 #include "../../include/xview_hip.h"
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
@@ -18,6 +20,19 @@ typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
 #define XV_CHECK_SHAPE(cond) \
   do {                       \
     if (!(cond)) return XV_ESHAPE; \
+  } while (0)
+
+// bf16-only entry points (everything except the forward convolutions, which read / write e4m3 maps too): an XV_FP8
+// descriptor handed to them would be reinterpreted as bf16 -- garbage and reads past the end of a map of half the bytes.
+// Null descriptors (optional arguments) pass; the entry point's own argument checks deal with them.
+static inline bool xv_all_bf16(std::initializer_list<const xv_act*> acts) {
+  for (const xv_act* a : acts)
+    if (a != nullptr && a->dtype != XV_BF16) return false;
+  return true;
+}
+#define XV_REQUIRE_BF16(...)                               \
+  do {                                                     \
+    if (!xv_all_bf16({__VA_ARGS__})) return XV_EINVAL;     \
   } while (0)
 
 static inline int xv_launch_status() {

@@ -103,6 +103,9 @@ class FcnEngine(object):
     # ---- weights -----------------------------------------------------------------------------
     def load(self, variables):
         p, dev = self.prefix, self.device
+        # new weights -> new activation ranges: the fp8 exponents of the previous weights would saturate (or underflow)
+        # silently, so the next batch seen calibrates again (or the caller calls calibrate())
+        self.fp8_scales = None
         v = {k: np.asarray(a, np.float32) for k, a in variables.items() if k.startswith(p + '/')}
         for need, shape in variable_shapes(p, self.cin, self.U, self.C).items():
             if need not in v:
@@ -293,8 +296,9 @@ class FcnEngine(object):
             ops.upsample2x_relu_add(s5, residual=s4, y=fused, scale=aff[0], shift=aff[1])
         L.update(score_conv4=s4, score_conv5=s5, fused=fused)
         if self.dropout_rate > 0 and 'features' in self.dropout_layers:
-            # decoder(..., dropout_rate) on its input features (simple_fcn.py:124-126)
-            L['fused'] = L['features_drop'] = self._dropout(fused, 'features_drop')
+            # decoder(..., dropout_rate) drops its input features INSIDE the decoder (simple_fcn.py:124-126): the layer
+            # dict keeps 'fused' undropped like the reference's, the head reads 'features_drop'
+            L['features_drop'] = self._dropout(fused, 'features_drop')
         self._dropout_pass += 1
         return L
 
@@ -318,7 +322,7 @@ class FcnEngine(object):
         """Trunk + the 1x1 score conv at 1/8 resolution: float32 [N][h/8+2][w/8+2][CP] (the first half of the decoder
         head, xv_score_lowres); the fused two-expert head of the fusion models takes it from here."""
         L = self.encoder(x)
-        f = L['fused']
+        f = L.get('features_drop', L['fused'])
         cp = (self.C + 3) // 4 * 4
         key = ('lowres_S', f.n, f.h, f.w)
         S = self._arena.get(key)
@@ -331,7 +335,7 @@ class FcnEngine(object):
         """fcn + test_pipeline (basic_fusion_model.py:9-23): returns dict with any of
         'score', 'prob' (float32 [N,H,W,C]) and 'label' == 'classification' (int64 [N,H,W])."""
         L = self.encoder(x, keep_all=keep_all)
-        f = L['fused']
+        f = L.get('features_drop', L['fused'])           # the decoder's input (dropped only when 'features' is a dropout site)
         key = ('head_ws', f.n, f.h, f.w)
         ws = self._arena.get(key)
         if ws is None:             # per-engine workspace: the two experts run on different streams

@@ -65,10 +65,11 @@ def sync_trainer_from_rank0(trainer):
     """Data-parallel replicas must start from ONE set of parameters: the reference trains a single graph
     (base_model.py:153-162), so N ranks reproduce it only if rank 0's master weights, batch-norm moving
     statistics and optimizer slots are everybody's.  Called when a trainer is created and after every
-    `load_from_variables` (random initialisers are drawn per process, imported files may differ per rank)."""
+    `load_from_variables` (random initialisers are drawn per process, imported files may differ per rank).  Returns True
+    if a broadcast took place: the caller's variable dict / folded inference weights are then stale on ranks != 0."""
     _, size = world()
     if size == 1:
-        return
+        return False
     broadcast_(trainer.param)
     for mm, mv in getattr(trainer, 'moving', {}).values():
         broadcast_(mm, mv)
@@ -86,6 +87,7 @@ def sync_trainer_from_rank0(trainer):
         trainer.state = {}
     trainer.t = int(has[1])
     trainer.repack()
+    return True
 
 
 def agree_any(flag, device):

@@ -86,7 +86,7 @@ class SimpleFCN(BaseModel):
         if getattr(self, 'trainer', None) is not None:
             from .parallel import sync_trainer_from_rank0
             self.trainer.load_from_variables(variables=self.variables)
-            sync_trainer_from_rank0(self.trainer)
+            self._after_rank0_sync(sync_trainer_from_rank0(self.trainer))
 
     # ---- training (base_model.py:153-162,180-261) ------------------------------------------------------
     def calibrate(self, data):
@@ -105,10 +105,17 @@ class SimpleFCN(BaseModel):
             cls = FcnBnTrainer if self.config['batch_normalization'] else FcnTrainer
             self.trainer = cls(self.engine, self.config.get('trainer', 'adam'), self.config.get('learning_rate', 0.0001))
             self.trainer.load_from_variables(variables=self.variables)
-            sync_trainer_from_rank0(self.trainer)        # every replica starts from rank 0's initialisers
+            # every replica starts from rank 0's initialisers
+            self._after_rank0_sync(sync_trainer_from_rank0(self.trainer))
             require_equal_batchsize(self.config['batchsize'], self.device)
             self._reducer = GradReducer(self.device) if world()[1] > 1 else None
         return self.trainer
+
+    def _after_rank0_sync(self, synced):
+        """Rank 0's parameters have just replaced this rank's own draw inside the trainer: mark the variable dict (and
+        the batch-norm-folded inference engine) stale, so that predict / score / export_weights on every rank see them."""
+        if synced:
+            self._dirty = True
 
     def _train_batch(self, batch):
         tr = self._ensure_trainer()

@@ -165,9 +165,13 @@ def oracle_predictions(variables, heldout, cms, dparams, policy='fp32'):
     return {k: np.concatenate(v) for k, v in out.items()}, dt, n
 
 
+LOGIT_TOL_REL = 0.04        # stated tolerance of the bf16 path: max |logit error| / max |logit|
+
+
 def compare(hip, ref, labels):
     """Per model: mIoU of both paths, the difference in percentage points, label agreement; per expert the logit
-    error relative to the largest |logit| and the agreement on pixels whose fp32 top-2 margin exceeds it."""
+    error relative to the largest |logit| and the agreement on pixels whose fp32 top-2 margin exceeds twice the STATED
+    logit tolerance (LOGIT_TOL_REL of the logit scale)."""
     res = {}
     for k in ('rgb', 'depth', 'bayes', 'dirichlet'):
         a, _ = _miou(labels, hip[k])
@@ -180,7 +184,9 @@ def compare(hip, ref, labels):
         err = float(np.abs(s - r).max())
         res[m]['logit_mean_abs_err_rel'] = round(float(np.abs(s - r).mean()) / scale, 7)
         top2 = np.sort(r, -1)[..., -2:]
-        clear = (top2[..., 1] - top2[..., 0]) > 2 * err
+        # a FIXED mask from the stated bf16 tolerance (worst logit within 4 % of the logit scale), not from the measured
+        # error: a mask of 2 x the measured error would make the agreement below 1.0 by construction
+        clear = (top2[..., 1] - top2[..., 0]) > 2 * LOGIT_TOL_REL * scale
         res[m].update(logit_max_abs_err=round(err, 5), logit_scale=round(scale, 3),
                       logit_rel_err=round(err / scale, 6), clear_margin_fraction=round(float(clear.mean()), 5),
                       label_agreement_clear_margin=round(float((hip[m][clear] == ref[m][clear]).mean()), 6))

@@ -120,7 +120,7 @@ def _sync_worker(rank, size, port, out):
     from modular_semantic_segmentation_amd import parallel
     # every rank draws its own initialisers (seed=None in the models); rank 0 alone has optimizer slots (a resumed run)
     tr = _StubTrainer(seed=10 + rank, stepped=(rank == 0))
-    parallel.sync_trainer_from_rank0(tr)
+    synced = parallel.sync_trainer_from_rank0(tr)
     fresh = _StubTrainer(seed=20 + rank, stepped=False)
     parallel.sync_trainer_from_rank0(fresh)
     stop = parallel.agree_any(rank == 1, 'cpu')              # only rank 1 crossed abort_at_iou
@@ -133,7 +133,7 @@ def _sync_worker(rank, size, port, out):
         unequal = True
     np.savez(out % rank, param=tr.param.numpy(), mm=tr.moving['conv1_1'][0].numpy(), mv=tr.moving['conv1_1'][1].numpy(),
              m=tr.state['m'].numpy(), v=tr.state['v'].numpy(), t=tr.t, repacked=tr.repacked,
-             fresh=fresh.param.numpy(), fresh_state=len(fresh.state), stop=stop, go_on=go_on, unequal=unequal)
+             fresh=fresh.param.numpy(), fresh_state=len(fresh.state), synced=synced, stop=stop, go_on=go_on, unequal=unequal)
     dist.destroy_process_group()
 
 
@@ -151,3 +151,21 @@ def test_replicas_start_from_rank0_parameters(tmp_path):
     assert int(r0['fresh_state']) == int(r1['fresh_state']) == 0
     assert bool(r0['stop']) and bool(r1['stop']) and not bool(r0['go_on']) and not bool(r1['go_on'])
     assert bool(r0['unequal']) and bool(r1['unequal'])
+    # a broadcast is reported, and the models mark their variable dict / folded engine stale after one
+    assert bool(r0['synced']) and bool(r1['synced'])
+
+
+def test_rank0_sync_marks_model_stale():
+    from modular_semantic_segmentation_amd import parallel
+    from modular_semantic_segmentation_amd.adapnet import Adapnet
+    from modular_semantic_segmentation_amd.fusion_fcn import FusionFCN
+    from modular_semantic_segmentation_amd.simple_fcn import SimpleFCN
+    assert parallel.sync_trainer_from_rank0(_StubTrainer(seed=1, stepped=False)) is False      # one process: nothing to do
+    for cls in (SimpleFCN, Adapnet, FusionFCN):
+        class Probe(object):
+            _dirty = False
+        p = Probe()
+        cls._after_rank0_sync(p, False)
+        assert p._dirty is False
+        cls._after_rank0_sync(p, True)
+        assert p._dirty is True

@@ -553,5 +553,8 @@ def test_mc_dropout_sites_of_encoder_and_decoder(gpu):
     assert 'pool4_drop' not in only4 and torch.equal(only4['fused'].interior().float(), plain['fused'])
     out = fcn(x, 'rgb', U, C, variables=w, dropout_rate=0.3, dropout_layers=['features'])
     assert 'features_drop' in out and out['score'].shape == (1, 64, 96, C)
+    # the reference's layer dict keeps 'fused' undropped: the decoder drops its input internally (simple_fcn.py:124-126)
+    assert torch.equal(out['fused'].interior().float(), plain['fused'])
+    assert not torch.equal(out['features_drop'].interior().float(), plain['fused'])
     again = encoder(x, 'rgb', U, variables=w, num_classes=C)                                   # dropout is off again
     assert torch.equal(again['fused'].interior().float(), plain['fused'])

@@ -1,7 +1,8 @@
 """north_star's accuracy clause on TRAINED weights: the HIP bf16 path and the fp32 oracle (the restated reference
 graph) segment held-out 768x384 RGB-D images with the same experts; mean IoU (base_model.py:315-329) of every model
 -- RGB expert, depth expert, Bayes fusion, Dirichlet fusion -- must agree within 0.1 percentage points, labels must
-be identical wherever the fp32 top-2 logit margin exceeds twice the measured logit error, and the logits must be
+be identical wherever the fp32 top-2 logit margin exceeds twice the STATED logit tolerance (a fixed mask: 8 % of the
+logit scale), and the logits must be
 within 4 % of the logit scale at the worst of ~2e8 values, 0.3 % on average (the stated fp tolerance of the bf16 path at 13
 conv layers).
 
@@ -37,7 +38,7 @@ def test_miou_of_hip_path_matches_fp32_oracle_on_trained_experts():
         assert acc[m]['logit_rel_err'] < 4e-2, (m, acc[m])
         assert acc[m]['logit_mean_abs_err_rel'] < 3e-3, (m, acc[m])
         assert acc[m]['label_agreement_clear_margin'] == 1.0, (m, acc[m])
-        assert acc[m]['clear_margin_fraction'] > 0.6, (m, acc[m])       # (a property of the trained net, not of the parity)
+        assert acc[m]['clear_margin_fraction'] > 0.05, (m, acc[m])      # (the mask is not empty; its size is a property of the net)
     for m in ('rgb', 'depth', 'bayes', 'dirichlet'):
         assert abs(acc[m]['delta_miou_pp']) <= 0.1, (m, acc[m])
         assert acc[m]['label_agreement'] > 0.995, (m, acc[m])
