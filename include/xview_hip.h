@@ -176,6 +176,20 @@ int xv_subsample2_bwd(const xv_act* dy, const xv_act* dx, void* stream);
 int xv_gather_conv7s2_bwd(const xv_act* dz, const xv_act* dx, void* stream);
 int xv_im2col_dilated_pair_bwd(const xv_act* dz, int dilation1, int dilation2, const xv_act* dx, void* stream);
 int xv_add(const xv_act* a, const xv_act* b, const xv_act* y, void* stream);
+/* Phase shuffles of AdapNet's two TRAINABLE transposed convs (adapnet.py:155-163 calls custom_layers.deconv2d:71-121
+ * without trainable=False): a k = 2*stride conv2d_transpose is one 3x3 conv onto stride*stride*C phase channels at the
+ * input resolution (xv_conv2d_fwd on the kernel custom_layers.dense_deconv_as_conv3x3 arranges) + a depth-to-space
+ * shuffle; its filter / data gradients are xv_conv2d_bwd_filter / xv_conv2d_bwd_data of the space-to-depth shuffle of
+ * the upstream gradient.  Phase channel (py*stride + px)*C + c <-> output pixel (stride*qy + py, stride*qx + px).
+ *   xv_space_to_depth        g [N,s*H,s*W,C] -> out [N,H,W,s*s*C]                         (C % 8 == 0)
+ *   xv_space_to_depth_dense  the same from a dense float32 [N,s*H,s*W,num_classes] gradient; out->c = s*s*Cp with
+ *                            Cp % 8 == 0, Cp >= num_classes, the padding channels written as zeros
+ *   xv_depth_to_space_dense  phase map z [N,H,W,s*s*Cp] -> dense float32 [N,s*H,s*W,num_classes], optional per-class
+ *                            scale / shift (the inference batch norm of second_deconvolution_upconv)               */
+int xv_space_to_depth(const xv_act* g, int stride, const xv_act* out, void* stream);
+int xv_space_to_depth_dense(const float* g, int num_classes, int stride, const xv_act* out, void* stream);
+int xv_depth_to_space_dense(const xv_act* z, int stride, int num_classes, const float* scale, const float* shift,
+                            float* out, void* stream);
 
 /* Decoder head: upscore = relu(bilinear_x8(fused)) (deconv2d k=16 s=8, simple_fcn.py:129-130),
  * score = conv1x1(upscore, Ws) + bs (no activation, simple_fcn.py:131-133), prob = softmax(score),

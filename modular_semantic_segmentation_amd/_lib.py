@@ -56,6 +56,9 @@ SIGNATURES = {
     'xv_gather_conv7s2_bwd': (_i, [_actp, _actp, _vp]),
     'xv_im2col_dilated_pair_bwd': (_i, [_actp, _i, _i, _actp, _vp]),
     'xv_add': (_i, [_actp, _actp, _actp, _vp]),
+    'xv_space_to_depth': (_i, [_actp, _i, _actp, _vp]),
+    'xv_space_to_depth_dense': (_i, [_vp, _i, _i, _actp, _vp]),
+    'xv_depth_to_space_dense': (_i, [_actp, _i, _i, _vp, _vp, _vp, _vp]),
     'xv_decoder_head_workspace_bytes': (ctypes.c_size_t, [_i, _i, _i, _i]),
     'xv_decoder_head_fwd': (_i, [_actp, _vp, _vp, _i, _vp, _vp, _vp, _vp, ctypes.c_size_t, _vp]),
     'xv_decoder_head_affine_fwd': (_i, [_actp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp]),

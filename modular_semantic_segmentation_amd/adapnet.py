@@ -8,17 +8,22 @@ gathers (csrc/resnet_ops.hip) that express the rest through them:
   * 1x1 stride 2 (blocks 4, 8)   -> xv_subsample2 + 1x1 conv;
   * block_b's two atrous 3x3     -> xv_im2col_dilated_pair + ONE 1x1 conv whose output is already their concat;
   * stage_3 + shortcut + relu    -> xv_conv2d_fwd_residual (the outer relu acts on a sum of two relu outputs);
-  * the two constant bilinear deconvs (kernel [k,k,filters,in], non-zero only at [.,.,i,i]) -> channel slices:
-    `first_deconvolution_conv` computes only the num_units channels the x2 deconv reads, and the x8 deconv + batch norm
-    + softmax + argmax is the FCN decoder-head kernel with a diagonal "score conv" holding the batch-norm scale.
-Training: adapnet_trainer.AdapnetTrainer (every batch norm in training mode, the gathers' transposes).
+  * the two deconvs (kernel [k,k,filters,in], custom_layers.py:71-121).  The reference leaves them TRAINABLE
+    (adapnet.py:155-163 omits trainable=False), so a kernel is either still the bilinear constant it is initialised to
+    -- non-zero only at [.,.,i,i], evaluated as channel slices: `first_deconvolution_conv` computes only the num_units
+    channels the x2 deconv reads, and the x8 deconv + batch norm + softmax + argmax is the FCN decoder-head kernel with
+    a diagonal "score conv" holding the batch-norm scale -- or dense (any trained checkpoint), evaluated as ONE 3x3 MFMA
+    conv onto stride^2 phase channels at the input resolution + a depth-to-space shuffle (custom_layers.
+    dense_deconv_as_conv3x3; xv_deconv_dense_fwd / xv_depth_to_space_dense).
+Training: adapnet_trainer.AdapnetTrainer (every batch norm in training mode, the gathers' transposes, both deconv
+kernels trained as the reference trains them).
 """
 import numpy as np
 import torch
 
 from . import ops
 from .base_model import BaseModel
-from .custom_layers import bilinear_filter
+from .custom_layers import bilinear_filter, dense_deconv_as_conv3x3
 from .fcn import BN_EPS
 
 # (scope, kind, arguments): a = (intermediate, filters, stride, shortcut_conv),
@@ -155,20 +160,11 @@ class AdapnetEngine(object):
                 raise KeyError('missing variable %s' % need)
             if tuple(v[need].shape) != tuple(shape):
                 raise ValueError('variable %s has shape %s, expected %s' % (need, v[need].shape, shape))
-        for scope in ('first_deconvolution_upconv', 'second_deconvolution_upconv'):
-            k = v['%s/%s/kernel' % (p, scope)]
-            if not np.allclose(k, rect_bilinear_filter(k.shape), atol=1e-6):
-                # KNOWN DEVIATION: the reference builds AdapNet's two deconvs with
-                # custom_layers.deconv2d's default trainable=True (adapnet.py:156-163), so a checkpoint it trained
-                # holds dense kernels after the first optimizer step.  This engine evaluates them as the depthwise
-                # bilinear constant they are initialised to (and AdapnetTrainer keeps them constant); the dense
-                # transposed-conv path (xv_deconv_dense_fwd) is wired into the FCN expert only.
-                raise NotImplementedError(
-                    '%s/%s/kernel differs from the bilinear constant it is initialised to (custom_layers.py:8-25): it was '
-                    'trained (the reference leaves AdapNet\'s deconvs trainable, adapnet.py:156-163).  This build keeps '
-                    'them constant; to import the other variables anyway, overwrite this kernel with '
-                    'adapnet.rect_bilinear_filter(kernel.shape) in the npz (accuracy will differ from the reference).'
-                    % (p, scope))
+        # which of the two deconv kernels is still the bilinear constant (fast depthwise forms) and which is dense
+        self.dense = {}
+        dense_scopes = [scope for scope in ('first_deconvolution_upconv', 'second_deconvolution_upconv')
+                        if not np.allclose(v['%s/%s/kernel' % (p, scope)],
+                                           rect_bilinear_filter(v['%s/%s/kernel' % (p, scope)].shape), atol=1e-6)]
 
         def up(a):
             return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dev)
@@ -207,15 +203,35 @@ class AdapnetEngine(object):
             return ops.pack_conv_weights(up(kp)), up(bp)
 
         self.w['shortcut'], self.b['shortcut'] = padded_units(*folded('shortcut'))
-        # the x2 deconv reads only channels [0, num_units) of first_deconvolution_conv: compute just those
-        self.w['first_deconvolution_conv'], self.b['first_deconvolution_conv'] = \
-            padded_units(*folded('first_deconvolution_conv'))
         s, t = affine('first_deconvolution_upconv')
         sp, tp = np.ones(self.Up, np.float32), np.zeros(self.Up, np.float32)
         sp[:self.U], tp[:self.U] = s, t
         self.deconv1_affine = (up(sp), up(tp))
-        # score = bilinear_x8(merge[..., :C]) * s + t: a diagonal score "conv" in front of the interpolation
+        if 'first_deconvolution_upconv' in dense_scopes:
+            # trained x2 deconv [4,4,U,Cin]: every channel of first_deconvolution_conv feeds it
+            k, b = folded('first_deconvolution_conv')
+            self.w['first_deconvolution_conv'], self.b['first_deconvolution_conv'] = ops.pack_conv_weights(up(k)), up(b)
+            w1 = v['%s/first_deconvolution_upconv/kernel' % p]
+            kp = np.zeros((4, 4, self.Up, w1.shape[3]), np.float32)
+            kp[:, :, :self.U] = w1
+            self.dense['first'] = (ops.pack_conv_weights(up(dense_deconv_as_conv3x3(kp, 2))),
+                                   torch.zeros(4 * self.Up, dtype=torch.float32, device=dev), int(w1.shape[3]))
+        else:
+            # bilinear constant: the x2 deconv reads only channels [0, num_units) of first_deconvolution_conv
+            self.w['first_deconvolution_conv'], self.b['first_deconvolution_conv'] = \
+                padded_units(*folded('first_deconvolution_conv'))
         s, t = affine('second_deconvolution_upconv')
+        if 'second_deconvolution_upconv' in dense_scopes:
+            # trained x8 deconv [16,16,C,U]: 3x3 conv U -> 64 phases x Cp classes at 1/8 resolution, then the shuffle
+            # (with the batch norm's scale / shift) straight into the dense float32 class scores
+            w2 = v['%s/second_deconvolution_upconv/kernel' % p]
+            self.Cp = (self.C + 7) // 8 * 8
+            kp = np.zeros((16, 16, self.Cp, self.Up), np.float32)
+            kp[:, :, :self.C, :self.U] = w2
+            self.dense['second'] = (ops.pack_conv_weights(up(dense_deconv_as_conv3x3(kp, 8))),
+                                    torch.zeros(64 * self.Cp, dtype=torch.float32, device=dev), up(s), up(t))
+        # bilinear constant: score = bilinear_x8(merge[..., :C]) * s + t, a diagonal score "conv" in front of the
+        # interpolation (kept in both cases: the trainer reads its shapes)
         ws = np.zeros((self.Up, self.C), np.float32)
         ws[np.arange(self.C), np.arange(self.C)] = s
         self.w['score'], self.b['score'] = up(ws), up(t)
@@ -270,6 +286,13 @@ class AdapnetEngine(object):
             L['block_%d' % index] = cur
             if name == 'block_layer_7':
                 L['shortcut'] = self._conv('shortcut', cur, 1, self.Up, relu=False)
+        if 'first' in self.dense:
+            wk, zb, width = self.dense['first']
+            d = self._conv('first_deconvolution_conv', cur, 1, width)
+            L['merge'], self._arena['dd_ws1'] = ops.deconv_dense_fwd(
+                d, wk, zb, 2, self.Up, y=self._act('merge', d.n, 2 * d.h, 2 * d.w, self.Up), scale=self.deconv1_affine[0],
+                shift=self.deconv1_affine[1], residual=L['shortcut'], relu=False, workspace=self._arena.get('dd_ws1'))
+            return L
         d = self._conv('first_deconvolution_conv', cur, 1, self.Up)
         L['merge'] = ops.upsample2x_relu_add(d, residual=L['shortcut'], scale=self.deconv1_affine[0],
                                              shift=self.deconv1_affine[1], relu=False,
@@ -281,6 +304,24 @@ class AdapnetEngine(object):
         'label' == 'classification' (int64 [N,H,W])."""
         L = self.trunk(x)
         m = L['merge']
+        if 'second' in self.dense:
+            wk, zb, sc, sh = self.dense['second']
+            zph = self._act('score_phases', m.n, m.h, m.w, 64 * self.Cp)
+            ops.conv2d_fwd(m, wk, zb, 3, relu=False, y=zph)
+            skey = ('dense_score', m.n, m.h, m.w)
+            if skey not in self._arena:
+                self._arena[skey] = torch.empty((m.n, 8 * m.h, 8 * m.w, self.C), dtype=torch.float32, device=self.device)
+            score = ops.depth_to_space_dense(zph, 8, self.C, self._arena[skey], scale=sc, shift=sh)
+            prob, label = ops.softmax_argmax(score, want_prob='prob' in want,
+                                             want_label=('label' in want or 'classification' in want))
+            out = {'layers': L}
+            if 'score' in want:
+                out['score'] = score
+            if prob is not None:
+                out['prob'] = prob
+            if label is not None:
+                out['label'] = out['classification'] = label
+            return out
         key = ('head_ws', m.n, m.h, m.w)
         ws = self._arena.get(key)
         if ws is None:

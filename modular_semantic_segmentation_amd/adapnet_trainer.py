@@ -10,19 +10,22 @@ through the same gathers as the inference engine (adapnet.AdapnetEngine); their 
 kernel scattered into 3x3 x 9 groups, the atrous pair stacked block-wise), rebuilt from the master weights every step,
 and their filter gradients are mapped back through the same index maps.
 
-KNOWN DEVIATION from the reference's training trajectory: adapnet.py:156-163 calls custom_layers.deconv2d without
-trainable=False, so the reference TRAINS the two deconv kernels (they start as the bilinear constant and become dense
-after the first optimizer step).  This trainer keeps them constant.  Consequences: `first_deconvolution_conv` is trained
-on the num_units output channels the x2 deconv reads -- the remaining 2048 - U channels have exactly zero gradient in the
-reference only at step 0 (while the deconv kernel is still zero there) and here at every step, so they keep their
-imported values; and a checkpoint trained by the reference cannot be imported unchanged (AdapnetEngine.load explains).  The loss is the reference's: the mean cross-entropy over the labelled pixels divided once
-more by their number (adapnet.py:202-203).
+The two deconvs are TRAINED, as in the reference: adapnet.py:155-163 calls custom_layers.deconv2d (:71-121) without
+trainable=False, so `first_deconvolution_upconv/kernel` [4,4,U,2048] and `second_deconvolution_upconv/kernel` [16,16,C,U]
+start as the bilinear constant and are dense after the first optimizer step.  Each runs as ONE 3x3 MFMA conv onto
+stride^2 phase channels at its input resolution (the derived kernel custom_layers.dense_deconv_as_conv3x3 arranges,
+rebuilt from the master kernel every step like the other derived kernels) + a depth-to-space shuffle; its filter
+gradient is the 3x3 conv's filter gradient against the space-to-depth shuffle of the upstream gradient, gathered back
+through the inverse index map (every kernel element sits at exactly one derived position), its data gradient the 3x3
+conv's data gradient.  `first_deconvolution_conv` is therefore trained on all of its output channels.  The loss is the
+reference's: the mean cross-entropy over the labelled pixels divided once more by their number (adapnet.py:202-203).
 """
 import numpy as np
 import torch
 
 from . import ops
 from .adapnet import _conv_scopes, conv7s2_as_3x3
+from .custom_layers import dense_deconv_as_conv3x3
 from .trainer import FcnTrainer
 
 
@@ -41,6 +44,24 @@ def conv7s2_index_maps(cin, cout):
     return src, inv
 
 
+def dense_deconv_index_maps(shape, stride):
+    """The same pair of maps between a (channel-padded) transposed-conv kernel [k,k,F,Cin] and the derived 3x3 kernel
+    [3,3,Cin,stride^2*F] of custom_layers.dense_deconv_as_conv3x3: derived = w.ravel()[src] (masked where src < 0), and
+    dw.ravel() = dderived.ravel()[inv]."""
+    n = int(np.prod(shape))
+    assert n < 2 ** 24
+    probe = np.arange(1, n + 1, dtype=np.float32).reshape(shape)
+    src = dense_deconv_as_conv3x3(probe, stride).astype(np.int64).ravel() - 1
+    inv = np.empty(n, np.int64)
+    pos = np.nonzero(src >= 0)[0]
+    assert len(pos) == n                                  # k = 2 * stride: every kernel element is used exactly once
+    inv[src[pos]] = pos
+    return src, inv
+
+
+DECONVS = (('first_deconvolution_upconv', 2), ('second_deconvolution_upconv', 8))
+
+
 class AdapnetTrainer(object):
     def __init__(self, engine, trainer='adam', learning_rate=1e-4):
         if trainer not in ('adam', 'rmsprop', 'adagrad'):
@@ -51,9 +72,15 @@ class AdapnetTrainer(object):
         self.units = {}
         self.blocks = e.blocks
         for scope, k, cin, cout, has_bias in _conv_scopes(e.cin, e.U, self.blocks):
-            if scope in ('shortcut', 'first_deconvolution_conv'):
+            if scope == 'shortcut':
                 cout = e.Up                                   # U padded to 64 lanes (zero kernels, gamma 1, beta 0)
             self.units[scope] = (k, cin, cout, has_bias)
+        self.width = self.units['first_deconvolution_conv'][2]         # 2048 in the reference graph
+        self.Cp = (e.C + 7) // 8 * 8
+        # the two trainable transposed-conv kernels [k,k,filters,in], channel-padded like the maps they touch
+        self.deconv_shape = {'first_deconvolution_upconv': (4, 4, e.Up, self.width),
+                             'second_deconvolution_upconv': (16, 16, self.Cp, e.Up)}
+        self.deconv_real = {'first_deconvolution_upconv': (e.U, self.width), 'second_deconvolution_upconv': (e.C, e.U)}
         self.bn_channels = {scope: u[2] for scope, u in self.units.items()}
         self.bn_channels.update(first_deconvolution_upconv=e.Up, second_deconvolution_upconv=e.C)
         self.offsets, total = {}, 0
@@ -64,6 +91,9 @@ class AdapnetTrainer(object):
                 self.offsets[(scope, kind)] = (total, n, shape)
                 total += (n + 63) // 64 * 64
         for scope in ('first_deconvolution_upconv', 'second_deconvolution_upconv'):
+            n = int(np.prod(self.deconv_shape[scope]))
+            self.offsets[(scope, 'kernel')] = (total, n, self.deconv_shape[scope])
+            total += (n + 63) // 64 * 64
             for kind in ('gamma', 'beta'):
                 n = self.bn_channels[scope]
                 self.offsets[(scope, kind)] = (total, n, (n,))
@@ -79,10 +109,12 @@ class AdapnetTrainer(object):
         self.loss = torch.zeros(1, dtype=torch.float64, device=dev)
         self.grad_scale = 1.0
         self.w, self.wd, self._a, self._scratch = {}, {}, {}, {}
-        # x8 deconv kernel [16,16,C,U] = channel i -> class i: a selector "score conv" in front of the dense batch norm
-        sel = torch.zeros(e.Up, e.C, dtype=torch.float32, device=dev)
-        sel[torch.arange(e.C), torch.arange(e.C)] = 1.0
-        self.selector = sel
+        self.dmap = {}
+        for scope, stride in DECONVS:
+            src, inv = dense_deconv_index_maps(self.deconv_shape[scope], stride)
+            idx = torch.from_numpy(src).to(dev)
+            k, _, f, cin = self.deconv_shape[scope]
+            self.dmap[scope] = (idx.clamp(min=0), (idx >= 0), torch.from_numpy(inv).to(dev), (3, 3, cin, stride * stride * f))
         src, inv = conv7s2_index_maps(64, 64)
         idx = torch.from_numpy(src).to(dev)
         self.map7 = (idx.clamp(min=0), (idx >= 0))
@@ -96,7 +128,7 @@ class AdapnetTrainer(object):
 
     def _real(self, scope):
         e = self.e
-        if scope in ('shortcut', 'first_deconvolution_conv', 'first_deconvolution_upconv'):
+        if scope in ('shortcut', 'first_deconvolution_upconv'):
             return e.U
         return self.bn_channels[scope]
 
@@ -109,6 +141,10 @@ class AdapnetTrainer(object):
             if kind == 'gamma':
                 dst.fill_(1.0)
             src = torch.from_numpy(np.asarray(variables['%s/%s/%s' % (p, scope, kind)], np.float32))
+            if kind == 'kernel' and scope in self.deconv_shape:
+                f, cin = self.deconv_real[scope]               # [k,k,filters,in]: both channel axes are padded
+                dst[:, :, :f, :cin].copy_(src)
+                continue
             dst[..., :real].copy_(src[..., :real])
         for scope, (mm, mv) in self.moving.items():
             real = self._real(scope)
@@ -123,13 +159,11 @@ class AdapnetTrainer(object):
         for (scope, kind), _ in self.offsets.items():
             real = self._real(scope)
             name = '%s/%s/%s' % (p, scope, kind)
-            t = (self.view(buf, scope, kind)[..., :real] * scale).cpu().numpy()
-            if scope == 'first_deconvolution_conv':
-                # only the first U output channels are trained; the others keep the values they had
-                full = np.array(variables[name], np.float32, copy=True) if name in variables else None
-                if full is not None and full.shape[-1] != real:
-                    full[..., :real] = t
-                    t = full
+            if kind == 'kernel' and scope in self.deconv_shape:
+                f, cin = self.deconv_real[scope]
+                t = (self.view(buf, scope, kind)[:, :, :f, :cin] * scale).cpu().numpy()
+            else:
+                t = (self.view(buf, scope, kind)[..., :real] * scale).cpu().numpy()
             variables[name] = np.ascontiguousarray(t)
         return variables
 
@@ -148,17 +182,8 @@ class AdapnetTrainer(object):
                 variables[name] = t
 
     def grads_as_variables(self):
-        """Gradient of the last step in the reference schema, including the 1/count of the loss (tests); the untrained
-        channels of first_deconvolution_conv are reported as the zeros they are."""
-        out = self._export(self.grad, {}, scale=self.grad_scale)
-        p = self.e.prefix
-        for kind in ('kernel', 'bias', 'gamma', 'beta'):
-            name = '%s/first_deconvolution_conv/%s' % (p, kind)
-            t = out[name]
-            full = np.zeros(t.shape[:-1] + (self.units['first_deconvolution_conv'][1],), np.float32)
-            full[..., :t.shape[-1]] = t
-            out[name] = full
-        return out
+        """Gradient of the last step in the reference schema, including the 1/count of the loss (tests)."""
+        return self._export(self.grad, {}, scale=self.grad_scale)
 
     def _kernel_for(self, scope):
         """The kernel the MFMA convs consume for `scope` (derived for the 7x7 stride-2 conv)."""
@@ -166,6 +191,9 @@ class AdapnetTrainer(object):
         if scope == 'block_0_2':
             src, mask = self.map7
             return (kv.reshape(-1)[src] * mask).view(3, 3, 9 * 64, 64)
+        if scope in self.dmap:
+            src, mask, _, shape = self.dmap[scope]
+            return (kv.reshape(-1)[src] * mask).view(*shape)
         return kv
 
     def _pair_kernel(self, name):
@@ -188,7 +216,7 @@ class AdapnetTrainer(object):
         ops.pack_conv_weights_pair(kernel, self.w[key], self.wd[key])
 
     def repack(self):
-        for scope in self.units:
+        for scope in list(self.units) + [d[0] for d in DECONVS]:
             if scope == 'block_0_1' or '/stage_2_' in scope:
                 continue
             self._pack(scope, self._kernel_for(scope))
@@ -372,31 +400,49 @@ class AdapnetTrainer(object):
             if name == 'block_layer_7':
                 shortcut = conv_bn('shortcut', curname, cur, 1, False, 'shortcut')
         d = conv_bn('first_deconvolution_conv', curname, cur, 1, True, 'deconv_in')
-        z_up = ops.upsample_raw_fwd(d, 2, self._act('z_deconv_1', d.n, 2 * d.h, 2 * d.w, e.Up))
-        y_up, bwd_bn_up = self._bn_unit('first_deconvolution_upconv', z_up, False, 'deconv_1')
+        fu, su = 'first_deconvolution_upconv', 'second_deconvolution_upconv'
+
+        def deconv_grads(scope, stride, xact, dph, xname, dxtag):
+            """filter gradient of the dense deconv (through the inverse index map) and its data gradient into `xname`"""
+            _, _, inv, kshape = self.dmap[scope]
+            dk = self._scratch.get(('dk', scope))
+            if dk is None:
+                dk = self._scratch[('dk', scope)] = torch.empty(kshape, dtype=torch.float32, device=e.device)
+            dk.zero_()
+            ops.conv2d_bwd_filter(xact, dph, dk, None, 3, workspace=wws)
+            G(scope, 'kernel').view(-1).add_(dk.view(-1)[inv])
+            self._accum(xname, ops.conv2d_bwd_data(dph, self.wd[scope], self.zeros[:xact.c], self._like(dxtag, xact), 3))
+
+        # x2 transposed conv [4,4,U,width] as a 3x3 conv onto 4 phases x U channels + depth-to-space
+        z_up, self._a['dd_ws1'] = ops.deconv_dense_fwd(d, self.w[fu], self.zeros[:4 * e.Up], 2, e.Up,
+                                                       y=self._act('z_deconv_1', d.n, 2 * d.h, 2 * d.w, e.Up), relu=False,
+                                                       workspace=self._a.get('dd_ws1'))
+        wneed[0] = max(wneed[0], ops.conv2d_bwd_filter_workspace_bytes(d, 4 * e.Up, 3))
+        y_up, bwd_bn_up = self._bn_unit(fu, z_up, False, 'deconv_1')
 
         def bwd_up2():
             dz = bwd_bn_up(self._grads.pop('deconv_1')[0])
-            self._accum('deconv_in', ops.upsample_raw_bwd(dz, 2, self._like('d_deconv_in', d)))
+            dph = ops.space_to_depth(dz, 2, self._act('dph_deconv_1', d.n, d.h, d.w, 4 * e.Up))
+            deconv_grads(fu, 2, d, dph, 'deconv_in', 'd_deconv_in')
         tape.append(bwd_up2)
         merge = residual('deconv_1', y_up, 'shortcut', shortcut, 'merge')
-        # ---- head: x8 deconv of the first C channels, batch norm, softmax cross-entropy -----------------------------
-        z8 = ops.upsample_raw_fwd(merge, 8, self._act('z_score', n, h, w, e.Up))
-        raw = ops.score_dense_fwd(z8, self.selector, self.zeros[:e.C], e.C, self._dense('score_raw', (n, h, w, e.C)))
-        s2d = 'second_deconvolution_upconv'
-        mm, mv = self.moving[s2d]
-        logits = ops.bn_dense_forward(raw, P(s2d, 'gamma'), P(s2d, 'beta'), mm, mv, self.bn[s2d],
+        # ---- head: x8 transposed conv [16,16,C,U] (3x3 conv onto 64 phases x Cp classes at 1/8 resolution, shuffled
+        # straight into dense float32 scores), batch norm, softmax cross-entropy ---------------------------------------
+        zph = ops.conv2d_fwd(merge, self.w[su], self.zeros[:64 * self.Cp], 3, relu=False,
+                             y=self._act('zph_score', merge.n, merge.h, merge.w, 64 * self.Cp))[0]
+        wneed[0] = max(wneed[0], ops.conv2d_bwd_filter_workspace_bytes(merge, 64 * self.Cp, 3))
+        raw = ops.depth_to_space_dense(zph, 8, e.C, self._dense('score_raw', (n, h, w, e.C)))
+        mm, mv = self.moving[su]
+        logits = ops.bn_dense_forward(raw, P(su, 'gamma'), P(su, 'beta'), mm, mv, self.bn[su],
                                       self._dense('logits', (n, h, w, e.C)), sync=self._sync)
         dlogits = ops.softmax_ce_dense(logits, labels, self.count, e.C, self.loss, self._dense('dlogits', (n, h, w, e.C)))
         # ---- backward ------------------------------------------------------------------------------------------------
         if wws is None or wws.numel() * 4 < wneed[0]:
             wws = self._a[wkey] = torch.empty(max(wneed[0] // 4, 1), dtype=torch.float32, device=e.device)
-        dscore = ops.bn_dense_backward(dlogits, raw, P(s2d, 'gamma'), self.bn[s2d], G(s2d, 'gamma'), G(s2d, 'beta'),
+        dscore = ops.bn_dense_backward(dlogits, raw, P(su, 'gamma'), self.bn[su], G(su, 'gamma'), G(su, 'beta'),
                                        self._dense('dscore', (n, h, w, e.C)), sync=self._sync)
-        dsel = self._scratch.setdefault('dsel', torch.zeros_like(self.selector))
-        dbias = self._scratch.setdefault('dselb', torch.zeros(e.C, dtype=torch.float32, device=e.device))
-        du = ops.score_dense_bwd(z8, dscore, self.selector, e.C, dsel, dbias, self._act('d_z_score', n, h, w, e.Up))
-        self._accum('merge', ops.upsample_raw_bwd(du, 8, self._like('d_merge', merge)))
+        dph8 = ops.space_to_depth_dense(dscore, 8, self._act('dph_score', merge.n, merge.h, merge.w, 64 * self.Cp))
+        deconv_grads(su, 8, merge, dph8, 'merge', 'd_merge')
         for bwd in reversed(tape):
             bwd()
         if reducer is not None:

@@ -180,6 +180,87 @@ __global__ __launch_bounds__(256) void add_kernel(const u32x4* __restrict__ a, c
   }
 }
 
+// ---- phase shuffles of the DENSE transposed convs (AdapNet trains its two deconv kernels: adapnet.py:155-163 calls
+// custom_layers.deconv2d:71-121 without trainable=False).  A k = 2s transposed conv is one 3x3 conv onto s*s*C "phase"
+// channels at the input resolution (custom_layers.dense_deconv_as_conv3x3) followed by a depth-to-space shuffle; its
+// gradients are the 3x3 conv's filter / data gradients of the space-to-depth shuffle of the upstream gradient.
+// Phase channel layout: (py*s + px)*C + c  <->  output pixel (s*qy + py, s*qx + px), channel c.
+
+// g [N][s*Hq][s*Wq][C] (padded NHWC bf16) -> out [N][Hq][Wq][s*s*C]: 16 bytes per thread
+__global__ __launch_bounds__(256) void space_to_depth_kernel(const u32x4* __restrict__ g, u32x4* __restrict__ out, int N,
+                                                            int Hq, int Wq, int c8, int S) {
+  const int Ho = Hq * S, Wo = Wq * S;
+  const int pc8 = S * S * c8;
+  const int64_t total = (int64_t)N * Hq * Wq * pc8;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    const int pc = (int)(idx % pc8);
+    int64_t r = idx / pc8;
+    const int qx = (int)(r % Wq);
+    r /= Wq;
+    const int qy = (int)(r % Hq);
+    const int n = (int)(r / Hq);
+    const int ph = pc / c8, cg = pc - ph * c8;
+    const int py = ph / S, px = ph - py * S;
+    out[(((int64_t)n * (Hq + 2) + qy + 1) * (Wq + 2) + qx + 1) * pc8 + pc] =
+        g[(((int64_t)n * (Ho + 2) + qy * S + py + 1) * (Wo + 2) + qx * S + px + 1) * c8 + cg];
+  }
+}
+
+// the same from a dense float32 [N][s*Hq][s*Wq][C] gradient (the class scores): channels C .. Cp-1 of every phase are zero
+__global__ __launch_bounds__(256) void space_to_depth_dense_kernel(const float* __restrict__ g, u32x4* __restrict__ out,
+                                                                  int N, int Hq, int Wq, int C, int c8, int S) {
+  const int Ho = Hq * S, Wo = Wq * S;
+  const int pc8 = S * S * c8;
+  const int64_t total = (int64_t)N * Hq * Wq * pc8;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    const int pc = (int)(idx % pc8);
+    int64_t r = idx / pc8;
+    const int qx = (int)(r % Wq);
+    r /= Wq;
+    const int qy = (int)(r % Hq);
+    const int n = (int)(r / Hq);
+    const int ph = pc / c8, cg = pc - ph * c8;
+    const int py = ph / S, px = ph - py * S;
+    const float* src = g + (((int64_t)n * Ho + qy * S + py) * Wo + qx * S + px) * C;
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = cg * 8 + j < C ? src[cg * 8 + j] : 0.f;
+    out[(((int64_t)n * (Hq + 2) + qy + 1) * (Wq + 2) + qx + 1) * pc8 + pc] =
+        u32x4{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
+  }
+}
+
+// phase map z [N][Hq][Wq][s*s*Cp] -> dense float32 [N][s*Hq][s*Wq][C] (the class scores), optional per-class affine
+// (inference batch norm of the x8 deconv): one thread per output pixel
+__global__ __launch_bounds__(256) void depth_to_space_dense_kernel(const __bf16* __restrict__ z,
+                                                                  const float* __restrict__ scale,
+                                                                  const float* __restrict__ shift, float* __restrict__ out,
+                                                                  int N, int Hq, int Wq, int C, int Cp, int S) {
+  const int Ho = Hq * S, Wo = Wq * S;
+  const int64_t total = (int64_t)N * Ho * Wo;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    const int ox = (int)(idx % Wo);
+    int64_t r = idx / Wo;
+    const int oy = (int)(r % Ho);
+    const int n = (int)(r / Ho);
+    const int qy = oy / S, py = oy - qy * S, qx = ox / S, px = ox - qx * S;
+    const __bf16* src = z + (((int64_t)n * (Hq + 2) + qy + 1) * (Wq + 2) + qx + 1) * ((int64_t)S * S * Cp) +
+                        (int64_t)(py * S + px) * Cp;
+    float* dst = out + idx * C;
+    for (int c0 = 0; c0 < C; c0 += 8) {
+      const u32x4 a = *reinterpret_cast<const u32x4*>(src + c0);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        if (c0 + j < C) {
+          float v = (j & 1) ? __builtin_bit_cast(float, a[j >> 1] & 0xffff0000u) : bf16_bits_to_f32(a[j >> 1] & 0xffffu);
+          if (scale != nullptr) v = v * scale[c0 + j] + shift[c0 + j];
+          dst[c0 + j] = v;
+        }
+      }
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" int xv_subsample2(const xv_act* x, const xv_act* y, void* stream) {
@@ -258,5 +339,41 @@ extern "C" int xv_add(const xv_act* a, const xv_act* b, const xv_act* y, void* s
   const int64_t total = (int64_t)a->n * (a->h + 2) * (a->w + 2) * (a->c >> 3);
   hipLaunchKernelGGL(add_kernel, dim3(rn_grid(total)), dim3(256), 0, (hipStream_t)stream, (const u32x4*)a->data,
                      (const u32x4*)b->data, (u32x4*)y->data, total);
+  return xv_launch_status();
+}
+
+extern "C" int xv_space_to_depth(const xv_act* g, int stride, const xv_act* out, void* stream) {
+  XV_REQUIRE_BF16(g, out);
+  XV_CHECK_ARG(g && out && g->data && out->data);
+  XV_CHECK_SHAPE(stride >= 1 && stride <= 16 && g->n == out->n && g->h == stride * out->h && g->w == stride * out->w &&
+                 out->c == stride * stride * g->c && (g->c & 7) == 0 && out->h > 0);
+  const int64_t total = (int64_t)out->n * out->h * out->w * (out->c >> 3);
+  hipLaunchKernelGGL(space_to_depth_kernel, dim3(rn_grid(total)), dim3(256), 0, (hipStream_t)stream,
+                     (const u32x4*)g->data, (u32x4*)out->data, out->n, out->h, out->w, g->c >> 3, stride);
+  return xv_launch_status();
+}
+
+extern "C" int xv_space_to_depth_dense(const float* g, int num_classes, int stride, const xv_act* out, void* stream) {
+  XV_REQUIRE_BF16(out);
+  XV_CHECK_ARG(g && out && out->data);
+  XV_CHECK_SHAPE(stride >= 1 && stride <= 16 && num_classes >= 1 && out->c % (stride * stride) == 0 && out->h > 0);
+  const int cp = out->c / (stride * stride);
+  XV_CHECK_SHAPE((cp & 7) == 0 && cp >= num_classes);
+  const int64_t total = (int64_t)out->n * out->h * out->w * (out->c >> 3);
+  hipLaunchKernelGGL(space_to_depth_dense_kernel, dim3(rn_grid(total)), dim3(256), 0, (hipStream_t)stream, g,
+                     (u32x4*)out->data, out->n, out->h, out->w, num_classes, cp >> 3, stride);
+  return xv_launch_status();
+}
+
+extern "C" int xv_depth_to_space_dense(const xv_act* z, int stride, int num_classes, const float* scale, const float* shift,
+                                       float* out, void* stream) {
+  XV_REQUIRE_BF16(z);
+  XV_CHECK_ARG(z && z->data && out && (scale == nullptr) == (shift == nullptr));
+  XV_CHECK_SHAPE(stride >= 1 && stride <= 16 && num_classes >= 1 && z->c % (stride * stride) == 0 && z->h > 0);
+  const int cp = z->c / (stride * stride);
+  XV_CHECK_SHAPE((cp & 7) == 0 && cp >= num_classes);
+  const int64_t total = (int64_t)z->n * z->h * z->w * stride * stride;
+  hipLaunchKernelGGL(depth_to_space_dense_kernel, dim3(rn_grid(total)), dim3(256), 0, (hipStream_t)stream,
+                     (const __bf16*)z->data, scale, shift, out, z->n, z->h, z->w, num_classes, cp, stride);
   return xv_launch_status();
 }

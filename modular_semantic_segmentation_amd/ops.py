@@ -242,6 +242,34 @@ def add(a, b, y=None):
     return y
 
 
+def space_to_depth(g, stride, out=None):
+    """[N,s*H,s*W,C] Act -> [N,H,W,s*s*C] Act, phase channel (py*s + px)*C + c (gradient side of a dense deconv)."""
+    if out is None:
+        out = Act(g.n, g.h // stride, g.w // stride, stride * stride * g.c, g.t.device)
+    _lib.check(_lib.lib().xv_space_to_depth(g.xv(), int(stride), out.xv(), _stream()), 'xv_space_to_depth')
+    return out
+
+
+def space_to_depth_dense(g, stride, out):
+    """dense float32 [N,s*H,s*W,C] -> Act [N,H,W,s*s*Cp] (Cp = out.c / s^2 >= C, padding channels zero)."""
+    _need(g, torch.float32, 'g')
+    _lib.check(_lib.lib().xv_space_to_depth_dense(_ptr(g), int(g.shape[-1]), int(stride), out.xv(), _stream()),
+               'xv_space_to_depth_dense')
+    return out
+
+
+def depth_to_space_dense(z, stride, num_classes, out, scale=None, shift=None):
+    """phase map Act [N,H,W,s*s*Cp] -> dense float32 [N,s*H,s*W,C] [* scale + shift]."""
+    _need(out, torch.float32, 'out')
+    if scale is not None:
+        _need(scale, torch.float32, 'scale')
+        _need(shift, torch.float32, 'shift')
+    rc = _lib.lib().xv_depth_to_space_dense(z.xv(), int(stride), int(num_classes), _ptr(scale), _ptr(shift), _ptr(out),
+                                            _stream())
+    _lib.check(rc, 'xv_depth_to_space_dense')
+    return out
+
+
 def im2col_dilated_pair(x, d1, d2, z=None):
     """[N,H,W,18C]: the nine taps at dilation d1 then the nine at d2."""
     if z is None:

@@ -123,7 +123,14 @@ def adapnet_forward(x_nhwc, weights, prefix, policy='fp32', keep=None, blocks=No
     def deconv_bn(h, scope, stride):
         w = weights['%s/%s/kernel' % (prefix, scope)]                 # [k,k,filters,in]
         k = w.shape[0]
+        # a kernel that is still the bilinear constant is applied in fp32 (depthwise interpolation on the MI355X path);
+        # a trained (dense) one runs on the bf16 MFMA conv: kernel and conv output rounded to bf16 under policy 'bf16'
+        dense = not np.allclose(w, rect_bilinear_kernel(k, w.shape[2], w.shape[3]), atol=1e-6)
+        if policy == 'bf16' and dense:
+            w = round_bf16(w)
         y = F.conv_transpose2d(h, _t(w).permute(3, 2, 0, 1).contiguous(), stride=stride, padding=(k - stride) // 2)
+        if dense:
+            y = rnd(y)
         s, t = affine(scope)
         return y * _t(s).view(1, -1, 1, 1) + _t(t).view(1, -1, 1, 1)
 
@@ -165,8 +172,10 @@ def adapnet_loss_and_grads(x_nhwc, labels, weights, prefix, num_classes, policy=
     variance, eps 1e-3, trainable gamma / beta -- and the loss of Adapnet._build_graph (adapnet.py:196-203):
     cross_entropy (models/utils.py:43-53, already a mean over the labelled pixels) divided once more by the number
     of labelled pixels.  Returns (loss, {variable: gradient}, {bn scope: (batch mean, unbiased batch variance)}).
-    `first_deconvolution_conv` is evaluated for the first `units` output channels only (default: all 2048): the others
-    feed nothing (the x2 deconv kernel is zero there) and have exactly zero gradients.
+    The two deconv kernels are parameters too (the reference trains them).  `units` (default: all channels) restricts
+    `first_deconvolution_conv` to its first `units` output channels -- only meaningful while the x2 deconv kernel is
+    still the bilinear constant AND its own gradient is not looked at (the kernel's gradient is non-zero for every
+    input channel).
     policy 'bf16': straight-through rounding where the MI355X path stores bf16 (see fcn_oracle.fcn_loss_and_grads)."""
     from .fcn_oracle import _RoundBf16STE
     params, stats = {}, {}
@@ -198,10 +207,11 @@ def adapnet_loss_and_grads(x_nhwc, labels, weights, prefix, num_classes, policy=
         return rnd(F.relu(y) if relu else y)
 
     def deconv_bn(h, scope, stride):
-        w = _t(weights['%s/%s/kernel' % (prefix, scope)])
+        # the reference TRAINS both transposed-conv kernels (adapnet.py:155-163: deconv2d without trainable=False,
+        # custom_layers.py:71-121, use_bias=False); policy 'bf16': kernel and conv output rounded like every MFMA conv
+        w = P('%s/%s/kernel' % (prefix, scope))
         k = w.shape[0]
-        y = F.conv_transpose2d(h, w.permute(3, 2, 0, 1).contiguous(), stride=stride, padding=(k - stride) // 2)
-        return y
+        return rnd(F.conv_transpose2d(h, rnd(w).permute(3, 2, 0, 1).contiguous(), stride=stride, padding=(k - stride) // 2))
 
     h = _t(np.asarray(x_nhwc, np.float32)).permute(0, 3, 1, 2).contiguous()
     h = conv(h, 'block_0_1')

@@ -200,6 +200,59 @@ def test_adapnet_graph_matches_oracle(ops, tmp_path):
     assert len(np.unique(ref_label)) > 2
 
 
+@pytest.mark.parametrize('which', ['both', 'first', 'second'])
+def test_adapnet_with_trained_deconv_kernels_matches_oracle(ops, tmp_path, which):
+    """A checkpoint the REFERENCE trained holds DENSE deconv kernels: adapnet.py:155-163 calls custom_layers.deconv2d
+    (:71-121) without trainable=False, so `first_/second_deconvolution_upconv/kernel` leave the bilinear constant at the
+    first optimizer step.  Such an npz is imported through the model API and evaluated on the dense transposed-conv path
+    (3x3 MFMA conv onto the stride^2 output phases + depth-to-space), against the oracle's conv_transpose2d; either
+    kernel alone may be dense (the other keeps its depthwise fast path)."""
+    from modular_semantic_segmentation_amd import get_model
+    from modular_semantic_segmentation_amd.adapnet import rect_bilinear_filter
+    w, _ = _weights(tmp_path, 'rgb', 3, 1, 0.02)
+    rng = np.random.default_rng(11)
+    for scope, on in (('first_deconvolution_upconv', which in ('both', 'first')),
+                      ('second_deconvolution_upconv', which in ('both', 'second'))):
+        if on:
+            k = w['rgb/%s/kernel' % scope]
+            # "trained-looking": the bilinear constant plus a dense perturbation of a comparable size per output
+            fan = k.shape[3]
+            w['rgb/%s/kernel' % scope] = (k + rng.standard_normal(k.shape) * (0.3 / np.sqrt(fan))).astype(np.float32)
+            assert not np.allclose(w['rgb/%s/kernel' % scope], rect_bilinear_filter(k.shape))
+        for v, lo, hi in (('gamma', 0.7, 1.3), ('beta', -0.2, 0.2), ('moving_mean', -0.2, 0.2), ('moving_variance', 0.5, 1.5)):
+            shape = w['rgb/%s/%s' % (scope, v)].shape
+            w['rgb/%s/%s' % (scope, v)] = rng.uniform(lo, hi, shape).astype(np.float32)
+    path = os.path.join(str(tmp_path), 'trained_adapnet.npz')
+    np.savez(path, **w)
+    data = _inputs(2, seed=3)
+    with get_model('adapnet')(_desc(), output_dir=str(tmp_path), modality='rgb', num_units=U, batchsize=2) as net:
+        net.import_weights(path)
+        assert set(net.engine.dense) == {'both': {'first', 'second'}, 'first': {'first'}, 'second': {'second'}}[which]
+        score = net.predict(data, output_attr='score')
+        label = net.predict(data)
+        prob = net.predict(data, output_attr='prob')
+        merge = net.engine.trunk(_dev(data['rgb']))['merge'].interior().float().cpu().numpy()
+    ref = ao.adapnet_forward(data['rgb'], w, 'rgb', policy='bf16', keep=['merge', 'score'])
+    err = np.abs(merge[..., :U] - ref['merge']).max() / np.abs(ref['merge']).max()
+    assert err < 3e-2, 'merge differs by %.3g of its max' % err
+    scale = np.abs(ref['score']).max()
+    print('dense deconv (%s): max logit error %.4f of scale' % (which, np.abs(score - ref['score']).max() / scale))
+    assert np.abs(score - ref['score']).max() / scale < 3e-2
+    assert np.array_equal(label, fo.argmax_last(fo.softmax(score)))
+    assert np.allclose(prob, fo.softmax(score), atol=1e-5)
+    ref_label = fo.argmax_last(fo.softmax(ref['score']))
+    top2 = np.sort(ref['score'], -1)[..., -2:]
+    clear = (top2[..., 1] - top2[..., 0]) > 6e-2 * scale
+    assert np.array_equal(label[clear], ref_label[clear])
+    # fp32 graph too: the dense kernels are honoured, not replaced by the bilinear constant (which would be far off)
+    ref32 = ao.adapnet_forward(data['rgb'], w, 'rgb', policy='fp32', keep=['score'])['score']
+    wb = dict(w)
+    for scope in ('first_deconvolution_upconv', 'second_deconvolution_upconv'):
+        wb['rgb/%s/kernel' % scope] = rect_bilinear_filter(w['rgb/%s/kernel' % scope].shape)
+    refb = ao.adapnet_forward(data['rgb'], wb, 'rgb', policy='fp32', keep=['score'])['score']
+    assert np.abs(score - ref32).max() < 0.25 * np.abs(refb - ref32).max()
+
+
 @pytest.mark.parametrize('n,h,w,cin', [(1, 16, 32, 1), (3, 48, 80, 3)])
 def test_adapnet_small_and_odd_shapes(ops, tmp_path, n, h, w, cin):
     """Maps down to 1x2 pixels at stride 16 (every atrous tap but the centre off the image), a depth-style one-channel
@@ -311,7 +364,7 @@ def test_adapnet_training_step_on_a_shallow_graph(ops):
     loss = tr.step(_dev(x), _dev(labels))
     torch.cuda.synchronize()
     got = tr.grads_as_variables()
-    ref_loss, ref_g, stats = ao.adapnet_loss_and_grads(x, labels, w_, 'rgb', C, policy='bf16', units=U, blocks=SHALLOW)
+    ref_loss, ref_g, stats = ao.adapnet_loss_and_grads(x, labels, w_, 'rgb', C, policy='bf16', blocks=SHALLOW)
     assert abs(loss.item() - ref_loss) < 1e-2 * abs(ref_loss), (loss.item(), ref_loss)
     assert set(got) == set(ref_g)
     rel, cos = _grad_agreement(got, ref_g)
@@ -322,6 +375,9 @@ def test_adapnet_training_step_on_a_shallow_graph(ops):
         assert rel[k] < 0.05, (k, rel[k])
     for k in ('rgb/shortcut/kernel', 'rgb/first_deconvolution_conv/kernel', 'rgb/first_deconvolution_upconv/gamma'):
         assert rel[k] < 0.2, (k, rel[k])
+    # the two TRAINED transposed-conv kernels (adapnet.py:155-163): the x8 one sits right under the loss
+    assert rel['rgb/second_deconvolution_upconv/kernel'] < 0.05, rel['rgb/second_deconvolution_upconv/kernel']
+    assert rel['rgb/first_deconvolution_upconv/kernel'] < 0.2, rel['rgb/first_deconvolution_upconv/kernel']
     assert min(cos.values()) > 0.85, min(cos.items(), key=lambda kv: kv[1])
     assert max(rel.values()) < 0.7, max(rel.items(), key=lambda kv: kv[1])
     out = dict(w_)
@@ -359,7 +415,7 @@ def test_adapnet_training_step(ops, tmp_path):
     loss = tr.step(_dev(data['rgb']), _dev(data['labels']))
     torch.cuda.synchronize()
     got = tr.grads_as_variables()
-    ref_loss, ref_g, stats = ao.adapnet_loss_and_grads(data['rgb'], data['labels'], w_, 'rgb', C, policy='bf16', units=U)
+    ref_loss, ref_g, stats = ao.adapnet_loss_and_grads(data['rgb'], data['labels'], w_, 'rgb', C, policy='bf16')
     assert abs(loss.item() - ref_loss) < 2e-2 * abs(ref_loss), (loss.item(), ref_loss)
     assert set(got) == set(ref_g)
     rel, cos = _grad_agreement(got, ref_g)
@@ -376,9 +432,13 @@ def test_adapnet_training_step(ops, tmp_path):
                                    rtol=3e-2, atol=3e-3)
         np.testing.assert_allclose(out['rgb/%s/moving_variance' % scope],
                                    0.99 * w_['rgb/%s/moving_variance' % scope] + 0.01 * var, rtol=3e-2, atol=3e-3)
-    # the 2048 - U untrained output channels of first_deconvolution_conv keep their values
+    # at step 0 the x2 deconv kernel is still the bilinear constant (zero off the channel diagonal), so output channels
+    # U.. of first_deconvolution_conv have exactly zero gradient ONCE; both deconv kernels are dense after this step
     k = 'rgb/first_deconvolution_conv/kernel'
     assert np.array_equal(out[k][..., U:], w_[k][..., U:]) and not np.array_equal(out[k][..., :U], w_[k][..., :U])
+    for scope in ('first_deconvolution_upconv', 'second_deconvolution_upconv'):
+        kk = out['rgb/%s/kernel' % scope]
+        assert kk.shape == w_['rgb/%s/kernel' % scope].shape and np.abs(kk[:, :, 0, 1]).max() > 0
     first = net._train_batch(data)
     for _ in range(6):
         last = net._train_batch(data)
@@ -417,7 +477,7 @@ def test_adapnet_with_the_reference_tests_configuration(ops):
     tr = AdapnetTrainer(eng, 'adam', 1e-3)
     tr.load_from_variables(w_)
     loss = tr.step(_dev(x), _dev(labels))
-    ref_loss, ref_g, _ = ao.adapnet_loss_and_grads(x, labels, w_, 'rgb', c, policy='bf16', units=u, blocks=SHALLOW)
+    ref_loss, ref_g, _ = ao.adapnet_loss_and_grads(x, labels, w_, 'rgb', c, policy='bf16', blocks=SHALLOW)
     assert abs(loss.item() - ref_loss) < 1e-2 * abs(ref_loss)
     got = tr.grads_as_variables()
     assert {k: v.shape for k, v in got.items()} == {k: v.shape for k, v in ref_g.items()}

@@ -279,3 +279,140 @@ def test_fp8_fusion_model_predicts(ops, golden_dir):
         assert la.shape == (2, 64, 96)
     assert preds['fp8'].shape == (2, 64, 96) and preds['fp8'].dtype == np.int64
     assert (preds['fp8'] == preds['bf16']).mean() > 0.5      # random-init logits are nearly degenerate
+
+
+# ---- BASELINE configs[4] at its FULL size (2048x1024): one-byte maps, other offsets, calibration over 4x the pixels ----
+
+@pytest.mark.parametrize('h,w,cin,cout', [(256, 512, 256, 256), (128, 256, 512, 512), (64, 128, 512, 512)])
+def test_fp8_conv_properties_at_2048x1024_layer_sizes(ops, h, w, cin, cout):
+    """The F8 kernel on the conv3 / conv4 / conv5 maps of a 2048x1024 image, through size-independent properties:
+    linearity (the same e4m3 bytes under scale_exp + 1 give exactly twice the bf16 output and the SAME e4m3 output
+    bytes under its scale + 1), shift equivariance bit for bit (the accumulation order of an output does not depend on
+    the tile it falls into) and batch independence."""
+    g = torch.Generator(device='cuda').manual_seed(5)
+    x = torch.randn((2, h, w, cin), device='cuda', generator=g)
+    wt = torch.randn((3, 3, cin, cout), device='cuda', generator=g) * (1.0 / (9 * cin) ** 0.5)
+    wp, _ = ops.pack_conv_weights_f8(wt)
+    b = torch.zeros(cout, device='cuda')
+    ex = ops.fp8_scale_exp(x.abs().max().item(), 1)
+    xa = ops.Act.from_dense(x, dtype='fp8', scale_exp=ex)
+    y1, _ = ops.conv2d_fwd(xa, wp, b, 3, relu=False)
+    ey = ops.fp8_scale_exp(y1.interior().abs().max().item(), 1)
+    q1 = ops.Act(2, h, w, cout, dtype='fp8', scale_exp=ey)
+    ops.conv2d_fwd(xa, wp, b, 3, relu=False, y=q1)
+    # linearity: 2x = the same bytes one exponent up
+    xa2 = ops.Act.from_dense(2 * x, dtype='fp8', scale_exp=ex + 1)
+    assert torch.equal(xa2.t.view(torch.uint8), xa.t.view(torch.uint8))
+    y2, _ = ops.conv2d_fwd(xa2, wp, b, 3, relu=False)
+    q2 = ops.Act(2, h, w, cout, dtype='fp8', scale_exp=ey + 1)
+    ops.conv2d_fwd(xa2, wp, b, 3, relu=False, y=q2)
+    torch.cuda.synchronize()
+    assert torch.equal(y2.interior().float(), 2 * y1.interior().float())
+    assert torch.equal(q2.t.view(torch.uint8), q1.t.view(torch.uint8))
+    assert not q1.t.view(torch.uint8)[:, 0].any() and not q1.t.view(torch.uint8)[:, :, -1].any()    # zero border kept
+    # batch independence: image 1 alone
+    xs = ops.Act.from_dense(x[1:2], dtype='fp8', scale_exp=ex)
+    ys, _ = ops.conv2d_fwd(xs, wp, b, 3, relu=False)
+    torch.cuda.synchronize()
+    assert torch.equal(ys.interior(), y1.interior()[1:2])
+    # shift by (24, 40): not a multiple of any tile size
+    xsft = torch.zeros_like(x[:1])
+    xsft[:, 24:, 40:] = x[:1, :-24, :-40]
+    y3, _ = ops.conv2d_fwd(ops.Act.from_dense(xsft, dtype='fp8', scale_exp=ex), wp, b, 3, relu=False)
+    torch.cuda.synchronize()
+    assert torch.equal(y3.interior()[:, 26:-1, 42:-1].float(), y1.interior()[:1, 2:-25, 2:-41].float())
+
+
+def test_fp8_engine_at_2048x1024_against_fp8_policy_oracle(ops):
+    """conv_dtype='fp8' on ONE 2048x1024 image (configs[4]'s size): calibration covers every fp8 map, and two deep
+    layers (conv3_2 on its 256x512 map, conv5_2 on 64x128) are recomputed by the fp8-policy oracle from the GPU's OWN
+    e4m3 input map -- the same operands, the same output rounding, so the two differ only where fp32 accumulation order
+    moves a value across an e4m3 rounding boundary, by one grid step."""
+    from modular_semantic_segmentation_amd.fcn import FP8_MAPS, FcnEngine
+    h, w = 1024, 2048
+    wts = _weights('rgb', 3, 1, 0.02)
+    rng = np.random.default_rng(0)
+    x = torch.from_numpy(rng.integers(0, 256, (1, h, w, 3)).astype(np.float32)).cuda()
+    eng = FcnEngine('rgb', 3, 64, 12, wts, conv_dtype='fp8')
+    scales = eng.calibrate(x)
+    assert sorted(scales) == sorted(FP8_MAPS)
+    out = eng.forward(x, want=('score', 'label'), keep_all=True)
+    torch.cuda.synchronize()
+    L = out['layers']
+    for name, src in (('conv3_2', 'conv3_1'), ('conv5_2', 'conv5_1')):
+        assert L[name].dtype == 'fp8' and L[src].dtype == 'fp8'
+        xin = L[src].real().cpu().numpy()
+        wq = fo.round_e4m3(wts['rgb/%s/kernel' % name], eng.w8_exp[name])
+        y32 = _nhwc(_oracle(xin, wq, wts['rgb/%s/bias' % name], True))
+        want = fo.round_e4m3(y32, scales[name])
+        got = L[name].real().cpu().numpy()
+        flips = got != want
+        print('%s at 2048x1024: %.5f of the e4m3 values one grid step off' % (name, flips.mean()))
+        assert flips.mean() < 1e-2, (name, flips.mean())
+        np.testing.assert_allclose(got, want, rtol=0.13, atol=5e-3 * np.abs(want).max(), err_msg=name)
+    # saturation is rare under the calibrated scales (one bit of headroom) and nothing is NaN / inf
+    for name in FP8_MAPS:
+        v = L[name].real() if name in L else None
+        if v is not None:
+            assert torch.isfinite(v).all(), name
+    score = out['score'].cpu().numpy()
+    assert np.isfinite(score).all()
+    assert np.array_equal(out['label'].cpu().numpy(), fo.argmax_last(fo.softmax(score)))
+
+
+def test_fp8_fusion_model_at_2048x1024_fused_head_equals_unfused(ops, golden_dir):
+    """The two-expert fp8 model at configs[4]'s size: the fused decoder-head kernel and the unfused path (expert label
+    maps materialised, then the fusion kernel) give identical label maps; an image gives the same labels alone."""
+    import os
+    from modular_semantic_segmentation_amd import get_model
+    g = np.load(os.path.join(golden_dir, 'notebook_868.npz'))
+    desc = ({'rgb': 'float32', 'depth': 'float32', 'labels': 'int32'},
+            {'rgb': (None, None, 3), 'depth': (None, None, 1), 'labels': (None, None)}, 12)
+    net = get_model('bayes_fusion')(conv_dtype='fp8', data_description=desc,
+                                    confusion_matrices={'rgb': g['cm_rgb'], 'depth': g['cm_depth']}, num_units=64,
+                                    prefixes={'rgb': 'rgb', 'depth': 'depth'}, num_channels={'rgb': 3, 'depth': 1},
+                                    expert_model='fcn', class_prior='data', batchsize=2, seed=3)
+    net.variables['depth/conv1_1/kernel'] = net.variables['depth/conv1_1/kernel'] / 256.0
+    net._variables_changed()
+    rng = np.random.default_rng(1)
+    data = {'rgb': rng.integers(0, 256, (2, 1024, 2048, 3)).astype(np.float32),
+            'depth': rng.integers(0, 65536, (2, 1024, 2048, 1)).astype(np.float32)}
+    net.calibrate(data)
+    both = net.predict(data)
+    assert both.shape == (2, 1024, 2048) and both.dtype == np.int64
+    score = net.predict(data, output_attr='fused_score')
+    assert np.array_equal(both, np.argmax(score, -1))
+    single = net.predict({k: v[1:2] for k, v in data.items()})
+    assert np.array_equal(single[0], both[1])
+
+
+def test_fp8_scales_are_dropped_when_weights_change(ops):
+    """FcnEngine.load() on other weights must not keep the activation exponents of the old ones (they would
+    saturate or underflow silently): the next batch calibrates again and matches a freshly calibrated engine."""
+    from modular_semantic_segmentation_amd.fcn import FcnEngine
+    w1 = _weights('rgb', 3, 1, 0.02)
+    w2 = {k: (v * 8.0 if k.endswith('conv2_2/kernel') else v) for k, v in _weights('rgb', 3, 2, 0.02).items()}
+    x = torch.from_numpy(np.random.default_rng(0).integers(0, 256, (1, 64, 96, 3)).astype(np.float32)).cuda()
+    eng = FcnEngine('rgb', 3, 64, 12, w1, conv_dtype='fp8')
+    eng.forward(x, want=('score',))
+    first = dict(eng.fp8_scales)
+    eng.load(w2)
+    assert eng.fp8_scales is None
+    got = eng.forward(x, want=('score',))['score'].clone()
+    fresh = FcnEngine('rgb', 3, 64, 12, w2, conv_dtype='fp8')
+    want = fresh.forward(x, want=('score',))['score']
+    torch.cuda.synchronize()
+    assert eng.fp8_scales == fresh.fp8_scales and eng.fp8_scales != first
+    assert torch.equal(got, want)
+
+
+def test_bf16_only_entry_points_refuse_fp8_maps(ops):
+    """an XV_FP8 descriptor handed to a bf16-only entry point is an error, not a reinterpretation."""
+    from modular_semantic_segmentation_amd._lib import XvError
+    a8 = ops.Act(1, 8, 8, 64, dtype='fp8', scale_exp=0)
+    ab = ops.Act(1, 8, 8, 64)
+    for call in (lambda: ops.maxpool2x2_fwd(a8), lambda: ops.add(a8, ab), lambda: ops.concat_channels(a8, ab),
+                 lambda: ops.upsample2x_relu_add(a8), lambda: ops.relu_bwd(ab, a8, ab),
+                 lambda: ops.bias_grad(a8, torch.zeros(64, device='cuda')), lambda: ops.subsample2(a8)):
+        with pytest.raises(XvError):
+            call()

@@ -350,3 +350,90 @@ def test_adapnet_training_step_op_by_op(ops, monkeypatch):
     assert worst['wgrad'] < 1e-3 and worst['dbias'] < 1e-3
     assert worst['dgrad'] < 1e-2 and worst['bn_dz'] < 1e-2
     assert worst['bn_dgamma'] < 2e-3 and worst['bn_dbeta'] < 2e-3
+
+
+def test_adapnet_deconv_kernel_gradients_on_frozen_state(ops, monkeypatch):
+    """AdapNet TRAINS its two transposed-conv kernels (adapnet.py:155-163 calls custom_layers.deconv2d:71-121 without
+    trainable=False).  Both kernel gradients and both data gradients of one step are recomputed by torch-CPU autograd
+    through F.conv_transpose2d itself -- from the exact bf16 input maps and upstream gradients the step left in HBM --
+    so the whole chain (space-to-depth shuffle, 3x3 filter / data gradient on the derived phase kernel, gather back
+    through the inverse index map) is pinned against the operation the reference differentiates.  A second step from
+    DENSE kernels (what a trained checkpoint holds) repeats it."""
+    from modular_semantic_segmentation_amd.adapnet import AdapnetEngine
+    from modular_semantic_segmentation_amd.adapnet_trainer import AdapnetTrainer
+    from oracle import adapnet_oracle as ao
+    h, w = 64, 96
+    rng = np.random.default_rng(0)
+    x = torch.from_numpy(rng.integers(0, 256, (2, h, w, 3)).astype(np.float32)).cuda()
+    labels = torch.from_numpy(rng.integers(-1, C, (2, h, w)).astype(np.int32)).cuda()
+    w_ = ao.init_adapnet_weights('rgb', 3, U, C, seed=1, gain=1.3, blocks=SHALLOW)
+    w_['rgb/block_0_1/kernel'] *= 0.02
+    eng = AdapnetEngine('rgb', 3, U, C, w_, blocks=SHALLOW)
+    tr = AdapnetTrainer(eng, 'rmsprop', 1e-3)
+    tr.load_from_variables(w_)
+    cap = {}
+    orig_s2d, orig_s2dd, orig_dgrad = ops.space_to_depth, ops.space_to_depth_dense, ops.conv2d_bwd_data
+
+    def s2d(g, stride, out=None):
+        cap['g1'] = _nchw(g)
+        res = orig_s2d(g, stride, out)
+        torch.cuda.synchronize()
+        # the shuffle itself: phase channel (py*s + px)*C + c  <->  pixel (s*qy + py, s*qx + px)
+        n, c, hh, ww = cap['g1'].shape
+        want = cap['g1'].view(n, c, hh // stride, stride, ww // stride, stride).permute(0, 3, 5, 1, 2, 4).reshape(
+            n, stride * stride * c, hh // stride, ww // stride)
+        assert torch.equal(_nchw(res), want)
+        assert not res.t[:, 0].any() and not res.t[:, :, -1].any()
+        return res
+
+    def s2dd(g, stride, out):
+        cap['g2'] = g.detach().float().cpu().permute(0, 3, 1, 2).contiguous()
+        res = orig_s2dd(g, stride, out)
+        torch.cuda.synchronize()
+        n, c, hh, ww = cap['g2'].shape
+        cp = out.c // (stride * stride)
+        gp = F.pad(cap['g2'], (0, 0, 0, 0, 0, cp - c))
+        want = gp.view(n, cp, hh // stride, stride, ww // stride, stride).permute(0, 3, 5, 1, 2, 4).reshape(
+            n, stride * stride * cp, hh // stride, ww // stride)
+        assert torch.equal(_nchw(res), fo.round_bf16(want))
+        return res
+
+    def dgrad(dy, w_packed_dgrad, zero_bias, dx, k, relu_ref=None, addend=None):
+        out = orig_dgrad(dy, w_packed_dgrad, zero_bias, dx, k, relu_ref=relu_ref, addend=addend)
+        for scope in ('first_deconvolution_upconv', 'second_deconvolution_upconv'):
+            if w_packed_dgrad.data_ptr() == tr.wd[scope].data_ptr():
+                torch.cuda.synchronize()
+                cap['dx_' + scope] = _nchw(dx)
+        return out
+
+    monkeypatch.setattr(ops, 'space_to_depth', s2d)
+    monkeypatch.setattr(ops, 'space_to_depth_dense', s2dd)
+    monkeypatch.setattr(ops, 'conv2d_bwd_data', dgrad)
+    for step in range(2):
+        kern = {s: tr.view(tr.param, s, 'kernel').detach().float().cpu().numpy().copy() for s in tr.deconv_shape}
+        if step == 1:
+            for s in kern:      # after one optimizer step the kernels are dense: what a trained checkpoint holds
+                f, cin = tr.deconv_real[s]
+                diag = np.zeros(kern[s].shape[2:], bool)
+                diag[np.arange(min(f, cin)), np.arange(min(f, cin))] = True
+                assert np.abs(kern[s][:, :, ~diag]).max() > 0
+        tr.step(x, labels)
+        torch.cuda.synchronize()
+        n = 2
+        ins = {'first_deconvolution_upconv': tr._a[('y_deconv_in', n, h // 16, w // 16, tr.width)],
+               'second_deconvolution_upconv': tr._a[('merge', n, h // 8, w // 8, eng.Up)]}
+        for scope, stride, gkey in (('first_deconvolution_upconv', 2, 'g1'), ('second_deconvolution_upconv', 8, 'g2')):
+            f, cin = tr.deconv_real[scope]
+            k = kern[scope].shape[0]
+            xin = _nchw(ins[scope])[:, :cin].clone().requires_grad_(True)
+            wt = torch.from_numpy(fo.round_bf16(kern[scope][:, :, :f, :cin])).requires_grad_(True)
+            y = F.conv_transpose2d(xin, wt.permute(3, 2, 0, 1), stride=stride, padding=(k - stride) // 2)
+            y.backward(fo.round_bf16(cap[gkey][:, :f]))             # the upstream gradient as the MFMA convs read it (bf16)
+            got = tr.view(tr.grad, scope, 'kernel').detach().float().cpu().numpy()
+            _close(got[:, :, :f, :cin], wt.grad.numpy(), 2e-3, 'step %d: d %s/kernel' % (step, scope))
+            if f < got.shape[2] or cin < got.shape[3]:         # channel padding: exactly zero gradient, stays zero
+                mask = np.ones(got.shape[2:], bool)
+                mask[:f, :cin] = False
+                assert not got[:, :, mask].any()
+            _close(cap['dx_' + scope][:, :cin].numpy(), fo.round_bf16(xin.grad).numpy(), 1e-2,
+                   'step %d: data gradient of %s' % (step, scope))
