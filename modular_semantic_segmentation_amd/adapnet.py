@@ -312,8 +312,9 @@ class AdapnetEngine(object):
             if skey not in self._arena:
                 self._arena[skey] = torch.empty((m.n, 8 * m.h, 8 * m.w, self.C), dtype=torch.float32, device=self.device)
             score = ops.depth_to_space_dense(zph, 8, self.C, self._arena[skey], scale=sc, shift=sh)
-            prob, label = ops.softmax_argmax(score, want_prob='prob' in want,
-                                             want_label=('label' in want or 'classification' in want))
+            want_label = 'label' in want or 'classification' in want
+            prob, label = (ops.softmax_argmax(score, want_prob='prob' in want, want_label=want_label)
+                           if ('prob' in want or want_label) else (None, None))
             out = {'layers': L}
             if 'score' in want:
                 out['score'] = score
