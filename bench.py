@@ -197,20 +197,6 @@ def fence(device, world, dist):
         torch.cuda.synchronize(device)
 
 
-def read_sclk():
-    """Current shader clock (MHz) of GPU 0 from sysfs, if this user may read it (a record of the box's clock state
-    next to the number; never a GPU call)."""
-    try:
-        import glob
-        for path in sorted(glob.glob('/sys/class/drm/card*/device/pp_dpm_sclk')):
-            for line in open(path):
-                if line.rstrip().endswith('*'):
-                    return int(re.search(r'(\d+)\s*mhz', line.lower()).group(1))
-    except Exception:       # noqa: BLE001
-        pass
-    return None
-
-
 def timed_blocks(step, steps, device, world, dist, min_seconds):
     """The timed region, made robust: blocks of EXACTLY `steps` steps, each bracketed by barrier + synchronize on both
     sides and reduced to the MAX over ranks, repeated until `min_seconds` of timed work have accumulated (a single block
@@ -619,9 +605,6 @@ def main():
     res.update(block_stats(times, args.steps))
     res['timing'] = ('blocks of exactly --steps steps, barrier + synchronize on both sides, max over ranks, repeated until '
                      '%.1f s; value and ms_per_step are the MEDIAN block' % args.min_seconds)
-    sclk = read_sclk()
-    if sclk is not None:
-        res['sclk_mhz_after_timed_region'] = sclk
     if args.dtype == 'fp8':
         res['config']['conv_dtype'] = 'e4m3 operands from conv2_2 on (81 % of the conv FLOPs), conv1_1 fp32, conv1_2 / conv2_1 bf16'
     if args.expert == 'adapnet':

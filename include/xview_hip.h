@@ -121,6 +121,21 @@ int xv_deconv_dense_fwd(const xv_act* x, const void* w_phases_packed, const floa
  * configurations; XV_ESHAPE if the configuration cannot tile this shape.                            */
 int xv_conv2d_fwd_cfg(const xv_act* x, const void* w_packed, const float* bias, const xv_act* y,
                       const xv_act* pooled, int k, int relu, int cfg, void* stream);
+/* Stream-K tail of the generation-2 3x3 kernel (conv_dma_kernel).  A persistent grid walks (pixel patch, cout tile)
+ * tiles round by round; when the last round is incomplete (conv4_x / conv5_x at 16 images: 4.5 / 1.5 rounds; one image:
+ * fewer tiles than CUs from conv2 on) its (tile, 32-channel chunk) items are dealt out evenly over ALL workgroups, the
+ * partial sums of a split tile meet in fp32 slabs of this workspace and the workgroup that arrives last adds them in
+ * a fixed order (bitwise reproducible) and runs the epilogue.  `workspace`: xv_conv2d_streamk_workspace_bytes() bytes,
+ * 16-byte aligned, ZERO when first used (the arrival counters; every launch leaves them zero again), owned by ONE
+ * stream at a time (two experts on two streams need one each).  NULL = every tile whole (the plain entry points).
+ * Same arguments and results otherwise as xv_conv2d_fwd_cfg / xv_conv2d_bwd_data; kernels other than generation 2
+ * ignore the workspace.                                                                                               */
+size_t xv_conv2d_streamk_workspace_bytes(void);
+int xv_conv2d_fwd_ws(const xv_act* x, const void* w_packed, const float* bias, const xv_act* y, const xv_act* pooled,
+                     int k, int relu, int cfg, void* workspace, size_t workspace_bytes, void* stream);
+int xv_conv2d_bwd_data_ws(const xv_act* dy, const void* w_packed_dgrad, const float* zero_bias, const xv_act* relu_ref,
+                          const xv_act* addend, const xv_act* dx, int k, void* workspace, size_t workspace_bytes,
+                          void* stream);
 int xv_conv2d_num_cfgs(void);
 
 /* First layer: conv1_1 = relu(conv3x3(x) + b) on the RAW float32 network input (dense unpadded

@@ -54,7 +54,15 @@ struct ConvArgs {
   int scale_x;    // E8M0 byte (127 + scale_exp of x) in all four bytes: the uniform block scale of the B operand
   float out_mul;
   int debug_same_patch;  // 0 except in -DXV_CONV_EXPERIMENTS tuning builds (configuration 21 only, see launch_conv_dma2)
+  // generation 2, stream-K tail (see conv_dma_kernel): workspace of xv_conv2d_streamk_workspace_bytes() -- arrival counters
+  // (zero between launches) + fp32 partial-tile slabs -- or null: every tile is computed whole by one workgroup
+  char* sk_ws;
 };
+
+// stream-K workspace: 8 x 64 arrival counters (4 KB header), then two partial-tile slabs per workgroup of the grid
+constexpr int XV_SK_HDR = 4096;
+constexpr int XV_SK_SLAB = 8 * 16 * 1024;  // 8 waves x 16 accumulator tiles x (64 lanes x 16 B)
+constexpr int XV_SK_MAX_CUS = 512;         // 64 workgroups per XCD group
 
 typedef __attribute__((ext_vector_type(8))) int i32x8;
 
@@ -764,7 +772,8 @@ struct DmaCfg {
   static constexpr int B_PIECES = 9 * 4;  // 9 taps x (64 rows x 64 B)
   static constexpr int B_BYTES = B_PIECES * 1024;
   static constexpr int BIAS_OFF = 2 * (A_BYTES + B_BYTES);  // two 256-byte bias slots (tile parity)
-  static constexpr int LDS_BYTES = BIAS_OFF + 512;
+  static constexpr int SK_FLAG_OFF = BIAS_OFF + 512;        // one word: "this workgroup arrived last" (stream-K tail)
+  static constexpr int LDS_BYTES = SK_FLAG_OFF + 16;
   static constexpr int A_ITERS = (A_PIECES + NWAVES - 1) / NWAVES;
   static constexpr int B_ITERS = (B_PIECES + NWAVES - 1) / NWAVES;
   static_assert(LDS_BYTES <= 160 * 1024, "does not fit the LDS");
@@ -808,6 +817,40 @@ __global__ __launch_bounds__(64 * WR * WC, 2) void conv_dma_kernel(ConvArgs a) {
   const int tq = T >> 3, trm = T & 7;
   const int t_begin = xcd * tq + (xcd < trm ? xcd : trm);
   const int t_end = t_begin + tq + (xcd < trm ? 1 : 0);
+  // STREAM-K TAIL.  The nb workgroups of this XCD group walk its tiles round by round; the last round holds only
+  // `rem` < nb tiles, so nb - rem CUs would idle for a whole tile (conv4_x at 16 images: 4.5 rounds, conv5_x: 1.5;
+  // one image: fewer tiles than CUs on every layer from conv2 on).  With a workspace the ITEMS (tile, 32-channel
+  // chunk) of that round are dealt out evenly instead: workgroup bi takes items [I bi / nb, I (bi+1) / nb) of the
+  // round's I = rem * nchunks, i.e. at most two partial tiles ("units" [c0, c1) of a tile's chunks).  A partial unit
+  // ends by writing its fp32 accumulators to a slab and drawing a ticket on the tile's arrival counter; the workgroup
+  // that arrives LAST adds the slabs of all contributors in workgroup order (a fixed order: bitwise reproducible) and
+  // runs the ordinary epilogue.  No workgroup ever waits for another one (two experts' launches share the CUs, so a
+  // spin could deadlock); visibility is the agent-scope release / acquire pair of cdna_hip_programming.md, Guideline 16.
+  const int Tx = t_end - t_begin;
+  const int R = Tx / nb, rem = Tx - R * nb;
+  const int sk_items = rem * nchunks;
+  const bool sk = a.sk_ws != nullptr && rem > 0 && nchunks >= 2 && ((sk_items + nb - 1) / nb) * 4 <= 3 * nchunks;
+  const int sk_a = sk ? (int)((int64_t)sk_items * bi / nb) : 0, sk_e = sk ? (int)((int64_t)sk_items * (bi + 1) / nb) : 0;
+  const int nfull = sk ? R : R + (bi < rem ? 1 : 0);
+  const int sk_t0 = sk_a / nchunks;  // first tail tile this workgroup touches
+  const int ntail = sk_e > sk_a ? (sk_e > (sk_t0 + 1) * nchunks ? 2 : 1) : 0;
+  const int nunits = nfull + ntail;
+  // unit u of this workgroup: tile lid, chunks [c0, c1)
+  auto unit_at = [&](int u, int& ulid, int& uc0, int& uc1) {
+    if (u < nfull) {
+      ulid = t_begin + bi + u * nb;
+      uc0 = 0;
+      uc1 = nchunks;
+    } else if (u == nfull) {
+      ulid = t_begin + R * nb + sk_t0;
+      uc0 = sk_a - sk_t0 * nchunks;
+      uc1 = sk_e - sk_t0 * nchunks < nchunks ? sk_e - sk_t0 * nchunks : nchunks;
+    } else {
+      ulid = t_begin + R * nb + sk_t0 + 1;
+      uc0 = 0;
+      uc1 = sk_e - (sk_t0 + 1) * nchunks;
+    }
+  };
 
   struct Tile {
     int n, y0, x0, co0;
@@ -834,13 +877,22 @@ __global__ __launch_bounds__(64 * WR * WC, 2) void conv_dma_kernel(ConvArgs a) {
     const int hy = p / C::HW, hx = p - hy * C::HW;
     aoff[it] = ((hy * Wp + hx) * Cin + xv_swz32(hx, g & 3) * 8) * 2;
   }
-  int pbase[3];
+  // LDS fragment base addresses of one item (this lane's pixel column for the three horizontal taps, its weight row):
+  // functions of the lane number and the buffer parity only, but as loop invariants they (and a copy with the parity
+  // added) held 8 registers the item loop does not have -- so they are re-derived for the NEXT item between taps 7 and 8,
+  // when the current item's last fragment reads have been issued, under the cover of tap 8's MFMAs
+  int wb, pb[3];
+  auto frag_bases = [&](int bufp) {
+    int ln = lane;
+    asm volatile("" : "+v"(ln));  // (keeps the arithmetic from being hoisted out of the item loop)
+    const int c15 = ln & 15, cg = ln >> 4;
 #pragma unroll
-  for (int dx = 0; dx < 3; ++dx) {
-    const int hx = wc * 16 + l15 + dx;
-    pbase[dx] = ((wr * MT) * C::HW + hx) * 64 + (xv_swz32(hx, lg) << 4);
-  }
-  const int wbase = 2 * C::A_BYTES + l15 * 64 + (xv_swz32(l15, lg) << 4);
+    for (int dx = 0; dx < 3; ++dx) {
+      const int hx = wc * 16 + c15 + dx;
+      pb[dx] = ((wr * MT) * C::HW + hx) * 64 + (xv_swz32(hx, cg) << 4) + bufp * C::A_BYTES;
+    }
+    wb = 2 * C::A_BYTES + c15 * 64 + (xv_swz32(c15, cg) << 4) + bufp * C::B_BYTES;
+  };
   const int64_t tap_pitch = (int64_t)nchunks * Cout * 64;  // bytes between taps of the packed image
   // channel offset of this lane's 16-byte output piece inside a 32-channel pair (see xv_pair16)
   const int csub = (lg & 1) * 16 + (lg >> 1) * 8;
@@ -856,7 +908,6 @@ __global__ __launch_bounds__(64 * WR * WC, 2) void conv_dma_kernel(ConvArgs a) {
   auto dma16 = [&](const char* sbase, int voff, int lds_off) {
     asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_off), "v"(voff), "s"(sbase) : "memory");
   };
-  const int lane16 = lane * 16;
   auto dma_bases = [&](const Tile& t, int chunk, const char*& xsrc, const char*& wsrc) {
     xsrc = reinterpret_cast<const char*>(a.x) + ((((int64_t)t.n * (H + 2) + t.y0) * Wp + t.x0) * Cin + chunk * 32) * 2;
     wsrc = reinterpret_cast<const char*>(a.wpk) + (((int64_t)chunk * Cout + t.co0) << 6);
@@ -868,7 +919,11 @@ __global__ __launch_bounds__(64 * WR * WC, 2) void conv_dma_kernel(ConvArgs a) {
     if (piece < C::A_PIECES) {
       int voff = aoff[it];
       if (edge) {
-        const int g = piece * 64 + lane;
+        // the clamped-offset arithmetic is re-derived from the lane number INSIDE this (rare) path: hoisted out of the
+        // item loop by the compiler it held 15 registers for the whole kernel (and spilled once the loop grew)
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+        const int g = piece * 64 + ln;
         int p = g >> 2;
         p = p < C::NPIX ? p : C::NPIX - 1;
         const int hy = p / C::HW, hx = p - hy * C::HW;
@@ -879,17 +934,20 @@ __global__ __launch_bounds__(64 * WR * WC, 2) void conv_dma_kernel(ConvArgs a) {
   };
   auto dma_b = [&](const char* wsrc, int it, int buf) {
     const int piece = wave + it * C::NWAVES;
-    if (piece < C::B_PIECES)
-      dma16(wsrc + (piece >> 2) * tap_pitch + (piece & 3) * 1024, lane16, 2 * C::A_BYTES + buf * C::B_BYTES + piece * 1024);
+    if (piece < C::B_PIECES) {
+      int ln = lane;
+      asm volatile("" : "+v"(ln));  // (lane * 16 as a loop invariant would hold a register through the whole item loop)
+      dma16(wsrc + (piece >> 2) * tap_pitch + (piece & 3) * 1024, ln * 16, 2 * C::A_BYTES + buf * C::B_BYTES + piece * 1024);
+    }
   };
   // the tile's 64 bias values ride along with its first chunk (one 4-byte-per-lane DMA by the last wave)
-  auto dma_bias = [&](const Tile& t, int chunk, int bslot) {
-    if (chunk == 0 && wave == C::NWAVES - 1)
+  auto dma_bias = [&](const Tile& t, bool unit_start, int bslot) {
+    if (unit_start && wave == C::NWAVES - 1)
       asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dword %1, %2" ::"s"(C::BIAS_OFF + bslot * 256), "v"(lane * 4),
                    "s"(a.bias + t.co0)
                    : "memory");
   };
-  auto issue_all = [&](const Tile& t, int chunk, int buf, int bslot) {
+  auto issue_all = [&](const Tile& t, int chunk, int buf, int bslot) {  // (first item of a workgroup: a unit start)
     const char *xsrc, *wsrc;
     dma_bases(t, chunk, xsrc, wsrc);
 #pragma unroll
@@ -897,7 +955,7 @@ __global__ __launch_bounds__(64 * WR * WC, 2) void conv_dma_kernel(ConvArgs a) {
       dma_a(xsrc, it, buf, t.y0 + C::TH > H || t.x0 + C::TW > W, H + 1 - t.y0, W + 1 - t.x0);
 #pragma unroll
     for (int it = 0; it < C::B_ITERS; ++it) dma_b(wsrc, it, buf);
-    dma_bias(t, chunk, bslot);
+    dma_bias(t, true, bslot);
   };
   constexpr int A_TAPS = (C::A_ITERS + 1) / 2;  // taps 0..A_TAPS-1 issue the patch pieces, two each
   constexpr int LAST_DMA_TAP = A_TAPS + C::B_ITERS - 1;
@@ -912,16 +970,18 @@ __global__ __launch_bounds__(64 * WR * WC, 2) void conv_dma_kernel(ConvArgs a) {
   // tap A_TAPS (last wave, chunk 0) or the patch piece before it, so RTAIL stores are younger than every DMA.
   constexpr int RTAIL = 2 * MT > A_TAPS ? 2 * MT - A_TAPS : 0;
   static_assert(RTAIL != YTAIL && RTAIL != 2 * MT, "the counted waits must differ");
-  const bool resident = nchunks == 2 && (nb % a.n_ct) == 0 && !(a.debug_same_patch & 8);  // (bit 3: XV_DMA_NO_RESIDENT, A/B timing)
+  // (a stream-K tail may start a unit at chunk 1: no fixed chunk <-> buffer parity then)
+  const bool resident = nchunks == 2 && (nb % a.n_ct) == 0 && !sk && !(a.debug_same_patch & 8);  // (bit 3: XV_DMA_NO_RESIDENT, A/B timing)
   int items_done = 0;
 
-  int lid = t_begin + bi;
-  if (lid >= t_end) return;
+  if (nunits == 0) return;
+  int unit = 0, lid, c_first, c_end;
+  unit_at(0, lid, c_first, c_end);
   if constexpr (PRIO == 1) {
     if (wave >= C::NWAVES / 2) __builtin_amdgcn_s_setprio(1);
   }
   Tile cur = decode(lid);
-  int chunk = 0, buf = 0, bslot = 0;
+  int chunk = c_first, buf = 0, bslot = 0;
 
   f32x4 acc[MT][4];
 #pragma unroll
@@ -935,7 +995,8 @@ __global__ __launch_bounds__(64 * WR * WC, 2) void conv_dma_kernel(ConvArgs a) {
   DmaPend pend{0, 0, 0, 0, false};
   const int npieces = a.y != nullptr ? 2 * MT : MT;  // 16-byte store instructions per tile and wave
   int in_flight = 0;  // stores issued after the last DMA of the previous item
-  issue_all(cur, 0, 0, 0);
+  issue_all(cur, chunk, 0, 0);
+  frag_bases(0);
 #ifdef XV_CONV_TRACE
   int trace_item = 0;
 #endif
@@ -963,10 +1024,6 @@ __global__ __launch_bounds__(64 * WR * WC, 2) void conv_dma_kernel(ConvArgs a) {
     // present.  Every wait names the fragments it releases as in/out operands, so the MFMAs that consume
     // them cannot move above it.  No other LGKM operation (s_load, ds_*) may sit inside this region -- the
     // counts below are exact: [W0 P0] W1 | W2 P1 | W3 | W4 | W5 P2 | W6 | W7 | W8 | -.
-    const int wb = wbase + buf * C::B_BYTES;
-    int pb[3];
-#pragma unroll
-    for (int dx = 0; dx < 3; ++dx) pb[dx] = pbase[dx] + buf * C::A_BYTES;
     bf16x8 wf[2][4], xf[2][6];
     static_assert(MT == 4 || MT == 3, "operand lists below");
     if constexpr (MT == 3) xf[0][5] = xf[1][5] = bf16x8{};  // named by the waits, never loaded
@@ -1015,7 +1072,7 @@ __global__ __launch_bounds__(64 * WR * WC, 2) void conv_dma_kernel(ConvArgs a) {
     if (2 * (t) < C::A_ITERS) dma_a(nx_src, 2 * (t), buf ^ 1, nx_edge, nx_ylim, nx_xlim);         \
     if (2 * (t) + 1 < C::A_ITERS) dma_a(nx_src, 2 * (t) + 1, buf ^ 1, nx_edge, nx_ylim, nx_xlim); \
     if ((t) >= A_TAPS && (t) - A_TAPS < C::B_ITERS && !skip_b) dma_b(nw_src, (t) - A_TAPS, buf ^ 1);  \
-    if ((t) == A_TAPS) dma_bias(nxt, nchunk, bslot ^ 1);                                   \
+    if ((t) == A_TAPS) dma_bias(nxt, last_chunk, bslot ^ 1);                                \
   }
 #define XV_TAP(t)                                                                                  \
   {                                                                                                \
@@ -1036,7 +1093,7 @@ __global__ __launch_bounds__(64 * WR * WC, 2) void conv_dma_kernel(ConvArgs a) {
        whole workgroup then waiting ~1.9 k cycles per item for the starved waves).  A burst therefore raises   \
        its priority after its first MFMA and drops it at its end: a wave cannot break into the other's burst, \
        and the two alternate tap by tap. */                                                                  \
-    if ((t) == 0 && chunk == 0) { /* first tap of a tile: C = 0 instead of cleared accumulators */   \
+    if ((t) == 0 && chunk == c_first) { /* first tap of a unit: C = 0 instead of cleared accumulators */ \
       acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[(t) & 1][0], xf[dx_ & 1][dy_], zero4, 0, 0, 0); \
       if constexpr (PRIO == 0) __builtin_amdgcn_s_setprio(2);                                      \
       __builtin_amdgcn_sched_barrier(0);                                                           \
@@ -1059,11 +1116,12 @@ __global__ __launch_bounds__(64 * WR * WC, 2) void conv_dma_kernel(ConvArgs a) {
     XV_LDP(0, 0);
     __builtin_amdgcn_sched_barrier(0);
 
-    const bool last_chunk = chunk + 1 == nchunks;
-    const int nlid = last_chunk ? lid + nb : lid;
-    const bool has_next = nlid < t_end;
+    const bool last_chunk = chunk + 1 == c_end;
+    const bool has_next = !last_chunk || unit + 1 < nunits;
+    int nlid = lid, nc_first = c_first, nc_end = c_end;
+    if (last_chunk && has_next) unit_at(unit + 1, nlid, nc_first, nc_end);
     const Tile nxt = (last_chunk && has_next) ? decode(nlid) : cur;
-    const int nchunk = last_chunk ? 0 : chunk + 1;
+    const int nchunk = last_chunk ? nc_first : chunk + 1;
     const char *nx_src = nullptr, *nw_src = nullptr;
     if (has_next) dma_bases(nxt, nchunk, nx_src, nw_src);
     const bool nx_edge = nxt.y0 + C::TH > H || nxt.x0 + C::TW > W;
@@ -1103,23 +1161,92 @@ __global__ __launch_bounds__(64 * WR * WC, 2) void conv_dma_kernel(ConvArgs a) {
     __builtin_amdgcn_sched_barrier(0);
     XV_STAMP(2)  // first fragments requested, DMA issued
 
-    XV_TAP(0) XV_TAP(1) XV_TAP(2) XV_TAP(3) XV_TAP(4) XV_TAP(5) XV_TAP(6) XV_TAP(7) XV_TAP(8)
+    XV_TAP(0) XV_TAP(1) XV_TAP(2) XV_TAP(3) XV_TAP(4) XV_TAP(5) XV_TAP(6) XV_TAP(7)
+    frag_bases(buf ^ 1);  // (tap 8 computes from registers: the bases of the current buffers are dead)
+    __builtin_amdgcn_sched_barrier(0);
+    XV_TAP(8)
     XV_STAMP(3)  // all MFMAs of the item issued
 
     if (last_chunk) {
-      dma_epilogue_pack<MT>(a, acc, pq, reinterpret_cast<const float*>(smem + C::BIAS_OFF + bslot * 256), cur.n,
-                            cur.y0 + wr * MT, cur.x0 + wc * 16 + l15, cur.co0 + lg * 4, lane);
-      pend = DmaPend{cur.n, cur.y0, cur.x0, cur.co0, true};
+      bool finish = true;  // this workgroup holds the tile's complete sums
+      if (c_first > 0 || c_end < nchunks) {
+        // ---- a partial unit of the stream-K tail: publish the partial sums, take a ticket ----
+        const int r = lid - (t_begin + R * nb);  // tail tile of this XCD group
+        const int slot = unit > nfull ? 1 : 0;   // the workgroup's first / second tail unit
+        float* slab = reinterpret_cast<float*>(a.sk_ws + XV_SK_HDR + (int64_t)(b * 2 + slot) * XV_SK_SLAB) +
+                      wave * (MT * 4 * 256) + lane * 4;
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4*>(slab + (i * 4 + j) * 256) = acc[i][j];
+        // contributors of tile r: the workgroups whose (non-empty: fewer items than workgroups leaves some without any)
+        // item range meets [r nchunks, (r+1) nchunks)
+        auto contributes = [&](int w, int& ws) {
+          ws = (int)((int64_t)sk_items * w / nb);
+          const int we = (int)((int64_t)sk_items * (w + 1) / nb);
+          return we > ws && we > r * nchunks && ws < (r + 1) * nchunks;
+        };
+        int ncontrib = 0;
+        for (int w = 0, ws; w < nb; ++w) ncontrib += contributes(w, ws) ? 1 : 0;
+        // every wave's slab stores have left (and, as a side effect, the next item's DMA has landed) ...
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        volatile int* flag = reinterpret_cast<volatile int*>(smem + C::SK_FLAG_OFF);
+        if (tid == 0) {
+          // ... one lane publishes them at agent scope and draws the ticket (the explicit wait keeps the write-back of
+          // the release ahead of the ticket: ROCm 7.2 may drop the fence's own)
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          unsigned* cnt = reinterpret_cast<unsigned*>(a.sk_ws) + xcd * 64 + r;
+          const unsigned ticket = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const int last = (int)ticket + 1 == ncontrib;
+          if (last) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // zero again for the next launch
+          }
+          *flag = last;
+        }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        finish = __builtin_amdgcn_readfirstlane(*flag) != 0;  // (wave-uniform by construction: keep the branch scalar)
+        if (finish) {
+          // last arriver: the tile = the contributors' slabs summed in workgroup order (its own included: one fixed
+          // expression whoever arrives last)
+          bool first_slab = true;
+          for (int w = 0; w < nb; ++w) {
+            int ws;
+            if (!contributes(w, ws)) continue;
+            const int wslot = ws < r * nchunks ? 1 : 0;
+            const float* src = reinterpret_cast<const float*>(a.sk_ws + XV_SK_HDR + (int64_t)((w * 8 + xcd) * 2 + wslot) * XV_SK_SLAB) +
+                               wave * (MT * 4 * 256) + lane * 4;
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+              f32x4 v[4];
+#pragma unroll
+              for (int j = 0; j < 4; ++j) v[j] = *reinterpret_cast<const f32x4*>(src + (i * 4 + j) * 256);
+#pragma unroll
+              for (int j = 0; j < 4; ++j) acc[i][j] = first_slab ? v[j] : acc[i][j] + v[j];
+            }
+            first_slab = false;
+          }
+        }
+        in_flight = 0;
+      }
+      if (finish) {
+        dma_epilogue_pack<MT>(a, acc, pq, reinterpret_cast<const float*>(smem + C::BIAS_OFF + bslot * 256), cur.n,
+                              cur.y0 + wr * MT, cur.x0 + wc * 16 + l15, cur.co0 + lg * 4, lane);
+        pend = DmaPend{cur.n, cur.y0, cur.x0, cur.co0, true};
+        // both maps wanted: the pack phase stored the pooled map (MT/2 x 4 instructions), the youngest operations now
+        static_assert(YTAIL != 2 * MT, "the two counted waits must differ");
+        in_flight = (a.y != nullptr && a.pooled != nullptr && !(cur.y0 + C::TH > H || cur.x0 + C::TW > W)) ? 2 * MT : 0;
+      }
       XV_STAMP(4)  // tile converted
       bslot ^= 1;
-      // both maps wanted: the pack phase stored the pooled map (MT/2 x 4 instructions), the youngest operations now
-      static_assert(YTAIL != 2 * MT, "the two counted waits must differ");
-      in_flight = (a.y != nullptr && a.pooled != nullptr && !(cur.y0 + C::TH > H || cur.x0 + C::TW > W)) ? 2 * MT : 0;
     }
 #ifdef XV_CONV_TRACE
     ++trace_item;
 #endif
     if (!has_next) {
+      if (!pend.on) break;  // (the last unit was a partial one that another workgroup completes)
       // last tile of this workgroup: store it now
       const int px = pend.x0 + wc * 16 + l15, py0 = pend.y0 + wr * MT;
       const int vrows = H - py0 < 0 ? 0 : (H - py0 < MT ? H - py0 : MT);
@@ -1142,6 +1269,11 @@ __global__ __launch_bounds__(64 * WR * WC, 2) void conv_dma_kernel(ConvArgs a) {
         }
       }
       break;
+    }
+    if (last_chunk) {
+      ++unit;
+      c_first = nc_first;
+      c_end = nc_end;
     }
     lid = nlid;
     cur = nxt;
@@ -1188,7 +1320,10 @@ int launch_conv_dma(const ConvArgs& a0, hipStream_t stream) {
   if ((int64_t)(C::HH * (a.W + 2) + C::HW) * a.Cin * 2 > 0x7fffffff) return XV_ESHAPE;  // 32-bit patch offsets
   a.n_tiles = (int)ntiles;
   const int64_t slots = a.num_cus;
-  const int64_t nblk = ntiles < slots ? ntiles : slots;
+  static const bool no_sk = getenv("XV_DMA_NO_STREAMK") != nullptr;  // (A/B timing)
+  if (no_sk || a.Cin < 64 || (slots & 7) != 0 || slots > XV_SK_MAX_CUS) a.sk_ws = nullptr;
+  // with a stream-K workspace every CU gets a workgroup: the kernel deals the items of an incomplete round out evenly
+  const int64_t nblk = a.sk_ws != nullptr ? slots : (ntiles < slots ? ntiles : slots);
   hipLaunchKernelGGL((conv_dma_kernel<WR, WC, PRIO, MT>), dim3((unsigned)nblk), dim3(C::NT), C::LDS_BYTES + XV_TRACE_LDS, stream, a);
   return xv_launch_status();
 }
@@ -1817,8 +1952,14 @@ int pick_cfg(const ConvArgs& a, int k) {
     auto round_cost = [&](int c, double speed) {
       const Geo& g = kGeo[c];
       const int64_t items = (int64_t)a.N * ((a.H + g.th - 1) / g.th) * ((a.W + g.tw - 1) / g.tw) * (a.Cout / 64);
-      const int64_t rounds = (items + a.num_cus - 1) / a.num_cus;
-      return (double)rounds * g.th * g.tw / speed;
+      double rounds = (double)((items + a.num_cus - 1) / a.num_cus);
+      const int nchunks = a.Cin / 32;
+      if (a.sk_ws != nullptr && nchunks >= 2 && items % a.num_cus) {
+        // stream-K tail: the last round's items are dealt out evenly (plus the slab reduction of the split tiles)
+        const double tail = (double)(((items % a.num_cus) * nchunks + a.num_cus - 1) / a.num_cus) / nchunks;
+        if (tail * 4 <= 3) rounds = (double)(items / a.num_cus) + tail + 0.1;
+      }
+      return rounds * g.th * g.tw / speed;
     };
     int g2 = 17;
     double s2 = 1.25;
@@ -1833,9 +1974,11 @@ int pick_cfg(const ConvArgs& a, int k) {
   return covered(15) < covered(14) ? 15 : 14;
 }
 
+size_t streamk_workspace_bytes() { return (size_t)XV_SK_HDR + (size_t)2 * xv_num_cus() * XV_SK_SLAB; }
+
 int conv_fwd_impl(const xv_act* x, const void* w_packed, const float* bias, const xv_act* y, const xv_act* pooled,
                   int k, int relu, int cfg, void* stream, const __bf16* mask = nullptr,
-                  const __bf16* addend = nullptr) {
+                  const __bf16* addend = nullptr, void* workspace = nullptr, size_t workspace_bytes = 0) {
   XV_CHECK_ARG(x && x->data && w_packed && bias && y);
   XV_CHECK_ARG(y->data || (pooled && pooled->data));
   XV_CHECK_SHAPE(k == 1 || k == 3);
@@ -1867,6 +2010,11 @@ int conv_fwd_impl(const xv_act* x, const void* w_packed, const float* bias, cons
   a.out_f8 = out_f8;
   a.scale_x = in_f8 ? ((127 + x->scale_exp) & 0xff) * 0x01010101 : 0;
   a.out_mul = out_f8 ? exp2f((float)-y->scale_exp) : 1.f;
+  if (workspace != nullptr) {
+    XV_CHECK_ARG(((uintptr_t)workspace & 15) == 0);
+    if (workspace_bytes < streamk_workspace_bytes()) return XV_EWORKSPACE;
+    a.sk_ws = (char*)workspace;
+  }
   if (pooled && pooled->data) {
     XV_CHECK_SHAPE(k == 3 && (x->h & 1) == 0 && (x->w & 1) == 0);
     XV_CHECK_SHAPE(pooled->n == x->n && pooled->h == x->h / 2 && pooled->w == x->w / 2 && pooled->c == y->c);
@@ -1999,6 +2147,28 @@ extern "C" int xv_conv2d_fwd(const xv_act* x, const void* w_packed, const float*
 extern "C" int xv_conv2d_fwd_cfg(const xv_act* x, const void* w_packed, const float* bias, const xv_act* y,
                                  const xv_act* pooled, int k, int relu, int cfg, void* stream) {
   return conv_fwd_impl(x, w_packed, bias, y, pooled, k, relu, cfg, stream);
+}
+
+extern "C" size_t xv_conv2d_streamk_workspace_bytes(void) { return streamk_workspace_bytes(); }
+
+extern "C" int xv_conv2d_fwd_ws(const xv_act* x, const void* w_packed, const float* bias, const xv_act* y,
+                                const xv_act* pooled, int k, int relu, int cfg, void* workspace, size_t workspace_bytes,
+                                void* stream) {
+  return conv_fwd_impl(x, w_packed, bias, y, pooled, k, relu, cfg, stream, nullptr, nullptr, workspace, workspace_bytes);
+}
+
+extern "C" int xv_conv2d_bwd_data_ws(const xv_act* dy, const void* w_packed_dgrad, const float* zero_bias,
+                                     const xv_act* relu_ref, const xv_act* addend, const xv_act* dx, int k, void* workspace,
+                                     size_t workspace_bytes, void* stream) {
+  XV_REQUIRE_BF16(dy, relu_ref, addend, dx);
+  XV_CHECK_ARG(dx && dx->data && zero_bias);
+  if (relu_ref && relu_ref->data)
+    XV_CHECK_SHAPE(relu_ref->n == dx->n && relu_ref->h == dx->h && relu_ref->w == dx->w && relu_ref->c == dx->c);
+  if (addend && addend->data)
+    XV_CHECK_SHAPE(addend->n == dx->n && addend->h == dx->h && addend->w == dx->w && addend->c == dx->c);
+  return conv_fwd_impl(dy, w_packed_dgrad, zero_bias, dx, nullptr, k, 0, -1, stream,
+                       relu_ref ? (const __bf16*)relu_ref->data : nullptr,
+                       addend ? (const __bf16*)addend->data : nullptr, workspace, workspace_bytes);
 }
 
 extern "C" int xv_conv2d_num_cfgs(void) { return XV_NUM_CONV_CFG; }

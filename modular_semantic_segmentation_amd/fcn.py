@@ -182,6 +182,14 @@ class FcnEngine(object):
                 self.w8[name], self.w8_exp[name] = ops.pack_conv_weights_f8(up(k))
         torch.cuda.synchronize(dev)
 
+    def _sk(self):
+        """This engine's stream-K workspace (ops.streamk_workspace: arrival counters + partial-tile slabs of the
+        generation-2 conv kernel's tail round).  One per engine: the two experts of a fusion model run on two streams."""
+        ws = self._arena.get('streamk_ws')
+        if ws is None:
+            ws = self._arena['streamk_ws'] = ops.streamk_workspace(self.device)
+        return ws
+
     # ---- activations ---------------------------------------------------------------------------
     def _act(self, name, n, h, w, c, dtype='bf16', scale_exp=0):
         key = (name, n, h, w, c, dtype)
@@ -265,13 +273,14 @@ class FcnEngine(object):
             for name, cout, pool in ENCODER[1:]:
                 if pool is None:
                     y = self._act(name, n, ch, cw, cout)
-                    ops.conv2d_fwd(cur, self.w[name], self.b[name], 3, relu=True, y=y)
+                    ops.conv2d_fwd(cur, self.w[name], self.b[name], 3, relu=True, y=y, workspace=self._sk())
                     L[name] = cur = y
                 else:
                     q = self._act(pool, n, ch // 2, cw // 2, cout)
                     need_full = keep_all or name == 'conv4_3'       # conv4_3 feeds score_conv4
                     y = self._act(name, n, ch, cw, cout) if need_full else None
-                    ops.conv2d_fwd(cur, self.w[name], self.b[name], 3, relu=True, y=y, pooled=q, write_y=need_full)
+                    ops.conv2d_fwd(cur, self.w[name], self.b[name], 3, relu=True, y=y, pooled=q, write_y=need_full,
+                                   workspace=self._sk())
                     if y is not None:
                         L[name] = y
                     L[pool] = cur = q

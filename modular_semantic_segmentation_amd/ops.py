@@ -118,9 +118,16 @@ def pack_conv_weights_f8(w_hwio, scale_exp=None):
     return out, int(scale_exp)
 
 
-def conv2d_fwd(x, w_packed, bias, k, relu=True, y=None, pooled=None, write_y=True, cfg=-1):
+def streamk_workspace(device):
+    """A zeroed stream-K workspace (xv_conv2d_streamk_workspace_bytes): hand it to every conv2d_fwd / conv2d_bwd_data of
+    ONE stream; two streams (the two experts of a fusion model) need one each."""
+    return torch.zeros(_lib.lib().xv_conv2d_streamk_workspace_bytes(), dtype=torch.uint8, device=device)
+
+
+def conv2d_fwd(x, w_packed, bias, k, relu=True, y=None, pooled=None, write_y=True, cfg=-1, workspace=None):
     """x: Act; returns (y Act or None, pooled Act or None).  An fp8 `x` needs weights from pack_conv_weights_f8; the
-    dtype / scale of y and pooled (which must agree) select the output conversion."""
+    dtype / scale of y and pooled (which must agree) select the output conversion.  workspace (streamk_workspace): the
+    generation-2 kernel deals the items of an incomplete last round of tiles out over all CUs (stream-K tail)."""
     cout = bias.numel()
     _need(bias, torch.float32, 'bias')
     if y is None and write_y:
@@ -133,9 +140,14 @@ def conv2d_fwd(x, w_packed, bias, k, relu=True, y=None, pooled=None, write_y=Tru
     if prof is not None:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
-    rc = _lib.lib().xv_conv2d_fwd_cfg(x.xv(), _ptr(w_packed), _ptr(bias), ctypes.byref(ydesc),
-                                     pooled.xv() if pooled is not None else _NULL_ACT, k, int(bool(relu)), int(cfg),
-                                     _stream())
+    if workspace is None:
+        rc = _lib.lib().xv_conv2d_fwd_cfg(x.xv(), _ptr(w_packed), _ptr(bias), ctypes.byref(ydesc),
+                                         pooled.xv() if pooled is not None else _NULL_ACT, k, int(bool(relu)), int(cfg),
+                                         _stream())
+    else:
+        rc = _lib.lib().xv_conv2d_fwd_ws(x.xv(), _ptr(w_packed), _ptr(bias), ctypes.byref(ydesc),
+                                        pooled.xv() if pooled is not None else _NULL_ACT, k, int(bool(relu)), int(cfg),
+                                        _ptr(workspace), workspace.numel() * workspace.element_size(), _stream())
     _lib.check(rc, 'xv_conv2d_fwd')
     if prof is not None:
         ev1.record()
@@ -485,11 +497,17 @@ class _Profiled(object):
             self.prof.append((self.kind, self.flops, self.ev0, self.ev1))
 
 
-def conv2d_bwd_data(dy, w_packed_dgrad, zero_bias, dx, k, relu_ref=None, addend=None):
+def conv2d_bwd_data(dy, w_packed_dgrad, zero_bias, dx, k, relu_ref=None, addend=None, workspace=None):
     with _Profiled('dgrad_k%d' % k, 2.0 * dx.n * dx.h * dx.w * dx.c * dy.c * k * k):
-        rc = _lib.lib().xv_conv2d_bwd_data(dy.xv(), _ptr(w_packed_dgrad), _ptr(zero_bias),
-                                          relu_ref.xv() if relu_ref is not None else _NULL_ACT,
-                                          addend.xv() if addend is not None else _NULL_ACT, dx.xv(), k, _stream())
+        if workspace is None:
+            rc = _lib.lib().xv_conv2d_bwd_data(dy.xv(), _ptr(w_packed_dgrad), _ptr(zero_bias),
+                                              relu_ref.xv() if relu_ref is not None else _NULL_ACT,
+                                              addend.xv() if addend is not None else _NULL_ACT, dx.xv(), k, _stream())
+        else:
+            rc = _lib.lib().xv_conv2d_bwd_data_ws(dy.xv(), _ptr(w_packed_dgrad), _ptr(zero_bias),
+                                                 relu_ref.xv() if relu_ref is not None else _NULL_ACT,
+                                                 addend.xv() if addend is not None else _NULL_ACT, dx.xv(), k,
+                                                 _ptr(workspace), workspace.numel() * workspace.element_size(), _stream())
     _lib.check(rc, 'xv_conv2d_bwd_data')
     return dx
 
