@@ -63,6 +63,24 @@ struct ConvArgs {
 constexpr int XV_SK_HDR = 4096;
 constexpr int XV_SK_SLAB = 8 * 16 * 1024;  // 8 waves x 16 accumulator tiles x (64 lanes x 16 B)
 constexpr int XV_SK_MAX_CUS = 512;         // 64 workgroups per XCD group
+constexpr int XV_SK_MAX_SPLIT = 4;
+
+// Is the stream-K tail worth it for one XCD group's last round -- `rem` tiles of `nchunks` items on `nb` workgroups, slabs
+// of `slab_kb` KB?  Returns the number of workgroups that share the tail's items (at most XV_SK_MAX_SPLIT per tile: the
+// last arriver reads every other contributor's slab at 60-70 GB/s), or 0 for "compute every tile whole".  Measured on
+// MI355X (bench.py --layer-profile, with / without XV_DMA_NO_STREAMK): an item takes ~2.9 us; the exchange costs ~8 us of
+// latency chain (drain of the write-through stores, ticket, slab reads, one more epilogue) plus its bytes, written through
+// and read back across XCDs, at ~2 TB/s chip-wide -- conv5_x at one image: 9 MB, 46 -> 27 us per launch; conv4_2 at one
+// image: 32 MB, 47 -> 51 us; the half-round tails at 16 images: 24-32 MB for 8 items saved, no gain.  Hence: only where
+// the items saved pay for the exchange 1.3 times over.
+__host__ __device__ inline int xv_sk_parts(int rem, int nb, int nchunks, int slab_kb) {
+  if (rem <= 0 || nchunks < 2) return 0;
+  const int nbp = nb < rem * XV_SK_MAX_SPLIT ? nb : rem * XV_SK_MAX_SPLIT;
+  const int saved = nchunks - (rem * nchunks + nbp - 1) / nbp;  // items off the critical path
+  const int gain = saved * 290;                                  // us x 100
+  const int cost = nbp * slab_kb * 100 / 125 + 800;              // 2 x (8 groups x nbp slabs) / 2 TB/s + 8 us, x 100
+  return gain * 10 > cost * 13 ? nbp : 0;
+}
 
 typedef __attribute__((ext_vector_type(8))) int i32x8;
 
@@ -829,8 +847,12 @@ __global__ __launch_bounds__(64 * WR * WC, 2) void conv_dma_kernel(ConvArgs a) {
   const int Tx = t_end - t_begin;
   const int R = Tx / nb, rem = Tx - R * nb;
   const int sk_items = rem * nchunks;
-  const bool sk = a.sk_ws != nullptr && rem > 0 && nchunks >= 2 && ((sk_items + nb - 1) / nb) * 4 <= 3 * nchunks;
-  const int sk_a = sk ? (int)((int64_t)sk_items * bi / nb) : 0, sk_e = sk ? (int)((int64_t)sk_items * (bi + 1) / nb) : 0;
+  // the tail's items go to the first nbp workgroups of the group (xv_sk_parts: 0 = the exchange would cost more than
+  // the idle CUs)
+  const int nbp = a.sk_ws != nullptr ? xv_sk_parts(rem, nb, nchunks, C::NWAVES * MT * 4) : 0;
+  const bool sk = nbp > 0;
+  const int sk_a = sk && bi < nbp ? (int)((int64_t)sk_items * bi / nbp) : 0;
+  const int sk_e = sk && bi < nbp ? (int)((int64_t)sk_items * (bi + 1) / nbp) : 0;
   const int nfull = sk ? R : R + (bi < rem ? 1 : 0);
   const int sk_t0 = sk_a / nchunks;  // first tail tile this workgroup touches
   const int ntail = sk_e > sk_a ? (sk_e > (sk_t0 + 1) * nchunks ? 2 : 1) : 0;
@@ -1170,62 +1192,71 @@ __global__ __launch_bounds__(64 * WR * WC, 2) void conv_dma_kernel(ConvArgs a) {
     if (last_chunk) {
       bool finish = true;  // this workgroup holds the tile's complete sums
       if (c_first > 0 || c_end < nchunks) {
-        // ---- a partial unit of the stream-K tail: publish the partial sums, take a ticket ----
+        // ---- a partial unit of the stream-K tail ----
+        // Hand-off form (cdna_hip_programming.md, Guideline 16, "every load sc1"; MI355X_MICROARCH.md, Valid forms, first
+        // row): slabs are stored WRITE-THROUGH (sc1) and read by sc1 loads, every storing wave drains its stores before
+        // the workgroup's barrier, ONE lane then adds to the tile's arrival counter (agent-scope atomic) and the workgroup
+        // whose add came last -- told by the value the add returned -- reads the slabs behind a barrier that lane joins.
+        // No release / acquire fence: a release would write back the whole L2 of the XCD (megabytes of freshly stored
+        // output) in every partial workgroup -- measured 30-40 us per launch.
         const int r = lid - (t_begin + R * nb);  // tail tile of this XCD group
         const int slot = unit > nfull ? 1 : 0;   // the workgroup's first / second tail unit
-        float* slab = reinterpret_cast<float*>(a.sk_ws + XV_SK_HDR + (int64_t)(b * 2 + slot) * XV_SK_SLAB) +
-                      wave * (MT * 4 * 256) + lane * 4;
-#pragma unroll
-        for (int i = 0; i < MT; ++i)
-#pragma unroll
-          for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4*>(slab + (i * 4 + j) * 256) = acc[i][j];
         // contributors of tile r: the workgroups whose (non-empty: fewer items than workgroups leaves some without any)
         // item range meets [r nchunks, (r+1) nchunks)
         auto contributes = [&](int w, int& ws) {
-          ws = (int)((int64_t)sk_items * w / nb);
-          const int we = (int)((int64_t)sk_items * (w + 1) / nb);
+          ws = (int)((int64_t)sk_items * w / nbp);
+          const int we = (int)((int64_t)sk_items * (w + 1) / nbp);
           return we > ws && we > r * nchunks && ws < (r + 1) * nchunks;
         };
         int ncontrib = 0;
-        for (int w = 0, ws; w < nb; ++w) ncontrib += contributes(w, ws) ? 1 : 0;
-        // every wave's slab stores have left (and, as a side effect, the next item's DMA has landed) ...
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        for (int w = 0, ws; w < nbp; ++w) ncontrib += contributes(w, ws) ? 1 : 0;
+        const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(a.sk_ws, 0, XV_SK_HDR + 2 * (int)gridDim.x * XV_SK_SLAB, 0x00020000);
+        const int lane_off = wave * (MT * 4 * 1024) + lane * 16;  // this lane's first 16 bytes inside a slab
+        unsigned* cnt = reinterpret_cast<unsigned*>(a.sk_ws) + xcd * 64 + r;
         volatile int* flag = reinterpret_cast<volatile int*>(smem + C::SK_FLAG_OFF);
-        if (tid == 0) {
-          // ... one lane publishes them at agent scope and draws the ticket (the explicit wait keeps the write-back of
-          // the release ahead of the ticket: ROCm 7.2 may drop the fence's own)
-          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-          unsigned* cnt = reinterpret_cast<unsigned*>(a.sk_ws) + xcd * 64 + r;
-          const unsigned ticket = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          const int last = (int)ticket + 1 == ncontrib;
-          if (last) {
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // zero again for the next launch
-          }
-          *flag = last;
+        // (1) a tile split in TWO (the tail of an even split at 16 images): the other half already here?  Then this
+        // workgroup is the last arriver for certain (nobody is left to add) and publishes nothing -- a + b == b + a bit
+        // for bit, so its own sums can stay in registers whichever half arrives last
+        finish = false;
+        if (ncontrib == 2) {
+          if (tid == 0) *flag = __hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 1u;
+          asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+          finish = __builtin_amdgcn_readfirstlane(*flag) != 0;  // (wave-uniform by construction: keep the branch scalar)
         }
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        finish = __builtin_amdgcn_readfirstlane(*flag) != 0;  // (wave-uniform by construction: keep the branch scalar)
+        if (!finish) {
+          // (2) publish the partial sums write-through, drain, barrier, ONE lane draws the ticket
+          const int mine = XV_SK_HDR + (b * 2 + slot) * XV_SK_SLAB + lane_off;
+#pragma unroll
+          for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+              __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[i][j]), rsrc, mine + (i * 4 + j) * 1024, 0, 16);
+          asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");  // (the flag word has been read by all)
+          if (tid == 0)
+            *flag = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1 == (unsigned)ncontrib;
+          asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+          finish = __builtin_amdgcn_readfirstlane(*flag) != 0;
+        }
         if (finish) {
-          // last arriver: the tile = the contributors' slabs summed in workgroup order (its own included: one fixed
-          // expression whoever arrives last)
-          bool first_slab = true;
-          for (int w = 0; w < nb; ++w) {
+          // last arriver: the tile = the contributors' partial sums added in workgroup order (two halves: its own from
+          // registers, see above; more: all of them, its own included, from the slabs -- one fixed expression whoever
+          // arrives last)
+          if (tid == 0) __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // zero for the next launch
+          bool first_slab = ncontrib != 2;
+          for (int w = 0; w < nbp; ++w) {
             int ws;
-            if (!contributes(w, ws)) continue;
-            const int wslot = ws < r * nchunks ? 1 : 0;
-            const float* src = reinterpret_cast<const float*>(a.sk_ws + XV_SK_HDR + (int64_t)((w * 8 + xcd) * 2 + wslot) * XV_SK_SLAB) +
-                               wave * (MT * 4 * 256) + lane * 4;
+            if (!contributes(w, ws) || (ncontrib == 2 && w == bi)) continue;
+            const int theirs = XV_SK_HDR + ((w * 8 + xcd) * 2 + (ws < r * nchunks ? 1 : 0)) * XV_SK_SLAB + lane_off;
+            u32x4 v[MT][4];  // the whole slab share of this lane in flight before the first add (one memory round trip)
 #pragma unroll
-            for (int i = 0; i < MT; ++i) {
-              f32x4 v[4];
+            for (int i = 0; i < MT; ++i)
 #pragma unroll
-              for (int j = 0; j < 4; ++j) v[j] = *reinterpret_cast<const f32x4*>(src + (i * 4 + j) * 256);
+              for (int j = 0; j < 4; ++j) v[i][j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, theirs + (i * 4 + j) * 1024, 0, 16);
 #pragma unroll
-              for (int j = 0; j < 4; ++j) acc[i][j] = first_slab ? v[j] : acc[i][j] + v[j];
-            }
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+              for (int j = 0; j < 4; ++j)
+                acc[i][j] = first_slab ? __builtin_bit_cast(f32x4, v[i][j]) : acc[i][j] + __builtin_bit_cast(f32x4, v[i][j]);
             first_slab = false;
           }
         }
@@ -1324,6 +1355,8 @@ int launch_conv_dma(const ConvArgs& a0, hipStream_t stream) {
   if (no_sk || a.Cin < 64 || (slots & 7) != 0 || slots > XV_SK_MAX_CUS) a.sk_ws = nullptr;
   // with a stream-K workspace every CU gets a workgroup: the kernel deals the items of an incomplete round out evenly
   const int64_t nblk = a.sk_ws != nullptr ? slots : (ntiles < slots ? ntiles : slots);
+  static const bool grid_only = getenv("XV_SK_GRID_ONLY") != nullptr;  // (experiment: the full grid without the tail split)
+  if (grid_only) a.sk_ws = nullptr;
   hipLaunchKernelGGL((conv_dma_kernel<WR, WC, PRIO, MT>), dim3((unsigned)nblk), dim3(C::NT), C::LDS_BYTES + XV_TRACE_LDS, stream, a);
   return xv_launch_status();
 }
@@ -1954,10 +1987,13 @@ int pick_cfg(const ConvArgs& a, int k) {
       const int64_t items = (int64_t)a.N * ((a.H + g.th - 1) / g.th) * ((a.W + g.tw - 1) / g.tw) * (a.Cout / 64);
       double rounds = (double)((items + a.num_cus - 1) / a.num_cus);
       const int nchunks = a.Cin / 32;
-      if (a.sk_ws != nullptr && nchunks >= 2 && items % a.num_cus) {
-        // stream-K tail: the last round's items are dealt out evenly (plus the slab reduction of the split tiles)
-        const double tail = (double)(((items % a.num_cus) * nchunks + a.num_cus - 1) / a.num_cus) / nchunks;
-        if (tail * 4 <= 3) rounds = (double)(items / a.num_cus) + tail + 0.1;
+      if (a.sk_ws != nullptr && items % a.num_cus && (a.num_cus & 7) == 0) {
+        // stream-K tail (conv_dma_kernel): the last round's items dealt out over nbp workgroups per XCD group
+        const int nb = a.num_cus / 8, rem = (int)((items % a.num_cus + 7) / 8);
+        const int nbp = xv_sk_parts(rem < nb ? rem : nb - 1, nb, nchunks, g.th == 24 ? 96 : 128);
+        if (nbp > 0)
+          rounds = (double)(items / a.num_cus) + (double)((rem * nchunks + nbp - 1) / nbp) / nchunks +
+                   (nbp * 128 / 125 + 8) / (2.9 * nchunks);
       }
       return rounds * g.th * g.tw / speed;
     };
