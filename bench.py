@@ -71,13 +71,13 @@ def adapnet_flops_per_image(h, w, cin):
     return f + 2.0 * (h // 16) * (w // 16) * 2048 * U
 
 
-def build_model(device, fusion='bayes', expert='fcn', batch=16, dtype='bf16'):
+def build_model(device, fusion='bayes', expert='fcn', batch=16, dtype='bf16', streamk=False):
     from modular_semantic_segmentation_amd import get_model
     g = np.load(os.path.join(ROOT, 'tests', 'golden', 'notebook_868.npz'))
     desc = ({'rgb': 'float32', 'depth': 'float32', 'labels': 'int32'},
             {'rgb': (None, None, 3), 'depth': (None, None, 1), 'labels': (None, None)}, C)
     common = dict(data_description=desc, num_units=U, num_channels={'rgb': 3, 'depth': 1}, expert_model=expert,
-                  class_prior='data', batchsize=batch, seed=1, device=str(device), conv_dtype=dtype)
+                  class_prior='data', batchsize=batch, seed=1, device=str(device), conv_dtype=dtype, streamk=streamk)
     if fusion == 'joint':
         # the reference's joint baseline fusion_fcn (experiments/timing.py:24-45): two VGG16 trunks + fused decoder
         net = get_model('fusion_fcn')({'rgb': 'rgb', 'depth': 'depth'}, {'rgb': 3, 'depth': 1}, U, C,
@@ -326,9 +326,10 @@ def committed_traffic(batch, h, w):
     return None
 
 
-def extra_inference(device, label, fusion, batch, h, w, dtype='bf16', steps=10, warmup=2, ones=False, fetch=False):
+def extra_inference(device, label, fusion, batch, h, w, dtype='bf16', steps=10, warmup=2, ones=False, fetch=False,
+                    streamk=False):
     """One more BASELINE.json configuration as an `extra` record (its own model, graph and roofline pass)."""
-    net = build_model(device, fusion=fusion, batch=batch, dtype=dtype)
+    net = build_model(device, fusion=fusion, batch=batch, dtype=dtype, streamk=streamk)
     data = synthetic_batch(device, batch, h, w, seed=77, ones=ones)
     if dtype == 'fp8':
         net.calibrate(data)
@@ -656,8 +657,13 @@ def main():
                                          'tf.ones([1,768,384,.]) input, label map fetched to the host every iteration '
                                          '(Inference Time.ipynb:139 publishes 0.0461 s on a GTX 1080 Ti)', 'bayes', 1, 768, 384,
                                          steps=50, warmup=5, ones=True, fetch=True)
+            guarded(extra_inference, device, 'the same protocol with streamk=True (the latency option: conv5_x split over idle '
+                                         'CUs; results then depend on the batch size at rounding level)', 'bayes', 1, 768, 384,
+                                         steps=50, warmup=5, ones=True, fetch=True, streamk=True)
             guarded(extra_inference, device, 'two-stream SimpleFCN + Bayes fusion 768x384, batch 1, random input', 'bayes', 1,
                                          384, 768, steps=30, warmup=3)
+            guarded(extra_inference, device, 'two-stream SimpleFCN + Bayes fusion 768x384, batch 1, random input, streamk=True',
+                                         'bayes', 1, 384, 768, steps=30, warmup=3, streamk=True)
             guarded(extra_inference, device, 'two-stream SimpleFCN + Dirichlet fusion 768x384 (configs[3] inference side)',
                                          'dirichlet', 16, 384, 768)
             guarded(extra_inference, device, 'BayesFusion of RGB+Depth FCN experts 1024x512 (configs[2])', 'bayes', 8, 512, 1024)

@@ -25,10 +25,15 @@ def expert_factory(expert_model):
 
 def engine_options(config):
     """Extra constructor arguments of the expert engines named by the model config (conv_dtype: the fp8 conv path of
-    the FCN expert; the AdapNet engine has none)."""
-    if config.get('expert_model', 'fcn') == 'fcn' and config.get('conv_dtype', 'bf16') != 'bf16':
-        return {'conv_dtype': config['conv_dtype']}
-    return {}
+    the FCN expert; streamk: its split tail rounds, a batch-1 latency option -- see FcnEngine; the AdapNet engine has
+    none)."""
+    opts = {}
+    if config.get('expert_model', 'fcn') == 'fcn':
+        if config.get('conv_dtype', 'bf16') != 'bf16':
+            opts['conv_dtype'] = config['conv_dtype']
+        if config.get('streamk', False):
+            opts['streamk'] = True
+    return opts
 
 
 def calibrate_experts(model, data):

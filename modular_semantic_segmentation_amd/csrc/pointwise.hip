@@ -463,6 +463,41 @@ __global__ __launch_bounds__(128) void score_lowres_kernel(const __bf16* __restr
 // Kernel 2: one thread per output pixel: 4-tap bilinear interpolation of the CM low-resolution class
 // scores, + bias, softmax, argmax.  The per-pixel pieces are device functions shared with the fused two-expert head
 // (fused_head_kernel), so both paths execute the same arithmetic in the same order: their labels are bit-identical.
+// the four low-resolution score vectors around output pixel (oy, ox) (shared by the 4 output pixels ox = 4m .. 4m + 3:
+// bilinear_taps<8> changes its source column at ox = 4 mod 8 only)
+template <int CM>
+__device__ __forceinline__ void head_load_taps(const float* __restrict__ S, int n, int iy1, int ix1, int Hi, int Wi,
+                                               f32x4 (&a)[CM / 4], f32x4 (&b)[CM / 4], f32x4 (&c)[CM / 4], f32x4 (&d)[CM / 4]) {
+  // padded coords: logical source (iy1-1, ix1-1) is padded (iy1, ix1)
+  const float* p00 = S + (((int64_t)n * (Hi + 2) + iy1) * (Wi + 2) + ix1) * CM;
+  const int64_t rowp = (int64_t)(Wi + 2) * CM;
+#pragma unroll
+  for (int k4 = 0; k4 < CM / 4; ++k4) {
+    a[k4] = *reinterpret_cast<const f32x4*>(p00 + 4 * k4);
+    b[k4] = *reinterpret_cast<const f32x4*>(p00 + CM + 4 * k4);
+    c[k4] = *reinterpret_cast<const f32x4*>(p00 + rowp + 4 * k4);
+    d[k4] = *reinterpret_cast<const f32x4*>(p00 + rowp + CM + 4 * k4);
+  }
+}
+
+// logits of one output pixel from its taps: explicit fmaf chain (shared by the unfused and the fused head: identical
+// bits by construction), then the bias
+template <int CM>
+__device__ __forceinline__ void head_eval_taps(const f32x4 (&a)[CM / 4], const f32x4 (&b)[CM / 4], const f32x4 (&c)[CM / 4],
+                                               const f32x4 (&d)[CM / 4], float wy1, float wy0, float wx1, float wx0,
+                                               const float* __restrict__ bs_g, int C, float (&sc)[CM]) {
+  const float w00 = wy0 * wx0, w01 = wy0 * wx1, w10 = wy1 * wx0, w11 = wy1 * wx1;
+#pragma unroll
+  for (int k4 = 0; k4 < CM / 4; ++k4) {
+    sc[4 * k4] = fmaf(d[k4].x, w11, fmaf(c[k4].x, w10, fmaf(b[k4].x, w01, a[k4].x * w00)));
+    sc[4 * k4 + 1] = fmaf(d[k4].y, w11, fmaf(c[k4].y, w10, fmaf(b[k4].y, w01, a[k4].y * w00)));
+    sc[4 * k4 + 2] = fmaf(d[k4].z, w11, fmaf(c[k4].z, w10, fmaf(b[k4].z, w01, a[k4].z * w00)));
+    sc[4 * k4 + 3] = fmaf(d[k4].w, w11, fmaf(c[k4].w, w10, fmaf(b[k4].w, w01, a[k4].w * w00)));
+  }
+#pragma unroll
+  for (int k = 0; k < CM; ++k) sc[k] += bs_g[k < C ? k : C - 1];
+}
+
 template <int CM>
 __device__ __forceinline__ void head_logits(const float* __restrict__ S, const float* __restrict__ bs_g, int n, int oy, int ox,
                                             int Hi, int Wi, int C, float (&sc)[CM]) {
@@ -470,22 +505,9 @@ __device__ __forceinline__ void head_logits(const float* __restrict__ S, const f
   float wy1, wy0, wx1, wx0;
   bilinear_taps<8>(oy, iy1, wy1, wy0);
   bilinear_taps<8>(ox, ix1, wx1, wx0);
-  const float w00 = wy0 * wx0, w01 = wy0 * wx1, w10 = wy1 * wx0, w11 = wy1 * wx1;
-  // padded coords: logical source (iy1-1, ix1-1) is padded (iy1, ix1)
-  const float* p00 = S + (((int64_t)n * (Hi + 2) + iy1) * (Wi + 2) + ix1) * CM;
-  const int64_t rowp = (int64_t)(Wi + 2) * CM;
-#pragma unroll
-  for (int k4 = 0; k4 < CM; k4 += 4) {
-    const f32x4 a = *reinterpret_cast<const f32x4*>(p00 + k4), b = *reinterpret_cast<const f32x4*>(p00 + CM + k4);
-    const f32x4 c = *reinterpret_cast<const f32x4*>(p00 + rowp + k4), d = *reinterpret_cast<const f32x4*>(p00 + rowp + CM + k4);
-    // explicit fmaf chain (shared by the unfused and the fused head: identical bits by construction)
-    sc[k4] = fmaf(d.x, w11, fmaf(c.x, w10, fmaf(b.x, w01, a.x * w00)));
-    sc[k4 + 1] = fmaf(d.y, w11, fmaf(c.y, w10, fmaf(b.y, w01, a.y * w00)));
-    sc[k4 + 2] = fmaf(d.z, w11, fmaf(c.z, w10, fmaf(b.z, w01, a.z * w00)));
-    sc[k4 + 3] = fmaf(d.w, w11, fmaf(c.w, w10, fmaf(b.w, w01, a.w * w00)));
-  }
-#pragma unroll
-  for (int k = 0; k < CM; ++k) sc[k] += bs_g[k < C ? k : C - 1];
+  f32x4 a[CM / 4], b[CM / 4], c[CM / 4], d[CM / 4];
+  head_load_taps<CM>(S, n, iy1, ix1, Hi, Wi, a, b, c, d);
+  head_eval_taps<CM>(a, b, c, d, wy1, wy0, wx1, wx0, bs_g, C, sc);
 }
 
 template <int CM>
@@ -578,7 +600,7 @@ __global__ __launch_bounds__(256) void decoder_head_kernel(const float* __restri
 // probability maps, 2 x 4C B per pixel each way).  The fusion arithmetic is the one of fusion.hip's kernels, term for
 // term, on the values the unfused path would have stored.  Tables in LDS: tab [2][C][CM], lognorm [2][CM] (Dirichlet),
 // logprior [CM].
-template <int CM, int DIRICHLET>
+template <int CM, int DIRICHLET, int P = (DIRICHLET ? 1 : 4)>
 __global__ __launch_bounds__(256) void fused_head_kernel(const float* __restrict__ Sa, const float* __restrict__ Sb,
                                                         const float* __restrict__ ba, const float* __restrict__ bb, int N,
                                                         int Hi, int Wi, int C, const float* __restrict__ tab_g,
@@ -597,58 +619,91 @@ __global__ __launch_bounds__(256) void fused_head_kernel(const float* __restrict
   }
   if (threadIdx.x < CM) lp[threadIdx.x] = threadIdx.x < C ? logprior_g[threadIdx.x] : 0.f;
   __syncthreads();
-  const int Ho = Hi * 8, Wo = Wi * 8;
-  const int64_t npix = (int64_t)N * Ho * Wo;
-  const int64_t opix = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (opix >= npix) return;
-  const int ox = (int)(opix % Wo);
-  const int oy = (int)((opix / Wo) % Ho);
-  const int n = (int)(opix / ((int64_t)Wo * Ho));
-  float total[CM];
+  // Bayes: one thread = P = FOUR consecutive output pixels ox = 4m .. 4m + 3: they share their four low-resolution source
+  // vectors (24 16-byte loads per expert pair instead of 96) and leave as two 16-byte stores: 71.8 -> 54.6 us for 37.7 MB
+  // at 16 images of 768x384 (profiles/r3_elementwise.json: not HBM-bound, 0.10 of the HBM rate: the per-pixel argmax
+  // chains and the lane-varying table reads in LDS remain).  Dirichlet (24 logs + 288 FMAs per pixel, 48 more live
+  // registers per extra pixel) keeps one pixel per thread: four measured 14 % slower.
+  const int Ho = Hi * 8, Wo = Wi * 8, Wq = Wo / P;
+  const int64_t nquads = (int64_t)N * Ho * Wq;
+  const int64_t quad = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (quad >= nquads) return;
+  const int ox0 = (int)(quad % Wq) * P;
+  const int oy = (int)((quad / Wq) % Ho);
+  const int n = (int)(quad / ((int64_t)Wq * Ho));
+  int iy1, ix1;
+  float wy1, wy0;
+  bilinear_taps<8>(oy, iy1, wy1, wy0);
+  float total[P][CM];
 #pragma unroll
   for (int e = 0; e < 2; ++e) {
-    float sc[CM];
-    head_logits<CM>(e == 0 ? Sa : Sb, e == 0 ? ba : bb, n, oy, ox, Hi, Wi, C, sc);
-    const float m = head_max<CM>(sc, C);
-    if (!DIRICHLET) {
-      int l = head_label_fast<CM>(sc, m, C);
-      if (l < 0) l = head_softmax<CM>(sc, m, C);
-      const float* row = tab + ((int64_t)e * C + l) * CM;
+    f32x4 ta[CM / 4], tb[CM / 4], tc[CM / 4], td[CM / 4];
+    {
+      float u1, u0;
+      bilinear_taps<8>(ox0, ix1, u1, u0);
+    }
+    head_load_taps<CM>(e == 0 ? Sa : Sb, n, iy1, ix1, Hi, Wi, ta, tb, tc, td);
 #pragma unroll
-      for (int k = 0; k < CM; ++k) total[k] = e == 0 ? row[k] : total[k] + row[k];
-    } else {
-      head_softmax<CM>(sc, m, C);  // sc = the probabilities the unfused path stores
-      float sum = 0.f;
+    for (int p = 0; p < P; ++p) {
+      int ixp;
+      float wx1, wx0;
+      bilinear_taps<8>(ox0 + p, ixp, wx1, wx0);
+      float sc[CM];
+      head_eval_taps<CM>(ta, tb, tc, td, wy1, wy0, wx1, wx0, e == 0 ? ba : bb, C, sc);
+      const float m = head_max<CM>(sc, C);
+      if (!DIRICHLET) {
+        int l = head_label_fast<CM>(sc, m, C);
+        if (l < 0) l = head_softmax<CM>(sc, m, C);
+        const float* row = tab + ((int64_t)e * C + l) * CM;
 #pragma unroll
-      for (int k = 0; k < CM; ++k) {
-        sc[k] = k < C ? sc[k] : 0.f;
-        sum += sc[k];
-      }
+        for (int k = 0; k < CM; ++k) total[p][k] = e == 0 ? row[k] : total[p][k] + row[k];
+      } else {
+        head_softmax<CM>(sc, m, C);  // sc = the probabilities the unfused path stores
+        float sum = 0.f;
 #pragma unroll
-      for (int k = 0; k < CM; ++k) sc[k] = k < C ? logf(1e-20f + sc[k] / sum) : 0.f;  // renormalise, then log(1e-20 + p)
-      for (int c = 0; c < C; ++c) {
-        const float* row = tab + ((int64_t)e * C + c) * CM;
-        float dot = 0.f;
+        for (int k = 0; k < CM; ++k) {
+          sc[k] = k < C ? sc[k] : 0.f;
+          sum += sc[k];
+        }
 #pragma unroll
-        for (int k = 0; k < CM; ++k) dot = fmaf(row[k], sc[k], dot);  // as dirichlet_fuse_kernel, bit for bit
-        const float L = dot - ln[e * CM + c];
+        for (int k = 0; k < CM; ++k) sc[k] = k < C ? logf(1e-20f + sc[k] / sum) : 0.f;  // renormalise, then log(1e-20 + p)
+        for (int c = 0; c < C; ++c) {
+          const float* row = tab + ((int64_t)e * C + c) * CM;
+          float dot = 0.f;
 #pragma unroll
-        for (int cc = 0; cc < CM; ++cc)
-          if (cc == c) total[cc] = e == 0 ? L : total[cc] + L;
+          for (int k = 0; k < CM; ++k) dot = fmaf(row[k], sc[k], dot);  // as dirichlet_fuse_kernel, bit for bit
+          const float L = dot - ln[e * CM + c];
+#pragma unroll
+          for (int cc = 0; cc < CM; ++cc)
+            if (cc == c) total[p][cc] = e == 0 ? L : total[p][cc] + L;
+        }
       }
     }
   }
-  float best = 0.f;
-  int bi = 0;
+  int64_t out[P];
 #pragma unroll
-  for (int k = 0; k < CM; ++k) {
-    const float v = total[k] + lp[k];
-    if (k < C && (k == 0 || v > best)) {
-      best = v;
-      bi = k;
+  for (int p = 0; p < P; ++p) {
+    float best = 0.f;
+    int bi = 0;
+#pragma unroll
+    for (int k = 0; k < CM; ++k) {
+      const float v = total[p][k] + lp[k];
+      if (k < C && (k == 0 || v > best)) {
+        best = v;
+        bi = k;
+      }
     }
+    out[p] = bi;
   }
-  fused[opix] = bi;
+  int64_t* dst = fused + (quad * P);
+  if constexpr (P == 4) {
+    typedef __attribute__((ext_vector_type(2))) long long i64x2;
+    *reinterpret_cast<i64x2*>(dst) = i64x2{out[0], out[1]};
+    *reinterpret_cast<i64x2*>(dst + 2) = i64x2{out[2], out[3]};
+  } else {
+#pragma unroll
+    for (int p = 0; p < P; ++p) dst[p] = out[p];
+  }
 }
 
 // ---- softmax + argmax on dense fp32 scores (basic_fusion_model.py:21-22) -------------------------
@@ -1055,8 +1110,10 @@ extern "C" int xv_fused_head_fwd(const float* Sa, const float* Sb, const float* 
                                  const float* logprior, int64_t* fused_label, void* stream) {
   XV_CHECK_ARG(Sa && Sb && bias_a && bias_b && tab && logprior && fused_label && (mode == 0 || (mode == 1 && lognorm)));
   XV_CHECK_SHAPE(n > 0 && hi > 0 && wi > 0 && num_classes >= 1 && num_classes <= 32);
-  const int64_t npix = (int64_t)n * hi * 8 * wi * 8;
-  const unsigned grid = (unsigned)((npix + 255) / 256);
+  // threads: four output pixels each (Bayes), one (Dirichlet) -- see fused_head_kernel
+  const int64_t nthreads = (int64_t)n * hi * 8 * wi * (mode == 0 ? 2 : 8);
+  XV_CHECK_ARG(((uintptr_t)fused_label & 15) == 0);
+  const unsigned grid = (unsigned)((nthreads + 255) / 256);
   hipStream_t s = (hipStream_t)stream;
 #define XV_FH(CMV)                                                                                                      \
   {                                                                                                                     \

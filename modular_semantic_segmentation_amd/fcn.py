@@ -85,13 +85,19 @@ def _fold_bn(variables, layer, kernel, bias):
 class FcnEngine(object):
     """One FCN expert resident on one GPU (inference graph of simple_fcn.py:137-170)."""
 
-    def __init__(self, prefix, in_channels, num_units, num_classes, variables, device='cuda', conv_dtype='bf16'):
+    def __init__(self, prefix, in_channels, num_units, num_classes, variables, device='cuda', conv_dtype='bf16',
+                 streamk=False):
         self.prefix, self.cin, self.U, self.C = prefix, int(in_channels), int(num_units), int(num_classes)
         self.device = torch.device(device)
         self.Up = ((self.U + 63) // 64) * 64      # score convs run on the MFMA kernel: pad U to 64 lanes of zeros
         if conv_dtype not in ('bf16', 'fp8'):
             raise ValueError("conv_dtype must be 'bf16' or 'fp8'")
         self.conv_dtype = conv_dtype
+        # streamk: hand the 3x3 convs a stream-K workspace (ops.streamk_workspace) -- the kernel then splits the tiles of an
+        # incomplete last round over idle CUs where that pays (conv5_x at one image: 46 -> 27 us).  Off by default: which
+        # tiles are split depends on the batch size, so an image's logits would no longer be bit-identical alone and in a
+        # batch (different fp32 groupings; still bitwise reproducible run to run).  A latency option for batch 1.
+        self.streamk = bool(streamk)
         self.fp8_scales = None                    # {map name: power-of-two exponent}, set by calibrate()
         # MC dropout (simple_fcn.py:50-62,71-78,124-126; only the uncertainty models enable it): sites after which
         # tf.layers.dropout(training=True) is applied -- 'pool3', 'conv4_3', 'conv5_3' in the encoder, 'features' for the
@@ -185,6 +191,8 @@ class FcnEngine(object):
     def _sk(self):
         """This engine's stream-K workspace (ops.streamk_workspace: arrival counters + partial-tile slabs of the
         generation-2 conv kernel's tail round).  One per engine: the two experts of a fusion model run on two streams."""
+        if not self.streamk:
+            return None
         ws = self._arena.get('streamk_ws')
         if ws is None:
             ws = self._arena['streamk_ws'] = ops.streamk_workspace(self.device)

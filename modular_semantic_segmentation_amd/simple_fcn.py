@@ -76,7 +76,8 @@ class SimpleFCN(BaseModel):
                                         seed=self.config.get('seed'))
         self.engine = FcnEngine(self.prefix, self.in_channels, self.config['num_units'],
                                 self.config['num_classes'], self.variables, device=self.device,
-                                conv_dtype=self.config.get('conv_dtype', 'bf16'))
+                                conv_dtype=self.config.get('conv_dtype', 'bf16'),
+                                streamk=self.config.get('streamk', False))
         self.loss = None            # scalar of the last training step (set by _train_batch)
         self.prediction = 'label'   # name of the engine output that is the model's prediction
 

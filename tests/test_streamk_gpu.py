@@ -175,14 +175,15 @@ def test_streamk_engine_matches_plain_engine(ops):
         if k.endswith('/kernel') and 'upscore' not in k and 'conv1_1' not in k:
             w[k] *= 1.6
     x = torch.from_numpy(np.random.default_rng(0).integers(0, 256, (1, 384, 768, 3)).astype(np.float32)).cuda()
-    eng = FcnEngine('rgb', 3, 64, 12, w)
+    eng = FcnEngine('rgb', 3, 64, 12, w, streamk=True)
     a = eng.forward(x, want=('score', 'label'))
     sa, la = a['score'].clone(), a['label'].clone()
     again = eng.forward(x, want=('score', 'label'))
     torch.cuda.synchronize()
     assert torch.equal(again['score'], sa) and torch.equal(again['label'], la)        # reproducible
     assert not _counters(eng._sk()).any()
-    eng._sk = lambda: None
+    assert FcnEngine('rgb', 3, 64, 12, w)._sk() is None           # off by default: results independent of the batch
+    eng.streamk = False
     b = eng.forward(x, want=('score', 'label'))
     torch.cuda.synchronize()
     scale = float(b['score'].abs().max())
