@@ -305,6 +305,11 @@ int xv_bias_grad(const xv_act* dy, float* dbias, void* stream);
  * dbias[64] += sum_pixels dy (may be NULL).                                                         */
 int xv_conv2d_first_bwd_filter(const float* x, int n, int h, int w, int cin, const xv_act* dy, float* dw_hwio,
                                float* dbias, void* stream);
+/* The same with per-workgroup partial sums in `workspace` (xv_conv2d_first_bwd_filter_workspace_bytes) and a fixed-order
+ * reduce instead of fp32 atomics: bitwise reproducible.  dbias must not be NULL.  NULL workspace = the plain form.       */
+size_t xv_conv2d_first_bwd_filter_workspace_bytes(int n, int h, int w, int cin);
+int xv_conv2d_first_bwd_filter_ws(const float* x, int n, int h, int w, int cin, const xv_act* dy, float* dw_hwio,
+                                  float* dbias, void* workspace, size_t workspace_bytes, void* stream);
 
 /* MaxPoolGrad + ReluGrad: dy = dpooled routed to the first maximum of each 2x2 window, zero where y <= 0. */
 int xv_maxpool2x2_bwd(const xv_act* y, const xv_act* dpooled, const xv_act* dy, void* stream);

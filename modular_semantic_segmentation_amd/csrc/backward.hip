@@ -176,10 +176,8 @@ __global__ __launch_bounds__(256) void head_loss_kernel(const float* __restrict_
                                                        const int32_t* __restrict__ labels,
                                                        const unsigned long long* __restrict__ count, int N, int Hi,
                                                        int Wi, int C, double* __restrict__ loss, float* __restrict__ dbs,
-                                                       float* __restrict__ P) {
-  __shared__ float red[CM + 1];
-  if (threadIdx.x <= CM) red[threadIdx.x] = 0.f;
-  __syncthreads();
+                                                       float* __restrict__ P, float* __restrict__ part_out) {
+  __shared__ float red[4][CM + 1];
   const int Ho = Hi * 8, Wo = Wi * 8;
   const int64_t ncols = (int64_t)N * Hi * Wo;
   float part[CM], lossterm = 0.f;
@@ -265,15 +263,44 @@ __global__ __launch_bounds__(256) void head_loss_kernel(const float* __restrict_
 #pragma unroll
     for (int k = 0; k < CM; ++k) part[k] += __shfl_xor(part[k], off, 64);
   }
+  // (the butterfly leaves the same bits in every lane: xor exchanges add the two halves in both orders, a + b == b + a)
   if ((threadIdx.x & 63) == 0) {
-    atomicAdd(&red[CM], lossterm);
+    red[threadIdx.x >> 6][CM] = lossterm;
 #pragma unroll
-    for (int k = 0; k < CM; ++k)
-      if (k < C) atomicAdd(&red[k], part[k]);
+    for (int k = 0; k < CM; ++k) red[threadIdx.x >> 6][k] = part[k];
   }
   __syncthreads();
-  if (threadIdx.x < C && red[threadIdx.x] != 0.f) atomicAdd(&dbs[threadIdx.x], red[threadIdx.x]);
-  if (threadIdx.x == 0 && red[CM] != 0.f) atomicAdd(loss, (double)red[CM]);
+  if (threadIdx.x <= CM) {
+    // the four waves in a fixed order; then this workgroup's partial sums go to its own row of `part_out`, which
+    // partials_reduce_kernel adds up in workgroup order (bitwise reproducible loss and bias gradient) -- or, without
+    // that buffer, straight into the results with atomics
+    const float v = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
+    if (part_out != nullptr)
+      part_out[(int64_t)blockIdx.x * (CM + 1) + threadIdx.x] = v;
+    else if (threadIdx.x < C && v != 0.f)
+      atomicAdd(&dbs[threadIdx.x], v);
+    else if (threadIdx.x == CM && v != 0.f)
+      atomicAdd(loss, (double)v);
+  }
+}
+
+// out[i] += sum_b part[b][i] for i < n_out, out64 += sum_b part[b][i64] (a loss): 16 lanes per element each take every
+// 16th row, then a butterfly -- a fixed tree, so the sums are bitwise reproducible (as head_dws_reduce_kernel)
+__global__ __launch_bounds__(256) void partials_reduce_kernel(const float* __restrict__ part, int nblocks, int len,
+                                                             float* __restrict__ out, int n_out, double* __restrict__ out64,
+                                                             int i64) {
+  const int i = blockIdx.x * 16 + (threadIdx.x >> 4), sub = threadIdx.x & 15;
+  const bool live = i < len;
+  double a = 0.0;  // (fp32 terms in a double accumulator: exact enough for the loss, rounded once for the gradients)
+  if (live)
+    for (int b = sub; b < nblocks; b += 16) a += (double)part[(int64_t)b * len + i];
+#pragma unroll
+  for (int off = 8; off >= 1; off >>= 1) a += __shfl_xor(a, off, 64);
+  if (!live || sub != 0) return;
+  if (i < n_out)
+    out[i] += (float)a;
+  else if (out64 != nullptr && i == i64)
+    *out64 += a;
 }
 
 // Kernel 2, per 1/8-resolution pixel: dS[k] = sum over the 16 footprint columns of wx * (kernel 1's row sums)
@@ -395,7 +422,8 @@ __global__ __launch_bounds__(256) void head_dws_reduce_kernel(const float* __res
 template <int CIN>
 __global__ __launch_bounds__(256) void conv_first_wgrad_kernel(const float* __restrict__ x, const __bf16* __restrict__ dy,
                                                               float* __restrict__ dw, float* __restrict__ db, int N,
-                                                              int H, int W, int chunks_per_block) {
+                                                              int H, int W, int chunks_per_block,
+                                                              float* __restrict__ part_out) {
   constexpr int K = 9 * CIN;
   constexpr int KP = (K + 3) / 4 * 4;  // padded to a multiple of 4 for 16-byte reads
   constexpr int PX = 128;              // pixels per staged chunk
@@ -472,6 +500,22 @@ __global__ __launch_bounds__(256) void conv_first_wgrad_kernel(const float* __re
       }
     }
   }
+  if (part_out != nullptr) {
+    // deterministic: the four waves (pixel quarters) of a channel take turns adding into LDS, then the workgroup's sums go
+    // to its own row of `part_out` ([K + 1][64], row K = the bias) for partials_reduce_kernel
+    __syncthreads();
+    float* red = ins;  // PX * KP >= (K + 1) * 64 floats
+    for (int w = 0; w < 4; ++w) {
+      if (wv == w) {
+#pragma unroll
+        for (int t = 0; t < K; ++t) red[t * 64 + co] = w == 0 ? acc[t / 2][t & 1] : red[t * 64 + co] + acc[t / 2][t & 1];
+        red[K * 64 + co] = w == 0 ? bacc : red[K * 64 + co] + bacc;
+      }
+      __syncthreads();
+    }
+    for (int c = threadIdx.x; c < (K + 1) * 64; c += 256) part_out[(int64_t)blockIdx.x * (K + 1) * 64 + c] = red[c];
+    return;
+  }
 #pragma unroll
   for (int t = 0; t < K; ++t) atomicAdd(&dw[t * 64 + co], acc[t / 2][t & 1]);
   if (db != nullptr) atomicAdd(&db[co], bacc);
@@ -522,7 +566,8 @@ __global__ __launch_bounds__(256) void adagrad_kernel(float* __restrict__ p, con
 template <int CIN>
 __global__ __launch_bounds__(512) void conv_first_wgrad_mfma_kernel(const float* __restrict__ x, const __bf16* __restrict__ dy,
                                                                    float* __restrict__ dw, float* __restrict__ db, int N,
-                                                                   int H, int W, int quads_per_wave) {
+                                                                   int H, int W, int quads_per_wave,
+                                                                   float* __restrict__ part_out) {
   constexpr int K = 9 * CIN, TB = (K + 1 + 15) / 16;
   __shared__ float red[TB * 16 * 64];
   for (int c = threadIdx.x; c < TB * 16 * 64; c += 512) red[c] = 0.f;
@@ -601,16 +646,27 @@ __global__ __launch_bounds__(512) void conv_first_wgrad_mfma_kernel(const float*
     }
   }
   __syncthreads();  // red is zeroed
-  // accumulator rows: tap row 16 tb + 4 kq + r, column i of block cb = channel 4 i + cb
+  // accumulator rows: tap row 16 tb + 4 kq + r, column i of block cb = channel 4 i + cb.  The eight waves add their
+  // sums into LDS ONE AFTER THE OTHER (a lane owns its cells within a wave: plain read-modify-write, a fixed order of
+  // the eight terms), and the workgroup's sums go to its own row of `part_out` for partials_reduce_kernel: bitwise
+  // reproducible.  Without that buffer: atomics onto dw / db as before.
+  for (int w = 0; w < 8; ++w) {
+    if (wave == w) {
 #pragma unroll
-  for (int tb = 0; tb < TB; ++tb)
+      for (int tb = 0; tb < TB; ++tb)
 #pragma unroll
-    for (int cb = 0; cb < 4; ++cb)
+        for (int cb = 0; cb < 4; ++cb)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) atomicAdd(&red[(16 * tb + 4 * kq + r) * 64 + 4 * i + cb], acc[tb][cb][r]);
-  __syncthreads();
+          for (int r = 0; r < 4; ++r) red[(16 * tb + 4 * kq + r) * 64 + 4 * i + cb] += acc[tb][cb][r];
+    }
+    __syncthreads();
+  }
   for (int c = threadIdx.x; c < (K + 1) * 64; c += 512) {
     const float v = red[c];
+    if (part_out != nullptr) {
+      part_out[(int64_t)blockIdx.x * (K + 1) * 64 + c] = v;
+      continue;
+    }
     if (v == 0.f) continue;
     if (c < K * 64)
       atomicAdd(dw + c, v);
@@ -670,7 +726,8 @@ extern "C" size_t xv_decoder_head_bwd_workspace_bytes(int n, int h, int w, int n
   // padded low-resolution scores + the row sums of the score gradient (3 target rows x 8w columns per 1/8-resolution
   // row) + one slab of weight-gradient partial sums per 256 low-resolution pixels (up to 256 decoder units)
   const size_t slabs = ((size_t)n * h * w + 255) / 256;
-  return ((size_t)n * (h + 2) * (w + 2) + (size_t)n * h * w * 24 + slabs * 256) * cm * sizeof(float);
+  // + per workgroup of the loss kernel (at most 4096) its partial bias gradient and loss
+  return (((size_t)n * (h + 2) * (w + 2) + (size_t)n * h * w * 24 + slabs * 256) * cm + 4096 * (cm + 1)) * sizeof(float);
 }
 
 extern "C" int xv_score_lowres(const xv_act* fused, const float* w_score, int num_classes, float* S, void* stream);
@@ -699,11 +756,15 @@ extern "C" int xv_decoder_head_bwd(const xv_act* fused, const float* w_score, co
   const unsigned g1 = (unsigned)((ncols + 255) / 256 < 4096 ? (ncols + 255) / 256 : 4096), g2 = (unsigned)((lowres + 255) / 256);
   const int U = fused->c;
   float* dws_part = dscore + (size_t)lowres * 24 * CM;  // g2 slabs of U x CM partial sums (U <= 256: sized by the query above)
+  float* loss_part = dws_part + (size_t)g2 * U * CM;     // g1 rows of CM + 1 partial sums: bias gradient and loss
   const unsigned long long* cnt = reinterpret_cast<const unsigned long long*>(valid_count);
 #define XV_HB(CMV)                                                                                                   \
   {                                                                                                                  \
     hipLaunchKernelGGL(head_loss_kernel<CMV>, dim3(g1), dim3(256), 0, s, (const float*)S, b_score, labels, cnt,       \
-                       fused->n, fused->h, fused->w, num_classes, loss, db_score, dscore);                            \
+                       fused->n, fused->h, fused->w, num_classes, loss, db_score, dscore, loss_part);                 \
+    hipLaunchKernelGGL(partials_reduce_kernel, dim3((CMV + 1 + 15) / 16), dim3(256), 0, s, (const float*)loss_part,   \
+                       (int)g1, CMV + 1,                                                                              \
+                       db_score, num_classes, loss, CMV);                                                             \
     const size_t lds = (size_t)(U * CMV + 256 * CMV) * 4 + (size_t)256 * U * 2;                                       \
     static bool attr[XV_MAX_DEVICES] = {false};                                                                      \
     {                                                                                                                \
@@ -731,18 +792,12 @@ extern "C" int xv_decoder_head_bwd(const xv_act* fused, const float* w_score, co
   return xv_launch_status();
 }
 
-extern "C" int xv_conv2d_first_bwd_filter(const float* x, int n, int h, int w, int cin, const xv_act* dy, float* dw_hwio,
-                                          float* dbias, void* stream) {
-  XV_REQUIRE_BF16(dy);
-  XV_CHECK_ARG(x && dy && dy->data && dw_hwio);
-  XV_CHECK_SHAPE(n > 0 && h > 0 && w > 0 && cin >= 1 && cin <= 4 && dy->n == n && dy->h == h && dy->w == w && dy->c == 64);
-  XV_CHECK_SHAPE((int64_t)n * h * w < 0x7fff0000);
-  const int64_t npix = (int64_t)n * h * w;
-  hipStream_t s = (hipStream_t)stream;
-  const __bf16* g = (const __bf16*)dy->data;
+// grid of the first-layer filter-gradient kernels (shared by the launcher and the workspace query)
+static void first_wgrad_geometry(int64_t npix, int w, int cin, bool& mfma, unsigned& grid, int& per) {
   static const bool use_old = getenv("XV_FIRST_WGRAD_OLD") != nullptr;  // the packed-FMA kernel (A/B timing)
-  if (!use_old && (w & 3) == 0 && npix * cin < 0x7ff00000) {
-    // 4 workgroups of 8 waves per CU (each ends with (9 cin + 1) * 64 same-address atomics: a bounded grid); 16 images at
+  mfma = !use_old && (w & 3) == 0 && npix * cin < 0x7ff00000;
+  if (mfma) {
+    // 4 workgroups of 8 waves per CU (a bounded grid: each ends with (9 cin + 1) * 64 partial sums); 16 images at
     // 768x384: 317 us RGB / 181 us depth (packed-FMA kernel: 537 / 340); widths that are not a multiple of 4 keep that kernel
     const int64_t nquads = (npix + 3) / 4;
     static const int per_cu = getenv("XV_FIRST_WGRAD_PER_CU") ? atoi(getenv("XV_FIRST_WGRAD_PER_CU")) : 4;
@@ -750,26 +805,75 @@ extern "C" int xv_conv2d_first_bwd_filter(const float* x, int n, int h, int w, i
     if (blocks * 8 * 4 > nquads) blocks = (nquads + 31) / 32;
     int64_t qpw = (nquads + blocks * 8 - 1) / (blocks * 8);
     qpw = (qpw + 3) / 4 * 4;
-    const unsigned grid = (unsigned)((nquads + qpw * 8 - 1) / (qpw * 8));
-    switch (cin) {
-      case 1: hipLaunchKernelGGL(conv_first_wgrad_mfma_kernel<1>, dim3(grid), dim3(512), 0, s, x, g, dw_hwio, dbias, n, h, w, (int)qpw); break;
-      case 2: hipLaunchKernelGGL(conv_first_wgrad_mfma_kernel<2>, dim3(grid), dim3(512), 0, s, x, g, dw_hwio, dbias, n, h, w, (int)qpw); break;
-      case 3: hipLaunchKernelGGL(conv_first_wgrad_mfma_kernel<3>, dim3(grid), dim3(512), 0, s, x, g, dw_hwio, dbias, n, h, w, (int)qpw); break;
-      default: hipLaunchKernelGGL(conv_first_wgrad_mfma_kernel<4>, dim3(grid), dim3(512), 0, s, x, g, dw_hwio, dbias, n, h, w, (int)qpw); break;
-    }
-    return xv_launch_status();
+    grid = (unsigned)((nquads + qpw * 8 - 1) / (qpw * 8));
+    per = (int)qpw;
+    return;
   }
-  // at most 512 workgroups: each ends with 9*cin*64 same-address global atomics (see xv_score_dense_bwd)
+  // at most 512 workgroups (see xv_score_dense_bwd)
   int chunks = (int)((npix + 128 * 512 - 1) / (128 * 512));
   if (chunks < 32) chunks = 32;
-  const unsigned grid = (unsigned)((npix + 128 * (int64_t)chunks - 1) / (128 * (int64_t)chunks));
-  switch (cin) {
-    case 1: hipLaunchKernelGGL(conv_first_wgrad_kernel<1>, dim3(grid), dim3(256), 0, s, x, g, dw_hwio, dbias, n, h, w, chunks); break;
-    case 2: hipLaunchKernelGGL(conv_first_wgrad_kernel<2>, dim3(grid), dim3(256), 0, s, x, g, dw_hwio, dbias, n, h, w, chunks); break;
-    case 3: hipLaunchKernelGGL(conv_first_wgrad_kernel<3>, dim3(grid), dim3(256), 0, s, x, g, dw_hwio, dbias, n, h, w, chunks); break;
-    default: hipLaunchKernelGGL(conv_first_wgrad_kernel<4>, dim3(grid), dim3(256), 0, s, x, g, dw_hwio, dbias, n, h, w, chunks); break;
+  grid = (unsigned)((npix + 128 * (int64_t)chunks - 1) / (128 * (int64_t)chunks));
+  per = chunks;
+}
+
+extern "C" size_t xv_conv2d_first_bwd_filter_workspace_bytes(int n, int h, int w, int cin) {
+  if (n <= 0 || h <= 0 || w <= 0 || cin < 1 || cin > 4) return 0;
+  bool mfma;
+  unsigned grid;
+  int per;
+  first_wgrad_geometry((int64_t)n * h * w, w, cin, mfma, grid, per);
+  return (size_t)grid * (9 * cin + 1) * 64 * sizeof(float);
+}
+
+extern "C" int xv_conv2d_first_bwd_filter_ws(const float* x, int n, int h, int w, int cin, const xv_act* dy, float* dw_hwio,
+                                             float* dbias, void* workspace, size_t workspace_bytes, void* stream) {
+  XV_REQUIRE_BF16(dy);
+  XV_CHECK_ARG(x && dy && dy->data && dw_hwio);
+  XV_CHECK_SHAPE(n > 0 && h > 0 && w > 0 && cin >= 1 && cin <= 4 && dy->n == n && dy->h == h && dy->w == w && dy->c == 64);
+  XV_CHECK_SHAPE((int64_t)n * h * w < 0x7fff0000);
+  const int64_t npix = (int64_t)n * h * w;
+  hipStream_t s = (hipStream_t)stream;
+  const __bf16* g = (const __bf16*)dy->data;
+  bool mfma;
+  unsigned grid;
+  int per;
+  first_wgrad_geometry(npix, w, cin, mfma, grid, per);
+  // with a workspace: per-workgroup partial sums + a fixed-order reduce (bitwise reproducible); without: atomics
+  float* part = nullptr;
+  if (workspace != nullptr) {
+    if (workspace_bytes < xv_conv2d_first_bwd_filter_workspace_bytes(n, h, w, cin)) return XV_EWORKSPACE;
+    XV_CHECK_ARG(((uintptr_t)workspace & 15) == 0 && dbias != nullptr);
+    part = (float*)workspace;
+  }
+  if (mfma) {
+    switch (cin) {
+      case 1: hipLaunchKernelGGL(conv_first_wgrad_mfma_kernel<1>, dim3(grid), dim3(512), 0, s, x, g, dw_hwio, dbias, n, h, w, per, part); break;
+      case 2: hipLaunchKernelGGL(conv_first_wgrad_mfma_kernel<2>, dim3(grid), dim3(512), 0, s, x, g, dw_hwio, dbias, n, h, w, per, part); break;
+      case 3: hipLaunchKernelGGL(conv_first_wgrad_mfma_kernel<3>, dim3(grid), dim3(512), 0, s, x, g, dw_hwio, dbias, n, h, w, per, part); break;
+      default: hipLaunchKernelGGL(conv_first_wgrad_mfma_kernel<4>, dim3(grid), dim3(512), 0, s, x, g, dw_hwio, dbias, n, h, w, per, part); break;
+    }
+  } else {
+    switch (cin) {
+      case 1: hipLaunchKernelGGL(conv_first_wgrad_kernel<1>, dim3(grid), dim3(256), 0, s, x, g, dw_hwio, dbias, n, h, w, per, part); break;
+      case 2: hipLaunchKernelGGL(conv_first_wgrad_kernel<2>, dim3(grid), dim3(256), 0, s, x, g, dw_hwio, dbias, n, h, w, per, part); break;
+      case 3: hipLaunchKernelGGL(conv_first_wgrad_kernel<3>, dim3(grid), dim3(256), 0, s, x, g, dw_hwio, dbias, n, h, w, per, part); break;
+      default: hipLaunchKernelGGL(conv_first_wgrad_kernel<4>, dim3(grid), dim3(256), 0, s, x, g, dw_hwio, dbias, n, h, w, per, part); break;
+    }
+  }
+  if (part != nullptr) {
+    // dW [9 cin][64] and db [64] are contiguous rows of a workgroup's partial block: two reduce launches into the two outputs
+    const int len = (9 * cin + 1) * 64;
+    hipLaunchKernelGGL(partials_reduce_kernel, dim3((len + 15) / 16), dim3(256), 0, s, (const float*)part, (int)grid, len,
+                       dw_hwio, 9 * cin * 64, (double*)nullptr, -1);
+    hipLaunchKernelGGL(partials_reduce_kernel, dim3(4), dim3(256), 0, s, (const float*)part + 9 * cin * 64, (int)grid, len,
+                       dbias, 64, (double*)nullptr, -1);
   }
   return xv_launch_status();
+}
+
+extern "C" int xv_conv2d_first_bwd_filter(const float* x, int n, int h, int w, int cin, const xv_act* dy, float* dw_hwio,
+                                          float* dbias, void* stream) {
+  return xv_conv2d_first_bwd_filter_ws(x, n, h, w, cin, dy, dw_hwio, dbias, nullptr, 0, stream);
 }
 
 extern "C" int xv_adam_step(float* param, const float* grad, float* m, float* v, int64_t n, float lr_t, float beta1,

@@ -31,6 +31,7 @@ struct WgradArgs {
   float* db;  // may be null; accumulated by the workgroups of input-channel block 0 from their dY tiles
   float* slab;  // may be null: per-split partial dW slabs [splits][taps][Cin][Cout] (plain stores, reduced by a
                 // second kernel in a fixed order) instead of fp32 atomics straight into dw
+  float* bslab;  // with slab: per-split partial bias gradients [splits][Cout], reduced by the same second kernel
   int N, H, W, Cin, Cout;
   int tiles_x, tiles_y, n_ptiles, splits;
 };
@@ -177,7 +178,18 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradArgs a) {
     }
   }
 
-  if (do_bias) atomicAdd(a.db + co0 + (tid & 63), bsum);
+  if (do_bias) {
+    if (a.bslab != nullptr) {
+      // deterministic: the four pixel quarters of a channel meet in LDS and are added in a fixed order
+      __syncthreads();  // (the last tile's fragments are consumed)
+      float* red = reinterpret_cast<float*>(smem);
+      red[tid] = bsum;
+      __syncthreads();
+      if (tid < 64) a.bslab[(int64_t)split * Cout + co0 + tid] = ((red[tid] + red[64 + tid]) + red[128 + tid]) + red[192 + tid];
+    } else {
+      atomicAdd(a.db + co0 + (tid & 63), bsum);
+    }
+  }
   // accumulator (row = cin = 4*(lane>>4) + r, col = cout = lane & 15) -> dW[tap][cin][cout] (HWIO)
   const int cin = ci0 + wave * 16 + g * 4;
   const int cout = co0 + li;
@@ -352,7 +364,23 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_dma_kernel(WgradArgs a) {
     __syncthreads();  // DMA of tile t+1 has landed and every wave is done with buffer b
   }
 
-  if (do_bias) atomicAdd(a.db + co0 + (tid & 63), bsum);
+  if (do_bias) {
+    if (a.bslab != nullptr) {
+      // deterministic: the eight pixel parts of a channel meet in LDS (both tile buffers are consumed: the loop ends
+      // with a barrier) and are added in a fixed order
+      float* red = reinterpret_cast<float*>(smem);
+      red[tid] = bsum;
+      __syncthreads();
+      if (tid < 64) {
+        float t = red[tid];
+#pragma unroll
+        for (int part = 1; part < 8; ++part) t += red[part * 64 + tid];
+        a.bslab[(int64_t)split * Cout + co0 + tid] = t;
+      }
+    } else {
+      atomicAdd(a.db + co0 + (tid & 63), bsum);
+    }
+  }
   const int cin = ci0 + cb * 16 + g * 4;
   const int cout = co0 + li;
   float* const out = a.slab ? a.slab + (int64_t)split * NTAPS * Cin * Cout : a.dw;
@@ -380,12 +408,17 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_dma_kernel(WgradArgs a) {
 }
 
 // dw[i] += sum_s slab[s][i], splits summed in a fixed order (bitwise reproducible filter gradients)
+// (and db[c] += sum_s bslab[s][c], the bias gradient's partial sums, in the same launch)
 __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw,
-                                                         int64_t n4, int splits) {
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
-    f32x4 s = *reinterpret_cast<const f32x4*>(slab + i * 4);
-    for (int k = 1; k < splits; ++k) s += *reinterpret_cast<const f32x4*>(slab + ((int64_t)k * n4 + i) * 4);
-    f32x4* d = reinterpret_cast<f32x4*>(dw + i * 4);
+                                                         int64_t n4, int splits, const float* __restrict__ bslab,
+                                                         float* __restrict__ db, int cout4) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4 + cout4; i += (int64_t)gridDim.x * 256) {
+    const bool bias = i >= n4;
+    const int64_t j = bias ? i - n4 : i, stride = bias ? cout4 : n4;
+    const float* src = bias ? bslab : slab;
+    f32x4 s = *reinterpret_cast<const f32x4*>(src + j * 4);
+    for (int k = 1; k < splits; ++k) s += *reinterpret_cast<const f32x4*>(src + ((int64_t)k * stride + j) * 4);
+    f32x4* d = reinterpret_cast<f32x4*>((bias ? db : dw) + j * 4);
     *d = *d + s;
   }
 }
@@ -457,7 +490,7 @@ extern "C" size_t xv_conv2d_bwd_filter_workspace_bytes(int n, int h, int w, int 
   int sp = (3 * xv_num_cus() + pairs - 1) / pairs;
   if (sp > ptiles) sp = (int)ptiles;
   if (sp < 1) sp = 1;
-  return (size_t)sp * k * k * cin * cout * sizeof(float);
+  return (size_t)sp * ((size_t)k * k * cin * cout + cout) * sizeof(float);  // dW slabs + bias slabs
 }
 
 extern "C" int xv_conv2d_bwd_filter_ws(const xv_act* x, const xv_act* dy, float* dw_hwio, float* dbias, int k,
@@ -497,13 +530,17 @@ extern "C" int xv_conv2d_bwd_filter_ws(const xv_act* x, const xv_act* dy, float*
   a.splits = splits;
   hipStream_t s = (hipStream_t)stream;
   const int64_t dw_elems = (int64_t)k * k * a.Cin * a.Cout;
-  a.slab = nullptr;
-  // slabs pay off once several (cin, cout) block pairs share the reduce kernel's work; with 1-2 pairs (64-channel
-  // layers) and for the small 1x1 layers the fp32 atomics are faster (tools/conv_tune.py)
-  if (workspace != nullptr && splits > 1 && k == 3 && pairs >= 4) {
-    if (workspace_bytes < (size_t)splits * dw_elems * sizeof(float)) return XV_EWORKSPACE;
+  a.slab = a.bslab = nullptr;
+  // With a workspace EVERY partial sum -- the dW blocks of the pixel splits and the bias gradient's -- goes to slabs that a
+  // second kernel adds in a fixed order: bitwise reproducible gradients.  (Round 2 kept fp32 atomics for the layers with
+  // 1-2 block pairs and for the 1x1 layers, where they are a few per cent faster: XV_WGRAD_ATOMICS=1 restores that for
+  // A/B timing.)  Without a workspace: atomics.
+  static const bool atomics_ok = getenv("XV_WGRAD_ATOMICS") != nullptr;
+  if (workspace != nullptr && !(atomics_ok && !(splits > 1 && k == 3 && pairs >= 4))) {
+    if (workspace_bytes < (size_t)splits * (dw_elems + a.Cout) * sizeof(float)) return XV_EWORKSPACE;
     XV_CHECK_ARG(((uintptr_t)workspace & 15) == 0);
     a.slab = (float*)workspace;
+    a.bslab = dbias != nullptr ? a.slab + (size_t)splits * dw_elems : nullptr;
   }
   auto finish = [&]() -> int {
     int rc = xv_launch_status();
@@ -512,7 +549,7 @@ extern "C" int xv_conv2d_bwd_filter_ws(const xv_act* x, const xv_act* dy, float*
     int64_t blocks = (n4 + 255) / 256;
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (const float*)a.slab, dw_hwio, n4,
-                       splits);
+                       splits, (const float*)a.bslab, dbias, a.bslab != nullptr ? a.Cout / 4 : 0);
     return xv_launch_status();
   };
   if (g_wgrad_variant == 2 && k == 3) {

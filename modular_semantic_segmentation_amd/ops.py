@@ -517,8 +517,8 @@ def conv2d_bwd_filter_workspace_bytes(x, cout, k):
 
 
 def conv2d_bwd_filter(x, dy, dw, dbias, k, workspace=None):
-    """workspace (float32 tensor of >= conv2d_bwd_filter_workspace_bytes): deterministic slab reduction;
-    None: fp32 atomics."""
+    """workspace (float32 tensor of >= conv2d_bwd_filter_workspace_bytes): every partial sum (the pixel splits of dW and
+    of the bias gradient) goes to slabs added in a fixed order -- bitwise reproducible; None: fp32 atomics."""
     _need(dw, torch.float32, 'dw')
     with _Profiled('wgrad_k%d' % k, 2.0 * x.n * x.h * x.w * x.c * dy.c * k * k):
         if workspace is None:
@@ -529,11 +529,22 @@ def conv2d_bwd_filter(x, dy, dw, dbias, k, workspace=None):
     _lib.check(rc, 'xv_conv2d_bwd_filter')
 
 
-def conv2d_first_bwd_filter(x, dy, dw, dbias=None):
+def conv2d_first_bwd_filter(x, dy, dw, dbias=None, workspace=None):
+    """workspace (float32 tensor of >= conv2d_first_bwd_filter_workspace_bytes): per-workgroup partial sums + a
+    fixed-order reduce (bitwise reproducible; needs dbias); None: fp32 atomics."""
     _need(x, torch.float32, 'x')
     n, h, w, cin = x.shape
-    _lib.check(_lib.lib().xv_conv2d_first_bwd_filter(_ptr(x), n, h, w, cin, dy.xv(), _ptr(dw), _ptr(dbias), _stream()),
-               'xv_conv2d_first_bwd_filter')
+    if workspace is None or dbias is None:
+        rc = _lib.lib().xv_conv2d_first_bwd_filter(_ptr(x), n, h, w, cin, dy.xv(), _ptr(dw), _ptr(dbias), _stream())
+    else:
+        rc = _lib.lib().xv_conv2d_first_bwd_filter_ws(_ptr(x), n, h, w, cin, dy.xv(), _ptr(dw), _ptr(dbias), _ptr(workspace),
+                                                      workspace.numel() * 4, _stream())
+    _lib.check(rc, 'xv_conv2d_first_bwd_filter')
+
+
+def conv2d_first_bwd_filter_workspace_bytes(x):
+    n, h, w, cin = x.shape
+    return _lib.lib().xv_conv2d_first_bwd_filter_workspace_bytes(n, h, w, cin)
 
 
 def maxpool2x2_bwd(y, dpooled, dy):

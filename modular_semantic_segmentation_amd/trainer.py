@@ -38,7 +38,7 @@ def encoder_backward(x, L, g, ds4, wd_s4, wd, zero_bias, G, gact, wws, after_lay
     for nm in reversed(names):
         xin = inputs[nm]
         if nm == 'conv1_1':
-            ops.conv2d_first_bwd_filter(x, g, G(nm, 'kernel'), G(nm, 'bias'))
+            ops.conv2d_first_bwd_filter(x, g, G(nm, 'kernel'), G(nm, 'bias'), workspace=wws)
         else:
             ops.conv2d_bwd_filter(L[xin], g, G(nm, 'kernel'), G(nm, 'bias'), 3, workspace=wws)
         if after_layer is not None:
@@ -207,6 +207,7 @@ class FcnTrainer(object):
                 need = max(need, ops.conv2d_bwd_filter_workspace_bytes(L[self._input_of(nm)], self.shapes[nm][1][0], 3))
             for nm, src in (('score_conv4', 'conv4_3'), ('score_conv5', 'conv5_3')):
                 need = max(need, ops.conv2d_bwd_filter_workspace_bytes(L[src], e.Up, 1))
+            need = max(need, ops.conv2d_first_bwd_filter_workspace_bytes(x))
             self._g[wkey] = torch.empty(need // 4, dtype=torch.float32, device=e.device)
         wws = self._g[wkey]
         dfused = self._gact(L['fused'], 'dfused')
@@ -785,6 +786,7 @@ class FusionFcnTrainer(object):
                     prev = pool if pool else nm
                 for src in ('conv4_3', 'conv5_3'):
                     need = max(need, ops.conv2d_bwd_filter_workspace_bytes(L[m][src], e.Up, 1))
+                need = max(need, ops.conv2d_first_bwd_filter_workspace_bytes(inputs[m]))
             self._a[wkey] = torch.empty(max(need // 4, 1), dtype=torch.float32, device=e.device)
         wws = self._a[wkey]
         # ---- backward: fused 1x1 convs block by block, then each trunk ----------------------------------------------

@@ -1,8 +1,11 @@
 #!/usr/bin/env python3
 """Run-to-run comparison of whole training steps: a fresh model + trainer every iteration (fresh allocations, first-step
 code paths), one step on fixed data, then every activation / gradient map the step left in the trainer's arenas is
-compared with the first iteration's: floating-point atomics (batch-norm sums, filter gradients, loss) reorder sums, so
-low-bit differences are expected and counted; anything beyond --tol of a map's largest entry is a defect.  Plain FCN, batch-norm FCN and the joint fusion_fcn model.  GPU box only."""
+compared with the first iteration's.  The PLAIN FCN step (no batch norm) is deterministic by construction since round 3 --
+every partial sum of the filter / bias gradients, the first layer's and the head's goes to slabs added in a fixed order --
+and must agree BIT FOR BIT, loss, gradients and updated parameters included.  The batch-norm and joint steps keep
+floating-point atomics in their statistics (f64) and dense-head reductions: low-bit differences there are expected and
+counted; anything beyond --tol of a map's largest entry is a defect.  GPU box only."""
 import argparse
 import os
 import sys
@@ -36,6 +39,8 @@ def arenas(tr):
             if hasattr(v, 'interior'):
                 out[('arena%d' % i, str(key))] = v.t
     out[('grad', '')] = tr.grad
+    out[('param', '')] = tr.param
+    out[('loss', '')] = tr.loss
     return out
 
 
@@ -64,7 +69,8 @@ def run(kind, it):
     tr = net._ensure_trainer()
     tr.step(inputs, torch.from_numpy(data['labels']).cuda())
     torch.cuda.synchronize()
-    return {k: v.detach().clone().float().cpu() for k, v in arenas(tr).items() if v.dtype in (torch.bfloat16, torch.float32)}
+    return {k: v.detach().clone().double().cpu() for k, v in arenas(tr).items()
+            if v.dtype in (torch.bfloat16, torch.float32, torch.float64)}
 
 
 for kind in ('plain', 'bn', 'joint'):
@@ -82,7 +88,7 @@ for kind in ('plain', 'bn', 'joint'):
                 continue
             scale = want[k].abs().max().item() + 1e-30
             d = (got[k] - want[k]).abs().max().item() / scale
-            if not d <= args.tol:         # also catches NaN
+            if not d <= (0.0 if kind == 'plain' else args.tol):         # also catches NaN; the plain step: bit for bit
                 bad += 1
                 print('MISMATCH', kind, 'iter', it, k, 'max difference %.3g of the largest entry' % d, flush=True)
             elif d > 0:
