@@ -423,6 +423,13 @@ def measure_training(args, device, world, rank, dist, batch, steps, warmup, expe
     ops.CONV_PROFILE = None
     fl = sum(p[1] for p in prof)
     sec = sum(p[2].elapsed_time(p[3]) for p in prof) * 1e-3
+    if getattr(args, 'layer_profile', False) and rank == 0 and prof:
+        per = len(prof) // min(steps, 5)
+        for i in range(per):
+            evs = prof[i::per]
+            ms = sum(e0.elapsed_time(e1) for _, _, e0, e1 in evs) / len(evs)
+            print('  launch %2d %-9s %7.1f GF %8.1f us %7.0f TF/s' % (i, evs[0][0], evs[0][1] / 1e9, ms * 1e3,
+                                                                    evs[0][1] / ms / 1e9), file=sys.stderr)
     if sec > 0:
         by = {}
         for kind, f, e0, e1 in prof:

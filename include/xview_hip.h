@@ -272,6 +272,17 @@ int xv_average_fuse(const float* const* probs, int num_experts, int num_classes,
 
 /* Packed weights of the data-gradient convolution: Wd[k*k-1-tap][co][ci] = W[tap][ci][co]
  * (xv_packed_weight_bytes(k, cout, cin) bytes).                                                     */
+/* All kernels of a model in one launch (the re-pack after every optimizer step): `table_device` = n descriptors in DEVICE
+ * memory; packed_dgrad may be NULL per entry.  Shapes as xv_pack_conv_weights / _dgrad (k in {1, 3}, cin, cout % 64 == 0). */
+typedef struct xv_pack_desc {
+  const float* w_hwio;
+  void* packed;
+  void* packed_dgrad;
+  int32_t k, cin, cout, reserved;
+} xv_pack_desc;
+int xv_pack_conv_weights_multi(const xv_pack_desc* table_device, int n, void* stream);
+/* hipMemsetAsync(p, 0, bytes) on `stream`: the step's own clear of its gradient / loss accumulators (no framework kernel). */
+int xv_memset_zero(void* p, size_t bytes, void* stream);
 int xv_pack_conv_weights_dgrad(const float* w_hwio, void* packed, int k, int cin, int cout, void* stream);
 
 /* dx = (conv(dy, Wd) + addend) * (relu_ref > 0): Conv2DBackpropInput of tf.layers.conv2d, the AddN

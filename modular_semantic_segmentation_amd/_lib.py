@@ -22,6 +22,11 @@ class xv_act(ctypes.Structure):
                 ('scale_exp', ctypes.c_int32)]
 
 
+class xv_pack_desc(ctypes.Structure):
+    _fields_ = [('w_hwio', ctypes.c_void_p), ('packed', ctypes.c_void_p), ('packed_dgrad', ctypes.c_void_p),
+                ('k', ctypes.c_int32), ('cin', ctypes.c_int32), ('cout', ctypes.c_int32), ('reserved', ctypes.c_int32)]
+
+
 _vp, _i, _i64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64
 _actp = ctypes.POINTER(xv_act)
 _vpp = ctypes.POINTER(ctypes.c_void_p)
@@ -71,6 +76,8 @@ SIGNATURES = {
     'xv_dirichlet_fuse': (_i, [_vpp, _i, _vp, _vp, _vp, _i, _i64, _vp, _vp, _vp]),
     'xv_average_fuse': (_i, [_vpp, _i, _i, _i64, _vp, _vp]),
     'xv_pack_conv_weights_dgrad': (_i, [_vp, _vp, _i, _i, _i, _vp]),
+    'xv_pack_conv_weights_multi': (_i, [_vp, _i, _vp]),
+    'xv_memset_zero': (_i, [_vp, ctypes.c_size_t, _vp]),
     'xv_conv2d_bwd_data': (_i, [_actp, _vp, _vp, _actp, _actp, _actp, _i, _vp]),
     'xv_conv2d_bwd_filter': (_i, [_actp, _actp, _vp, _vp, _i, _vp]),
     'xv_set_wgrad_variant': (_i, [_i]),

@@ -1826,6 +1826,20 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, __bf16* __restr
   }
 }
 
+// Every layer of a model in ONE launch (the optimizer step re-packs all kernels: 18 launches of ~12 us each were 2 % of a
+// training step): blockIdx.y = table entry, blockIdx.x strides over that kernel's elements
+__global__ void pack_weights_multi_kernel(const xv_pack_desc* __restrict__ table) {
+  const xv_pack_desc d = table[blockIdx.y];
+  const int taps = d.k * d.k;
+  const int64_t total = (int64_t)taps * d.cin * d.cout;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    pack_weights_image(d.w_hwio, reinterpret_cast<__bf16*>(d.packed), taps, d.cin, d.cout, 0, idx, total);
+    if (d.packed_dgrad != nullptr)
+      pack_weights_image(d.w_hwio, reinterpret_cast<__bf16*>(d.packed_dgrad), taps, d.cin, d.cout, 1, idx, total);
+  }
+}
+
 // fp8 image: [256-byte header][tap][cin/128][cout][128 B, 16-byte slots swizzled by xv_swz]; one thread = 4 bytes
 __global__ void pack_weights_f8_kernel(const float* __restrict__ w, char* __restrict__ out, int taps, int cin, int cout,
                                        int scale_exp, float mul) {
@@ -2106,6 +2120,18 @@ extern "C" int xv_pack_conv_weights_pair(const float* w_hwio, void* packed, void
   hipLaunchKernelGGL(pack_weights_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w_hwio, (__bf16*)packed,
                      k * k, cin, cout, 0, (__bf16*)packed_dgrad);
   return xv_launch_status();
+}
+
+extern "C" int xv_pack_conv_weights_multi(const xv_pack_desc* table_device, int n, void* stream) {
+  XV_CHECK_ARG(table_device != nullptr && n > 0 && n <= 65535);
+  hipLaunchKernelGGL(pack_weights_multi_kernel, dim3(96, (unsigned)n), dim3(256), 0, (hipStream_t)stream, table_device);
+  return xv_launch_status();
+}
+
+extern "C" int xv_memset_zero(void* p, size_t bytes, void* stream) {
+  XV_CHECK_ARG(p != nullptr);
+  const hipError_t e = hipMemsetAsync(p, 0, bytes, (hipStream_t)stream);
+  return e == hipSuccess ? XV_OK : (int)e;
 }
 
 extern "C" int xv_pack_conv_weights_dgrad(const float* w_hwio, void* packed, int k, int cin, int cout, void* stream) {

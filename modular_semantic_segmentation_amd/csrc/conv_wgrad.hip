@@ -262,45 +262,89 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_dma_kernel(WgradArgs a) {
 #pragma unroll
   for (int n = 0; n < 4; ++n) dbase[n] = X_BYTES + xk * 128 + (xv_swz(xk, n * 2 + (p >> 1)) << 4) + (p & 1) * 8;
 
-  // issue the LDS-DMA of pixel tile t into buffer b: instruction i of the tile is done by wave i % 8
-  auto stage = [&](int t, int b) {
+  // LDS-DMA of a pixel tile: 1-KB piece i of the tile (X patch pieces 0 .. XI-1, then the dY pieces) is moved by wave
+  // i % 8, i.e. this wave moves pieces wave + 8 j, j < NJ.  Their per-lane source offsets relative to the tile's origin
+  // do not depend on the tile (except on the image's right / bottom edge, where coordinates are clamped onto the zero
+  // border), so they are computed ONCE -- the ~20 integer instructions per piece used to run, for all ~10 pieces of a
+  // wave in one burst, at the start of every tile, in front of its first MFMA.  The pieces of tile t+1 are issued one per
+  // image row of tile t (the CU's vector-memory pipe takes a piece every ~25 cycles and a wave whose DMA does not fit its
+  // queue stalls in order, MFMAs included: the forward kernel's lesson).
+  constexpr int NJ = (XI + DI + 7) / 8;
+  int voff[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int i = wave + 8 * j;
+    if (i < XI) {
+      int idx = i * 64 + lane;  // 16-byte piece of the patch image: pixel idx>>3, PHYSICAL slot idx&7
+      idx = idx < NPIX * 8 ? idx : NPIX * 8 - 1;
+      const int pp = idx >> 3, ps = idx & 7;
+      const int hy = pp / HW, hx = pp - hy * HW;
+      voff[j] = ((hy * Wp + hx) * Cin + xv_swz(hx, ps) * 8) * 2;  // logical slot stored at this physical slot (involution)
+    } else {
+      const int idx = (i - XI) * 64 + lane;
+      const int pp = idx >> 3, ps = idx & 7;
+      const int py = pp / TW, px = pp - py * TW;
+      voff[j] = ((py * Wp + px) * Cout + xv_swz(px, ps) * 8) * 2;
+    }
+  }
+  struct TileSrc {
+    const __bf16 *xt, *dt;  // origins of the tile's X patch / dY tile (padded coordinates)
+    int y0, x0;
+    bool edge;
+  };
+  auto tile_src = [&](int t) {
     const int tx = t % a.tiles_x;
     int r = t / a.tiles_x;
     const int ty = r % a.tiles_y;
     const int n = r / a.tiles_y;
-    const int y0 = ty * TH, x0 = tx * TW;
+    TileSrc ts;
+    ts.y0 = ty * TH;
+    ts.x0 = tx * TW;
+    ts.edge = ts.y0 + TH > H || ts.x0 + TW > W;
     const __bf16* ximg = a.x + (int64_t)n * (H + 2) * Wp * Cin + ci0;
     const __bf16* dimg = a.dy + (int64_t)n * (H + 2) * Wp * Cout + co0;
-    for (int i = wave; i < XI + DI; i += 8) {
-      if (i < XI) {
-        int idx = i * 64 + lane;  // 16-byte piece of the patch image: pixel idx>>3, PHYSICAL slot idx&7
+    ts.xt = ximg + ((int64_t)(ts.y0 + 1 - HALO) * Wp + (ts.x0 + 1 - HALO)) * Cin;
+    ts.dt = dimg + ((int64_t)(ts.y0 + 1) * Wp + (ts.x0 + 1)) * Cout;
+    return ts;
+  };
+  // piece wave + 8 j of a tile into buffer b (in assembly, SGPR base + 32-bit lane offset: the builtin makes hipcc model
+  // a FLAT access, after which every LDS wait it inserts is lgkmcnt(0) instead of a counted one)
+  auto stage_piece = [&](const TileSrc& ts, int j, int b) {
+    const int i = wave + 8 * j;
+    if (i >= XI + DI) return;
+    int off = voff[j];
+    const bool isx = i < XI;
+    if (ts.edge) {
+      // right / bottom edge of the image: coordinates past it are clamped onto the zero border (rare path: the offset is
+      // re-derived from the lane number here instead of living in registers)
+      int ln = lane;
+      asm volatile("" : "+v"(ln));
+      if (isx) {
+        int idx = i * 64 + ln;
         idx = idx < NPIX * 8 ? idx : NPIX * 8 - 1;
         const int pp = idx >> 3, ps = idx & 7;
         const int hy = pp / HW, hx = pp - hy * HW;
-        const int s = xv_swz(hx, ps);  // logical slot stored at this physical slot (involution)
-        int yy = y0 + hy + (1 - HALO), xx = x0 + hx + (1 - HALO);
-        yy = yy < H + 1 ? yy : H + 1;
-        xx = xx < W + 1 ? xx : W + 1;
-        // in assembly (SGPR base + 32-bit lane offset): the builtin makes hipcc model a FLAT access, after which
-        // every LDS wait it inserts is lgkmcnt(0) instead of a counted one
-        const int voff = ((yy * Wp + xx) * Cin + s * 8) * 2;
-        asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(__builtin_amdgcn_readfirstlane(b * BUF + i * 1024)), "v"(voff), "s"(ximg)
-                     : "memory");
+        int yy = ts.y0 + hy + (1 - HALO), xx = ts.x0 + hx + (1 - HALO);
+        yy = (yy < H + 1 ? yy : H + 1) - (ts.y0 + 1 - HALO);
+        xx = (xx < W + 1 ? xx : W + 1) - (ts.x0 + 1 - HALO);
+        off = ((yy * Wp + xx) * Cin + xv_swz(hx, ps) * 8) * 2;
       } else {
-        const int j = i - XI;
-        const int idx = j * 64 + lane;
+        const int idx = (i - XI) * 64 + ln;
         const int pp = idx >> 3, ps = idx & 7;
         const int py = pp / TW, px = pp - py * TW;
-        const int s = xv_swz(px, ps);
-        int yy = y0 + py + 1, xx = x0 + px + 1;
-        yy = yy < H + 1 ? yy : H + 1;
-        xx = xx < W + 1 ? xx : W + 1;
-        const int voff = ((yy * Wp + xx) * Cout + s * 8) * 2;
-        asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(__builtin_amdgcn_readfirstlane(b * BUF + X_BYTES + j * 1024)), "v"(voff),
-                     "s"(dimg)
-                     : "memory");
+        int yy = ts.y0 + py + 1, xx = ts.x0 + px + 1;
+        yy = (yy < H + 1 ? yy : H + 1) - (ts.y0 + 1);
+        xx = (xx < W + 1 ? xx : W + 1) - (ts.x0 + 1);
+        off = ((yy * Wp + xx) * Cout + xv_swz(px, ps) * 8) * 2;
       }
     }
+    const int lds = __builtin_amdgcn_readfirstlane(b * BUF + (isx ? i * 1024 : X_BYTES + (i - XI) * 1024));
+    asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds), "v"(off), "s"(isx ? ts.xt : ts.dt) : "memory");
+  };
+  auto stage = [&](int t, int b) {  // a whole tile at once (the first tile of a workgroup)
+    const TileSrc ts = tile_src(t);
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) stage_piece(ts, j, b);
   };
 
   constexpr int NT = (T0 > NTAPS - T0) ? T0 : NTAPS - T0;  // accumulator tap slots per wave
@@ -319,7 +363,8 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_dma_kernel(WgradArgs a) {
   __syncthreads();
   for (int t = t_begin; t < t_end; ++t) {
     const int b = (t - t_begin) & 1;
-    if (t + 1 < t_end) stage(t + 1, b ^ 1);
+    const bool more = t + 1 < t_end;
+    const TileSrc nxt = tile_src(more ? t + 1 : t);
     const char* buf = smem + b * BUF;
     if (do_bias) {
       const int co = tid & 63, part = tid >> 6;  // 8 parts x 32 pixels
@@ -332,6 +377,12 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_dma_kernel(WgradArgs a) {
     }
 #pragma unroll XV_WGRAD_UNROLL
     for (int y = 0; y < TH; ++y) {
+      // the next tile's pieces: two per row over the first rows, so that the last of them has the remaining rows' MFMAs to
+      // land behind (issued one per row up to the last row, the tile ended waiting for its youngest piece)
+      if (more && 2 * y < NJ) {
+        stage_piece(nxt, 2 * y, b ^ 1);
+        if (2 * y + 1 < NJ) stage_piece(nxt, 2 * y + 1, b ^ 1);
+      }
       const int yd = y * (TW * 128), yx = y * (HW * 128);
       bf16x8 bfr[4];
 #pragma unroll
@@ -408,18 +459,33 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_dma_kernel(WgradArgs a) {
 }
 
 // dw[i] += sum_s slab[s][i], splits summed in a fixed order (bitwise reproducible filter gradients)
-// (and db[c] += sum_s bslab[s][c], the bias gradient's partial sums, in the same launch)
+// (and db[c] += sum_s bslab[s][c], the bias gradient's partial sums, in the same launch).  SUBS lanes share an element:
+// lane `sub` adds splits sub, sub + SUBS, ... in order, then a butterfly over the SUBS partial sums -- a fixed tree either
+// way.  With many splits of a small kernel (the 64-channel and 1x1 layers: up to 256 splits of 36 K elements) one thread
+// per element is a chain of `splits` dependent memory round trips on a handful of workgroups: 16 lanes per element cut
+// it 16-fold.
+template <int SUBS>
 __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw,
                                                          int64_t n4, int splits, const float* __restrict__ bslab,
                                                          float* __restrict__ db, int cout4) {
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4 + cout4; i += (int64_t)gridDim.x * 256) {
+  const int sub = threadIdx.x % SUBS;
+  for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) / SUBS; i < n4 + cout4; i += (int64_t)gridDim.x * 256 / SUBS) {
     const bool bias = i >= n4;
     const int64_t j = bias ? i - n4 : i, stride = bias ? cout4 : n4;
     const float* src = bias ? bslab : slab;
-    f32x4 s = *reinterpret_cast<const f32x4*>(src + j * 4);
-    for (int k = 1; k < splits; ++k) s += *reinterpret_cast<const f32x4*>(src + ((int64_t)k * stride + j) * 4);
-    f32x4* d = reinterpret_cast<f32x4*>((bias ? db : dw) + j * 4);
-    *d = *d + s;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    for (int k = sub; k < splits; k += SUBS) s += *reinterpret_cast<const f32x4*>(src + ((int64_t)k * stride + j) * 4);
+#pragma unroll
+    for (int off = SUBS / 2; off >= 1; off >>= 1) {
+      s.x += __shfl_xor(s.x, off, 64);
+      s.y += __shfl_xor(s.y, off, 64);
+      s.z += __shfl_xor(s.z, off, 64);
+      s.w += __shfl_xor(s.w, off, 64);
+    }
+    if (sub == 0) {
+      f32x4* d = reinterpret_cast<f32x4*>((bias ? db : dw) + j * 4);
+      *d = *d + s;
+    }
   }
 }
 
@@ -546,10 +612,18 @@ extern "C" int xv_conv2d_bwd_filter_ws(const xv_act* x, const xv_act* dy, float*
     int rc = xv_launch_status();
     if (rc != XV_OK || a.slab == nullptr) return rc;
     const int64_t n4 = dw_elems / 4;
-    int64_t blocks = (n4 + 255) / 256;
-    if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (const float*)a.slab, dw_hwio, n4,
-                       splits, (const float*)a.bslab, dbias, a.bslab != nullptr ? a.Cout / 4 : 0);
+    const int cout4 = a.bslab != nullptr ? a.Cout / 4 : 0;
+    if (splits >= 16) {
+      int64_t blocks = ((n4 + cout4) * 16 + 255) / 256;
+      if (blocks > 4096) blocks = 4096;
+      hipLaunchKernelGGL(slab_reduce_kernel<16>, dim3((unsigned)blocks), dim3(256), 0, s, (const float*)a.slab, dw_hwio, n4,
+                         splits, (const float*)a.bslab, dbias, cout4);
+    } else {
+      int64_t blocks = (n4 + cout4 + 255) / 256;
+      if (blocks > 2048) blocks = 2048;
+      hipLaunchKernelGGL(slab_reduce_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, s, (const float*)a.slab, dw_hwio, n4,
+                         splits, (const float*)a.bslab, dbias, cout4);
+    }
     return xv_launch_status();
   };
   if (g_wgrad_variant == 2 && k == 3) {

@@ -480,6 +480,32 @@ def pack_conv_weights_pair(w_hwio, out, out_dgrad):
                'xv_pack_conv_weights_pair')
 
 
+class PackTable(object):
+    """Descriptor table (in device memory) of every (master kernel, packed forward image, packed data-gradient image)
+    triple of a trainer; run() re-packs them all in ONE launch.  The tensors must stay where they are."""
+
+    def __init__(self, entries, device):
+        """entries: list of (w_hwio float32 [k,k,cin,cout] view, packed bf16 buffer, packed dgrad bf16 buffer or None)."""
+        self.keep = list(entries)
+        arr = (_lib.xv_pack_desc * len(entries))()
+        for i, (w, out, outd) in enumerate(entries):
+            _need(w, torch.float32, 'w_hwio')
+            k, _, cin, cout = w.shape
+            arr[i] = _lib.xv_pack_desc(w.data_ptr(), out.data_ptr(), outd.data_ptr() if outd is not None else None, k, cin, cout, 0)
+        raw = bytes(arr)
+        self.table = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(device)
+        self.n = len(entries)
+
+    def run(self):
+        _lib.check(_lib.lib().xv_pack_conv_weights_multi(_ptr(self.table), self.n, _stream()), 'xv_pack_conv_weights_multi')
+
+
+def zero_(t):
+    """Clear a tensor on the current stream with the library's memset (no framework kernel in the training step)."""
+    _lib.check(_lib.lib().xv_memset_zero(_ptr(t), t.numel() * t.element_size(), _stream()), 'xv_memset_zero')
+    return t
+
+
 class _Profiled(object):
     """with _Profiled(kind, flops): ... -- a HIP-event pair on the launch stream when bench.py collects CONV_PROFILE."""
 

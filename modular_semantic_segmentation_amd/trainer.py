@@ -152,20 +152,27 @@ class FcnTrainer(object):
             variables['%s/%s/bias' % (p, name)] = np.ascontiguousarray(bv)
 
     def repack(self):
-        """Master fp32 weights -> the engine's bf16 packed forward weights + packed dgrad weights."""
+        """Master fp32 weights -> the engine's bf16 packed forward weights + packed dgrad weights: ONE launch over a
+        descriptor table (built once: the master views and the packed buffers never move).  The engine is pointed at
+        these buffers every time (FcnEngine.load() installs buffers of its own when variables are imported)."""
         e = self.e
-        for name in LAYER_ORDER:
-            kv, bv = self.view(self.param, name, 'kernel'), self.view(self.param, name, 'bias')
-            e.b[name] = bv
-            if name in ('score', 'conv1_1'):
-                e.w[name] = kv
-                continue
-            if name not in self.wd:
+        if getattr(self, '_pack_table', None) is None:
+            entries, self._fwd = [], {}
+            for name in LAYER_ORDER:
+                kv = self.view(self.param, name, 'kernel')
+                if name in ('score', 'conv1_1'):
+                    self._fwd[name] = kv
+                    continue
                 k, _, cin, cout = kv.shape
                 nel = ops.packed_weight_elems(k, cin, cout)
-                e.w[name] = torch.empty(nel, dtype=torch.bfloat16, device=e.device)
+                self._fwd[name] = torch.empty(nel, dtype=torch.bfloat16, device=e.device)
                 self.wd[name] = torch.empty(nel, dtype=torch.bfloat16, device=e.device)
-            ops.pack_conv_weights_pair(kv, e.w[name], self.wd[name])
+                entries.append((kv, self._fwd[name], self.wd[name]))
+            self._pack_table = ops.PackTable(entries, e.device)
+        for name in LAYER_ORDER:
+            e.w[name] = self._fwd[name]
+            e.b[name] = self.view(self.param, name, 'bias')
+        self._pack_table.run()
 
     @staticmethod
     def _input_of(name):
@@ -192,9 +199,9 @@ class FcnTrainer(object):
         e = self.e
         L = e.encoder(x, keep_all=True)
         n, h, w, _ = x.shape
-        self.grad.zero_()
-        self.loss.zero_()
-        self.count.zero_()
+        ops.zero_(self.grad)                            # (the library's memset: no framework kernel runs in the step)
+        ops.zero_(self.loss)
+        ops.zero_(self.count)
         ops.count_valid_labels(labels, e.C, self.count)
         if reducer is not None:
             reducer.allreduce_now(self.count)           # loss denominator = labelled pixels of the GLOBAL batch
