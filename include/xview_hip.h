@@ -430,6 +430,26 @@ int xv_softmax_ce_dense(const float* logits, const int32_t* labels, const int64_
 int xv_score_dense_bwd(const xv_act* u, const float* dscore, const float* w_score, int num_classes, float* dw_score,
                        float* db_score, const xv_act* du, void* stream);
 
+/* ---- "exact" mode (conv_dtype='fp32'): the FCN trunk in plain float32 on dense UNPADDED NHWC maps -- the reference
+ * graph's own arithmetic type (tf.layers.conv2d / max_pooling2d / conv2d_transpose on float32: simple_fcn.py:39-87,
+ * custom_layers.py:71-139), fp32 FMAs, no bf16 storage.  About 1/100 of the MFMA path's speed; it exists so that a test can
+ * show label maps EQUAL to the fp32 oracle's on trained weights, i.e. that what the bf16 path loses it loses to bf16.
+ *   xv_conv2d_f32             y = [relu](conv_kxk_same(x, w_hwio) + bias), k in {1, 3}, any channel counts
+ *   xv_maxpool2x2_f32         2x2 / stride 2
+ *   xv_upsample2x_f32         y = relu(bilinear_x2(x)) [+ residual]            (upscore_conv5 + add_score)
+ *   xv_score_lowres_f32       S[n][i+1][j+1][k] = fused[n][i][j][:] . Ws[:][k] into the zero-bordered [N][h+2][w+2][CP]
+ *                             buffer (CP = num_classes rounded up to 4) that xv_decoder_head_from_scores reads
+ *   xv_decoder_head_from_scores  x8 bilinear interpolation of S + bias -> score / prob / label (the second half of
+ *                             xv_decoder_head_fwd; also serves the bf16 path's S)                                       */
+int xv_conv2d_f32(const float* x, int n, int h, int w, int cin, const float* w_hwio, const float* bias, int k, int cout,
+                  int relu, float* y, void* stream);
+int xv_maxpool2x2_f32(const float* x, int n, int h, int w, int c, float* y, void* stream);
+int xv_upsample2x_f32(const float* x, int n, int h, int w, int c, const float* residual, float* y, void* stream);
+int xv_score_lowres_f32(const float* fused, int n, int h, int w, int u, const float* w_score, int num_classes, float* S,
+                        void* stream);
+int xv_decoder_head_from_scores(const float* S, const float* b_score, int n, int hi, int wi, int num_classes, float* score,
+                                float* prob, int64_t* label, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

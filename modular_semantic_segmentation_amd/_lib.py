@@ -111,6 +111,11 @@ SIGNATURES = {
     'xv_score_dense_fwd': (_i, [_actp, _vp, _vp, _i, _vp, _vp]),
     'xv_softmax_ce_dense': (_i, [_vp, _vp, _vp, _i, _i64, _vp, _vp, _vp]),
     'xv_score_dense_bwd': (_i, [_actp, _vp, _vp, _i, _vp, _vp, _actp, _vp]),
+    'xv_conv2d_f32': (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _i, _i, _i, _vp, _vp]),
+    'xv_maxpool2x2_f32': (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
+    'xv_upsample2x_f32': (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp]),
+    'xv_score_lowres_f32': (_i, [_vp, _i, _i, _i, _i, _vp, _i, _vp, _vp]),
+    'xv_decoder_head_from_scores': (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     'xv_adam_step': (_i, [_vp, _vp, _vp, _vp, _i64, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float,
                           ctypes.c_float, _vp]),
     'xv_rmsprop_step': (_i, [_vp, _vp, _vp, _i64, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float, _vp]),

@@ -12,10 +12,13 @@ def test_pipeline(engine, inputs, want=('prob', 'classification')):
     return out
 
 
-def expert_factory(expert_model):
+def expert_factory(expert_model, conv_dtype='bf16'):
     """(engine class, initialiser) of an `expert_model` name, the choice test_pipeline makes
-    (basic_fusion_model.py:13-20)."""
+    (basic_fusion_model.py:13-20); conv_dtype='fp32': the plain-float32 FCN engine (fcn_exact, the parity mode)."""
     if expert_model == 'fcn':
+        if conv_dtype == 'fp32':
+            from .fcn_exact import FcnEngineF32
+            return FcnEngineF32, init_variables
         return FcnEngine, init_variables
     if expert_model == 'adapnet':
         from .adapnet import AdapnetEngine, init_variables as init_adapnet
@@ -117,7 +120,7 @@ class FusionModel(BaseModel):
         raise NotImplementedError
 
     def _build_graph(self):
-        engine_cls, init = expert_factory(self.config['expert_model'])
+        engine_cls, init = expert_factory(self.config['expert_model'], self.config.get('conv_dtype', 'bf16'))
         self.experts = {}
         for m in self.modalities:
             prefix = self.config['prefixes'][m]

@@ -1208,6 +1208,32 @@ extern "C" int xv_decoder_head_fwd(const xv_act* fused, const float* w_score, co
   return xv_launch_status();
 }
 
+// The second half of xv_decoder_head_fwd alone: low-resolution class scores S (float32 [N][hi+2][wi+2][CP], zero border;
+// from xv_score_lowres or xv_score_lowres_f32) -> score / prob / label at 8x the resolution.
+extern "C" int xv_decoder_head_from_scores(const float* S, const float* b_score, int n, int hi, int wi, int num_classes,
+                                           float* score, float* prob, int64_t* label, void* stream) {
+  XV_CHECK_ARG(S && b_score && (score || prob || label));
+  XV_CHECK_SHAPE(n > 0 && hi > 0 && wi > 0 && num_classes >= 1 && num_classes <= 32);
+  const int64_t npix = (int64_t)n * hi * wi * 64;
+  XV_CHECK_SHAPE((npix + 255) / 256 <= 0x7fffffff);
+  const unsigned g2 = (unsigned)((npix + 255) / 256);
+  hipStream_t s = (hipStream_t)stream;
+#define XV_HEAD(CMV) \
+  hipLaunchKernelGGL(decoder_head_kernel<CMV>, dim3(g2), dim3(256), 0, s, S, b_score, n, hi, wi, num_classes, score, prob, label)
+  switch ((num_classes + 3) / 4) {
+    case 1: XV_HEAD(4); break;
+    case 2: XV_HEAD(8); break;
+    case 3: XV_HEAD(12); break;
+    case 4: XV_HEAD(16); break;
+    case 5: XV_HEAD(20); break;
+    case 6: XV_HEAD(24); break;
+    case 7: XV_HEAD(28); break;
+    default: XV_HEAD(32); break;
+  }
+#undef XV_HEAD
+  return xv_launch_status();
+}
+
 extern "C" int xv_softmax_argmax(const float* score, int64_t npix, int num_classes, float* prob, int64_t* label,
                                  void* stream) {
   XV_CHECK_ARG(score && (prob || label));

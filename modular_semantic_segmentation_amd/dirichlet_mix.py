@@ -77,7 +77,7 @@ class DirichletFusion(BaseModel):
                            **standard_config)
 
     def _build_graph(self):
-        engine_cls, init = expert_factory(self.config['expert_model'])
+        engine_cls, init = expert_factory(self.config['expert_model'], self.config.get('conv_dtype', 'bf16'))
         if not hasattr(self, 'experts'):
             self.experts = {}
             for m in self.modalities:

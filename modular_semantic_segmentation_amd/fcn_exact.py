@@ -1,0 +1,133 @@
+"""The FCN expert in plain float32 (`conv_dtype='fp32'`, "exact" mode): the same graph as fcn.FcnEngine
+(xview/models/simple_fcn.py:10-170) on dense unpadded NHWC float32 maps through csrc/exact_f32.hip -- the reference
+graph's own arithmetic type, no bf16 storage.  Roughly 1/100 of the MFMA path's speed: it exists for the parity
+contract (tests/test_exact_f32_gpu.py: label maps equal to the fp32 oracle's on trained weights), not for throughput.
+Same surface as FcnEngine where the fusion models need it: load / encoder / lowres_scores / forward."""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib, ops
+from .custom_layers import is_bilinear_filter
+from .fcn import ENCODER, _fold_bn, variable_shapes
+
+
+def _p(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+class FcnEngineF32(object):
+    conv_dtype = 'fp32'
+
+    def __init__(self, prefix, in_channels, num_units, num_classes, variables, device='cuda', conv_dtype='fp32', **unused):
+        if conv_dtype != 'fp32':
+            raise ValueError("FcnEngineF32 is the conv_dtype='fp32' engine")
+        self.prefix, self.cin, self.U, self.C = prefix, int(in_channels), int(num_units), int(num_classes)
+        self.device = torch.device(device)
+        self.fp8_scales = None
+        self._arena = {}
+        self.load(variables)
+
+    def load(self, variables):
+        p, dev = self.prefix, self.device
+        v = {k: np.asarray(a, np.float32) for k, a in variables.items() if k.startswith(p + '/')}
+        for need, shape in variable_shapes(p, self.cin, self.U, self.C).items():
+            if need not in v:
+                raise KeyError('missing variable %s' % need)
+            if tuple(v[need].shape) != tuple(shape):
+                raise ValueError('variable %s has shape %s, expected %s' % (need, v[need].shape, shape))
+        for name in ('upscore_conv5', 'upscore'):
+            if not is_bilinear_filter(v['%s/%s/kernel' % (p, name)]) or '%s/%s/gamma' % (p, name) in v:
+                raise NotImplementedError("conv_dtype='fp32' evaluates the constant bilinear deconvs without batch norm "
+                                          '(%s/%s is something else): use the bf16 engine' % (p, name))
+
+        def up(a):
+            return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dev)
+
+        self.w, self.b = {}, {}
+        for name in [n for n, _, _ in ENCODER] + ['score_conv4', 'score_conv5', 'score']:
+            k, b = _fold_bn(v, '%s/%s' % (p, name), v['%s/%s/kernel' % (p, name)], v['%s/%s/bias' % (p, name)])
+            self.w[name], self.b[name] = up(k), up(b)
+        self.w['score'] = self.w['score'].reshape(self.U, self.C).contiguous()
+        torch.cuda.synchronize(dev)
+
+    # ---- ops ---------------------------------------------------------------------------------------------------------
+    def _buf(self, name, shape):
+        key = (name,) + tuple(shape)
+        t = self._arena.get(key)
+        if t is None:
+            t = self._arena[key] = torch.zeros(shape, dtype=torch.float32, device=self.device)
+        return t
+
+    def _conv(self, name, x, k, relu=True):
+        n, h, w, cin = x.shape
+        cout = self.b[name].numel()
+        y = self._buf(name, (n, h, w, cout))
+        rc = _lib.lib().xv_conv2d_f32(_p(x), n, h, w, cin, _p(self.w[name]), _p(self.b[name]), k, cout, int(relu), _p(y),
+                                      ops._stream())
+        _lib.check(rc, 'xv_conv2d_f32')
+        return y
+
+    def _pool(self, name, x):
+        n, h, w, c = x.shape
+        y = self._buf(name, (n, h // 2, w // 2, c))
+        _lib.check(_lib.lib().xv_maxpool2x2_f32(_p(x), n, h, w, c, _p(y), ops._stream()), 'xv_maxpool2x2_f32')
+        return y
+
+    def encoder(self, x, keep_all=False):
+        """float32 [N,H,W,cin] -> dict of dense float32 NHWC maps with the reference's layer names."""
+        n, h, w, cin = x.shape
+        if cin != self.cin:
+            raise ValueError('expected %d input channels, got %d' % (self.cin, cin))
+        if h % 16 or w % 16:
+            raise ValueError('H and W must be multiples of 16 (augmentation.py:244-262 crop_multiple)')
+        L = {}
+        cur = x.contiguous()
+        for name, _, pool in ENCODER:
+            cur = L[name] = self._conv(name, cur, 3)
+            if pool:
+                cur = L[pool] = self._pool(pool, cur)
+        s4 = L['score_conv4'] = self._conv('score_conv4', L['conv4_3'], 1)
+        s5 = L['score_conv5'] = self._conv('score_conv5', L['conv5_3'], 1)
+        fused = self._buf('fused', tuple(s4.shape))
+        n5, h5, w5, c5 = s5.shape
+        _lib.check(_lib.lib().xv_upsample2x_f32(_p(s5), n5, h5, w5, c5, _p(s4), _p(fused), ops._stream()), 'xv_upsample2x_f32')
+        L['fused'] = fused
+        return L
+
+    def _scores(self, f):
+        n, hi, wi, u = f.shape
+        cp = (self.C + 3) // 4 * 4
+        S = self._buf('lowres_S', (n, hi + 2, wi + 2, cp))          # zero border from the allocation, never written
+        _lib.check(_lib.lib().xv_score_lowres_f32(_p(f), n, hi, wi, u, _p(self.w['score']), self.C, _p(S), ops._stream()),
+                   'xv_score_lowres_f32')
+        return S, (n, hi, wi)
+
+    def lowres_scores(self, x):
+        return self._scores(self.encoder(x)['fused'])
+
+    def commuted_head(self):
+        return True
+
+    def forward(self, x, want=('label',), keep_all=False):
+        L = self.encoder(x)
+        S, (n, hi, wi) = self._scores(L['fused'])
+        dev = self.device
+        out = {}
+        if 'score' in want:
+            out['score'] = torch.empty((n, 8 * hi, 8 * wi, self.C), dtype=torch.float32, device=dev)
+        if 'prob' in want:
+            out['prob'] = torch.empty((n, 8 * hi, 8 * wi, self.C), dtype=torch.float32, device=dev)
+        if 'label' in want or 'classification' in want:
+            out['label'] = torch.empty((n, 8 * hi, 8 * wi), dtype=torch.int64, device=dev)
+        rc = _lib.lib().xv_decoder_head_from_scores(_p(S), _p(self.b['score']), n, hi, wi, self.C, _p(out.get('score')),
+                                                    _p(out.get('prob')), _p(out.get('label')), ops._stream())
+        _lib.check(rc, 'xv_decoder_head_from_scores')
+        if 'label' in out:
+            out['classification'] = out['label']
+        out['layers'] = L
+        return out
+
+    def calibrate(self, x, margin_bits=1):
+        return {}

@@ -74,7 +74,10 @@ class SimpleFCN(BaseModel):
                                         self.config['num_classes'],
                                         batch_normalization=self.config['batch_normalization'],
                                         seed=self.config.get('seed'))
-        self.engine = FcnEngine(self.prefix, self.in_channels, self.config['num_units'],
+        engine_cls = FcnEngine
+        if self.config.get('conv_dtype', 'bf16') == 'fp32':
+            from .fcn_exact import FcnEngineF32 as engine_cls       # the plain-float32 parity mode (inference only)
+        self.engine = engine_cls(self.prefix, self.in_channels, self.config['num_units'],
                                 self.config['num_classes'], self.variables, device=self.device,
                                 conv_dtype=self.config.get('conv_dtype', 'bf16'),
                                 streamk=self.config.get('streamk', False))
@@ -99,7 +102,8 @@ class SimpleFCN(BaseModel):
 
     def _ensure_trainer(self):
         if self.engine.conv_dtype != 'bf16':
-            raise UserWarning("ERROR: conv_dtype='fp8' is an inference configuration; train with conv_dtype='bf16'")
+            raise UserWarning("ERROR: conv_dtype='%s' is an inference configuration; train with conv_dtype='bf16'"
+                              % self.engine.conv_dtype)
         if getattr(self, 'trainer', None) is None:
             from .trainer import FcnBnTrainer, FcnTrainer
             from .parallel import GradReducer, require_equal_batchsize, sync_trainer_from_rank0, world

@@ -108,6 +108,45 @@ def hip_predictions_fp8(variables, calibration, heldout, cms, device='cuda'):
     return out
 
 
+def hip_predictions_exact(variables, heldout, cms, n_images, device='cuda'):
+    """The same experts with conv_dtype='fp32' (csrc/exact_f32.hip: the graph in plain float32, no bf16 storage) on the
+    first `n_images` held-out images: expert labels + logits and the Bayes fusion.  Against the fp32 oracle these differ
+    only by fp32 summation order -- so what the bf16 path loses against the oracle, it loses to bf16."""
+    from modular_semantic_segmentation_amd import get_model
+    from modular_semantic_segmentation_amd.datasets.synthetic import data_description
+    desc = data_description()
+    sub = {k: v[:n_images] for k, v in heldout.items()}
+    out = {}
+    for m, cin in MODS:
+        net = get_model('fcn')(m, desc, m, num_units=U, batch_normalization=False, batchsize=2, device=str(device),
+                               conv_dtype='fp32')
+        net.variables.update({k: v for k, v in variables.items() if k.startswith(m + '/')})
+        net._variables_changed()
+        out[m] = net.predict(sub)
+        out[m + '_score'] = net.predict(sub, output_attr='score')
+    bayes = get_model('bayes_fusion')(confusion_matrices=cms, prefixes={'rgb': 'rgb', 'depth': 'depth'},
+                                      data_description=desc, num_units=U, num_channels={'rgb': 3, 'depth': 1},
+                                      expert_model='fcn', class_prior='data', batchsize=2, device=str(device),
+                                      conv_dtype='fp32')
+    bayes.variables.update(variables)
+    bayes._variables_changed()
+    out['bayes'] = bayes.predict(sub)
+    return out
+
+
+def compare_exact(exact, ref, n_images):
+    """Label maps of the float32 HIP path against the fp32 oracle's: pixels that differ (fp32 summation order at exact
+    near-ties), and the worst logit difference relative to the logit scale."""
+    res = {'images': n_images}
+    for k in ('rgb', 'depth', 'bayes'):
+        a, b = exact[k], ref[k][:n_images]
+        res[k] = {'pixels': int(a.size), 'differing_pixels': int((a != b).sum())}
+    for m, _ in MODS:
+        s, r = exact[m + '_score'], ref[m + '_score'][:n_images]
+        res[m]['logit_rel_err'] = float(np.abs(s - r).max() / np.abs(r).max())
+    return res
+
+
 def hip_predictions(variables, measure, heldout, device='cuda'):
     """HIP path: expert confusion matrices and the Dirichlet fit on `measure` (the flows of
     experiments/bayes_fusion.py:146-195 and dirichlet_fusion.py:58-81), then every model's labels (and the experts'
@@ -194,7 +233,7 @@ def compare(hip, ref, labels):
 
 
 def run(h=384, w=768, steps=1500, batch=8, n_heldout=8, n_measure=16, device='cuda', log=None, fp8=True,
-        learning_rate=1e-4, depth_unit=DEPTH_UNIT):
+        learning_rate=1e-4, depth_unit=DEPTH_UNIT, exact_images=0):
     """The whole protocol; returns (accuracy dict, oracle seconds, oracle images)."""
     from modular_semantic_segmentation_amd.datasets.synthetic import make_rgbd_shapes
     variables, train = train_experts(h, w, steps, batch=batch, device=device, log=log, learning_rate=learning_rate,
@@ -204,6 +243,9 @@ def run(h=384, w=768, steps=1500, batch=8, n_heldout=8, n_measure=16, device='cu
     hip, cms, dparams = hip_predictions(variables, measure, heldout, device=device)
     ref, dt, n = oracle_predictions(variables, heldout, cms, dparams)
     acc = compare(hip, ref, heldout['labels'])
+    if exact_images:
+        acc['exact_fp32'] = compare_exact(hip_predictions_exact(variables, heldout, cms, exact_images, device=device), ref,
+                                          exact_images)
     if fp8:
         hip8 = hip_predictions_fp8(variables, measure, heldout, cms, device=device)
         acc['fp8'] = {}
