@@ -11,8 +11,14 @@ Iteration (same accept / fallback order as the reference so that results agree t
   2. quasi-Newton step with the Dirichlet Hessian  diag(h) + c*11^T,  h_k = (1-beta) trigamma(a_k),
      c = -(1-beta) trigamma(sum a)  (Minka, "Estimating a Dirichlet distribution", eq. 18; the
      delta term is NOT in the Hessian, as in the reference); accept if the loss decreases
-  3. otherwise plain gradient steps a + lr*grad with lr = 0.9, 0.81, ... until the loss does not
-     exceed the current one; stop when lr < 2^-10
+  3. the reference then evaluates a log-space trial a * exp(step) (:167-171) whose loss it never uses -- its effects
+     are (i) `math.exp` overflowing (step > ~709.78) ends the fit with the current alpha (:172-174) and (ii) the trial
+     is what the line search below starts from; both are kept
+  4. plain gradient steps a + lr*grad with lr = 0.9, 0.81, ..., starting from the constant loss 10000000 (:176, so a
+     current loss above that accepts the log-space trial unseen), until the loss does not exceed the current one; stop
+     when lr < 2^-10
+Pinned against the imported reference on well-conditioned AND degenerate statistics (tests/golden/dirichlet_fit.npz,
+dirichlet_fit_degenerate.npz: single-pixel classes, certain experts, strong regularisers, far starts, run-away fits).
 """
 import numpy as np
 from scipy.special import gammaln, polygamma, psi
@@ -43,6 +49,23 @@ def _newton_step(alpha, grad, beta):
     return (b - grad) / h_diag
 
 
+_EXP_OVERFLOW = 709.782712893384      # math.exp raises OverflowError above this (the reference's only source of one)
+
+
+def _log_space_trial(alpha, grad, beta):
+    """alpha * exp(step) with the diagonal-Hessian step on log alpha (getPredictedStepAlt, :80-99); None where the
+    reference's math.exp would raise OverflowError."""
+    h_const = -(1 - beta) * polygamma(1, alpha.sum())
+    h_diag = (1 - beta) * polygamma(1, alpha)
+    den = grad - alpha * h_diag
+    z = h_const * (alpha / den).sum()
+    big_s = (1.0 / den / (1 + z)).sum()
+    step = grad / den * (1 - h_const * alpha * big_s)
+    if np.any(step > _EXP_OVERFLOW):
+        return None
+    return alpha * np.exp(step)
+
+
 def find_dirichlet_priors(ss, neg_ss, init_alphas, max_iter=1000, delta=1e-2, beta=1e-2, verbose=False):
     """ss / neg_ss: mean log-probabilities of the class' own / all other pixels ([K] float64).
     Returns the fitted concentration parameters [K] (float64)."""
@@ -62,7 +85,13 @@ def find_dirichlet_priors(ss, neg_ss, init_alphas, max_iter=1000, delta=1e-2, be
         if loss < current:
             current, alpha = loss, trial
             continue
-        loss, rate = float('inf'), 1.0
+        with np.errstate(all='ignore'):
+            trial = _log_space_trial(alpha, grad, beta)
+        if trial is None:
+            if verbose:
+                print('got overflow error, returning')
+            return alpha
+        loss, rate = 10000000, 1.0
         while loss > current:
             rate *= 0.9
             trial = alpha + grad * rate

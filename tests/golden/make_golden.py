@@ -159,6 +159,43 @@ def main():
     cases['num_cases'] = np.array(idx)
     np.savez_compressed(os.path.join(OUT, 'dirichlet_fit.npz'), **cases)
 
+    # --- Dirichlet fitter, degenerate inputs (round 3): classes seen on ONE pixel, near-certain experts (log-probabilities
+    # near 0 / near log(1e-10)), strong regularisers, a far start with few iterations, statistics of opposite sign -- the
+    # corners where the reference's fallbacks (log-space trial that only matters through its OverflowError, the line
+    # search that starts from the constant 10000000: dirichletDifferentiation.py:167-187) decide the result
+    rng = np.random.default_rng(20261003)
+    deg, idx = {}, 0
+
+    def add(ss, neg_ss, init, max_iter, delta, beta):
+        nonlocal idx
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf), np.errstate(all='ignore'):
+            fit = dd.findDirichletPriors(np.asarray(ss, np.float64), np.asarray(neg_ss, np.float64),
+                                         np.asarray(init, np.float64), max_iter=max_iter, delta=delta, beta=beta)
+        deg['case%d_ss' % idx] = np.asarray(ss, np.float64)
+        deg['case%d_neg_ss' % idx] = np.asarray(neg_ss, np.float64)
+        deg['case%d_init' % idx] = np.asarray(init, np.float64)
+        deg['case%d_params' % idx] = np.array([max_iter, delta, beta], np.float64)
+        deg['case%d_alpha' % idx] = np.asarray(fit, np.float64)
+        deg['case%d_message' % idx] = np.array(buf.getvalue().strip().splitlines()[-1] if buf.getvalue().strip() else '')
+        idx += 1
+
+    C = 12
+    one = rng.dirichlet(np.full(C, 0.05))                      # a class seen on one pixel with a peaked posterior
+    many = np.log(1e-10 + rng.dirichlet(np.full(C, 0.5), size=3000)).mean(0)
+    add(np.log(1e-10 + one), many, np.ones(C), 10000, 1e-2, 1e-2)
+    certain = np.full(C, np.log(1e-10))                        # experts certain of class 3: log p = 0 there, log(1e-10) elsewhere
+    certain[3] = np.log(1e-10 + 1.0)
+    add(certain, many, np.ones(C), 10000, 1e-2, 1e-2)
+    add(np.full(C, -1e-3), np.full(C, -1e-3), np.ones(C), 10000, 1e-2, 1e-2)      # statistics near 0 (no such simplex)
+    add(many, many, np.ones(C), 10000, 5.0, 1e-2)              # strong delta
+    add(many, np.log(1e-10 + rng.dirichlet(np.full(C, 2.0), size=3000)).mean(0), np.ones(C), 10000, 1e-2, 0.9)  # strong beta
+    add(many, many, np.full(C, 50.0), 20, 1e-2, 1e-2)          # far start, 20 iterations: "Reached max iterations"
+    add(-many, many, np.ones(C), 200, 0.0, 0.0)                # positive statistics, no regulariser: runs away until max_iter
+    add(np.log(1e-10 + one), np.log(1e-10 + one), np.ones(C), 10000, 0.0, 0.5)
+    deg['num_cases'] = np.array(idx)
+    np.savez_compressed(os.path.join(OUT, 'dirichlet_fit_degenerate.npz'), **deg)
+
     # --- variable-name list of a BN-free FCN expert -------------------------
     nb = json.load(open(REF + '/Synthia Rand Cityscapes Examples.ipynb'))
     names = None

@@ -99,6 +99,29 @@ def test_dirichlet_fitter_golden(golden_dir):
         np.testing.assert_allclose(alpha, f['case%d_alpha' % i], rtol=1e-12, atol=1e-12)
 
 
+def test_dirichlet_fitter_degenerate_golden(golden_dir):
+    """Round 3: statistics at the corners -- a class seen on ONE pixel, experts certain of a class (log p = 0 / log 1e-10),
+    statistics near 0, strong delta / beta, a far start cut off after 20 iterations, a fit that runs away until max_iter
+    -- fitted by the IMPORTED reference (tests/golden/make_golden.py, dirichletDifferentiation.py:129-192).  The
+    vectorised fitter takes the same branches (same terminating message) and agrees to rounding: the two accumulate
+    the same sums in another order (Python loops vs numpy), 1e-9 relative after up to 10 000 iterations."""
+    import contextlib
+    import io
+    from modular_semantic_segmentation_amd.dirichlet_fit import find_dirichlet_priors
+    f = _g(golden_dir, 'dirichlet_fit_degenerate.npz')
+    assert int(f['num_cases']) >= 8
+    for i in range(int(f['num_cases'])):
+        max_iter, delta, beta = f['case%d_params' % i]
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf):
+            got = find_dirichlet_priors(f['case%d_ss' % i], f['case%d_neg_ss' % i], f['case%d_init' % i], max_iter=int(max_iter),
+                                        delta=float(delta), beta=float(beta), verbose=True)
+        want = f['case%d_alpha' % i]
+        assert buf.getvalue().strip().splitlines()[-1] == str(f['case%d_message' % i]), (i, buf.getvalue())
+        np.testing.assert_allclose(got, want, rtol=1e-8, atol=1e-12, err_msg='case %d' % i)
+        assert np.all(got > 0)
+
+
 def test_dirichlet_tables_match_oracle():
     rng = np.random.default_rng(0)
     C = 12
