@@ -2000,6 +2000,13 @@ int pick_cfg(const ConvArgs& a, int k) {
       const Geo& g = kGeo[c];
       const int64_t items = (int64_t)a.N * ((a.H + g.th - 1) / g.th) * ((a.W + g.tw - 1) / g.tw) * (a.Cout / 64);
       double rounds = (double)((items + a.num_cus - 1) / a.num_cus);
+      // From two rounds of workgroups on, the WORK decides, not the round count: the experts of a fusion model run on two
+      // streams and the other expert's workgroups fill an incomplete last round (conv4_x at 16 images: 4.5 rounds of
+      // 16x32 tiles against 6 even rounds of the slower 24x16 tile -- the same time one expert alone, 1.5-3.6 % of the
+      // whole two-stream step in favour of the 16x32 tile; XV_CFG_ROUNDS=1 restores the round count for A/B timing).
+      // Below two rounds a launch is latency: the rounds decide.
+      static const bool by_rounds = getenv("XV_CFG_ROUNDS") != nullptr;
+      if (!by_rounds && items >= 2 * (int64_t)a.num_cus) rounds = (double)items / a.num_cus;
       const int nchunks = a.Cin / 32;
       if (a.sk_ws != nullptr && items % a.num_cus && (a.num_cus & 7) == 0) {
         // stream-K tail (conv_dma_kernel): the last round's items dealt out over nbp workgroups per XCD group

@@ -67,6 +67,7 @@ def test_fcn_full_size_against_oracle(ops):
     ref = fo.fcn_forward(x, w, 'rgb', 'bf16')['score']
     got = out['score'].cpu().numpy()
     scale = np.abs(ref).max()
+    print('full-size logits vs the bf16-policy oracle: max error %.5f of the logit scale' % (np.abs(got - ref).max() / scale))
     assert np.abs(got - ref).max() / scale < 2e-2
     lab = out['label'].cpu().numpy()
     assert np.array_equal(lab, fo.argmax_last(fo.softmax(got)))

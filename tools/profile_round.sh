@@ -8,7 +8,7 @@ TAG=${1:-r2}
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out
 cd /tmp && export TMPDIR=/tmp
-BENCH="python3 $ROOT/bench.py --steps 3 --warmup 1 --serial-experts --no-graph --no-cpu-baseline --no-accuracy --no-extra"
+BENCH="python3 $ROOT/bench.py --steps 3 --warmup 1 --min-seconds 0 --serial-experts --no-graph --no-cpu-baseline --no-accuracy --no-extra"
 FP8="$BENCH --dtype fp8 --height 1024 --width 2048 --batch 4"
 run() { d=$1; shift; rm -rf $OUT/$d; rocprofv3 --output-format csv "$@" > $OUT/$d.log 2>&1; }
 run ${TAG}_trace   --kernel-trace --stats -d $OUT/${TAG}_trace -o bench -- $BENCH
