@@ -33,6 +33,8 @@
 // conv1x1_gemm.hip
 int xv_launch_conv1x1_gemm(const __bf16* x, const __bf16* wpk, const float* bias, __bf16* y, const __bf16* mask,
                            const __bf16* addend, int N, int H, int W, int Cin, int Cout, int relu, hipStream_t stream);
+int xv_launch_conv1x1_n64(const __bf16* x, const __bf16* wpk, const float* bias, __bf16* y, const __bf16* mask,
+                          const __bf16* addend, int N, int H, int W, int Cin, int Cout, int relu, hipStream_t stream);
 
 namespace {
 
@@ -1889,7 +1891,9 @@ __global__ void pack_weights_f8_kernel(const float* __restrict__ w, char* __rest
 //  21: generation 2b (conv_dma2_kernel): as 17 with the item barrier and the next item's first fragment reads inside tap 8
 //  22: generation 2 on a 24x16 tile (8 waves x 3 rows x 16 columns; 132 KB): the 24x48 conv5 maps of a 768x384 input, which
 //      the 16x32 tile covers at 56 %; no fused pool (a wave holds an odd number of rows)
-constexpr int XV_NUM_CONV_CFG = 23;
+//  23: the narrow flat GEMM for 1x1 convs onto 64 channels (conv1x1_gemm.hip): 64 padded rows x 64 channels, 4 waves,
+//      32 KB, several workgroups per CU: the FCN's two score convs
+constexpr int XV_NUM_CONV_CFG = 24;
 struct Geo {
   int th, tw, bn, per_cu;
 };
@@ -1898,7 +1902,7 @@ const Geo kGeo[XV_NUM_CONV_CFG] = {{16, 16, 128, 2}, {8, 16, 128, 2}, {8, 32, 12
                                    {16, 16, 128, 1}, {8, 32, 128, 1}, {16, 16, 64, 2},  {8, 32, 64, 2},
                                    {16, 32, 64, 1},  {16, 32, 64, 1},  {16, 16, 64, 2},  {8, 32, 64, 2},
                                    {16, 32, 64, 1},  {16, 32, 64, 1},  {1, 128, 128, 2},
-                                   {16, 16, 128, 1}, {8, 32, 128, 1}, {16, 32, 64, 1}, {24, 16, 64, 1}};
+                                   {16, 16, 128, 1}, {8, 32, 128, 1}, {16, 32, 64, 1}, {24, 16, 64, 1}, {1, 64, 64, 4}};
 
 template <int KS>
 int launch_cfg(int cfg, const ConvArgs& a, hipStream_t s) {
@@ -1926,7 +1930,7 @@ int launch_cfg(int cfg, const ConvArgs& a, hipStream_t s) {
       default: return XV_ESHAPE;
     }
   }
-  if (a.out_f8 && (cfg == 17 || cfg == 18 || cfg == 21 || cfg == 22)) return XV_ESHAPE;  // fp8 outputs come from the shared first-generation epilogue
+  if (a.out_f8 && (cfg == 17 || cfg == 18 || cfg == 21 || cfg == 22 || cfg == 23)) return XV_ESHAPE;  // fp8 outputs come from the shared first-generation epilogue
   switch (cfg) {
     case 0: return launch_conv<8, 2, 1, 2, KS, 2>(a, s);
     case 1: return launch_conv<4, 2, 1, 2, KS, 2>(a, s);
@@ -1952,6 +1956,12 @@ int launch_cfg(int cfg, const ConvArgs& a, hipStream_t s) {
       return XV_ESHAPE;
     case 22:
       if constexpr (KS == 3) return launch_conv_dma<8, 1, 0, 3>(a, s);
+      return XV_ESHAPE;
+    case 23:
+      if constexpr (KS == 1) {
+        if (a.pooled != nullptr || a.y == nullptr) return XV_ESHAPE;
+        return xv_launch_conv1x1_n64(a.x, a.wpk, a.bias, a.y, a.mask, a.addend, a.N, a.H, a.W, a.Cin, a.Cout, a.relu, s);
+      }
       return XV_ESHAPE;
     case 17:
       if constexpr (KS == 3) {
@@ -2027,6 +2037,8 @@ int pick_cfg(const ConvArgs& a, int k) {
   // (tools/conv1x1_tune.py: 1.1-1.7x over the 64-channel tiles from 128 input channels up); from 256 input channels
   // the flat-GEMM kernel (generation 3) is ahead by another 1.1-1.5x
   if (k == 1 && a.Cout % 128 == 0 && a.Cin >= 256 && a.pooled == nullptr && a.y != nullptr) return 18;
+  // ... and its narrow form for 64 output channels (the FCN's score convs: 20-28 us -> see conv1x1_gemm.hip)
+  if (k == 1 && a.Cout == 64 && a.Cin >= 128 && a.pooled == nullptr && a.y != nullptr) return 23;
   if (k == 1 && a.Cout % 128 == 0 && a.Cin >= 128 && covered(1) <= 1.1 * g1) return 1;
   return covered(15) < covered(14) ? 15 : 14;
 }

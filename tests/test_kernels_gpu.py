@@ -96,7 +96,8 @@ def test_conv2d_every_tile_configuration(ops, k):
         try:
             y, _ = ops.conv2d_fwd(xa, wp, bd, k, relu=True, pooled=q, cfg=cfg)
         except _lib.XvError:
-            assert (cfg in (17, 21, 22) and k == 1) or (cfg == 18 and k == 3)    # generation 2 / 2b: 3x3 only, generation 3: 1x1 only
+            # generation 2 / 2b: 3x3 only, generation 3: 1x1 only, its narrow form: 1x1 onto 64 channels only
+            assert (cfg in (17, 21, 22) and k == 1) or (cfg == 18 and k == 3) or cfg == 23
             continue
         ran += 1
         torch.cuda.synchronize()
@@ -104,6 +105,32 @@ def test_conv2d_every_tile_configuration(ops, k):
         if q is not None:
             assert np.array_equal(q.interior().float().cpu().numpy(), refq), 'cfg %d pooled' % cfg
     assert ran == (22 if k == 3 else 20)
+
+
+@pytest.mark.parametrize('n,h,w,cin', [(1, 24, 48, 512), (16, 24, 48, 512), (1, 48, 96, 512), (3, 7, 5, 128), (2, 30, 33, 192)])
+def test_conv1x1_narrow_gemm(ops, n, h, w, cin):
+    """Tile configuration 23 (the FCN's score convs, simple_fcn.py:69-79: 1x1 onto 64 channels): exact on integers, border
+    untouched, row counts that are not multiples of the 64-row tile, the library's own choice for this shape, and the
+    same bits as a first-generation tile."""
+    rng = np.random.default_rng(n * h * w + cin)
+    x = rng.integers(-2, 3, (n, h, w, cin)).astype(np.float32)
+    wt = rng.integers(-1, 2, (1, 1, cin, 64)).astype(np.float32)
+    b = rng.integers(-3, 4, 64).astype(np.float32)
+    xa, wp, bd = ops.Act.from_dense(_dev(x)), ops.pack_conv_weights(_dev(wt)), _dev(b)
+    _, ref = _conv_oracle(x, wt, b, True, 1)
+    for cfg in (23, -1):
+        y, _ = ops.conv2d_fwd(xa, wp, bd, 1, relu=True, cfg=cfg)
+        torch.cuda.synchronize()
+        assert np.array_equal(y.interior().float().cpu().numpy(), ref), cfg
+        for edge in (y.t[:, 0], y.t[:, -1], y.t[:, :, 0], y.t[:, :, -1]):
+            assert not edge.any()
+    g = torch.Generator(device='cuda').manual_seed(1)
+    xr = ops.Act.from_dense(torch.randn((n, h, w, cin), device='cuda', generator=g))
+    wr = ops.pack_conv_weights(torch.randn((1, 1, cin, 64), device='cuda', generator=g) * cin ** -0.5)
+    y0, _ = ops.conv2d_fwd(xr, wr, bd, 1, relu=False, cfg=23)
+    y1, _ = ops.conv2d_fwd(xr, wr, bd, 1, relu=False, cfg=14)
+    torch.cuda.synchronize()
+    assert torch.equal(y0.t, y1.t)
 
 
 @pytest.mark.parametrize('n,h,w,cin,cout', [(1, 6, 10, 64, 128), (2, 24, 48, 576, 256), (3, 7, 5, 128, 384),
