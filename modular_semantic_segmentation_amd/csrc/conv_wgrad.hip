@@ -375,7 +375,27 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_dma_kernel(WgradArgs a) {
         bsum += (float)*reinterpret_cast<const __bf16*>(buf + X_BYTES + pp * 128 + (xv_swz(px, slot) << 4) + e * 2);
       }
     }
-#pragma unroll XV_WGRAD_UNROLL
+    // Row y's fragments (4 dY tiles + one X fragment per tap of this wave's group) are requested one row AHEAD into a
+    // second register set, so a row is: [request row y+1] [wait for row y] [its 16-20 MFMAs in one burst at raised
+    // priority].  Two waves share a SIMD: the burst priority makes them alternate row by row instead of interleaving
+    // MFMA by MFMA (the forward kernel's scheme), and while one bursts the other's requests are in flight.
+    auto frag_row = [&](int y, bf16x8 (&bfr)[4], bf16x8 (&afr)[NT]) {
+      const int yd = y * (TW * 128), yx = y * (HW * 128);
+#pragma unroll
+      for (int n4 = 0; n4 < 4; ++n4) bfr[n4] = tr_read2(buf, dbase[n4] + yd, dbase[n4] + yd + 8 * 128);
+#pragma unroll
+      for (int ts = 0; ts < NT; ++ts) {
+        // (both groups' taps with compile-time indices: a runtime index into xbase[] would put it in scratch)
+        const int t0 = ts, t1 = T0 + ts < NTAPS ? T0 + ts : NTAPS - 1;
+        const int a0 = xbase[(KS == 3) ? t0 % 3 : 0] + ((KS == 3) ? t0 / 3 : 0) * (HW * 128);
+        const int a1 = xbase[(KS == 3) ? t1 % 3 : 0] + ((KS == 3) ? t1 / 3 : 0) * (HW * 128);
+        const int ad = (tg == 0 ? a0 : a1) + yx;
+        if ((tg == 0 ? ts : T0 + ts) < NTAPS) afr[ts] = tr_read2(buf, ad, ad + 8 * 128);
+      }
+    };
+    bf16x8 bfr[2][4], afr[2][NT];
+    frag_row(0, bfr[0], afr[0]);
+#pragma unroll
     for (int y = 0; y < TH; ++y) {
       // the next tile's pieces: two per row over the first rows, so that the last of them has the remaining rows' MFMAs to
       // land behind (issued one per row up to the last row, the tile ended waiting for its youngest piece)
@@ -383,33 +403,21 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_dma_kernel(WgradArgs a) {
         stage_piece(nxt, 2 * y, b ^ 1);
         if (2 * y + 1 < NJ) stage_piece(nxt, 2 * y + 1, b ^ 1);
       }
-      const int yd = y * (TW * 128), yx = y * (HW * 128);
-      bf16x8 bfr[4];
-#pragma unroll
-      for (int n4 = 0; n4 < 4; ++n4) bfr[n4] = tr_read2(buf, dbase[n4] + yd, dbase[n4] + yd + 8 * 128);
+      if (y + 1 < TH) frag_row(y + 1, bfr[(y + 1) & 1], afr[(y + 1) & 1]);
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int ts = 0; ts < NT; ++ts) {
-        // tap handled in slot ts by this wave's group (compile-time for each group; the branch is wave-uniform)
-        if (tg == 0) {
-          if (ts < T0) {
-            const int tap = ts;
-            const int dy = (KS == 3) ? tap / 3 : 0, dx = (KS == 3) ? tap % 3 : 0;
-            const bf16x8 afr = tr_read2(buf, xbase[dx] + yx + dy * (HW * 128), xbase[dx] + yx + dy * (HW * 128) + 8 * 128);
+        const int tap = tg == 0 ? ts : T0 + ts;
+        if (tap < NTAPS) {
 #pragma unroll
-            for (int n4 = 0; n4 < 4; ++n4)
-              acc[ts][n4] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr, bfr[n4], acc[ts][n4], 0, 0, 0);
-          }
-        } else {
-          if (T0 + ts < NTAPS) {
-            const int tap = T0 + ts;
-            const int dy = (KS == 3) ? tap / 3 : 0, dx = (KS == 3) ? tap % 3 : 0;
-            const bf16x8 afr = tr_read2(buf, xbase[dx] + yx + dy * (HW * 128), xbase[dx] + yx + dy * (HW * 128) + 8 * 128);
-#pragma unroll
-            for (int n4 = 0; n4 < 4; ++n4)
-              acc[ts][n4] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr, bfr[n4], acc[ts][n4], 0, 0, 0);
+          for (int n4 = 0; n4 < 4; ++n4) {
+            acc[ts][n4] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr[y & 1][ts], bfr[y & 1][n4], acc[ts][n4], 0, 0, 0);
+            if (ts == 0 && n4 == 0) __builtin_amdgcn_s_setprio(2);
           }
         }
       }
+      __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_sched_barrier(0);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();  // DMA of tile t+1 has landed and every wave is done with buffer b
