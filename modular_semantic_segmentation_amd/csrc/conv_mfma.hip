@@ -298,6 +298,7 @@ __global__ __launch_bounds__(64 * WR * WC * NW, OCC) void conv_mfma_kernel(ConvA
   const char* const wimg = reinterpret_cast<const char*>(a.wpk) + (F8 ? 256 : 0);
   int scale_w = 0;
   if constexpr (F8) scale_w = ((127 + *reinterpret_cast<const int*>(a.wpk)) & 0xff) * 0x01010101;
+  const bool f8_prio = !(a.debug_same_patch & 32);  // (bit 5: XV_F8_NO_PRIO, A/B timing)
 
   // ---- this workgroup's share of the tile list (XCD-aware, placement affects speed only) --------
   // workgroups b, b+8, ... share an XCD (round-robin dispatch); each XCD owns a contiguous range of
@@ -525,14 +526,20 @@ __global__ __launch_bounds__(64 * WR * WC * NW, OCC) void conv_mfma_kernel(ConvA
             auto cat = [](const u32x4 lo, const u32x4 hi) {
               return i32x8{(int)lo.x, (int)lo.y, (int)lo.z, (int)lo.w, (int)hi.x, (int)hi.y, (int)hi.z, (int)hi.w};
             };
+            // burst priority (the generation-2 / filter-gradient scheme): the tap's 4 MT MFMAs run as one burst at raised
+            // priority, so the SIMD's two waves alternate tap by tap -- one bursts while the other's fragment reads are in
+            // flight -- instead of interleaving MFMA by MFMA
 #pragma unroll
             for (int i = 0; i < MT; ++i) {
               const i32x8 xf = cat(xlo[i], xhi[i]);
 #pragma unroll
-              for (int j = 0; j < 4; ++j)
+              for (int j = 0; j < 4; ++j) {
                 acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(cat(wlo[j], whi[j]), xf, acc[i][j], 0, 0, 0,
                                                                             scale_w, 0, a.scale_x);
+                if (i == 0 && j == 0 && f8_prio) __builtin_amdgcn_s_setprio(2);
+              }
             }
+            if (f8_prio) __builtin_amdgcn_s_setprio(0);
             // An MFMA is a pure value to the instruction selector: nothing orders it against the (chained) asm reads of
             // the next tap, and it sank below them -- every tap's fragments then lived until the end of the item.  An
             // empty asm that "modifies" each accumulator pins this tap's MFMAs in front of the next tap's reads.
@@ -590,6 +597,8 @@ template <int MT, int WR, int WC, int NW, int KS, int OCC, int TPS = 1, int DMAB
 int launch_conv(const ConvArgs& a0, hipStream_t stream) {
   using C = ConvCfg<MT, WR, WC, NW, KS, TPS>;
   ConvArgs a = a0;
+  static const bool f8_no_prio = getenv("XV_F8_NO_PRIO") != nullptr;
+  if (F8 && f8_no_prio) a.debug_same_patch |= 32;
   a.tiles_x = (a.W + C::TW - 1) / C::TW;
   a.tiles_y = (a.H + C::TH - 1) / C::TH;
   a.n_ct = a.Cout / C::BN;
