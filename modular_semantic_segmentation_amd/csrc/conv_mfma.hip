@@ -1838,16 +1838,49 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, __bf16* __restr
 }
 
 // Every layer of a model in ONE launch (the optimizer step re-packs all kernels: 18 launches of ~12 us each were 2 % of a
-// training step): blockIdx.y = table entry, blockIdx.x strides over that kernel's elements
+// training step): blockIdx.y = table entry, blockIdx.x strides over that kernel's 8-channel groups.  One thread = the 8
+// reduction channels of one logical 16-byte slot for one (tap, output channel): 8 floats in (lanes = consecutive output
+// channels: coalesced for the forward image, 32 contiguous bytes per lane for the data-gradient image), the same 16 bytes
+// out to both images -- the element-per-thread form (pack_weights_image, kept for the single-layer entry points: same
+// bits) gathered 2 bytes at a time and took 210 us per training step for 14.7 M weights.
+__device__ __forceinline__ void pack_weights_group(const float* __restrict__ w, __bf16* __restrict__ out, int taps, int cin,
+                                                   int cout, int dgrad, int64_t g, int64_t total) {
+  const int rc = dgrad ? cout : cin;  // reduction channels
+  const int oc = dgrad ? cin : cout;  // output channels
+  const int ng = rc >> 3;
+  const int co = (int)(g % oc);
+  const int64_t rest = g / oc;
+  const int G = (int)(rest % ng);
+  const int tap = (int)(rest / ng);
+  float v[8];
+  if (dgrad) {
+    const float* src = w + ((int64_t)(taps - 1 - tap) * cin + co) * cout + G * 8;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = src[e];
+  } else {
+    const float* src = w + ((int64_t)tap * cin + G * 8) * cout + co;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = src[(int64_t)e * cout];
+  }
+  const u32x4 o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
+  {  // image 1: [tap][chunk64][co][phys_slot 0..7][e]
+    const int64_t at = ((((int64_t)tap * (rc >> 6) + (G >> 3)) * oc + co) << 6) + xv_swz(co, G & 7) * 8;
+    *reinterpret_cast<u32x4*>(out + at) = o;
+  }
+  if (taps == 9) {  // image 2 (generation-2 kernel): [tap][chunk32][co][phys_slot 0..3][e]
+    const int64_t at = ((((int64_t)tap * (rc >> 5) + (G >> 2)) * oc + co) << 5) + xv_swz32(co, G & 3) * 8;
+    *reinterpret_cast<u32x4*>(out + total + at) = o;
+  }
+}
+
 __global__ void pack_weights_multi_kernel(const xv_pack_desc* __restrict__ table) {
   const xv_pack_desc d = table[blockIdx.y];
   const int taps = d.k * d.k;
   const int64_t total = (int64_t)taps * d.cin * d.cout;
-  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
-       idx += (int64_t)gridDim.x * blockDim.x) {
-    pack_weights_image(d.w_hwio, reinterpret_cast<__bf16*>(d.packed), taps, d.cin, d.cout, 0, idx, total);
+  for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < (total >> 3); g += (int64_t)gridDim.x * blockDim.x) {
+    pack_weights_group(d.w_hwio, reinterpret_cast<__bf16*>(d.packed), taps, d.cin, d.cout, 0, g, total);
     if (d.packed_dgrad != nullptr)
-      pack_weights_image(d.w_hwio, reinterpret_cast<__bf16*>(d.packed_dgrad), taps, d.cin, d.cout, 1, idx, total);
+      pack_weights_group(d.w_hwio, reinterpret_cast<__bf16*>(d.packed_dgrad), taps, d.cin, d.cout, 1, g, total);
   }
 }
 
@@ -2152,7 +2185,7 @@ extern "C" int xv_pack_conv_weights_pair(const float* w_hwio, void* packed, void
 
 extern "C" int xv_pack_conv_weights_multi(const xv_pack_desc* table_device, int n, void* stream) {
   XV_CHECK_ARG(table_device != nullptr && n > 0 && n <= 65535);
-  hipLaunchKernelGGL(pack_weights_multi_kernel, dim3(96, (unsigned)n), dim3(256), 0, (hipStream_t)stream, table_device);
+  hipLaunchKernelGGL(pack_weights_multi_kernel, dim3(576, (unsigned)n), dim3(256), 0, (hipStream_t)stream, table_device);
   return xv_launch_status();
 }
 

@@ -463,3 +463,26 @@ def test_dense_transposed_conv_exact_on_integers(ops, k, s, n, h, w, cin, cout):
     y2, _ = ops.deconv_dense_fwd(xa, wp, zb, s, cout, relu=False, workspace=ws)          # plain form, workspace reused
     torch.cuda.synchronize()
     assert np.array_equal(y2.interior().float().cpu().numpy(), raw16.permute(0, 2, 3, 1).numpy())
+
+
+@pytest.mark.gpu
+def test_pack_table_matches_single_layer_packers(ops):
+    """The one-launch re-pack of a training step (xv_pack_conv_weights_multi, 8 channels per thread) writes the same bits
+    as the per-layer entry points (one element per thread): forward and data-gradient images, 3x3 (two images) and 1x1."""
+    g = torch.Generator().manual_seed(5)
+    shapes = [(3, 64, 64), (3, 64, 128), (3, 128, 64), (3, 256, 512), (1, 512, 64), (1, 64, 128)]
+    entries, want = [], []
+    for k, cin, cout in shapes:
+        w = torch.randn(k, k, cin, cout, generator=g).cuda()
+        fwd = torch.zeros(ops.packed_weight_elems(k, cin, cout), dtype=torch.bfloat16, device='cuda')
+        bwd = torch.zeros(ops.packed_weight_elems(k, cout, cin), dtype=torch.bfloat16, device='cuda')
+        entries.append((w, fwd, bwd))
+        want.append((ops.pack_conv_weights(w), ops.pack_conv_weights_dgrad(w)))
+    fwd_only = torch.zeros_like(entries[1][1])
+    entries.append((entries[1][0], fwd_only, None))
+    ops.PackTable(entries, 'cuda').run()
+    torch.cuda.synchronize()
+    for (w, fwd, bwd), (wf, wb) in zip(entries, want):
+        assert torch.equal(fwd.view(torch.int16), wf.view(torch.int16)), tuple(w.shape)
+        assert torch.equal(bwd.view(torch.int16), wb.view(torch.int16)), tuple(w.shape)
+    assert torch.equal(fwd_only.view(torch.int16), want[1][0].view(torch.int16))
