@@ -284,18 +284,29 @@ __global__ __launch_bounds__(256) void head_loss_kernel(const float* __restrict_
   }
 }
 
-// out[i] += sum_b part[b][i] for i < n_out, out64 += sum_b part[b][i64] (a loss): 16 lanes per element each take every
-// 16th row, then a butterfly -- a fixed tree, so the sums are bitwise reproducible (as head_dws_reduce_kernel)
+// out[i] += sum_b part[b][i] for i < n_out, out64 += sum_b part[b][i64] (a loss): LPE lanes per element each take every
+// LPE-th row, then a butterfly (and, for LPE = 256, the four waves' sums in wave order through LDS) -- a fixed tree, so the
+// sums are bitwise reproducible (as head_dws_reduce_kernel).  LPE = 256 (one workgroup per element) for the short vectors
+// (the head's 13 sums over 4 096 rows, the 64 bias sums): with 16 lanes per element those ran 128-256 dependent adds per
+// lane in a single workgroup, 23-37 us per launch.
+template <int LPE>
 __global__ __launch_bounds__(256) void partials_reduce_kernel(const float* __restrict__ part, int nblocks, int len,
                                                              float* __restrict__ out, int n_out, double* __restrict__ out64,
                                                              int i64) {
-  const int i = blockIdx.x * 16 + (threadIdx.x >> 4), sub = threadIdx.x & 15;
+  static_assert(LPE == 64 || LPE == 256, "a wave or a workgroup per element");
+  __shared__ double wsum[4];
+  const int i = blockIdx.x * (256 / LPE) + threadIdx.x / LPE, sub = threadIdx.x % LPE;
   const bool live = i < len;
   double a = 0.0;  // (fp32 terms in a double accumulator: exact enough for the loss, rounded once for the gradients)
   if (live)
-    for (int b = sub; b < nblocks; b += 16) a += (double)part[(int64_t)b * len + i];
+    for (int b = sub; b < nblocks; b += LPE) a += (double)part[(int64_t)b * len + i];
 #pragma unroll
-  for (int off = 8; off >= 1; off >>= 1) a += __shfl_xor(a, off, 64);
+  for (int off = 32; off >= 1; off >>= 1) a += __shfl_xor(a, off, 64);
+  if constexpr (LPE == 256) {
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = a;
+    __syncthreads();
+    a = ((wsum[0] + wsum[1]) + wsum[2]) + wsum[3];
+  }
   if (!live || sub != 0) return;
   if (i < n_out)
     out[i] += (float)a;
@@ -762,7 +773,7 @@ extern "C" int xv_decoder_head_bwd(const xv_act* fused, const float* w_score, co
   {                                                                                                                  \
     hipLaunchKernelGGL(head_loss_kernel<CMV>, dim3(g1), dim3(256), 0, s, (const float*)S, b_score, labels, cnt,       \
                        fused->n, fused->h, fused->w, num_classes, loss, db_score, dscore, loss_part);                 \
-    hipLaunchKernelGGL(partials_reduce_kernel, dim3((CMV + 1 + 15) / 16), dim3(256), 0, s, (const float*)loss_part,   \
+    hipLaunchKernelGGL(partials_reduce_kernel<256>, dim3(CMV + 1), dim3(256), 0, s, (const float*)loss_part,          \
                        (int)g1, CMV + 1,                                                                              \
                        db_score, num_classes, loss, CMV);                                                             \
     const size_t lds = (size_t)(U * CMV + 256 * CMV) * 4 + (size_t)256 * U * 2;                                       \
@@ -863,9 +874,9 @@ extern "C" int xv_conv2d_first_bwd_filter_ws(const float* x, int n, int h, int w
   if (part != nullptr) {
     // dW [9 cin][64] and db [64] are contiguous rows of a workgroup's partial block: two reduce launches into the two outputs
     const int len = (9 * cin + 1) * 64;
-    hipLaunchKernelGGL(partials_reduce_kernel, dim3((len + 15) / 16), dim3(256), 0, s, (const float*)part, (int)grid, len,
-                       dw_hwio, 9 * cin * 64, (double*)nullptr, -1);
-    hipLaunchKernelGGL(partials_reduce_kernel, dim3(4), dim3(256), 0, s, (const float*)part + 9 * cin * 64, (int)grid, len,
+    hipLaunchKernelGGL(partials_reduce_kernel<64>, dim3((9 * cin * 64 + 3) / 4), dim3(256), 0, s, (const float*)part, (int)grid,
+                       len, dw_hwio, 9 * cin * 64, (double*)nullptr, -1);
+    hipLaunchKernelGGL(partials_reduce_kernel<256>, dim3(64), dim3(256), 0, s, (const float*)part + 9 * cin * 64, (int)grid, len,
                        dbias, 64, (double*)nullptr, -1);
   }
   return xv_launch_status();

@@ -14,7 +14,8 @@ ap = argparse.ArgumentParser()
 ap.add_argument('--batch', type=int, default=16)
 ap.add_argument('--iters', type=int, default=10)
 args = ap.parse_args()
-SHAPES = [(96, 192, 64, 64), (96, 192, 64, 256), (96, 192, 256, 64), (48, 96, 256, 128), (48, 96, 128, 512),
+SHAPES = [(48, 96, 64, 512), (24, 48, 64, 512),    # the data gradients of the FCN's two score convs
+          (96, 192, 64, 64), (96, 192, 64, 256), (96, 192, 256, 64), (48, 96, 256, 128), (48, 96, 128, 512),
           (48, 96, 512, 128), (48, 96, 2304, 64), (24, 48, 512, 256), (24, 48, 256, 1024), (24, 48, 1024, 256),
           (24, 48, 4608, 256), (24, 48, 1024, 512), (24, 48, 9216, 512), (24, 48, 512, 2048), (24, 48, 2048, 512),
           (24, 48, 1024, 2048), (24, 48, 2048, 64)]
