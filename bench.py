@@ -342,7 +342,7 @@ def extra_inference(device, label, fusion, batch, h, w, dtype='bf16', steps=10, 
         rec['seconds_per_image_mean_std'] = [round(float(np.mean(per_iter)), 6), round(float(np.std(per_iter)), 6)]
     if dtype == 'fp8':
         rec['roofline'] = roofline_of(prof, ('k3f8',), PEAK_TFLOPS['fp8'],
-                                      'conv_mfma_kernel<F8> (v_mfma_scale_f32_16x16x128_f8f6f4, 3x3 launches on e4m3 operands)',
+                                      'conv_f8_dma_kernel (v_mfma_scale_f32_32x32x64_f8f6f4, 3x3 launches on e4m3 operands; conv_mfma_kernel<F8> where a map does not tile in 16x32)',
                                       dt_serial, steps)
         rec['roofline_bf16_layers'] = roofline_of(prof, ('k3',), PEAK_TFLOPS['bf16'], 'conv1_2 / conv2_1 (bf16 operands)',
                                                   dt_serial, steps)
@@ -577,7 +577,7 @@ def main():
     # dominant kernel: the 3x3 implicit-GEMM MFMA conv (fp8: the launches on e4m3 operands, against the fp8 peak)
     if args.dtype == 'fp8':
         roofline = roofline_of(prof, ('k3f8',), PEAK_TFLOPS['fp8'],
-                               'conv_mfma_kernel<F8> (v_mfma_scale_f32_16x16x128_f8f6f4, 3x3 launches on e4m3 operands)',
+                               'conv_f8_dma_kernel (v_mfma_scale_f32_32x32x64_f8f6f4, 3x3 launches on e4m3 operands; conv_mfma_kernel<F8> where a map does not tile in 16x32)',
                                times_serial, args.steps)
     else:
         roofline = roofline_of(prof, ('k3',), PEAK_TFLOPS['bf16'],

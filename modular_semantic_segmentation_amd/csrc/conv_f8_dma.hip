@@ -1,0 +1,462 @@
+// Generation 4: the 3x3 convolution on e4m3 operands with every operand staged by LDS-DMA (configuration 24).
+//
+// Replaces, like the other conv kernels, tf.layers.conv2d(3x3, 'same', relu) + max_pooling2d of the FCN trunk
+// (xview/models/simple_fcn.py:39-79) for the layers of conv_dtype='fp8' that read AND write e4m3 maps (conv2_2 .. conv5_3).
+//
+// The first-generation fp8 kernel (conv_mfma_kernel<.., F8>) stages its patch through registers, takes two to five
+// barriers per work item and feeds v_mfma_scale_f32_16x16x128_f8f6f4 (K = 128 channels of one tap).  This kernel is the
+// generation-2 design (conv_dma_kernel) moved to fp8 with the instruction shape that fits it:
+//   * v_mfma_scale_f32_32x32x64_f8f6f4: K = 64 = ONE tap of a 64-channel chunk, so a work item is (16x32 pixel tile,
+//     64 output channels, 64 input channels) -- 64 bytes per patch pixel and per weight row, byte for byte the LDS
+//     geometry of the bf16 generation 2 (39 KB patch + 36 KB weights, double buffered, 151 KB) at twice the FLOP per
+//     item and the same matrix-pipe cycles (9 taps x 4 MFMAs x 64 cycles per wave).  Pairing two taps into the K = 128
+//     instruction would idle a tenth of the pipe (nine taps) and needs per-pair address registers.
+//   * 8 waves; wave w owns image rows 2w, 2w+1 x 32 columns x 64 channels: 2 pixel blocks x 2 channel blocks of 32x32,
+//     64 accumulator registers.  Lane l supplies pixel column l & 31 (weights: row l & 31 of a 32-row block) and the
+//     32-byte half l >> 5 of its 64 bytes, as two ds_read_b128.
+//   * LDS images: pixel / weight row r at r * 64, logical 16-byte slot s at physical slot s ^ ((r >> 2) & 3): every
+//     16-lane group of a ds_read_b128 covers all 64 banks once for the three horizontal taps (checked by brute force over
+//     the lane groups of MI355X_MICROARCH.md, LDS).  An LDS-DMA writes 1 KB linearly, so the swizzle is applied on the
+//     SOURCE side: per-lane global offsets for the patch, a pre-swizzled packed image for the weights.
+//   * The weight rows of a 32-row block are permuted in the packed image (row 8g + 4h + q holds channel 16h + 4g + q) so
+//     that the 16 accumulator registers of lane half h are 16 CONSECUTIVE output channels: bias, relu, e4m3 and one
+//     16-byte store per block (4 stores per lane and tile, 2 more for the fused 2x2 max-pool).
+//   * dx-major taps, fragments one tap (weights) / half a column group (pixels) ahead in a second register set, issued
+//     and waited for by hand (counted lgkmcnt, never more than 12 reads in flight), each tap's 4 MFMAs as one burst at
+//     raised priority; the next item's DMA two pieces per tap; ONE barrier per item behind a counted vmcnt that leaves
+//     the tile's own stores (younger than every DMA) in flight.
+// Maps must tile exactly (H % 16 == 0, W % 32 == 0: every fp8 layer of a 2048x1024 or 768x384 input down to conv4);
+// other shapes stay on the first-generation kernel.
+#include "xv_common.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) int i32x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+struct F8Args {
+  const char* x;      // e4m3 [N][H+2][W+2][Cin], zero border
+  const char* wpk;    // packed fp8 weights: [256-byte header][generation-1 image][generation-4 image]
+  const float* bias;  // [Cout]
+  char* y;            // e4m3 [N][H+2][W+2][Cout] or null
+  char* pooled;       // e4m3 [N][H/2+2][W/2+2][Cout] or null
+  int N, H, W, Cin, Cout;
+  int tiles_x, tiles_y, n_ct, n_tiles;
+  int relu;
+  int scale_x;    // E8M0 byte of the input map's scale in all four bytes
+  float out_mul;  // 2^-scale_exp of the output map
+};
+
+struct G4 {
+  static constexpr int NWAVES = 8, NT = 512;
+  static constexpr int TH = 16, TW = 32, HH = TH + 2, HW = TW + 2, NPIX = HH * HW;
+  static constexpr int A_PIECES = (NPIX * 4 + 63) / 64;  // 1 KB per DMA wave-instruction
+  static constexpr int A_BYTES = A_PIECES * 1024;
+  static constexpr int B_PIECES = 9 * 4;  // 9 taps x (64 rows x 64 B)
+  static constexpr int B_BYTES = B_PIECES * 1024;
+  static constexpr int BIAS_OFF = 2 * (A_BYTES + B_BYTES);  // two 256-byte bias slots (tile parity)
+  static constexpr int LDS_BYTES = BIAS_OFF + 512;
+  static constexpr int A_ITERS = (A_PIECES + NWAVES - 1) / NWAVES;
+  static constexpr int B_ITERS = (B_PIECES + NWAVES - 1) / NWAVES;
+  static constexpr int PROW = HW * 64;  // bytes between patch rows
+  static_assert(LDS_BYTES <= 160 * 1024, "does not fit the LDS");
+};
+
+__device__ __forceinline__ int g4_swz(int row, int slot) { return slot ^ ((row >> 2) & 3); }
+
+// four fp32 -> four e4m3 bytes (round-to-nearest-even) of value * mul, saturating (as conv_mfma.hip pack_fp8x4)
+__device__ __forceinline__ uint32_t g4_pack_fp8x4(float v0, float v1, float v2, float v3, float mul) {
+  const float a = __builtin_amdgcn_fmed3f(v0 * mul, -448.f, 448.f);
+  const float b = __builtin_amdgcn_fmed3f(v1 * mul, -448.f, 448.f);
+  const float c = __builtin_amdgcn_fmed3f(v2 * mul, -448.f, 448.f);
+  const float d = __builtin_amdgcn_fmed3f(v3 * mul, -448.f, 448.f);
+  int p = 0;
+  p = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, p, false);
+  p = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, p, true);
+  return (uint32_t)p;
+}
+
+__device__ __forceinline__ float g4_dpp_swap1(float v) {  // value of lane ^ 1 (quad_perm [1,0,3,2])
+  return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));
+}
+
+__global__ __launch_bounds__(512, 2) void conv_f8_dma_kernel(F8Args a) {
+  using C = G4;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n31 = lane & 31, hh = lane >> 5;
+  const int H = a.H, W = a.W, Cin = a.Cin, Cout = a.Cout;
+  const int Wp = W + 2;
+  const int nchunks = Cin >> 6;
+  int scale_w = ((127 + *reinterpret_cast<const int*>(a.wpk)) & 0xff) * 0x01010101;
+  scale_w = __builtin_amdgcn_readfirstlane(scale_w);
+  // generation-4 image: behind the header and the generation-1 image
+  const char* const wimg = a.wpk + 256 + (int64_t)9 * Cin * Cout;
+
+  // persistent workgroups, XCD-contiguous tile ranges, the output-channel tiles of one patch adjacent (as generation 2)
+  const int G = gridDim.x, b = blockIdx.x;
+  const int xcd = b & 7, bi = b >> 3;
+  const int nb = (G - xcd + 7) >> 3;
+  const int T = a.n_tiles;
+  const int tq = T >> 3, trm = T & 7;
+  const int t_begin = xcd * tq + (xcd < trm ? xcd : trm);
+  const int t_end = t_begin + tq + (xcd < trm ? 1 : 0);
+  int lid = t_begin + bi;
+  if (lid >= t_end) return;
+
+  struct Tile {
+    int n, y0, x0, co0;
+  };
+  auto decode = [&](int l) {
+    Tile t;
+    t.co0 = (l % a.n_ct) * 64;
+    int r = l / a.n_ct;
+    t.x0 = (r % a.tiles_x) * C::TW;
+    r /= a.tiles_x;
+    t.y0 = (r % a.tiles_y) * C::TH;
+    t.n = r / a.tiles_y;
+    return t;
+  };
+
+  // per-lane source offsets (bytes, relative to the patch origin) of the patch pieces this wave moves: LDS granule
+  // g = piece * 64 + lane holds physical slot g & 3 of pixel g >> 2
+  int aoff[C::A_ITERS];
+#pragma unroll
+  for (int it = 0; it < C::A_ITERS; ++it) {
+    const int g = (wave + it * C::NWAVES) * 64 + lane;
+    int p = g >> 2;
+    p = p < C::NPIX ? p : C::NPIX - 1;
+    const int hy = p / C::HW, hx = p - hy * C::HW;
+    aoff[it] = (hy * Wp + hx) * Cin + (g4_swz(hx, g & 3) << 4);
+  }
+  // LDS fragment addresses: pixel column n31 + dx of patch row 2 * wave, weight row n31 of a 32-row block; the lane's two
+  // 16-byte slots 2 hh and 2 hh + 1 sit at swizzled positions, so each has its own base
+  int pbase0[3], pbase1[3], wbase0, wbase1;
+#pragma unroll
+  for (int dx = 0; dx < 3; ++dx) {
+    const int hx = n31 + dx;
+    pbase0[dx] = ((2 * wave) * C::HW + hx) * 64 + (g4_swz(hx, 2 * hh) << 4);
+    pbase1[dx] = ((2 * wave) * C::HW + hx) * 64 + (g4_swz(hx, 2 * hh + 1) << 4);
+  }
+  wbase0 = 2 * C::A_BYTES + n31 * 64 + (g4_swz(n31, 2 * hh) << 4);
+  wbase1 = 2 * C::A_BYTES + n31 * 64 + (g4_swz(n31, 2 * hh + 1) << 4);
+  const int64_t tap_pitch = (int64_t)nchunks * Cout * 64;  // bytes between taps of the packed image
+
+  // LDS-DMA in assembly (SGPR base + 32-bit VGPR offset; M0 = the wave's LDS destination), as generation 2
+  auto dma16 = [&](const char* sbase, int voff, int lds_off) {
+    asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_off), "v"(voff), "s"(sbase) : "memory");
+  };
+  auto dma_bases = [&](const Tile& t, int chunk, const char*& xsrc, const char*& wsrc) {
+    xsrc = a.x + (((int64_t)t.n * (H + 2) + t.y0) * Wp + t.x0) * Cin + chunk * 64;
+    wsrc = wimg + (((int64_t)chunk * Cout + t.co0) << 6);
+  };
+  auto dma_a = [&](const char* xsrc, int it, int buf) {
+    const int piece = wave + it * C::NWAVES;
+    if (piece < C::A_PIECES) dma16(xsrc, aoff[it], buf * C::A_BYTES + piece * 1024);
+  };
+  auto dma_b = [&](const char* wsrc, int it, int buf) {
+    const int piece = wave + it * C::NWAVES;
+    if (piece < C::B_PIECES)
+      dma16(wsrc + (piece >> 2) * tap_pitch + (piece & 3) * 1024, lane * 16, 2 * C::A_BYTES + buf * C::B_BYTES + piece * 1024);
+  };
+  // the tile's 64 bias values ride along with its first chunk (one 4-byte-per-lane DMA by the last wave)
+  auto dma_bias = [&](const Tile& t, bool tile_start, int bslot) {
+    if (tile_start && wave == C::NWAVES - 1)
+      asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dword %1, %2" ::"s"(C::BIAS_OFF + bslot * 256), "v"(lane * 4),
+                   "s"(a.bias + t.co0)
+                   : "memory");
+  };
+
+  Tile cur = decode(lid);
+  int chunk = 0, buf = 0, bslot = 0;
+  {
+    const char *xsrc, *wsrc;
+    dma_bases(cur, 0, xsrc, wsrc);
+#pragma unroll
+    for (int it = 0; it < C::A_ITERS; ++it) dma_a(xsrc, it, 0);
+#pragma unroll
+    for (int it = 0; it < C::B_ITERS; ++it) dma_b(wsrc, it, 0);
+    dma_bias(cur, true, 0);
+  }
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int nstores = (a.y != nullptr ? 4 : 0) + (a.pooled != nullptr ? 2 : 0);  // store instructions per tile and wave
+  int in_flight = 0;  // stores issued after the last DMA of the previous item
+
+  while (true) {
+    // This item's operands have landed (each wave retires its own DMA; the tile stores issued after it may stay in
+    // flight: vmcnt counts in issue order), and every wave has finished reading the other buffer pair.
+    if (in_flight == 6)
+      asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory");
+    else if (in_flight == 4)
+      asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
+    else if (in_flight == 2)
+      asm volatile("s_waitcnt vmcnt(2)\n\ts_barrier" ::: "memory");
+    else
+      asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    in_flight = 0;
+
+    const int pb0[3] = {pbase0[0] + buf * C::A_BYTES, pbase0[1] + buf * C::A_BYTES, pbase0[2] + buf * C::A_BYTES};
+    const int pb1[3] = {pbase1[0] + buf * C::A_BYTES, pbase1[1] + buf * C::A_BYTES, pbase1[2] + buf * C::A_BYTES};
+    const int wb0 = wbase0 + buf * C::B_BYTES, wb1 = wbase1 + buf * C::B_BYTES;
+
+    // Fragment registers: weights of tap t in set t & 1 ([channel block][slot]), the 4 patch rows of column group dx in
+    // set dx & 1 ([row][slot]).  Issue order and the counted waits (reads return in order; never more than 12 in flight,
+    // the counter holds 15): before the loop W0 Pa0; tap t: W(t+1) | wait | P part | MFMAs, the P parts being
+    // Pb0, Pa1, Pb1, -, Pa2, Pb2, -, -, - (a = rows 0-1, b = rows 2-3 of the next column group's set).
+    u32x4 wf[2][2][2], xf[2][4][2];
+#define G4_RD(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
+    // t = dx*3 + dy  ->  packed tap dy*3 + dx
+#define G4_LDW(t, set)                                \
+  {                                                   \
+    constexpr int tap_ = (((t) % 3) * 3 + (t) / 3) * 4096; \
+    G4_RD(wf[set][0][0], wb0, tap_);                  \
+    G4_RD(wf[set][0][1], wb1, tap_);                  \
+    G4_RD(wf[set][1][0], wb0, tap_ + 2048);           \
+    G4_RD(wf[set][1][1], wb1, tap_ + 2048);           \
+  }
+#define G4_LDPA(dx, set)                         \
+  {                                              \
+    G4_RD(xf[set][0][0], pb0[dx], 0);            \
+    G4_RD(xf[set][0][1], pb1[dx], 0);            \
+    G4_RD(xf[set][1][0], pb0[dx], C::PROW);      \
+    G4_RD(xf[set][1][1], pb1[dx], C::PROW);      \
+  }
+#define G4_LDPB(dx, set)                         \
+  {                                              \
+    G4_RD(xf[set][2][0], pb0[dx], 2 * C::PROW);  \
+    G4_RD(xf[set][2][1], pb1[dx], 2 * C::PROW);  \
+    G4_RD(xf[set][3][0], pb0[dx], 3 * C::PROW);  \
+    G4_RD(xf[set][3][1], pb1[dx], 3 * C::PROW);  \
+  }
+    // at most n newer reads outstanding: wf[ws] (and rows 0-1 / rows 2-3 of xf[ps]) have landed.  Every wait names exactly
+    // the registers it releases: the MFMAs that consume them cannot move above it, and no register with a read still in
+    // flight is an operand of anything.
+#define G4_WAIT_W(n, ws, ps) \
+  asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(wf[ws][0][0]), "+v"(wf[ws][0][1]), "+v"(wf[ws][1][0]), "+v"(wf[ws][1][1]) : "n"(n))
+#define G4_WAIT_WA(n, ws, ps)                                                                                         \
+  asm volatile("s_waitcnt lgkmcnt(%8)"                                                                                \
+               : "+v"(wf[ws][0][0]), "+v"(wf[ws][0][1]), "+v"(wf[ws][1][0]), "+v"(wf[ws][1][1]), "+v"(xf[ps][0][0]),  \
+                 "+v"(xf[ps][0][1]), "+v"(xf[ps][1][0]), "+v"(xf[ps][1][1])                                           \
+               : "n"(n))
+#define G4_WAIT_WB(n, ws, ps)                                                                                         \
+  asm volatile("s_waitcnt lgkmcnt(%8)"                                                                                \
+               : "+v"(wf[ws][0][0]), "+v"(wf[ws][0][1]), "+v"(wf[ws][1][0]), "+v"(wf[ws][1][1]), "+v"(xf[ps][2][0]),  \
+                 "+v"(xf[ps][2][1]), "+v"(xf[ps][3][0]), "+v"(xf[ps][3][1])                                           \
+               : "n"(n))
+#define G4_CAT(lo, hi) i32x8{(int)(lo).x, (int)(lo).y, (int)(lo).z, (int)(lo).w, (int)(hi).x, (int)(hi).y, (int)(hi).z, (int)(hi).w}
+#define G4_MFMA(i, j, ws, ps, dy)                                                                                   \
+  acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(G4_CAT(wf[ws][j][0], wf[ws][j][1]),                   \
+                                                              G4_CAT(xf[ps][(i) + (dy)][0], xf[ps][(i) + (dy)][1]), \
+                                                              acc[i][j], 0, 0, 0, scale_w, 0, a.scale_x)
+    // the next item's DMA: patch pieces two per tap from tap 0 (HBM / Infinity-Cache latency), weight pieces (L2) after,
+    // the bias with the first weight piece
+#define G4_DMA_PIECES(t)                                                                 \
+  if (has_next) {                                                                        \
+    if (2 * (t) < C::A_ITERS) dma_a(nx_src, 2 * (t), buf ^ 1);                           \
+    if (2 * (t) + 1 < C::A_ITERS) dma_a(nx_src, 2 * (t) + 1, buf ^ 1);                   \
+    if ((t) >= A_TAPS && (t) - A_TAPS < C::B_ITERS) dma_b(nw_src, (t) - A_TAPS, buf ^ 1); \
+    if ((t) == A_TAPS) dma_bias(nxt, last_chunk, bslot ^ 1);                             \
+  }
+    // An MFMA is a pure value to the optimizer: nothing orders it against the (volatile) asm reads, waits and priority
+    // changes around it, and left alone the MFMAs of several taps sink into one cluster behind them (seen in the ISA: the
+    // priority pairs back to back with nothing between).  An empty volatile asm that "modifies" an accumulator pins the
+    // MFMA that produced it in front of every later asm statement.
+#define G4_PIN(i, j) asm volatile("" : "+v"(acc[i][j]))
+#define G4_TAP(t, WAIT, NEWER, POST)                              \
+  {                                                               \
+    constexpr int dx_ = (t) / 3, dy_ = (t) % 3;                   \
+    if constexpr ((t) + 1 < 9) G4_LDW((t) + 1, ((t) + 1) & 1);    \
+    G4_DMA_PIECES(t)                                              \
+    WAIT(NEWER, (t) & 1, dx_ & 1);                                \
+    POST;                                                         \
+    __builtin_amdgcn_sched_barrier(0);                            \
+    G4_MFMA(0, 0, (t) & 1, dx_ & 1, dy_);                         \
+    G4_PIN(0, 0);                                                 \
+    __builtin_amdgcn_s_setprio(2);                                \
+    __builtin_amdgcn_sched_barrier(0);                            \
+    G4_MFMA(0, 1, (t) & 1, dx_ & 1, dy_);                         \
+    G4_MFMA(1, 0, (t) & 1, dx_ & 1, dy_);                         \
+    G4_MFMA(1, 1, (t) & 1, dx_ & 1, dy_);                         \
+    G4_PIN(0, 1);                                                 \
+    G4_PIN(1, 0);                                                 \
+    G4_PIN(1, 1);                                                 \
+    __builtin_amdgcn_sched_barrier(0);                            \
+    __builtin_amdgcn_s_setprio(1);                                \
+    __builtin_amdgcn_sched_barrier(0);                            \
+  }
+    constexpr int A_TAPS = (C::A_ITERS + 1) / 2;  // taps 0 .. A_TAPS-1 issue the patch pieces, two each
+    static_assert(A_TAPS + C::B_ITERS - 1 <= 8, "DMA pieces are issued inside the 9 taps");
+
+    G4_LDW(0, 0);
+    G4_LDPA(0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+
+    const bool last_chunk = chunk + 1 == nchunks;
+    const int nlid = last_chunk ? lid + nb : lid;
+    const bool has_next = nlid < t_end;
+    const Tile nxt = (last_chunk && has_next) ? decode(nlid) : cur;
+    const int nchunk = last_chunk ? 0 : chunk + 1;
+    const char *nx_src = nullptr, *nw_src = nullptr;
+    if (has_next) dma_bases(nxt, nchunk, nx_src, nw_src);
+    __builtin_amdgcn_sched_barrier(0);
+
+    G4_TAP(0, G4_WAIT_WA, 4, G4_LDPB(0, 0))
+    G4_TAP(1, G4_WAIT_WB, 4, G4_LDPA(1, 1))
+    G4_TAP(2, G4_WAIT_W, 8, G4_LDPB(1, 1))
+    G4_TAP(3, G4_WAIT_WA, 8, )
+    G4_TAP(4, G4_WAIT_WB, 4, G4_LDPA(2, 0))
+    G4_TAP(5, G4_WAIT_W, 8, G4_LDPB(2, 0))
+    G4_TAP(6, G4_WAIT_WA, 8, )
+    G4_TAP(7, G4_WAIT_WB, 4, )
+    G4_TAP(8, G4_WAIT_W, 0, )
+
+    if (last_chunk) {
+      // ---- tile epilogue: bias, relu, e4m3; one 16-byte store per (row, channel block) and the fused 2x2 max-pool ----
+      const float* bl = reinterpret_cast<const float*>(smem + C::BIAS_OFF + bslot * 256);
+      const int px = cur.x0 + n31;
+      const int py = cur.y0 + 2 * wave;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        float bv[16];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const f32x4 t4 = *reinterpret_cast<const f32x4*>(bl + 32 * j + 16 * hh + 4 * q);
+          bv[4 * q] = t4.x, bv[4 * q + 1] = t4.y, bv[4 * q + 2] = t4.z, bv[4 * q + 3] = t4.w;
+        }
+        float v[2][16];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const float s = acc[i][j][r] + bv[r];
+            v[i][r] = a.relu ? fmaxf(s, 0.f) : s;
+            acc[i][j][r] = 0.f;
+          }
+        const int cofs = cur.co0 + 32 * j + 16 * hh;
+        if (a.y != nullptr) {
+#pragma unroll
+          for (int i = 0; i < 2; ++i) {
+            const u32x4 o = {g4_pack_fp8x4(v[i][0], v[i][1], v[i][2], v[i][3], a.out_mul),
+                             g4_pack_fp8x4(v[i][4], v[i][5], v[i][6], v[i][7], a.out_mul),
+                             g4_pack_fp8x4(v[i][8], v[i][9], v[i][10], v[i][11], a.out_mul),
+                             g4_pack_fp8x4(v[i][12], v[i][13], v[i][14], v[i][15], a.out_mul)};
+            char* dst = a.y + (((int64_t)cur.n * (H + 2) + (py + i + 1)) * Wp + (px + 1)) * Cout + cofs;
+            *reinterpret_cast<u32x4*>(dst) = o;
+          }
+        }
+        if (a.pooled != nullptr) {
+          float m[16];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const float t = fmaxf(v[0][r], v[1][r]);
+            m[r] = fmaxf(t, g4_dpp_swap1(t));
+          }
+          const u32x4 o = {g4_pack_fp8x4(m[0], m[1], m[2], m[3], a.out_mul), g4_pack_fp8x4(m[4], m[5], m[6], m[7], a.out_mul),
+                           g4_pack_fp8x4(m[8], m[9], m[10], m[11], a.out_mul),
+                           g4_pack_fp8x4(m[12], m[13], m[14], m[15], a.out_mul)};
+          const int Hq = H >> 1, Wq = W >> 1;
+          char* dst = a.pooled + (((int64_t)cur.n * (Hq + 2) + ((py >> 1) + 1)) * (Wq + 2) + ((px >> 1) + 1)) * Cout + cofs;
+          // every wave issues this instruction (even lanes store): the counted vmcnt at the next barrier relies on it
+          if ((lane & 1) == 0) *reinterpret_cast<u32x4*>(dst) = o;
+        }
+      }
+      in_flight = nstores;
+      bslot ^= 1;
+    }
+    if (!has_next) break;
+    lid = nlid;
+    cur = nxt;
+    chunk = nchunk;
+    buf ^= 1;
+  }
+#undef G4_RD
+#undef G4_LDW
+#undef G4_LDPA
+#undef G4_LDPB
+#undef G4_WAIT_W
+#undef G4_WAIT_WA
+#undef G4_WAIT_WB
+#undef G4_CAT
+#undef G4_MFMA
+#undef G4_DMA_PIECES
+#undef G4_TAP
+#undef G4_PIN
+}
+
+// generation-4 fp8 image: [tap][cin / 64][row rho over cout][64 B], 16-byte slots swizzled by g4_swz(rho & 63, slot), rows
+// permuted inside every 32-row block (row 8g + 4h + q = channel 16h + 4g + q); one thread = 4 bytes
+__global__ void pack_weights_f8_g4_kernel(const float* __restrict__ w, char* __restrict__ out, int taps, int cin, int cout,
+                                          float mul) {
+  const int64_t total4 = (int64_t)taps * cin * cout / 4;
+  const int nch = cin >> 6;
+  for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < total4; q += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t idx = q * 4;  // destination byte
+    const int e = (int)(idx & 15);
+    const int ps = (int)((idx >> 4) & 3);
+    int64_t rest = idx >> 6;
+    const int rho = (int)(rest % cout);
+    rest /= cout;
+    const int chunk = (int)(rest % nch);
+    const int tap = (int)(rest / nch);
+    const int m = rho & 31;
+    const int co = (rho & ~31) + 16 * ((m >> 2) & 1) + 4 * (m >> 3) + (m & 3);
+    const int ci = chunk * 64 + g4_swz(rho & 63, ps) * 16 + e;
+    const float v0 = w[((int64_t)tap * cin + ci) * cout + co], v1 = w[((int64_t)tap * cin + ci + 1) * cout + co];
+    const float v2 = w[((int64_t)tap * cin + ci + 2) * cout + co], v3 = w[((int64_t)tap * cin + ci + 3) * cout + co];
+    *reinterpret_cast<uint32_t*>(out + idx) = g4_pack_fp8x4(v0, v1, v2, v3, mul);
+  }
+}
+
+}  // namespace
+
+// Can configuration 24 run this shape?  (3x3, e4m3 in and out, exact 16x32 tiling, 64-channel chunks)
+bool xv_conv3x3_f8_dma_ok(int H, int W, int Cin, int Cout) {
+  return H > 0 && W > 0 && (H & 15) == 0 && (W & 31) == 0 && Cin >= 128 && (Cin & 63) == 0 && (Cout & 63) == 0;
+}
+
+int xv_launch_conv3x3_f8_dma(const void* x, const void* wpk, const float* bias, void* y, void* pooled, int N, int H, int W,
+                             int Cin, int Cout, int relu, int scale_x, float out_mul, int num_cus, hipStream_t stream) {
+  if (!xv_conv3x3_f8_dma_ok(H, W, Cin, Cout) || (y == nullptr && pooled == nullptr)) return XV_ESHAPE;
+  F8Args a{};
+  a.x = (const char*)x;
+  a.wpk = (const char*)wpk;
+  a.bias = bias;
+  a.y = (char*)y;
+  a.pooled = (char*)pooled;
+  a.N = N, a.H = H, a.W = W, a.Cin = Cin, a.Cout = Cout;
+  a.tiles_x = W / G4::TW;
+  a.tiles_y = H / G4::TH;
+  a.n_ct = Cout / 64;
+  const int64_t ntiles = (int64_t)a.tiles_x * a.tiles_y * N * a.n_ct;
+  if (ntiles <= 0 || ntiles > 0x7fffffff) return XV_ESHAPE;
+  a.n_tiles = (int)ntiles;
+  a.relu = relu;
+  a.scale_x = scale_x;
+  a.out_mul = out_mul;
+  static bool attr_set[XV_MAX_DEVICES] = {false};
+  {
+    const hipError_t e = xv_allow_dynamic_lds(reinterpret_cast<const void*>(&conv_f8_dma_kernel), G4::LDS_BYTES, attr_set);
+    if (e != hipSuccess) return (int)e;
+  }
+  const int grid = num_cus > 0 ? num_cus : 256;
+  hipLaunchKernelGGL(conv_f8_dma_kernel, dim3((unsigned)grid), dim3(G4::NT), G4::LDS_BYTES, stream, a);
+  return xv_launch_status();
+}
+
+// second image of the packed fp8 buffer (xv_pack_conv_weights_f8 calls this for 3x3 kernels with cin % 64 == 0)
+void xv_launch_pack_weights_f8_g4(const float* w, char* out, int taps, int cin, int cout, float mul, hipStream_t stream) {
+  const int64_t total4 = (int64_t)taps * cin * cout / 4;
+  const int blocks = (int)((total4 + 255) / 256 < 4096 ? (total4 + 255) / 256 : 4096);
+  hipLaunchKernelGGL(pack_weights_f8_g4_kernel, dim3(blocks), dim3(256), 0, stream, w, out, taps, cin, cout, mul);
+}

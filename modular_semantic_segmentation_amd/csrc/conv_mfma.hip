@@ -36,6 +36,12 @@ int xv_launch_conv1x1_gemm(const __bf16* x, const __bf16* wpk, const float* bias
 int xv_launch_conv1x1_n64(const __bf16* x, const __bf16* wpk, const float* bias, __bf16* y, const __bf16* mask,
                           const __bf16* addend, int N, int H, int W, int Cin, int Cout, int relu, hipStream_t stream);
 
+// conv_f8_dma.hip (generation 4: the fp8 3x3 conv with all operands by LDS-DMA, configuration 24)
+bool xv_conv3x3_f8_dma_ok(int H, int W, int Cin, int Cout);
+int xv_launch_conv3x3_f8_dma(const void* x, const void* wpk, const float* bias, void* y, void* pooled, int N, int H, int W,
+                             int Cin, int Cout, int relu, int scale_x, float out_mul, int num_cus, hipStream_t stream);
+void xv_launch_pack_weights_f8_g4(const float* w, char* out, int taps, int cin, int cout, float mul, hipStream_t stream);
+
 namespace {
 
 struct ConvArgs {
@@ -1935,7 +1941,9 @@ __global__ void pack_weights_f8_kernel(const float* __restrict__ w, char* __rest
 //      the 16x32 tile covers at 56 %; no fused pool (a wave holds an odd number of rows)
 //  23: the narrow flat GEMM for 1x1 convs onto 64 channels (conv1x1_gemm.hip): 64 padded rows x 64 channels, 4 waves,
 //      32 KB, several workgroups per CU: the FCN's two score convs
-constexpr int XV_NUM_CONV_CFG = 24;
+//  24: generation 4 (conv_f8_dma.hip): e4m3 in and out, 16x32 x 64, 8 waves, 64-channel chunks on
+//      v_mfma_scale_f32_32x32x64_f8f6f4, all operands by LDS-DMA, 151 KB, 1/CU; maps that tile exactly
+constexpr int XV_NUM_CONV_CFG = 25;
 struct Geo {
   int th, tw, bn, per_cu;
 };
@@ -1944,12 +1952,18 @@ const Geo kGeo[XV_NUM_CONV_CFG] = {{16, 16, 128, 2}, {8, 16, 128, 2}, {8, 32, 12
                                    {16, 16, 128, 1}, {8, 32, 128, 1}, {16, 16, 64, 2},  {8, 32, 64, 2},
                                    {16, 32, 64, 1},  {16, 32, 64, 1},  {16, 16, 64, 2},  {8, 32, 64, 2},
                                    {16, 32, 64, 1},  {16, 32, 64, 1},  {1, 128, 128, 2},
-                                   {16, 16, 128, 1}, {8, 32, 128, 1}, {16, 32, 64, 1}, {24, 16, 64, 1}, {1, 64, 64, 4}};
+                                   {16, 16, 128, 1}, {8, 32, 128, 1}, {16, 32, 64, 1}, {24, 16, 64, 1}, {1, 64, 64, 4},
+                                   {16, 32, 64, 1}};
 
 template <int KS>
 int launch_cfg(int cfg, const ConvArgs& a, hipStream_t s) {
   if (cfg < 0 || cfg >= XV_NUM_CONV_CFG) return XV_EINVAL;
   if (a.Cout % kGeo[cfg].bn) return XV_ESHAPE;
+  if (cfg == 24) {
+    if (KS != 3 || !a.in_f8 || !a.out_f8 || a.mask != nullptr || a.addend != nullptr) return XV_ESHAPE;
+    return xv_launch_conv3x3_f8_dma(a.x, a.wpk, a.bias, a.y, a.pooled, a.N, a.H, a.W, a.Cin, a.Cout, a.relu, a.scale_x, a.out_mul,
+                                    a.num_cus, s);
+  }
   if (a.in_f8) {
     // the fp8 kernel is built for the tile shapes with LDS-DMA weight stages (the ones the bf16 chooser falls back to)
     static const bool pfa = getenv("XV_F8_PFA") != nullptr && getenv("XV_F8_PFA")[0] == '1';
@@ -2037,6 +2051,9 @@ int pick_cfg(const ConvArgs& a, int k) {
   };
   const double g1 = covered(14) < covered(15) ? covered(14) : covered(15);
   if (a.in_f8 || a.out_f8) {
+    // generation 4 wherever the map tiles exactly in 16x32 (XV_F8_NO_GEN4=1: first generation everywhere, A/B timing)
+    static const bool no_gen4 = getenv("XV_F8_NO_GEN4") != nullptr;
+    if (k == 3 && a.in_f8 && a.out_f8 && !no_gen4 && xv_conv3x3_f8_dma_ok(a.H, a.W, a.Cin, a.Cout)) return 24;
     // 16x32 patch, 8 waves, five taps per barrier where it tiles the map (large maps); else two 4-wave workgroups
     if (k == 3 && covered(16) <= g1 && (int64_t)a.N * a.H * a.W >= XV_F8_BIG_MAP) return 16;
     return covered(15) < covered(14) ? 15 : 14;
@@ -2147,7 +2164,7 @@ extern "C" size_t xv_packed_weight_bytes(int k, int cin, int cout) {
 
 extern "C" size_t xv_packed_weight_bytes_f8(int k, int cin, int cout) {
   if ((k != 1 && k != 3) || cin <= 0 || cout <= 0 || (cin & 127) || (cout & 63)) return 0;
-  return 256 + (size_t)k * k * cin * cout;
+  return 256 + (size_t)k * k * cin * cout * (k == 3 ? 2 : 1);  // 3x3: the generation-1 and the generation-4 image
 }
 
 extern "C" int xv_pack_conv_weights_f8(const float* w_hwio, void* packed, int k, int cin, int cout, int scale_exp,
@@ -2159,6 +2176,9 @@ extern "C" int xv_pack_conv_weights_f8(const float* w_hwio, void* packed, int k,
   const int blocks = (int)((total4 + 255) / 256 < 4096 ? (total4 + 255) / 256 : 4096);
   hipLaunchKernelGGL(pack_weights_f8_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w_hwio, (char*)packed, k * k,
                      cin, cout, scale_exp, exp2f((float)-scale_exp));
+  if (k == 3)
+    xv_launch_pack_weights_f8_g4(w_hwio, (char*)packed + 256 + (size_t)9 * cin * cout, 9, cin, cout, exp2f((float)-scale_exp),
+                                 (hipStream_t)stream);
   return xv_launch_status();
 }
 

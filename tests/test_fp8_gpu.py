@@ -46,6 +46,11 @@ CASES = [
     (3, 8, 8, 512, 64, 1, False, 14, (0, -2, 0)),         # score_conv shape (1x1, Cout 64)
     (1, 18, 22, 128, 256, 1, False, 15, (1, 1, 1)),
     (1, 16, 32, 384, 128, 3, False, -1, (0, 0, 2)),       # the library's own choice of tile
+    # generation 4 (configuration 24, conv_f8_dma.hip: 32x32x64 MFMA, all operands by LDS-DMA, exact 16x32 tiling)
+    (1, 16, 32, 128, 64, 3, True, 24, (0, 0, 0)),         # one tile, two 64-channel chunks
+    (2, 32, 64, 128, 64, 3, True, 24, (2, -1, 2)),
+    (1, 48, 96, 384, 192, 3, True, 24, (1, -2, 3)),       # six chunks, three output-channel tiles per patch
+    (3, 128, 256, 128, 128, 3, True, 24, (0, -1, 2)),     # 384 tiles on 256 workgroups: the persistent walk, tile after tile
 ]
 
 
@@ -81,6 +86,15 @@ def test_fp8_conv_exact_on_integers(ops, n, h, w, cin, cout, k, pool, cfg, exps)
         ops.conv2d_fwd(xa, wp, _dev(b), k, relu=True, pooled=q2, write_y=False, cfg=cfg)       # pooled-only launch
         torch.cuda.synchronize()
         assert torch.equal(q2.t.view(torch.uint8), q.t.view(torch.uint8))
+    if cfg == 24:
+        # generation 4 writes e4m3 maps only; without relu:
+        yn = ops.Act(n, h, w, cout, dtype='fp8', scale_exp=ey + 1)
+        ops.conv2d_fwd(xa, wp, _dev(b), k, relu=False, y=yn, cfg=cfg)
+        torch.cuda.synchronize()
+        assert np.array_equal(yn.real().cpu().numpy(), fo.round_e4m3(_nhwc(_oracle(x, wt, b, False)), ey + 1))
+        with pytest.raises(Exception):
+            ops.conv2d_fwd(xa, wp, _dev(b), k, relu=False, cfg=cfg)       # bf16 output: refused
+        return
     # ---- bf16 output from the same fp8 operands (conv4_3 / conv5_3 feed the bf16 decoder) ---------------------
     yb, _ = ops.conv2d_fwd(xa, wp, _dev(b), k, relu=False, cfg=cfg)
     torch.cuda.synchronize()
