@@ -1,4 +1,5 @@
-// Generation 4: the 3x3 convolution on e4m3 operands with every operand staged by LDS-DMA (configuration 24).
+// Generation 4: the 3x3 convolution on 32x32 MFMA blocks with every operand staged by LDS-DMA -- configuration 24 on e4m3
+// operands (conv_dma4_kernel<true>), configuration 25 on bf16 operands (conv_dma4_kernel<false>).
 //
 // Replaces, like the other conv kernels, tf.layers.conv2d(3x3, 'same', relu) + max_pooling2d of the FCN trunk
 // (xview/models/simple_fcn.py:39-79) for the layers of conv_dtype='fp8' that read AND write e4m3 maps (conv2_2 .. conv5_3).
@@ -27,6 +28,10 @@
 //     the tile's own stores (younger than every DMA) in flight.
 // Maps must tile exactly (H % 16 == 0, W % 32 == 0: every fp8 layer of a 2048x1024 or 768x384 input down to conv4);
 // other shapes stay on the first-generation kernel.
+//
+// bf16 (configuration 25): the same kernel with 32-channel chunks (again 64 bytes per pixel and weight row) on
+// v_mfma_f32_32x32x16_bf16 -- two K = 16 steps per tap, lane half h supplying k-group h of each step (slots h and 2 + h) --
+// and a bf16 epilogue (two 16-byte stores per block).  Inference shapes only: bias + relu (+ pool), no addend / mask / stream-K.
 #include "xv_common.h"
 
 namespace {
@@ -80,7 +85,8 @@ __device__ __forceinline__ float g4_dpp_swap1(float v) {  // value of lane ^ 1 (
   return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));
 }
 
-__global__ __launch_bounds__(512, 2) void conv_f8_dma_kernel(F8Args a) {
+template <bool F8>
+__global__ __launch_bounds__(512, 2) void conv_dma4_kernel(F8Args a) {
   using C = G4;
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -90,11 +96,15 @@ __global__ __launch_bounds__(512, 2) void conv_f8_dma_kernel(F8Args a) {
   const int n31 = lane & 31, hh = lane >> 5;
   const int H = a.H, W = a.W, Cin = a.Cin, Cout = a.Cout;
   const int Wp = W + 2;
-  const int nchunks = Cin >> 6;
-  int scale_w = ((127 + *reinterpret_cast<const int*>(a.wpk)) & 0xff) * 0x01010101;
-  scale_w = __builtin_amdgcn_readfirstlane(scale_w);
-  // generation-4 image: behind the header and the generation-1 image
-  const char* const wimg = a.wpk + 256 + (int64_t)9 * Cin * Cout;
+  const int Cb = F8 ? Cin : 2 * Cin, Ob = F8 ? Cout : 2 * Cout;  // bytes per pixel of the input / output maps
+  const int nchunks = Cb >> 6;                                   // 64 bytes of input channels per chunk
+  int scale_w = 0;
+  if constexpr (F8) {
+    scale_w = ((127 + *reinterpret_cast<const int*>(a.wpk)) & 0xff) * 0x01010101;
+    scale_w = __builtin_amdgcn_readfirstlane(scale_w);
+  }
+  // generation-4 image: fp8 -- behind the header and the generation-1 image; bf16 -- the third image of the packed buffer
+  const char* const wimg = F8 ? a.wpk + 256 + (int64_t)9 * Cin * Cout : a.wpk + (int64_t)4 * 9 * Cin * Cout;
 
   // persistent workgroups, XCD-contiguous tile ranges, the output-channel tiles of one patch adjacent (as generation 2)
   const int G = gridDim.x, b = blockIdx.x;
@@ -130,19 +140,21 @@ __global__ __launch_bounds__(512, 2) void conv_f8_dma_kernel(F8Args a) {
     int p = g >> 2;
     p = p < C::NPIX ? p : C::NPIX - 1;
     const int hy = p / C::HW, hx = p - hy * C::HW;
-    aoff[it] = (hy * Wp + hx) * Cin + (g4_swz(hx, g & 3) << 4);
+    aoff[it] = (hy * Wp + hx) * Cb + (g4_swz(hx, g & 3) << 4);
   }
-  // LDS fragment addresses: pixel column n31 + dx of patch row 2 * wave, weight row n31 of a 32-row block; the lane's two
-  // 16-byte slots 2 hh and 2 hh + 1 sit at swizzled positions, so each has its own base
+  // LDS fragment addresses: pixel column n31 + dx of patch row 2 * wave, weight row n31 of a 32-row block.  The lane's two
+  // 16-byte slots -- fp8: 2 hh and 2 hh + 1 (its 32-byte half of the K = 64 instruction); bf16: hh and 2 + hh (k-group hh
+  // of the two K = 16 steps) -- sit at swizzled positions, so each has its own base
+  const int s0 = F8 ? 2 * hh : hh, s1 = F8 ? 2 * hh + 1 : 2 + hh;
   int pbase0[3], pbase1[3], wbase0, wbase1;
 #pragma unroll
   for (int dx = 0; dx < 3; ++dx) {
     const int hx = n31 + dx;
-    pbase0[dx] = ((2 * wave) * C::HW + hx) * 64 + (g4_swz(hx, 2 * hh) << 4);
-    pbase1[dx] = ((2 * wave) * C::HW + hx) * 64 + (g4_swz(hx, 2 * hh + 1) << 4);
+    pbase0[dx] = ((2 * wave) * C::HW + hx) * 64 + (g4_swz(hx, s0) << 4);
+    pbase1[dx] = ((2 * wave) * C::HW + hx) * 64 + (g4_swz(hx, s1) << 4);
   }
-  wbase0 = 2 * C::A_BYTES + n31 * 64 + (g4_swz(n31, 2 * hh) << 4);
-  wbase1 = 2 * C::A_BYTES + n31 * 64 + (g4_swz(n31, 2 * hh + 1) << 4);
+  wbase0 = 2 * C::A_BYTES + n31 * 64 + (g4_swz(n31, s0) << 4);
+  wbase1 = 2 * C::A_BYTES + n31 * 64 + (g4_swz(n31, s1) << 4);
   const int64_t tap_pitch = (int64_t)nchunks * Cout * 64;  // bytes between taps of the packed image
 
   // LDS-DMA in assembly (SGPR base + 32-bit VGPR offset; M0 = the wave's LDS destination), as generation 2
@@ -150,7 +162,7 @@ __global__ __launch_bounds__(512, 2) void conv_f8_dma_kernel(F8Args a) {
     asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_off), "v"(voff), "s"(sbase) : "memory");
   };
   auto dma_bases = [&](const Tile& t, int chunk, const char*& xsrc, const char*& wsrc) {
-    xsrc = a.x + (((int64_t)t.n * (H + 2) + t.y0) * Wp + t.x0) * Cin + chunk * 64;
+    xsrc = a.x + (((int64_t)t.n * (H + 2) + t.y0) * Wp + t.x0) * Cb + chunk * 64;
     wsrc = wimg + (((int64_t)chunk * Cout + t.co0) << 6);
   };
   auto dma_a = [&](const char* xsrc, int it, int buf) {
@@ -190,13 +202,18 @@ __global__ __launch_bounds__(512, 2) void conv_f8_dma_kernel(F8Args a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  const int nstores = (a.y != nullptr ? 4 : 0) + (a.pooled != nullptr ? 2 : 0);  // store instructions per tile and wave
+  // 16-byte store instructions per tile and wave
+  const int nstores = ((a.y != nullptr ? 4 : 0) + (a.pooled != nullptr ? 2 : 0)) * (F8 ? 1 : 2);
   int in_flight = 0;  // stores issued after the last DMA of the previous item
 
   while (true) {
     // This item's operands have landed (each wave retires its own DMA; the tile stores issued after it may stay in
     // flight: vmcnt counts in issue order), and every wave has finished reading the other buffer pair.
-    if (in_flight == 6)
+    if (in_flight == 12)
+      asm volatile("s_waitcnt vmcnt(12)\n\ts_barrier" ::: "memory");
+    else if (in_flight == 8)
+      asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
+    else if (in_flight == 6)
       asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory");
     else if (in_flight == 4)
       asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
@@ -255,10 +272,17 @@ __global__ __launch_bounds__(512, 2) void conv_f8_dma_kernel(F8Args a) {
                  "+v"(xf[ps][2][1]), "+v"(xf[ps][3][0]), "+v"(xf[ps][3][1])                                           \
                : "n"(n))
 #define G4_CAT(lo, hi) i32x8{(int)(lo).x, (int)(lo).y, (int)(lo).z, (int)(lo).w, (int)(hi).x, (int)(hi).y, (int)(hi).z, (int)(hi).w}
-#define G4_MFMA(i, j, ws, ps, dy)                                                                                   \
-  acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(G4_CAT(wf[ws][j][0], wf[ws][j][1]),                   \
-                                                              G4_CAT(xf[ps][(i) + (dy)][0], xf[ps][(i) + (dy)][1]), \
-                                                              acc[i][j], 0, 0, 0, scale_w, 0, a.scale_x)
+#define G4_MFMA(i, j, ws, ps, dy)                                                                                      \
+  if constexpr (F8) {                                                                                                  \
+    acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(G4_CAT(wf[ws][j][0], wf[ws][j][1]),                    \
+                                                                G4_CAT(xf[ps][(i) + (dy)][0], xf[ps][(i) + (dy)][1]),  \
+                                                                acc[i][j], 0, 0, 0, scale_w, 0, a.scale_x);            \
+  } else {                                                                                                             \
+    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf[ws][j][0]),                      \
+                                                        __builtin_bit_cast(bf16x8, xf[ps][(i) + (dy)][0]), acc[i][j], 0, 0, 0); \
+    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf[ws][j][1]),                      \
+                                                        __builtin_bit_cast(bf16x8, xf[ps][(i) + (dy)][1]), acc[i][j], 0, 0, 0); \
+  }
     // the next item's DMA: patch pieces two per tap from tap 0 (HBM / Infinity-Cache latency), weight pieces (L2) after,
     // the bias with the first weight piece
 #define G4_DMA_PIECES(t)                                                                 \
@@ -343,17 +367,28 @@ __global__ __launch_bounds__(512, 2) void conv_f8_dma_kernel(F8Args a) {
             v[i][r] = a.relu ? fmaxf(s, 0.f) : s;
             acc[i][j][r] = 0.f;
           }
-        const int cofs = cur.co0 + 32 * j + 16 * hh;
+        const int cofs = cur.co0 + 32 * j + 16 * hh;  // first of this lane's 16 consecutive channels
+        // 16 values -> 16 bytes of e4m3, or 32 bytes of bf16 (round-to-nearest-even, as every other epilogue)
+        auto store16 = [&](char* dst, const float (&u)[16], bool on) {
+          if constexpr (F8) {
+            const u32x4 o = {g4_pack_fp8x4(u[0], u[1], u[2], u[3], a.out_mul), g4_pack_fp8x4(u[4], u[5], u[6], u[7], a.out_mul),
+                             g4_pack_fp8x4(u[8], u[9], u[10], u[11], a.out_mul),
+                             g4_pack_fp8x4(u[12], u[13], u[14], u[15], a.out_mul)};
+            if (on) *reinterpret_cast<u32x4*>(dst) = o;
+          } else {
+            const u32x4 o0 = {pack_bf16x2(u[0], u[1]), pack_bf16x2(u[2], u[3]), pack_bf16x2(u[4], u[5]), pack_bf16x2(u[6], u[7])};
+            const u32x4 o1 = {pack_bf16x2(u[8], u[9]), pack_bf16x2(u[10], u[11]), pack_bf16x2(u[12], u[13]),
+                              pack_bf16x2(u[14], u[15])};
+            if (on) {
+              *reinterpret_cast<u32x4*>(dst) = o0;
+              *reinterpret_cast<u32x4*>(dst + 16) = o1;
+            }
+          }
+        };
         if (a.y != nullptr) {
 #pragma unroll
-          for (int i = 0; i < 2; ++i) {
-            const u32x4 o = {g4_pack_fp8x4(v[i][0], v[i][1], v[i][2], v[i][3], a.out_mul),
-                             g4_pack_fp8x4(v[i][4], v[i][5], v[i][6], v[i][7], a.out_mul),
-                             g4_pack_fp8x4(v[i][8], v[i][9], v[i][10], v[i][11], a.out_mul),
-                             g4_pack_fp8x4(v[i][12], v[i][13], v[i][14], v[i][15], a.out_mul)};
-            char* dst = a.y + (((int64_t)cur.n * (H + 2) + (py + i + 1)) * Wp + (px + 1)) * Cout + cofs;
-            *reinterpret_cast<u32x4*>(dst) = o;
-          }
+          for (int i = 0; i < 2; ++i)
+            store16(a.y + (((int64_t)cur.n * (H + 2) + (py + i + 1)) * Wp + (px + 1)) * Ob + cofs * (F8 ? 1 : 2), v[i], true);
         }
         if (a.pooled != nullptr) {
           float m[16];
@@ -362,13 +397,10 @@ __global__ __launch_bounds__(512, 2) void conv_f8_dma_kernel(F8Args a) {
             const float t = fmaxf(v[0][r], v[1][r]);
             m[r] = fmaxf(t, g4_dpp_swap1(t));
           }
-          const u32x4 o = {g4_pack_fp8x4(m[0], m[1], m[2], m[3], a.out_mul), g4_pack_fp8x4(m[4], m[5], m[6], m[7], a.out_mul),
-                           g4_pack_fp8x4(m[8], m[9], m[10], m[11], a.out_mul),
-                           g4_pack_fp8x4(m[12], m[13], m[14], m[15], a.out_mul)};
           const int Hq = H >> 1, Wq = W >> 1;
-          char* dst = a.pooled + (((int64_t)cur.n * (Hq + 2) + ((py >> 1) + 1)) * (Wq + 2) + ((px >> 1) + 1)) * Cout + cofs;
-          // every wave issues this instruction (even lanes store): the counted vmcnt at the next barrier relies on it
-          if ((lane & 1) == 0) *reinterpret_cast<u32x4*>(dst) = o;
+          // every wave issues these instructions (even lanes store): the counted vmcnt at the next barrier relies on it
+          store16(a.pooled + (((int64_t)cur.n * (Hq + 2) + ((py >> 1) + 1)) * (Wq + 2) + ((px >> 1) + 1)) * Ob + cofs * (F8 ? 1 : 2),
+                  m, (lane & 1) == 0);
         }
       }
       in_flight = nstores;
@@ -420,14 +452,19 @@ __global__ void pack_weights_f8_g4_kernel(const float* __restrict__ w, char* __r
 
 }  // namespace
 
-// Can configuration 24 run this shape?  (3x3, e4m3 in and out, exact 16x32 tiling, 64-channel chunks)
+// Can generation 4 run this shape?  (3x3, exact 16x32 tiling, at least two 64-byte chunks of input channels)
 bool xv_conv3x3_f8_dma_ok(int H, int W, int Cin, int Cout) {
   return H > 0 && W > 0 && (H & 15) == 0 && (W & 31) == 0 && Cin >= 128 && (Cin & 63) == 0 && (Cout & 63) == 0;
 }
+bool xv_conv3x3_dma4_bf16_ok(int H, int W, int Cin, int Cout) {
+  return H > 0 && W > 0 && (H & 15) == 0 && (W & 31) == 0 && Cin >= 64 && (Cin & 31) == 0 && (Cout & 63) == 0;
+}
 
+// f8 != 0: configuration 24 (e4m3 maps, scale_x / out_mul as in ConvArgs); f8 == 0: configuration 25 (bf16 maps)
 int xv_launch_conv3x3_f8_dma(const void* x, const void* wpk, const float* bias, void* y, void* pooled, int N, int H, int W,
-                             int Cin, int Cout, int relu, int scale_x, float out_mul, int num_cus, hipStream_t stream) {
-  if (!xv_conv3x3_f8_dma_ok(H, W, Cin, Cout) || (y == nullptr && pooled == nullptr)) return XV_ESHAPE;
+                             int Cin, int Cout, int relu, int f8, int scale_x, float out_mul, int num_cus, hipStream_t stream) {
+  if (!(f8 ? xv_conv3x3_f8_dma_ok(H, W, Cin, Cout) : xv_conv3x3_dma4_bf16_ok(H, W, Cin, Cout)) || (y == nullptr && pooled == nullptr))
+    return XV_ESHAPE;
   F8Args a{};
   a.x = (const char*)x;
   a.wpk = (const char*)wpk;
@@ -444,13 +481,18 @@ int xv_launch_conv3x3_f8_dma(const void* x, const void* wpk, const float* bias, 
   a.relu = relu;
   a.scale_x = scale_x;
   a.out_mul = out_mul;
-  static bool attr_set[XV_MAX_DEVICES] = {false};
-  {
-    const hipError_t e = xv_allow_dynamic_lds(reinterpret_cast<const void*>(&conv_f8_dma_kernel), G4::LDS_BYTES, attr_set);
-    if (e != hipSuccess) return (int)e;
-  }
   const int grid = num_cus > 0 ? num_cus : 256;
-  hipLaunchKernelGGL(conv_f8_dma_kernel, dim3((unsigned)grid), dim3(G4::NT), G4::LDS_BYTES, stream, a);
+  if (f8) {
+    static bool attr_set[XV_MAX_DEVICES] = {false};
+    const hipError_t e = xv_allow_dynamic_lds(reinterpret_cast<const void*>(&conv_dma4_kernel<true>), G4::LDS_BYTES, attr_set);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(conv_dma4_kernel<true>, dim3((unsigned)grid), dim3(G4::NT), G4::LDS_BYTES, stream, a);
+  } else {
+    static bool attr_set[XV_MAX_DEVICES] = {false};
+    const hipError_t e = xv_allow_dynamic_lds(reinterpret_cast<const void*>(&conv_dma4_kernel<false>), G4::LDS_BYTES, attr_set);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(conv_dma4_kernel<false>, dim3((unsigned)grid), dim3(G4::NT), G4::LDS_BYTES, stream, a);
+  }
   return xv_launch_status();
 }
 

@@ -38,8 +38,9 @@ int xv_launch_conv1x1_n64(const __bf16* x, const __bf16* wpk, const float* bias,
 
 // conv_f8_dma.hip (generation 4: the fp8 3x3 conv with all operands by LDS-DMA, configuration 24)
 bool xv_conv3x3_f8_dma_ok(int H, int W, int Cin, int Cout);
+bool xv_conv3x3_dma4_bf16_ok(int H, int W, int Cin, int Cout);
 int xv_launch_conv3x3_f8_dma(const void* x, const void* wpk, const float* bias, void* y, void* pooled, int N, int H, int W,
-                             int Cin, int Cout, int relu, int scale_x, float out_mul, int num_cus, hipStream_t stream);
+                             int Cin, int Cout, int relu, int f8, int scale_x, float out_mul, int num_cus, hipStream_t stream);
 void xv_launch_pack_weights_f8_g4(const float* w, char* out, int taps, int cin, int cout, float mul, hipStream_t stream);
 
 namespace {
@@ -1828,6 +1829,11 @@ __device__ __forceinline__ void pack_weights_image(const float* __restrict__ w, 
     const int tap = (int)(rest / nch32);
     const int sl = xv_swz32(co, ps);
     out[total + idx] = (__bf16)wl(tap, chunk * 32 + sl * 8 + e, co);
+    // image 3 (generation 4, conv_f8_dma.hip): [tap][chunk32][row rho][phys_slot 0..3][e], slots swizzled by
+    // (rho >> 2) & 3, rows permuted inside every 32-row block (row 8g + 4h + q = channel 16h + 4g + q)
+    const int m = co & 31;  // here `co` is the ROW index rho
+    const int ch = (co & ~31) + 16 * ((m >> 2) & 1) + 4 * (m >> 3) + (m & 3);
+    out[2 * total + idx] = (__bf16)wl(tap, chunk * 32 + (ps ^ ((co >> 2) & 3)) * 8 + e, ch);
   }
 }
 
@@ -1876,6 +1882,11 @@ __device__ __forceinline__ void pack_weights_group(const float* __restrict__ w, 
   if (taps == 9) {  // image 2 (generation-2 kernel): [tap][chunk32][co][phys_slot 0..3][e]
     const int64_t at = ((((int64_t)tap * (rc >> 5) + (G >> 2)) * oc + co) << 5) + xv_swz32(co, G & 3) * 8;
     *reinterpret_cast<u32x4*>(out + total + at) = o;
+    // image 3 (generation 4): this channel's row rho of the permuted 32-row block, slot swizzled by (rho >> 2) & 3
+    const int c = co & 31;
+    const int rho = (co & ~31) + 8 * ((c >> 2) & 3) + 4 * (c >> 4) + (c & 3);
+    const int64_t at3 = ((((int64_t)tap * (rc >> 5) + (G >> 2)) * oc + rho) << 5) + (((G & 3) ^ ((rho >> 2) & 3)) << 3);
+    *reinterpret_cast<u32x4*>(out + 2 * total + at3) = o;
   }
 }
 
@@ -1943,7 +1954,8 @@ __global__ void pack_weights_f8_kernel(const float* __restrict__ w, char* __rest
 //      32 KB, several workgroups per CU: the FCN's two score convs
 //  24: generation 4 (conv_f8_dma.hip): e4m3 in and out, 16x32 x 64, 8 waves, 64-channel chunks on
 //      v_mfma_scale_f32_32x32x64_f8f6f4, all operands by LDS-DMA, 151 KB, 1/CU; maps that tile exactly
-constexpr int XV_NUM_CONV_CFG = 25;
+//  25: generation 4 on bf16 operands (v_mfma_f32_32x32x16_bf16, 32-channel chunks): bias + relu (+ pool) only
+constexpr int XV_NUM_CONV_CFG = 26;
 struct Geo {
   int th, tw, bn, per_cu;
 };
@@ -1953,7 +1965,7 @@ const Geo kGeo[XV_NUM_CONV_CFG] = {{16, 16, 128, 2}, {8, 16, 128, 2}, {8, 32, 12
                                    {16, 32, 64, 1},  {16, 32, 64, 1},  {16, 16, 64, 2},  {8, 32, 64, 2},
                                    {16, 32, 64, 1},  {16, 32, 64, 1},  {1, 128, 128, 2},
                                    {16, 16, 128, 1}, {8, 32, 128, 1}, {16, 32, 64, 1}, {24, 16, 64, 1}, {1, 64, 64, 4},
-                                   {16, 32, 64, 1}};
+                                   {16, 32, 64, 1},  {16, 32, 64, 1}};
 
 template <int KS>
 int launch_cfg(int cfg, const ConvArgs& a, hipStream_t s) {
@@ -1961,8 +1973,13 @@ int launch_cfg(int cfg, const ConvArgs& a, hipStream_t s) {
   if (a.Cout % kGeo[cfg].bn) return XV_ESHAPE;
   if (cfg == 24) {
     if (KS != 3 || !a.in_f8 || !a.out_f8 || a.mask != nullptr || a.addend != nullptr) return XV_ESHAPE;
-    return xv_launch_conv3x3_f8_dma(a.x, a.wpk, a.bias, a.y, a.pooled, a.N, a.H, a.W, a.Cin, a.Cout, a.relu, a.scale_x, a.out_mul,
-                                    a.num_cus, s);
+    return xv_launch_conv3x3_f8_dma(a.x, a.wpk, a.bias, a.y, a.pooled, a.N, a.H, a.W, a.Cin, a.Cout, a.relu, 1, a.scale_x,
+                                    a.out_mul, a.num_cus, s);
+  }
+  if (cfg == 25) {
+    if (KS != 3 || a.in_f8 || a.out_f8 || a.mask != nullptr || a.addend != nullptr) return XV_ESHAPE;
+    return xv_launch_conv3x3_f8_dma(a.x, a.wpk, a.bias, a.y, a.pooled, a.N, a.H, a.W, a.Cin, a.Cout, a.relu, 0, 0, 1.f, a.num_cus,
+                                    s);
   }
   if (a.in_f8) {
     // the fp8 kernel is built for the tile shapes with LDS-DMA weight stages (the ones the bf16 chooser falls back to)
@@ -2087,6 +2104,15 @@ int pick_cfg(const ConvArgs& a, int k) {
       }
       return rounds * g.th * g.tw / speed;
     };
+    // generation 4 (configuration 25: 32x32 MFMA blocks, leaner item loop) where the map tiles exactly and the tile has at
+    // least four 32-channel chunks... the two-chunk layers keep generation 2 (resident weights, stores spread over the next
+    // item).  Plain forward shapes only.  XV_BF16_GEN4=0: never; =2: every eligible shape (A/B timing).
+    {
+      static const int gen4 = getenv("XV_BF16_GEN4") != nullptr ? atoi(getenv("XV_BF16_GEN4")) : 1;
+      if (gen4 && a.mask == nullptr && a.addend == nullptr && a.sk_ws == nullptr && !a.in_f8 && !a.out_f8 &&
+          xv_conv3x3_dma4_bf16_ok(a.H, a.W, a.Cin, a.Cout) && (gen4 == 2 || a.Cin >= 256 || (a.Cin == 128 && a.Cout >= 256)))
+        return 25;
+    }
     int g2 = 17;
     double s2 = 1.25;
     if (a.pooled == nullptr && round_cost(22, 1.15) < round_cost(17, 1.25)) g2 = 22, s2 = 1.15;
@@ -2159,7 +2185,7 @@ int conv_fwd_impl(const xv_act* x, const void* w_packed, const float* bias, cons
 
 extern "C" size_t xv_packed_weight_bytes(int k, int cin, int cout) {
   if ((k != 1 && k != 3) || cin <= 0 || cout <= 0 || (cin & 63) || (cout & 63)) return 0;
-  return (size_t)k * k * cin * cout * 2 * (k == 3 ? 2 : 1);  // 3x3: both packed images
+  return (size_t)k * k * cin * cout * 2 * (k == 3 ? 3 : 1);  // 3x3: the three packed images (generations 1, 2, 4)
 }
 
 extern "C" size_t xv_packed_weight_bytes_f8(int k, int cin, int cout) {

@@ -97,7 +97,8 @@ def test_conv2d_every_tile_configuration(ops, k):
             y, _ = ops.conv2d_fwd(xa, wp, bd, k, relu=True, pooled=q, cfg=cfg)
         except _lib.XvError:
             # generation 2 / 2b: 3x3 only, generation 3: 1x1 only, its narrow form: 1x1 onto 64 channels only
-            assert (cfg in (17, 21, 22) and k == 1) or (cfg == 18 and k == 3) or cfg == 23
+            # generation 4 (24: e4m3 maps only, 25: bf16): 3x3 on maps that tile in 16x32 only
+            assert (cfg in (17, 21, 22) and k == 1) or (cfg == 18 and k == 3) or cfg in (23, 24, 25)
             continue
         ran += 1
         torch.cuda.synchronize()
@@ -186,6 +187,41 @@ def test_conv2d_generation2_all_dma(ops, shape, gen2):
     ops.conv2d_fwd(xa, wp, bd, 3, relu=True, pooled=q2, write_y=False, cfg=gen2)
     torch.cuda.synchronize()
     assert torch.equal(q2.t, q.t)
+
+
+@pytest.mark.parametrize('shape', [(1, 16, 32, 64, 64), (2, 32, 64, 128, 192), (1, 48, 96, 256, 64), (5, 96, 192, 64, 128)])
+def test_conv2d_generation4_bf16(ops, shape):
+    """Configuration 25 (conv_dma4_kernel<false>, conv_f8_dma.hip: 32x32x16 bf16 MFMA blocks, all operands by LDS-DMA, its
+    own packed image; the last shape gives every workgroup several two-chunk tiles) against the oracle, bit for bit on
+    integer operands: full output, fused pool, pooled-only launch, no relu, untouched border; maps that do not tile in
+    16x32 and data-gradient epilogues are refused."""
+    from modular_semantic_segmentation_amd import _lib
+    n, h, w, cin, cout = shape
+    rng = np.random.default_rng(sum(shape))
+    x = rng.integers(-2, 3, (n, h, w, cin)).astype(np.float32)
+    wt = rng.integers(-1, 2, (3, 3, cin, cout)).astype(np.float32)
+    b = rng.integers(-3, 4, cout).astype(np.float32)
+    xa, wp, bd = ops.Act.from_dense(_dev(x)), ops.pack_conv_weights(_dev(wt)), _dev(b)
+    y32, ref = _conv_oracle(x, wt, b, True, 3)
+    refq = fo.round_bf16(fo.maxpool2(y32)).permute(0, 2, 3, 1).numpy()
+    q = ops.Act(n, h // 2, w // 2, cout)
+    y, _ = ops.conv2d_fwd(xa, wp, bd, 3, relu=True, pooled=q, cfg=25)
+    torch.cuda.synchronize()
+    assert np.array_equal(y.interior().float().cpu().numpy(), ref)
+    assert np.array_equal(q.interior().float().cpu().numpy(), refq)
+    full = y.t.float().cpu().numpy()
+    assert np.all(full[:, 0] == 0) and np.all(full[:, -1] == 0) and np.all(full[:, :, 0] == 0) and np.all(full[:, :, -1] == 0)
+    q2 = ops.Act(n, h // 2, w // 2, cout)
+    ops.conv2d_fwd(xa, wp, bd, 3, relu=True, pooled=q2, write_y=False, cfg=25)
+    torch.cuda.synchronize()
+    assert torch.equal(q2.t, q.t)
+    _, refn = _conv_oracle(x, wt, b, False, 3)
+    yn, _ = ops.conv2d_fwd(xa, wp, bd, 3, relu=False, cfg=25)
+    torch.cuda.synchronize()
+    assert np.array_equal(yn.interior().float().cpu().numpy(), refn)
+    with pytest.raises(_lib.XvError):
+        xs = ops.Act.from_dense(_dev(x[:, :h - 8]))
+        ops.conv2d_fwd(xs, wp, bd, 3, relu=True, cfg=25)                       # 8 rows short of a tiling
 
 
 @pytest.mark.parametrize('shape', [(2, 24, 48, 512, 128), (1, 24, 16, 64, 64), (3, 30, 40, 128, 64), (2, 48, 20, 64, 192),
