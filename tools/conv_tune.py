@@ -18,7 +18,7 @@ LAYERS = [('conv1_2', 1, 64, 64, 3, True), ('conv2_1', 2, 64, 128, 3, False), ('
 
 
 def tune_fp8(args):
-    cfgs = [int(c) for c in args.cfgs.split(',')] if args.cfgs else [14, 15, 16, 19, 20]
+    cfgs = [int(c) for c in args.cfgs.split(',')] if args.cfgs else [14, 15, 16, 19, 20, 24]
     print('layer        ' + ''.join('cfg%-6d' % c for c in cfgs) + ' default   (fp8 e4m3 operands, TFLOP/s)')
     for name, s, cin, cout, k, pool in LAYERS:
         if cin < 128:
@@ -26,7 +26,10 @@ def tune_fp8(args):
         h, w = args.height // s, args.width // s
         x = ops.Act.from_dense(torch.randn(args.batch, h, w, cin, device='cuda').abs() * 40, dtype='fp8', scale_exp=0)
         wt = torch.randn(k, k, cin, cout, device='cuda') * (1.0 / (k * k * cin) ** 0.5)
-        wp, _ = ops.pack_conv_weights_f8(wt)
+        if args.data == 'zero':
+            x = ops.Act(args.batch, h, w, cin, dtype='fp8', scale_exp=0)
+            wt.zero_()
+        wp, _ = ops.pack_conv_weights_f8(wt, scale_exp=0 if args.data == 'zero' else None)
         b = torch.zeros(cout, device='cuda')
         y = ops.Act(args.batch, h, w, cout, dtype='fp8', scale_exp=1)
         q = ops.Act(args.batch, h // 2, w // 2, cout, dtype='fp8', scale_exp=1) if pool else None
@@ -59,6 +62,9 @@ def main():
     ap.add_argument('--no-wgrad', action='store_true')
     ap.add_argument('--pooled-only', action='store_true', help='pool layers write only the pooled map')
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp8'], help="fp8: e4m3 operands and outputs (cin >= 128)")
+    ap.add_argument('--data', default='normal', choices=['normal', 'zero', 'relu'],
+                    help="operand values (bf16): 'zero' = all-zero maps and weights (no operand toggling: what the matrix pipes "
+                         "reach when power does not hold the clock down), 'relu' = half the activations zero")
     args = ap.parse_args()
     if args.dtype == 'fp8':
         return tune_fp8(args)
@@ -70,6 +76,11 @@ def main():
         x = ops.Act(args.batch, h, w, cin)
         x.interior().normal_()
         wt = torch.randn(k, k, cin, cout, device='cuda') * (1.0 / (k * k * cin) ** 0.5)
+        if args.data == 'zero':
+            x.interior().zero_()
+            wt.zero_()
+        elif args.data == 'relu':
+            x.interior().clamp_(min=0)
         wp = ops.pack_conv_weights(wt)
         b = torch.zeros(cout, device='cuda')
         y = ops.Act(args.batch, h, w, cout)
