@@ -85,7 +85,9 @@ __device__ __forceinline__ float g4_dpp_swap1(float v) {  // value of lane ^ 1 (
   return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));
 }
 
-template <bool F8>
+// F8: e4m3 input map and weights; OF8: e4m3 output maps (an e4m3 input implies them; <false, true> is the bf16 conv that
+// writes the first e4m3 map of the fp8 graph)
+template <bool F8, bool OF8 = F8>
 __global__ __launch_bounds__(512, 2) void conv_dma4_kernel(F8Args a) {
   using C = G4;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -96,7 +98,7 @@ __global__ __launch_bounds__(512, 2) void conv_dma4_kernel(F8Args a) {
   const int n31 = lane & 31, hh = lane >> 5;
   const int H = a.H, W = a.W, Cin = a.Cin, Cout = a.Cout;
   const int Wp = W + 2;
-  const int Cb = F8 ? Cin : 2 * Cin, Ob = F8 ? Cout : 2 * Cout;  // bytes per pixel of the input / output maps
+  const int Cb = F8 ? Cin : 2 * Cin, Ob = OF8 ? Cout : 2 * Cout;  // bytes per pixel of the input / output maps
   const int nchunks = Cb >> 6;                                   // 64 bytes of input channels per chunk
   int scale_w = 0;
   if constexpr (F8) {
@@ -203,7 +205,13 @@ __global__ __launch_bounds__(512, 2) void conv_dma4_kernel(F8Args a) {
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   // 16-byte store instructions per tile and wave
-  const int nstores = ((a.y != nullptr ? 4 : 0) + (a.pooled != nullptr ? 2 : 0)) * (F8 ? 1 : 2);
+  // RESIDENT WEIGHTS (as generation 2).  With one or two chunks per tile the item parity IS the chunk (or there is only one),
+  // so weight buffer p only ever holds chunk p's weights -- of the same output-channel tile too when every workgroup of the
+  // XCD group keeps its tile residue (nb % n_ct == 0).  From its third item on such a workgroup requests no weights at all:
+  // half the DMA pieces of conv1_2 / conv2_1-like layers.
+  const bool resident = nchunks <= 2 && (nb % a.n_ct) == 0;
+  int items_done = 0;
+  const int nstores = ((a.y != nullptr ? 4 : 0) + (a.pooled != nullptr ? 2 : 0)) * (OF8 ? 1 : 2);
   int in_flight = 0;  // stores issued after the last DMA of the previous item
 
   while (true) {
@@ -289,7 +297,7 @@ __global__ __launch_bounds__(512, 2) void conv_dma4_kernel(F8Args a) {
   if (has_next) {                                                                        \
     if (2 * (t) < C::A_ITERS) dma_a(nx_src, 2 * (t), buf ^ 1);                           \
     if (2 * (t) + 1 < C::A_ITERS) dma_a(nx_src, 2 * (t) + 1, buf ^ 1);                   \
-    if ((t) >= A_TAPS && (t) - A_TAPS < C::B_ITERS) dma_b(nw_src, (t) - A_TAPS, buf ^ 1); \
+    if ((t) >= A_TAPS && (t) - A_TAPS < C::B_ITERS && !skip_b) dma_b(nw_src, (t) - A_TAPS, buf ^ 1); \
     if ((t) == A_TAPS) dma_bias(nxt, last_chunk, bslot ^ 1);                             \
   }
     // An MFMA is a pure value to the optimizer: nothing orders it against the (volatile) asm reads, waits and priority
@@ -333,6 +341,7 @@ __global__ __launch_bounds__(512, 2) void conv_dma4_kernel(F8Args a) {
     const int nchunk = last_chunk ? 0 : chunk + 1;
     const char *nx_src = nullptr, *nw_src = nullptr;
     if (has_next) dma_bases(nxt, nchunk, nx_src, nw_src);
+    const bool skip_b = resident && items_done >= 1;  // the NEXT item is this workgroup's third or later
     __builtin_amdgcn_sched_barrier(0);
 
     G4_TAP(0, G4_WAIT_WA, 4, G4_LDPB(0, 0))
@@ -370,7 +379,7 @@ __global__ __launch_bounds__(512, 2) void conv_dma4_kernel(F8Args a) {
         const int cofs = cur.co0 + 32 * j + 16 * hh;  // first of this lane's 16 consecutive channels
         // 16 values -> 16 bytes of e4m3, or 32 bytes of bf16 (round-to-nearest-even, as every other epilogue)
         auto store16 = [&](char* dst, const float (&u)[16], bool on) {
-          if constexpr (F8) {
+          if constexpr (OF8) {
             const u32x4 o = {g4_pack_fp8x4(u[0], u[1], u[2], u[3], a.out_mul), g4_pack_fp8x4(u[4], u[5], u[6], u[7], a.out_mul),
                              g4_pack_fp8x4(u[8], u[9], u[10], u[11], a.out_mul),
                              g4_pack_fp8x4(u[12], u[13], u[14], u[15], a.out_mul)};
@@ -388,7 +397,7 @@ __global__ __launch_bounds__(512, 2) void conv_dma4_kernel(F8Args a) {
         if (a.y != nullptr) {
 #pragma unroll
           for (int i = 0; i < 2; ++i)
-            store16(a.y + (((int64_t)cur.n * (H + 2) + (py + i + 1)) * Wp + (px + 1)) * Ob + cofs * (F8 ? 1 : 2), v[i], true);
+            store16(a.y + (((int64_t)cur.n * (H + 2) + (py + i + 1)) * Wp + (px + 1)) * Ob + cofs * (OF8 ? 1 : 2), v[i], true);
         }
         if (a.pooled != nullptr) {
           float m[16];
@@ -399,7 +408,7 @@ __global__ __launch_bounds__(512, 2) void conv_dma4_kernel(F8Args a) {
           }
           const int Hq = H >> 1, Wq = W >> 1;
           // every wave issues these instructions (even lanes store): the counted vmcnt at the next barrier relies on it
-          store16(a.pooled + (((int64_t)cur.n * (Hq + 2) + ((py >> 1) + 1)) * (Wq + 2) + ((px >> 1) + 1)) * Ob + cofs * (F8 ? 1 : 2),
+          store16(a.pooled + (((int64_t)cur.n * (Hq + 2) + ((py >> 1) + 1)) * (Wq + 2) + ((px >> 1) + 1)) * Ob + cofs * (OF8 ? 1 : 2),
                   m, (lane & 1) == 0);
         }
       }
@@ -407,6 +416,7 @@ __global__ __launch_bounds__(512, 2) void conv_dma4_kernel(F8Args a) {
       bslot ^= 1;
     }
     if (!has_next) break;
+    ++items_done;
     lid = nlid;
     cur = nxt;
     chunk = nchunk;
@@ -452,18 +462,32 @@ __global__ void pack_weights_f8_g4_kernel(const float* __restrict__ w, char* __r
 
 }  // namespace
 
-// Can generation 4 run this shape?  (3x3, exact 16x32 tiling, at least two 64-byte chunks of input channels)
+// Can generation 4 run this shape?  (3x3, exact 16x32 tiling, whole 64-byte chunks of input channels)
 bool xv_conv3x3_f8_dma_ok(int H, int W, int Cin, int Cout) {
-  return H > 0 && W > 0 && (H & 15) == 0 && (W & 31) == 0 && Cin >= 128 && (Cin & 63) == 0 && (Cout & 63) == 0;
+  return H > 0 && W > 0 && (H & 15) == 0 && (W & 31) == 0 && Cin >= 64 && (Cin & 63) == 0 && (Cout & 63) == 0;
 }
 bool xv_conv3x3_dma4_bf16_ok(int H, int W, int Cin, int Cout) {
   return H > 0 && W > 0 && (H & 15) == 0 && (W & 31) == 0 && Cin >= 64 && (Cin & 31) == 0 && (Cout & 63) == 0;
 }
 
-// f8 != 0: configuration 24 (e4m3 maps, scale_x / out_mul as in ConvArgs); f8 == 0: configuration 25 (bf16 maps)
+namespace {
+template <bool F8, bool OF8>
+int g4_launch(const F8Args& a, int grid, hipStream_t stream) {
+  static bool attr_set[XV_MAX_DEVICES] = {false};
+  const hipError_t e = xv_allow_dynamic_lds(reinterpret_cast<const void*>(&conv_dma4_kernel<F8, OF8>), G4::LDS_BYTES, attr_set);
+  if (e != hipSuccess) return (int)e;
+  hipLaunchKernelGGL((conv_dma4_kernel<F8, OF8>), dim3((unsigned)grid), dim3(G4::NT), G4::LDS_BYTES, stream, a);
+  return xv_launch_status();
+}
+}  // namespace
+
+// in_f8 / out_f8: e4m3 input (map and weights) / output maps: (1, 1) = configuration 24; (0, 0) and (0, 1) = configuration
+// 25.  scale_x / out_mul as in ConvArgs.
 int xv_launch_conv3x3_f8_dma(const void* x, const void* wpk, const float* bias, void* y, void* pooled, int N, int H, int W,
-                             int Cin, int Cout, int relu, int f8, int scale_x, float out_mul, int num_cus, hipStream_t stream) {
-  if (!(f8 ? xv_conv3x3_f8_dma_ok(H, W, Cin, Cout) : xv_conv3x3_dma4_bf16_ok(H, W, Cin, Cout)) || (y == nullptr && pooled == nullptr))
+                             int Cin, int Cout, int relu, int in_f8, int out_f8, int scale_x, float out_mul, int num_cus,
+                             hipStream_t stream) {
+  if (!(in_f8 ? xv_conv3x3_f8_dma_ok(H, W, Cin, Cout) : xv_conv3x3_dma4_bf16_ok(H, W, Cin, Cout)) ||
+      (y == nullptr && pooled == nullptr) || (in_f8 && !out_f8))
     return XV_ESHAPE;
   F8Args a{};
   a.x = (const char*)x;
@@ -482,18 +506,8 @@ int xv_launch_conv3x3_f8_dma(const void* x, const void* wpk, const float* bias, 
   a.scale_x = scale_x;
   a.out_mul = out_mul;
   const int grid = num_cus > 0 ? num_cus : 256;
-  if (f8) {
-    static bool attr_set[XV_MAX_DEVICES] = {false};
-    const hipError_t e = xv_allow_dynamic_lds(reinterpret_cast<const void*>(&conv_dma4_kernel<true>), G4::LDS_BYTES, attr_set);
-    if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(conv_dma4_kernel<true>, dim3((unsigned)grid), dim3(G4::NT), G4::LDS_BYTES, stream, a);
-  } else {
-    static bool attr_set[XV_MAX_DEVICES] = {false};
-    const hipError_t e = xv_allow_dynamic_lds(reinterpret_cast<const void*>(&conv_dma4_kernel<false>), G4::LDS_BYTES, attr_set);
-    if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(conv_dma4_kernel<false>, dim3((unsigned)grid), dim3(G4::NT), G4::LDS_BYTES, stream, a);
-  }
-  return xv_launch_status();
+  if (in_f8) return g4_launch<true, true>(a, grid, stream);
+  return out_f8 ? g4_launch<false, true>(a, grid, stream) : g4_launch<false, false>(a, grid, stream);
 }
 
 // second image of the packed fp8 buffer (xv_pack_conv_weights_f8 calls this for 3x3 kernels with cin % 64 == 0)

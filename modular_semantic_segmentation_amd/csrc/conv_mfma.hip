@@ -40,7 +40,8 @@ int xv_launch_conv1x1_n64(const __bf16* x, const __bf16* wpk, const float* bias,
 bool xv_conv3x3_f8_dma_ok(int H, int W, int Cin, int Cout);
 bool xv_conv3x3_dma4_bf16_ok(int H, int W, int Cin, int Cout);
 int xv_launch_conv3x3_f8_dma(const void* x, const void* wpk, const float* bias, void* y, void* pooled, int N, int H, int W,
-                             int Cin, int Cout, int relu, int f8, int scale_x, float out_mul, int num_cus, hipStream_t stream);
+                             int Cin, int Cout, int relu, int in_f8, int out_f8, int scale_x, float out_mul, int num_cus,
+                             hipStream_t stream);
 void xv_launch_pack_weights_f8_g4(const float* w, char* out, int taps, int cin, int cout, float mul, hipStream_t stream);
 
 namespace {
@@ -1901,6 +1902,10 @@ __global__ void pack_weights_multi_kernel(const xv_pack_desc* __restrict__ table
   }
 }
 
+__global__ void pack_weights_f8_header_kernel(char* __restrict__ out, int scale_exp) {
+  reinterpret_cast<int*>(out)[threadIdx.x] = threadIdx.x == 0 ? scale_exp : 0;
+}
+
 // fp8 image: [256-byte header][tap][cin/128][cout][128 B, 16-byte slots swizzled by xv_swz]; one thread = 4 bytes
 __global__ void pack_weights_f8_kernel(const float* __restrict__ w, char* __restrict__ out, int taps, int cin, int cout,
                                        int scale_exp, float mul) {
@@ -1973,13 +1978,13 @@ int launch_cfg(int cfg, const ConvArgs& a, hipStream_t s) {
   if (a.Cout % kGeo[cfg].bn) return XV_ESHAPE;
   if (cfg == 24) {
     if (KS != 3 || !a.in_f8 || !a.out_f8 || a.mask != nullptr || a.addend != nullptr) return XV_ESHAPE;
-    return xv_launch_conv3x3_f8_dma(a.x, a.wpk, a.bias, a.y, a.pooled, a.N, a.H, a.W, a.Cin, a.Cout, a.relu, 1, a.scale_x,
+    return xv_launch_conv3x3_f8_dma(a.x, a.wpk, a.bias, a.y, a.pooled, a.N, a.H, a.W, a.Cin, a.Cout, a.relu, 1, 1, a.scale_x,
                                     a.out_mul, a.num_cus, s);
   }
   if (cfg == 25) {
-    if (KS != 3 || a.in_f8 || a.out_f8 || a.mask != nullptr || a.addend != nullptr) return XV_ESHAPE;
-    return xv_launch_conv3x3_f8_dma(a.x, a.wpk, a.bias, a.y, a.pooled, a.N, a.H, a.W, a.Cin, a.Cout, a.relu, 0, 0, 1.f, a.num_cus,
-                                    s);
+    if (KS != 3 || a.in_f8 || a.mask != nullptr || a.addend != nullptr) return XV_ESHAPE;
+    return xv_launch_conv3x3_f8_dma(a.x, a.wpk, a.bias, a.y, a.pooled, a.N, a.H, a.W, a.Cin, a.Cout, a.relu, 0, a.out_f8, 0,
+                                    a.out_mul, a.num_cus, s);
   }
   if (a.in_f8) {
     // the fp8 kernel is built for the tile shapes with LDS-DMA weight stages (the ones the bf16 chooser falls back to)
@@ -2071,6 +2076,9 @@ int pick_cfg(const ConvArgs& a, int k) {
     // generation 4 wherever the map tiles exactly in 16x32 (XV_F8_NO_GEN4=1: first generation everywhere, A/B timing)
     static const bool no_gen4 = getenv("XV_F8_NO_GEN4") != nullptr;
     if (k == 3 && a.in_f8 && a.out_f8 && !no_gen4 && xv_conv3x3_f8_dma_ok(a.H, a.W, a.Cin, a.Cout)) return 24;
+    // the bf16 conv that writes the first e4m3 map: generation 2 has no e4m3 epilogue, generation 4 does
+    if (k == 3 && !a.in_f8 && a.out_f8 && !no_gen4 && xv_conv3x3_dma4_bf16_ok(a.H, a.W, a.Cin, a.Cout)) return 25;
+    if (a.in_f8 && (a.Cin & 127)) return -1;  // 64-channel e4m3 chunks: generation 4 only
     // 16x32 patch, 8 waves, five taps per barrier where it tiles the map (large maps); else two 4-wave workgroups
     if (k == 3 && covered(16) <= g1 && (int64_t)a.N * a.H * a.W >= XV_F8_BIG_MAP) return 16;
     return covered(15) < covered(14) ? 15 : 14;
@@ -2140,7 +2148,8 @@ int conv_fwd_impl(const xv_act* x, const void* w_packed, const float* bias, cons
   XV_CHECK_SHAPE(y->n == x->n && y->h == x->h && y->w == x->w && y->c > 0 && (y->c & 63) == 0);
   XV_CHECK_ARG((x->dtype == XV_BF16 || x->dtype == XV_FP8) && (y->dtype == XV_BF16 || y->dtype == XV_FP8));
   const int in_f8 = x->dtype == XV_FP8, out_f8 = y->dtype == XV_FP8;
-  if (in_f8) XV_CHECK_SHAPE((x->c & 127) == 0 && x->scale_exp > -127 && x->scale_exp < 127);
+  // e4m3 operands: 128-channel chunks (first generation); a 3x3 conv on the generation-4 kernel takes 64-channel chunks
+  if (in_f8) XV_CHECK_SHAPE((x->c & (k == 3 ? 63 : 127)) == 0 && x->scale_exp > -127 && x->scale_exp < 127);
   if (in_f8 || out_f8) XV_CHECK_SHAPE(mask == nullptr && addend == nullptr);  // forward only
   if (out_f8) XV_CHECK_SHAPE(y->scale_exp > -100 && y->scale_exp < 100);
   if (pooled && pooled->data) XV_CHECK_ARG(pooled->dtype == y->dtype && pooled->scale_exp == y->scale_exp);
@@ -2177,6 +2186,7 @@ int conv_fwd_impl(const xv_act* x, const void* w_packed, const float* bias, cons
   }
   if (cfg < 0) cfg = pick_cfg(a, k);
   if (cfg < 0) return XV_ESHAPE;
+  if (in_f8 && (a.Cin & 127) && cfg != 24) return XV_ESHAPE;  // 64-channel e4m3 chunks exist in generation 4 only
   hipStream_t s = (hipStream_t)stream;
   return k == 3 ? launch_cfg<3>(cfg, a, s) : launch_cfg<1>(cfg, a, s);
 }
@@ -2189,19 +2199,23 @@ extern "C" size_t xv_packed_weight_bytes(int k, int cin, int cout) {
 }
 
 extern "C" size_t xv_packed_weight_bytes_f8(int k, int cin, int cout) {
-  if ((k != 1 && k != 3) || cin <= 0 || cout <= 0 || (cin & 127) || (cout & 63)) return 0;
-  return 256 + (size_t)k * k * cin * cout * (k == 3 ? 2 : 1);  // 3x3: the generation-1 and the generation-4 image
+  if ((k != 1 && k != 3) || cin <= 0 || cout <= 0 || (cin & (k == 3 ? 63 : 127)) || (cout & 63)) return 0;
+  // 3x3: the generation-1 image (left empty when cin is not a multiple of 128) and the generation-4 image
+  return 256 + (size_t)k * k * cin * cout * (k == 3 ? 2 : 1);
 }
 
 extern "C" int xv_pack_conv_weights_f8(const float* w_hwio, void* packed, int k, int cin, int cout, int scale_exp,
                                         void* stream) {
   XV_CHECK_ARG(w_hwio && packed && (((uintptr_t)packed) & 15) == 0);
-  XV_CHECK_SHAPE((k == 1 || k == 3) && cin > 0 && cout > 0 && (cin & 127) == 0 && (cout & 63) == 0);
+  XV_CHECK_SHAPE((k == 1 || k == 3) && cin > 0 && cout > 0 && (cin & (k == 3 ? 63 : 127)) == 0 && (cout & 63) == 0);
   XV_CHECK_SHAPE(scale_exp > -127 && scale_exp < 127);
   const int64_t total4 = (int64_t)k * k * cin * cout / 4;
   const int blocks = (int)((total4 + 255) / 256 < 4096 ? (total4 + 255) / 256 : 4096);
-  hipLaunchKernelGGL(pack_weights_f8_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w_hwio, (char*)packed, k * k,
-                     cin, cout, scale_exp, exp2f((float)-scale_exp));
+  if ((cin & 127) == 0)
+    hipLaunchKernelGGL(pack_weights_f8_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w_hwio, (char*)packed, k * k,
+                       cin, cout, scale_exp, exp2f((float)-scale_exp));
+  else  // no 128-channel image: header only (scale exponent, zero padding)
+    hipLaunchKernelGGL(pack_weights_f8_header_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (char*)packed, scale_exp);
   if (k == 3)
     xv_launch_pack_weights_f8_g4(w_hwio, (char*)packed + 256 + (size_t)9 * cin * cout, 9, cin, cout, exp2f((float)-scale_exp),
                                  (hipStream_t)stream);

@@ -51,6 +51,8 @@ CASES = [
     (2, 32, 64, 128, 64, 3, True, 24, (2, -1, 2)),
     (1, 48, 96, 384, 192, 3, True, 24, (1, -2, 3)),       # six chunks, three output-channel tiles per patch
     (3, 128, 256, 128, 128, 3, True, 24, (0, -1, 2)),     # 384 tiles on 256 workgroups: the persistent walk, tile after tile
+    (2, 64, 128, 64, 128, 3, False, 24, (1, -1, 2)),      # conv2_1 of the fp8 plan: ONE 64-channel e4m3 chunk per tile
+    (1, 32, 64, 64, 64, 3, True, -1, (0, 0, 1)),          # ... and the chooser must find it (no first-generation form)
 ]
 
 
@@ -86,8 +88,8 @@ def test_fp8_conv_exact_on_integers(ops, n, h, w, cin, cout, k, pool, cfg, exps)
         ops.conv2d_fwd(xa, wp, _dev(b), k, relu=True, pooled=q2, write_y=False, cfg=cfg)       # pooled-only launch
         torch.cuda.synchronize()
         assert torch.equal(q2.t.view(torch.uint8), q.t.view(torch.uint8))
-    if cfg == 24:
-        # generation 4 writes e4m3 maps only; without relu:
+    if cfg == 24 or cin % 128:
+        # generation 4 writes e4m3 maps only (and 64-channel e4m3 chunks exist there only); without relu:
         yn = ops.Act(n, h, w, cout, dtype='fp8', scale_exp=ey + 1)
         ops.conv2d_fwd(xa, wp, _dev(b), k, relu=False, y=yn, cfg=cfg)
         torch.cuda.synchronize()
@@ -126,12 +128,14 @@ def test_fp8_conv_tile_configurations_agree(ops):
     assert all(torch.equal(outs[14], outs[c]) for c in (15, 16, 19, 20))
 
 
-@pytest.mark.parametrize('cfg', [-1, 4, 10, 14, 16])
+@pytest.mark.parametrize('cfg', [-1, 4, 10, 14, 16, 25])
 def test_bf16_conv_with_fp8_output(ops, cfg):
     """conv2_1 of the fp8 network: 64 input channels are half an fp8 MFMA, so it stays a bf16 convolution whose
     epilogue writes e4m3 for conv2_2 (first-generation tiles only; the chooser avoids the others)."""
     rng = np.random.default_rng(9)
     n, h, w, cin, cout, ey = 1, 24, 48, 64, 128, 2
+    if cfg == 25:           # generation 4 (conv1_2 of the fp8 plan where conv2_1 takes e4m3 chunks): exact 16x32 tilings
+        n, h, w = 2, 32, 96
     x = rng.integers(-2, 3, (n, h, w, cin)).astype(np.float32)
     wt = rng.integers(-1, 2, (3, 3, cin, cout)).astype(np.float32)
     b = rng.integers(-3, 4, cout).astype(np.float32)
@@ -214,10 +218,15 @@ def test_fp8_engine_against_fp8_policy_oracle(ops, h, w):
     # ---- every fp8 layer on the GPU's OWN input map: oracle conv of the same e4m3 operands, then the same output
     # rounding.  Only fp32 accumulation order separates the two, so they differ on the few values that sit on an
     # e4m3 rounding boundary, by one grid step.
-    from modular_semantic_segmentation_amd.fcn import ENCODER, FP8_CONVS
+    from modular_semantic_segmentation_amd.fcn import ENCODER, fp8_plan
+    convs8, maps8 = fp8_plan(h, w)
+    # 64x96: conv2_1's 32x48 map does not tile in 16x32 -> bf16 operands, it writes the first e4m3 map (first-generation
+    # kernels throughout); 384x768: conv2_1 takes 64-channel e4m3 chunks on the generation-4 kernel, conv1_2 writes e4m3
+    assert ('conv2_1' in convs8) == (h == 384) and ('conv1_2' in maps8) == (h == 384)
+    assert L['pool1'].dtype == ('fp8' if h == 384 else 'bf16')
     prev = None
     for name, cout, pool in ENCODER:
-        if name in FP8_CONVS:
+        if name in convs8:
             xin = L[prev].real().cpu().numpy()
             wq = fo.round_e4m3(wts['rgb/%s/kernel' % name], eng.w8_exp[name])
             y32 = _nhwc(_oracle(xin, wq, wts['rgb/%s/bias' % name], True))
@@ -339,7 +348,7 @@ def test_fp8_conv_properties_at_2048x1024_layer_sizes(ops, h, w, cin, cout):
 
 def test_fp8_engine_at_2048x1024_against_fp8_policy_oracle(ops):
     """conv_dtype='fp8' on ONE 2048x1024 image (configs[4]'s size): calibration covers every fp8 map, and two deep
-    layers (conv3_2 on its 256x512 map, conv5_2 on 64x128) are recomputed by the fp8-policy oracle from the GPU's OWN
+    layers (conv3_2 on its 256x512 map, conv5_2 on 64x128) and conv2_1 (64-channel e4m3 chunks, 512x1024) are recomputed by the fp8-policy oracle from the GPU's OWN
     e4m3 input map -- the same operands, the same output rounding, so the two differ only where fp32 accumulation order
     moves a value across an e4m3 rounding boundary, by one grid step."""
     from modular_semantic_segmentation_amd.fcn import FP8_MAPS, FcnEngine
@@ -353,7 +362,8 @@ def test_fp8_engine_at_2048x1024_against_fp8_policy_oracle(ops):
     out = eng.forward(x, want=('score', 'label'), keep_all=True)
     torch.cuda.synchronize()
     L = out['layers']
-    for name, src in (('conv3_2', 'conv3_1'), ('conv5_2', 'conv5_1')):
+    assert L['pool1'].dtype == 'fp8'            # conv1_2 wrote the first e4m3 map, conv2_1 read 64-channel e4m3 chunks
+    for name, src in (('conv2_1', 'pool1'), ('conv3_2', 'conv3_1'), ('conv5_2', 'conv5_1')):
         assert L[name].dtype == 'fp8' and L[src].dtype == 'fp8'
         xin = L[src].real().cpu().numpy()
         wq = fo.round_e4m3(wts['rgb/%s/kernel' % name], eng.w8_exp[name])
