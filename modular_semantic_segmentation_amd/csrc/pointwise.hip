@@ -151,10 +151,12 @@ __device__ __forceinline__ void split3_bf16x8(const float (&v)[8], bf16x8& h, bf
   l = __builtin_bit_cast(bf16x8, u32x4{hi16_pair(ll[0], ll[1]), hi16_pair(ll[2], ll[3]), hi16_pair(ll[4], ll[5]), hi16_pair(ll[6], ll[7])});
 }
 
-template <int CIN>
+// OUT8: the map is written as e4m3 of value * out_mul (the fp8 graph where conv1_2 takes e4m3 operands, fcn.fp8_plan): a
+// tile is then ONE contiguous 1 KB store (16 pixels x 64 channels)
+template <int CIN, bool OUT8 = false>
 __global__ __launch_bounds__(256) void conv_first_mfma_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                              const float* __restrict__ b, __bf16* __restrict__ y, int N,
-                                                             int H, int W, int relu, int tpw) {
+                                                             int H, int W, int relu, int tpw, float out_mul = 1.f) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int j = lane & 15, g = lane >> 4;
@@ -257,6 +259,7 @@ __global__ __launch_bounds__(256) void conv_first_mfma_kernel(const float* __res
     bf16x8 xh, xm, xl;
     split3_bf16x8(v, xh, xm, xl);
     __bf16* dst = y + (((int64_t)n * (H + 2) + (py + 1)) * (W + 2) + (tx * 16 + 1)) * 64 + st_g;
+    char* dst8 = reinterpret_cast<char*>(y) + (((int64_t)n * (H + 2) + (py + 1)) * (W + 2) + (tx * 16 + 1)) * 64 + lane * 16;
     // next tile: advance the walk and request its taps; they land behind this tile's MFMAs, and this tile's stores are
     // issued after them (the vector-memory counter retires in order: waiting for the taps then never waits for the
     // stores issued behind them)
@@ -284,6 +287,26 @@ __global__ __launch_bounds__(256) void conv_first_mfma_kernel(const float* __res
     for (int jb = 0; jb < 4; ++jb) acc[jb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm[jb], xh, acc[jb], 0, 0, 0);
 #pragma unroll
     for (int jb = 0; jb < 4; ++jb) acc[jb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[jb], xh, acc[jb], 0, 0, 0);
+    if constexpr (OUT8) {
+      // lane (pixel j, row group g) holds channels 16 jb + 4 g .. + 3 of block jb: one dword of e4m3 each, at 16-byte slot
+      // jb ^ ((j >> 1) & 3) of the pixel's 64-byte row in the wave's stage (two-way write conflicts: free); read back as
+      // 16 bytes per lane = pixel lane >> 2, slot lane & 3
+      uint32_t* st32 = reinterpret_cast<uint32_t*>(stage);
+#pragma unroll
+      for (int jb = 0; jb < 4; ++jb) {
+        f32x4 t = acc[jb];
+        if (relu) t = f32x4{fmaxf(t.x, 0.f), fmaxf(t.y, 0.f), fmaxf(t.z, 0.f), fmaxf(t.w, 0.f)};
+        st32[j * 16 + ((jb ^ ((j >> 1) & 3)) << 2) + g] = xv_pack_fp8x4(t.x, t.y, t.z, t.w, out_mul);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      const int pj = lane >> 2, sl = lane & 3;
+      const u32x4 r = stage[pj * 4 + (sl ^ ((pj >> 1) & 3))];
+      *reinterpret_cast<u32x4*>(dst8) = r;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      continue;
+    }
     u32x2 packed[4];
 #pragma unroll
     for (int jb = 0; jb < 4; ++jb)
@@ -891,10 +914,13 @@ inline int grid_for(int64_t total, int per_block = 256, int cap = 8192) {
 
 extern "C" int xv_conv2d_first_fwd(const float* x, int n, int h, int w, int cin, const float* w_hwio,
                                    const float* bias, const xv_act* y, int relu, void* stream) {
-  XV_REQUIRE_BF16(y);
   XV_CHECK_ARG(x && w_hwio && bias && y && y->data);
+  XV_CHECK_ARG(y->dtype == XV_BF16 || y->dtype == XV_FP8);
   XV_CHECK_SHAPE(n > 0 && h > 0 && w > 0 && cin >= 1 && cin <= 4);
   XV_CHECK_SHAPE(y->n == n && y->h == h && y->w == w && y->c == 64);
+  const bool out8 = y->dtype == XV_FP8;  // e4m3 output: the matrix-core kernel only (1 / 3 channels, w % 16 == 0)
+  if (out8) XV_CHECK_SHAPE((cin == 1 || cin == 3) && (w & 15) == 0 && y->scale_exp > -100 && y->scale_exp < 100);
+  const float out_mul = out8 ? exp2f((float)-y->scale_exp) : 1.f;
   XV_CHECK_SHAPE((w & 1) == 0 && w >= 16 && (int64_t)n * h * (w / 2) < 0x7fffff00);
   const int64_t npair = (int64_t)n * h * (w / 2);
   const unsigned grid = (unsigned)((npair + 255) / 256);
@@ -903,7 +929,7 @@ extern "C" int xv_conv2d_first_fwd(const float* x, int n, int h, int w, int cin,
   // The MFMA form takes whole 16-pixel tiles and 32-bit float offsets into x; XV_FIRST_OLD=1 keeps the FMA kernel
   // (A/B timing), XV_FIRST_WG_PER_CU sizes the persistent grid.
   static const bool use_old = getenv("XV_FIRST_OLD") != nullptr;
-  if ((cin == 1 || cin == 3) && (w & 15) == 0 && (int64_t)n * h * w * cin < 0x7ff00000 && !use_old) {
+  if ((cin == 1 || cin == 3) && (w & 15) == 0 && (int64_t)n * h * w * cin < 0x7ff00000 && (!use_old || out8)) {
     // 98 VGPRs: five workgroups resident per CU; measured at 8 x 384 x 768 with grid-stride tiles: 5 per CU (one round)
     // 78 / 102 us (depth / RGB), 8: 70 / 92, 16: 65 / 92, 32: 67 / 98, 64: 83 / 122; with contiguous runs per wave 8 per CU:
     // 59 / 84, 16: 62 / 96, 32: 71 / 101; 4 or 5 per CU (all resident, one round): 57 / 83; 3: 88 / 100; 6 (one more than
@@ -914,12 +940,20 @@ extern "C" int xv_conv2d_first_fwd(const float* x, int n, int h, int w, int cin,
     const int64_t g0 = want < cap ? want : cap;
     const int tpw = (int)((ntiles + g0 * 4 - 1) / (g0 * 4));               // tiles per wave
     const unsigned g2 = (unsigned)((ntiles + (int64_t)tpw * 4 - 1) / ((int64_t)tpw * 4));
-    if (cin == 1)
-      hipLaunchKernelGGL(conv_first_mfma_kernel<1>, dim3(g2), dim3(256), 0, s, x, w_hwio, bias, yp, n, h, w, relu, tpw);
+    if (out8) {
+      if (cin == 1)
+        hipLaunchKernelGGL((conv_first_mfma_kernel<1, true>), dim3(g2), dim3(256), 0, s, x, w_hwio, bias, yp, n, h, w, relu, tpw,
+                           out_mul);
+      else
+        hipLaunchKernelGGL((conv_first_mfma_kernel<3, true>), dim3(g2), dim3(256), 0, s, x, w_hwio, bias, yp, n, h, w, relu, tpw,
+                           out_mul);
+    } else if (cin == 1)
+      hipLaunchKernelGGL(conv_first_mfma_kernel<1>, dim3(g2), dim3(256), 0, s, x, w_hwio, bias, yp, n, h, w, relu, tpw, 1.f);
     else
-      hipLaunchKernelGGL(conv_first_mfma_kernel<3>, dim3(g2), dim3(256), 0, s, x, w_hwio, bias, yp, n, h, w, relu, tpw);
+      hipLaunchKernelGGL(conv_first_mfma_kernel<3>, dim3(g2), dim3(256), 0, s, x, w_hwio, bias, yp, n, h, w, relu, tpw, 1.f);
     return xv_launch_status();
   }
+  if (out8) return XV_ESHAPE;
   switch (cin) {
     case 1: hipLaunchKernelGGL(conv_first_kernel<1>, dim3(grid), dim3(256), 0, s, x, w_hwio, bias, yp, n, h, w, relu); break;
     case 2: hipLaunchKernelGGL(conv_first_kernel<2>, dim3(grid), dim3(256), 0, s, x, w_hwio, bias, yp, n, h, w, relu); break;

@@ -89,6 +89,19 @@ __host__ __device__ static inline int xv_swz(int row, int slot) { return slot ^ 
 // 64-byte rows (generation-2 conv kernel): slot s of row `row` lives at s ^ ((row >> 1) & 2)
 __host__ __device__ static inline int xv_swz32(int row, int slot) { return slot ^ ((row >> 1) & 2); }
 
+// four fp32 -> four OCP e4m3 bytes (round-to-nearest-even) of value * mul, saturating at the largest finite e4m3 (the
+// conversion's own overflow behaviour depends on a mode bit, so the clamp is explicit)
+__device__ static inline uint32_t xv_pack_fp8x4(float v0, float v1, float v2, float v3, float mul) {
+  const float a = __builtin_amdgcn_fmed3f(v0 * mul, -448.f, 448.f);
+  const float b = __builtin_amdgcn_fmed3f(v1 * mul, -448.f, 448.f);
+  const float c = __builtin_amdgcn_fmed3f(v2 * mul, -448.f, 448.f);
+  const float d = __builtin_amdgcn_fmed3f(v3 * mul, -448.f, 448.f);
+  int p = 0;
+  p = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, p, false);
+  p = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, p, true);
+  return (uint32_t)p;
+}
+
 __device__ static inline uint32_t pack_bf16x2(float lo, float hi) {
   typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
   bf16x2 v = {(__bf16)lo, (__bf16)hi};

@@ -20,20 +20,21 @@ ENCODER = [  # (name, cout, pool_after)   simple_fcn.py:39-67
     ('conv5_1', 512, None), ('conv5_2', 512, None), ('conv5_3', 512, None)]
 BN_EPS = 1e-3  # [TF1] tf.layers.batch_normalization default epsilon
 # conv_dtype='fp8' (BASELINE config "fp8 MFMA conv path"): the convs from 128 input channels up run on the block-scaled
-# e4m3 MFMA kernels; conv1_1 (fp32, raw input) and conv1_2 stay as they are; the two 1x1 score convs read fp8 and write
-# bf16 for the fp32 decoder head.  conv2_1 (64 input channels) depends on the map: see fp8_plan().
+# e4m3 MFMA kernels; conv1_1 reads the raw fp32 input; the two 1x1 score convs read fp8 and write bf16 for the fp32
+# decoder head.  conv1_2 and conv2_1 (64 input channels) depend on the map: see fp8_plan().
 FP8_CONVS = ('conv2_2', 'conv3_1', 'conv3_2', 'conv3_3', 'conv4_1', 'conv4_2', 'conv4_3', 'conv5_1', 'conv5_2', 'conv5_3')
 # conv outputs that may be stored as e4m3, each with a calibrated scale (pools inherit their conv's scale)
-FP8_MAPS = ('conv1_2', 'conv2_1') + FP8_CONVS
+FP8_MAPS = ('conv1_1', 'conv1_2', 'conv2_1') + FP8_CONVS
 
 
 def fp8_plan(h, w):
-    """(convs with e4m3 operands, conv outputs stored as e4m3) for an h x w input.  conv2_1 joins the e4m3 convs where its
-    h/2 x w/2 map tiles exactly in 16x32 pixels -- the generation-4 kernel (csrc/conv_f8_dma.hip) takes 64-channel e4m3
-    chunks, one tap per K = 64 MFMA; the first-generation kernel needs 128 -- and conv1_2 then writes the first e4m3 map
-    (its pooled output); elsewhere conv2_1 keeps bf16 operands and writes it.  oracle/fcn_oracle.py states the same rule."""
+    """(convs with e4m3 operands, conv outputs stored as e4m3) for an h x w input.  conv1_2 and conv2_1 (64 input channels)
+    join the e4m3 convs where conv2_1's h/2 x w/2 map (and with it conv1_2's) tiles exactly in 16x32 pixels -- the
+    generation-4 kernel (csrc/conv_f8_dma.hip) takes 64-channel e4m3 chunks, one tap per K = 64 MFMA; the first-generation
+    kernel needs 128 -- and conv1_1 then writes the first e4m3 map; elsewhere both keep bf16 operands and conv2_1 writes
+    it.  oracle/fcn_oracle.py states the same rule."""
     if (h // 2) % 16 == 0 and (w // 2) % 32 == 0:
-        return ('conv2_1',) + FP8_CONVS, ('conv1_2', 'conv2_1') + FP8_CONVS
+        return ('conv1_2', 'conv2_1') + FP8_CONVS, ('conv1_1', 'conv1_2', 'conv2_1') + FP8_CONVS
     return FP8_CONVS, ('conv2_1',) + FP8_CONVS
 
 
@@ -188,7 +189,7 @@ class FcnEngine(object):
         if self.conv_dtype == 'fp8':
             # e4m3 images of the same (batch-norm folded) kernels, each with its own power-of-two scale
             self.w8, self.w8_exp = {}, {}
-            for name in ('conv2_1',) + FP8_CONVS + ('score_conv4', 'score_conv5'):
+            for name in ('conv1_2', 'conv2_1') + FP8_CONVS + ('score_conv4', 'score_conv5'):
                 k, _ = _fold_bn(v, '%s/%s' % (p, name), v['%s/%s/kernel' % (p, name)], v['%s/%s/bias' % (p, name)])
                 if name == 'score_conv5' and 'upscore_conv5' in deconv_scale:
                     k = k * deconv_scale['upscore_conv5']
@@ -244,7 +245,7 @@ class FcnEngine(object):
         e = self.fp8_scales
         convs8, maps8 = fp8_plan(h, w)
         L = {}
-        cur = self._act('conv1_1', n, h, w, 64)
+        cur = self._act('conv1_1', n, h, w, 64, **(dict(dtype='fp8', scale_exp=e['conv1_1']) if 'conv1_1' in maps8 else {}))
         ops.conv2d_first_fwd(x.contiguous(), self.w['conv1_1'], self.b['conv1_1'], cur, relu=True)
         L['conv1_1'] = cur
         ch, cw = h, w

@@ -212,7 +212,7 @@ def test_fp8_engine_against_fp8_policy_oracle(ops, h, w):
     torch.cuda.synchronize()
     fs = dict(scales)
     fs.update({'w:' + k: v for k, v in eng.w8_exp.items()})
-    keep = ['conv2_1', 'conv2_2', 'conv3_3', 'conv4_3', 'conv5_3', 'fused', 'score']
+    keep = ['conv1_1', 'conv1_2', 'conv2_1', 'conv2_2', 'conv3_3', 'conv4_3', 'conv5_3', 'fused', 'score']
     ref = fo.fcn_forward(x, wts, 'rgb', 'fp8', keep=keep, fp8_scales=fs)
     L = out['layers']
     # ---- every fp8 layer on the GPU's OWN input map: oracle conv of the same e4m3 operands, then the same output
@@ -222,8 +222,8 @@ def test_fp8_engine_against_fp8_policy_oracle(ops, h, w):
     convs8, maps8 = fp8_plan(h, w)
     # 64x96: conv2_1's 32x48 map does not tile in 16x32 -> bf16 operands, it writes the first e4m3 map (first-generation
     # kernels throughout); 384x768: conv2_1 takes 64-channel e4m3 chunks on the generation-4 kernel, conv1_2 writes e4m3
-    assert ('conv2_1' in convs8) == (h == 384) and ('conv1_2' in maps8) == (h == 384)
-    assert L['pool1'].dtype == ('fp8' if h == 384 else 'bf16')
+    assert ('conv1_2' in convs8) == (h == 384) and ('conv2_1' in convs8) == (h == 384) and ('conv1_1' in maps8) == (h == 384)
+    assert L['conv1_1'].dtype == L['pool1'].dtype == ('fp8' if h == 384 else 'bf16')
     prev = None
     for name, cout, pool in ENCODER:
         if name in convs8:
@@ -247,10 +247,17 @@ def test_fp8_engine_against_fp8_policy_oracle(ops, h, w):
         np.testing.assert_allclose(got, fo.round_bf16(y32), rtol=2.0 ** -7, atol=1e-4 * np.abs(y32).max(), err_msg=name)
     # ---- end to end against the oracle run from the image: rounding flips compound through 10 coarse-grid layers of a
     # random-init network (the first fp8 maps agree almost everywhere, deeper ones drift)
-    for name, max_flip in (('conv2_1', 2e-3), ('conv2_2', 2e-2)):
+    # (the first e4m3 map is conv1_1's where conv1_2 / conv2_1 take e4m3 operands, conv2_1's elsewhere)
+    chain = (('conv1_1', 2e-3), ('conv1_2', 5e-3), ('conv2_1', 2e-2), ('conv2_2', 4e-2)) if 'conv1_1' in maps8 else \
+        (('conv2_1', 2e-3), ('conv2_2', 2e-2))
+    for name, max_flip in chain:
         got = L[name].real().cpu().numpy()
+        print('%s: %.5f of the e4m3 values differ from the oracle run from the image' % (name, (got != ref[name]).mean()))
         assert (got != ref[name]).mean() < max_flip, (name, (got != ref[name]).mean())
-    for name, tol in (('conv3_3', 0.03), ('conv4_3', 0.1), ('conv5_3', 0.15)):
+    # (two more e4m3 layers in front where conv1_2 / conv2_1 take e4m3 operands: the drift starts earlier)
+    deep = (('conv3_3', 0.05), ('conv4_3', 0.13), ('conv5_3', 0.2)) if 'conv1_1' in maps8 else \
+        (('conv3_3', 0.03), ('conv4_3', 0.1), ('conv5_3', 0.15))
+    for name, tol in deep:
         got = L[name].real().cpu().numpy()
         err = np.abs(got - ref[name]).mean() / (np.abs(ref[name]).mean() + 1e-20)
         assert err < tol, (name, err)
@@ -362,8 +369,8 @@ def test_fp8_engine_at_2048x1024_against_fp8_policy_oracle(ops):
     out = eng.forward(x, want=('score', 'label'), keep_all=True)
     torch.cuda.synchronize()
     L = out['layers']
-    assert L['pool1'].dtype == 'fp8'            # conv1_2 wrote the first e4m3 map, conv2_1 read 64-channel e4m3 chunks
-    for name, src in (('conv2_1', 'pool1'), ('conv3_2', 'conv3_1'), ('conv5_2', 'conv5_1')):
+    assert L['conv1_1'].dtype == 'fp8'          # conv1_1 wrote the first e4m3 map; conv1_2 / conv2_1 read 64-channel chunks
+    for name, src in (('conv2_1', 'pool1'), ('conv3_2', 'conv3_1'), ('conv5_2', 'conv5_1')):       # (conv1_2: the 384x768 test)
         assert L[name].dtype == 'fp8' and L[src].dtype == 'fp8'
         xin = L[src].real().cpu().numpy()
         wq = fo.round_e4m3(wts['rgb/%s/kernel' % name], eng.w8_exp[name])
