@@ -28,14 +28,16 @@ def expert_factory(expert_model, conv_dtype='bf16'):
 
 def engine_options(config):
     """Extra constructor arguments of the expert engines named by the model config (conv_dtype: the fp8 conv path of
-    the FCN expert; streamk: its split tail rounds, a batch-1 latency option -- see FcnEngine; the AdapNet engine has
-    none)."""
+    the FCN expert, fp8_deep: e4m3 operands from conv1_2 on -- see fcn.fp8_plan; streamk: its split tail rounds, a batch-1
+    latency option -- see FcnEngine; the AdapNet engine has none)."""
     opts = {}
     if config.get('expert_model', 'fcn') == 'fcn':
         if config.get('conv_dtype', 'bf16') != 'bf16':
             opts['conv_dtype'] = config['conv_dtype']
         if config.get('streamk', False):
             opts['streamk'] = True
+        if config.get('fp8_deep', False):
+            opts['fp8_deep'] = True
     return opts
 
 
