@@ -12,13 +12,13 @@ import re
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-CONV_SRC = os.path.join(ROOT, 'modular_semantic_segmentation_amd', 'csrc', 'conv_mfma.hip')
+CONV_SRCS = [os.path.join(ROOT, 'modular_semantic_segmentation_amd', 'csrc', f) for f in ('conv_mfma.hip', 'conv_f8_dma.hip')]
 
 
 def kernel_source_hash():
     """Ties a committed counter summary to the kernel source it was measured on: bench.py reports `traffic` only
     while this still matches."""
-    return hashlib.sha256(open(CONV_SRC, 'rb').read()).hexdigest()[:16]
+    return hashlib.sha256(b''.join(open(f, 'rb').read() for f in CONV_SRCS)).hexdigest()[:16]
 
 
 def counter_avg(dirname, counter, match):
@@ -86,12 +86,12 @@ def copy_stats(tag, sub, dest):
 
 
 def main(tag, batch=16):
-    is_conv3 = lambda k: 'conv_dma_kernel' in k or ('conv_mfma_kernel' in k and ', 3, ' in k)      # noqa: E731
+    is_conv3 = lambda k: 'conv_dma_kernel' in k or 'conv_dma4_kernel' in k or ('conv_mfma_kernel' in k and ', 3, ' in k)      # noqa: E731
     fetch = counter_avg('pmc_fetch', 'FETCH_SIZE', is_conv3)
     write = counter_avg('pmc_write', 'WRITE_SIZE', is_conv3)
-    out = {'kernel': 'conv_dma_kernel + conv_mfma_kernel (all 3x3 launches)', 'source': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, '
+    out = {'kernel': 'conv_dma_kernel + conv_dma4_kernel + conv_mfma_kernel (all 3x3 launches)', 'source': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, '
            'python3 bench.py --steps 3 --warmup 1 --serial-experts --no-graph (batch %d, 768x384)' % batch,
-           'batch': batch, 'kernel_source': 'csrc/conv_mfma.hip', 'kernel_source_sha256_16': kernel_source_hash()}
+           'batch': batch, 'kernel_source': 'csrc/conv_mfma.hip + csrc/conv_f8_dma.hip', 'kernel_source_sha256_16': kernel_source_hash()}
     if fetch and write:
         out.update(fetch_size_kb_per_launch=round(fetch[0], 1), write_size_kb_per_launch=round(write[0], 1),
                    launches=fetch[1],
@@ -106,10 +106,13 @@ def main(tag, batch=16):
 
     cmd = 'python3 bench.py --steps 3 --warmup 1 --serial-experts --no-graph --no-cpu-baseline --no-accuracy --no-extra'
     mfma_summary(tag, '', {'conv_dma_kernel': lambda k: 'conv_dma_kernel' in k,
+                           'conv_dma4_kernel<false, false> (generation 4, bf16)': lambda k: 'conv_dma4_kernel<false, false>' in k,
                            'conv_mfma_kernel (bf16, first generation)': lambda k: 'conv_mfma_kernel' in k and not is_f8(k)},
                  cmd + ' (batch 16, 768x384)')
-    mfma_summary(tag, '8', {'conv_mfma_kernel<F8> (e4m3 operands)': is_f8,
-                            'conv_dma_kernel (conv1_2, bf16)': lambda k: 'conv_dma_kernel' in k},
+    mfma_summary(tag, '8', {'conv_dma4_kernel<true, true> (generation 4, e4m3 operands)': lambda k: 'conv_dma4_kernel<true' in k,
+                            'conv_dma4_kernel<false, true> (conv1_2: bf16 in, e4m3 out)': lambda k: 'conv_dma4_kernel<false, true>' in k,
+                            'conv_mfma_kernel<F8> (e4m3 operands, first generation)': is_f8,
+                            'conv_dma_kernel (bf16)': lambda k: 'conv_dma_kernel' in k},
                  cmd + ' --dtype fp8 --height 1024 --width 2048 --batch 4')
     copy_stats(tag, tag + '_trace', '%s_bench_serial_kernel_stats.csv' % tag)
     copy_stats(tag, tag + '_trace8', '%s_bench_fp8_2048_kernel_stats.csv' % tag)

@@ -71,5 +71,44 @@ for (n, h, w, cin, cout, k) in CASES:
                     d = (g.cpu().float() - wv.float()).abs()
                     print('MISMATCH', (n, h, w, cin, cout, k), name, 'iter', it, 'n_diff', int((d > 0).sum()), 'max', float(d.max()), flush=True)
     print('case', (n, h, w, cin, cout, k), 'done', flush=True)
+
+# ---- generation 4 (conv_f8_dma.hip: all operands by LDS-DMA, counted vmcnt across the item barrier): maps that tile in
+# 16x32, bf16 (configuration 25) and e4m3 (24; 64- and 128-channel inputs: one and two chunks per tile), pooled outputs
+G4 = [(2, 32, 64, 256, 128, 25), (3, 48, 96, 64, 64, 25), (2, 32, 64, 128, 128, 24), (3, 32, 96, 64, 128, 24)]
+for (n, h, w, cin, cout, cfg) in G4:
+    xs = rng.integers(-2, 3, (n, h, w, cin)).astype(np.float32)
+    ws = rng.integers(-1, 2, (3, 3, cin, cout)).astype(np.float32)
+    want = None
+    for it in range(args.iters):
+        torch.cuda.empty_cache()
+        pad = torch.empty(int(rng.integers(1, 64)) * 1024 * 1024, dtype=torch.uint8, device='cuda')
+        wt = torch.from_numpy(ws).cuda()
+        b = torch.zeros(cout, device='cuda')
+        if cfg == 24:
+            x = ops.Act.from_dense(torch.from_numpy(xs).cuda(), dtype='fp8', scale_exp=0)
+            wp, _ = ops.pack_conv_weights_f8(wt, scale_exp=0)
+            y = ops.Act(n, h, w, cout, dtype='fp8', scale_exp=4)
+            q = ops.Act(n, h // 2, w // 2, cout, dtype='fp8', scale_exp=4)
+        else:
+            x = ops.Act.from_dense(torch.from_numpy(xs).cuda())
+            wp = ops.pack_conv_weights(wt)
+            y, q = ops.Act(n, h, w, cout), ops.Act(n, h // 2, w // 2, cout)
+        dirty_lds()
+        ops.conv2d_fwd(x, wp, b, 3, relu=True, y=y, pooled=q, cfg=cfg)
+        torch.cuda.synchronize()
+        got = (y.t.view(torch.uint8).clone().cpu(), q.t.view(torch.uint8).clone().cpu())
+        del pad
+        if want is None:
+            want = got
+            if cfg == 25:
+                import torch.nn.functional as F
+                y32 = F.conv2d(torch.from_numpy(xs).permute(0, 3, 1, 2), torch.from_numpy(ws).permute(3, 2, 0, 1), padding=1)
+                assert torch.equal(y.interior().cpu(), torch.relu(y32).permute(0, 2, 3, 1).to(torch.bfloat16)), 'forward wrong'
+        else:
+            for name, g, wv in zip(('y', 'pooled'), got, want):
+                if not torch.equal(g, wv):
+                    bad += 1
+                    print('MISMATCH', (n, h, w, cin, cout, cfg), name, 'iter', it, 'n_diff', int((g != wv).sum()), flush=True)
+    print('generation-4 case', (n, h, w, cin, cout, cfg), 'done', flush=True)
 print('mismatches:', bad)
 sys.exit(1 if bad else 0)
