@@ -328,10 +328,18 @@ def committed_traffic(batch, h, w):
 
 
 def extra_inference(device, label, fusion, batch, h, w, dtype='bf16', steps=10, warmup=2, ones=False, fetch=False,
-                    streamk=False, fp8_deep=False):
-    """One more BASELINE.json configuration as an `extra` record (its own model, graph and roofline pass)."""
+                    streamk=False, fp8_deep=False, zero_operands=False):
+    """One more BASELINE.json configuration as an `extra` record (its own model, graph and roofline pass).
+    zero_operands: a DIAGNOSTIC, not a workload -- every conv kernel, bias and input zero, so no MFMA operand toggles: the
+    rate the same binaries reach when power does not hold the clock down ('Generation 4')."""
     net = build_model(device, fusion=fusion, batch=batch, dtype=dtype, streamk=streamk, fp8_deep=fp8_deep)
     data = synthetic_batch(device, batch, h, w, seed=77, ones=ones)
+    if zero_operands:
+        for key in list(net.variables):
+            if 'upscore' not in key and key.rsplit('/', 1)[-1] in ('kernel', 'bias'):
+                net.variables[key] = np.zeros_like(net.variables[key])
+        net._variables_changed()
+        data = {k: torch.zeros_like(v) for k, v in data.items()}
     if dtype == 'fp8':
         net.calibrate(data)
     times, per_iter, prof, dt_serial = measure_inference(net, data, device, steps, warmup, fetch=fetch, min_seconds=1.0)
@@ -678,6 +686,9 @@ def main():
                                          'bayes', 1, 384, 768, steps=30, warmup=3, streamk=True)
             guarded(extra_inference, device, 'two-stream SimpleFCN + Dirichlet fusion 768x384 (configs[3] inference side)',
                                          'dirichlet', 16, 384, 768)
+            guarded(extra_inference, device, 'DIAGNOSTIC, not a workload: the headline step with all-zero weights, biases and inputs '
+                                             '(no MFMA operand toggles: what the same kernels reach when power does not hold the '
+                                             'clock down)', 'bayes', 16, 384, 768, zero_operands=True)
             guarded(extra_inference, device, 'BayesFusion of RGB+Depth FCN experts 1024x512 (configs[2])', 'bayes', 8, 512, 1024)
             guarded(extra_inference, device, 'two-stream SimpleFCN + Bayes fusion 2048x1024 bf16', 'bayes', 4, 1024, 2048,
                                          steps=5)
