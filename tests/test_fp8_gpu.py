@@ -312,6 +312,35 @@ def test_fp8_fusion_model_predicts(ops, golden_dir):
     assert (preds['fp8'] == preds['bf16']).mean() > 0.5      # random-init logits are nearly degenerate
 
 
+def test_fp8_deep_through_the_model_api(ops, golden_dir):
+    """`fp8_deep=True` (model config) reaches both experts: on a map that tiles conv1_1 writes e4m3 and conv1_2 / conv2_1
+    read 64-channel e4m3 chunks; predictions mostly agree with the default fp8 plan's, and the fused head equals the
+    unfused path."""
+    import os
+    from modular_semantic_segmentation_amd import get_model
+    g = np.load(os.path.join(golden_dir, 'notebook_868.npz'))
+    desc = ({'rgb': 'float32', 'depth': 'float32', 'labels': 'int32'},
+            {'rgb': (None, None, 3), 'depth': (None, None, 1), 'labels': (None, None)}, 12)
+    cfg = dict(data_description=desc, confusion_matrices={'rgb': g['cm_rgb'], 'depth': g['cm_depth']}, num_units=64,
+               prefixes={'rgb': 'rgb', 'depth': 'depth'}, num_channels={'rgb': 3, 'depth': 1}, expert_model='fcn',
+               class_prior='data', batchsize=2, seed=3, conv_dtype='fp8')
+    rng = np.random.default_rng(1)
+    data = {'rgb': rng.integers(0, 256, (2, 64, 128, 3)).astype(np.float32),
+            'depth': rng.integers(0, 65536, (2, 64, 128, 1)).astype(np.float32)}
+    preds = {}
+    for deep in (False, True):
+        net = get_model('bayes_fusion')(fp8_deep=deep, **cfg)
+        net.variables['depth/conv1_1/kernel'] = net.variables['depth/conv1_1/kernel'] / 256.0
+        net._variables_changed()
+        assert all(e.fp8_deep == deep for e in net.experts.values())
+        net.calibrate(data)
+        preds[deep] = net.predict(data)
+        assert np.array_equal(preds[deep], np.argmax(net.predict(data, output_attr='fused_score'), -1))
+        L = net.experts['rgb'].encoder(torch.from_numpy(data['rgb']).cuda(), keep_all=True)
+        assert L['conv1_1'].dtype == ('fp8' if deep else 'bf16') and L['pool1'].dtype == 'fp8'
+    assert (preds[True] == preds[False]).mean() > 0.5        # random-init logits are nearly degenerate
+
+
 # ---- BASELINE configs[4] at its FULL size (2048x1024): one-byte maps, other offsets, calibration over 4x the pixels ----
 
 @pytest.mark.parametrize('h,w,cin,cout', [(256, 512, 256, 256), (128, 256, 512, 512), (64, 128, 512, 512)])
