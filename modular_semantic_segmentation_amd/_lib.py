@@ -101,6 +101,8 @@ SIGNATURES = {
     'xv_bn_bwd': (_i, [_actp, _actp, _actp, _vp, _vp, _vp, _vp, _vp, _vp, _actp, _vp]),
     'xv_bn_bwd_reduce': (_i, [_actp, _actp, _actp, _vp, _vp, _vp, _vp, _vp, _vp]),
     'xv_bn_bwd_apply': (_i, [_actp, _actp, _actp, _vp, _vp, _vp, _vp, _i64, _actp, _vp]),
+    'xv_bn_bwd_reduce_zmask': (_i, [_actp, _actp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    'xv_bn_bwd_apply_zmask': (_i, [_actp, _actp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _actp, _vp]),
     'xv_bn_dense_bwd_reduce': (_i, [_vp, _vp, _i64, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     'xv_bn_dense_bwd_apply': (_i, [_vp, _vp, _i64, _i, _vp, _vp, _vp, _vp, _i64, _vp, _vp]),
     'xv_bn_dense_stats': (_i, [_vp, _i64, _i, _vp, _vp]),

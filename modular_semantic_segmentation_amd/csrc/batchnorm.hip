@@ -24,13 +24,16 @@ inline int bn_grid(int64_t total, int cap = 2048) {
 // ---- per-channel sums over the interior of a padded-NHWC bf16 tensor ----------------------------------------
 // MODE 0: sums[c] = sum z, sums[C + c] = sum z^2                                     (forward statistics)
 // MODE 1: sums[c] = sum g, sums[C + c] = sum g * zhat, g = dy * (y > 0 or 1)        (backward reductions)
+// MODE 2: as 1 with the relu mask RECOMPUTED from z (z * scale + shift > 0, the forward pass's own expression) instead
+//         of read from the activation map: a third less traffic (`y` then carries scale, `zsh` shift)
 // A thread owns one 8-channel group (the grid stride is a multiple of C/8), accumulates in fp32 over its pixels,
 // the block reduces through LDS and issues one double atomic per channel.
 template <int MODE>
 __global__ __launch_bounds__(256) void bn_reduce_kernel(const __bf16* __restrict__ z, const __bf16* __restrict__ dy,
                                                        const __bf16* __restrict__ y, const float* __restrict__ mean,
                                                        const float* __restrict__ invstd, double* __restrict__ sums,
-                                                       int N, int H, int W, int C) {
+                                                       int N, int H, int W, int C, const float* __restrict__ zsc = nullptr,
+                                                       const float* __restrict__ zsh = nullptr) {
   const int c8 = C >> 3;
   const int64_t total = (int64_t)N * H * W * c8;
   const int cg = threadIdx.x % c8;  // constant over the loop: 256 and gridDim.x * 256 are multiples of c8
@@ -38,9 +41,12 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const __bf16* __restrict
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
     s0[e] = s1[e] = 0.f;
-    mu[e] = MODE == 1 ? mean[cg * 8 + e] : 0.f;
-    is[e] = MODE == 1 ? invstd[cg * 8 + e] : 0.f;
+    mu[e] = MODE >= 1 ? mean[cg * 8 + e] : 0.f;
+    is[e] = MODE >= 1 ? invstd[cg * 8 + e] : 0.f;
   }
+  float sc[8], sh[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) sc[e] = MODE == 2 ? zsc[cg * 8 + e] : 0.f, sh[e] = MODE == 2 ? zsh[cg * 8 + e] : 0.f;
   // total < 2^31 (checked by the launchers): 32-bit index arithmetic
   const int total32 = (int)total, stride = (int)gridDim.x * 256;
   auto offset_of = [&](int idx) -> int64_t {
@@ -66,6 +72,68 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const __bf16* __restrict
           s1[2 * w] += a * a;
           s0[2 * w + 1] += b;
           s1[2 * w + 1] += b * b;
+        }
+    }
+  }
+  if (MODE == 2) {
+    for (; idx + stride < total32; idx += 2 * stride) {
+      u32x4 zv[2], gv[2];
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int64_t off = offset_of(idx + q * stride);
+        zv[q] = *reinterpret_cast<const u32x4*>(z + off);
+        gv[q] = *reinterpret_cast<const u32x4*>(dy + off);
+      }
+#pragma unroll
+      for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+          const float za = bf_lo(zv[q][w]), zb = bf_hi(zv[q][w]);
+          const float ga = za * sc[2 * w] + sh[2 * w] > 0.f ? bf_lo(gv[q][w]) : 0.f;
+          const float gb = zb * sc[2 * w + 1] + sh[2 * w + 1] > 0.f ? bf_hi(gv[q][w]) : 0.f;
+          s0[2 * w] += ga;
+          s1[2 * w] += ga * (za - mu[2 * w]) * is[2 * w];
+          s0[2 * w + 1] += gb;
+          s1[2 * w + 1] += gb * (zb - mu[2 * w + 1]) * is[2 * w + 1];
+        }
+    }
+    for (; idx < total32; idx += stride) {
+      const int64_t off = offset_of(idx);
+      const u32x4 zv = *reinterpret_cast<const u32x4*>(z + off), gv = *reinterpret_cast<const u32x4*>(dy + off);
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        const float za = bf_lo(zv[w]), zb = bf_hi(zv[w]);
+        const float ga = za * sc[2 * w] + sh[2 * w] > 0.f ? bf_lo(gv[w]) : 0.f;
+        const float gb = zb * sc[2 * w + 1] + sh[2 * w + 1] > 0.f ? bf_hi(gv[w]) : 0.f;
+        s0[2 * w] += ga;
+        s1[2 * w] += ga * (za - mu[2 * w]) * is[2 * w];
+        s0[2 * w + 1] += gb;
+        s1[2 * w + 1] += gb * (zb - mu[2 * w + 1]) * is[2 * w + 1];
+      }
+    }
+  }
+  if (MODE == 1) {
+    // three streams (z, dy, y): two pixels' loads in flight per thread, accumulated in pixel order (the sums do not depend
+    // on the unrolling)
+    const u32x4 ones = u32x4{0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};  // no relu mask
+    for (; idx + stride < total32; idx += 2 * stride) {
+      u32x4 zv[2], gv[2], yv[2];
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int64_t off = offset_of(idx + q * stride);
+        zv[q] = *reinterpret_cast<const u32x4*>(z + off);
+        gv[q] = *reinterpret_cast<const u32x4*>(dy + off);
+        yv[q] = y ? *reinterpret_cast<const u32x4*>(y + off) : ones;
+      }
+#pragma unroll
+      for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+          const float ga = bf_lo(yv[q][w]) > 0.f ? bf_lo(gv[q][w]) : 0.f, gb = bf_hi(yv[q][w]) > 0.f ? bf_hi(gv[q][w]) : 0.f;
+          s0[2 * w] += ga;
+          s1[2 * w] += ga * (bf_lo(zv[q][w]) - mu[2 * w]) * is[2 * w];
+          s0[2 * w + 1] += gb;
+          s1[2 * w + 1] += gb * (bf_hi(zv[q][w]) - mu[2 * w + 1]) * is[2 * w + 1];
         }
     }
   }
@@ -202,6 +270,124 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const __bf16* __restr
       o[w] = pack_bf16x2(v[0], v[1]);
     }
     *reinterpret_cast<u32x4*>(dz + off) = o;
+  }
+}
+
+// ---- the same two passes for the channel counts of the trunk (C / 8 divides 256: 64 .. 2048 channels) --------------
+// A thread keeps ONE 8-channel group for the whole launch (the grid stride is a multiple of C / 8), so the per-channel
+// constants are loaded -- and the two double divisions per channel of the backward pass done -- once per thread instead of
+// once per element (the generic kernels above ran at 1.9 TB/s on them); 32-bit index arithmetic; several pixels' loads in
+// flight per thread.  Same expressions, same bits.
+__global__ __launch_bounds__(256) void bn_apply_fast_kernel(const __bf16* __restrict__ z, const float* __restrict__ scale,
+                                                           const float* __restrict__ shift, int relu,
+                                                           __bf16* __restrict__ y, int N, int H, int W, int C) {
+  const int c8 = C >> 3;
+  const int cg = threadIdx.x % c8;
+  float sc[8], sh[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) sc[e] = scale[cg * 8 + e], sh[e] = shift[cg * 8 + e];
+  const int total = N * H * W * c8, stride = (int)gridDim.x * 256;  // < 2^31 (checked by the launcher)
+  auto offset_of = [&](int idx) -> int64_t {
+    const int p = idx / c8;
+    const int row = p / W;
+    const int x = p - row * W, n = row / H, yy = row - n * H;
+    return (((int64_t)n * (H + 2) + yy + 1) * (W + 2) + x + 1) * C + cg * 8;
+  };
+  auto apply = [&](const u32x4 zv) {
+    u32x4 o;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      float a = bf_lo(zv[w]) * sc[2 * w] + sh[2 * w];
+      float b = bf_hi(zv[w]) * sc[2 * w + 1] + sh[2 * w + 1];
+      if (relu) {
+        a = a > 0.f ? a : 0.f;
+        b = b > 0.f ? b : 0.f;
+      }
+      o[w] = pack_bf16x2(a, b);
+    }
+    return o;
+  };
+  int idx = (int)blockIdx.x * 256 + (int)threadIdx.x;
+  for (; idx + 3 * stride < total; idx += 4 * stride) {
+    int64_t off[4];
+    u32x4 v[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      off[q] = offset_of(idx + q * stride);
+      v[q] = *reinterpret_cast<const u32x4*>(z + off[q]);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) *reinterpret_cast<u32x4*>(y + off[q]) = apply(v[q]);
+  }
+  for (; idx < total; idx += stride) {
+    const int64_t off = offset_of(idx);
+    *reinterpret_cast<u32x4*>(y + off) = apply(*reinterpret_cast<const u32x4*>(z + off));
+  }
+}
+
+// MASKZ: the relu mask recomputed from z (z * zsc + zsh > 0) instead of read from y
+template <bool MASKZ>
+__global__ __launch_bounds__(256) void bn_bwd_apply_fast_kernel(const __bf16* __restrict__ dy, const __bf16* __restrict__ y,
+                                                               const __bf16* __restrict__ z, const float* __restrict__ mean,
+                                                               const float* __restrict__ invstd,
+                                                               const float* __restrict__ gamma,
+                                                               const double* __restrict__ sums, double M,
+                                                               __bf16* __restrict__ dz, int N, int H, int W, int C,
+                                                               const float* __restrict__ zsc, const float* __restrict__ zsh) {
+  const int c8 = C >> 3;
+  const int cg = threadIdx.x % c8;
+  float mu[8], is[8], gk[8], db[8], dg[8], sc[8], sh[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int c = cg * 8 + e;
+    mu[e] = mean[c], is[e] = invstd[c], gk[e] = gamma[c];
+    db[e] = (float)(sums[c] / M), dg[e] = (float)(sums[C + c] / M);
+    sc[e] = MASKZ ? zsc[c] : 0.f, sh[e] = MASKZ ? zsh[c] : 0.f;
+  }
+  const int total = N * H * W * c8, stride = (int)gridDim.x * 256;
+  auto offset_of = [&](int idx) -> int64_t {
+    const int p = idx / c8;
+    const int row = p / W;
+    const int x = p - row * W, n = row / H, yy = row - n * H;
+    return (((int64_t)n * (H + 2) + yy + 1) * (W + 2) + x + 1) * C + cg * 8;
+  };
+  const u32x4 ones = u32x4{0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
+  auto apply = [&](const u32x4 zv, const u32x4 gv, const u32x4 yv) {
+    u32x4 o;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      float v[2];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int e = 2 * w + h;
+        const float zz = h ? bf_hi(zv[w]) : bf_lo(zv[w]);
+        const float yy_ = MASKZ ? zz * sc[e] + sh[e] : (h ? bf_hi(yv[w]) : bf_lo(yv[w]));
+        const float g = yy_ > 0.f ? (h ? bf_hi(gv[w]) : bf_lo(gv[w])) : 0.f;
+        const float zh = (zz - mu[e]) * is[e];
+        v[h] = gk[e] * is[e] * (g - db[e] - zh * dg[e]);
+      }
+      o[w] = pack_bf16x2(v[0], v[1]);
+    }
+    return o;
+  };
+  int idx = (int)blockIdx.x * 256 + (int)threadIdx.x;
+  for (; idx + stride < total; idx += 2 * stride) {
+    int64_t off[2];
+    u32x4 zv[2], gv[2], yv[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      off[q] = offset_of(idx + q * stride);
+      zv[q] = *reinterpret_cast<const u32x4*>(z + off[q]);
+      gv[q] = *reinterpret_cast<const u32x4*>(dy + off[q]);
+      yv[q] = (y && !MASKZ) ? *reinterpret_cast<const u32x4*>(y + off[q]) : ones;
+    }
+#pragma unroll
+    for (int q = 0; q < 2; ++q) *reinterpret_cast<u32x4*>(dz + off[q]) = apply(zv[q], gv[q], yv[q]);
+  }
+  for (; idx < total; idx += stride) {
+    const int64_t off = offset_of(idx);
+    *reinterpret_cast<u32x4*>(dz + off) = apply(*reinterpret_cast<const u32x4*>(z + off), *reinterpret_cast<const u32x4*>(dy + off),
+                                                (y && !MASKZ) ? *reinterpret_cast<const u32x4*>(y + off) : ones);
   }
 }
 
@@ -611,8 +797,12 @@ extern "C" int xv_bn_apply(const xv_act* z, const float* scale, const float* shi
   XV_CHECK_ARG(z && y && z->data && y->data && scale && shift);
   XV_CHECK_SHAPE(same_shape(z, y) && (z->c & 7) == 0);
   const int64_t total = (int64_t)z->n * z->h * z->w * (z->c >> 3);
-  hipLaunchKernelGGL(bn_apply_kernel, dim3(bn_grid(total, 8192)), dim3(256), 0, (hipStream_t)stream,
-                     (const __bf16*)z->data, scale, shift, relu, (__bf16*)y->data, z->n, z->h, z->w, z->c);
+  if (z->c >= 64 && 2048 % z->c == 0 && total < 0x7fff0000)  // C / 8 divides the block size: a thread keeps its channels
+    hipLaunchKernelGGL(bn_apply_fast_kernel, dim3(bn_grid(total, 2048)), dim3(256), 0, (hipStream_t)stream,
+                       (const __bf16*)z->data, scale, shift, relu, (__bf16*)y->data, z->n, z->h, z->w, z->c);
+  else
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(bn_grid(total, 8192)), dim3(256), 0, (hipStream_t)stream,
+                       (const __bf16*)z->data, scale, shift, relu, (__bf16*)y->data, z->n, z->h, z->w, z->c);
   return xv_launch_status();
 }
 
@@ -648,9 +838,48 @@ extern "C" int xv_bn_bwd_apply(const xv_act* dy, const xv_act* y, const xv_act* 
   XV_CHECK_SHAPE(same_shape(dy, z) && same_shape(dz, z) && (z->c & 7) == 0 && count > 0);
   const __bf16* yp = (y && y->data) ? (const __bf16*)y->data : nullptr;
   const int64_t total = (int64_t)z->n * z->h * z->w * (z->c >> 3);
-  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(bn_grid(total, 8192)), dim3(256), 0, (hipStream_t)stream,
-                     (const __bf16*)dy->data, yp, (const __bf16*)z->data, mean, invstd, gamma, sums, (double)count,
-                     (__bf16*)dz->data, z->n, z->h, z->w, z->c);
+  if (z->c >= 64 && 2048 % z->c == 0 && total < 0x7fff0000)
+    hipLaunchKernelGGL(bn_bwd_apply_fast_kernel<false>, dim3(bn_grid(total, 2048)), dim3(256), 0, (hipStream_t)stream,
+                       (const __bf16*)dy->data, yp, (const __bf16*)z->data, mean, invstd, gamma, sums, (double)count,
+                       (__bf16*)dz->data, z->n, z->h, z->w, z->c, (const float*)nullptr, (const float*)nullptr);
+  else
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(bn_grid(total, 8192)), dim3(256), 0, (hipStream_t)stream,
+                       (const __bf16*)dy->data, yp, (const __bf16*)z->data, mean, invstd, gamma, sums, (double)count,
+                       (__bf16*)dz->data, z->n, z->h, z->w, z->c);
+  return xv_launch_status();
+}
+
+// The same two steps with the relu mask recomputed from z -- relu(z * scale + shift) > 0 exactly where z * scale + shift > 0
+// (the forward pass's own fp32 expression; a positive value never rounds to a bf16 zero above 2^-134) -- so the activation
+// map is not read: a third less traffic in the reduce step, a quarter less in the apply step.  Trunk channel counts only.
+extern "C" int xv_bn_bwd_reduce_zmask(const xv_act* dy, const xv_act* z, const float* mean, const float* invstd,
+                                      const float* scale, const float* shift, double* sums, float* dgamma, float* dbeta,
+                                      void* stream) {
+  XV_REQUIRE_BF16(dy, z);
+  XV_CHECK_ARG(dy && z && dy->data && z->data && mean && invstd && scale && shift && sums && dgamma && dbeta);
+  XV_CHECK_SHAPE(same_shape(dy, z) && z->c >= 64 && 2048 % z->c == 0);
+  hipStream_t s = (hipStream_t)stream;
+  hipError_t e = hipMemsetAsync(sums, 0, sizeof(double) * 2 * z->c, s);
+  if (e != hipSuccess) return (int)e;
+  const int64_t total = (int64_t)z->n * z->h * z->w * (z->c >> 3);
+  XV_CHECK_SHAPE(total < 0x7fff0000);
+  hipLaunchKernelGGL(bn_reduce_kernel<2>, dim3(bn_grid(total, 512)), dim3(256), 0, s, (const __bf16*)z->data,
+                     (const __bf16*)dy->data, (const __bf16*)nullptr, mean, invstd, sums, z->n, z->h, z->w, z->c, scale, shift);
+  hipLaunchKernelGGL(bn_grads_kernel, dim3((z->c + 255) / 256), dim3(256), 0, s, sums, z->c, dgamma, dbeta);
+  return xv_launch_status();
+}
+
+extern "C" int xv_bn_bwd_apply_zmask(const xv_act* dy, const xv_act* z, const float* mean, const float* invstd,
+                                     const float* scale, const float* shift, const float* gamma, const double* sums,
+                                     int64_t count, const xv_act* dz, void* stream) {
+  XV_REQUIRE_BF16(dy, z, dz);
+  XV_CHECK_ARG(dy && z && dz && dy->data && z->data && dz->data && mean && invstd && scale && shift && gamma && sums);
+  XV_CHECK_SHAPE(same_shape(dy, z) && same_shape(dz, z) && z->c >= 64 && 2048 % z->c == 0 && count > 0);
+  const int64_t total = (int64_t)z->n * z->h * z->w * (z->c >> 3);
+  XV_CHECK_SHAPE(total < 0x7fff0000);
+  hipLaunchKernelGGL(bn_bwd_apply_fast_kernel<true>, dim3(bn_grid(total, 2048)), dim3(256), 0, (hipStream_t)stream,
+                     (const __bf16*)dy->data, (const __bf16*)nullptr, (const __bf16*)z->data, mean, invstd, gamma, sums,
+                     (double)count, (__bf16*)dz->data, z->n, z->h, z->w, z->c, scale, shift);
   return xv_launch_status();
 }
 

@@ -668,10 +668,22 @@ def bn_forward(z, gamma, beta, moving_mean, moving_var, st, y, relu=True, sync=F
     return y
 
 
-def bn_backward(dy, y, z, gamma, st, dgamma, dbeta, dz, sync=False):
+def bn_backward(dy, y, z, gamma, st, dgamma, dbeta, dz, sync=False, mask_from_z=None):
     """dz from dy (gradient w.r.t. the post-relu output; y = None: no activation); accumulates the LOCAL dgamma /
-    dbeta (the gradient all-reduce sums them over ranks)."""
+    dbeta (the gradient all-reduce sums them over ranks).  With an activation the relu mask is recomputed from z
+    (z * scale + shift > 0 with the scale / shift the forward pass left in `st`) instead of read from y -- a third less
+    traffic -- for the trunk's channel counts (mask_from_z=False: always read y)."""
     lib = _lib.lib()
+    if mask_from_z is None:
+        mask_from_z = y is not None and z.c >= 64 and 2048 % z.c == 0
+    if mask_from_z and y is not None:
+        _lib.check(lib.xv_bn_bwd_reduce_zmask(dy.xv(), z.xv(), _ptr(st.mean), _ptr(st.invstd), _ptr(st.scale), _ptr(st.shift),
+                                              _ptr(st.sums), _ptr(dgamma), _ptr(dbeta), _stream()), 'xv_bn_bwd_reduce_zmask')
+        mult = _sync_sums(st, sync)
+        _lib.check(lib.xv_bn_bwd_apply_zmask(dy.xv(), z.xv(), _ptr(st.mean), _ptr(st.invstd), _ptr(st.scale), _ptr(st.shift),
+                                             _ptr(gamma), _ptr(st.sums), z.n * z.h * z.w * mult, dz.xv(), _stream()),
+                   'xv_bn_bwd_apply_zmask')
+        return dz
     yx = y.xv() if y is not None else _NULL_ACT
     _lib.check(lib.xv_bn_bwd_reduce(dy.xv(), yx, z.xv(), _ptr(st.mean), _ptr(st.invstd), _ptr(st.sums), _ptr(dgamma),
                                     _ptr(dbeta), _stream()), 'xv_bn_bwd_reduce')

@@ -68,6 +68,15 @@ def test_bn_forward_backward(ops, c, relu):
     dz_ref = zt.grad.permute(0, 2, 3, 1).numpy()
     got = dza.interior().float().cpu().numpy()
     assert np.abs(got - dz_ref).max() < 2e-2 * np.abs(dz_ref).max() + 1e-3
+    if relu:
+        # the default recomputed the relu mask from z (z * scale + shift > 0); read from the activation map instead, the
+        # gradients are the same bits (the reductions go through fp64 atomics: compare after rounding to fp32 precision)
+        dg2, db2, dz2 = torch.zeros(c, device='cuda'), torch.zeros(c, device='cuda'), ops.Act(n, h, w, c)
+        ops.bn_backward(ops.Act.from_dense(_dev(dy)), ya, za, _dev(gamma), st, dg2, db2, dz2, mask_from_z=False)
+        torch.cuda.synchronize()
+        np.testing.assert_allclose(dg2.cpu().numpy(), dgamma.cpu().numpy(), rtol=1e-6, atol=1e-6)
+        np.testing.assert_allclose(db2.cpu().numpy(), dbeta.cpu().numpy(), rtol=1e-6, atol=1e-6)
+        assert (dz2.t != dza.t).float().mean().item() < 1e-3
 
 
 def test_bn_dense_forward_backward(ops):
