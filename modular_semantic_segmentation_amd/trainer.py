@@ -415,17 +415,20 @@ class FcnBnTrainer(object):
     def repack(self):
         """Master fp32 kernels -> packed bf16 forward / data-gradient weights (training graph: no folding)."""
         dev = self.e.device
-        for name, (shape, _) in self.convs.items():
-            kv = self.view(self.param, name, 'kernel')
-            if name in ('score', 'conv1_1'):
-                self.w[name] = kv
-                continue
-            if name not in self.wd:
+        if getattr(self, '_pack_table', None) is None:
+            entries = []
+            for name, (shape, _) in self.convs.items():
+                kv = self.view(self.param, name, 'kernel')
+                if name in ('score', 'conv1_1'):
+                    self.w[name] = kv
+                    continue
                 k, _, cin, cout = shape
                 nel = ops.packed_weight_elems(k, cin, cout)
                 self.w[name] = torch.empty(nel, dtype=torch.bfloat16, device=dev)
                 self.wd[name] = torch.empty(nel, dtype=torch.bfloat16, device=dev)
-            ops.pack_conv_weights_pair(kv, self.w[name], self.wd[name])
+                entries.append((kv, self.w[name], self.wd[name]))
+            self._pack_table = ops.PackTable(entries, dev)      # all kernels in ONE launch (the master views never move)
+        self._pack_table.run()
 
     def _act(self, tag, n, h, w, c):
         key = (tag, n, h, w, c)
@@ -459,9 +462,9 @@ class FcnBnTrainer(object):
             raise ValueError('H and W must be multiples of 16')
         P = lambda name, kind: self.view(self.param, name, kind)   # noqa: E731
         G = lambda name, kind: self.view(self.grad, name, kind)    # noqa: E731
-        self.grad.zero_()
-        self.loss.zero_()
-        self.count.zero_()
+        ops.zero_(self.grad)                            # (the library's memset: no framework kernel runs in the step)
+        ops.zero_(self.loss)
+        ops.zero_(self.count)
         ops.count_valid_labels(labels, e.C, self.count)
         # Sync-BN under data parallelism: batch statistics (and their gradient sums) over the GLOBAL batch, one small
         # all-reduce per batch norm and direction, so that N ranks reproduce a single device on the whole batch
