@@ -418,7 +418,21 @@ int xv_bn_bwd_apply(const xv_act* dy, const xv_act* y, const xv_act* z, const fl
  * pass's own expression: scale / shift as xv_bn_finalize left them) instead of read from the activation map: a third / a
  * quarter less HBM traffic.  64 <= C, C divides 2048.                                                                    */
 int xv_bn_bwd_reduce_zmask(const xv_act* dy, const xv_act* z, const float* mean, const float* invstd, const float* scale,
-                           const float* shift, double* sums, float* dgamma, float* dbeta, void* stream);
+                           const float* shift, double* sums, float* dgamma, float* dbeta, void* workspace,
+                           size_t workspace_bytes, void* stream);
+/* Workspace forms of the reductions: with a workspace of xv_bn_workspace_bytes(C) bytes (16-byte aligned, owned by one
+ * stream) every workgroup writes its partial sums to its own row and a second kernel adds the rows in a fixed tree --
+ * bitwise reproducible statistics and gamma / beta gradients; workspace == NULL: f64 atomics in arrival order (the
+ * forms without _ws).                                                                                                   */
+size_t xv_bn_workspace_bytes(int channels);
+int xv_bn_stats_ws(const xv_act* z, double* sums, void* workspace, size_t workspace_bytes, void* stream);
+int xv_bn_bwd_reduce_ws(const xv_act* dy, const xv_act* y, const xv_act* z, const float* mean, const float* invstd,
+                        double* sums, float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes, void* stream);
+int xv_bn_dense_stats_ws(const float* z, int64_t rows, int channels, double* sums, void* workspace, size_t workspace_bytes,
+                         void* stream);
+int xv_bn_dense_bwd_reduce_ws(const float* dy, const float* z, int64_t rows, int channels, const float* mean,
+                              const float* invstd, double* sums, float* dgamma, float* dbeta, void* workspace,
+                              size_t workspace_bytes, void* stream);
 int xv_bn_bwd_apply_zmask(const xv_act* dy, const xv_act* z, const float* mean, const float* invstd, const float* scale,
                           const float* shift, const float* gamma, const double* sums, int64_t count, const xv_act* dz,
                           void* stream);

@@ -33,7 +33,7 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const __bf16* __restrict
                                                        const __bf16* __restrict__ y, const float* __restrict__ mean,
                                                        const float* __restrict__ invstd, double* __restrict__ sums,
                                                        int N, int H, int W, int C, const float* __restrict__ zsc = nullptr,
-                                                       const float* __restrict__ zsh = nullptr) {
+                                                       const float* __restrict__ zsh = nullptr, float* __restrict__ part = nullptr) {
   const int c8 = C >> 3;
   const int64_t total = (int64_t)N * H * W * c8;
   const int cg = threadIdx.x % c8;  // constant over the loop: 256 and gridDim.x * 256 are multiples of c8
@@ -176,8 +176,28 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const __bf16* __restrict
     float acc = 0.f;
     for (int row = g; row < 256; row += c8) acc += red[row][col];
     const int ch = g * 8 + (col & 7);
-    atomicAdd(sums + (col < 8 ? ch : C + ch), (double)acc);
+    // with a workspace the workgroup's sums go to its own row, added up in workgroup order by bn_sums_kernel (bitwise
+    // reproducible statistics); without one: f64 atomics (order not fixed, differences at 1e-16 relative)
+    if (part != nullptr)
+      part[(int64_t)blockIdx.x * 2 * C + (col < 8 ? ch : C + ch)] = acc;
+    else
+      atomicAdd(sums + (col < 8 ? ch : C + ch), (double)acc);
   }
+}
+
+// sums[i] = sum over the workgroups' partial rows, in a fixed tree (one workgroup per element: lane l adds rows l, l + 256,
+// ... in order, a butterfly inside each wave, the four waves in wave order): overwrites `sums` (no memset needed)
+__global__ __launch_bounds__(256) void bn_sums_kernel(const float* __restrict__ part, int nblocks, int len,
+                                                     double* __restrict__ sums) {
+  __shared__ double wsum[4];
+  const int i = blockIdx.x;
+  double a = 0.0;
+  for (int b = threadIdx.x; b < nblocks; b += 256) a += (double)part[(int64_t)b * len + i];
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) a += __shfl_xor(a, off, 64);
+  if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = a;
+  __syncthreads();
+  if (threadIdx.x == 0) sums[i] = ((wsum[0] + wsum[1]) + wsum[2]) + wsum[3];
 }
 
 // mean / biased variance -> invstd, scale = gamma * invstd, shift = beta - mean * scale; moving statistics
@@ -405,10 +425,9 @@ template <int MODE>
 __global__ __launch_bounds__(256) void bn_dense_reduce_kernel(const float* __restrict__ z, const float* __restrict__ dy,
                                                              const float* __restrict__ mean,
                                                              const float* __restrict__ invstd,
-                                                             double* __restrict__ sums, int64_t M, int C) {
-  __shared__ float red[64];
-  if (threadIdx.x < 64) red[threadIdx.x] = 0.f;
-  __syncthreads();
+                                                             double* __restrict__ sums, int64_t M, int C,
+                                                             float* __restrict__ part = nullptr) {
+  __shared__ float red[4][64];
   float s0[32], s1[32];
 #pragma unroll
   for (int c = 0; c < 32; ++c) s0[c] = s1[c] = 0.f;
@@ -444,16 +463,33 @@ __global__ __launch_bounds__(256) void bn_dense_reduce_kernel(const float* __res
         if (c < C) accumulate(c, z[p * C + c], MODE == 1 ? dy[p * C + c] : 0.f);
     }
   }
+  // a butterfly inside each wave, the four waves in wave order: a fixed tree (LDS float atomics added in arrival order)
 #pragma unroll
   for (int c = 0; c < 32; ++c)
     if (c < C) {
-      atomicAdd(&red[c], s0[c]);
-      atomicAdd(&red[32 + c], s1[c]);
+      float a = s0[c], b = s1[c];
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1) {
+        a += __shfl_xor(a, off, 64);
+        b += __shfl_xor(b, off, 64);
+      }
+      if ((threadIdx.x & 63) == 0) {
+        red[threadIdx.x >> 6][c] = a;
+        red[threadIdx.x >> 6][32 + c] = b;
+      }
     }
   __syncthreads();
   if ((int)threadIdx.x < C) {
-    atomicAdd(sums + threadIdx.x, (double)red[threadIdx.x]);
-    atomicAdd(sums + C + threadIdx.x, (double)red[32 + threadIdx.x]);
+    const int c = threadIdx.x;
+    const float a = ((red[0][c] + red[1][c]) + red[2][c]) + red[3][c];
+    const float b = ((red[0][32 + c] + red[1][32 + c]) + red[2][32 + c]) + red[3][32 + c];
+    if (part != nullptr) {
+      part[(int64_t)blockIdx.x * 2 * C + c] = a;
+      part[(int64_t)blockIdx.x * 2 * C + C + c] = b;
+    } else {
+      atomicAdd(sums + c, (double)a);
+      atomicAdd(sums + C + c, (double)b);
+    }
   }
 }
 
@@ -768,18 +804,45 @@ bool same_shape(const xv_act* a, const xv_act* b) { return a->n == b->n && a->h 
 
 }  // namespace
 
-extern "C" int xv_bn_stats(const xv_act* z, double* sums, void* stream) {
+// The per-channel sums of a reduce launch of `grid` workgroups: with a workspace (xv_bn_workspace_bytes) every workgroup
+// writes its partial sums to its own row and bn_sums_kernel adds the rows in a fixed tree -- bitwise reproducible
+// statistics and gradients; without one: a memset and f64 atomics in arrival order.
+namespace {
+constexpr int BN_MAX_GRID = 512;
+template <class F>
+int bn_sums_launch(double* sums, int len, int grid, void* ws, size_t ws_bytes, hipStream_t s, F launch) {
+  if (ws != nullptr) {
+    if (ws_bytes < (size_t)BN_MAX_GRID * len * sizeof(float) || ((uintptr_t)ws & 15)) return XV_EWORKSPACE;
+    launch((float*)ws);
+    hipLaunchKernelGGL(bn_sums_kernel, dim3(len), dim3(256), 0, s, (const float*)ws, grid, len, sums);
+    return XV_OK;
+  }
+  const hipError_t e = hipMemsetAsync(sums, 0, sizeof(double) * len, s);
+  if (e != hipSuccess) return (int)e;
+  launch((float*)nullptr);
+  return XV_OK;
+}
+}  // namespace
+
+extern "C" size_t xv_bn_workspace_bytes(int channels) {
+  return channels > 0 ? (size_t)BN_MAX_GRID * 2 * channels * sizeof(float) : 0;
+}
+
+extern "C" int xv_bn_stats_ws(const xv_act* z, double* sums, void* workspace, size_t workspace_bytes, void* stream) {
   XV_REQUIRE_BF16(z);
   XV_CHECK_ARG(z && z->data && sums);
   XV_CHECK_SHAPE(z->c >= 64 && 2048 % z->c == 0 && z->n > 0 && z->h > 0 && z->w > 0);  // C/8 divides the block size
-  hipError_t e = hipMemsetAsync(sums, 0, sizeof(double) * 2 * z->c, (hipStream_t)stream);
-  if (e != hipSuccess) return (int)e;
   const int64_t total = (int64_t)z->n * z->h * z->w * (z->c >> 3);
   XV_CHECK_SHAPE(total < 0x7fff0000);
-  hipLaunchKernelGGL(bn_reduce_kernel<0>, dim3(bn_grid(total, 512)), dim3(256), 0, (hipStream_t)stream,
-                     (const __bf16*)z->data, nullptr, nullptr, nullptr, nullptr, sums, z->n, z->h, z->w, z->c);
-  return xv_launch_status();
+  hipStream_t s = (hipStream_t)stream;
+  const int grid = bn_grid(total, BN_MAX_GRID);
+  const int rc = bn_sums_launch(sums, 2 * z->c, grid, workspace, workspace_bytes, s, [&](float* part) {
+    hipLaunchKernelGGL(bn_reduce_kernel<0>, dim3(grid), dim3(256), 0, s, (const __bf16*)z->data, nullptr, nullptr, nullptr,
+                       nullptr, sums, z->n, z->h, z->w, z->c, (const float*)nullptr, (const float*)nullptr, part);
+  });
+  return rc != XV_OK ? rc : xv_launch_status();
 }
+extern "C" int xv_bn_stats(const xv_act* z, double* sums, void* stream) { return xv_bn_stats_ws(z, sums, nullptr, 0, stream); }
 
 extern "C" int xv_bn_finalize(const double* sums, int channels, int64_t count, const float* gamma, const float* beta,
                               float eps, float momentum, float* moving_mean, float* moving_var, float* mean,
@@ -809,8 +872,9 @@ extern "C" int xv_bn_apply(const xv_act* z, const float* scale, const float* shi
 // The gradient in two steps, so that a data-parallel caller can all-reduce `sums` in between (Sync-BN): the reduce
 // step also adds the LOCAL sums into dgamma / dbeta (the gradient all-reduce sums those over ranks), the apply step
 // uses whatever `sums` / `count` hold by then (global under Sync-BN).
-extern "C" int xv_bn_bwd_reduce(const xv_act* dy, const xv_act* y, const xv_act* z, const float* mean,
-                                const float* invstd, double* sums, float* dgamma, float* dbeta, void* stream) {
+extern "C" int xv_bn_bwd_reduce_ws(const xv_act* dy, const xv_act* y, const xv_act* z, const float* mean,
+                                   const float* invstd, double* sums, float* dgamma, float* dbeta, void* workspace,
+                                   size_t workspace_bytes, void* stream) {
   XV_REQUIRE_BF16(dy, y, z);
   XV_CHECK_ARG(dy && z && dy->data && z->data && mean && invstd && sums && dgamma && dbeta);
   XV_CHECK_SHAPE(same_shape(dy, z) && z->c >= 64 && 2048 % z->c == 0);
@@ -820,14 +884,20 @@ extern "C" int xv_bn_bwd_reduce(const xv_act* dy, const xv_act* y, const xv_act*
     yp = (const __bf16*)y->data;
   }
   hipStream_t s = (hipStream_t)stream;
-  hipError_t e = hipMemsetAsync(sums, 0, sizeof(double) * 2 * z->c, s);
-  if (e != hipSuccess) return (int)e;
   const int64_t total = (int64_t)z->n * z->h * z->w * (z->c >> 3);
   XV_CHECK_SHAPE(total < 0x7fff0000);
-  hipLaunchKernelGGL(bn_reduce_kernel<1>, dim3(bn_grid(total, 512)), dim3(256), 0, s, (const __bf16*)z->data,
-                     (const __bf16*)dy->data, yp, mean, invstd, sums, z->n, z->h, z->w, z->c);
+  const int grid = bn_grid(total, BN_MAX_GRID);
+  const int rc = bn_sums_launch(sums, 2 * z->c, grid, workspace, workspace_bytes, s, [&](float* part) {
+    hipLaunchKernelGGL(bn_reduce_kernel<1>, dim3(grid), dim3(256), 0, s, (const __bf16*)z->data, (const __bf16*)dy->data, yp,
+                       mean, invstd, sums, z->n, z->h, z->w, z->c, (const float*)nullptr, (const float*)nullptr, part);
+  });
+  if (rc != XV_OK) return rc;
   hipLaunchKernelGGL(bn_grads_kernel, dim3((z->c + 63) / 64), dim3(64), 0, s, sums, z->c, dgamma, dbeta);
   return xv_launch_status();
+}
+extern "C" int xv_bn_bwd_reduce(const xv_act* dy, const xv_act* y, const xv_act* z, const float* mean,
+                                const float* invstd, double* sums, float* dgamma, float* dbeta, void* stream) {
+  return xv_bn_bwd_reduce_ws(dy, y, z, mean, invstd, sums, dgamma, dbeta, nullptr, 0, stream);
 }
 
 extern "C" int xv_bn_bwd_apply(const xv_act* dy, const xv_act* y, const xv_act* z, const float* mean,
@@ -854,17 +924,19 @@ extern "C" int xv_bn_bwd_apply(const xv_act* dy, const xv_act* y, const xv_act* 
 // map is not read: a third less traffic in the reduce step, a quarter less in the apply step.  Trunk channel counts only.
 extern "C" int xv_bn_bwd_reduce_zmask(const xv_act* dy, const xv_act* z, const float* mean, const float* invstd,
                                       const float* scale, const float* shift, double* sums, float* dgamma, float* dbeta,
-                                      void* stream) {
+                                      void* workspace, size_t workspace_bytes, void* stream) {
   XV_REQUIRE_BF16(dy, z);
   XV_CHECK_ARG(dy && z && dy->data && z->data && mean && invstd && scale && shift && sums && dgamma && dbeta);
   XV_CHECK_SHAPE(same_shape(dy, z) && z->c >= 64 && 2048 % z->c == 0);
   hipStream_t s = (hipStream_t)stream;
-  hipError_t e = hipMemsetAsync(sums, 0, sizeof(double) * 2 * z->c, s);
-  if (e != hipSuccess) return (int)e;
   const int64_t total = (int64_t)z->n * z->h * z->w * (z->c >> 3);
   XV_CHECK_SHAPE(total < 0x7fff0000);
-  hipLaunchKernelGGL(bn_reduce_kernel<2>, dim3(bn_grid(total, 512)), dim3(256), 0, s, (const __bf16*)z->data,
-                     (const __bf16*)dy->data, (const __bf16*)nullptr, mean, invstd, sums, z->n, z->h, z->w, z->c, scale, shift);
+  const int grid = bn_grid(total, BN_MAX_GRID);
+  const int rc = bn_sums_launch(sums, 2 * z->c, grid, workspace, workspace_bytes, s, [&](float* part) {
+    hipLaunchKernelGGL(bn_reduce_kernel<2>, dim3(grid), dim3(256), 0, s, (const __bf16*)z->data, (const __bf16*)dy->data,
+                       (const __bf16*)nullptr, mean, invstd, sums, z->n, z->h, z->w, z->c, scale, shift, part);
+  });
+  if (rc != XV_OK) return rc;
   hipLaunchKernelGGL(bn_grads_kernel, dim3((z->c + 255) / 256), dim3(256), 0, s, sums, z->c, dgamma, dbeta);
   return xv_launch_status();
 }
@@ -892,14 +964,20 @@ extern "C" int xv_bn_bwd(const xv_act* dy, const xv_act* y, const xv_act* z, con
   return xv_bn_bwd_apply(dy, y, z, mean, invstd, gamma, sums, (int64_t)z->n * z->h * z->w, dz, stream);
 }
 
-extern "C" int xv_bn_dense_stats(const float* z, int64_t rows, int channels, double* sums, void* stream) {
+extern "C" int xv_bn_dense_stats_ws(const float* z, int64_t rows, int channels, double* sums, void* workspace,
+                                    size_t workspace_bytes, void* stream) {
   XV_CHECK_ARG(z && sums);
   XV_CHECK_SHAPE(rows > 0 && channels >= 1 && channels <= 32);
-  hipError_t e = hipMemsetAsync(sums, 0, sizeof(double) * 2 * channels, (hipStream_t)stream);
-  if (e != hipSuccess) return (int)e;
-  hipLaunchKernelGGL(bn_dense_reduce_kernel<0>, dim3(bn_grid(rows, 512)), dim3(256), 0, (hipStream_t)stream, z, nullptr,
-                     nullptr, nullptr, sums, rows, channels);
-  return xv_launch_status();
+  hipStream_t s = (hipStream_t)stream;
+  const int grid = bn_grid(rows, BN_MAX_GRID);
+  const int rc = bn_sums_launch(sums, 2 * channels, grid, workspace, workspace_bytes, s, [&](float* part) {
+    hipLaunchKernelGGL(bn_dense_reduce_kernel<0>, dim3(grid), dim3(256), 0, s, z, nullptr, nullptr, nullptr, sums, rows, channels,
+                       part);
+  });
+  return rc != XV_OK ? rc : xv_launch_status();
+}
+extern "C" int xv_bn_dense_stats(const float* z, int64_t rows, int channels, double* sums, void* stream) {
+  return xv_bn_dense_stats_ws(z, rows, channels, sums, nullptr, 0, stream);
 }
 
 extern "C" int xv_bn_dense_apply(const float* z, int64_t rows, int channels, const float* scale, const float* shift,
@@ -911,17 +989,23 @@ extern "C" int xv_bn_dense_apply(const float* z, int64_t rows, int channels, con
   return xv_launch_status();
 }
 
-extern "C" int xv_bn_dense_bwd_reduce(const float* dy, const float* z, int64_t rows, int channels, const float* mean,
-                                      const float* invstd, double* sums, float* dgamma, float* dbeta, void* stream) {
+extern "C" int xv_bn_dense_bwd_reduce_ws(const float* dy, const float* z, int64_t rows, int channels, const float* mean,
+                                         const float* invstd, double* sums, float* dgamma, float* dbeta, void* workspace,
+                                         size_t workspace_bytes, void* stream) {
   XV_CHECK_ARG(dy && z && mean && invstd && sums && dgamma && dbeta);
   XV_CHECK_SHAPE(rows > 0 && channels >= 1 && channels <= 32);
   hipStream_t s = (hipStream_t)stream;
-  hipError_t e = hipMemsetAsync(sums, 0, sizeof(double) * 2 * channels, s);
-  if (e != hipSuccess) return (int)e;
-  hipLaunchKernelGGL(bn_dense_reduce_kernel<1>, dim3(bn_grid(rows, 512)), dim3(256), 0, s, z, dy, mean, invstd, sums,
-                     rows, channels);
+  const int grid = bn_grid(rows, BN_MAX_GRID);
+  const int rc = bn_sums_launch(sums, 2 * channels, grid, workspace, workspace_bytes, s, [&](float* part) {
+    hipLaunchKernelGGL(bn_dense_reduce_kernel<1>, dim3(grid), dim3(256), 0, s, z, dy, mean, invstd, sums, rows, channels, part);
+  });
+  if (rc != XV_OK) return rc;
   hipLaunchKernelGGL(bn_grads_kernel, dim3(1), dim3(64), 0, s, sums, channels, dgamma, dbeta);
   return xv_launch_status();
+}
+extern "C" int xv_bn_dense_bwd_reduce(const float* dy, const float* z, int64_t rows, int channels, const float* mean,
+                                      const float* invstd, double* sums, float* dgamma, float* dbeta, void* stream) {
+  return xv_bn_dense_bwd_reduce_ws(dy, z, rows, channels, mean, invstd, sums, dgamma, dbeta, nullptr, 0, stream);
 }
 
 extern "C" int xv_bn_dense_bwd_apply(const float* dy, const float* z, int64_t rows, int channels, const float* mean,

@@ -690,15 +690,19 @@ __global__ __launch_bounds__(256) void fused_head_kernel(const float* __restrict
         }
 #pragma unroll
         for (int k = 0; k < CM; ++k) sc[k] = k < C ? logf(1e-20f + sc[k] / sum) : 0.f;  // renormalise, then log(1e-20 + p)
-        for (int c = 0; c < C; ++c) {
-          const float* row = tab + ((int64_t)e * C + c) * CM;
-          float dot = 0.f;
+        // (unrolled over the class: a run-time class index made every write to `total` twelve compare-selects)
 #pragma unroll
-          for (int k = 0; k < CM; ++k) dot = fmaf(row[k], sc[k], dot);  // as dirichlet_fuse_kernel, bit for bit
-          const float L = dot - ln[e * CM + c];
+        for (int c = 0; c < CM; ++c) {
+          if (c < C) {
+            const float* row = tab + (e * C + c) * CM;
+            float dot = 0.f;
 #pragma unroll
-          for (int cc = 0; cc < CM; ++cc)
-            if (cc == c) total[p][cc] = e == 0 ? L : total[p][cc] + L;
+            for (int k = 0; k < CM; ++k) dot = fmaf(row[k], sc[k], dot);  // as dirichlet_fuse_kernel, bit for bit
+            const float L = dot - ln[e * CM + c];
+            total[p][c] = e == 0 ? L : total[p][c] + L;
+          } else {
+            total[p][c] = 0.f;
+          }
         }
       }
     }

@@ -636,11 +636,18 @@ BN_EPS, BN_MOMENTUM = 1e-3, 0.99        # [TF1] tf.layers.batch_normalization de
 class BnState(object):
     """Per-layer buffers of one training-mode batch norm: batch statistics, folded scale / shift, scratch."""
 
-    def __init__(self, channels, device):
+    def __init__(self, channels, device, deterministic=True):
         f = lambda: torch.zeros(channels, dtype=torch.float32, device=device)   # noqa: E731
         self.c = channels
         self.mean, self.invstd, self.scale, self.shift = f(), f(), f(), f()
         self.sums = torch.zeros(2 * channels, dtype=torch.float64, device=device)
+        # per-workgroup partial sums of the reductions, added in a fixed order (xv_bn_workspace_bytes): bitwise
+        # reproducible statistics and gamma / beta gradients; deterministic=False: f64 atomics in arrival order
+        self.ws = torch.empty(_lib.lib().xv_bn_workspace_bytes(channels) // 4, dtype=torch.float32, device=device) \
+            if deterministic else None
+
+    def wsp(self):
+        return (_ptr(self.ws), self.ws.numel() * 4) if self.ws is not None else (None, 0)
 
 
 def _sync_sums(st, sync):
@@ -659,7 +666,7 @@ def bn_forward(z, gamma, beta, moving_mean, moving_var, st, y, relu=True, sync=F
     """y = [relu](BN_batch(z)); updates the moving statistics in place (z, y: Act).  sync: statistics over all
     data-parallel ranks (one all-reduce of 2*C doubles)."""
     lib = _lib.lib()
-    _lib.check(lib.xv_bn_stats(z.xv(), _ptr(st.sums), _stream()), 'xv_bn_stats')
+    _lib.check(lib.xv_bn_stats_ws(z.xv(), _ptr(st.sums), *st.wsp(), _stream()), 'xv_bn_stats_ws')
     mult = _sync_sums(st, sync)
     _lib.check(lib.xv_bn_finalize(_ptr(st.sums), st.c, z.n * z.h * z.w * mult, _ptr(gamma), _ptr(beta), BN_EPS,
                                   BN_MOMENTUM, _ptr(moving_mean), _ptr(moving_var), _ptr(st.mean), _ptr(st.invstd),
@@ -678,15 +685,16 @@ def bn_backward(dy, y, z, gamma, st, dgamma, dbeta, dz, sync=False, mask_from_z=
         mask_from_z = y is not None and z.c >= 64 and 2048 % z.c == 0
     if mask_from_z and y is not None:
         _lib.check(lib.xv_bn_bwd_reduce_zmask(dy.xv(), z.xv(), _ptr(st.mean), _ptr(st.invstd), _ptr(st.scale), _ptr(st.shift),
-                                              _ptr(st.sums), _ptr(dgamma), _ptr(dbeta), _stream()), 'xv_bn_bwd_reduce_zmask')
+                                              _ptr(st.sums), _ptr(dgamma), _ptr(dbeta), *st.wsp(), _stream()),
+                   'xv_bn_bwd_reduce_zmask')
         mult = _sync_sums(st, sync)
         _lib.check(lib.xv_bn_bwd_apply_zmask(dy.xv(), z.xv(), _ptr(st.mean), _ptr(st.invstd), _ptr(st.scale), _ptr(st.shift),
                                              _ptr(gamma), _ptr(st.sums), z.n * z.h * z.w * mult, dz.xv(), _stream()),
                    'xv_bn_bwd_apply_zmask')
         return dz
     yx = y.xv() if y is not None else _NULL_ACT
-    _lib.check(lib.xv_bn_bwd_reduce(dy.xv(), yx, z.xv(), _ptr(st.mean), _ptr(st.invstd), _ptr(st.sums), _ptr(dgamma),
-                                    _ptr(dbeta), _stream()), 'xv_bn_bwd_reduce')
+    _lib.check(lib.xv_bn_bwd_reduce_ws(dy.xv(), yx, z.xv(), _ptr(st.mean), _ptr(st.invstd), _ptr(st.sums), _ptr(dgamma),
+                                       _ptr(dbeta), *st.wsp(), _stream()), 'xv_bn_bwd_reduce_ws')
     mult = _sync_sums(st, sync)
     _lib.check(lib.xv_bn_bwd_apply(dy.xv(), yx, z.xv(), _ptr(st.mean), _ptr(st.invstd), _ptr(gamma), _ptr(st.sums),
                                    z.n * z.h * z.w * mult, dz.xv(), _stream()), 'xv_bn_bwd_apply')
@@ -698,7 +706,7 @@ def bn_dense_forward(z, gamma, beta, moving_mean, moving_var, st, y, sync=False)
     lib = _lib.lib()
     c = z.shape[-1]
     rows = z.numel() // c
-    _lib.check(lib.xv_bn_dense_stats(_ptr(z), rows, c, _ptr(st.sums), _stream()), 'xv_bn_dense_stats')
+    _lib.check(lib.xv_bn_dense_stats_ws(_ptr(z), rows, c, _ptr(st.sums), *st.wsp(), _stream()), 'xv_bn_dense_stats_ws')
     mult = _sync_sums(st, sync)
     _lib.check(lib.xv_bn_finalize(_ptr(st.sums), c, rows * mult, _ptr(gamma), _ptr(beta), BN_EPS, BN_MOMENTUM,
                                   _ptr(moving_mean), _ptr(moving_var), _ptr(st.mean), _ptr(st.invstd), _ptr(st.scale),
@@ -712,8 +720,8 @@ def bn_dense_backward(dy, z, gamma, st, dgamma, dbeta, dz, sync=False):
     lib = _lib.lib()
     c = z.shape[-1]
     rows = z.numel() // c
-    _lib.check(lib.xv_bn_dense_bwd_reduce(_ptr(dy), _ptr(z), rows, c, _ptr(st.mean), _ptr(st.invstd), _ptr(st.sums),
-                                          _ptr(dgamma), _ptr(dbeta), _stream()), 'xv_bn_dense_bwd_reduce')
+    _lib.check(lib.xv_bn_dense_bwd_reduce_ws(_ptr(dy), _ptr(z), rows, c, _ptr(st.mean), _ptr(st.invstd), _ptr(st.sums),
+                                             _ptr(dgamma), _ptr(dbeta), *st.wsp(), _stream()), 'xv_bn_dense_bwd_reduce_ws')
     mult = _sync_sums(st, sync)
     _lib.check(lib.xv_bn_dense_bwd_apply(_ptr(dy), _ptr(z), rows, c, _ptr(st.mean), _ptr(st.invstd), _ptr(gamma),
                                          _ptr(st.sums), rows * mult, _ptr(dz), _stream()), 'xv_bn_dense_bwd_apply')

@@ -519,6 +519,7 @@ class FcnBnTrainer(object):
                 need = max(need, ops.conv2d_bwd_filter_workspace_bytes(inputs[nm], self.convs[nm][1], 3))
             for nm, src in (('score_conv4', 'conv4_3'), ('score_conv5', 'conv5_3')):
                 need = max(need, ops.conv2d_bwd_filter_workspace_bytes(Y[src], e.Up, 1))
+            need = max(need, ops.conv2d_first_bwd_filter_workspace_bytes(x))
             self._a[wkey] = torch.empty(need // 4, dtype=torch.float32, device=e.device)
         wws = self._a[wkey]
         # branch through score_conv4
@@ -537,7 +538,7 @@ class FcnBnTrainer(object):
             y = Y[nm]
             dz = self._bn_bwd(nm, g, y, Z[nm], self._act('dz_' + nm, y.n, y.h, y.w, y.c))
             if nm == 'conv1_1':
-                ops.conv2d_first_bwd_filter(x, dz, G(nm, 'kernel'), G(nm, 'bias'))
+                ops.conv2d_first_bwd_filter(x, dz, G(nm, 'kernel'), G(nm, 'bias'), workspace=wws)
                 break
             xin = inputs[nm]
             ops.conv2d_bwd_filter(xin, dz, G(nm, 'kernel'), G(nm, 'bias'), 3, workspace=wws)

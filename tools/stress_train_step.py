@@ -3,9 +3,11 @@
 code paths), one step on fixed data, then every activation / gradient map the step left in the trainer's arenas is
 compared with the first iteration's.  The PLAIN FCN step (no batch norm) is deterministic by construction since round 3 --
 every partial sum of the filter / bias gradients, the first layer's and the head's goes to slabs added in a fixed order --
-and must agree BIT FOR BIT, loss, gradients and updated parameters included.  The batch-norm and joint steps keep
-floating-point atomics in their statistics (f64) and dense-head reductions: low-bit differences there are expected and
-counted; anything beyond --tol of a map's largest entry is a defect.  GPU box only."""
+and must agree BIT FOR BIT, loss, gradients and updated parameters included.  The batch-norm step's statistics and
+gradient sums go through per-workgroup partials added in a fixed order too (every activation / gradient MAP of that step
+is bitwise reproducible); its dense head (loss, score-layer gradients) and the joint step keep floating-point atomics:
+low-bit differences there are expected and counted; anything beyond --tol of a map's largest entry is a defect.  GPU box
+only."""
 import argparse
 import os
 import sys
@@ -82,7 +84,7 @@ for kind in ('plain', 'bn', 'joint'):
         if want is None:
             want = got
             continue
-        small = 0
+        small, names = 0, []
         for k in want:
             if k not in got or got[k].shape != want[k].shape:
                 continue
@@ -93,8 +95,10 @@ for kind in ('plain', 'bn', 'joint'):
                 print('MISMATCH', kind, 'iter', it, k, 'max difference %.3g of the largest entry' % d, flush=True)
             elif d > 0:
                 small += 1
+                names.append(k)
         if small and it == 1:
-            print(kind, ': %d maps differ in low bits run to run (order of the floating-point atomics)' % small, flush=True)
+            print(kind, ': %d maps differ in low bits run to run (order of the floating-point atomics): %s' % (small, names),
+                  flush=True)
     print(kind, 'done', flush=True)
 print('mismatches:', bad)
 sys.exit(1 if bad else 0)
