@@ -420,6 +420,16 @@ int xv_bn_bwd_apply(const xv_act* dy, const xv_act* y, const xv_act* z, const fl
 int xv_bn_bwd_reduce_zmask(const xv_act* dy, const xv_act* z, const float* mean, const float* invstd, const float* scale,
                            const float* shift, double* sums, float* dgamma, float* dbeta, void* workspace,
                            size_t workspace_bytes, void* stream);
+/* The batch-norm gradient of a conv -> batch norm -> relu -> 2x2 max-pool block straight from the gradient of the POOLED map:
+ * each pass recomputes the window's activations from z, routes the pooled gradient to the first positive maximum
+ * (xv_maxpool2x2_bwd's rule on the same values) and reduces / applies -- no routed-gradient map in HBM.  count = n h w of z
+ * (x ranks under Sync-BN); workspace as in the _ws forms below (may be NULL).                                            */
+int xv_bn_pool_bwd_reduce(const xv_act* dpooled, const xv_act* z, const float* mean, const float* invstd, const float* scale,
+                          const float* shift, double* sums, float* dgamma, float* dbeta, void* workspace,
+                          size_t workspace_bytes, void* stream);
+int xv_bn_pool_bwd_apply(const xv_act* dpooled, const xv_act* z, const float* mean, const float* invstd, const float* scale,
+                         const float* shift, const float* gamma, const double* sums, int64_t count, const xv_act* dz,
+                         void* stream);
 /* Workspace forms of the reductions: with a workspace of xv_bn_workspace_bytes(C) bytes (16-byte aligned, owned by one
  * stream) every workgroup writes its partial sums to its own row and a second kernel adds the rows in a fixed tree --
  * bitwise reproducible statistics and gamma / beta gradients; workspace == NULL: f64 atomics in arrival order (the

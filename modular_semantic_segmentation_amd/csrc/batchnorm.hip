@@ -411,6 +411,112 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_fast_kernel(const __bf16* __
   }
 }
 
+// ---- MaxPoolGrad + ReluGrad + the batch-norm gradient of the conv in front of a 2x2 max-pool, in the two normalisation
+// passes themselves (xv_maxpool2x2_bwd wrote the routed gradient map, both passes then read it back: 3 of 7 streams).
+// A thread owns one 8-channel group and walks the POOLED pixels: it recomputes its window's four activations
+// y = relu(bf16(z * scale + shift)) -- the forward pass's own expression and rounding --, routes the pooled gradient to
+// the first maximum if that is positive (maxpool_bwd_kernel's rule, on the same values), and either accumulates
+// sum g / sum g * zhat (APPLY = 0) or writes dz = gamma * invstd * (g - dbeta / M - zhat * dgamma / M) for all four
+// positions (APPLY = 1).
+template <int APPLY>
+__global__ __launch_bounds__(256) void bn_pool_bwd_kernel(const __bf16* __restrict__ dp, const __bf16* __restrict__ z,
+                                                         const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                         const float* __restrict__ scale, const float* __restrict__ shift,
+                                                         const float* __restrict__ gamma, double* __restrict__ sums, double M,
+                                                         __bf16* __restrict__ dz, int N, int Ho, int Wo, int C,
+                                                         float* __restrict__ part) {
+  const int c8 = C >> 3;
+  const int cg = threadIdx.x % c8;  // constant over the loop: 256 and the grid stride are multiples of c8
+  float mu[8], is[8], sc[8], sh[8], gk[8], db[8], dg[8], s0[8], s1[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int c = cg * 8 + e;
+    mu[e] = mean[c], is[e] = invstd[c], sc[e] = scale[c], sh[e] = shift[c];
+    s0[e] = s1[e] = 0.f;
+    gk[e] = APPLY ? gamma[c] : 0.f;
+    db[e] = APPLY ? (float)(sums[c] / M) : 0.f;
+    dg[e] = APPLY ? (float)(sums[C + c] / M) : 0.f;
+  }
+  const int Hi = 2 * Ho, Wi = 2 * Wo;
+  const int64_t rowp = (int64_t)(Wi + 2) * C;
+  const int total = N * Ho * Wo * c8, stride = (int)gridDim.x * 256;  // < 2^31 (checked by the launcher)
+  for (int idx = (int)blockIdx.x * 256 + (int)threadIdx.x; idx < total; idx += stride) {
+    const int p = idx / c8;
+    const int row = p / Wo;
+    const int ox = p - row * Wo, n = row / Ho, oy = row - n * Ho;
+    const int64_t off = (((int64_t)n * (Hi + 2) + (2 * oy + 1)) * (Wi + 2) + (2 * ox + 1)) * C + cg * 8;
+    const u32x4 g = *reinterpret_cast<const u32x4*>(dp + (((int64_t)n * (Ho + 2) + (oy + 1)) * (Wo + 2) + (ox + 1)) * C + cg * 8);
+    const u32x4 v[4] = {*reinterpret_cast<const u32x4*>(z + off), *reinterpret_cast<const u32x4*>(z + off + C),
+                        *reinterpret_cast<const u32x4*>(z + off + rowp), *reinterpret_cast<const u32x4*>(z + off + rowp + C)};
+    u32x4 o[4];
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      float out[4][2];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int e = 2 * w + h;
+        float zz[4], yy[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          zz[k] = h ? bf_hi(v[k][w]) : bf_lo(v[k][w]);
+          const float a = zz[k] * sc[e] + sh[e];
+          yy[k] = bf_lo(pack_bf16x2(a > 0.f ? a : 0.f, 0.f));  // the stored activation: relu, rounded to bf16
+        }
+        int best = 0;
+        float m = yy[0];
+#pragma unroll
+        for (int k = 1; k < 4; ++k)
+          if (yy[k] > m) {
+            m = yy[k];
+            best = k;
+          }
+        const float gp = m > 0.f ? (h ? bf_hi(g[w]) : bf_lo(g[w])) : 0.f;
+        if (!APPLY) {
+          float zb = zz[0];
+#pragma unroll
+          for (int k = 1; k < 4; ++k) zb = best == k ? zz[k] : zb;
+          s0[e] += gp;
+          s1[e] += gp * (zb - mu[e]) * is[e];
+        } else {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const float zh = (zz[k] - mu[e]) * is[e];
+            out[k][h] = gk[e] * is[e] * ((k == best ? gp : 0.f) - db[e] - zh * dg[e]);
+          }
+        }
+      }
+      if (APPLY) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o[k][w] = pack_bf16x2(out[k][0], out[k][1]);
+      }
+    }
+    if (APPLY) {
+      *reinterpret_cast<u32x4*>(dz + off) = o[0];
+      *reinterpret_cast<u32x4*>(dz + off + C) = o[1];
+      *reinterpret_cast<u32x4*>(dz + off + rowp) = o[2];
+      *reinterpret_cast<u32x4*>(dz + off + rowp + C) = o[3];
+    }
+  }
+  if (APPLY) return;
+  __shared__ float red[256][17];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    red[threadIdx.x][e] = s0[e];
+    red[threadIdx.x][8 + e] = s1[e];
+  }
+  __syncthreads();
+  for (int t = threadIdx.x; t < c8 * 16; t += 256) {
+    const int gq = t >> 4, col = t & 15;
+    float acc = 0.f;
+    for (int row = gq; row < 256; row += c8) acc += red[row][col];
+    const int ch = gq * 8 + (col & 7);
+    if (part != nullptr)
+      part[(int64_t)blockIdx.x * 2 * C + (col < 8 ? ch : C + ch)] = acc;
+    else
+      atomicAdd(sums + (col < 8 ? ch : C + ch), (double)acc);
+  }
+}
+
 // dgamma[c] += sums[C + c], dbeta[c] += sums[c]
 __global__ void bn_grads_kernel(const double* __restrict__ sums, int C, float* __restrict__ dgamma,
                                 float* __restrict__ dbeta) {
@@ -952,6 +1058,45 @@ extern "C" int xv_bn_bwd_apply_zmask(const xv_act* dy, const xv_act* z, const fl
   hipLaunchKernelGGL(bn_bwd_apply_fast_kernel<true>, dim3(bn_grid(total, 2048)), dim3(256), 0, (hipStream_t)stream,
                      (const __bf16*)dy->data, (const __bf16*)nullptr, (const __bf16*)z->data, mean, invstd, gamma, sums,
                      (double)count, (__bf16*)dz->data, z->n, z->h, z->w, z->c, scale, shift);
+  return xv_launch_status();
+}
+
+// The batch-norm gradient of a conv -> batch norm -> relu -> 2x2 max-pool block straight from the gradient of the POOLED
+// map (see bn_pool_bwd_kernel): replaces xv_maxpool2x2_bwd + xv_bn_bwd_reduce + xv_bn_bwd_apply and the full-resolution
+// routed-gradient map between them.  z: the conv output [n][h][w][c], dpooled: [n][h/2][w/2][c]; count = n h w (x ranks).
+extern "C" int xv_bn_pool_bwd_reduce(const xv_act* dpooled, const xv_act* z, const float* mean, const float* invstd,
+                                     const float* scale, const float* shift, double* sums, float* dgamma, float* dbeta,
+                                     void* workspace, size_t workspace_bytes, void* stream) {
+  XV_REQUIRE_BF16(dpooled, z);
+  XV_CHECK_ARG(dpooled && z && dpooled->data && z->data && mean && invstd && scale && shift && sums && dgamma && dbeta);
+  XV_CHECK_SHAPE(z->c >= 64 && 2048 % z->c == 0 && (z->h & 1) == 0 && (z->w & 1) == 0);
+  XV_CHECK_SHAPE(dpooled->n == z->n && dpooled->h == z->h / 2 && dpooled->w == z->w / 2 && dpooled->c == z->c);
+  hipStream_t s = (hipStream_t)stream;
+  const int64_t total = (int64_t)z->n * (z->h / 2) * (z->w / 2) * (z->c >> 3);
+  XV_CHECK_SHAPE(total < 0x7fff0000);
+  const int grid = bn_grid(total, BN_MAX_GRID);
+  const int rc = bn_sums_launch(sums, 2 * z->c, grid, workspace, workspace_bytes, s, [&](float* part) {
+    hipLaunchKernelGGL(bn_pool_bwd_kernel<0>, dim3(grid), dim3(256), 0, s, (const __bf16*)dpooled->data, (const __bf16*)z->data,
+                       mean, invstd, scale, shift, (const float*)nullptr, sums, 1.0, (__bf16*)nullptr, z->n, z->h / 2, z->w / 2,
+                       z->c, part);
+  });
+  if (rc != XV_OK) return rc;
+  hipLaunchKernelGGL(bn_grads_kernel, dim3((z->c + 255) / 256), dim3(256), 0, s, sums, z->c, dgamma, dbeta);
+  return xv_launch_status();
+}
+
+extern "C" int xv_bn_pool_bwd_apply(const xv_act* dpooled, const xv_act* z, const float* mean, const float* invstd,
+                                    const float* scale, const float* shift, const float* gamma, const double* sums,
+                                    int64_t count, const xv_act* dz, void* stream) {
+  XV_REQUIRE_BF16(dpooled, z, dz);
+  XV_CHECK_ARG(dpooled && z && dz && dpooled->data && z->data && dz->data && mean && invstd && scale && shift && gamma && sums);
+  XV_CHECK_SHAPE(same_shape(dz, z) && z->c >= 64 && 2048 % z->c == 0 && (z->h & 1) == 0 && (z->w & 1) == 0 && count > 0);
+  XV_CHECK_SHAPE(dpooled->n == z->n && dpooled->h == z->h / 2 && dpooled->w == z->w / 2 && dpooled->c == z->c);
+  const int64_t total = (int64_t)z->n * (z->h / 2) * (z->w / 2) * (z->c >> 3);
+  XV_CHECK_SHAPE(total < 0x7fff0000);
+  hipLaunchKernelGGL(bn_pool_bwd_kernel<1>, dim3(bn_grid(total, 2048)), dim3(256), 0, (hipStream_t)stream,
+                     (const __bf16*)dpooled->data, (const __bf16*)z->data, mean, invstd, scale, shift, gamma,
+                     const_cast<double*>(sums), (double)count, (__bf16*)dz->data, z->n, z->h / 2, z->w / 2, z->c, (float*)nullptr);
   return xv_launch_status();
 }
 

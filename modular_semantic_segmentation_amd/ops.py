@@ -701,6 +701,19 @@ def bn_backward(dy, y, z, gamma, st, dgamma, dbeta, dz, sync=False, mask_from_z=
     return dz
 
 
+def bn_pool_backward(dpooled, z, gamma, st, dgamma, dbeta, dz, sync=False):
+    """dz of a conv -> batch norm -> relu -> 2x2 max-pool block from the gradient of the POOLED map: MaxPoolGrad, ReluGrad
+    and the batch-norm gradient in the two normalisation passes (the routed full-resolution gradient never reaches HBM)."""
+    lib = _lib.lib()
+    _lib.check(lib.xv_bn_pool_bwd_reduce(dpooled.xv(), z.xv(), _ptr(st.mean), _ptr(st.invstd), _ptr(st.scale), _ptr(st.shift),
+                                         _ptr(st.sums), _ptr(dgamma), _ptr(dbeta), *st.wsp(), _stream()), 'xv_bn_pool_bwd_reduce')
+    mult = _sync_sums(st, sync)
+    _lib.check(lib.xv_bn_pool_bwd_apply(dpooled.xv(), z.xv(), _ptr(st.mean), _ptr(st.invstd), _ptr(st.scale), _ptr(st.shift),
+                                        _ptr(gamma), _ptr(st.sums), z.n * z.h * z.w * mult, dz.xv(), _stream()),
+               'xv_bn_pool_bwd_apply')
+    return dz
+
+
 def bn_dense_forward(z, gamma, beta, moving_mean, moving_var, st, y, sync=False):
     """The same on a dense float32 [..., C] tensor (no activation)."""
     lib = _lib.lib()

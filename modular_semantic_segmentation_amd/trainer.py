@@ -534,9 +534,16 @@ class FcnBnTrainer(object):
         g = ops.conv2d_bwd_data(dz_s5, self.wd['score_conv5'], self.zero_bias, self._act('g_conv5_3', n, h8 // 2, w8 // 2, 512), 1)
         names = [nm for nm, _, _ in ENCODER]
         pool_after = {nm: pl for nm, _, pl in ENCODER}
+        g_is_pooled = False     # g is the gradient of the layer's POOLED output (routed inside the batch-norm passes)
         for nm in reversed(names):
             y = Y[nm]
-            dz = self._bn_bwd(nm, g, y, Z[nm], self._act('dz_' + nm, y.n, y.h, y.w, y.c))
+            if g_is_pooled:
+                dz = ops.bn_pool_backward(g, Z[nm], self.view(self.param, nm, 'gamma'), self.bn[nm],
+                                          self.view(self.grad, nm, 'gamma'), self.view(self.grad, nm, 'beta'),
+                                          self._act('dz_' + nm, y.n, y.h, y.w, y.c), sync=self._sync)
+            else:
+                dz = self._bn_bwd(nm, g, y, Z[nm], self._act('dz_' + nm, y.n, y.h, y.w, y.c))
+            g_is_pooled = False
             if nm == 'conv1_1':
                 ops.conv2d_first_bwd_filter(x, dz, G(nm, 'kernel'), G(nm, 'bias'), workspace=wws)
                 break
@@ -544,13 +551,13 @@ class FcnBnTrainer(object):
             ops.conv2d_bwd_filter(xin, dz, G(nm, 'kernel'), G(nm, 'bias'), 3, workspace=wws)
             dx = ops.conv2d_bwd_data(dz, self.wd[nm], self.zero_bias, self._act('dx_' + nm, xin.n, xin.h, xin.w, xin.c), 3)
             above = names[names.index(nm) - 1]
-            if pool_after[above]:
+            if pool_after[above] and above == 'conv4_3':
+                # second gradient path into conv4_3's output, through score_conv4 (AddN): the routed map is needed
                 routed = ops.maxpool2x2_bwd(Y[above], dx, self._act('r_' + above, Y[above].n, Y[above].h, Y[above].w, Y[above].c))
-                if above == 'conv4_3':      # second gradient path into conv4_3's output: through score_conv4 (AddN)
-                    g = ops.conv2d_bwd_data(dz_s4, self.wd['score_conv4'], self.zero_bias,
-                                            self._act('g_conv4_3', routed.n, routed.h, routed.w, routed.c), 1, addend=routed)
-                else:
-                    g = routed
+                g = ops.conv2d_bwd_data(dz_s4, self.wd['score_conv4'], self.zero_bias,
+                                        self._act('g_conv4_3', routed.n, routed.h, routed.w, routed.c), 1, addend=routed)
+            elif pool_after[above]:
+                g, g_is_pooled = dx, True   # MaxPoolGrad + ReluGrad happen inside the batch-norm gradient (ops.bn_pool_backward)
             else:
                 g = dx
         if reducer is not None:

@@ -156,3 +156,35 @@ def test_dense_score_conv_and_cross_entropy(ops, C):
     got = du.interior().float().cpu().numpy()
     ref = ut.grad.numpy()
     assert np.abs(got - ref).max() < 2 ** -7 * np.abs(ref).max() + 1e-7
+
+
+@pytest.mark.parametrize('c', [64, 256])
+def test_bn_pool_backward_equals_the_three_pass_form(ops, c):
+    """conv -> batch norm -> relu -> 2x2 max-pool: the fused gradient (MaxPoolGrad + ReluGrad + batch-norm gradient in the
+    two normalisation passes, from the gradient of the POOLED map) against xv_maxpool2x2_bwd + xv_bn_bwd on the same
+    tensors: same routing (first positive maximum of the stored activations, ties included), same values up to the order
+    of the per-channel sums."""
+    rng = np.random.default_rng(c + 1)
+    n, h, w = 2, 12, 20
+    z = fo.round_bf16((rng.standard_normal((n, h, w, c)) * 1.5 + 0.3).astype(np.float32))
+    z[:, ::4, ::4] = z[:, 1::4, 1::4]                                    # exact ties inside some windows
+    gamma = rng.uniform(0.5, 1.5, c).astype(np.float32)
+    beta = (0.3 * rng.standard_normal(c)).astype(np.float32)
+    dp = fo.round_bf16(rng.standard_normal((n, h // 2, w // 2, c)).astype(np.float32))
+    za, ya = ops.Act.from_dense(_dev(z)), ops.Act(n, h, w, c)
+    st = ops.BnState(c, 'cuda')
+    ops.bn_forward(za, _dev(gamma), _dev(beta), torch.zeros(c, device='cuda'), torch.ones(c, device='cuda'), st, ya, relu=True)
+    dpa = ops.Act.from_dense(_dev(dp))
+    routed = ops.maxpool2x2_bwd(ya, dpa, ops.Act(n, h, w, c))
+    dg1, db1, dz1 = torch.zeros(c, device='cuda'), torch.zeros(c, device='cuda'), ops.Act(n, h, w, c)
+    ops.bn_backward(routed, ya, za, _dev(gamma), st, dg1, db1, dz1)
+    dg2, db2, dz2 = torch.zeros(c, device='cuda'), torch.zeros(c, device='cuda'), ops.Act(n, h, w, c)
+    ops.bn_pool_backward(dpa, za, _dev(gamma), st, dg2, db2, dz2)
+    torch.cuda.synchronize()
+    # the per-channel sums are the same numbers added in another order (pooled-pixel walk against full-resolution walk):
+    # equal to fp32 rounding; dz then differs only where that moves a value across a bf16 rounding boundary
+    np.testing.assert_allclose(dg2.cpu().numpy(), dg1.cpu().numpy(), rtol=2e-5, atol=2e-5)
+    np.testing.assert_allclose(db2.cpu().numpy(), db1.cpu().numpy(), rtol=2e-5, atol=2e-5)
+    a, b = dz1.t.float(), dz2.t.float()
+    assert (a != b).float().mean().item() < 2e-3
+    assert ((a - b).abs() <= 2.0 ** -7 * a.abs() + 1e-6).all()

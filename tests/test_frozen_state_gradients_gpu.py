@@ -224,7 +224,14 @@ def test_batch_norm_training_step_layer_by_layer(ops, tmp_path):
         elif nm == 'conv4_3':
             dy = _nchw(A['g_conv4_3'])
         elif pool_after[nm]:
-            dy = _nchw(A['r_' + nm])
+            # MaxPoolGrad happens INSIDE the batch-norm gradient (ops.bn_pool_backward): route the pooled gradient here, to
+            # the first maximum of each 2x2 window of the stored activations if it is positive
+            dpool = _nchw(A['dx_' + names[names.index(nm) + 1]])
+            n_, c_, h_, w_ = y.shape
+            win = y.reshape(n_, c_, h_ // 2, 2, w_ // 2, 2).permute(0, 1, 2, 4, 3, 5).reshape(n_, c_, h_ // 2, w_ // 2, 4)
+            best = win.argmax(-1)                                           # (first occurrence on ties)
+            sel = torch.nn.functional.one_hot(best, 4).to(y.dtype) * (win.max(-1).values > 0).unsqueeze(-1) * dpool.unsqueeze(-1)
+            dy = sel.reshape(n_, c_, h_ // 2, w_ // 2, 2, 2).permute(0, 1, 2, 4, 3, 5).reshape(n_, c_, h_, w_)
         else:
             dy = _nchw(A['dx_' + names[names.index(nm) + 1]])
         # [TF1] batch norm backward with the relu mask, biased batch statistics of the stored z (fp32)
