@@ -420,6 +420,10 @@ int xv_bn_bwd_apply(const xv_act* dy, const xv_act* y, const xv_act* z, const fl
 int xv_bn_bwd_reduce_zmask(const xv_act* dy, const xv_act* z, const float* mean, const float* invstd, const float* scale,
                            const float* shift, double* sums, float* dgamma, float* dbeta, void* workspace,
                            size_t workspace_bytes, void* stream);
+/* y = relu(z * scale + shift) and pooled = maxpool2x2(y) in one pass; y may be a NULL-data descriptor (only the pooled map is
+ * written: the training step recomputes y from z in xv_bn_pool_bwd_*).  64 <= C, C divides 2048; h, w even.               */
+int xv_bn_apply_pool(const xv_act* z, const float* scale, const float* shift, const xv_act* y, const xv_act* pooled,
+                     void* stream);
 /* The batch-norm gradient of a conv -> batch norm -> relu -> 2x2 max-pool block straight from the gradient of the POOLED map:
  * each pass recomputes the window's activations from z, routes the pooled gradient to the first positive maximum
  * (xv_maxpool2x2_bwd's rule on the same values) and reduces / applies -- no routed-gradient map in HBM.  count = n h w of z

@@ -411,6 +411,53 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_fast_kernel(const __bf16* __
   }
 }
 
+// y = relu(z * scale + shift) AND its 2x2 max-pool in one pass over the POOLED pixels (a thread owns one 8-channel group):
+// bn_apply + maxpool_kernel read the activation map back once more; y == nullptr skips the full-resolution map
+// altogether (training: the gradient passes recompute it from z, bn_pool_bwd_kernel)
+__global__ __launch_bounds__(256) void bn_apply_pool_kernel(const __bf16* __restrict__ z, const float* __restrict__ scale,
+                                                           const float* __restrict__ shift, __bf16* __restrict__ y,
+                                                           __bf16* __restrict__ pooled, int N, int Ho, int Wo, int C) {
+  const int c8 = C >> 3;
+  const int cg = threadIdx.x % c8;
+  float sc[8], sh[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) sc[e] = scale[cg * 8 + e], sh[e] = shift[cg * 8 + e];
+  const int Hi = 2 * Ho, Wi = 2 * Wo;
+  const int64_t rowp = (int64_t)(Wi + 2) * C;
+  const int total = N * Ho * Wo * c8, stride = (int)gridDim.x * 256;
+  for (int idx = (int)blockIdx.x * 256 + (int)threadIdx.x; idx < total; idx += stride) {
+    const int p = idx / c8;
+    const int row = p / Wo;
+    const int ox = p - row * Wo, n = row / Ho, oy = row - n * Ho;
+    const int64_t off = (((int64_t)n * (Hi + 2) + (2 * oy + 1)) * (Wi + 2) + (2 * ox + 1)) * C + cg * 8;
+    const u32x4 v[4] = {*reinterpret_cast<const u32x4*>(z + off), *reinterpret_cast<const u32x4*>(z + off + C),
+                        *reinterpret_cast<const u32x4*>(z + off + rowp), *reinterpret_cast<const u32x4*>(z + off + rowp + C)};
+    u32x4 o[4], q;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      float m0 = 0.f, m1 = 0.f;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        float a = bf_lo(v[k][w]) * sc[2 * w] + sh[2 * w];
+        float b = bf_hi(v[k][w]) * sc[2 * w + 1] + sh[2 * w + 1];
+        a = a > 0.f ? a : 0.f;
+        b = b > 0.f ? b : 0.f;
+        o[k][w] = pack_bf16x2(a, b);
+        m0 = fmaxf(m0, bf_lo(o[k][w]));  // the max of the ROUNDED activations (what maxpool_kernel sees); all >= 0
+        m1 = fmaxf(m1, bf_hi(o[k][w]));
+      }
+      q[w] = pack_bf16x2(m0, m1);
+    }
+    if (y != nullptr) {
+      *reinterpret_cast<u32x4*>(y + off) = o[0];
+      *reinterpret_cast<u32x4*>(y + off + C) = o[1];
+      *reinterpret_cast<u32x4*>(y + off + rowp) = o[2];
+      *reinterpret_cast<u32x4*>(y + off + rowp + C) = o[3];
+    }
+    *reinterpret_cast<u32x4*>(pooled + (((int64_t)n * (Ho + 2) + (oy + 1)) * (Wo + 2) + (ox + 1)) * C + cg * 8) = q;
+  }
+}
+
 // ---- MaxPoolGrad + ReluGrad + the batch-norm gradient of the conv in front of a 2x2 max-pool, in the two normalisation
 // passes themselves (xv_maxpool2x2_bwd wrote the routed gradient map, both passes then read it back: 3 of 7 streams).
 // A thread owns one 8-channel group and walks the POOLED pixels: it recomputes its window's four activations
@@ -972,6 +1019,25 @@ extern "C" int xv_bn_apply(const xv_act* z, const float* scale, const float* shi
   else
     hipLaunchKernelGGL(bn_apply_kernel, dim3(bn_grid(total, 8192)), dim3(256), 0, (hipStream_t)stream,
                        (const __bf16*)z->data, scale, shift, relu, (__bf16*)y->data, z->n, z->h, z->w, z->c);
+  return xv_launch_status();
+}
+
+// y = relu(z * scale + shift) and pooled = maxpool2x2(y) in one pass (y may be a NULL-data descriptor: only the pooled map)
+extern "C" int xv_bn_apply_pool(const xv_act* z, const float* scale, const float* shift, const xv_act* y, const xv_act* pooled,
+                                void* stream) {
+  XV_REQUIRE_BF16(z, y, pooled);
+  XV_CHECK_ARG(z && pooled && z->data && pooled->data && scale && shift);
+  XV_CHECK_SHAPE(z->c >= 64 && 2048 % z->c == 0 && (z->h & 1) == 0 && (z->w & 1) == 0);
+  XV_CHECK_SHAPE(pooled->n == z->n && pooled->h == z->h / 2 && pooled->w == z->w / 2 && pooled->c == z->c);
+  __bf16* yp = nullptr;
+  if (y && y->data) {
+    XV_CHECK_SHAPE(same_shape(y, z));
+    yp = (__bf16*)y->data;
+  }
+  const int64_t total = (int64_t)z->n * (z->h / 2) * (z->w / 2) * (z->c >> 3);
+  XV_CHECK_SHAPE(total < 0x7fff0000);
+  hipLaunchKernelGGL(bn_apply_pool_kernel, dim3(bn_grid(total, 2048)), dim3(256), 0, (hipStream_t)stream,
+                     (const __bf16*)z->data, scale, shift, yp, (__bf16*)pooled->data, z->n, z->h / 2, z->w / 2, z->c);
   return xv_launch_status();
 }
 

@@ -662,15 +662,22 @@ def _sync_sums(st, sync):
     return world()[1]
 
 
-def bn_forward(z, gamma, beta, moving_mean, moving_var, st, y, relu=True, sync=False):
+def bn_forward(z, gamma, beta, moving_mean, moving_var, st, y, relu=True, sync=False, pooled=None):
     """y = [relu](BN_batch(z)); updates the moving statistics in place (z, y: Act).  sync: statistics over all
-    data-parallel ranks (one all-reduce of 2*C doubles)."""
+    data-parallel ranks (one all-reduce of 2*C doubles).  pooled (with relu): the 2x2 max-pool of y from the same pass; y
+    may then be None (only the pooled map is written)."""
     lib = _lib.lib()
     _lib.check(lib.xv_bn_stats_ws(z.xv(), _ptr(st.sums), *st.wsp(), _stream()), 'xv_bn_stats_ws')
     mult = _sync_sums(st, sync)
     _lib.check(lib.xv_bn_finalize(_ptr(st.sums), st.c, z.n * z.h * z.w * mult, _ptr(gamma), _ptr(beta), BN_EPS,
                                   BN_MOMENTUM, _ptr(moving_mean), _ptr(moving_var), _ptr(st.mean), _ptr(st.invstd),
                                   _ptr(st.scale), _ptr(st.shift), _stream()), 'xv_bn_finalize')
+    if pooled is not None:
+        if not relu:
+            raise ValueError('the fused pool follows the relu')
+        _lib.check(lib.xv_bn_apply_pool(z.xv(), _ptr(st.scale), _ptr(st.shift), y.xv() if y is not None else _NULL_ACT,
+                                        pooled.xv(), _stream()), 'xv_bn_apply_pool')
+        return y
     _lib.check(lib.xv_bn_apply(z.xv(), _ptr(st.scale), _ptr(st.shift), int(bool(relu)), y.xv(), _stream()), 'xv_bn_apply')
     return y
 

@@ -323,6 +323,7 @@ class FcnBnTrainer(object):
         self.bn = {name: ops.BnState(c, dev) for name, c in self.bn_channels.items()}
         self.state, self.t = {}, 0
         self.zero_bias = torch.zeros(512, dtype=torch.float32, device=dev)
+        self.keep_all = False   # True: also write the full-resolution activations of the pooled layers (tests, inspection)
         self.count = torch.zeros(1, dtype=torch.int64, device=dev)
         self.loss = torch.zeros(1, dtype=torch.float64, device=dev)
         self.w, self.wd, self._a = {}, {}, {}
@@ -444,10 +445,10 @@ class FcnBnTrainer(object):
             t = self._a[key] = torch.empty(shape, dtype=dtype, device=self.e.device)
         return t
 
-    def _bn_fwd(self, name, z, y, relu=True):
+    def _bn_fwd(self, name, z, y, relu=True, pooled=None):
         mm, mv = self.moving[name]
         return ops.bn_forward(z, self.view(self.param, name, 'gamma'), self.view(self.param, name, 'beta'), mm, mv,
-                              self.bn[name], y, relu=relu, sync=self._sync)
+                              self.bn[name], y, relu=relu, sync=self._sync, pooled=pooled)
 
     def _bn_bwd(self, name, dy, y, z, dz):
         return ops.bn_backward(dy, y, z, self.view(self.param, name, 'gamma'), self.bn[name],
@@ -483,10 +484,15 @@ class FcnBnTrainer(object):
                 ops.conv2d_fwd(cur, self.w[name], P(name, 'bias'), 3, relu=False, y=z)
             inputs[name] = cur
             Z[name] = z
-            Y[name] = cur = self._bn_fwd(name, z, self._act('y_' + name, n, ch, cw, cout))
             if pool:
+                # batch norm + relu + pool in one pass; the full-resolution activation is written only where something
+                # reads it (conv4_3 feeds score_conv4; keep_all: inspection) -- the gradient passes recompute it from z
+                ya = self._act('y_' + name, n, ch, cw, cout) if (name == 'conv4_3' or self.keep_all) else None
                 ch, cw = ch // 2, cw // 2
-                Y[pool] = cur = ops.maxpool2x2_fwd(cur, self._act(pool, n, ch, cw, cout))
+                Y[pool] = cur = self._act(pool, n, ch, cw, cout)
+                Y[name] = self._bn_fwd(name, z, ya, pooled=cur)
+            else:
+                Y[name] = cur = self._bn_fwd(name, z, self._act('y_' + name, n, ch, cw, cout))
         h8, w8 = h // 8, w // 8
         for name, src, hh, ww in (('score_conv4', 'conv4_3', h8, w8), ('score_conv5', 'conv5_3', h8 // 2, w8 // 2)):
             Z[name] = ops.conv2d_fwd(Y[src], self.w[name], P(name, 'bias'), 1, relu=False,
@@ -536,13 +542,13 @@ class FcnBnTrainer(object):
         pool_after = {nm: pl for nm, _, pl in ENCODER}
         g_is_pooled = False     # g is the gradient of the layer's POOLED output (routed inside the batch-norm passes)
         for nm in reversed(names):
-            y = Y[nm]
+            y = Z[nm]       # (shape only; the relu mask comes from z)
             if g_is_pooled:
                 dz = ops.bn_pool_backward(g, Z[nm], self.view(self.param, nm, 'gamma'), self.bn[nm],
                                           self.view(self.grad, nm, 'gamma'), self.view(self.grad, nm, 'beta'),
                                           self._act('dz_' + nm, y.n, y.h, y.w, y.c), sync=self._sync)
             else:
-                dz = self._bn_bwd(nm, g, y, Z[nm], self._act('dz_' + nm, y.n, y.h, y.w, y.c))
+                dz = self._bn_bwd(nm, g, Y[nm], Z[nm], self._act('dz_' + nm, y.n, y.h, y.w, y.c))
             g_is_pooled = False
             if nm == 'conv1_1':
                 ops.conv2d_first_bwd_filter(x, dz, G(nm, 'kernel'), G(nm, 'bias'), workspace=wws)

@@ -188,3 +188,24 @@ def test_bn_pool_backward_equals_the_three_pass_form(ops, c):
     a, b = dz1.t.float(), dz2.t.float()
     assert (a != b).float().mean().item() < 2e-3
     assert ((a - b).abs() <= 2.0 ** -7 * a.abs() + 1e-6).all()
+
+
+def test_bn_apply_with_fused_pool(ops):
+    """xv_bn_apply_pool: the activation and its 2x2 max-pool from one pass equal xv_bn_apply followed by xv_maxpool2x2_fwd,
+    bit for bit; without a full-resolution output only the pooled map is written."""
+    rng = np.random.default_rng(3)
+    n, h, w, c = 2, 12, 20, 128
+    z = fo.round_bf16((rng.standard_normal((n, h, w, c)) * 1.5 + 0.3).astype(np.float32))
+    gamma, beta = rng.uniform(0.5, 1.5, c).astype(np.float32), (0.3 * rng.standard_normal(c)).astype(np.float32)
+    za = ops.Act.from_dense(_dev(z))
+    st = ops.BnState(c, 'cuda')
+    y1 = ops.Act(n, h, w, c)
+    ops.bn_forward(za, _dev(gamma), _dev(beta), torch.zeros(c, device='cuda'), torch.ones(c, device='cuda'), st, y1, relu=True)
+    q1 = ops.maxpool2x2_fwd(y1, ops.Act(n, h // 2, w // 2, c))
+    y2, q2, q3 = ops.Act(n, h, w, c), ops.Act(n, h // 2, w // 2, c), ops.Act(n, h // 2, w // 2, c)
+    ops.bn_forward(za, _dev(gamma), _dev(beta), torch.zeros(c, device='cuda'), torch.ones(c, device='cuda'), st, y2, relu=True,
+                   pooled=q2)
+    ops.bn_forward(za, _dev(gamma), _dev(beta), torch.zeros(c, device='cuda'), torch.ones(c, device='cuda'), st, None, relu=True,
+                   pooled=q3)
+    torch.cuda.synchronize()
+    assert torch.equal(y1.t, y2.t) and torch.equal(q1.t, q2.t) and torch.equal(q1.t, q3.t)

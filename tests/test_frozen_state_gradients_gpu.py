@@ -62,6 +62,7 @@ def _setup(bn, tmp_path):
     net.variables.update(w)
     net._variables_changed()
     tr = net._ensure_trainer()
+    tr.keep_all = True      # (batch-norm trainer: keep the activations of the pooled layers for the checks below)
     tr.step(torch.from_numpy(data['rgb']).cuda(), torch.from_numpy(data['labels']).cuda())
     torch.cuda.synchronize()
     return net, tr, w, data
