@@ -953,6 +953,126 @@ __global__ __launch_bounds__(256) void score_dense_dgrad_kernel(const float* __r
   }
 }
 
+// ---- the per-pixel score conv and its data gradient on the matrix cores, straight from global memory ----------------
+// One lane per pixel read its 128-byte row in eight uncoalesced 16-byte loads (and the data gradient fetched 96 weights per
+// channel group through the scalar cache): 460 / 540 us for 0.8 GB each at 16 images.  As MFMA operands the same bytes are
+// 64 contiguous bytes per pixel and instruction.
+//   forward  score[px][c] = b[c] + sum_u y[px][u] W[u][c]: D[class][pixel] on v_mfma_f32_16x16x32_bf16, A = W^T (classes
+//            padded to 16) split EXACTLY into three bf16 terms (fp32 weights: 8 + 8 + 8 significant bits), B = the pixels'
+//            bf16 channels; every product is exact in fp32, only the order of the additions differs from an FMA chain.
+//            Lane (pixel l & 15, group l >> 4) ends with classes 4g .. 4g + 3 of its pixel.
+//   gradient du[px][u] = sum_c ds[px][c] W[u][c] in exact fp32 on v_mfma_f32_16x16x4_f32 (K = 4 classes per step).
+typedef __attribute__((ext_vector_type(4))) float sd_f32x4;
+
+__device__ __forceinline__ void sd_split3(const float (&v)[8], bf16x8& h, bf16x8& m, bf16x8& l) {
+  uint32_t hh[8], mm[8], ll[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    hh[e] = __builtin_bit_cast(uint32_t, v[e]) & 0xffff0000u;
+    const float r1 = v[e] - __builtin_bit_cast(float, hh[e]);  // exact
+    mm[e] = __builtin_bit_cast(uint32_t, r1) & 0xffff0000u;
+    ll[e] = __builtin_bit_cast(uint32_t, r1 - __builtin_bit_cast(float, mm[e]));  // exact, fits 8 bits
+  }
+  auto pk = [](const uint32_t (&a)[8]) {
+    return __builtin_bit_cast(bf16x8, u32x4{(a[0] >> 16) | (a[1] & 0xffff0000u), (a[2] >> 16) | (a[3] & 0xffff0000u),
+                                            (a[4] >> 16) | (a[5] & 0xffff0000u), (a[6] >> 16) | (a[7] & 0xffff0000u)});
+  };
+  h = pk(hh), m = pk(mm), l = pk(ll);
+}
+
+template <int KS>  // U / 32 K-steps
+__global__ __launch_bounds__(256) void score_dense_mfma_kernel(const __bf16* __restrict__ u, const float* __restrict__ ws,
+                                                              const float* __restrict__ bs, float* __restrict__ score, int N,
+                                                              int H, int W, int C) {
+  constexpr int U = 32 * KS;
+  const int lane = threadIdx.x & 63, l15 = lane & 15, lg = lane >> 4;
+  bf16x8 wh[KS], wm[KS], wl[KS];
+#pragma unroll
+  for (int s = 0; s < KS; ++s) {
+    float wv[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) wv[j] = l15 < C ? ws[(32 * s + 8 * lg + j) * C + l15] : 0.f;
+    sd_split3(wv, wh[s], wm[s], wl[s]);
+  }
+  sd_f32x4 bias;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) bias[r] = 4 * lg + r < C ? bs[4 * lg + r] : 0.f;
+  const int npix = N * H * W;  // < 2^31 (checked by the launcher)
+  const int ngroups = (npix + 15) >> 4;
+  const int wid = (int)(blockIdx.x * 4 + (threadIdx.x >> 6)), nw = (int)gridDim.x * 4;
+  for (int g0 = wid; g0 < ngroups; g0 += 4 * nw) {
+    u32x4 xf[4][KS];
+    int pp[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {  // four groups' loads in flight
+      const int p = (g0 + q * nw) * 16 + l15;
+      pp[q] = (g0 + q * nw < ngroups && p < npix) ? p : -1;
+      const __bf16* src = u + sd_padded_offset(pp[q] >= 0 ? p : 0, H, W, U) + 8 * lg;
+#pragma unroll
+      for (int s = 0; s < KS; ++s) xf[q][s] = *reinterpret_cast<const u32x4*>(src + 32 * s);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      sd_f32x4 acc = bias;
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        const bf16x8 x = __builtin_bit_cast(bf16x8, xf[q][s]);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[s], x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm[s], x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[s], x, acc, 0, 0, 0);
+      }
+      if (pp[q] >= 0) {
+        float* dst = score + (int64_t)pp[q] * C + 4 * lg;
+        if ((C & 3) == 0) {
+          if (4 * lg < C) *reinterpret_cast<sd_f32x4*>(dst) = acc;
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (4 * lg + r < C) dst[r] = acc[r];
+        }
+      }
+    }
+  }
+}
+
+template <int UB, int KC>  // U / 16 channel blocks, ceil(C / 4) class steps
+__global__ __launch_bounds__(256) void score_dense_dgrad_mfma_kernel(const float* __restrict__ ds, const float* __restrict__ ws,
+                                                                    __bf16* __restrict__ du, int N, int H, int W, int C) {
+  constexpr int U = 16 * UB;
+  const int lane = threadIdx.x & 63, l15 = lane & 15, lg = lane >> 4;
+  float wa[UB][KC];
+#pragma unroll
+  for (int b = 0; b < UB; ++b)
+#pragma unroll
+    for (int s = 0; s < KC; ++s) wa[b][s] = 4 * s + lg < C ? ws[(16 * b + l15) * C + 4 * s + lg] : 0.f;
+  const int npix = N * H * W;
+  const int ngroups = (npix + 15) >> 4;
+  const int wid = (int)(blockIdx.x * 4 + (threadIdx.x >> 6)), nw = (int)gridDim.x * 4;
+  for (int g0 = wid; g0 < ngroups; g0 += 2 * nw) {
+    float dv[2][KC];
+    int pp[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int p = (g0 + q * nw) * 16 + l15;
+      pp[q] = (g0 + q * nw < ngroups && p < npix) ? p : -1;
+#pragma unroll
+      for (int s = 0; s < KC; ++s) dv[q][s] = (pp[q] >= 0 && 4 * s + lg < C) ? ds[(int64_t)p * C + 4 * s + lg] : 0.f;
+    }
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      __bf16* dst = du + sd_padded_offset(pp[q] >= 0 ? pp[q] : 0, H, W, U) + 4 * lg;
+#pragma unroll
+      for (int b = 0; b < UB; ++b) {
+        sd_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < KC; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[b][s], dv[q][s], acc, 0, 0, 0);
+        if (pp[q] >= 0)
+          *reinterpret_cast<u32x2*>(dst + 16 * b) = u32x2{pack_bf16x2(acc[0], acc[1]), pack_bf16x2(acc[2], acc[3])};
+      }
+    }
+  }
+}
+
 bool same_shape(const xv_act* a, const xv_act* b) { return a->n == b->n && a->h == b->h && a->w == b->w && a->c == b->c; }
 
 }  // namespace
@@ -1286,6 +1406,13 @@ extern "C" int xv_score_dense_fwd(const xv_act* u, const float* w_score, const f
   XV_CHECK_SHAPE((u->c & 7) == 0 && u->c <= 256 && num_classes >= 1 && num_classes <= 32);
   const int64_t npix = (int64_t)u->n * u->h * u->w;
   hipStream_t s = (hipStream_t)stream;
+  // the matrix-core form for the FCN's head (64 channels, at most 16 classes); XV_SCORE_DENSE_OLD=1: the FMA kernels (A/B)
+  static const bool sd_old = getenv("XV_SCORE_DENSE_OLD") != nullptr;
+  if (u->c == 64 && num_classes <= 16 && npix < 0x7fff0000 && !sd_old) {
+    hipLaunchKernelGGL(score_dense_mfma_kernel<2>, dim3(bn_grid(npix / 4 + 1, 2048)), dim3(256), 0, s, (const __bf16*)u->data,
+                       w_score, b_score, score, u->n, u->h, u->w, num_classes);
+    return xv_launch_status();
+  }
 #define XV_SD(CMV)                                                                                                   \
   hipLaunchKernelGGL(score_dense_kernel<CMV>, dim3(bn_grid(npix, 4096)), dim3(256), (size_t)u->c * CMV * 4, s,        \
                      (const __bf16*)u->data, w_score, b_score, score, u->n, u->h, u->w, u->c, num_classes)
@@ -1321,6 +1448,9 @@ extern "C" int xv_score_dense_bwd(const xv_act* u, const float* dscore, const fl
   XV_CHECK_SHAPE(npix < 0x7fff0000);
   const size_t lds = (size_t)SD_TILE * (u->c + 8) * 2;
   const unsigned gd = (unsigned)bn_grid(npix, 2048);
+  const unsigned gm = (unsigned)bn_grid(npix / 2 + 1, 2048);
+  static const bool sd_old = getenv("XV_SCORE_DENSE_OLD") != nullptr;
+  const bool mfma_dgrad = u->c == 64 && num_classes <= 16 && !sd_old;  // exact fp32 on v_mfma_f32_16x16x4_f32
   hipStream_t s = (hipStream_t)stream;
 #define XV_SB(CMV)                                                                                                   \
   {                                                                                                                  \
@@ -1328,8 +1458,17 @@ extern "C" int xv_score_dense_bwd(const xv_act* u, const float* dscore, const fl
     (void)xv_allow_dynamic_lds(reinterpret_cast<const void*>(&score_dense_dgrad_kernel<CMV>), 160 * 1024, attr);      \
     hipLaunchKernelGGL(score_dense_wgrad_kernel<CMV>, dim3(gw), dim3(256), 0, s, (const __bf16*)u->data, dscore,      \
                        dw_score, db_score, u->n, u->h, u->w, u->c, num_classes, per_block);                           \
-    hipLaunchKernelGGL(score_dense_dgrad_kernel<CMV>, dim3(gd), dim3(256), lds, s, dscore, w_score,                   \
-                       (__bf16*)du->data, u->n, u->h, u->w, u->c, num_classes);                                       \
+    if (mfma_dgrad) {                                                                                                \
+      if (num_classes <= 12)                                                                                         \
+        hipLaunchKernelGGL((score_dense_dgrad_mfma_kernel<4, 3>), dim3(gm), dim3(256), 0, s, dscore, w_score,          \
+                           (__bf16*)du->data, u->n, u->h, u->w, num_classes);                                         \
+      else                                                                                                           \
+        hipLaunchKernelGGL((score_dense_dgrad_mfma_kernel<4, 4>), dim3(gm), dim3(256), 0, s, dscore, w_score,          \
+                           (__bf16*)du->data, u->n, u->h, u->w, num_classes);                                         \
+    } else {                                                                                                         \
+      hipLaunchKernelGGL(score_dense_dgrad_kernel<CMV>, dim3(gd), dim3(256), lds, s, dscore, w_score,                 \
+                         (__bf16*)du->data, u->n, u->h, u->w, u->c, num_classes);                                     \
+    }                                                                                                                \
   }
   XV_CM_SWITCH(num_classes, XV_SB)
 #undef XV_SB
