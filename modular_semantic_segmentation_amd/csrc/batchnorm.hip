@@ -1073,6 +1073,69 @@ __global__ __launch_bounds__(256) void score_dense_dgrad_mfma_kernel(const float
   }
 }
 
+//   filter gradient dW[u][c] = sum_px y[px][u] ds[px][c] (+ db[c] = sum_px ds[px][c]) on v_mfma_f32_16x16x4_f32: K = 4
+//            pixels per step, A = ds^T (class l & 15, pixel l >> 4), B = the pixels' channels.  The instruction takes ONE
+//            element per lane, but a lane may load 16 bytes: lane (n < 8, pixel g) loads channels 8n .. 8n + 7 of its pixel
+//            (128 contiguous bytes per pixel) and MFMA e = 0 .. 7 takes element e of every lane, i.e. column n of MFMA e is
+//            channel 8n + e (columns 8 .. 15 idle: the matrix pipe is not the limit here).  A wave keeps the 64 x 16 block
+//            of dW in 32 registers over its run of pixels; the four waves meet in LDS in wave order, one atomic per cell.
+//            (A first version with one 2-byte load per lane and MFMA ran at 900 us against the FMA kernel's 640.)
+template <int UE>  // U / 8 = channels per lane
+__global__ __launch_bounds__(256) void score_dense_wgrad_mfma_kernel(const __bf16* __restrict__ u, const float* __restrict__ ds,
+                                                                    float* __restrict__ dws, float* __restrict__ dbs, int N,
+                                                                    int H, int W, int C, int quads_per_wave) {
+  static_assert(UE == 8, "64 channels: 8 lanes x 8 channels per pixel");
+  constexpr int U = 8 * UE;
+  __shared__ float red[4][UE * 4 + 1][64];
+  const int lane = threadIdx.x & 63, l15 = lane & 15, lg = lane >> 4, wave = threadIdx.x >> 6;
+  const int npix = N * H * W;
+  const int nquads = (npix + 3) >> 2;
+  const int wid = (int)blockIdx.x * 4 + wave;
+  const int q0 = wid * quads_per_wave, q1 = q0 + quads_per_wave < nquads ? q0 + quads_per_wave : nquads;
+  sd_f32x4 acc[UE];
+#pragma unroll
+  for (int e = 0; e < UE; ++e) acc[e] = sd_f32x4{0.f, 0.f, 0.f, 0.f};
+  float bsum = 0.f;
+  for (int q = q0; q < q1; q += 4) {
+    u32x4 yv[4];
+    float dv[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {  // four quads' loads in flight
+      const int p = (q + t) * 4 + lg;
+      const bool ok = q + t < q1 && p < npix;
+      yv[t] = (ok && l15 < 8) ? *reinterpret_cast<const u32x4*>(u + sd_padded_offset(p, H, W, U) + 8 * l15) : u32x4{0u, 0u, 0u, 0u};
+      dv[t] = (ok && l15 < C) ? ds[(int64_t)p * C + l15] : 0.f;
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+#pragma unroll
+      for (int e = 0; e < UE; ++e) {
+        const float ye = (e & 1) ? bf_hi(yv[t][e >> 1]) : bf_lo(yv[t][e >> 1]);
+        acc[e] = __builtin_amdgcn_mfma_f32_16x16x4f32(dv[t], ye, acc[e], 0, 0, 0);
+      }
+      bsum += dv[t];
+    }
+  }
+  // lane (column n = l15, group lg): acc[e][r] = dW[channel 8 n + e][class 4 lg + r] (n < 8); bsum = a quarter of db[l15]
+#pragma unroll
+  for (int e = 0; e < UE; ++e)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) red[wave][e * 4 + r][lane] = acc[e][r];
+  red[wave][UE * 4][lane] = bsum;
+  __syncthreads();
+  for (int i = threadIdx.x; i < (UE * 4 + 1) * 64; i += 256) {
+    const int row = i >> 6, ln = i & 63;
+    const float v = ((red[0][row][ln] + red[1][row][ln]) + red[2][row][ln]) + red[3][row][ln];
+    const int n = ln & 15, g = ln >> 4;
+    if (row < UE * 4) {
+      const int cls = 4 * g + (row & 3), ch = 8 * n + (row >> 2);
+      if (n < 8 && cls < C && v != 0.f) atomicAdd(dws + ch * C + cls, v);
+    } else if (n < C && v != 0.f) {
+      atomicAdd(dbs + n, v);  // (the four pixel slots of class n add up here)
+    }
+  }
+}
+
 bool same_shape(const xv_act* a, const xv_act* b) { return a->n == b->n && a->h == b->h && a->w == b->w && a->c == b->c; }
 
 }  // namespace
@@ -1451,13 +1514,24 @@ extern "C" int xv_score_dense_bwd(const xv_act* u, const float* dscore, const fl
   const unsigned gm = (unsigned)bn_grid(npix / 2 + 1, 2048);
   static const bool sd_old = getenv("XV_SCORE_DENSE_OLD") != nullptr;
   const bool mfma_dgrad = u->c == 64 && num_classes <= 16 && !sd_old;  // exact fp32 on v_mfma_f32_16x16x4_f32
+  static const bool wg_old = getenv("XV_SCORE_WGRAD_OLD") != nullptr;
+  // filter gradient: at most 512 workgroups (each ends with ~800 same-address atomics); a wave walks a contiguous run
+  const int64_t nquads = (npix + 3) / 4;
+  int qpw = (int)((nquads + 2047) / 2048);
+  qpw = (qpw + 3) / 4 * 4;
+  const unsigned gwm = (unsigned)((nquads + (int64_t)4 * qpw - 1) / ((int64_t)4 * qpw));
   hipStream_t s = (hipStream_t)stream;
 #define XV_SB(CMV)                                                                                                   \
   {                                                                                                                  \
     static bool attr[XV_MAX_DEVICES] = {false};                                                                      \
     (void)xv_allow_dynamic_lds(reinterpret_cast<const void*>(&score_dense_dgrad_kernel<CMV>), 160 * 1024, attr);      \
-    hipLaunchKernelGGL(score_dense_wgrad_kernel<CMV>, dim3(gw), dim3(256), 0, s, (const __bf16*)u->data, dscore,      \
-                       dw_score, db_score, u->n, u->h, u->w, u->c, num_classes, per_block);                           \
+    if (mfma_dgrad && !wg_old) {                                                                                     \
+      hipLaunchKernelGGL(score_dense_wgrad_mfma_kernel<8>, dim3(gwm), dim3(256), 0, s, (const __bf16*)u->data, dscore, \
+                         dw_score, db_score, u->n, u->h, u->w, num_classes, qpw);                                     \
+    } else {                                                                                                         \
+      hipLaunchKernelGGL(score_dense_wgrad_kernel<CMV>, dim3(gw), dim3(256), 0, s, (const __bf16*)u->data, dscore,    \
+                         dw_score, db_score, u->n, u->h, u->w, u->c, num_classes, per_block);                         \
+    }                                                                                                                \
     if (mfma_dgrad) {                                                                                                \
       if (num_classes <= 12)                                                                                         \
         hipLaunchKernelGGL((score_dense_dgrad_mfma_kernel<4, 3>), dim3(gm), dim3(256), 0, s, dscore, w_score,          \
