@@ -722,19 +722,29 @@ __global__ __launch_bounds__(256) void upsample_raw_bwd_kernel(const __bf16* __r
     const int n = (int)(r / Hi);
     const __bf16* dimg = dy + (int64_t)n * (Ho + 2) * (Wo + 2) * C + cg * 8;
     float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    // A row of the footprint = 2S loads issued together (positions outside the map read the zero border of the padded
+    // buffer or a clamped address with weight 0): with one load in flight per thread the 256-tap gather of the x8 form was
+    // a chain of 256 memory latencies (422 us for 0.6 GB)
     for (int oy = i * S - S / 2; oy < i * S - S / 2 + 2 * S; ++oy) {
       if (oy < 0 || oy >= Ho) continue;
       const float wy = bl_w<S>(oy, i);
-      for (int ox = j * S - S / 2; ox < j * S - S / 2 + 2 * S; ++ox) {
-        if (ox < 0 || ox >= Wo) continue;
-        const float wgt = wy * bl_w<S>(ox, j);
-        const u32x4 gv = *reinterpret_cast<const u32x4*>(dimg + ((int64_t)(oy + 1) * (Wo + 2) + (ox + 1)) * C);
+      const __bf16* rowp = dimg + (int64_t)(oy + 1) * (Wo + 2) * C;
+      u32x4 gv[2 * S];
+      float wx[2 * S];
+#pragma unroll
+      for (int t = 0; t < 2 * S; ++t) {
+        const int ox = j * S - S / 2 + t;
+        const bool in = ox >= 0 && ox < Wo;
+        wx[t] = in ? wy * bl_w<S>(ox, j) : 0.f;
+        gv[t] = *reinterpret_cast<const u32x4*>(rowp + (int64_t)((in ? ox : 0) + 1) * C);
+      }
+#pragma unroll
+      for (int t = 0; t < 2 * S; ++t)
 #pragma unroll
         for (int w = 0; w < 4; ++w) {
-          acc[2 * w] += wgt * bf_lo(gv[w]);
-          acc[2 * w + 1] += wgt * bf_hi(gv[w]);
+          acc[2 * w] += wx[t] * bf_lo(gv[t][w]);
+          acc[2 * w + 1] += wx[t] * bf_hi(gv[t][w]);
         }
-      }
     }
     u32x4 o;
 #pragma unroll
