@@ -22,7 +22,6 @@ import argparse
 import hashlib
 import json
 import os
-import re
 import subprocess
 import sys
 import threading
