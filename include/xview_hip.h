@@ -472,6 +472,11 @@ int xv_score_dense_fwd(const xv_act* u, const float* w_score, const float* b_sco
                        void* stream);
 int xv_softmax_ce_dense(const float* logits, const int32_t* labels, const int64_t* valid_count, int num_classes,
                         int64_t npix, double* loss, float* dlogits, void* stream);
+/* The same with the batch norm's affine on the scores applied inside (logits = scores * scale + shift, the expression of
+ * xv_bn_dense_apply; scale == shift == NULL: plain logits): the normalised scores never go to HBM.                      */
+int xv_softmax_ce_dense_affine(const float* scores, const float* scale, const float* shift, const int32_t* labels,
+                               const int64_t* valid_count, int num_classes, int64_t npix, double* loss, float* dlogits,
+                               void* stream);
 int xv_score_dense_bwd(const xv_act* u, const float* dscore, const float* w_score, int num_classes, float* dw_score,
                        float* db_score, const xv_act* du, void* stream);
 

@@ -806,15 +806,22 @@ __global__ __launch_bounds__(256) void softmax_ce_dense_kernel(const float* __re
                                                               const int32_t* __restrict__ labels,
                                                               const unsigned long long* __restrict__ count, int C,
                                                               int64_t npix, double* __restrict__ loss,
-                                                              float* __restrict__ dlogits) {
+                                                              float* __restrict__ dlogits,
+                                                              const float* __restrict__ scale = nullptr,
+                                                              const float* __restrict__ shift = nullptr) {
   const float inv = 1.f / (1e-20f + (float)count[0]);
+  // scale != nullptr: `logits` holds the raw scores and the batch norm's affine (xv_bn_dense_apply's expression) is applied
+  // here, so the normalised scores never go to HBM
+  float sc[CM], sh[CM];
+#pragma unroll
+  for (int c = 0; c < CM; ++c) sc[c] = (scale && c < C) ? scale[c] : 1.f, sh[c] = (scale && c < C) ? shift[c] : 0.f;
   double local = 0.0;
   for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < npix; p += (int64_t)gridDim.x * 256) {
     const int lab = labels[p];
     // one pass over the row, kept in registers (a lane's C floats are contiguous: the wave reads a dense span)
     float l[CM];
 #pragma unroll
-    for (int c = 0; c < CM; ++c) l[c] = c < C ? logits[p * C + c] : -3.0e38f;
+    for (int c = 0; c < CM; ++c) l[c] = c < C ? (scale ? logits[p * C + c] * sc[c] + sh[c] : logits[p * C + c]) : -3.0e38f;
     float m = l[0];
 #pragma unroll
     for (int c = 1; c < CM; ++c) m = fmaxf(m, l[c]);
@@ -1494,16 +1501,23 @@ extern "C" int xv_score_dense_fwd(const xv_act* u, const float* w_score, const f
   return xv_launch_status();
 }
 
-extern "C" int xv_softmax_ce_dense(const float* logits, const int32_t* labels, const int64_t* valid_count,
-                                   int num_classes, int64_t npix, double* loss, float* dlogits, void* stream) {
-  XV_CHECK_ARG(logits && labels && valid_count && loss && dlogits);
+extern "C" int xv_softmax_ce_dense_affine(const float* scores, const float* scale, const float* shift,
+                                          const int32_t* labels, const int64_t* valid_count, int num_classes, int64_t npix,
+                                          double* loss, float* dlogits, void* stream) {
+  XV_CHECK_ARG(scores && labels && valid_count && loss && dlogits && (scale == nullptr) == (shift == nullptr));
   XV_CHECK_SHAPE(npix > 0 && num_classes >= 1 && num_classes <= 32);
 #define XV_CE(CMV)                                                                                                   \
-  hipLaunchKernelGGL(softmax_ce_dense_kernel<CMV>, dim3(bn_grid(npix, 2048)), dim3(256), 0, (hipStream_t)stream, logits, \
-                     labels, reinterpret_cast<const unsigned long long*>(valid_count), num_classes, npix, loss, dlogits)
+  hipLaunchKernelGGL(softmax_ce_dense_kernel<CMV>, dim3(bn_grid(npix, 2048)), dim3(256), 0, (hipStream_t)stream, scores, \
+                     labels, reinterpret_cast<const unsigned long long*>(valid_count), num_classes, npix, loss, dlogits,  \
+                     scale, shift)
   XV_CM_SWITCH(num_classes, XV_CE)
 #undef XV_CE
   return xv_launch_status();
+}
+
+extern "C" int xv_softmax_ce_dense(const float* logits, const int32_t* labels, const int64_t* valid_count,
+                                   int num_classes, int64_t npix, double* loss, float* dlogits, void* stream) {
+  return xv_softmax_ce_dense_affine(logits, nullptr, nullptr, labels, valid_count, num_classes, npix, loss, dlogits, stream);
 }
 
 extern "C" int xv_score_dense_bwd(const xv_act* u, const float* dscore, const float* w_score, int num_classes,

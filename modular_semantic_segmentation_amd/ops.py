@@ -731,8 +731,9 @@ def bn_dense_forward(z, gamma, beta, moving_mean, moving_var, st, y, sync=False)
     _lib.check(lib.xv_bn_finalize(_ptr(st.sums), c, rows * mult, _ptr(gamma), _ptr(beta), BN_EPS, BN_MOMENTUM,
                                   _ptr(moving_mean), _ptr(moving_var), _ptr(st.mean), _ptr(st.invstd), _ptr(st.scale),
                                   _ptr(st.shift), _stream()), 'xv_bn_finalize')
-    _lib.check(lib.xv_bn_dense_apply(_ptr(z), rows, c, _ptr(st.scale), _ptr(st.shift), _ptr(y), _stream()),
-               'xv_bn_dense_apply')
+    if y is not None:       # (y = None: the caller applies st.scale / st.shift itself, e.g. softmax_ce_dense(affine=st))
+        _lib.check(lib.xv_bn_dense_apply(_ptr(z), rows, c, _ptr(st.scale), _ptr(st.shift), _ptr(y), _stream()),
+                   'xv_bn_dense_apply')
     return y
 
 
@@ -766,11 +767,14 @@ def score_dense_fwd(u, w_score, b_score, num_classes, score):
     return score
 
 
-def softmax_ce_dense(logits, labels, count, num_classes, loss, dlogits):
+def softmax_ce_dense(logits, labels, count, num_classes, loss, dlogits, affine=None):
+    """affine (a BnState): `logits` holds raw scores, logits = scores * affine.scale + affine.shift inside the kernel."""
     _need(labels, torch.int32, 'labels')
     npix = labels.numel()
-    _lib.check(_lib.lib().xv_softmax_ce_dense(_ptr(logits), _ptr(labels), _ptr(count), num_classes, npix, _ptr(loss),
-                                              _ptr(dlogits), _stream()), 'xv_softmax_ce_dense')
+    _lib.check(_lib.lib().xv_softmax_ce_dense_affine(_ptr(logits), _ptr(affine.scale) if affine is not None else None,
+                                                     _ptr(affine.shift) if affine is not None else None, _ptr(labels),
+                                                     _ptr(count), num_classes, npix, _ptr(loss), _ptr(dlogits), _stream()),
+               'xv_softmax_ce_dense_affine')
     return dlogits
 
 

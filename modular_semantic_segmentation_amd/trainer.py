@@ -508,9 +508,15 @@ class FcnBnTrainer(object):
         score_raw = ops.score_dense_fwd(Y['upscore'], self.w['score'], P('score', 'bias'), e.C,
                                         self._dense('score_raw', (n, h, w, e.C)))
         mm, mv = self.moving['score']
-        logits = ops.bn_dense_forward(score_raw, P('score', 'gamma'), P('score', 'beta'), mm, mv, self.bn['score'],
-                                      self._dense('logits', (n, h, w, e.C)), sync=self._sync)
-        dlogits = ops.softmax_ce_dense(logits, labels, self.count, e.C, self.loss, self._dense('dlogits', (n, h, w, e.C)))
+        if self.keep_all:
+            logits = ops.bn_dense_forward(score_raw, P('score', 'gamma'), P('score', 'beta'), mm, mv, self.bn['score'],
+                                          self._dense('logits', (n, h, w, e.C)), sync=self._sync)
+            dlogits = ops.softmax_ce_dense(logits, labels, self.count, e.C, self.loss, self._dense('dlogits', (n, h, w, e.C)))
+        else:       # the normalised scores stay in registers: the loss kernel applies the batch norm's scale / shift
+            ops.bn_dense_forward(score_raw, P('score', 'gamma'), P('score', 'beta'), mm, mv, self.bn['score'], None,
+                                 sync=self._sync)
+            dlogits = ops.softmax_ce_dense(score_raw, labels, self.count, e.C, self.loss,
+                                           self._dense('dlogits', (n, h, w, e.C)), affine=self.bn['score'])
         # ---- backward ------------------------------------------------------------------------------------------
         dscore = ops.bn_dense_backward(dlogits, score_raw, P('score', 'gamma'), self.bn['score'], G('score', 'gamma'),
                                        G('score', 'beta'), self._dense('dscore', (n, h, w, e.C)), sync=self._sync)
