@@ -106,6 +106,16 @@ int xv_pack_conv_weights_f8(const float* w_hwio, void* packed, int k, int cin, i
 int xv_conv2d_fwd(const xv_act* x, const void* w_packed, const float* bias, const xv_act* y,
                   const xv_act* pooled, int k, int relu, void* stream);
 
+/* The 3x3 conv of a conv -> batch norm block with the batch statistics taken in the conv's own epilogue (generation 4: bf16
+ * maps that tile exactly in 16x32 pixels, cout <= 512): y = conv(x, W) + b as xv_conv2d_fwd(relu = 0), and row w of
+ * stats_rows ([xv_conv2d_stats_rows()][2 cout] floats) = workgroup w's per-channel sum | sum of squares of the STORED
+ * (bf16) outputs; xv_bn_sums_from_rows(stats_rows, xv_conv2d_stats_rows(), 2 cout, sums) adds the rows in a fixed tree and
+ * leaves what xv_bn_stats would have.  Returns XV_ESHAPE where that kernel does not apply (use xv_conv2d_fwd + xv_bn_stats). */
+int xv_conv2d_stats_rows(void);
+int xv_conv2d_fwd_stats(const xv_act* x, const void* w_packed, const float* bias, const xv_act* y, float* stats_rows,
+                        size_t stats_bytes, void* stream);
+int xv_bn_sums_from_rows(const float* rows, int nrows, int len, double* sums, void* stream);
+
 /* Residual form for the 1x1 convs that close a ResNet block: y = act(conv1x1(x, W) + b) + residual
  * (block_a / block_b of adapnet.py:38-51,80-100: stage_3 carries its own relu, the block's outer relu is the identity
  * on the sum of two non-negative maps).                                                                               */

@@ -103,6 +103,9 @@ SIGNATURES = {
     'xv_bn_bwd_apply': (_i, [_actp, _actp, _actp, _vp, _vp, _vp, _vp, _i64, _actp, _vp]),
     'xv_bn_bwd_reduce_zmask': (_i, [_actp, _actp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_size_t, _vp]),
     'xv_bn_workspace_bytes': (ctypes.c_size_t, [_i]),
+    'xv_conv2d_stats_rows': (_i, []),
+    'xv_conv2d_fwd_stats': (_i, [_actp, _vp, _vp, _actp, _vp, ctypes.c_size_t, _vp]),
+    'xv_bn_sums_from_rows': (_i, [_vp, _i, _i, _vp, _vp]),
     'xv_bn_apply_pool': (_i, [_actp, _vp, _vp, _actp, _actp, _vp]),
     'xv_bn_pool_bwd_reduce': (_i, [_actp, _actp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_size_t, _vp]),
     'xv_bn_pool_bwd_apply': (_i, [_actp, _actp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _actp, _vp]),

@@ -1181,6 +1181,15 @@ extern "C" size_t xv_bn_workspace_bytes(int channels) {
   return channels > 0 ? (size_t)BN_MAX_GRID * 2 * channels * sizeof(float) : 0;
 }
 
+// sums[0 .. len) = the column sums of `rows` ([nrows][len] floats: per-workgroup partial sums, e.g. of xv_conv2d_fwd_stats),
+// added in a fixed tree
+extern "C" int xv_bn_sums_from_rows(const float* rows, int nrows, int len, double* sums, void* stream) {
+  XV_CHECK_ARG(rows && sums);
+  XV_CHECK_SHAPE(nrows > 0 && len > 0 && len <= 65535);
+  hipLaunchKernelGGL(bn_sums_kernel, dim3(len), dim3(256), 0, (hipStream_t)stream, rows, nrows, len, sums);
+  return xv_launch_status();
+}
+
 extern "C" int xv_bn_stats_ws(const xv_act* z, double* sums, void* workspace, size_t workspace_bytes, void* stream) {
   XV_REQUIRE_BF16(z);
   XV_CHECK_ARG(z && z->data && sums);

@@ -50,6 +50,7 @@ struct F8Args {
   int relu;
   int scale_x;    // E8M0 byte of the input map's scale in all four bytes
   float out_mul;  // 2^-scale_exp of the output map
+  float* stats;   // STATS: [gridDim.x][2 Cout] per-workgroup sums / sums of squares of the stored outputs
 };
 
 struct G4 {
@@ -61,10 +62,12 @@ struct G4 {
   static constexpr int B_BYTES = B_PIECES * 1024;
   static constexpr int BIAS_OFF = 2 * (A_BYTES + B_BYTES);  // two 256-byte bias slots (tile parity)
   static constexpr int LDS_BYTES = BIAS_OFF + 512;
+  static constexpr int STATS_OFF = LDS_BYTES;          // STATS: [wave 0..7][sum 64 | sum of squares 64] fp32
+  static constexpr int LDS_BYTES_STATS = LDS_BYTES + 8 * 128 * 4;
   static constexpr int A_ITERS = (A_PIECES + NWAVES - 1) / NWAVES;
   static constexpr int B_ITERS = (B_PIECES + NWAVES - 1) / NWAVES;
   static constexpr int PROW = HW * 64;  // bytes between patch rows
-  static_assert(LDS_BYTES <= 160 * 1024, "does not fit the LDS");
+  static_assert(LDS_BYTES_STATS <= 160 * 1024, "does not fit the LDS");
 };
 
 __device__ __forceinline__ int g4_swz(int row, int slot) { return slot ^ ((row >> 2) & 3); }
@@ -87,7 +90,10 @@ __device__ __forceinline__ float g4_dpp_swap1(float v) {  // value of lane ^ 1 (
 
 // F8: e4m3 input map and weights; OF8: e4m3 output maps (an e4m3 input implies them; <false, true> is the bf16 conv that
 // writes the first e4m3 map of the fp8 graph)
-template <bool F8, bool OF8 = F8>
+// STATS (bf16 maps, training with batch norm): the epilogue also adds up, per output channel, the stored (bf16-rounded)
+// outputs and their squares -- lanes by DPP row shifts, the workgroup's tiles in LDS, one row of a.stats per workgroup at the
+// end (xv_bn_sums_from_rows adds the rows in a fixed tree): the statistics pass over the map (xv_bn_stats) disappears.
+template <bool F8, bool OF8 = F8, bool STATS = false>
 __global__ __launch_bounds__(512, 2) void conv_dma4_kernel(F8Args a) {
   using C = G4;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -117,6 +123,12 @@ __global__ __launch_bounds__(512, 2) void conv_dma4_kernel(F8Args a) {
   const int t_begin = xcd * tq + (xcd < trm ? xcd : trm);
   const int t_end = t_begin + tq + (xcd < trm ? 1 : 0);
   int lid = t_begin + bi;
+  if constexpr (STATS) {
+    if (lid >= t_end) {  // no tile: a row of zeros
+      for (int i = tid; i < 2 * Cout; i += C::NT) a.stats[(int64_t)b * 2 * Cout + i] = 0.f;
+      return;
+    }
+  }
   if (lid >= t_end) return;
 
   struct Tile {
@@ -205,6 +217,11 @@ __global__ __launch_bounds__(512, 2) void conv_dma4_kernel(F8Args a) {
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   // 16-byte store instructions per tile and wave
+  float ssum[2][16], ssq[2][16];  // STATS only
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) ssum[j][r] = ssq[j][r] = 0.f;
   // RESIDENT WEIGHTS (as generation 2).  With one or two chunks per tile the item parity IS the chunk (or there is only one),
   // so weight buffer p only ever holds chunk p's weights -- of the same output-channel tile too when every workgroup of the
   // XCD group keeps its tile residue (nb % n_ct == 0).  From its third item on such a workgroup requests no weights at all:
@@ -376,6 +393,18 @@ __global__ __launch_bounds__(512, 2) void conv_dma4_kernel(F8Args a) {
             v[i][r] = a.relu ? fmaxf(s, 0.f) : s;
             acc[i][j][r] = 0.f;
           }
+        if constexpr (STATS) {
+          // per lane and channel: sums of the two rows' STORED (bf16) values and of their squares, kept in registers over all
+          // the workgroup's tiles (every tile of a workgroup has the same output-channel tile: the launcher checks
+          // nb % n_ct == 0); lanes, waves and workgroups meet after the last tile
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const uint32_t pk = pack_bf16x2(v[0][r], v[1][r]);
+            const float a0 = __builtin_bit_cast(float, pk << 16), a1 = __builtin_bit_cast(float, pk & 0xffff0000u);
+            ssum[j][r] += a0 + a1;
+            ssq[j][r] = fmaf(a0, a0, fmaf(a1, a1, ssq[j][r]));
+          }
+        }
         const int cofs = cur.co0 + 32 * j + 16 * hh;  // first of this lane's 16 consecutive channels
         // 16 values -> 16 bytes of e4m3, or 32 bytes of bf16 (round-to-nearest-even, as every other epilogue)
         auto store16 = [&](char* dst, const float (&u)[16], bool on) {
@@ -421,6 +450,47 @@ __global__ __launch_bounds__(512, 2) void conv_dma4_kernel(F8Args a) {
     cur = nxt;
     chunk = nchunk;
     buf ^= 1;
+  }
+  if constexpr (STATS) {
+    // half-wave sums by DPP (row_shr 1, 2, 4, 8 inside each 16-lane row, row_bcast15 into the odd rows: lanes 31 / 63 hold
+    // the totals), each wave's totals to its own LDS row, the 8 rows added in wave order (a fixed tree: reproducible bits),
+    // then the workgroup's row of a.stats (zero outside its own output-channel tile)
+#define G4_DPP_ADD(x, ctrl, rows) \
+  x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), ctrl, rows, 0xf, true))
+    float* st = reinterpret_cast<float*>(smem + C::STATS_OFF);
+    const int cslot = cur.co0 >> 6;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float su = ssum[j][r], sq = ssq[j][r];
+        G4_DPP_ADD(su, 0x111, 0xf);
+        G4_DPP_ADD(sq, 0x111, 0xf);
+        G4_DPP_ADD(su, 0x112, 0xf);
+        G4_DPP_ADD(sq, 0x112, 0xf);
+        G4_DPP_ADD(su, 0x114, 0xf);
+        G4_DPP_ADD(sq, 0x114, 0xf);
+        G4_DPP_ADD(su, 0x118, 0xf);
+        G4_DPP_ADD(sq, 0x118, 0xf);
+        G4_DPP_ADD(su, 0x142, 0xa);
+        G4_DPP_ADD(sq, 0x142, 0xa);
+        if (n31 == 31) {
+          st[wave * 128 + 32 * j + 16 * hh + r] = su;
+          st[wave * 128 + 64 + 32 * j + 16 * hh + r] = sq;
+        }
+      }
+#undef G4_DPP_ADD
+    __syncthreads();
+    for (int i = tid; i < 2 * Cout; i += C::NT) {
+      const int c = i < Cout ? i : i - Cout;
+      float v = 0.f;
+      if ((c >> 6) == cslot) {
+        const int k = (i < Cout ? 0 : 64) + (c & 63);
+#pragma unroll
+        for (int w = 0; w < C::NWAVES; ++w) v += st[w * 128 + k];
+      }
+      a.stats[(int64_t)b * 2 * Cout + i] = v;
+    }
   }
 #undef G4_RD
 #undef G4_LDW
@@ -471,12 +541,13 @@ bool xv_conv3x3_dma4_bf16_ok(int H, int W, int Cin, int Cout) {
 }
 
 namespace {
-template <bool F8, bool OF8>
+template <bool F8, bool OF8, bool STATS = false>
 int g4_launch(const F8Args& a, int grid, hipStream_t stream) {
+  constexpr int lds = STATS ? G4::LDS_BYTES_STATS : G4::LDS_BYTES;
   static bool attr_set[XV_MAX_DEVICES] = {false};
-  const hipError_t e = xv_allow_dynamic_lds(reinterpret_cast<const void*>(&conv_dma4_kernel<F8, OF8>), G4::LDS_BYTES, attr_set);
+  const hipError_t e = xv_allow_dynamic_lds(reinterpret_cast<const void*>(&conv_dma4_kernel<F8, OF8, STATS>), lds, attr_set);
   if (e != hipSuccess) return (int)e;
-  hipLaunchKernelGGL((conv_dma4_kernel<F8, OF8>), dim3((unsigned)grid), dim3(G4::NT), G4::LDS_BYTES, stream, a);
+  hipLaunchKernelGGL((conv_dma4_kernel<F8, OF8, STATS>), dim3((unsigned)grid), dim3(G4::NT), lds, stream, a);
   return xv_launch_status();
 }
 }  // namespace
@@ -485,7 +556,7 @@ int g4_launch(const F8Args& a, int grid, hipStream_t stream) {
 // 25.  scale_x / out_mul as in ConvArgs.
 int xv_launch_conv3x3_f8_dma(const void* x, const void* wpk, const float* bias, void* y, void* pooled, int N, int H, int W,
                              int Cin, int Cout, int relu, int in_f8, int out_f8, int scale_x, float out_mul, int num_cus,
-                             hipStream_t stream) {
+                             hipStream_t stream, float* stats_rows) {
   if (!(in_f8 ? xv_conv3x3_f8_dma_ok(H, W, Cin, Cout) : xv_conv3x3_dma4_bf16_ok(H, W, Cin, Cout)) ||
       (y == nullptr && pooled == nullptr) || (in_f8 && !out_f8))
     return XV_ESHAPE;
@@ -506,6 +577,11 @@ int xv_launch_conv3x3_f8_dma(const void* x, const void* wpk, const float* bias, 
   a.scale_x = scale_x;
   a.out_mul = out_mul;
   const int grid = num_cus > 0 ? num_cus : 256;
+  if (stats_rows != nullptr) {  // per-channel sums of the outputs in the epilogue: bf16 maps, at most 8 channel tiles
+    if (in_f8 || out_f8 || Cout > 512 || (grid & 7) || (grid / 8) % a.n_ct) return XV_ESHAPE;  // one channel tile per workgroup
+    a.stats = stats_rows;
+    return g4_launch<false, false, true>(a, grid, stream);
+  }
   if (in_f8) return g4_launch<true, true>(a, grid, stream);
   return out_f8 ? g4_launch<false, true>(a, grid, stream) : g4_launch<false, false>(a, grid, stream);
 }

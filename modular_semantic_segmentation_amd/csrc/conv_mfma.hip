@@ -41,7 +41,7 @@ bool xv_conv3x3_f8_dma_ok(int H, int W, int Cin, int Cout);
 bool xv_conv3x3_dma4_bf16_ok(int H, int W, int Cin, int Cout);
 int xv_launch_conv3x3_f8_dma(const void* x, const void* wpk, const float* bias, void* y, void* pooled, int N, int H, int W,
                              int Cin, int Cout, int relu, int in_f8, int out_f8, int scale_x, float out_mul, int num_cus,
-                             hipStream_t stream);
+                             hipStream_t stream, float* stats_rows = nullptr);
 void xv_launch_pack_weights_f8_g4(const float* w, char* out, int taps, int cin, int cout, float mul, hipStream_t stream);
 
 namespace {
@@ -2294,6 +2294,25 @@ extern "C" int xv_conv2d_fwd_residual(const xv_act* x, const void* w_packed, con
 // pointwise.hip
 int xv_launch_depth_to_space(const xv_act* z, const float* scale, const float* shift, const xv_act* residual, const xv_act* y,
                              int stride, int relu, hipStream_t stream);
+
+// The 3x3 conv of a conv -> batch norm block with the batch statistics taken in the conv's own epilogue (generation 4, bf16
+// maps that tile exactly in 16x32, at most 512 output channels): y = conv(x, W) + b as xv_conv2d_fwd(relu = 0), and row
+// w of `stats_rows` ([xv_conv2d_stats_rows()][2 cout] floats) = workgroup w's per-channel sum and sum of squares of the
+// stored outputs; xv_bn_sums_from_rows adds the rows in a fixed tree.  XV_ESHAPE where that kernel does not apply: the
+// caller then uses xv_conv2d_fwd + xv_bn_stats.
+extern "C" int xv_conv2d_stats_rows(void) { return xv_num_cus(); }
+
+extern "C" int xv_conv2d_fwd_stats(const xv_act* x, const void* w_packed, const float* bias, const xv_act* y, float* stats_rows,
+                                   size_t stats_bytes, void* stream) {
+  XV_REQUIRE_BF16(x, y);
+  XV_CHECK_ARG(x && x->data && w_packed && bias && y && y->data && stats_rows);
+  XV_CHECK_ARG((((uintptr_t)x->data | (uintptr_t)w_packed | (uintptr_t)bias | (uintptr_t)y->data | (uintptr_t)stats_rows) & 15) == 0);
+  XV_CHECK_SHAPE(x->n > 0 && y->n == x->n && y->h == x->h && y->w == x->w && (x->c & 63) == 0 && (y->c & 63) == 0);
+  if (!xv_conv3x3_dma4_bf16_ok(x->h, x->w, x->c, y->c) || y->c > 512) return XV_ESHAPE;
+  if (stats_bytes < (size_t)xv_num_cus() * 2 * y->c * sizeof(float)) return XV_EWORKSPACE;
+  return xv_launch_conv3x3_f8_dma(x->data, w_packed, bias, y->data, nullptr, x->n, x->h, x->w, x->c, y->c, 0, 0, 0, 0, 1.f,
+                                  xv_num_cus(), (hipStream_t)stream, stats_rows);
+}
 
 extern "C" size_t xv_deconv_dense_workspace_bytes(int n, int h, int w, int cout, int stride) {
   if (n <= 0 || h <= 0 || w <= 0 || cout <= 0 || stride <= 0) return 0;

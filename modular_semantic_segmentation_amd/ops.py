@@ -4,6 +4,7 @@ PyTorch is plumbing here: it owns device memory and the stream; every arithmetic
 hot path runs in libxview_hip.so.
 """
 import ctypes
+import os
 
 import torch
 
@@ -662,12 +663,32 @@ def _sync_sums(st, sync):
     return world()[1]
 
 
-def bn_forward(z, gamma, beta, moving_mean, moving_var, st, y, relu=True, sync=False, pooled=None):
+def conv2d_fwd_stats(x, w_packed, bias, z, st):
+    """z = conv3x3(x) + bias with the batch statistics of z (st.sums, as xv_bn_stats leaves them) taken in the conv kernel's
+    epilogue.  Returns False (nothing launched) where that kernel does not apply: the caller then runs conv2d_fwd and lets
+    bn_forward take the statistics."""
+    if os.environ.get('XV_BN_CONV_STATS') == '0':        # A/B timing: the separate statistics pass
+        return False
+    lib = _lib.lib()
+    rows = lib.xv_conv2d_stats_rows()
+    if getattr(st, 'conv_rows', None) is None or st.conv_rows.numel() < rows * 2 * st.c:
+        st.conv_rows = torch.empty(rows * 2 * st.c, dtype=torch.float32, device=z.t.device)
+    rc = lib.xv_conv2d_fwd_stats(x.xv(), _ptr(w_packed), _ptr(bias), z.xv(), _ptr(st.conv_rows), st.conv_rows.numel() * 4,
+                                 _stream())
+    if rc == -2:            # XV_ESHAPE: the generation-4 kernel does not take this shape
+        return False
+    _lib.check(rc, 'xv_conv2d_fwd_stats')
+    _lib.check(lib.xv_bn_sums_from_rows(_ptr(st.conv_rows), rows, 2 * st.c, _ptr(st.sums), _stream()), 'xv_bn_sums_from_rows')
+    return True
+
+
+def bn_forward(z, gamma, beta, moving_mean, moving_var, st, y, relu=True, sync=False, pooled=None, have_stats=False):
     """y = [relu](BN_batch(z)); updates the moving statistics in place (z, y: Act).  sync: statistics over all
     data-parallel ranks (one all-reduce of 2*C doubles).  pooled (with relu): the 2x2 max-pool of y from the same pass; y
     may then be None (only the pooled map is written)."""
     lib = _lib.lib()
-    _lib.check(lib.xv_bn_stats_ws(z.xv(), _ptr(st.sums), *st.wsp(), _stream()), 'xv_bn_stats_ws')
+    if not have_stats:      # (have_stats: conv2d_fwd_stats already left the sums in st.sums)
+        _lib.check(lib.xv_bn_stats_ws(z.xv(), _ptr(st.sums), *st.wsp(), _stream()), 'xv_bn_stats_ws')
     mult = _sync_sums(st, sync)
     _lib.check(lib.xv_bn_finalize(_ptr(st.sums), st.c, z.n * z.h * z.w * mult, _ptr(gamma), _ptr(beta), BN_EPS,
                                   BN_MOMENTUM, _ptr(moving_mean), _ptr(moving_var), _ptr(st.mean), _ptr(st.invstd),

@@ -445,10 +445,10 @@ class FcnBnTrainer(object):
             t = self._a[key] = torch.empty(shape, dtype=dtype, device=self.e.device)
         return t
 
-    def _bn_fwd(self, name, z, y, relu=True, pooled=None):
+    def _bn_fwd(self, name, z, y, relu=True, pooled=None, have_stats=False):
         mm, mv = self.moving[name]
         return ops.bn_forward(z, self.view(self.param, name, 'gamma'), self.view(self.param, name, 'beta'), mm, mv,
-                              self.bn[name], y, relu=relu, sync=self._sync, pooled=pooled)
+                              self.bn[name], y, relu=relu, sync=self._sync, pooled=pooled, have_stats=have_stats)
 
     def _bn_bwd(self, name, dy, y, z, dz):
         return ops.bn_backward(dy, y, z, self.view(self.param, name, 'gamma'), self.bn[name],
@@ -478,10 +478,14 @@ class FcnBnTrainer(object):
         inputs = {}
         for name, cout, pool in ENCODER:
             z = self._act('z_' + name, n, ch, cw, cout)
+            have_stats = False
             if name == 'conv1_1':
                 ops.conv2d_first_fwd(x.contiguous(), self.w[name], P(name, 'bias'), z, relu=False)
             else:
-                ops.conv2d_fwd(cur, self.w[name], P(name, 'bias'), 3, relu=False, y=z)
+                # the batch statistics in the conv's own epilogue where its kernel allows (generation 4: exact 16x32 tilings)
+                have_stats = ops.conv2d_fwd_stats(cur, self.w[name], P(name, 'bias'), z, self.bn[name])
+                if not have_stats:
+                    ops.conv2d_fwd(cur, self.w[name], P(name, 'bias'), 3, relu=False, y=z)
             inputs[name] = cur
             Z[name] = z
             if pool:
@@ -490,9 +494,9 @@ class FcnBnTrainer(object):
                 ya = self._act('y_' + name, n, ch, cw, cout) if (name == 'conv4_3' or self.keep_all) else None
                 ch, cw = ch // 2, cw // 2
                 Y[pool] = cur = self._act(pool, n, ch, cw, cout)
-                Y[name] = self._bn_fwd(name, z, ya, pooled=cur)
+                Y[name] = self._bn_fwd(name, z, ya, pooled=cur, have_stats=have_stats)
             else:
-                Y[name] = cur = self._bn_fwd(name, z, self._act('y_' + name, n, ch, cw, cout))
+                Y[name] = cur = self._bn_fwd(name, z, self._act('y_' + name, n, ch, cw, cout), have_stats=have_stats)
         h8, w8 = h // 8, w // 8
         for name, src, hh, ww in (('score_conv4', 'conv4_3', h8, w8), ('score_conv5', 'conv5_3', h8 // 2, w8 // 2)):
             Z[name] = ops.conv2d_fwd(Y[src], self.w[name], P(name, 'bias'), 1, relu=False,

@@ -209,3 +209,30 @@ def test_bn_apply_with_fused_pool(ops):
                    pooled=q3)
     torch.cuda.synchronize()
     assert torch.equal(y1.t, y2.t) and torch.equal(q1.t, q2.t) and torch.equal(q1.t, q3.t)
+
+
+@pytest.mark.parametrize('shape', [(2, 16, 32, 64, 64), (3, 32, 64, 128, 256), (5, 96, 192, 64, 128)])
+def test_conv_with_batch_statistics_in_its_epilogue(ops, shape):
+    """xv_conv2d_fwd_stats (generation-4 conv kernel, STATS form): the conv output equals xv_conv2d_fwd's bit for bit and
+    the per-channel sums it leaves equal xv_bn_stats on that output to fp32 summation order (integer operands: the sums of
+    the stored values are exact in fp64, the partial sums in fp32 are not); shapes that do not tile are refused."""
+    n, h, w, cin, cout = shape
+    rng = np.random.default_rng(sum(shape))
+    x = rng.integers(-2, 3, (n, h, w, cin)).astype(np.float32)
+    wt = (rng.integers(-2, 3, (3, 3, cin, cout)) / 8.0).astype(np.float32)
+    b = (rng.integers(-3, 4, cout) / 4.0).astype(np.float32)
+    xa, wp, bd = ops.Act.from_dense(_dev(x)), ops.pack_conv_weights(_dev(wt)), _dev(b)
+    z1, _ = ops.conv2d_fwd(xa, wp, bd, 3, relu=False)
+    st1, st2 = ops.BnState(cout, 'cuda'), ops.BnState(cout, 'cuda')
+    from modular_semantic_segmentation_amd import _lib
+    _lib.check(_lib.lib().xv_bn_stats_ws(z1.xv(), st1.sums.data_ptr(), *st1.wsp(), None), 'xv_bn_stats_ws')
+    z2 = ops.Act(n, h, w, cout)
+    assert ops.conv2d_fwd_stats(xa, wp, bd, z2, st2)
+    torch.cuda.synchronize()
+    assert torch.equal(z1.t, z2.t)
+    zs = z1.interior().double()
+    want = torch.cat([zs.sum((0, 1, 2)), (zs * zs).sum((0, 1, 2))]).cpu().numpy()
+    np.testing.assert_allclose(st2.sums.cpu().numpy(), want, rtol=1e-5, atol=1e-3)
+    np.testing.assert_allclose(st1.sums.cpu().numpy(), want, rtol=1e-5, atol=1e-3)
+    xs = ops.Act.from_dense(_dev(x[:, :h - 8]))
+    assert not ops.conv2d_fwd_stats(xs, wp, bd, ops.Act(n, h - 8, w, cout), st2)          # 8 rows short of a tiling
