@@ -106,11 +106,11 @@ def main(tag, batch=16):
 
     cmd = 'python3 bench.py --steps 3 --warmup 1 --serial-experts --no-graph --no-cpu-baseline --no-accuracy --no-extra'
     mfma_summary(tag, '', {'conv_dma_kernel': lambda k: 'conv_dma_kernel' in k,
-                           'conv_dma4_kernel<false, false> (generation 4, bf16)': lambda k: 'conv_dma4_kernel<false, false>' in k,
+                           'conv_dma4_kernel<false, false> (generation 4, bf16)': lambda k: 'conv_dma4_kernel<false, false' in k,
                            'conv_mfma_kernel (bf16, first generation)': lambda k: 'conv_mfma_kernel' in k and not is_f8(k)},
                  cmd + ' (batch 16, 768x384)')
     mfma_summary(tag, '8', {'conv_dma4_kernel<true, true> (generation 4, e4m3 operands)': lambda k: 'conv_dma4_kernel<true' in k,
-                            'conv_dma4_kernel<false, true> (conv1_2: bf16 in, e4m3 out)': lambda k: 'conv_dma4_kernel<false, true>' in k,
+                            'conv_dma4_kernel<false, true> (conv1_2: bf16 in, e4m3 out)': lambda k: 'conv_dma4_kernel<false, true' in k,
                             'conv_mfma_kernel<F8> (e4m3 operands, first generation)': is_f8,
                             'conv_dma_kernel (bf16)': lambda k: 'conv_dma_kernel' in k},
                  cmd + ' --dtype fp8 --height 1024 --width 2048 --batch 4')
