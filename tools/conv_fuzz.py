@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Randomised bit-exact comparison of the generation-2 conv kernel (configuration 17) against generation 1
-(configuration 14) on integer-valued operands: random batch / image sizes (whole and partial tiles, fewer and many
+"""Randomised bit-exact comparison of the generation-2 conv kernel (configuration 17; generation 4, configuration 25,
+on the maps that tile) against generation 1 (configuration 14) on integer-valued operands: random batch / image sizes (whole and partial tiles, fewer and many
 more tiles than workgroups), channel counts, output modes (full map, fused pool, pooled only) and the data-gradient
 epilogue (addend + relu mask).  GPU box only."""
 import argparse
@@ -33,7 +33,10 @@ def fuzz_fp8():
         h = int(rng.integers(1, 24 if not big else 70)) * 2
         w = int(rng.integers(1, 30 if not big else 100)) * 2
         k = 1 if case % 5 == 4 else 3
-        cin = int(rng.choice([128, 256, 384, 512]))
+        tiles = k == 3 and case % 3 == 0     # a map that tiles exactly in 16x32: generation 4 (configuration 24; the default there)
+        if tiles:
+            h, w = (h + 15) // 16 * 16, (w + 31) // 32 * 32
+        cin = int(rng.choice([64, 128, 192, 256] if tiles else [128, 256, 384, 512]))
         cout = int(rng.choice([64, 128, 192]))
         ex, ew, ey = int(rng.integers(-3, 4)), int(rng.integers(-6, 2)), int(rng.integers(-2, 8))
         mode = int(rng.integers(0, 3)) if k == 3 else 0       # 0 full map, 1 full + pool, 2 pooled only
@@ -50,7 +53,7 @@ def fuzz_fp8():
         q8 = lambda t: (t * 2.0 ** -ey).clamp(-448, 448).to(torch.float8_e4m3fn).float() * 2.0 ** ey      # noqa: E731
         want_y = q8(y32).permute(0, 2, 3, 1)
         want_q = q8(F.max_pool2d(y32, 2, 2)).permute(0, 2, 3, 1) if mode else None
-        for cfg in (14, 15, 16, -1):
+        for cfg in ((24, -1) if tiles and cin % 128 else (14, 15, 16, -1) + ((24,) if tiles else ())):
             y = ops.Act(n, h, w, cout, dtype='fp8', scale_exp=ey) if mode != 2 else None
             q = ops.Act(n, h // 2, w // 2, cout, dtype='fp8', scale_exp=ey) if mode else None
             ops.conv2d_fwd(xa, wp, torch.from_numpy(b).cuda(), k, relu=relu, y=y, pooled=q, write_y=y is not None, cfg=cfg)
@@ -76,6 +79,9 @@ for case in range(args.cases):
     cin = int(rng.choice([64, 128, 192, 256]))
     cout = int(rng.choice([64, 128, 192]))
     mode = int(rng.integers(0, 4))          # 0 full map, 1 full + pool, 2 pooled only, 3 data gradient
+    tiles = case % 3 == 0 and mode != 3     # a map that tiles exactly in 16x32: generation 4 (configuration 25) joins
+    if tiles:
+        h, w = (h + 15) // 16 * 16, (w + 31) // 32 * 32
     relu = bool(rng.integers(0, 2)) if mode == 0 else (mode != 3)
     x = torch.from_numpy(rng.integers(-2, 3, (n, h, w, cin)).astype(np.float32)).cuda()
     wt = torch.from_numpy(rng.integers(-1, 2, (3, 3, cin, cout)).astype(np.float32)).cuda()
@@ -102,7 +108,7 @@ for case in range(args.cases):
             print('MISMATCH data-gradient epilogue', (n, h, w, cin, cout))
     else:
         wp = ops.pack_conv_weights(wt)
-        for cfg in (14, 17, 21) + ((22,) if mode == 0 else ()):          # 22: no fused pool
+        for cfg in (14, 17, 21) + ((22,) if mode == 0 else ()) + ((25,) if tiles else ()):          # 22: no fused pool
             y = ops.Act(n, h, w, cout) if mode != 2 else None
             q = ops.Act(n, h // 2, w // 2, cout) if mode in (1, 2) else None
             ops.conv2d_fwd(xa, wp, b, 3, relu=relu, y=y, pooled=q, write_y=y is not None, cfg=cfg)
