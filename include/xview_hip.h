@@ -79,8 +79,7 @@ int xv_pack_conv_weights_pair(const float* w_hwio, void* packed, void* packed_dg
  * stands for q * 2^e_w; the kernel feeds it to the MFMA as a uniform E8M0 block scale).  Values are rounded to
  * nearest-even after the scaling and saturate at +-448.  For k = 3 a second image follows for the generation-4 kernel:
  * [tap][cin/64][row][64], 64-byte rows, slot s of row r at s ^ ((r >> 2) & 3), rows permuted as in the bf16 image;
- * with it cin % 64 == 0 suffices for k = 3 (the first image is left empty unless cin % 128 == 0, and only maps that
- * tile exactly in 16x32 pixels can then be convolved).  k = 1: cin % 128 == 0.  cout % 64 == 0.                    */
+ * with it cin % 64 == 0 suffices for k = 3 (the first image is left empty unless cin % 128 == 0).  k = 1: cin % 128 == 0.  cout % 64 == 0.                    */
 size_t xv_packed_weight_bytes_f8(int k, int cin, int cout);
 int xv_pack_conv_weights_f8(const float* w_hwio, void* packed, int k, int cin, int cout, int scale_exp, void* stream);
 
@@ -98,11 +97,11 @@ int xv_pack_conv_weights_f8(const float* w_hwio, void* packed, int k, int cin, i
  * v_mfma_scale_f32_16x16x128_f8f6f4 kernel (e4m3 operands, 128-channel chunks, fp32 accumulate; x->scale_exp and the
  * weight header's exponent go in as uniform E8M0 scales, so the accumulators are in real units) and needs weights
  * packed by xv_pack_conv_weights_f8 and cin % 128 == 0; y->dtype / pooled->dtype == XV_FP8 make the epilogue write
- * e4m3 (value * 2^-scale_exp, round-to-nearest-even, saturating at 448) from either kernel.  3x3 convs whose map tiles
- * exactly in 16x32 pixels (h % 16 == 0, w % 32 == 0) run on the generation-4 kernel instead (configurations 24 / 25,
- * conv_f8_dma.hip: v_mfma_scale_f32_32x32x64_f8f6f4 on 64-channel e4m3 chunks, so cin % 64 == 0 suffices there;
- * v_mfma_f32_32x32x16_bf16 for bf16 maps -- bf16 in / e4m3 out included): conv2_1 (64 input channels) is an e4m3
- * convolution on such maps and a bf16 convolution that hands an e4m3 map to conv2_2 on the others.               */
+ * e4m3 (value * 2^-scale_exp, round-to-nearest-even, saturating at 448) from either kernel.  3x3 convs run on the
+ * generation-4 kernel where it is ahead (configurations 24 / 25, conv_f8_dma.hip: v_mfma_scale_f32_32x32x64_f8f6f4 on
+ * 64-channel e4m3 chunks, so cin % 64 == 0 suffices for k = 3; v_mfma_f32_32x32x16_bf16 for bf16 maps -- bf16 in / e4m3
+ * out included; any map size, partial tiles by clamped DMA offsets and predicated stores): conv2_1 (64 input channels)
+ * is an e4m3 convolution there.                                                                                  */
 int xv_conv2d_fwd(const xv_act* x, const void* w_packed, const float* bias, const xv_act* y,
                   const xv_act* pooled, int k, int relu, void* stream);
 

@@ -26,8 +26,10 @@
 //     and waited for by hand (counted lgkmcnt, never more than 12 reads in flight), each tap's 4 MFMAs as one burst at
 //     raised priority; the next item's DMA two pieces per tap; ONE barrier per item behind a counted vmcnt that leaves
 //     the tile's own stores (younger than every DMA) in flight.
-// Maps must tile exactly (H % 16 == 0, W % 32 == 0: every fp8 layer of a 2048x1024 or 768x384 input down to conv4);
-// other shapes stay on the first-generation kernel.
+// Partial tiles (maps that do not tile in 16x32) as in generation 2: the patch DMA of an edge tile clamps its source
+// coordinates onto the zero border of the padded map, stores are predicated, and the barrier behind an edge tile waits for
+// all its stores (a wave below the image issues none: no counted wait).  The chooser still prefers the first-generation fp8
+// kernel where the 16x32 tile wastes too much of a small map (the 24x48 conv5 maps of a 768x384 input: 56 % coverage).
 //
 // bf16 (configuration 25): the same kernel with 32-channel chunks (again 64 bytes per pixel and weight row) on
 // v_mfma_f32_32x32x16_bf16 -- two K = 16 steps per tap, lane half h supplying k-group h of each step (slots h and 2 + h) --
@@ -93,7 +95,9 @@ __device__ __forceinline__ float g4_dpp_swap1(float v) {  // value of lane ^ 1 (
 // STATS (bf16 maps, training with batch norm): the epilogue also adds up, per output channel, the stored (bf16-rounded)
 // outputs and their squares -- lanes by DPP row shifts, the workgroup's tiles in LDS, one row of a.stats per workgroup at the
 // end (xv_bn_sums_from_rows adds the rows in a fixed tree): the statistics pass over the map (xv_bn_stats) disappears.
-template <bool F8, bool OF8 = F8, bool STATS = false>
+// EDGE: partial tiles possible (clamped DMA offsets, predicated stores); maps that tile exactly run the form without that
+// code (it cost 3-5 % on the one- and two-chunk layers)
+template <bool F8, bool OF8 = F8, bool STATS = false, bool EDGE = false>
 __global__ __launch_bounds__(512, 2) void conv_dma4_kernel(F8Args a) {
   using C = G4;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -179,9 +183,24 @@ __global__ __launch_bounds__(512, 2) void conv_dma4_kernel(F8Args a) {
     xsrc = a.x + (((int64_t)t.n * (H + 2) + t.y0) * Wp + t.x0) * Cb + chunk * 64;
     wsrc = wimg + (((int64_t)chunk * Cout + t.co0) << 6);
   };
-  auto dma_a = [&](const char* xsrc, int it, int buf) {
+  // edge tiles (the patch reaches past the padded image): patch coordinates are clamped onto the zero border, i.e. the
+  // source offset is recomputed with hy <= ylim, hx <= xlim (re-derived from the lane number inside this rare path, as in
+  // generation 2); the LDS position (and its swizzle) is unchanged
+  auto dma_a = [&](const char* xsrc, int it, int buf, bool edge, int ylim, int xlim) {
     const int piece = wave + it * C::NWAVES;
-    if (piece < C::A_PIECES) dma16(xsrc, aoff[it], buf * C::A_BYTES + piece * 1024);
+    if (piece < C::A_PIECES) {
+      int voff = aoff[it];
+      if (EDGE && edge) {
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+        const int g = piece * 64 + ln;
+        int p = g >> 2;
+        p = p < C::NPIX ? p : C::NPIX - 1;
+        const int hy = p / C::HW, hx = p - hy * C::HW;
+        voff = ((hy < ylim ? hy : ylim) * Wp + (hx < xlim ? hx : xlim)) * Cb + (g4_swz(hx, g & 3) << 4);
+      }
+      dma16(xsrc, voff, buf * C::A_BYTES + piece * 1024);
+    }
   };
   auto dma_b = [&](const char* wsrc, int it, int buf) {
     const int piece = wave + it * C::NWAVES;
@@ -202,7 +221,8 @@ __global__ __launch_bounds__(512, 2) void conv_dma4_kernel(F8Args a) {
     const char *xsrc, *wsrc;
     dma_bases(cur, 0, xsrc, wsrc);
 #pragma unroll
-    for (int it = 0; it < C::A_ITERS; ++it) dma_a(xsrc, it, 0);
+    for (int it = 0; it < C::A_ITERS; ++it)
+      dma_a(xsrc, it, 0, cur.y0 + C::TH > H || cur.x0 + C::TW > W, H + 1 - cur.y0, W + 1 - cur.x0);
 #pragma unroll
     for (int it = 0; it < C::B_ITERS; ++it) dma_b(wsrc, it, 0);
     dma_bias(cur, true, 0);
@@ -312,8 +332,8 @@ __global__ __launch_bounds__(512, 2) void conv_dma4_kernel(F8Args a) {
     // the bias with the first weight piece
 #define G4_DMA_PIECES(t)                                                                 \
   if (has_next) {                                                                        \
-    if (2 * (t) < C::A_ITERS) dma_a(nx_src, 2 * (t), buf ^ 1);                           \
-    if (2 * (t) + 1 < C::A_ITERS) dma_a(nx_src, 2 * (t) + 1, buf ^ 1);                   \
+    if (2 * (t) < C::A_ITERS) dma_a(nx_src, 2 * (t), buf ^ 1, nx_edge, nx_ylim, nx_xlim);         \
+    if (2 * (t) + 1 < C::A_ITERS) dma_a(nx_src, 2 * (t) + 1, buf ^ 1, nx_edge, nx_ylim, nx_xlim); \
     if ((t) >= A_TAPS && (t) - A_TAPS < C::B_ITERS && !skip_b) dma_b(nw_src, (t) - A_TAPS, buf ^ 1); \
     if ((t) == A_TAPS) dma_bias(nxt, last_chunk, bslot ^ 1);                             \
   }
@@ -358,6 +378,8 @@ __global__ __launch_bounds__(512, 2) void conv_dma4_kernel(F8Args a) {
     const int nchunk = last_chunk ? 0 : chunk + 1;
     const char *nx_src = nullptr, *nw_src = nullptr;
     if (has_next) dma_bases(nxt, nchunk, nx_src, nw_src);
+    const bool nx_edge = nxt.y0 + C::TH > H || nxt.x0 + C::TW > W;
+    const int nx_ylim = H + 1 - nxt.y0, nx_xlim = W + 1 - nxt.x0;
     const bool skip_b = resident && items_done >= 1;  // the NEXT item is this workgroup's third or later
     __builtin_amdgcn_sched_barrier(0);
 
@@ -426,7 +448,8 @@ __global__ __launch_bounds__(512, 2) void conv_dma4_kernel(F8Args a) {
         if (a.y != nullptr) {
 #pragma unroll
           for (int i = 0; i < 2; ++i)
-            store16(a.y + (((int64_t)cur.n * (H + 2) + (py + i + 1)) * Wp + (px + 1)) * Ob + cofs * (OF8 ? 1 : 2), v[i], true);
+            store16(a.y + (((int64_t)cur.n * (H + 2) + (py + i + 1)) * Wp + (px + 1)) * Ob + cofs * (OF8 ? 1 : 2), v[i],
+                    !EDGE || (py + i < H && px < W));
         }
         if (a.pooled != nullptr) {
           float m[16];
@@ -438,10 +461,11 @@ __global__ __launch_bounds__(512, 2) void conv_dma4_kernel(F8Args a) {
           const int Hq = H >> 1, Wq = W >> 1;
           // every wave issues these instructions (even lanes store): the counted vmcnt at the next barrier relies on it
           store16(a.pooled + (((int64_t)cur.n * (Hq + 2) + ((py >> 1) + 1)) * (Wq + 2) + ((px >> 1) + 1)) * Ob + cofs * (OF8 ? 1 : 2),
-                  m, (lane & 1) == 0);
+                  m, (lane & 1) == 0 && (!EDGE || (py < H && px < W)));
         }
       }
-      in_flight = nstores;
+      // (an edge tile may skip store instructions -- a wave below the image stores nothing: no counted wait then)
+      in_flight = (EDGE && (cur.y0 + C::TH > H || cur.x0 + C::TW > W)) ? 0 : nstores;
       bslot ^= 1;
     }
     if (!has_next) break;
@@ -532,23 +556,31 @@ __global__ void pack_weights_f8_g4_kernel(const float* __restrict__ w, char* __r
 
 }  // namespace
 
-// Can generation 4 run this shape?  (3x3, exact 16x32 tiling, whole 64-byte chunks of input channels)
+// Can generation 4 run this shape?  (3x3, whole 64-byte chunks of input channels; any map size: partial tiles are
+// handled by clamped DMA offsets and predicated stores)
 bool xv_conv3x3_f8_dma_ok(int H, int W, int Cin, int Cout) {
-  return H > 0 && W > 0 && (H & 15) == 0 && (W & 31) == 0 && Cin >= 64 && (Cin & 63) == 0 && (Cout & 63) == 0;
+  return H > 0 && W > 0 && Cin >= 64 && (Cin & 63) == 0 && (Cout & 63) == 0;
 }
 bool xv_conv3x3_dma4_bf16_ok(int H, int W, int Cin, int Cout) {
-  return H > 0 && W > 0 && (H & 15) == 0 && (W & 31) == 0 && Cin >= 64 && (Cin & 31) == 0 && (Cout & 63) == 0;
+  return H > 0 && W > 0 && Cin >= 64 && (Cin & 31) == 0 && (Cout & 63) == 0;
 }
+// ... and does the map tile exactly in 16x32 pixels (no partial tiles)?
+bool xv_conv3x3_dma4_exact(int H, int W) { return (H & 15) == 0 && (W & 31) == 0; }
 
 namespace {
-template <bool F8, bool OF8, bool STATS = false>
-int g4_launch(const F8Args& a, int grid, hipStream_t stream) {
+template <bool F8, bool OF8, bool STATS, bool EDGE>
+int g4_launch1(const F8Args& a, int grid, hipStream_t stream) {
   constexpr int lds = STATS ? G4::LDS_BYTES_STATS : G4::LDS_BYTES;
   static bool attr_set[XV_MAX_DEVICES] = {false};
-  const hipError_t e = xv_allow_dynamic_lds(reinterpret_cast<const void*>(&conv_dma4_kernel<F8, OF8, STATS>), lds, attr_set);
+  const hipError_t e = xv_allow_dynamic_lds(reinterpret_cast<const void*>(&conv_dma4_kernel<F8, OF8, STATS, EDGE>), lds, attr_set);
   if (e != hipSuccess) return (int)e;
-  hipLaunchKernelGGL((conv_dma4_kernel<F8, OF8, STATS>), dim3((unsigned)grid), dim3(G4::NT), lds, stream, a);
+  hipLaunchKernelGGL((conv_dma4_kernel<F8, OF8, STATS, EDGE>), dim3((unsigned)grid), dim3(G4::NT), lds, stream, a);
   return xv_launch_status();
+}
+template <bool F8, bool OF8, bool STATS = false>
+int g4_launch(const F8Args& a, int grid, hipStream_t stream) {
+  if (STATS || xv_conv3x3_dma4_exact(a.H, a.W)) return g4_launch1<F8, OF8, STATS, false>(a, grid, stream);
+  return g4_launch1<F8, OF8, false, true>(a, grid, stream);
 }
 }  // namespace
 
@@ -567,8 +599,8 @@ int xv_launch_conv3x3_f8_dma(const void* x, const void* wpk, const float* bias, 
   a.y = (char*)y;
   a.pooled = (char*)pooled;
   a.N = N, a.H = H, a.W = W, a.Cin = Cin, a.Cout = Cout;
-  a.tiles_x = W / G4::TW;
-  a.tiles_y = H / G4::TH;
+  a.tiles_x = (W + G4::TW - 1) / G4::TW;
+  a.tiles_y = (H + G4::TH - 1) / G4::TH;
   a.n_ct = Cout / 64;
   const int64_t ntiles = (int64_t)a.tiles_x * a.tiles_y * N * a.n_ct;
   if (ntiles <= 0 || ntiles > 0x7fffffff) return XV_ESHAPE;
@@ -578,7 +610,8 @@ int xv_launch_conv3x3_f8_dma(const void* x, const void* wpk, const float* bias, 
   a.out_mul = out_mul;
   const int grid = num_cus > 0 ? num_cus : 256;
   if (stats_rows != nullptr) {  // per-channel sums of the outputs in the epilogue: bf16 maps, at most 8 channel tiles
-    if (in_f8 || out_f8 || Cout > 512 || (grid & 7) || (grid / 8) % a.n_ct) return XV_ESHAPE;  // one channel tile per workgroup
+    // exact tilings only (a partial tile's out-of-image pixels would enter the sums); one channel tile per workgroup
+    if (in_f8 || out_f8 || Cout > 512 || !xv_conv3x3_dma4_exact(H, W) || (grid & 7) || (grid / 8) % a.n_ct) return XV_ESHAPE;
     a.stats = stats_rows;
     return g4_launch<false, false, true>(a, grid, stream);
   }

@@ -39,6 +39,7 @@ int xv_launch_conv1x1_n64(const __bf16* x, const __bf16* wpk, const float* bias,
 // conv_f8_dma.hip (generation 4: the fp8 3x3 conv with all operands by LDS-DMA, configuration 24)
 bool xv_conv3x3_f8_dma_ok(int H, int W, int Cin, int Cout);
 bool xv_conv3x3_dma4_bf16_ok(int H, int W, int Cin, int Cout);
+bool xv_conv3x3_dma4_exact(int H, int W);
 int xv_launch_conv3x3_f8_dma(const void* x, const void* wpk, const float* bias, void* y, void* pooled, int N, int H, int W,
                              int Cin, int Cout, int relu, int in_f8, int out_f8, int scale_x, float out_mul, int num_cus,
                              hipStream_t stream, float* stats_rows = nullptr);
@@ -2075,7 +2076,11 @@ int pick_cfg(const ConvArgs& a, int k) {
   if (a.in_f8 || a.out_f8) {
     // generation 4 wherever the map tiles exactly in 16x32 (XV_F8_NO_GEN4=1: first generation everywhere, A/B timing)
     static const bool no_gen4 = getenv("XV_F8_NO_GEN4") != nullptr;
-    if (k == 3 && a.in_f8 && a.out_f8 && !no_gen4 && xv_conv3x3_f8_dma_ok(a.H, a.W, a.Cin, a.Cout)) return 24;
+    // (partial tiles: only where the 16x32 tile covers the map well enough -- or where nothing else exists: 64-channel
+    // e4m3 chunks)
+    if (k == 3 && a.in_f8 && a.out_f8 && !no_gen4 && xv_conv3x3_f8_dma_ok(a.H, a.W, a.Cin, a.Cout) &&
+        (xv_conv3x3_dma4_exact(a.H, a.W) || (a.Cin & 127) || covered(16) <= 1.3 * g1))
+      return 24;
     // the bf16 conv that writes the first e4m3 map: generation 2 has no e4m3 epilogue, generation 4 does
     if (k == 3 && !a.in_f8 && a.out_f8 && !no_gen4 && xv_conv3x3_dma4_bf16_ok(a.H, a.W, a.Cin, a.Cout)) return 25;
     if (a.in_f8 && (a.Cin & 127)) return -1;  // 64-channel e4m3 chunks: generation 4 only
@@ -2118,7 +2123,8 @@ int pick_cfg(const ConvArgs& a, int k) {
     {
       static const int gen4 = getenv("XV_BF16_GEN4") != nullptr ? atoi(getenv("XV_BF16_GEN4")) : 1;
       if (gen4 && a.mask == nullptr && a.addend == nullptr && a.sk_ws == nullptr && !a.in_f8 && !a.out_f8 &&
-          xv_conv3x3_dma4_bf16_ok(a.H, a.W, a.Cin, a.Cout) && (gen4 == 2 || a.Cin >= 256 || (a.Cin == 128 && a.Cout >= 256)))
+          xv_conv3x3_dma4_bf16_ok(a.H, a.W, a.Cin, a.Cout) && xv_conv3x3_dma4_exact(a.H, a.W) &&
+          (gen4 == 2 || a.Cin >= 256 || (a.Cin == 128 && a.Cout >= 256)))
         return 25;
     }
     int g2 = 17;

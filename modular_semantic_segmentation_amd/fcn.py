@@ -21,26 +21,24 @@ ENCODER = [  # (name, cout, pool_after)   simple_fcn.py:39-67
 BN_EPS = 1e-3  # [TF1] tf.layers.batch_normalization default epsilon
 # conv_dtype='fp8' (BASELINE config "fp8 MFMA conv path"): the convs from 128 input channels up run on the block-scaled
 # e4m3 MFMA kernels; conv1_1 reads the raw fp32 input; the two 1x1 score convs read fp8 and write bf16 for the fp32
-# decoder head.  conv1_2 and conv2_1 (64 input channels) depend on the map: see fp8_plan().
+# decoder head.  conv2_1 (64 input channels) is an e4m3 conv on the generation-4 kernel, conv1_2 only with fp8_deep: see
+# fp8_plan().
 FP8_CONVS = ('conv2_2', 'conv3_1', 'conv3_2', 'conv3_3', 'conv4_1', 'conv4_2', 'conv4_3', 'conv5_1', 'conv5_2', 'conv5_3')
 # conv outputs that may be stored as e4m3, each with a calibrated scale (pools inherit their conv's scale)
 FP8_MAPS = ('conv1_1', 'conv1_2', 'conv2_1') + FP8_CONVS
 
 
-def fp8_plan(h, w, deep=False):
-    """(convs with e4m3 operands, conv outputs stored as e4m3) for an h x w input.  conv2_1 (64 input channels) joins the
-    e4m3 convs where its h/2 x w/2 map tiles exactly in 16x32 pixels -- the generation-4 kernel (csrc/conv_f8_dma.hip)
-    takes 64-channel e4m3 chunks, one tap per K = 64 MFMA; the first-generation kernel needs 128 -- and conv1_2 then
-    writes the first e4m3 map (its pooled output); elsewhere conv2_1 keeps bf16 operands and writes it.
-    deep=True (model config `fp8_deep`): on such maps conv1_2 takes e4m3 operands as well and conv1_1 writes the first
-    e4m3 map: +14 % images/s at 2048x1024, paid for in accuracy on trained experts (mIoU against the fp32 graph: depth
-    expert -2.1 points instead of -0.6, RGB -0.25 / +0.1, Bayes fusion -0.22 / -0.03: bench.py `accuracy.fp8`), hence
-    opt-in.  oracle/fcn_oracle.py states the same rules."""
-    if (h // 2) % 16 == 0 and (w // 2) % 32 == 0:
-        if deep:
-            return ('conv1_2', 'conv2_1') + FP8_CONVS, ('conv1_1', 'conv1_2', 'conv2_1') + FP8_CONVS
-        return ('conv2_1',) + FP8_CONVS, ('conv1_2', 'conv2_1') + FP8_CONVS
-    return FP8_CONVS, ('conv2_1',) + FP8_CONVS
+def fp8_plan(h=None, w=None, deep=False):
+    """(convs with e4m3 operands, conv outputs stored as e4m3).  conv2_1 (64 input channels) is an e4m3 conv too -- the
+    generation-4 kernel (csrc/conv_f8_dma.hip) takes 64-channel e4m3 chunks, one tap per K = 64 MFMA, on any map size; the
+    first-generation kernel needs 128 -- and conv1_2 writes the first e4m3 map (its pooled output).
+    deep=True (model config `fp8_deep`): conv1_2 takes e4m3 operands as well and conv1_1 writes the first e4m3 map: +14 %
+    images/s at 2048x1024, paid for in accuracy on trained experts (mIoU against the fp32 graph: depth expert -2.1 points
+    instead of -0.6, RGB -0.25 / +0.1, Bayes fusion -0.22 / -0.03: bench.py `accuracy.fp8`), hence opt-in.
+    oracle/fcn_oracle.py states the same rules.  (h, w: unused since the kernel handles partial tiles; kept for callers.)"""
+    if deep:
+        return ('conv1_2', 'conv2_1') + FP8_CONVS, ('conv1_1', 'conv1_2', 'conv2_1') + FP8_CONVS
+    return ('conv2_1',) + FP8_CONVS, ('conv1_2', 'conv2_1') + FP8_CONVS
 
 
 def variable_shapes(prefix, in_channels, num_units, num_classes, batch_normalization=False):

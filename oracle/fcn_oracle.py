@@ -11,9 +11,8 @@ be fed *the same* rounded operands:
   'fp8'   BASELINE config "fp8 MFMA conv path": as 'bf16', but the operands of conv2_2 .. conv5_3 and of the
           two 1x1 score convs are OCP e4m3fn with per-tensor power-of-two scales (`fp8_scales`: the output
           exponent of every map that is stored as fp8, 'w:<layer>' the weight exponents); conv1_1 (fp32),
-          conv1_2 and conv2_1 (64 input channels: bf16 operands) are unchanged except that conv2_1 WRITES fp8 -- unless
-          conv2_1's map tiles exactly in 16x32 pixels: then conv2_1 takes e4m3 operands too and conv1_2 writes the first
-          fp8 map (fp8_deep: conv1_2 as well, conv1_1 writing it)
+          conv1_2 (bf16 operands) are unchanged except that conv1_2 WRITES the first fp8 map; conv2_1 takes e4m3 operands
+          too (fp8_deep: conv1_2 as well, conv1_1 writing the first fp8 map)
 """
 import numpy as np
 import torch
@@ -142,15 +141,14 @@ def fcn_forward(x_nhwc, weights, prefix, policy='fp32', keep=None, fp8_scales=No
     assert policy in ('fp32', 'bf16', 'fp8')
     rnd = (lambda t: t) if policy == 'fp32' else round_bf16
     fp8_scales = fp8_scales or {}
-    # maps stored as e4m3 in the 'fp8' policy: the outputs of conv2_1 .. conv5_3 (the score convs write bf16).  Where the
-    # h/2 x w/2 map of conv2_1 tiles exactly in 16x32 pixels, conv2_1 too takes e4m3 operands and conv1_2 writes the first
-    # e4m3 map; with fp8_deep also conv1_2 takes them and conv1_1 writes it (the product's fcn.fp8_plan: its generation-4
-    # kernel takes 64-channel e4m3 chunks on exact tilings only).
+    # maps stored as e4m3 in the 'fp8' policy: the outputs of conv1_2 .. conv5_3 (the score convs write bf16); conv2_1 ..
+    # conv5_3 and the score convs take e4m3 operands.  With fp8_deep also conv1_2 takes them and conv1_1 writes the first e4m3
+    # map (the product's fcn.fp8_plan).
     fp8_layers = FP8_LAYERS
-    fp8_out = set(('conv2_1',) + FP8_LAYERS[:10]) if policy == 'fp8' else set()
-    if policy == 'fp8' and (np.shape(x_nhwc)[1] // 2) % 16 == 0 and (np.shape(x_nhwc)[2] // 2) % 32 == 0:
+    fp8_out = set()
+    if policy == 'fp8':
         fp8_layers = (('conv1_2',) if fp8_deep else ()) + ('conv2_1',) + FP8_LAYERS
-        fp8_out.update(('conv1_1', 'conv1_2') if fp8_deep else ('conv1_2',))
+        fp8_out = set(('conv1_1', 'conv1_2') if fp8_deep else ('conv1_2',)) | set(('conv2_1',) + FP8_LAYERS[:10])
 
     def rnd_out(t, name):
         return round_e4m3(t, fp8_scales[name]) if name in fp8_out else rnd(t)

@@ -53,6 +53,9 @@ CASES = [
     (3, 128, 256, 128, 128, 3, True, 24, (0, -1, 2)),     # 384 tiles on 256 workgroups: the persistent walk, tile after tile
     (2, 64, 128, 64, 128, 3, False, 24, (1, -1, 2)),      # conv2_1 of the fp8 plan: ONE 64-channel e4m3 chunk per tile
     (1, 32, 64, 64, 64, 3, True, -1, (0, 0, 1)),          # ... and the chooser must find it (no first-generation form)
+    (1, 24, 40, 256, 128, 3, True, 24, (-1, 0, 2)),       # generation 4 on partial tiles in both directions
+    (2, 6, 10, 64, 64, 3, True, 24, (0, -1, 1)),          # ... a map smaller than one tile, one 64-channel chunk
+    (1, 20, 36, 128, 192, 3, False, -1, (0, 0, 1)),
 ]
 
 
@@ -105,7 +108,8 @@ def test_fp8_conv_exact_on_integers(ops, n, h, w, cin, cout, k, pool, cfg, exps)
 
 
 def test_fp8_conv_tile_configurations_agree(ops):
-    """Configurations 14 / 15 / 16 / 19 / 20 of the fp8 kernel: bit-identical outputs; the others refuse fp8 operands."""
+    """Configurations 14 / 15 / 16 / 19 / 20 of the first-generation fp8 kernel and 24 (generation 4, here on partial tiles):
+    bit-identical outputs on integer operands; the others refuse fp8 operands."""
     from modular_semantic_segmentation_amd import _lib
     rng = np.random.default_rng(5)
     n, h, w, cin, cout = 2, 24, 40, 256, 128
@@ -120,12 +124,12 @@ def test_fp8_conv_tile_configurations_agree(ops):
         try:
             ops.conv2d_fwd(xa, wp, _dev(b), 3, relu=True, y=y, cfg=cfg)
         except _lib.XvError:
-            assert cfg not in (14, 15, 16, 19, 20)
+            assert cfg not in (14, 15, 16, 19, 20, 24)
             continue
         torch.cuda.synchronize()
         outs[cfg] = y.t.view(torch.uint8).clone()
-    assert sorted(outs) == [14, 15, 16, 19, 20]
-    assert all(torch.equal(outs[14], outs[c]) for c in (15, 16, 19, 20))
+    assert sorted(outs) == [14, 15, 16, 19, 20, 24]
+    assert all(torch.equal(outs[14], outs[c]) for c in (15, 16, 19, 20, 24))
 
 
 @pytest.mark.parametrize('cfg', [-1, 4, 10, 14, 16, 25])
@@ -192,7 +196,7 @@ def _weights(prefix, cin, seed, scale_first):
     return w
 
 
-@pytest.mark.parametrize('h,w,deep', [(64, 96, False), (384, 768, False), (384, 768, True)])
+@pytest.mark.parametrize('h,w,deep', [(64, 96, False), (64, 96, True), (384, 768, False), (384, 768, True)])
 def test_fp8_engine_against_fp8_policy_oracle(ops, h, w, deep):
     """The whole expert with conv_dtype='fp8' against the oracle that quantises at the same points with the same
     scales (the engine's own calibration).  Layer by layer the two differ only where fp32 accumulation order moves a
@@ -220,11 +224,10 @@ def test_fp8_engine_against_fp8_policy_oracle(ops, h, w, deep):
     # e4m3 rounding boundary, by one grid step.
     from modular_semantic_segmentation_amd.fcn import ENCODER, fp8_plan
     convs8, maps8 = fp8_plan(h, w, deep)
-    # 64x96: conv2_1's 32x48 map does not tile in 16x32 -> bf16 operands, it writes the first e4m3 map (first-generation
-    # kernels throughout); 384x768: conv2_1 takes 64-channel e4m3 chunks on the generation-4 kernel, conv1_2 writes e4m3;
+    # conv2_1 takes 64-channel e4m3 chunks on the generation-4 kernel (64x96: on partial tiles), conv1_2 writes e4m3;
     # deep: conv1_2 too, conv1_1 writes e4m3
-    assert ('conv2_1' in convs8) == (h == 384) and ('conv1_2' in convs8) == deep and ('conv1_1' in maps8) == deep
-    assert L['pool1'].dtype == ('fp8' if h == 384 else 'bf16') and L['conv1_1'].dtype == ('fp8' if deep else 'bf16')
+    assert 'conv2_1' in convs8 and ('conv1_2' in convs8) == deep and ('conv1_1' in maps8) == deep
+    assert L['pool1'].dtype == 'fp8' and L['conv1_1'].dtype == ('fp8' if deep else 'bf16')
     prev = None
     for name, cout, pool in ENCODER:
         if name in convs8:

@@ -405,26 +405,25 @@ def test_dense_deconv_index_maps_are_the_kernel_map_and_its_adjoint(k, s):
 
 
 def test_fp8_plan_and_the_oracle_policy_agree():
-    """fcn.fp8_plan (which convs take e4m3 operands, which maps are stored as e4m3, by input size and `deep`) against the
+    """fcn.fp8_plan (which convs take e4m3 operands, which maps are stored as e4m3, by `deep`) against the
     oracle's restatement of the rule: the oracle's 'fp8' policy must quantise exactly the maps the plan names."""
     from modular_semantic_segmentation_amd.fcn import FP8_CONVS, fp8_plan, init_variables
     from oracle import fcn_oracle as fo
-    assert fp8_plan(64, 96) == (FP8_CONVS, ('conv2_1',) + FP8_CONVS)                      # 32x48 does not tile in 16x32
-    assert fp8_plan(64, 96, deep=True) == fp8_plan(64, 96)
-    convs, maps = fp8_plan(384, 768)
-    assert convs == ('conv2_1',) + FP8_CONVS and maps == ('conv1_2', 'conv2_1') + FP8_CONVS
-    convs, maps = fp8_plan(1024, 2048, deep=True)
-    assert convs == ('conv1_2', 'conv2_1') + FP8_CONVS and maps == ('conv1_1', 'conv1_2', 'conv2_1') + FP8_CONVS
-    # the oracle on a 32x64 image (conv2_1's 16x32 map tiles): a map is on the e4m3 grid of its scale iff the plan stores it
+    for hw in ((64, 96), (384, 768), (1024, 2048)):             # the same plan on every map size (partial tiles are handled)
+        convs, maps = fp8_plan(*hw)
+        assert convs == ('conv2_1',) + FP8_CONVS and maps == ('conv1_2', 'conv2_1') + FP8_CONVS
+        convs, maps = fp8_plan(*hw, deep=True)
+        assert convs == ('conv1_2', 'conv2_1') + FP8_CONVS and maps == ('conv1_1', 'conv1_2', 'conv2_1') + FP8_CONVS
+    # the oracle on a 32x48 image (partial tiles): a map is on the e4m3 grid of its scale iff the plan stores it
     wts = init_variables('rgb', 3, 64, 12, seed=4)
-    x = np.random.default_rng(0).integers(0, 256, (1, 32, 64, 3)).astype(np.float32)
+    x = np.random.default_rng(0).integers(0, 256, (1, 32, 48, 3)).astype(np.float32)
     names = ['conv1_1', 'conv1_2', 'conv2_1', 'conv2_2']
     allmaps = ('conv1_1', 'conv1_2', 'conv2_1') + FP8_CONVS
     plain = fo.fcn_forward(x, wts, 'rgb', 'bf16', keep=allmaps)
     scales = {n: fo.fp8_scale_exp(np.abs(plain[n]).max(), 1) for n in allmaps}
     for deep in (False, True):
         out = fo.fcn_forward(x, wts, 'rgb', 'fp8', keep=names, fp8_scales=scales, fp8_deep=deep)
-        _, maps = fp8_plan(32, 64, deep)
+        _, maps = fp8_plan(32, 48, deep)
         for n in names:
             on_grid = np.array_equal(out[n], fo.round_e4m3(out[n], scales[n]))
             assert on_grid == (n in maps), (deep, n)
