@@ -64,7 +64,9 @@ const char* xv_source_hash(void);
  * s ^ ((co >> 1) & 2); and a third for the generation-4 kernel (conv_f8_dma.hip, 32x32 MFMA blocks): the same
  * [tap][cin/32][row][32] with slot s of row r at s ^ ((r >> 2) & 3) and the rows of every 32-row block permuted
  * (row 8g + 4h + q = channel 16h + 4g + q, so that a lane's 16 accumulator registers are 16 consecutive output
- * channels).  xv_packed_weight_bytes is the size of all three.
+ * channels); and a fourth for the same kernel on 16x16x32 MFMA blocks (configuration 26): slot s of row r at
+ * s ^ ((r >> 1) & 2), the rows of every 64-row block permuted (row 16j + 4g + q = channel 16g + 4j + q).
+ * xv_packed_weight_bytes is the size of all four.
  * k = 1 or 3, cin % 64 == 0, cout % 64 == 0.                                                       */
 size_t xv_packed_weight_bytes(int k, int cin, int cout);
 int xv_pack_conv_weights(const float* w_hwio, void* packed, int k, int cin, int cout, void* stream);

@@ -55,6 +55,10 @@ struct F8Args {
   float* stats;   // STATS: [gridDim.x][2 Cout] per-workgroup sums / sums of squares of the stored outputs
 };
 
+#ifdef XV_CLOCK_STAMP
+__device__ unsigned long long xv_clk_g4[4 * XV_CLK_SLOTS];
+#endif
+
 struct G4 {
   static constexpr int NWAVES = 8, NT = 512;
   static constexpr int TH = 16, TW = 32, HH = TH + 2, HW = TW + 2, NPIX = HH * HW;
@@ -73,6 +77,14 @@ struct G4 {
 };
 
 __device__ __forceinline__ int g4_swz(int row, int slot) { return slot ^ ((row >> 2) & 3); }
+// the 16x16x32 form (M16): lane l reads row l & 15 (+ dx), logical slot l >> 4; slot s of row r sits at physical slot
+// s ^ ((r >> 1) & 2) -- every 16-lane group of a ds_read_b128 then covers the 64 banks once for every column offset 0..18
+// (tools/lds_swizzle_search.py --m16: brute force over the linear maps of the row bits)
+__device__ __forceinline__ int g4_swz16(int row, int slot) { return slot ^ ((row >> 1) & 2); }
+template <bool M16>
+__device__ __forceinline__ int g4_swz_t(int row, int slot) {
+  return M16 ? g4_swz16(row, slot) : g4_swz(row, slot);
+}
 
 // four fp32 -> four e4m3 bytes (round-to-nearest-even) of value * mul, saturating (as conv_mfma.hip pack_fp8x4)
 __device__ __forceinline__ uint32_t g4_pack_fp8x4(float v0, float v1, float v2, float v3, float mul) {
@@ -97,15 +109,24 @@ __device__ __forceinline__ float g4_dpp_swap1(float v) {  // value of lane ^ 1 (
 // end (xv_bn_sums_from_rows adds the rows in a fixed tree): the statistics pass over the map (xv_bn_stats) disappears.
 // EDGE: partial tiles possible (clamped DMA offsets, predicated stores); maps that tile exactly run the form without that
 // code (it cost 3-5 % on the one- and two-chunk layers)
-template <bool F8, bool OF8 = F8, bool STATS = false, bool EDGE = false>
+// M16 (bf16 operands only, configuration 26): the same item loop on v_mfma_f32_16x16x32_bf16 at the SAME output tile per
+// wave (2 rows x 32 columns x 64 channels = 4 pixel blocks x 4 channel blocks of 16x16, again 64 accumulator registers): a
+// tap is 16 MFMAs of K = 32 = the whole 32-channel chunk instead of 4 x 2 of K = 16 -- the same matrix-pipe cycles, the same
+// ds_read_b128 count (4 weight + 8/3 pixel reads per tap) and the same fragment registers.  The chip holds a higher clock
+// on this shape (MI355X_MICROARCH.md, DVFS give-back item 7: 1.12-1.15x the FLOP/s of the 32x32x16 loop on random data at
+// equal cycles).  Lane l = (column n15 = l & 15, k-group / channel group g = l >> 4); weight rows permuted so that the 16
+// accumulator registers of a lane and pixel block are channels 16 g .. 16 g + 15 (row 16 j + 4 g + q = channel 16 g + 4 j + q);
+// fragment j (pixel half h) of a row pair sits 1 KB behind fragment 0, so one base register serves a whole set.
+template <bool F8, bool OF8 = F8, bool STATS = false, bool EDGE = false, bool M16 = false>
 __global__ __launch_bounds__(512, 2) void conv_dma4_kernel(F8Args a) {
   using C = G4;
+  static_assert(!(M16 && F8), "the 16x16 form is a bf16 kernel");
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int n31 = lane & 31, hh = lane >> 5;
+  const int n31 = M16 ? (lane & 15) : (lane & 31), hh = M16 ? (lane >> 4) : (lane >> 5);  // M16: column n15, group g
   const int H = a.H, W = a.W, Cin = a.Cin, Cout = a.Cout;
   const int Wp = W + 2;
   const int Cb = F8 ? Cin : 2 * Cin, Ob = OF8 ? Cout : 2 * Cout;  // bytes per pixel of the input / output maps
@@ -116,7 +137,8 @@ __global__ __launch_bounds__(512, 2) void conv_dma4_kernel(F8Args a) {
     scale_w = __builtin_amdgcn_readfirstlane(scale_w);
   }
   // generation-4 image: fp8 -- behind the header and the generation-1 image; bf16 -- the third image of the packed buffer
-  const char* const wimg = F8 ? a.wpk + 256 + (int64_t)9 * Cin * Cout : a.wpk + (int64_t)4 * 9 * Cin * Cout;
+  // (M16: the fourth)
+  const char* const wimg = F8 ? a.wpk + 256 + (int64_t)9 * Cin * Cout : a.wpk + (int64_t)(M16 ? 6 : 4) * 9 * Cin * Cout;
 
   // persistent workgroups, XCD-contiguous tile ranges, the output-channel tiles of one patch adjacent (as generation 2)
   const int G = gridDim.x, b = blockIdx.x;
@@ -158,21 +180,24 @@ __global__ __launch_bounds__(512, 2) void conv_dma4_kernel(F8Args a) {
     int p = g >> 2;
     p = p < C::NPIX ? p : C::NPIX - 1;
     const int hy = p / C::HW, hx = p - hy * C::HW;
-    aoff[it] = (hy * Wp + hx) * Cb + (g4_swz(hx, g & 3) << 4);
+    aoff[it] = (hy * Wp + hx) * Cb + (g4_swz_t<M16>(hx, g & 3) << 4);
   }
   // LDS fragment addresses: pixel column n31 + dx of patch row 2 * wave, weight row n31 of a 32-row block.  The lane's two
   // 16-byte slots -- fp8: 2 hh and 2 hh + 1 (its 32-byte half of the K = 64 instruction); bf16: hh and 2 + hh (k-group hh
   // of the two K = 16 steps) -- sit at swizzled positions, so each has its own base
-  const int s0 = F8 ? 2 * hh : hh, s1 = F8 ? 2 * hh + 1 : 2 + hh;
+  // M16: ONE slot per lane (k-group g of the K = 32 step); the second fragment of a pair is the next 16 rows / columns,
+  // 1 KB further on (same swizzle: bit 2 of the row does not change), so the "second base" is the first
+  const int s0 = M16 ? hh : (F8 ? 2 * hh : hh), s1 = M16 ? hh : (F8 ? 2 * hh + 1 : 2 + hh);
+  constexpr int F1 = M16 ? 1024 : 0;  // byte offset of a pair's second fragment behind its (second) base
   int pbase0[3], pbase1[3], wbase0, wbase1;
 #pragma unroll
   for (int dx = 0; dx < 3; ++dx) {
     const int hx = n31 + dx;
-    pbase0[dx] = ((2 * wave) * C::HW + hx) * 64 + (g4_swz(hx, s0) << 4);
-    pbase1[dx] = ((2 * wave) * C::HW + hx) * 64 + (g4_swz(hx, s1) << 4);
+    pbase0[dx] = ((2 * wave) * C::HW + hx) * 64 + (g4_swz_t<M16>(hx, s0) << 4);
+    pbase1[dx] = ((2 * wave) * C::HW + hx) * 64 + (g4_swz_t<M16>(hx, s1) << 4);
   }
-  wbase0 = 2 * C::A_BYTES + n31 * 64 + (g4_swz(n31, s0) << 4);
-  wbase1 = 2 * C::A_BYTES + n31 * 64 + (g4_swz(n31, s1) << 4);
+  wbase0 = 2 * C::A_BYTES + n31 * 64 + (g4_swz_t<M16>(n31, s0) << 4);
+  wbase1 = 2 * C::A_BYTES + n31 * 64 + (g4_swz_t<M16>(n31, s1) << 4);
   const int64_t tap_pitch = (int64_t)nchunks * Cout * 64;  // bytes between taps of the packed image
 
   // LDS-DMA in assembly (SGPR base + 32-bit VGPR offset; M0 = the wave's LDS destination), as generation 2
@@ -197,7 +222,7 @@ __global__ __launch_bounds__(512, 2) void conv_dma4_kernel(F8Args a) {
         int p = g >> 2;
         p = p < C::NPIX ? p : C::NPIX - 1;
         const int hy = p / C::HW, hx = p - hy * C::HW;
-        voff = ((hy < ylim ? hy : ylim) * Wp + (hx < xlim ? hx : xlim)) * Cb + (g4_swz(hx, g & 3) << 4);
+        voff = ((hy < ylim ? hy : ylim) * Wp + (hx < xlim ? hx : xlim)) * Cb + (g4_swz_t<M16>(hx, g & 3) << 4);
       }
       dma16(xsrc, voff, buf * C::A_BYTES + piece * 1024);
     }
@@ -235,6 +260,16 @@ __global__ __launch_bounds__(512, 2) void conv_dma4_kernel(F8Args a) {
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  // M16: acc4[row i][channel pair j][pixel half h][jj] = the 16x16 block (row i, columns 16 h .., channel block 2 j + jj)
+  f32x4 acc4[2][2][2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) acc4[i][j][h][jj] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   // 16-byte store instructions per tile and wave
   float ssum[2][16], ssq[2][16];  // STATS only
@@ -251,6 +286,7 @@ __global__ __launch_bounds__(512, 2) void conv_dma4_kernel(F8Args a) {
   const int nstores = ((a.y != nullptr ? 4 : 0) + (a.pooled != nullptr ? 2 : 0)) * (OF8 ? 1 : 2);
   int in_flight = 0;  // stores issued after the last DMA of the previous item
 
+  XV_CLK_BEGIN()
   while (true) {
     // This item's operands have landed (each wave retires its own DMA; the tile stores issued after it may stay in
     // flight: vmcnt counts in issue order), and every wave has finished reading the other buffer pair.
@@ -283,23 +319,23 @@ __global__ __launch_bounds__(512, 2) void conv_dma4_kernel(F8Args a) {
   {                                                   \
     constexpr int tap_ = (((t) % 3) * 3 + (t) / 3) * 4096; \
     G4_RD(wf[set][0][0], wb0, tap_);                  \
-    G4_RD(wf[set][0][1], wb1, tap_);                  \
+    G4_RD(wf[set][0][1], wb1, tap_ + F1);             \
     G4_RD(wf[set][1][0], wb0, tap_ + 2048);           \
-    G4_RD(wf[set][1][1], wb1, tap_ + 2048);           \
+    G4_RD(wf[set][1][1], wb1, tap_ + 2048 + F1);      \
   }
 #define G4_LDPA(dx, set)                         \
   {                                              \
     G4_RD(xf[set][0][0], pb0[dx], 0);            \
-    G4_RD(xf[set][0][1], pb1[dx], 0);            \
+    G4_RD(xf[set][0][1], pb1[dx], F1);           \
     G4_RD(xf[set][1][0], pb0[dx], C::PROW);      \
-    G4_RD(xf[set][1][1], pb1[dx], C::PROW);      \
+    G4_RD(xf[set][1][1], pb1[dx], C::PROW + F1); \
   }
 #define G4_LDPB(dx, set)                         \
   {                                              \
-    G4_RD(xf[set][2][0], pb0[dx], 2 * C::PROW);  \
-    G4_RD(xf[set][2][1], pb1[dx], 2 * C::PROW);  \
-    G4_RD(xf[set][3][0], pb0[dx], 3 * C::PROW);  \
-    G4_RD(xf[set][3][1], pb1[dx], 3 * C::PROW);  \
+    G4_RD(xf[set][2][0], pb0[dx], 2 * C::PROW);       \
+    G4_RD(xf[set][2][1], pb1[dx], 2 * C::PROW + F1);  \
+    G4_RD(xf[set][3][0], pb0[dx], 3 * C::PROW);       \
+    G4_RD(xf[set][3][1], pb1[dx], 3 * C::PROW + F1);  \
   }
     // at most n newer reads outstanding: wf[ws] (and rows 0-1 / rows 2-3 of xf[ps]) have landed.  Every wait names exactly
     // the registers it releases: the MFMAs that consume them cannot move above it, and no register with a read still in
@@ -322,6 +358,16 @@ __global__ __launch_bounds__(512, 2) void conv_dma4_kernel(F8Args a) {
     acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(G4_CAT(wf[ws][j][0], wf[ws][j][1]),                    \
                                                                 G4_CAT(xf[ps][(i) + (dy)][0], xf[ps][(i) + (dy)][1]),  \
                                                                 acc[i][j], 0, 0, 0, scale_w, 0, a.scale_x);            \
+  } else if constexpr (M16) {                                                                                          \
+    /* wf[ws][j][jj]: channel block 2 j + jj; xf[ps][row][h]: pixel half h */                                          \
+    acc4[i][j][0][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[ws][j][0]),               \
+                                                               __builtin_bit_cast(bf16x8, xf[ps][(i) + (dy)][0]), acc4[i][j][0][0], 0, 0, 0); \
+    acc4[i][j][0][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[ws][j][1]),               \
+                                                               __builtin_bit_cast(bf16x8, xf[ps][(i) + (dy)][0]), acc4[i][j][0][1], 0, 0, 0); \
+    acc4[i][j][1][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[ws][j][0]),               \
+                                                               __builtin_bit_cast(bf16x8, xf[ps][(i) + (dy)][1]), acc4[i][j][1][0], 0, 0, 0); \
+    acc4[i][j][1][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[ws][j][1]),               \
+                                                               __builtin_bit_cast(bf16x8, xf[ps][(i) + (dy)][1]), acc4[i][j][1][1], 0, 0, 0); \
   } else {                                                                                                             \
     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf[ws][j][0]),                      \
                                                         __builtin_bit_cast(bf16x8, xf[ps][(i) + (dy)][0]), acc[i][j], 0, 0, 0); \
@@ -341,7 +387,11 @@ __global__ __launch_bounds__(512, 2) void conv_dma4_kernel(F8Args a) {
     // changes around it, and left alone the MFMAs of several taps sink into one cluster behind them (seen in the ISA: the
     // priority pairs back to back with nothing between).  An empty volatile asm that "modifies" an accumulator pins the
     // MFMA that produced it in front of every later asm statement.
-#define G4_PIN(i, j) asm volatile("" : "+v"(acc[i][j]))
+#define G4_PIN(i, j)                                                                                                  \
+  if constexpr (M16)                                                                                                  \
+    asm volatile("" : "+v"(acc4[i][j][0][0]), "+v"(acc4[i][j][0][1]), "+v"(acc4[i][j][1][0]), "+v"(acc4[i][j][1][1])); \
+  else                                                                                                                \
+    asm volatile("" : "+v"(acc[i][j]))
 #define G4_TAP(t, WAIT, NEWER, POST)                              \
   {                                                               \
     constexpr int dx_ = (t) / 3, dy_ = (t) % 3;                   \
@@ -396,14 +446,17 @@ __global__ __launch_bounds__(512, 2) void conv_dma4_kernel(F8Args a) {
     if (last_chunk) {
       // ---- tile epilogue: bias, relu, e4m3; one 16-byte store per (row, channel block) and the fused 2x2 max-pool ----
       const float* bl = reinterpret_cast<const float*>(smem + C::BIAS_OFF + bslot * 256);
-      const int px = cur.x0 + n31;
       const int py = cur.y0 + 2 * wave;
+      // 32x32 form: u = channel block j (the lane's 16 channels 32 j + 16 hh .., one pixel column n31);
+      // 16x16 form: u = pixel half h (column 16 h + n15, the lane's 16 channels 16 g ..)
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
+      for (int u = 0; u < 2; ++u) {
+        const int cl = M16 ? 16 * hh : 32 * u + 16 * hh;  // first of this lane's 16 consecutive channels within the tile
+        const int px = cur.x0 + (M16 ? 16 * u + n31 : n31);
         float bv[16];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          const f32x4 t4 = *reinterpret_cast<const f32x4*>(bl + 32 * j + 16 * hh + 4 * q);
+          const f32x4 t4 = *reinterpret_cast<const f32x4*>(bl + cl + 4 * q);
           bv[4 * q] = t4.x, bv[4 * q + 1] = t4.y, bv[4 * q + 2] = t4.z, bv[4 * q + 3] = t4.w;
         }
         float v[2][16];
@@ -411,34 +464,41 @@ __global__ __launch_bounds__(512, 2) void conv_dma4_kernel(F8Args a) {
         for (int i = 0; i < 2; ++i)
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
-            const float s = acc[i][j][r] + bv[r];
+            float s;
+            if constexpr (M16) {  // r = 4 (2 j + jj) + q
+              s = acc4[i][r >> 3][u][(r >> 2) & 1][r & 3] + bv[r];
+              acc4[i][r >> 3][u][(r >> 2) & 1][r & 3] = 0.f;
+            } else {
+              s = acc[i][u][r] + bv[r];
+              acc[i][u][r] = 0.f;
+            }
             v[i][r] = a.relu ? fmaxf(s, 0.f) : s;
-            acc[i][j][r] = 0.f;
           }
         if constexpr (STATS) {
           // per lane and channel: sums of the two rows' STORED (bf16) values and of their squares, kept in registers over all
           // the workgroup's tiles (every tile of a workgroup has the same output-channel tile: the launcher checks
           // nb % n_ct == 0); lanes, waves and workgroups meet after the last tile
+          // (M16: both pixel halves are the same 16 channels: one row of sums)
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const uint32_t pk = pack_bf16x2(v[0][r], v[1][r]);
             const float a0 = __builtin_bit_cast(float, pk << 16), a1 = __builtin_bit_cast(float, pk & 0xffff0000u);
-            ssum[j][r] += a0 + a1;
-            ssq[j][r] = fmaf(a0, a0, fmaf(a1, a1, ssq[j][r]));
+            ssum[M16 ? 0 : u][r] += a0 + a1;
+            ssq[M16 ? 0 : u][r] = fmaf(a0, a0, fmaf(a1, a1, ssq[M16 ? 0 : u][r]));
           }
         }
-        const int cofs = cur.co0 + 32 * j + 16 * hh;  // first of this lane's 16 consecutive channels
+        const int cofs = cur.co0 + cl;
         // 16 values -> 16 bytes of e4m3, or 32 bytes of bf16 (round-to-nearest-even, as every other epilogue)
-        auto store16 = [&](char* dst, const float (&u)[16], bool on) {
+        auto store16 = [&](char* dst, const float (&w)[16], bool on) {
           if constexpr (OF8) {
-            const u32x4 o = {g4_pack_fp8x4(u[0], u[1], u[2], u[3], a.out_mul), g4_pack_fp8x4(u[4], u[5], u[6], u[7], a.out_mul),
-                             g4_pack_fp8x4(u[8], u[9], u[10], u[11], a.out_mul),
-                             g4_pack_fp8x4(u[12], u[13], u[14], u[15], a.out_mul)};
+            const u32x4 o = {g4_pack_fp8x4(w[0], w[1], w[2], w[3], a.out_mul), g4_pack_fp8x4(w[4], w[5], w[6], w[7], a.out_mul),
+                             g4_pack_fp8x4(w[8], w[9], w[10], w[11], a.out_mul),
+                             g4_pack_fp8x4(w[12], w[13], w[14], w[15], a.out_mul)};
             if (on) *reinterpret_cast<u32x4*>(dst) = o;
           } else {
-            const u32x4 o0 = {pack_bf16x2(u[0], u[1]), pack_bf16x2(u[2], u[3]), pack_bf16x2(u[4], u[5]), pack_bf16x2(u[6], u[7])};
-            const u32x4 o1 = {pack_bf16x2(u[8], u[9]), pack_bf16x2(u[10], u[11]), pack_bf16x2(u[12], u[13]),
-                              pack_bf16x2(u[14], u[15])};
+            const u32x4 o0 = {pack_bf16x2(w[0], w[1]), pack_bf16x2(w[2], w[3]), pack_bf16x2(w[4], w[5]), pack_bf16x2(w[6], w[7])};
+            const u32x4 o1 = {pack_bf16x2(w[8], w[9]), pack_bf16x2(w[10], w[11]), pack_bf16x2(w[12], w[13]),
+                              pack_bf16x2(w[14], w[15])};
             if (on) {
               *reinterpret_cast<u32x4*>(dst) = o0;
               *reinterpret_cast<u32x4*>(dst + 16) = o1;
@@ -475,6 +535,7 @@ __global__ __launch_bounds__(512, 2) void conv_dma4_kernel(F8Args a) {
     chunk = nchunk;
     buf ^= 1;
   }
+  XV_CLK_END(xv_clk_g4)
   if constexpr (STATS) {
     // half-wave sums by DPP (row_shr 1, 2, 4, 8 inside each 16-lane row, row_bcast15 into the odd rows: lanes 31 / 63 hold
     // the totals), each wave's totals to its own LDS row, the 8 rows added in wave order (a fixed tree: reproducible bits),
@@ -496,11 +557,18 @@ __global__ __launch_bounds__(512, 2) void conv_dma4_kernel(F8Args a) {
         G4_DPP_ADD(sq, 0x114, 0xf);
         G4_DPP_ADD(su, 0x118, 0xf);
         G4_DPP_ADD(sq, 0x118, 0xf);
-        G4_DPP_ADD(su, 0x142, 0xa);
-        G4_DPP_ADD(sq, 0x142, 0xa);
-        if (n31 == 31) {
-          st[wave * 128 + 32 * j + 16 * hh + r] = su;
-          st[wave * 128 + 64 + 32 * j + 16 * hh + r] = sq;
+        if constexpr (M16) {  // lane 15 of each 16-lane row holds the total of the row's 16 channels-of-group-g sums
+          if (j == 0 && n31 == 15) {
+            st[wave * 128 + 16 * hh + r] = su;
+            st[wave * 128 + 64 + 16 * hh + r] = sq;
+          }
+        } else {
+          G4_DPP_ADD(su, 0x142, 0xa);
+          G4_DPP_ADD(sq, 0x142, 0xa);
+          if (n31 == 31) {
+            st[wave * 128 + 32 * j + 16 * hh + r] = su;
+            st[wave * 128 + 64 + 32 * j + 16 * hh + r] = sq;
+          }
         }
       }
 #undef G4_DPP_ADD
@@ -568,29 +636,30 @@ bool xv_conv3x3_dma4_bf16_ok(int H, int W, int Cin, int Cout) {
 bool xv_conv3x3_dma4_exact(int H, int W) { return (H & 15) == 0 && (W & 31) == 0; }
 
 namespace {
-template <bool F8, bool OF8, bool STATS, bool EDGE>
+template <bool F8, bool OF8, bool STATS, bool EDGE, bool M16>
 int g4_launch1(const F8Args& a, int grid, hipStream_t stream) {
   constexpr int lds = STATS ? G4::LDS_BYTES_STATS : G4::LDS_BYTES;
   static bool attr_set[XV_MAX_DEVICES] = {false};
-  const hipError_t e = xv_allow_dynamic_lds(reinterpret_cast<const void*>(&conv_dma4_kernel<F8, OF8, STATS, EDGE>), lds, attr_set);
+  const hipError_t e =
+      xv_allow_dynamic_lds(reinterpret_cast<const void*>(&conv_dma4_kernel<F8, OF8, STATS, EDGE, M16>), lds, attr_set);
   if (e != hipSuccess) return (int)e;
-  hipLaunchKernelGGL((conv_dma4_kernel<F8, OF8, STATS, EDGE>), dim3((unsigned)grid), dim3(G4::NT), lds, stream, a);
+  hipLaunchKernelGGL((conv_dma4_kernel<F8, OF8, STATS, EDGE, M16>), dim3((unsigned)grid), dim3(G4::NT), lds, stream, a);
   return xv_launch_status();
 }
-template <bool F8, bool OF8, bool STATS = false>
+template <bool F8, bool OF8, bool STATS = false, bool M16 = false>
 int g4_launch(const F8Args& a, int grid, hipStream_t stream) {
-  if (STATS || xv_conv3x3_dma4_exact(a.H, a.W)) return g4_launch1<F8, OF8, STATS, false>(a, grid, stream);
-  return g4_launch1<F8, OF8, false, true>(a, grid, stream);
+  if (STATS || xv_conv3x3_dma4_exact(a.H, a.W)) return g4_launch1<F8, OF8, STATS, false, M16>(a, grid, stream);
+  return g4_launch1<F8, OF8, false, true, M16>(a, grid, stream);
 }
 }  // namespace
 
 // in_f8 / out_f8: e4m3 input (map and weights) / output maps: (1, 1) = configuration 24; (0, 0) and (0, 1) = configuration
-// 25.  scale_x / out_mul as in ConvArgs.
+// 25, or 26 with m16 (the bf16 kernel on v_mfma_f32_16x16x32_bf16).  scale_x / out_mul as in ConvArgs.
 int xv_launch_conv3x3_f8_dma(const void* x, const void* wpk, const float* bias, void* y, void* pooled, int N, int H, int W,
                              int Cin, int Cout, int relu, int in_f8, int out_f8, int scale_x, float out_mul, int num_cus,
-                             hipStream_t stream, float* stats_rows) {
+                             hipStream_t stream, float* stats_rows, int m16) {
   if (!(in_f8 ? xv_conv3x3_f8_dma_ok(H, W, Cin, Cout) : xv_conv3x3_dma4_bf16_ok(H, W, Cin, Cout)) ||
-      (y == nullptr && pooled == nullptr) || (in_f8 && !out_f8))
+      (y == nullptr && pooled == nullptr) || (in_f8 && !out_f8) || (in_f8 && m16))
     return XV_ESHAPE;
   F8Args a{};
   a.x = (const char*)x;
@@ -613,9 +682,10 @@ int xv_launch_conv3x3_f8_dma(const void* x, const void* wpk, const float* bias, 
     // exact tilings only (a partial tile's out-of-image pixels would enter the sums); one channel tile per workgroup
     if (in_f8 || out_f8 || Cout > 512 || !xv_conv3x3_dma4_exact(H, W) || (grid & 7) || (grid / 8) % a.n_ct) return XV_ESHAPE;
     a.stats = stats_rows;
-    return g4_launch<false, false, true>(a, grid, stream);
+    return m16 ? g4_launch<false, false, true, true>(a, grid, stream) : g4_launch<false, false, true>(a, grid, stream);
   }
   if (in_f8) return g4_launch<true, true>(a, grid, stream);
+  if (m16) return out_f8 ? g4_launch<false, true, false, true>(a, grid, stream) : g4_launch<false, false, false, true>(a, grid, stream);
   return out_f8 ? g4_launch<false, true>(a, grid, stream) : g4_launch<false, false>(a, grid, stream);
 }
 
@@ -625,3 +695,12 @@ void xv_launch_pack_weights_f8_g4(const float* w, char* out, int taps, int cin, 
   const int blocks = (int)((total4 + 255) / 256 < 4096 ? (total4 + 255) / 256 : 4096);
   hipLaunchKernelGGL(pack_weights_f8_g4_kernel, dim3(blocks), dim3(256), 0, stream, w, out, taps, cin, cout, mul);
 }
+
+#ifdef XV_CLOCK_STAMP
+// [workgroup][s_memtime before, s_memrealtime before, s_memtime after, s_memrealtime after] of the last generation-4 launch
+extern "C" int xv_debug_read_clock_g4(void* dst, size_t bytes) { return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(xv_clk_g4), bytes); }
+extern "C" int xv_debug_reset_clock_g4(void) {
+  static unsigned long long zeros[4 * XV_CLK_SLOTS];
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(xv_clk_g4), zeros, sizeof(zeros));
+}
+#endif

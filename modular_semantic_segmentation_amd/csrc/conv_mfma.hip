@@ -42,7 +42,7 @@ bool xv_conv3x3_dma4_bf16_ok(int H, int W, int Cin, int Cout);
 bool xv_conv3x3_dma4_exact(int H, int W);
 int xv_launch_conv3x3_f8_dma(const void* x, const void* wpk, const float* bias, void* y, void* pooled, int N, int H, int W,
                              int Cin, int Cout, int relu, int in_f8, int out_f8, int scale_x, float out_mul, int num_cus,
-                             hipStream_t stream, float* stats_rows = nullptr);
+                             hipStream_t stream, float* stats_rows = nullptr, int m16 = 0);
 void xv_launch_pack_weights_f8_g4(const float* w, char* out, int taps, int cin, int cout, float mul, hipStream_t stream);
 
 namespace {
@@ -817,6 +817,10 @@ struct DmaCfg {
   static_assert(LDS_BYTES <= 160 * 1024, "does not fit the LDS");
 };
 
+#ifdef XV_CLOCK_STAMP
+__device__ unsigned long long xv_clk_g2[4 * XV_CLK_SLOTS];
+#endif
+
 #ifdef XV_CONV_TRACE
 // debug build only (tools/conv_trace.py): per work item four cycle stamps of wave 0 of every 32nd workgroup, kept in
 // spare LDS during the kernel (a global store per stamp would sit in the vmcnt queue this kernel counts on)
@@ -1043,6 +1047,7 @@ __global__ __launch_bounds__(64 * WR * WC, 2) void conv_dma_kernel(ConvArgs a) {
   int trace_item = 0;
 #endif
 
+  XV_CLK_BEGIN()
   while (true) {
     XV_STAMP(0)  // arrival at the item barrier
     // This item's operands have landed (each wave retires its own DMA; stores issued after it may stay in flight:
@@ -1332,6 +1337,7 @@ __global__ __launch_bounds__(64 * WR * WC, 2) void conv_dma_kernel(ConvArgs a) {
     buf ^= 1;
     ++items_done;
   }
+  XV_CLK_END(xv_clk_g2)
 #ifdef XV_CONV_TRACE
   __syncthreads();
   if (wave == 0 && (blockIdx.x & 31) == 0)
@@ -1836,6 +1842,11 @@ __device__ __forceinline__ void pack_weights_image(const float* __restrict__ w, 
     const int m = co & 31;  // here `co` is the ROW index rho
     const int ch = (co & ~31) + 16 * ((m >> 2) & 1) + 4 * (m >> 3) + (m & 3);
     out[2 * total + idx] = (__bf16)wl(tap, chunk * 32 + (ps ^ ((co >> 2) & 3)) * 8 + e, ch);
+    // image 4 (generation 4 on 16x16x32 MFMA blocks, configuration 26): rows permuted inside every 64-row block (row
+    // 16 j + 4 g + q = channel 16 g + 4 j + q: an involution), slots swizzled by (rho >> 1) & 2
+    const int m6 = co & 63;
+    const int ch16 = (co & ~63) + 16 * ((m6 >> 2) & 3) + 4 * (m6 >> 4) + (m6 & 3);
+    out[3 * total + idx] = (__bf16)wl(tap, chunk * 32 + (ps ^ ((co >> 1) & 2)) * 8 + e, ch16);
   }
 }
 
@@ -1889,6 +1900,11 @@ __device__ __forceinline__ void pack_weights_group(const float* __restrict__ w, 
     const int rho = (co & ~31) + 8 * ((c >> 2) & 3) + 4 * (c >> 4) + (c & 3);
     const int64_t at3 = ((((int64_t)tap * (rc >> 5) + (G >> 2)) * oc + rho) << 5) + (((G & 3) ^ ((rho >> 2) & 3)) << 3);
     *reinterpret_cast<u32x4*>(out + 2 * total + at3) = o;
+    // image 4 (generation 4, 16x16x32 blocks): row 16 j + 4 g + q of the 64-row block for channel 16 g + 4 j + q
+    const int c6 = co & 63;
+    const int rho16 = (co & ~63) + 16 * ((c6 >> 2) & 3) + 4 * (c6 >> 4) + (c6 & 3);
+    const int64_t at4 = ((((int64_t)tap * (rc >> 5) + (G >> 2)) * oc + rho16) << 5) + (((G & 3) ^ ((rho16 >> 1) & 2)) << 3);
+    *reinterpret_cast<u32x4*>(out + 3 * total + at4) = o;
   }
 }
 
@@ -1961,7 +1977,8 @@ __global__ void pack_weights_f8_kernel(const float* __restrict__ w, char* __rest
 //  24: generation 4 (conv_f8_dma.hip): e4m3 in and out, 16x32 x 64, 8 waves, 64-channel chunks on
 //      v_mfma_scale_f32_32x32x64_f8f6f4, all operands by LDS-DMA, 151 KB, 1/CU; maps that tile exactly
 //  25: generation 4 on bf16 operands (v_mfma_f32_32x32x16_bf16, 32-channel chunks): bias + relu (+ pool) only
-constexpr int XV_NUM_CONV_CFG = 26;
+//  26: as 25 on v_mfma_f32_16x16x32_bf16 at the same output tile per wave (the chip holds a higher clock on this shape)
+constexpr int XV_NUM_CONV_CFG = 27;
 struct Geo {
   int th, tw, bn, per_cu;
 };
@@ -1971,7 +1988,7 @@ const Geo kGeo[XV_NUM_CONV_CFG] = {{16, 16, 128, 2}, {8, 16, 128, 2}, {8, 32, 12
                                    {16, 32, 64, 1},  {16, 32, 64, 1},  {16, 16, 64, 2},  {8, 32, 64, 2},
                                    {16, 32, 64, 1},  {16, 32, 64, 1},  {1, 128, 128, 2},
                                    {16, 16, 128, 1}, {8, 32, 128, 1}, {16, 32, 64, 1}, {24, 16, 64, 1}, {1, 64, 64, 4},
-                                   {16, 32, 64, 1},  {16, 32, 64, 1}};
+                                   {16, 32, 64, 1},  {16, 32, 64, 1},  {16, 32, 64, 1}};
 
 template <int KS>
 int launch_cfg(int cfg, const ConvArgs& a, hipStream_t s) {
@@ -1982,10 +1999,10 @@ int launch_cfg(int cfg, const ConvArgs& a, hipStream_t s) {
     return xv_launch_conv3x3_f8_dma(a.x, a.wpk, a.bias, a.y, a.pooled, a.N, a.H, a.W, a.Cin, a.Cout, a.relu, 1, 1, a.scale_x,
                                     a.out_mul, a.num_cus, s);
   }
-  if (cfg == 25) {
+  if (cfg == 25 || cfg == 26) {
     if (KS != 3 || a.in_f8 || a.mask != nullptr || a.addend != nullptr) return XV_ESHAPE;
     return xv_launch_conv3x3_f8_dma(a.x, a.wpk, a.bias, a.y, a.pooled, a.N, a.H, a.W, a.Cin, a.Cout, a.relu, 0, a.out_f8, 0,
-                                    a.out_mul, a.num_cus, s);
+                                    a.out_mul, a.num_cus, s, nullptr, cfg == 26);
   }
   if (a.in_f8) {
     // the fp8 kernel is built for the tile shapes with LDS-DMA weight stages (the ones the bf16 chooser falls back to)
@@ -2082,7 +2099,7 @@ int pick_cfg(const ConvArgs& a, int k) {
         (xv_conv3x3_dma4_exact(a.H, a.W) || (a.Cin & 127) || covered(16) <= 1.3 * g1))
       return 24;
     // the bf16 conv that writes the first e4m3 map: generation 2 has no e4m3 epilogue, generation 4 does
-    if (k == 3 && !a.in_f8 && a.out_f8 && !no_gen4 && xv_conv3x3_dma4_bf16_ok(a.H, a.W, a.Cin, a.Cout)) return 25;
+    if (k == 3 && !a.in_f8 && a.out_f8 && !no_gen4 && xv_conv3x3_dma4_bf16_ok(a.H, a.W, a.Cin, a.Cout)) return 26;
     if (a.in_f8 && (a.Cin & 127)) return -1;  // 64-channel e4m3 chunks: generation 4 only
     // 16x32 patch, 8 waves, five taps per barrier where it tiles the map (large maps); else two 4-wave workgroups
     if (k == 3 && covered(16) <= g1 && (int64_t)a.N * a.H * a.W >= XV_F8_BIG_MAP) return 16;
@@ -2117,15 +2134,17 @@ int pick_cfg(const ConvArgs& a, int k) {
       }
       return rounds * g.th * g.tw / speed;
     };
-    // generation 4 (configuration 25: 32x32 MFMA blocks, leaner item loop) where the map tiles exactly and the tile has at
-    // least four 32-channel chunks... the two-chunk layers keep generation 2 (resident weights, stores spread over the next
-    // item).  Plain forward shapes only.  XV_BF16_GEN4=0: never; =2: every eligible shape (A/B timing).
+    // generation 4 where the map tiles exactly in 16x32: the leaner item loop on v_mfma_f32_16x16x32_bf16 (configuration 26).
+    // Round 4 measured the clock inside the item loops (profiles/r4_conv_inkernel_clock.json): on random operands the
+    // 32x32x16 form (25) holds 1.69-1.76 GHz, this one 1.89-1.98 GHz at 3 % more cycles, generation 2 (17: 16x16x32 too, a
+    // 15 % longer loop) 1.99-2.12 GHz; on zeros all three run at 2.39 GHz.  26 is ahead of both on every layer shape
+    // (profiles/r4_conv_mfma_shape_ab.txt: +7-10 % on conv3_x / conv4_x, +2-8 % on the one- and two-chunk layers).
+    // Plain forward shapes only.  XV_BF16_GEN4=0: never; =2: only from 128 input channels; =3: the 32x32x16 form (A/B timing).
     {
       static const int gen4 = getenv("XV_BF16_GEN4") != nullptr ? atoi(getenv("XV_BF16_GEN4")) : 1;
       if (gen4 && a.mask == nullptr && a.addend == nullptr && a.sk_ws == nullptr && !a.in_f8 && !a.out_f8 &&
-          xv_conv3x3_dma4_bf16_ok(a.H, a.W, a.Cin, a.Cout) && xv_conv3x3_dma4_exact(a.H, a.W) &&
-          (gen4 == 2 || a.Cin >= 256 || (a.Cin == 128 && a.Cout >= 256)))
-        return 25;
+          xv_conv3x3_dma4_bf16_ok(a.H, a.W, a.Cin, a.Cout) && xv_conv3x3_dma4_exact(a.H, a.W) && (gen4 != 2 || a.Cin >= 128))
+        return gen4 == 3 ? 25 : 26;
     }
     int g2 = 17;
     double s2 = 1.25;
@@ -2201,7 +2220,7 @@ int conv_fwd_impl(const xv_act* x, const void* w_packed, const float* bias, cons
 
 extern "C" size_t xv_packed_weight_bytes(int k, int cin, int cout) {
   if ((k != 1 && k != 3) || cin <= 0 || cout <= 0 || (cin & 63) || (cout & 63)) return 0;
-  return (size_t)k * k * cin * cout * 2 * (k == 3 ? 3 : 1);  // 3x3: the three packed images (generations 1, 2, 4)
+  return (size_t)k * k * cin * cout * 2 * (k == 3 ? 4 : 1);  // 3x3: the four packed images (generations 1, 2, 4, 4 on 16x16 blocks)
 }
 
 extern "C" size_t xv_packed_weight_bytes_f8(int k, int cin, int cout) {
@@ -2317,7 +2336,7 @@ extern "C" int xv_conv2d_fwd_stats(const xv_act* x, const void* w_packed, const 
   if (!xv_conv3x3_dma4_bf16_ok(x->h, x->w, x->c, y->c) || y->c > 512) return XV_ESHAPE;
   if (stats_bytes < (size_t)xv_num_cus() * 2 * y->c * sizeof(float)) return XV_EWORKSPACE;
   return xv_launch_conv3x3_f8_dma(x->data, w_packed, bias, y->data, nullptr, x->n, x->h, x->w, x->c, y->c, 0, 0, 0, 0, 1.f,
-                                  xv_num_cus(), (hipStream_t)stream, stats_rows);
+                                  xv_num_cus(), (hipStream_t)stream, stats_rows, 1);
 }
 
 extern "C" size_t xv_deconv_dense_workspace_bytes(int n, int h, int w, int cout, int stride) {
@@ -2384,5 +2403,14 @@ extern "C" int xv_conv2d_num_cfgs(void) { return XV_NUM_CONV_CFG; }
 #ifdef XV_CONV_TRACE
 extern "C" int xv_debug_read_trace(void* dst, size_t bytes) {
   return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(xv_trace_buf), bytes);
+}
+#endif
+
+#ifdef XV_CLOCK_STAMP
+// [workgroup][s_memtime before, s_memrealtime before, s_memtime after, s_memrealtime after] of the last generation-2 launch
+extern "C" int xv_debug_read_clock_g2(void* dst, size_t bytes) { return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(xv_clk_g2), bytes); }
+extern "C" int xv_debug_reset_clock_g2(void) {
+  static unsigned long long zeros[4 * XV_CLK_SLOTS];
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(xv_clk_g2), zeros, sizeof(zeros));
 }
 #endif

@@ -130,3 +130,27 @@ __device__ static __forceinline__ uint32_t pk_max_i16(uint32_t a, uint32_t b) {
   typedef short s16x2 __attribute__((ext_vector_type(2)));
   return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s16x2, a), __builtin_bit_cast(s16x2, b)));
 }
+
+// ---- diagnostic build only (-DXV_CLOCK_STAMP: `make stamp` -> tools/build/libxview_hip_stamp.so, read by tools/conv_clock.py;
+// never in the shipped library) --------------------------------------------------------------------------------------------
+// The clock the chip holds inside a conv kernel's item loop = delta s_memtime (shader cycles) / delta s_memrealtime (a
+// constant 100 MHz counter) x 100 MHz, stamped ONCE around the loop by every workgroup (MI355X_MICROARCH.md, 'DVFS
+// give-back' item 6).  The four values go to a buffer of their own after the loop; nothing is computed from them.
+#ifdef XV_CLOCK_STAMP
+#define XV_CLK_SLOTS 2048
+#define XV_CLK_BEGIN()                                              \
+  const unsigned long long clk_m0 = __builtin_amdgcn_s_memtime();   \
+  const unsigned long long clk_r0 = __builtin_amdgcn_s_memrealtime();
+#define XV_CLK_END(buf)                                                                   \
+  {                                                                                       \
+    const unsigned long long clk_m1 = __builtin_amdgcn_s_memtime();                       \
+    const unsigned long long clk_r1 = __builtin_amdgcn_s_memrealtime();                   \
+    if (threadIdx.x == 0 && blockIdx.x < XV_CLK_SLOTS) {                                  \
+      buf[blockIdx.x * 4 + 0] = clk_m0, buf[blockIdx.x * 4 + 1] = clk_r0;                 \
+      buf[blockIdx.x * 4 + 2] = clk_m1, buf[blockIdx.x * 4 + 3] = clk_r1;                 \
+    }                                                                                     \
+  }
+#else
+#define XV_CLK_BEGIN()
+#define XV_CLK_END(buf)
+#endif

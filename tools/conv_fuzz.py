@@ -79,7 +79,7 @@ for case in range(args.cases):
     cin = int(rng.choice([64, 128, 192, 256]))
     cout = int(rng.choice([64, 128, 192]))
     mode = int(rng.integers(0, 4))          # 0 full map, 1 full + pool, 2 pooled only, 3 data gradient
-    tiles = case % 3 == 0 and mode != 3     # a map that tiles exactly in 16x32: generation 4 (configuration 25) joins
+    tiles = case % 3 == 0 and mode != 3     # a map that tiles exactly in 16x32: generation 4 (configurations 25 / 26) joins
     if tiles:
         h, w = (h + 15) // 16 * 16, (w + 31) // 32 * 32
     relu = bool(rng.integers(0, 2)) if mode == 0 else (mode != 3)
@@ -108,7 +108,7 @@ for case in range(args.cases):
             print('MISMATCH data-gradient epilogue', (n, h, w, cin, cout))
     else:
         wp = ops.pack_conv_weights(wt)
-        for cfg in (14, 17, 21) + ((22,) if mode == 0 else ()) + ((25,) if tiles else ()):          # 22: no fused pool
+        for cfg in (14, 17, 21) + ((22,) if mode == 0 else ()) + ((25, 26) if tiles else ()):          # 22: no fused pool
             y = ops.Act(n, h, w, cout) if mode != 2 else None
             q = ops.Act(n, h // 2, w // 2, cout) if mode in (1, 2) else None
             ops.conv2d_fwd(xa, wp, b, 3, relu=relu, y=y, pooled=q, write_y=y is not None, cfg=cfg)
