@@ -745,15 +745,42 @@ def main():
             pass
 
 
+def sysfs_gpu_count():
+    """GPUs of this node as the kernel driver lists them (KFD topology nodes with SIMDs; CPUs are nodes with none), read from
+    sysfs: no HIP / HSA / amdsmi call, so nothing here opens /dev/kfd.  None when the topology is not readable (the ranks
+    then find out themselves).  HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES lists narrow the count."""
+    import glob
+    nodes = glob.glob('/sys/class/kfd/kfd/topology/nodes/*/properties')
+    if not nodes:
+        return None
+    count = 0
+    for path in nodes:
+        try:
+            with open(path) as f:
+                props = dict(line.split()[:2] for line in f if len(line.split()) >= 2)
+        except OSError:
+            return None
+        if int(props.get('simd_count', '0')) > 0:
+            count += 1
+    for var in ('HIP_VISIBLE_DEVICES', 'ROCR_VISIBLE_DEVICES'):
+        listed = os.environ.get(var)
+        if listed is not None and listed.strip() != '':
+            count = min(count, len([t for t in listed.split(',') if t.strip() != '']))
+    return count
+
+
 def launch_ranks(args):
     """`python bench.py --gpus N` without a launcher around it: start the N ranks as a CHILD process (the same command
     line under torch.distributed.run, one rank per GPU over RCCL), relay rank 0's JSON line and exit with the child's
     code.  Nothing here touches the GPU: a process that has initialised it must never exec another program, so the
-    ranks are children and this parent only waits (torch.cuda.device_count() does not initialise the device)."""
+    ranks are children and this parent only waits.  The parent makes NO torch.cuda call at all -- torch.cuda.device_count()
+    falls through to hipGetDeviceCount (which opens /dev/kfd) whenever its amdsmi probe fails -- and counts the GPUs from
+    sysfs instead (tests/test_host_logic.py::test_bench_launcher_parent_never_touches_the_gpu)."""
     import socket
-    if not args.share_device and torch.cuda.device_count() < args.gpus:
-        print('bench.py: --gpus %d but %d GPU(s) visible (use --share-device --dist-backend gloo for a one-GPU smoke run '
-              'of the multi-rank path)' % (args.gpus, torch.cuda.device_count()), file=sys.stderr)
+    have = None if args.share_device else sysfs_gpu_count()
+    if have is not None and have < args.gpus:
+        print('bench.py: --gpus %d but %d GPU(s) listed in the KFD topology (use --share-device --dist-backend gloo for a '
+              'one-GPU smoke run of the multi-rank path)' % (args.gpus, have), file=sys.stderr)
         sys.exit(2)
     with socket.socket() as sk:
         sk.bind(('127.0.0.1', 0))

@@ -56,6 +56,19 @@ def test_two_rank_reduction_matches_single_process(tmp_path):
     np.testing.assert_allclose(got['S'], S, rtol=1e-12, atol=1e-9)
 
 
+def test_four_rank_reduction_with_uneven_shards(tmp_path):
+    """World size 4 over 5 samples (shards of 2, 1, 1, 1 images: the remainder path of shard_range): the reduced confusion
+    matrix / sufficient statistics equal the single-process ones."""
+    out = str(tmp_path / 'r4.npz')
+    mp.spawn(_worker, args=(4, _free_port(), out), nprocs=4, join=True)
+    got = np.load(out)
+    full = _dataset()
+    assert np.array_equal(got['cm'], fu.confusion_matrix(full['labels'], full['pred'], C))
+    S, counts = fu.sufficient_statistics(full['prob'], full['labels'], C)
+    assert np.array_equal(got['counts'], counts)
+    np.testing.assert_allclose(got['S'], S, rtol=1e-12, atol=1e-9)
+
+
 def test_shard_range_is_a_partition():
     from modular_semantic_segmentation_amd import parallel
     for n in (0, 1, 7, 16):
@@ -92,6 +105,45 @@ def test_bucketed_gradient_allreduce(tmp_path):
     ref = sum(np.random.default_rng(100 + r).standard_normal(1000).astype(np.float32) for r in range(2))
     np.testing.assert_allclose(got['flat'], ref, rtol=1e-6)
     assert got['count'][0] == 21
+
+
+def test_bucketed_gradient_allreduce_four_ranks(tmp_path):
+    """The same three buckets over four ranks (the first time more than two ranks meet in the bucket path), plus the
+    collective early-abort vote and the equal-batchsize check of parallel.py."""
+    out = str(tmp_path / 'g4.npz')
+    mp.spawn(_grad_worker, args=(4, _free_port(), out), nprocs=4, join=True)
+    got = np.load(out)
+    ref = sum(np.random.default_rng(100 + r).standard_normal(1000).astype(np.float32) for r in range(4))
+    np.testing.assert_allclose(got['flat'], ref, rtol=1e-5, atol=1e-6)
+    assert got['count'][0] == 10 + 11 + 12 + 13
+
+
+def _vote_worker(rank, size, port, out):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=size)
+    from modular_semantic_segmentation_amd import parallel
+    any_failed = parallel.agree_any(rank == 2, 'cpu')          # one rank fails: every rank must learn it
+    none_failed = parallel.agree_any(False, 'cpu')
+    parallel.require_equal_batchsize(8, 'cpu')
+    try:
+        parallel.require_equal_batchsize(8 if rank != 3 else 7, 'cpu')
+        unequal = False
+    except ValueError:
+        unequal = True
+    res = torch.tensor([int(any_failed), int(none_failed), int(unequal)], dtype=torch.int64)
+    gathered = [torch.zeros(3, dtype=torch.int64) for _ in range(size)]
+    dist.all_gather(gathered, res)
+    if rank == 0:
+        np.save(out, torch.stack(gathered).numpy())
+    dist.destroy_process_group()
+
+
+def test_collective_votes_over_four_ranks(tmp_path):
+    out = str(tmp_path / 'v.npy')
+    mp.spawn(_vote_worker, args=(4, _free_port(), out), nprocs=4, join=True)
+    got = np.load(out)
+    assert got.shape == (4, 3) and np.all(got[:, 0] == 1) and np.all(got[:, 1] == 0) and np.all(got[:, 2] == 1)
 
 
 class _StubTrainer(object):

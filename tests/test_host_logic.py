@@ -427,3 +427,64 @@ def test_fp8_plan_and_the_oracle_policy_agree():
         for n in names:
             on_grid = np.array_equal(out[n], fo.round_e4m3(out[n], scales[n]))
             assert on_grid == (n in maps), (deep, n)
+
+
+def test_bench_launcher_parent_never_touches_the_gpu(monkeypatch, tmp_path):
+    """`python bench.py --gpus N` (no launcher around it): the parent that starts torch.distributed.run must make no
+    torch.cuda call -- torch.cuda.device_count() falls through to hipGetDeviceCount (which opens /dev/kfd and initialises
+    the HSA runtime) whenever its amdsmi probe fails, and a process that has initialised the GPU must never be followed by an
+    exec on this pool.  Every torch.cuda entry that could reach the driver is booby-trapped here; the
+    GPU count comes from the KFD topology in sysfs."""
+    import importlib
+    import sys
+    import types
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    monkeypatch.syspath_prepend(root)
+    bench = importlib.import_module('bench')
+    import torch
+
+    def boom(*a, **k):
+        raise AssertionError('the launcher parent called into torch.cuda')
+    for name in ('device_count', 'is_available', 'init', 'current_device', 'set_device', 'get_device_name', 'synchronize'):
+        monkeypatch.setattr(torch.cuda, name, boom)
+    if hasattr(torch._C, '_cuda_getDeviceCount'):
+        monkeypatch.setattr(torch._C, '_cuda_getDeviceCount', boom)
+
+    started = {}
+
+    class FakeProc:
+        stdout = iter(['{"metric": "x"}\n'])
+
+        def wait(self):
+            return 0
+
+    def fake_popen(cmd, **kw):
+        started['cmd'] = cmd
+        started['env'] = kw.get('env', {})
+        return FakeProc()
+    monkeypatch.setattr(bench.subprocess, 'Popen', fake_popen)
+    monkeypatch.setattr(sys, 'argv', ['bench.py', '--gpus', '8'])
+    # 8 GPUs + 2 CPU nodes in a fake topology
+    nodes = tmp_path / 'nodes'
+    for i in range(10):
+        d = nodes / str(i)
+        d.mkdir(parents=True)
+        (d / 'properties').write_text('cpu_cores_count %d\nsimd_count %d\n' % (0 if i >= 2 else 64, 1024 if i >= 2 else 0))
+    real_glob = importlib.import_module('glob').glob
+    monkeypatch.setattr('glob.glob', lambda pat: real_glob(str(nodes / '*' / 'properties')) if 'kfd' in pat else real_glob(pat))
+    assert bench.sysfs_gpu_count() == 8
+    monkeypatch.setenv('HIP_VISIBLE_DEVICES', '0,1')
+    assert bench.sysfs_gpu_count() == 2
+    monkeypatch.delenv('HIP_VISIBLE_DEVICES')
+    args = types.SimpleNamespace(gpus=8, share_device=False)
+    with pytest.raises(SystemExit) as e:
+        bench.launch_ranks(args)
+    assert e.value.code == 0
+    assert '--nproc-per-node' in started['cmd'] and started['cmd'][started['cmd'].index('--nproc-per-node') + 1] == '8'
+    assert '127.0.0.1' in started['cmd'] and started['env'].get('HSA_ENABLE_IPC_MODE_LEGACY') == '0'
+    # fewer GPUs than ranks: refused before anything is started
+    started.clear()
+    args = types.SimpleNamespace(gpus=16, share_device=False)
+    with pytest.raises(SystemExit) as e:
+        bench.launch_ranks(args)
+    assert e.value.code == 2 and not started
