@@ -157,6 +157,11 @@ int xv_conv2d_bwd_data_ws(const xv_act* dy, const void* w_packed_dgrad, const fl
                           const xv_act* addend, const xv_act* dx, int k, void* workspace, size_t workspace_bytes,
                           void* stream);
 int xv_conv2d_num_cfgs(void);
+/* The tile configuration the library would choose for this shape (what cfg < 0 resolves to), without launching anything:
+ * host arithmetic only.  in_dtype / out_dtype: XV_BF16 | XV_FP8; flags: bit 0 = with a pooled output, bit 1 = the
+ * data-gradient epilogue (addend / relu mask), bit 2 = with a stream-K workspace.  Returns the configuration index or
+ * XV_ESHAPE / XV_EINVAL.                                                                                              */
+int xv_conv2d_choose_cfg(int n, int h, int w, int cin, int cout, int k, int in_dtype, int out_dtype, int flags);
 
 /* First layer: conv1_1 = relu(conv3x3(x) + b) on the RAW float32 network input (dense unpadded
  * NHWC, cin = 1..4; simple_fcn.py:39), fp32 weights HWIO [3][3][cin][64], fp32 math, bf16 out.

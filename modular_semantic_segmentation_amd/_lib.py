@@ -34,6 +34,7 @@ _vpp = ctypes.POINTER(ctypes.c_void_p)
 # name -> (restype, argtypes); every symbol include/xview_hip.h declares
 SIGNATURES = {
     'xv_version': (_i, []),
+    'xv_conv2d_choose_cfg': (_i, [_i] * 9),
     'xv_arch': (ctypes.c_char_p, []),
     'xv_source_hash': (ctypes.c_char_p, []),
     'xv_packed_weight_bytes': (ctypes.c_size_t, [_i, _i, _i]),

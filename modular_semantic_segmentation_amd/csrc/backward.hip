@@ -732,13 +732,13 @@ extern "C" int xv_count_valid_labels(const int32_t* labels, int num_classes, int
 }
 
 extern "C" size_t xv_decoder_head_bwd_workspace_bytes(int n, int h, int w, int num_classes) {
-  if (n <= 0 || h <= 0 || w <= 0 || num_classes < 1 || num_classes > 32) return 0;
+  if (!xv_dims_sane(n, h, w) || num_classes < 1 || num_classes > 32) return 0;
   const size_t cm = (size_t)(num_classes + 3) / 4 * 4;
   // padded low-resolution scores + the row sums of the score gradient (3 target rows x 8w columns per 1/8-resolution
   // row) + one slab of weight-gradient partial sums per 256 low-resolution pixels (up to 256 decoder units)
   const size_t slabs = ((size_t)n * h * w + 255) / 256;
   // + per workgroup of the loss kernel (at most 4096) its partial bias gradient and loss
-  return (((size_t)n * (h + 2) * (w + 2) + (size_t)n * h * w * 24 + slabs * 256) * cm + 4096 * (cm + 1)) * sizeof(float);
+  return (((size_t)n * ((size_t)h + 2) * ((size_t)w + 2) + (size_t)n * h * w * 24 + slabs * 256) * cm + 4096 * (cm + 1)) * sizeof(float);
 }
 
 extern "C" int xv_score_lowres(const xv_act* fused, const float* w_score, int num_classes, float* S, void* stream);
@@ -828,7 +828,7 @@ static void first_wgrad_geometry(int64_t npix, int w, int cin, bool& mfma, unsig
 }
 
 extern "C" size_t xv_conv2d_first_bwd_filter_workspace_bytes(int n, int h, int w, int cin) {
-  if (n <= 0 || h <= 0 || w <= 0 || cin < 1 || cin > 4) return 0;
+  if (!xv_dims_sane(n, h, w) || cin < 1 || cin > 4 || (int64_t)n * h * w >= 0x7fff0000) return 0;
   bool mfma;
   unsigned grid;
   int per;

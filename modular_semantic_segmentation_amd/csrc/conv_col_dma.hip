@@ -1,0 +1,423 @@
+// Generation 5: the generation-4 item loop (conv_f8_dma.hip: every operand by LDS-DMA, one barrier per item, counted
+// vmcnt / lgkmcnt, v_mfma_f32_16x16x32_bf16) on a COLUMN of waves -- configuration 27 (24x16 pixel tile, 3 image rows per
+// wave) and 28 (32x16, 4 rows per wave).
+//
+// Replaces, like the other conv kernels, tf.layers.conv2d(3x3, 'same', relu) (+ max_pooling2d) of the FCN trunk
+// (xview/models/simple_fcn.py:39-79), here first of all conv5_1 .. conv5_3 of a 768x384 input: 24x48 maps.  The 16x32 tile of
+// generation 4 covers such a map at 56 % (2 x 2 tiles over 32 x 64 pixels), so round 3 ran them on generation 2's 24x16
+// tile (configuration 22: 0.38 of the MFMA peak, the kernel furthest below its roof).  24x16 tiles the
+// map exactly; this kernel gives that tile the lean loop.
+//
+//   * 8 waves, wave w owns image rows MT w .. MT w + MT - 1 x 16 columns x 64 output channels = MT pixel blocks x 4 channel
+//     blocks of 16x16 (16 MT accumulator registers).  Lane l = (column n15 = l & 15, k-group / channel group g = l >> 4).
+//   * A tap is 4 MT MFMAs of K = 32 (the whole 32-channel chunk).  Per tap the wave reads 4 weight fragments, per column
+//     group (3 taps) MT + 2 pixel fragments: 36 + 3 (MT + 2) ds_read_b128 per item against 36 + 24 for the 2 rows x 32
+//     columns of generation 4 -- 54 instead of 60 at MT = 4 for the same 144 MFMAs.
+//   * LDS images, the source-side swizzle of the DMA (g4_swz16: slot s of row r at s ^ ((r >> 1) & 2), conflict-free for
+//     every column offset), the packed weight image (the FOURTH image of xv_pack_conv_weights: rows permuted so that a
+//     lane's 16 accumulators of a pixel are 16 consecutive channels) and the epilogue are generation 4's 16x16 form.
+//   * Fragment schedule (reads return in order; at most 4 + (MT + 2) + 4 = 14 in flight, the counter holds 15):
+//       before tap 0: W0 P0 | tap t: W(t+1), wait, [P of the next column group at taps 1 and 3], MFMAs.
+//   * Exact tilings only (H % (8 MT) == 0, W % 16 == 0); fused 2x2 max-pool for even MT; bias + relu, no addend / mask.
+#include "xv_common.h"
+
+namespace {
+
+struct G5Args {
+  const char* x;      // bf16 [N][H+2][W+2][Cin], zero border
+  const char* wpk;    // packed bf16 weights (four images; this kernel reads the fourth)
+  const float* bias;  // [Cout]
+  char* y;            // bf16 [N][H+2][W+2][Cout] or null
+  char* pooled;       // bf16 [N][H/2+2][W/2+2][Cout] or null
+  int N, H, W, Cin, Cout;
+  int tiles_x, tiles_y, n_ct, n_tiles;
+  int relu;
+};
+
+template <int MT>
+struct G5 {
+  static constexpr int NWAVES = 8, NT = 512;
+  static constexpr int TH = NWAVES * MT, TW = 16, HH = TH + 2, HW = TW + 2, NPIX = HH * HW;
+  static constexpr int R = MT + 2;                       // patch rows a wave reads per column group
+  static constexpr int A_PIECES = (NPIX * 4 + 63) / 64;  // 1 KB per DMA wave-instruction
+  static constexpr int A_BYTES = A_PIECES * 1024;
+  static constexpr int B_PIECES = 9 * 4;  // 9 taps x (64 rows x 64 B)
+  static constexpr int B_BYTES = B_PIECES * 1024;
+  static constexpr int BIAS_OFF = 2 * (A_BYTES + B_BYTES);  // two 256-byte bias slots (tile parity)
+  static constexpr int LDS_BYTES = BIAS_OFF + 512;
+  static constexpr int A_ITERS = (A_PIECES + NWAVES - 1) / NWAVES;
+  static constexpr int B_ITERS = (B_PIECES + NWAVES - 1) / NWAVES;
+  static constexpr int PROW = HW * 64;  // bytes between patch rows
+  static_assert(LDS_BYTES <= 160 * 1024, "does not fit the LDS");
+  static_assert(R == 5 || R == 6, "the fragment macros are written for 5 or 6 patch rows");
+};
+
+__device__ __forceinline__ int g5_swz(int row, int slot) { return slot ^ ((row >> 1) & 2); }  // = g4_swz16
+
+__device__ __forceinline__ float g5_dpp_swap1(float v) {  // value of lane ^ 1 (quad_perm [1,0,3,2])
+  return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));
+}
+
+#ifdef XV_CLOCK_STAMP
+__device__ unsigned long long xv_clk_g5[4 * XV_CLK_SLOTS];
+#endif
+
+template <int MT>
+__global__ __launch_bounds__(512, 2) void conv_dma5_kernel(G5Args a) {
+  using C = G5<MT>;
+  constexpr int R = C::R;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n15 = lane & 15, g = lane >> 4;
+  const int H = a.H, W = a.W, Cin = a.Cin, Cout = a.Cout;
+  const int Wp = W + 2;
+  const int Cb = 2 * Cin, Ob = 2 * Cout;  // bytes per pixel of the input / output maps
+  const int nchunks = Cb >> 6;            // 64 bytes = 32 input channels per chunk
+  const char* const wimg = a.wpk + (int64_t)6 * 9 * Cin * Cout;  // the fourth packed image
+
+  // persistent workgroups, XCD-contiguous tile ranges, the output-channel tiles of one patch adjacent (as generation 2 / 4)
+  const int G = gridDim.x, b = blockIdx.x;
+  const int xcd = b & 7, bi = b >> 3;
+  const int nb = (G - xcd + 7) >> 3;
+  const int T = a.n_tiles;
+  const int tq = T >> 3, trm = T & 7;
+  const int t_begin = xcd * tq + (xcd < trm ? xcd : trm);
+  const int t_end = t_begin + tq + (xcd < trm ? 1 : 0);
+  int lid = t_begin + bi;
+  if (lid >= t_end) return;
+
+  struct Tile {
+    int n, y0, x0, co0;
+  };
+  auto decode = [&](int l) {
+    Tile t;
+    t.co0 = (l % a.n_ct) * 64;
+    int r = l / a.n_ct;
+    t.x0 = (r % a.tiles_x) * C::TW;
+    r /= a.tiles_x;
+    t.y0 = (r % a.tiles_y) * C::TH;
+    t.n = r / a.tiles_y;
+    return t;
+  };
+
+  // per-lane source offsets (bytes, relative to the patch origin) of the patch pieces this wave moves: LDS granule
+  // gr = piece * 64 + lane holds physical slot gr & 3 of pixel gr >> 2
+  int aoff[C::A_ITERS];
+#pragma unroll
+  for (int it = 0; it < C::A_ITERS; ++it) {
+    const int gr = (wave + it * C::NWAVES) * 64 + lane;
+    int p = gr >> 2;
+    p = p < C::NPIX ? p : C::NPIX - 1;
+    const int hy = p / C::HW, hx = p - hy * C::HW;
+    aoff[it] = (hy * Wp + hx) * Cb + (g5_swz(hx, gr & 3) << 4);
+  }
+  // LDS fragment addresses: pixel column n15 + dx of patch row MT * wave, weight row n15 of a 16-row block; k-group g
+  int pbase[3];
+#pragma unroll
+  for (int dx = 0; dx < 3; ++dx) pbase[dx] = ((MT * wave) * C::HW + n15 + dx) * 64 + (g5_swz(n15 + dx, g) << 4);
+  const int wbase = 2 * C::A_BYTES + n15 * 64 + (g5_swz(n15, g) << 4);
+  const int64_t tap_pitch = (int64_t)nchunks * Cout * 64;  // bytes between taps of the packed image
+
+  // LDS-DMA in assembly (SGPR base + 32-bit VGPR offset; M0 = the wave's LDS destination), as generation 2 / 4
+  auto dma16 = [&](const char* sbase, int voff, int lds_off) {
+    asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_off), "v"(voff), "s"(sbase) : "memory");
+  };
+  auto dma_bases = [&](const Tile& t, int chunk, const char*& xsrc, const char*& wsrc) {
+    xsrc = a.x + (((int64_t)t.n * (H + 2) + t.y0) * Wp + t.x0) * Cb + chunk * 64;
+    wsrc = wimg + (((int64_t)chunk * Cout + t.co0) << 6);
+  };
+  auto dma_a = [&](const char* xsrc, int it, int buf) {
+    const int piece = wave + it * C::NWAVES;
+    if (piece < C::A_PIECES) dma16(xsrc, aoff[it], buf * C::A_BYTES + piece * 1024);
+  };
+  auto dma_b = [&](const char* wsrc, int it, int buf) {
+    const int piece = wave + it * C::NWAVES;
+    if (piece < C::B_PIECES)
+      dma16(wsrc + (piece >> 2) * tap_pitch + (piece & 3) * 1024, lane * 16, 2 * C::A_BYTES + buf * C::B_BYTES + piece * 1024);
+  };
+  // the tile's 64 bias values ride along with its first chunk (one 4-byte-per-lane DMA by the last wave)
+  auto dma_bias = [&](const Tile& t, bool tile_start, int bslot) {
+    if (tile_start && wave == C::NWAVES - 1)
+      asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dword %1, %2" ::"s"(C::BIAS_OFF + bslot * 256), "v"(lane * 4),
+                   "s"(a.bias + t.co0)
+                   : "memory");
+  };
+
+  Tile cur = decode(lid);
+  int chunk = 0, buf = 0, bslot = 0;
+  {
+    const char *xsrc, *wsrc;
+    dma_bases(cur, 0, xsrc, wsrc);
+#pragma unroll
+    for (int it = 0; it < C::A_ITERS; ++it) dma_a(xsrc, it, 0);
+#pragma unroll
+    for (int it = 0; it < C::B_ITERS; ++it) dma_b(wsrc, it, 0);
+    dma_bias(cur, true, 0);
+  }
+
+  f32x4 acc[MT][4];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // RESIDENT WEIGHTS (as generation 2 / 4): with one or two chunks per tile weight buffer p only ever holds chunk p's
+  // weights -- of the same output-channel tile too when every workgroup of the XCD group keeps its tile residue
+  const bool resident = nchunks <= 2 && (nb % a.n_ct) == 0;
+  int items_done = 0;
+  // 16-byte store instructions per tile and wave: two per row, two per pooled row
+  const int nstores = (a.y != nullptr ? 2 * MT : 0) + (a.pooled != nullptr ? MT : 0);
+  int in_flight = 0;  // stores issued after the last DMA of the previous item
+
+  XV_CLK_BEGIN()
+  while (true) {
+    // This item's operands have landed (each wave retires its own DMA; the tile stores issued after it may stay in
+    // flight: vmcnt counts in issue order), and every wave has finished reading the other buffer pair.
+    if (in_flight == 3 * MT)
+      asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(3 * MT) : "memory");
+    else if (in_flight == 2 * MT)
+      asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(2 * MT) : "memory");
+    else if (in_flight == MT)
+      asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(MT) : "memory");
+    else
+      asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    in_flight = 0;
+
+    const int pb[3] = {pbase[0] + buf * C::A_BYTES, pbase[1] + buf * C::A_BYTES, pbase[2] + buf * C::A_BYTES};
+    const int wb = wbase + buf * C::B_BYTES;
+
+    // Fragment registers: weights of tap t in set t & 1 ([channel block]), the R patch rows of column group dx in set dx & 1
+    u32x4 wf[2][4], xf[2][6];
+#define G5_RD(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
+    // t = dx*3 + dy  ->  packed tap dy*3 + dx
+#define G5_LDW(t, set)                                      \
+  {                                                         \
+    constexpr int tap_ = (((t) % 3) * 3 + (t) / 3) * 4096;  \
+    G5_RD(wf[set][0], wb, tap_);                            \
+    G5_RD(wf[set][1], wb, tap_ + 1024);                     \
+    G5_RD(wf[set][2], wb, tap_ + 2048);                     \
+    G5_RD(wf[set][3], wb, tap_ + 3072);                     \
+  }
+#define G5_LDP(dx, set)                                              \
+  {                                                                  \
+    G5_RD(xf[set][0], pb[dx], 0);                                    \
+    G5_RD(xf[set][1], pb[dx], C::PROW);                              \
+    G5_RD(xf[set][2], pb[dx], 2 * C::PROW);                          \
+    G5_RD(xf[set][3], pb[dx], 3 * C::PROW);                          \
+    if constexpr (R > 4) G5_RD(xf[set][4], pb[dx], 4 * C::PROW);     \
+    if constexpr (R > 5) G5_RD(xf[set][5], pb[dx], 5 * C::PROW);     \
+  }
+    // at most n newer reads outstanding.  Every wait names exactly the registers it releases: the MFMAs that consume them
+    // cannot move above it, and no register with a read still in flight is an operand of anything.
+#define G5_WAIT_W(n, ws, ps) \
+  asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(wf[ws][0]), "+v"(wf[ws][1]), "+v"(wf[ws][2]), "+v"(wf[ws][3]) : "n"(n))
+#define G5_WAIT_WP(n, ws, ps)                                                                                          \
+  if constexpr (R == 5)                                                                                                \
+    asm volatile("s_waitcnt lgkmcnt(%9)"                                                                               \
+                 : "+v"(wf[ws][0]), "+v"(wf[ws][1]), "+v"(wf[ws][2]), "+v"(wf[ws][3]), "+v"(xf[ps][0]), "+v"(xf[ps][1]), \
+                   "+v"(xf[ps][2]), "+v"(xf[ps][3]), "+v"(xf[ps][4])                                                   \
+                 : "n"(n));                                                                                            \
+  else                                                                                                                 \
+    asm volatile("s_waitcnt lgkmcnt(%10)"                                                                              \
+                 : "+v"(wf[ws][0]), "+v"(wf[ws][1]), "+v"(wf[ws][2]), "+v"(wf[ws][3]), "+v"(xf[ps][0]), "+v"(xf[ps][1]), \
+                   "+v"(xf[ps][2]), "+v"(xf[ps][3]), "+v"(xf[ps][4]), "+v"(xf[ps][5])                                  \
+                 : "n"(n))
+#define G5_MFMA(i, ws, ps, dy)                                                                                       \
+  {                                                                                                                  \
+    acc[i][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[ws][0]),                       \
+                                                        __builtin_bit_cast(bf16x8, xf[ps][(i) + (dy)]), acc[i][0], 0, 0, 0); \
+    acc[i][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[ws][1]),                       \
+                                                        __builtin_bit_cast(bf16x8, xf[ps][(i) + (dy)]), acc[i][1], 0, 0, 0); \
+    acc[i][2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[ws][2]),                       \
+                                                        __builtin_bit_cast(bf16x8, xf[ps][(i) + (dy)]), acc[i][2], 0, 0, 0); \
+    acc[i][3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[ws][3]),                       \
+                                                        __builtin_bit_cast(bf16x8, xf[ps][(i) + (dy)]), acc[i][3], 0, 0, 0); \
+  }
+    // An MFMA is a pure value to the optimizer: an empty volatile asm that "modifies" its accumulators pins the MFMAs that
+    // produced them in front of every later asm statement (reads, waits, priority changes), as in generation 4.
+#define G5_PIN(i) asm volatile("" : "+v"(acc[i][0]), "+v"(acc[i][1]), "+v"(acc[i][2]), "+v"(acc[i][3]))
+    // the next item's DMA: patch pieces two per tap from tap 0 (HBM / Infinity-Cache latency), weight pieces (L2) after,
+    // the bias with the first weight piece
+#define G5_DMA_PIECES(t)                                                                              \
+  if (has_next) {                                                                                     \
+    if (2 * (t) < C::A_ITERS) dma_a(nx_src, 2 * (t), buf ^ 1);                                        \
+    if (2 * (t) + 1 < C::A_ITERS) dma_a(nx_src, 2 * (t) + 1, buf ^ 1);                                \
+    if ((t) >= A_TAPS && (t) - A_TAPS < C::B_ITERS && !skip_b) dma_b(nw_src, (t) - A_TAPS, buf ^ 1);  \
+    if ((t) == A_TAPS) dma_bias(nxt, last_chunk, bslot ^ 1);                                          \
+  }
+#define G5_TAP(t, WAIT, NEWER, POST)                              \
+  {                                                               \
+    constexpr int dx_ = (t) / 3, dy_ = (t) % 3;                   \
+    if constexpr ((t) + 1 < 9) G5_LDW((t) + 1, ((t) + 1) & 1);    \
+    G5_DMA_PIECES(t)                                              \
+    WAIT(NEWER, (t) & 1, dx_ & 1);                                \
+    POST;                                                         \
+    __builtin_amdgcn_sched_barrier(0);                            \
+    G5_MFMA(0, (t) & 1, dx_ & 1, dy_);                            \
+    G5_PIN(0);                                                    \
+    __builtin_amdgcn_s_setprio(2);                                \
+    __builtin_amdgcn_sched_barrier(0);                            \
+    G5_MFMA(1, (t) & 1, dx_ & 1, dy_);                            \
+    G5_MFMA(2, (t) & 1, dx_ & 1, dy_);                            \
+    if constexpr (MT > 3) G5_MFMA(3, (t) & 1, dx_ & 1, dy_);      \
+    G5_PIN(1);                                                    \
+    G5_PIN(2);                                                    \
+    if constexpr (MT > 3) G5_PIN(3);                              \
+    __builtin_amdgcn_sched_barrier(0);                            \
+    __builtin_amdgcn_s_setprio(1);                                \
+    __builtin_amdgcn_sched_barrier(0);                            \
+  }
+    constexpr int A_TAPS = (C::A_ITERS + 1) / 2;  // taps 0 .. A_TAPS-1 issue the patch pieces, two each
+    static_assert(A_TAPS + C::B_ITERS - 1 <= 8, "DMA pieces are issued inside the 9 taps");
+
+    G5_LDW(0, 0);
+    G5_LDP(0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+
+    const bool last_chunk = chunk + 1 == nchunks;
+    const int nlid = last_chunk ? lid + nb : lid;
+    const bool has_next = nlid < t_end;
+    const Tile nxt = (last_chunk && has_next) ? decode(nlid) : cur;
+    const int nchunk = last_chunk ? 0 : chunk + 1;
+    const char *nx_src = nullptr, *nw_src = nullptr;
+    if (has_next) dma_bases(nxt, nchunk, nx_src, nw_src);
+    const bool skip_b = resident && items_done >= 1;  // the NEXT item is this workgroup's third or later
+    __builtin_amdgcn_sched_barrier(0);
+
+    // in flight after each tap's wait (oldest first): see the header
+    G5_TAP(0, G5_WAIT_WP, 4, )               // [W0 P0 | W1]        -> W0, P0 landed
+    G5_TAP(1, G5_WAIT_W, 4, G5_LDP(1, 1))    // [W1 | W2]           -> W1; then P1 requested
+    G5_TAP(2, G5_WAIT_W, R + 4, )            // [W2 | P1 W3]        -> W2
+    G5_TAP(3, G5_WAIT_WP, 4, G5_LDP(2, 0))   // [P1 W3 | W4]        -> P1, W3; then P2 requested (set 0 is free)
+    G5_TAP(4, G5_WAIT_W, R + 4, )            // [W4 | P2 W5]        -> W4
+    G5_TAP(5, G5_WAIT_W, 4, )                // [P2 W5 | W6]        -> W5 (P2, older, has landed too)
+    G5_TAP(6, G5_WAIT_WP, 4, )               // [W6 | W7]           -> W6; names P2's registers (set 0) before their first use
+    G5_TAP(7, G5_WAIT_W, 4, )                // [W7 | W8]           -> W7
+    G5_TAP(8, G5_WAIT_W, 0, )                // [W8]                -> W8
+
+    if (last_chunk) {
+      // ---- tile epilogue: bias, relu, bf16; two 16-byte stores per row and the fused 2x2 max-pool ----
+      const float* bl = reinterpret_cast<const float*>(smem + C::BIAS_OFF + bslot * 256);
+      const int px = cur.x0 + n15;
+      const int py = cur.y0 + MT * wave;
+      const int cofs = cur.co0 + 16 * g;  // first of this lane's 16 consecutive channels
+      float bv[16];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 t4 = *reinterpret_cast<const f32x4*>(bl + 16 * g + 4 * q);
+        bv[4 * q] = t4.x, bv[4 * q + 1] = t4.y, bv[4 * q + 2] = t4.z, bv[4 * q + 3] = t4.w;
+      }
+      auto store16 = [&](char* dst, const float (&u)[16], bool on) {
+        const u32x4 o0 = {pack_bf16x2(u[0], u[1]), pack_bf16x2(u[2], u[3]), pack_bf16x2(u[4], u[5]), pack_bf16x2(u[6], u[7])};
+        const u32x4 o1 = {pack_bf16x2(u[8], u[9]), pack_bf16x2(u[10], u[11]), pack_bf16x2(u[12], u[13]),
+                          pack_bf16x2(u[14], u[15])};
+        if (on) {
+          *reinterpret_cast<u32x4*>(dst) = o0;
+          *reinterpret_cast<u32x4*>(dst + 16) = o1;
+        }
+      };
+      float v[MT][16];
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float s = acc[i][r >> 2][r & 3] + bv[r];
+          v[i][r] = a.relu ? fmaxf(s, 0.f) : s;
+          acc[i][r >> 2][r & 3] = 0.f;
+        }
+      if (a.y != nullptr) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+          store16(a.y + (((int64_t)cur.n * (H + 2) + (py + i + 1)) * Wp + (px + 1)) * Ob + cofs * 2, v[i], true);
+      }
+      if constexpr (MT % 2 == 0) {
+        if (a.pooled != nullptr) {
+          const int Hq = H >> 1, Wq = W >> 1;
+#pragma unroll
+          for (int i = 0; i < MT; i += 2) {
+            float m[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const float t = fmaxf(v[i][r], v[i + 1][r]);
+              m[r] = fmaxf(t, g5_dpp_swap1(t));
+            }
+            // every wave issues these instructions (even lanes store): the counted vmcnt at the next barrier relies on it
+            store16(a.pooled + (((int64_t)cur.n * (Hq + 2) + (((py + i) >> 1) + 1)) * (Wq + 2) + ((px >> 1) + 1)) * Ob + cofs * 2,
+                    m, (lane & 1) == 0);
+          }
+        }
+      }
+      in_flight = nstores;
+      bslot ^= 1;
+    }
+    if (!has_next) break;
+    ++items_done;
+    lid = nlid;
+    cur = nxt;
+    chunk = nchunk;
+    buf ^= 1;
+  }
+#ifdef XV_CLOCK_STAMP
+  XV_CLK_END(xv_clk_g5)
+#endif
+#undef G5_RD
+#undef G5_LDW
+#undef G5_LDP
+#undef G5_WAIT_W
+#undef G5_WAIT_WP
+#undef G5_MFMA
+#undef G5_PIN
+#undef G5_DMA_PIECES
+#undef G5_TAP
+}
+
+template <int MT>
+int g5_launch(const G5Args& a, int grid, hipStream_t stream) {
+  static bool attr_set[XV_MAX_DEVICES] = {false};
+  const hipError_t e = xv_allow_dynamic_lds(reinterpret_cast<const void*>(&conv_dma5_kernel<MT>), G5<MT>::LDS_BYTES, attr_set);
+  if (e != hipSuccess) return (int)e;
+  hipLaunchKernelGGL((conv_dma5_kernel<MT>), dim3((unsigned)grid), dim3(G5<MT>::NT), G5<MT>::LDS_BYTES, stream, a);
+  return xv_launch_status();
+}
+
+}  // namespace
+
+// Does generation 5 take this shape with `mt` rows per wave?  (3x3, whole 32-channel chunks from 64 channels, maps that
+// tile exactly in (8 mt) x 16)
+bool xv_conv3x3_col_ok(int H, int W, int Cin, int Cout, int mt) {
+  return (mt == 3 || mt == 4) && H > 0 && W > 0 && H % (8 * mt) == 0 && (W & 15) == 0 && Cin >= 64 && (Cin & 31) == 0 &&
+         (Cout & 63) == 0;
+}
+
+int xv_launch_conv3x3_col(const void* x, const void* wpk, const float* bias, void* y, void* pooled, int N, int H, int W, int Cin,
+                          int Cout, int relu, int mt, int num_cus, hipStream_t stream) {
+  if (!xv_conv3x3_col_ok(H, W, Cin, Cout, mt) || (y == nullptr && pooled == nullptr) || (pooled != nullptr && (mt & 1)))
+    return XV_ESHAPE;
+  G5Args a{};
+  a.x = (const char*)x;
+  a.wpk = (const char*)wpk;
+  a.bias = bias;
+  a.y = (char*)y;
+  a.pooled = (char*)pooled;
+  a.N = N, a.H = H, a.W = W, a.Cin = Cin, a.Cout = Cout;
+  a.tiles_x = W / 16;
+  a.tiles_y = H / (8 * mt);
+  a.n_ct = Cout / 64;
+  const int64_t ntiles = (int64_t)a.tiles_x * a.tiles_y * N * a.n_ct;
+  if (ntiles <= 0 || ntiles > 0x7fffffff) return XV_ESHAPE;
+  a.n_tiles = (int)ntiles;
+  a.relu = relu;
+  const int grid = num_cus > 0 ? num_cus : 256;
+  return mt == 3 ? g5_launch<3>(a, grid, stream) : g5_launch<4>(a, grid, stream);
+}
+
+#ifdef XV_CLOCK_STAMP
+extern "C" int xv_debug_read_clock_g5(void* dst, size_t bytes) { return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(xv_clk_g5), bytes); }
+extern "C" int xv_debug_reset_clock_g5(void) {
+  static unsigned long long zeros[4 * XV_CLK_SLOTS];
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(xv_clk_g5), zeros, sizeof(zeros));
+}
+#endif

@@ -44,6 +44,10 @@ int xv_launch_conv3x3_f8_dma(const void* x, const void* wpk, const float* bias, 
                              int Cin, int Cout, int relu, int in_f8, int out_f8, int scale_x, float out_mul, int num_cus,
                              hipStream_t stream, float* stats_rows = nullptr, int m16 = 0);
 void xv_launch_pack_weights_f8_g4(const float* w, char* out, int taps, int cin, int cout, float mul, hipStream_t stream);
+// conv_col_dma.hip (generation 5: the generation-4 loop on a column of waves, 24x16 / 32x16 tiles, configurations 27 / 28)
+bool xv_conv3x3_col_ok(int H, int W, int Cin, int Cout, int mt);
+int xv_launch_conv3x3_col(const void* x, const void* wpk, const float* bias, void* y, void* pooled, int N, int H, int W, int Cin,
+                          int Cout, int relu, int mt, int num_cus, hipStream_t stream);
 
 namespace {
 
@@ -1978,7 +1982,9 @@ __global__ void pack_weights_f8_kernel(const float* __restrict__ w, char* __rest
 //      v_mfma_scale_f32_32x32x64_f8f6f4, all operands by LDS-DMA, 151 KB, 1/CU; maps that tile exactly
 //  25: generation 4 on bf16 operands (v_mfma_f32_32x32x16_bf16, 32-channel chunks): bias + relu (+ pool) only
 //  26: as 25 on v_mfma_f32_16x16x32_bf16 at the same output tile per wave (the chip holds a higher clock on this shape)
-constexpr int XV_NUM_CONV_CFG = 27;
+//  27 / 28: generation 5 (conv_col_dma.hip): the loop of 26 on a column of 8 waves x 3 / 4 rows x 16 columns -- 24x16 and
+//      32x16 tiles (the 24x48 conv5 maps tile exactly in 24x16); exact tilings only, fused pool on 28 only
+constexpr int XV_NUM_CONV_CFG = 29;
 struct Geo {
   int th, tw, bn, per_cu;
 };
@@ -1988,7 +1994,7 @@ const Geo kGeo[XV_NUM_CONV_CFG] = {{16, 16, 128, 2}, {8, 16, 128, 2}, {8, 32, 12
                                    {16, 32, 64, 1},  {16, 32, 64, 1},  {16, 16, 64, 2},  {8, 32, 64, 2},
                                    {16, 32, 64, 1},  {16, 32, 64, 1},  {1, 128, 128, 2},
                                    {16, 16, 128, 1}, {8, 32, 128, 1}, {16, 32, 64, 1}, {24, 16, 64, 1}, {1, 64, 64, 4},
-                                   {16, 32, 64, 1},  {16, 32, 64, 1},  {16, 32, 64, 1}};
+                                   {16, 32, 64, 1},  {16, 32, 64, 1},  {16, 32, 64, 1},  {24, 16, 64, 1}, {32, 16, 64, 1}};
 
 template <int KS>
 int launch_cfg(int cfg, const ConvArgs& a, hipStream_t s) {
@@ -2003,6 +2009,11 @@ int launch_cfg(int cfg, const ConvArgs& a, hipStream_t s) {
     if (KS != 3 || a.in_f8 || a.mask != nullptr || a.addend != nullptr) return XV_ESHAPE;
     return xv_launch_conv3x3_f8_dma(a.x, a.wpk, a.bias, a.y, a.pooled, a.N, a.H, a.W, a.Cin, a.Cout, a.relu, 0, a.out_f8, 0,
                                     a.out_mul, a.num_cus, s, nullptr, cfg == 26);
+  }
+  if (cfg == 27 || cfg == 28) {
+    if (KS != 3 || a.in_f8 || a.out_f8 || a.mask != nullptr || a.addend != nullptr) return XV_ESHAPE;
+    return xv_launch_conv3x3_col(a.x, a.wpk, a.bias, a.y, a.pooled, a.N, a.H, a.W, a.Cin, a.Cout, a.relu, cfg == 27 ? 3 : 4,
+                                 a.num_cus, s);
   }
   if (a.in_f8) {
     // the fp8 kernel is built for the tile shapes with LDS-DMA weight stages (the ones the bf16 chooser falls back to)
@@ -2145,6 +2156,11 @@ int pick_cfg(const ConvArgs& a, int k) {
       if (gen4 && a.mask == nullptr && a.addend == nullptr && a.sk_ws == nullptr && !a.in_f8 && !a.out_f8 &&
           xv_conv3x3_dma4_bf16_ok(a.H, a.W, a.Cin, a.Cout) && xv_conv3x3_dma4_exact(a.H, a.W) && (gen4 != 2 || a.Cin >= 128))
         return gen4 == 3 ? 25 : 26;
+      // maps that tile in 24x16 but not in 16x32 (the 24x48 conv5 maps of a 768x384 input): the same loop on a column of
+      // waves, generation 5 -- conv5_1 at 16 images 1 190 against 985 TFLOP/s on generation 2's 24x16 tile (configuration 22)
+      if (gen4 && a.mask == nullptr && a.addend == nullptr && a.sk_ws == nullptr && !a.in_f8 && !a.out_f8 && a.pooled == nullptr &&
+          xv_conv3x3_col_ok(a.H, a.W, a.Cin, a.Cout, 3))
+        return 27;
     }
     int g2 = 17;
     double s2 = 1.25;
@@ -2340,8 +2356,8 @@ extern "C" int xv_conv2d_fwd_stats(const xv_act* x, const void* w_packed, const 
 }
 
 extern "C" size_t xv_deconv_dense_workspace_bytes(int n, int h, int w, int cout, int stride) {
-  if (n <= 0 || h <= 0 || w <= 0 || cout <= 0 || stride <= 0) return 0;
-  return (size_t)n * (h + 2) * (w + 2) * stride * stride * cout * 2;
+  if (!xv_dims_sane(n, h, w) || cout <= 0 || stride <= 0 || stride > 64 || cout > (1 << 20)) return 0;
+  return (size_t)n * ((size_t)h + 2) * ((size_t)w + 2) * stride * stride * cout * 2;
 }
 
 // A k x k / stride s transposed conv with k = 2s ('same': pad (k - s) / 2) is, per output phase (py, px), a 2x2-tap
@@ -2399,6 +2415,34 @@ extern "C" int xv_conv2d_bwd_data_ws(const xv_act* dy, const void* w_packed_dgra
 }
 
 extern "C" int xv_conv2d_num_cfgs(void) { return XV_NUM_CONV_CFG; }
+
+// The tile configuration xv_conv2d_fwd (cfg = -1) / xv_conv2d_bwd_data would choose for this shape, without launching
+// anything (host arithmetic only: the chooser is part of the contract the tests and the sanitizer build check).
+// flags: bit 0 = with a pooled output, bit 1 = data-gradient epilogue (addend / relu mask), bit 2 = with a stream-K workspace.
+extern "C" int xv_conv2d_choose_cfg(int n, int h, int w, int cin, int cout, int k, int in_dtype, int out_dtype, int flags) {
+  XV_CHECK_SHAPE(k == 1 || k == 3);
+  XV_CHECK_SHAPE(xv_dims_sane(n, h, w) && cin > 0 && cout > 0 && (cin & 63) == 0 && (cout & 63) == 0);
+  XV_CHECK_ARG((in_dtype == XV_BF16 || in_dtype == XV_FP8) && (out_dtype == XV_BF16 || out_dtype == XV_FP8));
+  static const __bf16 sentinel[8] = {};
+  static char sk_sentinel[16];
+  ConvArgs a{};
+  a.N = n, a.H = h, a.W = w, a.Cin = cin, a.Cout = cout;
+  a.relu = 1;
+  a.num_cus = xv_num_cus();
+  a.in_f8 = in_dtype == XV_FP8, a.out_f8 = out_dtype == XV_FP8;
+  if (a.in_f8) XV_CHECK_SHAPE((cin & (k == 3 ? 63 : 127)) == 0);
+  if (flags & 1) {
+    XV_CHECK_SHAPE(k == 3 && (h & 1) == 0 && (w & 1) == 0);
+    a.pooled = const_cast<__bf16*>(sentinel);
+  }
+  if (flags & 2) {
+    XV_CHECK_SHAPE(!a.in_f8 && !a.out_f8);
+    a.mask = sentinel, a.addend = sentinel;
+  }
+  if (flags & 4) a.sk_ws = sk_sentinel;
+  const int cfg = pick_cfg(a, k);
+  return cfg < 0 ? XV_ESHAPE : cfg;
+}
 
 #ifdef XV_CONV_TRACE
 extern "C" int xv_debug_read_trace(void* dst, size_t bytes) {

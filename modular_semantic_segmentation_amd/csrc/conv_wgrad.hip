@@ -557,12 +557,12 @@ static int wgrad_splits(int k, int pairs, int n_ptiles) {
 }
 
 extern "C" size_t xv_conv2d_bwd_filter_workspace_bytes(int n, int h, int w, int cin, int cout, int k) {
-  if (n <= 0 || h <= 0 || w <= 0 || cin <= 0 || cout <= 0 || (cin & 63) || (cout & 63) || (k != 1 && k != 3)) return 0;
-  const int64_t ptiles = (int64_t)((w + 31) / 32) * ((h + 7) / 8) * n;
-  const int pairs = (cin >> 6) * (cout >> 6);
+  if (!xv_dims_sane(n, h, w) || cin <= 0 || cout <= 0 || (cin & 63) || (cout & 63) || (k != 1 && k != 3)) return 0;
+  const int64_t ptiles = (((int64_t)w + 31) / 32) * (((int64_t)h + 7) / 8) * n;
+  const int64_t pairs = (int64_t)(cin >> 6) * (cout >> 6);
   // upper bound over both kernel variants
-  int sp = (3 * xv_num_cus() + pairs - 1) / pairs;
-  if (sp > ptiles) sp = (int)ptiles;
+  int64_t sp = (3 * (int64_t)xv_num_cus() + pairs - 1) / pairs;
+  if (sp > ptiles) sp = ptiles;
   if (sp < 1) sp = 1;
   return (size_t)sp * ((size_t)k * k * cin * cout + cout) * sizeof(float);  // dW slabs + bias slabs
 }

@@ -1206,8 +1206,8 @@ extern "C" int xv_decoder_head_affine_fwd(const xv_act* fused, const float* scal
 }
 
 extern "C" size_t xv_decoder_head_workspace_bytes(int n, int h, int w, int num_classes) {
-  if (n <= 0 || h <= 0 || w <= 0 || num_classes < 1 || num_classes > 32) return 0;
-  return (size_t)n * (h + 2) * (w + 2) * ((num_classes + 3) / 4 * 4) * sizeof(float);
+  if (!xv_dims_sane(n, h, w) || num_classes < 1 || num_classes > 32) return 0;
+  return (size_t)n * ((size_t)h + 2) * ((size_t)w + 2) * ((num_classes + 3) / 4 * 4) * sizeof(float);
 }
 
 extern "C" int xv_decoder_head_fwd(const xv_act* fused, const float* w_score, const float* b_score, int num_classes,

@@ -68,6 +68,15 @@ static inline hipError_t xv_allow_dynamic_lds(const void* kernel, int bytes, boo
   return e;
 }
 
+// A map this library can address at all: positive dimensions, fewer than 2^31 padded rows and 2^36 padded pixels (64 G
+// pixels: beyond any 288 GB buffer).  The size calculators return 0 and the choosers XV_ESHAPE past it, so that their
+// 64-bit arithmetic cannot overflow (tools/asan_host_check.py fuzzes them under UBSan).
+static inline bool xv_dims_sane(int n, int h, int w) {
+  if (n <= 0 || h <= 0 || w <= 0) return false;
+  const int64_t rows = (int64_t)n * ((int64_t)h + 2);
+  return rows < ((int64_t)1 << 31) && rows * ((int64_t)w + 2) < ((int64_t)1 << 36);
+}
+
 // padded-NHWC geometry helpers
 __host__ __device__ static inline int64_t xv_row_pitch(int w, int c) { return (int64_t)(w + 2) * c; }
 __host__ __device__ static inline int64_t xv_img_pitch(int h, int w, int c) {

@@ -229,6 +229,15 @@ def compare(hip, ref, labels):
         res[m].update(logit_max_abs_err=round(err, 5), logit_scale=round(scale, 3),
                       logit_rel_err=round(err / scale, 6), clear_margin_fraction=round(float(clear.mean()), 5),
                       label_agreement_clear_margin=round(float((hip[m][clear] == ref[m][clear]).mean()), 6))
+        # what the fixed mask leaves out (it covers 0.1 % of the depth expert's pixels): agreement on the
+        # COMPLEMENT of the mask, and a second mask from the MEASURED worst error -- a label can only differ where the fp32 top-2
+        # margin is below the sum of the two logits' errors, so agreement there is 1.0 for any correct kernel and its size
+        # says how much of the map the logit bound pins
+        near = ~clear
+        tight = (top2[..., 1] - top2[..., 0]) > 2 * err
+        res[m].update(label_agreement_inside_margin=round(float((hip[m][near] == ref[m][near]).mean()) if near.any() else 1.0, 6),
+                      measured_margin_fraction=round(float(tight.mean()), 5),
+                      label_agreement_measured_margin=round(float((hip[m][tight] == ref[m][tight]).mean()) if tight.any() else 1.0, 6))
     return res
 
 

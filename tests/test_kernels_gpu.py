@@ -98,7 +98,8 @@ def test_conv2d_every_tile_configuration(ops, k):
         except _lib.XvError:
             # generation 2 / 2b: 3x3 only, generation 3: 1x1 only, its narrow form: 1x1 onto 64 channels only
             # generation 4: 3x3 only; 24 takes e4m3 maps only
-            assert (cfg in (17, 21, 22, 25, 26) and k == 1) or (cfg == 18 and k == 3) or cfg in (23, 24)
+            # generation 5 (27 / 28): 3x3 on maps that tile exactly in 24x16 / 32x16 only
+            assert (cfg in (17, 21, 22, 25, 26) and k == 1) or (cfg == 18 and k == 3) or cfg in (23, 24, 27, 28)
             continue
         ran += 1
         torch.cuda.synchronize()
@@ -222,6 +223,49 @@ def test_conv2d_generation4_bf16(ops, shape, cfg):
     yn, _ = ops.conv2d_fwd(xa, wp, bd, 3, relu=False, cfg=cfg)
     torch.cuda.synchronize()
     assert np.array_equal(yn.interior().float().cpu().numpy(), refn)
+
+
+@pytest.mark.parametrize('shape,cfg', [((16, 24, 48, 512, 512), 27), ((1, 24, 16, 64, 64), 27), ((3, 48, 32, 128, 192), 27),
+                                       ((40, 24, 48, 64, 128), 27), ((2, 72, 16, 192, 64), 27),
+                                       ((1, 32, 16, 64, 64), 28), ((2, 64, 48, 128, 128), 28), ((5, 96, 192, 64, 128), 28),
+                                       ((3, 32, 64, 256, 192), 28), ((30, 32, 32, 64, 64), 28)])
+def test_conv2d_generation5_column_tiles(ops, shape, cfg):
+    """Configurations 27 / 28 (conv_dma5_kernel<3 / 4>, conv_col_dma.hip: the generation-4 loop on a column of 8 waves x 3 / 4
+    rows x 16 columns; 24x16 tiles cover the 24x48 conv5 maps exactly) against the oracle, bit for bit on integer operands:
+    full output, no relu, untouched border, one to many tiles per workgroup, one- and two-chunk layers with resident
+    weights; 28 also the fused pool and the pooled-only launch; 27 refuses a pooled output, both refuse maps that do not tile."""
+    from modular_semantic_segmentation_amd import _lib
+    n, h, w, cin, cout = shape
+    rng = np.random.default_rng(sum(shape) + cfg)
+    x = rng.integers(-2, 3, (n, h, w, cin)).astype(np.float32)
+    wt = rng.integers(-1, 2, (3, 3, cin, cout)).astype(np.float32)
+    b = rng.integers(-3, 4, cout).astype(np.float32)
+    xa, wp, bd = ops.Act.from_dense(_dev(x)), ops.pack_conv_weights(_dev(wt)), _dev(b)
+    y32, ref = _conv_oracle(x, wt, b, True, 3)
+    y, _ = ops.conv2d_fwd(xa, wp, bd, 3, relu=True, cfg=cfg)
+    torch.cuda.synchronize()
+    assert np.array_equal(y.interior().float().cpu().numpy(), ref)
+    full = y.t.float().cpu().numpy()
+    assert np.all(full[:, 0] == 0) and np.all(full[:, -1] == 0) and np.all(full[:, :, 0] == 0) and np.all(full[:, :, -1] == 0)
+    _, refn = _conv_oracle(x, wt, b, False, 3)
+    yn, _ = ops.conv2d_fwd(xa, wp, bd, 3, relu=False, cfg=cfg)
+    torch.cuda.synchronize()
+    assert np.array_equal(yn.interior().float().cpu().numpy(), refn)
+    if cfg == 28:
+        refq = fo.round_bf16(fo.maxpool2(y32)).permute(0, 2, 3, 1).numpy()
+        q = ops.Act(n, h // 2, w // 2, cout)
+        y2, _ = ops.conv2d_fwd(xa, wp, bd, 3, relu=True, pooled=q, cfg=cfg)
+        q2 = ops.Act(n, h // 2, w // 2, cout)
+        ops.conv2d_fwd(xa, wp, bd, 3, relu=True, pooled=q2, write_y=False, cfg=cfg)
+        torch.cuda.synchronize()
+        assert torch.equal(y2.t, y.t)
+        assert np.array_equal(q.interior().float().cpu().numpy(), refq) and torch.equal(q2.t, q.t)
+    else:
+        with pytest.raises(_lib.XvError):
+            ops.conv2d_fwd(xa, wp, bd, 3, relu=True, pooled=ops.Act(n, h // 2, w // 2, cout), cfg=cfg)
+    xs = ops.Act.from_dense(_dev(x[:, :h - 8]))
+    with pytest.raises(_lib.XvError):
+        ops.conv2d_fwd(xs, wp, bd, 3, relu=True, cfg=cfg)          # 8 rows short of a tiling
 
 
 @pytest.mark.parametrize('shape', [(2, 24, 48, 512, 128), (1, 24, 16, 64, 64), (3, 30, 40, 128, 64), (2, 48, 20, 64, 192),

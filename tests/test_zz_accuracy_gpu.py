@@ -40,6 +40,12 @@ def test_miou_of_hip_path_matches_fp32_oracle_on_trained_experts():
         assert acc[m]['label_agreement_clear_margin'] == 1.0, (m, acc[m])
         assert acc[m]['clear_margin_fraction'] > 0, (m, acc[m])         # (the mask is not empty; its size is a property of the net:
         #                                                                  0.3 % of the depth expert's pixels, 97 % of the RGB expert's)
+        # ... so the fixed mask alone says little about the depth expert.  Beside it: labels identical on every pixel whose
+        # fp32 margin exceeds twice the MEASURED worst logit error (true for any kernel whose logits are that close; the mask
+        # must cover most of the map for the logit bound to mean something), and agreement on the complement of the fixed mask
+        assert acc[m]['label_agreement_measured_margin'] == 1.0, (m, acc[m])
+        assert acc[m]['measured_margin_fraction'] > 0.5, (m, acc[m])
+        assert acc[m]['label_agreement_inside_margin'] > 0.99, (m, acc[m])
     for m in ('rgb', 'depth', 'bayes', 'dirichlet'):
         assert abs(acc[m]['delta_miou_pp']) <= 0.1, (m, acc[m])
         assert acc[m]['label_agreement'] > 0.995, (m, acc[m])

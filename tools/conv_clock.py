@@ -69,7 +69,7 @@ def main():
         cfg = int(cfg)
         s, cin, cout, pool = LAYERS[name]
         h, w = args.height // s, args.width // s
-        gen = 4 if cfg in (24, 25, 26) else 2
+        gen = 5 if cfg in (27, 28) else (4 if cfg in (24, 25, 26) else 2)
         for data in args.data.split(','):
             torch.manual_seed(0)
             x = ops.Act(args.batch, h, w, cin)
@@ -83,7 +83,7 @@ def main():
             wp = ops.pack_conv_weights(wt)
             b = torch.zeros(cout, device='cuda')
             y = ops.Act(args.batch, h, w, cout)
-            q = ops.Act(args.batch, h // 2, w // 2, cout) if (pool and cfg != 22) else None
+            q = ops.Act(args.batch, h // 2, w // 2, cout) if (pool and cfg not in (22, 27)) else None
             try:
                 ops.conv2d_fwd(x, wp, b, 3, y=y, pooled=q, cfg=cfg)
             except _lib.XvError:
