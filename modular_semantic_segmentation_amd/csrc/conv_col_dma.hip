@@ -17,7 +17,7 @@
 //     every column offset), the packed weight image (the FOURTH image of xv_pack_conv_weights: rows permuted so that a
 //     lane's 16 accumulators of a pixel are 16 consecutive channels) and the epilogue are generation 4's 16x16 form.
 //   * Fragment schedule (reads return in order; at most 4 + (MT + 2) + 4 = 14 in flight, the counter holds 15):
-//       before tap 0: W0 P0 | tap t: W(t+1), wait, [P of the next column group at taps 1 and 3], MFMAs.
+//       before tap 0: bias W0 P0 | tap 0: wait, W1 | tap t: W(t+1), wait, [P of the next column group at taps 1 and 3], MFMAs.
 //   * Exact tilings only (H % (8 MT) == 0, W % 16 == 0); fused 2x2 max-pool for even MT; bias + relu, no addend / mask.
 #include "xv_common.h"
 
@@ -53,10 +53,6 @@ struct G5 {
 };
 
 __device__ __forceinline__ int g5_swz(int row, int slot) { return slot ^ ((row >> 1) & 2); }  // = g4_swz16
-
-__device__ __forceinline__ float g5_dpp_swap1(float v) {  // value of lane ^ 1 (quad_perm [1,0,3,2])
-  return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));
-}
 
 #ifdef XV_CLOCK_STAMP
 __device__ unsigned long long xv_clk_g5[4 * XV_CLK_SLOTS];
@@ -225,16 +221,22 @@ __global__ __launch_bounds__(512, 2) void conv_dma5_kernel(G5Args a) {
                  : "+v"(wf[ws][0]), "+v"(wf[ws][1]), "+v"(wf[ws][2]), "+v"(wf[ws][3]), "+v"(xf[ps][0]), "+v"(xf[ps][1]), \
                    "+v"(xf[ps][2]), "+v"(xf[ps][3]), "+v"(xf[ps][4]), "+v"(xf[ps][5])                                  \
                  : "n"(n))
-#define G5_MFMA(i, ws, ps, dy)                                                                                       \
+#define G5_C_ACC(i, j) acc[i][j]
+    // first tap of a tile: the accumulation STARTS from the bias (lane's channels 16 g + 4 j + q) -- no bias add and no
+    // accumulator clearing in the epilogue (conv_f8_dma.hip, 16x16 form)
+#define G5_C_BIAS(i, j) __builtin_bit_cast(f32x4, bvec[j])
+#define G5_MFMA(i, ws, ps, dy) G5_MFMA_C(i, ws, ps, dy, G5_C_ACC)
+#define G5_MFMA_B(i, ws, ps, dy) G5_MFMA_C(i, ws, ps, dy, G5_C_BIAS)
+#define G5_MFMA_C(i, ws, ps, dy, CS)                                                                                 \
   {                                                                                                                  \
     acc[i][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[ws][0]),                       \
-                                                        __builtin_bit_cast(bf16x8, xf[ps][(i) + (dy)]), acc[i][0], 0, 0, 0); \
+                                                        __builtin_bit_cast(bf16x8, xf[ps][(i) + (dy)]), CS(i, 0), 0, 0, 0); \
     acc[i][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[ws][1]),                       \
-                                                        __builtin_bit_cast(bf16x8, xf[ps][(i) + (dy)]), acc[i][1], 0, 0, 0); \
+                                                        __builtin_bit_cast(bf16x8, xf[ps][(i) + (dy)]), CS(i, 1), 0, 0, 0); \
     acc[i][2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[ws][2]),                       \
-                                                        __builtin_bit_cast(bf16x8, xf[ps][(i) + (dy)]), acc[i][2], 0, 0, 0); \
+                                                        __builtin_bit_cast(bf16x8, xf[ps][(i) + (dy)]), CS(i, 2), 0, 0, 0); \
     acc[i][3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[ws][3]),                       \
-                                                        __builtin_bit_cast(bf16x8, xf[ps][(i) + (dy)]), acc[i][3], 0, 0, 0); \
+                                                        __builtin_bit_cast(bf16x8, xf[ps][(i) + (dy)]), CS(i, 3), 0, 0, 0); \
   }
     // An MFMA is a pure value to the optimizer: an empty volatile asm that "modifies" its accumulators pins the MFMAs that
     // produced them in front of every later asm statement (reads, waits, priority changes), as in generation 4.
@@ -248,21 +250,37 @@ __global__ __launch_bounds__(512, 2) void conv_dma5_kernel(G5Args a) {
     if ((t) >= A_TAPS && (t) - A_TAPS < C::B_ITERS && !skip_b) dma_b(nw_src, (t) - A_TAPS, buf ^ 1);  \
     if ((t) == A_TAPS) dma_bias(nxt, last_chunk, bslot ^ 1);                                          \
   }
-#define G5_TAP(t, WAIT, NEWER, POST)                              \
+#define G5_TAP(t, WAIT, NEWER, POST)   \
+  {                                    \
+    G5_TAP_HEAD(t, WAIT, NEWER, POST)  \
+    G5_TAP_BODY(t, G5_MFMA)            \
+  }
+#define G5_TAP_HEAD(t, WAIT, NEWER, POST)                         \
   {                                                               \
-    constexpr int dx_ = (t) / 3, dy_ = (t) % 3;                   \
     if constexpr ((t) + 1 < 9) G5_LDW((t) + 1, ((t) + 1) & 1);    \
     G5_DMA_PIECES(t)                                              \
-    WAIT(NEWER, (t) & 1, dx_ & 1);                                \
+    WAIT(NEWER, (t) & 1, ((t) / 3) & 1);                          \
     POST;                                                         \
     __builtin_amdgcn_sched_barrier(0);                            \
-    G5_MFMA(0, (t) & 1, dx_ & 1, dy_);                            \
+  }
+    // tap 0: bias + W0 + P0 = 4 + 4 + (MT + 2) <= 14 reads in flight; W1 only behind the wait for them
+#define G5_TAP_HEAD0(WAIT)                                        \
+  {                                                               \
+    G5_DMA_PIECES(0)                                              \
+    WAIT(0, 0, 0);                                                \
+    G5_LDW(1, 1);                                                 \
+    __builtin_amdgcn_sched_barrier(0);                            \
+  }
+#define G5_TAP_BODY(t, MF)                                        \
+  {                                                               \
+    constexpr int dx_ = (t) / 3, dy_ = (t) % 3;                   \
+    MF(0, (t) & 1, dx_ & 1, dy_);                                 \
     G5_PIN(0);                                                    \
     __builtin_amdgcn_s_setprio(2);                                \
     __builtin_amdgcn_sched_barrier(0);                            \
-    G5_MFMA(1, (t) & 1, dx_ & 1, dy_);                            \
-    G5_MFMA(2, (t) & 1, dx_ & 1, dy_);                            \
-    if constexpr (MT > 3) G5_MFMA(3, (t) & 1, dx_ & 1, dy_);      \
+    MF(1, (t) & 1, dx_ & 1, dy_);                                 \
+    MF(2, (t) & 1, dx_ & 1, dy_);                                 \
+    if constexpr (MT > 3) MF(3, (t) & 1, dx_ & 1, dy_);           \
     G5_PIN(1);                                                    \
     G5_PIN(2);                                                    \
     if constexpr (MT > 3) G5_PIN(3);                              \
@@ -273,6 +291,16 @@ __global__ __launch_bounds__(512, 2) void conv_dma5_kernel(G5Args a) {
     constexpr int A_TAPS = (C::A_ITERS + 1) / 2;  // taps 0 .. A_TAPS-1 issue the patch pieces, two each
     static_assert(A_TAPS + C::B_ITERS - 1 <= 8, "DMA pieces are issued inside the 9 taps");
 
+    // the lane's 16 bias values of this tile as four accumulator-shaped registers: read in every item (before everything
+    // else: tap 0's wait covers them), used by the first tap of a tile's first item
+    u32x4 bvec[4];
+    {
+      const int ba = C::BIAS_OFF + bslot * 256 + 64 * g;
+      G5_RD(bvec[0], ba, 0);
+      G5_RD(bvec[1], ba, 16);
+      G5_RD(bvec[2], ba, 32);
+      G5_RD(bvec[3], ba, 48);
+    }
     G5_LDW(0, 0);
     G5_LDP(0, 0);
     __builtin_amdgcn_sched_barrier(0);
@@ -288,7 +316,13 @@ __global__ __launch_bounds__(512, 2) void conv_dma5_kernel(G5Args a) {
     __builtin_amdgcn_sched_barrier(0);
 
     // in flight after each tap's wait (oldest first): see the header
-    G5_TAP(0, G5_WAIT_WP, 4, )               // [W0 P0 | W1]        -> W0, P0 landed
+    G5_TAP_HEAD0(G5_WAIT_WP)                 // [bias W0 P0]        -> all landed; then W1 requested
+    asm volatile("" : "+v"(bvec[0]), "+v"(bvec[1]), "+v"(bvec[2]), "+v"(bvec[3]));
+    if (chunk == 0) {
+      G5_TAP_BODY(0, G5_MFMA_B)
+    } else {
+      G5_TAP_BODY(0, G5_MFMA)
+    }
     G5_TAP(1, G5_WAIT_W, 4, G5_LDP(1, 1))    // [W1 | W2]           -> W1; then P1 requested
     G5_TAP(2, G5_WAIT_W, R + 4, )            // [W2 | P1 W3]        -> W2
     G5_TAP(3, G5_WAIT_WP, 4, G5_LDP(2, 0))   // [P1 W3 | W4]        -> P1, W3; then P2 requested (set 0 is free)
@@ -300,53 +334,56 @@ __global__ __launch_bounds__(512, 2) void conv_dma5_kernel(G5Args a) {
 
     if (last_chunk) {
       // ---- tile epilogue: bias, relu, bf16; two 16-byte stores per row and the fused 2x2 max-pool ----
-      const float* bl = reinterpret_cast<const float*>(smem + C::BIAS_OFF + bslot * 256);
       const int px = cur.x0 + n15;
       const int py = cur.y0 + MT * wave;
       const int cofs = cur.co0 + 16 * g;  // first of this lane's 16 consecutive channels
-      float bv[16];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const f32x4 t4 = *reinterpret_cast<const f32x4*>(bl + 16 * g + 4 * q);
-        bv[4 * q] = t4.x, bv[4 * q + 1] = t4.y, bv[4 * q + 2] = t4.z, bv[4 * q + 3] = t4.w;
-      }
-      auto store16 = [&](char* dst, const float (&u)[16], bool on) {
-        const u32x4 o0 = {pack_bf16x2(u[0], u[1]), pack_bf16x2(u[2], u[3]), pack_bf16x2(u[4], u[5]), pack_bf16x2(u[6], u[7])};
-        const u32x4 o1 = {pack_bf16x2(u[8], u[9]), pack_bf16x2(u[10], u[11]), pack_bf16x2(u[12], u[13]),
-                          pack_bf16x2(u[14], u[15])};
-        if (on) {
-          *reinterpret_cast<u32x4*>(dst) = o0;
-          *reinterpret_cast<u32x4*>(dst + 16) = o1;
-        }
-      };
-      float v[MT][16];
+      // PACKED epilogue (as generation 4's 16x16 form): bias add in fp32, one v_cvt_pk_bf16_f32 per channel pair, relu and
+      // the 2x2 max on the packed pairs as signed 16-bit integers -- 2-3 VALU instructions per value instead of ~10
+      uint32_t pk[MT][8];
 #pragma unroll
       for (int i = 0; i < MT; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const float s = acc[i][r >> 2][r & 3] + bv[r];
-          v[i][r] = a.relu ? fmaxf(s, 0.f) : s;
-          acc[i][r >> 2][r & 3] = 0.f;
+        for (int k = 0; k < 8; ++k) {  // channels 2 k, 2 k + 1 of the lane's 16 (r = 4 j + q)
+          const int r0 = 2 * k, r1 = 2 * k + 1;
+          // (the bias is already inside: the tile's first MFMAs started from it; nothing to clear either)
+          pk[i][k] = pack_bf16x2(acc[i][r0 >> 2][r0 & 3], acc[i][r1 >> 2][r1 & 3]);
         }
       if (a.y != nullptr) {
+        const uint32_t rfloor = a.relu ? 0u : 0x80008000u;  // (0x8000 = the smallest int16: a no-op)
 #pragma unroll
-        for (int i = 0; i < MT; ++i)
-          store16(a.y + (((int64_t)cur.n * (H + 2) + (py + i + 1)) * Wp + (px + 1)) * Ob + cofs * 2, v[i], true);
+        for (int i = 0; i < MT; ++i) {
+#pragma unroll
+          for (int k = 0; k < 8; ++k) pk[i][k] = pk_max_i16(pk[i][k], rfloor);
+          char* dst = a.y + (((int64_t)cur.n * (H + 2) + (py + i + 1)) * Wp + (px + 1)) * Ob + cofs * 2;
+          *reinterpret_cast<u32x4*>(dst) = u32x4{pk[i][0], pk[i][1], pk[i][2], pk[i][3]};
+          *reinterpret_cast<u32x4*>(dst + 16) = u32x4{pk[i][4], pk[i][5], pk[i][6], pk[i][7]};
+        }
       }
       if constexpr (MT % 2 == 0) {
         if (a.pooled != nullptr) {
           const int Hq = H >> 1, Wq = W >> 1;
 #pragma unroll
           for (int i = 0; i < MT; i += 2) {
-            float m[16];
+            uint32_t m[8];
+            if (a.relu) {  // max over the 2x2 block, relu once on the result (see conv_f8_dma.hip)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-              const float t = fmaxf(v[i][r], v[i + 1][r]);
-              m[r] = fmaxf(t, g5_dpp_swap1(t));
+              for (int k = 0; k < 8; ++k) {
+                const uint32_t t = pk_max_i16(pk[i][k], pk[i + 1][k]);
+                m[k] = pk_max_i16(pk_max_i16(t, pk_dpp_swap1(t)), 0u);
+              }
+            } else {
+#pragma unroll
+              for (int k = 0; k < 8; ++k) {
+                const uint32_t t = pk_max_i16(pk_ord_bf16(pk[i][k]), pk_ord_bf16(pk[i + 1][k]));
+                m[k] = pk_ord_bf16(pk_max_i16(t, pk_dpp_swap1(t)));
+              }
             }
             // every wave issues these instructions (even lanes store): the counted vmcnt at the next barrier relies on it
-            store16(a.pooled + (((int64_t)cur.n * (Hq + 2) + (((py + i) >> 1) + 1)) * (Wq + 2) + ((px >> 1) + 1)) * Ob + cofs * 2,
-                    m, (lane & 1) == 0);
+            char* dst = a.pooled + (((int64_t)cur.n * (Hq + 2) + (((py + i) >> 1) + 1)) * (Wq + 2) + ((px >> 1) + 1)) * Ob + cofs * 2;
+            if ((lane & 1) == 0) {
+              *reinterpret_cast<u32x4*>(dst) = u32x4{m[0], m[1], m[2], m[3]};
+              *reinterpret_cast<u32x4*>(dst + 16) = u32x4{m[4], m[5], m[6], m[7]};
+            }
           }
         }
       }
@@ -369,6 +406,13 @@ __global__ __launch_bounds__(512, 2) void conv_dma5_kernel(G5Args a) {
 #undef G5_WAIT_W
 #undef G5_WAIT_WP
 #undef G5_MFMA
+#undef G5_MFMA_B
+#undef G5_MFMA_C
+#undef G5_C_ACC
+#undef G5_C_BIAS
+#undef G5_TAP_HEAD
+#undef G5_TAP_HEAD0
+#undef G5_TAP_BODY
 #undef G5_PIN
 #undef G5_DMA_PIECES
 #undef G5_TAP

@@ -59,6 +59,19 @@ struct F8Args {
 __device__ unsigned long long xv_clk_g4[4 * XV_CLK_SLOTS];
 #endif
 
+#ifdef XV_CONV_TRACE
+// debug build only (`make trace`, tools/conv_trace.py --gen 4): per work item four cycle stamps of every wave of every 32nd
+// workgroup, kept in spare LDS during the kernel (a global store per stamp would sit in the vmcnt queue this kernel counts on)
+__device__ long long xv_trace_buf4[8 * 8 * 32 * 4];
+#define G4_TRACE_LDS 8192
+#define G4_STAMP(k)                                                                   \
+  if (!STATS && (blockIdx.x & 31) == 0 && trace_item < 32 && lane == 0)               \
+    reinterpret_cast<long long*>(smem + C::LDS_BYTES)[(wave * 32 + trace_item) * 4 + (k)] = __builtin_readcyclecounter();
+#else
+#define G4_TRACE_LDS 0
+#define G4_STAMP(k)
+#endif
+
 struct G4 {
   static constexpr int NWAVES = 8, NT = 512;
   static constexpr int TH = 16, TW = 32, HH = TH + 2, HW = TW + 2, NPIX = HH * HW;
@@ -287,7 +300,11 @@ __global__ __launch_bounds__(512, 2) void conv_dma4_kernel(F8Args a) {
   int in_flight = 0;  // stores issued after the last DMA of the previous item
 
   XV_CLK_BEGIN()
+#ifdef XV_CONV_TRACE
+  int trace_item = 0;
+#endif
   while (true) {
+    G4_STAMP(0)  // arrival at the item barrier
     // This item's operands have landed (each wave retires its own DMA; the tile stores issued after it may stay in
     // flight: vmcnt counts in issue order), and every wave has finished reading the other buffer pair.
     if (in_flight == 12)
@@ -303,6 +320,7 @@ __global__ __launch_bounds__(512, 2) void conv_dma4_kernel(F8Args a) {
     else
       asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
     in_flight = 0;
+    G4_STAMP(1)  // barrier passed
 
     const int pb0[3] = {pbase0[0] + buf * C::A_BYTES, pbase0[1] + buf * C::A_BYTES, pbase0[2] + buf * C::A_BYTES};
     const int pb1[3] = {pbase1[0] + buf * C::A_BYTES, pbase1[1] + buf * C::A_BYTES, pbase1[2] + buf * C::A_BYTES};
@@ -353,7 +371,13 @@ __global__ __launch_bounds__(512, 2) void conv_dma4_kernel(F8Args a) {
                  "+v"(xf[ps][2][1]), "+v"(xf[ps][3][0]), "+v"(xf[ps][3][1])                                           \
                : "n"(n))
 #define G4_CAT(lo, hi) i32x8{(int)(lo).x, (int)(lo).y, (int)(lo).z, (int)(lo).w, (int)(hi).x, (int)(hi).y, (int)(hi).z, (int)(hi).w}
-#define G4_MFMA(i, j, ws, ps, dy)                                                                                      \
+#define G4_C_ACC(i, j, h, jj) acc4[i][j][h][jj]
+    // first tap of a tile (M16): the accumulation STARTS from the bias (lane's channels 16 g + 4 (2 j + jj) + q) -- no bias add and
+    // no accumulator clearing in the epilogue (128 of its ~230 VALU instructions per lane)
+#define G4_C_BIAS(i, j, h, jj) __builtin_bit_cast(f32x4, bvec[2 * (j) + (jj)])
+#define G4_MFMA(i, j, ws, ps, dy) G4_MFMA_C(i, j, ws, ps, dy, G4_C_ACC)
+#define G4_MFMA_B(i, j, ws, ps, dy) G4_MFMA_C(i, j, ws, ps, dy, G4_C_BIAS)
+#define G4_MFMA_C(i, j, ws, ps, dy, CS)                                                                                \
   if constexpr (F8) {                                                                                                  \
     acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(G4_CAT(wf[ws][j][0], wf[ws][j][1]),                    \
                                                                 G4_CAT(xf[ps][(i) + (dy)][0], xf[ps][(i) + (dy)][1]),  \
@@ -361,13 +385,13 @@ __global__ __launch_bounds__(512, 2) void conv_dma4_kernel(F8Args a) {
   } else if constexpr (M16) {                                                                                          \
     /* wf[ws][j][jj]: channel block 2 j + jj; xf[ps][row][h]: pixel half h */                                          \
     acc4[i][j][0][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[ws][j][0]),               \
-                                                               __builtin_bit_cast(bf16x8, xf[ps][(i) + (dy)][0]), acc4[i][j][0][0], 0, 0, 0); \
+                                                               __builtin_bit_cast(bf16x8, xf[ps][(i) + (dy)][0]), CS(i, j, 0, 0), 0, 0, 0); \
     acc4[i][j][0][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[ws][j][1]),               \
-                                                               __builtin_bit_cast(bf16x8, xf[ps][(i) + (dy)][0]), acc4[i][j][0][1], 0, 0, 0); \
+                                                               __builtin_bit_cast(bf16x8, xf[ps][(i) + (dy)][0]), CS(i, j, 0, 1), 0, 0, 0); \
     acc4[i][j][1][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[ws][j][0]),               \
-                                                               __builtin_bit_cast(bf16x8, xf[ps][(i) + (dy)][1]), acc4[i][j][1][0], 0, 0, 0); \
+                                                               __builtin_bit_cast(bf16x8, xf[ps][(i) + (dy)][1]), CS(i, j, 1, 0), 0, 0, 0); \
     acc4[i][j][1][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[ws][j][1]),               \
-                                                               __builtin_bit_cast(bf16x8, xf[ps][(i) + (dy)][1]), acc4[i][j][1][1], 0, 0, 0); \
+                                                               __builtin_bit_cast(bf16x8, xf[ps][(i) + (dy)][1]), CS(i, j, 1, 1), 0, 0, 0); \
   } else {                                                                                                             \
     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf[ws][j][0]),                      \
                                                         __builtin_bit_cast(bf16x8, xf[ps][(i) + (dy)][0]), acc[i][j], 0, 0, 0); \
@@ -392,21 +416,39 @@ __global__ __launch_bounds__(512, 2) void conv_dma4_kernel(F8Args a) {
     asm volatile("" : "+v"(acc4[i][j][0][0]), "+v"(acc4[i][j][0][1]), "+v"(acc4[i][j][1][0]), "+v"(acc4[i][j][1][1])); \
   else                                                                                                                \
     asm volatile("" : "+v"(acc[i][j]))
-#define G4_TAP(t, WAIT, NEWER, POST)                              \
+#define G4_TAP(t, WAIT, NEWER, POST) \
+  {                                  \
+    G4_TAP_HEAD(t, WAIT, NEWER, POST) \
+    G4_TAP_BODY(t, G4_MFMA)          \
+  }
+#define G4_TAP_HEAD(t, WAIT, NEWER, POST)                         \
   {                                                               \
-    constexpr int dx_ = (t) / 3, dy_ = (t) % 3;                   \
     if constexpr ((t) + 1 < 9) G4_LDW((t) + 1, ((t) + 1) & 1);    \
     G4_DMA_PIECES(t)                                              \
-    WAIT(NEWER, (t) & 1, dx_ & 1);                                \
+    WAIT(NEWER, (t) & 1, ((t) / 3) & 1);                          \
     POST;                                                         \
     __builtin_amdgcn_sched_barrier(0);                            \
-    G4_MFMA(0, 0, (t) & 1, dx_ & 1, dy_);                         \
+  }
+    // tap 0: the item starts with bias (M16) + W0 + Pa0 = 12 reads in flight; W1 is requested only behind the wait for
+    // them (with it in front the counter would have to hold 16: it holds 15), and has all of tap 0's MFMAs to land
+#define G4_TAP_HEAD0(WAIT, POST)                                  \
+  {                                                               \
+    G4_DMA_PIECES(0)                                              \
+    WAIT(0, 0, 0);                                                \
+    G4_LDW(1, 1);                                                 \
+    POST;                                                         \
+    __builtin_amdgcn_sched_barrier(0);                            \
+  }
+#define G4_TAP_BODY(t, MF)                                        \
+  {                                                               \
+    constexpr int dx_ = (t) / 3, dy_ = (t) % 3;                   \
+    MF(0, 0, (t) & 1, dx_ & 1, dy_);                              \
     G4_PIN(0, 0);                                                 \
     __builtin_amdgcn_s_setprio(2);                                \
     __builtin_amdgcn_sched_barrier(0);                            \
-    G4_MFMA(0, 1, (t) & 1, dx_ & 1, dy_);                         \
-    G4_MFMA(1, 0, (t) & 1, dx_ & 1, dy_);                         \
-    G4_MFMA(1, 1, (t) & 1, dx_ & 1, dy_);                         \
+    MF(0, 1, (t) & 1, dx_ & 1, dy_);                              \
+    MF(1, 0, (t) & 1, dx_ & 1, dy_);                              \
+    MF(1, 1, (t) & 1, dx_ & 1, dy_);                              \
     G4_PIN(0, 1);                                                 \
     G4_PIN(1, 0);                                                 \
     G4_PIN(1, 1);                                                 \
@@ -417,6 +459,18 @@ __global__ __launch_bounds__(512, 2) void conv_dma4_kernel(F8Args a) {
     constexpr int A_TAPS = (C::A_ITERS + 1) / 2;  // taps 0 .. A_TAPS-1 issue the patch pieces, two each
     static_assert(A_TAPS + C::B_ITERS - 1 <= 8, "DMA pieces are issued inside the 9 taps");
 
+    // (M16) the lane's 16 bias values of this tile (its slot landed with the tile's first operands) as four accumulator-shaped
+    // registers, requested before everything else so that tap 0's wait covers them.  Read in EVERY item, used in a tile's
+    // first: only the 16 MFMAs of tap 0 differ between the two cases (a branch around the reads too made the two paths
+    // allocate their fragment registers differently: 16 two-register copies per item).
+    u32x4 bvec[4];
+    if constexpr (M16) {
+      const int ba = C::BIAS_OFF + bslot * 256 + 64 * hh;
+      G4_RD(bvec[0], ba, 0);
+      G4_RD(bvec[1], ba, 16);
+      G4_RD(bvec[2], ba, 32);
+      G4_RD(bvec[3], ba, 48);
+    }
     G4_LDW(0, 0);
     G4_LDPA(0, 0);
     __builtin_amdgcn_sched_barrier(0);
@@ -433,7 +487,18 @@ __global__ __launch_bounds__(512, 2) void conv_dma4_kernel(F8Args a) {
     const bool skip_b = resident && items_done >= 1;  // the NEXT item is this workgroup's third or later
     __builtin_amdgcn_sched_barrier(0);
 
-    G4_TAP(0, G4_WAIT_WA, 4, G4_LDPB(0, 0))
+    G4_TAP_HEAD0(G4_WAIT_WA, G4_LDPB(0, 0))
+    if constexpr (M16) {
+      // (the bias reads are older than W0: the wait that released W0 has released them; name them for the optimizer)
+      asm volatile("" : "+v"(bvec[0]), "+v"(bvec[1]), "+v"(bvec[2]), "+v"(bvec[3]));
+      if (chunk == 0) {
+        G4_TAP_BODY(0, G4_MFMA_B)
+      } else {
+        G4_TAP_BODY(0, G4_MFMA)
+      }
+    } else {
+      G4_TAP_BODY(0, G4_MFMA)
+    }
     G4_TAP(1, G4_WAIT_WB, 4, G4_LDPA(1, 1))
     G4_TAP(2, G4_WAIT_W, 8, G4_LDPB(1, 1))
     G4_TAP(3, G4_WAIT_WA, 8, )
@@ -442,6 +507,7 @@ __global__ __launch_bounds__(512, 2) void conv_dma4_kernel(F8Args a) {
     G4_TAP(6, G4_WAIT_WA, 8, )
     G4_TAP(7, G4_WAIT_WB, 4, )
     G4_TAP(8, G4_WAIT_W, 0, )
+    G4_STAMP(2)  // all MFMAs of the item issued
 
     if (last_chunk) {
       // ---- tile epilogue: bias, relu, e4m3; one 16-byte store per (row, channel block) and the fused 2x2 max-pool ----
@@ -454,10 +520,69 @@ __global__ __launch_bounds__(512, 2) void conv_dma4_kernel(F8Args a) {
         const int cl = M16 ? 16 * hh : 32 * u + 16 * hh;  // first of this lane's 16 consecutive channels within the tile
         const int px = cur.x0 + (M16 ? 16 * u + n31 : n31);
         float bv[16];
+        if constexpr (!M16) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const f32x4 t4 = *reinterpret_cast<const f32x4*>(bl + cl + 4 * q);
-          bv[4 * q] = t4.x, bv[4 * q + 1] = t4.y, bv[4 * q + 2] = t4.z, bv[4 * q + 3] = t4.w;
+          for (int q = 0; q < 4; ++q) {
+            const f32x4 t4 = *reinterpret_cast<const f32x4*>(bl + cl + 4 * q);
+            bv[4 * q] = t4.x, bv[4 * q + 1] = t4.y, bv[4 * q + 2] = t4.z, bv[4 * q + 3] = t4.w;
+          }
+        }
+        if constexpr (M16 && !OF8 && !STATS) {
+          // PACKED epilogue of the bf16 16x16 form.  The float form below spends ~10 VALU instructions per output value
+          // (fmaxf under IEEE mode quiets both operands; relu, vertical and horizontal pool each pay it): 3 000-3 900 cycles
+          // per wave and tile, exposed -- every wave is in its epilogue at once -- and a fifth of a two-chunk layer's time
+          // (tools/conv_trace4.py).  Here: bias add in fp32, ONE v_cvt_pk_bf16_f32 per channel pair, then relu and the 2x2 max
+          // on the packed pairs as signed 16-bit integers (a non-negative bf16 orders like its bit pattern, rounding is
+          // monotone, so pooling after rounding equals rounding after pooling): 2-3 instructions per value.
+          uint32_t pk[2][8];
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {  // channels 2 k, 2 k + 1 of the lane's 16: r = 4 (2 j + jj) + q
+              const int r0 = 2 * k, r1 = 2 * k + 1;
+              // (the bias is already inside: the tile's first MFMAs started from it; nothing to clear either)
+              pk[i][k] = pack_bf16x2(acc4[i][r0 >> 3][u][(r0 >> 2) & 1][r0 & 3], acc4[i][r1 >> 3][u][(r1 >> 2) & 1][r1 & 3]);
+            }
+          const int cofs = cur.co0 + cl;
+          if (a.y != nullptr) {
+            const uint32_t rfloor = a.relu ? 0u : 0x80008000u;  // (0x8000 = the smallest int16: a no-op)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+#pragma unroll
+              for (int k = 0; k < 8; ++k) pk[i][k] = pk_max_i16(pk[i][k], rfloor);
+              char* dst = a.y + (((int64_t)cur.n * (H + 2) + (py + i + 1)) * Wp + (px + 1)) * Ob + cofs * 2;
+              if (!EDGE || (py + i < H && px < W)) {
+                *reinterpret_cast<u32x4*>(dst) = u32x4{pk[i][0], pk[i][1], pk[i][2], pk[i][3]};
+                *reinterpret_cast<u32x4*>(dst + 16) = u32x4{pk[i][4], pk[i][5], pk[i][6], pk[i][7]};
+              }
+            }
+          }
+          if (a.pooled != nullptr) {
+            uint32_t m[8];
+            if (a.relu) {
+              // max over the 2x2 block first, relu once on the result: with at least one positive value the integer order is
+              // the float order among the candidates that can win, with none the result is clamped to zero anyway
+#pragma unroll
+              for (int k = 0; k < 8; ++k) {
+                const uint32_t t = pk_max_i16(pk[0][k], pk[1][k]);
+                m[k] = pk_max_i16(pk_max_i16(t, pk_dpp_swap1(t)), 0u);
+              }
+            } else {
+#pragma unroll
+              for (int k = 0; k < 8; ++k) {
+                const uint32_t t = pk_max_i16(pk_ord_bf16(pk[0][k]), pk_ord_bf16(pk[1][k]));
+                m[k] = pk_ord_bf16(pk_max_i16(t, pk_dpp_swap1(t)));
+              }
+            }
+            const int Hq = H >> 1, Wq = W >> 1;
+            char* dst = a.pooled + (((int64_t)cur.n * (Hq + 2) + ((py >> 1) + 1)) * (Wq + 2) + ((px >> 1) + 1)) * Ob + cofs * 2;
+            // every wave issues these instructions (even lanes store): the counted vmcnt at the next barrier relies on it
+            if ((lane & 1) == 0 && (!EDGE || (py < H && px < W))) {
+              *reinterpret_cast<u32x4*>(dst) = u32x4{m[0], m[1], m[2], m[3]};
+              *reinterpret_cast<u32x4*>(dst + 16) = u32x4{m[4], m[5], m[6], m[7]};
+            }
+          }
+          continue;
         }
         float v[2][16];
 #pragma unroll
@@ -465,9 +590,8 @@ __global__ __launch_bounds__(512, 2) void conv_dma4_kernel(F8Args a) {
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             float s;
-            if constexpr (M16) {  // r = 4 (2 j + jj) + q
-              s = acc4[i][r >> 3][u][(r >> 2) & 1][r & 3] + bv[r];
-              acc4[i][r >> 3][u][(r >> 2) & 1][r & 3] = 0.f;
+            if constexpr (M16) {  // r = 4 (2 j + jj) + q; the bias is already inside (the tile's first MFMAs started from it)
+              s = acc4[i][r >> 3][u][(r >> 2) & 1][r & 3];
             } else {
               s = acc[i][u][r] + bv[r];
               acc[i][u][r] = 0.f;
@@ -528,6 +652,10 @@ __global__ __launch_bounds__(512, 2) void conv_dma4_kernel(F8Args a) {
       in_flight = (EDGE && (cur.y0 + C::TH > H || cur.x0 + C::TW > W)) ? 0 : nstores;
       bslot ^= 1;
     }
+    G4_STAMP(3)  // tile epilogue done (stores issued)
+#ifdef XV_CONV_TRACE
+    ++trace_item;
+#endif
     if (!has_next) break;
     ++items_done;
     lid = nlid;
@@ -536,6 +664,12 @@ __global__ __launch_bounds__(512, 2) void conv_dma4_kernel(F8Args a) {
     buf ^= 1;
   }
   XV_CLK_END(xv_clk_g4)
+#ifdef XV_CONV_TRACE
+  __syncthreads();
+  if (!STATS && wave == 0 && (blockIdx.x & 31) == 0)
+    for (int i = lane; i < 8 * 32 * 4; i += 64)
+      xv_trace_buf4[(blockIdx.x >> 5) * (8 * 32 * 4) + i] = reinterpret_cast<long long*>(smem + C::LDS_BYTES)[i];
+#endif
   if constexpr (STATS) {
     // half-wave sums by DPP (row_shr 1, 2, 4, 8 inside each 16-lane row, row_bcast15 into the odd rows: lanes 31 / 63 hold
     // the totals), each wave's totals to its own LDS row, the 8 rows added in wave order (a fixed tree: reproducible bits),
@@ -593,6 +727,13 @@ __global__ __launch_bounds__(512, 2) void conv_dma4_kernel(F8Args a) {
 #undef G4_WAIT_WB
 #undef G4_CAT
 #undef G4_MFMA
+#undef G4_MFMA_B
+#undef G4_MFMA_C
+#undef G4_C_ACC
+#undef G4_C_BIAS
+#undef G4_TAP_HEAD
+#undef G4_TAP_HEAD0
+#undef G4_TAP_BODY
 #undef G4_DMA_PIECES
 #undef G4_TAP
 #undef G4_PIN
@@ -638,7 +779,8 @@ bool xv_conv3x3_dma4_exact(int H, int W) { return (H & 15) == 0 && (W & 31) == 0
 namespace {
 template <bool F8, bool OF8, bool STATS, bool EDGE, bool M16>
 int g4_launch1(const F8Args& a, int grid, hipStream_t stream) {
-  constexpr int lds = STATS ? G4::LDS_BYTES_STATS : G4::LDS_BYTES;
+  constexpr int lds = STATS ? G4::LDS_BYTES_STATS : G4::LDS_BYTES + G4_TRACE_LDS;
+  static_assert(lds <= 160 * 1024, "does not fit the LDS");
   static bool attr_set[XV_MAX_DEVICES] = {false};
   const hipError_t e =
       xv_allow_dynamic_lds(reinterpret_cast<const void*>(&conv_dma4_kernel<F8, OF8, STATS, EDGE, M16>), lds, attr_set);
@@ -703,4 +845,8 @@ extern "C" int xv_debug_reset_clock_g4(void) {
   static unsigned long long zeros[4 * XV_CLK_SLOTS];
   return (int)hipMemcpyToSymbol(HIP_SYMBOL(xv_clk_g4), zeros, sizeof(zeros));
 }
+#endif
+
+#ifdef XV_CONV_TRACE
+extern "C" int xv_debug_read_trace4(void* dst, size_t bytes) { return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(xv_trace_buf4), bytes); }
 #endif

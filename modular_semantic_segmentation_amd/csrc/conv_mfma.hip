@@ -2185,7 +2185,7 @@ int conv_fwd_impl(const xv_act* x, const void* w_packed, const float* bias, cons
   XV_CHECK_ARG(x && x->data && w_packed && bias && y);
   XV_CHECK_ARG(y->data || (pooled && pooled->data));
   XV_CHECK_SHAPE(k == 1 || k == 3);
-  XV_CHECK_SHAPE(x->n > 0 && x->h > 0 && x->w > 0 && x->c > 0 && (x->c & 63) == 0);
+  XV_CHECK_SHAPE(xv_dims_sane(x->n, x->h, x->w) && x->c > 0 && (x->c & 63) == 0);
   XV_CHECK_SHAPE(y->n == x->n && y->h == x->h && y->w == x->w && y->c > 0 && (y->c & 63) == 0);
   XV_CHECK_ARG((x->dtype == XV_BF16 || x->dtype == XV_FP8) && (y->dtype == XV_BF16 || y->dtype == XV_FP8));
   const int in_f8 = x->dtype == XV_FP8, out_f8 = y->dtype == XV_FP8;

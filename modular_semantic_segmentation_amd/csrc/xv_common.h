@@ -68,11 +68,11 @@ static inline hipError_t xv_allow_dynamic_lds(const void* kernel, int bytes, boo
   return e;
 }
 
-// A map this library can address at all: positive dimensions, fewer than 2^31 padded rows and 2^36 padded pixels (64 G
-// pixels: beyond any 288 GB buffer).  The size calculators return 0 and the choosers XV_ESHAPE past it, so that their
+// A map this library can address at all: positive dimensions, sides below 2^24, fewer than 2^31 padded rows and 2^36
+// padded pixels (64 G pixels: beyond any 288 GB buffer).  The size calculators return 0 and the choosers XV_ESHAPE past it, so that their
 // 64-bit arithmetic cannot overflow (tools/asan_host_check.py fuzzes them under UBSan).
 static inline bool xv_dims_sane(int n, int h, int w) {
-  if (n <= 0 || h <= 0 || w <= 0) return false;
+  if (n <= 0 || h <= 0 || w <= 0 || h >= (1 << 24) || w >= (1 << 24)) return false;
   const int64_t rows = (int64_t)n * ((int64_t)h + 2);
   return rows < ((int64_t)1 << 31) && rows * ((int64_t)w + 2) < ((int64_t)1 << 36);
 }
@@ -138,6 +138,20 @@ __device__ static __forceinline__ void xv_pair16(const u32x2 a, const u32x2 b, u
 __device__ static __forceinline__ uint32_t pk_max_i16(uint32_t a, uint32_t b) {
   typedef short s16x2 __attribute__((ext_vector_type(2)));
   return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s16x2, a), __builtin_bit_cast(s16x2, b)));
+}
+
+// Order-preserving map of packed bf16 bit patterns onto signed 16-bit integers (an involution: negative values have their
+// magnitude bits flipped), for a 2x2 max on packed pairs WITHOUT a preceding relu.
+__device__ static __forceinline__ uint32_t pk_ord_bf16(uint32_t x) {
+  typedef short s16x2 __attribute__((ext_vector_type(2)));
+  const s16x2 v = __builtin_bit_cast(s16x2, x);
+  const s16x2 m = (v >> 15) & (short)0x7fff;
+  return __builtin_bit_cast(uint32_t, v ^ m);
+}
+
+// value of lane ^ 1 (DPP quad_perm [1,0,3,2]) of a packed register
+__device__ static __forceinline__ uint32_t pk_dpp_swap1(uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xf, 0xf, true);
 }
 
 // ---- diagnostic build only (-DXV_CLOCK_STAMP: `make stamp` -> tools/build/libxview_hip_stamp.so, read by tools/conv_clock.py;
