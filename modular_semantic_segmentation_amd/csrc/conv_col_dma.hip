@@ -32,6 +32,9 @@ struct G5Args {
   int N, H, W, Cin, Cout;
   int tiles_x, tiles_y, n_ct, n_tiles;
   int relu;
+  // data-gradient epilogue: y = (conv + addend) where mask > 0, else 0 -- both maps shaped like y (either may be null)
+  const char* mask;
+  const char* addend;
 };
 
 template <int MT>
@@ -58,7 +61,9 @@ __device__ __forceinline__ int g5_swz(int row, int slot) { return slot ^ ((row >
 __device__ unsigned long long xv_clk_g5[4 * XV_CLK_SLOTS];
 #endif
 
-template <int MT>
+// DG: the data-gradient epilogue (addend + relu mask) as a kernel of its own (the forward kernel carries neither its registers
+// nor its branches)
+template <int MT, bool DG = false>
 __global__ __launch_bounds__(512, 2) void conv_dma5_kernel(G5Args a) {
   using C = G5<MT>;
   constexpr int R = C::R;
@@ -340,14 +345,57 @@ __global__ __launch_bounds__(512, 2) void conv_dma5_kernel(G5Args a) {
       // PACKED epilogue (as generation 4's 16x16 form): bias add in fp32, one v_cvt_pk_bf16_f32 per channel pair, relu and
       // the 2x2 max on the packed pairs as signed 16-bit integers -- 2-3 VALU instructions per value instead of ~10
       uint32_t pk[MT][8];
+      // data-gradient extras (Conv2DBackpropInput + AddN + ReluGrad): every addend / mask word of the lane's MT pixels is
+      // requested before the first is used
+      u32x4 ad[MT][2], mk[MT][2];
+      if constexpr (DG) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+          const int64_t off = (((int64_t)cur.n * (H + 2) + (py + i + 1)) * Wp + (px + 1)) * Ob + cofs * 2;
+          if (a.addend != nullptr) {
+            ad[i][0] = *reinterpret_cast<const u32x4*>(a.addend + off);
+            ad[i][1] = *reinterpret_cast<const u32x4*>(a.addend + off + 16);
+          }
+          if (a.mask != nullptr) {
+            mk[i][0] = *reinterpret_cast<const u32x4*>(a.mask + off);
+            mk[i][1] = *reinterpret_cast<const u32x4*>(a.mask + off + 16);
+          }
+        }
+      }
+      // (the bias is already inside the accumulators: the tile's first MFMAs started from it; nothing to clear either)
+      float sv[MT][16];
 #pragma unroll
       for (int i = 0; i < MT; ++i)
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {  // channels 2 k, 2 k + 1 of the lane's 16 (r = 4 j + q)
-          const int r0 = 2 * k, r1 = 2 * k + 1;
-          // (the bias is already inside: the tile's first MFMAs started from it; nothing to clear either)
-          pk[i][k] = pack_bf16x2(acc[i][r0 >> 2][r0 & 3], acc[i][r1 >> 2][r1 & 3]);
+        for (int r = 0; r < 16; ++r) sv[i][r] = acc[i][r >> 2][r & 3];  // r = 4 j + q
+      if constexpr (DG) {
+        if (a.addend != nullptr) {  // added in fp32, before the one rounding (as every other generation)
+#pragma unroll
+          for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+              const uint32_t w = k < 4 ? ad[i][0][k & 3] : ad[i][1][k & 3];
+              sv[i][2 * k] += __builtin_bit_cast(float, w << 16);
+              sv[i][2 * k + 1] += __builtin_bit_cast(float, w & 0xffff0000u);
+            }
         }
+      }
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) pk[i][k] = pack_bf16x2(sv[i][2 * k], sv[i][2 * k + 1]);  // channels 2 k, 2 k + 1 of the lane's 16
+      if constexpr (DG) {
+        if (a.mask != nullptr) {  // keep the value where the reference activation is > 0 (see conv_f8_dma.hip)
+#pragma unroll
+          for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+              const uint32_t w = k < 4 ? mk[i][0][k & 3] : mk[i][1][k & 3];
+              const uint32_t sel = ((int32_t)(w << 16) > 0 ? 0x0000ffffu : 0u) | ((int32_t)(w & 0xffff0000u) > 0 ? 0xffff0000u : 0u);
+              pk[i][k] &= sel;
+            }
+        }
+      }
       if (a.y != nullptr) {
         const uint32_t rfloor = a.relu ? 0u : 0x80008000u;  // (0x8000 = the smallest int16: a no-op)
 #pragma unroll
@@ -418,12 +466,12 @@ __global__ __launch_bounds__(512, 2) void conv_dma5_kernel(G5Args a) {
 #undef G5_TAP
 }
 
-template <int MT>
+template <int MT, bool DG = false>
 int g5_launch(const G5Args& a, int grid, hipStream_t stream) {
   static bool attr_set[XV_MAX_DEVICES] = {false};
-  const hipError_t e = xv_allow_dynamic_lds(reinterpret_cast<const void*>(&conv_dma5_kernel<MT>), G5<MT>::LDS_BYTES, attr_set);
+  const hipError_t e = xv_allow_dynamic_lds(reinterpret_cast<const void*>(&conv_dma5_kernel<MT, DG>), G5<MT>::LDS_BYTES, attr_set);
   if (e != hipSuccess) return (int)e;
-  hipLaunchKernelGGL((conv_dma5_kernel<MT>), dim3((unsigned)grid), dim3(G5<MT>::NT), G5<MT>::LDS_BYTES, stream, a);
+  hipLaunchKernelGGL((conv_dma5_kernel<MT, DG>), dim3((unsigned)grid), dim3(G5<MT>::NT), G5<MT>::LDS_BYTES, stream, a);
   return xv_launch_status();
 }
 
@@ -437,8 +485,9 @@ bool xv_conv3x3_col_ok(int H, int W, int Cin, int Cout, int mt) {
 }
 
 int xv_launch_conv3x3_col(const void* x, const void* wpk, const float* bias, void* y, void* pooled, int N, int H, int W, int Cin,
-                          int Cout, int relu, int mt, int num_cus, hipStream_t stream) {
-  if (!xv_conv3x3_col_ok(H, W, Cin, Cout, mt) || (y == nullptr && pooled == nullptr) || (pooled != nullptr && (mt & 1)))
+                          int Cout, int relu, int mt, int num_cus, hipStream_t stream, const void* mask, const void* addend) {
+  if (!xv_conv3x3_col_ok(H, W, Cin, Cout, mt) || (y == nullptr && pooled == nullptr) || (pooled != nullptr && (mt & 1)) ||
+      ((mask != nullptr || addend != nullptr) && y == nullptr))
     return XV_ESHAPE;
   G5Args a{};
   a.x = (const char*)x;
@@ -454,7 +503,10 @@ int xv_launch_conv3x3_col(const void* x, const void* wpk, const float* bias, voi
   if (ntiles <= 0 || ntiles > 0x7fffffff) return XV_ESHAPE;
   a.n_tiles = (int)ntiles;
   a.relu = relu;
+  a.mask = (const char*)mask;
+  a.addend = (const char*)addend;
   const int grid = num_cus > 0 ? num_cus : 256;
+  if (mask != nullptr || addend != nullptr) return mt == 3 ? g5_launch<3, true>(a, grid, stream) : g5_launch<4, true>(a, grid, stream);
   return mt == 3 ? g5_launch<3>(a, grid, stream) : g5_launch<4>(a, grid, stream);
 }
 

@@ -53,6 +53,9 @@ struct F8Args {
   int scale_x;    // E8M0 byte of the input map's scale in all four bytes
   float out_mul;  // 2^-scale_exp of the output map
   float* stats;   // STATS: [gridDim.x][2 Cout] per-workgroup sums / sums of squares of the stored outputs
+  // data-gradient epilogue (bf16 16x16 form only): y = (conv + addend) where mask > 0, else 0 -- both maps shaped like y
+  const char* mask;
+  const char* addend;
 };
 
 #ifdef XV_CLOCK_STAMP
@@ -130,10 +133,13 @@ __device__ __forceinline__ float g4_dpp_swap1(float v) {  // value of lane ^ 1 (
 // equal cycles).  Lane l = (column n15 = l & 15, k-group / channel group g = l >> 4); weight rows permuted so that the 16
 // accumulator registers of a lane and pixel block are channels 16 g .. 16 g + 15 (row 16 j + 4 g + q = channel 16 g + 4 j + q);
 // fragment j (pixel half h) of a row pair sits 1 KB behind fragment 0, so one base register serves a whole set.
-template <bool F8, bool OF8 = F8, bool STATS = false, bool EDGE = false, bool M16 = false>
+// DG (bf16 16x16 form only): the data-gradient epilogue -- y = (conv + addend) where mask > 0, else 0 -- as a kernel of its
+// own, so that the forward kernel carries neither its registers nor its branches
+template <bool F8, bool OF8 = F8, bool STATS = false, bool EDGE = false, bool M16 = false, bool DG = false>
 __global__ __launch_bounds__(512, 2) void conv_dma4_kernel(F8Args a) {
   using C = G4;
   static_assert(!(M16 && F8), "the 16x16 form is a bf16 kernel");
+  static_assert(!DG || (M16 && !OF8 && !STATS), "the data-gradient epilogue exists in the packed epilogue only");
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x;
@@ -535,15 +541,62 @@ __global__ __launch_bounds__(512, 2) void conv_dma4_kernel(F8Args a) {
           // on the packed pairs as signed 16-bit integers (a non-negative bf16 orders like its bit pattern, rounding is
           // monotone, so pooling after rounding equals rounding after pooling): 2-3 instructions per value.
           uint32_t pk[2][8];
+          const int cofs = cur.co0 + cl;
+          // data-gradient extras (Conv2DBackpropInput + AddN + ReluGrad): every addend / mask word of the lane's two pixels is
+          // requested before the first is used; pixels past the image (edge tiles) read the image's first pixel instead
+          u32x4 ad[2][2], mk[2][2];
+          if constexpr (DG) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+              const bool in = !EDGE || (py + i < H && px < W);
+              const int64_t off = (((int64_t)cur.n * (H + 2) + ((in ? py + i : 0) + 1)) * Wp + ((in ? px : 0) + 1)) * Ob + cofs * 2;
+              if (a.addend != nullptr) {
+                ad[i][0] = *reinterpret_cast<const u32x4*>(a.addend + off);
+                ad[i][1] = *reinterpret_cast<const u32x4*>(a.addend + off + 16);
+              }
+              if (a.mask != nullptr) {
+                mk[i][0] = *reinterpret_cast<const u32x4*>(a.mask + off);
+                mk[i][1] = *reinterpret_cast<const u32x4*>(a.mask + off + 16);
+              }
+            }
+          }
+          // (the bias is already inside the accumulators: the tile's first MFMAs started from it; nothing to clear either)
+          float sv[2][16];
 #pragma unroll
           for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {  // channels 2 k, 2 k + 1 of the lane's 16: r = 4 (2 j + jj) + q
-              const int r0 = 2 * k, r1 = 2 * k + 1;
-              // (the bias is already inside: the tile's first MFMAs started from it; nothing to clear either)
-              pk[i][k] = pack_bf16x2(acc4[i][r0 >> 3][u][(r0 >> 2) & 1][r0 & 3], acc4[i][r1 >> 3][u][(r1 >> 2) & 1][r1 & 3]);
+            for (int r = 0; r < 16; ++r) sv[i][r] = acc4[i][r >> 3][u][(r >> 2) & 1][r & 3];  // r = 4 (2 j + jj) + q
+          if constexpr (DG) {
+            if (a.addend != nullptr) {  // added in fp32, before the one rounding (as every other generation)
+#pragma unroll
+              for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                  const uint32_t w = k < 4 ? ad[i][0][k & 3] : ad[i][1][k & 3];
+                  sv[i][2 * k] += __builtin_bit_cast(float, w << 16);
+                  sv[i][2 * k + 1] += __builtin_bit_cast(float, w & 0xffff0000u);
+                }
             }
-          const int cofs = cur.co0 + cl;
+          }
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) pk[i][k] = pack_bf16x2(sv[i][2 * k], sv[i][2 * k + 1]);  // channels 2 k, 2 k + 1 of the lane's 16
+          if constexpr (DG) {
+            if (a.mask != nullptr) {
+              // keep the value where the reference activation is > 0: each bf16 half moved to the top of a 32-bit integer
+              // (negative values, -0 and +0 are <= 0 there).  (A packed 16-bit min / max form of this was miscompiled by
+              // hipcc 7.2: every pair tested the mask word of pair 0.)
+#pragma unroll
+              for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                  const uint32_t w = k < 4 ? mk[i][0][k & 3] : mk[i][1][k & 3];
+                  const uint32_t sel = ((int32_t)(w << 16) > 0 ? 0x0000ffffu : 0u) | ((int32_t)(w & 0xffff0000u) > 0 ? 0xffff0000u : 0u);
+                  pk[i][k] &= sel;
+                }
+            }
+          }
           if (a.y != nullptr) {
             const uint32_t rfloor = a.relu ? 0u : 0x80008000u;  // (0x8000 = the smallest int16: a no-op)
 #pragma unroll
@@ -777,15 +830,15 @@ bool xv_conv3x3_dma4_bf16_ok(int H, int W, int Cin, int Cout) {
 bool xv_conv3x3_dma4_exact(int H, int W) { return (H & 15) == 0 && (W & 31) == 0; }
 
 namespace {
-template <bool F8, bool OF8, bool STATS, bool EDGE, bool M16>
+template <bool F8, bool OF8, bool STATS, bool EDGE, bool M16, bool DG = false>
 int g4_launch1(const F8Args& a, int grid, hipStream_t stream) {
   constexpr int lds = STATS ? G4::LDS_BYTES_STATS : G4::LDS_BYTES + G4_TRACE_LDS;
   static_assert(lds <= 160 * 1024, "does not fit the LDS");
   static bool attr_set[XV_MAX_DEVICES] = {false};
   const hipError_t e =
-      xv_allow_dynamic_lds(reinterpret_cast<const void*>(&conv_dma4_kernel<F8, OF8, STATS, EDGE, M16>), lds, attr_set);
+      xv_allow_dynamic_lds(reinterpret_cast<const void*>(&conv_dma4_kernel<F8, OF8, STATS, EDGE, M16, DG>), lds, attr_set);
   if (e != hipSuccess) return (int)e;
-  hipLaunchKernelGGL((conv_dma4_kernel<F8, OF8, STATS, EDGE, M16>), dim3((unsigned)grid), dim3(G4::NT), lds, stream, a);
+  hipLaunchKernelGGL((conv_dma4_kernel<F8, OF8, STATS, EDGE, M16, DG>), dim3((unsigned)grid), dim3(G4::NT), lds, stream, a);
   return xv_launch_status();
 }
 template <bool F8, bool OF8, bool STATS = false, bool M16 = false>
@@ -799,10 +852,12 @@ int g4_launch(const F8Args& a, int grid, hipStream_t stream) {
 // 25, or 26 with m16 (the bf16 kernel on v_mfma_f32_16x16x32_bf16).  scale_x / out_mul as in ConvArgs.
 int xv_launch_conv3x3_f8_dma(const void* x, const void* wpk, const float* bias, void* y, void* pooled, int N, int H, int W,
                              int Cin, int Cout, int relu, int in_f8, int out_f8, int scale_x, float out_mul, int num_cus,
-                             hipStream_t stream, float* stats_rows, int m16) {
+                             hipStream_t stream, float* stats_rows, int m16, const void* mask, const void* addend) {
   if (!(in_f8 ? xv_conv3x3_f8_dma_ok(H, W, Cin, Cout) : xv_conv3x3_dma4_bf16_ok(H, W, Cin, Cout)) ||
       (y == nullptr && pooled == nullptr) || (in_f8 && !out_f8) || (in_f8 && m16))
     return XV_ESHAPE;
+  // the data-gradient epilogue exists in the packed epilogue of the bf16 16x16 form only
+  if ((mask != nullptr || addend != nullptr) && (!m16 || out_f8 || stats_rows != nullptr || y == nullptr)) return XV_ESHAPE;
   F8Args a{};
   a.x = (const char*)x;
   a.wpk = (const char*)wpk;
@@ -819,6 +874,8 @@ int xv_launch_conv3x3_f8_dma(const void* x, const void* wpk, const float* bias, 
   a.relu = relu;
   a.scale_x = scale_x;
   a.out_mul = out_mul;
+  a.mask = (const char*)mask;
+  a.addend = (const char*)addend;
   const int grid = num_cus > 0 ? num_cus : 256;
   if (stats_rows != nullptr) {  // per-channel sums of the outputs in the epilogue: bf16 maps, at most 8 channel tiles
     // exact tilings only (a partial tile's out-of-image pixels would enter the sums); one channel tile per workgroup
@@ -826,6 +883,9 @@ int xv_launch_conv3x3_f8_dma(const void* x, const void* wpk, const float* bias, 
     a.stats = stats_rows;
     return m16 ? g4_launch<false, false, true, true>(a, grid, stream) : g4_launch<false, false, true>(a, grid, stream);
   }
+  if (mask != nullptr || addend != nullptr)  // the data-gradient kernel (16x16 form, bf16 map out)
+    return xv_conv3x3_dma4_exact(H, W) ? g4_launch1<false, false, false, false, true, true>(a, grid, stream)
+                                       : g4_launch1<false, false, false, true, true, true>(a, grid, stream);
   if (in_f8) return g4_launch<true, true>(a, grid, stream);
   if (m16) return out_f8 ? g4_launch<false, true, false, true>(a, grid, stream) : g4_launch<false, false, false, true>(a, grid, stream);
   return out_f8 ? g4_launch<false, true>(a, grid, stream) : g4_launch<false, false>(a, grid, stream);

@@ -42,12 +42,14 @@ bool xv_conv3x3_dma4_bf16_ok(int H, int W, int Cin, int Cout);
 bool xv_conv3x3_dma4_exact(int H, int W);
 int xv_launch_conv3x3_f8_dma(const void* x, const void* wpk, const float* bias, void* y, void* pooled, int N, int H, int W,
                              int Cin, int Cout, int relu, int in_f8, int out_f8, int scale_x, float out_mul, int num_cus,
-                             hipStream_t stream, float* stats_rows = nullptr, int m16 = 0);
+                             hipStream_t stream, float* stats_rows = nullptr, int m16 = 0, const void* mask = nullptr,
+                             const void* addend = nullptr);
 void xv_launch_pack_weights_f8_g4(const float* w, char* out, int taps, int cin, int cout, float mul, hipStream_t stream);
 // conv_col_dma.hip (generation 5: the generation-4 loop on a column of waves, 24x16 / 32x16 tiles, configurations 27 / 28)
 bool xv_conv3x3_col_ok(int H, int W, int Cin, int Cout, int mt);
 int xv_launch_conv3x3_col(const void* x, const void* wpk, const float* bias, void* y, void* pooled, int N, int H, int W, int Cin,
-                          int Cout, int relu, int mt, int num_cus, hipStream_t stream);
+                          int Cout, int relu, int mt, int num_cus, hipStream_t stream, const void* mask = nullptr,
+                          const void* addend = nullptr);
 
 namespace {
 
@@ -2006,14 +2008,14 @@ int launch_cfg(int cfg, const ConvArgs& a, hipStream_t s) {
                                     a.out_mul, a.num_cus, s);
   }
   if (cfg == 25 || cfg == 26) {
-    if (KS != 3 || a.in_f8 || a.mask != nullptr || a.addend != nullptr) return XV_ESHAPE;
+    if (KS != 3 || a.in_f8 || (cfg == 25 && (a.mask != nullptr || a.addend != nullptr))) return XV_ESHAPE;
     return xv_launch_conv3x3_f8_dma(a.x, a.wpk, a.bias, a.y, a.pooled, a.N, a.H, a.W, a.Cin, a.Cout, a.relu, 0, a.out_f8, 0,
-                                    a.out_mul, a.num_cus, s, nullptr, cfg == 26);
+                                    a.out_mul, a.num_cus, s, nullptr, cfg == 26, a.mask, a.addend);
   }
   if (cfg == 27 || cfg == 28) {
-    if (KS != 3 || a.in_f8 || a.out_f8 || a.mask != nullptr || a.addend != nullptr) return XV_ESHAPE;
+    if (KS != 3 || a.in_f8 || a.out_f8) return XV_ESHAPE;
     return xv_launch_conv3x3_col(a.x, a.wpk, a.bias, a.y, a.pooled, a.N, a.H, a.W, a.Cin, a.Cout, a.relu, cfg == 27 ? 3 : 4,
-                                 a.num_cus, s);
+                                 a.num_cus, s, a.mask, a.addend);
   }
   if (a.in_f8) {
     // the fp8 kernel is built for the tile shapes with LDS-DMA weight stages (the ones the bf16 chooser falls back to)
@@ -2153,12 +2155,16 @@ int pick_cfg(const ConvArgs& a, int k) {
     // Plain forward shapes only.  XV_BF16_GEN4=0: never; =2: only from 128 input channels; =3: the 32x32x16 form (A/B timing).
     {
       static const int gen4 = getenv("XV_BF16_GEN4") != nullptr ? atoi(getenv("XV_BF16_GEN4")) : 1;
-      if (gen4 && a.mask == nullptr && a.addend == nullptr && a.sk_ws == nullptr && !a.in_f8 && !a.out_f8 &&
+      // (the data-gradient epilogue -- addend + relu mask -- exists in the 16x16 forms: XV_DGRAD_GEN4=0 keeps those convs on
+      // generation 2, A/B timing)
+      static const bool dgrad4 = getenv("XV_DGRAD_GEN4") == nullptr || atoi(getenv("XV_DGRAD_GEN4")) != 0;
+      const bool dg = a.mask != nullptr || a.addend != nullptr;
+      if (gen4 && (!dg || (dgrad4 && gen4 != 3 && a.pooled == nullptr)) && a.sk_ws == nullptr && !a.in_f8 && !a.out_f8 &&
           xv_conv3x3_dma4_bf16_ok(a.H, a.W, a.Cin, a.Cout) && xv_conv3x3_dma4_exact(a.H, a.W) && (gen4 != 2 || a.Cin >= 128))
         return gen4 == 3 ? 25 : 26;
       // maps that tile in 24x16 but not in 16x32 (the 24x48 conv5 maps of a 768x384 input): the same loop on a column of
       // waves, generation 5 -- conv5_1 at 16 images 1 190 against 985 TFLOP/s on generation 2's 24x16 tile (configuration 22)
-      if (gen4 && a.mask == nullptr && a.addend == nullptr && a.sk_ws == nullptr && !a.in_f8 && !a.out_f8 && a.pooled == nullptr &&
+      if (gen4 && (!dg || dgrad4) && a.sk_ws == nullptr && !a.in_f8 && !a.out_f8 && a.pooled == nullptr &&
           xv_conv3x3_col_ok(a.H, a.W, a.Cin, a.Cout, 3))
         return 27;
     }

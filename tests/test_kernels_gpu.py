@@ -293,6 +293,46 @@ def test_conv2d_generation2_three_row_tile(ops, shape):
             ops.conv2d_fwd(xa, wp, bd, 3, relu=True, pooled=ops.Act(n, h // 2, w // 2, cout), cfg=22)
 
 
+@pytest.mark.parametrize('shape', [(2, 32, 64, 128, 64), (3, 16, 32, 64, 192), (1, 48, 96, 256, 128), (4, 24, 48, 128, 128),
+                                   (2, 48, 16, 64, 64), (5, 24, 16, 192, 64), (1, 20, 36, 64, 64)])
+def test_data_gradient_epilogue_on_generation4_and_5(ops, shape):
+    """xv_conv2d_bwd_data (Conv2DBackpropInput + AddN + ReluGrad, base_model.py:153-162 over simple_fcn.py:39-79) on maps that
+    tile exactly: the library now takes the 16x16 forms of generation 4 (configuration 26, 16x32 tiles) and generation 5 (27,
+    24x16 tiles: the conv5 maps) with the addend + relu-mask epilogue on packed bf16 pairs.  Against the plain convolution of
+    a first-generation tile + the same arithmetic in float32 (one rounding), bit for bit on integer operands; every
+    combination of addend / mask; the chooser's pick is asserted so that the test cannot pass on a fallback."""
+    from modular_semantic_segmentation_amd import _lib
+    n, h, w, cin, cout = shape            # of the FORWARD conv: dy has cout channels, dx has cin
+    rng = np.random.default_rng(sum(shape))
+    wt = torch.from_numpy(rng.integers(-1, 2, (3, 3, cin, cout)).astype(np.float32)).cuda()
+    wd = ops.pack_conv_weights_dgrad(wt)
+    dy = ops.Act.from_dense(_dev(rng.integers(-2, 3, (n, h, w, cout)).astype(np.float32)))
+    ref = ops.Act.from_dense(_dev(rng.integers(-1, 3, (n, h, w, cin)).astype(np.float32) * 0.5))
+    ref.interior()[0, 0, 0, :8] = torch.tensor([0.0, -0.0, 1e-30, -1e-30, 3.0, -3.0, 0.0078125, -0.0078125], device='cuda').to(torch.bfloat16)
+    add = ops.Act.from_dense(_dev(rng.integers(-3, 4, (n, h, w, cin)).astype(np.float32)))
+    zb = torch.zeros(cin, device='cuda')
+    want_cfg = 26 if (h % 16 == 0 and w % 32 == 0) else (27 if (h % 24 == 0 and w % 16 == 0) else None)
+    got_cfg = _lib.lib().xv_conv2d_choose_cfg(n, h, w, cout, cin, 3, 0, 0, 2)
+    if want_cfg is not None:
+        assert got_cfg == want_cfg, (got_cfg, want_cfg)
+    else:
+        assert got_cfg not in (26, 27)
+    plain, _ = ops.conv2d_fwd(dy, wd, zb, 3, relu=False, cfg=14)
+    torch.cuda.synchronize()
+    base = plain.interior().float()
+    for use_add, use_ref in ((True, True), (False, True), (True, False), (False, False)):
+        dx = ops.conv2d_bwd_data(dy, wd, zb, ops.Act(n, h, w, cin), 3, relu_ref=ref if use_ref else None,
+                                 addend=add if use_add else None)
+        torch.cuda.synchronize()
+        v = base + (add.interior().float() if use_add else 0.0)
+        if use_ref:
+            v = v * (ref.interior().float() > 0)
+        assert torch.equal(dx.interior().float(), v.to(torch.bfloat16).float()), (use_add, use_ref)
+        full = dx.t.float()
+        assert float(full[:, 0].abs().max()) == 0 and float(full[:, -1].abs().max()) == 0
+        assert float(full[:, :, 0].abs().max()) == 0 and float(full[:, :, -1].abs().max()) == 0
+
+
 def test_conv2d_mfma_random_bf16(ops):
     """Random bf16 operands: fp32-accumulate result within accumulation-order tolerance."""
     rng = np.random.default_rng(7)

@@ -11,7 +11,7 @@ import numpy as np
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from modular_semantic_segmentation_amd import ops  # noqa: E402
+from modular_semantic_segmentation_amd import _lib, ops  # noqa: E402
 
 ap = argparse.ArgumentParser()
 ap.add_argument('--cases', type=int, default=60)
@@ -79,7 +79,8 @@ for case in range(args.cases):
     cin = int(rng.choice([64, 128, 192, 256]))
     cout = int(rng.choice([64, 128, 192]))
     mode = int(rng.integers(0, 4))          # 0 full map, 1 full + pool, 2 pooled only, 3 data gradient
-    tiles = case % 3 == 0 and mode != 3     # a map that tiles exactly in 16x32: generation 4 (configurations 25 / 26) joins
+    tiles = case % 3 == 0                   # a map that tiles exactly in 16x32: generation 4 (configurations 25 / 26) joins
+    #                                         (mode 3: the public data-gradient op then runs on configuration 26)
     if tiles:
         h, w = (h + 15) // 16 * 16, (w + 31) // 32 * 32
     relu = bool(rng.integers(0, 2)) if mode == 0 else (mode != 3)
@@ -103,9 +104,15 @@ for case in range(args.cases):
         dx3 = ops.conv2d_bwd_data(dy, wd, zb, ops.Act(n, h, w, cin), 3, relu_ref=ref, addend=add)
         plain = outs[0][:, 1:-1, 1:-1].float()
         want = ((plain + add.interior().float()) * (ref.interior().float() > 0)).to(torch.bfloat16)
-        if not torch.equal(dx3.interior(), want):
+        # `plain` is the ROUNDED output of the plain conv: beyond 256 (bf16 spacing 2) plain + addend is rounded twice here
+        # and once in the kernel -- compare only where the plain sum is an exactly representable integer with room for the addend
+        exact = plain.abs() <= 250
+        if not torch.equal(torch.where(exact, dx3.interior(), want), want):
             bad += 1
-            print('MISMATCH data-gradient epilogue', (n, h, w, cin, cout))
+            nz = (dx3.interior() != want).nonzero()
+            print('MISMATCH data-gradient epilogue', (n, h, w, cin, cout), 'case', case, 'differing', len(nz), 'first', nz[0].tolist(),
+                  'last', nz[-1].tolist(), 'got', float(dx3.interior()[tuple(nz[0])]), 'want', float(want[tuple(nz[0])]),
+                  'cfg', _lib.lib().xv_conv2d_choose_cfg(n, h, w, cout, cin, 3, 0, 0, 2))
     else:
         wp = ops.pack_conv_weights(wt)
         for cfg in (14, 17, 21) + ((22,) if mode == 0 else ()) + ((25, 26) if tiles else ()):          # 22: no fused pool
