@@ -169,6 +169,15 @@ int xv_conv2d_choose_cfg(int n, int h, int w, int cin, int cout, int k, int in_d
  * three bf16 terms (fp32 accumulation; rounds like the fp32 FMA chain the other shapes use).        */
 int xv_conv2d_first_fwd(const float* x, int n, int h, int w, int cin, const float* w_hwio,
                         const float* bias, const xv_act* y, int relu, void* stream);
+/* conv1_1 AND conv1_2 (+ max_pooling2d) of the FCN trunk in one launch (simple_fcn.py:39-41), inference only: conv1_1 is
+ * evaluated tile by tile straight into conv1_2's LDS patch buffers, so its 64-channel map never reaches memory.  x / w1_hwio
+ * / b1 as xv_conv2d_first_fwd (cin = 1 or 3), w2_packed / b2 as xv_conv2d_fwd (64 -> 64 channels, 3x3); y and / or pooled
+ * as xv_conv2d_fwd (either may be NULL or have NULL data).  Bit-identical to the two separate calls.  Maps that tile exactly
+ * in 16x32 only: XV_ESHAPE otherwise (run the two kernels).                                                               */
+int xv_conv_first_pair_fwd(const float* x, int n, int h, int w, int cin, const float* w1_hwio, const float* b1, int relu1,
+                           const void* w2_packed, const float* b2, int relu2, const xv_act* y, const xv_act* pooled,
+                           void* stream);
+
 
 /* 2x2 stride-2 'valid' max pooling (max_pooling2d, simple_fcn.py:41,44,48,58).                  */
 int xv_maxpool2x2_fwd(const xv_act* x, const xv_act* y, void* stream);

@@ -35,6 +35,7 @@ _vpp = ctypes.POINTER(ctypes.c_void_p)
 SIGNATURES = {
     'xv_version': (_i, []),
     'xv_conv2d_choose_cfg': (_i, [_i] * 9),
+    'xv_conv_first_pair_fwd': (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _i, _actp, _actp, _vp]),
     'xv_arch': (ctypes.c_char_p, []),
     'xv_source_hash': (ctypes.c_char_p, []),
     'xv_packed_weight_bytes': (ctypes.c_size_t, [_i, _i, _i]),

@@ -6,6 +6,8 @@ fp32 first-layer / score weights.  Per image and stream the encoder runs 13 conv
 pool1..pool4 fused into the epilogues of conv1_2/2_2/3_3/4_3), two 1x1 score convs, the x2
 bilinear + add, and ONE fused decoder-head kernel (x8 bilinear + relu + score + softmax + argmax).
 """
+import os
+
 import numpy as np
 import torch
 
@@ -95,6 +97,9 @@ def _fold_bn(variables, layer, kernel, bias):
         return kernel, bias
     s = g / np.sqrt(variables[layer + '/moving_variance'] + BN_EPS)
     return kernel * s, (bias - variables[layer + '/moving_mean']) * s + variables[layer + '/beta']
+
+
+_FUSE_FIRST = os.environ.get('XV_FUSE_FIRST', '1') != '0'
 
 
 class FcnEngine(object):
@@ -290,12 +295,24 @@ class FcnEngine(object):
             L, s4, s5 = self._encoder_fp8(x, keep_all)
         else:
             L = {}
-            cur = self._act('conv1_1', n, h, w, 64)
-            ops.conv2d_first_fwd(x.contiguous(), self.w['conv1_1'], self.b['conv1_1'], cur, relu=True)
-            L['conv1_1'] = cur
             ch, cw = h, w
             drop = self._dropout if self.dropout_layers and self.dropout_rate > 0 else None
-            for name, cout, pool in ENCODER[1:]:
+            first = 1
+            # conv1_1 + conv1_2 + pool1 in one launch where neither full-resolution map is wanted (inference): conv1_1 is
+            # evaluated straight into conv1_2's LDS patch buffers (csrc/conv_first_fused.hip; the same bits as the two
+            # kernels).  Maps that do not tile in 16x32 -- and XV_FUSE_FIRST=0, A/B timing -- take the two kernels.
+            if not keep_all and _FUSE_FIRST and ENCODER[1][0] == 'conv1_2' and ENCODER[1][2] == 'pool1':
+                q = self._act('pool1', n, h // 2, w // 2, 64)
+                if ops.conv_first_pair_fwd(x.contiguous(), self.w['conv1_1'], self.b['conv1_1'], self.w['conv1_2'],
+                                           self.b['conv1_2'], pooled=q):
+                    L['pool1'] = cur = q
+                    ch, cw = h // 2, w // 2
+                    first = 2
+            if first == 1:
+                cur = self._act('conv1_1', n, h, w, 64)
+                ops.conv2d_first_fwd(x.contiguous(), self.w['conv1_1'], self.b['conv1_1'], cur, relu=True)
+                L['conv1_1'] = cur
+            for name, cout, pool in ENCODER[first:]:
                 if pool is None:
                     y = self._act(name, n, ch, cw, cout)
                     ops.conv2d_fwd(cur, self.w[name], self.b[name], 3, relu=True, y=y, workspace=self._sk())

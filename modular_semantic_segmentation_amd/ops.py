@@ -167,6 +167,33 @@ def conv2d_first_fwd(x, w_hwio, bias, y, relu=True):
     return y
 
 
+def conv_first_pair_fwd(x, w1_hwio, b1, w2_packed, b2, y=None, pooled=None, relu1=True, relu2=True):
+    """conv1_1 + conv1_2 (+ pool) in one launch (xv_conv_first_pair_fwd): x raw float32 NHWC, y / pooled bf16 Acts (either
+    may be None).  Returns False -- nothing launched -- where the fused kernel does not apply (maps that do not tile in
+    16x32, other channel counts): the caller then runs conv2d_first_fwd + conv2d_fwd."""
+    _need(x, torch.float32, 'x')
+    _need(w1_hwio, torch.float32, 'w1_hwio')
+    n, h, w, cin = x.shape
+    if cin not in (1, 3) or h % 16 or w % 32 or (y is None and pooled is None):
+        return False
+    prof = CONV_PROFILE
+    if prof is not None:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+    rc = _lib.lib().xv_conv_first_pair_fwd(_ptr(x), n, h, w, cin, _ptr(w1_hwio), _ptr(b1), int(bool(relu1)), _ptr(w2_packed),
+                                           _ptr(b2), int(bool(relu2)), y.xv() if y is not None else _NULL_ACT,
+                                           pooled.xv() if pooled is not None else _NULL_ACT, _stream())
+    if rc == -2:
+        return False
+    _lib.check(rc, 'xv_conv_first_pair_fwd')
+    if prof is not None:
+        # bench.py's roofline: a 3x3 MFMA conv launch with conv1_2's algorithmic FLOPs -- conv1_1's work inside the same
+        # kernel (and its recomputation on the halo) counts as time, not as FLOPs
+        ev1.record()
+        prof.append(('k3', 2.0 * n * h * w * 64 * 64 * 9, ev0, ev1))
+    return True
+
+
 def maxpool2x2_fwd(x, y=None):
     if y is None:
         y = Act(x.n, x.h // 2, x.w // 2, x.c, x.t.device)

@@ -333,6 +333,39 @@ def test_data_gradient_epilogue_on_generation4_and_5(ops, shape):
         assert float(full[:, :, 0].abs().max()) == 0 and float(full[:, :, -1].abs().max()) == 0
 
 
+@pytest.mark.parametrize('n,h,w,cin', [(1, 16, 32, 3), (2, 32, 64, 1), (3, 48, 96, 3), (1, 64, 32, 1), (5, 96, 192, 3), (16, 32, 64, 1)])
+def test_first_pair_fused_equals_the_two_kernels(ops, n, h, w, cin):
+    """xv_conv_first_pair_fwd (conv1_1 evaluated into conv1_2's LDS patch buffers, simple_fcn.py:39-41) against
+    xv_conv2d_first_fwd + xv_conv2d_fwd: the same bits -- full map, fused pool, pooled-only launch, with and without relu --
+    on raw-image-like inputs (0 .. 255 / 0 .. 65535 floats, image borders inside and at the edge of tiles), and against the
+    float64 oracle of both layers within the bf16 storage tolerance; maps that do not tile are refused."""
+    rng = np.random.default_rng(n * h + w + cin)
+    x = rng.integers(0, 256 if cin == 3 else 65536, (n, h, w, cin)).astype(np.float32)
+    w1 = (rng.standard_normal((3, 3, cin, 64)) * (0.02 if cin == 3 else 0.02 / 256)).astype(np.float32)
+    b1 = (rng.standard_normal(64) * 0.1).astype(np.float32)
+    w2 = (rng.standard_normal((3, 3, 64, 64)) / np.sqrt(9 * 64)).astype(np.float32)
+    b2 = (rng.standard_normal(64) * 0.1).astype(np.float32)
+    xd, w1d, b1d, b2d = _dev(x), _dev(w1), _dev(b1), _dev(b2)
+    w2p = ops.pack_conv_weights(_dev(w2))
+    for relu2 in (True, False):
+        y1 = ops.conv2d_first_fwd(xd, w1d, b1d, ops.Act(n, h, w, 64))
+        q_ref = ops.Act(n, h // 2, w // 2, 64)
+        y_ref, _ = ops.conv2d_fwd(y1, w2p, b2d, 3, relu=relu2, pooled=q_ref)
+        y, q, q2 = ops.Act(n, h, w, 64), ops.Act(n, h // 2, w // 2, 64), ops.Act(n, h // 2, w // 2, 64)
+        assert ops.conv_first_pair_fwd(xd, w1d, b1d, w2p, b2d, y=y, pooled=q, relu2=relu2)
+        assert ops.conv_first_pair_fwd(xd, w1d, b1d, w2p, b2d, pooled=q2, relu2=relu2)
+        torch.cuda.synchronize()
+        assert torch.equal(y.t, y_ref.t), 'full map differs (relu2=%s): %d values' % (relu2, int((y.t != y_ref.t).sum()))
+        assert torch.equal(q.t, q_ref.t) and torch.equal(q2.t, q_ref.t)
+    # oracle: conv1_1 in float32 -> bf16, conv1_2 with bf16 operands and fp32 accumulation -> bf16
+    xo = torch.from_numpy(x).permute(0, 3, 1, 2).contiguous()
+    a1 = fo.round_bf16(fo.conv2d_same(xo, w1, b1, relu=True))
+    a2 = fo.round_bf16(fo.conv2d_same(a1, fo.round_bf16(torch.from_numpy(w2)).numpy(), b2, relu=False)).permute(0, 2, 3, 1).numpy()
+    got = y.interior().float().cpu().numpy()
+    assert np.abs(got - a2).max() <= 2e-2 * np.abs(a2).max()
+    assert not ops.conv_first_pair_fwd(_dev(x[:, :h - 8]), w1d, b1d, w2p, b2d, y=ops.Act(n, h - 8, w, 64))
+
+
 def test_conv2d_mfma_random_bf16(ops):
     """Random bf16 operands: fp32-accumulate result within accumulation-order tolerance."""
     rng = np.random.default_rng(7)
