@@ -319,7 +319,8 @@ def committed_traffic(batch, h, w):
     if not tfiles or (h, w) != (384, 768):
         return None
     tj = json.load(open(os.path.join(pdir, tfiles[-1])))
-    srcs = [os.path.join(ROOT, 'modular_semantic_segmentation_amd', 'csrc', f) for f in ('conv_mfma.hip', 'conv_f8_dma.hip')]
+    srcs = [os.path.join(ROOT, 'modular_semantic_segmentation_amd', 'csrc', f)
+            for f in ('conv_mfma.hip', 'conv_f8_dma.hip', 'conv_col_dma.hip', 'conv_first_fused.hip')]
     sha = hashlib.sha256(b''.join(open(f, 'rb').read() for f in srcs)).hexdigest()[:16]
     if tj.get('batch') == batch and tj.get('kernel_source_sha256_16') == sha:
         return tj.get('hbm_bytes_per_launch')
@@ -355,7 +356,7 @@ def extra_inference(device, label, fusion, batch, h, w, dtype='bf16', steps=10, 
         rec['roofline_bf16_layers'] = roofline_of(prof, ('k3',), PEAK_TFLOPS['bf16'], 'the 3x3 convs left on bf16 operands (conv1_2)',
                                                   dt_serial, steps)
     else:
-        rec['roofline'] = roofline_of(prof, ('k3',), PEAK_TFLOPS['bf16'], 'conv_dma_kernel / conv_dma4_kernel / conv_mfma_kernel (3x3, all launches)',
+        rec['roofline'] = roofline_of(prof, ('k3',), PEAK_TFLOPS['bf16'], 'conv_dma4_kernel / conv_dma5_kernel / conv_first_pair_kernel / conv_dma_kernel / conv_mfma_kernel (3x3, all launches)',
                                       dt_serial, steps)
     flops_img = conv_flops_per_image(h, w, 3) + conv_flops_per_image(h, w, 1)
     rec['conv_tflops_end_to_end'] = round(batch * steps * flops_img / dt / 1e12, 2)
@@ -591,7 +592,7 @@ def main():
                                times_serial, args.steps)
     else:
         roofline = roofline_of(prof, ('k3',), PEAK_TFLOPS['bf16'],
-                               'conv_dma_kernel / conv_dma4_kernel / conv_mfma_kernel (3x3 implicit GEMM, all launches)', times_serial,
+                               'conv_dma4_kernel / conv_dma5_kernel / conv_first_pair_kernel / conv_dma_kernel / conv_mfma_kernel (3x3 implicit GEMM, all launches)', times_serial,
                                args.steps, traffic=committed_traffic(args.batch, args.height, args.width))
     per_image = conv_flops_per_image if args.expert == 'fcn' else adapnet_flops_per_image
     flops_img = per_image(args.height, args.width, 3) + per_image(args.height, args.width, 1)

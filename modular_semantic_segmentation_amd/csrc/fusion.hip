@@ -105,8 +105,9 @@ __global__ __launch_bounds__(256) void dirichlet_fuse_kernel(ProbPtrs probs, int
         lx[k] = k < C ? probs.p[e][pix * C + k] : 0.f;
         sum += lx[k];
       }
+      const float rs = xv_fast_rcp(sum);  // (the same helper forms as the fused head: xv_common.h)
 #pragma unroll
-      for (int k = 0; k < CMAX; ++k) lx[k] = k < C ? logf(1e-20f + lx[k] / sum) : 0.f;  // renormalise, then log(1e-20 + p)
+      for (int k = 0; k < CMAX; ++k) lx[k] = k < C ? xv_fast_log(1e-20f + lx[k] * rs) : 0.f;  // renormalise, then log(1e-20 + p)
       for (int c = 0; c < C; ++c) {
         const float* row = tab + ((int64_t)e * C + c) * CMAX;
         // explicit fmaf chain: the fused two-expert head (pointwise.hip fused_head_kernel) repeats this arithmetic and

@@ -563,14 +563,15 @@ __device__ __forceinline__ int head_softmax(float (&sc)[CM], float m, int C) {
   float sum = 0.f;
 #pragma unroll
   for (int k = 0; k < CM; ++k) {
-    sc[k] = k < C ? expf(sc[k] - m) : 0.f;
+    sc[k] = k < C ? xv_fast_exp(sc[k] - m) : 0.f;
     sum += sc[k];
   }
+  const float rsum = xv_fast_rcp(sum);
   float best = -1.f;
   int bi = 0;
 #pragma unroll
   for (int k = 0; k < CM; ++k) {
-    sc[k] = sc[k] / sum;
+    sc[k] = sc[k] * rsum;
     if (k < C && sc[k] > best) {
       best = sc[k];
       bi = k;
@@ -688,8 +689,11 @@ __global__ __launch_bounds__(256) void fused_head_kernel(const float* __restrict
           sc[k] = k < C ? sc[k] : 0.f;
           sum += sc[k];
         }
+        {
+          const float rs = xv_fast_rcp(sum);
 #pragma unroll
-        for (int k = 0; k < CM; ++k) sc[k] = k < C ? logf(1e-20f + sc[k] / sum) : 0.f;  // renormalise, then log(1e-20 + p)
+          for (int k = 0; k < CM; ++k) sc[k] = k < C ? xv_fast_log(1e-20f + sc[k] * rs) : 0.f;  // renormalise, then log(1e-20 + p)
+        }
         // (unrolled over the class: a run-time class index made every write to `total` twelve compare-selects)
 #pragma unroll
         for (int c = 0; c < CM; ++c) {
@@ -749,14 +753,15 @@ __global__ __launch_bounds__(256) void softmax_argmax_kernel(const float* __rest
     float sum = 0.f;
 #pragma unroll
     for (int k = 0; k < CMAX; ++k) {
-      e[k] = k < C ? expf(sc[k] - m) : 0.f;
+      e[k] = k < C ? xv_fast_exp(sc[k] - m) : 0.f;
       sum += e[k];
     }
+    const float rsum = xv_fast_rcp(sum);
     float best = -1.f;
     int bi = 0;
 #pragma unroll
     for (int k = 0; k < CMAX; ++k) {
-      const float p = e[k] / sum;
+      const float p = e[k] * rsum;
       if (k < C) {
         if (prob) prob[pix * C + k] = p;
         if (p > best) {
@@ -873,14 +878,15 @@ __global__ __launch_bounds__(256) void decoder_head_affine_kernel(const __bf16* 
     float sum = 0.f;
 #pragma unroll
     for (int k = 0; k < CM; ++k) {
-      sc[j][k] = k < C ? expf(sc[j][k] - m) : 0.f;
+      sc[j][k] = k < C ? xv_fast_exp(sc[j][k] - m) : 0.f;
       sum += sc[j][k];
     }
+    const float rsum = xv_fast_rcp(sum);
     float best = -1.f;
     int bi = 0;
 #pragma unroll
     for (int k = 0; k < CM; ++k) {
-      const float p = sc[j][k] / sum;
+      const float p = sc[j][k] * rsum;
       if (k < C) {
         if (prob) prob[(opix + j) * C + k] = p;
         if (p > best) {

@@ -140,6 +140,15 @@ __device__ static __forceinline__ uint32_t pk_max_i16(uint32_t a, uint32_t b) {
   return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s16x2, a), __builtin_bit_cast(s16x2, b)));
 }
 
+// The per-pixel softmax / log-probability arithmetic of the heads (tf.nn.softmax, Dirichlet.log_prob: basic_fusion_model.py:
+// 21-22, dirichlet_mix.py:23-36) on the transcendental unit: v_exp_f32 / v_log_f32 / v_rcp_f32 (about 1 ulp each) in place of
+// the correctly rounded library forms (10-15 instructions each; an IEEE division is ten).  24 logs, 24 exps and 48 divisions
+// per pixel made the fused Dirichlet head 10x slower than its 288 FMAs.  Every kernel that must agree
+// bit for bit with another one (fused head <-> head + fusion kernels) uses the same helper.
+__device__ static __forceinline__ float xv_fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.4426950408889634f); }
+__device__ static __forceinline__ float xv_fast_log(float x) { return __builtin_amdgcn_logf(x) * 0.6931471805599453f; }
+__device__ static __forceinline__ float xv_fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+
 // Order-preserving map of packed bf16 bit patterns onto signed 16-bit integers (an involution: negative values have their
 // magnitude bits flipped), for a 2x2 max on packed pairs WITHOUT a preceding relu.
 __device__ static __forceinline__ uint32_t pk_ord_bf16(uint32_t x) {

@@ -12,7 +12,7 @@ import re
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-CONV_SRCS = [os.path.join(ROOT, 'modular_semantic_segmentation_amd', 'csrc', f) for f in ('conv_mfma.hip', 'conv_f8_dma.hip')]
+CONV_SRCS = [os.path.join(ROOT, 'modular_semantic_segmentation_amd', 'csrc', f) for f in ('conv_mfma.hip', 'conv_f8_dma.hip', 'conv_col_dma.hip', 'conv_first_fused.hip')]
 
 
 def kernel_source_hash():
@@ -86,12 +86,13 @@ def copy_stats(tag, sub, dest):
 
 
 def main(tag, batch=16):
-    is_conv3 = lambda k: 'conv_dma_kernel' in k or 'conv_dma4_kernel' in k or ('conv_mfma_kernel' in k and ', 3, ' in k)      # noqa: E731
+    is_conv3 = lambda k: ('conv_dma_kernel' in k or 'conv_dma4_kernel' in k or 'conv_dma5_kernel' in k or 'conv_first_pair_kernel' in k  # noqa: E731
+                          or ('conv_mfma_kernel' in k and ', 3, ' in k))
     fetch = counter_avg('pmc_fetch', 'FETCH_SIZE', is_conv3)
     write = counter_avg('pmc_write', 'WRITE_SIZE', is_conv3)
-    out = {'kernel': 'conv_dma_kernel + conv_dma4_kernel + conv_mfma_kernel (all 3x3 launches)', 'source': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, '
+    out = {'kernel': 'conv_dma4_kernel + conv_dma5_kernel + conv_first_pair_kernel + conv_dma_kernel + conv_mfma_kernel (all 3x3 launches)', 'source': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, '
            'python3 bench.py --steps 3 --warmup 1 --serial-experts --no-graph (batch %d, 768x384)' % batch,
-           'batch': batch, 'kernel_source': 'csrc/conv_mfma.hip + csrc/conv_f8_dma.hip', 'kernel_source_sha256_16': kernel_source_hash()}
+           'batch': batch, 'kernel_source': 'csrc/conv_mfma.hip + conv_f8_dma.hip + conv_col_dma.hip + conv_first_fused.hip', 'kernel_source_sha256_16': kernel_source_hash()}
     if fetch and write:
         out.update(fetch_size_kb_per_launch=round(fetch[0], 1), write_size_kb_per_launch=round(write[0], 1),
                    launches=fetch[1],
@@ -106,7 +107,9 @@ def main(tag, batch=16):
 
     cmd = 'python3 bench.py --steps 3 --warmup 1 --serial-experts --no-graph --no-cpu-baseline --no-accuracy --no-extra'
     mfma_summary(tag, '', {'conv_dma_kernel': lambda k: 'conv_dma_kernel' in k,
-                           'conv_dma4_kernel<false, false> (generation 4, bf16)': lambda k: 'conv_dma4_kernel<false, false' in k,
+                           'conv_dma4_kernel<false, false, ..., M16> (generation 4 on 16x16x32, bf16)': lambda k: 'conv_dma4_kernel<false, false' in k,
+                           'conv_dma5_kernel<3> (generation 5, 24x16 tiles: conv5_x)': lambda k: 'conv_dma5_kernel<3' in k,
+                           'conv_first_pair_kernel (conv1_1 + conv1_2 + pool1 fused)': lambda k: 'conv_first_pair_kernel' in k,
                            'conv_mfma_kernel (bf16, first generation)': lambda k: 'conv_mfma_kernel' in k and not is_f8(k)},
                  cmd + ' (batch 16, 768x384)')
     mfma_summary(tag, '8', {'conv_dma4_kernel<true, true> (generation 4, e4m3 operands)': lambda k: 'conv_dma4_kernel<true' in k,
