@@ -119,6 +119,8 @@ def main(tag, batch=16):
                  cmd + ' --dtype fp8 --height 1024 --width 2048 --batch 4')
     copy_stats(tag, tag + '_trace', '%s_bench_serial_kernel_stats.csv' % tag)
     copy_stats(tag, tag + '_trace8', '%s_bench_fp8_2048_kernel_stats.csv' % tag)
+    copy_stats(tag, tag + '_trace_train', '%s_train_kernel_stats.csv' % tag)
+    copy_stats(tag, tag + '_trace_train_bn', '%s_train_bn_kernel_stats.csv' % tag)
 
 
 if __name__ == '__main__':

@@ -13,6 +13,9 @@ FP8="$BENCH --dtype fp8 --height 1024 --width 2048 --batch 4"
 run() { d=$1; shift; rm -rf $OUT/$d; rocprofv3 --output-format csv "$@" > $OUT/$d.log 2>&1; }
 run ${TAG}_trace   --kernel-trace --stats -d $OUT/${TAG}_trace -o bench -- $BENCH
 run ${TAG}_trace8  --kernel-trace --stats -d $OUT/${TAG}_trace8 -o bench -- $FP8
+TRAIN="python3 $ROOT/bench.py --mode train --steps 3 --warmup 1 --min-seconds 0 --no-cpu-baseline --no-accuracy --no-extra"
+run ${TAG}_trace_train    --kernel-trace --stats -d $OUT/${TAG}_trace_train -o bench -- $TRAIN
+run ${TAG}_trace_train_bn --kernel-trace --stats -d $OUT/${TAG}_trace_train_bn -o bench -- $TRAIN --batch-norm
 run pmc_fetch      --pmc FETCH_SIZE -d $OUT/pmc_fetch -o c -- $BENCH
 run pmc_write      --pmc WRITE_SIZE -d $OUT/pmc_write -o c -- $BENCH
 run pmc_mfma       --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_WAVE_CYCLES -d $OUT/pmc_mfma -o c -- $BENCH
