@@ -61,12 +61,10 @@ const char* xv_source_hash(void);
  * 16-byte slot s of row `co` stored at slot s ^ (co & 6) (so a weight tile is a linear copy
  * into bank-conflict-free LDS).  For k = 3 a second image follows in the same buffer for the
  * 32-channel-chunk kernel: bf16 [tap][cin/32][cout][32], 64-byte rows, slot s of row `co` at
- * s ^ ((co >> 1) & 2); and a third for the generation-4 kernel (conv_f8_dma.hip, 32x32 MFMA blocks): the same
- * [tap][cin/32][row][32] with slot s of row r at s ^ ((r >> 2) & 3) and the rows of every 32-row block permuted
- * (row 8g + 4h + q = channel 16h + 4g + q, so that a lane's 16 accumulator registers are 16 consecutive output
- * channels); and a fourth for the same kernel on 16x16x32 MFMA blocks (configuration 26): slot s of row r at
- * s ^ ((r >> 1) & 2), the rows of every 64-row block permuted (row 16j + 4g + q = channel 16g + 4j + q).
- * xv_packed_weight_bytes is the size of all four.
+ * s ^ ((co >> 1) & 2); and a third for generations 4 / 5 and the fused first pair (16x16x32 MFMA blocks,
+ * configurations 26-28): the same [tap][cin/32][row][32] with slot s of row r at s ^ ((r >> 1) & 2) and the rows of
+ * every 64-row block permuted (row 16j + 4g + q = channel 16g + 4j + q, so that a lane's 16 accumulator registers of a
+ * pixel are 16 consecutive output channels).  xv_packed_weight_bytes is the size of all three.
  * k = 1 or 3, cin % 64 == 0, cout % 64 == 0.                                                       */
 size_t xv_packed_weight_bytes(int k, int cin, int cout);
 int xv_pack_conv_weights(const float* w_hwio, void* packed, int k, int cin, int cout, void* stream);

@@ -14,7 +14,7 @@
 //     group (3 taps) MT + 2 pixel fragments: 36 + 3 (MT + 2) ds_read_b128 per item against 36 + 24 for the 2 rows x 32
 //     columns of generation 4 -- 54 instead of 60 at MT = 4 for the same 144 MFMAs.
 //   * LDS images, the source-side swizzle of the DMA (g4_swz16: slot s of row r at s ^ ((r >> 1) & 2), conflict-free for
-//     every column offset), the packed weight image (the FOURTH image of xv_pack_conv_weights: rows permuted so that a
+//     every column offset), the packed weight image (the THIRD image of xv_pack_conv_weights: rows permuted so that a
 //     lane's 16 accumulators of a pixel are 16 consecutive channels) and the epilogue are generation 4's 16x16 form.
 //   * Fragment schedule (reads return in order; at most 4 + (MT + 2) + 4 = 14 in flight, the counter holds 15):
 //       before tap 0: bias W0 P0 | tap 0: wait, W1 | tap t: W(t+1), wait, [P of the next column group at taps 1 and 3], MFMAs.
@@ -25,7 +25,7 @@ namespace {
 
 struct G5Args {
   const char* x;      // bf16 [N][H+2][W+2][Cin], zero border
-  const char* wpk;    // packed bf16 weights (four images; this kernel reads the fourth)
+  const char* wpk;    // packed bf16 weights (three images; this kernel reads the third)
   const float* bias;  // [Cout]
   char* y;            // bf16 [N][H+2][W+2][Cout] or null
   char* pooled;       // bf16 [N][H/2+2][W/2+2][Cout] or null
@@ -77,7 +77,7 @@ __global__ __launch_bounds__(512, 2) void conv_dma5_kernel(G5Args a) {
   const int Wp = W + 2;
   const int Cb = 2 * Cin, Ob = 2 * Cout;  // bytes per pixel of the input / output maps
   const int nchunks = Cb >> 6;            // 64 bytes = 32 input channels per chunk
-  const char* const wimg = a.wpk + (int64_t)6 * 9 * Cin * Cout;  // the fourth packed image
+  const char* const wimg = a.wpk + (int64_t)4 * 9 * Cin * Cout;  // the third packed image
 
   // persistent workgroups, XCD-contiguous tile ranges, the output-channel tiles of one patch adjacent (as generation 2 / 4)
   const int G = gridDim.x, b = blockIdx.x;

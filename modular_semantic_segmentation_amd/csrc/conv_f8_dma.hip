@@ -138,7 +138,7 @@ __device__ __forceinline__ float g4_dpp_swap1(float v) {  // value of lane ^ 1 (
 template <bool F8, bool OF8 = F8, bool STATS = false, bool EDGE = false, bool M16 = false, bool DG = false>
 __global__ __launch_bounds__(512, 2) void conv_dma4_kernel(F8Args a) {
   using C = G4;
-  static_assert(!(M16 && F8), "the 16x16 form is a bf16 kernel");
+  static_assert(M16 != F8, "bf16 operands run on the 16x16x32 form, e4m3 operands on the 32x32x64 one");
   static_assert(!DG || (M16 && !OF8 && !STATS), "the data-gradient epilogue exists in the packed epilogue only");
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -156,8 +156,7 @@ __global__ __launch_bounds__(512, 2) void conv_dma4_kernel(F8Args a) {
     scale_w = __builtin_amdgcn_readfirstlane(scale_w);
   }
   // generation-4 image: fp8 -- behind the header and the generation-1 image; bf16 -- the third image of the packed buffer
-  // (M16: the fourth)
-  const char* const wimg = F8 ? a.wpk + 256 + (int64_t)9 * Cin * Cout : a.wpk + (int64_t)(M16 ? 6 : 4) * 9 * Cin * Cout;
+  const char* const wimg = F8 ? a.wpk + 256 + (int64_t)9 * Cin * Cout : a.wpk + (int64_t)4 * 9 * Cin * Cout;
 
   // persistent workgroups, XCD-contiguous tile ranges, the output-channel tiles of one patch adjacent (as generation 2)
   const int G = gridDim.x, b = blockIdx.x;
@@ -854,7 +853,7 @@ int xv_launch_conv3x3_f8_dma(const void* x, const void* wpk, const float* bias, 
                              int Cin, int Cout, int relu, int in_f8, int out_f8, int scale_x, float out_mul, int num_cus,
                              hipStream_t stream, float* stats_rows, int m16, const void* mask, const void* addend) {
   if (!(in_f8 ? xv_conv3x3_f8_dma_ok(H, W, Cin, Cout) : xv_conv3x3_dma4_bf16_ok(H, W, Cin, Cout)) ||
-      (y == nullptr && pooled == nullptr) || (in_f8 && !out_f8) || (in_f8 && m16))
+      (y == nullptr && pooled == nullptr) || (in_f8 && !out_f8) || (in_f8 && m16) || (!in_f8 && !m16))
     return XV_ESHAPE;
   // the data-gradient epilogue exists in the packed epilogue of the bf16 16x16 form only
   if ((mask != nullptr || addend != nullptr) && (!m16 || out_f8 || stats_rows != nullptr || y == nullptr)) return XV_ESHAPE;
@@ -881,14 +880,13 @@ int xv_launch_conv3x3_f8_dma(const void* x, const void* wpk, const float* bias, 
     // exact tilings only (a partial tile's out-of-image pixels would enter the sums); one channel tile per workgroup
     if (in_f8 || out_f8 || Cout > 512 || !xv_conv3x3_dma4_exact(H, W) || (grid & 7) || (grid / 8) % a.n_ct) return XV_ESHAPE;
     a.stats = stats_rows;
-    return m16 ? g4_launch<false, false, true, true>(a, grid, stream) : g4_launch<false, false, true>(a, grid, stream);
+    return g4_launch<false, false, true, true>(a, grid, stream);
   }
   if (mask != nullptr || addend != nullptr)  // the data-gradient kernel (16x16 form, bf16 map out)
     return xv_conv3x3_dma4_exact(H, W) ? g4_launch1<false, false, false, false, true, true>(a, grid, stream)
                                        : g4_launch1<false, false, false, true, true, true>(a, grid, stream);
   if (in_f8) return g4_launch<true, true>(a, grid, stream);
-  if (m16) return out_f8 ? g4_launch<false, true, false, true>(a, grid, stream) : g4_launch<false, false, false, true>(a, grid, stream);
-  return out_f8 ? g4_launch<false, true>(a, grid, stream) : g4_launch<false, false>(a, grid, stream);
+  return out_f8 ? g4_launch<false, true, false, true>(a, grid, stream) : g4_launch<false, false, false, true>(a, grid, stream);
 }
 
 // second image of the packed fp8 buffer (xv_pack_conv_weights_f8 calls this for 3x3 kernels with cin % 64 == 0)

@@ -33,7 +33,7 @@ struct F1Args {
   const float* x;     // raw input, dense NHWC fp32 [N][H][W][CIN]
   const float* w1;    // conv1_1 kernel, fp32 HWIO [3][3][CIN][64]
   const float* b1;    // [64]
-  const char* wpk2;   // conv1_2 packed weights (four images; this kernel reads the fourth)
+  const char* wpk2;   // conv1_2 packed weights (three images; this kernel reads the third)
   const float* b2;    // [64]
   char* y;            // bf16 [N][H+2][W+2][64] or null
   char* pooled;       // bf16 [N][H/2+2][W/2+2][64] or null
@@ -114,9 +114,9 @@ __global__ __launch_bounds__(512, 2) void conv_first_pair_kernel(F1Args a) {
   int lid = t_begin + bi;
   if (lid >= t_end) return;
 
-  // ---- once per workgroup: conv1_2's weights (fourth packed image, both 32-channel chunks) into LDS ----
+  // ---- once per workgroup: conv1_2's weights (third packed image, both 32-channel chunks) into LDS ----
   {
-    const char* wimg = a.wpk2 + (int64_t)6 * 9 * 64 * 64;  // [tap][chunk 0..1][64 rows][64 B]
+    const char* wimg = a.wpk2 + (int64_t)4 * 9 * 64 * 64;  // [tap][chunk 0..1][64 rows][64 B]
 #pragma unroll
     for (int it = 0; it < (2 * C::B_PIECES + C::NWAVES - 1) / C::NWAVES; ++it) {
       const int piece = wave + it * C::NWAVES;  // 0 .. 71: chunk = piece / 36, then tap, then KB of the tap

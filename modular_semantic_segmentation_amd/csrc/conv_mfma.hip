@@ -1843,16 +1843,11 @@ __device__ __forceinline__ void pack_weights_image(const float* __restrict__ w, 
     const int tap = (int)(rest / nch32);
     const int sl = xv_swz32(co, ps);
     out[total + idx] = (__bf16)wl(tap, chunk * 32 + sl * 8 + e, co);
-    // image 3 (generation 4, conv_f8_dma.hip): [tap][chunk32][row rho][phys_slot 0..3][e], slots swizzled by
-    // (rho >> 2) & 3, rows permuted inside every 32-row block (row 8g + 4h + q = channel 16h + 4g + q)
-    const int m = co & 31;  // here `co` is the ROW index rho
-    const int ch = (co & ~31) + 16 * ((m >> 2) & 1) + 4 * (m >> 3) + (m & 3);
-    out[2 * total + idx] = (__bf16)wl(tap, chunk * 32 + (ps ^ ((co >> 2) & 3)) * 8 + e, ch);
-    // image 4 (generation 4 on 16x16x32 MFMA blocks, configuration 26): rows permuted inside every 64-row block (row
+    // image 3 (generations 4 / 5 on 16x16x32 MFMA blocks, configurations 26-28, and the fused first pair): rows permuted inside every 64-row block (row
     // 16 j + 4 g + q = channel 16 g + 4 j + q: an involution), slots swizzled by (rho >> 1) & 2
     const int m6 = co & 63;
     const int ch16 = (co & ~63) + 16 * ((m6 >> 2) & 3) + 4 * (m6 >> 4) + (m6 & 3);
-    out[3 * total + idx] = (__bf16)wl(tap, chunk * 32 + (ps ^ ((co >> 1) & 2)) * 8 + e, ch16);
+    out[2 * total + idx] = (__bf16)wl(tap, chunk * 32 + (ps ^ ((co >> 1) & 2)) * 8 + e, ch16);
   }
 }
 
@@ -1901,16 +1896,11 @@ __device__ __forceinline__ void pack_weights_group(const float* __restrict__ w, 
   if (taps == 9) {  // image 2 (generation-2 kernel): [tap][chunk32][co][phys_slot 0..3][e]
     const int64_t at = ((((int64_t)tap * (rc >> 5) + (G >> 2)) * oc + co) << 5) + xv_swz32(co, G & 3) * 8;
     *reinterpret_cast<u32x4*>(out + total + at) = o;
-    // image 3 (generation 4): this channel's row rho of the permuted 32-row block, slot swizzled by (rho >> 2) & 3
-    const int c = co & 31;
-    const int rho = (co & ~31) + 8 * ((c >> 2) & 3) + 4 * (c >> 4) + (c & 3);
-    const int64_t at3 = ((((int64_t)tap * (rc >> 5) + (G >> 2)) * oc + rho) << 5) + (((G & 3) ^ ((rho >> 2) & 3)) << 3);
-    *reinterpret_cast<u32x4*>(out + 2 * total + at3) = o;
-    // image 4 (generation 4, 16x16x32 blocks): row 16 j + 4 g + q of the 64-row block for channel 16 g + 4 j + q
+    // image 3 (generations 4 / 5, 16x16x32 blocks): row 16 j + 4 g + q of the 64-row block for channel 16 g + 4 j + q
     const int c6 = co & 63;
     const int rho16 = (co & ~63) + 16 * ((c6 >> 2) & 3) + 4 * (c6 >> 4) + (c6 & 3);
     const int64_t at4 = ((((int64_t)tap * (rc >> 5) + (G >> 2)) * oc + rho16) << 5) + (((G & 3) ^ ((rho16 >> 1) & 2)) << 3);
-    *reinterpret_cast<u32x4*>(out + 3 * total + at4) = o;
+    *reinterpret_cast<u32x4*>(out + 2 * total + at4) = o;
   }
 }
 
@@ -1982,8 +1972,8 @@ __global__ void pack_weights_f8_kernel(const float* __restrict__ w, char* __rest
 //      32 KB, several workgroups per CU: the FCN's two score convs
 //  24: generation 4 (conv_f8_dma.hip): e4m3 in and out, 16x32 x 64, 8 waves, 64-channel chunks on
 //      v_mfma_scale_f32_32x32x64_f8f6f4, all operands by LDS-DMA, 151 KB, 1/CU; maps that tile exactly
-//  25: generation 4 on bf16 operands (v_mfma_f32_32x32x16_bf16, 32-channel chunks): bias + relu (+ pool) only
-//  26: as 25 on v_mfma_f32_16x16x32_bf16 at the same output tile per wave (the chip holds a higher clock on this shape)
+//  25: (retired in round 4: generation 4 on v_mfma_f32_32x32x16_bf16; held 0.2 GHz less clock than 26 on real data)
+//  26: generation 4 on bf16 operands, v_mfma_f32_16x16x32_bf16, 32-channel chunks: bias + relu (+ pool), data-gradient epilogue
 //  27 / 28: generation 5 (conv_col_dma.hip): the loop of 26 on a column of 8 waves x 3 / 4 rows x 16 columns -- 24x16 and
 //      32x16 tiles (the 24x48 conv5 maps tile exactly in 24x16); exact tilings only, fused pool on 28 only
 constexpr int XV_NUM_CONV_CFG = 29;
@@ -2007,10 +1997,11 @@ int launch_cfg(int cfg, const ConvArgs& a, hipStream_t s) {
     return xv_launch_conv3x3_f8_dma(a.x, a.wpk, a.bias, a.y, a.pooled, a.N, a.H, a.W, a.Cin, a.Cout, a.relu, 1, 1, a.scale_x,
                                     a.out_mul, a.num_cus, s);
   }
-  if (cfg == 25 || cfg == 26) {
-    if (KS != 3 || a.in_f8 || (cfg == 25 && (a.mask != nullptr || a.addend != nullptr))) return XV_ESHAPE;
+  if (cfg == 25) return XV_ESHAPE;  // (retired: generation 4 on 32x32x16 bf16 blocks, superseded by 26; its weight image is gone)
+  if (cfg == 26) {
+    if (KS != 3 || a.in_f8) return XV_ESHAPE;
     return xv_launch_conv3x3_f8_dma(a.x, a.wpk, a.bias, a.y, a.pooled, a.N, a.H, a.W, a.Cin, a.Cout, a.relu, 0, a.out_f8, 0,
-                                    a.out_mul, a.num_cus, s, nullptr, cfg == 26, a.mask, a.addend);
+                                    a.out_mul, a.num_cus, s, nullptr, 1, a.mask, a.addend);
   }
   if (cfg == 27 || cfg == 28) {
     if (KS != 3 || a.in_f8 || a.out_f8) return XV_ESHAPE;
@@ -2152,16 +2143,16 @@ int pick_cfg(const ConvArgs& a, int k) {
     // 32x32x16 form (25) holds 1.69-1.76 GHz, this one 1.89-1.98 GHz at 3 % more cycles, generation 2 (17: 16x16x32 too, a
     // 15 % longer loop) 1.99-2.12 GHz; on zeros all three run at 2.39 GHz.  26 is ahead of both on every layer shape
     // (profiles/r4_conv_mfma_shape_ab.txt: +7-10 % on conv3_x / conv4_x, +2-8 % on the one- and two-chunk layers).
-    // Plain forward shapes only.  XV_BF16_GEN4=0: never; =2: only from 128 input channels; =3: the 32x32x16 form (A/B timing).
+    // XV_BF16_GEN4=0: never; =2: only from 128 input channels (A/B timing).
     {
       static const int gen4 = getenv("XV_BF16_GEN4") != nullptr ? atoi(getenv("XV_BF16_GEN4")) : 1;
       // (the data-gradient epilogue -- addend + relu mask -- exists in the 16x16 forms: XV_DGRAD_GEN4=0 keeps those convs on
       // generation 2, A/B timing)
       static const bool dgrad4 = getenv("XV_DGRAD_GEN4") == nullptr || atoi(getenv("XV_DGRAD_GEN4")) != 0;
       const bool dg = a.mask != nullptr || a.addend != nullptr;
-      if (gen4 && (!dg || (dgrad4 && gen4 != 3 && a.pooled == nullptr)) && a.sk_ws == nullptr && !a.in_f8 && !a.out_f8 &&
+      if (gen4 && (!dg || (dgrad4 && a.pooled == nullptr)) && a.sk_ws == nullptr && !a.in_f8 && !a.out_f8 &&
           xv_conv3x3_dma4_bf16_ok(a.H, a.W, a.Cin, a.Cout) && xv_conv3x3_dma4_exact(a.H, a.W) && (gen4 != 2 || a.Cin >= 128))
-        return gen4 == 3 ? 25 : 26;
+        return 26;
       // maps that tile in 24x16 but not in 16x32 (the 24x48 conv5 maps of a 768x384 input): the same loop on a column of
       // waves, generation 5 -- conv5_1 at 16 images 1 190 against 985 TFLOP/s on generation 2's 24x16 tile (configuration 22)
       if (gen4 && (!dg || dgrad4) && a.sk_ws == nullptr && !a.in_f8 && !a.out_f8 && a.pooled == nullptr &&
@@ -2242,7 +2233,7 @@ int conv_fwd_impl(const xv_act* x, const void* w_packed, const float* bias, cons
 
 extern "C" size_t xv_packed_weight_bytes(int k, int cin, int cout) {
   if ((k != 1 && k != 3) || cin <= 0 || cout <= 0 || (cin & 63) || (cout & 63)) return 0;
-  return (size_t)k * k * cin * cout * 2 * (k == 3 ? 4 : 1);  // 3x3: the four packed images (generations 1, 2, 4, 4 on 16x16 blocks)
+  return (size_t)k * k * cin * cout * 2 * (k == 3 ? 3 : 1);  // 3x3: the three packed images (generations 1, 2, 4 / 5 on 16x16 blocks)
 }
 
 extern "C" size_t xv_packed_weight_bytes_f8(int k, int cin, int cout) {

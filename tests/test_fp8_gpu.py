@@ -132,13 +132,13 @@ def test_fp8_conv_tile_configurations_agree(ops):
     assert all(torch.equal(outs[14], outs[c]) for c in (15, 16, 19, 20, 24))
 
 
-@pytest.mark.parametrize('cfg', [-1, 4, 10, 14, 16, 25, 26])
+@pytest.mark.parametrize('cfg', [-1, 4, 10, 14, 16, 26])
 def test_bf16_conv_with_fp8_output(ops, cfg):
     """conv2_1 of the fp8 network: 64 input channels are half an fp8 MFMA, so it stays a bf16 convolution whose
     epilogue writes e4m3 for conv2_2 (first-generation tiles only; the chooser avoids the others)."""
     rng = np.random.default_rng(9)
     n, h, w, cin, cout, ey = 1, 24, 48, 64, 128, 2
-    if cfg in (25, 26):     # generation 4 (conv1_2 of the fp8 plan where conv2_1 takes e4m3 chunks): exact 16x32 tilings
+    if cfg == 26:           # generation 4 (conv1_2 of the fp8 plan where conv2_1 takes e4m3 chunks): exact 16x32 tilings
         n, h, w = 2, 32, 96
     x = rng.integers(-2, 3, (n, h, w, cin)).astype(np.float32)
     wt = rng.integers(-1, 2, (3, 3, cin, cout)).astype(np.float32)

@@ -28,7 +28,7 @@ def test_library_builds_and_exports_every_declared_symbol():
         assert hasattr(handle, name)
     assert handle.xv_version() >= 100
     assert handle.xv_arch() == b'gfx950'
-    assert handle.xv_packed_weight_bytes(3, 64, 128) == 4 * 9 * 64 * 128 * 2     # four packed images (generations 1, 2, 4, 4 on 16x16 blocks)
+    assert handle.xv_packed_weight_bytes(3, 64, 128) == 3 * 9 * 64 * 128 * 2     # three packed images (generations 1, 2, 4 / 5 on 16x16x32 blocks)
     assert handle.xv_packed_weight_bytes_f8(3, 128, 64) == 256 + 2 * 9 * 128 * 64    # header + generations 1 and 4
     assert handle.xv_packed_weight_bytes_f8(3, 64, 64) == 256 + 2 * 9 * 64 * 64     # 64-channel e4m3 chunks: generation 4 only
     assert handle.xv_packed_weight_bytes_f8(1, 64, 64) == 0                         # 1x1: 128-channel chunks

@@ -80,7 +80,7 @@ def child():
                     assert c in (ESHAPE,) or 0 <= c < ncfg, (name, n, hh, ww, flags, din, dout, c)
                     if (flags, din, dout) == (0, 0, 0):
                         seen[(n, H, W, name)] = c
-            assert h.xv_packed_weight_bytes(3, cin, cout) == 4 * 9 * cin * cout * 2
+            assert h.xv_packed_weight_bytes(3, cin, cout) == 3 * 9 * cin * cout * 2
             assert h.xv_packed_weight_bytes_f8(3, cin, cout) == 256 + 2 * 9 * cin * cout
             ws = h.xv_conv2d_bwd_filter_workspace_bytes(n, hh, ww, cin, cout, 3)
             assert ws >= 9 * cin * cout * 4, (name, ws)

@@ -55,8 +55,10 @@ def main():
     ap.add_argument('--height', type=int, default=384)
     ap.add_argument('--width', type=int, default=768)
     ap.add_argument('--seconds', type=float, default=2.0, help='back-to-back launches before the stamps are read')
-    ap.add_argument('--cases', default='conv3_2:25,conv3_2:26,conv3_2:17,conv4_2:25,conv4_2:26,conv4_2:17,conv3_1:25,conv3_1:26,'
-                                       'conv1_2:17,conv1_2:26,conv2_1:17,conv2_1:26,conv2_2:17,conv2_2:26,conv5_1:22,conv5_1:26')
+    ap.add_argument('--cases', default='conv3_2:26,conv3_2:17,conv4_2:26,conv4_2:17,conv3_1:26,conv1_2:17,conv1_2:26,conv2_1:17,conv2_1:26,conv2_2:17,'
+                                       'conv2_2:26,conv5_1:22,conv5_1:27',
+                    help='layer:configuration pairs (configuration 25, the 32x32x16 form in profiles/r4_conv_inkernel_clock.json, was '
+                         'retired after that measurement)')
     ap.add_argument('--data', default='normal,relu,zero')
     ap.add_argument('--out', default=os.path.join(ROOT, 'gpurun_out', 'r4_conv_inkernel_clock.json'))
     args = ap.parse_args()

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Randomised bit-exact comparison of the generation-2 conv kernel (configuration 17; generation 4, configuration 25,
+"""Randomised bit-exact comparison of the generation-2 conv kernel (configuration 17; generation 4, configuration 26,
 on the maps that tile) against generation 1 (configuration 14) on integer-valued operands: random batch / image sizes (whole and partial tiles, fewer and many
 more tiles than workgroups), channel counts, output modes (full map, fused pool, pooled only) and the data-gradient
 epilogue (addend + relu mask).  GPU box only."""
@@ -79,7 +79,7 @@ for case in range(args.cases):
     cin = int(rng.choice([64, 128, 192, 256]))
     cout = int(rng.choice([64, 128, 192]))
     mode = int(rng.integers(0, 4))          # 0 full map, 1 full + pool, 2 pooled only, 3 data gradient
-    tiles = case % 3 == 0                   # a map that tiles exactly in 16x32: generation 4 (configurations 25 / 26) joins
+    tiles = case % 3 == 0                   # a map that tiles exactly in 16x32: generation 4 (configuration 26) joins
     #                                         (mode 3: the public data-gradient op then runs on configuration 26)
     if tiles:
         h, w = (h + 15) // 16 * 16, (w + 31) // 32 * 32
@@ -115,7 +115,7 @@ for case in range(args.cases):
                   'cfg', _lib.lib().xv_conv2d_choose_cfg(n, h, w, cout, cin, 3, 0, 0, 2))
     else:
         wp = ops.pack_conv_weights(wt)
-        for cfg in (14, 17, 21) + ((22,) if mode == 0 else ()) + ((25, 26) if tiles else ()):          # 22: no fused pool
+        for cfg in (14, 17, 21) + ((22,) if mode == 0 else ()) + ((26,) if tiles else ()):          # 22: no fused pool
             y = ops.Act(n, h, w, cout) if mode != 2 else None
             q = ops.Act(n, h // 2, w // 2, cout) if mode in (1, 2) else None
             ops.conv2d_fwd(xa, wp, b, 3, relu=relu, y=y, pooled=q, write_y=y is not None, cfg=cfg)

@@ -73,8 +73,8 @@ for (n, h, w, cin, cout, k) in CASES:
     print('case', (n, h, w, cin, cout, k), 'done', flush=True)
 
 # ---- generation 4 (conv_f8_dma.hip: all operands by LDS-DMA, counted vmcnt across the item barrier): maps that tile in
-# 16x32, bf16 (configuration 25) and e4m3 (24; 64- and 128-channel inputs: one and two chunks per tile), pooled outputs
-G4 = [(2, 32, 64, 256, 128, 25), (3, 48, 96, 64, 64, 25), (2, 32, 64, 256, 128, 26), (3, 48, 96, 64, 64, 26), (2, 32, 64, 128, 128, 24), (3, 32, 96, 64, 128, 24)]
+# 16x32, bf16 (configuration 26) and e4m3 (24; 64- and 128-channel inputs: one and two chunks per tile), pooled outputs
+G4 = [(2, 32, 64, 256, 128, 26), (3, 48, 96, 64, 64, 26), (2, 32, 64, 128, 128, 24), (3, 32, 96, 64, 128, 24)]
 for (n, h, w, cin, cout, cfg) in G4:
     xs = rng.integers(-2, 3, (n, h, w, cin)).astype(np.float32)
     ws = rng.integers(-1, 2, (3, 3, cin, cout)).astype(np.float32)
@@ -100,7 +100,7 @@ for (n, h, w, cin, cout, cfg) in G4:
         del pad
         if want is None:
             want = got
-            if cfg in (25, 26):
+            if cfg == 26:
                 import torch.nn.functional as F
                 y32 = F.conv2d(torch.from_numpy(xs).permute(0, 3, 1, 2), torch.from_numpy(ws).permute(3, 2, 0, 1), padding=1)
                 assert torch.equal(y.interior().cpu(), torch.relu(y32).permute(0, 2, 3, 1).to(torch.bfloat16)), 'forward wrong'
