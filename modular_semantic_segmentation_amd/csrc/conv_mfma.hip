@@ -2150,6 +2150,14 @@ int pick_cfg(const ConvArgs& a, int k) {
       // generation 2, A/B timing)
       static const bool dgrad4 = getenv("XV_DGRAD_GEN4") == nullptr || atoi(getenv("XV_DGRAD_GEN4")) != 0;
       const bool dg = a.mask != nullptr || a.addend != nullptr;
+      // (XV_COL_ROUNDS=1, A/B timing: maps that tile both ways take the 24x16 tile when it makes whole rounds of workgroups
+      // and the 16x32 tile does not -- conv4_x at 16 images: 6 rounds against 4.5)
+      static const bool col_rounds = getenv("XV_COL_ROUNDS") != nullptr && atoi(getenv("XV_COL_ROUNDS")) != 0;
+      if (col_rounds && gen4 && (!dg || dgrad4) && a.sk_ws == nullptr && !a.in_f8 && !a.out_f8 && a.pooled == nullptr &&
+          xv_conv3x3_col_ok(a.H, a.W, a.Cin, a.Cout, 3) && xv_conv3x3_dma4_exact(a.H, a.W)) {
+        const int64_t i26 = (int64_t)a.N * (a.H / 16) * (a.W / 32) * (a.Cout / 64), i27 = (int64_t)a.N * (a.H / 24) * (a.W / 16) * (a.Cout / 64);
+        if (i27 % a.num_cus == 0 && i26 % a.num_cus != 0) return 27;
+      }
       if (gen4 && (!dg || (dgrad4 && a.pooled == nullptr)) && a.sk_ws == nullptr && !a.in_f8 && !a.out_f8 &&
           xv_conv3x3_dma4_bf16_ok(a.H, a.W, a.Cin, a.Cout) && xv_conv3x3_dma4_exact(a.H, a.W) && (gen4 != 2 || a.Cin >= 128))
         return 26;
