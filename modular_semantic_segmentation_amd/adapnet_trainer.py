@@ -277,9 +277,9 @@ class AdapnetTrainer(object):
         n, h, w, _ = x.shape
         if h % 16 or w % 16:
             raise ValueError('H and W must be multiples of 16')
-        self.grad.zero_()
-        self.loss.zero_()
-        self.count.zero_()
+        ops.zero_(self.grad)
+        ops.zero_(self.loss)
+        ops.zero_(self.count)
         ops.count_valid_labels(labels, e.C, self.count)
         self._sync = reducer is not None
         if reducer is not None:
@@ -313,7 +313,7 @@ class AdapnetTrainer(object):
                     if dw is None:
                         dw = self._scratch[('dw', key)] = torch.empty(k, k, xact.c, cout, dtype=torch.float32,
                                                                       device=e.device)
-                    dw.zero_()
+                    ops.zero_(dw)
                     ops.conv2d_bwd_filter(xact, dz, dw, G(scope, 'bias') if has_bias else None, k, workspace=wws)
                     scatter(dw)
                 if xname is not None:
@@ -408,7 +408,7 @@ class AdapnetTrainer(object):
             dk = self._scratch.get(('dk', scope))
             if dk is None:
                 dk = self._scratch[('dk', scope)] = torch.empty(kshape, dtype=torch.float32, device=e.device)
-            dk.zero_()
+            ops.zero_(dk)
             ops.conv2d_bwd_filter(xact, dph, dk, None, 3, workspace=wws)
             G(scope, 'kernel').view(-1).add_(dk.view(-1)[inv])
             self._accum(xname, ops.conv2d_bwd_data(dph, self.wd[scope], self.zeros[:xact.c], self._like(dxtag, xact), 3))
@@ -481,8 +481,8 @@ class AdapnetTrainer(object):
         self.moving[s2][1].copy_(st['mv'][c1:])
 
         def bwd_bn(dy):
-            st['dg'].zero_()
-            st['db'].zero_()
+            ops.zero_(st['dg'])
+            ops.zero_(st['db'])
             dz = ops.bn_backward(dy, y if relu else None, z, st['gamma'], st['bn'], st['dg'], st['db'],
                                  self._like('dz_' + name, z), sync=self._sync)
             self.view(self.grad, s1, 'gamma').add_(st['dg'][:c1])

@@ -89,8 +89,8 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const __bf16* __restrict
 #pragma unroll
         for (int w = 0; w < 4; ++w) {
           const float za = bf_lo(zv[q][w]), zb = bf_hi(zv[q][w]);
-          const float ga = za * sc[2 * w] + sh[2 * w] > 0.f ? bf_lo(gv[q][w]) : 0.f;
-          const float gb = zb * sc[2 * w + 1] + sh[2 * w + 1] > 0.f ? bf_hi(gv[q][w]) : 0.f;
+          const float ga = fmaf(za, sc[2 * w], sh[2 * w]) > 0.f ? bf_lo(gv[q][w]) : 0.f;
+          const float gb = fmaf(zb, sc[2 * w + 1], sh[2 * w + 1]) > 0.f ? bf_hi(gv[q][w]) : 0.f;
           s0[2 * w] += ga;
           s1[2 * w] += ga * (za - mu[2 * w]) * is[2 * w];
           s0[2 * w + 1] += gb;
@@ -103,8 +103,8 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const __bf16* __restrict
 #pragma unroll
       for (int w = 0; w < 4; ++w) {
         const float za = bf_lo(zv[w]), zb = bf_hi(zv[w]);
-        const float ga = za * sc[2 * w] + sh[2 * w] > 0.f ? bf_lo(gv[w]) : 0.f;
-        const float gb = zb * sc[2 * w + 1] + sh[2 * w + 1] > 0.f ? bf_hi(gv[w]) : 0.f;
+        const float ga = fmaf(za, sc[2 * w], sh[2 * w]) > 0.f ? bf_lo(gv[w]) : 0.f;
+        const float gb = fmaf(zb, sc[2 * w + 1], sh[2 * w + 1]) > 0.f ? bf_hi(gv[w]) : 0.f;
         s0[2 * w] += ga;
         s1[2 * w] += ga * (za - mu[2 * w]) * is[2 * w];
         s0[2 * w + 1] += gb;
@@ -241,8 +241,8 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const __bf16* __restrict_
     u32x4 o;
 #pragma unroll
     for (int w = 0; w < 4; ++w) {
-      float a = bf_lo(zv[w]) * scale[cg * 8 + 2 * w] + shift[cg * 8 + 2 * w];
-      float b = bf_hi(zv[w]) * scale[cg * 8 + 2 * w + 1] + shift[cg * 8 + 2 * w + 1];
+      float a = fmaf(bf_lo(zv[w]), scale[cg * 8 + 2 * w], shift[cg * 8 + 2 * w]);
+      float b = fmaf(bf_hi(zv[w]), scale[cg * 8 + 2 * w + 1], shift[cg * 8 + 2 * w + 1]);
       if (relu) {
         a = a > 0.f ? a : 0.f;
         b = b > 0.f ? b : 0.f;
@@ -317,8 +317,8 @@ __global__ __launch_bounds__(256) void bn_apply_fast_kernel(const __bf16* __rest
     u32x4 o;
 #pragma unroll
     for (int w = 0; w < 4; ++w) {
-      float a = bf_lo(zv[w]) * sc[2 * w] + sh[2 * w];
-      float b = bf_hi(zv[w]) * sc[2 * w + 1] + sh[2 * w + 1];
+      float a = fmaf(bf_lo(zv[w]), sc[2 * w], sh[2 * w]);
+      float b = fmaf(bf_hi(zv[w]), sc[2 * w + 1], sh[2 * w + 1]);
       if (relu) {
         a = a > 0.f ? a : 0.f;
         b = b > 0.f ? b : 0.f;
@@ -345,7 +345,8 @@ __global__ __launch_bounds__(256) void bn_apply_fast_kernel(const __bf16* __rest
   }
 }
 
-// MASKZ: the relu mask recomputed from z (z * zsc + zsh > 0) instead of read from y
+// MASKZ: the relu mask recomputed from z (fmaf(z, zsc, zsh) > 0: the SAME explicit fused multiply-add in the forward apply kernels and in every
+// kernel that recomputes the mask, so the sign test is identical by construction, not by the compiler's contraction choices) instead of read from y
 template <bool MASKZ>
 __global__ __launch_bounds__(256) void bn_bwd_apply_fast_kernel(const __bf16* __restrict__ dy, const __bf16* __restrict__ y,
                                                                const __bf16* __restrict__ z, const float* __restrict__ mean,
@@ -381,7 +382,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_fast_kernel(const __bf16* __
       for (int h = 0; h < 2; ++h) {
         const int e = 2 * w + h;
         const float zz = h ? bf_hi(zv[w]) : bf_lo(zv[w]);
-        const float yy_ = MASKZ ? zz * sc[e] + sh[e] : (h ? bf_hi(yv[w]) : bf_lo(yv[w]));
+        const float yy_ = MASKZ ? fmaf(zz, sc[e], sh[e]) : (h ? bf_hi(yv[w]) : bf_lo(yv[w]));
         const float g = yy_ > 0.f ? (h ? bf_hi(gv[w]) : bf_lo(gv[w])) : 0.f;
         const float zh = (zz - mu[e]) * is[e];
         v[h] = gk[e] * is[e] * (g - db[e] - zh * dg[e]);
@@ -438,8 +439,8 @@ __global__ __launch_bounds__(256) void bn_apply_pool_kernel(const __bf16* __rest
       float m0 = 0.f, m1 = 0.f;
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        float a = bf_lo(v[k][w]) * sc[2 * w] + sh[2 * w];
-        float b = bf_hi(v[k][w]) * sc[2 * w + 1] + sh[2 * w + 1];
+        float a = fmaf(bf_lo(v[k][w]), sc[2 * w], sh[2 * w]);
+        float b = fmaf(bf_hi(v[k][w]), sc[2 * w + 1], sh[2 * w + 1]);
         a = a > 0.f ? a : 0.f;
         b = b > 0.f ? b : 0.f;
         o[k][w] = pack_bf16x2(a, b);
@@ -506,7 +507,7 @@ __global__ __launch_bounds__(256) void bn_pool_bwd_kernel(const __bf16* __restri
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
           zz[k] = h ? bf_hi(v[k][w]) : bf_lo(v[k][w]);
-          const float a = zz[k] * sc[e] + sh[e];
+          const float a = fmaf(zz[k], sc[e], sh[e]);
           yy[k] = bf_lo(pack_bf16x2(a > 0.f ? a : 0.f, 0.f));  // the stored activation: relu, rounded to bf16
         }
         int best = 0;

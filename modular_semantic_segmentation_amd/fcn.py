@@ -131,8 +131,14 @@ class FcnEngine(object):
     def load(self, variables):
         p, dev = self.prefix, self.device
         # new weights -> new activation ranges: the fp8 exponents of the previous weights would saturate (or underflow)
-        # silently, so the next batch seen calibrates again (or the caller calls calibrate())
-        self.fp8_scales = None
+        # silently, so the next batch seen calibrates again (or the caller calls calibrate()).  An EXPLICIT calibration is not
+        # dropped silently: the first batch after this would become the calibration set (a host sync, and exponents that
+        # depend on which batch comes first -- per rank under data parallelism).
+        if getattr(self, 'fp8_scales', None) is not None and getattr(self, '_fp8_explicit', False):
+            import warnings
+            warnings.warn('FcnEngine.load(): new weights invalidate the fp8 calibration of %r; call calibrate() again '
+                          '(otherwise the next batch seen is used)' % self.prefix, RuntimeWarning, stacklevel=2)
+        self.fp8_scales, self._fp8_explicit = None, False
         v = {k: np.asarray(a, np.float32) for k, a in variables.items() if k.startswith(p + '/')}
         for need, shape in variable_shapes(p, self.cin, self.U, self.C).items():
             if need not in v:
@@ -231,7 +237,7 @@ class FcnEngine(object):
         return a
 
     # ---- fp8: static per-tensor scales -----------------------------------------------------------------------
-    def calibrate(self, x, margin_bits=1):
+    def calibrate(self, x, margin_bits=1, _implicit=False):
         """Choose the power-of-two scale of every fp8 activation map from one representative batch: run the bf16
         graph, take max|activation| per layer, and leave `margin_bits` of headroom (an e4m3 value keeps its 3
         mantissa bits anywhere in 2^-6 .. 2^8 of the scale, so headroom costs no precision; values beyond it
@@ -244,12 +250,13 @@ class FcnEngine(object):
             self.conv_dtype = dtype
         self.fp8_scales = {name: ops.fp8_scale_exp(L[name].interior().abs().max().item(), margin_bits)
                            for name in FP8_MAPS}
+        self._fp8_explicit = not _implicit
         return dict(self.fp8_scales)
 
     def _encoder_fp8(self, x, keep_all=False):
         """The trunk with e4m3 operands from conv2_1 / conv2_2 on (see fp8_plan); same layer dict as `encoder`."""
         if self.fp8_scales is None:
-            self.calibrate(x)           # first batch seen = calibration batch
+            self.calibrate(x, _implicit=True)           # first batch seen = calibration batch
         n, h, w, _ = x.shape
         e = self.fp8_scales
         convs8, maps8 = fp8_plan(h, w, self.fp8_deep)

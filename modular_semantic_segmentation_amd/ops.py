@@ -87,7 +87,7 @@ CONV_PROFILE = None
 
 
 def packed_weight_elems(k, cin, cout):
-    """bf16 elements of the packed weight buffer of a k x k conv (3x3: two images, see xview_hip.h)."""
+    """bf16 elements of the packed weight buffer of a k x k conv (3x3: three images, see xview_hip.h)."""
     return _lib.lib().xv_packed_weight_bytes(k, cin, cout) // 2
 
 
