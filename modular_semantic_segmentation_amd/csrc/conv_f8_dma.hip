@@ -381,6 +381,12 @@ __global__ __launch_bounds__(512, 2) void conv_dma4_kernel(F8Args a) {
     // no accumulator clearing in the epilogue (128 of its ~230 VALU instructions per lane)
 #define G4_C_BIAS(i, j, h, jj) __builtin_bit_cast(f32x4, bvec[2 * (j) + (jj)])
 #define G4_MFMA(i, j, ws, ps, dy) G4_MFMA_C(i, j, ws, ps, dy, G4_C_ACC)
+    // e4m3 form, first tap of a tile: C = 0 (an inline constant: no register, no clearing in the epilogue)
+#define G4_MFMA_Z(i, j, ws, ps, dy)                                                                                    \
+  acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(G4_CAT(wf[ws][j][0], wf[ws][j][1]),                      \
+                                                              G4_CAT(xf[ps][(i) + (dy)][0], xf[ps][(i) + (dy)][1]),    \
+                                                              f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, \
+                                                              0, 0, 0, scale_w, 0, a.scale_x);
 #define G4_MFMA_B(i, j, ws, ps, dy) G4_MFMA_C(i, j, ws, ps, dy, G4_C_BIAS)
 #define G4_MFMA_C(i, j, ws, ps, dy, CS)                                                                                \
   if constexpr (F8) {                                                                                                  \
@@ -502,7 +508,11 @@ __global__ __launch_bounds__(512, 2) void conv_dma4_kernel(F8Args a) {
         G4_TAP_BODY(0, G4_MFMA)
       }
     } else {
-      G4_TAP_BODY(0, G4_MFMA)
+      if (chunk == 0) {
+        G4_TAP_BODY(0, G4_MFMA_Z)
+      } else {
+        G4_TAP_BODY(0, G4_MFMA)
+      }
     }
     G4_TAP(1, G4_WAIT_WB, 4, G4_LDPA(1, 1))
     G4_TAP(2, G4_WAIT_W, 8, G4_LDPB(1, 1))
@@ -633,6 +643,62 @@ __global__ __launch_bounds__(512, 2) void conv_dma4_kernel(F8Args a) {
               *reinterpret_cast<u32x4*>(dst) = u32x4{m[0], m[1], m[2], m[3]};
               *reinterpret_cast<u32x4*>(dst + 16) = u32x4{m[4], m[5], m[6], m[7]};
             }
+          }
+          continue;
+        }
+        if constexpr (OF8 && !STATS) {
+          // e4m3 epilogue.  Scale (a power of two), bias, relu and saturation in TWO instructions per value: fma(s, mul, b mul)
+          // = (s + b) mul exactly (scaling by a power of two commutes with rounding), v_med3_f32 against (0 | -448, 448) is
+          // relu + clamp; the 2x2 max on those (scaling and clamping are monotone: pooling after them = them after pooling)
+          // as v_med3_f32(x, y, +inf) -- a max without the operand quieting fmaxf pays under IEEE mode; one conversion.
+          // (The float form below cost ~10 instructions per value; the e4m3 layers have HALF the items per tile of the bf16
+          // ones at the same epilogue, so it weighed twice as much.)
+          const float lo = a.relu ? 0.f : -448.f, inf = __builtin_inff();
+          float q[2][16];
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              float s;
+              if constexpr (M16) {  // (bias already inside the accumulators)
+                s = acc4[i][r >> 3][u][(r >> 2) & 1][r & 3] * a.out_mul;
+              } else {  // (nothing to clear: the next tile's first MFMAs start from C = 0)
+                s = fmaf(acc[i][u][r], a.out_mul, bv[r] * a.out_mul);
+              }
+              q[i][r] = __builtin_amdgcn_fmed3f(s, lo, 448.f);
+            }
+          const int cofs8 = cur.co0 + cl;
+          auto cvt16 = [&](const float (&w)[16]) {
+            u32x4 o;
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+              int p = 0;
+              p = __builtin_amdgcn_cvt_pk_fp8_f32(w[4 * d], w[4 * d + 1], p, false);
+              p = __builtin_amdgcn_cvt_pk_fp8_f32(w[4 * d + 2], w[4 * d + 3], p, true);
+              o[d] = (uint32_t)p;
+            }
+            return o;
+          };
+          if (a.y != nullptr) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+              const u32x4 o = cvt16(q[i]);
+              if (!EDGE || (py + i < H && px < W))
+                *reinterpret_cast<u32x4*>(a.y + (((int64_t)cur.n * (H + 2) + (py + i + 1)) * Wp + (px + 1)) * Ob + cofs8) = o;
+            }
+          }
+          if (a.pooled != nullptr) {
+            float m[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const float t = __builtin_amdgcn_fmed3f(q[0][r], q[1][r], inf);
+              m[r] = __builtin_amdgcn_fmed3f(t, g4_dpp_swap1(t), inf);
+            }
+            const int Hq = H >> 1, Wq = W >> 1;
+            const u32x4 o = cvt16(m);
+            // every wave issues this instruction (even lanes store): the counted vmcnt at the next barrier relies on it
+            if ((lane & 1) == 0 && (!EDGE || (py < H && px < W)))
+              *reinterpret_cast<u32x4*>(a.pooled + (((int64_t)cur.n * (Hq + 2) + ((py >> 1) + 1)) * (Wq + 2) + ((px >> 1) + 1)) * Ob + cofs8) = o;
           }
           continue;
         }
@@ -780,6 +846,7 @@ __global__ __launch_bounds__(512, 2) void conv_dma4_kernel(F8Args a) {
 #undef G4_CAT
 #undef G4_MFMA
 #undef G4_MFMA_B
+#undef G4_MFMA_Z
 #undef G4_MFMA_C
 #undef G4_C_ACC
 #undef G4_C_BIAS
