@@ -356,7 +356,7 @@ def extra_inference(device, label, fusion, batch, h, w, dtype='bf16', steps=10, 
         rec['roofline_bf16_layers'] = roofline_of(prof, ('k3',), PEAK_TFLOPS['bf16'], 'the 3x3 convs left on bf16 operands (conv1_2)',
                                                   dt_serial, steps)
     else:
-        rec['roofline'] = roofline_of(prof, ('k3',), PEAK_TFLOPS['bf16'], 'conv_dma4_kernel / conv_dma5_kernel / conv_first_pair_kernel / conv_dma_kernel / conv_mfma_kernel (3x3, all launches)',
+        rec['roofline'] = roofline_of(prof, ('k3', 'k3pair'), PEAK_TFLOPS['bf16'], 'conv_dma4_kernel / conv_dma5_kernel / conv_first_pair_kernel (+ fallback generations): every 3x3 launch incl. the fused first pair',
                                       dt_serial, steps)
     flops_img = conv_flops_per_image(h, w, 3) + conv_flops_per_image(h, w, 1)
     rec['conv_tflops_end_to_end'] = round(batch * steps * flops_img / dt / 1e12, 2)
@@ -586,14 +586,21 @@ def main():
             print('  conv launch %2d %s %7.1f GF %8.1f us %7.0f TF/s' % (i, evs[0][0], evs[0][1] / 1e9, ms * 1e3,
                                                                       evs[0][1] / ms / 1e9), file=sys.stderr)
     # dominant kernel: the 3x3 implicit-GEMM MFMA conv (fp8: the launches on e4m3 operands, against the fp8 peak)
+    pair = both = None
     if args.dtype == 'fp8':
         roofline = roofline_of(prof, ('k3f8',), PEAK_TFLOPS['fp8'],
                                'conv_f8_dma_kernel (v_mfma_scale_f32_32x32x64_f8f6f4, 3x3 launches on e4m3 operands; conv_mfma_kernel<F8> where a map does not tile in 16x32)',
                                times_serial, args.steps)
     else:
         roofline = roofline_of(prof, ('k3',), PEAK_TFLOPS['bf16'],
-                               'conv_dma4_kernel / conv_dma5_kernel / conv_first_pair_kernel / conv_dma_kernel / conv_mfma_kernel (3x3 implicit GEMM, all launches)', times_serial,
+                               'conv_dma4_kernel / conv_dma5_kernel (the 3x3 implicit-GEMM MFMA conv: every launch of conv2_1 .. '
+                               'conv5_3; conv_dma_kernel / conv_mfma_kernel on shapes that do not tile)', times_serial,
                                args.steps, traffic=committed_traffic(args.batch, args.height, args.width))
+        # conv1_1 + conv1_2 run as ONE kernel (conv_first_fused.hip): reported beside the dominant kernel, with the algorithmic
+        # FLOPs of both layers against the whole kernel's time, and both together so that nothing is left out
+        pair = roofline_of(prof, ('k3pair',), PEAK_TFLOPS['bf16'], 'conv_first_pair_kernel (conv1_1 + conv1_2 + pool1 fused; '
+                           'algorithmic FLOPs of both layers)', times_serial, args.steps)
+        both = roofline_of(prof, ('k3', 'k3pair'), PEAK_TFLOPS['bf16'], 'all of the above', times_serial, args.steps)
     per_image = conv_flops_per_image if args.expert == 'fcn' else adapnet_flops_per_image
     flops_img = per_image(args.height, args.width, 3) + per_image(args.height, args.width, 1)
     if args.expert == 'adapnet':
@@ -621,6 +628,9 @@ def main():
         'conv_tflops_end_to_end': round(images * flops_img / dt / 1e12, 2),
         'roofline': roofline,
     }
+    if pair is not None:
+        res['roofline_first_pair'] = pair
+        res['roofline_all_3x3'] = both
     res.update(block_stats(times, args.steps))
     res['timing'] = ('blocks of exactly --steps steps, barrier + synchronize on both sides, max over ranks, repeated until '
                      '%.1f s; value and ms_per_step are the MEDIAN block' % args.min_seconds)

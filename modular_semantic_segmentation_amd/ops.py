@@ -187,10 +187,10 @@ def conv_first_pair_fwd(x, w1_hwio, b1, w2_packed, b2, y=None, pooled=None, relu
         return False
     _lib.check(rc, 'xv_conv_first_pair_fwd')
     if prof is not None:
-        # bench.py's roofline: a 3x3 MFMA conv launch with conv1_2's algorithmic FLOPs -- conv1_1's work inside the same
-        # kernel (and its recomputation on the halo) counts as time, not as FLOPs
+        # bench.py: a kind of its own (not the plain 3x3 conv kernel the roofline record is about), with the algorithmic FLOPs
+        # of BOTH layers; conv1_1's recomputation on the halo and its three-way operand split count as time, not as FLOPs
         ev1.record()
-        prof.append(('k3', 2.0 * n * h * w * 64 * 64 * 9, ev0, ev1))
+        prof.append(('k3pair', 2.0 * n * h * w * 64 * 9 * (cin + 64), ev0, ev1))
     return True
 
 

@@ -86,11 +86,12 @@ def copy_stats(tag, sub, dest):
 
 
 def main(tag, batch=16):
-    is_conv3 = lambda k: ('conv_dma_kernel' in k or 'conv_dma4_kernel' in k or 'conv_dma5_kernel' in k or 'conv_first_pair_kernel' in k  # noqa: E731
+    # the plain 3x3 conv kernels = what bench.py's `roofline` record is about (the fused first pair is reported beside it)
+    is_conv3 = lambda k: ('conv_dma_kernel' in k or 'conv_dma4_kernel' in k or 'conv_dma5_kernel' in k  # noqa: E731
                           or ('conv_mfma_kernel' in k and ', 3, ' in k))
     fetch = counter_avg('pmc_fetch', 'FETCH_SIZE', is_conv3)
     write = counter_avg('pmc_write', 'WRITE_SIZE', is_conv3)
-    out = {'kernel': 'conv_dma4_kernel + conv_dma5_kernel + conv_first_pair_kernel + conv_dma_kernel + conv_mfma_kernel (all 3x3 launches)', 'source': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, '
+    out = {'kernel': 'conv_dma4_kernel + conv_dma5_kernel (+ conv_dma_kernel / conv_mfma_kernel): the plain 3x3 launches', 'source': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, '
            'python3 bench.py --steps 3 --warmup 1 --serial-experts --no-graph (batch %d, 768x384)' % batch,
            'batch': batch, 'kernel_source': 'csrc/conv_mfma.hip + conv_f8_dma.hip + conv_col_dma.hip + conv_first_fused.hip', 'kernel_source_sha256_16': kernel_source_hash()}
     if fetch and write:
@@ -98,6 +99,11 @@ def main(tag, batch=16):
                    launches=fetch[1],
                    hbm_bytes_per_launch=int((2 * fetch[0] + write[0]) * 1024),
                    correction='read bytes = 2 x FETCH_SIZE (gfx950 counts 128-B requests as 64 B); WRITE_SIZE exact')
+    pf = counter_avg('pmc_fetch', 'FETCH_SIZE', lambda k: 'conv_first_pair_kernel' in k)
+    pw = counter_avg('pmc_write', 'WRITE_SIZE', lambda k: 'conv_first_pair_kernel' in k)
+    if pf and pw:
+        out['conv_first_pair_kernel'] = {'fetch_size_kb_per_launch': round(pf[0], 1), 'write_size_kb_per_launch': round(pw[0], 1),
+                                         'launches': pf[1], 'hbm_bytes_per_launch': int((2 * pf[0] + pw[0]) * 1024)}
     json.dump(out, open('profiles/%s_conv_traffic.json' % tag, 'w'), indent=1)
     print(out)
     def is_f8(k):
