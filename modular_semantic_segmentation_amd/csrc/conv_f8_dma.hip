@@ -63,13 +63,14 @@ __device__ unsigned long long xv_clk_g4[4 * XV_CLK_SLOTS];
 #endif
 
 #ifdef XV_CONV_TRACE
-// debug build only (`make trace`, tools/conv_trace.py --gen 4): per work item four cycle stamps of every wave of every 32nd
-// workgroup, kept in spare LDS during the kernel (a global store per stamp would sit in the vmcnt queue this kernel counts on)
-__device__ long long xv_trace_buf4[8 * 8 * 32 * 4];
-#define G4_TRACE_LDS 8192
-#define G4_STAMP(k)                                                                   \
-  if (!STATS && (blockIdx.x & 31) == 0 && trace_item < 32 && lane == 0)               \
-    reinterpret_cast<long long*>(smem + C::LDS_BYTES)[(wave * 32 + trace_item) * 4 + (k)] = __builtin_readcyclecounter();
+// debug build only (`make trace`, tools/conv_trace4.py): per work item four cycle stamps of waves 0 and 4 (the two waves of
+// one SIMD) of every 32nd workgroup, kept in the last spare 1.5 KB of LDS during the kernel (a global store per stamp would
+// sit in the vmcnt queue this kernel counts on)
+__device__ long long xv_trace_buf4[8 * 2 * 24 * 4];
+#define G4_TRACE_LDS 1536
+#define G4_STAMP(k)                                                                                       \
+  if (!STATS && (blockIdx.x & 31) == 0 && trace_item < 24 && lane == 0 && (wave & 3) == 0)                \
+    reinterpret_cast<long long*>(smem + C::LDS_BYTES_STAGE)[((wave >> 2) * 24 + trace_item) * 4 + (k)] = __builtin_readcyclecounter();
 #else
 #define G4_TRACE_LDS 0
 #define G4_STAMP(k)
@@ -86,6 +87,14 @@ struct G4 {
   static constexpr int LDS_BYTES = BIAS_OFF + 512;
   static constexpr int STATS_OFF = LDS_BYTES;          // STATS: [wave 0..7][sum 64 | sum of squares 64] fp32
   static constexpr int LDS_BYTES_STATS = LDS_BYTES + 8 * 128 * 4;
+  // STORE STAGE (bf16 16x16 form, packed epilogue): 1 KB per wave.  A lane holds 32 contiguous bytes of ONE pixel and the
+  // 16 pixels of a block sit in consecutive lanes 128+ bytes apart, so a global_store_dwordx4 scattered 64 16-byte pieces
+  // over 16 lines -- the address path takes four lanes per cycle only when they share a line: ~64 cycles per store
+  // instruction, and with all 8 waves storing at once the tile's stores took 2 200-3 800 cycles.  Each 64-byte run of a
+  // pixel goes through this stage instead and comes back with its four pieces in four CONSECUTIVE lanes.
+  static constexpr int STAGE_OFF = LDS_BYTES;
+  static constexpr int LDS_BYTES_STAGE = LDS_BYTES + NWAVES * 1024;
+  static_assert(LDS_BYTES_STAGE + 1536 <= 160 * 1024, "does not fit the LDS");
   static constexpr int A_ITERS = (A_PIECES + NWAVES - 1) / NWAVES;
   static constexpr int B_ITERS = (B_PIECES + NWAVES - 1) / NWAVES;
   static constexpr int PROW = HW * 64;  // bytes between patch rows
@@ -301,7 +310,10 @@ __global__ __launch_bounds__(512, 2) void conv_dma4_kernel(F8Args a) {
   // half the DMA pieces of conv1_2 / conv2_1-like layers.
   const bool resident = nchunks <= 2 && (nb % a.n_ct) == 0;
   int items_done = 0;
-  const int nstores = ((a.y != nullptr ? 4 : 0) + (a.pooled != nullptr ? 2 : 0)) * (OF8 ? 1 : 2);
+  // (packed bf16 epilogue: 8 staged stores for the full map, ONE full-wave store per pixel half for the pooled map)
+  constexpr bool STAGED = M16 && !OF8 && !STATS;
+  const int nstores = STAGED ? (a.y != nullptr ? 8 : 0) + (a.pooled != nullptr ? 2 : 0)
+                             : ((a.y != nullptr ? 4 : 0) + (a.pooled != nullptr ? 2 : 0)) * (OF8 ? 1 : 2);
   int in_flight = 0;  // stores issued after the last DMA of the previous item
 
   XV_CLK_BEGIN()
@@ -314,6 +326,8 @@ __global__ __launch_bounds__(512, 2) void conv_dma4_kernel(F8Args a) {
     // flight: vmcnt counts in issue order), and every wave has finished reading the other buffer pair.
     if (in_flight == 12)
       asm volatile("s_waitcnt vmcnt(12)\n\ts_barrier" ::: "memory");
+    else if (in_flight == 10)
+      asm volatile("s_waitcnt vmcnt(10)\n\ts_barrier" ::: "memory");
     else if (in_flight == 8)
       asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
     else if (in_flight == 6)
@@ -612,10 +626,28 @@ __global__ __launch_bounds__(512, 2) void conv_dma4_kernel(F8Args a) {
             for (int i = 0; i < 2; ++i) {
 #pragma unroll
               for (int k = 0; k < 8; ++k) pk[i][k] = pk_max_i16(pk[i][k], rfloor);
-              char* dst = a.y + (((int64_t)cur.n * (H + 2) + (py + i + 1)) * Wp + (px + 1)) * Ob + cofs * 2;
-              if (!EDGE || (py + i < H && px < W)) {
-                *reinterpret_cast<u32x4*>(dst) = u32x4{pk[i][0], pk[i][1], pk[i][2], pk[i][3]};
-                *reinterpret_cast<u32x4*>(dst + 16) = u32x4{pk[i][4], pk[i][5], pk[i][6], pk[i][7]};
+              // through the wave's store stage: [pixel 0..15][piece 0..3] = one 64-byte run per pixel; lanes of channel
+              // groups 0-1 fill it for the pixel's bytes 0..63, then groups 2-3 for bytes 64..127; lane l reads back piece
+              // l & 3 of pixel l >> 2 (LDS operations of one wave execute in order: no wait between the rounds)
+              u32x4* stage = reinterpret_cast<u32x4*>(smem + C::STAGE_OFF + wave * 1024);
+              const int pxl = cur.x0 + 16 * u + (lane >> 2);
+              char* dst = a.y + (((int64_t)cur.n * (H + 2) + (py + i + 1)) * Wp + (pxl + 1)) * Ob + cur.co0 * 2 + (lane & 3) * 16;
+              const bool on = !EDGE || (py + i < H && pxl < W);
+#pragma unroll
+              for (int half = 0; half < 2; ++half) {
+                if ((hh >> 1) == half) {
+                  stage[n31 * 4 + 2 * (hh & 1)] = u32x4{pk[i][0], pk[i][1], pk[i][2], pk[i][3]};
+                  stage[n31 * 4 + 2 * (hh & 1) + 1] = u32x4{pk[i][4], pk[i][5], pk[i][6], pk[i][7]};
+                }
+                // lanes exchange data through LDS: a wave-scope fence on both sides (without it the compiler keeps a lane's
+                // previous read where the lane itself has not written -- per-thread reasoning; seen in the ISA)
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                const u32x4 r = stage[lane];
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                if (on) *reinterpret_cast<u32x4*>(dst + half * 64) = r;
               }
             }
           }
@@ -637,12 +669,25 @@ __global__ __launch_bounds__(512, 2) void conv_dma4_kernel(F8Args a) {
               }
             }
             const int Hq = H >> 1, Wq = W >> 1;
-            char* dst = a.pooled + (((int64_t)cur.n * (Hq + 2) + ((py >> 1) + 1)) * (Wq + 2) + ((px >> 1) + 1)) * Ob + cofs * 2;
-            // every wave issues these instructions (even lanes store): the counted vmcnt at the next barrier relies on it
-            if ((lane & 1) == 0 && (!EDGE || (py < H && px < W))) {
-              *reinterpret_cast<u32x4*>(dst) = u32x4{m[0], m[1], m[2], m[3]};
-              *reinterpret_cast<u32x4*>(dst + 16) = u32x4{m[4], m[5], m[6], m[7]};
+            // the 8 pooled pixels of this half (even lanes) through the stage as [64-byte half 0..1][pixel 0..7][piece 0..3]:
+            // ONE full-wave store -- lanes 0-31 the pixels' bytes 0..63, lanes 32-63 their bytes 64..127
+            u32x4* stage = reinterpret_cast<u32x4*>(smem + C::STAGE_OFF + wave * 1024);
+            if ((lane & 1) == 0) {
+              const int at = ((hh >> 1) * 8 + (n31 >> 1)) * 4 + 2 * (hh & 1);
+              stage[at] = u32x4{m[0], m[1], m[2], m[3]};
+              stage[at + 1] = u32x4{m[4], m[5], m[6], m[7]};
             }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const u32x4 r = stage[lane];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const int qx = ((cur.x0 + 16 * u) >> 1) + ((lane & 31) >> 2);
+            char* dst = a.pooled + (((int64_t)cur.n * (Hq + 2) + ((py >> 1) + 1)) * (Wq + 2) + (qx + 1)) * Ob + cur.co0 * 2 +
+                        (lane >> 5) * 64 + (lane & 3) * 16;
+            // every wave issues this instruction: the counted vmcnt at the next barrier relies on it
+            if (!EDGE || (py < H && 2 * qx < W)) *reinterpret_cast<u32x4*>(dst) = r;
           }
           continue;
         }
@@ -785,8 +830,8 @@ __global__ __launch_bounds__(512, 2) void conv_dma4_kernel(F8Args a) {
 #ifdef XV_CONV_TRACE
   __syncthreads();
   if (!STATS && wave == 0 && (blockIdx.x & 31) == 0)
-    for (int i = lane; i < 8 * 32 * 4; i += 64)
-      xv_trace_buf4[(blockIdx.x >> 5) * (8 * 32 * 4) + i] = reinterpret_cast<long long*>(smem + C::LDS_BYTES)[i];
+    for (int i = lane; i < 2 * 24 * 4; i += 64)
+      xv_trace_buf4[(blockIdx.x >> 5) * (2 * 24 * 4) + i] = reinterpret_cast<long long*>(smem + C::LDS_BYTES_STAGE)[i];
 #endif
   if constexpr (STATS) {
     // half-wave sums by DPP (row_shr 1, 2, 4, 8 inside each 16-lane row, row_bcast15 into the odd rows: lanes 31 / 63 hold
@@ -898,7 +943,7 @@ bool xv_conv3x3_dma4_exact(int H, int W) { return (H & 15) == 0 && (W & 31) == 0
 namespace {
 template <bool F8, bool OF8, bool STATS, bool EDGE, bool M16, bool DG = false>
 int g4_launch1(const F8Args& a, int grid, hipStream_t stream) {
-  constexpr int lds = STATS ? G4::LDS_BYTES_STATS : G4::LDS_BYTES + G4_TRACE_LDS;
+  constexpr int lds = STATS ? G4::LDS_BYTES_STATS : G4::LDS_BYTES_STAGE + G4_TRACE_LDS;
   static_assert(lds <= 160 * 1024, "does not fit the LDS");
   static bool attr_set[XV_MAX_DEVICES] = {false};
   const hipError_t e =

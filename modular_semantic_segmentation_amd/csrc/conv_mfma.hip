@@ -2150,20 +2150,25 @@ int pick_cfg(const ConvArgs& a, int k) {
       // generation 2, A/B timing)
       static const bool dgrad4 = getenv("XV_DGRAD_GEN4") == nullptr || atoi(getenv("XV_DGRAD_GEN4")) != 0;
       const bool dg = a.mask != nullptr || a.addend != nullptr;
+      // With a stream-K workspace (the `streamk` latency option) only launches that fill the chip at least twice take
+      // generations 4 / 5 (no tail to split there: conv1_2 .. conv3_3 at one image); the others keep generation 2 and its
+      // stream-K tail (conv4_x / conv5_x at one image: 72 / 24 tiles for 256 CUs).
+      const int64_t items16 = (int64_t)a.N * ((a.H + 15) / 16) * ((a.W + 31) / 32) * (a.Cout / 64);
+      const bool no_tail = a.sk_ws == nullptr || items16 >= 2 * (int64_t)a.num_cus;
       // (XV_COL_ROUNDS=1, A/B timing: maps that tile both ways take the 24x16 tile when it makes whole rounds of workgroups
       // and the 16x32 tile does not -- conv4_x at 16 images: 6 rounds against 4.5)
       static const bool col_rounds = getenv("XV_COL_ROUNDS") != nullptr && atoi(getenv("XV_COL_ROUNDS")) != 0;
-      if (col_rounds && gen4 && (!dg || dgrad4) && a.sk_ws == nullptr && !a.in_f8 && !a.out_f8 && a.pooled == nullptr &&
+      if (col_rounds && gen4 && (!dg || dgrad4) && no_tail && !a.in_f8 && !a.out_f8 && a.pooled == nullptr &&
           xv_conv3x3_col_ok(a.H, a.W, a.Cin, a.Cout, 3) && xv_conv3x3_dma4_exact(a.H, a.W)) {
         const int64_t i26 = (int64_t)a.N * (a.H / 16) * (a.W / 32) * (a.Cout / 64), i27 = (int64_t)a.N * (a.H / 24) * (a.W / 16) * (a.Cout / 64);
         if (i27 % a.num_cus == 0 && i26 % a.num_cus != 0) return 27;
       }
-      if (gen4 && (!dg || (dgrad4 && a.pooled == nullptr)) && a.sk_ws == nullptr && !a.in_f8 && !a.out_f8 &&
+      if (gen4 && (!dg || (dgrad4 && a.pooled == nullptr)) && no_tail && !a.in_f8 && !a.out_f8 &&
           xv_conv3x3_dma4_bf16_ok(a.H, a.W, a.Cin, a.Cout) && xv_conv3x3_dma4_exact(a.H, a.W) && (gen4 != 2 || a.Cin >= 128))
         return 26;
       // maps that tile in 24x16 but not in 16x32 (the 24x48 conv5 maps of a 768x384 input): the same loop on a column of
       // waves, generation 5 -- conv5_1 at 16 images 1 190 against 985 TFLOP/s on generation 2's 24x16 tile (configuration 22)
-      if (gen4 && (!dg || dgrad4) && a.sk_ws == nullptr && !a.in_f8 && !a.out_f8 && a.pooled == nullptr &&
+      if (gen4 && (!dg || dgrad4) && no_tail && !a.in_f8 && !a.out_f8 && a.pooled == nullptr &&
           xv_conv3x3_col_ok(a.H, a.W, a.Cin, a.Cout, 3))
         return 27;
     }

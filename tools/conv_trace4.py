@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Phase breakdown of the generation-4 conv kernel (conv_dma4_kernel) from in-kernel cycle stamps (`make -C csrc trace`
--> tools/build/libxview_hip_trace.so).  For the first 32 work items of every wave of every 32nd workgroup:
+-> tools/build/libxview_hip_trace.so).  For the first 24 work items of waves 0 and 4 of every 32nd workgroup:
 [0] arrival at the item barrier, [1] barrier passed, [2] all MFMAs issued, [3] tile epilogue done."""
 import argparse
 import ctypes
@@ -40,7 +40,7 @@ q = ops.Act(args.batch, h // 2, w // 2, args.cout) if args.mode != 'y' else None
 for _ in range(20):
     ops.conv2d_fwd(x, wp, b, 3, y=y, pooled=q, write_y=y is not None, cfg=args.cfg)
 torch.cuda.synchronize()
-buf = np.zeros((8, 8, 32, 4), dtype=np.int64)          # [traced block][wave][item][stamp]
+buf = np.zeros((8, 2, 24, 4), dtype=np.int64)          # [traced block][wave 0 / wave 4: the two waves of one SIMD][item][stamp]
 fn = _lib.lib().xv_debug_read_trace4
 fn.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
 assert fn(buf.ctypes.data, buf.nbytes) == 0
@@ -51,13 +51,13 @@ print('cfg %d, %dx%d x %d, %d -> %d channels, mode %s; traced workgroup %d' % (a
                                                                                 args.mode, args.block * 32))
 print('per item: cycles since the previous release; per wave [wait at the barrier | release -> MFMAs issued | epilogue]')
 tot = np.zeros(3)
-for it in range(2, 30):
+for it in range(2, 22):
     row = 'item %2d%s +%5d :' % (it, '*' if it % nchunks == nchunks - 1 else ' ', rel[it] - rel[it - 1])
-    for wv in range(8):
+    for wv in range(2):
         a, bq, c = rel[it] - t[wv, it, 0], t[wv, it, 2] - t[wv, it, 1], t[wv, it, 3] - t[wv, it, 2]
         tot += (a, bq, c)
         row += ' [%5d|%5d|%5d]' % (a, bq, c)
     print(row)
-n = 28 * 8
+n = 20 * 2
 print('mean per item and wave: barrier wait %.0f, taps %.0f, epilogue %.0f; item period %.0f cycles' % (
-    tot[0] / n, tot[1] / n, tot[2] / n, (rel[29] - rel[1]) / 28.0))
+    tot[0] / n, tot[1] / n, tot[2] / n, (rel[21] - rel[1]) / 20.0))
