@@ -52,9 +52,9 @@ def test_miou_of_hip_path_matches_fp32_oracle_on_trained_experts():
     # the fp8 conv path (config 5) on the same trained weights: 3-bit mantissas cost a fraction of a point of mIoU
     for m in ('rgb', 'depth', 'bayes'):
         # default plan (e4m3 operands from conv2_1 on): measured 0.05 .. 0.15 points (RGB, Bayes) and 0.6 .. 1.4 (the weak
-        # depth expert: raw uint16 depth through 3-bit mantissas), agreement 0.997 / 0.980; bounds at ~1.7x the worst seen
-        assert abs(acc['fp8'][m]['delta_miou_pp_vs_fp32']) < (2.5 if m == 'depth' else 0.5), (m, acc['fp8'][m])
-        assert acc['fp8'][m]['label_agreement_vs_fp32'] > (0.965 if m == 'depth' else 0.99), (m, acc['fp8'][m])
+        # depth expert: raw uint16 depth through 3-bit mantissas), agreement 0.997 / 0.980; bounds at about twice the worst seen (a run trains its experts from scratch: the numbers move)
+        assert abs(acc['fp8'][m]['delta_miou_pp_vs_fp32']) < (3.0 if m == 'depth' else 1.0), (m, acc['fp8'][m])
+        assert acc['fp8'][m]['label_agreement_vs_fp32'] > (0.96 if m == 'depth' else 0.985), (m, acc['fp8'][m])
     # conv_dtype='fp32' (the graph in plain float32 through csrc/exact_f32.hip) on the same TRAINED weights: label maps equal to
     # the fp32 oracle's at 768x384 up to fp32 summation order (a pixel can differ only where two logits tie to ~1e-6 of
     # the logit scale) -- so the 0.02-0.3 % of pixels the bf16 path flips are lost to bf16 storage, not to a kernel
