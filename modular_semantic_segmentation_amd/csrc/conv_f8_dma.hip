@@ -544,6 +544,28 @@ __global__ __launch_bounds__(512, 2) void conv_dma4_kernel(F8Args a) {
       const int py = cur.y0 + 2 * wave;
       // 32x32 form: u = channel block j (the lane's 16 channels 32 j + 16 hh .., one pixel column n31);
       // 16x16 form: u = pixel half h (column 16 h + n15, the lane's 16 channels 16 g ..)
+      // Data gradient: the addend / relu-reference words of a pixel half (2 rows x 16 pixels x 128 B x 2 maps) are requested
+      // in ONE batch before anything uses them, and COALESCED: lane l asks for piece l & 3 of pixel l >> 2 of a 64-byte half
+      // -- four consecutive lanes share a line -- and the pieces reach the lanes that own them (pixel n15, channel group g)
+      // through the wave's store stage.  The second half's batch is requested as soon as the first has left its landing
+      // registers, so it travels while the first half is packed and stored.  (16-byte loads at a one-pixel lane stride, one
+      // round trip per row pair: the epilogue took 16-18 thousand cycles per tile, tools/conv_trace4.py --dgrad.)
+      u32x4 ldA[2][2], ldM[2][2];  // [row i][64-byte half]
+      auto dg_request = [&](int u) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const int pxl = cur.x0 + 16 * u + (lane >> 2);
+          const bool in = !EDGE || (py + i < H && pxl < W);
+          const int64_t off = (((int64_t)cur.n * (H + 2) + ((in ? py + i : 0) + 1)) * Wp + ((in ? pxl : 0) + 1)) * Ob + cur.co0 * 2 +
+                              (lane & 3) * 16;
+#pragma unroll
+          for (int half = 0; half < 2; ++half) {
+            if (a.addend != nullptr) ldA[i][half] = *reinterpret_cast<const u32x4*>(a.addend + off + half * 64);
+            if (a.mask != nullptr) ldM[i][half] = *reinterpret_cast<const u32x4*>(a.mask + off + half * 64);
+          }
+        }
+      };
+      if constexpr (DG) dg_request(0);
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
         const int cl = M16 ? 16 * hh : 32 * u + 16 * hh;  // first of this lane's 16 consecutive channels within the tile
@@ -564,60 +586,64 @@ __global__ __launch_bounds__(512, 2) void conv_dma4_kernel(F8Args a) {
           // on the packed pairs as signed 16-bit integers (a non-negative bf16 orders like its bit pattern, rounding is
           // monotone, so pooling after rounding equals rounding after pooling): 2-3 instructions per value.
           uint32_t pk[2][8];
-          const int cofs = cur.co0 + cl;
-          // data-gradient extras (Conv2DBackpropInput + AddN + ReluGrad): every addend / mask word of the lane's two pixels is
-          // requested before the first is used; pixels past the image (edge tiles) read the image's first pixel instead
+          // data-gradient extras (Conv2DBackpropInput + AddN + ReluGrad): the words requested above, through the stage to the
+          // lane that owns the pixel and channel group (a lane's 32 bytes are two pieces of ONE 64-byte half: it reads them in
+          // the round of its half); then the other pixel half's request
           u32x4 ad[2][2], mk[2][2];
           if constexpr (DG) {
+            u32x4* const xstage = reinterpret_cast<u32x4*>(smem + C::STAGE_OFF + wave * 1024);
+            auto to_owner = [&](const u32x4 (&ld)[2], u32x4 (&own)[2]) {
+#pragma unroll
+              for (int half = 0; half < 2; ++half) {
+                xstage[lane] = ld[half];
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                if ((hh >> 1) == half) {
+                  own[0] = xstage[n31 * 4 + 2 * (hh & 1)];
+                  own[1] = xstage[n31 * 4 + 2 * (hh & 1) + 1];
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+              }
+            };
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-              const bool in = !EDGE || (py + i < H && px < W);
-              const int64_t off = (((int64_t)cur.n * (H + 2) + ((in ? py + i : 0) + 1)) * Wp + ((in ? px : 0) + 1)) * Ob + cofs * 2;
-              if (a.addend != nullptr) {
-                ad[i][0] = *reinterpret_cast<const u32x4*>(a.addend + off);
-                ad[i][1] = *reinterpret_cast<const u32x4*>(a.addend + off + 16);
-              }
-              if (a.mask != nullptr) {
-                mk[i][0] = *reinterpret_cast<const u32x4*>(a.mask + off);
-                mk[i][1] = *reinterpret_cast<const u32x4*>(a.mask + off + 16);
-              }
+              if (a.addend != nullptr) to_owner(ldA[i], ad[i]);
+              if (a.mask != nullptr) to_owner(ldM[i], mk[i]);
             }
+            if (u == 0) dg_request(1);
           }
           // (the bias is already inside the accumulators: the tile's first MFMAs started from it; nothing to clear either)
-          float sv[2][16];
 #pragma unroll
-          for (int i = 0; i < 2; ++i)
+          for (int i = 0; i < 2; ++i) {
+            float sv[16];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) sv[i][r] = acc4[i][r >> 3][u][(r >> 2) & 1][r & 3];  // r = 4 (2 j + jj) + q
-          if constexpr (DG) {
-            if (a.addend != nullptr) {  // added in fp32, before the one rounding (as every other generation)
-#pragma unroll
-              for (int i = 0; i < 2; ++i)
+            for (int r = 0; r < 16; ++r) sv[r] = acc4[i][r >> 3][u][(r >> 2) & 1][r & 3];  // r = 4 (2 j + jj) + q
+            if constexpr (DG) {
+              if (a.addend != nullptr) {  // added in fp32, before the one rounding (as every other generation)
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
                   const uint32_t w = k < 4 ? ad[i][0][k & 3] : ad[i][1][k & 3];
-                  sv[i][2 * k] += __builtin_bit_cast(float, w << 16);
-                  sv[i][2 * k + 1] += __builtin_bit_cast(float, w & 0xffff0000u);
+                  sv[2 * k] += __builtin_bit_cast(float, w << 16);
+                  sv[2 * k + 1] += __builtin_bit_cast(float, w & 0xffff0000u);
                 }
+              }
             }
-          }
 #pragma unroll
-          for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int k = 0; k < 8; ++k) pk[i][k] = pack_bf16x2(sv[i][2 * k], sv[i][2 * k + 1]);  // channels 2 k, 2 k + 1 of the lane's 16
-          if constexpr (DG) {
-            if (a.mask != nullptr) {
-              // keep the value where the reference activation is > 0: each bf16 half moved to the top of a 32-bit integer
-              // (negative values, -0 and +0 are <= 0 there).  (A packed 16-bit min / max form of this was miscompiled by
-              // hipcc 7.2: every pair tested the mask word of pair 0.)
-#pragma unroll
-              for (int i = 0; i < 2; ++i)
+            for (int k = 0; k < 8; ++k) pk[i][k] = pack_bf16x2(sv[2 * k], sv[2 * k + 1]);  // channels 2 k, 2 k + 1 of the lane's 16
+            if constexpr (DG) {
+              if (a.mask != nullptr) {
+                // keep the value where the reference activation is > 0: each bf16 half moved to the top of a 32-bit integer
+                // (negative values, -0 and +0 are <= 0 there).  (A packed 16-bit min / max form of this was miscompiled by
+                // hipcc 7.2: every pair tested the mask word of pair 0.)
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
                   const uint32_t w = k < 4 ? mk[i][0][k & 3] : mk[i][1][k & 3];
                   const uint32_t sel = ((int32_t)(w << 16) > 0 ? 0x0000ffffu : 0u) | ((int32_t)(w & 0xffff0000u) > 0 ? 0xffff0000u : 0u);
                   pk[i][k] &= sel;
                 }
+              }
             }
           }
           if (a.y != nullptr) {

@@ -108,6 +108,16 @@ def test_intermediate_layers_match_oracle(gpu, tmp_path):
         err = np.abs(got - ref[name]).max() / scale
         assert err < 2e-2, '%s: %.3g' % (name, err)
     _check_logits_and_labels(out['score'].cpu().numpy(), out['label'].cpu().numpy(), ref['score'], 'depth expert')
+    # the default inference pass (conv1_1 + conv1_2 + pool1 in ONE kernel where the map tiles in 16x32, no full-resolution
+    # map kept) gives the SAME bits as the pass above that materialised every layer with separate kernels
+    keep = {k: out['layers'][k].t.clone() for k in ('pool1', 'pool2', 'fused')}
+    score_all = out['score'].clone()
+    out2 = eng.forward(x, want=('score', 'label'))
+    torch.cuda.synchronize()
+    assert 'conv1_1' not in out2['layers'] and 'conv1_2' not in out2['layers']          # the fused first pair ran
+    for k, v in keep.items():
+        assert torch.equal(out2['layers'][k].t, v), k
+    assert torch.equal(out2['score'], score_all)
 
 
 def test_bayes_fusion_model(gpu, tmp_path, golden_dir):

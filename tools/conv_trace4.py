@@ -25,6 +25,7 @@ ap.add_argument('--mode', default='pool', choices=['y', 'pool', 'both'])
 ap.add_argument('--cfg', type=int, default=26)
 ap.add_argument('--block', type=int, default=0)
 ap.add_argument('--data', default='normal')
+ap.add_argument('--dgrad', action='store_true', help='the data-gradient kernel: addend + relu mask epilogue (mode y)')
 args = ap.parse_args()
 h, w = 384 // args.scale, 768 // args.scale
 x = ops.Act(args.batch, h, w, args.cin)
@@ -37,7 +38,15 @@ wp = ops.pack_conv_weights(wt)
 b = torch.zeros(args.cout, device='cuda')
 y = ops.Act(args.batch, h, w, args.cout) if args.mode != 'pool' else None
 q = ops.Act(args.batch, h // 2, w // 2, args.cout) if args.mode != 'y' else None
-for _ in range(20):
+if args.dgrad:
+    wd = ops.pack_conv_weights_dgrad(torch.randn(3, 3, args.cout, args.cin, device='cuda') * (1.0 / (9 * args.cin) ** 0.5))
+    ref, add, dx = ops.Act(args.batch, h, w, args.cout), ops.Act(args.batch, h, w, args.cout), ops.Act(args.batch, h, w, args.cout)
+    ref.interior().normal_()
+    add.interior().normal_()
+    for _ in range(20):
+        ops.conv2d_bwd_data(x, wd, b, dx, 3, relu_ref=ref, addend=add)
+else:
+  for _ in range(20):
     ops.conv2d_fwd(x, wp, b, 3, y=y, pooled=q, write_y=y is not None, cfg=args.cfg)
 torch.cuda.synchronize()
 buf = np.zeros((8, 2, 24, 4), dtype=np.int64)          # [traced block][wave 0 / wave 4: the two waves of one SIMD][item][stamp]
