@@ -1,39 +1,33 @@
-// Generation 4: the 3x3 convolution on 32x32 MFMA blocks with every operand staged by LDS-DMA -- configuration 24 on e4m3
-// operands (conv_dma4_kernel<true>), configuration 25 on bf16 operands (conv_dma4_kernel<false>).
+// Generation 4: the 3x3 convolution with every operand staged by LDS-DMA and one barrier per work item -- configuration 26
+// on bf16 operands (v_mfma_f32_16x16x32_bf16; THE default 3x3 conv of the engine, forward and data gradient) and
+// configuration 24 on e4m3 operands (v_mfma_scale_f32_32x32x64_f8f6f4; conv_dtype='fp8').
 //
 // Replaces, like the other conv kernels, tf.layers.conv2d(3x3, 'same', relu) + max_pooling2d of the FCN trunk
-// (xview/models/simple_fcn.py:39-79) for the layers of conv_dtype='fp8' that read AND write e4m3 maps (conv2_2 .. conv5_3).
+// (xview/models/simple_fcn.py:39-79) and, with the DG epilogue, the Conv2DBackpropInput + AddN + ReluGrad ops that
+// tf.train.*Optimizer.minimize adds for them (base_model.py:153-162).
 //
-// The first-generation fp8 kernel (conv_mfma_kernel<.., F8>) stages its patch through registers, takes two to five
-// barriers per work item and feeds v_mfma_scale_f32_16x16x128_f8f6f4 (K = 128 channels of one tap).  This kernel is the
-// generation-2 design (conv_dma_kernel) moved to fp8 with the instruction shape that fits it:
-//   * v_mfma_scale_f32_32x32x64_f8f6f4: K = 64 = ONE tap of a 64-channel chunk, so a work item is (16x32 pixel tile,
-//     64 output channels, 64 input channels) -- 64 bytes per patch pixel and per weight row, byte for byte the LDS
-//     geometry of the bf16 generation 2 (39 KB patch + 36 KB weights, double buffered, 151 KB) at twice the FLOP per
-//     item and the same matrix-pipe cycles (9 taps x 4 MFMAs x 64 cycles per wave).  Pairing two taps into the K = 128
-//     instruction would idle a tenth of the pipe (nine taps) and needs per-pair address registers.
-//   * 8 waves; wave w owns image rows 2w, 2w+1 x 32 columns x 64 channels: 2 pixel blocks x 2 channel blocks of 32x32,
-//     64 accumulator registers.  Lane l supplies pixel column l & 31 (weights: row l & 31 of a 32-row block) and the
-//     32-byte half l >> 5 of its 64 bytes, as two ds_read_b128.
-//   * LDS images: pixel / weight row r at r * 64, logical 16-byte slot s at physical slot s ^ ((r >> 2) & 3): every
-//     16-lane group of a ds_read_b128 covers all 64 banks once for the three horizontal taps (checked by brute force over
-//     the lane groups of MI355X_MICROARCH.md, LDS).  An LDS-DMA writes 1 KB linearly, so the swizzle is applied on the
-//     SOURCE side: per-lane global offsets for the patch, a pre-swizzled packed image for the weights.
-//   * The weight rows of a 32-row block are permuted in the packed image (row 8g + 4h + q holds channel 16h + 4g + q) so
-//     that the 16 accumulator registers of lane half h are 16 CONSECUTIVE output channels: bias, relu, e4m3 and one
-//     16-byte store per block (4 stores per lane and tile, 2 more for the fused 2x2 max-pool).
-//   * dx-major taps, fragments one tap (weights) / half a column group (pixels) ahead in a second register set, issued
-//     and waited for by hand (counted lgkmcnt, never more than 12 reads in flight), each tap's 4 MFMAs as one burst at
-//     raised priority; the next item's DMA two pieces per tap; ONE barrier per item behind a counted vmcnt that leaves
-//     the tile's own stores (younger than every DMA) in flight.
-// Partial tiles (maps that do not tile in 16x32) as in generation 2: the patch DMA of an edge tile clamps its source
-// coordinates onto the zero border of the padded map, stores are predicated, and the barrier behind an edge tile waits for
-// all its stores (a wave below the image issues none: no counted wait).  The chooser still prefers the first-generation fp8
-// kernel where the 16x32 tile wastes too much of a small map (the 24x48 conv5 maps of a 768x384 input: 56 % coverage).
-//
-// bf16 (configuration 25): the same kernel with 32-channel chunks (again 64 bytes per pixel and weight row) on
-// v_mfma_f32_32x32x16_bf16 -- two K = 16 steps per tap, lane half h supplying k-group h of each step (slots h and 2 + h) --
-// and a bf16 epilogue (two 16-byte stores per block).  Inference shapes only: bias + relu (+ pool), no addend / mask / stream-K.
+// Shared by both forms (the design of generation 2, conv_dma_kernel, with a leaner item loop):
+//   * a work item = (16x32 pixel tile, 64 output channels, one 64-BYTE chunk of input channels: 32 bf16 or 64 e4m3): an
+//     18x34 halo patch (39 KB) + all nine 64-row weight tiles (36 KB), both double buffered (151 KB of LDS), moved by
+//     global_load_lds_dwordx4 written in assembly; the next item's pieces are issued two per tap, ONE barrier per item behind
+//     a counted vmcnt that leaves the tile's own stores (younger than every DMA) in flight;
+//   * 8 waves, wave w owns image rows 2w, 2w+1 x 32 columns x 64 channels (64 accumulator registers);
+//   * LDS images: pixel / weight row r at r * 64 with its 16-byte slots swizzled so that every 16-lane group of a
+//     ds_read_b128 covers the 64 banks once for all three horizontal taps (brute-forced per MFMA shape); an LDS-DMA writes
+//     1 KB linearly, so the swizzle is applied on the SOURCE side (per-lane global offsets for the patch, pre-swizzled
+//     packed images for the weights);
+//   * the weight rows are permuted in the packed image so that a lane's 16 accumulator registers of a pixel are 16
+//     CONSECUTIVE output channels (one 16- or 32-byte run per pixel and lane);
+//   * dx-major taps, fragments one tap (weights) / half a column group (pixels) ahead in a second register set, issued and
+//     waited for by hand (counted lgkmcnt, never more than 12 reads in flight), each tap's MFMAs as one burst at raised
+//     priority; layers with one or two chunks keep their weights resident from the third item on;
+//   * partial tiles (EDGE): clamped DMA source coordinates onto the zero border, predicated stores.
+// bf16 form (M16): 16 MFMAs of K = 32 per tap on 4 x 4 blocks of 16x16 -- the chip holds ~0.2 GHz more clock on this shape
+// than on 32x32x16 at equal cycles (profiles/r4_conv_inkernel_clock.json); the tile's first MFMAs start from the bias; packed
+// bf16 epilogue (relu / 2x2 max on v_pk_max_i16), stores through a per-wave LDS stage so that four consecutive lanes write
+// one 64-byte run; STATS: per-channel sums of the stored values for batch-norm training; DG: addend + relu mask.
+// e4m3 form (F8): 4 block-scaled MFMAs of K = 64 per tap on 2 x 2 blocks of 32x32; first tap from C = 0; epilogue in two
+// instructions per value (fma + v_med3_f32 = scale, bias, relu, saturation), pooling by v_med3_f32 against +inf.
 #include "xv_common.h"
 
 namespace {
@@ -578,7 +572,7 @@ __global__ __launch_bounds__(512, 2) void conv_dma4_kernel(F8Args a) {
             bv[4 * q] = t4.x, bv[4 * q + 1] = t4.y, bv[4 * q + 2] = t4.z, bv[4 * q + 3] = t4.w;
           }
         }
-        if constexpr (M16 && !OF8 && !STATS) {
+        if constexpr (M16 && !OF8) {
           // PACKED epilogue of the bf16 16x16 form.  The float form below spends ~10 VALU instructions per output value
           // (fmaxf under IEEE mode quiets both operands; relu, vertical and horizontal pool each pay it): 3 000-3 900 cycles
           // per wave and tile, exposed -- every wave is in its epilogue at once -- and a fifth of a two-chunk layer's time
@@ -652,6 +646,25 @@ __global__ __launch_bounds__(512, 2) void conv_dma4_kernel(F8Args a) {
             for (int i = 0; i < 2; ++i) {
 #pragma unroll
               for (int k = 0; k < 8; ++k) pk[i][k] = pk_max_i16(pk[i][k], rfloor);
+              if constexpr (STATS) {
+                // per lane and channel: sums of the STORED (bf16) values and of their squares, kept in registers over all the
+                // workgroup's tiles (every tile of a workgroup has the same output-channel tile: the launcher checks
+                // nb % n_ct == 0); both pixel halves are the same 16 channels; lanes, waves and workgroups meet after the last
+                // tile.  The statistics kernel writes its rows straight from the lanes (no store stage: that LDS holds the
+                // waves' sums at the end).
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                  const float a0 = __builtin_bit_cast(float, pk[i][k] << 16), a1 = __builtin_bit_cast(float, pk[i][k] & 0xffff0000u);
+                  ssum[0][2 * k] += a0;
+                  ssum[0][2 * k + 1] += a1;
+                  ssq[0][2 * k] = fmaf(a0, a0, ssq[0][2 * k]);
+                  ssq[0][2 * k + 1] = fmaf(a1, a1, ssq[0][2 * k + 1]);
+                }
+                char* dst = a.y + (((int64_t)cur.n * (H + 2) + (py + i + 1)) * Wp + (px + 1)) * Ob + (cur.co0 + cl) * 2;
+                *reinterpret_cast<u32x4*>(dst) = u32x4{pk[i][0], pk[i][1], pk[i][2], pk[i][3]};
+                *reinterpret_cast<u32x4*>(dst + 16) = u32x4{pk[i][4], pk[i][5], pk[i][6], pk[i][7]};
+                continue;
+              }
               // through the wave's store stage: [pixel 0..15][piece 0..3] = one 64-byte run per pixel; lanes of channel
               // groups 0-1 fill it for the pixel's bytes 0..63, then groups 2-3 for bytes 64..127; lane l reads back piece
               // l & 3 of pixel l >> 2 (LDS operations of one wave execute in order: no wait between the rounds)
@@ -773,69 +786,7 @@ __global__ __launch_bounds__(512, 2) void conv_dma4_kernel(F8Args a) {
           }
           continue;
         }
-        float v[2][16];
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            float s;
-            if constexpr (M16) {  // r = 4 (2 j + jj) + q; the bias is already inside (the tile's first MFMAs started from it)
-              s = acc4[i][r >> 3][u][(r >> 2) & 1][r & 3];
-            } else {
-              s = acc[i][u][r] + bv[r];
-              acc[i][u][r] = 0.f;
-            }
-            v[i][r] = a.relu ? fmaxf(s, 0.f) : s;
-          }
-        if constexpr (STATS) {
-          // per lane and channel: sums of the two rows' STORED (bf16) values and of their squares, kept in registers over all
-          // the workgroup's tiles (every tile of a workgroup has the same output-channel tile: the launcher checks
-          // nb % n_ct == 0); lanes, waves and workgroups meet after the last tile
-          // (M16: both pixel halves are the same 16 channels: one row of sums)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const uint32_t pk = pack_bf16x2(v[0][r], v[1][r]);
-            const float a0 = __builtin_bit_cast(float, pk << 16), a1 = __builtin_bit_cast(float, pk & 0xffff0000u);
-            ssum[M16 ? 0 : u][r] += a0 + a1;
-            ssq[M16 ? 0 : u][r] = fmaf(a0, a0, fmaf(a1, a1, ssq[M16 ? 0 : u][r]));
-          }
-        }
-        const int cofs = cur.co0 + cl;
-        // 16 values -> 16 bytes of e4m3, or 32 bytes of bf16 (round-to-nearest-even, as every other epilogue)
-        auto store16 = [&](char* dst, const float (&w)[16], bool on) {
-          if constexpr (OF8) {
-            const u32x4 o = {g4_pack_fp8x4(w[0], w[1], w[2], w[3], a.out_mul), g4_pack_fp8x4(w[4], w[5], w[6], w[7], a.out_mul),
-                             g4_pack_fp8x4(w[8], w[9], w[10], w[11], a.out_mul),
-                             g4_pack_fp8x4(w[12], w[13], w[14], w[15], a.out_mul)};
-            if (on) *reinterpret_cast<u32x4*>(dst) = o;
-          } else {
-            const u32x4 o0 = {pack_bf16x2(w[0], w[1]), pack_bf16x2(w[2], w[3]), pack_bf16x2(w[4], w[5]), pack_bf16x2(w[6], w[7])};
-            const u32x4 o1 = {pack_bf16x2(w[8], w[9]), pack_bf16x2(w[10], w[11]), pack_bf16x2(w[12], w[13]),
-                              pack_bf16x2(w[14], w[15])};
-            if (on) {
-              *reinterpret_cast<u32x4*>(dst) = o0;
-              *reinterpret_cast<u32x4*>(dst + 16) = o1;
-            }
-          }
-        };
-        if (a.y != nullptr) {
-#pragma unroll
-          for (int i = 0; i < 2; ++i)
-            store16(a.y + (((int64_t)cur.n * (H + 2) + (py + i + 1)) * Wp + (px + 1)) * Ob + cofs * (OF8 ? 1 : 2), v[i],
-                    !EDGE || (py + i < H && px < W));
-        }
-        if (a.pooled != nullptr) {
-          float m[16];
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const float t = fmaxf(v[0][r], v[1][r]);
-            m[r] = fmaxf(t, g4_dpp_swap1(t));
-          }
-          const int Hq = H >> 1, Wq = W >> 1;
-          // every wave issues these instructions (even lanes store): the counted vmcnt at the next barrier relies on it
-          store16(a.pooled + (((int64_t)cur.n * (Hq + 2) + ((py >> 1) + 1)) * (Wq + 2) + ((px >> 1) + 1)) * Ob + cofs * (OF8 ? 1 : 2),
-                  m, (lane & 1) == 0 && (!EDGE || (py < H && px < W)));
-        }
+        static_assert(OF8 || M16, "every form has its packed / e4m3 epilogue above");
       }
       // (an edge tile may skip store instructions -- a wave below the image stores nothing: no counted wait then)
       in_flight = (EDGE && (cur.y0 + C::TH > H || cur.x0 + C::TW > W)) ? 0 : nstores;
