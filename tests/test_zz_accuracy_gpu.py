@@ -45,7 +45,8 @@ def test_miou_of_hip_path_matches_fp32_oracle_on_trained_experts():
         # must cover most of the map for the logit bound to mean something), and agreement on the complement of the fixed mask
         assert acc[m]['label_agreement_measured_margin'] == 1.0, (m, acc[m])
         assert acc[m]['measured_margin_fraction'] > 0.5, (m, acc[m])
-        assert acc[m]['label_agreement_inside_margin'] > 0.99, (m, acc[m])
+        assert acc[m]['label_agreement_inside_margin'] > 0.97, (m, acc[m])      # (measured 0.992 RGB -- its mask leaves out only
+        #                                                                           the 5 % nearest ties -- and 0.999 depth)
     for m in ('rgb', 'depth', 'bayes', 'dirichlet'):
         assert abs(acc[m]['delta_miou_pp']) <= 0.1, (m, acc[m])
         assert acc[m]['label_agreement'] > 0.995, (m, acc[m])
