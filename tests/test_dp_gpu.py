@@ -268,3 +268,33 @@ def test_two_rank_training_over_rccl(tmp_path):
     if not torch.cuda.is_available() or torch.cuda.device_count() < 2:
         pytest.skip('needs 2 GPUs')
     _check_unseeded(tmp_path, 'nccl')
+
+
+def _rccl_one_rank_worker(rank, port, out):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
+    # exactly the calls bench.py's fence() / timed_blocks() and parallel.py's gradient buckets make on RCCL
+    dist.barrier()
+    t = torch.tensor([0.125], dtype=torch.float64, device='cuda:0')
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    g = torch.arange(1 << 20, dtype=torch.float32, device='cuda:0')
+    work = dist.all_reduce(g[: 1 << 19], op=dist.ReduceOp.SUM, async_op=True)
+    b = torch.full((1024,), 3.0, device='cuda:0')
+    dist.broadcast(b, src=0)
+    work.wait()
+    torch.cuda.synchronize()
+    np.savez(out, t=t.cpu().numpy(), g=g[-4:].cpu().numpy(), b=b[:2].cpu().numpy())
+    dist.destroy_process_group()
+
+
+def test_rccl_process_group_on_one_gpu(tmp_path):
+    """The RCCL half of the N > 1 paths that a one-GPU box can run: a process group over 'nccl' with device_id, the barrier,
+    the float64 MAX all-reduce of the timing fence, an asynchronous fp32 SUM all-reduce on a bucket view and a broadcast."""
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU')
+    out = str(tmp_path / 'rccl1.npz')
+    mp.spawn(_rccl_one_rank_worker, args=(_free_port(), out), nprocs=1, join=True)
+    r = np.load(out)
+    assert float(r['t'][0]) == 0.125 and r['g'].tolist() == [1048572.0, 1048573.0, 1048574.0, 1048575.0] and r['b'].tolist() == [3.0, 3.0]
