@@ -1873,11 +1873,16 @@ __device__ __forceinline__ void pack_weights_group(const float* __restrict__ w, 
                                                    int cout, int dgrad, int64_t g, int64_t total) {
   const int rc = dgrad ? cout : cin;  // reduction channels
   const int oc = dgrad ? cin : cout;  // output channels
-  const int ng = rc >> 3;
-  const int co = (int)(g % oc);
-  const int64_t rest = g / oc;
-  const int G = (int)(rest % ng);
-  const int tap = (int)(rest / ng);
+  // g -> (tap, 64-channel chunk, output channel, slot of the chunk), the slot fastest: the eight lanes of one output channel
+  // fill one 128-byte row of image 1 (two 64-byte rows of images 2 / 3), eight consecutive channels per wave a contiguous
+  // 1 KB -- with the output channel fastest (round 3) every lane wrote its 16 bytes into a row of its own and the re-pack
+  // took 167 us of a training step for 235 MB of traffic.  The data-gradient image reads 8 x 32 contiguous bytes the same way.
+  const int nc64 = rc >> 6;          // rc is a multiple of 64: every packed layout is made of 64-channel rows
+  const int64_t r = g >> 3;
+  const int co = (int)(r % oc);
+  const int64_t rest = r / oc;
+  const int G = (int)(rest % nc64) * 8 + (int)(g & 7);
+  const int tap = (int)(rest / nc64);
   float v[8];
   if (dgrad) {
     const float* src = w + ((int64_t)(taps - 1 - tap) * cin + co) * cout + G * 8;
