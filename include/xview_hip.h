@@ -139,6 +139,17 @@ int xv_deconv_dense_fwd(const xv_act* x, const void* w_phases_packed, const floa
  * configurations; XV_ESHAPE if the configuration cannot tile this shape.                            */
 int xv_conv2d_fwd_cfg(const xv_act* x, const void* w_packed, const float* bias, const xv_act* y,
                       const xv_act* pooled, int k, int relu, int cfg, void* stream);
+/* The SAME 3x3 layer of TWO models in one launch: the two experts of a fusion model run identical layer shapes from conv1_2
+ * on (basic_fusion_model.py:25-60 builds one fcn() per modality), each with its own maps, weights and bias.  The persistent
+ * generation-4 / 5 kernel takes the concatenated tile lists, so the launch makes whole rounds of workgroups where each
+ * expert alone leaves its last round half empty (conv4_x at 16 images of 768x384: 2 x 1152 tiles = 9 rounds of 256 CUs
+ * against 2 x 5; conv5_x: 3 against 2 x 2).  Arguments per model as xv_conv2d_fwd (k = 3; y descriptors are required, their
+ * data may be null with a pooled output); both models give the same set of outputs.  Results are bit-identical to two
+ * xv_conv2d_fwd calls.  XV_ESHAPE -- nothing launched -- where the shape does not run on generation 4 / 5 (bf16 maps that
+ * tile exactly in 16x32, or in 24x16 / 32x16 without a pooled output): launch the two convs separately then.          */
+int xv_conv2d_fwd_pair(const xv_act* xa, const void* wa_packed, const float* bias_a, const xv_act* ya, const xv_act* pooled_a,
+                       const xv_act* xb, const void* wb_packed, const float* bias_b, const xv_act* yb, const xv_act* pooled_b,
+                       int relu, void* stream);
 /* Stream-K tail of the generation-2 3x3 kernel (conv_dma_kernel).  A persistent grid walks (pixel patch, cout tile)
  * tiles round by round; when the last round is incomplete (conv4_x / conv5_x at 16 images: 4.5 / 1.5 rounds; one image:
  * fewer tiles than CUs from conv2 on) its (tile, 32-channel chunk) items are dealt out evenly over ALL workgroups, the

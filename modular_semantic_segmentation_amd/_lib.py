@@ -45,6 +45,7 @@ SIGNATURES = {
     'xv_pack_conv_weights_f8': (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     'xv_conv2d_fwd': (_i, [_actp, _vp, _vp, _actp, _actp, _i, _i, _vp]),
     'xv_conv2d_fwd_cfg': (_i, [_actp, _vp, _vp, _actp, _actp, _i, _i, _i, _vp]),
+    'xv_conv2d_fwd_pair': (_i, [_actp, _vp, _vp, _actp, _actp, _actp, _vp, _vp, _actp, _actp, _i, _vp]),
     'xv_conv2d_num_cfgs': (_i, []),
     'xv_conv2d_streamk_workspace_bytes': (ctypes.c_size_t, []),
     'xv_conv2d_fwd_ws': (_i, [_actp, _vp, _vp, _actp, _actp, _i, _i, _i, _vp, ctypes.c_size_t, _vp]),

@@ -5,11 +5,12 @@ from .base_model import BaseModel
 from .fcn import FcnEngine, init_variables
 
 
-def test_pipeline(engine, inputs, want=('prob', 'classification')):
+def test_pipeline(engine, inputs, want=('prob', 'classification'), st=None):
     """Expert forward + softmax + argmax (basic_fusion_model.py:9-23) on an FcnEngine:
-    returns {'prob': f32 [N,H,W,C], 'classification': i64 [N,H,W]} (only what `want` names)."""
-    out = engine.forward(inputs, want=tuple('label' if w == 'classification' else w for w in want))
-    return out
+    returns {'prob': f32 [N,H,W,C], 'classification': i64 [N,H,W]} (only what `want` names).  st: an encoder state to
+    finish (the shared launches of two experts, run_trunks) instead of `inputs`."""
+    want = tuple('label' if w == 'classification' else w for w in want)
+    return engine.forward(inputs, want=want, st=st) if st is not None else engine.forward(inputs, want=want)
 
 
 def expert_factory(expert_model, conv_dtype='bf16'):
@@ -49,29 +50,66 @@ def calibrate_experts(model, data):
     return {m: model.experts[m].calibrate(model._to_device(batch[m], torch.float32)) for m in model.modalities}
 
 
-def run_experts(model, batch, wants):
-    """Forward every modality's expert, each on its own HIP stream: the experts are independent
-    until the fusion kernel, and the tail of one stream's persistent conv grid is filled by the
-    other stream's workgroups.  The current stream waits for all of them before fusing."""
-    if not getattr(model, 'concurrent_experts', True):
-        return {m: test_pipeline(model.experts[m], model._to_device(batch[m], torch.float32), want=wants)
-                for m in model.modalities}
+def paired_from(model):
+    """Index of the first encoder layer the two experts run as ONE launch each (fcn.encoder_layers_pair), or None: two FCN
+    experts on the bf16 path without dropout sites or the stream-K option."""
+    from .fcn import group_from_index
+    gi = group_from_index()
+    if gi is None or len(model.modalities) != 2 or not model.config.get('paired_launches', True):
+        return None
+    if not all(type(e) is FcnEngine and e.pairable() for e in model.experts.values()):
+        return None
+    return gi
+
+
+def run_trunks(model, inputs, finish):
+    """Both experts up to finish(modality, state-or-None) -> result: each on its own HIP stream (the experts are independent
+    until the fusion kernel); from paired_from() on the layers both experts share are ONE launch each on the current stream
+    -- whole rounds of workgroups where each expert alone leaves its last round half empty -- and the streams fork again for
+    the heads.  The current stream waits for all of them before returning."""
+    from .fcn import encoder_layers_pair
+    mods = model.modalities
+    conc = getattr(model, 'concurrent_experts', True)
     main = torch.cuda.current_stream(model.device)
-    if not hasattr(model, '_expert_streams'):
-        model._expert_streams = {m: torch.cuda.Stream(device=model.device) for m in model.modalities}
-    outs = {}
+    if conc and not hasattr(model, '_expert_streams'):
+        model._expert_streams = {m: torch.cuda.Stream(device=model.device) for m in mods}
+
+    def each(fn):
+        out = {}
+        for m in mods:
+            if conc:
+                side = model._expert_streams[m]
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    out[m] = fn(m)
+            else:
+                out[m] = fn(m)
+        if conc:
+            for m in mods:
+                main.wait_stream(model._expert_streams[m])
+        return out
+
+    gi = paired_from(model)
+    if gi is None:
+        return each(lambda m: finish(m, None))
+    st = each(lambda m: model.experts[m].encoder_begin(inputs[m], stop=gi))
+    a, b = mods
+    encoder_layers_pair(model.experts[a], st[a], model.experts[b], st[b])
+    return each(lambda m: finish(m, st[m]))
+
+
+def run_experts(model, batch, wants):
+    """Forward every modality's expert (run_trunks), each to its test_pipeline outputs."""
     inputs = {m: model._to_device(batch[m], torch.float32) for m in model.modalities}
-    for m in model.modalities:
-        side = model._expert_streams[m]
-        side.wait_stream(main)
-        with torch.cuda.stream(side):
-            outs[m] = test_pipeline(model.experts[m], inputs[m], want=wants)
-            for v in outs[m].values():
-                if isinstance(v, torch.Tensor):
-                    v.record_stream(main)
-    for m in model.modalities:
-        main.wait_stream(model._expert_streams[m])
-    return outs
+    main = torch.cuda.current_stream(model.device)
+
+    def finish(m, st):
+        out = test_pipeline(model.experts[m], inputs[m], want=wants, st=st)
+        for v in out.values():
+            if isinstance(v, torch.Tensor):
+                v.record_stream(main)
+        return out
+    return run_trunks(model, inputs, finish)
 
 
 def fused_head_applicable(model):
@@ -84,25 +122,12 @@ def fused_head_applicable(model):
 
 
 def run_fused_head(model, batch, tab, logprior, lognorm=None):
-    """Both trunks (each on its own HIP stream) up to their low-resolution class scores, then ONE kernel: per-pixel
-    logits, softmax / argmax per expert and the Bayes or Dirichlet fusion -> fused labels."""
-    main = torch.cuda.current_stream(model.device)
+    """Both trunks (run_trunks) up to their low-resolution class scores, then ONE kernel: per-pixel logits, softmax / argmax
+    per expert and the Bayes or Dirichlet fusion -> fused labels."""
     inputs = {m: model._to_device(batch[m], torch.float32) for m in model.modalities}
-    S, geo = {}, None
-    if getattr(model, 'concurrent_experts', True):
-        if not hasattr(model, '_expert_streams'):
-            model._expert_streams = {m: torch.cuda.Stream(device=model.device) for m in model.modalities}
-        for m in model.modalities:
-            side = model._expert_streams[m]
-            side.wait_stream(main)
-            with torch.cuda.stream(side):
-                S[m], geo = model.experts[m].lowres_scores(inputs[m])
-        for m in model.modalities:
-            main.wait_stream(model._expert_streams[m])
-    else:
-        for m in model.modalities:
-            S[m], geo = model.experts[m].lowres_scores(inputs[m])
+    res = run_trunks(model, inputs, lambda m, st: model.experts[m].lowres_scores(inputs[m], st=st))
     a, b = model.modalities
+    S, geo = {m: r[0] for m, r in res.items()}, res[a][1]
     from . import ops
     return ops.fused_head(S[a], S[b], model.experts[a].b['score'], model.experts[b].b['score'], geo[0], geo[1], geo[2],
                           model.config['num_classes'], tab, logprior, lognorm=lognorm)

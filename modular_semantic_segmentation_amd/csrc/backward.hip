@@ -780,7 +780,7 @@ extern "C" int xv_decoder_head_bwd(const xv_act* fused, const float* w_score, co
     static bool attr[XV_MAX_DEVICES] = {false};                                                                      \
     {                                                                                                                \
       const hipError_t e =                                                                                           \
-          xv_allow_dynamic_lds(reinterpret_cast<const void*>(&head_bwd_lowres_kernel<CMV>), 160 * 1024, attr);        \
+          xv_allow_dynamic_lds(reinterpret_cast<const void*>(&head_bwd_lowres_kernel<CMV>), 160 * 1024, attr, false);        \
       if (e != hipSuccess) return (int)e;                                                                            \
     }                                                                                                                \
     hipLaunchKernelGGL(head_bwd_lowres_kernel<CMV>, dim3(g2), dim3(1024), lds, s, (const float*)dscore,               \

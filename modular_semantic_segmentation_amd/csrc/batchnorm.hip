@@ -1558,7 +1558,7 @@ extern "C" int xv_score_dense_bwd(const xv_act* u, const float* dscore, const fl
 #define XV_SB(CMV)                                                                                                   \
   {                                                                                                                  \
     static bool attr[XV_MAX_DEVICES] = {false};                                                                      \
-    (void)xv_allow_dynamic_lds(reinterpret_cast<const void*>(&score_dense_dgrad_kernel<CMV>), 160 * 1024, attr);      \
+    (void)xv_allow_dynamic_lds(reinterpret_cast<const void*>(&score_dense_dgrad_kernel<CMV>), 160 * 1024, attr, false);      \
     if (mfma_dgrad && !wg_old) {                                                                                     \
       hipLaunchKernelGGL(score_dense_wgrad_mfma_kernel<8>, dim3(gwm), dim3(256), 0, s, (const __bf16*)u->data, dscore, \
                          dw_score, db_score, u->n, u->h, u->w, num_classes, qpw);                                     \

@@ -35,6 +35,14 @@ struct G5Args {
   // data-gradient epilogue: y = (conv + addend) where mask > 0, else 0 -- both maps shaped like y (either may be null)
   const char* mask;
   const char* addend;
+  // second problem of the same shape in the same launch (conv_f8_dma.hip F8Args::n_first): the conv5 maps of a 768x384 input
+  // at 16 images make 2 x 384 tiles = 3 rounds of 256 workgroups instead of 2 x 1.5 -> 2 x 2.  Forward form only.
+  const char* x2;
+  const char* wpk2;
+  const float* bias2;
+  char* y2;
+  char* pooled2;
+  int n_first;
 };
 
 template <int MT>
@@ -78,6 +86,7 @@ __global__ __launch_bounds__(512, 2) void conv_dma5_kernel(G5Args a) {
   const int Cb = 2 * Cin, Ob = 2 * Cout;  // bytes per pixel of the input / output maps
   const int nchunks = Cb >> 6;            // 64 bytes = 32 input channels per chunk
   const char* const wimg = a.wpk + (int64_t)4 * 9 * Cin * Cout;  // the third packed image
+  const char* const wimg2 = a.wpk2 + (int64_t)4 * 9 * Cin * Cout;
 
   // persistent workgroups, XCD-contiguous tile ranges, the output-channel tiles of one patch adjacent (as generation 2 / 4)
   const int G = gridDim.x, b = blockIdx.x;
@@ -92,6 +101,8 @@ __global__ __launch_bounds__(512, 2) void conv_dma5_kernel(G5Args a) {
 
   struct Tile {
     int n, y0, x0, co0;
+    int second;  // 1: a tile of the second problem (n counts its images).  (int: a bool member sent the struct through an
+                 // alloca that the compiler promoted into LDS, on top of the patch buffer)
   };
   auto decode = [&](int l) {
     Tile t;
@@ -101,6 +112,8 @@ __global__ __launch_bounds__(512, 2) void conv_dma5_kernel(G5Args a) {
     r /= a.tiles_x;
     t.y0 = (r % a.tiles_y) * C::TH;
     t.n = r / a.tiles_y;
+    t.second = (a.n_first > 0 && t.n >= a.n_first) ? 1 : 0;
+    t.n -= t.second ? a.n_first : 0;
     return t;
   };
 
@@ -127,8 +140,8 @@ __global__ __launch_bounds__(512, 2) void conv_dma5_kernel(G5Args a) {
     asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_off), "v"(voff), "s"(sbase) : "memory");
   };
   auto dma_bases = [&](const Tile& t, int chunk, const char*& xsrc, const char*& wsrc) {
-    xsrc = a.x + (((int64_t)t.n * (H + 2) + t.y0) * Wp + t.x0) * Cb + chunk * 64;
-    wsrc = wimg + (((int64_t)chunk * Cout + t.co0) << 6);
+    xsrc = (t.second ? a.x2 : a.x) + (((int64_t)t.n * (H + 2) + t.y0) * Wp + t.x0) * Cb + chunk * 64;
+    wsrc = (t.second ? wimg2 : wimg) + (((int64_t)chunk * Cout + t.co0) << 6);
   };
   auto dma_a = [&](const char* xsrc, int it, int buf) {
     const int piece = wave + it * C::NWAVES;
@@ -143,7 +156,7 @@ __global__ __launch_bounds__(512, 2) void conv_dma5_kernel(G5Args a) {
   auto dma_bias = [&](const Tile& t, bool tile_start, int bslot) {
     if (tile_start && wave == C::NWAVES - 1)
       asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dword %1, %2" ::"s"(C::BIAS_OFF + bslot * 256), "v"(lane * 4),
-                   "s"(a.bias + t.co0)
+                   "s"((t.second ? a.bias2 : a.bias) + t.co0)
                    : "memory");
   };
 
@@ -167,7 +180,7 @@ __global__ __launch_bounds__(512, 2) void conv_dma5_kernel(G5Args a) {
 
   // RESIDENT WEIGHTS (as generation 2 / 4): with one or two chunks per tile weight buffer p only ever holds chunk p's
   // weights -- of the same output-channel tile too when every workgroup of the XCD group keeps its tile residue
-  const bool resident = nchunks <= 2 && (nb % a.n_ct) == 0;
+  const bool resident = nchunks <= 2 && (nb % a.n_ct) == 0 && a.n_first == 0;  // (two problems: two sets of weights)
   int items_done = 0;
   // 16-byte store instructions per tile and wave: two per row, two per pooled row
   const int nstores = (a.y != nullptr ? 2 * MT : 0) + (a.pooled != nullptr ? MT : 0);
@@ -342,6 +355,8 @@ __global__ __launch_bounds__(512, 2) void conv_dma5_kernel(G5Args a) {
       const int px = cur.x0 + n15;
       const int py = cur.y0 + MT * wave;
       const int cofs = cur.co0 + 16 * g;  // first of this lane's 16 consecutive channels
+      char* const ymap = cur.second ? a.y2 : a.y;
+      char* const qmap = cur.second ? a.pooled2 : a.pooled;
       // PACKED epilogue (as generation 4's 16x16 form): bias add in fp32, one v_cvt_pk_bf16_f32 per channel pair, relu and
       // the 2x2 max on the packed pairs as signed 16-bit integers -- 2-3 VALU instructions per value instead of ~10
       uint32_t pk[MT][8];
@@ -402,7 +417,7 @@ __global__ __launch_bounds__(512, 2) void conv_dma5_kernel(G5Args a) {
         for (int i = 0; i < MT; ++i) {
 #pragma unroll
           for (int k = 0; k < 8; ++k) pk[i][k] = pk_max_i16(pk[i][k], rfloor);
-          char* dst = a.y + (((int64_t)cur.n * (H + 2) + (py + i + 1)) * Wp + (px + 1)) * Ob + cofs * 2;
+          char* dst = ymap + (((int64_t)cur.n * (H + 2) + (py + i + 1)) * Wp + (px + 1)) * Ob + cofs * 2;
           *reinterpret_cast<u32x4*>(dst) = u32x4{pk[i][0], pk[i][1], pk[i][2], pk[i][3]};
           *reinterpret_cast<u32x4*>(dst + 16) = u32x4{pk[i][4], pk[i][5], pk[i][6], pk[i][7]};
         }
@@ -427,7 +442,7 @@ __global__ __launch_bounds__(512, 2) void conv_dma5_kernel(G5Args a) {
               }
             }
             // every wave issues these instructions (even lanes store): the counted vmcnt at the next barrier relies on it
-            char* dst = a.pooled + (((int64_t)cur.n * (Hq + 2) + (((py + i) >> 1) + 1)) * (Wq + 2) + ((px >> 1) + 1)) * Ob + cofs * 2;
+            char* dst = qmap + (((int64_t)cur.n * (Hq + 2) + (((py + i) >> 1) + 1)) * (Wq + 2) + ((px >> 1) + 1)) * Ob + cofs * 2;
             if ((lane & 1) == 0) {
               *reinterpret_cast<u32x4*>(dst) = u32x4{m[0], m[1], m[2], m[3]};
               *reinterpret_cast<u32x4*>(dst + 16) = u32x4{m[4], m[5], m[6], m[7]};
@@ -507,6 +522,30 @@ int xv_launch_conv3x3_col(const void* x, const void* wpk, const float* bias, voi
   a.addend = (const char*)addend;
   const int grid = num_cus > 0 ? num_cus : 256;
   if (mask != nullptr || addend != nullptr) return mt == 3 ? g5_launch<3, true>(a, grid, stream) : g5_launch<4, true>(a, grid, stream);
+  return mt == 3 ? g5_launch<3>(a, grid, stream) : g5_launch<4>(a, grid, stream);
+}
+
+// Two problems of one shape in ONE launch (G5Args::n_first); both full maps or neither, both pooled maps or neither.
+int xv_launch_conv3x3_col_pair(const void* const x[2], const void* const wpk[2], const float* const bias[2], void* const y[2],
+                               void* const pooled[2], int N, int H, int W, int Cin, int Cout, int relu, int mt, int num_cus,
+                               hipStream_t stream) {
+  if (!xv_conv3x3_col_ok(H, W, Cin, Cout, mt) || (y[0] == nullptr) != (y[1] == nullptr) ||
+      (pooled[0] == nullptr) != (pooled[1] == nullptr) || (y[0] == nullptr && pooled[0] == nullptr) ||
+      (pooled[0] != nullptr && (mt & 1)))
+    return XV_ESHAPE;
+  G5Args a{};
+  a.x = (const char*)x[0], a.wpk = (const char*)wpk[0], a.bias = bias[0], a.y = (char*)y[0], a.pooled = (char*)pooled[0];
+  a.x2 = (const char*)x[1], a.wpk2 = (const char*)wpk[1], a.bias2 = bias[1], a.y2 = (char*)y[1], a.pooled2 = (char*)pooled[1];
+  a.n_first = N;
+  a.N = 2 * N, a.H = H, a.W = W, a.Cin = Cin, a.Cout = Cout;
+  a.tiles_x = W / 16;
+  a.tiles_y = H / (8 * mt);
+  a.n_ct = Cout / 64;
+  const int64_t ntiles = (int64_t)a.tiles_x * a.tiles_y * a.N * a.n_ct;
+  if (ntiles <= 0 || ntiles > 0x7fffffff) return XV_ESHAPE;
+  a.n_tiles = (int)ntiles;
+  a.relu = relu;
+  const int grid = num_cus > 0 ? num_cus : 256;
   return mt == 3 ? g5_launch<3>(a, grid, stream) : g5_launch<4>(a, grid, stream);
 }
 

@@ -50,6 +50,16 @@ struct F8Args {
   // data-gradient epilogue (bf16 16x16 form only): y = (conv + addend) where mask > 0, else 0 -- both maps shaped like y
   const char* mask;
   const char* addend;
+  // SECOND PROBLEM of the same shape (the other expert of a fusion model: its own maps, weights and bias), n_first > 0:
+  // images n_first .. N - 1 of the tile list are images 0 .. of these.  One launch then makes whole rounds of workgroups
+  // where each expert alone leaves the last one half empty (conv4_x at 16 images: 2 x 1152 tiles = 9 rounds of 256
+  // instead of 2 x 4.5 -> 2 x 5).  bf16 forward form only.
+  const char* x2;
+  const char* wpk2;
+  const float* bias2;
+  char* y2;
+  char* pooled2;
+  int n_first;
 };
 
 #ifdef XV_CLOCK_STAMP
@@ -160,6 +170,7 @@ __global__ __launch_bounds__(512, 2) void conv_dma4_kernel(F8Args a) {
   }
   // generation-4 image: fp8 -- behind the header and the generation-1 image; bf16 -- the third image of the packed buffer
   const char* const wimg = F8 ? a.wpk + 256 + (int64_t)9 * Cin * Cout : a.wpk + (int64_t)4 * 9 * Cin * Cout;
+  const char* const wimg2 = a.wpk2 + (int64_t)4 * 9 * Cin * Cout;  // (second problem: bf16 only)
 
   // persistent workgroups, XCD-contiguous tile ranges, the output-channel tiles of one patch adjacent (as generation 2)
   const int G = gridDim.x, b = blockIdx.x;
@@ -180,6 +191,8 @@ __global__ __launch_bounds__(512, 2) void conv_dma4_kernel(F8Args a) {
 
   struct Tile {
     int n, y0, x0, co0;
+    int second;  // 1: a tile of the second problem (n counts its images).  (int: a bool member sent the struct through an
+                 // alloca that the compiler promoted into LDS, on top of the patch buffer)
   };
   auto decode = [&](int l) {
     Tile t;
@@ -189,6 +202,8 @@ __global__ __launch_bounds__(512, 2) void conv_dma4_kernel(F8Args a) {
     r /= a.tiles_x;
     t.y0 = (r % a.tiles_y) * C::TH;
     t.n = r / a.tiles_y;
+    t.second = (a.n_first > 0 && t.n >= a.n_first) ? 1 : 0;
+    t.n -= t.second ? a.n_first : 0;
     return t;
   };
 
@@ -226,8 +241,8 @@ __global__ __launch_bounds__(512, 2) void conv_dma4_kernel(F8Args a) {
     asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_off), "v"(voff), "s"(sbase) : "memory");
   };
   auto dma_bases = [&](const Tile& t, int chunk, const char*& xsrc, const char*& wsrc) {
-    xsrc = a.x + (((int64_t)t.n * (H + 2) + t.y0) * Wp + t.x0) * Cb + chunk * 64;
-    wsrc = wimg + (((int64_t)chunk * Cout + t.co0) << 6);
+    xsrc = (t.second ? a.x2 : a.x) + (((int64_t)t.n * (H + 2) + t.y0) * Wp + t.x0) * Cb + chunk * 64;
+    wsrc = (t.second ? wimg2 : wimg) + (((int64_t)chunk * Cout + t.co0) << 6);
   };
   // edge tiles (the patch reaches past the padded image): patch coordinates are clamped onto the zero border, i.e. the
   // source offset is recomputed with hy <= ylim, hx <= xlim (re-derived from the lane number inside this rare path, as in
@@ -257,7 +272,7 @@ __global__ __launch_bounds__(512, 2) void conv_dma4_kernel(F8Args a) {
   auto dma_bias = [&](const Tile& t, bool tile_start, int bslot) {
     if (tile_start && wave == C::NWAVES - 1)
       asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dword %1, %2" ::"s"(C::BIAS_OFF + bslot * 256), "v"(lane * 4),
-                   "s"(a.bias + t.co0)
+                   "s"((t.second ? a.bias2 : a.bias) + t.co0)
                    : "memory");
   };
 
@@ -302,7 +317,7 @@ __global__ __launch_bounds__(512, 2) void conv_dma4_kernel(F8Args a) {
   // so weight buffer p only ever holds chunk p's weights -- of the same output-channel tile too when every workgroup of the
   // XCD group keeps its tile residue (nb % n_ct == 0).  From its third item on such a workgroup requests no weights at all:
   // half the DMA pieces of conv1_2 / conv2_1-like layers.
-  const bool resident = nchunks <= 2 && (nb % a.n_ct) == 0;
+  const bool resident = nchunks <= 2 && (nb % a.n_ct) == 0 && a.n_first == 0;  // (two problems: two sets of weights)
   int items_done = 0;
   // (packed bf16 epilogue: 8 staged stores for the full map, ONE full-wave store per pixel half for the pooled map)
   constexpr bool STAGED = M16 && !OF8 && !STATS;
@@ -560,6 +575,8 @@ __global__ __launch_bounds__(512, 2) void conv_dma4_kernel(F8Args a) {
         }
       };
       if constexpr (DG) dg_request(0);
+      char* const ymap = cur.second ? a.y2 : a.y;
+      char* const qmap = cur.second ? a.pooled2 : a.pooled;
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
         const int cl = M16 ? 16 * hh : 32 * u + 16 * hh;  // first of this lane's 16 consecutive channels within the tile
@@ -660,7 +677,7 @@ __global__ __launch_bounds__(512, 2) void conv_dma4_kernel(F8Args a) {
                   ssq[0][2 * k] = fmaf(a0, a0, ssq[0][2 * k]);
                   ssq[0][2 * k + 1] = fmaf(a1, a1, ssq[0][2 * k + 1]);
                 }
-                char* dst = a.y + (((int64_t)cur.n * (H + 2) + (py + i + 1)) * Wp + (px + 1)) * Ob + (cur.co0 + cl) * 2;
+                char* dst = ymap + (((int64_t)cur.n * (H + 2) + (py + i + 1)) * Wp + (px + 1)) * Ob + (cur.co0 + cl) * 2;
                 *reinterpret_cast<u32x4*>(dst) = u32x4{pk[i][0], pk[i][1], pk[i][2], pk[i][3]};
                 *reinterpret_cast<u32x4*>(dst + 16) = u32x4{pk[i][4], pk[i][5], pk[i][6], pk[i][7]};
                 continue;
@@ -670,7 +687,7 @@ __global__ __launch_bounds__(512, 2) void conv_dma4_kernel(F8Args a) {
               // l & 3 of pixel l >> 2 (LDS operations of one wave execute in order: no wait between the rounds)
               u32x4* stage = reinterpret_cast<u32x4*>(smem + C::STAGE_OFF + wave * 1024);
               const int pxl = cur.x0 + 16 * u + (lane >> 2);
-              char* dst = a.y + (((int64_t)cur.n * (H + 2) + (py + i + 1)) * Wp + (pxl + 1)) * Ob + cur.co0 * 2 + (lane & 3) * 16;
+              char* dst = ymap + (((int64_t)cur.n * (H + 2) + (py + i + 1)) * Wp + (pxl + 1)) * Ob + cur.co0 * 2 + (lane & 3) * 16;
               const bool on = !EDGE || (py + i < H && pxl < W);
 #pragma unroll
               for (int half = 0; half < 2; ++half) {
@@ -723,7 +740,7 @@ __global__ __launch_bounds__(512, 2) void conv_dma4_kernel(F8Args a) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             const int qx = ((cur.x0 + 16 * u) >> 1) + ((lane & 31) >> 2);
-            char* dst = a.pooled + (((int64_t)cur.n * (Hq + 2) + ((py >> 1) + 1)) * (Wq + 2) + (qx + 1)) * Ob + cur.co0 * 2 +
+            char* dst = qmap + (((int64_t)cur.n * (Hq + 2) + ((py >> 1) + 1)) * (Wq + 2) + (qx + 1)) * Ob + cur.co0 * 2 +
                         (lane >> 5) * 64 + (lane & 3) * 16;
             // every wave issues this instruction: the counted vmcnt at the next barrier relies on it
             if (!EDGE || (py < H && 2 * qx < W)) *reinterpret_cast<u32x4*>(dst) = r;
@@ -768,7 +785,7 @@ __global__ __launch_bounds__(512, 2) void conv_dma4_kernel(F8Args a) {
             for (int i = 0; i < 2; ++i) {
               const u32x4 o = cvt16(q[i]);
               if (!EDGE || (py + i < H && px < W))
-                *reinterpret_cast<u32x4*>(a.y + (((int64_t)cur.n * (H + 2) + (py + i + 1)) * Wp + (px + 1)) * Ob + cofs8) = o;
+                *reinterpret_cast<u32x4*>(ymap + (((int64_t)cur.n * (H + 2) + (py + i + 1)) * Wp + (px + 1)) * Ob + cofs8) = o;
             }
           }
           if (a.pooled != nullptr) {
@@ -782,7 +799,7 @@ __global__ __launch_bounds__(512, 2) void conv_dma4_kernel(F8Args a) {
             const u32x4 o = cvt16(m);
             // every wave issues this instruction (even lanes store): the counted vmcnt at the next barrier relies on it
             if ((lane & 1) == 0 && (!EDGE || (py < H && px < W)))
-              *reinterpret_cast<u32x4*>(a.pooled + (((int64_t)cur.n * (Hq + 2) + ((py >> 1) + 1)) * (Wq + 2) + ((px >> 1) + 1)) * Ob + cofs8) = o;
+              *reinterpret_cast<u32x4*>(qmap + (((int64_t)cur.n * (Hq + 2) + ((py >> 1) + 1)) * (Wq + 2) + ((px >> 1) + 1)) * Ob + cofs8) = o;
           }
           continue;
         }
@@ -976,6 +993,30 @@ int xv_launch_conv3x3_f8_dma(const void* x, const void* wpk, const float* bias, 
                                        : g4_launch1<false, false, false, true, true, true>(a, grid, stream);
   if (in_f8) return g4_launch<true, true>(a, grid, stream);
   return out_f8 ? g4_launch<false, true, false, true>(a, grid, stream) : g4_launch<false, false, false, true>(a, grid, stream);
+}
+
+// Two problems of one shape in ONE launch (F8Args::n_first): the bf16 forward form on maps that tile exactly in 16x32.
+// Both full maps or neither, both pooled maps or neither.
+int xv_launch_conv3x3_dma4_pair(const void* const x[2], const void* const wpk[2], const float* const bias[2], void* const y[2],
+                                void* const pooled[2], int N, int H, int W, int Cin, int Cout, int relu, int num_cus,
+                                hipStream_t stream) {
+  if (!xv_conv3x3_dma4_bf16_ok(H, W, Cin, Cout) || !xv_conv3x3_dma4_exact(H, W) || (y[0] == nullptr) != (y[1] == nullptr) ||
+      (pooled[0] == nullptr) != (pooled[1] == nullptr) || (y[0] == nullptr && pooled[0] == nullptr))
+    return XV_ESHAPE;
+  F8Args a{};
+  a.x = (const char*)x[0], a.wpk = (const char*)wpk[0], a.bias = bias[0], a.y = (char*)y[0], a.pooled = (char*)pooled[0];
+  a.x2 = (const char*)x[1], a.wpk2 = (const char*)wpk[1], a.bias2 = bias[1], a.y2 = (char*)y[1], a.pooled2 = (char*)pooled[1];
+  a.n_first = N;
+  a.N = 2 * N, a.H = H, a.W = W, a.Cin = Cin, a.Cout = Cout;
+  a.tiles_x = W / G4::TW;
+  a.tiles_y = H / G4::TH;
+  a.n_ct = Cout / 64;
+  const int64_t ntiles = (int64_t)a.tiles_x * a.tiles_y * a.N * a.n_ct;
+  if (ntiles <= 0 || ntiles > 0x7fffffff) return XV_ESHAPE;
+  a.n_tiles = (int)ntiles;
+  a.relu = relu;
+  a.out_mul = 1.f;
+  return g4_launch1<false, false, false, false, true>(a, num_cus > 0 ? num_cus : 256, stream);
 }
 
 // second image of the packed fp8 buffer (xv_pack_conv_weights_f8 calls this for 3x3 kernels with cin % 64 == 0)

@@ -50,6 +50,13 @@ bool xv_conv3x3_col_ok(int H, int W, int Cin, int Cout, int mt);
 int xv_launch_conv3x3_col(const void* x, const void* wpk, const float* bias, void* y, void* pooled, int N, int H, int W, int Cin,
                           int Cout, int relu, int mt, int num_cus, hipStream_t stream, const void* mask = nullptr,
                           const void* addend = nullptr);
+// two problems of one shape in one launch (generations 4 / 5)
+int xv_launch_conv3x3_dma4_pair(const void* const x[2], const void* const wpk[2], const float* const bias[2], void* const y[2],
+                                void* const pooled[2], int N, int H, int W, int Cin, int Cout, int relu, int num_cus,
+                                hipStream_t stream);
+int xv_launch_conv3x3_col_pair(const void* const x[2], const void* const wpk[2], const float* const bias[2], void* const y[2],
+                               void* const pooled[2], int N, int H, int W, int Cin, int Cout, int relu, int mt, int num_cus,
+                               hipStream_t stream);
 
 namespace {
 
@@ -2405,6 +2412,50 @@ extern "C" int xv_conv2d_fwd(const xv_act* x, const void* w_packed, const float*
 extern "C" int xv_conv2d_fwd_cfg(const xv_act* x, const void* w_packed, const float* bias, const xv_act* y,
                                  const xv_act* pooled, int k, int relu, int cfg, void* stream) {
   return conv_fwd_impl(x, w_packed, bias, y, pooled, k, relu, cfg, stream);
+}
+
+// The same 3x3 layer of TWO models (the two experts of a fusion model: own maps, weights and bias, one shape) in ONE launch
+// of the persistent generation-4 / 5 kernel: the tile lists are concatenated, so the launch makes whole rounds of workgroups
+// where each model alone leaves its last round half empty (conv4_x at 16 images of 768x384: 2 x 1152 tiles = 9 rounds of 256
+// against 2 x 5; conv5_x: 3 against 2 x 2).  Results are bit-identical to two xv_conv2d_fwd calls.  XV_ESHAPE where the shape
+// does not take configuration 26 / 27 / 28 (the caller then launches the two convs separately).
+extern "C" int xv_conv2d_fwd_pair(const xv_act* xa, const void* wa_packed, const float* bias_a, const xv_act* ya,
+                                  const xv_act* pooled_a, const xv_act* xb, const void* wb_packed, const float* bias_b,
+                                  const xv_act* yb, const xv_act* pooled_b, int relu, void* stream) {
+  XV_CHECK_ARG(xa && xa->data && xb && xb->data && wa_packed && wb_packed && bias_a && bias_b && ya && yb);
+  const bool pool = pooled_a && pooled_a->data;
+  XV_CHECK_ARG(pool == (pooled_b && pooled_b->data) && (ya->data != nullptr) == (yb->data != nullptr) && (ya->data || pool));
+  XV_CHECK_SHAPE(xv_dims_sane(xa->n, xa->h, xa->w) && xa->c > 0 && (xa->c & 63) == 0 && ya->c > 0 && (ya->c & 63) == 0);
+  XV_CHECK_SHAPE(xb->n == xa->n && xb->h == xa->h && xb->w == xa->w && xb->c == xa->c);
+  XV_CHECK_SHAPE(ya->n == xa->n && ya->h == xa->h && ya->w == xa->w && yb->n == xa->n && yb->h == xa->h && yb->w == xa->w &&
+                 yb->c == ya->c);
+  XV_CHECK_ARG(xa->dtype == XV_BF16 && xb->dtype == XV_BF16 && ya->dtype == XV_BF16 && yb->dtype == XV_BF16);
+  XV_CHECK_ARG((((uintptr_t)xa->data | (uintptr_t)xb->data | (uintptr_t)wa_packed | (uintptr_t)wb_packed | (uintptr_t)bias_a |
+                 (uintptr_t)bias_b | (uintptr_t)ya->data | (uintptr_t)yb->data) & 15) == 0);
+  if (pool) {
+    XV_CHECK_SHAPE((xa->h & 1) == 0 && (xa->w & 1) == 0);
+    XV_CHECK_SHAPE(pooled_a->n == xa->n && pooled_a->h == xa->h / 2 && pooled_a->w == xa->w / 2 && pooled_a->c == ya->c &&
+                   pooled_b->n == xa->n && pooled_b->h == xa->h / 2 && pooled_b->w == xa->w / 2 && pooled_b->c == ya->c);
+    XV_CHECK_ARG(pooled_a->dtype == XV_BF16 && pooled_b->dtype == XV_BF16 &&
+                 (((uintptr_t)pooled_a->data | (uintptr_t)pooled_b->data) & 15) == 0);
+  }
+  ConvArgs a{};
+  a.x = (const __bf16*)xa->data, a.y = (__bf16*)ya->data, a.pooled = pool ? (__bf16*)pooled_a->data : nullptr;
+  a.N = xa->n, a.H = xa->h, a.W = xa->w, a.Cin = xa->c, a.Cout = ya->c;
+  a.relu = relu;
+  a.num_cus = xv_num_cus();
+  const int cfg = pick_cfg(a, 3);
+  const void* const x[2] = {xa->data, xb->data};
+  const void* const w[2] = {wa_packed, wb_packed};
+  const float* const b[2] = {bias_a, bias_b};
+  void* const y[2] = {ya->data, yb->data};
+  void* const q[2] = {pool ? pooled_a->data : nullptr, pool ? pooled_b->data : nullptr};
+  if (cfg == 26)
+    return xv_launch_conv3x3_dma4_pair(x, w, b, y, q, a.N, a.H, a.W, a.Cin, a.Cout, relu, a.num_cus, (hipStream_t)stream);
+  if (cfg == 27 || cfg == 28)
+    return xv_launch_conv3x3_col_pair(x, w, b, y, q, a.N, a.H, a.W, a.Cin, a.Cout, relu, cfg == 27 ? 3 : 4, a.num_cus,
+                                      (hipStream_t)stream);
+  return XV_ESHAPE;
 }
 
 extern "C" size_t xv_conv2d_streamk_workspace_bytes(void) { return streamk_workspace_bytes(); }

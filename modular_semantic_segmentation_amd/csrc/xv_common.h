@@ -60,10 +60,19 @@ static inline int xv_num_cus() {
 }
 
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) is per device and per kernel: `done` is the kernel's own flag array
-static inline hipError_t xv_allow_dynamic_lds(const void* kernel, int bytes, bool (&done)[XV_MAX_DEVICES]) {
+static inline hipError_t xv_allow_dynamic_lds(const void* kernel, int bytes, bool (&done)[XV_MAX_DEVICES],
+                                              bool from_offset_0 = true) {
   const int dev = xv_current_device();
   if (dev >= 0 && dev < XV_MAX_DEVICES && done[dev]) return hipSuccess;
-  const hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e == hipSuccess && from_offset_0) {
+    // The conv kernels behind this helper address their dynamic LDS from offset 0 (LDS-DMA destinations in M0, ds_read offsets in
+    // assembly).  A static LDS object in front of it -- the compiler promotes an alloca into LDS when a struct does not stay
+    // in registers: round 4, a bool member in the tile record -- would sit on top of the first operand buffer: refuse to launch.
+    hipFuncAttributes attr;
+    e = hipFuncGetAttributes(&attr, kernel);
+    if (e == hipSuccess && attr.sharedSizeBytes != 0) e = hipErrorInvalidConfiguration;
+  }
   if (e == hipSuccess && dev >= 0 && dev < XV_MAX_DEVICES) done[dev] = true;
   return e;
 }

@@ -102,6 +102,33 @@ def _fold_bn(variables, layer, kernel, bias):
 _FUSE_FIRST = os.environ.get('XV_FUSE_FIRST', '1') != '0'
 
 
+# The two experts of a fusion model run the same layer shapes from conv1_2 on.  From this layer on each 3x3 layer of both is
+# ONE launch (ops.conv2d_fwd_pair: whole rounds of workgroups where each expert alone leaves its last round half empty).
+# XV_GROUP_FROM=<layer name> moves the start, XV_GROUP_FROM=0 keeps every launch per expert (A/B timing).
+GROUP_FROM = os.environ.get('XV_GROUP_FROM', 'conv4_1')
+
+
+def group_from_index():
+    names = [e[0] for e in ENCODER]
+    return names.index(GROUP_FROM) if GROUP_FROM in names else None
+
+
+def encoder_layers_pair(ea, sa, eb, sb):
+    """The remaining encoder layers of two engines (states from encoder_begin(..., stop=group_from_index())), each layer as
+    one launch for both where the kernel takes the shape, else one launch per engine."""
+    assert sa['next'] == sb['next']
+    for idx in range(sa['next'], len(ENCODER)):
+        name = ENCODER[idx][0]
+        ya, qa = ea._layer_outputs(sa, idx)
+        yb, qb = eb._layer_outputs(sb, idx)
+        if not ops.conv2d_fwd_pair(sa['cur'], ea.w[name], ea.b[name], sb['cur'], eb.w[name], eb.b[name], relu=True,
+                                   ya=ya, yb=yb, pa=qa, pb=qb):
+            for e, st, y, q in ((ea, sa, ya, qa), (eb, sb, yb, qb)):
+                ops.conv2d_fwd(st['cur'], e.w[name], e.b[name], 3, relu=True, y=y, pooled=q, write_y=y is not None)
+        ea._layer_done(sa, idx, ya, qa)
+        eb._layer_done(sb, idx, yb, qb)
+
+
 class FcnEngine(object):
     """One FCN expert resident on one GPU (inference graph of simple_fcn.py:137-170)."""
 
@@ -293,51 +320,93 @@ class FcnEngine(object):
         """x: float32 [N,H,W,cin] device tensor (raw 0..255 RGB / raw depth, data contract of
         xview/datasets/*) -> dict of Acts; 'fused' is the encoding (simple_fcn.py:10-87).
         keep_all=True also materialises every convX_Y / poolX like the reference's layer dict."""
+        return self.encoder_finish(self.encoder_begin(x, keep_all=keep_all, stop=len(ENCODER)))
+
+    # The encoder in three steps, so that a fusion model can run the layers its two experts share as ONE launch each
+    # (encoder_layers_pair below): encoder_begin (input checks, the first conv(s), the layers before `stop`), the remaining
+    # layers (here or paired), encoder_finish (score convs, x2 upsampling + skip).
+    def encoder_begin(self, x, keep_all=False, stop=None):
         n, h, w, cin = x.shape
         if cin != self.cin:
             raise ValueError('expected %d input channels, got %d' % (self.cin, cin))
         if h % 16 or w % 16:
             raise ValueError('H and W must be multiples of 16 (augmentation.py:244-262 crop_multiple)')
+        st = {'n': n, 'h': h, 'w': w, 'keep_all': keep_all}
         if self.conv_dtype == 'fp8':
-            L, s4, s5 = self._encoder_fp8(x, keep_all)
+            st['L'], st['s4'], st['s5'] = self._encoder_fp8(x, keep_all)
+            st['next'] = len(ENCODER)
+            return st
+        L = {}
+        ch, cw = h, w
+        first = 1
+        # conv1_1 + conv1_2 + pool1 in one launch where neither full-resolution map is wanted (inference): conv1_1 is
+        # evaluated straight into conv1_2's LDS patch buffers (csrc/conv_first_fused.hip; the same bits as the two
+        # kernels).  Maps that do not tile in 16x32 -- and XV_FUSE_FIRST=0, A/B timing -- take the two kernels.
+        if not keep_all and _FUSE_FIRST and ENCODER[1][0] == 'conv1_2' and ENCODER[1][2] == 'pool1':
+            q = self._act('pool1', n, h // 2, w // 2, 64)
+            if ops.conv_first_pair_fwd(x.contiguous(), self.w['conv1_1'], self.b['conv1_1'], self.w['conv1_2'],
+                                       self.b['conv1_2'], pooled=q):
+                L['pool1'] = cur = q
+                ch, cw = h // 2, w // 2
+                first = 2
+        if first == 1:
+            cur = self._act('conv1_1', n, h, w, 64)
+            ops.conv2d_first_fwd(x.contiguous(), self.w['conv1_1'], self.b['conv1_1'], cur, relu=True)
+            L['conv1_1'] = cur
+        st.update(L=L, cur=cur, ch=ch, cw=cw, next=first)
+        self.encoder_layers(st, len(ENCODER) if stop is None else stop)
+        return st
+
+    def _drop_fn(self):
+        return self._dropout if self.dropout_layers and self.dropout_rate > 0 else None
+
+    def _layer_outputs(self, st, idx):
+        """(full map or None, pooled map or None) of encoder layer idx"""
+        name, cout, pool = ENCODER[idx]
+        n, ch, cw = st['n'], st['ch'], st['cw']
+        if pool is None:
+            return self._act(name, n, ch, cw, cout), None
+        need_full = st['keep_all'] or name == 'conv4_3'       # conv4_3 feeds score_conv4
+        return (self._act(name, n, ch, cw, cout) if need_full else None), self._act(pool, n, ch // 2, cw // 2, cout)
+
+    def _layer_done(self, st, idx, y, q):
+        name, cout, pool = ENCODER[idx]
+        L = st['L']
+        if pool is None:
+            L[name] = st['cur'] = y
         else:
-            L = {}
-            ch, cw = h, w
-            drop = self._dropout if self.dropout_layers and self.dropout_rate > 0 else None
-            first = 1
-            # conv1_1 + conv1_2 + pool1 in one launch where neither full-resolution map is wanted (inference): conv1_1 is
-            # evaluated straight into conv1_2's LDS patch buffers (csrc/conv_first_fused.hip; the same bits as the two
-            # kernels).  Maps that do not tile in 16x32 -- and XV_FUSE_FIRST=0, A/B timing -- take the two kernels.
-            if not keep_all and _FUSE_FIRST and ENCODER[1][0] == 'conv1_2' and ENCODER[1][2] == 'pool1':
-                q = self._act('pool1', n, h // 2, w // 2, 64)
-                if ops.conv_first_pair_fwd(x.contiguous(), self.w['conv1_1'], self.b['conv1_1'], self.w['conv1_2'],
-                                           self.b['conv1_2'], pooled=q):
-                    L['pool1'] = cur = q
-                    ch, cw = h // 2, w // 2
-                    first = 2
-            if first == 1:
-                cur = self._act('conv1_1', n, h, w, 64)
-                ops.conv2d_first_fwd(x.contiguous(), self.w['conv1_1'], self.b['conv1_1'], cur, relu=True)
-                L['conv1_1'] = cur
-            for name, cout, pool in ENCODER[first:]:
-                if pool is None:
-                    y = self._act(name, n, ch, cw, cout)
-                    ops.conv2d_fwd(cur, self.w[name], self.b[name], 3, relu=True, y=y, workspace=self._sk())
-                    L[name] = cur = y
-                else:
-                    q = self._act(pool, n, ch // 2, cw // 2, cout)
-                    need_full = keep_all or name == 'conv4_3'       # conv4_3 feeds score_conv4
-                    y = self._act(name, n, ch, cw, cout) if need_full else None
-                    ops.conv2d_fwd(cur, self.w[name], self.b[name], 3, relu=True, y=y, pooled=q, write_y=need_full,
-                                   workspace=self._sk())
-                    if y is not None:
-                        L[name] = y
-                    L[pool] = cur = q
-                    ch, cw = ch // 2, cw // 2
-                    # simple_fcn.py:51-63: the dropout after pool4 is gated by 'pool3' too (a quirk of the reference:
-                    # 'pool4' alone enables nothing)
-                    if drop is not None and pool in ('pool3', 'pool4') and 'pool3' in self.dropout_layers:
-                        L[pool + '_drop'] = cur = drop(q, pool + '_drop')
+            if y is not None:
+                L[name] = y
+            L[pool] = st['cur'] = q
+            st['ch'], st['cw'] = st['ch'] // 2, st['cw'] // 2
+            # simple_fcn.py:51-63: the dropout after pool4 is gated by 'pool3' too (a quirk of the reference:
+            # 'pool4' alone enables nothing)
+            drop = self._drop_fn()
+            if drop is not None and pool in ('pool3', 'pool4') and 'pool3' in self.dropout_layers:
+                L[pool + '_drop'] = st['cur'] = drop(q, pool + '_drop')
+        st['next'] = idx + 1
+
+    def encoder_layers(self, st, stop):
+        """encoder layers [st['next'], stop), one launch each"""
+        for idx in range(st['next'], stop):
+            name = ENCODER[idx][0]
+            y, q = self._layer_outputs(st, idx)
+            ops.conv2d_fwd(st['cur'], self.w[name], self.b[name], 3, relu=True, y=y, pooled=q, write_y=y is not None,
+                           workspace=self._sk())
+            self._layer_done(st, idx, y, q)
+
+    def pairable(self):
+        """May this engine's 3x3 layers share launches with a twin's (encoder_layers_pair)?"""
+        return self.conv_dtype == 'bf16' and self._drop_fn() is None and self._sk() is None
+
+    def encoder_finish(self, st):
+        n, h, w = st['n'], st['h'], st['w']
+        L = st['L']
+        if 's4' in st:
+            s4, s5 = st['s4'], st['s5']
+        else:
+            self.encoder_layers(st, len(ENCODER))
+            drop = self._drop_fn()
             s4 = self._act('score_conv4', n, h // 8, w // 8, self.Up)
             c43 = drop(L['conv4_3'], 'conv4_3_drop') if drop is not None and 'conv4_3' in self.dropout_layers else L['conv4_3']
             ops.conv2d_fwd(c43, self.w['score_conv4'], self.b['score_conv4'], 1, relu=True, y=s4)
@@ -376,10 +445,11 @@ class FcnEngine(object):
         shift between the x8 deconv and its relu, bilinear deconv kernel -- the precondition of `lowres_scores`."""
         return 'upscore' not in self.affine and 'upscore' not in self.dense_deconv
 
-    def lowres_scores(self, x):
+    def lowres_scores(self, x=None, st=None):
         """Trunk + the 1x1 score conv at 1/8 resolution: float32 [N][h/8+2][w/8+2][CP] (the first half of the decoder
-        head, xv_score_lowres); the fused two-expert head of the fusion models takes it from here."""
-        L = self.encoder(x)
+        head, xv_score_lowres); the fused two-expert head of the fusion models takes it from here.  st: an encoder state
+        (encoder_begin / encoder_layers_pair) to finish instead of an input."""
+        L = self.encoder_finish(st) if st is not None else self.encoder(x)
         f = L.get('features_drop', L['fused'])
         cp = (self.C + 3) // 4 * 4
         key = ('lowres_S', f.n, f.h, f.w)
@@ -389,10 +459,10 @@ class FcnEngine(object):
         ops.score_lowres(f, self.w['score'], self.C, S)
         return S, (f.n, f.h, f.w)
 
-    def forward(self, x, want=('label',), keep_all=False):
+    def forward(self, x, want=('label',), keep_all=False, st=None):
         """fcn + test_pipeline (basic_fusion_model.py:9-23): returns dict with any of
         'score', 'prob' (float32 [N,H,W,C]) and 'label' == 'classification' (int64 [N,H,W])."""
-        L = self.encoder(x, keep_all=keep_all)
+        L = self.encoder_finish(st) if st is not None else self.encoder(x, keep_all=keep_all)
         f = L.get('features_drop', L['fused'])           # the decoder's input (dropped only when 'features' is a dropout site)
         key = ('head_ws', f.n, f.h, f.w)
         ws = self._arena.get(key)

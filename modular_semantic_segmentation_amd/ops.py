@@ -157,6 +157,36 @@ def conv2d_fwd(x, w_packed, bias, k, relu=True, y=None, pooled=None, write_y=Tru
     return y, pooled
 
 
+def conv2d_fwd_pair(xa, wa, ba, xb, wb, bb, relu=True, ya=None, yb=None, pa=None, pb=None):
+    """The same 3x3 layer of two models in ONE launch (xv_conv2d_fwd_pair): per model the arguments of conv2d_fwd; the
+    outputs wanted (full maps ya / yb, pooled maps pa / pb) must be given and be the same set for both.  Returns False --
+    nothing launched -- where the shape does not run on the generation-4 / 5 kernels: the caller launches two conv2d_fwd."""
+    _need(ba, torch.float32, 'bias_a')
+    _need(bb, torch.float32, 'bias_b')
+    cout = ba.numel()
+    if xa.dtype != 'bf16' or xb.dtype != 'bf16' or (ya is None) != (yb is None) or (pa is None) != (pb is None) or \
+            (ya is None and pa is None):
+        return False
+
+    def desc(y, x, p):
+        return y._xv if y is not None else xv_act(None, x.n, x.h, x.w, cout, p._xv.dtype, p._xv.scale_exp)
+    da, db = desc(ya, xa, pa), desc(yb, xb, pb)
+    prof = CONV_PROFILE
+    if prof is not None:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+    rc = _lib.lib().xv_conv2d_fwd_pair(xa.xv(), _ptr(wa), _ptr(ba), ctypes.byref(da), pa.xv() if pa is not None else _NULL_ACT,
+                                       xb.xv(), _ptr(wb), _ptr(bb), ctypes.byref(db), pb.xv() if pb is not None else _NULL_ACT,
+                                       int(bool(relu)), _stream())
+    if rc == -2:
+        return False
+    _lib.check(rc, 'xv_conv2d_fwd_pair')
+    if prof is not None:
+        ev1.record()
+        prof.append(('k3', 2.0 * 2 * xa.n * xa.h * xa.w * xa.c * cout * 9, ev0, ev1))
+    return True
+
+
 def conv2d_first_fwd(x, w_hwio, bias, y, relu=True):
     _need(x, torch.float32, 'x')
     _need(w_hwio, torch.float32, 'w_hwio')

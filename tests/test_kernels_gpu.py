@@ -268,6 +268,59 @@ def test_conv2d_generation5_column_tiles(ops, shape, cfg):
         ops.conv2d_fwd(xs, wp, bd, 3, relu=True, cfg=cfg)          # 8 rows short of a tiling
 
 
+@pytest.mark.parametrize('shape,mode', [((3, 32, 64, 128, 128), 'both'), ((16, 48, 96, 256, 512), 'y'), ((2, 16, 32, 64, 64), 'pool'),
+                                        ((5, 32, 32, 192, 64), 'both'), ((16, 24, 48, 512, 512), 'y'), ((3, 48, 16, 128, 128), 'y'),
+                                        ((1, 16, 32, 128, 64), 'y'), ((37, 16, 32, 64, 128), 'pool')])
+def test_conv2d_pair_equals_two_launches(ops, shape, mode):
+    """xv_conv2d_fwd_pair (the same layer of the two experts in ONE launch of the generation-4 / 5 kernel: concatenated tile
+    lists, per-tile maps / weights / bias) against two xv_conv2d_fwd launches, bit for bit on random real-valued operands --
+    full maps, fused pools, pooled-only; fewer tiles than workgroups up to many rounds; the border of every map untouched."""
+    n, h, w, cin, cout = shape
+    g = torch.Generator(device='cuda').manual_seed(sum(shape))
+    outs = {}
+    X, Wp, B = [], [], []
+    for e in range(2):
+        X.append(ops.Act.from_dense(torch.randn(n, h, w, cin, device='cuda', generator=g)))
+        Wp.append(ops.pack_conv_weights(torch.randn(3, 3, cin, cout, device='cuda', generator=g) * (9 * cin) ** -0.5))
+        B.append(torch.randn(cout, device='cuda', generator=g))
+
+    def outputs():
+        y = [ops.Act(n, h, w, cout) for _ in range(2)] if mode != 'pool' else [None, None]
+        q = [ops.Act(n, h // 2, w // 2, cout) for _ in range(2)] if mode != 'y' else [None, None]
+        return y, q
+    y1, q1 = outputs()
+    for e in range(2):
+        ops.conv2d_fwd(X[e], Wp[e], B[e], 3, relu=True, y=y1[e], pooled=q1[e], write_y=y1[e] is not None)
+    y2, q2 = outputs()
+    assert ops.conv2d_fwd_pair(X[0], Wp[0], B[0], X[1], Wp[1], B[1], relu=True, ya=y2[0], yb=y2[1], pa=q2[0], pb=q2[1])
+    torch.cuda.synchronize()
+    for e in range(2):
+        for a, b in ((y1[e], y2[e]), (q1[e], q2[e])):
+            if a is not None:
+                assert torch.equal(a.t, b.t)
+                assert float(a.interior().float().abs().sum()) > 0
+    if mode == 'y':
+        assert not torch.equal(y2[0].t, y2[1].t)
+
+
+def test_conv2d_pair_refuses_what_the_kernels_do_not_take(ops):
+    """Maps that do not tile (generation 2 would run them), a pooled output on the 24x16 tile, mismatched twins: False,
+    nothing launched."""
+    def mk(n, h, w, cin, cout):
+        return (ops.Act.from_dense(torch.randn(n, h, w, cin, device='cuda')),
+                ops.pack_conv_weights(torch.randn(3, 3, cin, cout, device='cuda') * 0.05), torch.zeros(cout, device='cuda'))
+    xa, wa, ba = mk(2, 20, 24, 64, 64)
+    y = [ops.Act(2, 20, 24, 64) for _ in range(2)]
+    assert not ops.conv2d_fwd_pair(xa, wa, ba, xa, wa, ba, ya=y[0], yb=y[1])
+    assert float(y[0].t.float().abs().sum()) == 0
+    xa, wa, ba = mk(2, 24, 48, 64, 64)
+    q = [ops.Act(2, 12, 24, 64) for _ in range(2)]
+    assert not ops.conv2d_fwd_pair(xa, wa, ba, xa, wa, ba, pa=q[0], pb=q[1])
+    xb, wb, bb = mk(2, 32, 64, 64, 64)
+    xc, wc, bc = mk(3, 32, 64, 64, 64)
+    assert not ops.conv2d_fwd_pair(xb, wb, bb, xc, wc, bc, ya=ops.Act(2, 32, 64, 64), yb=ops.Act(3, 32, 64, 64))
+
+
 @pytest.mark.parametrize('shape', [(2, 24, 48, 512, 128), (1, 24, 16, 64, 64), (3, 30, 40, 128, 64), (2, 48, 20, 64, 192),
                                    (40, 24, 48, 128, 128), (1, 6, 10, 64, 64)])
 def test_conv2d_generation2_three_row_tile(ops, shape):

@@ -498,6 +498,56 @@ def test_fused_head_equals_unfused_path(gpu, tmp_path, golden_dir, kind):
     assert np.array_equal(plain.predict(data), ref)
 
 
+def test_paired_expert_launches_equal_per_expert_launches(gpu, tmp_path, golden_dir):
+    """From conv4_1 on the two experts of a fusion model share ONE launch per layer (fcn.encoder_layers_pair ->
+    xv_conv2d_fwd_pair: whole rounds of workgroups on the persistent conv kernels).  At 768x384 -- conv4 maps tile in 16x32,
+    conv5 maps in 24x16 -- the fused labels must equal, bit for bit, those of per-expert launches, from any starting layer,
+    with and without the fused head, on one stream and on two."""
+    from modular_semantic_segmentation_amd import fcn, get_model, ops
+    g = np.load(os.path.join(golden_dir, 'notebook_868.npz'))
+    rng = np.random.default_rng(8)
+    n, h, w = 2, 384, 768
+    data = {'rgb': rng.integers(0, 256, (n, h, w, 3)).astype(np.float32),
+            'depth': rng.integers(0, 65536, (n, h, w, 1)).astype(np.float32)}
+    _, pr = _weights(tmp_path, 'rgb', 3, 1, 0.02)
+    _, pd = _weights(tmp_path, 'depth', 1, 2, 2e-4)
+    net = get_model('bayes_fusion')(data_description=_desc(), confusion_matrices={'rgb': g['cm_rgb'], 'depth': g['cm_depth']},
+                                    num_units=U, prefixes={'rgb': 'rgb', 'depth': 'depth'}, num_channels={'rgb': 3, 'depth': 1},
+                                    expert_model='fcn', class_prior='data', batchsize=n)
+    net.import_weights(pr, warnings=False)
+    net.import_weights(pd, warnings=False)
+    calls = []
+    real = ops.conv2d_fwd_pair
+
+    def counting(*a, **kw):
+        ok = real(*a, **kw)
+        calls.append(ok)
+        return ok
+    saved = fcn.GROUP_FROM
+    ops.conv2d_fwd_pair = counting
+    try:
+        fcn.GROUP_FROM = '0'
+        ref = net.predict(data)
+        assert not calls
+        for start, launches in (('conv4_1', 6), ('conv2_1', 11)):
+            fcn.GROUP_FROM = start
+            del calls[:]
+            net._graph = None
+            assert np.array_equal(net.predict(data), ref), start
+            assert calls == [True] * launches, (start, calls)
+        fcn.GROUP_FROM = 'conv4_1'
+        net.concurrent_experts = False
+        assert np.array_equal(net.predict(data), ref)
+        net.concurrent_experts = True
+        net.config['fused_head'] = False
+        assert np.array_equal(net.predict(data), ref)
+        assert len(np.unique(ref)) > 1
+    finally:
+        fcn.GROUP_FROM = saved
+        ops.conv2d_fwd_pair = real
+    net.close()
+
+
 def test_config1_simple_fcn_rgb_256x512_14_classes(gpu, tmp_path):
     """BASELINE.json configs[0]: SimpleFCN RGB-only, Synthia 256x512 (tensor [1,256,512,3]), batch 1, 14 classes -- the
     reference's own CPU-runnable case: the oracle IS that CPU path restated; the HIP path must reproduce its label map

@@ -62,6 +62,13 @@ def child():
     expect(h.xv_conv2d_fwd_cfg(x, fake, fake, y, None, 3, 1, 27, None), ESHAPE, 'conv: cfg 27 on a map that does not tile')
     expect(h.xv_conv2d_fwd_cfg(act(fake, 2, 24, 40, 128, 1, 300), fake, fake, y, None, 3, 1, -1, None), ESHAPE, 'conv: fp8 exponent')
     expect(h.xv_conv2d_fwd_ws(x, fake, fake, y, None, 3, 1, -1, fake, 16, None), EWS, 'conv: workspace too small')
+    # the two-model launch: null twin, mismatched twins, a shape the generation-4 / 5 kernels do not take
+    expect(h.xv_conv2d_fwd_pair(x, fake, fake, y, None, None, fake, fake, y, None, 1, None), EINVAL, 'pair: null twin')
+    expect(h.xv_conv2d_fwd_pair(x, fake, fake, y, None, act(fake, 3, 24, 40, 128, 0, 0), fake, fake, y, None, 1, None), ESHAPE,
+           'pair: mismatched twins')
+    expect(h.xv_conv2d_fwd_pair(x, fake, fake, y, None, x, fake, fake, y, None, 1, None), ESHAPE, 'pair: 24x40 does not tile')
+    expect(h.xv_conv2d_fwd_pair(x, fake, fake, y, None, x, fake, fake, act(fake, 2, 24, 40, 256, 1, 0), None, 1, None), EINVAL,
+           'pair: fp8 twin')
     expect(h.xv_maxpool2x2_fwd(act(fake, 1, 16, 16, 64, 1, 0), act(fake, 1, 8, 8, 64, 1, 0), None), EINVAL, 'pool: fp8 descriptor')
 
     # (3) size calculators and the tile chooser
@@ -132,6 +139,10 @@ def child():
                         launched += 1
                 rc = h.xv_conv2d_bwd_data(ya, fake, fake, xa, xa, xa, 3, None)
                 assert rc != 0
+                for p in (None, pool):
+                    rc = h.xv_conv2d_fwd_pair(xa, fake, fake, ya, p, xa, fake, fake, ya, p, 1, None)
+                    assert rc != 0
+                    launched += 1
         checks += launched
         print('launch geometry: %d conv entry calls ran to the (failing) launch' % launched)
     print('asan/ubsan host check: %d checks, no sanitizer report' % checks)
