@@ -50,14 +50,21 @@ def calibrate_experts(model, data):
     return {m: model.experts[m].calibrate(model._to_device(batch[m], torch.float32)) for m in model.modalities}
 
 
-def paired_from(model):
+def paired_from(model, inputs):
     """Index of the first encoder layer the two experts run as ONE launch each (fcn.encoder_layers_pair), or None: two FCN
-    experts on the bf16 path without dropout sites or the stream-K option."""
+    experts on the bf16 path without dropout sites or the stream-K option -- and a batch whose conv4 maps give one expert
+    at least one round of workgroups (16x32-pixel x 64-channel tiles against the CU count).  Below that the launches are
+    latency: both experts' kernels fit the chip side by side on their two streams, and the joins of a paired section only
+    cost (one image: 0.46 -> 0.49 ms per step with it)."""
     from .fcn import group_from_index
     gi = group_from_index()
     if gi is None or len(model.modalities) != 2 or not model.config.get('paired_launches', True):
         return None
     if not all(type(e) is FcnEngine and e.pairable() for e in model.experts.values()):
+        return None
+    n, h, w = next(iter(inputs.values())).shape[:3]
+    tiles = n * ((h // 8 + 15) // 16) * ((w // 8 + 31) // 32) * 8
+    if tiles < torch.cuda.get_device_properties(model.device).multi_processor_count:
         return None
     return gi
 
@@ -89,7 +96,7 @@ def run_trunks(model, inputs, finish):
                 main.wait_stream(model._expert_streams[m])
         return out
 
-    gi = paired_from(model)
+    gi = paired_from(model, inputs)
     if gi is None:
         return each(lambda m: finish(m, None))
     st = each(lambda m: model.experts[m].encoder_begin(inputs[m], stop=gi))

@@ -506,7 +506,7 @@ def test_paired_expert_launches_equal_per_expert_launches(gpu, tmp_path, golden_
     from modular_semantic_segmentation_amd import fcn, get_model, ops
     g = np.load(os.path.join(golden_dir, 'notebook_868.npz'))
     rng = np.random.default_rng(8)
-    n, h, w = 2, 384, 768
+    n, h, w = 4, 384, 768          # 4 x 3 x 3 x 8 conv4 tiles per expert: more than one round of the 256 CUs
     data = {'rgb': rng.integers(0, 256, (n, h, w, 3)).astype(np.float32),
             'depth': rng.integers(0, 65536, (n, h, w, 1)).astype(np.float32)}
     _, pr = _weights(tmp_path, 'rgb', 3, 1, 0.02)
@@ -542,6 +542,11 @@ def test_paired_expert_launches_equal_per_expert_launches(gpu, tmp_path, golden_
         net.config['fused_head'] = False
         assert np.array_equal(net.predict(data), ref)
         assert len(np.unique(ref)) > 1
+        # one image: fewer tiles than CUs, the experts' kernels run side by side on their streams -- no paired section
+        del calls[:]
+        net._graph = None
+        one = {k: v[:1] for k, v in data.items()}
+        assert np.array_equal(net.predict(one), ref[:1]) and not calls
     finally:
         fcn.GROUP_FROM = saved
         ops.conv2d_fwd_pair = real
