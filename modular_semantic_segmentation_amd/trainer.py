@@ -10,11 +10,17 @@ gradient buffer splits into contiguous buckets that become ready one after the o
 backward pass; each bucket is all-reduced (RCCL over xGMI) on a side HIP stream while the remaining
 layers are still differentiating.
 """
+import contextlib
+import os
+
 import numpy as np
 import torch
 
 from . import ops
 from .fcn import ENCODER
+
+# filter gradients on a second HIP stream (encoder_backward); XV_WGRAD_STREAM=0: everything on one stream (A/B timing)
+_WGRAD_STREAM = os.environ.get('XV_WGRAD_STREAM', '1') != '0'
 
 # backward order of the trainable layers
 LAYER_ORDER = ['score', 'score_conv5', 'score_conv4'] + [name for name, _, _ in reversed(ENCODER)]
@@ -23,27 +29,45 @@ BUCKETS = [['score', 'score_conv5', 'score_conv4', 'conv5_3', 'conv5_2', 'conv5_
            ['conv3_3', 'conv3_2', 'conv3_1', 'conv2_2', 'conv2_1', 'conv1_2', 'conv1_1']]
 
 
-def encoder_backward(x, L, g, ds4, wd_s4, wd, zero_bias, G, gact, wws, after_layer=None):
+def encoder_backward(x, L, g, ds4, wd_s4, wd, zero_bias, G, gact, wws, after_layer=None, wstream=None):
     """Backward walk over the 13 trunk convs (relu + fused pools) of one modality.
     x: raw network input; L: forward layer dict (every convX_Y and poolX); g: gradient w.r.t. conv5_3's output, already
     masked by its relu; ds4 / wd_s4: gradient of the 1x1 score conv on conv4_3 and its packed data-gradient weights
     (the second path into conv4_3, AddN); wd[name]: packed data-gradient weights; G(name, kind): gradient views;
-    gact(like, tag): scratch activations; after_layer(name): called once a layer's filter gradient is complete."""
+    gact(like, tag): scratch activations; after_layer(name): called once a layer's filter gradient is complete.
+    wstream: a second HIP stream for the filter gradients.  Nothing in the walk reads them (the optimizer does, after the
+    join at the end), every layer's gradient map and activation has a buffer of its own, and the one slab workspace is
+    used by this stream alone -- so a layer's filter gradient runs beside the next layers' data gradients, and its
+    workgroups fill the half-empty last rounds of the persistent data-gradient grids (conv4_x: 4.5 rounds, conv5_x: 1.5)."""
     names = [nm for nm, _, _ in ENCODER]
     pool_after = {nm: pl for nm, _, pl in ENCODER}
     inputs, prev = {}, None
     for nm in names:
         inputs[nm] = prev
         prev = pool_after[nm] if pool_after[nm] else nm
-    for nm in reversed(names):
-        xin = inputs[nm]
+    main = torch.cuda.current_stream(x.device) if wstream is not None else None
+
+    def filter_gradient(nm, xin, g):
         if nm == 'conv1_1':
             ops.conv2d_first_bwd_filter(x, g, G(nm, 'kernel'), G(nm, 'bias'), workspace=wws)
         else:
             ops.conv2d_bwd_filter(L[xin], g, G(nm, 'kernel'), G(nm, 'bias'), 3, workspace=wws)
         if after_layer is not None:
             after_layer(nm)
+
+    for nm in reversed(names):
+        xin = inputs[nm]
+        if wstream is None:
+            filter_gradient(nm, xin, g)
+        else:
+            ready = torch.cuda.Event()
+            ready.record(main)                   # g (and, the first time, the zeroed gradient buffer) is complete
+            with torch.cuda.stream(wstream):
+                wstream.wait_event(ready)
+                filter_gradient(nm, xin, g)
         if nm == 'conv1_1':
+            if wstream is not None:
+                main.wait_stream(wstream)
             break
         if xin.startswith('pool'):
             # gradient w.r.t. the pooled map, then MaxPoolGrad + ReluGrad onto the conv above
@@ -235,7 +259,10 @@ class FcnTrainer(object):
                 reducer.launch(self.grad, self.bucket_ranges[state['done']])
                 state['done'] += 1
 
-        encoder_backward(x, L, g, ds4, self.wd['score_conv4'], self.wd, self.zero_bias, G, self._gact, wws, after_layer)
+        if _WGRAD_STREAM and x.is_cuda and getattr(self, '_wstream', None) is None:
+            self._wstream = torch.cuda.Stream(device=x.device)
+        encoder_backward(x, L, g, ds4, self.wd['score_conv4'], self.wd, self.zero_bias, G, self._gact, wws, after_layer,
+                         wstream=self._wstream if _WGRAD_STREAM and x.is_cuda else None)
         scale = 1.0
         if reducer is not None:
             reducer.wait()
@@ -550,6 +577,11 @@ class FcnBnTrainer(object):
         g = ops.conv2d_bwd_data(dz_s5, self.wd['score_conv5'], self.zero_bias, self._act('g_conv5_3', n, h8 // 2, w8 // 2, 512), 1)
         names = [nm for nm, _, _ in ENCODER]
         pool_after = {nm: pl for nm, _, pl in ENCODER}
+        wstream = None
+        if _WGRAD_STREAM and x.is_cuda:
+            if getattr(self, '_wstream', None) is None:
+                self._wstream = torch.cuda.Stream(device=x.device)
+            wstream, main = self._wstream, torch.cuda.current_stream(x.device)
         g_is_pooled = False     # g is the gradient of the layer's POOLED output (routed inside the batch-norm passes)
         for nm in reversed(names):
             y = Z[nm]       # (shape only; the relu mask comes from z)
@@ -560,11 +592,22 @@ class FcnBnTrainer(object):
             else:
                 dz = self._bn_bwd(nm, g, Y[nm], Z[nm], self._act('dz_' + nm, y.n, y.h, y.w, y.c))
             g_is_pooled = False
+            # the filter gradients on a second stream, as encoder_backward does (dz_<layer> and the layer inputs are buffers
+            # of their own, nothing below reads the filter gradients, the slab workspace is this stream's from here on)
+            if wstream is not None:
+                ready = torch.cuda.Event()
+                ready.record(main)
             if nm == 'conv1_1':
-                ops.conv2d_first_bwd_filter(x, dz, G(nm, 'kernel'), G(nm, 'bias'), workspace=wws)
+                with (torch.cuda.stream(wstream) if wstream is not None else contextlib.nullcontext()):
+                    if wstream is not None:
+                        wstream.wait_event(ready)
+                    ops.conv2d_first_bwd_filter(x, dz, G(nm, 'kernel'), G(nm, 'bias'), workspace=wws)
                 break
             xin = inputs[nm]
-            ops.conv2d_bwd_filter(xin, dz, G(nm, 'kernel'), G(nm, 'bias'), 3, workspace=wws)
+            with (torch.cuda.stream(wstream) if wstream is not None else contextlib.nullcontext()):
+                if wstream is not None:
+                    wstream.wait_event(ready)
+                ops.conv2d_bwd_filter(xin, dz, G(nm, 'kernel'), G(nm, 'bias'), 3, workspace=wws)
             dx = ops.conv2d_bwd_data(dz, self.wd[nm], self.zero_bias, self._act('dx_' + nm, xin.n, xin.h, xin.w, xin.c), 3)
             above = names[names.index(nm) - 1]
             if pool_after[above] and above == 'conv4_3':
@@ -576,6 +619,8 @@ class FcnBnTrainer(object):
                 g, g_is_pooled = dx, True   # MaxPoolGrad + ReluGrad happen inside the batch-norm gradient (ops.bn_pool_backward)
             else:
                 g = dx
+        if wstream is not None:
+            main.wait_stream(wstream)
         if reducer is not None:
             reducer.launch(self.grad, (0, self.total))
             reducer.wait()
@@ -840,7 +885,10 @@ class FusionFcnTrainer(object):
             wd = {name: self.wd[(m, name)] for name, _, _ in ENCODER[1:]}
             Gm = lambda name, kind, m=m: self.view(self.grad, (m, name), kind)              # noqa: E731
             gact = lambda like, tag, m=m: self._gact(like, '%s_%s' % (tag, m))              # noqa: E731
-            encoder_backward(inputs[m], Lm, g, ds4, self.wd[(m, 'fused_score_conv4')], wd, self.zero_bias, Gm, gact, wws)
+            if _WGRAD_STREAM and inputs[m].is_cuda and getattr(self, '_wstream', None) is None:
+                self._wstream = torch.cuda.Stream(device=inputs[m].device)
+            encoder_backward(inputs[m], Lm, g, ds4, self.wd[(m, 'fused_score_conv4')], wd, self.zero_bias, Gm, gact, wws,
+                             wstream=self._wstream if _WGRAD_STREAM and inputs[m].is_cuda else None)
             if reducer is not None:
                 reducer.launch(self.grad, self.bucket_ranges[1 + i])
         if reducer is not None:
