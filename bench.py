@@ -423,13 +423,20 @@ def measure_training(args, device, world, rank, dist, batch, steps, warmup, expe
         rec['allreduce_ms_exposed'] = round((dt - dt_local) / steps * 1e3, 3)
         rec['gradient_bytes_per_step'] = int(net.trainer.grad.numel() * 4)
     # roofline of the MFMA convs of the step (rank 0's kernels; collectives run on their own stream)
+    # (the filter gradients go back onto the compute stream for this pass: a launch timed while another stream's kernel
+    # shares the chip would be charged that kernel's time as well -- as the inference pass serialises the two experts)
+    from modular_semantic_segmentation_amd import trainer as trainer_mod
     prof = []
+    side, trainer_mod._WGRAD_STREAM = trainer_mod._WGRAD_STREAM, False
     ops.CONV_PROFILE = prof
     torch.cuda.synchronize(device)
-    for _ in range(min(steps, 5)):
-        net._train_batch(data)
-    torch.cuda.synchronize(device)
-    ops.CONV_PROFILE = None
+    try:
+        for _ in range(min(steps, 5)):
+            net._train_batch(data)
+        torch.cuda.synchronize(device)
+    finally:
+        ops.CONV_PROFILE = None
+        trainer_mod._WGRAD_STREAM = side
     fl = sum(p[1] for p in prof)
     sec = sum(p[2].elapsed_time(p[3]) for p in prof) * 1e-3
     if getattr(args, 'layer_profile', False) and rank == 0 and prof:
@@ -450,7 +457,8 @@ def measure_training(args, device, world, rank, dist, batch, steps, warmup, expe
                            'peak': PEAK_TFLOPS['bf16'], 'unit': 'TFLOP/s', 'frac': round(fl / sec / 1e12 / PEAK_TFLOPS['bf16'], 4),
                            'traffic': None, 'launches': len(prof),
                            'by_pass_tflops': {k: round(v[0] / v[1] / 1e12, 1) for k, v in by.items() if v[1] > 0},
-                           'measured': 'HIP events per launch on the compute stream'}
+                           'measured': 'HIP events per launch, every kernel on ONE stream (the step itself runs the filter '
+                                       'gradients on a second stream)'}
     flops = 3.0 * conv_flops_per_image(h, w, 3) + (3.0 * conv_flops_per_image(h, w, 1) if joint else 0.0)
     if expert == 'adapnet':
         flops = 3.0 * adapnet_flops_per_image(h, w, 3)
