@@ -624,18 +624,30 @@ __global__ __launch_bounds__(256) void decoder_head_kernel(const float* __restri
 // probability maps, 2 x 4C B per pixel each way).  The fusion arithmetic is the one of fusion.hip's kernels, term for
 // term, on the values the unfused path would have stored.  Tables in LDS: tab [2][C][CM], lognorm [2][CM] (Dirichlet),
 // logprior [CM].
-template <int CM, int DIRICHLET, int P = (DIRICHLET ? 1 : 4)>
+// FULL: the class count IS CM (the 12 classes of the headline model): every `k < C` folds away -- 165 of the Dirichlet
+// form's ~800 vector instructions per pixel were compare-selects on the run-time class count.
+template <int CM, int DIRICHLET, bool FULL = false, int P = (DIRICHLET ? 1 : 4)>
 __global__ __launch_bounds__(256) void fused_head_kernel(const float* __restrict__ Sa, const float* __restrict__ Sb,
                                                         const float* __restrict__ ba, const float* __restrict__ bb, int N,
-                                                        int Hi, int Wi, int C, const float* __restrict__ tab_g,
+                                                        int Hi, int Wi, int C_, const float* __restrict__ tab_g,
                                                         const float* __restrict__ lognorm_g,
                                                         const float* __restrict__ logprior_g, int64_t* __restrict__ fused) {
+  const int C = FULL ? CM : C_;
   extern __shared__ __attribute__((aligned(16))) float tab[];
-  float* ln = tab + 2 * C * CM;
+  float* ln = tab + (DIRICHLET ? 2 * CM * CM : 2 * C * CM);
   float* lp = ln + 2 * CM;
-  for (int i = threadIdx.x; i < 2 * C * CM; i += 256) {
-    const int k = i % CM, row = i / CM;
-    tab[i] = k < C ? tab_g[row * C + k] : 0.f;
+  if constexpr (DIRICHLET) {
+    // transposed: tab[(e CM + k) CM + c] = alpha_e[c][k] - 1, so that the twelve dot products of a pixel advance together,
+    // two classes per v_pk_fma_f32 (below)
+    for (int i = threadIdx.x; i < 2 * CM * CM; i += 256) {
+      const int c = i % CM, k = (i / CM) % CM, e = i / (CM * CM);
+      tab[i] = (c < C && k < C) ? tab_g[(e * C + c) * C + k] : 0.f;
+    }
+  } else {
+    for (int i = threadIdx.x; i < 2 * C * CM; i += 256) {
+      const int k = i % CM, row = i / CM;
+      tab[i] = k < C ? tab_g[row * C + k] : 0.f;
+    }
   }
   for (int i = threadIdx.x; i < 2 * CM; i += 256) {
     const int k = i % CM, e = i / CM;
@@ -694,19 +706,24 @@ __global__ __launch_bounds__(256) void fused_head_kernel(const float* __restrict
 #pragma unroll
           for (int k = 0; k < CM; ++k) sc[k] = k < C ? xv_fast_log(1e-20f + sc[k] * rs) : 0.f;  // renormalise, then log(1e-20 + p)
         }
-        // (unrolled over the class: a run-time class index made every write to `total` twelve compare-selects)
+        // The C dot products sum_k (alpha[c][k] - 1) log p[k], each the fmaf chain over k of dirichlet_fuse_kernel (bit for
+        // bit), advanced TWO CLASSES PER INSTRUCTION: v_pk_fma_f32 on the transposed table halves the 2 C^2 = 288 FMAs that
+        // made this kernel VALU-bound (padded classes / terms are exact zeros: fma(0, 0, d) = d).
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        f32x2 dot2[CM / 2];
+#pragma unroll
+        for (int cp = 0; cp < CM / 2; ++cp) dot2[cp] = f32x2{0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < CM; ++k) {
+          const f32x2* rowk = reinterpret_cast<const f32x2*>(tab + (e * CM + k) * CM);
+          const f32x2 lk = f32x2{sc[k], sc[k]};
+#pragma unroll
+          for (int cp = 0; cp < CM / 2; ++cp) dot2[cp] = __builtin_elementwise_fma(rowk[cp], lk, dot2[cp]);
+        }
 #pragma unroll
         for (int c = 0; c < CM; ++c) {
-          if (c < C) {
-            const float* row = tab + (e * C + c) * CM;
-            float dot = 0.f;
-#pragma unroll
-            for (int k = 0; k < CM; ++k) dot = fmaf(row[k], sc[k], dot);  // as dirichlet_fuse_kernel, bit for bit
-            const float L = dot - ln[e * CM + c];
-            total[p][c] = e == 0 ? L : total[p][c] + L;
-          } else {
-            total[p][c] = 0.f;
-          }
+          const float L = dot2[c >> 1][c & 1] - ln[e * CM + c];
+          total[p][c] = c < C ? (e == 0 ? L : total[p][c] + L) : 0.f;
         }
       }
     }
@@ -1178,10 +1195,16 @@ extern "C" int xv_fused_head_fwd(const float* Sa, const float* Sb, const float* 
   hipStream_t s = (hipStream_t)stream;
 #define XV_FH(CMV)                                                                                                      \
   {                                                                                                                     \
-    const size_t lds = (size_t)(2 * num_classes * CMV + 3 * CMV) * 4;                                                   \
-    if (mode == 0)                                                                                                      \
+    const size_t lds = (size_t)(2 * (mode == 0 ? num_classes : CMV) * CMV + 3 * CMV) * 4;                               \
+    if (mode == 0 && num_classes == CMV)                                                                                \
+      hipLaunchKernelGGL((fused_head_kernel<CMV, 0, true>), dim3(grid), dim3(256), lds, s, Sa, Sb, bias_a, bias_b, n, hi, \
+                         wi, num_classes, tab, lognorm, logprior, fused_label);                                         \
+    else if (mode == 0)                                                                                                 \
       hipLaunchKernelGGL((fused_head_kernel<CMV, 0>), dim3(grid), dim3(256), lds, s, Sa, Sb, bias_a, bias_b, n, hi, wi,  \
                          num_classes, tab, lognorm, logprior, fused_label);                                             \
+    else if (num_classes == CMV)                                                                                        \
+      hipLaunchKernelGGL((fused_head_kernel<CMV, 1, true>), dim3(grid), dim3(256), lds, s, Sa, Sb, bias_a, bias_b, n, hi, \
+                         wi, num_classes, tab, lognorm, logprior, fused_label);                                         \
     else                                                                                                                \
       hipLaunchKernelGGL((fused_head_kernel<CMV, 1>), dim3(grid), dim3(256), lds, s, Sa, Sb, bias_a, bias_b, n, hi, wi,  \
                          num_classes, tab, lognorm, logprior, fused_label);                                             \
