@@ -171,12 +171,15 @@ __global__ __launch_bounds__(256) void count_valid_kernel(const int32_t* __restr
 //   1/8-resolution rows ib-1, ib, ib+1 -- the thread keeps those three row-weighted sums (P[n][ib][slot][ox][CM], slot =
 //   target row - (ib - 1)) and kernel 2 finishes along x.  (Round 1 wrote the dense fp32 gradient, 226 MB at 16 images,
 //   and kernel 2 gathered each 1/8-resolution pixel's 16 x 16 footprint from it: 390 us for the pair.)
-template <int CM>
+// FULL: the class count is CM (every `k < C` folds away).  exp / log / reciprocal are the hardware's (xv_common.h, as in the
+// inference heads: relative error ~1e-7, far inside what a bf16 training step resolves).
+template <int CM, bool FULL = false>
 __global__ __launch_bounds__(256) void head_loss_kernel(const float* __restrict__ S, const float* __restrict__ bs_g,
                                                        const int32_t* __restrict__ labels,
                                                        const unsigned long long* __restrict__ count, int N, int Hi,
-                                                       int Wi, int C, double* __restrict__ loss, float* __restrict__ dbs,
+                                                       int Wi, int C_, double* __restrict__ loss, float* __restrict__ dbs,
                                                        float* __restrict__ P, float* __restrict__ part_out) {
+  const int C = FULL ? CM : C_;
   __shared__ float red[4][CM + 1];
   const int Ho = Hi * 8, Wo = Wi * 8;
   const int64_t ncols = (int64_t)N * Hi * Wo;
@@ -229,16 +232,16 @@ __global__ __launch_bounds__(256) void head_loss_kernel(const float* __restrict_
 #pragma unroll
       for (int k = 0; k < CM; ++k) {
         if (k == lab) zlab = sc[k] - m;
-        sc[k] = k < C ? expf(sc[k] - m) : 0.f;
+        sc[k] = k < C ? xv_fast_exp(sc[k] - m) : 0.f;
         sum += sc[k];
       }
-      const float rsum = 1.f / sum;  // one division per pixel (the gradient does not need the forward's exact quotients)
+      const float rsum = xv_fast_rcp(sum);  // one reciprocal per pixel (the gradient does not need the forward's exact quotients)
 #pragma unroll
       for (int k = 0; k < CM; ++k) {
         const float p = sc[k] * rsum;
         sc[k] = (valid && k < C) ? (p - (k == lab ? 1.f : 0.f)) * inv_denom : 0.f;
       }
-      lossterm += valid ? -(zlab - logf(sum)) * inv_denom : 0.f;  // -(log_softmax)[label] / denom
+      lossterm += valid ? -(zlab - xv_fast_log(sum)) * inv_denom : 0.f;  // -(log_softmax)[label] / denom
       // this row feeds 1/8-resolution rows iy1 - 1 (weight wy0) and iy1 (weight wy1): slots r < 4 ? (0, 1) : (1, 2)
 #pragma unroll
       for (int k = 0; k < CM; ++k) {
@@ -771,8 +774,12 @@ extern "C" int xv_decoder_head_bwd(const xv_act* fused, const float* w_score, co
   const unsigned long long* cnt = reinterpret_cast<const unsigned long long*>(valid_count);
 #define XV_HB(CMV)                                                                                                   \
   {                                                                                                                  \
-    hipLaunchKernelGGL(head_loss_kernel<CMV>, dim3(g1), dim3(256), 0, s, (const float*)S, b_score, labels, cnt,       \
-                       fused->n, fused->h, fused->w, num_classes, loss, db_score, dscore, loss_part);                 \
+    if (num_classes == CMV)                                                                                          \
+      hipLaunchKernelGGL((head_loss_kernel<CMV, true>), dim3(g1), dim3(256), 0, s, (const float*)S, b_score, labels,   \
+                         cnt, fused->n, fused->h, fused->w, num_classes, loss, db_score, dscore, loss_part);          \
+    else                                                                                                             \
+      hipLaunchKernelGGL(head_loss_kernel<CMV>, dim3(g1), dim3(256), 0, s, (const float*)S, b_score, labels, cnt,     \
+                         fused->n, fused->h, fused->w, num_classes, loss, db_score, dscore, loss_part);               \
     hipLaunchKernelGGL(partials_reduce_kernel<256>, dim3(CMV + 1), dim3(256), 0, s, (const float*)loss_part,          \
                        (int)g1, CMV + 1,                                                                              \
                        db_score, num_classes, loss, CMV);                                                             \

@@ -2,6 +2,13 @@
 // All HBM-bound: one thread per pixel, class vectors in registers, tables in LDS.
 #include "xv_common.h"
 
+// Floating-point contraction by the SOURCE only (a * b + c inside one expression), never across statements: the fused
+// two-expert head and the unfused path (decoder head -> probability maps -> fusion kernel) must produce the same bits, and
+// under the default -ffp-contract=fast the optimizer fuses a product into a later sum wherever the two happen to meet --
+// round 4: specialising the fused head on the class count removed a select between `p = e * rsum` and `sum += p`, the
+// compiler made it an fma there and not in the kernel that reads p back from memory, and one pixel in a million flipped.
+#pragma clang fp contract(on)
+
 namespace {
 
 constexpr int MAXE = 4;

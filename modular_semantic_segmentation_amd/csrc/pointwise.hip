@@ -4,6 +4,13 @@
 
 #include "xv_common.h"
 
+// Floating-point contraction by the SOURCE only (a * b + c inside one expression), never across statements: the fused
+// two-expert head and the unfused path (decoder head -> probability maps -> fusion kernel) must produce the same bits, and
+// under the default -ffp-contract=fast the optimizer fuses a product into a later sum wherever the two happen to meet --
+// round 4: specialising the fused head on the class count removed a select between `p = e * rsum` and `sum += p`, the
+// compiler made it an fma there and not in the kernel that reads p back from memory, and one pixel in a million flipped.
+#pragma clang fp contract(on)
+
 namespace {
 
 // ---- conv1_1: relu(conv3x3(x) + b) on the raw fp32 input, fp32 math, bf16 padded-NHWC out -------
