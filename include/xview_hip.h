@@ -437,6 +437,15 @@ int xv_bn_stats(const xv_act* z, double* sums, void* stream);
 int xv_bn_finalize(const double* sums, int channels, int64_t count, const float* gamma, const float* beta, float eps,
                    float momentum, float* moving_mean, float* moving_var, float* mean, float* invstd, float* scale,
                    float* shift, void* stream);
+/* xv_bn_sums_from_rows + xv_bn_finalize, and xv_bn_stats_ws + xv_bn_finalize, with the row sums and the per-channel results
+ * in ONE launch (one workgroup per channel; `sums` is left as the two-call form leaves it, bit for bit).  Single-process
+ * statistics only: a data-parallel run all-reduces `sums` between the two calls and keeps them.                        */
+int xv_bn_finalize_from_rows(const float* rows, int nrows, int channels, int64_t count, const float* gamma, const float* beta,
+                             float eps, float momentum, float* moving_mean, float* moving_var, float* mean, float* invstd,
+                             float* scale, float* shift, double* sums, void* stream);
+int xv_bn_stats_finalize_ws(const xv_act* z, double* sums, void* workspace, size_t workspace_bytes, const float* gamma,
+                            const float* beta, float eps, float momentum, float* moving_mean, float* moving_var, float* mean,
+                            float* invstd, float* scale, float* shift, void* stream);
 int xv_bn_apply(const xv_act* z, const float* scale, const float* shift, int relu, const xv_act* y, void* stream);
 /* dz = gamma*invstd*(g - mean(g) - zhat*mean(g*zhat)), g = dy*(y>0); dgamma += sum g*zhat, dbeta += sum g.      */
 int xv_bn_bwd(const xv_act* dy, const xv_act* y, const xv_act* z, const float* mean, const float* invstd,

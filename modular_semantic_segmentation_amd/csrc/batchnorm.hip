@@ -187,8 +187,12 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const __bf16* __restrict
 
 // sums[i] = sum over the workgroups' partial rows, in a fixed tree (one workgroup per element: lane l adds rows l, l + 256,
 // ... in order, a butterfly inside each wave, the four waves in wave order): overwrites `sums` (no memset needed)
+// dgamma / dbeta (backward reductions, len = 2 C: sums[c] = sum dy, sums[C + c] = sum dy xhat): the gradient accumulation of
+// bn_grads_kernel in the same launch -- dbeta[c] += sums[c], dgamma[c] += sums[C + c] (18 five-microsecond launches per
+// training step with batch norm)
 __global__ __launch_bounds__(256) void bn_sums_kernel(const float* __restrict__ part, int nblocks, int len,
-                                                     double* __restrict__ sums) {
+                                                     double* __restrict__ sums, float* __restrict__ dgamma = nullptr,
+                                                     float* __restrict__ dbeta = nullptr) {
   __shared__ double wsum[4];
   const int i = blockIdx.x;
   double a = 0.0;
@@ -197,7 +201,17 @@ __global__ __launch_bounds__(256) void bn_sums_kernel(const float* __restrict__ 
   for (int off = 32; off >= 1; off >>= 1) a += __shfl_xor(a, off, 64);
   if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = a;
   __syncthreads();
-  if (threadIdx.x == 0) sums[i] = ((wsum[0] + wsum[1]) + wsum[2]) + wsum[3];
+  if (threadIdx.x == 0) {
+    const double t = ((wsum[0] + wsum[1]) + wsum[2]) + wsum[3];
+    sums[i] = t;
+    if (dgamma != nullptr) {
+      const int C = len >> 1;
+      if (i < C)
+        dbeta[i] += (float)t;
+      else
+        dgamma[i - C] += (float)t;
+    }
+  }
 }
 
 // mean / biased variance -> invstd, scale = gamma * invstd, shift = beta - mean * scale; moving statistics
@@ -210,6 +224,49 @@ __global__ void bn_finalize_kernel(const double* __restrict__ sums, int C, doubl
   if (c >= C) return;
   const double mu = sums[c] / M;
   double var = sums[C + c] / M - mu * mu;
+  var = var > 0.0 ? var : 0.0;
+  const float is = (float)(1.0 / sqrt(var + (double)eps));
+  mean[c] = (float)mu;
+  invstd[c] = is;
+  scale[c] = gamma[c] * is;
+  shift[c] = beta[c] - (float)mu * gamma[c] * is;
+  if (moving_mean) {
+    const double unbiased = M > 1.0 ? var * M / (M - 1.0) : var;
+    moving_mean[c] = moving_mean[c] * momentum + (float)mu * (1.f - momentum);
+    moving_var[c] = moving_var[c] * momentum + (float)unbiased * (1.f - momentum);
+  }
+}
+
+// bn_sums_kernel for the two columns of one channel (the same tree per column: the same bits in `sums`) + bn_finalize_kernel
+// for that channel, in ONE launch: one workgroup per channel (18 five-microsecond launches per training step with batch norm)
+__global__ __launch_bounds__(256) void bn_sums_finalize_kernel(const float* __restrict__ part, int nblocks, int C,
+                                                              double* __restrict__ sums, double M,
+                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                              float eps, float momentum, float* __restrict__ moving_mean,
+                                                              float* __restrict__ moving_var, float* __restrict__ mean,
+                                                              float* __restrict__ invstd, float* __restrict__ scale,
+                                                              float* __restrict__ shift) {
+  __shared__ double wsum[2][4];
+  const int c = blockIdx.x;
+  double a0 = 0.0, a1 = 0.0;
+  for (int b = threadIdx.x; b < nblocks; b += 256) {
+    a0 += (double)part[(int64_t)b * 2 * C + c];
+    a1 += (double)part[(int64_t)b * 2 * C + C + c];
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    a0 += __shfl_xor(a0, off, 64);
+    a1 += __shfl_xor(a1, off, 64);
+  }
+  if ((threadIdx.x & 63) == 0) wsum[0][threadIdx.x >> 6] = a0, wsum[1][threadIdx.x >> 6] = a1;
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  const double s0 = ((wsum[0][0] + wsum[0][1]) + wsum[0][2]) + wsum[0][3];
+  const double s1 = ((wsum[1][0] + wsum[1][1]) + wsum[1][2]) + wsum[1][3];
+  sums[c] = s0;
+  sums[C + c] = s1;
+  const double mu = s0 / M;
+  double var = s1 / M - mu * mu;
   var = var > 0.0 ? var : 0.0;
   const float is = (float)(1.0 / sqrt(var + (double)eps));
   mean[c] = (float)mu;
@@ -1163,17 +1220,21 @@ bool same_shape(const xv_act* a, const xv_act* b) { return a->n == b->n && a->h 
 // statistics and gradients; without one: a memset and f64 atomics in arrival order.
 namespace {
 constexpr int BN_MAX_GRID = 512;
+// dgamma / dbeta: a backward reduction -- the gradients are accumulated by the same launch that adds the rows (workspace
+// form) or by bn_grads_kernel behind the atomics
 template <class F>
-int bn_sums_launch(double* sums, int len, int grid, void* ws, size_t ws_bytes, hipStream_t s, F launch) {
+int bn_sums_launch(double* sums, int len, int grid, void* ws, size_t ws_bytes, hipStream_t s, F launch,
+                   float* dgamma = nullptr, float* dbeta = nullptr) {
   if (ws != nullptr) {
     if (ws_bytes < (size_t)BN_MAX_GRID * len * sizeof(float) || ((uintptr_t)ws & 15)) return XV_EWORKSPACE;
     launch((float*)ws);
-    hipLaunchKernelGGL(bn_sums_kernel, dim3(len), dim3(256), 0, s, (const float*)ws, grid, len, sums);
+    hipLaunchKernelGGL(bn_sums_kernel, dim3(len), dim3(256), 0, s, (const float*)ws, grid, len, sums, dgamma, dbeta);
     return XV_OK;
   }
   const hipError_t e = hipMemsetAsync(sums, 0, sizeof(double) * len, s);
   if (e != hipSuccess) return (int)e;
   launch((float*)nullptr);
+  if (dgamma != nullptr) hipLaunchKernelGGL(bn_grads_kernel, dim3((len / 2 + 63) / 64), dim3(64), 0, s, sums, len / 2, dgamma, dbeta);
   return XV_OK;
 }
 }  // namespace
@@ -1206,6 +1267,42 @@ extern "C" int xv_bn_stats_ws(const xv_act* z, double* sums, void* workspace, si
   return rc != XV_OK ? rc : xv_launch_status();
 }
 extern "C" int xv_bn_stats(const xv_act* z, double* sums, void* stream) { return xv_bn_stats_ws(z, sums, nullptr, 0, stream); }
+
+// xv_bn_sums_from_rows + xv_bn_finalize in one launch (rows: [nrows][2 channels] per-workgroup partial sums); `sums` is left
+// as xv_bn_sums_from_rows leaves it.  Single-process statistics only: a data-parallel run all-reduces `sums` between the two.
+extern "C" int xv_bn_finalize_from_rows(const float* rows, int nrows, int channels, int64_t count, const float* gamma,
+                                        const float* beta, float eps, float momentum, float* moving_mean, float* moving_var,
+                                        float* mean, float* invstd, float* scale, float* shift, double* sums, void* stream) {
+  XV_CHECK_ARG(rows && sums && gamma && beta && mean && invstd && scale && shift &&
+               (moving_mean == nullptr) == (moving_var == nullptr));
+  XV_CHECK_SHAPE(nrows > 0 && channels > 0 && channels <= 32767 && count > 0);
+  hipLaunchKernelGGL(bn_sums_finalize_kernel, dim3(channels), dim3(256), 0, (hipStream_t)stream, rows, nrows, channels, sums,
+                     (double)count, gamma, beta, eps, momentum, moving_mean, moving_var, mean, invstd, scale, shift);
+  return xv_launch_status();
+}
+
+// xv_bn_stats_ws + xv_bn_finalize: the statistics pass and ONE launch for the row sums and the per-channel results
+// (workspace required: the per-workgroup rows live there)
+extern "C" int xv_bn_stats_finalize_ws(const xv_act* z, double* sums, void* workspace, size_t workspace_bytes,
+                                       const float* gamma, const float* beta, float eps, float momentum, float* moving_mean,
+                                       float* moving_var, float* mean, float* invstd, float* scale, float* shift,
+                                       void* stream) {
+  XV_REQUIRE_BF16(z);
+  XV_CHECK_ARG(z && z->data && sums && workspace && gamma && beta && mean && invstd && scale && shift &&
+               (moving_mean == nullptr) == (moving_var == nullptr));
+  XV_CHECK_SHAPE(z->c >= 64 && 2048 % z->c == 0 && z->n > 0 && z->h > 0 && z->w > 0);
+  const int64_t total = (int64_t)z->n * z->h * z->w * (z->c >> 3);
+  XV_CHECK_SHAPE(total < 0x7fff0000);
+  if (workspace_bytes < (size_t)BN_MAX_GRID * 2 * z->c * sizeof(float) || ((uintptr_t)workspace & 15)) return XV_EWORKSPACE;
+  hipStream_t s = (hipStream_t)stream;
+  const int grid = bn_grid(total, BN_MAX_GRID);
+  hipLaunchKernelGGL(bn_reduce_kernel<0>, dim3(grid), dim3(256), 0, s, (const __bf16*)z->data, nullptr, nullptr, nullptr, nullptr,
+                     sums, z->n, z->h, z->w, z->c, (const float*)nullptr, (const float*)nullptr, (float*)workspace);
+  hipLaunchKernelGGL(bn_sums_finalize_kernel, dim3(z->c), dim3(256), 0, s, (const float*)workspace, grid, z->c, sums,
+                     (double)((int64_t)z->n * z->h * z->w), gamma, beta, eps, momentum, moving_mean, moving_var, mean, invstd,
+                     scale, shift);
+  return xv_launch_status();
+}
 
 extern "C" int xv_bn_finalize(const double* sums, int channels, int64_t count, const float* gamma, const float* beta,
                               float eps, float momentum, float* moving_mean, float* moving_var, float* mean,
@@ -1272,9 +1369,8 @@ extern "C" int xv_bn_bwd_reduce_ws(const xv_act* dy, const xv_act* y, const xv_a
   const int rc = bn_sums_launch(sums, 2 * z->c, grid, workspace, workspace_bytes, s, [&](float* part) {
     hipLaunchKernelGGL(bn_reduce_kernel<1>, dim3(grid), dim3(256), 0, s, (const __bf16*)z->data, (const __bf16*)dy->data, yp,
                        mean, invstd, sums, z->n, z->h, z->w, z->c, (const float*)nullptr, (const float*)nullptr, part);
-  });
+  }, dgamma, dbeta);
   if (rc != XV_OK) return rc;
-  hipLaunchKernelGGL(bn_grads_kernel, dim3((z->c + 63) / 64), dim3(64), 0, s, sums, z->c, dgamma, dbeta);
   return xv_launch_status();
 }
 extern "C" int xv_bn_bwd_reduce(const xv_act* dy, const xv_act* y, const xv_act* z, const float* mean,
@@ -1317,9 +1413,8 @@ extern "C" int xv_bn_bwd_reduce_zmask(const xv_act* dy, const xv_act* z, const f
   const int rc = bn_sums_launch(sums, 2 * z->c, grid, workspace, workspace_bytes, s, [&](float* part) {
     hipLaunchKernelGGL(bn_reduce_kernel<2>, dim3(grid), dim3(256), 0, s, (const __bf16*)z->data, (const __bf16*)dy->data,
                        (const __bf16*)nullptr, mean, invstd, sums, z->n, z->h, z->w, z->c, scale, shift, part);
-  });
+  }, dgamma, dbeta);
   if (rc != XV_OK) return rc;
-  hipLaunchKernelGGL(bn_grads_kernel, dim3((z->c + 255) / 256), dim3(256), 0, s, sums, z->c, dgamma, dbeta);
   return xv_launch_status();
 }
 
@@ -1355,9 +1450,8 @@ extern "C" int xv_bn_pool_bwd_reduce(const xv_act* dpooled, const xv_act* z, con
     hipLaunchKernelGGL(bn_pool_bwd_kernel<0>, dim3(grid), dim3(256), 0, s, (const __bf16*)dpooled->data, (const __bf16*)z->data,
                        mean, invstd, scale, shift, (const float*)nullptr, sums, 1.0, (__bf16*)nullptr, z->n, z->h / 2, z->w / 2,
                        z->c, part);
-  });
+  }, dgamma, dbeta);
   if (rc != XV_OK) return rc;
-  hipLaunchKernelGGL(bn_grads_kernel, dim3((z->c + 255) / 256), dim3(256), 0, s, sums, z->c, dgamma, dbeta);
   return xv_launch_status();
 }
 
@@ -1419,9 +1513,8 @@ extern "C" int xv_bn_dense_bwd_reduce_ws(const float* dy, const float* z, int64_
   const int grid = bn_grid(rows, BN_MAX_GRID);
   const int rc = bn_sums_launch(sums, 2 * channels, grid, workspace, workspace_bytes, s, [&](float* part) {
     hipLaunchKernelGGL(bn_dense_reduce_kernel<1>, dim3(grid), dim3(256), 0, s, z, dy, mean, invstd, sums, rows, channels, part);
-  });
+  }, dgamma, dbeta);
   if (rc != XV_OK) return rc;
-  hipLaunchKernelGGL(bn_grads_kernel, dim3(1), dim3(64), 0, s, sums, channels, dgamma, dbeta);
   return xv_launch_status();
 }
 extern "C" int xv_bn_dense_bwd_reduce(const float* dy, const float* z, int64_t rows, int channels, const float* mean,

@@ -735,7 +735,7 @@ def conv2d_fwd_stats(x, w_packed, bias, z, st):
     if rc == -2:            # XV_ESHAPE: the generation-4 kernel does not take this shape
         return False
     _lib.check(rc, 'xv_conv2d_fwd_stats')
-    _lib.check(lib.xv_bn_sums_from_rows(_ptr(st.conv_rows), rows, 2 * st.c, _ptr(st.sums), _stream()), 'xv_bn_sums_from_rows')
+    st.conv_rows_n = rows       # bn_forward(have_stats=True) adds the rows up (in the launch that finalises, where it can)
     return True
 
 
@@ -744,12 +744,23 @@ def bn_forward(z, gamma, beta, moving_mean, moving_var, st, y, relu=True, sync=F
     data-parallel ranks (one all-reduce of 2*C doubles).  pooled (with relu): the 2x2 max-pool of y from the same pass; y
     may then be None (only the pooled map is written)."""
     lib = _lib.lib()
-    if not have_stats:      # (have_stats: conv2d_fwd_stats already left the sums in st.sums)
-        _lib.check(lib.xv_bn_stats_ws(z.xv(), _ptr(st.sums), *st.wsp(), _stream()), 'xv_bn_stats_ws')
-    mult = _sync_sums(st, sync)
-    _lib.check(lib.xv_bn_finalize(_ptr(st.sums), st.c, z.n * z.h * z.w * mult, _ptr(gamma), _ptr(beta), BN_EPS,
-                                  BN_MOMENTUM, _ptr(moving_mean), _ptr(moving_var), _ptr(st.mean), _ptr(st.invstd),
-                                  _ptr(st.scale), _ptr(st.shift), _stream()), 'xv_bn_finalize')
+    fin = (_ptr(gamma), _ptr(beta), BN_EPS, BN_MOMENTUM, _ptr(moving_mean), _ptr(moving_var), _ptr(st.mean), _ptr(st.invstd),
+           _ptr(st.scale), _ptr(st.shift))
+    ws = st.wsp()
+    if not sync and have_stats:
+        # one process: the row sums of the conv epilogue's partial statistics and the per-channel results in ONE launch
+        _lib.check(lib.xv_bn_finalize_from_rows(_ptr(st.conv_rows), st.conv_rows_n, st.c, z.n * z.h * z.w, *fin, _ptr(st.sums),
+                                                _stream()), 'xv_bn_finalize_from_rows')
+    elif not sync and st.ws is not None:
+        _lib.check(lib.xv_bn_stats_finalize_ws(z.xv(), _ptr(st.sums), ws[0], ws[1], *fin, _stream()), 'xv_bn_stats_finalize_ws')
+    else:
+        if have_stats:
+            _lib.check(lib.xv_bn_sums_from_rows(_ptr(st.conv_rows), st.conv_rows_n, 2 * st.c, _ptr(st.sums), _stream()),
+                       'xv_bn_sums_from_rows')
+        else:
+            _lib.check(lib.xv_bn_stats_ws(z.xv(), _ptr(st.sums), *ws, _stream()), 'xv_bn_stats_ws')
+        mult = _sync_sums(st, sync)
+        _lib.check(lib.xv_bn_finalize(_ptr(st.sums), st.c, z.n * z.h * z.w * mult, *fin, _stream()), 'xv_bn_finalize')
     if pooled is not None:
         if not relu:
             raise ValueError('the fused pool follows the relu')

@@ -227,9 +227,46 @@ def test_conv_with_batch_statistics_in_its_epilogue(ops, shape):
     from modular_semantic_segmentation_amd import _lib
     _lib.check(_lib.lib().xv_bn_stats_ws(z1.xv(), st1.sums.data_ptr(), *st1.wsp(), None), 'xv_bn_stats_ws')
     z2 = ops.Act(n, h, w, cout)
-    assert ops.conv2d_fwd_stats(xa, wp, bd, z2, st2)
+    assert ops.conv2d_fwd_stats(xa, wp, bd, z2, st2)          # leaves per-workgroup rows; the sums are taken from them:
+    lib = _lib.lib()
+    _lib.check(lib.xv_bn_sums_from_rows(st2.conv_rows.data_ptr(), st2.conv_rows_n, 2 * cout, st2.sums.data_ptr(), None),
+               'xv_bn_sums_from_rows')
     torch.cuda.synchronize()
     assert torch.equal(z1.t, z2.t)
+    # ... or by the ONE launch that also finalises (xv_bn_finalize_from_rows): the same bits in sums, mean, invstd, scale,
+    # shift and the moving statistics as the two calls; likewise xv_bn_stats_finalize_ws against xv_bn_stats_ws + finalize
+    g = torch.Generator(device='cuda').manual_seed(3)
+    gamma, beta = torch.rand(cout, device='cuda', generator=g) + 0.5, torch.randn(cout, device='cuda', generator=g)
+
+    def fresh():
+        st = ops.BnState(cout, 'cuda')
+        return st, torch.zeros(cout, device='cuda') + 0.25, torch.ones(cout, device='cuda') * 2
+    M = n * h * w
+    sta, mma, mva = fresh()
+    sta.sums.copy_(st2.sums)
+    _lib.check(lib.xv_bn_finalize(sta.sums.data_ptr(), cout, M, gamma.data_ptr(), beta.data_ptr(), 1e-3, 0.99, mma.data_ptr(),
+                                  mva.data_ptr(), sta.mean.data_ptr(), sta.invstd.data_ptr(), sta.scale.data_ptr(),
+                                  sta.shift.data_ptr(), None), 'xv_bn_finalize')
+    stb, mmb, mvb = fresh()
+    _lib.check(lib.xv_bn_finalize_from_rows(st2.conv_rows.data_ptr(), st2.conv_rows_n, cout, M, gamma.data_ptr(), beta.data_ptr(),
+                                            1e-3, 0.99, mmb.data_ptr(), mvb.data_ptr(), stb.mean.data_ptr(), stb.invstd.data_ptr(),
+                                            stb.scale.data_ptr(), stb.shift.data_ptr(), stb.sums.data_ptr(), None),
+               'xv_bn_finalize_from_rows')
+    stc, mmc, mvc = fresh()
+    _lib.check(lib.xv_bn_stats_finalize_ws(z1.xv(), stc.sums.data_ptr(), *stc.wsp(), gamma.data_ptr(), beta.data_ptr(), 1e-3,
+                                           0.99, mmc.data_ptr(), mvc.data_ptr(), stc.mean.data_ptr(), stc.invstd.data_ptr(),
+                                           stc.scale.data_ptr(), stc.shift.data_ptr(), None), 'xv_bn_stats_finalize_ws')
+    std, mmd, mvd = fresh()
+    std.sums.copy_(st1.sums)
+    _lib.check(lib.xv_bn_finalize(std.sums.data_ptr(), cout, M, gamma.data_ptr(), beta.data_ptr(), 1e-3, 0.99, mmd.data_ptr(),
+                                  mvd.data_ptr(), std.mean.data_ptr(), std.invstd.data_ptr(), std.scale.data_ptr(),
+                                  std.shift.data_ptr(), None), 'xv_bn_finalize')
+    torch.cuda.synchronize()
+    for (a, ma, va), (b2, mb, vb) in (((sta, mma, mva), (stb, mmb, mvb)), ((std, mmd, mvd), (stc, mmc, mvc))):
+        assert torch.equal(a.sums, b2.sums) and torch.equal(ma, mb) and torch.equal(va, vb)
+        for name in ('mean', 'invstd', 'scale', 'shift'):
+            assert torch.equal(getattr(a, name), getattr(b2, name)), name
+    assert float(sta.scale.abs().sum()) > 0
     zs = z1.interior().double()
     want = torch.cat([zs.sum((0, 1, 2)), (zs * zs).sum((0, 1, 2))]).cpu().numpy()
     np.testing.assert_allclose(st2.sums.cpu().numpy(), want, rtol=1e-5, atol=1e-3)
