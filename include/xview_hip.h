@@ -182,7 +182,9 @@ int xv_conv2d_first_fwd(const float* x, int n, int h, int w, int cin, const floa
  * evaluated tile by tile straight into conv1_2's LDS patch buffers, so its 64-channel map never reaches memory.  x / w1_hwio
  * / b1 as xv_conv2d_first_fwd (cin = 1 or 3), w2_packed / b2 as xv_conv2d_fwd (64 -> 64 channels, 3x3); y and / or pooled
  * as xv_conv2d_fwd (either may be NULL or have NULL data).  Bit-identical to the two separate calls.  Maps that tile exactly
- * in 16x32 only: XV_ESHAPE otherwise (run the two kernels).                                                               */
+ * in 16x32 only: XV_ESHAPE otherwise (run the two kernels).
+ * y / pooled may be e4m3 maps (XV_FP8, one scale for both: value * 2^-scale_exp, saturating at +-448): the first e4m3 map of
+ * the fp8 graph, the same bytes as xv_conv2d_first_fwd + xv_conv2d_fwd onto e4m3 maps.                                  */
 int xv_conv_first_pair_fwd(const float* x, int n, int h, int w, int cin, const float* w1_hwio, const float* b1, int relu1,
                            const void* w2_packed, const float* b2, int relu2, const xv_act* y, const xv_act* pooled,
                            void* stream);

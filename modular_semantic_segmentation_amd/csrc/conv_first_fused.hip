@@ -40,6 +40,7 @@ struct F1Args {
   int N, H, W;
   int tiles_x, tiles_y, n_tiles;
   int relu1, relu2;
+  float out_mul;      // OF8: 2^-scale_exp of the e4m3 output maps
 };
 
 struct F1 {
@@ -91,7 +92,9 @@ __device__ __forceinline__ void f1_split3x8(const float (&v)[8], bf16x8& h, bf16
   l = __builtin_bit_cast(bf16x8, u32x4{f1_hi16_pair(ll[0], ll[1]), f1_hi16_pair(ll[2], ll[3]), f1_hi16_pair(ll[4], ll[5]), f1_hi16_pair(ll[6], ll[7])});
 }
 
-template <int CIN>
+// OF8: y / pooled are e4m3 maps (value * out_mul, saturating): the first e4m3 map of the fp8 graph (fcn.fp8_plan), with the
+// epilogue of generation 4's <bf16 in, e4m3 out> form -- the same bytes as xv_conv2d_first_fwd + xv_conv2d_fwd onto e4m3 maps
+template <int CIN, bool OF8 = false>
 __global__ __launch_bounds__(512, 2) void conv_first_pair_kernel(F1Args a) {
   using C = F1;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -101,7 +104,7 @@ __global__ __launch_bounds__(512, 2) void conv_first_pair_kernel(F1Args a) {
   const int n15 = lane & 15, g = lane >> 4;
   const int H = a.H, W = a.W;
   const int Wp = W + 2;
-  constexpr int Ob = 128;  // bytes per pixel of the output maps (64 channels of bf16)
+  constexpr int Ob = OF8 ? 64 : 128;  // bytes per pixel of the output maps (64 channels of bf16 / e4m3)
 
   // persistent workgroups, XCD-contiguous tile ranges (as generation 2 / 4)
   const int G = gridDim.x, b = blockIdx.x;
@@ -413,6 +416,47 @@ __global__ __launch_bounds__(512, 2) void conv_first_pair_kernel(F1Args a) {
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       const int px = x0 + 16 * u + n15;
+      if constexpr (OF8) {
+        // e4m3 epilogue (conv_f8_dma.hip, the 16x16 form: the bias is inside the accumulators): scale by a power of two,
+        // relu + saturation in one v_med3_f32, the 2x2 max as v_med3_f32(x, y, +inf), one conversion
+        const float lo = a.relu2 ? 0.f : -448.f, inf = __builtin_inff();
+        float q[2][16];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            q[i][r] = __builtin_amdgcn_fmed3f(acc4[i][r >> 3][u][(r >> 2) & 1][r & 3] * a.out_mul, lo, 448.f);
+        auto cvt16 = [&](const float (&w)[16]) {
+          u32x4 o;
+#pragma unroll
+          for (int d = 0; d < 4; ++d) {
+            int p = 0;
+            p = __builtin_amdgcn_cvt_pk_fp8_f32(w[4 * d], w[4 * d + 1], p, false);
+            p = __builtin_amdgcn_cvt_pk_fp8_f32(w[4 * d + 2], w[4 * d + 3], p, true);
+            o[d] = (uint32_t)p;
+          }
+          return o;
+        };
+        if (a.y != nullptr) {
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+            *reinterpret_cast<u32x4*>(a.y + (((int64_t)n * (H + 2) + (py + i + 1)) * Wp + (px + 1)) * Ob + cofs) = cvt16(q[i]);
+        }
+        if (a.pooled != nullptr) {
+          float m[16];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const float t = __builtin_amdgcn_fmed3f(q[0][r], q[1][r], inf);
+            const float o = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, t), 0xB1, 0xf, 0xf, true));
+            m[r] = __builtin_amdgcn_fmed3f(t, o, inf);
+          }
+          const int Hq = H >> 1, Wq = W >> 1;
+          const u32x4 o = cvt16(m);
+          if ((lane & 1) == 0)
+            *reinterpret_cast<u32x4*>(a.pooled + (((int64_t)n * (Hq + 2) + ((py >> 1) + 1)) * (Wq + 2) + ((px >> 1) + 1)) * Ob + cofs) = o;
+        }
+        continue;
+      }
       uint32_t pk[2][8];
 #pragma unroll
       for (int i = 0; i < 2; ++i)
@@ -461,12 +505,13 @@ __global__ __launch_bounds__(512, 2) void conv_first_pair_kernel(F1Args a) {
   }
 }
 
-template <int CIN>
+template <int CIN, bool OF8 = false>
 int f1_launch(const F1Args& a, int grid, hipStream_t stream) {
   static bool attr_set[XV_MAX_DEVICES] = {false};
-  const hipError_t e = xv_allow_dynamic_lds(reinterpret_cast<const void*>(&conv_first_pair_kernel<CIN>), F1::LDS_BYTES, attr_set);
+  const hipError_t e =
+      xv_allow_dynamic_lds(reinterpret_cast<const void*>(&conv_first_pair_kernel<CIN, OF8>), F1::LDS_BYTES, attr_set);
   if (e != hipSuccess) return (int)e;
-  hipLaunchKernelGGL((conv_first_pair_kernel<CIN>), dim3((unsigned)grid), dim3(F1::NT), F1::LDS_BYTES, stream, a);
+  hipLaunchKernelGGL((conv_first_pair_kernel<CIN, OF8>), dim3((unsigned)grid), dim3(F1::NT), F1::LDS_BYTES, stream, a);
   return xv_launch_status();
 }
 
@@ -478,10 +523,15 @@ int f1_launch(const F1Args& a, int grid, hipStream_t stream) {
 extern "C" int xv_conv_first_pair_fwd(const float* x, int n, int h, int w, int cin, const float* w1_hwio, const float* b1, int relu1,
                                       const void* w2_packed, const float* b2, int relu2, const xv_act* y, const xv_act* pooled,
                                       void* stream) {
-  XV_REQUIRE_BF16(y, pooled);
   XV_CHECK_ARG(x && w1_hwio && b1 && w2_packed && b2);
   const bool has_y = y && y->data, has_q = pooled && pooled->data;
   XV_CHECK_ARG(has_y || has_q);
+  // bf16 maps, or e4m3 maps (the first e4m3 map of the fp8 graph): both outputs of one dtype and scale
+  const xv_act* const o = has_q ? pooled : y;
+  XV_CHECK_ARG(o->dtype == XV_BF16 || o->dtype == XV_FP8);
+  if (has_y && has_q) XV_CHECK_ARG(y->dtype == pooled->dtype && y->scale_exp == pooled->scale_exp);
+  const bool of8 = o->dtype == XV_FP8;
+  if (of8) XV_CHECK_SHAPE(o->scale_exp > -100 && o->scale_exp < 100);
   XV_CHECK_SHAPE(xv_dims_sane(n, h, w) && (cin == 1 || cin == 3) && (h & 15) == 0 && (w & 31) == 0);
   XV_CHECK_SHAPE((int64_t)n * h * w * cin < 0x7ff00000);
   if (has_y) XV_CHECK_SHAPE(y->n == n && y->h == h && y->w == w && y->c == 64);
@@ -499,6 +549,8 @@ extern "C" int xv_conv_first_pair_fwd(const float* x, int n, int h, int w, int c
   XV_CHECK_SHAPE(ntiles > 0 && ntiles <= 0x7fffffff);
   a.n_tiles = (int)ntiles;
   a.relu1 = relu1, a.relu2 = relu2;
+  a.out_mul = of8 ? exp2f((float)-o->scale_exp) : 1.f;
   const int grid = xv_num_cus();
+  if (of8) return cin == 3 ? f1_launch<3, true>(a, grid, (hipStream_t)stream) : f1_launch<1, true>(a, grid, (hipStream_t)stream);
   return cin == 3 ? f1_launch<3>(a, grid, (hipStream_t)stream) : f1_launch<1>(a, grid, (hipStream_t)stream);
 }

@@ -288,11 +288,23 @@ class FcnEngine(object):
         e = self.fp8_scales
         convs8, maps8 = fp8_plan(h, w, self.fp8_deep)
         L = {}
-        cur = self._act('conv1_1', n, h, w, 64, **(dict(dtype='fp8', scale_exp=e['conv1_1']) if 'conv1_1' in maps8 else {}))
-        ops.conv2d_first_fwd(x.contiguous(), self.w['conv1_1'], self.b['conv1_1'], cur, relu=True)
-        L['conv1_1'] = cur
+        first = 1
         ch, cw = h, w
-        for name, cout, pool in ENCODER[1:]:
+        # conv1_1 + conv1_2 + pool1 in one launch straight onto the first e4m3 map (csrc/conv_first_fused.hip, its e4m3-out form:
+        # the same bytes as the two kernels) where conv1_2 takes bf16 operands (the default plan) and neither full map is wanted
+        if not keep_all and _FUSE_FIRST and 'conv1_1' not in maps8 and 'conv1_2' in maps8 and 'conv1_2' not in convs8 and \
+                ENCODER[1][0] == 'conv1_2' and ENCODER[1][2] == 'pool1':
+            q = self._act('pool1', n, h // 2, w // 2, 64, dtype='fp8', scale_exp=e['conv1_2'])
+            if ops.conv_first_pair_fwd(x.contiguous(), self.w['conv1_1'], self.b['conv1_1'], self.w['conv1_2'],
+                                       self.b['conv1_2'], pooled=q):
+                L['pool1'] = cur = q
+                ch, cw = h // 2, w // 2
+                first = 2
+        if first == 1:
+            cur = self._act('conv1_1', n, h, w, 64, **(dict(dtype='fp8', scale_exp=e['conv1_1']) if 'conv1_1' in maps8 else {}))
+            ops.conv2d_first_fwd(x.contiguous(), self.w['conv1_1'], self.b['conv1_1'], cur, relu=True)
+            L['conv1_1'] = cur
+        for name, cout, pool in ENCODER[first:]:
             f8_in = name in convs8
             f8_out = name in maps8
             wts = self.w8[name] if f8_in else self.w[name]

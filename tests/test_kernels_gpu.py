@@ -410,6 +410,21 @@ def test_first_pair_fused_equals_the_two_kernels(ops, n, h, w, cin):
         torch.cuda.synchronize()
         assert torch.equal(y.t, y_ref.t), 'full map differs (relu2=%s): %d values' % (relu2, int((y.t != y_ref.t).sum()))
         assert torch.equal(q.t, q_ref.t) and torch.equal(q2.t, q_ref.t)
+    # the e4m3-out form (the first e4m3 map of the fp8 graph): the same bytes as the two kernels onto e4m3 maps, with the
+    # scale that keeps the map inside +-448 and one that saturates
+    for scale_exp in (-3, -7):
+        y1 = ops.conv2d_first_fwd(xd, w1d, b1d, ops.Act(n, h, w, 64))
+        q_ref = ops.Act(n, h // 2, w // 2, 64, dtype='fp8', scale_exp=scale_exp)
+        y_ref = ops.Act(n, h, w, 64, dtype='fp8', scale_exp=scale_exp)
+        ops.conv2d_fwd(y1, w2p, b2d, 3, relu=True, y=y_ref, pooled=q_ref)
+        y8, q8 = ops.Act(n, h, w, 64, dtype='fp8', scale_exp=scale_exp), ops.Act(n, h // 2, w // 2, 64, dtype='fp8', scale_exp=scale_exp)
+        q8b = ops.Act(n, h // 2, w // 2, 64, dtype='fp8', scale_exp=scale_exp)
+        assert ops.conv_first_pair_fwd(xd, w1d, b1d, w2p, b2d, y=y8, pooled=q8)
+        assert ops.conv_first_pair_fwd(xd, w1d, b1d, w2p, b2d, pooled=q8b)
+        torch.cuda.synchronize()
+        assert torch.equal(y8.t.view(torch.uint8), y_ref.t.view(torch.uint8))
+        assert torch.equal(q8.t.view(torch.uint8), q_ref.t.view(torch.uint8)) and torch.equal(q8b.t.view(torch.uint8), q_ref.t.view(torch.uint8))
+        assert int((q8.t.view(torch.uint8) != 0).sum()) > 0
     # oracle: conv1_1 in float32 -> bf16, conv1_2 with bf16 operands and fp32 accumulation -> bf16
     xo = torch.from_numpy(x).permute(0, 3, 1, 2).contiguous()
     a1 = fo.round_bf16(fo.conv2d_same(xo, w1, b1, relu=True))
