@@ -527,9 +527,13 @@ int xv_score_dense_bwd(const xv_act* u, const float* dscore, const float* w_scor
 
 /* ---- "exact" mode (conv_dtype='fp32'): the FCN trunk in plain float32 on dense UNPADDED NHWC maps -- the reference
  * graph's own arithmetic type (tf.layers.conv2d / max_pooling2d / conv2d_transpose on float32: simple_fcn.py:39-87,
- * custom_layers.py:71-139), fp32 FMAs, no bf16 storage.  About 1/100 of the MFMA path's speed; it exists so that a test can
- * show label maps EQUAL to the fp32 oracle's on trained weights, i.e. that what the bf16 path loses it loses to bf16.
- *   xv_conv2d_f32             y = [relu](conv_kxk_same(x, w_hwio) + bias), k in {1, 3}, any channel counts
+ * custom_layers.py:71-139), no bf16 storage.  The convs run on the fp32 matrix instruction (v_mfma_f32_32x32x2_f32: bit for
+ * bit a k-ordered fmaf chain, at the fp32 vector rate = 1/16 of the bf16 MFMA rate); the mode exists so that label maps
+ * EQUAL to the fp32 oracle's on trained weights are a product mode and not only a test (basic_fusion_model.py:21-22).
+ *   xv_conv2d_f32             y = [relu](conv_kxk_same(x, w_hwio) + bias), k in {1, 3}, any channel counts and map sizes
+ *   xv_conv2d_f32_pool        the same; y and / or the 2x2 max-pooled map (h, w even) written from the accumulators
+ *                             (max_pooling2d fused, simple_fcn.py:41-63); y == NULL or pooled == NULL skips that output
+ *   xv_conv2d_f32_scalar      round 4's kernel (fp32 FMAs on the vector ALU): the A/B baseline of the bench record
  *   xv_maxpool2x2_f32         2x2 / stride 2
  *   xv_upsample2x_f32         y = relu(bilinear_x2(x)) [+ residual]            (upscore_conv5 + add_score)
  *   xv_score_lowres_f32       S[n][i+1][j+1][k] = fused[n][i][j][:] . Ws[:][k] into the zero-bordered [N][h+2][w+2][CP]
@@ -538,6 +542,10 @@ int xv_score_dense_bwd(const xv_act* u, const float* dscore, const float* w_scor
  *                             xv_decoder_head_fwd; also serves the bf16 path's S)                                       */
 int xv_conv2d_f32(const float* x, int n, int h, int w, int cin, const float* w_hwio, const float* bias, int k, int cout,
                   int relu, float* y, void* stream);
+int xv_conv2d_f32_pool(const float* x, int n, int h, int w, int cin, const float* w_hwio, const float* bias, int k, int cout,
+                       int relu, float* y, float* pooled, void* stream);
+int xv_conv2d_f32_scalar(const float* x, int n, int h, int w, int cin, const float* w_hwio, const float* bias, int k, int cout,
+                         int relu, float* y, void* stream);
 int xv_maxpool2x2_f32(const float* x, int n, int h, int w, int c, float* y, void* stream);
 int xv_upsample2x_f32(const float* x, int n, int h, int w, int c, const float* residual, float* y, void* stream);
 int xv_score_lowres_f32(const float* fused, int n, int h, int w, int u, const float* w_score, int num_classes, float* S,

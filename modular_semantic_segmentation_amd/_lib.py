@@ -133,6 +133,8 @@ SIGNATURES = {
     'xv_softmax_ce_dense_affine': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i64, _vp, _vp, _vp]),
     'xv_score_dense_bwd': (_i, [_actp, _vp, _vp, _i, _vp, _vp, _actp, _vp]),
     'xv_conv2d_f32': (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _i, _i, _i, _vp, _vp]),
+    'xv_conv2d_f32_pool': (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
+    'xv_conv2d_f32_scalar': (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _i, _i, _i, _vp, _vp]),
     'xv_maxpool2x2_f32': (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
     'xv_upsample2x_f32': (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     'xv_score_lowres_f32': (_i, [_vp, _i, _i, _i, _i, _vp, _i, _vp, _vp]),

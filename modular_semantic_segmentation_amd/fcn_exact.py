@@ -1,9 +1,11 @@
 """The FCN expert in plain float32 (`conv_dtype='fp32'`, "exact" mode): the same graph as fcn.FcnEngine
 (xview/models/simple_fcn.py:10-170) on dense unpadded NHWC float32 maps through csrc/exact_f32.hip -- the reference
-graph's own arithmetic type, no bf16 storage.  Roughly 1/100 of the MFMA path's speed: it exists for the parity
-contract (tests/test_exact_f32_gpu.py: label maps equal to the fp32 oracle's on trained weights), not for throughput.
-Same surface as FcnEngine where the fusion models need it: load / encoder / lowres_scores / forward."""
+graph's own arithmetic type, no bf16 storage.  The convs run on the fp32 matrix instruction (v_mfma_f32_32x32x2_f32: an
+fp32 fmaf chain bit for bit, 1/16 of the bf16 MFMA rate), the 2x2 max-pools leave the conv launches.  It is the label-exact
+product mode (tests/test_exact_f32_gpu.py: label maps equal to the fp32 oracle's on trained weights), about 1/9 of the bf16
+path's images/s.  Same surface as FcnEngine where the fusion models need it: load / encoder / lowres_scores / forward."""
 import ctypes
+import os
 
 import numpy as np
 import torch
@@ -11,6 +13,10 @@ import torch
 from . import _lib, ops
 from .custom_layers import is_bilinear_filter
 from .fcn import ENCODER, _fold_bn, variable_shapes
+
+
+# XV_EXACT_SCALAR=1: round 4's vector-ALU conv kernel + stand-alone pools (A/B baseline of the bench record)
+SCALAR_KERNEL = os.environ.get('XV_EXACT_SCALAR', '0') == '1'
 
 
 def _p(t):
@@ -60,20 +66,23 @@ class FcnEngineF32(object):
             t = self._arena[key] = torch.zeros(shape, dtype=torch.float32, device=self.device)
         return t
 
-    def _conv(self, name, x, k, relu=True):
+    def _conv(self, name, x, k, relu=True, pool=None):
+        """conv (+ bias, relu) -> full map; with `pool` also the 2x2 max-pooled map, from the same launch."""
         n, h, w, cin = x.shape
         cout = self.b[name].numel()
         y = self._buf(name, (n, h, w, cout))
-        rc = _lib.lib().xv_conv2d_f32(_p(x), n, h, w, cin, _p(self.w[name]), _p(self.b[name]), k, cout, int(relu), _p(y),
-                                      ops._stream())
+        q = self._buf(pool, (n, h // 2, w // 2, cout)) if pool else None
+        with ops._Profiled('k3f32' if k == 3 else 'k1f32', 2.0 * n * h * w * cin * cout * k * k):
+            if SCALAR_KERNEL:
+                rc = _lib.lib().xv_conv2d_f32_scalar(_p(x), n, h, w, cin, _p(self.w[name]), _p(self.b[name]), k, cout, int(relu),
+                                                     _p(y), ops._stream())
+                if rc == 0 and q is not None:
+                    rc = _lib.lib().xv_maxpool2x2_f32(_p(y), n, h, w, cout, _p(q), ops._stream())
+            else:
+                rc = _lib.lib().xv_conv2d_f32_pool(_p(x), n, h, w, cin, _p(self.w[name]), _p(self.b[name]), k, cout, int(relu),
+                                                   _p(y), _p(q), ops._stream())
         _lib.check(rc, 'xv_conv2d_f32')
-        return y
-
-    def _pool(self, name, x):
-        n, h, w, c = x.shape
-        y = self._buf(name, (n, h // 2, w // 2, c))
-        _lib.check(_lib.lib().xv_maxpool2x2_f32(_p(x), n, h, w, c, _p(y), ops._stream()), 'xv_maxpool2x2_f32')
-        return y
+        return y, q
 
     def encoder(self, x, keep_all=False):
         """float32 [N,H,W,cin] -> dict of dense float32 NHWC maps with the reference's layer names."""
@@ -85,11 +94,12 @@ class FcnEngineF32(object):
         L = {}
         cur = x.contiguous()
         for name, _, pool in ENCODER:
-            cur = L[name] = self._conv(name, cur, 3)
+            cur, q = self._conv(name, cur, 3, pool=pool)
+            L[name] = cur
             if pool:
-                cur = L[pool] = self._pool(pool, cur)
-        s4 = L['score_conv4'] = self._conv('score_conv4', L['conv4_3'], 1)
-        s5 = L['score_conv5'] = self._conv('score_conv5', L['conv5_3'], 1)
+                cur = L[pool] = q
+        s4 = L['score_conv4'] = self._conv('score_conv4', L['conv4_3'], 1)[0]
+        s5 = L['score_conv5'] = self._conv('score_conv5', L['conv5_3'], 1)[0]
         fused = self._buf('fused', tuple(s4.shape))
         n5, h5, w5, c5 = s5.shape
         _lib.check(_lib.lib().xv_upsample2x_f32(_p(s5), n5, h5, w5, c5, _p(s4), _p(fused), ops._stream()), 'xv_upsample2x_f32')
