@@ -34,7 +34,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 _JSON_OUT = sys.stdout
-PEAK_TFLOPS = {'bf16': 2500.0, 'fp8': 5000.0}     # dense MFMA, MI355X_MICROARCH.md chip table
+PEAK_TFLOPS = {'bf16': 2500.0, 'fp8': 5000.0, 'fp32': 157.3}     # dense MFMA, MI355X_MICROARCH.md chip table (fp32: the
+#                                                                  f32-input matrix instruction = the fp32 vector rate)
 C, U = 12, 64
 
 
@@ -328,10 +329,14 @@ def committed_traffic(batch, h, w):
 
 
 def extra_inference(device, label, fusion, batch, h, w, dtype='bf16', steps=10, warmup=2, ones=False, fetch=False,
-                    streamk=False, fp8_deep=False, zero_operands=False):
+                    streamk=False, fp8_deep=False, zero_operands=False, scalar_f32=False):
     """One more BASELINE.json configuration as an `extra` record (its own model, graph and roofline pass).
     zero_operands: a DIAGNOSTIC, not a workload -- every conv kernel, bias and input zero, so no MFMA operand toggles: the
     rate the same binaries reach when power does not hold the clock down ('Generation 4')."""
+    if dtype == 'fp32':
+        # the label-exact mode: A/B against round 4's vector-ALU kernel through the same engine (scalar_f32)
+        from modular_semantic_segmentation_amd import fcn_exact
+        fcn_exact.SCALAR_KERNEL = bool(scalar_f32)
     net = build_model(device, fusion=fusion, batch=batch, dtype=dtype, streamk=streamk, fp8_deep=fp8_deep)
     data = synthetic_batch(device, batch, h, w, seed=77, ones=ones)
     if zero_operands:
@@ -342,7 +347,8 @@ def extra_inference(device, label, fusion, batch, h, w, dtype='bf16', steps=10, 
         data = {k: torch.zeros_like(v) for k, v in data.items()}
     if dtype == 'fp8':
         net.calibrate(data)
-    times, per_iter, prof, dt_serial = measure_inference(net, data, device, steps, warmup, fetch=fetch, min_seconds=1.0)
+    times, per_iter, prof, dt_serial = measure_inference(net, data, device, steps, warmup, fetch=fetch, min_seconds=1.0,
+                                                         graph=dtype != 'fp32')
     dt = float(np.median(times))
     rec = {'workload': label, 'images_per_step': batch, 'dtype': dtype, 'value': round(batch * steps / dt, 2),
            'unit': 'images/s'}
@@ -355,11 +361,67 @@ def extra_inference(device, label, fusion, batch, h, w, dtype='bf16', steps=10, 
                                       dt_serial, steps)
         rec['roofline_bf16_layers'] = roofline_of(prof, ('k3',), PEAK_TFLOPS['bf16'], 'the 3x3 convs left on bf16 operands (conv1_2)',
                                                   dt_serial, steps)
+    elif dtype == 'fp32':
+        rec['roofline'] = roofline_of(prof, ('k3f32',), PEAK_TFLOPS['fp32'],
+                                      'conv_f32_kernel (round 4: fp32 FMAs on the vector ALU)' if scalar_f32 else
+                                      'conv_f32_mfma_kernel (v_mfma_f32_32x32x2_f32: every 3x3 launch, conv1_1 included)', dt_serial, steps)
+        from modular_semantic_segmentation_amd import fcn_exact
+        fcn_exact.SCALAR_KERNEL = False
     else:
         rec['roofline'] = roofline_of(prof, ('k3', 'k3pair'), PEAK_TFLOPS['bf16'], 'conv_dma4_kernel / conv_dma5_kernel / conv_first_pair_kernel (+ fallback generations): every 3x3 launch incl. the fused first pair',
                                       dt_serial, steps)
     flops_img = conv_flops_per_image(h, w, 3) + conv_flops_per_image(h, w, 1)
     rec['conv_tflops_end_to_end'] = round(batch * steps * flops_img / dt / 1e12, 2)
+    del net
+    torch.cuda.empty_cache()
+    return rec
+
+
+def host_boundary_record(device, samples=256, batch=16, h=384, w=768):
+    """predict() / score() / fit() fed from HOST numpy arrays -- the API the reference's callers use (base_model.py:180-331)
+    -- through the pipelined boundary (host_pipeline.py: pinned staging, uploads / label downloads on copy streams, the step
+    replayed from a hipGraph after two batches), next to the serial path (XV_HOST_PIPELINE=0: pageable copies, .cpu() per batch).
+    The results are kept until the clock stops: freeing a 600 MB label array is the caller's business."""
+    from modular_semantic_segmentation_amd import host_pipeline
+    net = build_model(device, batch=batch)
+    rng = np.random.default_rng(0)
+    uniq = 32
+    reps = (samples + uniq - 1) // uniq
+    data = {'rgb': np.tile(rng.integers(0, 256, (uniq, h, w, 3)).astype(np.float32), (reps, 1, 1, 1))[:samples],
+            'depth': np.tile(rng.integers(0, 65536, (uniq, h, w, 1)).astype(np.float32), (reps, 1, 1, 1))[:samples],
+            'labels': np.tile(rng.integers(-1, C, (uniq, h, w)).astype(np.int32), (reps, 1, 1))[:samples]}
+    inputs = {k: v for k, v in data.items() if k != 'labels'}
+    rec = {'workload': 'predict() and score() over %d HOST-resident %dx%d RGB-D samples, batchsize %d (two SimpleFCN experts + '
+                       'Bayes fusion)' % (samples, w, h, batch), 'unit': 'images/s', 'dtype': 'bf16'}
+
+    def timed(fn, arg, reps=3):
+        best = None
+        for _ in range(reps):
+            torch.cuda.synchronize(device)
+            t0 = time.perf_counter()
+            result = fn(arg)
+            torch.cuda.synchronize(device)
+            dt = time.perf_counter() - t0
+            del result
+            best = dt if best is None else min(best, dt)
+        return best
+
+    for mode in ('pipelined', 'serial'):
+        host_pipeline.ENABLED = mode == 'pipelined'
+        net._graph = None
+        try:
+            warm = {k: v[:4 * batch] for k, v in data.items()}
+            net.predict({k: v for k, v in warm.items() if k != 'labels'})
+            sub = samples if mode == 'pipelined' else min(samples, 8 * batch)
+            tp = timed(net.predict, {k: v[:sub] for k, v in inputs.items()})
+            ts = timed(net.score, {k: v[:sub] for k, v in data.items()})
+            rec[mode] = {'predict_images_per_s': round(sub / tp, 1), 'score_images_per_s': round(sub / ts, 1), 'samples': sub,
+                         'host_bytes_per_image': {'in': int(h * w * 4 * 4), 'labels_out': int(h * w * 8)}}
+        finally:
+            host_pipeline.ENABLED = True
+    rec['value'] = rec['pipelined']['predict_images_per_s']
+    rec['note'] = ('value = predict(); input staging 12.6 MB per RGB-D pair by worker threads into pinned memory, H2D on a copy '
+                   'stream, labels back as one byte per pixel and widened to int64 into the result array')
     del net
     torch.cuda.empty_cache()
     return rec
@@ -702,6 +764,12 @@ def main():
                                          384, 768, steps=30, warmup=3)
             guarded(extra_inference, device, 'two-stream SimpleFCN + Bayes fusion 768x384, batch 1, random input, streamk=True',
                                          'bayes', 1, 384, 768, steps=30, warmup=3, streamk=True)
+            guarded(extra_inference, device, "conv_dtype='fp32', the label-exact mode (argmax maps equal to the fp32 graph's): two "
+                                             'SimpleFCN experts + Bayes fusion 768x384 x 16, fp32 matrix instruction', 'bayes', 16,
+                                         384, 768, dtype='fp32', steps=5, warmup=1)
+            guarded(extra_inference, device, "the same on round 4's vector-ALU kernel (XV_EXACT_SCALAR=1): the A/B baseline of the "
+                                             'record above', 'bayes', 4, 384, 768, dtype='fp32', steps=2, warmup=1, scalar_f32=True)
+            guarded(host_boundary_record, device)
             guarded(extra_inference, device, 'two-stream SimpleFCN + Dirichlet fusion 768x384 (configs[3] inference side)',
                                          'dirichlet', 16, 384, 768)
             guarded(extra_inference, device, 'DIAGNOSTIC, not a workload: the headline step with all-zero weights, biases and inputs '
@@ -735,7 +803,7 @@ def main():
         def watchdog():
             res['train_dp'] = {'error': 'timeout: the train_dp phase did not finish within %.0f s' % args.train_dp_timeout}
             emit()
-            os._exit(0)
+            os._exit(3)         # a rank that gives up says so in its exit code (the record carries the reason)
         timer = threading.Timer(args.train_dp_timeout, watchdog)
         timer.daemon = True
         timer.start()

@@ -428,6 +428,10 @@ int xv_dirichlet_suffstats(const float* prob, const int32_t* labels, int num_cla
  * labels are the dropped (C+1)-th row); cm int64 [C][C], accumulated, rows = ground truth.         */
 int xv_confusion_matrix(const int32_t* labels, const int64_t* pred, int num_classes, int64_t npix,
                         int64_t* cm, void* stream);
+/* Label maps on their way to the host (predict(), base_model.py:279-288): int64 labels in [0, 256) -> one byte per pixel,
+ * out[i] = (uint8) labels[i].  The pipelined host boundary sends this image over PCIe (an eighth of the bytes) and widens it
+ * to the reference's np.int64 while it fills the result array.  labels 16-byte, out 8-byte aligned.                       */
+int xv_narrow_labels(const int64_t* labels, int64_t n, uint8_t* out, void* stream);
 
 /* ---- training-mode batch normalisation -----------------------------------------------------------
  * tf.layers.batch_normalization(training=True) between a conv / deconv and its activation
@@ -522,6 +526,15 @@ int xv_softmax_ce_dense(const float* logits, const int32_t* labels, const int64_
 int xv_softmax_ce_dense_affine(const float* scores, const float* scale, const float* shift, const int32_t* labels,
                                const int64_t* valid_count, int num_classes, int64_t npix, double* loss, float* dlogits,
                                void* stream);
+/* The same with the loss added up in a FIXED order: every workgroup leaves its partial sum in `ws` (at least
+ * xv_softmax_ce_dense_workspace_bytes(npix) bytes, 8-byte aligned, owned by the calling stream) and a second one-workgroup
+ * launch adds them to *loss -- bit for bit the same loss on every run (the two entries above add the partials with a double
+ * atomic in arrival order: equal to ~1e-16 relative).  ws == NULL: the arrival-order form.  scale == shift == NULL: plain
+ * logits.                                                                                                               */
+size_t xv_softmax_ce_dense_workspace_bytes(int64_t npix);
+int xv_softmax_ce_dense_ws(const float* scores, const float* scale, const float* shift, const int32_t* labels,
+                           const int64_t* valid_count, int num_classes, int64_t npix, double* loss, float* dlogits, void* ws,
+                           size_t ws_bytes, void* stream);
 int xv_score_dense_bwd(const xv_act* u, const float* dscore, const float* w_score, int num_classes, float* dw_score,
                        float* db_score, const xv_act* du, void* stream);
 

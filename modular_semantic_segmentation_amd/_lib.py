@@ -131,6 +131,8 @@ SIGNATURES = {
     'xv_score_dense_fwd': (_i, [_actp, _vp, _vp, _i, _vp, _vp]),
     'xv_softmax_ce_dense': (_i, [_vp, _vp, _vp, _i, _i64, _vp, _vp, _vp]),
     'xv_softmax_ce_dense_affine': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i64, _vp, _vp, _vp]),
+    'xv_softmax_ce_dense_workspace_bytes': (ctypes.c_size_t, [_i64]),
+    'xv_softmax_ce_dense_ws': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i64, _vp, _vp, _vp, ctypes.c_size_t, _vp]),
     'xv_score_dense_bwd': (_i, [_actp, _vp, _vp, _i, _vp, _vp, _actp, _vp]),
     'xv_conv2d_f32': (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _i, _i, _i, _vp, _vp]),
     'xv_conv2d_f32_pool': (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
@@ -145,6 +147,7 @@ SIGNATURES = {
     'xv_adagrad_step': (_i, [_vp, _vp, _vp, _i64, ctypes.c_float, ctypes.c_float, _vp]),
     'xv_dirichlet_suffstats': (_i, [_vp, _vp, _i, _i64, _vp, _vp, _vp]),
     'xv_confusion_matrix': (_i, [_vp, _vp, _i, _i64, _vp, _vp]),
+    'xv_narrow_labels': (_i, [_vp, _i64, _vp, _vp]),
 }
 
 _lib = None

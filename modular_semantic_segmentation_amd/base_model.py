@@ -95,16 +95,61 @@ class BaseModel(object):
         """batch: dict of numpy / device arrays -> device tensor (int64 [N,H,W] labels by default)."""
         raise NotImplementedError
 
+    def _graph_flags(self):
+        """Host-side switches a captured step depends on besides the weights: a graph captured under other values is not
+        replayed (tests and A/B timing flip them between calls)."""
+        return (getattr(self, 'concurrent_experts', True), self.config.get('fused_head', True),
+                self.config.get('paired_launches', True))
+
     def _predict_batch(self, batch, output_attr=None):
         g = getattr(self, '_graph', None)
-        if g is not None and output_attr is None and \
+        if g is not None and output_attr is None and g[4] == self._graph_flags() and \
                 all(k in batch and tuple(batch[k].shape) == shp for k, shp in g[3].items()):
-            graph, static, out, _ = g
+            graph, static, out = g[:3]
             for k in static:
                 static[k].copy_(self._to_device(batch[k], torch.float32))
             graph.replay()
             return out
         return self._predict_batch_impl(batch, output_attr)
+
+    # ---- the pipelined host boundary (host_pipeline.py) -----------------------------------------------------------------
+    def _host_dtypes(self, labels):
+        """{key: torch dtype} of the arrays a batch carries onto the device: every described input as float32 (the
+        reference's placeholders, base_model.py:86-94), labels as int32."""
+        d = {k: torch.float32 for k in self.testdata_description[0] if k != 'labels'}
+        if labels:
+            d['labels'] = torch.int32
+        return d
+
+    def _device_batches(self, batches, labels):
+        """`batches` (host or device dicts) as HBM-resident dicts, staged and uploaded ahead of the consumer."""
+        from . import host_pipeline
+        if not host_pipeline.ENABLED or self.device.type != 'cuda':
+            return batches
+        return host_pipeline.DevicePrefetcher(self.device, batches, self._host_dtypes(labels))
+
+    def _graph_capturable(self):
+        """May predict() / score() capture the inference step into a hipGraph on their own?  Off by config
+        (`auto_graph: False`), after a failed attempt, and for models whose step has host-side state."""
+        return self.config.get('auto_graph', True) and not getattr(self, '_graph_failed', False)
+
+    def _predict_batch_auto(self, batch, output_attr, state):
+        """_predict_batch, with the step captured into a hipGraph once two batches of one shape have run eagerly (the
+        third is the capture's warm-up and first replay): ~50 launches on two streams become one graph launch.  A model
+        whose step cannot be captured (a host synchronisation inside it) falls back to eager launches for good."""
+        if output_attr is None and self._graph_capturable() and self.device.type == 'cuda':
+            sig = tuple(sorted((k, tuple(v.shape)) for k, v in batch.items() if k != 'labels'))
+            state['count'] = state.get('count', 0) + 1 if state.get('sig') == sig else 1
+            state['sig'] = sig
+            g = getattr(self, '_graph', None)
+            have = g is not None and g[4] == self._graph_flags() and dict(sig) == g[3]
+            if state['count'] >= 3 and not have:
+                try:
+                    self.capture_graph(batch)
+                except Exception:               # noqa: BLE001  (capture is an optimisation: never fail the call over it)
+                    self._graph, self._graph_failed = None, True
+                    torch.cuda.synchronize(self.device)
+        return self._predict_batch(batch, output_attr=output_attr)
 
     def _train_batch(self, batch):
         raise UserWarning('ERROR: Model %s does not support training' % self.name)
@@ -126,7 +171,7 @@ class BaseModel(object):
         ~55 kernel launches on two streams collapse into one graph launch).  Later `_predict_batch` calls
         with the same input shapes copy into the static input buffers and replay.  All buffers the
         kernels touch are cached per shape in the engines, so the captured pointers stay valid."""
-        keys = [k for k in batch if k != 'labels']
+        keys = [k for k in batch if k != 'labels' and k in self.testdata_description[0]]
         static = {k: self._to_device(batch[k], torch.float32).clone() for k in keys}
         for _ in range(2):                       # warm-up: one-time attribute calls, buffer allocation
             self._predict_batch_impl(static)
@@ -134,7 +179,7 @@ class BaseModel(object):
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
             out = self._predict_batch_impl(static)
-        self._graph = (graph, static, out, {k: tuple(v.shape) for k, v in static.items()})
+        self._graph = (graph, static, out, {k: tuple(v.shape) for k, v in static.items()}, self._graph_flags())
         return self
 
     # ---- helpers ------------------------------------------------------------------------------------
@@ -145,9 +190,9 @@ class BaseModel(object):
         t = torch.from_numpy(np.ascontiguousarray(array))
         return t.to(device=self.device, dtype=dtype, non_blocking=False).contiguous()
 
-    def _confusion_of_batch(self, batch, cm_dev):
+    def _confusion_of_batch(self, batch, cm_dev, state=None):
         from . import ops
-        pred = self._predict_batch(batch)
+        pred = self._predict_batch(batch) if state is None else self._predict_batch_auto(batch, None, state)
         labels = self._to_device(batch['labels'], torch.int32)
         ops.confusion_matrix(labels, pred.contiguous(), cm_dev)
 
@@ -197,7 +242,8 @@ class BaseModel(object):
             log = open(os.path.join(self.output_dir, 'training_log.jsonl'), 'a')
         if output:
             print('INFO: Start training')
-        batches = endless()
+        # the next batches are staged into pinned memory and uploaded while the current step runs (host_pipeline.py)
+        batches = iter(self._device_batches(endless(), labels=True))
         for i in range(iterations):
             loss = self._train_batch(next(batches))
             self.global_step += 1
@@ -227,18 +273,31 @@ class BaseModel(object):
     def predict(self, data, output_attr=None):
         """Semantic segmentation of `data` (base_model.py:263-292): np.int64 [N,H,W], or the named
         output (e.g. 'prob', 'fused_score') when `output_attr` names something the model exposes."""
-        ret = []
-        for batch in iterate_batches(data, self.config['batchsize']):
-            out = self._predict_batch(batch, output_attr=output_attr)
-            ret.append(out.cpu().numpy())
-        return np.concatenate(ret)
+        from . import host_pipeline
+        batches = iterate_batches(data, self.config['batchsize'])
+        if not host_pipeline.ENABLED or self.device.type != 'cuda':
+            ret = []
+            for batch in batches:
+                out = self._predict_batch(batch, output_attr=output_attr)
+                ret.append(out.cpu().numpy())
+            return np.concatenate(ret)
+        # pipelined: batch i+2 is staged into pinned memory and batch i+1 uploaded while batch i computes and the labels
+        # of batch i-1 travel back (base_model.py:203-206: the reference's tf.data prefetch in front of sess.run)
+        total = len(next(iter(data.values()))) if isinstance(data, dict) else None
+        fetch = host_pipeline.ResultFetcher(self.device, total, narrow_labels=output_attr is None and
+                                            self.config['num_classes'] <= 256)
+        state = {}
+        for batch in self._device_batches(batches, labels=False):
+            fetch.push(self._predict_batch_auto(batch, output_attr, state))
+        return fetch.finish()
 
     def score(self, data, max_iterations=None):
         """(measures dict, confusion matrix float64 [C,C]) over `data` (base_model.py:294-331)."""
         C = self.config['num_classes']
         cm_dev = torch.zeros((C, C), dtype=torch.int64, device=self.device)
-        for batch in iterate_batches(data, self.config['batchsize'], max_iterations):
-            self._confusion_of_batch(batch, cm_dev)
+        state = {}
+        for batch in self._device_batches(iterate_batches(data, self.config['batchsize'], max_iterations), labels=True):
+            self._confusion_of_batch(batch, cm_dev, state)
         if self.config.get('reduce_score_over_ranks', False):
             # one process per GPU, each scored its own shard: sum the [C,C] counts (RCCL all-reduce)
             from .parallel import allreduce_sum_

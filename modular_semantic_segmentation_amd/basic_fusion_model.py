@@ -62,7 +62,10 @@ def paired_from(model, inputs):
         return None
     if not all(type(e) is FcnEngine and e.pairable() for e in model.experts.values()):
         return None
-    n, h, w = next(iter(inputs.values())).shape[:3]
+    shapes = {tuple(v.shape[:3]) for v in inputs.values()}
+    if len(shapes) != 1:        # modalities of different sizes cannot share a launch: keep both on their own streams
+        return None
+    n, h, w = next(iter(shapes))
     tiles = n * ((h // 8 + 15) // 16) * ((w // 8 + 31) // 32) * 8
     if tiles < torch.cuda.get_device_properties(model.device).multi_processor_count:
         return None

@@ -866,7 +866,8 @@ __global__ __launch_bounds__(256) void softmax_ce_dense_kernel(const float* __re
                                                               int64_t npix, double* __restrict__ loss,
                                                               float* __restrict__ dlogits,
                                                               const float* __restrict__ scale = nullptr,
-                                                              const float* __restrict__ shift = nullptr) {
+                                                              const float* __restrict__ shift = nullptr,
+                                                              double* __restrict__ partials = nullptr) {
   const float inv = 1.f / (1e-20f + (float)count[0]);
   // scale != nullptr: `logits` holds the raw scores and the batch norm's affine (xv_bn_dense_apply's expression) is applied
   // here, so the normalised scores never go to HBM
@@ -904,7 +905,28 @@ __global__ __launch_bounds__(256) void softmax_ce_dense_kernel(const float* __re
     if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
     __syncthreads();
   }
-  if (threadIdx.x == 0) atomicAdd(loss, red[0]);
+  // partials: one slot per workgroup, added up in workgroup order by loss_partials_sum_kernel (a bitwise reproducible
+  // loss); without a workspace the workgroups add to the loss in arrival order (equal to ~1e-16 relative, not bit for bit)
+  if (threadIdx.x == 0) {
+    if (partials != nullptr)
+      partials[blockIdx.x] = red[0];
+    else
+      atomicAdd(loss, red[0]);
+  }
+}
+
+// loss += sum_b part[b] in a fixed order: thread t adds slots t, t + 256, ... in sequence, then the 256 sums meet in a tree
+__global__ __launch_bounds__(256) void loss_partials_sum_kernel(const double* __restrict__ part, int n, double* __restrict__ loss) {
+  double a = 0.0;
+  for (int i = threadIdx.x; i < n; i += 256) a += part[i];
+  __shared__ double red[256];
+  red[threadIdx.x] = a;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *loss += red[0];
 }
 
 // dws[u][c] += sum_pix u[pix][u] * ds[pix][c]; dbs[c] += sum_pix ds[pix][c].  A block walks a contiguous run of pixels
@@ -1604,23 +1626,37 @@ extern "C" int xv_score_dense_fwd(const xv_act* u, const float* w_score, const f
   return xv_launch_status();
 }
 
-extern "C" int xv_softmax_ce_dense_affine(const float* scores, const float* scale, const float* shift,
-                                          const int32_t* labels, const int64_t* valid_count, int num_classes, int64_t npix,
-                                          double* loss, float* dlogits, void* stream) {
+extern "C" size_t xv_softmax_ce_dense_workspace_bytes(int64_t npix) {
+  return npix > 0 ? (size_t)bn_grid(npix, 2048) * sizeof(double) : 0;
+}
+
+extern "C" int xv_softmax_ce_dense_ws(const float* scores, const float* scale, const float* shift, const int32_t* labels,
+                                      const int64_t* valid_count, int num_classes, int64_t npix, double* loss, float* dlogits,
+                                      void* ws, size_t ws_bytes, void* stream) {
   XV_CHECK_ARG(scores && labels && valid_count && loss && dlogits && (scale == nullptr) == (shift == nullptr));
   XV_CHECK_SHAPE(npix > 0 && num_classes >= 1 && num_classes <= 32);
+  XV_CHECK_ARG(ws == nullptr || (ws_bytes >= xv_softmax_ce_dense_workspace_bytes(npix) && ((uintptr_t)ws & 7) == 0));
+  const unsigned grid = (unsigned)bn_grid(npix, 2048);
 #define XV_CE(CMV)                                                                                                   \
-  hipLaunchKernelGGL(softmax_ce_dense_kernel<CMV>, dim3(bn_grid(npix, 2048)), dim3(256), 0, (hipStream_t)stream, scores, \
-                     labels, reinterpret_cast<const unsigned long long*>(valid_count), num_classes, npix, loss, dlogits,  \
-                     scale, shift)
+  hipLaunchKernelGGL(softmax_ce_dense_kernel<CMV>, dim3(grid), dim3(256), 0, (hipStream_t)stream, scores, labels,     \
+                     reinterpret_cast<const unsigned long long*>(valid_count), num_classes, npix, loss, dlogits, scale, \
+                     shift, (double*)ws)
   XV_CM_SWITCH(num_classes, XV_CE)
 #undef XV_CE
+  if (ws != nullptr)
+    hipLaunchKernelGGL(loss_partials_sum_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const double*)ws, (int)grid, loss);
   return xv_launch_status();
+}
+
+extern "C" int xv_softmax_ce_dense_affine(const float* scores, const float* scale, const float* shift, const int32_t* labels,
+                                          const int64_t* valid_count, int num_classes, int64_t npix, double* loss,
+                                          float* dlogits, void* stream) {
+  return xv_softmax_ce_dense_ws(scores, scale, shift, labels, valid_count, num_classes, npix, loss, dlogits, nullptr, 0, stream);
 }
 
 extern "C" int xv_softmax_ce_dense(const float* logits, const int32_t* labels, const int64_t* valid_count,
                                    int num_classes, int64_t npix, double* loss, float* dlogits, void* stream) {
-  return xv_softmax_ce_dense_affine(logits, nullptr, nullptr, labels, valid_count, num_classes, npix, loss, dlogits, stream);
+  return xv_softmax_ce_dense_ws(logits, nullptr, nullptr, labels, valid_count, num_classes, npix, loss, dlogits, nullptr, 0, stream);
 }
 
 extern "C" int xv_score_dense_bwd(const xv_act* u, const float* dscore, const float* w_score, int num_classes,

@@ -212,7 +212,34 @@ __global__ __launch_bounds__(256) void confusion_kernel(const int32_t* __restric
     if (hist[i]) atomicAdd(&cm[i], (unsigned long long)hist[i]);
 }
 
+// int64 label map -> one byte per pixel for the trip to the host (predict()'s return value is np.int64 [N,H,W],
+// base_model.py:279-288: the host widens it again while it fills the result array).  8 labels per thread: four 16-byte
+// reads, one 8-byte store.
+__global__ __launch_bounds__(256) void narrow_labels_kernel(const int64_t* __restrict__ in, uint8_t* __restrict__ out, int64_t n) {
+  const int64_t stride = (int64_t)gridDim.x * 256 * 8;
+  for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 8; i < n; i += stride) {
+    if (i + 8 <= n) {
+      uint64_t packed = 0;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const u32x4 v = *reinterpret_cast<const u32x4*>(in + i + 2 * j);     // two labels: low words .x and .z
+        packed |= (uint64_t)(v.x & 0xffu) << (16 * j) | (uint64_t)(v.z & 0xffu) << (16 * j + 8);
+      }
+      *reinterpret_cast<uint64_t*>(out + i) = packed;
+    } else {
+      for (int64_t k = i; k < n; ++k) out[k] = (uint8_t)in[k];
+    }
+  }
+}
+
 }  // namespace
+
+extern "C" int xv_narrow_labels(const int64_t* labels, int64_t n, uint8_t* out, void* stream) {
+  XV_CHECK_ARG(labels && out && ((uintptr_t)labels & 15) == 0 && ((uintptr_t)out & 7) == 0);
+  XV_CHECK_SHAPE(n > 0);
+  hipLaunchKernelGGL(narrow_labels_kernel, dim3(grid_for((n + 7) / 8, 256, 2048)), dim3(256), 0, (hipStream_t)stream, labels, out, n);
+  return xv_launch_status();
+}
 
 extern "C" int xv_bayes_fuse(const int64_t* const* labels, int num_experts, const float* loglik, const float* logprior,
                              int num_classes, int64_t npix, int64_t* fused, float* score_out, void* stream) {

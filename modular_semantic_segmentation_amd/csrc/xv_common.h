@@ -150,8 +150,12 @@ __device__ static __forceinline__ uint32_t pk_max_i16(uint32_t a, uint32_t b) {
 }
 
 // The per-pixel softmax / log-probability arithmetic of the heads (tf.nn.softmax, Dirichlet.log_prob: basic_fusion_model.py:
-// 21-22, dirichlet_mix.py:23-36) on the transcendental unit: v_exp_f32 / v_log_f32 / v_rcp_f32 (about 1 ulp each) in place of
-// the correctly rounded library forms (10-15 instructions each; an IEEE division is ten).  24 logs, 24 exps and 48 divisions
+// 21-22, dirichlet_mix.py:23-36) on the transcendental unit: v_exp_f32 / v_log_f32 / v_rcp_f32 (about 1 ulp each, denormal
+// inputs / results flushed) in place of the correctly rounded library forms (10-15 instructions each; an IEEE division is ten).
+// xv_fast_exp(x) = exp2(x * log2 e): the rounding of the product is amplified by |x|, so its relative error GROWS as
+// ~|x| * 6e-8 (6e-7 at x = -10, 5e-6 at x = -80) -- terms that small are below fp32 resolution of the softmax sum they
+// enter.  Probabilities, Dirichlet log-probabilities and the training loss are therefore NOT correctly rounded libm
+// results (numerics notes); the accuracy tests bound what that costs.  24 logs, 24 exps and 48 divisions
 // per pixel made the fused Dirichlet head 10x slower than its 288 FMAs.  Every kernel that must agree
 // bit for bit with another one (fused head <-> head + fusion kernels) uses the same helper.
 __device__ static __forceinline__ float xv_fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.4426950408889634f); }

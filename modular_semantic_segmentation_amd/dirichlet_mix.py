@@ -127,7 +127,7 @@ class DirichletFusion(BaseModel):
         S = {m: torch.zeros((C, C), dtype=torch.float64, device=self.device) for m in self.modalities}
         counts = torch.zeros(C, dtype=torch.int64, device=self.device)
         scratch = torch.zeros(C, dtype=torch.int64, device=self.device)
-        for batch in iterate_batches(data, self.config['batchsize']):
+        for batch in self._device_batches(iterate_batches(data, self.config['batchsize']), labels=True):
             labels = self._to_device(batch['labels'], torch.int32)
             outs = run_experts(self, batch, ('prob',))
             for i, m in enumerate(self.modalities):

@@ -474,6 +474,8 @@ class FcnEngine(object):
     def forward(self, x, want=('label',), keep_all=False, st=None):
         """fcn + test_pipeline (basic_fusion_model.py:9-23): returns dict with any of
         'score', 'prob' (float32 [N,H,W,C]) and 'label' == 'classification' (int64 [N,H,W])."""
+        if st is not None and bool(keep_all) != bool(st['keep_all']):
+            raise ValueError('forward(st=...): the encoder state was begun with keep_all=%r' % st['keep_all'])
         L = self.encoder_finish(st) if st is not None else self.encoder(x, keep_all=keep_all)
         f = L.get('features_drop', L['fused'])           # the decoder's input (dropped only when 'features' is a dropout site)
         key = ('head_ws', f.n, f.h, f.w)

@@ -15,7 +15,7 @@ import torch
 
 from . import ops
 from .base_model import BaseModel
-from .custom_layers import bilinear_filter, is_bilinear_filter
+from .custom_layers import bilinear_filter, dense_deconv_as_conv3x3, is_bilinear_filter
 from .fcn import BN_EPS, ENCODER, _fold_bn
 
 
@@ -153,9 +153,19 @@ class FusionFcnEngine(object):
                 raise KeyError('missing variable %s' % need)
             if tuple(v[need].shape) != tuple(shape):
                 raise ValueError('variable %s has shape %s, expected %s' % (need, v[need].shape, shape))
-        for name in ('fused_upscore_conv5', 'fused/upscore'):
-            if not is_bilinear_filter(v[name + '/kernel']):
-                raise NotImplementedError('%s/kernel is not the constant bilinear kernel (custom_layers.py:8-25)' % name)
+        # The reference never trains its deconvs (fusion_fcn.py:26-31: trainable=False), so their kernels are the bilinear
+        # constant and run as depthwise interpolations.  An imported kernel that is anything else takes the dense
+        # transposed-conv path, as in fcn.FcnEngine (xv_deconv_dense_fwd on the MFMA conv; the decoder head is then the
+        # un-commuted one: dense x8 deconv -> [batch norm] -> relu, per-pixel score conv, softmax, argmax).
+        self.dense_deconv = {}
+        for name, stride in (('fused_upscore_conv5', 2), ('fused/upscore', 8)):
+            kern = v[name + '/kernel']
+            if not is_bilinear_filter(kern):
+                kp = np.zeros((kern.shape[0], kern.shape[1], self.Up, self.Up), np.float32)
+                kp[:, :, :self.U, :self.U] = kern                       # padding units: zero rows and columns
+                k3 = torch.from_numpy(dense_deconv_as_conv3x3(kp, stride)).to(dev)
+                self.dense_deconv[name] = (ops.pack_conv_weights(k3),
+                                           torch.zeros(stride * stride * self.Up, dtype=torch.float32, device=dev))
         for m, prefix in self.prefixes.items():
             if m in self.trunks:
                 self.trunks[m].load(v)
@@ -183,7 +193,7 @@ class FusionFcnEngine(object):
         if has_bn:
             s = v['fused/upscore/gamma'] / np.sqrt(v['fused/upscore/moving_variance'] + BN_EPS)
             t = v['fused/upscore/beta'] - v['fused/upscore/moving_mean'] * s
-            if np.all(s > 0) and np.all(np.abs(t) <= 1e-12):
+            if np.all(s > 0) and np.all(np.abs(t) <= 1e-12) and 'fused/upscore' not in self.dense_deconv:
                 k = k * s[:, None]
             else:
                 sp, tp = np.ones(self.Up, np.float32), np.zeros(self.Up, np.float32)
@@ -241,13 +251,36 @@ class FusionFcnEngine(object):
         s5 = self._act('score_conv5', n, h8 // 2, w8 // 2, self.Up)
         ops.conv2d_fwd(c5, self.w['fused_score_conv5'], self.b['fused_score_conv5'], 1, relu=True, y=s5)
         feat = self._act('features', n, h8, w8, self.Up)
-        ops.upsample2x_relu_add(s5, residual=s4, y=feat)
+        if 'fused_upscore_conv5' in self.dense_deconv:
+            wk, zb = self.dense_deconv['fused_upscore_conv5']
+            _, self._arena['dd_ws5'] = ops.deconv_dense_fwd(s5, wk, zb, 2, self.Up, y=feat, residual=s4, relu=True,
+                                                           workspace=self._arena.get('dd_ws5'))
+        else:
+            ops.upsample2x_relu_add(s5, residual=s4, y=feat)
         aff = self.head_affine or (None, None)
-        out = ops.decoder_head_fwd(feat, self.w['score'], self.b['score'], self.C, want_score='score' in want,
-                                   want_prob='prob' in want,
-                                   want_label=('label' in want or 'classification' in want),
-                                   scale=aff[0], shift=aff[1])
+        want_label = 'label' in want or 'classification' in want
         layers.update(concat_conv4=c4, concat_conv5=c5, score_conv4=s4, score_conv5=s5, features=feat)
+        if 'fused/upscore' in self.dense_deconv:
+            wk, zb = self.dense_deconv['fused/upscore']
+            up = self._act('upscore', n, 8 * h8, 8 * w8, self.Up)
+            _, self._arena['dd_ws'] = ops.deconv_dense_fwd(feat, wk, zb, 8, self.Up, y=up, scale=aff[0], shift=aff[1],
+                                                          relu=True, workspace=self._arena.get('dd_ws'))
+            skey = ('dense_score', n, h8, w8)
+            if skey not in self._arena:
+                self._arena[skey] = torch.empty((n, 8 * h8, 8 * w8, self.C), dtype=torch.float32, device=self.device)
+            score = ops.score_dense_fwd(up, self.w['score'], self.b['score'], self.C, self._arena[skey])
+            prob, label = ops.softmax_argmax(score, want_prob='prob' in want, want_label=want_label)
+            out = {}
+            layers['upscore'] = up
+            if 'score' in want:
+                out['score'] = score
+            if prob is not None:
+                out['prob'] = prob
+            if label is not None:
+                out['label'] = label
+        else:
+            out = ops.decoder_head_fwd(feat, self.w['score'], self.b['score'], self.C, want_score='score' in want,
+                                       want_prob='prob' in want, want_label=want_label, scale=aff[0], shift=aff[1])
         out['layers'] = layers
         return out
 

@@ -721,9 +721,11 @@ def _sync_sums(st, sync):
 
 
 def conv2d_fwd_stats(x, w_packed, bias, z, st):
-    """z = conv3x3(x) + bias with the batch statistics of z (st.sums, as xv_bn_stats leaves them) taken in the conv kernel's
-    epilogue.  Returns False (nothing launched) where that kernel does not apply: the caller then runs conv2d_fwd and lets
-    bn_forward take the statistics."""
+    """z = conv3x3(x) + bias with the batch statistics of z taken in the conv kernel's epilogue -- as PER-WORKGROUP ROWS in
+    st.conv_rows (st.conv_rows_n of them), NOT in st.sums: the sums are produced by the next bn_forward(have_stats=True)
+    (xv_bn_finalize_from_rows / xv_bn_sums_from_rows), until then st.sums still holds the previous step's values.  Returns
+    False (nothing launched) where that kernel does not apply: the caller then runs conv2d_fwd and lets bn_forward take the
+    statistics."""
     if os.environ.get('XV_BN_CONV_STATS') == '0':        # A/B timing: the separate statistics pass
         return False
     lib = _lib.lib()
@@ -771,15 +773,23 @@ def bn_forward(z, gamma, beta, moving_mean, moving_var, st, y, relu=True, sync=F
     return y
 
 
-def bn_backward(dy, y, z, gamma, st, dgamma, dbeta, dz, sync=False, mask_from_z=None):
-    """dz from dy (gradient w.r.t. the post-relu output; y = None: no activation); accumulates the LOCAL dgamma /
-    dbeta (the gradient all-reduce sums them over ranks).  With an activation the relu mask is recomputed from z
-    (z * scale + shift > 0 with the scale / shift the forward pass left in `st`) instead of read from y -- a third less
-    traffic -- for the trunk's channel counts (mask_from_z=False: always read y)."""
+def bn_backward(dy, y, z, gamma, st, dgamma, dbeta, dz, sync=False, mask_from_z=None, relu=None):
+    """dz from dy (gradient w.r.t. the post-relu output); accumulates the LOCAL dgamma / dbeta (the gradient all-reduce
+    sums them over ranks).  relu: is there an activation behind the batch norm (default: `y is not None`).  With one, the relu
+    mask is recomputed from z (z * scale + shift > 0 with the scale / shift the forward pass left in `st`) for the trunk's
+    channel counts (64 .. 2048, powers of two) -- a third less traffic, and `y` is then NOT read and may be None
+    (`relu=True`); other channel counts, and mask_from_z=False, read the mask from y, which must then be given."""
     lib = _lib.lib()
+    if relu is None:
+        relu = y is not None
+    can_zmask = z.c >= 64 and 2048 % z.c == 0
     if mask_from_z is None:
-        mask_from_z = y is not None and z.c >= 64 and 2048 % z.c == 0
-    if mask_from_z and y is not None:
+        mask_from_z = relu and can_zmask
+    if relu and not mask_from_z and y is None:
+        raise ValueError('bn_backward: %d channels take the relu mask from y (none given)' % z.c)
+    if not relu:
+        y = None
+    if mask_from_z and relu:
         _lib.check(lib.xv_bn_bwd_reduce_zmask(dy.xv(), z.xv(), _ptr(st.mean), _ptr(st.invstd), _ptr(st.scale), _ptr(st.shift),
                                               _ptr(st.sums), _ptr(dgamma), _ptr(dbeta), *st.wsp(), _stream()),
                    'xv_bn_bwd_reduce_zmask')
@@ -856,14 +866,24 @@ def score_dense_fwd(u, w_score, b_score, num_classes, score):
     return score
 
 
+_CE_WS = {}
+
+
 def softmax_ce_dense(logits, labels, count, num_classes, loss, dlogits, affine=None):
-    """affine (a BnState): `logits` holds raw scores, logits = scores * affine.scale + affine.shift inside the kernel."""
+    """affine (a BnState): `logits` holds raw scores, logits = scores * affine.scale + affine.shift inside the kernel.
+    The loss is added up in a fixed order (xv_softmax_ce_dense_ws: per-workgroup partials in a workspace kept per device and
+    stream, one small launch adds them): bitwise reproducible, like the rest of the training step."""
     _need(labels, torch.int32, 'labels')
     npix = labels.numel()
-    _lib.check(_lib.lib().xv_softmax_ce_dense_affine(_ptr(logits), _ptr(affine.scale) if affine is not None else None,
-                                                     _ptr(affine.shift) if affine is not None else None, _ptr(labels),
-                                                     _ptr(count), num_classes, npix, _ptr(loss), _ptr(dlogits), _stream()),
-               'xv_softmax_ce_dense_affine')
+    key = (logits.device, _stream().value)
+    nbytes = _lib.lib().xv_softmax_ce_dense_workspace_bytes(npix)
+    ws = _CE_WS.get(key)
+    if ws is None or ws.numel() * 8 < nbytes:
+        ws = _CE_WS[key] = torch.empty(max(nbytes // 8, 2048), dtype=torch.float64, device=logits.device)
+    _lib.check(_lib.lib().xv_softmax_ce_dense_ws(_ptr(logits), _ptr(affine.scale) if affine is not None else None,
+                                                 _ptr(affine.shift) if affine is not None else None, _ptr(labels),
+                                                 _ptr(count), num_classes, npix, _ptr(loss), _ptr(dlogits), _ptr(ws),
+                                                 ws.numel() * 8, _stream()), 'xv_softmax_ce_dense_ws')
     return dlogits
 
 

@@ -319,6 +319,42 @@ def test_fusion_fcn_joint_baseline(gpu, tmp_path, decoder_bn):
         assert np.array_equal(np.load(out)['fused/score/kernel'], w['fused/score/kernel'])
 
 
+def test_fusion_fcn_with_imported_dense_deconv_kernels(gpu):
+    """fusion_fcn() with imported deconv kernels that are not the bilinear constant (the joint model's deconv2d is the same
+    general tf.layers.conv2d_transpose, fusion_fcn.py:26-31): the dense transposed-conv path of the joint engine -- x2 deconv +
+    add into `features`, x8 deconv -> batch norm -> relu at full resolution, per-pixel score conv -- against the oracle."""
+    from modular_semantic_segmentation_amd.fusion_fcn import FusionFcnEngine
+    prefixes, nch = {'rgb': 'rgb', 'depth': 'depth'}, {'rgb': 3, 'depth': 1}
+    w = fo.init_fusion_fcn_weights(prefixes, nch, U, C, seed=5, bias_scale=0.02)
+    w['rgb_conv1_1/kernel'] *= 0.02
+    w['depth_conv1_1/kernel'] *= 2e-4
+    for k in w:
+        if k.endswith('/kernel') and 'upscore' not in k and 'conv1_1' not in k:
+            w[k] *= 1.6
+    rng = np.random.default_rng(9)
+    for name in ('fused_upscore_conv5', 'fused/upscore'):
+        kern = w[name + '/kernel']
+        w[name + '/kernel'] = (kern + 0.02 * rng.standard_normal(kern.shape) * np.abs(kern).max()).astype(np.float32)
+    data = _data(2, seed=33)
+    eng = FusionFcnEngine(prefixes, nch, U, C, w)
+    assert sorted(eng.dense_deconv) == ['fused/upscore', 'fused_upscore_conv5']
+    out = eng.forward({m: torch.from_numpy(data[m]).cuda() for m in prefixes}, want=('score', 'prob', 'label'))
+    torch.cuda.synchronize()
+    ref = fo.fusion_fcn_forward(data, w, prefixes, 'bf16', keep=['features', 'score'])
+    feat = out['layers']['features'].interior().float().cpu().numpy()[..., :U]
+    assert np.abs(feat - ref['features']).max() < 2e-2 * np.abs(ref['features']).max()
+    _check_logits_and_labels(out['score'].cpu().numpy(), out['label'].cpu().numpy(), ref['score'], 'fusion_fcn dense deconv')
+    np.testing.assert_allclose(out['prob'].cpu().numpy().sum(-1), 1.0, atol=1e-5)
+    # only the x8 kernel dense (the x2 one bilinear) takes the interpolation kernel for x2 and the dense path for x8
+    w2 = dict(w)
+    w2['fused_upscore_conv5/kernel'] = fo.init_fusion_fcn_weights(prefixes, nch, U, C, seed=5)['fused_upscore_conv5/kernel']
+    eng2 = FusionFcnEngine(prefixes, nch, U, C, w2)
+    assert sorted(eng2.dense_deconv) == ['fused/upscore']
+    out2 = eng2.forward({m: torch.from_numpy(data[m]).cuda() for m in prefixes}, want=('score', 'label'))
+    ref2 = fo.fusion_fcn_forward(data, w2, prefixes, 'bf16')['score']
+    _check_logits_and_labels(out2['score'].cpu().numpy(), out2['label'].cpu().numpy(), ref2, 'fusion_fcn dense x8 only')
+
+
 def test_experiment_flows_without_sacred(gpu, tmp_path):
     """experiments.py: the reference's fit-and-evaluate flows (experiments/bayes_fusion.py:146-195,
     dirichlet_fusion.py:58-81, training.py, evaluation.py) on a synthetic dict-of-arrays dataset."""
