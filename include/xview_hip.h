@@ -162,6 +162,16 @@ int xv_conv2d_fwd_pair(const xv_act* xa, const void* wa_packed, const float* bia
 size_t xv_conv2d_streamk_workspace_bytes(void);
 int xv_conv2d_fwd_ws(const xv_act* x, const void* w_packed, const float* bias, const xv_act* y, const xv_act* pooled,
                      int k, int relu, int cfg, void* workspace, size_t workspace_bytes, void* stream);
+/* The forward conv with a workspace for the SPLIT form of the 24x16-tile kernel (round 5, batch-1 latency): where a layer's
+ * whole tiles fill less than half the CUs AND its shape sums its input channels in chunk groups (maps that tile in 24x16 and
+ * not in 16x32 with >= 256 input channels: conv5_x of a 768x384 input), every (tile, group) is a work item of its own that
+ * leaves fp32 accumulators in the workspace, and a second launch adds the groups in order.  The unsplit launch of such a
+ * layer adds the same groups in the same order in registers: identical bits at every batch size.
+ * xv_conv2d_split_workspace_bytes: bytes this shape needs (0: it is never split; the call below then equals xv_conv2d_fwd_cfg).
+ * The workspace belongs to the calling stream until the launch has completed.                                          */
+size_t xv_conv2d_split_workspace_bytes(int n, int h, int w, int cin, int cout);
+int xv_conv2d_fwd_split(const xv_act* x, const void* w_packed, const float* bias, const xv_act* y, const xv_act* pooled, int k,
+                        int relu, int cfg, void* split_workspace, size_t split_workspace_bytes, void* stream);
 int xv_conv2d_bwd_data_ws(const xv_act* dy, const void* w_packed_dgrad, const float* zero_bias, const xv_act* relu_ref,
                           const xv_act* addend, const xv_act* dx, int k, void* workspace, size_t workspace_bytes,
                           void* stream);

@@ -49,6 +49,8 @@ SIGNATURES = {
     'xv_conv2d_num_cfgs': (_i, []),
     'xv_conv2d_streamk_workspace_bytes': (ctypes.c_size_t, []),
     'xv_conv2d_fwd_ws': (_i, [_actp, _vp, _vp, _actp, _actp, _i, _i, _i, _vp, ctypes.c_size_t, _vp]),
+    'xv_conv2d_split_workspace_bytes': (ctypes.c_size_t, [_i, _i, _i, _i, _i]),
+    'xv_conv2d_fwd_split': (_i, [_actp, _vp, _vp, _actp, _actp, _i, _i, _i, _vp, ctypes.c_size_t, _vp]),
     'xv_conv2d_bwd_data_ws': (_i, [_actp, _vp, _vp, _actp, _actp, _actp, _i, _vp, ctypes.c_size_t, _vp]),
     'xv_deconv_dense_workspace_bytes': (ctypes.c_size_t, [_i, _i, _i, _i, _i]),
     'xv_deconv_dense_fwd': (_i, [_actp, _vp, _vp, _vp, _vp, _actp, _actp, _i, _i, _vp, ctypes.c_size_t, _vp]),

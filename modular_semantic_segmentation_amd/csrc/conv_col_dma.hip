@@ -19,6 +19,13 @@
 //   * Fragment schedule (reads return in order; at most 4 + (MT + 2) + 4 = 14 in flight, the counter holds 15):
 //       before tap 0: bias W0 P0 | tap 0: wait, W1 | tap t: W(t+1), wait, [P of the next column group at taps 1 and 3], MFMAs.
 //   * Exact tilings only (H % (8 MT) == 0, W % 16 == 0); fused 2x2 max-pool for even MT; bias + relu, no addend / mask.
+//   * Round 5, CHUNK GROUPS (MODE 1 / 2): on the shapes only this kernel serves (maps that tile in 24x16 and not in 16x32: the
+//     24x48 conv5 maps) with eight or more chunks, a tile's sum over input channels is taken in groups of two chunks --
+//     group 0 starts from the bias, the others from zero, and the groups are added in order, out = ((g0 + g1) + g2) + ...
+//     MODE 1 does that in registers.  MODE 2 (SPLIT: fewer tiles than half the CUs -- conv5_x at one image is 24 tiles
+//     for 256 CUs, 38 us a layer at 142 TFLOP/s) makes every (tile, group) a work item of its own that leaves its fp32
+//     accumulators in a workspace slab, and splitk_reduce_kernel adds the slabs in the same order: the same bits as MODE 1
+//     whatever the batch size, so an image alone and in a batch still agree bit for bit.
 #include "xv_common.h"
 
 namespace {
@@ -43,6 +50,10 @@ struct G5Args {
   char* y2;
   char* pooled2;
   int n_first;
+  // chunk groups (MODE 1 / 2): grp chunks per group, ngrp groups per tile; MODE 2: n_tiles counts (tile, group) items and
+  // slabs holds their fp32 accumulators, [item][pixel of the tile][64 channels]
+  int grp, ngrp;
+  float* slabs;
 };
 
 template <int MT>
@@ -71,8 +82,9 @@ __device__ unsigned long long xv_clk_g5[4 * XV_CLK_SLOTS];
 
 // DG: the data-gradient epilogue (addend + relu mask) as a kernel of its own (the forward kernel carries neither its registers
 // nor its branches)
-template <int MT, bool DG = false>
+template <int MT, bool DG = false, int MODE = 0>
 __global__ __launch_bounds__(512, 2) void conv_dma5_kernel(G5Args a) {
+  static_assert(MODE == 0 || !DG, "chunk groups exist in the forward kernel only");
   using C = G5<MT>;
   constexpr int R = C::R;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -103,9 +115,15 @@ __global__ __launch_bounds__(512, 2) void conv_dma5_kernel(G5Args a) {
     int n, y0, x0, co0;
     int second;  // 1: a tile of the second problem (n counts its images).  (int: a bool member sent the struct through an
                  // alloca that the compiler promoted into LDS, on top of the patch buffer)
+    int split;   // MODE 2: the chunk group this item computes
   };
   auto decode = [&](int l) {
     Tile t;
+    t.split = 0;
+    if constexpr (MODE == 2) {
+      t.split = l % a.ngrp;
+      l /= a.ngrp;
+    }
     t.co0 = (l % a.n_ct) * 64;
     int r = l / a.n_ct;
     t.x0 = (r % a.tiles_x) * C::TW;
@@ -161,10 +179,10 @@ __global__ __launch_bounds__(512, 2) void conv_dma5_kernel(G5Args a) {
   };
 
   Tile cur = decode(lid);
-  int chunk = 0, buf = 0, bslot = 0;
+  int chunk = MODE == 2 ? cur.split * a.grp : 0, buf = 0, bslot = 0;
   {
     const char *xsrc, *wsrc;
-    dma_bases(cur, 0, xsrc, wsrc);
+    dma_bases(cur, chunk, xsrc, wsrc);
 #pragma unroll
     for (int it = 0; it < C::A_ITERS; ++it) dma_a(xsrc, it, 0);
 #pragma unroll
@@ -173,24 +191,31 @@ __global__ __launch_bounds__(512, 2) void conv_dma5_kernel(G5Args a) {
   }
 
   f32x4 acc[MT][4];
+  f32x4 tot[MODE == 1 ? MT : 1][4];      // MODE 1: the sum of the finished chunk groups
 #pragma unroll
   for (int i = 0; i < MT; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < (MODE == 1 ? MT : 1); ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) tot[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   // RESIDENT WEIGHTS (as generation 2 / 4): with one or two chunks per tile weight buffer p only ever holds chunk p's
   // weights -- of the same output-channel tile too when every workgroup of the XCD group keeps its tile residue
-  const bool resident = nchunks <= 2 && (nb % a.n_ct) == 0 && a.n_first == 0;  // (two problems: two sets of weights)
+  const bool resident = MODE != 2 && nchunks <= 2 && (nb % a.n_ct) == 0 && a.n_first == 0;  // (two problems: two sets of weights)
   int items_done = 0;
   // 16-byte store instructions per tile and wave: two per row, two per pooled row
-  const int nstores = (a.y != nullptr ? 2 * MT : 0) + (a.pooled != nullptr ? MT : 0);
+  const int nstores = MODE == 2 ? 4 * MT : (a.y != nullptr ? 2 * MT : 0) + (a.pooled != nullptr ? MT : 0);
   int in_flight = 0;  // stores issued after the last DMA of the previous item
 
   XV_CLK_BEGIN()
   while (true) {
     // This item's operands have landed (each wave retires its own DMA; the tile stores issued after it may stay in
     // flight: vmcnt counts in issue order), and every wave has finished reading the other buffer pair.
-    if (in_flight == 3 * MT)
+    if (in_flight == 4 * MT)
+      asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(4 * MT) : "memory");
+    else if (in_flight == 3 * MT)
       asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(3 * MT) : "memory");
     else if (in_flight == 2 * MT)
       asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(2 * MT) : "memory");
@@ -323,11 +348,12 @@ __global__ __launch_bounds__(512, 2) void conv_dma5_kernel(G5Args a) {
     G5_LDP(0, 0);
     __builtin_amdgcn_sched_barrier(0);
 
-    const bool last_chunk = chunk + 1 == nchunks;
+    // (MODE 2: an item ends with its chunk group)
+    const bool last_chunk = MODE == 2 ? (chunk + 1) % a.grp == 0 : chunk + 1 == nchunks;
     const int nlid = last_chunk ? lid + nb : lid;
     const bool has_next = nlid < t_end;
     const Tile nxt = (last_chunk && has_next) ? decode(nlid) : cur;
-    const int nchunk = last_chunk ? 0 : chunk + 1;
+    const int nchunk = last_chunk ? (MODE == 2 ? nxt.split * a.grp : 0) : chunk + 1;
     const char *nx_src = nullptr, *nw_src = nullptr;
     if (has_next) dma_bases(nxt, nchunk, nx_src, nw_src);
     const bool skip_b = resident && items_done >= 1;  // the NEXT item is this workgroup's third or later
@@ -336,7 +362,11 @@ __global__ __launch_bounds__(512, 2) void conv_dma5_kernel(G5Args a) {
     // in flight after each tap's wait (oldest first): see the header
     G5_TAP_HEAD0(G5_WAIT_WP)                 // [bias W0 P0]        -> all landed; then W1 requested
     asm volatile("" : "+v"(bvec[0]), "+v"(bvec[1]), "+v"(bvec[2]), "+v"(bvec[3]));
-    if (chunk == 0) {
+    if constexpr (MODE != 0) {
+      // a chunk group starts from the bias (group 0) or from zero
+      if (chunk != 0) bvec[0] = bvec[1] = bvec[2] = bvec[3] = u32x4{0u, 0u, 0u, 0u};
+    }
+    if (MODE != 0 ? chunk % a.grp == 0 : chunk == 0) {
       G5_TAP_BODY(0, G5_MFMA_B)
     } else {
       G5_TAP_BODY(0, G5_MFMA)
@@ -350,7 +380,29 @@ __global__ __launch_bounds__(512, 2) void conv_dma5_kernel(G5Args a) {
     G5_TAP(7, G5_WAIT_W, 4, )                // [W7 | W8]           -> W7
     G5_TAP(8, G5_WAIT_W, 0, )                // [W8]                -> W8
 
-    if (last_chunk) {
+    if constexpr (MODE == 1) {
+      if ((chunk + 1) % a.grp == 0) {       // a group is complete: out = ((g0 + g1) + g2) + ...  (plain fp32 adds, as the
+#pragma unroll                              //  reduction kernel of the split form makes them)
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) tot[i][j] = chunk + 1 == a.grp ? acc[i][j] : tot[i][j] + acc[i][j];
+      }
+    }
+    if constexpr (MODE == 2) {
+      if (last_chunk) {
+        // ---- item epilogue of the split form: the group's fp32 accumulators into this item's slab, 64 bytes per pixel and lane
+        float* slab = a.slabs + (int64_t)lid * (C::TH * C::TW * 64);
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+          float* dst = slab + ((MT * wave + i) * C::TW + n15) * 64 + 16 * g;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4*>(dst + 4 * j) = acc[i][j];
+        }
+        in_flight = nstores;
+        bslot ^= 1;
+      }
+    }
+    if (MODE != 2 && last_chunk) {
       // ---- tile epilogue: bias, relu, bf16; two 16-byte stores per row and the fused 2x2 max-pool ----
       const int px = cur.x0 + n15;
       const int py = cur.y0 + MT * wave;
@@ -382,7 +434,7 @@ __global__ __launch_bounds__(512, 2) void conv_dma5_kernel(G5Args a) {
 #pragma unroll
       for (int i = 0; i < MT; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) sv[i][r] = acc[i][r >> 2][r & 3];  // r = 4 j + q
+        for (int r = 0; r < 16; ++r) sv[i][r] = MODE == 1 ? tot[MODE == 1 ? i : 0][r >> 2][r & 3] : acc[i][r >> 2][r & 3];  // r = 4 j + q
       if constexpr (DG) {
         if (a.addend != nullptr) {  // added in fp32, before the one rounding (as every other generation)
 #pragma unroll
@@ -481,13 +533,45 @@ __global__ __launch_bounds__(512, 2) void conv_dma5_kernel(G5Args a) {
 #undef G5_TAP
 }
 
-template <int MT, bool DG = false>
+template <int MT, bool DG = false, int MODE = 0>
 int g5_launch(const G5Args& a, int grid, hipStream_t stream) {
   static bool attr_set[XV_MAX_DEVICES] = {false};
-  const hipError_t e = xv_allow_dynamic_lds(reinterpret_cast<const void*>(&conv_dma5_kernel<MT, DG>), G5<MT>::LDS_BYTES, attr_set);
+  const hipError_t e = xv_allow_dynamic_lds(reinterpret_cast<const void*>(&conv_dma5_kernel<MT, DG, MODE>), G5<MT>::LDS_BYTES, attr_set);
   if (e != hipSuccess) return (int)e;
-  hipLaunchKernelGGL((conv_dma5_kernel<MT, DG>), dim3((unsigned)grid), dim3(G5<MT>::NT), G5<MT>::LDS_BYTES, stream, a);
+  hipLaunchKernelGGL((conv_dma5_kernel<MT, DG, MODE>), dim3((unsigned)grid), dim3(G5<MT>::NT), G5<MT>::LDS_BYTES, stream, a);
   return xv_launch_status();
+}
+
+// The second half of the split form: out = relu(((g0 + g1) + g2) + ...) of a tile's slabs in group order (group 0 carries
+// the bias), rounded to bf16 once, into the padded map.  One thread per pixel and 8 channels (two 16-byte reads per group,
+// one 16-byte store).
+template <int MT>
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ slabs, char* __restrict__ y, int N, int H,
+                                                           int W, int Cout, int tiles_x, int tiles_y, int n_ct, int ngrp,
+                                                           int relu) {
+  constexpr int TH = 8 * MT, TW = 16, TPIX = TH * TW;
+  const int64_t total = (int64_t)N * H * W * (Cout >> 3);
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int c8 = (int)(i % (Cout >> 3));
+    int64_t r = i / (Cout >> 3);
+    const int px = (int)(r % W);
+    r /= W;
+    const int py = (int)(r % H);
+    const int n = (int)(r / H);
+    const int ty = py / TH, tx = px / TW, ct = c8 >> 3;
+    const int64_t tile = (((int64_t)n * tiles_y + ty) * tiles_x + tx) * n_ct + ct;
+    const float* src = slabs + (tile * ngrp) * (TPIX * 64) + ((py - ty * TH) * TW + (px - tx * TW)) * 64 + (c8 & 7) * 8;
+    f32x4 a0 = *reinterpret_cast<const f32x4*>(src), a1 = *reinterpret_cast<const f32x4*>(src + 4);
+    for (int s = 1; s < ngrp; ++s) {
+      const float* p = src + (int64_t)s * (TPIX * 64);
+      const f32x4 b0 = *reinterpret_cast<const f32x4*>(p), b1 = *reinterpret_cast<const f32x4*>(p + 4);
+      a0 = a0 + b0;
+      a1 = a1 + b1;
+    }
+    u32x4 o = {pack_bf16x2(a0.x, a0.y), pack_bf16x2(a0.z, a0.w), pack_bf16x2(a1.x, a1.y), pack_bf16x2(a1.z, a1.w)};
+    if (relu) o = u32x4{pk_max_i16(o.x, 0u), pk_max_i16(o.y, 0u), pk_max_i16(o.z, 0u), pk_max_i16(o.w, 0u)};
+    *reinterpret_cast<u32x4*>(y + ((((int64_t)n * (H + 2) + py + 1) * (W + 2) + px + 1) * Cout + c8 * 8) * 2) = o;
+  }
 }
 
 }  // namespace
@@ -499,8 +583,28 @@ bool xv_conv3x3_col_ok(int H, int W, int Cin, int Cout, int mt) {
          (Cout & 63) == 0;
 }
 
+// Chunks per group on this shape (= all of them: no grouping).  Groups of two from eight chunks on, on maps only generation 5
+// serves -- a function of the layer shape alone, never of the batch size: every launch of the layer adds in the same order.
+int xv_conv3x3_col_group(int H, int W, int Cin, int mt) {
+  const int nchunks = Cin / 32;
+  static const bool off = getenv("XV_COL_GROUPS") != nullptr && atoi(getenv("XV_COL_GROUPS")) == 0;
+  if (off || mt != 3 || ((H & 15) == 0 && (W & 31) == 0) || nchunks < 8 || (nchunks & 1)) return nchunks;
+  return 2;
+}
+
+// fp32 slabs of the split form: one per (tile, group); 0 where this shape / batch is not split (whole tiles fill at least
+// half the CUs, or the shape has no chunk groups)
+size_t xv_conv3x3_col_split_bytes(int N, int H, int W, int Cin, int Cout, int mt, int num_cus) {
+  if (!xv_conv3x3_col_ok(H, W, Cin, Cout, mt)) return 0;
+  const int grp = xv_conv3x3_col_group(H, W, Cin, mt), nchunks = Cin / 32;
+  const int64_t ntiles = (int64_t)(W / 16) * (H / (8 * mt)) * N * (Cout / 64);
+  if (grp == nchunks || 2 * ntiles >= num_cus) return 0;
+  return (size_t)ntiles * (nchunks / grp) * (8 * mt * 16 * 64) * sizeof(float);
+}
+
 int xv_launch_conv3x3_col(const void* x, const void* wpk, const float* bias, void* y, void* pooled, int N, int H, int W, int Cin,
-                          int Cout, int relu, int mt, int num_cus, hipStream_t stream, const void* mask, const void* addend) {
+                          int Cout, int relu, int mt, int num_cus, hipStream_t stream, const void* mask, const void* addend,
+                          void* split_ws, size_t split_bytes) {
   if (!xv_conv3x3_col_ok(H, W, Cin, Cout, mt) || (y == nullptr && pooled == nullptr) || (pooled != nullptr && (mt & 1)) ||
       ((mask != nullptr || addend != nullptr) && y == nullptr))
     return XV_ESHAPE;
@@ -522,6 +626,24 @@ int xv_launch_conv3x3_col(const void* x, const void* wpk, const float* bias, voi
   a.addend = (const char*)addend;
   const int grid = num_cus > 0 ? num_cus : 256;
   if (mask != nullptr || addend != nullptr) return mt == 3 ? g5_launch<3, true>(a, grid, stream) : g5_launch<4, true>(a, grid, stream);
+  a.grp = xv_conv3x3_col_group(H, W, Cin, mt);
+  a.ngrp = (Cin / 32) / a.grp;
+  if (a.ngrp > 1) {       // (mt == 3 only)
+    const size_t need = xv_conv3x3_col_split_bytes(N, H, W, Cin, Cout, mt, grid);
+    if (need > 0 && split_ws != nullptr && split_bytes >= need && pooled == nullptr && y != nullptr &&
+        ntiles * a.ngrp <= 0x7fffffff) {
+      a.slabs = (float*)split_ws;
+      a.n_tiles = (int)(ntiles * a.ngrp);
+      const int rc = g5_launch<3, false, 2>(a, grid, stream);
+      if (rc != XV_OK) return rc;
+      const int64_t total = (int64_t)N * H * W * (Cout / 8);
+      const int64_t blocks = (total + 255) / 256;
+      hipLaunchKernelGGL(splitk_reduce_kernel<3>, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, stream,
+                         (const float*)split_ws, (char*)y, N, H, W, Cout, a.tiles_x, a.tiles_y, a.n_ct, a.ngrp, relu);
+      return xv_launch_status();
+    }
+    return g5_launch<3, false, 1>(a, grid, stream);
+  }
   return mt == 3 ? g5_launch<3>(a, grid, stream) : g5_launch<4>(a, grid, stream);
 }
 
@@ -546,6 +668,9 @@ int xv_launch_conv3x3_col_pair(const void* const x[2], const void* const wpk[2],
   a.n_tiles = (int)ntiles;
   a.relu = relu;
   const int grid = num_cus > 0 ? num_cus : 256;
+  a.grp = xv_conv3x3_col_group(H, W, Cin, mt);
+  a.ngrp = (Cin / 32) / a.grp;
+  if (a.ngrp > 1) return g5_launch<3, false, 1>(a, grid, stream);      // the same chunk groups as a single problem
   return mt == 3 ? g5_launch<3>(a, grid, stream) : g5_launch<4>(a, grid, stream);
 }
 

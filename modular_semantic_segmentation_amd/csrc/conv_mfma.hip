@@ -49,7 +49,8 @@ void xv_launch_pack_weights_f8_g4(const float* w, char* out, int taps, int cin, 
 bool xv_conv3x3_col_ok(int H, int W, int Cin, int Cout, int mt);
 int xv_launch_conv3x3_col(const void* x, const void* wpk, const float* bias, void* y, void* pooled, int N, int H, int W, int Cin,
                           int Cout, int relu, int mt, int num_cus, hipStream_t stream, const void* mask = nullptr,
-                          const void* addend = nullptr);
+                          const void* addend = nullptr, void* split_ws = nullptr, size_t split_bytes = 0);
+size_t xv_conv3x3_col_split_bytes(int N, int H, int W, int Cin, int Cout, int mt, int num_cus);
 // two problems of one shape in one launch (generations 4 / 5)
 int xv_launch_conv3x3_dma4_pair(const void* const x[2], const void* const wpk[2], const float* const bias[2], void* const y[2],
                                 void* const pooled[2], int N, int H, int W, int Cin, int Cout, int relu, int num_cus,
@@ -81,6 +82,9 @@ struct ConvArgs {
   // generation 2, stream-K tail (see conv_dma_kernel): workspace of xv_conv2d_streamk_workspace_bytes() -- arrival counters
   // (zero between launches) + fp32 partial-tile slabs -- or null: every tile is computed whole by one workgroup
   char* sk_ws;
+  // generation 5, split form (conv_col_dma.hip, MODE 2): fp32 slabs for the (tile, chunk group) items, or null
+  void* split_ws;
+  size_t split_bytes;
 };
 
 // stream-K workspace: 8 x 64 arrival counters (4 KB header), then two partial-tile slabs per workgroup of the grid
@@ -2018,7 +2022,7 @@ int launch_cfg(int cfg, const ConvArgs& a, hipStream_t s) {
   if (cfg == 27 || cfg == 28) {
     if (KS != 3 || a.in_f8 || a.out_f8) return XV_ESHAPE;
     return xv_launch_conv3x3_col(a.x, a.wpk, a.bias, a.y, a.pooled, a.N, a.H, a.W, a.Cin, a.Cout, a.relu, cfg == 27 ? 3 : 4,
-                                 a.num_cus, s, a.mask, a.addend);
+                                 a.num_cus, s, a.mask, a.addend, a.split_ws, a.split_bytes);
   }
   if (a.in_f8) {
     // the fp8 kernel is built for the tile shapes with LDS-DMA weight stages (the ones the bf16 chooser falls back to)
@@ -2176,8 +2180,22 @@ int pick_cfg(const ConvArgs& a, int k) {
         if (i27 % a.num_cus == 0 && i26 % a.num_cus != 0) return 27;
       }
       if (gen4 && (!dg || (dgrad4 && a.pooled == nullptr)) && no_tail && !a.in_f8 && !a.out_f8 &&
-          xv_conv3x3_dma4_bf16_ok(a.H, a.W, a.Cin, a.Cout) && xv_conv3x3_dma4_exact(a.H, a.W) && (gen4 != 2 || a.Cin >= 128))
+          xv_conv3x3_dma4_bf16_ok(a.H, a.W, a.Cin, a.Cout) && xv_conv3x3_dma4_exact(a.H, a.W) && (gen4 != 2 || a.Cin >= 128)) {
+        // Latency rule (round 5, batch 1): below two rounds of 16x32 items a launch ends when its last round does, and the
+        // 24x16 tile of generation 5 (same loop, same bits) makes more and smaller items -- conv2_1 at one image: 288 items
+        // = 2 rounds of 512 pixels against 384 items = 2 rounds of 384; conv3_x / conv4_x: one round either way.
+        // tools/conv_tune.py --batch 1: conv2_1 694 against 571 TFLOP/s, conv3_2 974 / 840, conv4_2 578 / 486
+        // (profiles/r5_conv_tune_b1.txt).  The 24x16 tile is ~5 % slower per pixel once the chip is full.  XV_CFG_LATENCY=0: off.
+        static const bool latency_rule = getenv("XV_CFG_LATENCY") == nullptr || atoi(getenv("XV_CFG_LATENCY")) != 0;
+        if (latency_rule && a.pooled == nullptr && a.sk_ws == nullptr && items16 < 2 * (int64_t)a.num_cus &&
+            xv_conv3x3_col_ok(a.H, a.W, a.Cin, a.Cout, 3)) {
+          const int64_t items24 = (int64_t)a.N * (a.H / 24) * (a.W / 16) * (a.Cout / 64);
+          const double c26 = (double)((items16 + a.num_cus - 1) / a.num_cus) * 512.0;
+          const double c27 = (double)((items24 + a.num_cus - 1) / a.num_cus) * 384.0 / 0.95;
+          if (c27 < c26) return 27;
+        }
         return 26;
+      }
       // maps that tile in 24x16 but not in 16x32 (the 24x48 conv5 maps of a 768x384 input): the same loop on a column of
       // waves, generation 5 -- conv5_1 at 16 images 1 190 against 985 TFLOP/s on generation 2's 24x16 tile (configuration 22)
       if (gen4 && (!dg || dgrad4) && no_tail && !a.in_f8 && !a.out_f8 && a.pooled == nullptr &&
@@ -2203,7 +2221,8 @@ size_t streamk_workspace_bytes() { return (size_t)XV_SK_HDR + (size_t)2 * xv_num
 
 int conv_fwd_impl(const xv_act* x, const void* w_packed, const float* bias, const xv_act* y, const xv_act* pooled,
                   int k, int relu, int cfg, void* stream, const __bf16* mask = nullptr,
-                  const __bf16* addend = nullptr, void* workspace = nullptr, size_t workspace_bytes = 0) {
+                  const __bf16* addend = nullptr, void* workspace = nullptr, size_t workspace_bytes = 0,
+                  void* split_ws = nullptr, size_t split_bytes = 0) {
   XV_CHECK_ARG(x && x->data && w_packed && bias && y);
   XV_CHECK_ARG(y->data || (pooled && pooled->data));
   XV_CHECK_SHAPE(k == 1 || k == 3);
@@ -2240,6 +2259,10 @@ int conv_fwd_impl(const xv_act* x, const void* w_packed, const float* bias, cons
     XV_CHECK_ARG(((uintptr_t)workspace & 15) == 0);
     if (workspace_bytes < streamk_workspace_bytes()) return XV_EWORKSPACE;
     a.sk_ws = (char*)workspace;
+  }
+  if (split_ws != nullptr) {
+    XV_CHECK_ARG(((uintptr_t)split_ws & 15) == 0);
+    a.split_ws = split_ws, a.split_bytes = split_bytes;
   }
   if (pooled && pooled->data) {
     XV_CHECK_SHAPE(k == 3 && (x->h & 1) == 0 && (x->w & 1) == 0);
@@ -2464,6 +2487,21 @@ extern "C" int xv_conv2d_fwd_ws(const xv_act* x, const void* w_packed, const flo
                                 const xv_act* pooled, int k, int relu, int cfg, void* workspace, size_t workspace_bytes,
                                 void* stream) {
   return conv_fwd_impl(x, w_packed, bias, y, pooled, k, relu, cfg, stream, nullptr, nullptr, workspace, workspace_bytes);
+}
+
+// Forward conv with a workspace for the SPLIT form of generation 5 (conv_col_dma.hip: layers whose whole tiles fill less than
+// half the CUs -- conv5_x of a 768x384 input at one or two images -- run one work item per (tile, chunk group) and add the
+// groups' fp32 slabs in a second launch; the same bits as the unsplit launch of the same layer at any batch size).
+extern "C" size_t xv_conv2d_split_workspace_bytes(int n, int h, int w, int cin, int cout) {
+  if (!xv_dims_sane(n, h, w) || cin <= 0 || cout <= 0) return 0;
+  return xv_conv3x3_col_split_bytes(n, h, w, cin, cout, 3, xv_num_cus());
+}
+
+extern "C" int xv_conv2d_fwd_split(const xv_act* x, const void* w_packed, const float* bias, const xv_act* y,
+                                   const xv_act* pooled, int k, int relu, int cfg, void* split_workspace,
+                                   size_t split_workspace_bytes, void* stream) {
+  return conv_fwd_impl(x, w_packed, bias, y, pooled, k, relu, cfg, stream, nullptr, nullptr, nullptr, 0, split_workspace,
+                       split_workspace_bytes);
 }
 
 extern "C" int xv_conv2d_bwd_data_ws(const xv_act* dy, const void* w_packed_dgrad, const float* zero_bias,

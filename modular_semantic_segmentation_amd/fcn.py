@@ -404,7 +404,8 @@ class FcnEngine(object):
             name = ENCODER[idx][0]
             y, q = self._layer_outputs(st, idx)
             ops.conv2d_fwd(st['cur'], self.w[name], self.b[name], 3, relu=True, y=y, pooled=q, write_y=y is not None,
-                           workspace=self._sk())
+                           workspace=self._sk(),
+                           split_ws=ops.split_workspace(st['cur'], ENCODER[idx][1], self._arena) if q is None else None)
             self._layer_done(st, idx, y, q)
 
     def pairable(self):

@@ -125,10 +125,25 @@ def streamk_workspace(device):
     return torch.zeros(_lib.lib().xv_conv2d_streamk_workspace_bytes(), dtype=torch.uint8, device=device)
 
 
-def conv2d_fwd(x, w_packed, bias, k, relu=True, y=None, pooled=None, write_y=True, cfg=-1, workspace=None):
+def split_workspace(x, cout, arena, key='split_ws'):
+    """The fp32 slab workspace of the split form for a 3x3 conv of Act x onto `cout` channels (xv_conv2d_split_workspace_bytes),
+    kept in the caller's `arena` dict under `key` and grown as needed; None where this shape / batch is never split.  One per
+    stream: the launch owns it until it has completed."""
+    need = _lib.lib().xv_conv2d_split_workspace_bytes(x.n, x.h, x.w, x.c, cout)
+    if need == 0:
+        return None
+    ws = arena.get(key)
+    if ws is None or ws.numel() * 4 < need:
+        ws = arena[key] = torch.empty((need + 3) // 4, dtype=torch.float32, device=x.t.device)
+    return ws
+
+
+def conv2d_fwd(x, w_packed, bias, k, relu=True, y=None, pooled=None, write_y=True, cfg=-1, workspace=None, split_ws=None):
     """x: Act; returns (y Act or None, pooled Act or None).  An fp8 `x` needs weights from pack_conv_weights_f8; the
     dtype / scale of y and pooled (which must agree) select the output conversion.  workspace (streamk_workspace): the
-    generation-2 kernel deals the items of an incomplete last round of tiles out over all CUs (stream-K tail)."""
+    generation-2 kernel deals the items of an incomplete last round of tiles out over all CUs (stream-K tail).  split_ws
+    (split_workspace): layers whose tiles fill less than half the CUs run in the split form of the 24x16-tile kernel (batch-1
+    latency; the same bits as the unsplit launch)."""
     cout = bias.numel()
     _need(bias, torch.float32, 'bias')
     if y is None and write_y:
@@ -141,7 +156,11 @@ def conv2d_fwd(x, w_packed, bias, k, relu=True, y=None, pooled=None, write_y=Tru
     if prof is not None:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
-    if workspace is None:
+    if workspace is None and split_ws is not None:
+        rc = _lib.lib().xv_conv2d_fwd_split(x.xv(), _ptr(w_packed), _ptr(bias), ctypes.byref(ydesc),
+                                           pooled.xv() if pooled is not None else _NULL_ACT, k, int(bool(relu)), int(cfg),
+                                           _ptr(split_ws), split_ws.numel() * split_ws.element_size(), _stream())
+    elif workspace is None:
         rc = _lib.lib().xv_conv2d_fwd_cfg(x.xv(), _ptr(w_packed), _ptr(bias), ctypes.byref(ydesc),
                                          pooled.xv() if pooled is not None else _NULL_ACT, k, int(bool(relu)), int(cfg),
                                          _stream())

@@ -365,6 +365,12 @@ def test_data_gradient_epilogue_on_generation4_and_5(ops, shape):
     add = ops.Act.from_dense(_dev(rng.integers(-3, 4, (n, h, w, cin)).astype(np.float32)))
     zb = torch.zeros(cin, device='cuda')
     want_cfg = 26 if (h % 16 == 0 and w % 32 == 0) else (27 if (h % 24 == 0 and w % 16 == 0) else None)
+    if want_cfg == 26 and h % 24 == 0 and w % 16 == 0:
+        # the latency rule (round 5): below two rounds of 16x32 items the 24x16 tile's smaller items end sooner
+        cus = torch.cuda.get_device_properties(0).multi_processor_count
+        i16, i24 = n * (h // 16) * (w // 32) * (cin // 64), n * (h // 24) * (w // 16) * (cin // 64)
+        if i16 < 2 * cus and -(-i24 // cus) * 384 / 0.95 < -(-i16 // cus) * 512:
+            want_cfg = 27
     got_cfg = _lib.lib().xv_conv2d_choose_cfg(n, h, w, cout, cin, 3, 0, 0, 2)
     if want_cfg is not None:
         assert got_cfg == want_cfg, (got_cfg, want_cfg)
@@ -707,3 +713,56 @@ def test_pack_table_matches_single_layer_packers(ops):
         assert torch.equal(fwd.view(torch.int16), wf.view(torch.int16)), tuple(w.shape)
         assert torch.equal(bwd.view(torch.int16), wb.view(torch.int16)), tuple(w.shape)
     assert torch.equal(fwd_only.view(torch.int16), want[1][0].view(torch.int16))
+
+
+def test_conv2d_chunk_groups_and_split_form_agree_bit_for_bit(ops):
+    """Generation 5 on the shapes only it serves (24x48 conv5 maps, 512 channels: conv_col_dma.hip round 5): the sum over
+    input channels goes by chunk GROUPS, in registers for a full chip (MODE 1) and as one work item per (tile, group) plus a
+    reduction launch where the tiles fill less than half the CUs (MODE 2, the batch-1 latency form).  Both add the same
+    groups in the same order: exact on integers against the oracle, and -- on random operands -- the split launch of ONE image
+    equals that image inside a batch of 12 (unsplit) bit for bit."""
+    from modular_semantic_segmentation_amd import _lib
+    lib = _lib.lib()
+    h, w, cin, cout = 24, 48, 512, 512
+    assert lib.xv_conv2d_split_workspace_bytes(1, h, w, cin, cout) == 24 * 8 * 24 * 16 * 64 * 4     # 24 tiles x 8 groups
+    assert lib.xv_conv2d_split_workspace_bytes(2, h, w, cin, cout) == 2 * 24 * 8 * 24 * 16 * 64 * 4
+    assert lib.xv_conv2d_split_workspace_bytes(12, h, w, cin, cout) == 0                            # 288 tiles: whole tiles
+    assert lib.xv_conv2d_split_workspace_bytes(1, 48, 96, cin, cout) == 0                           # tiles in 16x32: no groups
+    assert lib.xv_conv2d_split_workspace_bytes(1, h, w, 128, cout) == 0                             # four chunks: no groups
+    rng = np.random.default_rng(12)
+    arena = {}
+    for exact in (True, False):
+        if exact:
+            x = rng.integers(-2, 3, (12, h, w, cin)).astype(np.float32)
+            wt = rng.integers(-1, 2, (3, 3, cin, cout)).astype(np.float32)
+            b = rng.integers(-3, 4, cout).astype(np.float32)
+        else:
+            x = rng.standard_normal((12, h, w, cin)).astype(np.float32)
+            wt = (rng.standard_normal((3, 3, cin, cout)) / np.sqrt(9 * cin)).astype(np.float32)
+            b = rng.standard_normal(cout).astype(np.float32)
+        wp, bd = ops.pack_conv_weights(_dev(wt)), _dev(b)
+        xa = ops.Act.from_dense(_dev(x))
+        y_batch, _ = ops.conv2d_fwd(xa, wp, bd, 3, relu=True)                       # 288 tiles: chunk groups in registers
+        for n in (1, 2):
+            xs = ops.Act.from_dense(_dev(x[:n]))
+            ws = ops.split_workspace(xs, cout, arena)
+            assert ws is not None
+            y_split, _ = ops.conv2d_fwd(xs, wp, bd, 3, relu=True, split_ws=ws)      # the split form
+            y_plain, _ = ops.conv2d_fwd(xs, wp, bd, 3, relu=True)                   # no workspace: groups in registers
+            torch.cuda.synchronize()
+            assert torch.equal(y_split.t, y_plain.t)
+            assert torch.equal(y_split.interior(), y_batch.interior()[:n])
+            full = y_split.t.float().cpu().numpy()
+            assert np.all(full[:, 0] == 0) and np.all(full[:, -1] == 0) and np.all(full[:, :, 0] == 0) and np.all(full[:, :, -1] == 0)
+        _, ref = _conv_oracle(x[:2], wt, b, True, 3)
+        got = y_batch.interior()[:2].float().cpu().numpy()
+        if exact:
+            assert np.array_equal(got, ref)
+        else:
+            assert np.abs(got - ref).max() <= 2 ** -7 * np.abs(ref).max()           # bf16 output rounding
+    # no relu: negative outputs survive the reduction launch
+    xs = ops.Act.from_dense(_dev(x[:1]))
+    y0, _ = ops.conv2d_fwd(xs, wp, bd, 3, relu=False, split_ws=ops.split_workspace(xs, cout, arena))
+    y1, _ = ops.conv2d_fwd(xs, wp, bd, 3, relu=False)
+    torch.cuda.synchronize()
+    assert torch.equal(y0.t, y1.t) and bool((y0.interior() < 0).any())
