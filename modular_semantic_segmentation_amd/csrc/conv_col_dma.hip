@@ -587,9 +587,11 @@ bool xv_conv3x3_col_ok(int H, int W, int Cin, int Cout, int mt) {
 // serves -- a function of the layer shape alone, never of the batch size: every launch of the layer adds in the same order.
 int xv_conv3x3_col_group(int H, int W, int Cin, int mt) {
   const int nchunks = Cin / 32;
-  static const bool off = getenv("XV_COL_GROUPS") != nullptr && atoi(getenv("XV_COL_GROUPS")) == 0;
-  if (off || mt != 3 || ((H & 15) == 0 && (W & 31) == 0) || nchunks < 8 || (nchunks & 1)) return nchunks;
-  return 2;
+  // XV_COL_GROUPS=<chunks per group> (0: no groups) for A/B timing; the default of four chunks keeps the fp32 slabs of the
+  // split form (98 KB per item, written and read once) at half the bytes of two-chunk groups
+  static const int env = getenv("XV_COL_GROUPS") != nullptr ? atoi(getenv("XV_COL_GROUPS")) : 4;
+  if (env <= 0 || mt != 3 || ((H & 15) == 0 && (W & 31) == 0) || nchunks < 8 || (nchunks % env) != 0) return nchunks;
+  return env;
 }
 
 // fp32 slabs of the split form: one per (tile, group); 0 where this shape / batch is not split (whole tiles fill at least

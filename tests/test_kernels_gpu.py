@@ -724,8 +724,8 @@ def test_conv2d_chunk_groups_and_split_form_agree_bit_for_bit(ops):
     from modular_semantic_segmentation_amd import _lib
     lib = _lib.lib()
     h, w, cin, cout = 24, 48, 512, 512
-    assert lib.xv_conv2d_split_workspace_bytes(1, h, w, cin, cout) == 24 * 8 * 24 * 16 * 64 * 4     # 24 tiles x 8 groups
-    assert lib.xv_conv2d_split_workspace_bytes(2, h, w, cin, cout) == 2 * 24 * 8 * 24 * 16 * 64 * 4
+    assert lib.xv_conv2d_split_workspace_bytes(1, h, w, cin, cout) == 24 * 4 * 24 * 16 * 64 * 4     # 24 tiles x 4 groups
+    assert lib.xv_conv2d_split_workspace_bytes(2, h, w, cin, cout) == 2 * 24 * 4 * 24 * 16 * 64 * 4
     assert lib.xv_conv2d_split_workspace_bytes(12, h, w, cin, cout) == 0                            # 288 tiles: whole tiles
     assert lib.xv_conv2d_split_workspace_bytes(1, 48, 96, cin, cout) == 0                           # tiles in 16x32: no groups
     assert lib.xv_conv2d_split_workspace_bytes(1, h, w, 128, cout) == 0                             # four chunks: no groups
