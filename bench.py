@@ -706,8 +706,7 @@ def main():
                      '%.1f s; value and ms_per_step are the MEDIAN block' % args.min_seconds)
     if args.dtype == 'fp8':
         res['config']['conv_dtype'] = ('e4m3 operands from conv1_2 on (fp8_deep), conv1_1 fp32 -> e4m3' if args.fp8_deep else
-                                       'e4m3 operands from conv2_1 on, conv1_1 fp32, '
-                                       'conv1_2 bf16 -> e4m3')
+                                       'e4m3 operands from conv2_2 on, conv1_1 fp32, conv1_2 bf16, conv2_1 bf16 -> e4m3')
     if args.expert == 'adapnet':
         res['metric'] = 'images/sec at %dx%d RGB-D, two AdapNet experts + %s fusion + argmax (inference)' % (
             args.width, args.height, args.fusion)

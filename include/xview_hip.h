@@ -260,6 +260,13 @@ int xv_space_to_depth(const xv_act* g, int stride, const xv_act* out, void* stre
 int xv_space_to_depth_dense(const float* g, int num_classes, int stride, const xv_act* out, void* stream);
 int xv_depth_to_space_dense(const xv_act* z, int stride, int num_classes, const float* scale, const float* shift,
                             float* out, void* stream);
+/* The float32 route of AdapNet's trained x8 score deconv (adapnet.py:155-163 computes the class scores in float32): the
+ * padded bf16 map as a dense float32 one (exact), the 3x3 conv onto the 64 phases x Cp classes through xv_conv2d_f32 (fp32
+ * matrix instruction), and the phases unshuffled from the dense float32 phase map [n][hq][wq][stride*stride*cp]
+ * (cp a multiple of 4) [* scale + shift] -- no bf16 rounding between the deconv and the batch norm / softmax.          */
+int xv_act_to_dense_f32(const xv_act* x, float* out, void* stream);
+int xv_depth_to_space_dense_f32(const float* z, int n, int hq, int wq, int stride, int cp, int num_classes, const float* scale,
+                                const float* shift, float* out, void* stream);
 
 /* Decoder head: upscore = relu(bilinear_x8(fused)) (deconv2d k=16 s=8, simple_fcn.py:129-130),
  * score = conv1x1(upscore, Ws) + bs (no activation, simple_fcn.py:131-133), prob = softmax(score),

@@ -72,6 +72,8 @@ SIGNATURES = {
     'xv_space_to_depth': (_i, [_actp, _i, _actp, _vp]),
     'xv_space_to_depth_dense': (_i, [_vp, _i, _i, _actp, _vp]),
     'xv_depth_to_space_dense': (_i, [_actp, _i, _i, _vp, _vp, _vp, _vp]),
+    'xv_act_to_dense_f32': (_i, [_actp, _vp, _vp]),
+    'xv_depth_to_space_dense_f32': (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     'xv_decoder_head_workspace_bytes': (ctypes.c_size_t, [_i, _i, _i, _i]),
     'xv_decoder_head_fwd': (_i, [_actp, _vp, _vp, _i, _vp, _vp, _vp, _vp, ctypes.c_size_t, _vp]),
     'xv_decoder_head_affine_fwd': (_i, [_actp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp]),

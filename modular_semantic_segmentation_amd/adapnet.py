@@ -228,8 +228,8 @@ class AdapnetEngine(object):
             self.Cp = (self.C + 7) // 8 * 8
             kp = np.zeros((16, 16, self.Cp, self.Up), np.float32)
             kp[:, :, :self.C, :self.U] = w2
-            self.dense['second'] = (ops.pack_conv_weights(up(dense_deconv_as_conv3x3(kp, 8))),
-                                    torch.zeros(64 * self.Cp, dtype=torch.float32, device=dev), up(s), up(t))
+            # (the derived 3x3 kernel stays float32: the class scores are computed in float32, ops.deconv8_scores_f32)
+            self.dense['second'] = (up(dense_deconv_as_conv3x3(kp, 8)), None, up(s), up(t))
         # bilinear constant: score = bilinear_x8(merge[..., :C]) * s + t, a diagonal score "conv" in front of the
         # interpolation (kept in both cases: the trainer reads its shapes)
         ws = np.zeros((self.Up, self.C), np.float32)
@@ -305,13 +305,11 @@ class AdapnetEngine(object):
         L = self.trunk(x)
         m = L['merge']
         if 'second' in self.dense:
-            wk, zb, sc, sh = self.dense['second']
-            zph = self._act('score_phases', m.n, m.h, m.w, 64 * self.Cp)
-            ops.conv2d_fwd(m, wk, zb, 3, relu=False, y=zph)
+            wk, _, sc, sh = self.dense['second']
             skey = ('dense_score', m.n, m.h, m.w)
             if skey not in self._arena:
                 self._arena[skey] = torch.empty((m.n, 8 * m.h, 8 * m.w, self.C), dtype=torch.float32, device=self.device)
-            score = ops.depth_to_space_dense(zph, 8, self.C, self._arena[skey], scale=sc, shift=sh)
+            score = ops.deconv8_scores_f32(m, wk, self.C, self.Cp, self._arena[skey], self._arena, scale=sc, shift=sh)
             want_label = 'label' in want or 'classification' in want
             prob, label = (ops.softmax_argmax(score, want_prob='prob' in want, want_label=want_label)
                            if ('prob' in want or want_label) else (None, None))

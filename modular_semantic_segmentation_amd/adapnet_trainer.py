@@ -219,7 +219,11 @@ class AdapnetTrainer(object):
         for scope in list(self.units) + [d[0] for d in DECONVS]:
             if scope == 'block_0_1' or '/stage_2_' in scope:
                 continue
-            self._pack(scope, self._kernel_for(scope))
+            kernel = self._kernel_for(scope)
+            self._pack(scope, kernel)
+            if scope == 'second_deconvolution_upconv':
+                # the class scores are computed in float32 (ops.deconv8_scores_f32): keep the derived 3x3 kernel as it is
+                self.w32_scores = kernel.contiguous()
         for name, kind, _ in self.blocks:
             if kind == 'b':
                 self._pack(name + '/stage_2', self._pair_kernel(name))
@@ -428,10 +432,10 @@ class AdapnetTrainer(object):
         merge = residual('deconv_1', y_up, 'shortcut', shortcut, 'merge')
         # ---- head: x8 transposed conv [16,16,C,U] (3x3 conv onto 64 phases x Cp classes at 1/8 resolution, shuffled
         # straight into dense float32 scores), batch norm, softmax cross-entropy ---------------------------------------
-        zph = ops.conv2d_fwd(merge, self.w[su], self.zeros[:64 * self.Cp], 3, relu=False,
-                             y=self._act('zph_score', merge.n, merge.h, merge.w, 64 * self.Cp))[0]
+        # (float32: the reference computes these scores in float32, adapnet.py:155-163 -- through a bf16 phase map they were
+        # rounded to 8 bits in front of the batch norm and the softmax; the backward pass keeps the bf16 MFMA convs)
+        raw = ops.deconv8_scores_f32(merge, self.w32_scores, e.C, self.Cp, self._dense('score_raw', (n, h, w, e.C)), self._a)
         wneed[0] = max(wneed[0], ops.conv2d_bwd_filter_workspace_bytes(merge, 64 * self.Cp, 3))
-        raw = ops.depth_to_space_dense(zph, 8, e.C, self._dense('score_raw', (n, h, w, e.C)))
         mm, mv = self.moving[su]
         logits = ops.bn_dense_forward(raw, P(su, 'gamma'), P(su, 'beta'), mm, mv, self.bn[su],
                                       self._dense('logits', (n, h, w, e.C)), sync=self._sync)

@@ -39,6 +39,8 @@ def engine_options(config):
             opts['streamk'] = True
         if config.get('fp8_deep', False):
             opts['fp8_deep'] = True
+        if config.get('fp8_start'):
+            opts['fp8_start'] = config['fp8_start']     # a layer name, or {prefix: layer name} per expert
     return opts
 
 

@@ -1404,422 +1404,6 @@ int launch_conv_dma(const ConvArgs& a0, hipStream_t stream) {
   return xv_launch_status();
 }
 
-// =================================================================================================
-// Generation 2b (configuration 21): conv_dma_kernel with the item boundary moved INSIDE the last tap.
-// Same tile, LDS images, DMA forms, epilogue and store phases; what changes is where the workgroup barrier sits and
-// when the next item's first fragments are requested (see the comment at `item` below).
-template <int WR, int WC>
-__global__ __launch_bounds__(64 * WR * WC, 2) void conv_dma2_kernel(ConvArgs a) {
-  using C = DmaCfg<WR, WC>;
-  constexpr int MT = C::MT;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wr = wave / WC, wc = wave % WC;
-  const int l15 = lane & 15, lg = lane >> 4;
-  const int H = a.H, W = a.W, Cin = a.Cin, Cout = a.Cout;
-  const int Wp = W + 2;
-  const int nchunks = Cin >> 5;
-
-  const int G = gridDim.x, b = blockIdx.x;
-  const int xcd = b & 7, bi = b >> 3;
-  const int nb = (G - xcd + 7) >> 3;
-  const int T = a.n_tiles;
-  const int tq = T >> 3, trm = T & 7;
-  const int t_begin = xcd * tq + (xcd < trm ? xcd : trm);
-  const int t_end = t_begin + tq + (xcd < trm ? 1 : 0);
-
-  struct Tile {
-    int n, y0, x0, co0;
-  };
-  auto decode = [&](int lid) {
-    Tile t;
-    t.co0 = (lid % a.n_ct) * 64;
-    int r = lid / a.n_ct;
-    t.x0 = (r % a.tiles_x) * C::TW;
-    r /= a.tiles_x;
-    t.y0 = (r % a.tiles_y) * C::TH;
-    t.n = r / a.tiles_y;
-    return t;
-  };
-
-  // per-lane source offsets (bytes, relative to the patch origin) of the patch pieces this wave moves: LDS
-  // granule g = piece*64 + lane holds physical slot g&3 of pixel g>>2
-  int aoff[C::A_ITERS];
-  int ayx[C::A_ITERS];  // hy << 16 | hx of the granule: what an edge tile re-derives its clamped offset from
-#pragma unroll
-  for (int it = 0; it < C::A_ITERS; ++it) {
-    const int g = (wave + it * C::NWAVES) * 64 + lane;
-    int p = g >> 2;
-    p = p < C::NPIX ? p : C::NPIX - 1;
-    const int hy = p / C::HW, hx = p - hy * C::HW;
-    aoff[it] = ((hy * Wp + hx) * Cin + xv_swz32(hx, g & 3) * 8) * 2;
-    ayx[it] = (hy << 16) | hx;
-  }
-  int pbase[3];
-#pragma unroll
-  for (int dx = 0; dx < 3; ++dx) {
-    const int hx = wc * 16 + l15 + dx;
-    pbase[dx] = ((wr * MT) * C::HW + hx) * 64 + (xv_swz32(hx, lg) << 4);
-  }
-  const int wbase = 2 * C::A_BYTES + l15 * 64 + (xv_swz32(l15, lg) << 4);
-  const int64_t tap_pitch = (int64_t)nchunks * Cout * 64;  // bytes between taps of the packed image
-  // channel offset of this lane's 16-byte output piece inside a 32-channel pair (see xv_pair16)
-  const int csub = (lg & 1) * 16 + (lg >> 1) * 8;
-
-  // One work item's operands = A_ITERS patch pieces + B_ITERS weight pieces per wave (1 KB each) + the tile's
-  // bias.  The CU's vector-memory pipe takes ~25 cycles per piece and a wave whose DMA does not fit its queue
-  // stalls in order, MFMAs included (measured: ~200 cycles per DMA when all ten were issued in one burst), so
-  // the pieces are issued one patch + one weight piece per tap over the first taps of the PREVIOUS item.
-  // The DMA is written in assembly: `global_load_lds` in its SGPR-base + 32-bit-VGPR-offset form keeps ONE offset
-  // register per patch piece (the builtin wants a 64-bit flat pointer per lane) and keeps the instruction out of the
-  // compiler's waitcnt model, which treats an LDS-DMA as a FLAT access and drains counters around it.  M0 (LDS
-  // destination of the wave) is set inside the statement; nothing else in this kernel uses M0.
-  auto dma16 = [&](const char* sbase, int voff, int lds_off) {
-    asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_off), "v"(voff), "s"(sbase) : "memory");
-  };
-  const int lane16 = lane * 16;
-  auto dma_bases = [&](const Tile& t, int chunk, const char*& xsrc, const char*& wsrc) {
-    xsrc = reinterpret_cast<const char*>(a.x) + ((((int64_t)t.n * (H + 2) + t.y0) * Wp + t.x0) * Cin + chunk * 32) * 2;
-    if (a.debug_same_patch & 1) xsrc = reinterpret_cast<const char*>(a.x) + (int64_t)(chunk * 32) * 2;  // (results are wrong: timing only)
-    wsrc = reinterpret_cast<const char*>(a.wpk) + (((int64_t)chunk * Cout + t.co0) << 6);
-  };
-  // edge tiles (the patch reaches past the padded image): patch coordinates are clamped onto the zero border, i.e.
-  // the source offset is recomputed with hy <= ylim, hx <= xlim; the LDS position (and its swizzle) is unchanged
-  auto dma_a = [&](const char* xsrc, int it, int buf, bool edge, int ylim, int xlim) {
-    const int piece = wave + it * C::NWAVES;
-    if (piece < C::A_PIECES) {
-      int voff = aoff[it];
-      if (edge) {
-        // the clamped-offset arithmetic stays inside this (rare) path: hoisted out of the item loop by the compiler it
-        // held 15 registers for the whole kernel
-        int yx = ayx[it];
-        asm volatile("" : "+v"(yx));
-        const int hy = yx >> 16, hx = yx & 0xffff;
-        const int g = piece * 64 + lane;
-        voff = (((hy < ylim ? hy : ylim) * Wp + (hx < xlim ? hx : xlim)) * Cin + xv_swz32(hx, g & 3) * 8) * 2;
-      }
-      dma16(xsrc, voff, buf * C::A_BYTES + piece * 1024);
-    }
-  };
-  auto dma_b = [&](const char* wsrc, int it, int buf) {
-    const int piece = wave + it * C::NWAVES;
-    if (piece < C::B_PIECES)
-      dma16(wsrc + (piece >> 2) * tap_pitch + (piece & 3) * 1024, lane16, 2 * C::A_BYTES + buf * C::B_BYTES + piece * 1024);
-  };
-  // the tile's 64 bias values ride along with its first chunk (one 4-byte-per-lane DMA by the last wave)
-  auto dma_bias = [&](const Tile& t, int chunk, int bslot) {
-    if (chunk == 0 && wave == C::NWAVES - 1)
-      asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dword %1, %2" ::"s"(C::BIAS_OFF + bslot * 256), "v"(lane * 4),
-                   "s"(a.bias + t.co0)
-                   : "memory");
-  };
-  auto issue_all = [&](const Tile& t, int chunk, int buf, int bslot) {
-    const char *xsrc, *wsrc;
-    dma_bases(t, chunk, xsrc, wsrc);
-#pragma unroll
-    for (int it = 0; it < C::A_ITERS; ++it)
-      dma_a(xsrc, it, buf, t.y0 + C::TH > H || t.x0 + C::TW > W, H + 1 - t.y0, W + 1 - t.x0);
-#pragma unroll
-    for (int it = 0; it < C::B_ITERS; ++it) dma_b(wsrc, it, buf);
-    dma_bias(t, chunk, bslot);
-  };
-  // DMA of the next item: patch pieces two per tap from tap 0, weight pieces one per tap from tap 1 -- everything is in
-  // flight by tap LAST_DMA_TAP and has taps LAST_DMA_TAP+1 .. 7 to land before the barrier inside tap 8
-  constexpr int A_TAPS = (C::A_ITERS + 1) / 2;
-  constexpr int B_TAP0 = XV_D2_BTAP0, B_PER_TAP = XV_D2_BPT;
-  constexpr int B_LAST = B_TAP0 + (C::B_ITERS + B_PER_TAP - 1) / B_PER_TAP - 1;
-  constexpr int LAST_DMA_TAP = (A_TAPS - 1 > B_LAST) ? A_TAPS - 1 : B_LAST;
-  static_assert(LAST_DMA_TAP <= 6, "the DMA needs taps to land in before the tap-8 barrier");
-  // full-map tile: store pieces 0..7 leave in taps 1..8; those of taps LAST_DMA_TAP+1..8 are younger than every DMA
-  constexpr int YTAIL = 8 - LAST_DMA_TAP;
-
-  int lid = t_begin + bi;
-  if (lid >= t_end) return;
-  Tile cur = decode(lid);
-  int chunk = 0, buf = 0, bslot = 0;
-
-  f32x4 acc[MT][4];
-#pragma unroll
-  for (int i = 0; i < MT; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-  u32x2 pq[MT][4];
-  const uint32_t rfloor = a.relu ? 0u : 0x80008000u;
-  DmaPend pend{0, 0, 0, 0, false};
-  const int npieces = a.y != nullptr ? 2 * MT : MT;  // 16-byte store instructions per tile and wave
-  issue_all(cur, 0, 0, 0);
-
-  // Fragment registers live across items: the first fragments of item i+1 are requested inside tap 8 of item i.
-  bf16x8 wf[2][4], xf[2][MT + 2];
-  static_assert(MT == 4, "operand lists below");
-  constexpr int PROW = C::HW * 64;
-#define XV_LDS128(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
-  // t = dx*3 + dy  ->  packed tap dy*3 + dx
-#define XV_LDW(wbv, t, set)                                                     \
-  {                                                                             \
-    constexpr int tap_ = (((t) % 3) * 3 + (t) / 3) * 4096;                       \
-    XV_LDS128(wf[set][0], wbv, tap_);                                           \
-    XV_LDS128(wf[set][1], wbv, tap_ + 1024);                                    \
-    XV_LDS128(wf[set][2], wbv, tap_ + 2048);                                    \
-    XV_LDS128(wf[set][3], wbv, tap_ + 3072);                                    \
-  }
-#define XV_LDP(pbv, set)                     \
-  {                                          \
-    XV_LDS128(xf[set][0], pbv, 0);           \
-    XV_LDS128(xf[set][1], pbv, PROW);        \
-    XV_LDS128(xf[set][2], pbv, 2 * PROW);    \
-    XV_LDS128(xf[set][3], pbv, 3 * PROW);    \
-    XV_LDS128(xf[set][4], pbv, 4 * PROW);    \
-    XV_LDS128(xf[set][5], pbv, 5 * PROW);    \
-  }
-  // at most n newer reads outstanding: wf[ws] (and xf[ps]) have landed
-#define XV_WAIT_W(n, ws)                                                                           \
-  asm volatile("s_waitcnt lgkmcnt(%4)"                                                             \
-               : "+v"(wf[ws][0]), "+v"(wf[ws][1]), "+v"(wf[ws][2]), "+v"(wf[ws][3])                 \
-               : "n"(n))
-#define XV_WAIT_WP(n, ws, ps)                                                                      \
-  asm volatile("s_waitcnt lgkmcnt(%10)"                                                            \
-               : "+v"(wf[ws][0]), "+v"(wf[ws][1]), "+v"(wf[ws][2]), "+v"(wf[ws][3]), "+v"(xf[ps][0]), \
-                 "+v"(xf[ps][1]), "+v"(xf[ps][2]), "+v"(xf[ps][3]), "+v"(xf[ps][4]), "+v"(xf[ps][5])  \
-               : "n"(n))
-#define XV_STORE_PIECE(p)                                                                          \
-  if ((p) >= 0 && (p) < 2 * MT && stores_now > (p)) {                                              \
-    const u32x4 o_ = dma_store_piece(pq[(((p) >> 1) + MT) % MT][2 * ((p) & 1)],                    \
-                                     pq[(((p) >> 1) + MT) % MT][2 * ((p) & 1) + 1], rfloor);       \
-    if (((p) >> 1) < st_rows && st_lane) *reinterpret_cast<u32x4*>(st_ptr + ((p) & 1) * 64) = o_;  \
-    if ((p) & 1) st_ptr += st_pitch;                                                               \
-  }
-#define XV_DMA_PIECES(t)                                                                   \
-  if (has_next && !(a.debug_same_patch & 2)) {                                             \
-    if (2 * (t) < C::A_ITERS) dma_a(nx_src, 2 * (t), buf ^ 1, nx_edge, nx_ylim, nx_xlim);         \
-    if (2 * (t) + 1 < C::A_ITERS) dma_a(nx_src, 2 * (t) + 1, buf ^ 1, nx_edge, nx_ylim, nx_xlim); \
-    _Pragma("unroll") for (int q_ = 0; q_ < B_PER_TAP; ++q_) {                             \
-      const int bi_ = ((t) - B_TAP0) * B_PER_TAP + q_;                                     \
-      if ((t) >= B_TAP0 && bi_ < C::B_ITERS) dma_b(nw_src, bi_, buf ^ 1);                  \
-    }                                                                                      \
-    if ((t) == B_TAP0) dma_bias(nxt, nchunk, bslot ^ 1);                                   \
-  }
-  // the 16 MFMAs of tap t (fragment sets by item parity P_); first tap of a tile: C = 0 instead of cleared accumulators
-#define XV_MFMAS(t)                                                                                \
-  {                                                                                                \
-    constexpr int dx_ = (t) / 3, dy_ = (t) % 3, ws_ = ((t) + P_) & 1, ps_ = (dx_ + P_) & 1;         \
-    if ((t) == 0 && chunk == 0) {                                                                  \
-      acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ws_][0], xf[ps_][dy_], zero4, 0, 0, 0); \
-      __builtin_amdgcn_s_setprio(2);                                                               \
-      __builtin_amdgcn_sched_barrier(0);                                                           \
-      _Pragma("unroll") for (int i = 0; i < MT; ++i) _Pragma("unroll") for (int j = 0; j < 4; ++j) \
-          if (i + j > 0)                                                                           \
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ws_][j], xf[ps_][i + dy_], zero4, 0, 0, 0); \
-    } else {                                                                                       \
-      acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ws_][0], xf[ps_][dy_], acc[0][0], 0, 0, 0); \
-      __builtin_amdgcn_s_setprio(2);                                                               \
-      __builtin_amdgcn_sched_barrier(0);                                                           \
-      _Pragma("unroll") for (int i = 0; i < MT; ++i) _Pragma("unroll") for (int j = 0; j < 4; ++j) \
-          if (i + j > 0)                                                                           \
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ws_][j], xf[ps_][i + dy_], acc[i][j], 0, 0, 0); \
-    }                                                                                              \
-    __builtin_amdgcn_sched_barrier(0);                                                             \
-    __builtin_amdgcn_s_setprio(1);                                                                 \
-    __builtin_amdgcn_sched_barrier(0);                                                             \
-  }
-  // taps 0..7: as in conv_dma_kernel -- next tap's weights (and next dx group's pixels) requested one tap ahead
-#define XV_TAP(t)                                                                                  \
-  {                                                                                                \
-    constexpr int dx_ = (t) / 3, dy_ = (t) % 3;                                                    \
-    XV_LDW(wb, (t) + 1, ((t) + 1 + P_) & 1);                                                       \
-    if constexpr (dy_ == 1 && dx_ + 1 < 3) XV_LDP(pb[dx_ + 1], (dx_ + 1 + P_) & 1);                 \
-    XV_STORE_PIECE((t) - 1)                                                                        \
-    XV_DMA_PIECES(t)                                                                               \
-    constexpr int newer_ = 4 + ((dy_ != 0 && dx_ + 1 < 3) ? 6 : 0);                                \
-    if constexpr (dy_ == 0)                                                                        \
-      XV_WAIT_WP(newer_, ((t) + P_) & 1, (dx_ + P_) & 1);                                          \
-    else                                                                                           \
-      XV_WAIT_W(newer_, ((t) + P_) & 1);                                                           \
-    __builtin_amdgcn_sched_barrier(0);                                                             \
-    XV_MFMAS(t)                                                                                    \
-  }
-
-  // first item: its operands have landed, first fragments into set 0
-  asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-  {
-    const int wb = wbase;
-    XV_LDW(wb, 0, 0);
-    XV_LDP(pbase[0], 0);
-  }
-  __builtin_amdgcn_sched_barrier(0);
-
-  // One work item with fragment-set parity P_ (weights of tap t in set (t + P_) & 1, pixels of dx in (dx + P_) & 1).
-  // Tap 8 computes from registers only, so the item boundary sits INSIDE it: once this wave's last reads of the item
-  // have landed it waits for the next item's DMA (counted: the stores of taps LAST_DMA_TAP+1..8 stay in flight), joins
-  // the workgroup barrier, requests the next item's first fragments from the other buffer pair into the sets tap 8 does
-  // not use -- and only then issues tap 8's 16 MFMAs, which cover the barrier release and the 80-read LDS burst that
-  // conv_dma_kernel pays between its barrier and its first MFMA (550-900 cycles of a 5 900-cycle item).  An item has
-  // nine taps and three dx groups, so the parity flips from item to item: two copies of the body.
-  auto item = [&](auto par_c) -> bool {
-    constexpr int P_ = decltype(par_c)::value;
-    const int wb = wbase + buf * C::B_BYTES;
-    int pb[3];
-#pragma unroll
-    for (int dx = 0; dx < 3; ++dx) pb[dx] = pbase[dx] + buf * C::A_BYTES;
-
-    const bool last_chunk = chunk + 1 == nchunks;
-    const int nlid = last_chunk ? lid + nb : lid;
-    const bool has_next = nlid < t_end;
-    const Tile nxt = (last_chunk && has_next) ? decode(nlid) : cur;
-    const int nchunk = last_chunk ? 0 : chunk + 1;
-    const char *nx_src = nullptr, *nw_src = nullptr;
-    if (has_next) dma_bases(nxt, nchunk, nx_src, nw_src);
-    const bool nx_edge = nxt.y0 + C::TH > H || nxt.x0 + C::TW > W;
-    const int nx_ylim = H + 1 - nxt.y0, nx_xlim = W + 1 - nxt.x0;
-
-    // the previous tile's stores go out one per tap, behind this item's DMA
-    const int stores_now = pend.on ? npieces : 0;
-    char* st_ptr = nullptr;  // this lane's 16-byte piece of row 0; steps one row every two pieces
-    int st_pitch = 0;        // bytes
-    int st_rows = 0;         // rows of the (pooled) map this wave may store: all of them except on a bottom edge tile
-    bool st_lane = false;    // this lane stores: its pixel column is inside the image (and even, for the pooled map)
-    bool st_edge = false;
-    if (pend.on) {
-      const int px = pend.x0 + wc * 16 + l15, py0 = pend.y0 + wr * MT;
-      const int vrows = H - py0 < 0 ? 0 : (H - py0 < MT ? H - py0 : MT);
-      st_edge = pend.y0 + C::TH > H || pend.x0 + C::TW > W;
-      if (a.y != nullptr) {
-        st_pitch = Wp * Cout * 2;
-        st_rows = vrows;
-        st_lane = px < W;
-        st_ptr = reinterpret_cast<char*>(a.y + (int64_t)pend.n * (H + 2) * Wp * Cout +
-                                         ((int64_t)(py0 + 1) * Wp + (px + 1)) * Cout + pend.co0 + csub);
-      } else {
-        const int Hq = H >> 1, Wq = W >> 1;
-        st_pitch = (Wq + 2) * Cout * 2;
-        st_rows = (vrows + 1) >> 1;
-        st_lane = px < W && (lane & 1) == 0;
-        st_ptr = reinterpret_cast<char*>(a.pooled + (int64_t)pend.n * (Hq + 2) * (Wq + 2) * Cout +
-                                         ((int64_t)((py0 >> 1) + 1) * (Wq + 2) + ((px >> 1) + 1)) * Cout + pend.co0 + csub);
-      }
-      pend.on = false;
-    }
-    // stores younger than the last DMA piece when tap 8 waits (an edge tile may skip store instructions: no counted wait)
-    const bool counted = stores_now == 2 * MT && !st_edge;
-    __builtin_amdgcn_sched_barrier(0);
-
-    XV_TAP(0) XV_TAP(1) XV_TAP(2) XV_TAP(3) XV_TAP(4) XV_TAP(5) XV_TAP(6) XV_TAP(7)
-    {  // tap 8
-      XV_STORE_PIECE(7)
-      XV_WAIT_W(0, P_);  // (8 + P_) & 1: the last reads of this item have landed
-      __builtin_amdgcn_sched_barrier(0);
-      if (has_next) {
-        if (a.debug_same_patch & 4) {
-          // timing experiment: no wait, no barrier
-        } else if (counted)
-          asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(YTAIL) : "memory");
-        else
-          asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-        // (a tile's last item converts the tile after tap 8 and needs the registers: its successor's fragments are
-        // requested after the conversion instead -- one exposed prologue per TILE rather than per item)
-        if (!last_chunk) {
-          XV_LDW(wbase + (buf ^ 1) * C::B_BYTES, 0, P_ ^ 1);
-          XV_LDP(pbase[0] + (buf ^ 1) * C::A_BYTES, P_ ^ 1);
-        }
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      XV_MFMAS(8)
-    }
-
-    if (last_chunk) {
-      dma_epilogue_pack<MT>(a, acc, pq, reinterpret_cast<const float*>(smem + C::BIAS_OFF + bslot * 256), cur.n,
-                            cur.y0 + wr * MT, cur.x0 + wc * 16 + l15, cur.co0 + lg * 4, lane);
-      pend = DmaPend{cur.n, cur.y0, cur.x0, cur.co0, true};
-      bslot ^= 1;
-      if (has_next) {
-        __builtin_amdgcn_sched_barrier(0);
-        XV_LDW(wbase + (buf ^ 1) * C::B_BYTES, 0, P_ ^ 1);
-        XV_LDP(pbase[0] + (buf ^ 1) * C::A_BYTES, P_ ^ 1);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    }
-    if (!has_next) {
-      // last tile of this workgroup: store it now
-      const int px = pend.x0 + wc * 16 + l15, py0 = pend.y0 + wr * MT;
-      const int vrows = H - py0 < 0 ? 0 : (H - py0 < MT ? H - py0 : MT);
-      if (a.y != nullptr) {
-        __bf16* base = a.y + (int64_t)pend.n * (H + 2) * Wp * Cout + ((int64_t)(py0 + 1) * Wp + (px + 1)) * Cout + pend.co0 + csub;
-#pragma unroll
-        for (int t = 0; t < 2 * MT; ++t) {
-          const u32x4 o = dma_store_piece(pq[t >> 1][2 * (t & 1)], pq[t >> 1][2 * (t & 1) + 1], rfloor);
-          if ((t >> 1) < vrows && px < W) *reinterpret_cast<u32x4*>(base + (int64_t)(t >> 1) * Wp * Cout + (t & 1) * 32) = o;
-        }
-      } else {
-        const int Hq = H >> 1, Wq = W >> 1;
-        __bf16* base = a.pooled + (int64_t)pend.n * (Hq + 2) * (Wq + 2) * Cout +
-                       ((int64_t)((py0 >> 1) + 1) * (Wq + 2) + ((px >> 1) + 1)) * Cout + pend.co0 + csub;
-#pragma unroll
-        for (int t = 0; t < MT; ++t) {
-          const u32x4 o = dma_store_piece(pq[t >> 1][2 * (t & 1)], pq[t >> 1][2 * (t & 1) + 1], rfloor);
-          if ((t >> 1) < ((vrows + 1) >> 1) && px < W && (lane & 1) == 0)
-            *reinterpret_cast<u32x4*>(base + (int64_t)(t >> 1) * (Wq + 2) * Cout + (t & 1) * 32) = o;
-        }
-      }
-      return true;
-    }
-    lid = nlid;
-    cur = nxt;
-    chunk = nchunk;
-    buf ^= 1;
-    return false;
-  };
-  while (true) {
-    if (item(std::integral_constant<int, 0>{})) break;
-    if (item(std::integral_constant<int, 1>{})) break;
-  }
-#undef XV_TAP
-#undef XV_MFMAS
-#undef XV_STORE_PIECE
-#undef XV_DMA_PIECES
-#undef XV_WAIT_WP
-#undef XV_WAIT_W
-#undef XV_LDP
-#undef XV_LDW
-#undef XV_LDS128
-}
-
-template <int WR, int WC>
-int launch_conv_dma2(const ConvArgs& a0, hipStream_t stream) {
-  using C = DmaCfg<WR, WC>;
-  ConvArgs a = a0;
-  a.wpk = a0.wpk + (int64_t)9 * a.Cin * a.Cout;  // second half of the packed buffer: the 32-channel-chunk image
-  a.tiles_x = (a.W + C::TW - 1) / C::TW;
-  a.tiles_y = (a.H + C::TH - 1) / C::TH;
-  a.n_ct = a.Cout / 64;
-  static bool attr_set[XV_MAX_DEVICES] = {false};
-  {
-    const hipError_t e = xv_allow_dynamic_lds(reinterpret_cast<const void*>(&conv_dma2_kernel<WR, WC>), C::LDS_BYTES, attr_set);
-    if (e != hipSuccess) return (int)e;
-  }
-  const int64_t ntiles = (int64_t)a.tiles_x * a.tiles_y * a.N * a.n_ct;
-  if (ntiles <= 0 || ntiles > 0x7fffffff) return XV_ESHAPE;
-  if ((int64_t)(C::HH * (a.W + 2) + C::HW) * a.Cin * 2 > 0x7fffffff) return XV_ESHAPE;  // 32-bit patch offsets
-  a.n_tiles = (int)ntiles;
-  a.debug_same_patch = 0;
-#ifdef XV_CONV_EXPERIMENTS
-  // timing experiments of a tuning build (results are WRONG): bit 0 every tile DMAs the patch of tile 0 (L2-hot operands),
-  // bit 1 no DMA at all, bit 2 no item barrier.  Round 2, 16 images, conv4_2: 1 331 TFLOP/s as shipped, 1 473 without
-  // DMA, 1 543 without DMA and barrier -- the ceiling of this compute structure (fragment reads + MFMA bursts of two
-  // waves per SIMD + tile conversion + 4.5 tile rounds) at the clock the chip holds.
-  static const int dbg = getenv("XV_DEBUG_SAME_PATCH") != nullptr ? atoi(getenv("XV_DEBUG_SAME_PATCH")) : 0;
-  a.debug_same_patch = dbg;
-#endif
-  const int64_t slots = a.num_cus;
-  const int64_t nblk = ntiles < slots ? ntiles : slots;
-  hipLaunchKernelGGL((conv_dma2_kernel<WR, WC>), dim3((unsigned)nblk), dim3(C::NT), C::LDS_BYTES, stream, a);
-  return xv_launch_status();
-}
-
 // ---- weight packing: fp32 HWIO -> bf16 [tap][cin/64][cout][64] (16-byte slots swizzled by xv_swz), followed for
 // 3x3 filters by the generation-2 image [tap][cin/32][cout][32] (xv_swz32).  dgrad != 0 packs the weights of the
 // data-gradient convolution instead: input/output channels swapped and the taps point-reflected.
@@ -2014,6 +1598,9 @@ int launch_cfg(int cfg, const ConvArgs& a, hipStream_t s) {
                                     a.out_mul, a.num_cus, s);
   }
   if (cfg == 25) return XV_ESHAPE;  // (retired: generation 4 on 32x32x16 bf16 blocks, superseded by 26; its weight image is gone)
+  // Retired in round 5 (never chosen by pick_cfg, the stream-K tail, a partial-tile fallback or the fp8 path): the
+  // first-generation tile variants 0, 2-13, 19, 20 and generation 2b (21).  Their indices stay reserved.
+  if (cfg == 0 || (cfg >= 2 && cfg <= 13) || cfg == 19 || cfg == 20 || cfg == 21) return XV_ESHAPE;
   if (cfg == 26) {
     if (KS != 3 || a.in_f8) return XV_ESHAPE;
     return xv_launch_conv3x3_f8_dma(a.x, a.wpk, a.bias, a.y, a.pooled, a.N, a.H, a.W, a.Cin, a.Cout, a.relu, 0, a.out_f8, 0,
@@ -2026,50 +1613,19 @@ int launch_cfg(int cfg, const ConvArgs& a, hipStream_t s) {
   }
   if (a.in_f8) {
     // the fp8 kernel is built for the tile shapes with LDS-DMA weight stages (the ones the bf16 chooser falls back to)
-    static const bool pfa = getenv("XV_F8_PFA") != nullptr && getenv("XV_F8_PFA")[0] == '1';
-    if (pfa) {
-      switch (cfg) {
-        case 14: return launch_conv<4, 4, 1, 1, KS, 2, 2, 1, 2>(a, s);
-        case 15: return launch_conv<4, 2, 2, 1, KS, 2, 2, 1, 2>(a, s);
-        case 16: return launch_conv<4, 4, 2, 1, KS, 2, 5, 1, 2>(a, s);
-        case 19: return launch_conv<4, 4, 1, 2, KS, 2, 2, 1, 2>(a, s);
-        case 20: return launch_conv<4, 2, 2, 2, KS, 2, 2, 1, 2>(a, s);
-        default: return XV_ESHAPE;
-      }
-    }
     switch (cfg) {
       case 14: return launch_conv<4, 4, 1, 1, KS, 2, 2, 1, 1>(a, s);
       case 15: return launch_conv<4, 2, 2, 1, KS, 2, 2, 1, 1>(a, s);
       case 16: return launch_conv<4, 4, 2, 1, KS, 2, 5, 1, 1>(a, s);
-      case 19: return launch_conv<4, 4, 1, 2, KS, 2, 2, 1, 1>(a, s);
-      case 20: return launch_conv<4, 2, 2, 2, KS, 2, 2, 1, 1>(a, s);
       default: return XV_ESHAPE;
     }
   }
   if (a.out_f8 && (cfg == 17 || cfg == 18 || cfg == 21 || cfg == 22 || cfg == 23)) return XV_ESHAPE;  // fp8 outputs come from the shared first-generation epilogue
   switch (cfg) {
-    case 0: return launch_conv<8, 2, 1, 2, KS, 2>(a, s);
     case 1: return launch_conv<4, 2, 1, 2, KS, 2>(a, s);
-    case 2: return launch_conv<8, 1, 2, 2, KS, 2>(a, s);
-    case 3: return launch_conv<8, 2, 2, 2, KS, 2>(a, s);
-    case 4: return launch_conv<4, 4, 1, 1, KS, 2>(a, s);
-    case 5: return launch_conv<8, 2, 2, 1, KS, 1>(a, s);
-    case 6: return launch_conv<4, 2, 2, 1, KS, 2>(a, s);
-    case 7: return launch_conv<8, 1, 1, 4, KS, 1>(a, s);
-    case 8: return launch_conv<8, 2, 1, 2, KS, 1>(a, s);
-    case 9: return launch_conv<8, 1, 2, 2, KS, 1>(a, s);
-    case 10: return launch_conv<4, 4, 1, 1, KS, 2, 2>(a, s);
-    case 11: return launch_conv<4, 2, 2, 1, KS, 2, 2>(a, s);
-    case 12: return launch_conv<4, 4, 2, 1, KS, 2, 3>(a, s);
-    case 13: return launch_conv<4, 4, 2, 1, KS, 2, 5>(a, s);
     case 14: return launch_conv<4, 4, 1, 1, KS, 2, 2, 1>(a, s);
     case 15: return launch_conv<4, 2, 2, 1, KS, 2, 2, 1>(a, s);
     case 16: return launch_conv<4, 4, 2, 1, KS, 2, 5, 1>(a, s);
-    case 19: return launch_conv<4, 4, 1, 2, KS, 2, 2, 1>(a, s);
-    case 20: return launch_conv<4, 2, 2, 2, KS, 2, 2, 1>(a, s);
-    case 21:
-      if constexpr (KS == 3) return launch_conv_dma2<4, 2>(a, s);
-      return XV_ESHAPE;
     case 22:
       if constexpr (KS == 3) return launch_conv_dma<8, 1, 0, 3>(a, s);
       return XV_ESHAPE;
@@ -2081,13 +1637,6 @@ int launch_cfg(int cfg, const ConvArgs& a, hipStream_t s) {
       return XV_ESHAPE;
     case 17:
       if constexpr (KS == 3) {
-#ifdef XV_DMA_PRIO_VARIANTS
-        // tuning build only (measured round 2, tools/conv_tune.py --cfgs 17 at 16 images: the per-burst scheme is 3-5 % ahead
-        // of both the static and the no-priority variant on every layer)
-        static const int prio = getenv("XV_DMA_PRIO") ? atoi(getenv("XV_DMA_PRIO")) : 0;
-        if (prio == 1) return launch_conv_dma<4, 2, 1>(a, s);
-        if (prio == 2) return launch_conv_dma<4, 2, 2>(a, s);
-#endif
         return launch_conv_dma<4, 2>(a, s);
       }
       return XV_ESHAPE;

@@ -261,7 +261,72 @@ __global__ __launch_bounds__(256) void depth_to_space_dense_kernel(const __bf16*
   }
 }
 
+// The same from a DENSE float32 phase map [N][Hq][Wq][s*s*Cp] (the x8 deconv of the class scores run in float32 on the fp32
+// matrix instruction, adapnet.py:155-163: the reference computes the scores in float32, a bf16 phase map in between would
+// round them to 8 bits before the batch norm and the softmax)
+__global__ __launch_bounds__(256) void depth_to_space_dense_f32_kernel(const float* __restrict__ z, const float* __restrict__ scale,
+                                                                      const float* __restrict__ shift, float* __restrict__ out,
+                                                                      int N, int Hq, int Wq, int C, int Cp, int S) {
+  const int Ho = Hq * S, Wo = Wq * S;
+  const int64_t total = (int64_t)N * Ho * Wo;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    const int ox = (int)(idx % Wo);
+    int64_t r = idx / Wo;
+    const int oy = (int)(r % Ho);
+    const int n = (int)(r / Ho);
+    const int qy = oy / S, py = oy - qy * S, qx = ox / S, px = ox - qx * S;
+    const float* src = z + (((int64_t)n * Hq + qy) * Wq + qx) * ((int64_t)S * S * Cp) + (int64_t)(py * S + px) * Cp;
+    float* dst = out + idx * C;
+    for (int c0 = 0; c0 < C; c0 += 4) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(src + c0);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (c0 + j < C) dst[c0 + j] = scale != nullptr ? a[j] * scale[c0 + j] + shift[c0 + j] : a[j];
+    }
+  }
+}
+
+// padded bf16 map -> dense float32 [N][H][W][C] (exact: every bf16 is a float), 8 channels per thread
+__global__ __launch_bounds__(256) void act_to_dense_f32_kernel(const __bf16* __restrict__ x, float* __restrict__ out, int N, int H,
+                                                              int W, int C8) {
+  const int64_t total = (int64_t)N * H * W * C8;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    const int c8 = (int)(idx % C8);
+    int64_t r = idx / C8;
+    const int px = (int)(r % W);
+    r /= W;
+    const int py = (int)(r % H);
+    const int n = (int)(r / H);
+    const u32x4 a = *reinterpret_cast<const u32x4*>(x + ((((int64_t)n * (H + 2) + py + 1) * (W + 2) + px + 1) * C8 + c8) * 8);
+    float* dst = out + idx * 8;
+    *reinterpret_cast<f32x4*>(dst) = f32x4{bf16_bits_to_f32(a.x & 0xffffu), __builtin_bit_cast(float, a.x & 0xffff0000u),
+                                           bf16_bits_to_f32(a.y & 0xffffu), __builtin_bit_cast(float, a.y & 0xffff0000u)};
+    *reinterpret_cast<f32x4*>(dst + 4) = f32x4{bf16_bits_to_f32(a.z & 0xffffu), __builtin_bit_cast(float, a.z & 0xffff0000u),
+                                               bf16_bits_to_f32(a.w & 0xffffu), __builtin_bit_cast(float, a.w & 0xffff0000u)};
+  }
+}
+
 }  // namespace
+
+extern "C" int xv_act_to_dense_f32(const xv_act* x, float* out, void* stream) {
+  XV_REQUIRE_BF16(x);
+  XV_CHECK_ARG(x && x->data && out && ((uintptr_t)out & 15) == 0);
+  XV_CHECK_SHAPE(xv_dims_sane(x->n, x->h, x->w) && x->c > 0 && (x->c & 7) == 0);
+  const int64_t total = (int64_t)x->n * x->h * x->w * (x->c >> 3);
+  hipLaunchKernelGGL(act_to_dense_f32_kernel, dim3(rn_grid(total)), dim3(256), 0, (hipStream_t)stream, (const __bf16*)x->data, out,
+                     x->n, x->h, x->w, x->c >> 3);
+  return xv_launch_status();
+}
+
+extern "C" int xv_depth_to_space_dense_f32(const float* z, int n, int hq, int wq, int stride, int cp, int num_classes,
+                                           const float* scale, const float* shift, float* out, void* stream) {
+  XV_CHECK_ARG(z && out && (scale == nullptr) == (shift == nullptr) && ((uintptr_t)z & 15) == 0);
+  XV_CHECK_SHAPE(n > 0 && hq > 0 && wq > 0 && stride >= 1 && stride <= 16 && num_classes >= 1 && (cp & 3) == 0 && cp >= num_classes);
+  const int64_t total = (int64_t)n * hq * wq * stride * stride;
+  hipLaunchKernelGGL(depth_to_space_dense_f32_kernel, dim3(rn_grid(total)), dim3(256), 0, (hipStream_t)stream, z, scale, shift, out,
+                     n, hq, wq, num_classes, cp, stride);
+  return xv_launch_status();
+}
 
 extern "C" int xv_subsample2(const xv_act* x, const xv_act* y, void* stream) {
   XV_REQUIRE_BF16(x, y);

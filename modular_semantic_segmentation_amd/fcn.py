@@ -30,17 +30,32 @@ FP8_CONVS = ('conv2_2', 'conv3_1', 'conv3_2', 'conv3_3', 'conv4_1', 'conv4_2', '
 FP8_MAPS = ('conv1_1', 'conv1_2', 'conv2_1') + FP8_CONVS
 
 
-def fp8_plan(h=None, w=None, deep=False):
-    """(convs with e4m3 operands, conv outputs stored as e4m3).  conv2_1 (64 input channels) is an e4m3 conv too -- the
-    generation-4 kernel (csrc/conv_f8_dma.hip) takes 64-channel e4m3 chunks, one tap per K = 64 MFMA, on any map size; the
-    first-generation kernel needs 128 -- and conv1_2 writes the first e4m3 map (its pooled output).
-    deep=True (model config `fp8_deep`): conv1_2 takes e4m3 operands as well and conv1_1 writes the first e4m3 map: +14 %
-    images/s at 2048x1024, paid for in accuracy on trained experts (mIoU against the fp32 graph: depth expert -2.1 points
-    instead of -0.6, RGB -0.25 / +0.1, Bayes fusion -0.22 / -0.03: bench.py `accuracy.fp8`), hence opt-in.
-    oracle/fcn_oracle.py states the same rules.  (h, w: unused since the kernel handles partial tiles; kept for callers.)"""
-    if deep:
-        return ('conv1_2', 'conv2_1') + FP8_CONVS, ('conv1_1', 'conv1_2', 'conv2_1') + FP8_CONVS
-    return ('conv2_1',) + FP8_CONVS, ('conv1_2', 'conv2_1') + FP8_CONVS
+# how calibrate() chooses an activation map's exponent: 'max' (largest magnitude + one bit of headroom) or 'mse' (least squared
+# e4m3 error on the calibration batch; XV_FP8_CALIBRATION for A/B)
+FP8_CALIBRATION = os.environ.get('XV_FP8_CALIBRATION', 'max')
+FP8_DEFAULT_START = 'conv2_2'
+
+
+def fp8_plan(h=None, w=None, deep=False, start=None):
+    """(convs with e4m3 operands, conv outputs stored as e4m3) of conv_dtype='fp8': the convs from `start` on take e4m3
+    operands, the conv in front of `start` is a bf16 conv that writes the first e4m3 map.
+
+      start='conv2_2' (default since round 5): conv1_1 fp32, conv1_2 and conv2_1 bf16, conv2_1 writes the first e4m3 map.
+          tools/fp8_calib_study.py on trained experts: the depth expert (classes are thresholds on ONE raw uint16 channel, so
+          its first pooled map carries the information in small relative differences) loses 2.9 - 3.7 points of mIoU when
+          pool1 is stored with 3-bit mantissas and 0.01 when the first e4m3 map is conv2_1's; the RGB expert is within 0.06
+          either way.  conv2_1 is 6 % of the FLOPs: ~3 % of the step at 2048x1024.
+      start='conv2_1' (model config `fp8_start`; the default of rounds 2-4): conv1_2 writes the first e4m3 map (pool1).
+      deep=True (model config `fp8_deep`) = start='conv1_2': conv1_1 writes the first e4m3 map: +14 % images/s at 2048x1024,
+          depth expert -6.5 points.
+    Any later layer may be named as well.  oracle/fcn_oracle.py states the same rule.  (h, w: unused since the kernels handle
+    partial tiles; kept for callers.)"""
+    names = [n for n, _, _ in ENCODER]
+    start = start or ('conv1_2' if deep else FP8_DEFAULT_START)
+    if start not in names[1:]:
+        raise ValueError('fp8_start must be one of %s' % names[1:])
+    i = names.index(start)
+    return tuple(names[i:]), tuple(names[i - 1:])
 
 
 def variable_shapes(prefix, in_channels, num_units, num_classes, batch_normalization=False):
@@ -133,7 +148,7 @@ class FcnEngine(object):
     """One FCN expert resident on one GPU (inference graph of simple_fcn.py:137-170)."""
 
     def __init__(self, prefix, in_channels, num_units, num_classes, variables, device='cuda', conv_dtype='bf16',
-                 streamk=False, fp8_deep=False):
+                 streamk=False, fp8_deep=False, fp8_start=None):
         self.prefix, self.cin, self.U, self.C = prefix, int(in_channels), int(num_units), int(num_classes)
         self.device = torch.device(device)
         self.Up = ((self.U + 63) // 64) * 64      # score convs run on the MFMA kernel: pad U to 64 lanes of zeros
@@ -146,6 +161,10 @@ class FcnEngine(object):
         # batch (different fp32 groupings; still bitwise reproducible run to run).  A latency option for batch 1.
         self.streamk = bool(streamk)
         self.fp8_deep = bool(fp8_deep)          # conv_dtype='fp8': e4m3 operands from conv1_2 on (see fp8_plan)
+        # conv_dtype='fp8': the first conv with e4m3 operands (fp8_plan); a dict {prefix or modality: layer} picks per expert
+        if isinstance(fp8_start, dict):
+            fp8_start = fp8_start.get(prefix)
+        self.fp8_start = fp8_start
         self.fp8_scales = None                    # {map name: power-of-two exponent}, set by calibrate()
         # MC dropout (simple_fcn.py:50-62,71-78,124-126; only the uncertainty models enable it): sites after which
         # tf.layers.dropout(training=True) is applied -- 'pool3', 'conv4_3', 'conv5_3' in the encoder, 'features' for the
@@ -264,7 +283,7 @@ class FcnEngine(object):
         return a
 
     # ---- fp8: static per-tensor scales -----------------------------------------------------------------------
-    def calibrate(self, x, margin_bits=1, _implicit=False):
+    def calibrate(self, x, margin_bits=1, _implicit=False, method=None):
         """Choose the power-of-two scale of every fp8 activation map from one representative batch: run the bf16
         graph, take max|activation| per layer, and leave `margin_bits` of headroom (an e4m3 value keeps its 3
         mantissa bits anywhere in 2^-6 .. 2^8 of the scale, so headroom costs no precision; values beyond it
@@ -275,8 +294,13 @@ class FcnEngine(object):
             L = self.encoder(x, keep_all=True)
         finally:
             self.conv_dtype = dtype
-        self.fp8_scales = {name: ops.fp8_scale_exp(L[name].interior().abs().max().item(), margin_bits)
-                           for name in FP8_MAPS}
+        method = method or FP8_CALIBRATION
+        if method == 'mse':
+            # the exponent that minimises the map's squared e4m3 error (outliers saturate), not the one that fits its maximum
+            self.fp8_scales = {name: ops.fp8_scale_exp_mse(L[name].interior(), margin_bits) for name in FP8_MAPS}
+        else:
+            self.fp8_scales = {name: ops.fp8_scale_exp(L[name].interior().abs().max().item(), margin_bits)
+                               for name in FP8_MAPS}
         self._fp8_explicit = not _implicit
         return dict(self.fp8_scales)
 
@@ -286,15 +310,16 @@ class FcnEngine(object):
             self.calibrate(x, _implicit=True)           # first batch seen = calibration batch
         n, h, w, _ = x.shape
         e = self.fp8_scales
-        convs8, maps8 = fp8_plan(h, w, self.fp8_deep)
+        convs8, maps8 = fp8_plan(h, w, self.fp8_deep, self.fp8_start)
         L = {}
         first = 1
         ch, cw = h, w
         # conv1_1 + conv1_2 + pool1 in one launch straight onto the first e4m3 map (csrc/conv_first_fused.hip, its e4m3-out form:
         # the same bytes as the two kernels) where conv1_2 takes bf16 operands (the default plan) and neither full map is wanted
-        if not keep_all and _FUSE_FIRST and 'conv1_1' not in maps8 and 'conv1_2' in maps8 and 'conv1_2' not in convs8 and \
+        if not keep_all and _FUSE_FIRST and 'conv1_1' not in maps8 and 'conv1_2' not in convs8 and \
                 ENCODER[1][0] == 'conv1_2' and ENCODER[1][2] == 'pool1':
-            q = self._act('pool1', n, h // 2, w // 2, 64, dtype='fp8', scale_exp=e['conv1_2'])
+            # (fp8_start behind conv2_1: pool1 stays bf16)
+            q = self._act('pool1', n, h // 2, w // 2, 64, **(dict(dtype='fp8', scale_exp=e['conv1_2']) if 'conv1_2' in maps8 else {}))
             if ops.conv_first_pair_fwd(x.contiguous(), self.w['conv1_1'], self.b['conv1_1'], self.w['conv1_2'],
                                        self.b['conv1_2'], pooled=q):
                 L['pool1'] = cur = q

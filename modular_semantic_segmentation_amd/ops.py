@@ -79,6 +79,29 @@ def fp8_scale_exp(amax, margin_bits=0):
     return int(math.ceil(math.log2(amax / FP8_MAX))) + int(margin_bits)
 
 
+def fp8_scale_exp_mse(values, margin_bits=0, search=6, max_elems=1 << 24):
+    """The power-of-two exponent e that minimises the squared error of `values` (a device tensor) stored as e4m3 of
+    value / 2**e, saturating at +-448: between the exponent that fits the largest magnitude (+ margin_bits) and `search`
+    below it.  A map whose magnitudes have a long tail (the depth expert: raw uint16 depth, logit scale 360) keeps three
+    mantissa bits for its bulk instead of spending the format's range on a few outliers, which then saturate.  Calibration
+    time only (torch ops on a strided sample of at most max_elems values)."""
+    v = values.reshape(-1)
+    if v.numel() > max_elems:
+        v = v[::(v.numel() + max_elems - 1) // max_elems]
+    v = v.float()
+    amax = float(v.abs().max())
+    if not amax > 0:
+        return 0
+    top = fp8_scale_exp(amax, margin_bits)
+    best, best_err = top, None
+    for e in range(top, top - search - 1, -1):
+        q = (v * (2.0 ** -e)).clamp_(-FP8_MAX, FP8_MAX).to(torch.float8_e4m3fn).float() * (2.0 ** e)
+        err = float(((q - v) ** 2).sum())
+        if best_err is None or err < best_err:
+            best, best_err = e, err
+    return best
+
+
 _NULL_ACT = ctypes.POINTER(xv_act)()
 
 # bench.py sets this to a list to collect (kind, flops, start_event, end_event) per MFMA-conv launch;
@@ -356,6 +379,29 @@ def depth_to_space_dense(z, stride, num_classes, out, scale=None, shift=None):
     rc = _lib.lib().xv_depth_to_space_dense(z.xv(), int(stride), int(num_classes), _ptr(scale), _ptr(shift), _ptr(out),
                                             _stream())
     _lib.check(rc, 'xv_depth_to_space_dense')
+    return out
+
+
+def deconv8_scores_f32(x, w_hwio_f32, num_classes, cp, out, arena, scale=None, shift=None):
+    """AdapNet's trained x8 score deconv in float32: the padded bf16 map `x` as dense float32 (exact), its 3x3 conv onto the 64
+    phases x cp classes (w_hwio_f32 = dense_deconv_as_conv3x3(kernel, 8), float32 [3,3,U,64*cp]) on the fp32 matrix
+    instruction, the phases unshuffled into the dense float32 scores `out` [N,8H,8W,C] [* scale + shift].  The scores never
+    pass through bf16 (adapnet.py:155-163).  arena: dict for the two float32 scratch maps."""
+    _need(out, torch.float32, 'out')
+    _need(w_hwio_f32, torch.float32, 'w_hwio_f32')
+    lib = _lib.lib()
+    xd = arena.get(('d8_x', x.n, x.h, x.w, x.c))
+    if xd is None:
+        xd = arena[('d8_x', x.n, x.h, x.w, x.c)] = torch.empty((x.n, x.h, x.w, x.c), dtype=torch.float32, device=x.t.device)
+    ph = arena.get(('d8_ph', x.n, x.h, x.w, cp))
+    if ph is None:
+        ph = arena[('d8_ph', x.n, x.h, x.w, cp)] = torch.empty((x.n, x.h, x.w, 64 * cp), dtype=torch.float32, device=x.t.device)
+        arena['d8_zero_bias'] = torch.zeros(64 * cp, dtype=torch.float32, device=x.t.device)
+    _lib.check(lib.xv_act_to_dense_f32(x.xv(), _ptr(xd), _stream()), 'xv_act_to_dense_f32')
+    _lib.check(lib.xv_conv2d_f32(_ptr(xd), x.n, x.h, x.w, x.c, _ptr(w_hwio_f32), _ptr(arena['d8_zero_bias']), 3, 64 * cp, 0,
+                                 _ptr(ph), _stream()), 'xv_conv2d_f32')
+    _lib.check(lib.xv_depth_to_space_dense_f32(_ptr(ph), x.n, x.h, x.w, 8, cp, num_classes, _ptr(scale), _ptr(shift), _ptr(out),
+                                               _stream()), 'xv_depth_to_space_dense_f32')
     return out
 
 

@@ -80,7 +80,8 @@ class SimpleFCN(BaseModel):
         self.engine = engine_cls(self.prefix, self.in_channels, self.config['num_units'],
                                 self.config['num_classes'], self.variables, device=self.device,
                                 conv_dtype=self.config.get('conv_dtype', 'bf16'),
-                                streamk=self.config.get('streamk', False), **({'fp8_deep': True} if self.config.get('fp8_deep') else {}))
+                                streamk=self.config.get('streamk', False), **({'fp8_deep': True} if self.config.get('fp8_deep') else {}),
+                                **({'fp8_start': self.config['fp8_start']} if self.config.get('fp8_start') else {}))
         self.loss = None            # scalar of the last training step (set by _train_batch)
         self.prediction = 'label'   # name of the engine output that is the model's prediction
 

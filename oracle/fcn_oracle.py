@@ -11,8 +11,9 @@ be fed *the same* rounded operands:
   'fp8'   BASELINE config "fp8 MFMA conv path": as 'bf16', but the operands of conv2_2 .. conv5_3 and of the
           two 1x1 score convs are OCP e4m3fn with per-tensor power-of-two scales (`fp8_scales`: the output
           exponent of every map that is stored as fp8, 'w:<layer>' the weight exponents); conv1_1 (fp32),
-          conv1_2 (bf16 operands) are unchanged except that conv1_2 WRITES the first fp8 map; conv2_1 takes e4m3 operands
-          too (fp8_deep: conv1_2 as well, conv1_1 writing the first fp8 map)
+          conv1_2 and conv2_1 (bf16 operands) are unchanged except that conv2_1 WRITES the first fp8 map
+          (fp8_start='conv2_1': conv2_1 takes e4m3 operands too and conv1_2 writes the first fp8 map -- the plan of rounds
+          2-4; fp8_deep: conv1_2 as well, conv1_1 writing the first fp8 map)
 """
 import numpy as np
 import torch
@@ -133,7 +134,7 @@ def deconv_same(x, w, stride, relu=False):
     return F.relu(y) if relu else y
 
 
-def fcn_forward(x_nhwc, weights, prefix, policy='fp32', keep=None, fp8_scales=None, fp8_deep=False):
+def fcn_forward(x_nhwc, weights, prefix, policy='fp32', keep=None, fp8_scales=None, fp8_deep=False, fp8_start=None):
     """fcn() = encoder + decoder (simple_fcn.py:137-170) with batchnorm=False, no dropout.
     Returns dict of NHWC fp32 numpy arrays.  keep: iterable of layer names to return
     (default: fused, upscore, score).  fp8_scales: {layer: output exponent, 'w:layer': weight exponent}
@@ -141,14 +142,17 @@ def fcn_forward(x_nhwc, weights, prefix, policy='fp32', keep=None, fp8_scales=No
     assert policy in ('fp32', 'bf16', 'fp8')
     rnd = (lambda t: t) if policy == 'fp32' else round_bf16
     fp8_scales = fp8_scales or {}
-    # maps stored as e4m3 in the 'fp8' policy: the outputs of conv1_2 .. conv5_3 (the score convs write bf16); conv2_1 ..
-    # conv5_3 and the score convs take e4m3 operands.  With fp8_deep also conv1_2 takes them and conv1_1 writes the first e4m3
-    # map (the product's fcn.fp8_plan).
+    # 'fp8' policy (the product's fcn.fp8_plan): the convs from `fp8_start` on take e4m3 operands (and the two 1x1 score
+    # convs, which write bf16), the conv in front of it and every conv from it on store their outputs as e4m3.  Default
+    # 'conv2_2' (conv2_1 writes the first e4m3 map); 'conv2_1' = the plan of rounds 2-4; fp8_deep = 'conv1_2'.
     fp8_layers = FP8_LAYERS
     fp8_out = set()
     if policy == 'fp8':
-        fp8_layers = (('conv1_2',) if fp8_deep else ()) + ('conv2_1',) + FP8_LAYERS
-        fp8_out = set(('conv1_1', 'conv1_2') if fp8_deep else ('conv1_2',)) | set(('conv2_1',) + FP8_LAYERS[:10])
+        convs = [item[0] for item in ENCODER_CONVS if not isinstance(item, str)]
+        i = convs.index(fp8_start or ('conv1_2' if fp8_deep else 'conv2_2'))
+        assert i >= 1
+        fp8_layers = tuple(convs[i:]) + ('score_conv4', 'score_conv5')
+        fp8_out = set(convs[i - 1:])
 
     def rnd_out(t, name):
         return round_e4m3(t, fp8_scales[name]) if name in fp8_out else rnd(t)

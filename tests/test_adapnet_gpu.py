@@ -396,6 +396,49 @@ def test_adapnet_training_step_on_a_shallow_graph(ops):
     np.testing.assert_allclose(out[k] - w_[k], -1e-3 * g / np.sqrt(0.9 + 0.1 * g * g + 1e-10), rtol=2e-3, atol=4e-9)
 
 
+def test_adapnet_score_deconv_is_float32_in_inference_and_training(ops):
+    """The trained x8 deconv of the class scores (adapnet.py:155-163, float32 in the reference): on the SAME `merge` map the
+    device scores equal a float32 conv_transpose2d with the trained kernel to 1e-5 of the score scale -- fp32 summation order
+    only -- in the inference engine and in the training step (round 4 sent them through a bf16 phase map: 4e-3)."""
+    from modular_semantic_segmentation_amd.adapnet import AdapnetEngine
+    from modular_semantic_segmentation_amd.adapnet_trainer import AdapnetTrainer
+    from modular_semantic_segmentation_amd.fcn import BN_EPS
+    h, w = 64, 96
+    rng = np.random.default_rng(3)
+    x = rng.integers(0, 256, (2, h, w, 3)).astype(np.float32)
+    labels = rng.integers(-1, C, (2, h, w)).astype(np.int32)
+    w_ = ao.init_adapnet_weights('rgb', 3, U, C, seed=2, gain=1.3, blocks=SHALLOW)
+    w_['rgb/block_0_1/kernel'] *= 0.02
+    k = w_['rgb/second_deconvolution_upconv/kernel']
+    w_['rgb/second_deconvolution_upconv/kernel'] = (k + rng.standard_normal(k.shape) * (0.3 / np.sqrt(k.shape[3]))).astype(np.float32)
+    kern = w_['rgb/second_deconvolution_upconv/kernel']
+
+    def reference(merge_act):
+        m = merge_act.interior().float().cpu()[..., :U].permute(0, 3, 1, 2).contiguous()
+        return fo.deconv_same(m, kern, 8).permute(0, 2, 3, 1).numpy()
+
+    eng = AdapnetEngine('rgb', 3, U, C, w_, blocks=SHALLOW)
+    assert 'second' in eng.dense
+    out = eng.forward(_dev(x), want=('score',))
+    torch.cuda.synchronize()
+    g = w_['rgb/second_deconvolution_upconv/gamma'] / np.sqrt(w_['rgb/second_deconvolution_upconv/moving_variance'] + BN_EPS)
+    t = w_['rgb/second_deconvolution_upconv/beta'] - w_['rgb/second_deconvolution_upconv/moving_mean'] * g
+    ref = reference(out['layers']['merge']) * g + t
+    err = np.abs(out['score'].cpu().numpy() - ref).max() / np.abs(ref).max()
+    print('inference: x8 score deconv vs float32 on the same merge map: %.2e of the scale' % err)
+    assert err < 1e-5
+    tr = AdapnetTrainer(eng, 'rmsprop', 1e-3)
+    tr.load_from_variables(w_)
+    tr.step(_dev(x), _dev(labels))
+    torch.cuda.synchronize()
+    merge = [a for key, a in tr._a.items() if key[0] == 'merge'][0]
+    raw = tr._dense('score_raw', (2, h, w, C)).cpu().numpy()
+    ref = reference(merge)
+    err = np.abs(raw - ref).max() / np.abs(ref).max()
+    print('training: raw scores vs float32 on the same merge map: %.2e of the scale' % err)
+    assert err < 1e-5
+
+
 def test_adapnet_training_step(ops, tmp_path):
     """One training step (adapnet.py:103-173 with is_training=True, loss :196-203) against autograd over the oracle's
     restatement: loss, gradients of every kernel / bias / gamma / beta, moving averages; then fit(), export and

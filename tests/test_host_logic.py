@@ -410,10 +410,15 @@ def test_fp8_plan_and_the_oracle_policy_agree():
     from modular_semantic_segmentation_amd.fcn import FP8_CONVS, fp8_plan, init_variables
     from oracle import fcn_oracle as fo
     for hw in ((64, 96), (384, 768), (1024, 2048)):             # the same plan on every map size (partial tiles are handled)
-        convs, maps = fp8_plan(*hw)
+        convs, maps = fp8_plan(*hw)                             # round 5: conv2_1 stays bf16 and writes the first e4m3 map
+        assert convs == FP8_CONVS and maps == ('conv2_1',) + FP8_CONVS
+        convs, maps = fp8_plan(*hw, start='conv2_1')            # the plan of rounds 2-4
         assert convs == ('conv2_1',) + FP8_CONVS and maps == ('conv1_2', 'conv2_1') + FP8_CONVS
         convs, maps = fp8_plan(*hw, deep=True)
         assert convs == ('conv1_2', 'conv2_1') + FP8_CONVS and maps == ('conv1_1', 'conv1_2', 'conv2_1') + FP8_CONVS
+        assert fp8_plan(*hw, start='conv4_1') == (FP8_CONVS[4:], FP8_CONVS[3:])
+    with pytest.raises(ValueError):
+        fp8_plan(start='conv1_1')
     # the oracle on a 32x48 image (partial tiles): a map is on the e4m3 grid of its scale iff the plan stores it
     wts = init_variables('rgb', 3, 64, 12, seed=4)
     x = np.random.default_rng(0).integers(0, 256, (1, 32, 48, 3)).astype(np.float32)
@@ -421,12 +426,13 @@ def test_fp8_plan_and_the_oracle_policy_agree():
     allmaps = ('conv1_1', 'conv1_2', 'conv2_1') + FP8_CONVS
     plain = fo.fcn_forward(x, wts, 'rgb', 'bf16', keep=allmaps)
     scales = {n: fo.fp8_scale_exp(np.abs(plain[n]).max(), 1) for n in allmaps}
-    for deep in (False, True):
-        out = fo.fcn_forward(x, wts, 'rgb', 'fp8', keep=names, fp8_scales=scales, fp8_deep=deep)
-        _, maps = fp8_plan(32, 48, deep)
+    for kw in ({}, {'start': 'conv2_1'}, {'deep': True}):
+        out = fo.fcn_forward(x, wts, 'rgb', 'fp8', keep=names, fp8_scales=scales, fp8_deep=kw.get('deep', False),
+                             fp8_start=kw.get('start'))
+        _, maps = fp8_plan(32, 48, **kw)
         for n in names:
             on_grid = np.array_equal(out[n], fo.round_e4m3(out[n], scales[n]))
-            assert on_grid == (n in maps), (deep, n)
+            assert on_grid == (n in maps), (kw, n)
 
 
 def test_bench_launcher_parent_never_touches_the_gpu(monkeypatch, tmp_path):

@@ -50,12 +50,13 @@ def test_miou_of_hip_path_matches_fp32_oracle_on_trained_experts():
     for m in ('rgb', 'depth', 'bayes', 'dirichlet'):
         assert abs(acc[m]['delta_miou_pp']) <= 0.1, (m, acc[m])
         assert acc[m]['label_agreement'] > 0.995, (m, acc[m])
-    # the fp8 conv path (config 5) on the same trained weights: 3-bit mantissas cost a fraction of a point of mIoU
+    # the fp8 conv path (config 5) on the same trained weights, default plan of round 5 (e4m3 operands from conv2_2 on; conv2_1
+    # writes the first e4m3 map).  With pool1 stored as e4m3 (rounds 2-4) the depth expert -- thresholds on one raw uint16
+    # channel -- lost 0.6 .. 3.7 points run by run; with this plan tools/fp8_calib_study.py measures -0.01 (depth), -0.01 (RGB),
+    # agreement 0.989 / 0.999.  Bounds: half a point of mIoU for every model.
     for m in ('rgb', 'depth', 'bayes'):
-        # default plan (e4m3 operands from conv2_1 on): measured 0.05 .. 0.15 points (RGB, Bayes) and 0.6 .. 1.4 (the weak
-        # depth expert: raw uint16 depth through 3-bit mantissas), agreement 0.997 / 0.980; bounds at about twice the worst seen (a run trains its experts from scratch: the numbers move)
-        assert abs(acc['fp8'][m]['delta_miou_pp_vs_fp32']) < (3.0 if m == 'depth' else 1.0), (m, acc['fp8'][m])
-        assert acc['fp8'][m]['label_agreement_vs_fp32'] > (0.96 if m == 'depth' else 0.985), (m, acc['fp8'][m])
+        assert abs(acc['fp8'][m]['delta_miou_pp_vs_fp32']) < 0.5, (m, acc['fp8'][m])
+        assert acc['fp8'][m]['label_agreement_vs_fp32'] > (0.98 if m == 'depth' else 0.99), (m, acc['fp8'][m])
     # conv_dtype='fp32' (the graph in plain float32 through csrc/exact_f32.hip) on the same TRAINED weights: label maps equal to
     # the fp32 oracle's at 768x384 up to fp32 summation order (a pixel can differ only where two logits tie to ~1e-6 of
     # the logit scale) -- so the 0.02-0.3 % of pixels the bf16 path flips are lost to bf16 storage, not to a kernel

@@ -18,7 +18,7 @@ LAYERS = [('conv1_2', 1, 64, 64, 3, True), ('conv2_1', 2, 64, 128, 3, False), ('
 
 
 def tune_fp8(args):
-    cfgs = [int(c) for c in args.cfgs.split(',')] if args.cfgs else [14, 15, 16, 19, 20, 24]
+    cfgs = [int(c) for c in args.cfgs.split(',')] if args.cfgs else [14, 15, 16, 24]
     print('layer        ' + ''.join('cfg%-6d' % c for c in cfgs) + ' default   (fp8 e4m3 operands, TFLOP/s)')
     for name, s, cin, cout, k, pool in LAYERS:
         if cin < 128:
