@@ -77,6 +77,27 @@ def mfma_summary(tag, suffix, groups, command):
     print(out)
 
 
+def exact_summary(tag):
+    """conv_dtype='fp32' (tools/exact_bench.py 16 3): the fp32-MFMA conv kernel's matrix-pipe busy fraction and HBM traffic."""
+    is_k = lambda k: 'conv_f32_mfma_kernel<3, 16' in k          # noqa: E731
+    mf = counters_by_kernel('pmc_mfma_exact', {'k': is_k}).get('k', {})
+    f, w = counter_avg('pmc_fetch_exact', 'FETCH_SIZE', is_k), counter_avg('pmc_write_exact', 'WRITE_SIZE', is_k)
+    if not mf:
+        return
+    busy, gui = mf['SQ_VALU_MFMA_BUSY_CYCLES'][0], mf['GRBM_GUI_ACTIVE'][0]
+    out = {'kernel': 'conv_f32_mfma_kernel<3, 16, true> (v_mfma_f32_32x32x2_f32: conv1_2 .. conv5_3 of both experts, 16 images)',
+           'source': 'rocprofv3 --pmc ... -- python3 tools/exact_bench.py 16 3 (separate passes: MFMA / FETCH_SIZE / WRITE_SIZE)',
+           'launches': mf['SQ_VALU_MFMA_BUSY_CYCLES'][1], 'mfma_busy_cycles_per_launch': int(busy),
+           'gui_active_cycles_per_launch': int(gui), 'mfma_util': round(busy / (1024 * gui / 8), 4),
+           'note': 'a 32x32x2 f32 MFMA holds its SIMD 64 cycles for 4096 FLOP: 157.3 TFLOP/s at 2.4 GHz'}
+    if f and w:
+        out.update(fetch_size_kb_per_launch=round(f[0], 1), write_size_kb_per_launch=round(w[0], 1),
+                   hbm_bytes_per_launch=int((2 * f[0] + w[0]) * 1024),
+                   correction='read bytes = 2 x FETCH_SIZE (gfx950 counts 128-B requests as 64 B); WRITE_SIZE exact')
+    json.dump(out, open('profiles/%s_exact_conv_counters.json' % tag, 'w'), indent=1)
+    print(out)
+
+
 def copy_stats(tag, sub, dest):
     """The rocprofv3 --kernel-trace --stats summary (per-kernel calls / total / average ns) -> profiles/."""
     f = glob.glob('gpurun_out/%s/**/*kernel_stats.csv' % sub, recursive=True)
@@ -123,6 +144,8 @@ def main(tag, batch=16):
                             'conv_mfma_kernel<F8> (e4m3 operands, first generation)': is_f8,
                             'conv_dma_kernel (bf16)': lambda k: 'conv_dma_kernel' in k},
                  cmd + ' --dtype fp8 --height 1024 --width 2048 --batch 4')
+    exact_summary(tag)
+    copy_stats(tag, tag + '_trace_exact', '%s_exact_kernel_stats.csv' % tag)
     copy_stats(tag, tag + '_trace', '%s_bench_serial_kernel_stats.csv' % tag)
     copy_stats(tag, tag + '_trace8', '%s_bench_fp8_2048_kernel_stats.csv' % tag)
     copy_stats(tag, tag + '_trace_train', '%s_train_kernel_stats.csv' % tag)

@@ -22,6 +22,19 @@ run pmc_mfma       --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES
 run pmc_wave       --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS -d $OUT/pmc_wave -o c -- $BENCH
 run pmc_mfma8      --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_WAVE_CYCLES -d $OUT/pmc_mfma8 -o c -- $FP8
 run pmc_wave8      --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS -d $OUT/pmc_wave8 -o c -- $FP8
+# round 5: the label-exact mode (fp32 matrix instruction) -- kernel stats and the matrix pipe's busy fraction
+EXACT="python3 $ROOT/tools/exact_bench.py 16 3"
+run ${TAG}_trace_exact --kernel-trace --stats -d $OUT/${TAG}_trace_exact -o bench -- $EXACT
+run pmc_mfma_exact --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_WAVE_CYCLES -d $OUT/pmc_mfma_exact -o c -- $EXACT
+run pmc_fetch_exact --pmc FETCH_SIZE -d $OUT/pmc_fetch_exact -o c -- $EXACT
+run pmc_write_exact --pmc WRITE_SIZE -d $OUT/pmc_write_exact -o c -- $EXACT
+# the elementwise / reduction kernels: event timing, then one launch each under the counters
+EW="python3 $ROOT/tools/elementwise_bench.py"
+$EW > $OUT/${TAG}_ew_timing.json 2>/dev/null
+run ew_fetch --pmc FETCH_SIZE -d $OUT/ew_fetch -o c -- $EW --once
+run ew_write --pmc WRITE_SIZE -d $OUT/ew_write -o c -- $EW --once
+run ew_trace --kernel-trace --stats -d $OUT/ew_trace -o c -- $EW --once
 cd $ROOT
+python3 tools/elementwise_bench.py --tag $TAG --merge $OUT/ew_fetch $OUT/ew_write $OUT/ew_trace < $OUT/${TAG}_ew_timing.json
 python3 tools/pmc_summary.py $TAG 16
 ls $OUT/${TAG}_trace/*/ 2>/dev/null | head; tail -3 $OUT/${TAG}_trace.log
