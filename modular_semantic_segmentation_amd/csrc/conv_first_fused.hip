@@ -23,8 +23,20 @@
 //     MFMA bursts at raised priority, accumulation started from the bias, packed bf16 epilogue with the fused 2x2 max-pool)
 //     over chunk 0 / buffer 0 and chunk 1 / buffer 1 -- without a single DMA or vmcnt wait.
 //   * Two barriers per tile: patch written -> taps; taps done -> next patch may be written.
+//   * Round 5, the RAW patch.  Switching the phases off one at a time showed phase A -- a twentieth of the FLOPs -- taking
+//     135 (depth) .. 190 us (RGB) of the kernel's 330 .. 410 us, phase B 160 us, the rest 57 us: every lane gathered its 3x3
+//     taps from global memory one 16-pixel block ahead (75 instructions of coordinate and mask arithmetic per block, and a
+//     dependent round trip).  Now the 20 x 36-pixel raw input patch of the NEXT tile (8.6 KB of fp32 for RGB) is fetched by
+//     LDS-DMA while phase B of the current tile runs, phase A gathers its taps from LDS, and tiles whose raw patch lies
+//     inside the image (84 % at 768x384) take a mask-free form.  Same values, same arithmetic: bit-identical results.
+//     One box, A/B (tools/first_pair_bench.py, non-integer inputs): RGB 411-418 -> 356-376 us, depth 333 -> 320 us.  Phase A
+//     is still ~110 us: it is bound by its instruction count (the three-way operand split, the bf16 conversion and the
+//     swizzled 8-byte LDS stores: ~120 vector instructions per 16-pixel block beside its 12-24 MFMAs, two waves per SIMD),
+//     not by latency -- only running it beside phase B (a second pair of patch buffers: 78 KB the LDS does not have) would hide it.
 // Results are identical to xv_conv2d_first_fwd followed by xv_conv2d_fwd (the same sums in the same order, the same bf16
 // rounding of conv1_1's output): tests/test_kernels_gpu.py::test_first_pair_fused_equals_the_two_kernels.
+#include <type_traits>
+
 #include "xv_common.h"
 
 namespace {
@@ -52,8 +64,13 @@ struct F1 {
   static constexpr int B_OFF = 2 * A_BYTES;
   static constexpr int LDS_BYTES = 2 * A_BYTES + 2 * B_BYTES;
   static constexpr int PROW = HW * 64;
-  static_assert(LDS_BYTES <= 160 * 1024, "does not fit the LDS");
+  // the raw input patch of a tile (conv1_1's taps of the 18 x 34 halo patch): 20 x 36 pixels x CIN floats, linear, row pitch
+  // 36 CIN floats; fetched by 256-byte LDS-DMA pieces (the last one padded)
+  static constexpr int RAW_H = HH + 2, RAW_W = HW + 2, RAW_OFF = LDS_BYTES;
+  static constexpr int raw_pieces(int cin) { return (RAW_H * RAW_W * cin + 63) / 64; }
+  static constexpr int lds_bytes(int cin) { return LDS_BYTES + raw_pieces(cin) * 256; }
 };
+static_assert(F1::lds_bytes(3) <= 160 * 1024, "does not fit the LDS");
 
 __device__ __forceinline__ int f1_swz(int row, int slot) { return slot ^ ((row >> 1) & 2); }  // = g4_swz16
 
@@ -183,105 +200,178 @@ __global__ __launch_bounds__(512, 2) void conv_first_pair_kernel(F1Args a) {
     tn = r / a.tiles_y;
   };
   decode(lid, n, y0, x0);
-  // the taps of one patch pixel per lane: block blk of tile (tn, ty0, tx0) (clamped addresses, masked at use)
+  // ---- the raw input patch by LDS-DMA: dword d of the linear [20][36 CIN] image comes from image row y0 - 2 + d / (36 CIN);
+  // offsets outside the image are clamped (what lands there is masked when it is used, as the global gather did)
+  constexpr int RP = C::RAW_W * CIN, RAW_PIECES = C::raw_pieces(CIN);
+  auto dma_raw = [&](int tn, int ty0, int tx0) {
+    tn = __builtin_amdgcn_readfirstlane(tn), ty0 = __builtin_amdgcn_readfirstlane(ty0), tx0 = __builtin_amdgcn_readfirstlane(tx0);
+    // (an "s" operand must be provably wave-uniform: the image base from two readfirstlane halves)
+    const uint64_t xa = (uint64_t)(a.x + (int64_t)tn * H * W * CIN);
+    const uint32_t xlo = __builtin_amdgcn_readfirstlane((uint32_t)xa), xhi = __builtin_amdgcn_readfirstlane((uint32_t)(xa >> 32));
+    const float* xi = reinterpret_cast<const float*>(((uint64_t)xhi << 32) | xlo);
+    const int last = H * W * CIN - 1;
+#pragma unroll
+    for (int it = 0; it < (RAW_PIECES + C::NWAVES - 1) / C::NWAVES; ++it) {
+      const int piece = wave + it * C::NWAVES;
+      if (piece < RAW_PIECES) {
+        const int d = piece * 64 + lane;
+        const int r = d / RP, c = d - r * RP;
+        int off = ((ty0 - 2 + r) * W + tx0 - 2) * CIN + c;
+        off = off < 0 ? 0 : (off > last ? last : off);
+        asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dword %1, %2" ::"s"(__builtin_amdgcn_readfirstlane(C::RAW_OFF + piece * 256)),
+                     "v"(off * 4), "s"(xi)
+                     : "memory");
+      }
+    }
+  };
+  dma_raw(n, y0, x0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the first barrier of the loop publishes it)
+  // the taps of one patch pixel per lane: block blk of the current tile, gathered from the raw patch in LDS (masked at use)
+  const float* const rawp = reinterpret_cast<const float*>(smem + C::RAW_OFF);
   float raw[3][CIN];
   bool ok[3], inside;
   int pcur, hxcur;
-  auto request = [&](int blk, int tn, int ty0, int tx0) {
-    const float* xi = a.x + (int64_t)tn * H * W * CIN;
+  // FAST (a tile whose whole raw patch lies inside the image -- 84 % of the tiles of a 768x384 input): no coordinate
+  // arithmetic and no masks; a lane's three taps sit at base + t * stride (stride = one pixel for the row lanes g < 3, one
+  // patch row for the leftover lanes g = 3).  The general form keeps the image-coordinate masks of the global gather.
+  const int lane_base = main ? g * RP : 2 * CIN, lane_stride = main ? CIN : RP;
+  auto request = [&](auto fast, int blk, int tn, int ty0, int tx0) {
     const int p = blk * 16 + n15;
     const int pc = p < C::NPIX ? p : C::NPIX - 1;
     const int hy = pc / C::HW, hx = pc - hy * C::HW;
-    const int iy = ty0 - 1 + hy, ix = tx0 - 1 + hx;  // conv1_1 output pixel (image coordinates)
-    inside = p < C::NPIX && iy >= 0 && iy < H && ix >= 0 && ix < W;
+    if constexpr (decltype(fast)::value) {
+      inside = p < C::NPIX;
+      const float* src = rawp + hy * RP + hx * CIN + lane_base;
 #pragma unroll
-    for (int t = 0; t < 3; ++t) {
-      const int ry = main ? iy + g - 1 : iy - 1 + t, rx = main ? ix - 1 + t : ix + 1;
-      ok[t] = inside && ry >= 0 && ry < H && rx >= 0 && rx < W && (main || CIN == 3);
-      const int off = ok[t] ? (ry * W + rx) * CIN : 0;
+      for (int t = 0; t < 3; ++t)
 #pragma unroll
-      for (int c = 0; c < CIN; ++c) raw[t][c] = xi[off + c];
+        for (int c = 0; c < CIN; ++c) raw[t][c] = src[t * lane_stride + c];
+    } else {
+      const int iy = ty0 - 1 + hy, ix = tx0 - 1 + hx;  // conv1_1 output pixel (image coordinates)
+      inside = p < C::NPIX && iy >= 0 && iy < H && ix >= 0 && ix < W;
+#pragma unroll
+      for (int t = 0; t < 3; ++t) {
+        const int ry = main ? iy + g - 1 : iy - 1 + t, rx = main ? ix - 1 + t : ix + 1;
+        ok[t] = inside && ry >= 0 && ry < H && rx >= 0 && rx < W && (main || CIN == 3);
+        // raw-patch coordinates of the same tap: row hy + (ry - iy + 1), column hx + (rx - ix + 1)
+        const int prow = main ? hy + g : hy + t, pcol = main ? hx + t : hx + 2;
+        const float* src = rawp + prow * RP + pcol * CIN;
+#pragma unroll
+        for (int c = 0; c < CIN; ++c) raw[t][c] = src[c];
+      }
     }
     pcur = p;
     hxcur = hx;
   };
-  request(wave, n, y0, x0);  // (the first tile's first block; every later tile's is requested before the previous epilogue)
 
   while (true) {
-    // every wave has finished reading the previous tile's patch buffers
+    // every wave has finished reading the previous tile's patch buffers -- and has seen its own raw-patch DMA land (the
+    // s_waitcnt vmcnt(0) in front of the previous epilogue / of the loop)
     asm volatile("s_barrier" ::: "memory");
+    // the tile's raw patch lies inside the image (uniform): the mask-free form of phase A
+    const bool interior = y0 >= 16 && y0 + 32 <= H && x0 >= 32 && x0 + 64 <= W;
+    auto phase_a = [&](auto fast) {
+      request(fast, wave, n, y0, x0);
 
-    // ---- phase A: conv1_1 on the 18 x 34 halo patch -> bf16 -> LDS ----
-    for (int blk = wave; blk < C::NBLK; blk += C::NWAVES) {
-      // B operand of this block (column = pixel n15, k-group g): masked taps in k order, split three ways
-      float v[8];
-      if (CIN == 3) {
-        v[0] = ok[0] ? (main ? raw[0][0] : raw[0][2]) : 0.f;
-        v[1] = main ? (ok[0] ? raw[0][1] : 0.f) : (ok[1] ? raw[1][2] : 0.f);
-        v[2] = main ? (ok[0] ? raw[0][2] : 0.f) : (ok[2] ? raw[2][2] : 0.f);
-        v[3] = main ? (ok[1] ? raw[1][0] : 0.f) : (inside ? 1.f : 0.f);  // k-group 3: the bias slot (zero padding outside)
-        v[4] = main && ok[1] ? raw[1][1] : 0.f;
-        v[5] = main && ok[1] ? raw[1][2] : 0.f;
-        v[6] = main && ok[2] ? raw[2][0] : 0.f;
-        v[7] = main && ok[2] ? raw[2][1] : 0.f;
-      } else {
-        v[0] = main ? (ok[0] ? raw[0][0] : 0.f) : (inside ? 1.f : 0.f);  // k-group 3: the bias slot
-        v[1] = ok[1] ? raw[1][0] : 0.f, v[2] = ok[2] ? raw[2][0] : 0.f;
-        v[3] = v[4] = v[5] = v[6] = v[7] = 0.f;
+      // ---- phase A: conv1_1 on the 18 x 34 halo patch -> bf16 -> LDS ----
+      for (int blk = wave; blk < C::NBLK; blk += C::NWAVES) {
+        // B operand of this block (column = pixel n15, k-group g): masked taps in k order, split three ways
+        float v[8];
+        if constexpr (decltype(fast)::value) {
+          // (every tap is inside the image: the values of the general form with all masks true)
+          const float one = inside ? 1.f : 0.f;
+          if constexpr (CIN == 3) {
+            v[0] = main ? raw[0][0] : raw[0][2], v[1] = main ? raw[0][1] : raw[1][2], v[2] = main ? raw[0][2] : raw[2][2];
+            v[3] = main ? raw[1][0] : one;
+            v[4] = main ? raw[1][1] : 0.f, v[5] = main ? raw[1][2] : 0.f, v[6] = main ? raw[2][0] : 0.f, v[7] = main ? raw[2][1] : 0.f;
+          } else {
+            v[0] = main ? raw[0][0] : one, v[1] = main ? raw[1][0] : 0.f, v[2] = main ? raw[2][0] : 0.f;
+            v[3] = v[4] = v[5] = v[6] = v[7] = 0.f;
+          }
+          if (!inside) {      // (lanes past the patch in the last block: all operands zero, as in the general form)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = 0.f;
+          }
+        } else if constexpr (CIN == 3) {
+          v[0] = ok[0] ? (main ? raw[0][0] : raw[0][2]) : 0.f;
+          v[1] = main ? (ok[0] ? raw[0][1] : 0.f) : (ok[1] ? raw[1][2] : 0.f);
+          v[2] = main ? (ok[0] ? raw[0][2] : 0.f) : (ok[2] ? raw[2][2] : 0.f);
+          v[3] = main ? (ok[1] ? raw[1][0] : 0.f) : (inside ? 1.f : 0.f);  // k-group 3: the bias slot (zero padding outside)
+          v[4] = main && ok[1] ? raw[1][1] : 0.f;
+          v[5] = main && ok[1] ? raw[1][2] : 0.f;
+          v[6] = main && ok[2] ? raw[2][0] : 0.f;
+          v[7] = main && ok[2] ? raw[2][1] : 0.f;
+        } else {
+          v[0] = main ? (ok[0] ? raw[0][0] : 0.f) : (inside ? 1.f : 0.f);  // k-group 3: the bias slot
+          v[1] = ok[1] ? raw[1][0] : 0.f, v[2] = ok[2] ? raw[2][0] : 0.f;
+          v[3] = v[4] = v[5] = v[6] = v[7] = 0.f;
+        }
+        // Operands that ARE bf16 values (raw 8-bit images as floats: the reference's rgb input, cityscapes.py:170-183) have
+        // no middle / low term: the four products with them add exact zeros.  Decided per block for the whole wave.
+        uint32_t lowbits = 0;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) lowbits |= __builtin_bit_cast(uint32_t, v[e]);
+        const bool exact8 = __builtin_amdgcn_ballot_w64((lowbits & 0xffffu) != 0) == 0;
+        bf16x8 xh, xm, xl;
+        if (exact8) {
+          xh = __builtin_bit_cast(bf16x8, u32x4{f1_hi16_pair(__builtin_bit_cast(uint32_t, v[0]), __builtin_bit_cast(uint32_t, v[1])),
+                                                f1_hi16_pair(__builtin_bit_cast(uint32_t, v[2]), __builtin_bit_cast(uint32_t, v[3])),
+                                                f1_hi16_pair(__builtin_bit_cast(uint32_t, v[4]), __builtin_bit_cast(uint32_t, v[5])),
+                                                f1_hi16_pair(__builtin_bit_cast(uint32_t, v[6]), __builtin_bit_cast(uint32_t, v[7]))});
+        } else {
+          f1_split3x8(v, xh, xm, xl);
+        }
+        const int p = pcur, hx = hxcur;
+        if (blk + C::NWAVES < C::NBLK) request(fast, blk + C::NWAVES, n, y0, x0);  // next block's taps land behind this block's MFMAs
+        f32x4 acc[4];
+        if (exact8) {  // the three products with xh, in the order they have among the six
+#pragma unroll
+          for (int jb = 0; jb < 4; ++jb) acc[jb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[jb], xh, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+#pragma unroll
+          for (int jb = 0; jb < 4; ++jb) acc[jb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm[jb], xh, acc[jb], 0, 0, 0);
+#pragma unroll
+          for (int jb = 0; jb < 4; ++jb) acc[jb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[jb], xh, acc[jb], 0, 0, 0);
+        } else {
+#pragma unroll
+          for (int jb = 0; jb < 4; ++jb) acc[jb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[jb], xl, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+#pragma unroll
+          for (int jb = 0; jb < 4; ++jb) acc[jb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[jb], xh, acc[jb], 0, 0, 0);
+#pragma unroll
+          for (int jb = 0; jb < 4; ++jb) acc[jb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm[jb], xm, acc[jb], 0, 0, 0);
+#pragma unroll
+          for (int jb = 0; jb < 4; ++jb) acc[jb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[jb], xm, acc[jb], 0, 0, 0);
+#pragma unroll
+          for (int jb = 0; jb < 4; ++jb) acc[jb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm[jb], xh, acc[jb], 0, 0, 0);
+#pragma unroll
+          for (int jb = 0; jb < 4; ++jb) acc[jb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[jb], xh, acc[jb], 0, 0, 0);
+        }
+        // lane (pixel n15, group g) holds channels 16 jb + 4 g .. + 3 of block jb: 8 bytes of chunk jb >> 1, 16-byte slot
+        // 2 (jb & 1) + (g >> 1) of the pixel's 64-byte row (swizzled by the pixel's patch column), half g & 1
+#pragma unroll
+        for (int jb = 0; jb < 4; ++jb) {
+          typedef float f32x2 __attribute__((ext_vector_type(2)));
+          typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+          const uint32_t lo = pk_max_i16(__builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{acc[jb][0], acc[jb][1]}, bf16x2)), floor1);
+          const uint32_t hi = pk_max_i16(__builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{acc[jb][2], acc[jb][3]}, bf16x2)), floor1);
+          const int slot = 2 * (jb & 1) + (g >> 1);
+          *reinterpret_cast<u32x2*>(smem + (jb >> 1) * C::A_BYTES + p * 64 + (f1_swz(hx, slot) << 4) + 8 * (g & 1)) = u32x2{lo, hi};
+        }
       }
-      // Operands that ARE bf16 values (raw 8-bit images as floats: the reference's rgb input, cityscapes.py:170-183) have
-      // no middle / low term: the four products with them add exact zeros.  Decided per block for the whole wave.
-      uint32_t lowbits = 0;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) lowbits |= __builtin_bit_cast(uint32_t, v[e]);
-      const bool exact8 = __builtin_amdgcn_ballot_w64((lowbits & 0xffffu) != 0) == 0;
-      bf16x8 xh, xm, xl;
-      if (exact8) {
-        xh = __builtin_bit_cast(bf16x8, u32x4{f1_hi16_pair(__builtin_bit_cast(uint32_t, v[0]), __builtin_bit_cast(uint32_t, v[1])),
-                                              f1_hi16_pair(__builtin_bit_cast(uint32_t, v[2]), __builtin_bit_cast(uint32_t, v[3])),
-                                              f1_hi16_pair(__builtin_bit_cast(uint32_t, v[4]), __builtin_bit_cast(uint32_t, v[5])),
-                                              f1_hi16_pair(__builtin_bit_cast(uint32_t, v[6]), __builtin_bit_cast(uint32_t, v[7]))});
-      } else {
-        f1_split3x8(v, xh, xm, xl);
-      }
-      const int p = pcur, hx = hxcur;
-      if (blk + C::NWAVES < C::NBLK) request(blk + C::NWAVES, n, y0, x0);  // next block's taps land behind this block's MFMAs
-      f32x4 acc[4];
-      if (exact8) {  // the three products with xh, in the order they have among the six
-#pragma unroll
-        for (int jb = 0; jb < 4; ++jb) acc[jb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[jb], xh, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-#pragma unroll
-        for (int jb = 0; jb < 4; ++jb) acc[jb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm[jb], xh, acc[jb], 0, 0, 0);
-#pragma unroll
-        for (int jb = 0; jb < 4; ++jb) acc[jb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[jb], xh, acc[jb], 0, 0, 0);
-      } else {
-#pragma unroll
-        for (int jb = 0; jb < 4; ++jb) acc[jb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[jb], xl, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-#pragma unroll
-        for (int jb = 0; jb < 4; ++jb) acc[jb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[jb], xh, acc[jb], 0, 0, 0);
-#pragma unroll
-        for (int jb = 0; jb < 4; ++jb) acc[jb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm[jb], xm, acc[jb], 0, 0, 0);
-#pragma unroll
-        for (int jb = 0; jb < 4; ++jb) acc[jb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[jb], xm, acc[jb], 0, 0, 0);
-#pragma unroll
-        for (int jb = 0; jb < 4; ++jb) acc[jb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm[jb], xh, acc[jb], 0, 0, 0);
-#pragma unroll
-        for (int jb = 0; jb < 4; ++jb) acc[jb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[jb], xh, acc[jb], 0, 0, 0);
-      }
-      // lane (pixel n15, group g) holds channels 16 jb + 4 g .. + 3 of block jb: 8 bytes of chunk jb >> 1, 16-byte slot
-      // 2 (jb & 1) + (g >> 1) of the pixel's 64-byte row (swizzled by the pixel's patch column), half g & 1
-#pragma unroll
-      for (int jb = 0; jb < 4; ++jb) {
-        typedef float f32x2 __attribute__((ext_vector_type(2)));
-        typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-        const uint32_t lo = pk_max_i16(__builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{acc[jb][0], acc[jb][1]}, bf16x2)), floor1);
-        const uint32_t hi = pk_max_i16(__builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{acc[jb][2], acc[jb][3]}, bf16x2)), floor1);
-        const int slot = 2 * (jb & 1) + (g >> 1);
-        *reinterpret_cast<u32x2*>(smem + (jb >> 1) * C::A_BYTES + p * 64 + (f1_swz(hx, slot) << 4) + 8 * (g & 1)) = u32x2{lo, hi};
-      }
-    }
+    };
+    if (interior)
+      phase_a(std::true_type{});
+    else
+      phase_a(std::false_type{});
     // the patch is complete: this wave's LDS stores have landed, then everybody's
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    // (nobody reads the raw patch any more:) the next tile's raw patch travels during phase B
+    const int nlid = lid + nb;
+    const bool has_next = nlid < t_end;
+    int n2 = n, y02 = y0, x02 = x0;
+    if (has_next) {
+      decode(nlid, n2, y02, x02);
+      dma_raw(n2, y02, x02);
+    }
 
     // ---- phase B: conv1_2, two items (chunk c = patch buffer c = weight buffer c), generation 4's 16x16 schedule ----
 #pragma unroll
@@ -401,14 +491,8 @@ __global__ __launch_bounds__(512, 2) void conv_first_pair_kernel(F1Args a) {
 #undef F1_TAP
     }
 
-    // the next tile's first taps travel during the epilogue and the barrier
-    const int nlid = lid + nb;
-    const bool has_next = nlid < t_end;
-    int n2 = n, y02 = y0, x02 = x0;
-    if (has_next) {
-      decode(nlid, n2, y02, x02);
-      request(wave, n2, y02, x02);
-    }
+    // this wave's share of the next raw patch has landed (requested a whole phase B ago; the tile's stores come after it)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
     // ---- tile epilogue (generation 4's packed form): bf16 pairs, relu and the 2x2 max on signed 16-bit integers ----
     const int py = y0 + 2 * wave;
@@ -509,9 +593,9 @@ template <int CIN, bool OF8 = false>
 int f1_launch(const F1Args& a, int grid, hipStream_t stream) {
   static bool attr_set[XV_MAX_DEVICES] = {false};
   const hipError_t e =
-      xv_allow_dynamic_lds(reinterpret_cast<const void*>(&conv_first_pair_kernel<CIN, OF8>), F1::LDS_BYTES, attr_set);
+      xv_allow_dynamic_lds(reinterpret_cast<const void*>(&conv_first_pair_kernel<CIN, OF8>), F1::lds_bytes(CIN), attr_set);
   if (e != hipSuccess) return (int)e;
-  hipLaunchKernelGGL((conv_first_pair_kernel<CIN, OF8>), dim3((unsigned)grid), dim3(F1::NT), F1::LDS_BYTES, stream, a);
+  hipLaunchKernelGGL((conv_first_pair_kernel<CIN, OF8>), dim3((unsigned)grid), dim3(F1::NT), F1::lds_bytes(CIN), stream, a);
   return xv_launch_status();
 }
 

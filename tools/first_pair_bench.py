@@ -4,6 +4,9 @@ import os
 import sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from modular_semantic_segmentation_amd import _lib  # noqa: E402
+if os.environ.get('XV_LIB'):            # A/B of library builds on one box (with XV_ALLOW_STALE_LIB=1)
+    _lib.LIB_PATH = os.environ['XV_LIB']
 from modular_semantic_segmentation_amd import ops  # noqa: E402
 
 N, H, W = 16, 384, 768
