@@ -274,7 +274,8 @@ def test_fp8_engine_against_fp8_policy_oracle(ops, h, w, plan):
     print('fp8 path vs fp8-policy oracle at %dx%d: max logit error %.4f of scale' % (w, h, np.abs(got - want).max() / scale))
     # the maximum over 3.5 M logits of a chaotic quantity (which e4m3 roundings flip depends on the last bit of every
     # earlier layer): 0.09-0.13 measured across kernel revisions; the layer-by-layer comparison above is the strict one
-    assert np.abs(got - want).max() / scale < 0.2
+    from tolerances import LOGIT_TOL_VS_POLICY
+    assert np.abs(got - want).max() / scale < LOGIT_TOL_VS_POLICY['fp8']
     lab, ref_lab = out['label'].cpu().numpy(), fo.argmax_last(fo.softmax(want))
     assert np.array_equal(lab, fo.argmax_last(fo.softmax(got)))
     top2 = np.sort(want, -1)[..., -2:]

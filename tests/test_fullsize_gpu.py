@@ -68,7 +68,8 @@ def test_fcn_full_size_against_oracle(ops):
     got = out['score'].cpu().numpy()
     scale = np.abs(ref).max()
     print('full-size logits vs the bf16-policy oracle: max error %.5f of the logit scale' % (np.abs(got - ref).max() / scale))
-    assert np.abs(got - ref).max() / scale < 1.8e-2        # 1.5 x the measured 1.2e-2 (13 conv layers of bf16 storage)
+    from tolerances import LOGIT_TOL_VS_POLICY
+    assert np.abs(got - ref).max() / scale < LOGIT_TOL_VS_POLICY['bf16']        # measured 1.2e-2 (13 conv layers of bf16 storage)
     lab = out['label'].cpu().numpy()
     assert np.array_equal(lab, fo.argmax_last(fo.softmax(got)))
     ref_lab = fo.argmax_last(fo.softmax(ref))

@@ -53,7 +53,8 @@ def _check_logits_and_labels(got_score, got_label, ref_score, what):
     scale = np.abs(ref_score).max()
     err = np.abs(got_score - ref_score).max() / scale
     # stated tolerance for bf16 storage + fp32 accumulation against the bf16-policy oracle
-    assert err < 2e-2, '%s: logits differ by %.3g of max|logit|' % (what, err)
+    from tolerances import LOGIT_TOL_VS_POLICY
+    assert err < LOGIT_TOL_VS_POLICY['bf16'], '%s: logits differ by %.3g of max|logit|' % (what, err)
     # labels: bit-exact against the oracle's softmax+argmax fed the SAME logits
     assert np.array_equal(got_label, fo.argmax_last(fo.softmax(got_score))), what
     ref_label = fo.argmax_last(fo.softmax(ref_score))
