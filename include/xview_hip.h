@@ -115,6 +115,22 @@ int xv_conv2d_fwd_stats(const xv_act* x, const void* w_packed, const float* bias
                         size_t stats_bytes, void* stream);
 int xv_bn_sums_from_rows(const float* rows, int nrows, int len, double* sums, void* stream);
 
+/* The routed pool of training (generation 4: bf16 maps that tile exactly in 16x32 pixels; XV_ESHAPE elsewhere -- keep the full
+ * map and xv_maxpool2x2_bwd there).  Replaces, bit for bit, tf.layers.conv2d(relu) + max_pooling2d forward and
+ * Conv2DBackpropInput + MaxPoolGrad + ReluGrad backward (simple_fcn.py:41,44,48 under base_model.py:153-162) without the
+ * full-resolution map and without the pooled gradient in memory:
+ *   xv_conv2d_fwd_route:      pooled = maxpool2x2(relu(conv3x3(x) + b)); route[n][h/2][w/2][cout] = one byte per pooled value:
+ *                             0 = the window's maximum is not positive, 1..4 = 1 + the first position of the maximum
+ *                             (row 0: columns 0, 1; row 1: columns 0, 1 -- MaxPoolGrad's order).
+ *   xv_conv2d_bwd_data_route: dx (twice dy's size) = conv3x3(dy, Wd) stored through `route`: every value at the position its
+ *                             byte names, zeros at the other three (every interior value of dx is written).
+ * xv_conv2d_route_bytes(n, h, w, cout): size of the route buffer of a conv over [n][h][w] maps (0: bad dimensions).      */
+size_t xv_conv2d_route_bytes(int n, int h, int w, int cout);
+int xv_conv2d_fwd_route(const xv_act* x, const void* w_packed, const float* bias, const xv_act* pooled, void* route,
+                        size_t route_bytes, void* stream);
+int xv_conv2d_bwd_data_route(const xv_act* dy, const void* w_packed_dgrad, const float* zero_bias, const void* route,
+                             size_t route_bytes, const xv_act* dx, void* stream);
+
 /* Residual form for the 1x1 convs that close a ResNet block: y = act(conv1x1(x, W) + b) + residual
  * (block_a / block_b of adapnet.py:38-51,80-100: stage_3 carries its own relu, the block's outer relu is the identity
  * on the sum of two non-negative maps).                                                                               */

@@ -113,6 +113,9 @@ SIGNATURES = {
     'xv_conv2d_stats_rows': (_i, []),
     'xv_conv2d_fwd_stats': (_i, [_actp, _vp, _vp, _actp, _vp, ctypes.c_size_t, _vp]),
     'xv_bn_sums_from_rows': (_i, [_vp, _i, _i, _vp, _vp]),
+    'xv_conv2d_route_bytes': (ctypes.c_size_t, [_i, _i, _i, _i]),
+    'xv_conv2d_fwd_route': (_i, [_actp, _vp, _vp, _actp, _vp, ctypes.c_size_t, _vp]),
+    'xv_conv2d_bwd_data_route': (_i, [_actp, _vp, _vp, _vp, ctypes.c_size_t, _actp, _vp]),
     'xv_bn_finalize_from_rows': (_i, [_vp, _i, _i, _i64, _vp, _vp, ctypes.c_float, ctypes.c_float, _vp, _vp, _vp, _vp, _vp, _vp,
                                       _vp, _vp]),
     'xv_bn_stats_finalize_ws': (_i, [_actp, _vp, _vp, ctypes.c_size_t, _vp, _vp, ctypes.c_float, ctypes.c_float, _vp, _vp, _vp,

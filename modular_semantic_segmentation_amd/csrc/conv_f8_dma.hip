@@ -60,6 +60,11 @@ struct F8Args {
   char* y2;
   char* pooled2;
   int n_first;
+  // ROUTED POOL (RT kernels, training): one byte per POOLED value -- 0 = the window's maximum is not positive (no gradient
+  // passes the relu), 1..4 = the first position of the maximum, in the order (row 0: columns 0, 1; row 1: columns 0, 1)
+  // MaxPoolGrad visits.  The forward form writes [N][H/2][W/2][Cout] beside the pooled map INSTEAD of the full map; the
+  // data-gradient form reads [N][H][W][Cout] and writes its result routed onto the map of twice the size (a.y).
+  char* route;
 };
 
 #ifdef XV_CLOCK_STAMP
@@ -148,9 +153,14 @@ __device__ __forceinline__ float g4_dpp_swap1(float v) {  // value of lane ^ 1 (
 // fragment j (pixel half h) of a row pair sits 1 KB behind fragment 0, so one base register serves a whole set.
 // DG (bf16 16x16 form only): the data-gradient epilogue -- y = (conv + addend) where mask > 0, else 0 -- as a kernel of its
 // own, so that the forward kernel carries neither its registers nor its branches
-template <bool F8, bool OF8 = F8, bool STATS = false, bool EDGE = false, bool M16 = false, bool DG = false>
+// RT (bf16 16x16 form, exact tilings): the routed pool of training (F8Args::route).  Forward: pooled map + route bytes, no
+// full map -- the layer's full-resolution output is read by nothing but MaxPoolGrad.  DG: MaxPoolGrad + ReluGrad in the
+// epilogue -- the gradient of the pooled map never goes to memory, every value is stored to the window position its route
+// byte names and zeros to the three others.
+template <bool F8, bool OF8 = F8, bool STATS = false, bool EDGE = false, bool M16 = false, bool DG = false, bool RT = false>
 __global__ __launch_bounds__(512, 2) void conv_dma4_kernel(F8Args a) {
   using C = G4;
+  static_assert(!RT || (M16 && !OF8 && !STATS && !EDGE), "the routed pool exists in the packed epilogue, exact tilings");
   static_assert(M16 != F8, "bf16 operands run on the 16x16x32 form, e4m3 operands on the 32x32x64 one");
   static_assert(!DG || (M16 && !OF8 && !STATS), "the data-gradient epilogue exists in the packed epilogue only");
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -321,8 +331,11 @@ __global__ __launch_bounds__(512, 2) void conv_dma4_kernel(F8Args a) {
   int items_done = 0;
   // (packed bf16 epilogue: 8 staged stores for the full map, ONE full-wave store per pixel half for the pooled map)
   constexpr bool STAGED = M16 && !OF8 && !STATS;
-  const int nstores = STAGED ? (a.y != nullptr ? 8 : 0) + (a.pooled != nullptr ? 2 : 0)
-                             : ((a.y != nullptr ? 4 : 0) + (a.pooled != nullptr ? 2 : 0)) * (OF8 ? 1 : 2);
+  // (routed pool: 2 more for the route bytes; its data-gradient form stores 2 rows x 4 window positions x 2 pixel halves,
+  // each as two staged 64-byte rounds)
+  const int nstores = RT ? (DG ? 32 : 4)
+                      : STAGED ? (a.y != nullptr ? 8 : 0) + (a.pooled != nullptr ? 2 : 0)
+                               : ((a.y != nullptr ? 4 : 0) + (a.pooled != nullptr ? 2 : 0)) * (OF8 ? 1 : 2);
   int in_flight = 0;  // stores issued after the last DMA of the previous item
 
   XV_CLK_BEGIN()
@@ -333,7 +346,9 @@ __global__ __launch_bounds__(512, 2) void conv_dma4_kernel(F8Args a) {
     G4_STAMP(0)  // arrival at the item barrier
     // This item's operands have landed (each wave retires its own DMA; the tile stores issued after it may stay in
     // flight: vmcnt counts in issue order), and every wave has finished reading the other buffer pair.
-    if (in_flight == 12)
+    if (RT && in_flight == 32)
+      asm volatile("s_waitcnt vmcnt(32)\n\ts_barrier" ::: "memory");
+    else if (in_flight == 12)
       asm volatile("s_waitcnt vmcnt(12)\n\ts_barrier" ::: "memory");
     else if (in_flight == 10)
       asm volatile("s_waitcnt vmcnt(10)\n\ts_barrier" ::: "memory");
@@ -574,7 +589,35 @@ __global__ __launch_bounds__(512, 2) void conv_dma4_kernel(F8Args a) {
           }
         }
       };
-      if constexpr (DG) dg_request(0);
+      if constexpr (DG && !RT) dg_request(0);
+      // routed pool, data gradient: the route bytes of the lane's 16 channels at its 2 rows x 2 pixel halves, requested at once
+      u32x4 rt[2][2];
+      if constexpr (DG && RT) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+            rt[u][i] = *reinterpret_cast<const u32x4*>(a.route + (((int64_t)cur.n * H + (py + i)) * W + (cur.x0 + 16 * u + n31)) * Cout +
+                                                       cur.co0 + 16 * hh);
+      }
+      // a lane's 16 channels of one pixel (8 packed words) to `dst` through the wave's store stage (see the full-map stores)
+      auto staged_store = [&](const uint32_t (&w8)[8], char* dst) {
+        u32x4* const stage = reinterpret_cast<u32x4*>(smem + C::STAGE_OFF + wave * 1024);
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+          if ((hh >> 1) == half) {
+            stage[n31 * 4 + 2 * (hh & 1)] = u32x4{w8[0], w8[1], w8[2], w8[3]};
+            stage[n31 * 4 + 2 * (hh & 1) + 1] = u32x4{w8[4], w8[5], w8[6], w8[7]};
+          }
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+          const u32x4 r = stage[lane];
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          *reinterpret_cast<u32x4*>(dst + half * 64) = r;
+        }
+      };
       char* const ymap = cur.second ? a.y2 : a.y;
       char* const qmap = cur.second ? a.pooled2 : a.pooled;
 #pragma unroll
@@ -601,7 +644,7 @@ __global__ __launch_bounds__(512, 2) void conv_dma4_kernel(F8Args a) {
           // lane that owns the pixel and channel group (a lane's 32 bytes are two pieces of ONE 64-byte half: it reads them in
           // the round of its half); then the other pixel half's request
           u32x4 ad[2][2], mk[2][2];
-          if constexpr (DG) {
+          if constexpr (DG && !RT) {
             u32x4* const xstage = reinterpret_cast<u32x4*>(smem + C::STAGE_OFF + wave * 1024);
             auto to_owner = [&](const u32x4 (&ld)[2], u32x4 (&own)[2]) {
 #pragma unroll
@@ -631,7 +674,7 @@ __global__ __launch_bounds__(512, 2) void conv_dma4_kernel(F8Args a) {
             float sv[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) sv[r] = acc4[i][r >> 3][u][(r >> 2) & 1][r & 3];  // r = 4 (2 j + jj) + q
-            if constexpr (DG) {
+            if constexpr (DG && !RT) {
               if (a.addend != nullptr) {  // added in fp32, before the one rounding (as every other generation)
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
@@ -643,7 +686,7 @@ __global__ __launch_bounds__(512, 2) void conv_dma4_kernel(F8Args a) {
             }
 #pragma unroll
             for (int k = 0; k < 8; ++k) pk[i][k] = pack_bf16x2(sv[2 * k], sv[2 * k + 1]);  // channels 2 k, 2 k + 1 of the lane's 16
-            if constexpr (DG) {
+            if constexpr (DG && !RT) {
               if (a.mask != nullptr) {
                 // keep the value where the reference activation is > 0: each bf16 half moved to the top of a 32-bit integer
                 // (negative values, -0 and +0 are <= 0 there).  (A packed 16-bit min / max form of this was miscompiled by
@@ -656,6 +699,35 @@ __global__ __launch_bounds__(512, 2) void conv_dma4_kernel(F8Args a) {
                 }
               }
             }
+          }
+          if constexpr (DG && RT) {
+            // MaxPoolGrad + ReluGrad: window position q of pooled pixel (py + i, pxl) is pixel (2 (py + i) + (q >> 1),
+            // 2 pxl + (q & 1)) of the full map; it takes the value where the route byte says q + 1, zero elsewhere (all
+            // four positions are written: the map needs no clearing).  Packed 16-bit arithmetic: min(code ^ (q + 1), 1) - 1
+            // = 0xffff where they are equal.
+            typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+            const int pxl = cur.x0 + 16 * u + (lane >> 2);
+            const int64_t Wf = 2 * (int64_t)W + 2;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+              uint32_t cd[8];
+#pragma unroll
+              for (int k = 0; k < 8; ++k)  // bytes 2 k, 2 k + 1 of the lane's 16 -> the two halves of a word
+                cd[k] = __builtin_amdgcn_perm(0u, rt[u][i][k >> 1], (k & 1) ? 0x0c030c02u : 0x0c010c00u);
+#pragma unroll
+              for (int q = 0; q < 4; ++q) {
+                uint32_t w8[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                  const u16x2 ne = __builtin_elementwise_min(__builtin_bit_cast(u16x2, cd[k]) ^ (u16x2)(unsigned short)(q + 1),
+                                                             (u16x2)(unsigned short)1);
+                  w8[k] = pk[i][k] & __builtin_bit_cast(uint32_t, ne - (u16x2)(unsigned short)1);
+                }
+                staged_store(w8, a.y + (((int64_t)cur.n * (2 * H + 2) + (2 * (py + i) + (q >> 1) + 1)) * Wf + (2 * pxl + (q & 1) + 1)) * Ob +
+                                     cur.co0 * 2 + (lane & 3) * 16);
+              }
+            }
+            continue;
           }
           if (a.y != nullptr) {
             const uint32_t rfloor = a.relu ? 0u : 0x80008000u;  // (0x8000 = the smallest int16: a no-op)
@@ -744,6 +816,32 @@ __global__ __launch_bounds__(512, 2) void conv_dma4_kernel(F8Args a) {
                         (lane >> 5) * 64 + (lane & 3) * 16;
             // every wave issues this instruction: the counted vmcnt at the next barrier relies on it
             if (!EDGE || (py < H && 2 * qx < W)) *reinterpret_cast<u32x4*>(dst) = r;
+            if constexpr (RT && !DG) {
+              // route bytes (relu form; the launcher takes no other): per channel the first window position whose value IS
+              // the maximum -- (row 0, own column), (row 0, lane ^ 1's column), (row 1, own), else (row 1, the other) -- and 0
+              // where the clamped maximum is 0.  Packed 16-bit arithmetic on the words the pool used: ne = min(v ^ max, 1) is 0
+              // where a value equals the maximum; equal bits are equal values here, the maximum being positive wherever the
+              // code is kept.  Even lanes (own column = window column 0) store, 16 bytes = the lane's 16 channels.
+              typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+              const u16x2 one = (u16x2)(unsigned short)1;
+              uint32_t rc[8];
+#pragma unroll
+              for (int k = 0; k < 8; ++k) {
+                const u16x2 mm = __builtin_bit_cast(u16x2, m[k]);
+                const u16x2 ne0 = __builtin_elementwise_min(__builtin_bit_cast(u16x2, pk[0][k]) ^ mm, one);
+                const u16x2 ne1 = __builtin_elementwise_min(__builtin_bit_cast(u16x2, pk_dpp_swap1(pk[0][k])) ^ mm, one);
+                const u16x2 ne2 = __builtin_elementwise_min(__builtin_bit_cast(u16x2, pk[1][k]) ^ mm, one);
+                const u16x2 n01 = ne0 & ne1;
+                rc[k] = __builtin_bit_cast(uint32_t, (u16x2)((ne0 + n01 + (n01 & ne2) + one) * __builtin_elementwise_min(mm, one)));
+              }
+              u32x4 rb;
+#pragma unroll
+              for (int j = 0; j < 4; ++j) rb[j] = __builtin_amdgcn_perm(rc[2 * j + 1], rc[2 * j], 0x06040200u);
+              const int rx = (cur.x0 + 16 * u + n31) >> 1;
+              // (every wave issues this instruction, as above)
+              if ((lane & 1) == 0)
+                *reinterpret_cast<u32x4*>(a.route + (((int64_t)cur.n * Hq + (py >> 1)) * Wq + rx) * Cout + cur.co0 + 16 * hh) = rb;
+            }
           }
           continue;
         }
@@ -935,15 +1033,15 @@ bool xv_conv3x3_dma4_bf16_ok(int H, int W, int Cin, int Cout) {
 bool xv_conv3x3_dma4_exact(int H, int W) { return (H & 15) == 0 && (W & 31) == 0; }
 
 namespace {
-template <bool F8, bool OF8, bool STATS, bool EDGE, bool M16, bool DG = false>
+template <bool F8, bool OF8, bool STATS, bool EDGE, bool M16, bool DG = false, bool RT = false>
 int g4_launch1(const F8Args& a, int grid, hipStream_t stream) {
   constexpr int lds = STATS ? G4::LDS_BYTES_STATS : G4::LDS_BYTES_STAGE + G4_TRACE_LDS;
   static_assert(lds <= 160 * 1024, "does not fit the LDS");
   static bool attr_set[XV_MAX_DEVICES] = {false};
   const hipError_t e =
-      xv_allow_dynamic_lds(reinterpret_cast<const void*>(&conv_dma4_kernel<F8, OF8, STATS, EDGE, M16, DG>), lds, attr_set);
+      xv_allow_dynamic_lds(reinterpret_cast<const void*>(&conv_dma4_kernel<F8, OF8, STATS, EDGE, M16, DG, RT>), lds, attr_set);
   if (e != hipSuccess) return (int)e;
-  hipLaunchKernelGGL((conv_dma4_kernel<F8, OF8, STATS, EDGE, M16, DG>), dim3((unsigned)grid), dim3(G4::NT), lds, stream, a);
+  hipLaunchKernelGGL((conv_dma4_kernel<F8, OF8, STATS, EDGE, M16, DG, RT>), dim3((unsigned)grid), dim3(G4::NT), lds, stream, a);
   return xv_launch_status();
 }
 template <bool F8, bool OF8, bool STATS = false, bool M16 = false>
@@ -993,6 +1091,34 @@ int xv_launch_conv3x3_f8_dma(const void* x, const void* wpk, const float* bias, 
                                        : g4_launch1<false, false, false, true, true, true>(a, grid, stream);
   if (in_f8) return g4_launch<true, true>(a, grid, stream);
   return out_f8 ? g4_launch<false, true, false, true>(a, grid, stream) : g4_launch<false, false, false, true>(a, grid, stream);
+}
+
+// The routed pool of training (F8Args::route), bf16 maps that tile exactly in 16x32.  dgrad = 0: pooled map + route bytes
+// [N][H/2][W/2][Cout] of relu(conv(x) + bias), no full map.  dgrad = 1: conv(x) (x = the gradient of the layer behind the
+// pool, at the pooled size H x W) routed onto `out`, the bf16 map [N][2H+2][2W+2][Cout].
+int xv_launch_conv3x3_dma4_route(const void* x, const void* wpk, const float* bias, void* out, void* route, int dgrad, int N,
+                                 int H, int W, int Cin, int Cout, int num_cus, hipStream_t stream) {
+  if (!xv_conv3x3_dma4_bf16_ok(H, W, Cin, Cout) || !xv_conv3x3_dma4_exact(H, W) || out == nullptr || route == nullptr)
+    return XV_ESHAPE;
+  F8Args a{};
+  a.x = (const char*)x, a.wpk = (const char*)wpk, a.bias = bias;
+  if (dgrad)
+    a.y = (char*)out;
+  else
+    a.pooled = (char*)out;
+  a.route = (char*)route;
+  a.N = N, a.H = H, a.W = W, a.Cin = Cin, a.Cout = Cout;
+  a.tiles_x = W / G4::TW;
+  a.tiles_y = H / G4::TH;
+  a.n_ct = Cout / 64;
+  const int64_t ntiles = (int64_t)a.tiles_x * a.tiles_y * N * a.n_ct;
+  if (ntiles <= 0 || ntiles > 0x7fffffff) return XV_ESHAPE;
+  a.n_tiles = (int)ntiles;
+  a.relu = dgrad ? 0 : 1;
+  a.out_mul = 1.f;
+  const int grid = num_cus > 0 ? num_cus : 256;
+  return dgrad ? g4_launch1<false, false, false, false, true, true, true>(a, grid, stream)
+               : g4_launch1<false, false, false, false, true, false, true>(a, grid, stream);
 }
 
 // Two problems of one shape in ONE launch (F8Args::n_first): the bf16 forward form on maps that tile exactly in 16x32.

@@ -44,6 +44,8 @@ int xv_launch_conv3x3_f8_dma(const void* x, const void* wpk, const float* bias, 
                              int Cin, int Cout, int relu, int in_f8, int out_f8, int scale_x, float out_mul, int num_cus,
                              hipStream_t stream, float* stats_rows = nullptr, int m16 = 0, const void* mask = nullptr,
                              const void* addend = nullptr);
+int xv_launch_conv3x3_dma4_route(const void* x, const void* wpk, const float* bias, void* out, void* route, int dgrad, int N,
+                                 int H, int W, int Cin, int Cout, int num_cus, hipStream_t stream);
 void xv_launch_pack_weights_f8_g4(const float* w, char* out, int taps, int cin, int cout, float mul, hipStream_t stream);
 // conv_col_dma.hip (generation 5: the generation-4 loop on a column of waves, 24x16 / 32x16 tiles, configurations 27 / 28)
 bool xv_conv3x3_col_ok(int H, int W, int Cin, int Cout, int mt);
@@ -1947,6 +1949,47 @@ extern "C" int xv_conv2d_fwd_stats(const xv_act* x, const void* w_packed, const 
   if (stats_bytes < (size_t)xv_num_cus() * 2 * y->c * sizeof(float)) return XV_EWORKSPACE;
   return xv_launch_conv3x3_f8_dma(x->data, w_packed, bias, y->data, nullptr, x->n, x->h, x->w, x->c, y->c, 0, 0, 0, 0, 1.f,
                                   xv_num_cus(), (hipStream_t)stream, stats_rows, 1);
+}
+
+// THE ROUTED POOL OF TRAINING (generation 4, bf16 maps that tile exactly in 16x32 pixels; XV_ESHAPE elsewhere: the caller then
+// keeps the full map and xv_maxpool2x2_bwd).  The full-resolution output of a conv in front of a pool is read by nothing
+// but MaxPoolGrad (max_pooling2d under the relu of tf.layers.conv2d: simple_fcn.py:41,44,48): the forward conv writes the
+// pooled map and one ROUTE BYTE per pooled value -- 0 where the window's maximum is not positive, else 1 + the first
+// position of the maximum in MaxPoolGrad's order -- and the data-gradient conv of the layer behind the pool stores its result
+// THROUGH the routes onto the full-resolution gradient map (zeros at the three other positions): 0.5 + 4 bytes per pooled
+// value of traffic where the full map (4 written, 4 read), the pooled gradient (1 + 1) and the routed map (4) made 14.
+extern "C" size_t xv_conv2d_route_bytes(int n, int h, int w, int cout) {
+  if (!xv_dims_sane(n, h, w) || cout <= 0 || (h & 1) || (w & 1)) return 0;
+  return (size_t)n * (h / 2) * (w / 2) * cout;
+}
+
+// pooled = maxpool2x2(relu(conv3x3(x) + bias)), route = its route bytes [n][h/2][w/2][cout]
+extern "C" int xv_conv2d_fwd_route(const xv_act* x, const void* w_packed, const float* bias, const xv_act* pooled, void* route,
+                                   size_t route_bytes, void* stream) {
+  XV_REQUIRE_BF16(x, pooled);
+  XV_CHECK_ARG(x && x->data && w_packed && bias && pooled && pooled->data && route);
+  XV_CHECK_ARG((((uintptr_t)x->data | (uintptr_t)w_packed | (uintptr_t)bias | (uintptr_t)pooled->data | (uintptr_t)route) & 15) == 0);
+  XV_CHECK_SHAPE(x->n > 0 && x->h > 0 && x->w > 0 && (x->c & 63) == 0 && (pooled->c & 63) == 0 && pooled->c > 0);
+  XV_CHECK_SHAPE(pooled->n == x->n && 2 * pooled->h == x->h && 2 * pooled->w == x->w);
+  if (!xv_conv3x3_dma4_bf16_ok(x->h, x->w, x->c, pooled->c) || !xv_conv3x3_dma4_exact(x->h, x->w)) return XV_ESHAPE;
+  if (route_bytes < xv_conv2d_route_bytes(x->n, x->h, x->w, pooled->c)) return XV_EWORKSPACE;
+  return xv_launch_conv3x3_dma4_route(x->data, w_packed, bias, pooled->data, route, 0, x->n, x->h, x->w, x->c, pooled->c,
+                                      xv_num_cus(), (hipStream_t)stream);
+}
+
+// dx (the map of twice dy's size) = MaxPoolGrad + ReluGrad of conv3x3(dy, Wd) through `route` ([n][dy.h][dy.w][dx.c] bytes of
+// xv_conv2d_fwd_route): the same bits as xv_conv2d_bwd_data onto a pooled-size map followed by xv_maxpool2x2_bwd
+extern "C" int xv_conv2d_bwd_data_route(const xv_act* dy, const void* w_packed_dgrad, const float* zero_bias, const void* route,
+                                        size_t route_bytes, const xv_act* dx, void* stream) {
+  XV_REQUIRE_BF16(dy, dx);
+  XV_CHECK_ARG(dy && dy->data && w_packed_dgrad && zero_bias && route && dx && dx->data);
+  XV_CHECK_ARG((((uintptr_t)dy->data | (uintptr_t)w_packed_dgrad | (uintptr_t)zero_bias | (uintptr_t)dx->data | (uintptr_t)route) & 15) == 0);
+  XV_CHECK_SHAPE(dy->n > 0 && dy->h > 0 && dy->w > 0 && (dy->c & 63) == 0 && (dx->c & 63) == 0 && dx->c > 0);
+  XV_CHECK_SHAPE(dx->n == dy->n && dx->h == 2 * dy->h && dx->w == 2 * dy->w);
+  if (!xv_conv3x3_dma4_bf16_ok(dy->h, dy->w, dy->c, dx->c) || !xv_conv3x3_dma4_exact(dy->h, dy->w)) return XV_ESHAPE;
+  if (route_bytes < xv_conv2d_route_bytes(dx->n, dx->h, dx->w, dx->c)) return XV_EWORKSPACE;
+  return xv_launch_conv3x3_dma4_route(dy->data, w_packed_dgrad, zero_bias, dx->data, const_cast<void*>(route), 1, dy->n, dy->h,
+                                      dy->w, dy->c, dx->c, xv_num_cus(), (hipStream_t)stream);
 }
 
 extern "C" size_t xv_deconv_dense_workspace_bytes(int n, int h, int w, int cout, int stride) {

@@ -353,22 +353,25 @@ class FcnEngine(object):
         ops.conv2d_fwd(L['conv5_3'], self.w8['score_conv5'], self.b['score_conv5'], 1, relu=True, y=s5)
         return L, s4, s5
 
-    def encoder(self, x, keep_all=False):
+    def encoder(self, x, keep_all=False, routed=False):
         """x: float32 [N,H,W,cin] device tensor (raw 0..255 RGB / raw depth, data contract of
         xview/datasets/*) -> dict of Acts; 'fused' is the encoding (simple_fcn.py:10-87).
-        keep_all=True also materialises every convX_Y / poolX like the reference's layer dict."""
-        return self.encoder_finish(self.encoder_begin(x, keep_all=keep_all, stop=len(ENCODER)))
+        keep_all=True also materialises every convX_Y / poolX like the reference's layer dict.
+        routed=True (with keep_all; the training step): a conv in front of a pool whose full map only MaxPoolGrad would read
+        leaves 'route_<name>' (uint8 route bytes, ops.conv2d_fwd_route) in the dict instead of '<name>', where the kernel
+        takes the shape."""
+        return self.encoder_finish(self.encoder_begin(x, keep_all=keep_all, stop=len(ENCODER), routed=routed))
 
     # The encoder in three steps, so that a fusion model can run the layers its two experts share as ONE launch each
     # (encoder_layers_pair below): encoder_begin (input checks, the first conv(s), the layers before `stop`), the remaining
     # layers (here or paired), encoder_finish (score convs, x2 upsampling + skip).
-    def encoder_begin(self, x, keep_all=False, stop=None):
+    def encoder_begin(self, x, keep_all=False, stop=None, routed=False):
         n, h, w, cin = x.shape
         if cin != self.cin:
             raise ValueError('expected %d input channels, got %d' % (self.cin, cin))
         if h % 16 or w % 16:
             raise ValueError('H and W must be multiples of 16 (augmentation.py:244-262 crop_multiple)')
-        st = {'n': n, 'h': h, 'w': w, 'keep_all': keep_all}
+        st = {'n': n, 'h': h, 'w': w, 'keep_all': keep_all, 'routed': bool(routed) and keep_all}
         if self.conv_dtype == 'fp8':
             st['L'], st['s4'], st['s5'] = self._encoder_fp8(x, keep_all)
             st['next'] = len(ENCODER)
@@ -428,6 +431,15 @@ class FcnEngine(object):
         for idx in range(st['next'], stop):
             name = ENCODER[idx][0]
             y, q = self._layer_outputs(st, idx)
+            if st.get('routed') and q is not None and name != 'conv4_3' and self._drop_fn() is None:
+                key = ('route_' + name, st['n'], q.h, q.w, q.c)
+                route = self._arena.get(key)
+                if route is None:
+                    route = self._arena[key] = torch.empty(st['n'] * q.h * q.w * q.c, dtype=torch.uint8, device=self.device)
+                if ops.conv2d_fwd_route(st['cur'], self.w[name], self.b[name], q, route):
+                    st['L']['route_' + name] = route
+                    self._layer_done(st, idx, None, q)
+                    continue
             ops.conv2d_fwd(st['cur'], self.w[name], self.b[name], 3, relu=True, y=y, pooled=q, write_y=y is not None,
                            workspace=self._sk(),
                            split_ws=ops.split_workspace(st['cur'], ENCODER[idx][1], self._arena) if q is None else None)

@@ -701,6 +701,37 @@ def maxpool2x2_bwd(y, dpooled, dy):
     return dy
 
 
+ROUTED_POOL = os.environ.get('XV_ROUTED_POOL', '1') != '0'     # 0: full maps + xv_maxpool2x2_bwd everywhere (A/B timing)
+
+
+def conv2d_fwd_route(x, w_packed, bias, pooled, route):
+    """pooled = maxpool2x2(relu(conv3x3(x) + bias)) and its route bytes (uint8 tensor of >= n * h/2 * w/2 * cout elements) in
+    one launch, no full map (xv_conv2d_fwd_route).  Returns False -- nothing launched -- where the generation-4 kernel does not
+    take the shape: the caller then writes the full map (conv2d_fwd) and routes with maxpool2x2_bwd."""
+    # (the data-gradient conv that reads the routes runs at the POOLED size: that must tile in 16x32 pixels too)
+    if not ROUTED_POOL or x.dtype != 'bf16' or x.h % 32 or x.w % 64:
+        return False
+    _need(bias, torch.float32, 'bias')
+    _need(route, torch.uint8, 'route')
+    with _Profiled('k3', 2.0 * x.n * x.h * x.w * x.c * pooled.c * 9):
+        rc = _lib.lib().xv_conv2d_fwd_route(x.xv(), _ptr(w_packed), _ptr(bias), pooled.xv(), _ptr(route), route.numel(), _stream())
+    if rc == -2:
+        return False
+    _lib.check(rc, 'xv_conv2d_fwd_route')
+    return True
+
+
+def conv2d_bwd_data_route(dy, w_packed_dgrad, zero_bias, route, dx):
+    """dx (twice dy's size) = MaxPoolGrad + ReluGrad of conv3x3(dy, Wd) through the route bytes of conv2d_fwd_route: the bits
+    of conv2d_bwd_data onto a pooled-size map + maxpool2x2_bwd, without either map in memory."""
+    _need(route, torch.uint8, 'route')
+    with _Profiled('dgrad_k3', 2.0 * dy.n * dy.h * dy.w * dx.c * dy.c * 9):
+        rc = _lib.lib().xv_conv2d_bwd_data_route(dy.xv(), _ptr(w_packed_dgrad), _ptr(zero_bias), _ptr(route), route.numel(),
+                                                 dx.xv(), _stream())
+    _lib.check(rc, 'xv_conv2d_bwd_data_route')
+    return dx
+
+
 def relu_bwd(g, ref, out):
     _lib.check(_lib.lib().xv_relu_bwd(g.xv(), ref.xv(), out.xv(), _stream()), 'xv_relu_bwd')
     return out

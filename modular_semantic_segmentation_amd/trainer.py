@@ -10,6 +10,7 @@ gradient buffer splits into contiguous buckets that become ready one after the o
 backward pass; each bucket is all-reduced (RCCL over xGMI) on a side HIP stream while the remaining
 layers are still differentiating.
 """
+import collections
 import contextlib
 import os
 
@@ -27,6 +28,9 @@ LAYER_ORDER = ['score', 'score_conv5', 'score_conv4'] + [name for name, _, _ in 
 BUCKETS = [['score', 'score_conv5', 'score_conv4', 'conv5_3', 'conv5_2', 'conv5_1'],
            ['conv4_3', 'conv4_2', 'conv4_1'],
            ['conv3_3', 'conv3_2', 'conv3_1', 'conv2_2', 'conv2_1', 'conv1_2', 'conv1_1']]
+
+
+_Shape = collections.namedtuple('_Shape', 'n h w c')      # what gact() reads of its `like` argument
 
 
 def encoder_backward(x, L, g, ds4, wd_s4, wd, zero_bias, G, gact, wws, after_layer=None, wstream=None):
@@ -71,8 +75,15 @@ def encoder_backward(x, L, g, ds4, wd_s4, wd, zero_bias, G, gact, wws, after_lay
             break
         if xin.startswith('pool'):
             # gradient w.r.t. the pooled map, then MaxPoolGrad + ReluGrad onto the conv above
-            dpool = ops.conv2d_bwd_data(g, wd[nm], zero_bias, gact(L[xin], 'g_' + xin), 3)
             above = names[names.index(nm) - 1]
+            route = L.get('route_' + above)
+            if route is not None:
+                # ... in the data-gradient conv's own epilogue, through the route bytes the forward conv left (the pooled
+                # gradient never reaches memory; the full map `above` was never written)
+                p = L[xin]
+                g = ops.conv2d_bwd_data_route(g, wd[nm], zero_bias, route, gact(_Shape(p.n, 2 * p.h, 2 * p.w, p.c), 'r_' + above))
+                continue
+            dpool = ops.conv2d_bwd_data(g, wd[nm], zero_bias, gact(L[xin], 'g_' + xin), 3)
             routed = ops.maxpool2x2_bwd(L[above], dpool, gact(L[above], 'r_' + above))
             if above == 'conv4_3':
                 # second gradient path into conv4_3: through the 1x1 score conv (AddN), then its relu
@@ -221,7 +232,7 @@ class FcnTrainer(object):
         """x: float32 [N,H,W,cin], labels: int32 [N,H,W] (device tensors).  Returns the loss (device
         float64 scalar tensor).  reducer: parallel.GradReducer for data-parallel runs."""
         e = self.e
-        L = e.encoder(x, keep_all=True)
+        L = e.encoder(x, keep_all=True, routed=True)
         n, h, w, _ = x.shape
         ops.zero_(self.grad)                            # (the library's memset: no framework kernel runs in the step)
         ops.zero_(self.loss)

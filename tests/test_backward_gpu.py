@@ -98,6 +98,84 @@ def test_maxpool_relu_backward_with_ties(ops):
     assert np.array_equal(dy.interior().float().cpu().numpy(), ref)
 
 
+@pytest.mark.parametrize('n,h,w,cin,cout,c2', [(2, 32, 64, 64, 64, 128), (1, 64, 64, 128, 128, 64), (1, 32, 128, 64, 256, 64)])
+def test_routed_pool_forward_and_data_gradient(ops, n, h, w, cin, cout, c2):
+    """The routed pool of the training step (xv_conv2d_fwd_route / xv_conv2d_bwd_data_route): pooled map and route bytes with no
+    full map, the data gradient of the layer behind the pool stored through the routes -- the same bits as the full map +
+    xv_conv2d_bwd_data + xv_maxpool2x2_bwd (MaxPoolGrad's first maximum, ReluGrad's y > 0), on sparse integers: many ties,
+    many windows without a positive value."""
+    rng = np.random.default_rng(n + h + cout)
+    x = (rng.integers(-2, 3, (n, h, w, cin)) * (rng.random((n, h, w, cin)) < 0.05)).astype(np.float32)
+    wt = rng.integers(-1, 2, (3, 3, cin, cout)).astype(np.float32)
+    b = _dev(rng.integers(-1, 2, cout).astype(np.float32))
+    wp = ops.pack_conv_weights(_dev(wt))
+    xa = ops.Act.from_dense(_dev(x))
+    y, q = ops.conv2d_fwd(xa, wp, b, 3, relu=True, y=ops.Act(n, h, w, cout), pooled=ops.Act(n, h // 2, w // 2, cout))
+    q2 = ops.Act(n, h // 2, w // 2, cout)
+    route = torch.full((n * (h // 2) * (w // 2) * cout,), 77, dtype=torch.uint8, device='cuda')
+    assert ops.conv2d_fwd_route(xa, wp, b, q2, route)
+    torch.cuda.synchronize()
+    assert torch.equal(q.t, q2.t)
+    yv = y.interior().float().cpu().numpy()
+    win = yv.reshape(n, h // 2, 2, w // 2, 2, cout).transpose(0, 1, 3, 5, 2, 4).reshape(n, h // 2, w // 2, cout, 4)
+    code = np.where(win.max(-1) > 0, 1 + win.argmax(-1), 0)              # (numpy's argmax: the first maximum)
+    got = route.view(n, h // 2, w // 2, cout).cpu().numpy()
+    assert np.array_equal(got, code)
+    assert 0.02 < (code == 0).mean() < 0.98 and len(np.unique(code)) == 5
+    # the layer behind the pool: gradient g of its output, data gradient onto the pooled map, routed onto the full map
+    w2 = rng.integers(-1, 2, (3, 3, cout, c2)).astype(np.float32)
+    g = ops.Act.from_dense(_dev(rng.integers(-2, 3, (n, h // 2, w // 2, c2)).astype(np.float32)))
+    wd = ops.pack_conv_weights_dgrad(_dev(w2))
+    zero = torch.zeros(cout, device='cuda')
+    dpool = ops.conv2d_bwd_data(g, wd, zero, ops.Act(n, h // 2, w // 2, cout), 3)
+    ref = ops.maxpool2x2_bwd(y, dpool, ops.Act(n, h, w, cout))
+    dx = ops.Act(n, h, w, cout)
+    dx.interior().fill_(3.0)                                              # every interior value is written
+    ops.conv2d_bwd_data_route(g, wd, zero, route, dx)
+    torch.cuda.synchronize()
+    assert torch.equal(dx.t, ref.t)
+    assert dx.interior().float().abs().sum().item() > 0
+
+
+def test_routed_pool_shapes_it_does_not_take(ops):
+    """Maps whose pooled size does not tile in 16x32 pixels: nothing launched, the caller keeps the full map."""
+    xa = ops.Act(1, 48, 96, 64)
+    wp = ops.pack_conv_weights(torch.zeros(3, 3, 64, 64, device='cuda'))
+    route = torch.zeros(24 * 48 * 64, dtype=torch.uint8, device='cuda')
+    assert not ops.conv2d_fwd_route(xa, wp, torch.zeros(64, device='cuda'), ops.Act(1, 24, 48, 64), route)
+
+
+def test_training_step_same_bits_with_and_without_routed_pool(ops, tmp_path, monkeypatch):
+    """Two Adam steps of an expert at 64x128 (pool1 and pool2 take the routed form, pool3 / pool4 do not): loss, gradients and
+    parameters bit-identical to the path through the full maps and xv_maxpool2x2_bwd."""
+    from modular_semantic_segmentation_amd import get_model
+    C, U, H, W = 12, 64, 64, 128
+    rng = np.random.default_rng(5)
+    data = {'rgb': rng.integers(0, 256, (2, H, W, 3)).astype(np.float32),
+            'labels': rng.integers(-1, C, (2, H, W)).astype(np.int32)}
+    w = fo.init_fcn_weights('rgb', 3, U, C, seed=2, bias_scale=0.02)
+    w['rgb/conv1_1/kernel'] *= 0.02
+    path = str(tmp_path / 'w.npz')
+    np.savez(path, **w)
+    desc = ({'rgb': 'float32', 'labels': 'int32'}, {'rgb': (None, None, 3), 'labels': (None, None)}, C)
+    results = []
+    for routed in (True, False):
+        monkeypatch.setattr(ops, 'ROUTED_POOL', routed)
+        net = get_model('fcn')('rgb', desc, 'rgb', output_dir=str(tmp_path), num_units=U, batch_normalization=False,
+                               batchsize=2, learning_rate=1e-3, trainer='adam')
+        net.import_weights(path, warnings=False)
+        tr = net._ensure_trainer()
+        losses = [tr.step(_dev(data['rgb']), _dev(data['labels'])).item() for _ in range(2)]
+        torch.cuda.synchronize()
+        L = tr.e.encoder(_dev(data['rgb']), keep_all=True, routed=True)
+        assert ('route_conv1_2' in L) == routed and ('route_conv2_2' in L) == routed and 'route_conv3_3' not in L
+        assert ('conv1_2' in L) != routed
+        results.append((losses, tr.grad.clone(), tr.param.clone()))
+    assert results[0][0] == results[1][0]
+    assert torch.equal(results[0][1], results[1][1])
+    assert torch.equal(results[0][2], results[1][2])
+
+
 def test_relu_backward(ops):
     rng = np.random.default_rng(2)
     g = fo.round_bf16(rng.standard_normal((1, 5, 7, 64)).astype(np.float32))
