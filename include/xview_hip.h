@@ -120,7 +120,7 @@ int xv_bn_sums_from_rows(const float* rows, int nrows, int len, double* sums, vo
  * Conv2DBackpropInput + MaxPoolGrad + ReluGrad backward (simple_fcn.py:41,44,48 under base_model.py:153-162) without the
  * full-resolution map and without the pooled gradient in memory:
  *   xv_conv2d_fwd_route:      pooled = maxpool2x2(relu(conv3x3(x) + b)); route[n][h/2][w/2][cout] = one byte per pooled value:
- *                             0 = the window's maximum is not positive, 1..4 = 1 + the first position of the maximum
+ *                             0 = the window's maximum is not positive, else 0x80 >> the first position of the maximum
  *                             (row 0: columns 0, 1; row 1: columns 0, 1 -- MaxPoolGrad's order).
  *   xv_conv2d_bwd_data_route: dx (twice dy's size) = conv3x3(dy, Wd) stored through `route`: every value at the position its
  *                             byte names, zeros at the other three (every interior value of dx is written).

@@ -61,7 +61,7 @@ struct F8Args {
   char* pooled2;
   int n_first;
   // ROUTED POOL (RT kernels, training): one byte per POOLED value -- 0 = the window's maximum is not positive (no gradient
-  // passes the relu), 1..4 = the first position of the maximum, in the order (row 0: columns 0, 1; row 1: columns 0, 1)
+  // passes the relu), else 0x80 >> the first position of the maximum, in the order (row 0: columns 0, 1; row 1: columns 0, 1)
   // MaxPoolGrad visits.  The forward form writes [N][H/2][W/2][Cout] beside the pooled map INSTEAD of the full map; the
   // data-gradient form reads [N][H][W][Cout] and writes its result routed onto the map of twice the size (a.y).
   char* route;
@@ -130,6 +130,35 @@ __device__ __forceinline__ uint32_t g4_pack_fp8x4(float v0, float v1, float v2, 
   p = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, p, false);
   p = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, p, true);
   return (uint32_t)p;
+}
+
+// packed 16-bit integer instructions of the routed pool, named explicitly: written as vector arithmetic the compiler turns
+// min(x ^ y, 1) into a compare and a select PER HALF (v_cmp_ne_u16 + SDWA twin + two v_cndmask + v_perm: 30 instructions per
+// word where these are 13)
+__device__ __forceinline__ uint32_t g4_pk_min_u16(uint32_t a, uint32_t k) {
+  uint32_t d;
+  asm("v_pk_min_u16 %0, %1, %2" : "=v"(d) : "v"(a), "s"(k));
+  return d;
+}
+__device__ __forceinline__ uint32_t g4_pk_mul_lo_u16(uint32_t a, uint32_t b) {
+  uint32_t d;
+  asm("v_pk_mul_lo_u16 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+  return d;
+}
+__device__ __forceinline__ uint32_t g4_pk_lshrrev_b16(uint32_t sh, uint32_t k) {  // k >> sh per half
+  uint32_t d;
+  asm("v_pk_lshrrev_b16 %0, %1, %2" : "=v"(d) : "v"(sh), "s"(k));
+  return d;
+}
+__device__ __forceinline__ uint32_t g4_pk_lshlrev_b16(uint32_t sh, uint32_t a) {  // a << sh per half
+  uint32_t d;
+  asm("v_pk_lshlrev_b16 %0, %1, %2" : "=v"(d) : "s"(sh), "v"(a));
+  return d;
+}
+__device__ __forceinline__ uint32_t g4_pk_sign_i16(uint32_t a) {  // 0xffff where bit 15 of a half is set, else 0
+  uint32_t d;
+  asm("v_pk_ashrrev_i16 %0, %1, %2" : "=v"(d) : "s"(0x000f000f), "v"(a));
+  return d;
 }
 
 __device__ __forceinline__ float g4_dpp_swap1(float v) {  // value of lane ^ 1 (quad_perm [1,0,3,2])
@@ -702,27 +731,22 @@ __global__ __launch_bounds__(512, 2) void conv_dma4_kernel(F8Args a) {
           }
           if constexpr (DG && RT) {
             // MaxPoolGrad + ReluGrad: window position q of pooled pixel (py + i, pxl) is pixel (2 (py + i) + (q >> 1),
-            // 2 pxl + (q & 1)) of the full map; it takes the value where the route byte says q + 1, zero elsewhere (all
-            // four positions are written: the map needs no clearing).  Packed 16-bit arithmetic: min(code ^ (q + 1), 1) - 1
-            // = 0xffff where they are equal.
-            typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+            // 2 pxl + (q & 1)) of the full map; it takes the value where the route byte is 0x80 >> q, zero elsewhere (all
+            // four positions are written: the map needs no clearing).
             const int pxl = cur.x0 + 16 * u + (lane >> 2);
             const int64_t Wf = 2 * (int64_t)W + 2;
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
               uint32_t cd[8];
 #pragma unroll
-              for (int k = 0; k < 8; ++k)  // bytes 2 k, 2 k + 1 of the lane's 16 -> the two halves of a word
-                cd[k] = __builtin_amdgcn_perm(0u, rt[u][i][k >> 1], (k & 1) ? 0x0c030c02u : 0x0c010c00u);
+              for (int k = 0; k < 8; ++k)  // bytes 2 k, 2 k + 1 of the lane's 16 -> the HIGH bytes of a word's two halves
+                cd[k] = __builtin_amdgcn_perm(0u, rt[u][i][k >> 1], (k & 1) ? 0x030c020cu : 0x010c000cu);
 #pragma unroll
               for (int q = 0; q < 4; ++q) {
                 uint32_t w8[8];
 #pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                  const u16x2 ne = __builtin_elementwise_min(__builtin_bit_cast(u16x2, cd[k]) ^ (u16x2)(unsigned short)(q + 1),
-                                                             (u16x2)(unsigned short)1);
-                  w8[k] = pk[i][k] & __builtin_bit_cast(uint32_t, ne - (u16x2)(unsigned short)1);
-                }
+                for (int k = 0; k < 8; ++k)  // position q's bit (0x80 >> q of the byte) to the sign, the sign over the half
+                  w8[k] = pk[i][k] & g4_pk_sign_i16(q == 0 ? cd[k] : g4_pk_lshlrev_b16(q * 0x00010001u, cd[k]));
                 staged_store(w8, a.y + (((int64_t)cur.n * (2 * H + 2) + (2 * (py + i) + (q >> 1) + 1)) * Wf + (2 * pxl + (q & 1) + 1)) * Ob +
                                      cur.co0 * 2 + (lane & 3) * 16);
               }
@@ -817,22 +841,21 @@ __global__ __launch_bounds__(512, 2) void conv_dma4_kernel(F8Args a) {
             // every wave issues this instruction: the counted vmcnt at the next barrier relies on it
             if (!EDGE || (py < H && 2 * qx < W)) *reinterpret_cast<u32x4*>(dst) = r;
             if constexpr (RT && !DG) {
-              // route bytes (relu form; the launcher takes no other): per channel the first window position whose value IS
-              // the maximum -- (row 0, own column), (row 0, lane ^ 1's column), (row 1, own), else (row 1, the other) -- and 0
+              // route bytes (relu form; the launcher takes no other): per channel 0x80 >> the first window position whose value
+              // IS the maximum -- (row 0, own column), (row 0, lane ^ 1's column), (row 1, own), else (row 1, the other) -- and 0
               // where the clamped maximum is 0.  Packed 16-bit arithmetic on the words the pool used: ne = min(v ^ max, 1) is 0
               // where a value equals the maximum; equal bits are equal values here, the maximum being positive wherever the
               // code is kept.  Even lanes (own column = window column 0) store, 16 bytes = the lane's 16 channels.
-              typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
-              const u16x2 one = (u16x2)(unsigned short)1;
+              constexpr uint32_t K1 = 0x00010001u;
               uint32_t rc[8];
 #pragma unroll
               for (int k = 0; k < 8; ++k) {
-                const u16x2 mm = __builtin_bit_cast(u16x2, m[k]);
-                const u16x2 ne0 = __builtin_elementwise_min(__builtin_bit_cast(u16x2, pk[0][k]) ^ mm, one);
-                const u16x2 ne1 = __builtin_elementwise_min(__builtin_bit_cast(u16x2, pk_dpp_swap1(pk[0][k])) ^ mm, one);
-                const u16x2 ne2 = __builtin_elementwise_min(__builtin_bit_cast(u16x2, pk[1][k]) ^ mm, one);
-                const u16x2 n01 = ne0 & ne1;
-                rc[k] = __builtin_bit_cast(uint32_t, (u16x2)((ne0 + n01 + (n01 & ne2) + one) * __builtin_elementwise_min(mm, one)));
+                const uint32_t ne0 = g4_pk_min_u16(pk[0][k] ^ m[k], K1);
+                const uint32_t ne1 = g4_pk_min_u16(pk_dpp_swap1(pk[0][k]) ^ m[k], K1);
+                const uint32_t ne2 = g4_pk_min_u16(pk[1][k] ^ m[k], K1);
+                const uint32_t n01 = ne0 & ne1;
+                // 0x80 >> (position of the first maximum), times (maximum != 0)   (no carries between the halves: sums <= 3)
+                rc[k] = g4_pk_mul_lo_u16(g4_pk_lshrrev_b16(ne0 + n01 + (n01 & ne2), 0x00800080u), g4_pk_min_u16(m[k], K1));
               }
               u32x4 rb;
 #pragma unroll

@@ -1954,7 +1954,7 @@ extern "C" int xv_conv2d_fwd_stats(const xv_act* x, const void* w_packed, const 
 // THE ROUTED POOL OF TRAINING (generation 4, bf16 maps that tile exactly in 16x32 pixels; XV_ESHAPE elsewhere: the caller then
 // keeps the full map and xv_maxpool2x2_bwd).  The full-resolution output of a conv in front of a pool is read by nothing
 // but MaxPoolGrad (max_pooling2d under the relu of tf.layers.conv2d: simple_fcn.py:41,44,48): the forward conv writes the
-// pooled map and one ROUTE BYTE per pooled value -- 0 where the window's maximum is not positive, else 1 + the first
+// pooled map and one ROUTE BYTE per pooled value -- 0 where the window's maximum is not positive, else 0x80 >> the first
 // position of the maximum in MaxPoolGrad's order -- and the data-gradient conv of the layer behind the pool stores its result
 // THROUGH the routes onto the full-resolution gradient map (zeros at the three other positions): 0.5 + 4 bytes per pooled
 // value of traffic where the full map (4 written, 4 read), the pooled gradient (1 + 1) and the routed map (4) made 14.

@@ -118,7 +118,7 @@ def test_routed_pool_forward_and_data_gradient(ops, n, h, w, cin, cout, c2):
     assert torch.equal(q.t, q2.t)
     yv = y.interior().float().cpu().numpy()
     win = yv.reshape(n, h // 2, 2, w // 2, 2, cout).transpose(0, 1, 3, 5, 2, 4).reshape(n, h // 2, w // 2, cout, 4)
-    code = np.where(win.max(-1) > 0, 1 + win.argmax(-1), 0)              # (numpy's argmax: the first maximum)
+    code = np.where(win.max(-1) > 0, 0x80 >> win.argmax(-1), 0)          # (numpy's argmax: the first maximum)
     got = route.view(n, h // 2, w // 2, cout).cpu().numpy()
     assert np.array_equal(got, code)
     assert 0.02 < (code == 0).mean() < 0.98 and len(np.unique(code)) == 5
