@@ -605,14 +605,13 @@ __global__ __launch_bounds__(512) void conv_first_wgrad_mfma_kernel(const float*
     for (int cb = 0; cb < 4; ++cb) acc[tb][cb] = f32x4{0.f, 0.f, 0.f, 0.f};
   // A quad = 4 consecutive pixels of one image row (W % 4 == 0, checked by the launcher): its position is wave-uniform
   // and walks incrementally (scalar unit); a lane's tap is at (quad origin) + a lane constant, outside the image only
-  // on the quad's edge flags (bit 0 first row, 1 last row, 2 first quad of the row, 3 last quad) -- as in the forward kernel
-  int loff[TB], kill[TB];
-#pragma unroll
-  for (int tb = 0; tb < TB; ++tb) {
-    loff[tb] = ((tdy[tb] * W + tdx[tb] + kq) * CIN + tci[tb]);
-    kill[tb] = kind[tb] != 0 ? 16 : ((tdy[tb] < 0 ? 1 : 0) | (tdy[tb] > 0 ? 2 : 0) | ((kq == 0 && tdx[tb] < 0) ? 4 : 0) |
-                                     ((kq == 3 && tdx[tb] > 0) ? 8 : 0));
-  }
+  // on the quad's edge flags (bit 0 first row, 1 last row, 2 first quad of the row, 3 last quad) -- as in the forward kernel.
+  // All loads are bounds-checked BUFFER loads from descriptors that start at the wave's first quad (X: one row and one
+  // pixel earlier, so every tap offset is non-negative): a tap outside the image, a row of the operand that is not a tap,
+  // a quad past the wave's share get an offset past the descriptor and read 0 -- no branch around any load (the plain
+  // loads compiled into an exec-mask branch per load and ~60 scalar instructions per quad of 64-bit addressing: 270 us where
+  // the 8 matrix instructions per quad need 125), and the scalar walk is two 32-bit additions.
+  constexpr uint32_t OOB = 0x80000000u;
   const int nquads = (N * H * W) >> 2;  // N * H * W < 2^31 (checked by the launcher)
   const int wid = __builtin_amdgcn_readfirstlane(blockIdx.x * 8 + wave);
   const int q0 = wid * quads_per_wave;
@@ -621,31 +620,53 @@ __global__ __launch_bounds__(512) void conv_first_wgrad_mfma_kernel(const float*
   int qrow = q0 / Wq;                 // n * H + y of the next quad to request
   int qx = (q0 - qrow * Wq) * 4;
   int qn = qrow / H, qy = qrow - qn * H;
+  const int back = (W + 1) * CIN * 4;  // bytes the X descriptor starts before the first quad
+  uint32_t xoff[TB], kill[TB];
+#pragma unroll
+  for (int tb = 0; tb < TB; ++tb) {
+    xoff[tb] = (uint32_t)(back + ((tdy[tb] * W + tdx[tb] + kq) * CIN + tci[tb]) * 4);
+    kill[tb] = kind[tb] != 0 ? 16u : ((tdy[tb] < 0 ? 1u : 0u) | (tdy[tb] > 0 ? 2u : 0u) | ((kq == 0 && tdx[tb] < 0) ? 4u : 0u) |
+                                      ((kq == 3 && tdx[tb] > 0) ? 8u : 0u));
+  }
+  auto wave_rsrc = [](const void* base, int64_t bytes) {  // (built from readfirstlane'd halves: no waterfall loop)
+    const uint64_t a = (uint64_t)base;
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)a), hi = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32));
+    const int nrec = __builtin_amdgcn_readfirstlane((int)(bytes < 0x40000000 ? bytes : 0x40000000));
+    return __builtin_amdgcn_make_buffer_rsrc((void*)(((uint64_t)hi << 32) | lo), 0, nrec, 0x00020000);
+  };
+  // (a wave's share is a few thousand pixels: its offsets stay far below the 1 GB the descriptors are capped at)
+  const int64_t xel0 = (int64_t)q0 * 4 * CIN;  // element of the first quad in X (dense [N][H][W][CIN]: linear in the quad)
+  const int64_t del0 = (((int64_t)qn * (H + 2) + (qy + 1)) * (W + 2) + (qx + 1)) * 64;
+  const auto xrs = wave_rsrc(reinterpret_cast<const char*>(x + xel0) - back, ((int64_t)N * H * W * CIN - xel0) * 4 + back);
+  const auto drs = wave_rsrc(dy + del0, ((int64_t)N * (H + 2) * (W + 2) * 64 - del0) * 2);
+  const uint32_t dlane = (uint32_t)(kq * 128 + i * 8);
+  uint32_t xwalk = 0, dwalk = 0;  // byte offsets of the next quad behind the descriptors' first
   for (int q = q0; q < q1; q += 4) {
     float a[4][TB];
     u32x2 g[4];
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
       const bool ok = q + b < q1;
-      const int edge = (qy == 0 ? 1 : 0) | (qy == H - 1 ? 2 : 0) | (qx == 0 ? 4 : 0) | (qx == W - 4 ? 8 : 0) | 16;
-      const int xbase = ((qn * H + qy) * W + qx) * CIN;  // < 2^31: N * H * W * CIN is checked by the launcher
-      const int64_t dbase = (((int64_t)qn * (H + 2) + (qy + 1)) * (W + 2) + (qx + 1)) * 64;
-      const u32x2 gv = *reinterpret_cast<const u32x2*>(dy + (ok ? dbase : 0) + (ok ? kq * 64 : 0) + 4 * i);
-      g[b] = ok ? gv : u32x2{0u, 0u};
+      const uint32_t edge = (qy == 0 ? 1u : 0u) | (qy == H - 1 ? 2u : 0u) | (qx == 0 ? 4u : 0u) | (qx == W - 4 ? 8u : 0u) | 16u;
+      g[b] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(drs, dlane, ok ? dwalk : OOB, 0));
 #pragma unroll
       for (int tb = 0; tb < TB; ++tb) {
-        const bool in = ok && (kill[tb] & edge) == 0;
-        const float v = x[in ? xbase + loff[tb] : 0];
-        a[b][tb] = in ? v : ((ok && kind[tb] == 1) ? 1.f : 0.f);
+        const float v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, (kill[tb] & edge) == 0 ? xoff[tb] : OOB,
+                                                                                      ok ? xwalk : OOB, 0));
+        a[b][tb] = kind[tb] == 1 ? (ok ? 1.f : 0.f) : v;
       }
-      // next quad (wave-uniform walk)
+      // next quad (wave-uniform walk): X is dense, dY skips its border columns at a row end and a border row pair at an image end
+      xwalk += 16 * CIN;
+      dwalk += 4 * 128;
       qx += 4;
       if (qx == W) {
         qx = 0;
         qy += 1;
+        dwalk += 2 * 128;
         if (qy == H) {
           qy = 0;
           qn += 1;
+          dwalk += 2 * (W + 2) * 128;
         }
       }
     }
