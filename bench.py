@@ -419,12 +419,39 @@ def host_boundary_record(device, samples=256, batch=16, h=384, w=768):
                          'host_bytes_per_image': {'in': int(h * w * 4 * 4), 'labels_out': int(h * w * 8)}}
         finally:
             host_pipeline.ENABLED = True
+    rec['fit'] = host_fit_rate(device, {k: data[k][:8 * batch] for k in ('rgb', 'labels')}, batch)
     rec['value'] = rec['pipelined']['predict_images_per_s']
     rec['note'] = ('value = predict(); input staging 12.6 MB per RGB-D pair by worker threads into pinned memory, H2D on a copy '
                    'stream, labels back as one byte per pixel and widened to int64 into the result array')
     del net
     torch.cuda.empty_cache()
     return rec
+
+
+def host_fit_rate(device, data, batch, steps=32):
+    """fit() of one RGB expert from HOST arrays (base_model.py:180-261: the reference feeds its training loop from a tf.data
+    prefetch): images/s of `steps` training steps including staging and upload, next to the same steps from batches resident in
+    HBM."""
+    from modular_semantic_segmentation_amd import get_model
+    desc = ({'rgb': 'float32', 'labels': 'int32'}, {'rgb': (None, None, 3), 'labels': (None, None)}, C)
+    net = get_model('fcn')('rgb', desc, 'rgb', num_units=U, batch_normalization=False, batchsize=batch, learning_rate=1e-4,
+                           trainer='adam', seed=1, device=str(device), output_dir=None)
+    out = {'steps': steps, 'batchsize': batch}
+    resident = {k: torch.from_numpy(v[:4 * batch]).to(device) for k, v in data.items()}
+    for name, d in (('host', data), ('resident', resident)):
+        net.fit(d, 4, output=False)
+        torch.cuda.synchronize(device)
+        best = None
+        for _ in range(3):
+            t0 = time.perf_counter()
+            net.fit(d, steps, output=False)
+            torch.cuda.synchronize(device)
+            dt = time.perf_counter() - t0
+            best = dt if best is None else min(best, dt)
+        out[name + '_images_per_s'] = round(steps * batch / best, 1)
+    del net
+    torch.cuda.empty_cache()
+    return out
 
 
 def make_trainer_net(args, device, expert, joint, batch):

@@ -570,6 +570,13 @@ int xv_softmax_ce_dense_ws(const float* scores, const float* scale, const float*
                            size_t ws_bytes, void* stream);
 int xv_score_dense_bwd(const xv_act* u, const float* dscore, const float* w_score, int num_classes, float* dw_score,
                        float* db_score, const xv_act* du, void* stream);
+/* The same with the filter and bias gradients added in a FIXED order (64 units, at most 16 classes -- the matrix-core form):
+ * every workgroup leaves its partial sums in `workspace` (xv_score_dense_bwd_workspace_bytes(n, h, w) bytes, 16-byte aligned),
+ * two small launches add them onto dw_score / db_score -- bitwise reproducible from run to run (the entry above adds them by
+ * fp32 atomics in arrival order).  workspace == NULL: that form.                                                          */
+size_t xv_score_dense_bwd_workspace_bytes(int n, int h, int w);
+int xv_score_dense_bwd_ws(const xv_act* u, const float* dscore, const float* w_score, int num_classes, float* dw_score,
+                          float* db_score, const xv_act* du, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- "exact" mode (conv_dtype='fp32'): the FCN trunk in plain float32 on dense UNPADDED NHWC maps -- the reference
  * graph's own arithmetic type (tf.layers.conv2d / max_pooling2d / conv2d_transpose on float32: simple_fcn.py:39-87,

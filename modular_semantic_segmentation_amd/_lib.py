@@ -141,6 +141,8 @@ SIGNATURES = {
     'xv_softmax_ce_dense_workspace_bytes': (ctypes.c_size_t, [_i64]),
     'xv_softmax_ce_dense_ws': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i64, _vp, _vp, _vp, ctypes.c_size_t, _vp]),
     'xv_score_dense_bwd': (_i, [_actp, _vp, _vp, _i, _vp, _vp, _actp, _vp]),
+    'xv_score_dense_bwd_workspace_bytes': (ctypes.c_size_t, [_i, _i, _i]),
+    'xv_score_dense_bwd_ws': (_i, [_actp, _vp, _vp, _i, _vp, _vp, _actp, _vp, ctypes.c_size_t, _vp]),
     'xv_conv2d_f32': (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _i, _i, _i, _vp, _vp]),
     'xv_conv2d_f32_pool': (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
     'xv_conv2d_f32_scalar': (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _i, _i, _i, _vp, _vp]),

@@ -1180,7 +1180,8 @@ __global__ __launch_bounds__(256) void score_dense_dgrad_mfma_kernel(const float
 template <int UE>  // U / 8 = channels per lane
 __global__ __launch_bounds__(256) void score_dense_wgrad_mfma_kernel(const __bf16* __restrict__ u, const float* __restrict__ ds,
                                                                     float* __restrict__ dws, float* __restrict__ dbs, int N,
-                                                                    int H, int W, int C, int quads_per_wave) {
+                                                                    int H, int W, int C, int quads_per_wave,
+                                                                    float* __restrict__ part) {
   static_assert(UE == 8, "64 channels: 8 lanes x 8 channels per pixel");
   constexpr int U = 8 * UE;
   __shared__ float red[4][UE * 4 + 1][64];
@@ -1223,6 +1224,10 @@ __global__ __launch_bounds__(256) void score_dense_wgrad_mfma_kernel(const __bf1
   for (int i = threadIdx.x; i < (UE * 4 + 1) * 64; i += 256) {
     const int row = i >> 6, ln = i & 63;
     const float v = ((red[0][row][ln] + red[1][row][ln]) + red[2][row][ln]) + red[3][row][ln];
+    if (part != nullptr) {  // the workgroup's own row of partial sums: bn_sums_kernel + score_dense_wgrad_scatter_kernel add
+      part[(int64_t)blockIdx.x * ((UE * 4 + 1) * 64) + i] = v;  // them in a fixed order (bitwise reproducible gradients)
+      continue;
+    }
     const int n = ln & 15, g = ln >> 4;
     if (row < UE * 4) {
       const int cls = 4 * g + (row & 3), ch = 8 * n + (row >> 2);
@@ -1230,6 +1235,22 @@ __global__ __launch_bounds__(256) void score_dense_wgrad_mfma_kernel(const __bf1
     } else if (n < C && v != 0.f) {
       atomicAdd(dbs + n, v);  // (the four pixel slots of class n add up here)
     }
+  }
+}
+
+// the cells of score_dense_wgrad_mfma_kernel's partial rows, summed over the workgroups (sums: [33][64] doubles), onto the
+// gradients: cell (row, lane) = dW[channel 8 (lane & 15) + row / 4][class 4 (lane >> 4) + row % 4]; row 32 = the four pixel
+// slots of db[lane & 15], added in slot order
+__global__ __launch_bounds__(256) void score_dense_wgrad_scatter_kernel(const double* __restrict__ sums, int C,
+                                                                       float* __restrict__ dws, float* __restrict__ dbs) {
+  for (int i = threadIdx.x; i < 32 * 64; i += 256) {
+    const int row = i >> 6, ln = i & 63, n = ln & 15, g = ln >> 4;
+    const int cls = 4 * g + (row & 3), ch = 8 * n + (row >> 2);
+    if (n < 8 && cls < C) dws[ch * C + cls] += (float)sums[i];
+  }
+  if ((int)threadIdx.x < C) {
+    const double* b = sums + 32 * 64 + threadIdx.x;
+    dbs[threadIdx.x] += (float)(((b[0] + b[16]) + b[32]) + b[48]);
   }
 }
 
@@ -1659,8 +1680,30 @@ extern "C" int xv_softmax_ce_dense(const float* logits, const int32_t* labels, c
   return xv_softmax_ce_dense_ws(logits, nullptr, nullptr, labels, valid_count, num_classes, npix, loss, dlogits, nullptr, 0, stream);
 }
 
+// workspace of xv_score_dense_bwd_ws: one row of 33 x 64 partial sums per workgroup of the filter-gradient kernel + their totals
+static unsigned score_dense_wgrad_grid(int64_t npix, int& qpw) {
+  const int64_t nquads = (npix + 3) / 4;
+  qpw = (int)((nquads + 2047) / 2048);
+  qpw = (qpw + 3) / 4 * 4;
+  return (unsigned)((nquads + (int64_t)4 * qpw - 1) / ((int64_t)4 * qpw));
+}
+extern "C" size_t xv_score_dense_bwd_workspace_bytes(int n, int h, int w) {
+  if (!xv_dims_sane(n, h, w) || (int64_t)n * h * w >= 0x7fff0000) return 0;
+  int qpw;
+  return (size_t)score_dense_wgrad_grid((int64_t)n * h * w, qpw) * 33 * 64 * sizeof(float) + 33 * 64 * sizeof(double);
+}
+
+extern "C" int xv_score_dense_bwd_ws(const xv_act* u, const float* dscore, const float* w_score, int num_classes, float* dw_score,
+                                     float* db_score, const xv_act* du, void* workspace, size_t workspace_bytes, void* stream);
 extern "C" int xv_score_dense_bwd(const xv_act* u, const float* dscore, const float* w_score, int num_classes,
                                   float* dw_score, float* db_score, const xv_act* du, void* stream) {
+  return xv_score_dense_bwd_ws(u, dscore, w_score, num_classes, dw_score, db_score, du, nullptr, 0, stream);
+}
+
+// workspace (xv_score_dense_bwd_workspace_bytes; 64 units and at most 16 classes -- the matrix-core form): the filter and bias
+// gradients are added in a fixed order instead of by atomics in arrival order: bitwise reproducible from run to run
+extern "C" int xv_score_dense_bwd_ws(const xv_act* u, const float* dscore, const float* w_score, int num_classes, float* dw_score,
+                                     float* db_score, const xv_act* du, void* workspace, size_t workspace_bytes, void* stream) {
   XV_REQUIRE_BF16(u, du);
   XV_CHECK_ARG(u && u->data && dscore && w_score && dw_score && db_score && du && du->data);
   XV_CHECK_SHAPE((u->c & 63) == 0 && u->c <= 256 && num_classes >= 1 && num_classes <= 32 && same_shape(u, du));
@@ -1679,18 +1722,29 @@ extern "C" int xv_score_dense_bwd(const xv_act* u, const float* dscore, const fl
   const bool mfma_dgrad = u->c == 64 && num_classes <= 16 && !sd_old;  // exact fp32 on v_mfma_f32_16x16x4_f32
   static const bool wg_old = getenv("XV_SCORE_WGRAD_OLD") != nullptr;
   // filter gradient: at most 512 workgroups (each ends with ~800 same-address atomics); a wave walks a contiguous run
-  const int64_t nquads = (npix + 3) / 4;
-  int qpw = (int)((nquads + 2047) / 2048);
-  qpw = (qpw + 3) / 4 * 4;
-  const unsigned gwm = (unsigned)((nquads + (int64_t)4 * qpw - 1) / ((int64_t)4 * qpw));
+  int qpw;
+  const unsigned gwm = score_dense_wgrad_grid(npix, qpw);
   hipStream_t s = (hipStream_t)stream;
+  float* part = nullptr;
+  if (workspace != nullptr && mfma_dgrad && !wg_old) {
+    if (workspace_bytes < xv_score_dense_bwd_workspace_bytes(u->n, u->h, u->w)) return XV_EWORKSPACE;
+    XV_CHECK_ARG(((uintptr_t)workspace & 15) == 0);
+    part = (float*)workspace;
+  }
 #define XV_SB(CMV)                                                                                                   \
   {                                                                                                                  \
     static bool attr[XV_MAX_DEVICES] = {false};                                                                      \
     (void)xv_allow_dynamic_lds(reinterpret_cast<const void*>(&score_dense_dgrad_kernel<CMV>), 160 * 1024, attr, false);      \
     if (mfma_dgrad && !wg_old) {                                                                                     \
       hipLaunchKernelGGL(score_dense_wgrad_mfma_kernel<8>, dim3(gwm), dim3(256), 0, s, (const __bf16*)u->data, dscore, \
-                         dw_score, db_score, u->n, u->h, u->w, num_classes, qpw);                                     \
+                         dw_score, db_score, u->n, u->h, u->w, num_classes, qpw, part);                               \
+      if (part != nullptr) {                                                                                         \
+        double* const tot = reinterpret_cast<double*>(part + (size_t)gwm * 33 * 64);                                 \
+        hipLaunchKernelGGL(bn_sums_kernel, dim3(33 * 64), dim3(256), 0, s, (const float*)part, (int)gwm, 33 * 64, tot, \
+                           (float*)nullptr, (float*)nullptr);                                                        \
+        hipLaunchKernelGGL(score_dense_wgrad_scatter_kernel, dim3(1), dim3(256), 0, s, (const double*)tot, num_classes, \
+                           dw_score, db_score);                                                                      \
+      }                                                                                                              \
     } else {                                                                                                         \
       hipLaunchKernelGGL(score_dense_wgrad_kernel<CMV>, dim3(gw), dim3(256), 0, s, (const __bf16*)u->data, dscore,    \
                          dw_score, db_score, u->n, u->h, u->w, u->c, num_classes, per_block);                         \

@@ -983,8 +983,19 @@ def softmax_ce_dense(logits, labels, count, num_classes, loss, dlogits, affine=N
     return dlogits
 
 
+_SD_WS = {}
+
+
 def score_dense_bwd(u, dscore, w_score, num_classes, dw_score, db_score, du):
-    rc = _lib.lib().xv_score_dense_bwd(u.xv(), _ptr(dscore), _ptr(w_score), num_classes, _ptr(dw_score), _ptr(db_score),
-                                       du.xv(), _stream())
-    _lib.check(rc, 'xv_score_dense_bwd')
+    """Backward of the dense 1x1 score layer at full resolution; filter and bias gradients added in a fixed order (a workspace
+    per device and map size, owned by the stream the trainers run on): bitwise reproducible."""
+    lib = _lib.lib()
+    key = (u.t.device, u.n, u.h, u.w)
+    ws = _SD_WS.get(key)
+    if ws is None:
+        ws = _SD_WS[key] = torch.empty(max(16, lib.xv_score_dense_bwd_workspace_bytes(u.n, u.h, u.w)) // 4, dtype=torch.float32,
+                                       device=u.t.device)
+    rc = lib.xv_score_dense_bwd_ws(u.xv(), _ptr(dscore), _ptr(w_score), num_classes, _ptr(dw_score), _ptr(db_score), du.xv(),
+                                   _ptr(ws), ws.numel() * 4, _stream())
+    _lib.check(rc, 'xv_score_dense_bwd_ws')
     return du

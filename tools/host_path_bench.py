@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""predict() / score() over HOST-resident numpy samples (the API the reference's callers use, base_model.py:265-331):
+"""predict() / score() / fit() over HOST-resident numpy samples (the API the reference's callers use, base_model.py:265-331):
 images/s including the host -> HBM copies and the label fetch.  usage: host_path_bench.py [samples] [batchsize]"""
 import json
 import os
@@ -37,6 +37,10 @@ def main():
             ts.append(time.perf_counter() - t0)
             del result
         out[name] = {'images_per_s': round(n / min(ts), 1), 'seconds': [round(t, 4) for t in ts]}
+    # fit(): 32 training steps of the RGB expert from the same host arrays (batches staged and uploaded ahead of the step)
+    del net
+    torch.cuda.empty_cache()
+    out['fit'] = bench.host_fit_rate(dev, {k: data[k] for k in ('rgb', 'labels')}, bs)
     print(json.dumps(out))
 
 
