@@ -225,10 +225,16 @@ class BaseModel(object):
                 # arrays (numpy on the host or torch tensors already resident in HBM) with wrapped indices
                 n, bs, start = len(next(iter(dataset.values()))), self.config['batchsize'], 0
                 while n > 0:
-                    idx = (start + np.arange(bs)) % n
+                    if start + bs <= n:
+                        # a contiguous run: views, no gather (the staging threads copy straight out of the caller's arrays;
+                        # a fancy-indexed copy of a 57 MB batch on this thread took longer than the training step)
+                        batch = {k: v[start:start + bs] for k, v in dataset.items()}
+                    else:
+                        idx = (start + np.arange(bs)) % n
+                        batch = {k: (v[torch.from_numpy(idx).to(v.device)] if isinstance(v, torch.Tensor) else
+                                     np.asarray(v)[idx]) for k, v in dataset.items()}
                     start = (start + bs) % n
-                    yield {k: (v[torch.from_numpy(idx).to(v.device)] if isinstance(v, torch.Tensor) else
-                               np.asarray(v)[idx]) for k, v in dataset.items()}
+                    yield batch
                 return
             return (yield from iterate_batches(samples(), self.config['batchsize']))
 
