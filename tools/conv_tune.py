@@ -8,7 +8,10 @@ import sys
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from modular_semantic_segmentation_amd import _lib, ops  # noqa: E402
+from modular_semantic_segmentation_amd import _lib  # noqa: E402
+if os.environ.get('XV_LIB'):            # another build of the library (A/B on one box; with XV_ALLOW_STALE_LIB=1)
+    _lib.LIB_PATH = os.environ['XV_LIB']
+from modular_semantic_segmentation_amd import ops  # noqa: E402
 
 LAYERS = [('conv1_2', 1, 64, 64, 3, True), ('conv2_1', 2, 64, 128, 3, False), ('conv2_2', 2, 128, 128, 3, True),
           ('conv3_1', 4, 128, 256, 3, False), ('conv3_2', 4, 256, 256, 3, False), ('conv3_3', 4, 256, 256, 3, True),
