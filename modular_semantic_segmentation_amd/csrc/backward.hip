@@ -625,8 +625,8 @@ __global__ __launch_bounds__(512) void conv_first_wgrad_mfma_kernel(const float*
 #pragma unroll
   for (int tb = 0; tb < TB; ++tb) {
     xoff[tb] = (uint32_t)(back + ((tdy[tb] * W + tdx[tb] + kq) * CIN + tci[tb]) * 4);
-    kill[tb] = kind[tb] != 0 ? 16u : ((tdy[tb] < 0 ? 1u : 0u) | (tdy[tb] > 0 ? 2u : 0u) | ((kq == 0 && tdx[tb] < 0) ? 4u : 0u) |
-                                      ((kq == 3 && tdx[tb] > 0) ? 8u : 0u));
+    kill[tb] = 32u | (kind[tb] != 0 ? 16u : ((tdy[tb] < 0 ? 1u : 0u) | (tdy[tb] > 0 ? 2u : 0u) | ((kq == 0 && tdx[tb] < 0) ? 4u : 0u) |
+                                             ((kq == 3 && tdx[tb] > 0) ? 8u : 0u)));  // (bit 5: a quad past the wave's share)
   }
   auto wave_rsrc = [](const void* base, int64_t bytes) {  // (built from readfirstlane'd halves: no waterfall loop)
     const uint64_t a = (uint64_t)base;
@@ -647,12 +647,14 @@ __global__ __launch_bounds__(512) void conv_first_wgrad_mfma_kernel(const float*
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
       const bool ok = q + b < q1;
-      const uint32_t edge = (qy == 0 ? 1u : 0u) | (qy == H - 1 ? 2u : 0u) | (qx == 0 ? 4u : 0u) | (qx == W - 4 ? 8u : 0u) | 16u;
-      g[b] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(drs, dlane, ok ? dwalk : OOB, 0));
+      const uint32_t edge = (qy == 0 ? 1u : 0u) | (qy == H - 1 ? 2u : 0u) | (qx == 0 ? 4u : 0u) | (qx == W - 4 ? 8u : 0u) | 16u |
+                            (ok ? 0u : 32u);
+      // (the out-of-range mark goes into the VECTOR offset: the scalar offset is not part of the descriptor's range check)
+      g[b] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(drs, ok ? dlane : OOB, dwalk, 0));
 #pragma unroll
       for (int tb = 0; tb < TB; ++tb) {
         const float v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, (kill[tb] & edge) == 0 ? xoff[tb] : OOB,
-                                                                                      ok ? xwalk : OOB, 0));
+                                                                                      xwalk, 0));
         a[b][tb] = kind[tb] == 1 ? (ok ? 1.f : 0.f) : v;
       }
       // next quad (wave-uniform walk): X is dense, dY skips its border columns at a row end and a border row pair at an image end
@@ -832,6 +834,15 @@ extern "C" int xv_decoder_head_bwd(const xv_act* fused, const float* w_score, co
 }
 
 // grid of the first-layer filter-gradient kernels (shared by the launcher and the workspace query)
+// conv_wgrad.hip: the bf16-split form (maps that tile in 8x32 pixels); the grid it launches, < 0 where it does not apply
+int xv_launch_first_wgrad_split(const float* x, const void* dy, float* dw, float* db, int n, int h, int w, int cin, float* part,
+                                int query_only, hipStream_t stream);
+static bool first_wgrad_split_ok() {
+  static const bool on = getenv("XV_FIRST_WGRAD_OLD") == nullptr &&
+                         (getenv("XV_FIRST_WGRAD_SPLIT") == nullptr || atoi(getenv("XV_FIRST_WGRAD_SPLIT")) != 0);
+  return on;
+}
+
 static void first_wgrad_geometry(int64_t npix, int w, int cin, bool& mfma, unsigned& grid, int& per) {
   static const bool use_old = getenv("XV_FIRST_WGRAD_OLD") != nullptr;  // the packed-FMA kernel (A/B timing)
   mfma = !use_old && (w & 3) == 0 && npix * cin < 0x7ff00000;
@@ -861,6 +872,8 @@ extern "C" size_t xv_conv2d_first_bwd_filter_workspace_bytes(int n, int h, int w
   unsigned grid;
   int per;
   first_wgrad_geometry((int64_t)n * h * w, w, cin, mfma, grid, per);
+  const int gs = first_wgrad_split_ok() ? xv_launch_first_wgrad_split(nullptr, nullptr, nullptr, nullptr, n, h, w, cin, nullptr, 1, nullptr) : -1;
+  if (gs > (int)grid) grid = (unsigned)gs;
   return (size_t)grid * (9 * cin + 1) * 64 * sizeof(float);
 }
 
@@ -884,7 +897,12 @@ extern "C" int xv_conv2d_first_bwd_filter_ws(const float* x, int n, int h, int w
     XV_CHECK_ARG(((uintptr_t)workspace & 15) == 0 && dbias != nullptr);
     part = (float*)workspace;
   }
-  if (mfma) {
+  // the bf16-split form on maps that tile in 8x32 pixels (XV_FIRST_WGRAD_SPLIT=0: the fp32 matrix instruction everywhere)
+  const int gs = first_wgrad_split_ok() ? xv_launch_first_wgrad_split(x, g, dw_hwio, dbias, n, h, w, cin, part, 0, s) : -1;
+  if (gs == -2) return XV_EINVAL;
+  if (gs > 0) {
+    grid = (unsigned)gs;
+  } else if (mfma) {
     switch (cin) {
       case 1: hipLaunchKernelGGL(conv_first_wgrad_mfma_kernel<1>, dim3(grid), dim3(512), 0, s, x, g, dw_hwio, dbias, n, h, w, per, part); break;
       case 2: hipLaunchKernelGGL(conv_first_wgrad_mfma_kernel<2>, dim3(grid), dim3(512), 0, s, x, g, dw_hwio, dbias, n, h, w, per, part); break;

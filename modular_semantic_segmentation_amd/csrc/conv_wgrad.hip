@@ -466,6 +466,203 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_dma_kernel(WgradArgs a) {
   }
 }
 
+// ---- conv1_1 (fp32 input of 1-4 channels, 64 output channels): filter + bias gradient on the bf16 matrix instruction -----
+// dW[t][co] = sum_pix X[pix][t] dY[pix][co] with 9 CIN + 1 rows t (row 9 CIN: X = 1, the bias gradient).  The fp32 form
+// (backward.hip, v_mfma_f32_16x16x4_f32) is bound by that instruction's rate: 8 of them per 4 pixels.  Here X is split
+// EXACTLY into three bf16 terms (hi = bf16(x), mid = bf16(x - hi), lo = bf16(x - hi - mid): 24 mantissa bits; the forward
+// kernel's scheme) and each term meets the bf16 dY on v_mfma_f32_16x16x32_bf16 -- every product exact in fp32, the sums in
+// fp32 as before, 3 x 8 instructions of 16 cycles per 32 pixels instead of 64 of 32.  Terms that are zero for the whole wave
+// (mid and lo of 8-bit image data) are skipped -- adding exact zeros changes no bit.
+// A workgroup walks 8x32-pixel tiles: the dY tile by LDS-DMA into the swizzled [pixel][64 ch] image of the filter-gradient
+// kernels above (same transposing fragment reads), the fp32 halo patch of X through registers into LDS; wave w takes image
+// row w of the tile as its K-step of 32 pixels and keeps the whole (9 CIN + 1) x 64 block in registers; the eight waves meet
+// in LDS in wave order and the workgroup's sums go to its row of `part_out` (fixed-order reduce) or onto dw / db by atomics.
+template <int CIN>
+__global__ __launch_bounds__(512) void conv_first_wgrad_split_kernel(const float* __restrict__ x, const __bf16* __restrict__ dy,
+                                                                    float* __restrict__ dw, float* __restrict__ db, int N, int H,
+                                                                    int W, float* __restrict__ part_out) {
+  constexpr int TH = 8, TW = 32, HH = TH + 2, HW = TW + 2;
+  constexpr int K = 9 * CIN, MB = (K + 1 + 15) / 16;
+  constexpr int D_BYTES = TH * TW * 128;
+  constexpr int XP = HH * HW * CIN;                      // floats of the X patch
+  constexpr int X_BYTES = (XP * 4 + 1023) / 1024 * 1024;
+  constexpr int BUF = D_BYTES + X_BYTES;
+  constexpr int XS = (XP + 511) / 512;                   // patch elements per thread
+  constexpr uint32_t OOB = 0x80000000u;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int Wp = W + 2;
+  const int tiles_x = W / TW, tiles_y = H / TH, n_tiles = N * tiles_y * tiles_x;
+
+  // dY fragment addresses (as conv_wgrad_dma_kernel): lane group g, element j <-> pixel 16 (g >> 1) + 8 (j >> 2) + 4 (g & 1) + (j & 3)
+  const int g = lane >> 4, li = lane & 15, q = li >> 2, p = li & 3;
+  const int xk = 16 * (g >> 1) + 4 * (g & 1) + q;
+  int dbase[4];
+#pragma unroll
+  for (int n = 0; n < 4; ++n) dbase[n] = xk * 128 + (xv_swz(xk, n * 2 + (p >> 1)) << 4) + (p & 1) * 8 + wave * (TW * 128);
+  // X fragment: row t = 16 mb + li of the operand -> (dy, dx, ci), the bias row, or nothing; element j of the lane is pixel
+  // 16 (g >> 1) + 8 (j >> 2) + 4 (g & 1) + (j & 3) of image row `wave` of the tile
+  int xfrag[MB], kind[MB];
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb) {
+    const int t = 16 * mb + li, tap = t / CIN;
+    kind[mb] = t < K ? 0 : (t == K ? 1 : 2);
+    const int tdy = tap / 3, tdx = tap % 3, ci = t - tap * CIN;  // (patch coordinates: the halo is already inside)
+    xfrag[mb] = D_BYTES + (kind[mb] == 0 ? (((wave + tdy) * HW + (16 * (g >> 1) + 4 * (g & 1) + tdx)) * CIN + ci) * 4 : 0);
+  }
+  // dY pieces of this wave (1 KB each: pieces wave, wave + 8, ..): per-lane source offsets, computed once
+  int dvoff[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int idx = (wave + 8 * j) * 64 + lane;
+    const int pp = idx >> 3, ps = idx & 7;
+    const int py = pp / TW, px = pp - py * TW;
+    dvoff[j] = ((py * Wp + px) * 64 + xv_swz(px, ps) * 8) * 2;
+  }
+  // X patch elements of this thread: offset inside the patch's bounding box of the image and the edge flags that void it
+  // (bit 0 first patch row, 1 last, 2 first column, 3 last): the tile's own flags say which of them lie outside the image
+  uint32_t xrel[XS], xkill[XS];
+#pragma unroll
+  for (int e = 0; e < XS; ++e) {
+    const int i = tid + 512 * e;
+    const int hy = i / (HW * CIN), r = i - hy * (HW * CIN), hx = r / CIN;
+    xrel[e] = (uint32_t)((hy * W * CIN + r) * 4);  // bytes behind element (y0 - 1, x0 - 1, 0)
+    xkill[e] = i < XP ? ((hy == 0 ? 1u : 0u) | (hy == HH - 1 ? 2u : 0u) | (hx == 0 ? 4u : 0u) | (hx == HW - 1 ? 8u : 0u)) : 16u;
+  }
+  // descriptor over X starting one row and one pixel BEFORE the tensor (only address arithmetic: the elements there are
+  // voided by the edge flags), so every offset is non-negative; the tile's position goes into the scalar offset
+  const int back = (W + 1) * CIN * 4;
+  const uint64_t xa = (uint64_t)x - back;
+  const uint32_t xlo = __builtin_amdgcn_readfirstlane((uint32_t)xa), xhi = __builtin_amdgcn_readfirstlane((uint32_t)(xa >> 32));
+  const auto xrs = __builtin_amdgcn_make_buffer_rsrc((void*)(((uint64_t)xhi << 32) | xlo), 0, 0x7fffffff, 0x00020000);
+
+  struct Tile {
+    int n, y0, x0;
+  };
+  auto decode = [&](int t) {
+    Tile tl;
+    tl.x0 = (t % tiles_x) * TW;
+    const int r = t / tiles_x;
+    tl.y0 = (r % tiles_y) * TH;
+    tl.n = r / tiles_y;
+    return tl;
+  };
+  float xreg[XS];
+  auto request = [&](const Tile& tl, int b) {  // dY by LDS-DMA into buffer b, X into registers
+    const __bf16* dsrc = dy + (((int64_t)tl.n * (H + 2) + (tl.y0 + 1)) * Wp + (tl.x0 + 1)) * 64;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int lds = __builtin_amdgcn_readfirstlane(b * BUF + (wave + 8 * j) * 1024);
+      asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds), "v"(dvoff[j]), "s"(dsrc) : "memory");
+    }
+    const uint32_t edge = (tl.y0 == 0 ? 1u : 0u) | (tl.y0 + TH == H ? 2u : 0u) | (tl.x0 == 0 ? 4u : 0u) | (tl.x0 + TW == W ? 8u : 0u) | 16u;
+    const uint32_t tbase = (uint32_t)(((tl.n * H + tl.y0) * W + tl.x0) * CIN * 4);  // (< 2^31: checked by the launcher)
+#pragma unroll
+    for (int e = 0; e < XS; ++e)
+      xreg[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, (xkill[e] & edge) == 0 ? xrel[e] : OOB, tbase, 0));
+  };
+  auto publish = [&](int b) {  // the X patch of the requested tile from the registers into buffer b
+#pragma unroll
+    for (int e = 0; e < XS; ++e)
+      if (tid + 512 * e < XP) *reinterpret_cast<float*>(smem + b * BUF + D_BYTES + (tid + 512 * e) * 4) = xreg[e];
+  };
+
+  f32x4 acc[MB][4];
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+    for (int n = 0; n < 4; ++n) acc[mb][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  int t = blockIdx.x;
+  if (t < n_tiles) {
+    request(decode(t), 0);
+    publish(0);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  int b = 0;
+  for (; t < n_tiles; t += gridDim.x) {
+    const bool more = t + (int)gridDim.x < n_tiles;
+    if (more) request(decode(t + gridDim.x), b ^ 1);
+    const char* buf = smem + b * BUF;
+    bf16x8 bfr[4];
+#pragma unroll
+    for (int n4 = 0; n4 < 4; ++n4) bfr[n4] = tr_read2(buf, dbase[n4], dbase[n4] + 8 * 128);
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) {
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = *reinterpret_cast<const float*>(buf + xfrag[mb] + ((j & 3) + 8 * (j >> 2)) * CIN * 4);
+      if (kind[mb] != 0) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = kind[mb] == 1 ? 1.f : 0.f;
+      }
+      // x = hi + mid + lo, each a bf16 (round to nearest even; the remainders are exact in fp32)
+      uint32_t hi[4], mid[4], lo[4];
+      float r1[8], r2[8];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        hi[k] = pack_bf16x2(v[2 * k], v[2 * k + 1]);
+        r1[2 * k] = v[2 * k] - __builtin_bit_cast(float, hi[k] << 16);
+        r1[2 * k + 1] = v[2 * k + 1] - __builtin_bit_cast(float, hi[k] & 0xffff0000u);
+        mid[k] = pack_bf16x2(r1[2 * k], r1[2 * k + 1]);
+        r2[2 * k] = r1[2 * k] - __builtin_bit_cast(float, mid[k] << 16);
+        r2[2 * k + 1] = r1[2 * k + 1] - __builtin_bit_cast(float, mid[k] & 0xffff0000u);
+        lo[k] = pack_bf16x2(r2[2 * k], r2[2 * k + 1]);
+      }
+      const bf16x8 ah = __builtin_bit_cast(bf16x8, u32x4{hi[0], hi[1], hi[2], hi[3]});
+#pragma unroll
+      for (int n4 = 0; n4 < 4; ++n4) acc[mb][n4] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bfr[n4], acc[mb][n4], 0, 0, 0);
+      // (wave-uniform: a term that is zero in every lane -- (mid | lo) & 0x7fff7fff ignores the sign of a zero -- adds nothing)
+      const uint32_t any_mid = (mid[0] | mid[1] | mid[2] | mid[3]) & 0x7fff7fffu;
+      if (__builtin_amdgcn_ballot_w64(any_mid != 0) != 0) {
+        const bf16x8 am = __builtin_bit_cast(bf16x8, u32x4{mid[0], mid[1], mid[2], mid[3]});
+#pragma unroll
+        for (int n4 = 0; n4 < 4; ++n4) acc[mb][n4] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bfr[n4], acc[mb][n4], 0, 0, 0);
+        const uint32_t any_lo = (lo[0] | lo[1] | lo[2] | lo[3]) & 0x7fff7fffu;
+        if (__builtin_amdgcn_ballot_w64(any_lo != 0) != 0) {
+          const bf16x8 al = __builtin_bit_cast(bf16x8, u32x4{lo[0], lo[1], lo[2], lo[3]});
+#pragma unroll
+          for (int n4 = 0; n4 < 4; ++n4) acc[mb][n4] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bfr[n4], acc[mb][n4], 0, 0, 0);
+        }
+      }
+    }
+    if (more) publish(b ^ 1);  // (nobody reads buffer b ^ 1 during this tile)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    b ^= 1;
+  }
+  // accumulator: row 16 mb + 4 g + r, column 16 n4 + li.  The eight waves add their blocks into LDS one after the other
+  // (fixed order), the workgroup's sums go to its row of part_out
+  float* red = reinterpret_cast<float*>(smem);
+  for (int c = tid; c < MB * 16 * 64; c += 512) red[c] = 0.f;
+  __syncthreads();
+  for (int w = 0; w < 8; ++w) {
+    if (wave == w) {
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int n4 = 0; n4 < 4; ++n4)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) red[(16 * mb + 4 * g + r) * 64 + 16 * n4 + li] += acc[mb][n4][r];
+    }
+    __syncthreads();
+  }
+  for (int c = tid; c < (K + 1) * 64; c += 512) {
+    const float v = red[c];
+    if (part_out != nullptr) {
+      part_out[(int64_t)blockIdx.x * (K + 1) * 64 + c] = v;
+      continue;
+    }
+    if (v == 0.f) continue;
+    if (c < K * 64)
+      atomicAdd(dw + c, v);
+    else if (db != nullptr)
+      atomicAdd(db + (c - K * 64), v);
+  }
+}
+
 // dw[i] += sum_s slab[s][i], splits summed in a fixed order (bitwise reproducible filter gradients)
 // (and db[c] += sum_s bslab[s][c], the bias gradient's partial sums, in the same launch).  SUBS lanes share an element:
 // lane `sub` adds splits sub, sub + SUBS, ... in order, then a butterfly over the SUBS partial sums -- a fixed tree either
@@ -663,4 +860,33 @@ extern "C" int xv_conv2d_bwd_filter_ws(const xv_act* x, const xv_act* dy, float*
     hipLaunchKernelGGL(conv_wgrad_kernel<1>, dim3(grid), dim3(256), lds, s, a);
   }
   return finish();
+}
+
+// conv1_1's filter gradient on the bf16 matrix instruction (conv_first_wgrad_split_kernel): maps that tile exactly in 8x32
+// pixels whose X fits 31-bit byte offsets.  grid <= 0: returns the grid it would launch (for the workspace query).
+int xv_launch_first_wgrad_split(const float* x, const void* dy, float* dw, float* db, int n, int h, int w, int cin, float* part,
+                                int query_only, hipStream_t stream) {
+  if (cin < 1 || cin > 4 || (h & 7) || (w & 31) || (int64_t)n * h * w * cin * 4 >= 0x7fff0000LL) return -1;
+  const int64_t tiles = (int64_t)n * (h / 8) * (w / 32);
+  const int64_t cap = 2 * (int64_t)xv_num_cus();
+  const int grid = (int)(tiles < cap ? tiles : cap);
+  if (query_only) return grid;
+  const int xp = 10 * 34 * cin * 4;
+  const int lds = 2 * (8 * 32 * 128 + (xp + 1023) / 1024 * 1024);
+#define XV_FWS(C)                                                                                                      \
+  {                                                                                                                    \
+    static bool attr[XV_MAX_DEVICES] = {false};                                                                        \
+    const hipError_t e = xv_allow_dynamic_lds(reinterpret_cast<const void*>(&conv_first_wgrad_split_kernel<C>), lds, attr); \
+    if (e != hipSuccess) return -2;                                                                                    \
+    hipLaunchKernelGGL(conv_first_wgrad_split_kernel<C>, dim3((unsigned)grid), dim3(512), lds, stream, x, (const __bf16*)dy, dw, \
+                       db, n, h, w, part);                                                                             \
+  }
+  switch (cin) {
+    case 1: XV_FWS(1) break;
+    case 2: XV_FWS(2) break;
+    case 3: XV_FWS(3) break;
+    default: XV_FWS(4) break;
+  }
+#undef XV_FWS
+  return grid;
 }

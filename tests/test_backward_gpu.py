@@ -244,13 +244,21 @@ def test_head_backward_loss_and_gradients(ops, C):
     np.testing.assert_allclose(got_df[pos], ref_df[pos], rtol=2 ** -7, atol=2e-3 * scale)
 
 
-@pytest.mark.parametrize('shape', [(2, 12, 20), (1, 9, 22), (3, 33, 64), (5, 40, 132)])
-@pytest.mark.parametrize('cin', [1, 3])
-def test_first_layer_filter_gradient(ops, cin, shape):
-    """W % 4 == 0: the fp32-MFMA kernel (exact fp32 products); other widths: the packed-FMA kernel."""
+@pytest.mark.parametrize('shape', [(2, 12, 20), (1, 9, 22), (3, 33, 64), (5, 40, 132), (1, 3, 12), (1, 5, 28), (2, 8, 32), (3, 16, 64),
+                                   (2, 24, 96)])
+@pytest.mark.parametrize('cin,data', [(1, 'u8'), (3, 'u8'), (1, 'u16'), (3, 'float'), (4, 'float')])
+def test_first_layer_filter_gradient(ops, cin, shape, data):
+    """Maps that tile in 8x32 pixels: the bf16-split kernel (exact three-way split of X; 8-bit data skip the two lower terms,
+    16-bit data the last, floats take all three); else W % 4 == 0: the fp32-MFMA kernel (the two small shapes end inside a
+    wave's batch of four quads); other widths: the packed-FMA kernel."""
     rng = np.random.default_rng(cin)
     n, h, w = shape
-    x = rng.integers(0, 256, (n, h, w, cin)).astype(np.float32)
+    if data == 'u8':
+        x = rng.integers(0, 256, (n, h, w, cin)).astype(np.float32)
+    elif data == 'u16':
+        x = rng.integers(0, 65536, (n, h, w, cin)).astype(np.float32)
+    else:
+        x = (rng.standard_normal((n, h, w, cin)) * 100).astype(np.float32)
     dy = fo.round_bf16(rng.standard_normal((n, h, w, 64)).astype(np.float32))
     dw = torch.zeros((3, 3, cin, 64), device='cuda')
     db = torch.zeros(64, device='cuda')
@@ -265,8 +273,18 @@ def test_first_layer_filter_gradient(ops, cin, shape):
     b = torch.zeros(64, requires_grad=True)
     F.conv2d(_nchw(x), wt, b, padding=1).backward(_nchw(dy))
     ref = wt.grad.permute(2, 3, 1, 0).numpy()
-    np.testing.assert_allclose(dw.cpu().numpy(), ref, rtol=1e-4, atol=1e-2 * grow)
+    np.testing.assert_allclose(dw.cpu().numpy(), ref, rtol=1e-4, atol=max(1e-2 * grow, 2e-5 * np.abs(ref).max()))       # (fp32 sums of terms up to 65535 x |dy|)
     np.testing.assert_allclose(db.cpu().numpy(), b.grad.numpy(), rtol=1e-4, atol=1e-4 * grow)
+    # with a workspace: the same sums in a fixed order -- bit for bit the same on every run, and within fp32 rounding of the above
+    ws = torch.empty(ops.conv2d_first_bwd_filter_workspace_bytes(_dev(x)) // 4, device='cuda')
+    runs = []
+    for _ in range(2):
+        dw2, db3 = torch.zeros((3, 3, cin, 64), device='cuda'), torch.zeros(64, device='cuda')
+        ops.conv2d_first_bwd_filter(_dev(x), dya, dw2, db3, workspace=ws)
+        torch.cuda.synchronize()
+        runs.append((dw2, db3))
+    assert torch.equal(runs[0][0], runs[1][0]) and torch.equal(runs[0][1], runs[1][1])
+    np.testing.assert_allclose(runs[0][0].cpu().numpy(), ref, rtol=1e-4, atol=max(1e-2 * grow, 2e-5 * np.abs(ref).max()))       # (fp32 sums of terms up to 65535 x |dy|)
 
 
 def test_optimizers_match_tf1_formulas(ops):
