@@ -227,12 +227,14 @@ def block_stats(times, steps):
             'timed_seconds': round(sum(times), 3)}
 
 
-def measure_inference(net, batch, device, steps, warmup, graph=True, serial=False, world=1, dist=None, fetch=False,
+def measure_inference(net, batch, device, steps, warmup, graph=True, serial=None, world=1, dist=None, fetch=False,
                       min_seconds=2.0):
     """Timed region + per-kernel roofline pass of one inference configuration.  Returns (block times of the timed region
     (max over ranks), [per-iteration seconds] if fetch, conv profile list, block times of the serialised pass)."""
     from modular_semantic_segmentation_amd import ops
-    net.concurrent_experts = not serial
+    # serial: True = the experts back to back on one stream, False = side by side on two, None = the model's own choice
+    # (basic_fusion_model.expert_streams: two streams while one expert's launches leave CUs idle)
+    net.concurrent_experts = None if serial is None else not serial
     net._graph = None
 
     def step():
@@ -277,7 +279,7 @@ def measure_inference(net, batch, device, steps, warmup, graph=True, serial=Fals
     ops.CONV_PROFILE = prof
     times_serial = timed_blocks(lambda: net._predict_batch(batch), steps, device, 1, None, min(min_seconds, 1.0))
     ops.CONV_PROFILE = None
-    net.concurrent_experts = not serial
+    net.concurrent_experts = None if serial is None else not serial
     return times, per_iter, prof, times_serial
 
 
@@ -620,7 +622,10 @@ def main():
     ap.add_argument('--no-graph', dest='graph', action='store_false',
                     help='launch every kernel eagerly instead of replaying the step from a captured hipGraph')
     ap.add_argument('--serial-experts', action='store_true',
-                    help='run the RGB and depth experts back to back on one stream (profiling: per-kernel times)')
+                    help='run the RGB and depth experts back to back on one stream at every batch size')
+    ap.add_argument('--two-streams', action='store_true',
+                    help='run the experts side by side on two streams at every batch size (default: the model chooses -- two '
+                         'streams for small batches, one from the batch on at which every launch fills the chip)')
     ap.add_argument('--min-seconds', type=float, default=2.0,
                     help='the timed block of --steps steps is repeated until this many seconds of timed work; the median '
                          'block is reported (0 = exactly one block)')
@@ -669,7 +674,8 @@ def main():
     if args.dtype == 'fp8':
         net.calibrate(batch)
     times, _, prof, times_serial = measure_inference(net, batch, device, args.steps, args.warmup, graph=args.graph,
-                                                     serial=args.serial_experts, world=world, dist=dist,
+                                                     serial=True if args.serial_experts else (False if args.two_streams else None),
+                                                     world=world, dist=dist,
                                                      min_seconds=args.min_seconds)
     dt = float(np.median(times))            # block times are already the max over ranks
     dt_serial = float(np.median(times_serial))
@@ -720,7 +726,7 @@ def main():
         'config': {'workload': 'two-stream SimpleFCN RGB+Depth %dx%d + %s fusion, U=%d, C=%d, random-init weights'
                                % (args.width, args.height, args.fusion, U, C),
                    'images_per_gpu_per_step': args.batch, 'global_batch': args.batch * world,
-                   'expert_streams': 1 if args.serial_experts else 2, 'hip_graph': bool(args.graph),
+                   'expert_streams': 1 if args.serial_experts else (2 if args.two_streams else 'auto: 2 for batches whose launches leave CUs idle, else 1'), 'hip_graph': bool(args.graph),
                    'parallelism': 'dp%d (batch sharding, no data-path collective)' % world},
         'conv_tflops_end_to_end': round(images * flops_img / dt / 1e12, 2),
         'roofline': roofline,

@@ -98,7 +98,7 @@ class BaseModel(object):
     def _graph_flags(self):
         """Host-side switches a captured step depends on besides the weights: a graph captured under other values is not
         replayed (tests and A/B timing flip them between calls)."""
-        return (getattr(self, 'concurrent_experts', True), self.config.get('fused_head', True),
+        return (getattr(self, 'concurrent_experts', None), self.config.get('fused_head', True),
                 self.config.get('paired_launches', True))
 
     def _predict_batch(self, batch, output_attr=None):

@@ -52,6 +52,30 @@ def calibrate_experts(model, data):
     return {m: model.experts[m].calibrate(model._to_device(batch[m], torch.float32)) for m in model.modalities}
 
 
+def fills_the_chip(model, inputs, rounds=1):
+    """Does ONE expert's conv4 map give at least `rounds` rounds of workgroups (16x32-pixel x 64-channel tiles against the CU
+    count)?"""
+    shapes = {tuple(v.shape[:3]) for v in inputs.values()}
+    if len(shapes) != 1:
+        return False
+    n, h, w = next(iter(shapes))
+    tiles = n * ((h // 8 + 15) // 16) * ((w // 8 + 31) // 32) * 8
+    return tiles >= rounds * torch.cuda.get_device_properties(model.device).multi_processor_count
+
+
+def expert_streams(model, inputs):
+    """Run the experts side by side on two HIP streams?  model.concurrent_experts: True / False force it; None (default): two
+    streams while the launches of one expert leave CUs idle or end in half-empty rounds (2 / 4 / 8 images of 768x384: 2 958 /
+    3 406 / 3 552 images/s against 2 176 / 3 051 / 3 461 on one stream), ONE stream from three rounds of conv4 workgroups
+    per expert on (12 images: 3 685 against 3 568; 16 images: 3 799-3 829 against 3 636-3 698 on one box, 3 735 against
+    3 574-3 617 on another): there every launch fills the chip for several rounds, and two queues only make the persistent
+    grids of two kernels share CUs.  Same kernels, same bits either way."""
+    conc = getattr(model, 'concurrent_experts', None)
+    if conc is None:
+        conc = not fills_the_chip(model, inputs, rounds=3)
+    return bool(conc)
+
+
 def paired_from(model, inputs):
     """Index of the first encoder layer the two experts run as ONE launch each (fcn.encoder_layers_pair), or None: two FCN
     experts on the bf16 path without dropout sites or the stream-K option -- and a batch whose conv4 maps give one expert
@@ -64,12 +88,8 @@ def paired_from(model, inputs):
         return None
     if not all(type(e) is FcnEngine and e.pairable() for e in model.experts.values()):
         return None
-    shapes = {tuple(v.shape[:3]) for v in inputs.values()}
-    if len(shapes) != 1:        # modalities of different sizes cannot share a launch: keep both on their own streams
-        return None
-    n, h, w = next(iter(shapes))
-    tiles = n * ((h // 8 + 15) // 16) * ((w // 8 + 31) // 32) * 8
-    if tiles < torch.cuda.get_device_properties(model.device).multi_processor_count:
+    # (modalities of different sizes cannot share a launch: both stay on their own streams)
+    if not fills_the_chip(model, inputs):
         return None
     return gi
 
@@ -81,7 +101,7 @@ def run_trunks(model, inputs, finish):
     the heads.  The current stream waits for all of them before returning."""
     from .fcn import encoder_layers_pair
     mods = model.modalities
-    conc = getattr(model, 'concurrent_experts', True)
+    conc = expert_streams(model, inputs)
     main = torch.cuda.current_stream(model.device)
     if conc and not hasattr(model, '_expert_streams'):
         model._expert_streams = {m: torch.cuda.Stream(device=model.device) for m in mods}
