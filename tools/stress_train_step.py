@@ -33,6 +33,8 @@ def arenas(tr):
     for name in ('_g', '_a'):
         for key, v in getattr(tr, name, {}).items():
             t = v.t if hasattr(v, 'interior') else v
+            if isinstance(key, tuple) and str(key[0]).endswith('_ws'):
+                continue        # scratch workspaces: the part a step does not write keeps whatever the allocator handed out
             if torch.is_tensor(t):
                 out[(name, str(key))] = t
     engines = [tr.e] if not hasattr(tr.e, 'trunks') else list(tr.e.trunks.values())
