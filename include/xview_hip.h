@@ -601,6 +601,15 @@ int xv_conv2d_f32_scalar(const float* x, int n, int h, int w, int cin, const flo
                          int relu, float* y, void* stream);
 int xv_maxpool2x2_f32(const float* x, int n, int h, int w, int c, float* y, void* stream);
 int xv_upsample2x_f32(const float* x, int n, int h, int w, int c, const float* residual, float* y, void* stream);
+/* ... with the inference batch norm of the deconv between it and its relu: y = relu(bilinear_x2(x) * scale + shift) + residual */
+int xv_upsample2x_affine_f32(const float* x, int n, int h, int w, int c, const float* scale, const float* shift,
+                             const float* residual, float* y, void* stream);
+/* The decoder head without the commutation, in float32 (a batch norm with a shift between the x8 deconv and its relu:
+ * custom_layers.py:112-119 under simple_fcn.py:89-135): fused [n][h][w][u] -> score / prob [n][8h][8w][C] float32, label
+ * [n][8h][8w] int64 (any of the three may be NULL).  scale / shift: the folded batch norm of `upscore` ([u]).            */
+int xv_decoder_head_affine_f32(const float* fused, int n, int h, int w, int u, const float* scale, const float* shift,
+                               const float* w_score, const float* b_score, int num_classes, float* score, float* prob,
+                               int64_t* label, void* stream);
 int xv_score_lowres_f32(const float* fused, int n, int h, int w, int u, const float* w_score, int num_classes, float* S,
                         void* stream);
 int xv_decoder_head_from_scores(const float* S, const float* b_score, int n, int hi, int wi, int num_classes, float* score,

@@ -148,6 +148,8 @@ SIGNATURES = {
     'xv_conv2d_f32_scalar': (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _i, _i, _i, _vp, _vp]),
     'xv_maxpool2x2_f32': (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
     'xv_upsample2x_f32': (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp]),
+    'xv_upsample2x_affine_f32': (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    'xv_decoder_head_affine_f32': (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
     'xv_score_lowres_f32': (_i, [_vp, _i, _i, _i, _i, _vp, _i, _vp, _vp]),
     'xv_decoder_head_from_scores': (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     'xv_adam_step': (_i, [_vp, _vp, _vp, _vp, _i64, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float,

@@ -396,8 +396,10 @@ __global__ __launch_bounds__(256) void maxpool_f32_kernel(const float* __restric
 // bilinear x2 transposed conv (k 4, stride 2, [TF1] 'same'): out[o] = sum_i in[i] * w1[o + 1 - 2 i], taps
 // w1 = {.25, .75, .75, .25} (custom_layers.py:8-25); accumulated in the order of increasing source index like
 // F.conv_transpose2d's scatter does not define -- any order of the (at most 4) products is within 1 ulp of another
+// scale / shift (may be null): the inference batch norm between the deconv and its relu (custom_layers.py:112-119)
 __global__ __launch_bounds__(256) void upsample2x_f32_kernel(const float* __restrict__ x, const float* __restrict__ res,
-                                                            float* __restrict__ y, int N, int Hi, int Wi, int C) {
+                                                            float* __restrict__ y, int N, int Hi, int Wi, int C,
+                                                            const float* __restrict__ scale, const float* __restrict__ shift) {
   const int Ho = 2 * Hi, Wo = 2 * Wi;
   const int64_t total = (int64_t)N * Ho * Wo * C;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
@@ -420,7 +422,73 @@ __global__ __launch_bounds__(256) void upsample2x_f32_kernel(const float* __rest
         const float wy = (ky == 0 || ky == 3) ? 0.25f : 0.75f, wx = (kx == 0 || kx == 3) ? 0.25f : 0.75f;
         a = fmaf(x[(((int64_t)n * Hi + iy) * Wi + ix) * C + c], wy * wx, a);
       }
+    if (scale != nullptr) a = fmaf(a, scale[c], shift[c]);
     y[i] = fmaxf(a, 0.f) + (res != nullptr ? res[i] : 0.f);
+  }
+}
+
+// The decoder head WITHOUT the commutation (a batch norm with a shift sits between the x8 deconv and its relu, so the class
+// scores cannot be interpolated at 1/8 resolution): per output pixel the 16x16 / stride-8 bilinear transposed conv of the U
+// feature channels (two source rows x two source columns; taps w1[k] = 1 - |k - 7.5| / 8, custom_layers.py:8-25), the affine,
+// the relu, the 1x1 score conv, bias, softmax, argmax -- all in fp32 (simple_fcn.py:89-135 on float32).  One thread per pixel.
+__global__ __launch_bounds__(256) void decoder_head_affine_f32_kernel(const float* __restrict__ f, const float* __restrict__ scale,
+                                                                     const float* __restrict__ shift, const float* __restrict__ ws,
+                                                                     const float* __restrict__ bs, int N, int Hi, int Wi, int U, int C,
+                                                                     float* __restrict__ score, float* __restrict__ prob,
+                                                                     int64_t* __restrict__ label) {
+  const int Ho = 8 * Hi, Wo = 8 * Wi;
+  const int64_t total = (int64_t)N * Ho * Wo;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int ox = (int)(i % Wo);
+    int64_t r = i / Wo;
+    const int oy = (int)(r % Ho);
+    const int n = (int)(r / Ho);
+    // sources iy with 0 <= oy + 4 - 8 iy < 16
+    const int iy0 = (oy + 4) / 8 - 1, ix0 = (ox + 4) / 8 - 1;
+    float wgt[4];
+    const float* src[4];
+#pragma unroll
+    for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+      for (int dx = 0; dx < 2; ++dx) {
+        const int iy = iy0 + dy, ix = ix0 + dx;
+        const bool in = iy >= 0 && iy < Hi && ix >= 0 && ix < Wi;
+        const int ky = oy + 4 - 8 * iy, kx = ox + 4 - 8 * ix;
+        wgt[2 * dy + dx] = in ? (1.f - fabsf((float)ky - 7.5f) * 0.125f) * (1.f - fabsf((float)kx - 7.5f) * 0.125f) : 0.f;
+        src[2 * dy + dx] = f + (((int64_t)n * Hi + (in ? iy : 0)) * Wi + (in ? ix : 0)) * U;
+      }
+    float s[32];
+#pragma unroll
+    for (int k = 0; k < 32; ++k) s[k] = k < C ? bs[k] : 0.f;
+    for (int u = 0; u < U; ++u) {
+      float a = 0.f;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) a = fmaf(src[t][u], wgt[t], a);
+      a = fmaxf(fmaf(a, scale[u], shift[u]), 0.f);
+#pragma unroll
+      for (int k = 0; k < 32; ++k)
+        if (k < C) s[k] = fmaf(a, ws[u * C + k], s[k]);
+    }
+    float m = s[0];
+    int best = 0;
+#pragma unroll
+    for (int k = 1; k < 32; ++k)
+      if (k < C && s[k] > m) {
+        m = s[k];
+        best = k;
+      }
+    if (score != nullptr)
+      for (int k = 0; k < C; ++k) score[i * C + k] = s[k];
+    if (prob != nullptr) {
+      float e[32], sum = 0.f;
+#pragma unroll
+      for (int k = 0; k < 32; ++k) {
+        e[k] = k < C ? expf(s[k] - m) : 0.f;
+        sum += e[k];
+      }
+      for (int k = 0; k < C; ++k) prob[i * C + k] = e[k] / sum;
+    }
+    if (label != nullptr) label[i] = best;
   }
 }
 
@@ -523,7 +591,32 @@ extern "C" int xv_upsample2x_f32(const float* x, int n, int h, int w, int c, con
   XV_CHECK_ARG(x && y);
   XV_CHECK_SHAPE(n > 0 && h > 0 && w > 0 && c > 0);
   const int64_t total = (int64_t)n * 4 * h * w * c;
-  hipLaunchKernelGGL(upsample2x_f32_kernel, dim3(f32_grid(total)), dim3(256), 0, (hipStream_t)stream, x, residual, y, n, h, w, c);
+  hipLaunchKernelGGL(upsample2x_f32_kernel, dim3(f32_grid(total)), dim3(256), 0, (hipStream_t)stream, x, residual, y, n, h, w, c,
+                     (const float*)nullptr, (const float*)nullptr);
+  return xv_launch_status();
+}
+
+// y = relu(bilinear_x2(x) * scale + shift) + residual (the batch norm of upscore_conv5 in float32)
+extern "C" int xv_upsample2x_affine_f32(const float* x, int n, int h, int w, int c, const float* scale, const float* shift,
+                                        const float* residual, float* y, void* stream) {
+  XV_CHECK_ARG(x && y && scale && shift);
+  XV_CHECK_SHAPE(n > 0 && h > 0 && w > 0 && c > 0);
+  const int64_t total = (int64_t)n * 4 * h * w * c;
+  hipLaunchKernelGGL(upsample2x_f32_kernel, dim3(f32_grid(total)), dim3(256), 0, (hipStream_t)stream, x, residual, y, n, h, w, c,
+                     scale, shift);
+  return xv_launch_status();
+}
+
+// The un-commuted decoder head in float32 (decoder_head_affine_f32_kernel): fused [n][h][w][u] -> score / prob
+// [n][8h][8w][C] float32 and label [n][8h][8w] int64 (any of them may be null)
+extern "C" int xv_decoder_head_affine_f32(const float* fused, int n, int h, int w, int u, const float* scale, const float* shift,
+                                          const float* w_score, const float* b_score, int num_classes, float* score, float* prob,
+                                          int64_t* label, void* stream) {
+  XV_CHECK_ARG(fused && scale && shift && w_score && b_score && (score || prob || label));
+  XV_CHECK_SHAPE(n > 0 && h > 0 && w > 0 && u > 0 && num_classes >= 1 && num_classes <= 32);
+  const int64_t total = (int64_t)n * 64 * h * w;
+  hipLaunchKernelGGL(decoder_head_affine_f32_kernel, dim3(f32_grid(total)), dim3(256), 0, (hipStream_t)stream, fused, scale, shift,
+                     w_score, b_score, n, h, w, u, num_classes, score, prob, label);
   return xv_launch_status();
 }
 

@@ -12,7 +12,7 @@ import torch
 
 from . import _lib, ops
 from .custom_layers import is_bilinear_filter
-from .fcn import ENCODER, _fold_bn, variable_shapes
+from .fcn import BN_EPS, ENCODER, _fold_bn, variable_shapes
 
 
 # XV_EXACT_SCALAR=1: round 4's vector-ALU conv kernel + stand-alone pools (A/B baseline of the bench record)
@@ -43,13 +43,20 @@ class FcnEngineF32(object):
                 raise KeyError('missing variable %s' % need)
             if tuple(v[need].shape) != tuple(shape):
                 raise ValueError('variable %s has shape %s, expected %s' % (need, v[need].shape, shape))
-        for name in ('upscore_conv5', 'upscore'):
-            if not is_bilinear_filter(v['%s/%s/kernel' % (p, name)]) or '%s/%s/gamma' % (p, name) in v:
-                raise NotImplementedError("conv_dtype='fp32' evaluates the constant bilinear deconvs without batch norm "
-                                          '(%s/%s is something else): use the bf16 engine' % (p, name))
-
         def up(a):
             return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dev)
+
+        # batch norms after the deconvs (custom_layers.py:112-119: BN before the relu; the reference's shipped configuration):
+        # a per-channel affine in the x2 kernel / the un-commuted float32 head.  Trained (non-bilinear) deconv kernels: not here.
+        self.affine = {}
+        for name in ('upscore_conv5', 'upscore'):
+            layer = '%s/%s' % (p, name)
+            if not is_bilinear_filter(v[layer + '/kernel']):
+                raise NotImplementedError("conv_dtype='fp32' evaluates the constant bilinear deconvs (%s is something else): "
+                                          'use the bf16 engine' % layer)
+            if layer + '/gamma' in v:
+                sc = v[layer + '/gamma'] / np.sqrt(v[layer + '/moving_variance'] + BN_EPS)
+                self.affine[name] = (up(sc), up(v[layer + '/beta'] - v[layer + '/moving_mean'] * sc))
 
         self.w, self.b = {}, {}
         for name in [n for n, _, _ in ENCODER] + ['score_conv4', 'score_conv5', 'score']:
@@ -102,7 +109,12 @@ class FcnEngineF32(object):
         s5 = L['score_conv5'] = self._conv('score_conv5', L['conv5_3'], 1)[0]
         fused = self._buf('fused', tuple(s4.shape))
         n5, h5, w5, c5 = s5.shape
-        _lib.check(_lib.lib().xv_upsample2x_f32(_p(s5), n5, h5, w5, c5, _p(s4), _p(fused), ops._stream()), 'xv_upsample2x_f32')
+        if 'upscore_conv5' in self.affine:
+            sc, sh = self.affine['upscore_conv5']
+            _lib.check(_lib.lib().xv_upsample2x_affine_f32(_p(s5), n5, h5, w5, c5, _p(sc), _p(sh), _p(s4), _p(fused), ops._stream()),
+                       'xv_upsample2x_affine_f32')
+        else:
+            _lib.check(_lib.lib().xv_upsample2x_f32(_p(s5), n5, h5, w5, c5, _p(s4), _p(fused), ops._stream()), 'xv_upsample2x_f32')
         L['fused'] = fused
         return L
 
@@ -115,16 +127,37 @@ class FcnEngineF32(object):
         return S, (n, hi, wi)
 
     def lowres_scores(self, x):
+        if not self.commuted_head():
+            raise NotImplementedError('no low-resolution class scores behind a batch norm with a shift: use forward()')
         return self._scores(self.encoder(x)['fused'])
 
     def commuted_head(self):
-        return True
+        """Class scores interpolated at 1/8 resolution (no batch-norm shift between the x8 deconv and its relu)?"""
+        return 'upscore' not in self.affine
 
     def forward(self, x, want=('label',), keep_all=False):
         L = self.encoder(x)
-        S, (n, hi, wi) = self._scores(L['fused'])
         dev = self.device
         out = {}
+        if not self.commuted_head():
+            f = L['fused']
+            n, hi, wi, u = f.shape
+            if 'score' in want:
+                out['score'] = torch.empty((n, 8 * hi, 8 * wi, self.C), dtype=torch.float32, device=dev)
+            if 'prob' in want:
+                out['prob'] = torch.empty((n, 8 * hi, 8 * wi, self.C), dtype=torch.float32, device=dev)
+            if 'label' in want or 'classification' in want or not out:
+                out['label'] = torch.empty((n, 8 * hi, 8 * wi), dtype=torch.int64, device=dev)
+            sc, sh = self.affine['upscore']
+            rc = _lib.lib().xv_decoder_head_affine_f32(_p(f), n, hi, wi, u, _p(sc), _p(sh), _p(self.w['score']), _p(self.b['score']),
+                                                       self.C, _p(out.get('score')), _p(out.get('prob')), _p(out.get('label')),
+                                                       ops._stream())
+            _lib.check(rc, 'xv_decoder_head_affine_f32')
+            if 'label' in out:
+                out['classification'] = out['label']
+            out['layers'] = L
+            return out
+        S, (n, hi, wi) = self._scores(L['fused'])
         if 'score' in want:
             out['score'] = torch.empty((n, 8 * hi, 8 * wi, self.C), dtype=torch.float32, device=dev)
         if 'prob' in want:

@@ -108,3 +108,58 @@ def test_conv2d_f32_is_batch_independent_bit_for_bit(lib):
         assert torch.equal(yi[0], y[i]) and torch.equal(qi[0], q[i])
     # and the pooled map is the 2x2 max of the full map, exactly
     assert torch.equal(q, torch.nn.functional.max_pool2d(y.permute(0, 3, 1, 2), 2).permute(0, 2, 3, 1))
+
+
+def test_exact_engine_with_batch_norm_after_every_layer(lib):
+    """The reference's shipped `batch_normalization: true` in the label-exact mode: conv batch norms folded into the float32
+    weights, the two deconv batch norms as per-channel affines (xv_upsample2x_affine_f32, the un-commuted float32 head
+    xv_decoder_head_affine_f32) -- logits within 1e-5 of the scale of the fp32 oracle's, labels identical outside twice
+    that margin, probabilities the softmax of the scores."""
+    from modular_semantic_segmentation_amd.fcn import init_variables
+    from modular_semantic_segmentation_amd.fcn_exact import FcnEngineF32
+    rng = np.random.default_rng(3)
+    w = init_variables('rgb', 3, 64, 12, batch_normalization=True, seed=2)
+    w['rgb/conv1_1/kernel'] *= 0.02
+    for k in list(w):
+        if k.endswith('/gamma'):
+            w[k] = rng.uniform(0.7, 1.3, w[k].shape).astype(np.float32)
+        elif k.endswith('/beta'):
+            w[k] = (0.2 * rng.standard_normal(w[k].shape)).astype(np.float32)
+        elif k.endswith('/moving_mean'):
+            w[k] = (0.1 * rng.standard_normal(w[k].shape)).astype(np.float32)
+        elif k.endswith('/moving_variance'):
+            w[k] = rng.uniform(0.5, 1.5, w[k].shape).astype(np.float32)
+        elif k.endswith('/kernel') and 'upscore' not in k and 'conv1_1' not in k:
+            w[k] = w[k] * 1.6
+    eng = FcnEngineF32('rgb', 3, 64, 12, w)
+    assert not eng.commuted_head()
+    x = rng.integers(0, 256, (2, 64, 96, 3)).astype(np.float32)
+    out = eng.forward(torch.from_numpy(x).cuda(), want=('score', 'prob', 'label'))
+    torch.cuda.synchronize()
+    ref = fo.fcn_forward(x, w, 'rgb', 'fp32', keep=['fused', 'score'])
+    got = out['layers']['fused'].cpu().numpy()
+    assert np.abs(got - ref['fused']).max() <= 1e-5 * np.abs(ref['fused']).max()
+    score = out['score'].cpu().numpy()
+    scale = np.abs(ref['score']).max()
+    err = np.abs(score - ref['score']).max() / scale
+    print('fp32 engine with batch norm vs fp32 oracle: max logit error %.2e of the scale' % err)
+    assert err < 1e-5
+    lab = out['label'].cpu().numpy()
+    assert np.array_equal(lab, fo.argmax_last(fo.softmax(score)))
+    top2 = np.sort(ref['score'], -1)[..., -2:]
+    clear = (top2[..., 1] - top2[..., 0]) > 2e-5 * scale
+    assert clear.mean() > 0.99 and np.array_equal(lab[clear], fo.argmax_last(fo.softmax(ref['score']))[clear])
+    assert np.allclose(out['prob'].cpu().numpy(), fo.softmax(score), atol=1e-6)
+    # label only (what predict() asks for)
+    only = eng.forward(torch.from_numpy(x).cuda())
+    assert torch.equal(only['label'], out['label'])
+    # ... and through the model API (get_model('fcn'), batch_normalization: true, conv_dtype: 'fp32')
+    import os
+    import tempfile
+    from modular_semantic_segmentation_amd import get_model
+    desc = ({'rgb': 'float32', 'labels': 'int32'}, {'rgb': (None, None, 3), 'labels': (None, None)}, 12)
+    net = get_model('fcn')('rgb', desc, 'rgb', num_units=64, batch_normalization=True, batchsize=2, conv_dtype='fp32')
+    with tempfile.TemporaryDirectory() as d:
+        np.savez(os.path.join(d, 'w.npz'), **w)
+        net.import_weights(os.path.join(d, 'w.npz'), warnings=False)
+    assert np.array_equal(np.asarray(net.predict({'rgb': x})), lab)
