@@ -121,7 +121,11 @@ def child():
         h.xv_decoder_head_bwd_workspace_bytes(n, hh, ww, int(rng.integers(-1, 40)))
         h.xv_deconv_dense_workspace_bytes(n, hh, ww, cout, int(rng.integers(-1, 9)))
         h.xv_conv2d_first_bwd_filter_workspace_bytes(n, hh, ww, int(rng.integers(-1, 6)))
-        checks += 8
+        h.xv_conv2d_route_bytes(n, hh, ww, cout)
+        h.xv_score_dense_bwd_workspace_bytes(n, hh, ww)
+        h.xv_conv2d_split_workspace_bytes(n, hh, ww, cin, cout)
+        h.xv_softmax_ce_dense_workspace_bytes(n * hh * ww)
+        checks += 12
 
     # (4) launch geometry: the whole host path of the conv entry points up to the launch (which fails: no device here)
     import torch
