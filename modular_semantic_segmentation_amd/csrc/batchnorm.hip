@@ -740,14 +740,13 @@ __global__ __launch_bounds__(256) void upsample_raw_kernel(const __bf16* __restr
                                                           int Hi, int Wi, int C) {
   const int c8 = C >> 3;
   const int Ho = Hi * S, Wo = Wi * S;
-  const int64_t total = (int64_t)N * Ho * Wo * c8;
-  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
-    const int cg = (int)(idx % c8);
-    int64_t r = idx / c8;
-    const int ox = (int)(r % Wo);
-    r /= Wo;
-    const int oy = (int)(r % Ho);
-    const int n = (int)(r / Ho);
+  // (32-bit index arithmetic: the launcher checks total < 2^31; the 64-bit divisions of the first form cost more than the
+  // kernel's memory traffic -- 215 us for a 0.6 GB store)
+  // grid: x over (output column, channel group) of one output row, y = output row, z = image -- no division per element
+  // (the flat index form spent more on 64-bit divisions than on its memory traffic: 215 us for a 0.6 GB store)
+  const int oy = blockIdx.y, n = blockIdx.z;
+  for (uint32_t idx = blockIdx.x * 256 + threadIdx.x; idx < (uint32_t)(Wo * c8); idx += gridDim.x * 256) {
+    const int ox = (int)(idx / (uint32_t)c8), cg = (int)(idx - (uint32_t)ox * c8);
     const int iy1 = (oy + S / 2) / S, ix1 = (ox + S / 2) / S;  // taps iy1-1, iy1 (padded coords iy1, iy1+1)
     const float wy1 = bl_w<S>(oy, iy1), wy0 = bl_w<S>(oy, iy1 - 1), wx1 = bl_w<S>(ox, ix1), wx0 = bl_w<S>(ox, ix1 - 1);
     const __bf16* p00 = x + (((int64_t)n * (Hi + 2) + iy1) * (Wi + 2) + ix1) * C + cg * 8;
@@ -770,14 +769,14 @@ __global__ __launch_bounds__(256) void upsample_raw_bwd_kernel(const __bf16* __r
                                                               int N, int Hi, int Wi, int C) {
   const int c8 = C >> 3;
   const int Ho = Hi * S, Wo = Wi * S;
-  const int64_t total = (int64_t)N * Hi * Wi * c8;
-  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
-    const int cg = (int)(idx % c8);
-    int64_t r = idx / c8;
-    const int j = (int)(r % Wi);
-    r /= Wi;
-    const int i = (int)(r % Hi);
-    const int n = (int)(r / Hi);
+  const uint32_t total = (uint32_t)N * Hi * Wi * c8;  // (< 2^31: checked by the launcher)
+  for (uint32_t idx = blockIdx.x * 256 + threadIdx.x; idx < total; idx += gridDim.x * 256) {
+    const int cg = (int)(idx % (uint32_t)c8);
+    uint32_t r = idx / (uint32_t)c8;
+    const int j = (int)(r % (uint32_t)Wi);
+    r /= (uint32_t)Wi;
+    const int i = (int)(r % (uint32_t)Hi);
+    const int n = (int)(r / (uint32_t)Hi);
     const __bf16* dimg = dy + (int64_t)n * (Ho + 2) * (Wo + 2) * C + cg * 8;
     float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     // A row of the footprint = 2S loads issued together (positions outside the map read the zero border of the padded
@@ -878,25 +877,54 @@ __global__ __launch_bounds__(256) void softmax_ce_dense_kernel(const float* __re
   for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < npix; p += (int64_t)gridDim.x * 256) {
     const int lab = labels[p];
     // one pass over the row, kept in registers (a lane's C floats are contiguous: the wave reads a dense span)
+    // (C == CM, a multiple of four: the row as 16-byte loads / stores; one exponential per class on the transcendental
+    // unit, the softmax as e / sum -- the scalar form spent 24 library exponentials and 24 four-byte accesses per pixel and ran
+    // at 1.7 TB/s)
     float l[CM];
+    const bool vec = C == CM && (CM & 3) == 0;
+    if (vec) {
 #pragma unroll
-    for (int c = 0; c < CM; ++c) l[c] = c < C ? (scale ? logits[p * C + c] * sc[c] + sh[c] : logits[p * C + c]) : -3.0e38f;
+      for (int c4 = 0; c4 < CM / 4; ++c4) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(logits + p * C + 4 * c4);
+        l[4 * c4] = v.x, l[4 * c4 + 1] = v.y, l[4 * c4 + 2] = v.z, l[4 * c4 + 3] = v.w;
+      }
+      if (scale) {
+#pragma unroll
+        for (int c = 0; c < CM; ++c) l[c] = l[c] * sc[c] + sh[c];
+      }
+    } else {
+#pragma unroll
+      for (int c = 0; c < CM; ++c) l[c] = c < C ? (scale ? logits[p * C + c] * sc[c] + sh[c] : logits[p * C + c]) : -3.0e38f;
+    }
     float m = l[0];
 #pragma unroll
     for (int c = 1; c < CM; ++c) m = fmaxf(m, l[c]);
-    float sum = 0.f;
+    float e[CM], sum = 0.f;
 #pragma unroll
-    for (int c = 0; c < CM; ++c) sum += c < C ? expf(l[c] - m) : 0.f;
-    const float lse = m + logf(sum);
+    for (int c = 0; c < CM; ++c) {
+      e[c] = c < C ? xv_fast_exp(l[c] - m) : 0.f;
+      sum += e[c];
+    }
+    const float lse = m + xv_fast_log(sum);
     const bool valid = lab >= 0 && lab < C;
     float llab = 0.f;
 #pragma unroll
     for (int c = 0; c < CM; ++c)
       if (c == lab) llab = l[c];
     if (valid) local += (double)(lse - llab) * inv;
+    const float k = valid ? inv / sum : 0.f, hot = valid ? inv : 0.f;
+    float d[CM];
 #pragma unroll
-    for (int c = 0; c < CM; ++c)
-      if (c < C) dlogits[p * C + c] = valid ? (expf(l[c] - lse) - (c == lab ? 1.f : 0.f)) * inv : 0.f;
+    for (int c = 0; c < CM; ++c) d[c] = e[c] * k - (c == lab ? hot : 0.f);
+    if (vec) {
+#pragma unroll
+      for (int c4 = 0; c4 < CM / 4; ++c4)
+        *reinterpret_cast<f32x4*>(dlogits + p * C + 4 * c4) = f32x4{d[4 * c4], d[4 * c4 + 1], d[4 * c4 + 2], d[4 * c4 + 3]};
+    } else {
+#pragma unroll
+      for (int c = 0; c < CM; ++c)
+        if (c < C) dlogits[p * C + c] = d[c];
+    }
   }
   __shared__ double red[256];
   red[threadIdx.x] = local;
@@ -1588,13 +1616,14 @@ extern "C" int xv_upsample_raw_fwd(const xv_act* x, int factor, const xv_act* y,
   XV_CHECK_ARG(x && y && x->data && y->data);
   XV_CHECK_SHAPE((factor == 2 || factor == 8) && (x->c & 7) == 0 && y->n == x->n && y->h == factor * x->h &&
                  y->w == factor * x->w && y->c == x->c);
-  const int64_t total = (int64_t)y->n * y->h * y->w * (y->c >> 3);
+  XV_CHECK_SHAPE(y->h <= 65535 && y->n <= 65535 && (int64_t)y->w * (y->c >> 3) < 0x7fff0000);
+  const dim3 grid((unsigned)(((int64_t)y->w * (y->c >> 3) + 255) / 256), (unsigned)y->h, (unsigned)y->n);
   if (factor == 2)
-    hipLaunchKernelGGL(upsample_raw_kernel<2>, dim3(bn_grid(total, 8192)), dim3(256), 0, (hipStream_t)stream,
-                       (const __bf16*)x->data, (__bf16*)y->data, x->n, x->h, x->w, x->c);
+    hipLaunchKernelGGL(upsample_raw_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, (const __bf16*)x->data, (__bf16*)y->data,
+                       x->n, x->h, x->w, x->c);
   else
-    hipLaunchKernelGGL(upsample_raw_kernel<8>, dim3(bn_grid(total, 8192)), dim3(256), 0, (hipStream_t)stream,
-                       (const __bf16*)x->data, (__bf16*)y->data, x->n, x->h, x->w, x->c);
+    hipLaunchKernelGGL(upsample_raw_kernel<8>, grid, dim3(256), 0, (hipStream_t)stream, (const __bf16*)x->data, (__bf16*)y->data,
+                       x->n, x->h, x->w, x->c);
   return xv_launch_status();
 }
 
@@ -1604,6 +1633,7 @@ extern "C" int xv_upsample_raw_bwd(const xv_act* dy, int factor, const xv_act* d
   XV_CHECK_SHAPE((factor == 2 || factor == 8) && (dx->c & 7) == 0 && dy->n == dx->n && dy->h == factor * dx->h &&
                  dy->w == factor * dx->w && dy->c == dx->c);
   const int64_t total = (int64_t)dx->n * dx->h * dx->w * (dx->c >> 3);
+  XV_CHECK_SHAPE(total < 0x7fff0000);  // (32-bit index arithmetic in the kernel)
   if (factor == 2)
     hipLaunchKernelGGL(upsample_raw_bwd_kernel<2>, dim3(bn_grid(total, 8192)), dim3(256), 0, (hipStream_t)stream,
                        (const __bf16*)dy->data, (__bf16*)dx->data, dx->n, dx->h, dx->w, dx->c);
