@@ -1282,6 +1282,17 @@ __global__ __launch_bounds__(256) void score_dense_wgrad_scatter_kernel(const do
   }
 }
 
+// ... and of score_dense_wgrad_split_kernel's rows (conv_wgrad.hip): sums [17][64] doubles, row c < 16 = class c x 64 units,
+// row 16 = db in its first 16 entries
+__global__ __launch_bounds__(256) void score_dense_wgrad_split_scatter_kernel(const double* __restrict__ sums, int C,
+                                                                             float* __restrict__ dws, float* __restrict__ dbs) {
+  for (int i = threadIdx.x; i < C * 64; i += 256) {
+    const int c = i >> 6, u = i & 63;
+    dws[u * C + c] += (float)sums[i];
+  }
+  if ((int)threadIdx.x < C) dbs[threadIdx.x] += (float)sums[16 * 64 + threadIdx.x];
+}
+
 bool same_shape(const xv_act* a, const xv_act* b) { return a->n == b->n && a->h == b->h && a->w == b->w && a->c == b->c; }
 
 }  // namespace
@@ -1717,10 +1728,20 @@ static unsigned score_dense_wgrad_grid(int64_t npix, int& qpw) {
   qpw = (qpw + 3) / 4 * 4;
   return (unsigned)((nquads + (int64_t)4 * qpw - 1) / ((int64_t)4 * qpw));
 }
+// conv_wgrad.hip: the bf16-split form (64 units, C <= 16, maps that tile in 8x32); the grid it launches, < 0: does not apply
+int xv_launch_score_wgrad_split(const float* ds, const void* y, int n, int h, int w, int c, float* part, int query_only,
+                                hipStream_t stream);
+static bool score_wgrad_split_ok() {
+  static const bool on = getenv("XV_SCORE_WGRAD_SPLIT") == nullptr || atoi(getenv("XV_SCORE_WGRAD_SPLIT")) != 0;
+  return on;
+}
 extern "C" size_t xv_score_dense_bwd_workspace_bytes(int n, int h, int w) {
   if (!xv_dims_sane(n, h, w) || (int64_t)n * h * w >= 0x7fff0000) return 0;
   int qpw;
-  return (size_t)score_dense_wgrad_grid((int64_t)n * h * w, qpw) * 33 * 64 * sizeof(float) + 33 * 64 * sizeof(double);
+  size_t rows = (size_t)score_dense_wgrad_grid((int64_t)n * h * w, qpw) * 33 * 64;
+  const int gs = xv_launch_score_wgrad_split(nullptr, nullptr, n, h, w, 16, nullptr, 1, nullptr);
+  if (gs > 0 && (size_t)gs * 17 * 64 > rows) rows = (size_t)gs * 17 * 64;
+  return rows * sizeof(float) + 33 * 64 * sizeof(double);
 }
 
 extern "C" int xv_score_dense_bwd_ws(const xv_act* u, const float* dscore, const float* w_score, int num_classes, float* dw_score,
@@ -1765,7 +1786,16 @@ extern "C" int xv_score_dense_bwd_ws(const xv_act* u, const float* dscore, const
   {                                                                                                                  \
     static bool attr[XV_MAX_DEVICES] = {false};                                                                      \
     (void)xv_allow_dynamic_lds(reinterpret_cast<const void*>(&score_dense_dgrad_kernel<CMV>), 160 * 1024, attr, false);      \
-    if (mfma_dgrad && !wg_old) {                                                                                     \
+    const int gs = (part != nullptr && score_wgrad_split_ok())                                                       \
+                       ? xv_launch_score_wgrad_split(dscore, u->data, u->n, u->h, u->w, num_classes, part, 0, s) : -1;  \
+    if (gs == -2) return XV_EINVAL;                                                                                  \
+    if (gs > 0) {                                                                                                    \
+      double* const tot = reinterpret_cast<double*>(part + (size_t)gs * 17 * 64);                                    \
+      hipLaunchKernelGGL(bn_sums_kernel, dim3(17 * 64), dim3(256), 0, s, (const float*)part, gs, 17 * 64, tot,         \
+                         (float*)nullptr, (float*)nullptr);                                                          \
+      hipLaunchKernelGGL(score_dense_wgrad_split_scatter_kernel, dim3(1), dim3(256), 0, s, (const double*)tot,         \
+                         num_classes, dw_score, db_score);                                                           \
+    } else if (mfma_dgrad && !wg_old) {                                                                              \
       hipLaunchKernelGGL(score_dense_wgrad_mfma_kernel<8>, dim3(gwm), dim3(256), 0, s, (const __bf16*)u->data, dscore, \
                          dw_score, db_score, u->n, u->h, u->w, num_classes, qpw, part);                               \
       if (part != nullptr) {                                                                                         \

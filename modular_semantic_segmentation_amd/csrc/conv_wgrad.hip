@@ -663,6 +663,150 @@ __global__ __launch_bounds__(512) void conv_first_wgrad_split_kernel(const float
   }
 }
 
+// ---- the dense 1x1 score layer at full resolution (batch-norm / joint trainers): filter + bias gradient --------------------
+// dW[u][c] = sum_pix Y[pix][u] dS[pix][c], db[c] = sum_pix dS[pix][c]: Y the bf16 64-channel feature map, dS the fp32
+// class-score gradient ([N][H][W][C] dense, C <= 16).  The scheme of conv_first_wgrad_split_kernel with the roles of a 1x1
+// layer: the Y tile (8x32 pixels) by LDS-DMA and transposing fragment reads as the matrix instruction's B operand, dS split
+// EXACTLY into three bf16 terms as its A operand (rows = classes), every product exact in fp32; the fp32 form
+// (batchnorm.hip, v_mfma_f32_16x16x4_f32: 8 instructions per 4 pixels) ran at 354 us against 150 us of memory traffic.  The
+// bias gradient is the lanes' own sum of the dS values they load.  Workgroup sums to part_out[block][(16 + 1) * 64]:
+// rows 0..15 = classes x 64 units, row 16 = db in its first 16 entries.
+__global__ __launch_bounds__(512) void score_dense_wgrad_split_kernel(const float* __restrict__ ds, const __bf16* __restrict__ y,
+                                                                     int N, int H, int W, int C, float* __restrict__ part_out) {
+  constexpr int TH = 8, TW = 32;
+  constexpr int D_BYTES = TH * TW * 128;
+  constexpr int XMAX = TH * TW * 16;  // floats of a dS tile at C = 16
+  constexpr int X_BYTES = XMAX * 4;
+  constexpr int BUF = D_BYTES + X_BYTES;
+  constexpr int XS = XMAX / 512;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int Wp = W + 2;
+  const int tiles_x = W / TW, tiles_y = H / TH, n_tiles = N * tiles_y * tiles_x;
+  const int XP = TH * TW * C;
+  const int g = lane >> 4, li = lane & 15, q = li >> 2, p = li & 3;
+  const int xk = 16 * (g >> 1) + 4 * (g & 1) + q;
+  int dbase[4];
+#pragma unroll
+  for (int n = 0; n < 4; ++n) dbase[n] = xk * 128 + (xv_swz(xk, n * 2 + (p >> 1)) << 4) + (p & 1) * 8 + wave * (TW * 128);
+  // dS fragment: row li = class; element j of the lane = pixel 16 (g >> 1) + 8 (j >> 2) + 4 (g & 1) + (j & 3) of image row `wave`
+  const bool live = li < C;
+  const int xfrag = D_BYTES + (live ? ((wave * TW + 16 * (g >> 1) + 4 * (g & 1)) * C + li) * 4 : 0);
+  int dvoff[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int idx = (wave + 8 * j) * 64 + lane;
+    const int pp = idx >> 3, ps = idx & 7;
+    const int py = pp / TW, px = pp - py * TW;
+    dvoff[j] = ((py * Wp + px) * 64 + xv_swz(px, ps) * 8) * 2;
+  }
+  // dS tile elements of this thread: row r of the tile (32 pixels x C floats, contiguous in memory), offset inside the row
+  uint32_t xrel[XS];
+#pragma unroll
+  for (int e = 0; e < XS; ++e) {
+    const int i = tid + 512 * e;
+    const int row = i / (TW * C), r = i - row * (TW * C);
+    xrel[e] = i < XP ? (uint32_t)((row * W * C + r) * 4) : 0x80000000u;
+  }
+  const uint64_t xa = (uint64_t)ds;
+  const uint32_t xlo = __builtin_amdgcn_readfirstlane((uint32_t)xa), xhi = __builtin_amdgcn_readfirstlane((uint32_t)(xa >> 32));
+  const auto xrs = __builtin_amdgcn_make_buffer_rsrc((void*)(((uint64_t)xhi << 32) | xlo), 0, 0x7fffffff, 0x00020000);
+  struct Tile {
+    int n, y0, x0;
+  };
+  auto decode = [&](int t) {
+    Tile tl;
+    tl.x0 = (t % tiles_x) * TW;
+    const int r = t / tiles_x;
+    tl.y0 = (r % tiles_y) * TH;
+    tl.n = r / tiles_y;
+    return tl;
+  };
+  float xreg[XS];
+  auto request = [&](const Tile& tl, int b) {
+    const __bf16* dsrc = y + (((int64_t)tl.n * (H + 2) + (tl.y0 + 1)) * Wp + (tl.x0 + 1)) * 64;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int lds = __builtin_amdgcn_readfirstlane(b * BUF + (wave + 8 * j) * 1024);
+      asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds), "v"(dvoff[j]), "s"(dsrc) : "memory");
+    }
+    const uint32_t tbase = (uint32_t)(((tl.n * H + tl.y0) * W + tl.x0) * C * 4);  // (< 2^31: checked by the launcher)
+#pragma unroll
+    for (int e = 0; e < XS; ++e) xreg[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, xrel[e], tbase, 0));
+  };
+  auto publish = [&](int b) {
+#pragma unroll
+    for (int e = 0; e < XS; ++e)
+      if (tid + 512 * e < XP) *reinterpret_cast<float*>(smem + b * BUF + D_BYTES + (tid + 512 * e) * 4) = xreg[e];
+  };
+  f32x4 acc[4];
+#pragma unroll
+  for (int n = 0; n < 4; ++n) acc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float bsum = 0.f;
+  int t = blockIdx.x;
+  if (t < n_tiles) {
+    request(decode(t), 0);
+    publish(0);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  int b = 0;
+  for (; t < n_tiles; t += gridDim.x) {
+    const bool more = t + (int)gridDim.x < n_tiles;
+    if (more) request(decode(t + gridDim.x), b ^ 1);
+    const char* buf = smem + b * BUF;
+    bf16x8 bfr[4];
+#pragma unroll
+    for (int n4 = 0; n4 < 4; ++n4) bfr[n4] = tr_read2(buf, dbase[n4], dbase[n4] + 8 * 128);
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = live ? *reinterpret_cast<const float*>(buf + xfrag + ((j & 3) + 8 * (j >> 2)) * C * 4) : 0.f;
+    bsum += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+    uint32_t hi[4], mid[4], lo[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      hi[k] = pack_bf16x2(v[2 * k], v[2 * k + 1]);
+      const float r0 = v[2 * k] - __builtin_bit_cast(float, hi[k] << 16), r1 = v[2 * k + 1] - __builtin_bit_cast(float, hi[k] & 0xffff0000u);
+      mid[k] = pack_bf16x2(r0, r1);
+      lo[k] = pack_bf16x2(r0 - __builtin_bit_cast(float, mid[k] << 16), r1 - __builtin_bit_cast(float, mid[k] & 0xffff0000u));
+    }
+    const bf16x8 ah = __builtin_bit_cast(bf16x8, u32x4{hi[0], hi[1], hi[2], hi[3]});
+    const bf16x8 am = __builtin_bit_cast(bf16x8, u32x4{mid[0], mid[1], mid[2], mid[3]});
+    const bf16x8 al = __builtin_bit_cast(bf16x8, u32x4{lo[0], lo[1], lo[2], lo[3]});
+#pragma unroll
+    for (int n4 = 0; n4 < 4; ++n4) acc[n4] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bfr[n4], acc[n4], 0, 0, 0);
+#pragma unroll
+    for (int n4 = 0; n4 < 4; ++n4) acc[n4] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bfr[n4], acc[n4], 0, 0, 0);
+#pragma unroll
+    for (int n4 = 0; n4 < 4; ++n4) acc[n4] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bfr[n4], acc[n4], 0, 0, 0);
+    if (more) publish(b ^ 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    b ^= 1;
+  }
+  // accumulator: row (class) 4 g + r, column (unit) 16 n4 + li; bsum: class li, one of 4 x 8 partial sums (g, wave)
+  float* red = reinterpret_cast<float*>(smem);
+  for (int c = tid; c < 17 * 64; c += 512) red[c] = 0.f;
+  __syncthreads();
+  for (int w = 0; w < 8; ++w) {
+    if (wave == w) {
+#pragma unroll
+      for (int n4 = 0; n4 < 4; ++n4)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[(4 * g + r) * 64 + 16 * n4 + li] += acc[n4][r];
+      for (int gg = 0; gg < 4; ++gg) {  // the four pixel groups of a class, in order
+        if (g == gg) red[16 * 64 + li] += bsum;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      }
+    }
+    __syncthreads();
+  }
+  for (int c = tid; c < 17 * 64; c += 512) part_out[(int64_t)blockIdx.x * (17 * 64) + c] = red[c];
+}
+
 // dw[i] += sum_s slab[s][i], splits summed in a fixed order (bitwise reproducible filter gradients)
 // (and db[c] += sum_s bslab[s][c], the bias gradient's partial sums, in the same launch).  SUBS lanes share an element:
 // lane `sub` adds splits sub, sub + SUBS, ... in order, then a butterfly over the SUBS partial sums -- a fixed tree either
@@ -888,5 +1032,22 @@ int xv_launch_first_wgrad_split(const float* x, const void* dy, float* dw, float
     default: XV_FWS(4) break;
   }
 #undef XV_FWS
+  return grid;
+}
+
+// the score layer's filter + bias gradient on the bf16 matrix instruction (score_dense_wgrad_split_kernel): 64 units, C <= 16,
+// maps that tile in 8x32 pixels.  Returns the grid (rows of 17 x 64 floats in `part`), < 0 where it does not apply.
+int xv_launch_score_wgrad_split(const float* ds, const void* y, int n, int h, int w, int c, float* part, int query_only,
+                                hipStream_t stream) {
+  if (c < 1 || c > 16 || (h & 7) || (w & 31) || (int64_t)n * h * w * c * 4 >= 0x7fff0000LL) return -1;
+  const int64_t tiles = (int64_t)n * (h / 8) * (w / 32);
+  const int64_t cap = (int64_t)xv_num_cus();  // (96 KB of LDS: one workgroup per CU)
+  const int grid = (int)(tiles < cap ? tiles : cap);
+  if (query_only) return grid;
+  constexpr int lds = 2 * (8 * 32 * 128 + 8 * 32 * 16 * 4);
+  static bool attr[XV_MAX_DEVICES] = {false};
+  const hipError_t e = xv_allow_dynamic_lds(reinterpret_cast<const void*>(&score_dense_wgrad_split_kernel), lds, attr);
+  if (e != hipSuccess) return -2;
+  hipLaunchKernelGGL(score_dense_wgrad_split_kernel, dim3((unsigned)grid), dim3(512), lds, stream, ds, (const __bf16*)y, n, h, w, c, part);
   return grid;
 }

@@ -123,10 +123,12 @@ def test_upsample_raw_and_its_transpose(ops, factor):
     assert np.abs(got - dref).max() < 2 ** -7 * np.abs(dref).max() + 1e-4
 
 
-@pytest.mark.parametrize('C', [12, 5])
-def test_dense_score_conv_and_cross_entropy(ops, C):
+@pytest.mark.parametrize('C,shape', [(12, (2, 8, 12)), (5, (2, 8, 12)), (12, (2, 16, 64)), (16, (1, 8, 32)), (5, (3, 24, 96))])
+def test_dense_score_conv_and_cross_entropy(ops, C, shape):
+    """(maps that tile in 8x32 pixels take the score layer's filter gradient on the bf16 matrix instruction with an exact
+    three-way split of the fp32 score gradient -- conv_wgrad.hip score_dense_wgrad_split_kernel -- the others the fp32 form)"""
     rng = np.random.default_rng(C)
-    n, h, w, U = 2, 8, 12, 64
+    (n, h, w), U = shape, 64
     u = fo.round_bf16(np.abs(rng.standard_normal((n, h, w, U))).astype(np.float32))
     ws = (0.3 * rng.standard_normal((U, C))).astype(np.float32)
     bs = rng.standard_normal(C).astype(np.float32)
