@@ -532,6 +532,21 @@ int xv_bn_dense_bwd_reduce_ws(const float* dy, const float* z, int64_t rows, int
 int xv_bn_bwd_apply_zmask(const xv_act* dy, const xv_act* z, const float* mean, const float* invstd, const float* scale,
                           const float* shift, const float* gamma, const double* sums, int64_t count, const xv_act* dz,
                           void* stream);
+
+/* The batch norm BEHIND the x8 deconv without its input in memory: `low` is the deconv's input (padded bf16, 64 .. 2048
+ * channels), the normalised map is z = bilinear_x8(low) rounded to bf16 -- exactly what xv_upsample_raw_fwd(low, 8) would
+ * store -- recomputed per element in the four passes that would read it back (custom_layers.py:112-119 behind
+ * simple_fcn.py:117-119 in training).  Same results, bit for bit, as the entry points without `_ups8` on the stored map.      */
+int xv_bn_stats_finalize_ups8_ws(const xv_act* low, double* sums, void* workspace, size_t workspace_bytes, const float* gamma,
+                                 const float* beta, float eps, float momentum, float* moving_mean, float* moving_var, float* mean,
+                                 float* invstd, float* scale, float* shift, void* stream);
+int xv_bn_apply_ups8(const xv_act* low, const float* scale, const float* shift, int relu, const xv_act* y, void* stream);
+int xv_bn_bwd_reduce_zmask_ups8(const xv_act* dy, const xv_act* low, const float* mean, const float* invstd, const float* scale,
+                                const float* shift, double* sums, float* dgamma, float* dbeta, void* workspace,
+                                size_t workspace_bytes, void* stream);
+int xv_bn_bwd_apply_zmask_ups8(const xv_act* dy, const xv_act* low, const float* mean, const float* invstd, const float* scale,
+                               const float* shift, const float* gamma, const double* sums, int64_t count, const xv_act* dz,
+                               void* stream);
 /* The same on a dense float32 [rows][C] tensor, C <= 32 (the batch norm on `score`, simple_fcn.py:131-133).        */
 int xv_bn_dense_stats(const float* z, int64_t rows, int channels, double* sums, void* stream);
 int xv_bn_dense_apply(const float* z, int64_t rows, int channels, const float* scale, const float* shift, float* y,

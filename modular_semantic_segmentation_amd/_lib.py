@@ -105,10 +105,12 @@ SIGNATURES = {
     'xv_bn_stats': (_i, [_actp, _vp, _vp]),
     'xv_bn_finalize': (_i, [_vp, _i, _i64, _vp, _vp, ctypes.c_float, ctypes.c_float, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     'xv_bn_apply': (_i, [_actp, _vp, _vp, _i, _actp, _vp]),
+    'xv_bn_apply_ups8': (_i, [_actp, _vp, _vp, _i, _actp, _vp]),
     'xv_bn_bwd': (_i, [_actp, _actp, _actp, _vp, _vp, _vp, _vp, _vp, _vp, _actp, _vp]),
     'xv_bn_bwd_reduce': (_i, [_actp, _actp, _actp, _vp, _vp, _vp, _vp, _vp, _vp]),
     'xv_bn_bwd_apply': (_i, [_actp, _actp, _actp, _vp, _vp, _vp, _vp, _i64, _actp, _vp]),
     'xv_bn_bwd_reduce_zmask': (_i, [_actp, _actp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_size_t, _vp]),
+    'xv_bn_bwd_reduce_zmask_ups8': (_i, [_actp, _actp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_size_t, _vp]),
     'xv_bn_workspace_bytes': (ctypes.c_size_t, [_i]),
     'xv_conv2d_stats_rows': (_i, []),
     'xv_conv2d_fwd_stats': (_i, [_actp, _vp, _vp, _actp, _vp, ctypes.c_size_t, _vp]),
@@ -120,6 +122,8 @@ SIGNATURES = {
                                       _vp, _vp]),
     'xv_bn_stats_finalize_ws': (_i, [_actp, _vp, _vp, ctypes.c_size_t, _vp, _vp, ctypes.c_float, ctypes.c_float, _vp, _vp, _vp,
                                      _vp, _vp, _vp, _vp]),
+    'xv_bn_stats_finalize_ups8_ws': (_i, [_actp, _vp, _vp, ctypes.c_size_t, _vp, _vp, ctypes.c_float, ctypes.c_float, _vp, _vp, _vp,
+                                     _vp, _vp, _vp, _vp]),
     'xv_bn_apply_pool': (_i, [_actp, _vp, _vp, _actp, _actp, _vp]),
     'xv_bn_pool_bwd_reduce': (_i, [_actp, _actp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_size_t, _vp]),
     'xv_bn_pool_bwd_apply': (_i, [_actp, _actp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _actp, _vp]),
@@ -128,6 +132,7 @@ SIGNATURES = {
     'xv_bn_dense_stats_ws': (_i, [_vp, _i64, _i, _vp, _vp, ctypes.c_size_t, _vp]),
     'xv_bn_dense_bwd_reduce_ws': (_i, [_vp, _vp, _i64, _i, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_size_t, _vp]),
     'xv_bn_bwd_apply_zmask': (_i, [_actp, _actp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _actp, _vp]),
+    'xv_bn_bwd_apply_zmask_ups8': (_i, [_actp, _actp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _actp, _vp]),
     'xv_bn_dense_bwd_reduce': (_i, [_vp, _vp, _i64, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     'xv_bn_dense_bwd_apply': (_i, [_vp, _vp, _i64, _i, _vp, _vp, _vp, _vp, _i64, _vp, _vp]),
     'xv_bn_dense_stats': (_i, [_vp, _i64, _i, _vp, _vp]),

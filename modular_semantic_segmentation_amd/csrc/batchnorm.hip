@@ -22,13 +22,82 @@ inline int bn_grid(int64_t total, int cap = 2048) {
 }
 
 // ---- per-channel sums over the interior of a padded-NHWC bf16 tensor ----------------------------------------
+// idx -> (pixel p = idx / c8, then row = p / W, n = row / H) without integer divisions where the sizes allow: c8 a power of
+// two (a shift), quotients through a float reciprocal with one correction step (exact below 2^24).  The recomputing (UPS)
+// batch-norm passes are ALU-bound, and three 32-bit divisions per 16 bytes were a third of their instructions.
+struct BnDiv {
+  int c8shift;   // log2(c8) or -1
+  bool small;    // N H W < 2^24: the float path is exact
+  float invW, invH;
+};
+__device__ __forceinline__ BnDiv bn_div_make(int c8, int N, int H, int W) {
+  BnDiv d;
+  d.c8shift = (c8 & (c8 - 1)) == 0 ? 31 - __builtin_clz(c8) : -1;
+  d.small = (int64_t)N * H * W < (1 << 24);
+  d.invW = 1.f / (float)W, d.invH = 1.f / (float)H;
+  return d;
+}
+__device__ __forceinline__ int bn_div_q(int a, int b, float invb) {  // a / b for 0 <= a < 2^24
+  int q = (int)((float)a * invb);
+  q -= (q * b > a) ? 1 : 0;
+  q += ((q + 1) * b <= a) ? 1 : 0;
+  return q;
+}
+__device__ __forceinline__ void bn_div_pos(const BnDiv& d, int idx, int c8, int H, int W, int& n, int& yy, int& x) {
+  const int p = d.c8shift >= 0 ? idx >> d.c8shift : idx / c8;
+  const int row = d.small ? bn_div_q(p, W, d.invW) : p / W;
+  x = p - row * W;
+  n = d.small ? bn_div_q(row, H, d.invH) : row / H;
+  yy = row - n * H;
+}
+
+// weight of source pixel i in output pixel o of the bilinear x S transposed conv (0 if not a tap; custom_layers.py:8-25)
+template <int S>
+__device__ __forceinline__ float bl_w(int o, int i) {
+  constexpr float center = (2.f * S - 1.f - (S % 2)) / (2.f * S);
+  const int p = o + S / 2 - i * S;  // tap index along the kernel: 0 .. 2S-1
+  if (p < 0 || p >= 2 * S) return 0.f;
+  return 1.f - fabsf((float)p / S - center);
+}
+// Eight channels (cg) of output pixel (oy, ox) of the x S up-sampled map of the padded low-resolution map x, rounded to
+// bf16: what upsample_raw_kernel stores.  The batch-norm passes of the layer behind the x8 deconv (UPS kernels below) call
+// the same function instead of reading the 0.6 GB map back -- an explicit fmaf chain, so every caller gets the same bits.
+template <int S>
+__device__ __forceinline__ u32x4 upsample_words(const __bf16* __restrict__ x, int n, int oy, int ox, int cg, int Hi, int Wi, int C) {
+  const int iy1 = (oy + S / 2) / S, ix1 = (ox + S / 2) / S;  // taps iy1-1, iy1 (padded coords iy1, iy1+1)
+  float wy1, wy0, wx1, wx0;
+  if constexpr (S == 8) {
+    // bl_w in closed form: with tap index p = (o + 4) & 7 of the nearer source, w1 = (2 p + 1) / 16 and w0 = (15 - 2 p) / 16 --
+    // the same floats (every term of bl_w's expression is a dyadic rational of a few bits: exact), without its branch,
+    // division and fabs (recomputing the map was ALU-bound: 230 us a pass)
+    const int py = (oy + 4) & 7, px = (ox + 4) & 7;
+    wy1 = (float)(2 * py + 1) * 0.0625f, wy0 = (float)(15 - 2 * py) * 0.0625f;
+    wx1 = (float)(2 * px + 1) * 0.0625f, wx0 = (float)(15 - 2 * px) * 0.0625f;
+  } else {
+    wy1 = bl_w<S>(oy, iy1), wy0 = bl_w<S>(oy, iy1 - 1), wx1 = bl_w<S>(ox, ix1), wx0 = bl_w<S>(ox, ix1 - 1);
+  }
+  const __bf16* p00 = x + (((int64_t)n * (Hi + 2) + iy1) * (Wi + 2) + ix1) * C + cg * 8;
+  const int64_t rowp = (int64_t)(Wi + 2) * C;
+  const u32x4 a00 = *reinterpret_cast<const u32x4*>(p00), a01 = *reinterpret_cast<const u32x4*>(p00 + C);
+  const u32x4 a10 = *reinterpret_cast<const u32x4*>(p00 + rowp), a11 = *reinterpret_cast<const u32x4*>(p00 + rowp + C);
+  const float w00 = wy0 * wx0, w01 = wy0 * wx1, w10 = wy1 * wx0, w11 = wy1 * wx1;
+  u32x4 o;
+#pragma unroll
+  for (int w = 0; w < 4; ++w)
+    o[w] = pack_bf16x2(fmaf(bf_lo(a11[w]), w11, fmaf(bf_lo(a10[w]), w10, fmaf(bf_lo(a01[w]), w01, bf_lo(a00[w]) * w00))),
+                       fmaf(bf_hi(a11[w]), w11, fmaf(bf_hi(a10[w]), w10, fmaf(bf_hi(a01[w]), w01, bf_hi(a00[w]) * w00))));
+  return o;
+}
+
 // MODE 0: sums[c] = sum z, sums[C + c] = sum z^2                                     (forward statistics)
 // MODE 1: sums[c] = sum g, sums[C + c] = sum g * zhat, g = dy * (y > 0 or 1)        (backward reductions)
 // MODE 2: as 1 with the relu mask RECOMPUTED from z (z * scale + shift > 0, the forward pass's own expression) instead
 //         of read from the activation map: a third less traffic (`y` then carries scale, `zsh` shift)
 // A thread owns one 8-channel group (the grid stride is a multiple of C/8), accumulates in fp32 over its pixels,
 // the block reduces through LDS and issues one double atomic per channel.
-template <int MODE>
+// UPS = 8 (MODE 0 / 2): `z` is the LOW-resolution map and the [N][H][W] values are its x8 up-sampling, recomputed per element
+// (upsample_words) instead of read: the layer behind the x8 deconv never stores its 0.6 GB pre-activation.
+template <int MODE, int UPS = 0>
 __global__ __launch_bounds__(256) void bn_reduce_kernel(const __bf16* __restrict__ z, const __bf16* __restrict__ dy,
                                                        const __bf16* __restrict__ y, const float* __restrict__ mean,
                                                        const float* __restrict__ invstd, double* __restrict__ sums,
@@ -49,11 +118,28 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const __bf16* __restrict
   for (int e = 0; e < 8; ++e) sc[e] = MODE == 2 ? zsc[cg * 8 + e] : 0.f, sh[e] = MODE == 2 ? zsh[cg * 8 + e] : 0.f;
   // total < 2^31 (checked by the launchers): 32-bit index arithmetic
   const int total32 = (int)total, stride = (int)gridDim.x * 256;
-  auto offset_of = [&](int idx) -> int64_t {
-    const int p = idx / c8;
-    const int row = p / W;
-    const int x = p - row * W, n = row / H, yy = row - n * H;
-    return (((int64_t)n * (H + 2) + yy + 1) * (W + 2) + x + 1) * C + cg * 8;
+  struct Pos {
+    int64_t off;
+    int n, yy, x;
+  };
+  const BnDiv dv = bn_div_make(c8, N, H, W);
+  auto pos_of = [&](int idx) {
+    int n, yy, x;
+    if constexpr (UPS != 0) {
+      bn_div_pos(dv, idx, c8, H, W, n, yy, x);
+    } else {
+      const int p = idx / c8;
+      const int row = p / W;
+      x = p - row * W, n = row / H, yy = row - n * H;
+    }
+    return Pos{(((int64_t)n * (H + 2) + yy + 1) * (W + 2) + x + 1) * C + cg * 8, n, yy, x};
+  };
+  auto offset_of = [&](int idx) -> int64_t { return pos_of(idx).off; };
+  auto load_z = [&](const Pos& ps) {
+    if constexpr (UPS != 0)
+      return upsample_words<UPS == 0 ? 8 : UPS>(z, ps.n, ps.yy, ps.x, cg, H / (UPS == 0 ? 8 : UPS), W / (UPS == 0 ? 8 : UPS), C);
+    else
+      return *reinterpret_cast<const u32x4*>(z + ps.off);
   };
   int idx = (int)blockIdx.x * 256 + (int)threadIdx.x;
   if (MODE == 0) {
@@ -62,7 +148,7 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const __bf16* __restrict
     for (; idx + 3 * stride < total32; idx += 4 * stride) {
       u32x4 v[4];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) v[q] = *reinterpret_cast<const u32x4*>(z + offset_of(idx + q * stride));
+      for (int q = 0; q < 4; ++q) v[q] = load_z(pos_of(idx + q * stride));
 #pragma unroll
       for (int q = 0; q < 4; ++q)
 #pragma unroll
@@ -80,9 +166,9 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const __bf16* __restrict
       u32x4 zv[2], gv[2];
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
-        const int64_t off = offset_of(idx + q * stride);
-        zv[q] = *reinterpret_cast<const u32x4*>(z + off);
-        gv[q] = *reinterpret_cast<const u32x4*>(dy + off);
+        const Pos ps = pos_of(idx + q * stride);
+        zv[q] = load_z(ps);
+        gv[q] = *reinterpret_cast<const u32x4*>(dy + ps.off);
       }
 #pragma unroll
       for (int q = 0; q < 2; ++q)
@@ -98,8 +184,9 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const __bf16* __restrict
         }
     }
     for (; idx < total32; idx += stride) {
-      const int64_t off = offset_of(idx);
-      const u32x4 zv = *reinterpret_cast<const u32x4*>(z + off), gv = *reinterpret_cast<const u32x4*>(dy + off);
+      const Pos ps = pos_of(idx);
+      const int64_t off = ps.off;
+      const u32x4 zv = load_z(ps), gv = *reinterpret_cast<const u32x4*>(dy + off);
 #pragma unroll
       for (int w = 0; w < 4; ++w) {
         const float za = bf_lo(zv[w]), zb = bf_hi(zv[w]);
@@ -138,8 +225,9 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const __bf16* __restrict
     }
   }
   for (; idx < total32; idx += stride) {
-    const int64_t off = offset_of(idx);
-    const u32x4 zv = *reinterpret_cast<const u32x4*>(z + off);
+    const Pos ps = pos_of(idx);
+    const int64_t off = ps.off;
+    const u32x4 zv = load_z(ps);
     if (MODE == 0) {
 #pragma unroll
       for (int w = 0; w < 4; ++w) {
@@ -355,6 +443,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const __bf16* __restr
 // constants are loaded -- and the two double divisions per channel of the backward pass done -- once per thread instead of
 // once per element (the generic kernels above ran at 1.9 TB/s on them); 32-bit index arithmetic; several pixels' loads in
 // flight per thread.  Same expressions, same bits.
+template <int UPS = 0>  // UPS = 8: z is the low-resolution map, its x8 up-sampling recomputed per element (see bn_reduce_kernel)
 __global__ __launch_bounds__(256) void bn_apply_fast_kernel(const __bf16* __restrict__ z, const float* __restrict__ scale,
                                                            const float* __restrict__ shift, int relu,
                                                            __bf16* __restrict__ y, int N, int H, int W, int C) {
@@ -364,11 +453,27 @@ __global__ __launch_bounds__(256) void bn_apply_fast_kernel(const __bf16* __rest
 #pragma unroll
   for (int e = 0; e < 8; ++e) sc[e] = scale[cg * 8 + e], sh[e] = shift[cg * 8 + e];
   const int total = N * H * W * c8, stride = (int)gridDim.x * 256;  // < 2^31 (checked by the launcher)
-  auto offset_of = [&](int idx) -> int64_t {
-    const int p = idx / c8;
-    const int row = p / W;
-    const int x = p - row * W, n = row / H, yy = row - n * H;
-    return (((int64_t)n * (H + 2) + yy + 1) * (W + 2) + x + 1) * C + cg * 8;
+  struct Pos {
+    int64_t off;
+    int n, yy, x;
+  };
+  const BnDiv dv = bn_div_make(c8, N, H, W);
+  auto pos_of = [&](int idx) {
+    int n, yy, x;
+    if constexpr (UPS != 0) {
+      bn_div_pos(dv, idx, c8, H, W, n, yy, x);
+    } else {
+      const int p = idx / c8;
+      const int row = p / W;
+      x = p - row * W, n = row / H, yy = row - n * H;
+    }
+    return Pos{(((int64_t)n * (H + 2) + yy + 1) * (W + 2) + x + 1) * C + cg * 8, n, yy, x};
+  };
+  auto load_z = [&](const Pos& ps) {
+    if constexpr (UPS != 0)
+      return upsample_words<UPS == 0 ? 8 : UPS>(z, ps.n, ps.yy, ps.x, cg, H / (UPS == 0 ? 8 : UPS), W / (UPS == 0 ? 8 : UPS), C);
+    else
+      return *reinterpret_cast<const u32x4*>(z + ps.off);
   };
   auto apply = [&](const u32x4 zv) {
     u32x4 o;
@@ -390,21 +495,22 @@ __global__ __launch_bounds__(256) void bn_apply_fast_kernel(const __bf16* __rest
     u32x4 v[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      off[q] = offset_of(idx + q * stride);
-      v[q] = *reinterpret_cast<const u32x4*>(z + off[q]);
+      const Pos ps = pos_of(idx + q * stride);
+      off[q] = ps.off;
+      v[q] = load_z(ps);
     }
 #pragma unroll
     for (int q = 0; q < 4; ++q) *reinterpret_cast<u32x4*>(y + off[q]) = apply(v[q]);
   }
   for (; idx < total; idx += stride) {
-    const int64_t off = offset_of(idx);
-    *reinterpret_cast<u32x4*>(y + off) = apply(*reinterpret_cast<const u32x4*>(z + off));
+    const Pos ps = pos_of(idx);
+    *reinterpret_cast<u32x4*>(y + ps.off) = apply(load_z(ps));
   }
 }
 
 // MASKZ: the relu mask recomputed from z (fmaf(z, zsc, zsh) > 0: the SAME explicit fused multiply-add in the forward apply kernels and in every
 // kernel that recomputes the mask, so the sign test is identical by construction, not by the compiler's contraction choices) instead of read from y
-template <bool MASKZ>
+template <bool MASKZ, int UPS = 0>  // UPS = 8: z is the low-resolution map (see bn_reduce_kernel)
 __global__ __launch_bounds__(256) void bn_bwd_apply_fast_kernel(const __bf16* __restrict__ dy, const __bf16* __restrict__ y,
                                                                const __bf16* __restrict__ z, const float* __restrict__ mean,
                                                                const float* __restrict__ invstd,
@@ -423,11 +529,27 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_fast_kernel(const __bf16* __
     sc[e] = MASKZ ? zsc[c] : 0.f, sh[e] = MASKZ ? zsh[c] : 0.f;
   }
   const int total = N * H * W * c8, stride = (int)gridDim.x * 256;
-  auto offset_of = [&](int idx) -> int64_t {
-    const int p = idx / c8;
-    const int row = p / W;
-    const int x = p - row * W, n = row / H, yy = row - n * H;
-    return (((int64_t)n * (H + 2) + yy + 1) * (W + 2) + x + 1) * C + cg * 8;
+  struct Pos {
+    int64_t off;
+    int n, yy, x;
+  };
+  const BnDiv dv = bn_div_make(c8, N, H, W);
+  auto pos_of = [&](int idx) {
+    int n, yy, x;
+    if constexpr (UPS != 0) {
+      bn_div_pos(dv, idx, c8, H, W, n, yy, x);
+    } else {
+      const int p = idx / c8;
+      const int row = p / W;
+      x = p - row * W, n = row / H, yy = row - n * H;
+    }
+    return Pos{(((int64_t)n * (H + 2) + yy + 1) * (W + 2) + x + 1) * C + cg * 8, n, yy, x};
+  };
+  auto load_z = [&](const Pos& ps) {
+    if constexpr (UPS != 0)
+      return upsample_words<UPS == 0 ? 8 : UPS>(z, ps.n, ps.yy, ps.x, cg, H / (UPS == 0 ? 8 : UPS), W / (UPS == 0 ? 8 : UPS), C);
+    else
+      return *reinterpret_cast<const u32x4*>(z + ps.off);
   };
   const u32x4 ones = u32x4{0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
   auto apply = [&](const u32x4 zv, const u32x4 gv, const u32x4 yv) {
@@ -454,8 +576,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_fast_kernel(const __bf16* __
     u32x4 zv[2], gv[2], yv[2];
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
-      off[q] = offset_of(idx + q * stride);
-      zv[q] = *reinterpret_cast<const u32x4*>(z + off[q]);
+      const Pos ps = pos_of(idx + q * stride);
+      off[q] = ps.off;
+      zv[q] = load_z(ps);
       gv[q] = *reinterpret_cast<const u32x4*>(dy + off[q]);
       yv[q] = (y && !MASKZ) ? *reinterpret_cast<const u32x4*>(y + off[q]) : ones;
     }
@@ -463,8 +586,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_fast_kernel(const __bf16* __
     for (int q = 0; q < 2; ++q) *reinterpret_cast<u32x4*>(dz + off[q]) = apply(zv[q], gv[q], yv[q]);
   }
   for (; idx < total; idx += stride) {
-    const int64_t off = offset_of(idx);
-    *reinterpret_cast<u32x4*>(dz + off) = apply(*reinterpret_cast<const u32x4*>(z + off), *reinterpret_cast<const u32x4*>(dy + off),
+    const Pos ps = pos_of(idx);
+    const int64_t off = ps.off;
+    *reinterpret_cast<u32x4*>(dz + off) = apply(load_z(ps), *reinterpret_cast<const u32x4*>(dy + off),
                                                 (y && !MASKZ) ? *reinterpret_cast<const u32x4*>(y + off) : ones);
   }
 }
@@ -727,13 +851,6 @@ __global__ __launch_bounds__(256) void bn_dense_bwd_apply_kernel(const float* __
 }
 
 // ---- raw bilinear up-sampling (the constant deconv kernel, custom_layers.py:8-25) and its transpose -----------
-template <int S>
-__device__ __forceinline__ float bl_w(int o, int i) {  // weight of source pixel i in output pixel o (0 if not a tap)
-  constexpr float center = (2.f * S - 1.f - (S % 2)) / (2.f * S);
-  const int p = o + S / 2 - i * S;  // tap index along the kernel: 0 .. 2S-1
-  if (p < 0 || p >= 2 * S) return 0.f;
-  return 1.f - fabsf((float)p / S - center);
-}
 
 template <int S>
 __global__ __launch_bounds__(256) void upsample_raw_kernel(const __bf16* __restrict__ x, __bf16* __restrict__ y, int N,
@@ -747,18 +864,7 @@ __global__ __launch_bounds__(256) void upsample_raw_kernel(const __bf16* __restr
   const int oy = blockIdx.y, n = blockIdx.z;
   for (uint32_t idx = blockIdx.x * 256 + threadIdx.x; idx < (uint32_t)(Wo * c8); idx += gridDim.x * 256) {
     const int ox = (int)(idx / (uint32_t)c8), cg = (int)(idx - (uint32_t)ox * c8);
-    const int iy1 = (oy + S / 2) / S, ix1 = (ox + S / 2) / S;  // taps iy1-1, iy1 (padded coords iy1, iy1+1)
-    const float wy1 = bl_w<S>(oy, iy1), wy0 = bl_w<S>(oy, iy1 - 1), wx1 = bl_w<S>(ox, ix1), wx0 = bl_w<S>(ox, ix1 - 1);
-    const __bf16* p00 = x + (((int64_t)n * (Hi + 2) + iy1) * (Wi + 2) + ix1) * C + cg * 8;
-    const int64_t rowp = (int64_t)(Wi + 2) * C;
-    const u32x4 a00 = *reinterpret_cast<const u32x4*>(p00), a01 = *reinterpret_cast<const u32x4*>(p00 + C);
-    const u32x4 a10 = *reinterpret_cast<const u32x4*>(p00 + rowp), a11 = *reinterpret_cast<const u32x4*>(p00 + rowp + C);
-    const float w00 = wy0 * wx0, w01 = wy0 * wx1, w10 = wy1 * wx0, w11 = wy1 * wx1;
-    u32x4 o;
-#pragma unroll
-    for (int w = 0; w < 4; ++w)
-      o[w] = pack_bf16x2(bf_lo(a00[w]) * w00 + bf_lo(a01[w]) * w01 + bf_lo(a10[w]) * w10 + bf_lo(a11[w]) * w11,
-                         bf_hi(a00[w]) * w00 + bf_hi(a01[w]) * w01 + bf_hi(a10[w]) * w10 + bf_hi(a11[w]) * w11);
+    const u32x4 o = upsample_words<S>(x, n, oy, ox, cg, Hi, Wi, C);
     *reinterpret_cast<u32x4*>(y + (((int64_t)n * (Ho + 2) + oy + 1) * (Wo + 2) + ox + 1) * C + cg * 8) = o;
   }
 }
@@ -1403,7 +1509,7 @@ extern "C" int xv_bn_apply(const xv_act* z, const float* scale, const float* shi
   XV_CHECK_SHAPE(same_shape(z, y) && (z->c & 7) == 0);
   const int64_t total = (int64_t)z->n * z->h * z->w * (z->c >> 3);
   if (z->c >= 64 && 2048 % z->c == 0 && total < 0x7fff0000)  // C / 8 divides the block size: a thread keeps its channels
-    hipLaunchKernelGGL(bn_apply_fast_kernel, dim3(bn_grid(total, 2048)), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(bn_apply_fast_kernel<0>, dim3(bn_grid(total, 2048)), dim3(256), 0, (hipStream_t)stream,
                        (const __bf16*)z->data, scale, shift, relu, (__bf16*)y->data, z->n, z->h, z->w, z->c);
   else
     hipLaunchKernelGGL(bn_apply_kernel, dim3(bn_grid(total, 8192)), dim3(256), 0, (hipStream_t)stream,
@@ -1511,6 +1617,71 @@ extern "C" int xv_bn_bwd_apply_zmask(const xv_act* dy, const xv_act* z, const fl
   hipLaunchKernelGGL(bn_bwd_apply_fast_kernel<true>, dim3(bn_grid(total, 2048)), dim3(256), 0, (hipStream_t)stream,
                      (const __bf16*)dy->data, (const __bf16*)nullptr, (const __bf16*)z->data, mean, invstd, gamma, sums,
                      (double)count, (__bf16*)dz->data, z->n, z->h, z->w, z->c, scale, shift);
+  return xv_launch_status();
+}
+
+// ---- the batch norm BEHIND the x8 deconv without its input in memory ------------------------------------------------------
+// `low` is the deconv's input (padded bf16, 64 .. 2048 channels); the normalised map is z = bilinear_x8(low) rounded to bf16
+// -- exactly what xv_upsample_raw_fwd(low, 8) stores -- recomputed per element (four 16-byte reads of a map 64 times smaller,
+// cache-resident) in the four passes that would read it back: statistics + finalize, apply, gradient sums, gradient.  The
+// training step of `batch_normalization: true` then never writes or reads the 0.6 GB pre-activation of `upscore`
+// (custom_layers.py:112-119 behind simple_fcn.py:117-119): five of its thirteen passes over maps of that size.
+static bool ups_ok(const xv_act* low, int n, int h, int w, int c) {
+  return low && low->data && low->dtype == XV_BF16 && low->n == n && 8 * low->h == h && 8 * low->w == w && low->c == c &&
+         c >= 64 && 2048 % c == 0 && (int64_t)n * h * w * (c >> 3) < 0x7fff0000;
+}
+extern "C" int xv_bn_stats_finalize_ups8_ws(const xv_act* low, double* sums, void* workspace, size_t workspace_bytes,
+                                            const float* gamma, const float* beta, float eps, float momentum, float* moving_mean,
+                                            float* moving_var, float* mean, float* invstd, float* scale, float* shift,
+                                            void* stream) {
+  XV_CHECK_ARG(low && sums && workspace && gamma && beta && mean && invstd && scale && shift &&
+               (moving_mean == nullptr) == (moving_var == nullptr));
+  const int n = low->n, h = 8 * low->h, w = 8 * low->w, c = low->c;
+  XV_CHECK_SHAPE(ups_ok(low, n, h, w, c));
+  if (workspace_bytes < (size_t)BN_MAX_GRID * 2 * c * sizeof(float) || ((uintptr_t)workspace & 15)) return XV_EWORKSPACE;
+  hipStream_t s = (hipStream_t)stream;
+  const int grid = bn_grid((int64_t)n * h * w * (c >> 3), BN_MAX_GRID);
+  hipLaunchKernelGGL((bn_reduce_kernel<0, 8>), dim3(grid), dim3(256), 0, s, (const __bf16*)low->data, nullptr, nullptr, nullptr,
+                     nullptr, sums, n, h, w, c, (const float*)nullptr, (const float*)nullptr, (float*)workspace);
+  hipLaunchKernelGGL(bn_sums_finalize_kernel, dim3(c), dim3(256), 0, s, (const float*)workspace, grid, c, sums,
+                     (double)((int64_t)n * h * w), gamma, beta, eps, momentum, moving_mean, moving_var, mean, invstd, scale, shift);
+  return xv_launch_status();
+}
+extern "C" int xv_bn_apply_ups8(const xv_act* low, const float* scale, const float* shift, int relu, const xv_act* y, void* stream) {
+  XV_REQUIRE_BF16(y);
+  XV_CHECK_ARG(low && y && y->data && scale && shift);
+  XV_CHECK_SHAPE(ups_ok(low, y->n, y->h, y->w, y->c));
+  const int64_t total = (int64_t)y->n * y->h * y->w * (y->c >> 3);
+  hipLaunchKernelGGL(bn_apply_fast_kernel<8>, dim3(bn_grid(total, 2048)), dim3(256), 0, (hipStream_t)stream,
+                     (const __bf16*)low->data, scale, shift, relu, (__bf16*)y->data, y->n, y->h, y->w, y->c);
+  return xv_launch_status();
+}
+extern "C" int xv_bn_bwd_reduce_zmask_ups8(const xv_act* dy, const xv_act* low, const float* mean, const float* invstd,
+                                           const float* scale, const float* shift, double* sums, float* dgamma, float* dbeta,
+                                           void* workspace, size_t workspace_bytes, void* stream) {
+  XV_REQUIRE_BF16(dy);
+  XV_CHECK_ARG(dy && low && dy->data && mean && invstd && scale && shift && sums && dgamma && dbeta);
+  XV_CHECK_SHAPE(ups_ok(low, dy->n, dy->h, dy->w, dy->c));
+  hipStream_t s = (hipStream_t)stream;
+  const int64_t total = (int64_t)dy->n * dy->h * dy->w * (dy->c >> 3);
+  const int grid = bn_grid(total, BN_MAX_GRID);
+  const int rc = bn_sums_launch(sums, 2 * dy->c, grid, workspace, workspace_bytes, s, [&](float* part) {
+    hipLaunchKernelGGL((bn_reduce_kernel<2, 8>), dim3(grid), dim3(256), 0, s, (const __bf16*)low->data, (const __bf16*)dy->data,
+                       (const __bf16*)nullptr, mean, invstd, sums, dy->n, dy->h, dy->w, dy->c, scale, shift, part);
+  }, dgamma, dbeta);
+  if (rc != XV_OK) return rc;
+  return xv_launch_status();
+}
+extern "C" int xv_bn_bwd_apply_zmask_ups8(const xv_act* dy, const xv_act* low, const float* mean, const float* invstd,
+                                          const float* scale, const float* shift, const float* gamma, const double* sums,
+                                          int64_t count, const xv_act* dz, void* stream) {
+  XV_REQUIRE_BF16(dy, dz);
+  XV_CHECK_ARG(dy && low && dz && dy->data && dz->data && mean && invstd && scale && shift && gamma && sums);
+  XV_CHECK_SHAPE(same_shape(dy, dz) && ups_ok(low, dy->n, dy->h, dy->w, dy->c) && count > 0);
+  const int64_t total = (int64_t)dy->n * dy->h * dy->w * (dy->c >> 3);
+  hipLaunchKernelGGL((bn_bwd_apply_fast_kernel<true, 8>), dim3(bn_grid(total, 2048)), dim3(256), 0, (hipStream_t)stream,
+                     (const __bf16*)dy->data, (const __bf16*)nullptr, (const __bf16*)low->data, mean, invstd, gamma, sums,
+                     (double)count, (__bf16*)dz->data, dy->n, dy->h, dy->w, dy->c, scale, shift);
   return xv_launch_status();
 }
 

@@ -837,14 +837,24 @@ def conv2d_fwd_stats(x, w_packed, bias, z, st):
     return True
 
 
-def bn_forward(z, gamma, beta, moving_mean, moving_var, st, y, relu=True, sync=False, pooled=None, have_stats=False):
+def bn_forward(z, gamma, beta, moving_mean, moving_var, st, y, relu=True, sync=False, pooled=None, have_stats=False,
+               ups8_of=None):
     """y = [relu](BN_batch(z)); updates the moving statistics in place (z, y: Act).  sync: statistics over all
     data-parallel ranks (one all-reduce of 2*C doubles).  pooled (with relu): the 2x2 max-pool of y from the same pass; y
-    may then be None (only the pooled map is written)."""
+    may then be None (only the pooled map is written).  ups8_of (an Act 8 times smaller, with z None): z IS its bilinear x8
+    up-sampling and is recomputed per element instead of read (one process, deterministic workspace only)."""
     lib = _lib.lib()
     fin = (_ptr(gamma), _ptr(beta), BN_EPS, BN_MOMENTUM, _ptr(moving_mean), _ptr(moving_var), _ptr(st.mean), _ptr(st.invstd),
            _ptr(st.scale), _ptr(st.shift))
     ws = st.wsp()
+    if ups8_of is not None:
+        if sync or st.ws is None or pooled is not None or have_stats:
+            raise ValueError('bn_forward(ups8_of=): single-process statistics with a workspace, no pool')
+        _lib.check(lib.xv_bn_stats_finalize_ups8_ws(ups8_of.xv(), _ptr(st.sums), ws[0], ws[1], *fin, _stream()),
+                   'xv_bn_stats_finalize_ups8_ws')
+        _lib.check(lib.xv_bn_apply_ups8(ups8_of.xv(), _ptr(st.scale), _ptr(st.shift), int(bool(relu)), y.xv(), _stream()),
+                   'xv_bn_apply_ups8')
+        return y
     if not sync and have_stats:
         # one process: the row sums of the conv epilogue's partial statistics and the per-channel results in ONE launch
         _lib.check(lib.xv_bn_finalize_from_rows(_ptr(st.conv_rows), st.conv_rows_n, st.c, z.n * z.h * z.w, *fin, _ptr(st.sums),
@@ -869,13 +879,22 @@ def bn_forward(z, gamma, beta, moving_mean, moving_var, st, y, relu=True, sync=F
     return y
 
 
-def bn_backward(dy, y, z, gamma, st, dgamma, dbeta, dz, sync=False, mask_from_z=None, relu=None):
+def bn_backward(dy, y, z, gamma, st, dgamma, dbeta, dz, sync=False, mask_from_z=None, relu=None, ups8_of=None):
     """dz from dy (gradient w.r.t. the post-relu output); accumulates the LOCAL dgamma / dbeta (the gradient all-reduce
     sums them over ranks).  relu: is there an activation behind the batch norm (default: `y is not None`).  With one, the relu
     mask is recomputed from z (z * scale + shift > 0 with the scale / shift the forward pass left in `st`) for the trunk's
     channel counts (64 .. 2048, powers of two) -- a third less traffic, and `y` is then NOT read and may be None
     (`relu=True`); other channel counts, and mask_from_z=False, read the mask from y, which must then be given."""
     lib = _lib.lib()
+    if ups8_of is not None:     # z = bilinear_x8(ups8_of), recomputed per element (relu behind the batch norm, mask from z)
+        _lib.check(lib.xv_bn_bwd_reduce_zmask_ups8(dy.xv(), ups8_of.xv(), _ptr(st.mean), _ptr(st.invstd), _ptr(st.scale),
+                                                   _ptr(st.shift), _ptr(st.sums), _ptr(dgamma), _ptr(dbeta), *st.wsp(), _stream()),
+                   'xv_bn_bwd_reduce_zmask_ups8')
+        mult = _sync_sums(st, sync)
+        _lib.check(lib.xv_bn_bwd_apply_zmask_ups8(dy.xv(), ups8_of.xv(), _ptr(st.mean), _ptr(st.invstd), _ptr(st.scale),
+                                                  _ptr(st.shift), _ptr(gamma), _ptr(st.sums), dy.n * dy.h * dy.w * mult, dz.xv(),
+                                                  _stream()), 'xv_bn_bwd_apply_zmask_ups8')
+        return dz
     if relu is None:
         relu = y is not None
     can_zmask = z.c >= 64 and 2048 % z.c == 0

@@ -20,6 +20,8 @@ import torch
 from . import ops
 from .fcn import ENCODER
 
+# XV_VIRTUAL_UPSCORE=0: the batch-norm trainers store the x8 deconv's output and read it back (A/B timing)
+_VIRTUAL_UPSCORE = os.environ.get('XV_VIRTUAL_UPSCORE', '1') != '0'
 # filter gradients on a second HIP stream (encoder_backward); XV_WGRAD_STREAM=0: everything on one stream (A/B timing)
 _WGRAD_STREAM = os.environ.get('XV_WGRAD_STREAM', '1') != '0'
 
@@ -483,15 +485,16 @@ class FcnBnTrainer(object):
             t = self._a[key] = torch.empty(shape, dtype=dtype, device=self.e.device)
         return t
 
-    def _bn_fwd(self, name, z, y, relu=True, pooled=None, have_stats=False):
+    def _bn_fwd(self, name, z, y, relu=True, pooled=None, have_stats=False, ups8_of=None):
         mm, mv = self.moving[name]
         return ops.bn_forward(z, self.view(self.param, name, 'gamma'), self.view(self.param, name, 'beta'), mm, mv,
-                              self.bn[name], y, relu=relu, sync=self._sync, pooled=pooled, have_stats=have_stats)
+                              self.bn[name], y, relu=relu, sync=self._sync, pooled=pooled, have_stats=have_stats,
+                              ups8_of=ups8_of)
 
-    def _bn_bwd(self, name, dy, y, z, dz):
+    def _bn_bwd(self, name, dy, y, z, dz, ups8_of=None):
         return ops.bn_backward(dy, y, z, self.view(self.param, name, 'gamma'), self.bn[name],
                                self.view(self.grad, name, 'gamma'), self.view(self.grad, name, 'beta'), dz,
-                               sync=self._sync)
+                               sync=self._sync, ups8_of=ups8_of)
 
     # ---- one training step ----------------------------------------------------------------------------------
     def step(self, x, labels, reducer=None):
@@ -545,8 +548,16 @@ class FcnBnTrainer(object):
         st = self.bn['upscore_conv5']
         fused = ops.upsample2x_relu_add(Y['score_conv5'], residual=Y['score_conv4'], y=self._act('fused', n, h8, w8, e.Up),
                                         scale=st.scale, shift=st.shift)            # = y_up5 + y_score_conv4
-        Z['upscore'] = ops.upsample_raw_fwd(fused, 8, self._act('z_up', n, h, w, e.Up))
-        Y['upscore'] = self._bn_fwd('upscore', Z['upscore'], self._act('y_up', n, h, w, e.Up))
+        # The x8 deconv's output (0.6 GB at 16 images) is not stored: the four batch-norm passes that would read it back
+        # recompute it from `fused` per element (ops.bn_forward / bn_backward, ups8_of=).  Data-parallel runs (statistics
+        # all-reduced between the passes) and keep_all (inspection) keep the stored map.
+        virtual_up = _VIRTUAL_UPSCORE and not self._sync and not self.keep_all and self.bn['upscore'].ws is not None
+        if virtual_up:
+            Z['upscore'] = None
+            Y['upscore'] = self._bn_fwd('upscore', None, self._act('y_up', n, h, w, e.Up), ups8_of=fused)
+        else:
+            Z['upscore'] = ops.upsample_raw_fwd(fused, 8, self._act('z_up', n, h, w, e.Up))
+            Y['upscore'] = self._bn_fwd('upscore', Z['upscore'], self._act('y_up', n, h, w, e.Up))
         score_raw = ops.score_dense_fwd(Y['upscore'], self.w['score'], P('score', 'bias'), e.C,
                                         self._dense('score_raw', (n, h, w, e.C)))
         mm, mv = self.moving['score']
@@ -564,7 +575,7 @@ class FcnBnTrainer(object):
                                        G('score', 'beta'), self._dense('dscore', (n, h, w, e.C)), sync=self._sync)
         du = ops.score_dense_bwd(Y['upscore'], dscore, self.w['score'], e.C, G('score', 'kernel'), G('score', 'bias'),
                                  self._act('d_up', n, h, w, e.Up))
-        dz_up = self._bn_bwd('upscore', du, Y['upscore'], Z['upscore'], du)                 # in place
+        dz_up = self._bn_bwd('upscore', du, Y['upscore'], Z['upscore'], du, ups8_of=fused if virtual_up else None)   # in place
         dfused = ops.upsample_raw_bwd(dz_up, 8, self._act('dfused', n, h8, w8, e.Up))
         wkey = ('wgrad_ws', n, h, w)
         if wkey not in self._a:
@@ -845,10 +856,12 @@ class FusionFcnTrainer(object):
         s5 = ops.conv2d_fwd(concat('conv5_3'), e.w['fused_score_conv5'], e.b['fused_score_conv5'], 1, relu=True,
                             y=self._act('s5', n, h8 // 2, w8 // 2, e.Up))[0]
         feat = ops.upsample2x_relu_add(s5, residual=s4, y=self._act('features', n, h8, w8, e.Up))
-        z_up = ops.upsample_raw_fwd(feat, 8, self._act('z_up', n, h, w, e.Up))
+        # (the x8 deconv's output is not stored: see FcnBnTrainer.step)
+        virtual_up = _VIRTUAL_UPSCORE and not self._sync and self.bn['upscore'].ws is not None
         mm, mv = self.moving['upscore']
+        z_up = None if virtual_up else ops.upsample_raw_fwd(feat, 8, self._act('z_up', n, h, w, e.Up))
         y_up = ops.bn_forward(z_up, P('upscore', 'gamma'), P('upscore', 'beta'), mm, mv, self.bn['upscore'],
-                              self._act('y_up', n, h, w, e.Up), relu=True, sync=self._sync)
+                              self._act('y_up', n, h, w, e.Up), relu=True, sync=self._sync, ups8_of=feat if virtual_up else None)
         score_raw = ops.score_dense_fwd(y_up, P('score', 'kernel'), P('score', 'bias'), e.C,
                                         self._dense('score_raw', (n, h, w, e.C)))
         mm, mv = self.moving['score']
@@ -861,7 +874,7 @@ class FusionFcnTrainer(object):
         du = ops.score_dense_bwd(y_up, dscore, P('score', 'kernel'), e.C, G('score', 'kernel'), G('score', 'bias'),
                                  self._act('d_up', n, h, w, e.Up))
         dz_up = ops.bn_backward(du, y_up, z_up, P('upscore', 'gamma'), self.bn['upscore'], G('upscore', 'gamma'),
-                                G('upscore', 'beta'), du, sync=self._sync)
+                                G('upscore', 'beta'), du, sync=self._sync, ups8_of=feat if virtual_up else None)
         dfeat = ops.upsample_raw_bwd(dz_up, 8, self._act('dfeat', n, h8, w8, e.Up))
         ds4 = ops.relu_bwd(dfeat, s4, self._act('ds4', n, h8, w8, e.Up))
         ds5 = ops.upsample2x_bwd(dfeat, s5, self._act('ds5', n, h8 // 2, w8 // 2, e.Up))

@@ -615,3 +615,47 @@ def test_filter_gradients_on_their_own_stream_same_bits(ops, tmp_path, monkeypat
     assert results[0][0] == results[1][0]
     assert torch.equal(results[0][1], results[1][1])
     assert torch.equal(results[0][2], results[1][2])
+
+
+@pytest.mark.parametrize('kind', ['fcn_bn', 'fusion_fcn'])
+def test_batch_norm_behind_the_x8_deconv_without_its_input_in_memory(ops, tmp_path, monkeypatch, kind):
+    """The batch-norm and joint trainers recompute the x8 deconv's output per element in the four batch-norm passes that
+    would read it back (xv_bn_*_ups8, trainer._VIRTUAL_UPSCORE) instead of storing 0.6 GB: two steps with and without --
+    loss, gradient buffer and parameters bit-identical (the same bilinear arithmetic and rounding in every caller)."""
+    from modular_semantic_segmentation_amd import get_model, trainer
+    from modular_semantic_segmentation_amd.fcn import init_variables
+    C, U, H, W = 12, 64, 64, 96
+    rng = np.random.default_rng(12)
+    data = {'rgb': rng.integers(0, 256, (2, H, W, 3)).astype(np.float32),
+            'depth': rng.integers(0, 65536, (2, H, W, 1)).astype(np.float32),
+            'labels': rng.integers(-1, C, (2, H, W)).astype(np.int32)}
+    desc = ({'rgb': 'float32', 'labels': 'int32'}, {'rgb': (None, None, 3), 'labels': (None, None)}, C)
+    path = str(tmp_path / 'w.npz')
+    if kind == 'fusion_fcn':
+        prefixes, channels = {'rgb': 'rgb', 'depth': 'depth'}, {'rgb': 3, 'depth': 1}
+        w = fo.init_fusion_fcn_weights(prefixes, channels, U, C, seed=4, bias_scale=0.02)
+        w['rgb_conv1_1/kernel'] *= 0.02
+        w['depth_conv1_1/kernel'] *= 2e-4
+    else:
+        w = init_variables('rgb', 3, U, C, batch_normalization=True, seed=4)
+        w['rgb/conv1_1/kernel'] *= 0.02
+    np.savez(path, **w)
+    results = []
+    for virtual in (True, False):
+        monkeypatch.setattr(trainer, '_VIRTUAL_UPSCORE', virtual)
+        if kind == 'fusion_fcn':
+            net = get_model('fusion_fcn')(prefixes, channels, U, C, trainer='rmsprop', learning_rate=1e-4,
+                                          output_dir=str(tmp_path), batchsize=2)
+            x = {m: _dev(data[m]) for m in prefixes}
+        else:
+            net = get_model('fcn')('rgb', desc, 'rgb', output_dir=str(tmp_path), num_units=U, batch_normalization=True,
+                                   batchsize=2, learning_rate=1e-3, trainer='adam')
+            x = _dev(data['rgb'])
+        net.import_weights(path, warnings=False)
+        tr = net._ensure_trainer()
+        losses = [tr.step(x, _dev(data['labels'])).item() for _ in range(2)]
+        torch.cuda.synchronize()
+        results.append((losses, tr.grad.clone(), tr.param.clone()))
+    assert results[0][0] == results[1][0]
+    assert torch.equal(results[0][1], results[1][1])
+    assert torch.equal(results[0][2], results[1][2])
