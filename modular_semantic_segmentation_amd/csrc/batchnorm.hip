@@ -22,35 +22,6 @@ inline int bn_grid(int64_t total, int cap = 2048) {
 }
 
 // ---- per-channel sums over the interior of a padded-NHWC bf16 tensor ----------------------------------------
-// idx -> (pixel p = idx / c8, then row = p / W, n = row / H) without integer divisions where the sizes allow: c8 a power of
-// two (a shift), quotients through a float reciprocal with one correction step (exact below 2^24).  The recomputing (UPS)
-// batch-norm passes are ALU-bound, and three 32-bit divisions per 16 bytes were a third of their instructions.
-struct BnDiv {
-  int c8shift;   // log2(c8) or -1
-  bool small;    // N H W < 2^24: the float path is exact
-  float invW, invH;
-};
-__device__ __forceinline__ BnDiv bn_div_make(int c8, int N, int H, int W) {
-  BnDiv d;
-  d.c8shift = (c8 & (c8 - 1)) == 0 ? 31 - __builtin_clz(c8) : -1;
-  d.small = (int64_t)N * H * W < (1 << 24);
-  d.invW = 1.f / (float)W, d.invH = 1.f / (float)H;
-  return d;
-}
-__device__ __forceinline__ int bn_div_q(int a, int b, float invb) {  // a / b for 0 <= a < 2^24
-  int q = (int)((float)a * invb);
-  q -= (q * b > a) ? 1 : 0;
-  q += ((q + 1) * b <= a) ? 1 : 0;
-  return q;
-}
-__device__ __forceinline__ void bn_div_pos(const BnDiv& d, int idx, int c8, int H, int W, int& n, int& yy, int& x) {
-  const int p = d.c8shift >= 0 ? idx >> d.c8shift : idx / c8;
-  const int row = d.small ? bn_div_q(p, W, d.invW) : p / W;
-  x = p - row * W;
-  n = d.small ? bn_div_q(row, H, d.invH) : row / H;
-  yy = row - n * H;
-}
-
 // weight of source pixel i in output pixel o of the bilinear x S transposed conv (0 if not a tap; custom_layers.py:8-25)
 template <int S>
 __device__ __forceinline__ float bl_w(int o, int i) {
@@ -60,8 +31,8 @@ __device__ __forceinline__ float bl_w(int o, int i) {
   return 1.f - fabsf((float)p / S - center);
 }
 // Eight channels (cg) of output pixel (oy, ox) of the x S up-sampled map of the padded low-resolution map x, rounded to
-// bf16: what upsample_raw_kernel stores.  The batch-norm passes of the layer behind the x8 deconv (UPS kernels below) call
-// the same function instead of reading the 0.6 GB map back -- an explicit fmaf chain, so every caller gets the same bits.
+// bf16: what upsample_raw_kernel stores -- an explicit fmaf chain, which the batch-norm passes of the layer behind the x8 deconv
+// (bn_ups8_*_kernel below) repeat with compile-time column weights instead of reading the 0.6 GB map back: same bits.
 template <int S>
 __device__ __forceinline__ u32x4 upsample_words(const __bf16* __restrict__ x, int n, int oy, int ox, int cg, int Hi, int Wi, int C) {
   const int iy1 = (oy + S / 2) / S, ix1 = (ox + S / 2) / S;  // taps iy1-1, iy1 (padded coords iy1, iy1+1)
@@ -95,9 +66,7 @@ __device__ __forceinline__ u32x4 upsample_words(const __bf16* __restrict__ x, in
 //         of read from the activation map: a third less traffic (`y` then carries scale, `zsh` shift)
 // A thread owns one 8-channel group (the grid stride is a multiple of C/8), accumulates in fp32 over its pixels,
 // the block reduces through LDS and issues one double atomic per channel.
-// UPS = 8 (MODE 0 / 2): `z` is the LOW-resolution map and the [N][H][W] values are its x8 up-sampling, recomputed per element
-// (upsample_words) instead of read: the layer behind the x8 deconv never stores its 0.6 GB pre-activation.
-template <int MODE, int UPS = 0>
+template <int MODE>
 __global__ __launch_bounds__(256) void bn_reduce_kernel(const __bf16* __restrict__ z, const __bf16* __restrict__ dy,
                                                        const __bf16* __restrict__ y, const float* __restrict__ mean,
                                                        const float* __restrict__ invstd, double* __restrict__ sums,
@@ -118,28 +87,11 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const __bf16* __restrict
   for (int e = 0; e < 8; ++e) sc[e] = MODE == 2 ? zsc[cg * 8 + e] : 0.f, sh[e] = MODE == 2 ? zsh[cg * 8 + e] : 0.f;
   // total < 2^31 (checked by the launchers): 32-bit index arithmetic
   const int total32 = (int)total, stride = (int)gridDim.x * 256;
-  struct Pos {
-    int64_t off;
-    int n, yy, x;
-  };
-  const BnDiv dv = bn_div_make(c8, N, H, W);
-  auto pos_of = [&](int idx) {
-    int n, yy, x;
-    if constexpr (UPS != 0) {
-      bn_div_pos(dv, idx, c8, H, W, n, yy, x);
-    } else {
-      const int p = idx / c8;
-      const int row = p / W;
-      x = p - row * W, n = row / H, yy = row - n * H;
-    }
-    return Pos{(((int64_t)n * (H + 2) + yy + 1) * (W + 2) + x + 1) * C + cg * 8, n, yy, x};
-  };
-  auto offset_of = [&](int idx) -> int64_t { return pos_of(idx).off; };
-  auto load_z = [&](const Pos& ps) {
-    if constexpr (UPS != 0)
-      return upsample_words<UPS == 0 ? 8 : UPS>(z, ps.n, ps.yy, ps.x, cg, H / (UPS == 0 ? 8 : UPS), W / (UPS == 0 ? 8 : UPS), C);
-    else
-      return *reinterpret_cast<const u32x4*>(z + ps.off);
+  auto offset_of = [&](int idx) -> int64_t {
+    const int p = idx / c8;
+    const int row = p / W;
+    const int x = p - row * W, n = row / H, yy = row - n * H;
+    return (((int64_t)n * (H + 2) + yy + 1) * (W + 2) + x + 1) * C + cg * 8;
   };
   int idx = (int)blockIdx.x * 256 + (int)threadIdx.x;
   if (MODE == 0) {
@@ -148,7 +100,7 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const __bf16* __restrict
     for (; idx + 3 * stride < total32; idx += 4 * stride) {
       u32x4 v[4];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) v[q] = load_z(pos_of(idx + q * stride));
+      for (int q = 0; q < 4; ++q) v[q] = *reinterpret_cast<const u32x4*>(z + offset_of(idx + q * stride));
 #pragma unroll
       for (int q = 0; q < 4; ++q)
 #pragma unroll
@@ -166,9 +118,9 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const __bf16* __restrict
       u32x4 zv[2], gv[2];
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
-        const Pos ps = pos_of(idx + q * stride);
-        zv[q] = load_z(ps);
-        gv[q] = *reinterpret_cast<const u32x4*>(dy + ps.off);
+        const int64_t off = offset_of(idx + q * stride);
+        zv[q] = *reinterpret_cast<const u32x4*>(z + off);
+        gv[q] = *reinterpret_cast<const u32x4*>(dy + off);
       }
 #pragma unroll
       for (int q = 0; q < 2; ++q)
@@ -184,9 +136,8 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const __bf16* __restrict
         }
     }
     for (; idx < total32; idx += stride) {
-      const Pos ps = pos_of(idx);
-      const int64_t off = ps.off;
-      const u32x4 zv = load_z(ps), gv = *reinterpret_cast<const u32x4*>(dy + off);
+      const int64_t off = offset_of(idx);
+      const u32x4 zv = *reinterpret_cast<const u32x4*>(z + off), gv = *reinterpret_cast<const u32x4*>(dy + off);
 #pragma unroll
       for (int w = 0; w < 4; ++w) {
         const float za = bf_lo(zv[w]), zb = bf_hi(zv[w]);
@@ -225,9 +176,8 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const __bf16* __restrict
     }
   }
   for (; idx < total32; idx += stride) {
-    const Pos ps = pos_of(idx);
-    const int64_t off = ps.off;
-    const u32x4 zv = load_z(ps);
+    const int64_t off = offset_of(idx);
+    const u32x4 zv = *reinterpret_cast<const u32x4*>(z + off);
     if (MODE == 0) {
 #pragma unroll
       for (int w = 0; w < 4; ++w) {
@@ -443,7 +393,6 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const __bf16* __restr
 // constants are loaded -- and the two double divisions per channel of the backward pass done -- once per thread instead of
 // once per element (the generic kernels above ran at 1.9 TB/s on them); 32-bit index arithmetic; several pixels' loads in
 // flight per thread.  Same expressions, same bits.
-template <int UPS = 0>  // UPS = 8: z is the low-resolution map, its x8 up-sampling recomputed per element (see bn_reduce_kernel)
 __global__ __launch_bounds__(256) void bn_apply_fast_kernel(const __bf16* __restrict__ z, const float* __restrict__ scale,
                                                            const float* __restrict__ shift, int relu,
                                                            __bf16* __restrict__ y, int N, int H, int W, int C) {
@@ -453,27 +402,11 @@ __global__ __launch_bounds__(256) void bn_apply_fast_kernel(const __bf16* __rest
 #pragma unroll
   for (int e = 0; e < 8; ++e) sc[e] = scale[cg * 8 + e], sh[e] = shift[cg * 8 + e];
   const int total = N * H * W * c8, stride = (int)gridDim.x * 256;  // < 2^31 (checked by the launcher)
-  struct Pos {
-    int64_t off;
-    int n, yy, x;
-  };
-  const BnDiv dv = bn_div_make(c8, N, H, W);
-  auto pos_of = [&](int idx) {
-    int n, yy, x;
-    if constexpr (UPS != 0) {
-      bn_div_pos(dv, idx, c8, H, W, n, yy, x);
-    } else {
-      const int p = idx / c8;
-      const int row = p / W;
-      x = p - row * W, n = row / H, yy = row - n * H;
-    }
-    return Pos{(((int64_t)n * (H + 2) + yy + 1) * (W + 2) + x + 1) * C + cg * 8, n, yy, x};
-  };
-  auto load_z = [&](const Pos& ps) {
-    if constexpr (UPS != 0)
-      return upsample_words<UPS == 0 ? 8 : UPS>(z, ps.n, ps.yy, ps.x, cg, H / (UPS == 0 ? 8 : UPS), W / (UPS == 0 ? 8 : UPS), C);
-    else
-      return *reinterpret_cast<const u32x4*>(z + ps.off);
+  auto offset_of = [&](int idx) -> int64_t {
+    const int p = idx / c8;
+    const int row = p / W;
+    const int x = p - row * W, n = row / H, yy = row - n * H;
+    return (((int64_t)n * (H + 2) + yy + 1) * (W + 2) + x + 1) * C + cg * 8;
   };
   auto apply = [&](const u32x4 zv) {
     u32x4 o;
@@ -495,22 +428,21 @@ __global__ __launch_bounds__(256) void bn_apply_fast_kernel(const __bf16* __rest
     u32x4 v[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const Pos ps = pos_of(idx + q * stride);
-      off[q] = ps.off;
-      v[q] = load_z(ps);
+      off[q] = offset_of(idx + q * stride);
+      v[q] = *reinterpret_cast<const u32x4*>(z + off[q]);
     }
 #pragma unroll
     for (int q = 0; q < 4; ++q) *reinterpret_cast<u32x4*>(y + off[q]) = apply(v[q]);
   }
   for (; idx < total; idx += stride) {
-    const Pos ps = pos_of(idx);
-    *reinterpret_cast<u32x4*>(y + ps.off) = apply(load_z(ps));
+    const int64_t off = offset_of(idx);
+    *reinterpret_cast<u32x4*>(y + off) = apply(*reinterpret_cast<const u32x4*>(z + off));
   }
 }
 
 // MASKZ: the relu mask recomputed from z (fmaf(z, zsc, zsh) > 0: the SAME explicit fused multiply-add in the forward apply kernels and in every
 // kernel that recomputes the mask, so the sign test is identical by construction, not by the compiler's contraction choices) instead of read from y
-template <bool MASKZ, int UPS = 0>  // UPS = 8: z is the low-resolution map (see bn_reduce_kernel)
+template <bool MASKZ>
 __global__ __launch_bounds__(256) void bn_bwd_apply_fast_kernel(const __bf16* __restrict__ dy, const __bf16* __restrict__ y,
                                                                const __bf16* __restrict__ z, const float* __restrict__ mean,
                                                                const float* __restrict__ invstd,
@@ -529,27 +461,11 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_fast_kernel(const __bf16* __
     sc[e] = MASKZ ? zsc[c] : 0.f, sh[e] = MASKZ ? zsh[c] : 0.f;
   }
   const int total = N * H * W * c8, stride = (int)gridDim.x * 256;
-  struct Pos {
-    int64_t off;
-    int n, yy, x;
-  };
-  const BnDiv dv = bn_div_make(c8, N, H, W);
-  auto pos_of = [&](int idx) {
-    int n, yy, x;
-    if constexpr (UPS != 0) {
-      bn_div_pos(dv, idx, c8, H, W, n, yy, x);
-    } else {
-      const int p = idx / c8;
-      const int row = p / W;
-      x = p - row * W, n = row / H, yy = row - n * H;
-    }
-    return Pos{(((int64_t)n * (H + 2) + yy + 1) * (W + 2) + x + 1) * C + cg * 8, n, yy, x};
-  };
-  auto load_z = [&](const Pos& ps) {
-    if constexpr (UPS != 0)
-      return upsample_words<UPS == 0 ? 8 : UPS>(z, ps.n, ps.yy, ps.x, cg, H / (UPS == 0 ? 8 : UPS), W / (UPS == 0 ? 8 : UPS), C);
-    else
-      return *reinterpret_cast<const u32x4*>(z + ps.off);
+  auto offset_of = [&](int idx) -> int64_t {
+    const int p = idx / c8;
+    const int row = p / W;
+    const int x = p - row * W, n = row / H, yy = row - n * H;
+    return (((int64_t)n * (H + 2) + yy + 1) * (W + 2) + x + 1) * C + cg * 8;
   };
   const u32x4 ones = u32x4{0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
   auto apply = [&](const u32x4 zv, const u32x4 gv, const u32x4 yv) {
@@ -576,9 +492,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_fast_kernel(const __bf16* __
     u32x4 zv[2], gv[2], yv[2];
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
-      const Pos ps = pos_of(idx + q * stride);
-      off[q] = ps.off;
-      zv[q] = load_z(ps);
+      off[q] = offset_of(idx + q * stride);
+      zv[q] = *reinterpret_cast<const u32x4*>(z + off[q]);
       gv[q] = *reinterpret_cast<const u32x4*>(dy + off[q]);
       yv[q] = (y && !MASKZ) ? *reinterpret_cast<const u32x4*>(y + off[q]) : ones;
     }
@@ -586,10 +501,177 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_fast_kernel(const __bf16* __
     for (int q = 0; q < 2; ++q) *reinterpret_cast<u32x4*>(dz + off[q]) = apply(zv[q], gv[q], yv[q]);
   }
   for (; idx < total; idx += stride) {
-    const Pos ps = pos_of(idx);
-    const int64_t off = ps.off;
-    *reinterpret_cast<u32x4*>(dz + off) = apply(load_z(ps), *reinterpret_cast<const u32x4*>(dy + off),
+    const int64_t off = offset_of(idx);
+    *reinterpret_cast<u32x4*>(dz + off) = apply(*reinterpret_cast<const u32x4*>(z + off), *reinterpret_cast<const u32x4*>(dy + off),
                                                 (y && !MASKZ) ? *reinterpret_cast<const u32x4*>(y + off) : ones);
+  }
+}
+
+// The two APPLY passes of the batch norm behind the x8 deconv, eight output pixels per thread: the pixels 8 k - 4 .. 8 k + 3 of
+// an output row share their four source vectors (one phase group of the deconv), so a thread loads and unpacks them once and
+// produces eight 16-byte results with compile-time column weights -- a per-element form (upsample_words per result inside the
+// grid-stride kernels above) spent ~150 instructions per result on its loads, address arithmetic and weights and was ALU-bound:
+// no faster than reading the stored map.  Same expressions per value (upsample_words' fmaf chain, the apply lambdas of the kernels above): same bits.
+// Grid: x over (phase group k = 0 .. W/8, channel group), y strides over the N H output rows (a thread keeps its channels'
+// constants for all its rows).
+template <bool BWD>
+__global__ __launch_bounds__(256) void bn_ups8_apply8_kernel(const __bf16* __restrict__ low, const __bf16* __restrict__ dy,
+                                                            const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                            const float* __restrict__ gamma, const double* __restrict__ sums,
+                                                            double M, const float* __restrict__ zsc, const float* __restrict__ zsh,
+                                                            int relu, __bf16* __restrict__ out, int N, int H, int W, int C) {
+  const int c8 = C >> 3, Hi = H >> 3, Wi = W >> 3;
+  const int idx = (int)blockIdx.x * 256 + (int)threadIdx.x;
+  if (idx >= (Wi + 1) * c8) return;
+  const int k = idx / c8, cg = idx - k * c8;
+  float mu[8], is[8], gk[8], db[8], dg[8], sc[8], sh[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int c = cg * 8 + e;
+    sc[e] = zsc[c], sh[e] = zsh[c];
+    mu[e] = BWD ? mean[c] : 0.f, is[e] = BWD ? invstd[c] : 0.f, gk[e] = BWD ? gamma[c] : 0.f;
+    db[e] = BWD ? (float)(sums[c] / M) : 0.f, dg[e] = BWD ? (float)(sums[C + c] / M) : 0.f;
+  }
+  const int64_t rowp = (int64_t)(Wi + 2) * C;
+  for (int row = blockIdx.y; row < N * H; row += gridDim.y) {
+    const int n = row / H, yy = row - n * H;
+    const int iy1 = (yy + 4) >> 3, py = (yy + 4) & 7;
+    const float wy1 = (float)(2 * py + 1) * 0.0625f, wy0 = (float)(15 - 2 * py) * 0.0625f;
+    const __bf16* p00 = low + (((int64_t)n * (Hi + 2) + iy1) * (Wi + 2) + k) * C + cg * 8;
+    const u32x4 a00 = *reinterpret_cast<const u32x4*>(p00), a01 = *reinterpret_cast<const u32x4*>(p00 + C);
+    const u32x4 a10 = *reinterpret_cast<const u32x4*>(p00 + rowp), a11 = *reinterpret_cast<const u32x4*>(p00 + rowp + C);
+    const int64_t orow = ((int64_t)n * (H + 2) + yy + 1) * (W + 2) + 1;
+    u32x4 gv[8];
+    if constexpr (BWD) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int ox = 8 * k - 4 + j;
+        if (ox >= 0 && ox < W) gv[j] = *reinterpret_cast<const u32x4*>(dy + (orow + ox) * C + cg * 8);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int ox = 8 * k - 4 + j;
+      if (ox < 0 || ox >= W) continue;
+      const float wx1 = (float)(2 * j + 1) * 0.0625f, wx0 = (float)(15 - 2 * j) * 0.0625f;  // ((ox + 4) & 7 == j)
+      const float w00 = wy0 * wx0, w01 = wy0 * wx1, w10 = wy1 * wx0, w11 = wy1 * wx1;
+      u32x4 zv;
+#pragma unroll
+      for (int w = 0; w < 4; ++w)
+        zv[w] = pack_bf16x2(fmaf(bf_lo(a11[w]), w11, fmaf(bf_lo(a10[w]), w10, fmaf(bf_lo(a01[w]), w01, bf_lo(a00[w]) * w00))),
+                            fmaf(bf_hi(a11[w]), w11, fmaf(bf_hi(a10[w]), w10, fmaf(bf_hi(a01[w]), w01, bf_hi(a00[w]) * w00))));
+      u32x4 o;
+      if constexpr (!BWD) {
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+          float a = fmaf(bf_lo(zv[w]), sc[2 * w], sh[2 * w]);
+          float b = fmaf(bf_hi(zv[w]), sc[2 * w + 1], sh[2 * w + 1]);
+          if (relu) {
+            a = a > 0.f ? a : 0.f;
+            b = b > 0.f ? b : 0.f;
+          }
+          o[w] = pack_bf16x2(a, b);
+        }
+      } else {
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+          float v[2];
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const int e = 2 * w + h;
+            const float zz = h ? bf_hi(zv[w]) : bf_lo(zv[w]);
+            const float yy_ = fmaf(zz, sc[e], sh[e]);
+            const float g = yy_ > 0.f ? (h ? bf_hi(gv[j][w]) : bf_lo(gv[j][w])) : 0.f;
+            const float zh = (zz - mu[e]) * is[e];
+            v[h] = gk[e] * is[e] * (g - db[e] - zh * dg[e]);
+          }
+          o[w] = pack_bf16x2(v[0], v[1]);
+        }
+      }
+      *reinterpret_cast<u32x4*>(out + (orow + ox) * C + cg * 8) = o;
+    }
+  }
+}
+
+// ... and the two REDUCE passes in the same thread layout (BWD = false: sum z, sum z^2; true: sum g, sum g zhat with the relu
+// mask from z -- bn_reduce_kernel's MODE 0 / 2).  fp32 per thread over its rows, the workgroup through LDS, one row of `part`
+// per workgroup (blockIdx.y * gridDim.x + blockIdx.x) for bn_sums_kernel / bn_sums_finalize_kernel: a fixed order, bitwise
+// reproducible -- but a DIFFERENT order of the same terms than bn_reduce_kernel's, so the sums agree with the stored-map
+// path to fp32 rounding, not bit for bit.
+template <bool BWD>
+__global__ __launch_bounds__(256) void bn_ups8_reduce8_kernel(const __bf16* __restrict__ low, const __bf16* __restrict__ dy,
+                                                             const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                             const float* __restrict__ zsc, const float* __restrict__ zsh,
+                                                             float* __restrict__ part, int N, int H, int W, int C) {
+  const int c8 = C >> 3, Hi = H >> 3, Wi = W >> 3;
+  const int idx = (int)blockIdx.x * 256 + (int)threadIdx.x;
+  const bool live = idx < (Wi + 1) * c8;
+  const int k = live ? idx / c8 : 0, cg = threadIdx.x % c8;  // (256 and blockIdx.x * 256 are multiples of c8)
+  float s0[8], s1[8], mu[8], is[8], sc[8], sh[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int c = cg * 8 + e;
+    s0[e] = s1[e] = 0.f;
+    mu[e] = BWD ? mean[c] : 0.f, is[e] = BWD ? invstd[c] : 0.f, sc[e] = BWD ? zsc[c] : 0.f, sh[e] = BWD ? zsh[c] : 0.f;
+  }
+  const int64_t rowp = (int64_t)(Wi + 2) * C;
+  for (int row = blockIdx.y; live && row < N * H; row += gridDim.y) {
+    const int n = row / H, yy = row - n * H;
+    const int iy1 = (yy + 4) >> 3, py = (yy + 4) & 7;
+    const float wy1 = (float)(2 * py + 1) * 0.0625f, wy0 = (float)(15 - 2 * py) * 0.0625f;
+    const __bf16* p00 = low + (((int64_t)n * (Hi + 2) + iy1) * (Wi + 2) + k) * C + cg * 8;
+    const u32x4 a00 = *reinterpret_cast<const u32x4*>(p00), a01 = *reinterpret_cast<const u32x4*>(p00 + C);
+    const u32x4 a10 = *reinterpret_cast<const u32x4*>(p00 + rowp), a11 = *reinterpret_cast<const u32x4*>(p00 + rowp + C);
+    const int64_t orow = ((int64_t)n * (H + 2) + yy + 1) * (W + 2) + 1;
+    u32x4 gv[8];
+    if constexpr (BWD) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int ox = 8 * k - 4 + j;
+        if (ox >= 0 && ox < W) gv[j] = *reinterpret_cast<const u32x4*>(dy + (orow + ox) * C + cg * 8);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int ox = 8 * k - 4 + j;
+      if (ox < 0 || ox >= W) continue;
+      const float wx1 = (float)(2 * j + 1) * 0.0625f, wx0 = (float)(15 - 2 * j) * 0.0625f;
+      const float w00 = wy0 * wx0, w01 = wy0 * wx1, w10 = wy1 * wx0, w11 = wy1 * wx1;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        const uint32_t zw = pack_bf16x2(fmaf(bf_lo(a11[w]), w11, fmaf(bf_lo(a10[w]), w10, fmaf(bf_lo(a01[w]), w01, bf_lo(a00[w]) * w00))),
+                                        fmaf(bf_hi(a11[w]), w11, fmaf(bf_hi(a10[w]), w10, fmaf(bf_hi(a01[w]), w01, bf_hi(a00[w]) * w00))));
+        const float za = bf_lo(zw), zb = bf_hi(zw);
+        if constexpr (!BWD) {
+          s0[2 * w] += za;
+          s1[2 * w] += za * za;
+          s0[2 * w + 1] += zb;
+          s1[2 * w + 1] += zb * zb;
+        } else {
+          const float ga = fmaf(za, sc[2 * w], sh[2 * w]) > 0.f ? bf_lo(gv[j][w]) : 0.f;
+          const float gb = fmaf(zb, sc[2 * w + 1], sh[2 * w + 1]) > 0.f ? bf_hi(gv[j][w]) : 0.f;
+          s0[2 * w] += ga;
+          s1[2 * w] += ga * (za - mu[2 * w]) * is[2 * w];
+          s0[2 * w + 1] += gb;
+          s1[2 * w + 1] += gb * (zb - mu[2 * w + 1]) * is[2 * w + 1];
+        }
+      }
+    }
+  }
+  __shared__ float red[256][17];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    red[threadIdx.x][e] = s0[e];
+    red[threadIdx.x][8 + e] = s1[e];
+  }
+  __syncthreads();
+  const int64_t prow = (int64_t)blockIdx.y * gridDim.x + blockIdx.x;
+  for (int t = threadIdx.x; t < c8 * 16; t += 256) {
+    const int g = t >> 4, col = t & 15;
+    float acc = 0.f;
+    for (int r = g; r < 256; r += c8) acc += red[r][col];
+    const int ch = g * 8 + (col & 7);
+    part[prow * 2 * C + (col < 8 ? ch : C + ch)] = acc;
   }
 }
 
@@ -1509,7 +1591,7 @@ extern "C" int xv_bn_apply(const xv_act* z, const float* scale, const float* shi
   XV_CHECK_SHAPE(same_shape(z, y) && (z->c & 7) == 0);
   const int64_t total = (int64_t)z->n * z->h * z->w * (z->c >> 3);
   if (z->c >= 64 && 2048 % z->c == 0 && total < 0x7fff0000)  // C / 8 divides the block size: a thread keeps its channels
-    hipLaunchKernelGGL(bn_apply_fast_kernel<0>, dim3(bn_grid(total, 2048)), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(bn_apply_fast_kernel, dim3(bn_grid(total, 2048)), dim3(256), 0, (hipStream_t)stream,
                        (const __bf16*)z->data, scale, shift, relu, (__bf16*)y->data, z->n, z->h, z->w, z->c);
   else
     hipLaunchKernelGGL(bn_apply_kernel, dim3(bn_grid(total, 8192)), dim3(256), 0, (hipStream_t)stream,
@@ -1626,6 +1708,14 @@ extern "C" int xv_bn_bwd_apply_zmask(const xv_act* dy, const xv_act* z, const fl
 // cache-resident) in the four passes that would read it back: statistics + finalize, apply, gradient sums, gradient.  The
 // training step of `batch_normalization: true` then never writes or reads the 0.6 GB pre-activation of `upscore`
 // (custom_layers.py:112-119 behind simple_fcn.py:117-119): five of its thirteen passes over maps of that size.
+// grid of bn_ups8_reduce8_kernel: x over the row's (phase group, channel group) pairs, y over rows; x * y <= BN_MAX_GRID
+static dim3 ups8_reduce_grid(int n, int h, int w, int c) {
+  const unsigned gx = (unsigned)(((w / 8 + 1) * (c >> 3) + 255) / 256);
+  unsigned gy = (unsigned)BN_MAX_GRID / (gx < 1 ? 1 : gx);
+  if (gy < 1) gy = 1;
+  if ((int64_t)gy > (int64_t)n * h) gy = (unsigned)(n * h);
+  return dim3(gx, gy);
+}
 static bool ups_ok(const xv_act* low, int n, int h, int w, int c) {
   return low && low->data && low->dtype == XV_BF16 && low->n == n && 8 * low->h == h && 8 * low->w == w && low->c == c &&
          c >= 64 && 2048 % c == 0 && (int64_t)n * h * w * (c >> 3) < 0x7fff0000;
@@ -1640,9 +1730,12 @@ extern "C" int xv_bn_stats_finalize_ups8_ws(const xv_act* low, double* sums, voi
   XV_CHECK_SHAPE(ups_ok(low, n, h, w, c));
   if (workspace_bytes < (size_t)BN_MAX_GRID * 2 * c * sizeof(float) || ((uintptr_t)workspace & 15)) return XV_EWORKSPACE;
   hipStream_t s = (hipStream_t)stream;
-  const int grid = bn_grid((int64_t)n * h * w * (c >> 3), BN_MAX_GRID);
-  hipLaunchKernelGGL((bn_reduce_kernel<0, 8>), dim3(grid), dim3(256), 0, s, (const __bf16*)low->data, nullptr, nullptr, nullptr,
-                     nullptr, sums, n, h, w, c, (const float*)nullptr, (const float*)nullptr, (float*)workspace);
+  const dim3 g2 = ups8_reduce_grid(n, h, w, c);
+  const int grid = (int)(g2.x * g2.y);
+  XV_CHECK_SHAPE(grid <= BN_MAX_GRID);
+  hipLaunchKernelGGL(bn_ups8_reduce8_kernel<false>, g2, dim3(256), 0, s, (const __bf16*)low->data, (const __bf16*)nullptr,
+                     (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (float*)workspace, n,
+                     h, w, c);
   hipLaunchKernelGGL(bn_sums_finalize_kernel, dim3(c), dim3(256), 0, s, (const float*)workspace, grid, c, sums,
                      (double)((int64_t)n * h * w), gamma, beta, eps, momentum, moving_mean, moving_var, mean, invstd, scale, shift);
   return xv_launch_status();
@@ -1651,9 +1744,11 @@ extern "C" int xv_bn_apply_ups8(const xv_act* low, const float* scale, const flo
   XV_REQUIRE_BF16(y);
   XV_CHECK_ARG(low && y && y->data && scale && shift);
   XV_CHECK_SHAPE(ups_ok(low, y->n, y->h, y->w, y->c));
-  const int64_t total = (int64_t)y->n * y->h * y->w * (y->c >> 3);
-  hipLaunchKernelGGL(bn_apply_fast_kernel<8>, dim3(bn_grid(total, 2048)), dim3(256), 0, (hipStream_t)stream,
-                     (const __bf16*)low->data, scale, shift, relu, (__bf16*)y->data, y->n, y->h, y->w, y->c);
+  const int rows = y->n * y->h;
+  const dim3 grid((unsigned)(((y->w / 8 + 1) * (y->c >> 3) + 255) / 256), (unsigned)(rows < 512 ? rows : 512));
+  hipLaunchKernelGGL(bn_ups8_apply8_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, (const __bf16*)low->data,
+                     (const __bf16*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr,
+                     (const double*)nullptr, 1.0, scale, shift, relu, (__bf16*)y->data, y->n, y->h, y->w, y->c);
   return xv_launch_status();
 }
 extern "C" int xv_bn_bwd_reduce_zmask_ups8(const xv_act* dy, const xv_act* low, const float* mean, const float* invstd,
@@ -1663,11 +1758,13 @@ extern "C" int xv_bn_bwd_reduce_zmask_ups8(const xv_act* dy, const xv_act* low, 
   XV_CHECK_ARG(dy && low && dy->data && mean && invstd && scale && shift && sums && dgamma && dbeta);
   XV_CHECK_SHAPE(ups_ok(low, dy->n, dy->h, dy->w, dy->c));
   hipStream_t s = (hipStream_t)stream;
-  const int64_t total = (int64_t)dy->n * dy->h * dy->w * (dy->c >> 3);
-  const int grid = bn_grid(total, BN_MAX_GRID);
+  if (workspace == nullptr) return XV_EWORKSPACE;  // (the eight-pixel form has no atomic variant)
+  const dim3 g2 = ups8_reduce_grid(dy->n, dy->h, dy->w, dy->c);
+  const int grid = (int)(g2.x * g2.y);
+  XV_CHECK_SHAPE(grid <= BN_MAX_GRID);
   const int rc = bn_sums_launch(sums, 2 * dy->c, grid, workspace, workspace_bytes, s, [&](float* part) {
-    hipLaunchKernelGGL((bn_reduce_kernel<2, 8>), dim3(grid), dim3(256), 0, s, (const __bf16*)low->data, (const __bf16*)dy->data,
-                       (const __bf16*)nullptr, mean, invstd, sums, dy->n, dy->h, dy->w, dy->c, scale, shift, part);
+    hipLaunchKernelGGL(bn_ups8_reduce8_kernel<true>, g2, dim3(256), 0, s, (const __bf16*)low->data, (const __bf16*)dy->data, mean,
+                       invstd, scale, shift, part, dy->n, dy->h, dy->w, dy->c);
   }, dgamma, dbeta);
   if (rc != XV_OK) return rc;
   return xv_launch_status();
@@ -1678,10 +1775,11 @@ extern "C" int xv_bn_bwd_apply_zmask_ups8(const xv_act* dy, const xv_act* low, c
   XV_REQUIRE_BF16(dy, dz);
   XV_CHECK_ARG(dy && low && dz && dy->data && dz->data && mean && invstd && scale && shift && gamma && sums);
   XV_CHECK_SHAPE(same_shape(dy, dz) && ups_ok(low, dy->n, dy->h, dy->w, dy->c) && count > 0);
-  const int64_t total = (int64_t)dy->n * dy->h * dy->w * (dy->c >> 3);
-  hipLaunchKernelGGL((bn_bwd_apply_fast_kernel<true, 8>), dim3(bn_grid(total, 2048)), dim3(256), 0, (hipStream_t)stream,
-                     (const __bf16*)dy->data, (const __bf16*)nullptr, (const __bf16*)low->data, mean, invstd, gamma, sums,
-                     (double)count, (__bf16*)dz->data, dy->n, dy->h, dy->w, dy->c, scale, shift);
+  const int rows = dy->n * dy->h;
+  const dim3 grid((unsigned)(((dy->w / 8 + 1) * (dy->c >> 3) + 255) / 256), (unsigned)(rows < 512 ? rows : 512));
+  hipLaunchKernelGGL(bn_ups8_apply8_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, (const __bf16*)low->data,
+                     (const __bf16*)dy->data, mean, invstd, gamma, sums, (double)count, scale, shift, 1, (__bf16*)dz->data, dy->n,
+                     dy->h, dy->w, dy->c);
   return xv_launch_status();
 }
 
