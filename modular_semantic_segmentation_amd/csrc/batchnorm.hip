@@ -1352,6 +1352,7 @@ template <int UB, int KC>  // U / 16 channel blocks, ceil(C / 4) class steps
 __global__ __launch_bounds__(256) void score_dense_dgrad_mfma_kernel(const float* __restrict__ ds, const float* __restrict__ ws,
                                                                     __bf16* __restrict__ du, int N, int H, int W, int C) {
   constexpr int U = 16 * UB;
+  __shared__ __attribute__((aligned(16))) uint32_t stage[4][512];  // 2 KB per wave: the store stage below
   const int lane = threadIdx.x & 63, l15 = lane & 15, lg = lane >> 4;
   float wa[UB][KC];
 #pragma unroll
@@ -1373,14 +1374,42 @@ __global__ __launch_bounds__(256) void score_dense_dgrad_mfma_kernel(const float
     }
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
-      __bf16* dst = du + sd_padded_offset(pp[q] >= 0 ? pp[q] : 0, H, W, U) + 4 * lg;
+      // A lane holds 4 channels (8 bytes) of pixel l15 per channel block: stored directly, an instruction scattered 64 8-byte
+      // pieces over 16 lines, and a pixel's 128-byte line was completed by four different instructions (279 us for a 0.6 GB
+      // map).  Through 2 KB of LDS per wave instead: [pixel][128 B], read back as 16-byte pieces with four consecutive lanes on
+      // one 64-byte run -- two store instructions of 16 x 64 bytes per group of 16 pixels.
+      if constexpr (UB == 4) {
+        char* const st = reinterpret_cast<char*>(stage[threadIdx.x >> 6]);
 #pragma unroll
-      for (int b = 0; b < UB; ++b) {
-        sd_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int b = 0; b < UB; ++b) {
+          sd_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int s = 0; s < KC; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[b][s], dv[q][s], acc, 0, 0, 0);
-        if (pp[q] >= 0)
-          *reinterpret_cast<u32x2*>(dst + 16 * b) = u32x2{pack_bf16x2(acc[0], acc[1]), pack_bf16x2(acc[2], acc[3])};
+          for (int s = 0; s < KC; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[b][s], dv[q][s], acc, 0, 0, 0);
+          *reinterpret_cast<u32x2*>(st + l15 * 128 + b * 32 + lg * 8) = u32x2{pack_bf16x2(acc[0], acc[1]), pack_bf16x2(acc[2], acc[3])};
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const int pq = (g0 + q * nw) * 16 + (lane >> 2);  // the pixel this lane stores
+        const bool on = g0 + q * nw < ngroups && pq < npix;
+        char* const dst = reinterpret_cast<char*>(du + sd_padded_offset(on ? pq : 0, H, W, U)) + (lane & 3) * 16;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+          const u32x4 r = *reinterpret_cast<const u32x4*>(st + (lane >> 2) * 128 + half * 64 + (lane & 3) * 16);
+          if (on) *reinterpret_cast<u32x4*>(dst + half * 64) = r;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+      } else {
+        __bf16* dst = du + sd_padded_offset(pp[q] >= 0 ? pp[q] : 0, H, W, U) + 4 * lg;
+#pragma unroll
+        for (int b = 0; b < UB; ++b) {
+          sd_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int s = 0; s < KC; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[b][s], dv[q][s], acc, 0, 0, 0);
+          if (pp[q] >= 0)
+            *reinterpret_cast<u32x2*>(dst + 16 * b) = u32x2{pack_bf16x2(acc[0], acc[1]), pack_bf16x2(acc[2], acc[3])};
+        }
       }
     }
   }
