@@ -565,6 +565,11 @@ int xv_bn_dense_bwd_apply(const float* dy, const float* z, int64_t rows, int cha
  * labelled pixels with the loss normalised by *valid_count (models/utils.py:43-53); gradients of the score conv.   */
 int xv_upsample_raw_fwd(const xv_act* x, int factor, const xv_act* y, void* stream);
 int xv_upsample_raw_bwd(const xv_act* dy, int factor, const xv_act* dx, void* stream);
+/* The x8 gradient through per-block sums in a workspace (xv_upsample_raw_bwd_workspace_bytes(n, h, w, c) for the LOW-resolution
+ * map [n][h][w][c]): every element of dy is read once instead of from four source pixels' 16x16 footprints.  Same sums in
+ * another (fixed) order.  factor 2 or workspace == NULL: xv_upsample_raw_bwd.                                              */
+size_t xv_upsample_raw_bwd_workspace_bytes(int n, int h, int w, int c);
+int xv_upsample_raw_bwd_ws(const xv_act* dy, int factor, const xv_act* dx, void* workspace, size_t workspace_bytes, void* stream);
 int xv_score_dense_fwd(const xv_act* u, const float* w_score, const float* b_score, int num_classes, float* score,
                        void* stream);
 int xv_softmax_ce_dense(const float* logits, const int32_t* labels, const int64_t* valid_count, int num_classes,

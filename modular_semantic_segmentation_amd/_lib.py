@@ -140,6 +140,8 @@ SIGNATURES = {
     'xv_bn_dense_bwd': (_i, [_vp, _vp, _i64, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     'xv_upsample_raw_fwd': (_i, [_actp, _i, _actp, _vp]),
     'xv_upsample_raw_bwd': (_i, [_actp, _i, _actp, _vp]),
+    'xv_upsample_raw_bwd_workspace_bytes': (ctypes.c_size_t, [_i, _i, _i, _i]),
+    'xv_upsample_raw_bwd_ws': (_i, [_actp, _i, _actp, _vp, ctypes.c_size_t, _vp]),
     'xv_score_dense_fwd': (_i, [_actp, _vp, _vp, _i, _vp, _vp]),
     'xv_softmax_ce_dense': (_i, [_vp, _vp, _vp, _i, _i64, _vp, _vp, _vp]),
     'xv_softmax_ce_dense_affine': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i64, _vp, _vp, _vp]),

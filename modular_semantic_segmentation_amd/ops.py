@@ -970,8 +970,23 @@ def upsample_raw_fwd(x, factor, y=None):
     return y
 
 
+_UPS_WS = {}
+UPS8_BLOCK_SUMS = os.environ.get('XV_UPS8_BLOCK_SUMS', '1') != '0'      # 0: the gather form of the x8 gradient (A/B timing)
+
+
 def upsample_raw_bwd(dy, factor, dx):
-    _lib.check(_lib.lib().xv_upsample_raw_bwd(dy.xv(), factor, dx.xv(), _stream()), 'xv_upsample_raw_bwd')
+    """Gradient of the raw bilinear up-sampling.  factor 8: through per-block sums in a workspace (one per device and map size,
+    owned by the stream the trainers run on), every element of dy read once."""
+    lib = _lib.lib()
+    if factor == 8 and UPS8_BLOCK_SUMS:
+        key = (dx.t.device, dx.n, dx.h, dx.w, dx.c)
+        ws = _UPS_WS.get(key)
+        if ws is None:
+            ws = _UPS_WS[key] = torch.empty(max(16, lib.xv_upsample_raw_bwd_workspace_bytes(dx.n, dx.h, dx.w, dx.c)) // 4,
+                                            dtype=torch.float32, device=dx.t.device)
+        _lib.check(lib.xv_upsample_raw_bwd_ws(dy.xv(), factor, dx.xv(), _ptr(ws), ws.numel() * 4, _stream()), 'xv_upsample_raw_bwd_ws')
+        return dx
+    _lib.check(lib.xv_upsample_raw_bwd(dy.xv(), factor, dx.xv(), _stream()), 'xv_upsample_raw_bwd')
     return dx
 
 

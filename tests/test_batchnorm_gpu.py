@@ -121,6 +121,19 @@ def test_upsample_raw_and_its_transpose(ops, factor):
     dref = xt.grad.permute(0, 2, 3, 1).numpy()
     got = dx.interior().float().cpu().numpy()
     assert np.abs(got - dref).max() < 2 ** -7 * np.abs(dref).max() + 1e-4
+    if factor == 8:
+        # the two forms of the x8 gradient (per-block sums in a workspace: the default; the 256-tap gather): the same sums in
+        # two orders -- equal to the rounding of the bf16 result
+        import modular_semantic_segmentation_amd.ops as o
+        saved = o.UPS8_BLOCK_SUMS
+        try:
+            o.UPS8_BLOCK_SUMS = False
+            dx2 = ops.upsample_raw_bwd(ops.Act.from_dense(_dev(dy)), factor, ops.Act(n, h, w, c))
+        finally:
+            o.UPS8_BLOCK_SUMS = saved
+        torch.cuda.synchronize()
+        assert torch.equal(dx.t[:, 0], dx2.t[:, 0]) and torch.equal(dx.t[:, :, 0], dx2.t[:, :, 0])        # zero border untouched
+        assert (dx.t.float() - dx2.t.float()).abs().max().item() <= 2 ** -7 * np.abs(dref).max()
 
 
 @pytest.mark.parametrize('C,shape', [(12, (2, 8, 12)), (5, (2, 8, 12)), (12, (2, 16, 64)), (16, (1, 8, 32)), (5, (3, 24, 96))])
