@@ -125,7 +125,8 @@ def child():
         h.xv_score_dense_bwd_workspace_bytes(n, hh, ww)
         h.xv_conv2d_split_workspace_bytes(n, hh, ww, cin, cout)
         h.xv_softmax_ce_dense_workspace_bytes(n * hh * ww)
-        checks += 12
+        h.xv_upsample_raw_bwd_workspace_bytes(n, hh, ww, cout)
+        checks += 13
 
     # (4) launch geometry: the whole host path of the conv entry points up to the launch (which fails: no device here)
     import torch
