@@ -541,6 +541,10 @@ int xv_bn_stats_finalize_ups8_ws(const xv_act* low, double* sums, void* workspac
                                  const float* beta, float eps, float momentum, float* moving_mean, float* moving_var, float* mean,
                                  float* invstd, float* scale, float* shift, void* stream);
 int xv_bn_apply_ups8(const xv_act* low, const float* scale, const float* shift, int relu, const xv_act* y, void* stream);
+/* ... the forward apply pass FUSED with the dense score conv behind it: y (as xv_bn_apply_ups8 with relu) and score = y . W + b
+ * (as xv_score_dense_fwd) in one launch -- 64 units, at most 16 classes; XV_ESHAPE elsewhere.                                  */
+int xv_score_dense_fwd_ups8(const xv_act* low, const float* scale, const float* shift, const float* w_score,
+                            const float* b_score, int num_classes, const xv_act* y, float* score, void* stream);
 int xv_bn_bwd_reduce_zmask_ups8(const xv_act* dy, const xv_act* low, const float* mean, const float* invstd, const float* scale,
                                 const float* shift, double* sums, float* dgamma, float* dbeta, void* workspace,
                                 size_t workspace_bytes, void* stream);

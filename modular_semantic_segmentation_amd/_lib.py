@@ -106,6 +106,7 @@ SIGNATURES = {
     'xv_bn_finalize': (_i, [_vp, _i, _i64, _vp, _vp, ctypes.c_float, ctypes.c_float, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     'xv_bn_apply': (_i, [_actp, _vp, _vp, _i, _actp, _vp]),
     'xv_bn_apply_ups8': (_i, [_actp, _vp, _vp, _i, _actp, _vp]),
+    'xv_score_dense_fwd_ups8': (_i, [_actp, _vp, _vp, _vp, _vp, _i, _actp, _vp, _vp]),
     'xv_bn_bwd': (_i, [_actp, _actp, _actp, _vp, _vp, _vp, _vp, _vp, _vp, _actp, _vp]),
     'xv_bn_bwd_reduce': (_i, [_actp, _actp, _actp, _vp, _vp, _vp, _vp, _vp, _vp]),
     'xv_bn_bwd_apply': (_i, [_actp, _actp, _actp, _vp, _vp, _vp, _vp, _i64, _actp, _vp]),

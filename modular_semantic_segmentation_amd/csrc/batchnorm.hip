@@ -1457,6 +1457,86 @@ __global__ __launch_bounds__(256) void score_dense_mfma_kernel(const __bf16* __r
   }
 }
 
+// The forward apply pass of the batch norm behind the x8 deconv FUSED with the score conv: a lane's B fragment (8 channels of
+// its pixel) is computed -- upsample_words of the low-resolution map, the batch norm's affine, relu, bf16 -- instead of loaded;
+// it is stored to y (the map the backward pass reads: 16 pixels x 64-byte runs per instruction) and multiplied as in
+// score_dense_mfma_kernel.  Replaces bn_ups8_apply8_kernel<false> + score_dense_mfma_kernel: one 0.6 GB store instead of a
+// store and a load.  64 channels (KS = 2).
+__global__ __launch_bounds__(256) void score_dense_ups8_mfma_kernel(const __bf16* __restrict__ low, const float* __restrict__ zsc,
+                                                                   const float* __restrict__ zsh, const float* __restrict__ ws,
+                                                                   const float* __restrict__ bs, __bf16* __restrict__ y,
+                                                                   float* __restrict__ score, int N, int H, int W, int C) {
+  constexpr int KS = 2, U = 64;
+  const int lane = threadIdx.x & 63, l15 = lane & 15, lg = lane >> 4;
+  bf16x8 wh[KS], wm[KS], wl[KS];
+  float sc[KS][8], sh[KS][8];
+#pragma unroll
+  for (int s = 0; s < KS; ++s) {
+    float wv[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      wv[j] = l15 < C ? ws[(32 * s + 8 * lg + j) * C + l15] : 0.f;
+      sc[s][j] = zsc[32 * s + 8 * lg + j], sh[s][j] = zsh[32 * s + 8 * lg + j];
+    }
+    sd_split3(wv, wh[s], wm[s], wl[s]);
+  }
+  sd_f32x4 bias;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) bias[r] = 4 * lg + r < C ? bs[4 * lg + r] : 0.f;
+  const int npix = N * H * W;  // < 2^31 (checked by the launcher)
+  const int ngroups = (npix + 15) >> 4;
+  const int Hi = H >> 3, Wi = W >> 3;
+  const int wid = (int)(blockIdx.x * 4 + (threadIdx.x >> 6)), nw = (int)gridDim.x * 4;
+  for (int g0 = wid; g0 < ngroups; g0 += 2 * nw) {
+    u32x4 xf[2][KS];
+    int pp[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int p = (g0 + q * nw) * 16 + l15;
+      pp[q] = (g0 + q * nw < ngroups && p < npix) ? p : -1;
+      const int pc = pp[q] >= 0 ? p : 0;
+      const int row = pc / W, ox = pc - row * W, n = row / H, oy = row - n * H;
+      __bf16* dst = y + (((int64_t)n * (H + 2) + oy + 1) * (W + 2) + ox + 1) * U + 8 * lg;
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        const u32x4 zv = upsample_words<8>(low, n, oy, ox, 4 * s + lg, Hi, Wi, U);
+        u32x4 o;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+          float a = fmaf(bf_lo(zv[w]), sc[s][2 * w], sh[s][2 * w]);
+          float b = fmaf(bf_hi(zv[w]), sc[s][2 * w + 1], sh[s][2 * w + 1]);
+          a = a > 0.f ? a : 0.f;
+          b = b > 0.f ? b : 0.f;
+          o[w] = pack_bf16x2(a, b);
+        }
+        xf[q][s] = o;
+        if (pp[q] >= 0) *reinterpret_cast<u32x4*>(dst + 32 * s) = o;
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      sd_f32x4 acc = bias;
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        const bf16x8 x = __builtin_bit_cast(bf16x8, xf[q][s]);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[s], x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm[s], x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[s], x, acc, 0, 0, 0);
+      }
+      if (pp[q] >= 0) {
+        float* dst = score + (int64_t)pp[q] * C + 4 * lg;
+        if ((C & 3) == 0) {
+          if (4 * lg < C) *reinterpret_cast<sd_f32x4*>(dst) = acc;
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (4 * lg + r < C) dst[r] = acc[r];
+        }
+      }
+    }
+  }
+}
+
 template <int UB, int KC>  // U / 16 channel blocks, ceil(C / 4) class steps
 __global__ __launch_bounds__(256) void score_dense_dgrad_mfma_kernel(const float* __restrict__ ds, const float* __restrict__ ws,
                                                                     __bf16* __restrict__ du, int N, int H, int W, int C) {
@@ -2116,6 +2196,21 @@ extern "C" int xv_score_dense_fwd(const xv_act* u, const float* w_score, const f
                      (const __bf16*)u->data, w_score, b_score, score, u->n, u->h, u->w, u->c, num_classes)
   XV_CM_SWITCH(num_classes, XV_SD)
 #undef XV_SD
+  return xv_launch_status();
+}
+
+// y = relu(bilinear_x8(low) * scale + shift) (the forward apply pass of the batch norm behind the x8 deconv; what
+// xv_bn_apply_ups8 writes, bit for bit) AND score = y . W + b (xv_score_dense_fwd's matrix-core form, bit for bit) in one
+// launch: 64 units, at most 16 classes; XV_ESHAPE elsewhere (use the two calls).
+extern "C" int xv_score_dense_fwd_ups8(const xv_act* low, const float* scale, const float* shift, const float* w_score,
+                                       const float* b_score, int num_classes, const xv_act* y, float* score, void* stream) {
+  XV_REQUIRE_BF16(low, y);
+  XV_CHECK_ARG(low && low->data && y && y->data && scale && shift && w_score && b_score && score);
+  const int64_t npix = (int64_t)y->n * y->h * y->w;
+  if (y->c != 64 || num_classes < 1 || num_classes > 16 || npix >= 0x7fff0000) return XV_ESHAPE;
+  XV_CHECK_SHAPE(low->n == y->n && 8 * low->h == y->h && 8 * low->w == y->w && low->c == 64);
+  hipLaunchKernelGGL(score_dense_ups8_mfma_kernel, dim3(bn_grid(npix / 4 + 1, 2048)), dim3(256), 0, (hipStream_t)stream,
+                     (const __bf16*)low->data, scale, shift, w_score, b_score, (__bf16*)y->data, score, y->n, y->h, y->w, num_classes);
   return xv_launch_status();
 }
 

@@ -852,6 +852,8 @@ def bn_forward(z, gamma, beta, moving_mean, moving_var, st, y, relu=True, sync=F
             raise ValueError('bn_forward(ups8_of=): single-process statistics with a workspace, no pool')
         _lib.check(lib.xv_bn_stats_finalize_ups8_ws(ups8_of.xv(), _ptr(st.sums), ws[0], ws[1], *fin, _stream()),
                    'xv_bn_stats_finalize_ups8_ws')
+        if y is None:           # statistics only: the apply pass is fused into what follows (score_dense_fwd_ups8)
+            return None
         _lib.check(lib.xv_bn_apply_ups8(ups8_of.xv(), _ptr(st.scale), _ptr(st.shift), int(bool(relu)), y.xv(), _stream()),
                    'xv_bn_apply_ups8')
         return y
@@ -988,6 +990,26 @@ def upsample_raw_bwd(dy, factor, dx):
         return dx
     _lib.check(lib.xv_upsample_raw_bwd(dy.xv(), factor, dx.xv(), _stream()), 'xv_upsample_raw_bwd')
     return dx
+
+
+def bn_apply_ups8(low, st, y, relu=True):
+    """y = [relu](bilinear_x8(low) * scale + shift) with the scale / shift bn_forward(ups8_of=low, y=None) left in `st`."""
+    _lib.check(_lib.lib().xv_bn_apply_ups8(low.xv(), _ptr(st.scale), _ptr(st.shift), int(bool(relu)), y.xv(), _stream()),
+               'xv_bn_apply_ups8')
+    return y
+
+
+def score_dense_fwd_ups8(low, st, w_score, b_score, num_classes, y, score):
+    """y = relu(BN(bilinear_x8(low))) with the batch norm's scale / shift in `st` (bn_forward(ups8_of=low, y=None) before this)
+    AND score = y . W + b in one launch.  Returns False -- nothing launched -- where the fused kernel does not take the shape."""
+    if os.environ.get('XV_FUSED_SCORE_UPS8') == '0':        # A/B timing: the apply pass and the score conv as two launches
+        return False
+    rc = _lib.lib().xv_score_dense_fwd_ups8(low.xv(), _ptr(st.scale), _ptr(st.shift), _ptr(w_score), _ptr(b_score), num_classes,
+                                            y.xv(), _ptr(score), _stream())
+    if rc == -2:
+        return False
+    _lib.check(rc, 'xv_score_dense_fwd_ups8')
+    return True
 
 
 def score_dense_fwd(u, w_score, b_score, num_classes, score):

@@ -552,14 +552,22 @@ class FcnBnTrainer(object):
         # recompute it from `fused` per element (ops.bn_forward / bn_backward, ups8_of=).  Data-parallel runs (statistics
         # all-reduced between the passes) and keep_all (inspection) keep the stored map.
         virtual_up = _VIRTUAL_UPSCORE and not self._sync and not self.keep_all and self.bn['upscore'].ws is not None
+        score_raw = None
         if virtual_up:
             Z['upscore'] = None
-            Y['upscore'] = self._bn_fwd('upscore', None, self._act('y_up', n, h, w, e.Up), ups8_of=fused)
+            y_up = self._act('y_up', n, h, w, e.Up)
+            self._bn_fwd('upscore', None, None, ups8_of=fused)                    # statistics, scale / shift
+            score_raw = self._dense('score_raw', (n, h, w, e.C))
+            if not ops.score_dense_fwd_ups8(fused, self.bn['upscore'], self.w['score'], P('score', 'bias'), e.C, y_up, score_raw):
+                score_raw = None
+                ops.bn_apply_ups8(fused, self.bn['upscore'], y_up)
+            Y['upscore'] = y_up
         else:
             Z['upscore'] = ops.upsample_raw_fwd(fused, 8, self._act('z_up', n, h, w, e.Up))
             Y['upscore'] = self._bn_fwd('upscore', Z['upscore'], self._act('y_up', n, h, w, e.Up))
-        score_raw = ops.score_dense_fwd(Y['upscore'], self.w['score'], P('score', 'bias'), e.C,
-                                        self._dense('score_raw', (n, h, w, e.C)))
+        if score_raw is None:
+            score_raw = ops.score_dense_fwd(Y['upscore'], self.w['score'], P('score', 'bias'), e.C,
+                                            self._dense('score_raw', (n, h, w, e.C)))
         mm, mv = self.moving['score']
         if self.keep_all:
             logits = ops.bn_dense_forward(score_raw, P('score', 'gamma'), P('score', 'beta'), mm, mv, self.bn['score'],
@@ -860,10 +868,21 @@ class FusionFcnTrainer(object):
         virtual_up = _VIRTUAL_UPSCORE and not self._sync and self.bn['upscore'].ws is not None
         mm, mv = self.moving['upscore']
         z_up = None if virtual_up else ops.upsample_raw_fwd(feat, 8, self._act('z_up', n, h, w, e.Up))
-        y_up = ops.bn_forward(z_up, P('upscore', 'gamma'), P('upscore', 'beta'), mm, mv, self.bn['upscore'],
-                              self._act('y_up', n, h, w, e.Up), relu=True, sync=self._sync, ups8_of=feat if virtual_up else None)
-        score_raw = ops.score_dense_fwd(y_up, P('score', 'kernel'), P('score', 'bias'), e.C,
-                                        self._dense('score_raw', (n, h, w, e.C)))
+        score_raw = None
+        if virtual_up:
+            y_up = self._act('y_up', n, h, w, e.Up)
+            ops.bn_forward(None, P('upscore', 'gamma'), P('upscore', 'beta'), mm, mv, self.bn['upscore'], None, relu=True,
+                           ups8_of=feat)                                            # statistics, scale / shift
+            score_raw = self._dense('score_raw', (n, h, w, e.C))
+            if not ops.score_dense_fwd_ups8(feat, self.bn['upscore'], P('score', 'kernel'), P('score', 'bias'), e.C, y_up, score_raw):
+                score_raw = None
+                ops.bn_apply_ups8(feat, self.bn['upscore'], y_up)
+        else:
+            y_up = ops.bn_forward(z_up, P('upscore', 'gamma'), P('upscore', 'beta'), mm, mv, self.bn['upscore'],
+                                  self._act('y_up', n, h, w, e.Up), relu=True, sync=self._sync)
+        if score_raw is None:
+            score_raw = ops.score_dense_fwd(y_up, P('score', 'kernel'), P('score', 'bias'), e.C,
+                                            self._dense('score_raw', (n, h, w, e.C)))
         mm, mv = self.moving['score']
         logits = ops.bn_dense_forward(score_raw, P('score', 'gamma'), P('score', 'beta'), mm, mv, self.bn['score'],
                                       self._dense('logits', (n, h, w, e.C)), sync=self._sync)
