@@ -977,15 +977,15 @@ UPS8_BLOCK_SUMS = os.environ.get('XV_UPS8_BLOCK_SUMS', '1') != '0'      # 0: the
 
 
 def upsample_raw_bwd(dy, factor, dx):
-    """Gradient of the raw bilinear up-sampling.  factor 8: through per-block sums in a workspace (one per device and map size,
-    owned by the stream the trainers run on), every element of dy read once."""
+    """Gradient of the raw bilinear up-sampling.  factor 8: through per-block sums in a workspace (one per device and stream,
+    grown to the largest map seen), every element of dy read once."""
     lib = _lib.lib()
     if factor == 8 and UPS8_BLOCK_SUMS:
-        key = (dx.t.device, dx.n, dx.h, dx.w, dx.c)
+        key = (dx.t.device, _stream().value)
+        need = max(16, lib.xv_upsample_raw_bwd_workspace_bytes(dx.n, dx.h, dx.w, dx.c)) // 4
         ws = _UPS_WS.get(key)
-        if ws is None:
-            ws = _UPS_WS[key] = torch.empty(max(16, lib.xv_upsample_raw_bwd_workspace_bytes(dx.n, dx.h, dx.w, dx.c)) // 4,
-                                            dtype=torch.float32, device=dx.t.device)
+        if ws is None or ws.numel() < need:
+            ws = _UPS_WS[key] = torch.empty(need, dtype=torch.float32, device=dx.t.device)
         _lib.check(lib.xv_upsample_raw_bwd_ws(dy.xv(), factor, dx.xv(), _ptr(ws), ws.numel() * 4, _stream()), 'xv_upsample_raw_bwd_ws')
         return dx
     _lib.check(lib.xv_upsample_raw_bwd(dy.xv(), factor, dx.xv(), _stream()), 'xv_upsample_raw_bwd')
@@ -1044,13 +1044,13 @@ _SD_WS = {}
 
 def score_dense_bwd(u, dscore, w_score, num_classes, dw_score, db_score, du):
     """Backward of the dense 1x1 score layer at full resolution; filter and bias gradients added in a fixed order (a workspace
-    per device and map size, owned by the stream the trainers run on): bitwise reproducible."""
+    per device and stream, grown to the largest map seen): bitwise reproducible."""
     lib = _lib.lib()
-    key = (u.t.device, u.n, u.h, u.w)
+    key = (u.t.device, _stream().value)
+    need = max(16, lib.xv_score_dense_bwd_workspace_bytes(u.n, u.h, u.w)) // 4
     ws = _SD_WS.get(key)
-    if ws is None:
-        ws = _SD_WS[key] = torch.empty(max(16, lib.xv_score_dense_bwd_workspace_bytes(u.n, u.h, u.w)) // 4, dtype=torch.float32,
-                                       device=u.t.device)
+    if ws is None or ws.numel() < need:
+        ws = _SD_WS[key] = torch.empty(need, dtype=torch.float32, device=u.t.device)
     rc = lib.xv_score_dense_bwd_ws(u.xv(), _ptr(dscore), _ptr(w_score), num_classes, _ptr(dw_score), _ptr(db_score), du.xv(),
                                    _ptr(ws), ws.numel() * 4, _stream())
     _lib.check(rc, 'xv_score_dense_bwd_ws')
