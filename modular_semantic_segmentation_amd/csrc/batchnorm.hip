@@ -87,11 +87,26 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const __bf16* __restrict
   for (int e = 0; e < 8; ++e) sc[e] = MODE == 2 ? zsc[cg * 8 + e] : 0.f, sh[e] = MODE == 2 ? zsh[cg * 8 + e] : 0.f;
   // total < 2^31 (checked by the launchers): 32-bit index arithmetic
   const int total32 = (int)total, stride = (int)gridDim.x * 256;
-  auto offset_of = [&](int idx) -> int64_t {
-    const int p = idx / c8;
-    const int row = p / W;
-    const int x = p - row * W, n = row / H, yy = row - n * H;
-    return (((int64_t)n * (H + 2) + yy + 1) * (W + 2) + x + 1) * C + cg * 8;
+  // The positions idx0, idx0 + stride, idx0 + 2 stride, ... are visited IN ORDER, and the stride is a whole number of pixels
+  // (a multiple of c8): (n, y, x) of a position follow from the previous one by constant increments with two carries --
+  // the three 32-bit divisions per 16-byte element of the first form were more instructions than the rest of the pass
+  // (bn_reduce<0> on a 0.6 GB map: 165 us, ALU-bound).
+  int wk_x, wk_y, wk_n;
+  {
+    const int p0 = ((int)blockIdx.x * 256 + (int)threadIdx.x) / c8, row0 = p0 / W;
+    wk_x = p0 - row0 * W, wk_n = row0 / H, wk_y = row0 - wk_n * H;
+  }
+  const int wk_dp = stride / c8, wk_drow = wk_dp / W, wk_dx = wk_dp - wk_drow * W, wk_dn = wk_drow / H, wk_dy = wk_drow - wk_dn * H;
+  auto next_offset = [&]() -> int64_t {
+    const int64_t off = (((int64_t)wk_n * (H + 2) + wk_y + 1) * (W + 2) + wk_x + 1) * C + cg * 8;
+    wk_x += wk_dx;
+    const int cx = wk_x >= W ? 1 : 0;
+    wk_x -= cx ? W : 0;
+    wk_y += wk_dy + cx;
+    const int cy = wk_y >= H ? 1 : 0;
+    wk_y -= cy ? H : 0;
+    wk_n += wk_dn + cy;
+    return off;
   };
   int idx = (int)blockIdx.x * 256 + (int)threadIdx.x;
   if (MODE == 0) {
@@ -100,7 +115,7 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const __bf16* __restrict
     for (; idx + 3 * stride < total32; idx += 4 * stride) {
       u32x4 v[4];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) v[q] = *reinterpret_cast<const u32x4*>(z + offset_of(idx + q * stride));
+      for (int q = 0; q < 4; ++q) v[q] = *reinterpret_cast<const u32x4*>(z + next_offset());
 #pragma unroll
       for (int q = 0; q < 4; ++q)
 #pragma unroll
@@ -118,7 +133,7 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const __bf16* __restrict
       u32x4 zv[2], gv[2];
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
-        const int64_t off = offset_of(idx + q * stride);
+        const int64_t off = next_offset();
         zv[q] = *reinterpret_cast<const u32x4*>(z + off);
         gv[q] = *reinterpret_cast<const u32x4*>(dy + off);
       }
@@ -136,7 +151,7 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const __bf16* __restrict
         }
     }
     for (; idx < total32; idx += stride) {
-      const int64_t off = offset_of(idx);
+      const int64_t off = next_offset();
       const u32x4 zv = *reinterpret_cast<const u32x4*>(z + off), gv = *reinterpret_cast<const u32x4*>(dy + off);
 #pragma unroll
       for (int w = 0; w < 4; ++w) {
@@ -158,7 +173,7 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const __bf16* __restrict
       u32x4 zv[2], gv[2], yv[2];
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
-        const int64_t off = offset_of(idx + q * stride);
+        const int64_t off = next_offset();
         zv[q] = *reinterpret_cast<const u32x4*>(z + off);
         gv[q] = *reinterpret_cast<const u32x4*>(dy + off);
         yv[q] = y ? *reinterpret_cast<const u32x4*>(y + off) : ones;
@@ -176,7 +191,7 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const __bf16* __restrict
     }
   }
   for (; idx < total32; idx += stride) {
-    const int64_t off = offset_of(idx);
+    const int64_t off = next_offset();
     const u32x4 zv = *reinterpret_cast<const u32x4*>(z + off);
     if (MODE == 0) {
 #pragma unroll
@@ -402,11 +417,26 @@ __global__ __launch_bounds__(256) void bn_apply_fast_kernel(const __bf16* __rest
 #pragma unroll
   for (int e = 0; e < 8; ++e) sc[e] = scale[cg * 8 + e], sh[e] = shift[cg * 8 + e];
   const int total = N * H * W * c8, stride = (int)gridDim.x * 256;  // < 2^31 (checked by the launcher)
-  auto offset_of = [&](int idx) -> int64_t {
-    const int p = idx / c8;
-    const int row = p / W;
-    const int x = p - row * W, n = row / H, yy = row - n * H;
-    return (((int64_t)n * (H + 2) + yy + 1) * (W + 2) + x + 1) * C + cg * 8;
+  // The positions idx0, idx0 + stride, idx0 + 2 stride, ... are visited IN ORDER, and the stride is a whole number of pixels
+  // (a multiple of c8): (n, y, x) of a position follow from the previous one by constant increments with two carries --
+  // the three 32-bit divisions per 16-byte element of the first form were more instructions than the rest of the pass
+  // (bn_reduce<0> on a 0.6 GB map: 165 us, ALU-bound).
+  int wk_x, wk_y, wk_n;
+  {
+    const int p0 = ((int)blockIdx.x * 256 + (int)threadIdx.x) / c8, row0 = p0 / W;
+    wk_x = p0 - row0 * W, wk_n = row0 / H, wk_y = row0 - wk_n * H;
+  }
+  const int wk_dp = stride / c8, wk_drow = wk_dp / W, wk_dx = wk_dp - wk_drow * W, wk_dn = wk_drow / H, wk_dy = wk_drow - wk_dn * H;
+  auto next_offset = [&]() -> int64_t {
+    const int64_t off = (((int64_t)wk_n * (H + 2) + wk_y + 1) * (W + 2) + wk_x + 1) * C + cg * 8;
+    wk_x += wk_dx;
+    const int cx = wk_x >= W ? 1 : 0;
+    wk_x -= cx ? W : 0;
+    wk_y += wk_dy + cx;
+    const int cy = wk_y >= H ? 1 : 0;
+    wk_y -= cy ? H : 0;
+    wk_n += wk_dn + cy;
+    return off;
   };
   auto apply = [&](const u32x4 zv) {
     u32x4 o;
@@ -428,14 +458,14 @@ __global__ __launch_bounds__(256) void bn_apply_fast_kernel(const __bf16* __rest
     u32x4 v[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      off[q] = offset_of(idx + q * stride);
+      off[q] = next_offset();
       v[q] = *reinterpret_cast<const u32x4*>(z + off[q]);
     }
 #pragma unroll
     for (int q = 0; q < 4; ++q) *reinterpret_cast<u32x4*>(y + off[q]) = apply(v[q]);
   }
   for (; idx < total; idx += stride) {
-    const int64_t off = offset_of(idx);
+    const int64_t off = next_offset();
     *reinterpret_cast<u32x4*>(y + off) = apply(*reinterpret_cast<const u32x4*>(z + off));
   }
 }
@@ -461,11 +491,26 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_fast_kernel(const __bf16* __
     sc[e] = MASKZ ? zsc[c] : 0.f, sh[e] = MASKZ ? zsh[c] : 0.f;
   }
   const int total = N * H * W * c8, stride = (int)gridDim.x * 256;
-  auto offset_of = [&](int idx) -> int64_t {
-    const int p = idx / c8;
-    const int row = p / W;
-    const int x = p - row * W, n = row / H, yy = row - n * H;
-    return (((int64_t)n * (H + 2) + yy + 1) * (W + 2) + x + 1) * C + cg * 8;
+  // The positions idx0, idx0 + stride, idx0 + 2 stride, ... are visited IN ORDER, and the stride is a whole number of pixels
+  // (a multiple of c8): (n, y, x) of a position follow from the previous one by constant increments with two carries --
+  // the three 32-bit divisions per 16-byte element of the first form were more instructions than the rest of the pass
+  // (bn_reduce<0> on a 0.6 GB map: 165 us, ALU-bound).
+  int wk_x, wk_y, wk_n;
+  {
+    const int p0 = ((int)blockIdx.x * 256 + (int)threadIdx.x) / c8, row0 = p0 / W;
+    wk_x = p0 - row0 * W, wk_n = row0 / H, wk_y = row0 - wk_n * H;
+  }
+  const int wk_dp = stride / c8, wk_drow = wk_dp / W, wk_dx = wk_dp - wk_drow * W, wk_dn = wk_drow / H, wk_dy = wk_drow - wk_dn * H;
+  auto next_offset = [&]() -> int64_t {
+    const int64_t off = (((int64_t)wk_n * (H + 2) + wk_y + 1) * (W + 2) + wk_x + 1) * C + cg * 8;
+    wk_x += wk_dx;
+    const int cx = wk_x >= W ? 1 : 0;
+    wk_x -= cx ? W : 0;
+    wk_y += wk_dy + cx;
+    const int cy = wk_y >= H ? 1 : 0;
+    wk_y -= cy ? H : 0;
+    wk_n += wk_dn + cy;
+    return off;
   };
   const u32x4 ones = u32x4{0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
   auto apply = [&](const u32x4 zv, const u32x4 gv, const u32x4 yv) {
@@ -492,7 +537,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_fast_kernel(const __bf16* __
     u32x4 zv[2], gv[2], yv[2];
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
-      off[q] = offset_of(idx + q * stride);
+      off[q] = next_offset();
       zv[q] = *reinterpret_cast<const u32x4*>(z + off[q]);
       gv[q] = *reinterpret_cast<const u32x4*>(dy + off[q]);
       yv[q] = (y && !MASKZ) ? *reinterpret_cast<const u32x4*>(y + off[q]) : ones;
@@ -501,7 +546,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_fast_kernel(const __bf16* __
     for (int q = 0; q < 2; ++q) *reinterpret_cast<u32x4*>(dz + off[q]) = apply(zv[q], gv[q], yv[q]);
   }
   for (; idx < total; idx += stride) {
-    const int64_t off = offset_of(idx);
+    const int64_t off = next_offset();
     *reinterpret_cast<u32x4*>(dz + off) = apply(*reinterpret_cast<const u32x4*>(z + off), *reinterpret_cast<const u32x4*>(dy + off),
                                                 (y && !MASKZ) ? *reinterpret_cast<const u32x4*>(y + off) : ones);
   }
