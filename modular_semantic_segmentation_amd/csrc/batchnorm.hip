@@ -893,16 +893,13 @@ __global__ __launch_bounds__(256) void bn_dense_reduce_kernel(const float* __res
   float s0[32], s1[32];
 #pragma unroll
   for (int c = 0; c < 32; ++c) s0[c] = s1[c] = 0.f;
-  float mu[32], is[32];  // (in registers: read from memory inside the loop they were 2 C extra loads per pixel)
-#pragma unroll
-  for (int c = 0; c < 32; ++c) mu[c] = (MODE == 1 && c < C) ? mean[c] : 0.f, is[c] = (MODE == 1 && c < C) ? invstd[c] : 0.f;
   auto accumulate = [&](int c, float v, float g) {
     if (MODE == 0) {
       s0[c] += v;
       s1[c] += v * v;
     } else {
       s0[c] += g;
-      s1[c] += g * (v - mu[c]) * is[c];
+      s1[c] += g * (v - mean[c]) * invstd[c];
     }
   };
   if ((C & 3) == 0) {
@@ -973,32 +970,6 @@ __global__ __launch_bounds__(256) void bn_dense_bwd_apply_kernel(const float* __
                                                                 const float* __restrict__ gamma,
                                                                 const double* __restrict__ sums, double M,
                                                                 float* __restrict__ dz, int64_t total, int C) {
-  if ((C & 3) == 0 && (((uintptr_t)dy | (uintptr_t)z | (uintptr_t)dz) & 15) == 0) {
-    // a thread owns whole rows of C floats (16-byte loads / stores) and keeps the per-channel constants in registers: the
-    // per-element form paid a 64-bit modulo, two double divisions and three constant loads per FLOAT (175 us for 0.7 GB)
-    float mu[32], is[32], gk[32], db[32], dg[32];
-#pragma unroll
-    for (int c = 0; c < 32; ++c) {
-      const bool in = c < C;
-      mu[c] = in ? mean[c] : 0.f, is[c] = in ? invstd[c] : 0.f, gk[c] = in ? gamma[c] * invstd[c] : 0.f;
-      db[c] = in ? (float)(sums[c] / M) : 0.f, dg[c] = in ? (float)(sums[C + c] / M) : 0.f;
-    }
-    const int64_t rows = total / C;
-    for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < rows; p += (int64_t)gridDim.x * 256) {
-#pragma unroll
-      for (int c4 = 0; c4 < 8; ++c4)
-        if (c4 * 4 < C) {
-          const f32x4 g = *reinterpret_cast<const f32x4*>(dy + p * C + c4 * 4), v = *reinterpret_cast<const f32x4*>(z + p * C + c4 * 4);
-          f32x4 o;
-          o.x = gk[c4 * 4] * (g.x - db[c4 * 4] - (v.x - mu[c4 * 4]) * is[c4 * 4] * dg[c4 * 4]);
-          o.y = gk[c4 * 4 + 1] * (g.y - db[c4 * 4 + 1] - (v.y - mu[c4 * 4 + 1]) * is[c4 * 4 + 1] * dg[c4 * 4 + 1]);
-          o.z = gk[c4 * 4 + 2] * (g.z - db[c4 * 4 + 2] - (v.z - mu[c4 * 4 + 2]) * is[c4 * 4 + 2] * dg[c4 * 4 + 2]);
-          o.w = gk[c4 * 4 + 3] * (g.w - db[c4 * 4 + 3] - (v.w - mu[c4 * 4 + 3]) * is[c4 * 4 + 3] * dg[c4 * 4 + 3]);
-          *reinterpret_cast<f32x4*>(dz + p * C + c4 * 4) = o;
-        }
-    }
-    return;
-  }
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
     const int c = (int)(i % C);
     const float zh = (z[i] - mean[c]) * invstd[c];
@@ -1753,6 +1724,14 @@ bool same_shape(const xv_act* a, const xv_act* b) { return a->n == b->n && a->h 
 // statistics and gradients; without one: a memset and f64 atomics in arrival order.
 namespace {
 constexpr int BN_MAX_GRID = 2048;  // (512 left the reduce passes at 3.7 TB/s: 8 waves per CU with 4 loads in flight each)
+// workgroups of a fixed-order reduce pass: enough to keep the loads of a large map in flight, but at least 16 elements per
+// thread -- every workgroup is a row the small summing launch behind it has to add (37 of them per training step)
+static int bn_reduce_grid(int64_t total) {
+  int64_t g = (total + 256 * 16 - 1) / (256 * 16);
+  if (g < 64) g = 64;
+  const int cap = bn_grid(total, BN_MAX_GRID);
+  return (int)(g < cap ? g : cap);
+}
 // dgamma / dbeta: a backward reduction -- the gradients are accumulated by the same launch that adds the rows (workspace
 // form) or by bn_grads_kernel behind the atomics
 template <class F>
@@ -1792,7 +1771,7 @@ extern "C" int xv_bn_stats_ws(const xv_act* z, double* sums, void* workspace, si
   const int64_t total = (int64_t)z->n * z->h * z->w * (z->c >> 3);
   XV_CHECK_SHAPE(total < 0x7fff0000);
   hipStream_t s = (hipStream_t)stream;
-  const int grid = bn_grid(total, BN_MAX_GRID);
+  const int grid = bn_reduce_grid(total);
   const int rc = bn_sums_launch(sums, 2 * z->c, grid, workspace, workspace_bytes, s, [&](float* part) {
     hipLaunchKernelGGL(bn_reduce_kernel<0>, dim3(grid), dim3(256), 0, s, (const __bf16*)z->data, nullptr, nullptr, nullptr,
                        nullptr, sums, z->n, z->h, z->w, z->c, (const float*)nullptr, (const float*)nullptr, part);
@@ -1828,7 +1807,7 @@ extern "C" int xv_bn_stats_finalize_ws(const xv_act* z, double* sums, void* work
   XV_CHECK_SHAPE(total < 0x7fff0000);
   if (workspace_bytes < (size_t)BN_MAX_GRID * 2 * z->c * sizeof(float) || ((uintptr_t)workspace & 15)) return XV_EWORKSPACE;
   hipStream_t s = (hipStream_t)stream;
-  const int grid = bn_grid(total, BN_MAX_GRID);
+  const int grid = bn_reduce_grid(total);
   hipLaunchKernelGGL(bn_reduce_kernel<0>, dim3(grid), dim3(256), 0, s, (const __bf16*)z->data, nullptr, nullptr, nullptr, nullptr,
                      sums, z->n, z->h, z->w, z->c, (const float*)nullptr, (const float*)nullptr, (float*)workspace);
   hipLaunchKernelGGL(bn_sums_finalize_kernel, dim3(z->c), dim3(256), 0, s, (const float*)workspace, grid, z->c, sums,
@@ -1898,7 +1877,7 @@ extern "C" int xv_bn_bwd_reduce_ws(const xv_act* dy, const xv_act* y, const xv_a
   hipStream_t s = (hipStream_t)stream;
   const int64_t total = (int64_t)z->n * z->h * z->w * (z->c >> 3);
   XV_CHECK_SHAPE(total < 0x7fff0000);
-  const int grid = bn_grid(total, BN_MAX_GRID);
+  const int grid = bn_reduce_grid(total);
   const int rc = bn_sums_launch(sums, 2 * z->c, grid, workspace, workspace_bytes, s, [&](float* part) {
     hipLaunchKernelGGL(bn_reduce_kernel<1>, dim3(grid), dim3(256), 0, s, (const __bf16*)z->data, (const __bf16*)dy->data, yp,
                        mean, invstd, sums, z->n, z->h, z->w, z->c, (const float*)nullptr, (const float*)nullptr, part);
@@ -1942,7 +1921,7 @@ extern "C" int xv_bn_bwd_reduce_zmask(const xv_act* dy, const xv_act* z, const f
   hipStream_t s = (hipStream_t)stream;
   const int64_t total = (int64_t)z->n * z->h * z->w * (z->c >> 3);
   XV_CHECK_SHAPE(total < 0x7fff0000);
-  const int grid = bn_grid(total, BN_MAX_GRID);
+  const int grid = bn_reduce_grid(total);
   const int rc = bn_sums_launch(sums, 2 * z->c, grid, workspace, workspace_bytes, s, [&](float* part) {
     hipLaunchKernelGGL(bn_reduce_kernel<2>, dim3(grid), dim3(256), 0, s, (const __bf16*)z->data, (const __bf16*)dy->data,
                        (const __bf16*)nullptr, mean, invstd, sums, z->n, z->h, z->w, z->c, scale, shift, part);
@@ -2059,7 +2038,7 @@ extern "C" int xv_bn_pool_bwd_reduce(const xv_act* dpooled, const xv_act* z, con
   hipStream_t s = (hipStream_t)stream;
   const int64_t total = (int64_t)z->n * (z->h / 2) * (z->w / 2) * (z->c >> 3);
   XV_CHECK_SHAPE(total < 0x7fff0000);
-  const int grid = bn_grid(total, BN_MAX_GRID);
+  const int grid = bn_reduce_grid(total);
   const int rc = bn_sums_launch(sums, 2 * z->c, grid, workspace, workspace_bytes, s, [&](float* part) {
     hipLaunchKernelGGL(bn_pool_bwd_kernel<0>, dim3(grid), dim3(256), 0, s, (const __bf16*)dpooled->data, (const __bf16*)z->data,
                        mean, invstd, scale, shift, (const float*)nullptr, sums, 1.0, (__bf16*)nullptr, z->n, z->h / 2, z->w / 2,
@@ -2098,7 +2077,7 @@ extern "C" int xv_bn_dense_stats_ws(const float* z, int64_t rows, int channels, 
   XV_CHECK_ARG(z && sums);
   XV_CHECK_SHAPE(rows > 0 && channels >= 1 && channels <= 32);
   hipStream_t s = (hipStream_t)stream;
-  const int grid = bn_grid(rows, BN_MAX_GRID);
+  const int grid = bn_grid(rows, 512);  // (a thread keeps 2 x 32 sums: amortised over many rows)
   const int rc = bn_sums_launch(sums, 2 * channels, grid, workspace, workspace_bytes, s, [&](float* part) {
     hipLaunchKernelGGL(bn_dense_reduce_kernel<0>, dim3(grid), dim3(256), 0, s, z, nullptr, nullptr, nullptr, sums, rows, channels,
                        part);
@@ -2124,7 +2103,7 @@ extern "C" int xv_bn_dense_bwd_reduce_ws(const float* dy, const float* z, int64_
   XV_CHECK_ARG(dy && z && mean && invstd && sums && dgamma && dbeta);
   XV_CHECK_SHAPE(rows > 0 && channels >= 1 && channels <= 32);
   hipStream_t s = (hipStream_t)stream;
-  const int grid = bn_grid(rows, BN_MAX_GRID);
+  const int grid = bn_grid(rows, 512);  // (a thread keeps 2 x 32 sums: amortised over many rows)
   const int rc = bn_sums_launch(sums, 2 * channels, grid, workspace, workspace_bytes, s, [&](float* part) {
     hipLaunchKernelGGL(bn_dense_reduce_kernel<1>, dim3(grid), dim3(256), 0, s, z, dy, mean, invstd, sums, rows, channels, part);
   }, dgamma, dbeta);
@@ -2141,8 +2120,8 @@ extern "C" int xv_bn_dense_bwd_apply(const float* dy, const float* z, int64_t ro
                                      float* dz, void* stream) {
   XV_CHECK_ARG(dy && z && mean && invstd && gamma && sums && dz);
   XV_CHECK_SHAPE(rows > 0 && channels >= 1 && channels <= 32 && count > 0);
-  hipLaunchKernelGGL(bn_dense_bwd_apply_kernel, dim3(bn_grid((channels & 3) == 0 ? rows : rows * channels, 4096)), dim3(256), 0,
-                     (hipStream_t)stream, dy, z, mean, invstd, gamma, sums, (double)count, dz, rows * channels, channels);
+  hipLaunchKernelGGL(bn_dense_bwd_apply_kernel, dim3(bn_grid(rows * channels, 8192)), dim3(256), 0, (hipStream_t)stream,
+                     dy, z, mean, invstd, gamma, sums, (double)count, dz, rows * channels, channels);
   return xv_launch_status();
 }
 
