@@ -964,6 +964,44 @@ __global__ __launch_bounds__(256) void bn_dense_apply_kernel(const float* __rest
   }
 }
 
+// The same pass for C == CM, a multiple of four: a thread owns whole rows (16-byte loads / stores), the per-channel constants
+// -- computed once per workgroup, through LDS -- in 5 CM registers.  (The per-float form below pays a 64-bit modulo, two
+// double divisions and three constant loads per float: 172 us for 0.7 GB; a first row form with constants for up to 32
+// classes per thread lost more to its 160 registers than it gained.)
+template <int CM>
+__global__ __launch_bounds__(256) void bn_dense_bwd_apply_rows_kernel(const float* __restrict__ dy, const float* __restrict__ z,
+                                                                     const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                                     const float* __restrict__ gamma, const double* __restrict__ sums,
+                                                                     double M, float* __restrict__ dz, int64_t rows) {
+  __shared__ float cst[5][CM];
+  if ((int)threadIdx.x < CM) {
+    const int c = threadIdx.x;
+    cst[0][c] = mean[c], cst[1][c] = invstd[c], cst[2][c] = gamma[c] * invstd[c];
+    cst[3][c] = (float)(sums[c] / M), cst[4][c] = (float)(sums[CM + c] / M);
+  }
+  __syncthreads();
+  float mu[CM], is[CM], gk[CM], db[CM], dg[CM];
+#pragma unroll
+  for (int c = 0; c < CM; ++c) mu[c] = cst[0][c], is[c] = cst[1][c], gk[c] = cst[2][c], db[c] = cst[3][c], dg[c] = cst[4][c];
+  for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < rows; p += (int64_t)gridDim.x * 256) {
+    f32x4 g[CM / 4], v[CM / 4];
+#pragma unroll
+    for (int c4 = 0; c4 < CM / 4; ++c4) {
+      g[c4] = *reinterpret_cast<const f32x4*>(dy + p * CM + c4 * 4);
+      v[c4] = *reinterpret_cast<const f32x4*>(z + p * CM + c4 * 4);
+    }
+#pragma unroll
+    for (int c4 = 0; c4 < CM / 4; ++c4) {
+      f32x4 o;
+      o.x = gk[c4 * 4] * (g[c4].x - db[c4 * 4] - (v[c4].x - mu[c4 * 4]) * is[c4 * 4] * dg[c4 * 4]);
+      o.y = gk[c4 * 4 + 1] * (g[c4].y - db[c4 * 4 + 1] - (v[c4].y - mu[c4 * 4 + 1]) * is[c4 * 4 + 1] * dg[c4 * 4 + 1]);
+      o.z = gk[c4 * 4 + 2] * (g[c4].z - db[c4 * 4 + 2] - (v[c4].z - mu[c4 * 4 + 2]) * is[c4 * 4 + 2] * dg[c4 * 4 + 2]);
+      o.w = gk[c4 * 4 + 3] * (g[c4].w - db[c4 * 4 + 3] - (v[c4].w - mu[c4 * 4 + 3]) * is[c4 * 4 + 3] * dg[c4 * 4 + 3]);
+      *reinterpret_cast<f32x4*>(dz + p * CM + c4 * 4) = o;
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void bn_dense_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ z,
                                                                 const float* __restrict__ mean,
                                                                 const float* __restrict__ invstd,
@@ -2120,6 +2158,21 @@ extern "C" int xv_bn_dense_bwd_apply(const float* dy, const float* z, int64_t ro
                                      float* dz, void* stream) {
   XV_CHECK_ARG(dy && z && mean && invstd && gamma && sums && dz);
   XV_CHECK_SHAPE(rows > 0 && channels >= 1 && channels <= 32 && count > 0);
+  if ((channels == 4 || channels == 8 || channels == 12 || channels == 16) &&
+      (((uintptr_t)dy | (uintptr_t)z | (uintptr_t)dz) & 15) == 0) {
+    const dim3 grid(bn_grid(rows, 2048));
+#define XV_BDA(CMV)                                                                                                          \
+  hipLaunchKernelGGL(bn_dense_bwd_apply_rows_kernel<CMV>, grid, dim3(256), 0, (hipStream_t)stream, dy, z, mean, invstd, gamma, \
+                     sums, (double)count, dz, rows)
+    switch (channels) {
+      case 4: XV_BDA(4); break;
+      case 8: XV_BDA(8); break;
+      case 12: XV_BDA(12); break;
+      default: XV_BDA(16); break;
+    }
+#undef XV_BDA
+    return xv_launch_status();
+  }
   hipLaunchKernelGGL(bn_dense_bwd_apply_kernel, dim3(bn_grid(rows * channels, 8192)), dim3(256), 0, (hipStream_t)stream,
                      dy, z, mean, invstd, gamma, sums, (double)count, dz, rows * channels, channels);
   return xv_launch_status();
