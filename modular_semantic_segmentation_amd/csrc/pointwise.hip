@@ -666,7 +666,8 @@ __global__ __launch_bounds__(256) void fused_head_kernel(const float* __restrict
   // vectors (24 16-byte loads per expert pair instead of 96) and leave as two 16-byte stores: 71.8 -> 54.6 us for 37.7 MB
   // at 16 images of 768x384 (profiles/r3_elementwise.json: not HBM-bound, 0.10 of the HBM rate: the per-pixel argmax
   // chains and the lane-varying table reads in LDS remain).  Dirichlet (24 logs + 288 FMAs per pixel, 48 more live
-  // registers per extra pixel) keeps one pixel per thread: four measured 14 % slower.
+  // registers per extra pixel) keeps one pixel per thread in this scalar form: four measured 14 % slower.  (C == CM runs
+  // fused_dirichlet_head_pk_kernel below.)
   const int Ho = Hi * 8, Wo = Wi * 8, Wq = Wo / P;
   const int64_t nquads = (int64_t)N * Ho * Wq;
   const int64_t quad = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -755,6 +756,164 @@ __global__ __launch_bounds__(256) void fused_head_kernel(const float* __restrict
     typedef __attribute__((ext_vector_type(2))) long long i64x2;
     *reinterpret_cast<i64x2*>(dst) = i64x2{out[0], out[1]};
     *reinterpret_cast<i64x2*>(dst + 2) = i64x2{out[2], out[3]};
+  } else {
+#pragma unroll
+    for (int p = 0; p < P; ++p) dst[p] = out[p];
+  }
+}
+
+// The Dirichlet form of fused_head_kernel for C == CM on PACKED fp32 (v_pk_mul / v_pk_add / v_pk_fma_f32, two classes per
+// instruction): every per-class step of the scalar form that is not a summation chain -- the four-tap interpolation, the bias,
+// x - max, the products with log2 e / 1 / sum / ln 2, fma(p, 1 / sum', 1e-20), dot - lognorm, + logprior -- is the same IEEE
+// operation on the same operands, so the labels stay those of fused_head_kernel<CM, 1, true> and of the unfused path bit for
+// bit; the sums (softmax denominator, renormalisation) keep their order.  P consecutive output pixels ox = P m .. P m + P - 1
+// per thread share their taps and every table row read from LDS: the 72 16-byte broadcast reads per pixel of the scalar form
+// load the LDS pipe about as long as its instructions load the vector ALU.  16 images of 768x384 (tools/dirichlet_head_ab.py):
+// scalar 97-105 us; packed, P = 1: 93-100 (VALU instructions 913 -> 751, the LDS reads as before); P = 2: 82; P = 4: 75 us
+// (162 VGPRs, 3 waves per SIMD -- the scalar form with four pixels had measured 14 % SLOWER than with one).
+template <int CM, int P>
+__global__ __launch_bounds__(256) void fused_dirichlet_head_pk_kernel(const float* __restrict__ Sa, const float* __restrict__ Sb,
+                                                                     const float* __restrict__ ba, const float* __restrict__ bb,
+                                                                     int N, int Hi, int Wi, const float* __restrict__ tab_g,
+                                                                     const float* __restrict__ lognorm_g,
+                                                                     const float* __restrict__ logprior_g,
+                                                                     int64_t* __restrict__ fused) {
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  constexpr int H2 = CM / 2;
+  extern __shared__ __attribute__((aligned(16))) float tab[];  // [2][CM k][CM c] = alpha_e[c][k] - 1, lognorm [2][CM], logprior [CM]
+  float* ln = tab + 2 * CM * CM;
+  float* lp = ln + 2 * CM;
+  for (int i = threadIdx.x; i < 2 * CM * CM; i += 256) {
+    const int c = i % CM, k = (i / CM) % CM, e = i / (CM * CM);
+    tab[i] = tab_g[(e * CM + c) * CM + k];
+  }
+  for (int i = threadIdx.x; i < 2 * CM; i += 256) ln[i] = lognorm_g[i];
+  if (threadIdx.x < CM) lp[threadIdx.x] = logprior_g[threadIdx.x];
+  __syncthreads();
+  const int Ho = Hi * 8, Wo = Wi * 8, Wq = Wo / P;
+  const int64_t nquads = (int64_t)N * Ho * Wq;
+  const int64_t quad = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (quad >= nquads) return;
+  const int ox0 = (int)(quad % Wq) * P;
+  const int oy = (int)((quad / Wq) % Ho);
+  const int n = (int)(quad / ((int64_t)Wq * Ho));
+  int iy1, ix1;
+  float wy1, wy0;
+  bilinear_taps<8>(oy, iy1, wy1, wy0);
+  {
+    float u1, u0;
+    bilinear_taps<8>(ox0, ix1, u1, u0);
+  }
+  f32x2 total[P][H2];
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    f32x4 ta[CM / 4], tb[CM / 4], tc[CM / 4], td[CM / 4];
+    head_load_taps<CM>(e == 0 ? Sa : Sb, n, iy1, ix1, Hi, Wi, ta, tb, tc, td);
+    const float* bs = e == 0 ? ba : bb;
+    f32x2 lg[P][H2];  // log(1e-20 + p) of the P pixels
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+      int ixp;
+      float wx1, wx0;
+      bilinear_taps<8>(ox0 + p, ixp, wx1, wx0);
+      const float w00 = wy0 * wx0, w01 = wy0 * wx1, w10 = wy1 * wx0, w11 = wy1 * wx1;
+      const f32x2 v00 = f32x2{w00, w00}, v01 = f32x2{w01, w01}, v10 = f32x2{w10, w10}, v11 = f32x2{w11, w11};
+      f32x2 s[H2];
+#pragma unroll
+      for (int j = 0; j < H2; ++j) {  // head_eval_taps: fmaf(d, w11, fmaf(c, w10, fmaf(b, w01, a * w00))) + bias
+        const int k4 = j >> 1;
+        const f32x2 a2 = (j & 1) ? f32x2{ta[k4].z, ta[k4].w} : f32x2{ta[k4].x, ta[k4].y};
+        const f32x2 b2 = (j & 1) ? f32x2{tb[k4].z, tb[k4].w} : f32x2{tb[k4].x, tb[k4].y};
+        const f32x2 c2 = (j & 1) ? f32x2{tc[k4].z, tc[k4].w} : f32x2{tc[k4].x, tc[k4].y};
+        const f32x2 d2 = (j & 1) ? f32x2{td[k4].z, td[k4].w} : f32x2{td[k4].x, td[k4].y};
+        f32x2 t = a2 * v00;
+        t = __builtin_elementwise_fma(b2, v01, t);
+        t = __builtin_elementwise_fma(c2, v10, t);
+        t = __builtin_elementwise_fma(d2, v11, t);
+        const f32x2 bias2 = f32x2{bs[2 * j], bs[2 * j + 1]};
+        s[j] = t + bias2;
+      }
+      float m = s[0].x;  // head_max
+#pragma unroll
+      for (int j = 0; j < H2; ++j) {
+        if (j) m = fmaxf(m, s[j].x);
+        m = fmaxf(m, s[j].y);
+      }
+      const f32x2 m2 = f32x2{m, m};
+      float sum = 0.f;  // head_softmax: exp(x - max) / sum
+#pragma unroll
+      for (int j = 0; j < H2; ++j) {
+        f32x2 t = s[j] - m2;
+        t = t * f32x2{1.4426950408889634f, 1.4426950408889634f};
+        s[j] = f32x2{__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)};
+        sum += s[j].x;
+        sum += s[j].y;
+      }
+      const float rsum = xv_fast_rcp(sum);
+      const f32x2 rsum2 = f32x2{rsum, rsum};
+      float sum1 = 0.f;  // the probabilities the unfused path stores, renormalised, log(1e-20 + p)
+#pragma unroll
+      for (int j = 0; j < H2; ++j) {
+        s[j] = s[j] * rsum2;
+        sum1 += s[j].x;
+        sum1 += s[j].y;
+      }
+      const float rs = xv_fast_rcp(sum1);
+      const f32x2 rs2 = f32x2{rs, rs};
+#pragma unroll
+      for (int j = 0; j < H2; ++j) {
+        const f32x2 t = __builtin_elementwise_fma(s[j], rs2, f32x2{1e-20f, 1e-20f});
+        const f32x2 l = f32x2{__builtin_amdgcn_logf(t.x), __builtin_amdgcn_logf(t.y)};
+        lg[p][j] = l * f32x2{0.6931471805599453f, 0.6931471805599453f};
+      }
+    }
+    // sum_k (alpha[c][k] - 1) log p[k]: the fmaf chain over k of dirichlet_fuse_kernel, two classes per v_pk_fma_f32
+    f32x2 dot[P][H2];
+#pragma unroll
+    for (int p = 0; p < P; ++p)
+#pragma unroll
+      for (int cp = 0; cp < H2; ++cp) dot[p][cp] = f32x2{0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < CM; ++k) {
+      const f32x2* rowk = reinterpret_cast<const f32x2*>(tab + (e * CM + k) * CM);
+#pragma unroll
+      for (int cp = 0; cp < H2; ++cp) {
+        const f32x2 r = rowk[cp];
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+          const float lk = lg[p][k >> 1][k & 1];
+          dot[p][cp] = __builtin_elementwise_fma(r, f32x2{lk, lk}, dot[p][cp]);
+        }
+      }
+    }
+    const f32x2* ln2 = reinterpret_cast<const f32x2*>(ln + e * CM);
+#pragma unroll
+    for (int p = 0; p < P; ++p)
+#pragma unroll
+      for (int cp = 0; cp < H2; ++cp) {
+        const f32x2 L = dot[p][cp] - ln2[cp];
+        total[p][cp] = e == 0 ? L : total[p][cp] + L;
+      }
+  }
+  const f32x2* lp2 = reinterpret_cast<const f32x2*>(lp);
+  int64_t out[P];
+#pragma unroll
+  for (int p = 0; p < P; ++p) {
+    float best = 0.f;
+    int bi = 0;
+#pragma unroll
+    for (int j = 0; j < H2; ++j) {
+      const f32x2 v = total[p][j] + lp2[j];
+      if (j == 0 || v.x > best) best = v.x, bi = 2 * j;
+      if (v.y > best) best = v.y, bi = 2 * j + 1;
+    }
+    out[p] = bi;
+  }
+  int64_t* dst = fused + quad * P;
+  if constexpr (P % 2 == 0) {
+    typedef __attribute__((ext_vector_type(2))) long long i64x2;
+#pragma unroll
+    for (int p = 0; p < P; p += 2) *reinterpret_cast<i64x2*>(dst + p) = i64x2{out[p], out[p + 1]};
   } else {
 #pragma unroll
     for (int p = 0; p < P; ++p) dst[p] = out[p];
@@ -1195,11 +1354,15 @@ extern "C" int xv_fused_head_fwd(const float* Sa, const float* Sb, const float* 
                                  const float* logprior, int64_t* fused_label, void* stream) {
   XV_CHECK_ARG(Sa && Sb && bias_a && bias_b && tab && logprior && fused_label && (mode == 0 || (mode == 1 && lognorm)));
   XV_CHECK_SHAPE(n > 0 && hi > 0 && wi > 0 && num_classes >= 1 && num_classes <= 32);
-  // threads: four output pixels each (Bayes), one (Dirichlet) -- see fused_head_kernel
+  // threads: four output pixels each (Bayes; Dirichlet in the packed form), one (Dirichlet, scalar form) -- see fused_head_kernel
   const int64_t nthreads = (int64_t)n * hi * 8 * wi * (mode == 0 ? 2 : 8);
   XV_CHECK_ARG(((uintptr_t)fused_label & 15) == 0);
   const unsigned grid = (unsigned)((nthreads + 255) / 256);
   hipStream_t s = (hipStream_t)stream;
+  // XV_DIRICHLET_HEAD_PK=0: the scalar form of the Dirichlet head for C == CM too (read per call: the test that pins the two
+  // forms to the same labels switches it)
+  const char* pk_env = getenv("XV_DIRICHLET_HEAD_PK");
+  const bool pk = !(pk_env && pk_env[0] == '0');
 #define XV_FH(CMV)                                                                                                      \
   {                                                                                                                     \
     const size_t lds = (size_t)(2 * (mode == 0 ? num_classes : CMV) * CMV + 3 * CMV) * 4;                               \
@@ -1209,6 +1372,9 @@ extern "C" int xv_fused_head_fwd(const float* Sa, const float* Sb, const float* 
     else if (mode == 0)                                                                                                 \
       hipLaunchKernelGGL((fused_head_kernel<CMV, 0>), dim3(grid), dim3(256), lds, s, Sa, Sb, bias_a, bias_b, n, hi, wi,  \
                          num_classes, tab, lognorm, logprior, fused_label);                                             \
+    else if (num_classes == CMV && pk)                                                                                  \
+      hipLaunchKernelGGL((fused_dirichlet_head_pk_kernel<CMV, 4>), dim3((grid + 3) / 4), dim3(256), lds, s, Sa, Sb, bias_a, \
+                         bias_b, n, hi, wi, tab, lognorm, logprior, fused_label);                                       \
     else if (num_classes == CMV)                                                                                        \
       hipLaunchKernelGGL((fused_head_kernel<CMV, 1, true>), dim3(grid), dim3(256), lds, s, Sa, Sb, bias_a, bias_b, n, hi, \
                          wi, num_classes, tab, lognorm, logprior, fused_label);                                         \

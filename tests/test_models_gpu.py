@@ -535,6 +535,38 @@ def test_fused_head_equals_unfused_path(gpu, tmp_path, golden_dir, kind):
     assert np.array_equal(plain.predict(data), ref)
 
 
+@pytest.mark.parametrize('c', [4, 8, 12, 16])
+@pytest.mark.parametrize('shape', [(1, 3, 5), (2, 6, 4), (3, 7, 9)])
+def test_dirichlet_head_packed_form_equals_scalar_form(gpu, c, shape):
+    """The fused Dirichlet head for a class count that fills its template (C == CM) runs on packed fp32, four output pixels
+    per thread (fused_dirichlet_head_pk_kernel); XV_DIRICHLET_HEAD_PK=0 keeps the scalar one-pixel form, which the test
+    above pins to the unfused path.  Same IEEE operations, same summation order: the labels must be equal."""
+    from modular_semantic_segmentation_amd import ops
+    n, hi, wi = shape
+    g = torch.Generator().manual_seed(100 * c + hi)
+    S = [torch.zeros((n, hi + 2, wi + 2, c)) for _ in range(2)]
+    for t in S:
+        t[:, 1:-1, 1:-1] = torch.randn((n, hi, wi, c), generator=g) * 3
+    Sa, Sb = (t.to('cuda:0') for t in S)
+    ba, bb = torch.randn(c, generator=g).to('cuda:0'), torch.randn(c, generator=g).to('cuda:0')
+    am1 = (torch.rand((2, c, c), generator=g) - 0.5 + 4 * torch.eye(c)).to('cuda:0')   # each class likeliest under its own row
+    lognorm = (torch.randn((2, c), generator=g) * 0.1).to('cuda:0')
+    logprior = (torch.randn(c, generator=g) * 0.1).to('cuda:0')
+    old = os.environ.get('XV_DIRICHLET_HEAD_PK')
+    try:
+        os.environ['XV_DIRICHLET_HEAD_PK'] = '0'
+        ref = ops.fused_head(Sa, Sb, ba, bb, n, hi, wi, c, am1, logprior, lognorm=lognorm)
+        os.environ['XV_DIRICHLET_HEAD_PK'] = '1'
+        got = ops.fused_head(Sa, Sb, ba, bb, n, hi, wi, c, am1, logprior, lognorm=lognorm)
+    finally:
+        if old is None:
+            os.environ.pop('XV_DIRICHLET_HEAD_PK', None)
+        else:
+            os.environ['XV_DIRICHLET_HEAD_PK'] = old
+    assert ref.unique().numel() > 1
+    assert torch.equal(got, ref)
+
+
 def test_paired_expert_launches_equal_per_expert_launches(gpu, tmp_path, golden_dir):
     """From conv4_1 on the two experts of a fusion model share ONE launch per layer (fcn.encoder_layers_pair ->
     xv_conv2d_fwd_pair: whole rounds of workgroups on the persistent conv kernels).  At 768x384 -- conv4 maps tile in 16x32,
