@@ -1,5 +1,8 @@
 // Per-pixel probabilistic fusion, sufficient statistics and confusion matrix for gfx950.
 // All HBM-bound: one thread per pixel, class vectors in registers, tables in LDS.
+#include <stdint.h>
+#include <stdlib.h>
+
 #include "xv_common.h"
 
 // Floating-point contraction by the SOURCE only (a * b + c inside one expression), never across statements: the fused
@@ -232,6 +235,96 @@ __global__ __launch_bounds__(256) void dirichlet_fuse_kernel(ProbPtrs probs, int
   }
 }
 
+// dirichlet_fuse_kernel<CM, true> for two experts on PACKED fp32: the table in LDS transposed ([e][k][c] = alpha_e[c][k] - 1),
+// so that the CM dot products of a pixel advance together, two classes per v_pk_fma_f32, each still the fmaf chain over k
+// of the scalar form; the renormalisation fma and the ln 2 product two classes per instruction as well -- the same IEEE
+// operations on the same operands, the sums in the same order: the same labels and scores bit for bit.  One pixel per
+// thread and NO grid-stride loop: around a loop the compiler keeps the whole loop-invariant table in registers (256 VGPRs +
+// 116 AGPRs, one wave per SIMD: 161 us).  16 images of 768x384 (tools/dirichlet_head_ab.py): scalar form 108-117 us (0.52-0.57
+// of 8 TB/s, bound by its 288 scalar FMAs and their index arithmetic), this one 87 us (0.70; 5.65 TB/s of the 6.29 TB/s a
+// float4 copy reaches); two / four pixels per thread sharing the table rows read from LDS: 89 / 92 us -- the rows are not
+// what binds this kernel once the FMAs are packed, unlike the fused head (pointwise.hip).
+template <int CM>
+__global__ __launch_bounds__(256) void dirichlet_fuse_pk_kernel(const float* __restrict__ pa, const float* __restrict__ pb,
+                                                               const float* __restrict__ am1, const float* __restrict__ lognorm,
+                                                               const float* __restrict__ logprior, int64_t npix,
+                                                               int64_t* __restrict__ fused, float* __restrict__ score_out) {
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  constexpr int H2 = CM / 2;
+  extern __shared__ __attribute__((aligned(16))) float tab[];
+  float* ln = tab + 2 * CM * CM;
+  float* lp = ln + 2 * CM;
+  for (int i = threadIdx.x; i < 2 * CM * CM; i += 256) {
+    const int c = i % CM, k = (i / CM) % CM, e = i / (CM * CM);
+    tab[i] = am1[(e * CM + c) * CM + k];
+  }
+  for (int i = threadIdx.x; i < 2 * CM; i += 256) ln[i] = lognorm[i];
+  if (threadIdx.x < CM) lp[threadIdx.x] = logprior[threadIdx.x];
+  __syncthreads();
+  const int64_t pix = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (pix >= npix) return;
+  f32x4 raw[2][CM / 4];
+#pragma unroll
+  for (int e = 0; e < 2; ++e)
+#pragma unroll
+    for (int q = 0; q < CM / 4; ++q) raw[e][q] = *reinterpret_cast<const f32x4*>((e == 0 ? pa : pb) + pix * CM + 4 * q);
+  f32x2 total[H2];
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    float sum = 0.f;
+#pragma unroll
+    for (int q = 0; q < CM / 4; ++q) {
+      sum += raw[e][q].x;
+      sum += raw[e][q].y;
+      sum += raw[e][q].z;
+      sum += raw[e][q].w;
+    }
+    const float rs = xv_fast_rcp(sum);
+    const f32x2 rs2 = f32x2{rs, rs};
+    f32x2 lg[H2];
+#pragma unroll
+    for (int j = 0; j < H2; ++j) {  // renormalise, then log(1e-20 + p)
+      const f32x4 r = raw[e][j >> 1];
+      const f32x2 x2 = (j & 1) ? f32x2{r.z, r.w} : f32x2{r.x, r.y};
+      const f32x2 t = __builtin_elementwise_fma(x2, rs2, f32x2{1e-20f, 1e-20f});
+      const f32x2 l = f32x2{__builtin_amdgcn_logf(t.x), __builtin_amdgcn_logf(t.y)};
+      lg[j] = l * f32x2{0.6931471805599453f, 0.6931471805599453f};
+    }
+    f32x2 dot[H2];
+#pragma unroll
+    for (int cp = 0; cp < H2; ++cp) dot[cp] = f32x2{0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < CM; ++k) {
+      const f32x2* rowk = reinterpret_cast<const f32x2*>(tab + (e * CM + k) * CM);
+      const float lk = lg[k >> 1][k & 1];
+#pragma unroll
+      for (int cp = 0; cp < H2; ++cp) dot[cp] = __builtin_elementwise_fma(rowk[cp], f32x2{lk, lk}, dot[cp]);
+    }
+    const f32x2* ln2 = reinterpret_cast<const f32x2*>(ln + e * CM);
+#pragma unroll
+    for (int cp = 0; cp < H2; ++cp) {
+      const f32x2 L = dot[cp] - ln2[cp];
+      total[cp] = e == 0 ? L : total[cp] + L;
+    }
+  }
+  const f32x2* lp2 = reinterpret_cast<const f32x2*>(lp);
+  float best = 0.f;
+  int bi = 0;
+  f32x2 v[H2];
+#pragma unroll
+  for (int j = 0; j < H2; ++j) {
+    v[j] = total[j] + lp2[j];
+    if (j == 0 || v[j].x > best) best = v[j].x, bi = 2 * j;
+    if (v[j].y > best) best = v[j].y, bi = 2 * j + 1;
+  }
+  if (score_out) {
+#pragma unroll
+    for (int q = 0; q < CM / 4; ++q)
+      *reinterpret_cast<f32x4*>(score_out + pix * CM + 4 * q) = f32x4{v[2 * q].x, v[2 * q].y, v[2 * q + 1].x, v[2 * q + 1].y};
+  }
+  fused[pix] = bi;
+}
+
 // average_mix.py:18-21: argmax of the mean of the experts' probabilities
 template <int CMAX>
 __global__ __launch_bounds__(256) void average_fuse_kernel(ProbPtrs probs, int E, int C, int64_t npix,
@@ -445,7 +538,16 @@ extern "C" int xv_dirichlet_fuse(const float* const* probs, int num_experts, con
   const size_t lds = (size_t)(num_experts * num_classes * cm + num_experts * cm + cm) * 4;
   int vec = (num_classes & 3) == 0;
   for (int e = 0; e < num_experts; ++e) vec = vec && ((uintptr_t)probs[e] & 15) == 0;
-  if (num_classes == 12 && vec)
+  // XV_DIRICHLET_FUSE_PK=0: the scalar form for the two-expert 12-class case too (read per call: the test that pins the two
+  // forms to the same bits switches it)
+  const char* pk_env = getenv("XV_DIRICHLET_FUSE_PK");
+  const bool pk = !(pk_env && pk_env[0] == '0');
+  const bool score_ok = !score_out || ((uintptr_t)score_out & 15) == 0;
+  if (num_classes == 12 && vec && num_experts == 2 && score_ok && pk)
+    hipLaunchKernelGGL(dirichlet_fuse_pk_kernel<12>, dim3((unsigned)((npix + 255) / 256)), dim3(256),
+                       (size_t)(2 * 12 * 12 + 2 * 12 + 12) * 4, s, pp.p[0], pp.p[1], am1, lognorm, logprior, npix, fused,
+                       score_out);
+  else if (num_classes == 12 && vec)
     hipLaunchKernelGGL((dirichlet_fuse_kernel<12, true>), dim3(grid_for(npix, 256, xv_num_cus() * 8)), dim3(256),
                        (size_t)(num_experts * 12 * 12 + num_experts * 12 + 12) * 4, s, pp, num_experts, am1, lognorm, logprior,
                        num_classes, npix, fused, score_out, vec);

@@ -1,6 +1,8 @@
 """Parity of every HIP kernel (called through the C ABI) against the CPU oracle.
 Integer-valued operands make the conv checks bit-exact (fp32 sums of small integers are exact
 in any order), so a layout / swizzle / fragment-map bug cannot hide inside a tolerance."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -631,6 +633,38 @@ def test_dirichlet_fuse(ops):
         top2 = np.sort(ref, -1)[..., -2:]
         clear = (top2[..., 1] - top2[..., 0]) > 1e-2
         assert np.array_equal(fused.cpu().numpy()[clear], np.argmax(ref, -1)[clear])
+
+
+@pytest.mark.parametrize('shape', [(1, 1, 1), (2, 19, 21), (1, 37, 53)])
+def test_dirichlet_fuse_packed_form_equals_scalar_form(ops, shape):
+    """Two experts, 12 classes: the fusion kernel runs on packed fp32 with the table transposed (dirichlet_fuse_pk_kernel);
+    XV_DIRICHLET_FUSE_PK=0 keeps the scalar form the test above compares with the oracle.  Same IEEE operations in the same
+    order: scores and labels must be equal bit for bit, for pixel counts that are not multiples of the workgroup."""
+    from modular_semantic_segmentation_amd import dirichlet_mix
+    rng = np.random.default_rng(14)
+    C = 12
+    pa = fo.softmax((rng.standard_normal(shape + (C,)) * 3).astype(np.float32))
+    pb = fo.softmax((rng.standard_normal(shape + (C,)) * 3).astype(np.float32))
+    pa[0, 0, 0] = 0
+    pa[0, 0, 0, 5] = 1.0
+    A = [rng.uniform(0.3, 5.0, (C, C)).astype(np.float32) for _ in range(2)]
+    am1, lognorm, logprior = dirichlet_mix.dirichlet_tables(A, rng.integers(1, 1000, C), 'data', 1.0)
+    args = ([_dev(pa), _dev(pb)], _dev(am1), _dev(lognorm), _dev(logprior))
+    old = os.environ.get('XV_DIRICHLET_FUSE_PK')
+    try:
+        os.environ['XV_DIRICHLET_FUSE_PK'] = '0'
+        ref = ops.dirichlet_fuse(*args, want_score=True)
+        ref_l, _ = ops.dirichlet_fuse(*args)
+        os.environ['XV_DIRICHLET_FUSE_PK'] = '1'
+        got = ops.dirichlet_fuse(*args, want_score=True)
+        got_l, _ = ops.dirichlet_fuse(*args)
+    finally:
+        if old is None:
+            os.environ.pop('XV_DIRICHLET_FUSE_PK', None)
+        else:
+            os.environ['XV_DIRICHLET_FUSE_PK'] = old
+    assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1])
+    assert torch.equal(got_l, ref_l) and torch.equal(got_l, ref[0])
 
 
 def test_average_fuse(ops):
