@@ -201,19 +201,30 @@ __global__ __launch_bounds__(256) void head_loss_kernel(const float* __restrict_
     for (int sl = 0; sl < 3; ++sl)
 #pragma unroll
       for (int k = 0; k < CM; ++k) colsum[sl][k] = 0.f;
+    // The column's eight pixels interpolate between the padded source rows ib, ib + 1 (r < 4) and ib + 1, ib + 2 (r >= 4) at
+    // columns ix1, ix1 + 1: 6 CM / 4 loads, made once.  (Written per pixel -- four loads per class quad in each of the
+    // eight rows -- the compiler requested all 96 first: 256 VGPRs + 156 AGPRs, one wave per SIMD.)
+    f32x4 T[3][2][CM / 4];
+    {
+      const float* t00 = S + (((int64_t)n * (Hi + 2) + ib) * (Wi + 2) + ix1) * CM;
+#pragma unroll
+      for (int sr = 0; sr < 3; ++sr)
+#pragma unroll
+        for (int sx = 0; sx < 2; ++sx)
+#pragma unroll
+          for (int q = 0; q < CM / 4; ++q) T[sr][sx][q] = *reinterpret_cast<const f32x4*>(t00 + sr * rowp + sx * CM + 4 * q);
+    }
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
       const int oy = 8 * ib + r;
       const int iy1 = ib + (r >= 4 ? 1 : 0);  // = (oy + 4) >> 3
       const float wy1 = bilinear_w<8>(oy, iy1), wy0 = bilinear_w<8>(oy, iy1 - 1);
       const float w00 = wy0 * wx0, w01 = wy0 * wx1, w10 = wy1 * wx0, w11 = wy1 * wx1;
-      const float* p00 = S + (((int64_t)n * (Hi + 2) + iy1) * (Wi + 2) + ix1) * CM;
       float sc[CM];
 #pragma unroll
       for (int k4 = 0; k4 < CM; k4 += 4) {
-        const f32x4 a = *reinterpret_cast<const f32x4*>(p00 + k4), b = *reinterpret_cast<const f32x4*>(p00 + CM + k4);
-        const f32x4 c = *reinterpret_cast<const f32x4*>(p00 + rowp + k4),
-                    d = *reinterpret_cast<const f32x4*>(p00 + rowp + CM + k4);
+        const f32x4 a = T[r >= 4 ? 1 : 0][0][k4 / 4], b = T[r >= 4 ? 1 : 0][1][k4 / 4];
+        const f32x4 c = T[r >= 4 ? 2 : 1][0][k4 / 4], d = T[r >= 4 ? 2 : 1][1][k4 / 4];
         const f32x4 v = a * w00 + b * w01 + c * w10 + d * w11;
         sc[k4] = v.x;
         sc[k4 + 1] = v.y;
