@@ -662,6 +662,30 @@ __global__ __launch_bounds__(256) void fused_head_kernel(const float* __restrict
   }
   if (threadIdx.x < CM) lp[threadIdx.x] = threadIdx.x < C ? logprior_g[threadIdx.x] : 0.f;
   __syncthreads();
+  // Bayes: the fused label is a function of the two experts' labels alone -- dec[a][b] = argmax_k (tab_0[a][k] + tab_1[b][k] +
+  // logprior[k]), built here by the workgroup with the sums in the order of bayes_fuse_kernel (fusion.hip; as bayes_fuse2_kernel
+  // does for the unfused path): a pixel is then ONE 4-byte LDS lookup instead of six lane-varying 16-byte row reads, 36 adds
+  // and a 12-way argmax chain, and the thread keeps two labels per pixel instead of CM sums.
+  int* dec = reinterpret_cast<int*>(lp + CM);  // [C][C]
+  if constexpr (!DIRICHLET) {
+    for (int i = threadIdx.x; i < C * C; i += 256) {
+      const float* ra = tab + (i / C) * CM;
+      const float* rb = tab + (C + i % C) * CM;
+      float best = 0.f;
+      int bi = 0;
+      for (int k = 0; k < C; ++k) {
+        float sc = ra[k];
+        sc = sc + rb[k];
+        const float v = sc + lp[k];
+        if (k == 0 || v > best) {
+          best = v;
+          bi = k;
+        }
+      }
+      dec[i] = bi;
+    }
+    __syncthreads();
+  }
   // Bayes: one thread = P = FOUR consecutive output pixels ox = 4m .. 4m + 3: they share their four low-resolution source
   // vectors (24 16-byte loads per expert pair instead of 96) and leave as two 16-byte stores: 71.8 -> 54.6 us for 37.7 MB
   // at 16 images of 768x384 (profiles/r3_elementwise.json: not HBM-bound, 0.10 of the HBM rate: the per-pixel argmax
@@ -679,6 +703,7 @@ __global__ __launch_bounds__(256) void fused_head_kernel(const float* __restrict
   float wy1, wy0;
   bilinear_taps<8>(oy, iy1, wy1, wy0);
   float total[P][CM];
+  int lab[2][P];
 #pragma unroll
   for (int e = 0; e < 2; ++e) {
     f32x4 ta[CM / 4], tb[CM / 4], tc[CM / 4], td[CM / 4];
@@ -698,9 +723,7 @@ __global__ __launch_bounds__(256) void fused_head_kernel(const float* __restrict
       if (!DIRICHLET) {
         int l = head_label_fast<CM>(sc, m, C);
         if (l < 0) l = head_softmax<CM>(sc, m, C);
-        const float* row = tab + ((int64_t)e * C + l) * CM;
-#pragma unroll
-        for (int k = 0; k < CM; ++k) total[p][k] = e == 0 ? row[k] : total[p][k] + row[k];
+        lab[e][p] = l;
       } else {
         head_softmax<CM>(sc, m, C);  // sc = the probabilities the unfused path stores
         float sum = 0.f;
@@ -739,17 +762,21 @@ __global__ __launch_bounds__(256) void fused_head_kernel(const float* __restrict
   int64_t out[P];
 #pragma unroll
   for (int p = 0; p < P; ++p) {
-    float best = 0.f;
-    int bi = 0;
+    if constexpr (!DIRICHLET) {
+      out[p] = dec[lab[0][p] * C + lab[1][p]];
+    } else {
+      float best = 0.f;
+      int bi = 0;
 #pragma unroll
-    for (int k = 0; k < CM; ++k) {
-      const float v = total[p][k] + lp[k];
-      if (k < C && (k == 0 || v > best)) {
-        best = v;
-        bi = k;
+      for (int k = 0; k < CM; ++k) {
+        const float v = total[p][k] + lp[k];
+        if (k < C && (k == 0 || v > best)) {
+          best = v;
+          bi = k;
+        }
       }
+      out[p] = bi;
     }
-    out[p] = bi;
   }
   int64_t* dst = fused + (quad * P);
   if constexpr (P == 4) {
@@ -1365,7 +1392,7 @@ extern "C" int xv_fused_head_fwd(const float* Sa, const float* Sb, const float* 
   const bool pk = !(pk_env && pk_env[0] == '0');
 #define XV_FH(CMV)                                                                                                      \
   {                                                                                                                     \
-    const size_t lds = (size_t)(2 * (mode == 0 ? num_classes : CMV) * CMV + 3 * CMV) * 4;                               \
+    const size_t lds = (size_t)(2 * (mode == 0 ? num_classes : CMV) * CMV + 3 * CMV + (mode == 0 ? num_classes * num_classes : 0)) * 4; \
     if (mode == 0 && num_classes == CMV)                                                                                \
       hipLaunchKernelGGL((fused_head_kernel<CMV, 0, true>), dim3(grid), dim3(256), lds, s, Sa, Sb, bias_a, bias_b, n, hi, \
                          wi, num_classes, tab, lognorm, logprior, fused_label);                                         \

@@ -535,6 +535,37 @@ def test_fused_head_equals_unfused_path(gpu, tmp_path, golden_dir, kind):
     assert np.array_equal(plain.predict(data), ref)
 
 
+@pytest.mark.parametrize('c', [3, 5, 12, 14, 16])
+def test_fused_head_op_equals_decoder_heads_and_fusion_kernels(gpu, c):
+    """Op level, for class counts that fill their template (12, 16) and that do not (3, 5, 14): both experts' 1/8-resolution
+    features -> xv_score_lowres -> xv_fused_head_fwd against decoder head per expert (labels / probabilities in HBM) ->
+    bayes_fuse / dirichlet_fuse.  The Bayes head decides through a [C][C] table its workgroups build from the log-likelihood
+    tables (the sums of bayes_fuse_kernel in its order): labels must be equal bit for bit."""
+    from modular_semantic_segmentation_amd import ops
+    n, hi, wi, u = 2, 5, 7, 64
+    g = torch.Generator().manual_seed(7 * c)
+    dev = 'cuda:0'
+    feats = [ops.Act.from_dense((torch.rand((n, hi, wi, u), generator=g) * 2).to(dev)) for _ in range(2)]
+    ws = [(torch.randn((u, c), generator=g) * 0.3).to(dev) for _ in range(2)]
+    bs = [torch.randn(c, generator=g).to(dev) for _ in range(2)]
+    cp = (c + 3) // 4 * 4
+    S = [torch.zeros((n, hi + 2, wi + 2, cp), device=dev) for _ in range(2)]
+    for e in range(2):
+        ops.score_lowres(feats[e], ws[e], c, S[e])
+    heads = [ops.decoder_head_fwd(feats[e], ws[e], bs[e], c, want_prob=True, want_label=True) for e in range(2)]
+    loglik = torch.randn((2, c, c), generator=g).to(dev)
+    logprior = torch.randn(c, generator=g).to(dev)
+    ref, _ = ops.bayes_fuse([heads[0]['label'], heads[1]['label']], loglik, logprior)
+    got = ops.fused_head(S[0], S[1], bs[0], bs[1], n, hi, wi, c, loglik, logprior)
+    assert ref.unique().numel() > 1
+    assert torch.equal(got, ref)
+    am1 = (torch.rand((2, c, c), generator=g) - 0.5 + 4 * torch.eye(c)).to(dev)
+    lognorm = (torch.randn((2, c), generator=g) * 0.1).to(dev)
+    ref, _ = ops.dirichlet_fuse([heads[0]['prob'], heads[1]['prob']], am1, lognorm, logprior)
+    got = ops.fused_head(S[0], S[1], bs[0], bs[1], n, hi, wi, c, am1, logprior, lognorm=lognorm)
+    assert torch.equal(got, ref)
+
+
 @pytest.mark.parametrize('c', [4, 8, 12, 16])
 @pytest.mark.parametrize('shape', [(1, 3, 5), (2, 6, 4), (3, 7, 9)])
 def test_dirichlet_head_packed_form_equals_scalar_form(gpu, c, shape):
