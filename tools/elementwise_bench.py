@@ -47,7 +47,7 @@ def cases(ops, dev):
     pb = torch.softmax(torch.randn((N, H, W, C), generator=g), -1).to(dev)
     am1 = torch.rand((2, C, C), generator=g).to(dev)
     lognorm = torch.randn((2, C), generator=g).to(dev)
-    out.append(('dirichlet_fuse (probabilities -> fused label)', 'dirichlet_fuse_kernel', npix * (2 * C * 4 + 8),
+    out.append(('dirichlet_fuse (probabilities -> fused label)', 'dirichlet_fuse_pk_kernel', npix * (2 * C * 4 + 8),
                 lambda: ops.dirichlet_fuse([pa, pb], am1, lognorm, logprior)))
     out.append(('average_fuse', 'average_fuse_kernel', npix * (2 * C * 4 + 8), lambda: ops.average_fuse([pa, pb])))
     score = torch.randn((N, H, W, C), generator=g).to(dev)
@@ -79,7 +79,7 @@ def cases(ops, dev):
     low_bytes = 2 * N * (hi + 2) * (wi + 2) * cp * 4
     out.append(('fused_head, Bayes (both experts\' low-res scores -> fused label)', 'fused_head_kernel<12, 0>', npix * 8 + low_bytes,
                 lambda: ops.fused_head(Sa, Sb, bs, bs, N, hi, wi, C, tab, logprior, out=lab_out)))
-    out.append(('fused_head, Dirichlet', 'fused_head_kernel<12, 1>', npix * 8 + low_bytes,
+    out.append(('fused_head, Dirichlet', 'fused_dirichlet_head_pk_kernel<12', npix * 8 + low_bytes,
                 lambda: ops.fused_head(Sa, Sb, bs, bs, N, hi, wi, C, am1, logprior, lognorm=lognorm, out=lab_out)))
     head_out = {}
     out.append(('decoder_head (one expert: features -> label)', 'decoder_head_kernel', npix * 8 + N * hi * wi * U * 2,
