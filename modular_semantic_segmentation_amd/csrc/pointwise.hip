@@ -798,6 +798,8 @@ __global__ __launch_bounds__(256) void fused_head_kernel(const float* __restrict
 // load the LDS pipe about as long as its instructions load the vector ALU.  16 images of 768x384 (tools/dirichlet_head_ab.py):
 // scalar 97-105 us; packed, P = 1: 93-100 (VALU instructions 913 -> 751, the LDS reads as before); P = 2: 82; P = 4: 75 us
 // (162 VGPRs, 3 waves per SIMD -- the scalar form with four pixels had measured 14 % SLOWER than with one).
+// Other class counts, scalar -> this form: 8: 62-69 -> 45-53 us; 16: 135-141 -> 113-121; 20: 185-191 -> 171-178; 24: 254-259 ->
+// 312-314; 32: 396-398 -> 576 (328 / 434 registers): the launcher keeps the scalar form above 20 classes.
 template <int CM, int P>
 __global__ __launch_bounds__(256) void fused_dirichlet_head_pk_kernel(const float* __restrict__ Sa, const float* __restrict__ Sb,
                                                                      const float* __restrict__ ba, const float* __restrict__ bb,
@@ -1399,9 +1401,9 @@ extern "C" int xv_fused_head_fwd(const float* Sa, const float* Sb, const float* 
     else if (mode == 0)                                                                                                 \
       hipLaunchKernelGGL((fused_head_kernel<CMV, 0>), dim3(grid), dim3(256), lds, s, Sa, Sb, bias_a, bias_b, n, hi, wi,  \
                          num_classes, tab, lognorm, logprior, fused_label);                                             \
-    else if (num_classes == CMV && pk)                                                                                  \
-      hipLaunchKernelGGL((fused_dirichlet_head_pk_kernel<CMV, 4>), dim3((grid + 3) / 4), dim3(256), lds, s, Sa, Sb, bias_a, \
-                         bias_b, n, hi, wi, tab, lognorm, logprior, fused_label);                                       \
+    else if (num_classes == CMV && pk && CMV <= 20)                                                                     \
+      hipLaunchKernelGGL((fused_dirichlet_head_pk_kernel<(CMV <= 20 ? CMV : 4), 4>), dim3((grid + 3) / 4), dim3(256), lds, s, \
+                         Sa, Sb, bias_a, bias_b, n, hi, wi, tab, lognorm, logprior, fused_label);                       \
     else if (num_classes == CMV)                                                                                        \
       hipLaunchKernelGGL((fused_head_kernel<CMV, 1, true>), dim3(grid), dim3(256), lds, s, Sa, Sb, bias_a, bias_b, n, hi, \
                          wi, num_classes, tab, lognorm, logprior, fused_label);                                         \

@@ -8,7 +8,7 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-N, H, W, C, U = 16, 384, 768, 12, 64
+N, H, W, C, U = 16, 384, 768, int(sys.argv[1]) if len(sys.argv) > 1 else 12, 64   # argv[1]: another class count
 
 
 def main():
@@ -46,6 +46,8 @@ def main():
         res.setdefault(str(pk), []).append({'us': round(us, 2), 'equal': bool(torch.equal(out, ref)),
                                             'classes_used': int(out.unique().numel())})
     print(json.dumps(res))
+    if C != 12:
+        return
     # the unfused fusion kernel (probability maps -> fused label): XV_DIRICHLET_FUSE_PK = 0 scalar, P pixels per thread packed
     pa = torch.softmax(torch.randn((N, H, W, C), generator=g), -1).to(dev)
     pb = torch.softmax(torch.randn((N, H, W, C), generator=g), -1).to(dev)
