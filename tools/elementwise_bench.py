@@ -77,7 +77,7 @@ def cases(ops, dev):
     tab = torch.randn((2, C, C), generator=g).to(dev)
     lab_out = torch.empty((N, H, W), dtype=torch.int64, device=dev)
     low_bytes = 2 * N * (hi + 2) * (wi + 2) * cp * 4
-    out.append(('fused_head, Bayes (both experts\' low-res scores -> fused label)', 'fused_head_kernel<12, 0>', npix * 8 + low_bytes,
+    out.append(('fused_head, Bayes (both experts\' low-res scores -> fused label)', 'fused_head_kernel<12, 0,', npix * 8 + low_bytes,
                 lambda: ops.fused_head(Sa, Sb, bs, bs, N, hi, wi, C, tab, logprior, out=lab_out)))
     out.append(('fused_head, Dirichlet', 'fused_dirichlet_head_pk_kernel<12', npix * 8 + low_bytes,
                 lambda: ops.fused_head(Sa, Sb, bs, bs, N, hi, wi, C, am1, logprior, lognorm=lognorm, out=lab_out)))
