@@ -553,6 +553,8 @@ def test_fused_head_op_equals_decoder_heads_and_fusion_kernels(gpu, c):
     for e in range(2):
         ops.score_lowres(feats[e], ws[e], c, S[e])
     heads = [ops.decoder_head_fwd(feats[e], ws[e], bs[e], c, want_prob=True, want_label=True) for e in range(2)]
+    for e in range(2):      # the label alone runs four pixels per thread (decoder_head_label4_kernel): the same labels
+        assert torch.equal(ops.decoder_head_fwd(feats[e], ws[e], bs[e], c)['label'], heads[e]['label'])
     loglik = torch.randn((2, c, c), generator=g).to(dev)
     logprior = torch.randn(c, generator=g).to(dev)
     ref, _ = ops.bayes_fuse([heads[0]['label'], heads[1]['label']], loglik, logprior)
