@@ -148,7 +148,16 @@ __global__ __launch_bounds__(256) void upsample2x_bwd_kernel(const __bf16* __res
 __global__ __launch_bounds__(256) void count_valid_kernel(const int32_t* __restrict__ labels, int C, int64_t npix,
                                                          unsigned long long* __restrict__ count) {
   unsigned int c = 0;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < npix; i += (int64_t)gridDim.x * 256) {
+  // four labels per 16-byte load (the 19 MB label map of 16 images took 20 us through 4-byte loads), the last npix % 4 alone
+  typedef int i32x4 __attribute__((ext_vector_type(4)));
+  const bool vec = ((uintptr_t)labels & 15) == 0;
+  const int64_t nquads = vec ? npix >> 2 : 0;
+  for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < nquads; q += (int64_t)gridDim.x * 256) {
+    const i32x4 l = *reinterpret_cast<const i32x4*>(labels + 4 * q);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) c += ((unsigned)l[j] < (unsigned)C) ? 1u : 0u;
+  }
+  for (int64_t i = 4 * nquads + (int64_t)blockIdx.x * 256 + threadIdx.x; i < npix; i += (int64_t)gridDim.x * 256) {
     const int l = labels[i];
     c += (l >= 0 && l < C) ? 1u : 0u;
   }
