@@ -372,23 +372,39 @@ __global__ __launch_bounds__(1024) void head_bwd_lowres_kernel(const float* __re
     const int n = (int)(idx / ((int64_t)Wi * Hi));
     // along x over kernel 1's row sums: 1/8-resolution row i collects slot 1 of its own column block, slot 0 of the
     // block below and slot 2 of the block above; this thread takes 4 of the 16 footprint columns
-    for (int ox = 8 * j - 4 + 4 * q; ox < 8 * j + 4 * q; ++ox) {
-      if (ox < 0 || ox >= Wo) continue;
-      const float w = bilinear_w<8>(ox, j);
+    // branch-free: a column / row block outside the map is read at a clamped (valid, finite) position with weight 0 --
+    // fmaf(0, g, ds) = ds exactly (ds is never -0) -- so that a column's 3 CM / 4 loads are requested together and the next
+    // column's may follow without waiting for a range check
+    // (one column = 3 CM / 4 vectors at a time: more in flight would not fit the 128 registers of a 1 024-thread workgroup)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      f32x4 g[3][CM / 4];
+      float wv[3];
+      const int ox = 8 * j - 4 + 4 * q + c;
+      const bool okx = ox >= 0 && ox < Wo;
+      const int oxc = ox < 0 ? 0 : (ox >= Wo ? Wo - 1 : ox);
+      const float w = bilinear_w<8>(oxc, j);
 #pragma unroll
       for (int sl = 0; sl < 3; ++sl) {
         const int ib = i + 1 - sl;  // the column block whose slot sl targets row i
-        if (ib < 0 || ib >= Hi) continue;
-        const float* src = P + ((((int64_t)n * Hi + ib) * 3 + sl) * Wo + ox) * CM;
+        const bool ok = okx && ib >= 0 && ib < Hi;
+        const int ibc = ib < 0 ? 0 : (ib >= Hi ? Hi - 1 : ib);
+        wv[sl] = ok ? w : 0.f;
+        const float* src = P + ((((int64_t)n * Hi + ibc) * 3 + sl) * Wo + oxc) * CM;
 #pragma unroll
-        for (int k4 = 0; k4 < CM; k4 += 4) {
-          const f32x4 g = *reinterpret_cast<const f32x4*>(src + k4);
-          ds[k4] = fmaf(w, g.x, ds[k4]);
-          ds[k4 + 1] = fmaf(w, g.y, ds[k4 + 1]);
-          ds[k4 + 2] = fmaf(w, g.z, ds[k4 + 2]);
-          ds[k4 + 3] = fmaf(w, g.w, ds[k4 + 3]);
-        }
+        for (int k4 = 0; k4 < CM / 4; ++k4) g[sl][k4] = *reinterpret_cast<const f32x4*>(src + 4 * k4);
       }
+#pragma unroll
+      for (int sl = 0; sl < 3; ++sl)
+#pragma unroll
+        for (int k4 = 0; k4 < CM / 4; ++k4) {
+          const float ww = wv[sl];
+          ds[4 * k4] = fmaf(ww, g[sl][k4].x, ds[4 * k4]);
+          ds[4 * k4 + 1] = fmaf(ww, g[sl][k4].y, ds[4 * k4 + 1]);
+          ds[4 * k4 + 2] = fmaf(ww, g[sl][k4].z, ds[4 * k4 + 2]);
+          ds[4 * k4 + 3] = fmaf(ww, g[sl][k4].w, ds[4 * k4 + 3]);
+        }
+      if (c & 1) asm volatile("" ::: "memory");  // at most two columns' loads in flight
     }
     pad_off = (((int64_t)n * (Hi + 2) + (i + 1)) * (Wi + 2) + (j + 1)) * U;
   }
@@ -427,8 +443,10 @@ __global__ __launch_bounds__(1024) void head_bwd_lowres_kernel(const float* __re
   for (int cell = threadIdx.x; cell < U * CM; cell += 1024) {
     const int u = cell / CM, k = cell - u * CM;
     float a = 0.f;
-    if (k < C)
-      for (int px = 0; px < 256; ++px) a = fmaf((float)fm[px * U + u], dsm[px * CM + k], a);
+    if (k < C) {
+#pragma unroll 8
+      for (int px = 0; px < 256; ++px) a = fmaf((float)fm[px * U + u], dsm[px * CM + k], a);  // (one chain, in pixel order)
+    }
     dws_part[(int64_t)blockIdx.x * U * CM + cell] = a;
   }
 }
