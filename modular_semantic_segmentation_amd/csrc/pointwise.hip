@@ -672,7 +672,7 @@ __global__ __launch_bounds__(256) void decoder_head_label4_kernel(const float* _
 // every per-pixel intermediate between them (Bayes: two int64 label maps written and read back; Dirichlet: two fp32
 // probability maps, 2 x 4C B per pixel each way).  The fusion arithmetic is the one of fusion.hip's kernels, term for
 // term, on the values the unfused path would have stored.  Tables in LDS: tab [2][C][CM], lognorm [2][CM] (Dirichlet),
-// logprior [CM].
+// logprior [CM], dec [C][C] (Bayes: the decision per label pair, built by the workgroup).
 // FULL: the class count IS CM (the 12 classes of the headline model): every `k < C` folds away -- 165 of the Dirichlet
 // form's ~800 vector instructions per pixel were compare-selects on the run-time class count.
 template <int CM, int DIRICHLET, bool FULL = false, int P = (DIRICHLET ? 1 : 4)>
@@ -1443,7 +1443,7 @@ extern "C" int xv_fused_head_fwd(const float* Sa, const float* Sb, const float* 
     else if (mode == 0)                                                                                                 \
       hipLaunchKernelGGL((fused_head_kernel<CMV, 0>), dim3(grid), dim3(256), lds, s, Sa, Sb, bias_a, bias_b, n, hi, wi,  \
                          num_classes, tab, lognorm, logprior, fused_label);                                             \
-    else if (num_classes == CMV && pk && CMV <= 20)                                                                     \
+    else if (num_classes == CMV && pk && CMV <= 20) /* (the template argument below only keeps CMV > 20 from instantiating) */ \
       hipLaunchKernelGGL((fused_dirichlet_head_pk_kernel<(CMV <= 20 ? CMV : 4), 4>), dim3((grid + 3) / 4), dim3(256), lds, s, \
                          Sa, Sb, bias_a, bias_b, n, hi, wi, tab, lognorm, logprior, fused_label);                       \
     else if (num_classes == CMV)                                                                                        \
