@@ -554,14 +554,21 @@ __device__ __forceinline__ float head_max(const float (&sc)[CM], int C) {
 // (lowest index among equal PROBABILITIES) need the probabilities themselves.  Returns -1 in that case.
 template <int CM>
 __device__ __forceinline__ int head_label_fast(const float (&sc)[CM], float m, int C) {
-  int bi = 0, near = 0;
+  // exactly one k with (m - sc[k]) <= 1e-5 (the maximum itself)  <=>  the SECOND largest value, duplicates counted, is more
+  // than 1e-5 below m (the subtraction is monotone in sc[k]): s2 = med3(s1, s2, x) under the running maximum s1.  Counting the
+  // near classes cost a subtraction, a compare and an add per class: 2 242 -> 1 822 vector instructions in the fused Bayes head.
+  float s1 = sc[0], s2 = -__builtin_inff();
+  int bi = 0;
+#pragma unroll
+  for (int k = 1; k < CM; ++k)
+    if (k < C) {
+      s2 = __builtin_amdgcn_fmed3f(s1, s2, sc[k]);
+      s1 = fmaxf(s1, sc[k]);
+    }
 #pragma unroll
   for (int k = CM - 1; k >= 0; --k)
-    if (k < C) {
-      if (sc[k] == m) bi = k;
-      near += (m - sc[k]) <= 1e-5f ? 1 : 0;
-    }
-  return near == 1 ? bi : -1;
+    if (k < C && sc[k] == m) bi = k;
+  return (m - s2) <= 1e-5f ? -1 : bi;
 }
 
 // sc <- softmax(sc) (tf.nn.softmax: exp(x - max) / sum); returns the label, lowest index on ties
