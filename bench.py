@@ -476,7 +476,118 @@ def host_fit_rate(device, data, batch, steps=32):
     return out
 
 
-def make_trainer_net(args, device, expert, joint, batch):
+def committed_gpu_busy(name):
+    """GPU-busy fraction of the training step from the committed kernel trace of the same command (tools/dp_regime.sh ->
+    tools/gpu_busy.py: union of the kernel intervals / wall time over whole steps) -- a trace cannot be taken from inside the
+    process.  None when the record is not in profiles/."""
+    pdir = os.path.join(ROOT, 'profiles')
+    files = sorted(f for f in os.listdir(pdir) if f.endswith('_train_%s_gpu_busy.json' % name)) if os.path.isdir(pdir) else []
+    if not files:
+        return None
+    rec = json.load(open(os.path.join(pdir, files[-1])))
+    rec['source'] = 'profiles/' + files[-1]
+    rec.pop('largest_gaps_us', None)
+    return rec
+
+
+def dp_regime_records(args, device, dist):
+    """The data-parallel regime on ONE GPU: the training step at 4 images -- the reference's shipped batchsize
+    (experiments/example_config.yaml:18; with batch_normalization: true, :27) and the per-rank batch of a 32-image step on 8
+    GPUs -- next to the 16-image step, plain and with batch norm, each with images/s per image relative to its 16-image form
+    and the GPU-busy fraction of the committed kernel trace (is the chip waiting for the host's eager launches?)."""
+    out = []
+    ref = {}
+    for bn in (False, True):
+        for b in (16, 4):
+            if b == 16 and not bn:
+                continue        # the 16-image plain step is the record in front of these
+            tr = measure_training(args, device, 1, 0, dist, b, 8, 2, batch_norm=bn)
+            tr['workload'] = ('SimpleFCN RGB expert training step 768x384 (fwd + bwd + Adam%s), %d images%s'
+                              % (', batch_normalization=true' if bn else '', b,
+                                 ' -- the reference\'s shipped batchsize / the per-rank batch of a 32-image DP-8 step' if b == 4 else ''))
+            if b == 4:
+                tr['gpu_busy'] = committed_gpu_busy('b4_%s' % ('bn' if bn else 'plain'))
+            ref[(bn, b)] = tr['value']
+            out.append(tr)
+    return out, ref
+
+
+def dirichlet_fit_record(device, batch=4, h=1024, w=2048, nbatches=4):
+    """BASELINE configs[3]'s own workload: DirichletFusion.fit() at 2048x1024 (dirichlet_mix.py:175-273) -- both experts'
+    forward to class probabilities, the sufficient statistics S[c,k] = sum_{label=c} log(1e-10 + p[k]) on the device
+    (suffstats_kernel), the [C,C] reduction to the host, the Newton fit of the class-conditional Dirichlets on the host
+    (dirichlet_fit.py).  Inputs resident in HBM; images/s counts RGB-D pairs through the statistics pass; the host fit is
+    timed beside it (it does not depend on the number of images)."""
+    from modular_semantic_segmentation_amd import ops
+    net = build_model(device, fusion='dirichlet', batch=batch)
+    n = batch * nbatches
+    gen = torch.Generator(device='cpu').manual_seed(5)
+    one = {'rgb': torch.randint(0, 256, (batch, h, w, 3), generator=gen).float().to(device),
+           'depth': torch.randint(0, 65536, (batch, h, w, 1), generator=gen).float().to(device),
+           'labels': torch.randint(0, C, (batch, h, w), generator=gen).int().to(device)}
+    data = {k: v.repeat((nbatches,) + (1,) * (v.dim() - 1)) for k, v in one.items()}
+    # random-init experts saturate their softmax (logits of scale 1e2: log(1e-10 + p) = -23 for eleven of twelve classes, a
+    # statistic no trained expert produces and on which the host fit runs its 10 000 iterations per class): scale each
+    # expert's score layer so that its logits have unit spread, as a trained expert's do
+    from modular_semantic_segmentation_amd.basic_fusion_model import run_experts
+    outs = run_experts(net, {k: v[:1] for k, v in one.items()}, ('score',))
+    for m in net.modalities:
+        spread = float(outs[m]['score'].std())
+        for key in ('%s/score/kernel' % m, '%s/score/bias' % m):
+            net.variables[key] = net.variables[key] / max(spread, 1e-6)
+    net._variables_changed()
+    net._get_sufficient_statistic(one)                         # warm-up: buffers, first-use costs
+    torch.cuda.synchronize(device)
+    best = None
+    for _ in range(3):
+        t0 = time.perf_counter()
+        S, counts = net._get_sufficient_statistic(data)
+        torch.cuda.synchronize(device)
+        dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+    t0 = time.perf_counter()
+    net._fit_sufficient_statistic(S, counts)
+    t_host = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    params = net.fit(data)
+    torch.cuda.synchronize(device)
+    t_fit = time.perf_counter() - t0
+    # the statistics kernel alone: HIP events over 50 launches on one expert's probability map of one batch
+    prob = torch.softmax(torch.randn((batch, h, w, C), generator=torch.Generator(device='cpu').manual_seed(6)), -1).to(device)
+    S1 = torch.zeros((C, C), dtype=torch.float64, device=device)
+    cnt = torch.zeros(C, dtype=torch.int64, device=device)
+    for _ in range(3):
+        ops.dirichlet_suffstats(prob, one['labels'], S1, cnt)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(50):
+        ops.dirichlet_suffstats(prob, one['labels'], S1, cnt)
+    e1.record()
+    torch.cuda.synchronize(device)
+    sec = e0.elapsed_time(e1) * 1e-3 / 50
+    nbytes = batch * h * w * (4 * C + 4)                        # 12 float32 probabilities + one int32 label per pixel
+    flops_img = conv_flops_per_image(h, w, 3) + conv_flops_per_image(h, w, 1)
+    rec = {'workload': 'configs[3] fit: DirichletFusion.fit() at %dx%d, %d RGB-D images in batches of %d (two SimpleFCN experts -> '
+                       'probabilities -> sufficient statistics -> host Newton fit), U=%d, C=%d' % (w, h, n, batch, U, C),
+           'images_per_step': batch, 'dtype': 'bf16', 'unit': 'images/s',
+           'value': round(n / best, 2), 'ms_per_step': round(best / nbatches * 1e3, 3),
+           'statistics_pass_s': round(best, 4), 'host_newton_fit_s': round(t_host, 4), 'fit_total_s': round(t_fit, 4),
+           'fit_images_per_s_incl_host_fit': round(n / t_fit, 2),
+           'conv_tflops_end_to_end': round(n * flops_img / best / 1e12, 2),
+           'roofline_suffstats': {'bound': 'hbm', 'kernel': 'suffstats_kernel (fusion.hip): one expert, one batch', 'achieved': round(nbytes / sec / 1e9, 1),
+                                  'peak': 8000.0, 'unit': 'GB/s', 'frac': round(nbytes / sec / 8e12, 4), 'traffic': None,
+                                  'avg_launch_ms': round(sec * 1e3, 4), 'bytes_per_launch': nbytes,
+                                  'measured': 'HIP events over 50 launches'},
+           'params_finite': bool(all(np.isfinite(np.asarray(params[m])).all() for m in net.modalities)),
+           'note': 'random-init experts with the score layer scaled to unit logit spread (a saturated softmax makes the host fit '
+                   'run its 10 000 iterations per class: 9.4 s); the host fit is the reference\'s own numpy procedure '
+                   '(dirichletDifferentiation.py:129-192 restated) and does not depend on the number of images'}
+    del net
+    torch.cuda.empty_cache()
+    return rec
+
+
+def make_trainer_net(args, device, expert, joint, batch, batch_norm=None):
     from modular_semantic_segmentation_amd import get_model
     desc = ({'rgb': 'float32', 'labels': 'int32'}, {'rgb': (None, None, 3), 'labels': (None, None)}, C)
     if joint:
@@ -489,13 +600,15 @@ def make_trainer_net(args, device, expert, joint, batch):
         net = get_model('adapnet')(desc, modality='rgb', num_units=U, batchsize=batch, learning_rate=1e-4,
                                    trainer='adam', seed=1, device=str(device), sync_loss=False)
     else:
-        net = get_model('fcn')('rgb', desc, 'rgb', num_units=U, batch_normalization=bool(args.batch_norm),
+        net = get_model('fcn')('rgb', desc, 'rgb', num_units=U,
+                               batch_normalization=bool(args.batch_norm if batch_norm is None else batch_norm),
                                batchsize=batch, learning_rate=1e-4, trainer='adam', seed=1, device=str(device),
                                sync_loss=False)
     return net
 
 
-def measure_training(args, device, world, rank, dist, batch, steps, warmup, expert='fcn', joint=False, h=None, w=None):
+def measure_training(args, device, world, rank, dist, batch, steps, warmup, expert='fcn', joint=False, h=None, w=None,
+                     batch_norm=None):
     """Data-parallel expert training: every rank differentiates its own images, gradients are all-reduced in buckets on
     a side stream during backward (RCCL over xGMI).  Returns a record with images/s, the roofline of the MFMA convs
     (forward + data gradient + filter gradient FLOPs over their summed HIP-event times) and, for N > 1, the exposed
@@ -507,7 +620,7 @@ def measure_training(args, device, world, rank, dist, batch, steps, warmup, expe
             'labels': torch.randint(-1, C, (batch, h, w), generator=gen).int().to(device)}
     if joint:
         data['depth'] = torch.randint(0, 65536, (batch, h, w, 1), generator=gen).float().to(device)
-    net = make_trainer_net(args, device, expert, joint, batch)
+    net = make_trainer_net(args, device, expert, joint, batch, batch_norm)
 
     def timed(n, min_seconds=1.0):
         return timed_blocks(lambda: net._train_batch(data), n, device, world, dist, min_seconds)
@@ -542,7 +655,7 @@ def measure_training(args, device, world, rank, dist, batch, steps, warmup, expe
     ops.CONV_PROFILE = prof
     torch.cuda.synchronize(device)
     try:
-        for _ in range(min(steps, 5)):
+        for _ in range(0 if getattr(args, 'no_roofline_pass', False) else min(steps, 5)):
             net._train_batch(data)
         torch.cuda.synchronize(device)
     finally:
@@ -618,6 +731,8 @@ def main():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--batch-norm', action='store_true', help='train mode: the batch_normalization=true training graph')
     ap.add_argument('--layer-profile', action='store_true', help='print per-conv-launch times of the roofline pass')
+    ap.add_argument('--no-roofline-pass', action='store_true',
+                    help='train mode: skip the per-launch HIP-event pass after the timed region (kernel traces of the step alone)')
     ap.add_argument('--batch', type=int, default=16, help='images per GPU per step')
     ap.add_argument('--height', type=int, default=384)
     ap.add_argument('--width', type=int, default=768)
@@ -631,6 +746,8 @@ def main():
                     help="'infer' (headline): two experts + fusion; 'train': one SimpleFCN training step (fwd+bwd+Adam)")
     ap.add_argument('--fp8-deep', action='store_true',
                     help="--dtype fp8: e4m3 operands from conv1_2 on (model config fp8_deep: faster, costs accuracy)")
+    ap.add_argument('--record', default=None, choices=['dirichlet_fit', 'dp_regime'],
+                    help='print ONE of the extra records alone (N = 1) instead of the headline line')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-accuracy', action='store_true', help='skip the trained-experts accuracy evidence (N = 1 only)')
     ap.add_argument('--accuracy-steps', type=int, default=1500)
@@ -686,6 +803,14 @@ def main():
     device = torch.device('cuda', local_rank)
     torch.cuda.set_device(device)
 
+    if args.record is not None:
+        if args.record == 'dirichlet_fit':
+            rec = dirichlet_fit_record(device)
+        else:
+            recs, ref = dp_regime_records(args, device, dist)
+            rec = {'records': recs}
+        print(json.dumps(rec), file=_JSON_OUT, flush=True)
+        return
     if args.mode == 'train':
         return bench_train(args, device, world, rank, dist)
     default_line = (args.fusion, args.expert, args.dtype, args.height, args.width) == ('bayes', 'fcn', 'bf16', 384, 768)
@@ -844,6 +969,19 @@ def main():
                 tr['workload'] = 'SimpleFCN RGB expert training step 768x384 (fwd + bwd + Adam), 16 images'
                 return tr
             guarded(training_record)
+
+            def regime():
+                recs, ref = dp_regime_records(args, device, dist)
+                base = {False: next((e.get('value') for e in extra if str(e.get('workload', '')).startswith(
+                    'SimpleFCN RGB expert training step 768x384 (fwd + bwd + Adam), 16 images')), None), True: ref.get((True, 16))}
+                for r in recs:
+                    bn = 'batch_normalization' in r['workload']
+                    if r['images_per_gpu_per_step'] == 4 and base[bn]:
+                        r['images_per_s_relative_to_the_16_image_step'] = round(r['value'] / base[bn], 4)
+                extra.extend(recs[:-1])
+                return recs[-1]
+            guarded(regime)
+            guarded(dirichlet_fit_record, device)
         if extra:
             res['extra'] = extra
     elif world > 1 and not args.no_extra and default_line:

@@ -130,7 +130,8 @@ class BaseModel(object):
 
     def _graph_capturable(self):
         """May predict() / score() capture the inference step into a hipGraph on their own?  Off by config
-        (`auto_graph: False`), after a failed attempt, and for models whose step has host-side state."""
+        (`auto_graph: False`) and after a failed attempt (a step with a host synchronisation inside fails its first capture
+        and stays eager)."""
         return self.config.get('auto_graph', True) and not getattr(self, '_graph_failed', False)
 
     def _predict_batch_auto(self, batch, output_attr, state):
@@ -138,7 +139,9 @@ class BaseModel(object):
         third is the capture's warm-up and first replay): ~50 launches on two streams become one graph launch.  A model
         whose step cannot be captured (a host synchronisation inside it) falls back to eager launches for good."""
         if output_attr is None and self._graph_capturable() and self.device.type == 'cuda':
-            sig = tuple(sorted((k, tuple(v.shape)) for k, v in batch.items() if k != 'labels'))
+            # (the keys capture_graph makes static: an extra key in the batch must not make every batch look new)
+            sig = tuple(sorted((k, tuple(v.shape)) for k, v in batch.items()
+                               if k != 'labels' and k in self.testdata_description[0]))
             state['count'] = state.get('count', 0) + 1 if state.get('sig') == sig else 1
             state['sig'] = sig
             g = getattr(self, '_graph', None)

@@ -36,6 +36,17 @@ FP8_CALIBRATION = os.environ.get('XV_FP8_CALIBRATION', 'max')
 FP8_DEFAULT_START = 'conv2_2'
 
 
+def padded_units(num_units):
+    """Lanes the `num_units`-channel decoder maps are padded to (zero weights, zero maps): 64, 128 or 256 -- the widths every
+    kernel behind them takes, the batch-norm passes of training included (batchnorm.hip: C >= 64, 2048 % C == 0; a 192-lane
+    map has no statistics kernel) -- and multiples of 64 beyond 256 (inference; the batch-norm trainers refuse those)."""
+    u = int(num_units)
+    for lanes in (64, 128, 256):
+        if u <= lanes:
+            return lanes
+    return (u + 63) // 64 * 64
+
+
 def fp8_plan(h=None, w=None, deep=False, start=None):
     """(convs with e4m3 operands, conv outputs stored as e4m3) of conv_dtype='fp8': the convs from `start` on take e4m3
     operands, the conv in front of `start` is a bf16 conv that writes the first e4m3 map.
@@ -48,12 +59,14 @@ def fp8_plan(h=None, w=None, deep=False, start=None):
       start='conv2_1' (model config `fp8_start`; the default of rounds 2-4): conv1_2 writes the first e4m3 map (pool1).
       deep=True (model config `fp8_deep`) = start='conv1_2': conv1_1 writes the first e4m3 map: +14 % images/s at 2048x1024,
           depth expert -6.5 points.
-    Any later layer may be named as well.  oracle/fcn_oracle.py states the same rule.  (h, w: unused since the kernels handle
-    partial tiles; kept for callers.)"""
+    Any later layer up to conv5_1 may be named as well (the 1x1 score convs read conv4_3 / conv5_3 with e4m3-packed weights:
+    a plan that leaves either map in bf16 would hand bf16 operands to those weights).  oracle/fcn_oracle.py states the same
+    rule.  (h, w: unused since the kernels handle partial tiles; kept for callers.)"""
     names = [n for n, _, _ in ENCODER]
     start = start or ('conv1_2' if deep else FP8_DEFAULT_START)
-    if start not in names[1:]:
-        raise ValueError('fp8_start must be one of %s' % names[1:])
+    allowed = names[1:names.index('conv5_1') + 1]
+    if start not in allowed:
+        raise ValueError('fp8_start must be one of %s' % allowed)
     i = names.index(start)
     return tuple(names[i:]), tuple(names[i - 1:])
 
@@ -151,7 +164,7 @@ class FcnEngine(object):
                  streamk=False, fp8_deep=False, fp8_start=None):
         self.prefix, self.cin, self.U, self.C = prefix, int(in_channels), int(num_units), int(num_classes)
         self.device = torch.device(device)
-        self.Up = ((self.U + 63) // 64) * 64      # score convs run on the MFMA kernel: pad U to 64 lanes of zeros
+        self.Up = padded_units(self.U)            # score convs run on the MFMA kernel: pad U to 64 / 128 / 256 / ... lanes of zeros
         if conv_dtype not in ('bf16', 'fp8'):
             raise ValueError("conv_dtype must be 'bf16' or 'fp8'")
         self.conv_dtype = conv_dtype

@@ -16,7 +16,7 @@ import torch
 from . import ops
 from .base_model import BaseModel
 from .custom_layers import bilinear_filter, dense_deconv_as_conv3x3, is_bilinear_filter
-from .fcn import BN_EPS, ENCODER, _fold_bn
+from .fcn import BN_EPS, ENCODER, _fold_bn, padded_units
 
 
 def vgg16_variable_shapes(prefix, in_channels):
@@ -138,7 +138,7 @@ class FusionFcnEngine(object):
         self.prefixes = dict(prefixes)
         self.num_channels = {m: int(num_channels[m]) for m in self.prefixes}
         self.U, self.C = int(num_units), int(num_classes)
-        self.Up = ((self.U + 63) // 64) * 64
+        self.Up = padded_units(self.U)
         self.device = torch.device(device)
         self._arena = {}
         self.trunks = {}

@@ -811,8 +811,8 @@ def _sync_sums(st, sync):
     (parallel.require_equal_batchsize)."""
     if not sync:
         return 1
-    from .parallel import allreduce_sum_, world
-    allreduce_sum_(st.sums)
+    from .parallel import allreduce_stats_, world
+    allreduce_stats_(st.sums)           # on a communicator of its own: never queued behind a gradient bucket in flight
     return world()[1]
 
 

@@ -38,6 +38,35 @@ def allreduce_sum_(*tensors):
     return tensors
 
 
+_STATS_GROUP = {}
+
+
+def stats_group():
+    """A second process group (its own RCCL communicator, hence its own collective stream) for the Sync-BN moment
+    all-reduces.  They sit ON the critical path of the step -- a layer cannot be normalised before its global statistics
+    exist -- while the gradient buckets of GradReducer are in flight beside it: on one communicator a 2*C-double all-reduce
+    issued behind a 28 MB bucket waits for the whole bucket's wire time (collectives of one communicator run in issue
+    order).  Created collectively the first time any rank needs it: every rank reaches its first Sync-BN layer at the same
+    point of the same program.  None for a single process."""
+    _, size = world()
+    if size == 1:
+        return None
+    key = id(dist.group.WORLD)
+    if key not in _STATS_GROUP:
+        _STATS_GROUP.clear()                   # (a process group of an earlier init_process_group is gone)
+        _STATS_GROUP[key] = dist.new_group(backend=dist.get_backend())
+    return _STATS_GROUP[key]
+
+
+def allreduce_stats_(*tensors):
+    """In-place sum over ranks on stats_group() (the Sync-BN moments: 2*C doubles per layer and direction)."""
+    group = stats_group()
+    if group is not None:
+        for t in tensors:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return tensors
+
+
 def broadcast_(*tensors, src=0):
     """In-place broadcast from rank `src` (no-op for a single process)."""
     _, size = world()

@@ -37,6 +37,28 @@ def encoder(inputs, prefix, num_units, dropout_rate=0.0, variables=None, num_cla
         eng.set_dropout((), 0.0)
 
 
+def decoder(features, prefix, num_units, num_classes, trainable=True, is_training=False, reuse=None, dropout_rate=None,
+            batchnorm=True, variables=None, dropout_seed=0):
+    """simple_fcn.py:90-134 under its own name: {'upscore': x8 bilinear deconv [+ batch norm] + relu of `features` (ops.Act,
+    N x 8h x 8w x num_units), 'score': its 1x1 conv onto num_classes [+ batch norm], dense float32 [N,8h,8w,C]} -- the
+    un-commuted form, layer by layer through custom_layers.deconv2d / conv2d (the engines' own decoder commutes the score
+    conv in front of the deconv and never writes `upscore`; this is the entry point fusion_fcn.py:4-7 imports, for callers
+    that want the layer dict).  features: ops.Act or dense float32 [N,h,w,num_units]; variables: reference-schema dict with
+    `<prefix>/upscore/...` (kernel optional: the bilinear constant) and `<prefix>/score/...`; dropout_rate: dropout on the
+    input features (always training=True, simple_fcn.py:124-126)."""
+    from . import custom_layers as cl, ops
+    x = cl._as_act(features)
+    if dropout_rate:
+        x = ops.dropout(x, float(dropout_rate), int(dropout_seed))
+    up = cl.deconv2d(x, num_units, [16, 16], strides=[8, 8], name='upscore', activation='relu', padding='same',
+                     batch_normalization=batchnorm, training=is_training, trainable=False, reuse=reuse,
+                     variables=variables, scope=prefix)
+    score = cl.conv2d(up, num_classes, [1, 1], name='score', activation=None, padding='same',
+                      batch_normalization=batchnorm, training=is_training, trainable=trainable, reuse=reuse,
+                      variables=variables, scope=prefix)
+    return {'upscore': up, 'score': score}
+
+
 def fcn(inputs, prefix, num_units, num_classes, variables=None, dropout_rate=0.0, dropout_layers=(), dropout_seed=0,
         **unused):
     """Functional form of simple_fcn.py:137-170 as experiments/timing.py uses it: all encoder layers plus

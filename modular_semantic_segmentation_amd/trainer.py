@@ -25,6 +25,13 @@ _VIRTUAL_UPSCORE = os.environ.get('XV_VIRTUAL_UPSCORE', '1') != '0'
 # filter gradients on a second HIP stream (encoder_backward); XV_WGRAD_STREAM=0: everything on one stream (A/B timing)
 _WGRAD_STREAM = os.environ.get('XV_WGRAD_STREAM', '1') != '0'
 
+
+def _ups8_channels_ok(c):
+    """Channel counts the batch-norm kernels take (batchnorm.hip: c >= 64 and 2048 % c == 0 -- 64, 128, 256, ...; the
+    xv_bn_*_ups8 entry points, ups_ok, the same).  fcn.padded_units pads num_units <= 256 to one of them (129..192 used to be
+    padded to 192 lanes, for which no statistics kernel exists: batch-norm training failed with XV_ESHAPE)."""
+    return c >= 64 and 2048 % c == 0
+
 # backward order of the trainable layers
 LAYER_ORDER = ['score', 'score_conv5', 'score_conv4'] + [name for name, _, _ in reversed(ENCODER)]
 BUCKETS = [['score', 'score_conv5', 'score_conv4', 'conv5_3', 'conv5_2', 'conv5_1'],
@@ -318,6 +325,12 @@ class FcnTrainer(object):
 # =========================================================================================================
 BN_LAYERS = [name for name, _, _ in ENCODER] + ['score_conv4', 'score_conv5', 'upscore_conv5', 'upscore', 'score']
 BN_ORDER = ['score', 'upscore', 'score_conv5', 'upscore_conv5', 'score_conv4'] + [name for name, _, _ in reversed(ENCODER)]
+# gradient buckets of the data-parallel step, contiguous runs of BN_ORDER (every layer's kernel, bias, gamma and beta lie
+# together): a bucket is complete once the filter gradient of its LAST layer has been enqueued (FcnTrainer's BUCKETS with the
+# head's batch norms in the first one)
+BN_BUCKETS = [BN_ORDER[:5] + ['conv5_3', 'conv5_2', 'conv5_1'], ['conv4_3', 'conv4_2', 'conv4_1'],
+              ['conv3_3', 'conv3_2', 'conv3_1', 'conv2_2', 'conv2_1', 'conv1_2', 'conv1_1']]
+assert [n for b in BN_BUCKETS for n in b] == BN_ORDER
 
 
 class FcnBnTrainer(object):
@@ -336,6 +349,9 @@ class FcnBnTrainer(object):
             raise KeyError(trainer)
         self.e, self.kind, self.lr = engine, trainer, float(learning_rate)
         e, dev = engine, engine.device
+        if not _ups8_channels_ok(e.Up):
+            raise ValueError('batch-norm training: num_units = %d is padded to %d lanes; the batch-norm kernels take 64, 128 '
+                             'or 256 (num_units <= 256)' % (e.U, e.Up))
         self.convs = {}                      # conv layers: (kernel shape, cout)
         cin = e.cin
         for name, cout, _ in ENCODER:
@@ -347,15 +363,19 @@ class FcnBnTrainer(object):
         self.bn_channels = {name: self.convs[name][1] for name in self.convs}
         self.bn_channels.update(upscore_conv5=e.Up, upscore=e.Up)
         self.offsets, total = {}, 0
-        for name in BN_ORDER:
-            entries = []
-            if name in self.convs:
-                entries += [('kernel', self.convs[name][0]), ('bias', (self.convs[name][1],))]
-            entries += [('gamma', (self.bn_channels[name],)), ('beta', (self.bn_channels[name],))]
-            for kind, shape in entries:
-                n = int(np.prod(shape))
-                self.offsets[(name, kind)] = (total, n, shape)
-                total += (n + 63) // 64 * 64
+        self.bucket_ranges = []
+        for bucket in BN_BUCKETS:
+            b0 = total
+            for name in bucket:
+                entries = []
+                if name in self.convs:
+                    entries += [('kernel', self.convs[name][0]), ('bias', (self.convs[name][1],))]
+                entries += [('gamma', (self.bn_channels[name],)), ('beta', (self.bn_channels[name],))]
+                for kind, shape in entries:
+                    n = int(np.prod(shape))
+                    self.offsets[(name, kind)] = (total, n, shape)
+                    total += (n + 63) // 64 * 64
+            self.bucket_ranges.append((b0, total))
         self.total = total
         self.param = torch.zeros(total, dtype=torch.float32, device=dev)
         self.grad = torch.zeros(total, dtype=torch.float32, device=dev)
@@ -551,7 +571,8 @@ class FcnBnTrainer(object):
         # The x8 deconv's output (0.6 GB at 16 images) is not stored: the four batch-norm passes that would read it back
         # recompute it from `fused` per element (ops.bn_forward / bn_backward, ups8_of=).  Data-parallel runs (statistics
         # all-reduced between the passes) and keep_all (inspection) keep the stored map.
-        virtual_up = _VIRTUAL_UPSCORE and not self._sync and not self.keep_all and self.bn['upscore'].ws is not None
+        virtual_up = (_VIRTUAL_UPSCORE and not self._sync and not self.keep_all and self.bn['upscore'].ws is not None
+                      and _ups8_channels_ok(e.Up))
         score_raw = None
         if virtual_up:
             Z['upscore'] = None
@@ -613,6 +634,19 @@ class FcnBnTrainer(object):
                 self._wstream = torch.cuda.Stream(device=x.device)
             wstream, main = self._wstream, torch.cuda.current_stream(x.device)
         g_is_pooled = False     # g is the gradient of the layer's POOLED output (routed inside the batch-norm passes)
+        buckets_done = 0
+
+        def bucket_ready(nm):
+            # Called right behind the enqueue of layer nm's filter gradient, on the stream that carries it.  That stream is
+            # ordered behind everything the bucket holds: the filter gradient waited for the event recorded on the main stream
+            # after dz_<nm>, i.e. after this layer's and every earlier layer's dgamma / dbeta (main stream) and after the head's
+            # gradients; earlier filter gradients precede it on the same stream.  So the bucket's all-reduce (side stream,
+            # parallel.GradReducer) starts while the layers below are still differentiating, as in FcnTrainer.step.
+            nonlocal buckets_done
+            if reducer is not None and buckets_done < len(BN_BUCKETS) and nm == BN_BUCKETS[buckets_done][-1]:
+                reducer.launch(self.grad, self.bucket_ranges[buckets_done])
+                buckets_done += 1
+
         for nm in reversed(names):
             y = Z[nm]       # (shape only; the relu mask comes from z)
             if g_is_pooled:
@@ -632,12 +666,14 @@ class FcnBnTrainer(object):
                     if wstream is not None:
                         wstream.wait_event(ready)
                     ops.conv2d_first_bwd_filter(x, dz, G(nm, 'kernel'), G(nm, 'bias'), workspace=wws)
+                    bucket_ready(nm)
                 break
             xin = inputs[nm]
             with (torch.cuda.stream(wstream) if wstream is not None else contextlib.nullcontext()):
                 if wstream is not None:
                     wstream.wait_event(ready)
                 ops.conv2d_bwd_filter(xin, dz, G(nm, 'kernel'), G(nm, 'bias'), 3, workspace=wws)
+                bucket_ready(nm)
             dx = ops.conv2d_bwd_data(dz, self.wd[nm], self.zero_bias, self._act('dx_' + nm, xin.n, xin.h, xin.w, xin.c), 3)
             above = names[names.index(nm) - 1]
             if pool_after[above] and above == 'conv4_3':
@@ -652,7 +688,7 @@ class FcnBnTrainer(object):
         if wstream is not None:
             main.wait_stream(wstream)
         if reducer is not None:
-            reducer.launch(self.grad, (0, self.total))
+            assert buckets_done == len(BN_BUCKETS)
             reducer.wait()
         self.t += 1
         FcnTrainer._apply(self, 1.0)
@@ -680,6 +716,9 @@ class FusionFcnTrainer(object):
             raise KeyError(trainer)
         self.e, self.kind, self.lr = engine, trainer, float(learning_rate)
         e, dev = engine, engine.device
+        if not _ups8_channels_ok(e.Up):
+            raise ValueError('fusion_fcn training: num_units = %d is padded to %d lanes; the decoder\'s batch-norm kernels take '
+                             '64, 128 or 256 (num_units <= 256)' % (e.U, e.Up))
         self.mods = list(e.prefixes)
         nm = len(self.mods)
         entries = [(('score', 'kernel'), (e.Up, e.C)), (('score', 'bias'), (e.C,)), (('score', 'gamma'), (e.C,)),
@@ -865,7 +904,7 @@ class FusionFcnTrainer(object):
                             y=self._act('s5', n, h8 // 2, w8 // 2, e.Up))[0]
         feat = ops.upsample2x_relu_add(s5, residual=s4, y=self._act('features', n, h8, w8, e.Up))
         # (the x8 deconv's output is not stored: see FcnBnTrainer.step)
-        virtual_up = _VIRTUAL_UPSCORE and not self._sync and self.bn['upscore'].ws is not None
+        virtual_up = _VIRTUAL_UPSCORE and not self._sync and self.bn['upscore'].ws is not None and _ups8_channels_ok(e.Up)
         mm, mv = self.moving['upscore']
         z_up = None if virtual_up else ops.upsample_raw_fwd(feat, 8, self._act('z_up', n, h, w, e.Up))
         score_raw = None

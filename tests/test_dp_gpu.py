@@ -105,6 +105,76 @@ def test_two_rank_batch_norm_training_uses_global_statistics(tmp_path):
     np.testing.assert_allclose(a, ref, rtol=0, atol=3e-4)
 
 
+def _data4(h, w):
+    rng = np.random.default_rng(8)
+    rgb = np.stack([rng.integers(lo, hi, (h, w, 3)) for lo, hi in ((0, 128), (96, 256), (0, 256), (64, 192))]).astype(np.float32)
+    return {'rgb': rgb, 'labels': rng.integers(-1, C, (4, h, w)).astype(np.int32)}
+
+
+def _bn_bucket_worker(rank, size, port, out, hw):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group('gloo', rank=rank, world_size=size)
+    from modular_semantic_segmentation_amd import parallel
+    net = _make_net(4 // size, True)
+    net._ensure_trainer()
+    launched = []
+    launch = net._reducer.launch
+    net._reducer.launch = lambda flat, rng: (launched.append(tuple(rng)), launch(flat, rng))[1]
+    shard = parallel.shard_data(_data4(*hw))
+    net._train_batch(shard)
+    net._sync_variables()
+    first = {'step1__' + k.replace('/', '__'): np.array(v) for k, v in net.variables.items()}
+    net._train_batch(shard)
+    net._sync_variables()
+    if rank == 0:
+        np.savez(out, launched=np.asarray(launched), total=net.trainer.total, **first,
+                 **{k.replace('/', '__'): v for k, v in net.variables.items()})
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('size', [2, 4])
+def test_batch_norm_trainer_buckets_its_gradient_all_reduce(tmp_path, size):
+    """FcnBnTrainer under data parallelism (round 6): the gradient goes out in THREE buckets, each launched behind the filter
+    gradient of its last layer (score .. conv5_1, conv4_x, conv3_x .. conv1_1 -- kernels, biases, gammas and betas of a layer
+    lie together), no longer as one all-reduce of the whole buffer behind the backward pass; the Sync-BN moments travel on a
+    process group of their own.  Two and four ranks on the four images of one batch (two steps) end where one process on
+    the whole batch ends: moving statistics by the update they received, parameters to the tolerance of the two-rank test
+    above (RMSProp's steps are bounded by lr / sqrt(0.1))."""
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU')
+    hw = (64, 96)
+    out = str(tmp_path / ('dp_bn_%d.npz' % size))
+    mp.spawn(_bn_bucket_worker, args=(size, _free_port(), out, hw), nprocs=size, join=True)
+    got = np.load(out)
+    ranges = got['launched'].tolist()
+    assert len(ranges) == 6 and ranges[:3] == ranges[3:]                        # three buckets per step
+    assert ranges[0][0] == 0 and ranges[2][1] == int(got['total'])
+    assert ranges[0][1] == ranges[1][0] and ranges[1][1] == ranges[2][0]         # contiguous, in backward order
+    net = _make_net(4, True)
+    net._train_batch(_data4(*hw))
+    net._sync_variables()
+    # after ONE step: the moving statistics by the update they received (1 % of the batch statistic: global, not per rank) ...
+    for layer in ('conv1_1', 'conv2_1', 'conv4_2', 'score_conv5'):
+        for v, init in (('moving_mean', 0.0), ('moving_variance', 1.0)):
+            name = 'rgb/%s/%s' % (layer, v)
+            a, ref = got['step1__' + name.replace('/', '__')], net.variables[name]
+            upd_a, upd_ref = (a - 0.99 * init) / 0.01, (ref - 0.99 * init) / 0.01
+            assert np.abs(upd_a - upd_ref).max() < 0.03 * np.abs(upd_ref).max() + 1e-3, name
+    # ... and EVERY trained parameter of all three buckets (RMSProp's first step is lr * g / sqrt(0.9 + 0.1 g^2) <= 3.2e-3,
+    # continuous in g: what remains is the bf16 noise of a batch-norm network, tests/test_backward_gpu.py)
+    worst = 0.0
+    for name, ref in net.variables.items():
+        if name.rsplit('/', 1)[-1] in ('kernel', 'bias', 'gamma', 'beta') and 'upscore/kernel' not in name and \
+                'upscore_conv5/kernel' not in name:
+            a = got['step1__' + name.replace('/', '__')]
+            worst = max(worst, float(np.abs(a - ref).max()))
+            np.testing.assert_allclose(a, ref, rtol=0, atol=1e-3, err_msg=name)
+    # the second step ran (buckets launched again) and moved the weights on
+    assert np.abs(got['rgb__conv3_1__kernel'] - got['step1__rgb__conv3_1__kernel']).max() > 1e-5
+
+
 def _joint_data():
     rng = np.random.default_rng(4)
     return {'rgb': np.stack([rng.integers(0, 128, (H, W, 3)), rng.integers(96, 256, (H, W, 3))]).astype(np.float32),

@@ -404,6 +404,16 @@ def test_dense_deconv_index_maps_are_the_kernel_map_and_its_adjoint(k, s):
     assert float((fo.deconv_same(x.detach(), W, s) - y.detach()).abs().max()) < 1e-5
 
 
+def test_padded_units():
+    """Decoder widths: 64 / 128 / 256 lanes (every kernel behind them, the batch-norm passes included, takes those), multiples
+    of 64 beyond."""
+    from modular_semantic_segmentation_amd.fcn import padded_units
+    from modular_semantic_segmentation_amd.trainer import _ups8_channels_ok
+    assert [padded_units(u) for u in (1, 20, 64, 65, 128, 129, 160, 192, 256, 257, 300)] == \
+        [64, 64, 64, 128, 128, 256, 256, 256, 256, 320, 320]
+    assert all(_ups8_channels_ok(padded_units(u)) for u in range(1, 257)) and not _ups8_channels_ok(192)
+
+
 def test_fp8_plan_and_the_oracle_policy_agree():
     """fcn.fp8_plan (which convs take e4m3 operands, which maps are stored as e4m3, by `deep`) against the
     oracle's restatement of the rule: the oracle's 'fp8' policy must quantise exactly the maps the plan names."""
@@ -419,6 +429,10 @@ def test_fp8_plan_and_the_oracle_policy_agree():
         assert fp8_plan(*hw, start='conv4_1') == (FP8_CONVS[4:], FP8_CONVS[3:])
     with pytest.raises(ValueError):
         fp8_plan(start='conv1_1')
+    for late in ('conv5_2', 'conv5_3'):         # would leave conv4_3 / conv5_3 in bf16 under e4m3-packed score-conv weights
+        with pytest.raises(ValueError):
+            fp8_plan(start=late)
+    assert fp8_plan(start='conv5_1') == (FP8_CONVS[7:], FP8_CONVS[6:])
     # the oracle on a 32x48 image (partial tiles): a map is on the e4m3 grid of its scale iff the plan stores it
     wts = init_variables('rgb', 3, 64, 12, seed=4)
     x = np.random.default_rng(0).integers(0, 256, (1, 32, 48, 3)).astype(np.float32)

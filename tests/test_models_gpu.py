@@ -433,6 +433,31 @@ def test_fusion_fcn_and_bn_training_with_padded_units(gpu, tmp_path):
     assert net.predict(batch).shape == (2, h, w)
 
 
+def test_bn_training_with_units_between_129_and_192(gpu):
+    """num_units = 160 used to be padded to 192 lanes, a width no batch-norm kernel takes (batchnorm.hip: c >= 64,
+    2048 % c == 0): batch-norm training raised XV_ESHAPE (ADVICE r5).  fcn.padded_units now pads to 64 / 128 / 256 lanes;
+    the step must train and keep the padding lanes at zero, the inference engine must accept the trained variables."""
+    from modular_semantic_segmentation_amd import get_model, trainer
+    from modular_semantic_segmentation_amd.fcn import padded_units
+    assert not trainer._ups8_channels_ok(192) and trainer._ups8_channels_ok(64) and trainer._ups8_channels_ok(128)
+    assert [padded_units(u) for u in (1, 64, 65, 128, 129, 160, 192, 256, 257, 300)] == [64, 64, 128, 128, 256, 256, 256, 256, 320, 320]
+    u, c, h, w = 160, 12, 32, 48
+    rng = np.random.default_rng(21)
+    desc = ({'rgb': 'float32', 'labels': 'int32'}, {'rgb': (None, None, 3), 'labels': (None, None)}, c)
+    net = get_model('fcn')('rgb', desc, 'rgb', num_units=u, batch_normalization=True, batchsize=2, learning_rate=1e-3,
+                           trainer='adam', seed=5)
+    batch = {'rgb': rng.integers(0, 256, (2, h, w, 3)).astype(np.float32),
+             'labels': rng.integers(-1, c, (2, h, w)).astype(np.int32)}
+    first = net._train_batch(batch)
+    for _ in range(6):
+        last = net._train_batch(batch)
+    assert net.engine.Up == 256
+    assert np.isfinite(last) and last < first
+    tr = net.trainer
+    assert float(tr.view(tr.param, 'score_conv4', 'kernel')[..., u:].abs().max()) == 0.0
+    assert net.predict(batch).shape == (2, h, w)
+
+
 def test_dataset_readers_drive_training_and_fusion_flows(gpu, tmp_path):
     """the SynthiaCityscapes reader's streams (per-image dicts, the reference's tf.data
     role) feed fit / score and the Bayes-fusion experiment flow; a stream and the stacked numpy batch of the

@@ -13,9 +13,9 @@ LOGIT_TOL_VS_FP32 -- THE STATED TOLERANCE of an arithmetic type: the worst |logi
 
 LOGIT_TOL_VS_POLICY -- an IMPLEMENTATION check, not a stated tolerance: a kernel path against the oracle that rounds at the same
     points (policy 'bf16' / 'fp8'); what remains is fp32 summation order moving values across rounding boundaries:
-      'bf16'  2e-2   (measured 1.2e-2 at 768x384 on random-init weights)
+      'bf16'  1.8e-2 (measured 1.2e-2 at 768x384 on random-init weights; the bound the full-size test has always had)
       'fp8'   0.2    (the maximum over 3.5 M logits of a chaotic quantity; the layer-by-layer comparison is the strict one)
 """
 LOGIT_TOL_VS_FP32 = {'fp32': 1e-5, 'bf16': 4e-2}
 LOGIT_MEAN_TOL_VS_FP32 = {'bf16': 3e-3}
-LOGIT_TOL_VS_POLICY = {'bf16': 2e-2, 'fp8': 0.2}
+LOGIT_TOL_VS_POLICY = {'bf16': 1.8e-2, 'fp8': 0.2}
