@@ -71,14 +71,17 @@ def adapnet_flops_per_image(h, w, cin):
     return f + 2.0 * (h // 16) * (w // 16) * 2048 * U
 
 
-def build_model(device, fusion='bayes', expert='fcn', batch=16, dtype='bf16', streamk=False, fp8_deep=False):
+def build_model(device, fusion='bayes', expert='fcn', batch=16, dtype='bf16', streamk=False, fp8_deep=False, fp8_start=None):
     from modular_semantic_segmentation_amd import get_model
     g = np.load(os.path.join(ROOT, 'tests', 'golden', 'notebook_868.npz'))
     desc = ({'rgb': 'float32', 'depth': 'float32', 'labels': 'int32'},
             {'rgb': (None, None, 3), 'depth': (None, None, 1), 'labels': (None, None)}, C)
     common = dict(data_description=desc, num_units=U, num_channels={'rgb': 3, 'depth': 1}, expert_model=expert,
                   class_prior='data', batchsize=batch, seed=1, device=str(device), conv_dtype=dtype, streamk=streamk,
-                  fp8_deep=fp8_deep)
+                  fp8_deep=fp8_deep, fp8_start=fp8_start,
+                  fp8_agreement=0)     # (speed records of FIXED e4m3 plans: random-init logits are nearly degenerate, the
+    #                                     accuracy guard of calibrate() would send every expert back to bf16; the guarded plan is
+    #                                     chosen on the TRAINED experts of the accuracy leg and passed in as fp8_start)
     if fusion == 'joint':
         # the reference's joint baseline fusion_fcn (experiments/timing.py:24-45): two VGG16 trunks + fused decoder
         net = get_model('fusion_fcn')({'rgb': 'rgb', 'depth': 'depth'}, {'rgb': 3, 'depth': 1}, U, C,
@@ -171,15 +174,18 @@ def accuracy_and_cpu_baseline(args, device, cores, avail):
     measure = {k: v[:16] for k, v in train.items()}
     heldout = make_rgbd_shapes(args.accuracy_images, h, w, seed=1001)
     hip, cms, dparams = ae.hip_predictions(variables, measure, heldout, device=device)
-    hip8 = ae.hip_predictions_fp8(variables, measure, heldout, cms, device=device)
     ref, dt, n = ae.oracle_predictions(variables, heldout, cms, dparams)
     acc = ae.compare(hip, ref, heldout['labels'])
-    acc['fp8'] = {}
-    for k in ('rgb', 'depth', 'bayes'):
-        a, _ = ae._miou(heldout['labels'], hip8[k])
-        acc['fp8'][k] = {'miou_hip_fp8': round(a, 5),
-                         'delta_miou_pp_vs_fp32': round(100 * (a - acc[k]['miou_fp32_oracle']), 4),
-                         'label_agreement_vs_fp32': round(float((hip8[k] == ref[k]).mean()), 6)}
+    # 'fp8': the models' default, the accuracy-guarded plan per expert (calibrate() -> FcnEngine.calibrate_guarded);
+    # 'fp8_fixed_plan': round 5's one global plan (e4m3 operands from conv2_2 on)
+    for key, guarded in (('fp8', True), ('fp8_fixed_plan', False)):
+        hip8 = ae.hip_predictions_fp8(variables, measure, heldout, cms, device=device, guarded=guarded)
+        acc[key] = {'plan': hip8['plan']}
+        for k in ('rgb', 'depth', 'bayes'):
+            a, _ = ae._miou(heldout['labels'], hip8[k])
+            acc[key][k] = {'miou_hip_fp8': round(a, 5),
+                           'delta_miou_pp_vs_fp32': round(100 * (a - acc[k]['miou_fp32_oracle']), 4),
+                           'label_agreement_vs_fp32': round(float((hip8[k] == ref[k]).mean()), 6)}
     acc['protocol'] = ('both experts trained %d Adam steps x 8 images on procedural RGB-D shapes (datasets/synthetic.py) at '
                        '%dx%d through the HIP fit(); %d held-out images; the same trained weights through the HIP path and '
                        'the fp32 CPU oracle; mean IoU over classes 1..%d (base_model.py:329)'
@@ -351,7 +357,7 @@ def committed_traffic(batch, h, w):
 
 
 def extra_inference(device, label, fusion, batch, h, w, dtype='bf16', steps=10, warmup=2, ones=False, fetch=False,
-                    streamk=False, fp8_deep=False, zero_operands=False, scalar_f32=False):
+                    streamk=False, fp8_deep=False, zero_operands=False, scalar_f32=False, fp8_start=None):
     """One more BASELINE.json configuration as an `extra` record (its own model, graph and roofline pass).
     zero_operands: a DIAGNOSTIC, not a workload -- every conv kernel, bias and input zero, so no MFMA operand toggles: the
     rate the same binaries reach when power does not hold the clock down ('Generation 4')."""
@@ -359,7 +365,7 @@ def extra_inference(device, label, fusion, batch, h, w, dtype='bf16', steps=10, 
         # the label-exact mode: A/B against round 4's vector-ALU kernel through the same engine (scalar_f32)
         from modular_semantic_segmentation_amd import fcn_exact
         fcn_exact.SCALAR_KERNEL = bool(scalar_f32)
-    net = build_model(device, fusion=fusion, batch=batch, dtype=dtype, streamk=streamk, fp8_deep=fp8_deep)
+    net = build_model(device, fusion=fusion, batch=batch, dtype=dtype, streamk=streamk, fp8_deep=fp8_deep, fp8_start=fp8_start)
     data = synthetic_batch(device, batch, h, w, seed=77, ones=ones)
     if zero_operands:
         for key in list(net.variables):
@@ -378,6 +384,8 @@ def extra_inference(device, label, fusion, batch, h, w, dtype='bf16', steps=10, 
     if fetch:
         rec['seconds_per_image_mean_std'] = [round(float(np.mean(per_iter)), 6), round(float(np.std(per_iter)), 6)]
     if dtype == 'fp8':
+        from modular_semantic_segmentation_amd.basic_fusion_model import fp8_plan_report
+        rec['fp8_plan'] = {m: r['chosen'] for m, r in fp8_plan_report(net).items()}
         rec['roofline'] = roofline_of(prof, ('k3f8',), PEAK_TFLOPS['fp8'],
                                       'conv_f8_dma_kernel (v_mfma_scale_f32_32x32x64_f8f6f4, 3x3 launches on e4m3 operands; conv_mfma_kernel<F8> where a map does not tile in 16x32)',
                                       dt_serial, steps)
@@ -744,6 +752,8 @@ def main():
                     help="'fp8': the block-scaled e4m3 conv path (BASELINE config 5; quote it with --height 1024 --width 2048)")
     ap.add_argument('--mode', default='infer', choices=['infer', 'train'],
                     help="'infer' (headline): two experts + fusion; 'train': one SimpleFCN training step (fwd+bwd+Adam)")
+    ap.add_argument('--fp8-start', default=None,
+                    help="--dtype fp8: first e4m3 conv, one layer name or rgb=<layer>,depth=<layer> ('bf16': that expert keeps bf16 operands)")
     ap.add_argument('--fp8-deep', action='store_true',
                     help="--dtype fp8: e4m3 operands from conv1_2 on (model config fp8_deep: faster, costs accuracy)")
     ap.add_argument('--record', default=None, choices=['dirichlet_fit', 'dp_regime'],
@@ -814,7 +824,10 @@ def main():
     if args.mode == 'train':
         return bench_train(args, device, world, rank, dist)
     default_line = (args.fusion, args.expert, args.dtype, args.height, args.width) == ('bayes', 'fcn', 'bf16', 384, 768)
-    net = build_model(device, args.fusion, args.expert, args.batch, args.dtype, fp8_deep=args.fp8_deep)
+    fp8_start = args.fp8_start
+    if fp8_start and '=' in fp8_start:
+        fp8_start = dict(kv.split('=') for kv in fp8_start.split(','))
+    net = build_model(device, args.fusion, args.expert, args.batch, args.dtype, fp8_deep=args.fp8_deep, fp8_start=fp8_start)
     batch = synthetic_batch(device, args.batch, args.height, args.width, seed=1234 + rank)
     if args.dtype == 'fp8':
         net.calibrate(batch)
@@ -963,6 +976,18 @@ def main():
             guarded(extra_inference, device, 'the same with fp8_deep=True (e4m3 operands from conv1_2 on: faster, and it costs '
                                              'accuracy -- DESIGN.md, the fp8 plan)', 'bayes', 4, 1024, 2048, dtype='fp8', steps=5,
                                          fp8_deep=True)
+            plan = None
+            try:
+                plan = {m: r['chosen'] for m, r in res['accuracy']['fp8']['plan']['bayes'].items()}
+            except (KeyError, TypeError):
+                pass
+            if plan is not None:
+                guarded(extra_inference, device, 'configs[4] at north_star\'s accuracy bound: 2048x1024 x 4, conv_dtype=fp8 with the '
+                                                 'ACCURACY-GUARDED plan calibrate() chose per expert on the trained experts of the '
+                                                 'accuracy record (label agreement with the bf16 graph >= 0.995 on the calibration '
+                                                 'batch; an expert no e4m3 plan serves keeps bf16 operands): %s'
+                                                 % json.dumps(plan, sort_keys=True), 'bayes', 4, 1024, 2048, dtype='fp8', steps=5,
+                                             fp8_start=plan)
 
             def training_record():
                 tr = measure_training(args, device, 1, 0, dist, 16, 8, 2)

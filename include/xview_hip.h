@@ -383,8 +383,10 @@ int xv_conv2d_bwd_filter_ws(const xv_act* x, const xv_act* dy, float* dw_hwio, f
                             void* workspace, size_t workspace_bytes, void* stream);
 
 /* Test / tuning switch for the 3x3 filter-gradient kernel: 1 = register-staged tiles, two 4-wave workgroups
- * per CU; 2 (default) = LDS-DMA double-buffered tiles, one 8-wave workgroup per CU.  Same results up to the
- * order of the fp32 atomics.                                                                          */
+ * per CU; 2 = LDS-DMA double-buffered tiles, one 8-wave workgroup per CU (round 5's default); 3 (default) = the
+ * same tiles with four loader waves beside four compute waves that walk the halo rows (three X fragments per
+ * row serve all nine taps); 0 = back to the default (XV_WGRAD_VARIANT in the environment, else 3).  Same sums,
+ * equal on integers; the fp32 summation order differs between the variants.                           */
 int xv_set_wgrad_variant(int variant);
 
 /* dbias[c] += sum over all pixels of dy[.., c] (BiasAddGrad).                                        */

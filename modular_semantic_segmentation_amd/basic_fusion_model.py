@@ -44,12 +44,41 @@ def engine_options(config):
     return opts
 
 
+def fp8_guard_bound(config):
+    """Label-agreement bound of the accuracy-guarded fp8 plan (FcnEngine.calibrate_guarded), or None where the plan is given:
+    model config `fp8_agreement` (default fcn.FP8_GUARD_AGREEMENT = 0.995; 0 / None: off); an explicit `fp8_start` or
+    `fp8_deep` is a plan of the caller's and is not second-guessed."""
+    from .fcn import FP8_GUARD_AGREEMENT
+    if config.get('fp8_start') or config.get('fp8_deep'):
+        return None
+    bound = config.get('fp8_agreement', FP8_GUARD_AGREEMENT)
+    return float(bound) if bound else None
+
+
 def calibrate_experts(model, data):
-    """conv_dtype='fp8': fix every expert's activation scales from the first batch of `data`."""
+    """conv_dtype='fp8': fix every expert's activation scales from the first batch of `data` -- and, unless the config names
+    a plan, choose every expert's e4m3 plan by its label agreement with the bf16 graph on that batch (fp8_guard_bound)."""
     from .base_model import iterate_batches
     batch = next(iterate_batches(data, model.config['batchsize']))
     model._graph = None
-    return {m: model.experts[m].calibrate(model._to_device(batch[m], torch.float32)) for m in model.modalities}
+    bound = fp8_guard_bound(model.config)
+    out = {}
+    for m in model.modalities:
+        x = model._to_device(batch[m], torch.float32)
+        eng = model.experts[m]
+        out[m] = eng.calibrate_guarded(x, bound) if bound is not None and hasattr(eng, 'calibrate_guarded') else eng.calibrate(x)
+    return out
+
+
+def fp8_plan_report(model):
+    """{modality: the engine's calibrate_guarded report or its fixed plan} of an fp8 model (bench records, logs)."""
+    rep = {}
+    for m in model.modalities:
+        eng = model.experts[m]
+        rep[m] = eng.fp8_guard if getattr(eng, 'fp8_guard', None) else {
+            'chosen': 'bf16' if getattr(eng, 'fp8_off', False) else (getattr(eng, 'fp8_start', None) or ('conv1_2' if getattr(eng, 'fp8_deep', False) else 'conv2_2')),
+            'bound': None}
+    return rep
 
 
 def fills_the_chip(model, inputs, rounds=1):

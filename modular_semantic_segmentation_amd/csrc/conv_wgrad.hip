@@ -16,6 +16,13 @@
 // finally adds them into dW with fp32 global atomics (run-to-run summation order is not fixed).
 #include "xv_common.h"
 
+// Diagnostic builds only (tools/wgrad_exp.sh; wrong results): XV_WGRAD_EXP bit 0 = no LDS-DMA after a workgroup's first tile,
+// bit 1 = no per-tile barrier, bit 2 = fragments read for the first row of a tile only.  Which of the three the matrix pipe
+// waits for is read off the launch time of each build.
+#ifndef XV_WGRAD_EXP
+#define XV_WGRAD_EXP 0
+#endif
+
 #ifndef XV_WGRAD_UNROLL
 #define XV_WGRAD_UNROLL 8  // rows of a tile fully unrolled: +30 % over the rolled loop (profiles/r1_conv_tune_*.txt)
 #endif
@@ -399,11 +406,11 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_dma_kernel(WgradArgs a) {
     for (int y = 0; y < TH; ++y) {
       // the next tile's pieces: two per row over the first rows, so that the last of them has the remaining rows' MFMAs to
       // land behind (issued one per row up to the last row, the tile ended waiting for its youngest piece)
-      if (more && 2 * y < NJ) {
+      if (more && 2 * y < NJ && !(XV_WGRAD_EXP & 1)) {
         stage_piece(nxt, 2 * y, b ^ 1);
         if (2 * y + 1 < NJ) stage_piece(nxt, 2 * y + 1, b ^ 1);
       }
-      if (y + 1 < TH) frag_row(y + 1, bfr[(y + 1) & 1], afr[(y + 1) & 1]);
+      if (y + 1 < TH && !(XV_WGRAD_EXP & 4)) frag_row(y + 1, bfr[(y + 1) & 1], afr[(y + 1) & 1]);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int ts = 0; ts < NT; ++ts) {
@@ -411,7 +418,8 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_dma_kernel(WgradArgs a) {
         if (tap < NTAPS) {
 #pragma unroll
           for (int n4 = 0; n4 < 4; ++n4) {
-            acc[ts][n4] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr[y & 1][ts], bfr[y & 1][n4], acc[ts][n4], 0, 0, 0);
+            acc[ts][n4] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr[(XV_WGRAD_EXP & 4) ? 0 : (y & 1)][ts],
+                                                                  bfr[(XV_WGRAD_EXP & 4) ? 0 : (y & 1)][n4], acc[ts][n4], 0, 0, 0);
             if (ts == 0 && n4 == 0) __builtin_amdgcn_s_setprio(2);
           }
         }
@@ -419,8 +427,10 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_dma_kernel(WgradArgs a) {
       __builtin_amdgcn_s_setprio(0);
       __builtin_amdgcn_sched_barrier(0);
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();  // DMA of tile t+1 has landed and every wave is done with buffer b
+    if (!(XV_WGRAD_EXP & 2)) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();  // DMA of tile t+1 has landed and every wave is done with buffer b
+    }
   }
 
   if (do_bias) {
@@ -464,6 +474,250 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_dma_kernel(WgradArgs a) {
       }
     }
   }
+}
+
+// ---- version 3 (round 6): loader waves + halo-row-major fragments ---------------------------------------------------------
+// What version 2 waits for was measured with parts of its tile loop switched off (tools/wgrad_exp.sh, profiles/r6_wgrad_exp.txt;
+// conv3_2, 16 images, one box): 299 us as it is, 250 without the LDS-DMA of the next tile, 264 without the per-row fragment
+// reads, 177 without both (the per-tile barrier alone: nothing); matrix pipe 47 % busy AT FULL CLOCK (rocprofv3 counters,
+// profiles/r6_wgrad_counters.json: no LDS bank conflict, LDS array 24 % busy) -- not power, not bandwidth: every one of its
+// eight waves carries MFMAs, 18 transposing reads per 20 MFMAs and the DMA instructions in ONE in-order stream, and a wave
+// stalled in the vector-memory queue or behind its reads issues no MFMA.
+//   * ROLES.  Waves 0-3 (one per SIMD) compute and issue nothing but LDS reads and MFMAs; waves 4-7 (their SIMD partners) move
+//     the next tile by LDS-DMA a whole tile ahead, add up the bias gradient from the staged dY tile and otherwise sleep at the
+//     barrier.  A stalled DMA instruction stalls a loader.
+//   * FRAGMENT REUSE.  Compute wave cb owns input channels 16 cb .. 16 cb + 15 x 64 output channels x ALL nine taps (144
+//     accumulators, as version 1).  The X fragment of halo row r and column offset kx serves the taps (ky, kx) of the three
+//     output rows y = r - ky: the wave walks the ten HALO rows, reads three X fragments per row and keeps the dY fragments of
+//     three output rows in a ring -- 30 + 32 fragment reads per tile and wave where version 2 makes 8 x 18 per tile in each of
+//     its eight waves (248 KB of LDS reads per tile instead of 576).
+//   * Order inside halo row r: request X(r + 1); MFMAs of ky = 2 (output row r - 2, whose ring slot is then free); request
+//     dY(r + 1) into that slot; MFMAs of ky = 1, ky = 0 -- 24 to 36 MFMAs (400-600 cycles) between a request and its first use.
+// Same tile geometry, LDS images, split-K slabs and reduction kernels as version 2; per accumulator the pixels are added in
+// tile order, rows in order (another order than version 2's: bitwise reproducible against itself, equal on integers).
+__global__ __launch_bounds__(512, 2) void conv_wgrad_lw_kernel(WgradArgs a) {
+  constexpr int TH = 8, TW = 32, HH = TH + 2, HW = TW + 2, NPIX = HH * HW;
+  constexpr int X_BYTES = ((NPIX * 128 + 1023) / 1024) * 1024;
+  constexpr int D_BYTES = TH * TW * 128;
+  constexpr int BUF = X_BYTES + D_BYTES;
+  constexpr int XI = X_BYTES / 1024, DI = D_BYTES / 1024;
+  constexpr int NL = 4;                                  // loader waves
+  constexpr int NJ = (XI + DI + NL - 1) / NL;            // DMA pieces per loader wave and tile
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int H = a.H, W = a.W, Cin = a.Cin, Cout = a.Cout;
+  const int Wp = W + 2;
+  const int split = blockIdx.x % a.splits;
+  const int pair = blockIdx.x / a.splits;
+  const int n_co = Cout >> 6;
+  const int co0 = (pair % n_co) << 6;
+  const int ci0 = (pair / n_co) << 6;
+  const int per = (a.n_ptiles + a.splits - 1) / a.splits;
+  const int t_begin = split * per;
+  const int t_end = t_begin + per < a.n_ptiles ? t_begin + per : a.n_ptiles;
+  const bool do_bias = a.db != nullptr && ci0 == 0;
+  float* const out = a.slab ? a.slab + (int64_t)split * 9 * Cin * Cout : a.dw;
+
+  if (wave >= NL) {
+    // ================================================ loader waves ================================================
+    const int lw = wave - NL;
+    int voff[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const int i = lw + NL * j;
+      if (i < XI) {
+        int idx = i * 64 + lane;  // 16-byte piece of the patch image: pixel idx >> 3, PHYSICAL slot idx & 7
+        idx = idx < NPIX * 8 ? idx : NPIX * 8 - 1;
+        const int pp = idx >> 3, ps = idx & 7;
+        const int hy = pp / HW, hx = pp - hy * HW;
+        voff[j] = ((hy * Wp + hx) * Cin + xv_swz(hx, ps) * 8) * 2;
+      } else {
+        const int idx = (i - XI) * 64 + lane;
+        const int pp = idx >> 3, ps = idx & 7;
+        const int py = pp / TW, px = pp - py * TW;
+        voff[j] = ((py * Wp + px) * Cout + xv_swz(px, ps) * 8) * 2;
+      }
+    }
+    auto stage = [&](int t, int b) {
+      const int tx = t % a.tiles_x;
+      int r = t / a.tiles_x;
+      const int ty = r % a.tiles_y;
+      const int n = r / a.tiles_y;
+      const int y0 = ty * TH, x0 = tx * TW;
+      const bool edge = y0 + TH > H || x0 + TW > W;
+      const __bf16* xt = a.x + (int64_t)n * (H + 2) * Wp * Cin + ci0 + ((int64_t)y0 * Wp + x0) * Cin;
+      const __bf16* dt = a.dy + (int64_t)n * (H + 2) * Wp * Cout + co0 + ((int64_t)(y0 + 1) * Wp + (x0 + 1)) * Cout;
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        const int i = lw + NL * j;
+        if (i >= XI + DI) continue;
+        int off = voff[j];
+        const bool isx = i < XI;
+        if (edge) {  // right / bottom edge of the image: coordinates past it are clamped onto the zero border (rare path)
+          int ln = lane;
+          asm volatile("" : "+v"(ln));
+          if (isx) {
+            int idx = i * 64 + ln;
+            idx = idx < NPIX * 8 ? idx : NPIX * 8 - 1;
+            const int pp = idx >> 3, ps = idx & 7;
+            const int hy = pp / HW, hx = pp - hy * HW;
+            int yy = y0 + hy, xx = x0 + hx;
+            yy = (yy < H + 1 ? yy : H + 1) - y0;
+            xx = (xx < W + 1 ? xx : W + 1) - x0;
+            off = ((yy * Wp + xx) * Cin + xv_swz(hx, ps) * 8) * 2;
+          } else {
+            const int idx = (i - XI) * 64 + ln;
+            const int pp = idx >> 3, ps = idx & 7;
+            const int py = pp / TW, px = pp - py * TW;
+            int yy = y0 + py + 1, xx = x0 + px + 1;
+            yy = (yy < H + 1 ? yy : H + 1) - (y0 + 1);
+            xx = (xx < W + 1 ? xx : W + 1) - (x0 + 1);
+            off = ((yy * Wp + xx) * Cout + xv_swz(px, ps) * 8) * 2;
+          }
+        }
+        const int lds = __builtin_amdgcn_readfirstlane(b * BUF + (isx ? i * 1024 : X_BYTES + (i - XI) * 1024));
+        asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds), "v"(off), "s"(isx ? xt : dt) : "memory");
+      }
+    };
+    float bsum = 0.f;
+    if (t_begin < t_end) stage(t_begin, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    for (int t = t_begin; t < t_end; ++t) {
+      const int b = (t - t_begin) & 1;
+      if (t + 1 < t_end) stage(t + 1, b ^ 1);  // (buffer b ^ 1 was released by the barrier that ended tile t - 1)
+      if (do_bias) {
+        const char* buf = smem + b * BUF + X_BYTES;
+        const int lt = tid - NL * 64;
+        const int co = lt & 63, part = lt >> 6;  // 4 parts x 64 pixels
+        const int slot = co >> 3, e = co & 7;
+#pragma unroll 4
+        for (int pp = part * 64; pp < part * 64 + 64; ++pp) {
+          const int px = pp & (TW - 1);
+          bsum += (float)*reinterpret_cast<const __bf16*>(buf + pp * 128 + (xv_swz(px, slot) << 4) + e * 2);
+        }
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();  // tile t + 1 has landed; the compute waves are done with buffer b
+    }
+    if (do_bias) {
+      const int lt = tid - NL * 64;
+      if (a.bslab != nullptr) {
+        // deterministic: the four pixel parts of a channel meet in LDS (both tile buffers are consumed) in a fixed order
+        float* red = reinterpret_cast<float*>(smem);
+        red[lt] = bsum;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (lt < 64) a.bslab[(int64_t)split * Cout + co0 + lt] = ((red[lt] + red[64 + lt]) + red[128 + lt]) + red[192 + lt];
+      } else {
+        atomicAdd(a.db + co0 + (lt & 63), bsum);
+        __builtin_amdgcn_s_barrier();
+      }
+    } else {
+      __builtin_amdgcn_s_barrier();
+    }
+    return;
+  }
+
+  // ================================================== compute waves ==================================================
+  const int cb = wave;
+  const int g = lane >> 4, li = lane & 15, q = li >> 2, p = li & 3;
+  const int xk = 16 * (g >> 1) + 4 * (g & 1) + q;
+  int xbase[3];
+#pragma unroll
+  for (int dx = 0; dx < 3; ++dx) {
+    const int c = xk + dx;
+    xbase[dx] = c * 128 + (xv_swz(c, cb * 2 + (p >> 1)) << 4) + (p & 1) * 8;
+  }
+  int dbase[4];
+#pragma unroll
+  for (int n = 0; n < 4; ++n) dbase[n] = X_BYTES + xk * 128 + (xv_swz(xk, n * 2 + (p >> 1)) << 4) + (p & 1) * 8;
+
+  f32x4 acc[9][4];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int n = 0; n < 4; ++n) acc[t][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  __builtin_amdgcn_s_barrier();  // (the loaders' first tile)
+  __builtin_amdgcn_s_setprio(2);
+  // The fragment registers live across tiles: the tile's ONE barrier sits in front of its LAST halo row -- by then every read
+  // of this buffer is in registers (the row's own fragments were requested a row earlier) and the loaders have seen the next
+  // tile land -- and the first fragments of the next tile are requested right behind it, under the last row's 12 MFMAs: a
+  // tile starts with its operands in registers instead of an LDS round trip behind a barrier.
+  bf16x8 xf[2][3], df[3][4];
+  auto req_x = [&](const char* buf, int r, bf16x8 (&dst)[3]) {
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) dst[kx] = tr_read2(buf, xbase[kx] + r * (HW * 128), xbase[kx] + r * (HW * 128) + 8 * 128);
+  };
+  auto req_d = [&](const char* buf, int y, bf16x8 (&dst)[4]) {
+#pragma unroll
+    for (int n4 = 0; n4 < 4; ++n4) dst[n4] = tr_read2(buf, dbase[n4] + y * (TW * 128), dbase[n4] + y * (TW * 128) + 8 * 128);
+  };
+  if (t_begin < t_end) {
+    req_x(smem, 0, xf[0]);
+    req_d(smem, 0, df[0]);
+  }
+  for (int t = t_begin; t < t_end; ++t) {
+    const char* buf = smem + ((t - t_begin) & 1) * BUF;
+    const char* nbuf = smem + ((t + 1 - t_begin) & 1) * BUF;
+#pragma unroll
+    for (int r = 0; r < HH; ++r) {
+      if (r + 1 < HH) req_x(buf, r + 1, xf[(r + 1) & 1]);
+      if (r == HH - 1) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (requested a row ago: landed)
+        __builtin_amdgcn_s_barrier();  // every compute wave holds its last fragments of this buffer; the next tile has landed
+        if (t + 1 < t_end) {
+          req_x(nbuf, 0, xf[0]);   // (xf[0] was halo row 8's, df[0] output row 6's: both consumed)
+          req_d(nbuf, 0, df[0]);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int o = 0; o < 3; ++o) {
+        const int ky = o == 0 ? 2 : (o == 1 ? 1 : 0);  // ky = 2 first: it frees the ring slot of output row r - 2
+        const int y = r - ky;
+        if (y >= 0 && y < TH) {
+#pragma unroll
+          for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+            for (int n4 = 0; n4 < 4; ++n4)
+              acc[ky * 3 + kx][n4] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[r & 1][kx], df[y % 3][n4], acc[ky * 3 + kx][n4], 0, 0, 0);
+        }
+        if (o == 0) {
+          __builtin_amdgcn_sched_barrier(0);
+          if (r + 1 < TH) req_d(buf, r + 1, df[(r + 1) % 3]);  // (slot (r + 1) % 3 = (r - 2) % 3: just released)
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  __builtin_amdgcn_s_setprio(0);
+  __builtin_amdgcn_s_barrier();  // (the loaders' bias reduction uses the tile buffers: after the last fragment read)
+
+  const int cin = ci0 + cb * 16 + g * 4;
+  const int cout = co0 + li;
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+    for (int n4 = 0; n4 < 4; ++n4) {
+      float* dst = out + ((int64_t)tap * Cin + cin) * Cout + cout + n4 * 16;
+      if (a.slab) {
+        dst[0] = acc[tap][n4].x;
+        dst[Cout] = acc[tap][n4].y;
+        dst[2 * Cout] = acc[tap][n4].z;
+        dst[3 * Cout] = acc[tap][n4].w;
+      } else {
+        atomicAdd(dst, acc[tap][n4].x);
+        atomicAdd(dst + Cout, acc[tap][n4].y);
+        atomicAdd(dst + 2 * Cout, acc[tap][n4].z);
+        atomicAdd(dst + 3 * Cout, acc[tap][n4].w);
+      }
+    }
 }
 
 // ---- conv1_1 (fp32 input of 1-4 channels, 64 output channels): filter + bias gradient on the bf16 matrix instruction -----
@@ -883,16 +1137,22 @@ extern "C" int xv_bias_grad(const xv_act* dy, float* dbias, void* stream) {
   return xv_launch_status();
 }
 
-static int g_wgrad_variant = 2;
+static int wgrad_default_variant() {
+  const char* e = getenv("XV_WGRAD_VARIANT");  // A/B timing: 1, 2 (round 5's default) or 3
+  const int v = e != nullptr ? atoi(e) : 3;
+  return v >= 1 && v <= 3 ? v : 3;
+}
+static int g_wgrad_variant = wgrad_default_variant();
 extern "C" int xv_set_wgrad_variant(int v) {
-  if (v != 1 && v != 2) return XV_EINVAL;
+  if (v == 0) v = wgrad_default_variant();
+  if (v < 1 || v > 3) return XV_EINVAL;
   g_wgrad_variant = v;
   return XV_OK;
 }
 
 static int wgrad_splits(int k, int pairs, int n_ptiles) {
   // 3x3, LDS-DMA kernel: one 8-wave workgroup per CU; otherwise ~3 four-wave workgroups per CU
-  int sp = (g_wgrad_variant == 2 && k == 3) ? (xv_num_cus() + pairs - 1) / pairs : (3 * xv_num_cus() + pairs - 1) / pairs;
+  int sp = (g_wgrad_variant >= 2 && k == 3) ? (xv_num_cus() + pairs - 1) / pairs : (3 * xv_num_cus() + pairs - 1) / pairs;
   if (sp > n_ptiles) sp = n_ptiles;
   return sp < 1 ? 1 : sp;
 }
@@ -975,6 +1235,16 @@ extern "C" int xv_conv2d_bwd_filter_ws(const xv_act* x, const xv_act* dy, float*
     }
     return xv_launch_status();
   };
+  if (g_wgrad_variant == 3 && k == 3) {
+    constexpr int lds = 2 * (((10 * 34 * 128 + 1023) / 1024) * 1024 + 8 * 32 * 128);
+    static bool attr[XV_MAX_DEVICES] = {false};
+    {
+      const hipError_t e = xv_allow_dynamic_lds(reinterpret_cast<const void*>(&conv_wgrad_lw_kernel), lds, attr);
+      if (e != hipSuccess) return (int)e;
+    }
+    hipLaunchKernelGGL(conv_wgrad_lw_kernel, dim3((unsigned)(pairs * splits)), dim3(512), lds, s, a);
+    return finish();
+  }
   if (g_wgrad_variant == 2 && k == 3) {
     constexpr int lds = 2 * (((10 * 34 * 128 + 1023) / 1024) * 1024 + 8 * 32 * 128);
     static bool attr[XV_MAX_DEVICES] = {false};

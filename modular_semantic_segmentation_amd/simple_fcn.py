@@ -117,11 +117,16 @@ class SimpleFCN(BaseModel):
 
     # ---- training (base_model.py:153-162,180-261) ------------------------------------------------------
     def calibrate(self, data):
-        """conv_dtype='fp8': fix the activation scales from the first batch of `data` (FcnEngine.calibrate)."""
+        """conv_dtype='fp8': fix the activation scales from the first batch of `data` (FcnEngine.calibrate) and -- unless the
+        config names a plan (`fp8_start`, `fp8_deep`) -- choose the e4m3 plan by its label agreement with the bf16 graph on
+        that batch (FcnEngine.calibrate_guarded; config `fp8_agreement`, default 0.995, 0 = off)."""
         from .base_model import iterate_batches
+        from .basic_fusion_model import fp8_guard_bound
         batch = next(iterate_batches(data, self.config['batchsize']))
         self._graph = None
-        return self.engine.calibrate(self._to_device(batch[self.modality], torch.float32))
+        x = self._to_device(batch[self.modality], torch.float32)
+        bound = fp8_guard_bound(self.config)
+        return self.engine.calibrate_guarded(x, bound) if bound is not None else self.engine.calibrate(x)
 
     def _ensure_trainer(self):
         if self.engine.conv_dtype != 'bf16':

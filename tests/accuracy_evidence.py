@@ -83,28 +83,35 @@ def _miou(labels, pred):
     return float(score_measures(cm)['mean_IoU']), cm
 
 
-def hip_predictions_fp8(variables, calibration, heldout, cms, device='cuda'):
+def hip_predictions_fp8(variables, calibration, heldout, cms, device='cuda', guarded=True):
     """The same experts with conv_dtype='fp8' (BASELINE config "fp8 MFMA conv path"): scales calibrated on a batch of the
-    training set, then each expert's labels and the Bayes fusion of them on `heldout`."""
+    training set, then each expert's labels and the Bayes fusion of them on `heldout`.  guarded (the models' default): every
+    expert's e4m3 plan is chosen by calibrate() from its label agreement with the bf16 graph on the calibration batch
+    (FcnEngine.calibrate_guarded, bound 0.995); guarded=False: round 5's fixed plan (e4m3 operands from conv2_2 on) for both.
+    out['plan'] = {model: {modality: report}}."""
     from modular_semantic_segmentation_amd import get_model
+    from modular_semantic_segmentation_amd.basic_fusion_model import fp8_plan_report
     from modular_semantic_segmentation_amd.datasets.synthetic import data_description
     desc = data_description()
-    out = {}
+    extra = {} if guarded else {'fp8_agreement': 0}
+    out = {'plan': {}}
     for m, cin in MODS:
         net = get_model('fcn')(m, desc, m, num_units=U, batch_normalization=False, batchsize=4, device=str(device),
-                               conv_dtype='fp8')
+                               conv_dtype='fp8', **extra)
         net.variables.update({k: v for k, v in variables.items() if k.startswith(m + '/')})
         net._variables_changed()
         net.calibrate(calibration)
         out[m] = net.predict(heldout)
+        out['plan'][m] = net.engine.fp8_guard if net.engine.fp8_guard else {'chosen': 'conv2_2', 'bound': None}
     bayes = get_model('bayes_fusion')(confusion_matrices=cms, prefixes={'rgb': 'rgb', 'depth': 'depth'},
                                       data_description=desc, num_units=U, num_channels={'rgb': 3, 'depth': 1},
                                       expert_model='fcn', class_prior='data', batchsize=4, device=str(device),
-                                      conv_dtype='fp8')
+                                      conv_dtype='fp8', **extra)
     bayes.variables.update(variables)
     bayes._variables_changed()
     bayes.calibrate(calibration)
     out['bayes'] = bayes.predict(heldout)
+    out['plan']['bayes'] = fp8_plan_report(bayes)
     return out
 
 
@@ -256,12 +263,14 @@ def run(h=384, w=768, steps=1500, batch=8, n_heldout=8, n_measure=16, device='cu
         acc['exact_fp32'] = compare_exact(hip_predictions_exact(variables, heldout, cms, exact_images, device=device), ref,
                                           exact_images)
     if fp8:
-        hip8 = hip_predictions_fp8(variables, measure, heldout, cms, device=device)
-        acc['fp8'] = {}
-        for k in ('rgb', 'depth', 'bayes'):
-            a, _ = _miou(heldout['labels'], hip8[k])
-            acc['fp8'][k] = {'miou_hip_fp8': round(a, 5), 'delta_miou_pp_vs_fp32': round(100 * (a - acc[k]['miou_fp32_oracle']), 4),
-                             'label_agreement_vs_fp32': round(float((hip8[k] == ref[k]).mean()), 6)}
+        # 'fp8': the product's default -- the accuracy-guarded plan per expert; 'fp8_fixed_plan': round 5's one global plan
+        for key, guarded in (('fp8', True), ('fp8_fixed_plan', False)):
+            hip8 = hip_predictions_fp8(variables, measure, heldout, cms, device=device, guarded=guarded)
+            acc[key] = {'plan': hip8['plan']}
+            for k in ('rgb', 'depth', 'bayes'):
+                a, _ = _miou(heldout['labels'], hip8[k])
+                acc[key][k] = {'miou_hip_fp8': round(a, 5), 'delta_miou_pp_vs_fp32': round(100 * (a - acc[k]['miou_fp32_oracle']), 4),
+                               'label_agreement_vs_fp32': round(float((hip8[k] == ref[k]).mean()), 6)}
     acc['protocol'] = ('experts trained %d Adam steps x %d images on procedural RGB-D shapes at %dx%d through the HIP fit(); '
                        '%d held-out images; same trained weights through the HIP bf16 path and the fp32 CPU oracle; '
                        'mean IoU over classes 1..%d (base_model.py:329)' % (steps, batch, w, h, n_heldout, C - 1))

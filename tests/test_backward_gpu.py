@@ -36,7 +36,7 @@ def _nhwc(t):
 
 @pytest.mark.parametrize('n,h,w,cin,cout,k', [(2, 16, 32, 64, 64, 3), (1, 24, 40, 128, 64, 3), (2, 6, 10, 64, 128, 3),
                                               (1, 20, 36, 128, 64, 1), (3, 8, 8, 512, 64, 1), (2, 16, 32, 128, 256, 3)])
-@pytest.mark.parametrize('variant', [1, 2])
+@pytest.mark.parametrize('variant', [1, 2, 3])
 def test_conv_filter_and_bias_gradient_exact_on_integers(ops, n, h, w, cin, cout, k, variant):
     from modular_semantic_segmentation_amd import _lib
     assert _lib.lib().xv_set_wgrad_variant(variant) == 0
@@ -59,7 +59,7 @@ def test_conv_filter_and_bias_gradient_exact_on_integers(ops, n, h, w, cin, cout
     dw2 = torch.ones((k, k, cin, cout), device='cuda')
     ops.conv2d_bwd_filter(xa, dya, dw2, None, k, workspace=ws)
     torch.cuda.synchronize()
-    _lib.lib().xv_set_wgrad_variant(2)
+    _lib.lib().xv_set_wgrad_variant(0)          # back to the default
     assert np.array_equal(dw2.cpu().numpy(), ref + 1)
 
 

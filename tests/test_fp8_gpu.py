@@ -305,7 +305,7 @@ def test_fp8_fusion_model_predicts(ops, golden_dir):
             'depth': rng.integers(0, 65536, (2, 64, 96, 1)).astype(np.float32)}
     preds = {}
     for dt in ('bf16', 'fp8'):
-        net = get_model('bayes_fusion')(conv_dtype=dt, **cfg)
+        net = get_model('bayes_fusion')(conv_dtype=dt, fp8_agreement=0, **cfg)       # (the fixed default plan: no guard)
         net.variables['depth/conv1_1/kernel'] = net.variables['depth/conv1_1/kernel'] / 256.0
         net._variables_changed()
         if dt == 'fp8':
@@ -331,7 +331,7 @@ def test_fp8_deep_through_the_model_api(ops, golden_dir):
             {'rgb': (None, None, 3), 'depth': (None, None, 1), 'labels': (None, None)}, 12)
     cfg = dict(data_description=desc, confusion_matrices={'rgb': g['cm_rgb'], 'depth': g['cm_depth']}, num_units=64,
                prefixes={'rgb': 'rgb', 'depth': 'depth'}, num_channels={'rgb': 3, 'depth': 1}, expert_model='fcn',
-               class_prior='data', batchsize=2, seed=3, conv_dtype='fp8')
+               class_prior='data', batchsize=2, seed=3, conv_dtype='fp8', fp8_agreement=0)
     rng = np.random.default_rng(1)
     data = {'rgb': rng.integers(0, 256, (2, 64, 128, 3)).astype(np.float32),
             'depth': rng.integers(0, 65536, (2, 64, 128, 1)).astype(np.float32)}
@@ -457,7 +457,7 @@ def test_fp8_fusion_model_at_2048x1024_fused_head_equals_unfused(ops, golden_dir
     net = get_model('bayes_fusion')(conv_dtype='fp8', data_description=desc,
                                     confusion_matrices={'rgb': g['cm_rgb'], 'depth': g['cm_depth']}, num_units=64,
                                     prefixes={'rgb': 'rgb', 'depth': 'depth'}, num_channels={'rgb': 3, 'depth': 1},
-                                    expert_model='fcn', class_prior='data', batchsize=2, seed=3)
+                                    expert_model='fcn', class_prior='data', batchsize=2, seed=3, fp8_agreement=0)
     net.variables['depth/conv1_1/kernel'] = net.variables['depth/conv1_1/kernel'] / 256.0
     net._variables_changed()
     rng = np.random.default_rng(1)
@@ -470,6 +470,63 @@ def test_fp8_fusion_model_at_2048x1024_fused_head_equals_unfused(ops, golden_dir
     assert np.array_equal(both, np.argmax(score, -1))
     single = net.predict({k: v[1:2] for k, v in data.items()})
     assert np.array_equal(single[0], both[1])
+
+
+def test_accuracy_guarded_fp8_plan(ops, golden_dir):
+    """calibrate() of an fp8 model chooses every expert's e4m3 plan by its effect (FcnEngine.calibrate_guarded): label
+    agreement with the bf16 graph on the calibration batch against a bound (config `fp8_agreement`, default 0.995), deepest
+    candidate first, bf16 operands for an expert no candidate serves.  Random-init experts have nearly degenerate logits --
+    no e4m3 plan reproduces their labels -- so at the default bound both fall back to bf16 and the model then equals the
+    bf16 model BIT FOR BIT; a bound of 0.3 takes the deepest candidate (the fixed default plan of round 5); an explicit
+    `fp8_start` is not second-guessed."""
+    import os
+    from modular_semantic_segmentation_amd import get_model
+    from modular_semantic_segmentation_amd.basic_fusion_model import fp8_plan_report
+    from modular_semantic_segmentation_amd.fcn import FP8_GUARD_CANDIDATES
+    g = np.load(os.path.join(golden_dir, 'notebook_868.npz'))
+    desc = ({'rgb': 'float32', 'depth': 'float32', 'labels': 'int32'},
+            {'rgb': (None, None, 3), 'depth': (None, None, 1), 'labels': (None, None)}, 12)
+    cfg = dict(data_description=desc, confusion_matrices={'rgb': g['cm_rgb'], 'depth': g['cm_depth']}, num_units=64,
+               prefixes={'rgb': 'rgb', 'depth': 'depth'}, num_channels={'rgb': 3, 'depth': 1}, expert_model='fcn',
+               class_prior='data', batchsize=2, seed=3)
+    rng = np.random.default_rng(1)
+    data = {'rgb': rng.integers(0, 256, (2, 64, 96, 3)).astype(np.float32),
+            'depth': rng.integers(0, 65536, (2, 64, 96, 1)).astype(np.float32)}
+
+    def make(**kw):
+        net = get_model('bayes_fusion')(**cfg, **kw)
+        net.variables['depth/conv1_1/kernel'] = net.variables['depth/conv1_1/kernel'] / 256.0
+        net._variables_changed()
+        return net
+
+    ref = make(conv_dtype='bf16').predict(data)
+    net = make(conv_dtype='fp8')
+    net.calibrate(data)
+    rep = fp8_plan_report(net)
+    for m in ('rgb', 'depth'):
+        assert rep[m]['bound'] == 0.995 and set(rep[m]['agreement']) <= set(FP8_GUARD_CANDIDATES)
+        assert all(0.0 <= a <= 1.0 for a in rep[m]['agreement'].values())
+        if rep[m]['chosen'] == 'bf16':
+            assert len(rep[m]['agreement']) == len(FP8_GUARD_CANDIDATES) and max(rep[m]['agreement'].values()) < 0.995
+        else:
+            assert rep[m]['agreement'][rep[m]['chosen']] >= 0.995
+    if all(rep[m]['chosen'] == 'bf16' for m in rep):
+        assert np.array_equal(net.predict(data), ref)                   # an fp8 model whose experts all fell back IS the bf16 model
+    loose = make(conv_dtype='fp8', fp8_agreement=0.3)
+    loose.calibrate(data)
+    rep = fp8_plan_report(loose)
+    assert all(rep[m]['chosen'] == 'conv2_2' and list(rep[m]['agreement']) == ['conv2_2'] for m in rep), rep
+    L = loose.experts['rgb'].encoder(torch.from_numpy(data['rgb']).cuda(), keep_all=True)
+    assert L['conv2_1'].dtype == 'fp8' and L['pool1'].dtype == 'bf16'
+    fixed = make(conv_dtype='fp8', fp8_start={'rgb': 'conv4_1', 'depth': 'bf16'})
+    fixed.calibrate(data)
+    rep = fp8_plan_report(fixed)
+    assert rep['rgb']['chosen'] == 'conv4_1' and rep['depth']['chosen'] == 'bf16' and rep['rgb']['bound'] is None
+    L = fixed.experts['depth'].encoder(torch.from_numpy(data['depth']).cuda(), keep_all=True)
+    assert all(a.dtype == 'bf16' for k, a in L.items() if hasattr(a, 'dtype'))
+    L = fixed.experts['rgb'].encoder(torch.from_numpy(data['rgb']).cuda(), keep_all=True)
+    assert L['conv3_3'].dtype == 'fp8' and L['conv3_2'].dtype == 'bf16'
+    assert fixed.predict(data).shape == (2, 64, 96)
 
 
 def test_fp8_scales_are_dropped_when_weights_change(ops):
