@@ -293,14 +293,25 @@ __global__ __launch_bounds__(512, 2) void conv_first_pair_kernel(F1Args a) {
             for (int e = 0; e < 8; ++e) v[e] = 0.f;
           }
         } else if constexpr (CIN == 3) {
-          v[0] = ok[0] ? (main ? raw[0][0] : raw[0][2]) : 0.f;
-          v[1] = main ? (ok[0] ? raw[0][1] : 0.f) : (ok[1] ? raw[1][2] : 0.f);
-          v[2] = main ? (ok[0] ? raw[0][2] : 0.f) : (ok[2] ? raw[2][2] : 0.f);
-          v[3] = main ? (ok[1] ? raw[1][0] : 0.f) : (inside ? 1.f : 0.f);  // k-group 3: the bias slot (zero padding outside)
-          v[4] = main && ok[1] ? raw[1][1] : 0.f;
-          v[5] = main && ok[1] ? raw[1][2] : 0.f;
-          v[6] = main && ok[2] ? raw[2][0] : 0.f;
-          v[7] = main && ok[2] ? raw[2][1] : 0.f;
+          // (the taps as VALUES before they meet a select: the compiler turned `main ? raw[0][0] : raw[0][2]` into one load at
+          // a selected address, which put the whole array on the stack -- 32 bytes of scratch and an indexed scratch_load per
+          // block in this edge-tile form, found by tools/occupancy_scan.py in round 5)
+          float r[3][3];
+#pragma unroll
+          for (int t = 0; t < 3; ++t)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+              r[t][c] = raw[t][c];
+              asm volatile("" : "+v"(r[t][c]));
+            }
+          v[0] = ok[0] ? (main ? r[0][0] : r[0][2]) : 0.f;
+          v[1] = main ? (ok[0] ? r[0][1] : 0.f) : (ok[1] ? r[1][2] : 0.f);
+          v[2] = main ? (ok[0] ? r[0][2] : 0.f) : (ok[2] ? r[2][2] : 0.f);
+          v[3] = main ? (ok[1] ? r[1][0] : 0.f) : (inside ? 1.f : 0.f);  // k-group 3: the bias slot (zero padding outside)
+          v[4] = main && ok[1] ? r[1][1] : 0.f;
+          v[5] = main && ok[1] ? r[1][2] : 0.f;
+          v[6] = main && ok[2] ? r[2][0] : 0.f;
+          v[7] = main && ok[2] ? r[2][1] : 0.f;
         } else {
           v[0] = main ? (ok[0] ? raw[0][0] : 0.f) : (inside ? 1.f : 0.f);  // k-group 3: the bias slot
           v[1] = ok[1] ? raw[1][0] : 0.f, v[2] = ok[2] ? raw[2][0] : 0.f;

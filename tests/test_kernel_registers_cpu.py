@@ -17,6 +17,15 @@ BUDGETS = [
     ('pointwise.hip', 'fused_head_kernelILi12ELi0ELb1ELi4E', 4, 0),        # Bayes: 98 registers (168 with per-pixel class sums)
     ('pointwise.hip', 'decoder_head_label4_kernelILi12E', 5, 0),
     ('fusion.hip', 'dirichlet_fuse_pk_kernelILi12E', 6, 0),                # 66 registers; 372 inside a grid-stride loop
+    # round 6: the fused first pair carried 32 bytes of scratch in its RGB forms -- the masked tap gather of its edge-tile path
+    # selected between array elements, which the compiler turned into an indexed load from a stack copy of the array
+    ('conv_first_fused.hip', 'conv_first_pair_kernelILi3ELb0E', 2, 0),
+    ('conv_first_fused.hip', 'conv_first_pair_kernelILi3ELb1E', 2, 0),
+    ('conv_first_fused.hip', 'conv_first_pair_kernelILi1ELb0E', 2, 0),
+    ('conv_wgrad.hip', 'conv_wgrad_lw_kernel', 2, 0),                      # 248 registers: 144 accumulators + the fragment rings
+    # (36 bytes of true spills at the 128 registers a 1 024-thread workgroup allows: nine 64-bit load addresses per column
+    # batch; a 60 us kernel)
+    ('backward.hip', 'head_bwd_lowres_kernelILi12E', 4, 36),
 ]
 
 

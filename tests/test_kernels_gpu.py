@@ -139,10 +139,12 @@ def test_conv1x1_narrow_gemm(ops, n, h, w, cin):
 
 
 @pytest.mark.parametrize('n,h,w,cin,cout', [(1, 6, 10, 64, 128), (2, 24, 48, 576, 256), (3, 7, 5, 128, 384),
-                                            (1, 30, 33, 256, 128)])
+                                            (1, 30, 33, 256, 128), (4, 95, 190, 192, 128), (5, 47, 97, 64, 256),
+                                            (3, 96, 191, 128, 384)])
 def test_conv1x1_flat_gemm(ops, n, h, w, cin, cout):
     """Generation 3 (flat GEMM over the padded rows, cfg 18): exact on integers, with activation + addend + mask in
-    the order of the other kernels, border untouched, row counts that are not multiples of the 128-row tile."""
+    the order of the other kernels, border untouched, row counts that are not multiples of the 128-row tile.  The last three
+    shapes (round 6) are launches of hundreds of workgroups with one, three and six K steps."""
     rng = np.random.default_rng(n * h * w + cin)
     x = rng.integers(-2, 3, (n, h, w, cin)).astype(np.float32)
     wt = rng.integers(-1, 2, (1, 1, cin, cout)).astype(np.float32)

@@ -20,7 +20,7 @@ for d in ('${TAG}_wgrad_pmc1', '${TAG}_wgrad_pmc2'):
         for r in csv.DictReader(open(f)):
             name = r['Kernel_Name']
             key = None
-            for k in ('conv_wgrad_dma_kernel', 'conv_dma4_kernel', 'conv_dma5_kernel'):
+            for k in ('conv_wgrad_lw_kernel', 'conv_wgrad_dma_kernel', 'conv_dma4_kernel', 'conv_dma5_kernel'):
                 if k in name:
                     key = k + ('<DG>' if k == 'conv_dma4_kernel' and 'true, true, false>' in name.replace(', true>', ', true, X>') else '')
             if key is None:
