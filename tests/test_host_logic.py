@@ -6,6 +6,7 @@ import re
 
 import numpy as np
 import pytest
+import torch
 
 from modular_semantic_segmentation_amd import _lib, get_model
 from modular_semantic_segmentation_amd import base_model, bayes_mix, custom_layers, dirichlet_fit, dirichlet_mix, fcn
@@ -402,6 +403,43 @@ def test_dense_deconv_index_maps_are_the_kernel_map_and_its_adjoint(k, s):
     assert np.abs(dW - Wt.grad.numpy()).max() < 1e-4 * np.abs(Wt.grad.numpy()).max()
     assert float((x2.grad - x.grad).abs().max()) < 1e-4 * float(x.grad.abs().max())
     assert float((fo.deconv_same(x.detach(), W, s) - y.detach()).abs().max()) < 1e-5
+
+
+def test_reference_named_layer_functions_host_side(golden_dir):
+    """custom_layers' reference-named entry points, the parts that need no GPU: bilinear_filter_initializer is the reference's
+    constant (tests/golden/bilinear_kernels.npz, generated by importing custom_layers.py:8-25) behind a verify_shape=True
+    initializer; argument checking of conv2d / deconv2d happens before any launch."""
+    import numpy as np
+    g = np.load(os.path.join(golden_dir, 'bilinear_kernels.npz'))
+    init = custom_layers.bilinear_filter_initializer([4, 4, 3, 7])
+    np.testing.assert_array_equal(init([4, 4, 3, 7]), g['k4_rect'].astype(np.float32))
+    np.testing.assert_array_equal(custom_layers.bilinear_filter_initializer((16, 16, 2, 5))(), g['k16_rect'].astype(np.float32))
+    with pytest.raises(ValueError):
+        init([4, 4, 3, 3])
+    assert custom_layers._is_relu('relu') and custom_layers._is_relu(torch.relu) and not custom_layers._is_relu(None)
+    with pytest.raises(NotImplementedError):
+        custom_layers._is_relu('tanh')
+    assert custom_layers._square([3, 3], 'k') == 3 and custom_layers._square(8, 'k') == 8
+    with pytest.raises(NotImplementedError):
+        custom_layers._square([3, 5], 'kernel_size')
+    with pytest.raises(KeyError):
+        custom_layers._var({'a/b/kernel': 1}, 'a', 'c', 'kernel')
+
+
+def test_fp8_guard_bound_from_the_model_config():
+    """The accuracy guard of calibrate() (basic_fusion_model.fp8_guard_bound): on by default at 0.995, a bound of the caller's,
+    off at 0 / None, and never second-guessing an explicit plan."""
+    from modular_semantic_segmentation_amd.basic_fusion_model import fp8_guard_bound
+    from modular_semantic_segmentation_amd.fcn import FP8_GUARD_AGREEMENT, FP8_GUARD_CANDIDATES
+    assert FP8_GUARD_AGREEMENT == 0.995 and FP8_GUARD_CANDIDATES[0] == fcn.FP8_DEFAULT_START
+    assert fp8_guard_bound({}) == 0.995 and fp8_guard_bound({'fp8_agreement': 0.99}) == 0.99
+    assert fp8_guard_bound({'fp8_agreement': 0}) is None and fp8_guard_bound({'fp8_agreement': None}) is None
+    assert fp8_guard_bound({'fp8_start': 'conv3_1'}) is None and fp8_guard_bound({'fp8_deep': True}) is None
+    assert fp8_guard_bound({'fp8_start': {'rgb': 'conv2_2', 'depth': 'bf16'}}) is None
+    # every candidate is a plan fp8_plan accepts
+    for start in FP8_GUARD_CANDIDATES:
+        convs, maps = fcn.fp8_plan(start=start)
+        assert convs[0] == start and 'conv5_3' in convs
 
 
 def test_padded_units():
