@@ -205,6 +205,9 @@ class FcnEngine(object):
             warnings.warn('FcnEngine.load(): new weights invalidate the fp8 calibration of %r; call calibrate() again '
                           '(otherwise the next batch seen is used)' % self.prefix, RuntimeWarning, stacklevel=2)
         self.fp8_scales, self._fp8_explicit = None, False
+        if getattr(self, 'fp8_guard', None) is not None:
+            # a plan calibrate_guarded() chose was chosen FOR THE OLD WEIGHTS: back to the default plan until it is called again
+            self.fp8_off, self.fp8_start, self.fp8_guard = False, None, None
         v = {k: np.asarray(a, np.float32) for k, a in variables.items() if k.startswith(p + '/')}
         for need, shape in variable_shapes(p, self.cin, self.U, self.C).items():
             if need not in v:
