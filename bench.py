@@ -303,7 +303,17 @@ def measure_inference(net, batch, device, steps, warmup, graph=True, serial=None
     net.concurrent_experts = False
     net._predict_batch(batch)
     ops.CONV_PROFILE = prof
-    times_serial = timed_blocks(lambda: net._predict_batch(batch), steps, device, 1, None, min(min_seconds, 1.0))
+    # (an event pair around an EAGER launch also spans the gap if the host delivers the launch late: a collector pause of a
+    # few milliseconds inside this pass showed as one block at half the rate -- `frac_min` 0.07-0.25 of a record whose other
+    # 40 blocks agree to 2 %; the median never saw it.  No collections during the pass.)
+    import gc
+    gc_was = gc.isenabled()
+    gc.disable()
+    try:
+        times_serial = timed_blocks(lambda: net._predict_batch(batch), steps, device, 1, None, min(min_seconds, 1.0))
+    finally:
+        if gc_was:
+            gc.enable()
     ops.CONV_PROFILE = None
     net.concurrent_experts = None if serial is None else not serial
     return times, per_iter, prof, times_serial

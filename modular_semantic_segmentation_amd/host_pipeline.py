@@ -36,6 +36,20 @@ def _pool():
     return _POOL
 
 
+_COLLECT_POOL = None
+
+
+def _collect_pool():
+    """The collect tasks of ResultFetcher wait for the sub-copies they hand to _pool(): they run on an executor of their own,
+    so that however many predict() / score() calls are in flight on other threads (each keeps up to three collects alive) no
+    collect can hold a worker of the pool its own sub-copies are queued on (three concurrent calls could fill all
+    eight workers with collects waiting for sub-tasks that never got a worker)."""
+    global _COLLECT_POOL
+    if _COLLECT_POOL is None:
+        _COLLECT_POOL = ThreadPoolExecutor(max_workers=4, thread_name_prefix='xv-collect')
+    return _COLLECT_POOL
+
+
 class _blocked(object):
     """with _blocked('cause'): ...  -- accumulates wall time into TRACE when tracing is on"""
 
@@ -199,8 +213,8 @@ class ResultFetcher(object):
     @staticmethod
     def _collect(slot, dst, n):
         slot.d2h_done.synchronize()
-        # the result array is fresh memory: first touch costs more than the copy, so split it over the pool as well (a
-        # small pool copies here: at most three collects wait at a time, they must never hold every worker)
+        # the result array is fresh memory: first touch costs more than the copy, so split it over the pool as well (this
+        # task itself runs on _collect_pool(): it never occupies a worker of the pool it waits on)
         if _pool()._max_workers >= 8:
             for f in _parallel_copy(dst, slot.pinned.numpy(), n):
                 f.result()
@@ -245,7 +259,7 @@ class ResultFetcher(object):
             dst = np.empty(tuple(out.shape), dtype=host_dtype)
             self.chunks.append(dst)
         self.pos += n
-        slot.collected = _pool().submit(self._collect, slot, dst, n)
+        slot.collected = _collect_pool().submit(self._collect, slot, dst, n)
 
     def finish(self):
         with _blocked('finish: last collects'):

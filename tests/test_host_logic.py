@@ -442,6 +442,23 @@ def test_fp8_guard_bound_from_the_model_config():
         assert convs[0] == start and 'conv5_3' in convs
 
 
+def test_result_collects_never_wait_on_their_own_pool():
+    """ResultFetcher's collect tasks wait for sub-copies on the shared staging pool; they run on a pool of their
+    own, so forty of them in flight (far more than the eight staging workers) all finish."""
+    from modular_semantic_segmentation_amd import host_pipeline as hp
+    assert hp._collect_pool() is not hp._pool()
+    src = np.arange(1 << 18, dtype=np.uint8).reshape(64, -1)
+
+    def collect():
+        dst = np.empty(src.shape, np.int64)
+        for f in hp._parallel_copy(dst, src, 64):
+            f.result()
+        return bool((dst == src).all())
+
+    futures = [hp._collect_pool().submit(collect) for _ in range(40)]
+    assert all(f.result(timeout=120) for f in futures)
+
+
 def test_padded_units():
     """Decoder widths: 64 / 128 / 256 lanes (every kernel behind them, the batch-norm passes included, takes those), multiples
     of 64 beyond."""
