@@ -248,9 +248,18 @@ def measure_inference(net, batch, device, steps, warmup, graph=True, serial=None
 
     for _ in range(warmup):
         step()
+    net._bench_graph_used = False
     if graph:
-        net.capture_graph(batch)
+        try:
+            net.capture_graph(batch)
+        except Exception as exc:       # noqa: BLE001  (a failed capture must not cost the line: the eager step is the same work)
+            print('bench.py: hipGraph capture failed (%s: %s); timing eager launches' % (type(exc).__name__, exc), file=sys.stderr)
+            net._graph = None
+            torch.cuda.synchronize(device)
+            graph = False
+    if graph:
         g = net._graph[0]
+        net._bench_graph_used = True
 
         def step():             # noqa: F811  (inputs already sit in the graph's static buffers)
             g.replay()
@@ -894,7 +903,7 @@ def main():
         'config': {'workload': 'two-stream SimpleFCN RGB+Depth %dx%d + %s fusion, U=%d, C=%d, random-init weights'
                                % (args.width, args.height, args.fusion, U, C),
                    'images_per_gpu_per_step': args.batch, 'global_batch': args.batch * world,
-                   'expert_streams': 1 if args.serial_experts else (2 if args.two_streams else 'auto: 2 for batches whose launches leave CUs idle, else 1'), 'hip_graph': bool(args.graph),
+                   'expert_streams': 1 if args.serial_experts else (2 if args.two_streams else 'auto: 2 for batches whose launches leave CUs idle, else 1'), 'hip_graph': bool(getattr(net, '_bench_graph_used', args.graph)),
                    'parallelism': 'dp%d (batch sharding, no data-path collective)' % world},
         'conv_tflops_end_to_end': round(images * flops_img / dt / 1e12, 2),
         'roofline': roofline,

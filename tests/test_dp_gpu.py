@@ -384,3 +384,45 @@ def test_rccl_process_group_on_one_gpu(tmp_path):
     mp.spawn(_rccl_one_rank_worker, args=(_free_port(), out), nprocs=1, join=True)
     r = np.load(out)
     assert float(r['t'][0]) == 0.125 and r['g'].tolist() == [1048572.0, 1048573.0, 1048574.0, 1048575.0] and r['b'].tolist() == [3.0, 3.0]
+
+
+def _rccl_graph_worker(rank, port, out):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
+    t = torch.ones(8, device='cuda:0')
+    dist.all_reduce(t)                       # the communicator (and its watchdog thread) exist from here on
+    torch.cuda.synchronize()
+    from modular_semantic_segmentation_amd import get_model
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'notebook_868.npz'))
+    desc = ({'rgb': 'float32', 'depth': 'float32', 'labels': 'int32'},
+            {'rgb': (None, None, 3), 'depth': (None, None, 1), 'labels': (None, None)}, C)
+    net = get_model('bayes_fusion')(data_description=desc, confusion_matrices={'rgb': g['cm_rgb'], 'depth': g['cm_depth']},
+                                    num_units=U, prefixes={'rgb': 'rgb', 'depth': 'depth'}, num_channels={'rgb': 3, 'depth': 1},
+                                    expert_model='fcn', class_prior='data', batchsize=2, seed=3)
+    rng = np.random.default_rng(2)
+    batch = {'rgb': torch.from_numpy(rng.integers(0, 256, (2, 64, 96, 3)).astype(np.float32)).cuda(),
+             'depth': torch.from_numpy(rng.integers(0, 65536, (2, 64, 96, 1)).astype(np.float32)).cuda()}
+    eager = net._predict_batch(batch).clone()
+    net.capture_graph(batch)                 # what bench.py's timed region replays, here beside a live RCCL communicator
+    for _ in range(3):
+        dist.all_reduce(t)                   # collectives between replays, as the bench's fences issue them
+        net._graph[0].replay()
+    torch.cuda.synchronize()
+    same = bool(torch.equal(net._graph[2], eager))
+    dist.barrier()
+    np.savez(out, same=same, t=t.cpu().numpy())
+    dist.destroy_process_group()
+
+
+def test_graph_capture_beside_an_rccl_process_group(tmp_path):
+    """bench.py --gpus N captures the inference step into a hipGraph AFTER init_process_group('nccl'): the capture must
+    survive the communicator's watchdog thread (a capture in 'global' error mode is invalidated by another thread's event
+    query), and replays must interleave with collectives.  One rank on one GPU exercises exactly that."""
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU')
+    out = str(tmp_path / 'rccl_graph.npz')
+    mp.spawn(_rccl_graph_worker, args=(_free_port(), out), nprocs=1, join=True)
+    r = np.load(out)
+    assert bool(r['same']) and float(r['t'][0]) == 1.0
