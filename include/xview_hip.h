@@ -542,6 +542,9 @@ int xv_bn_bwd_apply_zmask(const xv_act* dy, const xv_act* z, const float* mean, 
 int xv_bn_stats_finalize_ups8_ws(const xv_act* low, double* sums, void* workspace, size_t workspace_bytes, const float* gamma,
                                  const float* beta, float eps, float momentum, float* moving_mean, float* moving_var, float* mean,
                                  float* invstd, float* scale, float* shift, void* stream);
+/* (round 6) the statistics pass alone, for data-parallel runs: sums[c] = sum z, sums[C + c] = sum z^2 over the recomputed map;
+ * the caller all-reduces `sums` and finalises with xv_bn_finalize on the global pixel count.                                   */
+int xv_bn_stats_ups8_ws(const xv_act* low, double* sums, void* workspace, size_t workspace_bytes, void* stream);
 int xv_bn_apply_ups8(const xv_act* low, const float* scale, const float* shift, int relu, const xv_act* y, void* stream);
 /* ... the forward apply pass FUSED with the dense score conv behind it: y (as xv_bn_apply_ups8 with relu) and score = y . W + b
  * (as xv_score_dense_fwd) in one launch -- 64 units, at most 16 classes; XV_ESHAPE elsewhere.                                  */

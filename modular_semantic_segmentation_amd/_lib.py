@@ -129,6 +129,7 @@ SIGNATURES = {
     'xv_bn_pool_bwd_reduce': (_i, [_actp, _actp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_size_t, _vp]),
     'xv_bn_pool_bwd_apply': (_i, [_actp, _actp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _actp, _vp]),
     'xv_bn_stats_ws': (_i, [_actp, _vp, _vp, ctypes.c_size_t, _vp]),
+    'xv_bn_stats_ups8_ws': (_i, [_actp, _vp, _vp, ctypes.c_size_t, _vp]),
     'xv_bn_bwd_reduce_ws': (_i, [_actp, _actp, _actp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_size_t, _vp]),
     'xv_bn_dense_stats_ws': (_i, [_vp, _i64, _i, _vp, _vp, ctypes.c_size_t, _vp]),
     'xv_bn_dense_bwd_reduce_ws': (_i, [_vp, _vp, _i64, _i, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_size_t, _vp]),

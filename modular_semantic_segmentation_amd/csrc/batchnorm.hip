@@ -2048,6 +2048,25 @@ extern "C" int xv_bn_stats_finalize_ups8_ws(const xv_act* low, double* sums, voi
                      (double)((int64_t)n * h * w), gamma, beta, eps, momentum, moving_mean, moving_var, mean, invstd, scale, shift);
   return xv_launch_status();
 }
+// The statistics pass alone (sums[c] = sum z, sums[C + c] = sum z^2 over the recomputed map), for data-parallel runs: the
+// caller all-reduces `sums` over the ranks and finalises with xv_bn_finalize (count = pixels of the GLOBAL batch).  The same
+// per-workgroup rows in the same order as xv_bn_stats_finalize_ups8_ws: bitwise reproducible.
+extern "C" int xv_bn_stats_ups8_ws(const xv_act* low, double* sums, void* workspace, size_t workspace_bytes, void* stream) {
+  XV_CHECK_ARG(low && sums && workspace);
+  const int n = low->n, h = 8 * low->h, w = 8 * low->w, c = low->c;
+  XV_CHECK_SHAPE(ups_ok(low, n, h, w, c));
+  if (workspace_bytes < (size_t)BN_MAX_GRID * 2 * c * sizeof(float) || ((uintptr_t)workspace & 15)) return XV_EWORKSPACE;
+  hipStream_t s = (hipStream_t)stream;
+  const dim3 g2 = ups8_reduce_grid(n, h, w, c);
+  const int grid = (int)(g2.x * g2.y);
+  XV_CHECK_SHAPE(grid <= BN_MAX_GRID);
+  hipLaunchKernelGGL(bn_ups8_reduce8_kernel<false>, g2, dim3(256), 0, s, (const __bf16*)low->data, (const __bf16*)nullptr,
+                     (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (float*)workspace, n,
+                     h, w, c);
+  hipLaunchKernelGGL(bn_sums_kernel, dim3(2 * c), dim3(256), 0, s, (const float*)workspace, grid, 2 * c, sums, (float*)nullptr,
+                     (float*)nullptr);
+  return xv_launch_status();
+}
 extern "C" int xv_bn_apply_ups8(const xv_act* low, const float* scale, const float* shift, int relu, const xv_act* y, void* stream) {
   XV_REQUIRE_BF16(y);
   XV_CHECK_ARG(low && y && y->data && scale && shift);

@@ -842,16 +842,23 @@ def bn_forward(z, gamma, beta, moving_mean, moving_var, st, y, relu=True, sync=F
     """y = [relu](BN_batch(z)); updates the moving statistics in place (z, y: Act).  sync: statistics over all
     data-parallel ranks (one all-reduce of 2*C doubles).  pooled (with relu): the 2x2 max-pool of y from the same pass; y
     may then be None (only the pooled map is written).  ups8_of (an Act 8 times smaller, with z None): z IS its bilinear x8
-    up-sampling and is recomputed per element instead of read (one process, deterministic workspace only)."""
+    up-sampling and is recomputed per element instead of read (deterministic workspace only; with sync the sums are all-reduced
+    between the statistics pass and the per-channel results, like every other batch norm)."""
     lib = _lib.lib()
     fin = (_ptr(gamma), _ptr(beta), BN_EPS, BN_MOMENTUM, _ptr(moving_mean), _ptr(moving_var), _ptr(st.mean), _ptr(st.invstd),
            _ptr(st.scale), _ptr(st.shift))
     ws = st.wsp()
     if ups8_of is not None:
-        if sync or st.ws is None or pooled is not None or have_stats:
-            raise ValueError('bn_forward(ups8_of=): single-process statistics with a workspace, no pool')
-        _lib.check(lib.xv_bn_stats_finalize_ups8_ws(ups8_of.xv(), _ptr(st.sums), ws[0], ws[1], *fin, _stream()),
-                   'xv_bn_stats_finalize_ups8_ws')
+        if st.ws is None or pooled is not None or have_stats:
+            raise ValueError('bn_forward(ups8_of=): statistics with a workspace, no pool')
+        if sync:    # data parallel: the sums alone, all-reduced over the ranks, then the per-channel results
+            _lib.check(lib.xv_bn_stats_ups8_ws(ups8_of.xv(), _ptr(st.sums), ws[0], ws[1], _stream()), 'xv_bn_stats_ups8_ws')
+            mult = _sync_sums(st, sync)
+            _lib.check(lib.xv_bn_finalize(_ptr(st.sums), st.c, ups8_of.n * 64 * ups8_of.h * ups8_of.w * mult, *fin, _stream()),
+                       'xv_bn_finalize')
+        else:
+            _lib.check(lib.xv_bn_stats_finalize_ups8_ws(ups8_of.xv(), _ptr(st.sums), ws[0], ws[1], *fin, _stream()),
+                       'xv_bn_stats_finalize_ups8_ws')
         if y is None:           # statistics only: the apply pass is fused into what follows (score_dense_fwd_ups8)
             return None
         _lib.check(lib.xv_bn_apply_ups8(ups8_of.xv(), _ptr(st.scale), _ptr(st.shift), int(bool(relu)), y.xv(), _stream()),

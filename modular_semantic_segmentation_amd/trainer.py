@@ -569,15 +569,15 @@ class FcnBnTrainer(object):
         fused = ops.upsample2x_relu_add(Y['score_conv5'], residual=Y['score_conv4'], y=self._act('fused', n, h8, w8, e.Up),
                                         scale=st.scale, shift=st.shift)            # = y_up5 + y_score_conv4
         # The x8 deconv's output (0.6 GB at 16 images) is not stored: the four batch-norm passes that would read it back
-        # recompute it from `fused` per element (ops.bn_forward / bn_backward, ups8_of=).  Data-parallel runs (statistics
-        # all-reduced between the passes) and keep_all (inspection) keep the stored map.
-        virtual_up = (_VIRTUAL_UPSCORE and not self._sync and not self.keep_all and self.bn['upscore'].ws is not None
+        # recompute it from `fused` per element (ops.bn_forward / bn_backward, ups8_of=) -- data-parallel runs too since round 6
+        # (the statistics all-reduced between the passes: xv_bn_stats_ups8_ws); keep_all (inspection) keeps the stored map.
+        virtual_up = (_VIRTUAL_UPSCORE and not self.keep_all and self.bn['upscore'].ws is not None
                       and _ups8_channels_ok(e.Up))
         score_raw = None
         if virtual_up:
             Z['upscore'] = None
             y_up = self._act('y_up', n, h, w, e.Up)
-            self._bn_fwd('upscore', None, None, ups8_of=fused)                    # statistics, scale / shift
+            self._bn_fwd('upscore', None, None, ups8_of=fused)                    # statistics (global under data parallelism), scale / shift
             score_raw = self._dense('score_raw', (n, h, w, e.C))
             if not ops.score_dense_fwd_ups8(fused, self.bn['upscore'], self.w['score'], P('score', 'bias'), e.C, y_up, score_raw):
                 score_raw = None
@@ -904,14 +904,14 @@ class FusionFcnTrainer(object):
                             y=self._act('s5', n, h8 // 2, w8 // 2, e.Up))[0]
         feat = ops.upsample2x_relu_add(s5, residual=s4, y=self._act('features', n, h8, w8, e.Up))
         # (the x8 deconv's output is not stored: see FcnBnTrainer.step)
-        virtual_up = _VIRTUAL_UPSCORE and not self._sync and self.bn['upscore'].ws is not None and _ups8_channels_ok(e.Up)
+        virtual_up = _VIRTUAL_UPSCORE and self.bn['upscore'].ws is not None and _ups8_channels_ok(e.Up)
         mm, mv = self.moving['upscore']
         z_up = None if virtual_up else ops.upsample_raw_fwd(feat, 8, self._act('z_up', n, h, w, e.Up))
         score_raw = None
         if virtual_up:
             y_up = self._act('y_up', n, h, w, e.Up)
             ops.bn_forward(None, P('upscore', 'gamma'), P('upscore', 'beta'), mm, mv, self.bn['upscore'], None, relu=True,
-                           ups8_of=feat)                                            # statistics, scale / shift
+                           sync=self._sync, ups8_of=feat)                           # statistics, scale / shift
             score_raw = self._dense('score_raw', (n, h, w, e.C))
             if not ops.score_dense_fwd_ups8(feat, self.bn['upscore'], P('score', 'kernel'), P('score', 'bias'), e.C, y_up, score_raw):
                 score_raw = None
