@@ -67,7 +67,8 @@ def dense_deconv_as_conv3x3(kernel, stride):
 # 'channels_last'`) are accepted and ignored.  Packed weights are cached per (variables dict, layer): call
 # `clear_layer_cache()` after changing a dict in place.
 # =====================================================================================================================
-_LAYER_CACHE = {}
+_LAYER_CACHE = {}         # key (kind, id(variables), ...) -> (variables, payload): the entry keeps the dict alive, so that the
+#                           id in its key cannot be handed to another dict while the entry exists
 _IGNORED = ('reuse', 'trainable', 'kernel_initializer', 'bias_initializer', 'kernel_regularizer', 'bias_regularizer',
             'activity_regularizer', 'data_format')
 BN_EPSILON = 1e-3       # [TF1] tf.layers.batch_normalization default
@@ -75,6 +76,16 @@ BN_EPSILON = 1e-3       # [TF1] tf.layers.batch_normalization default
 
 def clear_layer_cache():
     _LAYER_CACHE.clear()
+
+
+def _cache_get(key, variables):
+    ent = _LAYER_CACHE.get(key)
+    return ent[1] if ent is not None and ent[0] is variables else None
+
+
+def _cache_put(key, variables, payload):
+    _LAYER_CACHE[key] = (variables, payload)
+    return payload
 
 
 class _ConstantInitializer(object):
@@ -144,7 +155,7 @@ def _bn_training_state(variables, scope, name, channels, real, device):
     import torch
     from . import ops
     key = ('bn', id(variables), scope, name, channels, str(device))
-    st = _LAYER_CACHE.get(key)
+    st = _cache_get(key, variables)
     if st is None:
         def pad(kind, fill):
             v, _ = _var(variables, scope, name, kind)
@@ -153,7 +164,7 @@ def _bn_training_state(variables, scope, name, channels, real, device):
             return torch.from_numpy(out).to(device)
         st = {'gamma': pad('gamma', 1.0), 'beta': pad('beta', 0.0), 'mm': pad('moving_mean', 0.0),
               'mv': pad('moving_variance', 1.0), 'st': ops.BnState(channels, device)}
-        _LAYER_CACHE[key] = st
+        _cache_put(key, variables, st)
     return st
 
 
@@ -198,7 +209,7 @@ def conv2d(inputs, filters, kernel_size, batch_normalization=False, training=Fal
     b = _var(variables, scope, name, 'bias')[0] if use_bias else np.zeros(filters, np.float32)
     fold = batch_normalization and not training
     ckey = ('conv', id(variables), wkey, fold, cin, str(dev))
-    ent = _LAYER_CACHE.get(ckey)
+    ent = _cache_get(ckey, variables)
     first = cin <= 4
     score = (not first) and k == 1 and filters <= 32 and cin <= 256 and not relu
     cout_p = filters if (first or score) else (filters + 63) // 64 * 64
@@ -224,7 +235,7 @@ def conv2d(inputs, filters, kernel_size, batch_normalization=False, training=Fal
             bp = np.zeros(cout_p, np.float32)
             bp[:filters] = bf
             ent = (ops.pack_conv_weights(torch.from_numpy(wp).to(dev)), torch.from_numpy(bp).to(dev))
-        _LAYER_CACHE[ckey] = ent
+        _cache_put(ckey, variables, ent)
     wdev, bdev = ent
     bn_train = batch_normalization and training
     if score:
@@ -306,13 +317,13 @@ def deconv2d(inputs, filters, kernel_size, strides=(1, 1), padding='valid', acti
                                                   ops._stream()), 'xv_bn_apply')
     else:
         ckey = ('deconv', id(variables), wkey, x.c, str(dev))
-        ent = _LAYER_CACHE.get(ckey)
+        ent = _cache_get(ckey, variables)
         if ent is None:
             wp = np.zeros((k, k, cp, x.c), np.float32)
             wp[:, :, :filters, :real_in] = w
             ent = (ops.pack_conv_weights(torch.from_numpy(dense_deconv_as_conv3x3(wp, s)).to(dev)),
                    torch.zeros(s * s * cp, dtype=torch.float32, device=dev))
-            _LAYER_CACHE[ckey] = ent
+            _cache_put(ckey, variables, ent)
         y = ops.deconv_dense_fwd(x, ent[0], ent[1], s, cp, scale=scale, shift=shift, relu=relu and not bn_train)[0]
     if bn_train:
         st = _bn_training_state(variables, scope, name, cp, filters, dev)

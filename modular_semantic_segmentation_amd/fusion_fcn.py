@@ -295,7 +295,9 @@ def vgg16(inputs, prefix, params=None, variables=None):
     initialisers)."""
     cin = int(inputs.shape[-1])
     key = (prefix, cin, id(variables))
-    t = _TRUNKS.get(key)
+    ent = _TRUNKS.get(key)      # (variables dict, trunk): the entry keeps the dict alive -- its id is part of the key -- and checks identity
+    t = ent[1] if ent is not None and ent[0] is variables else None
+    given = variables
     if t is None:
         if variables is None:
             rng = np.random.default_rng(0)
@@ -306,7 +308,8 @@ def vgg16(inputs, prefix, params=None, variables=None):
                     variables[name] = rng.uniform(-lim, lim, size=shape).astype(np.float32)
                 else:
                     variables[name] = np.zeros(shape, np.float32)
-        t = _TRUNKS[key] = VggTrunk(prefix, cin, variables, inputs.device)
+        t = VggTrunk(prefix, cin, variables, inputs.device)
+        _TRUNKS[key] = (given, t)
     return t.forward(inputs, keep_all=True)
 
 
@@ -317,12 +320,15 @@ def fusion_fcn(inputs, prefixes, num_units, num_classes, variables=None, **unuse
     num_channels = {m: int(inputs[m].shape[-1]) for m in prefixes}
     key = (tuple(sorted(prefixes.items())), tuple(sorted(num_channels.items())), int(num_units), int(num_classes),
            id(variables))
-    eng = _ENGINES.get(key)
+    ent = _ENGINES.get(key)
+    eng = ent[1] if ent is not None and ent[0] is variables else None
     if eng is None:
+        given = variables
         if variables is None:
             variables = init_variables(prefixes, num_channels, num_units, num_classes)
-        eng = _ENGINES[key] = FusionFcnEngine(prefixes, num_channels, num_units, num_classes, variables,
-                                              device=next(iter(inputs.values())).device)
+        eng = FusionFcnEngine(prefixes, num_channels, num_units, num_classes, variables,
+                              device=next(iter(inputs.values())).device)
+        _ENGINES[key] = (given, eng)
     out = eng.forward(inputs, want=('score', 'prob', 'label'), keep_all=True)
     layers = dict(out['layers'])
     layers.update(score=out['score'], prob=out['prob'], classification=out['label'])

@@ -12,13 +12,16 @@ def _engine_for(prefix, inputs, num_units, num_classes, variables):
     """Functional entry points cache one engine per (prefix, shape, weights object), like
     tf.variable_scope(prefix, reuse=tf.AUTO_REUSE) shares variables between calls (simple_fcn.py:11)."""
     key = (prefix, int(inputs.shape[-1]), int(num_units), int(num_classes), id(variables))
-    eng = _ENGINES.get(key)
-    if eng is None:
+    ent = _ENGINES.get(key)
+    # (the entry keeps the caller's dict alive and checks identity: an id in a key must not be handed to another dict while
+    # the entry exists -- a freed dict's id is reused, and the cached engine would answer with the old weights)
+    if ent is None or ent[0] is not variables:
+        given = variables
         if variables is None:
             variables = init_variables(prefix, int(inputs.shape[-1]), num_units, num_classes)
-        eng = FcnEngine(prefix, int(inputs.shape[-1]), num_units, num_classes, variables, device=inputs.device)
-        _ENGINES[key] = eng
-    return eng
+        ent = (given, FcnEngine(prefix, int(inputs.shape[-1]), num_units, num_classes, variables, device=inputs.device))
+        _ENGINES[key] = ent
+    return ent[1]
 
 
 def encoder(inputs, prefix, num_units, dropout_rate=0.0, variables=None, num_classes=2, dropout_layers=(),

@@ -426,6 +426,19 @@ def test_reference_named_layer_functions_host_side(golden_dir):
         custom_layers._var({'a/b/kernel': 1}, 'a', 'c', 'kernel')
 
 
+def test_variable_dict_caches_check_identity():
+    """The functional entry points cache packed weights / engines per variables dict (key: id(dict), like a TF variable scope
+    with reuse); an entry keeps its dict alive and checks identity, so a freed dict's id -- which Python hands to the next
+    dict -- can never answer with the old weights."""
+    a = {'x': 1}
+    key = ('conv', id(a), 'm/l/kernel')
+    custom_layers._cache_put(key, a, 'packed a')
+    assert custom_layers._cache_get(key, a) == 'packed a'
+    assert custom_layers._cache_get(key, {'x': 1}) is None          # another dict, even an equal one, under the same key
+    custom_layers.clear_layer_cache()
+    assert custom_layers._cache_get(key, a) is None
+
+
 def test_fp8_guard_bound_from_the_model_config():
     """The accuracy guard of calibrate() (basic_fusion_model.fp8_guard_bound): on by default at 0.995, a bound of the caller's,
     off at 0 / None, and never second-guessing an explicit plan."""
