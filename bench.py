@@ -534,6 +534,13 @@ def dp_regime_records(args, device, dist):
                                  ' -- the reference\'s shipped batchsize / the per-rank batch of a 32-image DP-8 step' if b == 4 else ''))
             if b == 4:
                 tr['gpu_busy'] = committed_gpu_busy('b4_%s' % ('bn' if bn else 'plain'))
+                if not bn:
+                    # the API-level loop at this batch size: fit() from HOST arrays with the loss fetched every step (what the
+                    # reference's training loop does, base_model.py:257) next to batches resident in HBM
+                    rng = np.random.default_rng(0)
+                    host = {'rgb': rng.integers(0, 256, (64, args.height, args.width, 3)).astype(np.float32),
+                            'labels': rng.integers(-1, C, (64, args.height, args.width)).astype(np.int32)}
+                    tr['fit_api'] = host_fit_rate(device, host, 4, steps=32)
             ref[(bn, b)] = tr['value']
             out.append(tr)
     return out, ref
