@@ -426,6 +426,28 @@ def test_reference_named_layer_functions_host_side(golden_dir):
         custom_layers._var({'a/b/kernel': 1}, 'a', 'c', 'kernel')
 
 
+def test_gpu_busy_is_the_union_of_kernel_intervals(tmp_path):
+    """tools/gpu_busy.py (the GPU-busy fraction of the 4-image training step in the bench line): kernels of two streams
+    overlap, so busy time is the UNION of the intervals over whole steps, not the sum of durations.  Synthetic trace: 4 steps
+    of [0-40] + [30-60 on a second stream] + [70-90] + the marker [90-100] per 100 ns -> 90 % busy (union), sum of durations 100 %."""
+    import subprocess
+    import sys
+    rows = ['"Kind","Agent_Id","Queue_Id","Stream_Id","Thread_Id","Dispatch_Id","Kernel_Id","Kernel_Name","Correlation_Id",'
+            '"Start_Timestamp","End_Timestamp"']
+    for step in range(4):
+        t = 1000 + 100 * step
+        for name, a, b in (('conv_a', 0, 40), ('conv_b', 30, 60), ('small', 70, 90), ('adam_kernel(float*)', 90, 100)):
+            rows.append('"KERNEL_DISPATCH","Agent 2",1,0,1,1,1,"%s",1,%d,%d' % (name, t + a, t + b))
+    trace = tmp_path / 'trace.csv'
+    trace.write_text('\n'.join(rows) + '\n')
+    tool = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools', 'gpu_busy.py')
+    out = json.loads(subprocess.run([sys.executable, tool, str(trace), '--last', '3'], capture_output=True, text=True, check=True).stdout)
+    assert out['steps'] == 3 and out['kernels_per_step'] == 4.0
+    assert abs(out['gpu_busy_frac'] - 0.9) < 1e-9          # window = from the end of a marker to the end of the last: 3 x 100 ns,
+    #                                                         busy 3 x (60 + 20 + 10) = 270 (the marker itself counts: it is GPU work)
+    assert abs(out['kernel_sum_ms_per_step'] * 1e6 - 100) < 1e-6
+
+
 def test_variable_dict_caches_check_identity():
     """The functional entry points cache packed weights / engines per variables dict (key: id(dict), like a TF variable scope
     with reuse); an entry keeps its dict alive and checks identity, so a freed dict's id -- which Python hands to the next
