@@ -163,6 +163,154 @@ __global__ __launch_bounds__(256, 2) void conv1x1_gemm_kernel(GemmArgs a) {
   }
 }
 
+// ---- wide form (round 6): 256 pixel rows x 128 channels per workgroup, three stages ---------------------------------------
+// The 128x128 form above moves (128 + 128) rows x 128 B per 128x128x64 block of the product -- 64 FLOP per byte of L2
+// traffic, i.e. 39 TB/s at the matrix peak: as much as the eight L2s deliver at best -- and requests a K step only one step
+// (512-1 024 matrix-pipe cycles) before it is consumed: a miss to the Infinity Cache or HBM does not come back in that time.
+// AdapNet's 1x1 convs (half of that expert's step, profiles/r6_adapnet_kernel_stats.csv) run at 0.3-0.8 PFLOP/s on it.
+// Here: 8 waves (4 x 2, each 64 pixels x 64 channels as above), 48 KB per stage (85 FLOP per byte), THREE stages = 144 KB,
+// one workgroup per CU, a K step requested two steps ahead behind a counted vmcnt (the six DMA instructions of the step in
+// between stay in flight across the barrier).  Same fragment layout, same accumulation order: the same bits as the
+// 128x128 form.  Where it pays is measured, not obvious (profiles/r6_conv1x1_wide_ab.txt): +30 % on the longest sums
+// (24x48x9216->512: 511 -> 665 TFLOP/s), level or a few per cent either way on most shapes, -14 % on x1024->2048 alone --
+// eight waves behind ONE per-step barrier hide less than two independent 4-wave workgroups per CU -- and +5 % on the whole
+// AdapNet step with the launcher's rule (launches of at least three quarters of a round of workgroups).
+constexpr int B_BM = 256;
+constexpr int B_W_BYTES = 128 * 128, B_X_BYTES = 256 * 128;
+constexpr int B_STAGE_BYTES = B_W_BYTES + B_X_BYTES;
+constexpr int B_STAGES = 3;
+constexpr int B_LDS_BYTES = B_STAGES * B_STAGE_BYTES;
+
+__global__ __launch_bounds__(512, 2) void conv1x1_gemm_wide_kernel(GemmArgs a) {
+  extern __shared__ __attribute__((aligned(1024))) char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wr = wave >> 1, wc = wave & 1;
+  int bid = blockIdx.x;
+  if ((a.nblk & 7) == 0) bid = (bid & 7) * (a.nblk >> 3) + (bid >> 3);
+  const int mt = bid / a.n_tiles, nt = bid - mt * a.n_tiles;
+  const int64_t m0 = (int64_t)mt * B_BM;
+  const int n0 = nt * G_BN;
+  const int Cin = a.Cin, Cout = a.Cout;
+  const int nsteps = Cin >> 6;
+
+  // DMA addressing: piece p of a tile = rows 8p .. 8p+7, lane -> (row, 16-byte slot); wave w moves weight pieces w, w + 8
+  // and pixel pieces w, w + 8, w + 16, w + 24
+  const int drow = lane >> 3, dslot = lane & 7;
+  int woff[2], xoff[4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int r = (wave + 8 * i) * 8 + drow;
+    const int g = (r >> 1) & 7;
+    woff[i] = ((n0 + r) << 7) + ((dslot ^ g ^ (r & 6)) << 4);
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = (wave + 8 * i) * 8 + drow;
+    const int g = (r >> 1) & 7;
+    int64_t m = m0 + r;
+    if (m >= a.Mp) m = a.Mp - 1;  // rows past the end: any valid row, never stored
+    xoff[i] = (int)(m - m0) * Cin * 2 + ((dslot ^ g) << 4);
+  }
+  const char* wbase = reinterpret_cast<const char*>(a.wpk);
+  const char* xbase = reinterpret_cast<const char*>(a.x) + m0 * Cin * 2;
+  auto issue = [&](int step, int stage) {
+    const char* ws = wbase + ((int64_t)step * Cout << 7);
+    const char* xs = xbase + (step << 7);
+    const int dst = stage * B_STAGE_BYTES;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+      asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(dst + (wave + 8 * i) * 1024), "v"(woff[i]), "s"(ws)
+                   : "memory");
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(dst + B_W_BYTES + (wave + 8 * i) * 1024),
+                   "v"(xoff[i]), "s"(xs)
+                   : "memory");
+  };
+
+  const int t = lane & 15, q = lane >> 4, g = t >> 1;
+  const int fo0 = t * 128 + (((q ^ (g & 3)) + ((g >> 2) << 2)) << 4);
+  const int fo1 = t * 128 + (((q ^ (g & 3)) + (((g >> 2) ^ 1) << 2)) << 4);
+  const int wfrag = wc * 64 * 128, xfrag = B_W_BYTES + wr * 64 * 128;
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  issue(0, 0);
+  if (nsteps > 1) issue(1, 1);
+  int stage = 0;
+  for (int step = 0; step < nsteps; ++step) {
+    // this step's six DMA instructions have landed (the six of the next step may still be in flight) ...
+    if (step + 1 < nsteps)
+      asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();  // ... for every wave; and every wave is done with the stage of step - 1, which step + 2 overwrites
+    const int nstage = stage == 0 ? 2 : stage - 1;  // (step + 2) % 3
+    if (step + 2 < nsteps) issue(step + 2, nstage);
+    const char* sb = smem + stage * B_STAGE_BYTES;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const int fo = kk ? fo1 : fo0;
+      bf16x8 wf[4], xf[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) wf[j] = *reinterpret_cast<const bf16x8*>(sb + wfrag + j * 2048 + fo);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) xf[i] = *reinterpret_cast<const bf16x8*>(sb + xfrag + i * 2048 + fo);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], xf[i], acc[i][j], 0, 0, 0);
+    }
+    stage = stage == 2 ? 0 : stage + 1;
+  }
+
+  // ---- epilogue: as the 128x128 form
+  const int Wp = a.W + 2, Hp = a.H + 2;
+  const int cb = n0 + wc * 64 + q * 4;
+  f32x4 bj[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) bj[j] = *reinterpret_cast<const f32x4*>(a.bias + cb + j * 16);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = (int)m0 + wr * 64 + i * 16 + t;  // Mp < 2^31 (checked by the launcher)
+    const int row = m / Wp;
+    const int xx = m - row * Wp;
+    const int yy = row % Hp;
+    if (m >= a.Mp || xx < 1 || xx > a.W || yy < 1 || yy > a.H) continue;
+    const int64_t off = (int64_t)m * Cout + cb;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      f32x4 v = acc[i][j] + bj[j];
+      if (a.relu) {
+        v.x = fmaxf(v.x, 0.f);
+        v.y = fmaxf(v.y, 0.f);
+        v.z = fmaxf(v.z, 0.f);
+        v.w = fmaxf(v.w, 0.f);
+      }
+      if (a.addend != nullptr) {
+        const u32x2 ad = *reinterpret_cast<const u32x2*>(a.addend + off + j * 16);
+        v.x += bf16_bits_to_f32(ad.x & 0xffffu);
+        v.y += __builtin_bit_cast(float, ad.x & 0xffff0000u);
+        v.z += bf16_bits_to_f32(ad.y & 0xffffu);
+        v.w += __builtin_bit_cast(float, ad.y & 0xffff0000u);
+      }
+      if (a.mask != nullptr) {
+        const u32x2 mk = *reinterpret_cast<const u32x2*>(a.mask + off + j * 16);
+        v.x = bf16_bits_to_f32(mk.x & 0xffffu) > 0.f ? v.x : 0.f;
+        v.y = __builtin_bit_cast(float, mk.x & 0xffff0000u) > 0.f ? v.y : 0.f;
+        v.z = bf16_bits_to_f32(mk.y & 0xffffu) > 0.f ? v.z : 0.f;
+        v.w = __builtin_bit_cast(float, mk.y & 0xffff0000u) > 0.f ? v.w : 0.f;
+      }
+      *reinterpret_cast<u32x2*>(a.y + off + j * 16) = u32x2{pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w)};
+    }
+  }
+}
+
 // ---- narrow form (tile configuration 23): 64 output channels, 64 pixel rows per workgroup ---------------------------
 // The two score convs of the FCN (score_conv4 / score_conv5, simple_fcn.py:69-79: 512 -> num_units = 64 channels on the
 // 1/8- and 1/16-resolution maps) are tiny GEMMs: 1.2-4.8 GFLOP on 18 k-74 k pixels at 16 images, 1.2 k-4.6 k at one.  On
@@ -311,6 +459,25 @@ int xv_launch_conv1x1_gemm(const __bf16* x, const __bf16* wpk, const float* bias
   a.Cout = Cout;
   a.relu = relu;
   a.n_tiles = Cout / G_BN;
+  {
+    // the wide form wherever the launch makes at least a quarter of a round of its workgroups (the whole AdapNet step, 16 images,
+    // one box, alternating: 1 500 images/s without it, 1 574 with a three-quarter-round rule, 1 600 everywhere -- although
+    // ALONE on the chip it is the slower form on most short sums, profiles/r6_conv1x1_wide_ab.txt: in the network two experts'
+    // launches share the chip); XV_GEMM_WIDE=0 / 1: never / wherever the shape allows (A/B timing).  Same bits either way.
+    static const int wide_env = getenv("XV_GEMM_WIDE") != nullptr ? atoi(getenv("XV_GEMM_WIDE")) : -1;
+    const int64_t m_wide = (a.Mp + B_BM - 1) / B_BM;
+    const int64_t nblk_wide = m_wide * a.n_tiles;
+    const bool fits = nblk_wide <= 0x7fffffff && a.Mp + B_BM <= 0x7fffffff && (int64_t)B_BM * Cin * 2 <= 0x7fffffff;
+    const bool enough = 4 * nblk_wide >= (int64_t)xv_num_cus();   // at least a quarter of a round: below that, more and smaller workgroups
+    if (fits && wide_env != 0 && (wide_env == 1 || enough)) {
+      a.nblk = (int)nblk_wide;
+      static bool attr_w[XV_MAX_DEVICES] = {false};
+      const hipError_t e = xv_allow_dynamic_lds(reinterpret_cast<const void*>(conv1x1_gemm_wide_kernel), B_LDS_BYTES, attr_w);
+      if (e != hipSuccess) return (int)e;
+      hipLaunchKernelGGL(conv1x1_gemm_wide_kernel, dim3((unsigned)nblk_wide), dim3(512), B_LDS_BYTES, stream, a);
+      return xv_launch_status();
+    }
+  }
   const int64_t m_tiles = (a.Mp + G_BM - 1) / G_BM;
   const int64_t nblk = m_tiles * a.n_tiles;
   if (nblk > 0x7fffffff || a.Mp + G_BM > 0x7fffffff || (int64_t)G_BM * Cin * 2 > 0x7fffffff) return XV_ESHAPE;

@@ -144,7 +144,8 @@ def test_conv1x1_narrow_gemm(ops, n, h, w, cin):
 def test_conv1x1_flat_gemm(ops, n, h, w, cin, cout):
     """Generation 3 (flat GEMM over the padded rows, cfg 18): exact on integers, with activation + addend + mask in
     the order of the other kernels, border untouched, row counts that are not multiples of the 128-row tile.  The last three
-    shapes (round 6) are launches of hundreds of workgroups with one, three and six K steps."""
+    shapes make enough workgroups for the WIDE form of round 6 (256 rows x 128 channels, three stages, conv1x1_gemm_wide_kernel:
+    one, three and six K steps; row counts that are not multiples of 256) -- the same bits as generation 1."""
     rng = np.random.default_rng(n * h * w + cin)
     x = rng.integers(-2, 3, (n, h, w, cin)).astype(np.float32)
     wt = rng.integers(-1, 2, (1, 1, cin, cout)).astype(np.float32)
