@@ -80,6 +80,80 @@ __global__ __launch_bounds__(256) void im2col_pair_kernel(const u32x4* __restric
   }
 }
 
+// Row forms of the two gathers above (the defaults): a destination row (n, y) is CONTIGUOUS in z (x-major, then tap, then
+// channel group), so a workgroup walks 1024 consecutive 16-byte elements of one row and only has to split the in-row index
+// into (x, tap, channel group).  The flat forms do that with three 64-bit divisions per 16 bytes -- a few hundred
+// instructions per element, which made a pure copy ALU-bound at 2.7 TB/s of writes; here the two divisions are one
+// v_mul_hi each by a reciprocal the launcher computed (exact while row_length * divisor < 2^32, which it checks).
+__device__ __forceinline__ uint32_t div_magic(uint32_t n, uint32_t magic) { return __umulhi(n, magic); }
+
+__global__ __launch_bounds__(256) void im2col_pair_rows_kernel(const u32x4* __restrict__ x, u32x4* __restrict__ z, int H,
+                                                              int W, int c8, uint32_t magic_g8, uint32_t magic_c8, int d1,
+                                                              int d2) {
+  const uint32_t g8 = 18u * (uint32_t)c8, L = (uint32_t)W * g8;
+  const int row = blockIdx.y, n = row / H, py = row - n * H;
+  const u32x4* xn = x + (int64_t)n * (H + 2) * (W + 2) * c8;
+  u32x4* zr = z + (((int64_t)n * (H + 2) + py + 1) * (W + 2) + 1) * g8;
+  const uint32_t base = blockIdx.x * 1024u + threadIdx.x;
+  u32x4 v[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const uint32_t i = base + 256u * u;
+    v[u] = u32x4{0u, 0u, 0u, 0u};
+    if (i < L) {
+      const uint32_t px = div_magic(i, magic_g8), gc = i - px * g8;
+      const uint32_t t = div_magic(gc, magic_c8), cg = gc - t * (uint32_t)c8;
+      const int d = t < 9u ? d1 : d2;
+      const int tt = t < 9u ? (int)t : (int)t - 9;
+      const int ky = tt / 3, kx = tt - 3 * ky;
+      const int sy = py + (ky - 1) * d, sx = (int)px + (kx - 1) * d;
+      if (sy >= 0 && sy < H && sx >= 0 && sx < W) v[u] = xn[((int64_t)(sy + 1) * (W + 2) + sx + 1) * c8 + cg];
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const uint32_t i = base + 256u * u;
+    if (i < L) zr[i] = v[u];
+  }
+}
+
+__global__ __launch_bounds__(256) void gather_conv7s2_rows_kernel(const u32x4* __restrict__ x, u32x4* __restrict__ z,
+                                                                 int Ho, int Wo, int c8, uint32_t magic_g8,
+                                                                 uint32_t magic_c8) {
+  const int Hi = Ho * 2, Wi = Wo * 2;
+  const uint32_t g8 = 9u * (uint32_t)c8, L = (uint32_t)Wo * g8;
+  const int row = blockIdx.y, n = row / Ho, j = row - n * Ho;
+  const u32x4* xn = x + (int64_t)n * (Hi + 2) * (Wi + 2) * c8;
+  u32x4* zr = z + (((int64_t)n * (Ho + 2) + j + 1) * (Wo + 2) + 1) * g8;
+  const uint32_t base = blockIdx.x * 1024u + threadIdx.x;
+  u32x4 v[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const uint32_t i = base + 256u * u;
+    v[u] = u32x4{0u, 0u, 0u, 0u};
+    if (i < L) {
+      const uint32_t px = div_magic(i, magic_g8), gc = i - px * g8;
+      const uint32_t g = div_magic(gc, magic_c8), cg = gc - g * (uint32_t)c8;
+      const int rv = (int)g / 3, cv = (int)g - rv * 3;
+      const int sy = 2 * j + (rv == 1 ? 2 : (rv == 2 ? 1 : 0));
+      const int sx = 2 * (int)px + (cv == 1 ? 2 : (cv == 2 ? 1 : 0));
+      if (sy < Hi && sx < Wi) v[u] = xn[((int64_t)(sy + 1) * (Wi + 2) + sx + 1) * c8 + cg];
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const uint32_t i = base + 256u * u;
+    if (i < L) zr[i] = v[u];
+  }
+}
+
+// floor(2^32 / d) + 1: __umulhi(n, magic) == n / d for every n with n * d < 2^32
+inline uint32_t magic_of(uint32_t d) { return (uint32_t)((((uint64_t)1) << 32) / d) + 1u; }
+inline bool rows_form_ok(int64_t rows, int64_t row_len, int64_t g8) {
+  static const bool flat = getenv("XV_GATHER_FLAT") != nullptr && atoi(getenv("XV_GATHER_FLAT")) != 0;  // A/B switch
+  return rows <= 65535 && row_len * g8 < (((int64_t)1) << 32) && !flat;
+}
+
 // ---- transposes of the three gathers (training) and the residual add, all written as gathers themselves: every
 // destination element is produced by exactly one thread, no atomics, deterministic -------------------------------------
 __device__ __forceinline__ void acc_bf16x8(float (&s)[8], const u32x4 v) {
@@ -344,6 +418,13 @@ extern "C" int xv_gather_conv7s2(const xv_act* x, const xv_act* z, void* stream)
   XV_CHECK_SHAPE(x->n == z->n && z->c == 9 * x->c && (x->c & 7) == 0 && x->h == 2 * z->h && x->w == 2 * z->w &&
                  z->h > 0);
   const int64_t total = (int64_t)z->n * z->h * z->w * (z->c >> 3);
+  const int c8 = x->c >> 3, g8 = 9 * c8;
+  if (rows_form_ok((int64_t)z->n * z->h, (int64_t)z->w * g8, g8)) {
+    hipLaunchKernelGGL(gather_conv7s2_rows_kernel, dim3((z->w * g8 + 1023) / 1024, z->n * z->h), dim3(256), 0,
+                       (hipStream_t)stream, (const u32x4*)x->data, (u32x4*)z->data, z->h, z->w, c8, magic_of(g8),
+                       magic_of(c8));
+    return xv_launch_status();
+  }
   hipLaunchKernelGGL(gather_conv7s2_kernel, dim3(rn_grid(total)), dim3(256), 0, (hipStream_t)stream,
                      (const u32x4*)x->data, (u32x4*)z->data, z->n, z->h, z->w, x->c >> 3);
   return xv_launch_status();
@@ -355,6 +436,13 @@ extern "C" int xv_im2col_dilated_pair(const xv_act* x, int dilation1, int dilati
   XV_CHECK_SHAPE(x->n == z->n && x->h == z->h && x->w == z->w && z->c == 18 * x->c && (x->c & 7) == 0 &&
                  dilation1 >= 1 && dilation2 >= 1);
   const int64_t total = (int64_t)z->n * z->h * z->w * (z->c >> 3);
+  const int c8 = x->c >> 3, g8 = 18 * c8;
+  if (rows_form_ok((int64_t)z->n * z->h, (int64_t)z->w * g8, g8)) {
+    hipLaunchKernelGGL(im2col_pair_rows_kernel, dim3((z->w * g8 + 1023) / 1024, z->n * z->h), dim3(256), 0,
+                       (hipStream_t)stream, (const u32x4*)x->data, (u32x4*)z->data, z->h, z->w, c8, magic_of(g8),
+                       magic_of(c8), dilation1, dilation2);
+    return xv_launch_status();
+  }
   hipLaunchKernelGGL(im2col_pair_kernel, dim3(rn_grid(total)), dim3(256), 0, (hipStream_t)stream, (const u32x4*)x->data,
                      (u32x4*)z->data, z->n, z->h, z->w, x->c >> 3, dilation1, dilation2);
   return xv_launch_status();
