@@ -67,6 +67,7 @@ SIGNATURES = {
     'xv_im2col_dilated_pair': (_i, [_actp, _i, _i, _actp, _vp]),
     'xv_subsample2_bwd': (_i, [_actp, _actp, _vp]),
     'xv_gather_conv7s2_bwd': (_i, [_actp, _actp, _vp]),
+    'xv_conv_dilated_pair_fwd': (_i, [_actp, _vp, _vp, _i, _i, _i, _actp, _vp]),
     'xv_im2col_dilated_pair_bwd': (_i, [_actp, _i, _i, _actp, _vp]),
     'xv_add': (_i, [_actp, _actp, _actp, _vp]),
     'xv_space_to_depth': (_i, [_actp, _i, _actp, _vp]),

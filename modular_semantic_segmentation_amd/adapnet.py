@@ -6,7 +6,9 @@ the batch norm folds into kernel and bias, so the trunk is 1x1 and 3x3 stride-1 
 gathers (csrc/resnet_ops.hip) that express the rest through them:
   * block_0_2, 7x7 stride 2      -> xv_gather_conv7s2 + ONE 3x3 conv over 9*64 channels, 2x2 max-pool fused;
   * 1x1 stride 2 (blocks 4, 8)   -> xv_subsample2 + 1x1 conv;
-  * block_b's two atrous 3x3     -> xv_im2col_dilated_pair + ONE 1x1 conv whose output is already their concat;
+  * block_b's two atrous 3x3     -> ONE implicit GEMM over nine taps per output half whose output is already their concat
+    (xv_conv_dilated_pair_fwd; halves that are not multiples of 128 channels, block_layer_7: xv_im2col_dilated_pair + a
+    1x1 conv over the 18C operand, the same bits);
   * stage_3 + shortcut + relu    -> xv_conv2d_fwd_residual (the outer relu acts on a sum of two relu outputs);
   * the two deconvs (kernel [k,k,filters,in], custom_layers.py:71-121).  The reference leaves them TRAINABLE
     (adapnet.py:155-163 omits trainable=False), so a kernel is either still the bilinear constant it is initialised to
@@ -18,6 +20,8 @@ gathers (csrc/resnet_ops.hip) that express the rest through them:
 Training: adapnet_trainer.AdapnetTrainer (every batch norm in training mode, the gathers' transposes, both deconv
 kernels trained as the reference trains them).
 """
+import os
+
 import numpy as np
 import torch
 
@@ -149,6 +153,7 @@ class AdapnetEngine(object):
         self.device = torch.device(device)
         self.Up = ((self.U + 63) // 64) * 64
         self._arena = {}
+        self.implicit_pairs = os.environ.get('XV_IMPLICIT_PAIRS', '1') != '0'   # 0: the materialised form everywhere (A/B)
         self.load(variables)
 
     # ---- weights -------------------------------------------------------------------------------------------
@@ -278,8 +283,13 @@ class AdapnetEngine(object):
             else:
                 f1, f2, cout, d1, d2, shortcut_conv = args
                 s1 = self._conv(name + '/stage_1', inp, 1, f1)
-                z = ops.im2col_dilated_pair(s1, d1, d2, self._act(name + '/operand', s1.n, s1.h, s1.w, 18 * f1))
-                s2 = self._conv(name + '/stage_2', z, 1, f2)
+                if self.implicit_pairs and ops.dilated_pair_implicit_ok(f1, f2):
+                    # the nine taps of each half gathered by the GEMM's own loads: no 18 f1 operand (ops.conv_dilated_pair)
+                    s2 = ops.conv_dilated_pair(s1, self.w[name + '/stage_2'], self.b[name + '/stage_2'], d1, d2, relu=True,
+                                               y=self._act(name + '/stage_2', s1.n, s1.h, s1.w, f2))
+                else:
+                    z = ops.im2col_dilated_pair(s1, d1, d2, self._act(name + '/operand', s1.n, s1.h, s1.w, 18 * f1))
+                    s2 = self._conv(name + '/stage_2', z, 1, f2)
             short = self._conv(name + '/shortcut', inp, 1, cout) if shortcut_conv else inp
             cur = ops.conv1x1_residual(s2, self.w[name + '/stage_3'], self.b[name + '/stage_3'], short, relu=True,
                                        y=self._act('block_%d' % index, s2.n, s2.h, s2.w, cout))

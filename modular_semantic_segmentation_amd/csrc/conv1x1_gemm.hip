@@ -34,6 +34,7 @@ struct GemmArgs {
   int relu;
   int n_tiles;
   int nblk;
+  int pair_d1, pair_d2;  // conv1x1_gemm_wide_kernel<true>: the dilation rates of the two atrous 3x3 convs (see there)
 };
 
 constexpr int G_BM = 128, G_BN = 128;
@@ -181,6 +182,16 @@ constexpr int B_STAGE_BYTES = B_W_BYTES + B_X_BYTES;
 constexpr int B_STAGES = 3;
 constexpr int B_LDS_BYTES = B_STAGES * B_STAGE_BYTES;
 
+// PAIR = true (block_b of AdapNet, adapnet.py:84-88: two atrous 3x3 convs of the same input, rates d1 / d2, concatenated): the
+// same kernel as an IMPLICIT GEMM over nine taps.  The materialised form (xv_im2col_dilated_pair + this kernel over K = 18 C)
+// wrote and re-read an operand 18 x the input and multiplied every output channel by the nine taps of the OTHER conv's rate
+// too, whose weights are zero.  Here a workgroup's 128 output channels lie in one half of the concat (launcher: cout / 2 a
+// multiple of 128), so its K loop runs over that half's nine taps only -- steps [0, 9 C/64) or [9 C/64, 18 C/64) of the same
+// packed [1,1,18C,F] image -- and the pixel tile of a step is gathered by the DMA itself: row m of the tile reads padded
+// pixel m + ((ky-1) (W+2) + (kx-1)) d, or, where that tap falls outside the image (or m is a border row), padded pixel 0,
+// which is a border pixel of the map and therefore zero.  Same products in the same order as the materialised form (whose
+// other nine taps add exact zeros): the same bits.
+template <bool PAIR>
 __global__ __launch_bounds__(512, 2) void conv1x1_gemm_wide_kernel(GemmArgs a) {
   extern __shared__ __attribute__((aligned(1024))) char smem[];
   const int lane = threadIdx.x & 63;
@@ -192,12 +203,17 @@ __global__ __launch_bounds__(512, 2) void conv1x1_gemm_wide_kernel(GemmArgs a) {
   const int64_t m0 = (int64_t)mt * B_BM;
   const int n0 = nt * G_BN;
   const int Cin = a.Cin, Cout = a.Cout;
-  const int nsteps = Cin >> 6;
+  const int cpt = Cin >> 6;                                   // K steps per tap (PAIR), all steps otherwise
+  const int nsteps = PAIR ? 9 * cpt : cpt;
+  const bool second = PAIR && 2 * n0 >= Cout;                 // this workgroup's channels belong to the second conv
+  const int kbase = second ? 9 * cpt : 0;
+  const int dil = second ? a.pair_d2 : a.pair_d1;
 
   // DMA addressing: piece p of a tile = rows 8p .. 8p+7, lane -> (row, 16-byte slot); wave w moves weight pieces w, w + 8
   // and pixel pieces w, w + 8, w + 16, w + 24
   const int drow = lane >> 3, dslot = lane & 7;
   int woff[2], xoff[4];
+  int pyy[4], pxx[4], pm[4], pslot[4];                        // PAIR: the rows' padded coordinates (yy < 0: never a valid tap)
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int r = (wave + 8 * i) * 8 + drow;
@@ -209,14 +225,36 @@ __global__ __launch_bounds__(512, 2) void conv1x1_gemm_wide_kernel(GemmArgs a) {
     const int r = (wave + 8 * i) * 8 + drow;
     const int g = (r >> 1) & 7;
     int64_t m = m0 + r;
-    if (m >= a.Mp) m = a.Mp - 1;  // rows past the end: any valid row, never stored
-    xoff[i] = (int)(m - m0) * Cin * 2 + ((dslot ^ g) << 4);
+    if (PAIR) {
+      const int Wp = a.W + 2, Hp = a.H + 2;
+      const int mi = (int)m, row = mi / Wp, xx = mi - row * Wp, yy = row % Hp;
+      const bool interior = m < a.Mp && xx >= 1 && xx <= a.W && yy >= 1 && yy <= a.H;
+      pyy[i] = interior ? yy : -(1 << 20), pxx[i] = xx, pm[i] = mi, pslot[i] = (dslot ^ g) << 4;
+      xoff[i] = 0;
+    } else {
+      if (m >= a.Mp) m = a.Mp - 1;  // rows past the end: any valid row, never stored
+      xoff[i] = (int)(m - m0) * Cin * 2 + ((dslot ^ g) << 4);
+    }
   }
   const char* wbase = reinterpret_cast<const char*>(a.wpk);
-  const char* xbase = reinterpret_cast<const char*>(a.x) + m0 * Cin * 2;
+  const char* xbase = reinterpret_cast<const char*>(a.x) + (PAIR ? 0 : m0 * Cin * 2);
+  // PAIR: issue() is called for steps 0, 1, 2, ... in order; (itap, icb) = (step / cpt, step % cpt) follow along
+  int itap = 0, icb = 0;
+  auto tap_offsets = [&]() {
+    const int ky = itap / 3, kx = itap - 3 * ky;
+    const int dy = (ky - 1) * dil, dx = (kx - 1) * dil;
+    const int dm = dy * (a.W + 2) + dx;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int sy = pyy[i] + dy, sx = pxx[i] + dx;
+      const bool ok = sy >= 1 && sy <= a.H && sx >= 1 && sx <= a.W;
+      xoff[i] = (ok ? (pm[i] + dm) * Cin * 2 : 0) + pslot[i];
+    }
+  };
+  if (PAIR) tap_offsets();
   auto issue = [&](int step, int stage) {
-    const char* ws = wbase + ((int64_t)step * Cout << 7);
-    const char* xs = xbase + (step << 7);
+    const char* ws = wbase + ((int64_t)(kbase + step) * Cout << 7);
+    const char* xs = xbase + ((PAIR ? icb : step) << 7);
     const int dst = stage * B_STAGE_BYTES;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -227,6 +265,10 @@ __global__ __launch_bounds__(512, 2) void conv1x1_gemm_wide_kernel(GemmArgs a) {
       asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(dst + B_W_BYTES + (wave + 8 * i) * 1024),
                    "v"(xoff[i]), "s"(xs)
                    : "memory");
+    if (PAIR && ++icb == cpt) {
+      icb = 0;
+      if (++itap < 9) tap_offsets();
+    }
   };
 
   const int t = lane & 15, q = lane >> 4, g = t >> 1;
@@ -418,6 +460,41 @@ __global__ __launch_bounds__(256, 4) void conv1x1_n64_kernel(GemmArgs a) {
 
 }  // namespace
 
+// block_b's two atrous 3x3 convs + concat as ONE implicit GEMM (conv1x1_gemm_wide_kernel<true>), no materialised operand.
+// wpk: the packed [1,1,18 cin,cout] image xv_im2col_dilated_pair's 1x1 conv takes (adapnet.dilated_pair_as_1x1: rows [0,9 cin)
+// x columns [0,cout/2) = conv 1, rows [9 cin,18 cin) x columns [cout/2,cout) = conv 2; the other two blocks are never read).
+extern "C" int xv_conv_dilated_pair_fwd(const xv_act* x, const void* wpk, const float* bias, int dilation1, int dilation2,
+                                        int relu, const xv_act* y, void* stream) {
+  XV_REQUIRE_BF16(x, y);
+  XV_CHECK_ARG(x && y && x->data && y->data && wpk && bias);
+  XV_CHECK_SHAPE(x->n == y->n && x->h == y->h && x->w == y->w && x->h > 0 && (x->c & 63) == 0 && (y->c & 255) == 0 &&
+                 dilation1 >= 1 && dilation2 >= 1);
+  GemmArgs a{};
+  a.x = (const __bf16*)x->data;
+  a.wpk = (const __bf16*)wpk;
+  a.bias = bias;
+  a.y = (__bf16*)y->data;
+  a.Mp = (int64_t)x->n * (x->h + 2) * (x->w + 2);
+  a.H = x->h;
+  a.W = x->w;
+  a.Cin = x->c;
+  a.Cout = y->c;
+  a.relu = relu;
+  a.n_tiles = y->c / G_BN;
+  a.pair_d1 = dilation1;
+  a.pair_d2 = dilation2;
+  const int64_t nblk = (a.Mp + B_BM - 1) / B_BM * a.n_tiles;
+  // 32-bit byte offsets into x from its base, tap displacement included
+  const int64_t reach = (int64_t)(dilation1 > dilation2 ? dilation1 : dilation2) * (x->w + 3);
+  XV_CHECK_SHAPE(nblk <= 0x7fffffff && (a.Mp + B_BM + reach) * x->c * 2 <= 0x7fffffff);
+  a.nblk = (int)nblk;
+  static bool attr_p[XV_MAX_DEVICES] = {false};
+  const hipError_t e = xv_allow_dynamic_lds(reinterpret_cast<const void*>(conv1x1_gemm_wide_kernel<true>), B_LDS_BYTES, attr_p);
+  if (e != hipSuccess) return (int)e;
+  hipLaunchKernelGGL(conv1x1_gemm_wide_kernel<true>, dim3((unsigned)nblk), dim3(512), B_LDS_BYTES, (hipStream_t)stream, a);
+  return xv_launch_status();
+}
+
 // Entry for conv_mfma.hip's dispatcher (tile configuration 23).  Shapes: cin % 64 == 0, cout == 64.
 int xv_launch_conv1x1_n64(const __bf16* x, const __bf16* wpk, const float* bias, __bf16* y, const __bf16* mask,
                           const __bf16* addend, int N, int H, int W, int Cin, int Cout, int relu, hipStream_t stream) {
@@ -472,9 +549,9 @@ int xv_launch_conv1x1_gemm(const __bf16* x, const __bf16* wpk, const float* bias
     if (fits && wide_env != 0 && (wide_env == 1 || enough)) {
       a.nblk = (int)nblk_wide;
       static bool attr_w[XV_MAX_DEVICES] = {false};
-      const hipError_t e = xv_allow_dynamic_lds(reinterpret_cast<const void*>(conv1x1_gemm_wide_kernel), B_LDS_BYTES, attr_w);
+      const hipError_t e = xv_allow_dynamic_lds(reinterpret_cast<const void*>(conv1x1_gemm_wide_kernel<false>), B_LDS_BYTES, attr_w);
       if (e != hipSuccess) return (int)e;
-      hipLaunchKernelGGL(conv1x1_gemm_wide_kernel, dim3((unsigned)nblk_wide), dim3(512), B_LDS_BYTES, stream, a);
+      hipLaunchKernelGGL(conv1x1_gemm_wide_kernel<false>, dim3((unsigned)nblk_wide), dim3(512), B_LDS_BYTES, stream, a);
       return xv_launch_status();
     }
   }

@@ -413,6 +413,22 @@ def im2col_dilated_pair(x, d1, d2, z=None):
     return z
 
 
+def dilated_pair_implicit_ok(cin, cout):
+    """Shapes xv_conv_dilated_pair_fwd takes: 64-channel K steps, each 128-channel output block inside one half."""
+    return cin % 64 == 0 and cout % 256 == 0
+
+
+def conv_dilated_pair(x, w_packed, bias, d1, d2, relu=True, y=None):
+    """concat(atrous3x3(x, d1), atrous3x3(x, d2)) [+ relu] without the 18C operand (adapnet.py:84-88); w_packed / bias as the
+    1x1 conv over im2col_dilated_pair(x) takes them (adapnet.dilated_pair_as_1x1).  Same bits as that pair of calls."""
+    _need(bias, torch.float32, 'bias')
+    if y is None:
+        y = Act(x.n, x.h, x.w, bias.numel(), x.t.device)
+    _lib.check(_lib.lib().xv_conv_dilated_pair_fwd(x.xv(), _ptr(w_packed), _ptr(bias), int(d1), int(d2), int(bool(relu)),
+                                                   y.xv(), _stream()), 'xv_conv_dilated_pair_fwd')
+    return y
+
+
 def dropout(x, rate, seed, y=None):
     """tf.layers.dropout(x, rate, training=True): keep with probability 1 - rate, scale by 1 / (1 - rate)."""
     if y is None:

@@ -86,6 +86,46 @@ def test_dilated_pair_through_im2col_is_exact(ops, h, w, c, half, d1, d2):
     assert np.array_equal(y.interior().float().cpu().numpy(), fo.round_bf16(_nhwc(F.relu(ref))))
 
 
+@pytest.mark.parametrize('n,h,w,c,half,d1,d2', [(2, 12, 20, 64, 128, 1, 2), (2, 6, 10, 256, 128, 1, 16), (1, 24, 48, 128, 256, 2, 16),
+                                                (3, 5, 7, 64, 128, 3, 5), (16, 24, 48, 64, 128, 2, 8)])
+def test_dilated_pair_as_implicit_gemm(ops, n, h, w, c, half, d1, d2):
+    """xv_conv_dilated_pair_fwd (no 18C operand, nine taps per output half gathered by the GEMM's loads): exact on integers
+    against the two atrous convs + concat (adapnet.py:84-88), and bit for bit the materialised form on floats."""
+    from modular_semantic_segmentation_amd.adapnet import dilated_pair_as_1x1
+    rng = np.random.default_rng(h * w + d2)
+    x = rng.integers(-2, 3, (n, h, w, c)).astype(np.float32)
+    k1 = rng.integers(-1, 2, (3, 3, c, half)).astype(np.float32)
+    k2 = rng.integers(-1, 2, (3, 3, c, half)).astype(np.float32)
+    b = rng.integers(-3, 4, 2 * half).astype(np.float32)
+    wp = ops.pack_conv_weights(_dev(dilated_pair_as_1x1(k1, k2)))
+    assert ops.dilated_pair_implicit_ok(c, 2 * half)
+    y = ops.conv_dilated_pair(ops.Act.from_dense(_dev(x)), wp, _dev(b), d1, d2, relu=True)
+    torch.cuda.synchronize()
+    xt = _nchw(x)
+    ref = torch.cat([F.conv2d(xt, _wt(k1), torch.from_numpy(b[:half]), padding=d1, dilation=d1),
+                     F.conv2d(xt, _wt(k2), torch.from_numpy(b[half:]), padding=d2, dilation=d2)], dim=1)
+    assert np.array_equal(y.interior().float().cpu().numpy(), fo.round_bf16(_nhwc(F.relu(ref))))
+    assert float(y.t.float().abs().sum()) == float(y.interior().float().abs().sum())      # the border stays zero
+    # floats: the same products in the same order as im2col + 1x1 conv (whose other nine taps add exact zeros)
+    xf = ops.Act.from_dense(_dev(rng.standard_normal((n, h, w, c)).astype(np.float32)))
+    wf = ops.pack_conv_weights(_dev(dilated_pair_as_1x1(rng.standard_normal(k1.shape).astype(np.float32) * 0.05,
+                                                        rng.standard_normal(k2.shape).astype(np.float32) * 0.05)))
+    bf = _dev(rng.standard_normal(2 * half).astype(np.float32))
+    for relu in (True, False):
+        a = ops.conv_dilated_pair(xf, wf, bf, d1, d2, relu=relu)
+        m, _ = ops.conv2d_fwd(ops.im2col_dilated_pair(xf, d1, d2), wf, bf, 1, relu=relu)
+        assert torch.equal(a.t, m.t), relu
+
+
+def test_dilated_pair_implicit_rejects_other_shapes(ops):
+    from modular_semantic_segmentation_amd import _lib
+    x = ops.Act(1, 4, 4, 64)
+    assert not ops.dilated_pair_implicit_ok(64, 128) and not ops.dilated_pair_implicit_ok(32, 256)
+    with pytest.raises(_lib.XvError):
+        ops.conv_dilated_pair(x, torch.zeros(18 * 64 * 128, dtype=torch.bfloat16, device='cuda'),
+                              torch.zeros(128, device='cuda'), 1, 2)
+
+
 def test_residual_conv_and_affine_upsample(ops):
     rng = np.random.default_rng(3)
     x = rng.integers(-2, 3, (2, 10, 14, 128)).astype(np.float32)
