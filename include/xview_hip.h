@@ -259,7 +259,8 @@ int xv_im2col_dilated_pair(const xv_act* x, int dilation1, int dilation2, const 
 /* The same two atrous convs + concat WITHOUT the 18C operand: an implicit GEMM over nine taps per output half, the taps
  * gathered by the kernel's own loads (adapnet.py:84-88: stage_2_1, stage_2_2, tf.concat).  wpk: the packed [1,1,18C,F] image
  * the materialised form's 1x1 conv takes (rows [0,9C) x columns [0,F/2) = conv 1, rows [9C,18C) x [F/2,F) = conv 2; the two
- * off-diagonal blocks are never read).  C a multiple of 64, F of 256; y [N,H,W,F]; the same bits as xv_im2col_dilated_pair +
+ * off-diagonal blocks are never read -- except F = 64, where both halves share a tile and all 18 taps are multiplied).  C a
+ * multiple of 64, F of 256 or F = 64; y [N,H,W,F]; the same bits as xv_im2col_dilated_pair +
  * xv_conv2d_fwd(ksize 1).  XV_ESHAPE otherwise (callers then take the materialised form).                              */
 int xv_conv_dilated_pair_fwd(const xv_act* x, const void* wpk, const float* bias, int dilation1, int dilation2, int relu,
                              const xv_act* y, void* stream);

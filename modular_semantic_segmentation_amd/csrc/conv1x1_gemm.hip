@@ -364,29 +364,57 @@ constexpr int N_TILE_BYTES = 64 * 128;
 constexpr int N_STAGE_BYTES = 2 * N_TILE_BYTES;
 constexpr int N_LDS_BYTES = 2 * N_STAGE_BYTES;
 
+// PAIR = true: block_b with 64 output channels (block_layer_7, 32 + 32): both convs' channels share the one 64-channel tile,
+// so the K loop runs over all 18 taps of the packed [1,1,18C,64] image (the zero blocks included: the same products as the
+// materialised form) -- taps 0..8 at rate d1, 9..17 at rate d2, gathered by the DMA as in conv1x1_gemm_wide_kernel<true>.
+template <bool PAIR>
 __global__ __launch_bounds__(256, 4) void conv1x1_n64_kernel(GemmArgs a) {
   extern __shared__ __attribute__((aligned(1024))) char smem[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int64_t m0 = (int64_t)blockIdx.x * N_BM;
   const int Cin = a.Cin, Cout = a.Cout;
-  const int nsteps = Cin >> 6;
+  const int cpt = Cin >> 6;                    // K steps per tap (PAIR), all steps otherwise
+  const int nsteps = PAIR ? 18 * cpt : cpt;
   const int drow = lane >> 3, dslot = lane & 7;
   int woff[2], xoff[2];
+  int pyy[2], pxx[2], pm[2], pslot[2];
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int r = (wave * 2 + i) * 8 + drow;
     const int g = (r >> 1) & 7;
     woff[i] = (r << 7) + ((dslot ^ g ^ (r & 6)) << 4);
     int64_t m = m0 + r;
-    if (m >= a.Mp) m = a.Mp - 1;  // rows past the end: any valid row, never stored
-    xoff[i] = (int)(m - m0) * Cin * 2 + ((dslot ^ g) << 4);
+    if (PAIR) {
+      const int Wp = a.W + 2, Hp = a.H + 2;
+      const int mi = (int)m, row = mi / Wp, xx = mi - row * Wp, yy = row % Hp;
+      const bool interior = m < a.Mp && xx >= 1 && xx <= a.W && yy >= 1 && yy <= a.H;
+      pyy[i] = interior ? yy : -(1 << 20), pxx[i] = xx, pm[i] = mi, pslot[i] = (dslot ^ g) << 4;
+      xoff[i] = 0;
+    } else {
+      if (m >= a.Mp) m = a.Mp - 1;  // rows past the end: any valid row, never stored
+      xoff[i] = (int)(m - m0) * Cin * 2 + ((dslot ^ g) << 4);
+    }
   }
   const char* wbase = reinterpret_cast<const char*>(a.wpk);
-  const char* xbase = reinterpret_cast<const char*>(a.x) + m0 * Cin * 2;
+  const char* xbase = reinterpret_cast<const char*>(a.x) + (PAIR ? 0 : m0 * Cin * 2);
+  int itap = 0, icb = 0;                       // PAIR: (step / cpt, step % cpt) of the next issue() -- steps come in order
+  auto tap_offsets = [&]() {
+    const int tt = itap < 9 ? itap : itap - 9, dil = itap < 9 ? a.pair_d1 : a.pair_d2;
+    const int ky = tt / 3, kx = tt - 3 * ky;
+    const int dy = (ky - 1) * dil, dx = (kx - 1) * dil;
+    const int dm = dy * (a.W + 2) + dx;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int sy = pyy[i] + dy, sx = pxx[i] + dx;
+      const bool ok = sy >= 1 && sy <= a.H && sx >= 1 && sx <= a.W;
+      xoff[i] = (ok ? (pm[i] + dm) * Cin * 2 : 0) + pslot[i];   // outside the image: padded pixel 0, a zero border pixel
+    }
+  };
+  if (PAIR) tap_offsets();
   auto issue = [&](int step, int stage) {
     const char* ws = wbase + ((int64_t)step * Cout << 7);
-    const char* xs = xbase + (step << 7);
+    const char* xs = xbase + ((PAIR ? icb : step) << 7);
     const int dst = stage * N_STAGE_BYTES + wave * 2048;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -397,6 +425,10 @@ __global__ __launch_bounds__(256, 4) void conv1x1_n64_kernel(GemmArgs a) {
       asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(dst + N_TILE_BYTES + i * 1024),
                    "v"(xoff[i]), "s"(xs)
                    : "memory");
+    if (PAIR && ++icb == cpt) {
+      icb = 0;
+      if (++itap < 18) tap_offsets();
+    }
   };
   const int t = lane & 15, q = lane >> 4, g = t >> 1;
   const int fo0 = t * 128 + (((q ^ (g & 3)) + ((g >> 2) << 2)) << 4);
@@ -467,8 +499,8 @@ extern "C" int xv_conv_dilated_pair_fwd(const xv_act* x, const void* wpk, const 
                                         int relu, const xv_act* y, void* stream) {
   XV_REQUIRE_BF16(x, y);
   XV_CHECK_ARG(x && y && x->data && y->data && wpk && bias);
-  XV_CHECK_SHAPE(x->n == y->n && x->h == y->h && x->w == y->w && x->h > 0 && (x->c & 63) == 0 && (y->c & 255) == 0 &&
-                 dilation1 >= 1 && dilation2 >= 1);
+  XV_CHECK_SHAPE(x->n == y->n && x->h == y->h && x->w == y->w && x->h > 0 && (x->c & 63) == 0 &&
+                 ((y->c & 255) == 0 || y->c == 64) && dilation1 >= 1 && dilation2 >= 1);
   GemmArgs a{};
   a.x = (const __bf16*)x->data;
   a.wpk = (const __bf16*)wpk;
@@ -483,10 +515,17 @@ extern "C" int xv_conv_dilated_pair_fwd(const xv_act* x, const void* wpk, const 
   a.n_tiles = y->c / G_BN;
   a.pair_d1 = dilation1;
   a.pair_d2 = dilation2;
-  const int64_t nblk = (a.Mp + B_BM - 1) / B_BM * a.n_tiles;
   // 32-bit byte offsets into x from its base, tap displacement included
   const int64_t reach = (int64_t)(dilation1 > dilation2 ? dilation1 : dilation2) * (x->w + 3);
-  XV_CHECK_SHAPE(nblk <= 0x7fffffff && (a.Mp + B_BM + reach) * x->c * 2 <= 0x7fffffff);
+  XV_CHECK_SHAPE((a.Mp + B_BM + reach) * x->c * 2 <= 0x7fffffff);
+  if (y->c == 64) {
+    const int64_t nb = (a.Mp + N_BM - 1) / N_BM;
+    XV_CHECK_SHAPE(nb <= 0x7fffffff);
+    hipLaunchKernelGGL(conv1x1_n64_kernel<true>, dim3((unsigned)nb), dim3(256), N_LDS_BYTES, (hipStream_t)stream, a);
+    return xv_launch_status();
+  }
+  const int64_t nblk = (a.Mp + B_BM - 1) / B_BM * a.n_tiles;
+  XV_CHECK_SHAPE(nblk <= 0x7fffffff);
   a.nblk = (int)nblk;
   static bool attr_p[XV_MAX_DEVICES] = {false};
   const hipError_t e = xv_allow_dynamic_lds(reinterpret_cast<const void*>(conv1x1_gemm_wide_kernel<true>), B_LDS_BYTES, attr_p);
@@ -514,7 +553,7 @@ int xv_launch_conv1x1_n64(const __bf16* x, const __bf16* wpk, const float* bias,
   a.relu = relu;
   const int64_t nblk = (a.Mp + N_BM - 1) / N_BM;
   if (nblk > 0x7fffffff || a.Mp + N_BM > 0x7fffffff || (int64_t)N_BM * Cin * 2 > 0x7fffffff) return XV_ESHAPE;
-  hipLaunchKernelGGL(conv1x1_n64_kernel, dim3((unsigned)nblk), dim3(256), N_LDS_BYTES, stream, a);
+  hipLaunchKernelGGL(conv1x1_n64_kernel<false>, dim3((unsigned)nblk), dim3(256), N_LDS_BYTES, stream, a);
   return xv_launch_status();
 }
 

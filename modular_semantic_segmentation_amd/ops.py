@@ -414,8 +414,9 @@ def im2col_dilated_pair(x, d1, d2, z=None):
 
 
 def dilated_pair_implicit_ok(cin, cout):
-    """Shapes xv_conv_dilated_pair_fwd takes: 64-channel K steps, each 128-channel output block inside one half."""
-    return cin % 64 == 0 and cout % 256 == 0
+    """Shapes xv_conv_dilated_pair_fwd takes: 64-channel K steps; each 128-channel output block inside one half, or one
+    64-channel tile for both."""
+    return cin % 64 == 0 and (cout % 256 == 0 or cout == 64)
 
 
 def conv_dilated_pair(x, w_packed, bias, d1, d2, relu=True, y=None):

@@ -87,7 +87,8 @@ def test_dilated_pair_through_im2col_is_exact(ops, h, w, c, half, d1, d2):
 
 
 @pytest.mark.parametrize('n,h,w,c,half,d1,d2', [(2, 12, 20, 64, 128, 1, 2), (2, 6, 10, 256, 128, 1, 16), (1, 24, 48, 128, 256, 2, 16),
-                                                (3, 5, 7, 64, 128, 3, 5), (16, 24, 48, 64, 128, 2, 8)])
+                                                (3, 5, 7, 64, 128, 3, 5), (16, 24, 48, 64, 128, 2, 8), (2, 12, 20, 128, 32, 1, 2),
+                                                (3, 5, 9, 64, 32, 2, 7)])
 def test_dilated_pair_as_implicit_gemm(ops, n, h, w, c, half, d1, d2):
     """xv_conv_dilated_pair_fwd (no 18C operand, nine taps per output half gathered by the GEMM's loads): exact on integers
     against the two atrous convs + concat (adapnet.py:84-88), and bit for bit the materialised form on floats."""
@@ -120,7 +121,7 @@ def test_dilated_pair_as_implicit_gemm(ops, n, h, w, c, half, d1, d2):
 def test_dilated_pair_implicit_rejects_other_shapes(ops):
     from modular_semantic_segmentation_amd import _lib
     x = ops.Act(1, 4, 4, 64)
-    assert not ops.dilated_pair_implicit_ok(64, 128) and not ops.dilated_pair_implicit_ok(32, 256)
+    assert not ops.dilated_pair_implicit_ok(64, 128) and not ops.dilated_pair_implicit_ok(32, 256) and ops.dilated_pair_implicit_ok(128, 64)
     with pytest.raises(_lib.XvError):
         ops.conv_dilated_pair(x, torch.zeros(18 * 64 * 128, dtype=torch.bfloat16, device='cuda'),
                               torch.zeros(128, device='cuda'), 1, 2)

@@ -45,4 +45,14 @@ for h, w, cin, cout in SHAPES:
         tf = flops * args.iters / (e0.elapsed_time(e1) * 1e-3) / 1e12
         row.append('%6.0f' % tf)
         best = max(best, (tf, cfg))
-    print('%-24s' % ('%dx%dx%d->%d' % (h, w, cin, cout)) + ''.join(row) + '   cfg %d (%.0f)' % (best[1], best[0]))
+    # what the chooser picks (pick_cfg, conv_mfma.hip)
+    ops.conv2d_fwd(x, wp, b, 1, y=y)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(args.iters):
+        ops.conv2d_fwd(x, wp, b, 1, y=y)
+    e1.record()
+    torch.cuda.synchronize()
+    auto = flops * args.iters / (e0.elapsed_time(e1) * 1e-3) / 1e12
+    print('%-24s' % ('%dx%dx%d->%d' % (h, w, cin, cout)) + ''.join(row) + '   cfg %d (%.0f)   chooser %.0f' % (best[1], best[0], auto))
