@@ -204,6 +204,12 @@ int xv_conv2d_choose_cfg(int n, int h, int w, int cin, int cout, int k, int in_d
  * three bf16 terms (fp32 accumulation; rounds like the fp32 FMA chain the other shapes use).        */
 int xv_conv2d_first_fwd(const float* x, int n, int h, int w, int cin, const float* w_hwio,
                         const float* bias, const xv_act* y, int relu, void* stream);
+/* AdapNet's block_0_1 written straight into the operand of block_0_2 (adapnet.py:126-127): the same values as
+ * xv_conv2d_first_fwd + xv_gather_conv7s2, without the 64-channel full-resolution map in between.  cin = 1 or 3, w % 16 == 0,
+ * h even; z [N,h/2,w/2,576] bf16, which must hold zeros where the gather has no source pixel (variant 1 of the last operand
+ * row / column: neither this kernel nor xv_gather_conv7s2 writes anything else there).                                   */
+int xv_conv2d_first_gather7s2_fwd(const float* x, int n, int h, int w, int cin, const float* w_hwio,
+                                  const float* bias, const xv_act* z, int relu, void* stream);
 /* conv1_1 AND conv1_2 (+ max_pooling2d) of the FCN trunk in one launch (simple_fcn.py:39-41), inference only: conv1_1 is
  * evaluated tile by tile straight into conv1_2's LDS patch buffers, so its 64-channel map never reaches memory.  x / w1_hwio
  * / b1 as xv_conv2d_first_fwd (cin = 1 or 3), w2_packed / b2 as xv_conv2d_fwd (64 -> 64 channels, 3x3); y and / or pooled

@@ -55,6 +55,7 @@ SIGNATURES = {
     'xv_deconv_dense_workspace_bytes': (ctypes.c_size_t, [_i, _i, _i, _i, _i]),
     'xv_deconv_dense_fwd': (_i, [_actp, _vp, _vp, _vp, _vp, _actp, _actp, _i, _i, _vp, ctypes.c_size_t, _vp]),
     'xv_conv2d_first_fwd': (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _actp, _i, _vp]),
+    'xv_conv2d_first_gather7s2_fwd': (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _actp, _i, _vp]),
     'xv_maxpool2x2_fwd': (_i, [_actp, _actp, _vp]),
     'xv_upsample2x_relu_add': (_i, [_actp, _actp, _actp, _vp]),
     'xv_upsample2x_affine_relu_add': (_i, [_actp, _vp, _vp, _actp, _actp, _vp]),

@@ -4,7 +4,8 @@
 Every conv of the graph is followed by a batch norm and (mostly) a relu (custom_layers.py:124-139); at inference
 the batch norm folds into kernel and bias, so the trunk is 1x1 and 3x3 stride-1 convs on the MFMA kernels plus three
 gathers (csrc/resnet_ops.hip) that express the rest through them:
-  * block_0_2, 7x7 stride 2      -> xv_gather_conv7s2 + ONE 3x3 conv over 9*64 channels, 2x2 max-pool fused;
+  * block_0_2, 7x7 stride 2      -> xv_gather_conv7s2 + ONE 3x3 conv over 9*64 channels, 2x2 max-pool fused (inference:
+    block_0_1's kernel writes that operand itself, xv_conv2d_first_gather7s2_fwd);
   * 1x1 stride 2 (blocks 4, 8)   -> xv_subsample2 + 1x1 conv;
   * block_b's two atrous 3x3     -> ONE implicit GEMM over nine taps per output half whose output is already their concat
     (xv_conv_dilated_pair_fwd; halves that are not multiples of 128 channels, block_layer_7: xv_im2col_dilated_pair + a
@@ -154,6 +155,7 @@ class AdapnetEngine(object):
         self.Up = ((self.U + 63) // 64) * 64
         self._arena = {}
         self.implicit_pairs = os.environ.get('XV_IMPLICIT_PAIRS', '1') != '0'   # 0: the materialised form everywhere (A/B)
+        self.fused_first = os.environ.get('XV_ADAPNET_FUSED_FIRST', '1') != '0'  # 0: block_0_1's map written, then gathered
         self.load(variables)
 
     # ---- weights -------------------------------------------------------------------------------------------
@@ -256,19 +258,25 @@ class AdapnetEngine(object):
         ops.conv2d_fwd(x, self.w[name], self.b[name], k, relu=relu, y=y)
         return y
 
-    def trunk(self, x):
+    def trunk(self, x, keep_all=True):
         """x: float32 [N,H,W,cin] device tensor -> dict of Acts (keys as the reference's layer dict, adapnet.py:165-173;
-        block_0_2 itself is only produced pooled)."""
+        block_0_2 itself is only produced pooled; keep_all=False: 'block_0_1' is not produced either where its kernel can
+        write the operand of block_0_2 directly)."""
         n, h, w, cin = x.shape
         if cin != self.cin:
             raise ValueError('expected %d input channels, got %d' % (self.cin, cin))
         if h % 16 or w % 16:
             raise ValueError('H and W must be multiples of 16 (augmentation.py:244-262 crop_multiple)')
         L = {}
-        cur = self._act('block_0_1', n, h, w, 64)
-        ops.conv2d_first_fwd(x.contiguous(), self.w['block_0_1'], self.b['block_0_1'], cur, relu=True)
-        L['block_0_1'] = cur
-        z = ops.gather_conv7s2(cur, self._act('block_0_2/operand', n, h // 2, w // 2, 9 * 64))
+        z = self._act('block_0_2/operand', n, h // 2, w // 2, 9 * 64)
+        if not keep_all and self.fused_first and cin in (1, 3):
+            # block_0_1 straight into the operand of block_0_2: its 64-channel full-resolution map is neither written nor read
+            ops.conv2d_first_gather7s2_fwd(x.contiguous(), self.w['block_0_1'], self.b['block_0_1'], z, relu=True)
+        else:
+            cur = self._act('block_0_1', n, h, w, 64)
+            ops.conv2d_first_fwd(x.contiguous(), self.w['block_0_1'], self.b['block_0_1'], cur, relu=True)
+            L['block_0_1'] = cur
+            ops.gather_conv7s2(cur, z)
         cur = self._act('block_0_pool', n, h // 4, w // 4, 64)
         ops.conv2d_fwd(z, self.w['block_0_2'], self.b['block_0_2'], 3, relu=True, pooled=cur, write_y=False)
         L['block_0_pool'] = cur
@@ -312,7 +320,7 @@ class AdapnetEngine(object):
     def forward(self, x, want=('label',), keep_all=False):
         """adapnet + test_pipeline (basic_fusion_model.py:9-23): any of 'score', 'prob' (float32 [N,H,W,C]) and
         'label' == 'classification' (int64 [N,H,W])."""
-        L = self.trunk(x)
+        L = self.trunk(x, keep_all=keep_all)
         m = L['merge']
         if 'second' in self.dense:
             wk, _, sc, sh = self.dense['second']

@@ -160,10 +160,16 @@ __device__ __forceinline__ void split3_bf16x8(const float (&v)[8], bf16x8& h, bf
 
 // OUT8: the map is written as e4m3 of value * out_mul (the fp8 graph where conv1_2 takes e4m3 operands, fcn.fp8_plan): a
 // tile is then ONE contiguous 1 KB store (16 pixels x 64 channels)
-template <int CIN, bool OUT8 = false>
+// G7: the map is not written at all; every pixel goes straight to its places in the operand of AdapNet's 7x7 stride-2 conv
+// (xv_gather_conv7s2's z [N,H/2,W/2,9*64], adapnet.py:126-127): row variant 0 / 1 of an even row Y at j = Y/2 / Y/2 - 1,
+// variant 2 of an odd row at j = (Y-1)/2, columns alike -- 2.25 stores of 128 bytes per pixel on average instead of one,
+// and neither the 0.6 GB map nor the gather's read of it.  Positions of z without a source pixel (variant 1 in the last
+// row / column) are never written: the caller's buffer holds zeros there (as xv_gather_conv7s2 leaves them).
+template <int CIN, bool OUT8 = false, bool G7 = false>
 __global__ __launch_bounds__(256) void conv_first_mfma_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                              const float* __restrict__ b, __bf16* __restrict__ y, int N,
                                                              int H, int W, int relu, int tpw, float out_mul = 1.f) {
+  static_assert(!(OUT8 && G7), "the gathered form writes bf16");
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int j = lane & 15, g = lane >> 4;
@@ -267,6 +273,17 @@ __global__ __launch_bounds__(256) void conv_first_mfma_kernel(const float* __res
     split3_bf16x8(v, xh, xm, xl);
     __bf16* dst = y + (((int64_t)n * (H + 2) + (py + 1)) * (W + 2) + (tx * 16 + 1)) * 64 + st_g;
     char* dst8 = reinterpret_cast<char*>(y) + (((int64_t)n * (H + 2) + (py + 1)) * (W + 2) + (tx * 16 + 1)) * 64 + lane * 16;
+    // G7: the lane's pixel X = 16 tx + pj0 (and X + 8: four operand columns further) in row variant A = 0 (even py) / 2 (odd)
+    // and column variant C = 0 (even X) / 2 (odd), at operand pixel (py >> 1, X >> 1)
+    char* zA_C = nullptr;
+    bool g7_d0 = false, g7_rowb = false;
+    if constexpr (G7) {
+      const int Ho = H >> 1, Wo = W >> 1, X = tx * 16 + pj0;
+      const int rvA = (py & 1) ? 2 : 0, cvC = (pj0 & 1) ? 2 : 0;
+      zA_C = reinterpret_cast<char*>(y) + ((((int64_t)n * (Ho + 2) + (py >> 1) + 1) * (Wo + 2) + (X >> 1) + 1) * 576 + (rvA * 3 + cvC) * 64) * 2 + sl * 16;
+      g7_d0 = X >= 2;                        // the even pixel's second column place (variant 1 at X/2 - 1) exists
+      g7_rowb = (py & 1) == 0 && py >= 2;    // the even row's second place (variant 1 at py/2 - 1) exists
+    }
     // next tile: advance the walk and request its taps; they land behind this tile's MFMAs, and this tile's stores are
     // issued after them (the vector-memory counter retires in order: waiting for the taps then never waits for the
     // stores issued behind them)
@@ -329,8 +346,28 @@ __global__ __launch_bounds__(256) void conv_first_mfma_kernel(const float* __res
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     const u32x4 r0 = stage[st_r0], r1 = stage[st_r1];
-    *reinterpret_cast<u32x4*>(dst) = r0;
-    *reinterpret_cast<u32x4*>(dst + 8 * 64) = r1;
+    if constexpr (G7) {
+      const int Wo = W >> 1;
+      const int64_t rowb = -(int64_t)(Wo + 2) * 1152 + 3 * 128;   // row variant 0 -> 1, one operand row up
+      const bool even_x = (pj0 & 1) == 0;
+      *reinterpret_cast<u32x4*>(zA_C) = r0;
+      *reinterpret_cast<u32x4*>(zA_C + 4 * 1152) = r1;
+      if (even_x) {                                                // column variant 0 -> 1, one operand column to the left
+        if (g7_d0) *reinterpret_cast<u32x4*>(zA_C - 1152 + 128) = r0;
+        *reinterpret_cast<u32x4*>(zA_C + 3 * 1152 + 128) = r1;
+      }
+      if (g7_rowb) {
+        *reinterpret_cast<u32x4*>(zA_C + rowb) = r0;
+        *reinterpret_cast<u32x4*>(zA_C + rowb + 4 * 1152) = r1;
+        if (even_x) {
+          if (g7_d0) *reinterpret_cast<u32x4*>(zA_C + rowb - 1152 + 128) = r0;
+          *reinterpret_cast<u32x4*>(zA_C + rowb + 3 * 1152 + 128) = r1;
+        }
+      }
+    } else {
+      *reinterpret_cast<u32x4*>(dst) = r0;
+      *reinterpret_cast<u32x4*>(dst + 8 * 64) = r1;
+    }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
   }
@@ -1199,6 +1236,30 @@ inline int grid_for(int64_t total, int per_block = 256, int cap = 8192) {
 }
 
 }  // namespace
+
+// block_0_1 + the gather of block_0_2 in one pass (conv_first_mfma_kernel<CIN, false, true>): z as xv_gather_conv7s2 writes it.
+extern "C" int xv_conv2d_first_gather7s2_fwd(const float* x, int n, int h, int w, int cin, const float* w_hwio,
+                                             const float* bias, const xv_act* z, int relu, void* stream) {
+  XV_CHECK_ARG(x && w_hwio && bias && z && z->data);
+  XV_CHECK_ARG(z->dtype == XV_BF16);
+  XV_CHECK_SHAPE(n > 0 && h > 0 && w >= 16 && (cin == 1 || cin == 3) && (w & 15) == 0 && (h & 1) == 0 &&
+                 (int64_t)n * h * w * cin < 0x7ff00000);
+  XV_CHECK_SHAPE(z->n == n && z->h == h / 2 && z->w == w / 2 && z->c == 576);
+  static const int per_cu = getenv("XV_FIRST_WG_PER_CU") ? atoi(getenv("XV_FIRST_WG_PER_CU")) : 4;
+  const int64_t ntiles = (int64_t)n * h * (w / 16);
+  const int64_t want = (ntiles + 3) / 4, cap = (int64_t)xv_num_cus() * (per_cu > 0 ? per_cu : 4);
+  const int64_t g0 = want < cap ? want : cap;
+  const int tpw = (int)((ntiles + g0 * 4 - 1) / (g0 * 4));
+  const unsigned g2 = (unsigned)((ntiles + (int64_t)tpw * 4 - 1) / ((int64_t)tpw * 4));
+  hipStream_t s = (hipStream_t)stream;
+  if (cin == 1)
+    hipLaunchKernelGGL((conv_first_mfma_kernel<1, false, true>), dim3(g2), dim3(256), 0, s, x, w_hwio, bias, (__bf16*)z->data, n, h,
+                       w, relu, tpw, 1.f);
+  else
+    hipLaunchKernelGGL((conv_first_mfma_kernel<3, false, true>), dim3(g2), dim3(256), 0, s, x, w_hwio, bias, (__bf16*)z->data, n, h,
+                       w, relu, tpw, 1.f);
+  return xv_launch_status();
+}
 
 extern "C" int xv_conv2d_first_fwd(const float* x, int n, int h, int w, int cin, const float* w_hwio,
                                    const float* bias, const xv_act* y, int relu, void* stream) {

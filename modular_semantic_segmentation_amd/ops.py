@@ -239,6 +239,19 @@ def conv2d_first_fwd(x, w_hwio, bias, y, relu=True):
     return y
 
 
+def conv2d_first_gather7s2_fwd(x, w_hwio, bias, z, relu=True):
+    """relu(conv3x3(x) + b) of the raw input written directly as gather_conv7s2's operand z [N,H/2,W/2,576] (z must hold
+    zeros where the gather has no source pixel: a fresh Act, or one only ever written by this op / gather_conv7s2)."""
+    _need(x, torch.float32, 'x')
+    _need(w_hwio, torch.float32, 'w_hwio')
+    _need(bias, torch.float32, 'bias')
+    n, h, w, cin = x.shape
+    rc = _lib.lib().xv_conv2d_first_gather7s2_fwd(_ptr(x), n, h, w, cin, _ptr(w_hwio), _ptr(bias), z.xv(), int(bool(relu)),
+                                                  _stream())
+    _lib.check(rc, 'xv_conv2d_first_gather7s2_fwd')
+    return z
+
+
 def conv_first_pair_fwd(x, w1_hwio, b1, w2_packed, b2, y=None, pooled=None, relu1=True, relu2=True):
     """conv1_1 + conv1_2 (+ pool) in one launch (xv_conv_first_pair_fwd): x raw float32 NHWC, y / pooled bf16 Acts (either
     may be None).  Returns False -- nothing launched -- where the fused kernel does not apply (maps that do not tile in

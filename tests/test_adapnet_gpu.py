@@ -67,6 +67,22 @@ def test_conv7x7_stride2_through_gather_is_exact(ops, n, h, w, pool):
         assert np.array_equal(q.interior().float().cpu().numpy(), fo.round_bf16(_nhwc(F.max_pool2d(ref, 2, 2))))
 
 
+@pytest.mark.parametrize('n,h,w,cin', [(2, 32, 48, 3), (1, 16, 16, 1), (3, 6, 32, 3), (1, 2, 16, 3), (2, 64, 96, 1)])
+def test_first_conv_written_as_the_7x7_operand(ops, n, h, w, cin):
+    """xv_conv2d_first_gather7s2_fwd: block_0_1 (adapnet.py:126) stored directly as the operand of block_0_2 -- the same bytes
+    as conv2d_first_fwd + gather_conv7s2, border and source-less positions included."""
+    rng = np.random.default_rng(n * h + w + cin)
+    x = _dev(rng.uniform(0, 255, (n, h, w, cin)).astype(np.float32))
+    k = _dev((rng.standard_normal((3, 3, cin, 64)) * 0.05).astype(np.float32))
+    b = _dev(rng.standard_normal(64).astype(np.float32))
+    for relu in (True, False):
+        y = ops.conv2d_first_fwd(x, k, b, ops.Act(n, h, w, 64), relu=relu)
+        ref = ops.gather_conv7s2(y)
+        z = ops.conv2d_first_gather7s2_fwd(x, k, b, ops.Act(n, h // 2, w // 2, 576), relu=relu)
+        torch.cuda.synchronize()
+        assert torch.equal(z.t, ref.t), (relu, float((z.t.float() - ref.t.float()).abs().max()))
+
+
 @pytest.mark.parametrize('h,w,c,half,d1,d2', [(12, 20, 128, 32, 1, 2), (6, 10, 256, 128, 1, 16), (8, 12, 64, 32, 2, 4),
                                               (4, 6, 512, 256, 2, 16)])
 def test_dilated_pair_through_im2col_is_exact(ops, h, w, c, half, d1, d2):
