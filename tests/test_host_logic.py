@@ -504,6 +504,21 @@ def test_padded_units():
     assert all(_ups8_channels_ok(padded_units(u)) for u in range(1, 257)) and not _ups8_channels_ok(192)
 
 
+def test_adapnet_block_b_shapes_take_the_implicit_pair():
+    """Every block_b of the reference's AdapNet (adapnet.py:84-88 through BLOCKS) has a shape xv_conv_dilated_pair_fwd takes --
+    inference materialises no im2col operand -- and the packed [1,1,18C,F] image is block-diagonal as that kernel assumes."""
+    from modular_semantic_segmentation_amd import ops
+    from modular_semantic_segmentation_amd.adapnet import BLOCKS, dilated_pair_as_1x1
+    pairs = [args for _, kind, args in BLOCKS if kind == 'b']
+    assert len(pairs) == 8 and all(ops.dilated_pair_implicit_ok(f1, f2) for f1, f2, *_ in pairs)
+    assert not ops.dilated_pair_implicit_ok(64, 128) and not ops.dilated_pair_implicit_ok(96, 256)
+    rng = np.random.default_rng(0)
+    k1, k2 = rng.standard_normal((3, 3, 8, 4)).astype(np.float32), rng.standard_normal((3, 3, 8, 4)).astype(np.float32)
+    w = dilated_pair_as_1x1(k1, k2)[0, 0]
+    assert w.shape == (144, 8) and not w[:72, 4:].any() and not w[72:, :4].any()
+    assert np.array_equal(w[:72, :4], k1.reshape(72, 4)) and np.array_equal(w[72:, 4:], k2.reshape(72, 4))
+
+
 def test_fp8_plan_and_the_oracle_policy_agree():
     """fcn.fp8_plan (which convs take e4m3 operands, which maps are stored as e4m3, by `deep`) against the
     oracle's restatement of the rule: the oracle's 'fp8' policy must quantise exactly the maps the plan names."""
