@@ -1061,6 +1061,156 @@ __global__ __launch_bounds__(512) void score_dense_wgrad_split_kernel(const floa
   for (int c = tid; c < 17 * 64; c += 512) part_out[(int64_t)blockIdx.x * (17 * 64) + c] = red[c];
 }
 
+// ---- 1x1 filter gradient as a flat GEMM (round 6): dW[cin][cout] = sum over ALL padded pixels m of X[m][cin] dY[m][cout] ----
+// AdapNet's block stages are 1x1 convs (and its atrous pairs in training: a 1x1 conv over the 18C im2col operand, cin up to
+// 9 216): conv_wgrad_kernel<1> above gave them 64 x 64 blocks of dW per workgroup -- X re-read cout/64 times and dY cin/64
+// times through registers, 32 FLOP per byte -- 24 % of the AdapNet training step.  Here the padded maps are what they are in
+// memory, two flat matrices [Mp][C] whose border rows are zero in X, so the reduction runs over consecutive rows with no
+// tile geometry: a workgroup owns 256 cin x 128 cout of dW and a slice of the rows (split-K into slabs, added in a fixed
+// order by slab_reduce_kernel), eight waves of 64 x 64, 64 rows per step as six [64 rows][64 channels] LDS images (four of
+// X, two of dY) filled by LDS-DMA three stages deep behind a counted vmcnt -- the wide flat GEMM's pipeline
+// (conv1x1_gemm.hip) with the transposing fragment reads of the kernels above.
+constexpr int W1_STAGE = 6 * 8192, W1_STAGES = 3, W1_LDS = W1_STAGES * W1_STAGE;
+
+struct Wgrad1Args {
+  const __bf16* x;
+  const __bf16* dy;
+  float* slab;   // [splits][Cin][Cout]
+  float* bslab;  // [splits][Cout] or null
+  int64_t Mp;
+  int Cin, Cout, n_co, splits, steps_per_split;
+};
+
+__global__ __launch_bounds__(512, 2) void conv_wgrad_1x1_gemm_kernel(Wgrad1Args a) {
+  extern __shared__ __attribute__((aligned(1024))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 1, wc = wave & 1;
+  const int Cin = a.Cin, Cout = a.Cout;
+  const int split = blockIdx.x % a.splits, pair = blockIdx.x / a.splits;
+  const int co0 = (pair % a.n_co) * 128, ci0 = (pair / a.n_co) * 256;
+  const int64_t m_begin = (int64_t)split * a.steps_per_split * 64;
+  int64_t m_end = m_begin + (int64_t)a.steps_per_split * 64;
+  m_end = m_end < a.Mp ? m_end : a.Mp;
+  const int nsteps = m_begin < m_end ? (int)((m_end - m_begin + 63) >> 6) : 0;
+
+  // DMA: wave w moves rows 8w .. 8w+7 of each of the six images; lane -> (row, physical 16-byte slot), logical slot through
+  // the swizzle of the transposing reads (xv_swz: slot ^ (row & 6))
+  const int drow = wave * 8 + (lane >> 3), dslot = (lane & 7) ^ (drow & 6);
+  int voff[6];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) voff[k] = (k < 4 ? (ci0 + k * 64) : (co0 + (k - 4) * 64)) * 2 + dslot * 16;
+  auto issue = [&](int step, int stage) {
+    const int64_t m = m_begin + (int64_t)step * 64;
+    // rows past the end of the maps: the last padded pixel, a border pixel (zero in X: no contribution)
+    const int64_t rowi = m + drow < a.Mp ? m + drow : a.Mp - 1;
+    const int rx = (int)(rowi - m) * Cin * 2, rd = (int)(rowi - m) * Cout * 2;
+    const char* xs = reinterpret_cast<const char*>(a.x) + m * Cin * 2;
+    const char* ds = reinterpret_cast<const char*>(a.dy) + m * Cout * 2;
+    const int dst = stage * W1_STAGE + wave * 1024;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(dst + k * 8192), "v"(voff[k] + rx), "s"(xs)
+                   : "memory");
+#pragma unroll
+    for (int k = 4; k < 6; ++k)
+      asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(dst + k * 8192), "v"(voff[k] + rd), "s"(ds)
+                   : "memory");
+  };
+
+  // fragments: lane roles of a transposing read as in the kernels above (pixel xk of a 32-row half, 4-channel piece p)
+  const int g = lane >> 4, li = lane & 15, q = li >> 2, pc = li & 3;
+  const int xk = 16 * (g >> 1) + 4 * (g & 1) + q;
+  int fo[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) fo[i] = xk * 128 + (xv_swz(xk, i * 2 + (pc >> 1)) << 4) + (pc & 1) * 8;
+  const int xfrag = wr * 8192, dfrag = (4 + wc) * 8192;
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // BiasAddGrad rides along in the workgroups of cin block 0: thread -> (cout = tid & 127, row quarter = tid >> 7)
+  const bool do_bias = a.bslab != nullptr && ci0 == 0;
+  float bsum = 0.f;
+
+  if (nsteps > 0) issue(0, 0);
+  if (nsteps > 1) issue(1, 1);
+  int stage = 0;
+  for (int step = 0; step < nsteps; ++step) {
+    if (step + 1 < nsteps)
+      asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const int nstage = stage == 0 ? 2 : stage - 1;  // (step + 2) % 3
+    if (step + 2 < nsteps) issue(step + 2, nstage);
+    const char* sb = smem + stage * W1_STAGE;
+    if (do_bias) {
+      const int co = tid & 127, qt = tid >> 7;
+      const char* dimg = sb + (4 + (co >> 6)) * 8192 + (co & 7) * 2;
+      const int slot = (co & 63) >> 3;
+#pragma unroll 4
+      for (int r = qt * 16; r < qt * 16 + 16; ++r)
+        bsum += (float)*reinterpret_cast<const __bf16*>(dimg + r * 128 + (xv_swz(r, slot) << 4));
+    }
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      bf16x8 af[4], bf[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) af[i] = tr_read2(sb, xfrag + h * 4096 + fo[i], xfrag + h * 4096 + fo[i] + 8 * 128);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bf[j] = tr_read2(sb, dfrag + h * 4096 + fo[j], dfrag + h * 4096 + fo[j] + 8 * 128);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+    }
+    stage = stage == 2 ? 0 : stage + 1;
+  }
+
+  if (do_bias) {
+    __syncthreads();  // (the last step's images are consumed)
+    float* red = reinterpret_cast<float*>(smem);
+    red[tid] = bsum;
+    __syncthreads();
+    if (tid < 128) a.bslab[(int64_t)split * Cout + co0 + tid] = ((red[tid] + red[128 + tid]) + red[256 + tid]) + red[384 + tid];
+  }
+  // accumulator (row = cin = 4 (lane >> 4) + r, column = cout = lane & 15) -> slab [cin][cout]
+  float* const out = a.slab + (int64_t)split * Cin * Cout;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float* dst = out + (int64_t)(ci0 + wr * 64 + i * 16 + g * 4) * Cout + co0 + wc * 64 + j * 16 + li;
+      dst[0] = acc[i][j].x;
+      dst[Cout] = acc[i][j].y;
+      dst[2 * Cout] = acc[i][j].z;
+      dst[3 * Cout] = acc[i][j].w;
+    }
+}
+
+// Split count of the kernel above: the one that needs the fewest (rounds of workgroups) x (steps per workgroup), one
+// workgroup per CU.  A pure function of the shape: the workspace query and the launcher must agree.
+static int wgrad1_splits(int64_t mp, int cin, int cout, int* steps_per_split) {
+  const int64_t steps = (mp + 63) / 64, tiles = (int64_t)(cin / 256) * (cout / 128);
+  const int cus = xv_num_cus();
+  int best = 1;
+  int64_t best_cost = -1;
+  for (int sp = 1; sp <= 64 && sp <= steps; ++sp) {
+    const int64_t per = (steps + sp - 1) / sp, rounds = (tiles * sp + cus - 1) / cus;
+    const int64_t cost = rounds * (per + 3);  // (+3: pipeline fill and the slab's stores)
+    if (best_cost < 0 || cost < best_cost) best = sp, best_cost = cost;
+  }
+  if (steps_per_split) *steps_per_split = (int)((steps + best - 1) / best);
+  return best;
+}
+static bool wgrad1_ok(int64_t mp, int cin, int cout) {
+  static const bool off = getenv("XV_WGRAD_1X1_GEMM") != nullptr && atoi(getenv("XV_WGRAD_1X1_GEMM")) == 0;  // A/B switch
+  return !off && (cin & 255) == 0 && (cout & 127) == 0 && mp >= 64 && 64LL * (cin > cout ? cin : cout) * 2 < 0x7fffffffLL;
+}
+
 // dw[i] += sum_s slab[s][i], splits summed in a fixed order (bitwise reproducible filter gradients)
 // (and db[c] += sum_s bslab[s][c], the bias gradient's partial sums, in the same launch).  SUBS lanes share an element:
 // lane `sub` adds splits sub, sub + SUBS, ... in order, then a butterfly over the SUBS partial sums -- a fixed tree either
@@ -1165,6 +1315,10 @@ extern "C" size_t xv_conv2d_bwd_filter_workspace_bytes(int n, int h, int w, int 
   int64_t sp = (3 * (int64_t)xv_num_cus() + pairs - 1) / pairs;
   if (sp > ptiles) sp = ptiles;
   if (sp < 1) sp = 1;
+  if (k == 1 && wgrad1_ok((int64_t)n * (h + 2) * (w + 2), cin, cout)) {
+    const int64_t sp1 = wgrad1_splits((int64_t)n * (h + 2) * (w + 2), cin, cout, nullptr);
+    if (sp1 > sp) sp = sp1;
+  }
   return (size_t)sp * ((size_t)k * k * cin * cout + cout) * sizeof(float);  // dW slabs + bias slabs
 }
 
@@ -1200,10 +1354,42 @@ extern "C" int xv_conv2d_bwd_filter_ws(const xv_act* x, const xv_act* dy, float*
   const int64_t ptiles = (int64_t)a.tiles_x * a.tiles_y * a.N;
   XV_CHECK_SHAPE(ptiles <= 0x7fffffff);
   a.n_ptiles = (int)ptiles;
+  hipStream_t s = (hipStream_t)stream;
+  const int64_t mp = (int64_t)a.N * (a.H + 2) * (a.W + 2);
+  if (k == 1 && workspace != nullptr && wgrad1_ok(mp, a.Cin, a.Cout)) {
+    // the flat-GEMM form (conv_wgrad_1x1_gemm_kernel): slabs always, added in a fixed order
+    Wgrad1Args g{};
+    g.x = a.x, g.dy = a.dy, g.Mp = mp, g.Cin = a.Cin, g.Cout = a.Cout, g.n_co = a.Cout / 128;
+    g.splits = wgrad1_splits(mp, a.Cin, a.Cout, &g.steps_per_split);
+    const int64_t dw1 = (int64_t)a.Cin * a.Cout;
+    if (workspace_bytes < (size_t)g.splits * (dw1 + a.Cout) * sizeof(float)) return XV_EWORKSPACE;
+    XV_CHECK_ARG(((uintptr_t)workspace & 15) == 0);
+    g.slab = (float*)workspace;
+    g.bslab = dbias != nullptr ? g.slab + (size_t)g.splits * dw1 : nullptr;
+    static bool attr1[XV_MAX_DEVICES] = {false};
+    const hipError_t e = xv_allow_dynamic_lds(reinterpret_cast<const void*>(&conv_wgrad_1x1_gemm_kernel), W1_LDS, attr1);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(conv_wgrad_1x1_gemm_kernel, dim3((unsigned)((a.Cin / 256) * (a.Cout / 128) * g.splits)), dim3(512), W1_LDS, s, g);
+    int rc = xv_launch_status();
+    if (rc != XV_OK) return rc;
+    const int64_t n4 = dw1 / 4;
+    const int cout4 = g.bslab != nullptr ? a.Cout / 4 : 0;
+    int64_t blocks = (n4 + cout4 + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    if (g.splits >= 16) {
+      blocks = ((n4 + cout4) * 16 + 255) / 256;
+      if (blocks > 4096) blocks = 4096;
+      hipLaunchKernelGGL(slab_reduce_kernel<16>, dim3((unsigned)blocks), dim3(256), 0, s, (const float*)g.slab, dw_hwio, n4, g.splits,
+                         (const float*)g.bslab, dbias, cout4);
+    } else {
+      hipLaunchKernelGGL(slab_reduce_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, s, (const float*)g.slab, dw_hwio, n4, g.splits,
+                         (const float*)g.bslab, dbias, cout4);
+    }
+    return xv_launch_status();
+  }
   const int pairs = (a.Cin >> 6) * (a.Cout >> 6);
   const int splits = wgrad_splits(k, pairs, a.n_ptiles);
   a.splits = splits;
-  hipStream_t s = (hipStream_t)stream;
   const int64_t dw_elems = (int64_t)k * k * a.Cin * a.Cout;
   a.slab = a.bslab = nullptr;
   // With a workspace EVERY partial sum -- the dW blocks of the pixel splits and the bias gradient's -- goes to slabs that a

@@ -63,6 +63,44 @@ def test_conv_filter_and_bias_gradient_exact_on_integers(ops, n, h, w, cin, cout
     assert np.array_equal(dw2.cpu().numpy(), ref + 1)
 
 
+@pytest.mark.parametrize('n,h,w,cin,cout', [(2, 12, 20, 256, 128), (1, 24, 48, 512, 256), (3, 5, 7, 256, 384), (8, 24, 48, 1024, 128),
+                                            (1, 6, 6, 2304, 128), (1, 1, 1, 256, 128)])
+def test_1x1_filter_gradient_as_flat_gemm_exact_on_integers(ops, n, h, w, cin, cout):
+    """conv_wgrad_1x1_gemm_kernel (1x1 convs with cin % 256 == 0, cout % 128 == 0 and a workspace: AdapNet's block stages and
+    the 1x1 conv over its im2col operand): the reduction runs over all padded pixels in 64-row steps, split into slabs --
+    exact on integers with and without the bias gradient, accumulated INTO dw, the same bits from run to run."""
+    rng = np.random.default_rng(cin + cout + h)
+    x = rng.integers(-2, 3, (n, h, w, cin)).astype(np.float32)
+    dy = rng.integers(-1, 2, (n, h, w, cout)).astype(np.float32)
+    wt = torch.zeros((cout, cin, 1, 1), requires_grad=True)
+    b = torch.zeros(cout, requires_grad=True)
+    F.conv2d(_nchw(x), wt, b).backward(_nchw(dy))
+    ref = wt.grad.permute(2, 3, 1, 0).numpy()
+    xa, dya = ops.Act.from_dense(_dev(x)), ops.Act.from_dense(_dev(dy))
+    ws = torch.empty(ops.conv2d_bwd_filter_workspace_bytes(xa, cout, 1) // 4, device='cuda').fill_(float('nan'))
+    dw = torch.ones((1, 1, cin, cout), device='cuda')
+    db = torch.full((cout,), 2.0, device='cuda')
+    ops.conv2d_bwd_filter(xa, dya, dw, db, 1, workspace=ws)
+    torch.cuda.synchronize()
+    assert np.array_equal(dw.cpu().numpy(), ref + 1) and np.array_equal(db.cpu().numpy(), b.grad.numpy() + 2)
+    dw2 = torch.zeros((1, 1, cin, cout), device='cuda')
+    ops.conv2d_bwd_filter(xa, dya, dw2, None, 1, workspace=ws)
+    assert np.array_equal(dw2.cpu().numpy(), ref)
+    # floats: bitwise reproducible, and the float32 sum to rounding
+    xf = ops.Act.from_dense(_dev(rng.standard_normal((n, h, w, cin)).astype(np.float32)))
+    df = ops.Act.from_dense(_dev(rng.standard_normal((n, h, w, cout)).astype(np.float32)))
+    outs = []
+    for _ in range(2):
+        d = torch.zeros((1, 1, cin, cout), device='cuda')
+        ops.conv2d_bwd_filter(xf, df, d, None, 1, workspace=ws)
+        outs.append(d)
+    assert torch.equal(outs[0], outs[1])
+    xi, di = xf.interior().double(), df.interior().double()
+    want = torch.einsum('nhwi,nhwo->io', xi, di)
+    bound = 1e-5 * float(torch.einsum('nhwi,nhwo->io', xi.abs(), di.abs()).max())      # fp32 sums of exact bf16 products
+    assert float((outs[0][0, 0].double() - want).abs().max()) <= bound
+
+
 @pytest.mark.parametrize('k,h,w', [(3, 24, 40), (1, 24, 40), (3, 32, 64), (3, 40, 72)])
 def test_conv_data_gradient_with_relu_mask_and_addend(ops, k, h, w):
     """24x40: generation-1 kernel; 32x64: whole tiles of the all-DMA generation-2 kernel with its split-phase
