@@ -1066,7 +1066,7 @@ __global__ __launch_bounds__(512) void score_dense_wgrad_split_kernel(const floa
 // 9 216): conv_wgrad_kernel<1> above gave them 64 x 64 blocks of dW per workgroup -- X re-read cout/64 times and dY cin/64
 // times through registers, 32 FLOP per byte -- 24 % of the AdapNet training step.  Here the padded maps are what they are in
 // memory, two flat matrices [Mp][C] whose border rows are zero in X, so the reduction runs over consecutive rows with no
-// tile geometry: a workgroup owns 256 cin x 128 cout of dW and a slice of the rows (split-K into slabs, added in a fixed
+// tile geometry: a workgroup owns 256 cin x 128 cout (or 128 x 256) of dW and a slice of the rows (split-K into slabs, added in a fixed
 // order by slab_reduce_kernel), eight waves of 64 x 64, 64 rows per step as six [64 rows][64 channels] LDS images (four of
 // X, two of dY) filled by LDS-DMA three stages deep behind a counted vmcnt -- the wide flat GEMM's pipeline
 // (conv1x1_gemm.hip) with the transposing fragment reads of the kernels above.
@@ -1081,14 +1081,17 @@ struct Wgrad1Args {
   int Cin, Cout, n_co, splits, steps_per_split;
 };
 
+// GI = 4: 256 cin x 128 cout per workgroup (four X images, two dY images per stage); GI = 2: 128 cin x 256 cout.
+template <int GI>
 __global__ __launch_bounds__(512, 2) void conv_wgrad_1x1_gemm_kernel(Wgrad1Args a) {
+  constexpr int GO = 6 - GI;
   extern __shared__ __attribute__((aligned(1024))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wr = wave >> 1, wc = wave & 1;
+  const int wr = GI == 4 ? wave >> 1 : wave >> 2, wc = GI == 4 ? wave & 1 : wave & 3;
   const int Cin = a.Cin, Cout = a.Cout;
   const int split = blockIdx.x % a.splits, pair = blockIdx.x / a.splits;
-  const int co0 = (pair % a.n_co) * 128, ci0 = (pair / a.n_co) * 256;
+  const int co0 = (pair % a.n_co) * (64 * GO), ci0 = (pair / a.n_co) * (64 * GI);
   const int64_t m_begin = (int64_t)split * a.steps_per_split * 64;
   int64_t m_end = m_begin + (int64_t)a.steps_per_split * 64;
   m_end = m_end < a.Mp ? m_end : a.Mp;
@@ -1099,7 +1102,7 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_1x1_gemm_kernel(Wgrad1Args 
   const int drow = wave * 8 + (lane >> 3), dslot = (lane & 7) ^ (drow & 6);
   int voff[6];
 #pragma unroll
-  for (int k = 0; k < 6; ++k) voff[k] = (k < 4 ? (ci0 + k * 64) : (co0 + (k - 4) * 64)) * 2 + dslot * 16;
+  for (int k = 0; k < 6; ++k) voff[k] = (k < GI ? (ci0 + k * 64) : (co0 + (k - GI) * 64)) * 2 + dslot * 16;
   auto issue = [&](int step, int stage) {
     const int64_t m = m_begin + (int64_t)step * 64;
     // rows past the end of the maps: the last padded pixel, a border pixel (zero in X: no contribution)
@@ -1109,11 +1112,11 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_1x1_gemm_kernel(Wgrad1Args 
     const char* ds = reinterpret_cast<const char*>(a.dy) + m * Cout * 2;
     const int dst = stage * W1_STAGE + wave * 1024;
 #pragma unroll
-    for (int k = 0; k < 4; ++k)
+    for (int k = 0; k < GI; ++k)
       asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(dst + k * 8192), "v"(voff[k] + rx), "s"(xs)
                    : "memory");
 #pragma unroll
-    for (int k = 4; k < 6; ++k)
+    for (int k = GI; k < 6; ++k)
       asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(dst + k * 8192), "v"(voff[k] + rd), "s"(ds)
                    : "memory");
   };
@@ -1124,14 +1127,14 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_1x1_gemm_kernel(Wgrad1Args 
   int fo[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) fo[i] = xk * 128 + (xv_swz(xk, i * 2 + (pc >> 1)) << 4) + (pc & 1) * 8;
-  const int xfrag = wr * 8192, dfrag = (4 + wc) * 8192;
+  const int xfrag = wr * 8192, dfrag = (GI + wc) * 8192;
 
   f32x4 acc[4][4];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  // BiasAddGrad rides along in the workgroups of cin block 0: thread -> (cout = tid & 127, row quarter = tid >> 7)
+  // BiasAddGrad rides along in the workgroups of cin block 0: thread -> (cout = tid % (64 GO), row part = tid / (64 GO))
   const bool do_bias = a.bslab != nullptr && ci0 == 0;
   float bsum = 0.f;
 
@@ -1148,11 +1151,12 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_1x1_gemm_kernel(Wgrad1Args 
     if (step + 2 < nsteps) issue(step + 2, nstage);
     const char* sb = smem + stage * W1_STAGE;
     if (do_bias) {
-      const int co = tid & 127, qt = tid >> 7;
-      const char* dimg = sb + (4 + (co >> 6)) * 8192 + (co & 7) * 2;
+      constexpr int NCO = 64 * GO, PARTS = 512 / NCO, RPP = 64 / PARTS;   // 128 couts x 4 parts of 16 rows / 256 x 2 of 32
+      const int co = tid % NCO, qt = tid / NCO;
+      const char* dimg = sb + (GI + (co >> 6)) * 8192 + (co & 7) * 2;
       const int slot = (co & 63) >> 3;
 #pragma unroll 4
-      for (int r = qt * 16; r < qt * 16 + 16; ++r)
+      for (int r = qt * RPP; r < qt * RPP + RPP; ++r)
         bsum += (float)*reinterpret_cast<const __bf16*>(dimg + r * 128 + (xv_swz(r, slot) << 4));
     }
 #pragma unroll
@@ -1175,7 +1179,11 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_1x1_gemm_kernel(Wgrad1Args 
     float* red = reinterpret_cast<float*>(smem);
     red[tid] = bsum;
     __syncthreads();
-    if (tid < 128) a.bslab[(int64_t)split * Cout + co0 + tid] = ((red[tid] + red[128 + tid]) + red[256 + tid]) + red[384 + tid];
+    if (GI == 4) {
+      if (tid < 128) a.bslab[(int64_t)split * Cout + co0 + tid] = ((red[tid] + red[128 + tid]) + red[256 + tid]) + red[384 + tid];
+    } else {
+      if (tid < 256) a.bslab[(int64_t)split * Cout + co0 + tid] = red[tid] + red[256 + tid];
+    }
   }
   // accumulator (row = cin = 4 (lane >> 4) + r, column = cout = lane & 15) -> slab [cin][cout]
   float* const out = a.slab + (int64_t)split * Cin * Cout;
@@ -1193,8 +1201,10 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_1x1_gemm_kernel(Wgrad1Args 
 
 // Split count of the kernel above: the one that needs the fewest (rounds of workgroups) x (steps per workgroup), one
 // workgroup per CU.  A pure function of the shape: the workspace query and the launcher must agree.
+static int wgrad1_gi(int cin, int cout) { return ((cin & 255) == 0 && (cout & 127) == 0) ? 4 : (((cin & 127) == 0 && (cout & 255) == 0) ? 2 : 0); }
 static int wgrad1_splits(int64_t mp, int cin, int cout, int* steps_per_split) {
-  const int64_t steps = (mp + 63) / 64, tiles = (int64_t)(cin / 256) * (cout / 128);
+  const int gi = wgrad1_gi(cin, cout);
+  const int64_t steps = (mp + 63) / 64, tiles = (int64_t)(cin / (64 * gi)) * (cout / (64 * (6 - gi)));
   const int cus = xv_num_cus();
   int best = 1;
   int64_t best_cost = -1;
@@ -1208,7 +1218,7 @@ static int wgrad1_splits(int64_t mp, int cin, int cout, int* steps_per_split) {
 }
 static bool wgrad1_ok(int64_t mp, int cin, int cout) {
   static const bool off = getenv("XV_WGRAD_1X1_GEMM") != nullptr && atoi(getenv("XV_WGRAD_1X1_GEMM")) == 0;  // A/B switch
-  return !off && (cin & 255) == 0 && (cout & 127) == 0 && mp >= 64 && 64LL * (cin > cout ? cin : cout) * 2 < 0x7fffffffLL;
+  return !off && wgrad1_gi(cin, cout) != 0 && mp >= 64 && 64LL * (cin > cout ? cin : cout) * 2 < 0x7fffffffLL;
 }
 
 // dw[i] += sum_s slab[s][i], splits summed in a fixed order (bitwise reproducible filter gradients)
@@ -1359,17 +1369,25 @@ extern "C" int xv_conv2d_bwd_filter_ws(const xv_act* x, const xv_act* dy, float*
   if (k == 1 && workspace != nullptr && wgrad1_ok(mp, a.Cin, a.Cout)) {
     // the flat-GEMM form (conv_wgrad_1x1_gemm_kernel): slabs always, added in a fixed order
     Wgrad1Args g{};
-    g.x = a.x, g.dy = a.dy, g.Mp = mp, g.Cin = a.Cin, g.Cout = a.Cout, g.n_co = a.Cout / 128;
+    const int gi = wgrad1_gi(a.Cin, a.Cout);
+    g.x = a.x, g.dy = a.dy, g.Mp = mp, g.Cin = a.Cin, g.Cout = a.Cout, g.n_co = a.Cout / (64 * (6 - gi));
     g.splits = wgrad1_splits(mp, a.Cin, a.Cout, &g.steps_per_split);
     const int64_t dw1 = (int64_t)a.Cin * a.Cout;
     if (workspace_bytes < (size_t)g.splits * (dw1 + a.Cout) * sizeof(float)) return XV_EWORKSPACE;
     XV_CHECK_ARG(((uintptr_t)workspace & 15) == 0);
     g.slab = (float*)workspace;
     g.bslab = dbias != nullptr ? g.slab + (size_t)g.splits * dw1 : nullptr;
-    static bool attr1[XV_MAX_DEVICES] = {false};
-    const hipError_t e = xv_allow_dynamic_lds(reinterpret_cast<const void*>(&conv_wgrad_1x1_gemm_kernel), W1_LDS, attr1);
-    if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(conv_wgrad_1x1_gemm_kernel, dim3((unsigned)((a.Cin / 256) * (a.Cout / 128) * g.splits)), dim3(512), W1_LDS, s, g);
+    static bool attr4[XV_MAX_DEVICES] = {false}, attr2[XV_MAX_DEVICES] = {false};
+    const unsigned grid1 = (unsigned)((a.Cin / (64 * gi)) * g.n_co * g.splits);
+    if (gi == 4) {
+      const hipError_t e = xv_allow_dynamic_lds(reinterpret_cast<const void*>(&conv_wgrad_1x1_gemm_kernel<4>), W1_LDS, attr4);
+      if (e != hipSuccess) return (int)e;
+      hipLaunchKernelGGL(conv_wgrad_1x1_gemm_kernel<4>, dim3(grid1), dim3(512), W1_LDS, s, g);
+    } else {
+      const hipError_t e = xv_allow_dynamic_lds(reinterpret_cast<const void*>(&conv_wgrad_1x1_gemm_kernel<2>), W1_LDS, attr2);
+      if (e != hipSuccess) return (int)e;
+      hipLaunchKernelGGL(conv_wgrad_1x1_gemm_kernel<2>, dim3(grid1), dim3(512), W1_LDS, s, g);
+    }
     int rc = xv_launch_status();
     if (rc != XV_OK) return rc;
     const int64_t n4 = dw1 / 4;

@@ -64,9 +64,9 @@ def test_conv_filter_and_bias_gradient_exact_on_integers(ops, n, h, w, cin, cout
 
 
 @pytest.mark.parametrize('n,h,w,cin,cout', [(2, 12, 20, 256, 128), (1, 24, 48, 512, 256), (3, 5, 7, 256, 384), (8, 24, 48, 1024, 128),
-                                            (1, 6, 6, 2304, 128), (1, 1, 1, 256, 128)])
+                                            (1, 6, 6, 2304, 128), (1, 1, 1, 256, 128), (2, 12, 20, 128, 256), (3, 9, 7, 128, 512)])
 def test_1x1_filter_gradient_as_flat_gemm_exact_on_integers(ops, n, h, w, cin, cout):
-    """conv_wgrad_1x1_gemm_kernel (1x1 convs with cin % 256 == 0, cout % 128 == 0 and a workspace: AdapNet's block stages and
+    """conv_wgrad_1x1_gemm_kernel (1x1 convs with cin % 256 == 0, cout % 128 == 0 -- or 128 / 256 -- and a workspace: AdapNet's block stages and
     the 1x1 conv over its im2col operand): the reduction runs over all padded pixels in 64-row steps, split into slabs --
     exact on integers with and without the bias gradient, accumulated INTO dw, the same bits from run to run."""
     rng = np.random.default_rng(cin + cout + h)
