@@ -16,7 +16,7 @@ import torch
 from . import ops
 from .base_model import BaseModel
 from .custom_layers import bilinear_filter, dense_deconv_as_conv3x3, is_bilinear_filter
-from .fcn import BN_EPS, ENCODER, _fold_bn, padded_units
+from .fcn import BN_EPS, ENCODER, _FUSE_FIRST, _fold_bn, padded_units
 
 
 def vgg16_variable_shapes(prefix, in_channels):
@@ -102,25 +102,47 @@ class VggTrunk(object):
             a = self._arena[key] = ops.Act(n, h, w, c, self.device)
         return a
 
-    def forward(self, x, keep_all=False):
-        """x: float32 [N,H,W,cin] device tensor -> dict of Acts (always 'conv4_3', 'conv5_3')."""
+    def forward(self, x, keep_all=False, routed=False):
+        """x: float32 [N,H,W,cin] device tensor -> dict of Acts (always 'conv4_3', 'conv5_3').  As FcnEngine.encoder:
+        without keep_all, conv1_1 + conv1_2 + pool1 are one launch (ops.conv_first_pair_fwd: neither full-resolution map is
+        written); routed=True (with keep_all: the training step) leaves out the full map of a conv in front of a pool, whose
+        only reader would be MaxPoolGrad, and keeps the pool's route bytes ('route_<conv>') for the data-gradient conv."""
         n, h, w, cin = x.shape
         if cin != self.cin:
             raise ValueError('expected %d input channels, got %d' % (self.cin, cin))
         if h % 16 or w % 16:
             raise ValueError('H and W must be multiples of 16')
         L = {}
-        cur = self._act('conv1_1', n, h, w, 64)
-        ops.conv2d_first_fwd(x.contiguous(), self.w['conv1_1'], self.b['conv1_1'], cur, relu=True)
-        L['conv1_1'] = cur
         ch, cw = h, w
-        for name, cout, pool in ENCODER[1:]:
+        first = 1
+        if not keep_all and _FUSE_FIRST and ENCODER[1][0] == 'conv1_2' and ENCODER[1][2] == 'pool1':
+            q = self._act('pool1', n, h // 2, w // 2, 64)
+            if ops.conv_first_pair_fwd(x.contiguous(), self.w['conv1_1'], self.b['conv1_1'], self.w['conv1_2'], self.b['conv1_2'],
+                                       pooled=q):
+                L['pool1'] = cur = q
+                ch, cw = h // 2, w // 2
+                first = 2
+        if first == 1:
+            cur = self._act('conv1_1', n, h, w, 64)
+            ops.conv2d_first_fwd(x.contiguous(), self.w['conv1_1'], self.b['conv1_1'], cur, relu=True)
+            L['conv1_1'] = cur
+        for name, cout, pool in ENCODER[first:]:
             if pool is None:
                 y = self._act(name, n, ch, cw, cout)
                 ops.conv2d_fwd(cur, self.w[name], self.b[name], 3, relu=True, y=y)
                 L[name] = cur = y
             else:
                 q = self._act(pool, n, ch // 2, cw // 2, cout)
+                if routed and keep_all and name != 'conv4_3':
+                    key = ('route_' + name, n, q.h, q.w, q.c)
+                    route = self._arena.get(key)
+                    if route is None:
+                        route = self._arena[key] = torch.empty(n * q.h * q.w * q.c, dtype=torch.uint8, device=self.device)
+                    if ops.conv2d_fwd_route(cur, self.w[name], self.b[name], q, route):
+                        L['route_' + name] = route
+                        L[pool] = cur = q
+                        ch, cw = ch // 2, cw // 2
+                        continue
                 need_full = keep_all or name == 'conv4_3'
                 y = self._act(name, n, ch, cw, cout) if need_full else None
                 ops.conv2d_fwd(cur, self.w[name], self.b[name], 3, relu=True, y=y, pooled=q, write_y=need_full)

@@ -832,6 +832,10 @@ class FusionFcnTrainer(object):
                 store[key] = torch.empty(ops.packed_weight_elems(k, cin, cout), dtype=torch.bfloat16, device=dev)
             (ops.pack_conv_weights_dgrad if dgrad else ops.pack_conv_weights_into)(kv, store[key])
 
+        # the 2 x 12 trunk kernels: ONE launch over a descriptor table (as FcnTrainer.repack; the master views and the packed
+        # buffers never move -- a trunk whose load() installed buffers of its own gets a new table)
+        entries = []
+        stale = getattr(self, '_pack_table', None) is None
         for m in self.mods:
             trunk = e.trunks[m]
             for name, _, _ in ENCODER:
@@ -843,10 +847,15 @@ class FusionFcnTrainer(object):
                 if not getattr(trunk, '_trainer_owned', False) or name not in trunk.w:
                     trunk.w[name] = torch.empty(ops.packed_weight_elems(3, kv.shape[2], kv.shape[3]), dtype=torch.bfloat16,
                                                 device=dev)
+                    stale = True
                 if (m, name) not in self.wd:
                     self.wd[(m, name)] = torch.empty_like(trunk.w[name])
-                ops.pack_conv_weights_pair(kv, trunk.w[name], self.wd[(m, name)])
+                    stale = True
+                entries.append((kv, trunk.w[name], self.wd[(m, name)]))
             trunk._trainer_owned = True
+        if stale:
+            self._pack_table = ops.PackTable(entries, dev)
+        self._pack_table.run()
         for name in ('fused_score_conv4', 'fused_score_conv5'):
             kv = self.view(self.param, name, 'kernel')
             e.b[name] = self.view(self.param, name, 'bias')
@@ -889,7 +898,7 @@ class FusionFcnTrainer(object):
         if reducer is not None:
             reducer.allreduce_now(self.count)
         # ---- forward ---------------------------------------------------------------------------------------------
-        L = {m: e.trunks[m].forward(inputs[m], keep_all=True) for m in self.mods}
+        L = {m: e.trunks[m].forward(inputs[m], keep_all=True, routed=True) for m in self.mods}
 
         def concat(name):
             cur = L[self.mods[0]][name]
