@@ -270,6 +270,18 @@ int xv_im2col_dilated_pair(const xv_act* x, int dilation1, int dilation2, const 
  * xv_conv2d_fwd(ksize 1).  XV_ESHAPE otherwise (callers then take the materialised form).                              */
 int xv_conv_dilated_pair_fwd(const xv_act* x, const void* wpk, const float* bias, int dilation1, int dilation2, int relu,
                              const xv_act* y, void* stream);
+/* The pair's gradients, also without the operand (training; adapnet.py:84-88 behind base_model.py:153-162).
+ * xv_conv_dilated_pair_bwd_data: dx [N,H,W,C] = gradient of the pair's input from dy [N,H,W,F] (both halves): an implicit GEMM
+ *   over 18 taps x F/2 channels; wpk_dgrad = the packed forward-format image (xv_pack_conv_weights) of the [1,1,18 F/2,C]
+ *   kernel whose row (h * 9 + t) * F/2 + co holds k_h[t][:, co] of conv h; F and C multiples of 128.
+ * xv_conv_dilated_pair_bwd_filter_ws: dw1 / dw2 (+=) = HWIO [3][3][C][F/2] gradients of the two kernels; the taps of x gathered
+ *   by the kernel's loads, split-K slabs in the workspace (>= ..._workspace_bytes; 0 = shape not taken: C and F multiples of
+ *   256) added in a fixed order -- bitwise reproducible.  XV_ESHAPE: callers take the im2col operand + the 1x1 entries.   */
+int xv_conv_dilated_pair_bwd_data(const xv_act* dy, const void* wpk_dgrad, const float* zero_bias, int dilation1, int dilation2,
+                                  const xv_act* dx, void* stream);
+size_t xv_conv_dilated_pair_bwd_filter_workspace_bytes(int n, int h, int w, int c, int f);
+int xv_conv_dilated_pair_bwd_filter_ws(const xv_act* x, const xv_act* dy, int dilation1, int dilation2, float* dw1, float* dw2,
+                                       void* workspace, size_t workspace_bytes, void* stream);
 /* Their transposes for the training graph (each destination element summed by one thread: deterministic), and the
  * residual add y = a + b of a block whose closing conv is followed by a batch norm (adapnet.py:38-51).             */
 int xv_subsample2_bwd(const xv_act* dy, const xv_act* dx, void* stream);

@@ -92,6 +92,9 @@ SIGNATURES = {
     'xv_set_wgrad_variant': (_i, [_i]),
     'xv_conv2d_bwd_filter_workspace_bytes': (ctypes.c_size_t, [_i, _i, _i, _i, _i, _i]),
     'xv_conv2d_bwd_filter_ws': (_i, [_actp, _actp, _vp, _vp, _i, _vp, ctypes.c_size_t, _vp]),
+    'xv_conv_dilated_pair_bwd_data': (_i, [_actp, _vp, _vp, _i, _i, _actp, _vp]),
+    'xv_conv_dilated_pair_bwd_filter_workspace_bytes': (ctypes.c_size_t, [_i, _i, _i, _i, _i]),
+    'xv_conv_dilated_pair_bwd_filter_ws': (_i, [_actp, _actp, _i, _i, _vp, _vp, _vp, ctypes.c_size_t, _vp]),
     'xv_bias_grad': (_i, [_actp, _vp, _vp]),
     'xv_conv2d_first_bwd_filter': (_i, [_vp, _i, _i, _i, _i, _actp, _vp, _vp, _vp]),
     'xv_conv2d_first_bwd_filter_workspace_bytes': (ctypes.c_size_t, [_i, _i, _i, _i]),

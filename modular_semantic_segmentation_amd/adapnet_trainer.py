@@ -20,6 +20,8 @@ through the inverse index map (every kernel element sits at exactly one derived 
 conv's data gradient.  `first_deconvolution_conv` is therefore trained on all of its output channels.  The loss is the
 reference's: the mean cross-entropy over the labelled pixels divided once more by their number (adapnet.py:202-203).
 """
+import os
+
 import numpy as np
 import torch
 
@@ -27,6 +29,8 @@ from . import ops
 from .adapnet import _conv_scopes, conv7s2_as_3x3
 from .custom_layers import dense_deconv_as_conv3x3
 from .trainer import FcnTrainer
+
+_IMPLICIT_PAIRS = os.environ.get('XV_IMPLICIT_PAIRS', '1') != '0'   # 0: the atrous pairs through the im2col operand (A/B)
 
 
 def conv7s2_index_maps(cin, cout):
@@ -109,6 +113,7 @@ class AdapnetTrainer(object):
         self.loss = torch.zeros(1, dtype=torch.float64, device=dev)
         self.grad_scale = 1.0
         self.w, self.wd, self._a, self._scratch = {}, {}, {}, {}
+        self.wd_pair = {}      # block_b name -> packed image of the pair's implicit data gradient
         self.dmap = {}
         for scope, stride in DECONVS:
             src, inv = dense_deconv_index_maps(self.deconv_shape[scope], stride)
@@ -233,11 +238,24 @@ class AdapnetTrainer(object):
                     self.w32_scores = kernel.contiguous()
             elif entries is not None:
                 entries.append((scope, self.view(self.param, scope, 'kernel')))
-        for name, kind, _ in self.blocks:
+        pair_entries = []
+        for name, kind, args in self.blocks:
             if kind == 'b':
                 w = self._pair_kernel(name)             # (two slice copies into a scratch tensor of its own)
                 if entries is not None:
                     entries.append((name + '/stage_2', w))
+                f1, f2 = args[0], args[1]
+                if _IMPLICIT_PAIRS and f1 % 256 == 0 and f2 % 256 == 0:
+                    # the [1,1,18 f2/2,f1] kernel of the pair's implicit data gradient (ops.dilated_pair_dgrad_kernel), packed
+                    # in the forward format: a scratch tensor of its own too
+                    wdk = ops.dilated_pair_dgrad_kernel(self.view(self.param, name + '/stage_2_1', 'kernel'),
+                                                        self.view(self.param, name + '/stage_2_2', 'kernel'),
+                                                        out=self._scratch.get(('pairwd', name)))
+                    self._scratch[('pairwd', name)] = wdk
+                    if entries is not None:
+                        self.wd_pair[name] = torch.empty(ops.packed_weight_elems(1, wdk.shape[2], wdk.shape[3]), dtype=torch.bfloat16,
+                                                         device=wdk.device)
+                        pair_entries.append((wdk, self.wd_pair[name], None))
         if entries is not None:
             triples = []
             for key, kernel in entries:
@@ -248,7 +266,7 @@ class AdapnetTrainer(object):
                 self.w[key] = torch.empty(nel, dtype=torch.bfloat16, device=kernel.device)
                 self.wd[key] = torch.empty(nel, dtype=torch.bfloat16, device=kernel.device)
                 triples.append((kernel, self.w[key], self.wd[key]))
-            table = self._pack_table = ops.PackTable(triples, self.param.device)
+            table = self._pack_table = ops.PackTable(triples + pair_entries, self.param.device)
         table.run()
 
     # ---- scratch ---------------------------------------------------------------------------------------------------
@@ -403,20 +421,36 @@ class AdapnetTrainer(object):
             else:
                 f1, f2, cout, d1, d2, shortcut_conv = args
                 s1 = conv_bn(name + '/stage_1', inpname, inp, 1, True, name + '/s1')
-                op = ops.im2col_dilated_pair(s1, d1, d2, self._act(name + '/operand', s1.n, s1.h, s1.w, 18 * f1))
+                pair_bn = [(name + '/stage_2_1', f2 // 2), (name + '/stage_2_2', f2 // 2)]
+                if name in self.wd_pair and ops.dilated_pair_training_ok(s1, f2):
+                    # the pair forward and backward WITHOUT the 18 f1 operand: the taps gathered by the GEMMs' own loads, only
+                    # the diagonal blocks of the block-diagonal product computed (ops.conv_dilated_pair*)
+                    z2 = ops.conv_dilated_pair(s1, self.w[name + '/stage_2'], self.zeros[:f2], d1, d2, relu=False,
+                                               y=self._act('z_' + name + '/s2', s1.n, s1.h, s1.w, f2))
+                    wneed[0] = max(wneed[0], ops.conv_dilated_pair_bwd_filter_workspace_bytes(s1, f2))
+                    s2, bwd_bn2 = self._bn_pair(pair_bn, z2, True, name + '/s2')
 
-                def bwd_col(name=name, s1=s1, d1=d1, d2=d2):
-                    self._accum(name + '/s1', ops.im2col_dilated_pair_bwd(self._grads.pop(name + '/operand')[0], d1, d2,
-                                                                          self._like('dcol_' + name, s1)))
-                tape.append(bwd_col)
+                    def bwd_pair(name=name, s1=s1, d1=d1, d2=d2, bwd_bn2=bwd_bn2):
+                        dz = bwd_bn2(self._grads.pop(name + '/s2')[0])
+                        ops.conv_dilated_pair_bwd_filter(s1, dz, d1, d2, G(name + '/stage_2_1', 'kernel'),
+                                                         G(name + '/stage_2_2', 'kernel'), wws)
+                        self._accum(name + '/s1', ops.conv_dilated_pair_bwd_data(dz, self.wd_pair[name], self.zeros[:s1.c], d1, d2,
+                                                                                 self._like('dx_' + name + '/s2', s1)))
+                    tape.append(bwd_pair)
+                else:
+                    op = ops.im2col_dilated_pair(s1, d1, d2, self._act(name + '/operand', s1.n, s1.h, s1.w, 18 * f1))
 
-                def scatter_pair(dw, name=name, f1=f1, f2=f2):
-                    half = f2 // 2
-                    G(name + '/stage_2_1', 'kernel').add_(dw[0, 0, :9 * f1, :half].reshape(3, 3, f1, half))
-                    G(name + '/stage_2_2', 'kernel').add_(dw[0, 0, 9 * f1:, half:].reshape(3, 3, f1, half))
-                s2 = conv_bn(name + '/stage_2_1', name + '/operand', op, 1, True, name + '/s2', key=name + '/stage_2',
-                             cout=f2, scatter=scatter_pair,
-                             bn_scope=[(name + '/stage_2_1', f2 // 2), (name + '/stage_2_2', f2 // 2)])
+                    def bwd_col(name=name, s1=s1, d1=d1, d2=d2):
+                        self._accum(name + '/s1', ops.im2col_dilated_pair_bwd(self._grads.pop(name + '/operand')[0], d1, d2,
+                                                                              self._like('dcol_' + name, s1)))
+                    tape.append(bwd_col)
+
+                    def scatter_pair(dw, name=name, f1=f1, f2=f2):
+                        half = f2 // 2
+                        G(name + '/stage_2_1', 'kernel').add_(dw[0, 0, :9 * f1, :half].reshape(3, 3, f1, half))
+                        G(name + '/stage_2_2', 'kernel').add_(dw[0, 0, 9 * f1:, half:].reshape(3, 3, f1, half))
+                    s2 = conv_bn(name + '/stage_2_1', name + '/operand', op, 1, True, name + '/s2', key=name + '/stage_2',
+                                 cout=f2, scatter=scatter_pair, bn_scope=pair_bn)
             s3 = conv_bn(name + '/stage_3', name + '/s2', s2, 1, True, name + '/s3')
             if shortcut_conv:
                 short, shortname = conv_bn(name + '/shortcut', inpname, inp, 1, True, name + '/sc'), name + '/sc'

@@ -34,7 +34,7 @@ struct GemmArgs {
   int relu;
   int n_tiles;
   int nblk;
-  int pair_d1, pair_d2;  // conv1x1_gemm_wide_kernel<true>: the dilation rates of the two atrous 3x3 convs (see there)
+  int pair_d1, pair_d2;  // conv1x1_gemm_wide_kernel<1>: the dilation rates of the two atrous 3x3 convs (see there)
 };
 
 constexpr int G_BM = 128, G_BN = 128;
@@ -191,8 +191,13 @@ constexpr int B_LDS_BYTES = B_STAGES * B_STAGE_BYTES;
 // pixel m + ((ky-1) (W+2) + (kx-1)) d, or, where that tap falls outside the image (or m is a border row), padded pixel 0,
 // which is a border pixel of the map and therefore zero.  Same products in the same order as the materialised form (whose
 // other nine taps add exact zeros): the same bits.
-template <bool PAIR>
+// MODE 2: the data gradient of the same pair (training): dx[p][cin] = sum over both convs h and their taps t of
+// dy_h[p - off_h(t)] . k_h[t][cin][:] -- an implicit GEMM over 18 taps x (cout/2) channels per tap, the taps gathered from the
+// two channel halves of dy with the displacement NEGATED, the weights a packed [1,1,18 cout/2,cin] image whose rows are
+// (h, t, cout-of-the-half) (adapnet_trainer builds it).  a.Cin = channels of dy (both halves), a.Cout = channels of dx.
+template <int MODE>
 __global__ __launch_bounds__(512, 2) void conv1x1_gemm_wide_kernel(GemmArgs a) {
+  constexpr bool PAIR = MODE != 0;
   extern __shared__ __attribute__((aligned(1024))) char smem[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -203,11 +208,11 @@ __global__ __launch_bounds__(512, 2) void conv1x1_gemm_wide_kernel(GemmArgs a) {
   const int64_t m0 = (int64_t)mt * B_BM;
   const int n0 = nt * G_BN;
   const int Cin = a.Cin, Cout = a.Cout;
-  const int cpt = Cin >> 6;                                   // K steps per tap (PAIR), all steps otherwise
-  const int nsteps = PAIR ? 9 * cpt : cpt;
-  const bool second = PAIR && 2 * n0 >= Cout;                 // this workgroup's channels belong to the second conv
+  const int cpt = MODE == 2 ? Cin >> 7 : Cin >> 6;            // K steps per tap (PAIR; MODE 2: of one channel half), all steps otherwise
+  const int nsteps = MODE == 2 ? 18 * cpt : (PAIR ? 9 * cpt : cpt);
+  const bool second = MODE == 1 && 2 * n0 >= Cout;            // this workgroup's channels belong to the second conv
   const int kbase = second ? 9 * cpt : 0;
-  const int dil = second ? a.pair_d2 : a.pair_d1;
+  int dil = second ? a.pair_d2 : a.pair_d1;                   // (MODE 2: of the tap being requested, see tap_offsets)
 
   // DMA addressing: piece p of a tile = rows 8p .. 8p+7, lane -> (row, 16-byte slot); wave w moves weight pieces w, w + 8
   // and pixel pieces w, w + 8, w + 16, w + 24
@@ -241,8 +246,11 @@ __global__ __launch_bounds__(512, 2) void conv1x1_gemm_wide_kernel(GemmArgs a) {
   // PAIR: issue() is called for steps 0, 1, 2, ... in order; (itap, icb) = (step / cpt, step % cpt) follow along
   int itap = 0, icb = 0;
   auto tap_offsets = [&]() {
-    const int ky = itap / 3, kx = itap - 3 * ky;
-    const int dy = (ky - 1) * dil, dx = (kx - 1) * dil;
+    const int tt = MODE == 2 && itap >= 9 ? itap - 9 : itap;
+    if (MODE == 2) dil = itap >= 9 ? a.pair_d2 : a.pair_d1;
+    const int ky = tt / 3, kx = tt - 3 * ky;
+    const int sgn = MODE == 2 ? -1 : 1;                       // the data gradient reads dy at p - off
+    const int dy = sgn * (ky - 1) * dil, dx = sgn * (kx - 1) * dil;
     const int dm = dy * (a.W + 2) + dx;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -254,7 +262,8 @@ __global__ __launch_bounds__(512, 2) void conv1x1_gemm_wide_kernel(GemmArgs a) {
   if (PAIR) tap_offsets();
   auto issue = [&](int step, int stage) {
     const char* ws = wbase + ((int64_t)(kbase + step) * Cout << 7);
-    const char* xs = xbase + ((PAIR ? icb : step) << 7);
+    // MODE 2: taps 9 .. 17 read the second channel half of dy
+    const char* xs = xbase + ((PAIR ? icb : step) << 7) + (MODE == 2 && itap >= 9 ? Cin : 0);
     const int dst = stage * B_STAGE_BYTES;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -267,7 +276,7 @@ __global__ __launch_bounds__(512, 2) void conv1x1_gemm_wide_kernel(GemmArgs a) {
                    : "memory");
     if (PAIR && ++icb == cpt) {
       icb = 0;
-      if (++itap < 9) tap_offsets();
+      if (++itap < (MODE == 2 ? 18 : 9)) tap_offsets();
     }
   };
 
@@ -366,7 +375,7 @@ constexpr int N_LDS_BYTES = 2 * N_STAGE_BYTES;
 
 // PAIR = true: block_b with 64 output channels (block_layer_7, 32 + 32): both convs' channels share the one 64-channel tile,
 // so the K loop runs over all 18 taps of the packed [1,1,18C,64] image (the zero blocks included: the same products as the
-// materialised form) -- taps 0..8 at rate d1, 9..17 at rate d2, gathered by the DMA as in conv1x1_gemm_wide_kernel<true>.
+// materialised form) -- taps 0..8 at rate d1, 9..17 at rate d2, gathered by the DMA as in conv1x1_gemm_wide_kernel<1>.
 template <bool PAIR>
 __global__ __launch_bounds__(256, 4) void conv1x1_n64_kernel(GemmArgs a) {
   extern __shared__ __attribute__((aligned(1024))) char smem[];
@@ -492,7 +501,7 @@ __global__ __launch_bounds__(256, 4) void conv1x1_n64_kernel(GemmArgs a) {
 
 }  // namespace
 
-// block_b's two atrous 3x3 convs + concat as ONE implicit GEMM (conv1x1_gemm_wide_kernel<true>), no materialised operand.
+// block_b's two atrous 3x3 convs + concat as ONE implicit GEMM (conv1x1_gemm_wide_kernel<1>), no materialised operand.
 // wpk: the packed [1,1,18 cin,cout] image xv_im2col_dilated_pair's 1x1 conv takes (adapnet.dilated_pair_as_1x1: rows [0,9 cin)
 // x columns [0,cout/2) = conv 1, rows [9 cin,18 cin) x columns [cout/2,cout) = conv 2; the other two blocks are never read).
 extern "C" int xv_conv_dilated_pair_fwd(const xv_act* x, const void* wpk, const float* bias, int dilation1, int dilation2,
@@ -528,9 +537,43 @@ extern "C" int xv_conv_dilated_pair_fwd(const xv_act* x, const void* wpk, const 
   XV_CHECK_SHAPE(nblk <= 0x7fffffff);
   a.nblk = (int)nblk;
   static bool attr_p[XV_MAX_DEVICES] = {false};
-  const hipError_t e = xv_allow_dynamic_lds(reinterpret_cast<const void*>(conv1x1_gemm_wide_kernel<true>), B_LDS_BYTES, attr_p);
+  const hipError_t e = xv_allow_dynamic_lds(reinterpret_cast<const void*>(conv1x1_gemm_wide_kernel<1>), B_LDS_BYTES, attr_p);
   if (e != hipSuccess) return (int)e;
-  hipLaunchKernelGGL(conv1x1_gemm_wide_kernel<true>, dim3((unsigned)nblk), dim3(512), B_LDS_BYTES, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(conv1x1_gemm_wide_kernel<1>, dim3((unsigned)nblk), dim3(512), B_LDS_BYTES, (hipStream_t)stream, a);
+  return xv_launch_status();
+}
+
+// The data gradient of xv_conv_dilated_pair_fwd (conv1x1_gemm_wide_kernel<2>).  dy [N,H,W,F] (both halves), dx [N,H,W,C];
+// wpk_dgrad: packed forward-format image of the [1,1,18 F/2,C] kernel whose row (h * 9 + t) * F/2 + co holds k_h[t][:, co].
+extern "C" int xv_conv_dilated_pair_bwd_data(const xv_act* dy, const void* wpk_dgrad, const float* zero_bias, int dilation1,
+                                             int dilation2, const xv_act* dx, void* stream) {
+  XV_REQUIRE_BF16(dy, dx);
+  XV_CHECK_ARG(dy && dx && dy->data && dx->data && wpk_dgrad && zero_bias);
+  XV_CHECK_SHAPE(dy->n == dx->n && dy->h == dx->h && dy->w == dx->w && dy->h > 0 && (dy->c & 127) == 0 && (dx->c & 127) == 0 &&
+                 dilation1 >= 1 && dilation2 >= 1);
+  GemmArgs a{};
+  a.x = (const __bf16*)dy->data;
+  a.wpk = (const __bf16*)wpk_dgrad;
+  a.bias = zero_bias;
+  a.y = (__bf16*)dx->data;
+  a.Mp = (int64_t)dy->n * (dy->h + 2) * (dy->w + 2);
+  a.H = dy->h;
+  a.W = dy->w;
+  a.Cin = dy->c;
+  a.Cout = dx->c;
+  a.relu = 0;
+  a.n_tiles = dx->c / G_BN;
+  a.pair_d1 = dilation1;
+  a.pair_d2 = dilation2;
+  const int64_t reach = (int64_t)(dilation1 > dilation2 ? dilation1 : dilation2) * (dy->w + 3);
+  XV_CHECK_SHAPE((a.Mp + B_BM + reach) * dy->c * 2 <= 0x7fffffff);
+  const int64_t nblk = (a.Mp + B_BM - 1) / B_BM * a.n_tiles;
+  XV_CHECK_SHAPE(nblk <= 0x7fffffff);
+  a.nblk = (int)nblk;
+  static bool attr_d[XV_MAX_DEVICES] = {false};
+  const hipError_t e = xv_allow_dynamic_lds(reinterpret_cast<const void*>(conv1x1_gemm_wide_kernel<2>), B_LDS_BYTES, attr_d);
+  if (e != hipSuccess) return (int)e;
+  hipLaunchKernelGGL(conv1x1_gemm_wide_kernel<2>, dim3((unsigned)nblk), dim3(512), B_LDS_BYTES, (hipStream_t)stream, a);
   return xv_launch_status();
 }
 
@@ -588,9 +631,9 @@ int xv_launch_conv1x1_gemm(const __bf16* x, const __bf16* wpk, const float* bias
     if (fits && wide_env != 0 && (wide_env == 1 || enough)) {
       a.nblk = (int)nblk_wide;
       static bool attr_w[XV_MAX_DEVICES] = {false};
-      const hipError_t e = xv_allow_dynamic_lds(reinterpret_cast<const void*>(conv1x1_gemm_wide_kernel<false>), B_LDS_BYTES, attr_w);
+      const hipError_t e = xv_allow_dynamic_lds(reinterpret_cast<const void*>(conv1x1_gemm_wide_kernel<0>), B_LDS_BYTES, attr_w);
       if (e != hipSuccess) return (int)e;
-      hipLaunchKernelGGL(conv1x1_gemm_wide_kernel<false>, dim3((unsigned)nblk_wide), dim3(512), B_LDS_BYTES, stream, a);
+      hipLaunchKernelGGL(conv1x1_gemm_wide_kernel<0>, dim3((unsigned)nblk_wide), dim3(512), B_LDS_BYTES, stream, a);
       return xv_launch_status();
     }
   }

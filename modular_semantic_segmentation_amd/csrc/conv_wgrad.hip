@@ -1079,18 +1079,32 @@ struct Wgrad1Args {
   float* bslab;  // [splits][Cout] or null
   int64_t Mp;
   int Cin, Cout, n_co, splits, steps_per_split;
+  int H, W, d1, d2;  // PAIR: map size and the two dilation rates
 };
 
 // GI = 4: 256 cin x 128 cout per workgroup (four X images, two dY images per stage); GI = 2: 128 cin x 256 cout.
-template <int GI>
+// PAIR (GI = 4): the filter gradients of AdapNet's two atrous 3x3 convs (adapnet.py:84-88) WITHOUT the 18C im2col operand: the
+// "cin" axis is virtual, (tap, channel) of one conv, and an X image of a stage -- 64 channels of ONE tap -- is gathered by
+// the DMA from the map itself, row m reading padded pixel m + off(tap) (or pixel 0, a zero border pixel, where the tap leaves
+// the image).  Only the two diagonal blocks of the [18C][F] product exist: a workgroup's four tap-channel groups and its 128
+// output channels belong to the same conv; its slab is that conv's own [9C][F/2] matrix = the HWIO gradient of its kernel.
+// a.Cin = C (channels of the map), a.Cout = F (channels of dY, both halves); slabs [conv][split][9C][F/2].
+template <int GI, bool PAIR = false>
 __global__ __launch_bounds__(512, 2) void conv_wgrad_1x1_gemm_kernel(Wgrad1Args a) {
+  static_assert(!PAIR || GI == 4, "the pair form is the 256 x 128 layout");
   constexpr int GO = 6 - GI;
   extern __shared__ __attribute__((aligned(1024))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = GI == 4 ? wave >> 1 : wave >> 2, wc = GI == 4 ? wave & 1 : wave & 3;
   const int Cin = a.Cin, Cout = a.Cout;
-  const int split = blockIdx.x % a.splits, pair = blockIdx.x / a.splits;
+  const int split = blockIdx.x % a.splits;
+  int pair = blockIdx.x / a.splits;
+  // PAIR: n_co = 128-channel blocks of ONE half; tiles of one conv first, then the other's
+  const int half = Cout >> 1, vcin = 9 * Cin;                       // (PAIR) channels of one conv's output, its virtual cin
+  const int tiles_half = PAIR ? (vcin >> 8) * a.n_co : 0;
+  const int conv = PAIR && pair >= tiles_half ? 1 : 0;
+  if (PAIR) pair -= conv * tiles_half;
   const int co0 = (pair % a.n_co) * (64 * GO), ci0 = (pair / a.n_co) * (64 * GI);
   const int64_t m_begin = (int64_t)split * a.steps_per_split * 64;
   int64_t m_end = m_begin + (int64_t)a.steps_per_split * 64;
@@ -1102,19 +1116,46 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_1x1_gemm_kernel(Wgrad1Args 
   const int drow = wave * 8 + (lane >> 3), dslot = (lane & 7) ^ (drow & 6);
   int voff[6];
 #pragma unroll
-  for (int k = 0; k < 6; ++k) voff[k] = (k < GI ? (ci0 + k * 64) : (co0 + (k - GI) * 64)) * 2 + dslot * 16;
+  for (int k = 0; k < 6; ++k)
+    voff[k] = (k < GI ? (PAIR ? 0 : ci0 + k * 64) : (conv * half + co0 + (k - GI) * 64)) * 2 + dslot * 16;
+  // PAIR: image k is 64 channels of tap tap_k: displacement in padded pixels, channel block
+  int tdy[4], tdx[4];
+  if (PAIR) {
+    const int cpt = Cin >> 6, dil = conv ? a.d2 : a.d1;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int gidx = (ci0 >> 6) + k, tap = gidx / cpt, cb = gidx - tap * cpt, ky = tap / 3, kx = tap - 3 * ky;
+      tdy[k] = (ky - 1) * dil, tdx[k] = (kx - 1) * dil;
+      voff[k] += cb * 128;
+    }
+  }
   auto issue = [&](int step, int stage) {
     const int64_t m = m_begin + (int64_t)step * 64;
     // rows past the end of the maps: the last padded pixel, a border pixel (zero in X: no contribution)
     const int64_t rowi = m + drow < a.Mp ? m + drow : a.Mp - 1;
     const int rx = (int)(rowi - m) * Cin * 2, rd = (int)(rowi - m) * Cout * 2;
-    const char* xs = reinterpret_cast<const char*>(a.x) + m * Cin * 2;
+    const char* xs = reinterpret_cast<const char*>(a.x) + (PAIR ? 0 : m * Cin * 2);
     const char* ds = reinterpret_cast<const char*>(a.dy) + m * Cout * 2;
     const int dst = stage * W1_STAGE + wave * 1024;
+    if (PAIR) {
+      // the row's padded coordinates; a row that is itself a border pixel (its dY is zero) or past the end reads pixel 0
+      const int Wp = a.W + 2, Hp = a.H + 2;
+      const int mi = (int)rowi, prow = mi / Wp, xx = mi - prow * Wp, yy = prow % Hp;
+      const bool interior = m + drow < a.Mp && xx >= 1 && xx <= a.W && yy >= 1 && yy <= a.H;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int sy = yy + tdy[k], sx = xx + tdx[k];
+        const bool ok = interior && sy >= 1 && sy <= a.H && sx >= 1 && sx <= a.W;
+        const int src = ok ? (mi + tdy[k] * Wp + tdx[k]) * Cin * 2 : 0;
+        asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(dst + k * 8192), "v"(voff[k] + src), "s"(xs)
+                     : "memory");
+      }
+    } else {
 #pragma unroll
     for (int k = 0; k < GI; ++k)
       asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(dst + k * 8192), "v"(voff[k] + rx), "s"(xs)
                    : "memory");
+    }
 #pragma unroll
     for (int k = GI; k < 6; ++k)
       asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(dst + k * 8192), "v"(voff[k] + rd), "s"(ds)
@@ -1135,7 +1176,7 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_1x1_gemm_kernel(Wgrad1Args 
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   // BiasAddGrad rides along in the workgroups of cin block 0: thread -> (cout = tid % (64 GO), row part = tid / (64 GO))
-  const bool do_bias = a.bslab != nullptr && ci0 == 0;
+  const bool do_bias = !PAIR && a.bslab != nullptr && ci0 == 0;
   float bsum = 0.f;
 
   if (nsteps > 0) issue(0, 0);
@@ -1186,25 +1227,30 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_1x1_gemm_kernel(Wgrad1Args 
     }
   }
   // accumulator (row = cin = 4 (lane >> 4) + r, column = cout = lane & 15) -> slab [cin][cout]
-  float* const out = a.slab + (int64_t)split * Cin * Cout;
+  const int ldo = PAIR ? half : Cout;   // row pitch of the slab
+  float* const out = PAIR ? a.slab + ((int64_t)conv * a.splits + split) * vcin * half : a.slab + (int64_t)split * Cin * Cout;
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      float* dst = out + (int64_t)(ci0 + wr * 64 + i * 16 + g * 4) * Cout + co0 + wc * 64 + j * 16 + li;
+      float* dst = out + (int64_t)(ci0 + wr * 64 + i * 16 + g * 4) * ldo + co0 + wc * 64 + j * 16 + li;
       dst[0] = acc[i][j].x;
-      dst[Cout] = acc[i][j].y;
-      dst[2 * Cout] = acc[i][j].z;
-      dst[3 * Cout] = acc[i][j].w;
+      dst[ldo] = acc[i][j].y;
+      dst[2 * ldo] = acc[i][j].z;
+      dst[3 * ldo] = acc[i][j].w;
     }
 }
 
 // Split count of the kernel above: the one that needs the fewest (rounds of workgroups) x (steps per workgroup), one
 // workgroup per CU.  A pure function of the shape: the workspace query and the launcher must agree.
 static int wgrad1_gi(int cin, int cout) { return ((cin & 255) == 0 && (cout & 127) == 0) ? 4 : (((cin & 127) == 0 && (cout & 255) == 0) ? 2 : 0); }
+static int wgrad1_splits_of(int64_t mp, int64_t tiles, int* steps_per_split);
 static int wgrad1_splits(int64_t mp, int cin, int cout, int* steps_per_split) {
   const int gi = wgrad1_gi(cin, cout);
-  const int64_t steps = (mp + 63) / 64, tiles = (int64_t)(cin / (64 * gi)) * (cout / (64 * (6 - gi)));
+  return wgrad1_splits_of(mp, (int64_t)(cin / (64 * gi)) * (cout / (64 * (6 - gi))), steps_per_split);
+}
+static int wgrad1_splits_of(int64_t mp, int64_t tiles, int* steps_per_split) {
+  const int64_t steps = (mp + 63) / 64;
   const int cus = xv_num_cus();
   int best = 1;
   int64_t best_cost = -1;
@@ -1330,6 +1376,64 @@ extern "C" size_t xv_conv2d_bwd_filter_workspace_bytes(int n, int h, int w, int 
     if (sp1 > sp) sp = sp1;
   }
   return (size_t)sp * ((size_t)k * k * cin * cout + cout) * sizeof(float);  // dW slabs + bias slabs
+}
+
+// ---- filter gradients of AdapNet's atrous pair without the im2col operand (conv_wgrad_1x1_gemm_kernel<4, true>) ----------
+static bool wgrad_pair_ok(int64_t mp, int c, int f) {
+  return (c & 255) == 0 && (f & 255) == 0 && mp >= 64 && mp * (c > f ? c : f) * 2 < 0x7fffffffLL;
+}
+static int64_t wgrad_pair_tiles(int c, int f) { return 2LL * (9 * c / 256) * (f / 256); }
+
+extern "C" size_t xv_conv_dilated_pair_bwd_filter_workspace_bytes(int n, int h, int w, int c, int f) {
+  if (!xv_dims_sane(n, h, w) || c <= 0 || f <= 0) return 0;
+  const int64_t mp = (int64_t)n * (h + 2) * (w + 2);
+  if (!wgrad_pair_ok(mp, c, f)) return 0;
+  return (size_t)wgrad1_splits_of(mp, wgrad_pair_tiles(c, f), nullptr) * 2 * 9 * c * (f / 2) * sizeof(float);
+}
+
+// dw1 / dw2 (+=): HWIO [3][3][C][F/2] gradients of the kernels of the two convs (rates dilation1 / dilation2) whose outputs are
+// the two channel halves of dy; x [N,H,W,C].  Split-K slabs in the workspace, added in a fixed order: bitwise reproducible.
+extern "C" int xv_conv_dilated_pair_bwd_filter_ws(const xv_act* x, const xv_act* dy, int dilation1, int dilation2, float* dw1,
+                                                  float* dw2, void* workspace, size_t workspace_bytes, void* stream) {
+  XV_REQUIRE_BF16(x, dy);
+  XV_CHECK_ARG(x && dy && x->data && dy->data && dw1 && dw2 && workspace);
+  XV_CHECK_SHAPE(dy->n == x->n && dy->h == x->h && dy->w == x->w && x->h > 0 && dilation1 >= 1 && dilation2 >= 1);
+  const int64_t mp = (int64_t)x->n * (x->h + 2) * (x->w + 2);
+  XV_CHECK_SHAPE(wgrad_pair_ok(mp, x->c, dy->c));
+  XV_CHECK_ARG((((uintptr_t)x->data | (uintptr_t)dy->data | (uintptr_t)dw1 | (uintptr_t)dw2 | (uintptr_t)workspace) & 15) == 0);
+  Wgrad1Args g{};
+  g.x = (const __bf16*)x->data, g.dy = (const __bf16*)dy->data, g.Mp = mp, g.Cin = x->c, g.Cout = dy->c;
+  g.n_co = dy->c / 256;  // 128-channel blocks of one half
+  g.H = x->h, g.W = x->w, g.d1 = dilation1, g.d2 = dilation2;
+  const int64_t tiles = wgrad_pair_tiles(x->c, dy->c);
+  g.splits = wgrad1_splits_of(mp, tiles, &g.steps_per_split);
+  const int64_t per_conv = 9LL * x->c * (dy->c / 2);
+  if (workspace_bytes < (size_t)g.splits * 2 * per_conv * sizeof(float)) return XV_EWORKSPACE;
+  g.slab = (float*)workspace, g.bslab = nullptr;
+  hipStream_t s = (hipStream_t)stream;
+  static bool attrp[XV_MAX_DEVICES] = {false};
+  const hipError_t e = xv_allow_dynamic_lds(reinterpret_cast<const void*>(&conv_wgrad_1x1_gemm_kernel<4, true>), W1_LDS, attrp);
+  if (e != hipSuccess) return (int)e;
+  hipLaunchKernelGGL((conv_wgrad_1x1_gemm_kernel<4, true>), dim3((unsigned)(tiles * g.splits)), dim3(512), W1_LDS, s, g);
+  int rc = xv_launch_status();
+  if (rc != XV_OK) return rc;
+  const int64_t n4 = per_conv / 4;
+  for (int conv = 0; conv < 2; ++conv) {
+    const float* src = g.slab + (int64_t)conv * g.splits * per_conv;
+    float* dst = conv ? dw2 : dw1;
+    if (g.splits >= 16) {
+      int64_t blocks = (n4 * 16 + 255) / 256;
+      if (blocks > 4096) blocks = 4096;
+      hipLaunchKernelGGL(slab_reduce_kernel<16>, dim3((unsigned)blocks), dim3(256), 0, s, src, dst, n4, g.splits, (const float*)nullptr,
+                         (float*)nullptr, 0);
+    } else {
+      int64_t blocks = (n4 + 255) / 256;
+      if (blocks > 2048) blocks = 2048;
+      hipLaunchKernelGGL(slab_reduce_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, s, src, dst, n4, g.splits, (const float*)nullptr,
+                         (float*)nullptr, 0);
+    }
+  }
+  return xv_launch_status();
 }
 
 extern "C" int xv_conv2d_bwd_filter_ws(const xv_act* x, const xv_act* dy, float* dw_hwio, float* dbias, int k,

@@ -443,6 +443,48 @@ def conv_dilated_pair(x, w_packed, bias, d1, d2, relu=True, y=None):
     return y
 
 
+def dilated_pair_training_ok(x, cout):
+    """Shapes both gradient entries of the implicit pair take (xv_conv_dilated_pair_bwd_data / _bwd_filter_ws)."""
+    return x.c % 256 == 0 and cout % 256 == 0 and \
+        _lib.lib().xv_conv_dilated_pair_bwd_filter_workspace_bytes(x.n, x.h, x.w, x.c, cout) > 0
+
+
+def dilated_pair_dgrad_kernel(kernel1, kernel2, out=None):
+    """float32 [1,1,18 F/2,C] kernel of the pair's data gradient as a 1x1 conv over (conv, tap, output channel of the conv): row
+    (h * 9 + t) * F/2 + co = k_h[t][:, co].  kernel1 / kernel2: [3,3,C,F/2] device tensors; `out`: a tensor to fill in place."""
+    _, _, c, half = kernel1.shape
+    if out is None:
+        out = torch.empty(1, 1, 18 * half, c, dtype=torch.float32, device=kernel1.device)
+    v = out.view(2, 9, half, c)
+    v[0].copy_(kernel1.reshape(9, c, half).transpose(1, 2))
+    v[1].copy_(kernel2.reshape(9, c, half).transpose(1, 2))
+    return out
+
+
+def conv_dilated_pair_bwd_data(dy, w_packed_dgrad, zero_bias, d1, d2, dx):
+    """dx = gradient of the pair's input (xv_conv_dilated_pair_bwd_data); w_packed_dgrad: pack_conv_weights of
+    dilated_pair_dgrad_kernel(k1, k2)."""
+    with _Profiled('dgrad_pair', 2.0 * dy.n * dy.h * dy.w * dx.c * dy.c * 9):
+        rc = _lib.lib().xv_conv_dilated_pair_bwd_data(dy.xv(), _ptr(w_packed_dgrad), _ptr(zero_bias), int(d1), int(d2), dx.xv(),
+                                                      _stream())
+    _lib.check(rc, 'xv_conv_dilated_pair_bwd_data')
+    return dx
+
+
+def conv_dilated_pair_bwd_filter_workspace_bytes(x, cout):
+    return _lib.lib().xv_conv_dilated_pair_bwd_filter_workspace_bytes(x.n, x.h, x.w, x.c, cout)
+
+
+def conv_dilated_pair_bwd_filter(x, dy, d1, d2, dw1, dw2, workspace):
+    """dw1 / dw2 (+=): HWIO [3,3,C,F/2] gradients of the two atrous kernels, without the im2col operand."""
+    _need(dw1, torch.float32, 'dw1')
+    _need(dw2, torch.float32, 'dw2')
+    with _Profiled('wgrad_pair', 2.0 * x.n * x.h * x.w * x.c * dy.c * 9):
+        rc = _lib.lib().xv_conv_dilated_pair_bwd_filter_ws(x.xv(), dy.xv(), int(d1), int(d2), _ptr(dw1), _ptr(dw2), _ptr(workspace),
+                                                           workspace.numel() * 4, _stream())
+    _lib.check(rc, 'xv_conv_dilated_pair_bwd_filter_ws')
+
+
 def dropout(x, rate, seed, y=None):
     """tf.layers.dropout(x, rate, training=True): keep with probability 1 - rate, scale by 1 / (1 - rate)."""
     if y is None:

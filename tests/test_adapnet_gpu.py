@@ -134,6 +134,53 @@ def test_dilated_pair_as_implicit_gemm(ops, n, h, w, c, half, d1, d2):
         assert torch.equal(a.t, m.t), relu
 
 
+@pytest.mark.parametrize('n,h,w,c,half,d1,d2', [(2, 12, 20, 256, 128, 1, 2), (1, 24, 48, 256, 128, 2, 16), (2, 6, 10, 512, 256, 1, 16),
+                                                (3, 5, 7, 256, 128, 3, 5), (8, 24, 48, 256, 128, 1, 4)])
+def test_dilated_pair_gradients_without_the_operand(ops, n, h, w, c, half, d1, d2):
+    """xv_conv_dilated_pair_bwd_data / _bwd_filter_ws: the gradients of the two atrous convs + concat (adapnet.py:84-88) with the
+    taps gathered by the kernels' loads -- exact on integers against autograd, accumulated INTO dw, bitwise reproducible."""
+    rng = np.random.default_rng(h * w + d2 + c)
+    x = rng.integers(-2, 3, (n, h, w, c)).astype(np.float32)
+    k1 = rng.integers(-1, 2, (3, 3, c, half)).astype(np.float32)
+    k2 = rng.integers(-1, 2, (3, 3, c, half)).astype(np.float32)
+    dy = (rng.integers(-1, 2, (n, h, w, 2 * half)) * (rng.random((n, h, w, 2 * half)) < 0.1)).astype(np.float32)
+    xt = _nchw(x).requires_grad_(True)
+    w1, w2 = _wt(k1).requires_grad_(True), _wt(k2).requires_grad_(True)
+    y = torch.cat([F.conv2d(xt, w1, padding=d1, dilation=d1), F.conv2d(xt, w2, padding=d2, dilation=d2)], dim=1)
+    y.backward(_nchw(dy))
+    xa, dya = ops.Act.from_dense(_dev(x)), ops.Act.from_dense(_dev(dy))
+    assert ops.dilated_pair_training_ok(xa, 2 * half)
+    # data gradient
+    wd = ops.pack_conv_weights(ops.dilated_pair_dgrad_kernel(_dev(k1), _dev(k2)))
+    dx = ops.conv_dilated_pair_bwd_data(dya, wd, torch.zeros(c, device='cuda'), d1, d2, ops.Act(n, h, w, c))
+    torch.cuda.synchronize()
+    assert np.array_equal(dx.interior().float().cpu().numpy(), fo.round_bf16(_nhwc(xt.grad)))
+    assert float(dx.t.float().abs().sum()) == float(dx.interior().float().abs().sum())
+    # filter gradients
+    ws = torch.empty(ops.conv_dilated_pair_bwd_filter_workspace_bytes(xa, 2 * half) // 4, device='cuda').fill_(float('nan'))
+    dw1, dw2 = torch.ones(3, 3, c, half, device='cuda'), torch.full((3, 3, c, half), -2.0, device='cuda')
+    ops.conv_dilated_pair_bwd_filter(xa, dya, d1, d2, dw1, dw2, ws)
+    torch.cuda.synchronize()
+    assert np.array_equal(dw1.cpu().numpy(), w1.grad.permute(2, 3, 1, 0).numpy() + 1)
+    assert np.array_equal(dw2.cpu().numpy(), w2.grad.permute(2, 3, 1, 0).numpy() - 2)
+    # floats: the same bits from run to run, and the materialised form's sums to rounding
+    xf = ops.Act.from_dense(_dev(rng.standard_normal((n, h, w, c)).astype(np.float32)))
+    df = ops.Act.from_dense(_dev(rng.standard_normal((n, h, w, 2 * half)).astype(np.float32)))
+    outs = []
+    for _ in range(2):
+        a, b = torch.zeros(3, 3, c, half, device='cuda'), torch.zeros(3, 3, c, half, device='cuda')
+        ops.conv_dilated_pair_bwd_filter(xf, df, d1, d2, a, b, ws)
+        outs.append((a, b))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    z = ops.im2col_dilated_pair(xf, d1, d2)
+    full = torch.zeros(1, 1, 18 * c, 2 * half, device='cuda')
+    ws1 = torch.empty(ops.conv2d_bwd_filter_workspace_bytes(z, 2 * half, 1) // 4, device='cuda')
+    ops.conv2d_bwd_filter(z, df, full, None, 1, workspace=ws1)
+    want1, want2 = full[0, 0, :9 * c, :half].reshape(3, 3, c, half), full[0, 0, 9 * c:, half:].reshape(3, 3, c, half)
+    scale = float(full.abs().max())
+    assert float((outs[0][0] - want1).abs().max()) <= 2e-5 * scale and float((outs[0][1] - want2).abs().max()) <= 2e-5 * scale
+
+
 def test_dilated_pair_implicit_rejects_other_shapes(ops):
     from modular_semantic_segmentation_amd import _lib
     x = ops.Act(1, 4, 4, 64)
@@ -394,6 +441,46 @@ def _grad_agreement(got, ref_g):
         rel[k] = np.linalg.norm(a - b) / (np.linalg.norm(b) + 1e-30)
         cos[k] = a @ b / (np.linalg.norm(a) * np.linalg.norm(b) + 1e-30)
     return rel, cos
+
+
+WIDE = [('block_layer_1', 'a', (64, 128, 1, True)), ('block_layer_4', 'a', (64, 256, 2, True)),
+        ('block_layer_7', 'b', (64, 64, 256, 1, 2, False)), ('block_layer_8', 'a', (128, 512, 2, True)),
+        ('block_layer_10', 'b', (256, 256, 512, 2, 4, False))]
+
+
+def test_adapnet_training_step_with_the_implicit_atrous_pair(ops):
+    """block_b with 256-channel pairs trains WITHOUT the im2col operand (ops.conv_dilated_pair + _bwd_filter + _bwd_data);
+    the same step through the operand (adapnet_trainer._IMPLICIT_PAIRS = False) must give the same loss, the same pair-kernel
+    gradients up to the order of the fp32 sums, and the other gradients up to the bf16 rounding of the pair's data gradient
+    (the operand form rounds every tap's contribution to bf16 before adding them, the implicit one rounds the sum)."""
+    from modular_semantic_segmentation_amd import adapnet_trainer
+    from modular_semantic_segmentation_amd.adapnet import AdapnetEngine
+    h, w = 64, 96
+    rng = np.random.default_rng(5)
+    x = rng.integers(0, 256, (2, h, w, 3)).astype(np.float32)
+    labels = rng.integers(-1, C, (2, h, w)).astype(np.int32)
+    w_ = ao.init_adapnet_weights('rgb', 3, U, C, seed=2, gain=1.3, blocks=WIDE)
+    w_['rgb/block_0_1/kernel'] *= 0.02
+    results = {}
+    for implicit in (True, False):
+        adapnet_trainer._IMPLICIT_PAIRS = implicit
+        try:
+            eng = AdapnetEngine('rgb', 3, U, C, w_, blocks=WIDE)
+            tr = adapnet_trainer.AdapnetTrainer(eng, 'rmsprop', 1e-3)
+            tr.load_from_variables(w_)
+            assert ('block_layer_10' in tr.wd_pair) == implicit and 'block_layer_7' not in tr.wd_pair
+            loss = tr.step(_dev(x), _dev(labels))
+            torch.cuda.synchronize()
+            results[implicit] = (loss.item(), tr.grads_as_variables())
+        finally:
+            adapnet_trainer._IMPLICIT_PAIRS = True
+    (la, ga), (lb, gb) = results[True], results[False]
+    assert la == lb                                        # the forward passes are the same bits
+    rel, cos = _grad_agreement(ga, gb)
+    for k in ('rgb/block_layer_10/stage_2_1/kernel', 'rgb/block_layer_10/stage_2_2/kernel'):
+        assert rel[k] < 1e-4, (k, rel[k])                  # same dz, same map: only the order of the fp32 sums differs
+    worst = max(rel.items(), key=lambda kv: kv[1])
+    assert worst[1] < 0.1 and min(cos.values()) > 0.995, (worst, min(cos.items(), key=lambda kv: kv[1]))
 
 
 def test_adapnet_training_step_on_a_shallow_graph(ops):
