@@ -31,6 +31,7 @@ from .custom_layers import dense_deconv_as_conv3x3
 from .trainer import FcnTrainer
 
 _IMPLICIT_PAIRS = os.environ.get('XV_IMPLICIT_PAIRS', '1') != '0'   # 0: the atrous pairs through the im2col operand (A/B)
+_FUSE_ACCUM = os.environ.get('XV_ADAPNET_FUSE_ACCUM', '1') != '0'   # 0: every second gradient of a tensor through an add pass (A/B)
 
 
 def conv7s2_index_maps(cin, cout):
@@ -362,8 +363,16 @@ class AdapnetTrainer(object):
                     ops.conv2d_bwd_filter(xact, dz, dw, G(scope, 'bias') if has_bias else None, k, workspace=wws)
                     scatter(dw)
                 if xname is not None:
-                    dx = ops.conv2d_bwd_data(dz, self.wd[key], self.zeros[:xact.c], self._like('dx_' + out, xact), k)
-                    self._accum(xname, dx)
+                    prev = self._grads.get(xname) if _FUSE_ACCUM else None
+                    if prev is not None:
+                        # a gradient of this tensor already exists (the other branch of a residual block): the data-gradient
+                        # conv adds it in its own epilogue -- fp32 sum, one rounding -- instead of an add pass over three maps
+                        dx = ops.conv2d_bwd_data(dz, self.wd[key], self.zeros[:xact.c], self._like('dx_' + out, xact), k,
+                                                 addend=prev[0])
+                        self._grads[xname] = (dx, False)
+                    else:
+                        dx = ops.conv2d_bwd_data(dz, self.wd[key], self.zeros[:xact.c], self._like('dx_' + out, xact), k)
+                        self._accum(xname, dx)
             tape.append(bwd)
             return y
 
