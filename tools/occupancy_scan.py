@@ -56,9 +56,14 @@ def demangle(names):
 
 
 if __name__ == '__main__':
-    args = [os.path.abspath(a) for a in sys.argv[1:]]
+    if any(a in ('-h', '--help') for a in sys.argv[1:]):
+        print(__doc__)
+        print('  --all   list every kernel, not only the flagged ones')
+        sys.exit(0)
+    show_all = '--all' in sys.argv[1:]
+    args = [os.path.abspath(a) for a in sys.argv[1:] if not a.startswith('--')]
     for fname, rows in scan(args or None).items():
-        flagged = [r for r in rows if r[3] <= 2 or r[2] > 0]
+        flagged = [r for r in rows if show_all or r[3] <= 2 or r[2] > 0]
         print('%s: %d kernels, %d at <= 2 waves per SIMD or with scratch' % (fname, len(rows), len(flagged)))
         for (k, tot, scr, occ), pretty in zip(flagged, demangle([r[0] for r in flagged])):
             print('  waves %d  registers %3d  scratch %4d B  %s' % (occ, tot, scr, re.sub(r'\(anonymous namespace\)::', '', pretty)[:120]))
