@@ -26,6 +26,10 @@ BUDGETS = [
     # (36 bytes of true spills at the 128 registers a 1 024-thread workgroup allows: nine 64-bit load addresses per column
     # batch; a 60 us kernel)
     ('backward.hip', 'head_bwd_lowres_kernelILi12E', 4, 36),
+    # round 6: the flat 1x1 filter gradient (all three forms) and the wide flat GEMM with its gathering modes: two 8-wave
+    # workgroups' worth of registers (<= 128), no scratch
+    ('conv_wgrad.hip', 'conv_wgrad_1x1_gemm_kernel', 4, 0),
+    ('conv1x1_gemm.hip', 'conv1x1_gemm_wide_kernel', 4, 0),
 ]
 
 
